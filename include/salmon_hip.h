@@ -1,0 +1,323 @@
+/* salmon_hip.h — C ABI of libsalmon_hip.so: the MI355X-native `salmon quant` hot path.
+ *
+ * The reference (COMBINE-lab/salmon v1.11.4) has no FFI; it is one statically linked binary.  This
+ * header therefore defines the drop-in boundary at the reference's own in-process seams
+ * (SURVEY.md §8b).  Each entry point names the reference call site it replaces (paths relative to
+ * the reference tree).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * All functions return 0 on success or a negative sq_status; they never abort the process
+ * (the reference's loop calls std::exit(1) on fatal paths — SalmonQuantify.cpp:1202-1210).
+ * sq_last_error() returns a thread-local message for the last failing call.
+ */
+#ifndef SALMON_HIP_H
+#define SALMON_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SQ_OK = 0,
+  SQ_ERR_ARG = -1,      /* bad argument */
+  SQ_ERR_IO = -2,       /* file missing / unreadable / bad format (SalmonIndex.hpp:120-160 throws) */
+  SQ_ERR_NOMEM = -3,
+  SQ_ERR_DEVICE = -4,   /* HIP runtime failure or no gfx950 device (there is NO CPU fallback) */
+  SQ_ERR_STATE = -5,    /* call order violated */
+  SQ_ERR_OVERFLOW = -6  /* a device work buffer would overflow; batch must be split */
+} sq_status;
+
+const char* sq_last_error(void);
+const char* sq_version(void); /* "salmon-hip x.y (salmon 1.11.4 semantics)" */
+
+/* ------------------------------------------------------------------------------------------------
+ * B0  index handle — replaces checkLoadIndex()/SalmonIndex::load (src/index/BuildSalmonIndex.cpp:264-284,
+ *     include/salmon/internal/index/SalmonIndex.hpp:33-67,120-205) and `salmon index`
+ *     (BuildSalmonIndex.cpp:49-262 -> pufferfishIndex(IndexOptions&)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sq_index sq_index;
+
+typedef struct {
+  uint32_t k;               /* odd, <= 31 (BuildSalmonIndex.cpp:204-210); 0 -> 31 */
+  uint32_t m;               /* minimizer length; 0 -> min(20, max(4, k-4)) (BuildSalmonIndex.cpp:78-81) */
+  uint32_t keep_duplicates; /* --keepDuplicates */
+  uint32_t no_clip_polya;   /* --no-clip */
+  uint32_t threads;         /* -p */
+  uint32_t gencode;         /* --gencode: split names at first '|' */
+} sq_index_opts;
+
+/* Build from a FASTA file (plain or .gz). decoys_path may be NULL; outdir receives index.bin,
+ * info.json, versionInfo.json, duplicate_clusters.tsv. */
+int sq_index_build(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path,
+                   const char* outdir);
+/* Build from in-memory sequences (ASCII, not NUL-terminated; lens in nt). Names NUL-terminated.
+ * first_decoy = index of the first decoy sequence (== nrefs when none). Either writes outdir (if
+ * non-NULL) and/or returns a host-resident handle in *out (if non-NULL). */
+int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, const char* const* names,
+                       const char* const* seqs, const uint32_t* lens, uint32_t first_decoy,
+                       const char* outdir, sq_index** out);
+/* Load index.bin from dir. device >= 0 uploads the query structures to that GPU's HBM;
+ * device < 0 keeps a host-only handle (metadata queries, tests without a GPU). */
+int sq_index_load(const char* dir, int device, sq_index** out);
+/* Upload an already-built host handle to a device (idempotent). */
+int sq_index_to_device(sq_index* idx, int device);
+void sq_index_free(sq_index* idx);
+
+uint32_t sq_index_k(const sq_index*);
+uint32_t sq_index_m(const sq_index*);
+uint32_t sq_index_num_refs(const sq_index*);
+uint32_t sq_index_first_decoy(const sq_index*);
+const char* sq_index_ref_name(const sq_index*, uint32_t tid);
+uint32_t sq_index_ref_len(const sq_index*, uint32_t tid);          /* RefLength (post-clipping) */
+uint32_t sq_index_ref_complete_len(const sq_index*, uint32_t tid); /* CompleteLength */
+int sq_index_is_decoy(const sq_index*, uint32_t tid);
+uint64_t sq_index_num_unitigs(const sq_index*);
+uint64_t sq_index_num_kmers(const sq_index*);
+uint64_t sq_index_device_bytes(const sq_index*);
+/* Raw views of host-side sections (for the checker and tests; do not free). */
+typedef struct {
+  uint32_t k, m;
+  uint32_t num_refs, first_decoy;
+  uint64_t num_unitigs, total_unitig_nt, num_kmers, total_ref_nt, num_occ;
+  const uint64_t* ref_accum;   /* [num_refs+1] start of each reference in refseq (nt) */
+  const uint32_t* ref_len;     /* [num_refs] */
+  const uint32_t* ref_clen;    /* [num_refs] complete length */
+  const uint64_t* refseq;      /* 2-bit packed, 32 nt per word, little-endian in the word */
+  const uint64_t* useq;        /* unitig pool, same packing */
+  const uint64_t* uoff;        /* [num_unitigs+1] unitig start (nt) in the pool */
+  const uint64_t* ctab_off;    /* [num_unitigs+1] */
+  const uint64_t* ctab;        /* occurrences: tid<<32 | ori<<31 | pos */
+} sq_index_view;
+int sq_index_get_view(const sq_index*, sq_index_view* out);
+
+/* Single k-mer dictionary query on the HOST copy of the SSHash-style dictionary (used by tests to
+ * check the dictionary against brute force for every k-mer; the device kernel is the product
+ * path).  kmer = 2-bit packed, base i in bits [2i,2i+1].  Returns 1 if found. */
+int sq_index_lookup_host(const sq_index*, uint64_t kmer, uint64_t* unitig, uint32_t* offset,
+                         int* is_fw);
+
+/* ------------------------------------------------------------------------------------------------
+ * Options that define hot-path behaviour (subset of SalmonOpts, include/salmon/internal/config/
+ * SalmonOpts.hpp:23-306; defaults from SalmonDefaults.hpp:8-127).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  /* library format (LibraryFormat; src/util/LibraryTypeUtils.cpp:22-46) */
+  uint8_t lib_type;        /* 0 single-end, 1 paired-end */
+  uint8_t lib_orientation; /* 0 SAME(M), 1 AWAY(O), 2 TOWARD(I), 3 NONE */
+  uint8_t lib_strand;      /* 0 SA(SF for PE), 1 AS(SR for PE), 2 S, 3 A, 4 U */
+  uint8_t _pad0;
+  /* mapping (ProgramOptionsGenerator.cpp:103-289) */
+  int32_t match_score;        /* --ma 2 */
+  int32_t mismatch_penalty;   /* --mp -4 */
+  int32_t gap_open;           /* --go 6 */
+  int32_t gap_extend;         /* --ge 2 */
+  int32_t bandwidth;          /* --bandwidth 15 */
+  uint32_t mismatch_seed_skip;/* 3 */
+  uint32_t max_occs_per_hit;  /* 1000 */
+  uint32_t max_read_occs;     /* 200 (flag only; see SPEC) */
+  uint32_t frag_len_max;      /* --fldMax 1000 */
+  double consensus_slack;     /* 0.35 */
+  double min_score_fraction;  /* 0.65 */
+  double pre_merge_chain_sub_thresh;  /* 0.75 */
+  double post_merge_chain_sub_thresh; /* 0.9 */
+  double orphan_chain_sub_thresh;     /* 0.95 */
+  double score_exp;           /* 1.0 */
+  double decoy_threshold;     /* 1.0 */
+  double min_aln_prob;        /* 1e-5 */
+  uint8_t hard_filter;        /* 0 */
+  uint8_t allow_dovetail;     /* 0 */
+  uint8_t allow_orphans;      /* 1 (discardOrphansQuasi=false) */
+  uint8_t disable_chaining_heuristic; /* 0 */
+  uint8_t ignore_incompat;    /* 1 (incompatPrior == 0) */
+  uint8_t _pad1[3];
+  /* online model (SalmonQuantify.cpp:426-1023) */
+  uint32_t mini_batch_size;   /* 5000 (SalmonQuantify.cpp:150) */
+  uint32_t num_pre_burnin_frags; /* 5000 */
+  uint64_t num_burnin_frags;  /* 5,000,000 */
+  double fld_mean, fld_sd;    /* 250, 25 */
+  double forgetting_factor;   /* 0.65 */
+  double incompat_prior;      /* 0.0 -> ignore_incompat */
+  uint32_t range_factorization_bins; /* 4 */
+  uint8_t use_frag_len_dist;  /* 1 (!noFragLengthDist) */
+  uint8_t model_single_frag_prob; /* 1 (!noSingleFragProb) */
+  uint8_t no_length_correction;   /* 0 */
+  uint8_t no_eff_length_correction; /* 0 */
+  uint64_t seed;              /* seed of the counter-based RNG for FLD sampling (reference: random_device) */
+} sq_quant_opts;
+void sq_quant_opts_default(sq_quant_opts* o); /* -l IU defaults */
+
+/* ------------------------------------------------------------------------------------------------
+ * B1  mapping — replaces the worker-loop body between parser->refill(rg) and processMiniBatch
+ *     (src/quant/SalmonQuantify.cpp:1199-1854 paired, :2032-2314 single): MemCollector::operator(),
+ *     findChains, joinReadsAndFilter, PuffAligner::calculateAlignments [external pufferfish@ace68c1c]
+ *     + updateRefMappings / filterAndCollectAlignments (SalmonMappingUtils.hpp:225-485).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sq_ctx sq_ctx;
+int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads,
+                  sq_ctx** out);
+void sq_ctx_free(sq_ctx*);
+
+typedef struct {
+  uint32_t n;              /* fragments (pairs or single reads) */
+  uint32_t paired;         /* 1: seq holds 2n records, record 2i = mate1, 2i+1 = mate2 */
+  const uint8_t* seq;      /* concatenated ASCII bases */
+  const uint64_t* seq_off; /* [nrec+1] byte offsets into seq */
+  int on_device;           /* 0: host pointers (copied H2D); 1: pointers are already in HBM */
+} sq_read_batch;
+
+/* mate_status values follow pufferfish::util::MateStatus as used in SalmonMappingUtils.hpp:349-383 */
+enum { SQ_MS_SINGLE_END = 0, SQ_MS_PAIRED_END_LEFT = 1, SQ_MS_PAIRED_END_RIGHT = 2,
+       SQ_MS_PAIRED_END_PAIRED = 3 };
+/* mapping type per fragment (salmon::utils::MappingType, SalmonQuantify.cpp:1604-1630) */
+enum { SQ_MT_UNMAPPED = 0, SQ_MT_LEFT_ORPHAN = 1, SQ_MT_RIGHT_ORPHAN = 2, SQ_MT_BOTH_ORPHAN = 3,
+       SQ_MT_PAIRED_MAPPED = 4, SQ_MT_SINGLE_MAPPED = 5, SQ_MT_DECOY = 6 };
+
+typedef struct {           /* one QuasiAlignment (fields salmon reads: SURVEY.md §8a row a6) */
+  uint32_t tid;
+  int32_t pos;             /* implied start of (left/orphan) read on the transcript */
+  int32_t mate_pos;
+  int32_t score, mate_score;
+  uint32_t frag_len;       /* jointHit.fragmentLen (0 for orphans) */
+  uint16_t read_len, mate_len;
+  uint8_t fwd, mate_fwd, mate_status, format_id; /* LibraryFormat::formatID of the observed hit */
+  double est_aln_prob;
+} sq_aln;
+
+typedef struct {
+  uint32_t n;              /* fragments */
+  uint64_t* read_off;      /* [n+1] CSR offsets into aln (caller-owned, n+1 entries) */
+  sq_aln* aln;             /* caller-owned, capacity aln_cap */
+  uint64_t aln_cap;
+  uint8_t* map_type;       /* [n] SQ_MT_* (caller-owned, may be NULL) */
+} sq_aln_batch;
+
+typedef struct {           /* HitCounters / MappingStatistics subset (SalmonQuantify.cpp:1861-1865) */
+  uint64_t num_reads, num_mapped_at_least_a_kmer, num_with_joint_hits /* upperBoundHits */,
+      num_mapped /* >=1 kept alignment */, num_alignments /* validHits */,
+      num_mappings_filtered, num_fragments_filtered, num_dovetails, num_decoy_fragments,
+      num_seeds, num_lookups, num_mems, num_chains, num_candidates, num_dp_alignments;
+} sq_map_stats;
+
+/* Map one batch. Results stay resident on the device for sq_eq_accumulate(); if out != NULL they
+ * are also copied to the caller's buffers (SQ_ERR_OVERFLOW if aln_cap is too small). */
+int sq_map_batch(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +
+ *     EquivalenceClassBuilder::addGroup/finish (EquivalenceClassBuilder.hpp:165-181,237-250).
+ * ---------------------------------------------------------------------------------------------- */
+/* Run the online model over the batch last mapped by sq_map_batch (mini-batches of
+ * opts.mini_batch_size in input order) and add its fragments to the device eq-class table. */
+int sq_eq_accumulate(sq_ctx*);
+
+typedef struct {
+  uint64_t num_classes;   /* E */
+  uint64_t num_labels;    /* L = sum of class sizes (transcripts only) */
+  uint64_t* off;          /* [E+1] */
+  uint32_t* tid;          /* [L] */
+  double* w;              /* [L] normalised aux weights (TGValue::normalizeAux) */
+  uint64_t* wq;           /* [L] raw fixed-point weight sums (SQ_WFRAC_BITS) — exact reduction form */
+  uint64_t* count;        /* [E] */
+  uint32_t* bins;         /* [L] range-factorization bin ids (label tail), or NULL */
+  uint64_t* h1;           /* [E] label hash (canonical class order = ascending (h1,h2)) */
+  uint64_t* h2;
+} sq_eq_table;
+/* Query sizes (out arrays NULL) then fetch into caller buffers. Classes come out in canonical order. */
+int sq_eq_finish(sq_ctx*, sq_eq_table* out);
+/* Merge an externally provided table (e.g. all-gathered from other GPUs) into this ctx's table:
+ * counts and fixed-point weight sums add exactly, so any merge order gives identical bits. */
+int sq_eq_merge(sq_ctx*, const sq_eq_table* other);
+
+typedef struct {          /* online-model state needed downstream (Transcript, FLD, counters) */
+  uint64_t num_observed, num_assigned, num_mapped_ub;
+  int burned_in;
+} sq_model_summary;
+int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
+/* per-transcript state after the online phase: log-mass (LOG_0 = +inf when none), unique/total
+ * counts, log effective length (Transcript.hpp:136-141,210-283). Arrays of length num_refs. */
+int sq_model_fetch(sq_ctx*, double* log_mass, uint64_t* unique_count, uint64_t* total_count,
+                   double* log_eff_len);
+int sq_model_fetch_fld(sq_ctx*, double* log_pmf_1001); /* log PMF bins 0..1000 (flenDist) */
+
+/* ------------------------------------------------------------------------------------------------
+ * B3  inference — replaces CollapsedEMOptimizer::optimize (src/inference/CollapsedEMOptimizer.cpp:
+ *     732-1035), ::gatherBootstraps (:554-690), CollapsedGibbsSampler::sample
+ *     (src/inference/CollapsedGibbsSampler.cpp:317-508).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint8_t use_vbem;             /* useVBOpt = true */
+  uint8_t per_transcript_prior; /* true */
+  uint8_t init_uniform;         /* false; forced true in -e mode */
+  uint8_t eq_class_mode;        /* combined weight = file weight verbatim (:862) */
+  uint8_t no_rich_eq_classes;
+  uint8_t _pad[3];
+  double vb_prior;              /* 1e-2 */
+  double rel_diff_tolerance;    /* 0.01 */
+  uint32_t max_iter;            /* 10000 */
+  uint32_t min_iter;            /* 100 */
+  double num_required_fragments;/* 5e7 (deprecated knob, still used for init mixing :790) */
+} sq_em_opts;
+void sq_em_opts_default(sq_em_opts*);
+
+typedef struct {
+  uint32_t num_txp;             /* M */
+  const double* projected_counts; /* [M] alphas from normalizeAlphas (ignored with init_uniform) */
+  const uint64_t* unique_count; /* [M] (altInitMode only; may be NULL) */
+  const double* eff_len;        /* [M] linear-space effective lengths */
+} sq_txp_in;
+
+typedef struct {
+  uint32_t iters;
+  int converged;
+  double max_rel_diff;
+  double alpha_sum;
+  double device_ms;             /* HIP-event time of the iteration loop */
+  double ms_per_iter;
+} sq_em_report;
+
+/* Full optimisation. eq arrays are host pointers (copied) — tid/w/count/off as in sq_eq_table. */
+int sq_em_optimize(sq_ctx*, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
+                   double* alpha_out /*[M]*/, sq_em_report* report);
+/* Standalone variant that needs no index/ctx (the `salmon quant -e` seam,
+ * SalmonQuantifyAlignments.cpp:1407-1441). */
+int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp,
+                       const sq_em_opts* opts, double* alpha_out, sq_em_report* report);
+/* Run exactly `iters` update steps from the given alpha (benchmarking / parity of single steps). */
+int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
+                    const double* alpha_in, uint32_t iters, double* alpha_out, sq_em_report* report);
+
+typedef int (*sq_replicate_cb)(const double* alphas, uint32_t m, void* user);
+int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
+                     uint32_t num_bootstraps, uint64_t seed, uint64_t num_mapped,
+                     sq_replicate_cb cb, void* user);
+typedef struct {
+  uint32_t thinning_factor;     /* 16 */
+  uint8_t no_gamma_draw;
+  uint8_t use_vbem;
+  uint8_t per_transcript_prior;
+  uint8_t _pad;
+  double vb_prior;
+} sq_gibbs_opts;
+int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* opts,
+                 const double* alpha_init, uint32_t num_samples, uint64_t seed, uint64_t num_mapped,
+                 sq_replicate_cb cb, void* user);
+
+/* ------------------------------------------------------------------------------------------------
+ * Debug / parity taps: copy an intermediate stage of the LAST sq_map_batch to the host.
+ * ---------------------------------------------------------------------------------------------- */
+enum { SQ_TAP_UNIMEMS = 1, SQ_TAP_MEMS = 2, SQ_TAP_CHAINS = 3, SQ_TAP_CANDIDATES = 4 };
+typedef struct { uint32_t end; uint16_t qpos, len; uint64_t unitig; uint32_t uoff; uint8_t fw; uint8_t _p[3]; } sq_unimem;
+typedef struct { uint32_t end; uint32_t tid; int32_t rpos; uint16_t qpos, len; uint8_t fw; uint8_t _p[3]; } sq_mem;
+typedef struct { uint32_t end; uint32_t tid; int32_t pos; int32_t last_end; uint8_t fw; uint8_t _p[3];
+                 uint32_t n_mems; double score; } sq_chain;
+typedef struct { uint32_t frag; uint32_t tid; int32_t lpos, rpos; uint8_t lfw, rfw, mate_status, valid;
+                 int32_t lscore, rscore; uint32_t frag_len; } sq_cand;
+/* Returns number of records (or negative status). buf may be NULL to query the count. */
+int64_t sq_debug_tap(sq_ctx*, int what, void* buf, uint64_t cap_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALMON_HIP_H */

@@ -1,0 +1,1085 @@
+// oracle/oracle.cpp — CPU restatement of the `salmon quant` hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the checker the HIP path is compared against (tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py are its only callers).  Nothing under salmon_amd/ links, imports or
+// calls it; the product path fails loudly without the HIP extension.
+//
+// PARITY STATUS: **parity unpinned** for rows a1-a6 (k-mer lookup / MEM collection / chaining /
+// pair joining / selective-alignment scoring): that arithmetic lives in COMBINE-lab/pufferfish @
+// ace68c1c022816ba8c50a1a07c5d08f2abd597d6 (cmake/SalmonDependencies.cmake:11-16), which is absent
+// from /root/reference and cannot be fetched; the reference's tests hold no golden vectors for it
+// (SURVEY.md §4, §8c).  Those stages restate the published algorithms (SSHash, pufferfish uni-MEMs,
+// minimap2 chaining, ksw2 affine DP) with the choices frozen in oracle/SPEC.md.  Rows a7-a18 follow
+// the in-tree reference files line by line; each function cites them.  Library-format compatibility
+// (a9) IS pinned by the reference's tests/LibraryTypeTests.cpp truth tables (tests/test_libtype.py).
+//
+// Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <map>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include "../include/salmon_hip.h"
+#include "../include/sq_math.h"
+
+namespace orc {
+
+constexpr int MAX_UNIMEMS = 64;      // SPEC §a1
+constexpr int MAX_CHAIN_GAP = 200;   // SPEC §a2
+constexpr double AVG_SEED = 31.0;    // SPEC §a2 (pufferfish uses a constant average seed length)
+constexpr int REF_EXTEND = 20;       // aconf.refExtendLength (SalmonMappingUtils.hpp:184)
+constexpr int32_t INVALID_SCORE = INT32_MIN;
+constexpr int32_t NEG_INF = -(1 << 29);
+
+// ---- own small k-mer helpers (independent of salmon_amd/csrc/sq_internal.h) ----------------------
+static inline uint64_t kmask(uint32_t k) { return k >= 32 ? ~0ULL : (1ULL << (2 * k)) - 1; }
+static inline uint64_t revcomp(uint64_t x, uint32_t k) {
+  uint64_t r = 0;
+  for (uint32_t i = 0; i < k; ++i) { r = (r << 2) | (3 - (x & 3)); x >>= 2; }
+  return r;
+}
+static inline uint32_t base_at(const uint64_t* pool, uint64_t p) { return (uint32_t)(pool[p >> 5] >> ((p & 31) * 2)) & 3u; }
+
+struct Index {
+  uint32_t k = 31, first_decoy = 0;
+  std::vector<std::string> names;
+  std::vector<uint32_t> ref_len, ref_clen;
+  std::vector<uint64_t> ref_accum, refseq, useq, uoff, ctab_off, ctab;
+  // brute-force dictionary: canonical k-mer -> (unitig<<31 | off<<1 | canonical_is_fw_in_unitig)
+  std::vector<uint64_t> hkeys, hvals; uint64_t hmask = 0;
+  uint64_t num_kmers = 0;
+
+  void build_dict() {
+    uint64_t U = uoff.size() - 1, nk = 0;
+    for (uint64_t u = 0; u < U; ++u) nk += uoff[u + 1] - uoff[u] - (k - 1);
+    num_kmers = nk;
+    uint64_t cap = 16; while (cap < nk * 2) cap <<= 1;
+    hkeys.assign(cap, ~0ULL); hvals.assign(cap, 0); hmask = cap - 1;
+    const uint64_t km = kmask(k);
+    for (uint64_t u = 0; u < U; ++u) {
+      uint64_t b = uoff[u]; uint32_t ulen = (uint32_t)(uoff[u + 1] - b);
+      uint64_t fw = 0;
+      for (uint32_t i = 0; i < ulen; ++i) {
+        fw = (fw >> 2) | ((uint64_t)base_at(useq.data(), b + i) << (2 * (k - 1)));
+        if (i + 1 < k) continue;
+        fw &= km; uint64_t rc = revcomp(fw, k); bool cf = fw < rc; uint64_t c = cf ? fw : rc;
+        uint64_t h = sq_mix64(c) & hmask;
+        while (hkeys[h] != ~0ULL && hkeys[h] != c) h = (h + 1) & hmask;
+        hkeys[h] = c; hvals[h] = (u << 31) | ((uint64_t)(i + 1 - k) << 1) | (cf ? 1 : 0);
+      }
+    }
+  }
+  // SPEC §a1: canonical k-mer -> (unitig, offset, orientation of the *query* w.r.t. the unitig)
+  inline bool lookup(uint64_t kmer, uint64_t& u, uint32_t& off, bool& fw) const {
+    uint64_t rc = revcomp(kmer, k); bool qcf = kmer < rc; uint64_t c = qcf ? kmer : rc;
+    uint64_t h = sq_mix64(c) & hmask;
+    for (;;) {
+      uint64_t kk = hkeys[h];
+      if (kk == ~0ULL) return false;
+      if (kk == c) { uint64_t v = hvals[h]; u = v >> 31; off = (uint32_t)((v >> 1) & 0x3FFFFFFF); fw = ((v & 1) != 0) == qcf; return true; }
+      h = (h + 1) & hmask;
+    }
+  }
+};
+
+// ---- data carried between stages ----------------------------------------------------------------
+struct UniMem { uint16_t qpos, len; uint64_t unitig; uint32_t ustart; bool fw; };
+struct Mem { uint32_t tid; int32_t rpos; uint16_t q, len; bool fw; };  // q = strand-normalised read pos
+struct Chain { uint32_t tid; bool fw; double score; int32_t pos; int32_t last_end; uint16_t read_len; std::vector<uint32_t> mems; /* indices into the end's Mem array, ascending */ };
+struct Cand { uint32_t tid; int lc, rc; uint32_t frag_len; uint8_t mate_status; double cov; int32_t lscore = INVALID_SCORE, rscore = INVALID_SCORE; bool valid = false; };
+
+struct Opts { sq_quant_opts o; std::vector<double> gapcost; int32_t ma, mp, go, ge, bw; };
+
+static void make_opts(const sq_quant_opts* o, Opts& op) {
+  op.o = *o; op.ma = o->match_score; op.mp = o->mismatch_penalty; op.go = o->gap_open; op.ge = o->gap_extend; op.bw = o->bandwidth;
+  op.gapcost.assign(MAX_CHAIN_GAP + 1, 0.0);
+  const double inv_ln2 = 1.0 / 0.6931471805599453;
+  for (int l = 1; l <= MAX_CHAIN_GAP; ++l) op.gapcost[l] = 0.01 * AVG_SEED * (double)l + 0.5 * (sq_log((double)l) * inv_ln2);
+}
+
+struct ReadCodes { std::vector<uint8_t> c; };  // 0..3, 4 = N
+static inline void encode_read(const uint8_t* s, uint32_t n, std::vector<uint8_t>& c) {
+  c.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    switch (s[i]) { case 'A': case 'a': c[i] = 0; break; case 'C': case 'c': c[i] = 1; break; case 'G': case 'g': c[i] = 2; break; case 'T': case 't': c[i] = 3; break; default: c[i] = 4; }
+  }
+}
+
+// a1 — MemCollector::operator() [external pufferfish]; call site SalmonQuantify.cpp:1266-1275.
+static void collect_unimems(const Index& ix, const Opts& op, const std::vector<uint8_t>& rd, std::vector<UniMem>& out, sq_map_stats* st) {
+  out.clear();
+  const uint32_t k = ix.k; const int L = (int)rd.size();
+  if (L < (int)k) return;
+  int pos = 0, skip_until = -1; const int alt = (int)op.o.mismatch_seed_skip;
+  while (pos + (int)k <= L && (int)out.size() < MAX_UNIMEMS) {
+    int lastN = -1; for (int i = pos; i < pos + (int)k; ++i) if (rd[i] > 3) lastN = i;
+    if (lastN >= 0) { pos = lastN + 1; continue; }
+    uint64_t km = 0; for (uint32_t i = 0; i < k; ++i) km |= (uint64_t)rd[pos + i] << (2 * i);
+    uint64_t u; uint32_t off; bool fw;
+    if (st) st->num_lookups++;
+    if (!ix.lookup(km, u, off, fw)) {
+      if (pos < skip_until) { int np = pos + alt; if (np > skip_until) np = skip_until; pos = np; } else pos += 1;
+      continue;
+    }
+    const uint64_t ub = ix.uoff[u]; const int ulen = (int)(ix.uoff[u + 1] - ub);
+    int len = k; bool uend = false;
+    if (fw) {
+      for (;;) { if (pos + len >= L) break; if ((int)off + len >= ulen) { uend = true; break; } if (rd[pos + len] != base_at(ix.useq.data(), ub + off + len)) break; ++len; }
+    } else {
+      for (;;) { if (pos + len >= L) break; int up = (int)off - 1 - (len - (int)k); if (up < 0) { uend = true; break; } if (rd[pos + len] != 3 - base_at(ix.useq.data(), ub + up)) break; ++len; }
+    }
+    UniMem m; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.unitig = u; m.fw = fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - (int)k));
+    out.push_back(m);
+    if (pos + len >= L) break;
+    int e = pos + len;
+    pos = pos + len - (int)k + 1;
+    skip_until = uend ? -1 : e + 1;
+  }
+  if (st) st->num_seeds += out.size();
+}
+
+// a2a — projection of uni-MEMs through the contig table (MemClusterer::fillMemCollection [external]).
+static void project_mems(const Index& ix, const Opts& op, const std::vector<UniMem>& um, int L, std::vector<Mem>& mems) {
+  mems.clear();
+  for (const UniMem& m : um) {
+    uint64_t a = ix.ctab_off[m.unitig], b = ix.ctab_off[m.unitig + 1];
+    if (b - a > op.o.max_occs_per_hit) continue;  // configureMemClusterer(maxOccsPerHit), SalmonMappingUtils.hpp:159
+    int ulen = (int)(ix.uoff[m.unitig + 1] - ix.uoff[m.unitig]);
+    for (uint64_t i = a; i < b; ++i) {
+      uint64_t e = ix.ctab[i]; Mem x; x.tid = (uint32_t)(e >> 32); bool ufw = (e >> 31) & 1; int upos = (int)(e & 0x7FFFFFFF);
+      x.rpos = ufw ? upos + (int)m.ustart : upos + (ulen - ((int)m.ustart + (int)m.len));
+      x.fw = (ufw == m.fw); x.len = m.len; x.q = x.fw ? m.qpos : (uint16_t)(L - (m.qpos + m.len));
+      mems.push_back(x);
+    }
+  }
+  // SPEC §a2: order by (tid, refPos); ties keep (uni-MEM, occurrence) emission order
+  std::stable_sort(mems.begin(), mems.end(), [&](const Mem& a, const Mem& b) {
+    uint64_t ka = ix.ref_accum[a.tid] + (uint64_t)(a.rpos < 0 ? 0 : a.rpos), kb = ix.ref_accum[b.tid] + (uint64_t)(b.rpos < 0 ? 0 : b.rpos);
+    return ka < kb; });
+}
+
+// a2b — MemCollector::findChains / findOptChain [external]; call site SalmonQuantify.cpp:1276-1288.
+static void chain_end(const Index&, const Opts& op, const std::vector<Mem>& mems, int L, std::vector<Chain>& chains) {
+  chains.clear();
+  const size_t n = mems.size();
+  std::vector<double> f; std::vector<int> p; std::vector<uint8_t> used;
+  size_t g0 = 0;
+  while (g0 < n) {
+    size_t g1 = g0; while (g1 < n && mems[g1].tid == mems[g0].tid) ++g1;
+    const size_t gn = g1 - g0;
+    f.assign(gn, 0); p.assign(gn, -1); used.assign(gn, 0);
+    double best = 0;
+    for (size_t i = 0; i < gn; ++i) {
+      const Mem& hi = mems[g0 + i];
+      f[i] = (double)hi.len; p[i] = -1; int rounds = 2;
+      for (int j = (int)i - 1; j >= 0; --j) {
+        const Mem& hj = mems[g0 + j];
+        if (hj.fw != hi.fw) continue;
+        int qd = (int)hi.q - (int)hj.q, rd = hi.rpos - hj.rpos;
+        if (qd < 0 || std::max(qd, rd) > MAX_CHAIN_GAP) continue;
+        int l = std::abs(qd - rd);
+        double a = (double)std::min((int)hi.len, std::min(qd, rd));
+        double s = f[j] + a - op.gapcost[l];
+        if (s > f[i]) { f[i] = s; p[i] = j; }
+        if (!op.o.disable_chaining_heuristic && p[i] >= 0) { if (--rounds <= 0) break; }  // Li 2018 heuristic (ProgramOptionsGenerator.cpp:160-167)
+      }
+      if (f[i] > best) best = f[i];
+    }
+    const double thr = op.o.pre_merge_chain_sub_thresh * best;  // ProgramOptionsGenerator.cpp:111-118
+    // accept chain ends by (score desc, index asc); a chain touching an already used MEM is dropped
+    std::vector<uint8_t> tried(gn, 0);
+    for (;;) {
+      int bi = -1;
+      for (size_t i = 0; i < gn; ++i) if (!tried[i] && !used[i] && f[i] >= thr && (bi < 0 || f[i] > f[bi])) bi = (int)i;
+      if (bi < 0) break;
+      tried[bi] = 1;
+      bool clash = false; for (int x = bi; x >= 0; x = p[x]) if (used[x]) { clash = true; break; }
+      if (clash) continue;
+      Chain c; c.tid = mems[g0].tid; c.fw = mems[g0 + bi].fw; c.score = f[bi]; c.read_len = (uint16_t)L;
+      for (int x = bi; x >= 0; x = p[x]) { used[x] = 1; c.mems.push_back((uint32_t)(g0 + x)); }
+      std::reverse(c.mems.begin(), c.mems.end());
+      const Mem& m0 = mems[c.mems.front()]; const Mem& ml = mems[c.mems.back()];
+      c.pos = m0.rpos - (int)m0.q; c.last_end = ml.rpos + (int)ml.len;
+      chains.push_back(std::move(c));
+    }
+    g0 = g1;
+  }
+  // hitFilterPolicy AFTER + consensusSlack (ProgramOptionsGenerator.cpp:103-110): per read end
+  double bestAll = 0; for (auto& c : chains) bestAll = std::max(bestAll, c.score);
+  const double cf = (op.o.consensus_slack == 0.0) ? 1.0 : (1.0 - op.o.consensus_slack);  // SalmonMappingUtils.hpp:160-162
+  const double cthr = cf * bestAll;
+  chains.erase(std::remove_if(chains.begin(), chains.end(), [&](const Chain& c) { return c.score < cthr; }), chains.end());
+}
+
+// a3 — pufferfish::util::joinReadsAndFilter [external]; call site SalmonQuantify.cpp:1339-1341,
+// policy from SalmonMappingUtils.hpp:208-220.
+static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::vector<Chain>& rc, std::vector<Cand>& out, bool* had_dovetail) {
+  out.clear(); *had_dovetail = false;
+  size_t i = 0, j = 0;
+  while (i < lc.size() && j < rc.size()) {
+    if (lc[i].tid < rc[j].tid) { ++i; continue; }
+    if (lc[i].tid > rc[j].tid) { ++j; continue; }
+    uint32_t t = lc[i].tid; size_t i1 = i, j1 = j;
+    while (i1 < lc.size() && lc[i1].tid == t) ++i1;
+    while (j1 < rc.size() && rc[j1].tid == t) ++j1;
+    for (size_t a = i; a < i1; ++a) for (size_t b = j; b < j1; ++b) {
+      const Chain& x = lc[a]; const Chain& y = rc[b];
+      if (x.fw == y.fw) continue;  // mpol.noDiscordant = true
+      const Chain& fwc = x.fw ? x : y; const Chain& rcc = x.fw ? y : x;
+      if (rcc.pos < fwc.pos) { *had_dovetail = true; if (!op.o.allow_dovetail) continue; }
+      int32_t fragEnd = rcc.pos + (int)rcc.read_len, fragStart = fwc.pos;
+      int32_t fl = fragEnd - fragStart;
+      if (fl <= 0 || fl > (int32_t)op.o.frag_len_max) continue;
+      Cand c; c.tid = t; c.lc = (int)a; c.rc = (int)b; c.frag_len = (uint32_t)fl; c.mate_status = SQ_MS_PAIRED_END_PAIRED; c.cov = x.score + y.score;
+      out.push_back(c);
+    }
+    i = i1; j = j1;
+  }
+  const double cf = (op.o.consensus_slack == 0.0) ? 1.0 : (1.0 - op.o.consensus_slack);
+  if (!out.empty()) {
+    double best = 0; for (auto& c : out) best = std::max(best, c.cov);
+    double thr = cf * best;
+    out.erase(std::remove_if(out.begin(), out.end(), [&](const Cand& c) { return c.cov < thr; }), out.end());
+    // post-merge sub-optimality per target (ProgramOptionsGenerator.cpp:119-129)
+    std::vector<Cand> kept; size_t a = 0;
+    while (a < out.size()) {
+      size_t b = a; double bt = 0; while (b < out.size() && out[b].tid == out[a].tid) { bt = std::max(bt, out[b].cov); ++b; }
+      for (size_t c = a; c < b; ++c) if (out[c].cov >= op.o.post_merge_chain_sub_thresh * bt) kept.push_back(out[c]);
+      a = b;
+    }
+    out.swap(kept);
+    return 1;  // HAD_CONCORDANT
+  }
+  if (!op.o.allow_orphans) return 0;
+  double best = 0;
+  for (auto& c : lc) best = std::max(best, c.score);
+  for (auto& c : rc) best = std::max(best, c.score);
+  double thr = op.o.orphan_chain_sub_thresh * best;  // global (ProgramOptionsGenerator.cpp:130-137)
+  for (size_t a = 0; a < lc.size(); ++a) if (lc[a].score >= thr) { Cand c; c.tid = lc[a].tid; c.lc = (int)a; c.rc = -1; c.frag_len = 0; c.mate_status = SQ_MS_PAIRED_END_LEFT; c.cov = lc[a].score; out.push_back(c); }
+  for (size_t b = 0; b < rc.size(); ++b) if (rc[b].score >= thr) { Cand c; c.tid = rc[b].tid; c.lc = -1; c.rc = (int)b; c.frag_len = 0; c.mate_status = SQ_MS_PAIRED_END_RIGHT; c.cov = rc[b].score; out.push_back(c); }
+  return out.empty() ? 0 : 2;
+}
+
+// ---- a4 — PuffAligner::calculateAlignments [external] with ksw2 affine-gap DP --------------------
+// call site SalmonQuantify.cpp:1523-1525; configuration SalmonMappingUtils.hpp:168-206.
+// Banded Gotoh (band |i-j| <= bandwidth). mode 0: global (query and target both consumed);
+// mode 1: extension (query consumed, target end free).  SPEC §a4.
+static int32_t dp_align(const Opts& op, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) {
+  const int w = op.bw, go = op.go, ge = op.ge;
+  if (n == 0) return mode == 1 ? 0 : (tl == 0 ? 0 : (tl <= w ? -(go + ge * tl) : NEG_INF));
+  if (tl == 0) return n <= w ? -(go + ge * n) : NEG_INF;
+  const int W = tl + 1;
+  std::vector<int32_t> H((size_t)(n + 1) * W, NEG_INF), E((size_t)(n + 1) * W, NEG_INF), F((size_t)(n + 1) * W, NEG_INF);
+  H[0] = 0;
+  for (int j = 1; j <= tl && j <= w; ++j) { H[j] = -(go + ge * j); E[j] = H[j]; }
+  for (int i = 1; i <= n; ++i) {
+    if (i <= w) { H[(size_t)i * W] = -(go + ge * i); F[(size_t)i * W] = H[(size_t)i * W]; }
+    int jlo = std::max(1, i - w), jhi = std::min(tl, i + w);
+    for (int j = jlo; j <= jhi; ++j) {
+      size_t c = (size_t)i * W + j;
+      int32_t e = std::max(E[c - 1], H[c - 1] - go) - ge;
+      int32_t f = std::max(F[c - W], H[c - W] - go) - ge;
+      int32_t s = (q[i - 1] == t[j - 1] && q[i - 1] < 4) ? op.ma : op.mp;
+      int32_t h = std::max(H[c - W - 1] + s, std::max(e, f));
+      E[c] = std::max(e, NEG_INF); F[c] = std::max(f, NEG_INF); H[c] = std::max(h, NEG_INF);
+    }
+  }
+  if (mode == 0) return (std::abs(n - tl) <= w) ? H[(size_t)n * W + tl] : NEG_INF;
+  int32_t best = NEG_INF;
+  for (int j = std::max(0, n - w); j <= std::min(tl, n + w); ++j) best = std::max(best, H[(size_t)n * W + j]);
+  return best;
+}
+
+// score of a region; uses the mismatch-count fast path when it is provably optimal (SPEC §a4)
+static int32_t region_score(const Opts& op, const uint8_t* q, int n, const uint8_t* t, int tl, int mode, sq_map_stats* st) {
+  if (n == 0 && mode == 1) return 0;
+  if (n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n))) {
+    int mm = 0; for (int i = 0; i < n; ++i) mm += !(q[i] == t[i] && q[i] < 4);
+    int lim = (mode == 0) ? (2 * (op.go + op.ge) + op.ma) : (op.go + op.ge);
+    if (mm * (op.ma - op.mp) <= lim) return op.ma * (n - mm) + op.mp * mm;
+  }
+  if (st) st->num_dp_alignments++;
+  return dp_align(op, q, n, t, tl, mode);
+}
+
+static int32_t align_chain(const Index& ix, const Opts& op, const Chain& ch, const std::vector<Mem>& mems,
+                           const std::vector<uint8_t>& read_fw, sq_map_stats* st) {
+  const int L = (int)read_fw.size();
+  std::vector<uint8_t> R(L);
+  if (ch.fw) R = read_fw; else for (int i = 0; i < L; ++i) { uint8_t c = read_fw[L - 1 - i]; R[i] = c > 3 ? 4 : (uint8_t)(3 - c); }
+  const uint32_t tid = ch.tid; const int Tlen = (int)ix.ref_len[tid]; const uint64_t g = ix.ref_accum[tid];
+  auto refb = [&](int x) -> uint8_t { return (uint8_t)base_at(ix.refseq.data(), g + (uint64_t)x); };
+  std::vector<uint8_t> qb, tb;
+  int64_t score = 0; int prevQ = 0, prevR = 0; bool first = true;
+  for (uint32_t mi : ch.mems) {
+    const Mem& m = mems[mi];
+    int qs = m.q, rs = m.rpos, ln = m.len;
+    if (first) {
+      if (qs > 0) {  // read prefix, extended leftwards over <= qs + REF_EXTEND reference bases
+        int ws = std::max(0, rs - qs - REF_EXTEND); int tl = std::max(0, rs - ws);
+        qb.resize(qs); for (int i = 0; i < qs; ++i) qb[i] = R[qs - 1 - i];
+        tb.resize(tl); for (int i = 0; i < tl; ++i) tb[i] = refb(rs - 1 - i);
+        score += region_score(op, qb.data(), qs, tb.data(), tl, 1, st);
+      }
+      first = false;
+    } else {
+      int ov = std::max(0, std::max(prevQ - qs, prevR - rs));
+      if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) continue; }
+      int gq = qs - prevQ, gr = rs - prevR;
+      if (gq > 0 || gr > 0) {
+        qb.assign(R.begin() + prevQ, R.begin() + qs);
+        tb.resize(gr); for (int i = 0; i < gr; ++i) tb[i] = refb(prevR + i);
+        score += region_score(op, qb.data(), gq, tb.data(), gr, 0, st);
+      }
+    }
+    score += (int64_t)op.ma * ln; prevQ = qs + ln; prevR = rs + ln;
+  }
+  if (prevQ < L) {
+    int tail = L - prevQ; int we = std::min(Tlen, prevR + tail + REF_EXTEND); int tl = std::max(0, we - prevR);
+    qb.assign(R.begin() + prevQ, R.end());
+    tb.resize(tl); for (int i = 0; i < tl; ++i) tb[i] = refb(prevR + i);
+    score += region_score(op, qb.data(), tail, tb.data(), tl, 1, st);
+  }
+  if (score < NEG_INF / 2) return INVALID_SCORE;
+  int32_t min_acc = (int32_t)(op.o.min_score_fraction * (double)(op.ma * L));
+  return (score >= min_acc) ? (int32_t)score : INVALID_SCORE;
+}
+
+// ---- a9 — library-format compatibility (src/util/SalmonUtils.cpp:138-298, :531-652) ---------------
+enum { T_SE = 0, T_PE = 1 };
+enum { O_SAME = 0, O_AWAY = 1, O_TOWARD = 2, O_NONE = 3 };
+enum { S_SA = 0, S_AS = 1, S_S = 2, S_A = 3, S_U = 4 };
+struct LibFmt { uint8_t type, orient, strand; };
+static inline uint8_t format_id(LibFmt f) { return (uint8_t)(f.type | (f.orient << 1) | (f.strand << 3)); }
+static LibFmt hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t e2, bool f2, uint32_t l2, bool canDovetail) {  // SalmonUtils.cpp:577-631
+  if (f1 != f2) {
+    if (f1) { int32_t stretch = canDovetail ? (int32_t)l2 : 0; return (e1 <= e2 + stretch) ? LibFmt{T_PE, O_TOWARD, S_SA} : LibFmt{T_PE, O_AWAY, S_SA}; }
+    int32_t stretch = canDovetail ? (int32_t)l1 : 0; return (e2 <= e1 + stretch) ? LibFmt{T_PE, O_TOWARD, S_AS} : LibFmt{T_PE, O_AWAY, S_AS};
+  }
+  return f1 ? LibFmt{T_PE, O_SAME, S_S} : LibFmt{T_PE, O_SAME, S_A};
+}
+static LibFmt hit_type_se(bool fwd) { return fwd ? LibFmt{T_SE, O_NONE, S_S} : LibFmt{T_SE, O_NONE, S_A}; }  // :633-648
+static bool compatible_hit_se(LibFmt exp, bool isForward, uint8_t ms) {  // SalmonUtils.cpp:195-268
+  switch (ms) {
+    case SQ_MS_SINGLE_END: return isForward ? (exp.strand == S_U || exp.strand == S_S) : (exp.strand == S_U || exp.strand == S_A);
+    case SQ_MS_PAIRED_END_LEFT:
+      if (exp.orient == O_SAME) return exp.strand == S_U || (exp.strand == S_S && isForward) || (exp.strand == S_A && !isForward);
+      return isForward ? (exp.strand == S_U || exp.strand == S_SA) : (exp.strand == S_U || exp.strand == S_AS);
+    case SQ_MS_PAIRED_END_RIGHT:
+      if (exp.orient == O_SAME) return exp.strand == S_U || (exp.strand == S_S && isForward) || (exp.strand == S_A && !isForward);
+      return isForward ? (exp.strand == S_U || exp.strand == S_AS) : (exp.strand == S_U || exp.strand == S_SA);
+    default: return false;
+  }
+}
+static bool compatible_hit_pe(LibFmt exp, LibFmt obs) {  // SalmonUtils.cpp:271-297
+  if (obs.type != T_PE) return false;
+  if (exp.orient != obs.orient) return false;
+  return exp.strand == S_U || exp.strand == obs.strand;
+}
+static bool is_compatible(LibFmt obs, LibFmt exp, bool isForward, uint8_t ms) {  // :138-148
+  return (ms != SQ_MS_PAIRED_END_PAIRED) ? compatible_hit_se(exp, isForward, ms) : compatible_hit_pe(exp, obs);
+}
+// pre-alignment compatibility of a joint hit (SalmonQuantify.cpp:1467-1516)
+static bool joint_compat(LibFmt exp, bool orphan, bool isLeft, bool lfw, bool rfw) {
+  bool unstr = exp.strand == S_U;
+  bool c = unstr ? (orphan ? true : (lfw != rfw)) : false;
+  if (c) return true;
+  if (orphan) {
+    if (exp.strand == S_SA) return (isLeft && lfw) || (!isLeft && !rfw);
+    if (exp.strand == S_AS) return (isLeft && !lfw) || (!isLeft && rfw);
+    return false;
+  }
+  if (exp.strand == S_SA) return lfw && !rfw;
+  if (exp.strand == S_AS) return !lfw && rfw;
+  return false;
+}
+
+// ---- a7/a8 — updateRefMappings + filterAndCollectAlignments (SalmonMappingUtils.hpp:225-405) ------
+struct FragResult { std::vector<sq_aln> alns; uint8_t map_type = SQ_MT_UNMAPPED; };
+
+struct Taps { std::vector<sq_unimem> unimems; std::vector<sq_mem> mems; std::vector<sq_chain> chains; std::vector<sq_cand> cands; bool on = false; };
+
+static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const uint8_t* s1, uint32_t n1, const uint8_t* s2, uint32_t n2, bool paired,
+                         FragResult& out, sq_map_stats& st, Taps* taps) {
+  out.alns.clear(); out.map_type = SQ_MT_UNMAPPED;
+  st.num_reads++;
+  std::vector<uint8_t> rd[2]; std::vector<UniMem> um[2]; std::vector<Mem> mems[2]; std::vector<Chain> ch[2];
+  const int nends = paired ? 2 : 1;
+  for (int e = 0; e < nends; ++e) {
+    encode_read(e ? s2 : s1, e ? n2 : n1, rd[e]);
+    collect_unimems(ix, op, rd[e], um[e], &st);
+    project_mems(ix, op, um[e], (int)rd[e].size(), mems[e]);
+    st.num_mems += mems[e].size();
+    chain_end(ix, op, mems[e], (int)rd[e].size(), ch[e]);
+    st.num_chains += ch[e].size();
+    if (taps && taps->on) {
+      uint32_t eid = paired ? frag * 2 + e : frag;
+      for (auto& u : um[e]) { sq_unimem x{}; x.end = eid; x.qpos = u.qpos; x.len = u.len; x.unitig = u.unitig; x.uoff = u.ustart; x.fw = u.fw; taps->unimems.push_back(x); }
+      for (auto& m : mems[e]) { sq_mem x{}; x.end = eid; x.tid = m.tid; x.rpos = m.rpos; x.qpos = m.q; x.len = m.len; x.fw = m.fw; taps->mems.push_back(x); }
+      for (auto& c : ch[e]) { sq_chain x{}; x.end = eid; x.tid = c.tid; x.pos = c.pos; x.last_end = c.last_end; x.fw = c.fw; x.n_mems = (uint32_t)c.mems.size(); x.score = c.score; taps->chains.push_back(x); }
+    }
+  }
+  if (!ch[0].empty() || !ch[1].empty()) st.num_mapped_at_least_a_kmer++;
+  std::vector<Cand> cands; bool dovetail = false;
+  if (paired) { join_pair(op, ch[0], ch[1], cands, &dovetail); }
+  else {  // joinReadsAndFilterSingle: every surviving chain is a candidate (SalmonQuantify.cpp:2108-2109)
+    for (size_t a = 0; a < ch[0].size(); ++a) { Cand c; c.tid = ch[0][a].tid; c.lc = (int)a; c.rc = -1; c.frag_len = 0; c.mate_status = SQ_MS_SINGLE_END; c.cov = ch[0][a].score; cands.push_back(c); }
+  }
+  if (cands.empty() && dovetail) st.num_dovetails++;
+  st.num_candidates += cands.size();
+  if (!cands.empty()) st.num_with_joint_hits++;  // upperBoundHits (SalmonQuantify.cpp:1368-1370)
+  const LibFmt expf{op.o.lib_type, op.o.lib_orientation, op.o.lib_strand};
+  // scoring + updateRefMappings
+  int32_t bestDecoy = INVALID_SCORE, bestScore = INVALID_SCORE;
+  std::vector<uint8_t> compat(cands.size(), 0), scored(cands.size(), 0);
+  std::vector<int32_t> score(cands.size(), INVALID_SCORE);
+  for (size_t i = 0; i < cands.size(); ++i) {
+    Cand& c = cands[i];
+    bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
+    bool lfw = c.lc >= 0 ? ch[0][c.lc].fw : false, rfw = c.rc >= 0 ? ch[1][c.rc].fw : false;
+    bool isc;
+    if (!paired) isc = compatible_hit_se(expf, lfw, SQ_MS_SINGLE_END);  // SalmonQuantify.cpp:2141-2150
+    else isc = joint_compat(expf, orphan, c.lc >= 0, lfw, rfw);
+    compat[i] = isc;
+    if (!isc && op.o.ignore_incompat) continue;
+    if (c.lc >= 0) c.lscore = align_chain(ix, op, ch[0][c.lc], mems[0], rd[0], &st);
+    if (c.rc >= 0) c.rscore = align_chain(ix, op, ch[1][c.rc], mems[1], rd[1], &st);
+    int32_t hs;
+    if (!orphan) hs = (c.lscore == INVALID_SCORE || c.rscore == INVALID_SCORE) ? INVALID_SCORE : c.lscore + c.rscore;
+    else hs = c.lc >= 0 ? c.lscore : c.rscore;
+    if (hs == INVALID_SCORE) { st.num_mappings_filtered++; continue; }
+    c.valid = true; score[i] = hs; scored[i] = 1;
+  }
+  if (taps && taps->on) for (auto& c : cands) { sq_cand x{}; x.frag = frag; x.tid = c.tid; x.lpos = c.lc >= 0 ? ch[0][c.lc].pos : 0; x.rpos = c.rc >= 0 ? ch[1][c.rc].pos : 0;
+      x.lfw = c.lc >= 0 ? ch[0][c.lc].fw : 0; x.rfw = c.rc >= 0 ? ch[1][c.rc].fw : 0; x.mate_status = c.mate_status; x.valid = c.valid; x.lscore = c.lscore; x.rscore = c.rscore; x.frag_len = c.frag_len; taps->cands.push_back(x); }
+  // updateRefMappings, order-independent form (SPEC §a7): decoys only set bestDecoy; non-decoys
+  // keep one best hit per transcript (ties: the later compatible hit wins).
+  for (size_t i = 0; i < cands.size(); ++i) if (scored[i] && cands[i].tid >= ix.first_decoy) bestDecoy = std::max(bestDecoy, score[i]);
+  auto decoy_cut = [&](int32_t bd) -> int32_t { return (int32_t)(op.o.decoy_threshold * (double)bd); };
+  std::vector<uint8_t> keep(cands.size(), 0);
+  {
+    int32_t runDecoy = INVALID_SCORE;
+    std::unordered_map<uint32_t, size_t> bestPer;
+    for (size_t i = 0; i < cands.size(); ++i) {
+      if (!scored[i]) continue;
+      if (cands[i].tid >= ix.first_decoy) { runDecoy = std::max(runDecoy, score[i]); continue; }
+      if (score[i] < decoy_cut(runDecoy)) continue;
+      auto it = bestPer.find(cands[i].tid);
+      if (it == bestPer.end()) { bestPer[cands[i].tid] = i; keep[i] = 1; }
+      else if (score[i] > score[it->second] || (score[i] == score[it->second] && compat[i])) { keep[it->second] = 0; it->second = i; keep[i] = 1; }
+      if (score[i] > bestScore) bestScore = score[i];
+    }
+  }
+  bool onlyDecoy = (bestScore < decoy_cut(bestDecoy)) && (bestDecoy > INVALID_SCORE);  // MappingScoreInfo::haveOnlyDecoyMappings :115-122
+  if (bestScore > INVALID_SCORE && !onlyDecoy) {
+    int32_t bd = (bestDecoy == INVALID_SCORE) ? INVALID_SCORE + 1 : bestDecoy;  // :292-294
+    int32_t thr = op.o.hard_filter ? bestScore : decoy_cut(bd);
+    std::vector<size_t> kept; for (size_t i = 0; i < cands.size(); ++i) if (keep[i] && score[i] >= thr) kept.push_back(i);
+    std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t b) { return cands[a].tid < cands[b].tid; });
+    for (size_t i : kept) {
+      const Cand& c = cands[i];
+      double v = (double)bestScore - (double)score[i];
+      double p = op.o.hard_filter ? -1.0 : sq_exp(-op.o.score_exp * v);
+      if (!op.o.hard_filter && p < op.o.min_aln_prob) continue;
+      sq_aln a{}; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
+      if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
+        const Chain& l = ch[0][c.lc]; const Chain& r = ch[1][c.rc];
+        a.pos = l.pos; a.fwd = l.fw; a.read_len = (uint16_t)n1; a.mate_pos = r.pos; a.mate_fwd = r.fw; a.mate_len = (uint16_t)n2; a.score = c.lscore; a.mate_score = c.rscore;
+        int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
+        a.format_id = format_id(hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len, false));  // SalmonQuantify.cpp:1770-1777
+      } else {
+        bool left = c.lc >= 0; const Chain& o = left ? ch[0][c.lc] : ch[1][c.rc];
+        a.pos = o.pos; a.fwd = o.fw; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
+        a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
+        a.format_id = format_id(hit_type_se(a.fwd));  // :1760-1768
+      }
+      out.alns.push_back(a);
+    }
+    if (!out.alns.empty()) {
+      switch (out.alns.front().mate_status) {
+        case SQ_MS_PAIRED_END_PAIRED: out.map_type = SQ_MT_PAIRED_MAPPED; break;
+        case SQ_MS_PAIRED_END_LEFT: out.map_type = SQ_MT_LEFT_ORPHAN; break;
+        case SQ_MS_PAIRED_END_RIGHT: out.map_type = SQ_MT_RIGHT_ORPHAN; break;
+        default: out.map_type = SQ_MT_SINGLE_MAPPED; break;
+      }
+    }
+  } else if (!cands.empty()) {
+    // only reached with candidates (SalmonQuantify.cpp:1631-1654): decoy or unmapped
+    bool anyScored = false; for (auto s : scored) anyScored |= (s != 0);
+    (void)anyScored;
+    out.map_type = onlyDecoy ? SQ_MT_DECOY : SQ_MT_UNMAPPED;
+    st.num_decoy_fragments += onlyDecoy ? 1 : 0; st.num_fragments_filtered++;
+  }
+  st.num_alignments += out.alns.size();
+  if (!out.alns.empty()) st.num_mapped++;
+}
+
+// ================================================================================================
+// Online model + eq-classes (processMiniBatch, SalmonQuantify.cpp:426-1023) — batch-synchronous
+// restatement (SPEC §D1): every fragment of a mini-batch sees the model as of the batch start.
+// ================================================================================================
+struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, kernel Binomial(4, 0.5))
+  std::vector<double> hist; double totMass = SQ_LOG_0; double kernel[5]; bool cached = false; std::vector<double> cpmf, ccmf; uint32_t minLen = 1000;
+  static double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
+  void init(double mu, double sd) {
+    hist.assign(1001, SQ_LOG_0);
+    for (int i = 0; i <= 1000; ++i) {
+      // boost::math::cdf(normal(mu, sd), i+.5) - cdf(i-.5): the prior is a table of constants;
+      // the product receives the same table from the host, so libm's erfc is fine here.
+      double nm = phi((i + 0.5 - mu) / sd) - phi((i - 0.5 - mu) / sd);
+      double mass = SQ_LOG_EPSILON; if (nm != 0) mass = 0.0 /*log(alpha=1)*/ + sq_log(nm);
+      hist[i] = mass;
+    }
+    const double pk[5] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    for (int i = 0; i < 5; ++i) kernel[i] = sq_log(pk[i]);
+    totMass = tree_total();
+  }
+  double tree_total() const {  // SPEC §D3: strided-halving logAdd tree over 1024 leaves
+    std::vector<double> v(1024, SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i];
+    for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
+    return v[0];
+  }
+  double pmf(size_t len) const { if (cached) return len < cpmf.size() ? cpmf[len] : cpmf.back(); if (len > 1000) len = 1000; return hist[len] - totMass; }
+  double cmf(size_t len) const { return len < ccmf.size() ? ccmf[len] : ccmf.back(); }  // only used once cached
+  void apply_counts(const std::vector<uint32_t>& cnt, double logFM) {  // batched addVal (:85-110)
+    for (int b = 1; b <= 1000; ++b)
+      for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000 || cnt[len] == 0) continue; hist[b] = sq_log_add(hist[b], logFM + kernel[i] + sq_log((double)cnt[len])); }
+    totMass = tree_total();
+  }
+  void cache() {  // cacheCMF (:174-186) + getLockedPMF (:159-172)
+    cpmf.resize(1001); double tot = SQ_LOG_0;
+    for (int i = 0; i <= 1000; ++i) { cpmf[i] = hist[i] - totMass; tot = sq_log_add(tot, cpmf[i]); }
+    for (int i = 0; i <= 1000; ++i) cpmf[i] -= tot;
+    ccmf.resize(1001); double cum = SQ_LOG_0; for (int i = 0; i <= 1000; ++i) { cum = sq_log_add(cum, cpmf[i]); ccmf[i] = cum; }
+    cached = true;
+  }
+};
+
+struct EqVal { uint64_t count = 0; std::vector<uint64_t> wq; };
+struct QuantState {
+  const Index* ix; Opts op;
+  FLD fld; std::vector<double> ambigCMF;  // LogCMFCache pre-burn-in table (DistributionUtils.cpp:104-118)
+  std::vector<double> mass, priorMass, logEffLen; std::vector<uint64_t> uniq, total, massAcc;
+  std::vector<double> fm;  // forgetting masses per mini-batch
+  uint64_t numObserved = 0, numAssigned = 0, numMappedUB = 0, batchNo = 0; bool burnedIn = false;
+  std::map<std::vector<uint32_t>, EqVal> eq;  // label (tids + bins) -> value
+  std::vector<uint64_t> libCounts;
+  uint64_t readCounter = 0;
+  void init(const Index* i, const sq_quant_opts* o) {
+    ix = i; make_opts(o, op);
+    size_t M = ix->names.size();
+    fld.init(o->fld_mean, o->fld_sd);
+    ambigCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambigCMF[j] = cum; } }
+    mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
+    for (size_t t = 0; t < M; ++t) { double len = (double)ix->ref_len[t]; priorMass[t] = sq_log(0.005 * len); logEffLen[t] = sq_log(len); }  // Transcript.hpp:48-56, ReadExperiment.inl:114
+    libCounts.assign(64, 0);
+  }
+  double forgetting_mass(uint64_t b) {  // ForgettingMassCalculator.hpp:30-40 (prefill recurrence)
+    while (fm.size() <= b) {
+      if (fm.empty()) { fm.push_back(0.0); continue; }
+      uint64_t i = fm.size() + 1;  // i = 2,3,... for index 1,2,...
+      double ff = op.o.forgetting_factor;
+      fm.push_back(fm.back() + ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0));
+    }
+    return fm[b];
+  }
+  void burnin_finalize();
+};
+
+// updateTranscriptLengthsAtomic (ReadExperiment.inl:62-94) + correctionFactorsFromMass /
+// computeSmoothedEffectiveLengths (DistributionUtils.cpp:9-55)
+static void compute_eff_lengths(const FLD& fld, const std::vector<uint32_t>& ref_len, std::vector<double>& logEffLen) {
+  size_t minV = (fld.minLen == 1000) ? 1 : fld.minLen, maxV = 1000;
+  std::vector<double> lp; for (size_t i = minV; i <= maxV; ++i) lp.push_back(fld.pmf(i));
+  double sum = SQ_LOG_0; for (double v : lp) sum = sq_log_add(sum, v);
+  for (double& v : lp) v -= sum;
+  std::vector<double> pmf(maxV + 1, 0.0);
+  for (size_t i = minV; i < maxV; ++i) pmf[i] = 100.0 * sq_exp(lp[i - minV]);
+  size_t n = pmf.size(); std::vector<double> cf(n, 0.0), vals(n, 0.0), mult(n, 0.0);
+  mult[0] = pmf[0];
+  for (size_t i = 1; i < n; ++i) { double v = pmf[i]; vals[i] = v * (double)i + vals[i - 1]; mult[i] = v + mult[i - 1]; if (mult[i] > 0) cf[i] = vals[i] / mult[i]; }
+  for (size_t t = 0; t < ref_len.size(); ++t) {
+    double ol = (double)ref_len[t]; double c = (ol >= (double)n) ? cf[n - 1] : cf[ref_len[t]];
+    double el = ol - c; if (el < 1.0) el = ol;
+    logEffLen[t] = sq_log(el);
+  }
+}
+void QuantState::burnin_finalize() { compute_eff_lengths(fld, ix->ref_len, logEffLen); fld.cache(); burnedIn = true; }
+
+static inline double u01(uint64_t seed, uint64_t read, uint64_t aln) {
+  uint64_t x = sq_mix64(seed ^ sq_mix64(read * 0x9E3779B97F4A7C15ULL + aln + 1));
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+static inline uint32_t frag_len_pedantic(const sq_aln& a, uint32_t txpLen) {  // ReadPair.hpp:149-168 semantics
+  if (a.mate_status != SQ_MS_PAIRED_END_PAIRED || a.fwd == a.mate_fwd) return 0;
+  int32_t T = (int32_t)txpLen;
+  int32_t p1 = a.fwd ? a.pos : a.mate_pos; p1 = p1 < 0 ? 0 : p1; p1 = p1 > T ? T : p1;
+  int32_t p2 = a.fwd ? a.mate_pos + (int32_t)a.mate_len : a.pos + (int32_t)a.read_len; p2 = p2 < 0 ? 0 : p2; p2 = p2 > T ? T : p2;
+  return (uint32_t)(p1 > p2 ? p1 - p2 : p2 - p1);
+}
+
+// one mini-batch [r0, r1) of a CSR alignment batch
+static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln* alns, uint64_t r0, uint64_t r1) {
+  const Opts& op = S.op; const sq_quant_opts& o = op.o; const Index& ix = *S.ix;
+  const double logFM = S.forgetting_mass(S.batchNo);
+  const bool burned = S.burnedIn; const uint64_t assigned0 = S.numAssigned;
+  const LibFmt expf{o.lib_type, o.lib_orientation, o.lib_strand};
+  const bool singleEnd = (o.lib_type == T_SE);
+  std::vector<uint32_t> fldCnt(1001, 0); uint32_t minLen = S.fld.minLen;
+  uint64_t local = 0;
+  std::vector<double> aux, lp; std::vector<uint32_t> tids; std::vector<const sq_aln*> ka;
+  for (uint64_t r = r0; r < r1; ++r) {
+    uint64_t a0 = off[r], a1 = off[r + 1]; uint64_t readIdx = S.readCounter + (r - r0);
+    if (a1 == a0) continue;
+    const bool useAux = (assigned0 + local) >= o.num_pre_burnin_frags;
+    const bool cond = burned || useAux;
+    aux.clear(); lp.clear(); tids.clear(); ka.clear();
+    double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint64_t fmtSeen = 0;
+    for (uint64_t ai = a0; ai < a1; ++ai) {
+      const sq_aln& a = alns[ai]; uint32_t t = a.tid;
+      double refLength = ix.ref_len[t] > 0 ? (double)ix.ref_len[t] : 1.0;
+      double logFragCov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
+      double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)ix.ref_len[t]) : S.logEffLen[t]);
+      double tlc = sq_log_add(S.priorMass[t], S.mass[t]);  // transcript.mass(initialRound = true)
+      uint32_t flen = a.frag_len;
+      if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = frag_len_pedantic(a, ix.ref_len[t]);
+      double logFragProb = 0.0;
+      bool unexpectedOrphan = (expf.type == T_PE && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
+      if (o.model_single_frag_prob && o.use_frag_len_dist && (singleEnd || unexpectedOrphan)) {
+        // LogCMFCache::getAmbigFragLengthProb (DistributionUtils.cpp:151-172)
+        int32_t tl = (int32_t)ix.ref_clen[t], maxFL;
+        if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
+        else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
+        bool useFLD = singleEnd || burned;
+        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.ambigCMF[std::min<size_t>(len, 1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
+        double refCM = cmfv((size_t)tl); bool cm = !(refCM == SQ_LOG_0);
+        logFragProb = cm ? (cmfv((size_t)maxFL) - refCM) : SQ_LOG_EPSILON;
+      } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
+      if (flen > 0 && o.use_frag_len_dist && cond) {
+        double lenProb = S.fld.pmf(flen);
+        if (burned) { double cm = S.fld.cmf(flen); bool ok = ((double)flen < refLength) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+        else if (useAux) logFragProb = lenProb;
+      }
+      LibFmt obs{(uint8_t)(a.format_id & 1), (uint8_t)((a.format_id >> 1) & 3), (uint8_t)(a.format_id >> 3)};
+      bool isCompat = is_compatible(obs, expf, a.fwd, a.mate_status);
+      double logCompat = isCompat ? 0.0 : o.incompat_prior;
+      if (!isCompat && o.ignore_incompat) continue;
+      double startPosProb = -logRefLength;
+      if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction)
+        startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
+      fmtSeen |= 1ULL << a.format_id;
+      double auxProb = logFragProb + logFragCov + logCompat;
+      double logProb = tlc + auxProb + startPosProb;
+      if (std::fabs(logProb) == SQ_LOG_0) continue;
+      sumProbs = sq_log_add(sumProbs, logProb);
+      tids.push_back(t); aux.push_back(auxProb); lp.push_back(logProb); ka.push_back(&a);
+      auxDenom = sq_log_add(auxDenom, auxProb);
+    }
+    if (sumProbs == SQ_LOG_0) continue;
+    ++local;
+    const size_t n = tids.size();
+    for (size_t i = 0; i < n; ++i) aux[i] = sq_exp(aux[i] - auxDenom);
+    std::vector<uint32_t> label(tids);
+    if (o.range_factorization_bins > 0) {  // SalmonQuantify.cpp:845-853
+      int32_t rangeCount = (int32_t)(std::sqrt((double)n) + (double)o.range_factorization_bins);
+      for (size_t i = 0; i < n; ++i) label.push_back((uint32_t)(int32_t)(aux[i] * (double)rangeCount));
+    }
+    EqVal& ev = S.eq[label]; if (ev.wq.empty()) ev.wq.assign(n, 0);
+    ev.count++; for (size_t i = 0; i < n; ++i) ev.wq[i] += sq_to_fixed(aux[i], SQ_WFRAC_BITS);
+    for (size_t i = 0; i < n; ++i) {
+      double nlp = lp[i] - sumProbs; double pr = sq_exp(nlp);
+      S.massAcc[tids[i]] += sq_to_fixed(pr, SQ_MFRAC_BITS);
+      S.total[tids[i]] += 1;
+      if (!burned) {
+        double rr = u01(o.seed, readIdx, i);
+        if (rr < pr) { uint32_t fl = frag_len_pedantic(*ka[i], ix.ref_len[tids[i]]); if (fl > 0) { if (fl > 1000) fl = 1000; fldCnt[fl]++; if (fl < minLen) minLen = fl; } }
+      }
+    }
+    if (n == 1) S.uniq[tids[0]] += 1;
+    for (int f = 0; f < 64; ++f) if (fmtSeen >> f & 1) S.libCounts[f]++;
+  }
+  // batch end: apply updates
+  for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) { S.mass[t] = sq_log_add(S.mass[t], logFM + sq_log(sq_from_fixed(S.massAcc[t], SQ_MFRAC_BITS))); S.massAcc[t] = 0; }
+  if (!burned) { bool any = false; for (auto c : fldCnt) any |= (c != 0); if (any) { S.fld.apply_counts(fldCnt, logFM); S.fld.minLen = minLen; } }
+  S.numAssigned += local; S.numObserved += (r1 - r0); S.readCounter += (r1 - r0); S.batchNo++;
+  if (S.numAssigned >= o.num_burnin_frags && !S.burnedIn) S.burnin_finalize();
+}
+
+// ================================================================================================
+// Inference (CollapsedEMOptimizer.cpp) — deterministic restatement (SPEC §D4)
+// ================================================================================================
+static double canonical_sum(std::vector<double> x) {  // SPEC §D2
+  for (;;) {
+    size_t n = x.size(); if (n == 0) return 0.0;
+    size_t g = (n + 63) / 64; std::vector<double> p(g);
+    for (size_t b = 0; b < g; ++b) {
+      double v[64]; for (int i = 0; i < 64; ++i) v[i] = (b * 64 + i < n) ? x[b * 64 + i] : 0.0;
+      for (int s = 32; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = v[i] + v[i + s];
+      p[b] = v[0];
+    }
+    if (g == 1) return p[0];
+    x.swap(p);
+  }
+}
+
+struct EMProblem {
+  uint32_t M; uint64_t E; std::vector<uint64_t> off, count; std::vector<uint32_t> tid; std::vector<double> cw;  // combined weights
+  std::vector<uint64_t> t_off; std::vector<uint64_t> t_cls, t_pos;  // transcript-major incidence (class order)
+  std::vector<double> prior; std::vector<uint8_t> valid;
+};
+static void em_setup(EMProblem& P, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o) {
+  P.M = txp->num_txp; P.E = eq->num_classes; P.off.assign(eq->off, eq->off + P.E + 1); P.count.assign(eq->count, eq->count + P.E);
+  P.tid.assign(eq->tid, eq->tid + eq->num_labels); P.cw.resize(eq->num_labels);
+  for (uint64_t c = 0; c < P.E; ++c) {  // CollapsedEMOptimizer.cpp:830-873
+    double wsum = 0.0;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) {
+      double el = txp->eff_len[P.tid[i]]; if (el <= 1.0) el = 1.0;
+      double w = o->no_rich_eq_classes ? 1.0 : eq->w[i];
+      double wt = o->eq_class_mode ? w : (double)P.count[c] * w * (1.0 / el);
+      P.cw[i] = wt; wsum += wt;
+    }
+    double wn = 1.0 / wsum;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = P.cw[i] * wn;
+  }
+  P.prior.assign(P.M, o->vb_prior);
+  if (!o->per_transcript_prior) for (uint32_t i = 0; i < P.M; ++i) P.prior[i] = o->vb_prior * txp->eff_len[i];  // :82-99
+  P.t_off.assign(P.M + 1, 0);
+  for (uint64_t i = 0; i < P.tid.size(); ++i) P.t_off[P.tid[i] + 1]++;
+  for (uint32_t t = 0; t < P.M; ++t) P.t_off[t + 1] += P.t_off[t];
+  P.t_cls.resize(P.tid.size()); P.t_pos.resize(P.tid.size());
+  std::vector<uint64_t> cur(P.t_off.begin(), P.t_off.end() - 1);
+  for (uint64_t c = 0; c < P.E; ++c) for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) { uint64_t d = cur[P.tid[i]]++; P.t_cls[d] = c; P.t_pos[d] = i; }
+}
+// one update: returns alphaOut (EMUpdate_ :178-234 / VBEMUpdate_ :241-328), transcript-major sums
+static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<double>& alphaIn, std::vector<double>& alphaOut, std::vector<double>& theta, std::vector<double>& invDenom) {
+  const uint32_t M = P.M;
+  if (o->use_vbem) {
+    std::vector<double> ap(M); for (uint32_t i = 0; i < M; ++i) ap[i] = alphaIn[i] + P.prior[i];
+    double logNorm = sq_digamma(canonical_sum(ap));
+    for (uint32_t i = 0; i < M; ++i) theta[i] = (ap[i] > 1e-10) ? sq_exp(sq_digamma(ap[i]) - logNorm) : 0.0;
+  } else theta = alphaIn;
+  for (uint64_t c = 0; c < P.E; ++c) {
+    uint64_t a = P.off[c], b = P.off[c + 1];
+    if (b - a <= 1) { invDenom[c] = 0.0; continue; }
+    double denom = 0.0;
+    for (uint64_t i = a; i < b; ++i) { double th = theta[P.tid[i]]; if (!o->use_vbem || th > 0.0) denom += th * P.cw[i]; }
+    invDenom[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : (double)P.count[c] / denom;
+  }
+  for (uint32_t t = 0; t < M; ++t) {
+    double acc = 0.0; double th = theta[t];
+    for (uint64_t d = P.t_off[t]; d < P.t_off[t + 1]; ++d) {
+      uint64_t c = P.t_cls[d];
+      if (P.off[c + 1] - P.off[c] == 1) { acc += (double)P.count[c]; continue; }
+      if (invDenom[c] == 0.0) continue;
+      if (o->use_vbem && !(th > 0.0)) continue;
+      double v = th * P.cw[P.t_pos[d]];
+      acc += v * invDenom[c];
+    }
+    alphaOut[t] = acc;
+  }
+}
+
+static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+  EMProblem P; em_setup(P, eq, txp, o);
+  const uint32_t M = P.M;
+  std::vector<double> alpha(M), alphaP(M), theta(M), inv(P.E);
+  // initialisation (CollapsedEMOptimizer.cpp:778-823)
+  std::vector<double> pc(M); double totalWeight = 0.0;
+  for (uint32_t i = 0; i < M; ++i) { pc[i] = txp->projected_counts ? txp->projected_counts[i] : 0.0; }
+  totalWeight = canonical_sum(pc);
+  double uniformPrior = totalWeight / (double)M;
+  double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
+  for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
+  uint32_t it = 0; bool conv = false; double maxRel = -1.7976931348623157e308;
+  while (it < o->min_iter || (it < o->max_iter && !conv)) {
+    em_step(P, o, alpha, alphaP, theta, inv);
+    conv = true; maxRel = -1.7976931348623157e308;
+    for (uint32_t i = 0; i < M; ++i) {
+      if (alphaP[i] > 1e-2) { double rd = std::fabs(alpha[i] - alphaP[i]) / alphaP[i]; if (rd > maxRel) maxRel = rd; if (rd > o->rel_diff_tolerance) conv = false; }
+      alpha[i] = alphaP[i]; alphaP[i] = 0.0;
+    }
+    ++it;
+  }
+  for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector :64-76
+  double asum = canonical_sum(alpha);
+  for (uint32_t i = 0; i < M; ++i) alpha_out[i] = alpha[i];
+  if (rep) { rep->iters = it; rep->converged = conv; rep->max_rel_diff = maxRel; rep->alpha_sum = asum; rep->device_ms = 0; rep->ms_per_iter = 0; }
+  return asum < 2.2250738585072014e-308 ? SQ_ERR_STATE : SQ_OK;
+}
+
+}  // namespace orc
+
+// ================================================================================================
+// C interface used by tests / smoke / bench cpu_baseline (ctypes)
+// ================================================================================================
+using namespace orc;
+struct orc_index { Index ix; };
+struct orc_state { QuantState S; };
+
+extern "C" {
+
+// Build the checker's index from the product's host-side sections (unitigs + contig table are the
+// shared *input*; the dictionary itself is rebuilt here as a brute-force hash map).
+orc_index* orc_index_from_view(const sq_index_view* v, const char* const* names) {
+  orc_index* o = new orc_index(); Index& ix = o->ix;
+  ix.k = v->k; ix.first_decoy = v->first_decoy;
+  for (uint32_t i = 0; i < v->num_refs; ++i) ix.names.push_back(names ? names[i] : std::to_string(i));
+  ix.ref_len.assign(v->ref_len, v->ref_len + v->num_refs); ix.ref_clen.assign(v->ref_clen, v->ref_clen + v->num_refs);
+  ix.ref_accum.assign(v->ref_accum, v->ref_accum + v->num_refs + 1);
+  ix.refseq.assign(v->refseq, v->refseq + (v->total_ref_nt + 31) / 32 + 1);
+  ix.useq.assign(v->useq, v->useq + (v->total_unitig_nt + 31) / 32 + 1);
+  ix.uoff.assign(v->uoff, v->uoff + v->num_unitigs + 1); ix.ctab_off.assign(v->ctab_off, v->ctab_off + v->num_unitigs + 1);
+  ix.ctab.assign(v->ctab, v->ctab + v->num_occ);
+  ix.build_dict();
+  return o;
+}
+void orc_index_free(orc_index* o) { delete o; }
+uint64_t orc_index_num_kmers(const orc_index* o) { return o->ix.num_kmers; }
+int orc_index_lookup(const orc_index* o, uint64_t kmer, uint64_t* u, uint32_t* off, int* fw) {
+  bool f; uint64_t uu; uint32_t oo; if (!o->ix.lookup(kmer & kmask(o->ix.k), uu, oo, f)) return 0; *u = uu; *off = oo; *fw = f; return 1;
+}
+
+// Independent brute-force check of the compacted de Bruijn graph held in a view: returns 0 if the
+// unitigs (a) tile every reference exactly as the contig table says, (b) contain every canonical
+// k-mer exactly once, (c) are maximal under the rules of SPEC §I; else a positive error code.
+int orc_check_cdbg(const sq_index_view* v) {
+  const uint32_t k = v->k; const uint64_t km = kmask(k);
+  std::unordered_map<uint64_t, uint32_t> seen;  // canonical k-mer -> count in unitigs
+  for (uint64_t u = 0; u < v->num_unitigs; ++u) {
+    uint64_t b = v->uoff[u], e = v->uoff[u + 1]; if (e - b < k) return 1;
+    uint64_t fw = 0;
+    for (uint64_t i = 0; i < e - b; ++i) { fw = (fw >> 2) | ((uint64_t)base_at(v->useq, b + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km; uint64_t rc = revcomp(fw, k); if (++seen[std::min(fw, rc)] > 1) return 2; }
+  }
+  // every reference k-mer present; occurrences reproduce references
+  std::vector<uint8_t> covered;
+  for (uint32_t r = 0; r < v->num_refs; ++r) {
+    uint32_t L = v->ref_len[r]; covered.assign(L, 0);
+    if (L >= k) { uint64_t fw = 0; for (uint32_t i = 0; i < L; ++i) { fw = (fw >> 2) | ((uint64_t)base_at(v->refseq, v->ref_accum[r] + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km; uint64_t rc = revcomp(fw, k); if (!seen.count(std::min(fw, rc))) return 3; } }
+  }
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> cov(v->num_refs);
+  for (uint64_t u = 0; u < v->num_unitigs; ++u) {
+    uint64_t ulen = v->uoff[u + 1] - v->uoff[u];
+    if (v->ctab_off[u + 1] == v->ctab_off[u]) return 4;
+    for (uint64_t i = v->ctab_off[u]; i < v->ctab_off[u + 1]; ++i) {
+      uint64_t e = v->ctab[i]; uint32_t t = (uint32_t)(e >> 32); bool fw = (e >> 31) & 1; uint32_t pos = (uint32_t)(e & 0x7FFFFFFF);
+      if (pos + ulen > v->ref_len[t]) return 5;
+      for (uint64_t j = 0; j < ulen; ++j) {
+        uint32_t rb = base_at(v->refseq, v->ref_accum[t] + pos + j);
+        uint32_t ub = fw ? base_at(v->useq, v->uoff[u] + j) : 3 - base_at(v->useq, v->uoff[u] + (ulen - 1 - j));
+        if (rb != ub) return 6;
+      }
+      cov[t].push_back({pos, (uint32_t)ulen});
+    }
+  }
+  for (uint32_t r = 0; r < v->num_refs; ++r) {
+    if (v->ref_len[r] < k) { if (!cov[r].empty()) return 7; continue; }
+    std::sort(cov[r].begin(), cov[r].end());
+    uint32_t expect = 0;  // consecutive unitigs overlap by k-1
+    for (auto& pr : cov[r]) { if (pr.first != expect) return 8; expect = pr.first + pr.second - (k - 1); }
+    if (expect + (k - 1) != v->ref_len[r]) return 9;
+  }
+  // maximality: rebuild edge sets by brute force and check that no two adjacent unitig ends could merge
+  std::unordered_map<uint64_t, uint32_t> info;  // canonical -> bits (R mask 0-3, L mask 4-7, Rterm 8, Lterm 9)
+  for (uint32_t r = 0; r < v->num_refs; ++r) {
+    uint32_t L = v->ref_len[r]; if (L < k) continue; uint32_t nk = L - k + 1; uint64_t fw = 0;
+    for (uint32_t i = 0; i < L; ++i) {
+      fw = (fw >> 2) | ((uint64_t)base_at(v->refseq, v->ref_accum[r] + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km;
+      uint32_t p = i + 1 - k; uint64_t rc = revcomp(fw, k); bool o1 = fw < rc; uint32_t bits = 0;
+      if (p + 1 < nk) { uint32_t s = base_at(v->refseq, v->ref_accum[r] + p + k); bits |= o1 ? (1u << s) : (1u << (4 + 3 - s)); } else bits |= o1 ? 256u : 512u;
+      if (p > 0) { uint32_t q = base_at(v->refseq, v->ref_accum[r] + p - 1); bits |= o1 ? (1u << (4 + q)) : (1u << (3 - q)); } else bits |= o1 ? 512u : 256u;
+      info[std::min(fw, rc)] |= bits;
+    }
+  }
+  auto side_break = [&](uint64_t can, bool right) { uint32_t inf = info[can]; uint32_t m = right ? (inf & 15) : ((inf >> 4) & 15); bool t = right ? (inf >> 8) & 1 : (inf >> 9) & 1; return t || __builtin_popcount(m) != 1; };
+  for (uint64_t u = 0; u < v->num_unitigs; ++u) {
+    uint64_t b = v->uoff[u], ulen = v->uoff[u + 1] - b;
+    // interior joins must all be non-breaking; the two outer sides must be breaking
+    uint64_t fw = 0, prevc = 0; bool prevo = false;
+    for (uint64_t i = 0; i < ulen; ++i) {
+      fw = (fw >> 2) | ((uint64_t)base_at(v->useq, b + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km;
+      uint64_t rc = revcomp(fw, k); bool o1 = fw < rc; uint64_t c = o1 ? fw : rc; uint64_t p = i + 1 - k;
+      if (p == 0) {
+        // outer left side must break, unless merging is blocked by a hairpin (neighbour is itself)
+        if (!side_break(c, !o1)) {
+          // unique predecessor exists: breaking is still legal if the predecessor's facing side breaks or it is a hairpin
+          uint32_t inf = info[c]; uint32_t m = (!o1) ? (inf & 15) : ((inf >> 4) & 15); uint32_t bs = __builtin_ctz(m);
+          // reconstruct predecessor k-mer in walk orientation
+          uint32_t base = o1 ? bs : 3 - bs;  // base preceding fw
+          uint64_t pf = ((fw << 2) | base) & km; uint64_t prc = revcomp(pf, k); bool po = pf < prc; uint64_t pcn = po ? pf : prc;
+          if (!(side_break(pcn, po) || pcn == c)) return 10;
+        }
+      } else {
+        if (side_break(prevc, prevo) || side_break(c, !o1) || prevc == c) return 11;
+      }
+      prevc = c; prevo = o1;
+    }
+  }
+  return 0;
+}
+
+void orc_map_batch(const orc_index* oi, const sq_quant_opts* o, const sq_read_batch* in, uint32_t nthreads,
+                   uint64_t* read_off /*[n+1]*/, sq_aln* alns, uint64_t aln_cap, uint8_t* map_type, sq_map_stats* stats, uint64_t* n_alns_out) {
+  Opts op; make_opts(o, op);
+  const uint32_t n = in->n; std::vector<FragResult> res(n);
+  std::vector<sq_map_stats> sts(std::max(1u, nthreads)); for (auto& s : sts) memset(&s, 0, sizeof(s));
+  std::atomic<uint32_t> next(0);
+  auto work = [&](uint32_t t) {
+    for (;;) {
+      uint32_t b = next.fetch_add(256); if (b >= n) break; uint32_t e = std::min(n, b + 256);
+      for (uint32_t i = b; i < e; ++i) {
+        if (in->paired) { const uint8_t* s1 = in->seq + in->seq_off[2 * i]; uint32_t n1 = (uint32_t)(in->seq_off[2 * i + 1] - in->seq_off[2 * i]); const uint8_t* s2 = in->seq + in->seq_off[2 * i + 1]; uint32_t n2 = (uint32_t)(in->seq_off[2 * i + 2] - in->seq_off[2 * i + 1]);
+          map_fragment(oi->ix, op, i, s1, n1, s2, n2, true, res[i], sts[t], nullptr); }
+        else { const uint8_t* s1 = in->seq + in->seq_off[i]; uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]); map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, res[i], sts[t], nullptr); }
+      }
+    }
+  };
+  if (nthreads <= 1) work(0); else { std::vector<std::thread> th; for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  uint64_t tot = 0; read_off[0] = 0;
+  for (uint32_t i = 0; i < n; ++i) { for (auto& a : res[i].alns) { if (tot < aln_cap) alns[tot] = a; ++tot; } read_off[i + 1] = tot; if (map_type) map_type[i] = res[i].map_type; }
+  if (n_alns_out) *n_alns_out = tot;
+  if (stats) { memset(stats, 0, sizeof(*stats)); uint64_t* d = (uint64_t*)stats; for (auto& s : sts) { const uint64_t* p = (const uint64_t*)&s; for (size_t j = 0; j < sizeof(sq_map_stats) / 8; ++j) d[j] += p[j]; } }
+}
+
+// stage taps for one batch (single-threaded): fills caller buffers, returns counts via n_out[4]
+void orc_map_taps(const orc_index* oi, const sq_quant_opts* o, const sq_read_batch* in, sq_unimem* um, uint64_t um_cap, sq_mem* mm, uint64_t mm_cap,
+                  sq_chain* ch, uint64_t ch_cap, sq_cand* cd, uint64_t cd_cap, uint64_t* n_out) {
+  Opts op; make_opts(o, op); Taps tp; tp.on = true; sq_map_stats st; memset(&st, 0, sizeof(st)); FragResult fr;
+  for (uint32_t i = 0; i < in->n; ++i) {
+    if (in->paired) { const uint8_t* s1 = in->seq + in->seq_off[2 * i]; uint32_t n1 = (uint32_t)(in->seq_off[2 * i + 1] - in->seq_off[2 * i]); const uint8_t* s2 = in->seq + in->seq_off[2 * i + 1]; uint32_t n2 = (uint32_t)(in->seq_off[2 * i + 2] - in->seq_off[2 * i + 1]); map_fragment(oi->ix, op, i, s1, n1, s2, n2, true, fr, st, &tp); }
+    else { const uint8_t* s1 = in->seq + in->seq_off[i]; uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]); map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, fr, st, &tp); }
+  }
+  n_out[0] = tp.unimems.size(); n_out[1] = tp.mems.size(); n_out[2] = tp.chains.size(); n_out[3] = tp.cands.size();
+  for (size_t i = 0; i < tp.unimems.size() && i < um_cap; ++i) um[i] = tp.unimems[i];
+  for (size_t i = 0; i < tp.mems.size() && i < mm_cap; ++i) mm[i] = tp.mems[i];
+  for (size_t i = 0; i < tp.chains.size() && i < ch_cap; ++i) ch[i] = tp.chains[i];
+  for (size_t i = 0; i < tp.cands.size() && i < cd_cap; ++i) cd[i] = tp.cands[i];
+}
+
+orc_state* orc_state_create(const orc_index* oi, const sq_quant_opts* o) { orc_state* s = new orc_state(); s->S.init(&oi->ix, o); return s; }
+void orc_state_free(orc_state* s) { delete s; }
+// feed one mapped batch (CSR) through the online model in mini-batches, in input order
+void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, uint64_t num_with_joint_hits) {
+  QuantState& S = s->S; uint32_t mb = S.op.o.mini_batch_size ? S.op.o.mini_batch_size : 5000;
+  for (uint64_t r0 = 0; r0 < n; r0 += mb) process_mini_batch(S, read_off, alns, r0, std::min<uint64_t>(n, r0 + mb));
+  S.numMappedUB += num_with_joint_hits;
+}
+// finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
+void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }
+void orc_state_summary(orc_state* s, sq_model_summary* m) { m->num_observed = s->S.numObserved; m->num_assigned = s->S.numAssigned; m->num_mapped_ub = s->S.numMappedUB; m->burned_in = s->S.burnedIn; }
+void orc_state_fetch(orc_state* s, double* log_mass, uint64_t* uniq, uint64_t* total, double* log_eff_len, double* fld_logpmf) {
+  QuantState& S = s->S; size_t M = S.mass.size();
+  for (size_t t = 0; t < M; ++t) { if (log_mass) log_mass[t] = S.mass[t]; if (uniq) uniq[t] = S.uniq[t]; if (total) total[t] = S.total[t]; if (log_eff_len) log_eff_len[t] = S.logEffLen[t]; }
+  if (fld_logpmf) for (int i = 0; i <= 1000; ++i) fld_logpmf[i] = S.fld.pmf(i);
+}
+// label hash shared with the product (two independent 64-bit mixes over tids+bins)
+static void label_hash(const std::vector<uint32_t>& lab, uint64_t* h1, uint64_t* h2) {
+  uint64_t a = 0x243F6A8885A308D3ULL ^ lab.size(), b = 0x13198A2E03707344ULL + lab.size();
+  for (uint32_t x : lab) { a = sq_mix64(a ^ (uint64_t)x) + 0x9E3779B97F4A7C15ULL; b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29); }
+  *h1 = sq_mix64(a); *h2 = sq_mix64(b);
+}
+// eq table in canonical order (ascending (h1,h2)); call with NULL arrays to get sizes
+void orc_eq_finish(orc_state* s, sq_eq_table* out) {
+  QuantState& S = s->S;
+  struct Row { uint64_t h1, h2; const std::vector<uint32_t>* lab; const EqVal* v; };
+  std::vector<Row> rows; rows.reserve(S.eq.size()); uint64_t L = 0;
+  for (auto& kv : S.eq) { Row r; label_hash(kv.first, &r.h1, &r.h2); r.lab = &kv.first; r.v = &kv.second; rows.push_back(r); L += kv.second.wq.size(); }
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
+  out->num_classes = rows.size(); out->num_labels = L;
+  if (!out->off) return;
+  uint64_t p = 0;
+  for (size_t c = 0; c < rows.size(); ++c) {
+    const Row& r = rows[c]; size_t n = r.v->wq.size(); out->off[c] = p; out->count[c] = r.v->count; if (out->h1) out->h1[c] = r.h1; if (out->h2) out->h2[c] = r.h2;
+    double sum = 0.0; for (size_t i = 0; i < n; ++i) sum += sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS);
+    double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
+    for (size_t i = 0; i < n; ++i) { out->tid[p + i] = (*r.lab)[i]; out->w[p + i] = sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS) * norm; if (out->wq) out->wq[p + i] = r.v->wq[i]; if (out->bins) out->bins[p + i] = r.lab->size() > n ? (*r.lab)[n + i] : 0; }
+    p += n;
+  }
+  out->off[rows.size()] = p;
+}
+
+// normalizeAlphas (SalmonUtils.cpp:461-529) + TranscriptCluster::projectToPolytope (TranscriptCluster.hpp:46-102)
+// over clusters = connected components of the eq-class labels; members in ascending tid (SPEC §D5).
+void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
+  std::vector<uint32_t> parent(M); for (uint32_t i = 0; i < M; ++i) parent[i] = i;
+  auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+  for (uint64_t c = 0; c < eq->num_classes; ++c) for (uint64_t i = eq->off[c] + 1; i < eq->off[c + 1]; ++i) { uint32_t a = find(eq->tid[eq->off[c]]), b = find(eq->tid[i]); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }
+  std::vector<double> hits(M, 0.0);
+  for (uint64_t c = 0; c < eq->num_classes; ++c) hits[find(eq->tid[eq->off[c]])] += (double)eq->count[c];
+  std::vector<std::vector<uint32_t>> members(M);
+  for (uint32_t t = 0; t < M; ++t) members[find(t)].push_back(t);
+  for (uint32_t r = 0; r < M; ++r) {
+    auto& mem = members[r]; if (mem.empty()) continue;
+    double logClusterMass = SQ_LOG_0; for (uint32_t t : mem) logClusterMass = sq_log_add(logClusterMass, log_mass[t]);
+    double logClusterCount = hits[r] > 0 ? sq_log(hits[r]) : SQ_LOG_0;  // salmon::math-free std::log(0) = -inf in the reference; exp(-inf)=0 either way
+    bool need = false;
+    for (uint32_t t : mem) {
+      if (log_mass[t] == SQ_LOG_0) projected[t] = 0;
+      else { projected[t] = (hits[r] > 0) ? sq_exp(log_mass[t] - logClusterMass + logClusterCount) : 0.0; need |= projected[t] > (double)total[t] || projected[t] < (double)uniq[t]; }
+    }
+    if (mem.size() > 1 && need) {
+      double clusterCounts = hits[r]; std::vector<uint8_t> bound(mem.size(), 0); size_t round = 0;
+      for (;;) {
+        double unb = 0.0, bnd = 0.0;
+        for (size_t i = 0; i < mem.size(); ++i) { uint32_t t = mem[i];
+          if (projected[t] > (double)total[t]) { projected[t] = (double)total[t]; bound[i] = 1; } else if (projected[t] < (double)uniq[t]) { projected[t] = (double)uniq[t]; bound[i] = 1; }
+          if (bound[i]) bnd += projected[t]; else unb += projected[t]; }
+        if (std::fabs(unb + bnd - clusterCounts) <= 0.375e-10) break;
+        if (unb == 0) { std::fill(bound.begin(), bound.end(), 0); unb = bnd; bnd = 0; }
+        double nz = (clusterCounts - bnd) / unb;
+        for (size_t i = 0; i < mem.size(); ++i) if (!bound[i]) projected[mem[i]] *= nz;
+        if (++round > 5000) break;
+      }
+    }
+  }
+}
+
+int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) { return em_optimize(eq, txp, o, alpha_out, rep); }
+int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out) {
+  EMProblem P; em_setup(P, eq, txp, o); std::vector<double> a(alpha_in, alpha_in + P.M), b(P.M), th(P.M), inv(P.E);
+  for (uint32_t i = 0; i < iters; ++i) { em_step(P, o, a, b, th, inv); a.swap(b); }
+  for (uint32_t i = 0; i < P.M; ++i) alpha_out[i] = a[i];
+  return 0;
+}
+// multi-threaded EM timing leg for the CPU baseline: class pass + transcript pass over thread ranges
+double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t iters, uint32_t nthreads);
+
+double orc_canonical_sum(const double* x, uint64_t n) { return canonical_sum(std::vector<double>(x, x + n)); }
+double orc_exp(double x) { return sq_exp(x); }
+double orc_log(double x) { return sq_log(x); }
+double orc_digamma(double x) { return sq_digamma(x); }
+double orc_log_add(double x, double y) { return sq_log_add(x, y); }
+int orc_compatible_pe(int et, int eo, int es, int ot, int oo, int os) { return compatible_hit_pe(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, LibFmt{(uint8_t)ot, (uint8_t)oo, (uint8_t)os}); }
+int orc_compatible_se(int et, int eo, int es, int fwd, int ms) { return compatible_hit_se(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, fwd != 0, (uint8_t)ms); }
+int orc_format_id(int t, int o, int s) { return format_id(LibFmt{(uint8_t)t, (uint8_t)o, (uint8_t)s}); }
+int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) { Opts op; make_opts(o, op); return dp_align(op, q, n, t, tl, mode); }
+void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) { FLD f; f.init(mu, sd); for (int i = 0; i <= 1000; ++i) log_hist_1001[i] = f.hist[i]; *tot = f.totMass; }
+double orc_forgetting_mass(double ff, uint64_t b) { QuantState S; S.op.o.forgetting_factor = ff; return S.forgetting_mass(b); }
+
+}  // extern "C"
+
+// threads split classes / transcripts statically; per-iteration barrier via join (coarse but fair)
+double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t iters, uint32_t nthreads) {
+  EMProblem P; em_setup(P, eq, txp, o); const uint32_t M = P.M;
+  std::vector<double> a(M, 100.0), b(M), th(M), inv(P.E);
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t it = 0; it < iters; ++it) {
+    if (o->use_vbem) { std::vector<double> ap(M); for (uint32_t i = 0; i < M; ++i) ap[i] = a[i] + P.prior[i]; double ln = sq_digamma(canonical_sum(ap));
+      auto f1 = [&](uint32_t t) { for (uint32_t i = t; i < M; i += nthreads) th[i] = ap[i] > 1e-10 ? sq_exp(sq_digamma(ap[i]) - ln) : 0.0; };
+      std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f1, t); for (auto& x : tv) x.join(); } else th = a;
+    auto f2 = [&](uint32_t t) { uint64_t c0 = P.E * t / nthreads, c1 = P.E * (t + 1) / nthreads;
+      for (uint64_t c = c0; c < c1; ++c) { uint64_t x = P.off[c], y = P.off[c + 1]; if (y - x <= 1) { inv[c] = 0; continue; } double d = 0; for (uint64_t i = x; i < y; ++i) { double v = th[P.tid[i]]; if (!o->use_vbem || v > 0) d += v * P.cw[i]; } inv[c] = d <= 2.2250738585072014e-308 ? 0.0 : (double)P.count[c] / d; } };
+    { std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f2, t); for (auto& x : tv) x.join(); }
+    auto f3 = [&](uint32_t t) { uint32_t m0 = (uint64_t)M * t / nthreads, m1 = (uint64_t)M * (t + 1) / nthreads;
+      for (uint32_t m = m0; m < m1; ++m) { double acc = 0, v0 = th[m]; for (uint64_t d = P.t_off[m]; d < P.t_off[m + 1]; ++d) { uint64_t c = P.t_cls[d]; if (P.off[c + 1] - P.off[c] == 1) { acc += (double)P.count[c]; continue; } if (inv[c] == 0.0 || (o->use_vbem && !(v0 > 0))) continue; acc += v0 * P.cw[P.t_pos[d]] * inv[c]; } b[m] = acc; } };
+    { std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f3, t); for (auto& x : tv) x.join(); }
+    a.swap(b);
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's seams over the C ABI (numpy in / numpy out).
+
+Names follow the reference: SalmonIndex (include/salmon/internal/index/SalmonIndex.hpp),
+processReads -> QuantContext.map_batch (src/quant/SalmonQuantify.cpp:1026-1874),
+EquivalenceClassBuilder.finish -> QuantContext.eq_finish, CollapsedEMOptimizer.optimize ->
+em_optimize (src/inference/CollapsedEMOptimizer.cpp:732-1035).  All compute happens in
+libsalmon_hip.so on a gfx950 device; nothing here computes.
+"""
+import ctypes as C
+import numpy as np
+from . import capi
+from .capi import check, lib
+
+ALN_DTYPE = np.dtype([("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("score", "<i4"), ("mate_score", "<i4"),
+                      ("frag_len", "<u4"), ("read_len", "<u2"), ("mate_len", "<u2"), ("fwd", "u1"), ("mate_fwd", "u1"),
+                      ("mate_status", "u1"), ("format_id", "u1"), ("est_aln_prob", "<f8")], align=True)
+UNIMEM_DTYPE = np.dtype([("end", "<u4"), ("qpos", "<u2"), ("len", "<u2"), ("unitig", "<u8"), ("uoff", "<u4"), ("fw", "u1")], align=True)
+MEM_DTYPE = np.dtype([("end", "<u4"), ("tid", "<u4"), ("rpos", "<i4"), ("qpos", "<u2"), ("len", "<u2"), ("fw", "u1")], align=True)
+CHAIN_DTYPE = np.dtype([("end", "<u4"), ("tid", "<u4"), ("pos", "<i4"), ("last_end", "<i4"), ("fw", "u1"), ("n_mems", "<u4"), ("score", "<f8")], align=True)
+CAND_DTYPE = np.dtype([("frag", "<u4"), ("tid", "<u4"), ("lpos", "<i4"), ("rpos", "<i4"), ("lfw", "u1"), ("rfw", "u1"),
+                       ("mate_status", "u1"), ("valid", "u1"), ("lscore", "<i4"), ("rscore", "<i4"), ("frag_len", "<u4")], align=True)
+assert ALN_DTYPE.itemsize == C.sizeof(capi.Aln)
+assert UNIMEM_DTYPE.itemsize == C.sizeof(capi.UniMem) and MEM_DTYPE.itemsize == C.sizeof(capi.Mem)
+assert CHAIN_DTYPE.itemsize == C.sizeof(capi.Chain) and CAND_DTYPE.itemsize == C.sizeof(capi.Cand)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def quant_opts(**kw):
+    o = capi.QuantOpts()
+    lib().sq_quant_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+LIBTYPES = {  # src/util/LibraryTypeUtils.cpp:22-46 -> (type, orientation, strandedness)
+    "IU": (1, 2, 4), "ISF": (1, 2, 0), "ISR": (1, 2, 1), "OU": (1, 1, 4), "OSF": (1, 1, 0), "OSR": (1, 1, 1),
+    "MU": (1, 0, 4), "MSF": (1, 0, 2), "MSR": (1, 0, 3), "U": (0, 3, 4), "SF": (0, 3, 2), "SR": (0, 3, 3)}
+
+
+def set_libtype(o, name):
+    t, orient, s = LIBTYPES[name.upper()]
+    o.lib_type, o.lib_orientation, o.lib_strand = t, orient, s
+    return o
+
+
+def em_opts(**kw):
+    o = capi.EmOpts()
+    lib().sq_em_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class SalmonIndex:
+    """B0: `salmon index` + index handle."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @staticmethod
+    def build(fasta, outdir, decoys=None, k=31, m=0, threads=0, keep_duplicates=False, no_clip=False, gencode=False):
+        o = capi.IndexOpts(k, m, int(keep_duplicates), int(no_clip), threads, int(gencode))
+        check(lib().sq_index_build(C.byref(o), fasta.encode(), decoys.encode() if decoys else None, outdir.encode()), "sq_index_build")
+
+    @staticmethod
+    def build_mem(names, seqs, k=31, m=0, threads=0, first_decoy=None, outdir=None, keep_duplicates=False, no_clip=False):
+        n = len(names)
+        o = capi.IndexOpts(k, m, int(keep_duplicates), int(no_clip), threads, 0)
+        nm = (C.c_char_p * n)(*[x.encode() if isinstance(x, str) else x for x in names])
+        sb = [x.encode() if isinstance(x, str) else bytes(x) for x in seqs]
+        sq = (C.c_char_p * n)(*sb)
+        ln = (C.c_uint32 * n)(*[len(x) for x in sb])
+        out = C.c_void_p()
+        check(lib().sq_index_build_mem(C.byref(o), n, nm, sq, ln, n if first_decoy is None else first_decoy,
+                                       outdir.encode() if outdir else None, C.byref(out)), "sq_index_build_mem")
+        return SalmonIndex(out.value)
+
+    @staticmethod
+    def build_mem_raw(n, names_p, seqs_p, lens_p, k=31, m=0, threads=0, first_decoy=None, outdir=None):
+        o = capi.IndexOpts(k, m, 0, 0, threads, 0)
+        out = C.c_void_p()
+        check(lib().sq_index_build_mem(C.byref(o), n, names_p, seqs_p, lens_p, n if first_decoy is None else first_decoy,
+                                       outdir.encode() if outdir else None, C.byref(out)), "sq_index_build_mem")
+        return SalmonIndex(out.value)
+
+    @staticmethod
+    def load(dirname, device=-1):
+        out = C.c_void_p()
+        check(lib().sq_index_load(dirname.encode(), device, C.byref(out)), "sq_index_load")
+        return SalmonIndex(out.value)
+
+    def to_device(self, device=0):
+        check(lib().sq_index_to_device(self.h, device), "sq_index_to_device")
+        return self
+
+    def free(self):
+        if self.h:
+            lib().sq_index_free(self.h)
+            self.h = None
+
+    k = property(lambda s: lib().sq_index_k(s.h))
+    m = property(lambda s: lib().sq_index_m(s.h))
+    num_refs = property(lambda s: lib().sq_index_num_refs(s.h))
+    first_decoy = property(lambda s: lib().sq_index_first_decoy(s.h))
+    num_unitigs = property(lambda s: lib().sq_index_num_unitigs(s.h))
+    num_kmers = property(lambda s: lib().sq_index_num_kmers(s.h))
+    device_bytes = property(lambda s: lib().sq_index_device_bytes(s.h))
+
+    def ref_names(self):
+        return [lib().sq_index_ref_name(self.h, i).decode() for i in range(self.num_refs)]
+
+    def ref_lens(self):
+        return np.array([lib().sq_index_ref_len(self.h, i) for i in range(self.num_refs)], dtype=np.uint32)
+
+    def ref_complete_lens(self):
+        return np.array([lib().sq_index_ref_complete_len(self.h, i) for i in range(self.num_refs)], dtype=np.uint32)
+
+    def view(self):
+        v = capi.IndexView()
+        check(lib().sq_index_get_view(self.h, C.byref(v)), "sq_index_get_view")
+        return v
+
+    def lookup_host(self, kmer):
+        u, off, fw = C.c_uint64(), C.c_uint32(), C.c_int()
+        ok = lib().sq_index_lookup_host(self.h, int(kmer), C.byref(u), C.byref(off), C.byref(fw))
+        return (u.value, off.value, bool(fw.value)) if ok else None
+
+
+def make_read_batch(seq, seq_off, n, paired=True, on_device=False):
+    """seq: uint8 array (or device pointer int), seq_off: uint64 array of nrec+1 (or device pointer)."""
+    rb = capi.ReadBatch()
+    rb.n = n
+    rb.paired = int(paired)
+    rb.seq = seq if isinstance(seq, int) else seq.ctypes.data
+    rb.seq_off = seq_off if isinstance(seq_off, int) else seq_off.ctypes.data
+    rb.on_device = int(on_device)
+    return rb
+
+
+def eq_table_from_arrays(off, tid, w, count, wq=None, bins=None, h1=None, h2=None):
+    t = capi.EqTable()
+    t.num_classes = len(count)
+    t.num_labels = len(tid)
+    t.off = _ptr(off, C.c_uint64); t.tid = _ptr(tid, C.c_uint32); t.w = _ptr(w, C.c_double); t.count = _ptr(count, C.c_uint64)
+    if wq is not None: t.wq = _ptr(wq, C.c_uint64)
+    if bins is not None: t.bins = _ptr(bins, C.c_uint32)
+    if h1 is not None: t.h1 = _ptr(h1, C.c_uint64)
+    if h2 is not None: t.h2 = _ptr(h2, C.c_uint64)
+    t._keep = (off, tid, w, count, wq, bins, h1, h2)
+    return t
+
+
+class EqClasses:
+    """Flattened eqVec() (EquivalenceClassBuilder.hpp:165-181): CSR of (label tids, weights, count)."""
+
+    def __init__(self, off, tid, w, count, wq=None, bins=None, h1=None, h2=None):
+        self.off, self.tid, self.w, self.count, self.wq, self.bins, self.h1, self.h2 = off, tid, w, count, wq, bins, h1, h2
+
+    def table(self):
+        return eq_table_from_arrays(self.off, self.tid, self.w, self.count, self.wq, self.bins, self.h1, self.h2)
+
+    @staticmethod
+    def alloc(E, L):
+        return EqClasses(np.zeros(E + 1, np.uint64), np.zeros(L, np.uint32), np.zeros(L, np.float64), np.zeros(E, np.uint64),
+                         np.zeros(L, np.uint64), np.zeros(L, np.uint32), np.zeros(E, np.uint64), np.zeros(E, np.uint64))
+
+    def collapsed(self):
+        """Collapse range-factorised labels to transcript sets (GZipWriter.cpp:89-114) -> {tuple(tids): count}."""
+        d = {}
+        for c in range(len(self.count)):
+            key = tuple(int(x) for x in self.tid[self.off[c]:self.off[c + 1]])
+            d[key] = d.get(key, 0) + int(self.count[c])
+        return d
+
+
+class QuantContext:
+    """B1/B2: per-device mapping + online model + eq-class table."""
+
+    def __init__(self, index, opts=None, device=0, max_batch_reads=1 << 20):
+        self.index = index
+        self.opts = opts if opts is not None else quant_opts()
+        out = C.c_void_p()
+        check(lib().sq_ctx_create(index.h, C.byref(self.opts), device, max_batch_reads, C.byref(out)), "sq_ctx_create")
+        self.h = out
+
+    def free(self):
+        if self.h:
+            lib().sq_ctx_free(self.h)
+            self.h = None
+
+    def map_batch(self, rb, fetch=True, aln_cap=None):
+        st = capi.MapStats()
+        if not fetch:
+            check(lib().sq_map_batch(self.h, C.byref(rb), None, C.byref(st)), "sq_map_batch")
+            return None, None, None, st.as_dict()
+        n = rb.n
+        cap = aln_cap or max(1024, 8 * n)
+        while True:
+            read_off = np.zeros(n + 1, np.uint64)
+            aln = np.zeros(cap, ALN_DTYPE)
+            mt = np.zeros(n, np.uint8)
+            ab = capi.AlnBatch(n, _ptr(read_off, C.c_uint64), aln.ctypes.data_as(C.POINTER(capi.Aln)), cap, _ptr(mt, C.c_uint8))
+            rc = lib().sq_map_batch(self.h, C.byref(rb), C.byref(ab), C.byref(st))
+            if rc == -6 and cap < (1 << 31):
+                cap *= 4
+                continue
+            check(rc, "sq_map_batch")
+            break
+        return read_off, aln[: int(read_off[-1])], mt, st.as_dict()
+
+    def tap(self, what, dtype):
+        n = lib().sq_debug_tap(self.h, what, None, 0)
+        if n < 0:
+            check(int(n), "sq_debug_tap")
+        buf = np.zeros(int(n), dtype)
+        if n:
+            lib().sq_debug_tap(self.h, what, buf.ctypes.data, int(n))
+        return buf
+
+    def eq_accumulate(self):
+        check(lib().sq_eq_accumulate(self.h), "sq_eq_accumulate")
+
+    def eq_finish(self):
+        t = capi.EqTable()
+        check(lib().sq_eq_finish(self.h, C.byref(t)), "sq_eq_finish(size)")
+        eq = EqClasses.alloc(int(t.num_classes), int(t.num_labels))
+        tt = eq.table()
+        check(lib().sq_eq_finish(self.h, C.byref(tt)), "sq_eq_finish")
+        return eq
+
+    def eq_merge(self, eq):
+        t = eq.table()
+        check(lib().sq_eq_merge(self.h, C.byref(t)), "sq_eq_merge")
+
+    def summary(self):
+        s = capi.ModelSummary()
+        check(lib().sq_model_summary_get(self.h, C.byref(s)), "sq_model_summary_get")
+        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in))
+
+    def model(self):
+        M = self.index.num_refs
+        lm, uq, tc, le = np.zeros(M), np.zeros(M, np.uint64), np.zeros(M, np.uint64), np.zeros(M)
+        check(lib().sq_model_fetch(self.h, _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(le, C.c_double)), "sq_model_fetch")
+        return lm, uq, tc, le
+
+    def fld(self):
+        f = np.zeros(1001)
+        check(lib().sq_model_fetch_fld(self.h, _ptr(f, C.c_double)), "sq_model_fetch_fld")
+        return f
+
+
+def make_txp_in(eff_len, projected=None, unique=None):
+    t = capi.TxpIn()
+    eff_len = np.ascontiguousarray(eff_len, np.float64)
+    t.num_txp = len(eff_len)
+    t.eff_len = _ptr(eff_len, C.c_double)
+    keep = [eff_len]
+    if projected is not None:
+        projected = np.ascontiguousarray(projected, np.float64); t.projected_counts = _ptr(projected, C.c_double); keep.append(projected)
+    if unique is not None:
+        unique = np.ascontiguousarray(unique, np.uint64); t.unique_count = _ptr(unique, C.c_uint64); keep.append(unique)
+    t._keep = keep
+    return t
+
+
+def em_optimize(eq, eff_len, projected=None, opts=None, device=0):
+    """CollapsedEMOptimizer::optimize on the GPU. Returns (alphas, report dict)."""
+    o = opts or em_opts()
+    t = eq.table()
+    txp = make_txp_in(eff_len, projected)
+    out = np.zeros(txp.num_txp)
+    rep = capi.EmReport()
+    check(lib().sq_em_optimize_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(out, C.c_double), C.byref(rep)), "sq_em_optimize_dev")
+    return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum,
+                     device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+
+
+def em_steps(eq, eff_len, alpha_in, iters, opts=None, device=0):
+    o = opts or em_opts()
+    t = eq.table()
+    txp = make_txp_in(eff_len)
+    a = np.ascontiguousarray(alpha_in, np.float64)
+    out = np.zeros(txp.num_txp)
+    rep = capi.EmReport()
+    check(lib().sq_em_steps_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(a, C.c_double), iters, _ptr(out, C.c_double), C.byref(rep)), "sq_em_steps_dev")
+    return out, dict(iters=rep.iters, device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)

@@ -1,0 +1,91 @@
+"""Build every native artefact of salmon_amd for gfx950 (in-tree, no JIT cache).
+
+  libsalmon_hip.so   product: host index builder + HIP kernels + C ABI   (hipcc --offload-arch=gfx950)
+  oracle/_build/liboracle.so   CPU checker (test infrastructure)         (g++)
+  tools/_build/libsqsynth.so   synthetic transcriptome / read generator  (g++)
+"""
+import os, subprocess, sys, hashlib, concurrent.futures as cf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "salmon_amd", "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(ROOT, "salmon_amd", "libsalmon_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-march=x86-64-v3", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")]
+
+
+def _sources():
+    out = []
+    for sub in ("host", "hip"):
+        d = os.path.join(CSRC, sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".cpp", ".hip")):
+                out.append(os.path.join(d, f))
+    return out
+
+
+def _deps_stamp():
+    h = hashlib.sha1()
+    for base, _, files in os.walk(CSRC):
+        for f in sorted(files):
+            if f.endswith((".h", ".hpp")):
+                h.update(open(os.path.join(base, f), "rb").read())
+    for f in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        h.update(open(os.path.join(ROOT, "include", f), "rb").read())
+    h.update(" ".join(COMMON).encode())
+    return h.hexdigest()[:12]
+
+
+def _compile(src, stamp):
+    obj = os.path.join(OBJ, os.path.basename(src) + "." + stamp + ".o")
+    if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src):
+        return obj, False
+    cmd = [HIPCC] + COMMON + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout[-4000:], r.stderr[-8000:]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr[-3000:])
+    return obj, True
+
+
+def build_product(verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    stamp = _deps_stamp()
+    srcs = _sources()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, stamp), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lz", "-lpthread", "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-8000:])
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+def build_oracle():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout[-3000:] + r.stderr[-6000:])
+    return os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+
+
+def build_tools():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("tools build failed:\n" + r.stdout[-3000:] + r.stderr[-6000:])
+    return os.path.join(ROOT, "tools", "_build", "libsqsynth.so")
+
+
+def build_all():
+    build_product()
+    build_oracle()
+    build_tools()
+
+
+if __name__ == "__main__":
+    build_all()

@@ -1,0 +1,24 @@
+// host/opts.cpp — defaults mirrored from include/salmon/internal/config/SalmonDefaults.hpp:8-127.
+#include "../../../include/salmon_hip.h"
+#include <string.h>
+extern "C" void sq_quant_opts_default(sq_quant_opts* o) {
+  memset(o, 0, sizeof(*o));
+  o->lib_type = 1; o->lib_orientation = 2; o->lib_strand = 4;  // -l IU
+  o->match_score = 2; o->mismatch_penalty = -4; o->gap_open = 6; o->gap_extend = 2; o->bandwidth = 15;  // :32-36
+  o->mismatch_seed_skip = 3; o->max_occs_per_hit = 1000; o->max_read_occs = 200; o->frag_len_max = 1000;  // :37,66,64,58
+  o->consensus_slack = 0.35f; o->min_score_fraction = 0.65; o->pre_merge_chain_sub_thresh = 0.75;        // :26-28
+  o->post_merge_chain_sub_thresh = 0.9; o->orphan_chain_sub_thresh = 0.95; o->score_exp = 1.0;           // :29-31
+  o->decoy_threshold = 1.0; o->min_aln_prob = 1e-5;                                                      // :91,93
+  o->hard_filter = 0; o->allow_dovetail = 0; o->allow_orphans = 1; o->disable_chaining_heuristic = 0;
+  o->ignore_incompat = 1;  // incompatPrior == 0 -> ignoreIncompat (QuantOptionsUtils.cpp:608-612)
+  o->mini_batch_size = 5000; o->num_pre_burnin_frags = 5000; o->num_burnin_frags = 5000000;             // SalmonQuantify.cpp:150; :73-74
+  o->fld_mean = 250.0; o->fld_sd = 25.0; o->forgetting_factor = 0.65; o->incompat_prior = 0.0;           // :59-61,16
+  o->range_factorization_bins = 4; o->use_frag_len_dist = 1; o->model_single_frag_prob = 1;             // :78
+  o->no_length_correction = 0; o->no_eff_length_correction = 0; o->seed = 0x5EED5A1A0ULL;
+}
+extern "C" void sq_em_opts_default(sq_em_opts* o) {
+  memset(o, 0, sizeof(*o));
+  o->use_vbem = 1; o->per_transcript_prior = 1; o->init_uniform = 0; o->eq_class_mode = 0; o->no_rich_eq_classes = 0;  // :76,87,63
+  o->vb_prior = 1e-2; o->rel_diff_tolerance = 0.01; o->max_iter = 10000; o->min_iter = 100;                             // :85; MappingPipelineStages.cpp:46-49
+  o->num_required_fragments = 50000000.0;                                                                               // :110
+}

@@ -1,0 +1,162 @@
+// sq_internal.h — index layout + k-mer / dictionary primitives shared by the host builder
+// (host/index_build.cpp), the host-side query used in tests, and the gfx950 kernels (hip/*.hip).
+//
+// The dictionary is our own HBM-first layout of the SSHash idea (Pibiri 2022; the reference reaches
+// it through PufferfishIndex::getRefPos — call sites SalmonQuantify.cpp:1266-1275): unitigs are
+// 2-bit packed into one string pool; every k-mer is keyed by its canonical minimizer (length m);
+// a partitioned hash-and-displace MPHF (PTHash-style pilots) maps a minimizer to one 8-byte slot
+// record; the record either holds the single string position of that minimizer inline (the common
+// case: ONE dependent HBM read after the pilot) or points to a short list of positions; buckets
+// larger than SQ_SKEW_THRESH use a k-mer-keyed skew table.  A candidate is always verified against
+// the string pool, so absent k-mers can never produce false hits.
+#pragma once
+#include <stdint.h>
+#include "../../include/sq_math.h"
+
+#define SQ_INDEX_MAGIC 0x3158444951535153ULL /* "SQSQIDX1" */
+#define SQ_INDEX_VERSION 3u
+#define SQ_SKEW_THRESH 32u
+#define SQ_MPHF_LAMBDA 4.0
+#define SQ_MPHF_ALPHA 0.90
+#define SQ_MPHF_PART_KEYS 65536u
+#define SQ_POS_BITS 40
+#define SQ_POS_MASK ((1ULL << SQ_POS_BITS) - 1)
+#define SQ_SLOT_INLINE (1ULL << 63)
+#define SQ_SLOT_EMPTY (~0ULL)
+
+SQ_HD uint64_t sq_kmask(uint32_t k) { return (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1); }
+
+// reverse-complement of a k-mer stored with base j at bits [2j,2j+1]
+SQ_HD uint64_t sq_revcomp(uint64_t x, uint32_t k) {
+  x = ~x;
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+  x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+  x = (x >> 32) | (x << 32);
+  return x >> (64 - 2 * k);
+}
+
+// fetch `n` (<=32) bases starting at nt position p from a packed pool
+SQ_HD uint64_t sq_fetch_bases(const uint64_t* pool, uint64_t p, uint32_t n) {
+  uint64_t w = p >> 5;
+  uint32_t sh = (uint32_t)(p & 31) * 2;
+  uint64_t lo = pool[w] >> sh;
+  if (sh != 0 && sh + 2 * n > 64) lo |= pool[w + 1] << (64 - sh);
+  return lo & sq_kmask(n);
+}
+SQ_HD uint32_t sq_fetch_base(const uint64_t* pool, uint64_t p) {
+  return (uint32_t)(pool[p >> 5] >> ((p & 31) * 2)) & 3u;
+}
+
+SQ_HD uint32_t sq_fastrange32(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32); }
+
+// canonical minimizer of a k-mer: value = canonical m-mer with the smallest mix64; returns value.
+// (mix64 is a bijection, so equal hashes mean equal canonical m-mers.)
+SQ_HD uint64_t sq_minimizer(uint64_t kmer, uint64_t rc, uint32_t k, uint32_t m) {
+  const uint64_t mm = sq_kmask(m);
+  uint64_t best = ~0ULL, bestv = 0;
+  const uint32_t w = k - m;
+  for (uint32_t j = 0; j <= w; ++j) {
+    uint64_t a = (kmer >> (2 * j)) & mm;
+    uint64_t b = (rc >> (2 * (w - j))) & mm;
+    uint64_t c = a < b ? a : b;
+    uint64_t h = sq_mix64(c);
+    if (h < best) { best = h; bestv = c; }
+  }
+  return bestv;
+}
+
+struct sq_dict_view {
+  uint32_t k, m;
+  uint32_t n_parts;
+  const uint64_t* part_slot_off;  // [n_parts+1]
+  const uint32_t* part_bkt_off;   // [n_parts+1]
+  const uint16_t* pilots;         // [sum buckets]
+  const uint64_t* slots;          // [sum slots]
+  const uint64_t* entries;        // list entries: unitig<<30 | minimizer offset
+  const uint64_t* skew_keys;      // open addressing, canonical k-mer or ~0
+  const uint64_t* skew_vals;      // unitig<<30 | k-mer start offset
+  uint64_t skew_mask;             // capacity-1 (0 if no skew table)
+  const uint64_t* useq;           // string pool
+  const uint64_t* uoff;           // [U+1]
+  uint64_t num_unitigs;
+};
+
+SQ_HD uint64_t sq_mphf_slot(const sq_dict_view& d, uint64_t minimizer) {
+  uint64_t h = sq_mix64(minimizer ^ 0x9E3779B97F4A7C15ULL);
+  uint32_t part = sq_fastrange32((uint32_t)(h >> 32), d.n_parts);
+  uint32_t b0 = d.part_bkt_off[part], nb = d.part_bkt_off[part + 1] - b0;
+  uint64_t s0 = d.part_slot_off[part];
+  uint32_t ns = (uint32_t)(d.part_slot_off[part + 1] - s0);
+  uint32_t bkt = sq_fastrange32((uint32_t)h, nb);
+  uint64_t pilot = d.pilots[b0 + bkt];
+  uint64_t h2 = sq_mix64(h ^ sq_mix64(pilot + 0x632BE59BD9B4E019ULL));
+  return s0 + sq_fastrange32((uint32_t)(h2 >> 32), ns);
+}
+
+// A minimizer occurrence is stored as (unitig id, offset of the minimizer inside the unitig):
+//   entry = unitig << SQ_UOFF_BITS | offset          (60 bits)
+// so a candidate k-mer start is checked against the unitig's own length without any search.
+#define SQ_UOFF_BITS 30
+#define SQ_UOFF_MASK ((1ULL << SQ_UOFF_BITS) - 1)
+#define SQ_ENT_MASK ((1ULL << 60) - 1)
+
+// Try one candidate: k-mer starting at offset `st` of unitig u. Returns 1 if the pool holds `kmer`
+// (fw) or `rc` there.
+SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t u, int64_t st,
+                      uint64_t* unitig, uint32_t* off, int* fw) {
+  if (st < 0) return 0;
+  uint64_t b = d.uoff[u], e = d.uoff[u + 1];
+  if (b + (uint64_t)st + d.k > e) return 0;
+  uint64_t s = sq_fetch_bases(d.useq, b + (uint64_t)st, d.k);
+  int f;
+  if (s == kmer) f = 1; else if (s == rc) f = 0; else return 0;
+  *unitig = u; *off = (uint32_t)st; *fw = f;
+  return 1;
+}
+
+// Full dictionary query. kmer in read orientation; on success fw tells whether the read k-mer
+// equals the unitig's forward string at (unitig, off).
+SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
+  const uint32_t k = d.k, m = d.m, w = k - m;
+  const uint64_t mm = sq_kmask(m);
+  uint64_t rc = sq_revcomp(kmer, k);
+  uint64_t mini = sq_minimizer(kmer, rc, k, m);
+  uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
+  if (rec == SQ_SLOT_EMPTY) return 0;
+  uint64_t nent; const uint64_t* ent; uint64_t inl;
+  if (rec & SQ_SLOT_INLINE) { inl = rec & SQ_ENT_MASK; ent = &inl; nent = 1; }
+  else {
+    nent = rec >> SQ_POS_BITS; ent = d.entries + (rec & SQ_POS_MASK);
+    if (nent > SQ_SKEW_THRESH) {  // heavy bucket -> skew table keyed by canonical k-mer
+      if (!d.skew_mask) return 0;
+      uint64_t can = kmer < rc ? kmer : rc;
+      uint64_t h = sq_mix64(can) & d.skew_mask;
+      for (;;) {
+        uint64_t kk = d.skew_keys[h];
+        if (kk == ~0ULL) return 0;
+        if (kk == can) {
+          uint64_t v = d.skew_vals[h] & SQ_ENT_MASK;
+          return sq_dict_try(d, kmer, rc, v >> SQ_UOFF_BITS, (int64_t)(v & SQ_UOFF_MASK), unitig, off, fw);
+        }
+        h = (h + 1) & d.skew_mask;
+      }
+    }
+  }
+  // positions j (in the read-orientation k-mer) where the canonical m-mer equals the minimizer
+  for (uint32_t j = 0; j <= w; ++j) {
+    uint64_t a = (kmer >> (2 * j)) & mm;
+    uint64_t b = (rc >> (2 * (w - j))) & mm;
+    uint64_t c = a < b ? a : b;
+    if (c != mini) continue;
+    for (uint64_t e = 0; e < nent; ++e) {
+      uint64_t u = (ent[e] & SQ_ENT_MASK) >> SQ_UOFF_BITS;
+      int64_t A = (int64_t)(ent[e] & SQ_UOFF_MASK);  // minimizer offset in the unitig
+      // same strand: k-mer starts at A - j ; opposite strand: starts at A - (w - j)
+      if (sq_dict_try(d, kmer, rc, u, A - (int64_t)j, unitig, off, fw)) return 1;
+      if (j != w - j && sq_dict_try(d, kmer, rc, u, A - (int64_t)(w - j), unitig, off, fw)) return 1;
+    }
+  }
+  return 0;
+}
