@@ -28,7 +28,7 @@
 /* salmon's log-space constants (SalmonMath.hpp:40-46). LOG_0 is +inf by design. */
 #define SQ_LOG_0 ((double)HUGE_VAL)
 #define SQ_LOG_1 (0.0)
-#define SQ_LOG_EPSILON (-24.006646558927852) /* log(0.375e-10), fixed literal so host == device */
+#define SQ_LOG_EPSILON (-24.006680182952184) /* log(0.375e-10), fixed literal so host == device */
 
 SQ_HD double sq_bits2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 SQ_HD uint64_t sq_d2bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }

@@ -1,0 +1,97 @@
+"""EM / VBEM: CPU checker properties (no GPU) and GPU-vs-checker bit parity (-m gpu)."""
+import numpy as np
+import pytest
+from salmon_amd import api
+import orc
+from conftest import random_eq_classes
+
+
+def test_oracle_em_single_class_fixed_point(built):
+    # one class {0,1} with equal weights and equal lengths: EM keeps a uniform split of the count
+    eq = api.EqClasses(np.array([0, 2], np.uint64), np.array([0, 1], np.uint32), np.array([0.5, 0.5]), np.array([10], np.uint64))
+    a, rep = orc.em_optimize(eq, np.array([100.0, 100.0]), opts=api.em_opts(use_vbem=0, init_uniform=1))
+    assert np.allclose(a, [5.0, 5.0]) and rep["iters"] == 100
+
+
+def test_oracle_em_conserves_counts(built):
+    eq = random_eq_classes(500, 3000, seed=3)
+    eff = np.random.default_rng(1).uniform(50, 3000, 500)
+    a, rep = orc.em_optimize(eq, eff, opts=api.em_opts(use_vbem=0, init_uniform=1))
+    assert abs(a.sum() - float(eq.count.sum())) < 1e-6 * float(eq.count.sum())
+    assert rep["iters"] >= 100
+
+
+def test_oracle_vbem_matches_scipy_reference(built):
+    # independent numpy/scipy restatement of VBEMUpdate_ (CollapsedEMOptimizer.cpp:241-328), 3 steps
+    from scipy.special import digamma
+    M, E = 60, 200
+    eq = random_eq_classes(M, E, seed=5)
+    eff = np.random.default_rng(2).uniform(80, 2000, M)
+    o = api.em_opts(init_uniform=1)
+    cw = np.zeros(len(eq.tid))
+    for c in range(E):
+        a, b = int(eq.off[c]), int(eq.off[c + 1])
+        x = float(eq.count[c]) * eq.w[a:b] / np.maximum(eff[eq.tid[a:b]], 1.0)
+        cw[a:b] = x / x.sum()
+    alpha = np.full(M, 100.0)
+    for _ in range(3):
+        ap = alpha + 1e-2
+        th = np.where(ap > 1e-10, np.exp(digamma(ap) - digamma(ap.sum())), 0.0)
+        out = np.zeros(M)
+        for c in range(E):
+            a, b = int(eq.off[c]), int(eq.off[c + 1])
+            if b - a == 1:
+                out[eq.tid[a]] += float(eq.count[c]); continue
+            v = th[eq.tid[a:b]] * cw[a:b]
+            out[eq.tid[a:b]] += float(eq.count[c]) * v / v.sum()
+        alpha = out
+    got = orc.em_steps(eq, eff, np.full(M, 100.0), 3, o)
+    assert np.allclose(got, alpha, rtol=1e-12, atol=1e-12)
+
+
+def test_canonical_sum_is_a_sum(built):
+    x = np.random.default_rng(0).uniform(0, 1e6, 70001)
+    s = orc.lib().orc_canonical_sum(x.ctypes.data, len(x))
+    assert abs(s - float(np.sum(x))) < 1e-9 * float(np.sum(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vb", [0, 1])
+@pytest.mark.parametrize("M,E", [(64, 300), (1000, 20000), (70000, 150000)])
+def test_gpu_em_steps_bit_exact(built, vb, M, E):
+    eq = random_eq_classes(M, E, seed=M + vb, max_size=12 if M > 64 else 6)
+    eff = np.random.default_rng(4).uniform(50, 5000, M)
+    a0 = np.random.default_rng(5).uniform(0, 50, M)
+    o = api.em_opts(use_vbem=vb)
+    want = orc.em_steps(eq, eff, a0, 7, o)
+    got, rep = api.em_steps(eq, eff, a0, 7, o)
+    assert np.array_equal(got, want), float(np.max(np.abs(got - want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vb,uni", [(1, 0), (0, 1), (1, 1)])
+def test_gpu_em_optimize_bit_exact(built, vb, uni):
+    M, E = 3000, 40000
+    eq = random_eq_classes(M, E, seed=17)
+    eff = np.random.default_rng(6).uniform(50, 5000, M)
+    proj = np.random.default_rng(7).uniform(0, 30, M)
+    o = api.em_opts(use_vbem=vb, init_uniform=uni)
+    want, wrep = orc.em_optimize(eq, eff, proj, o)
+    got, grep = api.em_optimize(eq, eff, proj, o)
+    assert grep["iters"] == wrep["iters"] and grep["converged"] == wrep["converged"]
+    assert np.array_equal(got, want)
+    assert grep["max_rel_diff"] == wrep["max_rel_diff"]
+
+
+@pytest.mark.gpu
+def test_gpu_em_eqclass_mode_and_degenerate(built):
+    # `salmon quant -e` seam (SalmonQuantifyAlignments.cpp:1407-1441): weights verbatim, uniform init;
+    # plus empty-ish inputs: a transcript in no class, a class of size 1
+    off = np.array([0, 1, 3, 6], np.uint64); tid = np.array([2, 0, 1, 0, 2, 4], np.uint32)
+    w = np.array([1.0, 0.3, 0.7, 0.2, 0.5, 0.3]); cnt = np.array([5, 10, 7], np.uint64)
+    eq = api.EqClasses(off, tid, w, cnt)
+    eff = np.array([100.0, 200.0, 50.0, 10.0, 0.5])
+    o = api.em_opts(eq_class_mode=1, init_uniform=1)
+    want, _ = orc.em_optimize(eq, eff, None, o)
+    got, _ = api.em_optimize(eq, eff, None, o)
+    assert np.array_equal(got, want) and got[3] == 0.0
