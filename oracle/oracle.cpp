@@ -31,7 +31,7 @@
 
 namespace orc {
 
-constexpr int MAX_UNIMEMS = 64;      // SPEC §a1
+constexpr int MAX_UNIMEMS = 32;      // SPEC §a1
 constexpr int MAX_CHAIN_GAP = 200;   // SPEC §a2
 constexpr double AVG_SEED = 31.0;    // SPEC §a2 (pufferfish uses a constant average seed length)
 constexpr int REF_EXTEND = 20;       // aconf.refExtendLength (SalmonMappingUtils.hpp:184)
@@ -983,6 +983,8 @@ static void label_hash(const std::vector<uint32_t>& lab, uint64_t* h1, uint64_t*
   uint64_t a = 0x243F6A8885A308D3ULL ^ lab.size(), b = 0x13198A2E03707344ULL + lab.size();
   for (uint32_t x : lab) { a = sq_mix64(a ^ (uint64_t)x) + 0x9E3779B97F4A7C15ULL; b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29); }
   *h1 = sq_mix64(a); *h2 = sq_mix64(b);
+  if (*h1 == ~0ULL) *h1 = ~0ULL - 1;  // ~0 marks an empty slot in the device table
+  if (*h2 == 0) *h2 = 1;              // 0 marks "second hash not published yet"
 }
 // eq table in canonical order (ascending (h1,h2)); call with NULL arrays to get sizes
 void orc_eq_finish(orc_state* s, sq_eq_table* out) {

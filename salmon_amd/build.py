@@ -12,7 +12,7 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(ROOT, "salmon_amd", "libsalmon_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-march=x86-64-v3", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-result", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")]
+          "-Wno-unused-result", "-Wno-unused-value", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")]
 
 
 def _sources():

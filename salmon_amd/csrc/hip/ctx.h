@@ -1,0 +1,83 @@
+// hip/ctx.h — per-device quantification context: HBM work buffers of the mapping pipeline, the
+// online model and the equivalence-class table.  One sq_ctx per GPU (one process per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "device_index.h"
+
+#define SQ_MAX_READ_LEN 256u
+#define SQ_READ_WORDS 8u          // 2-bit words per read end
+#define SQ_NMASK_WORDS 4u         // N-mask words per read end (1 bit / base)
+#define SQ_MAX_UNIMEMS 32u        // SPEC §a1
+#define SQ_MAX_CHAIN_GAP 200      // SPEC §a2
+#define SQ_REF_EXTEND 20          // aconf.refExtendLength (SalmonMappingUtils.hpp:184)
+#define SQ_MAX_BAND 15            // DP band kept in registers (runtime bandwidth must be <= this)
+#define SQ_INVALID_SCORE INT32_MIN
+#define SQ_NEG_INF (-(1 << 29))
+
+struct sq_unimem_dev { uint32_t unitig, ustart; uint16_t qpos, len; uint8_t fw, pad[3]; };  // 16 B
+
+struct sq_chain_dev {   // 40 B
+  double score; uint32_t tid; int32_t pos; int32_t last_end; uint32_t first; uint16_t n_mems, read_len; uint8_t fw, pad[3]; uint32_t pad2;
+};
+struct sq_cand_dev {    // 48 B
+  double cov; uint32_t tid; uint32_t lc, rc; uint32_t frag_len; int32_t lscore, rscore; uint8_t mate_status, valid, compat, lfail, rfail, pad[3]; uint32_t pad2;
+};
+
+struct sq_dp_item {     // one banded-DP region queued by the fast scorer
+  uint32_t cand; uint8_t end, mode, rc, pad; int32_t qstart, qdir, n; int64_t tstart; int32_t tdir, tl; uint32_t rec;
+};
+
+struct sq_map_params {
+  int32_t ma, mp, go, ge, bw;
+  uint32_t k, alt_skip, max_occ, frag_len_max, first_decoy;
+  double pre_thr, post_thr, orphan_thr, consensus_frac, min_score_fraction, score_exp, decoy_threshold, min_aln_prob;
+  uint8_t lib_type, lib_orient, lib_strand, hard_filter, allow_dovetail, allow_orphans, no_heuristic, ignore_incompat;
+};
+
+template <class T>
+struct sq_dbuf {
+  T* p = nullptr; size_t n = 0;
+  int ensure(size_t want) {
+    if (want <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (hipMalloc((void**)&p, (want ? want : 1) * sizeof(T)) != hipSuccess) return -1;
+    n = want; return 0;
+  }
+  void free_() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct sq_online_dev;  // online.hip
+struct sq_eq_dev;      // eq.hip
+
+struct sq_ctx {
+  sq_index* idx = nullptr; sq_device_index* di = nullptr; int device = 0;
+  sq_quant_opts opts; sq_map_params mp; uint32_t max_reads = 0;
+  hipStream_t stream = nullptr;
+  // reads
+  sq_dbuf<uint8_t> seq; sq_dbuf<uint64_t> seq_off; sq_dbuf<uint64_t> rpack; sq_dbuf<uint64_t> rnmask; sq_dbuf<uint16_t> rlen;
+  // seeds / MEMs
+  sq_dbuf<sq_unimem_dev> unimems; sq_dbuf<uint32_t> n_uni; sq_dbuf<uint32_t> n_proj; sq_dbuf<uint64_t> mem_off;
+  sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;
+  sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
+  // chains
+  sq_dbuf<sq_chain_dev> chains; sq_dbuf<uint32_t> n_chains;
+  // candidates / alignments
+  sq_dbuf<uint32_t> n_cand; sq_dbuf<uint64_t> cand_off; sq_dbuf<sq_cand_dev> cands; uint64_t cand_cap = 0;
+  sq_dbuf<sq_dp_item> dpq; sq_dbuf<uint32_t> counters; sq_dbuf<uint8_t> frag_flags;
+  sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
+  sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;
+  // last batch bookkeeping
+  uint32_t last_n = 0; uint32_t last_paired = 0; uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0;
+  bool have_batch = false;
+  // online model + eq table
+  sq_online_dev* online = nullptr; sq_eq_dev* eq = nullptr;
+  uint64_t reads_seen = 0;
+};
+
+// stats slots (device array of unsigned long long, same order as sq_map_stats)
+enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };
+
+int sq_online_create(sq_ctx* c);
+void sq_online_free(sq_ctx* c);

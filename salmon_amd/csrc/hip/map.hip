@@ -1,0 +1,218 @@
+// hip/map.hip — host orchestration of the mapping pipeline (seam B1): sq_ctx_create / sq_map_batch /
+// sq_debug_tap.  Stage kernels live in map_kernels.h.  All intermediate data stay in HBM between
+// stages; the host only reads back three totals (MEMs, candidates, DP regions) to size buffers.
+#include "map_kernels.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstring>
+
+using namespace sqk;
+
+namespace {
+const int TB = 256;
+inline uint32_t nblk(uint64_t n) { return (uint32_t)((n + TB - 1) / TB); }
+
+int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_plus_1) {
+  size_t tmp = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n_plus_1, c->stream);
+  if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
+  tmp = c->sort_tmp.n;
+  SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp, in, out, (int)n_plus_1, c->stream));
+  return SQ_OK;
+}
+
+void fill_params(sq_ctx* c) {
+  const sq_quant_opts& o = c->opts; sq_map_params& P = c->mp;
+  P.ma = o.match_score; P.mp = o.mismatch_penalty; P.go = o.gap_open; P.ge = o.gap_extend; P.bw = o.bandwidth;
+  P.k = c->idx->k; P.alt_skip = o.mismatch_seed_skip; P.max_occ = o.max_occs_per_hit; P.frag_len_max = o.frag_len_max; P.first_decoy = c->idx->first_decoy;
+  P.pre_thr = o.pre_merge_chain_sub_thresh; P.post_thr = o.post_merge_chain_sub_thresh; P.orphan_thr = o.orphan_chain_sub_thresh;
+  P.consensus_frac = (o.consensus_slack == 0.0) ? 1.0 : (1.0 - o.consensus_slack);  // SalmonMappingUtils.hpp:160-162
+  P.min_score_fraction = o.min_score_fraction; P.score_exp = o.score_exp; P.decoy_threshold = o.decoy_threshold; P.min_aln_prob = o.min_aln_prob;
+  P.lib_type = o.lib_type; P.lib_orient = o.lib_orientation; P.lib_strand = o.lib_strand; P.hard_filter = o.hard_filter; P.allow_dovetail = o.allow_dovetail;
+  P.allow_orphans = o.allow_orphans; P.no_heuristic = o.disable_chaining_heuristic; P.ignore_incompat = o.ignore_incompat;
+}
+}  // namespace
+
+extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx** out) {
+  if (!idx || !opts || !out || max_batch_reads == 0) { sq_set_error("sq_ctx_create: bad arguments"); return SQ_ERR_ARG; }
+  if (max_batch_reads > (1u << 23)) { sq_set_error("max_batch_reads %u exceeds 2^23 (sort key layout)", max_batch_reads); return SQ_ERR_ARG; }
+  if (opts->bandwidth > SQ_MAX_BAND || opts->bandwidth < 0) { sq_set_error("bandwidth %d not supported (max %d)", opts->bandwidth, SQ_MAX_BAND); return SQ_ERR_ARG; }
+  int rc = sq_index_to_device(idx, device); if (rc) return rc;
+  SQ_HIP_CHECK(hipSetDevice(device));
+  sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads;
+  fill_params(c);
+  SQ_HIP_CHECK(hipStreamCreate(&c->stream));
+  const uint32_t nends = 2 * max_batch_reads;
+  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
+             c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
+             c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) || c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
+             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
+             c->stats.ensure(ST_N) || c->gapcost.ensure(SQ_MAX_CHAIN_GAP + 1);
+  if (bad) { sq_set_error("device allocation failed in sq_ctx_create"); sq_ctx_free(c); return SQ_ERR_NOMEM; }
+  // chaining gap-cost table: 0.01*avgSeed*l + 0.5*log2(l) (SPEC §a2), built with the shared deterministic log
+  std::vector<double> gc(SQ_MAX_CHAIN_GAP + 1, 0.0); const double inv_ln2 = 1.0 / 0.6931471805599453;
+  for (int l = 1; l <= SQ_MAX_CHAIN_GAP; ++l) gc[l] = 0.01 * 31.0 * (double)l + 0.5 * (sq_log((double)l) * inv_ln2);
+  SQ_HIP_CHECK(hipMemcpy(c->gapcost.p, gc.data(), gc.size() * 8, hipMemcpyHostToDevice));
+  rc = sq_online_create(c); if (rc) { sq_ctx_free(c); return rc; }
+  *out = c;
+  return SQ_OK;
+}
+
+extern "C" void sq_ctx_free(sq_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  sq_online_free(c);
+  c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
+  c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->chains.free_(); c->n_chains.free_();
+  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_();
+  c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
+  if (!c || !in || !in->seq_off || !in->seq) { sq_set_error("sq_map_batch: bad arguments"); return SQ_ERR_ARG; }
+  const uint32_t n = in->n, paired = in->paired ? 1 : 0, nrec = paired ? 2 * n : n;
+  if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  c->have_batch = false;
+  if (n == 0) { c->last_n = 0; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
+  // ---- stage reads in HBM ----
+  const uint8_t* d_seq; const uint64_t* d_seq_off;
+  if (in->on_device) { d_seq = in->seq; d_seq_off = in->seq_off; }
+  else {
+    uint64_t bytes = in->seq_off[nrec];
+    if (c->seq.ensure(bytes + 16)) { sq_set_error("device allocation failed (reads)"); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpyAsync(c->seq.p, in->seq, bytes, hipMemcpyHostToDevice, st));
+    SQ_HIP_CHECK(hipMemcpyAsync(c->seq_off.p, in->seq_off, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, st));
+    d_seq = c->seq.p; d_seq_off = c->seq_off.p;
+  }
+  SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
+  const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
+  k_pack<<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
+  k_seed<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p);
+  SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
+  int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
+  uint64_t total_mems = 0;
+  SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  c->last_total_mems = total_mems;
+  const size_t MP = (size_t)total_mems + 8;
+  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) || c->mused.ensure(MP) || c->chains.ensure(MP)) {
+    sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
+  uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
+  if (total_mems) {
+    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, c->mkey.p, c->mval.p);
+    int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st);
+    if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
+    tmp = c->sort_tmp.n;
+    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st));
+    skey = c->mkey2.p; sval = c->mval2.p;
+  }
+  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p, c->n_chains.p, c->stats.p);
+  k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
+  k_join<false><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, nullptr, nullptr, c->frag_flags.p);
+  SQ_HIP_CHECK(hipMemsetAsync(c->n_cand.p + n, 0, sizeof(uint32_t), st));
+  rc = exclusive_scan_u32(c, c->n_cand.p, c->cand_off.p, n + 1); if (rc) return rc;
+  uint64_t total_cands = 0;
+  SQ_HIP_CHECK(hipMemcpyAsync(&total_cands, c->cand_off.p + n, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  c->last_total_cands = total_cands;
+  const size_t CP = (size_t)total_cands + 8;
+  // cand_frag shares the mused... no: dedicated buffer (u32 per candidate) carved from cp (int32 per MEM) is not safe; allocate
+  static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
+  if (c->cands.ensure(CP) || c->aln_slots.ensure(CP) || c->aln.ensure(CP) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
+  sq_dbuf<uint32_t> cand_frag; if (cand_frag.ensure(CP)) { sq_set_error("device allocation failed (cand_frag)"); return SQ_ERR_NOMEM; }
+  ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
+  S.mkey = skey; S.mval = sval; S.mnext = c->mnext.p; S.dpq = c->dpq.p; S.counters = c->counters.p; S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
+  uint32_t hcount[2] = {0, 0};
+  if (total_cands) {
+    k_join<true><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->frag_flags.p);
+    k_fill_cand_frag<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, cand_frag.p);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
+      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p);
+      SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
+      SQ_HIP_CHECK(hipStreamSynchronize(st));
+      if (hcount[0] <= S.dpq_cap) break;
+      if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) { cand_frag.free_(); sq_set_error("DP queue overflow (%u regions)", hcount[0]); return SQ_ERR_OVERFLOW; }
+      S.dpq = c->dpq.p; S.dpq_cap = (uint32_t)c->dpq.n;
+    }
+    if (hcount[0]) k_dp<<<nblk(hcount[0]), 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
+  }
+  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->cands.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p);
+  SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
+  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) { cand_frag.free_(); return rc; }
+  k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off.p, c->n_aln.p, c->aln_slots.p, c->aln.p);
+  uint64_t total_aln = 0; unsigned long long hst[ST_N];
+  SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off.p + n, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  cand_frag.free_();
+  c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->num_reads = n; stats->num_mapped_at_least_a_kmer = hst[ST_KMER]; stats->num_with_joint_hits = hst[ST_JOINT]; stats->num_mapped = hst[ST_MAPPED]; stats->num_alignments = hst[ST_ALNS];
+    stats->num_mappings_filtered = hst[ST_MAPFILT]; stats->num_fragments_filtered = hst[ST_FRAGFILT]; stats->num_dovetails = hst[ST_DOVETAIL]; stats->num_decoy_fragments = hst[ST_DECOY];
+    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hcount[1];
+  }
+  if (out) {
+    if (!out->read_off || (!out->aln && total_aln)) { sq_set_error("sq_map_batch: output arrays missing"); return SQ_ERR_ARG; }
+    if (total_aln > out->aln_cap) { sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total_aln, (unsigned long long)out->aln_cap); return SQ_ERR_OVERFLOW; }
+    SQ_HIP_CHECK(hipMemcpy(out->read_off, c->aln_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+    if (total_aln) SQ_HIP_CHECK(hipMemcpy(out->aln, c->aln.p, (size_t)total_aln * sizeof(sq_aln), hipMemcpyDeviceToHost));
+    if (out->map_type) SQ_HIP_CHECK(hipMemcpy(out->map_type, c->map_type.p, n, hipMemcpyDeviceToHost));
+    out->n = n;
+  }
+  return SQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int64_t sq_debug_tap(sq_ctx* c, int what, void* buf, uint64_t cap) {
+  if (!c || !c->have_batch) { sq_set_error("sq_debug_tap: no mapped batch"); return SQ_ERR_STATE; }
+  if (hipSetDevice(c->device) != hipSuccess) return SQ_ERR_DEVICE;
+  const uint32_t n = c->last_n, nrec = c->last_paired ? 2 * n : n;
+  std::vector<uint64_t> moff(nrec + 1);
+  if (nrec && hipMemcpy(moff.data(), c->mem_off.p, (size_t)(nrec + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  const uint64_t* racc = c->idx->ref_accum.data();
+  if (what == SQ_TAP_UNIMEMS) {
+    std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * SQ_MAX_UNIMEMS);
+    if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p, um.size() * sizeof(sq_unimem_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    uint64_t cnt = 0; sq_unimem* o = (sq_unimem*)buf;
+    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) { if (o && cnt < cap) { const sq_unimem_dev& m = um[(size_t)e * SQ_MAX_UNIMEMS + i]; sq_unimem x; memset(&x, 0, sizeof(x)); x.end = e; x.qpos = m.qpos; x.len = m.len; x.unitig = m.unitig; x.uoff = m.ustart; x.fw = m.fw; o[cnt] = x; } ++cnt; }
+    return (int64_t)cnt;
+  }
+  const uint64_t tm = c->last_total_mems;
+  std::vector<uint64_t> key(tm), val(tm);
+  if (tm) { const uint64_t* sk = c->mkey2.p; const uint64_t* sv = c->mval2.p; if (hipMemcpy(key.data(), sk, tm * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(val.data(), sv, tm * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE; }
+  if (what == SQ_TAP_MEMS) {
+    sq_mem* o = (sq_mem*)buf;
+    for (uint64_t i = 0; i < tm && o && i < cap; ++i) { sq_mem x; memset(&x, 0, sizeof(x)); x.end = (uint32_t)(key[i] >> 40); x.tid = (uint32_t)(val[i] >> 32); x.rpos = (int32_t)((key[i] & ((1ULL << 40) - 1)) - racc[x.tid]); x.qpos = (uint16_t)((val[i] >> 10) & 1023); x.len = (uint16_t)(val[i] & 1023); x.fw = (val[i] >> 20) & 1; o[i] = x; }
+    return (int64_t)tm;
+  }
+  std::vector<uint32_t> nch(nrec); std::vector<sq_chain_dev> ch(tm);
+  if (nrec && hipMemcpy(nch.data(), c->n_chains.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  if (tm && hipMemcpy(ch.data(), c->chains.p, tm * sizeof(sq_chain_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  if (what == SQ_TAP_CHAINS) {
+    uint64_t cnt = 0; sq_chain* o = (sq_chain*)buf;
+    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nch[e]; ++i) { if (o && cnt < cap) { const sq_chain_dev& d = ch[moff[e] + i]; sq_chain x; memset(&x, 0, sizeof(x)); x.end = e; x.tid = d.tid; x.pos = d.pos; x.last_end = d.last_end; x.fw = d.fw; x.n_mems = d.n_mems; x.score = d.score; o[cnt] = x; } ++cnt; }
+    return (int64_t)cnt;
+  }
+  if (what == SQ_TAP_CANDIDATES) {
+    const uint64_t tc = c->last_total_cands; std::vector<sq_cand_dev> cd(tc); std::vector<uint64_t> coff(n + 1);
+    if (tc && hipMemcpy(cd.data(), c->cands.p, tc * sizeof(sq_cand_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    sq_cand* o = (sq_cand*)buf; uint64_t cnt = 0;
+    for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f + 1]; ++i) {
+      if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0, sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu, hr = d.rc != 0xFFFFFFFFu;
+        x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status; x.valid = d.valid; x.lscore = d.lscore; x.rscore = d.rscore; x.frag_len = d.frag_len; o[cnt] = x; }
+      ++cnt; }
+    return (int64_t)cnt;
+  }
+  sq_set_error("sq_debug_tap: unknown tap %d", what);
+  return SQ_ERR_ARG;
+}

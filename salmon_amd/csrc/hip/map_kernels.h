@@ -1,0 +1,580 @@
+// hip/map_kernels.h — device kernels of the mapping pipeline (seam B1), one stage per kernel:
+//   k_pack      ASCII reads -> 2-bit words + N mask                        (K1 of SURVEY.md §7.4)
+//   k_seed      per read end: SSHash lookup + uni-MEM extension            (K2+K3; row a1)
+//   k_project   uni-MEM x contig-table occurrences -> MEM sort records     (K4;    row a2)
+//   [radix sort by (read end, global reference position)]
+//   k_chain     per read end: minimap2-style chaining DP per transcript    (K5;    row a2)
+//   k_join      per fragment: pair / orphan candidates                     (K6;    row a3)
+//   k_score     per candidate: selective-alignment score, fast path        (K7;    row a4)
+//   k_dp        queued banded affine-gap DP regions                        (K7)
+//   k_select    per fragment: best-per-transcript, decoys, estAlnProb      (K8;    rows a7-a9)
+// Everything is integer / fixed-order arithmetic so results equal the CPU checker bit for bit.
+#pragma once
+#include "ctx.h"
+
+namespace sqk {
+
+struct ReadView { const uint64_t* w; const uint64_t* nm; int L; };
+
+__device__ inline uint64_t fetch_bits(const uint64_t* m, uint32_t p, uint32_t n) {  // n <= 32 one-bit flags from p
+  uint32_t w = p >> 6, sh = p & 63;
+  uint64_t lo = m[w] >> sh;
+  if (sh + n > 64) lo |= m[w + 1] << (64 - sh);
+  return lo & ((n >= 64) ? ~0ULL : ((1ULL << n) - 1));
+}
+__device__ inline uint32_t rd_base(const ReadView& r, int i) {
+  if ((r.nm[i >> 6] >> (i & 63)) & 1) return 4;
+  return (uint32_t)(r.w[i >> 5] >> ((i & 31) * 2)) & 3u;
+}
+__device__ inline uint32_t norm_base(const ReadView& r, bool fw, int x) {  // strand-normalised read
+  if (fw) return rd_base(r, x);
+  uint32_t b = rd_base(r, r.L - 1 - x);
+  return b > 3 ? 4u : 3u - b;
+}
+__device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnmask, const uint16_t* rlen, uint32_t e) {
+  ReadView r; r.w = rpack + (size_t)e * SQ_READ_WORDS; r.nm = rnmask + (size_t)e * SQ_NMASK_WORDS; r.L = rlen[e]; return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
+                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrec) return;
+  uint64_t a = seq_off[e], b = seq_off[e + 1];
+  uint32_t L = (uint32_t)(b - a); if (L > SQ_MAX_READ_LEN) L = SQ_MAX_READ_LEN;
+  const uint8_t* s = seq + a;
+  uint64_t* w = rpack + (size_t)e * SQ_READ_WORDS; uint64_t* nm = rnmask + (size_t)e * SQ_NMASK_WORDS;
+  uint64_t cw = 0, cn = 0;
+  for (uint32_t i = 0; i < SQ_MAX_READ_LEN; ++i) {
+    if (i < L) {
+      uint32_t c; uint8_t ch = s[i];
+      switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 4; }
+      if (c > 3) cn |= 1ULL << (i & 63); else cw |= (uint64_t)c << ((i & 31) * 2);
+    }
+    if ((i & 31) == 31) { w[i >> 5] = cw; cw = 0; }
+    if ((i & 63) == 63) { nm[i >> 6] = cn; cn = 0; }
+  }
+  rlen[e] = (uint16_t)L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1 — MemCollector::operator() (reference call site SalmonQuantify.cpp:1266-1275); SPEC §a1.
+__global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
+                       const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
+                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nends) return;
+  ReadView r = read_view(rpack, rnmask, rlen, e);
+  const int k = (int)P.k, L = r.L;
+  uint32_t nu = 0, np = 0, nlook = 0;
+  sq_unimem_dev* out = um + (size_t)e * SQ_MAX_UNIMEMS;
+  if (L >= k) {
+    int pos = 0, skip_until = -1; const int alt = (int)P.alt_skip;
+    while (pos + k <= L && nu < SQ_MAX_UNIMEMS) {
+      uint64_t nb = fetch_bits(r.nm, (uint32_t)pos, (uint32_t)k);
+      if (nb) { pos = pos + (63 - __clzll((long long)nb)) + 1; continue; }
+      uint64_t km = sq_fetch_bases(r.w, (uint64_t)pos, (uint32_t)k);
+      uint64_t u; uint32_t off; int fw;
+      ++nlook;
+      if (!sq_dict_lookup(d, km, &u, &off, &fw)) {
+        if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
+        continue;
+      }
+      const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);
+      int len = k;
+      int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
+      bool mism = false;
+      while (avail > 0) {
+        int c = avail < 32 ? avail : 32;
+        uint64_t rc_ = sq_fetch_bases(r.w, (uint64_t)(pos + len), (uint32_t)c);
+        uint64_t nn = fetch_bits(r.nm, (uint32_t)(pos + len), (uint32_t)c);
+        uint64_t uc;
+        if (fw) uc = sq_fetch_bases(d.useq, ub + off + len, (uint32_t)c);
+        else { int up = (int)off - 1 - (len - k); uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c); }
+        uint64_t x = rc_ ^ uc; uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ULL;
+        int i1 = mm ? (__ffsll((long long)mm) - 1) / 2 : 64; int i2 = nn ? (__ffsll((long long)nn) - 1) : 64;
+        int im = i1 < i2 ? i1 : i2;
+        if (im < c) { len += im; mism = true; break; }
+        len += c; avail -= c;
+      }
+      bool rend = (pos + len >= L);
+      bool uend = !rend && !mism;
+      sq_unimem_dev m; m.unitig = (uint32_t)u; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.fw = (uint8_t)fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
+      m.pad[0] = m.pad[1] = m.pad[2] = 0;
+      out[nu++] = m;
+      uint64_t occ = ctab_off[u + 1] - ctab_off[u];
+      if (occ <= P.max_occ) np += (uint32_t)occ;
+      if (rend) break;
+      int ee = pos + len;
+      pos = pos + len - k + 1;
+      skip_until = uend ? -1 : ee + 1;
+    }
+  }
+  n_uni[e] = nu; n_proj[e] = np;
+  atomicAdd(&stats[ST_SEEDS], (unsigned long long)nu); atomicAdd(&stats[ST_LOOKUPS], (unsigned long long)nlook);
+}
+
+// val layout: len[0,10) q[10,20) fw[20] tid[32,64)
+__device__ inline uint64_t mem_pack_val(uint32_t tid, uint32_t q, uint32_t len, uint32_t fw) { return ((uint64_t)tid << 32) | ((uint64_t)fw << 20) | ((uint64_t)q << 10) | len; }
+struct MemD { uint32_t tid; int32_t rpos; int32_t q; int32_t len; bool fw; };
+__device__ inline MemD mem_decode(uint64_t key, uint64_t val, const uint64_t* ref_accum) {
+  MemD m; m.tid = (uint32_t)(val >> 32); m.fw = (val >> 20) & 1; m.q = (int32_t)((val >> 10) & 1023); m.len = (int32_t)(val & 1023);
+  m.rpos = (int32_t)((key & ((1ULL << 40) - 1)) - ref_accum[m.tid]); return m;
+}
+
+// a2a — projection through the contig table (fillMemCollection); SPEC §a2.
+__global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab, const uint64_t* __restrict__ ref_accum,
+                          sq_map_params P, uint32_t nends, const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um,
+                          const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off, uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nends) return;
+  uint64_t w = mem_off[e]; const int L = rlen[e];
+  const sq_unimem_dev* in = um + (size_t)e * SQ_MAX_UNIMEMS;
+  for (uint32_t i = 0; i < n_uni[e]; ++i) {
+    sq_unimem_dev m = in[i];
+    uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
+    if (b - a > P.max_occ) continue;
+    int ulen = (int)(d.uoff[m.unitig + 1] - d.uoff[m.unitig]);
+    for (uint64_t j = a; j < b; ++j) {
+      uint64_t o = ctab[j]; uint32_t tid = (uint32_t)(o >> 32); bool ufw = (o >> 31) & 1; int upos = (int)(o & 0x7FFFFFFF);
+      int rpos = ufw ? upos + (int)m.ustart : upos + (ulen - ((int)m.ustart + (int)m.len));
+      bool fw = (ufw == (m.fw != 0));
+      uint32_t q = fw ? m.qpos : (uint32_t)(L - ((int)m.qpos + (int)m.len));
+      mkey[w] = ((uint64_t)e << 40) | (ref_accum[tid] + (uint64_t)rpos);
+      mval[w] = mem_pack_val(tid, q, m.len, fw);
+      ++w;
+    }
+  }
+}
+
+// a2b — findChains / findOptChain; SPEC §a2.
+__global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost, uint32_t nends,
+                        const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ mval,
+                        double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
+                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nends) return;
+  const uint64_t base = mem_off[e]; const uint32_t n = (uint32_t)(mem_off[e + 1] - base);
+  const int L = rlen[e];
+  uint32_t nch = 0; double bestAll = 0.0;
+  uint32_t g0 = 0;
+  while (g0 < n) {
+    const uint32_t tid0 = (uint32_t)(mval[base + g0] >> 32);
+    uint32_t g1 = g0; while (g1 < n && (uint32_t)(mval[base + g1] >> 32) == tid0) ++g1;
+    double best = 0.0;
+    for (uint32_t i = g0; i < g1; ++i) {
+      MemD hi = mem_decode(mkey[base + i], mval[base + i], ref_accum);
+      double fi = (double)hi.len; int pi = -1; int rounds = 2;
+      for (int j = (int)i - 1; j >= (int)g0; --j) {
+        MemD hj = mem_decode(mkey[base + j], mval[base + j], ref_accum);
+        if (hj.fw != hi.fw) continue;
+        int qd = hi.q - hj.q, rd = hi.rpos - hj.rpos;
+        if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
+        int l = abs(qd - rd);
+        double a = (double)min(hi.len, min(qd, rd));
+        double s = cf[base + j] + a - gapcost[l];
+        if (s > fi) { fi = s; pi = j; }
+        if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
+      }
+      cf[base + i] = fi; cp[base + i] = pi; mused[base + i] = 0; mnext[base + i] = 0xFFFFFFFFu;
+      if (fi > best) best = fi;
+    }
+    const double thr = P.pre_thr * best;
+    // accept chain ends by (score desc, index asc); mused: bit0 used, bit1 tried
+    for (;;) {
+      int bi = -1; double bf = 0.0;
+      for (uint32_t i = g0; i < g1; ++i) { uint8_t fl = mused[base + i]; if (fl) continue; double fv = cf[base + i]; if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; } }
+      if (bi < 0) break;
+      bool clash = false;
+      for (int x = bi; x >= 0; x = cp[base + x]) if (mused[base + x] & 1) { clash = true; break; }
+      if (clash) { mused[base + bi] |= 2; continue; }
+      uint32_t cnt = 0; int first = bi;
+      for (int x = bi; x >= 0; x = cp[base + x]) { mused[base + x] |= 1; ++cnt; int pr = cp[base + x]; if (pr >= 0) mnext[base + pr] = (uint32_t)x; first = x; }
+      MemD m0 = mem_decode(mkey[base + first], mval[base + first], ref_accum);
+      MemD ml = mem_decode(mkey[base + bi], mval[base + bi], ref_accum);
+      sq_chain_dev c; c.score = bf; c.tid = tid0; c.pos = m0.rpos - m0.q; c.last_end = ml.rpos + ml.len; c.first = (uint32_t)first; c.n_mems = (uint16_t)cnt; c.read_len = (uint16_t)L;
+      c.fw = ml.fw; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0;
+      chains[base + nch++] = c;
+      if (bf > bestAll) bestAll = bf;
+    }
+    g0 = g1;
+  }
+  // hitFilterPolicy AFTER + consensus fraction, per read end
+  const double cthr = P.consensus_frac * bestAll;
+  uint32_t kept = 0;
+  for (uint32_t i = 0; i < nch; ++i) { sq_chain_dev c = chains[base + i]; if (c.score < cthr) continue; chains[base + kept++] = c; }
+  n_chains[e] = kept;
+  atomicAdd(&stats[ST_MEMS], (unsigned long long)n); atomicAdd(&stats[ST_CHAINS], (unsigned long long)kept);
+}
+
+// a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.
+__device__ inline bool pair_ok(const sq_map_params& P, const sq_chain_dev& x, const sq_chain_dev& y, int32_t* fl, bool* dove) {
+  if (x.fw == y.fw) return false;  // mpol.noDiscordant
+  const sq_chain_dev& fwc = x.fw ? x : y; const sq_chain_dev& rcc = x.fw ? y : x;
+  if (rcc.pos < fwc.pos) { *dove = true; if (!P.allow_dovetail) return false; }
+  int32_t f = rcc.pos + (int32_t)rcc.read_len - fwc.pos;
+  if (f <= 0 || f > (int32_t)P.frag_len_max) return false;
+  *fl = f; return true;
+}
+__device__ inline void cand_init(sq_cand_dev& c, double cov, uint32_t tid, uint32_t lc, uint32_t rc, uint32_t fl, uint8_t ms) {
+  c.cov = cov; c.tid = tid; c.lc = lc; c.rc = rc; c.frag_len = fl; c.lscore = c.rscore = SQ_INVALID_SCORE; c.mate_status = ms;
+  c.valid = 0; c.compat = 0; c.lfail = c.rfail = 0; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0;
+}
+template <bool FILL>
+__device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_dev* lc, uint32_t nl, uint32_t lbase, const sq_chain_dev* rc, uint32_t nr, uint32_t rbase,
+                                         sq_cand_dev* out, bool* dovetail) {
+  uint32_t cnt = 0; bool dove = false;
+  // pass 1: global best coverage over concordant pairs
+  double best = -1.0;
+  for (uint32_t i = 0, j = 0; i < nl && j < nr;) {
+    uint32_t ti = lc[i].tid, tj = rc[j].tid;
+    if (ti < tj) { ++i; continue; }
+    if (ti > tj) { ++j; continue; }
+    uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
+    for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) { int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue; double cov = lc[a].score + rc[b].score; if (cov > best) best = cov; }
+    i = i1; j = j1;
+  }
+  *dovetail = dove;
+  if (best >= 0.0) {
+    const double thr = P.consensus_frac * best;
+    for (uint32_t i = 0, j = 0; i < nl && j < nr;) {
+      uint32_t ti = lc[i].tid, tj = rc[j].tid;
+      if (ti < tj) { ++i; continue; }
+      if (ti > tj) { ++j; continue; }
+      uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
+      double bt = 0.0; bool d2;
+      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) { int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue; double cov = lc[a].score + rc[b].score; if (cov < thr) continue; if (cov > bt) bt = cov; }
+      const double pthr = P.post_thr * bt;
+      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
+        int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue; double cov = lc[a].score + rc[b].score; if (cov < thr || cov < pthr) continue;
+        if (FILL) cand_init(out[cnt], cov, ti, lbase + a, rbase + b, (uint32_t)fl, SQ_MS_PAIRED_END_PAIRED);
+        ++cnt;
+      }
+      i = i1; j = j1;
+    }
+    return cnt;
+  }
+  if (!P.allow_orphans) return 0;
+  double ob = 0.0;
+  for (uint32_t a = 0; a < nl; ++a) if (lc[a].score > ob) ob = lc[a].score;
+  for (uint32_t b = 0; b < nr; ++b) if (rc[b].score > ob) ob = rc[b].score;
+  const double othr = P.orphan_thr * ob;
+  for (uint32_t a = 0; a < nl; ++a) if (lc[a].score >= othr) { if (FILL) cand_init(out[cnt], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_PAIRED_END_LEFT); ++cnt; }
+  for (uint32_t b = 0; b < nr; ++b) if (rc[b].score >= othr) { if (FILL) cand_init(out[cnt], rc[b].score, rc[b].tid, 0xFFFFFFFFu, rbase + b, 0, SQ_MS_PAIRED_END_RIGHT); ++cnt; }
+  return cnt;
+}
+
+template <bool FILL>
+__global__ void k_join(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ mem_off, const sq_chain_dev* __restrict__ chains, const uint32_t* __restrict__ n_chains,
+                       uint32_t* __restrict__ n_cand, const uint64_t* __restrict__ cand_off, sq_cand_dev* __restrict__ cands, uint8_t* __restrict__ frag_flags) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nfrag) return;
+  sq_cand_dev* out = FILL ? cands + cand_off[f] : nullptr;
+  uint32_t cnt = 0; bool dove = false;
+  if (paired) {
+    uint32_t e0 = 2 * f, e1 = 2 * f + 1;
+    uint64_t lb = mem_off[e0], rb = mem_off[e1];
+    cnt = join_fragment<FILL>(P, chains + lb, n_chains[e0], (uint32_t)lb, chains + rb, n_chains[e1], (uint32_t)rb, out, &dove);
+  } else {  // joinReadsAndFilterSingle: every surviving chain is a candidate
+    uint64_t lb = mem_off[f]; uint32_t nl = n_chains[f];
+    for (uint32_t a = 0; a < nl; ++a) {
+      if (FILL) { const sq_chain_dev& ch = chains[lb + a]; cand_init(out[cnt], ch.score, ch.tid, (uint32_t)lb + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END); }
+      ++cnt;
+    }
+  }
+  if (!FILL) { n_cand[f] = cnt; frag_flags[f] = (uint8_t)((dove ? 1 : 0)); }
+}
+
+// ---- a4 scoring --------------------------------------------------------------------------------
+struct ScoreCtx {
+  const uint64_t* refseq; const uint64_t* ref_accum; const uint32_t* ref_len;
+  const uint64_t* rpack; const uint64_t* rnmask; const uint16_t* rlen;
+  const uint64_t* mkey; const uint64_t* mval; const uint32_t* mnext;
+  sq_dp_item* dpq; uint32_t* counters; uint32_t dpq_cap;
+};
+
+// mismatch count of q[0..n) vs t[0..n) with direction-aware accessors
+__device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir, const uint64_t* refseq, int64_t tstart, int tdir, int n) {
+  int mm = 0;
+  for (int i = 0; i < n; ++i) { uint32_t qb = norm_base(r, fw, qstart + qdir * i); uint32_t tb = sq_fetch_base(refseq, (uint64_t)(tstart + (int64_t)tdir * i)); mm += !(qb == tb && qb < 4); }
+  return mm;
+}
+
+// region score; returns true if resolved immediately (value in *sc), false if queued for DP
+__device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, const ReadView& r, bool fw, uint32_t cand, uint8_t end, int mode,
+                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc) {
+  if (n == 0 && mode == 1) { *sc = 0; return true; }
+  if (n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n))) {
+    int mm = count_mm(r, fw, qstart, qdir, S.refseq, tstart, tdir, n);
+    int lim = (mode == 0) ? (2 * (P.go + P.ge) + P.ma) : (P.go + P.ge);
+    if (mm * (P.ma - P.mp) <= lim) { *sc = P.ma * (n - mm) + P.mp * mm; return true; }
+  }
+  // trivial DP outcomes that need no matrix (mirrors dp_align's early returns)
+  if (n == 0) { *sc = (tl == 0) ? 0 : (tl <= P.bw ? -(P.go + P.ge * tl) : SQ_NEG_INF); atomicAdd(&S.counters[1], 1u); return true; }
+  if (tl == 0) { *sc = (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF; atomicAdd(&S.counters[1], 1u); return true; }
+  uint32_t slot = atomicAdd(&S.counters[0], 1u);
+  atomicAdd(&S.counters[1], 1u);
+  if (slot < S.dpq_cap) {
+    sq_dp_item it; it.cand = cand; it.end = end; it.mode = (uint8_t)mode; it.rc = fw ? 0 : 1; it.pad = 0; it.qstart = qstart; it.qdir = qdir; it.n = n; it.tstart = tstart; it.tdir = tdir; it.tl = tl; it.rec = 0;
+    S.dpq[slot] = it;
+  }
+  return false;
+}
+
+// score one chain against its read end; DP regions are queued and added later by k_dp
+__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end) {
+  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  const int L = r.L; const bool fw = ch.fw != 0;
+  const uint32_t tid = ch.tid; const int Tlen = (int)S.ref_len[tid]; const int64_t g = (int64_t)S.ref_accum[tid];
+  int64_t score = 0; int prevQ = 0, prevR = 0; bool first = true;
+  uint32_t mi = ch.first;
+  for (uint32_t it = 0; it < ch.n_mems; ++it) {
+    MemD m = mem_decode(S.mkey[mem_base + mi], S.mval[mem_base + mi], S.ref_accum);
+    int qs = m.q, rs = m.rpos, ln = m.len;
+    bool use = true;
+    if (first) {
+      if (qs > 0) {
+        int ws = max(0, rs - qs - SQ_REF_EXTEND); int tl = max(0, rs - ws);
+        int32_t sc; if (region_fast(P, S, r, fw, cand, end, 1, qs - 1, -1, qs, g + rs - 1, -1, tl, &sc)) score += sc;
+      }
+      first = false;
+    } else {
+      int ov = max(0, max(prevQ - qs, prevR - rs));
+      if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) use = false; }
+      if (use) {
+        int gq = qs - prevQ, gr = rs - prevR;
+        if (gq > 0 || gr > 0) { int32_t sc; if (region_fast(P, S, r, fw, cand, end, 0, prevQ, 1, gq, g + prevR, 1, gr, &sc)) score += sc; }
+      }
+    }
+    if (use) { score += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
+    mi = S.mnext[mem_base + mi];
+  }
+  if (prevQ < L) {
+    int tail = L - prevQ; int we = min(Tlen, prevR + tail + SQ_REF_EXTEND); int tl = max(0, we - prevR);
+    int32_t sc; if (region_fast(P, S, r, fw, cand, end, 1, prevQ, 1, tail, g + prevR, 1, tl, &sc)) score += sc;
+  }
+  if (score < -(1 << 30)) score = -(1 << 30);
+  return (int32_t)score;
+}
+
+__device__ inline bool joint_compat(const sq_map_params& P, bool orphan, bool isLeft, bool lfw, bool rfw) {  // SalmonQuantify.cpp:1467-1516
+  const uint8_t s = P.lib_strand;
+  bool c = (s == 4) ? (orphan ? true : (lfw != rfw)) : false;
+  if (c) return true;
+  if (orphan) { if (s == 0) return (isLeft && lfw) || (!isLeft && !rfw); if (s == 1) return (isLeft && !lfw) || (!isLeft && rfw); return false; }
+  if (s == 0) return lfw && !rfw;
+  if (s == 1) return !lfw && rfw;
+  return false;
+}
+__device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {  // SalmonUtils.cpp:195-268
+  const uint8_t s = P.lib_strand, o = P.lib_orient;
+  switch (ms) {
+    case SQ_MS_SINGLE_END: return fwd ? (s == 4 || s == 2) : (s == 4 || s == 3);
+    case SQ_MS_PAIRED_END_LEFT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd); return fwd ? (s == 4 || s == 0) : (s == 4 || s == 1);
+    case SQ_MS_PAIRED_END_RIGHT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd); return fwd ? (s == 4 || s == 1) : (s == 4 || s == 0);
+    default: return false;
+  }
+}
+
+__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ cand_off, uint32_t nfrag,
+                        const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag) {
+  uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= ncand) return;
+  sq_cand_dev c = cands[ci];
+  const uint32_t f = cand_frag[ci];
+  const bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
+  const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
+  bool lfw = hasL ? chains[c.lc].fw != 0 : false, rfw = hasR ? chains[c.rc].fw != 0 : false;
+  bool isc = paired ? joint_compat(P, orphan, hasL, lfw, rfw) : compat_se(P, lfw, SQ_MS_SINGLE_END);
+  c.compat = isc;
+  if (!isc && P.ignore_incompat) { c.valid = 0; c.lfail = c.rfail = 2; cands[ci] = c; return; }   // 2 = skipped (not scored)
+  uint32_t e0 = paired ? 2 * f : f, e1 = 2 * f + 1;
+  if (hasL) c.lscore = score_chain(P, S, chains[c.lc], mem_off[e0], e0, (uint32_t)ci, 0);
+  if (hasR) c.rscore = score_chain(P, S, chains[c.rc], mem_off[e1], e1, (uint32_t)ci, 1);
+  cands[ci] = c;
+}
+
+// banded Gotoh in registers: band index b = j - i + W, W = SQ_MAX_BAND (runtime bw <= W). SPEC §a4.
+__global__ void k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, uint32_t paired) {
+  uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= nitems) return;
+  const sq_dp_item it = S.dpq[ii];
+  const uint32_t f = cand_frag[it.cand];
+  const uint32_t end_id = paired ? 2 * f + it.end : f;
+  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  const bool fw = it.rc == 0;
+  const int n = it.n, tl = it.tl, w = P.bw, go = P.go, ge = P.ge;
+  constexpr int W = SQ_MAX_BAND, BW = 2 * SQ_MAX_BAND + 1;
+  int32_t Hp[BW + 1], Fp[BW + 1];
+#pragma unroll
+  for (int b = 0; b <= BW; ++b) { Hp[b] = SQ_NEG_INF; Fp[b] = SQ_NEG_INF; }
+#pragma unroll
+  for (int b = 0; b < BW; ++b) { int j = b - W; if (j >= 0 && j <= tl && j <= w) Hp[b] = (j == 0) ? 0 : -(go + ge * j); }
+  for (int i = 1; i <= n; ++i) {
+    const uint32_t qb = norm_base(r, fw, it.qstart + it.qdir * (i - 1));
+    int32_t left_h = SQ_NEG_INF, left_e = SQ_NEG_INF;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+      const int j = i + b - W;
+      int32_t hv = SQ_NEG_INF, ev = SQ_NEG_INF, fv = SQ_NEG_INF;
+      const bool inband = (j >= 0 && j <= tl && (b - W) >= -w && (b - W) <= w);
+      if (inband) {
+        if (j == 0) { hv = (i <= w) ? -(go + ge * i) : SQ_NEG_INF; fv = hv; }
+        else {
+          ev = max(left_e, left_h - go) - ge;
+          fv = max(Fp[b + 1], Hp[b + 1] - go) - ge;
+          const uint32_t tb = sq_fetch_base(S.refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * (j - 1)));
+          const int32_t s = (qb == tb && qb < 4) ? P.ma : P.mp;
+          hv = max(Hp[b] + s, max(ev, fv));
+          ev = max(ev, SQ_NEG_INF); fv = max(fv, SQ_NEG_INF); hv = max(hv, SQ_NEG_INF);
+        }
+      }
+      // Hp[b] (diagonal for this cell) is no longer needed by later cells of this row: overwrite in place
+      Hp[b] = hv; Fp[b] = fv; left_h = hv; left_e = ev;
+    }
+  }
+  int32_t res = SQ_NEG_INF;
+  if (it.mode == 0) {
+    if (abs(n - tl) <= w) {
+#pragma unroll
+      for (int b = 0; b < BW; ++b) if (b == tl - n + W) res = Hp[b];
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BW; ++b) { int j = n + b - W; if (j >= max(0, n - w) && j <= min(tl, n + w) && Hp[b] > res) res = Hp[b]; }
+  }
+  sq_cand_dev* c = &cands[it.cand];
+  if (res <= SQ_NEG_INF / 2) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; }
+  else atomicAdd(it.end == 0 ? &c->lscore : &c->rscore, res);
+}
+
+// ---- a7/a8/a9 — updateRefMappings + filterAndCollectAlignments (SalmonMappingUtils.hpp:225-405) ----
+__device__ inline uint8_t fmt_id(uint8_t t, uint8_t o, uint8_t s) { return (uint8_t)(t | (o << 1) | (s << 3)); }
+__device__ inline uint8_t hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t e2, bool f2, uint32_t l2) {  // SalmonUtils.cpp:577-631, canDovetail=false
+  (void)l1; (void)l2;
+  if (f1 != f2) { if (f1) return (e1 <= e2) ? fmt_id(1, 2, 0) : fmt_id(1, 1, 0); return (e2 <= e1) ? fmt_id(1, 2, 1) : fmt_id(1, 1, 1); }
+  return f1 ? fmt_id(1, 0, 2) : fmt_id(1, 0, 3);
+}
+
+__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, sq_cand_dev* __restrict__ cands, const sq_chain_dev* __restrict__ chains,
+                         const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln, uint8_t* __restrict__ map_type,
+                         unsigned long long* __restrict__ stats) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nfrag) return;
+  const uint64_t c0 = cand_off[f]; const uint32_t nc = (uint32_t)(cand_off[f + 1] - c0);
+  sq_cand_dev* C = cands + c0;
+  const uint32_t e0 = paired ? 2 * f : f;
+  const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
+  uint32_t nfilt = 0;
+  int32_t bestDecoy = SQ_INVALID_SCORE, bestScore = SQ_INVALID_SCORE;
+  // finalise scores (validity against minScoreFraction) — hitScore stored in lscore for orphans/singles, sum kept implicit
+  for (uint32_t i = 0; i < nc; ++i) {
+    sq_cand_dev c = C[i];
+    if (c.lfail == 2) continue;  // incompatible, skipped before alignment
+    const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
+    int32_t ls = SQ_INVALID_SCORE, rs = SQ_INVALID_SCORE;
+    if (hasL) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1)); ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore; }
+    if (hasR) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2)); rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore; }
+    c.lscore = ls; c.rscore = rs;
+    bool ok = (hasL && hasR) ? (ls != SQ_INVALID_SCORE && rs != SQ_INVALID_SCORE) : ((hasL ? ls : rs) != SQ_INVALID_SCORE);
+    c.valid = ok;
+    if (!ok) ++nfilt;
+    C[i] = c;
+    if (ok && c.tid >= P.first_decoy) { int32_t hs = (hasL && hasR) ? ls + rs : (hasL ? ls : rs); if (hs > bestDecoy) bestDecoy = hs; }
+  }
+  auto hit_score = [&](const sq_cand_dev& c) -> int32_t { const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu; return (hasL && hasR) ? c.lscore + c.rscore : (hasL ? c.lscore : c.rscore); };
+  auto decoy_cut = [&](int32_t bd) -> int32_t { return (int32_t)(P.decoy_threshold * (double)bd); };
+  // order-dependent part of updateRefMappings: a non-decoy hit is recorded only if it reaches the
+  // best decoy score seen *so far* (SPEC §a7); `compat` doubles as the "recorded" flag from here on
+  {
+    int32_t runDecoy = SQ_INVALID_SCORE;
+    for (uint32_t i = 0; i < nc; ++i) {
+      sq_cand_dev& c = C[i];
+      bool rec = false;
+      if (c.valid) {
+        int32_t hs = hit_score(c);
+        if (c.tid >= P.first_decoy) { if (hs > runDecoy) runDecoy = hs; }
+        else if (hs >= decoy_cut(runDecoy)) { rec = true; if (hs > bestScore) bestScore = hs; }
+      }
+      c.pad[0] = rec ? 1 : 0;
+    }
+  }
+  const bool onlyDecoy = (bestScore < decoy_cut(bestDecoy)) && (bestDecoy > SQ_INVALID_SCORE);
+  uint32_t na = 0; uint8_t mt = SQ_MT_UNMAPPED;
+  sq_aln* out = aln_slots + c0;
+  if (bestScore > SQ_INVALID_SCORE && !onlyDecoy) {
+    const int32_t bd = (bestDecoy == SQ_INVALID_SCORE) ? SQ_INVALID_SCORE + 1 : bestDecoy;
+    const int32_t thr = P.hard_filter ? bestScore : decoy_cut(bd);
+    // winners: per transcript the best recorded hit, ties -> the later compatible hit (all recorded hits are compatible
+    // when ignore_incompat; otherwise the reference prefers compatible on ties)
+    for (uint32_t i = 0; i < nc; ++i) {
+      const sq_cand_dev& c = C[i];
+      if (!c.pad[0]) continue;
+      const int32_t hs = hit_score(c);
+      bool win = true;
+      // replay of the sequential per-transcript rule: candidate i wins iff no later recorded hit j displaces it and it displaced all earlier ones
+      int32_t cur = SQ_INVALID_SCORE; int curi = -1;
+      for (uint32_t j = 0; j < nc; ++j) {
+        const sq_cand_dev& d = C[j];
+        if (!d.pad[0] || d.tid != c.tid) continue;
+        int32_t ds = hit_score(d);
+        if (curi < 0 || ds > cur || (ds == cur && d.compat)) { cur = ds; curi = (int)j; }
+      }
+      win = (curi == (int)i);
+      if (!win || hs < thr) continue;
+      double v = (double)bestScore - (double)hs;
+      double p = P.hard_filter ? -1.0 : sq_exp(-P.score_exp * v);
+      if (!P.hard_filter && p < P.min_aln_prob) continue;
+      // rank by tid among emitted: insertion keeps ascending tid (stable on equal tid cannot happen: one winner per tid)
+      sq_aln a; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
+      if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
+        const sq_chain_dev& l = chains[c.lc]; const sq_chain_dev& rr = chains[c.rc];
+        a.pos = l.pos; a.fwd = l.fw; a.read_len = (uint16_t)n1; a.mate_pos = rr.pos; a.mate_fwd = rr.fw; a.mate_len = (uint16_t)n2; a.score = c.lscore; a.mate_score = c.rscore;
+        int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
+        a.format_id = hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len);
+      } else {
+        const bool left = c.lc != 0xFFFFFFFFu; const sq_chain_dev& o = left ? chains[c.lc] : chains[c.rc];
+        a.pos = o.pos; a.fwd = o.fw; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
+        a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
+        a.format_id = a.fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3);
+      }
+      uint32_t ins = na; while (ins > 0 && out[ins - 1].tid > a.tid) { out[ins] = out[ins - 1]; --ins; }
+      out[ins] = a; ++na;
+    }
+    if (na) {
+      switch (out[0].mate_status) { case SQ_MS_PAIRED_END_PAIRED: mt = SQ_MT_PAIRED_MAPPED; break; case SQ_MS_PAIRED_END_LEFT: mt = SQ_MT_LEFT_ORPHAN; break; case SQ_MS_PAIRED_END_RIGHT: mt = SQ_MT_RIGHT_ORPHAN; break; default: mt = SQ_MT_SINGLE_MAPPED; }
+    }
+  } else if (nc) {
+    mt = onlyDecoy ? SQ_MT_DECOY : SQ_MT_UNMAPPED;
+    atomicAdd(&stats[ST_FRAGFILT], 1ULL); if (onlyDecoy) atomicAdd(&stats[ST_DECOY], 1ULL);
+  }
+  n_aln[f] = na; map_type[f] = mt;
+  atomicAdd(&stats[ST_MAPFILT], (unsigned long long)nfilt);
+  atomicAdd(&stats[ST_ALNS], (unsigned long long)na);
+  if (na) atomicAdd(&stats[ST_MAPPED], 1ULL);
+  if (nc) atomicAdd(&stats[ST_JOINT], 1ULL);
+  if (!nc && (frag_flags[f] & 1)) atomicAdd(&stats[ST_DOVETAIL], 1ULL);
+}
+
+__global__ void k_fill_cand_frag(uint32_t nfrag, const uint64_t* __restrict__ cand_off, uint32_t* __restrict__ cand_frag) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nfrag) return;
+  for (uint64_t i = cand_off[f]; i < cand_off[f + 1]; ++i) cand_frag[i] = f;
+}
+
+__global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ n_aln,
+                               const sq_aln* __restrict__ slots, sq_aln* __restrict__ out) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nfrag) return;
+  const sq_aln* s = slots + cand_off[f]; sq_aln* o = out + aln_off[f];
+  for (uint32_t i = 0; i < n_aln[f]; ++i) o[i] = s[i];
+}
+
+__global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nfrag) return;
+  bool any = paired ? (n_chains[2 * f] || n_chains[2 * f + 1]) : (n_chains[f] != 0);
+  if (any) atomicAdd(&stats[ST_KMER], 1ULL);
+}
+
+}  // namespace sqk

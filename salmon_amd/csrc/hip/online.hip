@@ -1,0 +1,548 @@
+// hip/online.hip — online model + equivalence-class accumulation on gfx950 (seam B2).
+//
+// Replaces processMiniBatch (reference src/quant/SalmonQuantify.cpp:426-1023),
+// FragmentLengthDistribution (src/model/FragmentLengthDistribution.cpp:23-186), the transcript
+// mass / count atomics (include/salmon/internal/model/Transcript.hpp:136-141,210-217) and
+// EquivalenceClassBuilder::addGroup/finish (include/salmon/internal/quant/EquivalenceClassBuilder.hpp).
+//
+// The reference mutates shared state from N threads in arrival order (nondeterministic).  Here a
+// mini-batch (5000 fragments, SalmonQuantify.cpp:150) is the unit of synchrony: every fragment of a
+// mini-batch reads the model as of the batch start; increments are accumulated with INTEGER atomics
+// (fixed-point masses, histogram counts, fixed-point class weights) and applied at the batch end,
+// so results do not depend on thread order and equal the CPU checker bit for bit (SPEC §D1).
+// The equivalence-class table is an HBM open-addressing table keyed by a 128-bit label hash.
+#include "ctx.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct sq_online_dev {
+  uint32_t M = 0;
+  // model
+  sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac; sq_dbuf<double> scal;  // scal[0]=totMass
+  sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize
+  // per big batch
+  sq_dbuf<uint8_t> has_compat; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
+  // eq table
+  uint64_t tcap = 0; sq_dbuf<unsigned long long> tk1, tk2, tcount, tpool; sq_dbuf<uint32_t> tn; sq_dbuf<uint32_t> pool_tid, pool_bin; sq_dbuf<unsigned long long> pool_wq; sq_dbuf<unsigned long long> pool_cursor;  // [0] labels used, [1] classes, [2] overflow flag
+  uint64_t pool_cap = 0;
+  std::vector<double> fm_host;
+  uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0; bool burned_known = false;
+};
+
+namespace {
+const int TB = 256;
+inline uint32_t nblk(uint64_t n) { return (uint32_t)((n + TB - 1) / TB); }
+#define EQ_EMPTY (~0ULL)
+
+__device__ inline double dev_u01(uint64_t seed, uint64_t read, uint64_t aln) {
+  uint64_t x = sq_mix64(seed ^ sq_mix64(read * 0x9E3779B97F4A7C15ULL + aln + 1));
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ inline uint32_t frag_len_pedantic(const sq_aln& a, uint32_t txpLen) {  // ReadPair.hpp:149-168 semantics
+  if (a.mate_status != SQ_MS_PAIRED_END_PAIRED || a.fwd == a.mate_fwd) return 0;
+  int32_t T = (int32_t)txpLen;
+  int32_t p1 = a.fwd ? a.pos : a.mate_pos; p1 = p1 < 0 ? 0 : p1; p1 = p1 > T ? T : p1;
+  int32_t p2 = a.fwd ? a.mate_pos + (int32_t)a.mate_len : a.pos + (int32_t)a.read_len; p2 = p2 < 0 ? 0 : p2; p2 = p2 > T ? T : p2;
+  return (uint32_t)(p1 > p2 ? p1 - p2 : p2 - p1);
+}
+// library compatibility (SalmonUtils.cpp:138-298)
+__device__ inline bool is_compatible(uint8_t fid, uint8_t et, uint8_t eo, uint8_t es, bool fwd, uint8_t ms) {
+  if (ms != SQ_MS_PAIRED_END_PAIRED) {
+    switch (ms) {
+      case SQ_MS_SINGLE_END: return fwd ? (es == 4 || es == 2) : (es == 4 || es == 3);
+      case SQ_MS_PAIRED_END_LEFT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd); return fwd ? (es == 4 || es == 0) : (es == 4 || es == 1);
+      case SQ_MS_PAIRED_END_RIGHT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd); return fwd ? (es == 4 || es == 1) : (es == 4 || es == 0);
+      default: return false;
+    }
+  }
+  uint8_t ot = fid & 1, oo = (fid >> 1) & 3, os = fid >> 3;
+  if (ot != 1) return false;
+  if (eo != oo) return false;
+  return es == 4 || es == os;
+}
+
+struct OnlineView {
+  uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen;
+  double* hist; double* cpmf; double* ccmf; const double* ambig; double* mass; const double* prior_mass; double* log_eff_len; double* scal; double* cfac;
+  unsigned long long* mass_acc; unsigned long long* uniq; unsigned long long* total; unsigned long long* lib_counts; uint32_t* fld_cnt; unsigned long long* ctr;
+};
+
+__global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o, uint32_t* __restrict__ flag) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { flag[n] = 0; return; }
+  uint32_t f = 0;
+  for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; ++i) { const sq_aln a = aln[i]; bool c = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status); if (c || !o.ignore_incompat) { f = 1; break; } }
+  flag[r] = f;
+}
+
+__device__ inline void label_hash_step(uint64_t& a, uint64_t& b, uint32_t x) {
+  a = sq_mix64(a ^ (uint64_t)x) + 0x9E3779B97F4A7C15ULL;
+  b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29);
+}
+
+// one mini-batch: fragments [r0, r1) of the current mapped batch
+__global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0, double logFM,
+                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
+                             unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2) {
+  uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r1) return;
+  const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
+  rh1[r] = EQ_EMPTY; rh2[r] = 0;
+  if (a1 == a0) return;
+  const bool burned = V.ctr[1] != 0; const bool cached = V.ctr[3] != 0;
+  const uint64_t assigned_before = assigned_base + assigned_prefix[r];
+  const bool useAux = assigned_before >= o.num_pre_burnin_frags;
+  const bool cond = burned || useAux;
+  const bool singleEnd = (o.lib_type == 0);
+  const double totMass = V.scal[0];
+  auto pmf = [&](uint32_t len) -> double { if (cached) return len < 1001 ? V.cpmf[len] : V.cpmf[1000]; if (len > 1000) len = 1000; return V.hist[len] - totMass; };
+  auto cmf = [&](uint32_t len) -> double { return len < 1001 ? V.ccmf[len] : V.ccmf[1000]; };
+  // pass 1: auxProb / logProb per kept alignment, their log-sums (fixed order = alignment order)
+  double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtSeen = 0;
+  for (uint64_t ai = a0; ai < a1; ++ai) {
+    const sq_aln a = aln[ai]; const uint32_t t = a.tid;
+    abin[ai] = 0xFFFFFFFFu;
+    const uint32_t rl = V.ref_len[t];
+    const double refLength = rl > 0 ? (double)rl : 1.0;
+    const double logFragCov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
+    const double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)rl) : V.log_eff_len[t]);
+    const double tlc = sq_log_add(V.prior_mass[t], V.mass[t]);
+    uint32_t flen = a.frag_len;
+    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = frag_len_pedantic(a, rl);
+    double logFragProb = 0.0;
+    const bool unexpectedOrphan = (o.lib_type == 1 && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
+    if (o.model_single_frag_prob && o.use_frag_len_dist && (singleEnd || unexpectedOrphan)) {
+      int32_t tl = (int32_t)V.ref_clen[t], maxFL;
+      if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
+      else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
+      const bool useFLD = singleEnd || burned;
+      auto cmfv = [&](uint32_t len) -> double { if (useFLD && cached) return cmf(len); return V.ambig[len < 1000 ? len : 1000]; };
+      double refCM = cmfv((uint32_t)tl); bool cm = !(refCM == SQ_LOG_0);
+      logFragProb = cm ? (cmfv((uint32_t)maxFL) - refCM) : SQ_LOG_EPSILON;
+    } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
+    if (flen > 0 && o.use_frag_len_dist && cond) {
+      double lenProb = pmf(flen);
+      if (burned) { double cm = cmf(flen); bool ok = ((double)flen < refLength) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+      else if (useAux) logFragProb = lenProb;
+    }
+    const bool isCompat = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
+    const double logCompat = isCompat ? 0.0 : o.incompat_prior;
+    if (!isCompat && o.ignore_incompat) continue;
+    double startPosProb = -logRefLength;
+    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction)
+      startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
+    fmtSeen |= 1ULL << a.format_id;
+    const double auxProb = logFragProb + logFragCov + logCompat;
+    const double logProb = tlc + auxProb + startPosProb;
+    if (fabs(logProb) == SQ_LOG_0) continue;
+    sumProbs = sq_log_add(sumProbs, logProb);
+    auxDenom = sq_log_add(auxDenom, auxProb);
+    // stash: awq temporarily holds auxProb bits, abin marks "kept" (0), rslot unused here
+    awq[ai] = (unsigned long long)__double_as_longlong(auxProb); abin[ai] = 0;
+    ++nk;
+  }
+  if (nk == 0 || sumProbs == SQ_LOG_0) { for (uint64_t ai = a0; ai < a1; ++ai) abin[ai] = 0xFFFFFFFFu; return; }
+  // pass 2: normalise, range-factorization bins, label hash, model increments
+  const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
+  const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
+  uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen;
+  for (uint64_t ai = a0; ai < a1; ++ai) if (abin[ai] == 0) label_hash_step(ha, hb, aln[ai].tid);
+  const uint64_t readIdx = read_counter0 + (r - r0);
+  uint32_t ki = 0; uint32_t firstTid = 0;
+  for (uint64_t ai = a0; ai < a1; ++ai) {
+    if (abin[ai] != 0) continue;
+    const sq_aln a = aln[ai]; const uint32_t t = a.tid;
+    const double auxProb = __longlong_as_double((long long)awq[ai]);
+    const double w = sq_exp(auxProb - auxDenom);
+    uint32_t bin = 0;
+    if (o.range_factorization_bins > 0) bin = (uint32_t)(int32_t)(w * (double)rangeCount);
+    awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
+    // recompute logProb for the mass update (same operations as pass 1)
+    const uint32_t rl = V.ref_len[t]; const double refLength = rl > 0 ? (double)rl : 1.0;
+    const double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)rl) : V.log_eff_len[t]);
+    const double tlc = sq_log_add(V.prior_mass[t], V.mass[t]);
+    uint32_t flen = a.frag_len; if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = frag_len_pedantic(a, rl);
+    double startPosProb = -logRefLength;
+    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction) startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
+    const double logProb = tlc + auxProb + startPosProb;
+    const double pr = sq_exp(logProb - sumProbs);
+    atomicAdd(&V.mass_acc[t], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+    atomicAdd(&V.total[t], 1ULL);
+    if (!burned) {
+      double rr = dev_u01(o.seed, readIdx, ki);
+      if (rr < pr) { uint32_t fl = frag_len_pedantic(a, rl); if (fl > 0) { if (fl > 1000) fl = 1000; atomicAdd(&V.fld_cnt[fl], 1u); atomicMin(&V.ctr[2], (unsigned long long)fl); } }
+    }
+    abin[ai] = bin;   // kept alignments now carry their bin id (< 0xFFFFFFFF)
+    if (ki == 0) firstTid = t;
+    ++ki;
+  }
+  if (o.range_factorization_bins > 0) for (uint64_t ai = a0; ai < a1; ++ai) if (abin[ai] != 0xFFFFFFFFu) label_hash_step(ha, hb, abin[ai]);
+  uint64_t h1 = sq_mix64(ha), h2 = sq_mix64(hb);
+  if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
+  rh1[r] = h1; rh2[r] = h2;
+  if (nk == 1) atomicAdd(&V.uniq[firstTid], 1ULL);
+  for (int f = 0; f < 64; ++f) if ((fmtSeen >> f) & 1) atomicAdd(&V.lib_counts[f], 1ULL);
+}
+
+// batch end, part 1: masses (one thread per transcript)
+__global__ void k_apply_mass(OnlineView V, double logFM) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.M) return;
+  unsigned long long q = V.mass_acc[t];
+  if (q) { V.mass[t] = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass_acc[t] = 0; }
+}
+
+// batch end, part 2 (one block of 1024): FLD histogram update + tree total + counters + burn-in trigger
+__global__ void __launch_bounds__(1024) k_apply_fld(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin) {
+  __shared__ double v[1024]; __shared__ uint32_t cnt[1008]; __shared__ int any;
+  const int b = threadIdx.x;
+  if (b == 0) any = 0;
+  __syncthreads();
+  const bool burned = V.ctr[1] != 0;
+  if (!burned) { if (b <= 1000) { uint32_t c = V.fld_cnt[b]; cnt[b] = c; if (c) any = 1; } }
+  __syncthreads();
+  if (!burned && any) {
+    if (b >= 1 && b <= 1000) {
+      double h = V.hist[b];
+      const double kern[5] = {sq_log(0.0625), sq_log(0.25), sq_log(0.375), sq_log(0.25), sq_log(0.0625)};
+      for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000) continue; uint32_t c = cnt[len]; if (!c) continue; h = sq_log_add(h, logFM + kern[i] + sq_log((double)c)); }
+      V.hist[b] = h;
+    }
+    __syncthreads();
+    v[b] = (b <= 1000) ? V.hist[b] : SQ_LOG_0;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) { if (b < s) v[b] = sq_log_add(v[b], v[b + s]); __syncthreads(); }
+    if (b == 0) V.scal[0] = v[0];
+    if (b <= 1000) V.fld_cnt[b] = 0;
+  }
+  if (b == 0) {
+    V.ctr[0] = assigned_after;
+    if (assigned_after >= num_burnin && V.ctr[1] == 0 && V.ctr[4] == 0) V.ctr[4] = 1;  // burn-in finalisation pending
+  }
+}
+
+// burn-in finalisation (FLD.cacheCMF :174-186 + updateTranscriptLengthsAtomic ReadExperiment.inl:62-94), one thread: 3 chains of 1001 logAdds, once
+__global__ void k_burnin_tables(OnlineView V, int force) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!(V.ctr[4] == 1 || force)) return;
+  const double tot0 = V.scal[0];
+  // effective-length correction factors use the *uncached* pmf over [minV, 1000]
+  uint32_t minLen = (uint32_t)V.ctr[2]; uint32_t minV = (minLen == 1000) ? 1 : minLen;
+  if (V.ctr[3] == 0) {
+    double sum = SQ_LOG_0; for (uint32_t i = minV; i <= 1000; ++i) sum = sq_log_add(sum, V.hist[i] - tot0);
+    double vals = 0.0, mult = 0.0;  // correctionFactorsFromMass (DistributionUtils.cpp:9-32); pmf[0] = 0 unless minV == 0 (never)
+    V.cfac[0] = 0.0;
+    for (uint32_t i = 1; i <= 1000; ++i) {
+      double p = (i >= minV && i < 1000) ? 100.0 * sq_exp((V.hist[i] - tot0) - sum) : 0.0;
+      vals = p * (double)i + vals; mult = p + mult;
+      V.cfac[i] = (mult > 0) ? vals / mult : 0.0;
+    }
+  }
+  if (!force) {
+    // cacheCMF: normalised pmf then prefix log-sum
+    double tot = SQ_LOG_0; for (int i = 0; i <= 1000; ++i) { double p = V.hist[i] - tot0; V.cpmf[i] = p; tot = sq_log_add(tot, p); }
+    double cum = SQ_LOG_0; for (int i = 0; i <= 1000; ++i) { double p = V.cpmf[i] - tot; V.cpmf[i] = p; cum = sq_log_add(cum, p); V.ccmf[i] = cum; }
+    V.ctr[3] = 1; V.ctr[1] = 1; V.ctr[4] = 2;
+  } else V.ctr[4] = 3;
+}
+__global__ void k_burnin_efflen(OnlineView V, int stage /*2 after burn-in, 3 forced at finish*/) {
+  if (V.ctr[4] != (unsigned long long)stage) return;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.M) return;
+  double ol = (double)V.ref_len[t]; uint32_t rl = V.ref_len[t];
+  double c = (rl >= 1001) ? V.cfac[1000] : V.cfac[rl];
+  double el = ol - c; if (el < 1.0) el = ol;
+  V.log_eff_len[t] = sq_log(el);
+}
+__global__ void k_burnin_done(OnlineView V) { if (threadIdx.x == 0 && blockIdx.x == 0 && (V.ctr[4] == 2 || V.ctr[4] == 3)) V.ctr[4] = 4; }
+
+// ---- eq-class table ---------------------------------------------------------------------------
+struct EqView { uint64_t cap; unsigned long long* k1; unsigned long long* k2; unsigned long long* count; unsigned long long* pool; uint32_t* n; uint32_t* pool_tid; uint32_t* pool_bin; unsigned long long* pool_wq; unsigned long long* cursor; uint64_t pool_cap; };
+
+__device__ inline uint64_t eq_find_or_insert(const EqView& T, uint64_t h1, uint64_t h2, bool* is_new) {
+  uint64_t slot = h1 & (T.cap - 1); *is_new = false;
+  for (uint64_t probes = 0; probes < T.cap; ++probes) {
+    unsigned long long cur = __hip_atomic_load(&T.k1[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == EQ_EMPTY) {
+      unsigned long long old = atomicCAS(&T.k1[slot], EQ_EMPTY, (unsigned long long)h1);
+      if (old == EQ_EMPTY) { __hip_atomic_store(&T.k2[slot], (unsigned long long)h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *is_new = true; return slot; }
+      cur = old;
+    }
+    if (cur == h1) {
+      unsigned long long o2 = __hip_atomic_load(&T.k2[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o2 == 0) { --probes; continue; }  // inserter has not published h2 yet: re-poll this slot (loop re-converges every iteration)
+      if (o2 == h2) return slot;
+    }
+    slot = (slot + 1) & (T.cap - 1);
+  }
+  return ~0ULL;
+}
+
+__global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ abin,
+                            const uint64_t* __restrict__ rh1, const uint64_t* __restrict__ rh2, uint32_t* __restrict__ rslot, uint32_t bins_on) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  rslot[r] = 0xFFFFFFFFu;
+  const uint64_t h1 = rh1[r]; if (h1 == EQ_EMPTY) return;
+  bool is_new; uint64_t slot = eq_find_or_insert(T, h1, rh2[r], &is_new);
+  if (slot == ~0ULL) { T.cursor[2] = 1; return; }
+  rslot[r] = (uint32_t)slot;
+  if (is_new) {
+    uint32_t nk = 0; for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) ++nk;
+    unsigned long long off = atomicAdd(&T.cursor[0], (unsigned long long)nk); atomicAdd(&T.cursor[1], 1ULL);
+    if (off + nk > T.pool_cap) { T.cursor[2] = 2; T.n[slot] = 0; T.pool[slot] = 0; return; }
+    uint32_t i = 0;
+    for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) { T.pool_tid[off + i] = aln[ai].tid; T.pool_bin[off + i] = bins_on ? abin[ai] : 0; ++i; }
+    T.n[slot] = nk; T.pool[slot] = off;
+  }
+}
+__global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ abin, const unsigned long long* __restrict__ awq, const uint32_t* __restrict__ rslot) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint32_t slot = rslot[r]; if (slot == 0xFFFFFFFFu) return;
+  atomicAdd(&T.count[slot], 1ULL);
+  if (T.n[slot] == 0) return;
+  unsigned long long off = T.pool[slot]; uint32_t i = 0;
+  for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) { atomicAdd(&T.pool_wq[off + i], awq[ai]); ++i; }
+}
+// merge an external table (classes given as CSR) — exact integer adds, any order
+__global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const uint32_t* __restrict__ bins, const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, uint32_t* __restrict__ cslot) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  bool is_new; uint64_t slot = eq_find_or_insert(T, h1[c], h2[c], &is_new);
+  if (slot == ~0ULL) { T.cursor[2] = 1; cslot[c] = 0xFFFFFFFFu; return; }
+  cslot[c] = (uint32_t)slot;
+  if (is_new) {
+    uint32_t nk = (uint32_t)(off[c + 1] - off[c]);
+    unsigned long long po = atomicAdd(&T.cursor[0], (unsigned long long)nk); atomicAdd(&T.cursor[1], 1ULL);
+    if (po + nk > T.pool_cap) { T.cursor[2] = 2; T.n[slot] = 0; T.pool[slot] = 0; return; }
+    for (uint32_t i = 0; i < nk; ++i) { T.pool_tid[po + i] = tid[off[c] + i]; T.pool_bin[po + i] = bins ? bins[off[c] + i] : 0; }
+    T.n[slot] = nk; T.pool[slot] = po;
+  }
+}
+__global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wq, const uint64_t* __restrict__ count, const uint32_t* __restrict__ cslot) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  uint32_t slot = cslot[c]; if (slot == 0xFFFFFFFFu) return;
+  atomicAdd(&T.count[slot], (unsigned long long)count[c]);
+  if (T.n[slot] == 0) return;
+  unsigned long long po = T.pool[slot];
+  for (uint64_t i = off[c]; i < off[c + 1]; ++i) atomicAdd(&T.pool_wq[po + (i - off[c])], (unsigned long long)wq[i]);
+}
+
+OnlineView make_view(sq_ctx* c) {
+  sq_online_dev* o = c->online; OnlineView V;
+  V.M = o->M; V.ref_len = c->di->ref_len; V.ref_clen = c->di->ref_clen; V.hist = o->hist.p; V.cpmf = o->cpmf.p; V.ccmf = o->ccmf.p; V.ambig = o->ambig.p; V.mass = o->mass.p; V.prior_mass = o->prior_mass.p;
+  V.log_eff_len = o->log_eff_len.p; V.scal = o->scal.p; V.cfac = o->cfac.p; V.mass_acc = o->mass_acc.p; V.uniq = o->uniq.p; V.total = o->total.p; V.lib_counts = o->lib_counts.p; V.fld_cnt = o->fld_cnt.p; V.ctr = o->ctr.p;
+  return V;
+}
+EqView make_eq_view(sq_online_dev* o) {
+  EqView T; T.cap = o->tcap; T.k1 = o->tk1.p; T.k2 = o->tk2.p; T.count = o->tcount.p; T.pool = o->tpool.p; T.n = o->tn.p; T.pool_tid = o->pool_tid.p; T.pool_bin = o->pool_bin.p; T.pool_wq = o->pool_wq.p; T.cursor = o->pool_cursor.p; T.pool_cap = o->pool_cap;
+  return T;
+}
+double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
+}  // namespace
+
+#include <hipcub/hipcub.hpp>
+
+int sq_online_create(sq_ctx* c) {
+  sq_online_dev* o = new sq_online_dev(); c->online = o;
+  const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
+  // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
+  uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
+  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(1024) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
+             o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
+             o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) || o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
+             o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) || o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
+  if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
+  const sq_quant_opts& q = c->opts;
+  std::vector<double> hist(1024, SQ_LOG_0), ambig(1024, 0.0), pm(M), le(M), mass(M, SQ_LOG_0);
+  for (int i = 0; i <= 1000; ++i) {  // FragmentLengthDistribution.cpp:38-55 (alpha = 1)
+    double nm = phi((i + 0.5 - q.fld_mean) / q.fld_sd) - phi((i - 0.5 - q.fld_mean) / q.fld_sd);
+    hist[i] = (nm != 0) ? sq_log(nm) : SQ_LOG_EPSILON;
+  }
+  { std::vector<double> v(1024, SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
+    double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
+  { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambig[j] = cum; } }  // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
+  for (uint32_t t = 0; t < M; ++t) { double len = (double)c->idx->ref_len[t]; pm[t] = sq_log(0.005 * len); le[t] = sq_log(len); }  // Transcript.hpp:48-56; alpha = 0.005 (ReadExperiment.inl:114)
+  SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 1024 * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
+  SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8)); SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4)); SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
+  unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
+  SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, o->pool_cap * 8)); SQ_HIP_CHECK(hipMemset(o->pool_cursor.p, 0, 4 * 8));
+  return SQ_OK;
+}
+
+void sq_online_free(sq_ctx* c) {
+  sq_online_dev* o = c->online; if (!o) return;
+  o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
+  o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
+  o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
+  delete o; c->online = nullptr;
+}
+
+static double forgetting_mass(sq_online_dev* o, double ff, uint64_t b) {  // ForgettingMassCalculator.hpp:30-40
+  while (o->fm_host.size() <= b) {
+    if (o->fm_host.empty()) { o->fm_host.push_back(0.0); continue; }
+    uint64_t i = o->fm_host.size() + 1;
+    o->fm_host.push_back(o->fm_host.back() + ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0));
+  }
+  return o->fm_host[b];
+}
+
+static int check_eq_overflow(sq_ctx* c) {
+  unsigned long long cur[4];
+  SQ_HIP_CHECK(hipMemcpy(cur, c->online->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
+  if (cur[2]) { sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]); return SQ_ERR_OVERFLOW; }
+  if (cur[1] * 10 > c->online->tcap * 7) { sq_set_error("equivalence-class table over 70%% full (%llu classes)", cur[1]); return SQ_ERR_OVERFLOW; }
+  return SQ_OK;
+}
+
+extern "C" int sq_eq_accumulate(sq_ctx* c) {
+  if (!c || !c->have_batch) { sq_set_error("sq_eq_accumulate: call sq_map_batch first"); return SQ_ERR_STATE; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_dev* o = c->online; hipStream_t st = c->stream; const uint32_t n = c->last_n; const sq_quant_opts& q = c->opts;
+  c->have_batch = false;
+  if (n == 0) return SQ_OK;
+  const size_t A = (size_t)c->last_total_aln + 8;
+  if (o->awq.ensure(A) || o->abin.ensure(A)) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
+  OnlineView V = make_view(c);
+  // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
+  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, c->aln_off.p, c->aln.p, q, o->assigned_flag.p);
+  { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
+    if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
+    tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
+  std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
+  const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
+  const uint32_t nmb = (n + mb - 1) / mb;
+  std::vector<uint64_t> bound(nmb + 1);
+  for (uint32_t b = 0; b <= nmb; ++b) { uint32_t r = std::min<uint64_t>((uint64_t)b * mb, n); SQ_HIP_CHECK(hipMemcpyAsync(&bound[b], o->assigned_prefix.p + r, 8, hipMemcpyDeviceToHost, st)); }
+  unsigned long long hctr[8];
+  SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  const uint64_t assigned_base = hctr[0];
+  bool burned_host = hctr[1] != 0;
+  for (uint32_t b = 0; b < nmb; ++b) {
+    const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
+    const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
+    k_mini_batch<<<nblk(r1 - r0), TB, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, logFM, c->aln_off.p, c->aln.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p);
+    k_apply_mass<<<nblk(o->M), TB, 0, st>>>(V, logFM);
+    const uint64_t assigned_after = assigned_base + bound[b + 1];
+    k_apply_fld<<<1, 1024, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags);
+    if (!burned_host && assigned_after >= q.num_burnin_frags) {
+      k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
+      k_burnin_efflen<<<nblk(o->M), TB, 0, st>>>(V, 2);
+      k_burnin_done<<<1, 64, 0, st>>>(V);
+      burned_host = true;
+    }
+    o->batch_no++;
+  }
+  // eq-class table: insert labels, then add counts / fixed-point weights
+  EqView T = make_eq_view(o);
+  k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, c->aln.p, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
+  k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, o->abin.p, o->awq.p, o->rslot.p);
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  o->num_observed += n; o->num_mapped_ub += c->last_joint; c->reads_seen += n;
+  return check_eq_overflow(c);
+}
+
+extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
+  if (!c || !out) return SQ_ERR_ARG;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
+  out->num_observed = c->online->num_observed; out->num_assigned = hctr[0]; out->num_mapped_ub = c->online->num_mapped_ub; out->burned_in = hctr[1] != 0;
+  return SQ_OK;
+}
+
+// finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745): effective lengths from the observed FLD
+static int finish_efflen(sq_ctx* c) {
+  unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
+  if (hctr[1] != 0 || hctr[4] == 4) return SQ_OK;
+  OnlineView V = make_view(c);
+  k_burnin_tables<<<1, 64, 0, c->stream>>>(V, 1);
+  k_burnin_efflen<<<nblk(c->online->M), TB, 0, c->stream>>>(V, 3);
+  k_burnin_done<<<1, 64, 0, c->stream>>>(V);
+  SQ_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return SQ_OK;
+}
+
+extern "C" int sq_model_fetch(sq_ctx* c, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len) {
+  if (!c) return SQ_ERR_ARG;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  int rc = finish_efflen(c); if (rc) return rc;
+  sq_online_dev* o = c->online; size_t M = o->M;
+  if (log_mass) SQ_HIP_CHECK(hipMemcpy(log_mass, o->mass.p, M * 8, hipMemcpyDeviceToHost));
+  if (unique_count) SQ_HIP_CHECK(hipMemcpy(unique_count, o->uniq.p, M * 8, hipMemcpyDeviceToHost));
+  if (total_count) SQ_HIP_CHECK(hipMemcpy(total_count, o->total.p, M * 8, hipMemcpyDeviceToHost));
+  if (log_eff_len) SQ_HIP_CHECK(hipMemcpy(log_eff_len, o->log_eff_len.p, M * 8, hipMemcpyDeviceToHost));
+  return SQ_OK;
+}
+
+extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
+  if (!c || !out) return SQ_ERR_ARG;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_dev* o = c->online; unsigned long long hctr[8]; double scal[8]; std::vector<double> h(1024);
+  SQ_HIP_CHECK(hipMemcpy(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(scal, o->scal.p, sizeof(scal), hipMemcpyDeviceToHost));
+  if (hctr[3]) { SQ_HIP_CHECK(hipMemcpy(h.data(), o->cpmf.p, 1024 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i <= 1000; ++i) out[i] = h[i]; }
+  else { SQ_HIP_CHECK(hipMemcpy(h.data(), o->hist.p, 1024 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i <= 1000; ++i) out[i] = h[i] - scal[0]; }
+  return SQ_OK;
+}
+
+// export in canonical order (ascending (h1,h2)); sizes first when arrays are NULL
+extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
+  if (!c || !out) return SQ_ERR_ARG;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_dev* o = c->online;
+  unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
+  out->num_classes = cur[1]; out->num_labels = cur[0];
+  if (!out->off) return SQ_OK;
+  const uint64_t cap = o->tcap;
+  std::vector<unsigned long long> k1(cap), k2(cap), cnt(cap), pl(cap); std::vector<uint32_t> tn(cap);
+  SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, cap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, cap * 8, hipMemcpyDeviceToHost));
+  SQ_HIP_CHECK(hipMemcpy(cnt.data(), o->tcount.p, cap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pl.data(), o->tpool.p, cap * 8, hipMemcpyDeviceToHost));
+  SQ_HIP_CHECK(hipMemcpy(tn.data(), o->tn.p, cap * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> ptid(cur[0] + 1), pbin(cur[0] + 1); std::vector<unsigned long long> pwq(cur[0] + 1);
+  if (cur[0]) { SQ_HIP_CHECK(hipMemcpy(ptid.data(), o->pool_tid.p, cur[0] * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pbin.data(), o->pool_bin.p, cur[0] * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pwq.data(), o->pool_wq.p, cur[0] * 8, hipMemcpyDeviceToHost)); }
+  std::vector<uint64_t> slots; slots.reserve(cur[1]);
+  for (uint64_t s = 0; s < cap; ++s) if (k1[s] != EQ_EMPTY) slots.push_back(s);
+  std::sort(slots.begin(), slots.end(), [&](uint64_t a, uint64_t b) { return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
+  uint64_t p = 0;
+  for (size_t ci = 0; ci < slots.size(); ++ci) {
+    uint64_t s = slots[ci]; uint32_t n = tn[s]; uint64_t po = pl[s];
+    out->off[ci] = p; out->count[ci] = cnt[s]; if (out->h1) out->h1[ci] = k1[s]; if (out->h2) out->h2[ci] = k2[s];
+    double sum = 0.0; for (uint32_t i = 0; i < n; ++i) sum += sq_from_fixed(pwq[po + i], SQ_WFRAC_BITS);
+    double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
+    for (uint32_t i = 0; i < n; ++i) { out->tid[p + i] = ptid[po + i]; out->w[p + i] = sq_from_fixed(pwq[po + i], SQ_WFRAC_BITS) * norm; if (out->wq) out->wq[p + i] = pwq[po + i]; if (out->bins) out->bins[p + i] = pbin[po + i]; }
+    p += n;
+  }
+  out->off[slots.size()] = p;
+  return SQ_OK;
+}
+
+extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
+  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  const uint64_t E = t->num_classes, L = t->num_labels; if (E == 0) return SQ_OK;
+  sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins, d_slot;
+  if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L) || d_slot.ensure(E)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
+  hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice); hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d_h1.p, t->h1, E * 8, hipMemcpyHostToDevice); hipMemcpy(d_h2.p, t->h2, E * 8, hipMemcpyHostToDevice); hipMemcpy(d_tid.p, t->tid, L * 4, hipMemcpyHostToDevice);
+  if (t->bins) hipMemcpy(d_bins.p, t->bins, L * 4, hipMemcpyHostToDevice);
+  EqView T = make_eq_view(c->online);
+  k_eq_merge_insert<<<nblk(E), TB, 0, c->stream>>>(T, E, d_off.p, d_tid.p, t->bins ? d_bins.p : nullptr, d_h1.p, d_h2.p, d_slot.p);
+  k_eq_merge_add<<<nblk(E), TB, 0, c->stream>>>(T, E, d_off.p, d_wq.p, d_cnt.p, d_slot.p);
+  SQ_HIP_CHECK(hipStreamSynchronize(c->stream));
+  d_off.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_tid.free_(); d_bins.free_(); d_slot.free_();
+  return check_eq_overflow(c);
+}
+
+extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+  if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
+  return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
+}

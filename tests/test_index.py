@@ -1,0 +1,89 @@
+"""Index builder (cDBG + contig table + SSHash-style dictionary) against brute force (CPU only)."""
+import numpy as np
+import os, tarfile, tempfile
+import pytest
+from salmon_amd import api, synth, capi
+import orc
+
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def enc(s):
+    x = 0
+    for i, c in enumerate(s):
+        x |= CODE[c] << (2 * i)
+    return x
+
+
+def test_cdbg_invariants_and_dictionary_small(small_world):
+    idx = small_world["idx"]
+    assert orc.check_cdbg(idx) == 0          # tiles every reference, each k-mer once, unitigs maximal
+    oi = small_world["oidx"]
+    assert idx.num_kmers == orc.lib().orc_index_num_kmers(oi.h)
+    v = idx.view(); k = idx.k
+    U = idx.num_unitigs
+    useq = np.ctypeslib.as_array(v.useq, shape=((v.total_unitig_nt + 31) // 32 + 1,))
+    uoff = np.ctypeslib.as_array(v.uoff, shape=(U + 1,))
+    rng = np.random.default_rng(0)
+    for u in rng.choice(U, size=min(U, 400), replace=False):
+        b, e = int(uoff[u]), int(uoff[u + 1])
+        for p in range(b, e - k + 1, 3):
+            x = 0
+            for i in range(k):
+                x |= ((int(useq[(p + i) >> 5]) >> (((p + i) & 31) * 2)) & 3) << (2 * i)
+            assert idx.lookup_host(x) == (u, p - b, True)
+            assert oi.lookup(x) == (u, p - b, True)
+    # random (absent) k-mers agree with brute force too
+    for x in rng.integers(0, 1 << 62, 3000):
+        assert idx.lookup_host(int(x)) == oi.lookup(int(x))
+
+
+def test_reverse_complement_lookup(small_world):
+    idx = small_world["idx"]; tx = small_world["tx"]
+    s = tx.seqs()[0].decode(); k = idx.k
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for p in range(0, min(len(s) - k, 300), 11):
+        km = s[p:p + k]; rc = "".join(comp[c] for c in reversed(km))
+        a, b = idx.lookup_host(enc(km)), idx.lookup_host(enc(rc))
+        assert a is not None and b is not None
+        assert a[0] == b[0] and a[1] == b[1] and a[2] != b[2]
+
+
+def test_sample_data_index_roundtrip(built):
+    src = "/root/reference/sample_data.tgz"
+    if not os.path.exists(src):
+        pytest.skip("reference sample data not present on this box")
+    with tempfile.TemporaryDirectory() as d:
+        tarfile.open(src).extractall(d)
+        out = os.path.join(d, "idx")
+        api.SalmonIndex.build(os.path.join(d, "sample_data", "transcripts.fasta"), out, threads=2)
+        for f in ("index.bin", "info.json", "versionInfo.json", "duplicate_clusters.tsv"):
+            assert os.path.exists(os.path.join(out, f))
+        idx = api.SalmonIndex.load(out)
+        assert idx.num_refs == 15 and idx.k == 31 and idx.m == 20      # SURVEY.md §4 fixtures; m = min(20, max(4, k-4))
+        assert int(idx.ref_lens().sum()) <= 28562
+        assert orc.check_cdbg(idx) == 0
+        idx.free()
+
+
+def test_bad_arguments_and_missing_index(built, tmp_path):
+    with pytest.raises(capi.SalmonHipError):
+        api.SalmonIndex.load(str(tmp_path / "nope"))               # SalmonIndex.hpp:124-131 throws on missing versionInfo.json
+    fa = tmp_path / "t.fa"; fa.write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    with pytest.raises(capi.SalmonHipError):
+        api.SalmonIndex.build(str(fa), str(tmp_path / "i"), k=30)  # k must be odd (BuildSalmonIndex.cpp:204)
+    with pytest.raises(capi.SalmonHipError):
+        api.SalmonIndex.build(str(fa), str(tmp_path / "i"), k=33)  # k <= 31 (:207)
+
+
+def test_polya_clipping_duplicates_and_short_refs(built):
+    body = "ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGGGATATCGCGATTAGC" * 2
+    names = ["t1", "t2_dup", "t3_polyA", "t4_short"]
+    seqs = [body, body, body[:69] + "C" + "A" * 40, "ACGTACGTAC"]
+    idx = api.SalmonIndex.build_mem(names, seqs, threads=1)
+    assert idx.ref_names() == ["t1", "t3_polyA", "t4_short"]       # duplicate dropped (keepDuplicates=false)
+    assert list(idx.ref_lens()) == [100, 70, 10] and list(idx.ref_complete_lens()) == [100, 110, 10]
+    assert orc.check_cdbg(idx) == 0
+    idx2 = api.SalmonIndex.build_mem(names, seqs, threads=1, keep_duplicates=True, no_clip=True)
+    assert idx2.num_refs == 4 and list(idx2.ref_lens()) == [100, 100, 110, 10]
+    assert orc.check_cdbg(idx2) == 0

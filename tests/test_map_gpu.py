@@ -1,0 +1,150 @@
+"""GPU mapping pipeline vs the CPU checker, stage by stage and end to end (bit-exact; -m gpu)."""
+import numpy as np
+import pytest
+from salmon_amd import api, capi
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields_equal(a, b, fields, what):
+    assert len(a) == len(b), "%s: %d vs %d records" % (what, len(a), len(b))
+    for f in fields:
+        if not np.array_equal(a[f], b[f]):
+            i = int(np.nonzero(a[f] != b[f])[0][0])
+            raise AssertionError("%s: field %s differs first at %d: gpu=%s cpu=%s" % (what, f, i, a[i], b[i]))
+
+
+@pytest.fixture(scope="module")
+def gpu_world(small_world):
+    w = small_world
+    w["idx"].to_device(0)
+    opts = api.quant_opts()
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=8192)
+    rb = api.make_read_batch(w["seq"], w["off"], w["n"], paired=True)
+    return dict(w=w, opts=opts, ctx=ctx, rb=rb)
+
+
+def test_stages_match_checker(gpu_world):
+    g = gpu_world; w = g["w"]
+    ro, aln, mt, st = g["ctx"].map_batch(g["rb"])
+    um_c, mm_c, ch_c, cd_c = orc.map_taps(w["oidx"], g["opts"], g["rb"])
+    um_g = g["ctx"].tap(capi.lib and 1, api.UNIMEM_DTYPE)
+    _fields_equal(um_g, um_c, ["end", "qpos", "len", "unitig", "uoff", "fw"], "uni-MEMs")
+    mm_g = g["ctx"].tap(2, api.MEM_DTYPE)
+    _fields_equal(mm_g, mm_c, ["end", "tid", "rpos", "qpos", "len", "fw"], "MEMs")
+    ch_g = g["ctx"].tap(3, api.CHAIN_DTYPE)
+    _fields_equal(ch_g, ch_c, ["end", "tid", "pos", "last_end", "fw", "n_mems", "score"], "chains")
+    cd_g = g["ctx"].tap(4, api.CAND_DTYPE)
+    _fields_equal(cd_g, cd_c, ["frag", "tid", "lpos", "rpos", "lfw", "rfw", "mate_status", "valid", "lscore", "rscore", "frag_len"], "candidates")
+
+
+def test_alignments_and_stats_match_checker(gpu_world):
+    g = gpu_world; w = g["w"]
+    ro_g, aln_g, mt_g, st_g = g["ctx"].map_batch(g["rb"])
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], g["opts"], g["rb"], threads=4)
+    assert np.array_equal(ro_g, ro_c)
+    assert np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    assert st_g == st_c
+    assert st_g["num_mapped"] > 0.9 * w["n"] * 0.98
+
+
+def test_small_and_ragged_batches(gpu_world):
+    # empty batch, a single pair, reads shorter than k, reads with N, unequal lengths
+    g = gpu_world; w = g["w"]
+    rb0 = api.make_read_batch(np.zeros(1, np.uint8), np.zeros(1, np.uint64), 0, paired=True)
+    ro, aln, mt, st = g["ctx"].map_batch(rb0)
+    assert len(aln) == 0 and st["num_reads"] == 0
+    seqs = []
+    base = bytes(w["seq"][:200].tobytes())
+    r1, r2 = base[:100], base[100:200]
+    seqs += [r1, r2]                                   # ordinary pair
+    seqs += [r1[:20], r2[:25]]                         # both shorter than k
+    seqs += [r1[:60] + b"N" + r1[61:], r2]             # an N in the middle
+    seqs += [b"N" * 100, r2]                           # all-N mate -> orphan
+    seqs += [r1[:75], r2[:90]]                         # ragged lengths
+    seqs += [r1.lower(), r2]                           # lower case
+    seqs += [b"", r2]                                  # empty mate
+    seq = np.frombuffer(b"".join(seqs), np.uint8).copy()
+    off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(s) for s in seqs])
+    rb = api.make_read_batch(seq, off, len(seqs) // 2, paired=True)
+    ro_g, aln_g, mt_g, st_g = g["ctx"].map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], g["opts"], rb, threads=1)
+    assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c) and st_g == st_c
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    assert ro_g[1] - ro_g[0] >= 1 and ro_g[2] - ro_g[1] == 0
+
+
+@pytest.mark.parametrize("libtype", ["IU", "ISF", "ISR"])
+def test_library_types(small_world, libtype):
+    w = small_world
+    opts = api.set_libtype(api.quant_opts(), libtype)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=2048)
+    rb = api.make_read_batch(w["seq"], w["off"], 1500, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+    assert np.array_equal(ro_g, ro_c) and st_g == st_c
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.free()
+
+
+def test_single_end(small_world):
+    w = small_world
+    opts = api.set_libtype(api.quant_opts(), "U")
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    rb = api.make_read_batch(w["seq"], w["off"], 3000, paired=False)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+    assert np.array_equal(ro_g, ro_c) and st_g == st_c
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.free()
+
+
+def test_online_model_and_eq_classes_match_checker(small_world):
+    w = small_world
+    # small burn-in so the test crosses pre-burn-in -> aux params -> burned-in regimes
+    opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=2200)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ost = orc.OrcState(w["oidx"], opts)
+    for lo, hi in [(0, 1700), (1700, 4000)]:
+        seq = w["seq"][lo * 200: hi * 200]; off = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        rb = api.make_read_batch(seq, off, hi - lo, paired=True)
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+        ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+        ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+    ost.finish()
+    sg, sc = ctx.summary(), ost.summary()
+    assert sg == sc and sg["burned_in"]
+    lm_g, uq_g, tc_g, le_g = ctx.model()
+    lm_c, uq_c, tc_c, le_c, fld_c = ost.model()
+    assert np.array_equal(uq_g, uq_c) and np.array_equal(tc_g, tc_c)
+    assert np.array_equal(lm_g, lm_c), float(np.nanmax(np.abs(np.where(np.isinf(lm_c), 0, lm_g - lm_c))))
+    assert np.array_equal(le_g, le_c)
+    assert np.array_equal(ctx.fld(), fld_c)
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    assert int(eq_g.count.sum()) == sg["num_assigned"]
+    ctx.free(); ost.free()
+
+
+def test_eq_merge_is_exact_and_order_free(small_world):
+    # shard the reads over two contexts, merge the tables both ways: identical bits (multi-GPU reduction)
+    w = small_world
+    opts = api.quant_opts(num_burnin_frags=10**9, num_pre_burnin_frags=10**9)   # model-independent weights
+    def run(lo, hi):
+        ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+        seq = w["seq"][lo * 200: hi * 200]; off = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        ctx.map_batch(api.make_read_batch(seq, off, hi - lo, paired=True), fetch=False); ctx.eq_accumulate()
+        return ctx
+    a, b, full = run(0, 2000), run(2000, 4000), run(0, 4000)
+    ea, eb = a.eq_finish(), b.eq_finish()
+    a.eq_merge(eb); b.eq_merge(ea)
+    m1, m2, ef = a.eq_finish(), b.eq_finish(), full.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(m1, f), getattr(m2, f)), f
+        assert np.array_equal(getattr(m1, f), getattr(ef, f)), f
+    for c in (a, b, full):
+        c.free()
