@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py — `salmon quant` hot path (map + eq-classes + EM) on MI355X, BASELINE.json metric.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (sq_map_batch + sq_eq_accumulate) over one batch of synthetic
+read pairs already resident in HBM.  The default N=1 workload is BASELINE.json configs[1]: a
+human-transcriptome-shaped index (synthetic T200k: 20 000 genes x ~10 isoforms, k=31) and
+K x batch = 10 x 1 000 000 = 10 M synthetic 2x100 bp pairs, followed by the job's inference tail
+(eq-class export, normalizeAlphas, VBEM to convergence), all inside the timed region.  Weak scaling:
+every rank maps its own K batches; eq-class tables are all-gathered over RCCL and merged exactly.
+Prints ONE JSON line on rank 0.
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1000000, help="read pairs per step")
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--iso", type=int, default=10)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+# algorithmic bytes per unit for every stage (DESIGN.md §5 states the same table)
+def stage_bytes(st, n_pairs, read_len, paired=True):
+    nrec = 2 * n_pairs if paired else n_pairs
+    L = read_len
+    return {
+        "k_pack": nrec * (L + 8 + 64 + 32 + 2),
+        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 4 * 64 + st["num_seeds"] * (16 + 16 + 32),
+        "scan_mems": nrec * (4 + 8),
+        "k_project": st["num_seeds"] * (16 + 16) + st["num_mems"] * (8 + 16) + nrec * 14,
+        "radix_sort": st["num_mems"] * 32,
+        "k_chain": st["num_mems"] * (16 + 8 + 4 + 4 + 1) + st["num_chains"] * 40 + nrec * 20,
+        "k_join_count": st["num_chains"] * 40 + n_pairs * 21,
+        "scan_cands": n_pairs * 12,
+        "k_join_fill": st["num_chains"] * 40 + st["num_candidates"] * 52 + n_pairs * 16,
+        "k_score": st["num_candidates"] * (48 * 2 + 2 * 40 + 2 * (96 + 64) + 4) + st["num_mems"] * 0,
+        "k_dp": st["num_dp_alignments"] * (48 + 96 + 64),
+        "k_select": st["num_candidates"] * (48 * 2) + st["num_alignments"] * 40 + n_pairs * 30,
+        "compact_alns": st["num_alignments"] * 80 + n_pairs * 28,
+        "eq_flags_scan": st["num_alignments"] * 40 + n_pairs * 24,
+        "eq_mini_batches": st["num_alignments"] * (40 + 12 + 3 * 16) + n_pairs * 32,
+        "eq_table": st["num_alignments"] * (40 + 12 + 8) + n_pairs * (16 + 4 + 32),
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from salmon_amd import api, synth, capi
+    ncores = os.cpu_count() or 8
+    thr = max(4, ncores // max(1, world))
+    t_setup = time.time()
+    tx = synth.Txome(seed=1, n_genes=a.genes, iso_per_gene=a.iso, threads=min(thr, 32))
+    names, seqs, lens = tx.tables()
+    idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=thr)
+    t_index = time.time() - t_setup
+    idx.to_device(local)
+    B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len
+    opts = api.quant_opts()
+    ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
+    # synthetic reads: rank r, step s -> pairs [((r*(K+W))+s)*B, ...), generated on the host, parked in HBM
+    dev = torch.device("cuda", local)
+    off_np = (np.arange(0, 2 * B + 1, dtype=np.int64) * RL)
+    off_d = torch.from_numpy(off_np).to(dev)
+    batches = []
+    host_first = None
+    for s in range(W + K):
+        seq, off, tt, tp = tx.reads(B, read_len=RL, seed=2, first_pair=(rank * (K + W) + s) * B, threads=min(thr, 64), truth=False)
+        if s == W and rank == 0:
+            host_first = seq[: 2 * RL * min(B, a.cpu_sample)].copy() if a.cpu_sample > 0 else None
+        batches.append(torch.from_numpy(seq).to(dev))
+    torch.cuda.synchronize()
+    rbs = [api.make_read_batch(int(b.data_ptr()), int(off_d.data_ptr()), B, paired=True, on_device=True) for b in batches]
+    # ---- warmup (sizes every work buffer; model/eq state is reset afterwards) ----
+    for s in range(W):
+        ctx.map_batch(rbs[s], fetch=False); ctx.eq_accumulate()
+    if W:
+        e = ctx.eq_finish()
+        api.em_steps(e, idx.ref_lens().astype(np.float64), np.full(idx.num_refs, 100.0), 2, api.em_opts(), device=local)
+    ctx.reset()
+    ctx.set_profiling(not a.no_profile)
+    ctx.stage_times(reset=True)
+    eff_ref = idx.ref_lens().astype(np.float64)
+    # ---- timed region: exactly K steps + the job's inference tail ----
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot = None
+    for s in range(W, W + K):
+        _, _, _, st = ctx.map_batch(rbs[s], fetch=False)
+        ctx.eq_accumulate()
+        tot = st if tot is None else {k: tot[k] + v for k, v in st.items()}
+    t_map = time.perf_counter() - t0
+    eq = ctx.eq_finish()
+    lm, uq, tc, le = ctx.model()
+    if dist:  # one RCCL all-gather of the packed class tables, merged exactly (integer sums) on every rank
+        def gather_np(x, dtype):
+            t = torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)).to(dev)
+            n = torch.tensor([t.numel()], device=dev, dtype=torch.int64); ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n); mx = int(max(int(v) for v in ns))
+            pad = torch.zeros(mx, device=dev, dtype=t.dtype); pad[: t.numel()] = t
+            outs = [torch.zeros_like(pad) for _ in range(world)]; dist.all_gather(outs, pad)
+            return [o[: int(k)].cpu().numpy().view(dtype) for o, k in zip(outs, ns)]
+        parts = {f: gather_np(getattr(eq, f), getattr(eq, f).dtype) for f in ["off", "tid", "wq", "count", "bins", "h1", "h2"]}
+        for r in range(world):
+            if r == rank: continue
+            other = api.EqClasses(parts["off"][r], parts["tid"][r], np.zeros(len(parts["tid"][r])), parts["count"][r], parts["wq"][r], parts["bins"][r], parts["h1"][r], parts["h2"][r])
+            ctx.eq_merge(other)
+        eq = ctx.eq_finish()
+        tq = torch.from_numpy(np.stack([uq.astype(np.int64), tc.astype(np.int64)])).to(dev); dist.all_reduce(tq); uq, tc = tq[0].cpu().numpy().astype(np.uint64), tq[1].cpu().numpy().astype(np.uint64)
+        ml = torch.from_numpy(np.where(np.isinf(lm), 0.0, np.exp(lm - 0.0))).to(dev); dist.all_reduce(ml); mlc = ml.cpu().numpy(); lm = np.where(mlc > 0, np.log(np.maximum(mlc, 1e-300)), np.inf)
+        le_t = torch.from_numpy(le).to(dev); dist.broadcast(le_t, 0); le = le_t.cpu().numpy()
+    proj = api.normalize_alphas(eq, lm, uq, tc)
+    eff = np.exp(le)
+    alphas, rep = api.em_optimize(eq, eff, proj, api.em_opts(), device=local)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    if dist:
+        tt_ = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt_, op=dist.ReduceOp.MAX); dt = float(tt_.item())
+    stages = ctx.stage_times()
+    # EM iteration rate from a fixed-count run on the final table (outside the timed region)
+    _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)
+    if rank != 0:
+        return
+    E = len(eq.count); Lb = len(eq.tid); M = idx.num_refs
+    em_bytes = 36 * Lb + 16 * E + 64 * M
+    em_gbs = em_bytes / (rep_it["ms_per_iter"] * 1e-3) / 1e9
+    sb = stage_bytes(tot, K * B, RL)
+    stage_rows = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / max(1, v[1]), 4), "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
+    dom = max(stage_rows, key=lambda k: stage_rows[k]["ms_total"]) if stage_rows else None
+    roof = None
+    if dom:
+        ach = sb[dom] / (stage_rows[dom]["ms_total"] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
+                "avg_launch_ms": stage_rows[dom]["avg_ms"], "alg_bytes_per_launch": int(sb[dom] / max(1, stage_rows[dom]["launches"]))}
+    cpu = None
+    if a.cpu_sample > 0 and world == 1 and host_first is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        S = min(B, a.cpu_sample)
+        oidx = orc.OrcIndex(idx)
+        soff = (np.arange(0, 2 * S + 1, dtype=np.uint64) * np.uint64(RL))
+        rb = api.make_read_batch(host_first, soff, S, paired=True)
+        c0 = time.perf_counter()
+        ro, aln, mt, stc = orc.map_batch(oidx, opts, rb, threads=ncores)
+        c1 = time.perf_counter()
+        ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, stc["num_with_joint_hits"]); ost.finish(); eqc = ost.eq_finish()
+        lmc, uqc, tcc, lec, _ = ost.model()
+        pc = orc.normalize_alphas(M, eqc, lmc, uqc, tcc)
+        c2 = time.perf_counter()
+        _, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
+        c3 = time.perf_counter()
+        em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
+        cpu = {"value": round(S / (c3 - c0) / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
+               "sample": "%d of the %d pairs of step 0: CPU checker map (%d threads) %.2fs + online/eq (1 thread) %.2fs + VBEM %d iters (1 thread) %.2fs" % (S, B, ncores, c1 - c0, c2 - c1, repc["iters"], c3 - c2),
+               "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2)}
+    out = {
+        "metric": "M reads/s quantified (map+EM), 2x100bp vs human-shaped txome; EM iters/s", "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
+        "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K, B, K * B, RL),
+                   "transcripts": int(M), "txome_nt": int(tx.total_nt()), "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
+                   "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly; EM replicated" % world},
+        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "em_iters": rep["iters"], "em_converged": rep["converged"], "em_device_ms": round(rep["device_ms"], 2),
+                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4), "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
+                      "eq_classes": E, "label_entries": Lb, "stats": tot},
+        "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes, "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
+        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

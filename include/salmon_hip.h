@@ -158,6 +158,8 @@ typedef struct sq_ctx sq_ctx;
 int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads,
                   sq_ctx** out);
 void sq_ctx_free(sq_ctx*);
+/* Forget the online model and the eq-class table (fresh ReadExperiment), keeping work buffers. */
+int sq_ctx_reset(sq_ctx*);
 
 typedef struct {
   uint32_t n;              /* fragments (pairs or single reads) */
@@ -288,6 +290,15 @@ int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp,
 int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                     const double* alpha_in, uint32_t iters, double* alpha_out, sq_em_report* report);
 
+/* Host-side, once per run: salmon::utils::normalizeAlphas (src/util/SalmonUtils.cpp:461-529) with
+ * TranscriptCluster::projectToPolytope — online masses -> projectedCounts used to initialise EM. */
+int sq_normalize_alphas(uint32_t num_txp, const sq_eq_table* eq, const double* log_mass, const uint64_t* unique_count,
+                        const uint64_t* total_count, double* projected_out);
+/* B4 output files: quant.sf (GZipWriter.cpp:684-739; num_mapped_frags <= 0 -> explicit sum) and
+ * aux_info/eq_classes.txt.gz (GZipWriter.cpp:64-168). */
+int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags);
+int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights);
+
 typedef int (*sq_replicate_cb)(const double* alphas, uint32_t m, void* user);
 int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                      uint32_t num_bootstraps, uint64_t seed, uint64_t num_mapped,
@@ -303,6 +314,14 @@ typedef struct {
 int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* opts,
                  const double* alpha_init, uint32_t num_samples, uint64_t seed, uint64_t num_mapped,
                  sq_replicate_cb cb, void* user);
+
+/* Per-stage HIP-event timing of the mapping / eq pipeline (measurement).  When enabled,
+ * every stage kernel of sq_map_batch / sq_eq_accumulate is bracketed by hipEventRecord on the ctx
+ * stream; sq_ctx_stage_times returns accumulated milliseconds and launch counts per stage. */
+int sq_ctx_set_profiling(sq_ctx*, int on);
+int sq_ctx_num_stages(void);
+const char* sq_ctx_stage_name(int stage);
+int sq_ctx_stage_times(sq_ctx*, double* ms /*[num_stages]*/, uint64_t* calls /*[num_stages]*/, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Debug / parity taps: copy an intermediate stage of the LAST sq_map_batch to the host.

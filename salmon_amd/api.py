@@ -223,6 +223,18 @@ class QuantContext:
             lib().sq_debug_tap(self.h, what, buf.ctypes.data, int(n))
         return buf
 
+    def reset(self):
+        check(lib().sq_ctx_reset(self.h), "sq_ctx_reset")
+
+    def set_profiling(self, on=True):
+        check(lib().sq_ctx_set_profiling(self.h, int(on)), "sq_ctx_set_profiling")
+
+    def stage_times(self, reset=False):
+        n = lib().sq_ctx_num_stages()
+        ms = (C.c_double * n)(); calls = (C.c_uint64 * n)()
+        check(lib().sq_ctx_stage_times(self.h, ms, calls, int(reset)), "sq_ctx_stage_times")
+        return {lib().sq_ctx_stage_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
+
     def eq_accumulate(self):
         check(lib().sq_eq_accumulate(self.h), "sq_eq_accumulate")
 
@@ -290,3 +302,23 @@ def em_steps(eq, eff_len, alpha_in, iters, opts=None, device=0):
     rep = capi.EmReport()
     check(lib().sq_em_steps_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(a, C.c_double), iters, _ptr(out, C.c_double), C.byref(rep)), "sq_em_steps_dev")
     return out, dict(iters=rep.iters, device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+
+
+def normalize_alphas(eq, log_mass, uniq, total):
+    """salmon::utils::normalizeAlphas (host, once per run) -> projectedCounts."""
+    M = len(log_mass)
+    out = np.zeros(M)
+    t = eq.table()
+    lm = np.ascontiguousarray(log_mass, np.float64); uq = np.ascontiguousarray(uniq, np.uint64); tc = np.ascontiguousarray(total, np.uint64)
+    check(lib().sq_normalize_alphas(M, C.byref(t), _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(out, C.c_double)), "sq_normalize_alphas")
+    return out
+
+
+def write_quant_sf(path, index, eff_len, num_reads, num_mapped=0.0):
+    e = np.ascontiguousarray(eff_len, np.float64); r = np.ascontiguousarray(num_reads, np.float64)
+    check(lib().sq_write_quant_sf(path.encode(), index.h, _ptr(e, C.c_double), _ptr(r, C.c_double), float(num_mapped)), "sq_write_quant_sf")
+
+
+def write_eq_classes(path, index, eq, with_weights=False):
+    t = eq.table()
+    check(lib().sq_write_eq_classes(path.encode(), index.h, C.byref(t), int(with_weights)), "sq_write_eq_classes")

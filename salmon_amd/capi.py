@@ -135,7 +135,7 @@ def lib():
         "sq_index_device_bytes": (u64, [vp]), "sq_index_get_view": (C.c_int, [vp, P(IndexView)]),
         "sq_index_lookup_host": (C.c_int, [vp, u64, P(u64), P(u32), P(C.c_int)]),
         "sq_quant_opts_default": (None, [P(QuantOpts)]), "sq_em_opts_default": (None, [P(EmOpts)]),
-        "sq_ctx_create": (C.c_int, [vp, P(QuantOpts), C.c_int, u32, P(vp)]), "sq_ctx_free": (None, [vp]),
+        "sq_ctx_create": (C.c_int, [vp, P(QuantOpts), C.c_int, u32, P(vp)]), "sq_ctx_free": (None, [vp]), "sq_ctx_reset": (C.c_int, [vp]),
         "sq_map_batch": (C.c_int, [vp, P(ReadBatch), P(AlnBatch), P(MapStats)]),
         "sq_eq_accumulate": (C.c_int, [vp]), "sq_eq_finish": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge": (C.c_int, [vp, P(EqTable)]),
         "sq_model_summary_get": (C.c_int, [vp, P(ModelSummary)]),
@@ -146,6 +146,10 @@ def lib():
         "sq_bootstrap_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_debug_tap": (C.c_int64, [vp, C.c_int, vp, u64]),
+        "sq_normalize_alphas": (C.c_int, [u32, P(EqTable), P(f64), P(u64), P(u64), P(f64)]),
+        "sq_write_quant_sf": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64]), "sq_write_eq_classes": (C.c_int, [C.c_char_p, vp, P(EqTable), C.c_int]),
+        "sq_ctx_set_profiling": (C.c_int, [vp, C.c_int]), "sq_ctx_num_stages": (C.c_int, []), "sq_ctx_stage_name": (C.c_char_p, [C.c_int]),
+        "sq_ctx_stage_times": (C.c_int, [vp, P(f64), P(u64), C.c_int]),
     }
     missing = []
     for name, (res, args) in sig.items():

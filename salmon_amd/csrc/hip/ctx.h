@@ -74,7 +74,15 @@ struct sq_ctx {
   // online model + eq table
   sq_online_dev* online = nullptr; sq_eq_dev* eq = nullptr;
   uint64_t reads_seen = 0;
+  // stage profiling
+  bool prof_on = false; std::vector<hipEvent_t> prof_ev; std::vector<int> prof_stage; double stage_ms[32] = {0}; uint64_t stage_calls[32] = {0};
 };
+
+enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP, SG_SELECT, SG_COMPACT,
+       SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_NUM };
+void sq_prof_mark(sq_ctx* c, int stage);   // records an event: time since the previous mark is charged to `stage`
+void sq_prof_begin(sq_ctx* c);
+void sq_prof_end(sq_ctx* c);               // call after the stream has been synchronised
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };

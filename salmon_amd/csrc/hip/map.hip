@@ -33,6 +33,20 @@ void fill_params(sq_ctx* c) {
 }
 }  // namespace
 
+static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score", "k_dp", "k_select", "compact_alns",
+                                          "eq_flags_scan", "eq_mini_batches", "eq_table"};
+void sq_prof_begin(sq_ctx* c) { if (!c->prof_on) return; c->prof_stage.clear(); size_t need = 1; if (c->prof_ev.size() < need) { hipEvent_t e; hipEventCreate(&e); c->prof_ev.push_back(e); } hipEventRecord(c->prof_ev[0], c->stream); c->prof_stage.push_back(-1); }
+void sq_prof_mark(sq_ctx* c, int stage) { if (!c->prof_on) return; size_t i = c->prof_stage.size(); if (c->prof_ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); c->prof_ev.push_back(e); } hipEventRecord(c->prof_ev[i], c->stream); c->prof_stage.push_back(stage); }
+void sq_prof_end(sq_ctx* c) { if (!c->prof_on) return; for (size_t i = 1; i < c->prof_stage.size(); ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->prof_ev[i - 1], c->prof_ev[i]) == hipSuccess) { c->stage_ms[c->prof_stage[i]] += ms; c->stage_calls[c->prof_stage[i]]++; } } c->prof_stage.clear(); }
+extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) { if (!c) return SQ_ERR_ARG; c->prof_on = on != 0; return SQ_OK; }
+extern "C" int sq_ctx_num_stages(void) { return SG_NUM; }
+extern "C" const char* sq_ctx_stage_name(int s) { return (s >= 0 && s < SG_NUM) ? kStageNames[s] : nullptr; }
+extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int reset) {
+  if (!c) return SQ_ERR_ARG;
+  for (int i = 0; i < SG_NUM; ++i) { if (ms) ms[i] = c->stage_ms[i]; if (calls) calls[i] = c->stage_calls[i]; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
+  return SQ_OK;
+}
+
 extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx** out) {
   if (!idx || !opts || !out || max_batch_reads == 0) { sq_set_error("sq_ctx_create: bad arguments"); return SQ_ERR_ARG; }
   if (max_batch_reads > (1u << 23)) { sq_set_error("max_batch_reads %u exceeds 2^23 (sort key layout)", max_batch_reads); return SQ_ERR_ARG; }
@@ -91,11 +105,15 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
+  sq_prof_begin(c);
   k_pack<<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
+  sq_prof_mark(c, SG_PACK);
   k_seed<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p);
+  sq_prof_mark(c, SG_SEED);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
   uint64_t total_mems = 0;
+  sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_mems = total_mems;
@@ -105,6 +123,7 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
   if (total_mems) {
     k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, c->mkey.p, c->mval.p);
+    sq_prof_mark(c, SG_PROJECT);
     int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
     size_t tmp = 0;
     hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st);
@@ -112,13 +131,17 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
     tmp = c->sort_tmp.n;
     SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st));
     skey = c->mkey2.p; sval = c->mval2.p;
+    sq_prof_mark(c, SG_SORT);
   }
   k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p, c->n_chains.p, c->stats.p);
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
+  sq_prof_mark(c, SG_CHAIN);
   k_join<false><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, nullptr, nullptr, c->frag_flags.p);
+  sq_prof_mark(c, SG_JOIN_COUNT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_cand.p + n, 0, sizeof(uint32_t), st));
   rc = exclusive_scan_u32(c, c->n_cand.p, c->cand_off.p, n + 1); if (rc) return rc;
   uint64_t total_cands = 0;
+  sq_prof_mark(c, SG_SCAN_CANDS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_cands, c->cand_off.p + n, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_cands = total_cands;
@@ -133,26 +156,32 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   if (total_cands) {
     k_join<true><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->frag_flags.p);
     k_fill_cand_frag<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, cand_frag.p);
+    sq_prof_mark(c, SG_JOIN_FILL);
     for (int attempt = 0; attempt < 2; ++attempt) {
       SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
       k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p);
+      sq_prof_mark(c, SG_SCORE);
       SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
       if (hcount[0] <= S.dpq_cap) break;
       if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) { cand_frag.free_(); sq_set_error("DP queue overflow (%u regions)", hcount[0]); return SQ_ERR_OVERFLOW; }
       S.dpq = c->dpq.p; S.dpq_cap = (uint32_t)c->dpq.n;
     }
-    if (hcount[0]) k_dp<<<nblk(hcount[0]), 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
+    if (hcount[0]) k_dp<<<(hcount[0] + 63) / 64, 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
+    sq_prof_mark(c, SG_DP);
   }
   k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->cands.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p);
+  sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
   rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) { cand_frag.free_(); return rc; }
   k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off.p, c->n_aln.p, c->aln_slots.p, c->aln.p);
+  sq_prof_mark(c, SG_COMPACT);
   uint64_t total_aln = 0; unsigned long long hst[ST_N];
   SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off.p + n, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   cand_frag.free_();
+  sq_prof_end(c);
   c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true;
   if (stats) {
     memset(stats, 0, sizeof(*stats));

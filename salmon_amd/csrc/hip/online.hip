@@ -413,11 +413,13 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   const size_t A = (size_t)c->last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A)) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
+  sq_prof_begin(c);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, c->aln_off.p, c->aln.p, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
     if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
+  sq_prof_mark(c, SG_EQ_FLAGS);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
@@ -443,13 +445,24 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
     }
     o->batch_no++;
   }
+  sq_prof_mark(c, SG_EQ_MINIBATCH);
   // eq-class table: insert labels, then add counts / fixed-point weights
   EqView T = make_eq_view(o);
   k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, c->aln.p, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
   k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, o->abin.p, o->awq.p, o->rslot.p);
+  sq_prof_mark(c, SG_EQ_TABLE);
   SQ_HIP_CHECK(hipStreamSynchronize(st));
+  sq_prof_end(c);
   o->num_observed += n; o->num_mapped_ub += c->last_joint; c->reads_seen += n;
   return check_eq_overflow(c);
+}
+
+extern "C" int sq_ctx_reset(sq_ctx* c) {
+  if (!c) return SQ_ERR_ARG;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_free(c);
+  c->reads_seen = 0; c->have_batch = false;
+  return sq_online_create(c);
 }
 
 extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
