@@ -113,6 +113,7 @@ def main():
         tot = st if tot is None else {k: tot[k] + v for k, v in st.items()}
     t_map = time.perf_counter() - t0
     eq = ctx.eq_finish()
+    t_eqf = time.perf_counter() - t0 - t_map
     lm, uq, tc, le = ctx.model()
     if dist:  # one RCCL all-gather of the packed class tables, merged exactly (integer sums) on every rank
         def gather_np(x, dtype):
@@ -131,9 +132,13 @@ def main():
         tq = torch.from_numpy(np.stack([uq.astype(np.int64), tc.astype(np.int64)])).to(dev); dist.all_reduce(tq); uq, tc = tq[0].cpu().numpy().astype(np.uint64), tq[1].cpu().numpy().astype(np.uint64)
         ml = torch.from_numpy(np.where(np.isinf(lm), 0.0, np.exp(lm - 0.0))).to(dev); dist.all_reduce(ml); mlc = ml.cpu().numpy(); lm = np.where(mlc > 0, np.log(np.maximum(mlc, 1e-300)), np.inf)
         le_t = torch.from_numpy(le).to(dev); dist.broadcast(le_t, 0); le = le_t.cpu().numpy()
+    t_a = time.perf_counter()
     proj = api.normalize_alphas(eq, lm, uq, tc)
+    t_norm = time.perf_counter() - t_a
     eff = np.exp(le)
+    t_a = time.perf_counter()
     alphas, rep = api.em_optimize(eq, eff, proj, api.em_opts(), device=local)
+    t_em = time.perf_counter() - t_a
     torch.cuda.synchronize()
     if dist: dist.barrier()
     t1 = time.perf_counter()
@@ -184,7 +189,7 @@ def main():
         "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K, B, K * B, RL),
                    "transcripts": int(M), "txome_nt": int(tx.total_nt()), "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
                    "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly; EM replicated" % world},
-        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "em_iters": rep["iters"], "em_converged": rep["converged"], "em_device_ms": round(rep["device_ms"], 2),
+        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4), "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"], "em_device_ms": round(rep["device_ms"], 2),
                       "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4), "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes, "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},

@@ -772,17 +772,24 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
     for (uint64_t i = a; i < b; ++i) { double th = theta[P.tid[i]]; if (!o->use_vbem || th > 0.0) denom += th * P.cw[i]; }
     invDenom[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : (double)P.count[c] / denom;
   }
-  for (uint32_t t = 0; t < M; ++t) {
-    double acc = 0.0; double th = theta[t];
+  std::vector<double> v, w;
+  for (uint32_t t = 0; t < M; ++t) {  // SPEC §D4: blocked-64 sums over the transcript's incidences (class order)
+    const double th = theta[t];
+    v.clear();
     for (uint64_t d = P.t_off[t]; d < P.t_off[t + 1]; ++d) {
-      uint64_t c = P.t_cls[d];
-      if (P.off[c + 1] - P.off[c] == 1) { acc += (double)P.count[c]; continue; }
-      if (invDenom[c] == 0.0) continue;
-      if (o->use_vbem && !(th > 0.0)) continue;
-      double v = th * P.cw[P.t_pos[d]];
-      acc += v * invDenom[c];
+      uint64_t c = P.t_cls[d]; double term = 0.0;
+      if (P.off[c + 1] - P.off[c] == 1) term = (double)P.count[c];
+      else if (invDenom[c] != 0.0 && !(o->use_vbem && !(th > 0.0))) { double x = th * P.cw[P.t_pos[d]]; term = x * invDenom[c]; }
+      v.push_back(term);
     }
-    alphaOut[t] = acc;
+    if (v.empty()) { alphaOut[t] = 0.0; continue; }
+    for (;;) {
+      w.clear();
+      for (size_t i = 0; i < v.size(); i += 64) { double acc = 0.0; for (size_t j = i; j < std::min(v.size(), i + 64); ++j) acc += v[j]; w.push_back(acc); }
+      v.swap(w);
+      if (v.size() == 1) break;
+    }
+    alphaOut[t] = v[0];
   }
 }
 

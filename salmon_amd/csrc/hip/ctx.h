@@ -38,12 +38,15 @@ struct sq_map_params {
 template <class T>
 struct sq_dbuf {
   T* p = nullptr; size_t n = 0;
+  // grow-only with 25 % headroom: per-batch totals (MEMs, candidates) drift by a few percent, and a
+  // hipFree + hipMalloc of a multi-GB buffer inside the hot loop costs milliseconds
   int ensure(size_t want) {
     if (want <= n && p) return 0;
     if (p) (void)hipFree(p);
     p = nullptr; n = 0;
-    if (hipMalloc((void**)&p, (want ? want : 1) * sizeof(T)) != hipSuccess) return -1;
-    n = want; return 0;
+    size_t cap = want + want / 4 + 64;
+    if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) { cap = want ? want : 1; if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) return -1; }
+    n = cap; return 0;
   }
   void free_() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
@@ -65,6 +68,7 @@ struct sq_ctx {
   sq_dbuf<sq_chain_dev> chains; sq_dbuf<uint32_t> n_chains;
   // candidates / alignments
   sq_dbuf<uint32_t> n_cand; sq_dbuf<uint64_t> cand_off; sq_dbuf<sq_cand_dev> cands; uint64_t cand_cap = 0;
+  sq_dbuf<uint32_t> cand_frag, tid_arr; sq_dbuf<int32_t> hs_arr;
   sq_dbuf<sq_dp_item> dpq; sq_dbuf<uint32_t> counters; sq_dbuf<uint8_t> frag_flags;
   sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;

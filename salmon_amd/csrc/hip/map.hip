@@ -78,7 +78,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   sq_online_free(c);
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
   c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->chains.free_(); c->n_chains.free_();
-  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_();
+  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -106,7 +106,7 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
   sq_prof_begin(c);
-  k_pack<<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
+  k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
   sq_prof_mark(c, SG_PACK);
   k_seed<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p);
   sq_prof_mark(c, SG_SEED);
@@ -149,7 +149,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   // cand_frag shares the mused... no: dedicated buffer (u32 per candidate) carved from cp (int32 per MEM) is not safe; allocate
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
   if (c->cands.ensure(CP) || c->aln_slots.ensure(CP) || c->aln.ensure(CP) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
-  sq_dbuf<uint32_t> cand_frag; if (cand_frag.ensure(CP)) { sq_set_error("device allocation failed (cand_frag)"); return SQ_ERR_NOMEM; }
+  sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
+  if (cand_frag.ensure(CP) || hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
   ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
   S.mkey = skey; S.mval = sval; S.mnext = c->mnext.p; S.dpq = c->dpq.p; S.counters = c->counters.p; S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
   uint32_t hcount[2] = {0, 0};
@@ -164,23 +165,23 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
       SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
       if (hcount[0] <= S.dpq_cap) break;
-      if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) { cand_frag.free_(); sq_set_error("DP queue overflow (%u regions)", hcount[0]); return SQ_ERR_OVERFLOW; }
+      if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) { sq_set_error("DP queue overflow (%u regions)", hcount[0]); return SQ_ERR_OVERFLOW; }
       S.dpq = c->dpq.p; S.dpq_cap = (uint32_t)c->dpq.n;
     }
     if (hcount[0]) k_dp<<<(hcount[0] + 63) / 64, 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
     sq_prof_mark(c, SG_DP);
   }
-  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->cands.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p);
+  if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p, tid_arr.p);
+  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p);
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
-  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) { cand_frag.free_(); return rc; }
+  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) return rc;
   k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off.p, c->n_aln.p, c->aln_slots.p, c->aln.p);
   sq_prof_mark(c, SG_COMPACT);
   uint64_t total_aln = 0; unsigned long long hst[ST_N];
   SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off.p + n, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
-  cand_frag.free_();
   sq_prof_end(c);
   c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true;
   if (stats) {

@@ -16,6 +16,14 @@ namespace sqk {
 
 struct ReadView { const uint64_t* w; const uint64_t* nm; int L; };
 
+// Same-address atomics serialise at ~4-12 ns each on gfx950 (one per THREAD turned a 1M-thread kernel
+// into 12 ms of atomic traffic).  Counters are therefore summed across the wave first; ALL 64 lanes
+// must call this (kernels keep out-of-range lanes alive with a zero contribution).
+__device__ inline void wave_stat_add(unsigned long long* p, unsigned long long v) {
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_down(v, s, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
+}
+
 __device__ inline uint64_t fetch_bits(const uint64_t* m, uint32_t p, uint32_t n) {  // n <= 32 one-bit flags from p
   uint32_t w = p >> 6, sh = p & 63;
   uint64_t lo = m[w] >> sh;
@@ -36,25 +44,30 @@ __device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnma
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8 threads per record, 32 bases each: adjacent lanes read adjacent 32-byte runs (coalesced)
 __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
                        uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t e = (uint32_t)(gid >> 3), wi = (uint32_t)(gid & 7);
   if (e >= nrec) return;
   uint64_t a = seq_off[e], b = seq_off[e + 1];
   uint32_t L = (uint32_t)(b - a); if (L > SQ_MAX_READ_LEN) L = SQ_MAX_READ_LEN;
-  const uint8_t* s = seq + a;
-  uint64_t* w = rpack + (size_t)e * SQ_READ_WORDS; uint64_t* nm = rnmask + (size_t)e * SQ_NMASK_WORDS;
-  uint64_t cw = 0, cn = 0;
-  for (uint32_t i = 0; i < SQ_MAX_READ_LEN; ++i) {
-    if (i < L) {
-      uint32_t c; uint8_t ch = s[i];
-      switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 4; }
-      if (c > 3) cn |= 1ULL << (i & 63); else cw |= (uint64_t)c << ((i & 31) * 2);
-    }
-    if ((i & 31) == 31) { w[i >> 5] = cw; cw = 0; }
-    if ((i & 63) == 63) { nm[i >> 6] = cn; cn = 0; }
-  }
-  rlen[e] = (uint16_t)L;
+  const uint8_t* s = seq + a + 32 * wi;
+  uint64_t cw = 0; uint32_t cn = 0;
+  const uint32_t lo = 32 * wi; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);
+  auto put = [&](uint32_t i, uint8_t ch) {
+    uint32_t c;
+    switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 4; }
+    if (c > 3) cn |= 1u << i; else cw |= (uint64_t)c << (i * 2);
+  };
+  if (cnt == 32 && (((uintptr_t)s) & 3) == 0) {
+    const uint32_t* s4 = (const uint32_t*)s;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) { uint32_t v = s4[q]; put(4 * q, (uint8_t)v); put(4 * q + 1, (uint8_t)(v >> 8)); put(4 * q + 2, (uint8_t)(v >> 16)); put(4 * q + 3, (uint8_t)(v >> 24)); }
+  } else for (uint32_t i = 0; i < cnt; ++i) put(i, s[i]);
+  rpack[(size_t)e * SQ_READ_WORDS + wi] = cw;
+  ((uint32_t*)(rnmask + (size_t)e * SQ_NMASK_WORDS))[wi] = cn;
+  if (wi == 0) rlen[e] = (uint16_t)L;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -63,11 +76,11 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nends) return;
-  ReadView r = read_view(rpack, rnmask, rlen, e);
-  const int k = (int)P.k, L = r.L;
+  const bool act = e < nends;
+  ReadView r = read_view(rpack, rnmask, rlen, act ? e : 0);
+  const int k = (int)P.k, L = act ? r.L : 0;
   uint32_t nu = 0, np = 0, nlook = 0;
-  sq_unimem_dev* out = um + (size_t)e * SQ_MAX_UNIMEMS;
+  sq_unimem_dev* out = um + (size_t)(act ? e : 0) * SQ_MAX_UNIMEMS;
   if (L >= k) {
     int pos = 0, skip_until = -1; const int alt = (int)P.alt_skip;
     while (pos + k <= L && nu < SQ_MAX_UNIMEMS) {
@@ -110,8 +123,8 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
       skip_until = uend ? -1 : ee + 1;
     }
   }
-  n_uni[e] = nu; n_proj[e] = np;
-  atomicAdd(&stats[ST_SEEDS], (unsigned long long)nu); atomicAdd(&stats[ST_LOOKUPS], (unsigned long long)nlook);
+  if (act) { n_uni[e] = nu; n_proj[e] = np; }
+  wave_stat_add(&stats[ST_SEEDS], nu); wave_stat_add(&stats[ST_LOOKUPS], nlook);
 }
 
 // val layout: len[0,10) q[10,20) fw[20] tid[32,64)
@@ -153,9 +166,9 @@ __global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
                         double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
                         sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nends) return;
-  const uint64_t base = mem_off[e]; const uint32_t n = (uint32_t)(mem_off[e + 1] - base);
-  const int L = rlen[e];
+  const bool act = e < nends;
+  const uint64_t base = act ? mem_off[e] : 0; const uint32_t n = act ? (uint32_t)(mem_off[e + 1] - base) : 0;
+  const int L = act ? rlen[e] : 0;
   uint32_t nch = 0; double bestAll = 0.0;
   uint32_t g0 = 0;
   while (g0 < n) {
@@ -203,8 +216,8 @@ __global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
   const double cthr = P.consensus_frac * bestAll;
   uint32_t kept = 0;
   for (uint32_t i = 0; i < nch; ++i) { sq_chain_dev c = chains[base + i]; if (c.score < cthr) continue; chains[base + kept++] = c; }
-  n_chains[e] = kept;
-  atomicAdd(&stats[ST_MEMS], (unsigned long long)n); atomicAdd(&stats[ST_CHAINS], (unsigned long long)kept);
+  if (act) n_chains[e] = kept;
+  wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept);
 }
 
 // a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.
@@ -293,10 +306,28 @@ struct ScoreCtx {
   sq_dp_item* dpq; uint32_t* counters; uint32_t dpq_cap;
 };
 
-// mismatch count of q[0..n) vs t[0..n) with direction-aware accessors
+// mismatch count of q[0..n) vs t[0..n).  A mismatch count does not depend on the order in which the
+// aligned pairs are visited, so reversed (leftward) regions are compared as forward windows; the
+// strand-normalised read window comes from one revcomp of the packed read.  32 bases per step.
 __device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir, const uint64_t* refseq, int64_t tstart, int tdir, int n) {
+  const int qlo = qdir > 0 ? qstart : qstart - n + 1;
+  const int64_t tlo = tdir > 0 ? tstart : tstart - n + 1;
   int mm = 0;
-  for (int i = 0; i < n; ++i) { uint32_t qb = norm_base(r, fw, qstart + qdir * i); uint32_t tb = sq_fetch_base(refseq, (uint64_t)(tstart + (int64_t)tdir * i)); mm += !(qb == tb && qb < 4); }
+  for (int j = 0; j < n; j += 32) {
+    const int c = (n - j) < 32 ? (n - j) : 32;
+    uint64_t q, nn;
+    if (fw) { q = sq_fetch_bases(r.w, (uint64_t)(qlo + j), (uint32_t)c); nn = fetch_bits(r.nm, (uint32_t)(qlo + j), (uint32_t)c); }
+    else {
+      const int p = r.L - (qlo + j + c);   // read window whose reverse complement is R[qlo+j .. qlo+j+c)
+      q = sq_revcomp(sq_fetch_bases(r.w, (uint64_t)p, (uint32_t)c), (uint32_t)c);
+      nn = __brevll(fetch_bits(r.nm, (uint32_t)p, (uint32_t)c)) >> (64 - c);
+    }
+    const uint64_t t = sq_fetch_bases(refseq, (uint64_t)(tlo + j), (uint32_t)c);
+    const uint64_t x = q ^ t; uint64_t d = (x | (x >> 1)) & 0x5555555555555555ULL;
+    // spread the N flags to even bit positions and OR them in
+    uint64_t ns = nn; ns = (ns | (ns << 16)) & 0x0000FFFF0000FFFFULL; ns = (ns | (ns << 8)) & 0x00FF00FF00FF00FFULL; ns = (ns | (ns << 4)) & 0x0F0F0F0F0F0F0F0FULL; ns = (ns | (ns << 2)) & 0x3333333333333333ULL; ns = (ns | (ns << 1)) & 0x5555555555555555ULL;
+    mm += __popcll(d | ns);
+  }
   return mm;
 }
 
@@ -456,76 +487,85 @@ __device__ inline uint8_t hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t 
   return f1 ? fmt_id(1, 0, 2) : fmt_id(1, 0, 3);
 }
 
-__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, sq_cand_dev* __restrict__ cands, const sq_chain_dev* __restrict__ chains,
+// thread per candidate: validity against minScoreFraction and the hit score, written as two compact
+// arrays (SoA) so the per-fragment selection below streams 8 bytes per candidate instead of 48
+__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, const uint16_t* __restrict__ rlen,
+                           int32_t* __restrict__ hs_out, uint32_t* __restrict__ tid_out) {
+  uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= ncand) return;
+  sq_cand_dev c = cands[ci];
+  tid_out[ci] = c.tid;
+  if (c.lfail == 2) { hs_out[ci] = SQ_INVALID_SCORE; return; }   // incompatible, skipped before alignment (not counted as filtered)
+  const uint32_t f = cand_frag[ci]; const uint32_t e0 = paired ? 2 * f : f;
+  const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
+  const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
+  int32_t ls = SQ_INVALID_SCORE, rs = SQ_INVALID_SCORE;
+  if (hasL) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1)); ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore; }
+  if (hasR) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2)); rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore; }
+  const bool ok = (hasL && hasR) ? (ls != SQ_INVALID_SCORE && rs != SQ_INVALID_SCORE) : ((hasL ? ls : rs) != SQ_INVALID_SCORE);
+  c.lscore = ls; c.rscore = rs; c.valid = ok;
+  cands[ci] = c;
+  // INVALID_SCORE + 1 marks "scored but invalid" (counts as a filtered mapping); valid hits carry their score
+  hs_out[ci] = ok ? ((hasL && hasR) ? ls + rs : (hasL ? ls : rs)) : (SQ_INVALID_SCORE + 1);
+}
+
+__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
+                         const uint32_t* __restrict__ tid_arr, const sq_chain_dev* __restrict__ chains,
                          const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln, uint8_t* __restrict__ map_type,
                          unsigned long long* __restrict__ stats) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nfrag) return;
-  const uint64_t c0 = cand_off[f]; const uint32_t nc = (uint32_t)(cand_off[f + 1] - c0);
-  sq_cand_dev* C = cands + c0;
-  const uint32_t e0 = paired ? 2 * f : f;
+  const bool act = f < nfrag;
+  const uint64_t c0 = act ? cand_off[f] : 0; const uint32_t nc = act ? (uint32_t)(cand_off[f + 1] - c0) : 0;
+  const sq_cand_dev* C = cands + c0; const int32_t* HS = hs_arr + c0; const uint32_t* TID = tid_arr + c0;
+  const uint32_t e0 = act ? (paired ? 2 * f : f) : 0;
   const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
   uint32_t nfilt = 0;
   int32_t bestDecoy = SQ_INVALID_SCORE, bestScore = SQ_INVALID_SCORE;
-  // finalise scores (validity against minScoreFraction) — hitScore stored in lscore for orphans/singles, sum kept implicit
-  for (uint32_t i = 0; i < nc; ++i) {
-    sq_cand_dev c = C[i];
-    if (c.lfail == 2) continue;  // incompatible, skipped before alignment
-    const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
-    int32_t ls = SQ_INVALID_SCORE, rs = SQ_INVALID_SCORE;
-    if (hasL) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1)); ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore; }
-    if (hasR) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2)); rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore; }
-    c.lscore = ls; c.rscore = rs;
-    bool ok = (hasL && hasR) ? (ls != SQ_INVALID_SCORE && rs != SQ_INVALID_SCORE) : ((hasL ? ls : rs) != SQ_INVALID_SCORE);
-    c.valid = ok;
-    if (!ok) ++nfilt;
-    C[i] = c;
-    if (ok && c.tid >= P.first_decoy) { int32_t hs = (hasL && hasR) ? ls + rs : (hasL ? ls : rs); if (hs > bestDecoy) bestDecoy = hs; }
-  }
-  auto hit_score = [&](const sq_cand_dev& c) -> int32_t { const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu; return (hasL && hasR) ? c.lscore + c.rscore : (hasL ? c.lscore : c.rscore); };
   auto decoy_cut = [&](int32_t bd) -> int32_t { return (int32_t)(P.decoy_threshold * (double)bd); };
-  // order-dependent part of updateRefMappings: a non-decoy hit is recorded only if it reaches the
-  // best decoy score seen *so far* (SPEC §a7); `compat` doubles as the "recorded" flag from here on
+  // pass 1 (updateRefMappings, SalmonMappingUtils.hpp:225-281): decoys raise the running cut-off; a
+  // non-decoy hit is "recorded" only if it reaches the best decoy score seen so far (SPEC §a7)
   {
     int32_t runDecoy = SQ_INVALID_SCORE;
     for (uint32_t i = 0; i < nc; ++i) {
-      sq_cand_dev& c = C[i];
-      bool rec = false;
-      if (c.valid) {
-        int32_t hs = hit_score(c);
-        if (c.tid >= P.first_decoy) { if (hs > runDecoy) runDecoy = hs; }
-        else if (hs >= decoy_cut(runDecoy)) { rec = true; if (hs > bestScore) bestScore = hs; }
-      }
-      c.pad[0] = rec ? 1 : 0;
+      const int32_t hs = HS[i];
+      if (hs == SQ_INVALID_SCORE) continue;
+      if (hs == SQ_INVALID_SCORE + 1) { ++nfilt; continue; }
+      if (TID[i] >= P.first_decoy) { if (hs > runDecoy) runDecoy = hs; if (hs > bestDecoy) bestDecoy = hs; }
+      else if (hs >= decoy_cut(runDecoy)) { if (hs > bestScore) bestScore = hs; }
     }
   }
   const bool onlyDecoy = (bestScore < decoy_cut(bestDecoy)) && (bestDecoy > SQ_INVALID_SCORE);
-  uint32_t na = 0; uint8_t mt = SQ_MT_UNMAPPED;
+  uint32_t na = 0; uint8_t mt = SQ_MT_UNMAPPED; uint32_t ffilt = 0, fdecoy = 0;
   sq_aln* out = aln_slots + c0;
   if (bestScore > SQ_INVALID_SCORE && !onlyDecoy) {
     const int32_t bd = (bestDecoy == SQ_INVALID_SCORE) ? SQ_INVALID_SCORE + 1 : bestDecoy;
     const int32_t thr = P.hard_filter ? bestScore : decoy_cut(bd);
-    // winners: per transcript the best recorded hit, ties -> the later compatible hit (all recorded hits are compatible
-    // when ignore_incompat; otherwise the reference prefers compatible on ties)
-    for (uint32_t i = 0; i < nc; ++i) {
-      const sq_cand_dev& c = C[i];
-      if (!c.pad[0]) continue;
-      const int32_t hs = hit_score(c);
-      bool win = true;
-      // replay of the sequential per-transcript rule: candidate i wins iff no later recorded hit j displaces it and it displaced all earlier ones
+    // winners: per transcript the best recorded hit (ties -> the later compatible hit).  Candidates come
+    // as one tid-sorted run (pairs / single-end) or two tid-sorted runs (left orphans, then right
+    // orphans); a two-pointer merge visits every transcript once, in ascending tid, in index order.
+    // "recorded" is re-derived on the fly: replaying the running decoy cut-off needs index order, so
+    // the prefix maximum of decoy scores is recomputed per run position.
+    uint32_t split = nc;
+    if (nc && C[0].mate_status != SQ_MS_PAIRED_END_PAIRED && paired) { split = 0; while (split < nc && C[split].lc != 0xFFFFFFFFu) ++split; }
+    // running decoy maxima at the start of the second run (the first run starts from INVALID)
+    int32_t runA = SQ_INVALID_SCORE, runB = SQ_INVALID_SCORE;
+    for (uint32_t i = 0; i < split && split < nc; ++i) { const int32_t hs = HS[i]; if (hs > SQ_INVALID_SCORE + 1 && TID[i] >= P.first_decoy && hs > runB) runB = hs; }
+    uint32_t ia = 0, ib = split;
+    while (ia < split || ib < nc) {
+      const uint32_t ta = ia < split ? TID[ia] : 0xFFFFFFFFu, tb = ib < nc ? TID[ib] : 0xFFFFFFFFu;
+      const uint32_t t = ta < tb ? ta : tb;
       int32_t cur = SQ_INVALID_SCORE; int curi = -1;
-      for (uint32_t j = 0; j < nc; ++j) {
-        const sq_cand_dev& d = C[j];
-        if (!d.pad[0] || d.tid != c.tid) continue;
-        int32_t ds = hit_score(d);
-        if (curi < 0 || ds > cur || (ds == cur && d.compat)) { cur = ds; curi = (int)j; }
-      }
-      win = (curi == (int)i);
-      if (!win || hs < thr) continue;
+      while (ia < split && TID[ia] == t) { const int32_t ds = HS[ia];
+        if (ds > SQ_INVALID_SCORE + 1) { if (t >= P.first_decoy) { if (ds > runA) runA = ds; } else if (ds >= decoy_cut(runA)) { if (curi < 0 || ds > cur || (ds == cur && C[ia].compat)) { cur = ds; curi = (int)ia; } } }
+        ++ia; }
+      while (ib < nc && TID[ib] == t) { const int32_t ds = HS[ib];
+        if (ds > SQ_INVALID_SCORE + 1) { if (t >= P.first_decoy) { if (ds > runB) runB = ds; } else if (ds >= decoy_cut(runB)) { if (curi < 0 || ds > cur || (ds == cur && C[ib].compat)) { cur = ds; curi = (int)ib; } } }
+        ++ib; }
+      if (curi < 0 || cur < thr) continue;
+      const sq_cand_dev c = C[curi]; const int32_t hs = cur;
       double v = (double)bestScore - (double)hs;
       double p = P.hard_filter ? -1.0 : sq_exp(-P.score_exp * v);
       if (!P.hard_filter && p < P.min_aln_prob) continue;
-      // rank by tid among emitted: insertion keeps ascending tid (stable on equal tid cannot happen: one winner per tid)
       sq_aln a; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
         const sq_chain_dev& l = chains[c.lc]; const sq_chain_dev& rr = chains[c.rc];
@@ -538,22 +578,22 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
         a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
         a.format_id = a.fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3);
       }
-      uint32_t ins = na; while (ins > 0 && out[ins - 1].tid > a.tid) { out[ins] = out[ins - 1]; --ins; }
-      out[ins] = a; ++na;
+      out[na++] = a;
     }
     if (na) {
       switch (out[0].mate_status) { case SQ_MS_PAIRED_END_PAIRED: mt = SQ_MT_PAIRED_MAPPED; break; case SQ_MS_PAIRED_END_LEFT: mt = SQ_MT_LEFT_ORPHAN; break; case SQ_MS_PAIRED_END_RIGHT: mt = SQ_MT_RIGHT_ORPHAN; break; default: mt = SQ_MT_SINGLE_MAPPED; }
     }
   } else if (nc) {
     mt = onlyDecoy ? SQ_MT_DECOY : SQ_MT_UNMAPPED;
-    atomicAdd(&stats[ST_FRAGFILT], 1ULL); if (onlyDecoy) atomicAdd(&stats[ST_DECOY], 1ULL);
+    ffilt = 1; fdecoy = onlyDecoy ? 1 : 0;
   }
-  n_aln[f] = na; map_type[f] = mt;
-  atomicAdd(&stats[ST_MAPFILT], (unsigned long long)nfilt);
-  atomicAdd(&stats[ST_ALNS], (unsigned long long)na);
-  if (na) atomicAdd(&stats[ST_MAPPED], 1ULL);
-  if (nc) atomicAdd(&stats[ST_JOINT], 1ULL);
-  if (!nc && (frag_flags[f] & 1)) atomicAdd(&stats[ST_DOVETAIL], 1ULL);
+  if (act) { n_aln[f] = na; map_type[f] = mt; }
+  wave_stat_add(&stats[ST_FRAGFILT], ffilt); wave_stat_add(&stats[ST_DECOY], fdecoy);
+  wave_stat_add(&stats[ST_MAPFILT], nfilt);
+  wave_stat_add(&stats[ST_ALNS], na);
+  wave_stat_add(&stats[ST_MAPPED], na ? 1 : 0);
+  wave_stat_add(&stats[ST_JOINT], nc ? 1 : 0);
+  wave_stat_add(&stats[ST_DOVETAIL], (act && !nc && (frag_flags[f] & 1)) ? 1 : 0);
 }
 
 __global__ void k_fill_cand_frag(uint32_t nfrag, const uint64_t* __restrict__ cand_off, uint32_t* __restrict__ cand_frag) {
@@ -572,9 +612,9 @@ __global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand
 
 __global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nfrag) return;
-  bool any = paired ? (n_chains[2 * f] || n_chains[2 * f + 1]) : (n_chains[f] != 0);
-  if (any) atomicAdd(&stats[ST_KMER], 1ULL);
+  bool any = false;
+  if (f < nfrag) any = paired ? (n_chains[2 * f] || n_chains[2 * f + 1]) : (n_chains[f] != 0);
+  wave_stat_add(&stats[ST_KMER], any ? 1 : 0);
 }
 
 }  // namespace sqk

@@ -20,10 +20,10 @@
 struct sq_online_dev {
   uint32_t M = 0;
   // model
-  sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac; sq_dbuf<double> scal;  // scal[0]=totMass
+  sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
   sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize
   // per big batch
-  sq_dbuf<uint8_t> has_compat; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
+  sq_dbuf<uint8_t> has_compat; struct PreAln; sq_dbuf<uint8_t> pre; sq_dbuf<double> alp; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
   // eq table
   uint64_t tcap = 0; sq_dbuf<unsigned long long> tk1, tk2, tcount, tpool; sq_dbuf<uint32_t> tn; sq_dbuf<uint32_t> pool_tid, pool_bin; sq_dbuf<unsigned long long> pool_wq; sq_dbuf<unsigned long long> pool_cursor;  // [0] labels used, [1] classes, [2] overflow flag
   uint64_t pool_cap = 0;
@@ -64,7 +64,7 @@ __device__ inline bool is_compatible(uint8_t fid, uint8_t et, uint8_t eo, uint8_
 }
 
 struct OnlineView {
-  uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen;
+  uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen; double* tlc;
   double* hist; double* cpmf; double* ccmf; const double* ambig; double* mass; const double* prior_mass; double* log_eff_len; double* scal; double* cfac;
   unsigned long long* mass_acc; unsigned long long* uniq; unsigned long long* total; unsigned long long* lib_counts; uint32_t* fld_cnt; unsigned long long* ctr;
 };
@@ -83,11 +83,46 @@ __device__ inline void label_hash_step(uint64_t& a, uint64_t& b, uint32_t x) {
   b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29);
 }
 
-// one mini-batch: fragments [r0, r1) of the current mapped batch
-__global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0, double logFM,
-                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2) {
-  uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+// Model-independent per-alignment terms, computed once per mapped batch (thread per alignment):
+// logFragCov, the paired-end start-position term, log(RefLength), the fragment lengths and the
+// compatibility verdict.  Everything a mini-batch still has to evaluate per alignment is then a
+// table lookup (FLD pmf/cmf, cached transcript log-mass) plus the in-order log-sum chains.
+struct PreAln { double c_cov; double c_start; uint32_t flen; uint16_t fl_ped, max_fl; uint16_t tl; uint8_t flags, fmt; uint32_t pad; };  // 32 B
+enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16 };
+
+__global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ ref_clen, sq_quant_opts o, PreAln* __restrict__ pre) {
+  uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ai >= na) return;
+  const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
+  PreAln p; p.flags = 0; p.fmt = a.format_id; p.pad = 0;
+  const double refLength = rl > 0 ? (double)rl : 1.0;
+  p.c_cov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
+  uint32_t ped = frag_len_pedantic(a, rl);
+  uint32_t flen = a.frag_len; if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = ped;
+  p.flen = flen; p.fl_ped = (uint16_t)(ped > 1000 ? 1000 : ped);
+  const bool isCompat = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
+  if (isCompat) p.flags |= PF_COMPAT;
+  if (isCompat || !o.ignore_incompat) p.flags |= PF_KEEP;
+  if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction) { p.flags |= PF_PE_START; p.c_start = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON; }
+  else p.c_start = sq_log((double)rl);   // log(RefLength); the mini-batch negates it or uses the cached effective length
+  const bool singleEnd = (o.lib_type == 0);
+  const bool unexpectedOrphan = (o.lib_type == 1 && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
+  if (unexpectedOrphan) p.flags |= PF_UNEXP_ORPHAN;
+  p.max_fl = 0; p.tl = 0;
+  if (o.model_single_frag_prob && o.use_frag_len_dist && (singleEnd || unexpectedOrphan)) {
+    p.flags |= PF_ORPHAN_MODEL;
+    int32_t tl = (int32_t)ref_clen[a.tid], maxFL;
+    if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
+    else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
+    p.max_fl = (uint16_t)(maxFL > 1000 ? 1000 : maxFL); p.tl = (uint16_t)(tl > 1000 ? 1000 : tl);   // tables saturate at 1000
+  }
+  pre[ai] = p;
+}
+
+// one mini-batch: fragments [r0, r1) of the current mapped batch (thread per fragment)
+__device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint64_t read_counter0,
+                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   rh1[r] = EQ_EMPTY; rh2[r] = 0;
@@ -98,50 +133,37 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const bool cond = burned || useAux;
   const bool singleEnd = (o.lib_type == 0);
   const double totMass = V.scal[0];
-  auto pmf = [&](uint32_t len) -> double { if (cached) return len < 1001 ? V.cpmf[len] : V.cpmf[1000]; if (len > 1000) len = 1000; return V.hist[len] - totMass; };
-  auto cmf = [&](uint32_t len) -> double { return len < 1001 ? V.ccmf[len] : V.ccmf[1000]; };
-  // pass 1: auxProb / logProb per kept alignment, their log-sums (fixed order = alignment order)
+  // pass 1: auxProb / logProb per kept alignment and their in-order log-sums
   double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtSeen = 0;
   for (uint64_t ai = a0; ai < a1; ++ai) {
-    const sq_aln a = aln[ai]; const uint32_t t = a.tid;
+    const PreAln p = pre[ai];
     abin[ai] = 0xFFFFFFFFu;
-    const uint32_t rl = V.ref_len[t];
-    const double refLength = rl > 0 ? (double)rl : 1.0;
-    const double logFragCov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
-    const double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)rl) : V.log_eff_len[t]);
-    const double tlc = sq_log_add(V.prior_mass[t], V.mass[t]);
-    uint32_t flen = a.frag_len;
-    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = frag_len_pedantic(a, rl);
+    if (!(p.flags & PF_KEEP)) continue;
+    const uint32_t t = aln[ai].tid;
     double logFragProb = 0.0;
-    const bool unexpectedOrphan = (o.lib_type == 1 && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
-    if (o.model_single_frag_prob && o.use_frag_len_dist && (singleEnd || unexpectedOrphan)) {
-      int32_t tl = (int32_t)V.ref_clen[t], maxFL;
-      if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
-      else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
+    if (p.flags & PF_ORPHAN_MODEL) {
       const bool useFLD = singleEnd || burned;
-      auto cmfv = [&](uint32_t len) -> double { if (useFLD && cached) return cmf(len); return V.ambig[len < 1000 ? len : 1000]; };
-      double refCM = cmfv((uint32_t)tl); bool cm = !(refCM == SQ_LOG_0);
-      logFragProb = cm ? (cmfv((uint32_t)maxFL) - refCM) : SQ_LOG_EPSILON;
-    } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
-    if (flen > 0 && o.use_frag_len_dist && cond) {
-      double lenProb = pmf(flen);
-      if (burned) { double cm = cmf(flen); bool ok = ((double)flen < refLength) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+      const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
+      double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
+      logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
+    } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
+    if (p.flen > 0 && o.use_frag_len_dist && cond) {
+      const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
+      const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
+      if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[t] || (V.ref_len[t] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
       else if (useAux) logFragProb = lenProb;
     }
-    const bool isCompat = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
-    const double logCompat = isCompat ? 0.0 : o.incompat_prior;
-    if (!isCompat && o.ignore_incompat) continue;
-    double startPosProb = -logRefLength;
-    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction)
-      startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
-    fmtSeen |= 1ULL << a.format_id;
-    const double auxProb = logFragProb + logFragCov + logCompat;
-    const double logProb = tlc + auxProb + startPosProb;
+    const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
+    double startPosProb;
+    if (p.flags & PF_PE_START) startPosProb = p.c_start;
+    else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[t]); startPosProb = -logRefLength; }
+    fmtSeen |= 1ULL << p.fmt;
+    const double auxProb = logFragProb + p.c_cov + logCompat;
+    const double logProb = V.tlc[t] + auxProb + startPosProb;
     if (fabs(logProb) == SQ_LOG_0) continue;
     sumProbs = sq_log_add(sumProbs, logProb);
     auxDenom = sq_log_add(auxDenom, auxProb);
-    // stash: awq temporarily holds auxProb bits, abin marks "kept" (0), rslot unused here
-    awq[ai] = (unsigned long long)__double_as_longlong(auxProb); abin[ai] = 0;
+    awq[ai] = (unsigned long long)__double_as_longlong(auxProb); alp[ai] = logProb; abin[ai] = 0;
     ++nk;
   }
   if (nk == 0 || sumProbs == SQ_LOG_0) { for (uint64_t ai = a0; ai < a1; ++ai) abin[ai] = 0xFFFFFFFFu; return; }
@@ -154,26 +176,18 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   uint32_t ki = 0; uint32_t firstTid = 0;
   for (uint64_t ai = a0; ai < a1; ++ai) {
     if (abin[ai] != 0) continue;
-    const sq_aln a = aln[ai]; const uint32_t t = a.tid;
+    const uint32_t t = aln[ai].tid;
     const double auxProb = __longlong_as_double((long long)awq[ai]);
     const double w = sq_exp(auxProb - auxDenom);
     uint32_t bin = 0;
     if (o.range_factorization_bins > 0) bin = (uint32_t)(int32_t)(w * (double)rangeCount);
     awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
-    // recompute logProb for the mass update (same operations as pass 1)
-    const uint32_t rl = V.ref_len[t]; const double refLength = rl > 0 ? (double)rl : 1.0;
-    const double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)rl) : V.log_eff_len[t]);
-    const double tlc = sq_log_add(V.prior_mass[t], V.mass[t]);
-    uint32_t flen = a.frag_len; if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = frag_len_pedantic(a, rl);
-    double startPosProb = -logRefLength;
-    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction) startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
-    const double logProb = tlc + auxProb + startPosProb;
-    const double pr = sq_exp(logProb - sumProbs);
+    const double pr = sq_exp(alp[ai] - sumProbs);
     atomicAdd(&V.mass_acc[t], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
     atomicAdd(&V.total[t], 1ULL);
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
-      if (rr < pr) { uint32_t fl = frag_len_pedantic(a, rl); if (fl > 0) { if (fl > 1000) fl = 1000; atomicAdd(&V.fld_cnt[fl], 1u); atomicMin(&V.ctr[2], (unsigned long long)fl); } }
+      if (rr < pr) { uint32_t fl = pre[ai].fl_ped; if (fl > 0) { atomicAdd(&V.fld_cnt[fl], 1u); if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl); } }
     }
     abin[ai] = bin;   // kept alignments now carry their bin id (< 0xFFFFFFFF)
     if (ki == 0) firstTid = t;
@@ -184,15 +198,122 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
   rh1[r] = h1; rh2[r] = h2;
   if (nk == 1) atomicAdd(&V.uniq[firstTid], 1ULL);
-  for (int f = 0; f < 64; ++f) if ((fmtSeen >> f) & 1) atomicAdd(&V.lib_counts[f], 1ULL);
+  *fmt_out = fmtSeen;
 }
 
-// batch end, part 1: masses (one thread per transcript)
-__global__ void k_apply_mass(OnlineView V, double logFM) {
+
+// 16 lanes per fragment: each lane evaluates one alignment (table lookups only), the in-order
+// log-sum chains are replayed by all 16 lanes from shuffled values (SIMT-free), then every lane
+// finishes its own alignment (two exps, fixed-point increments).  Fragments with more than 16
+// alignments take the sequential path on lane 0.  Same arithmetic, same order as the checker.
+#define MB_G 16
+__global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
+                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2) {
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
+  uint64_t fmtSeen = 0;
+  const bool valid = r < r1;
+  const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
+  const uint32_t nA = (uint32_t)(a1 - a0);
+  if (valid && nA > MB_G) {
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen);
+  } else if (valid) {
+    if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
+    if (nA > 0) {
+      const bool burned = V.ctr[1] != 0; const bool cached = V.ctr[3] != 0;
+      const bool useAux = (assigned_base + assigned_prefix[r]) >= o.num_pre_burnin_frags;
+      const bool cond = burned || useAux; const bool singleEnd = (o.lib_type == 0);
+      const double totMass = V.scal[0];
+      // phase 1: lane j -> alignment a0 + j
+      bool keep = false; double auxProb = 0.0, logProb = 0.0; uint32_t t = 0; uint32_t fl_ped = 0; uint8_t fmt = 0;
+      const uint64_t ai = a0 + j;
+      if (j < nA) {
+        const PreAln p = pre[ai]; fl_ped = p.fl_ped; fmt = p.fmt;
+        if (p.flags & PF_KEEP) {
+          t = aln[ai].tid;
+          double logFragProb = 0.0;
+          if (p.flags & PF_ORPHAN_MODEL) {
+            const bool useFLD = singleEnd || burned; const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
+            double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
+            logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
+          } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
+          if (p.flen > 0 && o.use_frag_len_dist && cond) {
+            const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
+            const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
+            if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[t] || (V.ref_len[t] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+            else if (useAux) logFragProb = lenProb;
+          }
+          const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
+          double startPosProb;
+          if (p.flags & PF_PE_START) startPosProb = p.c_start;
+          else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[t]); startPosProb = -logRefLength; }
+          fmtSeen = 1ULL << fmt;
+          auxProb = logFragProb + p.c_cov + logCompat;
+          logProb = V.tlc[t] + auxProb + startPosProb;
+          keep = !(fabs(logProb) == SQ_LOG_0);
+        }
+      }
+      // chains, replayed identically by the 16 lanes of the group
+      double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtAll = 0;
+      for (uint32_t i = 0; i < nA; ++i) {
+        const int kp = __shfl((int)keep, (int)i, MB_G); const double xa = __shfl(auxProb, (int)i, MB_G); const double xl = __shfl(logProb, (int)i, MB_G);
+        const unsigned long long fm = __shfl((unsigned long long)fmtSeen, (int)i, MB_G);
+        fmtAll |= fm;
+        if (kp) { sumProbs = sq_log_add(sumProbs, xl); auxDenom = sq_log_add(auxDenom, xa); ++nk; }
+      }
+      const bool assigned = !(nk == 0 || sumProbs == SQ_LOG_0);
+      // kept-index of this lane's alignment (ki of the sequential form); ballot in group-uniform code
+      const unsigned long long kb = __ballot(keep);
+      const uint32_t gbits = (uint32_t)((kb >> ((threadIdx.x & 63) & ~(MB_G - 1))) & ((1u << MB_G) - 1));
+      const uint32_t ki = (uint32_t)__popc(gbits & ((1u << j) - 1));
+      // phase 2
+      uint32_t bin = 0xFFFFFFFFu;
+      if (j < nA) {
+        if (assigned && keep) {
+          const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
+          const double w = sq_exp(auxProb - auxDenom);
+          bin = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
+          awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
+          const double pr = sq_exp(logProb - sumProbs);
+          atomicAdd(&V.mass_acc[t], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+          atomicAdd(&V.total[t], 1ULL);
+          if (!burned) {
+            double rr = dev_u01(o.seed, read_counter0 + (r - r0), ki);
+            if (rr < pr && fl_ped > 0) { atomicAdd(&V.fld_cnt[fl_ped], 1u); if ((unsigned long long)fl_ped < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped); }
+          }
+        }
+        abin[ai] = bin;
+      }
+      // label hash (tids of kept alignments, then their bins), replayed by all lanes; lane 0 publishes
+      if (assigned) {
+        const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
+        uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen; uint32_t firstTid = 0; bool gotFirst = false;
+        for (uint32_t i = 0; i < nA; ++i) { const int kp = __shfl((int)keep, (int)i, MB_G); const uint32_t ti = (uint32_t)__shfl((int)t, (int)i, MB_G); if (kp) { label_hash_step(ha, hb, ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } } }
+        if (o.range_factorization_bins > 0) for (uint32_t i = 0; i < nA; ++i) { const uint32_t bi = (uint32_t)__shfl((int)bin, (int)i, MB_G); if (bi != 0xFFFFFFFFu) label_hash_step(ha, hb, bi); }
+        if (j == 0) {
+          uint64_t h1 = sq_mix64(ha), h2 = sq_mix64(hb);
+          if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
+          rh1[r] = h1; rh2[r] = h2;
+          if (nk == 1) atomicAdd(&V.uniq[firstTid], 1ULL);
+        }
+      }
+      fmtSeen = (j == 0 && assigned) ? fmtAll : 0;
+    }
+  }
+  // library-format counts: one atomic per (wave, format)
+  uint64_t any = fmtSeen; for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s, 64);
+  while (any) { int f = __ffsll((long long)any) - 1; any &= any - 1; unsigned long long m = __ballot((fmtSeen >> f) & 1); if ((threadIdx.x & 63) == 0) atomicAdd(&V.lib_counts[f], (unsigned long long)__popcll(m)); }
+}
+
+// batch end, part 1: masses (one thread per transcript); also refreshes the cached
+// transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
+__global__ void k_apply_mass(OnlineView V, double logFM, uint64_t assigned_after, int set_ctr) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && set_ctr) V.ctr[0] = assigned_after;
   if (t >= V.M) return;
   unsigned long long q = V.mass_acc[t];
-  if (q) { V.mass[t] = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass_acc[t] = 0; }
+  if (q) { double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass[t] = m; V.tlc[t] = sq_log_add(V.prior_mass[t], m); V.mass_acc[t] = 0; }
 }
 
 // batch end, part 2 (one block of 1024): FLD histogram update + tree total + counters + burn-in trigger
@@ -333,9 +454,44 @@ __global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict_
   for (uint64_t i = off[c]; i < off[c + 1]; ++i) atomicAdd(&T.pool_wq[po + (i - off[c])], (unsigned long long)wq[i]);
 }
 
+__global__ void k_gather_bounds(const uint64_t* __restrict__ prefix, uint32_t mb, uint32_t n, uint32_t nmb, uint64_t* __restrict__ out) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nmb) return;
+  uint64_t r = (uint64_t)b * mb; if (r > n) r = n;
+  out[b] = prefix[r];
+}
+
+// ---- device-side export of the table in canonical order --------------------------------------
+__global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, uint32_t* __restrict__ slots, unsigned long long* __restrict__ counter) {
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool occ = s < T.cap && T.k1[s] != EQ_EMPTY;
+  const unsigned long long m = __ballot(occ);
+  unsigned long long base = 0;
+  if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (occ) { uint64_t i = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1)); keys[i] = T.k1[s]; slots[i] = (uint32_t)s; }
+}
+__global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab, uint32_t* __restrict__ tie) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > E) return;
+  if (c == E) { nlab[E] = 0; return; }
+  nlab[c] = T.n[slots[c]];
+  if (c + 1 < E && keys[c] == keys[c + 1] && T.k2[slots[c]] > T.k2[slots[c + 1]]) *tie = 1;   // equal h1: order by h2 (fixed up on the host, ~never)
+}
+__global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off, uint32_t* __restrict__ tid, double* __restrict__ w, unsigned long long* __restrict__ wq,
+                            unsigned long long* __restrict__ count, uint32_t* __restrict__ bins, unsigned long long* __restrict__ h1, unsigned long long* __restrict__ h2) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  const uint32_t s = slots[c]; const uint32_t n = T.n[s]; const unsigned long long po = T.pool[s]; const uint64_t p = off[c];
+  count[c] = T.count[s]; h1[c] = T.k1[s]; h2[c] = T.k2[s];
+  double sum = 0.0; for (uint32_t i = 0; i < n; ++i) sum += sq_from_fixed(T.pool_wq[po + i], SQ_WFRAC_BITS);
+  const double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
+  for (uint32_t i = 0; i < n; ++i) { unsigned long long q = T.pool_wq[po + i]; tid[p + i] = T.pool_tid[po + i]; bins[p + i] = T.pool_bin[po + i]; wq[p + i] = q; w[p + i] = sq_from_fixed(q, SQ_WFRAC_BITS) * norm; }
+}
+
 OnlineView make_view(sq_ctx* c) {
   sq_online_dev* o = c->online; OnlineView V;
-  V.M = o->M; V.ref_len = c->di->ref_len; V.ref_clen = c->di->ref_clen; V.hist = o->hist.p; V.cpmf = o->cpmf.p; V.ccmf = o->ccmf.p; V.ambig = o->ambig.p; V.mass = o->mass.p; V.prior_mass = o->prior_mass.p;
+  V.M = o->M; V.ref_len = c->di->ref_len; V.ref_clen = c->di->ref_clen; V.tlc = o->tlc.p; V.hist = o->hist.p; V.cpmf = o->cpmf.p; V.ccmf = o->ccmf.p; V.ambig = o->ambig.p; V.mass = o->mass.p; V.prior_mass = o->prior_mass.p;
   V.log_eff_len = o->log_eff_len.p; V.scal = o->scal.p; V.cfac = o->cfac.p; V.mass_acc = o->mass_acc.p; V.uniq = o->uniq.p; V.total = o->total.p; V.lib_counts = o->lib_counts.p; V.fld_cnt = o->fld_cnt.p; V.ctr = o->ctr.p;
   return V;
 }
@@ -353,7 +509,7 @@ int sq_online_create(sq_ctx* c) {
   const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
-  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(1024) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
+  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(1024) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
              o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) || o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
              o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) || o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
@@ -371,6 +527,7 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 1024 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior
   SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8)); SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4)); SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
@@ -381,7 +538,7 @@ int sq_online_create(sq_ctx* c) {
 
 void sq_online_free(sq_ctx* c) {
   sq_online_dev* o = c->online; if (!o) return;
-  o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
+  o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->tlc.free_(); o->pre.free_(); o->alp.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
   o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
   o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
   delete o; c->online = nullptr;
@@ -411,9 +568,10 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   c->have_batch = false;
   if (n == 0) return SQ_OK;
   const size_t A = (size_t)c->last_total_aln + 8;
-  if (o->awq.ensure(A) || o->abin.ensure(A)) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
+  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
   sq_prof_begin(c);
+  if (c->last_total_aln) k_pre_aln<<<nblk(c->last_total_aln), TB, 0, st>>>(c->last_total_aln, c->aln.p, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, c->aln_off.p, c->aln.p, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
@@ -424,7 +582,9 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
   std::vector<uint64_t> bound(nmb + 1);
-  for (uint32_t b = 0; b <= nmb; ++b) { uint32_t r = std::min<uint64_t>((uint64_t)b * mb, n); SQ_HIP_CHECK(hipMemcpyAsync(&bound[b], o->assigned_prefix.p + r, 8, hipMemcpyDeviceToHost, st)); }
+  if (o->rh2.n < nmb + 2) { sq_set_error("internal: bounds scratch too small"); return SQ_ERR_STATE; }
+  k_gather_bounds<<<nblk(nmb + 1), TB, 0, st>>>(o->assigned_prefix.p, mb, n, nmb, o->rh2.p);   // rh2 is rewritten by the mini-batches below
+  SQ_HIP_CHECK(hipMemcpyAsync(bound.data(), o->rh2.p, (size_t)(nmb + 1) * 8, hipMemcpyDeviceToHost, st));
   unsigned long long hctr[8];
   SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
@@ -433,10 +593,10 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   for (uint32_t b = 0; b < nmb; ++b) {
     const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
     const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
-    k_mini_batch<<<nblk(r1 - r0), TB, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, logFM, c->aln_off.p, c->aln.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p);
-    k_apply_mass<<<nblk(o->M), TB, 0, st>>>(V, logFM);
     const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_apply_fld<<<1, 1024, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags);
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, c->aln_off.p, c->aln.p, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p);
+    k_apply_mass<<<nblk(o->M), TB, 0, st>>>(V, logFM, assigned_after, burned_host ? 1 : 0);
+    if (!burned_host) k_apply_fld<<<1, 1024, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags);
     if (!burned_host && assigned_after >= q.num_burnin_frags) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
       k_burnin_efflen<<<nblk(o->M), TB, 0, st>>>(V, 2);
@@ -507,34 +667,53 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
   return SQ_OK;
 }
 
-// export in canonical order (ascending (h1,h2)); sizes first when arrays are NULL
+// export in canonical order (ascending (h1,h2)); sizes first when arrays are NULL.  Compaction, sort
+// (rocPRIM radix sort on h1), offsets (scan) and the gather all run on the device; only the compact
+// CSR crosses PCIe.
 extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   if (!c || !out) return SQ_ERR_ARG;
   SQ_HIP_CHECK(hipSetDevice(c->device));
-  sq_online_dev* o = c->online;
+  sq_online_dev* o = c->online; hipStream_t st = c->stream;
   unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
-  out->num_classes = cur[1]; out->num_labels = cur[0];
+  const uint64_t E = cur[1], L = cur[0];
+  out->num_classes = E; out->num_labels = L;
   if (!out->off) return SQ_OK;
-  const uint64_t cap = o->tcap;
-  std::vector<unsigned long long> k1(cap), k2(cap), cnt(cap), pl(cap); std::vector<uint32_t> tn(cap);
-  SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, cap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, cap * 8, hipMemcpyDeviceToHost));
-  SQ_HIP_CHECK(hipMemcpy(cnt.data(), o->tcount.p, cap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pl.data(), o->tpool.p, cap * 8, hipMemcpyDeviceToHost));
-  SQ_HIP_CHECK(hipMemcpy(tn.data(), o->tn.p, cap * 4, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> ptid(cur[0] + 1), pbin(cur[0] + 1); std::vector<unsigned long long> pwq(cur[0] + 1);
-  if (cur[0]) { SQ_HIP_CHECK(hipMemcpy(ptid.data(), o->pool_tid.p, cur[0] * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pbin.data(), o->pool_bin.p, cur[0] * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(pwq.data(), o->pool_wq.p, cur[0] * 8, hipMemcpyDeviceToHost)); }
-  std::vector<uint64_t> slots; slots.reserve(cur[1]);
-  for (uint64_t s = 0; s < cap; ++s) if (k1[s] != EQ_EMPTY) slots.push_back(s);
-  std::sort(slots.begin(), slots.end(), [&](uint64_t a, uint64_t b) { return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
-  uint64_t p = 0;
-  for (size_t ci = 0; ci < slots.size(); ++ci) {
-    uint64_t s = slots[ci]; uint32_t n = tn[s]; uint64_t po = pl[s];
-    out->off[ci] = p; out->count[ci] = cnt[s]; if (out->h1) out->h1[ci] = k1[s]; if (out->h2) out->h2[ci] = k2[s];
-    double sum = 0.0; for (uint32_t i = 0; i < n; ++i) sum += sq_from_fixed(pwq[po + i], SQ_WFRAC_BITS);
-    double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
-    for (uint32_t i = 0; i < n; ++i) { out->tid[p + i] = ptid[po + i]; out->w[p + i] = sq_from_fixed(pwq[po + i], SQ_WFRAC_BITS) * norm; if (out->wq) out->wq[p + i] = pwq[po + i]; if (out->bins) out->bins[p + i] = pbin[po + i]; }
-    p += n;
+  if (E == 0) { out->off[0] = 0; return SQ_OK; }
+  EqView T = make_eq_view(o);
+  sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr; sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie; sq_dbuf<uint64_t> d_off; sq_dbuf<double> d_w; sq_dbuf<uint8_t> tmp;
+  if (keys.ensure(E) || keys2.ensure(E) || slots.ensure(E) || slots2.ensure(E) || nlab.ensure(E + 1) || d_off.ensure(E + 1) || d_tid.ensure(L) || d_bins.ensure(L) || d_wq.ensure(L) || d_w.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_ctr.ensure(1) || d_tie.ensure(1)) {
+    sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
+  SQ_HIP_CHECK(hipMemsetAsync(d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_tie.p, 0, 4, st));
+  k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, keys.p, slots.p, d_ctr.p);
+  size_t tb = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, keys2.p, slots.p, slots2.p, (int)E, 0, 64, st);
+  if (tmp.ensure(tb + 256)) { sq_set_error("device allocation failed (eq export sort)"); return SQ_ERR_NOMEM; }
+  tb = tmp.n;
+  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, keys2.p, slots.p, slots2.p, (int)E, 0, 64, st));
+  k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, slots2.p, keys2.p, nlab.p, d_tie.p);
+  size_t tb2 = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, nlab.p, d_off.p, (int)(E + 1), st);
+  if (tmp.ensure(tb2 + 256)) { sq_set_error("device allocation failed (eq export scan)"); return SQ_ERR_NOMEM; }
+  tb2 = tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
+  uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+  if (tie) {  // two classes share h1 and arrived out of h2 order: re-sort the slot list on the host (astronomically rare)
+    std::vector<uint32_t> hs(E); std::vector<unsigned long long> k1(o->tcap), k2(o->tcap);
+    SQ_HIP_CHECK(hipMemcpy(hs.data(), slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
+    std::sort(hs.begin(), hs.end(), [&](uint32_t a, uint32_t b) { return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
+    SQ_HIP_CHECK(hipMemcpy(slots2.p, hs.data(), E * 4, hipMemcpyHostToDevice));
+    k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, slots2.p, keys2.p, nlab.p, d_tie.p);
+    SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
   }
-  out->off[slots.size()] = p;
+  k_eq_gather<<<nblk(E), TB, 0, st>>>(T, E, slots2.p, d_off.p, d_tid.p, d_w.p, d_wq.p, d_cnt.p, d_bins.p, d_h1.p, d_h2.p);
+  SQ_HIP_CHECK(hipMemcpyAsync(out->off, d_off.p, (E + 1) * 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(out->tid, d_tid.p, L * 4, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(out->w, d_w.p, L * 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(out->count, d_cnt.p, E * 8, hipMemcpyDeviceToHost, st));
+  if (out->wq) SQ_HIP_CHECK(hipMemcpyAsync(out->wq, d_wq.p, L * 8, hipMemcpyDeviceToHost, st));
+  if (out->bins) SQ_HIP_CHECK(hipMemcpyAsync(out->bins, d_bins.p, L * 4, hipMemcpyDeviceToHost, st));
+  if (out->h1) SQ_HIP_CHECK(hipMemcpyAsync(out->h1, d_h1.p, E * 8, hipMemcpyDeviceToHost, st));
+  if (out->h2) SQ_HIP_CHECK(hipMemcpyAsync(out->h2, d_h2.p, E * 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
   return SQ_OK;
 }
 

@@ -32,20 +32,20 @@ def small_world(built):
 
 
 def random_eq_classes(M, E, seed=0, max_size=8, init_uniform_weights=False):
-    """Random CSR eq-classes with sorted, duplicate-free labels."""
+    """Random CSR eq-classes with sorted, duplicate-free labels (vectorised; zipf-hot transcripts)."""
     from salmon_amd import api
     rng = np.random.default_rng(seed)
-    sizes = rng.integers(1, max_size + 1, E)
-    sizes = np.minimum(sizes, M)
-    off = np.zeros(E + 1, np.uint64); off[1:] = np.cumsum(sizes)
-    L = int(off[-1])
-    tid = np.zeros(L, np.uint32); w = np.zeros(L)
+    sizes = np.minimum(rng.integers(1, max_size + 1, E), M)
+    cls = np.repeat(np.arange(E), sizes)
     hot = rng.zipf(1.3, size=M).astype(np.float64); hot /= hot.sum()
-    for c in range(E):
-        a, b = int(off[c]), int(off[c + 1])
-        t = np.sort(rng.choice(M, size=b - a, replace=False, p=hot))
-        tid[a:b] = t
-        x = np.ones(b - a) if init_uniform_weights else rng.random(b - a) + 0.05
-        w[a:b] = x / x.sum()
+    tid = rng.choice(M, size=len(cls), replace=True, p=hot)
+    key = np.unique(cls.astype(np.int64) * M + tid)          # sorted by (class, tid), duplicates removed
+    cls2 = (key // M).astype(np.int64); tid2 = (key % M).astype(np.uint32)
+    # every class keeps at least one label (cls is dense in 0..E-1 because sizes >= 1)
+    cnt = np.bincount(cls2, minlength=E)
+    off = np.zeros(E + 1, np.uint64); off[1:] = np.cumsum(cnt)
+    x = np.ones(len(tid2)) if init_uniform_weights else rng.random(len(tid2)) + 0.05
+    s = np.add.reduceat(x, off[:-1].astype(np.int64))
+    w = x / np.repeat(s, cnt)
     count = rng.integers(1, 200, E).astype(np.uint64)
-    return api.EqClasses(off, tid, w, count)
+    return api.EqClasses(off, tid2, w, count)
