@@ -25,7 +25,7 @@ struct sq_cand_dev {    // 48 B
 };
 
 struct sq_dp_item {     // one banded-DP region queued by the fast scorer
-  uint32_t cand; uint8_t end, mode, rc, pad; int32_t qstart, qdir, n; int64_t tstart; int32_t tdir, tl; uint32_t rec;
+  uint32_t cand; uint8_t end, mode, rc, pad; int32_t qstart, qdir, n; int64_t tstart; int32_t tdir, tl; int32_t budget;  // region scores below `budget` cannot yield a valid alignment
 };
 
 struct sq_map_params {

@@ -183,8 +183,12 @@ __global__ void k_fin(EmDev d, const double* __restrict__ alpha, double* __restr
   }
   if (partials) { double ls = wave_halving_sum(leaf); if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls; }  // level 1 of next iteration's canonical sum
   for (int s = 32; s >= 1; s >>= 1) { double o = __shfl_down(rel, s, 64); int ob = __shfl_down(bad, s, 64); rel = o > rel ? o : rel; bad |= ob; }
-  // one atomic per wave only when it can raise the running maximum (same-address atomics serialise)
-  if ((threadIdx.x & 63) == 0) {
+  // block-level combine, then one atomic per block only when it can raise the running maximum
+  __shared__ double srel[16]; __shared__ int sbad[16];
+  if ((threadIdx.x & 63) == 0) { srel[threadIdx.x >> 6] = rel; sbad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; } }
+  if (threadIdx.x == 0) {
     if (rel >= 0.0) { unsigned long long b = (unsigned long long)__double_as_longlong(rel); if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b); }
     if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) d.flags[1] = 1;
   }

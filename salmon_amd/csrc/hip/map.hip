@@ -160,7 +160,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
     sq_prof_mark(c, SG_JOIN_FILL);
     for (int attempt = 0; attempt < 2; ++attempt) {
       SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
-      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p);
+      SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_DP, 0, sizeof(unsigned long long), st));
+      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p, c->stats.p);
       sq_prof_mark(c, SG_SCORE);
       SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
@@ -188,7 +189,7 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
     memset(stats, 0, sizeof(*stats));
     stats->num_reads = n; stats->num_mapped_at_least_a_kmer = hst[ST_KMER]; stats->num_with_joint_hits = hst[ST_JOINT]; stats->num_mapped = hst[ST_MAPPED]; stats->num_alignments = hst[ST_ALNS];
     stats->num_mappings_filtered = hst[ST_MAPFILT]; stats->num_fragments_filtered = hst[ST_FRAGFILT]; stats->num_dovetails = hst[ST_DOVETAIL]; stats->num_decoy_fragments = hst[ST_DECOY];
-    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hcount[1];
+    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hst[ST_DP];
   }
   if (out) {
     if (!out->read_off || (!out->aln && total_aln)) { sq_set_error("sq_map_batch: output arrays missing"); return SQ_ERR_ARG; }

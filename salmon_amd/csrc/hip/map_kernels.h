@@ -43,6 +43,17 @@ __device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnma
   ReadView r; r.w = rpack + (size_t)e * SQ_READ_WORDS; r.nm = rnmask + (size_t)e * SQ_NMASK_WORDS; r.L = rlen[e]; return r;
 }
 
+// unique slot for every calling lane with ONE atomic per wave (works in divergent code: the ballot
+// only sees the active lanes)
+__device__ inline uint32_t wave_alloc(uint32_t* ctr) {
+  const unsigned long long m = __ballot(1);
+  const int leader = __ffsll((long long)m) - 1, lane = (int)(threadIdx.x & 63);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + (uint32_t)__popcll(m & ((1ULL << lane) - 1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8 threads per record, 32 bases each: adjacent lanes read adjacent 32-byte runs (coalesced)
 __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
@@ -331,9 +342,11 @@ __device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir,
   return mm;
 }
 
-// region score; returns true if resolved immediately (value in *sc), false if queued for DP
+// region score; returns true if resolved immediately (value in *sc), false if it needs the DP.
+// In `collect` mode nothing is queued: the caller only accumulates the upper bound ma*n of the
+// region; in queue mode the region is appended to the DP queue with its pass/fail budget.
 __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, const ReadView& r, bool fw, uint32_t cand, uint8_t end, int mode,
-                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc) {
+                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc, bool queue, int32_t budget, uint32_t* ndp) {
   if (n == 0 && mode == 1) { *sc = 0; return true; }
   if (n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n))) {
     int mm = count_mm(r, fw, qstart, qdir, S.refseq, tstart, tdir, n);
@@ -341,48 +354,62 @@ __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, co
     if (mm * (P.ma - P.mp) <= lim) { *sc = P.ma * (n - mm) + P.mp * mm; return true; }
   }
   // trivial DP outcomes that need no matrix (mirrors dp_align's early returns)
-  if (n == 0) { *sc = (tl == 0) ? 0 : (tl <= P.bw ? -(P.go + P.ge * tl) : SQ_NEG_INF); atomicAdd(&S.counters[1], 1u); return true; }
-  if (tl == 0) { *sc = (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF; atomicAdd(&S.counters[1], 1u); return true; }
-  uint32_t slot = atomicAdd(&S.counters[0], 1u);
-  atomicAdd(&S.counters[1], 1u);
-  if (slot < S.dpq_cap) {
-    sq_dp_item it; it.cand = cand; it.end = end; it.mode = (uint8_t)mode; it.rc = fw ? 0 : 1; it.pad = 0; it.qstart = qstart; it.qdir = qdir; it.n = n; it.tstart = tstart; it.tdir = tdir; it.tl = tl; it.rec = 0;
-    S.dpq[slot] = it;
+  // num_dp_alignments counts every region the fast path cannot decide (pass 0 sees them all once)
+  if (n == 0) { *sc = (tl == 0) ? 0 : (tl <= P.bw ? -(P.go + P.ge * tl) : SQ_NEG_INF); if (!queue) ++*ndp; return true; }
+  if (tl == 0) { *sc = (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF; if (!queue) ++*ndp; return true; }
+  if (!queue) ++*ndp;
+  if (queue) {
+    uint32_t slot = wave_alloc(&S.counters[0]);
+    if (slot < S.dpq_cap) {
+      sq_dp_item it; it.cand = cand; it.end = end; it.mode = (uint8_t)mode; it.rc = fw ? 0 : 1; it.pad = 0; it.qstart = qstart; it.qdir = qdir; it.n = n; it.tstart = tstart; it.tdir = tdir; it.tl = tl; it.budget = budget;
+      S.dpq[slot] = it;
+    }
   }
   return false;
 }
 
-// score one chain against its read end; DP regions are queued and added later by k_dp
-__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end) {
+// Score one chain against its read end.  Pass 0 resolves every region the mismatch-count fast path
+// can decide and sums an upper bound (ma * n) for the rest; if even that bound misses
+// minScoreFraction the end is invalid and no DP is queued.  Otherwise pass 1 queues the DP regions,
+// each with the lowest region score that could still make the end valid (k_dp stops early below it).
+__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end, uint32_t* ndp, uint8_t* fail) {
   ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
   const int L = r.L; const bool fw = ch.fw != 0;
   const uint32_t tid = ch.tid; const int Tlen = (int)S.ref_len[tid]; const int64_t g = (int64_t)S.ref_accum[tid];
-  int64_t score = 0; int prevQ = 0, prevR = 0; bool first = true;
-  uint32_t mi = ch.first;
-  for (uint32_t it = 0; it < ch.n_mems; ++it) {
-    MemD m = mem_decode(S.mkey[mem_base + mi], S.mval[mem_base + mi], S.ref_accum);
-    int qs = m.q, rs = m.rpos, ln = m.len;
-    bool use = true;
-    if (first) {
-      if (qs > 0) {
-        int ws = max(0, rs - qs - SQ_REF_EXTEND); int tl = max(0, rs - ws);
-        int32_t sc; if (region_fast(P, S, r, fw, cand, end, 1, qs - 1, -1, qs, g + rs - 1, -1, tl, &sc)) score += sc;
+  const int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * L));
+  int64_t score = 0; int64_t ub_dp = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool queue = pass == 1;
+    const int64_t fast_total = score; const int64_t ub_total = ub_dp;
+    if (queue) { score = 0; }
+    int prevQ = 0, prevR = 0; bool first = true; uint32_t mi = ch.first; int64_t sc_fast = 0; int64_t ub = 0;
+    auto region = [&](int mode, int qstart, int qdir, int n, int64_t tstart, int tdir, int tl) {
+      int32_t sc;
+      // budget for this region: minacc - (everything else at its best)
+      int32_t budget = queue ? (int32_t)max((int64_t)SQ_NEG_INF, (int64_t)minacc - (fast_total + ub_total - (int64_t)P.ma * n)) : 0;
+      if (region_fast(P, S, r, fw, cand, end, mode, qstart, qdir, n, tstart, tdir, tl, &sc, queue, budget, ndp)) sc_fast += sc; else ub += (int64_t)P.ma * n;
+    };
+    for (uint32_t it = 0; it < ch.n_mems; ++it) {
+      MemD m = mem_decode(S.mkey[mem_base + mi], S.mval[mem_base + mi], S.ref_accum);
+      int qs = m.q, rs = m.rpos, ln = m.len;
+      bool use = true;
+      if (first) {
+        if (qs > 0) { int ws = max(0, rs - qs - SQ_REF_EXTEND); int tl = max(0, rs - ws); region(1, qs - 1, -1, qs, g + rs - 1, -1, tl); }
+        first = false;
+      } else {
+        int ov = max(0, max(prevQ - qs, prevR - rs));
+        if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) use = false; }
+        if (use) { int gq = qs - prevQ, gr = rs - prevR; if (gq > 0 || gr > 0) region(0, prevQ, 1, gq, g + prevR, 1, gr); }
       }
-      first = false;
-    } else {
-      int ov = max(0, max(prevQ - qs, prevR - rs));
-      if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) use = false; }
-      if (use) {
-        int gq = qs - prevQ, gr = rs - prevR;
-        if (gq > 0 || gr > 0) { int32_t sc; if (region_fast(P, S, r, fw, cand, end, 0, prevQ, 1, gq, g + prevR, 1, gr, &sc)) score += sc; }
-      }
+      if (use) { sc_fast += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
+      mi = S.mnext[mem_base + mi];
     }
-    if (use) { score += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
-    mi = S.mnext[mem_base + mi];
-  }
-  if (prevQ < L) {
-    int tail = L - prevQ; int we = min(Tlen, prevR + tail + SQ_REF_EXTEND); int tl = max(0, we - prevR);
-    int32_t sc; if (region_fast(P, S, r, fw, cand, end, 1, prevQ, 1, tail, g + prevR, 1, tl, &sc)) score += sc;
+    if (prevQ < L) { int tail = L - prevQ; int we = min(Tlen, prevR + tail + SQ_REF_EXTEND); int tl = max(0, we - prevR); region(1, prevQ, 1, tail, g + prevR, 1, tl); }
+    score = sc_fast; ub_dp = ub;
+    if (!queue) {
+      if (ub == 0) break;                                   // nothing needs the DP
+      if (score + ub < (int64_t)minacc || score < -(1 << 29)) { *fail = 1; break; }  // cannot reach minScoreFraction: invalid without any DP
+    }
   }
   if (score < -(1 << 30)) score = -(1 << 30);
   return (int32_t)score;
@@ -408,25 +435,40 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
 }
 
 __global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ cand_off, uint32_t nfrag,
-                        const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag) {
+                        const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, unsigned long long* __restrict__ stats) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ci >= ncand) return;
-  sq_cand_dev c = cands[ci];
-  const uint32_t f = cand_frag[ci];
-  const bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
-  const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
-  bool lfw = hasL ? chains[c.lc].fw != 0 : false, rfw = hasR ? chains[c.rc].fw != 0 : false;
-  bool isc = paired ? joint_compat(P, orphan, hasL, lfw, rfw) : compat_se(P, lfw, SQ_MS_SINGLE_END);
-  c.compat = isc;
-  if (!isc && P.ignore_incompat) { c.valid = 0; c.lfail = c.rfail = 2; cands[ci] = c; return; }   // 2 = skipped (not scored)
-  uint32_t e0 = paired ? 2 * f : f, e1 = 2 * f + 1;
-  if (hasL) c.lscore = score_chain(P, S, chains[c.lc], mem_off[e0], e0, (uint32_t)ci, 0);
-  if (hasR) c.rscore = score_chain(P, S, chains[c.rc], mem_off[e1], e1, (uint32_t)ci, 1);
-  cands[ci] = c;
+  uint32_t ndp = 0;
+  if (ci < ncand) {
+    sq_cand_dev c = cands[ci];
+    const uint32_t f = cand_frag[ci];
+    const bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
+    const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
+    bool lfw = hasL ? chains[c.lc].fw != 0 : false, rfw = hasR ? chains[c.rc].fw != 0 : false;
+    bool isc = paired ? joint_compat(P, orphan, hasL, lfw, rfw) : compat_se(P, lfw, SQ_MS_SINGLE_END);
+    c.compat = isc;
+    if (!isc && P.ignore_incompat) { c.valid = 0; c.lfail = c.rfail = 2; }   // 2 = skipped (not scored)
+    else {
+      uint32_t e0 = paired ? 2 * f : f, e1 = 2 * f + 1;
+      c.lfail = c.rfail = 0;
+      if (hasL) c.lscore = score_chain(P, S, chains[c.lc], mem_off[e0], e0, (uint32_t)ci, 0, &ndp, &c.lfail);
+      // an end that already failed makes the pair invalid: the mate's DP regions are not needed
+      // (SPEC §a4: the pair is dropped either way; only num_dp_alignments would differ, so the mate is still scored)
+      if (hasR) c.rscore = score_chain(P, S, chains[c.rc], mem_off[e1], e1, (uint32_t)ci, 1, &ndp, &c.rfail);
+    }
+    cands[ci] = c;
+  }
+  wave_stat_add(&stats[ST_DP], ndp);
 }
 
 // banded Gotoh in registers: band index b = j - i + W, W = SQ_MAX_BAND (runtime bw <= W). SPEC §a4.
-__global__ void k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, uint32_t paired) {
+// One thread per queued region; both DP rows (H, F) live in VGPRs (launch bound 64 -> no spills) and
+// the 31 target bases under the band ride in one 64-bit window that shifts by one base per row, so a
+// row costs one query base + one target base fetch instead of 31 gathers.
+__device__ inline uint32_t dp_tbase(const uint64_t* refseq, const sq_dp_item& it, int x) {   // target base x of the region (0 when outside)
+  if (x < 0 || x >= it.tl) return 0u;
+  return sq_fetch_base(refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * x));
+}
+__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, uint32_t paired) {
   uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii >= nitems) return;
   const sq_dp_item it = S.dpq[ii];
@@ -441,9 +483,14 @@ __global__ void k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* 
   for (int b = 0; b <= BW; ++b) { Hp[b] = SQ_NEG_INF; Fp[b] = SQ_NEG_INF; }
 #pragma unroll
   for (int b = 0; b < BW; ++b) { int j = b - W; if (j >= 0 && j <= tl && j <= w) Hp[b] = (j == 0) ? 0 : -(go + ge * j); }
+  // window for row i holds target bases x = i - W - 1 + b (b = 0..30) at bits [2b, 2b+1]; row 1 -> x = b - W
+  uint64_t twin = 0;
+#pragma unroll
+  for (int b = 0; b < BW; ++b) twin |= (uint64_t)dp_tbase(S.refseq, it, b - W) << (2 * b);
+  bool hopeless = false;
   for (int i = 1; i <= n; ++i) {
     const uint32_t qb = norm_base(r, fw, it.qstart + it.qdir * (i - 1));
-    int32_t left_h = SQ_NEG_INF, left_e = SQ_NEG_INF;
+    int32_t left_h = SQ_NEG_INF, left_e = SQ_NEG_INF, rowmax = SQ_NEG_INF;
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
       const int j = i + b - W;
@@ -454,16 +501,20 @@ __global__ void k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* 
         else {
           ev = max(left_e, left_h - go) - ge;
           fv = max(Fp[b + 1], Hp[b + 1] - go) - ge;
-          const uint32_t tb = sq_fetch_base(S.refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * (j - 1)));
-          const int32_t s = (qb == tb && qb < 4) ? P.ma : P.mp;
-          hv = max(Hp[b] + s, max(ev, fv));
+          const uint32_t tb = (uint32_t)(twin >> (2 * b)) & 3u;
+          const int32_t sc = (qb == tb) ? P.ma : P.mp;   // qb == 4 (N) never equals a target base
+          hv = max(Hp[b] + sc, max(ev, fv));
           ev = max(ev, SQ_NEG_INF); fv = max(fv, SQ_NEG_INF); hv = max(hv, SQ_NEG_INF);
         }
       }
-      // Hp[b] (diagonal for this cell) is no longer needed by later cells of this row: overwrite in place
-      Hp[b] = hv; Fp[b] = fv; left_h = hv; left_e = ev;
+      Hp[b] = hv; Fp[b] = fv; left_h = hv; left_e = ev; rowmax = max(rowmax, max(hv, max(ev, fv)));
     }
+    // every remaining query base adds at most `ma`: once even that cannot reach the budget the end is invalid
+    if ((int64_t)rowmax + (int64_t)P.ma * (n - i) < (int64_t)it.budget) { hopeless = true; break; }
+    twin = (twin >> 2) | ((uint64_t)dp_tbase(S.refseq, it, i + W) << (2 * (BW - 1)));
   }
+  sq_cand_dev* c = &cands[it.cand];
+  if (hopeless) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; return; }
   int32_t res = SQ_NEG_INF;
   if (it.mode == 0) {
     if (abs(n - tl) <= w) {
@@ -474,8 +525,7 @@ __global__ void k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* 
 #pragma unroll
     for (int b = 0; b < BW; ++b) { int j = n + b - W; if (j >= max(0, n - w) && j <= min(tl, n + w) && Hp[b] > res) res = Hp[b]; }
   }
-  sq_cand_dev* c = &cands[it.cand];
-  if (res <= SQ_NEG_INF / 2) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; }
+  if (res <= SQ_NEG_INF / 2 || res < it.budget) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; }
   else atomicAdd(it.end == 0 ? &c->lscore : &c->rscore, res);
 }
 
