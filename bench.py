@@ -115,23 +115,14 @@ def main():
     eq = ctx.eq_finish()
     t_eqf = time.perf_counter() - t0 - t_map
     lm, uq, tc, le = ctx.model()
-    if dist:  # one RCCL all-gather of the packed class tables, merged exactly (integer sums) on every rank
-        def gather_np(x, dtype):
-            t = torch.from_numpy(np.ascontiguousarray(x).view(np.int64 if x.dtype.itemsize == 8 else np.int32)).to(dev)
-            n = torch.tensor([t.numel()], device=dev, dtype=torch.int64); ns = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(ns, n); mx = int(max(int(v) for v in ns))
-            pad = torch.zeros(mx, device=dev, dtype=t.dtype); pad[: t.numel()] = t
-            outs = [torch.zeros_like(pad) for _ in range(world)]; dist.all_gather(outs, pad)
-            return [o[: int(k)].cpu().numpy().view(dtype) for o, k in zip(outs, ns)]
-        parts = {f: gather_np(getattr(eq, f), getattr(eq, f).dtype) for f in ["off", "tid", "wq", "count", "bins", "h1", "h2"]}
+    if dist:  # one RCCL all-gather per packed field; every rank merges the others' tables exactly (integer sums)
+        from salmon_amd import dist as sqdist
+        tables = sqdist.all_gather_tables(eq, dist, dev)
         for r in range(world):
-            if r == rank: continue
-            other = api.EqClasses(parts["off"][r], parts["tid"][r], np.zeros(len(parts["tid"][r])), parts["count"][r], parts["wq"][r], parts["bins"][r], parts["h1"][r], parts["h2"][r])
-            ctx.eq_merge(other)
+            if r != rank:
+                ctx.eq_merge(tables[r])
         eq = ctx.eq_finish()
-        tq = torch.from_numpy(np.stack([uq.astype(np.int64), tc.astype(np.int64)])).to(dev); dist.all_reduce(tq); uq, tc = tq[0].cpu().numpy().astype(np.uint64), tq[1].cpu().numpy().astype(np.uint64)
-        ml = torch.from_numpy(np.where(np.isinf(lm), 0.0, np.exp(lm - 0.0))).to(dev); dist.all_reduce(ml); mlc = ml.cpu().numpy(); lm = np.where(mlc > 0, np.log(np.maximum(mlc, 1e-300)), np.inf)
-        le_t = torch.from_numpy(le).to(dev); dist.broadcast(le_t, 0); le = le_t.cpu().numpy()
+        lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, dev)
     t_a = time.perf_counter()
     proj = api.normalize_alphas(eq, lm, uq, tc)
     t_norm = time.perf_counter() - t_a

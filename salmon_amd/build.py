@@ -67,6 +67,22 @@ def build_product(verbose=True):
     return LIB
 
 
+def build_cli():
+    """salmon-hip: C++ host driver (index / quant) over the C ABI."""
+    out = os.path.join(ROOT, "salmon_amd", "bin")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "salmon-hip")
+    src = os.path.join(CSRC, "cli", "salmon_main.cpp")
+    if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return exe
+    cmd = ["g++", "-O2", "-std=c++17", "-march=x86-64-v3", src, "-o", exe, "-L" + os.path.dirname(LIB), "-lsalmon_hip", "-lz",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cli build failed:\n" + r.stderr[-6000:])
+    return exe
+
+
 def build_oracle():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
     if r.returncode != 0:
@@ -83,6 +99,7 @@ def build_tools():
 
 def build_all():
     build_product()
+    build_cli()
     build_oracle()
     build_tools()
 

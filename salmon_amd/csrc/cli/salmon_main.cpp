@@ -1,0 +1,153 @@
+// cli/salmon_main.cpp — `salmon-hip index|quant`: the reference's CLI surface for the hot path
+// (flag names from src/cli/ProgramOptionsGenerator.cpp and src/index/BuildSalmonIndex.cpp:70-127)
+// over the C ABI.  Host side only: FASTQ(.gz) parsing, batching, output files.  All mapping,
+// eq-class and inference work happens in libsalmon_hip.so on the GPU.
+#include <zlib.h>
+#include <sys/stat.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../../include/salmon_hip.h"
+
+static void die(const char* what) { fprintf(stderr, "[salmon-hip] %s: %s\n", what, sq_last_error()); exit(1); }
+static const char* arg(int argc, char** argv, const char* a, const char* b = nullptr) {
+  for (int i = 2; i + 1 < argc; ++i) if (!strcmp(argv[i], a) || (b && !strcmp(argv[i], b))) return argv[i + 1];
+  return nullptr;
+}
+static bool flag(int argc, char** argv, const char* a) { for (int i = 2; i < argc; ++i) if (!strcmp(argv[i], a)) return true; return false; }
+
+struct Fastq {
+  gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0;
+  bool open(const char* p) { f = gzopen(p, "rb"); if (f) { gzbuffer(f, 1 << 20); buf.resize(1 << 20); } return f != nullptr; }
+  bool line(std::string& out) {
+    out.clear();
+    for (;;) {
+      if (pos == len) { int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) return !out.empty(); len = (size_t)n; pos = 0; }
+      char* s = buf.data() + pos; char* e = (char*)memchr(s, '\n', len - pos);
+      if (e) { out.append(s, e - s); pos = (size_t)(e - buf.data()) + 1; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+      out.append(s, len - pos); pos = len;
+    }
+  }
+  bool record(std::string& seq) {  // FASTQ (@) or FASTA (>), single-line sequence records
+    std::string h, q;
+    if (!line(h)) return false;
+    if (!line(seq)) return false;
+    if (!h.empty() && h[0] == '@') { line(q); line(q); }
+    return true;
+  }
+};
+
+static int cmd_index(int argc, char** argv) {
+  const char* t = arg(argc, argv, "-t", "--transcripts"); const char* i = arg(argc, argv, "-i", "--index");
+  if (!t || !i) { fprintf(stderr, "usage: salmon-hip index -t transcripts.fa -i index_dir [-k 31] [-m 0] [-d decoys.txt] [-p threads] [--keepDuplicates] [--no-clip] [--gencode]\n"); return 1; }
+  sq_index_opts o{}; const char* v;
+  o.k = (v = arg(argc, argv, "-k", "--kmerLen")) ? (uint32_t)atoi(v) : 31; o.m = (v = arg(argc, argv, "-m", "--minimizerLen")) ? (uint32_t)atoi(v) : 0;
+  o.threads = (v = arg(argc, argv, "-p", "--threads")) ? (uint32_t)atoi(v) : 0;
+  o.keep_duplicates = flag(argc, argv, "--keepDuplicates"); o.no_clip_polya = flag(argc, argv, "--no-clip") || flag(argc, argv, "-n"); o.gencode = flag(argc, argv, "--gencode");
+  if (sq_index_build(&o, t, arg(argc, argv, "-d", "--decoys"), i)) die("index");
+  fprintf(stderr, "[salmon-hip] index written to %s\n", i);
+  return 0;
+}
+
+static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util/LibraryTypeUtils.cpp:22-46
+  {"IU", {1, 2, 4}}, {"ISF", {1, 2, 0}}, {"ISR", {1, 2, 1}}, {"OU", {1, 1, 4}}, {"OSF", {1, 1, 0}}, {"OSR", {1, 1, 1}},
+  {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
+
+static int cmd_quant(int argc, char** argv) {
+  const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
+  const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
+  const char* lt = arg(argc, argv, "-l", "--libType");
+  if (!idir || !odir || (!ru && !(r1 && r2))) { fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--device 0] [--batch 1000000]\n"); return 1; }
+  std::string lib = lt ? lt : (ru ? "U" : "IU");
+  for (auto& c : lib) c = (char)toupper((unsigned char)c);
+  if (lib == "A") { fprintf(stderr, "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n"); return 1; }
+  auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
+  const char* v; int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0; uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
+  const bool paired = !ru;
+  auto t0 = std::chrono::steady_clock::now();
+  sq_index* idx = nullptr; if (sq_index_load(idir, device, &idx)) die("loading index");
+  sq_quant_opts qo; sq_quant_opts_default(&qo); qo.lib_type = li->second[0]; qo.lib_orientation = li->second[1]; qo.lib_strand = li->second[2];
+  if ((v = arg(argc, argv, "--minScoreFraction"))) qo.min_score_fraction = atof(v);
+  if ((v = arg(argc, argv, "--consensusSlack"))) qo.consensus_slack = atof(v);
+  if ((v = arg(argc, argv, "--rangeFactorizationBins"))) qo.range_factorization_bins = (uint32_t)atoi(v);
+  if ((v = arg(argc, argv, "--mismatchSeedSkip"))) qo.mismatch_seed_skip = (uint32_t)atoi(v);
+  if (flag(argc, argv, "--hardFilter")) qo.hard_filter = 1;
+  if (flag(argc, argv, "--allowDovetail")) qo.allow_dovetail = 1;
+  if (flag(argc, argv, "--discardOrphansQuasi")) qo.allow_orphans = 0;
+  if (flag(argc, argv, "--disableChainingHeuristic")) qo.disable_chaining_heuristic = 1;
+  sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
+  Fastq f1, f2; if (!f1.open(paired ? r1 : ru) || (paired && !f2.open(r2))) { fprintf(stderr, "[salmon-hip] cannot open read files\n"); return 1; }
+  std::vector<uint8_t> seq; std::vector<uint64_t> off; std::string s1, s2; sq_map_stats tot{}; uint64_t nfrag = 0; bool more = true;
+  while (more) {
+    seq.clear(); off.assign(1, 0); uint32_t n = 0;
+    while (n < B) {
+      if (!f1.record(s1) || (paired && !f2.record(s2))) { more = false; break; }
+      seq.insert(seq.end(), s1.begin(), s1.end()); off.push_back(seq.size());
+      if (paired) { seq.insert(seq.end(), s2.begin(), s2.end()); off.push_back(seq.size()); }
+      ++n;
+    }
+    if (!n) break;
+    seq.resize(seq.size() + 16);
+    sq_read_batch in{n, paired ? 1u : 0u, seq.data(), off.data(), 0}; sq_map_stats st{};
+    if (sq_map_batch(ctx, &in, nullptr, &st)) die("mapping");
+    if (sq_eq_accumulate(ctx)) die("eq-class accumulation");
+    uint64_t* a = (uint64_t*)&tot; const uint64_t* b = (const uint64_t*)&st; for (size_t i = 0; i < sizeof(st) / 8; ++i) a[i] += b[i];
+    nfrag += n;
+    fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
+  }
+  fprintf(stderr, "\n");
+  const uint32_t M = sq_index_num_refs(idx);
+  sq_eq_table t{}; if (sq_eq_finish(ctx, &t)) die("eq finish");
+  std::vector<uint64_t> eo(t.num_classes + 1), ec(t.num_classes); std::vector<uint32_t> et(t.num_labels); std::vector<double> ew(t.num_labels);
+  t.off = eo.data(); t.tid = et.data(); t.w = ew.data(); t.count = ec.data(); if (sq_eq_finish(ctx, &t)) die("eq finish");
+  std::vector<double> lm(M), le(M), proj(M), eff(M), alphas(M, 0.0); std::vector<uint64_t> uq(M), tc(M);
+  if (sq_model_fetch(ctx, lm.data(), uq.data(), tc.data(), le.data())) die("model fetch");
+  for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
+  sq_model_summary ms{}; sq_model_summary_get(ctx, &ms);
+  mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
+  sq_em_report rep{};
+  if (ms.num_assigned < 10) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
+    fprintf(stderr, "[salmon-hip] only %llu fragments were assigned; writing empty quantification\n", (unsigned long long)ms.num_assigned);
+  } else {
+    if (sq_normalize_alphas(M, &t, lm.data(), uq.data(), tc.data(), proj.data())) die("normalizeAlphas");
+    sq_em_opts eop; sq_em_opts_default(&eop); if (flag(argc, argv, "--useEM")) eop.use_vbem = 0; if (flag(argc, argv, "--initUniform")) eop.init_uniform = 1;
+    if ((v = arg(argc, argv, "--vbPrior"))) eop.vb_prior = atof(v);
+    if (flag(argc, argv, "--perNucleotidePrior")) eop.per_transcript_prior = 0;
+    sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
+    if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
+  }
+  if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
+  if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
+  if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)
+    fprintf(mf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
+                "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
+                "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f\n}\n",
+            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes, (unsigned long long)nfrag, (unsigned long long)ms.num_assigned,
+            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails, (unsigned long long)tot.num_fragments_filtered, (unsigned long long)tot.num_mappings_filtered,
+            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb", rep.iters, ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs);
+    fclose(mf);
+  }
+  FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
+  if (cf) { fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir, lib.c_str(), odir); fclose(cf); }
+  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n", (unsigned long long)nfrag, (unsigned long long)ms.num_assigned,
+          nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv, "--useEM") ? "EM" : "VBEM", secs, odir);
+  sq_ctx_free(ctx); sq_index_free(idx);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "salmon-hip (%s)\nusage: salmon-hip index|quant ...\n", sq_version()); return 1; }
+  if (!strcmp(argv[1], "index")) return cmd_index(argc, argv);
+  if (!strcmp(argv[1], "quant")) return cmd_quant(argc, argv);
+  if (!strcmp(argv[1], "--version") || !strcmp(argv[1], "-v")) { printf("%s\n", sq_version()); return 0; }
+  fprintf(stderr, "unknown command %s (supported: index, quant)\n", argv[1]);
+  return 1;
+}

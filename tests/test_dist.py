@@ -1,0 +1,82 @@
+"""N>1 path on CPU: two gloo ranks shard the reads, all-gather their eq-class tables with the same
+helper bench.py uses over RCCL, and merge them; the result must equal the single-process table bit
+for bit (counts and fixed-point weight sums are integers, so the merge is exact in any order)."""
+import os, socket
+import numpy as np
+import pytest
+
+
+def merge_tables_host(tables):
+    """numpy reference of sq_eq_merge: key = (h1, h2); counts and wq add; output in canonical order."""
+    acc = {}
+    for t in tables:
+        for c in range(len(t.count)):
+            a, b = int(t.off[c]), int(t.off[c + 1])
+            key = (int(t.h1[c]), int(t.h2[c]))
+            if key not in acc:
+                acc[key] = [t.tid[a:b].copy(), t.bins[a:b].copy(), t.wq[a:b].astype(object), int(t.count[c])]
+            else:
+                assert np.array_equal(acc[key][0], t.tid[a:b]) and np.array_equal(acc[key][1], t.bins[a:b])
+                acc[key][2] = acc[key][2] + t.wq[a:b].astype(object); acc[key][3] += int(t.count[c])
+    keys = sorted(acc)
+    return keys, [acc[k] for k in keys]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch, torch.distributed as dist
+    from salmon_amd import api, synth, dist as sqdist
+    import orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tx = synth.Txome(seed=9, n_genes=50, iso_per_gene=5, threads=1)
+    names, seqs, lens = tx.tables()
+    idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=1)
+    oidx = orc.OrcIndex(idx)
+    N = 1200; per = N // world
+    seq, off, _, _ = tx.reads(N, read_len=100, seed=3, threads=1)
+    opts = api.quant_opts(num_burnin_frags=10**9, num_pre_burnin_frags=10**9)   # weights independent of the online model
+    def run(lo, hi):
+        s = seq[lo * 200: hi * 200]; o = (off[2 * lo: 2 * hi + 1] - off[2 * lo]).copy()
+        rb = api.make_read_batch(s, o, hi - lo, paired=True)
+        ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=1)
+        ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish()
+        return ost.eq_finish(), ost.model()
+    eq, (lm, uq, tc, le, _) = run(rank * per, (rank + 1) * per)
+    dev = torch.device("cpu")
+    tables = sqdist.all_gather_tables(eq, dist, dev)
+    lm2, uq2, tc2, le2 = sqdist.reduce_model(lm, uq, tc, le, dist, dev)
+    keys, rows = merge_tables_host(tables)
+    ok = True; msg = ""
+    if rank == 0:
+        full, (lmf, uqf, tcf, lef, _) = run(0, N)
+        fk = [(int(a), int(b)) for a, b in zip(full.h1, full.h2)]
+        ok = fk == keys
+        for c, row in enumerate(rows):
+            a, b = int(full.off[c]), int(full.off[c + 1])
+            ok = ok and np.array_equal(full.tid[a:b], row[0]) and int(full.count[c]) == row[3] and [int(x) for x in full.wq[a:b]] == [int(x) for x in row[2]]
+        ok = ok and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf)
+        msg = "classes=%d" % len(keys)
+    # every rank must hold identical merged keys: compare a digest
+    digest = torch.tensor([hash(tuple(keys)) % (2**31)], dtype=torch.int64)
+    ds = [torch.zeros_like(digest) for _ in range(world)]; dist.all_gather(ds, digest)
+    ok = ok and all(int(d) == int(ds[0]) for d in ds)
+    q.put((rank, bool(ok), msg))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_eq_table_reduction(built):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
