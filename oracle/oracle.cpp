@@ -28,6 +28,7 @@
 #include <vector>
 #include "../include/salmon_hip.h"
 #include "../include/sq_math.h"
+#include "../include/sq_rng.h"
 
 namespace orc {
 
@@ -793,19 +794,12 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
   }
 }
 
-static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
-  EMProblem P; em_setup(P, eq, txp, o);
+// iteration loop shared by optimize (minIter 100) and the bootstrap replicates (minIter 50)
+static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters, bool* converged, double* max_rel) {
   const uint32_t M = P.M;
-  std::vector<double> alpha(M), alphaP(M), theta(M), inv(P.E);
-  // initialisation (CollapsedEMOptimizer.cpp:778-823)
-  std::vector<double> pc(M); double totalWeight = 0.0;
-  for (uint32_t i = 0; i < M; ++i) { pc[i] = txp->projected_counts ? txp->projected_counts[i] : 0.0; }
-  totalWeight = canonical_sum(pc);
-  double uniformPrior = totalWeight / (double)M;
-  double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
-  for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
+  std::vector<double> alphaP(M), theta(M), inv(P.E);
   uint32_t it = 0; bool conv = false; double maxRel = -1.7976931348623157e308;
-  while (it < o->min_iter || (it < o->max_iter && !conv)) {
+  while (it < min_iter || (it < o->max_iter && !conv)) {
     em_step(P, o, alpha, alphaP, theta, inv);
     conv = true; maxRel = -1.7976931348623157e308;
     for (uint32_t i = 0; i < M; ++i) {
@@ -814,11 +808,86 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
     }
     ++it;
   }
+  *iters = it; *converged = conv; *max_rel = maxRel;
+}
+
+static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+  EMProblem P; em_setup(P, eq, txp, o);
+  const uint32_t M = P.M;
+  std::vector<double> alpha(M);
+  // initialisation (CollapsedEMOptimizer.cpp:778-823)
+  std::vector<double> pc(M); double totalWeight = 0.0;
+  for (uint32_t i = 0; i < M; ++i) { pc[i] = txp->projected_counts ? txp->projected_counts[i] : 0.0; }
+  totalWeight = canonical_sum(pc);
+  double uniformPrior = totalWeight / (double)M;
+  double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
+  for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
+  uint32_t it; bool conv; double maxRel;
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel);
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector :64-76
   double asum = canonical_sum(alpha);
   for (uint32_t i = 0; i < M; ++i) alpha_out[i] = alpha[i];
   if (rep) { rep->iters = it; rep->converged = conv; rep->max_rel_diff = maxRel; rep->alpha_sum = asum; rep->device_ms = 0; rep->ms_per_iter = 0; }
   return asum < 2.2250738585072014e-308 ? SQ_ERR_STATE : SQ_OK;
+}
+
+// a16 — gatherBootstraps / doBootstrap (CollapsedEMOptimizer.cpp:398-690); SPEC §a16
+static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) {
+  EMProblem P; em_setup(P, eq, txp, o);
+  const uint32_t M = P.M; const uint64_t E = P.E;
+  std::vector<uint64_t> cum(E), orig(P.count); uint64_t total = 0; for (uint64_t c = 0; c < E; ++c) { total += orig[c]; cum[c] = total; }
+  std::vector<uint8_t> active(M, 0); for (uint32_t t : P.tid) active[t] = 1;
+  uint32_t nact = 0; for (auto a : active) nact += a;
+  if (!nact || !total) return SQ_ERR_STATE;
+  const double scale = 1.0 / (double)nact;
+  for (uint32_t b = 0; b < B; ++b) {
+    std::fill(P.count.begin(), P.count.end(), 0);
+    for (uint64_t i = 0; i < total; ++i) { uint64_t idx = sq_mulhi64(sq_r64(seed, b, i), total); size_t c = std::upper_bound(cum.begin(), cum.end(), idx) - cum.begin(); P.count[c]++; }
+    std::vector<double> alpha(M); for (uint32_t i = 0; i < M; ++i) alpha[i] = active[i] ? scale * (double)num_mapped : 0.0;
+    uint32_t it; bool conv; double mr; em_loop(P, o, alpha, 50, &it, &conv, &mr);
+    for (uint32_t i = 0; i < M; ++i) out[(size_t)b * M + i] = alpha[i] <= 1e-8 ? 0.0 : alpha[i];
+  }
+  return SQ_OK;
+}
+
+// a17 — CollapsedGibbsSampler::sample + sampleRoundNonCollapsedMultithreaded_ (CollapsedGibbsSampler.cpp:92-278, 317-508); SPEC §a17
+static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) {
+  const uint32_t M = txp->num_txp; const uint64_t E = eq->num_classes;
+  const bool perTxp = go->use_vbem ? go->per_transcript_prior != 0 : true;
+  double pv = 1e-3; if (go->use_vbem) pv = perTxp ? (go->vb_prior < 1.0 ? 1.0 : go->vb_prior) : (go->vb_prior < 1e-3 ? 1e-3 : go->vb_prior);
+  std::vector<double> prior(M, pv); if (!perTxp) for (uint32_t i = 0; i < M; ++i) prior[i] = pv * txp->eff_len[i];
+  std::vector<uint8_t> active(M, 0); for (uint64_t i = 0; i < eq->num_labels; ++i) active[eq->tid[i]] = 1;
+  std::vector<double> init(alpha_init, alpha_init + M); for (uint32_t i = 0; i < M; ++i) if (!active[i]) init[i] = 0.0;
+  std::vector<uint64_t> draw_off(E + 1, 0); for (uint64_t c = 0; c < E; ++c) draw_off[c + 1] = draw_off[c] + eq->count[c];
+  uint32_t nchains = 1; if (S >= 50) nchains = 2; if (S >= 100) nchains = 4; if (S >= 200) nchains = 8;
+  const uint32_t step = nchains > 1 ? S / nchains : S + 1; const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16;
+  std::vector<double> cf(init), mu(M, 0.0), me(M); std::vector<uint64_t> ci(M);
+  for (uint32_t sid = 0; sid < S; ++sid) {
+    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) cf = init;
+    for (uint32_t r = 0; r < thin; ++r) {
+      const uint64_t key = (uint64_t)sid * thin + r;
+      for (uint32_t i = 0; i < M; ++i) { if (!active[i]) { mu[i] = 0.0; continue; } double c = cf[i] + prior[i]; mu[i] = go->no_gamma_draw ? c / txp->eff_len[i] : sq_gamma_draw(c, 1.0 / (0.1 + txp->eff_len[i]), seed, key, i); }
+      std::fill(ci.begin(), ci.end(), 0);
+      for (uint64_t c = 0; c < E; ++c) {
+        const uint64_t a = eq->off[c]; const uint32_t n = (uint32_t)(eq->off[c + 1] - a); const uint64_t cnt = eq->count[c];
+        if (n == 0 || cnt == 0) continue;
+        if (n == 1) { ci[eq->tid[a]] += cnt; continue; }
+        auto pf = [&](int mode, uint32_t i) { uint32_t t = eq->tid[a + i]; return mode == 0 ? (1000.0 * mu[t]) * eq->w[a + i] : (mode == 1 ? 1.0 / txp->eff_len[t] : 1.0); };
+        int mode = 0; double denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += pf(0, i);
+        if (denom <= 2.2250738585072014e-308) { mode = 1; denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += pf(1, i); if (denom <= 2.2250738585072014e-308) { mode = 2; denom = (double)n; } }
+        for (uint64_t sidx = 0; sidx < cnt; ++sidx) {
+          double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, key, draw_off[c] + sidx)) * denom;
+          double acc = 0.0; uint32_t pick = n - 1; for (uint32_t i = 0; i < n; ++i) { acc += pf(mode, i); if (u < acc) { pick = i; break; } }
+          ci[eq->tid[a + pick]]++;
+        }
+      }
+      for (uint32_t i = 0; i < M; ++i) cf[i] = (double)ci[i];
+    }
+    for (uint32_t i = 0; i < M; ++i) me[i] = mu[i] * txp->eff_len[i];
+    double scale = (double)num_mapped / canonical_sum(me);
+    for (uint32_t i = 0; i < M; ++i) { double v = me[i] * scale; out[(size_t)sid * M + i] = v > 1e-8 ? v : 0.0; }
+  }
+  return SQ_OK;
 }
 
 }  // namespace orc
@@ -1050,6 +1119,8 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
 }
 
 int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) { return em_optimize(eq, txp, o, alpha_out, rep); }
+int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) { return bootstrap(eq, txp, o, B, seed, num_mapped, out); }
+int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) { return gibbs(eq, txp, go, alpha_init, S, seed, num_mapped, out); }
 int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out) {
   EMProblem P; em_setup(P, eq, txp, o); std::vector<double> a(alpha_in, alpha_in + P.M), b(P.M), th(P.M), inv(P.E);
   for (uint32_t i = 0; i < iters; ++i) { em_step(P, o, a, b, th, inv); a.swap(b); }

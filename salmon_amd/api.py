@@ -322,3 +322,33 @@ def write_quant_sf(path, index, eff_len, num_reads, num_mapped=0.0):
 def write_eq_classes(path, index, eq, with_weights=False):
     t = eq.table()
     check(lib().sq_write_eq_classes(path.encode(), index.h, C.byref(t), int(with_weights)), "sq_write_eq_classes")
+
+
+def _collect(n_txp):
+    rows = []
+
+    def cb(ptr, m, user):
+        rows.append(np.ctypeslib.as_array(ptr, shape=(m,)).copy())
+        return 0
+    return rows, capi.REPLICATE_CB(cb)
+
+
+def bootstrap(eq, eff_len, num_bootstraps, seed, num_mapped, opts=None, device=0):
+    """CollapsedEMOptimizer::gatherBootstraps on the GPU -> array [B, M] (what writeBootstrap receives)."""
+    o = opts or em_opts(); t = eq.table(); txp = make_txp_in(eff_len)
+    rows, cb = _collect(txp.num_txp)
+    check(lib().sq_bootstrap_dev(device, C.byref(t), C.byref(txp), C.byref(o), num_bootstraps, seed, num_mapped, cb, None), "sq_bootstrap_dev")
+    return np.array(rows)
+
+
+def gibbs_opts(thinning_factor=16, no_gamma_draw=0, use_vbem=1, per_transcript_prior=1, vb_prior=1e-2):
+    return capi.GibbsOpts(thinning_factor, no_gamma_draw, use_vbem, per_transcript_prior, 0, vb_prior)
+
+
+def gibbs(eq, eff_len, alpha_init, num_samples, seed, num_mapped, gopts=None, device=0):
+    """CollapsedGibbsSampler::sample on the GPU -> array [S, M]."""
+    g = gopts or gibbs_opts(); t = eq.table(); txp = make_txp_in(eff_len)
+    a = np.ascontiguousarray(alpha_init, np.float64)
+    rows, cb = _collect(txp.num_txp)
+    check(lib().sq_gibbs_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, seed, num_mapped, cb, None), "sq_gibbs_dev")
+    return np.array(rows)

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include "device_index.h"
+#include "../../../include/sq_rng.h"
 
 namespace {
 
@@ -275,90 +276,159 @@ int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, Em
 }
 
 // Runs the iteration loop. mode 0: optimise to convergence; mode 1: exactly `fixed_iters` steps.
-int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha,
-           int mode, uint32_t fixed_iters, sq_em_report* rep) {
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
-  SQ_HIP_CHECK(hipSetDevice(device));
-  EmHost H; int rc = prepare(eq, txp, o, H); if (rc) return rc;
-  const uint32_t M = txp->num_txp; const uint32_t E = (uint32_t)eq->num_classes; const uint64_t L = eq->num_labels;
+// One uploaded problem (CSR + CSC + reduction plan); `run` can be called repeatedly, e.g. once per
+// bootstrap replicate with resampled class counts (the combined weights stay those of the original
+// counts, as in doBootstrap — CollapsedEMOptimizer.cpp:398-552).
+struct EmSession {
+  uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmHost H; EmDev d;
   DBuf<uint64_t> d_off, d_toff; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
-  std::vector<uint64_t> off(eq->off, eq->off + E + 1); std::vector<uint32_t> tid(eq->tid, eq->tid + L);
-  uint32_t g1 = (M + 63) / 64;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
-  for (int l = 0; l < H.nlevels; ++l) if (d_slo[l].upload(H.seg_lo[l]) || d_stx[l].upload(H.seg_txp[l]) || d_scn[l].upload(H.seg_cnt[l]) || d_lpart[l].alloc(H.seg_lo[l].size() + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
-  bool ok = !d_off.upload(off) && !d_tid.upload(tid) && !d_cw.upload(H.cw) && !d_cnt.upload(H.cnt) && !d_toff.upload(H.t_off) && !d_tcls.upload(H.t_cls) &&
-            !d_tcw.upload(H.t_cw) && !d_prior.upload(H.prior) && !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.upload(alpha) && !d_a1.alloc(M) &&
-            !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
-  if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
-  SQ_HIP_CHECK(hipMemset(d_flags.p, 0, 4 * sizeof(uint32_t))); SQ_HIP_CHECK(hipMemset(d_maxrel.p, 0, 8)); SQ_HIP_CHECK(hipMemset(d_log.p, 0, 8));
-  EmDev d; d.M = M; d.E = E; d.L = L; d.off = d_off.p; d.tid = d_tid.p; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
-  d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
-  d.min_iter = (mode == 0) ? o->min_iter : 0xFFFFFFFFu;
-  d.nlevels = H.nlevels; for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.nseg[l] = l < H.nlevels ? (uint32_t)H.seg_lo[l].size() : 0; d.part[l] = d_lpart[l].p; }
-  hipStream_t st; SQ_HIP_CHECK(hipStreamCreate(&st));
-  hipEvent_t e0, e1; SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
-  const int TB = 256;
-  double* cur = d_a0.p; double* nxt = d_a1.p;
-  // level-1 partials of (alpha + prior) live in d.partial; levels above are finished inside k_theta.
-  // If there are more than 4096 of them (M > 262144) extra level kernels shrink the list first.
-  double* part_lvl1 = d.partial; double* part_tmp = d.partial + g1 + 64;
-  bool pending_close = false; uint32_t pending_it = 0;
-  auto launch_iter = [&](uint32_t it) {
-    const double* theta_src = cur;
-    if (o->use_vbem) {
-      const double* pin = part_lvl1; uint32_t n1 = g1;
-      double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
-      while (n1 > 4096) { k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a); pin = a; n1 = (n1 + 63) / 64; std::swap(a, b); }
-      k_top<<<1, 1024, 0, st>>>(d, pin, n1, pending_close ? 1 : 0, pending_it, d_log.p, d_lognorm.p);
-      k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p);
-      pending_close = false;
-      theta_src = d.theta;
-    } else if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; }
-    k_class<<<(E + TB - 1) / TB, TB, 0, st>>>(d, theta_src);
-    if (d.nseg[0]) k_l1<<<(d.nseg[0] + TB - 1) / TB, TB, 0, st>>>(d, theta_src, nxt);
-    { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
-      if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }
-    k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, nxt, o->use_vbem ? part_lvl1 : nullptr);
-    pending_close = true; pending_it = it;
-    std::swap(cur, nxt);
-  };
-  auto flush_close = [&]() { if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; } };
-  if (o->use_vbem) k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1);
-  uint32_t it = 0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
-  SQ_HIP_CHECK(hipEventRecord(e0, st));
-  if (mode == 1) {
-    for (; it < fixed_iters; ++it) launch_iter(it);
-    flush_close();
-    executed = fixed_iters;
-  } else {
-    const uint32_t maxIter = o->max_iter, minIter = o->min_iter;
-    // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
-    while (it < maxIter || it < minIter) {
-      uint32_t chunk = (it < minIter) ? (minIter - it) : 16;
-      uint32_t lim = std::max(maxIter, minIter);
-      if (it + chunk > lim) chunk = lim - it;
-      for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
+  hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st) (void)hipStreamDestroy(st); }
+
+  int setup(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
+    SQ_HIP_CHECK(hipSetDevice(device));
+    o = opts;
+    int rc = prepare(eq, txp, o, H); if (rc) return rc;
+    M = txp->num_txp; E = (uint32_t)eq->num_classes; L = eq->num_labels; g1 = (M + 63) / 64;
+    std::vector<uint64_t> off(eq->off, eq->off + E + 1); std::vector<uint32_t> tid(eq->tid, eq->tid + L);
+    for (int l = 0; l < H.nlevels; ++l) if (d_slo[l].upload(H.seg_lo[l]) || d_stx[l].upload(H.seg_txp[l]) || d_scn[l].upload(H.seg_cnt[l]) || d_lpart[l].alloc(H.seg_lo[l].size() + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+    bool ok = !d_off.upload(off) && !d_tid.upload(tid) && !d_cw.upload(H.cw) && !d_cnt.upload(H.cnt) && !d_toff.upload(H.t_off) && !d_tcls.upload(H.t_cls) &&
+              !d_tcw.upload(H.t_cw) && !d_prior.upload(H.prior) && !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) &&
+              !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
+    if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
+    d.M = M; d.E = E; d.L = L; d.off = d_off.p; d.tid = d_tid.p; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
+    d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
+    d.nlevels = H.nlevels; for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.nseg[l] = l < H.nlevels ? (uint32_t)H.seg_lo[l].size() : 0; d.part[l] = d_lpart[l].p; }
+    SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+    return SQ_OK;
+  }
+
+  // mode 0: optimise to convergence (min_iter / o->max_iter); mode 1: exactly `fixed_iters` steps.
+  // alpha_dev != nullptr: the initial alphas are already in d_a0 (device); else they are uploaded from `alpha`.
+  int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false, bool fetch = true) {
+    const int TB = 256;
+    if (!alpha_on_device) SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st)); SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
+    d.min_iter = (mode == 0) ? min_iter : 0xFFFFFFFFu;
+    double* cur = d_a0.p; double* nxt = d_a1.p;
+    // level-1 partials of (alpha + prior) live in d.partial; k_top finishes the levels above (<= 4096
+    // partials); for M > 262144 extra level kernels shrink the list first.
+    double* part_lvl1 = d.partial; double* part_tmp = d.partial + g1 + 64;
+    bool pending_close = false; uint32_t pending_it = 0;
+    auto launch_iter = [&](uint32_t it) {
+      const double* theta_src = cur;
+      if (o->use_vbem) {
+        const double* pin = part_lvl1; uint32_t n1 = g1;
+        double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
+        while (n1 > 4096) { k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a); pin = a; n1 = (n1 + 63) / 64; std::swap(a, b); }
+        k_top<<<1, 1024, 0, st>>>(d, pin, n1, pending_close ? 1 : 0, pending_it, d_log.p, d_lognorm.p);
+        k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p);
+        pending_close = false;
+        theta_src = d.theta;
+      } else if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; }
+      k_class<<<(E + TB - 1) / TB, TB, 0, st>>>(d, theta_src);
+      if (d.nseg[0]) k_l1<<<(d.nseg[0] + TB - 1) / TB, TB, 0, st>>>(d, theta_src, nxt);
+      { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
+        if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }
+      k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, nxt, o->use_vbem ? part_lvl1 : nullptr);
+      pending_close = true; pending_it = it;
+      std::swap(cur, nxt);
+    };
+    auto flush_close = [&]() { if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; } };
+    if (o->use_vbem) k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1);
+    uint32_t it = 0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
+    SQ_HIP_CHECK(hipEventRecord(e0, st));
+    if (mode == 1) {
+      for (; it < fixed_iters; ++it) launch_iter(it);
       flush_close();
-      SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
-      SQ_HIP_CHECK(hipStreamSynchronize(st));
-      if (hflags[0]) { done = hflags[0]; break; }
+      executed = fixed_iters;
+    } else {
+      const uint32_t maxIter = o->max_iter, minIter = min_iter;
+      // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
+      while (it < maxIter || it < minIter) {
+        uint32_t chunk = (it < minIter) ? (minIter - it) : 16;
+        uint32_t lim = std::max(maxIter, minIter);
+        if (it + chunk > lim) chunk = lim - it;
+        for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
+        flush_close();
+        SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
+        SQ_HIP_CHECK(hipStreamSynchronize(st));
+        if (hflags[0]) { done = hflags[0]; break; }
+      }
+      executed = done ? done : it;
     }
-    executed = done ? done : it;
+    SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    result_dev = (executed % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed` swaps starting from d_a0
+    if (fetch) SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
+    unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
+    if (rep) {
+      rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
+      rep->device_ms = ms; rep->ms_per_iter = (mode == 1 ? fixed_iters : it) ? ms / (double)(mode == 1 ? fixed_iters : it) : 0.0; rep->alpha_sum = 0;
+    }
+    return SQ_OK;
   }
-  SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
-  float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  // result buffer: after `executed` swaps starting from d_a0
-  double* res = (executed % 2 == 0) ? d_a0.p : d_a1.p;
-  SQ_HIP_CHECK(hipMemcpy(alpha.data(), res, (size_t)M * 8, hipMemcpyDeviceToHost));
-  unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
-  if (rep) {
-    rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
-    rep->device_ms = ms; rep->ms_per_iter = (mode == 1 ? fixed_iters : it) ? ms / (double)(mode == 1 ? fixed_iters : it) : 0.0; rep->alpha_sum = 0;
-  }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
-  return SQ_OK;
+  double* result_dev = nullptr;
+};
+
+int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep) {
+  EmSession S; int rc = S.setup(device, eq, txp, o); if (rc) return rc;
+  return S.run(alpha, mode, fixed_iters, o->min_iter, rep);
 }
+
+// ---- a16 bootstrap (doBootstrap, CollapsedEMOptimizer.cpp:398-552) ----------------------------------
+// multinomial resample of the class counts: draw i of replicate b picks the class whose cumulative
+// count interval contains mulhi(r64(seed, b, i), total)
+__global__ void k_bs_sample(uint64_t total, uint32_t E, const uint64_t* __restrict__ cum, uint64_t seed, uint64_t rep, unsigned long long* __restrict__ samp) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t idx = sq_mulhi64(sq_r64(seed, rep, i), total);
+    uint32_t lo = 0, hi = E;  // first c with cum[c] > idx
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] > idx) hi = mid; else lo = mid + 1; }
+    atomicAdd(&samp[lo], 1ULL);
+  }
+}
+__global__ void k_u64_to_f64(uint32_t n, const unsigned long long* __restrict__ in, double* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = (double)in[i];
+}
+__global__ void k_truncate(uint32_t n, double* __restrict__ a) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n && a[i] <= 1e-8) a[i] = 0.0; }
+
+// ---- a17 Gibbs (sampleRoundNonCollapsedMultithreaded_, CollapsedGibbsSampler.cpp:92-278) --------------
+struct GibbsDev { uint32_t M, E; const uint64_t* off; const uint32_t* tid; const double* w; const uint64_t* cnt; const double* eff; const double* prior; const uint8_t* active;
+                  double* mu; double* count_f; unsigned long long* count_i; const uint64_t* draw_off; };
+__global__ void k_gibbs_mu(GibbsDev g, uint64_t seed, uint64_t round_key, int no_gamma) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
+  if (!g.active[i]) { g.mu[i] = 0.0; return; }
+  double ci = g.count_f[i] + g.prior[i];
+  g.mu[i] = no_gamma ? ci / g.eff[i] : sq_gamma_draw(ci, 1.0 / (0.1 + g.eff[i]), seed, round_key, (uint64_t)i);   // beta = 0.1 (:104)
+}
+__device__ inline double gibbs_class_p(const GibbsDev& g, uint64_t a, uint32_t n, int mode, uint32_t i) {
+  uint32_t t = g.tid[a + i];
+  return mode == 0 ? (1000.0 * g.mu[t]) * g.w[a + i] : (mode == 1 ? 1.0 / g.eff[t] : 1.0);
+}
+__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed, uint64_t round_key) {
+  uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
+  const uint32_t c = item_cls[it]; const uint64_t a = g.off[c]; const uint32_t n = (uint32_t)(g.off[c + 1] - a); const uint64_t cnt = g.cnt[c];
+  if (n == 1) { if (item_s0[it] == 0) atomicAdd(&g.count_i[g.tid[a]], (unsigned long long)cnt); return; }
+  int mode = 0; double denom = 0.0;
+  for (uint32_t i = 0; i < n; ++i) denom += gibbs_class_p(g, a, n, 0, i);
+  if (denom <= 2.2250738585072014e-308) { mode = 1; denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += gibbs_class_p(g, a, n, 1, i);
+    if (denom <= 2.2250738585072014e-308) { mode = 2; denom = (double)n; } }
+  const uint64_t s1 = min((uint64_t)item_s0[it] + 256, cnt);
+  for (uint64_t sidx = item_s0[it]; sidx < s1; ++sidx) {
+    double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, round_key, g.draw_off[c] + sidx)) * denom;
+    double acc = 0.0; uint32_t pick = n - 1;
+    for (uint32_t i = 0; i < n; ++i) { acc += gibbs_class_p(g, a, n, mode, i); if (u < acc) { pick = i; break; } }
+    atomicAdd(&g.count_i[g.tid[a + pick]], 1ULL);
+  }
+}
+__global__ void k_gibbs_alpha(GibbsDev g, double scale, double* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
+  double v = (g.mu[i] * g.eff[i]) * scale; out[i] = v > 1e-8 ? v : 0.0;
+}
+__global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) o[i] = a[i] * b[i]; }
 
 }  // namespace
 
@@ -391,3 +461,73 @@ extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_i
   return SQ_OK;
 }
 
+
+extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  if (!eq || !txp || !o || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_bootstrap_dev: bad arguments"); return SQ_ERR_ARG; }
+  EmSession S; int rc = S.setup(device, eq, txp, o); if (rc) return rc;
+  const uint32_t M = S.M, E = S.E;
+  std::vector<uint64_t> cum(E); uint64_t total = 0; for (uint32_t c = 0; c < E; ++c) { total += eq->count[c]; cum[c] = total; }
+  std::vector<uint8_t> active(M, 0); for (uint64_t i = 0; i < S.L; ++i) active[eq->tid[i]] = 1;
+  uint32_t nact = 0; for (auto a : active) nact += a;
+  if (nact == 0 || total == 0) { sq_set_error("It seems that no transcripts are expressed; something is likely wrong!"); return SQ_ERR_STATE; }   // :598-602
+  const double scale = 1.0 / (double)nact, totalNumFrags = (double)num_mapped;
+  std::vector<double> init(M), alpha(M); for (uint32_t i = 0; i < M; ++i) init[i] = active[i] ? scale * totalNumFrags : 0.0;   // :605-606
+  DBuf<uint64_t> d_cum; DBuf<unsigned long long> d_samp; if (d_cum.upload(cum) || d_samp.alloc(E)) { sq_set_error("device allocation failed (bootstrap)"); return SQ_ERR_NOMEM; }
+  const int TB = 256;
+  for (uint32_t b = 0; b < B; ++b) {
+    SQ_HIP_CHECK(hipMemsetAsync(d_samp.p, 0, (size_t)E * 8, S.st));
+    uint32_t grid = (uint32_t)std::min<uint64_t>((total + TB - 1) / TB, 65536);
+    k_bs_sample<<<grid, TB, 0, S.st>>>(total, E, d_cum.p, seed, b, d_samp.p);
+    k_u64_to_f64<<<(E + TB - 1) / TB, TB, 0, S.st>>>(E, d_samp.p, S.d_cnt.p);
+    alpha = init; sq_em_report rep;
+    rc = S.run(alpha, 0, 0, /*minIter=*/50, &rep); if (rc) return rc;                                  // :412
+    for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;                             // truncateCountVector (:509-520)
+    double asum = canonical_sum_host(alpha);
+    if (asum < 2.2250738585072014e-308) { sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly."); return SQ_ERR_STATE; }
+    if (cb(alpha.data(), M, user)) break;
+  }
+  return SQ_OK;
+}
+
+extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S_n, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_gibbs_dev: bad arguments"); return SQ_ERR_ARG; }
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): Gibbs has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
+  SQ_HIP_CHECK(hipSetDevice(device));
+  const uint32_t M = txp->num_txp; const uint32_t E = (uint32_t)eq->num_classes; const uint64_t L = eq->num_labels;
+  // prior (CollapsedGibbsSampler.cpp:357-371): 1e-3 per transcript after EM; under VB max(vbPrior,1) per transcript or max(vbPrior,1e-3) per nucleotide
+  const bool perTxp = go->use_vbem ? go->per_transcript_prior != 0 : true;
+  double pv = 1e-3; if (go->use_vbem) pv = perTxp ? (go->vb_prior < 1.0 ? 1.0 : go->vb_prior) : (go->vb_prior < 1e-3 ? 1e-3 : go->vb_prior);
+  std::vector<double> prior(M, pv); if (!perTxp) for (uint32_t i = 0; i < M; ++i) prior[i] = pv * txp->eff_len[i];
+  std::vector<uint8_t> active(M, 0); for (uint64_t i = 0; i < L; ++i) active[eq->tid[i]] = 1;
+  std::vector<double> init(alpha_init, alpha_init + M); for (uint32_t i = 0; i < M; ++i) if (!active[i]) init[i] = 0.0;
+  std::vector<uint64_t> off(eq->off, eq->off + E + 1), cnt(eq->count, eq->count + E), draw_off(E + 1, 0); std::vector<uint32_t> tid(eq->tid, eq->tid + L); std::vector<double> w(eq->w, eq->w + L), eff(txp->eff_len, txp->eff_len + M);
+  std::vector<uint32_t> item_cls, item_s0;
+  for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; uint64_t n = off[c + 1] - off[c]; if (n == 0 || cnt[c] == 0) continue;
+    if (n == 1) { item_cls.push_back(c); item_s0.push_back(0); } else for (uint64_t s0 = 0; s0 < cnt[c]; s0 += 256) { item_cls.push_back(c); item_s0.push_back((uint32_t)s0); } }
+  DBuf<uint64_t> d_off, d_cnt, d_doff; DBuf<uint32_t> d_tid, d_ic, d_is; DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me; DBuf<uint8_t> d_act; DBuf<unsigned long long> d_ci;
+  if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) || d_is.upload(item_s0) || d_w.upload(w) || d_eff.upload(eff) || d_prior.upload(prior) ||
+      d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) || d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
+  GibbsDev g; g.M = M; g.E = E; g.off = d_off.p; g.tid = d_tid.p; g.w = d_w.p; g.cnt = d_cnt.p; g.eff = d_eff.p; g.prior = d_prior.p; g.active = d_act.p; g.mu = d_mu.p; g.count_f = d_cf.p; g.count_i = d_ci.p; g.draw_off = d_doff.p;
+  uint32_t nchains = 1; if (S_n >= 50) nchains = 2; if (S_n >= 100) nchains = 4; if (S_n >= 200) nchains = 8;    // :425-434
+  const uint32_t step = nchains > 1 ? S_n / nchains : S_n + 1;
+  const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16; const int TB = 256; const uint32_t nitems = (uint32_t)item_cls.size();
+  std::vector<double> me(M), alphas(M);
+  for (uint32_t sid = 0; sid < S_n; ++sid) {
+    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpy(d_cf.p, init.data(), (size_t)M * 8, hipMemcpyHostToDevice));   // chain restart (:452-455)
+    for (uint32_t r = 0; r < thin; ++r) {
+      const uint64_t key = (uint64_t)sid * thin + r;
+      k_gibbs_mu<<<(M + TB - 1) / TB, TB>>>(g, seed, key, go->no_gamma_draw);
+      SQ_HIP_CHECK(hipMemsetAsync(d_ci.p, 0, (size_t)M * 8));
+      if (nitems) k_gibbs_items<<<(nitems + TB - 1) / TB, TB>>>(g, nitems, d_ic.p, d_is.p, seed, key);
+      k_u64_to_f64<<<(M + TB - 1) / TB, TB>>>(M, d_ci.p, d_cf.p);
+    }
+    k_mul<<<(M + TB - 1) / TB, TB>>>(M, d_mu.p, d_eff.p, d_me.p);
+    SQ_HIP_CHECK(hipMemcpy(me.data(), d_me.p, (size_t)M * 8, hipMemcpyDeviceToHost));
+    double denom = canonical_sum_host(me);                                                                // :489-492 (order-defined sum)
+    double scale = (double)num_mapped / denom;
+    k_gibbs_alpha<<<(M + TB - 1) / TB, TB>>>(g, scale, d_out.p);
+    SQ_HIP_CHECK(hipMemcpy(alphas.data(), d_out.p, (size_t)M * 8, hipMemcpyDeviceToHost));
+    if (cb(alphas.data(), M, user)) break;
+  }
+  return SQ_OK;
+}

@@ -39,6 +39,8 @@ def lib():
         L.orc_normalize_alphas.argtypes = [C.c_uint32, P(capi.EqTable), vp, vp, vp, vp]
         L.orc_em_optimize.restype = C.c_int; L.orc_em_optimize.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, P(capi.EmReport)]
         L.orc_em_steps.restype = C.c_int; L.orc_em_steps.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, C.c_uint32, vp]
+        L.orc_bootstrap.restype = C.c_int; L.orc_bootstrap.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32, C.c_uint64, C.c_uint64, vp]
+        L.orc_gibbs.restype = C.c_int; L.orc_gibbs.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.GibbsOpts), vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
         L.orc_em_time_iters.restype = C.c_double; L.orc_em_time_iters.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32, C.c_uint32]
         L.orc_canonical_sum.restype = C.c_double; L.orc_canonical_sum.argtypes = [vp, C.c_uint64]
         for f in ("orc_exp", "orc_log", "orc_digamma"):
@@ -150,3 +152,19 @@ def em_steps(eq, eff_len, alpha_in, iters, opts=None):
 def em_time_iters(eq, eff_len, iters, threads, opts=None):
     o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len)
     return lib().orc_em_time_iters(C.byref(t), C.byref(txp), C.byref(o), iters, threads)
+
+
+def bootstrap(eq, eff_len, B, seed, num_mapped, opts=None):
+    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len)
+    out = np.zeros((B, txp.num_txp))
+    rc = lib().orc_bootstrap(C.byref(t), C.byref(txp), C.byref(o), B, seed, num_mapped, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def gibbs(eq, eff_len, alpha_init, S, seed, num_mapped, gopts):
+    t = eq.table(); txp = api.make_txp_in(eff_len)
+    a = np.ascontiguousarray(alpha_init, np.float64); out = np.zeros((S, txp.num_txp))
+    rc = lib().orc_gibbs(C.byref(t), C.byref(txp), C.byref(gopts), a.ctypes.data, S, seed, num_mapped, out.ctypes.data)
+    assert rc == 0
+    return out
