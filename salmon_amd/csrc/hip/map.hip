@@ -12,6 +12,16 @@ namespace {
 const int TB = 256;
 inline uint32_t nblk(uint64_t n) { return (uint32_t)((n + TB - 1) / TB); }
 
+// ids sorted by descending key (20 significant bits)
+int sort_desc(sq_ctx* c, uint32_t n, uint32_t* perm_out) {
+  size_t tmp = 0;
+  hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20, c->stream);
+  if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
+  tmp = c->sort_tmp.n;
+  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(c->sort_tmp.p, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20, c->stream));
+  return SQ_OK;
+}
+
 int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_plus_1) {
   size_t tmp = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n_plus_1, c->stream);
@@ -59,7 +69,7 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
   const uint32_t nends = 2 * max_batch_reads;
   bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
-             c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) || c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
+             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) || c->wid.ensure(nends) || c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) || c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
              c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
              c->stats.ensure(ST_N) || c->gapcost.ensure(SQ_MAX_CHAIN_GAP + 1);
   if (bad) { sq_set_error("device allocation failed in sq_ctx_create"); sq_ctx_free(c); return SQ_ERR_NOMEM; }
@@ -77,7 +87,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   (void)hipSetDevice(c->device);
   sq_online_free(c);
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
-  c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->chains.free_(); c->n_chains.free_();
+  c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->wkey.free_(); c->wkey2.free_(); c->wid.free_(); c->perm_ends.free_(); c->perm_frags.free_(); c->chains.free_(); c->chains_d.free_(); c->chain_off.free_(); c->n_chains.free_();
   c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -108,7 +118,10 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   sq_prof_begin(c);
   k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
   sq_prof_mark(c, SG_PACK);
-  k_seed<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p);
+  {  // persistent grid: 256 CUs x 8 blocks of 256 threads (all resident at 24 VGPRs); lanes pull read ends from counters[2]
+    uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * 8u);
+    k_seed<<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2);
+  }
   sq_prof_mark(c, SG_SEED);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
@@ -133,35 +146,46 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
     skey = c->mkey2.p; sval = c->mval2.p;
     sq_prof_mark(c, SG_SORT);
   }
-  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p, c->n_chains.p, c->stats.p);
+  // (measured: visiting ends / fragments in work-sorted order lost more to scattered access than it gained in balance)
+  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p, c->n_chains.p, c->stats.p, nullptr);
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
+  SQ_HIP_CHECK(hipMemsetAsync(c->n_chains.p + nrec, 0, sizeof(uint32_t), st));
+  rc = exclusive_scan_u32(c, c->n_chains.p, c->chain_off.p, nrec + 1); if (rc) return rc;
+  if (c->chains_d.ensure(MP)) { sq_set_error("device allocation failed (dense chains)"); return SQ_ERR_NOMEM; }   // #chains <= #MEMs
+  k_compact_chains<<<nblk(nrec), TB, 0, st>>>(nrec, c->mem_off.p, c->chain_off.p, c->n_chains.p, c->chains.p, c->chains_d.p);
   sq_prof_mark(c, SG_CHAIN);
-  k_join<false><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, nullptr, nullptr, c->frag_flags.p);
-  sq_prof_mark(c, SG_JOIN_COUNT);
-  SQ_HIP_CHECK(hipMemsetAsync(c->n_cand.p + n, 0, sizeof(uint32_t), st));
-  rc = exclusive_scan_u32(c, c->n_cand.p, c->cand_off.p, n + 1); if (rc) return rc;
+  // single-pass join; candidate blocks come from a global cursor (stats slot reused as the 64-bit cursor)
   uint64_t total_cands = 0;
-  sq_prof_mark(c, SG_SCAN_CANDS);
-  SQ_HIP_CHECK(hipMemcpyAsync(&total_cands, c->cand_off.p + n, 8, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  {
+    size_t cap_guess = std::max<size_t>(c->cands.n, (size_t)n * 8 + 1024);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      if (c->cands.ensure(cap_guess) || c->cand_frag.ensure(cap_guess)) { sq_set_error("device allocation failed for candidates; split the batch"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_CANDS, 0, sizeof(unsigned long long), st));
+      k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->chain_off.p, c->chains_d.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p, c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS);
+      unsigned long long tc = 0;
+      SQ_HIP_CHECK(hipMemcpyAsync(&tc, c->stats.p + ST_CANDS, 8, hipMemcpyDeviceToHost, st));
+      SQ_HIP_CHECK(hipStreamSynchronize(st));
+      total_cands = tc;
+      if (total_cands <= c->cands.n) break;
+      if (attempt == 2) { sq_set_error("candidate array overflow (%llu)", tc); return SQ_ERR_OVERFLOW; }
+      cap_guess = (size_t)total_cands + 1024;
+    }
+  }
+  sq_prof_mark(c, SG_JOIN_FILL);
   c->last_total_cands = total_cands;
   const size_t CP = (size_t)total_cands + 8;
-  // cand_frag shares the mused... no: dedicated buffer (u32 per candidate) carved from cp (int32 per MEM) is not safe; allocate
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
-  if (c->cands.ensure(CP) || c->aln_slots.ensure(CP) || c->aln.ensure(CP) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
+  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || c->aln.ensure(CP) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
   sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
-  if (cand_frag.ensure(CP) || hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
+  if (hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
   ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
   S.mkey = skey; S.mval = sval; S.mnext = c->mnext.p; S.dpq = c->dpq.p; S.counters = c->counters.p; S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
   uint32_t hcount[2] = {0, 0};
   if (total_cands) {
-    k_join<true><<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->frag_flags.p);
-    k_fill_cand_frag<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, cand_frag.p);
-    sq_prof_mark(c, SG_JOIN_FILL);
     for (int attempt = 0; attempt < 2; ++attempt) {
       SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_DP, 0, sizeof(unsigned long long), st));
-      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p, c->stats.p);
+      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains_d.p, c->cands.p, cand_frag.p, c->stats.p);
       sq_prof_mark(c, SG_SCORE);
       SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
@@ -173,7 +197,7 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
     sq_prof_mark(c, SG_DP);
   }
   if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p, tid_arr.p);
-  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p);
+  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains_d.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
   rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) return rc;
@@ -225,20 +249,22 @@ extern "C" int64_t sq_debug_tap(sq_ctx* c, int what, void* buf, uint64_t cap) {
     for (uint64_t i = 0; i < tm && o && i < cap; ++i) { sq_mem x; memset(&x, 0, sizeof(x)); x.end = (uint32_t)(key[i] >> 40); x.tid = (uint32_t)(val[i] >> 32); x.rpos = (int32_t)((key[i] & ((1ULL << 40) - 1)) - racc[x.tid]); x.qpos = (uint16_t)((val[i] >> 10) & 1023); x.len = (uint16_t)(val[i] & 1023); x.fw = (val[i] >> 20) & 1; o[i] = x; }
     return (int64_t)tm;
   }
-  std::vector<uint32_t> nch(nrec); std::vector<sq_chain_dev> ch(tm);
+  std::vector<uint32_t> nch(nrec); std::vector<uint64_t> choff(nrec + 1);
   if (nrec && hipMemcpy(nch.data(), c->n_chains.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
-  if (tm && hipMemcpy(ch.data(), c->chains.p, tm * sizeof(sq_chain_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  if (nrec && hipMemcpy(choff.data(), c->chain_off.p, (size_t)(nrec + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  const uint64_t tch = nrec ? choff[nrec] : 0; std::vector<sq_chain_dev> ch(tch);
+  if (tch && hipMemcpy(ch.data(), c->chains_d.p, tch * sizeof(sq_chain_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   if (what == SQ_TAP_CHAINS) {
     uint64_t cnt = 0; sq_chain* o = (sq_chain*)buf;
-    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nch[e]; ++i) { if (o && cnt < cap) { const sq_chain_dev& d = ch[moff[e] + i]; sq_chain x; memset(&x, 0, sizeof(x)); x.end = e; x.tid = d.tid; x.pos = d.pos; x.last_end = d.last_end; x.fw = d.fw; x.n_mems = d.n_mems; x.score = d.score; o[cnt] = x; } ++cnt; }
+    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nch[e]; ++i) { if (o && cnt < cap) { const sq_chain_dev& d = ch[choff[e] + i]; sq_chain x; memset(&x, 0, sizeof(x)); x.end = e; x.tid = d.tid; x.pos = d.pos; x.last_end = d.last_end; x.fw = d.fw; x.n_mems = d.n_mems; x.score = d.score; o[cnt] = x; } ++cnt; }
     return (int64_t)cnt;
   }
   if (what == SQ_TAP_CANDIDATES) {
-    const uint64_t tc = c->last_total_cands; std::vector<sq_cand_dev> cd(tc); std::vector<uint64_t> coff(n + 1);
+    const uint64_t tc = c->last_total_cands; std::vector<sq_cand_dev> cd(tc); std::vector<uint64_t> coff(n + 1); std::vector<uint32_t> ncd(n);
     if (tc && hipMemcpy(cd.data(), c->cands.p, tc * sizeof(sq_cand_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
-    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     sq_cand* o = (sq_cand*)buf; uint64_t cnt = 0;
-    for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f + 1]; ++i) {
+    for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f] + ncd[f]; ++i) {
       if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0, sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu, hr = d.rc != 0xFFFFFFFFu;
         x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status; x.valid = d.valid; x.lscore = d.lscore; x.rscore = d.rscore; x.frag_len = d.frag_len; o[cnt] = x; }
       ++cnt; }

@@ -83,59 +83,81 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // a1 — MemCollector::operator() (reference call site SalmonQuantify.cpp:1266-1275); SPEC §a1.
+// Lane-level dynamic scheduling: the number of dictionary probes per read end ranges from 1 (a clean
+// read inside one unitig) to ~70 (an unmappable read), and a wave waits for its slowest lane.  So a
+// lane does ONE probe step per loop trip and, when its read end is finished, takes the next one
+// from a global cursor (one atomic per wave via ballot).  The persistent grid keeps every lane busy
+// until the batch is drained; results are keyed by read end, so they do not depend on scheduling.
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
-                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = e < nends;
-  ReadView r = read_view(rpack, rnmask, rlen, act ? e : 0);
-  const int k = (int)P.k, L = act ? r.L : 0;
-  uint32_t nu = 0, np = 0, nlook = 0;
-  sq_unimem_dev* out = um + (size_t)(act ? e : 0) * SQ_MAX_UNIMEMS;
-  if (L >= k) {
-    int pos = 0, skip_until = -1; const int alt = (int)P.alt_skip;
-    while (pos + k <= L && nu < SQ_MAX_UNIMEMS) {
-      uint64_t nb = fetch_bits(r.nm, (uint32_t)pos, (uint32_t)k);
-      if (nb) { pos = pos + (63 - __clzll((long long)nb)) + 1; continue; }
-      uint64_t km = sq_fetch_bases(r.w, (uint64_t)pos, (uint32_t)k);
-      uint64_t u; uint32_t off; int fw;
-      ++nlook;
-      if (!sq_dict_lookup(d, km, &u, &off, &fw)) {
-        if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
-        continue;
+                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor) {
+  const int k = (int)P.k; const int alt = (int)P.alt_skip;
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false;
+  ReadView r; r.w = nullptr; r.nm = nullptr; r.L = 0;
+  int pos = 0, skip_until = -1; uint32_t nu = 0, np = 0;
+  unsigned long long tot_nu = 0, tot_look = 0;
+  sq_unimem_dev* out = nullptr;
+  for (;;) {
+    // refill: every lane without a read end asks for one
+    const unsigned long long want = __ballot(!have && !drained);
+    if (want) {
+      uint32_t base = 0; const int leader = __ffsll((long long)want) - 1;
+      if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(want));
+      base = (uint32_t)__shfl((int)base, leader, 64);
+      if (!have && !drained) {
+        e = base + (uint32_t)__popcll(want & ((1ULL << lane) - 1));
+        if (e >= nends) drained = true;
+        else { have = true; r = read_view(rpack, rnmask, rlen, e); pos = 0; skip_until = -1; nu = 0; np = 0; out = um + (size_t)e * SQ_MAX_UNIMEMS; }
       }
-      const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);
-      int len = k;
-      int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
-      bool mism = false;
-      while (avail > 0) {
-        int c = avail < 32 ? avail : 32;
-        uint64_t rc_ = sq_fetch_bases(r.w, (uint64_t)(pos + len), (uint32_t)c);
-        uint64_t nn = fetch_bits(r.nm, (uint32_t)(pos + len), (uint32_t)c);
-        uint64_t uc;
-        if (fw) uc = sq_fetch_bases(d.useq, ub + off + len, (uint32_t)c);
-        else { int up = (int)off - 1 - (len - k); uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c); }
-        uint64_t x = rc_ ^ uc; uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ULL;
-        int i1 = mm ? (__ffsll((long long)mm) - 1) / 2 : 64; int i2 = nn ? (__ffsll((long long)nn) - 1) : 64;
-        int im = i1 < i2 ? i1 : i2;
-        if (im < c) { len += im; mism = true; break; }
-        len += c; avail -= c;
+    }
+    if (!__ballot(have)) break;
+    if (have) {
+      const int L = r.L; bool done = false;
+      if (!(L >= k && pos + k <= L && nu < SQ_MAX_UNIMEMS)) done = true;
+      else {
+        uint64_t nb = fetch_bits(r.nm, (uint32_t)pos, (uint32_t)k);
+        if (nb) pos = pos + (63 - __clzll((long long)nb)) + 1;
+        else {
+          uint64_t km = sq_fetch_bases(r.w, (uint64_t)pos, (uint32_t)k);
+          uint64_t u; uint32_t off; int fw;
+          ++tot_look;
+          if (!sq_dict_lookup(d, km, &u, &off, &fw)) {
+            if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
+          } else {
+            const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);
+            int len = k;
+            int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
+            bool mism = false;
+            while (avail > 0) {
+              int c = avail < 32 ? avail : 32;
+              uint64_t rc_ = sq_fetch_bases(r.w, (uint64_t)(pos + len), (uint32_t)c);
+              uint64_t nn = fetch_bits(r.nm, (uint32_t)(pos + len), (uint32_t)c);
+              uint64_t uc;
+              if (fw) uc = sq_fetch_bases(d.useq, ub + off + len, (uint32_t)c);
+              else { int up = (int)off - 1 - (len - k); uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c); }
+              uint64_t x = rc_ ^ uc; uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ULL;
+              int i1 = mm ? (__ffsll((long long)mm) - 1) / 2 : 64; int i2 = nn ? (__ffsll((long long)nn) - 1) : 64;
+              int im = i1 < i2 ? i1 : i2;
+              if (im < c) { len += im; mism = true; break; }
+              len += c; avail -= c;
+            }
+            const bool rend = (pos + len >= L);
+            const bool uend = !rend && !mism;
+            sq_unimem_dev m; m.unitig = (uint32_t)u; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.fw = (uint8_t)fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
+            m.pad[0] = m.pad[1] = m.pad[2] = 0;
+            out[nu++] = m;
+            uint64_t occ = ctab_off[u + 1] - ctab_off[u];
+            if (occ <= P.max_occ) np += (uint32_t)occ;
+            if (rend) done = true;
+            else { int ee = pos + len; pos = pos + len - k + 1; skip_until = uend ? -1 : ee + 1; }
+          }
+        }
       }
-      bool rend = (pos + len >= L);
-      bool uend = !rend && !mism;
-      sq_unimem_dev m; m.unitig = (uint32_t)u; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.fw = (uint8_t)fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
-      m.pad[0] = m.pad[1] = m.pad[2] = 0;
-      out[nu++] = m;
-      uint64_t occ = ctab_off[u + 1] - ctab_off[u];
-      if (occ <= P.max_occ) np += (uint32_t)occ;
-      if (rend) break;
-      int ee = pos + len;
-      pos = pos + len - k + 1;
-      skip_until = uend ? -1 : ee + 1;
+      if (done) { n_uni[e] = nu; n_proj[e] = np; tot_nu += nu; have = false; }
     }
   }
-  if (act) { n_uni[e] = nu; n_proj[e] = np; }
-  wave_stat_add(&stats[ST_SEEDS], nu); wave_stat_add(&stats[ST_LOOKUPS], nlook);
+  wave_stat_add(&stats[ST_SEEDS], tot_nu); wave_stat_add(&stats[ST_LOOKUPS], tot_look);
 }
 
 // val layout: len[0,10) q[10,20) fw[20] tid[32,64)
@@ -172,12 +194,21 @@ __global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off,
 }
 
 // a2b — findChains / findOptChain; SPEC §a2.
-__global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost, uint32_t nends,
+// A transcript's MEMs for one read end are almost always a handful: groups of <= CH_SMALL MEMs run
+// the DP entirely in LDS (thread-private columns, [slot][thread] layout, no bank conflicts) and hand
+// the chain's members on as a bit mask, so nothing but the chain record is written to HBM.  Larger
+// groups use the HBM scratch arrays (f, prev, flags, next links).
+#define CH_SMALL 8
+#define CH_TB 256
+__global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost, uint32_t nends,
                         const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ mval,
                         double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
-                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = e < nends;
+                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
+  __shared__ double s_f[CH_SMALL][CH_TB]; __shared__ int32_t s_r[CH_SMALL][CH_TB]; __shared__ int16_t s_q[CH_SMALL][CH_TB]; __shared__ int16_t s_len[CH_SMALL][CH_TB]; __shared__ int8_t s_p[CH_SMALL][CH_TB];
+  const uint32_t tx = threadIdx.x;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = gid < nends;
+  const uint32_t e = act ? (perm ? perm[gid] : gid) : 0;   // optional work-balancing permutation
   const uint64_t base = act ? mem_off[e] : 0; const uint32_t n = act ? (uint32_t)(mem_off[e + 1] - base) : 0;
   const int L = act ? rlen[e] : 0;
   uint32_t nch = 0; double bestAll = 0.0;
@@ -185,6 +216,45 @@ __global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
   while (g0 < n) {
     const uint32_t tid0 = (uint32_t)(mval[base + g0] >> 32);
     uint32_t g1 = g0; while (g1 < n && (uint32_t)(mval[base + g1] >> 32) == tid0) ++g1;
+    const uint32_t gn = g1 - g0;
+    if (gn <= CH_SMALL) {
+      uint32_t fwbits = 0;
+      for (uint32_t i = 0; i < gn; ++i) { MemD m = mem_decode(mkey[base + g0 + i], mval[base + g0 + i], ref_accum); s_r[i][tx] = m.rpos; s_q[i][tx] = (int16_t)m.q; s_len[i][tx] = (int16_t)m.len; if (m.fw) fwbits |= 1u << i; }
+      double best = 0.0;
+      for (uint32_t i = 0; i < gn; ++i) {
+        const int qi = s_q[i][tx], ri = s_r[i][tx], li = s_len[i][tx]; const bool fwi = (fwbits >> i) & 1;
+        double fi = (double)li; int pi = -1; int rounds = 2;
+        for (int j = (int)i - 1; j >= 0; --j) {
+          if ((((fwbits >> j) & 1) != 0) != fwi) continue;
+          int qd = qi - s_q[j][tx], rd = ri - s_r[j][tx];
+          if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
+          int l = abs(qd - rd);
+          double a = (double)min(li, min(qd, rd));
+          double sc = s_f[j][tx] + a - gapcost[l];
+          if (sc > fi) { fi = sc; pi = j; }
+          if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
+        }
+        s_f[i][tx] = fi; s_p[i][tx] = (int8_t)pi;
+        if (fi > best) best = fi;
+      }
+      const double thr = P.pre_thr * best;
+      uint32_t used = 0, tried = 0;
+      for (;;) {
+        int bi = -1; double bf = 0.0;
+        for (uint32_t i = 0; i < gn; ++i) { if (((used | tried) >> i) & 1) continue; double fv = s_f[i][tx]; if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; } }
+        if (bi < 0) break;
+        uint32_t mask = 0; bool clash = false;
+        for (int x = bi; x >= 0; x = s_p[x][tx]) { if ((used >> x) & 1) { clash = true; break; } mask |= 1u << x; }
+        if (clash) { tried |= 1u << bi; continue; }
+        used |= mask;
+        const int first = __ffs((int)mask) - 1;
+        sq_chain_dev c; c.score = bf; c.tid = tid0; c.pos = s_r[first][tx] - s_q[first][tx]; c.last_end = s_r[bi][tx] + s_len[bi][tx]; c.first = g0; c.n_mems = (uint16_t)__popc(mask); c.read_len = (uint16_t)L;
+        c.fw = (fwbits >> bi) & 1; c.pad[0] = 1; c.pad[1] = c.pad[2] = 0; c.pad2 = mask;   // pad[0] = 1: members are the bits of pad2 relative to `first`
+        chains[base + nch++] = c;
+        if (bf > bestAll) bestAll = bf;
+      }
+      g0 = g1; continue;
+    }
     double best = 0.0;
     for (uint32_t i = g0; i < g1; ++i) {
       MemD hi = mem_decode(mkey[base + i], mval[base + i], ref_accum);
@@ -229,6 +299,27 @@ __global__ void k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
   for (uint32_t i = 0; i < nch; ++i) { sq_chain_dev c = chains[base + i]; if (c.score < cthr) continue; chains[base + kept++] = c; }
   if (act) n_chains[e] = kept;
   wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept);
+}
+
+// work-balancing permutations: sort item ids by a cheap work estimate (descending) so a wave's 64 lanes
+// finish together; the heavy tail (repeat families) otherwise pins whole waves for ~1 ms
+__global__ void k_work_keys_ends(uint32_t nends, const uint64_t* __restrict__ mem_off, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= nends) return;
+  uint64_t n = mem_off[e + 1] - mem_off[e]; keys[e] = (uint32_t)(n > 0xFFFFFu ? 0xFFFFFu : n); ids[e] = e;
+}
+__global__ void k_work_keys_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; if (f >= nfrag) return;
+  uint32_t n = paired ? n_chains[2 * f] + n_chains[2 * f + 1] : n_chains[f]; keys[f] = n > 0xFFFFFu ? 0xFFFFFu : n; ids[f] = f;
+}
+
+// chains are produced into per-end slabs sized by the MEM count (sparse); pack them densely so that a
+// fragment's chains are one contiguous run (k_join streams them several times)
+__global__ void k_compact_chains(uint32_t nends, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ chain_off, const uint32_t* __restrict__ n_chains,
+                                 const sq_chain_dev* __restrict__ sparse, sq_chain_dev* __restrict__ dense) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nends) return;
+  const sq_chain_dev* s = sparse + mem_off[e]; sq_chain_dev* d = dense + chain_off[e];
+  for (uint32_t i = 0; i < n_chains[e]; ++i) d[i] = s[i];
 }
 
 // a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.
@@ -288,25 +379,75 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
   return cnt;
 }
 
-template <bool FILL>
-__global__ void k_join(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ mem_off, const sq_chain_dev* __restrict__ chains, const uint32_t* __restrict__ n_chains,
-                       uint32_t* __restrict__ n_cand, const uint64_t* __restrict__ cand_off, sq_cand_dev* __restrict__ cands, uint8_t* __restrict__ frag_flags) {
-  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nfrag) return;
-  sq_cand_dev* out = FILL ? cands + cand_off[f] : nullptr;
-  uint32_t cnt = 0; bool dove = false;
-  if (paired) {
-    uint32_t e0 = 2 * f, e1 = 2 * f + 1;
-    uint64_t lb = mem_off[e0], rb = mem_off[e1];
-    cnt = join_fragment<FILL>(P, chains + lb, n_chains[e0], (uint32_t)lb, chains + rb, n_chains[e1], (uint32_t)rb, out, &dove);
-  } else {  // joinReadsAndFilterSingle: every surviving chain is a candidate
-    uint64_t lb = mem_off[f]; uint32_t nl = n_chains[f];
-    for (uint32_t a = 0; a < nl; ++a) {
-      if (FILL) { const sq_chain_dev& ch = chains[lb + a]; cand_init(out[cnt], ch.score, ch.tid, (uint32_t)lb + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END); }
-      ++cnt;
+// Single-pass join: the chains of a fragment are read from HBM once.  Concordant pairs (almost always
+// < 8 per fragment) are held in registers for the consensus / post-merge filters; the candidate block of
+// the fragment is carved out of one global array with a wave-aggregated cursor (one atomic per wave), so
+// there is no count kernel, no scan and no second enumeration.  Fragments with more than JP pairs, and
+// orphan-only fragments, fall back to the multi-pass enumeration of join_fragment<>.
+#define JP 8
+__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains, const uint32_t* __restrict__ n_chains,
+                        uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag, uint64_t cand_cap,
+                        uint8_t* __restrict__ frag_flags, unsigned long long* __restrict__ cursor) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = f < nfrag;
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t cnt = 0; bool dove = false; int mode = 0;   // mode 1: pairs in registers, 2: multi-pass pairs, 3: orphans, 4: single-end
+  double pc[JP]; uint32_t pt[JP], pa[JP], pb[JP], pf[JP]; uint32_t np = 0; double best = -1.0;
+  const sq_chain_dev* lc = nullptr; const sq_chain_dev* rc = nullptr; uint32_t nl = 0, nr = 0, lbase = 0, rbase = 0;
+#pragma unroll
+  for (int i = 0; i < JP; ++i) { pc[i] = 0.0; pt[i] = 0; pa[i] = 0; pb[i] = 0; pf[i] = 0; }
+  if (act && paired) {
+    const uint32_t e0 = 2 * f, e1 = 2 * f + 1;
+    lbase = (uint32_t)chain_off[e0]; rbase = (uint32_t)chain_off[e1]; nl = n_chains[e0]; nr = n_chains[e1];
+    lc = chains + lbase; rc = chains + rbase;
+    for (uint32_t i = 0, j = 0; i < nl && j < nr;) {
+      const uint32_t ti = lc[i].tid, tj = rc[j].tid;
+      if (ti < tj) { ++i; continue; }
+      if (ti > tj) { ++j; continue; }
+      uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
+      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
+        int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue;
+        const double cov = lc[a].score + rc[b].score; if (cov > best) best = cov;
+#pragma unroll
+        for (int q = 0; q < JP; ++q) if ((uint32_t)q == np) { pc[q] = cov; pt[q] = ti; pa[q] = a; pb[q] = b; pf[q] = (uint32_t)fl; }
+        ++np;
+      }
+      i = i1; j = j1;
     }
-  }
-  if (!FILL) { n_cand[f] = cnt; frag_flags[f] = (uint8_t)((dove ? 1 : 0)); }
+    if (np > JP) { mode = 2; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &d2); }
+    else if (np > 0) {
+      mode = 1;
+      const double thr = P.consensus_frac * best;
+#pragma unroll
+      for (int q = 0; q < JP; ++q) {
+        bool keep = (uint32_t)q < np && pc[q] >= thr;
+        if (keep) { double bt = 0.0;
+#pragma unroll
+          for (int z = 0; z < JP; ++z) if ((uint32_t)z < np && pt[z] == pt[q] && pc[z] >= thr && pc[z] > bt) bt = pc[z];
+          keep = pc[q] >= P.post_thr * bt; }
+        if (keep) ++cnt; else if ((uint32_t)q < np) pf[q] = 0xFFFFFFFFu;   // dropped
+      }
+    } else if (P.allow_orphans && (nl || nr)) { mode = 3; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &d2); }
+  } else if (act) { mode = 4; lbase = (uint32_t)chain_off[f]; nl = n_chains[f]; lc = chains + lbase; cnt = nl; }
+  // block allocation: exclusive prefix of cnt over the wave + one atomic
+  uint32_t incl = cnt;
+  for (int sft = 1; sft < 64; sft <<= 1) { uint32_t o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
+  const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
+  unsigned long long base = 0;
+  if (lane == 0 && wave_total) base = atomicAdd(cursor, (unsigned long long)wave_total);
+  base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+  const uint64_t start = base + (incl - cnt);
+  if (!act) return;
+  n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0);
+  if (cnt == 0 || start + cnt > cand_cap) return;   // overflow: the host re-runs with a larger array
+  sq_cand_dev* out = cands + start;
+  if (mode == 1) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int q = 0; q < JP; ++q) if ((uint32_t)q < np && pf[q] != 0xFFFFFFFFu) { cand_init(out[w], pc[q], pt[q], lbase + pa[q], rbase + pb[q], pf[q], SQ_MS_PAIRED_END_PAIRED); ++w; }
+  } else if (mode == 2 || mode == 3) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); }
+  else if (mode == 4) { for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END); }
+  for (uint32_t i = 0; i < cnt; ++i) cand_frag[start + i] = f;
 }
 
 // ---- a4 scoring --------------------------------------------------------------------------------
@@ -382,7 +523,7 @@ __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S,
     const bool queue = pass == 1;
     const int64_t fast_total = score; const int64_t ub_total = ub_dp;
     if (queue) { score = 0; }
-    int prevQ = 0, prevR = 0; bool first = true; uint32_t mi = ch.first; int64_t sc_fast = 0; int64_t ub = 0;
+    int prevQ = 0, prevR = 0; bool first = true; const bool by_mask = ch.pad[0] != 0; uint32_t mbits = ch.pad2; uint32_t mi = by_mask ? ch.first + (uint32_t)(__ffs((int)mbits) - 1) : ch.first; int64_t sc_fast = 0; int64_t ub = 0;
     auto region = [&](int mode, int qstart, int qdir, int n, int64_t tstart, int tdir, int tl) {
       int32_t sc;
       // budget for this region: minacc - (everything else at its best)
@@ -402,7 +543,7 @@ __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S,
         if (use) { int gq = qs - prevQ, gr = rs - prevR; if (gq > 0 || gr > 0) region(0, prevQ, 1, gq, g + prevR, 1, gr); }
       }
       if (use) { sc_fast += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
-      mi = S.mnext[mem_base + mi];
+      if (by_mask) { mbits &= mbits - 1; mi = ch.first + (uint32_t)(__ffs((int)mbits) - 1); } else mi = S.mnext[mem_base + mi];
     }
     if (prevQ < L) { int tail = L - prevQ; int we = min(Tlen, prevR + tail + SQ_REF_EXTEND); int tl = max(0, we - prevR); region(1, prevQ, 1, tail, g + prevR, 1, tl); }
     score = sc_fast; ub_dp = ub;
@@ -559,13 +700,14 @@ __global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_
   hs_out[ci] = ok ? ((hasL && hasR) ? ls + rs : (hasL ? ls : rs)) : (SQ_INVALID_SCORE + 1);
 }
 
-__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
+__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand, const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
                          const uint32_t* __restrict__ tid_arr, const sq_chain_dev* __restrict__ chains,
                          const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln, uint8_t* __restrict__ map_type,
-                         unsigned long long* __restrict__ stats) {
-  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = f < nfrag;
-  const uint64_t c0 = act ? cand_off[f] : 0; const uint32_t nc = act ? (uint32_t)(cand_off[f + 1] - c0) : 0;
+                         unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = gid < nfrag;
+  const uint32_t f = act ? (perm ? perm[gid] : gid) : 0;
+  const uint64_t c0 = act ? cand_off[f] : 0; const uint32_t nc = act ? n_cand[f] : 0;
   const sq_cand_dev* C = cands + c0; const int32_t* HS = hs_arr + c0; const uint32_t* TID = tid_arr + c0;
   const uint32_t e0 = act ? (paired ? 2 * f : f) : 0;
   const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
@@ -644,12 +786,6 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
   wave_stat_add(&stats[ST_MAPPED], na ? 1 : 0);
   wave_stat_add(&stats[ST_JOINT], nc ? 1 : 0);
   wave_stat_add(&stats[ST_DOVETAIL], (act && !nc && (frag_flags[f] & 1)) ? 1 : 0);
-}
-
-__global__ void k_fill_cand_frag(uint32_t nfrag, const uint64_t* __restrict__ cand_off, uint32_t* __restrict__ cand_frag) {
-  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nfrag) return;
-  for (uint64_t i = cand_off[f]; i < cand_off[f + 1]; ++i) cand_frag[i] = f;
 }
 
 __global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ n_aln,

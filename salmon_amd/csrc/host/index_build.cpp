@@ -206,6 +206,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     T.aux[kslot(s)] = (uint32_t)u;  // now: unitig id
   }
   const uint64_t pool_nt = idx->uoff[U];
+  if (pool_nt >= (1ULL << SQ_APOS_BITS)) { sq_set_error("unitig pool too large (%llu nt)", (unsigned long long)pool_nt); return SQ_ERR_OVERFLOW; }
   idx->useq.assign((pool_nt + 31) / 32 + 2, 0);
   sq_parallel_for(U, nthreads, 4096, [&](uint64_t b, uint64_t e, uint32_t) {
     for (uint64_t u = b; u < e; ++u) {
@@ -264,7 +265,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       for (uint32_t p = 0; p < nk; ++p) {
         uint32_t bj = p; uint64_t bh = hv[p];
         for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh) { bh = hv[j]; bj = j; }  // leftmost minimum
-        if (bj != prev) { out.push_back({cv[bj], (u << SQ_UOFF_BITS) | bj, p, 1}); prev = bj; }
+        if (bj != prev) { out.push_back({cv[bj], (u << SQ_APOS_BITS) | (ub + bj), p, 1}); prev = bj; }
         else out.back().nk++;
       }
     }
@@ -356,11 +357,11 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     for (uint64_t i = a; i < b; ++i) idx->entries.push_back(ents[i].e);
     if (cnt > SQ_SKEW_THRESH) {
       for (uint64_t i = a; i < b; ++i) {
-        uint64_t u = ents[i].e >> SQ_UOFF_BITS;
+        uint64_t u = ents[i].e >> SQ_APOS_BITS;
         for (uint32_t q = 0; q < ents[i].nk; ++q) {
           uint64_t st = ents[i].kstart + q;
           uint64_t f = sq_fetch_bases(up, idx->uoff[u] + st, k), r = sq_revcomp(f, k);
-          skew_k.push_back(f < r ? f : r); skew_v.push_back((u << SQ_UOFF_BITS) | st);
+          skew_k.push_back(f < r ? f : r); skew_v.push_back((u << SQ_APOS_BITS) | (idx->uoff[u] + st));
         }
       }
     }

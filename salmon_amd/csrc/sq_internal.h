@@ -14,7 +14,7 @@
 #include "../../include/sq_math.h"
 
 #define SQ_INDEX_MAGIC 0x3158444951535153ULL /* "SQSQIDX1" */
-#define SQ_INDEX_VERSION 3u
+#define SQ_INDEX_VERSION 4u
 #define SQ_SKEW_THRESH 32u
 #define SQ_MPHF_LAMBDA 4.0
 #define SQ_MPHF_ALPHA 0.90
@@ -74,9 +74,9 @@ struct sq_dict_view {
   const uint32_t* part_bkt_off;   // [n_parts+1]
   const uint16_t* pilots;         // [sum buckets]
   const uint64_t* slots;          // [sum slots]
-  const uint64_t* entries;        // list entries: unitig<<30 | minimizer offset
+  const uint64_t* entries;        // list entries: unitig<<33 | minimizer pool position
   const uint64_t* skew_keys;      // open addressing, canonical k-mer or ~0
-  const uint64_t* skew_vals;      // unitig<<30 | k-mer start offset
+  const uint64_t* skew_vals;      // unitig<<33 | k-mer start pool position
   uint64_t skew_mask;             // capacity-1 (0 if no skew table)
   const uint64_t* useq;           // string pool
   const uint64_t* uoff;           // [U+1]
@@ -95,24 +95,26 @@ SQ_HD uint64_t sq_mphf_slot(const sq_dict_view& d, uint64_t minimizer) {
   return s0 + sq_fastrange32((uint32_t)(h2 >> 32), ns);
 }
 
-// A minimizer occurrence is stored as (unitig id, offset of the minimizer inside the unitig):
-//   entry = unitig << SQ_UOFF_BITS | offset          (60 bits)
-// so a candidate k-mer start is checked against the unitig's own length without any search.
-#define SQ_UOFF_BITS 30
-#define SQ_UOFF_MASK ((1ULL << SQ_UOFF_BITS) - 1)
-#define SQ_ENT_MASK ((1ULL << 60) - 1)
+// A minimizer occurrence is stored as (unitig id, ABSOLUTE pool position of the minimizer):
+//   entry = unitig << SQ_APOS_BITS | pool position          (63 bits)
+// so after the slot record arrives, the pool words and the unitig bounds (uoff[u], uoff[u+1]) can be
+// fetched in parallel: the dependent chain of a lookup is pilot -> slot -> {pool, bounds}.
+#define SQ_APOS_BITS 33
+#define SQ_APOS_MASK ((1ULL << SQ_APOS_BITS) - 1)
+#define SQ_ENT_MASK ((1ULL << 63) - 1)
+#define SQ_UOFF_BITS 30   /* unitig ids and in-unitig offsets stay below 2^30 */
 
-// Try one candidate: k-mer starting at offset `st` of unitig u. Returns 1 if the pool holds `kmer`
-// (fw) or `rc` there.
-SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t u, int64_t st,
+// Try one candidate: k-mer starting at pool position `sp` inside unitig u. Returns 1 if the pool holds
+// `kmer` (fw) or `rc` there and the k-mer lies inside the unitig.
+SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t u, int64_t sp,
                       uint64_t* unitig, uint32_t* off, int* fw) {
-  if (st < 0) return 0;
-  uint64_t b = d.uoff[u], e = d.uoff[u + 1];
-  if (b + (uint64_t)st + d.k > e) return 0;
-  uint64_t s = sq_fetch_bases(d.useq, b + (uint64_t)st, d.k);
+  if (sp < 0) return 0;
+  const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
+  const uint64_t s = sq_fetch_bases(d.useq, (uint64_t)sp, d.k);   // independent of the bounds loads
+  if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
   int f;
   if (s == kmer) f = 1; else if (s == rc) f = 0; else return 0;
-  *unitig = u; *off = (uint32_t)st; *fw = f;
+  *unitig = u; *off = (uint32_t)((uint64_t)sp - b); *fw = f;
   return 1;
 }
 
@@ -138,7 +140,7 @@ SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig,
         if (kk == ~0ULL) return 0;
         if (kk == can) {
           uint64_t v = d.skew_vals[h] & SQ_ENT_MASK;
-          return sq_dict_try(d, kmer, rc, v >> SQ_UOFF_BITS, (int64_t)(v & SQ_UOFF_MASK), unitig, off, fw);
+          return sq_dict_try(d, kmer, rc, v >> SQ_APOS_BITS, (int64_t)(v & SQ_APOS_MASK), unitig, off, fw);
         }
         h = (h + 1) & d.skew_mask;
       }
@@ -151,8 +153,8 @@ SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig,
     uint64_t c = a < b ? a : b;
     if (c != mini) continue;
     for (uint64_t e = 0; e < nent; ++e) {
-      uint64_t u = (ent[e] & SQ_ENT_MASK) >> SQ_UOFF_BITS;
-      int64_t A = (int64_t)(ent[e] & SQ_UOFF_MASK);  // minimizer offset in the unitig
+      uint64_t u = (ent[e] & SQ_ENT_MASK) >> SQ_APOS_BITS;
+      int64_t A = (int64_t)(ent[e] & SQ_APOS_MASK);  // minimizer position in the pool
       // same strand: k-mer starts at A - j ; opposite strand: starts at A - (w - j)
       if (sq_dict_try(d, kmer, rc, u, A - (int64_t)j, unitig, off, fw)) return 1;
       if (j != w - j && sq_dict_try(d, kmer, rc, u, A - (int64_t)(w - j), unitig, off, fw)) return 1;
