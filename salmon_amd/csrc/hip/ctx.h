@@ -79,15 +79,23 @@ struct sq_ctx {
   // online model + eq table
   sq_online_dev* online = nullptr; sq_eq_dev* eq = nullptr;
   uint64_t reads_seen = 0;
+  // eq stage runs on its own stream so the online model of batch b overlaps the mapping of batch b+1;
+  // alignments are double-buffered (alnb[2], aln_offb[2]) and handed over with events
+  hipStream_t stream2 = nullptr; hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr}; int cur_buf = 0, last_buf = 0; bool eq_pending[2] = {false, false};
+  sq_dbuf<sq_aln> aln_b1; sq_dbuf<uint64_t> aln_off_b1;
+  sq_aln* aln_ptr(int b) { return b ? aln_b1.p : aln.p; }
+  uint64_t* aln_off_ptr(int b) { return b ? aln_off_b1.p : aln_off.p; }
+  std::vector<hipEvent_t> prof_ev2; std::vector<int> prof_stage2;
   // stage profiling
   bool prof_on = false; std::vector<hipEvent_t> prof_ev; std::vector<int> prof_stage; double stage_ms[32] = {0}; uint64_t stage_calls[32] = {0};
 };
 
 enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP, SG_SELECT, SG_COMPACT,
        SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_NUM };
-void sq_prof_mark(sq_ctx* c, int stage);   // records an event: time since the previous mark is charged to `stage`
-void sq_prof_begin(sq_ctx* c);
-void sq_prof_end(sq_ctx* c);               // call after the stream has been synchronised
+void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream)
+void sq_prof_begin(sq_ctx* c, int which = 0);
+void sq_prof_end(sq_ctx* c, int which = 0);               // call after the stream has been synchronised
+int sq_eq_sync(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };

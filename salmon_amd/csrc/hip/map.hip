@@ -45,14 +45,19 @@ void fill_params(sq_ctx* c) {
 
 static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score", "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table"};
-void sq_prof_begin(sq_ctx* c) { if (!c->prof_on) return; c->prof_stage.clear(); size_t need = 1; if (c->prof_ev.size() < need) { hipEvent_t e; hipEventCreate(&e); c->prof_ev.push_back(e); } hipEventRecord(c->prof_ev[0], c->stream); c->prof_stage.push_back(-1); }
-void sq_prof_mark(sq_ctx* c, int stage) { if (!c->prof_on) return; size_t i = c->prof_stage.size(); if (c->prof_ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); c->prof_ev.push_back(e); } hipEventRecord(c->prof_ev[i], c->stream); c->prof_stage.push_back(stage); }
-void sq_prof_end(sq_ctx* c) { if (!c->prof_on) return; for (size_t i = 1; i < c->prof_stage.size(); ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->prof_ev[i - 1], c->prof_ev[i]) == hipSuccess) { c->stage_ms[c->prof_stage[i]] += ms; c->stage_calls[c->prof_stage[i]]++; } } c->prof_stage.clear(); }
+void sq_prof_begin(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? c->stream2 : c->stream;
+  if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(-1); }
+void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? c->stream2 : c->stream;
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
+void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
+  for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
 extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) { if (!c) return SQ_ERR_ARG; c->prof_on = on != 0; return SQ_OK; }
 extern "C" int sq_ctx_num_stages(void) { return SG_NUM; }
 extern "C" const char* sq_ctx_stage_name(int s) { return (s >= 0 && s < SG_NUM) ? kStageNames[s] : nullptr; }
 extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int reset) {
   if (!c) return SQ_ERR_ARG;
+  (void)sq_eq_sync(c);
   for (int i = 0; i < SG_NUM; ++i) { if (ms) ms[i] = c->stage_ms[i]; if (calls) calls[i] = c->stage_calls[i]; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
   return SQ_OK;
 }
@@ -65,12 +70,13 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
   SQ_HIP_CHECK(hipSetDevice(device));
   sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads;
   fill_params(c);
-  SQ_HIP_CHECK(hipStreamCreate(&c->stream));
+  SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
+  for (int b = 0; b < 2; ++b) { SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_map_done[b], hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming)); }
   const uint32_t nends = 2 * max_batch_reads;
   bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
              c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) || c->wid.ensure(nends) || c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) || c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
-             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
+             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) || c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
              c->stats.ensure(ST_N) || c->gapcost.ensure(SQ_MAX_CHAIN_GAP + 1);
   if (bad) { sq_set_error("device allocation failed in sq_ctx_create"); sq_ctx_free(c); return SQ_ERR_NOMEM; }
   // chaining gap-cost table: 0.01*avgSeed*l + 0.5*log2(l) (SPEC §a2), built with the shared deterministic log
@@ -85,11 +91,15 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   sq_online_free(c);
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
   c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->wkey.free_(); c->wkey2.free_(); c->wid.free_(); c->perm_ends.free_(); c->perm_frags.free_(); c->chains.free_(); c->chains_d.free_(); c->chain_off.free_(); c->n_chains.free_();
-  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_();
+  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_(); c->aln_b1.free_(); c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  for (int b = 0; b < 2; ++b) { if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]); if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -101,7 +111,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   SQ_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   c->have_batch = false;
-  if (n == 0) { c->last_n = 0; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
+  const int buf = c->cur_buf;
+  if (n == 0) { c->last_n = 0; c->last_buf = buf; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
   // ---- stage reads in HBM ----
   const uint8_t* d_seq; const uint64_t* d_seq_off;
   if (in->on_device) { d_seq = in->seq; d_seq_off = in->seq_off; }
@@ -175,7 +186,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   c->last_total_cands = total_cands;
   const size_t CP = (size_t)total_cands + 8;
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
-  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || c->aln.ensure(CP) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
+  if (c->eq_pending[buf]) { SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf])); c->eq_pending[buf] = false; }   // the eq stage that read this buffer two batches ago
+  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
   sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
   if (hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
   ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
@@ -200,15 +212,16 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains_d.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
-  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off.p, n + 1); if (rc) return rc;
-  k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off.p, c->n_aln.p, c->aln_slots.p, c->aln.p);
+  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off_ptr(buf), n + 1); if (rc) return rc;
+  k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off_ptr(buf), c->n_aln.p, c->aln_slots.p, c->aln_ptr(buf));
+  SQ_HIP_CHECK(hipEventRecord(c->ev_map_done[buf], st));
   sq_prof_mark(c, SG_COMPACT);
   uint64_t total_aln = 0; unsigned long long hst[ST_N];
-  SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off.p + n, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off_ptr(buf) + n, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   sq_prof_end(c);
-  c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true;
+  c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true; c->last_buf = buf; c->cur_buf = buf ^ 1;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->num_reads = n; stats->num_mapped_at_least_a_kmer = hst[ST_KMER]; stats->num_with_joint_hits = hst[ST_JOINT]; stats->num_mapped = hst[ST_MAPPED]; stats->num_alignments = hst[ST_ALNS];
@@ -218,8 +231,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   if (out) {
     if (!out->read_off || (!out->aln && total_aln)) { sq_set_error("sq_map_batch: output arrays missing"); return SQ_ERR_ARG; }
     if (total_aln > out->aln_cap) { sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total_aln, (unsigned long long)out->aln_cap); return SQ_ERR_OVERFLOW; }
-    SQ_HIP_CHECK(hipMemcpy(out->read_off, c->aln_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
-    if (total_aln) SQ_HIP_CHECK(hipMemcpy(out->aln, c->aln.p, (size_t)total_aln * sizeof(sq_aln), hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(out->read_off, c->aln_off_ptr(buf), (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+    if (total_aln) SQ_HIP_CHECK(hipMemcpy(out->aln, c->aln_ptr(buf), (size_t)total_aln * sizeof(sq_aln), hipMemcpyDeviceToHost));
     if (out->map_type) SQ_HIP_CHECK(hipMemcpy(out->map_type, c->map_type.p, n, hipMemcpyDeviceToHost));
     out->n = n;
   }

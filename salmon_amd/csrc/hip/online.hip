@@ -561,23 +561,34 @@ static int check_eq_overflow(sq_ctx* c) {
   return SQ_OK;
 }
 
+int sq_eq_sync(sq_ctx* c) {
+  if (!c || !c->stream2) return SQ_OK;
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  SQ_HIP_CHECK(hipStreamSynchronize(c->stream2));
+  c->eq_pending[0] = c->eq_pending[1] = false;
+  sq_prof_end(c, 1);
+  return check_eq_overflow(c);
+}
+
 extern "C" int sq_eq_accumulate(sq_ctx* c) {
   if (!c || !c->have_batch) { sq_set_error("sq_eq_accumulate: call sq_map_batch first"); return SQ_ERR_STATE; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
-  sq_online_dev* o = c->online; hipStream_t st = c->stream; const uint32_t n = c->last_n; const sq_quant_opts& q = c->opts;
+  sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t n = c->last_n; const sq_quant_opts& q = c->opts;
+  const int buf = c->last_buf; const sq_aln* d_aln = c->aln_ptr(buf); const uint64_t* d_aln_off = c->aln_off_ptr(buf);
   c->have_batch = false;
   if (n == 0) return SQ_OK;
+  SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)c->last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
-  sq_prof_begin(c);
-  if (c->last_total_aln) k_pre_aln<<<nblk(c->last_total_aln), TB, 0, st>>>(c->last_total_aln, c->aln.p, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
+  sq_prof_begin(c, 1);
+  if (c->last_total_aln) k_pre_aln<<<nblk(c->last_total_aln), TB, 0, st>>>(c->last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
-  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, c->aln_off.p, c->aln.p, q, o->assigned_flag.p);
+  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, d_aln_off, d_aln, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
     if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
-  sq_prof_mark(c, SG_EQ_FLAGS);
+  sq_prof_mark(c, SG_EQ_FLAGS, 1);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
@@ -594,7 +605,7 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
     const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
     const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
     const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, c->aln_off.p, c->aln.p, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p);
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p);
     k_apply_mass<<<nblk(o->M), TB, 0, st>>>(V, logFM, assigned_after, burned_host ? 1 : 0);
     if (!burned_host) k_apply_fld<<<1, 1024, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags);
     if (!burned_host && assigned_after >= q.num_burnin_frags) {
@@ -605,20 +616,20 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
     }
     o->batch_no++;
   }
-  sq_prof_mark(c, SG_EQ_MINIBATCH);
+  sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
   // eq-class table: insert labels, then add counts / fixed-point weights
   EqView T = make_eq_view(o);
-  k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, c->aln.p, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
-  k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, c->aln_off.p, o->abin.p, o->awq.p, o->rslot.p);
-  sq_prof_mark(c, SG_EQ_TABLE);
-  SQ_HIP_CHECK(hipStreamSynchronize(st));
-  sq_prof_end(c);
+  k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
+  k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
+  sq_prof_mark(c, SG_EQ_TABLE, 1);
+  SQ_HIP_CHECK(hipEventRecord(c->ev_eq_done[buf], st)); c->eq_pending[buf] = true;
   o->num_observed += n; o->num_mapped_ub += c->last_joint; c->reads_seen += n;
-  return check_eq_overflow(c);
+  return SQ_OK;   // asynchronous: sq_eq_sync() (called by finish / fetch / reset) waits and reports table overflow
 }
 
 extern "C" int sq_ctx_reset(sq_ctx* c) {
   if (!c) return SQ_ERR_ARG;
+  (void)sq_eq_sync(c);
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_free(c);
   c->reads_seen = 0; c->have_batch = false;
@@ -627,6 +638,7 @@ extern "C" int sq_ctx_reset(sq_ctx* c) {
 
 extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
   if (!c || !out) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
   out->num_observed = c->online->num_observed; out->num_assigned = hctr[0]; out->num_mapped_ub = c->online->num_mapped_ub; out->burned_in = hctr[1] != 0;
@@ -647,6 +659,7 @@ static int finish_efflen(sq_ctx* c) {
 
 extern "C" int sq_model_fetch(sq_ctx* c, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len) {
   if (!c) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   int rc = finish_efflen(c); if (rc) return rc;
   sq_online_dev* o = c->online; size_t M = o->M;
@@ -659,6 +672,7 @@ extern "C" int sq_model_fetch(sq_ctx* c, double* log_mass, uint64_t* unique_coun
 
 extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
   if (!c || !out) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_dev* o = c->online; unsigned long long hctr[8]; double scal[8]; std::vector<double> h(1024);
   SQ_HIP_CHECK(hipMemcpy(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(scal, o->scal.p, sizeof(scal), hipMemcpyDeviceToHost));
@@ -672,6 +686,7 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
 // CSR crosses PCIe.
 extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   if (!c || !out) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_dev* o = c->online; hipStream_t st = c->stream;
   unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
@@ -721,6 +736,7 @@ extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
   if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   const uint64_t E = t->num_classes, L = t->num_labels; if (E == 0) return SQ_OK;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
   sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins, d_slot;
   if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L) || d_slot.ensure(E)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
   hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice); hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice);
