@@ -223,7 +223,7 @@ typedef struct {
   uint64_t* wq;           /* [L] raw fixed-point weight sums (SQ_WFRAC_BITS) — exact reduction form */
   uint64_t* count;        /* [E] */
   uint32_t* bins;         /* [L] range-factorization bin ids (label tail), or NULL */
-  uint64_t* h1;           /* [E] label hash (canonical class order = ascending (h1,h2)) */
+  uint64_t* h1;           /* [E] label hash (canonical class order = ascending (first tid, h1, h2)) */
   uint64_t* h2;
 } sq_eq_table;
 /* Query sizes (out arrays NULL) then fetch into caller buffers. Classes come out in canonical order. */

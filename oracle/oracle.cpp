@@ -1062,13 +1062,13 @@ static void label_hash(const std::vector<uint32_t>& lab, uint64_t* h1, uint64_t*
   if (*h1 == ~0ULL) *h1 = ~0ULL - 1;  // ~0 marks an empty slot in the device table
   if (*h2 == 0) *h2 = 1;              // 0 marks "second hash not published yet"
 }
-// eq table in canonical order (ascending (h1,h2)); call with NULL arrays to get sizes
+// eq table in canonical order (ascending (first transcript id, h1, h2) — SPEC §D7); call with NULL arrays to get sizes
 void orc_eq_finish(orc_state* s, sq_eq_table* out) {
   QuantState& S = s->S;
   struct Row { uint64_t h1, h2; const std::vector<uint32_t>* lab; const EqVal* v; };
   std::vector<Row> rows; rows.reserve(S.eq.size()); uint64_t L = 0;
   for (auto& kv : S.eq) { Row r; label_hash(kv.first, &r.h1, &r.h2); r.lab = &kv.first; r.v = &kv.second; rows.push_back(r); L += kv.second.wq.size(); }
-  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { const uint32_t ta = (*a.lab)[0], tb = (*b.lab)[0]; if (ta != tb) return ta < tb; return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
   out->num_classes = rows.size(); out->num_labels = L;
   if (!out->off) return;
   uint64_t p = 0;

@@ -1,6 +1,12 @@
 // hip/ctx.h — per-device quantification context: HBM work buffers of the mapping pipeline, the
 // online model and the equivalence-class table.  One sq_ctx per GPU (one process per GPU).
 #pragma once
+#include <thread>
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <string>
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "device_index.h"
@@ -81,11 +87,20 @@ struct sq_ctx {
   uint64_t reads_seen = 0;
   // eq stage runs on its own stream so the online model of batch b overlaps the mapping of batch b+1;
   // alignments are double-buffered (alnb[2], aln_offb[2]) and handed over with events
+  // With a CU partition (eq_cus > 0) stream/stream2 are CU-masked to disjoint sets: the eq stage's chain of small
+  // dependent kernels then never queues behind the mapping kernels' workgroups.  stream3 is unmasked: an eq job that
+  // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
+  hipStream_t stream3 = nullptr; hipStream_t eq_stream_cur = nullptr; int eq_cus = 0; std::atomic<int> map_active{0}; hipEvent_t ev_eq_last = nullptr;
   hipStream_t stream2 = nullptr; hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr}; int cur_buf = 0, last_buf = 0; bool eq_pending[2] = {false, false};
   sq_dbuf<sq_aln> aln_b1; sq_dbuf<uint64_t> aln_off_b1;
   sq_aln* aln_ptr(int b) { return b ? aln_b1.p : aln.p; }
   uint64_t* aln_off_ptr(int b) { return b ? aln_off_b1.p : aln_off.p; }
   std::vector<hipEvent_t> prof_ev2; std::vector<int> prof_stage2;
+  // The eq stage of a batch is several hundred small launches (three per mini-batch of 5000 fragments):
+  // a worker thread enqueues them on stream2 so the caller can go straight on to mapping the next batch.
+  struct eq_job { uint32_t n; int buf; uint64_t total_aln, joint; };
+  std::thread eq_thread; std::mutex eq_mu; std::condition_variable eq_cv, eq_cv_done; std::deque<eq_job> eq_q;
+  uint64_t eq_submitted = 0, eq_enqueued = 0; uint64_t eq_job_of_buf[2] = {0, 0}; bool eq_stop = false; int eq_err = 0; std::string eq_errmsg;
   // stage profiling
   bool prof_on = false; std::vector<hipEvent_t> prof_ev; std::vector<int> prof_stage; double stage_ms[32] = {0}; uint64_t stage_calls[32] = {0};
 };
@@ -95,7 +110,9 @@ enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOI
 void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream)
 void sq_prof_begin(sq_ctx* c, int which = 0);
 void sq_prof_end(sq_ctx* c, int which = 0);               // call after the stream has been synchronised
-int sq_eq_sync(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
+int sq_eq_sync(sq_ctx* c);
+void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id);        // block until the eq worker has enqueued job `id`
+void sq_eq_worker_stop(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };

@@ -18,8 +18,18 @@
 #include <cmath>
 #include "device_index.h"
 #include "../../../include/sq_rng.h"
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
 
 namespace {
+
+// SQ_TIMING=1: host-side phase timings on stderr (diagnostics only)
+struct PhaseTimer {
+  bool on; std::chrono::steady_clock::time_point t0; const char* tag;
+  explicit PhaseTimer(const char* tg) : on(getenv("SQ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), tag(tg) {}
+  void mark(const char* what) { if (!on) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] %s %s %.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+};
 
 // ---- SPEC §D2 canonical sum: 64-wide strided-halving tree, applied level by level -------------
 __device__ inline double wave_halving_sum(double v) {
@@ -49,16 +59,22 @@ struct EmDev {
   uint32_t* flags;   // [0] = done (iteration count at convergence, 0 = running), [1] = not-converged marker, [2] = iters executed
   unsigned long long* maxrel;  // bit pattern of max relDiff (non-negative doubles order like integers)
   double tol; int use_vbem; uint32_t min_iter;
+  // k_l1 work plan: block b stages the CSC entries of level-1 segments [chunk_seg[b], chunk_seg[b+1]) through LDS
+  const uint32_t* chunk_seg; uint32_t nchunks; const uint8_t* t_seg8;   // t_seg8[p] = index of entry p's run within its block
+  // level 2 folded into k_fin (plans with exactly two levels): transcript t sums part[0][l2_lo[t] .. +l2_cnt[t])
+  const uint32_t* l2_lo; const uint8_t* l2_cnt;
 };
 
-__device__ inline void em_close(EmDev& d, uint32_t it_index, unsigned long long* maxrel_log) {
+__device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long* maxrel_log) {
   uint32_t it = it_index + 1;
   d.flags[2] = it;
-  bool conv = (d.flags[1] == 0);
-  maxrel_log[0] = *d.maxrel;
-  if (conv && it >= d.min_iter) d.flags[0] = it;
+  bool conv = (__hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0);   // written by other blocks: bypass the CU-local L1
+  maxrel_log[0] = __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool done = conv && it >= d.min_iter;
+  if (done) d.flags[0] = it;
   d.flags[1] = 0;
   *d.maxrel = 0ULL;
+  return done;
 }
 
 // First kernel of an iteration (ONE block): closes the previous iteration's convergence bookkeeping,
@@ -103,45 +119,59 @@ __global__ void k_class(EmDev d, const double* __restrict__ theta) {
   if (d.flags[0]) return;
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.E) return;
-  uint64_t a = d.off[c], b = d.off[c + 1];
+  const uint64_t a = d.off[c], b = d.off[c + 1];
   if (b - a <= 1) { d.inv[c] = (b - a == 1) ? -d.cnt[c] : 0.0; return; }  // single-transcript class gets the full count (:316-318)
+  const double cnt = d.cnt[c];
   double denom = 0.0;
-  uint64_t i = a;
-  for (; i + 4 <= b; i += 4) {   // gathers issued together, sums kept in label order
-    const uint32_t t0 = d.tid[i], t1 = d.tid[i + 1], t2 = d.tid[i + 2], t3 = d.tid[i + 3];
-    const double w0 = d.cw[i], w1 = d.cw[i + 1], w2 = d.cw[i + 2], w3 = d.cw[i + 3];
-    const double h0 = theta[t0], h1 = theta[t1], h2 = theta[t2], h3 = theta[t3];
-    if (!d.use_vbem || h0 > 0.0) denom += h0 * w0;
-    if (!d.use_vbem || h1 > 0.0) denom += h1 * w1;
-    if (!d.use_vbem || h2 > 0.0) denom += h2 * w2;
-    if (!d.use_vbem || h3 > 0.0) denom += h3 * w3;
+  for (uint64_t i = a; i < b; i += 4) {   // 4 predicated gathers in flight per round (most classes need one round); sums kept in label order
+    uint32_t t[4]; double w[4], h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint64_t q = (i + j < b) ? i + j : b - 1; t[j] = d.tid[q]; w[j] = d.cw[q]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = theta[t[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (i + j < b && (!d.use_vbem || h[j] > 0.0)) denom += h[j] * w[j];
   }
-  for (; i < b; ++i) { double th = theta[d.tid[i]]; if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
-  d.inv[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : d.cnt[c] / denom;  // minEQClassWeight (:40)
+  d.inv[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : cnt / denom;  // minEQClassWeight (:40)
 }
 
 #define SEG_TOP 0x80000000u
-// level 1: one thread per run of <= 64 consecutive CSC entries of one transcript
-__global__ void k_l1(EmDev d, const double* __restrict__ theta, double* __restrict__ alpha_out) {
+// level 1: one thread per run of <= 64 consecutive CSC entries of one transcript.  A block first
+// evaluates the terms of all its runs with coalesced loads and every inv[] gather in flight at once
+// (theta of the owning run comes from LDS via a 1-byte run index per entry), parks them in LDS, then
+// each thread adds up its own run left to right (SPEC §D4) — no chain of dependent global gathers.
+// A skipped term is stored as +0.0, which leaves the non-negative running sum unchanged bit for bit.
+#define L1_CHUNK 2048
+#define L1_TB 256
+__global__ void __launch_bounds__(L1_TB) k_l1(EmDev d, const double* __restrict__ theta, double* __restrict__ alpha_out) {
   if (d.flags[0]) return;
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= d.nseg[0]) return;
-  const uint32_t tt = d.seg_txp[0][g]; const uint32_t t = tt & ~SEG_TOP;
-  const double th = theta[t]; const bool live = !d.use_vbem || th > 0.0;
-  double acc = 0.0;
-  uint64_t p = d.seg_lo[0][g]; const uint64_t e = p + d.seg_cnt[0][g];
-  auto term = [&](double iv, double cw) { if (iv < 0.0) acc += -iv; else if (iv != 0.0 && live) { double v = th * cw; acc += v * iv; } };
-  for (; p + 8 <= e; p += 8) {   // 8 gathers in flight, terms added in CSC order
-    uint32_t c[8]; double w[8], iv[8];
+  __shared__ double s_term[L1_CHUNK]; __shared__ double s_th[L1_TB];
+  const uint32_t s0 = d.chunk_seg[blockIdx.x], s1 = d.chunk_seg[blockIdx.x + 1];
+  const uint32_t e0 = d.seg_lo[0][s0], e1 = d.seg_lo[0][s1 - 1] + d.seg_cnt[0][s1 - 1];
+  const uint32_t g = s0 + threadIdx.x; const bool has = g < s1;
+  uint32_t tt = 0, lo = 0, n = 0;
+  uint32_t c[L1_CHUNK / L1_TB]; double w[L1_CHUNK / L1_TB], iv[L1_CHUNK / L1_TB]; uint8_t sg[L1_CHUNK / L1_TB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { c[j] = d.t_cls[p + j]; w[j] = d.t_cw[p + j]; }
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) { const uint32_t p = e0 + j * L1_TB + threadIdx.x; const uint32_t q = p < e1 ? p : e1 - 1; c[j] = d.t_cls[q]; w[j] = d.t_cw[q]; sg[j] = d.t_seg8[q]; }
+  if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; s_th[threadIdx.x] = theta[tt & ~SEG_TOP]; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) iv[j] = d.inv[c[j]];
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) iv[j] = d.inv[c[j]];
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) term(iv[j], w[j]);
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) {
+    const uint32_t p = e0 + j * L1_TB + threadIdx.x;
+    if (p < e1) {
+      const double th = s_th[sg[j]]; double term = 0.0;
+      if (iv[j] < 0.0) term = -iv[j];                                                   // single-transcript class: the full count
+      else if (iv[j] != 0.0 && (!d.use_vbem || th > 0.0)) { const double v = th * w[j]; term = v * iv[j]; }
+      s_term[p - e0] = term;
+    }
   }
-  for (; p < e; ++p) term(d.inv[d.t_cls[p]], d.t_cw[p]);
-  if (tt & SEG_TOP) alpha_out[t] = acc; else d.part[0][g] = acc;
+  __syncthreads();
+  if (!has) return;
+  double acc = 0.0;
+  for (uint32_t i = 0; i < n; ++i) acc += s_term[lo + i];
+  if (tt & SEG_TOP) alpha_out[tt & ~SEG_TOP] = acc; else d.part[0][g] = acc;
 }
 // levels >= 2 (runs of <= 64 partial sums of the previous level): few segments, so ONE block walks
 // the levels with a barrier between them instead of one launch per level
@@ -168,14 +198,25 @@ __global__ void __launch_bounds__(1024) k_upper(EmDev d, int first_lvl, double* 
     __syncthreads();
   }
 }
-// convergence scan (CollapsedEMOptimizer.cpp:945-957)
-__global__ void k_fin(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials) {
+// convergence scan (CollapsedEMOptimizer.cpp:945-957); also level 1 of the next iteration's canonical
+// sum and, for two-level plans, level 2 of the blocked-64 transcript sums.
+// (A "last block finishes the sum" variant was measured and dropped: the device-scope fence it needs
+// writes back the XCD's L2 in every block — 53 us vs 9 us per launch on MI355X.)
+__global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials) {
   if (d.flags[0]) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   double rel = -1.0; int bad = 0; double leaf = 0.0;
   if (t < d.M) {
-    double acc = (d.t_off[t + 1] == d.t_off[t]) ? 0.0 : alpha_out[t];
-    if (d.t_off[t + 1] == d.t_off[t]) alpha_out[t] = 0.0;
+    const bool empty = d.t_off[t + 1] == d.t_off[t];
+    double acc;
+    uint32_t n2 = d.l2_cnt ? d.l2_cnt[t] : 0;
+    if (n2) {   // level 2 of the blocked-64 sum, folded in: <= 64 level-1 partials, left to right
+      const double* src = d.part[0] + d.l2_lo[t];
+      acc = 0.0;
+      for (uint32_t i = 0; i < n2; ++i) acc += src[i];
+      alpha_out[t] = acc;
+    } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
+    else acc = alpha_out[t];
     leaf = acc + d.prior[t];
     if (acc > 1e-2) {  // alphaCheckCutoff (:884)
       rel = fabs(alpha[t] - acc) / acc;
@@ -191,7 +232,7 @@ __global__ void k_fin(EmDev d, const double* __restrict__ alpha, double* __restr
   if (threadIdx.x == 0) { for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; } }
   if (threadIdx.x == 0) {
     if (rel >= 0.0) { unsigned long long b = (unsigned long long)__double_as_longlong(rel); if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b); }
-    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) d.flags[1] = 1;
+    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -227,6 +268,7 @@ double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used
 struct EmHost {  // host-side preparation (CollapsedEMOptimizer.cpp:760-873)
   std::vector<double> cw, cnt, prior, t_cw; std::vector<uint64_t> t_off; std::vector<uint32_t> t_cls;
   std::vector<uint32_t> seg_lo[4], seg_txp[4]; std::vector<uint8_t> seg_cnt[4]; int nlevels = 0;
+  std::vector<uint32_t> chunk_seg, l2_lo; std::vector<uint8_t> l2_cnt, t_seg8;   // k_l1 block plan; level 2 folded into k_fin (two-level plans)
 };
 
 int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, EmHost& H) {
@@ -272,6 +314,23 @@ int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, Em
     H.nlevels = lvl + 1;
   }
   for (uint32_t t = 0; t < M; ++t) if (cnt_prev[t] > 1) { sq_set_error("EM reduction plan deeper than 4 levels"); return SQ_ERR_OVERFLOW; }
+  // k_l1 blocks: consecutive level-1 segments packed up to L1_CHUNK entries / L1_TB segments
+  H.chunk_seg.clear(); H.chunk_seg.push_back(0);
+  { uint32_t ents = 0, segs = 0; const uint32_t ns = (uint32_t)H.seg_lo[0].size();
+    for (uint32_t g = 0; g < ns; ++g) {
+      const uint32_t c = H.seg_cnt[0][g];
+      if (segs && (ents + c > L1_CHUNK || segs == L1_TB)) { H.chunk_seg.push_back(g); ents = 0; segs = 0; }
+      ents += c; ++segs;
+    }
+    if (ns) H.chunk_seg.push_back(ns); }
+  H.t_seg8.resize(L);
+  for (size_t cidx = 0; cidx + 1 < H.chunk_seg.size(); ++cidx)
+    for (uint32_t g = H.chunk_seg[cidx]; g < H.chunk_seg[cidx + 1]; ++g) { const uint32_t lo = H.seg_lo[0][g], n = H.seg_cnt[0][g]; for (uint32_t i = 0; i < n; ++i) H.t_seg8[lo + i] = (uint8_t)(g - H.chunk_seg[cidx]); }
+  H.l2_lo.clear(); H.l2_cnt.clear();
+  if (H.nlevels == 2) {
+    H.l2_lo.assign(M, 0); H.l2_cnt.assign(M, 0);
+    for (size_t g = 0; g < H.seg_lo[1].size(); ++g) { const uint32_t t = H.seg_txp[1][g] & ~SEG_TOP; H.l2_lo[t] = H.seg_lo[1][g]; H.l2_cnt[t] = H.seg_cnt[1][g]; }
+  }
   return SQ_OK;
 }
 
@@ -283,6 +342,7 @@ struct EmSession {
   uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmHost H; EmDev d;
   DBuf<uint64_t> d_off, d_toff; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
+  DBuf<uint32_t> d_chunk, d_l2lo; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
   ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st) (void)hipStreamDestroy(st); }
 
@@ -291,18 +351,24 @@ struct EmSession {
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
     SQ_HIP_CHECK(hipSetDevice(device));
     o = opts;
+    PhaseTimer pt("em.setup");
     int rc = prepare(eq, txp, o, H); if (rc) return rc;
+    pt.mark("prepare");
     M = txp->num_txp; E = (uint32_t)eq->num_classes; L = eq->num_labels; g1 = (M + 63) / 64;
     std::vector<uint64_t> off(eq->off, eq->off + E + 1); std::vector<uint32_t> tid(eq->tid, eq->tid + L);
     for (int l = 0; l < H.nlevels; ++l) if (d_slo[l].upload(H.seg_lo[l]) || d_stx[l].upload(H.seg_txp[l]) || d_scn[l].upload(H.seg_cnt[l]) || d_lpart[l].alloc(H.seg_lo[l].size() + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
     bool ok = !d_off.upload(off) && !d_tid.upload(tid) && !d_cw.upload(H.cw) && !d_cnt.upload(H.cnt) && !d_toff.upload(H.t_off) && !d_tcls.upload(H.t_cls) &&
               !d_tcw.upload(H.t_cw) && !d_prior.upload(H.prior) && !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) &&
-              !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
+              !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) &&
+              !d_chunk.upload(H.chunk_seg) && !d_seg8.upload(H.t_seg8) && (H.l2_cnt.empty() || (!d_l2lo.upload(H.l2_lo) && !d_l2cnt.upload(H.l2_cnt)));
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     d.M = M; d.E = E; d.L = L; d.off = d_off.p; d.tid = d_tid.p; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
     d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
     d.nlevels = H.nlevels; for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.nseg[l] = l < H.nlevels ? (uint32_t)H.seg_lo[l].size() : 0; d.part[l] = d_lpart[l].p; }
+    d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = H.chunk_seg.size() > 1 ? (uint32_t)H.chunk_seg.size() - 1 : 0;
+    d.l2_lo = H.l2_cnt.empty() ? nullptr : d_l2lo.p; d.l2_cnt = H.l2_cnt.empty() ? nullptr : d_l2cnt.p;
     SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+    pt.mark("alloc+upload");
     return SQ_OK;
   }
 
@@ -314,36 +380,31 @@ struct EmSession {
     SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st)); SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
     d.min_iter = (mode == 0) ? min_iter : 0xFFFFFFFFu;
     double* cur = d_a0.p; double* nxt = d_a1.p;
-    // level-1 partials of (alpha + prior) live in d.partial; k_top finishes the levels above (<= 4096
-    // partials); for M > 262144 extra level kernels shrink the list first.
+    // level-1 partials of (alpha + prior) live in d.partial (written by k_fin); k_top finishes the
+    // levels above (<= 4096 partials); for M > 262144 k_sum_level kernels shrink the list first.
     double* part_lvl1 = d.partial; double* part_tmp = d.partial + g1 + 64;
-    bool pending_close = false; uint32_t pending_it = 0;
+    auto launch_top = [&](int close_prev, uint32_t prev_it) {
+      const double* pin = part_lvl1; uint32_t n1 = g1;
+      double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
+      while (n1 > 4096) { k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a); pin = a; n1 = (n1 + 63) / 64; std::swap(a, b); }
+      k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p);
+    };
     auto launch_iter = [&](uint32_t it) {
       const double* theta_src = cur;
-      if (o->use_vbem) {
-        const double* pin = part_lvl1; uint32_t n1 = g1;
-        double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
-        while (n1 > 4096) { k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a); pin = a; n1 = (n1 + 63) / 64; std::swap(a, b); }
-        k_top<<<1, 1024, 0, st>>>(d, pin, n1, pending_close ? 1 : 0, pending_it, d_log.p, d_lognorm.p);
-        k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p);
-        pending_close = false;
-        theta_src = d.theta;
-      } else if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; }
+      if (o->use_vbem) { k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p); theta_src = d.theta; }
       k_class<<<(E + TB - 1) / TB, TB, 0, st>>>(d, theta_src);
-      if (d.nseg[0]) k_l1<<<(d.nseg[0] + TB - 1) / TB, TB, 0, st>>>(d, theta_src, nxt);
-      { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
+      if (d.nchunks) k_l1<<<d.nchunks, L1_TB, 0, st>>>(d, theta_src, nxt);
+      if (!d.l2_cnt) { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
         if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }
       k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, nxt, o->use_vbem ? part_lvl1 : nullptr);
-      pending_close = true; pending_it = it;
+      if (o->use_vbem) launch_top(1, it); else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);   // closes iteration `it`; VBEM: also logNorm for the next one
       std::swap(cur, nxt);
     };
-    auto flush_close = [&]() { if (pending_close) { k_close<<<1, 1, 0, st>>>(d, pending_it, d_log.p); pending_close = false; } };
-    if (o->use_vbem) k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1);
+    if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0); }
     uint32_t it = 0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     if (mode == 1) {
       for (; it < fixed_iters; ++it) launch_iter(it);
-      flush_close();
       executed = fixed_iters;
     } else {
       const uint32_t maxIter = o->max_iter, minIter = min_iter;
@@ -353,8 +414,7 @@ struct EmSession {
         uint32_t lim = std::max(maxIter, minIter);
         if (it + chunk > lim) chunk = lim - it;
         for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
-        flush_close();
-        SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
+          SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
         SQ_HIP_CHECK(hipStreamSynchronize(st));
         if (hflags[0]) { done = hflags[0]; break; }
       }
@@ -375,8 +435,14 @@ struct EmSession {
 };
 
 int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep) {
-  EmSession S; int rc = S.setup(device, eq, txp, o); if (rc) return rc;
-  return S.run(alpha, mode, fixed_iters, o->min_iter, rep);
+  PhaseTimer pt("em");
+  int rc;
+  { EmSession S; rc = S.setup(device, eq, txp, o); if (rc) return rc;
+    pt.mark("setup");
+    rc = S.run(alpha, mode, fixed_iters, o->min_iter, rep);
+    pt.mark("run"); }
+  pt.mark("teardown");
+  return rc;
 }
 
 // ---- a16 bootstrap (doBootstrap, CollapsedEMOptimizer.cpp:398-552) ----------------------------------

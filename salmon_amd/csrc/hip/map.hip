@@ -45,10 +45,10 @@ void fill_params(sq_ctx* c) {
 
 static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score", "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table"};
-void sq_prof_begin(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? c->stream2 : c->stream;
+void sq_prof_begin(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(-1); }
-void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? c->stream2 : c->stream;
+void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
 void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
   for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
@@ -70,7 +70,25 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
   SQ_HIP_CHECK(hipSetDevice(device));
   sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads;
   fill_params(c);
-  SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
+  { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 32 of 256; SQ_EQ_CUS=0 disables) and the
+    // mapping stream keeps off them.  Measured on MI355X (configs[1]): mapping kernels lose ~3% on 224 CUs, while
+    // the eq chain no longer waits behind their workgroups (mapping stalled ~30 ms per 10 M pairs on it).
+    hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount;
+    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 8 : 0);
+    if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
+    c->eq_cus = eq_cus;
+    if (eq_cus > 0) {
+      std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
+      for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
+      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()));
+      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()));
+      SQ_HIP_CHECK(hipStreamCreate(&c->stream3));
+    } else {
+      SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
+    }
+    c->eq_stream_cur = c->stream2;
+  }
   for (int b = 0; b < 2; ++b) { SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_map_done[b], hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming)); }
   const uint32_t nends = 2 * max_batch_reads;
   bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
@@ -91,7 +109,9 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  sq_eq_worker_stop(c);   // drains the queued eq-stage jobs first
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   sq_online_free(c);
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
@@ -99,6 +119,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_(); c->aln_b1.free_(); c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   for (int b = 0; b < 2; ++b) { if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]); if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -111,6 +132,7 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   SQ_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   c->have_batch = false;
+  struct ActiveGuard { std::atomic<int>& a; explicit ActiveGuard(std::atomic<int>& x) : a(x) { a.store(1); } ~ActiveGuard() { a.store(0); } } active_guard(c->map_active);
   const int buf = c->cur_buf;
   if (n == 0) { c->last_n = 0; c->last_buf = buf; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
   // ---- stage reads in HBM ----
@@ -129,8 +151,11 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   sq_prof_begin(c);
   k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
   sq_prof_mark(c, SG_PACK);
-  {  // persistent grid: 256 CUs x 8 blocks of 256 threads (all resident at 24 VGPRs); lanes pull read ends from counters[2]
-    uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * 8u);
+  {  // persistent grid: 256 CUs x 6 blocks of 256 threads; lanes pull read ends from counters[2].  The probe rate is
+     // bound by the memory system, not by occupancy (4..8 blocks/CU measure the same), so two blocks' worth of wave
+     // slots per CU stay free for the eq stage's small kernels on stream2 — a full grid starves them for the whole 5 ms.
+    static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
+    uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     k_seed<<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2);
   }
   sq_prof_mark(c, SG_SEED);
@@ -186,7 +211,10 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   c->last_total_cands = total_cands;
   const size_t CP = (size_t)total_cands + 8;
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
-  if (c->eq_pending[buf]) { SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf])); c->eq_pending[buf] = false; }   // the eq stage that read this buffer two batches ago
+  if (c->eq_pending[buf]) {   // the eq stage that read this alignment buffer two batches ago: wait (on the device) for it
+    sq_eq_wait_enqueued(c, c->eq_job_of_buf[buf]);
+    SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
+  }
   if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
   sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
   if (hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }

@@ -16,11 +16,15 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
 
 struct sq_online_dev {
   uint32_t M = 0;
   // model
   sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
+  sq_dbuf<uint32_t> touched, touched_n;   // transcripts whose mass changed in the current mini-batch: two lists (mini-batch parity), [2*M] + [2]
   sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize
   // per big batch
   sq_dbuf<uint8_t> has_compat; struct PreAln; sq_dbuf<uint8_t> pre; sq_dbuf<double> alp; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
@@ -67,6 +71,7 @@ struct OnlineView {
   uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen; double* tlc;
   double* hist; double* cpmf; double* ccmf; const double* ambig; double* mass; const double* prior_mass; double* log_eff_len; double* scal; double* cfac;
   unsigned long long* mass_acc; unsigned long long* uniq; unsigned long long* total; unsigned long long* lib_counts; uint32_t* fld_cnt; unsigned long long* ctr;
+  uint32_t* touched; uint32_t* touched_n;
 };
 
 __global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o, uint32_t* __restrict__ flag) {
@@ -120,9 +125,23 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
 }
 
 // one mini-batch: fragments [r0, r1) of the current mapped batch (thread per fragment)
+// first toucher of a transcript in this mini-batch records it (one atomic per wave: the ballot sees the calling lanes only)
+__device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, unsigned long long q) {
+  if (!q) return;
+  const unsigned long long old = atomicAdd(&V.mass_acc[t], q);
+  if (old == 0) {
+    const unsigned long long m = __ballot(1);
+    const int leader = __ffsll((long long)m) - 1, lane = (int)(threadIdx.x & 63);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&V.touched_n[par], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    V.touched[(size_t)par * V.M + base + (uint32_t)__popcll(m & ((1ULL << lane) - 1))] = t;
+  }
+}
+
 __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out) {
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   rh1[r] = EQ_EMPTY; rh2[r] = 0;
@@ -183,7 +202,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     if (o.range_factorization_bins > 0) bin = (uint32_t)(int32_t)(w * (double)rangeCount);
     awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
     const double pr = sq_exp(alp[ai] - sumProbs);
-    atomicAdd(&V.mass_acc[t], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+    mass_add(V, par, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
     atomicAdd(&V.total[t], 1ULL);
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
@@ -209,7 +228,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 #define MB_G 16
 __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2) {
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint32_t par) {
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
   uint64_t fmtSeen = 0;
@@ -217,7 +236,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
   if (valid && nA > MB_G) {
-    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen);
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
     if (nA > 0) {
@@ -276,7 +295,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
           bin = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
           awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
           const double pr = sq_exp(logProb - sumProbs);
-          atomicAdd(&V.mass_acc[t], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+          mass_add(V, par, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
           atomicAdd(&V.total[t], 1ULL);
           if (!burned) {
             double rr = dev_u01(o.seed, read_counter0 + (r - r0), ki);
@@ -308,41 +327,57 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
 // transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
-__global__ void k_apply_mass(OnlineView V, double logFM, uint64_t assigned_after, int set_ctr) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0 && set_ctr) V.ctr[0] = assigned_after;
-  if (t >= V.M) return;
-  unsigned long long q = V.mass_acc[t];
-  if (q) { double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass[t] = m; V.tlc[t] = sq_log_add(V.prior_mass[t], m); V.mass_acc[t] = 0; }
+__device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64_t assigned_after, int set_ctr, uint32_t par, uint32_t mass_blocks) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (set_ctr) V.ctr[0] = assigned_after; V.touched_n[par ^ 1] = 0; }   // the other list is idle until the next mini-batch
+  const uint32_t n = V.touched_n[par]; const uint32_t* list = V.touched + (size_t)par * V.M;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += mass_blocks * blockDim.x) {
+    const uint32_t t = list[i];
+    const unsigned long long q = V.mass_acc[t];
+    const double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass[t] = m; V.tlc[t] = sq_log_add(V.prior_mass[t], m); V.mass_acc[t] = 0;
+  }
 }
 
 // batch end, part 2 (one block of 1024): FLD histogram update + tree total + counters + burn-in trigger
-__global__ void __launch_bounds__(1024) k_apply_fld(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin) {
-  __shared__ double v[1024]; __shared__ uint32_t cnt[1008]; __shared__ int any;
-  const int b = threadIdx.x;
-  if (b == 0) any = 0;
+// 256 threads walk the 1024 histogram bins (4 per thread): blocks of 256 threads slot in beside the
+// resident waves of the mapping kernels, a 1024-thread block has to wait for a whole CU to drain.
+#define AP_TB 256
+__device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_t assigned_after, uint64_t num_burnin) {
+  __shared__ double v[1024]; __shared__ uint32_t cnt[1024]; __shared__ int any;
+  const int tid = threadIdx.x;
+  if (tid == 0) any = 0;
   __syncthreads();
   const bool burned = V.ctr[1] != 0;
-  if (!burned) { if (b <= 1000) { uint32_t c = V.fld_cnt[b]; cnt[b] = c; if (c) any = 1; } }
+  if (!burned) for (int b = tid; b <= 1000; b += AP_TB) { uint32_t c = V.fld_cnt[b]; cnt[b] = c; if (c) any = 1; }
   __syncthreads();
   if (!burned && any) {
-    if (b >= 1 && b <= 1000) {
-      double h = V.hist[b];
-      const double kern[5] = {sq_log(0.0625), sq_log(0.25), sq_log(0.375), sq_log(0.25), sq_log(0.0625)};
-      for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000) continue; uint32_t c = cnt[len]; if (!c) continue; h = sq_log_add(h, logFM + kern[i] + sq_log((double)c)); }
-      V.hist[b] = h;
+    const double kern[5] = {sq_log(0.0625), sq_log(0.25), sq_log(0.375), sq_log(0.25), sq_log(0.0625)};
+    for (int b = tid; b < 1024; b += AP_TB) {
+      double h = (b <= 1000) ? V.hist[b] : SQ_LOG_0;
+      if (b >= 1 && b <= 1000) {
+        for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000) continue; uint32_t c = cnt[len]; if (!c) continue; h = sq_log_add(h, logFM + kern[i] + sq_log((double)c)); }
+        V.hist[b] = h;
+      }
+      v[b] = h;
     }
     __syncthreads();
-    v[b] = (b <= 1000) ? V.hist[b] : SQ_LOG_0;
-    __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) { if (b < s) v[b] = sq_log_add(v[b], v[b + s]); __syncthreads(); }
-    if (b == 0) V.scal[0] = v[0];
-    if (b <= 1000) V.fld_cnt[b] = 0;
+    for (int s = 512; s >= 1; s >>= 1) { for (int b = tid; b < s; b += AP_TB) v[b] = sq_log_add(v[b], v[b + s]); __syncthreads(); }
+    if (tid == 0) V.scal[0] = v[0];
+    for (int b = tid; b <= 1000; b += AP_TB) V.fld_cnt[b] = 0;
   }
-  if (b == 0) {
+  if (tid == 0) {
     V.ctr[0] = assigned_after;
     if (assigned_after >= num_burnin && V.ctr[1] == 0 && V.ctr[4] == 0) V.ctr[4] = 1;  // burn-in finalisation pending
   }
+}
+
+// ONE launch per mini-batch end: blocks [0, mass_blocks) update the masses of the transcripts the mini-batch
+// touched (a list the first toucher appends to — a few thousand entries instead of a sweep over all M, so the
+// kernel needs few workgroups and squeezes in beside the mapping kernels), the extra last block (before
+// burn-in only) updates the FLD — the two parts touch disjoint state, and every launch saved shortens
+// the sequential mini-batch chain (the model of mini-batch i+1 depends on the end of mini-batch i).
+__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin, uint32_t mass_blocks, int with_fld, uint32_t par) {
+  if (blockIdx.x < mass_blocks) apply_mass_part(V, logFM, assigned_after, with_fld ? 0 : 1, par, mass_blocks);
+  else apply_fld_part(V, logFM, assigned_after, num_burnin);
 }
 
 // burn-in finalisation (FLD.cacheCMF :174-186 + updateTranscriptLengthsAtomic ReadExperiment.inl:62-94), one thread: 3 chains of 1001 logAdds, once
@@ -462,6 +497,10 @@ __global__ void k_gather_bounds(const uint64_t* __restrict__ prefix, uint32_t mb
 }
 
 // ---- device-side export of the table in canonical order --------------------------------------
+// Canonical class order = ascending (first transcript id, h1, h2).  Leading with the first label
+// keeps classes of one gene family adjacent, so the EM's theta[tid] / inv[class] gathers
+// (em.hip k_class / k_l1) land in a few cache lines instead of being spread by the hash.
+// Sort key = first_tid << 32 | h1 >> 32; a key tie that is out of (h1,h2) order is fixed on the host.
 __global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, uint32_t* __restrict__ slots, unsigned long long* __restrict__ counter) {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool occ = s < T.cap && T.k1[s] != EQ_EMPTY;
@@ -469,14 +508,17 @@ __global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, ui
   unsigned long long base = 0;
   if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(counter, (unsigned long long)__popcll(m));
   base = __shfl(base, 0, 64);
-  if (occ) { uint64_t i = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1)); keys[i] = T.k1[s]; slots[i] = (uint32_t)s; }
+  if (occ) { uint64_t i = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1)); keys[i] = ((unsigned long long)T.pool_tid[T.pool[s]] << 32) | (T.k1[s] >> 32); slots[i] = (uint32_t)s; }
 }
 __global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab, uint32_t* __restrict__ tie) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c > E) return;
   if (c == E) { nlab[E] = 0; return; }
   nlab[c] = T.n[slots[c]];
-  if (c + 1 < E && keys[c] == keys[c + 1] && T.k2[slots[c]] > T.k2[slots[c + 1]]) *tie = 1;   // equal h1: order by h2 (fixed up on the host, ~never)
+  if (c + 1 < E && keys[c] == keys[c + 1]) {   // equal (first tid, h1 hi): order by the full (h1, h2) (fixed up on the host, rare)
+    const unsigned long long a1 = T.k1[slots[c]], b1 = T.k1[slots[c + 1]];
+    if (a1 > b1 || (a1 == b1 && T.k2[slots[c]] > T.k2[slots[c + 1]])) *tie = 1;
+  }
 }
 __global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off, uint32_t* __restrict__ tid, double* __restrict__ w, unsigned long long* __restrict__ wq,
                             unsigned long long* __restrict__ count, uint32_t* __restrict__ bins, unsigned long long* __restrict__ h1, unsigned long long* __restrict__ h2) {
@@ -492,7 +534,7 @@ __global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ s
 OnlineView make_view(sq_ctx* c) {
   sq_online_dev* o = c->online; OnlineView V;
   V.M = o->M; V.ref_len = c->di->ref_len; V.ref_clen = c->di->ref_clen; V.tlc = o->tlc.p; V.hist = o->hist.p; V.cpmf = o->cpmf.p; V.ccmf = o->ccmf.p; V.ambig = o->ambig.p; V.mass = o->mass.p; V.prior_mass = o->prior_mass.p;
-  V.log_eff_len = o->log_eff_len.p; V.scal = o->scal.p; V.cfac = o->cfac.p; V.mass_acc = o->mass_acc.p; V.uniq = o->uniq.p; V.total = o->total.p; V.lib_counts = o->lib_counts.p; V.fld_cnt = o->fld_cnt.p; V.ctr = o->ctr.p;
+  V.log_eff_len = o->log_eff_len.p; V.scal = o->scal.p; V.cfac = o->cfac.p; V.mass_acc = o->mass_acc.p; V.uniq = o->uniq.p; V.total = o->total.p; V.lib_counts = o->lib_counts.p; V.fld_cnt = o->fld_cnt.p; V.ctr = o->ctr.p; V.touched = o->touched.p; V.touched_n = o->touched_n.p;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
@@ -510,7 +552,7 @@ int sq_online_create(sq_ctx* c) {
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
   bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(1024) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
-             o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
+             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) || o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
              o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) || o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
@@ -528,6 +570,7 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior
+  SQ_HIP_CHECK(hipMemset(o->touched_n.p, 0, 8));
   SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8)); SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4)); SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
@@ -539,7 +582,7 @@ int sq_online_create(sq_ctx* c) {
 void sq_online_free(sq_ctx* c) {
   sq_online_dev* o = c->online; if (!o) return;
   o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->tlc.free_(); o->pre.free_(); o->alp.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
-  o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
+  o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
   o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
   delete o; c->online = nullptr;
 }
@@ -561,28 +604,75 @@ static int check_eq_overflow(sq_ctx* c) {
   return SQ_OK;
 }
 
+// wait until the worker has enqueued job `id` (ids count from 1)
+void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id) {
+  std::unique_lock<std::mutex> lk(c->eq_mu);
+  c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= id; });
+}
 int sq_eq_sync(sq_ctx* c) {
   if (!c || !c->stream2) return SQ_OK;
+  { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= c->eq_submitted; }); }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream2));
+  if (c->stream3) SQ_HIP_CHECK(hipStreamSynchronize(c->stream3));
   c->eq_pending[0] = c->eq_pending[1] = false;
   sq_prof_end(c, 1);
+  { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); c->eq_err = 0; c->eq_errmsg.clear(); return e; } }
   return check_eq_overflow(c);
+}
+
+static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J);
+static void eq_worker(sq_ctx* c) {
+  (void)hipSetDevice(c->device);
+  for (;;) {
+    sq_ctx::eq_job J;
+    { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv.wait(lk, [&] { return c->eq_stop || !c->eq_q.empty(); });
+      if (c->eq_q.empty()) return;
+      J = c->eq_q.front(); c->eq_q.pop_front(); }
+    int rc = 0;
+    { std::lock_guard<std::mutex> lk(c->eq_mu); rc = c->eq_err; }
+    if (!rc) { rc = eq_accumulate_job(c, J); if (rc) { std::lock_guard<std::mutex> lk(c->eq_mu); if (!c->eq_err) { c->eq_err = rc; c->eq_errmsg = sq_last_error(); } } }
+    { std::lock_guard<std::mutex> lk(c->eq_mu); c->eq_enqueued++; }
+    c->eq_cv_done.notify_all();
+  }
+}
+void sq_eq_worker_stop(sq_ctx* c) {
+  if (!c->eq_thread.joinable()) return;
+  { std::lock_guard<std::mutex> lk(c->eq_mu); c->eq_stop = true; }
+  c->eq_cv.notify_all(); c->eq_thread.join(); c->eq_stop = false;
 }
 
 extern "C" int sq_eq_accumulate(sq_ctx* c) {
   if (!c || !c->have_batch) { sq_set_error("sq_eq_accumulate: call sq_map_batch first"); return SQ_ERR_STATE; }
-  SQ_HIP_CHECK(hipSetDevice(c->device));
-  sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t n = c->last_n; const sq_quant_opts& q = c->opts;
-  const int buf = c->last_buf; const sq_aln* d_aln = c->aln_ptr(buf); const uint64_t* d_aln_off = c->aln_off_ptr(buf);
   c->have_batch = false;
-  if (n == 0) return SQ_OK;
+  if (c->last_n == 0) return SQ_OK;
+  sq_ctx::eq_job J; J.n = c->last_n; J.buf = c->last_buf; J.total_aln = c->last_total_aln; J.joint = c->last_joint;
+  { std::lock_guard<std::mutex> lk(c->eq_mu);
+    if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); return e; }   // an earlier batch failed
+    if (!c->eq_thread.joinable()) c->eq_thread = std::thread(eq_worker, c);
+    c->eq_q.push_back(J); c->eq_job_of_buf[J.buf] = ++c->eq_submitted; }
+  c->eq_pending[J.buf] = true;
+  c->eq_cv.notify_one();
+  return SQ_OK;   // asynchronous: sq_eq_sync() (called by finish / fetch / merge / reset) waits and reports errors
+}
+
+// runs on the worker thread
+static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
+  sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t n = J.n; const sq_quant_opts& q = c->opts;
+  if (c->stream3) {   // CU partition on: use the CU-masked stream only while a mapping batch is (about to be) in flight
+    for (int spin = 0; spin < 300 && !c->map_active.load(); ++spin) std::this_thread::sleep_for(std::chrono::microseconds(1));
+    if (!c->map_active.load()) st = c->stream3;
+  }
+  c->eq_stream_cur = st;
+  if (c->ev_eq_last) SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_last, 0));   // eq jobs run in order even when they change streams
+  const int buf = J.buf; const sq_aln* d_aln = c->aln_ptr(buf); const uint64_t* d_aln_off = c->aln_off_ptr(buf);
+  const uint64_t last_total_aln = J.total_aln;
   SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_map_done[buf], 0));   // alignments of this batch are complete
-  const size_t A = (size_t)c->last_total_aln + 8;
+  const size_t A = (size_t)last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
   sq_prof_begin(c, 1);
-  if (c->last_total_aln) k_pre_aln<<<nblk(c->last_total_aln), TB, 0, st>>>(c->last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
+  if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, d_aln_off, d_aln, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
@@ -605,9 +695,9 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
     const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
     const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
     const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p);
-    k_apply_mass<<<nblk(o->M), TB, 0, st>>>(V, logFM, assigned_after, burned_host ? 1 : 0);
-    if (!burned_host) k_apply_fld<<<1, 1024, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags);
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, (uint32_t)(o->batch_no & 1));
+    { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
+      k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, (uint32_t)(o->batch_no & 1)); }
     if (!burned_host && assigned_after >= q.num_burnin_frags) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
       k_burnin_efflen<<<nblk(o->M), TB, 0, st>>>(V, 2);
@@ -622,9 +712,9 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
   k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
   sq_prof_mark(c, SG_EQ_TABLE, 1);
-  SQ_HIP_CHECK(hipEventRecord(c->ev_eq_done[buf], st)); c->eq_pending[buf] = true;
-  o->num_observed += n; o->num_mapped_ub += c->last_joint; c->reads_seen += n;
-  return SQ_OK;   // asynchronous: sq_eq_sync() (called by finish / fetch / reset) waits and reports table overflow
+  SQ_HIP_CHECK(hipEventRecord(c->ev_eq_done[buf], st)); c->ev_eq_last = c->ev_eq_done[buf];
+  o->num_observed += n; o->num_mapped_ub += J.joint; c->reads_seen += n;
+  return SQ_OK;
 }
 
 extern "C" int sq_ctx_reset(sq_ctx* c) {
@@ -686,7 +776,10 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
 // CSR crosses PCIe.
 extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   if (!c || !out) return SQ_ERR_ARG;
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_finish %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
   { int rs = sq_eq_sync(c); if (rs) return rs; }
+  mark("sync");
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_dev* o = c->online; hipStream_t st = c->stream;
   unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
@@ -698,6 +791,7 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr; sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie; sq_dbuf<uint64_t> d_off; sq_dbuf<double> d_w; sq_dbuf<uint8_t> tmp;
   if (keys.ensure(E) || keys2.ensure(E) || slots.ensure(E) || slots2.ensure(E) || nlab.ensure(E + 1) || d_off.ensure(E + 1) || d_tid.ensure(L) || d_bins.ensure(L) || d_wq.ensure(L) || d_w.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_ctr.ensure(1) || d_tie.ensure(1)) {
     sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
+  mark("alloc");
   SQ_HIP_CHECK(hipMemsetAsync(d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_tie.p, 0, 4, st));
   k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, keys.p, slots.p, d_ctr.p);
   size_t tb = 0;
@@ -710,15 +804,19 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   if (tmp.ensure(tb2 + 256)) { sq_set_error("device allocation failed (eq export scan)"); return SQ_ERR_NOMEM; }
   tb2 = tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
   uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
-  if (tie) {  // two classes share h1 and arrived out of h2 order: re-sort the slot list on the host (astronomically rare)
-    std::vector<uint32_t> hs(E); std::vector<unsigned long long> k1(o->tcap), k2(o->tcap);
-    SQ_HIP_CHECK(hipMemcpy(hs.data(), slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
-    std::sort(hs.begin(), hs.end(), [&](uint32_t a, uint32_t b) { return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
-    SQ_HIP_CHECK(hipMemcpy(slots2.p, hs.data(), E * 4, hipMemcpyHostToDevice));
+  if (tie) {  // two classes share a sort key and arrived out of (h1,h2) order: re-sort the slot list on the host (rare)
+    std::vector<uint32_t> hs(E), ord(E); std::vector<unsigned long long> hk(E), k1(o->tcap), k2(o->tcap);
+    SQ_HIP_CHECK(hipMemcpy(hs.data(), slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(hk.data(), keys2.p, E * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < E; ++i) ord[i] = (uint32_t)i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { if (hk[x] != hk[y]) return hk[x] < hk[y]; const uint32_t a = hs[x], b = hs[y]; return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
+    std::vector<uint32_t> hs2(E); for (uint64_t i = 0; i < E; ++i) hs2[i] = hs[ord[i]];
+    SQ_HIP_CHECK(hipMemcpy(slots2.p, hs2.data(), E * 4, hipMemcpyHostToDevice));
     k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, slots2.p, keys2.p, nlab.p, d_tie.p);
     SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
   }
   k_eq_gather<<<nblk(E), TB, 0, st>>>(T, E, slots2.p, d_off.p, d_tid.p, d_w.p, d_wq.p, d_cnt.p, d_bins.p, d_h1.p, d_h2.p);
+  if (timing) { (void)hipStreamSynchronize(st); mark("kernels"); }
   SQ_HIP_CHECK(hipMemcpyAsync(out->off, d_off.p, (E + 1) * 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(out->tid, d_tid.p, L * 4, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(out->w, d_w.p, L * 8, hipMemcpyDeviceToHost, st));
@@ -728,7 +826,9 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   if (out->h1) SQ_HIP_CHECK(hipMemcpyAsync(out->h1, d_h1.p, E * 8, hipMemcpyDeviceToHost, st));
   if (out->h2) SQ_HIP_CHECK(hipMemcpyAsync(out->h2, d_h2.p, E * 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
+  mark("d2h");
   keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
+  mark("free");
   return SQ_OK;
 }
 

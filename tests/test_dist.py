@@ -18,7 +18,7 @@ def merge_tables_host(tables):
             else:
                 assert np.array_equal(acc[key][0], t.tid[a:b]) and np.array_equal(acc[key][1], t.bins[a:b])
                 acc[key][2] = acc[key][2] + t.wq[a:b].astype(object); acc[key][3] += int(t.count[c])
-    keys = sorted(acc)
+    keys = sorted(acc, key=lambda k: (int(acc[k][0][0]), k[0], k[1]))   # canonical order: (first tid, h1, h2)
     return keys, [acc[k] for k in keys]
 
 
