@@ -60,6 +60,7 @@ struct EmDev {
   unsigned long long* maxrel;  // bit pattern of max relDiff (non-negative doubles order like integers)
   double tol; int use_vbem; uint32_t min_iter;
   // k_l1 work plan: block b stages the CSC entries of level-1 segments [chunk_seg[b], chunk_seg[b+1]) through LDS
+  const uint32_t* cchunk; uint32_t ncchunks;   // k_class work plan: block b owns classes [cchunk[b], cchunk[b+1])
   const uint32_t* chunk_seg; uint32_t nchunks; const uint8_t* t_seg8;   // t_seg8[p] = index of entry p's run within its block
   // level 2 folded into k_fin (plans with exactly two levels): transcript t sums part[0][l2_lo[t] .. +l2_cnt[t])
   const uint32_t* l2_lo; const uint8_t* l2_cnt;
@@ -115,24 +116,44 @@ __global__ void k_theta(EmDev d, const double* __restrict__ alpha, const double*
   }
 }
 
-__global__ void k_class(EmDev d, const double* __restrict__ theta) {
+// class pass: inv_c = count_c / sum_t theta_t * w_ct.  A block owns a run of consecutive classes whose
+// label entries (<= CL_CHUNK) are staged through LDS: coalesced loads of (tid, weight), all theta[]
+// gathers in flight at once, the products parked in LDS, then one thread per class adds its terms in
+// label order.  A skipped term (VBEM, theta = 0) is stored as +0.0, which leaves the non-negative
+// sum unchanged bit for bit.  A single class larger than the chunk (rare) is walked by one thread.
+#define CL_CHUNK 2048
+#define CL_TB 256
+__global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restrict__ theta) {
   if (d.flags[0]) return;
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.E) return;
-  const uint64_t a = d.off[c], b = d.off[c + 1];
-  if (b - a <= 1) { d.inv[c] = (b - a == 1) ? -d.cnt[c] : 0.0; return; }  // single-transcript class gets the full count (:316-318)
-  const double cnt = d.cnt[c];
-  double denom = 0.0;
-  for (uint64_t i = a; i < b; i += 4) {   // 4 predicated gathers in flight per round (most classes need one round); sums kept in label order
-    uint32_t t[4]; double w[4], h[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint64_t q = (i + j < b) ? i + j : b - 1; t[j] = d.tid[q]; w[j] = d.cw[q]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = theta[t[j]];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (i + j < b && (!d.use_vbem || h[j] > 0.0)) denom += h[j] * w[j];
+  __shared__ double s_term[CL_CHUNK];
+  const uint32_t c0 = d.cchunk[blockIdx.x], c1 = d.cchunk[blockIdx.x + 1];
+  const uint64_t e0 = d.off[c0], e1 = d.off[c1];
+  if (e1 - e0 > CL_CHUNK) {   // c1 == c0 + 1
+    if (threadIdx.x == 0) {
+      double denom = 0.0;
+      for (uint64_t i = e0; i < e1; ++i) { const double th = theta[d.tid[i]]; if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
+      d.inv[c0] = (denom <= 2.2250738585072014e-308) ? 0.0 : d.cnt[c0] / denom;
+    }
+    return;
   }
-  d.inv[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : cnt / denom;  // minEQClassWeight (:40)
+  if (e1 > e0) {
+    uint32_t t[CL_CHUNK / CL_TB]; double w[CL_CHUNK / CL_TB], h[CL_CHUNK / CL_TB];
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; const uint64_t q = p < e1 ? p : e1 - 1; t[j] = d.tid[q]; w[j] = d.cw[q]; }
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta[t[j]];
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; if (p < e1) s_term[p - e0] = (!d.use_vbem || h[j] > 0.0) ? h[j] * w[j] : 0.0; }
+  }
+  __syncthreads();
+  for (uint32_t c = c0 + threadIdx.x; c < c1; c += CL_TB) {
+    const uint64_t a = d.off[c], b = d.off[c + 1];
+    if (b - a <= 1) { d.inv[c] = (b - a == 1) ? -d.cnt[c] : 0.0; continue; }  // single-transcript class gets the full count (:316-318)
+    double denom = 0.0;
+    const uint32_t lo = (uint32_t)(a - e0), n = (uint32_t)(b - a);
+    for (uint32_t i = 0; i < n; ++i) denom += s_term[lo + i];
+    d.inv[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : d.cnt[c] / denom;  // minEQClassWeight (:40)
+  }
 }
 
 #define SEG_TOP 0x80000000u
@@ -268,7 +289,7 @@ double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used
 struct EmHost {  // host-side preparation (CollapsedEMOptimizer.cpp:760-873)
   std::vector<double> cw, cnt, prior, t_cw; std::vector<uint64_t> t_off; std::vector<uint32_t> t_cls;
   std::vector<uint32_t> seg_lo[4], seg_txp[4]; std::vector<uint8_t> seg_cnt[4]; int nlevels = 0;
-  std::vector<uint32_t> chunk_seg, l2_lo; std::vector<uint8_t> l2_cnt, t_seg8;   // k_l1 block plan; level 2 folded into k_fin (two-level plans)
+  std::vector<uint32_t> chunk_seg, l2_lo, cchunk; std::vector<uint8_t> l2_cnt, t_seg8;   // k_l1 block plan; level 2 folded into k_fin (two-level plans)
 };
 
 int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, EmHost& H) {
@@ -326,6 +347,15 @@ int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, Em
   H.t_seg8.resize(L);
   for (size_t cidx = 0; cidx + 1 < H.chunk_seg.size(); ++cidx)
     for (uint32_t g = H.chunk_seg[cidx]; g < H.chunk_seg[cidx + 1]; ++g) { const uint32_t lo = H.seg_lo[0][g], n = H.seg_cnt[0][g]; for (uint32_t i = 0; i < n; ++i) H.t_seg8[lo + i] = (uint8_t)(g - H.chunk_seg[cidx]); }
+  // k_class blocks: consecutive classes packed up to CL_CHUNK label entries (a larger class stands alone)
+  H.cchunk.clear(); H.cchunk.push_back(0);
+  { uint64_t ents = 0; uint32_t ncl = 0;
+    for (uint64_t c = 0; c < E; ++c) {
+      const uint64_t n = eq->off[c + 1] - eq->off[c];
+      if (ncl && ents + n > CL_CHUNK) { H.cchunk.push_back((uint32_t)c); ents = 0; ncl = 0; }
+      ents += n; ++ncl;
+    }
+    if (E) H.cchunk.push_back((uint32_t)E); }
   H.l2_lo.clear(); H.l2_cnt.clear();
   if (H.nlevels == 2) {
     H.l2_lo.assign(M, 0); H.l2_cnt.assign(M, 0);
@@ -342,7 +372,7 @@ struct EmSession {
   uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmHost H; EmDev d;
   DBuf<uint64_t> d_off, d_toff; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
-  DBuf<uint32_t> d_chunk, d_l2lo; DBuf<uint8_t> d_l2cnt, d_seg8;
+  DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
   ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st) (void)hipStreamDestroy(st); }
 
@@ -360,11 +390,12 @@ struct EmSession {
     bool ok = !d_off.upload(off) && !d_tid.upload(tid) && !d_cw.upload(H.cw) && !d_cnt.upload(H.cnt) && !d_toff.upload(H.t_off) && !d_tcls.upload(H.t_cls) &&
               !d_tcw.upload(H.t_cw) && !d_prior.upload(H.prior) && !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) &&
               !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) &&
-              !d_chunk.upload(H.chunk_seg) && !d_seg8.upload(H.t_seg8) && (H.l2_cnt.empty() || (!d_l2lo.upload(H.l2_lo) && !d_l2cnt.upload(H.l2_cnt)));
+              !d_chunk.upload(H.chunk_seg) && !d_cchunk.upload(H.cchunk) && !d_seg8.upload(H.t_seg8) && (H.l2_cnt.empty() || (!d_l2lo.upload(H.l2_lo) && !d_l2cnt.upload(H.l2_cnt)));
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     d.M = M; d.E = E; d.L = L; d.off = d_off.p; d.tid = d_tid.p; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
     d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
     d.nlevels = H.nlevels; for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.nseg[l] = l < H.nlevels ? (uint32_t)H.seg_lo[l].size() : 0; d.part[l] = d_lpart[l].p; }
+    d.cchunk = d_cchunk.p; d.ncchunks = H.cchunk.size() > 1 ? (uint32_t)H.cchunk.size() - 1 : 0;
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = H.chunk_seg.size() > 1 ? (uint32_t)H.chunk_seg.size() - 1 : 0;
     d.l2_lo = H.l2_cnt.empty() ? nullptr : d_l2lo.p; d.l2_cnt = H.l2_cnt.empty() ? nullptr : d_l2cnt.p;
     SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
@@ -392,7 +423,7 @@ struct EmSession {
     auto launch_iter = [&](uint32_t it) {
       const double* theta_src = cur;
       if (o->use_vbem) { k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p); theta_src = d.theta; }
-      k_class<<<(E + TB - 1) / TB, TB, 0, st>>>(d, theta_src);
+      if (d.ncchunks) k_class<<<d.ncchunks, CL_TB, 0, st>>>(d, theta_src);
       if (d.nchunks) k_l1<<<d.nchunks, L1_TB, 0, st>>>(d, theta_src, nxt);
       if (!d.l2_cnt) { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
         if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }

@@ -31,6 +31,16 @@ struct sq_online_dev {
   // eq table
   uint64_t tcap = 0; sq_dbuf<unsigned long long> tk1, tk2, tcount, tpool; sq_dbuf<uint32_t> tn; sq_dbuf<uint32_t> pool_tid, pool_bin; sq_dbuf<unsigned long long> pool_wq; sq_dbuf<unsigned long long> pool_cursor;  // [0] labels used, [1] classes, [2] overflow flag
   uint64_t pool_cap = 0;
+  // export of the table in canonical order: persistent device buffers + a pinned host staging area.  The export
+  // (kernels + D2H) runs back to back with the end of the eq stage on the first sq_eq_finish call; the second call
+  // (caller's arrays now allocated) is a host copy.  Touching the GPU again after the short idle gap in between
+  // was measured to stall 20-35 ms on MI355X (first dispatch after heavy load + ~2 ms idle).
+  struct eq_export {
+    sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr; sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie; sq_dbuf<uint64_t> d_off; sq_dbuf<double> d_w; sq_dbuf<uint8_t> tmp;
+    uint8_t* host = nullptr; size_t host_cap = 0; uint64_t E = 0, L = 0; bool valid = false, model_valid = false; size_t model_off = 0;   // staged model summary (mass, uniq, total, logEffLen) at host + model_off
+    void release() { keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
+                     if (host) (void)hipHostFree(host); host = nullptr; host_cap = 0; valid = false; }
+  } exp;
   std::vector<double> fm_host;
   uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0; bool burned_known = false;
 };
@@ -221,11 +231,14 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 }
 
 
-// 16 lanes per fragment: each lane evaluates one alignment (table lookups only), the in-order
-// log-sum chains are replayed by all 16 lanes from shuffled values (SIMT-free), then every lane
-// finishes its own alignment (two exps, fixed-point increments).  Fragments with more than 16
-// alignments take the sequential path on lane 0.  Same arithmetic, same order as the checker.
-#define MB_G 16
+// 8 lanes per fragment, two alignment slots per lane (alignments j and j+8): each lane evaluates its
+// alignments (table lookups only), the in-order log-sum chains are replayed by all lanes of the group
+// from shuffled values (SIMT-free), then every lane finishes its own alignments (two exps, fixed-point
+// increments).  Fragments with more than 16 alignments take the sequential path on lane 0.  Same
+// arithmetic, same order as the checker.  (8 rather than 16 lanes: half the workgroups per mini-batch,
+// so the kernel fits the eq stage's CU partition in one round.)
+#define MB_G 8
+#define MB_S 2
 __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
                              unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint32_t par) {
@@ -235,7 +248,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const bool valid = r < r1;
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
-  if (valid && nA > MB_G) {
+  if (valid && nA > MB_G * MB_S) {
     if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
@@ -244,72 +257,92 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       const bool useAux = (assigned_base + assigned_prefix[r]) >= o.num_pre_burnin_frags;
       const bool cond = burned || useAux; const bool singleEnd = (o.lib_type == 0);
       const double totMass = V.scal[0];
-      // phase 1: lane j -> alignment a0 + j
-      bool keep = false; double auxProb = 0.0, logProb = 0.0; uint32_t t = 0; uint32_t fl_ped = 0; uint8_t fmt = 0;
-      const uint64_t ai = a0 + j;
-      if (j < nA) {
-        const PreAln p = pre[ai]; fl_ped = p.fl_ped; fmt = p.fmt;
-        if (p.flags & PF_KEEP) {
-          t = aln[ai].tid;
-          double logFragProb = 0.0;
-          if (p.flags & PF_ORPHAN_MODEL) {
-            const bool useFLD = singleEnd || burned; const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
-            double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
-            logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
-          } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
-          if (p.flen > 0 && o.use_frag_len_dist && cond) {
-            const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
-            const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
-            if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[t] || (V.ref_len[t] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
-            else if (useAux) logFragProb = lenProb;
+      // phase 1: lane j -> alignments a0 + j and a0 + j + 8
+      bool keep[MB_S]; double auxProb[MB_S], logProb[MB_S]; uint32_t t[MB_S]; uint32_t fl_ped[MB_S]; uint64_t fmtBit[MB_S];
+#pragma unroll
+      for (int sl = 0; sl < MB_S; ++sl) {
+        keep[sl] = false; auxProb[sl] = 0.0; logProb[sl] = 0.0; t[sl] = 0; fl_ped[sl] = 0; fmtBit[sl] = 0;
+        const uint32_t idx = j + MB_G * sl;
+        if (idx < nA) {
+          const uint64_t ai = a0 + idx;
+          const PreAln p = pre[ai]; fl_ped[sl] = p.fl_ped;
+          if (p.flags & PF_KEEP) {
+            const uint32_t tt = aln[ai].tid; t[sl] = tt;
+            double logFragProb = 0.0;
+            if (p.flags & PF_ORPHAN_MODEL) {
+              const bool useFLD = singleEnd || burned; const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
+              double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
+              logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
+            } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
+            if (p.flen > 0 && o.use_frag_len_dist && cond) {
+              const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
+              const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
+              if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[tt] || (V.ref_len[tt] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+              else if (useAux) logFragProb = lenProb;
+            }
+            const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
+            double startPosProb;
+            if (p.flags & PF_PE_START) startPosProb = p.c_start;
+            else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[tt]); startPosProb = -logRefLength; }
+            fmtBit[sl] = 1ULL << p.fmt;
+            auxProb[sl] = logFragProb + p.c_cov + logCompat;
+            logProb[sl] = V.tlc[tt] + auxProb[sl] + startPosProb;
+            keep[sl] = !(fabs(logProb[sl]) == SQ_LOG_0);
           }
-          const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
-          double startPosProb;
-          if (p.flags & PF_PE_START) startPosProb = p.c_start;
-          else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[t]); startPosProb = -logRefLength; }
-          fmtSeen = 1ULL << fmt;
-          auxProb = logFragProb + p.c_cov + logCompat;
-          logProb = V.tlc[t] + auxProb + startPosProb;
-          keep = !(fabs(logProb) == SQ_LOG_0);
         }
       }
-      // chains, replayed identically by the 16 lanes of the group
+      // chains, replayed identically by the lanes of the group (alignment i lives in lane i & 7, slot i >> 3)
       double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtAll = 0;
       for (uint32_t i = 0; i < nA; ++i) {
-        const int kp = __shfl((int)keep, (int)i, MB_G); const double xa = __shfl(auxProb, (int)i, MB_G); const double xl = __shfl(logProb, (int)i, MB_G);
-        const unsigned long long fm = __shfl((unsigned long long)fmtSeen, (int)i, MB_G);
+        const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
+        const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G);
+        const double xa = __shfl(hi ? auxProb[1] : auxProb[0], src, MB_G); const double xl = __shfl(hi ? logProb[1] : logProb[0], src, MB_G);
+        const unsigned long long fm = __shfl((unsigned long long)(hi ? fmtBit[1] : fmtBit[0]), src, MB_G);
         fmtAll |= fm;
         if (kp) { sumProbs = sq_log_add(sumProbs, xl); auxDenom = sq_log_add(auxDenom, xa); ++nk; }
       }
       const bool assigned = !(nk == 0 || sumProbs == SQ_LOG_0);
-      // kept-index of this lane's alignment (ki of the sequential form); ballot in group-uniform code
-      const unsigned long long kb = __ballot(keep);
-      const uint32_t gbits = (uint32_t)((kb >> ((threadIdx.x & 63) & ~(MB_G - 1))) & ((1u << MB_G) - 1));
-      const uint32_t ki = (uint32_t)__popc(gbits & ((1u << j) - 1));
+      // kept-index of this lane's alignments (ki of the sequential form); ballots in group-uniform code
+      const unsigned long long kb0 = __ballot(keep[0]), kb1 = __ballot(keep[1]);
+      const int gsh = (int)((threadIdx.x & 63) & ~(MB_G - 1));
+      const uint32_t g0 = (uint32_t)((kb0 >> gsh) & ((1u << MB_G) - 1)), g1 = (uint32_t)((kb1 >> gsh) & ((1u << MB_G) - 1));
+      const uint32_t kis[MB_S] = {(uint32_t)__popc(g0 & ((1u << j) - 1)), (uint32_t)(__popc(g0) + __popc(g1 & ((1u << j) - 1)))};
       // phase 2
-      uint32_t bin = 0xFFFFFFFFu;
-      if (j < nA) {
-        if (assigned && keep) {
-          const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
-          const double w = sq_exp(auxProb - auxDenom);
-          bin = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
-          awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
-          const double pr = sq_exp(logProb - sumProbs);
-          mass_add(V, par, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
-          atomicAdd(&V.total[t], 1ULL);
-          if (!burned) {
-            double rr = dev_u01(o.seed, read_counter0 + (r - r0), ki);
-            if (rr < pr && fl_ped > 0) { atomicAdd(&V.fld_cnt[fl_ped], 1u); if ((unsigned long long)fl_ped < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped); }
+      uint32_t bin[MB_S] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+      for (int sl = 0; sl < MB_S; ++sl) {
+        const uint32_t idx = j + MB_G * sl;
+        if (idx < nA) {
+          const uint64_t ai = a0 + idx;
+          if (assigned && keep[sl]) {
+            const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
+            const double w = sq_exp(auxProb[sl] - auxDenom);
+            bin[sl] = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
+            awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
+            const double pr = sq_exp(logProb[sl] - sumProbs);
+            mass_add(V, par, t[sl], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+            atomicAdd(&V.total[t[sl]], 1ULL);
+            if (!burned) {
+              double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
+              if (rr < pr && fl_ped[sl] > 0) { atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u); if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped[sl]); }
+            }
           }
+          abin[ai] = bin[sl];
         }
-        abin[ai] = bin;
       }
       // label hash (tids of kept alignments, then their bins), replayed by all lanes; lane 0 publishes
       if (assigned) {
         const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
         uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen; uint32_t firstTid = 0; bool gotFirst = false;
-        for (uint32_t i = 0; i < nA; ++i) { const int kp = __shfl((int)keep, (int)i, MB_G); const uint32_t ti = (uint32_t)__shfl((int)t, (int)i, MB_G); if (kp) { label_hash_step(ha, hb, ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } } }
-        if (o.range_factorization_bins > 0) for (uint32_t i = 0; i < nA; ++i) { const uint32_t bi = (uint32_t)__shfl((int)bin, (int)i, MB_G); if (bi != 0xFFFFFFFFu) label_hash_step(ha, hb, bi); }
+        for (uint32_t i = 0; i < nA; ++i) {
+          const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
+          const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G); const uint32_t ti = (uint32_t)__shfl((int)(hi ? t[1] : t[0]), src, MB_G);
+          if (kp) { label_hash_step(ha, hb, ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } }
+        }
+        if (o.range_factorization_bins > 0) for (uint32_t i = 0; i < nA; ++i) {
+          const uint32_t bi = (uint32_t)__shfl((int)(i >= MB_G ? bin[1] : bin[0]), (int)(i & (MB_G - 1)), MB_G);
+          if (bi != 0xFFFFFFFFu) label_hash_step(ha, hb, bi);
+        }
         if (j == 0) {
           uint64_t h1 = sq_mix64(ha), h2 = sq_mix64(hb);
           if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
@@ -582,7 +615,7 @@ int sq_online_create(sq_ctx* c) {
 void sq_online_free(sq_ctx* c) {
   sq_online_dev* o = c->online; if (!o) return;
   o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->tlc.free_(); o->pre.free_(); o->alp.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
-  o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
+  o->exp.release(); o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
   o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
   delete o; c->online = nullptr;
 }
@@ -598,7 +631,12 @@ static double forgetting_mass(sq_online_dev* o, double ff, uint64_t b) {  // For
 
 static int check_eq_overflow(sq_ctx* c) {
   unsigned long long cur[4];
-  SQ_HIP_CHECK(hipMemcpy(cur, c->online->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] ovf %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  SQ_HIP_CHECK(hipMemcpyAsync(cur, c->online->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, c->stream));
+  mark("memcpyAsync");
+  SQ_HIP_CHECK(hipStreamSynchronize(c->stream));   // not the null stream (device-wide implicit sync), not the eq streams (the runtime may still be retiring their thousands of launches)
+  mark("streamSync");
   if (cur[2]) { sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]); return SQ_ERR_OVERFLOW; }
   if (cur[1] * 10 > c->online->tcap * 7) { sq_set_error("equivalence-class table over 70%% full (%llu classes)", cur[1]); return SQ_ERR_OVERFLOW; }
   return SQ_OK;
@@ -611,14 +649,22 @@ void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id) {
 }
 int sq_eq_sync(sq_ctx* c) {
   if (!c || !c->stream2) return SQ_OK;
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_sync %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
   { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= c->eq_submitted; }); }
+  mark("worker");
   SQ_HIP_CHECK(hipSetDevice(c->device));
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream2));
+  mark("stream2");
   if (c->stream3) SQ_HIP_CHECK(hipStreamSynchronize(c->stream3));
+  mark("stream3");
   c->eq_pending[0] = c->eq_pending[1] = false;
   sq_prof_end(c, 1);
+  mark("prof");
   { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); c->eq_err = 0; c->eq_errmsg.clear(); return e; } }
-  return check_eq_overflow(c);
+  int rc = check_eq_overflow(c);
+  mark("overflow-check");
+  return rc;
 }
 
 static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J);
@@ -646,6 +692,7 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
   if (!c || !c->have_batch) { sq_set_error("sq_eq_accumulate: call sq_map_batch first"); return SQ_ERR_STATE; }
   c->have_batch = false;
   if (c->last_n == 0) return SQ_OK;
+  c->online->exp.valid = false;
   sq_ctx::eq_job J; J.n = c->last_n; J.buf = c->last_buf; J.total_aln = c->last_total_aln; J.joint = c->last_joint;
   { std::lock_guard<std::mutex> lk(c->eq_mu);
     if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); return e; }   // an earlier batch failed
@@ -680,7 +727,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
-  const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
+  uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
+  if (getenv("SQ_DBG_MB")) mb = (uint32_t)atoi(getenv("SQ_DBG_MB"));
   const uint32_t nmb = (n + mb - 1) / mb;
   std::vector<uint64_t> bound(nmb + 1);
   if (o->rh2.n < nmb + 2) { sq_set_error("internal: bounds scratch too small"); return SQ_ERR_STATE; }
@@ -749,6 +797,12 @@ static int finish_efflen(sq_ctx* c) {
 
 extern "C" int sq_model_fetch(sq_ctx* c, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len) {
   if (!c) return SQ_ERR_ARG;
+  if (c->online->exp.valid && c->online->exp.model_valid) {   // staged together with the eq-class export: no GPU round trip
+    const auto& X = c->online->exp; const size_t M = c->online->M; const uint8_t* h = X.host + X.model_off;
+    if (log_mass) memcpy(log_mass, h, M * 8); if (unique_count) memcpy(unique_count, h + M * 8, M * 8);
+    if (total_count) memcpy(total_count, h + 2 * M * 8, M * 8); if (log_eff_len) memcpy(log_eff_len, h + 3 * M * 8, M * 8);
+    return SQ_OK;
+  }
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   int rc = finish_efflen(c); if (rc) return rc;
@@ -774,61 +828,98 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
 // export in canonical order (ascending (h1,h2)); sizes first when arrays are NULL.  Compaction, sort
 // (rocPRIM radix sort on h1), offsets (scan) and the gather all run on the device; only the compact
 // CSR crosses PCIe.
-extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
-  if (!c || !out) return SQ_ERR_ARG;
+// device-side export into o->exp (see sq_online_dev::eq_export)
+static int eq_export_run(sq_ctx* c) {
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_finish %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_export %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   mark("sync");
   SQ_HIP_CHECK(hipSetDevice(c->device));
-  sq_online_dev* o = c->online; hipStream_t st = c->stream;
-  unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
+  sq_online_dev* o = c->online; hipStream_t st = c->stream; auto& X = o->exp;
+  unsigned long long cur[4], hctr[8]; SQ_HIP_CHECK(hipMemcpyAsync(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
   const uint64_t E = cur[1], L = cur[0];
-  out->num_classes = E; out->num_labels = L;
-  if (!out->off) return SQ_OK;
-  if (E == 0) { out->off[0] = 0; return SQ_OK; }
+  const bool model_final = hctr[1] != 0 || hctr[4] == 4;   // effective lengths already final (burned in / finalised): the model summary can ride along
+  X.E = E; X.L = L; X.valid = false;
+  X.model_valid = false;
+  if (E == 0) return SQ_OK;   // nothing staged; fetches fall back to direct copies
   EqView T = make_eq_view(o);
-  sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr; sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie; sq_dbuf<uint64_t> d_off; sq_dbuf<double> d_w; sq_dbuf<uint8_t> tmp;
-  if (keys.ensure(E) || keys2.ensure(E) || slots.ensure(E) || slots2.ensure(E) || nlab.ensure(E + 1) || d_off.ensure(E + 1) || d_tid.ensure(L) || d_bins.ensure(L) || d_wq.ensure(L) || d_w.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_ctr.ensure(1) || d_tie.ensure(1)) {
-    sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
+      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1)) { sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
+  const size_t M = o->M; const size_t need = 32 * E + 24 * L + 64 + 32 * M;
+  if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0; const size_t cap = need + need / 4;
+    if (hipHostMalloc((void**)&X.host, cap, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (eq export, %zu bytes)", cap); return SQ_ERR_NOMEM; } X.host_cap = cap; }
   mark("alloc");
-  SQ_HIP_CHECK(hipMemsetAsync(d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_tie.p, 0, 4, st));
-  k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, keys.p, slots.p, d_ctr.p);
+  SQ_HIP_CHECK(hipMemsetAsync(X.d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(X.d_tie.p, 0, 4, st));
+  k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, X.keys.p, X.slots.p, X.d_ctr.p);
   size_t tb = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, keys2.p, slots.p, slots2.p, (int)E, 0, 64, st);
-  if (tmp.ensure(tb + 256)) { sq_set_error("device allocation failed (eq export sort)"); return SQ_ERR_NOMEM; }
-  tb = tmp.n;
-  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, keys2.p, slots.p, slots2.p, (int)E, 0, 64, st));
-  k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, slots2.p, keys2.p, nlab.p, d_tie.p);
-  size_t tb2 = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, nlab.p, d_off.p, (int)(E + 1), st);
-  if (tmp.ensure(tb2 + 256)) { sq_set_error("device allocation failed (eq export scan)"); return SQ_ERR_NOMEM; }
-  tb2 = tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
-  uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+  hipcub::DeviceRadixSort::SortPairs(nullptr, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (int)E, 0, 64, st);
+  size_t tb2 = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st);
+  if (X.tmp.ensure(std::max(tb, tb2) + 256)) { sq_set_error("device allocation failed (eq export temp)"); return SQ_ERR_NOMEM; }
+  tb = X.tmp.n;
+  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(X.tmp.p, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (int)E, 0, 64, st));
+  k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, X.slots2.p, X.keys2.p, X.nlab.p, X.d_tie.p);
+  tb2 = X.tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st));
+  uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, X.d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
   if (tie) {  // two classes share a sort key and arrived out of (h1,h2) order: re-sort the slot list on the host (rare)
     std::vector<uint32_t> hs(E), ord(E); std::vector<unsigned long long> hk(E), k1(o->tcap), k2(o->tcap);
-    SQ_HIP_CHECK(hipMemcpy(hs.data(), slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(hk.data(), keys2.p, E * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(hs.data(), X.slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(hk.data(), X.keys2.p, E * 8, hipMemcpyDeviceToHost));
     SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < E; ++i) ord[i] = (uint32_t)i;
     std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { if (hk[x] != hk[y]) return hk[x] < hk[y]; const uint32_t a = hs[x], b = hs[y]; return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
     std::vector<uint32_t> hs2(E); for (uint64_t i = 0; i < E; ++i) hs2[i] = hs[ord[i]];
-    SQ_HIP_CHECK(hipMemcpy(slots2.p, hs2.data(), E * 4, hipMemcpyHostToDevice));
-    k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, slots2.p, keys2.p, nlab.p, d_tie.p);
-    SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb2, nlab.p, d_off.p, (int)(E + 1), st));
+    SQ_HIP_CHECK(hipMemcpy(X.slots2.p, hs2.data(), E * 4, hipMemcpyHostToDevice));
+    k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, X.slots2.p, X.keys2.p, X.nlab.p, X.d_tie.p);
+    SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st));
   }
-  k_eq_gather<<<nblk(E), TB, 0, st>>>(T, E, slots2.p, d_off.p, d_tid.p, d_w.p, d_wq.p, d_cnt.p, d_bins.p, d_h1.p, d_h2.p);
-  if (timing) { (void)hipStreamSynchronize(st); mark("kernels"); }
-  SQ_HIP_CHECK(hipMemcpyAsync(out->off, d_off.p, (E + 1) * 8, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipMemcpyAsync(out->tid, d_tid.p, L * 4, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipMemcpyAsync(out->w, d_w.p, L * 8, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipMemcpyAsync(out->count, d_cnt.p, E * 8, hipMemcpyDeviceToHost, st));
-  if (out->wq) SQ_HIP_CHECK(hipMemcpyAsync(out->wq, d_wq.p, L * 8, hipMemcpyDeviceToHost, st));
-  if (out->bins) SQ_HIP_CHECK(hipMemcpyAsync(out->bins, d_bins.p, L * 4, hipMemcpyDeviceToHost, st));
-  if (out->h1) SQ_HIP_CHECK(hipMemcpyAsync(out->h1, d_h1.p, E * 8, hipMemcpyDeviceToHost, st));
-  if (out->h2) SQ_HIP_CHECK(hipMemcpyAsync(out->h2, d_h2.p, E * 8, hipMemcpyDeviceToHost, st));
+  k_eq_gather<<<nblk(E), TB, 0, st>>>(T, E, X.slots2.p, X.d_off.p, X.d_tid.p, X.d_w.p, X.d_wq.p, X.d_cnt.p, X.d_bins.p, X.d_h1.p, X.d_h2.p);
+  // staging layout: off[E+1] | count[E] | h1[E] | h2[E] | wq[L] | w[L] | tid[L] | bins[L]
+  uint8_t* h = X.host;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_off.p, (E + 1) * 8, hipMemcpyDeviceToHost, st)); h += (E + 1) * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_cnt.p, E * 8, hipMemcpyDeviceToHost, st)); h += E * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_h1.p, E * 8, hipMemcpyDeviceToHost, st)); h += E * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_h2.p, E * 8, hipMemcpyDeviceToHost, st)); h += E * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_wq.p, L * 8, hipMemcpyDeviceToHost, st)); h += L * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_w.p, L * 8, hipMemcpyDeviceToHost, st)); h += L * 8;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_tid.p, L * 4, hipMemcpyDeviceToHost, st)); h += L * 4;
+  SQ_HIP_CHECK(hipMemcpyAsync(h, X.d_bins.p, L * 4, hipMemcpyDeviceToHost, st)); h += L * 4;
+  h = X.host + (((size_t)(h - X.host) + 7) & ~(size_t)7); X.model_off = (size_t)(h - X.host);
+  if (model_final) {
+    SQ_HIP_CHECK(hipMemcpyAsync(h, o->mass.p, M * 8, hipMemcpyDeviceToHost, st)); h += M * 8;
+    SQ_HIP_CHECK(hipMemcpyAsync(h, o->uniq.p, M * 8, hipMemcpyDeviceToHost, st)); h += M * 8;
+    SQ_HIP_CHECK(hipMemcpyAsync(h, o->total.p, M * 8, hipMemcpyDeviceToHost, st)); h += M * 8;
+    SQ_HIP_CHECK(hipMemcpyAsync(h, o->log_eff_len.p, M * 8, hipMemcpyDeviceToHost, st));
+  }
   SQ_HIP_CHECK(hipStreamSynchronize(st));
-  mark("d2h");
-  keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
-  mark("free");
+  X.model_valid = model_final;
+  mark("kernels+d2h");
+  X.valid = true;
+  return SQ_OK;
+}
+
+extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
+  if (!c || !out) return SQ_ERR_ARG;
+  sq_online_dev* o = c->online; auto& X = o->exp;
+  if (!X.valid) { int rc = eq_export_run(c); if (rc) return rc; }
+  const uint64_t E = X.E, L = X.L;
+  out->num_classes = E; out->num_labels = L;
+  if (!out->off) return SQ_OK;          // size query; the table is already staged for the fetch that follows
+  if (E == 0) { out->off[0] = 0; return SQ_OK; }
+  if (!out->tid || !out->w || !out->count) { sq_set_error("sq_eq_finish: output arrays missing"); return SQ_ERR_ARG; }
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  // host copy out of the pinned staging area, a few threads wide
+  struct Seg { uint8_t* dst; const uint8_t* src; size_t n; };
+  std::vector<Seg> segs; const uint8_t* h = X.host;
+  auto add = [&](void* dst, size_t n) { if (dst && n) segs.push_back({(uint8_t*)dst, h, n}); h += n; };
+  add(out->off, (E + 1) * 8); add(out->count, E * 8); add(out->h1, E * 8); add(out->h2, E * 8); add(out->wq, L * 8); add(out->w, L * 8); add(out->tid, L * 4); add(out->bins, L * 4);
+  std::vector<Seg> chunks; const size_t CH = 4u << 20;
+  for (auto& sg : segs) for (size_t p = 0; p < sg.n; p += CH) chunks.push_back({sg.dst + p, sg.src + p, std::min(CH, sg.n - p)});
+  std::atomic<size_t> next{0};
+  auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= chunks.size()) break; memcpy(chunks[i].dst, chunks[i].src, chunks[i].n); } };
+  const unsigned nth = (unsigned)std::min<size_t>(8, std::max<size_t>(1, chunks.size() / 2));
+  std::vector<std::thread> th; for (unsigned i = 1; i < nth; ++i) th.emplace_back(work);
+  work(); for (auto& t : th) t.join();
+  if (timing) fprintf(stderr, "[sq-timing] eq_finish host-copy %.3f ms (%u threads)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), nth);
   return SQ_OK;
 }
 
@@ -837,6 +928,7 @@ extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
   SQ_HIP_CHECK(hipSetDevice(c->device));
   const uint64_t E = t->num_classes, L = t->num_labels; if (E == 0) return SQ_OK;
   { int rs = sq_eq_sync(c); if (rs) return rs; }
+  c->online->exp.valid = false;
   sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins, d_slot;
   if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L) || d_slot.ensure(E)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
   hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice); hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice);

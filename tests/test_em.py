@@ -95,3 +95,25 @@ def test_gpu_em_eqclass_mode_and_degenerate(built):
     want, _ = orc.em_optimize(eq, eff, None, o)
     got, _ = api.em_optimize(eq, eff, None, o)
     assert np.array_equal(got, want) and got[3] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vb", [0, 1])
+def test_gpu_em_giant_class_and_hot_transcript(built, vb):
+    # one class wider than the k_class LDS chunk (2048 labels) stands alone in its block; transcript 0
+    # sits in every class (deep blocked-64 plan); a block of single-label classes exercises the -count path
+    M, E = 5000, 9000
+    rng = np.random.default_rng(23)
+    labs = [np.arange(3000, dtype=np.uint32)]                                   # the giant class
+    for c in range(1, E):
+        if c % 7 == 0: labs.append(np.array([rng.integers(0, M)], np.uint32))
+        else: labs.append(np.unique(np.concatenate([[0], rng.integers(1, M, rng.integers(1, 9))]).astype(np.uint32)))
+    cnt = np.array([len(l) for l in labs]); off = np.zeros(E + 1, np.uint64); off[1:] = np.cumsum(cnt)
+    tid = np.concatenate(labs); x = rng.random(len(tid)) + 0.05
+    w = x / np.repeat(np.add.reduceat(x, off[:-1].astype(np.int64)), cnt)
+    eq = api.EqClasses(off, tid, w, rng.integers(1, 300, E).astype(np.uint64))
+    eff = rng.uniform(50, 5000, M); a0 = rng.uniform(0, 50, M)
+    o = api.em_opts(use_vbem=vb)
+    want = orc.em_steps(eq, eff, a0, 5, o)
+    got, _ = api.em_steps(eq, eff, a0, 5, o)
+    assert np.array_equal(got, want), float(np.max(np.abs(got - want)))
