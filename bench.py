@@ -128,7 +128,7 @@ def main():
     t_norm = time.perf_counter() - t_a
     eff = np.exp(le)
     t_a = time.perf_counter()
-    alphas, rep = api.em_optimize(eq, eff, proj, api.em_opts(), device=local)
+    alphas, rep = ctx.em_optimize(eff, proj, api.em_opts())   # the ctx's own classes (incl. merged ones), read from the export resident in HBM
     t_em = time.perf_counter() - t_a
     torch.cuda.synchronize()
     if dist: dist.barrier()

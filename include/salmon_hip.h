@@ -279,7 +279,10 @@ typedef struct {
   double ms_per_iter;
 } sq_em_report;
 
-/* Full optimisation. eq arrays are host pointers (copied) — tid/w/count/off as in sq_eq_table. */
+/* Full optimisation. eq arrays are host pointers (copied) — tid/w/count/off as in sq_eq_table.
+ * eq == NULL: optimise over the classes the ctx itself has accumulated (the reference passes the
+ * experiment, which owns its eq-classes: optimizer.optimize(experiment, ...)); they are read from the
+ * canonical-order export already resident in HBM, nothing is re-uploaded. */
 int sq_em_optimize(sq_ctx*, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                    double* alpha_out /*[M]*/, sq_em_report* report);
 /* Standalone variant that needs no index/ctx (the `salmon quant -e` seam,

@@ -246,6 +246,17 @@ class QuantContext:
         check(lib().sq_eq_finish(self.h, C.byref(tt)), "sq_eq_finish")
         return eq
 
+    def em_optimize(self, eff_len, projected=None, opts=None):
+        """CollapsedEMOptimizer::optimize over the classes this context accumulated (sq_em_optimize with eq = NULL):
+        the optimizer reads the canonical-order export that already sits in HBM."""
+        o = opts or em_opts()
+        txp = make_txp_in(eff_len, projected)
+        out = np.zeros(txp.num_txp)
+        rep = capi.EmReport()
+        check(lib().sq_em_optimize(self.h, None, C.byref(txp), C.byref(o), _ptr(out, C.c_double), C.byref(rep)), "sq_em_optimize")
+        return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum,
+                         device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+
     def eq_merge(self, eq):
         t = eq.table()
         check(lib().sq_eq_merge(self.h, C.byref(t)), "sq_eq_merge")

@@ -117,5 +117,6 @@ void sq_eq_worker_stop(sq_ctx* c);                                // wait for ou
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };
 
+int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_online_create(sq_ctx* c);
 void sq_online_free(sq_ctx* c);

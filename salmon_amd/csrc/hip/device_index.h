@@ -25,3 +25,8 @@ struct sq_device_index {
       return SQ_ERR_DEVICE;                                                                    \
     }                                                                                          \
   } while (0)
+
+// label-major CSR already resident in HBM (a ctx's staged eq-class export): off[E+1], tid[L], w[L], count[E]
+struct sq_eq_dev_csr { uint64_t E, L; const uint64_t* off; const uint32_t* tid; const double* w; const unsigned long long* cnt; };
+// EM over a host table (eq) or over a CSR that already lives on `device` (dv); em.hip
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep);

@@ -13,6 +13,7 @@
 // GPU result is bit-identical run to run and to the CPU checker.  Memory-bound gather/stream:
 // per iteration 36·L + 16·E + 64·M algorithmic bytes.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -286,82 +287,83 @@ double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used
   }
 }
 
-struct EmHost {  // host-side preparation (CollapsedEMOptimizer.cpp:760-873)
-  std::vector<double> cw, cnt, prior, t_cw; std::vector<uint64_t> t_off; std::vector<uint32_t> t_cls;
-  std::vector<uint32_t> seg_lo[4], seg_txp[4]; std::vector<uint8_t> seg_cnt[4]; int nlevels = 0;
-  std::vector<uint32_t> chunk_seg, l2_lo, cchunk; std::vector<uint8_t> l2_cnt, t_seg8;   // k_l1 block plan; level 2 folded into k_fin (two-level plans)
-};
-
-int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, EmHost& H) {
-  const uint64_t E = eq->num_classes, L = eq->num_labels; const uint32_t M = txp->num_txp;
-  if (E >= 0xFFFFFFFFull) { sq_set_error("too many equivalence classes"); return SQ_ERR_OVERFLOW; }
-  for (uint64_t i = 0; i < L; ++i) if (eq->tid[i] >= M) { sq_set_error("eq-class label references transcript %u >= %u", eq->tid[i], M); return SQ_ERR_ARG; }
-  H.cw.resize(L); H.cnt.resize(E);
-  for (uint64_t c = 0; c < E; ++c) {
-    H.cnt[c] = (double)eq->count[c];
-    double wsum = 0.0;
-    for (uint64_t i = eq->off[c]; i < eq->off[c + 1]; ++i) {
-      double el = txp->eff_len[eq->tid[i]]; if (el <= 1.0) el = 1.0;           // :841-844
-      double w = o->no_rich_eq_classes ? 1.0 : eq->w[i];                        // :845-848
-      double wt = o->eq_class_mode ? w : (double)eq->count[c] * w * (1.0 / el); // :850-853
-      H.cw[i] = wt; wsum += wt;
-    }
-    double wn = 1.0 / wsum;
-    for (uint64_t i = eq->off[c]; i < eq->off[c + 1]; ++i) H.cw[i] = H.cw[i] * wn;
+// ---- problem preparation on the device (CollapsedEMOptimizer.cpp:760-873) ---------------------------
+// combined weights, transcript-major CSC (radix sort of (tid, class) keys), the blocked-64 reduction
+// plan (SPEC §D4) and the block plans of k_class / k_l1 are all built in HBM from the label-major
+// CSR; the host only follows two short "next block" chains.
+__global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const double* __restrict__ w, const uint64_t* __restrict__ cnt_u,
+                          const double* __restrict__ eff, int no_rich, int eq_mode, double* __restrict__ cw, double* __restrict__ cnt_f, uint32_t* __restrict__ err) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
+  const uint64_t a = off[c], b = off[c + 1]; const double cn = (double)cnt_u[c];
+  if (cnt_f) cnt_f[c] = cn;
+  double wsum = 0.0;
+  for (uint64_t i = a; i < b; ++i) {
+    const uint32_t t = tid[i]; if (t >= M) { atomicMax(err, t + 1); return; }
+    double el = eff[t]; if (el <= 1.0) el = 1.0;                 // :841-844
+    const double ww = no_rich ? 1.0 : w[i];                      // :845-848
+    const double wt = eq_mode ? ww : cn * ww * (1.0 / el);       // :850-853
+    cw[i] = wt; wsum += wt;
   }
-  H.prior.assign(M, o->vb_prior);
-  if (!o->per_transcript_prior) for (uint32_t i = 0; i < M; ++i) H.prior[i] = o->vb_prior * txp->eff_len[i];  // populatePriorAlphas_ :82-99
-  H.t_off.assign((size_t)M + 1, 0);
-  for (uint64_t i = 0; i < L; ++i) H.t_off[eq->tid[i] + 1]++;
-  for (uint32_t t = 0; t < M; ++t) H.t_off[t + 1] += H.t_off[t];
-  H.t_cls.resize(L); H.t_cw.resize(L);
-  std::vector<uint64_t> cur(H.t_off.begin(), H.t_off.end() - 1);
-  for (uint64_t c = 0; c < E; ++c) for (uint64_t i = eq->off[c]; i < eq->off[c + 1]; ++i) { uint64_t d = cur[eq->tid[i]]++; H.t_cls[d] = (uint32_t)c; H.t_cw[d] = H.cw[i]; }
-  // blocked-64 reduction plan (SPEC §D4)
-  if (L >= 0x7FFFFFFFull) { sq_set_error("too many label entries for the EM reduction plan"); return SQ_ERR_OVERFLOW; }
-  std::vector<uint32_t> cnt_prev(M), lo_prev(M);   // per transcript: number of items and first item index at the previous level
-  for (uint32_t t = 0; t < M; ++t) { cnt_prev[t] = (uint32_t)(H.t_off[t + 1] - H.t_off[t]); lo_prev[t] = (uint32_t)H.t_off[t]; }
-  H.nlevels = 0;
-  for (int lvl = 0; lvl < 4; ++lvl) {
-    bool any = false;
-    for (uint32_t t = 0; t < M; ++t) {
-      uint32_t n = cnt_prev[t]; if (n == 0 || (lvl > 0 && n == 1)) { if (lvl > 0) cnt_prev[t] = 0; continue; }
-      any = true;
-      uint32_t ns = (n + 63) / 64; uint32_t first = (uint32_t)H.seg_lo[lvl].size();
-      for (uint32_t j = 0; j < ns; ++j) { H.seg_lo[lvl].push_back(lo_prev[t] + 64 * j); H.seg_cnt[lvl].push_back((uint8_t)std::min<uint32_t>(64, n - 64 * j)); H.seg_txp[lvl].push_back(t | (ns == 1 ? SEG_TOP : 0u)); }
-      cnt_prev[t] = ns; lo_prev[t] = first;
-    }
-    if (!any) break;
-    H.nlevels = lvl + 1;
-  }
-  for (uint32_t t = 0; t < M; ++t) if (cnt_prev[t] > 1) { sq_set_error("EM reduction plan deeper than 4 levels"); return SQ_ERR_OVERFLOW; }
-  // k_l1 blocks: consecutive level-1 segments packed up to L1_CHUNK entries / L1_TB segments
-  H.chunk_seg.clear(); H.chunk_seg.push_back(0);
-  { uint32_t ents = 0, segs = 0; const uint32_t ns = (uint32_t)H.seg_lo[0].size();
-    for (uint32_t g = 0; g < ns; ++g) {
-      const uint32_t c = H.seg_cnt[0][g];
-      if (segs && (ents + c > L1_CHUNK || segs == L1_TB)) { H.chunk_seg.push_back(g); ents = 0; segs = 0; }
-      ents += c; ++segs;
-    }
-    if (ns) H.chunk_seg.push_back(ns); }
-  H.t_seg8.resize(L);
-  for (size_t cidx = 0; cidx + 1 < H.chunk_seg.size(); ++cidx)
-    for (uint32_t g = H.chunk_seg[cidx]; g < H.chunk_seg[cidx + 1]; ++g) { const uint32_t lo = H.seg_lo[0][g], n = H.seg_cnt[0][g]; for (uint32_t i = 0; i < n; ++i) H.t_seg8[lo + i] = (uint8_t)(g - H.chunk_seg[cidx]); }
-  // k_class blocks: consecutive classes packed up to CL_CHUNK label entries (a larger class stands alone)
-  H.cchunk.clear(); H.cchunk.push_back(0);
-  { uint64_t ents = 0; uint32_t ncl = 0;
-    for (uint64_t c = 0; c < E; ++c) {
-      const uint64_t n = eq->off[c + 1] - eq->off[c];
-      if (ncl && ents + n > CL_CHUNK) { H.cchunk.push_back((uint32_t)c); ents = 0; ncl = 0; }
-      ents += n; ++ncl;
-    }
-    if (E) H.cchunk.push_back((uint32_t)E); }
-  H.l2_lo.clear(); H.l2_cnt.clear();
-  if (H.nlevels == 2) {
-    H.l2_lo.assign(M, 0); H.l2_cnt.assign(M, 0);
-    for (size_t g = 0; g < H.seg_lo[1].size(); ++g) { const uint32_t t = H.seg_txp[1][g] & ~SEG_TOP; H.l2_lo[t] = H.seg_lo[1][g]; H.l2_cnt[t] = H.seg_cnt[1][g]; }
-  }
-  return SQ_OK;
+  const double wn = 1.0 / wsum;
+  for (uint64_t i = a; i < b; ++i) cw[i] = cw[i] * wn;
+}
+__global__ void k_prep_prior(uint32_t M, const double* __restrict__ eff, double vb_prior, int per_txp, double* __restrict__ prior) {   // populatePriorAlphas_ :82-99
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t < M) prior[t] = per_txp ? vb_prior : vb_prior * eff[t];
+}
+__global__ void k_prep_keys(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, unsigned long long* __restrict__ key, uint32_t* __restrict__ val) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
+  for (uint64_t i = off[c]; i < off[c + 1]; ++i) { key[i] = ((unsigned long long)tid[i] << 32) | c; val[i] = (uint32_t)i; }
+}
+__global__ void k_prep_csc(uint64_t L, uint32_t M, const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const double* __restrict__ cw,
+                           uint32_t* __restrict__ t_cls, double* __restrict__ t_cw, uint64_t* __restrict__ t_off) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= L) return;
+  const unsigned long long k = key[i]; const uint32_t t = (uint32_t)(k >> 32);
+  t_cls[i] = (uint32_t)k; t_cw[i] = cw[val[i]];
+  const int64_t tp = i ? (int64_t)(key[i - 1] >> 32) : -1;
+  for (int64_t x = tp + 1; x <= (int64_t)t; ++x) t_off[x] = i;          // transcripts (tp, t] start here
+  if (i + 1 == L) for (uint64_t x = (uint64_t)t + 1; x <= M; ++x) t_off[x] = L;
+}
+// number of blocked-64 segments of every transcript at each level (0 where the level is not needed)
+__global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, uint32_t* __restrict__ ns0, uint32_t* __restrict__ ns1, uint32_t* __restrict__ ns2, uint32_t* __restrict__ ns3, uint32_t* __restrict__ err) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t > M) return;
+  if (t == M) { ns0[M] = ns1[M] = ns2[M] = ns3[M] = 0; return; }
+  const uint64_t n = t_off[t + 1] - t_off[t];
+  const uint32_t a = (uint32_t)((n + 63) / 64);
+  const uint32_t b = a > 1 ? (a + 63) / 64 : 0, c = b > 1 ? (b + 63) / 64 : 0, dd = c > 1 ? (c + 63) / 64 : 0;
+  if (dd > 1) atomicMax(err, 0xFFFFFFFFu);
+  ns0[t] = a; ns1[t] = b; ns2[t] = c; ns3[t] = dd;
+}
+// segments of level `lvl` for transcript t: runs of 64 items of the previous level (CSC entries for level 0)
+__global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_off, const uint32_t* __restrict__ ns_prev, const uint32_t* __restrict__ base_prev,
+                            const uint32_t* __restrict__ ns, const uint32_t* __restrict__ base, uint32_t* __restrict__ seg_lo, uint8_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_txp) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= M) return;
+  const uint32_t k = ns[t]; if (!k) return;
+  const uint32_t n = lvl == 0 ? (uint32_t)(t_off[t + 1] - t_off[t]) : ns_prev[t];
+  const uint32_t lo = lvl == 0 ? (uint32_t)t_off[t] : base_prev[t];
+  const uint32_t first = base[t];
+  for (uint32_t j = 0; j < k; ++j) { seg_lo[first + j] = lo + 64 * j; seg_cnt[first + j] = (uint8_t)min(64u, n - 64 * j); seg_txp[first + j] = t | (k == 1 ? SEG_TOP : 0u); }
+}
+// greedy block packing as a jump table: nxt[g] = first unit of the block after the one starting at g
+// (a block takes units while its entries stay <= cap and, optionally, its unit count <= maxu)
+template <class T>
+__global__ void k_next_block(uint32_t n, const T* __restrict__ lo /* [n+1], lo[n] = total */, uint32_t cap, uint32_t maxu, uint32_t* __restrict__ nxt) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= n) return;
+  const T lim = lo[g] + cap;
+  uint32_t a = g + 1, b = n;           // largest k in [g+1, n] with lo[k] <= lim; at least g+1
+  while (a < b) { uint32_t m = (a + b + 1) >> 1; if (lo[m] <= lim) a = m; else b = m - 1; }
+  if (maxu && a > g + maxu) a = g + maxu;
+  nxt[g] = a;
+}
+__global__ void k_plan_seg8(uint32_t S0, const uint32_t* __restrict__ chunk_seg, uint32_t nchunks, const uint32_t* __restrict__ seg_lo, const uint8_t* __restrict__ seg_cnt, uint8_t* __restrict__ t_seg8) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= S0) return;
+  uint32_t a = 0, b = nchunks - 1;     // last block with chunk_seg[block] <= g
+  while (a < b) { uint32_t m = (a + b + 1) >> 1; if (chunk_seg[m] <= g) a = m; else b = m - 1; }
+  const uint8_t idx = (uint8_t)(g - chunk_seg[a]); const uint32_t lo = seg_lo[g], n = seg_cnt[g];
+  for (uint32_t i = 0; i < n; ++i) t_seg8[lo + i] = idx;
+}
+__global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, const uint8_t* __restrict__ seg_cnt1, const uint32_t* __restrict__ seg_txp1, uint32_t* __restrict__ l2_lo, uint8_t* __restrict__ l2_cnt) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= S1) return;
+  const uint32_t t = seg_txp1[g] & ~SEG_TOP; l2_lo[t] = seg_lo1[g]; l2_cnt[t] = seg_cnt1[g];
 }
 
 // Runs the iteration loop. mode 0: optimise to convergence; mode 1: exactly `fixed_iters` steps.
@@ -369,37 +371,103 @@ int prepare(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, Em
 // bootstrap replicate with resampled class counts (the combined weights stay those of the original
 // counts, as in doBootstrap — CollapsedEMOptimizer.cpp:398-552).
 struct EmSession {
-  uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmHost H; EmDev d;
-  DBuf<uint64_t> d_off, d_toff; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
+  typedef sq_eq_dev_csr EqDevCsr;
+  uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmDev d;
+  DBuf<uint64_t> d_off, d_toff, d_cntu; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
   ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st) (void)hipStreamDestroy(st); }
 
-  int setup(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts) {
+  // eq: host table (uploaded) — or dv: a CSR that already lives on this device
+  int setup(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, const EqDevCsr* dv = nullptr) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
     SQ_HIP_CHECK(hipSetDevice(device));
     o = opts;
     PhaseTimer pt("em.setup");
-    int rc = prepare(eq, txp, o, H); if (rc) return rc;
-    pt.mark("prepare");
-    M = txp->num_txp; E = (uint32_t)eq->num_classes; L = eq->num_labels; g1 = (M + 63) / 64;
-    std::vector<uint64_t> off(eq->off, eq->off + E + 1); std::vector<uint32_t> tid(eq->tid, eq->tid + L);
-    for (int l = 0; l < H.nlevels; ++l) if (d_slo[l].upload(H.seg_lo[l]) || d_stx[l].upload(H.seg_txp[l]) || d_scn[l].upload(H.seg_cnt[l]) || d_lpart[l].alloc(H.seg_lo[l].size() + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
-    bool ok = !d_off.upload(off) && !d_tid.upload(tid) && !d_cw.upload(H.cw) && !d_cnt.upload(H.cnt) && !d_toff.upload(H.t_off) && !d_tcls.upload(H.t_cls) &&
-              !d_tcw.upload(H.t_cw) && !d_prior.upload(H.prior) && !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) &&
-              !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) &&
-              !d_chunk.upload(H.chunk_seg) && !d_cchunk.upload(H.cchunk) && !d_seg8.upload(H.t_seg8) && (H.l2_cnt.empty() || (!d_l2lo.upload(H.l2_lo) && !d_l2cnt.upload(H.l2_cnt)));
-    if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
-    d.M = M; d.E = E; d.L = L; d.off = d_off.p; d.tid = d_tid.p; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
-    d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
-    d.nlevels = H.nlevels; for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.nseg[l] = l < H.nlevels ? (uint32_t)H.seg_lo[l].size() : 0; d.part[l] = d_lpart[l].p; }
-    d.cchunk = d_cchunk.p; d.ncchunks = H.cchunk.size() > 1 ? (uint32_t)H.cchunk.size() - 1 : 0;
-    d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = H.chunk_seg.size() > 1 ? (uint32_t)H.chunk_seg.size() - 1 : 0;
-    d.l2_lo = H.l2_cnt.empty() ? nullptr : d_l2lo.p; d.l2_cnt = H.l2_cnt.empty() ? nullptr : d_l2cnt.p;
+    const uint64_t E64 = dv ? dv->E : eq->num_classes; L = dv ? dv->L : eq->num_labels; M = txp->num_txp; g1 = (M + 63) / 64;
+    if (E64 >= 0xFFFFFFFFull) { sq_set_error("too many equivalence classes"); return SQ_ERR_OVERFLOW; }
+    if (L >= 0x7FFFFFFFull) { sq_set_error("too many label entries for the EM reduction plan"); return SQ_ERR_OVERFLOW; }
+    E = (uint32_t)E64;
     SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+    const int TB = 256; auto nb = [&](uint64_t n) { return (uint32_t)((n + TB - 1) / TB); };
+    // inputs
+    const uint64_t* p_off; const uint32_t* p_tid; const double* p_w; const unsigned long long* p_cnt;
+    if (dv) { p_off = dv->off; p_tid = dv->tid; p_w = dv->w; p_cnt = dv->cnt; }
+    else {
+      if (d_off.alloc((size_t)E + 1) || d_tid.alloc(L) || d_w.alloc(L) || d_cntu.alloc(E)) { sq_set_error("device allocation failed in EM (inputs)"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemcpyAsync(d_off.p, eq->off, ((size_t)E + 1) * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(d_tid.p, eq->tid, L * 4, hipMemcpyHostToDevice, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(d_w.p, eq->w, L * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(d_cntu.p, eq->count, (size_t)E * 8, hipMemcpyHostToDevice, st));
+      p_off = d_off.p; p_tid = d_tid.p; p_w = d_w.p; p_cnt = (const unsigned long long*)d_cntu.p;
+    }
+    DBuf<unsigned long long> key, key2; DBuf<uint32_t> val, val2, ns[4], base[4], d_err, nxt; DBuf<uint8_t> tmp;
+    bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) && !d_tcls.alloc(L) && !d_tcw.alloc(L) && !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
+              !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
+    for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
+    if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));
     pt.mark("alloc+upload");
+    // combined weights, prior, CSC
+    if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes, o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
+    k_prep_prior<<<nb(M), TB, 0, st>>>(M, d_eff.p, o->vb_prior, o->per_transcript_prior, d_prior.p);
+    if (L) {
+      k_prep_keys<<<nb(E), TB, 0, st>>>(E, p_off, p_tid, key.p, val.p);
+      int tbits = 1; while ((1ull << tbits) < M) ++tbits;
+      size_t tb = 0; hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st);
+      if (tmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (sort)"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st));
+      k_prep_csc<<<nb(L), TB, 0, st>>>(L, M, key2.p, val2.p, d_cw.p, d_tcls.p, d_tcw.p, d_toff.p);
+    }
+    // blocked-64 plan: per-transcript segment counts, exclusive scans, fill
+    k_plan_counts<<<nb((uint64_t)M + 1), TB, 0, st>>>(M, d_toff.p, ns[0].p, ns[1].p, ns[2].p, ns[3].p, d_err.p);
+    { size_t tb = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ns[0].p, base[0].p, (int)(M + 1), st);
+      DBuf<uint8_t> stmp; if (stmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (scan)"); return SQ_ERR_NOMEM; }
+      for (int l = 0; l < 4; ++l) { size_t t2 = tb + 256; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp.p, t2, ns[l].p, base[l].p, (int)(M + 1), st)); }
+      uint32_t S[4] = {0, 0, 0, 0}, herr = 0;
+      for (int l = 0; l < 4; ++l) SQ_HIP_CHECK(hipMemcpyAsync(&S[l], base[l].p + M, 4, hipMemcpyDeviceToHost, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, 4, hipMemcpyDeviceToHost, st));
+      SQ_HIP_CHECK(hipStreamSynchronize(st));
+      if (herr == 0xFFFFFFFFu) { sq_set_error("EM reduction plan deeper than 4 levels"); return SQ_ERR_OVERFLOW; }
+      if (herr) { sq_set_error("eq-class label references transcript %u >= %u", herr - 1, M); return SQ_ERR_ARG; }
+      d.nlevels = 0;
+      for (int l = 0; l < 4; ++l) { d.nseg[l] = S[l]; if (S[l]) d.nlevels = l + 1; }
+    }
+    for (int l = 0; l < 4; ++l) {
+      const size_t n = d.nseg[l];
+      if (d_slo[l].alloc(n + 1) || d_stx[l].alloc(n + 1) || d_scn[l].alloc(n + 1) || d_lpart[l].alloc(n + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p, d_slo[l].p, d_scn[l].p, d_stx[l].p);
+    }
+    // block plans (greedy packing = following a jump table; the chain has ~L/2048 links)
+    std::vector<uint32_t> h_chunk, h_cchunk;
+    { const uint32_t S0 = d.nseg[0]; const uint32_t Lu = (uint32_t)L;
+      SQ_HIP_CHECK(hipMemcpyAsync(d_slo[0].p + S0, &Lu, 4, hipMemcpyHostToDevice, st));   // sentinel: seg_lo[S0] = L
+      if (nxt.alloc(std::max<size_t>(S0, E) + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      std::vector<uint32_t> hn;
+      if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, L1_CHUNK, L1_TB, nxt.p); hn.resize(S0);
+        SQ_HIP_CHECK(hipMemcpyAsync(hn.data(), nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+        for (uint32_t g = 0; g < S0; g = hn[g]) h_chunk.push_back(g); h_chunk.push_back(S0); }
+      if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, CL_CHUNK, 0, nxt.p); hn.resize(E);
+        SQ_HIP_CHECK(hipMemcpyAsync(hn.data(), nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+        for (uint32_t c = 0; c < E; c = hn[c]) h_cchunk.push_back(c); h_cchunk.push_back(E); }
+      if (d_chunk.upload(h_chunk) || d_cchunk.upload(h_cchunk) || d_seg8.alloc(L)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      if (S0) k_plan_seg8<<<nb(S0), TB, 0, st>>>(S0, d_chunk.p, (uint32_t)h_chunk.size() - 1, d_slo[0].p, d_scn[0].p, d_seg8.p);
+    }
+    const bool fold_l2 = d.nlevels == 2;
+    if (fold_l2) {
+      if (d_l2lo.alloc(M) || d_l2cnt.alloc(M)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemsetAsync(d_l2cnt.p, 0, M, st)); SQ_HIP_CHECK(hipMemsetAsync(d_l2lo.p, 0, (size_t)M * 4, st));
+      k_plan_l2<<<nb(d.nseg[1]), TB, 0, st>>>(d.nseg[1], d_slo[1].p, d_scn[1].p, d_stx[1].p, d_l2lo.p, d_l2cnt.p);
+    }
+    SQ_HIP_CHECK(hipStreamSynchronize(st));
+    d.M = M; d.E = E; d.L = L; d.off = p_off; d.tid = p_tid; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
+    d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
+    for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.part[l] = d_lpart[l].p; }
+    d.cchunk = d_cchunk.p; d.ncchunks = h_cchunk.size() > 1 ? (uint32_t)h_cchunk.size() - 1 : 0;
+    d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
+    d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
+    pt.mark("device-prepare");
     return SQ_OK;
   }
 
@@ -465,10 +533,10 @@ struct EmSession {
   double* result_dev = nullptr;
 };
 
-int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep) {
+int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep, const sq_eq_dev_csr* dv = nullptr) {
   PhaseTimer pt("em");
   int rc;
-  { EmSession S; rc = S.setup(device, eq, txp, o); if (rc) return rc;
+  { EmSession S; rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
     pt.mark("setup");
     rc = S.run(alpha, mode, fixed_iters, o->min_iter, rep);
     pt.mark("run"); }
@@ -531,6 +599,11 @@ __global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __
 
 extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   if (!eq || !txp || !o || !alpha_out || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_em_optimize_dev: bad arguments"); return SQ_ERR_ARG; }
+  return sq_em_optimize_impl(device, eq, nullptr, txp, o, alpha_out, rep);
+}
+
+// eq: host table, or dv: the label-major CSR already resident on `device` (the ctx's staged export)
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   const uint32_t M = txp->num_txp;
   // initial alphas (CollapsedEMOptimizer.cpp:778-823)
   std::vector<double> pc(M, 0.0); if (txp->projected_counts) pc.assign(txp->projected_counts, txp->projected_counts + M);
@@ -539,7 +612,7 @@ extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_tx
   double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
   std::vector<double> alpha(M);
   for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
-  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep);
+  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep, dv);
   if (rc) return rc;
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector (:64-76), minAlpha 1e-8
   double asum = canonical_sum_host(alpha);

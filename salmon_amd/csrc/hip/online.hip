@@ -942,7 +942,19 @@ extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
   return check_eq_overflow(c);
 }
 
+int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out) {
+  auto& X = c->online->exp;
+  if (!X.valid) { int rc = eq_export_run(c); if (rc) return rc; }
+  out->E = X.E; out->L = X.L; out->off = X.d_off.p; out->tid = X.d_tid.p; out->w = X.d_w.p; out->cnt = X.d_cnt.p;
+  return SQ_OK;
+}
+
+// eq == NULL: optimise over the ctx's own accumulated classes, straight from the export that already sits in HBM
 extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
-  return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
+  if (eq) return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
+  if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
+  sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
+  if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
+  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep);
 }
