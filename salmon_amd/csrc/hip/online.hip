@@ -706,8 +706,11 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
 // runs on the worker thread
 static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t n = J.n; const sq_quant_opts& q = c->opts;
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_job %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
   if (c->stream3) {   // CU partition on: use the CU-masked stream only while a mapping batch is (about to be) in flight
-    for (int spin = 0; spin < 300 && !c->map_active.load(); ++spin) std::this_thread::sleep_for(std::chrono::microseconds(1));
+    // give the caller ~200 us to enter the next sq_map_batch (sleep_for has ~50 us granularity: poll instead)
+    for (auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200); !c->map_active.load() && std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
     if (!c->map_active.load()) st = c->stream3;
   }
   c->eq_stream_cur = st;
@@ -718,6 +721,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   const size_t A = (size_t)last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
+  mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
   if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
@@ -736,7 +740,9 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   SQ_HIP_CHECK(hipMemcpyAsync(bound.data(), o->rh2.p, (size_t)(nmb + 1) * 8, hipMemcpyDeviceToHost, st));
   unsigned long long hctr[8];
   SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st));
+  mark("pre-launches");
   SQ_HIP_CHECK(hipStreamSynchronize(st));
+  mark("bounds-sync");
   const uint64_t assigned_base = hctr[0];
   bool burned_host = hctr[1] != 0;
   for (uint32_t b = 0; b < nmb; ++b) {
@@ -761,6 +767,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
   sq_prof_mark(c, SG_EQ_TABLE, 1);
   SQ_HIP_CHECK(hipEventRecord(c->ev_eq_done[buf], st)); c->ev_eq_last = c->ev_eq_done[buf];
+  mark("chain-launches");
   o->num_observed += n; o->num_mapped_ub += J.joint; c->reads_seen += n;
   return SQ_OK;
 }
