@@ -66,15 +66,17 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
   const uint8_t* s = seq + a + 32 * wi;
   uint64_t cw = 0; uint32_t cn = 0;
   const uint32_t lo = 32 * wi; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);
-  auto put = [&](uint32_t i, uint8_t ch) {
-    uint32_t c;
-    switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = 4; }
-    if (c > 3) cn |= 1u << i; else cw |= (uint64_t)c << (i * 2);
+  // branch-free base code: upper-case, then (x >> 1) & 3 maps A,C,T,G -> 0,1,2,3; x ^ (x >> 1) swaps the last two
+  auto put = [&](uint32_t i, uint32_t ch) {
+    const uint32_t x = ch & 0xDFu;
+    const uint32_t ok = (x == 0x41u) | (x == 0x43u) | (x == 0x47u) | (x == 0x54u);
+    const uint32_t c2 = (x >> 1) & 3u; const uint32_t c = c2 ^ (c2 >> 1);
+    cw |= (uint64_t)(ok ? c : 0u) << (i * 2); cn |= (ok ^ 1u) << i;
   };
   if (cnt == 32 && (((uintptr_t)s) & 3) == 0) {
     const uint32_t* s4 = (const uint32_t*)s;
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) { uint32_t v = s4[q]; put(4 * q, (uint8_t)v); put(4 * q + 1, (uint8_t)(v >> 8)); put(4 * q + 2, (uint8_t)(v >> 16)); put(4 * q + 3, (uint8_t)(v >> 24)); }
+    for (uint32_t q = 0; q < 8; ++q) { uint32_t v = s4[q]; put(4 * q, v & 0xFF); put(4 * q + 1, (v >> 8) & 0xFF); put(4 * q + 2, (v >> 16) & 0xFF); put(4 * q + 3, v >> 24); }
   } else for (uint32_t i = 0; i < cnt; ++i) put(i, s[i]);
   rpack[(size_t)e * SQ_READ_WORDS + wi] = cw;
   ((uint32_t*)(rnmask + (size_t)e * SQ_NMASK_WORDS))[wi] = cn;
