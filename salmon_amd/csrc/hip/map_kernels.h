@@ -90,29 +90,42 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 // lane does ONE probe step per loop trip and, when its read end is finished, takes the next one
 // from a global cursor (one atomic per wave via ballot).  The persistent grid keeps every lane busy
 // until the batch is drained; results are keyed by read end, so they do not depend on scheduling.
+template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor) {
-  const int k = (int)P.k; const int alt = (int)P.alt_skip;
+  const int k = KT ? KT : (int)P.k; const int alt = (int)P.alt_skip;
   const int lane = (int)(threadIdx.x & 63);
   uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false;
   ReadView r; r.w = nullptr; r.nm = nullptr; r.L = 0;
   int pos = 0, skip_until = -1; uint32_t nu = 0, np = 0;
   unsigned long long tot_nu = 0, tot_look = 0;
   sq_unimem_dev* out = nullptr;
+  uint32_t pool_next = 0, pool_end = 0; bool global_drained = false;   // wave-uniform: the wave's private run of read ends
   for (;;) {
-    // refill: every lane without a read end asks for one
-    const unsigned long long want = __ballot(!have && !drained);
-    if (want) {
-      uint32_t base = 0; const int leader = __ffsll((long long)want) - 1;
-      if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(want));
-      base = (uint32_t)__shfl((int)base, leader, 64);
-      if (!have && !drained) {
-        e = base + (uint32_t)__popcll(want & ((1ULL << lane) - 1));
-        if (e >= nends) drained = true;
-        else { have = true; r = read_view(rpack, rnmask, rlen, e); pos = 0; skip_until = -1; nu = 0; np = 0; out = um + (size_t)e * SQ_MAX_UNIMEMS; }
+    // refill: lanes without a read end take the next ones of the wave's run; the run is renewed 64 at a time with ONE
+    // atomic (a per-trip atomic on the single cursor serialised the whole grid: ~700 k same-address atomics per batch)
+    unsigned long long want = __ballot(!have && !drained);
+    while (want) {
+      if (pool_next == pool_end) {
+        if (global_drained) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (base >= nends) { global_drained = true; break; }
+        pool_next = base; pool_end = base + 64u < nends ? base + 64u : nends;
       }
+      const uint32_t avail = pool_end - pool_next, nw = (uint32_t)__popcll(want);
+      const uint32_t take = avail < nw ? avail : nw;
+      const uint32_t rank = (uint32_t)__popcll(want & ((1ULL << lane) - 1));
+      if (!have && !drained && rank < take) {
+        e = pool_next + rank; have = true;
+        r = read_view(rpack, rnmask, rlen, e); pos = 0; skip_until = -1; nu = 0; np = 0; out = um + (size_t)e * SQ_MAX_UNIMEMS;
+      }
+      pool_next += take;
+      want = __ballot(!have && !drained);
     }
+    if (global_drained && !have) drained = true;
     if (!__ballot(have)) break;
     if (have) {
       const int L = r.L; bool done = false;
@@ -124,7 +137,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
           uint64_t km = sq_fetch_bases(r.w, (uint64_t)pos, (uint32_t)k);
           uint64_t u; uint32_t off; int fw;
           ++tot_look;
-          if (!sq_dict_lookup(d, km, &u, &off, &fw)) {
+          if (!sq_dict_lookup_t<KT, MT>(d, km, &u, &off, &fw)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
             const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);

@@ -259,12 +259,12 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       uint64_t f = sq_fetch_bases(up, ub, m), r = sq_revcomp(f, m);
       for (uint32_t i = 0; i < nm; ++i) {
         if (i) { uint64_t nb = sq_fetch_base(up, ub + i + m - 1); f = (f >> 2) | (nb << (2 * (m - 1))); r = ((r << 2) | (3 - nb)) & mm; }
-        uint64_t c = f < r ? f : r; cv[i] = c; hv[i] = sq_mix64(c);
+        uint64_t c = f < r ? f : r; cv[i] = c; hv[i] = sq_mhash(c);
       }
       uint32_t prev = 0xFFFFFFFFu;
       for (uint32_t p = 0; p < nk; ++p) {
         uint32_t bj = p; uint64_t bh = hv[p];
-        for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh) { bh = hv[j]; bj = j; }  // leftmost minimum
+        for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh || (hv[j] == bh && cv[j] < cv[bj])) { bh = hv[j]; bj = j; }  // leftmost minimum of (sq_mhash, value)
         if (bj != prev) { out.push_back({cv[bj], (u << SQ_APOS_BITS) | (ub + bj), p, 1}); prev = bj; }
         else out.back().nk++;
       }
@@ -327,10 +327,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
         auto& B = bk[bi]; if (B.empty()) continue;
         bool ok = false;
         for (uint32_t pilot = 0; pilot < 65536 && !ok; ++pilot) {
-          uint64_t pm = sq_mix64((uint64_t)pilot + 0x632BE59BD9B4E019ULL);
+          uint64_t pm = sq_pilot_mix(pilot);
           pos.clear(); bool good = true;
           for (uint64_t ki : B) {
-            uint32_t s = sq_fastrange32((uint32_t)(sq_mix64(kh[ki] ^ pm) >> 32), ns);
+            uint32_t s = sq_fastrange32(sq_slot_mix(kh[ki], pm), ns);
             if (taken[s]) { good = false; break; }
             for (uint32_t x : pos) if (x == s) { good = false; break; }
             if (!good) break;

@@ -14,7 +14,7 @@
 #include "../../include/sq_math.h"
 
 #define SQ_INDEX_MAGIC 0x3158444951535153ULL /* "SQSQIDX1" */
-#define SQ_INDEX_VERSION 4u
+#define SQ_INDEX_VERSION 5u
 #define SQ_SKEW_THRESH 32u
 #define SQ_MPHF_LAMBDA 4.0
 #define SQ_MPHF_ALPHA 0.90
@@ -51,18 +51,27 @@ SQ_HD uint32_t sq_fetch_base(const uint64_t* pool, uint64_t p) {
 
 SQ_HD uint32_t sq_fastrange32(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32); }
 
-// canonical minimizer of a k-mer: value = canonical m-mer with the smallest mix64; returns value.
-// (mix64 is a bijection, so equal hashes mean equal canonical m-mers.)
+// Minimizer order: a cheap 32-bit hash of the canonical m-mer, ties broken by the m-mer value (so a
+// k-mer and its reverse complement always agree).  The probe kernel evaluates it k-m+1 times per
+// lookup; with the 64-bit murmur finaliser the lookup was VALU-bound (k_seed reached ~30 % of the
+// measured random-sector gather rate of the chip), this form costs ~8 integer ops.
+SQ_HD uint32_t sq_mhash(uint64_t c) {
+  uint32_t x = (uint32_t)c * 0x9E3779B1u + 0x7F4A7C15u;
+  x ^= (uint32_t)(c >> 32) * 0x85EBCA77u;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return x;
+}
+// canonical minimizer of a k-mer: the canonical m-mer with the smallest (sq_mhash, value); returns the value.
 SQ_HD uint64_t sq_minimizer(uint64_t kmer, uint64_t rc, uint32_t k, uint32_t m) {
   const uint64_t mm = sq_kmask(m);
-  uint64_t best = ~0ULL, bestv = 0;
+  uint32_t best = 0xFFFFFFFFu; uint64_t bestv = ~0ULL;
   const uint32_t w = k - m;
   for (uint32_t j = 0; j <= w; ++j) {
     uint64_t a = (kmer >> (2 * j)) & mm;
     uint64_t b = (rc >> (2 * (w - j))) & mm;
     uint64_t c = a < b ? a : b;
-    uint64_t h = sq_mix64(c);
-    if (h < best) { best = h; bestv = c; }
+    uint32_t h = sq_mhash(c);
+    if (h < best || (h == best && c < bestv)) { best = h; bestv = c; }
   }
   return bestv;
 }
@@ -83,6 +92,10 @@ struct sq_dict_view {
   uint64_t num_unitigs;
 };
 
+// displacement of a key hash by its bucket's pilot (PTHash: hash(key) xor hash(pilot), then reduce); one multiply each
+SQ_HD uint64_t sq_pilot_mix(uint64_t pilot) { return (pilot + 1) * 0x9E3779B97F4A7C15ULL; }
+SQ_HD uint32_t sq_slot_mix(uint64_t h, uint64_t pm) { return (uint32_t)(((h ^ pm) * 0xD6E8FEB86659FD93ULL) >> 32); }
+
 SQ_HD uint64_t sq_mphf_slot(const sq_dict_view& d, uint64_t minimizer) {
   uint64_t h = sq_mix64(minimizer ^ 0x9E3779B97F4A7C15ULL);
   uint32_t part = sq_fastrange32((uint32_t)(h >> 32), d.n_parts);
@@ -91,8 +104,7 @@ SQ_HD uint64_t sq_mphf_slot(const sq_dict_view& d, uint64_t minimizer) {
   uint32_t ns = (uint32_t)(d.part_slot_off[part + 1] - s0);
   uint32_t bkt = sq_fastrange32((uint32_t)h, nb);
   uint64_t pilot = d.pilots[b0 + bkt];
-  uint64_t h2 = sq_mix64(h ^ sq_mix64(pilot + 0x632BE59BD9B4E019ULL));
-  return s0 + sq_fastrange32((uint32_t)(h2 >> 32), ns);
+  return s0 + sq_fastrange32(sq_slot_mix(h, sq_pilot_mix(pilot)), ns);
 }
 
 // A minimizer occurrence is stored as (unitig id, ABSOLUTE pool position of the minimizer):
@@ -109,27 +121,43 @@ SQ_HD uint64_t sq_mphf_slot(const sq_dict_view& d, uint64_t minimizer) {
 SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t u, int64_t sp,
                       uint64_t* unitig, uint32_t* off, int* fw) {
   if (sp < 0) return 0;
-  const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
-  const uint64_t s = sq_fetch_bases(d.useq, (uint64_t)sp, d.k);   // independent of the bounds loads
-  if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
+  const uint64_t s = sq_fetch_bases(d.useq, (uint64_t)sp, d.k);
   int f;
-  if (s == kmer) f = 1; else if (s == rc) f = 0; else return 0;
+  if (s == kmer) f = 1; else if (s == rc) f = 0; else return 0;   // most failed probes end here: the unitig bounds are only fetched for a string match
+  const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
+  if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
   *unitig = u; *off = (uint32_t)((uint64_t)sp - b); *fw = f;
   return 1;
 }
 
 // Full dictionary query. kmer in read orientation; on success fw tells whether the read k-mer
-// equals the unitig's forward string at (unitig, off).
-SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
-  const uint32_t k = d.k, m = d.m, w = k - m;
+// equals the unitig's forward string at (unitig, off).  KT/MT > 0 fix k and m at compile time (the
+// probe kernel is instruction-issue bound: constant shifts/masks and fully unrolled window loops
+// roughly halve its instruction count); 0 = take them from the view.
+template <int KT, int MT>
+SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
+  const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
   const uint64_t mm = sq_kmask(m);
-  uint64_t rc = sq_revcomp(kmer, k);
-  uint64_t mini = sq_minimizer(kmer, rc, k, m);
-  uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
+  const uint64_t rc = sq_revcomp(kmer, k);
+  // one pass over the window: the minimizer and the set of positions j that hold it (bit j of `at`),
+  // with the strand of the canonical form at each of them (bit j of `fwc`: the read-orientation m-mer is the canonical one)
+  uint32_t best = 0xFFFFFFFFu; uint64_t mini = ~0ULL; uint32_t at = 0, fwc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t j = 0; j <= w; ++j) {
+    const uint64_t a = (kmer >> (2 * j)) & mm;
+    const uint64_t b = (rc >> (2 * (w - j))) & mm;
+    const uint64_t c = a < b ? a : b;
+    const uint32_t h = sq_mhash(c);
+    if (h < best || (h == best && c < mini)) { best = h; mini = c; at = 0; fwc = 0; }
+    if (c == mini) { at |= 1u << j; if (a <= b) fwc |= 1u << j; }
+  }
+  const uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
   if (rec == SQ_SLOT_EMPTY) return 0;
-  uint64_t nent; const uint64_t* ent; uint64_t inl;
-  if (rec & SQ_SLOT_INLINE) { inl = rec & SQ_ENT_MASK; ent = &inl; nent = 1; }
-  else {
+  const bool inl = (rec & SQ_SLOT_INLINE) != 0;     // the common case: the record IS the single occurrence (no pointer, no scratch)
+  uint64_t nent = 1; const uint64_t* ent = nullptr;
+  if (!inl) {
     nent = rec >> SQ_POS_BITS; ent = d.entries + (rec & SQ_POS_MASK);
     if (nent > SQ_SKEW_THRESH) {  // heavy bucket -> skew table keyed by canonical k-mer
       if (!d.skew_mask) return 0;
@@ -147,18 +175,18 @@ SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig,
     }
   }
   // positions j (in the read-orientation k-mer) where the canonical m-mer equals the minimizer
-  for (uint32_t j = 0; j <= w; ++j) {
-    uint64_t a = (kmer >> (2 * j)) & mm;
-    uint64_t b = (rc >> (2 * (w - j))) & mm;
-    uint64_t c = a < b ? a : b;
-    if (c != mini) continue;
+  while (at) {
+    const uint32_t j = (uint32_t)__builtin_ctz(at); at &= at - 1;
     for (uint64_t e = 0; e < nent; ++e) {
-      uint64_t u = (ent[e] & SQ_ENT_MASK) >> SQ_APOS_BITS;
-      int64_t A = (int64_t)(ent[e] & SQ_APOS_MASK);  // minimizer position in the pool
+      const uint64_t ev = (inl ? rec : ent[e]) & SQ_ENT_MASK;
+      uint64_t u = ev >> SQ_APOS_BITS;
+      int64_t A = (int64_t)(ev & SQ_APOS_MASK);  // minimizer position in the pool
       // same strand: k-mer starts at A - j ; opposite strand: starts at A - (w - j)
       if (sq_dict_try(d, kmer, rc, u, A - (int64_t)j, unitig, off, fw)) return 1;
       if (j != w - j && sq_dict_try(d, kmer, rc, u, A - (int64_t)(w - j), unitig, off, fw)) return 1;
     }
   }
+  (void)fwc;
   return 0;
 }
+SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) { return sq_dict_lookup_t<0, 0>(d, kmer, unitig, off, fw); }
