@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
     return ap.parse_args()
 
 
@@ -93,6 +94,11 @@ def main():
     # ---- warmup (sizes every work buffer; model/eq state is reset afterwards) ----
     for s in range(W):
         ctx.map_batch(rbs[s], fetch=False); ctx.eq_accumulate()
+    if a.lanes > 1:
+        for s in range(min(W, a.lanes)):   # size the work buffers of every lane
+            ctx.map_submit(rbs[0])
+        for s in range(min(W, a.lanes)):
+            ctx.map_wait()
     if W:
         e = ctx.eq_finish()
         api.em_steps(e, idx.ref_lens().astype(np.float64), np.full(idx.num_refs, 100.0), 2, api.em_opts(), device=local)
@@ -105,9 +111,18 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot = None
+    depth = max(1, a.lanes)          # batches in flight on the mapping lanes (sq_map_submit / sq_map_wait)
+    if depth > 1:
+        for s in range(W, min(W + K, W + depth)):
+            ctx.map_submit(rbs[s])
     for s in range(W, W + K):
-        _, _, _, st = ctx.map_batch(rbs[s], fetch=False)
+        if depth > 1:
+            _, _, _, st = ctx.map_wait()
+        else:
+            _, _, _, st = ctx.map_batch(rbs[s], fetch=False)
         ctx.eq_accumulate()
+        if depth > 1 and s + depth < W + K:
+            ctx.map_submit(rbs[s + depth])
         tot = st if tot is None else {k: tot[k] + v for k, v in st.items()}
     t_map = time.perf_counter() - t0
     eq = ctx.eq_finish()

@@ -205,6 +205,14 @@ typedef struct {           /* HitCounters / MappingStatistics subset (SalmonQuan
 /* Map one batch. Results stay resident on the device for sq_eq_accumulate(); if out != NULL they
  * are also copied to the caller's buffers (SQ_ERR_OVERFLOW if aln_cap is too small). */
 int sq_map_batch(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);
+/* Pipelined form of sq_map_batch: submit queues a batch on the next mapping lane (a worker thread with
+ * its own HIP stream and work buffers; two lanes by default) and returns at once; wait returns the
+ * batches in submission order, after which sq_eq_accumulate / sq_debug_tap refer to that batch, exactly
+ * as after sq_map_batch.  Keeping two batches in flight lets their kernels fill each other's stalls.
+ * `in` (and `out`, if given) must stay valid until the matching sq_map_wait returns.  This replaces
+ * the reference's N worker threads pulling chunks from the parser (SalmonQuantify.cpp:2390-2403). */
+int sq_map_submit(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out /* may be NULL */);
+int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stats);
 
 /* ------------------------------------------------------------------------------------------------
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +

@@ -214,6 +214,26 @@ class QuantContext:
             break
         return read_off, aln[: int(read_off[-1])], mt, st.as_dict()
 
+    def map_submit(self, rb, aln_cap=None, fetch=False):
+        """Queue a batch on the next mapping lane (sq_map_submit); pair with map_wait(). Keeps `rb` alive."""
+        if not hasattr(self, "_inflight"): self._inflight = []
+        ent = dict(rb=rb, ab=None)
+        if fetch:
+            n = rb.n; cap = aln_cap or max(1024, 16 * n)
+            ent.update(read_off=np.zeros(n + 1, np.uint64), aln=np.zeros(cap, ALN_DTYPE), mt=np.zeros(n, np.uint8))
+            ent["ab"] = capi.AlnBatch(n, _ptr(ent["read_off"], C.c_uint64), ent["aln"].ctypes.data_as(C.POINTER(capi.Aln)), cap, _ptr(ent["mt"], C.c_uint8))
+        check(lib().sq_map_submit(self.h, C.byref(rb), C.byref(ent["ab"]) if ent["ab"] is not None else None), "sq_map_submit")
+        self._inflight.append(ent)
+
+    def map_wait(self):
+        """Oldest submitted batch (sq_map_wait) -> (read_off, aln, map_type, stats); arrays are None unless fetch=True was submitted."""
+        st = capi.MapStats()
+        check(lib().sq_map_wait(self.h, None, C.byref(st)), "sq_map_wait")
+        ent = self._inflight.pop(0)
+        if ent["ab"] is None:
+            return None, None, None, st.as_dict()
+        return ent["read_off"], ent["aln"][: int(ent["read_off"][-1])], ent["mt"], st.as_dict()
+
     def tap(self, what, dtype):
         n = lib().sq_debug_tap(self.h, what, None, 0)
         if n < 0:

@@ -1,6 +1,7 @@
 // hip/ctx.h — per-device quantification context: HBM work buffers of the mapping pipeline, the
 // online model and the equivalence-class table.  One sq_ctx per GPU (one process per GPU).
 #pragma once
+#include <memory>
 #include <thread>
 #include <atomic>
 #include <mutex>
@@ -98,9 +99,21 @@ struct sq_ctx {
   std::vector<hipEvent_t> prof_ev2; std::vector<int> prof_stage2;
   // The eq stage of a batch is several hundred small launches (three per mini-batch of 5000 fragments):
   // a worker thread enqueues them on stream2 so the caller can go straight on to mapping the next batch.
-  struct eq_job { uint32_t n; int buf; uint64_t total_aln, joint; };
+  struct eq_job { uint32_t n; int buf; uint64_t total_aln, joint; sq_ctx* src; };
   std::thread eq_thread; std::mutex eq_mu; std::condition_variable eq_cv, eq_cv_done; std::deque<eq_job> eq_q;
   uint64_t eq_submitted = 0, eq_enqueued = 0; uint64_t eq_job_of_buf[2] = {0, 0}; bool eq_stop = false; int eq_err = 0; std::string eq_errmsg;
+  // Mapping lanes: sq_map_submit / sq_map_wait run batches on alternating lanes, each a worker thread with its own
+  // stream and work buffers (lane 0 = this ctx, further lanes = shadow ctxs that own buffers only).  The mapping
+  // kernels are latency- or issue-bound one at a time; two batches in flight fill each other's stalls.  Results come
+  // back in submission order; the online/eq stage stays strictly ordered on its own stream.
+  struct map_job { sq_read_batch in; sq_aln_batch out; bool has_out = false; int rc = 0; sq_map_stats st; bool done = false; std::string err; uint32_t n = 0; int buf = 0; uint64_t total_aln = 0, joint = 0; };
+  uint32_t acc_n = 0; int acc_buf = 0; uint64_t acc_total_aln = 0, acc_joint = 0;   // the batch sq_eq_accumulate will take (set by sq_map_batch / sq_map_wait)
+  sq_ctx* owner = nullptr;                 // set in a shadow ctx: the ctx that owns the online model and the eq worker
+  std::vector<sq_ctx*> shadows;            // lanes 1.. (owned by lane 0)
+  sq_ctx* last_src = nullptr;              // lane whose batch the next sq_eq_accumulate / sq_debug_tap refers to
+  bool api_have = false;                   // a mapped batch has been returned to the caller and not yet accumulated
+  std::thread lane_thread; std::mutex lane_mu; std::condition_variable lane_cv, lane_cv_done; std::deque<std::shared_ptr<map_job>> lane_q; bool lane_stop = false;
+  std::deque<std::pair<sq_ctx*, std::shared_ptr<map_job>>> tickets; uint64_t submitted = 0;
   // stage profiling
   bool prof_on = false; std::vector<hipEvent_t> prof_ev; std::vector<int> prof_stage; double stage_ms[32] = {0}; uint64_t stage_calls[32] = {0};
 };
@@ -118,5 +131,6 @@ void sq_eq_worker_stop(sq_ctx* c);                                // wait for ou
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
+int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`
 int sq_online_create(sq_ctx* c);
 void sq_online_free(sq_ctx* c);

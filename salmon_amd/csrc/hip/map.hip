@@ -52,23 +52,31 @@ void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; au
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
 void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
   for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
-extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) { if (!c) return SQ_ERR_ARG; c->prof_on = on != 0; return SQ_OK; }
+extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) { if (!c) return SQ_ERR_ARG; c->prof_on = on != 0; for (sq_ctx* sh : c->shadows) sh->prof_on = c->prof_on; return SQ_OK; }
 extern "C" int sq_ctx_num_stages(void) { return SG_NUM; }
 extern "C" const char* sq_ctx_stage_name(int s) { return (s >= 0 && s < SG_NUM) ? kStageNames[s] : nullptr; }
 extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int reset) {
   if (!c) return SQ_ERR_ARG;
   (void)sq_eq_sync(c);
-  for (int i = 0; i < SG_NUM; ++i) { if (ms) ms[i] = c->stage_ms[i]; if (calls) calls[i] = c->stage_calls[i]; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
+  for (int i = 0; i < SG_NUM; ++i) {
+    double m = c->stage_ms[i]; uint64_t n = c->stage_calls[i];
+    for (sq_ctx* sh : c->shadows) { m += sh->stage_ms[i]; n += sh->stage_calls[i]; if (reset) { sh->stage_ms[i] = 0; sh->stage_calls[i] = 0; } }
+    if (ms) ms[i] = m; if (calls) calls[i] = n; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
   return SQ_OK;
 }
 
+static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx* owner, sq_ctx** out);
 extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx** out) {
+  return ctx_create_lane(idx, opts, device, max_batch_reads, nullptr, out);
+}
+// owner == nullptr: a full context (lane 0); else a shadow lane: work buffers and a stream only
+static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx* owner, sq_ctx** out) {
   if (!idx || !opts || !out || max_batch_reads == 0) { sq_set_error("sq_ctx_create: bad arguments"); return SQ_ERR_ARG; }
   if (max_batch_reads > (1u << 23)) { sq_set_error("max_batch_reads %u exceeds 2^23 (sort key layout)", max_batch_reads); return SQ_ERR_ARG; }
   if (opts->bandwidth > SQ_MAX_BAND || opts->bandwidth < 0) { sq_set_error("bandwidth %d not supported (max %d)", opts->bandwidth, SQ_MAX_BAND); return SQ_ERR_ARG; }
   int rc = sq_index_to_device(idx, device); if (rc) return rc;
   SQ_HIP_CHECK(hipSetDevice(device));
-  sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads;
+  sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads; c->owner = owner; c->last_src = c;
   fill_params(c);
   { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 32 of 256; SQ_EQ_CUS=0 disables) and the
     // mapping stream keeps off them.  Measured on MI355X (configs[1]): mapping kernels lose ~3% on 224 CUs, while
@@ -82,10 +90,9 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
       SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()));
-      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()));
-      SQ_HIP_CHECK(hipStreamCreate(&c->stream3));
+      if (!owner) { SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data())); SQ_HIP_CHECK(hipStreamCreate(&c->stream3)); }
     } else {
-      SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
+      SQ_HIP_CHECK(hipStreamCreate(&c->stream)); if (!owner) SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
     }
     c->eq_stream_cur = c->stream2;
   }
@@ -101,7 +108,7 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
   std::vector<double> gc(SQ_MAX_CHAIN_GAP + 1, 0.0); const double inv_ln2 = 1.0 / 0.6931471805599453;
   for (int l = 1; l <= SQ_MAX_CHAIN_GAP; ++l) gc[l] = 0.01 * 31.0 * (double)l + 0.5 * (sq_log((double)l) * inv_ln2);
   SQ_HIP_CHECK(hipMemcpy(c->gapcost.p, gc.data(), gc.size() * 8, hipMemcpyHostToDevice));
-  rc = sq_online_create(c); if (rc) { sq_ctx_free(c); return rc; }
+  if (!owner) { rc = sq_online_create(c); if (rc) { sq_ctx_free(c); return rc; } }
   *out = c;
   return SQ_OK;
 }
@@ -109,11 +116,14 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  sq_eq_worker_stop(c);   // drains the queued eq-stage jobs first
+  if (c->lane_thread.joinable()) { { std::lock_guard<std::mutex> lk(c->lane_mu); c->lane_stop = true; } c->lane_cv.notify_all(); c->lane_thread.join(); }
+  if (!c->owner) { for (sq_ctx* sh : c->shadows) if (sh->lane_thread.joinable()) { { std::lock_guard<std::mutex> lk(sh->lane_mu); sh->lane_stop = true; } sh->lane_cv.notify_all(); sh->lane_thread.join(); } }
+  if (!c->owner) sq_eq_worker_stop(c);   // drains the queued eq-stage jobs first
+  if (!c->owner) { for (sq_ctx* sh : c->shadows) sq_ctx_free(sh); c->shadows.clear(); }
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  sq_online_free(c);
+  if (!c->owner) sq_online_free(c);
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
   c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->wkey.free_(); c->wkey2.free_(); c->wid.free_(); c->perm_ends.free_(); c->perm_frags.free_(); c->chains.free_(); c->chains_d.free_(); c->chain_off.free_(); c->n_chains.free_();
   c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_(); c->aln_b1.free_(); c->aln_off_b1.free_();
@@ -126,13 +136,62 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
 }
 
 extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
+  if (!c || c->owner) { sq_set_error("sq_map_batch: bad context"); return SQ_ERR_ARG; }
+  if (!c->tickets.empty()) { sq_set_error("sq_map_batch: %zu submitted batches are still outstanding (sq_map_wait them first)", c->tickets.size()); return SQ_ERR_STATE; }
+  int rc = sq_map_batch_impl(c, in, out, stats);
+  c->last_src = c; c->api_have = (rc == SQ_OK);
+  c->acc_n = c->last_n; c->acc_buf = c->last_buf; c->acc_total_aln = c->last_total_aln; c->acc_joint = c->last_joint;
+  return rc;
+}
+
+// ---- lanes: asynchronous submit / in-order wait ---------------------------------------------------
+static void lane_worker(sq_ctx* c) {
+  (void)hipSetDevice(c->device);
+  for (;;) {
+    std::shared_ptr<sq_ctx::map_job> J;
+    { std::unique_lock<std::mutex> lk(c->lane_mu); c->lane_cv.wait(lk, [&] { return c->lane_stop || !c->lane_q.empty(); });
+      if (c->lane_q.empty()) return;
+      J = c->lane_q.front(); c->lane_q.pop_front(); }
+    int rc = sq_map_batch_impl(c, &J->in, J->has_out ? &J->out : nullptr, &J->st);
+    { std::lock_guard<std::mutex> lk(c->lane_mu); J->rc = rc; if (rc) J->err = sq_last_error(); J->n = c->last_n; J->buf = c->last_buf; J->total_aln = c->last_total_aln; J->joint = c->last_joint; J->done = true; }
+    c->lane_cv_done.notify_all();
+  }
+}
+extern "C" int sq_map_submit(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out) {
+  if (!c || c->owner || !in) { sq_set_error("sq_map_submit: bad arguments"); return SQ_ERR_ARG; }
+  static const int nl_env = getenv("SQ_MAP_LANES") ? atoi(getenv("SQ_MAP_LANES")) : 2;
+  const size_t want_lanes = (size_t)std::max(1, std::min(4, nl_env));
+  while (c->shadows.size() + 1 < want_lanes) { sq_ctx* sh = nullptr; int rc = ctx_create_lane(c->idx, &c->opts, c->device, c->max_reads, c, &sh); if (rc) return rc; sh->prof_on = c->prof_on; c->shadows.push_back(sh); }
+  if (c->tickets.size() >= want_lanes) { sq_set_error("sq_map_submit: %zu batches already in flight (one per lane); call sq_map_wait first", c->tickets.size()); return SQ_ERR_STATE; }
+  sq_ctx* lane = (c->submitted % want_lanes) == 0 ? c : c->shadows[(c->submitted % want_lanes) - 1];
+  auto J = std::make_shared<sq_ctx::map_job>(); J->in = *in; if (out) { J->out = *out; J->has_out = true; }
+  { std::lock_guard<std::mutex> lk(lane->lane_mu); if (!lane->lane_thread.joinable()) lane->lane_thread = std::thread(lane_worker, lane); lane->lane_q.push_back(J); }
+  lane->lane_cv.notify_one();
+  c->tickets.emplace_back(lane, J); c->submitted++;
+  return SQ_OK;
+}
+extern "C" int sq_map_wait(sq_ctx* c, sq_aln_batch* out, sq_map_stats* stats) {
+  if (!c || c->owner) { sq_set_error("sq_map_wait: bad context"); return SQ_ERR_ARG; }
+  if (c->tickets.empty()) { sq_set_error("sq_map_wait: nothing submitted"); return SQ_ERR_STATE; }
+  auto tk = c->tickets.front(); c->tickets.pop_front();
+  sq_ctx* lane = tk.first; auto J = tk.second;
+  { std::unique_lock<std::mutex> lk(lane->lane_mu); lane->lane_cv_done.wait(lk, [&] { return J->done; }); }
+  if (J->rc) { sq_set_error("%s", J->err.c_str()); return J->rc; }
+  if (stats) *stats = J->st;
+  if (out && J->has_out) *out = J->out;
+  c->last_src = lane; c->api_have = true;
+  c->acc_n = J->n; c->acc_buf = J->buf; c->acc_total_aln = J->total_aln; c->acc_joint = J->joint;
+  return SQ_OK;
+}
+
+int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
   if (!c || !in || !in->seq_off || !in->seq) { sq_set_error("sq_map_batch: bad arguments"); return SQ_ERR_ARG; }
   const uint32_t n = in->n, paired = in->paired ? 1 : 0, nrec = paired ? 2 * n : n;
   if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   c->have_batch = false;
-  struct ActiveGuard { std::atomic<int>& a; explicit ActiveGuard(std::atomic<int>& x) : a(x) { a.store(1); } ~ActiveGuard() { a.store(0); } } active_guard(c->map_active);
+  struct ActiveGuard { std::atomic<int>& a; explicit ActiveGuard(std::atomic<int>& x) : a(x) { a.fetch_add(1); } ~ActiveGuard() { a.fetch_sub(1); } } active_guard((c->owner ? c->owner : c)->map_active);
   const int buf = c->cur_buf;
   if (n == 0) { c->last_n = 0; c->last_buf = buf; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
   // ---- stage reads in HBM ----
@@ -217,7 +276,8 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   const size_t CP = (size_t)total_cands + 8;
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
   if (c->eq_pending[buf]) {   // the eq stage that read this alignment buffer two batches ago: wait (on the device) for it
-    sq_eq_wait_enqueued(c, c->eq_job_of_buf[buf]);
+    sq_eq_wait_enqueued(c->owner ? c->owner : c, c->eq_job_of_buf[buf]);
+    if ((buf ? c->aln_b1.n : c->aln.n) < CP) SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf]));   // the buffer is about to be reallocated: the eq stage must be done with it
     SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
   }
   if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
@@ -273,8 +333,12 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
 }
 
 // ------------------------------------------------------------------------------------------------
+static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap);
 extern "C" int64_t sq_debug_tap(sq_ctx* c, int what, void* buf, uint64_t cap) {
-  if (!c || !c->have_batch) { sq_set_error("sq_debug_tap: no mapped batch"); return SQ_ERR_STATE; }
+  if (!c || c->owner || !c->api_have) { sq_set_error("sq_debug_tap: no mapped batch"); return SQ_ERR_STATE; }
+  return tap_impl(c->last_src ? c->last_src : c, what, buf, cap);   // the lane that mapped the batch last returned
+}
+static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   if (hipSetDevice(c->device) != hipSuccess) return SQ_ERR_DEVICE;
   const uint32_t n = c->last_n, nrec = c->last_paired ? 2 * n : n;
   std::vector<uint64_t> moff(nrec + 1);

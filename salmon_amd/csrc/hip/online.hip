@@ -659,6 +659,7 @@ int sq_eq_sync(sq_ctx* c) {
   if (c->stream3) SQ_HIP_CHECK(hipStreamSynchronize(c->stream3));
   mark("stream3");
   c->eq_pending[0] = c->eq_pending[1] = false;
+  for (sq_ctx* sh : c->shadows) sh->eq_pending[0] = sh->eq_pending[1] = false;
   sq_prof_end(c, 1);
   mark("prof");
   { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); c->eq_err = 0; c->eq_errmsg.clear(); return e; } }
@@ -689,16 +690,17 @@ void sq_eq_worker_stop(sq_ctx* c) {
 }
 
 extern "C" int sq_eq_accumulate(sq_ctx* c) {
-  if (!c || !c->have_batch) { sq_set_error("sq_eq_accumulate: call sq_map_batch first"); return SQ_ERR_STATE; }
-  c->have_batch = false;
-  if (c->last_n == 0) return SQ_OK;
+  if (!c || c->owner || !c->api_have) { sq_set_error("sq_eq_accumulate: call sq_map_batch (or sq_map_wait) first"); return SQ_ERR_STATE; }
+  c->api_have = false;
+  sq_ctx* src = c->last_src ? c->last_src : c;   // the lane that mapped the batch
+  if (c->acc_n == 0) return SQ_OK;
   c->online->exp.valid = false;
-  sq_ctx::eq_job J; J.n = c->last_n; J.buf = c->last_buf; J.total_aln = c->last_total_aln; J.joint = c->last_joint;
+  sq_ctx::eq_job J; J.n = c->acc_n; J.buf = c->acc_buf; J.total_aln = c->acc_total_aln; J.joint = c->acc_joint; J.src = src;
   { std::lock_guard<std::mutex> lk(c->eq_mu);
     if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); return e; }   // an earlier batch failed
     if (!c->eq_thread.joinable()) c->eq_thread = std::thread(eq_worker, c);
-    c->eq_q.push_back(J); c->eq_job_of_buf[J.buf] = ++c->eq_submitted; }
-  c->eq_pending[J.buf] = true;
+    c->eq_q.push_back(J); src->eq_job_of_buf[J.buf] = ++c->eq_submitted; }
+  src->eq_pending[J.buf] = true;
   c->eq_cv.notify_one();
   return SQ_OK;   // asynchronous: sq_eq_sync() (called by finish / fetch / merge / reset) waits and reports errors
 }
@@ -715,9 +717,10 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   }
   c->eq_stream_cur = st;
   if (c->ev_eq_last) SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_last, 0));   // eq jobs run in order even when they change streams
-  const int buf = J.buf; const sq_aln* d_aln = c->aln_ptr(buf); const uint64_t* d_aln_off = c->aln_off_ptr(buf);
+  sq_ctx* src = J.src ? J.src : c;
+  const int buf = J.buf; const sq_aln* d_aln = src->aln_ptr(buf); const uint64_t* d_aln_off = src->aln_off_ptr(buf);
   const uint64_t last_total_aln = J.total_aln;
-  SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_map_done[buf], 0));   // alignments of this batch are complete
+  SQ_HIP_CHECK(hipStreamWaitEvent(st, src->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
   OnlineView V = make_view(c);
@@ -766,7 +769,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
   k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
   sq_prof_mark(c, SG_EQ_TABLE, 1);
-  SQ_HIP_CHECK(hipEventRecord(c->ev_eq_done[buf], st)); c->ev_eq_last = c->ev_eq_done[buf];
+  SQ_HIP_CHECK(hipEventRecord(src->ev_eq_done[buf], st)); c->ev_eq_last = src->ev_eq_done[buf];
   mark("chain-launches");
   o->num_observed += n; o->num_mapped_ub += J.joint; c->reads_seen += n;
   return SQ_OK;
@@ -777,7 +780,7 @@ extern "C" int sq_ctx_reset(sq_ctx* c) {
   (void)sq_eq_sync(c);
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_free(c);
-  c->reads_seen = 0; c->have_batch = false;
+  c->reads_seen = 0; c->have_batch = false; c->api_have = false;
   return sq_online_create(c);
 }
 

@@ -148,3 +148,42 @@ def test_eq_merge_is_exact_and_order_free(small_world):
         assert np.array_equal(getattr(m1, f), getattr(ef, f)), f
     for c in (a, b, full):
         c.free()
+
+
+def test_pipelined_lanes_match_sequential(small_world):
+    # sq_map_submit / sq_map_wait (two batches in flight on two lanes) must give the same alignments, model and
+    # eq-classes as sq_map_batch called batch by batch
+    w = small_world
+    opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=2200)
+    cuts = [(0, 900), (900, 2100), (2100, 2600), (2600, 4000)]
+    keep = []   # a read batch holds raw pointers: the arrays must outlive it
+    def rbs():
+        out = []
+        for lo, hi in cuts:
+            seq = w["seq"][lo * 200: hi * 200]; off = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+            keep.append((seq, off)); out.append(api.make_read_batch(seq, off, hi - lo, paired=True))
+        return out
+    seq_ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    want = []
+    for rb in rbs():
+        ro, aln, mt, st = seq_ctx.map_batch(rb); seq_ctx.eq_accumulate(); want.append((ro, aln, mt, st))
+    pip = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    batches = rbs()
+    pip.map_submit(batches[0], fetch=True); pip.map_submit(batches[1], fetch=True)
+    for i in range(len(batches)):
+        ro, aln, mt, st = pip.map_wait()
+        assert st == want[i][3]
+        assert np.array_equal(ro, want[i][0]) and np.array_equal(mt, want[i][2])
+        _fields_equal(aln, want[i][1], list(api.ALN_DTYPE.names), "alignments of batch %d" % i)
+        if i in (1, 2):   # taps refer to the batch just waited for (lane 1, then lane 0)
+            assert len(pip.tap(3, api.CHAIN_DTYPE)) == st["num_chains"]
+        pip.eq_accumulate()
+        if i + 2 < len(batches):
+            pip.map_submit(batches[i + 2], fetch=True)
+    assert pip.summary() == seq_ctx.summary()
+    for a, b in zip(pip.model(), seq_ctx.model()):
+        assert np.array_equal(a, b)
+    e1, e2 = pip.eq_finish(), seq_ctx.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(e1, f), getattr(e2, f)), f
+    pip.free(); seq_ctx.free()
