@@ -197,9 +197,13 @@ def main():
         c2 = time.perf_counter()
         _, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
         c3 = time.perf_counter()
+        # the checker's EM loop is single-threaded (order-defined sums); its multi-threaded iteration (same arithmetic,
+        # transcripts split over threads) is timed separately and used for the composite so the CPU gets its cores
+        em_thr_s = orc.em_time_iters(eqc, np.exp(lec), 20, ncores) / 20.0 * repc["iters"]
         em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
-        cpu = {"value": round(S / (c3 - c0) / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0: CPU checker map (%d threads) %.2fs + online/eq (1 thread) %.2fs + VBEM %d iters (1 thread) %.2fs" % (S, B, ncores, c1 - c0, c2 - c1, repc["iters"], c3 - c2),
+        t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
+        cpu = {"value": round(S / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
+               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (%d threads; the single-threaded loop took %.2fs)" % (S, B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, c3 - c2),
                "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2)}
     out = {
         "metric": "M reads/s quantified (map+EM), 2x100bp vs human-shaped txome; EM iters/s", "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",
