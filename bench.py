@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--debug-one-device", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
     ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
     return ap.parse_args()
 
@@ -61,11 +62,14 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if a.debug_one_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.debug_one_device: dist.init_process_group("gloo")
+        else: dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from salmon_amd import api, synth, capi
     ncores = os.cpu_count() or 8
     thr = max(4, ncores // max(1, world))
@@ -130,12 +134,13 @@ def main():
     lm, uq, tc, le = ctx.model()
     if dist:  # one RCCL all-gather per packed field; every rank merges the others' tables exactly (integer sums)
         from salmon_amd import dist as sqdist
-        tables = sqdist.all_gather_tables(eq, dist, dev)
+        cdev = torch.device("cpu") if a.debug_one_device else dev
+        tables = sqdist.all_gather_tables(eq, dist, cdev)
         for r in range(world):
             if r != rank:
                 ctx.eq_merge(tables[r])
         eq = ctx.eq_finish()
-        lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, dev)
+        lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, cdev)
     t_a = time.perf_counter()
     proj = api.normalize_alphas(eq, lm, uq, tc)
     t_norm = time.perf_counter() - t_a
@@ -148,7 +153,7 @@ def main():
     t1 = time.perf_counter()
     dt = t1 - t0
     if dist:
-        tt_ = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt_, op=dist.ReduceOp.MAX); dt = float(tt_.item())
+        tt_ = torch.tensor([dt], device=(torch.device("cpu") if a.debug_one_device else dev), dtype=torch.float64); dist.all_reduce(tt_, op=dist.ReduceOp.MAX); dt = float(tt_.item())
     stages = ctx.stage_times()
     # EM iteration rate from a fixed-count run on the final table (outside the timed region)
     _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)

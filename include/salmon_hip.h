@@ -310,6 +310,29 @@ int sq_normalize_alphas(uint32_t num_txp, const sq_eq_table* eq, const double* l
 int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags);
 int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights);
 
+/* quant.sf from plain name / length arrays (`salmon quant -e` has no index; lens may be NULL). */
+int sq_write_quant_sf_names(const char* path, uint32_t m, const char* const* names, const uint32_t* lens,
+                            const double* eff_len, const double* num_reads, double num_mapped_frags);
+
+/* `salmon quant -e eq_classes.txt[.gz]` input (salmon::utils::readEquivCounts, SalmonUtils.cpp:1026-1122;
+ * consumed by processEqClasses, SalmonQuantifyAlignments.cpp:1407-1441): the file written with
+ * --dumpEqWeights, optionally followed by "name effLen" pairs (missing ones default to 100).
+ * sq_eq_file_table fills off/tid/w/count with pointers owned by the file object. */
+typedef struct sq_eq_file sq_eq_file;
+int sq_eq_file_read(const char* path, sq_eq_file** out);
+void sq_eq_file_free(sq_eq_file*);
+uint32_t sq_eq_file_num_txp(const sq_eq_file*);
+const char* sq_eq_file_name(const sq_eq_file*, uint32_t i);
+const double* sq_eq_file_eff_lens(const sq_eq_file*);
+int sq_eq_file_table(const sq_eq_file*, sq_eq_table* out);
+
+/* aux_info/bootstrap/names.tsv.gz + bootstraps.gz (raw f64[M] per replicate, GZipWriter.cpp:306-326,765-788);
+ * sq_boot_writer_append has the signature shape of the replicate callback below. */
+typedef struct sq_boot_writer sq_boot_writer;
+int sq_boot_writer_open(const char* aux_dir, uint32_t m, const char* const* names, sq_boot_writer** out);
+int sq_boot_writer_append(sq_boot_writer*, const double* alphas, uint32_t m);
+uint64_t sq_boot_writer_close(sq_boot_writer*);   /* returns the number of replicates written */
+
 typedef int (*sq_replicate_cb)(const double* alphas, uint32_t m, void* user);
 int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                      uint32_t num_bootstraps, uint64_t seed, uint64_t num_mapped,

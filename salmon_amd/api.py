@@ -355,6 +355,35 @@ def write_eq_classes(path, index, eq, with_weights=False):
     check(lib().sq_write_eq_classes(path.encode(), index.h, C.byref(t), int(with_weights)), "sq_write_eq_classes")
 
 
+def read_eq_classes(path):
+    """salmon::utils::readEquivCounts: (names, eff_lens, EqClasses) from an eq_classes.txt[.gz] written with weights."""
+    h = C.c_void_p()
+    check(lib().sq_eq_file_read(path.encode(), C.byref(h)), "sq_eq_file_read")
+    try:
+        M = lib().sq_eq_file_num_txp(h)
+        names = [lib().sq_eq_file_name(h, i).decode() for i in range(M)]
+        eff = np.ctypeslib.as_array(lib().sq_eq_file_eff_lens(h), shape=(M,)).copy()
+        t = capi.EqTable(); check(lib().sq_eq_file_table(h, C.byref(t)), "sq_eq_file_table")
+        E, L = int(t.num_classes), int(t.num_labels)
+        off = np.ctypeslib.as_array(t.off, shape=(E + 1,)).copy()
+        tid = np.ctypeslib.as_array(t.tid, shape=(L,)).copy() if L else np.zeros(0, np.uint32)
+        w = np.ctypeslib.as_array(t.w, shape=(L,)).copy() if L else np.zeros(0)
+        cnt = np.ctypeslib.as_array(t.count, shape=(E,)).copy() if E else np.zeros(0, np.uint64)
+        return names, eff, EqClasses(off, tid, w, cnt)
+    finally:
+        lib().sq_eq_file_free(h)
+
+
+def write_bootstraps(aux_dir, names, rows):
+    """aux_info/bootstrap/{names.tsv.gz, bootstraps.gz} (GZipWriter::writeBootstrap); returns the count written."""
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names]); h = C.c_void_p()
+    check(lib().sq_boot_writer_open(aux_dir.encode(), len(names), arr, C.byref(h)), "sq_boot_writer_open")
+    for r in rows:
+        r = np.ascontiguousarray(r, np.float64)
+        check(lib().sq_boot_writer_append(h, _ptr(r, C.c_double), len(r)), "sq_boot_writer_append")
+    return int(lib().sq_boot_writer_close(h))
+
+
 def _collect(n_txp):
     rows = []
 

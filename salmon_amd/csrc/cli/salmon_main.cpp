@@ -59,7 +59,49 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
   {"IU", {1, 2, 4}}, {"ISF", {1, 2, 0}}, {"ISR", {1, 2, 1}}, {"OU", {1, 1, 4}}, {"OSF", {1, 1, 0}}, {"OSR", {1, 1, 1}},
   {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
 
+static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
+
+// posterior samples into aux_info/bootstrap (MappingPipelineStages.cpp:60-95): --numBootstraps wins over --numGibbsSamples
+static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop, const double* alphas, uint32_t M,
+                         const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped) {
+  const char* v; const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv, "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
+  if (!nb && !ng) return;
+  const uint64_t seed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
+  sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
+  if (nb) { if (sq_bootstrap_dev(device, t, tx, eop, nb, seed, num_mapped, boot_cb, bw)) die("bootstrap"); }
+  else {
+    sq_gibbs_opts go{}; go.thinning_factor = (v = arg(argc, argv, "--thinningFactor")) ? (uint32_t)atoi(v) : 16; go.no_gamma_draw = flag(argc, argv, "--noGammaDraw"); go.use_vbem = eop->use_vbem;
+    go.per_transcript_prior = eop->per_transcript_prior; go.vb_prior = eop->vb_prior;
+    if (sq_gibbs_dev(device, t, tx, &go, alphas, ng, seed, num_mapped, boot_cb, bw)) die("Gibbs sampling");
+  }
+  fprintf(stderr, "[salmon-hip] wrote %llu %s samples\n", (unsigned long long)sq_boot_writer_close(bw), nb ? "bootstrap" : "Gibbs");
+}
+
+// salmon quant -e eq_classes.txt[.gz] -o out : EM straight from a dumped table (SalmonQuantifyAlignments.cpp:1407-1441)
+static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
+  const char* odir = arg(argc, argv, "-o", "--output"); if (!odir) { fprintf(stderr, "usage: salmon-hip quant -e eq_classes.txt[.gz] -o out_dir [--useEM] [--numBootstraps N | --numGibbsSamples N]\n"); return 1; }
+  const char* v; int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0;
+  sq_eq_file* F = nullptr; if (sq_eq_file_read(eqf, &F)) die("reading eq classes");
+  const uint32_t M = sq_eq_file_num_txp(F); sq_eq_table t{}; sq_eq_file_table(F, &t);
+  fprintf(stderr, "[salmon-hip] Found total %llu eqclasses and %u transcripts\n", (unsigned long long)t.num_classes, M);
+  sq_em_opts eop; sq_em_opts_default(&eop); eop.init_uniform = 1; eop.eq_class_mode = 1;   // "Using Uniform Prior" (:1421-1425)
+  if (flag(argc, argv, "--useEM")) eop.use_vbem = 0;
+  if ((v = arg(argc, argv, "--vbPrior"))) eop.vb_prior = atof(v);
+  if (flag(argc, argv, "--perNucleotidePrior")) eop.per_transcript_prior = 0;
+  std::vector<double> alphas(M, 0.0); sq_txp_in tx{M, nullptr, nullptr, const_cast<double*>(sq_eq_file_eff_lens(F))}; sq_em_report rep{};
+  if (sq_em_optimize_dev(device, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
+  mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
+  std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_eq_file_name(F, i);
+  if (sq_write_quant_sf_names((od + "/quant.sf").c_str(), M, names.data(), nullptr, sq_eq_file_eff_lens(F), alphas.data(), 0.0)) die("quant.sf");
+  uint64_t nm = 0; for (uint64_t c = 0; c < t.num_classes; ++c) nm += t.count[c];
+  run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, nm);
+  fprintf(stderr, "[salmon-hip] %llu eq-classes, %u %s iterations -> %s/quant.sf\n", (unsigned long long)t.num_classes, rep.iters, eop.use_vbem ? "VBEM" : "EM", odir);
+  sq_eq_file_free(F);
+  return 0;
+}
+
 static int cmd_quant(int argc, char** argv) {
+  if (const char* eqf = arg(argc, argv, "-e", "--eqclasses")) return cmd_quant_eq(argc, argv, eqf);
   const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
   const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
@@ -121,6 +163,8 @@ static int cmd_quant(int argc, char** argv) {
     if (flag(argc, argv, "--perNucleotidePrior")) eop.per_transcript_prior = 0;
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
     if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
+    std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_index_ref_name(idx, i);
+    run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned);
   }
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");

@@ -13,6 +13,11 @@
 #include <cstdio>
 #include <map>
 #include <numeric>
+#include <memory>
+#include <string>
+#include <cstring>
+#include <cctype>
+#include <sys/stat.h>
 
 namespace {
 struct DSU {
@@ -110,3 +115,85 @@ extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const 
   gzclose(g);
   return SQ_OK;
 }
+
+// ---- `salmon quant -e` input: aux_info/eq_classes.txt[.gz] written with --dumpEqWeights -------------
+// salmon::utils::readEquivCounts (reference src/util/SalmonUtils.cpp:1026-1122): M, E, M names, E rows
+// "n  tid*n  weight*n  count", then optional "name effLen" pairs; missing effective lengths are 100.
+struct sq_eq_file { std::vector<std::string> names; std::vector<double> eff; std::vector<uint64_t> off, count; std::vector<uint32_t> tid; std::vector<double> w; };
+extern "C" int sq_eq_file_read(const char* path, sq_eq_file** out) {
+  if (!path || !out) { sq_set_error("sq_eq_file_read: bad arguments"); return SQ_ERR_ARG; }
+  gzFile g = gzopen(path, "rb"); if (!g) { sq_set_error("cannot read '%s'", path); return SQ_ERR_IO; }   // gzopen reads plain text too
+  std::string all; char buf[1 << 16]; int n;
+  while ((n = gzread(g, buf, sizeof(buf))) > 0) all.append(buf, (size_t)n);
+  gzclose(g);
+  const char* p = all.c_str(); const char* end = p + all.size();
+  auto tok = [&](std::string& t) { while (p < end && isspace((unsigned char)*p)) ++p; const char* b = p; while (p < end && !isspace((unsigned char)*p)) ++p; t.assign(b, p); return !t.empty(); };
+  std::string t; std::unique_ptr<sq_eq_file> F(new sq_eq_file());
+  if (!tok(t)) { sq_set_error("'%s': empty eq-class file", path); return SQ_ERR_IO; } const uint64_t M = strtoull(t.c_str(), nullptr, 10);
+  if (!tok(t)) { sq_set_error("'%s': truncated header", path); return SQ_ERR_IO; } const uint64_t E = strtoull(t.c_str(), nullptr, 10);
+  std::map<std::string, size_t> idx;
+  for (uint64_t i = 0; i < M; ++i) { if (!tok(t)) { sq_set_error("'%s': truncated name list", path); return SQ_ERR_IO; } idx[t] = F->names.size(); F->names.push_back(t); }
+  F->off.assign(1, 0);
+  for (uint64_t c = 0; c < E; ++c) {
+    if (!tok(t)) { sq_set_error("'%s': truncated at class %llu", path, (unsigned long long)c); return SQ_ERR_IO; }
+    const uint64_t k = strtoull(t.c_str(), nullptr, 10);
+    for (uint64_t i = 0; i < k; ++i) { if (!tok(t)) { sq_set_error("'%s': truncated labels", path); return SQ_ERR_IO; } const uint64_t x = strtoull(t.c_str(), nullptr, 10); if (x >= M) { sq_set_error("'%s': transcript id %llu out of range", path, (unsigned long long)x); return SQ_ERR_IO; } F->tid.push_back((uint32_t)x); }
+    for (uint64_t i = 0; i < k; ++i) { if (!tok(t)) { sq_set_error("'%s': class %llu has no weights (write the file with --dumpEqWeights)", path, (unsigned long long)c); return SQ_ERR_IO; } F->w.push_back(strtod(t.c_str(), nullptr)); }
+    if (!tok(t)) { sq_set_error("'%s': class %llu has no count", path, (unsigned long long)c); return SQ_ERR_IO; }
+    F->count.push_back(strtoull(t.c_str(), nullptr, 10)); F->off.push_back(F->tid.size());
+  }
+  F->eff.assign(M, 100.0);
+  std::string nm;
+  while (tok(nm)) { if (!tok(t)) break; auto it = idx.find(nm); if (it == idx.end()) { sq_set_error("'%s': effective length for unknown transcript '%s'", path, nm.c_str()); return SQ_ERR_IO; } F->eff[it->second] = strtod(t.c_str(), nullptr); }
+  *out = F.release();
+  return SQ_OK;
+}
+extern "C" void sq_eq_file_free(sq_eq_file* f) { delete f; }
+extern "C" uint32_t sq_eq_file_num_txp(const sq_eq_file* f) { return f ? (uint32_t)f->names.size() : 0; }
+extern "C" const char* sq_eq_file_name(const sq_eq_file* f, uint32_t i) { return (f && i < f->names.size()) ? f->names[i].c_str() : nullptr; }
+extern "C" const double* sq_eq_file_eff_lens(const sq_eq_file* f) { return f ? f->eff.data() : nullptr; }
+extern "C" int sq_eq_file_table(const sq_eq_file* f, sq_eq_table* t) {
+  if (!f || !t) return SQ_ERR_ARG;
+  memset(t, 0, sizeof(*t)); t->num_classes = f->count.size(); t->num_labels = f->tid.size();
+  t->off = const_cast<uint64_t*>(f->off.data()); t->tid = const_cast<uint32_t*>(f->tid.data()); t->w = const_cast<double*>(f->w.data()); t->count = const_cast<uint64_t*>(f->count.data());
+  return SQ_OK;
+}
+
+// quant.sf from plain name / length arrays (the -e mode has no index)
+extern "C" int sq_write_quant_sf_names(const char* path, uint32_t M, const char* const* names, const uint32_t* lens, const double* eff_len, const double* num_reads, double num_mapped_frags) {
+  if (!path || !names || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf_names: bad arguments"); return SQ_ERR_ARG; }
+  FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  if (!(num_mapped_frags > 0)) { num_mapped_frags = 0; for (uint32_t i = 0; i < M; ++i) num_mapped_frags += num_reads[i]; }
+  double denom = 0.0;
+  for (uint32_t i = 0; i < M; ++i) denom += (num_reads[i] / num_mapped_frags) / eff_len[i];
+  fprintf(f, "Name\tLength\tEffectiveLength\tTPM\tNumReads\n");
+  for (uint32_t i = 0; i < M; ++i) {
+    double npm = num_reads[i] / num_mapped_frags; double tpm = denom > 0 ? ((npm / eff_len[i]) / denom) * 1000000.0 : 0.0;
+    fprintf(f, "%s\t%u\t%.3f\t%f\t%.3f\n", names[i], lens ? lens[i] : (uint32_t)eff_len[i], eff_len[i], tpm, num_reads[i]);
+  }
+  fclose(f);
+  return SQ_OK;
+}
+
+// aux_info/bootstrap/{names.tsv.gz, bootstraps.gz}: one tab-separated name row; raw f64[M] per replicate,
+// appended in arrival order (GZipWriter.cpp:306-326, 765-788)
+struct sq_boot_writer { gzFile g = nullptr; uint32_t M = 0; uint64_t written = 0; };
+extern "C" int sq_boot_writer_open(const char* aux_dir, uint32_t M, const char* const* names, sq_boot_writer** out) {
+  if (!aux_dir || !names || !out || M == 0) { sq_set_error("sq_boot_writer_open: bad arguments"); return SQ_ERR_ARG; }
+  const std::string d = std::string(aux_dir) + "/bootstrap";
+  mkdir(aux_dir, 0755); mkdir(d.c_str(), 0755);
+  gzFile n = gzopen((d + "/names.tsv.gz").c_str(), "wb6"); if (!n) { sq_set_error("cannot write '%s/names.tsv.gz'", d.c_str()); return SQ_ERR_IO; }
+  for (uint32_t i = 0; i < M; ++i) { gzputs(n, names[i]); if (i + 1 < M) gzputc(n, '\t'); }
+  gzputc(n, '\n'); gzclose(n);
+  std::unique_ptr<sq_boot_writer> W(new sq_boot_writer()); W->M = M;
+  W->g = gzopen((d + "/bootstraps.gz").c_str(), "wb6"); if (!W->g) { sq_set_error("cannot write '%s/bootstraps.gz'", d.c_str()); return SQ_ERR_IO; }
+  *out = W.release();
+  return SQ_OK;
+}
+extern "C" int sq_boot_writer_append(sq_boot_writer* w, const double* alphas, uint32_t M) {
+  if (!w || !w->g || !alphas || M != w->M) { sq_set_error("sq_boot_writer_append: bad arguments"); return SQ_ERR_ARG; }
+  if (gzwrite(w->g, alphas, (unsigned)((size_t)M * 8)) != (int)((size_t)M * 8)) { sq_set_error("short write to bootstraps.gz"); return SQ_ERR_IO; }
+  w->written++;
+  return SQ_OK;
+}
+extern "C" uint64_t sq_boot_writer_close(sq_boot_writer* w) { if (!w) return 0; uint64_t n = w->written; if (w->g) gzclose(w->g); delete w; return n; }

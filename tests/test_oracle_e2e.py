@@ -50,3 +50,32 @@ def test_sample_data_maps_to_the_true_transcripts(sample):
     r = np.corrcoef(alphas, true)[0, 1]
     assert r > 0.98
     assert abs(alphas.sum() - ost.summary()["num_assigned"]) < 1e-6 * alphas.sum()
+
+
+def test_eq_class_file_round_trip_and_bootstrap_writer(built, tmp_path):
+    # `salmon quant -e` interchange (readEquivCounts) against our own --dumpEqWeights writer, and the
+    # bootstraps.gz / names.tsv.gz layout (raw f64[M] per replicate)
+    import gzip
+    from conftest import random_eq_classes
+    from salmon_amd import synth
+    tx = synth.Txome(seed=21, n_genes=10, iso_per_gene=3, threads=1)
+    names, seqs, lens = tx.tables()
+    idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=1)
+    M = idx.num_refs
+    eq = random_eq_classes(M, 200, seed=3)
+    p = str(tmp_path / "eq_classes.txt.gz")
+    api.write_eq_classes(p, idx, eq, with_weights=True)
+    rnames, eff, eq2 = api.read_eq_classes(p)
+    assert rnames == list(idx.ref_names()) and np.all(eff == 100.0)
+    assert np.array_equal(eq2.off, eq.off) and np.array_equal(eq2.tid, eq.tid) and np.array_equal(eq2.count, eq.count)
+    assert np.array_equal(eq2.w, eq.w)          # %.17g round-trips doubles exactly
+    # optional trailing "name effLen" pairs
+    with gzip.open(p, "at") as f:
+        f.write("%s\t123.5\n" % rnames[2])
+    _, eff2, _ = api.read_eq_classes(p)
+    assert eff2[2] == 123.5 and eff2[0] == 100.0
+    rows = np.random.default_rng(1).uniform(0, 50, (3, M))
+    assert api.write_bootstraps(str(tmp_path / "aux_info"), rnames, rows) == 3
+    raw = gzip.open(tmp_path / "aux_info" / "bootstrap" / "bootstraps.gz").read()
+    assert np.array_equal(np.frombuffer(raw, np.float64).reshape(3, M), rows)
+    assert gzip.open(tmp_path / "aux_info" / "bootstrap" / "names.tsv.gz").read().decode() == "\t".join(rnames) + "\n"
