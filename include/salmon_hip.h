@@ -211,6 +211,7 @@ int sq_map_batch(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out, sq_map_sta
  * as after sq_map_batch.  Keeping two batches in flight lets their kernels fill each other's stalls.
  * `in` (and `out`, if given) must stay valid until the matching sq_map_wait returns.  This replaces
  * the reference's N worker threads pulling chunks from the parser (SalmonQuantify.cpp:2390-2403). */
+int sq_ctx_set_lanes(sq_ctx*, int lanes /* 1..4, default 2 */);
 int sq_map_submit(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out /* may be NULL */);
 int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stats);
 
@@ -218,6 +219,19 @@ int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stat
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +
  *     EquivalenceClassBuilder::addGroup/finish (EquivalenceClassBuilder.hpp:165-181,237-250).
  * ---------------------------------------------------------------------------------------------- */
+/* Host read pipeline in front of the mapping seam (replaces the FQFeeder parser threads and chunk queues,
+ * SalmonQuantify.cpp:2419-2443): one producer thread per mate stream inflates (.gz or plain) and splits
+ * FASTQ/FASTA records; sq_reader_next interleaves the mates into a read batch in one of `num_slots`
+ * rotating page-locked host buffers (layout = sq_read_batch, on_device = 0).  A batch stays valid until
+ * sq_reader_release(reader, slot).  files2 == NULL / n2 == 0: single-end.  End of input: batch->n == 0. */
+typedef struct sq_reader sq_reader;
+int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2,
+                   uint32_t batch_reads, uint32_t num_slots, sq_reader** out);
+int sq_reader_next(sq_reader*, sq_read_batch* batch, int* slot);
+void sq_reader_release(sq_reader*, int slot);
+uint64_t sq_reader_total(const sq_reader*);
+void sq_reader_close(sq_reader*);
+
 /* Run the online model over the batch last mapped by sq_map_batch (mini-batches of
  * opts.mini_batch_size in input order) and add its fragments to the device eq-class table. */
 int sq_eq_accumulate(sq_ctx*);

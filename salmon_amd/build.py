@@ -57,6 +57,9 @@ def build_product(verbose=True):
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, stamp), srcs))
     objs = [o for o, _ in res]
+    for f in os.listdir(OBJ):   # objects of older header stamps only bloat the tree that travels to the GPU box
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
     if any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lz", "-lpthread", "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <array>
 #include <map>
 #include <string>
@@ -124,25 +125,34 @@ static int cmd_quant(int argc, char** argv) {
   if (flag(argc, argv, "--discardOrphansQuasi")) qo.allow_orphans = 0;
   if (flag(argc, argv, "--disableChainingHeuristic")) qo.disable_chaining_heuristic = 1;
   sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
-  Fastq f1, f2; if (!f1.open(paired ? r1 : ru) || (paired && !f2.open(r2))) { fprintf(stderr, "[salmon-hip] cannot open read files\n"); return 1; }
-  std::vector<uint8_t> seq; std::vector<uint64_t> off; std::string s1, s2; sq_map_stats tot{}; uint64_t nfrag = 0; bool more = true;
-  while (more) {
-    seq.clear(); off.assign(1, 0); uint32_t n = 0;
-    while (n < B) {
-      if (!f1.record(s1) || (paired && !f2.record(s2))) { more = false; break; }
-      seq.insert(seq.end(), s1.begin(), s1.end()); off.push_back(seq.size());
-      if (paired) { seq.insert(seq.end(), s2.begin(), s2.end()); off.push_back(seq.size()); }
-      ++n;
-    }
-    if (!n) break;
-    seq.resize(seq.size() + 16);
-    sq_read_batch in{n, paired ? 1u : 0u, seq.data(), off.data(), 0}; sq_map_stats st{};
-    if (sq_map_batch(ctx, &in, nullptr, &st)) die("mapping");
+  // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
+  // the mapping lanes: up to `lanes` batches are in flight (H2D + mapping) while the next one is parsed
+  auto split = [](const char* s) { std::vector<std::string> v; std::string cur; for (const char* p = s; ; ++p) { if (*p == ',' || *p == ' ' || !*p) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; } else cur.push_back(*p); } return v; };
+  std::vector<std::string> l1 = split(paired ? r1 : ru), l2 = paired ? split(r2) : std::vector<std::string>();
+  std::vector<const char*> p1, p2; for (auto& x : l1) p1.push_back(x.c_str()); for (auto& x : l2) p2.push_back(x.c_str());
+  const uint32_t lanes = (v = arg(argc, argv, "--lanes")) ? (uint32_t)std::max(1, std::min(4, atoi(v))) : 2;
+  if (sq_ctx_set_lanes(ctx, (int)lanes)) die("lanes");
+  sq_reader* rd = nullptr; if (sq_reader_open(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, &rd)) die("opening reads");
+  sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight;
+  auto finish_one = [&]() {
+    sq_map_stats st{};
+    if (sq_map_wait(ctx, nullptr, &st)) die("mapping");
     if (sq_eq_accumulate(ctx)) die("eq-class accumulation");
+    sq_reader_release(rd, inflight.front()); inflight.erase(inflight.begin());
     uint64_t* a = (uint64_t*)&tot; const uint64_t* b = (const uint64_t*)&st; for (size_t i = 0; i < sizeof(st) / 8; ++i) a[i] += b[i];
-    nfrag += n;
+    nfrag += st.num_reads;
     fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
+  };
+  for (;;) {
+    sq_read_batch in; int slot = -1;
+    if (sq_reader_next(rd, &in, &slot)) die("reading");
+    if (in.n == 0) break;
+    if (inflight.size() == lanes) finish_one();
+    if (sq_map_submit(ctx, &in, nullptr)) die("mapping");
+    inflight.push_back(slot);
   }
+  while (!inflight.empty()) finish_one();
+  sq_reader_close(rd);
   fprintf(stderr, "\n");
   const uint32_t M = sq_index_num_refs(idx);
   sq_eq_table t{}; if (sq_eq_finish(ctx, &t)) die("eq finish");

@@ -110,6 +110,7 @@ struct sq_ctx {
   uint32_t acc_n = 0; int acc_buf = 0; uint64_t acc_total_aln = 0, acc_joint = 0;   // the batch sq_eq_accumulate will take (set by sq_map_batch / sq_map_wait)
   sq_ctx* owner = nullptr;                 // set in a shadow ctx: the ctx that owns the online model and the eq worker
   std::vector<sq_ctx*> shadows;            // lanes 1.. (owned by lane 0)
+  int n_lanes = 0;                         // 0 = not chosen yet (SQ_MAP_LANES or 2 at the first submit)
   sq_ctx* last_src = nullptr;              // lane whose batch the next sq_eq_accumulate / sq_debug_tap refers to
   bool api_have = false;                   // a mapped batch has been returned to the caller and not yet accumulated
   std::thread lane_thread; std::mutex lane_mu; std::condition_variable lane_cv, lane_cv_done; std::deque<std::shared_ptr<map_job>> lane_q; bool lane_stop = false;

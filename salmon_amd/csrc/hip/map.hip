@@ -157,10 +157,16 @@ static void lane_worker(sq_ctx* c) {
     c->lane_cv_done.notify_all();
   }
 }
+extern "C" int sq_ctx_set_lanes(sq_ctx* c, int lanes) {
+  if (!c || c->owner || lanes < 1 || lanes > 4) { sq_set_error("sq_ctx_set_lanes: 1..4 lanes"); return SQ_ERR_ARG; }
+  if (!c->tickets.empty()) { sq_set_error("sq_ctx_set_lanes: batches are in flight"); return SQ_ERR_STATE; }
+  c->n_lanes = lanes; c->submitted = 0;
+  return SQ_OK;
+}
 extern "C" int sq_map_submit(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out) {
   if (!c || c->owner || !in) { sq_set_error("sq_map_submit: bad arguments"); return SQ_ERR_ARG; }
-  static const int nl_env = getenv("SQ_MAP_LANES") ? atoi(getenv("SQ_MAP_LANES")) : 2;
-  const size_t want_lanes = (size_t)std::max(1, std::min(4, nl_env));
+  if (c->n_lanes == 0) c->n_lanes = std::max(1, std::min(4, getenv("SQ_MAP_LANES") ? atoi(getenv("SQ_MAP_LANES")) : 2));
+  const size_t want_lanes = (size_t)c->n_lanes;
   while (c->shadows.size() + 1 < want_lanes) { sq_ctx* sh = nullptr; int rc = ctx_create_lane(c->idx, &c->opts, c->device, c->max_reads, c, &sh); if (rc) return rc; sh->prof_on = c->prof_on; c->shadows.push_back(sh); }
   if (c->tickets.size() >= want_lanes) { sq_set_error("sq_map_submit: %zu batches already in flight (one per lane); call sq_map_wait first", c->tickets.size()); return SQ_ERR_STATE; }
   sq_ctx* lane = (c->submitted % want_lanes) == 0 ? c : c->shadows[(c->submitted % want_lanes) - 1];

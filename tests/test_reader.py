@@ -1,0 +1,86 @@
+"""Host read pipeline (sq_reader): FASTQ/FASTA, gzip or plain, several files per mate,
+CRLF, batches that do not divide the input, error paths.  No GPU needed."""
+import ctypes as C, gzip, os
+import numpy as np
+import pytest
+from salmon_amd import capi
+
+
+def _open(f1, f2, batch, slots=3):
+    L = capi.lib()
+    a1 = (C.c_char_p * len(f1))(*[x.encode() for x in f1]); a2 = (C.c_char_p * len(f2))(*[x.encode() for x in f2]) if f2 else None
+    h = C.c_void_p(); rc = L.sq_reader_open(a1, len(f1), a2, len(f2) if f2 else 0, batch, slots, C.byref(h))
+    assert rc == 0, L.sq_last_error()
+    return h
+
+
+def _drain(h):
+    L = capi.lib(); out = []
+    while True:
+        rb = capi.ReadBatch(); slot = C.c_int(-1)
+        rc = L.sq_reader_next(h, C.byref(rb), C.byref(slot))
+        if rc != 0:
+            return out, L.sq_last_error().decode()
+        if rb.n == 0:
+            return out, None
+        nrec = rb.n * (2 if rb.paired else 1)
+        off = np.ctypeslib.as_array(C.cast(rb.seq_off, C.POINTER(C.c_uint64)), shape=(nrec + 1,)).copy()
+        seq = C.string_at(rb.seq, int(off[-1]))
+        out.append([seq[int(off[i]):int(off[i + 1])] for i in range(nrec)])
+        L.sq_reader_release(h, slot.value)
+
+
+def _fq(path, recs, gz=False, crlf=False, fasta=False, trailing_newline=True):
+    nl = "\r\n" if crlf else "\n"
+    txt = "".join((">r%d%s%s%s" % (i, nl, s, nl)) if fasta else ("@r%d%s%s%s+%s%s%s" % (i, nl, s, nl, nl, "I" * len(s), nl)) for i, s in enumerate(recs))
+    if not trailing_newline: txt = txt.rstrip("\r\n")
+    (gzip.open(path, "wt", newline="") if gz else open(path, "w", newline="")).write(txt)
+
+
+def test_reader_paired_multi_file_formats(built, tmp_path):
+    rng = np.random.default_rng(0)
+    def reads(n): return ["".join(rng.choice(list("ACGTN"), size=int(rng.integers(30, 151)))) for _ in range(n)]
+    a1, a2, b1, b2 = reads(700), reads(700), reads(333), reads(333)
+    _fq(tmp_path / "a_1.fq.gz", a1, gz=True); _fq(tmp_path / "a_2.fq.gz", a2, gz=True, crlf=True)
+    _fq(tmp_path / "b_1.fq", b1, trailing_newline=False); _fq(tmp_path / "b_2.fa", b2, fasta=True)
+    h = _open([str(tmp_path / "a_1.fq.gz"), str(tmp_path / "b_1.fq")], [str(tmp_path / "a_2.fq.gz"), str(tmp_path / "b_2.fa")], batch=256)
+    got, err = _drain(h)
+    assert err is None and capi.lib().sq_reader_total(h) == 1033
+    capi.lib().sq_reader_close(h)
+    assert [len(b) // 2 for b in got] == [256, 256, 256, 256, 9]
+    flat = [r for b in got for r in b]
+    want = [x.encode() for pair in zip(a1 + b1, a2 + b2) for x in pair]
+    assert flat == want
+
+
+def test_reader_single_end_and_errors(built, tmp_path):
+    recs = ["ACGT" * 10, "", "TTTTGGGG"]
+    _fq(tmp_path / "s.fq", recs)
+    h = _open([str(tmp_path / "s.fq")], None, batch=2); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is None and [r for b in got for r in b] == [r.encode() for r in recs]
+    # mate files of different length
+    _fq(tmp_path / "m1.fq", ["ACGT"] * 5); _fq(tmp_path / "m2.fq", ["ACGT"] * 4)
+    h = _open([str(tmp_path / "m1.fq")], [str(tmp_path / "m2.fq")], batch=100); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "different numbers of records" in err
+    # truncated record
+    open(tmp_path / "t.fq", "w").write("@r0\nACGT\n+\nIIII\n@r1\nACG")
+    h = _open([str(tmp_path / "t.fq")], None, batch=100); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "truncated" in err
+    # not FASTQ/FASTA
+    open(tmp_path / "x.fq", "w").write("hello\nworld\n")
+    h = _open([str(tmp_path / "x.fq")], None, batch=100); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "does not start" in err
+    # missing file
+    h = _open([str(tmp_path / "nope.fq")], None, batch=100); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "cannot open" in err
+
+
+def test_reader_refuses_when_all_slots_busy(built, tmp_path):
+    _fq(tmp_path / "s.fq", ["ACGT"] * 10)
+    L = capi.lib(); h = _open([str(tmp_path / "s.fq")], None, batch=2, slots=2)
+    rb = capi.ReadBatch(); s = C.c_int()
+    assert L.sq_reader_next(h, C.byref(rb), C.byref(s)) == 0 and L.sq_reader_next(h, C.byref(rb), C.byref(s)) == 0
+    assert L.sq_reader_next(h, C.byref(rb), C.byref(s)) != 0 and b"in use" in L.sq_last_error()
+    L.sq_reader_release(h, 0)
+    assert L.sq_reader_next(h, C.byref(rb), C.byref(s)) == 0 and rb.n == 2
+    L.sq_reader_close(h)
