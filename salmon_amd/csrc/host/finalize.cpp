@@ -13,6 +13,10 @@
 #include <cstdio>
 #include <map>
 #include <numeric>
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <cstring>
@@ -30,8 +34,11 @@ struct DSU {
 
 extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
   if (!eq || !log_mass || !uniq || !total || !projected) { sq_set_error("sq_normalize_alphas: bad arguments"); return SQ_ERR_ARG; }
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] normalize %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
   DSU d(M);
   for (uint64_t c = 0; c < eq->num_classes; ++c) { const uint64_t a = eq->off[c], b = eq->off[c + 1]; for (uint64_t i = a + 1; i < b; ++i) d.join(eq->tid[a], eq->tid[i]); }
+  mark("union-find");
   std::vector<double> hits(M, 0.0);
   for (uint64_t c = 0; c < eq->num_classes; ++c) if (eq->off[c + 1] > eq->off[c]) hits[d.root(eq->tid[eq->off[c]])] += (double)eq->count[c];
   // bucket members by root (counting sort keeps ascending tid inside each cluster)
@@ -39,8 +46,12 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
   for (uint32_t t = 0; t < M; ++t) start[d.root(t) + 1]++;
   for (uint32_t r = 0; r < M; ++r) start[r + 1] += start[r];
   { std::vector<uint32_t> cur(start.begin(), start.end() - 1); for (uint32_t t = 0; t < M; ++t) order[cur[d.root(t)]++] = t; }
+  mark("bucket");
+  // clusters are independent (each writes only its members' projected counts; sums inside a cluster keep their order)
+  const uint32_t nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  sq_parallel_for(M, nthr, 4096, [&](uint64_t r_lo, uint64_t r_hi, uint32_t) {
   std::vector<uint8_t> bound;
-  for (uint32_t r = 0; r < M; ++r) {
+  for (uint32_t r = (uint32_t)r_lo; r < (uint32_t)r_hi; ++r) {
     const uint32_t lo = start[r], hi = start[r + 1]; if (lo == hi) continue;
     double clusterMass = SQ_LOG_0;
     for (uint32_t i = lo; i < hi; ++i) clusterMass = sq_log_add(clusterMass, log_mass[order[i]]);     // SalmonUtils.cpp:483-490
@@ -69,6 +80,8 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
       }
     }
   }
+  });
+  mark("clusters");
   return SQ_OK;
 }
 
