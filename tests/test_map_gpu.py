@@ -187,3 +187,21 @@ def test_pipelined_lanes_match_sequential(small_world):
     for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
         assert np.array_equal(getattr(e1, f), getattr(e2, f)), f
     pip.free(); seq_ctx.free()
+
+
+@pytest.mark.parametrize("read_len,sub,indel", [(150, 0.02, 0.004), (250, 0.01, 0.002), (75, 0.03, 0.0)])
+def test_noisy_and_long_reads_match_checker(small_world, read_len, sub, indel):
+    # error-rich reads drive the banded DP (global + extension regions, early exits) and the mismatch-skip walk;
+    # 150 / 250 bp exercise the multi-word read packing (256 bases max per end)
+    w = small_world
+    N = 1500
+    seq, off, _, _ = w["tx"].reads(N, read_len=read_len, seed=77 + read_len, sub_rate=sub, indel_rate=indel, threads=4)
+    opts = api.quant_opts()
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=2048)
+    rb = api.make_read_batch(seq, off, N, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+    assert st_g == st_c and st_g["num_dp_alignments"] > 0
+    assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.free()
