@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
     ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
     return ap.parse_args()
@@ -66,7 +67,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         if a.debug_one_device: dist.init_process_group("gloo")
         else: dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -135,10 +136,13 @@ def main():
     if dist:  # one RCCL all-gather per packed field; every rank merges the others' tables exactly (integer sums)
         from salmon_amd import dist as sqdist
         cdev = torch.device("cpu") if a.debug_one_device else dev
-        tables = sqdist.all_gather_tables(eq, dist, cdev)
-        for r in range(world):
-            if r != rank:
-                ctx.eq_merge(tables[r])
+        if a.debug_one_device:      # gloo has no device collectives: host tables
+            tables = sqdist.all_gather_tables(eq, dist, cdev)
+            for r in range(world):
+                if r != rank:
+                    ctx.eq_merge(tables[r])
+        else:                       # tables go HBM -> xGMI -> HBM and are merged where they land
+            sqdist.merge_all_device(ctx, dist, dev)
         eq = ctx.eq_finish()
         lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, cdev)
     t_a = time.perf_counter()
@@ -158,6 +162,8 @@ def main():
     # EM iteration rate from a fixed-count run on the final table (outside the timed region)
     _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)
     if rank != 0:
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
         return
     E = len(eq.count); Lb = len(eq.tid); M = idx.num_refs
     em_bytes = 36 * Lb + 16 * E + 64 * M
@@ -223,7 +229,9 @@ def main():
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes, "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
         "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":

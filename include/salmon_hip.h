@@ -253,6 +253,12 @@ int sq_eq_finish(sq_ctx*, sq_eq_table* out);
 /* Merge an externally provided table (e.g. all-gathered from other GPUs) into this ctx's table:
  * counts and fixed-point weight sums add exactly, so any merge order gives identical bits. */
 int sq_eq_merge(sq_ctx*, const sq_eq_table* other);
+/* Device-resident forms for the multi-GPU reduction: sq_eq_export_device fills `out` with DEVICE pointers to
+ * the canonical-order export (valid until the next accumulate / merge / reset); sq_eq_merge_device merges a table
+ * whose arrays are device pointers on this ctx's GPU (e.g. the receive buffers of an RCCL all_gather), so the
+ * tables never bounce through host memory. */
+int sq_eq_export_device(sq_ctx*, sq_eq_table* out);
+int sq_eq_merge_device(sq_ctx*, const sq_eq_table* t);
 
 typedef struct {          /* online-model state needed downstream (Transcript, FLD, counters) */
   uint64_t num_observed, num_assigned, num_mapped_ub;

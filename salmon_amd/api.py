@@ -277,6 +277,22 @@ class QuantContext:
         return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum,
                          device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
 
+    def eq_export_device(self):
+        """Device pointers of the canonical-order export (sq_eq_export_device): dict field -> (ptr, count, numpy dtype)."""
+        t = capi.EqTable()
+        check(lib().sq_eq_export_device(self.h, C.byref(t)), "sq_eq_export_device")
+        E, L = int(t.num_classes), int(t.num_labels)
+        def addr(p): return C.cast(p, C.c_void_p).value or 0
+        return dict(E=E, L=L, off=(addr(t.off), E + 1 if E else 0, np.uint64), tid=(addr(t.tid), L, np.uint32), wq=(addr(t.wq), L, np.uint64), count=(addr(t.count), E, np.uint64),
+                    bins=(addr(t.bins), L, np.uint32), h1=(addr(t.h1), E, np.uint64), h2=(addr(t.h2), E, np.uint64))
+
+    def eq_merge_device(self, E, L, ptrs):
+        """sq_eq_merge_device: ptrs = dict field -> device address (off, tid, wq, count, bins, h1, h2) on this ctx's GPU."""
+        t = capi.EqTable(); t.num_classes = E; t.num_labels = L
+        t.off = C.cast(ptrs["off"], C.POINTER(C.c_uint64)); t.tid = C.cast(ptrs["tid"], C.POINTER(C.c_uint32)); t.wq = C.cast(ptrs["wq"], C.POINTER(C.c_uint64))
+        t.count = C.cast(ptrs["count"], C.POINTER(C.c_uint64)); t.bins = C.cast(ptrs["bins"], C.POINTER(C.c_uint32)); t.h1 = C.cast(ptrs["h1"], C.POINTER(C.c_uint64)); t.h2 = C.cast(ptrs["h2"], C.POINTER(C.c_uint64))
+        check(lib().sq_eq_merge_device(self.h, C.byref(t)), "sq_eq_merge_device")
+
     def eq_merge(self, eq):
         t = eq.table()
         check(lib().sq_eq_merge(self.h, C.byref(t)), "sq_eq_merge")

@@ -137,6 +137,7 @@ def lib():
         "sq_quant_opts_default": (None, [P(QuantOpts)]), "sq_em_opts_default": (None, [P(EmOpts)]),
         "sq_ctx_create": (C.c_int, [vp, P(QuantOpts), C.c_int, u32, P(vp)]), "sq_ctx_free": (None, [vp]), "sq_ctx_reset": (C.c_int, [vp]),
         "sq_map_batch": (C.c_int, [vp, P(ReadBatch), P(AlnBatch), P(MapStats)]),
+        "sq_eq_export_device": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge_device": (C.c_int, [vp, P(EqTable)]),
         "sq_map_submit": (C.c_int, [vp, P(ReadBatch), P(AlnBatch)]), "sq_ctx_set_lanes": (C.c_int, [vp, C.c_int]),
         "sq_reader_open": (C.c_int, [P(C.c_char_p), u32, P(C.c_char_p), u32, u32, u32, P(vp)]), "sq_reader_next": (C.c_int, [vp, P(ReadBatch), P(C.c_int)]),
         "sq_reader_release": (None, [vp, C.c_int]), "sq_reader_total": (u64, [vp]), "sq_reader_close": (None, [vp]),

@@ -41,6 +41,7 @@ struct sq_online_dev {
     void release() { keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
                      if (host) (void)hipHostFree(host); host = nullptr; host_cap = 0; valid = false; }
   } exp;
+  sq_dbuf<uint32_t> merge_slot;
   std::vector<double> fm_host;
   uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0; bool burned_known = false;
 };
@@ -615,7 +616,7 @@ int sq_online_create(sq_ctx* c) {
 void sq_online_free(sq_ctx* c) {
   sq_online_dev* o = c->online; if (!o) return;
   o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->tlc.free_(); o->pre.free_(); o->alp.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
-  o->exp.release(); o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
+  o->exp.release(); o->merge_slot.free_(); o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
   o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
   delete o; c->online = nullptr;
 }
@@ -933,23 +934,45 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   return SQ_OK;
 }
 
+// merge a table whose arrays already live on this ctx's device (e.g. gathered over RCCL straight into HBM)
+extern "C" int sq_eq_merge_device(sq_ctx* c, const sq_eq_table* t) {
+  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge_device: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  const uint64_t E = t->num_classes; if (E == 0) return SQ_OK;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  c->online->exp.valid = false;
+  sq_dbuf<uint32_t>& d_slot = c->online->merge_slot;
+  if (d_slot.ensure(E)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
+  EqView T = make_eq_view(c->online);
+  k_eq_merge_insert<<<nblk(E), TB, 0, c->stream>>>(T, E, t->off, t->tid, t->bins, (const uint64_t*)t->h1, (const uint64_t*)t->h2, d_slot.p);
+  k_eq_merge_add<<<nblk(E), TB, 0, c->stream>>>(T, E, t->off, t->wq, t->count, d_slot.p);
+  SQ_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return check_eq_overflow(c);
+}
+
 extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
   if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   const uint64_t E = t->num_classes, L = t->num_labels; if (E == 0) return SQ_OK;
-  { int rs = sq_eq_sync(c); if (rs) return rs; }
-  c->online->exp.valid = false;
-  sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins, d_slot;
-  if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L) || d_slot.ensure(E)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
-  hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice); hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice);
-  hipMemcpy(d_h1.p, t->h1, E * 8, hipMemcpyHostToDevice); hipMemcpy(d_h2.p, t->h2, E * 8, hipMemcpyHostToDevice); hipMemcpy(d_tid.p, t->tid, L * 4, hipMemcpyHostToDevice);
-  if (t->bins) hipMemcpy(d_bins.p, t->bins, L * 4, hipMemcpyHostToDevice);
-  EqView T = make_eq_view(c->online);
-  k_eq_merge_insert<<<nblk(E), TB, 0, c->stream>>>(T, E, d_off.p, d_tid.p, t->bins ? d_bins.p : nullptr, d_h1.p, d_h2.p, d_slot.p);
-  k_eq_merge_add<<<nblk(E), TB, 0, c->stream>>>(T, E, d_off.p, d_wq.p, d_cnt.p, d_slot.p);
-  SQ_HIP_CHECK(hipStreamSynchronize(c->stream));
-  d_off.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_tid.free_(); d_bins.free_(); d_slot.free_();
-  return check_eq_overflow(c);
+  sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins;
+  if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
+  SQ_HIP_CHECK(hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_h1.p, t->h1, E * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_h2.p, t->h2, E * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_tid.p, t->tid, L * 4, hipMemcpyHostToDevice));
+  if (t->bins) SQ_HIP_CHECK(hipMemcpy(d_bins.p, t->bins, L * 4, hipMemcpyHostToDevice));
+  sq_eq_table dt = *t; dt.off = d_off.p; dt.wq = d_wq.p; dt.count = d_cnt.p; dt.h1 = d_h1.p; dt.h2 = d_h2.p; dt.tid = d_tid.p; dt.bins = t->bins ? d_bins.p : nullptr; dt.w = nullptr;
+  int rc = sq_eq_merge_device(c, &dt);
+  d_off.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_tid.free_(); d_bins.free_();
+  return rc;
+}
+
+// the canonical-order export as DEVICE pointers (valid until the next accumulate / merge / reset of this ctx)
+extern "C" int sq_eq_export_device(sq_ctx* c, sq_eq_table* out) {
+  if (!c || !out) return SQ_ERR_ARG;
+  auto& X = c->online->exp;
+  if (!X.valid) { int rc = eq_export_run(c); if (rc) return rc; }
+  memset(out, 0, sizeof(*out)); out->num_classes = X.E; out->num_labels = X.L;
+  if (X.E) { out->off = X.d_off.p; out->tid = X.d_tid.p; out->w = X.d_w.p; out->wq = (uint64_t*)X.d_wq.p; out->count = (uint64_t*)X.d_cnt.p; out->bins = X.d_bins.p; out->h1 = (uint64_t*)X.d_h1.p; out->h2 = (uint64_t*)X.d_h2.p; }
+  return SQ_OK;
 }
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out) {

@@ -49,3 +49,39 @@ def reduce_model(log_mass, uniq, total, log_eff_len, dist, device):
     le = torch.from_numpy(np.ascontiguousarray(log_eff_len)).to(device)
     dist.broadcast(le, 0)
     return lm, uq, tc, le.cpu().numpy()
+
+
+class _DevArray:
+    """Zero-copy view of a device allocation for torch (torch.as_tensor honours __cuda_array_interface__)."""
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def merge_all_device(ctx, dist, device):
+    """The whole eq-class reduction without leaving HBM: every rank exposes its canonical-order export as torch views
+    of the library's device buffers, ONE padded all_gather per field (RCCL over xGMI) lands the other ranks' tables in
+    device tensors, and sq_eq_merge_device folds them in (integer counts / fixed-point sums: exact in any order)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ex = ctx.eq_export_device()
+    sizes = torch.tensor([ex["E"], ex["L"]], device=device, dtype=torch.int64)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    EL = [(int(s[0]), int(s[1])) for s in all_sizes]
+    gathered = {}
+    for f in FIELDS:
+        ptr, n, dt = ex[f]
+        is64 = np.dtype(dt).itemsize == 8
+        tdt = torch.int64 if is64 else torch.int32
+        mine = torch.as_tensor(_DevArray(ptr, n, "<i8" if is64 else "<i4"), device=device) if n else torch.zeros(0, device=device, dtype=tdt)
+        mx = max(1, max((e + 1 if f == "off" else (e if f in ("count", "h1", "h2") else l)) for e, l in EL))
+        pad = torch.zeros(mx, device=device, dtype=tdt); pad[: mine.numel()] = mine
+        outs = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad)
+        gathered[f] = outs
+    torch.cuda.synchronize(device)
+    for r in range(world):
+        if r == rank or EL[r][0] == 0:
+            continue
+        ctx.eq_merge_device(EL[r][0], EL[r][1], {f: gathered[f][r].data_ptr() for f in FIELDS})
+    return EL

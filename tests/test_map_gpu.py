@@ -205,3 +205,33 @@ def test_noisy_and_long_reads_match_checker(small_world, read_len, sub, indel):
     assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
     _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
     ctx.free()
+
+
+def test_device_resident_merge_matches_host_merge(small_world):
+    # multi-GPU reduction without host staging: export as device pointers (wrapped zero-copy by torch), copy as an
+    # all_gather would, merge with sq_eq_merge_device; must equal the host-table merge bit for bit
+    import torch
+    from salmon_amd.dist import _DevArray, FIELDS
+    w = small_world
+    opts = api.quant_opts(num_burnin_frags=10**9, num_pre_burnin_frags=10**9)
+    def run(lo, hi):
+        ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+        seq = w["seq"][lo * 200: hi * 200]; off = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        ctx.map_batch(api.make_read_batch(seq, off, hi - lo, paired=True), fetch=False); ctx.eq_accumulate()
+        return ctx
+    a, b, a2 = run(0, 2000), run(2000, 4000), run(0, 2000)
+    ex = b.eq_export_device(); dev = torch.device("cuda", 0)
+    recv = {}
+    for f in FIELDS:
+        ptr, n, dt = ex[f]; is64 = np.dtype(dt).itemsize == 8
+        view = torch.as_tensor(_DevArray(ptr, n, "<i8" if is64 else "<i4"), device=dev)
+        recv[f] = view.clone()                                   # stands in for the all_gather receive buffer
+    hb = b.eq_finish()
+    assert np.array_equal(recv["tid"].cpu().numpy().view(np.uint32), hb.tid) and np.array_equal(recv["h1"].cpu().numpy().view(np.uint64), hb.h1)
+    a.eq_merge_device(ex["E"], ex["L"], {f: recv[f].data_ptr() for f in FIELDS})
+    a2.eq_merge(hb)
+    m1, m2 = a.eq_finish(), a2.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(m1, f), getattr(m2, f)), f
+    for c in (a, b, a2):
+        c.free()
