@@ -210,11 +210,14 @@ def main():
         c3 = time.perf_counter()
         # the checker's EM loop is single-threaded (order-defined sums); its multi-threaded iteration (same arithmetic,
         # transcripts split over threads) is timed separately and used for the composite so the CPU gets its cores
-        em_thr_s = orc.em_time_iters(eqc, np.exp(lec), 20, ncores) / 20.0 * repc["iters"]
+        em_single_s = c3 - c2
+        em_try = {t: orc.em_time_iters(eqc, np.exp(lec), 20, t) / 20.0 * repc["iters"] for t in sorted({min(ncores, 8), min(ncores, 32), ncores})}
+        em_thr_n, em_thr_s = min(em_try.items(), key=lambda kv: kv[1])
+        if em_single_s < em_thr_s: em_thr_n, em_thr_s = 1, em_single_s       # the CPU side gets its best configuration
         em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
         t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
         cpu = {"value": round(S / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (%d threads; the single-threaded loop took %.2fs)" % (S, B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, c3 - c2),
+               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S, B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
                "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2)}
     out = {
         "metric": "M reads/s quantified (map+EM), 2x100bp vs human-shaped txome; EM iters/s", "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",

@@ -735,8 +735,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
-  uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
-  if (getenv("SQ_DBG_MB")) mb = (uint32_t)atoi(getenv("SQ_DBG_MB"));
+  const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
   std::vector<uint64_t> bound(nmb + 1);
   if (o->rh2.n < nmb + 2) { sq_set_error("internal: bounds scratch too small"); return SQ_ERR_STATE; }
