@@ -567,6 +567,7 @@ struct EqVal { uint64_t count = 0; std::vector<uint64_t> wq; };
 struct QuantState {
   const Index* ix; Opts op;
   FLD fld; std::vector<double> ambigCMF;  // LogCMFCache pre-burn-in table (DistributionUtils.cpp:104-118)
+  std::vector<double> liveCMF;            // FLD::cmf(len) before cacheCMF (FragmentLengthDistribution.cpp:143-158); read by single-end libraries only, whose histogram stays the prior
   std::vector<double> mass, priorMass, logEffLen; std::vector<uint64_t> uniq, total, massAcc;
   std::vector<double> fm;  // forgetting masses per mini-batch
   uint64_t numObserved = 0, numAssigned = 0, numMappedUB = 0, batchNo = 0; bool burnedIn = false;
@@ -578,6 +579,7 @@ struct QuantState {
     size_t M = ix->names.size();
     fld.init(o->fld_mean, o->fld_sd);
     ambigCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambigCMF[j] = cum; } }
+    liveCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, fld.hist[j]); liveCMF[j] = cum - fld.totMass; } }
     mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
     for (size_t t = 0; t < M; ++t) { double len = (double)ix->ref_len[t]; priorMass[t] = sq_log(0.005 * len); logEffLen[t] = sq_log(len); }  // Transcript.hpp:48-56, ReadExperiment.inl:114
     libCounts.assign(64, 0);
@@ -659,7 +661,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
         if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
         else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
         bool useFLD = singleEnd || burned;
-        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.ambigCMF[std::min<size_t>(len, 1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
+        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.liveCMF[std::min<size_t>(len, 1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
         double refCM = cmfv((size_t)tl); bool cm = !(refCM == SQ_LOG_0);
         logFragProb = cm ? (cmfv((size_t)maxFL) - refCM) : SQ_LOG_EPSILON;
       } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;

@@ -173,7 +173,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     double logFragProb = 0.0;
     if (p.flags & PF_ORPHAN_MODEL) {
       const bool useFLD = singleEnd || burned;
-      const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
+      const double* tab = useFLD ? (cached ? V.ccmf : V.ambig + 1024) : V.ambig;   // FLD::cmf live (uncached) / LogCMFCache table
       double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
       logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
     } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
@@ -271,7 +271,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             const uint32_t tt = aln[ai].tid; t[sl] = tt;
             double logFragProb = 0.0;
             if (p.flags & PF_ORPHAN_MODEL) {
-              const bool useFLD = singleEnd || burned; const double* tab = (useFLD && cached) ? V.ccmf : V.ambig;
+              const bool useFLD = singleEnd || burned; const double* tab = useFLD ? (cached ? V.ccmf : V.ambig + 1024) : V.ambig;   // FLD::cmf live (uncached) / LogCMFCache table
               double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
               logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
             } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
@@ -585,22 +585,26 @@ int sq_online_create(sq_ctx* c) {
   const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
-  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(1024) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
+  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
              o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) || o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
              o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) || o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
   const sq_quant_opts& q = c->opts;
-  std::vector<double> hist(1024, SQ_LOG_0), ambig(1024, 0.0), pm(M), le(M), mass(M, SQ_LOG_0);
+  std::vector<double> hist(1024, SQ_LOG_0), ambig(2048, 0.0), pm(M), le(M), mass(M, SQ_LOG_0); double tot0 = 0.0;
   for (int i = 0; i <= 1000; ++i) {  // FragmentLengthDistribution.cpp:38-55 (alpha = 1)
     double nm = phi((i + 0.5 - q.fld_mean) / q.fld_sd) - phi((i - 0.5 - q.fld_mean) / q.fld_sd);
     hist[i] = (nm != 0) ? sq_log(nm) : SQ_LOG_EPSILON;
   }
   { std::vector<double> v(1024, SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
-    double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
+    tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
   { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambig[j] = cum; } }  // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
+  // ambig[1024..]: FragmentLengthDistribution::cmf(len) before cacheCMF (:143-158) — the sequential log-sum prefix of the
+  // histogram minus its total mass.  Only single-end libraries read it (useFLD before burn-in), and they never add
+  // fragment lengths to the histogram, so the prior's table is the live one.
+  { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, hist[j]); ambig[1024 + j] = cum - tot0; } }
   for (uint32_t t = 0; t < M; ++t) { double len = (double)c->idx->ref_len[t]; pm[t] = sq_log(0.005 * len); le[t] = sq_log(len); }  // Transcript.hpp:48-56; alpha = 0.005 (ReadExperiment.inl:114)
-  SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 1024 * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior

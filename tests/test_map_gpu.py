@@ -101,6 +101,30 @@ def test_single_end(small_world):
     ctx.free()
 
 
+@pytest.mark.parametrize("lt", ["U", "SF"])
+def test_single_end_online_model_and_eq_classes(small_world, lt):
+    # single-end libraries take the ambiguous-fragment-length branch (LogCMFCache::getAmbigFragLengthProb with the live,
+    # uncached FLD::cmf before burn-in and the cached one after): model, eq-classes and weights must match the checker
+    w = small_world
+    opts = api.set_libtype(api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=2500), lt)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ost = orc.OrcState(w["oidx"], opts)
+    for lo, hi in [(0, 2200), (2200, 6000)]:
+        seq = w["seq"][lo * 100: hi * 100]; off = (w["off"][lo: hi + 1] - w["off"][lo]).copy()
+        rb = api.make_read_batch(seq, off, hi - lo, paired=False)
+        ctx.map_batch(rb, fetch=False); ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+        ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+    ost.finish()
+    assert ctx.summary() == ost.summary() and ctx.summary()["burned_in"]
+    for a, b in zip(ctx.model(), ost.model()[:4]):
+        assert np.array_equal(a, b)
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    ctx.free(); ost.free()
+
+
 def test_online_model_and_eq_classes_match_checker(small_world):
     w = small_world
     # small burn-in so the test crosses pre-burn-in -> aux params -> burned-in regimes
