@@ -8,6 +8,7 @@ for f in files:
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]; n = n.replace("(anonymous namespace)::", "").replace("sqk::", "")
         n = n[: n.index("(")] if "(" in n else n
+        n = n.replace("void ", "").split("<")[0].strip()
         a = agg[n][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {}
 for k, cs in agg.items():
