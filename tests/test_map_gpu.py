@@ -1,7 +1,7 @@
 """GPU mapping pipeline vs the CPU checker, stage by stage and end to end (bit-exact; -m gpu)."""
 import numpy as np
 import pytest
-from salmon_amd import api, capi
+from salmon_amd import api, capi, synth
 import orc
 
 pytestmark = pytest.mark.gpu
@@ -259,3 +259,44 @@ def test_device_resident_merge_matches_host_merge(small_world):
         assert np.array_equal(getattr(m1, f), getattr(m2, f)), f
     for c in (a, b, a2):
         c.free()
+
+
+def test_decoy_aware_mapping_matches_checker(built):
+    # decoys (SalmonMappingUtils.hpp:82-151,407-485): sequences listed after the targets; a fragment whose best hit is a decoy is
+    # counted as a decoy fragment and target hits below decoyThreshold x bestDecoy are dropped.  Decoys here embed mutated
+    # copies of transcripts between random flanks, so reads drawn from a decoy hit both the decoy and the transcript.
+    rng = np.random.default_rng(5)
+    tx = synth.Txome(seed=13, n_genes=40, iso_per_gene=3, threads=2)
+    names = list(tx.names()); seqs = [s.decode() for s in tx.seqs()]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    def mutate(s, rate): return "".join((rng.choice([c for c in "ACGT" if c != ch]) if rng.random() < rate else ch) for ch in s)
+    decoys = [rnd(400) + mutate(seqs[j], 0.01) + rnd(400) for j in rng.choice(len(seqs), 12, replace=False)]
+    first_decoy = len(seqs)
+    idx = api.SalmonIndex.build_mem(names + ["decoy%d" % i for i in range(len(decoys))], seqs + decoys, threads=2, first_decoy=first_decoy, keep_duplicates=True)
+    oidx = orc.OrcIndex(idx)
+    recs = []
+    def pair(s):
+        fl = int(rng.integers(180, 320)); p = int(rng.integers(0, len(s) - fl))
+        r1 = s[p:p + 100]; r2 = "".join(comp[c] for c in reversed(s[p + fl - 100:p + fl]))
+        return (r1, r2) if rng.random() < 0.5 else (r2, r1)
+    for _ in range(1500): recs += pair(decoys[int(rng.integers(len(decoys)))])        # decoy-derived fragments
+    for _ in range(1500): recs += pair(seqs[int(rng.integers(len(seqs)))])            # transcript-derived fragments
+    seq = np.frombuffer("".join(recs).encode(), np.uint8).copy(); off = np.arange(0, len(recs) + 1, dtype=np.uint64) * np.uint64(100)
+    n = len(recs) // 2
+    opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=1800)
+    ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=4096)
+    rb = api.make_read_batch(seq, off, n, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(oidx, opts, rb, threads=4)
+    assert st_g == st_c and st_g["num_decoy_fragments"] > 200
+    assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    assert np.all(aln_g["tid"] < first_decoy)            # decoys never reach the alignment lists
+    ctx.eq_accumulate()
+    ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    assert ctx.summary() == ost.summary()
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    ctx.free(); ost.free()
