@@ -300,3 +300,42 @@ def test_decoy_aware_mapping_matches_checker(built):
     for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
         assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
     ctx.free(); ost.free()
+
+
+OPTION_VARIANTS = [
+    dict(hard_filter=1), dict(allow_dovetail=1), dict(allow_orphans=0), dict(disable_chaining_heuristic=1),
+    dict(range_factorization_bins=0), dict(range_factorization_bins=8), dict(consensus_slack=0.1, min_score_fraction=0.8),
+    dict(mismatch_seed_skip=5, max_occs_per_hit=20), dict(match_score=1, mismatch_penalty=-3, gap_open=4, gap_extend=1, bandwidth=8),
+    dict(score_exp=2.0, min_aln_prob=1e-3, decoy_threshold=0.9), dict(no_length_correction=1), dict(no_eff_length_correction=1),
+    dict(use_frag_len_dist=0), dict(model_single_frag_prob=0), dict(ignore_incompat=0, incompat_prior=-20.0, _lib="ISF"),
+    dict(pre_merge_chain_sub_thresh=0.9, post_merge_chain_sub_thresh=0.95, orphan_chain_sub_thresh=0.5), dict(frag_len_max=400, fld_mean=200.0, fld_sd=40.0),
+    dict(forgetting_factor=0.8, seed=12345),
+]
+
+
+@pytest.mark.parametrize("variant", OPTION_VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
+def test_option_variants_match_checker(small_world, variant):
+    # every mapping / model option the C ABI exposes (the SalmonOpts fields initMapperSettings and processMiniBatch read),
+    # away from its default: alignments, counters, online model and eq-classes must still equal the checker's
+    w = small_world
+    kw = {k: v for k, v in variant.items() if not k.startswith("_")}
+    opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=1500, **kw)
+    if "_lib" in variant: api.set_libtype(opts, variant["_lib"])
+    N = 2500
+    seq, off, _, _ = w["tx"].reads(N, read_len=100, seed=909, sub_rate=0.015, indel_rate=0.002, threads=4)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    rb = api.make_read_batch(seq, off, N, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+    assert st_g == st_c
+    assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.eq_accumulate()
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    assert ctx.summary() == ost.summary()
+    for a, b in zip(ctx.model(), ost.model()[:4]):
+        assert np.array_equal(a, b)
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    ctx.free(); ost.free()
