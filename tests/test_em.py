@@ -117,3 +117,19 @@ def test_gpu_em_giant_class_and_hot_transcript(built, vb):
     want = orc.em_steps(eq, eff, a0, 5, o)
     got, _ = api.em_steps(eq, eff, a0, 5, o)
     assert np.array_equal(got, want), float(np.max(np.abs(got - want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(no_rich_eq_classes=1), dict(per_transcript_prior=0, vb_prior=1e-5), dict(vb_prior=1.0), dict(use_vbem=0, no_rich_eq_classes=1),
+                                dict(rel_diff_tolerance=0.001, max_iter=300), dict(min_iter=10, max_iter=40), dict(num_required_fragments=1000.0)],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_gpu_em_option_variants_bit_exact(built, kw):
+    M, E = 2000, 15000
+    eq = random_eq_classes(M, E, seed=31)
+    eff = np.random.default_rng(8).uniform(50, 5000, M)
+    proj = np.random.default_rng(9).uniform(0, 30, M)
+    o = api.em_opts(**kw)
+    want, wrep = orc.em_optimize(eq, eff, proj, o)
+    got, grep = api.em_optimize(eq, eff, proj, o)
+    assert grep["iters"] == wrep["iters"] and grep["converged"] == wrep["converged"]
+    assert np.array_equal(got, want)
