@@ -103,19 +103,20 @@ __device__ inline void label_hash_step(uint64_t& a, uint64_t& b, uint32_t x) {
 // logFragCov, the paired-end start-position term, log(RefLength), the fragment lengths and the
 // compatibility verdict.  Everything a mini-batch still has to evaluate per alignment is then a
 // table lookup (FLD pmf/cmf, cached transcript log-mass) plus the in-order log-sum chains.
-struct PreAln { double c_cov; double c_start; uint32_t flen; uint16_t fl_ped, max_fl; uint16_t tl; uint8_t flags, fmt; uint32_t pad; };  // 32 B
-enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16 };
+struct PreAln { double c_cov; double c_start; uint32_t flen; uint16_t fl_ped, max_fl; uint16_t tl; uint8_t flags, fmt; uint32_t tid; };  // 32 B: everything about an alignment that does not depend on the evolving model
+enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16, PF_FLEN_IN_REF = 32 /* flen < refLength (refLength = max(RefLength, 1)) */ };
 
 __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ ref_clen, sq_quant_opts o, PreAln* __restrict__ pre) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
   const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
-  PreAln p; p.flags = 0; p.fmt = a.format_id; p.pad = 0;
+  PreAln p; p.flags = 0; p.fmt = a.format_id; p.tid = a.tid;
   const double refLength = rl > 0 ? (double)rl : 1.0;
   p.c_cov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
   uint32_t ped = frag_len_pedantic(a, rl);
   uint32_t flen = a.frag_len; if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && a.fwd != a.mate_fwd) flen = ped;
   p.flen = flen; p.fl_ped = (uint16_t)(ped > 1000 ? 1000 : ped);
+  if (flen < rl || (rl == 0 && flen < 1)) p.flags |= PF_FLEN_IN_REF;
   const bool isCompat = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
   if (isCompat) p.flags |= PF_COMPAT;
   if (isCompat || !o.ignore_incompat) p.flags |= PF_KEEP;
@@ -268,7 +269,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
           const uint64_t ai = a0 + idx;
           const PreAln p = pre[ai]; fl_ped[sl] = p.fl_ped;
           if (p.flags & PF_KEEP) {
-            const uint32_t tt = aln[ai].tid; t[sl] = tt;
+            const uint32_t tt = p.tid; t[sl] = tt;
             double logFragProb = 0.0;
             if (p.flags & PF_ORPHAN_MODEL) {
               const bool useFLD = singleEnd || burned; const double* tab = useFLD ? (cached ? V.ccmf : V.ambig + 1024) : V.ambig;   // FLD::cmf live (uncached) / LogCMFCache table
@@ -278,7 +279,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             if (p.flen > 0 && o.use_frag_len_dist && cond) {
               const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
               const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
-              if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[tt] || (V.ref_len[tt] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+              if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flags & PF_FLEN_IN_REF) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
               else if (useAux) logFragProb = lenProb;
             }
             const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
