@@ -100,11 +100,24 @@ def build_tools():
     return os.path.join(ROOT, "tools", "_build", "libsqsynth.so")
 
 
+def build_microbench():
+    """tools/*.hip: stand-alone gfx950 microbenchmarks quoted in DESIGN.md (random-sector gather ceiling, grid-barrier cost)."""
+    out = os.path.join(ROOT, "tools", "_build"); os.makedirs(out, exist_ok=True)
+    for name in ("gather_bench", "gridbar_bench"):
+        src = os.path.join(ROOT, "tools", name + ".hip"); exe = os.path.join(out, name)
+        if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+            continue
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-Wno-unused-result", src, "-o", exe], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+
+
 def build_all():
     build_product()
     build_cli()
     build_oracle()
     build_tools()
+    build_microbench()
 
 
 if __name__ == "__main__":
