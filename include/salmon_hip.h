@@ -330,6 +330,9 @@ int sq_normalize_alphas(uint32_t num_txp, const sq_eq_table* eq, const double* l
 int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags);
 int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights);
 
+/* aux_info/ambig_info.tsv (GZipWriter.cpp:601-638): UniqueCount / AmbigCount per transcript from the eq-classes. */
+int sq_write_ambig_info(const char* path, uint32_t m, const sq_eq_table* eq);
+
 /* quant.sf from plain name / length arrays (`salmon quant -e` has no index; lens may be NULL). */
 int sq_write_quant_sf_names(const char* path, uint32_t m, const char* const* names, const uint32_t* lens,
                             const double* eff_len, const double* num_reads, double num_mapped_frags);

@@ -371,6 +371,11 @@ def write_eq_classes(path, index, eq, with_weights=False):
     check(lib().sq_write_eq_classes(path.encode(), index.h, C.byref(t), int(with_weights)), "sq_write_eq_classes")
 
 
+def write_ambig_info(path, M, eq):
+    t = eq.table()
+    check(lib().sq_write_ambig_info(path.encode(), M, C.byref(t)), "sq_write_ambig_info")
+
+
 def read_eq_classes(path):
     """salmon::utils::readEquivCounts: (names, eff_lens, EqClasses) from an eq_classes.txt[.gz] written with weights."""
     h = C.c_void_p()

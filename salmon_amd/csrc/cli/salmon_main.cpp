@@ -177,6 +177,7 @@ static int cmd_quant(int argc, char** argv) {
     run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned);
   }
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
+  if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");

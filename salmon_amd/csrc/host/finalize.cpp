@@ -210,3 +210,20 @@ extern "C" int sq_boot_writer_append(sq_boot_writer* w, const double* alphas, ui
   return SQ_OK;
 }
 extern "C" uint64_t sq_boot_writer_close(sq_boot_writer* w) { if (!w) return 0; uint64_t n = w->written; if (w->g) gzclose(w->g); delete w; return n; }
+
+// aux_info/ambig_info.tsv (GZipWriter.cpp:601-638): per transcript, fragments in single-transcript classes and the
+// count mass of the multi-transcript classes it belongs to (uint32 accumulators, as in the reference)
+extern "C" int sq_write_ambig_info(const char* path, uint32_t M, const sq_eq_table* eq) {
+  if (!path || !eq || (eq->num_classes && (!eq->off || !eq->tid || !eq->count))) { sq_set_error("sq_write_ambig_info: bad arguments"); return SQ_ERR_ARG; }
+  std::vector<uint32_t> uniq(M, 0), amb(M, 0);
+  for (uint64_t c = 0; c < eq->num_classes; ++c) {
+    const uint64_t a = eq->off[c], b = eq->off[c + 1];
+    if (b - a > 1) { for (uint64_t i = a; i < b; ++i) if (eq->tid[i] < M) amb[eq->tid[i]] += (uint32_t)eq->count[c]; }
+    else if (b - a == 1 && eq->tid[a] < M) uniq[eq->tid[a]] += (uint32_t)eq->count[c];
+  }
+  FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  fprintf(f, "UniqueCount\tAmbigCount\n");
+  for (uint32_t i = 0; i < M; ++i) fprintf(f, "%u\t%u\n", uniq[i], amb[i]);
+  fclose(f);
+  return SQ_OK;
+}

@@ -74,6 +74,16 @@ def test_eq_class_file_round_trip_and_bootstrap_writer(built, tmp_path):
         f.write("%s\t123.5\n" % rnames[2])
     _, eff2, _ = api.read_eq_classes(p)
     assert eff2[2] == 123.5 and eff2[0] == 100.0
+    # ambig_info.tsv: unique = counts of single-transcript classes, ambiguous = counts of the multi-transcript classes a transcript is in
+    api.write_ambig_info(str(tmp_path / "ambig_info.tsv"), M, eq)
+    lines = open(tmp_path / "ambig_info.tsv").read().splitlines()
+    assert lines[0] == "UniqueCount\tAmbigCount" and len(lines) == M + 1
+    uq = np.zeros(M, np.int64); am = np.zeros(M, np.int64)
+    for c in range(len(eq.count)):
+        ts = eq.tid[int(eq.off[c]):int(eq.off[c + 1])]
+        if len(ts) == 1: uq[ts[0]] += int(eq.count[c])
+        else: am[ts] += int(eq.count[c])
+    assert [tuple(map(int, l.split("\t"))) for l in lines[1:]] == list(zip(uq.tolist(), am.tolist()))
     rows = np.random.default_rng(1).uniform(0, 50, (3, M))
     assert api.write_bootstraps(str(tmp_path / "aux_info"), rnames, rows) == 3
     raw = gzip.open(tmp_path / "aux_info" / "bootstrap" / "bootstraps.gz").read()
