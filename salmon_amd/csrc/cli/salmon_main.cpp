@@ -178,6 +178,10 @@ static int cmd_quant(int argc, char** argv) {
   }
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
+  { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
+    std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
+    mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
+    if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
