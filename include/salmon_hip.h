@@ -263,6 +263,7 @@ int sq_eq_merge_device(sq_ctx*, const sq_eq_table* t);
 typedef struct {          /* online-model state needed downstream (Transcript, FLD, counters) */
   uint64_t num_observed, num_assigned, num_mapped_ub;
   int burned_in;
+  uint64_t num_compatible;   /* assigned fragments with at least one library-compatible alignment (SalmonQuantify.cpp:811-815) */
 } sq_model_summary;
 int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
 /* per-transcript state after the online phase: log-mass (LOG_0 = +inf when none), unique/total
@@ -270,6 +271,12 @@ int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
 int sq_model_fetch(sq_ctx*, double* log_mass, uint64_t* unique_count, uint64_t* total_count,
                    double* log_eff_len);
 int sq_model_fetch_fld(sq_ctx*, double* log_pmf_1001); /* log PMF bins 0..1000 (flenDist) */
+/* fragments per observed library format id (type | orientation << 1 | strandedness << 3), 64 slots
+ * (ReadLibrary::libTypeCounts, SalmonQuantify.cpp:1000-1021). */
+int sq_model_fetch_lib_counts(sq_ctx*, uint64_t* counts64);
+/* lib_format_counts.json (ReadExperiment::summarizeLibraryTypeCounts, ReadExperiment.inl:219-348). */
+int sq_write_lib_format_counts(const char* path, const char* read_files, uint8_t lib_type, uint8_t lib_orientation, uint8_t lib_strand,
+                               const uint64_t* counts64, uint64_t num_assigned, uint64_t num_compatible);
 
 /* ------------------------------------------------------------------------------------------------
  * B3  inference — replaces CollapsedEMOptimizer::optimize (src/inference/CollapsedEMOptimizer.cpp:

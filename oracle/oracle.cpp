@@ -570,7 +570,7 @@ struct QuantState {
   std::vector<double> liveCMF;            // FLD::cmf(len) before cacheCMF (FragmentLengthDistribution.cpp:143-158); read by single-end libraries only, whose histogram stays the prior
   std::vector<double> mass, priorMass, logEffLen; std::vector<uint64_t> uniq, total, massAcc;
   std::vector<double> fm;  // forgetting masses per mini-batch
-  uint64_t numObserved = 0, numAssigned = 0, numMappedUB = 0, batchNo = 0; bool burnedIn = false;
+  uint64_t numObserved = 0, numAssigned = 0, numMappedUB = 0, batchNo = 0, numCompat = 0; bool burnedIn = false;
   std::map<std::vector<uint32_t>, EqVal> eq;  // label (tids + bins) -> value
   std::vector<uint64_t> libCounts;
   uint64_t readCounter = 0;
@@ -644,7 +644,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
     const bool useAux = (assigned0 + local) >= o.num_pre_burnin_frags;
     const bool cond = burned || useAux;
     aux.clear(); lp.clear(); tids.clear(); ka.clear();
-    double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint64_t fmtSeen = 0;
+    double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint64_t fmtSeen = 0; bool hasCompat = false;
     for (uint64_t ai = a0; ai < a1; ++ai) {
       const sq_aln& a = alns[ai]; uint32_t t = a.tid;
       double refLength = ix.ref_len[t] > 0 ? (double)ix.ref_len[t] : 1.0;
@@ -674,6 +674,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       bool isCompat = is_compatible(obs, expf, a.fwd, a.mate_status);
       double logCompat = isCompat ? 0.0 : o.incompat_prior;
       if (!isCompat && o.ignore_incompat) continue;
+      if (isCompat) hasCompat = true;                       // hasCompatibleMapping (:767-769)
       double startPosProb = -logRefLength;
       if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction)
         startPosProb = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
@@ -686,7 +687,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       auxDenom = sq_log_add(auxDenom, auxProb);
     }
     if (sumProbs == SQ_LOG_0) continue;
-    ++local;
+    ++local; if (hasCompat) ++S.numCompat;                 // numCompatibleFragments (:811-815)
     const size_t n = tids.size();
     for (size_t i = 0; i < n; ++i) aux[i] = sq_exp(aux[i] - auxDenom);
     std::vector<uint32_t> label(tids);
@@ -1050,7 +1051,8 @@ void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const
 }
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
 void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }
-void orc_state_summary(orc_state* s, sq_model_summary* m) { m->num_observed = s->S.numObserved; m->num_assigned = s->S.numAssigned; m->num_mapped_ub = s->S.numMappedUB; m->burned_in = s->S.burnedIn; }
+void orc_state_summary(orc_state* s, sq_model_summary* m) { m->num_observed = s->S.numObserved; m->num_assigned = s->S.numAssigned; m->num_mapped_ub = s->S.numMappedUB; m->burned_in = s->S.burnedIn; m->num_compatible = s->S.numCompat; }
+void orc_state_lib_counts(orc_state* s, uint64_t* out64) { for (int i = 0; i < 64; ++i) out64[i] = s->S.libCounts[i]; }
 void orc_state_fetch(orc_state* s, double* log_mass, uint64_t* uniq, uint64_t* total, double* log_eff_len, double* fld_logpmf) {
   QuantState& S = s->S; size_t M = S.mass.size();
   for (size_t t = 0; t < M; ++t) { if (log_mass) log_mass[t] = S.mass[t]; if (uniq) uniq[t] = S.uniq[t]; if (total) total[t] = S.total[t]; if (log_eff_len) log_eff_len[t] = S.logEffLen[t]; }

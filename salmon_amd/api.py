@@ -300,7 +300,12 @@ class QuantContext:
     def summary(self):
         s = capi.ModelSummary()
         check(lib().sq_model_summary_get(self.h, C.byref(s)), "sq_model_summary_get")
-        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in))
+        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+
+    def lib_counts(self):
+        out = np.zeros(64, np.uint64)
+        check(lib().sq_model_fetch_lib_counts(self.h, _ptr(out, C.c_uint64)), "sq_model_fetch_lib_counts")
+        return out
 
     def model(self):
         M = self.index.num_refs

@@ -178,6 +178,9 @@ static int cmd_quant(int argc, char** argv) {
   }
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
+  { uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
+    const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
+    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand, lc, ms.num_assigned, ms.num_compatible)) die("lib_format_counts"); }
   { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
     std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");

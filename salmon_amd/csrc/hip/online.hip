@@ -25,7 +25,7 @@ struct sq_online_dev {
   // model
   sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
   sq_dbuf<uint32_t> touched, touched_n;   // transcripts whose mass changed in the current mini-batch: two lists (mini-batch parity), [2*M] + [2]
-  sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize
+  sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
   // per big batch
   sq_dbuf<uint8_t> has_compat; struct PreAln; sq_dbuf<uint8_t> pre; sq_dbuf<double> alp; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
   // eq table
@@ -153,7 +153,7 @@ __device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, u
 
 __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par) {
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   rh1[r] = EQ_EMPTY; rh2[r] = 0;
@@ -165,11 +165,12 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
   const bool singleEnd = (o.lib_type == 0);
   const double totMass = V.scal[0];
   // pass 1: auxProb / logProb per kept alignment and their in-order log-sums
-  double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtSeen = 0;
+  double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtSeen = 0; bool hasCompat = false;
   for (uint64_t ai = a0; ai < a1; ++ai) {
     const PreAln p = pre[ai];
     abin[ai] = 0xFFFFFFFFu;
     if (!(p.flags & PF_KEEP)) continue;
+    if (p.flags & PF_COMPAT) hasCompat = true;                      // hasCompatibleMapping (SalmonQuantify.cpp:767-769)
     const uint32_t t = aln[ai].tid;
     double logFragProb = 0.0;
     if (p.flags & PF_ORPHAN_MODEL) {
@@ -198,6 +199,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     ++nk;
   }
   if (nk == 0 || sumProbs == SQ_LOG_0) { for (uint64_t ai = a0; ai < a1; ++ai) abin[ai] = 0xFFFFFFFFu; return; }
+  *compat_out = hasCompat ? 1 : 0;
   // pass 2: normalise, range-factorization bins, label hash, model increments
   const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
   const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
@@ -246,12 +248,12 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
                              unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint32_t par) {
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
-  uint64_t fmtSeen = 0;
+  uint64_t fmtSeen = 0; int compatFrag = 0;   // this lane reports an assigned fragment that has a compatible alignment
   const bool valid = r < r1;
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
   if (valid && nA > MB_G * MB_S) {
-    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par);
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par, &compatFrag);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
     if (nA > 0) {
@@ -260,15 +262,16 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       const bool cond = burned || useAux; const bool singleEnd = (o.lib_type == 0);
       const double totMass = V.scal[0];
       // phase 1: lane j -> alignments a0 + j and a0 + j + 8
-      bool keep[MB_S]; double auxProb[MB_S], logProb[MB_S]; uint32_t t[MB_S]; uint32_t fl_ped[MB_S]; uint64_t fmtBit[MB_S];
+      bool keep[MB_S]; double auxProb[MB_S], logProb[MB_S]; uint32_t t[MB_S]; uint32_t fl_ped[MB_S]; uint64_t fmtBit[MB_S]; bool compat[MB_S];
 #pragma unroll
       for (int sl = 0; sl < MB_S; ++sl) {
-        keep[sl] = false; auxProb[sl] = 0.0; logProb[sl] = 0.0; t[sl] = 0; fl_ped[sl] = 0; fmtBit[sl] = 0;
+        keep[sl] = false; auxProb[sl] = 0.0; logProb[sl] = 0.0; t[sl] = 0; fl_ped[sl] = 0; fmtBit[sl] = 0; compat[sl] = false;
         const uint32_t idx = j + MB_G * sl;
         if (idx < nA) {
           const uint64_t ai = a0 + idx;
           const PreAln p = pre[ai]; fl_ped[sl] = p.fl_ped;
           if (p.flags & PF_KEEP) {
+            compat[sl] = (p.flags & PF_COMPAT) != 0;
             const uint32_t tt = p.tid; t[sl] = tt;
             double logFragProb = 0.0;
             if (p.flags & PF_ORPHAN_MODEL) {
@@ -353,11 +356,14 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
         }
       }
       fmtSeen = (j == 0 && assigned) ? fmtAll : 0;
+      { const unsigned long long cb = __ballot(compat[0]) | __ballot(compat[1]);      // group-uniform code
+        compatFrag = (j == 0 && assigned && ((cb >> gsh) & ((1u << MB_G) - 1))) ? 1 : 0; }
     }
   }
   // library-format counts: one atomic per (wave, format)
   uint64_t any = fmtSeen; for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s, 64);
   while (any) { int f = __ffsll((long long)any) - 1; any &= any - 1; unsigned long long m = __ballot((fmtSeen >> f) & 1); if ((threadIdx.x & 63) == 0) atomicAdd(&V.lib_counts[f], (unsigned long long)__popcll(m)); }
+  { const unsigned long long m = __ballot(compatFrag); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&V.ctr[5], (unsigned long long)__popcll(m)); }   // numCompatibleFragments (:811-815)
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -794,7 +800,7 @@ extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
-  out->num_observed = c->online->num_observed; out->num_assigned = hctr[0]; out->num_mapped_ub = c->online->num_mapped_ub; out->burned_in = hctr[1] != 0;
+  out->num_observed = c->online->num_observed; out->num_assigned = hctr[0]; out->num_mapped_ub = c->online->num_mapped_ub; out->burned_in = hctr[1] != 0; out->num_compatible = hctr[5];
   return SQ_OK;
 }
 
@@ -826,6 +832,14 @@ extern "C" int sq_model_fetch(sq_ctx* c, double* log_mass, uint64_t* unique_coun
   if (unique_count) SQ_HIP_CHECK(hipMemcpy(unique_count, o->uniq.p, M * 8, hipMemcpyDeviceToHost));
   if (total_count) SQ_HIP_CHECK(hipMemcpy(total_count, o->total.p, M * 8, hipMemcpyDeviceToHost));
   if (log_eff_len) SQ_HIP_CHECK(hipMemcpy(log_eff_len, o->log_eff_len.p, M * 8, hipMemcpyDeviceToHost));
+  return SQ_OK;
+}
+
+extern "C" int sq_model_fetch_lib_counts(sq_ctx* c, uint64_t* out64) {
+  if (!c || !out64) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  SQ_HIP_CHECK(hipMemcpy(out64, c->online->lib_counts.p, 64 * 8, hipMemcpyDeviceToHost));
   return SQ_OK;
 }
 

@@ -227,3 +227,42 @@ extern "C" int sq_write_ambig_info(const char* path, uint32_t M, const sq_eq_tab
   fclose(f);
   return SQ_OK;
 }
+
+// lib_format_counts.json (ReadExperiment::summarizeLibraryTypeCounts, reference
+// include/salmon/internal/quant/ReadExperiment.inl:219-348).  Format id = type | orientation << 1 | strandedness << 3
+// with type {0 single, 1 paired}, orientation {0 same, 1 away, 2 toward, 3 none}, strandedness {0 SA, 1 AS, 2 S, 3 A, 4 U}.
+static std::string lib_format_name(uint32_t id) {   // the salmon library-type string, empty for combinations LibraryFormat::check() rejects
+  const uint32_t type = id & 1, orient = (id >> 1) & 3, strand = id >> 3;
+  if (strand > 4) return "";
+  if (type == 0) { if (orient != 3) return ""; return strand == 2 ? "SF" : strand == 3 ? "SR" : strand == 4 ? "U" : ""; }
+  if (orient == 3) return "";
+  const char* o = orient == 0 ? "M" : orient == 1 ? "O" : "I";
+  if (orient == 0) { if (strand == 2) return std::string(o) + "SF"; if (strand == 3) return std::string(o) + "SR"; if (strand == 4) return std::string(o) + "U"; return ""; }
+  if (strand == 0) return std::string(o) + "SF"; if (strand == 1) return std::string(o) + "SR"; if (strand == 4) return std::string(o) + "U";
+  return "";
+}
+extern "C" int sq_write_lib_format_counts(const char* path, const char* read_files, uint8_t lib_type, uint8_t lib_orientation, uint8_t lib_strand,
+                                          const uint64_t* counts, uint64_t num_assigned, uint64_t num_compatible) {
+  if (!path || !counts) { sq_set_error("sq_write_lib_format_counts: bad arguments"); return SQ_ERR_ARG; }
+  const uint32_t fid = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | ((uint32_t)lib_strand << 3);
+  // the two stranded variants of the expected orientation (:247-262)
+  const uint32_t s1 = (lib_orientation == 0 || lib_orientation == 3) ? 2u : 0u, s2 = (lib_orientation == 0 || lib_orientation == 3) ? 3u : 1u;
+  const uint32_t f1 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s1 << 3), f2 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s2 << 3);
+  uint64_t nAgree = 0, nDisStranded = 0, nF1 = 0, nF2 = 0, nDisUnstranded = 0;
+  for (uint32_t i = 0; i < 64; ++i) {
+    if (i == fid) nAgree = counts[i]; else nDisStranded += counts[i];
+    if (i == f1) nF1 = counts[i]; else if (i == f2) nF2 = counts[i]; else nDisUnstranded += counts[i];
+  }
+  uint64_t nDisagree; double ratio;
+  if (lib_strand == 4) { nAgree = nF1 + nF2; nDisagree = nDisUnstranded; ratio = nAgree > 0 ? (double)nF1 / (double)(nF1 + nF2) : 0.0; }
+  else { nDisagree = nDisStranded; ratio = nAgree > 0 ? (double)nF1 / (double)(nF1 + nF2) : 0.0; }
+  FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  fprintf(f, "{\n    \"read_files\": \"%s\",\n    \"expected_format\": \"%s\",\n    \"compatible_fragment_ratio\": %.17g,\n    \"num_compatible_fragments\": %llu,\n    \"num_assigned_fragments\": %llu,\n"
+             "    \"num_frags_with_concordant_consistent_mappings\": %llu,\n    \"num_frags_with_inconsistent_or_orphan_mappings\": %llu,\n    \"strand_mapping_bias\": %.17g",
+          read_files ? read_files : "", lib_format_name(fid).c_str(), num_assigned ? (double)num_compatible / (double)num_assigned : 0.0,
+          (unsigned long long)num_compatible, (unsigned long long)num_assigned, (unsigned long long)nAgree, (unsigned long long)nDisagree, ratio);
+  for (uint32_t i = 0; i < 64; ++i) { const std::string d = lib_format_name(i); if (!d.empty()) fprintf(f, ",\n    \"%s\": %llu", d.c_str(), (unsigned long long)counts[i]); }
+  fprintf(f, "\n}\n");
+  fclose(f);
+  return SQ_OK;
+}

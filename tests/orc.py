@@ -34,6 +34,7 @@ def lib():
         L.orc_eq_accumulate.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64]
         L.orc_state_finish.argtypes = [vp]
         L.orc_state_summary.argtypes = [vp, P(capi.ModelSummary)]
+        L.orc_state_lib_counts.argtypes = [vp, vp]
         L.orc_state_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orc_eq_finish.argtypes = [vp, P(capi.EqTable)]
         L.orc_normalize_alphas.argtypes = [C.c_uint32, P(capi.EqTable), vp, vp, vp, vp]
@@ -114,7 +115,10 @@ class OrcState:
 
     def summary(self):
         s = capi.ModelSummary(); lib().orc_state_summary(self.h, C.byref(s))
-        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in))
+        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+
+    def lib_counts(self):
+        out = np.zeros(64, np.uint64); lib().orc_state_lib_counts(self.h, out.ctypes.data); return out
 
     def model(self):
         M = self.M

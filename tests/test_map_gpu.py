@@ -333,6 +333,7 @@ def test_option_variants_match_checker(small_world, variant):
     ctx.eq_accumulate()
     ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
     assert ctx.summary() == ost.summary()
+    assert np.array_equal(ctx.lib_counts(), ost.lib_counts())      # fragments per observed library format
     for a, b in zip(ctx.model(), ost.model()[:4]):
         assert np.array_equal(a, b)
     eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
