@@ -340,3 +340,23 @@ def test_option_variants_match_checker(small_world, variant):
     for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
         assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
     ctx.free(); ost.free()
+
+
+def test_limits_capacity_and_long_reads(small_world):
+    w = small_world
+    opts = api.quant_opts()
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=512)
+    # a batch larger than the context was created for is refused, not truncated
+    rb = api.make_read_batch(w["seq"], w["off"], 600, paired=True)
+    with pytest.raises(Exception) as ei:
+        ctx.map_batch(rb)
+    assert "exceeds ctx capacity" in str(ei.value)
+    # read ends longer than the 256-base packing limit are cut to their first 256 bases (the checker does the same)
+    seq, off, _, _ = w["tx"].reads(300, read_len=300, seed=5, threads=2)
+    rb = api.make_read_batch(seq, off, 300, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=2)
+    assert st_g == st_c and np.array_equal(ro_g, ro_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    assert len(aln_g) > 0 and int(aln_g["read_len"].max()) == 256
+    ctx.free()
