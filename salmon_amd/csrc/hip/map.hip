@@ -89,8 +89,15 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     if (eq_cus > 0) {
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
-      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()));
-      if (!owner) { SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data())); SQ_HIP_CHECK(hipStreamCreate(&c->stream3)); }
+      // a partition is an optimisation: if the platform refuses CU masks, fall back to plain streams
+      bool ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()) == hipSuccess;
+      if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess && hipStreamCreate(&c->stream3) == hipSuccess;
+      if (!ok) {
+        (void)hipGetLastError();
+        if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; } if (c->stream2) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; } if (c->stream3) { (void)hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
+        c->eq_cus = 0;
+        SQ_HIP_CHECK(hipStreamCreate(&c->stream)); if (!owner) SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
+      }
     } else {
       SQ_HIP_CHECK(hipStreamCreate(&c->stream)); if (!owner) SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
     }
