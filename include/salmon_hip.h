@@ -131,7 +131,8 @@ typedef struct {
   uint8_t allow_orphans;      /* 1 (discardOrphansQuasi=false) */
   uint8_t disable_chaining_heuristic; /* 0 */
   uint8_t ignore_incompat;    /* 1 (incompatPrior == 0) */
-  uint8_t _pad1[3];
+  uint8_t recover_orphans;    /* 0 (--recoverOrphans, SalmonQuantify.cpp:1356-1364; SPEC §a5) */
+  uint8_t _pad1[2];
   /* online model (SalmonQuantify.cpp:426-1023) */
   uint32_t mini_batch_size;   /* 5000 (SalmonQuantify.cpp:150) */
   uint32_t num_pre_burnin_frags; /* 5000 */
@@ -199,7 +200,8 @@ typedef struct {           /* HitCounters / MappingStatistics subset (SalmonQuan
   uint64_t num_reads, num_mapped_at_least_a_kmer, num_with_joint_hits /* upperBoundHits */,
       num_mapped /* >=1 kept alignment */, num_alignments /* validHits */,
       num_mappings_filtered, num_fragments_filtered, num_dovetails, num_decoy_fragments,
-      num_seeds, num_lookups, num_mems, num_chains, num_candidates, num_dp_alignments;
+      num_seeds, num_lookups, num_mems, num_chains, num_candidates, num_dp_alignments,
+      num_orphans_rescued /* fragments with a recovered mate (mstats.numOrphansRescued) */;
 } sq_map_stats;
 
 /* Map one batch. Results stay resident on the device for sq_eq_accumulate(); if out != NULL they
@@ -399,6 +401,14 @@ typedef struct { uint32_t frag; uint32_t tid; int32_t lpos, rpos; uint8_t lfw, r
                  int32_t lscore, rscore; uint32_t frag_len; } sq_cand;
 /* Returns number of records (or negative status). buf may be NULL to query the count. */
 int64_t sq_debug_tap(sq_ctx*, int what, void* buf, uint64_t cap_records);
+
+/* Parity tap for orphan recovery's infix aligner (row a5; reference src/edlib.cpp:290-372 called with
+ * {k, EDLIB_MODE_HW, EDLIB_TASK_LOC}): runs the DEVICE aligner on ncases (query, window) pairs.  Queries: ASCII, at most
+ * 256 bases, any non-ACGT byte matches nothing; windows: ASCII ACGT only.  out[4i..4i+3] = found, edit distance,
+ * startLocations[0], endLocations[0] (-1 when not found). */
+int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off /*[ncases+1]*/,
+                         const uint8_t* windows, const uint64_t* w_off /*[ncases+1]*/, const int32_t* k /*[ncases]*/,
+                         int32_t* out /*[4*ncases]*/);
 
 #ifdef __cplusplus
 }

@@ -268,6 +268,85 @@ static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::ve
   return out.empty() ? 0 : 2;
 }
 
+// ---- a5 — selective_alignment::utils::recoverOrphans [external] + in-tree edlib ---------------------
+// call site SalmonQuantify.cpp:1356-1364; the infix aligner is reference src/edlib.cpp:290-372 called with
+// {k, EDLIB_MODE_HW, EDLIB_TASK_LOC}.  Plain dynamic-programming restatement of what that call returns
+// (edit distance, endLocations[0], startLocations[0]); checked against the compiled reference file in
+// tests/test_recover.py.  Codes: 0..3 bases, anything else never matches (edlib compares bytes; the
+// reference text holds no N).  SPEC §a5.
+static bool infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k, int* ed, int* start, int* end) {
+  if (n <= 0 || m <= 0) return false;
+  if (k > n) k = n;                                           // edlib.cpp:683-685
+  std::vector<int> col(n + 1), lastrow(m + 1);
+  for (int i = 0; i <= n; ++i) col[i] = i;                    // D[i][0] = i
+  lastrow[0] = n;
+  for (int j = 1; j <= m; ++j) {                              // D[0][j] = 0: the gap before the query is free
+    int diag = col[0]; col[0] = 0;
+    for (int i = 1; i <= n; ++i) {
+      int up = col[i];                                        // D[i][j-1]
+      int v = std::min(std::min(diag + ((q[i - 1] == t[j - 1] && q[i - 1] < 4) ? 0 : 1), up + 1), col[i - 1] + 1);
+      diag = up; col[i] = v;
+    }
+    lastrow[j] = col[n];
+  }
+  int best = -1, e0 = -1;
+  for (int j = 1; j <= m; ++j) if (lastrow[j] <= k && (best < 0 || lastrow[j] < best)) { best = lastrow[j]; e0 = j - 1; }   // first end among the minima
+  if (best < 0) return false;
+  // start location (edlib.cpp:353-369): reversed query against the reversed target prefix [0, e0], prefix mode
+  // (D'[0][j] = j), score limit = best; the LAST column that reaches `best` gives the start.
+  const int m2 = e0 + 1; int jlast = -1;
+  for (int i = 0; i <= n; ++i) col[i] = i;
+  for (int j = 1; j <= m2; ++j) {
+    int diag = col[0]; col[0] = j;
+    const uint8_t tc = t[e0 - (j - 1)];
+    for (int i = 1; i <= n; ++i) {
+      int up = col[i]; const uint8_t qc = q[n - i];
+      int v = std::min(std::min(diag + ((qc == tc && qc < 4) ? 0 : 1), up + 1), col[i - 1] + 1);
+      diag = up; col[i] = v;
+    }
+    if (col[n] == best) jlast = j;
+  }
+  if (jlast < 0) return false;                                // cannot happen: the forward optimum is reachable backwards
+  *ed = best; *end = e0; *start = e0 - (jlast - 1);
+  return true;
+}
+
+#define RECOVER_WINDOW 1000   // "within the maximum fragment length" (doc/source/salmon.rst:323-331); the look-up window of one anchor
+// Orphan-only fragments: look for the missing mate next to every anchor.  An anchor on the forward strand expects its
+// mate reverse-complemented downstream (window = [max(0,pos), +1000) clipped to the transcript); an anchor on the
+// reverse strand expects the mate forward, upstream (window = the 1000 bases ending at the anchor's end).  The mate
+// (strand-normalised) is placed by infix alignment with at most len/4 edits.  A recovered mate becomes a chain without
+// MEMs at the recovered start; the candidate becomes a proper pair.  Returns true if any mate was recovered.
+static bool recover_orphans(const Index& ix, const Opts& op, const std::vector<uint8_t> rd[2], std::vector<Chain> ch[2], std::vector<Cand>& cands) {
+  bool any = false;
+  std::vector<uint8_t> qn, win;
+  for (auto& c : cands) {
+    if (c.mate_status != SQ_MS_PAIRED_END_LEFT && c.mate_status != SQ_MS_PAIRED_END_RIGHT) continue;
+    const int ae = c.mate_status == SQ_MS_PAIRED_END_LEFT ? 0 : 1, me = 1 - ae;
+    const Chain anchor = ch[ae][ae == 0 ? c.lc : c.rc];
+    const int ML = (int)rd[me].size(); if (ML == 0) continue;
+    const int Tlen = (int)ix.ref_len[anchor.tid]; const uint64_t g = ix.ref_accum[anchor.tid];
+    int ws, wl;
+    if (anchor.fw) { ws = std::max(0, anchor.pos); wl = std::min(RECOVER_WINDOW, Tlen - ws); }
+    else { int endPos = std::min(Tlen, anchor.pos + (int)anchor.read_len); ws = std::max(0, endPos - RECOVER_WINDOW); wl = endPos - ws; }
+    if (wl <= 0) continue;
+    const bool mate_fw = !anchor.fw;
+    qn.resize(ML);
+    if (mate_fw) qn = rd[me]; else for (int i = 0; i < ML; ++i) { uint8_t b = rd[me][ML - 1 - i]; qn[i] = b > 3 ? 4 : (uint8_t)(3 - b); }
+    win.resize(wl); for (int i = 0; i < wl; ++i) win[i] = (uint8_t)base_at(ix.refseq.data(), g + (uint64_t)(ws + i));
+    int ed, st, en;
+    if (!infix_align(qn.data(), ML, win.data(), wl, ML / 4, &ed, &st, &en)) continue;
+    const int mpos = ws + st;
+    const int fl = anchor.fw ? (mpos + ML - anchor.pos) : (anchor.pos + (int)anchor.read_len - mpos);
+    if (fl <= 0 || fl > (int)op.o.frag_len_max) continue;     // keeps the invariant of joined pairs (§a3)
+    Chain m; m.tid = anchor.tid; m.fw = mate_fw; m.score = 0.0; m.pos = mpos; m.last_end = ws + en + 1; m.read_len = (uint16_t)ML;
+    ch[me].push_back(m);
+    if (me == 1) c.rc = (int)ch[1].size() - 1; else c.lc = (int)ch[0].size() - 1;
+    c.mate_status = SQ_MS_PAIRED_END_PAIRED; c.frag_len = (uint32_t)fl; any = true;
+  }
+  return any;
+}
+
 // ---- a4 — PuffAligner::calculateAlignments [external] with ksw2 affine-gap DP --------------------
 // call site SalmonQuantify.cpp:1523-1525; configuration SalmonMappingUtils.hpp:168-206.
 // Banded Gotoh (band |i-j| <= bandwidth). mode 0: global (query and target both consumed);
@@ -319,6 +398,7 @@ static int32_t align_chain(const Index& ix, const Opts& op, const Chain& ch, con
   auto refb = [&](int x) -> uint8_t { return (uint8_t)base_at(ix.refseq.data(), g + (uint64_t)x); };
   std::vector<uint8_t> qb, tb;
   int64_t score = 0; int prevQ = 0, prevR = 0; bool first = true;
+  if (ch.mems.empty()) prevR = ch.pos;   // recovered mate (§a5): one extension alignment of the whole read from its start
   for (uint32_t mi : ch.mems) {
     const Mem& m = mems[mi];
     int qs = m.q, rs = m.rpos, ln = m.len;
@@ -411,7 +491,8 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
                          FragResult& out, sq_map_stats& st, Taps* taps) {
   out.alns.clear(); out.map_type = SQ_MT_UNMAPPED;
   st.num_reads++;
-  if (n1 > 256) n1 = 256; if (n2 > 256) n2 = 256;   // SPEC §I: a read end is its first 256 bases (the product's packing limit)
+  if (n1 > 256) n1 = 256;
+  if (n2 > 256) n2 = 256;   // SPEC §I: a read end is its first 256 bases (the product's packing limit)
   std::vector<uint8_t> rd[2]; std::vector<UniMem> um[2]; std::vector<Mem> mems[2]; std::vector<Chain> ch[2];
   const int nends = paired ? 2 : 1;
   for (int e = 0; e < nends; ++e) {
@@ -430,7 +511,11 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
   }
   if (!ch[0].empty() || !ch[1].empty()) st.num_mapped_at_least_a_kmer++;
   std::vector<Cand> cands; bool dovetail = false;
-  if (paired) { join_pair(op, ch[0], ch[1], cands, &dovetail); }
+  if (paired) {
+    const int jr = join_pair(op, ch[0], ch[1], cands, &dovetail);
+    // orphan recovery (SalmonQuantify.cpp:1343-1364): orphan-only fragments with at most maxReadOccs candidates
+    if (jr == 2 && op.o.recover_orphans && cands.size() <= op.o.max_read_occs && recover_orphans(ix, op, rd, ch, cands)) st.num_orphans_rescued++;
+  }
   else {  // joinReadsAndFilterSingle: every surviving chain is a candidate (SalmonQuantify.cpp:2108-2109)
     for (size_t a = 0; a < ch[0].size(); ++a) { Cand c; c.tid = ch[0][a].tid; c.lc = (int)a; c.rc = -1; c.frag_len = 0; c.mate_status = SQ_MS_SINGLE_END; c.cov = ch[0][a].score; cands.push_back(c); }
   }
@@ -1144,6 +1229,8 @@ int orc_compatible_pe(int et, int eo, int es, int ot, int oo, int os) { return c
 int orc_compatible_se(int et, int eo, int es, int fwd, int ms) { return compatible_hit_se(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, fwd != 0, (uint8_t)ms); }
 int orc_format_id(int t, int o, int s) { return format_id(LibFmt{(uint8_t)t, (uint8_t)o, (uint8_t)s}); }
 int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) { Opts op; make_opts(o, op); return dp_align(op, q, n, t, tl, mode); }
+// a5: the infix aligner alone (codes 0..3, other values match nothing); returns 1 and (distance, start, end) or 0
+int orc_infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k, int* ed, int* start, int* end) { return infix_align(q, n, t, m, k, ed, start, end) ? 1 : 0; }
 void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) { FLD f; f.init(mu, sd); for (int i = 0; i <= 1000; ++i) log_hist_1001[i] = f.hist[i]; *tot = f.totMass; }
 double orc_forgetting_mass(double ff, uint64_t b) { QuantState S; S.op.o.forgetting_factor = ff; return S.forgetting_mass(b); }
 

@@ -438,3 +438,14 @@ def gibbs(eq, eff_len, alpha_init, num_samples, seed, num_mapped, gopts=None, de
     rows, cb = _collect(txp.num_txp)
     check(lib().sq_gibbs_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, seed, num_mapped, cb, None), "sq_gibbs_dev")
     return np.array(rows)
+
+
+def debug_infix_align(queries, windows, ks, device=0):
+    """Device infix aligner (orphan recovery, row a5) on (query, window) ASCII pairs -> int32[n, 4] = found, distance, start, end."""
+    n = len(queries)
+    qo = np.zeros(n + 1, np.uint64); wo = np.zeros(n + 1, np.uint64)
+    qo[1:] = np.cumsum([len(q) for q in queries]); wo[1:] = np.cumsum([len(w) for w in windows])
+    qb = np.frombuffer(b"".join(queries) + b"\0", np.uint8); wb = np.frombuffer(b"".join(windows) + b"\0", np.uint8)
+    k = np.ascontiguousarray(ks, np.int32); out = np.zeros((n, 4), np.int32)
+    check(lib().sq_debug_infix_align(device, n, qb.ctypes.data, qo.ctypes.data, wb.ctypes.data, wo.ctypes.data, k.ctypes.data, out.ctypes.data), "sq_debug_infix_align")
+    return out

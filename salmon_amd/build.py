@@ -2,6 +2,7 @@
 
   libsalmon_hip.so   product: host index builder + HIP kernels + C ABI   (hipcc --offload-arch=gfx950)
   oracle/_build/liboracle.so   CPU checker (test infrastructure)         (g++)
+  oracle/_ref/libedlib_ref.so  the reference's infix aligner, compiled from /root/reference where present (g++)
   tools/_build/libsqsynth.so   synthetic transcriptome / read generator  (g++)
 """
 import os, subprocess, sys, hashlib, concurrent.futures as cf
@@ -93,6 +94,19 @@ def build_oracle():
     return os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 
 
+def build_oracle_ref(reference="/root/reference"):
+    """oracle/_ref/libedlib_ref.so: the reference's own infix aligner (src/edlib.cpp, row a5) compiled from where it lies
+    under /root/reference plus a C shim.  Only where the reference tree exists (this container); the GPU box uses the
+    prebuilt file that travels with the snapshot.  Returns the path or None."""
+    out = os.path.join(ROOT, "oracle", "_ref", "libedlib_ref.so")
+    if not os.path.exists(os.path.join(reference, "src", "edlib.cpp")):
+        return out if os.path.exists(out) else None
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "REF=" + reference], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle/_ref build failed:\n" + r.stdout[-3000:] + r.stderr[-6000:])
+    return out
+
+
 def build_tools():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], capture_output=True, text=True)
     if r.returncode != 0:
@@ -116,6 +130,7 @@ def build_all():
     build_product()
     build_cli()
     build_oracle()
+    build_oracle_ref()
     build_tools()
     build_microbench()
 

@@ -31,7 +31,7 @@ class QuantOpts(C.Structure):
                 ("post_merge_chain_sub_thresh", f64), ("orphan_chain_sub_thresh", f64), ("score_exp", f64),
                 ("decoy_threshold", f64), ("min_aln_prob", f64),
                 ("hard_filter", u8), ("allow_dovetail", u8), ("allow_orphans", u8), ("disable_chaining_heuristic", u8),
-                ("ignore_incompat", u8), ("_pad1", u8 * 3),
+                ("ignore_incompat", u8), ("recover_orphans", u8), ("_pad1", u8 * 2),
                 ("mini_batch_size", u32), ("num_pre_burnin_frags", u32), ("num_burnin_frags", u64),
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
@@ -55,7 +55,7 @@ class AlnBatch(C.Structure):
 class MapStats(C.Structure):
     _names = ["num_reads", "num_mapped_at_least_a_kmer", "num_with_joint_hits", "num_mapped", "num_alignments",
               "num_mappings_filtered", "num_fragments_filtered", "num_dovetails", "num_decoy_fragments", "num_seeds",
-              "num_lookups", "num_mems", "num_chains", "num_candidates", "num_dp_alignments"]
+              "num_lookups", "num_mems", "num_chains", "num_candidates", "num_dp_alignments", "num_orphans_rescued"]
     _fields_ = [(n, u64) for n in _names]
 
     def as_dict(self):
@@ -151,6 +151,7 @@ def lib():
         "sq_bootstrap_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_debug_tap": (C.c_int64, [vp, C.c_int, vp, u64]),
+        "sq_debug_infix_align": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, vp, vp]),
         "sq_normalize_alphas": (C.c_int, [u32, P(EqTable), P(f64), P(u64), P(u64), P(f64)]),
         "sq_write_quant_sf": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64]), "sq_write_eq_classes": (C.c_int, [C.c_char_p, vp, P(EqTable), C.c_int]),
         "sq_model_fetch_lib_counts": (C.c_int, [vp, P(u64)]), "sq_write_lib_format_counts": (C.c_int, [C.c_char_p, C.c_char_p, u8, u8, u8, P(u64), u64, u64]),

@@ -106,7 +106,7 @@ static int cmd_quant(int argc, char** argv) {
   const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
   const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
-  if (!idir || !odir || (!ru && !(r1 && r2))) { fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--device 0] [--batch 1000000]\n"); return 1; }
+  if (!idir || !odir || (!ru && !(r1 && r2))) { fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n"); return 1; }
   std::string lib = lt ? lt : (ru ? "U" : "IU");
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
   if (lib == "A") { fprintf(stderr, "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n"); return 1; }
@@ -122,6 +122,7 @@ static int cmd_quant(int argc, char** argv) {
   if ((v = arg(argc, argv, "--mismatchSeedSkip"))) qo.mismatch_seed_skip = (uint32_t)atoi(v);
   if (flag(argc, argv, "--hardFilter")) qo.hard_filter = 1;
   if (flag(argc, argv, "--allowDovetail")) qo.allow_dovetail = 1;
+  if (flag(argc, argv, "--recoverOrphans")) qo.recover_orphans = 1;   // ProgramOptionsGenerator.cpp:202-206
   if (flag(argc, argv, "--discardOrphansQuasi")) qo.allow_orphans = 0;
   if (flag(argc, argv, "--disableChainingHeuristic")) qo.disable_chaining_heuristic = 1;
   sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
@@ -186,6 +187,7 @@ static int cmd_quant(int argc, char** argv) {
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
     if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
+  if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n", (unsigned long long)tot.num_orphans_rescued);   // SalmonQuantify.cpp:2697-2701
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
   if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)

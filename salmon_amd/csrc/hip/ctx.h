@@ -37,9 +37,9 @@ struct sq_dp_item {     // one banded-DP region queued by the fast scorer
 
 struct sq_map_params {
   int32_t ma, mp, go, ge, bw;
-  uint32_t k, alt_skip, max_occ, frag_len_max, first_decoy;
+  uint32_t k, alt_skip, max_occ, frag_len_max, first_decoy, max_read_occs;
   double pre_thr, post_thr, orphan_thr, consensus_frac, min_score_fraction, score_exp, decoy_threshold, min_aln_prob;
-  uint8_t lib_type, lib_orient, lib_strand, hard_filter, allow_dovetail, allow_orphans, no_heuristic, ignore_incompat;
+  uint8_t lib_type, lib_orient, lib_strand, hard_filter, allow_dovetail, allow_orphans, no_heuristic, ignore_incompat, recover_orphans;
 };
 
 template <class T>
@@ -81,7 +81,7 @@ struct sq_ctx {
   sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;
   // last batch bookkeeping
-  uint32_t last_n = 0; uint32_t last_paired = 0; uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0;
+  uint32_t last_n = 0; uint32_t last_paired = 0; uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0, last_chain_slots = 0;
   bool have_batch = false;
   // online model + eq table
   sq_online_dev* online = nullptr; sq_eq_dev* eq = nullptr;
@@ -129,7 +129,7 @@ void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id);        // block until the eq w
 void sq_eq_worker_stop(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
-enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_N };
+enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_RESCUED, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`

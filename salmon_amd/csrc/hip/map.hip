@@ -40,6 +40,7 @@ void fill_params(sq_ctx* c) {
   P.min_score_fraction = o.min_score_fraction; P.score_exp = o.score_exp; P.decoy_threshold = o.decoy_threshold; P.min_aln_prob = o.min_aln_prob;
   P.lib_type = o.lib_type; P.lib_orient = o.lib_orientation; P.lib_strand = o.lib_strand; P.hard_filter = o.hard_filter; P.allow_dovetail = o.allow_dovetail;
   P.allow_orphans = o.allow_orphans; P.no_heuristic = o.disable_chaining_heuristic; P.ignore_incompat = o.ignore_incompat;
+  P.recover_orphans = o.recover_orphans; P.max_read_occs = o.max_read_occs;
 }
 }  // namespace
 
@@ -242,7 +243,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_mems = total_mems;
   const size_t MP = (size_t)total_mems + 8;
-  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) || c->mused.ensure(MP) || c->chains.ensure(MP)) {
+  const bool recover = P.recover_orphans && paired;   // recovered mates live in a second set of chain slabs (k_recover)
+  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) || c->mused.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
   if (total_mems) {
@@ -264,7 +266,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
   // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
   // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
-  if (total_mems >= 0xFFFFFFF0ull) { sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems); return SQ_ERR_OVERFLOW; }
+  if (total_mems >= (recover ? 0x7FFFFFF0ull : 0xFFFFFFF0ull)) { sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems); return SQ_ERR_OVERFLOW; }
   sq_prof_mark(c, SG_CHAIN);
   // single-pass join; candidate blocks come from a global cursor (stats slot reused as the 64-bit cursor)
   uint64_t total_cands = 0;
@@ -298,6 +300,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
   S.mkey = skey; S.mval = sval; S.mnext = c->mnext.p; S.dpq = c->dpq.p; S.counters = c->counters.p; S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
   uint32_t hcount[2] = {0, 0};
+  c->last_chain_slots = recover ? 2 * total_mems : total_mems;
+  if (total_cands && recover) k_recover<<<nblk(n), TB, 0, st>>>(P, S, n, c->cand_off.p, c->n_cand.p, c->cands.p, c->chains.p, (uint32_t)total_mems, c->stats.p);
   if (total_cands) {
     for (int attempt = 0; attempt < 2; ++attempt) {
       SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
@@ -331,7 +335,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     memset(stats, 0, sizeof(*stats));
     stats->num_reads = n; stats->num_mapped_at_least_a_kmer = hst[ST_KMER]; stats->num_with_joint_hits = hst[ST_JOINT]; stats->num_mapped = hst[ST_MAPPED]; stats->num_alignments = hst[ST_ALNS];
     stats->num_mappings_filtered = hst[ST_MAPFILT]; stats->num_fragments_filtered = hst[ST_FRAGFILT]; stats->num_dovetails = hst[ST_DOVETAIL]; stats->num_decoy_fragments = hst[ST_DECOY];
-    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hst[ST_DP];
+    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hst[ST_DP]; stats->num_orphans_rescued = hst[ST_RESCUED];
   }
   if (out) {
     if (!out->read_off || (!out->aln && total_aln)) { sq_set_error("sq_map_batch: output arrays missing"); return SQ_ERR_ARG; }
@@ -345,6 +349,37 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off, const uint8_t* windows, const uint64_t* w_off, const int32_t* k, int32_t* out) {
+  if (!ncases) return SQ_OK;
+  if (!queries || !q_off || !windows || !w_off || !k || !out) { sq_set_error("sq_debug_infix_align: null argument"); return SQ_ERR_ARG; }
+  if (hipSetDevice(device) != hipSuccess) { sq_set_error("sq_debug_infix_align: no device %d", device); return SQ_ERR_DEVICE; }
+  // host-side packing into the layouts the pipeline uses: read ends as SQ_READ_WORDS 2-bit words + N mask, text as one 2-bit pool
+  std::vector<uint64_t> rp((size_t)ncases * SQ_READ_WORDS, 0), rn((size_t)ncases * SQ_NMASK_WORDS, 0), toff(ncases + 1, 0); std::vector<uint16_t> rl(ncases);
+  auto code = [](uint8_t ch) -> int { switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } };
+  for (uint32_t i = 0; i < ncases; ++i) {
+    const uint64_t n = q_off[i + 1] - q_off[i]; if (n > 256) { sq_set_error("sq_debug_infix_align: query %u longer than 256", i); return SQ_ERR_ARG; }
+    rl[i] = (uint16_t)n;
+    for (uint64_t j = 0; j < n; ++j) { const int cd = code(queries[q_off[i] + j]); if (cd > 3) rn[(size_t)i * SQ_NMASK_WORDS + (j >> 6)] |= 1ull << (j & 63); else rp[(size_t)i * SQ_READ_WORDS + (j >> 5)] |= (uint64_t)cd << ((j & 31) * 2); }
+    toff[i + 1] = toff[i] + (w_off[i + 1] - w_off[i]);
+  }
+  std::vector<uint64_t> text((size_t)(toff[ncases] >> 5) + 2, 0);
+  for (uint32_t i = 0; i < ncases; ++i) for (uint64_t j = 0, m = w_off[i + 1] - w_off[i]; j < m; ++j) {
+    const int cd = code(windows[w_off[i] + j]); if (cd > 3) { sq_set_error("sq_debug_infix_align: window %u holds a non-ACGT byte", i); return SQ_ERR_ARG; }
+    const uint64_t p = toff[i] + j; text[p >> 5] |= (uint64_t)cd << ((p & 31) * 2);
+  }
+  sq_dbuf<uint64_t> d_rp, d_rn, d_text, d_toff; sq_dbuf<uint16_t> d_rl; sq_dbuf<int32_t> d_k, d_out;
+  int rc = SQ_OK;
+  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) || d_out.ensure((size_t)4 * ncases)) { sq_set_error("sq_debug_infix_align: device allocation failed"); rc = SQ_ERR_NOMEM; }
+  auto up = [&](void* d, const void* h, size_t b) { if (rc == SQ_OK && hipMemcpy(d, h, b, hipMemcpyHostToDevice) != hipSuccess) { sq_set_error("sq_debug_infix_align: copy failed"); rc = SQ_ERR_DEVICE; } };
+  up(d_rp.p, rp.data(), rp.size() * 8); up(d_rn.p, rn.data(), rn.size() * 8); up(d_text.p, text.data(), text.size() * 8); up(d_toff.p, toff.data(), toff.size() * 8); up(d_rl.p, rl.data(), (size_t)ncases * 2); up(d_k.p, k, (size_t)ncases * 4);
+  if (rc == SQ_OK) {
+    k_infix_cases<<<(ncases + 63) / 64, 64>>>(ncases, d_rp.p, d_rn.p, d_rl.p, d_text.p, d_toff.p, d_k.p, d_out.p);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_out.p, (size_t)16 * ncases, hipMemcpyDeviceToHost) != hipSuccess) { sq_set_error("sq_debug_infix_align: kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = SQ_ERR_DEVICE; }
+  }
+  d_rp.free_(); d_rn.free_(); d_text.free_(); d_toff.free_(); d_rl.free_(); d_k.free_(); d_out.free_();
+  return rc;
+}
+
 static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap);
 extern "C" int64_t sq_debug_tap(sq_ctx* c, int what, void* buf, uint64_t cap) {
   if (!c || c->owner || !c->api_have) { sq_set_error("sq_debug_tap: no mapped batch"); return SQ_ERR_STATE; }
@@ -374,7 +409,7 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   std::vector<uint32_t> nch(nrec); std::vector<uint64_t> choff(nrec + 1);
   if (nrec && hipMemcpy(nch.data(), c->n_chains.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   choff = moff;   // chains live in per-end slabs that start at mem_off[e]
-  const uint64_t tch = nrec ? choff[nrec] : 0; std::vector<sq_chain_dev> ch(tch);
+  const uint64_t tch = nrec ? std::max<uint64_t>(choff[nrec], c->last_chain_slots) : 0; std::vector<sq_chain_dev> ch(tch);   // recovered mates (k_recover) sit past the MEM-count slabs
   if (tch && hipMemcpy(ch.data(), c->chains.p, tch * sizeof(sq_chain_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   if (what == SQ_TAP_CHAINS) {
     uint64_t cnt = 0; sq_chain* o = (sq_chain*)buf;

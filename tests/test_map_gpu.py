@@ -309,7 +309,7 @@ OPTION_VARIANTS = [
     dict(score_exp=2.0, min_aln_prob=1e-3, decoy_threshold=0.9), dict(no_length_correction=1), dict(no_eff_length_correction=1),
     dict(use_frag_len_dist=0), dict(model_single_frag_prob=0), dict(ignore_incompat=0, incompat_prior=-20.0, _lib="ISF"),
     dict(pre_merge_chain_sub_thresh=0.9, post_merge_chain_sub_thresh=0.95, orphan_chain_sub_thresh=0.5), dict(frag_len_max=400, fld_mean=200.0, fld_sd=40.0),
-    dict(forgetting_factor=0.8, seed=12345),
+    dict(forgetting_factor=0.8, seed=12345), dict(recover_orphans=1), dict(recover_orphans=1, max_read_occs=2, allow_dovetail=1),
 ]
 
 
