@@ -12,6 +12,9 @@
 // minimap2 chaining, ksw2 affine DP) with the choices frozen in oracle/SPEC.md.  Rows a7-a18 follow
 // the in-tree reference files line by line; each function cites them.  Library-format compatibility
 // (a9) IS pinned by the reference's tests/LibraryTypeTests.cpp truth tables (tests/test_libtype.py).
+// The infix aligner of orphan recovery (a5) IS pinned against the reference's own src/edlib.cpp, compiled from
+// /root/reference into oracle/_ref/libedlib_ref.so (oracle/Makefile `ref`), and through 600 committed vectors made
+// from it (tests/golden/edlib_infix_vectors.json.gz).
 //
 // Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.
 #include <algorithm>
