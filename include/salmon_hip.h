@@ -161,6 +161,11 @@ int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t
 void sq_ctx_free(sq_ctx*);
 /* Forget the online model and the eq-class table (fresh ReadExperiment), keeping work buffers. */
 int sq_ctx_reset(sq_ctx*);
+/* Pre-size what the END of a job allocates (eq-class export buffers + their page-locked staging area, the EM
+ * workspace) for up to max_classes equivalence classes with max_labels label entries; (0, 0) = 10^6 classes, the size
+ * the reference gives its eq-class map up front (countMap_.reserve(1000000), EquivalenceClassBuilder.hpp:140), with 6
+ * labels each.  Optional: larger jobs grow the buffers as before. */
+int sq_ctx_reserve(sq_ctx*, uint64_t max_classes, uint64_t max_labels);
 
 typedef struct {
   uint32_t n;              /* fragments (pairs or single reads) */

@@ -243,6 +243,9 @@ class QuantContext:
             lib().sq_debug_tap(self.h, what, buf.ctypes.data, int(n))
         return buf
 
+    def reserve(self, max_classes=0, max_labels=0):
+        check(lib().sq_ctx_reserve(self.h, int(max_classes), int(max_labels)), "sq_ctx_reserve")
+
     def reset(self):
         check(lib().sq_ctx_reset(self.h), "sq_ctx_reset")
 

@@ -151,6 +151,7 @@ def lib():
         "sq_bootstrap_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_debug_tap": (C.c_int64, [vp, C.c_int, vp, u64]),
+        "sq_ctx_reserve": (C.c_int, [vp, u64, u64]),
         "sq_debug_infix_align": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, vp, vp]),
         "sq_normalize_alphas": (C.c_int, [u32, P(EqTable), P(f64), P(u64), P(u64), P(f64)]),
         "sq_write_quant_sf": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64]), "sq_write_eq_classes": (C.c_int, [C.c_char_p, vp, P(EqTable), C.c_int]),

@@ -82,6 +82,7 @@ struct sq_ctx {
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;
   // last batch bookkeeping
   uint32_t last_n = 0; uint32_t last_paired = 0; uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0, last_chain_slots = 0;
+  void* em_arena = nullptr;   // persistent EM workspace (em.hip: EmArena), grown by sq_ctx_reserve / sq_em_optimize(ctx, ...)
   bool have_batch = false;
   // online model + eq table
   sq_online_dev* online = nullptr; sq_eq_dev* eq = nullptr;

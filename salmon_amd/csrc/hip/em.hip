@@ -265,11 +265,44 @@ __global__ void k_close(EmDev d, uint32_t it_index /* 0-based index of the itera
   em_close(d, it_index, maxrel_log);
 }
 
+// Workspace arena: an EM session needs ~50 device buffers; hipMalloc + hipFree of each costs more (≈ 6 ms per
+// session) than the 1.3 ms the device-side preparation takes.  While a session sets itself up its buffers are
+// bump-allocated from a few large chunks that outlive it: a ctx keeps its arena across calls (sq_em_optimize(ctx, …),
+// pre-sized by sq_ctx_reserve), a ctx-less call owns a private one.  A request that does not fit adds a chunk.
+struct EmArena {
+  struct Chunk { char* base; size_t cap, used; };
+  std::vector<Chunk> chunks;
+  // page-locked staging for the MB-sized host<->device copies of a session (slot 0: eff_len / alphas, slot 1: the block-plan
+  // jump tables); pageable copies of 1-2 MB into fresh host pages were seen to take 3-17 ms
+  void* pin[2] = {nullptr, nullptr}; size_t pin_cap[2] = {0, 0};
+  ~EmArena() { for (auto& c : chunks) (void)hipFree(c.base); for (void* p : pin) if (p) (void)hipHostFree(p); }
+  void* pinned(int slot, size_t bytes) {
+    if (bytes <= pin_cap[slot]) return pin[slot];
+    if (pin[slot]) (void)hipHostFree(pin[slot]); pin[slot] = nullptr; pin_cap[slot] = 0;
+    if (hipHostMalloc(&pin[slot], bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[slot] = nullptr; return nullptr; }
+    pin_cap[slot] = bytes; return pin[slot];
+  }
+  void reset() { for (auto& c : chunks) c.used = 0; }
+  size_t capacity() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
+  int add_chunk(size_t bytes) { Chunk c{nullptr, bytes, 0}; if (hipMalloc((void**)&c.base, bytes) != hipSuccess) return -1; chunks.push_back(c); return 0; }
+  void* take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& c : chunks) if (c.cap - c.used >= bytes) { void* p = c.base + c.used; c.used += bytes; return p; }
+    if (add_chunk(std::max<size_t>(bytes, (size_t)64 << 20))) return nullptr;
+    Chunk& c = chunks.back(); c.used = bytes; return c.base;
+  }
+};
+thread_local EmArena* tl_arena = nullptr;   // set while an EmSession sets itself up
+
 template <class T>
 struct DBuf {
-  T* p = nullptr;
-  ~DBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+  T* p = nullptr; bool owned = false;
+  ~DBuf() { if (p && owned) (void)hipFree(p); }
+  int alloc(size_t n) {
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    if (tl_arena) { p = (T*)tl_arena->take(bytes); owned = false; return p ? 0 : -1; }
+    owned = true; return hipMalloc((void**)&p, bytes) == hipSuccess ? 0 : -1;
+  }
   int upload(const std::vector<T>& v) { if (alloc(v.size())) return -1; return v.empty() || hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 };
 
@@ -377,10 +410,17 @@ struct EmSession {
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
-  ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st) (void)hipStreamDestroy(st); }
+  EmArena* arena = nullptr; EmArena own_arena;   // arena: borrowed from a ctx (set before setup), else own_arena
+  bool own_stream = true;   // false: `st` was lent by a ctx (set before setup) — a new stream means a new hardware queue, whose first dispatch was seen to stall 15-30 ms
+  ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st && own_stream) (void)hipStreamDestroy(st); if (arena && arena != &own_arena) arena->reset(); }
 
   // eq: host table (uploaded) — or dv: a CSR that already lives on this device
   int setup(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, const EqDevCsr* dv = nullptr) {
+    if (!arena) arena = &own_arena;
+    struct Scope { Scope(EmArena* a) { tl_arena = a; } ~Scope() { tl_arena = nullptr; } } scope(arena);   // every DBuf::alloc below draws from the arena
+    return setup_impl(device, eq, txp, opts, dv);
+  }
+  int setup_impl(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, const EqDevCsr* dv) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
     SQ_HIP_CHECK(hipSetDevice(device));
@@ -390,7 +430,9 @@ struct EmSession {
     if (E64 >= 0xFFFFFFFFull) { sq_set_error("too many equivalence classes"); return SQ_ERR_OVERFLOW; }
     if (L >= 0x7FFFFFFFull) { sq_set_error("too many label entries for the EM reduction plan"); return SQ_ERR_OVERFLOW; }
     E = (uint32_t)E64;
-    SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+    if (!st) { SQ_HIP_CHECK(hipStreamCreate(&st)); own_stream = true; }
+    SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+    pt.mark("stream+events");
     const int TB = 256; auto nb = [&](uint64_t n) { return (uint32_t)((n + TB - 1) / TB); };
     // inputs
     const uint64_t* p_off; const uint32_t* p_tid; const double* p_w; const unsigned long long* p_cnt;
@@ -406,7 +448,10 @@ struct EmSession {
               !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
-    SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
+    pt.mark("buffers");
+    h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down; nullptr: plain pageable copies
+    if (h_stage) { memcpy(h_stage, txp->eff_len, (size_t)M * 8); SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
+    else SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));
     pt.mark("alloc+upload");
     // combined weights, prior, CSC
@@ -429,6 +474,7 @@ struct EmSession {
       for (int l = 0; l < 4; ++l) SQ_HIP_CHECK(hipMemcpyAsync(&S[l], base[l].p + M, 4, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, 4, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
+      pt.mark("prep:csc+plan-sizes");
       if (herr == 0xFFFFFFFFu) { sq_set_error("EM reduction plan deeper than 4 levels"); return SQ_ERR_OVERFLOW; }
       if (herr) { sq_set_error("eq-class label references transcript %u >= %u", herr - 1, M); return SQ_ERR_ARG; }
       d.nlevels = 0;
@@ -444,13 +490,16 @@ struct EmSession {
     { const uint32_t S0 = d.nseg[0]; const uint32_t Lu = (uint32_t)L;
       SQ_HIP_CHECK(hipMemcpyAsync(d_slo[0].p + S0, &Lu, 4, hipMemcpyHostToDevice, st));   // sentinel: seg_lo[S0] = L
       if (nxt.alloc(std::max<size_t>(S0, E) + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
-      std::vector<uint32_t> hn;
-      if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, L1_CHUNK, L1_TB, nxt.p); hn.resize(S0);
-        SQ_HIP_CHECK(hipMemcpyAsync(hn.data(), nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<uint32_t> hn_pageable; uint32_t* hn = (uint32_t*)arena->pinned(1, (std::max<size_t>(S0, E) + 1) * 4);
+      if (!hn) { hn_pageable.resize(std::max<size_t>(S0, E) + 1); hn = hn_pageable.data(); }
+      if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, L1_CHUNK, L1_TB, nxt.p);
+        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
         for (uint32_t g = 0; g < S0; g = hn[g]) h_chunk.push_back(g); h_chunk.push_back(S0); }
-      if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, CL_CHUNK, 0, nxt.p); hn.resize(E);
-        SQ_HIP_CHECK(hipMemcpyAsync(hn.data(), nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+      pt.mark("prep:jump1");
+      if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, CL_CHUNK, 0, nxt.p);
+        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
         for (uint32_t c = 0; c < E; c = hn[c]) h_cchunk.push_back(c); h_cchunk.push_back(E); }
+      pt.mark("prep:jump2");
       if (d_chunk.upload(h_chunk) || d_cchunk.upload(h_cchunk) || d_seg8.alloc(L)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
       if (S0) k_plan_seg8<<<nb(S0), TB, 0, st>>>(S0, d_chunk.p, (uint32_t)h_chunk.size() - 1, d_slo[0].p, d_scn[0].p, d_seg8.p);
     }
@@ -475,7 +524,10 @@ struct EmSession {
   // alpha_dev != nullptr: the initial alphas are already in d_a0 (device); else they are uploaded from `alpha`.
   int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false, bool fetch = true) {
     const int TB = 256;
-    if (!alpha_on_device) SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
+    if (!alpha_on_device) {
+      if (h_stage) { memcpy(h_stage + M, alpha.data(), (size_t)M * 8); SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, h_stage + M, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
+      else SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
+    }
     SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st)); SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
     d.min_iter = (mode == 0) ? min_iter : 0xFFFFFFFFu;
     double* cur = d_a0.p; double* nxt = d_a1.p;
@@ -509,7 +561,7 @@ struct EmSession {
       const uint32_t maxIter = o->max_iter, minIter = min_iter;
       // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
       while (it < maxIter || it < minIter) {
-        uint32_t chunk = (it < minIter) ? (minIter - it) : 16;
+        uint32_t chunk = (it < minIter) ? (minIter - it) : 64;   // a look costs a stream drain (~25 us); an iteration queued past convergence is five no-op launches
         uint32_t lim = std::max(maxIter, minIter);
         if (it + chunk > lim) chunk = lim - it;
         for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
@@ -522,21 +574,24 @@ struct EmSession {
     SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     result_dev = (executed % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed` swaps starting from d_a0
-    if (fetch) SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
+    if (fetch) {
+      if (h_stage) { SQ_HIP_CHECK(hipMemcpyAsync(h_stage + 2 * (size_t)M, result_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st)); memcpy(alpha.data(), h_stage + 2 * (size_t)M, (size_t)M * 8); }
+      else SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
+    }
     unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
     if (rep) {
       rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
-      rep->device_ms = ms; rep->ms_per_iter = (mode == 1 ? fixed_iters : it) ? ms / (double)(mode == 1 ? fixed_iters : it) : 0.0; rep->alpha_sum = 0;
+      rep->device_ms = ms; rep->ms_per_iter = executed ? ms / (double)executed : 0.0; rep->alpha_sum = 0;
     }
     return SQ_OK;
   }
-  double* result_dev = nullptr;
+  double* result_dev = nullptr; double* h_stage = nullptr;
 };
 
-int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep, const sq_eq_dev_csr* dv = nullptr) {
+int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep, const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr) {
   PhaseTimer pt("em");
   int rc;
-  { EmSession S; rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
+  { EmSession S; S.arena = arena; if (lent) { S.st = lent; S.own_stream = false; } rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
     pt.mark("setup");
     rc = S.run(alpha, mode, fixed_iters, o->min_iter, rep);
     pt.mark("run"); }
@@ -599,11 +654,24 @@ __global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __
 
 extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   if (!eq || !txp || !o || !alpha_out || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_em_optimize_dev: bad arguments"); return SQ_ERR_ARG; }
-  return sq_em_optimize_impl(device, eq, nullptr, txp, o, alpha_out, rep);
+  return sq_em_optimize_impl(device, eq, nullptr, txp, o, alpha_out, rep, nullptr, nullptr);
 }
 
 // eq: host table, or dv: the label-major CSR already resident on `device` (the ctx's staged export)
-int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+// a ctx's persistent EM workspace (opaque to the other translation units)
+int sq_em_arena_reserve(void** slot, size_t bytes, size_t pinned_bytes, size_t pinned_plan_bytes) {
+  if (!*slot) *slot = new EmArena();
+  EmArena* a = (EmArena*)*slot;
+  (void)a->pinned(0, pinned_bytes); (void)a->pinned(1, pinned_plan_bytes);
+  if (a->capacity() >= bytes) return SQ_OK;
+  if (a->add_chunk(bytes - a->capacity() + ((size_t)8 << 20))) { sq_set_error("device allocation failed (EM workspace, %zu bytes)", bytes); return SQ_ERR_NOMEM; }
+  return SQ_OK;
+}
+void sq_em_arena_free(void* slot) { delete (EmArena*)slot; }
+size_t sq_em_workspace_bytes(uint64_t E, uint64_t L, uint64_t M) { return (size_t)(46 * L + 17 * (L / 64 + M) + 24 * E + 128 * M + ((size_t)16 << 20)); }   // the allocations of EmSession::setup_impl, rounded up
+
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep, void** arena_slot, void* lent_stream) {
+  if (arena_slot && !*arena_slot) *arena_slot = new EmArena();
   const uint32_t M = txp->num_txp;
   // initial alphas (CollapsedEMOptimizer.cpp:778-823)
   std::vector<double> pc(M, 0.0); if (txp->projected_counts) pc.assign(txp->projected_counts, txp->projected_counts + M);
@@ -612,7 +680,7 @@ int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* 
   double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
   std::vector<double> alpha(M);
   for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
-  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep, dv);
+  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep, dv, arena_slot ? (EmArena*)*arena_slot : nullptr, (hipStream_t)lent_stream);
   if (rc) return rc;
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector (:64-76), minAlpha 1e-8
   double asum = canonical_sum_host(alpha);

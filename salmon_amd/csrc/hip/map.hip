@@ -132,6 +132,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->owner) sq_online_free(c);
+  if (c->em_arena) { sq_em_arena_free(c->em_arena); c->em_arena = nullptr; }
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
   c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->wkey.free_(); c->wkey2.free_(); c->wid.free_(); c->perm_ends.free_(); c->perm_frags.free_(); c->chains.free_(); c->chains_d.free_(); c->chain_off.free_(); c->n_chains.free_();
   c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_(); c->aln_b1.free_(); c->aln_off_b1.free_();

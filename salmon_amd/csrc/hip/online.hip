@@ -790,9 +790,14 @@ extern "C" int sq_ctx_reset(sq_ctx* c) {
   if (!c) return SQ_ERR_ARG;
   (void)sq_eq_sync(c);
   SQ_HIP_CHECK(hipSetDevice(c->device));
+  // the export buffers and their page-locked staging area are work buffers (sized by earlier jobs / sq_ctx_reserve): they survive
+  auto keep = c->online->exp; c->online->exp = decltype(keep)();
   sq_online_free(c);
   c->reads_seen = 0; c->have_batch = false; c->api_have = false;
-  return sq_online_create(c);
+  int rc = sq_online_create(c);
+  if (rc == SQ_OK) { keep.valid = false; keep.model_valid = false; keep.E = keep.L = 0; c->online->exp = keep; }
+  else { keep.release(); }
+  return rc;
 }
 
 extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
@@ -867,6 +872,7 @@ static int eq_export_run(sq_ctx* c) {
   sq_online_dev* o = c->online; hipStream_t st = c->stream; auto& X = o->exp;
   unsigned long long cur[4], hctr[8]; SQ_HIP_CHECK(hipMemcpyAsync(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+  mark("cursor-read");
   const uint64_t E = cur[1], L = cur[0];
   const bool model_final = hctr[1] != 0 || hctr[4] == 4;   // effective lengths already final (burned in / finalised): the model summary can ride along
   X.E = E; X.L = L; X.valid = false;
@@ -1007,5 +1013,24 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep);
+  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
+}
+
+// Pre-size everything the end of a job allocates — the device buffers and the page-locked staging area of the eq-class
+// export, and the EM workspace — for up to max_classes classes with max_labels label entries (0, 0: the reference's own
+// initial map size, 10^6 classes, with 6 labels each).  Without it the first export / EM of a job pays ≈ 10 ms of hipMalloc / hipHostMalloc; larger
+// jobs than reserved still work (the buffers grow).  
+extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labels) {
+  if (!c || c->owner) { sq_set_error("sq_ctx_reserve: bad context"); return SQ_ERR_ARG; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_dev* o = c->online; auto& X = o->exp; const size_t M = o->M;
+  uint64_t E = max_classes ? max_classes : 1000000;   // countMap_.reserve(1000000), EquivalenceClassBuilder.hpp:140
+  uint64_t L = max_labels ? max_labels : 6 * E;
+  E = std::min<uint64_t>(E, o->tcap); L = std::min<uint64_t>(L, o->pool_cap);
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
+      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) || X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
+  const size_t need = 32 * E + 24 * L + 64 + 32 * M;
+  if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0;
+    if (hipHostMalloc((void**)&X.host, need, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)", need); return SQ_ERR_NOMEM; } X.host_cap = need; }
+  return sq_em_arena_reserve(&c->em_arena, sq_em_workspace_bytes(E, L, M), (size_t)3 * M * 8, (size_t)(std::max<uint64_t>(E, L / 64 + M) + 1) * 4);
 }

@@ -9,6 +9,7 @@
 // labels, so they are rebuilt here from the final table (members visited in ascending transcript id).
 #include "index.h"
 #include <zlib.h>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -24,11 +25,27 @@
 #include <sys/stat.h>
 
 namespace {
+// Lock-free union-find (the larger root is always linked under the smaller one, so every component ends up rooted at
+// its smallest transcript id whatever the interleaving): classes are united by several threads at once.
 struct DSU {
-  std::vector<uint32_t> p;
-  explicit DSU(uint32_t n) : p(n) { std::iota(p.begin(), p.end(), 0u); }
-  uint32_t root(uint32_t x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
-  void join(uint32_t a, uint32_t b) { a = root(a); b = root(b); if (a == b) return; if (a < b) p[b] = a; else p[a] = b; }
+  std::unique_ptr<std::atomic<uint32_t>[]> p; uint32_t n;
+  explicit DSU(uint32_t n_) : p(new std::atomic<uint32_t>[n_]), n(n_) { for (uint32_t i = 0; i < n; ++i) p[i].store(i, std::memory_order_relaxed); }
+  uint32_t root(uint32_t x) {
+    for (;;) {
+      uint32_t px = p[x].load(std::memory_order_relaxed); if (px == x) return x;
+      uint32_t gp = p[px].load(std::memory_order_relaxed);
+      if (gp != px) p[x].compare_exchange_weak(px, gp, std::memory_order_relaxed);   // path halving; losing the race is harmless
+      x = gp;
+    }
+  }
+  void join(uint32_t a, uint32_t b) {
+    for (;;) {
+      a = root(a); b = root(b); if (a == b) return;
+      if (a > b) std::swap(a, b);
+      uint32_t expect = b;
+      if (p[b].compare_exchange_strong(expect, a, std::memory_order_relaxed)) return;   // b was still a root: now under a
+    }
+  }
 };
 }  // namespace
 
@@ -36,19 +53,34 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
   if (!eq || !log_mass || !uniq || !total || !projected) { sq_set_error("sq_normalize_alphas: bad arguments"); return SQ_ERR_ARG; }
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] normalize %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
-  DSU d(M);
-  for (uint64_t c = 0; c < eq->num_classes; ++c) { const uint64_t a = eq->off[c], b = eq->off[c + 1]; for (uint64_t i = a + 1; i < b; ++i) d.join(eq->tid[a], eq->tid[i]); }
+  const uint32_t nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  DSU d(M); std::atomic<uint32_t> bad{0};
+  sq_parallel_for(eq->num_classes, nthr, 8192, [&](uint64_t c_lo, uint64_t c_hi, uint32_t) {
+    for (uint64_t c = c_lo; c < c_hi; ++c) {
+      const uint64_t a = eq->off[c], b = eq->off[c + 1];
+      for (uint64_t i = a; i < b; ++i) if (eq->tid[i] >= M) { bad.store(eq->tid[i] + 1 ? eq->tid[i] + 1 : 1, std::memory_order_relaxed); goto next; }
+      for (uint64_t i = a + 1; i < b; ++i) d.join(eq->tid[a], eq->tid[i]);
+      next:;
+    }
+  });
+  if (bad.load()) { sq_set_error("sq_normalize_alphas: a label names transcript %u >= %u", bad.load() - 1, M); return SQ_ERR_ARG; }
+  std::vector<uint32_t> rootOf(M);
+  sq_parallel_for(M, nthr, 8192, [&](uint64_t lo, uint64_t hi, uint32_t) { for (uint64_t t = lo; t < hi; ++t) rootOf[t] = d.root((uint32_t)t); });
   mark("union-find");
-  std::vector<double> hits(M, 0.0);
-  for (uint64_t c = 0; c < eq->num_classes; ++c) if (eq->off[c + 1] > eq->off[c]) hits[d.root(eq->tid[eq->off[c]])] += (double)eq->count[c];
+  // hits per cluster: class counts are integers, so the (atomic, any-order) integer sum is the reference's sum exactly
+  std::unique_ptr<std::atomic<uint64_t>[]> hitsI(new std::atomic<uint64_t>[M]);
+  for (uint32_t t = 0; t < M; ++t) hitsI[t].store(0, std::memory_order_relaxed);
+  sq_parallel_for(eq->num_classes, nthr, 8192, [&](uint64_t c_lo, uint64_t c_hi, uint32_t) {
+    for (uint64_t c = c_lo; c < c_hi; ++c) if (eq->off[c + 1] > eq->off[c]) hitsI[rootOf[eq->tid[eq->off[c]]]].fetch_add(eq->count[c], std::memory_order_relaxed);
+  });
+  std::vector<double> hits(M); for (uint32_t t = 0; t < M; ++t) hits[t] = (double)hitsI[t].load(std::memory_order_relaxed);
   // bucket members by root (counting sort keeps ascending tid inside each cluster)
   std::vector<uint32_t> start(M + 1, 0), order(M);
-  for (uint32_t t = 0; t < M; ++t) start[d.root(t) + 1]++;
+  for (uint32_t t = 0; t < M; ++t) start[rootOf[t] + 1]++;
   for (uint32_t r = 0; r < M; ++r) start[r + 1] += start[r];
-  { std::vector<uint32_t> cur(start.begin(), start.end() - 1); for (uint32_t t = 0; t < M; ++t) order[cur[d.root(t)]++] = t; }
+  { std::vector<uint32_t> cur(start.begin(), start.end() - 1); for (uint32_t t = 0; t < M; ++t) order[cur[rootOf[t]]++] = t; }
   mark("bucket");
   // clusters are independent (each writes only its members' projected counts; sums inside a cluster keep their order)
-  const uint32_t nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   sq_parallel_for(M, nthr, 4096, [&](uint64_t r_lo, uint64_t r_hi, uint32_t) {
   std::vector<uint8_t> bound;
   for (uint32_t r = (uint32_t)r_lo; r < (uint32_t)r_hi; ++r) {
