@@ -456,6 +456,7 @@ struct EmSession {
     pt.mark("alloc+upload");
     // combined weights, prior, CSC
     if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes, o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
+    pt.mark("prep:first-launch-returned");
     k_prep_prior<<<nb(M), TB, 0, st>>>(M, d_eff.p, o->vb_prior, o->per_transcript_prior, d_prior.p);
     if (L) {
       k_prep_keys<<<nb(E), TB, 0, st>>>(E, p_off, p_tid, key.p, val.p);
@@ -464,6 +465,7 @@ struct EmSession {
       if (tmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (sort)"); return SQ_ERR_NOMEM; }
       SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st));
       k_prep_csc<<<nb(L), TB, 0, st>>>(L, M, key2.p, val2.p, d_cw.p, d_tcls.p, d_tcw.p, d_toff.p);
+      pt.mark("prep:sort+csc-launched");
     }
     // blocked-64 plan: per-transcript segment counts, exclusive scans, fill
     k_plan_counts<<<nb((uint64_t)M + 1), TB, 0, st>>>(M, d_toff.p, ns[0].p, ns[1].p, ns[2].p, ns[3].p, d_err.p);
