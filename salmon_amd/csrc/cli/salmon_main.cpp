@@ -126,6 +126,7 @@ static int cmd_quant(int argc, char** argv) {
   if (flag(argc, argv, "--discardOrphansQuasi")) qo.allow_orphans = 0;
   if (flag(argc, argv, "--disableChainingHeuristic")) qo.disable_chaining_heuristic = 1;
   sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
+  if (sq_ctx_reserve(ctx, 0, 0)) die("reserving end-of-job buffers");   // the reference pre-sizes its eq-class map the same way (EquivalenceClassBuilder.hpp:140)
   // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
   // the mapping lanes: up to `lanes` batches are in flight (H2D + mapping) while the next one is parsed
   auto split = [](const char* s) { std::vector<std::string> v; std::string cur; for (const char* p = s; ; ++p) { if (*p == ',' || *p == ' ' || !*p) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; } else cur.push_back(*p); } return v; };
