@@ -33,8 +33,8 @@ struct BlockQueue {
   std::unique_ptr<RecBlock> get() { std::unique_lock<std::mutex> lk(mu); cv_get.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return nullptr; auto b = std::move(q.front()); q.pop_front(); cv_put.notify_one(); return b; }
 };
 
-// one mate stream: inflate + split records.  FASTQ (@: 4 lines) and FASTA (>: 2 lines) with single-line
-// sequences, LF or CRLF, blank lines between records tolerated.
+// one mate stream: inflate + split records.  FASTQ and FASTA, sequences and qualities on one or several lines
+// (what the reference's kseq-based parser accepts), LF or CRLF, blank lines between records tolerated.
 void produce(std::vector<std::string> files, BlockQueue* out) {
   const size_t BUF = 4u << 20; std::vector<char> buf(BUF); const uint32_t PER_BLOCK = 16384;
   auto fresh = [&] { auto b = std::make_unique<RecBlock>(); b->seq.reserve((size_t)PER_BLOCK * 128); b->len.reserve(PER_BLOCK); return b; };
@@ -42,19 +42,31 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
   for (const auto& path : files) {
     gzFile f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; }
     gzbuffer(f, 1 << 20);
-    uint64_t have = 0; int state = 0; bool fastq = true; std::string bad;   // state: 0 header, 1 sequence, 2 '+', 3 quality
+    uint64_t have = 0; int state = 0; bool fastq = true; std::string bad;   // state: 0 header, 1 sequence lines, 3 quality lines
+    uint32_t cur_len = 0; uint64_t qual_len = 0;                              // bases of the open record / quality characters seen for it
+    auto close_record = [&] {
+      blk->len.push_back(cur_len); ++have; cur_len = 0; qual_len = 0; state = 0;
+      if (blk->len.size() == PER_BLOCK) { out->put(std::move(blk)); blk = fresh(); }
+    };
+    // kseq-style records: the sequence (and the quality string) may span several lines; a FASTA record ends at the
+    // next '>' line, a FASTQ sequence at the '+' line, a FASTQ record once the quality is as long as the sequence
+    // (so a quality line may begin with '@')
     auto line = [&](const char* ls, size_t ll) {
       if (ll && ls[ll - 1] == '\r') --ll;
+      if (state == 1 && !fastq && ll && ls[0] == '>') close_record();       // falls through to the header branch
       if (state == 0) {
         if (!ll) return;                                   // blank line between records
         if (ls[0] == '@') fastq = true; else if (ls[0] == '>') fastq = false;
         else { bad = "'" + path + "': record " + std::to_string(have + 1) + " does not start with '@' or '>'"; return; }
-        state = 1;
+        state = 1; cur_len = 0; qual_len = 0;
       } else if (state == 1) {
-        blk->seq.insert(blk->seq.end(), ls, ls + ll); blk->len.push_back((uint32_t)ll); ++have; state = fastq ? 2 : 0;
-        if (blk->len.size() == PER_BLOCK) { out->put(std::move(blk)); blk = fresh(); }
-      } else if (state == 2) state = 3;
-      else state = 0;
+        if (fastq && ll && ls[0] == '+') { state = 3; if (cur_len == 0) close_record(); return; }
+        blk->seq.insert(blk->seq.end(), ls, ls + ll); cur_len += (uint32_t)ll;
+      } else {                                             // quality
+        qual_len += ll;
+        if (qual_len > cur_len) { bad = "'" + path + "': record " + std::to_string(have + 1) + " has a quality string longer than its sequence"; return; }
+        if (qual_len == cur_len) close_record();
+      }
     };
     std::vector<char> pend; size_t start = 0;
     for (;;) {
@@ -76,6 +88,7 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
       }
     }
     gzclose(f);
+    if (state == 1 && !fastq) close_record();              // the last FASTA record ends with the file
     if (state != 0) { out->finish("'" + path + "': truncated record at end of file (after " + std::to_string(have) + " records)"); return; }
   }
   if (!blk->len.empty()) out->put(std::move(blk));

@@ -84,3 +84,32 @@ def test_reader_refuses_when_all_slots_busy(built, tmp_path):
     L.sq_reader_release(h, 0)
     assert L.sq_reader_next(h, C.byref(rb), C.byref(s)) == 0 and rb.n == 2
     L.sq_reader_close(h)
+
+
+def test_reader_multi_line_records(built, tmp_path):
+    # kseq-style input: sequences / qualities wrapped over several lines, a quality line that begins with '@',
+    # an empty record, blank lines, a FASTA file that ends without a newline
+    rng = np.random.default_rng(3)
+    recs = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in (150, 61, 60, 1, 0, 250, 120)]
+    def wrap(s, w): return [s[i:i + w] for i in range(0, len(s), w)] or [""]
+    with open(tmp_path / "w.fa", "w") as f:
+        for i, s in enumerate(recs):
+            f.write(">r%d some description\n" % i + "\n".join(wrap(s, 60)) + ("\n\n" if i % 2 else "\n"))
+    with open(tmp_path / "w.fq", "w") as f:
+        for i, s in enumerate(recs):
+            q = ("@" + "I" * (len(s) - 1)) if s else ""
+            f.write("@r%d\n%s\n+r%d\n%s\n" % (i, "\n".join(wrap(s, 50)), i, "\n".join(wrap(q, 50))))
+    open(tmp_path / "e.fa", "w").write(">a\nACGT\nAC\n>b\nGG\nT")
+    for name in ("w.fa", "w.fq"):
+        h = _open([str(tmp_path / name)], None, batch=3); got, err = _drain(h); capi.lib().sq_reader_close(h)
+        assert err is None, err
+        assert [r for b in got for r in b] == [r.encode() for r in recs], name
+    h = _open([str(tmp_path / "e.fa")], None, batch=8); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is None and got == [[b"ACGTAC", b"GGT"]]
+    # quality longer than the sequence / sequence without quality
+    open(tmp_path / "q.fq", "w").write("@r0\nACGT\n+\nIIIII\n")
+    h = _open([str(tmp_path / "q.fq")], None, batch=8); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "quality string longer" in err
+    open(tmp_path / "u.fq", "w").write("@r0\nACGT\n+\nII\n")
+    h = _open([str(tmp_path / "u.fq")], None, batch=8); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "truncated" in err
