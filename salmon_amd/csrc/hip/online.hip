@@ -650,7 +650,7 @@ static int check_eq_overflow(sq_ctx* c) {
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream));   // not the null stream (device-wide implicit sync), not the eq streams (the runtime may still be retiring their thousands of launches)
   mark("streamSync");
   if (cur[2]) { sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]); return SQ_ERR_OVERFLOW; }
-  if (cur[1] * 10 > c->online->tcap * 7) { sq_set_error("equivalence-class table over 70%% full (%llu classes)", cur[1]); return SQ_ERR_OVERFLOW; }
+  if (cur[1] * 10 > c->online->tcap * 7) { sq_set_error("equivalence-class table over 70%% full (%llu classes of %llu slots): call sq_ctx_reserve with the expected number of classes before the first batch", cur[1], (unsigned long long)c->online->tcap); return SQ_ERR_OVERFLOW; }
   return SQ_OK;
 }
 
@@ -1026,7 +1026,20 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
   sq_online_dev* o = c->online; auto& X = o->exp; const size_t M = o->M;
   uint64_t E = max_classes ? max_classes : 1000000;   // countMap_.reserve(1000000), EquivalenceClassBuilder.hpp:140
   uint64_t L = max_labels ? max_labels : 6 * E;
-  E = std::min<uint64_t>(E, o->tcap); L = std::min<uint64_t>(L, o->pool_cap);
+  // the class table itself (open addressing, at most 70 % full; 2^22 slots by default = 2.9 M classes) is sized here too: it can
+  // only be re-made while it is empty — there is no rehash — so a job that expects more classes reserves before its first batch
+  if (E * 10 > o->tcap * 7 || L > o->pool_cap) {
+    { int rs = sq_eq_sync(c); if (rs) return rs; }
+    unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
+    if (cur[1]) { sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1], (unsigned long long)E); return SQ_ERR_STATE; }
+    uint64_t cap = o->tcap; while (E * 10 > cap * 7) cap <<= 1;
+    const uint64_t pcap = std::max<uint64_t>(std::max<uint64_t>(o->pool_cap, cap * 4), L);
+    if (cap >= (1ull << 32) || pcap >= (1ull << 40)) { sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E, (unsigned long long)L); return SQ_ERR_ARG; }
+    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) || o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) { sq_set_error("device allocation failed (class table for %llu classes)", (unsigned long long)E); return SQ_ERR_NOMEM; }
+    o->tcap = cap; o->pool_cap = pcap;
+    SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
+    SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, pcap * 8));
+  }
   if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
       X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) || X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
   const size_t need = 32 * E + 24 * L + 64 + 32 * M;

@@ -360,3 +360,29 @@ def test_limits_capacity_and_long_reads(small_world):
     _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
     assert len(aln_g) > 0 and int(aln_g["read_len"].max()) == 256
     ctx.free()
+
+
+def test_reserved_class_table_and_workspace(small_world):
+    # sq_ctx_reserve: a larger class table (made while empty), pre-sized export buffers and EM workspace; results are
+    # unchanged (canonical class order does not depend on the table size); reserving more once classes exist is refused
+    w = small_world
+    opts = api.quant_opts()
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ctx.reserve(4_000_000, 20_000_000)
+    rb = api.make_read_batch(w["seq"], w["off"], w["n"], paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    with pytest.raises(Exception, match="already holds"):
+        ctx.reserve(12_000_000, 0)
+    lm, uq, tc, le = ctx.model()
+    proj = api.normalize_alphas(eq_g, lm, uq, tc)
+    a1, r1 = ctx.em_optimize(np.exp(le), proj, api.em_opts())          # ctx workspace (arena), lent stream
+    a2, r2 = api.em_optimize(eq_g, np.exp(le), proj, api.em_opts(), device=0)   # private workspace
+    a3, r3 = ctx.em_optimize(np.exp(le), proj, api.em_opts())          # the arena is reused
+    assert r1["iters"] == r2["iters"] == r3["iters"] and np.array_equal(a1, a2) and np.array_equal(a1, a3)
+    ctx.reset(); ctx.reserve(0, 0)                                     # after a reset the table is empty again
+    ctx.free(); ost.free()
