@@ -83,7 +83,9 @@ def main():
     B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len
     opts = api.quant_opts()
     ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
-    ctx.reserve()   # end-of-job buffers (eq-class export, EM workspace) sized like the reference's initial eq-class map (10^6 classes)
+    # end-of-job buffers (eq-class export, EM workspace) sized like the reference's initial eq-class map (10^6 classes); with several
+    # ranks every GPU ends up holding the union of all ranks' classes, so the class table is sized for that
+    ctx.reserve(1000000 * max(1, world // 2), 0)
     # synthetic reads: rank r, step s -> pairs [((r*(K+W))+s)*B, ...), generated on the host, parked in HBM
     dev = torch.device("cuda", local)
     off_np = (np.arange(0, 2 * B + 1, dtype=np.int64) * RL)
