@@ -1042,6 +1042,7 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
   }
   if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
       X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) || X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
+  X.valid = false; X.model_valid = false;   // buffers may have moved: a staged export is made again on its next use
   const size_t need = 32 * E + 24 * L + 64 + 32 * M;
   if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0;
     if (hipHostMalloc((void**)&X.host, need, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)", need); return SQ_ERR_NOMEM; } X.host_cap = need; }
