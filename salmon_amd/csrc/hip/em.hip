@@ -411,7 +411,7 @@ struct EmSession {
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
   EmArena* arena = nullptr; EmArena own_arena;   // arena: borrowed from a ctx (set before setup), else own_arena
-  bool own_stream = true;   // false: `st` was lent by a ctx (set before setup) — a new stream means a new hardware queue, whose first dispatch was seen to stall 15-30 ms
+  bool own_stream = true;   // false: `st` was lent by a ctx (set before setup): no stream / hardware queue is created per session
   ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st && own_stream) (void)hipStreamDestroy(st); if (arena && arena != &own_arena) arena->reset(); }
 
   // eq: host table (uploaded) — or dv: a CSR that already lives on this device
