@@ -1,0 +1,84 @@
+// tools/host_sanitize.cpp — drives the HOST side of the library (index builder + dictionary, read pipeline,
+// normalizeAlphas with its lock-free union-find, the file writers / readers) so that it can be run under
+// AddressSanitizer + UBSan and under ThreadSanitizer:  make -C tools sanitize   (g++ only, no GPU).
+#include "../include/salmon_hip.h"
+#include <zlib.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include <sys/stat.h>
+
+#include "../salmon_amd/csrc/host/index.h"
+// the HIP side (hip/index_dev.hip) is not linked here: host-only stand-ins for its three entry points
+void sq_device_index_free(sq_device_index*) {}
+extern "C" int sq_index_load(const char* dir, int, sq_index** out) { return sq_index_load_host(dir, out); }
+extern "C" void sq_index_free(sq_index* idx) { delete idx; }
+#define CHECK(x) do { if (!(x)) { fprintf(stderr, "FAILED %s:%d: %s  [%s]\n", __FILE__, __LINE__, #x, sq_last_error()); exit(1); } } while (0)
+
+static std::string rnd_seq(std::mt19937_64& g, size_t n) { std::string s(n, 'A'); for (auto& c : s) c = "ACGT"[g() & 3]; return s; }
+
+int main(int argc, char** argv) {
+  const std::string dir = argc > 1 ? argv[1] : "/tmp/sq_host_sanitize"; mkdir(dir.c_str(), 0755);
+  std::mt19937_64 g(12345);
+  // ---- index: transcripts that share exons (branching cDBG), one with a poly-A tail, a duplicate, a short one, two decoys
+  std::vector<std::string> exons; for (int i = 0; i < 60; ++i) exons.push_back(rnd_seq(g, 40 + g() % 400));
+  std::vector<std::string> names, seqs;
+  for (int t = 0; t < 80; ++t) { std::string s; int ne = 2 + (int)(g() % 6); int e = (int)(g() % 50); for (int j = 0; j < ne; ++j) s += exons[(e + j * (1 + (int)(g() % 2))) % exons.size()]; if (t % 7 == 0) s += std::string(30, 'A'); names.push_back("tx" + std::to_string(t)); seqs.push_back(s); }
+  names.push_back("dup"); seqs.push_back(seqs[3]); names.push_back("tiny"); seqs.push_back("ACGTACGTAC");
+  const uint32_t first_decoy = (uint32_t)seqs.size();
+  for (int d = 0; d < 2; ++d) { names.push_back("decoy" + std::to_string(d)); seqs.push_back(rnd_seq(g, 3000) + seqs[5 + d] + rnd_seq(g, 3000)); }
+  std::vector<const char*> np, sp; std::vector<uint32_t> lens; for (size_t i = 0; i < seqs.size(); ++i) { np.push_back(names[i].c_str()); sp.push_back(seqs[i].data()); lens.push_back((uint32_t)seqs[i].size()); }
+  sq_index_opts io; memset(&io, 0, sizeof(io)); io.threads = 4;
+  sq_index* idx = nullptr; CHECK(sq_index_build_mem(&io, (uint32_t)seqs.size(), np.data(), sp.data(), lens.data(), first_decoy, (dir + "/idx").c_str(), &idx) == SQ_OK);
+  sq_index_view v; CHECK(sq_index_get_view(idx, &v) == SQ_OK);
+  // every k-mer of every kept reference must be found, on either strand
+  uint64_t found = 0, tried = 0; const uint32_t k = v.k;
+  for (uint32_t t = 0; t < v.num_refs; ++t) for (uint32_t p = 0; p + k <= v.ref_len[t]; p += 1 + (uint32_t)(g() % 3)) {
+    uint64_t km = 0; for (uint32_t i = 0; i < k; ++i) { const uint64_t q = v.ref_accum[t] + p + i; km |= ((v.refseq[q >> 5] >> ((q & 31) * 2)) & 3ull) << (2 * i); }
+    uint64_t u; uint32_t off; int fw; ++tried; found += sq_index_lookup_host(idx, km, &u, &off, &fw);
+  }
+  CHECK(found == tried && tried > 1000);
+  sq_index* idx2 = nullptr; CHECK(sq_index_load((dir + "/idx").c_str(), -1, &idx2) == SQ_OK); CHECK(sq_index_num_kmers(idx2) == sq_index_num_kmers(idx)); sq_index_free(idx2);
+  const uint32_t M = sq_index_num_refs(idx);
+  // ---- reader: gzip FASTQ pairs + a wrapped FASTA, three batches in flight
+  { gzFile f1 = gzopen((dir + "/r_1.fq.gz").c_str(), "wb"), f2 = gzopen((dir + "/r_2.fq.gz").c_str(), "wb");
+    for (int i = 0; i < 5000; ++i) { std::string a = rnd_seq(g, 50 + g() % 120), b = rnd_seq(g, 50 + g() % 120);
+      gzprintf(f1, "@r%d/1\n%s\n+\n%s\n", i, a.c_str(), std::string(a.size(), 'I').c_str()); gzprintf(f2, "@r%d/2\n%s\n+\n%s\n", i, b.c_str(), std::string(b.size(), 'I').c_str()); }
+    gzclose(f1); gzclose(f2);
+    const char* a1[] = {(dir + "/r_1.fq.gz").c_str()}; std::string p1 = dir + "/r_1.fq.gz", p2 = dir + "/r_2.fq.gz"; const char* q1[] = {p1.c_str()}; const char* q2[] = {p2.c_str()}; (void)a1;
+    sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, q2, 1, 700, 3, &rd) == SQ_OK);
+    uint64_t n = 0, bytes = 0; int held[2] = {-1, -1};
+    for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break; n += b.n; bytes += b.seq_off[2 * b.n];
+      for (uint64_t i = 0; i < b.seq_off[2 * b.n]; i += 97) CHECK(strchr("ACGT", (char)b.seq[i]) != nullptr);
+      if (held[0] >= 0) sq_reader_release(rd, held[0]); held[0] = held[1]; held[1] = slot; }
+    CHECK(n == 5000 && sq_reader_total(rd) == 5000 && bytes > 5000 * 100); sq_reader_close(rd); }
+  // ---- eq classes inside gene-like groups -> normalizeAlphas (parallel union-find), twice, same answer
+  std::vector<uint64_t> off{0}, cnt; std::vector<uint32_t> tid; std::vector<double> w;
+  for (int c = 0; c < 4000; ++c) { uint32_t base = (uint32_t)(g() % (M - 8)); int n = 1 + (int)(g() % 5); std::vector<uint32_t> lab; for (int j = 0; j < n; ++j) lab.push_back(base + (uint32_t)(g() % 8)); std::sort(lab.begin(), lab.end()); lab.erase(std::unique(lab.begin(), lab.end()), lab.end());
+    for (uint32_t t : lab) { tid.push_back(t); w.push_back(1.0 / (double)lab.size()); } off.push_back(tid.size()); cnt.push_back(1 + g() % 300); }
+  sq_eq_table eq; memset(&eq, 0, sizeof(eq)); eq.num_classes = cnt.size(); eq.num_labels = tid.size(); eq.off = off.data(); eq.tid = tid.data(); eq.w = w.data(); eq.count = cnt.data();
+  std::vector<double> lm(M), p1(M), p2(M); std::vector<uint64_t> uq(M), tc(M); std::vector<char> seen(M, 0); for (uint32_t t : tid) seen[t] = 1;
+  for (uint32_t t = 0; t < M; ++t) { lm[t] = seen[t] ? std::log(1e-3 + (double)(g() % 1000)) : HUGE_VAL; tc[t] = g() % 500; uq[t] = tc[t] / 3; }
+  CHECK(sq_normalize_alphas(M, &eq, lm.data(), uq.data(), tc.data(), p1.data()) == SQ_OK); CHECK(sq_normalize_alphas(M, &eq, lm.data(), uq.data(), tc.data(), p2.data()) == SQ_OK);
+  CHECK(memcmp(p1.data(), p2.data(), M * 8) == 0);
+  // ---- writers and the eq-class file round trip
+  std::vector<double> eff(M); for (uint32_t t = 0; t < M; ++t) eff[t] = std::max(1.0, (double)sq_index_ref_len(idx, t) - 200.0);
+  mkdir((dir + "/out").c_str(), 0755); mkdir((dir + "/out/aux_info").c_str(), 0755);
+  CHECK(sq_write_quant_sf((dir + "/out/quant.sf").c_str(), idx, eff.data(), p1.data(), 0.0) == SQ_OK);
+  CHECK(sq_write_eq_classes((dir + "/out/aux_info/eq_classes.txt.gz").c_str(), idx, &eq, 1) == SQ_OK);
+  CHECK(sq_write_ambig_info((dir + "/out/aux_info/ambig_info.tsv").c_str(), M, &eq) == SQ_OK);
+  uint64_t lc[64]; for (auto& x : lc) x = g() % 1000; CHECK(sq_write_lib_format_counts((dir + "/out/lib_format_counts.json").c_str(), "r_1.fq.gz,r_2.fq.gz", 1, 2, 4, lc, 12345, 12000) == SQ_OK);
+  sq_eq_file* ef = nullptr; CHECK(sq_eq_file_read((dir + "/out/aux_info/eq_classes.txt.gz").c_str(), &ef) == SQ_OK); CHECK(sq_eq_file_num_txp(ef) == M);
+  sq_eq_table back; memset(&back, 0, sizeof(back)); CHECK(sq_eq_file_table(ef, &back) == SQ_OK); CHECK(back.num_classes == eq.num_classes && back.num_labels == eq.num_labels && memcmp(back.tid, eq.tid, eq.num_labels * 4) == 0);
+  sq_eq_file_free(ef);
+  std::vector<const char*> nm; for (uint32_t t = 0; t < M; ++t) nm.push_back(sq_index_ref_name(idx, t));
+  sq_boot_writer* bw = nullptr; CHECK(sq_boot_writer_open((dir + "/out/aux_info").c_str(), M, nm.data(), &bw) == SQ_OK); for (int r = 0; r < 5; ++r) CHECK(sq_boot_writer_append(bw, p1.data(), M) == SQ_OK); CHECK(sq_boot_writer_close(bw) == 5);
+  sq_index_free(idx);
+  printf("host sanitize run ok: %u refs, %llu k-mer lookups, 5000 read pairs, %zu classes\n", M, (unsigned long long)tried, cnt.size());
+  return 0;
+}
