@@ -71,3 +71,26 @@ def test_forgetting_mass_recurrence(built):
         i = b + 1
         fm += ff * math.log(i - 1) - math.log(i ** ff - 1)
         assert abs(L.orc_forgetting_mass(ff, b) - fm) < 1e-12
+
+
+def test_effective_lengths_closed_form(small_world):
+    # a13: effLen(len) = len - E[fl | fl <= len] under the (prior) fragment-length law, the value at 1000 for longer
+    # transcripts, `len` itself when that is below 1 (ReadExperiment.inl:62-94, DistributionUtils.cpp:9-55) — evaluated
+    # here with numpy/scipy, independently of the checker's C++
+    from scipy.stats import norm
+    from salmon_amd import api
+    w = small_world
+    st = orc.OrcState(w["oidx"], api.quant_opts()); st.finish()          # no fragments: the FLD is the prior
+    log_eff = st.model()[3]; st.free()
+    i = np.arange(0, 1001)
+    nm = norm.cdf(i + 0.5, 250, 25) - norm.cdf(i - 0.5, 250, 25)
+    hist = np.where(nm != 0, np.log(np.where(nm != 0, nm, 1.0)), math.log(0.375e-10))
+    lp = hist[1:1001] - np.logaddexp.reduce(hist[1:1001])                # dumpPMF over [1, 1000], renormalised
+    pmf = np.zeros(1001); pmf[1:1000] = 100.0 * np.exp(lp[:999])         # i < maxVal: bin 1000 stays 0
+    vals = np.cumsum(pmf * i); mult = np.cumsum(pmf)
+    cf = np.where(mult > 0, vals / np.where(mult > 0, mult, 1.0), 0.0); cf[0] = 0.0
+    lens = w["idx"].ref_lens().astype(np.int64)
+    c = np.where(lens >= 1001, cf[1000], cf[np.minimum(lens, 1000)])
+    eff = lens - c; eff = np.where(eff < 1.0, lens, eff)
+    assert np.allclose(np.exp(log_eff), eff, rtol=1e-9, atol=0)
+    assert np.all(eff[lens > 600] < lens[lens > 600] - 240) and np.all(eff[lens > 600] > lens[lens > 600] - 260)   # ~ len - 250
