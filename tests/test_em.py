@@ -49,6 +49,31 @@ def test_oracle_vbem_matches_scipy_reference(built):
     assert np.allclose(got, alpha, rtol=1e-12, atol=1e-12)
 
 
+def test_oracle_em_matches_numpy_reference(built):
+    # the same for EMUpdate_ (CollapsedEMOptimizer.cpp:178-234): alpha itself in place of expTheta, no prior
+    M, E = 60, 200
+    eq = random_eq_classes(M, E, seed=7)
+    eff = np.random.default_rng(3).uniform(80, 2000, M)
+    o = api.em_opts(init_uniform=1, use_vbem=0)
+    cw = np.zeros(len(eq.tid))
+    for c in range(E):
+        a, b = int(eq.off[c]), int(eq.off[c + 1])
+        x = float(eq.count[c]) * eq.w[a:b] / np.maximum(eff[eq.tid[a:b]], 1.0)
+        cw[a:b] = x / x.sum()
+    alpha = np.full(M, 100.0)
+    for _ in range(4):
+        out = np.zeros(M)
+        for c in range(E):
+            a, b = int(eq.off[c]), int(eq.off[c + 1])
+            if b - a == 1:
+                out[eq.tid[a]] += float(eq.count[c]); continue
+            v = alpha[eq.tid[a:b]] * cw[a:b]
+            if v.sum() > 0: out[eq.tid[a:b]] += float(eq.count[c]) * v / v.sum()
+        alpha = out
+    got = orc.em_steps(eq, eff, np.full(M, 100.0), 4, o)
+    assert np.allclose(got, alpha, rtol=1e-12, atol=1e-12)
+
+
 def test_canonical_sum_is_a_sum(built):
     x = np.random.default_rng(0).uniform(0, 1e6, 70001)
     s = orc.lib().orc_canonical_sum(x.ctypes.data, len(x))
