@@ -486,33 +486,47 @@ __device__ inline int myers_step(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hi
   const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
   uint64_t Ph = Mv | ~(Xh | Pv), Mh = Pv & Xh;
   const int hout = (int)((Ph >> obit) & 1) - (int)((Mh >> obit) & 1);
-  Ph = (Ph << 1) | hpos; Mh = (Mh << 1) | hneg;
-  Pv = Mh | ~(Xv | Ph); Mv = Ph & Xv;
+  Ph = (Ph << 1) | hpos;
+  Mh = (Mh << 1) | hneg;
+  Pv = Mh | ~(Xv | Ph);
+  Mv = Ph & Xv;
   return hout;
 }
+
 // infix alignment of the strand-normalised mate (fw: as read, else reverse complement) inside the window
 // [wstart, wstart + wl) of the 2-bit reference text; SPEC §a5: minimum edit distance <= k, FIRST end among the minima,
 // and for that end the start that the backward prefix pass reports LAST (the longest span).  True if found.
 template <int NW>
-__device__ inline bool infix_align(const ReadView& r, bool fw, const uint64_t* __restrict__ refseq, uint64_t wstart, int wl, int k, int* start, int* end, int* dist = nullptr) {
-  const int n = r.L; const int lastw = (n - 1) >> 6, lastb = (n - 1) & 63;
-  uint64_t E0[NW], E1[NW], E2[NW], E3[NW], Pv[NW], Mv[NW];
+__device__ inline bool infix_align(const ReadView& r, bool fw, const uint64_t* __restrict__ refseq, uint64_t wstart, int wl, int k,
+                                   int* start, int* end, int* dist = nullptr) {
+  const int n = r.L;
+  const int lastw = (n - 1) >> 6, lastb = (n - 1) & 63;
+  uint64_t E0[NW], E1[NW], E2[NW], E3[NW], Pv[NW], Mv[NW];   // match masks of the four bases; vertical +1 / -1 deltas
 #pragma unroll
   for (int w = 0; w < NW; ++w) { E0[w] = E1[w] = E2[w] = E3[w] = 0; Pv[w] = ~0ull; Mv[w] = 0; }
   for (int i = 0; i < n; ++i) {
-    const uint32_t b = norm_base(r, fw, i); const uint64_t bit = 1ull << (i & 63);
+    const uint32_t b = norm_base(r, fw, i);
+    const uint64_t bit = 1ull << (i & 63);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) if (w == (i >> 6)) { if (b == 0) E0[w] |= bit; else if (b == 1) E1[w] |= bit; else if (b == 2) E2[w] |= bit; else if (b == 3) E3[w] |= bit; }
+    for (int w = 0; w < NW; ++w)
+      if (w == (i >> 6)) {
+        if (b == 0) E0[w] |= bit;
+        else if (b == 1) E1[w] |= bit;
+        else if (b == 2) E2[w] |= bit;
+        else if (b == 3) E3[w] |= bit;          // b == 4 (N) stays out of every mask: it matches nothing
+      }
   }
+  // forward pass, infix mode: score = D[n][j], the best alignment of the whole query ending at window column j
   int score = n, best = -1, e0 = -1;
   for (int j = 0; j < wl; ++j) {
     const uint32_t tc = sq_fetch_base(refseq, wstart + (uint64_t)j);
     int h = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) if (w <= lastw) {
-      const uint64_t eq = tc == 0 ? E0[w] : tc == 1 ? E1[w] : tc == 2 ? E2[w] : E3[w];
-      h = myers_step(Pv[w], Mv[w], eq, h, w == lastw ? lastb : 63);
-    }
+    for (int w = 0; w < NW; ++w)
+      if (w <= lastw) {
+        const uint64_t eq = tc == 0 ? E0[w] : tc == 1 ? E1[w] : tc == 2 ? E2[w] : E3[w];
+        h = myers_step(Pv[w], Mv[w], eq, h, w == lastw ? lastb : 63);
+      }
     score += h;
     if (score <= k && (best < 0 || score < best)) { best = score; e0 = j; }
   }
@@ -521,79 +535,109 @@ __device__ inline bool infix_align(const ReadView& r, bool fw, const uint64_t* _
 #pragma unroll
   for (int w = 0; w < NW; ++w) { E0[w] = E1[w] = E2[w] = E3[w] = 0; Pv[w] = ~0ull; Mv[w] = 0; }
   for (int i = 0; i < n; ++i) {
-    const uint32_t b = norm_base(r, fw, n - 1 - i); const uint64_t bit = 1ull << (i & 63);
+    const uint32_t b = norm_base(r, fw, n - 1 - i);
+    const uint64_t bit = 1ull << (i & 63);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) if (w == (i >> 6)) { if (b == 0) E0[w] |= bit; else if (b == 1) E1[w] |= bit; else if (b == 2) E2[w] |= bit; else if (b == 3) E3[w] |= bit; }
+    for (int w = 0; w < NW; ++w)
+      if (w == (i >> 6)) {
+        if (b == 0) E0[w] |= bit;
+        else if (b == 1) E1[w] |= bit;
+        else if (b == 2) E2[w] |= bit;
+        else if (b == 3) E3[w] |= bit;
+      }
   }
   const int m2 = min(e0 + 1, n + best);     // D'[n][j] >= j - n: columns past n + best cannot reach `best`
-  score = n; int jlast = -1;
+  score = n;
+  int jlast = -1;
   for (int j = 1; j <= m2; ++j) {
     const uint32_t tc = sq_fetch_base(refseq, wstart + (uint64_t)(e0 - (j - 1)));
     int h = 1;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) if (w <= lastw) {
-      const uint64_t eq = tc == 0 ? E0[w] : tc == 1 ? E1[w] : tc == 2 ? E2[w] : E3[w];
-      h = myers_step(Pv[w], Mv[w], eq, h, w == lastw ? lastb : 63);
-    }
+    for (int w = 0; w < NW; ++w)
+      if (w <= lastw) {
+        const uint64_t eq = tc == 0 ? E0[w] : tc == 1 ? E1[w] : tc == 2 ? E2[w] : E3[w];
+        h = myers_step(Pv[w], Mv[w], eq, h, w == lastw ? lastb : 63);
+      }
     score += h;
     if (score == best) jlast = j;
   }
   if (jlast < 0) return false;
-  *end = e0; *start = e0 - (jlast - 1); if (dist) *dist = best;
+  *end = e0;
+  *start = e0 - (jlast - 1);
+  if (dist) *dist = best;
   return true;
 }
 
 // parity tap for the aligner alone (sq_debug_infix_align): case i = packed query i against window [toff[i], toff[i+1]) of `text`
-__global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ text,
-                              const uint64_t* __restrict__ toff, const int32_t* __restrict__ kmax, int32_t* __restrict__ out) {
+__global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
+                              const uint64_t* __restrict__ text, const uint64_t* __restrict__ toff, const int32_t* __restrict__ kmax, int32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ncases) return;
   const ReadView r = read_view(rpack, rnmask, rlen, i);
-  int st = -1, en = -1, ed = -1; bool ok = false; const int wl = (int)(toff[i + 1] - toff[i]);
+  int st = -1, en = -1, ed = -1;
+  bool ok = false;
+  const int wl = (int)(toff[i + 1] - toff[i]);
   if (r.L > 0 && wl > 0) {
     if (r.L <= 64) ok = infix_align<1>(r, true, text, toff[i], wl, kmax[i], &st, &en, &ed);
     else if (r.L <= 128) ok = infix_align<2>(r, true, text, toff[i], wl, kmax[i], &st, &en, &ed);
     else ok = infix_align<4>(r, true, text, toff[i], wl, kmax[i], &st, &en, &ed);
   }
-  out[4 * i] = ok ? 1 : 0; out[4 * i + 1] = ok ? ed : -1; out[4 * i + 2] = ok ? st : -1; out[4 * i + 3] = ok ? en : -1;
+  out[4 * i] = ok ? 1 : 0;
+  out[4 * i + 1] = ok ? ed : -1;
+  out[4 * i + 2] = ok ? st : -1;
+  out[4 * i + 3] = ok ? en : -1;
 }
 
 // thread per fragment: orphan-only fragments with at most maxReadOccs candidates look for the missing mate of every
 // anchor.  A recovered mate is written as a chain without MEMs at slab index rec_base + (anchor's chain index) — every
 // chain anchors at most one orphan candidate — and the candidate becomes a proper pair.
 #define SQ_RECOVER_WINDOW 1000
-__global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand, sq_cand_dev* __restrict__ cands,
-                          sq_chain_dev* __restrict__ chains, uint32_t rec_base, unsigned long long* __restrict__ stats) {
+__global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand,
+                          sq_cand_dev* __restrict__ cands, sq_chain_dev* __restrict__ chains, uint32_t rec_base, unsigned long long* __restrict__ stats) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t rescued = 0;
   if (f < nfrag) {
-    const uint32_t nc = n_cand[f]; sq_cand_dev* C = cands + cand_off[f];
-    if (nc && nc <= P.max_read_occs && C[0].pad[0] != 0) {
+    const uint32_t nc = n_cand[f];
+    sq_cand_dev* C = cands + cand_off[f];
+    if (nc && nc <= P.max_read_occs && C[0].pad[0] != 0) {     // orphan-only fragment, not "too many hits" (SalmonQuantify.cpp:1343-1356)
       for (uint32_t i = 0; i < nc; ++i) {
-        const bool left = C[i].pad[0] == 1;
+        const bool left = C[i].pad[0] == 1;                    // the anchor is the left end: look for the right mate
         const uint32_t ai = left ? C[i].lc : C[i].rc;
         const sq_chain_dev an = chains[ai];
         const uint32_t me = 2 * f + (left ? 1u : 0u);
         const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, me);
-        const int ML = r.L; if (ML == 0) continue;
-        const int Tlen = (int)S.ref_len[an.tid]; const uint64_t g = S.ref_accum[an.tid];
-        int ws, wl;
-        if (an.fw) { ws = max(0, an.pos); wl = min(SQ_RECOVER_WINDOW, Tlen - ws); }
-        else { const int endPos = min(Tlen, an.pos + (int)an.read_len); ws = max(0, endPos - SQ_RECOVER_WINDOW); wl = endPos - ws; }
+        const int ML = r.L;
+        if (ML == 0) continue;
+        const int Tlen = (int)S.ref_len[an.tid];
+        const uint64_t g = S.ref_accum[an.tid];
+        int ws, wl;                                            // window on the transcript: downstream of a forward anchor, upstream of a reverse one
+        if (an.fw) {
+          ws = max(0, an.pos);
+          wl = min(SQ_RECOVER_WINDOW, Tlen - ws);
+        } else {
+          const int endPos = min(Tlen, an.pos + (int)an.read_len);
+          ws = max(0, endPos - SQ_RECOVER_WINDOW);
+          wl = endPos - ws;
+        }
         if (wl <= 0) continue;
-        const bool mfw = an.fw == 0;
-        int st = 0, en = 0; bool ok;
+        const bool mfw = an.fw == 0;                           // the mate lies on the other strand
+        int st = 0, en = 0;
+        bool ok;
         if (ML <= 64) ok = infix_align<1>(r, mfw, S.refseq, g + (uint64_t)ws, wl, ML / 4, &st, &en);
         else if (ML <= 128) ok = infix_align<2>(r, mfw, S.refseq, g + (uint64_t)ws, wl, ML / 4, &st, &en);
         else ok = infix_align<4>(r, mfw, S.refseq, g + (uint64_t)ws, wl, ML / 4, &st, &en);
         if (!ok) continue;
         const int mpos = ws + st;
         const int fl = an.fw ? (mpos + ML - an.pos) : (an.pos + (int)an.read_len - mpos);
-        if (fl <= 0 || fl > (int)P.frag_len_max) continue;
-        sq_chain_dev m; m.score = 0.0; m.tid = an.tid; m.pos = mpos; m.last_end = ws + en + 1; m.first = 0; m.n_mems = 0; m.read_len = (uint16_t)ML; m.fw = mfw ? 1 : 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.pad2 = 0;
+        if (fl <= 0 || fl > (int)P.frag_len_max) continue;     // same bound as a joined pair (SPEC §a3)
+        sq_chain_dev m;
+        m.score = 0.0; m.tid = an.tid; m.pos = mpos; m.last_end = ws + en + 1; m.first = 0; m.n_mems = 0;
+        m.read_len = (uint16_t)ML; m.fw = mfw ? 1 : 0; m.pad[0] = m.pad[1] = m.pad[2] = 0; m.pad2 = 0;
         chains[rec_base + ai] = m;
         if (left) C[i].rc = rec_base + ai; else C[i].lc = rec_base + ai;
-        C[i].mate_status = SQ_MS_PAIRED_END_PAIRED; C[i].frag_len = (uint32_t)fl; rescued = 1;
+        C[i].mate_status = SQ_MS_PAIRED_END_PAIRED;
+        C[i].frag_len = (uint32_t)fl;
+        rescued = 1;
       }
     }
   }
