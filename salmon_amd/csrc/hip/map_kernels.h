@@ -76,7 +76,13 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
   if (cnt == 32 && (((uintptr_t)s) & 3) == 0) {
     const uint32_t* s4 = (const uint32_t*)s;
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) { uint32_t v = s4[q]; put(4 * q, v & 0xFF); put(4 * q + 1, (v >> 8) & 0xFF); put(4 * q + 2, (v >> 16) & 0xFF); put(4 * q + 3, v >> 24); }
+    for (uint32_t q = 0; q < 8; ++q) {
+      uint32_t v = s4[q];
+      put(4 * q, v & 0xFF);
+      put(4 * q + 1, (v >> 8) & 0xFF);
+      put(4 * q + 2, (v >> 16) & 0xFF);
+      put(4 * q + 3, v >> 24);
+    }
   } else for (uint32_t i = 0; i < cnt; ++i) put(i, s[i]);
   rpack[(size_t)e * SQ_READ_WORDS + wi] = cw;
   ((uint32_t*)(rnmask + (size_t)e * SQ_NMASK_WORDS))[wi] = cn;
@@ -159,7 +165,12 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             }
             const bool rend = (pos + len >= L);
             const bool uend = !rend && !mism;
-            sq_unimem_dev m; m.unitig = (uint32_t)u; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.fw = (uint8_t)fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
+            sq_unimem_dev m;
+            m.unitig = (uint32_t)u;
+            m.qpos = (uint16_t)pos;
+            m.len = (uint16_t)len;
+            m.fw = (uint8_t)fw;
+            m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
             m.pad[0] = m.pad[1] = m.pad[2] = 0;
             out[nu++] = m;
             uint64_t occ = ctab_off[u + 1] - ctab_off[u];
@@ -176,7 +187,9 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
 }
 
 // val layout: len[0,10) q[10,20) fw[20] tid[32,64)
-__device__ inline uint64_t mem_pack_val(uint32_t tid, uint32_t q, uint32_t len, uint32_t fw) { return ((uint64_t)tid << 32) | ((uint64_t)fw << 20) | ((uint64_t)q << 10) | len; }
+__device__ inline uint64_t mem_pack_val(uint32_t tid, uint32_t q, uint32_t len, uint32_t fw) {
+  return ((uint64_t)tid << 32) | ((uint64_t)fw << 20) | ((uint64_t)q << 10) | len;
+}
 struct MemD { uint32_t tid; int32_t rpos; int32_t q; int32_t len; bool fw; };
 __device__ inline MemD mem_decode(uint64_t key, uint64_t val, const uint64_t* ref_accum) {
   MemD m; m.tid = (uint32_t)(val >> 32); m.fw = (val >> 20) & 1; m.q = (int32_t)((val >> 10) & 1023); m.len = (int32_t)(val & 1023);
@@ -219,7 +232,11 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
                         const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ mval,
                         double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
                         sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
-  __shared__ double s_f[CH_SMALL][CH_TB]; __shared__ int32_t s_r[CH_SMALL][CH_TB]; __shared__ int16_t s_q[CH_SMALL][CH_TB]; __shared__ int16_t s_len[CH_SMALL][CH_TB]; __shared__ int8_t s_p[CH_SMALL][CH_TB];
+  __shared__ double s_f[CH_SMALL][CH_TB];
+  __shared__ int32_t s_r[CH_SMALL][CH_TB];
+  __shared__ int16_t s_q[CH_SMALL][CH_TB];
+  __shared__ int16_t s_len[CH_SMALL][CH_TB];
+  __shared__ int8_t s_p[CH_SMALL][CH_TB];
   const uint32_t tx = threadIdx.x;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = gid < nends;
@@ -234,7 +251,13 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
     const uint32_t gn = g1 - g0;
     if (gn <= CH_SMALL) {
       uint32_t fwbits = 0;
-      for (uint32_t i = 0; i < gn; ++i) { MemD m = mem_decode(mkey[base + g0 + i], mval[base + g0 + i], ref_accum); s_r[i][tx] = m.rpos; s_q[i][tx] = (int16_t)m.q; s_len[i][tx] = (int16_t)m.len; if (m.fw) fwbits |= 1u << i; }
+      for (uint32_t i = 0; i < gn; ++i) {
+        MemD m = mem_decode(mkey[base + g0 + i], mval[base + g0 + i], ref_accum);
+        s_r[i][tx] = m.rpos;
+        s_q[i][tx] = (int16_t)m.q;
+        s_len[i][tx] = (int16_t)m.len;
+        if (m.fw) fwbits |= 1u << i;
+      }
       double best = 0.0;
       for (uint32_t i = 0; i < gn; ++i) {
         const int qi = s_q[i][tx], ri = s_r[i][tx], li = s_len[i][tx]; const bool fwi = (fwbits >> i) & 1;
@@ -256,14 +279,28 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
       uint32_t used = 0, tried = 0;
       for (;;) {
         int bi = -1; double bf = 0.0;
-        for (uint32_t i = 0; i < gn; ++i) { if (((used | tried) >> i) & 1) continue; double fv = s_f[i][tx]; if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; } }
+        for (uint32_t i = 0; i < gn; ++i) {
+          if (((used | tried) >> i) & 1) continue;
+          double fv = s_f[i][tx];
+          if (fv >= thr && (bi < 0 || fv > bf)) {
+            bi = (int)i;
+            bf = fv;
+          }
+        }
         if (bi < 0) break;
         uint32_t mask = 0; bool clash = false;
         for (int x = bi; x >= 0; x = s_p[x][tx]) { if ((used >> x) & 1) { clash = true; break; } mask |= 1u << x; }
         if (clash) { tried |= 1u << bi; continue; }
         used |= mask;
         const int first = __ffs((int)mask) - 1;
-        sq_chain_dev c; c.score = bf; c.tid = tid0; c.pos = s_r[first][tx] - s_q[first][tx]; c.last_end = s_r[bi][tx] + s_len[bi][tx]; c.first = g0; c.n_mems = (uint16_t)__popc(mask); c.read_len = (uint16_t)L;
+        sq_chain_dev c;
+        c.score = bf;
+        c.tid = tid0;
+        c.pos = s_r[first][tx] - s_q[first][tx];
+        c.last_end = s_r[bi][tx] + s_len[bi][tx];
+        c.first = g0;
+        c.n_mems = (uint16_t)__popc(mask);
+        c.read_len = (uint16_t)L;
         c.fw = (fwbits >> bi) & 1; c.pad[0] = 1; c.pad[1] = c.pad[2] = 0; c.pad2 = mask;   // pad[0] = 1: members are the bits of pad2 relative to `first`
         chains[base + nch++] = c;
         if (bf > bestAll) bestAll = bf;
@@ -292,7 +329,15 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
     // accept chain ends by (score desc, index asc); mused: bit0 used, bit1 tried
     for (;;) {
       int bi = -1; double bf = 0.0;
-      for (uint32_t i = g0; i < g1; ++i) { uint8_t fl = mused[base + i]; if (fl) continue; double fv = cf[base + i]; if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; } }
+      for (uint32_t i = g0; i < g1; ++i) {
+        uint8_t fl = mused[base + i];
+        if (fl) continue;
+        double fv = cf[base + i];
+        if (fv >= thr && (bi < 0 || fv > bf)) {
+          bi = (int)i;
+          bf = fv;
+        }
+      }
       if (bi < 0) break;
       bool clash = false;
       for (int x = bi; x >= 0; x = cp[base + x]) if (mused[base + x] & 1) { clash = true; break; }
@@ -301,7 +346,14 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
       for (int x = bi; x >= 0; x = cp[base + x]) { mused[base + x] |= 1; ++cnt; int pr = cp[base + x]; if (pr >= 0) mnext[base + pr] = (uint32_t)x; first = x; }
       MemD m0 = mem_decode(mkey[base + first], mval[base + first], ref_accum);
       MemD ml = mem_decode(mkey[base + bi], mval[base + bi], ref_accum);
-      sq_chain_dev c; c.score = bf; c.tid = tid0; c.pos = m0.rpos - m0.q; c.last_end = ml.rpos + ml.len; c.first = (uint32_t)first; c.n_mems = (uint16_t)cnt; c.read_len = (uint16_t)L;
+      sq_chain_dev c;
+      c.score = bf;
+      c.tid = tid0;
+      c.pos = m0.rpos - m0.q;
+      c.last_end = ml.rpos + ml.len;
+      c.first = (uint32_t)first;
+      c.n_mems = (uint16_t)cnt;
+      c.read_len = (uint16_t)L;
       c.fw = ml.fw; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0;
       chains[base + nch++] = c;
       if (bf > bestAll) bestAll = bf;
@@ -361,7 +413,12 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
     if (ti < tj) { ++i; continue; }
     if (ti > tj) { ++j; continue; }
     uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
-    for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) { int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue; double cov = lc[a].score + rc[b].score; if (cov > best) best = cov; }
+    for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
+      int32_t fl;
+      if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue;
+      double cov = lc[a].score + rc[b].score;
+      if (cov > best) best = cov;
+    }
     i = i1; j = j1;
   }
   *dovetail = dove;
@@ -373,7 +430,13 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
       if (ti > tj) { ++j; continue; }
       uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
       double bt = 0.0; bool d2;
-      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) { int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue; double cov = lc[a].score + rc[b].score; if (cov < thr) continue; if (cov > bt) bt = cov; }
+      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
+        int32_t fl;
+        if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue;
+        double cov = lc[a].score + rc[b].score;
+        if (cov < thr) continue;
+        if (cov > bt) bt = cov;
+      }
       const double pthr = P.post_thr * bt;
       for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
         int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue; double cov = lc[a].score + rc[b].score; if (cov < thr || cov < pthr) continue;
@@ -391,8 +454,20 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
   const double othr = P.orphan_thr * ob;
   // pad[0] remembers which end anchors an orphan candidate (1 left, 2 right): orphan recovery (k_recover) may turn the
   // candidate into a pair, and k_select still needs the two tid-sorted runs (left-anchored, then right-anchored)
-  for (uint32_t a = 0; a < nl; ++a) if (lc[a].score >= othr) { if (FILL) { cand_init(out[cnt], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_PAIRED_END_LEFT); out[cnt].pad[0] = 1; } ++cnt; }
-  for (uint32_t b = 0; b < nr; ++b) if (rc[b].score >= othr) { if (FILL) { cand_init(out[cnt], rc[b].score, rc[b].tid, 0xFFFFFFFFu, rbase + b, 0, SQ_MS_PAIRED_END_RIGHT); out[cnt].pad[0] = 2; } ++cnt; }
+  for (uint32_t a = 0; a < nl; ++a) if (lc[a].score >= othr) {
+    if (FILL) {
+      cand_init(out[cnt], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_PAIRED_END_LEFT);
+      out[cnt].pad[0] = 1;
+    }
+    ++cnt;
+  }
+  for (uint32_t b = 0; b < nr; ++b) if (rc[b].score >= othr) {
+    if (FILL) {
+      cand_init(out[cnt], rc[b].score, rc[b].tid, 0xFFFFFFFFu, rbase + b, 0, SQ_MS_PAIRED_END_RIGHT);
+      out[cnt].pad[0] = 2;
+    }
+    ++cnt;
+  }
   return cnt;
 }
 
@@ -461,7 +536,10 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
   if (mode == 1) {
     uint32_t w = 0;
 #pragma unroll
-    for (int q = 0; q < JP; ++q) if ((uint32_t)q < np && pf[q] != 0xFFFFFFFFu) { cand_init(out[w], pc[q], pt[q], lbase + pa[q], rbase + pb[q], pf[q], SQ_MS_PAIRED_END_PAIRED); ++w; }
+    for (int q = 0; q < JP; ++q) if ((uint32_t)q < np && pf[q] != 0xFFFFFFFFu) {
+      cand_init(out[w], pc[q], pt[q], lbase + pa[q], rbase + pb[q], pf[q], SQ_MS_PAIRED_END_PAIRED);
+      ++w;
+    }
   } else if (mode == 2 || mode == 3) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); }
   else if (mode == 4) { for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END); }
   for (uint32_t i = 0; i < cnt; ++i) cand_frag[start + i] = f;
@@ -664,7 +742,12 @@ __device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir,
     const uint64_t t = sq_fetch_bases(refseq, (uint64_t)(tlo + j), (uint32_t)c);
     const uint64_t x = q ^ t; uint64_t d = (x | (x >> 1)) & 0x5555555555555555ULL;
     // spread the N flags to even bit positions and OR them in
-    uint64_t ns = nn; ns = (ns | (ns << 16)) & 0x0000FFFF0000FFFFULL; ns = (ns | (ns << 8)) & 0x00FF00FF00FF00FFULL; ns = (ns | (ns << 4)) & 0x0F0F0F0F0F0F0F0FULL; ns = (ns | (ns << 2)) & 0x3333333333333333ULL; ns = (ns | (ns << 1)) & 0x5555555555555555ULL;
+    uint64_t ns = nn;
+    ns = (ns | (ns << 16)) & 0x0000FFFF0000FFFFULL;
+    ns = (ns | (ns << 8)) & 0x00FF00FF00FF00FFULL;
+    ns = (ns | (ns << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    ns = (ns | (ns << 2)) & 0x3333333333333333ULL;
+    ns = (ns | (ns << 1)) & 0x5555555555555555ULL;
     mm += __popcll(d | ns);
   }
   return mm;
@@ -689,7 +772,19 @@ __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, co
   if (queue) {
     uint32_t slot = wave_alloc(&S.counters[0]);
     if (slot < S.dpq_cap) {
-      sq_dp_item it; it.cand = cand; it.end = end; it.mode = (uint8_t)mode; it.rc = fw ? 0 : 1; it.pad = 0; it.qstart = qstart; it.qdir = qdir; it.n = n; it.tstart = tstart; it.tdir = tdir; it.tl = tl; it.budget = budget;
+      sq_dp_item it;
+      it.cand = cand;
+      it.end = end;
+      it.mode = (uint8_t)mode;
+      it.rc = fw ? 0 : 1;
+      it.pad = 0;
+      it.qstart = qstart;
+      it.qdir = qdir;
+      it.n = n;
+      it.tstart = tstart;
+      it.tdir = tdir;
+      it.tl = tl;
+      it.budget = budget;
       S.dpq[slot] = it;
     }
   }
@@ -710,7 +805,10 @@ __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S,
     const bool queue = pass == 1;
     const int64_t fast_total = score; const int64_t ub_total = ub_dp;
     if (queue) { score = 0; }
-    int prevQ = 0, prevR = (ch.n_mems == 0) ? ch.pos : 0; bool first = true; const bool by_mask = ch.pad[0] != 0;   // n_mems == 0: recovered mate (SPEC §a5), one extension alignment from its start
+    // n_mems == 0: recovered mate (SPEC §a5), one extension alignment from its start
+    int prevQ = 0, prevR = (ch.n_mems == 0) ? ch.pos : 0;
+    bool first = true;
+    const bool by_mask = ch.pad[0] != 0;
     uint32_t mbits = ch.pad2; uint32_t mi = by_mask ? ch.first + (uint32_t)(__ffs((int)mbits) - 1) : ch.first; int64_t sc_fast = 0; int64_t ub = 0;
     auto region = [&](int mode, int qstart, int qdir, int n, int64_t tstart, int tdir, int tl) {
       int32_t sc;
@@ -879,8 +977,14 @@ __global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_
   const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
   const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
   int32_t ls = SQ_INVALID_SCORE, rs = SQ_INVALID_SCORE;
-  if (hasL) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1)); ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore; }
-  if (hasR) { int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2)); rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore; }
+  if (hasL) {
+    int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1));
+    ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore;
+  }
+  if (hasR) {
+    int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2));
+    rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore;
+  }
   const bool ok = (hasL && hasR) ? (ls != SQ_INVALID_SCORE && rs != SQ_INVALID_SCORE) : ((hasL ? ls : rs) != SQ_INVALID_SCORE);
   c.lscore = ls; c.rscore = rs; c.valid = ok;
   cands[ci] = c;
@@ -926,7 +1030,11 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
     // "recorded" is re-derived on the fly: replaying the running decoy cut-off needs index order, so
     // the prefix maximum of decoy scores is recomputed per run position.
     uint32_t split = nc;
-    if (nc && C[0].pad[0] != 0 && paired) { split = 0; while (split < nc && C[split].pad[0] == 1) ++split; }   // orphan-only fragment: left-anchored run, then right-anchored run
+    // orphan-only fragment: left-anchored run, then right-anchored run
+    if (nc && C[0].pad[0] != 0 && paired) {
+      split = 0;
+      while (split < nc && C[split].pad[0] == 1) ++split;
+    }
     // running decoy maxima at the start of the second run (the first run starts from INVALID)
     int32_t runA = SQ_INVALID_SCORE, runB = SQ_INVALID_SCORE;
     for (uint32_t i = 0; i < split && split < nc; ++i) { const int32_t hs = HS[i]; if (hs > SQ_INVALID_SCORE + 1 && TID[i] >= P.first_decoy && hs > runB) runB = hs; }
@@ -936,10 +1044,28 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
       const uint32_t t = ta < tb ? ta : tb;
       int32_t cur = SQ_INVALID_SCORE; int curi = -1;
       while (ia < split && TID[ia] == t) { const int32_t ds = HS[ia];
-        if (ds > SQ_INVALID_SCORE + 1) { if (t >= P.first_decoy) { if (ds > runA) runA = ds; } else if (ds >= decoy_cut(runA)) { if (curi < 0 || ds > cur || (ds == cur && C[ia].compat)) { cur = ds; curi = (int)ia; } } }
+        if (ds > SQ_INVALID_SCORE + 1) {
+          if (t >= P.first_decoy) {
+            if (ds > runA) runA = ds;
+          } else if (ds >= decoy_cut(runA)) {
+            if (curi < 0 || ds > cur || (ds == cur && C[ia].compat)) {
+              cur = ds;
+              curi = (int)ia;
+            }
+          }
+        }
         ++ia; }
       while (ib < nc && TID[ib] == t) { const int32_t ds = HS[ib];
-        if (ds > SQ_INVALID_SCORE + 1) { if (t >= P.first_decoy) { if (ds > runB) runB = ds; } else if (ds >= decoy_cut(runB)) { if (curi < 0 || ds > cur || (ds == cur && C[ib].compat)) { cur = ds; curi = (int)ib; } } }
+        if (ds > SQ_INVALID_SCORE + 1) {
+          if (t >= P.first_decoy) {
+            if (ds > runB) runB = ds;
+          } else if (ds >= decoy_cut(runB)) {
+            if (curi < 0 || ds > cur || (ds == cur && C[ib].compat)) {
+              cur = ds;
+              curi = (int)ib;
+            }
+          }
+        }
         ++ib; }
       if (curi < 0 || cur < thr) continue;
       const sq_cand_dev c = C[curi]; const int32_t hs = cur;
@@ -949,7 +1075,14 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
       sq_aln a; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
         const sq_chain_dev& l = chains[c.lc]; const sq_chain_dev& rr = chains[c.rc];
-        a.pos = l.pos; a.fwd = l.fw; a.read_len = (uint16_t)n1; a.mate_pos = rr.pos; a.mate_fwd = rr.fw; a.mate_len = (uint16_t)n2; a.score = c.lscore; a.mate_score = c.rscore;
+        a.pos = l.pos;
+        a.fwd = l.fw;
+        a.read_len = (uint16_t)n1;
+        a.mate_pos = rr.pos;
+        a.mate_fwd = rr.fw;
+        a.mate_len = (uint16_t)n2;
+        a.score = c.lscore;
+        a.mate_score = c.rscore;
         int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
         a.format_id = hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len);
       } else {
@@ -961,7 +1094,15 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
       out[na++] = a;
     }
     if (na) {
-      switch (out[0].mate_status) { case SQ_MS_PAIRED_END_PAIRED: mt = SQ_MT_PAIRED_MAPPED; break; case SQ_MS_PAIRED_END_LEFT: mt = SQ_MT_LEFT_ORPHAN; break; case SQ_MS_PAIRED_END_RIGHT: mt = SQ_MT_RIGHT_ORPHAN; break; default: mt = SQ_MT_SINGLE_MAPPED; }
+      switch (out[0].mate_status) {
+        case SQ_MS_PAIRED_END_PAIRED: mt = SQ_MT_PAIRED_MAPPED;
+        break;
+        case SQ_MS_PAIRED_END_LEFT: mt = SQ_MT_LEFT_ORPHAN;
+        break;
+        case SQ_MS_PAIRED_END_RIGHT: mt = SQ_MT_RIGHT_ORPHAN;
+        break;
+        default: mt = SQ_MT_SINGLE_MAPPED;
+      }
     }
   } else if (nc) {
     mt = onlyDecoy ? SQ_MT_DECOY : SQ_MT_UNMAPPED;
