@@ -53,7 +53,12 @@ void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; au
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
 void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
   for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
-extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) { if (!c) return SQ_ERR_ARG; c->prof_on = on != 0; for (sq_ctx* sh : c->shadows) sh->prof_on = c->prof_on; return SQ_OK; }
+extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) {
+  if (!c) return SQ_ERR_ARG;
+  c->prof_on = on != 0;
+  for (sq_ctx* sh : c->shadows) sh->prof_on = c->prof_on;
+  return SQ_OK;
+}
 extern "C" int sq_ctx_num_stages(void) { return SG_NUM; }
 extern "C" const char* sq_ctx_stage_name(int s) { return (s >= 0 && s < SG_NUM) ? kStageNames[s] : nullptr; }
 extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int reset) {
@@ -95,7 +100,18 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
       if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess && hipStreamCreate(&c->stream3) == hipSuccess;
       if (!ok) {
         (void)hipGetLastError();
-        if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; } if (c->stream2) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; } if (c->stream3) { (void)hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
+        if (c->stream) {
+          (void)hipStreamDestroy(c->stream);
+          c->stream = nullptr;
+        }
+        if (c->stream2) {
+          (void)hipStreamDestroy(c->stream2);
+          c->stream2 = nullptr;
+        }
+        if (c->stream3) {
+          (void)hipStreamDestroy(c->stream3);
+          c->stream3 = nullptr;
+        }
         c->eq_cus = 0;
         SQ_HIP_CHECK(hipStreamCreate(&c->stream)); if (!owner) SQ_HIP_CHECK(hipStreamCreate(&c->stream2));
       }
@@ -104,7 +120,10 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     }
     c->eq_stream_cur = c->stream2;
   }
-  for (int b = 0; b < 2; ++b) { SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_map_done[b], hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming)); }
+  for (int b = 0; b < 2; ++b) {
+    SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_map_done[b], hipEventDisableTiming));
+    SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming));
+  }
   const uint32_t nends = 2 * max_batch_reads;
   bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
@@ -125,7 +144,16 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->lane_thread.joinable()) { { std::lock_guard<std::mutex> lk(c->lane_mu); c->lane_stop = true; } c->lane_cv.notify_all(); c->lane_thread.join(); }
-  if (!c->owner) { for (sq_ctx* sh : c->shadows) if (sh->lane_thread.joinable()) { { std::lock_guard<std::mutex> lk(sh->lane_mu); sh->lane_stop = true; } sh->lane_cv.notify_all(); sh->lane_thread.join(); } }
+  if (!c->owner) {
+    for (sq_ctx* sh : c->shadows) if (sh->lane_thread.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(sh->lane_mu);
+        sh->lane_stop = true;
+      }
+      sh->lane_cv.notify_all();
+      sh->lane_thread.join();
+    }
+  }
   if (!c->owner) sq_eq_worker_stop(c);   // drains the queued eq-stage jobs first
   if (!c->owner) { for (sq_ctx* sh : c->shadows) sq_ctx_free(sh); c->shadows.clear(); }
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -134,8 +162,39 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c->owner) sq_online_free(c);
   if (c->em_arena) { sq_em_arena_free(c->em_arena); c->em_arena = nullptr; }
   c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
-  c->mkey.free_(); c->mval.free_(); c->mkey2.free_(); c->mval2.free_(); c->sort_tmp.free_(); c->cf.free_(); c->cp.free_(); c->mnext.free_(); c->mused.free_(); c->wkey.free_(); c->wkey2.free_(); c->wid.free_(); c->perm_ends.free_(); c->perm_frags.free_(); c->chains.free_(); c->chains_d.free_(); c->chain_off.free_(); c->n_chains.free_();
-  c->n_cand.free_(); c->cand_off.free_(); c->cands.free_(); c->cand_frag.free_(); c->hs_arr.free_(); c->tid_arr.free_(); c->dpq.free_(); c->counters.free_(); c->frag_flags.free_(); c->n_aln.free_(); c->aln_off.free_(); c->aln_slots.free_(); c->aln.free_(); c->aln_b1.free_(); c->aln_off_b1.free_();
+  c->mkey.free_();
+  c->mval.free_();
+  c->mkey2.free_();
+  c->mval2.free_();
+  c->sort_tmp.free_();
+  c->cf.free_();
+  c->cp.free_();
+  c->mnext.free_();
+  c->mused.free_();
+  c->wkey.free_();
+  c->wkey2.free_();
+  c->wid.free_();
+  c->perm_ends.free_();
+  c->perm_frags.free_();
+  c->chains.free_();
+  c->chains_d.free_();
+  c->chain_off.free_();
+  c->n_chains.free_();
+  c->n_cand.free_();
+  c->cand_off.free_();
+  c->cands.free_();
+  c->cand_frag.free_();
+  c->hs_arr.free_();
+  c->tid_arr.free_();
+  c->dpq.free_();
+  c->counters.free_();
+  c->frag_flags.free_();
+  c->n_aln.free_();
+  c->aln_off.free_();
+  c->aln_slots.free_();
+  c->aln.free_();
+  c->aln_b1.free_();
+  c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
@@ -162,7 +221,16 @@ static void lane_worker(sq_ctx* c) {
       if (c->lane_q.empty()) return;
       J = c->lane_q.front(); c->lane_q.pop_front(); }
     int rc = sq_map_batch_impl(c, &J->in, J->has_out ? &J->out : nullptr, &J->st);
-    { std::lock_guard<std::mutex> lk(c->lane_mu); J->rc = rc; if (rc) J->err = sq_last_error(); J->n = c->last_n; J->buf = c->last_buf; J->total_aln = c->last_total_aln; J->joint = c->last_joint; J->done = true; }
+    {
+      std::lock_guard<std::mutex> lk(c->lane_mu);
+      J->rc = rc;
+      if (rc) J->err = sq_last_error();
+      J->n = c->last_n;
+      J->buf = c->last_buf;
+      J->total_aln = c->last_total_aln;
+      J->joint = c->last_joint;
+      J->done = true;
+    }
     c->lane_cv_done.notify_all();
   }
 }
@@ -176,8 +244,17 @@ extern "C" int sq_map_submit(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* o
   if (!c || c->owner || !in) { sq_set_error("sq_map_submit: bad arguments"); return SQ_ERR_ARG; }
   if (c->n_lanes == 0) c->n_lanes = std::max(1, std::min(4, getenv("SQ_MAP_LANES") ? atoi(getenv("SQ_MAP_LANES")) : 2));
   const size_t want_lanes = (size_t)c->n_lanes;
-  while (c->shadows.size() + 1 < want_lanes) { sq_ctx* sh = nullptr; int rc = ctx_create_lane(c->idx, &c->opts, c->device, c->max_reads, c, &sh); if (rc) return rc; sh->prof_on = c->prof_on; c->shadows.push_back(sh); }
-  if (c->tickets.size() >= want_lanes) { sq_set_error("sq_map_submit: %zu batches already in flight (one per lane); call sq_map_wait first", c->tickets.size()); return SQ_ERR_STATE; }
+  while (c->shadows.size() + 1 < want_lanes) {
+    sq_ctx* sh = nullptr;
+    int rc = ctx_create_lane(c->idx, &c->opts, c->device, c->max_reads, c, &sh);
+    if (rc) return rc;
+    sh->prof_on = c->prof_on;
+    c->shadows.push_back(sh);
+  }
+  if (c->tickets.size() >= want_lanes) {
+    sq_set_error("sq_map_submit: %zu batches already in flight (one per lane); call sq_map_wait first", c->tickets.size());
+    return SQ_ERR_STATE;
+  }
   sq_ctx* lane = (c->submitted % want_lanes) == 0 ? c : c->shadows[(c->submitted % want_lanes) - 1];
   auto J = std::make_shared<sq_ctx::map_job>(); J->in = *in; if (out) { J->out = *out; J->has_out = true; }
   { std::lock_guard<std::mutex> lk(lane->lane_mu); if (!lane->lane_thread.joinable()) lane->lane_thread = std::thread(lane_worker, lane); lane->lane_q.push_back(J); }
@@ -208,7 +285,16 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   c->have_batch = false;
   struct ActiveGuard { std::atomic<int>& a; explicit ActiveGuard(std::atomic<int>& x) : a(x) { a.fetch_add(1); } ~ActiveGuard() { a.fetch_sub(1); } } active_guard((c->owner ? c->owner : c)->map_active);
   const int buf = c->cur_buf;
-  if (n == 0) { c->last_n = 0; c->last_buf = buf; c->last_paired = paired; c->last_total_aln = 0; c->have_batch = true; if (stats) memset(stats, 0, sizeof(*stats)); if (out && out->read_off) out->read_off[0] = 0; return SQ_OK; }
+  if (n == 0) {
+    c->last_n = 0;
+    c->last_buf = buf;
+    c->last_paired = paired;
+    c->last_total_aln = 0;
+    c->have_batch = true;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (out && out->read_off) out->read_off[0] = 0;
+    return SQ_OK;
+  }
   // ---- stage reads in HBM ----
   const uint8_t* d_seq; const uint64_t* d_seq_off;
   if (in->on_device) { d_seq = in->seq; d_seq_off = in->seq_off; }
@@ -267,7 +353,10 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
   // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
   // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
-  if (total_mems >= (recover ? 0x7FFFFFF0ull : 0xFFFFFFF0ull)) { sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems); return SQ_ERR_OVERFLOW; }
+  if (total_mems >= (recover ? 0x7FFFFFF0ull : 0xFFFFFFF0ull)) {
+    sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems);
+    return SQ_ERR_OVERFLOW;
+  }
   sq_prof_mark(c, SG_CHAIN);
   // single-pass join; candidate blocks come from a global cursor (stats slot reused as the 64-bit cursor)
   uint64_t total_cands = 0;
@@ -295,7 +384,10 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     if ((buf ? c->aln_b1.n : c->aln.n) < CP) SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf]));   // the buffer is about to be reallocated: the eq stage must be done with it
     SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
   }
-  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) { sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands); return SQ_ERR_NOMEM; }
+  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) {
+    sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands);
+    return SQ_ERR_NOMEM;
+  }
   sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
   if (hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
   ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
@@ -334,13 +426,29 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true; c->last_buf = buf; c->cur_buf = buf ^ 1;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
-    stats->num_reads = n; stats->num_mapped_at_least_a_kmer = hst[ST_KMER]; stats->num_with_joint_hits = hst[ST_JOINT]; stats->num_mapped = hst[ST_MAPPED]; stats->num_alignments = hst[ST_ALNS];
-    stats->num_mappings_filtered = hst[ST_MAPFILT]; stats->num_fragments_filtered = hst[ST_FRAGFILT]; stats->num_dovetails = hst[ST_DOVETAIL]; stats->num_decoy_fragments = hst[ST_DECOY];
-    stats->num_seeds = hst[ST_SEEDS]; stats->num_lookups = hst[ST_LOOKUPS]; stats->num_mems = hst[ST_MEMS]; stats->num_chains = hst[ST_CHAINS]; stats->num_candidates = total_cands; stats->num_dp_alignments = hst[ST_DP]; stats->num_orphans_rescued = hst[ST_RESCUED];
+    stats->num_reads = n;
+    stats->num_mapped_at_least_a_kmer = hst[ST_KMER];
+    stats->num_with_joint_hits = hst[ST_JOINT];
+    stats->num_mapped = hst[ST_MAPPED];
+    stats->num_alignments = hst[ST_ALNS];
+    stats->num_mappings_filtered = hst[ST_MAPFILT];
+    stats->num_fragments_filtered = hst[ST_FRAGFILT];
+    stats->num_dovetails = hst[ST_DOVETAIL];
+    stats->num_decoy_fragments = hst[ST_DECOY];
+    stats->num_seeds = hst[ST_SEEDS];
+    stats->num_lookups = hst[ST_LOOKUPS];
+    stats->num_mems = hst[ST_MEMS];
+    stats->num_chains = hst[ST_CHAINS];
+    stats->num_candidates = total_cands;
+    stats->num_dp_alignments = hst[ST_DP];
+    stats->num_orphans_rescued = hst[ST_RESCUED];
   }
   if (out) {
     if (!out->read_off || (!out->aln && total_aln)) { sq_set_error("sq_map_batch: output arrays missing"); return SQ_ERR_ARG; }
-    if (total_aln > out->aln_cap) { sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total_aln, (unsigned long long)out->aln_cap); return SQ_ERR_OVERFLOW; }
+    if (total_aln > out->aln_cap) {
+      sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total_aln, (unsigned long long)out->aln_cap);
+      return SQ_ERR_OVERFLOW;
+    }
     SQ_HIP_CHECK(hipMemcpy(out->read_off, c->aln_off_ptr(buf), (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
     if (total_aln) SQ_HIP_CHECK(hipMemcpy(out->aln, c->aln_ptr(buf), (size_t)total_aln * sizeof(sq_aln), hipMemcpyDeviceToHost));
     if (out->map_type) SQ_HIP_CHECK(hipMemcpy(out->map_type, c->map_type.p, n, hipMemcpyDeviceToHost));
@@ -360,7 +468,11 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
   for (uint32_t i = 0; i < ncases; ++i) {
     const uint64_t n = q_off[i + 1] - q_off[i]; if (n > 256) { sq_set_error("sq_debug_infix_align: query %u longer than 256", i); return SQ_ERR_ARG; }
     rl[i] = (uint16_t)n;
-    for (uint64_t j = 0; j < n; ++j) { const int cd = code(queries[q_off[i] + j]); if (cd > 3) rn[(size_t)i * SQ_NMASK_WORDS + (j >> 6)] |= 1ull << (j & 63); else rp[(size_t)i * SQ_READ_WORDS + (j >> 5)] |= (uint64_t)cd << ((j & 31) * 2); }
+    for (uint64_t j = 0; j < n; ++j) {
+      const int cd = code(queries[q_off[i] + j]);
+      if (cd > 3) rn[(size_t)i * SQ_NMASK_WORDS + (j >> 6)] |= 1ull << (j & 63);
+      else rp[(size_t)i * SQ_READ_WORDS + (j >> 5)] |= (uint64_t)cd << ((j & 31) * 2);
+    }
     toff[i + 1] = toff[i] + (w_off[i + 1] - w_off[i]);
   }
   std::vector<uint64_t> text((size_t)(toff[ncases] >> 5) + 2, 0);
@@ -370,12 +482,28 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
   }
   sq_dbuf<uint64_t> d_rp, d_rn, d_text, d_toff; sq_dbuf<uint16_t> d_rl; sq_dbuf<int32_t> d_k, d_out;
   int rc = SQ_OK;
-  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) || d_out.ensure((size_t)4 * ncases)) { sq_set_error("sq_debug_infix_align: device allocation failed"); rc = SQ_ERR_NOMEM; }
-  auto up = [&](void* d, const void* h, size_t b) { if (rc == SQ_OK && hipMemcpy(d, h, b, hipMemcpyHostToDevice) != hipSuccess) { sq_set_error("sq_debug_infix_align: copy failed"); rc = SQ_ERR_DEVICE; } };
-  up(d_rp.p, rp.data(), rp.size() * 8); up(d_rn.p, rn.data(), rn.size() * 8); up(d_text.p, text.data(), text.size() * 8); up(d_toff.p, toff.data(), toff.size() * 8); up(d_rl.p, rl.data(), (size_t)ncases * 2); up(d_k.p, k, (size_t)ncases * 4);
+  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) || d_out.ensure((size_t)4 * ncases)) {
+    sq_set_error("sq_debug_infix_align: device allocation failed");
+    rc = SQ_ERR_NOMEM;
+  }
+  auto up = [&](void* d, const void* h, size_t b) {
+    if (rc == SQ_OK && hipMemcpy(d, h, b, hipMemcpyHostToDevice) != hipSuccess) {
+      sq_set_error("sq_debug_infix_align: copy failed");
+      rc = SQ_ERR_DEVICE;
+    }
+  };
+  up(d_rp.p, rp.data(), rp.size() * 8);
+  up(d_rn.p, rn.data(), rn.size() * 8);
+  up(d_text.p, text.data(), text.size() * 8);
+  up(d_toff.p, toff.data(), toff.size() * 8);
+  up(d_rl.p, rl.data(), (size_t)ncases * 2);
+  up(d_k.p, k, (size_t)ncases * 4);
   if (rc == SQ_OK) {
     k_infix_cases<<<(ncases + 63) / 64, 64>>>(ncases, d_rp.p, d_rn.p, d_rl.p, d_text.p, d_toff.p, d_k.p, d_out.p);
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_out.p, (size_t)16 * ncases, hipMemcpyDeviceToHost) != hipSuccess) { sq_set_error("sq_debug_infix_align: kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = SQ_ERR_DEVICE; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_out.p, (size_t)16 * ncases, hipMemcpyDeviceToHost) != hipSuccess) {
+      sq_set_error("sq_debug_infix_align: kernel failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = SQ_ERR_DEVICE;
+    }
   }
   d_rp.free_(); d_rn.free_(); d_text.free_(); d_toff.free_(); d_rl.free_(); d_k.free_(); d_out.free_();
   return rc;
@@ -396,25 +524,70 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
     std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * SQ_MAX_UNIMEMS);
     if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p, um.size() * sizeof(sq_unimem_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     uint64_t cnt = 0; sq_unimem* o = (sq_unimem*)buf;
-    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) { if (o && cnt < cap) { const sq_unimem_dev& m = um[(size_t)e * SQ_MAX_UNIMEMS + i]; sq_unimem x; memset(&x, 0, sizeof(x)); x.end = e; x.qpos = m.qpos; x.len = m.len; x.unitig = m.unitig; x.uoff = m.ustart; x.fw = m.fw; o[cnt] = x; } ++cnt; }
+    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) {
+      if (o && cnt < cap) {
+        const sq_unimem_dev& m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
+        sq_unimem x;
+        memset(&x, 0, sizeof(x));
+        x.end = e;
+        x.qpos = m.qpos;
+        x.len = m.len;
+        x.unitig = m.unitig;
+        x.uoff = m.ustart;
+        x.fw = m.fw;
+        o[cnt] = x;
+      }
+      ++cnt;
+    }
     return (int64_t)cnt;
   }
   const uint64_t tm = c->last_total_mems;
   std::vector<uint64_t> key(tm), val(tm);
-  if (tm) { const uint64_t* sk = c->mkey2.p; const uint64_t* sv = c->mval2.p; if (hipMemcpy(key.data(), sk, tm * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(val.data(), sv, tm * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE; }
+  if (tm) {
+    const uint64_t* sk = c->mkey2.p;
+    const uint64_t* sv = c->mval2.p;
+    if (hipMemcpy(key.data(), sk, tm * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(val.data(), sv, tm * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+  }
   if (what == SQ_TAP_MEMS) {
     sq_mem* o = (sq_mem*)buf;
-    for (uint64_t i = 0; i < tm && o && i < cap; ++i) { sq_mem x; memset(&x, 0, sizeof(x)); x.end = (uint32_t)(key[i] >> 40); x.tid = (uint32_t)(val[i] >> 32); x.rpos = (int32_t)((key[i] & ((1ULL << 40) - 1)) - racc[x.tid]); x.qpos = (uint16_t)((val[i] >> 10) & 1023); x.len = (uint16_t)(val[i] & 1023); x.fw = (val[i] >> 20) & 1; o[i] = x; }
+    for (uint64_t i = 0; i < tm && o && i < cap; ++i) {
+      sq_mem x;
+      memset(&x, 0, sizeof(x));
+      x.end = (uint32_t)(key[i] >> 40);
+      x.tid = (uint32_t)(val[i] >> 32);
+      x.rpos = (int32_t)((key[i] & ((1ULL << 40) - 1)) - racc[x.tid]);
+      x.qpos = (uint16_t)((val[i] >> 10) & 1023);
+      x.len = (uint16_t)(val[i] & 1023);
+      x.fw = (val[i] >> 20) & 1;
+      o[i] = x;
+    }
     return (int64_t)tm;
   }
   std::vector<uint32_t> nch(nrec); std::vector<uint64_t> choff(nrec + 1);
   if (nrec && hipMemcpy(nch.data(), c->n_chains.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   choff = moff;   // chains live in per-end slabs that start at mem_off[e]
-  const uint64_t tch = nrec ? std::max<uint64_t>(choff[nrec], c->last_chain_slots) : 0; std::vector<sq_chain_dev> ch(tch);   // recovered mates (k_recover) sit past the MEM-count slabs
+  // recovered mates (k_recover) sit past the MEM-count slabs
+  const uint64_t tch = nrec ? std::max<uint64_t>(choff[nrec], c->last_chain_slots) : 0;
+  std::vector<sq_chain_dev> ch(tch);
   if (tch && hipMemcpy(ch.data(), c->chains.p, tch * sizeof(sq_chain_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   if (what == SQ_TAP_CHAINS) {
     uint64_t cnt = 0; sq_chain* o = (sq_chain*)buf;
-    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nch[e]; ++i) { if (o && cnt < cap) { const sq_chain_dev& d = ch[choff[e] + i]; sq_chain x; memset(&x, 0, sizeof(x)); x.end = e; x.tid = d.tid; x.pos = d.pos; x.last_end = d.last_end; x.fw = d.fw; x.n_mems = d.n_mems; x.score = d.score; o[cnt] = x; } ++cnt; }
+    for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nch[e]; ++i) {
+      if (o && cnt < cap) {
+        const sq_chain_dev& d = ch[choff[e] + i];
+        sq_chain x;
+        memset(&x, 0, sizeof(x));
+        x.end = e;
+        x.tid = d.tid;
+        x.pos = d.pos;
+        x.last_end = d.last_end;
+        x.fw = d.fw;
+        x.n_mems = d.n_mems;
+        x.score = d.score;
+        o[cnt] = x;
+      }
+      ++cnt;
+    }
     return (int64_t)cnt;
   }
   if (what == SQ_TAP_CANDIDATES) {
