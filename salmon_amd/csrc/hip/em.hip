@@ -29,7 +29,12 @@ namespace {
 struct PhaseTimer {
   bool on; std::chrono::steady_clock::time_point t0; const char* tag;
   explicit PhaseTimer(const char* tg) : on(getenv("SQ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), tag(tg) {}
-  void mark(const char* what) { if (!on) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] %s %s %.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+  void mark(const char* what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] %s %s %.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
 };
 
 // ---- SPEC §D2 canonical sum: 64-wide strided-halving tree, applied level by level -------------
@@ -140,11 +145,19 @@ __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restri
   if (e1 > e0) {
     uint32_t t[CL_CHUNK / CL_TB]; double w[CL_CHUNK / CL_TB], h[CL_CHUNK / CL_TB];
 #pragma unroll
-    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; const uint64_t q = p < e1 ? p : e1 - 1; t[j] = d.tid[q]; w[j] = d.cw[q]; }
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) {
+      const uint64_t p = e0 + j * CL_TB + threadIdx.x;
+      const uint64_t q = p < e1 ? p : e1 - 1;
+      t[j] = d.tid[q];
+      w[j] = d.cw[q];
+    }
 #pragma unroll
     for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta[t[j]];
 #pragma unroll
-    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; if (p < e1) s_term[p - e0] = (!d.use_vbem || h[j] > 0.0) ? h[j] * w[j] : 0.0; }
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) {
+      const uint64_t p = e0 + j * CL_TB + threadIdx.x;
+      if (p < e1) s_term[p - e0] = (!d.use_vbem || h[j] > 0.0) ? h[j] * w[j] : 0.0;
+    }
   }
   __syncthreads();
   for (uint32_t c = c0 + threadIdx.x; c < c1; c += CL_TB) {
@@ -174,7 +187,13 @@ __global__ void __launch_bounds__(L1_TB) k_l1(EmDev d, const double* __restrict_
   uint32_t tt = 0, lo = 0, n = 0;
   uint32_t c[L1_CHUNK / L1_TB]; double w[L1_CHUNK / L1_TB], iv[L1_CHUNK / L1_TB]; uint8_t sg[L1_CHUNK / L1_TB];
 #pragma unroll
-  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) { const uint32_t p = e0 + j * L1_TB + threadIdx.x; const uint32_t q = p < e1 ? p : e1 - 1; c[j] = d.t_cls[q]; w[j] = d.t_cw[q]; sg[j] = d.t_seg8[q]; }
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) {
+    const uint32_t p = e0 + j * L1_TB + threadIdx.x;
+    const uint32_t q = p < e1 ? p : e1 - 1;
+    c[j] = d.t_cls[q];
+    w[j] = d.t_cw[q];
+    sg[j] = d.t_seg8[q];
+  }
   if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; s_th[threadIdx.x] = theta[tt & ~SEG_TOP]; }
 #pragma unroll
   for (int j = 0; j < L1_CHUNK / L1_TB; ++j) iv[j] = d.inv[c[j]];
@@ -245,7 +264,11 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
       if (rel > d.tol) bad = 1;
     }
   }
-  if (partials) { double ls = wave_halving_sum(leaf); if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls; }  // level 1 of next iteration's canonical sum
+  // level 1 of next iteration's canonical sum
+  if (partials) {
+    double ls = wave_halving_sum(leaf);
+    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls;
+  }
   for (int s = 32; s >= 1; s >>= 1) { double o = __shfl_down(rel, s, 64); int ob = __shfl_down(bad, s, 64); rel = o > rel ? o : rel; bad |= ob; }
   // block-level combine, then one atomic per block only when it can raise the running maximum
   __shared__ double srel[16]; __shared__ int sbad[16];
@@ -253,7 +276,10 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) { for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; } }
   if (threadIdx.x == 0) {
-    if (rel >= 0.0) { unsigned long long b = (unsigned long long)__double_as_longlong(rel); if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b); }
+    if (rel >= 0.0) {
+      unsigned long long b = (unsigned long long)__double_as_longlong(rel);
+      if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b);
+    }
     if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -303,7 +329,10 @@ struct DBuf {
     if (tl_arena) { p = (T*)tl_arena->take(bytes); owned = false; return p ? 0 : -1; }
     owned = true; return hipMalloc((void**)&p, bytes) == hipSuccess ? 0 : -1;
   }
-  int upload(const std::vector<T>& v) { if (alloc(v.size())) return -1; return v.empty() || hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+  int upload(const std::vector<T>& v) {
+    if (alloc(v.size())) return -1;
+    return v.empty() || hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+  }
 };
 
 double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used for init / final sum)
@@ -374,7 +403,11 @@ __global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_
   const uint32_t n = lvl == 0 ? (uint32_t)(t_off[t + 1] - t_off[t]) : ns_prev[t];
   const uint32_t lo = lvl == 0 ? (uint32_t)t_off[t] : base_prev[t];
   const uint32_t first = base[t];
-  for (uint32_t j = 0; j < k; ++j) { seg_lo[first + j] = lo + 64 * j; seg_cnt[first + j] = (uint8_t)min(64u, n - 64 * j); seg_txp[first + j] = t | (k == 1 ? SEG_TOP : 0u); }
+  for (uint32_t j = 0; j < k; ++j) {
+    seg_lo[first + j] = lo + 64 * j;
+    seg_cnt[first + j] = (uint8_t)min(64u, n - 64 * j);
+    seg_txp[first + j] = t | (k == 1 ? SEG_TOP : 0u);
+  }
 }
 // greedy block packing as a jump table: nxt[g] = first unit of the block after the one starting at g
 // (a block takes units while its entries stay <= cap and, optionally, its unit count <= maxu)
@@ -406,13 +439,22 @@ __global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, con
 struct EmSession {
   typedef sq_eq_dev_csr EqDevCsr;
   uint32_t M = 0, E = 0; uint64_t L = 0; uint32_t g1 = 0; const sq_em_opts* o = nullptr; EmDev d;
-  DBuf<uint64_t> d_off, d_toff, d_cntu; DBuf<uint32_t> d_tid, d_tcls, d_flags; DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part; DBuf<unsigned long long> d_maxrel, d_log; DBuf<double> d_lognorm;
+  DBuf<uint64_t> d_off, d_toff, d_cntu;
+  DBuf<uint32_t> d_tid, d_tcls, d_flags;
+  DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part;
+  DBuf<unsigned long long> d_maxrel, d_log;
+  DBuf<double> d_lognorm;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
   EmArena* arena = nullptr; EmArena own_arena;   // arena: borrowed from a ctx (set before setup), else own_arena
   bool own_stream = true;   // false: `st` was lent by a ctx (set before setup): no stream / hardware queue is created per session
-  ~EmSession() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (st && own_stream) (void)hipStreamDestroy(st); if (arena && arena != &own_arena) arena->reset(); }
+  ~EmSession() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st && own_stream) (void)hipStreamDestroy(st);
+    if (arena && arena != &own_arena) arena->reset();
+  }
 
   // eq: host table (uploaded) — or dv: a CSR that already lives on this device
   int setup(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, const EqDevCsr* dv = nullptr) {
@@ -422,7 +464,10 @@ struct EmSession {
   }
   int setup_impl(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, const EqDevCsr* dv) {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+      sq_set_error("no HIP device %d (found %d): EM has no CPU fallback", device, ndev);
+      return SQ_ERR_DEVICE;
+    }
     SQ_HIP_CHECK(hipSetDevice(device));
     o = opts;
     PhaseTimer pt("em.setup");
@@ -438,9 +483,14 @@ struct EmSession {
     const uint64_t* p_off; const uint32_t* p_tid; const double* p_w; const unsigned long long* p_cnt;
     if (dv) { p_off = dv->off; p_tid = dv->tid; p_w = dv->w; p_cnt = dv->cnt; }
     else {
-      if (d_off.alloc((size_t)E + 1) || d_tid.alloc(L) || d_w.alloc(L) || d_cntu.alloc(E)) { sq_set_error("device allocation failed in EM (inputs)"); return SQ_ERR_NOMEM; }
-      SQ_HIP_CHECK(hipMemcpyAsync(d_off.p, eq->off, ((size_t)E + 1) * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(d_tid.p, eq->tid, L * 4, hipMemcpyHostToDevice, st));
-      SQ_HIP_CHECK(hipMemcpyAsync(d_w.p, eq->w, L * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(d_cntu.p, eq->count, (size_t)E * 8, hipMemcpyHostToDevice, st));
+      if (d_off.alloc((size_t)E + 1) || d_tid.alloc(L) || d_w.alloc(L) || d_cntu.alloc(E)) {
+        sq_set_error("device allocation failed in EM (inputs)");
+        return SQ_ERR_NOMEM;
+      }
+      SQ_HIP_CHECK(hipMemcpyAsync(d_off.p, eq->off, ((size_t)E + 1) * 8, hipMemcpyHostToDevice, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(d_tid.p, eq->tid, L * 4, hipMemcpyHostToDevice, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(d_w.p, eq->w, L * 8, hipMemcpyHostToDevice, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(d_cntu.p, eq->count, (size_t)E * 8, hipMemcpyHostToDevice, st));
       p_off = d_off.p; p_tid = d_tid.p; p_w = d_w.p; p_cnt = (const unsigned long long*)d_cntu.p;
     }
     DBuf<unsigned long long> key, key2; DBuf<uint32_t> val, val2, ns[4], base[4], d_err, nxt; DBuf<uint8_t> tmp;
@@ -484,7 +534,10 @@ struct EmSession {
     }
     for (int l = 0; l < 4; ++l) {
       const size_t n = d.nseg[l];
-      if (d_slo[l].alloc(n + 1) || d_stx[l].alloc(n + 1) || d_scn[l].alloc(n + 1) || d_lpart[l].alloc(n + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      if (d_slo[l].alloc(n + 1) || d_stx[l].alloc(n + 1) || d_scn[l].alloc(n + 1) || d_lpart[l].alloc(n + 1)) {
+        sq_set_error("device allocation failed in EM plan");
+        return SQ_ERR_NOMEM;
+      }
       if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p, d_slo[l].p, d_scn[l].p, d_stx[l].p);
     }
     // block plans (greedy packing = following a jump table; the chain has ~L/2048 links)
@@ -513,7 +566,14 @@ struct EmSession {
     }
     SQ_HIP_CHECK(hipStreamSynchronize(st));
     d.M = M; d.E = E; d.L = L; d.off = p_off; d.tid = p_tid; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
-    d.prior = d_prior.p; d.theta = d_theta.p; d.inv = d_inv.p; d.partial = d_part.p; d.flags = d_flags.p; d.maxrel = d_maxrel.p; d.tol = o->rel_diff_tolerance; d.use_vbem = o->use_vbem;
+    d.prior = d_prior.p;
+    d.theta = d_theta.p;
+    d.inv = d_inv.p;
+    d.partial = d_part.p;
+    d.flags = d_flags.p;
+    d.maxrel = d_maxrel.p;
+    d.tol = o->rel_diff_tolerance;
+    d.use_vbem = o->use_vbem;
     for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.part[l] = d_lpart[l].p; }
     d.cchunk = d_cchunk.p; d.ncchunks = h_cchunk.size() > 1 ? (uint32_t)h_cchunk.size() - 1 : 0;
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
@@ -530,7 +590,9 @@ struct EmSession {
       if (h_stage) { memcpy(h_stage + M, alpha.data(), (size_t)M * 8); SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, h_stage + M, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
       else SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
     }
-    SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st)); SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
     d.min_iter = (mode == 0) ? min_iter : 0xFFFFFFFFu;
     double* cur = d_a0.p; double* nxt = d_a1.p;
     // level-1 partials of (alpha + prior) live in d.partial (written by k_fin); k_top finishes the
@@ -577,7 +639,11 @@ struct EmSession {
     float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     result_dev = (executed % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed` swaps starting from d_a0
     if (fetch) {
-      if (h_stage) { SQ_HIP_CHECK(hipMemcpyAsync(h_stage + 2 * (size_t)M, result_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st)); memcpy(alpha.data(), h_stage + 2 * (size_t)M, (size_t)M * 8); }
+      if (h_stage) {
+        SQ_HIP_CHECK(hipMemcpyAsync(h_stage + 2 * (size_t)M, result_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+        SQ_HIP_CHECK(hipStreamSynchronize(st));
+        memcpy(alpha.data(), h_stage + 2 * (size_t)M, (size_t)M * 8);
+      }
       else SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
     }
     unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
@@ -650,12 +716,18 @@ __global__ void k_gibbs_alpha(GibbsDev g, double scale, double* __restrict__ out
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
   double v = (g.mu[i] * g.eff[i]) * scale; out[i] = v > 1e-8 ? v : 0.0;
 }
-__global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) o[i] = a[i] * b[i]; }
+__global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] * b[i];
+}
 
 }  // namespace
 
 extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
-  if (!eq || !txp || !o || !alpha_out || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_em_optimize_dev: bad arguments"); return SQ_ERR_ARG; }
+  if (!eq || !txp || !o || !alpha_out || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
+    sq_set_error("sq_em_optimize_dev: bad arguments");
+    return SQ_ERR_ARG;
+  }
   return sq_em_optimize_impl(device, eq, nullptr, txp, o, alpha_out, rep, nullptr, nullptr);
 }
 
@@ -670,7 +742,10 @@ int sq_em_arena_reserve(void** slot, size_t bytes, size_t pinned_bytes, size_t p
   return SQ_OK;
 }
 void sq_em_arena_free(void* slot) { delete (EmArena*)slot; }
-size_t sq_em_workspace_bytes(uint64_t E, uint64_t L, uint64_t M) { return (size_t)(46 * L + 17 * (L / 64 + M) + 24 * E + 128 * M + ((size_t)16 << 20)); }   // the allocations of EmSession::setup_impl, rounded up
+// the allocations of EmSession::setup_impl, rounded up
+size_t sq_em_workspace_bytes(uint64_t E, uint64_t L, uint64_t M) {
+  return (size_t)(46 * L + 17 * (L / 64 + M) + 24 * E + 128 * M + ((size_t)16 << 20));
+}
 
 int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep, void** arena_slot, void* lent_stream) {
   if (arena_slot && !*arena_slot) *arena_slot = new EmArena();
@@ -712,7 +787,12 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
   if (nact == 0 || total == 0) { sq_set_error("It seems that no transcripts are expressed; something is likely wrong!"); return SQ_ERR_STATE; }   // :598-602
   const double scale = 1.0 / (double)nact, totalNumFrags = (double)num_mapped;
   std::vector<double> init(M), alpha(M); for (uint32_t i = 0; i < M; ++i) init[i] = active[i] ? scale * totalNumFrags : 0.0;   // :605-606
-  DBuf<uint64_t> d_cum; DBuf<unsigned long long> d_samp; if (d_cum.upload(cum) || d_samp.alloc(E)) { sq_set_error("device allocation failed (bootstrap)"); return SQ_ERR_NOMEM; }
+  DBuf<uint64_t> d_cum;
+  DBuf<unsigned long long> d_samp;
+  if (d_cum.upload(cum) || d_samp.alloc(E)) {
+    sq_set_error("device allocation failed (bootstrap)");
+    return SQ_ERR_NOMEM;
+  }
   const int TB = 256;
   for (uint32_t b = 0; b < B; ++b) {
     SQ_HIP_CHECK(hipMemsetAsync(d_samp.p, 0, (size_t)E * 8, S.st));
@@ -730,8 +810,15 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
 }
 
 extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S_n, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
-  if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_gibbs_dev: bad arguments"); return SQ_ERR_ARG; }
-  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { sq_set_error("no HIP device %d (found %d): Gibbs has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
+  if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
+    sq_set_error("sq_gibbs_dev: bad arguments");
+    return SQ_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    sq_set_error("no HIP device %d (found %d): Gibbs has no CPU fallback", device, ndev);
+    return SQ_ERR_DEVICE;
+  }
   SQ_HIP_CHECK(hipSetDevice(device));
   const uint32_t M = txp->num_txp; const uint32_t E = (uint32_t)eq->num_classes; const uint64_t L = eq->num_labels;
   // prior (CollapsedGibbsSampler.cpp:357-371): 1e-3 per transcript after EM; under VB max(vbPrior,1) per transcript or max(vbPrior,1e-3) per nucleotide
@@ -740,14 +827,33 @@ extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* 
   std::vector<double> prior(M, pv); if (!perTxp) for (uint32_t i = 0; i < M; ++i) prior[i] = pv * txp->eff_len[i];
   std::vector<uint8_t> active(M, 0); for (uint64_t i = 0; i < L; ++i) active[eq->tid[i]] = 1;
   std::vector<double> init(alpha_init, alpha_init + M); for (uint32_t i = 0; i < M; ++i) if (!active[i]) init[i] = 0.0;
-  std::vector<uint64_t> off(eq->off, eq->off + E + 1), cnt(eq->count, eq->count + E), draw_off(E + 1, 0); std::vector<uint32_t> tid(eq->tid, eq->tid + L); std::vector<double> w(eq->w, eq->w + L), eff(txp->eff_len, txp->eff_len + M);
+  std::vector<uint64_t> off(eq->off, eq->off + E + 1), cnt(eq->count, eq->count + E), draw_off(E + 1, 0);
+  std::vector<uint32_t> tid(eq->tid, eq->tid + L);
+  std::vector<double> w(eq->w, eq->w + L), eff(txp->eff_len, txp->eff_len + M);
   std::vector<uint32_t> item_cls, item_s0;
   for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; uint64_t n = off[c + 1] - off[c]; if (n == 0 || cnt[c] == 0) continue;
     if (n == 1) { item_cls.push_back(c); item_s0.push_back(0); } else for (uint64_t s0 = 0; s0 < cnt[c]; s0 += 256) { item_cls.push_back(c); item_s0.push_back((uint32_t)s0); } }
-  DBuf<uint64_t> d_off, d_cnt, d_doff; DBuf<uint32_t> d_tid, d_ic, d_is; DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me; DBuf<uint8_t> d_act; DBuf<unsigned long long> d_ci;
+  DBuf<uint64_t> d_off, d_cnt, d_doff;
+  DBuf<uint32_t> d_tid, d_ic, d_is;
+  DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me;
+  DBuf<uint8_t> d_act;
+  DBuf<unsigned long long> d_ci;
   if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) || d_is.upload(item_s0) || d_w.upload(w) || d_eff.upload(eff) || d_prior.upload(prior) ||
       d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) || d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
-  GibbsDev g; g.M = M; g.E = E; g.off = d_off.p; g.tid = d_tid.p; g.w = d_w.p; g.cnt = d_cnt.p; g.eff = d_eff.p; g.prior = d_prior.p; g.active = d_act.p; g.mu = d_mu.p; g.count_f = d_cf.p; g.count_i = d_ci.p; g.draw_off = d_doff.p;
+  GibbsDev g;
+  g.M = M;
+  g.E = E;
+  g.off = d_off.p;
+  g.tid = d_tid.p;
+  g.w = d_w.p;
+  g.cnt = d_cnt.p;
+  g.eff = d_eff.p;
+  g.prior = d_prior.p;
+  g.active = d_act.p;
+  g.mu = d_mu.p;
+  g.count_f = d_cf.p;
+  g.count_i = d_ci.p;
+  g.draw_off = d_doff.p;
   uint32_t nchains = 1; if (S_n >= 50) nchains = 2; if (S_n >= 100) nchains = 4; if (S_n >= 200) nchains = 8;    // :425-434
   const uint32_t step = nchains > 1 ? S_n / nchains : S_n + 1;
   const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16; const int TB = 256; const uint32_t nitems = (uint32_t)item_cls.size();

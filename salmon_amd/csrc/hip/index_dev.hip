@@ -22,7 +22,10 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
   if (!idx || device < 0) { sq_set_error("sq_index_to_device: bad arguments"); return SQ_ERR_ARG; }
   if (idx->dev && idx->dev->device == device) return SQ_OK;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { sq_set_error("no HIP device %d (found %d): the mapping/EM path has no CPU fallback", device, ndev); return SQ_ERR_DEVICE; }
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) {
+    sq_set_error("no HIP device %d (found %d): the mapping/EM path has no CPU fallback", device, ndev);
+    return SQ_ERR_DEVICE;
+  }
   SQ_HIP_CHECK(hipSetDevice(device));
   if (idx->dev) { sq_device_index_free(idx->dev); idx->dev = nullptr; }
   sq_device_index* d = new sq_device_index(); d->device = device;

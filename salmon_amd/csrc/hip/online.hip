@@ -25,19 +25,47 @@ struct sq_online_dev {
   // model
   sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
   sq_dbuf<uint32_t> touched, touched_n;   // transcripts whose mass changed in the current mini-batch: two lists (mini-batch parity), [2*M] + [2]
-  sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts; sq_dbuf<uint32_t> fld_cnt; sq_dbuf<unsigned long long> ctr;  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
+  // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
+  sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts;
+  sq_dbuf<uint32_t> fld_cnt;
+  sq_dbuf<unsigned long long> ctr;
   // per big batch
-  sq_dbuf<uint8_t> has_compat; struct PreAln; sq_dbuf<uint8_t> pre; sq_dbuf<double> alp; sq_dbuf<uint32_t> assigned_flag; sq_dbuf<uint64_t> assigned_prefix; sq_dbuf<unsigned long long> awq; sq_dbuf<uint32_t> abin; sq_dbuf<uint64_t> rh1, rh2; sq_dbuf<uint32_t> rslot; sq_dbuf<uint8_t> scan_tmp;
+  sq_dbuf<uint8_t> has_compat;
+  struct PreAln;
+  sq_dbuf<uint8_t> pre;
+  sq_dbuf<double> alp;
+  sq_dbuf<uint32_t> assigned_flag;
+  sq_dbuf<uint64_t> assigned_prefix;
+  sq_dbuf<unsigned long long> awq;
+  sq_dbuf<uint32_t> abin;
+  sq_dbuf<uint64_t> rh1, rh2;
+  sq_dbuf<uint32_t> rslot;
+  sq_dbuf<uint8_t> scan_tmp;
   // eq table
-  uint64_t tcap = 0; sq_dbuf<unsigned long long> tk1, tk2, tcount, tpool; sq_dbuf<uint32_t> tn; sq_dbuf<uint32_t> pool_tid, pool_bin; sq_dbuf<unsigned long long> pool_wq; sq_dbuf<unsigned long long> pool_cursor;  // [0] labels used, [1] classes, [2] overflow flag
+  // [0] labels used, [1] classes, [2] overflow flag
+  uint64_t tcap = 0;
+  sq_dbuf<unsigned long long> tk1, tk2, tcount, tpool;
+  sq_dbuf<uint32_t> tn;
+  sq_dbuf<uint32_t> pool_tid, pool_bin;
+  sq_dbuf<unsigned long long> pool_wq;
+  sq_dbuf<unsigned long long> pool_cursor;
   uint64_t pool_cap = 0;
   // export of the table in canonical order: persistent device buffers + a pinned host staging area.  The export
   // (kernels + D2H) runs back to back with the end of the eq stage on the first sq_eq_finish call; the second call
   // (caller's arrays now allocated) is a host copy.  Touching the GPU again after the short idle gap in between
   // was measured to stall 20-35 ms on MI355X (first dispatch after heavy load + ~2 ms idle).
   struct eq_export {
-    sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr; sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie; sq_dbuf<uint64_t> d_off; sq_dbuf<double> d_w; sq_dbuf<uint8_t> tmp;
-    uint8_t* host = nullptr; size_t host_cap = 0; uint64_t E = 0, L = 0; bool valid = false, model_valid = false; size_t model_off = 0;   // staged model summary (mass, uniq, total, logEffLen) at host + model_off
+    sq_dbuf<unsigned long long> keys, keys2, d_wq, d_cnt, d_h1, d_h2, d_ctr;
+    sq_dbuf<uint32_t> slots, slots2, nlab, d_tid, d_bins, d_tie;
+    sq_dbuf<uint64_t> d_off;
+    sq_dbuf<double> d_w;
+    sq_dbuf<uint8_t> tmp;
+    // staged model summary (mass, uniq, total, logEffLen) at host + model_off
+    uint8_t* host = nullptr;
+    size_t host_cap = 0;
+    uint64_t E = 0, L = 0;
+    bool valid = false, model_valid = false;
+    size_t model_off = 0;
     void release() { keys.free_(); keys2.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_ctr.free_(); slots.free_(); slots2.free_(); nlab.free_(); d_tid.free_(); d_bins.free_(); d_tie.free_(); d_off.free_(); d_w.free_(); tmp.free_();
                      if (host) (void)hipHostFree(host); host = nullptr; host_cap = 0; valid = false; }
   } exp;
@@ -90,7 +118,14 @@ __global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, 
   if (r > n) return;
   if (r == n) { flag[n] = 0; return; }
   uint32_t f = 0;
-  for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; ++i) { const sq_aln a = aln[i]; bool c = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status); if (c || !o.ignore_incompat) { f = 1; break; } }
+  for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; ++i) {
+    const sq_aln a = aln[i];
+    bool c = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
+    if (c || !o.ignore_incompat) {
+      f = 1;
+      break;
+    }
+  }
   flag[r] = f;
 }
 
@@ -120,7 +155,10 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
   const bool isCompat = is_compatible(a.format_id, o.lib_type, o.lib_orientation, o.lib_strand, a.fwd, a.mate_status);
   if (isCompat) p.flags |= PF_COMPAT;
   if (isCompat || !o.ignore_incompat) p.flags |= PF_KEEP;
-  if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction) { p.flags |= PF_PE_START; p.c_start = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON; }
+  if (a.mate_status == SQ_MS_PAIRED_END_PAIRED && !o.no_length_correction) {
+    p.flags |= PF_PE_START;
+    p.c_start = ((double)flen <= refLength) ? -sq_log(refLength - (double)flen + 1.0) : SQ_LOG_EPSILON;
+  }
   else p.c_start = sq_log((double)rl);   // log(RefLength); the mini-batch negates it or uses the cached effective length
   const bool singleEnd = (o.lib_type == 0);
   const bool unexpectedOrphan = (o.lib_type == 1 && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
@@ -182,7 +220,11 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     if (p.flen > 0 && o.use_frag_len_dist && cond) {
       const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
       const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
-      if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flen < V.ref_len[t] || (V.ref_len[t] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+      if (burned) {
+        double cm = V.ccmf[fi];
+        bool ok = (p.flen < V.ref_len[t] || (V.ref_len[t] == 0 && p.flen < 1)) && !(cm == SQ_LOG_0);
+        logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON;
+      }
       else if (useAux) logFragProb = lenProb;
     }
     const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
@@ -220,7 +262,13 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     atomicAdd(&V.total[t], 1ULL);
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
-      if (rr < pr) { uint32_t fl = pre[ai].fl_ped; if (fl > 0) { atomicAdd(&V.fld_cnt[fl], 1u); if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl); } }
+      if (rr < pr) {
+        uint32_t fl = pre[ai].fl_ped;
+        if (fl > 0) {
+          atomicAdd(&V.fld_cnt[fl], 1u);
+          if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl);
+        }
+      }
     }
     abin[ai] = bin;   // kept alignments now carry their bin id (< 0xFFFFFFFF)
     if (ki == 0) firstTid = t;
@@ -275,7 +323,9 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             const uint32_t tt = p.tid; t[sl] = tt;
             double logFragProb = 0.0;
             if (p.flags & PF_ORPHAN_MODEL) {
-              const bool useFLD = singleEnd || burned; const double* tab = useFLD ? (cached ? V.ccmf : V.ambig + 1024) : V.ambig;   // FLD::cmf live (uncached) / LogCMFCache table
+              // FLD::cmf live (uncached) / LogCMFCache table
+              const bool useFLD = singleEnd || burned;
+              const double* tab = useFLD ? (cached ? V.ccmf : V.ambig + 1024) : V.ambig;
               double refCM = tab[p.tl]; bool cm = !(refCM == SQ_LOG_0);
               logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
             } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
@@ -288,7 +338,10 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
             double startPosProb;
             if (p.flags & PF_PE_START) startPosProb = p.c_start;
-            else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[tt]); startPosProb = -logRefLength; }
+            else {
+              double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[tt]);
+              startPosProb = -logRefLength;
+            }
             fmtBit[sl] = 1ULL << p.fmt;
             auxProb[sl] = logFragProb + p.c_cov + logCompat;
             logProb[sl] = V.tlc[tt] + auxProb[sl] + startPosProb;
@@ -329,7 +382,10 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             atomicAdd(&V.total[t[sl]], 1ULL);
             if (!burned) {
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
-              if (rr < pr && fl_ped[sl] > 0) { atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u); if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped[sl]); }
+              if (rr < pr && fl_ped[sl] > 0) {
+                atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u);
+                if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped[sl]);
+              }
             }
           }
           abin[ai] = bin[sl];
@@ -362,8 +418,17 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   }
   // library-format counts: one atomic per (wave, format)
   uint64_t any = fmtSeen; for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s, 64);
-  while (any) { int f = __ffsll((long long)any) - 1; any &= any - 1; unsigned long long m = __ballot((fmtSeen >> f) & 1); if ((threadIdx.x & 63) == 0) atomicAdd(&V.lib_counts[f], (unsigned long long)__popcll(m)); }
-  { const unsigned long long m = __ballot(compatFrag); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&V.ctr[5], (unsigned long long)__popcll(m)); }   // numCompatibleFragments (:811-815)
+  while (any) {
+    int f = __ffsll((long long)any) - 1;
+    any &= any - 1;
+    unsigned long long m = __ballot((fmtSeen >> f) & 1);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&V.lib_counts[f], (unsigned long long)__popcll(m));
+  }
+  // numCompatibleFragments (:811-815)
+  {
+    const unsigned long long m = __ballot(compatFrag);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&V.ctr[5], (unsigned long long)__popcll(m));
+  }
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -395,7 +460,13 @@ __device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_
     for (int b = tid; b < 1024; b += AP_TB) {
       double h = (b <= 1000) ? V.hist[b] : SQ_LOG_0;
       if (b >= 1 && b <= 1000) {
-        for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000) continue; uint32_t c = cnt[len]; if (!c) continue; h = sq_log_add(h, logFM + kern[i] + sq_log((double)c)); }
+        for (int i = 4; i >= 0; --i) {
+          int len = b + 2 - i;
+          if (len < 0 || len > 1000) continue;
+          uint32_t c = cnt[len];
+          if (!c) continue;
+          h = sq_log_add(h, logFM + kern[i] + sq_log((double)c));
+        }
         V.hist[b] = h;
       }
       v[b] = h;
@@ -492,7 +563,11 @@ __global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ a
     unsigned long long off = atomicAdd(&T.cursor[0], (unsigned long long)nk); atomicAdd(&T.cursor[1], 1ULL);
     if (off + nk > T.pool_cap) { T.cursor[2] = 2; T.n[slot] = 0; T.pool[slot] = 0; return; }
     uint32_t i = 0;
-    for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) { T.pool_tid[off + i] = aln[ai].tid; T.pool_bin[off + i] = bins_on ? abin[ai] : 0; ++i; }
+    for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) {
+      T.pool_tid[off + i] = aln[ai].tid;
+      T.pool_bin[off + i] = bins_on ? abin[ai] : 0;
+      ++i;
+    }
     T.n[slot] = nk; T.pool[slot] = off;
   }
 }
@@ -549,7 +624,11 @@ __global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, ui
   unsigned long long base = 0;
   if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(counter, (unsigned long long)__popcll(m));
   base = __shfl(base, 0, 64);
-  if (occ) { uint64_t i = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1)); keys[i] = ((unsigned long long)T.pool_tid[T.pool[s]] << 32) | (T.k1[s] >> 32); slots[i] = (uint32_t)s; }
+  if (occ) {
+    uint64_t i = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1));
+    keys[i] = ((unsigned long long)T.pool_tid[T.pool[s]] << 32) | (T.k1[s] >> 32);
+    slots[i] = (uint32_t)s;
+  }
 }
 __global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab, uint32_t* __restrict__ tie) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,17 +648,53 @@ __global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ s
   count[c] = T.count[s]; h1[c] = T.k1[s]; h2[c] = T.k2[s];
   double sum = 0.0; for (uint32_t i = 0; i < n; ++i) sum += sq_from_fixed(T.pool_wq[po + i], SQ_WFRAC_BITS);
   const double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
-  for (uint32_t i = 0; i < n; ++i) { unsigned long long q = T.pool_wq[po + i]; tid[p + i] = T.pool_tid[po + i]; bins[p + i] = T.pool_bin[po + i]; wq[p + i] = q; w[p + i] = sq_from_fixed(q, SQ_WFRAC_BITS) * norm; }
+  for (uint32_t i = 0; i < n; ++i) {
+    unsigned long long q = T.pool_wq[po + i];
+    tid[p + i] = T.pool_tid[po + i];
+    bins[p + i] = T.pool_bin[po + i];
+    wq[p + i] = q;
+    w[p + i] = sq_from_fixed(q, SQ_WFRAC_BITS) * norm;
+  }
 }
 
 OnlineView make_view(sq_ctx* c) {
   sq_online_dev* o = c->online; OnlineView V;
-  V.M = o->M; V.ref_len = c->di->ref_len; V.ref_clen = c->di->ref_clen; V.tlc = o->tlc.p; V.hist = o->hist.p; V.cpmf = o->cpmf.p; V.ccmf = o->ccmf.p; V.ambig = o->ambig.p; V.mass = o->mass.p; V.prior_mass = o->prior_mass.p;
-  V.log_eff_len = o->log_eff_len.p; V.scal = o->scal.p; V.cfac = o->cfac.p; V.mass_acc = o->mass_acc.p; V.uniq = o->uniq.p; V.total = o->total.p; V.lib_counts = o->lib_counts.p; V.fld_cnt = o->fld_cnt.p; V.ctr = o->ctr.p; V.touched = o->touched.p; V.touched_n = o->touched_n.p;
+  V.M = o->M;
+  V.ref_len = c->di->ref_len;
+  V.ref_clen = c->di->ref_clen;
+  V.tlc = o->tlc.p;
+  V.hist = o->hist.p;
+  V.cpmf = o->cpmf.p;
+  V.ccmf = o->ccmf.p;
+  V.ambig = o->ambig.p;
+  V.mass = o->mass.p;
+  V.prior_mass = o->prior_mass.p;
+  V.log_eff_len = o->log_eff_len.p;
+  V.scal = o->scal.p;
+  V.cfac = o->cfac.p;
+  V.mass_acc = o->mass_acc.p;
+  V.uniq = o->uniq.p;
+  V.total = o->total.p;
+  V.lib_counts = o->lib_counts.p;
+  V.fld_cnt = o->fld_cnt.p;
+  V.ctr = o->ctr.p;
+  V.touched = o->touched.p;
+  V.touched_n = o->touched_n.p;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
-  EqView T; T.cap = o->tcap; T.k1 = o->tk1.p; T.k2 = o->tk2.p; T.count = o->tcount.p; T.pool = o->tpool.p; T.n = o->tn.p; T.pool_tid = o->pool_tid.p; T.pool_bin = o->pool_bin.p; T.pool_wq = o->pool_wq.p; T.cursor = o->pool_cursor.p; T.pool_cap = o->pool_cap;
+  EqView T;
+  T.cap = o->tcap;
+  T.k1 = o->tk1.p;
+  T.k2 = o->tk2.p;
+  T.count = o->tcount.p;
+  T.pool = o->tpool.p;
+  T.n = o->tn.p;
+  T.pool_tid = o->pool_tid.p;
+  T.pool_bin = o->pool_bin.p;
+  T.pool_wq = o->pool_wq.p;
+  T.cursor = o->pool_cursor.p;
+  T.pool_cap = o->pool_cap;
   return T;
 }
 double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
@@ -605,30 +720,84 @@ int sq_online_create(sq_ctx* c) {
   }
   { std::vector<double> v(1024, SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
     tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
-  { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambig[j] = cum; } }  // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
+  // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
+  {
+    double cum = SQ_LOG_0;
+    for (int j = 0; j <= 1000; ++j) {
+      cum = sq_log_add(cum, SQ_LOG_EPSILON);
+      ambig[j] = cum;
+    }
+  }
   // ambig[1024..]: FragmentLengthDistribution::cmf(len) before cacheCMF (:143-158) — the sequential log-sum prefix of the
   // histogram minus its total mass.  Only single-end libraries read it (useFLD before burn-in), and they never add
   // fragment lengths to the histogram, so the prior's table is the live one.
   { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, hist[j]); ambig[1024 + j] = cum - tot0; } }
-  for (uint32_t t = 0; t < M; ++t) { double len = (double)c->idx->ref_len[t]; pm[t] = sq_log(0.005 * len); le[t] = sq_log(len); }  // Transcript.hpp:48-56; alpha = 0.005 (ReadExperiment.inl:114)
+  // Transcript.hpp:48-56; alpha = 0.005 (ReadExperiment.inl:114)
+  for (uint32_t t = 0; t < M; ++t) {
+    double len = (double)c->idx->ref_len[t];
+    pm[t] = sq_log(0.005 * len);
+    le[t] = sq_log(len);
+  }
   SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
-  SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior
   SQ_HIP_CHECK(hipMemset(o->touched_n.p, 0, 8));
   SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8)); SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4)); SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
-  SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
+  SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8));
+  SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8));
+  SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8));
+  SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
   SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, o->pool_cap * 8)); SQ_HIP_CHECK(hipMemset(o->pool_cursor.p, 0, 4 * 8));
   return SQ_OK;
 }
 
 void sq_online_free(sq_ctx* c) {
   sq_online_dev* o = c->online; if (!o) return;
-  o->hist.free_(); o->cpmf.free_(); o->ccmf.free_(); o->ambig.free_(); o->mass.free_(); o->prior_mass.free_(); o->log_eff_len.free_(); o->tlc.free_(); o->pre.free_(); o->alp.free_(); o->fm_table.free_(); o->cfac.free_(); o->scal.free_();
-  o->exp.release(); o->merge_slot.free_(); o->touched.free_(); o->touched_n.free_(); o->mass_acc.free_(); o->uniq.free_(); o->total.free_(); o->lib_counts.free_(); o->fld_cnt.free_(); o->ctr.free_(); o->has_compat.free_(); o->assigned_flag.free_(); o->assigned_prefix.free_(); o->awq.free_(); o->abin.free_();
-  o->rh1.free_(); o->rh2.free_(); o->rslot.free_(); o->scan_tmp.free_(); o->tk1.free_(); o->tk2.free_(); o->tcount.free_(); o->tpool.free_(); o->tn.free_(); o->pool_tid.free_(); o->pool_bin.free_(); o->pool_wq.free_(); o->pool_cursor.free_();
+  o->hist.free_();
+  o->cpmf.free_();
+  o->ccmf.free_();
+  o->ambig.free_();
+  o->mass.free_();
+  o->prior_mass.free_();
+  o->log_eff_len.free_();
+  o->tlc.free_();
+  o->pre.free_();
+  o->alp.free_();
+  o->fm_table.free_();
+  o->cfac.free_();
+  o->scal.free_();
+  o->exp.release();
+  o->merge_slot.free_();
+  o->touched.free_();
+  o->touched_n.free_();
+  o->mass_acc.free_();
+  o->uniq.free_();
+  o->total.free_();
+  o->lib_counts.free_();
+  o->fld_cnt.free_();
+  o->ctr.free_();
+  o->has_compat.free_();
+  o->assigned_flag.free_();
+  o->assigned_prefix.free_();
+  o->awq.free_();
+  o->abin.free_();
+  o->rh1.free_();
+  o->rh2.free_();
+  o->rslot.free_();
+  o->scan_tmp.free_();
+  o->tk1.free_();
+  o->tk2.free_();
+  o->tcount.free_();
+  o->tpool.free_();
+  o->tn.free_();
+  o->pool_tid.free_();
+  o->pool_bin.free_();
+  o->pool_wq.free_();
+  o->pool_cursor.free_();
   delete o; c->online = nullptr;
 }
 
@@ -644,13 +813,24 @@ static double forgetting_mass(sq_online_dev* o, double ff, uint64_t b) {  // For
 static int check_eq_overflow(sq_ctx* c) {
   unsigned long long cur[4];
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] ovf %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] ovf %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
+    tm0 = t1;
+  };
   SQ_HIP_CHECK(hipMemcpyAsync(cur, c->online->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, c->stream));
   mark("memcpyAsync");
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream));   // not the null stream (device-wide implicit sync), not the eq streams (the runtime may still be retiring their thousands of launches)
   mark("streamSync");
-  if (cur[2]) { sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]); return SQ_ERR_OVERFLOW; }
-  if (cur[1] * 10 > c->online->tcap * 7) { sq_set_error("equivalence-class table over 70%% full (%llu classes of %llu slots): call sq_ctx_reserve with the expected number of classes before the first batch", cur[1], (unsigned long long)c->online->tcap); return SQ_ERR_OVERFLOW; }
+  if (cur[2]) {
+    sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]);
+    return SQ_ERR_OVERFLOW;
+  }
+  if (cur[1] * 10 > c->online->tcap * 7) {
+    sq_set_error("equivalence-class table over 70%% full (%llu classes of %llu slots): call sq_ctx_reserve with the expected number of classes before the first batch", cur[1], (unsigned long long)c->online->tcap);
+    return SQ_ERR_OVERFLOW;
+  }
   return SQ_OK;
 }
 
@@ -662,7 +842,12 @@ void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id) {
 int sq_eq_sync(sq_ctx* c) {
   if (!c || !c->stream2) return SQ_OK;
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_sync %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] eq_sync %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
+    tm0 = t1;
+  };
   { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= c->eq_submitted; }); }
   mark("worker");
   SQ_HIP_CHECK(hipSetDevice(c->device));
@@ -674,7 +859,16 @@ int sq_eq_sync(sq_ctx* c) {
   for (sq_ctx* sh : c->shadows) sh->eq_pending[0] = sh->eq_pending[1] = false;
   sq_prof_end(c, 1);
   mark("prof");
-  { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_err) { int e = c->eq_err; sq_set_error("%s", c->eq_errmsg.c_str()); c->eq_err = 0; c->eq_errmsg.clear(); return e; } }
+  {
+    std::lock_guard<std::mutex> lk(c->eq_mu);
+    if (c->eq_err) {
+      int e = c->eq_err;
+      sq_set_error("%s", c->eq_errmsg.c_str());
+      c->eq_err = 0;
+      c->eq_errmsg.clear();
+      return e;
+    }
+  }
   int rc = check_eq_overflow(c);
   mark("overflow-check");
   return rc;
@@ -721,7 +915,12 @@ extern "C" int sq_eq_accumulate(sq_ctx* c) {
 static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t n = J.n; const sq_quant_opts& q = c->opts;
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_job %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] eq_job %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
+    tm0 = t1;
+  };
   if (c->stream3) {   // CU partition on: use the CU-masked stream only while a mapping batch is (about to be) in flight
     // give the caller ~200 us to enter the next sq_map_batch (sleep_for has ~50 us granularity: poll instead)
     for (auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200); !c->map_active.load() && std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
@@ -734,7 +933,10 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   const uint64_t last_total_aln = J.total_aln;
   SQ_HIP_CHECK(hipStreamWaitEvent(st, src->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)last_total_aln + 8;
-  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
+  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) {
+    sq_set_error("device allocation failed (online scratch)");
+    return SQ_ERR_NOMEM;
+  }
   OnlineView V = make_view(c);
   mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
@@ -805,7 +1007,11 @@ extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
-  out->num_observed = c->online->num_observed; out->num_assigned = hctr[0]; out->num_mapped_ub = c->online->num_mapped_ub; out->burned_in = hctr[1] != 0; out->num_compatible = hctr[5];
+  out->num_observed = c->online->num_observed;
+  out->num_assigned = hctr[0];
+  out->num_mapped_ub = c->online->num_mapped_ub;
+  out->burned_in = hctr[1] != 0;
+  out->num_compatible = hctr[5];
   return SQ_OK;
 }
 
@@ -865,7 +1071,12 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
 // device-side export into o->exp (see sq_online_dev::eq_export)
 static int eq_export_run(sq_ctx* c) {
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] eq_export %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] eq_export %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
+    tm0 = t1;
+  };
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   mark("sync");
   SQ_HIP_CHECK(hipSetDevice(c->device));
@@ -946,7 +1157,14 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   struct Seg { uint8_t* dst; const uint8_t* src; size_t n; };
   std::vector<Seg> segs; const uint8_t* h = X.host;
   auto add = [&](void* dst, size_t n) { if (dst && n) segs.push_back({(uint8_t*)dst, h, n}); h += n; };
-  add(out->off, (E + 1) * 8); add(out->count, E * 8); add(out->h1, E * 8); add(out->h2, E * 8); add(out->wq, L * 8); add(out->w, L * 8); add(out->tid, L * 4); add(out->bins, L * 4);
+  add(out->off, (E + 1) * 8);
+  add(out->count, E * 8);
+  add(out->h1, E * 8);
+  add(out->h2, E * 8);
+  add(out->wq, L * 8);
+  add(out->w, L * 8);
+  add(out->tid, L * 4);
+  add(out->bins, L * 4);
   std::vector<Seg> chunks; const size_t CH = 4u << 20;
   for (auto& sg : segs) for (size_t p = 0; p < sg.n; p += CH) chunks.push_back({sg.dst + p, sg.src + p, std::min(CH, sg.n - p)});
   std::atomic<size_t> next{0};
@@ -960,7 +1178,10 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
 
 // merge a table whose arrays already live on this ctx's device (e.g. gathered over RCCL straight into HBM)
 extern "C" int sq_eq_merge_device(sq_ctx* c, const sq_eq_table* t) {
-  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge_device: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
+  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) {
+    sq_set_error("sq_eq_merge_device: table must carry off/tid/wq/count/h1/h2");
+    return SQ_ERR_ARG;
+  }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   const uint64_t E = t->num_classes; if (E == 0) return SQ_OK;
   { int rs = sq_eq_sync(c); if (rs) return rs; }
@@ -975,15 +1196,33 @@ extern "C" int sq_eq_merge_device(sq_ctx* c, const sq_eq_table* t) {
 }
 
 extern "C" int sq_eq_merge(sq_ctx* c, const sq_eq_table* t) {
-  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) { sq_set_error("sq_eq_merge: table must carry off/tid/wq/count/h1/h2"); return SQ_ERR_ARG; }
+  if (!c || !t || !t->off || !t->tid || !t->wq || !t->count || !t->h1 || !t->h2) {
+    sq_set_error("sq_eq_merge: table must carry off/tid/wq/count/h1/h2");
+    return SQ_ERR_ARG;
+  }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   const uint64_t E = t->num_classes, L = t->num_labels; if (E == 0) return SQ_OK;
   sq_dbuf<uint64_t> d_off, d_wq, d_cnt, d_h1, d_h2; sq_dbuf<uint32_t> d_tid, d_bins;
-  if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L)) { sq_set_error("device allocation failed (eq merge)"); return SQ_ERR_NOMEM; }
-  SQ_HIP_CHECK(hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice));
-  SQ_HIP_CHECK(hipMemcpy(d_h1.p, t->h1, E * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_h2.p, t->h2, E * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(d_tid.p, t->tid, L * 4, hipMemcpyHostToDevice));
+  if (d_off.ensure(E + 1) || d_wq.ensure(L) || d_cnt.ensure(E) || d_h1.ensure(E) || d_h2.ensure(E) || d_tid.ensure(L) || d_bins.ensure(L)) {
+    sq_set_error("device allocation failed (eq merge)");
+    return SQ_ERR_NOMEM;
+  }
+  SQ_HIP_CHECK(hipMemcpy(d_off.p, t->off, (E + 1) * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_wq.p, t->wq, L * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_cnt.p, t->count, E * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_h1.p, t->h1, E * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_h2.p, t->h2, E * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(d_tid.p, t->tid, L * 4, hipMemcpyHostToDevice));
   if (t->bins) SQ_HIP_CHECK(hipMemcpy(d_bins.p, t->bins, L * 4, hipMemcpyHostToDevice));
-  sq_eq_table dt = *t; dt.off = d_off.p; dt.wq = d_wq.p; dt.count = d_cnt.p; dt.h1 = d_h1.p; dt.h2 = d_h2.p; dt.tid = d_tid.p; dt.bins = t->bins ? d_bins.p : nullptr; dt.w = nullptr;
+  sq_eq_table dt = *t;
+  dt.off = d_off.p;
+  dt.wq = d_wq.p;
+  dt.count = d_cnt.p;
+  dt.h1 = d_h1.p;
+  dt.h2 = d_h2.p;
+  dt.tid = d_tid.p;
+  dt.bins = t->bins ? d_bins.p : nullptr;
+  dt.w = nullptr;
   int rc = sq_eq_merge_device(c, &dt);
   d_off.free_(); d_wq.free_(); d_cnt.free_(); d_h1.free_(); d_h2.free_(); d_tid.free_(); d_bins.free_();
   return rc;
@@ -995,7 +1234,16 @@ extern "C" int sq_eq_export_device(sq_ctx* c, sq_eq_table* out) {
   auto& X = c->online->exp;
   if (!X.valid) { int rc = eq_export_run(c); if (rc) return rc; }
   memset(out, 0, sizeof(*out)); out->num_classes = X.E; out->num_labels = X.L;
-  if (X.E) { out->off = X.d_off.p; out->tid = X.d_tid.p; out->w = X.d_w.p; out->wq = (uint64_t*)X.d_wq.p; out->count = (uint64_t*)X.d_cnt.p; out->bins = X.d_bins.p; out->h1 = (uint64_t*)X.d_h1.p; out->h2 = (uint64_t*)X.d_h2.p; }
+  if (X.E) {
+    out->off = X.d_off.p;
+    out->tid = X.d_tid.p;
+    out->w = X.d_w.p;
+    out->wq = (uint64_t*)X.d_wq.p;
+    out->count = (uint64_t*)X.d_cnt.p;
+    out->bins = X.d_bins.p;
+    out->h1 = (uint64_t*)X.d_h1.p;
+    out->h2 = (uint64_t*)X.d_h2.p;
+  }
   return SQ_OK;
 }
 
@@ -1031,13 +1279,25 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
   if (E * 10 > o->tcap * 7 || L > o->pool_cap) {
     { int rs = sq_eq_sync(c); if (rs) return rs; }
     unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
-    if (cur[1]) { sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1], (unsigned long long)E); return SQ_ERR_STATE; }
+    if (cur[1]) {
+      sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1], (unsigned long long)E);
+      return SQ_ERR_STATE;
+    }
     uint64_t cap = o->tcap; while (E * 10 > cap * 7) cap <<= 1;
     const uint64_t pcap = std::max<uint64_t>(std::max<uint64_t>(o->pool_cap, cap * 4), L);
-    if (cap >= (1ull << 32) || pcap >= (1ull << 40)) { sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E, (unsigned long long)L); return SQ_ERR_ARG; }
-    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) || o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) { sq_set_error("device allocation failed (class table for %llu classes)", (unsigned long long)E); return SQ_ERR_NOMEM; }
+    if (cap >= (1ull << 32) || pcap >= (1ull << 40)) {
+      sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E, (unsigned long long)L);
+      return SQ_ERR_ARG;
+    }
+    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) || o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) {
+      sq_set_error("device allocation failed (class table for %llu classes)", (unsigned long long)E);
+      return SQ_ERR_NOMEM;
+    }
     o->tcap = cap; o->pool_cap = pcap;
-    SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8)); SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
+    SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8));
+    SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8));
+    SQ_HIP_CHECK(hipMemset(o->tcount.p, 0, cap * 8));
+    SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
     SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, pcap * 8));
   }
   if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
