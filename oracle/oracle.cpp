@@ -112,7 +112,17 @@ struct ReadCodes { std::vector<uint8_t> c; };  // 0..3, 4 = N
 static inline void encode_read(const uint8_t* s, uint32_t n, std::vector<uint8_t>& c) {
   c.resize(n);
   for (uint32_t i = 0; i < n; ++i) {
-    switch (s[i]) { case 'A': case 'a': c[i] = 0; break; case 'C': case 'c': c[i] = 1; break; case 'G': case 'g': c[i] = 2; break; case 'T': case 't': c[i] = 3; break; default: c[i] = 4; }
+    switch (s[i]) {
+      case 'A': case 'a': c[i] = 0;
+      break;
+      case 'C': case 'c': c[i] = 1;
+      break;
+      case 'G': case 'g': c[i] = 2;
+      break;
+      case 'T': case 't': c[i] = 3;
+      break;
+      default: c[i] = 4;
+    }
   }
 }
 
@@ -135,9 +145,26 @@ static void collect_unimems(const Index& ix, const Opts& op, const std::vector<u
     const uint64_t ub = ix.uoff[u]; const int ulen = (int)(ix.uoff[u + 1] - ub);
     int len = k; bool uend = false;
     if (fw) {
-      for (;;) { if (pos + len >= L) break; if ((int)off + len >= ulen) { uend = true; break; } if (rd[pos + len] != base_at(ix.useq.data(), ub + off + len)) break; ++len; }
+      for (;;) {
+        if (pos + len >= L) break;
+        if ((int)off + len >= ulen) {
+          uend = true;
+          break;
+        }
+        if (rd[pos + len] != base_at(ix.useq.data(), ub + off + len)) break;
+        ++len;
+      }
     } else {
-      for (;;) { if (pos + len >= L) break; int up = (int)off - 1 - (len - (int)k); if (up < 0) { uend = true; break; } if (rd[pos + len] != 3 - base_at(ix.useq.data(), ub + up)) break; ++len; }
+      for (;;) {
+        if (pos + len >= L) break;
+        int up = (int)off - 1 - (len - (int)k);
+        if (up < 0) {
+          uend = true;
+          break;
+        }
+        if (rd[pos + len] != 3 - base_at(ix.useq.data(), ub + up)) break;
+        ++len;
+      }
     }
     UniMem m; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.unitig = u; m.fw = fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - (int)k));
     out.push_back(m);
@@ -266,8 +293,26 @@ static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::ve
   for (auto& c : lc) best = std::max(best, c.score);
   for (auto& c : rc) best = std::max(best, c.score);
   double thr = op.o.orphan_chain_sub_thresh * best;  // global (ProgramOptionsGenerator.cpp:130-137)
-  for (size_t a = 0; a < lc.size(); ++a) if (lc[a].score >= thr) { Cand c; c.tid = lc[a].tid; c.lc = (int)a; c.rc = -1; c.frag_len = 0; c.mate_status = SQ_MS_PAIRED_END_LEFT; c.cov = lc[a].score; out.push_back(c); }
-  for (size_t b = 0; b < rc.size(); ++b) if (rc[b].score >= thr) { Cand c; c.tid = rc[b].tid; c.lc = -1; c.rc = (int)b; c.frag_len = 0; c.mate_status = SQ_MS_PAIRED_END_RIGHT; c.cov = rc[b].score; out.push_back(c); }
+  for (size_t a = 0; a < lc.size(); ++a) if (lc[a].score >= thr) {
+    Cand c;
+    c.tid = lc[a].tid;
+    c.lc = (int)a;
+    c.rc = -1;
+    c.frag_len = 0;
+    c.mate_status = SQ_MS_PAIRED_END_LEFT;
+    c.cov = lc[a].score;
+    out.push_back(c);
+  }
+  for (size_t b = 0; b < rc.size(); ++b) if (rc[b].score >= thr) {
+    Cand c;
+    c.tid = rc[b].tid;
+    c.lc = -1;
+    c.rc = (int)b;
+    c.frag_len = 0;
+    c.mate_status = SQ_MS_PAIRED_END_RIGHT;
+    c.cov = rc[b].score;
+    out.push_back(c);
+  }
   return out.empty() ? 0 : 2;
 }
 
@@ -507,9 +552,28 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
     st.num_chains += ch[e].size();
     if (taps && taps->on) {
       uint32_t eid = paired ? frag * 2 + e : frag;
-      for (auto& u : um[e]) { sq_unimem x{}; x.end = eid; x.qpos = u.qpos; x.len = u.len; x.unitig = u.unitig; x.uoff = u.ustart; x.fw = u.fw; taps->unimems.push_back(x); }
+      for (auto& u : um[e]) {
+        sq_unimem x{};
+        x.end = eid;
+        x.qpos = u.qpos;
+        x.len = u.len;
+        x.unitig = u.unitig;
+        x.uoff = u.ustart;
+        x.fw = u.fw;
+        taps->unimems.push_back(x);
+      }
       for (auto& m : mems[e]) { sq_mem x{}; x.end = eid; x.tid = m.tid; x.rpos = m.rpos; x.qpos = m.q; x.len = m.len; x.fw = m.fw; taps->mems.push_back(x); }
-      for (auto& c : ch[e]) { sq_chain x{}; x.end = eid; x.tid = c.tid; x.pos = c.pos; x.last_end = c.last_end; x.fw = c.fw; x.n_mems = (uint32_t)c.mems.size(); x.score = c.score; taps->chains.push_back(x); }
+      for (auto& c : ch[e]) {
+        sq_chain x{};
+        x.end = eid;
+        x.tid = c.tid;
+        x.pos = c.pos;
+        x.last_end = c.last_end;
+        x.fw = c.fw;
+        x.n_mems = (uint32_t)c.mems.size();
+        x.score = c.score;
+        taps->chains.push_back(x);
+      }
     }
   }
   if (!ch[0].empty() || !ch[1].empty()) st.num_mapped_at_least_a_kmer++;
@@ -520,7 +584,16 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
     if (jr == 2 && op.o.recover_orphans && cands.size() <= op.o.max_read_occs && recover_orphans(ix, op, rd, ch, cands)) st.num_orphans_rescued++;
   }
   else {  // joinReadsAndFilterSingle: every surviving chain is a candidate (SalmonQuantify.cpp:2108-2109)
-    for (size_t a = 0; a < ch[0].size(); ++a) { Cand c; c.tid = ch[0][a].tid; c.lc = (int)a; c.rc = -1; c.frag_len = 0; c.mate_status = SQ_MS_SINGLE_END; c.cov = ch[0][a].score; cands.push_back(c); }
+    for (size_t a = 0; a < ch[0].size(); ++a) {
+      Cand c;
+      c.tid = ch[0][a].tid;
+      c.lc = (int)a;
+      c.rc = -1;
+      c.frag_len = 0;
+      c.mate_status = SQ_MS_SINGLE_END;
+      c.cov = ch[0][a].score;
+      cands.push_back(c);
+    }
   }
   if (cands.empty() && dovetail) st.num_dovetails++;
   st.num_candidates += cands.size();
@@ -581,7 +654,14 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
       sq_aln a{}; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
         const Chain& l = ch[0][c.lc]; const Chain& r = ch[1][c.rc];
-        a.pos = l.pos; a.fwd = l.fw; a.read_len = (uint16_t)n1; a.mate_pos = r.pos; a.mate_fwd = r.fw; a.mate_len = (uint16_t)n2; a.score = c.lscore; a.mate_score = c.rscore;
+        a.pos = l.pos;
+        a.fwd = l.fw;
+        a.read_len = (uint16_t)n1;
+        a.mate_pos = r.pos;
+        a.mate_fwd = r.fw;
+        a.mate_len = (uint16_t)n2;
+        a.score = c.lscore;
+        a.mate_score = c.rscore;
         int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
         a.format_id = format_id(hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len, false));  // SalmonQuantify.cpp:1770-1777
       } else {
@@ -640,7 +720,11 @@ struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, ke
   double cmf(size_t len) const { return len < ccmf.size() ? ccmf[len] : ccmf.back(); }  // only used once cached
   void apply_counts(const std::vector<uint32_t>& cnt, double logFM) {  // batched addVal (:85-110)
     for (int b = 1; b <= 1000; ++b)
-      for (int i = 4; i >= 0; --i) { int len = b + 2 - i; if (len < 0 || len > 1000 || cnt[len] == 0) continue; hist[b] = sq_log_add(hist[b], logFM + kernel[i] + sq_log((double)cnt[len])); }
+      for (int i = 4; i >= 0; --i) {
+        int len = b + 2 - i;
+        if (len < 0 || len > 1000 || cnt[len] == 0) continue;
+        hist[b] = sq_log_add(hist[b], logFM + kernel[i] + sq_log((double)cnt[len]));
+      }
     totMass = tree_total();
   }
   void cache() {  // cacheCMF (:174-186) + getLockedPMF (:159-172)
@@ -670,7 +754,12 @@ struct QuantState {
     ambigCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambigCMF[j] = cum; } }
     liveCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, fld.hist[j]); liveCMF[j] = cum - fld.totMass; } }
     mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
-    for (size_t t = 0; t < M; ++t) { double len = (double)ix->ref_len[t]; priorMass[t] = sq_log(0.005 * len); logEffLen[t] = sq_log(len); }  // Transcript.hpp:48-56, ReadExperiment.inl:114
+    // Transcript.hpp:48-56, ReadExperiment.inl:114
+    for (size_t t = 0; t < M; ++t) {
+      double len = (double)ix->ref_len[t];
+      priorMass[t] = sq_log(0.005 * len);
+      logEffLen[t] = sq_log(len);
+    }
     libCounts.assign(64, 0);
   }
   double forgetting_mass(uint64_t b) {  // ForgettingMassCalculator.hpp:30-40 (prefill recurrence)
@@ -792,14 +881,24 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       S.total[tids[i]] += 1;
       if (!burned) {
         double rr = u01(o.seed, readIdx, i);
-        if (rr < pr) { uint32_t fl = frag_len_pedantic(*ka[i], ix.ref_len[tids[i]]); if (fl > 0) { if (fl > 1000) fl = 1000; fldCnt[fl]++; if (fl < minLen) minLen = fl; } }
+        if (rr < pr) {
+          uint32_t fl = frag_len_pedantic(*ka[i], ix.ref_len[tids[i]]);
+          if (fl > 0) {
+            if (fl > 1000) fl = 1000;
+            fldCnt[fl]++;
+            if (fl < minLen) minLen = fl;
+          }
+        }
       }
     }
     if (n == 1) S.uniq[tids[0]] += 1;
     for (int f = 0; f < 64; ++f) if (fmtSeen >> f & 1) S.libCounts[f]++;
   }
   // batch end: apply updates
-  for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) { S.mass[t] = sq_log_add(S.mass[t], logFM + sq_log(sq_from_fixed(S.massAcc[t], SQ_MFRAC_BITS))); S.massAcc[t] = 0; }
+  for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) {
+    S.mass[t] = sq_log_add(S.mass[t], logFM + sq_log(sq_from_fixed(S.massAcc[t], SQ_MFRAC_BITS)));
+    S.massAcc[t] = 0;
+  }
   if (!burned) { bool any = false; for (auto c : fldCnt) any |= (c != 0); if (any) { S.fld.apply_counts(fldCnt, logFM); S.fld.minLen = minLen; } }
   S.numAssigned += local; S.numObserved += (r1 - r0); S.readCounter += (r1 - r0); S.batchNo++;
   if (S.numAssigned >= o.num_burnin_frags && !S.burnedIn) S.burnin_finalize();
@@ -934,7 +1033,11 @@ static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_op
   const double scale = 1.0 / (double)nact;
   for (uint32_t b = 0; b < B; ++b) {
     std::fill(P.count.begin(), P.count.end(), 0);
-    for (uint64_t i = 0; i < total; ++i) { uint64_t idx = sq_mulhi64(sq_r64(seed, b, i), total); size_t c = std::upper_bound(cum.begin(), cum.end(), idx) - cum.begin(); P.count[c]++; }
+    for (uint64_t i = 0; i < total; ++i) {
+      uint64_t idx = sq_mulhi64(sq_r64(seed, b, i), total);
+      size_t c = std::upper_bound(cum.begin(), cum.end(), idx) - cum.begin();
+      P.count[c]++;
+    }
     std::vector<double> alpha(M); for (uint32_t i = 0; i < M; ++i) alpha[i] = active[i] ? scale * (double)num_mapped : 0.0;
     uint32_t it; bool conv; double mr; em_loop(P, o, alpha, 50, &it, &conv, &mr);
     for (uint32_t i = 0; i < M; ++i) out[(size_t)b * M + i] = alpha[i] <= 1e-8 ? 0.0 : alpha[i];
@@ -958,15 +1061,33 @@ static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opt
     if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) cf = init;
     for (uint32_t r = 0; r < thin; ++r) {
       const uint64_t key = (uint64_t)sid * thin + r;
-      for (uint32_t i = 0; i < M; ++i) { if (!active[i]) { mu[i] = 0.0; continue; } double c = cf[i] + prior[i]; mu[i] = go->no_gamma_draw ? c / txp->eff_len[i] : sq_gamma_draw(c, 1.0 / (0.1 + txp->eff_len[i]), seed, key, i); }
+      for (uint32_t i = 0; i < M; ++i) {
+        if (!active[i]) {
+          mu[i] = 0.0;
+          continue;
+        }
+        double c = cf[i] + prior[i];
+        mu[i] = go->no_gamma_draw ? c / txp->eff_len[i] : sq_gamma_draw(c, 1.0 / (0.1 + txp->eff_len[i]), seed, key, i);
+      }
       std::fill(ci.begin(), ci.end(), 0);
       for (uint64_t c = 0; c < E; ++c) {
         const uint64_t a = eq->off[c]; const uint32_t n = (uint32_t)(eq->off[c + 1] - a); const uint64_t cnt = eq->count[c];
         if (n == 0 || cnt == 0) continue;
         if (n == 1) { ci[eq->tid[a]] += cnt; continue; }
-        auto pf = [&](int mode, uint32_t i) { uint32_t t = eq->tid[a + i]; return mode == 0 ? (1000.0 * mu[t]) * eq->w[a + i] : (mode == 1 ? 1.0 / txp->eff_len[t] : 1.0); };
+        auto pf = [&](int mode, uint32_t i) {
+          uint32_t t = eq->tid[a + i];
+          return mode == 0 ? (1000.0 * mu[t]) * eq->w[a + i] : (mode == 1 ? 1.0 / txp->eff_len[t] : 1.0);
+        };
         int mode = 0; double denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += pf(0, i);
-        if (denom <= 2.2250738585072014e-308) { mode = 1; denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += pf(1, i); if (denom <= 2.2250738585072014e-308) { mode = 2; denom = (double)n; } }
+        if (denom <= 2.2250738585072014e-308) {
+          mode = 1;
+          denom = 0.0;
+          for (uint32_t i = 0; i < n; ++i) denom += pf(1, i);
+          if (denom <= 2.2250738585072014e-308) {
+            mode = 2;
+            denom = (double)n;
+          }
+        }
         for (uint64_t sidx = 0; sidx < cnt; ++sidx) {
           double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, key, draw_off[c] + sidx)) * denom;
           double acc = 0.0; uint32_t pick = n - 1; for (uint32_t i = 0; i < n; ++i) { acc += pf(mode, i); if (u < acc) { pick = i; break; } }
@@ -1023,13 +1144,28 @@ int orc_check_cdbg(const sq_index_view* v) {
   for (uint64_t u = 0; u < v->num_unitigs; ++u) {
     uint64_t b = v->uoff[u], e = v->uoff[u + 1]; if (e - b < k) return 1;
     uint64_t fw = 0;
-    for (uint64_t i = 0; i < e - b; ++i) { fw = (fw >> 2) | ((uint64_t)base_at(v->useq, b + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km; uint64_t rc = revcomp(fw, k); if (++seen[std::min(fw, rc)] > 1) return 2; }
+    for (uint64_t i = 0; i < e - b; ++i) {
+      fw = (fw >> 2) | ((uint64_t)base_at(v->useq, b + i) << (2 * (k - 1)));
+      if (i + 1 < k) continue;
+      fw &= km;
+      uint64_t rc = revcomp(fw, k);
+      if (++seen[std::min(fw, rc)] > 1) return 2;
+    }
   }
   // every reference k-mer present; occurrences reproduce references
   std::vector<uint8_t> covered;
   for (uint32_t r = 0; r < v->num_refs; ++r) {
     uint32_t L = v->ref_len[r]; covered.assign(L, 0);
-    if (L >= k) { uint64_t fw = 0; for (uint32_t i = 0; i < L; ++i) { fw = (fw >> 2) | ((uint64_t)base_at(v->refseq, v->ref_accum[r] + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km; uint64_t rc = revcomp(fw, k); if (!seen.count(std::min(fw, rc))) return 3; } }
+    if (L >= k) {
+      uint64_t fw = 0;
+      for (uint32_t i = 0; i < L; ++i) {
+        fw = (fw >> 2) | ((uint64_t)base_at(v->refseq, v->ref_accum[r] + i) << (2 * (k - 1)));
+        if (i + 1 < k) continue;
+        fw &= km;
+        uint64_t rc = revcomp(fw, k);
+        if (!seen.count(std::min(fw, rc))) return 3;
+      }
+    }
   }
   std::vector<std::vector<std::pair<uint32_t, uint32_t>>> cov(v->num_refs);
   for (uint64_t u = 0; u < v->num_unitigs; ++u) {
@@ -1065,7 +1201,12 @@ int orc_check_cdbg(const sq_index_view* v) {
       info[std::min(fw, rc)] |= bits;
     }
   }
-  auto side_break = [&](uint64_t can, bool right) { uint32_t inf = info[can]; uint32_t m = right ? (inf & 15) : ((inf >> 4) & 15); bool t = right ? (inf >> 8) & 1 : (inf >> 9) & 1; return t || __builtin_popcount(m) != 1; };
+  auto side_break = [&](uint64_t can, bool right) {
+    uint32_t inf = info[can];
+    uint32_t m = right ? (inf & 15) : ((inf >> 4) & 15);
+    bool t = right ? (inf >> 8) & 1 : (inf >> 9) & 1;
+    return t || __builtin_popcount(m) != 1;
+  };
   for (uint64_t u = 0; u < v->num_unitigs; ++u) {
     uint64_t b = v->uoff[u], ulen = v->uoff[u + 1] - b;
     // interior joins must all be non-breaking; the two outer sides must be breaking
@@ -1104,15 +1245,33 @@ void orc_map_batch(const orc_index* oi, const sq_quant_opts* o, const sq_read_ba
       for (uint32_t i = b; i < e; ++i) {
         if (in->paired) { const uint8_t* s1 = in->seq + in->seq_off[2 * i]; uint32_t n1 = (uint32_t)(in->seq_off[2 * i + 1] - in->seq_off[2 * i]); const uint8_t* s2 = in->seq + in->seq_off[2 * i + 1]; uint32_t n2 = (uint32_t)(in->seq_off[2 * i + 2] - in->seq_off[2 * i + 1]);
           map_fragment(oi->ix, op, i, s1, n1, s2, n2, true, res[i], sts[t], nullptr); }
-        else { const uint8_t* s1 = in->seq + in->seq_off[i]; uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]); map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, res[i], sts[t], nullptr); }
+        else {
+          const uint8_t* s1 = in->seq + in->seq_off[i];
+          uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]);
+          map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, res[i], sts[t], nullptr);
+        }
       }
     }
   };
   if (nthreads <= 1) work(0); else { std::vector<std::thread> th; for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
   uint64_t tot = 0; read_off[0] = 0;
-  for (uint32_t i = 0; i < n; ++i) { for (auto& a : res[i].alns) { if (tot < aln_cap) alns[tot] = a; ++tot; } read_off[i + 1] = tot; if (map_type) map_type[i] = res[i].map_type; }
+  for (uint32_t i = 0; i < n; ++i) {
+    for (auto& a : res[i].alns) {
+      if (tot < aln_cap) alns[tot] = a;
+      ++tot;
+    }
+    read_off[i + 1] = tot;
+    if (map_type) map_type[i] = res[i].map_type;
+  }
   if (n_alns_out) *n_alns_out = tot;
-  if (stats) { memset(stats, 0, sizeof(*stats)); uint64_t* d = (uint64_t*)stats; for (auto& s : sts) { const uint64_t* p = (const uint64_t*)&s; for (size_t j = 0; j < sizeof(sq_map_stats) / 8; ++j) d[j] += p[j]; } }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    uint64_t* d = (uint64_t*)stats;
+    for (auto& s : sts) {
+      const uint64_t* p = (const uint64_t*)&s;
+      for (size_t j = 0; j < sizeof(sq_map_stats) / 8; ++j) d[j] += p[j];
+    }
+  }
 }
 
 // stage taps for one batch (single-threaded): fills caller buffers, returns counts via n_out[4]
@@ -1120,8 +1279,18 @@ void orc_map_taps(const orc_index* oi, const sq_quant_opts* o, const sq_read_bat
                   sq_chain* ch, uint64_t ch_cap, sq_cand* cd, uint64_t cd_cap, uint64_t* n_out) {
   Opts op; make_opts(o, op); Taps tp; tp.on = true; sq_map_stats st; memset(&st, 0, sizeof(st)); FragResult fr;
   for (uint32_t i = 0; i < in->n; ++i) {
-    if (in->paired) { const uint8_t* s1 = in->seq + in->seq_off[2 * i]; uint32_t n1 = (uint32_t)(in->seq_off[2 * i + 1] - in->seq_off[2 * i]); const uint8_t* s2 = in->seq + in->seq_off[2 * i + 1]; uint32_t n2 = (uint32_t)(in->seq_off[2 * i + 2] - in->seq_off[2 * i + 1]); map_fragment(oi->ix, op, i, s1, n1, s2, n2, true, fr, st, &tp); }
-    else { const uint8_t* s1 = in->seq + in->seq_off[i]; uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]); map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, fr, st, &tp); }
+    if (in->paired) {
+      const uint8_t* s1 = in->seq + in->seq_off[2 * i];
+      uint32_t n1 = (uint32_t)(in->seq_off[2 * i + 1] - in->seq_off[2 * i]);
+      const uint8_t* s2 = in->seq + in->seq_off[2 * i + 1];
+      uint32_t n2 = (uint32_t)(in->seq_off[2 * i + 2] - in->seq_off[2 * i + 1]);
+      map_fragment(oi->ix, op, i, s1, n1, s2, n2, true, fr, st, &tp);
+    }
+    else {
+      const uint8_t* s1 = in->seq + in->seq_off[i];
+      uint32_t n1 = (uint32_t)(in->seq_off[i + 1] - in->seq_off[i]);
+      map_fragment(oi->ix, op, i, s1, n1, nullptr, 0, false, fr, st, &tp);
+    }
   }
   n_out[0] = tp.unimems.size(); n_out[1] = tp.mems.size(); n_out[2] = tp.chains.size(); n_out[3] = tp.cands.size();
   for (size_t i = 0; i < tp.unimems.size() && i < um_cap; ++i) um[i] = tp.unimems[i];
@@ -1140,11 +1309,22 @@ void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const
 }
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
 void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }
-void orc_state_summary(orc_state* s, sq_model_summary* m) { m->num_observed = s->S.numObserved; m->num_assigned = s->S.numAssigned; m->num_mapped_ub = s->S.numMappedUB; m->burned_in = s->S.burnedIn; m->num_compatible = s->S.numCompat; }
+void orc_state_summary(orc_state* s, sq_model_summary* m) {
+  m->num_observed = s->S.numObserved;
+  m->num_assigned = s->S.numAssigned;
+  m->num_mapped_ub = s->S.numMappedUB;
+  m->burned_in = s->S.burnedIn;
+  m->num_compatible = s->S.numCompat;
+}
 void orc_state_lib_counts(orc_state* s, uint64_t* out64) { for (int i = 0; i < 64; ++i) out64[i] = s->S.libCounts[i]; }
 void orc_state_fetch(orc_state* s, double* log_mass, uint64_t* uniq, uint64_t* total, double* log_eff_len, double* fld_logpmf) {
   QuantState& S = s->S; size_t M = S.mass.size();
-  for (size_t t = 0; t < M; ++t) { if (log_mass) log_mass[t] = S.mass[t]; if (uniq) uniq[t] = S.uniq[t]; if (total) total[t] = S.total[t]; if (log_eff_len) log_eff_len[t] = S.logEffLen[t]; }
+  for (size_t t = 0; t < M; ++t) {
+    if (log_mass) log_mass[t] = S.mass[t];
+    if (uniq) uniq[t] = S.uniq[t];
+    if (total) total[t] = S.total[t];
+    if (log_eff_len) log_eff_len[t] = S.logEffLen[t];
+  }
   if (fld_logpmf) for (int i = 0; i <= 1000; ++i) fld_logpmf[i] = S.fld.pmf(i);
 }
 // label hash shared with the product (two independent 64-bit mixes over tids+bins)
@@ -1169,7 +1349,12 @@ void orc_eq_finish(orc_state* s, sq_eq_table* out) {
     const Row& r = rows[c]; size_t n = r.v->wq.size(); out->off[c] = p; out->count[c] = r.v->count; if (out->h1) out->h1[c] = r.h1; if (out->h2) out->h2[c] = r.h2;
     double sum = 0.0; for (size_t i = 0; i < n; ++i) sum += sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS);
     double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
-    for (size_t i = 0; i < n; ++i) { out->tid[p + i] = (*r.lab)[i]; out->w[p + i] = sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS) * norm; if (out->wq) out->wq[p + i] = r.v->wq[i]; if (out->bins) out->bins[p + i] = r.lab->size() > n ? (*r.lab)[n + i] : 0; }
+    for (size_t i = 0; i < n; ++i) {
+      out->tid[p + i] = (*r.lab)[i];
+      out->w[p + i] = sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS) * norm;
+      if (out->wq) out->wq[p + i] = r.v->wq[i];
+      if (out->bins) out->bins[p + i] = r.lab->size() > n ? (*r.lab)[n + i] : 0;
+    }
     p += n;
   }
   out->off[rows.size()] = p;
@@ -1180,7 +1365,13 @@ void orc_eq_finish(orc_state* s, sq_eq_table* out) {
 void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
   std::vector<uint32_t> parent(M); for (uint32_t i = 0; i < M; ++i) parent[i] = i;
   auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-  for (uint64_t c = 0; c < eq->num_classes; ++c) for (uint64_t i = eq->off[c] + 1; i < eq->off[c + 1]; ++i) { uint32_t a = find(eq->tid[eq->off[c]]), b = find(eq->tid[i]); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }
+  for (uint64_t c = 0; c < eq->num_classes; ++c) for (uint64_t i = eq->off[c] + 1; i < eq->off[c + 1]; ++i) {
+    uint32_t a = find(eq->tid[eq->off[c]]), b = find(eq->tid[i]);
+    if (a != b) {
+      if (a < b) parent[b] = a;
+      else parent[a] = b;
+    }
+  }
   std::vector<double> hits(M, 0.0);
   for (uint64_t c = 0; c < eq->num_classes; ++c) hits[find(eq->tid[eq->off[c]])] += (double)eq->count[c];
   std::vector<std::vector<uint32_t>> members(M);
@@ -1192,14 +1383,23 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
     bool need = false;
     for (uint32_t t : mem) {
       if (log_mass[t] == SQ_LOG_0) projected[t] = 0;
-      else { projected[t] = (hits[r] > 0) ? sq_exp(log_mass[t] - logClusterMass + logClusterCount) : 0.0; need |= projected[t] > (double)total[t] || projected[t] < (double)uniq[t]; }
+      else {
+        projected[t] = (hits[r] > 0) ? sq_exp(log_mass[t] - logClusterMass + logClusterCount) : 0.0;
+        need |= projected[t] > (double)total[t] || projected[t] < (double)uniq[t];
+      }
     }
     if (mem.size() > 1 && need) {
       double clusterCounts = hits[r]; std::vector<uint8_t> bound(mem.size(), 0); size_t round = 0;
       for (;;) {
         double unb = 0.0, bnd = 0.0;
         for (size_t i = 0; i < mem.size(); ++i) { uint32_t t = mem[i];
-          if (projected[t] > (double)total[t]) { projected[t] = (double)total[t]; bound[i] = 1; } else if (projected[t] < (double)uniq[t]) { projected[t] = (double)uniq[t]; bound[i] = 1; }
+          if (projected[t] > (double)total[t]) {
+            projected[t] = (double)total[t];
+            bound[i] = 1;
+          } else if (projected[t] < (double)uniq[t]) {
+            projected[t] = (double)uniq[t];
+            bound[i] = 1;
+          }
           if (bound[i]) bnd += projected[t]; else unb += projected[t]; }
         if (std::fabs(unb + bnd - clusterCounts) <= 0.375e-10) break;
         if (unb == 0) { std::fill(bound.begin(), bound.end(), 0); unb = bnd; bnd = 0; }
@@ -1211,9 +1411,15 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
   }
 }
 
-int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) { return em_optimize(eq, txp, o, alpha_out, rep); }
-int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) { return bootstrap(eq, txp, o, B, seed, num_mapped, out); }
-int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) { return gibbs(eq, txp, go, alpha_init, S, seed, num_mapped, out); }
+int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+  return em_optimize(eq, txp, o, alpha_out, rep);
+}
+int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) {
+  return bootstrap(eq, txp, o, B, seed, num_mapped, out);
+}
+int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) {
+  return gibbs(eq, txp, go, alpha_init, S, seed, num_mapped, out);
+}
 int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out) {
   EMProblem P; em_setup(P, eq, txp, o); std::vector<double> a(alpha_in, alpha_in + P.M), b(P.M), th(P.M), inv(P.E);
   for (uint32_t i = 0; i < iters; ++i) { em_step(P, o, a, b, th, inv); a.swap(b); }
@@ -1228,13 +1434,24 @@ double orc_exp(double x) { return sq_exp(x); }
 double orc_log(double x) { return sq_log(x); }
 double orc_digamma(double x) { return sq_digamma(x); }
 double orc_log_add(double x, double y) { return sq_log_add(x, y); }
-int orc_compatible_pe(int et, int eo, int es, int ot, int oo, int os) { return compatible_hit_pe(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, LibFmt{(uint8_t)ot, (uint8_t)oo, (uint8_t)os}); }
+int orc_compatible_pe(int et, int eo, int es, int ot, int oo, int os) {
+  return compatible_hit_pe(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, LibFmt{(uint8_t)ot, (uint8_t)oo, (uint8_t)os});
+}
 int orc_compatible_se(int et, int eo, int es, int fwd, int ms) { return compatible_hit_se(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, fwd != 0, (uint8_t)ms); }
 int orc_format_id(int t, int o, int s) { return format_id(LibFmt{(uint8_t)t, (uint8_t)o, (uint8_t)s}); }
-int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) { Opts op; make_opts(o, op); return dp_align(op, q, n, t, tl, mode); }
+int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) {
+  Opts op;
+  make_opts(o, op);
+  return dp_align(op, q, n, t, tl, mode);
+}
 // a5: the infix aligner alone (codes 0..3, other values match nothing); returns 1 and (distance, start, end) or 0
 int orc_infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k, int* ed, int* start, int* end) { return infix_align(q, n, t, m, k, ed, start, end) ? 1 : 0; }
-void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) { FLD f; f.init(mu, sd); for (int i = 0; i <= 1000; ++i) log_hist_1001[i] = f.hist[i]; *tot = f.totMass; }
+void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) {
+  FLD f;
+  f.init(mu, sd);
+  for (int i = 0; i <= 1000; ++i) log_hist_1001[i] = f.hist[i];
+  *tot = f.totMass;
+}
 double orc_forgetting_mass(double ff, uint64_t b) { QuantState S; S.op.o.forgetting_factor = ff; return S.forgetting_mass(b); }
 
 }  // extern "C"

@@ -46,11 +46,16 @@ struct Fastq {
 
 static int cmd_index(int argc, char** argv) {
   const char* t = arg(argc, argv, "-t", "--transcripts"); const char* i = arg(argc, argv, "-i", "--index");
-  if (!t || !i) { fprintf(stderr, "usage: salmon-hip index -t transcripts.fa -i index_dir [-k 31] [-m 0] [-d decoys.txt] [-p threads] [--keepDuplicates] [--no-clip] [--gencode]\n"); return 1; }
+  if (!t || !i) {
+    fprintf(stderr, "usage: salmon-hip index -t transcripts.fa -i index_dir [-k 31] [-m 0] [-d decoys.txt] [-p threads] [--keepDuplicates] [--no-clip] [--gencode]\n");
+    return 1;
+  }
   sq_index_opts o{}; const char* v;
   o.k = (v = arg(argc, argv, "-k", "--kmerLen")) ? (uint32_t)atoi(v) : 31; o.m = (v = arg(argc, argv, "-m", "--minimizerLen")) ? (uint32_t)atoi(v) : 0;
   o.threads = (v = arg(argc, argv, "-p", "--threads")) ? (uint32_t)atoi(v) : 0;
-  o.keep_duplicates = flag(argc, argv, "--keepDuplicates"); o.no_clip_polya = flag(argc, argv, "--no-clip") || flag(argc, argv, "-n"); o.gencode = flag(argc, argv, "--gencode");
+  o.keep_duplicates = flag(argc, argv, "--keepDuplicates");
+  o.no_clip_polya = flag(argc, argv, "--no-clip") || flag(argc, argv, "-n");
+  o.gencode = flag(argc, argv, "--gencode");
   if (sq_index_build(&o, t, arg(argc, argv, "-d", "--decoys"), i)) die("index");
   fprintf(stderr, "[salmon-hip] index written to %s\n", i);
   return 0;
@@ -65,13 +70,17 @@ static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_wri
 // posterior samples into aux_info/bootstrap (MappingPipelineStages.cpp:60-95): --numBootstraps wins over --numGibbsSamples
 static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop, const double* alphas, uint32_t M,
                          const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped) {
-  const char* v; const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv, "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
+  const char* v;
+  const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv, "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
   if (!nb && !ng) return;
   const uint64_t seed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
   sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
   if (nb) { if (sq_bootstrap_dev(device, t, tx, eop, nb, seed, num_mapped, boot_cb, bw)) die("bootstrap"); }
   else {
-    sq_gibbs_opts go{}; go.thinning_factor = (v = arg(argc, argv, "--thinningFactor")) ? (uint32_t)atoi(v) : 16; go.no_gamma_draw = flag(argc, argv, "--noGammaDraw"); go.use_vbem = eop->use_vbem;
+    sq_gibbs_opts go{};
+    go.thinning_factor = (v = arg(argc, argv, "--thinningFactor")) ? (uint32_t)atoi(v) : 16;
+    go.no_gamma_draw = flag(argc, argv, "--noGammaDraw");
+    go.use_vbem = eop->use_vbem;
     go.per_transcript_prior = eop->per_transcript_prior; go.vb_prior = eop->vb_prior;
     if (sq_gibbs_dev(device, t, tx, &go, alphas, ng, seed, num_mapped, boot_cb, bw)) die("Gibbs sampling");
   }
@@ -80,7 +89,11 @@ static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t
 
 // salmon quant -e eq_classes.txt[.gz] -o out : EM straight from a dumped table (SalmonQuantifyAlignments.cpp:1407-1441)
 static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
-  const char* odir = arg(argc, argv, "-o", "--output"); if (!odir) { fprintf(stderr, "usage: salmon-hip quant -e eq_classes.txt[.gz] -o out_dir [--useEM] [--numBootstraps N | --numGibbsSamples N]\n"); return 1; }
+  const char* odir = arg(argc, argv, "-o", "--output");
+  if (!odir) {
+    fprintf(stderr, "usage: salmon-hip quant -e eq_classes.txt[.gz] -o out_dir [--useEM] [--numBootstraps N | --numGibbsSamples N]\n");
+    return 1;
+  }
   const char* v; int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0;
   sq_eq_file* F = nullptr; if (sq_eq_file_read(eqf, &F)) die("reading eq classes");
   const uint32_t M = sq_eq_file_num_txp(F); sq_eq_table t{}; sq_eq_file_table(F, &t);
@@ -106,10 +119,16 @@ static int cmd_quant(int argc, char** argv) {
   const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
   const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
-  if (!idir || !odir || (!ru && !(r1 && r2))) { fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n"); return 1; }
+  if (!idir || !odir || (!ru && !(r1 && r2))) {
+    fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
+    return 1;
+  }
   std::string lib = lt ? lt : (ru ? "U" : "IU");
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
-  if (lib == "A") { fprintf(stderr, "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n"); return 1; }
+  if (lib == "A") {
+    fprintf(stderr, "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n");
+    return 1;
+  }
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
   const char* v; int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0; uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
   const bool paired = !ru;
@@ -129,7 +148,18 @@ static int cmd_quant(int argc, char** argv) {
   if (sq_ctx_reserve(ctx, 0, 0)) die("reserving end-of-job buffers");   // the reference pre-sizes its eq-class map the same way (EquivalenceClassBuilder.hpp:140)
   // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
   // the mapping lanes: up to `lanes` batches are in flight (H2D + mapping) while the next one is parsed
-  auto split = [](const char* s) { std::vector<std::string> v; std::string cur; for (const char* p = s; ; ++p) { if (*p == ',' || *p == ' ' || !*p) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; } else cur.push_back(*p); } return v; };
+  auto split = [](const char* s) {
+    std::vector<std::string> v;
+    std::string cur;
+    for (const char* p = s; ; ++p) {
+      if (*p == ',' || *p == ' ' || !*p) {
+        if (!cur.empty()) v.push_back(cur);
+        cur.clear();
+        if (!*p) break;
+      } else cur.push_back(*p);
+    }
+    return v;
+  };
   std::vector<std::string> l1 = split(paired ? r1 : ru), l2 = paired ? split(r2) : std::vector<std::string>();
   std::vector<const char*> p1, p2; for (auto& x : l1) p1.push_back(x.c_str()); for (auto& x : l2) p2.push_back(x.c_str());
   const uint32_t lanes = (v = arg(argc, argv, "--lanes")) ? (uint32_t)std::max(1, std::min(4, atoi(v))) : 2;
@@ -201,7 +231,10 @@ static int cmd_quant(int argc, char** argv) {
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
-  if (cf) { fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir, lib.c_str(), odir); fclose(cf); }
+  if (cf) {
+    fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir, lib.c_str(), odir);
+    fclose(cf);
+  }
   fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n", (unsigned long long)nfrag, (unsigned long long)ms.num_assigned,
           nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv, "--useEM") ? "EM" : "VBEM", secs, odir);
   sq_ctx_free(ctx); sq_index_free(idx);

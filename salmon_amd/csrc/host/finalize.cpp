@@ -52,7 +52,12 @@ struct DSU {
 extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
   if (!eq || !log_mass || !uniq || !total || !projected) { sq_set_error("sq_normalize_alphas: bad arguments"); return SQ_ERR_ARG; }
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[sq-timing] normalize %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count()); tm0 = t1; };
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] normalize %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
+    tm0 = t1;
+  };
   const uint32_t nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   DSU d(M); std::atomic<uint32_t> bad{0};
   sq_parallel_for(eq->num_classes, nthr, 8192, [&](uint64_t c_lo, uint64_t c_hi, uint32_t) {
@@ -155,7 +160,11 @@ extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const 
     for (uint64_t c = 0; c < eq->num_classes; ++c) { std::vector<uint32_t> k(eq->tid + eq->off[c], eq->tid + eq->off[c + 1]); col[k] += eq->count[c]; }
     gzprintf(g, "%u\n%zu\n", M, col.size());
     for (auto& n : idx->names) gzprintf(g, "%s\n", n.c_str());
-    for (auto& kv : col) { gzprintf(g, "%zu\t", kv.first.size()); for (uint32_t t : kv.first) gzprintf(g, "%u\t", t); gzprintf(g, "%llu\n", (unsigned long long)kv.second); }
+    for (auto& kv : col) {
+      gzprintf(g, "%zu\t", kv.first.size());
+      for (uint32_t t : kv.first) gzprintf(g, "%u\t", t);
+      gzprintf(g, "%llu\n", (unsigned long long)kv.second);
+    }
   }
   gzclose(g);
   return SQ_OK;
@@ -172,24 +181,62 @@ extern "C" int sq_eq_file_read(const char* path, sq_eq_file** out) {
   while ((n = gzread(g, buf, sizeof(buf))) > 0) all.append(buf, (size_t)n);
   gzclose(g);
   const char* p = all.c_str(); const char* end = p + all.size();
-  auto tok = [&](std::string& t) { while (p < end && isspace((unsigned char)*p)) ++p; const char* b = p; while (p < end && !isspace((unsigned char)*p)) ++p; t.assign(b, p); return !t.empty(); };
+  auto tok = [&](std::string& t) {
+    while (p < end && isspace((unsigned char)*p)) ++p;
+    const char* b = p;
+    while (p < end && !isspace((unsigned char)*p)) ++p;
+    t.assign(b, p);
+    return !t.empty();
+  };
   std::string t; std::unique_ptr<sq_eq_file> F(new sq_eq_file());
   if (!tok(t)) { sq_set_error("'%s': empty eq-class file", path); return SQ_ERR_IO; } const uint64_t M = strtoull(t.c_str(), nullptr, 10);
   if (!tok(t)) { sq_set_error("'%s': truncated header", path); return SQ_ERR_IO; } const uint64_t E = strtoull(t.c_str(), nullptr, 10);
   std::map<std::string, size_t> idx;
-  for (uint64_t i = 0; i < M; ++i) { if (!tok(t)) { sq_set_error("'%s': truncated name list", path); return SQ_ERR_IO; } idx[t] = F->names.size(); F->names.push_back(t); }
+  for (uint64_t i = 0; i < M; ++i) {
+    if (!tok(t)) {
+      sq_set_error("'%s': truncated name list", path);
+      return SQ_ERR_IO;
+    }
+    idx[t] = F->names.size();
+    F->names.push_back(t);
+  }
   F->off.assign(1, 0);
   for (uint64_t c = 0; c < E; ++c) {
     if (!tok(t)) { sq_set_error("'%s': truncated at class %llu", path, (unsigned long long)c); return SQ_ERR_IO; }
     const uint64_t k = strtoull(t.c_str(), nullptr, 10);
-    for (uint64_t i = 0; i < k; ++i) { if (!tok(t)) { sq_set_error("'%s': truncated labels", path); return SQ_ERR_IO; } const uint64_t x = strtoull(t.c_str(), nullptr, 10); if (x >= M) { sq_set_error("'%s': transcript id %llu out of range", path, (unsigned long long)x); return SQ_ERR_IO; } F->tid.push_back((uint32_t)x); }
-    for (uint64_t i = 0; i < k; ++i) { if (!tok(t)) { sq_set_error("'%s': class %llu has no weights (write the file with --dumpEqWeights)", path, (unsigned long long)c); return SQ_ERR_IO; } F->w.push_back(strtod(t.c_str(), nullptr)); }
+    for (uint64_t i = 0; i < k; ++i) {
+      if (!tok(t)) {
+        sq_set_error("'%s': truncated labels", path);
+        return SQ_ERR_IO;
+      }
+      const uint64_t x = strtoull(t.c_str(), nullptr, 10);
+      if (x >= M) {
+        sq_set_error("'%s': transcript id %llu out of range", path, (unsigned long long)x);
+        return SQ_ERR_IO;
+      }
+      F->tid.push_back((uint32_t)x);
+    }
+    for (uint64_t i = 0; i < k; ++i) {
+      if (!tok(t)) {
+        sq_set_error("'%s': class %llu has no weights (write the file with --dumpEqWeights)", path, (unsigned long long)c);
+        return SQ_ERR_IO;
+      }
+      F->w.push_back(strtod(t.c_str(), nullptr));
+    }
     if (!tok(t)) { sq_set_error("'%s': class %llu has no count", path, (unsigned long long)c); return SQ_ERR_IO; }
     F->count.push_back(strtoull(t.c_str(), nullptr, 10)); F->off.push_back(F->tid.size());
   }
   F->eff.assign(M, 100.0);
   std::string nm;
-  while (tok(nm)) { if (!tok(t)) break; auto it = idx.find(nm); if (it == idx.end()) { sq_set_error("'%s': effective length for unknown transcript '%s'", path, nm.c_str()); return SQ_ERR_IO; } F->eff[it->second] = strtod(t.c_str(), nullptr); }
+  while (tok(nm)) {
+    if (!tok(t)) break;
+    auto it = idx.find(nm);
+    if (it == idx.end()) {
+      sq_set_error("'%s': effective length for unknown transcript '%s'", path, nm.c_str());
+      return SQ_ERR_IO;
+    }
+    F->eff[it->second] = strtod(t.c_str(), nullptr);
+  }
   *out = F.release();
   return SQ_OK;
 }
@@ -200,7 +247,10 @@ extern "C" const double* sq_eq_file_eff_lens(const sq_eq_file* f) { return f ? f
 extern "C" int sq_eq_file_table(const sq_eq_file* f, sq_eq_table* t) {
   if (!f || !t) return SQ_ERR_ARG;
   memset(t, 0, sizeof(*t)); t->num_classes = f->count.size(); t->num_labels = f->tid.size();
-  t->off = const_cast<uint64_t*>(f->off.data()); t->tid = const_cast<uint32_t*>(f->tid.data()); t->w = const_cast<double*>(f->w.data()); t->count = const_cast<uint64_t*>(f->count.data());
+  t->off = const_cast<uint64_t*>(f->off.data());
+  t->tid = const_cast<uint32_t*>(f->tid.data());
+  t->w = const_cast<double*>(f->w.data());
+  t->count = const_cast<uint64_t*>(f->count.data());
   return SQ_OK;
 }
 
@@ -269,7 +319,12 @@ static std::string lib_format_name(uint32_t id) {   // the salmon library-type s
   if (type == 0) { if (orient != 3) return ""; return strand == 2 ? "SF" : strand == 3 ? "SR" : strand == 4 ? "U" : ""; }
   if (orient == 3) return "";
   const char* o = orient == 0 ? "M" : orient == 1 ? "O" : "I";
-  if (orient == 0) { if (strand == 2) return std::string(o) + "SF"; if (strand == 3) return std::string(o) + "SR"; if (strand == 4) return std::string(o) + "U"; return ""; }
+  if (orient == 0) {
+    if (strand == 2) return std::string(o) + "SF";
+    if (strand == 3) return std::string(o) + "SR";
+    if (strand == 4) return std::string(o) + "U";
+    return "";
+  }
   if (strand == 0) return std::string(o) + "SF"; if (strand == 1) return std::string(o) + "SR"; if (strand == 4) return std::string(o) + "U";
   return "";
 }
@@ -293,7 +348,10 @@ extern "C" int sq_write_lib_format_counts(const char* path, const char* read_fil
              "    \"num_frags_with_concordant_consistent_mappings\": %llu,\n    \"num_frags_with_inconsistent_or_orphan_mappings\": %llu,\n    \"strand_mapping_bias\": %.17g",
           read_files ? read_files : "", lib_format_name(fid).c_str(), num_assigned ? (double)num_compatible / (double)num_assigned : 0.0,
           (unsigned long long)num_compatible, (unsigned long long)num_assigned, (unsigned long long)nAgree, (unsigned long long)nDisagree, ratio);
-  for (uint32_t i = 0; i < 64; ++i) { const std::string d = lib_format_name(i); if (!d.empty()) fprintf(f, ",\n    \"%s\": %llu", d.c_str(), (unsigned long long)counts[i]); }
+  for (uint32_t i = 0; i < 64; ++i) {
+    const std::string d = lib_format_name(i);
+    if (!d.empty()) fprintf(f, ",\n    \"%s\": %llu", d.c_str(), (unsigned long long)counts[i]);
+  }
   fprintf(f, "\n}\n");
   fclose(f);
   return SQ_OK;

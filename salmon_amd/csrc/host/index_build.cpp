@@ -271,7 +271,15 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     }
   });
   std::vector<MiniEnt> ents;
-  { uint64_t n = 0; for (auto& v : tent) n += v.size(); ents.reserve(n); for (auto& v : tent) { ents.insert(ents.end(), v.begin(), v.end()); std::vector<MiniEnt>().swap(v); } }
+  {
+    uint64_t n = 0;
+    for (auto& v : tent) n += v.size();
+    ents.reserve(n);
+    for (auto& v : tent) {
+      ents.insert(ents.end(), v.begin(), v.end());
+      std::vector<MiniEnt>().swap(v);
+    }
+  }
   idx->num_superkmers = ents.size();
   // parallel sort by (v, e): bucket by top bits of mix(v) is unnecessary; a plain parallel merge is enough
   {
@@ -299,7 +307,11 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   idx->n_parts = nparts;
   std::vector<uint64_t> kh(NK); std::vector<uint32_t> kpart(NK);
   std::vector<uint64_t> pcount(nparts + 1, 0);
-  for (uint64_t i = 0; i < NK; ++i) { kh[i] = sq_mix64(keys[i] ^ 0x9E3779B97F4A7C15ULL); kpart[i] = sq_fastrange32((uint32_t)(kh[i] >> 32), nparts); pcount[kpart[i] + 1]++; }
+  for (uint64_t i = 0; i < NK; ++i) {
+    kh[i] = sq_mix64(keys[i] ^ 0x9E3779B97F4A7C15ULL);
+    kpart[i] = sq_fastrange32((uint32_t)(kh[i] >> 32), nparts);
+    pcount[kpart[i] + 1]++;
+  }
   for (uint32_t p = 0; p < nparts; ++p) pcount[p + 1] += pcount[p];
   std::vector<uint64_t> pkeys(NK);  // key indices grouped by partition
   { std::vector<uint64_t> cur(pcount.begin(), pcount.end() - 1); for (uint64_t i = 0; i < NK; ++i) pkeys[cur[kpart[i]]++] = i; }
@@ -413,7 +425,11 @@ static void prep_refs(const sq_index_opts* o, std::vector<std::string>& names, s
   // keep order: targets first, then decoys
   std::vector<std::string> n2, s2; std::vector<uint32_t> c2;
   for (int pass = 0; pass < 2; ++pass)
-    for (size_t i = 0; i < n; ++i) if (!drop[i] && (is_decoy[i] != 0) == (pass == 1)) { n2.push_back(std::move(names[i])); s2.push_back(std::move(seqs[i])); c2.push_back(clen[i]); }
+    for (size_t i = 0; i < n; ++i) if (!drop[i] && (is_decoy[i] != 0) == (pass == 1)) {
+      n2.push_back(std::move(names[i]));
+      s2.push_back(std::move(seqs[i]));
+      c2.push_back(clen[i]);
+    }
   uint32_t fd = 0; for (size_t i = 0; i < n; ++i) if (!drop[i] && !is_decoy[i]) ++fd;
   *first_decoy = fd;
   names.swap(n2); seqs.swap(s2); clen.swap(c2);
@@ -426,12 +442,24 @@ static int read_fasta(const char* path, std::vector<std::string>& names, std::ve
   std::vector<char> buf(1 << 20); std::string line; bool have = false;
   auto flush_line = [&](const std::string& l) {
     if (l.empty()) return;
-    if (l[0] == '>') { size_t e = l.find_first_of(" \t", 1); names.push_back(l.substr(1, e == std::string::npos ? std::string::npos : e - 1)); seqs.emplace_back(); have = true; }
+    if (l[0] == '>') {
+      size_t e = l.find_first_of(" \t", 1);
+      names.push_back(l.substr(1, e == std::string::npos ? std::string::npos : e - 1));
+      seqs.emplace_back();
+      have = true;
+    }
     else if (have) { for (char c : l) if (!isspace((unsigned char)c)) seqs.back().push_back(c); }
   };
   int n;
   while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
-    for (int i = 0; i < n; ++i) { char c = buf[i]; if (c == '\n') { if (!line.empty() && line.back() == '\r') line.pop_back(); flush_line(line); line.clear(); } else line.push_back(c); }
+    for (int i = 0; i < n; ++i) {
+      char c = buf[i];
+      if (c == '\n') {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        flush_line(line);
+        line.clear();
+      } else line.push_back(c);
+    }
   }
   flush_line(line);
   gzclose(f);
@@ -492,8 +520,16 @@ extern "C" int sq_index_build(const sq_index_opts* opts, const char* fasta_path,
 // names the reference reads back (SalmonIndex.hpp:138-154, SalmonIndexVersionInfo.hpp:93-105).
 namespace {
 struct Hdr { uint64_t magic; uint32_t version, k, m, nrefs, first_decoy, n_parts; uint64_t num_kmers, nsec; };
-template <class T> bool wvec(FILE* f, const std::vector<T>& v) { uint64_t n = v.size(); return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n); }
-template <class T> bool rvec(FILE* f, std::vector<T>& v) { uint64_t n; if (fread(&n, 8, 1, f) != 1) return false; v.resize(n); return n == 0 || fread(v.data(), sizeof(T), n, f) == n; }
+template <class T> bool wvec(FILE* f, const std::vector<T>& v) {
+  uint64_t n = v.size();
+  return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T> bool rvec(FILE* f, std::vector<T>& v) {
+  uint64_t n;
+  if (fread(&n, 8, 1, f) != 1) return false;
+  v.resize(n);
+  return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
 }
 
 int sq_index_save(const sq_index& idx, const std::string& dir) {
@@ -520,7 +556,10 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
     fclose(f);
   }
   f = fopen((dir + "/versionInfo.json").c_str(), "w");
-  if (f) { fprintf(f, "{\n  \"indexVersion\": 6,\n  \"hasAuxIndex\": false,\n  \"auxKmerLength\": %u,\n  \"indexType\": 2,\n  \"salmonVersion\": \"1.11.4\"\n}\n", idx.k); fclose(f); }
+  if (f) {
+    fprintf(f, "{\n  \"indexVersion\": 6,\n  \"hasAuxIndex\": false,\n  \"auxKmerLength\": %u,\n  \"indexType\": 2,\n  \"salmonVersion\": \"1.11.4\"\n}\n", idx.k);
+    fclose(f);
+  }
   f = fopen((dir + "/duplicate_clusters.tsv").c_str(), "w");
   if (f) { fprintf(f, "RetainedRef\tDuplicateRef\n"); for (auto& d : idx.duplicates) fprintf(f, "%s\t%s\n", d.first.c_str(), d.second.c_str()); fclose(f); }
   return SQ_OK;
@@ -529,9 +568,18 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
 int sq_index_load_host(const std::string& dir, sq_index** out) {
   std::string p = dir + "/index.bin";
   struct stat st;
-  if (stat((dir + "/versionInfo.json").c_str(), &st) != 0) { sq_set_error("index directory '%s' has no versionInfo.json", dir.c_str()); return SQ_ERR_IO; }  // SalmonIndex.hpp:124-131
+  // SalmonIndex.hpp:124-131
+  if (stat((dir + "/versionInfo.json").c_str(), &st) != 0) {
+    sq_set_error("index directory '%s' has no versionInfo.json", dir.c_str());
+    return SQ_ERR_IO;
+  }
   FILE* f = fopen(p.c_str(), "rb"); if (!f) { sq_set_error("cannot open '%s'", p.c_str()); return SQ_ERR_IO; }
-  Hdr h; if (fread(&h, sizeof(h), 1, f) != 1 || h.magic != SQ_INDEX_MAGIC || h.version != SQ_INDEX_VERSION) { fclose(f); sq_set_error("'%s' is not a salmon-hip index of version %u", p.c_str(), SQ_INDEX_VERSION); return SQ_ERR_IO; }
+  Hdr h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || h.magic != SQ_INDEX_MAGIC || h.version != SQ_INDEX_VERSION) {
+    fclose(f);
+    sq_set_error("'%s' is not a salmon-hip index of version %u", p.c_str(), SQ_INDEX_VERSION);
+    return SQ_ERR_IO;
+  }
   sq_index* idx = new sq_index(); idx->k = h.k; idx->m = h.m; idx->first_decoy = h.first_decoy; idx->n_parts = h.n_parts; idx->num_kmers = h.num_kmers;
   std::vector<char> nm;
   bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f, idx->useq) && rvec(f, idx->uoff) &&

@@ -28,9 +28,31 @@ struct RecBlock { std::vector<char> seq; std::vector<uint32_t> len; };   // sequ
 // bounded single-producer / single-consumer queue of record blocks
 struct BlockQueue {
   std::mutex mu; std::condition_variable cv_put, cv_get; std::deque<std::unique_ptr<RecBlock>> q; bool done = false; std::string err; size_t cap = 8;
-  void put(std::unique_ptr<RecBlock> b) { std::unique_lock<std::mutex> lk(mu); cv_put.wait(lk, [&] { return q.size() < cap || done; }); if (done) return; q.push_back(std::move(b)); cv_get.notify_one(); }
-  void finish(const std::string& e = std::string()) { { std::lock_guard<std::mutex> lk(mu); done = true; if (!e.empty()) err = e; } cv_get.notify_all(); cv_put.notify_all(); }
-  std::unique_ptr<RecBlock> get() { std::unique_lock<std::mutex> lk(mu); cv_get.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return nullptr; auto b = std::move(q.front()); q.pop_front(); cv_put.notify_one(); return b; }
+  void put(std::unique_ptr<RecBlock> b) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_put.wait(lk, [&] { return q.size() < cap || done; });
+    if (done) return;
+    q.push_back(std::move(b));
+    cv_get.notify_one();
+  }
+  void finish(const std::string& e = std::string()) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done = true;
+      if (!e.empty()) err = e;
+    }
+    cv_get.notify_all();
+    cv_put.notify_all();
+  }
+  std::unique_ptr<RecBlock> get() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_get.wait(lk, [&] { return !q.empty() || done; });
+    if (q.empty()) return nullptr;
+    auto b = std::move(q.front());
+    q.pop_front();
+    cv_put.notify_one();
+    return b;
+  }
 };
 
 // one mate stream: inflate + split records.  FASTQ and FASTA, sequences and qualities on one or several lines
@@ -117,7 +139,13 @@ struct sq_reader {
   // next record of stream i -> (ptr, len); false at end of stream
   bool rec(int i, const char** p, uint32_t* l) {
     for (;;) {
-      if (cur[i] && cur_rec[i] < cur[i]->len.size()) { *l = cur[i]->len[cur_rec[i]]; *p = cur[i]->seq.data() + cur_byte[i]; cur_byte[i] += *l; ++cur_rec[i]; return true; }
+      if (cur[i] && cur_rec[i] < cur[i]->len.size()) {
+        *l = cur[i]->len[cur_rec[i]];
+        *p = cur[i]->seq.data() + cur_byte[i];
+        cur_byte[i] += *l;
+        ++cur_rec[i];
+        return true;
+      }
       cur[i] = q[i].get(); cur_rec[i] = 0; cur_byte[i] = 0;
       if (!cur[i]) return false;
     }
@@ -146,7 +174,17 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
   if (si < 0) { sq_set_error("sq_reader_next: all %zu batch buffers are in use (sq_reader_release one first)", R->slots.size()); return SQ_ERR_STATE; }
   Slot& S = R->slots[(size_t)si];
   const size_t nrec_max = (size_t)R->batch * (R->paired ? 2 : 1);
-  if (S.off_cap < nrec_max + 1) { host_free(S.off, S.off_pinned); bool pin = false; S.off = (uint64_t*)host_alloc((nrec_max + 1) * 8, &pin); S.off_pinned = pin; S.off_cap = nrec_max + 1; if (!S.off) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; } }
+  if (S.off_cap < nrec_max + 1) {
+    host_free(S.off, S.off_pinned);
+    bool pin = false;
+    S.off = (uint64_t*)host_alloc((nrec_max + 1) * 8, &pin);
+    S.off_pinned = pin;
+    S.off_cap = nrec_max + 1;
+    if (!S.off) {
+      sq_set_error("sq_reader: out of memory");
+      return SQ_ERR_NOMEM;
+    }
+  }
   auto grow = [&](size_t need) -> bool {
     if (need <= S.seq_cap) return true;
     size_t cap = need + need / 2 + (1u << 20); bool pin; uint8_t* nb = (uint8_t*)host_alloc(cap, &pin); if (!nb) return false;
@@ -160,8 +198,17 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
     const bool h1 = R->rec(0, &p1, &l1); const bool h2 = R->paired ? R->rec(1, &p2, &l2) : h1;
     if (!h1 || !h2) {
       R->ended = true;
-      for (int i = 0; i < (R->paired ? 2 : 1); ++i) { std::lock_guard<std::mutex> lk(R->q[i].mu); if (!R->q[i].err.empty()) { sq_set_error("%s", R->q[i].err.c_str()); return SQ_ERR_IO; } }
-      if (R->paired && h1 != h2) { sq_set_error("mate files have different numbers of records (stopped after %llu pairs)", (unsigned long long)(R->total + n)); return SQ_ERR_IO; }
+      for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
+        std::lock_guard<std::mutex> lk(R->q[i].mu);
+        if (!R->q[i].err.empty()) {
+          sq_set_error("%s", R->q[i].err.c_str());
+          return SQ_ERR_IO;
+        }
+      }
+      if (R->paired && h1 != h2) {
+        sq_set_error("mate files have different numbers of records (stopped after %llu pairs)", (unsigned long long)(R->total + n));
+        return SQ_ERR_IO;
+      }
       break;
     }
     if (!grow(bytes + l1 + l2 + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
