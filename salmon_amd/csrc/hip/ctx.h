@@ -32,7 +32,13 @@ struct sq_cand_dev {    // 48 B
 };
 
 struct sq_dp_item {     // one banded-DP region queued by the fast scorer
-  uint32_t cand; uint8_t end, mode, rc, pad; int32_t qstart, qdir, n; int64_t tstart; int32_t tdir, tl; int32_t budget;  // region scores below `budget` cannot yield a valid alignment
+  // region scores below `budget` cannot yield a valid alignment
+  uint32_t cand;
+  uint8_t end, mode, rc, pad;
+  int32_t qstart, qdir, n;
+  int64_t tstart;
+  int32_t tdir, tl;
+  int32_t budget;
 };
 
 struct sq_map_params {
@@ -93,7 +99,10 @@ struct sq_ctx {
   // dependent kernels then never queues behind the mapping kernels' workgroups.  stream3 is unmasked: an eq job that
   // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
   hipStream_t stream3 = nullptr; hipStream_t eq_stream_cur = nullptr; int eq_cus = 0; std::atomic<int> map_active{0}; hipEvent_t ev_eq_last = nullptr;
-  hipStream_t stream2 = nullptr; hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr}; int cur_buf = 0, last_buf = 0; bool eq_pending[2] = {false, false};
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr};
+  int cur_buf = 0, last_buf = 0;
+  bool eq_pending[2] = {false, false};
   sq_dbuf<sq_aln> aln_b1; sq_dbuf<uint64_t> aln_off_b1;
   sq_aln* aln_ptr(int b) { return b ? aln_b1.p : aln.p; }
   uint64_t* aln_off_ptr(int b) { return b ? aln_off_b1.p : aln_off.p; }
