@@ -620,7 +620,8 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
     if (hs == INVALID_SCORE) { st.num_mappings_filtered++; continue; }
     c.valid = true; score[i] = hs; scored[i] = 1;
   }
-  if (taps && taps->on) for (auto& c : cands) { sq_cand x{}; x.frag = frag; x.tid = c.tid; x.lpos = c.lc >= 0 ? ch[0][c.lc].pos : 0; x.rpos = c.rc >= 0 ? ch[1][c.rc].pos : 0;
+  if (taps &&
+      taps->on) for (auto& c : cands) { sq_cand x{}; x.frag = frag; x.tid = c.tid; x.lpos = c.lc >= 0 ? ch[0][c.lc].pos : 0; x.rpos = c.rc >= 0 ? ch[1][c.rc].pos : 0;
       x.lfw = c.lc >= 0 ? ch[0][c.lc].fw : 0; x.rfw = c.rc >= 0 ? ch[1][c.rc].fw : 0; x.mate_status = c.mate_status; x.valid = c.valid; x.lscore = c.lscore; x.rscore = c.rscore; x.frag_len = c.frag_len; taps->cands.push_back(x); }
   // updateRefMappings, order-independent form (SPEC §a7): decoys only set bestDecoy; non-decoys
   // keep one best hit per transcript (ties: the later compatible hit wins).
@@ -839,7 +840,8 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
         if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
         else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
         bool useFLD = singleEnd || burned;
-        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.liveCMF[std::min<size_t>(len, 1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
+        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.liveCMF[std::min<size_t>(len,
+            1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
         double refCM = cmfv((size_t)tl); bool cm = !(refCM == SQ_LOG_0);
         logFragProb = cm ? (cmfv((size_t)maxFL) - refCM) : SQ_LOG_EPSILON;
       } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
@@ -950,7 +952,8 @@ static void em_setup(EMProblem& P, const sq_eq_table* eq, const sq_txp_in* txp, 
   for (uint64_t c = 0; c < P.E; ++c) for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) { uint64_t d = cur[P.tid[i]]++; P.t_cls[d] = c; P.t_pos[d] = i; }
 }
 // one update: returns alphaOut (EMUpdate_ :178-234 / VBEMUpdate_ :241-328), transcript-major sums
-static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<double>& alphaIn, std::vector<double>& alphaOut, std::vector<double>& theta, std::vector<double>& invDenom) {
+static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<double>& alphaIn, std::vector<double>& alphaOut, std::vector<double>& theta,
+    std::vector<double>& invDenom) {
   const uint32_t M = P.M;
   if (o->use_vbem) {
     std::vector<double> ap(M); for (uint32_t i = 0; i < M; ++i) ap[i] = alphaIn[i] + P.prior[i];
@@ -1046,7 +1049,8 @@ static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_op
 }
 
 // a17 — CollapsedGibbsSampler::sample + sampleRoundNonCollapsedMultithreaded_ (CollapsedGibbsSampler.cpp:92-278, 317-508); SPEC §a17
-static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) {
+static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped,
+    double* out) {
   const uint32_t M = txp->num_txp; const uint64_t E = eq->num_classes;
   const bool perTxp = go->use_vbem ? go->per_transcript_prior != 0 : true;
   double pv = 1e-3; if (go->use_vbem) pv = perTxp ? (go->vb_prior < 1.0 ? 1.0 : go->vb_prior) : (go->vb_prior < 1e-3 ? 1e-3 : go->vb_prior);
@@ -1341,7 +1345,8 @@ void orc_eq_finish(orc_state* s, sq_eq_table* out) {
   struct Row { uint64_t h1, h2; const std::vector<uint32_t>* lab; const EqVal* v; };
   std::vector<Row> rows; rows.reserve(S.eq.size()); uint64_t L = 0;
   for (auto& kv : S.eq) { Row r; label_hash(kv.first, &r.h1, &r.h2); r.lab = &kv.first; r.v = &kv.second; rows.push_back(r); L += kv.second.wq.size(); }
-  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { const uint32_t ta = (*a.lab)[0], tb = (*b.lab)[0]; if (ta != tb) return ta < tb; return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { const uint32_t ta = (*a.lab)[0],
+      tb = (*b.lab)[0]; if (ta != tb) return ta < tb; return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
   out->num_classes = rows.size(); out->num_labels = L;
   if (!out->off) return;
   uint64_t p = 0;
@@ -1417,7 +1422,8 @@ int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opt
 int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) {
   return bootstrap(eq, txp, o, B, seed, num_mapped, out);
 }
-int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped, double* out) {
+int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped,
+    double* out) {
   return gibbs(eq, txp, go, alpha_init, S, seed, num_mapped, out);
 }
 int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out) {
@@ -1466,10 +1472,14 @@ double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_e
       auto f1 = [&](uint32_t t) { for (uint32_t i = t; i < M; i += nthreads) th[i] = ap[i] > 1e-10 ? sq_exp(sq_digamma(ap[i]) - ln) : 0.0; };
       std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f1, t); for (auto& x : tv) x.join(); } else th = a;
     auto f2 = [&](uint32_t t) { uint64_t c0 = P.E * t / nthreads, c1 = P.E * (t + 1) / nthreads;
-      for (uint64_t c = c0; c < c1; ++c) { uint64_t x = P.off[c], y = P.off[c + 1]; if (y - x <= 1) { inv[c] = 0; continue; } double d = 0; for (uint64_t i = x; i < y; ++i) { double v = th[P.tid[i]]; if (!o->use_vbem || v > 0) d += v * P.cw[i]; } inv[c] = d <= 2.2250738585072014e-308 ? 0.0 : (double)P.count[c] / d; } };
+      for (uint64_t c = c0; c < c1; ++c) { uint64_t x = P.off[c],
+          y = P.off[c + 1]; if (y - x <= 1) { inv[c] = 0; continue; } double d = 0; for (uint64_t i = x; i < y; ++i) { double v = th[P.tid[i]]; if (!o->use_vbem ||
+          v > 0) d += v * P.cw[i]; } inv[c] = d <= 2.2250738585072014e-308 ? 0.0 : (double)P.count[c] / d; } };
     { std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f2, t); for (auto& x : tv) x.join(); }
     auto f3 = [&](uint32_t t) { uint32_t m0 = (uint64_t)M * t / nthreads, m1 = (uint64_t)M * (t + 1) / nthreads;
-      for (uint32_t m = m0; m < m1; ++m) { double acc = 0, v0 = th[m]; for (uint64_t d = P.t_off[m]; d < P.t_off[m + 1]; ++d) { uint64_t c = P.t_cls[d]; if (P.off[c + 1] - P.off[c] == 1) { acc += (double)P.count[c]; continue; } if (inv[c] == 0.0 || (o->use_vbem && !(v0 > 0))) continue; acc += v0 * P.cw[P.t_pos[d]] * inv[c]; } b[m] = acc; } };
+      for (uint32_t m = m0; m < m1; ++m) { double acc = 0,
+          v0 = th[m]; for (uint64_t d = P.t_off[m]; d < P.t_off[m + 1]; ++d) { uint64_t c = P.t_cls[d]; if (P.off[c + 1] - P.off[c] == 1) { acc += (double)P.count[c]; continue; } if (inv[c] == 0.0 ||
+          (o->use_vbem && !(v0 > 0))) continue; acc += v0 * P.cw[P.t_pos[d]] * inv[c]; } b[m] = acc; } };
     { std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f3, t); for (auto& x : tv) x.join(); }
     a.swap(b);
   }

@@ -120,7 +120,8 @@ static int cmd_quant(int argc, char** argv) {
   const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
   if (!idir || !odir || (!ru && !(r1 && r2))) {
-    fprintf(stderr, "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
+    fprintf(stderr,
+        "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
     return 1;
   }
   std::string lib = lt ? lt : (ru ? "U" : "IU");
@@ -212,22 +213,28 @@ static int cmd_quant(int argc, char** argv) {
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
   { uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
     const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
-    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand, lc, ms.num_assigned, ms.num_compatible)) die("lib_format_counts"); }
+    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand, lc, ms.num_assigned,
+        ms.num_compatible)) die("lib_format_counts"); }
   { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
     std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
     if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
-  if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
+  if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv,
+      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
   if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n", (unsigned long long)tot.num_orphans_rescued);   // SalmonQuantify.cpp:2697-2701
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
   if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)
-    fprintf(mf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
+    fprintf(mf,
+        "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
                 "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
                 "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f\n}\n",
-            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes, (unsigned long long)nfrag, (unsigned long long)ms.num_assigned,
-            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails, (unsigned long long)tot.num_fragments_filtered, (unsigned long long)tot.num_mappings_filtered,
-            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb", rep.iters, ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs);
+            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes, (unsigned long long)nfrag,
+                (unsigned long long)ms.num_assigned,
+            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails, (unsigned long long)tot.num_fragments_filtered,
+                (unsigned long long)tot.num_mappings_filtered,
+            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb", rep.iters,
+                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs);
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
@@ -235,8 +242,10 @@ static int cmd_quant(int argc, char** argv) {
     fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir, lib.c_str(), odir);
     fclose(cf);
   }
-  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n", (unsigned long long)nfrag, (unsigned long long)ms.num_assigned,
-          nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv, "--useEM") ? "EM" : "VBEM", secs, odir);
+  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n", (unsigned long long)nfrag,
+      (unsigned long long)ms.num_assigned,
+          nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv, "--useEM") ? "EM" : "VBEM", secs,
+              odir);
   sq_ctx_free(ctx); sq_index_free(idx);
   return 0;
 }

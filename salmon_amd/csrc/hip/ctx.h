@@ -116,7 +116,8 @@ struct sq_ctx {
   // stream and work buffers (lane 0 = this ctx, further lanes = shadow ctxs that own buffers only).  The mapping
   // kernels are latency- or issue-bound one at a time; two batches in flight fill each other's stalls.  Results come
   // back in submission order; the online/eq stage stays strictly ordered on its own stream.
-  struct map_job { sq_read_batch in; sq_aln_batch out; bool has_out = false; int rc = 0; sq_map_stats st; bool done = false; std::string err; uint32_t n = 0; int buf = 0; uint64_t total_aln = 0, joint = 0; };
+  struct map_job { sq_read_batch in; sq_aln_batch out; bool has_out = false; int rc = 0; sq_map_stats st; bool done = false; std::string err; uint32_t n = 0; int buf = 0; uint64_t total_aln = 0,
+      joint = 0; };
   uint32_t acc_n = 0; int acc_buf = 0; uint64_t acc_total_aln = 0, acc_joint = 0;   // the batch sq_eq_accumulate will take (set by sq_map_batch / sq_map_wait)
   sq_ctx* owner = nullptr;                 // set in a shadow ctx: the ctx that owns the online model and the eq worker
   std::vector<sq_ctx*> shadows;            // lanes 1.. (owned by lane 0)
@@ -139,7 +140,8 @@ void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id);        // block until the eq w
 void sq_eq_worker_stop(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
-enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP, ST_RESCUED, ST_N };
+enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP,
+    ST_RESCUED, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`

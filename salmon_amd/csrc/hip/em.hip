@@ -88,7 +88,8 @@ __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long*
 // then finishes the canonical sum of (alpha + prior) from the level-1 partials (SPEC §D2: 64-leaf
 // strided-halving trees, level by level) and publishes logNorm = digamma(sum).  Being a single
 // block, the `done` flag it may set is visible to every later kernel of the iteration.
-__global__ void __launch_bounds__(1024) k_top(EmDev d, const double* __restrict__ partials, uint32_t n1, int close_prev, uint32_t prev_it, unsigned long long* maxrel_log, double* __restrict__ log_norm) {
+__global__ void __launch_bounds__(1024) k_top(EmDev d, const double* __restrict__ partials, uint32_t n1, int close_prev, uint32_t prev_it,
+    unsigned long long* maxrel_log, double* __restrict__ log_norm) {
   __shared__ double buf[2][4096];
   if (threadIdx.x == 0 && close_prev && !d.flags[0]) em_close(d, prev_it, maxrel_log);
   __syncthreads();
@@ -280,7 +281,8 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
       unsigned long long b = (unsigned long long)__double_as_longlong(rel);
       if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b);
     }
-    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -353,7 +355,8 @@ double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used
 // combined weights, transcript-major CSC (radix sort of (tid, class) keys), the blocked-64 reduction
 // plan (SPEC §D4) and the block plans of k_class / k_l1 are all built in HBM from the label-major
 // CSR; the host only follows two short "next block" chains.
-__global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const double* __restrict__ w, const uint64_t* __restrict__ cnt_u,
+__global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const double* __restrict__ w,
+    const uint64_t* __restrict__ cnt_u,
                           const double* __restrict__ eff, int no_rich, int eq_mode, double* __restrict__ cw, double* __restrict__ cnt_f, uint32_t* __restrict__ err) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
   const uint64_t a = off[c], b = off[c + 1]; const double cn = (double)cnt_u[c];
@@ -372,7 +375,8 @@ __global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ o
 __global__ void k_prep_prior(uint32_t M, const double* __restrict__ eff, double vb_prior, int per_txp, double* __restrict__ prior) {   // populatePriorAlphas_ :82-99
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t < M) prior[t] = per_txp ? vb_prior : vb_prior * eff[t];
 }
-__global__ void k_prep_keys(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, unsigned long long* __restrict__ key, uint32_t* __restrict__ val) {
+__global__ void k_prep_keys(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, unsigned long long* __restrict__ key,
+    uint32_t* __restrict__ val) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
   for (uint64_t i = off[c]; i < off[c + 1]; ++i) { key[i] = ((unsigned long long)tid[i] << 32) | c; val[i] = (uint32_t)i; }
 }
@@ -386,7 +390,8 @@ __global__ void k_prep_csc(uint64_t L, uint32_t M, const unsigned long long* __r
   if (i + 1 == L) for (uint64_t x = (uint64_t)t + 1; x <= M; ++x) t_off[x] = L;
 }
 // number of blocked-64 segments of every transcript at each level (0 where the level is not needed)
-__global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, uint32_t* __restrict__ ns0, uint32_t* __restrict__ ns1, uint32_t* __restrict__ ns2, uint32_t* __restrict__ ns3, uint32_t* __restrict__ err) {
+__global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, uint32_t* __restrict__ ns0, uint32_t* __restrict__ ns1, uint32_t* __restrict__ ns2,
+    uint32_t* __restrict__ ns3, uint32_t* __restrict__ err) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t > M) return;
   if (t == M) { ns0[M] = ns1[M] = ns2[M] = ns3[M] = 0; return; }
   const uint64_t n = t_off[t + 1] - t_off[t];
@@ -397,7 +402,8 @@ __global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, ui
 }
 // segments of level `lvl` for transcript t: runs of 64 items of the previous level (CSC entries for level 0)
 __global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_off, const uint32_t* __restrict__ ns_prev, const uint32_t* __restrict__ base_prev,
-                            const uint32_t* __restrict__ ns, const uint32_t* __restrict__ base, uint32_t* __restrict__ seg_lo, uint8_t* __restrict__ seg_cnt, uint32_t* __restrict__ seg_txp) {
+                            const uint32_t* __restrict__ ns, const uint32_t* __restrict__ base, uint32_t* __restrict__ seg_lo, uint8_t* __restrict__ seg_cnt,
+                                uint32_t* __restrict__ seg_txp) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= M) return;
   const uint32_t k = ns[t]; if (!k) return;
   const uint32_t n = lvl == 0 ? (uint32_t)(t_off[t + 1] - t_off[t]) : ns_prev[t];
@@ -420,14 +426,16 @@ __global__ void k_next_block(uint32_t n, const T* __restrict__ lo /* [n+1], lo[n
   if (maxu && a > g + maxu) a = g + maxu;
   nxt[g] = a;
 }
-__global__ void k_plan_seg8(uint32_t S0, const uint32_t* __restrict__ chunk_seg, uint32_t nchunks, const uint32_t* __restrict__ seg_lo, const uint8_t* __restrict__ seg_cnt, uint8_t* __restrict__ t_seg8) {
+__global__ void k_plan_seg8(uint32_t S0, const uint32_t* __restrict__ chunk_seg, uint32_t nchunks, const uint32_t* __restrict__ seg_lo,
+    const uint8_t* __restrict__ seg_cnt, uint8_t* __restrict__ t_seg8) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= S0) return;
   uint32_t a = 0, b = nchunks - 1;     // last block with chunk_seg[block] <= g
   while (a < b) { uint32_t m = (a + b + 1) >> 1; if (chunk_seg[m] <= g) a = m; else b = m - 1; }
   const uint8_t idx = (uint8_t)(g - chunk_seg[a]); const uint32_t lo = seg_lo[g], n = seg_cnt[g];
   for (uint32_t i = 0; i < n; ++i) t_seg8[lo + i] = idx;
 }
-__global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, const uint8_t* __restrict__ seg_cnt1, const uint32_t* __restrict__ seg_txp1, uint32_t* __restrict__ l2_lo, uint8_t* __restrict__ l2_cnt) {
+__global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, const uint8_t* __restrict__ seg_cnt1, const uint32_t* __restrict__ seg_txp1,
+    uint32_t* __restrict__ l2_lo, uint8_t* __restrict__ l2_cnt) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= S1) return;
   const uint32_t t = seg_txp1[g] & ~SEG_TOP; l2_lo[t] = seg_lo1[g]; l2_cnt[t] = seg_cnt1[g];
 }
@@ -494,8 +502,10 @@ struct EmSession {
       p_off = d_off.p; p_tid = d_tid.p; p_w = d_w.p; p_cnt = (const unsigned long long*)d_cntu.p;
     }
     DBuf<unsigned long long> key, key2; DBuf<uint32_t> val, val2, ns[4], base[4], d_err, nxt; DBuf<uint8_t> tmp;
-    bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) && !d_tcls.alloc(L) && !d_tcw.alloc(L) && !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
-              !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) && !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
+    bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) && !d_tcls.alloc(L) && !d_tcw.alloc(L) &&
+        !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
+              !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) &&
+                  !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     pt.mark("buffers");
@@ -538,7 +548,8 @@ struct EmSession {
         sq_set_error("device allocation failed in EM plan");
         return SQ_ERR_NOMEM;
       }
-      if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p, d_slo[l].p, d_scn[l].p, d_stx[l].p);
+      if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p, d_slo[l].p, d_scn[l].p,
+          d_stx[l].p);
     }
     // block plans (greedy packing = following a jump table; the chain has ~L/2048 links)
     std::vector<uint32_t> h_chunk, h_cchunk;
@@ -656,7 +667,8 @@ struct EmSession {
   double* result_dev = nullptr; double* h_stage = nullptr;
 };
 
-int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep, const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr) {
+int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep,
+    const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr) {
   PhaseTimer pt("em");
   int rc;
   { EmSession S; S.arena = arena; if (lent) { S.st = lent; S.own_stream = false; } rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
@@ -684,7 +696,8 @@ __global__ void k_u64_to_f64(uint32_t n, const unsigned long long* __restrict__ 
 __global__ void k_truncate(uint32_t n, double* __restrict__ a) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n && a[i] <= 1e-8) a[i] = 0.0; }
 
 // ---- a17 Gibbs (sampleRoundNonCollapsedMultithreaded_, CollapsedGibbsSampler.cpp:92-278) --------------
-struct GibbsDev { uint32_t M, E; const uint64_t* off; const uint32_t* tid; const double* w; const uint64_t* cnt; const double* eff; const double* prior; const uint8_t* active;
+struct GibbsDev { uint32_t M,
+    E; const uint64_t* off; const uint32_t* tid; const double* w; const uint64_t* cnt; const double* eff; const double* prior; const uint8_t* active;
                   double* mu; double* count_f; unsigned long long* count_i; const uint64_t* draw_off; };
 __global__ void k_gibbs_mu(GibbsDev g, uint64_t seed, uint64_t round_key, int no_gamma) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
@@ -696,7 +709,8 @@ __device__ inline double gibbs_class_p(const GibbsDev& g, uint64_t a, uint32_t n
   uint32_t t = g.tid[a + i];
   return mode == 0 ? (1000.0 * g.mu[t]) * g.w[a + i] : (mode == 1 ? 1.0 / g.eff[t] : 1.0);
 }
-__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed, uint64_t round_key) {
+__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed,
+    uint64_t round_key) {
   uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
   const uint32_t c = item_cls[it]; const uint64_t a = g.off[c]; const uint32_t n = (uint32_t)(g.off[c + 1] - a); const uint64_t cnt = g.cnt[c];
   if (n == 1) { if (item_s0[it] == 0) atomicAdd(&g.count_i[g.tid[a]], (unsigned long long)cnt); return; }
@@ -747,7 +761,8 @@ size_t sq_em_workspace_bytes(uint64_t E, uint64_t L, uint64_t M) {
   return (size_t)(46 * L + 17 * (L / 64 + M) + 24 * E + 128 * M + ((size_t)16 << 20));
 }
 
-int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep, void** arena_slot, void* lent_stream) {
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep,
+    void** arena_slot, void* lent_stream) {
   if (arena_slot && !*arena_slot) *arena_slot = new EmArena();
   const uint32_t M = txp->num_txp;
   // initial alphas (CollapsedEMOptimizer.cpp:778-823)
@@ -767,7 +782,8 @@ int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* 
   return SQ_OK;
 }
 
-extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out, sq_em_report* rep) {
+extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out,
+    sq_em_report* rep) {
   if (!eq || !txp || !o || !alpha_in || !alpha_out) { sq_set_error("sq_em_steps_dev: bad arguments"); return SQ_ERR_ARG; }
   std::vector<double> alpha(alpha_in, alpha_in + txp->num_txp);
   int rc = run_em(device, eq, txp, o, alpha, 1, iters, rep);
@@ -777,7 +793,8 @@ extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_i
 }
 
 
-extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped,
+    sq_replicate_cb cb, void* user) {
   if (!eq || !txp || !o || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_bootstrap_dev: bad arguments"); return SQ_ERR_ARG; }
   EmSession S; int rc = S.setup(device, eq, txp, o); if (rc) return rc;
   const uint32_t M = S.M, E = S.E;
@@ -809,7 +826,8 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
   return SQ_OK;
 }
 
-extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S_n, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S_n, uint64_t seed,
+    uint64_t num_mapped, sq_replicate_cb cb, void* user) {
   if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
     sq_set_error("sq_gibbs_dev: bad arguments");
     return SQ_ERR_ARG;
@@ -838,8 +856,10 @@ extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* 
   DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me;
   DBuf<uint8_t> d_act;
   DBuf<unsigned long long> d_ci;
-  if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) || d_is.upload(item_s0) || d_w.upload(w) || d_eff.upload(eff) || d_prior.upload(prior) ||
-      d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) || d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
+  if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) || d_is.upload(item_s0) || d_w.upload(w) ||
+      d_eff.upload(eff) || d_prior.upload(prior) ||
+      d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) ||
+          d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
   GibbsDev g;
   g.M = M;
   g.E = E;

@@ -44,15 +44,19 @@ void fill_params(sq_ctx* c) {
 }
 }  // namespace
 
-static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score", "k_dp", "k_select", "compact_alns",
+static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score",
+    "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table"};
-void sq_prof_begin(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
+void sq_prof_begin(sq_ctx* c,
+    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(-1); }
-void sq_prof_mark(sq_ctx* c, int stage, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
+void sq_prof_mark(sq_ctx* c, int stage,
+    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
 void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
-  for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
+  for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1],
+      ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
 extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) {
   if (!c) return SQ_ERR_ARG;
   c->prof_on = on != 0;
@@ -125,10 +129,14 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming));
   }
   const uint32_t nends = 2 * max_batch_reads;
-  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) || c->rlen.ensure(nends) ||
+  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) ||
+      c->rlen.ensure(nends) ||
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
-             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) || c->wid.ensure(nends) || c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) || c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
-             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) || c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
+             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) || c->wid.ensure(nends) ||
+                 c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) ||
+                 c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
+             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) ||
+                 c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
              c->stats.ensure(ST_N) || c->gapcost.ensure(SQ_MAX_CHAIN_GAP + 1);
   if (bad) { sq_set_error("device allocation failed in sq_ctx_create"); sq_ctx_free(c); return SQ_ERR_NOMEM; }
   // chaining gap-cost table: 0.01*avgSeed*l + 0.5*log2(l) (SPEC §a2), built with the shared deterministic log
@@ -317,9 +325,11 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     if (P.k == 31 && di->dict.m == 20)   // the default (k = 31, m = 20) gets the fully specialised kernel
-      k_seed<31, 20><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2);
+      k_seed<31, 20><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p,
+          c->counters.p + 2);
     else
-      k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2);
+      k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p,
+          c->counters.p + 2);
   }
   sq_prof_mark(c, SG_SEED);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
@@ -331,11 +341,13 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   c->last_total_mems = total_mems;
   const size_t MP = (size_t)total_mems + 8;
   const bool recover = P.recover_orphans && paired;   // recovered mates live in a second set of chain slabs (k_recover)
-  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) || c->mused.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
+  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) ||
+      c->mused.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
   if (total_mems) {
-    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, c->mkey.p, c->mval.p);
+    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, c->mkey.p,
+        c->mval.p);
     sq_prof_mark(c, SG_PROJECT);
     // one global radix sort on (read end, global reference position); a segmented sort over the position bits only
     // (rocPRIM DeviceSegmentedRadixSort, ~12 MEMs per segment) measured slower: 2.56 vs 2.05 ms per 1 M pairs
@@ -349,7 +361,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     sq_prof_mark(c, SG_SORT);
   }
   // (measured: visiting ends / fragments in work-sorted order lost more to scattered access than it gained in balance)
-  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p, c->n_chains.p, c->stats.p, nullptr);
+  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p,
+      c->n_chains.p, c->stats.p, nullptr);
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
   // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
   // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
@@ -365,7 +378,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     for (int attempt = 0; attempt < 3; ++attempt) {
       if (c->cands.ensure(cap_guess) || c->cand_frag.ensure(cap_guess)) { sq_set_error("device allocation failed for candidates; split the batch"); return SQ_ERR_NOMEM; }
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_CANDS, 0, sizeof(unsigned long long), st));
-      k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p, c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS);
+      k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p, c->cands.n,
+          c->frag_flags.p, c->stats.p + ST_CANDS);
       unsigned long long tc = 0;
       SQ_HIP_CHECK(hipMemcpyAsync(&tc, c->stats.p + ST_CANDS, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
@@ -411,7 +425,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     sq_prof_mark(c, SG_DP);
   }
   if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p, tid_arr.p);
-  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
+  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p,
+      c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
   rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off_ptr(buf), n + 1); if (rc) return rc;
@@ -458,7 +473,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off, const uint8_t* windows, const uint64_t* w_off, const int32_t* k, int32_t* out) {
+extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off, const uint8_t* windows, const uint64_t* w_off,
+    const int32_t* k, int32_t* out) {
   if (!ncases) return SQ_OK;
   if (!queries || !q_off || !windows || !w_off || !k || !out) { sq_set_error("sq_debug_infix_align: null argument"); return SQ_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { sq_set_error("sq_debug_infix_align: no device %d", device); return SQ_ERR_DEVICE; }
@@ -482,7 +498,8 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
   }
   sq_dbuf<uint64_t> d_rp, d_rn, d_text, d_toff; sq_dbuf<uint16_t> d_rl; sq_dbuf<int32_t> d_k, d_out;
   int rc = SQ_OK;
-  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) || d_out.ensure((size_t)4 * ncases)) {
+  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) ||
+      d_out.ensure((size_t)4 * ncases)) {
     sq_set_error("sq_debug_infix_align: device allocation failed");
     rc = SQ_ERR_NOMEM;
   }
@@ -522,7 +539,8 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   const uint64_t* racc = c->idx->ref_accum.data();
   if (what == SQ_TAP_UNIMEMS) {
     std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * SQ_MAX_UNIMEMS);
-    if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p, um.size() * sizeof(sq_unimem_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p, um.size() * sizeof(sq_unimem_dev),
+        hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     uint64_t cnt = 0; sq_unimem* o = (sq_unimem*)buf;
     for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) {
       if (o && cnt < cap) {
@@ -546,7 +564,8 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   if (tm) {
     const uint64_t* sk = c->mkey2.p;
     const uint64_t* sv = c->mval2.p;
-    if (hipMemcpy(key.data(), sk, tm * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(val.data(), sv, tm * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    if (hipMemcpy(key.data(), sk, tm * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(val.data(), sv, tm * 8,
+        hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   }
   if (what == SQ_TAP_MEMS) {
     sq_mem* o = (sq_mem*)buf;
@@ -593,10 +612,12 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   if (what == SQ_TAP_CANDIDATES) {
     const uint64_t tc = c->last_total_cands; std::vector<sq_cand_dev> cd(tc); std::vector<uint64_t> coff(n + 1); std::vector<uint32_t> ncd(n);
     if (tc && hipMemcpy(cd.data(), c->cands.p, tc * sizeof(sq_cand_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
-    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p, (size_t)n * 4,
+        hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     sq_cand* o = (sq_cand*)buf; uint64_t cnt = 0;
     for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f] + ncd[f]; ++i) {
-      if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0, sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu, hr = d.rc != 0xFFFFFFFFu;
+      if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0, sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu,
+          hr = d.rc != 0xFFFFFFFFu;
         x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status; x.valid = d.valid; x.lscore = d.lscore; x.rscore = d.rscore; x.frag_len = d.frag_len; o[cnt] = x; }
       ++cnt; }
     return (int64_t)cnt;

@@ -99,7 +99,8 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
-                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor) {
+                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats,
+                           uint32_t* __restrict__ cursor) {
   const int k = KT ? KT : (int)P.k; const int alt = (int)P.alt_skip;
   const int lane = (int)(threadIdx.x & 63);
   uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false;
@@ -477,8 +478,10 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
 // there is no count kernel, no scan and no second enumeration.  Fragments with more than JP pairs, and
 // orphan-only fragments, fall back to the multi-pass enumeration of join_fragment<>.
 #define JP 8
-__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains, const uint32_t* __restrict__ n_chains,
-                        uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag, uint64_t cand_cap,
+__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains,
+    const uint32_t* __restrict__ n_chains,
+                        uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag,
+                            uint64_t cand_cap,
                         uint8_t* __restrict__ frag_flags, unsigned long long* __restrict__ cursor) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = f < nfrag;
@@ -795,7 +798,8 @@ __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, co
 // can decide and sums an upper bound (ma * n) for the rest; if even that bound misses
 // minScoreFraction the end is invalid and no DP is queued.  Otherwise pass 1 queues the DP regions,
 // each with the lowest region score that could still make the end valid (k_dp stops early below it).
-__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end, uint32_t* ndp, uint8_t* fail) {
+__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end,
+    uint32_t* ndp, uint8_t* fail) {
   ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
   const int L = r.L; const bool fw = ch.fw != 0;
   const uint32_t tid = ch.tid; const int Tlen = (int)S.ref_len[tid]; const int64_t g = (int64_t)S.ref_accum[tid];
@@ -861,8 +865,10 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
   }
 }
 
-__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ cand_off, uint32_t nfrag,
-                        const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, unsigned long long* __restrict__ stats) {
+__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ cand_off,
+    uint32_t nfrag,
+                        const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
+                            unsigned long long* __restrict__ stats) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ndp = 0;
   if (ci < ncand) {
@@ -895,7 +901,8 @@ __device__ inline uint32_t dp_tbase(const uint64_t* refseq, const sq_dp_item& it
   if (x < 0 || x >= it.tl) return 0u;
   return sq_fetch_base(refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * x));
 }
-__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, uint32_t paired) {
+__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
+    uint32_t paired) {
   uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii >= nitems) return;
   const sq_dp_item it = S.dpq[ii];
@@ -966,7 +973,8 @@ __device__ inline uint8_t hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t 
 
 // thread per candidate: validity against minScoreFraction and the hit score, written as two compact
 // arrays (SoA) so the per-fragment selection below streams 8 bytes per candidate instead of 48
-__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag, const uint16_t* __restrict__ rlen,
+__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
+    const uint16_t* __restrict__ rlen,
                            int32_t* __restrict__ hs_out, uint32_t* __restrict__ tid_out) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= ncand) return;
@@ -992,9 +1000,11 @@ __global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_
   hs_out[ci] = ok ? ((hasL && hasR) ? ls + rs : (hasL ? ls : rs)) : (SQ_INVALID_SCORE + 1);
 }
 
-__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand, const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
+__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand,
+    const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
                          const uint32_t* __restrict__ tid_arr, const sq_chain_dev* __restrict__ chains,
-                         const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln, uint8_t* __restrict__ map_type,
+                         const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln,
+                             uint8_t* __restrict__ map_type,
                          unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = gid < nfrag;

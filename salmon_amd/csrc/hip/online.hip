@@ -139,9 +139,11 @@ __device__ inline void label_hash_step(uint64_t& a, uint64_t& b, uint32_t x) {
 // compatibility verdict.  Everything a mini-batch still has to evaluate per alignment is then a
 // table lookup (FLD pmf/cmf, cached transcript log-mass) plus the in-order log-sum chains.
 struct PreAln { double c_cov; double c_start; uint32_t flen; uint16_t fl_ped, max_fl; uint16_t tl; uint8_t flags, fmt; uint32_t tid; };  // 32 B: everything about an alignment that does not depend on the evolving model
-enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16, PF_FLEN_IN_REF = 32 /* flen < refLength (refLength = max(RefLength, 1)) */ };
+enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16,
+    PF_FLEN_IN_REF = 32 /* flen < refLength (refLength = max(RefLength, 1)) */ };
 
-__global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ ref_clen, sq_quant_opts o, PreAln* __restrict__ pre) {
+__global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
+    PreAln* __restrict__ pre) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
   const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
@@ -190,8 +192,10 @@ __device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, u
 }
 
 __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint64_t read_counter0,
-                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out) {
+                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
+                                 const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1,
+                                 uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   rh1[r] = EQ_EMPTY; rh2[r] = 0;
@@ -292,8 +296,10 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 #define MB_G 8
 #define MB_S 2
 __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
-                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre, const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2, uint32_t par) {
+                             const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
+                                 const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1,
+                                 uint64_t* __restrict__ rh2, uint32_t par) {
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
   uint64_t fmtSeen = 0; int compatFrag = 0;   // this lane reports an assigned fragment that has a compatible alignment
@@ -301,7 +307,8 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
   if (valid && nA > MB_G * MB_S) {
-    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par, &compatFrag);
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par,
+        &compatFrag);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
     if (nA > 0) {
@@ -384,7 +391,8 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
               if (rr < pr && fl_ped[sl] > 0) {
                 atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u);
-                if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl_ped[sl]);
+                if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
+                    (unsigned long long)fl_ped[sl]);
               }
             }
           }
@@ -487,7 +495,8 @@ __device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_
 // kernel needs few workgroups and squeezes in beside the mapping kernels), the extra last block (before
 // burn-in only) updates the FLD — the two parts touch disjoint state, and every launch saved shortens
 // the sequential mini-batch chain (the model of mini-batch i+1 depends on the end of mini-batch i).
-__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin, uint32_t mass_blocks, int with_fld, uint32_t par) {
+__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin, uint32_t mass_blocks, int with_fld,
+    uint32_t par) {
   if (blockIdx.x < mass_blocks) apply_mass_part(V, logFM, assigned_after, with_fld ? 0 : 1, par, mass_blocks);
   else apply_fld_part(V, logFM, assigned_after, num_burnin);
 }
@@ -571,7 +580,8 @@ __global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ a
     T.n[slot] = nk; T.pool[slot] = off;
   }
 }
-__global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ abin, const unsigned long long* __restrict__ awq, const uint32_t* __restrict__ rslot) {
+__global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ abin, const unsigned long long* __restrict__ awq,
+    const uint32_t* __restrict__ rslot) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   uint32_t slot = rslot[r]; if (slot == 0xFFFFFFFFu) return;
@@ -581,7 +591,8 @@ __global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_
   for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) { atomicAdd(&T.pool_wq[off + i], awq[ai]); ++i; }
 }
 // merge an external table (classes given as CSR) — exact integer adds, any order
-__global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const uint32_t* __restrict__ bins, const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, uint32_t* __restrict__ cslot) {
+__global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const uint32_t* __restrict__ bins,
+    const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, uint32_t* __restrict__ cslot) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= E) return;
   bool is_new; uint64_t slot = eq_find_or_insert(T, h1[c], h2[c], &is_new);
@@ -595,7 +606,8 @@ __global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restri
     T.n[slot] = nk; T.pool[slot] = po;
   }
 }
-__global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wq, const uint64_t* __restrict__ count, const uint32_t* __restrict__ cslot) {
+__global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wq, const uint64_t* __restrict__ count,
+    const uint32_t* __restrict__ cslot) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= E) return;
   uint32_t slot = cslot[c]; if (slot == 0xFFFFFFFFu) return;
@@ -630,7 +642,8 @@ __global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, ui
     slots[i] = (uint32_t)s;
   }
 }
-__global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab, uint32_t* __restrict__ tie) {
+__global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab,
+    uint32_t* __restrict__ tie) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c > E) return;
   if (c == E) { nlab[E] = 0; return; }
@@ -640,8 +653,10 @@ __global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ sl
     if (a1 > b1 || (a1 == b1 && T.k2[slots[c]] > T.k2[slots[c + 1]])) *tie = 1;
   }
 }
-__global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off, uint32_t* __restrict__ tid, double* __restrict__ w, unsigned long long* __restrict__ wq,
-                            unsigned long long* __restrict__ count, uint32_t* __restrict__ bins, unsigned long long* __restrict__ h1, unsigned long long* __restrict__ h2) {
+__global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off, uint32_t* __restrict__ tid,
+    double* __restrict__ w, unsigned long long* __restrict__ wq,
+                            unsigned long long* __restrict__ count, uint32_t* __restrict__ bins, unsigned long long* __restrict__ h1,
+                                unsigned long long* __restrict__ h2) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= E) return;
   const uint32_t s = slots[c]; const uint32_t n = T.n[s]; const unsigned long long po = T.pool[s]; const uint64_t p = off[c];
@@ -707,10 +722,14 @@ int sq_online_create(sq_ctx* c) {
   const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
-  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) || o->prior_mass.ensure(M) || o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
-             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) || o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
-             o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) || o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
-             o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) || o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
+  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) || o->prior_mass.ensure(M) ||
+      o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
+             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) ||
+                 o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
+             o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) ||
+                 o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
+             o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) ||
+                 o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
   const sq_quant_opts& q = c->opts;
   std::vector<double> hist(1024, SQ_LOG_0), ambig(2048, 0.0), pm(M), le(M), mass(M, SQ_LOG_0); double tot0 = 0.0;
@@ -718,7 +737,8 @@ int sq_online_create(sq_ctx* c) {
     double nm = phi((i + 0.5 - q.fld_mean) / q.fld_sd) - phi((i - 0.5 - q.fld_mean) / q.fld_sd);
     hist[i] = (nm != 0) ? sq_log(nm) : SQ_LOG_EPSILON;
   }
-  { std::vector<double> v(1024, SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
+  { std::vector<double> v(1024,
+      SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
     tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
   // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
   {
@@ -828,7 +848,8 @@ static int check_eq_overflow(sq_ctx* c) {
     return SQ_ERR_OVERFLOW;
   }
   if (cur[1] * 10 > c->online->tcap * 7) {
-    sq_set_error("equivalence-class table over 70%% full (%llu classes of %llu slots): call sq_ctx_reserve with the expected number of classes before the first batch", cur[1], (unsigned long long)c->online->tcap);
+    sq_set_error("equivalence-class table over 70%% full (%llu classes of %llu slots): call sq_ctx_reserve with the expected number of classes before the first batch",
+        cur[1], (unsigned long long)c->online->tcap);
     return SQ_ERR_OVERFLOW;
   }
   return SQ_OK;
@@ -923,7 +944,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   };
   if (c->stream3) {   // CU partition on: use the CU-masked stream only while a mapping batch is (about to be) in flight
     // give the caller ~200 us to enter the next sq_map_batch (sleep_for has ~50 us granularity: poll instead)
-    for (auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200); !c->map_active.load() && std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
+    for (auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200); !c->map_active.load() &&
+        std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
     if (!c->map_active.load()) st = c->stream3;
   }
   c->eq_stream_cur = st;
@@ -965,7 +987,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
     const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
     const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p, o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, (uint32_t)(o->batch_no & 1));
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p,
+        o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, (uint32_t)(o->batch_no & 1));
     { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
       k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, (uint32_t)(o->batch_no & 1)); }
     if (!burned_host && assigned_after >= q.num_burnin_frags) {
@@ -1090,11 +1113,14 @@ static int eq_export_run(sq_ctx* c) {
   X.model_valid = false;
   if (E == 0) return SQ_OK;   // nothing staged; fetches fall back to direct copies
   EqView T = make_eq_view(o);
-  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
-      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1)) { sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) ||
+      X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
+      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) ||
+          X.d_tie.ensure(1)) { sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
   const size_t M = o->M; const size_t need = 32 * E + 24 * L + 64 + 32 * M;
   if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0; const size_t cap = need + need / 4;
-    if (hipHostMalloc((void**)&X.host, cap, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (eq export, %zu bytes)", cap); return SQ_ERR_NOMEM; } X.host_cap = cap; }
+    if (hipHostMalloc((void**)&X.host, cap, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (eq export, %zu bytes)",
+        cap); return SQ_ERR_NOMEM; } X.host_cap = cap; }
   mark("alloc");
   SQ_HIP_CHECK(hipMemsetAsync(X.d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(X.d_tie.p, 0, 4, st));
   k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, X.keys.p, X.slots.p, X.d_ctr.p);
@@ -1112,7 +1138,8 @@ static int eq_export_run(sq_ctx* c) {
     SQ_HIP_CHECK(hipMemcpy(hs.data(), X.slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(hk.data(), X.keys2.p, E * 8, hipMemcpyDeviceToHost));
     SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < E; ++i) ord[i] = (uint32_t)i;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { if (hk[x] != hk[y]) return hk[x] < hk[y]; const uint32_t a = hs[x], b = hs[y]; return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { if (hk[x] != hk[y]) return hk[x] < hk[y]; const uint32_t a = hs[x],
+        b = hs[y]; return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
     std::vector<uint32_t> hs2(E); for (uint64_t i = 0; i < E; ++i) hs2[i] = hs[ord[i]];
     SQ_HIP_CHECK(hipMemcpy(X.slots2.p, hs2.data(), E * 4, hipMemcpyHostToDevice));
     k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, X.slots2.p, X.keys2.p, X.nlab.p, X.d_tie.p);
@@ -1172,7 +1199,8 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   const unsigned nth = (unsigned)std::min<size_t>(8, std::max<size_t>(1, chunks.size() / 2));
   std::vector<std::thread> th; for (unsigned i = 1; i < nth; ++i) th.emplace_back(work);
   work(); for (auto& t : th) t.join();
-  if (timing) fprintf(stderr, "[sq-timing] eq_finish host-copy %.3f ms (%u threads)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), nth);
+  if (timing) fprintf(stderr, "[sq-timing] eq_finish host-copy %.3f ms (%u threads)\n", std::chrono::duration<double,
+      std::milli>(std::chrono::steady_clock::now() - tm0).count(), nth);
   return SQ_OK;
 }
 
@@ -1280,7 +1308,8 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
     { int rs = sq_eq_sync(c); if (rs) return rs; }
     unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
     if (cur[1]) {
-      sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1], (unsigned long long)E);
+      sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1],
+          (unsigned long long)E);
       return SQ_ERR_STATE;
     }
     uint64_t cap = o->tcap; while (E * 10 > cap * 7) cap <<= 1;
@@ -1289,7 +1318,8 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
       sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E, (unsigned long long)L);
       return SQ_ERR_ARG;
     }
-    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) || o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) {
+    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) ||
+        o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) {
       sq_set_error("device allocation failed (class table for %llu classes)", (unsigned long long)E);
       return SQ_ERR_NOMEM;
     }
@@ -1300,11 +1330,14 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
     SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
     SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, pcap * 8));
   }
-  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) || X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
-      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) || X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) ||
+      X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
+      X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) ||
+          X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
   X.valid = false; X.model_valid = false;   // buffers may have moved: a staged export is made again on its next use
   const size_t need = 32 * E + 24 * L + 64 + 32 * M;
   if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0;
-    if (hipHostMalloc((void**)&X.host, need, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)", need); return SQ_ERR_NOMEM; } X.host_cap = need; }
+    if (hipHostMalloc((void**)&X.host, need, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)",
+        need); return SQ_ERR_NOMEM; } X.host_cap = need; }
   return sq_em_arena_reserve(&c->em_arena, sq_em_workspace_bytes(E, L, M), (size_t)3 * M * 8, (size_t)(std::max<uint64_t>(E, L / 64 + M) + 1) * 4);
 }

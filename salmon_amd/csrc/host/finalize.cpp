@@ -255,7 +255,8 @@ extern "C" int sq_eq_file_table(const sq_eq_file* f, sq_eq_table* t) {
 }
 
 // quant.sf from plain name / length arrays (the -e mode has no index)
-extern "C" int sq_write_quant_sf_names(const char* path, uint32_t M, const char* const* names, const uint32_t* lens, const double* eff_len, const double* num_reads, double num_mapped_frags) {
+extern "C" int sq_write_quant_sf_names(const char* path, uint32_t M, const char* const* names, const uint32_t* lens, const double* eff_len, const double* num_reads,
+    double num_mapped_frags) {
   if (!path || !names || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf_names: bad arguments"); return SQ_ERR_ARG; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
   if (!(num_mapped_frags > 0)) { num_mapped_frags = 0; for (uint32_t i = 0; i < M; ++i) num_mapped_frags += num_reads[i]; }
@@ -344,7 +345,8 @@ extern "C" int sq_write_lib_format_counts(const char* path, const char* read_fil
   if (lib_strand == 4) { nAgree = nF1 + nF2; nDisagree = nDisUnstranded; ratio = nAgree > 0 ? (double)nF1 / (double)(nF1 + nF2) : 0.0; }
   else { nDisagree = nDisStranded; ratio = nAgree > 0 ? (double)nF1 / (double)(nF1 + nF2) : 0.0; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
-  fprintf(f, "{\n    \"read_files\": \"%s\",\n    \"expected_format\": \"%s\",\n    \"compatible_fragment_ratio\": %.17g,\n    \"num_compatible_fragments\": %llu,\n    \"num_assigned_fragments\": %llu,\n"
+  fprintf(f,
+      "{\n    \"read_files\": \"%s\",\n    \"expected_format\": \"%s\",\n    \"compatible_fragment_ratio\": %.17g,\n    \"num_compatible_fragments\": %llu,\n    \"num_assigned_fragments\": %llu,\n"
              "    \"num_frags_with_concordant_consistent_mappings\": %llu,\n    \"num_frags_with_inconsistent_or_orphan_mappings\": %llu,\n    \"strand_mapping_bias\": %.17g",
           read_files ? read_files : "", lib_format_name(fid).c_str(), num_assigned ? (double)num_compatible / (double)num_assigned : 0.0,
           (unsigned long long)num_compatible, (unsigned long long)num_assigned, (unsigned long long)nAgree, (unsigned long long)nDisagree, ratio);

@@ -286,7 +286,8 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     uint64_t n = ents.size(); uint32_t P = nthreads; std::vector<uint64_t> cut(P + 1);
     for (uint32_t i = 0; i <= P; ++i) cut[i] = n * i / P;
     auto cmp = [](const MiniEnt& a, const MiniEnt& b) { return a.v < b.v || (a.v == b.v && a.e < b.e); };
-    sq_parallel_for(P, P, 1, [&](uint64_t b, uint64_t e, uint32_t) { for (uint64_t i = b; i < e; ++i) std::sort(ents.begin() + cut[i], ents.begin() + cut[i + 1], cmp); });
+    sq_parallel_for(P, P, 1, [&](uint64_t b, uint64_t e, uint32_t) { for (uint64_t i = b; i < e; ++i) std::sort(ents.begin() + cut[i], ents.begin() + cut[i + 1],
+        cmp); });
     for (uint32_t step = 1; step < P; step <<= 1) {
       std::vector<std::thread> th;
       for (uint32_t i = 0; i + step < P; i += 2 * step) {
@@ -548,11 +549,14 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
   for (auto w : idx.refseq) sh = sq_mix64(sh ^ w); for (auto& s : idx.names) for (unsigned char c : s) nh = sq_mix64(nh ^ c);
   f = fopen((dir + "/info.json").c_str(), "w");
   if (f) {
-    fprintf(f, "{\n  \"index_version\": %u,\n  \"sampling_type\": \"sshash-hip\",\n  \"k\": %u,\n  \"m\": %u,\n  \"num_kmers\": %llu,\n  \"num_contigs\": %llu,\n  \"seq_len\": %llu,\n"
+    fprintf(f,
+        "{\n  \"index_version\": %u,\n  \"sampling_type\": \"sshash-hip\",\n  \"k\": %u,\n  \"m\": %u,\n  \"num_kmers\": %llu,\n  \"num_contigs\": %llu,\n  \"seq_len\": %llu,\n"
                "  \"num_refs\": %zu,\n  \"first_decoy_index\": %u,\n  \"num_minimizers\": %llu,\n  \"num_super_kmers\": %llu,\n  \"num_skew_kmers\": %llu,\n  \"max_bucket\": %llu,\n"
                "  \"keep_duplicates\": false,\n  \"SeqHash\": \"%016llx\",\n  \"NameHash\": \"%016llx\",\n  \"SeqHash512\": \"\",\n  \"NameHash512\": \"\",\n  \"DecoySeqHash\": \"\",\n  \"DecoyNameHash\": \"\"\n}\n",
-            SQ_INDEX_VERSION, idx.k, idx.m, (unsigned long long)idx.num_kmers, (unsigned long long)(idx.uoff.size() - 1), (unsigned long long)idx.uoff.back(), idx.names.size(), idx.first_decoy,
-            (unsigned long long)idx.num_minimizers, (unsigned long long)idx.num_superkmers, (unsigned long long)idx.num_skew_kmers, (unsigned long long)idx.max_bucket, (unsigned long long)sh, (unsigned long long)nh);
+            SQ_INDEX_VERSION, idx.k, idx.m, (unsigned long long)idx.num_kmers, (unsigned long long)(idx.uoff.size() - 1), (unsigned long long)idx.uoff.back(),
+                idx.names.size(), idx.first_decoy,
+            (unsigned long long)idx.num_minimizers, (unsigned long long)idx.num_superkmers, (unsigned long long)idx.num_skew_kmers, (unsigned long long)idx.max_bucket,
+                (unsigned long long)sh, (unsigned long long)nh);
     fclose(f);
   }
   f = fopen((dir + "/versionInfo.json").c_str(), "w");
@@ -582,7 +586,8 @@ int sq_index_load_host(const std::string& dir, sq_index** out) {
   }
   sq_index* idx = new sq_index(); idx->k = h.k; idx->m = h.m; idx->first_decoy = h.first_decoy; idx->n_parts = h.n_parts; idx->num_kmers = h.num_kmers;
   std::vector<char> nm;
-  bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f, idx->useq) && rvec(f, idx->uoff) &&
+  bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f, idx->useq) && rvec(f,
+      idx->uoff) &&
             rvec(f, idx->ctab_off) && rvec(f, idx->ctab) && rvec(f, idx->part_slot_off) && rvec(f, idx->part_bkt_off) && rvec(f, idx->pilots) && rvec(f, idx->slots) &&
             rvec(f, idx->entries) && rvec(f, idx->skew_keys) && rvec(f, idx->skew_vals);
   fclose(f);

@@ -9,6 +9,9 @@ def scan(code):
     i, n, depth = 0, len(code), 0
     while i < n:
         c = code[i]
+        if c == "/" and code[i:i + 2] == "/*":          # block comment: nothing inside it is a break point
+            j = code.find("*/", i + 2)
+            i = n if j < 0 else j + 2; continue
         if c in "\"'":
             q = c; j = i + 1
             while j < n and code[j] != q:
@@ -96,12 +99,41 @@ def relayout(line, min_len):
     return [m + "\n" for m in merged]
 
 
+def wrap(line, max_len):
+    """second pass: a single statement that is still too long is broken after top-level `, ` / ` || ` / ` && ` (never inside a
+    literal or a comment), continuation lines indented by four more columns"""
+    if len(line) <= max_len or line.lstrip().startswith("#") or line.rstrip().endswith("\\"): return [line]
+    code, comment = split_comment(line)
+    if len(code) <= max_len: return [line]
+    indent = re.match(r"\s*", code).group(0)
+    cands = []                                   # break positions (index after the separator)
+    for i, c, depth in scan(code):
+        if c == "," and code[i:i + 2] == ", " and depth <= 2: cands.append(i + 2)
+        elif c in "|&" and code[i:i + 3] in ("|| ", "&& ") and code[i - 1] == " " and depth <= 1: cands.append(i + 3)
+    out, start, cont = [], 0, indent + "    "
+    while len(code) - start + (len(cont) if out else 0) > max_len:
+        limit = start + max_len - (len(cont) if out else 0)
+        best = [p for p in cands if start < p <= limit]
+        if not best:
+            later = [p for p in cands if p > limit]
+            if not later: break
+            cut = later[0]
+        else: cut = best[-1]
+        out.append((cont if out else "") + code[start:cut].rstrip())
+        start = cut
+    out.append((cont if out else "") + code[start:].rstrip())
+    if len(out) == 1: return [line]
+    if comment: out.insert(0, indent + comment)
+    return out
+
+
 def main():
     path = sys.argv[1]; min_len = int(sys.argv[2]) if len(sys.argv) > 2 else 180
     src = open(path).read().split("\n")
     out = []
     for l in src:
-        out.extend(x.rstrip("\n") for x in relayout(l, min_len))
+        for x in relayout(l, min_len):
+            out.extend(wrap(x.rstrip("\n"), min_len))
     open(path, "w").write("\n".join(out))
 
 
