@@ -97,7 +97,8 @@ struct Index {
 struct UniMem { uint16_t qpos, len; uint64_t unitig; uint32_t ustart; bool fw; };
 struct Mem { uint32_t tid; int32_t rpos; uint16_t q, len; bool fw; };  // q = strand-normalised read pos
 struct Chain { uint32_t tid; bool fw; double score; int32_t pos; int32_t last_end; uint16_t read_len; std::vector<uint32_t> mems; /* indices into the end's Mem array, ascending */ };
-struct Cand { uint32_t tid; int lc, rc; uint32_t frag_len; uint8_t mate_status; double cov; int32_t lscore = INVALID_SCORE, rscore = INVALID_SCORE; bool valid = false; };
+struct Cand { uint32_t tid; int lc, rc; uint32_t frag_len; uint8_t mate_status; double cov; int32_t lscore = INVALID_SCORE,
+    rscore = INVALID_SCORE; bool valid = false; };
 
 struct Opts { sq_quant_opts o; std::vector<double> gapcost; int32_t ma, mp, go, ge, bw; };
 
@@ -166,7 +167,12 @@ static void collect_unimems(const Index& ix, const Opts& op, const std::vector<u
         ++len;
       }
     }
-    UniMem m; m.qpos = (uint16_t)pos; m.len = (uint16_t)len; m.unitig = u; m.fw = fw; m.ustart = fw ? off : (uint32_t)((int)off - (len - (int)k));
+    UniMem m;
+    m.qpos = (uint16_t)pos;
+    m.len = (uint16_t)len;
+    m.unitig = u;
+    m.fw = fw;
+    m.ustart = fw ? off : (uint32_t)((int)off - (len - (int)k));
     out.push_back(m);
     if (pos + len >= L) break;
     int e = pos + len;
@@ -219,7 +225,10 @@ static void chain_end(const Index&, const Opts& op, const std::vector<Mem>& mems
         double a = (double)std::min((int)hi.len, std::min(qd, rd));
         double s = f[j] + a - op.gapcost[l];
         if (s > f[i]) { f[i] = s; p[i] = j; }
-        if (!op.o.disable_chaining_heuristic && p[i] >= 0) { if (--rounds <= 0) break; }  // Li 2018 heuristic (ProgramOptionsGenerator.cpp:160-167)
+        // Li 2018 heuristic (ProgramOptionsGenerator.cpp:160-167)
+        if (!op.o.disable_chaining_heuristic && p[i] >= 0) {
+          if (--rounds <= 0) break;
+        }
       }
       if (f[i] > best) best = f[i];
     }
@@ -251,7 +260,8 @@ static void chain_end(const Index&, const Opts& op, const std::vector<Mem>& mems
 
 // a3 — pufferfish::util::joinReadsAndFilter [external]; call site SalmonQuantify.cpp:1339-1341,
 // policy from SalmonMappingUtils.hpp:208-220.
-static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::vector<Chain>& rc, std::vector<Cand>& out, bool* had_dovetail) {
+static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::vector<Chain>& rc, std::vector<Cand>& out,
+    bool* had_dovetail) {
   out.clear(); *had_dovetail = false;
   size_t i = 0, j = 0;
   while (i < lc.size() && j < rc.size()) {
@@ -268,7 +278,13 @@ static int join_pair(const Opts& op, const std::vector<Chain>& lc, const std::ve
       int32_t fragEnd = rcc.pos + (int)rcc.read_len, fragStart = fwc.pos;
       int32_t fl = fragEnd - fragStart;
       if (fl <= 0 || fl > (int32_t)op.o.frag_len_max) continue;
-      Cand c; c.tid = t; c.lc = (int)a; c.rc = (int)b; c.frag_len = (uint32_t)fl; c.mate_status = SQ_MS_PAIRED_END_PAIRED; c.cov = x.score + y.score;
+      Cand c;
+      c.tid = t;
+      c.lc = (int)a;
+      c.rc = (int)b;
+      c.frag_len = (uint32_t)fl;
+      c.mate_status = SQ_MS_PAIRED_END_PAIRED;
+      c.cov = x.score + y.score;
       out.push_back(c);
     }
     i = i1; j = j1;
@@ -338,7 +354,11 @@ static bool infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k,
     lastrow[j] = col[n];
   }
   int best = -1, e0 = -1;
-  for (int j = 1; j <= m; ++j) if (lastrow[j] <= k && (best < 0 || lastrow[j] < best)) { best = lastrow[j]; e0 = j - 1; }   // first end among the minima
+  // first end among the minima
+  for (int j = 1; j <= m; ++j) if (lastrow[j] <= k && (best < 0 || lastrow[j] < best)) {
+    best = lastrow[j];
+    e0 = j - 1;
+  }
   if (best < 0) return false;
   // start location (edlib.cpp:353-369): reversed query against the reversed target prefix [0, e0], prefix mode
   // (D'[0][j] = j), score limit = best; the LAST column that reaches `best` gives the start.
@@ -365,7 +385,8 @@ static bool infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k,
 // reverse strand expects the mate forward, upstream (window = the 1000 bases ending at the anchor's end).  The mate
 // (strand-normalised) is placed by infix alignment with at most len/4 edits.  A recovered mate becomes a chain without
 // MEMs at the recovered start; the candidate becomes a proper pair.  Returns true if any mate was recovered.
-static bool recover_orphans(const Index& ix, const Opts& op, const std::vector<uint8_t> rd[2], std::vector<Chain> ch[2], std::vector<Cand>& cands) {
+static bool recover_orphans(const Index& ix, const Opts& op, const std::vector<uint8_t> rd[2], std::vector<Chain> ch[2],
+    std::vector<Cand>& cands) {
   bool any = false;
   std::vector<uint8_t> qn, win;
   for (auto& c : cands) {
@@ -489,8 +510,12 @@ struct LibFmt { uint8_t type, orient, strand; };
 static inline uint8_t format_id(LibFmt f) { return (uint8_t)(f.type | (f.orient << 1) | (f.strand << 3)); }
 static LibFmt hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t e2, bool f2, uint32_t l2, bool canDovetail) {  // SalmonUtils.cpp:577-631
   if (f1 != f2) {
-    if (f1) { int32_t stretch = canDovetail ? (int32_t)l2 : 0; return (e1 <= e2 + stretch) ? LibFmt{T_PE, O_TOWARD, S_SA} : LibFmt{T_PE, O_AWAY, S_SA}; }
-    int32_t stretch = canDovetail ? (int32_t)l1 : 0; return (e2 <= e1 + stretch) ? LibFmt{T_PE, O_TOWARD, S_AS} : LibFmt{T_PE, O_AWAY, S_AS};
+    if (f1) {
+      int32_t stretch = canDovetail ? (int32_t)l2 : 0;
+      return (e1 <= e2 + stretch) ? LibFmt{T_PE, O_TOWARD, S_SA} : LibFmt{T_PE, O_AWAY, S_SA};
+    }
+    int32_t stretch = canDovetail ? (int32_t)l1 : 0;
+    return (e2 <= e1 + stretch) ? LibFmt{T_PE, O_TOWARD, S_AS} : LibFmt{T_PE, O_AWAY, S_AS};
   }
   return f1 ? LibFmt{T_PE, O_SAME, S_S} : LibFmt{T_PE, O_SAME, S_A};
 }
@@ -535,7 +560,8 @@ struct FragResult { std::vector<sq_aln> alns; uint8_t map_type = SQ_MT_UNMAPPED;
 
 struct Taps { std::vector<sq_unimem> unimems; std::vector<sq_mem> mems; std::vector<sq_chain> chains; std::vector<sq_cand> cands; bool on = false; };
 
-static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const uint8_t* s1, uint32_t n1, const uint8_t* s2, uint32_t n2, bool paired,
+static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const uint8_t* s1, uint32_t n1, const uint8_t* s2, uint32_t n2,
+    bool paired,
                          FragResult& out, sq_map_stats& st, Taps* taps) {
   out.alns.clear(); out.map_type = SQ_MT_UNMAPPED;
   st.num_reads++;
@@ -562,7 +588,16 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
         x.fw = u.fw;
         taps->unimems.push_back(x);
       }
-      for (auto& m : mems[e]) { sq_mem x{}; x.end = eid; x.tid = m.tid; x.rpos = m.rpos; x.qpos = m.q; x.len = m.len; x.fw = m.fw; taps->mems.push_back(x); }
+      for (auto& m : mems[e]) {
+        sq_mem x{};
+        x.end = eid;
+        x.tid = m.tid;
+        x.rpos = m.rpos;
+        x.qpos = m.q;
+        x.len = m.len;
+        x.fw = m.fw;
+        taps->mems.push_back(x);
+      }
       for (auto& c : ch[e]) {
         sq_chain x{};
         x.end = eid;
@@ -581,7 +616,8 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
   if (paired) {
     const int jr = join_pair(op, ch[0], ch[1], cands, &dovetail);
     // orphan recovery (SalmonQuantify.cpp:1343-1364): orphan-only fragments with at most maxReadOccs candidates
-    if (jr == 2 && op.o.recover_orphans && cands.size() <= op.o.max_read_occs && recover_orphans(ix, op, rd, ch, cands)) st.num_orphans_rescued++;
+    if (jr == 2 && op.o.recover_orphans && cands.size() <= op.o.max_read_occs && recover_orphans(ix, op, rd, ch,
+        cands)) st.num_orphans_rescued++;
   }
   else {  // joinReadsAndFilterSingle: every surviving chain is a candidate (SalmonQuantify.cpp:2108-2109)
     for (size_t a = 0; a < ch[0].size(); ++a) {
@@ -637,7 +673,11 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
       if (score[i] < decoy_cut(runDecoy)) continue;
       auto it = bestPer.find(cands[i].tid);
       if (it == bestPer.end()) { bestPer[cands[i].tid] = i; keep[i] = 1; }
-      else if (score[i] > score[it->second] || (score[i] == score[it->second] && compat[i])) { keep[it->second] = 0; it->second = i; keep[i] = 1; }
+      else if (score[i] > score[it->second] || (score[i] == score[it->second] && compat[i])) {
+        keep[it->second] = 0;
+        it->second = i;
+        keep[i] = 1;
+      }
       if (score[i] > bestScore) bestScore = score[i];
     }
   }
@@ -697,7 +737,12 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
 // restatement (SPEC §D1): every fragment of a mini-batch sees the model as of the batch start.
 // ================================================================================================
 struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, kernel Binomial(4, 0.5))
-  std::vector<double> hist; double totMass = SQ_LOG_0; double kernel[5]; bool cached = false; std::vector<double> cpmf, ccmf; uint32_t minLen = 1000;
+  std::vector<double> hist;
+  double totMass = SQ_LOG_0;
+  double kernel[5];
+  bool cached = false;
+  std::vector<double> cpmf, ccmf;
+  uint32_t minLen = 1000;
   static double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
   void init(double mu, double sd) {
     hist.assign(1001, SQ_LOG_0);
@@ -717,7 +762,11 @@ struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, ke
     for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
     return v[0];
   }
-  double pmf(size_t len) const { if (cached) return len < cpmf.size() ? cpmf[len] : cpmf.back(); if (len > 1000) len = 1000; return hist[len] - totMass; }
+  double pmf(size_t len) const {
+    if (cached) return len < cpmf.size() ? cpmf[len] : cpmf.back();
+    if (len > 1000) len = 1000;
+    return hist[len] - totMass;
+  }
   double cmf(size_t len) const { return len < ccmf.size() ? ccmf[len] : ccmf.back(); }  // only used once cached
   void apply_counts(const std::vector<uint32_t>& cnt, double logFM) {  // batched addVal (:85-110)
     for (int b = 1; b <= 1000; ++b)
@@ -752,8 +801,22 @@ struct QuantState {
     ix = i; make_opts(o, op);
     size_t M = ix->names.size();
     fld.init(o->fld_mean, o->fld_sd);
-    ambigCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, SQ_LOG_EPSILON); ambigCMF[j] = cum; } }
-    liveCMF.resize(1001); { double cum = SQ_LOG_0; for (int j = 0; j <= 1000; ++j) { cum = sq_log_add(cum, fld.hist[j]); liveCMF[j] = cum - fld.totMass; } }
+    ambigCMF.resize(1001);
+    {
+      double cum = SQ_LOG_0;
+      for (int j = 0; j <= 1000; ++j) {
+        cum = sq_log_add(cum, SQ_LOG_EPSILON);
+        ambigCMF[j] = cum;
+      }
+    }
+    liveCMF.resize(1001);
+    {
+      double cum = SQ_LOG_0;
+      for (int j = 0; j <= 1000; ++j) {
+        cum = sq_log_add(cum, fld.hist[j]);
+        liveCMF[j] = cum - fld.totMass;
+      }
+    }
     mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
     // Transcript.hpp:48-56, ReadExperiment.inl:114
     for (size_t t = 0; t < M; ++t) {
@@ -786,7 +849,12 @@ static void compute_eff_lengths(const FLD& fld, const std::vector<uint32_t>& ref
   for (size_t i = minV; i < maxV; ++i) pmf[i] = 100.0 * sq_exp(lp[i - minV]);
   size_t n = pmf.size(); std::vector<double> cf(n, 0.0), vals(n, 0.0), mult(n, 0.0);
   mult[0] = pmf[0];
-  for (size_t i = 1; i < n; ++i) { double v = pmf[i]; vals[i] = v * (double)i + vals[i - 1]; mult[i] = v + mult[i - 1]; if (mult[i] > 0) cf[i] = vals[i] / mult[i]; }
+  for (size_t i = 1; i < n; ++i) {
+    double v = pmf[i];
+    vals[i] = v * (double)i + vals[i - 1];
+    mult[i] = v + mult[i - 1];
+    if (mult[i] > 0) cf[i] = vals[i] / mult[i];
+  }
   for (size_t t = 0; t < ref_len.size(); ++t) {
     double ol = (double)ref_len[t]; double c = (ol >= (double)n) ? cf[n - 1] : cf[ref_len[t]];
     double el = ol - c; if (el < 1.0) el = ol;
@@ -847,7 +915,11 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
       if (flen > 0 && o.use_frag_len_dist && cond) {
         double lenProb = S.fld.pmf(flen);
-        if (burned) { double cm = S.fld.cmf(flen); bool ok = ((double)flen < refLength) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+        if (burned) {
+          double cm = S.fld.cmf(flen);
+          bool ok = ((double)flen < refLength) && !(cm == SQ_LOG_0);
+          logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON;
+        }
         else if (useAux) logFragProb = lenProb;
       }
       LibFmt obs{(uint8_t)(a.format_id & 1), (uint8_t)((a.format_id >> 1) & 3), (uint8_t)(a.format_id >> 3)};
@@ -901,7 +973,14 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
     S.mass[t] = sq_log_add(S.mass[t], logFM + sq_log(sq_from_fixed(S.massAcc[t], SQ_MFRAC_BITS)));
     S.massAcc[t] = 0;
   }
-  if (!burned) { bool any = false; for (auto c : fldCnt) any |= (c != 0); if (any) { S.fld.apply_counts(fldCnt, logFM); S.fld.minLen = minLen; } }
+  if (!burned) {
+    bool any = false;
+    for (auto c : fldCnt) any |= (c != 0);
+    if (any) {
+      S.fld.apply_counts(fldCnt, logFM);
+      S.fld.minLen = minLen;
+    }
+  }
   S.numAssigned += local; S.numObserved += (r1 - r0); S.readCounter += (r1 - r0); S.batchNo++;
   if (S.numAssigned >= o.num_burnin_frags && !S.burnedIn) S.burnin_finalize();
 }
@@ -949,10 +1028,15 @@ static void em_setup(EMProblem& P, const sq_eq_table* eq, const sq_txp_in* txp, 
   for (uint32_t t = 0; t < P.M; ++t) P.t_off[t + 1] += P.t_off[t];
   P.t_cls.resize(P.tid.size()); P.t_pos.resize(P.tid.size());
   std::vector<uint64_t> cur(P.t_off.begin(), P.t_off.end() - 1);
-  for (uint64_t c = 0; c < P.E; ++c) for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) { uint64_t d = cur[P.tid[i]]++; P.t_cls[d] = c; P.t_pos[d] = i; }
+  for (uint64_t c = 0; c < P.E; ++c) for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) {
+    uint64_t d = cur[P.tid[i]]++;
+    P.t_cls[d] = c;
+    P.t_pos[d] = i;
+  }
 }
 // one update: returns alphaOut (EMUpdate_ :178-234 / VBEMUpdate_ :241-328), transcript-major sums
-static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<double>& alphaIn, std::vector<double>& alphaOut, std::vector<double>& theta,
+static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<double>& alphaIn, std::vector<double>& alphaOut,
+    std::vector<double>& theta,
     std::vector<double>& invDenom) {
   const uint32_t M = P.M;
   if (o->use_vbem) {
@@ -980,7 +1064,11 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
     if (v.empty()) { alphaOut[t] = 0.0; continue; }
     for (;;) {
       w.clear();
-      for (size_t i = 0; i < v.size(); i += 64) { double acc = 0.0; for (size_t j = i; j < std::min(v.size(), i + 64); ++j) acc += v[j]; w.push_back(acc); }
+      for (size_t i = 0; i < v.size(); i += 64) {
+        double acc = 0.0;
+        for (size_t j = i; j < std::min(v.size(), i + 64); ++j) acc += v[j];
+        w.push_back(acc);
+      }
       v.swap(w);
       if (v.size() == 1) break;
     }
@@ -989,7 +1077,8 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
 }
 
 // iteration loop shared by optimize (minIter 100) and the bootstrap replicates (minIter 50)
-static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters, bool* converged, double* max_rel) {
+static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters,
+    bool* converged, double* max_rel) {
   const uint32_t M = P.M;
   std::vector<double> alphaP(M), theta(M), inv(P.E);
   uint32_t it = 0; bool conv = false; double maxRel = -1.7976931348623157e308;
@@ -997,7 +1086,11 @@ static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>
     em_step(P, o, alpha, alphaP, theta, inv);
     conv = true; maxRel = -1.7976931348623157e308;
     for (uint32_t i = 0; i < M; ++i) {
-      if (alphaP[i] > 1e-2) { double rd = std::fabs(alpha[i] - alphaP[i]) / alphaP[i]; if (rd > maxRel) maxRel = rd; if (rd > o->rel_diff_tolerance) conv = false; }
+      if (alphaP[i] > 1e-2) {
+        double rd = std::fabs(alpha[i] - alphaP[i]) / alphaP[i];
+        if (rd > maxRel) maxRel = rd;
+        if (rd > o->rel_diff_tolerance) conv = false;
+      }
       alpha[i] = alphaP[i]; alphaP[i] = 0.0;
     }
     ++it;
@@ -1021,12 +1114,20 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector :64-76
   double asum = canonical_sum(alpha);
   for (uint32_t i = 0; i < M; ++i) alpha_out[i] = alpha[i];
-  if (rep) { rep->iters = it; rep->converged = conv; rep->max_rel_diff = maxRel; rep->alpha_sum = asum; rep->device_ms = 0; rep->ms_per_iter = 0; }
+  if (rep) {
+    rep->iters = it;
+    rep->converged = conv;
+    rep->max_rel_diff = maxRel;
+    rep->alpha_sum = asum;
+    rep->device_ms = 0;
+    rep->ms_per_iter = 0;
+  }
   return asum < 2.2250738585072014e-308 ? SQ_ERR_STATE : SQ_OK;
 }
 
 // a16 — gatherBootstraps / doBootstrap (CollapsedEMOptimizer.cpp:398-690); SPEC §a16
-static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) {
+static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped,
+    double* out) {
   EMProblem P; em_setup(P, eq, txp, o);
   const uint32_t M = P.M; const uint64_t E = P.E;
   std::vector<uint64_t> cum(E), orig(P.count); uint64_t total = 0; for (uint64_t c = 0; c < E; ++c) { total += orig[c]; cum[c] = total; }
@@ -1049,7 +1150,8 @@ static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_op
 }
 
 // a17 — CollapsedGibbsSampler::sample + sampleRoundNonCollapsedMultithreaded_ (CollapsedGibbsSampler.cpp:92-278, 317-508); SPEC §a17
-static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped,
+static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed,
+    uint64_t num_mapped,
     double* out) {
   const uint32_t M = txp->num_txp; const uint64_t E = eq->num_classes;
   const bool perTxp = go->use_vbem ? go->per_transcript_prior != 0 : true;
@@ -1094,7 +1196,15 @@ static int gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opt
         }
         for (uint64_t sidx = 0; sidx < cnt; ++sidx) {
           double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, key, draw_off[c] + sidx)) * denom;
-          double acc = 0.0; uint32_t pick = n - 1; for (uint32_t i = 0; i < n; ++i) { acc += pf(mode, i); if (u < acc) { pick = i; break; } }
+          double acc = 0.0;
+          uint32_t pick = n - 1;
+          for (uint32_t i = 0; i < n; ++i) {
+            acc += pf(mode, i);
+            if (u < acc) {
+              pick = i;
+              break;
+            }
+          }
           ci[eq->tid[a + pick]]++;
         }
       }
@@ -1200,8 +1310,14 @@ int orc_check_cdbg(const sq_index_view* v) {
     for (uint32_t i = 0; i < L; ++i) {
       fw = (fw >> 2) | ((uint64_t)base_at(v->refseq, v->ref_accum[r] + i) << (2 * (k - 1))); if (i + 1 < k) continue; fw &= km;
       uint32_t p = i + 1 - k; uint64_t rc = revcomp(fw, k); bool o1 = fw < rc; uint32_t bits = 0;
-      if (p + 1 < nk) { uint32_t s = base_at(v->refseq, v->ref_accum[r] + p + k); bits |= o1 ? (1u << s) : (1u << (4 + 3 - s)); } else bits |= o1 ? 256u : 512u;
-      if (p > 0) { uint32_t q = base_at(v->refseq, v->ref_accum[r] + p - 1); bits |= o1 ? (1u << (4 + q)) : (1u << (3 - q)); } else bits |= o1 ? 512u : 256u;
+      if (p + 1 < nk) {
+        uint32_t s = base_at(v->refseq, v->ref_accum[r] + p + k);
+        bits |= o1 ? (1u << s) : (1u << (4 + 3 - s));
+      } else bits |= o1 ? 256u : 512u;
+      if (p > 0) {
+        uint32_t q = base_at(v->refseq, v->ref_accum[r] + p - 1);
+        bits |= o1 ? (1u << (4 + q)) : (1u << (3 - q));
+      } else bits |= o1 ? 512u : 256u;
       info[std::min(fw, rc)] |= bits;
     }
   }
@@ -1238,7 +1354,8 @@ int orc_check_cdbg(const sq_index_view* v) {
 }
 
 void orc_map_batch(const orc_index* oi, const sq_quant_opts* o, const sq_read_batch* in, uint32_t nthreads,
-                   uint64_t* read_off /*[n+1]*/, sq_aln* alns, uint64_t aln_cap, uint8_t* map_type, sq_map_stats* stats, uint64_t* n_alns_out) {
+                   uint64_t* read_off /*[n+1]*/, sq_aln* alns, uint64_t aln_cap, uint8_t* map_type, sq_map_stats* stats,
+                       uint64_t* n_alns_out) {
   Opts op; make_opts(o, op);
   const uint32_t n = in->n; std::vector<FragResult> res(n);
   std::vector<sq_map_stats> sts(std::max(1u, nthreads)); for (auto& s : sts) memset(&s, 0, sizeof(s));
@@ -1257,7 +1374,12 @@ void orc_map_batch(const orc_index* oi, const sq_quant_opts* o, const sq_read_ba
       }
     }
   };
-  if (nthreads <= 1) work(0); else { std::vector<std::thread> th; for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  if (nthreads <= 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
   uint64_t tot = 0; read_off[0] = 0;
   for (uint32_t i = 0; i < n; ++i) {
     for (auto& a : res[i].alns) {
@@ -1279,7 +1401,8 @@ void orc_map_batch(const orc_index* oi, const sq_quant_opts* o, const sq_read_ba
 }
 
 // stage taps for one batch (single-threaded): fills caller buffers, returns counts via n_out[4]
-void orc_map_taps(const orc_index* oi, const sq_quant_opts* o, const sq_read_batch* in, sq_unimem* um, uint64_t um_cap, sq_mem* mm, uint64_t mm_cap,
+void orc_map_taps(const orc_index* oi, const sq_quant_opts* o, const sq_read_batch* in, sq_unimem* um, uint64_t um_cap, sq_mem* mm,
+    uint64_t mm_cap,
                   sq_chain* ch, uint64_t ch_cap, sq_cand* cd, uint64_t cd_cap, uint64_t* n_out) {
   Opts op; make_opts(o, op); Taps tp; tp.on = true; sq_map_stats st; memset(&st, 0, sizeof(st)); FragResult fr;
   for (uint32_t i = 0; i < in->n; ++i) {
@@ -1303,7 +1426,11 @@ void orc_map_taps(const orc_index* oi, const sq_quant_opts* o, const sq_read_bat
   for (size_t i = 0; i < tp.cands.size() && i < cd_cap; ++i) cd[i] = tp.cands[i];
 }
 
-orc_state* orc_state_create(const orc_index* oi, const sq_quant_opts* o) { orc_state* s = new orc_state(); s->S.init(&oi->ix, o); return s; }
+orc_state* orc_state_create(const orc_index* oi, const sq_quant_opts* o) {
+  orc_state* s = new orc_state();
+  s->S.init(&oi->ix, o);
+  return s;
+}
 void orc_state_free(orc_state* s) { delete s; }
 // feed one mapped batch (CSR) through the online model in mini-batches, in input order
 void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, uint64_t num_with_joint_hits) {
@@ -1334,7 +1461,10 @@ void orc_state_fetch(orc_state* s, double* log_mass, uint64_t* uniq, uint64_t* t
 // label hash shared with the product (two independent 64-bit mixes over tids+bins)
 static void label_hash(const std::vector<uint32_t>& lab, uint64_t* h1, uint64_t* h2) {
   uint64_t a = 0x243F6A8885A308D3ULL ^ lab.size(), b = 0x13198A2E03707344ULL + lab.size();
-  for (uint32_t x : lab) { a = sq_mix64(a ^ (uint64_t)x) + 0x9E3779B97F4A7C15ULL; b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29); }
+  for (uint32_t x : lab) {
+    a = sq_mix64(a ^ (uint64_t)x) + 0x9E3779B97F4A7C15ULL;
+    b = sq_mix64(b + (uint64_t)x * 0xD6E8FEB86659FD93ULL) ^ (b >> 29);
+  }
   *h1 = sq_mix64(a); *h2 = sq_mix64(b);
   if (*h1 == ~0ULL) *h1 = ~0ULL - 1;  // ~0 marks an empty slot in the device table
   if (*h2 == 0) *h2 = 1;              // 0 marks "second hash not published yet"
@@ -1344,14 +1474,26 @@ void orc_eq_finish(orc_state* s, sq_eq_table* out) {
   QuantState& S = s->S;
   struct Row { uint64_t h1, h2; const std::vector<uint32_t>* lab; const EqVal* v; };
   std::vector<Row> rows; rows.reserve(S.eq.size()); uint64_t L = 0;
-  for (auto& kv : S.eq) { Row r; label_hash(kv.first, &r.h1, &r.h2); r.lab = &kv.first; r.v = &kv.second; rows.push_back(r); L += kv.second.wq.size(); }
+  for (auto& kv : S.eq) {
+    Row r;
+    label_hash(kv.first, &r.h1, &r.h2);
+    r.lab = &kv.first;
+    r.v = &kv.second;
+    rows.push_back(r);
+    L += kv.second.wq.size();
+  }
   std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { const uint32_t ta = (*a.lab)[0],
       tb = (*b.lab)[0]; if (ta != tb) return ta < tb; return a.h1 < b.h1 || (a.h1 == b.h1 && a.h2 < b.h2); });
   out->num_classes = rows.size(); out->num_labels = L;
   if (!out->off) return;
   uint64_t p = 0;
   for (size_t c = 0; c < rows.size(); ++c) {
-    const Row& r = rows[c]; size_t n = r.v->wq.size(); out->off[c] = p; out->count[c] = r.v->count; if (out->h1) out->h1[c] = r.h1; if (out->h2) out->h2[c] = r.h2;
+    const Row& r = rows[c];
+    size_t n = r.v->wq.size();
+    out->off[c] = p;
+    out->count[c] = r.v->count;
+    if (out->h1) out->h1[c] = r.h1;
+    if (out->h2) out->h2[c] = r.h2;
     double sum = 0.0; for (size_t i = 0; i < n; ++i) sum += sq_from_fixed(r.v->wq[i], SQ_WFRAC_BITS);
     double norm = 1.0 / sum;  // TGValue::normalizeAux (EquivalenceClassBuilder.hpp:116-125)
     for (size_t i = 0; i < n; ++i) {
@@ -1367,7 +1509,8 @@ void orc_eq_finish(orc_state* s, sq_eq_table* out) {
 
 // normalizeAlphas (SalmonUtils.cpp:461-529) + TranscriptCluster::projectToPolytope (TranscriptCluster.hpp:46-102)
 // over clusters = connected components of the eq-class labels; members in ascending tid (SPEC §D5).
-void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
+void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total,
+    double* projected) {
   std::vector<uint32_t> parent(M); for (uint32_t i = 0; i < M; ++i) parent[i] = i;
   auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
   for (uint64_t c = 0; c < eq->num_classes; ++c) for (uint64_t i = eq->off[c] + 1; i < eq->off[c + 1]; ++i) {
@@ -1419,14 +1562,17 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
 int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   return em_optimize(eq, txp, o, alpha_out, rep);
 }
-int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped, double* out) {
+int orc_bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped,
+    double* out) {
   return bootstrap(eq, txp, o, B, seed, num_mapped, out);
 }
-int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed, uint64_t num_mapped,
+int orc_gibbs(const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S, uint64_t seed,
+    uint64_t num_mapped,
     double* out) {
   return gibbs(eq, txp, go, alpha_init, S, seed, num_mapped, out);
 }
-int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out) {
+int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters,
+    double* alpha_out) {
   EMProblem P; em_setup(P, eq, txp, o); std::vector<double> a(alpha_in, alpha_in + P.M), b(P.M), th(P.M), inv(P.E);
   for (uint32_t i = 0; i < iters; ++i) { em_step(P, o, a, b, th, inv); a.swap(b); }
   for (uint32_t i = 0; i < P.M; ++i) alpha_out[i] = a[i];
@@ -1443,7 +1589,9 @@ double orc_log_add(double x, double y) { return sq_log_add(x, y); }
 int orc_compatible_pe(int et, int eo, int es, int ot, int oo, int os) {
   return compatible_hit_pe(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, LibFmt{(uint8_t)ot, (uint8_t)oo, (uint8_t)os});
 }
-int orc_compatible_se(int et, int eo, int es, int fwd, int ms) { return compatible_hit_se(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, fwd != 0, (uint8_t)ms); }
+int orc_compatible_se(int et, int eo, int es, int fwd, int ms) {
+  return compatible_hit_se(LibFmt{(uint8_t)et, (uint8_t)eo, (uint8_t)es}, fwd != 0, (uint8_t)ms);
+}
 int orc_format_id(int t, int o, int s) { return format_id(LibFmt{(uint8_t)t, (uint8_t)o, (uint8_t)s}); }
 int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t* t, int tl, int mode) {
   Opts op;
@@ -1451,7 +1599,9 @@ int orc_dp_align(const sq_quant_opts* o, const uint8_t* q, int n, const uint8_t*
   return dp_align(op, q, n, t, tl, mode);
 }
 // a5: the infix aligner alone (codes 0..3, other values match nothing); returns 1 and (distance, start, end) or 0
-int orc_infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k, int* ed, int* start, int* end) { return infix_align(q, n, t, m, k, ed, start, end) ? 1 : 0; }
+int orc_infix_align(const uint8_t* q, int n, const uint8_t* t, int m, int k, int* ed, int* start, int* end) {
+  return infix_align(q, n, t, m, k, ed, start, end) ? 1 : 0;
+}
 void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) {
   FLD f;
   f.init(mu, sd);
@@ -1469,8 +1619,11 @@ double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_e
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t it = 0; it < iters; ++it) {
     if (o->use_vbem) { std::vector<double> ap(M); for (uint32_t i = 0; i < M; ++i) ap[i] = a[i] + P.prior[i]; double ln = sq_digamma(canonical_sum(ap));
-      auto f1 = [&](uint32_t t) { for (uint32_t i = t; i < M; i += nthreads) th[i] = ap[i] > 1e-10 ? sq_exp(sq_digamma(ap[i]) - ln) : 0.0; };
-      std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f1, t); for (auto& x : tv) x.join(); } else th = a;
+      auto f1 = [&](uint32_t t) {
+        for (uint32_t i = t; i < M; i += nthreads) th[i] = ap[i] > 1e-10 ? sq_exp(sq_digamma(ap[i]) - ln) : 0.0;
+      };
+      std::vector<std::thread> tv; for (uint32_t t = 0; t < nthreads; ++t) tv.emplace_back(f1,
+          t); for (auto& x : tv) x.join(); } else th = a;
     auto f2 = [&](uint32_t t) { uint64_t c0 = P.E * t / nthreads, c1 = P.E * (t + 1) / nthreads;
       for (uint64_t c = c0; c < c1; ++c) { uint64_t x = P.off[c],
           y = P.off[c + 1]; if (y - x <= 1) { inv[c] = 0; continue; } double d = 0; for (uint64_t i = x; i < y; ++i) { double v = th[P.tid[i]]; if (!o->use_vbem ||

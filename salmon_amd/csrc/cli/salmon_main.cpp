@@ -21,7 +21,10 @@ static const char* arg(int argc, char** argv, const char* a, const char* b = nul
   for (int i = 2; i + 1 < argc; ++i) if (!strcmp(argv[i], a) || (b && !strcmp(argv[i], b))) return argv[i + 1];
   return nullptr;
 }
-static bool flag(int argc, char** argv, const char* a) { for (int i = 2; i < argc; ++i) if (!strcmp(argv[i], a)) return true; return false; }
+static bool flag(int argc, char** argv, const char* a) {
+  for (int i = 2; i < argc; ++i) if (!strcmp(argv[i], a)) return true;
+  return false;
+}
 
 struct Fastq {
   gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0;
@@ -31,7 +34,12 @@ struct Fastq {
     for (;;) {
       if (pos == len) { int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) return !out.empty(); len = (size_t)n; pos = 0; }
       char* s = buf.data() + pos; char* e = (char*)memchr(s, '\n', len - pos);
-      if (e) { out.append(s, e - s); pos = (size_t)(e - buf.data()) + 1; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+      if (e) {
+        out.append(s, e - s);
+        pos = (size_t)(e - buf.data()) + 1;
+        if (!out.empty() && out.back() == '\r') out.pop_back();
+        return true;
+      }
       out.append(s, len - pos); pos = len;
     }
   }
@@ -47,11 +55,13 @@ struct Fastq {
 static int cmd_index(int argc, char** argv) {
   const char* t = arg(argc, argv, "-t", "--transcripts"); const char* i = arg(argc, argv, "-i", "--index");
   if (!t || !i) {
-    fprintf(stderr, "usage: salmon-hip index -t transcripts.fa -i index_dir [-k 31] [-m 0] [-d decoys.txt] [-p threads] [--keepDuplicates] [--no-clip] [--gencode]\n");
+    fprintf(stderr,
+        "usage: salmon-hip index -t transcripts.fa -i index_dir [-k 31] [-m 0] [-d decoys.txt] [-p threads] [--keepDuplicates] [--no-clip] [--gencode]\n");
     return 1;
   }
   sq_index_opts o{}; const char* v;
-  o.k = (v = arg(argc, argv, "-k", "--kmerLen")) ? (uint32_t)atoi(v) : 31; o.m = (v = arg(argc, argv, "-m", "--minimizerLen")) ? (uint32_t)atoi(v) : 0;
+  o.k = (v = arg(argc, argv, "-k", "--kmerLen")) ? (uint32_t)atoi(v) : 31;
+  o.m = (v = arg(argc, argv, "-m", "--minimizerLen")) ? (uint32_t)atoi(v) : 0;
   o.threads = (v = arg(argc, argv, "-p", "--threads")) ? (uint32_t)atoi(v) : 0;
   o.keep_duplicates = flag(argc, argv, "--keepDuplicates");
   o.no_clip_polya = flag(argc, argv, "--no-clip") || flag(argc, argv, "-n");
@@ -68,10 +78,12 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 
 // posterior samples into aux_info/bootstrap (MappingPipelineStages.cpp:60-95): --numBootstraps wins over --numGibbsSamples
-static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop, const double* alphas, uint32_t M,
+static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop,
+    const double* alphas, uint32_t M,
                          const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped) {
   const char* v;
-  const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv, "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
+  const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv,
+      "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
   if (!nb && !ng) return;
   const uint64_t seed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
   sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
@@ -106,10 +118,12 @@ static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
   if (sq_em_optimize_dev(device, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
   mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
   std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_eq_file_name(F, i);
-  if (sq_write_quant_sf_names((od + "/quant.sf").c_str(), M, names.data(), nullptr, sq_eq_file_eff_lens(F), alphas.data(), 0.0)) die("quant.sf");
+  if (sq_write_quant_sf_names((od + "/quant.sf").c_str(), M, names.data(), nullptr, sq_eq_file_eff_lens(F), alphas.data(),
+      0.0)) die("quant.sf");
   uint64_t nm = 0; for (uint64_t c = 0; c < t.num_classes; ++c) nm += t.count[c];
   run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, nm);
-  fprintf(stderr, "[salmon-hip] %llu eq-classes, %u %s iterations -> %s/quant.sf\n", (unsigned long long)t.num_classes, rep.iters, eop.use_vbem ? "VBEM" : "EM", odir);
+  fprintf(stderr, "[salmon-hip] %llu eq-classes, %u %s iterations -> %s/quant.sf\n", (unsigned long long)t.num_classes, rep.iters,
+      eop.use_vbem ? "VBEM" : "EM", odir);
   sq_eq_file_free(F);
   return 0;
 }
@@ -117,7 +131,9 @@ static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
 static int cmd_quant(int argc, char** argv) {
   if (const char* eqf = arg(argc, argv, "-e", "--eqclasses")) return cmd_quant_eq(argc, argv, eqf);
   const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
-  const char* r1 = arg(argc, argv, "-1", "--mates1"); const char* r2 = arg(argc, argv, "-2", "--mates2"); const char* ru = arg(argc, argv, "-r", "--unmatedReads");
+  const char* r1 = arg(argc, argv, "-1", "--mates1");
+  const char* r2 = arg(argc, argv, "-2", "--mates2");
+  const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
   if (!idir || !odir || (!ru && !(r1 && r2))) {
     fprintf(stderr,
@@ -127,15 +143,22 @@ static int cmd_quant(int argc, char** argv) {
   std::string lib = lt ? lt : (ru ? "U" : "IU");
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
   if (lib == "A") {
-    fprintf(stderr, "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n");
+    fprintf(stderr,
+        "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n");
     return 1;
   }
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
-  const char* v; int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0; uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
+  const char* v;
+  int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0;
+  uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
   const bool paired = !ru;
   auto t0 = std::chrono::steady_clock::now();
   sq_index* idx = nullptr; if (sq_index_load(idir, device, &idx)) die("loading index");
-  sq_quant_opts qo; sq_quant_opts_default(&qo); qo.lib_type = li->second[0]; qo.lib_orientation = li->second[1]; qo.lib_strand = li->second[2];
+  sq_quant_opts qo;
+  sq_quant_opts_default(&qo);
+  qo.lib_type = li->second[0];
+  qo.lib_orientation = li->second[1];
+  qo.lib_strand = li->second[2];
   if ((v = arg(argc, argv, "--minScoreFraction"))) qo.min_score_fraction = atof(v);
   if ((v = arg(argc, argv, "--consensusSlack"))) qo.consensus_slack = atof(v);
   if ((v = arg(argc, argv, "--rangeFactorizationBins"))) qo.range_factorization_bins = (uint32_t)atoi(v);
@@ -165,7 +188,9 @@ static int cmd_quant(int argc, char** argv) {
   std::vector<const char*> p1, p2; for (auto& x : l1) p1.push_back(x.c_str()); for (auto& x : l2) p2.push_back(x.c_str());
   const uint32_t lanes = (v = arg(argc, argv, "--lanes")) ? (uint32_t)std::max(1, std::min(4, atoi(v))) : 2;
   if (sq_ctx_set_lanes(ctx, (int)lanes)) die("lanes");
-  sq_reader* rd = nullptr; if (sq_reader_open(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, &rd)) die("opening reads");
+  sq_reader* rd = nullptr;
+  if (sq_reader_open(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1,
+      &rd)) die("opening reads");
   sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight;
   auto finish_one = [&]() {
     sq_map_stats st{};
@@ -189,7 +214,9 @@ static int cmd_quant(int argc, char** argv) {
   fprintf(stderr, "\n");
   const uint32_t M = sq_index_num_refs(idx);
   sq_eq_table t{}; if (sq_eq_finish(ctx, &t)) die("eq finish");
-  std::vector<uint64_t> eo(t.num_classes + 1), ec(t.num_classes); std::vector<uint32_t> et(t.num_labels); std::vector<double> ew(t.num_labels);
+  std::vector<uint64_t> eo(t.num_classes + 1), ec(t.num_classes);
+  std::vector<uint32_t> et(t.num_labels);
+  std::vector<double> ew(t.num_labels);
   t.off = eo.data(); t.tid = et.data(); t.w = ew.data(); t.count = ec.data(); if (sq_eq_finish(ctx, &t)) die("eq finish");
   std::vector<double> lm(M), le(M), proj(M), eff(M), alphas(M, 0.0); std::vector<uint64_t> uq(M), tc(M);
   if (sq_model_fetch(ctx, lm.data(), uq.data(), tc.data(), le.data())) die("model fetch");
@@ -201,7 +228,10 @@ static int cmd_quant(int argc, char** argv) {
     fprintf(stderr, "[salmon-hip] only %llu fragments were assigned; writing empty quantification\n", (unsigned long long)ms.num_assigned);
   } else {
     if (sq_normalize_alphas(M, &t, lm.data(), uq.data(), tc.data(), proj.data())) die("normalizeAlphas");
-    sq_em_opts eop; sq_em_opts_default(&eop); if (flag(argc, argv, "--useEM")) eop.use_vbem = 0; if (flag(argc, argv, "--initUniform")) eop.init_uniform = 1;
+    sq_em_opts eop;
+    sq_em_opts_default(&eop);
+    if (flag(argc, argv, "--useEM")) eop.use_vbem = 0;
+    if (flag(argc, argv, "--initUniform")) eop.init_uniform = 1;
     if ((v = arg(argc, argv, "--vbPrior"))) eop.vb_prior = atof(v);
     if (flag(argc, argv, "--perNucleotidePrior")) eop.per_transcript_prior = 0;
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
@@ -213,15 +243,19 @@ static int cmd_quant(int argc, char** argv) {
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
   { uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
     const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
-    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand, lc, ms.num_assigned,
+    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand,
+        lc, ms.num_assigned,
         ms.num_compatible)) die("lib_format_counts"); }
   { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
     std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
     if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv,
-      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
-  if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n", (unsigned long long)tot.num_orphans_rescued);   // SalmonQuantify.cpp:2697-2701
+      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv,
+          "--dumpEqWeights"))) die("eq_classes");
+  // SalmonQuantify.cpp:2697-2701
+  if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n",
+      (unsigned long long)tot.num_orphans_rescued);
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
   if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)
@@ -229,22 +263,28 @@ static int cmd_quant(int argc, char** argv) {
         "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
                 "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
                 "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f\n}\n",
-            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes, (unsigned long long)nfrag,
+            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes,
+                (unsigned long long)nfrag,
                 (unsigned long long)ms.num_assigned,
-            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails, (unsigned long long)tot.num_fragments_filtered,
+            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails,
+                (unsigned long long)tot.num_fragments_filtered,
                 (unsigned long long)tot.num_mappings_filtered,
-            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb", rep.iters,
+            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
+                rep.iters,
                 ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs);
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
   if (cf) {
-    fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir, lib.c_str(), odir);
+    fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir,
+        lib.c_str(), odir);
     fclose(cf);
   }
-  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n", (unsigned long long)nfrag,
+  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n",
+      (unsigned long long)nfrag,
       (unsigned long long)ms.num_assigned,
-          nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv, "--useEM") ? "EM" : "VBEM", secs,
+          nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv,
+              "--useEM") ? "EM" : "VBEM", secs,
               odir);
   sq_ctx_free(ctx); sq_index_free(idx);
   return 0;

@@ -28,7 +28,13 @@ struct sq_chain_dev {   // 40 B
   double score; uint32_t tid; int32_t pos; int32_t last_end; uint32_t first; uint16_t n_mems, read_len; uint8_t fw, pad[3]; uint32_t pad2;
 };
 struct sq_cand_dev {    // 48 B
-  double cov; uint32_t tid; uint32_t lc, rc; uint32_t frag_len; int32_t lscore, rscore; uint8_t mate_status, valid, compat, lfail, rfail, pad[3]; uint32_t pad2;
+  double cov;
+  uint32_t tid;
+  uint32_t lc, rc;
+  uint32_t frag_len;
+  int32_t lscore, rscore;
+  uint8_t mate_status, valid, compat, lfail, rfail, pad[3];
+  uint32_t pad2;
 };
 
 struct sq_dp_item {     // one banded-DP region queued by the fast scorer
@@ -58,7 +64,10 @@ struct sq_dbuf {
     if (p) (void)hipFree(p);
     p = nullptr; n = 0;
     size_t cap = want + want / 4 + 64;
-    if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) { cap = want ? want : 1; if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) return -1; }
+    if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) {
+      cap = want ? want : 1;
+      if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) return -1;
+    }
     n = cap; return 0;
   }
   void free_() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
@@ -87,7 +96,9 @@ struct sq_ctx {
   sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;
   // last batch bookkeeping
-  uint32_t last_n = 0; uint32_t last_paired = 0; uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0, last_chain_slots = 0;
+  uint32_t last_n = 0;
+  uint32_t last_paired = 0;
+  uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0, last_chain_slots = 0;
   void* em_arena = nullptr;   // persistent EM workspace (em.hip: EmArena), grown by sq_ctx_reserve / sq_em_optimize(ctx, ...)
   bool have_batch = false;
   // online model + eq table
@@ -98,7 +109,11 @@ struct sq_ctx {
   // With a CU partition (eq_cus > 0) stream/stream2 are CU-masked to disjoint sets: the eq stage's chain of small
   // dependent kernels then never queues behind the mapping kernels' workgroups.  stream3 is unmasked: an eq job that
   // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
-  hipStream_t stream3 = nullptr; hipStream_t eq_stream_cur = nullptr; int eq_cus = 0; std::atomic<int> map_active{0}; hipEvent_t ev_eq_last = nullptr;
+  hipStream_t stream3 = nullptr;
+  hipStream_t eq_stream_cur = nullptr;
+  int eq_cus = 0;
+  std::atomic<int> map_active{0};
+  hipEvent_t ev_eq_last = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr};
   int cur_buf = 0, last_buf = 0;
@@ -111,26 +126,42 @@ struct sq_ctx {
   // a worker thread enqueues them on stream2 so the caller can go straight on to mapping the next batch.
   struct eq_job { uint32_t n; int buf; uint64_t total_aln, joint; sq_ctx* src; };
   std::thread eq_thread; std::mutex eq_mu; std::condition_variable eq_cv, eq_cv_done; std::deque<eq_job> eq_q;
-  uint64_t eq_submitted = 0, eq_enqueued = 0; uint64_t eq_job_of_buf[2] = {0, 0}; bool eq_stop = false; int eq_err = 0; std::string eq_errmsg;
+  uint64_t eq_submitted = 0, eq_enqueued = 0;
+  uint64_t eq_job_of_buf[2] = {0, 0};
+  bool eq_stop = false;
+  int eq_err = 0;
+  std::string eq_errmsg;
   // Mapping lanes: sq_map_submit / sq_map_wait run batches on alternating lanes, each a worker thread with its own
   // stream and work buffers (lane 0 = this ctx, further lanes = shadow ctxs that own buffers only).  The mapping
   // kernels are latency- or issue-bound one at a time; two batches in flight fill each other's stalls.  Results come
   // back in submission order; the online/eq stage stays strictly ordered on its own stream.
   struct map_job { sq_read_batch in; sq_aln_batch out; bool has_out = false; int rc = 0; sq_map_stats st; bool done = false; std::string err; uint32_t n = 0; int buf = 0; uint64_t total_aln = 0,
       joint = 0; };
-  uint32_t acc_n = 0; int acc_buf = 0; uint64_t acc_total_aln = 0, acc_joint = 0;   // the batch sq_eq_accumulate will take (set by sq_map_batch / sq_map_wait)
+  // the batch sq_eq_accumulate will take (set by sq_map_batch / sq_map_wait)
+  uint32_t acc_n = 0;
+  int acc_buf = 0;
+  uint64_t acc_total_aln = 0, acc_joint = 0;
   sq_ctx* owner = nullptr;                 // set in a shadow ctx: the ctx that owns the online model and the eq worker
   std::vector<sq_ctx*> shadows;            // lanes 1.. (owned by lane 0)
   int n_lanes = 0;                         // 0 = not chosen yet (SQ_MAP_LANES or 2 at the first submit)
   sq_ctx* last_src = nullptr;              // lane whose batch the next sq_eq_accumulate / sq_debug_tap refers to
   bool api_have = false;                   // a mapped batch has been returned to the caller and not yet accumulated
-  std::thread lane_thread; std::mutex lane_mu; std::condition_variable lane_cv, lane_cv_done; std::deque<std::shared_ptr<map_job>> lane_q; bool lane_stop = false;
+  std::thread lane_thread;
+  std::mutex lane_mu;
+  std::condition_variable lane_cv, lane_cv_done;
+  std::deque<std::shared_ptr<map_job>> lane_q;
+  bool lane_stop = false;
   std::deque<std::pair<sq_ctx*, std::shared_ptr<map_job>>> tickets; uint64_t submitted = 0;
   // stage profiling
-  bool prof_on = false; std::vector<hipEvent_t> prof_ev; std::vector<int> prof_stage; double stage_ms[32] = {0}; uint64_t stage_calls[32] = {0};
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_stage;
+  double stage_ms[32] = {0};
+  uint64_t stage_calls[32] = {0};
 };
 
-enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP, SG_SELECT, SG_COMPACT,
+enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP,
+    SG_SELECT, SG_COMPACT,
        SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_NUM };
 void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream)
 void sq_prof_begin(sq_ctx* c, int which = 0);
@@ -140,7 +171,8 @@ void sq_eq_wait_enqueued(sq_ctx* c, uint64_t id);        // block until the eq w
 void sq_eq_worker_stop(sq_ctx* c);                                // wait for outstanding eq-stage work, collect its timings, report table overflow
 
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
-enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS, ST_CHAINS, ST_CANDS, ST_DP,
+enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS,
+    ST_CHAINS, ST_CANDS, ST_DP,
     ST_RESCUED, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset

@@ -31,7 +31,8 @@ struct sq_eq_dev_csr { uint64_t E, L; const uint64_t* off; const uint32_t* tid; 
 // EM over a host table (eq) or over a CSR that already lives on `device` (dv); em.hip
 // arena_slot: where the caller keeps its persistent EM workspace (a ctx), or nullptr for a private one
 // lent_stream: an idle hipStream_t of the caller to run on (nullptr: the session creates its own)
-int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep,
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o,
+    double* alpha_out, sq_em_report* rep,
     void** arena_slot, void* lent_stream);
 int sq_em_arena_reserve(void** slot, size_t bytes, size_t pinned_bytes, size_t pinned_plan_bytes);
 void sq_em_arena_free(void* slot);

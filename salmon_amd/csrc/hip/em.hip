@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(1024) k_upper(EmDev d, int first_lvl, double* 
 // sum and, for two-level plans, level 2 of the blocked-64 transcript sums.
 // (A "last block finishes the sum" variant was measured and dropped: the device-scope fence it needs
 // writes back the XCD's L2 in every block — 53 us vs 9 us per launch on MI355X.)
-__global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out,
+    double* __restrict__ partials) {
   if (d.flags[0]) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   double rel = -1.0; int bad = 0; double leaf = 0.0;
@@ -270,7 +271,12 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
     double ls = wave_halving_sum(leaf);
     if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls;
   }
-  for (int s = 32; s >= 1; s >>= 1) { double o = __shfl_down(rel, s, 64); int ob = __shfl_down(bad, s, 64); rel = o > rel ? o : rel; bad |= ob; }
+  for (int s = 32; s >= 1; s >>= 1) {
+    double o = __shfl_down(rel, s, 64);
+    int ob = __shfl_down(bad, s, 64);
+    rel = o > rel ? o : rel;
+    bad |= ob;
+  }
   // block-level combine, then one atomic per block only when it can raise the running maximum
   __shared__ double srel[16]; __shared__ int sbad[16];
   if ((threadIdx.x & 63) == 0) { srel[threadIdx.x >> 6] = rel; sbad[threadIdx.x >> 6] = bad; }
@@ -281,7 +287,8 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
       unsigned long long b = (unsigned long long)__double_as_longlong(rel);
       if (b > __hip_atomic_load(d.maxrel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d.maxrel, b);
     }
-    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u, __ATOMIC_RELAXED,
+    if (bad && __hip_atomic_load(&d.flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&d.flags[1], 1u,
+        __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -307,12 +314,21 @@ struct EmArena {
   void* pinned(int slot, size_t bytes) {
     if (bytes <= pin_cap[slot]) return pin[slot];
     if (pin[slot]) (void)hipHostFree(pin[slot]); pin[slot] = nullptr; pin_cap[slot] = 0;
-    if (hipHostMalloc(&pin[slot], bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[slot] = nullptr; return nullptr; }
+    if (hipHostMalloc(&pin[slot], bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      pin[slot] = nullptr;
+      return nullptr;
+    }
     pin_cap[slot] = bytes; return pin[slot];
   }
   void reset() { for (auto& c : chunks) c.used = 0; }
   size_t capacity() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
-  int add_chunk(size_t bytes) { Chunk c{nullptr, bytes, 0}; if (hipMalloc((void**)&c.base, bytes) != hipSuccess) return -1; chunks.push_back(c); return 0; }
+  int add_chunk(size_t bytes) {
+    Chunk c{nullptr, bytes, 0};
+    if (hipMalloc((void**)&c.base, bytes) != hipSuccess) return -1;
+    chunks.push_back(c);
+    return 0;
+  }
   void* take(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     for (auto& c : chunks) if (c.cap - c.used >= bytes) { void* p = c.base + c.used; c.used += bytes; return p; }
@@ -355,9 +371,11 @@ double canonical_sum_host(std::vector<double> x) {  // SPEC §D2 (host copy used
 // combined weights, transcript-major CSC (radix sort of (tid, class) keys), the blocked-64 reduction
 // plan (SPEC §D4) and the block plans of k_class / k_l1 are all built in HBM from the label-major
 // CSR; the host only follows two short "next block" chains.
-__global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const double* __restrict__ w,
+__global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid,
+    const double* __restrict__ w,
     const uint64_t* __restrict__ cnt_u,
-                          const double* __restrict__ eff, int no_rich, int eq_mode, double* __restrict__ cw, double* __restrict__ cnt_f, uint32_t* __restrict__ err) {
+                          const double* __restrict__ eff, int no_rich, int eq_mode, double* __restrict__ cw, double* __restrict__ cnt_f,
+                              uint32_t* __restrict__ err) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
   const uint64_t a = off[c], b = off[c + 1]; const double cn = (double)cnt_u[c];
   if (cnt_f) cnt_f[c] = cn;
@@ -375,12 +393,14 @@ __global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ o
 __global__ void k_prep_prior(uint32_t M, const double* __restrict__ eff, double vb_prior, int per_txp, double* __restrict__ prior) {   // populatePriorAlphas_ :82-99
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t < M) prior[t] = per_txp ? vb_prior : vb_prior * eff[t];
 }
-__global__ void k_prep_keys(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, unsigned long long* __restrict__ key,
+__global__ void k_prep_keys(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid,
+    unsigned long long* __restrict__ key,
     uint32_t* __restrict__ val) {
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
   for (uint64_t i = off[c]; i < off[c + 1]; ++i) { key[i] = ((unsigned long long)tid[i] << 32) | c; val[i] = (uint32_t)i; }
 }
-__global__ void k_prep_csc(uint64_t L, uint32_t M, const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const double* __restrict__ cw,
+__global__ void k_prep_csc(uint64_t L, uint32_t M, const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val,
+    const double* __restrict__ cw,
                            uint32_t* __restrict__ t_cls, double* __restrict__ t_cw, uint64_t* __restrict__ t_off) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= L) return;
   const unsigned long long k = key[i]; const uint32_t t = (uint32_t)(k >> 32);
@@ -390,7 +410,8 @@ __global__ void k_prep_csc(uint64_t L, uint32_t M, const unsigned long long* __r
   if (i + 1 == L) for (uint64_t x = (uint64_t)t + 1; x <= M; ++x) t_off[x] = L;
 }
 // number of blocked-64 segments of every transcript at each level (0 where the level is not needed)
-__global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, uint32_t* __restrict__ ns0, uint32_t* __restrict__ ns1, uint32_t* __restrict__ ns2,
+__global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, uint32_t* __restrict__ ns0, uint32_t* __restrict__ ns1,
+    uint32_t* __restrict__ ns2,
     uint32_t* __restrict__ ns3, uint32_t* __restrict__ err) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t > M) return;
   if (t == M) { ns0[M] = ns1[M] = ns2[M] = ns3[M] = 0; return; }
@@ -401,8 +422,10 @@ __global__ void k_plan_counts(uint32_t M, const uint64_t* __restrict__ t_off, ui
   ns0[t] = a; ns1[t] = b; ns2[t] = c; ns3[t] = dd;
 }
 // segments of level `lvl` for transcript t: runs of 64 items of the previous level (CSC entries for level 0)
-__global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_off, const uint32_t* __restrict__ ns_prev, const uint32_t* __restrict__ base_prev,
-                            const uint32_t* __restrict__ ns, const uint32_t* __restrict__ base, uint32_t* __restrict__ seg_lo, uint8_t* __restrict__ seg_cnt,
+__global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_off, const uint32_t* __restrict__ ns_prev,
+    const uint32_t* __restrict__ base_prev,
+                            const uint32_t* __restrict__ ns, const uint32_t* __restrict__ base, uint32_t* __restrict__ seg_lo,
+                                uint8_t* __restrict__ seg_cnt,
                                 uint32_t* __restrict__ seg_txp) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= M) return;
   const uint32_t k = ns[t]; if (!k) return;
@@ -418,7 +441,8 @@ __global__ void k_plan_fill(int lvl, uint32_t M, const uint64_t* __restrict__ t_
 // greedy block packing as a jump table: nxt[g] = first unit of the block after the one starting at g
 // (a block takes units while its entries stay <= cap and, optionally, its unit count <= maxu)
 template <class T>
-__global__ void k_next_block(uint32_t n, const T* __restrict__ lo /* [n+1], lo[n] = total */, uint32_t cap, uint32_t maxu, uint32_t* __restrict__ nxt) {
+__global__ void k_next_block(uint32_t n, const T* __restrict__ lo /* [n+1], lo[n] = total */, uint32_t cap, uint32_t maxu,
+    uint32_t* __restrict__ nxt) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= n) return;
   const T lim = lo[g] + cap;
   uint32_t a = g + 1, b = n;           // largest k in [g+1, n] with lo[k] <= lim; at least g+1
@@ -434,7 +458,8 @@ __global__ void k_plan_seg8(uint32_t S0, const uint32_t* __restrict__ chunk_seg,
   const uint8_t idx = (uint8_t)(g - chunk_seg[a]); const uint32_t lo = seg_lo[g], n = seg_cnt[g];
   for (uint32_t i = 0; i < n; ++i) t_seg8[lo + i] = idx;
 }
-__global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, const uint8_t* __restrict__ seg_cnt1, const uint32_t* __restrict__ seg_txp1,
+__global__ void k_plan_l2(uint32_t S1, const uint32_t* __restrict__ seg_lo1, const uint8_t* __restrict__ seg_cnt1,
+    const uint32_t* __restrict__ seg_txp1,
     uint32_t* __restrict__ l2_lo, uint8_t* __restrict__ l2_cnt) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= S1) return;
   const uint32_t t = seg_txp1[g] & ~SEG_TOP; l2_lo[t] = seg_lo1[g]; l2_cnt[t] = seg_cnt1[g];
@@ -502,20 +527,26 @@ struct EmSession {
       p_off = d_off.p; p_tid = d_tid.p; p_w = d_w.p; p_cnt = (const unsigned long long*)d_cntu.p;
     }
     DBuf<unsigned long long> key, key2; DBuf<uint32_t> val, val2, ns[4], base[4], d_err, nxt; DBuf<uint8_t> tmp;
-    bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) && !d_tcls.alloc(L) && !d_tcw.alloc(L) &&
+    bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) &&
+        !d_tcls.alloc(L) && !d_tcw.alloc(L) &&
         !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
-              !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) && !d_flags.alloc(4) &&
+              !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) &&
+                  !d_flags.alloc(4) &&
                   !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     pt.mark("buffers");
     h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down; nullptr: plain pageable copies
-    if (h_stage) { memcpy(h_stage, txp->eff_len, (size_t)M * 8); SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
+    if (h_stage) {
+      memcpy(h_stage, txp->eff_len, (size_t)M * 8);
+      SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st));
+    }
     else SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));
     pt.mark("alloc+upload");
     // combined weights, prior, CSC
-    if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes, o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
+    if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes,
+        o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
     pt.mark("prep:first-launch-returned");
     k_prep_prior<<<nb(M), TB, 0, st>>>(M, d_eff.p, o->vb_prior, o->per_transcript_prior, d_prior.p);
     if (L) {
@@ -531,7 +562,10 @@ struct EmSession {
     k_plan_counts<<<nb((uint64_t)M + 1), TB, 0, st>>>(M, d_toff.p, ns[0].p, ns[1].p, ns[2].p, ns[3].p, d_err.p);
     { size_t tb = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ns[0].p, base[0].p, (int)(M + 1), st);
       DBuf<uint8_t> stmp; if (stmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (scan)"); return SQ_ERR_NOMEM; }
-      for (int l = 0; l < 4; ++l) { size_t t2 = tb + 256; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp.p, t2, ns[l].p, base[l].p, (int)(M + 1), st)); }
+      for (int l = 0; l < 4; ++l) {
+        size_t t2 = tb + 256;
+        SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp.p, t2, ns[l].p, base[l].p, (int)(M + 1), st));
+      }
       uint32_t S[4] = {0, 0, 0, 0}, herr = 0;
       for (int l = 0; l < 4; ++l) SQ_HIP_CHECK(hipMemcpyAsync(&S[l], base[l].p + M, 4, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, 4, hipMemcpyDeviceToHost, st));
@@ -548,7 +582,8 @@ struct EmSession {
         sq_set_error("device allocation failed in EM plan");
         return SQ_ERR_NOMEM;
       }
-      if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p, d_slo[l].p, d_scn[l].p,
+      if (n) k_plan_fill<<<nb(M), TB, 0, st>>>(l, M, d_toff.p, l ? ns[l - 1].p : nullptr, l ? base[l - 1].p : nullptr, ns[l].p, base[l].p,
+          d_slo[l].p, d_scn[l].p,
           d_stx[l].p);
     }
     // block plans (greedy packing = following a jump table; the chain has ~L/2048 links)
@@ -566,7 +601,10 @@ struct EmSession {
         SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
         for (uint32_t c = 0; c < E; c = hn[c]) h_cchunk.push_back(c); h_cchunk.push_back(E); }
       pt.mark("prep:jump2");
-      if (d_chunk.upload(h_chunk) || d_cchunk.upload(h_cchunk) || d_seg8.alloc(L)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      if (d_chunk.upload(h_chunk) || d_cchunk.upload(h_cchunk) || d_seg8.alloc(L)) {
+        sq_set_error("device allocation failed in EM plan");
+        return SQ_ERR_NOMEM;
+      }
       if (S0) k_plan_seg8<<<nb(S0), TB, 0, st>>>(S0, d_chunk.p, (uint32_t)h_chunk.size() - 1, d_slo[0].p, d_scn[0].p, d_seg8.p);
     }
     const bool fold_l2 = d.nlevels == 2;
@@ -576,7 +614,16 @@ struct EmSession {
       k_plan_l2<<<nb(d.nseg[1]), TB, 0, st>>>(d.nseg[1], d_slo[1].p, d_scn[1].p, d_stx[1].p, d_l2lo.p, d_l2cnt.p);
     }
     SQ_HIP_CHECK(hipStreamSynchronize(st));
-    d.M = M; d.E = E; d.L = L; d.off = p_off; d.tid = p_tid; d.cw = d_cw.p; d.cnt = d_cnt.p; d.t_off = d_toff.p; d.t_cls = d_tcls.p; d.t_cw = d_tcw.p;
+    d.M = M;
+    d.E = E;
+    d.L = L;
+    d.off = p_off;
+    d.tid = p_tid;
+    d.cw = d_cw.p;
+    d.cnt = d_cnt.p;
+    d.t_off = d_toff.p;
+    d.t_cls = d_tcls.p;
+    d.t_cw = d_tcw.p;
     d.prior = d_prior.p;
     d.theta = d_theta.p;
     d.inv = d_inv.p;
@@ -585,7 +632,12 @@ struct EmSession {
     d.maxrel = d_maxrel.p;
     d.tol = o->rel_diff_tolerance;
     d.use_vbem = o->use_vbem;
-    for (int l = 0; l < 4; ++l) { d.seg_lo[l] = d_slo[l].p; d.seg_cnt[l] = d_scn[l].p; d.seg_txp[l] = d_stx[l].p; d.part[l] = d_lpart[l].p; }
+    for (int l = 0; l < 4; ++l) {
+      d.seg_lo[l] = d_slo[l].p;
+      d.seg_cnt[l] = d_scn[l].p;
+      d.seg_txp[l] = d_stx[l].p;
+      d.part[l] = d_lpart[l].p;
+    }
     d.cchunk = d_cchunk.p; d.ncchunks = h_cchunk.size() > 1 ? (uint32_t)h_cchunk.size() - 1 : 0;
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
     d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
@@ -595,10 +647,14 @@ struct EmSession {
 
   // mode 0: optimise to convergence (min_iter / o->max_iter); mode 1: exactly `fixed_iters` steps.
   // alpha_dev != nullptr: the initial alphas are already in d_a0 (device); else they are uploaded from `alpha`.
-  int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false, bool fetch = true) {
+  int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false,
+      bool fetch = true) {
     const int TB = 256;
     if (!alpha_on_device) {
-      if (h_stage) { memcpy(h_stage + M, alpha.data(), (size_t)M * 8); SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, h_stage + M, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
+      if (h_stage) {
+        memcpy(h_stage + M, alpha.data(), (size_t)M * 8);
+        SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, h_stage + M, (size_t)M * 8, hipMemcpyHostToDevice, st));
+      }
       else SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
     }
     SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st));
@@ -612,7 +668,12 @@ struct EmSession {
     auto launch_top = [&](int close_prev, uint32_t prev_it) {
       const double* pin = part_lvl1; uint32_t n1 = g1;
       double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
-      while (n1 > 4096) { k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a); pin = a; n1 = (n1 + 63) / 64; std::swap(a, b); }
+      while (n1 > 4096) {
+        k_sum_level<<<(n1 + TB - 1) / TB, TB, 0, st>>>(pin, nullptr, n1, a);
+        pin = a;
+        n1 = (n1 + 63) / 64;
+        std::swap(a, b);
+      }
       k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p);
     };
     auto launch_iter = [&](uint32_t it) {
@@ -620,10 +681,13 @@ struct EmSession {
       if (o->use_vbem) { k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p); theta_src = d.theta; }
       if (d.ncchunks) k_class<<<d.ncchunks, CL_TB, 0, st>>>(d, theta_src);
       if (d.nchunks) k_l1<<<d.nchunks, L1_TB, 0, st>>>(d, theta_src, nxt);
-      if (!d.l2_cnt) { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l, nxt);
+      if (!d.l2_cnt) { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l,
+          nxt);
         if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }
       k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, nxt, o->use_vbem ? part_lvl1 : nullptr);
-      if (o->use_vbem) launch_top(1, it); else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);   // closes iteration `it`; VBEM: also logNorm for the next one
+      // closes iteration `it`; VBEM: also logNorm for the next one
+      if (o->use_vbem) launch_top(1, it);
+      else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);
       std::swap(cur, nxt);
     };
     if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0); }
@@ -667,7 +731,8 @@ struct EmSession {
   double* result_dev = nullptr; double* h_stage = nullptr;
 };
 
-int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode, uint32_t fixed_iters, sq_em_report* rep,
+int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode,
+    uint32_t fixed_iters, sq_em_report* rep,
     const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr) {
   PhaseTimer pt("em");
   int rc;
@@ -682,7 +747,8 @@ int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
 // ---- a16 bootstrap (doBootstrap, CollapsedEMOptimizer.cpp:398-552) ----------------------------------
 // multinomial resample of the class counts: draw i of replicate b picks the class whose cumulative
 // count interval contains mulhi(r64(seed, b, i), total)
-__global__ void k_bs_sample(uint64_t total, uint32_t E, const uint64_t* __restrict__ cum, uint64_t seed, uint64_t rep, unsigned long long* __restrict__ samp) {
+__global__ void k_bs_sample(uint64_t total, uint32_t E, const uint64_t* __restrict__ cum, uint64_t seed, uint64_t rep,
+    unsigned long long* __restrict__ samp) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t idx = sq_mulhi64(sq_r64(seed, rep, i), total);
     uint32_t lo = 0, hi = E;  // first c with cum[c] > idx
@@ -693,11 +759,21 @@ __global__ void k_bs_sample(uint64_t total, uint32_t E, const uint64_t* __restri
 __global__ void k_u64_to_f64(uint32_t n, const unsigned long long* __restrict__ in, double* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = (double)in[i];
 }
-__global__ void k_truncate(uint32_t n, double* __restrict__ a) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n && a[i] <= 1e-8) a[i] = 0.0; }
+__global__ void k_truncate(uint32_t n, double* __restrict__ a) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] <= 1e-8) a[i] = 0.0;
+}
 
 // ---- a17 Gibbs (sampleRoundNonCollapsedMultithreaded_, CollapsedGibbsSampler.cpp:92-278) --------------
 struct GibbsDev { uint32_t M,
-    E; const uint64_t* off; const uint32_t* tid; const double* w; const uint64_t* cnt; const double* eff; const double* prior; const uint8_t* active;
+    E;
+    const uint64_t* off;
+    const uint32_t* tid;
+    const double* w;
+    const uint64_t* cnt;
+    const double* eff;
+    const double* prior;
+    const uint8_t* active;
                   double* mu; double* count_f; unsigned long long* count_i; const uint64_t* draw_off; };
 __global__ void k_gibbs_mu(GibbsDev g, uint64_t seed, uint64_t round_key, int no_gamma) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
@@ -709,10 +785,14 @@ __device__ inline double gibbs_class_p(const GibbsDev& g, uint64_t a, uint32_t n
   uint32_t t = g.tid[a + i];
   return mode == 0 ? (1000.0 * g.mu[t]) * g.w[a + i] : (mode == 1 ? 1.0 / g.eff[t] : 1.0);
 }
-__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed,
+__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+    uint64_t seed,
     uint64_t round_key) {
   uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
-  const uint32_t c = item_cls[it]; const uint64_t a = g.off[c]; const uint32_t n = (uint32_t)(g.off[c + 1] - a); const uint64_t cnt = g.cnt[c];
+  const uint32_t c = item_cls[it];
+  const uint64_t a = g.off[c];
+  const uint32_t n = (uint32_t)(g.off[c + 1] - a);
+  const uint64_t cnt = g.cnt[c];
   if (n == 1) { if (item_s0[it] == 0) atomicAdd(&g.count_i[g.tid[a]], (unsigned long long)cnt); return; }
   int mode = 0; double denom = 0.0;
   for (uint32_t i = 0; i < n; ++i) denom += gibbs_class_p(g, a, n, 0, i);
@@ -737,7 +817,8 @@ __global__ void k_mul(uint32_t n, const double* __restrict__ a, const double* __
 
 }  // namespace
 
-extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+extern "C" int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out,
+    sq_em_report* rep) {
   if (!eq || !txp || !o || !alpha_out || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
     sq_set_error("sq_em_optimize_dev: bad arguments");
     return SQ_ERR_ARG;
@@ -752,7 +833,10 @@ int sq_em_arena_reserve(void** slot, size_t bytes, size_t pinned_bytes, size_t p
   EmArena* a = (EmArena*)*slot;
   (void)a->pinned(0, pinned_bytes); (void)a->pinned(1, pinned_plan_bytes);
   if (a->capacity() >= bytes) return SQ_OK;
-  if (a->add_chunk(bytes - a->capacity() + ((size_t)8 << 20))) { sq_set_error("device allocation failed (EM workspace, %zu bytes)", bytes); return SQ_ERR_NOMEM; }
+  if (a->add_chunk(bytes - a->capacity() + ((size_t)8 << 20))) {
+    sq_set_error("device allocation failed (EM workspace, %zu bytes)", bytes);
+    return SQ_ERR_NOMEM;
+  }
   return SQ_OK;
 }
 void sq_em_arena_free(void* slot) { delete (EmArena*)slot; }
@@ -761,7 +845,8 @@ size_t sq_em_workspace_bytes(uint64_t E, uint64_t L, uint64_t M) {
   return (size_t)(46 * L + 17 * (L / 64 + M) + 24 * E + 128 * M + ((size_t)16 << 20));
 }
 
-int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep,
+int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o,
+    double* alpha_out, sq_em_report* rep,
     void** arena_slot, void* lent_stream) {
   if (arena_slot && !*arena_slot) *arena_slot = new EmArena();
   const uint32_t M = txp->num_txp;
@@ -778,11 +863,16 @@ int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* 
   double asum = canonical_sum_host(alpha);
   for (uint32_t i = 0; i < M; ++i) alpha_out[i] = alpha[i];
   if (rep) rep->alpha_sum = asum;
-  if (asum < 2.2250738585072014e-308) { sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly."); return SQ_ERR_STATE; }  // :1016-1020
+  // :1016-1020
+  if (asum < 2.2250738585072014e-308) {
+    sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly.");
+    return SQ_ERR_STATE;
+  }
   return SQ_OK;
 }
 
-extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in, uint32_t iters, double* alpha_out,
+extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const double* alpha_in,
+    uint32_t iters, double* alpha_out,
     sq_em_report* rep) {
   if (!eq || !txp || !o || !alpha_in || !alpha_out) { sq_set_error("sq_em_steps_dev: bad arguments"); return SQ_ERR_ARG; }
   std::vector<double> alpha(alpha_in, alpha_in + txp->num_txp);
@@ -793,15 +883,23 @@ extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_i
 }
 
 
-extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped,
+extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed,
+    uint64_t num_mapped,
     sq_replicate_cb cb, void* user) {
-  if (!eq || !txp || !o || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) { sq_set_error("sq_bootstrap_dev: bad arguments"); return SQ_ERR_ARG; }
+  if (!eq || !txp || !o || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
+    sq_set_error("sq_bootstrap_dev: bad arguments");
+    return SQ_ERR_ARG;
+  }
   EmSession S; int rc = S.setup(device, eq, txp, o); if (rc) return rc;
   const uint32_t M = S.M, E = S.E;
   std::vector<uint64_t> cum(E); uint64_t total = 0; for (uint32_t c = 0; c < E; ++c) { total += eq->count[c]; cum[c] = total; }
   std::vector<uint8_t> active(M, 0); for (uint64_t i = 0; i < S.L; ++i) active[eq->tid[i]] = 1;
   uint32_t nact = 0; for (auto a : active) nact += a;
-  if (nact == 0 || total == 0) { sq_set_error("It seems that no transcripts are expressed; something is likely wrong!"); return SQ_ERR_STATE; }   // :598-602
+  // :598-602
+  if (nact == 0 || total == 0) {
+    sq_set_error("It seems that no transcripts are expressed; something is likely wrong!");
+    return SQ_ERR_STATE;
+  }
   const double scale = 1.0 / (double)nact, totalNumFrags = (double)num_mapped;
   std::vector<double> init(M), alpha(M); for (uint32_t i = 0; i < M; ++i) init[i] = active[i] ? scale * totalNumFrags : 0.0;   // :605-606
   DBuf<uint64_t> d_cum;
@@ -820,13 +918,17 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
     rc = S.run(alpha, 0, 0, /*minIter=*/50, &rep); if (rc) return rc;                                  // :412
     for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;                             // truncateCountVector (:509-520)
     double asum = canonical_sum_host(alpha);
-    if (asum < 2.2250738585072014e-308) { sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly."); return SQ_ERR_STATE; }
+    if (asum < 2.2250738585072014e-308) {
+      sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly.");
+      return SQ_ERR_STATE;
+    }
     if (cb(alpha.data(), M, user)) break;
   }
   return SQ_OK;
 }
 
-extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init, uint32_t S_n, uint64_t seed,
+extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init,
+    uint32_t S_n, uint64_t seed,
     uint64_t num_mapped, sq_replicate_cb cb, void* user) {
   if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
     sq_set_error("sq_gibbs_dev: bad arguments");
@@ -849,14 +951,16 @@ extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* 
   std::vector<uint32_t> tid(eq->tid, eq->tid + L);
   std::vector<double> w(eq->w, eq->w + L), eff(txp->eff_len, txp->eff_len + M);
   std::vector<uint32_t> item_cls, item_s0;
-  for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; uint64_t n = off[c + 1] - off[c]; if (n == 0 || cnt[c] == 0) continue;
+  for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; uint64_t n = off[c + 1] - off[c]; if (n == 0 ||
+      cnt[c] == 0) continue;
     if (n == 1) { item_cls.push_back(c); item_s0.push_back(0); } else for (uint64_t s0 = 0; s0 < cnt[c]; s0 += 256) { item_cls.push_back(c); item_s0.push_back((uint32_t)s0); } }
   DBuf<uint64_t> d_off, d_cnt, d_doff;
   DBuf<uint32_t> d_tid, d_ic, d_is;
   DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me;
   DBuf<uint8_t> d_act;
   DBuf<unsigned long long> d_ci;
-  if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) || d_is.upload(item_s0) || d_w.upload(w) ||
+  if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) ||
+      d_is.upload(item_s0) || d_w.upload(w) ||
       d_eff.upload(eff) || d_prior.upload(prior) ||
       d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) ||
           d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
@@ -876,10 +980,14 @@ extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* 
   g.draw_off = d_doff.p;
   uint32_t nchains = 1; if (S_n >= 50) nchains = 2; if (S_n >= 100) nchains = 4; if (S_n >= 200) nchains = 8;    // :425-434
   const uint32_t step = nchains > 1 ? S_n / nchains : S_n + 1;
-  const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16; const int TB = 256; const uint32_t nitems = (uint32_t)item_cls.size();
+  const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16;
+  const int TB = 256;
+  const uint32_t nitems = (uint32_t)item_cls.size();
   std::vector<double> me(M), alphas(M);
   for (uint32_t sid = 0; sid < S_n; ++sid) {
-    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpy(d_cf.p, init.data(), (size_t)M * 8, hipMemcpyHostToDevice));   // chain restart (:452-455)
+    // chain restart (:452-455)
+    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpy(d_cf.p, init.data(), (size_t)M * 8,
+        hipMemcpyHostToDevice));
     for (uint32_t r = 0; r < thin; ++r) {
       const uint64_t key = (uint64_t)sid * thin + r;
       k_gibbs_mu<<<(M + TB - 1) / TB, TB>>>(g, seed, key, go->no_gamma_draw);

@@ -18,7 +18,8 @@ int sort_desc(sq_ctx* c, uint32_t n, uint32_t* perm_out) {
   hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20, c->stream);
   if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
   tmp = c->sort_tmp.n;
-  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(c->sort_tmp.p, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20, c->stream));
+  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(c->sort_tmp.p, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20,
+      c->stream));
   return SQ_OK;
 }
 
@@ -34,27 +35,42 @@ int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_
 void fill_params(sq_ctx* c) {
   const sq_quant_opts& o = c->opts; sq_map_params& P = c->mp;
   P.ma = o.match_score; P.mp = o.mismatch_penalty; P.go = o.gap_open; P.ge = o.gap_extend; P.bw = o.bandwidth;
-  P.k = c->idx->k; P.alt_skip = o.mismatch_seed_skip; P.max_occ = o.max_occs_per_hit; P.frag_len_max = o.frag_len_max; P.first_decoy = c->idx->first_decoy;
+  P.k = c->idx->k;
+  P.alt_skip = o.mismatch_seed_skip;
+  P.max_occ = o.max_occs_per_hit;
+  P.frag_len_max = o.frag_len_max;
+  P.first_decoy = c->idx->first_decoy;
   P.pre_thr = o.pre_merge_chain_sub_thresh; P.post_thr = o.post_merge_chain_sub_thresh; P.orphan_thr = o.orphan_chain_sub_thresh;
   P.consensus_frac = (o.consensus_slack == 0.0) ? 1.0 : (1.0 - o.consensus_slack);  // SalmonMappingUtils.hpp:160-162
-  P.min_score_fraction = o.min_score_fraction; P.score_exp = o.score_exp; P.decoy_threshold = o.decoy_threshold; P.min_aln_prob = o.min_aln_prob;
-  P.lib_type = o.lib_type; P.lib_orient = o.lib_orientation; P.lib_strand = o.lib_strand; P.hard_filter = o.hard_filter; P.allow_dovetail = o.allow_dovetail;
+  P.min_score_fraction = o.min_score_fraction;
+  P.score_exp = o.score_exp;
+  P.decoy_threshold = o.decoy_threshold;
+  P.min_aln_prob = o.min_aln_prob;
+  P.lib_type = o.lib_type;
+  P.lib_orient = o.lib_orientation;
+  P.lib_strand = o.lib_strand;
+  P.hard_filter = o.hard_filter;
+  P.allow_dovetail = o.allow_dovetail;
   P.allow_orphans = o.allow_orphans; P.no_heuristic = o.disable_chaining_heuristic; P.ignore_incompat = o.ignore_incompat;
   P.recover_orphans = o.recover_orphans; P.max_read_occs = o.max_read_occs;
 }
 }  // namespace
 
-static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count", "scan_cands", "k_join_fill", "k_score",
+static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count",
+    "scan_cands", "k_join_fill", "k_score",
     "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table"};
 void sq_prof_begin(sq_ctx* c,
     int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
-  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(-1); }
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i],
+      st); stg.push_back(-1); }
 void sq_prof_mark(sq_ctx* c, int stage,
     int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
-  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
-void sq_prof_end(sq_ctx* c, int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i],
+      st); stg.push_back(stage); }
+void sq_prof_end(sq_ctx* c,
+    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
   for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1],
       ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
 extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) {
@@ -70,7 +86,14 @@ extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int re
   (void)sq_eq_sync(c);
   for (int i = 0; i < SG_NUM; ++i) {
     double m = c->stage_ms[i]; uint64_t n = c->stage_calls[i];
-    for (sq_ctx* sh : c->shadows) { m += sh->stage_ms[i]; n += sh->stage_calls[i]; if (reset) { sh->stage_ms[i] = 0; sh->stage_calls[i] = 0; } }
+    for (sq_ctx* sh : c->shadows) {
+      m += sh->stage_ms[i];
+      n += sh->stage_calls[i];
+      if (reset) {
+        sh->stage_ms[i] = 0;
+        sh->stage_calls[i] = 0;
+      }
+    }
     if (ms) ms[i] = m; if (calls) calls[i] = n; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
   return SQ_OK;
 }
@@ -82,11 +105,24 @@ extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int devic
 // owner == nullptr: a full context (lane 0); else a shadow lane: work buffers and a stream only
 static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx* owner, sq_ctx** out) {
   if (!idx || !opts || !out || max_batch_reads == 0) { sq_set_error("sq_ctx_create: bad arguments"); return SQ_ERR_ARG; }
-  if (max_batch_reads > (1u << 23)) { sq_set_error("max_batch_reads %u exceeds 2^23 (sort key layout)", max_batch_reads); return SQ_ERR_ARG; }
-  if (opts->bandwidth > SQ_MAX_BAND || opts->bandwidth < 0) { sq_set_error("bandwidth %d not supported (max %d)", opts->bandwidth, SQ_MAX_BAND); return SQ_ERR_ARG; }
+  if (max_batch_reads > (1u << 23)) {
+    sq_set_error("max_batch_reads %u exceeds 2^23 (sort key layout)", max_batch_reads);
+    return SQ_ERR_ARG;
+  }
+  if (opts->bandwidth > SQ_MAX_BAND || opts->bandwidth < 0) {
+    sq_set_error("bandwidth %d not supported (max %d)", opts->bandwidth, SQ_MAX_BAND);
+    return SQ_ERR_ARG;
+  }
   int rc = sq_index_to_device(idx, device); if (rc) return rc;
   SQ_HIP_CHECK(hipSetDevice(device));
-  sq_ctx* c = new sq_ctx(); c->idx = idx; c->di = idx->dev; c->device = device; c->opts = *opts; c->max_reads = max_batch_reads; c->owner = owner; c->last_src = c;
+  sq_ctx* c = new sq_ctx();
+  c->idx = idx;
+  c->di = idx->dev;
+  c->device = device;
+  c->opts = *opts;
+  c->max_reads = max_batch_reads;
+  c->owner = owner;
+  c->last_src = c;
   fill_params(c);
   { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 32 of 256; SQ_EQ_CUS=0 disables) and the
     // mapping stream keeps off them.  Measured on MI355X (configs[1]): mapping kernels lose ~3% on 224 CUs, while
@@ -101,7 +137,8 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
       // a partition is an optimisation: if the platform refuses CU masks, fall back to plain streams
       bool ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()) == hipSuccess;
-      if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess && hipStreamCreate(&c->stream3) == hipSuccess;
+      if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess &&
+          hipStreamCreate(&c->stream3) == hipSuccess;
       if (!ok) {
         (void)hipGetLastError();
         if (c->stream) {
@@ -129,13 +166,17 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming));
   }
   const uint32_t nends = 2 * max_batch_reads;
-  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) || c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) ||
+  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) ||
+      c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) ||
       c->rlen.ensure(nends) ||
-             c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) || c->mem_off.ensure((size_t)nends + 2) ||
-             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) || c->wid.ensure(nends) ||
+             c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
+                 c->mem_off.ensure((size_t)nends + 2) ||
+             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) ||
+                 c->wid.ensure(nends) ||
                  c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) ||
                  c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
-             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) || c->aln_off.ensure((size_t)max_batch_reads + 2) ||
+             c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) ||
+                 c->aln_off.ensure((size_t)max_batch_reads + 2) ||
                  c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
              c->stats.ensure(ST_N) || c->gapcost.ensure(SQ_MAX_CHAIN_GAP + 1);
   if (bad) { sq_set_error("device allocation failed in sq_ctx_create"); sq_ctx_free(c); return SQ_ERR_NOMEM; }
@@ -151,7 +192,14 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->lane_thread.joinable()) { { std::lock_guard<std::mutex> lk(c->lane_mu); c->lane_stop = true; } c->lane_cv.notify_all(); c->lane_thread.join(); }
+  if (c->lane_thread.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(c->lane_mu);
+      c->lane_stop = true;
+    }
+    c->lane_cv.notify_all();
+    c->lane_thread.join();
+  }
   if (!c->owner) {
     for (sq_ctx* sh : c->shadows) if (sh->lane_thread.joinable()) {
       {
@@ -169,7 +217,15 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->owner) sq_online_free(c);
   if (c->em_arena) { sq_em_arena_free(c->em_arena); c->em_arena = nullptr; }
-  c->seq.free_(); c->seq_off.free_(); c->rpack.free_(); c->rnmask.free_(); c->rlen.free_(); c->unimems.free_(); c->n_uni.free_(); c->n_proj.free_(); c->mem_off.free_();
+  c->seq.free_();
+  c->seq_off.free_();
+  c->rpack.free_();
+  c->rnmask.free_();
+  c->rlen.free_();
+  c->unimems.free_();
+  c->n_uni.free_();
+  c->n_proj.free_();
+  c->mem_off.free_();
   c->mkey.free_();
   c->mval.free_();
   c->mkey2.free_();
@@ -206,14 +262,20 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
-  for (int b = 0; b < 2; ++b) { if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]); if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]); }
+  for (int b = 0; b < 2; ++b) {
+    if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]);
+    if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
   if (!c || c->owner) { sq_set_error("sq_map_batch: bad context"); return SQ_ERR_ARG; }
-  if (!c->tickets.empty()) { sq_set_error("sq_map_batch: %zu submitted batches are still outstanding (sq_map_wait them first)", c->tickets.size()); return SQ_ERR_STATE; }
+  if (!c->tickets.empty()) {
+    sq_set_error("sq_map_batch: %zu submitted batches are still outstanding (sq_map_wait them first)", c->tickets.size());
+    return SQ_ERR_STATE;
+  }
   int rc = sq_map_batch_impl(c, in, out, stats);
   c->last_src = c; c->api_have = (rc == SQ_OK);
   c->acc_n = c->last_n; c->acc_buf = c->last_buf; c->acc_total_aln = c->last_total_aln; c->acc_joint = c->last_joint;
@@ -265,7 +327,11 @@ extern "C" int sq_map_submit(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* o
   }
   sq_ctx* lane = (c->submitted % want_lanes) == 0 ? c : c->shadows[(c->submitted % want_lanes) - 1];
   auto J = std::make_shared<sq_ctx::map_job>(); J->in = *in; if (out) { J->out = *out; J->has_out = true; }
-  { std::lock_guard<std::mutex> lk(lane->lane_mu); if (!lane->lane_thread.joinable()) lane->lane_thread = std::thread(lane_worker, lane); lane->lane_q.push_back(J); }
+  {
+    std::lock_guard<std::mutex> lk(lane->lane_mu);
+    if (!lane->lane_thread.joinable()) lane->lane_thread = std::thread(lane_worker, lane);
+    lane->lane_q.push_back(J);
+  }
   lane->lane_cv.notify_one();
   c->tickets.emplace_back(lane, J); c->submitted++;
   return SQ_OK;
@@ -325,10 +391,12 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     if (P.k == 31 && di->dict.m == 20)   // the default (k = 31, m = 20) gets the fully specialised kernel
-      k_seed<31, 20><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p,
+      k_seed<31, 20><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p,
+          c->n_proj.p, c->stats.p,
           c->counters.p + 2);
     else
-      k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p,
+      k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p,
+          c->n_proj.p, c->stats.p,
           c->counters.p + 2);
   }
   sq_prof_mark(c, SG_SEED);
@@ -341,12 +409,14 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   c->last_total_mems = total_mems;
   const size_t MP = (size_t)total_mems + 8;
   const bool recover = P.recover_orphans && paired;   // recovered mates live in a second set of chain slabs (k_recover)
-  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mnext.ensure(MP) ||
+  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) ||
+      c->mnext.ensure(MP) ||
       c->mused.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
   if (total_mems) {
-    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, c->mkey.p,
+    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p,
+        c->mem_off.p, c->mkey.p,
         c->mval.p);
     sq_prof_mark(c, SG_PROJECT);
     // one global radix sort on (read end, global reference position); a segmented sort over the position bits only
@@ -356,12 +426,14 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st);
     if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = c->sort_tmp.n;
-    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st));
+    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0,
+        40 + endbits, st));
     skey = c->mkey2.p; sval = c->mval2.p;
     sq_prof_mark(c, SG_SORT);
   }
   // (measured: visiting ends / fragments in work-sorted order lost more to scattered access than it gained in balance)
-  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p, c->chains.p,
+  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p,
+      c->mnext.p, c->mused.p, c->chains.p,
       c->n_chains.p, c->stats.p, nullptr);
   k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
   // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
@@ -376,9 +448,13 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   {
     size_t cap_guess = std::max<size_t>(c->cands.n, (size_t)n * 8 + 1024);
     for (int attempt = 0; attempt < 3; ++attempt) {
-      if (c->cands.ensure(cap_guess) || c->cand_frag.ensure(cap_guess)) { sq_set_error("device allocation failed for candidates; split the batch"); return SQ_ERR_NOMEM; }
+      if (c->cands.ensure(cap_guess) || c->cand_frag.ensure(cap_guess)) {
+        sq_set_error("device allocation failed for candidates; split the batch");
+        return SQ_ERR_NOMEM;
+      }
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_CANDS, 0, sizeof(unsigned long long), st));
-      k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p, c->cands.n,
+      k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p,
+          c->cand_frag.p, c->cands.n,
           c->frag_flags.p, c->stats.p + ST_CANDS);
       unsigned long long tc = 0;
       SQ_HIP_CHECK(hipMemcpyAsync(&tc, c->stats.p + ST_CANDS, 8, hipMemcpyDeviceToHost, st));
@@ -398,34 +474,53 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     if ((buf ? c->aln_b1.n : c->aln.n) < CP) SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf]));   // the buffer is about to be reallocated: the eq stage must be done with it
     SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
   }
-  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) || c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) {
+  if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) ||
+      c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) {
     sq_set_error("device allocation failed for %llu candidates; split the batch", (unsigned long long)total_cands);
     return SQ_ERR_NOMEM;
   }
   sq_dbuf<uint32_t>& cand_frag = c->cand_frag; sq_dbuf<int32_t>& hs_arr = c->hs_arr; sq_dbuf<uint32_t>& tid_arr = c->tid_arr;
   if (hs_arr.ensure(CP) || tid_arr.ensure(CP)) { sq_set_error("device allocation failed (candidate side arrays)"); return SQ_ERR_NOMEM; }
-  ScoreCtx S; S.refseq = di->refseq; S.ref_accum = di->ref_accum; S.ref_len = di->ref_len; S.rpack = c->rpack.p; S.rnmask = c->rnmask.p; S.rlen = c->rlen.p;
-  S.mkey = skey; S.mval = sval; S.mnext = c->mnext.p; S.dpq = c->dpq.p; S.counters = c->counters.p; S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
+  ScoreCtx S;
+  S.refseq = di->refseq;
+  S.ref_accum = di->ref_accum;
+  S.ref_len = di->ref_len;
+  S.rpack = c->rpack.p;
+  S.rnmask = c->rnmask.p;
+  S.rlen = c->rlen.p;
+  S.mkey = skey;
+  S.mval = sval;
+  S.mnext = c->mnext.p;
+  S.dpq = c->dpq.p;
+  S.counters = c->counters.p;
+  S.dpq_cap = (uint32_t)std::min<size_t>(c->dpq.n, 0xFFFFFFFFu);
   uint32_t hcount[2] = {0, 0};
   c->last_chain_slots = recover ? 2 * total_mems : total_mems;
-  if (total_cands && recover) k_recover<<<nblk(n), TB, 0, st>>>(P, S, n, c->cand_off.p, c->n_cand.p, c->cands.p, c->chains.p, (uint32_t)total_mems, c->stats.p);
+  if (total_cands && recover) k_recover<<<nblk(n), TB, 0, st>>>(P, S, n, c->cand_off.p, c->n_cand.p, c->cands.p, c->chains.p,
+      (uint32_t)total_mems, c->stats.p);
   if (total_cands) {
     for (int attempt = 0; attempt < 2; ++attempt) {
       SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_DP, 0, sizeof(unsigned long long), st));
-      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p, cand_frag.p, c->stats.p);
+      k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p,
+          cand_frag.p, c->stats.p);
       sq_prof_mark(c, SG_SCORE);
       SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
       if (hcount[0] <= S.dpq_cap) break;
-      if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) { sq_set_error("DP queue overflow (%u regions)", hcount[0]); return SQ_ERR_OVERFLOW; }
+      if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) {
+        sq_set_error("DP queue overflow (%u regions)", hcount[0]);
+        return SQ_ERR_OVERFLOW;
+      }
       S.dpq = c->dpq.p; S.dpq_cap = (uint32_t)c->dpq.n;
     }
     if (hcount[0]) k_dp<<<(hcount[0] + 63) / 64, 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
     sq_prof_mark(c, SG_DP);
   }
-  if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p, tid_arr.p);
-  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p, c->frag_flags.p, c->aln_slots.p,
+  if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p,
+      tid_arr.p);
+  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p,
+      c->frag_flags.p, c->aln_slots.p,
       c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
@@ -438,7 +533,13 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   sq_prof_end(c);
-  c->last_n = n; c->last_paired = paired; c->last_total_aln = total_aln; c->last_joint = hst[ST_JOINT]; c->have_batch = true; c->last_buf = buf; c->cur_buf = buf ^ 1;
+  c->last_n = n;
+  c->last_paired = paired;
+  c->last_total_aln = total_aln;
+  c->last_joint = hst[ST_JOINT];
+  c->have_batch = true;
+  c->last_buf = buf;
+  c->cur_buf = buf ^ 1;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->num_reads = n;
@@ -473,16 +574,22 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off, const uint8_t* windows, const uint64_t* w_off,
+extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, const uint64_t* q_off, const uint8_t* windows,
+    const uint64_t* w_off,
     const int32_t* k, int32_t* out) {
   if (!ncases) return SQ_OK;
   if (!queries || !q_off || !windows || !w_off || !k || !out) { sq_set_error("sq_debug_infix_align: null argument"); return SQ_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { sq_set_error("sq_debug_infix_align: no device %d", device); return SQ_ERR_DEVICE; }
   // host-side packing into the layouts the pipeline uses: read ends as SQ_READ_WORDS 2-bit words + N mask, text as one 2-bit pool
-  std::vector<uint64_t> rp((size_t)ncases * SQ_READ_WORDS, 0), rn((size_t)ncases * SQ_NMASK_WORDS, 0), toff(ncases + 1, 0); std::vector<uint16_t> rl(ncases);
+  std::vector<uint64_t> rp((size_t)ncases * SQ_READ_WORDS, 0), rn((size_t)ncases * SQ_NMASK_WORDS, 0), toff(ncases + 1, 0);
+  std::vector<uint16_t> rl(ncases);
   auto code = [](uint8_t ch) -> int { switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } };
   for (uint32_t i = 0; i < ncases; ++i) {
-    const uint64_t n = q_off[i + 1] - q_off[i]; if (n > 256) { sq_set_error("sq_debug_infix_align: query %u longer than 256", i); return SQ_ERR_ARG; }
+    const uint64_t n = q_off[i + 1] - q_off[i];
+    if (n > 256) {
+      sq_set_error("sq_debug_infix_align: query %u longer than 256", i);
+      return SQ_ERR_ARG;
+    }
     rl[i] = (uint16_t)n;
     for (uint64_t j = 0; j < n; ++j) {
       const int cd = code(queries[q_off[i] + j]);
@@ -493,12 +600,17 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
   }
   std::vector<uint64_t> text((size_t)(toff[ncases] >> 5) + 2, 0);
   for (uint32_t i = 0; i < ncases; ++i) for (uint64_t j = 0, m = w_off[i + 1] - w_off[i]; j < m; ++j) {
-    const int cd = code(windows[w_off[i] + j]); if (cd > 3) { sq_set_error("sq_debug_infix_align: window %u holds a non-ACGT byte", i); return SQ_ERR_ARG; }
+    const int cd = code(windows[w_off[i] + j]);
+    if (cd > 3) {
+      sq_set_error("sq_debug_infix_align: window %u holds a non-ACGT byte", i);
+      return SQ_ERR_ARG;
+    }
     const uint64_t p = toff[i] + j; text[p >> 5] |= (uint64_t)cd << ((p & 31) * 2);
   }
   sq_dbuf<uint64_t> d_rp, d_rn, d_text, d_toff; sq_dbuf<uint16_t> d_rl; sq_dbuf<int32_t> d_k, d_out;
   int rc = SQ_OK;
-  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) || d_rl.ensure(ncases) || d_k.ensure(ncases) ||
+  if (d_rp.ensure(rp.size()) || d_rn.ensure(rn.size()) || d_text.ensure(text.size()) || d_toff.ensure(toff.size()) ||
+      d_rl.ensure(ncases) || d_k.ensure(ncases) ||
       d_out.ensure((size_t)4 * ncases)) {
     sq_set_error("sq_debug_infix_align: device allocation failed");
     rc = SQ_ERR_NOMEM;
@@ -539,7 +651,8 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   const uint64_t* racc = c->idx->ref_accum.data();
   if (what == SQ_TAP_UNIMEMS) {
     std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * SQ_MAX_UNIMEMS);
-    if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p, um.size() * sizeof(sq_unimem_dev),
+    if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p,
+        um.size() * sizeof(sq_unimem_dev),
         hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     uint64_t cnt = 0; sq_unimem* o = (sq_unimem*)buf;
     for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) {
@@ -610,13 +723,18 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
     return (int64_t)cnt;
   }
   if (what == SQ_TAP_CANDIDATES) {
-    const uint64_t tc = c->last_total_cands; std::vector<sq_cand_dev> cd(tc); std::vector<uint64_t> coff(n + 1); std::vector<uint32_t> ncd(n);
+    const uint64_t tc = c->last_total_cands;
+    std::vector<sq_cand_dev> cd(tc);
+    std::vector<uint64_t> coff(n + 1);
+    std::vector<uint32_t> ncd(n);
     if (tc && hipMemcpy(cd.data(), c->cands.p, tc * sizeof(sq_cand_dev), hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
-    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p, (size_t)n * 4,
+    if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p,
+        (size_t)n * 4,
         hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     sq_cand* o = (sq_cand*)buf; uint64_t cnt = 0;
     for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f] + ncd[f]; ++i) {
-      if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0, sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu,
+      if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0,
+          sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu,
           hr = d.rc != 0xFFFFFFFFu;
         x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status; x.valid = d.valid; x.lscore = d.lscore; x.rscore = d.rscore; x.frag_len = d.frag_len; o[cnt] = x; }
       ++cnt; }

@@ -99,7 +99,8 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
-                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj, unsigned long long* __restrict__ stats,
+                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
+                           unsigned long long* __restrict__ stats,
                            uint32_t* __restrict__ cursor) {
   const int k = KT ? KT : (int)P.k; const int alt = (int)P.alt_skip;
   const int lane = (int)(threadIdx.x & 63);
@@ -157,7 +158,10 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
               uint64_t nn = fetch_bits(r.nm, (uint32_t)(pos + len), (uint32_t)c);
               uint64_t uc;
               if (fw) uc = sq_fetch_bases(d.useq, ub + off + len, (uint32_t)c);
-              else { int up = (int)off - 1 - (len - k); uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c); }
+              else {
+                int up = (int)off - 1 - (len - k);
+                uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c);
+              }
               uint64_t x = rc_ ^ uc; uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ULL;
               int i1 = mm ? (__ffsll((long long)mm) - 1) / 2 : 64; int i2 = nn ? (__ffsll((long long)nn) - 1) : 64;
               int im = i1 < i2 ? i1 : i2;
@@ -198,9 +202,11 @@ __device__ inline MemD mem_decode(uint64_t key, uint64_t val, const uint64_t* re
 }
 
 // a2a — projection through the contig table (fillMemCollection); SPEC §a2.
-__global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab, const uint64_t* __restrict__ ref_accum,
+__global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab,
+    const uint64_t* __restrict__ ref_accum,
                           sq_map_params P, uint32_t nends, const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um,
-                          const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off, uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval) {
+                          const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off, uint64_t* __restrict__ mkey,
+                              uint64_t* __restrict__ mval) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nends) return;
   uint64_t w = mem_off[e]; const int L = rlen[e];
@@ -229,10 +235,13 @@ __global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off,
 // groups use the HBM scratch arrays (f, prev, flags, next links).
 #define CH_SMALL 8
 #define CH_TB 256
-__global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost, uint32_t nends,
-                        const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ mval,
+__global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
+    const double* __restrict__ gapcost, uint32_t nends,
+                        const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey,
+                            const uint64_t* __restrict__ mval,
                         double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
-                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
+                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats,
+                            const uint32_t* __restrict__ perm) {
   __shared__ double s_f[CH_SMALL][CH_TB];
   __shared__ int32_t s_r[CH_SMALL][CH_TB];
   __shared__ int16_t s_q[CH_SMALL][CH_TB];
@@ -302,7 +311,11 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
         c.first = g0;
         c.n_mems = (uint16_t)__popc(mask);
         c.read_len = (uint16_t)L;
-        c.fw = (fwbits >> bi) & 1; c.pad[0] = 1; c.pad[1] = c.pad[2] = 0; c.pad2 = mask;   // pad[0] = 1: members are the bits of pad2 relative to `first`
+        // pad[0] = 1: members are the bits of pad2 relative to `first`
+        c.fw = (fwbits >> bi) & 1;
+        c.pad[0] = 1;
+        c.pad[1] = c.pad[2] = 0;
+        c.pad2 = mask;
         chains[base + nch++] = c;
         if (bf > bestAll) bestAll = bf;
       }
@@ -344,7 +357,13 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
       for (int x = bi; x >= 0; x = cp[base + x]) if (mused[base + x] & 1) { clash = true; break; }
       if (clash) { mused[base + bi] |= 2; continue; }
       uint32_t cnt = 0; int first = bi;
-      for (int x = bi; x >= 0; x = cp[base + x]) { mused[base + x] |= 1; ++cnt; int pr = cp[base + x]; if (pr >= 0) mnext[base + pr] = (uint32_t)x; first = x; }
+      for (int x = bi; x >= 0; x = cp[base + x]) {
+        mused[base + x] |= 1;
+        ++cnt;
+        int pr = cp[base + x];
+        if (pr >= 0) mnext[base + pr] = (uint32_t)x;
+        first = x;
+      }
       MemD m0 = mem_decode(mkey[base + first], mval[base + first], ref_accum);
       MemD ml = mem_decode(mkey[base + bi], mval[base + bi], ref_accum);
       sq_chain_dev c;
@@ -371,18 +390,21 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
 
 // work-balancing permutations: sort item ids by a cheap work estimate (descending) so a wave's 64 lanes
 // finish together; the heavy tail (repeat families) otherwise pins whole waves for ~1 ms
-__global__ void k_work_keys_ends(uint32_t nends, const uint64_t* __restrict__ mem_off, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+__global__ void k_work_keys_ends(uint32_t nends, const uint64_t* __restrict__ mem_off, uint32_t* __restrict__ keys,
+    uint32_t* __restrict__ ids) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= nends) return;
   uint64_t n = mem_off[e + 1] - mem_off[e]; keys[e] = (uint32_t)(n > 0xFFFFFu ? 0xFFFFFu : n); ids[e] = e;
 }
-__global__ void k_work_keys_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+__global__ void k_work_keys_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ keys,
+    uint32_t* __restrict__ ids) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; if (f >= nfrag) return;
   uint32_t n = paired ? n_chains[2 * f] + n_chains[2 * f + 1] : n_chains[f]; keys[f] = n > 0xFFFFFu ? 0xFFFFFu : n; ids[f] = f;
 }
 
 // chains are produced into per-end slabs sized by the MEM count (sparse); pack them densely so that a
 // fragment's chains are one contiguous run (k_join streams them several times)
-__global__ void k_compact_chains(uint32_t nends, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ chain_off, const uint32_t* __restrict__ n_chains,
+__global__ void k_compact_chains(uint32_t nends, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ chain_off,
+    const uint32_t* __restrict__ n_chains,
                                  const sq_chain_dev* __restrict__ sparse, sq_chain_dev* __restrict__ dense) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nends) return;
@@ -404,7 +426,8 @@ __device__ inline void cand_init(sq_cand_dev& c, double cov, uint32_t tid, uint3
   c.valid = 0; c.compat = 0; c.lfail = c.rfail = 0; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0;
 }
 template <bool FILL>
-__device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_dev* lc, uint32_t nl, uint32_t lbase, const sq_chain_dev* rc, uint32_t nr, uint32_t rbase,
+__device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_dev* lc, uint32_t nl, uint32_t lbase,
+    const sq_chain_dev* rc, uint32_t nr, uint32_t rbase,
                                          sq_cand_dev* out, bool* dovetail) {
   uint32_t cnt = 0; bool dove = false;
   // pass 1: global best coverage over concordant pairs
@@ -440,7 +463,10 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
       }
       const double pthr = P.post_thr * bt;
       for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
-        int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue; double cov = lc[a].score + rc[b].score; if (cov < thr || cov < pthr) continue;
+        int32_t fl;
+        if (!pair_ok(P, lc[a], rc[b], &fl, &d2)) continue;
+        double cov = lc[a].score + rc[b].score;
+        if (cov < thr || cov < pthr) continue;
         if (FILL) cand_init(out[cnt], cov, ti, lbase + a, rbase + b, (uint32_t)fl, SQ_MS_PAIRED_END_PAIRED);
         ++cnt;
       }
@@ -478,9 +504,11 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
 // there is no count kernel, no scan and no second enumeration.  Fragments with more than JP pairs, and
 // orphan-only fragments, fall back to the multi-pass enumeration of join_fragment<>.
 #define JP 8
-__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains,
+__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off,
+    const sq_chain_dev* __restrict__ chains,
     const uint32_t* __restrict__ n_chains,
-                        uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag,
+                        uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands,
+                            uint32_t* __restrict__ cand_frag,
                             uint64_t cand_cap,
                         uint8_t* __restrict__ frag_flags, unsigned long long* __restrict__ cursor) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -522,7 +550,8 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
           keep = pc[q] >= P.post_thr * bt; }
         if (keep) ++cnt; else if ((uint32_t)q < np) pf[q] = 0xFFFFFFFFu;   // dropped
       }
-    } else if (P.allow_orphans && (nl || nr)) { mode = 3; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &d2); }
+    } else if (P.allow_orphans && (nl || nr)) { mode = 3; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr,
+        &d2); }
   } else if (act) { mode = 4; lbase = (uint32_t)chain_off[f]; nl = n_chains[f]; lc = chains + lbase; cnt = nl; }
   // block allocation: exclusive prefix of cnt over the wave + one atomic
   uint32_t incl = cnt;
@@ -544,7 +573,9 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
       ++w;
     }
   } else if (mode == 2 || mode == 3) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); }
-  else if (mode == 4) { for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END); }
+  else if (mode == 4) {
+    for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END);
+  }
   for (uint32_t i = 0; i < cnt; ++i) cand_frag[start + i] = f;
 }
 
@@ -650,8 +681,10 @@ __device__ inline bool infix_align(const ReadView& r, bool fw, const uint64_t* _
 }
 
 // parity tap for the aligner alone (sq_debug_infix_align): case i = packed query i against window [toff[i], toff[i+1]) of `text`
-__global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
-                              const uint64_t* __restrict__ text, const uint64_t* __restrict__ toff, const int32_t* __restrict__ kmax, int32_t* __restrict__ out) {
+__global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask,
+    const uint16_t* __restrict__ rlen,
+                              const uint64_t* __restrict__ text, const uint64_t* __restrict__ toff, const int32_t* __restrict__ kmax,
+                                  int32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ncases) return;
   const ReadView r = read_view(rpack, rnmask, rlen, i);
@@ -673,8 +706,10 @@ __global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpac
 // anchor.  A recovered mate is written as a chain without MEMs at slab index rec_base + (anchor's chain index) — every
 // chain anchors at most one orphan candidate — and the candidate becomes a proper pair.
 #define SQ_RECOVER_WINDOW 1000
-__global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand,
-                          sq_cand_dev* __restrict__ cands, sq_chain_dev* __restrict__ chains, uint32_t rec_base, unsigned long long* __restrict__ stats) {
+__global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uint64_t* __restrict__ cand_off,
+    const uint32_t* __restrict__ n_cand,
+                          sq_cand_dev* __restrict__ cands, sq_chain_dev* __restrict__ chains, uint32_t rec_base,
+                              unsigned long long* __restrict__ stats) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t rescued = 0;
   if (f < nfrag) {
@@ -759,8 +794,10 @@ __device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir,
 // region score; returns true if resolved immediately (value in *sc), false if it needs the DP.
 // In `collect` mode nothing is queued: the caller only accumulates the upper bound ma*n of the
 // region; in queue mode the region is appended to the DP queue with its pass/fail budget.
-__device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, const ReadView& r, bool fw, uint32_t cand, uint8_t end, int mode,
-                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc, bool queue, int32_t budget, uint32_t* ndp) {
+__device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, const ReadView& r, bool fw, uint32_t cand, uint8_t end,
+    int mode,
+                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc, bool queue, int32_t budget,
+                                       uint32_t* ndp) {
   if (n == 0 && mode == 1) { *sc = 0; return true; }
   if (n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n))) {
     int mm = count_mm(r, fw, qstart, qdir, S.refseq, tstart, tdir, n);
@@ -798,7 +835,8 @@ __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, co
 // can decide and sums an upper bound (ma * n) for the rest; if even that bound misses
 // minScoreFraction the end is invalid and no DP is queued.  Otherwise pass 1 queues the DP regions,
 // each with the lowest region score that could still make the end valid (k_dp stops early below it).
-__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base, uint32_t end_id, uint32_t cand, uint8_t end,
+__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base,
+    uint32_t end_id, uint32_t cand, uint8_t end,
     uint32_t* ndp, uint8_t* fail) {
   ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
   const int L = r.L; const bool fw = ch.fw != 0;
@@ -813,12 +851,16 @@ __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S,
     int prevQ = 0, prevR = (ch.n_mems == 0) ? ch.pos : 0;
     bool first = true;
     const bool by_mask = ch.pad[0] != 0;
-    uint32_t mbits = ch.pad2; uint32_t mi = by_mask ? ch.first + (uint32_t)(__ffs((int)mbits) - 1) : ch.first; int64_t sc_fast = 0; int64_t ub = 0;
+    uint32_t mbits = ch.pad2;
+    uint32_t mi = by_mask ? ch.first + (uint32_t)(__ffs((int)mbits) - 1) : ch.first;
+    int64_t sc_fast = 0;
+    int64_t ub = 0;
     auto region = [&](int mode, int qstart, int qdir, int n, int64_t tstart, int tdir, int tl) {
       int32_t sc;
       // budget for this region: minacc - (everything else at its best)
       int32_t budget = queue ? (int32_t)max((int64_t)SQ_NEG_INF, (int64_t)minacc - (fast_total + ub_total - (int64_t)P.ma * n)) : 0;
-      if (region_fast(P, S, r, fw, cand, end, mode, qstart, qdir, n, tstart, tdir, tl, &sc, queue, budget, ndp)) sc_fast += sc; else ub += (int64_t)P.ma * n;
+      if (region_fast(P, S, r, fw, cand, end, mode, qstart, qdir, n, tstart, tdir, tl, &sc, queue, budget, ndp)) sc_fast += sc;
+      else ub += (int64_t)P.ma * n;
     };
     for (uint32_t it = 0; it < ch.n_mems; ++it) {
       MemD m = mem_decode(S.mkey[mem_base + mi], S.mval[mem_base + mi], S.ref_accum);
@@ -835,11 +877,20 @@ __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S,
       if (use) { sc_fast += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
       if (by_mask) { mbits &= mbits - 1; mi = ch.first + (uint32_t)(__ffs((int)mbits) - 1); } else mi = S.mnext[mem_base + mi];
     }
-    if (prevQ < L) { int tail = L - prevQ; int we = min(Tlen, prevR + tail + SQ_REF_EXTEND); int tl = max(0, we - prevR); region(1, prevQ, 1, tail, g + prevR, 1, tl); }
+    if (prevQ < L) {
+      int tail = L - prevQ;
+      int we = min(Tlen, prevR + tail + SQ_REF_EXTEND);
+      int tl = max(0, we - prevR);
+      region(1, prevQ, 1, tail, g + prevR, 1, tl);
+    }
     score = sc_fast; ub_dp = ub;
     if (!queue) {
       if (ub == 0) break;                                   // nothing needs the DP
-      if (score + ub < (int64_t)minacc || score < -(1 << 29)) { *fail = 1; break; }  // cannot reach minScoreFraction: invalid without any DP
+      // cannot reach minScoreFraction: invalid without any DP
+      if (score + ub < (int64_t)minacc || score < -(1 << 29)) {
+        *fail = 1;
+        break;
+      }
     }
   }
   if (score < -(1 << 30)) score = -(1 << 30);
@@ -850,7 +901,11 @@ __device__ inline bool joint_compat(const sq_map_params& P, bool orphan, bool is
   const uint8_t s = P.lib_strand;
   bool c = (s == 4) ? (orphan ? true : (lfw != rfw)) : false;
   if (c) return true;
-  if (orphan) { if (s == 0) return (isLeft && lfw) || (!isLeft && !rfw); if (s == 1) return (isLeft && !lfw) || (!isLeft && rfw); return false; }
+  if (orphan) {
+    if (s == 0) return (isLeft && lfw) || (!isLeft && !rfw);
+    if (s == 1) return (isLeft && !lfw) || (!isLeft && rfw);
+    return false;
+  }
   if (s == 0) return lfw && !rfw;
   if (s == 1) return !lfw && rfw;
   return false;
@@ -859,13 +914,16 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
   const uint8_t s = P.lib_strand, o = P.lib_orient;
   switch (ms) {
     case SQ_MS_SINGLE_END: return fwd ? (s == 4 || s == 2) : (s == 4 || s == 3);
-    case SQ_MS_PAIRED_END_LEFT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd); return fwd ? (s == 4 || s == 0) : (s == 4 || s == 1);
-    case SQ_MS_PAIRED_END_RIGHT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd); return fwd ? (s == 4 || s == 1) : (s == 4 || s == 0);
+    case SQ_MS_PAIRED_END_LEFT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd);
+    return fwd ? (s == 4 || s == 0) : (s == 4 || s == 1);
+    case SQ_MS_PAIRED_END_RIGHT: if (o == 0) return s == 4 || (s == 2 && fwd) || (s == 3 && !fwd);
+    return fwd ? (s == 4 || s == 1) : (s == 4 || s == 0);
     default: return false;
   }
 }
 
-__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ cand_off,
+__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,
+    const uint64_t* __restrict__ cand_off,
     uint32_t nfrag,
                         const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
                             unsigned long long* __restrict__ stats) {
@@ -901,7 +959,8 @@ __device__ inline uint32_t dp_tbase(const uint64_t* refseq, const sq_dp_item& it
   if (x < 0 || x >= it.tl) return 0u;
   return sq_fetch_base(refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * x));
 }
-__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
+__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
+    const uint32_t* __restrict__ cand_frag,
     uint32_t paired) {
   uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii >= nitems) return;
@@ -973,7 +1032,8 @@ __device__ inline uint8_t hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t 
 
 // thread per candidate: validity against minScoreFraction and the hit score, written as two compact
 // arrays (SoA) so the per-fragment selection below streams 8 bytes per candidate instead of 48
-__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
+__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands,
+    const uint32_t* __restrict__ cand_frag,
     const uint16_t* __restrict__ rlen,
                            int32_t* __restrict__ hs_out, uint32_t* __restrict__ tid_out) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1000,10 +1060,12 @@ __global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_
   hs_out[ci] = ok ? ((hasL && hasR) ? ls + rs : (hasL ? ls : rs)) : (SQ_INVALID_SCORE + 1);
 }
 
-__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ n_cand,
+__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off,
+    const uint32_t* __restrict__ n_cand,
     const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
                          const uint32_t* __restrict__ tid_arr, const sq_chain_dev* __restrict__ chains,
-                         const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots, uint32_t* __restrict__ n_aln,
+                         const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots,
+                             uint32_t* __restrict__ n_aln,
                              uint8_t* __restrict__ map_type,
                          unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1047,7 +1109,10 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
     }
     // running decoy maxima at the start of the second run (the first run starts from INVALID)
     int32_t runA = SQ_INVALID_SCORE, runB = SQ_INVALID_SCORE;
-    for (uint32_t i = 0; i < split && split < nc; ++i) { const int32_t hs = HS[i]; if (hs > SQ_INVALID_SCORE + 1 && TID[i] >= P.first_decoy && hs > runB) runB = hs; }
+    for (uint32_t i = 0; i < split && split < nc; ++i) {
+      const int32_t hs = HS[i];
+      if (hs > SQ_INVALID_SCORE + 1 && TID[i] >= P.first_decoy && hs > runB) runB = hs;
+    }
     uint32_t ia = 0, ib = split;
     while (ia < split || ib < nc) {
       const uint32_t ta = ia < split ? TID[ia] : 0xFFFFFFFFu, tb = ib < nc ? TID[ib] : 0xFFFFFFFFu;
@@ -1082,7 +1147,11 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
       double v = (double)bestScore - (double)hs;
       double p = P.hard_filter ? -1.0 : sq_exp(-P.score_exp * v);
       if (!P.hard_filter && p < P.min_aln_prob) continue;
-      sq_aln a; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
+      sq_aln a;
+      a.tid = c.tid;
+      a.est_aln_prob = p;
+      a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END;
+      a.frag_len = c.frag_len;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
         const sq_chain_dev& l = chains[c.lc]; const sq_chain_dev& rr = chains[c.rc];
         a.pos = l.pos;
@@ -1127,7 +1196,8 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
   wave_stat_add(&stats[ST_DOVETAIL], (act && !nc && (frag_flags[f] & 1)) ? 1 : 0);
 }
 
-__global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ n_aln,
+__global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ aln_off,
+    const uint32_t* __restrict__ n_aln,
                                const sq_aln* __restrict__ slots, sq_aln* __restrict__ out) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nfrag) return;
@@ -1135,7 +1205,8 @@ __global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand
   for (uint32_t i = 0; i < n_aln[f]; ++i) o[i] = s[i];
 }
 
-__global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats) {
+__global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains,
+    unsigned long long* __restrict__ stats) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   bool any = false;
   if (f < nfrag) any = paired ? (n_chains[2 * f] || n_chains[2 * f + 1]) : (n_chains[f] != 0);

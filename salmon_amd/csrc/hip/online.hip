@@ -95,8 +95,10 @@ __device__ inline bool is_compatible(uint8_t fid, uint8_t et, uint8_t eo, uint8_
   if (ms != SQ_MS_PAIRED_END_PAIRED) {
     switch (ms) {
       case SQ_MS_SINGLE_END: return fwd ? (es == 4 || es == 2) : (es == 4 || es == 3);
-      case SQ_MS_PAIRED_END_LEFT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd); return fwd ? (es == 4 || es == 0) : (es == 4 || es == 1);
-      case SQ_MS_PAIRED_END_RIGHT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd); return fwd ? (es == 4 || es == 1) : (es == 4 || es == 0);
+      case SQ_MS_PAIRED_END_LEFT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd);
+      return fwd ? (es == 4 || es == 0) : (es == 4 || es == 1);
+      case SQ_MS_PAIRED_END_RIGHT: if (eo == 0) return es == 4 || (es == 2 && fwd) || (es == 3 && !fwd);
+      return fwd ? (es == 4 || es == 1) : (es == 4 || es == 0);
       default: return false;
     }
   }
@@ -108,12 +110,26 @@ __device__ inline bool is_compatible(uint8_t fid, uint8_t et, uint8_t eo, uint8_
 
 struct OnlineView {
   uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen; double* tlc;
-  double* hist; double* cpmf; double* ccmf; const double* ambig; double* mass; const double* prior_mass; double* log_eff_len; double* scal; double* cfac;
-  unsigned long long* mass_acc; unsigned long long* uniq; unsigned long long* total; unsigned long long* lib_counts; uint32_t* fld_cnt; unsigned long long* ctr;
+  double* hist;
+  double* cpmf;
+  double* ccmf;
+  const double* ambig;
+  double* mass;
+  const double* prior_mass;
+  double* log_eff_len;
+  double* scal;
+  double* cfac;
+  unsigned long long* mass_acc;
+  unsigned long long* uniq;
+  unsigned long long* total;
+  unsigned long long* lib_counts;
+  uint32_t* fld_cnt;
+  unsigned long long* ctr;
   uint32_t* touched; uint32_t* touched_n;
 };
 
-__global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o, uint32_t* __restrict__ flag) {
+__global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o,
+    uint32_t* __restrict__ flag) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r > n) return;
   if (r == n) { flag[n] = 0; return; }
@@ -142,7 +158,8 @@ struct PreAln { double c_cov; double c_start; uint32_t flen; uint16_t fl_ped, ma
 enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEXP_ORPHAN = 16,
     PF_FLEN_IN_REF = 32 /* flen < refLength (refLength = max(RefLength, 1)) */ };
 
-__global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
+__global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len,
+    const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
     PreAln* __restrict__ pre) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
@@ -191,10 +208,12 @@ __device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, u
   }
 }
 
-__device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint64_t read_counter0,
+__device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1,
+    uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin,
+                                 uint64_t* __restrict__ rh1,
                                  uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
@@ -234,7 +253,10 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
     double startPosProb;
     if (p.flags & PF_PE_START) startPosProb = p.c_start;
-    else { double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[t]); startPosProb = -logRefLength; }
+    else {
+      double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? p.c_start : V.log_eff_len[t]);
+      startPosProb = -logRefLength;
+    }
     fmtSeen |= 1ULL << p.fmt;
     const double auxProb = logFragProb + p.c_cov + logCompat;
     const double logProb = V.tlc[t] + auxProb + startPosProb;
@@ -270,7 +292,8 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
         uint32_t fl = pre[ai].fl_ped;
         if (fl > 0) {
           atomicAdd(&V.fld_cnt[fl], 1u);
-          if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2], (unsigned long long)fl);
+          if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
+              (unsigned long long)fl);
         }
       }
     }
@@ -298,7 +321,8 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
-                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1,
+                             unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin,
+                                 uint64_t* __restrict__ rh1,
                                  uint64_t* __restrict__ rh2, uint32_t par) {
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
@@ -307,7 +331,8 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
   if (valid && nA > MB_G * MB_S) {
-    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1, rh2, &fmtSeen, par,
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1,
+        rh2, &fmtSeen, par,
         &compatFrag);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
@@ -317,7 +342,12 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       const bool cond = burned || useAux; const bool singleEnd = (o.lib_type == 0);
       const double totMass = V.scal[0];
       // phase 1: lane j -> alignments a0 + j and a0 + j + 8
-      bool keep[MB_S]; double auxProb[MB_S], logProb[MB_S]; uint32_t t[MB_S]; uint32_t fl_ped[MB_S]; uint64_t fmtBit[MB_S]; bool compat[MB_S];
+      bool keep[MB_S];
+      double auxProb[MB_S], logProb[MB_S];
+      uint32_t t[MB_S];
+      uint32_t fl_ped[MB_S];
+      uint64_t fmtBit[MB_S];
+      bool compat[MB_S];
 #pragma unroll
       for (int sl = 0; sl < MB_S; ++sl) {
         keep[sl] = false; auxProb[sl] = 0.0; logProb[sl] = 0.0; t[sl] = 0; fl_ped[sl] = 0; fmtBit[sl] = 0; compat[sl] = false;
@@ -339,7 +369,11 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             if (p.flen > 0 && o.use_frag_len_dist && cond) {
               const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
               const double lenProb = cached ? V.cpmf[fi] : (V.hist[fi] - totMass);
-              if (burned) { double cm = V.ccmf[fi]; bool ok = (p.flags & PF_FLEN_IN_REF) && !(cm == SQ_LOG_0); logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON; }
+              if (burned) {
+                double cm = V.ccmf[fi];
+                bool ok = (p.flags & PF_FLEN_IN_REF) && !(cm == SQ_LOG_0);
+                logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON;
+              }
               else if (useAux) logFragProb = lenProb;
             }
             const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
@@ -361,7 +395,8 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       for (uint32_t i = 0; i < nA; ++i) {
         const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
         const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G);
-        const double xa = __shfl(hi ? auxProb[1] : auxProb[0], src, MB_G); const double xl = __shfl(hi ? logProb[1] : logProb[0], src, MB_G);
+        const double xa = __shfl(hi ? auxProb[1] : auxProb[0], src, MB_G);
+        const double xl = __shfl(hi ? logProb[1] : logProb[0], src, MB_G);
         const unsigned long long fm = __shfl((unsigned long long)(hi ? fmtBit[1] : fmtBit[0]), src, MB_G);
         fmtAll |= fm;
         if (kp) { sumProbs = sq_log_add(sumProbs, xl); auxDenom = sq_log_add(auxDenom, xa); ++nk; }
@@ -391,7 +426,8 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
               if (rr < pr && fl_ped[sl] > 0) {
                 atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u);
-                if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
+                if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
                     (unsigned long long)fl_ped[sl]);
               }
             }
@@ -402,10 +438,13 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       // label hash (tids of kept alignments, then their bins), replayed by all lanes; lane 0 publishes
       if (assigned) {
         const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
-        uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen; uint32_t firstTid = 0; bool gotFirst = false;
+        uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen;
+        uint32_t firstTid = 0;
+        bool gotFirst = false;
         for (uint32_t i = 0; i < nA; ++i) {
           const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
-          const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G); const uint32_t ti = (uint32_t)__shfl((int)(hi ? t[1] : t[0]), src, MB_G);
+          const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G);
+          const uint32_t ti = (uint32_t)__shfl((int)(hi ? t[1] : t[0]), src, MB_G);
           if (kp) { label_hash_step(ha, hb, ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } }
         }
         if (o.range_factorization_bins > 0) for (uint32_t i = 0; i < nA; ++i) {
@@ -441,13 +480,21 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
 // transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
-__device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64_t assigned_after, int set_ctr, uint32_t par, uint32_t mass_blocks) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { if (set_ctr) V.ctr[0] = assigned_after; V.touched_n[par ^ 1] = 0; }   // the other list is idle until the next mini-batch
+__device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64_t assigned_after, int set_ctr, uint32_t par,
+    uint32_t mass_blocks) {
+  // the other list is idle until the next mini-batch
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (set_ctr) V.ctr[0] = assigned_after;
+    V.touched_n[par ^ 1] = 0;
+  }
   const uint32_t n = V.touched_n[par]; const uint32_t* list = V.touched + (size_t)par * V.M;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += mass_blocks * blockDim.x) {
     const uint32_t t = list[i];
     const unsigned long long q = V.mass_acc[t];
-    const double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); V.mass[t] = m; V.tlc[t] = sq_log_add(V.prior_mass[t], m); V.mass_acc[t] = 0;
+    const double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
+    V.mass[t] = m;
+    V.tlc[t] = sq_log_add(V.prior_mass[t], m);
+    V.mass_acc[t] = 0;
   }
 }
 
@@ -495,7 +542,8 @@ __device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_
 // kernel needs few workgroups and squeezes in beside the mapping kernels), the extra last block (before
 // burn-in only) updates the FLD — the two parts touch disjoint state, and every launch saved shortens
 // the sequential mini-batch chain (the model of mini-batch i+1 depends on the end of mini-batch i).
-__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin, uint32_t mass_blocks, int with_fld,
+__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin,
+    uint32_t mass_blocks, int with_fld,
     uint32_t par) {
   if (blockIdx.x < mass_blocks) apply_mass_part(V, logFM, assigned_after, with_fld ? 0 : 1, par, mass_blocks);
   else apply_fld_part(V, logFM, assigned_after, num_burnin);
@@ -521,7 +569,13 @@ __global__ void k_burnin_tables(OnlineView V, int force) {
   if (!force) {
     // cacheCMF: normalised pmf then prefix log-sum
     double tot = SQ_LOG_0; for (int i = 0; i <= 1000; ++i) { double p = V.hist[i] - tot0; V.cpmf[i] = p; tot = sq_log_add(tot, p); }
-    double cum = SQ_LOG_0; for (int i = 0; i <= 1000; ++i) { double p = V.cpmf[i] - tot; V.cpmf[i] = p; cum = sq_log_add(cum, p); V.ccmf[i] = cum; }
+    double cum = SQ_LOG_0;
+    for (int i = 0; i <= 1000; ++i) {
+      double p = V.cpmf[i] - tot;
+      V.cpmf[i] = p;
+      cum = sq_log_add(cum, p);
+      V.ccmf[i] = cum;
+    }
     V.ctr[3] = 1; V.ctr[1] = 1; V.ctr[4] = 2;
   } else V.ctr[4] = 3;
 }
@@ -545,7 +599,11 @@ __device__ inline uint64_t eq_find_or_insert(const EqView& T, uint64_t h1, uint6
     unsigned long long cur = __hip_atomic_load(&T.k1[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == EQ_EMPTY) {
       unsigned long long old = atomicCAS(&T.k1[slot], EQ_EMPTY, (unsigned long long)h1);
-      if (old == EQ_EMPTY) { __hip_atomic_store(&T.k2[slot], (unsigned long long)h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *is_new = true; return slot; }
+      if (old == EQ_EMPTY) {
+        __hip_atomic_store(&T.k2[slot], (unsigned long long)h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_new = true;
+        return slot;
+      }
       cur = old;
     }
     if (cur == h1) {
@@ -558,8 +616,10 @@ __device__ inline uint64_t eq_find_or_insert(const EqView& T, uint64_t h1, uint6
   return ~0ULL;
 }
 
-__global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ abin,
-                            const uint64_t* __restrict__ rh1, const uint64_t* __restrict__ rh2, uint32_t* __restrict__ rslot, uint32_t bins_on) {
+__global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln,
+    const uint32_t* __restrict__ abin,
+                            const uint64_t* __restrict__ rh1, const uint64_t* __restrict__ rh2, uint32_t* __restrict__ rslot,
+                                uint32_t bins_on) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   rslot[r] = 0xFFFFFFFFu;
@@ -580,7 +640,8 @@ __global__ void k_eq_insert(EqView T, uint32_t n, const uint64_t* __restrict__ a
     T.n[slot] = nk; T.pool[slot] = off;
   }
 }
-__global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ abin, const unsigned long long* __restrict__ awq,
+__global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ abin,
+    const unsigned long long* __restrict__ awq,
     const uint32_t* __restrict__ rslot) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -591,7 +652,8 @@ __global__ void k_eq_add(EqView T, uint32_t n, const uint64_t* __restrict__ aln_
   for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) if (abin[ai] != 0xFFFFFFFFu) { atomicAdd(&T.pool_wq[off + i], awq[ai]); ++i; }
 }
 // merge an external table (classes given as CSR) — exact integer adds, any order
-__global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, const uint32_t* __restrict__ bins,
+__global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid,
+    const uint32_t* __restrict__ bins,
     const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, uint32_t* __restrict__ cslot) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= E) return;
@@ -606,7 +668,8 @@ __global__ void k_eq_merge_insert(EqView T, uint64_t E, const uint64_t* __restri
     T.n[slot] = nk; T.pool[slot] = po;
   }
 }
-__global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wq, const uint64_t* __restrict__ count,
+__global__ void k_eq_merge_add(EqView T, uint64_t E, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wq,
+    const uint64_t* __restrict__ count,
     const uint32_t* __restrict__ cslot) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= E) return;
@@ -629,7 +692,8 @@ __global__ void k_gather_bounds(const uint64_t* __restrict__ prefix, uint32_t mb
 // keeps classes of one gene family adjacent, so the EM's theta[tid] / inv[class] gathers
 // (em.hip k_class / k_l1) land in a few cache lines instead of being spread by the hash.
 // Sort key = first_tid << 32 | h1 >> 32; a key tie that is out of (h1,h2) order is fixed on the host.
-__global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, uint32_t* __restrict__ slots, unsigned long long* __restrict__ counter) {
+__global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, uint32_t* __restrict__ slots,
+    unsigned long long* __restrict__ counter) {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool occ = s < T.cap && T.k1[s] != EQ_EMPTY;
   const unsigned long long m = __ballot(occ);
@@ -642,7 +706,8 @@ __global__ void k_eq_collect(EqView T, unsigned long long* __restrict__ keys, ui
     slots[i] = (uint32_t)s;
   }
 }
-__global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ nlab,
+__global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const unsigned long long* __restrict__ keys,
+    uint32_t* __restrict__ nlab,
     uint32_t* __restrict__ tie) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c > E) return;
@@ -653,7 +718,8 @@ __global__ void k_eq_sizes(EqView T, uint64_t E, const uint32_t* __restrict__ sl
     if (a1 > b1 || (a1 == b1 && T.k2[slots[c]] > T.k2[slots[c + 1]])) *tie = 1;
   }
 }
-__global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off, uint32_t* __restrict__ tid,
+__global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ slots, const uint64_t* __restrict__ off,
+    uint32_t* __restrict__ tid,
     double* __restrict__ w, unsigned long long* __restrict__ wq,
                             unsigned long long* __restrict__ count, uint32_t* __restrict__ bins, unsigned long long* __restrict__ h1,
                                 unsigned long long* __restrict__ h2) {
@@ -722,13 +788,17 @@ int sq_online_create(sq_ctx* c) {
   const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
-  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) || o->prior_mass.ensure(M) ||
+  bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) ||
+      o->prior_mass.ensure(M) ||
       o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
-             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) || o->total.ensure(M) ||
+             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) ||
+                 o->total.ensure(M) ||
                  o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
-             o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) || o->rh1.ensure(c->max_reads) ||
+             o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) ||
+                 o->rh1.ensure(c->max_reads) ||
                  o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
-             o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(o->pool_cap) ||
+             o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) ||
+                 o->pool_tid.ensure(o->pool_cap) ||
                  o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
   const sq_quant_opts& q = c->opts;
@@ -738,8 +808,15 @@ int sq_online_create(sq_ctx* c) {
     hist[i] = (nm != 0) ? sq_log(nm) : SQ_LOG_EPSILON;
   }
   { std::vector<double> v(1024,
-      SQ_LOG_0); for (int i = 0; i <= 1000; ++i) v[i] = hist[i]; for (int s = 512; s >= 1; s >>= 1) for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
-    tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice)); }
+      SQ_LOG_0); for (int i = 0;
+      i <= 1000;
+      ++i) v[i] = hist[i]; for (int s = 512;
+      s >= 1;
+      s >>= 1) for (int i = 0;
+      i < s;
+      ++i) v[i] = sq_log_add(v[i], v[i + s]);
+    tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal),
+        hipMemcpyHostToDevice)); }
   // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
   {
     double cum = SQ_LOG_0;
@@ -758,14 +835,19 @@ int sq_online_create(sq_ctx* c) {
     pm[t] = sq_log(0.005 * len);
     le[t] = sq_log(len);
   }
-  SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice));
+  SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->log_eff_len.p, le.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior
   SQ_HIP_CHECK(hipMemset(o->touched_n.p, 0, 8));
-  SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8)); SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
-  SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8)); SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4)); SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
+  SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8));
+  SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8));
+  SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
+  SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8));
+  SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4));
+  SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8));
   SQ_HIP_CHECK(hipMemset(o->tk2.p, 0, cap * 8));
@@ -905,7 +987,16 @@ static void eq_worker(sq_ctx* c) {
       J = c->eq_q.front(); c->eq_q.pop_front(); }
     int rc = 0;
     { std::lock_guard<std::mutex> lk(c->eq_mu); rc = c->eq_err; }
-    if (!rc) { rc = eq_accumulate_job(c, J); if (rc) { std::lock_guard<std::mutex> lk(c->eq_mu); if (!c->eq_err) { c->eq_err = rc; c->eq_errmsg = sq_last_error(); } } }
+    if (!rc) {
+      rc = eq_accumulate_job(c, J);
+      if (rc) {
+        std::lock_guard<std::mutex> lk(c->eq_mu);
+        if (!c->eq_err) {
+          c->eq_err = rc;
+          c->eq_errmsg = sq_last_error();
+        }
+      }
+    }
     { std::lock_guard<std::mutex> lk(c->eq_mu); c->eq_enqueued++; }
     c->eq_cv_done.notify_all();
   }
@@ -962,12 +1053,14 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   OnlineView V = make_view(c);
   mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
-  if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
+  if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
+      (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, d_aln_off, d_aln, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
     if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
-    tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st)); }
+    tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
+        (int)(n + 1), st)); }
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
@@ -987,10 +1080,12 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
     const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
     const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln, (const PreAln*)o->pre.p,
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln,
+        (const PreAln*)o->pre.p,
         o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, (uint32_t)(o->batch_no & 1));
     { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
-      k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, (uint32_t)(o->batch_no & 1)); }
+      k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags, mass_blocks, with_fld,
+          (uint32_t)(o->batch_no & 1)); }
     if (!burned_host && assigned_after >= q.num_burnin_frags) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
       k_burnin_efflen<<<nblk(o->M), TB, 0, st>>>(V, 2);
@@ -1082,9 +1177,16 @@ extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   sq_online_dev* o = c->online; unsigned long long hctr[8]; double scal[8]; std::vector<double> h(1024);
-  SQ_HIP_CHECK(hipMemcpy(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(scal, o->scal.p, sizeof(scal), hipMemcpyDeviceToHost));
-  if (hctr[3]) { SQ_HIP_CHECK(hipMemcpy(h.data(), o->cpmf.p, 1024 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i <= 1000; ++i) out[i] = h[i]; }
-  else { SQ_HIP_CHECK(hipMemcpy(h.data(), o->hist.p, 1024 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i <= 1000; ++i) out[i] = h[i] - scal[0]; }
+  SQ_HIP_CHECK(hipMemcpy(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
+  SQ_HIP_CHECK(hipMemcpy(scal, o->scal.p, sizeof(scal), hipMemcpyDeviceToHost));
+  if (hctr[3]) {
+    SQ_HIP_CHECK(hipMemcpy(h.data(), o->cpmf.p, 1024 * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i <= 1000; ++i) out[i] = h[i];
+  }
+  else {
+    SQ_HIP_CHECK(hipMemcpy(h.data(), o->hist.p, 1024 * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i <= 1000; ++i) out[i] = h[i] - scal[0];
+  }
   return SQ_OK;
 }
 
@@ -1113,13 +1215,15 @@ static int eq_export_run(sq_ctx* c) {
   X.model_valid = false;
   if (E == 0) return SQ_OK;   // nothing staged; fetches fall back to direct copies
   EqView T = make_eq_view(o);
-  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) ||
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) ||
+      X.d_tid.ensure(L) ||
       X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
       X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) ||
           X.d_tie.ensure(1)) { sq_set_error("device allocation failed (eq export)"); return SQ_ERR_NOMEM; }
   const size_t M = o->M; const size_t need = 32 * E + 24 * L + 64 + 32 * M;
   if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0; const size_t cap = need + need / 4;
-    if (hipHostMalloc((void**)&X.host, cap, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (eq export, %zu bytes)",
+    if (hipHostMalloc((void**)&X.host, cap,
+        hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (eq export, %zu bytes)",
         cap); return SQ_ERR_NOMEM; } X.host_cap = cap; }
   mark("alloc");
   SQ_HIP_CHECK(hipMemsetAsync(X.d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(X.d_tie.p, 0, 4, st));
@@ -1135,8 +1239,10 @@ static int eq_export_run(sq_ctx* c) {
   uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, X.d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
   if (tie) {  // two classes share a sort key and arrived out of (h1,h2) order: re-sort the slot list on the host (rare)
     std::vector<uint32_t> hs(E), ord(E); std::vector<unsigned long long> hk(E), k1(o->tcap), k2(o->tcap);
-    SQ_HIP_CHECK(hipMemcpy(hs.data(), X.slots2.p, E * 4, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(hk.data(), X.keys2.p, E * 8, hipMemcpyDeviceToHost));
-    SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost)); SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(hs.data(), X.slots2.p, E * 4, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(hk.data(), X.keys2.p, E * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(k1.data(), o->tk1.p, o->tcap * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipMemcpy(k2.data(), o->tk2.p, o->tcap * 8, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < E; ++i) ord[i] = (uint32_t)i;
     std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { if (hk[x] != hk[y]) return hk[x] < hk[y]; const uint32_t a = hs[x],
         b = hs[y]; return k1[a] < k1[b] || (k1[a] == k1[b] && k2[a] < k2[b]); });
@@ -1195,7 +1301,13 @@ extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
   std::vector<Seg> chunks; const size_t CH = 4u << 20;
   for (auto& sg : segs) for (size_t p = 0; p < sg.n; p += CH) chunks.push_back({sg.dst + p, sg.src + p, std::min(CH, sg.n - p)});
   std::atomic<size_t> next{0};
-  auto work = [&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= chunks.size()) break; memcpy(chunks[i].dst, chunks[i].src, chunks[i].n); } };
+  auto work = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= chunks.size()) break;
+      memcpy(chunks[i].dst, chunks[i].src, chunks[i].n);
+    }
+  };
   const unsigned nth = (unsigned)std::min<size_t>(8, std::max<size_t>(1, chunks.size() / 2));
   std::vector<std::thread> th; for (unsigned i = 1; i < nth; ++i) th.emplace_back(work);
   work(); for (auto& t : th) t.join();
@@ -1283,7 +1395,8 @@ int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out) {
 }
 
 // eq == NULL: optimise over the ctx's own accumulated classes, straight from the export that already sits in HBM
-extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
+extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out,
+    sq_em_report* rep) {
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
   if (eq) return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
@@ -1308,17 +1421,20 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
     { int rs = sq_eq_sync(c); if (rs) return rs; }
     unsigned long long cur[4]; SQ_HIP_CHECK(hipMemcpy(cur, o->pool_cursor.p, sizeof(cur), hipMemcpyDeviceToHost));
     if (cur[1]) {
-      sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)", cur[1],
+      sq_set_error("sq_ctx_reserve: the class table already holds %llu classes; reserve %llu classes before the first sq_eq_accumulate (or after sq_ctx_reset)",
+          cur[1],
           (unsigned long long)E);
       return SQ_ERR_STATE;
     }
     uint64_t cap = o->tcap; while (E * 10 > cap * 7) cap <<= 1;
     const uint64_t pcap = std::max<uint64_t>(std::max<uint64_t>(o->pool_cap, cap * 4), L);
     if (cap >= (1ull << 32) || pcap >= (1ull << 40)) {
-      sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E, (unsigned long long)L);
+      sq_set_error("sq_ctx_reserve: %llu classes / %llu labels are beyond the table's addressing", (unsigned long long)E,
+          (unsigned long long)L);
       return SQ_ERR_ARG;
     }
-    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) || o->pool_tid.ensure(pcap) ||
+    if (o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) ||
+        o->pool_tid.ensure(pcap) ||
         o->pool_bin.ensure(pcap) || o->pool_wq.ensure(pcap)) {
       sq_set_error("device allocation failed (class table for %llu classes)", (unsigned long long)E);
       return SQ_ERR_NOMEM;
@@ -1330,14 +1446,17 @@ extern "C" int sq_ctx_reserve(sq_ctx* c, uint64_t max_classes, uint64_t max_labe
     SQ_HIP_CHECK(hipMemset(o->tn.p, 0, cap * 4));
     SQ_HIP_CHECK(hipMemset(o->pool_wq.p, 0, pcap * 8));
   }
-  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) || X.d_tid.ensure(L) ||
+  if (X.keys.ensure(E) || X.keys2.ensure(E) || X.slots.ensure(E) || X.slots2.ensure(E) || X.nlab.ensure(E + 1) || X.d_off.ensure(E + 1) ||
+      X.d_tid.ensure(L) ||
       X.d_bins.ensure(L) || X.d_wq.ensure(L) || X.d_w.ensure(L) ||
       X.d_cnt.ensure(E) || X.d_h1.ensure(E) || X.d_h2.ensure(E) || X.d_ctr.ensure(1) || X.d_tie.ensure(1) ||
           X.tmp.ensure((size_t)32 << 20)) { sq_set_error("device allocation failed (sq_ctx_reserve)"); return SQ_ERR_NOMEM; }
   X.valid = false; X.model_valid = false;   // buffers may have moved: a staged export is made again on its next use
   const size_t need = 32 * E + 24 * L + 64 + 32 * M;
   if (X.host_cap < need) { if (X.host) (void)hipHostFree(X.host); X.host = nullptr; X.host_cap = 0;
-    if (hipHostMalloc((void**)&X.host, need, hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)",
+    if (hipHostMalloc((void**)&X.host, need,
+        hipHostMallocDefault) != hipSuccess) { sq_set_error("pinned staging allocation failed (sq_ctx_reserve, %zu bytes)",
         need); return SQ_ERR_NOMEM; } X.host_cap = need; }
-  return sq_em_arena_reserve(&c->em_arena, sq_em_workspace_bytes(E, L, M), (size_t)3 * M * 8, (size_t)(std::max<uint64_t>(E, L / 64 + M) + 1) * 4);
+  return sq_em_arena_reserve(&c->em_arena, sq_em_workspace_bytes(E, L, M), (size_t)3 * M * 8,
+      (size_t)(std::max<uint64_t>(E, L / 64 + M) + 1) * 4);
 }

@@ -29,7 +29,9 @@ namespace {
 // its smallest transcript id whatever the interleaving): classes are united by several threads at once.
 struct DSU {
   std::unique_ptr<std::atomic<uint32_t>[]> p; uint32_t n;
-  explicit DSU(uint32_t n_) : p(new std::atomic<uint32_t>[n_]), n(n_) { for (uint32_t i = 0; i < n; ++i) p[i].store(i, std::memory_order_relaxed); }
+  explicit DSU(uint32_t n_) : p(new std::atomic<uint32_t>[n_]), n(n_) {
+    for (uint32_t i = 0; i < n; ++i) p[i].store(i, std::memory_order_relaxed);
+  }
   uint32_t root(uint32_t x) {
     for (;;) {
       uint32_t px = p[x].load(std::memory_order_relaxed); if (px == x) return x;
@@ -49,7 +51,8 @@ struct DSU {
 };
 }  // namespace
 
-extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total, double* projected) {
+extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_mass, const uint64_t* uniq, const uint64_t* total,
+    double* projected) {
   if (!eq || !log_mass || !uniq || !total || !projected) { sq_set_error("sq_normalize_alphas: bad arguments"); return SQ_ERR_ARG; }
   const bool timing = getenv("SQ_TIMING") != nullptr; auto tm0 = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
@@ -63,20 +66,25 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
   sq_parallel_for(eq->num_classes, nthr, 8192, [&](uint64_t c_lo, uint64_t c_hi, uint32_t) {
     for (uint64_t c = c_lo; c < c_hi; ++c) {
       const uint64_t a = eq->off[c], b = eq->off[c + 1];
-      for (uint64_t i = a; i < b; ++i) if (eq->tid[i] >= M) { bad.store(eq->tid[i] + 1 ? eq->tid[i] + 1 : 1, std::memory_order_relaxed); goto next; }
+      for (uint64_t i = a; i < b; ++i) if (eq->tid[i] >= M) {
+        bad.store(eq->tid[i] + 1 ? eq->tid[i] + 1 : 1, std::memory_order_relaxed);
+        goto next;
+      }
       for (uint64_t i = a + 1; i < b; ++i) d.join(eq->tid[a], eq->tid[i]);
       next:;
     }
   });
   if (bad.load()) { sq_set_error("sq_normalize_alphas: a label names transcript %u >= %u", bad.load() - 1, M); return SQ_ERR_ARG; }
   std::vector<uint32_t> rootOf(M);
-  sq_parallel_for(M, nthr, 8192, [&](uint64_t lo, uint64_t hi, uint32_t) { for (uint64_t t = lo; t < hi; ++t) rootOf[t] = d.root((uint32_t)t); });
+  sq_parallel_for(M, nthr, 8192, [&](uint64_t lo, uint64_t hi,
+      uint32_t) { for (uint64_t t = lo; t < hi; ++t) rootOf[t] = d.root((uint32_t)t); });
   mark("union-find");
   // hits per cluster: class counts are integers, so the (atomic, any-order) integer sum is the reference's sum exactly
   std::unique_ptr<std::atomic<uint64_t>[]> hitsI(new std::atomic<uint64_t>[M]);
   for (uint32_t t = 0; t < M; ++t) hitsI[t].store(0, std::memory_order_relaxed);
   sq_parallel_for(eq->num_classes, nthr, 8192, [&](uint64_t c_lo, uint64_t c_hi, uint32_t) {
-    for (uint64_t c = c_lo; c < c_hi; ++c) if (eq->off[c + 1] > eq->off[c]) hitsI[rootOf[eq->tid[eq->off[c]]]].fetch_add(eq->count[c], std::memory_order_relaxed);
+    for (uint64_t c = c_lo; c < c_hi; ++c) if (eq->off[c + 1] > eq->off[c]) hitsI[rootOf[eq->tid[eq->off[c]]]].fetch_add(eq->count[c],
+        std::memory_order_relaxed);
   });
   std::vector<double> hits(M); for (uint32_t t = 0; t < M; ++t) hits[t] = (double)hitsI[t].load(std::memory_order_relaxed);
   // bucket members by root (counting sort keeps ascending tid inside each cluster)
@@ -123,11 +131,16 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
 }
 
 // quant.sf: Name Length EffectiveLength TPM NumReads (GZipWriter.cpp:698-736)
-extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags) {
+extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads,
+    double num_mapped_frags) {
   if (!path || !idx || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf: bad arguments"); return SQ_ERR_ARG; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
   const uint32_t M = (uint32_t)idx->names.size();
-  if (!(num_mapped_frags > 0)) { num_mapped_frags = 0; for (uint32_t i = 0; i < M; ++i) num_mapped_frags += num_reads[i]; }   // explicitSum (:704-708)
+  // explicitSum (:704-708)
+  if (!(num_mapped_frags > 0)) {
+    num_mapped_frags = 0;
+    for (uint32_t i = 0; i < M; ++i) num_mapped_frags += num_reads[i];
+  }
   double denom = 0.0;
   for (uint32_t i = 0; i < M; ++i) denom += (num_reads[i] / num_mapped_frags) / eff_len[i];                                       // :718-722
   fprintf(f, "Name\tLength\tEffectiveLength\tTPM\tNumReads\n");
@@ -157,7 +170,10 @@ extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const 
     }
   } else {
     std::map<std::vector<uint32_t>, uint64_t> col;
-    for (uint64_t c = 0; c < eq->num_classes; ++c) { std::vector<uint32_t> k(eq->tid + eq->off[c], eq->tid + eq->off[c + 1]); col[k] += eq->count[c]; }
+    for (uint64_t c = 0; c < eq->num_classes; ++c) {
+      std::vector<uint32_t> k(eq->tid + eq->off[c], eq->tid + eq->off[c + 1]);
+      col[k] += eq->count[c];
+    }
     gzprintf(g, "%u\n%zu\n", M, col.size());
     for (auto& n : idx->names) gzprintf(g, "%s\n", n.c_str());
     for (auto& kv : col) {
@@ -173,7 +189,8 @@ extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const 
 // ---- `salmon quant -e` input: aux_info/eq_classes.txt[.gz] written with --dumpEqWeights -------------
 // salmon::utils::readEquivCounts (reference src/util/SalmonUtils.cpp:1026-1122): M, E, M names, E rows
 // "n  tid*n  weight*n  count", then optional "name effLen" pairs; missing effective lengths are 100.
-struct sq_eq_file { std::vector<std::string> names; std::vector<double> eff; std::vector<uint64_t> off, count; std::vector<uint32_t> tid; std::vector<double> w; };
+struct sq_eq_file { std::vector<std::string> names; std::vector<double> eff; std::vector<uint64_t> off,
+    count; std::vector<uint32_t> tid; std::vector<double> w; };
 extern "C" int sq_eq_file_read(const char* path, sq_eq_file** out) {
   if (!path || !out) { sq_set_error("sq_eq_file_read: bad arguments"); return SQ_ERR_ARG; }
   gzFile g = gzopen(path, "rb"); if (!g) { sq_set_error("cannot read '%s'", path); return SQ_ERR_IO; }   // gzopen reads plain text too
@@ -242,7 +259,9 @@ extern "C" int sq_eq_file_read(const char* path, sq_eq_file** out) {
 }
 extern "C" void sq_eq_file_free(sq_eq_file* f) { delete f; }
 extern "C" uint32_t sq_eq_file_num_txp(const sq_eq_file* f) { return f ? (uint32_t)f->names.size() : 0; }
-extern "C" const char* sq_eq_file_name(const sq_eq_file* f, uint32_t i) { return (f && i < f->names.size()) ? f->names[i].c_str() : nullptr; }
+extern "C" const char* sq_eq_file_name(const sq_eq_file* f, uint32_t i) {
+  return (f && i < f->names.size()) ? f->names[i].c_str() : nullptr;
+}
 extern "C" const double* sq_eq_file_eff_lens(const sq_eq_file* f) { return f ? f->eff.data() : nullptr; }
 extern "C" int sq_eq_file_table(const sq_eq_file* f, sq_eq_table* t) {
   if (!f || !t) return SQ_ERR_ARG;
@@ -255,7 +274,8 @@ extern "C" int sq_eq_file_table(const sq_eq_file* f, sq_eq_table* t) {
 }
 
 // quant.sf from plain name / length arrays (the -e mode has no index)
-extern "C" int sq_write_quant_sf_names(const char* path, uint32_t M, const char* const* names, const uint32_t* lens, const double* eff_len, const double* num_reads,
+extern "C" int sq_write_quant_sf_names(const char* path, uint32_t M, const char* const* names, const uint32_t* lens, const double* eff_len,
+    const double* num_reads,
     double num_mapped_frags) {
   if (!path || !names || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf_names: bad arguments"); return SQ_ERR_ARG; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
@@ -278,26 +298,46 @@ extern "C" int sq_boot_writer_open(const char* aux_dir, uint32_t M, const char* 
   if (!aux_dir || !names || !out || M == 0) { sq_set_error("sq_boot_writer_open: bad arguments"); return SQ_ERR_ARG; }
   const std::string d = std::string(aux_dir) + "/bootstrap";
   mkdir(aux_dir, 0755); mkdir(d.c_str(), 0755);
-  gzFile n = gzopen((d + "/names.tsv.gz").c_str(), "wb6"); if (!n) { sq_set_error("cannot write '%s/names.tsv.gz'", d.c_str()); return SQ_ERR_IO; }
+  gzFile n = gzopen((d + "/names.tsv.gz").c_str(), "wb6");
+  if (!n) {
+    sq_set_error("cannot write '%s/names.tsv.gz'", d.c_str());
+    return SQ_ERR_IO;
+  }
   for (uint32_t i = 0; i < M; ++i) { gzputs(n, names[i]); if (i + 1 < M) gzputc(n, '\t'); }
   gzputc(n, '\n'); gzclose(n);
   std::unique_ptr<sq_boot_writer> W(new sq_boot_writer()); W->M = M;
-  W->g = gzopen((d + "/bootstraps.gz").c_str(), "wb6"); if (!W->g) { sq_set_error("cannot write '%s/bootstraps.gz'", d.c_str()); return SQ_ERR_IO; }
+  W->g = gzopen((d + "/bootstraps.gz").c_str(), "wb6");
+  if (!W->g) {
+    sq_set_error("cannot write '%s/bootstraps.gz'", d.c_str());
+    return SQ_ERR_IO;
+  }
   *out = W.release();
   return SQ_OK;
 }
 extern "C" int sq_boot_writer_append(sq_boot_writer* w, const double* alphas, uint32_t M) {
   if (!w || !w->g || !alphas || M != w->M) { sq_set_error("sq_boot_writer_append: bad arguments"); return SQ_ERR_ARG; }
-  if (gzwrite(w->g, alphas, (unsigned)((size_t)M * 8)) != (int)((size_t)M * 8)) { sq_set_error("short write to bootstraps.gz"); return SQ_ERR_IO; }
+  if (gzwrite(w->g, alphas, (unsigned)((size_t)M * 8)) != (int)((size_t)M * 8)) {
+    sq_set_error("short write to bootstraps.gz");
+    return SQ_ERR_IO;
+  }
   w->written++;
   return SQ_OK;
 }
-extern "C" uint64_t sq_boot_writer_close(sq_boot_writer* w) { if (!w) return 0; uint64_t n = w->written; if (w->g) gzclose(w->g); delete w; return n; }
+extern "C" uint64_t sq_boot_writer_close(sq_boot_writer* w) {
+  if (!w) return 0;
+  uint64_t n = w->written;
+  if (w->g) gzclose(w->g);
+  delete w;
+  return n;
+}
 
 // aux_info/ambig_info.tsv (GZipWriter.cpp:601-638): per transcript, fragments in single-transcript classes and the
 // count mass of the multi-transcript classes it belongs to (uint32 accumulators, as in the reference)
 extern "C" int sq_write_ambig_info(const char* path, uint32_t M, const sq_eq_table* eq) {
-  if (!path || !eq || (eq->num_classes && (!eq->off || !eq->tid || !eq->count))) { sq_set_error("sq_write_ambig_info: bad arguments"); return SQ_ERR_ARG; }
+  if (!path || !eq || (eq->num_classes && (!eq->off || !eq->tid || !eq->count))) {
+    sq_set_error("sq_write_ambig_info: bad arguments");
+    return SQ_ERR_ARG;
+  }
   std::vector<uint32_t> uniq(M, 0), amb(M, 0);
   for (uint64_t c = 0; c < eq->num_classes; ++c) {
     const uint64_t a = eq->off[c], b = eq->off[c + 1];
@@ -326,16 +366,21 @@ static std::string lib_format_name(uint32_t id) {   // the salmon library-type s
     if (strand == 4) return std::string(o) + "U";
     return "";
   }
-  if (strand == 0) return std::string(o) + "SF"; if (strand == 1) return std::string(o) + "SR"; if (strand == 4) return std::string(o) + "U";
+  if (strand == 0) return std::string(o) + "SF";
+  if (strand == 1) return std::string(o) + "SR";
+  if (strand == 4) return std::string(o) + "U";
   return "";
 }
-extern "C" int sq_write_lib_format_counts(const char* path, const char* read_files, uint8_t lib_type, uint8_t lib_orientation, uint8_t lib_strand,
+extern "C" int sq_write_lib_format_counts(const char* path, const char* read_files, uint8_t lib_type, uint8_t lib_orientation,
+    uint8_t lib_strand,
                                           const uint64_t* counts, uint64_t num_assigned, uint64_t num_compatible) {
   if (!path || !counts) { sq_set_error("sq_write_lib_format_counts: bad arguments"); return SQ_ERR_ARG; }
   const uint32_t fid = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | ((uint32_t)lib_strand << 3);
   // the two stranded variants of the expected orientation (:247-262)
-  const uint32_t s1 = (lib_orientation == 0 || lib_orientation == 3) ? 2u : 0u, s2 = (lib_orientation == 0 || lib_orientation == 3) ? 3u : 1u;
-  const uint32_t f1 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s1 << 3), f2 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s2 << 3);
+  const uint32_t s1 = (lib_orientation == 0 || lib_orientation == 3) ? 2u : 0u, s2 = (lib_orientation == 0 ||
+      lib_orientation == 3) ? 3u : 1u;
+  const uint32_t f1 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s1 << 3),
+      f2 = (uint32_t)lib_type | ((uint32_t)lib_orientation << 1) | (s2 << 3);
   uint64_t nAgree = 0, nDisStranded = 0, nF1 = 0, nF2 = 0, nDisUnstranded = 0;
   for (uint32_t i = 0; i < 64; ++i) {
     if (i == fid) nAgree = counts[i]; else nDisStranded += counts[i];
@@ -349,7 +394,8 @@ extern "C" int sq_write_lib_format_counts(const char* path, const char* read_fil
       "{\n    \"read_files\": \"%s\",\n    \"expected_format\": \"%s\",\n    \"compatible_fragment_ratio\": %.17g,\n    \"num_compatible_fragments\": %llu,\n    \"num_assigned_fragments\": %llu,\n"
              "    \"num_frags_with_concordant_consistent_mappings\": %llu,\n    \"num_frags_with_inconsistent_or_orphan_mappings\": %llu,\n    \"strand_mapping_bias\": %.17g",
           read_files ? read_files : "", lib_format_name(fid).c_str(), num_assigned ? (double)num_compatible / (double)num_assigned : 0.0,
-          (unsigned long long)num_compatible, (unsigned long long)num_assigned, (unsigned long long)nAgree, (unsigned long long)nDisagree, ratio);
+          (unsigned long long)num_compatible, (unsigned long long)num_assigned, (unsigned long long)nAgree, (unsigned long long)nDisagree,
+              ratio);
   for (uint32_t i = 0; i < 64; ++i) {
     const std::string d = lib_format_name(i);
     if (!d.empty()) fprintf(f, ",\n    \"%s\": %llu", d.c_str(), (unsigned long long)counts[i]);

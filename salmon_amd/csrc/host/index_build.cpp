@@ -93,7 +93,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   const uint32_t nrefs = (uint32_t)names.size();
   idx->names = names; idx->first_decoy = first_decoy;
   idx->ref_len.resize(nrefs); idx->ref_clen = clen; idx->ref_accum.assign(nrefs + 1, 0);
-  for (uint32_t r = 0; r < nrefs; ++r) { idx->ref_len[r] = (uint32_t)seqs[r].size(); idx->ref_accum[r + 1] = idx->ref_accum[r] + seqs[r].size(); }
+  for (uint32_t r = 0; r < nrefs; ++r) {
+    idx->ref_len[r] = (uint32_t)seqs[r].size();
+    idx->ref_accum[r + 1] = idx->ref_accum[r] + seqs[r].size();
+  }
   const uint64_t total_nt = idx->ref_accum[nrefs];
   // ---- pack references (non-ACGT -> deterministic pseudo-random base; pufferfish fixFasta does
   // the same with an RNG) ----
@@ -175,7 +178,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   std::vector<uint64_t> seg_off(nrefs + 1, 0);
   for (uint32_t r = 0; r < nrefs; ++r) seg_off[r + 1] = seg_off[r] + rsegs[r].size();
   const uint64_t S = seg_off[nrefs];
-  if (S >= 0xFFFFFFFFull) { sq_set_error("too many unitig occurrences (%llu) for this index format", (unsigned long long)S); return SQ_ERR_OVERFLOW; }
+  if (S >= 0xFFFFFFFFull) {
+    sq_set_error("too many unitig occurrences (%llu) for this index format", (unsigned long long)S);
+    return SQ_ERR_OVERFLOW;
+  }
   std::vector<Seg> segs(S);
   sq_parallel_for(nrefs, nthreads, 64, [&](uint64_t b, uint64_t e, uint32_t) {
     for (uint64_t r = b; r < e; ++r) {
@@ -206,7 +212,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     T.aux[kslot(s)] = (uint32_t)u;  // now: unitig id
   }
   const uint64_t pool_nt = idx->uoff[U];
-  if (pool_nt >= (1ULL << SQ_APOS_BITS)) { sq_set_error("unitig pool too large (%llu nt)", (unsigned long long)pool_nt); return SQ_ERR_OVERFLOW; }
+  if (pool_nt >= (1ULL << SQ_APOS_BITS)) {
+    sq_set_error("unitig pool too large (%llu nt)", (unsigned long long)pool_nt);
+    return SQ_ERR_OVERFLOW;
+  }
   idx->useq.assign((pool_nt + 31) / 32 + 2, 0);
   sq_parallel_for(U, nthreads, 4096, [&](uint64_t b, uint64_t e, uint32_t) {
     for (uint64_t u = b; u < e; ++u) {
@@ -243,7 +252,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   for (uint64_t u = 0; u < U; ++u) nk_total += idx->uoff[u + 1] - idx->uoff[u] - (k - 1);
   idx->num_kmers = nk_total;
   // free the table before the dictionary build
-  std::vector<Seg>().swap(segs); std::vector<uint64_t>().swap(T.keys); std::vector<uint32_t>().swap(T.info); std::vector<uint32_t>().swap(T.aux);
+  std::vector<Seg>().swap(segs);
+  std::vector<uint64_t>().swap(T.keys);
+  std::vector<uint32_t>().swap(T.info);
+  std::vector<uint32_t>().swap(T.aux);
 
   // ---- minimizers / super-k-mers ----
   const uint64_t* up = idx->useq.data();
@@ -264,7 +276,11 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       uint32_t prev = 0xFFFFFFFFu;
       for (uint32_t p = 0; p < nk; ++p) {
         uint32_t bj = p; uint64_t bh = hv[p];
-        for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh || (hv[j] == bh && cv[j] < cv[bj])) { bh = hv[j]; bj = j; }  // leftmost minimum of (sq_mhash, value)
+        // leftmost minimum of (sq_mhash, value)
+        for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh || (hv[j] == bh && cv[j] < cv[bj])) {
+          bh = hv[j];
+          bj = j;
+        }
         if (bj != prev) { out.push_back({cv[bj], (u << SQ_APOS_BITS) | (ub + bj), p, 1}); prev = bj; }
         else out.back().nk++;
       }
@@ -286,7 +302,8 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     uint64_t n = ents.size(); uint32_t P = nthreads; std::vector<uint64_t> cut(P + 1);
     for (uint32_t i = 0; i <= P; ++i) cut[i] = n * i / P;
     auto cmp = [](const MiniEnt& a, const MiniEnt& b) { return a.v < b.v || (a.v == b.v && a.e < b.e); };
-    sq_parallel_for(P, P, 1, [&](uint64_t b, uint64_t e, uint32_t) { for (uint64_t i = b; i < e; ++i) std::sort(ents.begin() + cut[i], ents.begin() + cut[i + 1],
+    sq_parallel_for(P, P, 1, [&](uint64_t b, uint64_t e, uint32_t) { for (uint64_t i = b; i < e; ++i) std::sort(ents.begin() + cut[i],
+        ents.begin() + cut[i + 1],
         cmp); });
     for (uint32_t step = 1; step < P; step <<= 1) {
       std::vector<std::thread> th;
@@ -333,7 +350,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     for (uint64_t p = pb; p < pe; ++p) {
       uint32_t ns = pns[p], nb = pnb[p]; uint64_t s0 = idx->part_slot_off[p]; uint32_t b0 = idx->part_bkt_off[p];
       bk.assign(nb, {}); taken.assign(ns, 0);
-      for (uint64_t q = pcount[p]; q < pcount[p + 1]; ++q) { uint64_t ki = pkeys[q]; bk[sq_fastrange32((uint32_t)kh[ki], nb)].push_back(ki); }
+      for (uint64_t q = pcount[p]; q < pcount[p + 1]; ++q) {
+        uint64_t ki = pkeys[q];
+        bk[sq_fastrange32((uint32_t)kh[ki], nb)].push_back(ki);
+      }
       bord.resize(nb); for (uint32_t i = 0; i < nb; ++i) bord[i] = i;
       std::stable_sort(bord.begin(), bord.end(), [&](uint32_t a, uint32_t b) { return bk[a].size() > bk[b].size(); });
       for (uint32_t bi : bord) {
@@ -349,7 +369,14 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
             if (!good) break;
             pos.push_back(s);
           }
-          if (good) { for (size_t i = 0; i < B.size(); ++i) { taken[pos[i]] = 1; slot_key[s0 + pos[i]] = B[i]; } idx->pilots[b0 + bi] = (uint16_t)pilot; ok = true; }
+          if (good) {
+            for (size_t i = 0; i < B.size(); ++i) {
+              taken[pos[i]] = 1;
+              slot_key[s0 + pos[i]] = B[i];
+            }
+            idx->pilots[b0 + bi] = (uint16_t)pilot;
+            ok = true;
+          }
         }
         if (!ok) { mphf_fail.store(1); return; }
       }
@@ -504,7 +531,11 @@ extern "C" int sq_index_build(const sq_index_opts* opts, const char* fasta_path,
   if (decoys_path && decoys_path[0]) {
     FILE* f = fopen(decoys_path, "r"); if (!f) { sq_set_error("cannot open decoy list '%s'", decoys_path); delete idx; return SQ_ERR_IO; }
     std::unordered_set<std::string> ds; char line[4096];
-    while (fgets(line, sizeof(line), f)) { std::string l(line); while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back(); if (!l.empty()) ds.insert(l); }
+    while (fgets(line, sizeof(line), f)) {
+      std::string l(line);
+      while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();
+      if (!l.empty()) ds.insert(l);
+    }
     fclose(f);
     for (size_t i = 0; i < n.size(); ++i) if (ds.count(n[i])) dec[i] = 1;
   }
@@ -542,7 +573,8 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
   std::vector<char> nm; for (auto& s : idx.names) { nm.insert(nm.end(), s.begin(), s.end()); nm.push_back('\0'); }
   ok = ok && wvec(f, nm) && wvec(f, idx.ref_len) && wvec(f, idx.ref_clen) && wvec(f, idx.ref_accum) && wvec(f, idx.refseq) &&
        wvec(f, idx.useq) && wvec(f, idx.uoff) && wvec(f, idx.ctab_off) && wvec(f, idx.ctab) && wvec(f, idx.part_slot_off) &&
-       wvec(f, idx.part_bkt_off) && wvec(f, idx.pilots) && wvec(f, idx.slots) && wvec(f, idx.entries) && wvec(f, idx.skew_keys) && wvec(f, idx.skew_vals);
+       wvec(f, idx.part_bkt_off) && wvec(f, idx.pilots) && wvec(f, idx.slots) && wvec(f, idx.entries) && wvec(f, idx.skew_keys) && wvec(f,
+           idx.skew_vals);
   fclose(f);
   if (!ok) { sq_set_error("short write on '%s'", p.c_str()); return SQ_ERR_IO; }
   uint64_t sh = 0, nh = 0;
@@ -553,19 +585,27 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
         "{\n  \"index_version\": %u,\n  \"sampling_type\": \"sshash-hip\",\n  \"k\": %u,\n  \"m\": %u,\n  \"num_kmers\": %llu,\n  \"num_contigs\": %llu,\n  \"seq_len\": %llu,\n"
                "  \"num_refs\": %zu,\n  \"first_decoy_index\": %u,\n  \"num_minimizers\": %llu,\n  \"num_super_kmers\": %llu,\n  \"num_skew_kmers\": %llu,\n  \"max_bucket\": %llu,\n"
                "  \"keep_duplicates\": false,\n  \"SeqHash\": \"%016llx\",\n  \"NameHash\": \"%016llx\",\n  \"SeqHash512\": \"\",\n  \"NameHash512\": \"\",\n  \"DecoySeqHash\": \"\",\n  \"DecoyNameHash\": \"\"\n}\n",
-            SQ_INDEX_VERSION, idx.k, idx.m, (unsigned long long)idx.num_kmers, (unsigned long long)(idx.uoff.size() - 1), (unsigned long long)idx.uoff.back(),
+            SQ_INDEX_VERSION, idx.k, idx.m, (unsigned long long)idx.num_kmers, (unsigned long long)(idx.uoff.size() - 1),
+                (unsigned long long)idx.uoff.back(),
                 idx.names.size(), idx.first_decoy,
-            (unsigned long long)idx.num_minimizers, (unsigned long long)idx.num_superkmers, (unsigned long long)idx.num_skew_kmers, (unsigned long long)idx.max_bucket,
+            (unsigned long long)idx.num_minimizers, (unsigned long long)idx.num_superkmers, (unsigned long long)idx.num_skew_kmers,
+                (unsigned long long)idx.max_bucket,
                 (unsigned long long)sh, (unsigned long long)nh);
     fclose(f);
   }
   f = fopen((dir + "/versionInfo.json").c_str(), "w");
   if (f) {
-    fprintf(f, "{\n  \"indexVersion\": 6,\n  \"hasAuxIndex\": false,\n  \"auxKmerLength\": %u,\n  \"indexType\": 2,\n  \"salmonVersion\": \"1.11.4\"\n}\n", idx.k);
+    fprintf(f,
+        "{\n  \"indexVersion\": 6,\n  \"hasAuxIndex\": false,\n  \"auxKmerLength\": %u,\n  \"indexType\": 2,\n  \"salmonVersion\": \"1.11.4\"\n}\n",
+        idx.k);
     fclose(f);
   }
   f = fopen((dir + "/duplicate_clusters.tsv").c_str(), "w");
-  if (f) { fprintf(f, "RetainedRef\tDuplicateRef\n"); for (auto& d : idx.duplicates) fprintf(f, "%s\t%s\n", d.first.c_str(), d.second.c_str()); fclose(f); }
+  if (f) {
+    fprintf(f, "RetainedRef\tDuplicateRef\n");
+    for (auto& d : idx.duplicates) fprintf(f, "%s\t%s\n", d.first.c_str(), d.second.c_str());
+    fclose(f);
+  }
   return SQ_OK;
 }
 
@@ -584,11 +624,18 @@ int sq_index_load_host(const std::string& dir, sq_index** out) {
     sq_set_error("'%s' is not a salmon-hip index of version %u", p.c_str(), SQ_INDEX_VERSION);
     return SQ_ERR_IO;
   }
-  sq_index* idx = new sq_index(); idx->k = h.k; idx->m = h.m; idx->first_decoy = h.first_decoy; idx->n_parts = h.n_parts; idx->num_kmers = h.num_kmers;
+  sq_index* idx = new sq_index();
+  idx->k = h.k;
+  idx->m = h.m;
+  idx->first_decoy = h.first_decoy;
+  idx->n_parts = h.n_parts;
+  idx->num_kmers = h.num_kmers;
   std::vector<char> nm;
-  bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f, idx->useq) && rvec(f,
+  bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f,
+      idx->useq) && rvec(f,
       idx->uoff) &&
-            rvec(f, idx->ctab_off) && rvec(f, idx->ctab) && rvec(f, idx->part_slot_off) && rvec(f, idx->part_bkt_off) && rvec(f, idx->pilots) && rvec(f, idx->slots) &&
+            rvec(f, idx->ctab_off) && rvec(f, idx->ctab) && rvec(f, idx->part_slot_off) && rvec(f, idx->part_bkt_off) && rvec(f,
+                idx->pilots) && rvec(f, idx->slots) &&
             rvec(f, idx->entries) && rvec(f, idx->skew_keys) && rvec(f, idx->skew_vals);
   fclose(f);
   if (!ok) { delete idx; sq_set_error("truncated index '%s'", p.c_str()); return SQ_ERR_IO; }

@@ -19,6 +19,10 @@ extern "C" void sq_quant_opts_default(sq_quant_opts* o) {
 extern "C" void sq_em_opts_default(sq_em_opts* o) {
   memset(o, 0, sizeof(*o));
   o->use_vbem = 1; o->per_transcript_prior = 1; o->init_uniform = 0; o->eq_class_mode = 0; o->no_rich_eq_classes = 0;  // :76,87,63
-  o->vb_prior = 1e-2; o->rel_diff_tolerance = 0.01; o->max_iter = 10000; o->min_iter = 100;                             // :85; MappingPipelineStages.cpp:46-49
+  // :85; MappingPipelineStages.cpp:46-49
+  o->vb_prior = 1e-2;
+  o->rel_diff_tolerance = 0.01;
+  o->max_iter = 10000;
+  o->min_iter = 100;
   o->num_required_fragments = 50000000.0;                                                                               // :110
 }

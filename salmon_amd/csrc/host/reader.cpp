@@ -27,7 +27,12 @@ struct RecBlock { std::vector<char> seq; std::vector<uint32_t> len; };   // sequ
 
 // bounded single-producer / single-consumer queue of record blocks
 struct BlockQueue {
-  std::mutex mu; std::condition_variable cv_put, cv_get; std::deque<std::unique_ptr<RecBlock>> q; bool done = false; std::string err; size_t cap = 8;
+  std::mutex mu;
+  std::condition_variable cv_put, cv_get;
+  std::deque<std::unique_ptr<RecBlock>> q;
+  bool done = false;
+  std::string err;
+  size_t cap = 8;
   void put(std::unique_ptr<RecBlock> b) {
     std::unique_lock<std::mutex> lk(mu);
     cv_put.wait(lk, [&] { return q.size() < cap || done; });
@@ -86,7 +91,10 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
         blk->seq.insert(blk->seq.end(), ls, ls + ll); cur_len += (uint32_t)ll;
       } else {                                             // quality
         qual_len += ll;
-        if (qual_len > cur_len) { bad = "'" + path + "': record " + std::to_string(have + 1) + " has a quality string longer than its sequence"; return; }
+        if (qual_len > cur_len) {
+          bad = "'" + path + "': record " + std::to_string(have + 1) + " has a quality string longer than its sequence";
+          return;
+        }
         if (qual_len == cur_len) close_record();
       }
     };
@@ -105,7 +113,14 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
           if (!bad.empty()) { gzclose(f); out->finish(bad); return; }
         }
       } else {
-        if (start < pend.size()) { line(pend.data() + start, pend.size() - start); if (!bad.empty()) { gzclose(f); out->finish(bad); return; } }
+        if (start < pend.size()) {
+          line(pend.data() + start, pend.size() - start);
+          if (!bad.empty()) {
+            gzclose(f);
+            out->finish(bad);
+            return;
+          }
+        }
         break;
       }
     }
@@ -117,12 +132,16 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
   out->finish();
 }
 
-struct Slot { uint8_t* seq = nullptr; size_t seq_cap = 0; uint64_t* off = nullptr; size_t off_cap = 0; bool pinned = false, off_pinned = false; bool busy = false; };
+struct Slot { uint8_t* seq = nullptr; size_t seq_cap = 0; uint64_t* off = nullptr; size_t off_cap = 0; bool pinned = false,
+    off_pinned = false; bool busy = false; };
 
 void* host_alloc(size_t bytes, bool* pinned) {
   void* p = nullptr;
   if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) { *pinned = true; return p; }
-  (void)hipGetLastError(); *pinned = false; return malloc(bytes);    // no device (CPU-side tests): pageable memory works the same, only slower to upload
+  // no device (CPU-side tests): pageable memory works the same, only slower to upload
+  (void)hipGetLastError();
+  *pinned = false;
+  return malloc(bytes);
 }
 void host_free(void* p, bool pinned) { if (!p) return; if (pinned) (void)hipHostFree(p); else free(p); }
 
@@ -152,8 +171,12 @@ struct sq_reader {
   }
 };
 
-extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2, uint32_t batch_reads, uint32_t num_slots, sq_reader** out) {
-  if (!files1 || n1 == 0 || !out || batch_reads == 0 || (n2 && !files2)) { sq_set_error("sq_reader_open: bad arguments"); return SQ_ERR_ARG; }
+extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2, uint32_t batch_reads,
+    uint32_t num_slots, sq_reader** out) {
+  if (!files1 || n1 == 0 || !out || batch_reads == 0 || (n2 && !files2)) {
+    sq_set_error("sq_reader_open: bad arguments");
+    return SQ_ERR_ARG;
+  }
   if (n2 && n2 != n1) { sq_set_error("sq_reader_open: %u mate-1 files but %u mate-2 files", n1, n2); return SQ_ERR_ARG; }
   std::unique_ptr<sq_reader> R(new sq_reader()); R->paired = n2 > 0; R->batch = batch_reads;
   R->slots.resize(num_slots < 2 ? 2 : (num_slots > 8 ? 8 : num_slots));
@@ -171,7 +194,10 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
   memset(b, 0, sizeof(*b)); *slot = -1; b->paired = R->paired ? 1 : 0;
   if (R->ended) return SQ_OK;
   int si = -1; for (size_t i = 0; i < R->slots.size(); ++i) if (!R->slots[i].busy) { si = (int)i; break; }
-  if (si < 0) { sq_set_error("sq_reader_next: all %zu batch buffers are in use (sq_reader_release one first)", R->slots.size()); return SQ_ERR_STATE; }
+  if (si < 0) {
+    sq_set_error("sq_reader_next: all %zu batch buffers are in use (sq_reader_release one first)", R->slots.size());
+    return SQ_ERR_STATE;
+  }
   Slot& S = R->slots[(size_t)si];
   const size_t nrec_max = (size_t)R->batch * (R->paired ? 2 : 1);
   if (S.off_cap < nrec_max + 1) {
@@ -222,6 +248,8 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
   b->n = n; b->seq = S.seq; b->seq_off = S.off; b->on_device = 0; *slot = si;
   return SQ_OK;
 }
-extern "C" void sq_reader_release(sq_reader* R, int slot) { if (R && slot >= 0 && (size_t)slot < R->slots.size()) R->slots[(size_t)slot].busy = false; }
+extern "C" void sq_reader_release(sq_reader* R, int slot) {
+  if (R && slot >= 0 && (size_t)slot < R->slots.size()) R->slots[(size_t)slot].busy = false;
+}
 extern "C" uint64_t sq_reader_total(const sq_reader* R) { return R ? R->total : 0; }
 extern "C" void sq_reader_close(sq_reader* R) { delete R; }

@@ -123,7 +123,10 @@ SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_
   if (sp < 0) return 0;
   const uint64_t s = sq_fetch_bases(d.useq, (uint64_t)sp, d.k);
   int f;
-  if (s == kmer) f = 1; else if (s == rc) f = 0; else return 0;   // most failed probes end here: the unitig bounds are only fetched for a string match
+  // most failed probes end here: the unitig bounds are only fetched for a string match
+  if (s == kmer) f = 1;
+  else if (s == rc) f = 0;
+  else return 0;
   const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
   if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
   *unitig = u; *off = (uint32_t)((uint64_t)sp - b); *fw = f;
@@ -189,4 +192,6 @@ SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* uniti
   (void)fwc;
   return 0;
 }
-SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) { return sq_dict_lookup_t<0, 0>(d, kmer, unitig, off, fw); }
+SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
+  return sq_dict_lookup_t<0, 0>(d, kmer, unitig, off, fw);
+}
