@@ -29,9 +29,12 @@ def parse():
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
-    ap.add_argument("--debug-one-device", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
-    ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
+    ap.add_argument("--force-dist", action="store_true",
+        help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
+    ap.add_argument("--debug-one-device", action="store_true",
+        help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
+    ap.add_argument("--lanes", type=int, default=1,
+        help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
     return ap.parse_args()
 
 
@@ -168,7 +171,9 @@ def main():
     t1 = time.perf_counter()
     dt = t1 - t0
     if dist:
-        tt_ = torch.tensor([dt], device=(torch.device("cpu") if a.debug_one_device else dev), dtype=torch.float64); dist.all_reduce(tt_, op=dist.ReduceOp.MAX); dt = float(tt_.item())
+        tt_ = torch.tensor([dt], device=(torch.device("cpu") if a.debug_one_device else dev), dtype=torch.float64)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        dt = float(tt_.item())
     stages = ctx.stage_times()
     # EM iteration rate from a fixed-count run on the final table (outside the timed region)
     _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)
@@ -180,10 +185,12 @@ def main():
     em_bytes = 36 * Lb + 16 * E + 64 * M
     em_gbs = em_bytes / (rep_it["ms_per_iter"] * 1e-3) / 1e9
     sb = stage_bytes(tot, K * B, RL)
-    stage_rows = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / max(1, v[1]), 4), "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
+    stage_rows = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / max(1, v[1]), 4),
+        "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
     # roofline: the dominant SINGLE kernel (stages that aggregate many launches — the library sort, the scans, the
     # eq stage's mini-batch chain that overlaps mapping on its own stream — are not kernels and are excluded)
-    single = {"k_pack": "k_pack", "k_seed": "k_seed", "k_project": "k_project", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp", "k_select": "k_select"}
+    single = {"k_pack": "k_pack", "k_seed": "k_seed", "k_project": "k_project", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
+        "k_select": "k_select"}
     cand = [k for k in stage_rows if k in single]
     dom = max(cand, key=lambda k: stage_rows[k]["ms_total"]) if cand else None
     roof = None
@@ -199,7 +206,8 @@ def main():
                 tnote = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload at --steps 2); PMC cannot be sampled inside the timed run"
         except Exception:
             pass
-        roof = {"kernel": single[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic,
+        roof = {"kernel": single[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
+            "traffic": traffic,
                 "avg_launch_ms": stage_rows[dom]["avg_ms"], "alg_bytes_per_launch": int(per_launch), "traffic_note": tnote,
                 "alg_bytes_note": "k_seed: 4 dependent 64 B lines per dictionary probe (pilot, slot record, string-pool word, unitig bounds) + per uni-MEM 64 B (extension words, contig-table bounds, record) + the packed read; DESIGN.md section 6"}
     cpu = None
@@ -228,19 +236,26 @@ def main():
         em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
         t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
         cpu = {"value": round(S / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S, B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
+               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S,
+                   B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
                "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2)}
     out = {
         "metric": baseline_metric(), "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
-        "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K, B, K * B, RL),
+        "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K,
+            B, K * B, RL),
                    "transcripts": int(M), "txome_nt": int(tx.total_nt()), "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
                    "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly; EM replicated" % world},
-        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4), "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"], "em_device_ms": round(rep["device_ms"], 2),
-                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4), "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
+        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
+            "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
+            "em_device_ms": round(rep["device_ms"], 2),
+                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"],
+                          4), "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
-        "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes, "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
+        "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes,
+            "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
         "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

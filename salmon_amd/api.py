@@ -16,7 +16,8 @@ ALN_DTYPE = np.dtype([("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("sco
                       ("mate_status", "u1"), ("format_id", "u1"), ("est_aln_prob", "<f8")], align=True)
 UNIMEM_DTYPE = np.dtype([("end", "<u4"), ("qpos", "<u2"), ("len", "<u2"), ("unitig", "<u8"), ("uoff", "<u4"), ("fw", "u1")], align=True)
 MEM_DTYPE = np.dtype([("end", "<u4"), ("tid", "<u4"), ("rpos", "<i4"), ("qpos", "<u2"), ("len", "<u2"), ("fw", "u1")], align=True)
-CHAIN_DTYPE = np.dtype([("end", "<u4"), ("tid", "<u4"), ("pos", "<i4"), ("last_end", "<i4"), ("fw", "u1"), ("n_mems", "<u4"), ("score", "<f8")], align=True)
+CHAIN_DTYPE = np.dtype([("end", "<u4"), ("tid", "<u4"), ("pos", "<i4"), ("last_end", "<i4"), ("fw", "u1"), ("n_mems", "<u4"), ("score", "<f8")],
+    align=True)
 CAND_DTYPE = np.dtype([("frag", "<u4"), ("tid", "<u4"), ("lpos", "<i4"), ("rpos", "<i4"), ("lfw", "u1"), ("rfw", "u1"),
                        ("mate_status", "u1"), ("valid", "u1"), ("lscore", "<i4"), ("rscore", "<i4"), ("frag_len", "<u4")], align=True)
 assert ALN_DTYPE.itemsize == C.sizeof(capi.Aln)
@@ -221,7 +222,8 @@ class QuantContext:
         if fetch:
             n = rb.n; cap = aln_cap or max(1024, 16 * n)
             ent.update(read_off=np.zeros(n + 1, np.uint64), aln=np.zeros(cap, ALN_DTYPE), mt=np.zeros(n, np.uint8))
-            ent["ab"] = capi.AlnBatch(n, _ptr(ent["read_off"], C.c_uint64), ent["aln"].ctypes.data_as(C.POINTER(capi.Aln)), cap, _ptr(ent["mt"], C.c_uint8))
+            ent["ab"] = capi.AlnBatch(n, _ptr(ent["read_off"], C.c_uint64), ent["aln"].ctypes.data_as(C.POINTER(capi.Aln)), cap, _ptr(ent["mt"],
+                C.c_uint8))
         check(lib().sq_map_submit(self.h, C.byref(rb), C.byref(ent["ab"]) if ent["ab"] is not None else None), "sq_map_submit")
         self._inflight.append(ent)
 
@@ -286,14 +288,17 @@ class QuantContext:
         check(lib().sq_eq_export_device(self.h, C.byref(t)), "sq_eq_export_device")
         E, L = int(t.num_classes), int(t.num_labels)
         def addr(p): return C.cast(p, C.c_void_p).value or 0
-        return dict(E=E, L=L, off=(addr(t.off), E + 1 if E else 0, np.uint64), tid=(addr(t.tid), L, np.uint32), wq=(addr(t.wq), L, np.uint64), count=(addr(t.count), E, np.uint64),
+        return dict(E=E, L=L, off=(addr(t.off), E + 1 if E else 0, np.uint64), tid=(addr(t.tid), L, np.uint32), wq=(addr(t.wq), L, np.uint64),
+            count=(addr(t.count), E, np.uint64),
                     bins=(addr(t.bins), L, np.uint32), h1=(addr(t.h1), E, np.uint64), h2=(addr(t.h2), E, np.uint64))
 
     def eq_merge_device(self, E, L, ptrs):
         """sq_eq_merge_device: ptrs = dict field -> device address (off, tid, wq, count, bins, h1, h2) on this ctx's GPU."""
         t = capi.EqTable(); t.num_classes = E; t.num_labels = L
-        t.off = C.cast(ptrs["off"], C.POINTER(C.c_uint64)); t.tid = C.cast(ptrs["tid"], C.POINTER(C.c_uint32)); t.wq = C.cast(ptrs["wq"], C.POINTER(C.c_uint64))
-        t.count = C.cast(ptrs["count"], C.POINTER(C.c_uint64)); t.bins = C.cast(ptrs["bins"], C.POINTER(C.c_uint32)); t.h1 = C.cast(ptrs["h1"], C.POINTER(C.c_uint64)); t.h2 = C.cast(ptrs["h2"], C.POINTER(C.c_uint64))
+        t.off = C.cast(ptrs["off"], C.POINTER(C.c_uint64)); t.tid = C.cast(ptrs["tid"], C.POINTER(C.c_uint32)); t.wq = C.cast(ptrs["wq"],
+            C.POINTER(C.c_uint64))
+        t.count = C.cast(ptrs["count"], C.POINTER(C.c_uint64)); t.bins = C.cast(ptrs["bins"], C.POINTER(C.c_uint32)); t.h1 = C.cast(ptrs["h1"],
+            C.POINTER(C.c_uint64)); t.h2 = C.cast(ptrs["h2"], C.POINTER(C.c_uint64))
         check(lib().sq_eq_merge_device(self.h, C.byref(t)), "sq_eq_merge_device")
 
     def eq_merge(self, eq):
@@ -303,7 +308,8 @@ class QuantContext:
     def summary(self):
         s = capi.ModelSummary()
         check(lib().sq_model_summary_get(self.h, C.byref(s)), "sq_model_summary_get")
-        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub),
+            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
 
     def lib_counts(self):
         out = np.zeros(64, np.uint64)
@@ -355,7 +361,8 @@ def em_steps(eq, eff_len, alpha_in, iters, opts=None, device=0):
     a = np.ascontiguousarray(alpha_in, np.float64)
     out = np.zeros(txp.num_txp)
     rep = capi.EmReport()
-    check(lib().sq_em_steps_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(a, C.c_double), iters, _ptr(out, C.c_double), C.byref(rep)), "sq_em_steps_dev")
+    check(lib().sq_em_steps_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(a, C.c_double), iters, _ptr(out, C.c_double), C.byref(rep)),
+        "sq_em_steps_dev")
     return out, dict(iters=rep.iters, device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
 
 
@@ -365,7 +372,8 @@ def normalize_alphas(eq, log_mass, uniq, total):
     out = np.zeros(M)
     t = eq.table()
     lm = np.ascontiguousarray(log_mass, np.float64); uq = np.ascontiguousarray(uniq, np.uint64); tc = np.ascontiguousarray(total, np.uint64)
-    check(lib().sq_normalize_alphas(M, C.byref(t), _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(out, C.c_double)), "sq_normalize_alphas")
+    check(lib().sq_normalize_alphas(M, C.byref(t), _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(out, C.c_double)),
+        "sq_normalize_alphas")
     return out
 
 
@@ -439,7 +447,8 @@ def gibbs(eq, eff_len, alpha_init, num_samples, seed, num_mapped, gopts=None, de
     g = gopts or gibbs_opts(); t = eq.table(); txp = make_txp_in(eff_len)
     a = np.ascontiguousarray(alpha_init, np.float64)
     rows, cb = _collect(txp.num_txp)
-    check(lib().sq_gibbs_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, seed, num_mapped, cb, None), "sq_gibbs_dev")
+    check(lib().sq_gibbs_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, seed, num_mapped, cb, None),
+        "sq_gibbs_dev")
     return np.array(rows)
 
 
@@ -450,5 +459,6 @@ def debug_infix_align(queries, windows, ks, device=0):
     qo[1:] = np.cumsum([len(q) for q in queries]); wo[1:] = np.cumsum([len(w) for w in windows])
     qb = np.frombuffer(b"".join(queries) + b"\0", np.uint8); wb = np.frombuffer(b"".join(windows) + b"\0", np.uint8)
     k = np.ascontiguousarray(ks, np.int32); out = np.zeros((n, 4), np.int32)
-    check(lib().sq_debug_infix_align(device, n, qb.ctypes.data, qo.ctypes.data, wb.ctypes.data, wo.ctypes.data, k.ctypes.data, out.ctypes.data), "sq_debug_infix_align")
+    check(lib().sq_debug_infix_align(device, n, qb.ctypes.data, qo.ctypes.data, wb.ctypes.data, wo.ctypes.data, k.ctypes.data, out.ctypes.data),
+        "sq_debug_infix_align")
     return out

@@ -139,7 +139,8 @@ def lib():
         "sq_map_batch": (C.c_int, [vp, P(ReadBatch), P(AlnBatch), P(MapStats)]),
         "sq_eq_export_device": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge_device": (C.c_int, [vp, P(EqTable)]),
         "sq_map_submit": (C.c_int, [vp, P(ReadBatch), P(AlnBatch)]), "sq_ctx_set_lanes": (C.c_int, [vp, C.c_int]),
-        "sq_reader_open": (C.c_int, [P(C.c_char_p), u32, P(C.c_char_p), u32, u32, u32, P(vp)]), "sq_reader_next": (C.c_int, [vp, P(ReadBatch), P(C.c_int)]),
+        "sq_reader_open": (C.c_int, [P(C.c_char_p), u32, P(C.c_char_p), u32, u32, u32, P(vp)]), "sq_reader_next": (C.c_int, [vp, P(ReadBatch),
+            P(C.c_int)]),
         "sq_reader_release": (None, [vp, C.c_int]), "sq_reader_total": (u64, [vp]), "sq_reader_close": (None, [vp]),
         "sq_map_wait": (C.c_int, [vp, P(AlnBatch), P(MapStats)]),
         "sq_eq_accumulate": (C.c_int, [vp]), "sq_eq_finish": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge": (C.c_int, [vp, P(EqTable)]),
@@ -154,13 +155,17 @@ def lib():
         "sq_ctx_reserve": (C.c_int, [vp, u64, u64]),
         "sq_debug_infix_align": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, vp, vp]),
         "sq_normalize_alphas": (C.c_int, [u32, P(EqTable), P(f64), P(u64), P(u64), P(f64)]),
-        "sq_write_quant_sf": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64]), "sq_write_eq_classes": (C.c_int, [C.c_char_p, vp, P(EqTable), C.c_int]),
-        "sq_model_fetch_lib_counts": (C.c_int, [vp, P(u64)]), "sq_write_lib_format_counts": (C.c_int, [C.c_char_p, C.c_char_p, u8, u8, u8, P(u64), u64, u64]),
+        "sq_write_quant_sf": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64]), "sq_write_eq_classes": (C.c_int, [C.c_char_p, vp, P(EqTable),
+            C.c_int]),
+        "sq_model_fetch_lib_counts": (C.c_int, [vp, P(u64)]), "sq_write_lib_format_counts": (C.c_int, [C.c_char_p, C.c_char_p, u8, u8, u8, P(u64),
+            u64, u64]),
         "sq_write_ambig_info": (C.c_int, [C.c_char_p, u32, P(EqTable)]),
         "sq_write_quant_sf_names": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(u32), P(f64), P(f64), f64]),
-        "sq_eq_file_read": (C.c_int, [C.c_char_p, P(vp)]), "sq_eq_file_free": (None, [vp]), "sq_eq_file_num_txp": (u32, [vp]), "sq_eq_file_name": (C.c_char_p, [vp, u32]),
+        "sq_eq_file_read": (C.c_int, [C.c_char_p, P(vp)]), "sq_eq_file_free": (None, [vp]), "sq_eq_file_num_txp": (u32,
+            [vp]), "sq_eq_file_name": (C.c_char_p, [vp, u32]),
         "sq_eq_file_eff_lens": (P(f64), [vp]), "sq_eq_file_table": (C.c_int, [vp, P(EqTable)]),
-        "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64), u32]), "sq_boot_writer_close": (u64, [vp]),
+        "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64),
+            u32]), "sq_boot_writer_close": (u64, [vp]),
         "sq_ctx_set_profiling": (C.c_int, [vp, C.c_int]), "sq_ctx_num_stages": (C.c_int, []), "sq_ctx_stage_name": (C.c_char_p, [C.c_int]),
         "sq_ctx_stage_times": (C.c_int, [vp, P(f64), P(u64), C.c_int]),
     }

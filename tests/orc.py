@@ -28,7 +28,8 @@ def lib():
         L.orc_index_lookup.restype = C.c_int; L.orc_index_lookup.argtypes = [vp, C.c_uint64, P(C.c_uint64), P(C.c_uint32), P(C.c_int)]
         L.orc_check_cdbg.restype = C.c_int; L.orc_check_cdbg.argtypes = [P(capi.IndexView)]
         L.orc_map_batch.argtypes = [vp, P(capi.QuantOpts), P(capi.ReadBatch), C.c_uint32, vp, vp, C.c_uint64, vp, P(capi.MapStats), P(C.c_uint64)]
-        L.orc_map_taps.argtypes = [vp, P(capi.QuantOpts), P(capi.ReadBatch), vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, P(C.c_uint64)]
+        L.orc_map_taps.argtypes = [vp, P(capi.QuantOpts), P(capi.ReadBatch), vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64,
+            P(C.c_uint64)]
         L.orc_state_create.restype = vp; L.orc_state_create.argtypes = [vp, P(capi.QuantOpts)]
         L.orc_state_free.argtypes = [vp]
         L.orc_eq_accumulate.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64]
@@ -40,9 +41,12 @@ def lib():
         L.orc_normalize_alphas.argtypes = [C.c_uint32, P(capi.EqTable), vp, vp, vp, vp]
         L.orc_em_optimize.restype = C.c_int; L.orc_em_optimize.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, P(capi.EmReport)]
         L.orc_em_steps.restype = C.c_int; L.orc_em_steps.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, C.c_uint32, vp]
-        L.orc_bootstrap.restype = C.c_int; L.orc_bootstrap.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32, C.c_uint64, C.c_uint64, vp]
-        L.orc_gibbs.restype = C.c_int; L.orc_gibbs.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.GibbsOpts), vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
-        L.orc_em_time_iters.restype = C.c_double; L.orc_em_time_iters.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32, C.c_uint32]
+        L.orc_bootstrap.restype = C.c_int; L.orc_bootstrap.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32, C.c_uint64,
+            C.c_uint64, vp]
+        L.orc_gibbs.restype = C.c_int; L.orc_gibbs.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.GibbsOpts), vp, C.c_uint32, C.c_uint64,
+            C.c_uint64, vp]
+        L.orc_em_time_iters.restype = C.c_double; L.orc_em_time_iters.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), C.c_uint32,
+            C.c_uint32]
         L.orc_canonical_sum.restype = C.c_double; L.orc_canonical_sum.argtypes = [vp, C.c_uint64]
         for f in ("orc_exp", "orc_log", "orc_digamma"):
             getattr(L, f).restype = C.c_double; getattr(L, f).argtypes = [C.c_double]
@@ -83,7 +87,8 @@ def map_batch(oidx, opts, rb, threads=1, aln_cap=None):
     cap = aln_cap or max(1024, 16 * n)
     read_off = np.zeros(n + 1, np.uint64); aln = np.zeros(cap, api.ALN_DTYPE); mt = np.zeros(n, np.uint8)
     st = capi.MapStats(); na = C.c_uint64()
-    lib().orc_map_batch(oidx.h, C.byref(opts), C.byref(rb), threads, read_off.ctypes.data, aln.ctypes.data, cap, mt.ctypes.data, C.byref(st), C.byref(na))
+    lib().orc_map_batch(oidx.h, C.byref(opts), C.byref(rb), threads, read_off.ctypes.data, aln.ctypes.data, cap, mt.ctypes.data, C.byref(st),
+        C.byref(na))
     assert na.value <= cap, "oracle alignment buffer too small"
     return read_off, aln[: na.value], mt, st.as_dict()
 
@@ -115,7 +120,8 @@ class OrcState:
 
     def summary(self):
         s = capi.ModelSummary(); lib().orc_state_summary(self.h, C.byref(s))
-        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub), burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+        return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub),
+            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
 
     def lib_counts(self):
         out = np.zeros(64, np.uint64); lib().orc_state_lib_counts(self.h, out.ctypes.data); return out

@@ -60,7 +60,8 @@ def _worker(rank, world, port, q):
         ok = fk == keys
         for c, row in enumerate(rows):
             a, b = int(full.off[c]), int(full.off[c + 1])
-            ok = ok and np.array_equal(full.tid[a:b], row[0]) and int(full.count[c]) == row[3] and [int(x) for x in full.wq[a:b]] == [int(x) for x in row[2]]
+            ok = ok and np.array_equal(full.tid[a:b],
+                row[0]) and int(full.count[c]) == row[3] and [int(x) for x in full.wq[a:b]] == [int(x) for x in row[2]]
         ok = ok and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf)
         msg = "classes=%d" % len(keys)
     # every rank must hold identical merged keys: compare a digest

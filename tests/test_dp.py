@@ -30,7 +30,8 @@ def checker(opts, q, t, mode):
     return orc.lib().orc_dp_align(C.byref(opts), qa.ctypes.data, len(qa), ta.ctypes.data, len(ta), mode)
 
 
-@pytest.mark.parametrize("scoring", [dict(), dict(match_score=1, mismatch_penalty=-3, gap_open=4, gap_extend=1), dict(match_score=3, mismatch_penalty=-2, gap_open=2, gap_extend=3)])
+@pytest.mark.parametrize("scoring", [dict(), dict(match_score=1, mismatch_penalty=-3, gap_open=4, gap_extend=1),
+    dict(match_score=3, mismatch_penalty=-2, gap_open=2, gap_extend=3)])
 def test_banded_dp_equals_unbanded_gotoh_when_the_band_covers_the_matrix(built, scoring):
     rng = np.random.default_rng(17)
     opts = api.quant_opts(bandwidth=64, **scoring)     # band >= every case below

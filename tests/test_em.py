@@ -145,7 +145,8 @@ def test_gpu_em_giant_class_and_hot_transcript(built, vb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw", [dict(no_rich_eq_classes=1), dict(per_transcript_prior=0, vb_prior=1e-5), dict(vb_prior=1.0), dict(use_vbem=0, no_rich_eq_classes=1),
+@pytest.mark.parametrize("kw", [dict(no_rich_eq_classes=1), dict(per_transcript_prior=0, vb_prior=1e-5), dict(vb_prior=1.0),
+    dict(use_vbem=0, no_rich_eq_classes=1),
                                 dict(rel_diff_tolerance=0.001, max_iter=300), dict(min_iter=10, max_iter=40), dict(num_required_fragments=1000.0)],
                          ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_gpu_em_option_variants_bit_exact(built, kw):

@@ -273,7 +273,8 @@ def test_decoy_aware_mapping_matches_checker(built):
     def mutate(s, rate): return "".join((rng.choice([c for c in "ACGT" if c != ch]) if rng.random() < rate else ch) for ch in s)
     decoys = [rnd(400) + mutate(seqs[j], 0.01) + rnd(400) for j in rng.choice(len(seqs), 12, replace=False)]
     first_decoy = len(seqs)
-    idx = api.SalmonIndex.build_mem(names + ["decoy%d" % i for i in range(len(decoys))], seqs + decoys, threads=2, first_decoy=first_decoy, keep_duplicates=True)
+    idx = api.SalmonIndex.build_mem(names + ["decoy%d" % i for i in range(len(decoys))], seqs + decoys, threads=2, first_decoy=first_decoy,
+        keep_duplicates=True)
     oidx = orc.OrcIndex(idx)
     recs = []
     def pair(s):
@@ -308,7 +309,8 @@ OPTION_VARIANTS = [
     dict(mismatch_seed_skip=5, max_occs_per_hit=20), dict(match_score=1, mismatch_penalty=-3, gap_open=4, gap_extend=1, bandwidth=8),
     dict(score_exp=2.0, min_aln_prob=1e-3, decoy_threshold=0.9), dict(no_length_correction=1), dict(no_eff_length_correction=1),
     dict(use_frag_len_dist=0), dict(model_single_frag_prob=0), dict(ignore_incompat=0, incompat_prior=-20.0, _lib="ISF"),
-    dict(pre_merge_chain_sub_thresh=0.9, post_merge_chain_sub_thresh=0.95, orphan_chain_sub_thresh=0.5), dict(frag_len_max=400, fld_mean=200.0, fld_sd=40.0),
+    dict(pre_merge_chain_sub_thresh=0.9, post_merge_chain_sub_thresh=0.95, orphan_chain_sub_thresh=0.5), dict(frag_len_max=400, fld_mean=200.0,
+        fld_sd=40.0),
     dict(forgetting_factor=0.8, seed=12345), dict(recover_orphans=1), dict(recover_orphans=1, max_read_occs=2, allow_dovetail=1),
 ]
 

@@ -46,7 +46,8 @@ def test_invariants_and_schedule_independence(big):
     # per-read alignment lists: ascending transcript id, probabilities in (0, 1], read counts add up
     for ro, aln, mt, st in a["outs"]:
         assert ro[0] == 0 and ro[-1] == len(aln) and np.all(np.diff(ro.astype(np.int64)) >= 0)
-        tid = aln["tid"].astype(np.int64); starts = ro[:-1].astype(np.int64); first = np.zeros(len(aln), bool); first[starts[starts < len(aln)]] = True
+        tid = aln["tid"].astype(np.int64); starts = ro[:-1].astype(np.int64); first = np.zeros(len(aln),
+            bool); first[starts[starts < len(aln)]] = True
         assert np.all((np.diff(tid) > 0) | first[1:])
         assert np.all(aln["est_aln_prob"] > 0) and np.all(aln["est_aln_prob"] <= 1.0)
     s = a["summ"]; eq = a["eq"]

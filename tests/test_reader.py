@@ -32,7 +32,8 @@ def _drain(h):
 
 def _fq(path, recs, gz=False, crlf=False, fasta=False, trailing_newline=True):
     nl = "\r\n" if crlf else "\n"
-    txt = "".join((">r%d%s%s%s" % (i, nl, s, nl)) if fasta else ("@r%d%s%s%s+%s%s%s" % (i, nl, s, nl, nl, "I" * len(s), nl)) for i, s in enumerate(recs))
+    txt = "".join((">r%d%s%s%s" % (i, nl, s, nl)) if fasta else ("@r%d%s%s%s+%s%s%s" % (i, nl, s, nl, nl, "I" * len(s), nl)) for i,
+        s in enumerate(recs))
     if not trailing_newline: txt = txt.rstrip("\r\n")
     (gzip.open(path, "wt", newline="") if gz else open(path, "w", newline="")).write(txt)
 
