@@ -87,11 +87,10 @@ struct sq_ctx {
   sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;
   sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
   // chains
-  sq_dbuf<sq_chain_dev> chains, chains_d; sq_dbuf<uint32_t> n_chains; sq_dbuf<uint64_t> chain_off; uint64_t last_total_chains = 0;
+  sq_dbuf<sq_chain_dev> chains; sq_dbuf<uint32_t> n_chains; uint64_t last_total_chains = 0;
   // candidates / alignments
   sq_dbuf<uint32_t> n_cand; sq_dbuf<uint64_t> cand_off; sq_dbuf<sq_cand_dev> cands; uint64_t cand_cap = 0;
   sq_dbuf<uint32_t> cand_frag, tid_arr; sq_dbuf<int32_t> hs_arr;
-  sq_dbuf<uint32_t> wkey, wkey2, wid, perm_ends, perm_frags;
   sq_dbuf<sq_dp_item> dpq; sq_dbuf<uint32_t> counters; sq_dbuf<uint8_t> frag_flags;
   sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;

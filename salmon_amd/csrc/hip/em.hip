@@ -759,10 +759,6 @@ __global__ void k_bs_sample(uint64_t total, uint32_t E, const uint64_t* __restri
 __global__ void k_u64_to_f64(uint32_t n, const unsigned long long* __restrict__ in, double* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = (double)in[i];
 }
-__global__ void k_truncate(uint32_t n, double* __restrict__ a) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && a[i] <= 1e-8) a[i] = 0.0;
-}
 
 // ---- a17 Gibbs (sampleRoundNonCollapsedMultithreaded_, CollapsedGibbsSampler.cpp:92-278) --------------
 struct GibbsDev { uint32_t M,

@@ -12,17 +12,6 @@ namespace {
 const int TB = 256;
 inline uint32_t nblk(uint64_t n) { return (uint32_t)((n + TB - 1) / TB); }
 
-// ids sorted by descending key (20 significant bits)
-int sort_desc(sq_ctx* c, uint32_t n, uint32_t* perm_out) {
-  size_t tmp = 0;
-  hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20, c->stream);
-  if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
-  tmp = c->sort_tmp.n;
-  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(c->sort_tmp.p, tmp, c->wkey.p, c->wkey2.p, c->wid.p, perm_out, (int)n, 0, 20,
-      c->stream));
-  return SQ_OK;
-}
-
 int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_plus_1) {
   size_t tmp = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n_plus_1, c->stream);
@@ -171,9 +160,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
       c->rlen.ensure(nends) ||
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
                  c->mem_off.ensure((size_t)nends + 2) ||
-             c->n_chains.ensure(nends + 1) || c->chain_off.ensure((size_t)nends + 2) || c->wkey.ensure(nends) || c->wkey2.ensure(nends) ||
-                 c->wid.ensure(nends) ||
-                 c->perm_ends.ensure(nends) || c->perm_frags.ensure(max_batch_reads) || c->n_cand.ensure(max_batch_reads + 1) ||
+             c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) ||
                  c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
              c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) ||
                  c->aln_off.ensure((size_t)max_batch_reads + 2) ||
@@ -235,14 +222,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->cp.free_();
   c->mnext.free_();
   c->mused.free_();
-  c->wkey.free_();
-  c->wkey2.free_();
-  c->wid.free_();
-  c->perm_ends.free_();
-  c->perm_frags.free_();
   c->chains.free_();
-  c->chains_d.free_();
-  c->chain_off.free_();
   c->n_chains.free_();
   c->n_cand.free_();
   c->cand_off.free_();

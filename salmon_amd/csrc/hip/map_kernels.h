@@ -388,30 +388,6 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
   wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept);
 }
 
-// work-balancing permutations: sort item ids by a cheap work estimate (descending) so a wave's 64 lanes
-// finish together; the heavy tail (repeat families) otherwise pins whole waves for ~1 ms
-__global__ void k_work_keys_ends(uint32_t nends, const uint64_t* __restrict__ mem_off, uint32_t* __restrict__ keys,
-    uint32_t* __restrict__ ids) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= nends) return;
-  uint64_t n = mem_off[e + 1] - mem_off[e]; keys[e] = (uint32_t)(n > 0xFFFFFu ? 0xFFFFFu : n); ids[e] = e;
-}
-__global__ void k_work_keys_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ keys,
-    uint32_t* __restrict__ ids) {
-  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; if (f >= nfrag) return;
-  uint32_t n = paired ? n_chains[2 * f] + n_chains[2 * f + 1] : n_chains[f]; keys[f] = n > 0xFFFFFu ? 0xFFFFFu : n; ids[f] = f;
-}
-
-// chains are produced into per-end slabs sized by the MEM count (sparse); pack them densely so that a
-// fragment's chains are one contiguous run (k_join streams them several times)
-__global__ void k_compact_chains(uint32_t nends, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ chain_off,
-    const uint32_t* __restrict__ n_chains,
-                                 const sq_chain_dev* __restrict__ sparse, sq_chain_dev* __restrict__ dense) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nends) return;
-  const sq_chain_dev* s = sparse + mem_off[e]; sq_chain_dev* d = dense + chain_off[e];
-  for (uint32_t i = 0; i < n_chains[e]; ++i) d[i] = s[i];
-}
-
 // a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.
 __device__ inline bool pair_ok(const sq_map_params& P, const sq_chain_dev& x, const sq_chain_dev& y, int32_t* fl, bool* dove) {
   if (x.fw == y.fw) return false;  // mpol.noDiscordant
