@@ -78,6 +78,37 @@ int main(int argc, char** argv) {
   sq_eq_file_free(ef);
   std::vector<const char*> nm; for (uint32_t t = 0; t < M; ++t) nm.push_back(sq_index_ref_name(idx, t));
   sq_boot_writer* bw = nullptr; CHECK(sq_boot_writer_open((dir + "/out/aux_info").c_str(), M, nm.data(), &bw) == SQ_OK); for (int r = 0; r < 5; ++r) CHECK(sq_boot_writer_append(bw, p1.data(), M) == SQ_OK); CHECK(sq_boot_writer_close(bw) == 5);
+  // ---- malformed input: mutated / truncated copies of a small eq-class file and of a small FASTQ must be rejected or read, never crash
+  { std::vector<uint64_t> o2(off.begin(), off.begin() + 101), c2(cnt.begin(), cnt.begin() + 100); sq_eq_table small = eq; small.num_classes = 100; small.num_labels = o2[100]; small.off = o2.data(); small.count = c2.data();
+    const std::string src = dir + "/small_eq.txt", mut = dir + "/mut_eq.txt";
+    CHECK(sq_write_eq_classes(src.c_str(), idx, &small, 1) == SQ_OK);
+    std::string bytes; { gzFile f = gzopen(src.c_str(), "rb"); char buf[4096]; int n; while ((n = gzread(f, buf, sizeof buf)) > 0) bytes.append(buf, (size_t)n); gzclose(f); }
+    int accepted = 0;
+    for (int it = 0; it < 300; ++it) { std::string b = bytes; const int nm = 1 + (int)(g() % 4);
+      for (int j = 0; j < nm; ++j) { const size_t p = g() % b.size(); const int op = (int)(g() % 4);
+        if (op == 0) b[p] = (char)(g() & 0xFF); else if (op == 1) b.resize(p); else if (op == 2) b.insert(p, std::to_string(g())); else b[p] = "0123456789 \n\t-e."[g() % 16];
+        if (b.empty()) b = "1"; }
+      FILE* f = fopen(mut.c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
+      sq_eq_file* e2 = nullptr; if (sq_eq_file_read(mut.c_str(), &e2) == SQ_OK) { sq_eq_table t2; memset(&t2, 0, sizeof(t2)); CHECK(sq_eq_file_table(e2, &t2) == SQ_OK); for (uint64_t i = 0; i < t2.num_labels; ++i) CHECK(t2.tid[i] < sq_eq_file_num_txp(e2)); sq_eq_file_free(e2); ++accepted; } }
+    std::string fq; for (int i = 0; i < 40; ++i) { std::string a = rnd_seq(g, 30 + g() % 60); fq += "@r" + std::to_string(i) + "\n" + a + "\n+\n" + std::string(a.size(), 'I') + "\n"; }
+    int ok_reads = 0;
+    for (int it = 0; it < 300; ++it) { std::string b = fq; const int nm = 1 + (int)(g() % 4);
+      for (int j = 0; j < nm; ++j) { const size_t p = g() % b.size(); const int op = (int)(g() % 4);
+        if (op == 0) b[p] = (char)(g() & 0xFF); else if (op == 1) b.resize(p); else if (op == 2) b.insert(p, "\n@x\n"); else b[p] = "@+>\n\rACGTN"[g() % 10];
+        if (b.empty()) b = "@"; }
+      const std::string mp = dir + "/mut.fq"; FILE* f = fopen(mp.c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
+      const char* q1[] = {mp.c_str()}; sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, nullptr, 0, 16, 2, &rd) == SQ_OK);
+      for (;;) { sq_read_batch rb; int slot; if (sq_reader_next(rd, &rb, &slot) != SQ_OK || rb.n == 0) break; CHECK(rb.seq_off[rb.n] < (1u << 20)); ok_reads += (int)rb.n; sq_reader_release(rd, slot); }
+      sq_reader_close(rd); }
+    // corrupt index files: truncated anywhere, or with bytes of the header / section tables overwritten
+    { std::string ib; { FILE* f = fopen((dir + "/idx/index.bin").c_str(), "rb"); CHECK(f != nullptr); char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) ib.append(buf, n); fclose(f); }
+      mkdir((dir + "/idx_mut").c_str(), 0755); int loaded = 0;
+      for (int it = 0; it < 200; ++it) { std::string b = ib;
+        if (it % 3 == 0) b.resize(g() % b.size()); else for (int j = 0; j < 1 + (int)(g() % 3); ++j) b[g() % std::min<size_t>(b.size(), it % 3 == 1 ? 512 : b.size())] = (char)(g() & 0xFF);
+        FILE* f = fopen((dir + "/idx_mut/index.bin").c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
+        sq_index* bad = nullptr; if (sq_index_load((dir + "/idx_mut").c_str(), -1, &bad) == SQ_OK) { ++loaded; sq_index_free(bad); } }
+      printf("corrupt index: %d of 200 damaged files still loaded\n", loaded); }
+    printf("malformed input: %d of 300 mutated eq files still parsed, %d reads came out of 300 mutated FASTQ files\n", accepted, ok_reads); }
   sq_index_free(idx);
   printf("host sanitize run ok: %u refs, %llu k-mer lookups, 5000 read pairs, %zu classes\n", M, (unsigned long long)tried, cnt.size());
   return 0;
