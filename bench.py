@@ -210,7 +210,7 @@ def main():
             "traffic": traffic,
                 "avg_launch_ms": stage_rows[dom]["avg_ms"], "alg_bytes_per_launch": int(per_launch), "traffic_note": tnote,
                 "alg_bytes_note": "k_seed: 4 dependent 64 B lines per dictionary probe (pilot, slot record, string-pool word, unitig bounds) + per uni-MEM 64 B (extension words, contig-table bounds, record) + the packed read; DESIGN.md section 6"}
-    cpu = None
+    cpu = None; parity = None
     if a.cpu_sample > 0 and world == 1 and host_first is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
@@ -235,6 +235,23 @@ def main():
         if em_single_s < em_thr_s: em_thr_n, em_thr_s = 1, em_single_s       # the CPU side gets its best configuration
         em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
         t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
+        # parity at bench scale (outside the timed region): the same S pairs through the HIP path on a reset context, compared with
+        # what the checker just produced — alignment records, per-read offsets, mapping types, counters, the class table (labels,
+        # bins, counts, fixed-point weight sums), the online model, projected counts and the VBEM result
+        import hashlib
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        ctx.set_profiling(False); ctx.reset()
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+        ctx.eq_accumulate(); eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
+        p_g = api.normalize_alphas(eq_g, lm_g, uq_g, tc_g)
+        a_g, rep_g = ctx.em_optimize(np.exp(le_g), p_g, api.em_opts())
+        a_c, _ = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
+        checks = {"alignments": sha(aln_g) == sha(aln), "read_offsets": sha(ro_g) == sha(ro), "map_types": sha(mt_g) == sha(mt), "counters": st_g == stc,
+            "eq_classes": all(sha(getattr(eq_g, f)) == sha(getattr(eqc, f)) for f in ("off", "tid", "bins", "count", "wq", "h1", "h2")),
+            "online_model": sha(lm_g) == sha(lmc) and sha(uq_g) == sha(uqc) and sha(tc_g) == sha(tcc) and sha(le_g) == sha(lec),
+            "projected_counts": sha(p_g) == sha(pc), "vbem": rep_g["iters"] == repc["iters"] and sha(a_g) == sha(a_c)}
+        parity = {"pairs": S, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
+            "checks": checks, "alignments_sha256": sha(aln_g), "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % S}
         cpu = {"value": round(S / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
                "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S,
                    B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
@@ -256,7 +273,7 @@ def main():
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes,
             "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
-        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu,
+        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu, "parity_check": parity,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:
