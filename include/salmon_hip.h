@@ -146,6 +146,10 @@ typedef struct {
   uint8_t no_length_correction;   /* 0 */
   uint8_t no_eff_length_correction; /* 0 */
   uint64_t seed;              /* seed of the counter-based RNG for FLD sampling (reference: random_device) */
+  uint32_t mini_batches_in_flight; /* 8 = the reference's default numThreads (SalmonDefaults.hpp:15): W worker threads each run a mini-batch
+                                      against the shared model (SalmonQuantify.cpp:2390-2403); here W consecutive mini-batches read
+                                      one model snapshot and their increments are applied in order (SPEC §D1).  1..64; 1 = strictly serial */
+  uint32_t _pad2;
 } sq_quant_opts;
 void sq_quant_opts_default(sq_quant_opts* o); /* -l IU defaults */
 

@@ -797,6 +797,17 @@ struct QuantState {
   std::map<std::vector<uint32_t>, EqVal> eq;  // label (tids + bins) -> value
   std::vector<uint64_t> libCounts;
   uint64_t readCounter = 0;
+  // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
+  // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
+  struct PendingMB { double logFM; std::vector<std::pair<uint32_t, uint64_t>> massInc; std::vector<uint32_t> fldCnt; bool anyFld; uint32_t minLen; };
+  std::vector<PendingMB> pending;
+  void flush_pending() {
+    for (PendingMB& p : pending) {
+      for (auto& tq : p.massInc) mass[tq.first] = sq_log_add(mass[tq.first], p.logFM + sq_log(sq_from_fixed(tq.second, SQ_MFRAC_BITS)));
+      if (p.anyFld) { fld.apply_counts(p.fldCnt, p.logFM); fld.minLen = std::min(fld.minLen, p.minLen); }
+    }
+    pending.clear();
+  }
   void init(const Index* i, const sq_quant_opts* o) {
     ix = i; make_opts(o, op);
     size_t M = ix->names.size();
@@ -968,21 +979,20 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
     if (n == 1) S.uniq[tids[0]] += 1;
     for (int f = 0; f < 64; ++f) if (fmtSeen >> f & 1) S.libCounts[f]++;
   }
-  // batch end: apply updates
-  for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) {
-    S.mass[t] = sq_log_add(S.mass[t], logFM + sq_log(sq_from_fixed(S.massAcc[t], SQ_MFRAC_BITS)));
-    S.massAcc[t] = 0;
-  }
+  // mini-batch end: its increments join the group's queue; the group is applied (in mini-batch order) once W mini-batches are in
+  // it, at the mini-batch that reaches numBurninFrags (:1012-1018), or at the end of the mapped batch (orc_eq_accumulate)
+  QuantState::PendingMB pm; pm.logFM = logFM; pm.anyFld = false; pm.minLen = minLen;
+  for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) { pm.massInc.emplace_back((uint32_t)t, S.massAcc[t]); S.massAcc[t] = 0; }
   if (!burned) {
-    bool any = false;
-    for (auto c : fldCnt) any |= (c != 0);
-    if (any) {
-      S.fld.apply_counts(fldCnt, logFM);
-      S.fld.minLen = minLen;
-    }
+    for (auto c : fldCnt) pm.anyFld |= (c != 0);
+    if (pm.anyFld) pm.fldCnt = fldCnt;
   }
+  S.pending.push_back(std::move(pm));
   S.numAssigned += local; S.numObserved += (r1 - r0); S.readCounter += (r1 - r0); S.batchNo++;
-  if (S.numAssigned >= o.num_burnin_frags && !S.burnedIn) S.burnin_finalize();
+  const bool burnNow = S.numAssigned >= o.num_burnin_frags && !S.burnedIn;
+  const uint32_t W = std::max(1u, std::min(o.mini_batches_in_flight ? o.mini_batches_in_flight : 1u, 64u));
+  if (S.pending.size() >= W || burnNow) S.flush_pending();
+  if (burnNow) S.burnin_finalize();
 }
 
 // ================================================================================================
@@ -1436,6 +1446,7 @@ void orc_state_free(orc_state* s) { delete s; }
 void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, uint64_t num_with_joint_hits) {
   QuantState& S = s->S; uint32_t mb = S.op.o.mini_batch_size ? S.op.o.mini_batch_size : 5000;
   for (uint64_t r0 = 0; r0 < n; r0 += mb) process_mini_batch(S, read_off, alns, r0, std::min<uint64_t>(n, r0 + mb));
+  S.flush_pending();   // a group never straddles two mapped batches
   S.numMappedUB += num_with_joint_hits;
 }
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)

@@ -35,7 +35,8 @@ class QuantOpts(C.Structure):
                 ("mini_batch_size", u32), ("num_pre_burnin_frags", u32), ("num_burnin_frags", u64),
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
-                ("no_length_correction", u8), ("no_eff_length_correction", u8), ("seed", u64)]
+                ("no_length_correction", u8), ("no_eff_length_correction", u8), ("seed", u64),
+                ("mini_batches_in_flight", u32), ("_pad2", u32)]
 
 
 class ReadBatch(C.Structure):

@@ -24,7 +24,8 @@ struct sq_online_dev {
   uint32_t M = 0;
   // model
   sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
-  sq_dbuf<uint32_t> touched, touched_n;   // transcripts whose mass changed in the current mini-batch: two lists (mini-batch parity), [2*M] + [2]
+  sq_dbuf<uint32_t> touched, touched_n, tflag;   // transcripts whose mass changed in the current group of mini-batches: two lists (group parity), [2*M] + [2]; tflag[M] = already listed
+  uint32_t inflight = 1;                          // W: mini-batches per model snapshot (SPEC §D1); mass_acc is [W][M], fld_cnt [W][1024]
   // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
   sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts;
   sq_dbuf<uint32_t> fld_cnt;
@@ -71,7 +72,7 @@ struct sq_online_dev {
   } exp;
   sq_dbuf<uint32_t> merge_slot;
   std::vector<double> fm_host;
-  uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0; bool burned_known = false;
+  uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0, group_no = 0; bool burned_known = false;
 };
 
 namespace {
@@ -125,7 +126,7 @@ struct OnlineView {
   unsigned long long* lib_counts;
   uint32_t* fld_cnt;
   unsigned long long* ctr;
-  uint32_t* touched; uint32_t* touched_n;
+  uint32_t* touched; uint32_t* touched_n; uint32_t* tflag;
 };
 
 __global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o,
@@ -195,10 +196,10 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
 
 // one mini-batch: fragments [r0, r1) of the current mapped batch (thread per fragment)
 // first toucher of a transcript in this mini-batch records it (one atomic per wave: the ballot sees the calling lanes only)
-__device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, unsigned long long q) {
+__device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t w, uint32_t t, unsigned long long q) {
   if (!q) return;
-  const unsigned long long old = atomicAdd(&V.mass_acc[t], q);
-  if (old == 0) {
+  const unsigned long long old = atomicAdd(&V.mass_acc[(size_t)w * V.M + t], q);
+  if (old == 0 && atomicExch(&V.tflag[t], 1u) == 0u) {   // first toucher of (mini-batch slot, transcript), and the transcript is not listed yet
     const unsigned long long m = __ballot(1);
     const int leader = __ffsll((long long)m) - 1, lane = (int)(threadIdx.x & 63);
     uint32_t base = 0;
@@ -208,7 +209,7 @@ __device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t t, u
   }
 }
 
-__device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1,
+__device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_opts& o, uint32_t r, uint32_t r0, uint32_t r1, uint32_t mbs,
     uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
@@ -284,14 +285,14 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     if (o.range_factorization_bins > 0) bin = (uint32_t)(int32_t)(w * (double)rangeCount);
     awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
     const double pr = sq_exp(alp[ai] - sumProbs);
-    mass_add(V, par, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+    mass_add(V, par, mbs, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
     atomicAdd(&V.total[t], 1ULL);
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
       if (rr < pr) {
         uint32_t fl = pre[ai].fl_ped;
         if (fl > 0) {
-          atomicAdd(&V.fld_cnt[fl], 1u);
+          atomicAdd(&V.fld_cnt[mbs * 1024u + fl], 1u);
           if ((unsigned long long)fl < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
               (unsigned long long)fl);
         }
@@ -318,7 +319,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 // so the kernel fits the eq stage's CU partition in one round.)
 #define MB_G 8
 #define MB_S 2
-__global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint64_t read_counter0,
+__global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint32_t mb, uint64_t read_counter0,
                              const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const PreAln* __restrict__ pre,
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
                              unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin,
@@ -328,10 +329,11 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
   uint64_t fmtSeen = 0; int compatFrag = 0;   // this lane reports an assigned fragment that has a compatible alignment
   const bool valid = r < r1;
+  const uint32_t mbs = valid ? (r - r0) / mb : 0;   // mini-batch slot inside the group: increments are kept apart per mini-batch (each has its own forgetting mass)
   const uint64_t a0 = valid ? aln_off[r] : 0, a1 = valid ? aln_off[r + 1] : 0;
   const uint32_t nA = (uint32_t)(a1 - a0);
   if (valid && nA > MB_G * MB_S) {
-    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1,
+    if (j == 0) mini_batch_fragment(V, o, r, r0, r1, mbs, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1,
         rh2, &fmtSeen, par,
         &compatFrag);
   } else if (valid) {
@@ -420,12 +422,12 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             bin[sl] = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
             awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
             const double pr = sq_exp(logProb[sl] - sumProbs);
-            mass_add(V, par, t[sl], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+            mass_add(V, par, mbs, t[sl], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
             atomicAdd(&V.total[t[sl]], 1ULL);
             if (!burned) {
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
               if (rr < pr && fl_ped[sl] > 0) {
-                atomicAdd(&V.fld_cnt[fl_ped[sl]], 1u);
+                atomicAdd(&V.fld_cnt[mbs * 1024u + fl_ped[sl]], 1u);
                 if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&V.ctr[2],
                     (unsigned long long)fl_ped[sl]);
@@ -480,7 +482,9 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
 // transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
-__device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64_t assigned_after, int set_ctr, uint32_t par,
+#define SQ_MAX_INFLIGHT 64
+struct FmArr { double v[SQ_MAX_INFLIGHT]; };   // forgetting masses of the group's mini-batches, in order
+__device__ inline void apply_mass_part(const OnlineView& V, const FmArr& FM, uint32_t nw, uint64_t assigned_after, int set_ctr, uint32_t par,
     uint32_t mass_blocks) {
   // the other list is idle until the next mini-batch
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -490,11 +494,16 @@ __device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64
   const uint32_t n = V.touched_n[par]; const uint32_t* list = V.touched + (size_t)par * V.M;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += mass_blocks * blockDim.x) {
     const uint32_t t = list[i];
-    const unsigned long long q = V.mass_acc[t];
-    const double m = sq_log_add(V.mass[t], logFM + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
+    double m = V.mass[t];
+    for (uint32_t w = 0; w < nw; ++w) {                    // the group's mini-batches in order, each with its own forgetting mass
+      const unsigned long long q = V.mass_acc[(size_t)w * V.M + t];
+      if (!q) continue;
+      m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
+      V.mass_acc[(size_t)w * V.M + t] = 0;
+    }
     V.mass[t] = m;
     V.tlc[t] = sq_log_add(V.prior_mass[t], m);
-    V.mass_acc[t] = 0;
+    V.tflag[t] = 0;
   }
 }
 
@@ -502,25 +511,28 @@ __device__ inline void apply_mass_part(const OnlineView& V, double logFM, uint64
 // 256 threads walk the 1024 histogram bins (4 per thread): blocks of 256 threads slot in beside the
 // resident waves of the mapping kernels, a 1024-thread block has to wait for a whole CU to drain.
 #define AP_TB 256
-__device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_t assigned_after, uint64_t num_burnin) {
-  __shared__ double v[1024]; __shared__ uint32_t cnt[1024]; __shared__ int any;
+__device__ inline void apply_fld_part(const OnlineView& V, const FmArr& FM, uint32_t nw, uint64_t assigned_after, uint64_t num_burnin) {
+  __shared__ double v[1024]; __shared__ int any;
   const int tid = threadIdx.x;
   if (tid == 0) any = 0;
   __syncthreads();
   const bool burned = V.ctr[1] != 0;
-  if (!burned) for (int b = tid; b <= 1000; b += AP_TB) { uint32_t c = V.fld_cnt[b]; cnt[b] = c; if (c) any = 1; }
+  if (!burned) { int mine = 0; for (uint32_t b = tid; b < nw * 1024u; b += AP_TB) if (V.fld_cnt[b]) mine = 1; if (mine) any = 1; }
   __syncthreads();
   if (!burned && any) {
     const double kern[5] = {sq_log(0.0625), sq_log(0.25), sq_log(0.375), sq_log(0.25), sq_log(0.0625)};
     for (int b = tid; b < 1024; b += AP_TB) {
       double h = (b <= 1000) ? V.hist[b] : SQ_LOG_0;
       if (b >= 1 && b <= 1000) {
-        for (int i = 4; i >= 0; --i) {
-          int len = b + 2 - i;
-          if (len < 0 || len > 1000) continue;
-          uint32_t c = cnt[len];
-          if (!c) continue;
-          h = sq_log_add(h, logFM + kern[i] + sq_log((double)c));
+        for (uint32_t w = 0; w < nw; ++w) {                // a bin's updates depend on nothing but the counts: mini-batch after mini-batch
+          const uint32_t* cnt = V.fld_cnt + w * 1024u;
+          for (int i = 4; i >= 0; --i) {
+            int len = b + 2 - i;
+            if (len < 0 || len > 1000) continue;
+            uint32_t c = cnt[len];
+            if (!c) continue;
+            h = sq_log_add(h, FM.v[w] + kern[i] + sq_log((double)c));
+          }
         }
         V.hist[b] = h;
       }
@@ -529,7 +541,7 @@ __device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_
     __syncthreads();
     for (int s = 512; s >= 1; s >>= 1) { for (int b = tid; b < s; b += AP_TB) v[b] = sq_log_add(v[b], v[b + s]); __syncthreads(); }
     if (tid == 0) V.scal[0] = v[0];
-    for (int b = tid; b <= 1000; b += AP_TB) V.fld_cnt[b] = 0;
+    for (uint32_t b = tid; b < nw * 1024u; b += AP_TB) V.fld_cnt[b] = 0;
   }
   if (tid == 0) {
     V.ctr[0] = assigned_after;
@@ -542,11 +554,11 @@ __device__ inline void apply_fld_part(const OnlineView& V, double logFM, uint64_
 // kernel needs few workgroups and squeezes in beside the mapping kernels), the extra last block (before
 // burn-in only) updates the FLD — the two parts touch disjoint state, and every launch saved shortens
 // the sequential mini-batch chain (the model of mini-batch i+1 depends on the end of mini-batch i).
-__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, double logFM, uint64_t assigned_after, uint64_t num_burnin,
+__global__ void __launch_bounds__(AP_TB) k_apply(OnlineView V, FmArr FM, uint32_t nw, uint64_t assigned_after, uint64_t num_burnin,
     uint32_t mass_blocks, int with_fld,
     uint32_t par) {
-  if (blockIdx.x < mass_blocks) apply_mass_part(V, logFM, assigned_after, with_fld ? 0 : 1, par, mass_blocks);
-  else apply_fld_part(V, logFM, assigned_after, num_burnin);
+  if (blockIdx.x < mass_blocks) apply_mass_part(V, FM, nw, assigned_after, with_fld ? 0 : 1, par, mass_blocks);
+  else apply_fld_part(V, FM, nw, assigned_after, num_burnin);
 }
 
 // burn-in finalisation (FLD.cacheCMF :174-186 + updateTranscriptLengthsAtomic ReadExperiment.inl:62-94), one thread: 3 chains of 1001 logAdds, once
@@ -761,6 +773,7 @@ OnlineView make_view(sq_ctx* c) {
   V.ctr = o->ctr.p;
   V.touched = o->touched.p;
   V.touched_n = o->touched_n.p;
+  V.tflag = o->tflag.p;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
@@ -786,14 +799,15 @@ double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
 int sq_online_create(sq_ctx* c) {
   sq_online_dev* o = new sq_online_dev(); c->online = o;
   const uint32_t M = (uint32_t)c->idx->names.size(); o->M = M;
+  const uint32_t W = std::max(1u, std::min<uint32_t>(c->opts.mini_batches_in_flight ? c->opts.mini_batches_in_flight : 1u, SQ_MAX_INFLIGHT)); o->inflight = W;
   // eq table capacity: 2^22 slots per million batch reads, min 2^20, max 2^26
   uint64_t cap = 1ull << 22; o->tcap = cap; o->pool_cap = cap * 4;
   bool bad = o->hist.ensure(1024) || o->cpmf.ensure(1024) || o->ccmf.ensure(1024) || o->ambig.ensure(2048) || o->mass.ensure(M) ||
       o->prior_mass.ensure(M) ||
       o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
-             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->mass_acc.ensure(M) || o->uniq.ensure(M) ||
+             o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->tflag.ensure(M) || o->mass_acc.ensure((size_t)W * M) || o->uniq.ensure(M) ||
                  o->total.ensure(M) ||
-                 o->lib_counts.ensure(64) || o->fld_cnt.ensure(1024) || o->ctr.ensure(8) ||
+                 o->lib_counts.ensure(64) || o->fld_cnt.ensure((size_t)W * 1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) ||
                  o->rh1.ensure(c->max_reads) ||
                  o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
@@ -842,11 +856,12 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemcpy(o->mass.p, mass.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->tlc.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));  // logAdd(prior, LOG_0) = prior
   SQ_HIP_CHECK(hipMemset(o->touched_n.p, 0, 8));
-  SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)M * 8));
+  SQ_HIP_CHECK(hipMemset(o->mass_acc.p, 0, (size_t)W * M * 8));
+  SQ_HIP_CHECK(hipMemset(o->tflag.p, 0, (size_t)M * 4));
   SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8));
-  SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, 1024 * 4));
+  SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, (size_t)W * 1024 * 4));
   SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8));
@@ -876,6 +891,7 @@ void sq_online_free(sq_ctx* c) {
   o->merge_slot.free_();
   o->touched.free_();
   o->touched_n.free_();
+  o->tflag.free_();
   o->mass_acc.free_();
   o->uniq.free_();
   o->total.free_();
@@ -1076,23 +1092,34 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   mark("bounds-sync");
   const uint64_t assigned_base = hctr[0];
   bool burned_host = hctr[1] != 0;
-  for (uint32_t b = 0; b < nmb; ++b) {
-    const uint32_t r0 = b * mb, r1 = std::min<uint64_t>((uint64_t)(b + 1) * mb, n);
-    const double logFM = forgetting_mass(o, q.forgetting_factor, o->batch_no);
-    const uint64_t assigned_after = assigned_base + bound[b + 1];
-    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, c->reads_seen + r0, d_aln_off, d_aln,
+  // Groups of up to W consecutive mini-batches share one model snapshot (SPEC §D1: the reference's W = numThreads workers read a
+  // shared, slightly stale model, SalmonQuantify.cpp:2390-2403): ONE k_mini_batch over the group's fragments + ONE k_apply that
+  // folds the mini-batches' increments in order, each with its own forgetting mass.  A group also ends at the mini-batch that
+  // reaches numBurninFrags (the burn-in tables are made right there, as with W = 1) and at the end of the mapped batch.
+  const uint32_t W = o->inflight;
+  for (uint32_t b = 0; b < nmb;) {
+    FmArr FM; uint32_t nw = 0; bool burn_now = false; const uint32_t b0 = b;
+    while (b < nmb && nw < W && !burn_now) {
+      FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++);
+      burn_now = !burned_host && assigned_base + bound[b + 1] >= q.num_burnin_frags;
+      ++b;
+    }
+    for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
+    const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
+    const uint64_t assigned_after = assigned_base + bound[b];
+    const uint32_t par = (uint32_t)(o->group_no & 1);
+    k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, mb, c->reads_seen + r0, d_aln_off, d_aln,
         (const PreAln*)o->pre.p,
-        o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, (uint32_t)(o->batch_no & 1));
+        o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, par);
     { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
-      k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, logFM, assigned_after, q.num_burnin_frags, mass_blocks, with_fld,
-          (uint32_t)(o->batch_no & 1)); }
-    if (!burned_host && assigned_after >= q.num_burnin_frags) {
+      k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, FM, nw, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, par); }
+    if (burn_now) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
       k_burnin_efflen<<<nblk(o->M), TB, 0, st>>>(V, 2);
       k_burnin_done<<<1, 64, 0, st>>>(V);
       burned_host = true;
     }
-    o->batch_no++;
+    o->group_no++;
   }
   sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
   // eq-class table: insert labels, then add counts / fixed-point weights

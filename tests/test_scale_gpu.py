@@ -12,7 +12,7 @@ N, B = 200000, 100000
 
 
 def test_gpu_equals_checker_at_20k_transcripts_200k_pairs(built):
-    tx = synth.Txome(seed=5, n_genes=2500, iso_per_gene=8, threads=16)
+    tx = synth.Txome(seed=5, n_genes=3200, iso_per_gene=8, threads=16)
     names, seqs, lens = tx.tables()
     idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=16).to_device(0)
     assert idx.num_refs >= 19000
