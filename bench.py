@@ -33,6 +33,8 @@ def parse():
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
+    ap.add_argument("--inflight", type=int, default=0,
+        help="mini-batches per model snapshot (sq_quant_opts.mini_batches_in_flight = the reference's -p / numThreads); 0 = the library default (8)")
     ap.add_argument("--lanes", type=int, default=1,
         help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
     return ap.parse_args()
@@ -46,9 +48,8 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         "k_pack": nrec * (L + 8 + 64 + 32 + 2),
         "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 4 * 64 + st["num_seeds"] * (16 + 16 + 32),
         "scan_mems": nrec * (4 + 8),
-        "k_project": st["num_seeds"] * (16 + 16) + st["num_mems"] * (8 + 16) + nrec * 14,
-        "radix_sort": st["num_mems"] * 32,
-        "k_chain": st["num_mems"] * (16 + 8 + 4 + 4 + 1) + st["num_chains"] * 40 + nrec * 20,
+        # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
+        "k_mems": st["num_seeds"] * (16 + 16) + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (4 + 16 + 2 + 4),
         "k_join_fill": st["num_chains"] * 40 + st["num_candidates"] * 52 + n_pairs * 16,
         "k_score": st["num_candidates"] * (48 * 2 + 2 * 40 + 2 * (96 + 64) + 4) + st["num_mems"] * 0,
         "k_dp": st["num_dp_alignments"] * (48 + 96 + 64),
@@ -93,6 +94,7 @@ def main():
     idx.to_device(local)
     B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len
     opts = api.quant_opts()
+    if a.inflight > 0: opts.mini_batches_in_flight = a.inflight
     ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
     # end-of-job buffers (eq-class export, EM workspace) sized like the reference's initial eq-class map (10^6 classes); with several
     # ranks every GPU ends up holding the union of all ranks' classes, so the class table is sized for that
@@ -189,7 +191,7 @@ def main():
         "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
     # roofline: the dominant SINGLE kernel (stages that aggregate many launches — the library sort, the scans, the
     # eq stage's mini-batch chain that overlaps mapping on its own stream — are not kernels and are excluded)
-    single = {"k_pack": "k_pack", "k_seed": "k_seed", "k_project": "k_project", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
+    single = {"k_pack": "k_pack", "k_seed": "k_seed", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
         "k_select": "k_select"}
     cand = [k for k in stage_rows if k in single]
     dom = max(cand, key=lambda k: stage_rows[k]["ms_total"]) if cand else None

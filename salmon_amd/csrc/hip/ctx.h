@@ -86,6 +86,7 @@ struct sq_ctx {
   sq_dbuf<sq_unimem_dev> unimems; sq_dbuf<uint32_t> n_uni; sq_dbuf<uint32_t> n_proj; sq_dbuf<uint64_t> mem_off;
   sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;
   sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
+  sq_dbuf<uint32_t> mlist, mlbase; sq_dbuf<uint64_t> lkey, lval;   // read ends by MEM-count class (mem_kernels.h); sorted compact buffer of the large class
   // chains
   sq_dbuf<sq_chain_dev> chains; sq_dbuf<uint32_t> n_chains; uint64_t last_total_chains = 0;
   // candidates / alignments

@@ -2,6 +2,7 @@
 // sq_debug_tap.  Stage kernels live in map_kernels.h.  All intermediate data stay in HBM between
 // stages; the host only reads back three totals (MEMs, candidates, DP regions) to size buffers.
 #include "map_kernels.h"
+#include "mem_kernels.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
@@ -45,7 +46,7 @@ void fill_params(sq_ctx* c) {
 }
 }  // namespace
 
-static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_project", "radix_sort", "k_chain", "k_join_count",
+static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_mems", "large_ends", "count_kmer_frags", "k_join_count",
     "scan_cands", "k_join_fill", "k_score",
     "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table"};
@@ -222,6 +223,10 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->cp.free_();
   c->mnext.free_();
   c->mused.free_();
+  c->mlist.free_();
+  c->mlbase.free_();
+  c->lkey.free_();
+  c->lval.free_();
   c->chains.free_();
   c->n_chains.free_();
   c->n_cand.free_();
@@ -382,46 +387,52 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   sq_prof_mark(c, SG_SEED);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
-  uint64_t total_mems = 0;
+  // size classes of the ends (mem_kernels.h); their counts come back with the MEM total in the same read-back
+  if (c->mlist.ensure((size_t)3 * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
+  uint32_t* list_s = c->mlist.p; uint32_t* list_m = c->mlist.p + nrec; uint32_t* list_l = c->mlist.p + 2 * (size_t)nrec;
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 4, 0, 4 * sizeof(uint32_t), st));
+  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, list_s, list_m, list_l, c->mlbase.p, c->n_chains.p, c->counters.p + 4);
+  uint64_t total_mems = 0; uint32_t hcls[4] = {0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 4, sizeof(hcls), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_mems = total_mems;
-  const size_t MP = (size_t)total_mems + 8;
-  const bool recover = P.recover_orphans && paired;   // recovered mates live in a second set of chain slabs (k_recover)
-  if (c->mkey.ensure(MP) || c->mval.ensure(MP) || c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->cf.ensure(MP) || c->cp.ensure(MP) ||
-      c->mnext.ensure(MP) ||
-      c->mused.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
-    sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
-  uint64_t* skey = c->mkey.p; uint64_t* sval = c->mval.p;
-  if (total_mems) {
-    k_project<<<nblk(nrec), TB, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, nrec, c->rlen.p, c->unimems.p, c->n_uni.p,
-        c->mem_off.p, c->mkey.p,
-        c->mval.p);
-    sq_prof_mark(c, SG_PROJECT);
-    // one global radix sort on (read end, global reference position); a segmented sort over the position bits only
-    // (rocPRIM DeviceSegmentedRadixSort, ~12 MEMs per segment) measured slower: 2.56 vs 2.05 ms per 1 M pairs
-    int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
-    size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0, 40 + endbits, st);
-    if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
-    tmp = c->sort_tmp.n;
-    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->mkey2.p, c->mval.p, c->mval2.p, (int)total_mems, 0,
-        40 + endbits, st));
-    skey = c->mkey2.p; sval = c->mval2.p;
-    sq_prof_mark(c, SG_SORT);
-  }
-  // (measured: visiting ends / fragments in work-sorted order lost more to scattered access than it gained in balance)
-  k_chain<<<nblk(nrec), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nrec, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p,
-      c->mnext.p, c->mused.p, c->chains.p,
-      c->n_chains.p, c->stats.p, nullptr);
-  k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
-  // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
-  // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
-  if (total_mems >= (recover ? 0x7FFFFFF0ull : 0xFFFFFFF0ull)) {
+  if (total_mems >= 0x7FFFFFF0ull) {   // 32-bit slab indices (candidates name chains by slab index; recovery doubles the slabs)
     sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems);
     return SQ_ERR_OVERFLOW;
   }
+  const size_t MP = (size_t)total_mems + 8;
+  const bool recover = P.recover_orphans && paired;   // recovered mates live in a second set of chain slabs (k_recover)
+  if (c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->mnext.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
+    sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
+  uint64_t* skey = c->mkey2.p; uint64_t* sval = c->mval2.p;
+  const uint32_t nS = hcls[0], nM = hcls[1], nL = hcls[2], memsL = hcls[3];
+  if (nS) k_mems<16, MK_S_CAP, 256><<<(nS + 15) / 16, 256, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_s, nS,
+      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
+  if (nM) k_mems<64, MK_M_CAP, 128><<<(nM + 1) / 2, 128, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_m, nM,
+      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
+  sq_prof_mark(c, SG_PROJECT);
+  if (nL) {   // ends with more than MK_M_CAP MEMs (deep repeats): compact projection, library radix sort, back into the slabs, HBM chaining
+    const size_t LP = (size_t)memsL + 8;
+    if (c->mkey.ensure(LP) || c->mval.ensure(LP) || c->lkey.ensure(LP) || c->lval.ensure(LP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mused.ensure(MP)) {
+      sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }
+    k_project_list<<<(nL + 3) / 4, 256, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, list_l, c->mlbase.p, nL, c->rlen.p, c->unimems.p,
+        c->n_uni.p, c->mkey.p, c->mval.p);
+    int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (int)memsL, 0, 40 + endbits, st);
+    if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
+    tmp = c->sort_tmp.n;
+    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (int)memsL, 0, 40 + endbits, st));
+    k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->mem_off.p, skey, sval);
+    k_chain<<<nblk(nL), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nL, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p,
+        c->chains.p, c->n_chains.p, nullptr, list_l);
+  }
+  sq_prof_mark(c, SG_SORT);
+  k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
+  // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
+  // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
   sq_prof_mark(c, SG_CHAIN);
   // single-pass join; candidate blocks come from a global cursor (stats slot reused as the 64-bit cursor)
   uint64_t total_cands = 0;
@@ -533,7 +544,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     stats->num_decoy_fragments = hst[ST_DECOY];
     stats->num_seeds = hst[ST_SEEDS];
     stats->num_lookups = hst[ST_LOOKUPS];
-    stats->num_mems = hst[ST_MEMS];
+    stats->num_mems = total_mems;
     stats->num_chains = hst[ST_CHAINS];
     stats->num_candidates = total_cands;
     stats->num_dp_alignments = hst[ST_DP];

@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
   uint32_t kept = 0;
   for (uint32_t i = 0; i < nch; ++i) { sq_chain_dev c = chains[base + i]; if (c.score < cthr) continue; chains[base + kept++] = c; }
   if (act) n_chains[e] = kept;
-  wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept);
+  if (stats) { wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept); }   // stats == nullptr: counted elsewhere (map.hip)
 }
 
 // a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.
@@ -1184,9 +1184,9 @@ __global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand
 __global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains,
     unsigned long long* __restrict__ stats) {
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  bool any = false;
-  if (f < nfrag) any = paired ? (n_chains[2 * f] || n_chains[2 * f + 1]) : (n_chains[f] != 0);
-  wave_stat_add(&stats[ST_KMER], any ? 1 : 0);
+  bool any = false; uint32_t nch = 0;
+  if (f < nfrag) { nch = paired ? (n_chains[2 * f] + n_chains[2 * f + 1]) : n_chains[f]; any = nch != 0; }
+  wave_stat_add(&stats[ST_KMER], any ? 1 : 0); wave_stat_add(&stats[ST_CHAINS], nch);
 }
 
 }  // namespace sqk

@@ -1,0 +1,277 @@
+// hip/mem_kernels.h — row a2 in ONE kernel per size class: projection of a read end's uni-MEMs through the contig
+// table (fillMemCollection), the per-end sort by (transcript, reference position) and the chaining DP (findOptChain)
+// all happen in LDS; HBM sees the uni-MEM records and contig-table runs once on the way in, and the sorted MEM
+// records + chains once on the way out.  (Round 1 ran k_project -> a global 61-bit radix sort -> k_chain: the MEM
+// records crossed HBM about ten times, and the thread-per-end projection stored them 8 bytes at a time.)
+//
+// A read end with n projected MEMs is handled by a group of G lanes:
+//   n <= 64    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 64, 256>
+//   n <= 1024  G = 64  (one wave per end)                                                       k_mems<64, 1024, 128>
+//   larger     the round-1 path on a compacted list (k_project_list -> radix sort -> k_chain)
+// Lanes expand one occurrence each (coalesced contig-table loads, all gathers in flight), rank-sort the keys held
+// in LDS (stable: ties keep emission order, SPEC §a2), then every lane runs the chaining DP of whole transcripts.
+// Same arithmetic, same order of operations as the checker: results are bit-identical whatever the class.
+#pragma once
+#include "map_kernels.h"
+
+namespace sqk {
+
+#define MK_S_CAP 64
+#define MK_M_CAP 1024
+
+__device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// ends by size class; an end without MEMs has no chains.  ctr: [0] small [1] medium [2] large [3] MEMs of the large ends.
+// Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs three same-address atomics.
+__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ list_s,
+                              uint32_t* __restrict__ list_m, uint32_t* __restrict__ list_l, uint32_t* __restrict__ lbase, uint32_t* __restrict__ n_chains,
+                              uint32_t* __restrict__ ctr) {
+  __shared__ uint32_t s_cnt[3][16]; __shared__ uint32_t s_base[3];
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+  const uint32_t n = e < nends ? n_proj[e] : 0;
+  const int cls = (e >= nends || n == 0) ? -1 : (n <= MK_S_CAP ? 0 : (n <= MK_M_CAP ? 1 : 2));
+  if (e < nends && n == 0) n_chains[e] = 0;
+  unsigned long long m[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { m[c] = __ballot(cls == c); if (lane == 0) s_cnt[c][wv] = (uint32_t)__popcll(m[c]); }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += v; }
+    s_base[threadIdx.x] = tot ? atomicAdd(&ctr[threadIdx.x], tot) : 0u;
+  }
+  __syncthreads();
+  if (cls >= 0) {
+    const uint32_t pos = s_base[cls] + s_cnt[cls][wv] + (uint32_t)__popcll(m[cls] & ((1ULL << lane) - 1));
+    if (cls == 0) list_s[pos] = e; else if (cls == 1) list_m[pos] = e;
+    else { list_l[pos] = e; lbase[pos] = atomicAdd(&ctr[3], n); }
+  }
+}
+
+struct MkHdr { uint64_t a; uint32_t cnt, ulen, ustart; uint16_t qpos, lenfw; };   // one uni-MEM of the end: contig-table run + what the projection needs
+
+template <int G, int CAP, int TBK>
+__global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab,
+                                              const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost,
+                                              const uint32_t* __restrict__ list, uint32_t nlist, const uint16_t* __restrict__ rlen,
+                                              const sq_unimem_dev* __restrict__ um, const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off,
+                                              uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval, uint32_t* __restrict__ mnext,
+                                              sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains) {
+  constexpr int GPB = TBK / G, E = CAP / G;
+  static_assert(G == 16 || G == 32 || G == 64, "group = a power-of-two slice of a wave");
+  constexpr int CP8 = CAP + 1, CP4 = CAP + 1, CP2 = CAP + 2, CP1 = CAP + 4;   // padded rows: the groups of a wave must not sit on the same banks
+  __shared__ uint64_t s_key[GPB][CP8];                 // ranking keys, then (same bytes) the DP scores f[] as doubles
+  __shared__ int32_t s_r[GPB][CP4]; __shared__ uint32_t s_tid[GPB][CP4];
+  __shared__ int16_t s_q[GPB][CP2]; __shared__ uint16_t s_lf[GPB][CP2];      // len | fw << 15
+  __shared__ int16_t s_p[GPB][CP2]; __shared__ uint16_t s_acc[GPB][CP2]; __shared__ uint16_t s_gs[GPB][CP2 + 2]; __shared__ uint16_t s_gc[GPB][CP2];
+  __shared__ uint8_t s_fl[GPB][CP1];
+  __shared__ MkHdr s_h[GPB][SQ_MAX_UNIMEMS];
+  __shared__ double s_gap[SQ_MAX_CHAIN_GAP + 1];
+  const int tx = (int)threadIdx.x, gl = tx % G, gi = tx / G, lane = tx & 63, gsh = lane & ~(G - 1);
+  for (int i = tx; i <= SQ_MAX_CHAIN_GAP; i += TBK) s_gap[i] = gapcost[i];
+  __syncthreads();
+  const uint32_t li = blockIdx.x * GPB + (uint32_t)gi;
+  const bool act = li < nlist;
+  const uint32_t e = act ? list[li] : 0;
+  const uint64_t base = act ? mem_off[e] : 0;
+  const uint32_t n = act ? (uint32_t)(mem_off[e + 1] - base) : 0;
+  const uint32_t nu = act ? n_uni[e] : 0;
+  const int L = act ? (int)rlen[e] : 0;
+  // ---- uni-MEM headers: lane i fetches uni-MEM i, its contig-table run and its unitig's length ----
+  for (uint32_t i = (uint32_t)gl; i < nu; i += G) {
+    const sq_unimem_dev m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
+    const uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
+    MkHdr h; h.a = a; h.cnt = (b - a > P.max_occ) ? 0u : (uint32_t)(b - a);
+    h.ulen = (uint32_t)(uoff[m.unitig + 1] - uoff[m.unitig]); h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u));
+    s_h[gi][i] = h;
+  }
+  mk_wsync();
+  // ---- projection: output slot p = occurrence (uni-MEM i, j - a_i) in emission order; one lane per occurrence ----
+  uint64_t K[E]; int32_t R[E]; uint32_t T[E]; int16_t Q[E]; uint16_t LF[E]; uint32_t rk[E];
+  {
+    uint32_t hi = 0, hacc = 0;
+#pragma unroll
+    for (int t = 0; t < E; ++t) {
+      const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
+      K[t] = 0; R[t] = 0; T[t] = 0; Q[t] = 0; LF[t] = 0; rk[t] = 0;
+      if (p < n) {
+        while (p >= hacc + s_h[gi][hi].cnt) { hacc += s_h[gi][hi].cnt; ++hi; }
+        const MkHdr h = s_h[gi][hi];
+        const uint64_t o = ctab[h.a + (p - hacc)];
+        const uint32_t tid = (uint32_t)(o >> 32); const bool ufw = (o >> 31) & 1; const int upos = (int)(o & 0x7FFFFFFF);
+        const int mlen = (int)(h.lenfw & 0x7FFFu); const bool mfw = (h.lenfw & 0x8000u) != 0;
+        const int rpos = ufw ? upos + (int)h.ustart : upos + ((int)h.ulen - ((int)h.ustart + mlen));
+        const bool fw = (ufw == mfw);
+        const uint32_t q = fw ? (uint32_t)h.qpos : (uint32_t)(L - ((int)h.qpos + mlen));
+        K[t] = ref_accum[tid] + (uint64_t)rpos; R[t] = rpos; T[t] = tid; Q[t] = (int16_t)q; LF[t] = (uint16_t)(mlen | (fw ? 0x8000 : 0));
+        s_key[gi][p] = K[t];
+      }
+    }
+  }
+  mk_wsync();
+  // ---- stable rank sort: rank = number of records that come before mine ----
+  for (uint32_t q2 = 0; q2 < n; ++q2) {
+    const uint64_t kq = s_key[gi][q2];
+#pragma unroll
+    for (int t = 0; t < E; ++t) {
+      const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
+      rk[t] += ((kq < K[t]) | ((kq == K[t]) & (q2 < p))) ? 1u : 0u;
+    }
+  }
+  mk_wsync();
+#pragma unroll
+  for (int t = 0; t < E; ++t) {
+    const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
+    if (p < n) {
+      const uint32_t r = rk[t];
+      s_r[gi][r] = R[t]; s_tid[gi][r] = T[t]; s_q[gi][r] = Q[t]; s_lf[gi][r] = LF[t]; s_fl[gi][r] = 0;
+      mkey[base + r] = ((uint64_t)e << 40) | K[t];
+      mval[base + r] = mem_pack_val(T[t], (uint32_t)(uint16_t)Q[t], (uint32_t)(LF[t] & 0x7FFFu), (LF[t] >> 15) & 1u);
+    }
+  }
+  mk_wsync();
+  // ---- transcript groups: starts of the runs of equal transcript id ----
+  uint32_t ng = 0;
+#pragma unroll
+  for (int t = 0; t < E; ++t) {
+    const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
+    const bool st = p < n && (p == 0 || s_tid[gi][p] != s_tid[gi][p - 1]);
+    const unsigned long long bm = __ballot(st);
+    const uint32_t gm = (G == 64) ? 0u : (uint32_t)((bm >> gsh) & ((1ull << (G & 63)) - 1));
+    const uint32_t below = (G == 64) ? (uint32_t)__popcll(bm & ((1ull << lane) - 1)) : (uint32_t)__popc(gm & ((1u << gl) - 1));
+    const uint32_t tot = (G == 64) ? (uint32_t)__popcll(bm) : (uint32_t)__popc(gm);
+    if (st) s_gs[gi][ng + below] = (uint16_t)p;
+    ng += tot;
+  }
+  if (gl == 0) s_gs[gi][ng] = (uint16_t)n;
+  mk_wsync();
+  // ---- chaining DP, one lane per transcript (SPEC §a2; same operations in the same order as the checker) ----
+  double* f = (double*)s_key[gi];
+  double lbest = 0.0;
+  for (uint32_t k = (uint32_t)gl; k < ng; k += G) {
+    const int g0 = (int)s_gs[gi][k], g1 = (int)s_gs[gi][k + 1];
+    double best = 0.0;
+    for (int i = g0; i < g1; ++i) {
+      const int qi = s_q[gi][i], ri = s_r[gi][i], len_i = (int)(s_lf[gi][i] & 0x7FFFu); const uint32_t fwi = s_lf[gi][i] >> 15;
+      double fi = (double)len_i; int pi = -1; int rounds = 2;
+      for (int j = i - 1; j >= g0; --j) {
+        if ((uint32_t)(s_lf[gi][j] >> 15) != fwi) continue;
+        const int qd = qi - (int)s_q[gi][j], rd = ri - s_r[gi][j];
+        if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
+        const int l = abs(qd - rd);
+        const double a = (double)min(len_i, min(qd, rd));
+        const double sc = f[j] + a - s_gap[l];
+        if (sc > fi) { fi = sc; pi = j; }
+        if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
+      }
+      f[i] = fi; s_p[gi][i] = (int16_t)pi;
+      if (fi > best) best = fi;
+    }
+    const double thr = P.pre_thr * best;
+    uint32_t nacc = 0;
+    for (;;) {   // accept chain ends by (score desc, index asc); s_fl: bit 0 used by an accepted chain, bit 1 tried and dropped
+      int bi = -1; double bf = 0.0;
+      for (int i = g0; i < g1; ++i) {
+        if (s_fl[gi][i]) continue;
+        const double fv = f[i];
+        if (fv >= thr && (bi < 0 || fv > bf)) { bi = i; bf = fv; }
+      }
+      if (bi < 0) break;
+      bool clash = false;
+      for (int x = bi; x >= 0; x = s_p[gi][x]) if (s_fl[gi][x] & 1) { clash = true; break; }
+      if (clash) { s_fl[gi][bi] |= 2; continue; }
+      for (int x = bi; x >= 0; x = s_p[gi][x]) s_fl[gi][x] |= 1;
+      s_acc[gi][g0 + (int)nacc] = (uint16_t)bi; ++nacc;
+      if (bf > lbest) lbest = bf;
+    }
+    s_gc[gi][k] = (uint16_t)nacc;
+  }
+  // ---- hitFilterPolicy AFTER + consensus fraction over the end's chains; chains go out in (transcript, acceptance) order ----
+  double bestAll = lbest;
+  uint32_t ngmax = ng;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    if (s < G) { const double o = __shfl_xor(bestAll, s, 64); if (o > bestAll) bestAll = o; }
+    const uint32_t og = (uint32_t)__shfl_xor((int)ngmax, s, 64); if (og > ngmax) ngmax = og;
+  }
+  const double cthr = P.consensus_frac * bestAll;
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < ngmax; t0 += G) {
+    const uint32_t k = t0 + (uint32_t)gl;
+    uint32_t kept = 0; int g0 = 0, g1 = 0; uint32_t nacc = 0;
+    if (k < ng) {
+      g0 = (int)s_gs[gi][k]; g1 = (int)s_gs[gi][k + 1]; nacc = s_gc[gi][k];
+      for (uint32_t c = 0; c < nacc; ++c) if (f[s_acc[gi][g0 + (int)c]] >= cthr) ++kept;
+    }
+    uint32_t incl = kept;
+#pragma unroll
+    for (int s = 1; s < G; s <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, s, G); if (gl >= s) incl += o; }
+    const uint32_t tot = (uint32_t)__shfl((int)incl, G - 1, G);
+    uint32_t w = carry + incl - kept;
+    if (k < ng && kept) {
+      const int gn = g1 - g0; const bool by_mask = gn <= 32;
+      for (uint32_t c = 0; c < nacc; ++c) {
+        const int bi = (int)s_acc[gi][g0 + (int)c];
+        const double bf = f[bi];
+        if (bf < cthr) continue;
+        uint32_t mask = 0, cnt = 0; int first = bi;
+        for (int x = bi; x >= 0; x = s_p[gi][x]) {
+          ++cnt; first = x;
+          if (by_mask) mask |= 1u << (x - g0);
+          else { const int pr = s_p[gi][x]; if (pr >= 0) mnext[base + (uint32_t)pr] = (uint32_t)x; }
+        }
+        sq_chain_dev ch;
+        ch.score = bf; ch.tid = s_tid[gi][bi]; ch.pos = s_r[gi][first] - (int32_t)s_q[gi][first];
+        ch.last_end = s_r[gi][bi] + (int32_t)(s_lf[gi][bi] & 0x7FFFu);
+        ch.first = by_mask ? (uint32_t)g0 : (uint32_t)first; ch.n_mems = (uint16_t)cnt; ch.read_len = (uint16_t)L;
+        ch.fw = (uint8_t)(s_lf[gi][bi] >> 15); ch.pad[0] = by_mask ? 1 : 0; ch.pad[1] = ch.pad[2] = 0; ch.pad2 = mask;
+        chains[base + w] = ch; ++w;
+      }
+    }
+    carry += tot;
+  }
+  if (act && gl == 0) n_chains[e] = carry;
+  // no counters here: four ends per wave would mean a same-address atomic per wave (~10 ns each, 5 x 10^5 waves per 10^6 pairs);
+  // the MEM total is the scan's last element and the chains are counted per fragment in k_count_kmer_frags
+}
+
+// ---- the rare large ends (more than MK_M_CAP MEMs): projection into a compact buffer, library radix sort, scatter back ----
+__global__ void k_project_list(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab, const uint64_t* __restrict__ ref_accum,
+                               sq_map_params P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ lbase, uint32_t nlist,
+                               const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um, const uint32_t* __restrict__ n_uni,
+                               uint64_t* __restrict__ ckey, uint64_t* __restrict__ cval) {
+  // one wave per end, a lane per occurrence of the current uni-MEM (runs of up to maxOccsPerHit = 1000 entries)
+  const uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
+  if (wi >= nlist) return;
+  const uint32_t e = list[wi]; uint64_t w = lbase[wi]; const int L = rlen[e];
+  const sq_unimem_dev* in = um + (size_t)e * SQ_MAX_UNIMEMS;
+  for (uint32_t i = 0; i < n_uni[e]; ++i) {
+    const sq_unimem_dev m = in[i];
+    const uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
+    if (b - a > P.max_occ) continue;
+    const int ulen = (int)(d.uoff[m.unitig + 1] - d.uoff[m.unitig]);
+    for (uint64_t j = a + lane; j < b; j += 64) {
+      const uint64_t o = ctab[j]; const uint32_t tid = (uint32_t)(o >> 32); const bool ufw = (o >> 31) & 1; const int upos = (int)(o & 0x7FFFFFFF);
+      const int rpos = ufw ? upos + (int)m.ustart : upos + (ulen - ((int)m.ustart + (int)m.len));
+      const bool fw = (ufw == (m.fw != 0));
+      const uint32_t q = fw ? m.qpos : (uint32_t)(L - ((int)m.qpos + (int)m.len));
+      ckey[w + (j - a)] = ((uint64_t)e << 40) | (ref_accum[tid] + (uint64_t)rpos);
+      cval[w + (j - a)] = mem_pack_val(tid, q, m.len, fw);
+    }
+    w += b - a;
+  }
+}
+// sorted compact records -> the ends' slabs: record i of end e lands at mem_off[e] + (i - first record of e)
+__global__ void k_scatter_sorted(uint64_t total, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, const uint64_t* __restrict__ mem_off,
+                                 uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t key = skey[i]; const uint64_t e = key >> 40; const uint64_t lo_key = e << 40;
+  uint64_t lo = 0, hi = i;                       // first index whose key >= e << 40
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (skey[mid] < lo_key) lo = mid + 1; else hi = mid; }
+  const uint64_t dst = mem_off[e] + (i - lo);
+  mkey[dst] = key; mval[dst] = sval[i];
+}
+
+}  // namespace sqk

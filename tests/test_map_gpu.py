@@ -388,3 +388,48 @@ def test_reserved_class_table_and_workspace(small_world):
     assert r1["iters"] == r2["iters"] == r3["iters"] and np.array_equal(a1, a2) and np.array_equal(a1, a3)
     ctx.reset(); ctx.reserve(0, 0)                                     # after a reset the table is empty again
     ctx.free(); ost.free()
+
+
+def test_repeat_families_cover_every_mem_size_class(built):
+    # The fused projection / sort / chaining kernels pick a lane-group size by the MEM count of a read end (mem_kernels.h:
+    # <= 64, <= 1024, larger -> compact radix-sort path).  Two repeat families put reads in every class: family A (900
+    # transcripts share a 160-base element that comes in two variants differing by one base: a read across the variant
+    # site collects three uni-MEMs of 900 / ~450 / 900 occurrences = ~2250 MEMs), family B (150 copies of another element).
+    rng = np.random.default_rng(17)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    repA = rnd(160); repA2 = repA[:80] + comp[repA[80]] + repA[81:]; repB = rnd(160)
+    seqs = []
+    for i in range(1300):
+        body = rnd(int(rng.integers(500, 900)))
+        if i < 900: body = body[:250] + (repA if i % 2 else repA2) + body[250:]
+        elif i < 1050: body = body[:250] + repB + body[250:]
+        seqs.append(body)
+    names = ["t%d" % i for i in range(len(seqs))]
+    idx = api.SalmonIndex.build_mem(names, seqs, threads=4, keep_duplicates=True).to_device(0)
+    oidx = orc.OrcIndex(idx)
+    recs = []
+    def pair(s, p, fl):
+        r1 = s[p:p + 100]; r2 = "".join(comp[c] for c in reversed(s[p + fl - 100:p + fl]))
+        return [r1, r2] if rng.random() < 0.5 else [r2, r1]
+    for _ in range(150): recs += pair(seqs[int(rng.integers(0, 900))], int(rng.integers(225, 245)), int(rng.integers(200, 300)))      # mate 1 spans the variant site
+    for _ in range(150): recs += pair(seqs[int(rng.integers(0, 900))], int(rng.integers(170, 200)), int(rng.integers(200, 300)))      # partly inside the element
+    for _ in range(200): recs += pair(seqs[int(rng.integers(900, 1050))], int(rng.integers(200, 300)), int(rng.integers(200, 300)))   # family B
+    for _ in range(300): recs += pair(seqs[int(rng.integers(1050, 1300))], int(rng.integers(0, 200)), int(rng.integers(200, 300)))    # unique transcripts
+    seq = np.frombuffer("".join(recs).encode(), np.uint8).copy(); off = np.arange(0, len(recs) + 1, dtype=np.uint64) * np.uint64(100)
+    n = len(recs) // 2
+    opts = api.quant_opts()
+    ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=1024)
+    rb = api.make_read_batch(seq, off, n, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    um_c, mm_c, ch_c, cd_c = orc.map_taps(oidx, opts, rb, cap=1 << 23)
+    mm_g = ctx.tap(2, api.MEM_DTYPE)
+    per_end = np.bincount(mm_g["end"], minlength=2 * n)
+    assert per_end.max() > 1024 and np.any((per_end > 64) & (per_end <= 1024)) and np.any((per_end > 0) & (per_end <= 64))
+    _fields_equal(mm_g, mm_c, ["end", "tid", "rpos", "qpos", "len", "fw"], "MEMs")
+    ch_g = ctx.tap(3, api.CHAIN_DTYPE)
+    _fields_equal(ch_g, ch_c, ["end", "tid", "pos", "last_end", "fw", "n_mems", "score"], "chains")
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(oidx, opts, rb, threads=8)
+    assert st_g == st_c and np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.free()
