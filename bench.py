@@ -46,7 +46,10 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
     L = read_len
     return {
         "k_pack": nrec * (L + 8 + 64 + 32 + 2),
-        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 4 * 64 + st["num_seeds"] * (16 + 16 + 32),
+        # every probe reads one word (a 64 B sector) of the k-mer membership filter; a probe that passes (every hit; < 1 % of the misses)
+        # then walks 4 dependent sectors (pilot, slot record, string-pool word, unitig bounds) and a uni-MEM adds extension words,
+        # contig-table bounds and its record
+        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32),
         "scan_mems": nrec * (4 + 8),
         # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
         "k_mems": st["num_seeds"] * (16 + 16) + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (4 + 16 + 2 + 4),
@@ -211,7 +214,7 @@ def main():
         roof = {"kernel": single[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
             "traffic": traffic,
                 "avg_launch_ms": stage_rows[dom]["avg_ms"], "alg_bytes_per_launch": int(per_launch), "traffic_note": tnote,
-                "alg_bytes_note": "k_seed: 4 dependent 64 B lines per dictionary probe (pilot, slot record, string-pool word, unitig bounds) + per uni-MEM 64 B (extension words, contig-table bounds, record) + the packed read; DESIGN.md section 6"}
+                "alg_bytes_note": "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5); k_seed: 64 B filter word per probe + 4 dependent 64 B sectors (pilot, slot record, string-pool word, unitig bounds) per hit + 64 B per uni-MEM (extension words, contig-table bounds, record) + the packed read"}
     cpu = None; parity = None
     if a.cpu_sample > 0 and world == 1 and host_first is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,7 @@
 // hip/index_dev.hip — sq_index_load / sq_index_to_device / sq_index_free (seam B0).
 #include "device_index.h"
+#include <algorithm>
+#include <cstdlib>
 
 template <class T>
 static int up(sq_device_index* d, const std::vector<T>& v, const T** out) {
@@ -9,6 +11,22 @@ static int up(sq_device_index* d, const std::vector<T>& v, const T** out) {
   if (n) SQ_HIP_CHECK(hipMemcpy(p, v.data(), n, hipMemcpyHostToDevice));
   d->allocs.push_back(p); d->bytes += n; *out = (const T*)p;
   return SQ_OK;
+}
+
+// one wave per unitig (grid-stride): every k-mer of the string pool sets its four signature bits in its filter word
+__global__ void k_build_kfilter(const uint64_t* __restrict__ useq, const uint64_t* __restrict__ uoff, uint64_t num_unitigs, uint32_t k,
+                                unsigned long long* __restrict__ filter, uint64_t nwords) {
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint64_t u = wave; u < num_unitigs; u += nwaves) {
+    const uint64_t b = uoff[u], e = uoff[u + 1];
+    if (e - b < k) continue;
+    for (uint64_t p = b + lane; p + k <= e; p += 64) {
+      const uint64_t km = sq_fetch_bases(useq, p, k), rc = sq_revcomp(km, k);
+      const uint64_t h = sq_kf_hash(km < rc ? km : rc);
+      atomicOr(&filter[sq_kf_word(h, nwords)], (unsigned long long)sq_kf_mask(h));
+    }
+  }
 }
 
 void sq_device_index_free(sq_device_index* d) {
@@ -40,6 +58,17 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
   rc |= up(d, idx->ref_accum, &d->ref_accum); rc |= up(d, idx->ref_len, &d->ref_len); rc |= up(d, idx->ref_clen, &d->ref_clen);
   rc |= up(d, idx->refseq, &d->refseq); rc |= up(d, idx->ctab_off, &d->ctab_off); rc |= up(d, idx->ctab, &d->ctab);
   if (rc) { sq_device_index_free(d); return SQ_ERR_DEVICE; }
+  v.kfilter = nullptr; v.kfilter_words = 0;
+  if (!getenv("SQ_NO_KFILTER") && idx->num_kmers > 0) {   // k-mer membership filter (sq_internal.h): SQ_KF_BITS_PER_KEY bits per distinct k-mer
+    const uint64_t nwords = std::max<uint64_t>(1024, (idx->num_kmers * SQ_KF_BITS_PER_KEY + 63) / 64);
+    void* p = nullptr;
+    SQ_HIP_CHECK(hipMalloc(&p, nwords * 8));
+    d->allocs.push_back(p); d->bytes += nwords * 8;
+    SQ_HIP_CHECK(hipMemset(p, 0, nwords * 8));
+    k_build_kfilter<<<4096, 256>>>(v.useq, v.uoff, v.num_unitigs, idx->k, (unsigned long long*)p, nwords);
+    SQ_HIP_CHECK(hipDeviceSynchronize());
+    v.kfilter = (const uint64_t*)p; v.kfilter_words = nwords;
+  }
   d->k = idx->k; d->first_decoy = idx->first_decoy; d->num_refs = (uint32_t)idx->names.size();
   idx->dev = d;
   return SQ_OK;

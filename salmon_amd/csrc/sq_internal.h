@@ -90,7 +90,25 @@ struct sq_dict_view {
   const uint64_t* useq;           // string pool
   const uint64_t* uoff;           // [U+1]
   uint64_t num_unitigs;
+  const uint64_t* kfilter;        // k-mer membership filter (device only; nullptr = none): word-blocked Bloom, SQ_KF_BITS_PER_KEY bits per k-mer
+  uint64_t kfilter_words;
 };
+
+// k-mer membership filter in front of the dictionary.  ~80 % of the probes of a read are misses (the mismatchSeedSkip walk across a
+// sequencing error looks up ~10 k-mers that contain the error); a miss used to cost the whole minimizer scan (~300 integer ops) and
+// four dependent 64-byte sectors (pilot, slot record, two string-pool candidates).  One 8-byte word of this filter answers "not in
+// the index" for > 99 % of them: the word is picked by the hash of the canonical k-mer, four of its 64 bits are the k-mer's
+// signature.  No false negatives (every k-mer of every unitig is inserted when the index is uploaded: index_dev.hip), so results
+// are unchanged; false positives (~0.6 % at 16 bits per k-mer) just take the full path.  288 GB of HBM buys this: 2 bytes per k-mer.
+#define SQ_KF_BITS_PER_KEY 16
+SQ_HD uint64_t sq_kf_hash(uint64_t canonical_kmer) { return sq_mix64(canonical_kmer ^ 0xA24BAED4963EE407ULL); }
+SQ_HD uint64_t sq_kf_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)) | (1ULL << ((h >> 18) & 63)); }
+SQ_HD uint64_t sq_kf_word(uint64_t h, uint64_t nwords) {   // mulhi(h, nwords): the high bits of h choose the word, the low 24 the signature
+  const uint64_t a_lo = (uint32_t)h, a_hi = h >> 32, b_lo = (uint32_t)nwords, b_hi = nwords >> 32;   // portable 64 x 64 -> high 64
+  const uint64_t p0 = a_lo * b_lo, p1 = a_lo * b_hi, p2 = a_hi * b_lo, p3 = a_hi * b_hi;
+  const uint64_t mid = (p0 >> 32) + (uint32_t)p1 + (uint32_t)p2;
+  return p3 + (p1 >> 32) + (p2 >> 32) + (mid >> 32);
+}
 
 // displacement of a key hash by its bucket's pilot (PTHash: hash(key) xor hash(pilot), then reduce); one multiply each
 SQ_HD uint64_t sq_pilot_mix(uint64_t pilot) { return (pilot + 1) * 0x9E3779B97F4A7C15ULL; }
@@ -142,6 +160,10 @@ SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* uniti
   const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
   const uint64_t mm = sq_kmask(m);
   const uint64_t rc = sq_revcomp(kmer, k);
+  if (d.kfilter) {   // membership filter first: most misses end here after one 8-byte load
+    const uint64_t h = sq_kf_hash(kmer < rc ? kmer : rc), msk = sq_kf_mask(h);
+    if ((d.kfilter[sq_kf_word(h, d.kfilter_words)] & msk) != msk) return 0;
+  }
   // one pass over the window: the minimizer and the set of positions j that hold it (bit j of `at`),
   // with the strand of the canonical form at each of them (bit j of `fwc`: the read-orientation m-mer is the canonical one)
   uint32_t best = 0xFFFFFFFFu; uint64_t mini = ~0ULL; uint32_t at = 0, fwc = 0;
