@@ -132,7 +132,10 @@ typedef struct {
   uint8_t disable_chaining_heuristic; /* 0 */
   uint8_t ignore_incompat;    /* 1 (incompatPrior == 0) */
   uint8_t recover_orphans;    /* 0 (--recoverOrphans, SalmonQuantify.cpp:1356-1364; SPEC §a5) */
-  uint8_t _pad1[2];
+  uint8_t lib_autodetect;     /* 0; 1 = `-l A` (LibraryTypeDetector.hpp, SalmonQuantify.cpp:496-501,692-704): lib_* above hold the starting format
+                                 (IU paired / U single, nothing is penalised as incompatible meanwhile); once 50 000 alignments of the
+                                 library's read type have been seen the most likely format replaces it for the online model (SPEC §D8) */
+  uint8_t _pad1;
   /* online model (SalmonQuantify.cpp:426-1023) */
   uint32_t mini_batch_size;   /* 5000 (SalmonQuantify.cpp:150) */
   uint32_t num_pre_burnin_frags; /* 5000 */
@@ -275,6 +278,8 @@ typedef struct {          /* online-model state needed downstream (Transcript, F
   uint64_t num_observed, num_assigned, num_mapped_ub;
   int burned_in;
   uint64_t num_compatible;   /* assigned fragments with at least one library-compatible alignment (SalmonQuantify.cpp:811-815) */
+  uint32_t lib_format_id;    /* format the online model expects now: type | orientation << 1 | strandedness << 3 (LibraryFormat::formatID) */
+  uint32_t lib_detected;     /* 1 once `-l A` auto-detection has replaced the starting format */
 } sq_model_summary;
 int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
 /* per-transcript state after the online phase: log-mass (LOG_0 = +inf when none), unique/total
@@ -300,7 +305,9 @@ typedef struct {
   uint8_t init_uniform;         /* false; forced true in -e mode */
   uint8_t eq_class_mode;        /* combined weight = file weight verbatim (:862) */
   uint8_t no_rich_eq_classes;
-  uint8_t _pad[3];
+  uint8_t alt_init_mode;        /* --alternativeInitMode / --meta: mix the online estimate with (uniqueCount + 0.5) * 1e-3 * effLen instead
+                                   of the uniform abundance (CollapsedEMOptimizer.cpp:790-792, 817-818); needs sq_txp_in.unique_count */
+  uint8_t _pad[2];
   double vb_prior;              /* 1e-2 */
   double rel_diff_tolerance;    /* 0.01 */
   uint32_t max_iter;            /* 10000 */
@@ -323,6 +330,9 @@ typedef struct {
   double alpha_sum;
   double device_ms;             /* HIP-event time of the iteration loop */
   double ms_per_iter;
+  uint32_t num_degenerate;      /* classes dropped by markDegenerateClasses (CollapsedEMOptimizer.cpp:330-394): sum_i alpha0[tid_i] * w_i <= DBL_MIN;
+                                   they take no part in the optimisation ("Marked {} weighted equivalence classes as degenerate") */
+  uint32_t _pad;
 } sq_em_report;
 
 /* Full optimisation. eq arrays are host pointers (copied) — tid/w/count/off as in sq_eq_table.

@@ -801,6 +801,36 @@ struct QuantState {
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
   struct PendingMB { double logFM; std::vector<std::pair<uint32_t, uint64_t>> massInc; std::vector<uint32_t> fldCnt; bool anyFld; uint32_t minLen; };
   std::vector<PendingMB> pending;
+  // `-l A` (SPEC §D8): LibraryTypeDetector restated at mini-batch granularity
+  bool detectActive = false, detected = false; uint64_t detCounts[64] = {0}; uint64_t detSamples = 0;
+  void detect_format() {  // mostLikelyType, LibraryTypeDetector.hpp:33-152
+    sq_quant_opts& o = op.o;
+    if (o.lib_type == T_SE) {
+      uint64_t nf = 0, nr = 0;
+      for (int i = 0; i < 64; ++i) { int st = i >> 3; if (st == S_S) nf += detCounts[i]; if (st == S_A) nr += detCounts[i]; }
+      double ratio = (nf + nr > 0) ? (double)nf / (double)(nf + nr) : -1.0;
+      o.lib_orientation = O_NONE;
+      if (ratio < 0.0) o.lib_strand = S_U; else if (ratio < 0.3) o.lib_strand = S_A; else if (ratio < 0.7) o.lib_strand = S_U; else o.lib_strand = S_S;
+    } else {
+      uint64_t nsf = 0, nsr = 0, nin = 0, nout = 0, nsame = 0;
+      for (int i = 0; i < 64; ++i) {
+        int orient = (i >> 1) & 3, st = i >> 3; uint64_t c = detCounts[i];
+        if (st == S_S || st == S_SA) nsf += c;
+        if (st == S_A || st == S_AS) nsr += c;
+        if (orient == O_TOWARD) nin += c;
+        if (orient == O_AWAY) nout += c;
+        if (orient == O_SAME) nsame += c;
+      }
+      if (nin + nout + nsame > 0 && nsf + nsr > 0) {
+        uint64_t no = nin + nout + nsame;
+        double rin = (double)nin / (double)no, rout = (double)nout / (double)no, rsame = (double)nsame / (double)no; bool same = false;
+        if (rin >= rout && rin >= rsame) o.lib_orientation = O_TOWARD; else if (rout >= rin && rout >= rsame) o.lib_orientation = O_AWAY; else { o.lib_orientation = O_SAME; same = true; }
+        double rfw = (double)nsf / (double)(nsf + nsr);
+        if (rfw < 0.3) o.lib_strand = same ? S_A : S_AS; else if (rfw < 0.7) o.lib_strand = S_U; else o.lib_strand = same ? S_S : S_SA;
+      } else { o.lib_orientation = O_TOWARD; o.lib_strand = S_U; }
+    }
+    detectActive = false; detected = true;
+  }
   void flush_pending() {
     for (PendingMB& p : pending) {
       for (auto& tq : p.massInc) mass[tq.first] = sq_log_add(mass[tq.first], p.logFM + sq_log(sq_from_fixed(tq.second, SQ_MFRAC_BITS)));
@@ -836,6 +866,7 @@ struct QuantState {
       logEffLen[t] = sq_log(len);
     }
     libCounts.assign(64, 0);
+    detectActive = o->lib_autodetect != 0;
   }
   double forgetting_mass(uint64_t b) {  // ForgettingMassCalculator.hpp:30-40 (prefill recurrence)
     while (fm.size() <= b) {
@@ -990,9 +1021,15 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
   S.pending.push_back(std::move(pm));
   S.numAssigned += local; S.numObserved += (r1 - r0); S.readCounter += (r1 - r0); S.batchNo++;
   const bool burnNow = S.numAssigned >= o.num_burnin_frags && !S.burnedIn;
+  bool detectNow = false;
+  if (S.detectActive) {   // addSample (LibraryTypeDetector.hpp:155-160): every alignment whose observed format has the library's read type
+    for (uint64_t ai = off[r0]; ai < off[r1]; ++ai) if ((alns[ai].format_id & 1u) == o.lib_type) { S.detCounts[alns[ai].format_id & 63u]++; S.detSamples++; }
+    detectNow = S.detSamples >= 50000;
+  }
   const uint32_t W = std::max(1u, std::min(o.mini_batches_in_flight ? o.mini_batches_in_flight : 1u, 64u));
-  if (S.pending.size() >= W || burnNow) S.flush_pending();
+  if (S.pending.size() >= W || burnNow || detectNow) S.flush_pending();
   if (burnNow) S.burnin_finalize();
+  if (detectNow) S.detect_format();   // the following mini-batches expect the detected format
 }
 
 // ================================================================================================
@@ -1015,7 +1052,7 @@ static double canonical_sum(std::vector<double> x) {  // SPEC §D2
 struct EMProblem {
   uint32_t M; uint64_t E; std::vector<uint64_t> off, count; std::vector<uint32_t> tid; std::vector<double> cw;  // combined weights
   std::vector<uint64_t> t_off; std::vector<uint64_t> t_cls, t_pos;  // transcript-major incidence (class order)
-  std::vector<double> prior; std::vector<uint8_t> valid;
+  std::vector<double> prior;
 };
 static void em_setup(EMProblem& P, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o) {
   P.M = txp->num_txp; P.E = eq->num_classes; P.off.assign(eq->off, eq->off + P.E + 1); P.count.assign(eq->count, eq->count + P.E);
@@ -1118,7 +1155,18 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
   totalWeight = canonical_sum(pc);
   double uniformPrior = totalWeight / (double)M;
   double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
-  for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
+  const bool alt = o->alt_init_mode && txp->unique_count;   // metaGenomeMode or altInitMode (CollapsedEMOptimizer.cpp:817-818)
+  for (uint32_t i = 0; i < M; ++i) {
+    const double uni = alt ? ((double)txp->unique_count[i] + 0.5) * 1e-3 * txp->eff_len[i] : uniformPrior;   // alphasPrime (:790-792)
+    alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uni * (1.0 - fracObserved));
+  }
+  // markDegenerateClasses (:330-394): invalid classes are skipped by every update (:197, :289) = they count for nothing
+  uint32_t ndeg = 0;
+  for (uint64_t c = 0; c < P.E; ++c) {
+    double denom = 0.0;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) { double v = alpha[P.tid[i]] * P.cw[i]; if (!std::isnan(v)) denom += v; }
+    if (denom <= 2.2250738585072014e-308) { P.count[c] = 0; for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = 0.0; ++ndeg; }   // no count, no weight (the weights may be NaN)
+  }
   uint32_t it; bool conv; double maxRel;
   em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel);
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector :64-76
@@ -1131,6 +1179,7 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
     rep->alpha_sum = asum;
     rep->device_ms = 0;
     rep->ms_per_iter = 0;
+    rep->num_degenerate = ndeg; rep->_pad = 0;
   }
   return asum < 2.2250738585072014e-308 ? SQ_ERR_STATE : SQ_OK;
 }
@@ -1452,6 +1501,7 @@ void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
 void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }
 void orc_state_summary(orc_state* s, sq_model_summary* m) {
+  m->lib_format_id = (uint32_t)(s->S.op.o.lib_type | (s->S.op.o.lib_orientation << 1) | (s->S.op.o.lib_strand << 3)); m->lib_detected = s->S.detected ? 1u : 0u;
   m->num_observed = s->S.numObserved;
   m->num_assigned = s->S.numAssigned;
   m->num_mapped_ub = s->S.numMappedUB;

@@ -271,16 +271,16 @@ class QuantContext:
         check(lib().sq_eq_finish(self.h, C.byref(tt)), "sq_eq_finish")
         return eq
 
-    def em_optimize(self, eff_len, projected=None, opts=None):
+    def em_optimize(self, eff_len, projected=None, opts=None, unique=None):
         """CollapsedEMOptimizer::optimize over the classes this context accumulated (sq_em_optimize with eq = NULL):
         the optimizer reads the canonical-order export that already sits in HBM."""
         o = opts or em_opts()
-        txp = make_txp_in(eff_len, projected)
+        txp = make_txp_in(eff_len, projected, unique)
         out = np.zeros(txp.num_txp)
         rep = capi.EmReport()
         check(lib().sq_em_optimize(self.h, None, C.byref(txp), C.byref(o), _ptr(out, C.c_double), C.byref(rep)), "sq_em_optimize")
         return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum,
-                         device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+                         device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter, num_degenerate=rep.num_degenerate)
 
     def eq_export_device(self):
         """Device pointers of the canonical-order export (sq_eq_export_device): dict field -> (ptr, count, numpy dtype)."""
@@ -309,7 +309,7 @@ class QuantContext:
         s = capi.ModelSummary()
         check(lib().sq_model_summary_get(self.h, C.byref(s)), "sq_model_summary_get")
         return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub),
-            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible), lib_format_id=int(s.lib_format_id), lib_detected=int(s.lib_detected))
 
     def lib_counts(self):
         out = np.zeros(64, np.uint64)
@@ -342,16 +342,16 @@ def make_txp_in(eff_len, projected=None, unique=None):
     return t
 
 
-def em_optimize(eq, eff_len, projected=None, opts=None, device=0):
+def em_optimize(eq, eff_len, projected=None, opts=None, device=0, unique=None):
     """CollapsedEMOptimizer::optimize on the GPU. Returns (alphas, report dict)."""
     o = opts or em_opts()
     t = eq.table()
-    txp = make_txp_in(eff_len, projected)
+    txp = make_txp_in(eff_len, projected, unique)
     out = np.zeros(txp.num_txp)
     rep = capi.EmReport()
     check(lib().sq_em_optimize_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(out, C.c_double), C.byref(rep)), "sq_em_optimize_dev")
     return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum,
-                     device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+                     device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter, num_degenerate=rep.num_degenerate)
 
 
 def em_steps(eq, eff_len, alpha_in, iters, opts=None, device=0):

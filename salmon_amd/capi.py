@@ -31,7 +31,7 @@ class QuantOpts(C.Structure):
                 ("post_merge_chain_sub_thresh", f64), ("orphan_chain_sub_thresh", f64), ("score_exp", f64),
                 ("decoy_threshold", f64), ("min_aln_prob", f64),
                 ("hard_filter", u8), ("allow_dovetail", u8), ("allow_orphans", u8), ("disable_chaining_heuristic", u8),
-                ("ignore_incompat", u8), ("recover_orphans", u8), ("_pad1", u8 * 2),
+                ("ignore_incompat", u8), ("recover_orphans", u8), ("lib_autodetect", u8), ("_pad1", u8),
                 ("mini_batch_size", u32), ("num_pre_burnin_frags", u32), ("num_burnin_frags", u64),
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
@@ -69,12 +69,13 @@ class EqTable(C.Structure):
 
 
 class ModelSummary(C.Structure):
-    _fields_ = [("num_observed", u64), ("num_assigned", u64), ("num_mapped_ub", u64), ("burned_in", C.c_int), ("num_compatible", u64)]
+    _fields_ = [("num_observed", u64), ("num_assigned", u64), ("num_mapped_ub", u64), ("burned_in", C.c_int), ("num_compatible", u64),
+                ("lib_format_id", u32), ("lib_detected", u32)]
 
 
 class EmOpts(C.Structure):
     _fields_ = [("use_vbem", u8), ("per_transcript_prior", u8), ("init_uniform", u8), ("eq_class_mode", u8),
-                ("no_rich_eq_classes", u8), ("_pad", u8 * 3), ("vb_prior", f64), ("rel_diff_tolerance", f64),
+                ("no_rich_eq_classes", u8), ("alt_init_mode", u8), ("_pad", u8 * 2), ("vb_prior", f64), ("rel_diff_tolerance", f64),
                 ("max_iter", u32), ("min_iter", u32), ("num_required_fragments", f64)]
 
 
@@ -84,7 +85,7 @@ class TxpIn(C.Structure):
 
 class EmReport(C.Structure):
     _fields_ = [("iters", u32), ("converged", C.c_int), ("max_rel_diff", f64), ("alpha_sum", f64), ("device_ms", f64),
-                ("ms_per_iter", f64)]
+                ("ms_per_iter", f64), ("num_degenerate", u32), ("_pad", u32)]
 
 
 class GibbsOpts(C.Structure):

@@ -25,6 +25,30 @@ static bool flag(int argc, char** argv, const char* a) {
   for (int i = 2; i < argc; ++i) if (!strcmp(argv[i], a)) return true;
   return false;
 }
+// Every option must be one this driver implements: a reference option that is silently ignored would change the semantics of the run
+// (e.g. --seqBias, --gcBias, --posBias, --incompatPrior).  `takes` = options followed by one value (read-file options: one or more).
+static void check_args(int argc, char** argv, const std::vector<const char*>& takes, const std::vector<const char*>& flags, const std::vector<const char*>& multi) {
+  auto in = [](const std::vector<const char*>& v, const char* a) { for (auto x : v) if (!strcmp(x, a)) return true; return false; };
+  for (int i = 2; i < argc; ++i) {
+    const char* a = argv[i];
+    if (in(multi, a)) { if (i + 1 >= argc) { fprintf(stderr, "[salmon-hip] option %s needs a value\n", a); exit(1); } ++i; while (i + 1 < argc && argv[i + 1][0] != '-') ++i; continue; }
+    if (in(takes, a)) { if (i + 1 >= argc) { fprintf(stderr, "[salmon-hip] option %s needs a value\n", a); exit(1); } ++i; continue; }
+    if (in(flags, a)) continue;
+    fprintf(stderr, "[salmon-hip] option %s is not supported by this driver (no silent fallback: a salmon option that is ignored would change the results)\n", a);
+    exit(1);
+  }
+}
+// values of a read-file option: "-1 a.fq b.fq" and "-1 a.fq,b.fq" both name two files
+static std::vector<std::string> file_args(int argc, char** argv, const char* a, const char* b) {
+  std::vector<std::string> out;
+  for (int i = 2; i + 1 < argc; ++i) if (!strcmp(argv[i], a) || !strcmp(argv[i], b)) {
+    for (int j = i + 1; j < argc && (j == i + 1 || argv[j][0] != '-'); ++j) {
+      std::string cur;
+      for (const char* p = argv[j]; ; ++p) { if (*p == ',' || !*p) { if (!cur.empty()) out.push_back(cur); cur.clear(); if (!*p) break; } else cur.push_back(*p); }
+    }
+  }
+  return out;
+}
 
 struct Fastq {
   gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, len = 0;
@@ -53,6 +77,8 @@ struct Fastq {
 };
 
 static int cmd_index(int argc, char** argv) {
+  check_args(argc, argv, {"-t", "--transcripts", "-i", "--index", "-k", "--kmerLen", "-m", "--minimizerLen", "-p", "--threads", "-d", "--decoys"},
+             {"--keepDuplicates", "--no-clip", "-n", "--gencode"}, {});
   const char* t = arg(argc, argv, "-t", "--transcripts"); const char* i = arg(argc, argv, "-i", "--index");
   if (!t || !i) {
     fprintf(stderr,
@@ -78,13 +104,14 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 
 // posterior samples into aux_info/bootstrap (MappingPipelineStages.cpp:60-95): --numBootstraps wins over --numGibbsSamples
-static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop,
+struct SampInfo { uint64_t n = 0; const char* type = "none"; };   // meta_info.json: num_bootstraps / samp_type (GZipWriter.cpp:455-470)
+static SampInfo run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop,
     const double* alphas, uint32_t M,
                          const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped) {
   const char* v;
   const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv,
       "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
-  if (!nb && !ng) return;
+  if (!nb && !ng) return SampInfo();
   const uint64_t seed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
   sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
   if (nb) { if (sq_bootstrap_dev(device, t, tx, eop, nb, seed, num_mapped, boot_cb, bw)) die("bootstrap"); }
@@ -96,11 +123,15 @@ static void run_sampling(int argc, char** argv, int device, const sq_eq_table* t
     go.per_transcript_prior = eop->per_transcript_prior; go.vb_prior = eop->vb_prior;
     if (sq_gibbs_dev(device, t, tx, &go, alphas, ng, seed, num_mapped, boot_cb, bw)) die("Gibbs sampling");
   }
-  fprintf(stderr, "[salmon-hip] wrote %llu %s samples\n", (unsigned long long)sq_boot_writer_close(bw), nb ? "bootstrap" : "Gibbs");
+  SampInfo si; si.n = sq_boot_writer_close(bw); si.type = nb ? "bootstrap" : "gibbs";
+  fprintf(stderr, "[salmon-hip] wrote %llu %s samples\n", (unsigned long long)si.n, nb ? "bootstrap" : "Gibbs");
+  return si;
 }
 
 // salmon quant -e eq_classes.txt[.gz] -o out : EM straight from a dumped table (SalmonQuantifyAlignments.cpp:1407-1441)
 static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
+  check_args(argc, argv, {"-e", "--eqclasses", "-o", "--output", "--device", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor"},
+             {"--useEM", "--useVBOpt", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw"}, {});
   const char* odir = arg(argc, argv, "-o", "--output");
   if (!odir) {
     fprintf(stderr, "usage: salmon-hip quant -e eq_classes.txt[.gz] -o out_dir [--useEM] [--numBootstraps N | --numGibbsSamples N]\n");
@@ -121,7 +152,14 @@ static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
   if (sq_write_quant_sf_names((od + "/quant.sf").c_str(), M, names.data(), nullptr, sq_eq_file_eff_lens(F), alphas.data(),
       0.0)) die("quant.sf");
   uint64_t nm = 0; for (uint64_t c = 0; c < t.num_classes; ++c) nm += t.count[c];
-  run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, nm);
+  const SampInfo si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, nm);
+  if (FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w")) {   // GZipWriter::writeMeta keys that exist in eq-class mode
+    fprintf(mf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"samp_type\": \"%s\",\n  \"opt_type\": \"%s\",\n  \"quant_errors\": [],\n"
+                "  \"num_libraries\": 0,\n  \"num_bootstraps\": %llu,\n  \"num_valid_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_mapped\": %llu,\n  \"num_em_iterations\": %u,\n"
+                "  \"mapping_type\": \"eqclasses\"\n}\n", sq_version(), si.type, eop.use_vbem ? "vb" : "em", (unsigned long long)si.n, M,
+            (unsigned long long)t.num_classes, (unsigned long long)nm, rep.iters);
+    fclose(mf);
+  }
   fprintf(stderr, "[salmon-hip] %llu eq-classes, %u %s iterations -> %s/quant.sf\n", (unsigned long long)t.num_classes, rep.iters,
       eop.use_vbem ? "VBEM" : "EM", odir);
   sq_eq_file_free(F);
@@ -140,13 +178,18 @@ static int cmd_quant(int argc, char** argv) {
         "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
     return 1;
   }
-  std::string lib = lt ? lt : (ru ? "U" : "IU");
+  check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "--device", "--batch", "--lanes", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
+                          "--rangeFactorizationBins", "--mismatchSeedSkip", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor",
+                          "--incompatPrior", "--maxOccsPerHit", "--maxReadOcc", "--fldMax", "--fldMean", "--fldSD", "--forgettingFactor", "--numPreAuxModelSamples",
+                          "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth"},
+             {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
+              "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses"},
+             {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
+  std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
-  if (lib == "A") {
-    fprintf(stderr,
-        "[salmon-hip] -l A (auto-detection) is thread-timing dependent in the reference (SalmonQuantify.cpp:496-501); pass an explicit library type\n");
-    return 1;
-  }
+  const bool autodetect = lib == "A";
+  if (autodetect) lib = ru ? "U" : "IU";   // enableAutodetect(): the library starts unstranded / inward (LibraryTypeUtils.cpp:110-146)
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
   const char* v;
   int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0;
@@ -159,6 +202,29 @@ static int cmd_quant(int argc, char** argv) {
   qo.lib_type = li->second[0];
   qo.lib_orientation = li->second[1];
   qo.lib_strand = li->second[2];
+  qo.lib_autodetect = autodetect ? 1 : 0;
+  if ((v = arg(argc, argv, "--incompatPrior"))) { qo.incompat_prior = atof(v) > 0 ? std::log(atof(v)) : 0.0; qo.ignore_incompat = atof(v) == 0.0; }   // QuantOptionsUtils.cpp:608-612
+  if ((v = arg(argc, argv, "--maxOccsPerHit"))) qo.max_occs_per_hit = (uint32_t)atoi(v);
+  if ((v = arg(argc, argv, "--maxReadOcc"))) qo.max_read_occs = (uint32_t)atoi(v);
+  if ((v = arg(argc, argv, "--fldMax"))) qo.frag_len_max = (uint32_t)atoi(v);
+  if ((v = arg(argc, argv, "--fldMean"))) qo.fld_mean = atof(v);
+  if ((v = arg(argc, argv, "--fldSD"))) qo.fld_sd = atof(v);
+  if ((v = arg(argc, argv, "--forgettingFactor"))) qo.forgetting_factor = atof(v);
+  if ((v = arg(argc, argv, "--numPreAuxModelSamples"))) qo.num_pre_burnin_frags = (uint32_t)atoi(v);
+  if ((v = arg(argc, argv, "--numAuxModelSamples"))) qo.num_burnin_frags = strtoull(v, nullptr, 10);
+  if ((v = arg(argc, argv, "--scoreExp"))) qo.score_exp = atof(v);
+  if ((v = arg(argc, argv, "--decoyThreshold"))) qo.decoy_threshold = atof(v);
+  if ((v = arg(argc, argv, "--minAlnProb"))) qo.min_aln_prob = atof(v);
+  if ((v = arg(argc, argv, "--ma"))) qo.match_score = atoi(v);
+  if ((v = arg(argc, argv, "--mp"))) qo.mismatch_penalty = atoi(v);
+  if ((v = arg(argc, argv, "--go"))) qo.gap_open = atoi(v);
+  if ((v = arg(argc, argv, "--ge"))) qo.gap_extend = atoi(v);
+  if ((v = arg(argc, argv, "--bandwidth"))) qo.bandwidth = atoi(v);
+  if ((v = arg(argc, argv, "-p", "--threads"))) qo.mini_batches_in_flight = (uint32_t)std::max(1, std::min(64, atoi(v)));   // workers = mini-batches in flight (SPEC D1)
+  if (flag(argc, argv, "--noLengthCorrection")) qo.no_length_correction = 1;
+  if (flag(argc, argv, "--noEffectiveLengthCorrection")) qo.no_eff_length_correction = 1;
+  if (flag(argc, argv, "--noFragLengthDist")) qo.use_frag_len_dist = 0;
+  if (flag(argc, argv, "--noSingleFragProb")) qo.model_single_frag_prob = 0;
   if ((v = arg(argc, argv, "--minScoreFraction"))) qo.min_score_fraction = atof(v);
   if ((v = arg(argc, argv, "--consensusSlack"))) qo.consensus_slack = atof(v);
   if ((v = arg(argc, argv, "--rangeFactorizationBins"))) qo.range_factorization_bins = (uint32_t)atoi(v);
@@ -172,19 +238,9 @@ static int cmd_quant(int argc, char** argv) {
   if (sq_ctx_reserve(ctx, 0, 0)) die("reserving end-of-job buffers");   // the reference pre-sizes its eq-class map the same way (EquivalenceClassBuilder.hpp:140)
   // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
   // the mapping lanes: up to `lanes` batches are in flight (H2D + mapping) while the next one is parsed
-  auto split = [](const char* s) {
-    std::vector<std::string> v;
-    std::string cur;
-    for (const char* p = s; ; ++p) {
-      if (*p == ',' || *p == ' ' || !*p) {
-        if (!cur.empty()) v.push_back(cur);
-        cur.clear();
-        if (!*p) break;
-      } else cur.push_back(*p);
-    }
-    return v;
-  };
-  std::vector<std::string> l1 = split(paired ? r1 : ru), l2 = paired ? split(r2) : std::vector<std::string>();
+  std::vector<std::string> l1 = paired ? file_args(argc, argv, "-1", "--mates1") : file_args(argc, argv, "-r", "--unmatedReads");
+  std::vector<std::string> l2 = paired ? file_args(argc, argv, "-2", "--mates2") : std::vector<std::string>();
+  if (paired && l1.size() != l2.size()) { fprintf(stderr, "[salmon-hip] -1 names %zu files, -2 names %zu\n", l1.size(), l2.size()); return 1; }
   std::vector<const char*> p1, p2; for (auto& x : l1) p1.push_back(x.c_str()); for (auto& x : l2) p2.push_back(x.c_str());
   const uint32_t lanes = (v = arg(argc, argv, "--lanes")) ? (uint32_t)std::max(1, std::min(4, atoi(v))) : 2;
   if (sq_ctx_set_lanes(ctx, (int)lanes)) die("lanes");
@@ -212,18 +268,20 @@ static int cmd_quant(int argc, char** argv) {
   while (!inflight.empty()) finish_one();
   sq_reader_close(rd);
   fprintf(stderr, "\n");
-  const uint32_t M = sq_index_num_refs(idx);
+  // decoys are dropped before inference and output (readExp.dropDecoyTranscripts(), SalmonQuantify.cpp:2479): M = num_valid_targets;
+  // no alignment ever names a decoy (SalmonMappingUtils.hpp:407-485), so the eq-class labels already lie below M
+  const uint32_t Mall = sq_index_num_refs(idx), M = sq_index_first_decoy(idx);
   sq_eq_table t{}; if (sq_eq_finish(ctx, &t)) die("eq finish");
   std::vector<uint64_t> eo(t.num_classes + 1), ec(t.num_classes);
   std::vector<uint32_t> et(t.num_labels);
   std::vector<double> ew(t.num_labels);
   t.off = eo.data(); t.tid = et.data(); t.w = ew.data(); t.count = ec.data(); if (sq_eq_finish(ctx, &t)) die("eq finish");
-  std::vector<double> lm(M), le(M), proj(M), eff(M), alphas(M, 0.0); std::vector<uint64_t> uq(M), tc(M);
+  std::vector<double> lm(Mall), le(Mall), proj(M), eff(M), alphas(M, 0.0); std::vector<uint64_t> uq(Mall), tc(Mall);
   if (sq_model_fetch(ctx, lm.data(), uq.data(), tc.data(), le.data())) die("model fetch");
   for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
   sq_model_summary ms{}; sq_model_summary_get(ctx, &ms);
   mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
-  sq_em_report rep{};
+  sq_em_report rep{}; SampInfo si;
   if (ms.num_assigned < 10) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
     fprintf(stderr, "[salmon-hip] only %llu fragments were assigned; writing empty quantification\n", (unsigned long long)ms.num_assigned);
   } else {
@@ -234,20 +292,30 @@ static int cmd_quant(int argc, char** argv) {
     if (flag(argc, argv, "--initUniform")) eop.init_uniform = 1;
     if ((v = arg(argc, argv, "--vbPrior"))) eop.vb_prior = atof(v);
     if (flag(argc, argv, "--perNucleotidePrior")) eop.per_transcript_prior = 0;
+    if (flag(argc, argv, "--alternativeInitMode") || flag(argc, argv, "--meta")) eop.alt_init_mode = 1;
+    if (flag(argc, argv, "--noRichEqClasses")) eop.no_rich_eq_classes = 1;
+    if (qo.no_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = 100.0;                              // CollapsedEMOptimizer.cpp:783-785
+    else if (qo.no_eff_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = (double)sq_index_ref_len(idx, i);   // :780-782
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
     if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
     std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_index_ref_name(idx, i);
-    run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned);
+    si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned);
   }
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
   { uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
     const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
-    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), qo.lib_type, qo.lib_orientation, qo.lib_strand,
+    const uint8_t dt = (uint8_t)(ms.lib_format_id & 1), dor = (uint8_t)((ms.lib_format_id >> 1) & 3), dst = (uint8_t)(ms.lib_format_id >> 3);   // the detected format with -l A
+    for (auto& kv : kLib) if (kv.second[0] == dt && kv.second[1] == dor && kv.second[2] == dst) lib = kv.first;
+    if (autodetect) fprintf(stderr, "[salmon-hip] Automatically detected most likely library type as %s%s\n", lib.c_str(), ms.lib_detected ? "" : " (fewer than 50000 samples: the starting format was kept)");
+    if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), dt, dor, dst,
         lc, ms.num_assigned,
         ms.num_compatible)) die("lib_format_counts"); }
+  double fl_mean = 0.0, fl_sd = 0.0;
   { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
     std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
+    { double tot = 0, m1 = 0, m2 = 0; for (int i = 0; i <= 1000; ++i) { const double p = std::exp(fld[i]); tot += p; m1 += p * i; m2 += p * (double)i * i; }
+      if (tot > 0) { fl_mean = m1 / tot; fl_sd = std::sqrt(std::max(0.0, m2 / tot - fl_mean * fl_mean)); } }
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
     if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv,
@@ -262,7 +330,9 @@ static int cmd_quant(int argc, char** argv) {
     fprintf(mf,
         "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
                 "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
-                "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f\n}\n",
+                "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f,\n"
+                "  \"samp_type\": \"%s\",\n  \"num_bootstraps\": %llu,\n  \"num_libraries\": 1,\n  \"frag_length_mean\": %.6f,\n  \"frag_length_sd\": %.6f,\n  \"frag_dist_length\": 1001,\n"
+                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u\n}\n",
             sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes,
                 (unsigned long long)nfrag,
                 (unsigned long long)ms.num_assigned,
@@ -271,7 +341,7 @@ static int cmd_quant(int argc, char** argv) {
                 (unsigned long long)tot.num_mappings_filtered,
             nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
                 rep.iters,
-                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs);
+                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate);
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");

@@ -390,6 +390,17 @@ __global__ void k_prep_cw(uint32_t E, uint32_t M, const uint64_t* __restrict__ o
   const double wn = 1.0 / wsum;
   for (uint64_t i = a; i < b; ++i) cw[i] = cw[i] * wn;
 }
+// markDegenerateClasses (CollapsedEMOptimizer.cpp:330-394): a class whose sum_i alpha0[tid_i] * combinedWeight_i (NaN terms skipped, class
+// order) is <= minEQClassWeight is set invalid; the update rules then skip it (:197, :289) — the same as a zero count here
+__global__ void k_mark_degenerate(uint32_t E, const uint64_t* __restrict__ off, const uint32_t* __restrict__ tid, double* __restrict__ cw,
+                                  const double* __restrict__ alpha0, double* __restrict__ cnt_f, uint32_t* __restrict__ ndrop) {   // cw is written: the dropped class loses its (possibly NaN) weights
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
+  double denom = 0.0;
+  for (uint64_t i = off[c]; i < off[c + 1]; ++i) { const double v = alpha0[tid[i]] * cw[i]; if (!(v != v)) denom += v; }
+  if (denom <= 2.2250738585072014e-308) {   // count 0 and weights 0: denom = 0 in every update -> inv = 0 -> no term (k_class, k_l1)
+    cnt_f[c] = 0.0; for (uint64_t i = off[c]; i < off[c + 1]; ++i) cw[i] = 0.0; atomicAdd(ndrop, 1u);
+  }
+}
 __global__ void k_prep_prior(uint32_t M, const double* __restrict__ eff, double vb_prior, int per_txp, double* __restrict__ prior) {   // populatePriorAlphas_ :82-99
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t < M) prior[t] = per_txp ? vb_prior : vb_prior * eff[t];
 }
@@ -658,6 +669,11 @@ struct EmSession {
       else SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
     }
     SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st));
+    num_degenerate = 0;
+    if (mark_degenerate && E) {   // optimize() only: the initial alphas decide (flags[3] counts the dropped classes)
+      k_mark_degenerate<<<(E + TB - 1) / TB, TB, 0, st>>>(E, d.off, d.tid, d_cw.p, d_a0.p, d_cnt.p, d_flags.p + 3);
+      SQ_HIP_CHECK(hipMemcpyAsync(&num_degenerate, d_flags.p + 3, 4, hipMemcpyDeviceToHost, st));
+    }
     SQ_HIP_CHECK(hipMemsetAsync(d_maxrel.p, 0, 8, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_log.p, 0, 8, st));
     d.min_iter = (mode == 0) ? min_iter : 0xFFFFFFFFu;
@@ -724,19 +740,20 @@ struct EmSession {
     unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
     if (rep) {
       rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
-      rep->device_ms = ms; rep->ms_per_iter = executed ? ms / (double)executed : 0.0; rep->alpha_sum = 0;
+      rep->device_ms = ms; rep->ms_per_iter = executed ? ms / (double)executed : 0.0; rep->alpha_sum = 0; rep->num_degenerate = num_degenerate; rep->_pad = 0;
     }
     return SQ_OK;
   }
   double* result_dev = nullptr; double* h_stage = nullptr;
+  bool mark_degenerate = false; uint32_t num_degenerate = 0;
 };
 
 int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode,
     uint32_t fixed_iters, sq_em_report* rep,
-    const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr) {
+    const sq_eq_dev_csr* dv = nullptr, EmArena* arena = nullptr, hipStream_t lent = nullptr, bool mark_degenerate = false) {
   PhaseTimer pt("em");
   int rc;
-  { EmSession S; S.arena = arena; if (lent) { S.st = lent; S.own_stream = false; } rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
+  { EmSession S; S.arena = arena; S.mark_degenerate = mark_degenerate; if (lent) { S.st = lent; S.own_stream = false; } rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
     pt.mark("setup");
     rc = S.run(alpha, mode, fixed_iters, o->min_iter, rep);
     pt.mark("run"); }
@@ -852,8 +869,12 @@ int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* 
   double uniformPrior = totalWeight / (double)M;
   double fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
   std::vector<double> alpha(M);
-  for (uint32_t i = 0; i < M; ++i) alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uniformPrior * (1.0 - fracObserved));
-  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep, dv, arena_slot ? (EmArena*)*arena_slot : nullptr, (hipStream_t)lent_stream);
+  const bool alt = o->alt_init_mode && txp->unique_count;   // metaGenomeMode or altInitMode (:817-818)
+  for (uint32_t i = 0; i < M; ++i) {
+    const double uni = alt ? ((double)txp->unique_count[i] + 0.5) * 1e-3 * txp->eff_len[i] : uniformPrior;   // alphasPrime (:790-792)
+    alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uni * (1.0 - fracObserved));
+  }
+  int rc = run_em(device, eq, txp, o, alpha, 0, 0, rep, dv, arena_slot ? (EmArena*)*arena_slot : nullptr, (hipStream_t)lent_stream, true);
   if (rc) return rc;
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector (:64-76), minAlpha 1e-8
   double asum = canonical_sum_host(alpha);

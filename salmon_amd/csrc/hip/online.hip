@@ -73,6 +73,10 @@ struct sq_online_dev {
   sq_dbuf<uint32_t> merge_slot;
   std::vector<double> fm_host;
   uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0, group_no = 0; bool burned_known = false;
+  // `-l A` (SPEC §D8): per-format sample counts of the mini-batches seen so far while detection is active
+  bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
+  sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
+  sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
 };
 
 namespace {
@@ -129,11 +133,27 @@ struct OnlineView {
   uint32_t* touched; uint32_t* touched_n; uint32_t* tflag;
 };
 
-__global__ void k_flag_compat(uint32_t n, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o,
+// LibraryTypeDetector::addSample (LibraryTypeDetector.hpp:155-160): every alignment whose observed format has the library's read type
+// is a sample; block b histograms the samples of mini-batch b by format id
+__global__ void k_mb_samples(uint32_t n, uint32_t mb, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, uint32_t lib_type,
+                             uint32_t* __restrict__ out /*[nmb][64]*/) {
+  __shared__ uint32_t h[64];
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t r0 = (uint64_t)blockIdx.x * mb, r1 = min((uint64_t)n, r0 + mb);
+  for (uint64_t i = aln_off[r0] + threadIdx.x; i < aln_off[r1]; i += blockDim.x) {
+    const uint32_t f = aln[i].format_id;
+    if ((f & 1u) == lib_type) atomicAdd(&h[f & 63u], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) out[(size_t)blockIdx.x * 64 + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ void k_flag_compat(uint32_t n, uint32_t r_start, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, sq_quant_opts o,
     uint32_t* __restrict__ flag) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r > n) return;
-  if (r == n) { flag[n] = 0; return; }
+  if (r == n || r < r_start) { flag[r] = 0; return; }   // rows before r_start belong to an earlier segment of the batch (format switch, SPEC §D8)
   uint32_t f = 0;
   for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; ++i) {
     const sq_aln a = aln[i];
@@ -816,6 +836,7 @@ int sq_online_create(sq_ctx* c) {
                  o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
   const sq_quant_opts& q = c->opts;
+  o->detect_active = q.lib_autodetect != 0;
   std::vector<double> hist(1024, SQ_LOG_0), ambig(2048, 0.0), pm(M), le(M), mass(M, SQ_LOG_0); double tot0 = 0.0;
   for (int i = 0; i <= 1000; ++i) {  // FragmentLengthDistribution.cpp:38-55 (alpha = 1)
     double nm = phi((i + 0.5 - q.fld_mean) / q.fld_sd) - phi((i - 0.5 - q.fld_mean) / q.fld_sd);
@@ -892,6 +913,8 @@ void sq_online_free(sq_ctx* c) {
   o->touched.free_();
   o->touched_n.free_();
   o->tflag.free_();
+  o->mb_samples.free_();
+  o->assigned_prefix_b.free_();
   o->mass_acc.free_();
   o->uniq.free_();
   o->total.free_();
@@ -1072,7 +1095,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
       (PreAln*)o->pre.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
-  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, d_aln_off, d_aln, q, o->assigned_flag.p);
+  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
     if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
@@ -1085,12 +1108,19 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   if (o->rh2.n < nmb + 2) { sq_set_error("internal: bounds scratch too small"); return SQ_ERR_STATE; }
   k_gather_bounds<<<nblk(nmb + 1), TB, 0, st>>>(o->assigned_prefix.p, mb, n, nmb, o->rh2.p);   // rh2 is rewritten by the mini-batches below
   SQ_HIP_CHECK(hipMemcpyAsync(bound.data(), o->rh2.p, (size_t)(nmb + 1) * 8, hipMemcpyDeviceToHost, st));
+  std::vector<uint32_t> mbs;   // `-l A`: per mini-batch, samples by observed format
+  if (o->detect_active) {
+    if (o->mb_samples.ensure((size_t)nmb * 64)) { sq_set_error("device allocation failed (library-type samples)"); return SQ_ERR_NOMEM; }
+    k_mb_samples<<<nmb, TB, 0, st>>>(n, mb, d_aln_off, d_aln, q.lib_type, o->mb_samples.p);
+    mbs.resize((size_t)nmb * 64);
+    SQ_HIP_CHECK(hipMemcpyAsync(mbs.data(), o->mb_samples.p, (size_t)nmb * 64 * 4, hipMemcpyDeviceToHost, st));
+  }
   unsigned long long hctr[8];
   SQ_HIP_CHECK(hipMemcpyAsync(hctr, o->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st));
   mark("pre-launches");
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   mark("bounds-sync");
-  const uint64_t assigned_base = hctr[0];
+  uint64_t assigned_base = hctr[0];
   bool burned_host = hctr[1] != 0;
   // Groups of up to W consecutive mini-batches share one model snapshot (SPEC §D1: the reference's W = numThreads workers read a
   // shared, slightly stale model, SalmonQuantify.cpp:2390-2403): ONE k_mini_batch over the group's fragments + ONE k_apply that
@@ -1098,10 +1128,14 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   // reaches numBurninFrags (the burn-in tables are made right there, as with W = 1) and at the end of the mapped batch.
   const uint32_t W = o->inflight;
   for (uint32_t b = 0; b < nmb;) {
-    FmArr FM; uint32_t nw = 0; bool burn_now = false; const uint32_t b0 = b;
-    while (b < nmb && nw < W && !burn_now) {
+    FmArr FM; uint32_t nw = 0; bool burn_now = false, detect_now = false; const uint32_t b0 = b;
+    while (b < nmb && nw < W && !burn_now && !detect_now) {
       FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++);
       burn_now = !burned_host && assigned_base + bound[b + 1] >= q.num_burnin_frags;
+      if (o->detect_active) {   // the group also ends at the mini-batch that completes the detector's 50 000 samples
+        for (int f = 0; f < 64; ++f) { o->det_counts[f] += mbs[(size_t)b * 64 + f]; o->det_samples += mbs[(size_t)b * 64 + f]; }
+        detect_now = o->det_samples >= 50000;
+      }
       ++b;
     }
     for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
@@ -1120,6 +1154,28 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       burned_host = true;
     }
     o->group_no++;
+    if (detect_now) {
+      // mostLikelyType (LibraryTypeDetector.hpp:33-152): from here on the online model expects the detected format.  What depended
+      // on the format — the per-alignment compatibility flags, the assigned flags and their prefix — is made again for the rest of
+      // the batch; the rows before r1 keep what they were given (their groups have run).
+      uint8_t nt, no_, ns; sq_detect_lib_format(q.lib_type, o->det_counts, &nt, &no_, &ns);
+      c->opts.lib_type = nt; c->opts.lib_orientation = no_; c->opts.lib_strand = ns;
+      o->detect_active = false; o->detected = true;
+      if (b < nmb) {
+        const uint32_t rs = r1;
+        assigned_base = assigned_after;
+        if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
+        k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, rs, d_aln_off, d_aln, q, o->assigned_flag.p);
+        { size_t tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
+            (int)(n + 1), st)); }
+        // the mini-batches still to come read rh1/rh2 only after writing them: rh2 doubles as the bounds scratch again
+        sq_dbuf<uint64_t>& scratch = o->assigned_prefix_b;
+        if (scratch.ensure(nmb + 2)) { sq_set_error("device allocation failed (bounds scratch)"); return SQ_ERR_NOMEM; }
+        k_gather_bounds<<<nblk(nmb + 1), TB, 0, st>>>(o->assigned_prefix.p, mb, n, nmb, scratch.p);
+        SQ_HIP_CHECK(hipMemcpyAsync(bound.data(), scratch.p, (size_t)(nmb + 1) * 8, hipMemcpyDeviceToHost, st));
+        SQ_HIP_CHECK(hipStreamSynchronize(st));
+      }
+    }
   }
   sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
   // eq-class table: insert labels, then add counts / fixed-point weights
@@ -1157,6 +1213,8 @@ extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
   out->num_mapped_ub = c->online->num_mapped_ub;
   out->burned_in = hctr[1] != 0;
   out->num_compatible = hctr[5];
+  out->lib_format_id = (uint32_t)(c->opts.lib_type | (c->opts.lib_orientation << 1) | (c->opts.lib_strand << 3));
+  out->lib_detected = c->online->detected ? 1u : 0u;
   return SQ_OK;
 }
 

@@ -135,7 +135,8 @@ extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const do
     double num_mapped_frags) {
   if (!path || !idx || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf: bad arguments"); return SQ_ERR_ARG; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
-  const uint32_t M = (uint32_t)idx->names.size();
+  // decoys are dropped before inference and output (readExp.dropDecoyTranscripts(), SalmonQuantify.cpp:2479): targets only
+  const uint32_t M = std::min<uint32_t>((uint32_t)idx->names.size(), idx->first_decoy);
   // explicitSum (:704-708)
   if (!(num_mapped_frags > 0)) {
     num_mapped_frags = 0;
@@ -157,10 +158,11 @@ extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const do
 extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights) {
   if (!path || !idx || !eq) { sq_set_error("sq_write_eq_classes: bad arguments"); return SQ_ERR_ARG; }
   gzFile g = gzopen(path, "wb"); if (!g) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
-  const uint32_t M = (uint32_t)idx->names.size();
+  // decoys are dropped before inference and output (readExp.dropDecoyTranscripts(), SalmonQuantify.cpp:2479): targets only
+  const uint32_t M = std::min<uint32_t>((uint32_t)idx->names.size(), idx->first_decoy);
   if (with_weights) {
     gzprintf(g, "%u\n%llu\n", M, (unsigned long long)eq->num_classes);
-    for (auto& n : idx->names) gzprintf(g, "%s\n", n.c_str());
+    for (uint32_t t = 0; t < M; ++t) gzprintf(g, "%s\n", idx->names[t].c_str());
     for (uint64_t c = 0; c < eq->num_classes; ++c) {
       const uint64_t a = eq->off[c], b = eq->off[c + 1];
       gzprintf(g, "%llu\t", (unsigned long long)(b - a));
@@ -175,7 +177,7 @@ extern "C" int sq_write_eq_classes(const char* path, const sq_index* idx, const 
       col[k] += eq->count[c];
     }
     gzprintf(g, "%u\n%zu\n", M, col.size());
-    for (auto& n : idx->names) gzprintf(g, "%s\n", n.c_str());
+    for (uint32_t t = 0; t < M; ++t) gzprintf(g, "%s\n", idx->names[t].c_str());
     for (auto& kv : col) {
       gzprintf(g, "%zu\t", kv.first.size());
       for (uint32_t t : kv.first) gzprintf(g, "%u\t", t);

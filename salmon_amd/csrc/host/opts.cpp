@@ -27,3 +27,32 @@ extern "C" void sq_em_opts_default(sq_em_opts* o) {
   o->min_iter = 100;
   o->num_required_fragments = 50000000.0;                                                                               // :110
 }
+
+// LibraryTypeDetector::mostLikelyType (include/salmon/internal/model/LibraryTypeDetector.hpp:33-152): the most likely library format
+// from the per-format sample counts (index = formatID: type | orientation << 1 | strandedness << 3; strandedness SA 0, AS 1, S 2, A 3, U 4;
+// orientation SAME 0, AWAY 1, TOWARD 2, NONE 3).
+void sq_detect_lib_format(uint8_t type, const uint64_t* counts64, uint8_t* out_type, uint8_t* out_orient, uint8_t* out_strand) {
+  *out_type = type;
+  if (type == 0) {                          // single end
+    uint64_t nf = 0, nr = 0;
+    for (int i = 0; i < 64; ++i) { const int st = i >> 3; nf += (st == 2) ? counts64[i] : 0; nr += (st == 3) ? counts64[i] : 0; }
+    const double ratio = (nf + nr > 0) ? (double)nf / (double)(nf + nr) : -1.0;
+    *out_orient = 3;
+    *out_strand = ratio < 0.0 ? 4 : (ratio < 0.3 ? 3 : (ratio < 0.7 ? 4 : 2));
+    return;
+  }
+  uint64_t nsf = 0, nsr = 0, nin = 0, nout = 0, nsame = 0;
+  for (int i = 0; i < 64; ++i) {
+    const int orient = (i >> 1) & 3, st = i >> 3; const uint64_t c = counts64[i];
+    nsf += (st == 2 || st == 0) ? c : 0; nsr += (st == 3 || st == 1) ? c : 0;
+    nin += (orient == 2) ? c : 0; nout += (orient == 1) ? c : 0; nsame += (orient == 0) ? c : 0;
+  }
+  if (nin + nout + nsame > 0 && nsf + nsr > 0) {
+    const uint64_t no = nin + nout + nsame;
+    const double rin = (double)nin / (double)no, rout = (double)nout / (double)no, rsame = (double)nsame / (double)no;
+    bool same = false;
+    if (rin >= rout && rin >= rsame) *out_orient = 2; else if (rout >= rin && rout >= rsame) *out_orient = 1; else { *out_orient = 0; same = true; }
+    const double rfw = (double)nsf / (double)(nsf + nsr);
+    if (rfw < 0.3) *out_strand = same ? 3 : 1; else if (rfw < 0.7) *out_strand = 4; else *out_strand = same ? 2 : 0;
+  } else { *out_orient = 2; *out_strand = 4; }
+}

@@ -121,7 +121,7 @@ class OrcState:
     def summary(self):
         s = capi.ModelSummary(); lib().orc_state_summary(self.h, C.byref(s))
         return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub),
-            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible))
+            burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible), lib_format_id=int(s.lib_format_id), lib_detected=int(s.lib_detected))
 
     def lib_counts(self):
         out = np.zeros(64, np.uint64); lib().orc_state_lib_counts(self.h, out.ctypes.data); return out
@@ -145,11 +145,12 @@ def normalize_alphas(M, eq, log_mass, uniq, total):
     return out
 
 
-def em_optimize(eq, eff_len, projected=None, opts=None):
-    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len, projected)
+def em_optimize(eq, eff_len, projected=None, opts=None, unique=None):
+    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len, projected, unique)
     out = np.zeros(txp.num_txp); rep = capi.EmReport()
     rc = lib().orc_em_optimize(C.byref(t), C.byref(txp), C.byref(o), out.ctypes.data, C.byref(rep))
-    return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum, rc=rc)
+    return out, dict(iters=rep.iters, converged=bool(rep.converged), max_rel_diff=rep.max_rel_diff, alpha_sum=rep.alpha_sum, rc=rc,
+        num_degenerate=rep.num_degenerate)
 
 
 def em_steps(eq, eff_len, alpha_in, iters, opts=None):

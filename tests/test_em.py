@@ -122,6 +122,52 @@ def test_gpu_em_eqclass_mode_and_degenerate(built):
     assert np.array_equal(got, want) and got[3] == 0.0
 
 
+def _degenerate_case():
+    # class 1 carries all-zero file weights: its combined weights are 0 * inf = NaN, markDegenerateClasses (CollapsedEMOptimizer.cpp:
+    # 330-394) skips the NaN terms, finds denom = 0 and drops the class; without that the NaNs would reach every alpha
+    off = np.array([0, 1, 3, 6, 8], np.uint64); tid = np.array([2, 0, 1, 0, 2, 4, 1, 3], np.uint32)
+    w = np.array([1.0, 0.0, 0.0, 0.2, 0.5, 0.3, 0.6, 0.4]); cnt = np.array([5, 10, 7, 9], np.uint64)
+    return api.EqClasses(off, tid, w, cnt), np.array([100.0, 200.0, 50.0, 10.0, 0.5])
+
+
+@pytest.mark.parametrize("vb", [0, 1])
+def test_oracle_marks_degenerate_classes(built, vb):
+    eq, eff = _degenerate_case()
+    a, rep = orc.em_optimize(eq, eff, None, api.em_opts(eq_class_mode=1, init_uniform=1, use_vbem=vb))
+    assert rep["num_degenerate"] == 1 and np.all(np.isfinite(a))
+    assert abs(a.sum() - (5 + 7 + 9)) < (1e-6 if not vb else 0.5)      # the dropped class's 10 fragments take no part
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vb", [0, 1])
+def test_gpu_marks_degenerate_classes_like_the_checker(built, vb):
+    eq, eff = _degenerate_case()
+    o = api.em_opts(eq_class_mode=1, init_uniform=1, use_vbem=vb)
+    want, wrep = orc.em_optimize(eq, eff, None, o)
+    got, grep = api.em_optimize(eq, eff, None, o)
+    assert grep["num_degenerate"] == wrep["num_degenerate"] == 1 and grep["iters"] == wrep["iters"] and np.array_equal(got, want)
+    eq2 = random_eq_classes(800, 5000, seed=9)                           # nothing to drop in an ordinary table
+    _, r2 = api.em_optimize(eq2, np.random.default_rng(3).uniform(50, 3000, 800), None, api.em_opts(init_uniform=1, use_vbem=vb))
+    assert r2["num_degenerate"] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_alternative_init_mode_matches_checker(built):
+    # --alternativeInitMode / --meta (CollapsedEMOptimizer.cpp:790-792, 817-818): the online estimate is mixed with
+    # (uniqueCount + 0.5) * 1e-3 * effLen instead of the uniform abundance
+    M, E = 3000, 20000
+    eq = random_eq_classes(M, E, seed=21); rng = np.random.default_rng(22)
+    eff = rng.uniform(50, 3000, M); proj = rng.gamma(0.3, 200.0, M); uq = rng.integers(0, 50, M).astype(np.uint64)
+    o = api.em_opts(alt_init_mode=1, max_iter=150)
+    want, wrep = orc.em_optimize(eq, eff, proj, o, unique=uq)
+    got, grep = api.em_optimize(eq, eff, proj, o, unique=uq)
+    assert grep["iters"] == wrep["iters"] and np.array_equal(got, want)
+    plain, _ = orc.em_optimize(eq, eff, proj, api.em_opts(max_iter=150))
+    assert not np.array_equal(plain, want)                                # the option changes the starting point
+    nouq, _ = orc.em_optimize(eq, eff, proj, o)                           # without unique counts the mode has nothing to use
+    assert np.array_equal(nouq, plain)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("vb", [0, 1])
 def test_gpu_em_giant_class_and_hot_transcript(built, vb):

@@ -433,3 +433,52 @@ def test_repeat_families_cover_every_mem_size_class(built):
     assert st_g == st_c and np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
     _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
     ctx.free()
+
+
+def _stranded_pairs(seqs, n, rng, flip_from=None):
+    # fragments read in ISF orientation (mate 1 = forward strand of the transcript, mate 2 = reverse complement of the fragment's end);
+    # from pair index `flip_from` on every third pair is turned into ISR (the mates swapped)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}; recs = []
+    for i in range(n):
+        s = seqs[int(rng.integers(len(seqs)))]
+        while len(s) < 340: s = seqs[int(rng.integers(len(seqs)))]
+        fl = int(rng.integers(200, 320)); p = int(rng.integers(0, len(s) - fl))
+        r1 = s[p:p + 100]; r2 = "".join(comp[c] for c in reversed(s[p + fl - 100:p + fl]))
+        if flip_from is not None and i >= flip_from and i % 3 == 0: r1, r2 = r2, r1
+        recs += [r1, r2]
+    seq = np.frombuffer("".join(recs).encode(), np.uint8).copy(); off = np.arange(0, len(recs) + 1, dtype=np.uint64) * np.uint64(100)
+    return seq, off
+
+
+def test_library_type_autodetect_matches_checker(small_world):
+    # `-l A` (LibraryTypeDetector.hpp; SalmonQuantify.cpp:496-501,692-704; SPEC D8): the library starts as IU; once 50 000 alignments have been
+    # seen the most likely format (here ISF) is what the online model expects — the ISR pairs that follow are then incompatible and dropped
+    w = small_world; rng = np.random.default_rng(23)
+    seqs = [s.decode() for s in w["tx"].seqs()]
+    N = 24000
+    seq, off = _stranded_pairs(seqs, N, rng, flip_from=16000)
+    opts = api.quant_opts(mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=9000, lib_autodetect=1)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=10240)
+    ost = orc.OrcState(w["oidx"], opts)
+    seen = []
+    for lo, hi in [(0, 8000), (8000, 18000), (18000, 24000)]:      # ~3.6 alignments per fragment: the 50 000th sample falls inside the second batch
+        s = seq[lo * 200: hi * 200]; o = (off[2 * lo: 2 * hi + 1] - off[2 * lo]).copy()
+        rb = api.make_read_batch(s, o, hi - lo, paired=True)
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4)
+        ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+        assert st_g == st_c and np.array_equal(ro_g, ro_c)
+        _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+        seen.append(ctx.summary()["lib_detected"])
+    ost.finish()
+    sg, sc = ctx.summary(), ost.summary()
+    assert sg == sc and sg["lib_detected"] == 1 and sg["lib_format_id"] == (1 | (2 << 1) | (0 << 3))      # ISF
+    assert seen == [0, 1, 1]
+    assert sg["num_assigned"] < sg["num_observed"] - 2000                     # the ISR pairs after detection were dropped as incompatible
+    for a, b in zip(ctx.model(), ost.model()[:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ctx.lib_counts(), ost.lib_counts())
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    ctx.free(); ost.free()

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
   }
   CHECK(found == tried && tried > 1000);
   sq_index* idx2 = nullptr; CHECK(sq_index_load((dir + "/idx").c_str(), -1, &idx2) == SQ_OK); CHECK(sq_index_num_kmers(idx2) == sq_index_num_kmers(idx)); sq_index_free(idx2);
-  const uint32_t M = sq_index_num_refs(idx);
+  const uint32_t M = sq_index_first_decoy(idx);   // targets only: decoys are dropped before inference and output (SalmonQuantify.cpp:2479)
   // ---- reader: gzip FASTQ pairs + a wrapped FASTA, three batches in flight
   { gzFile f1 = gzopen((dir + "/r_1.fq.gz").c_str(), "wb"), f2 = gzopen((dir + "/r_2.fq.gz").c_str(), "wb");
     for (int i = 0; i < 5000; ++i) { std::string a = rnd_seq(g, 50 + g() % 120), b = rnd_seq(g, 50 + g() % 120);
