@@ -333,7 +333,7 @@ static int cmd_quant(int argc, char** argv) {
                 "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f,\n"
                 "  \"samp_type\": \"%s\",\n  \"num_bootstraps\": %llu,\n  \"num_libraries\": 1,\n  \"frag_length_mean\": %.6f,\n  \"frag_length_sd\": %.6f,\n  \"frag_dist_length\": 1001,\n"
                 "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u\n}\n",
-            sq_version(), sq_index_first_decoy(idx), M - sq_index_first_decoy(idx), (unsigned long long)t.num_classes,
+            sq_version(), M, Mall - M, (unsigned long long)t.num_classes,
                 (unsigned long long)nfrag,
                 (unsigned long long)ms.num_assigned,
             (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails,

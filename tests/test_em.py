@@ -158,11 +158,14 @@ def test_gpu_alternative_init_mode_matches_checker(built):
     M, E = 3000, 20000
     eq = random_eq_classes(M, E, seed=21); rng = np.random.default_rng(22)
     eff = rng.uniform(50, 3000, M); proj = rng.gamma(0.3, 200.0, M); uq = rng.integers(0, 50, M).astype(np.uint64)
-    o = api.em_opts(alt_init_mode=1, max_iter=150)
+    o = api.em_opts(alt_init_mode=1, min_iter=3, max_iter=3)               # three steps: the starting point still shows
     want, wrep = orc.em_optimize(eq, eff, proj, o, unique=uq)
     got, grep = api.em_optimize(eq, eff, proj, o, unique=uq)
-    assert grep["iters"] == wrep["iters"] and np.array_equal(got, want)
-    plain, _ = orc.em_optimize(eq, eff, proj, api.em_opts(max_iter=150))
+    assert grep["iters"] == wrep["iters"] == 3 and np.array_equal(got, want)
+    full_c, rc = orc.em_optimize(eq, eff, proj, api.em_opts(alt_init_mode=1), unique=uq)
+    full_g, rg = api.em_optimize(eq, eff, proj, api.em_opts(alt_init_mode=1), unique=uq)
+    assert rc["iters"] == rg["iters"] and np.array_equal(full_c, full_g)
+    plain, _ = orc.em_optimize(eq, eff, proj, api.em_opts(min_iter=3, max_iter=3))
     assert not np.array_equal(plain, want)                                # the option changes the starting point
     nouq, _ = orc.em_optimize(eq, eff, proj, o)                           # without unique counts the mode has nothing to use
     assert np.array_equal(nouq, plain)
