@@ -33,6 +33,8 @@ def parse():
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
+    ap.add_argument("--py-dist", action="store_true",
+        help="N>1: exchange the class tables with torch.distributed collectives (salmon_amd/dist.py) instead of the library's own RCCL path (sq_dist_*, the default)")
     ap.add_argument("--inflight", type=int, default=0,
         help="mini-batches per model snapshot (sq_quant_opts.mini_batches_in_flight = the reference's -p / numThreads); 0 = the library default (8)")
     ap.add_argument("--lanes", type=int, default=1,
@@ -87,6 +89,14 @@ def main():
         if a.debug_one_device: dist.init_process_group("gloo")
         else: dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from salmon_amd import api, synth, capi
+    sqd = None
+    if dist is not None and not a.debug_one_device and not a.py_dist:
+        # the product's multi-GPU seam: an RCCL communicator owned by libsalmon_hip.so (hip/dist.hip); torch.distributed only carries the
+        # 128-byte unique id to the ranks and keeps the barrier / timing contract of this script
+        idt = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", local))
+        if rank == 0: idt.copy_(torch.frombuffer(bytearray(api.Dist.make_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        sqd = api.Dist(bytes(idt.cpu().numpy().tobytes()), rank, world, local)
     ncores = os.cpu_count() or 8
     thr = max(4, ncores // max(1, world))
     t_setup = time.time()
@@ -160,10 +170,13 @@ def main():
             for r in range(world):
                 if r != rank:
                     ctx.eq_merge(tables[r])
-        else:                       # tables go HBM -> xGMI -> HBM and are merged where they land
+        elif sqd is not None:       # sq_dist_merge_eq: one packed all-gather over RCCL (HBM -> xGMI -> HBM), merged where it lands
+            sqd.merge_eq(ctx)
+        else:
             sqdist.merge_all_device(ctx, dist, dev)
         eq = ctx.eq_finish()
-        lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, cdev)
+        if sqd is not None: lm, uq, tc, le = sqd.reduce_model(lm, uq, tc, le)      # SPEC MG
+        else: lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, cdev)
     t_a = time.perf_counter()
     proj = api.normalize_alphas(eq, lm, uq, tc)
     t_norm = time.perf_counter() - t_a
@@ -269,7 +282,8 @@ def main():
         "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K,
             B, K * B, RL),
                    "transcripts": int(M), "txome_nt": int(tx.total_nt()), "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
-                   "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly; EM replicated" % world},
+                   "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly (%s); EM replicated" % (world,
+                       "sq_dist_* over RCCL" if sqd is not None else ("torch.distributed" if dist is not None else "single rank"))},
         "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
             "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
             "em_device_ms": round(rep["device_ms"], 2),

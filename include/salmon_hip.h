@@ -388,6 +388,10 @@ typedef int (*sq_replicate_cb)(const double* alphas, uint32_t m, void* user);
 int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                      uint32_t num_bootstraps, uint64_t seed, uint64_t num_mapped,
                      sq_replicate_cb cb, void* user);
+/* Replicates [first, first + count) of num_bootstraps: the same bytes whichever GPU computes them (counter RNG keyed by the replicate). */
+int sq_bootstrap_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
+                           uint32_t num_bootstraps, uint32_t first, uint32_t count, uint64_t seed, uint64_t num_mapped,
+                           sq_replicate_cb cb, void* user);
 typedef struct {
   uint32_t thinning_factor;     /* 16 */
   uint8_t no_gamma_draw;
@@ -399,6 +403,39 @@ typedef struct {
 int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* opts,
                  const double* alpha_init, uint32_t num_samples, uint64_t seed, uint64_t num_mapped,
                  sq_replicate_cb cb, void* user);
+/* Samples [first, first + count) of num_samples; `first` must start a chain (a multiple of sq_gibbs_chain_step(num_samples)). */
+uint32_t sq_gibbs_chain_step(uint32_t num_samples);
+int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* opts,
+                       const double* alpha_init, uint32_t num_samples, uint32_t first, uint32_t count, uint64_t seed,
+                       uint64_t num_mapped, sq_replicate_cb cb, void* user);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU (oracle/SPEC.md §MG): one process per GPU.  Reads shard by rank — there is no collective on the mapping path;
+ * after mapping ONE exchange of the equivalence-class tables over RCCL (xGMI inside a node), the per-transcript model state reduced
+ * by a defined rule, the inference tail replicated, posterior replicates sharded by rank.  The reference has no multi-process mode;
+ * this seam sits where its worker threads join (SalmonQuantify.cpp:2445-2480) and where doBootstrap / the Gibbs chains fan out
+ * (CollapsedEMOptimizer.cpp:554-690, CollapsedGibbsSampler.cpp:425-470).
+ * ---------------------------------------------------------------------------------------------- */
+#define SQ_DIST_ID_BYTES 128
+typedef struct sq_dist sq_dist;
+int sq_dist_make_id(uint8_t* id128);              /* rank 0: an RCCL unique id; the launcher hands it to every rank (file, pipe, MPI, torch) */
+int sq_dist_init(const uint8_t* id128, int rank, int world, int device, sq_dist** out);   /* collective: all ranks call it */
+void sq_dist_free(sq_dist*);
+int sq_dist_rank(const sq_dist*);
+int sq_dist_world(const sq_dist*);
+/* Collective. All-gathers every rank's canonical-order class table (HBM -> xGMI -> HBM) and merges the others' into this ctx: every
+ * rank ends with the same table; counts and fixed-point weight sums add exactly, so the bits do not depend on the gather order. */
+int sq_dist_merge_eq(sq_dist*, sq_ctx*);
+/* Collective. SPEC §MG: unique / total counts add; masses combine by logAdd in rank order; effective lengths are rank 0's. */
+int sq_dist_reduce_model(sq_dist*, uint32_t num_txp, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len);
+/* The mass rule on its own (host arithmetic, no device): row r of all_log_mass = rank r's log-masses; out[t] = logAdd over r = 0..R-1. */
+int sq_merge_log_masses(uint32_t num_txp, uint32_t num_ranks, const double* all_log_mass /*[R][M]*/, double* out /*[M]*/);
+int sq_dist_allreduce_u64(sq_dist*, uint64_t* host, size_t n);                  /* element-wise sums (mapping statistics, fragment counts) */
+int sq_dist_bcast(sq_dist*, void* host, size_t bytes, int root);
+int sq_dist_allgather(sq_dist*, const void* host_in, size_t bytes, void* host_out /* world * bytes */);
+int sq_dist_barrier(sq_dist*);
+/* This rank's contiguous share of `total` replicates, cut at multiples of `unit` (1 for bootstraps, sq_gibbs_chain_step(total) for Gibbs). */
+void sq_dist_share(const sq_dist*, uint32_t total, uint32_t unit, uint32_t* first, uint32_t* count);
 
 /* Per-stage HIP-event timing of the mapping / eq pipeline (measurement).  When enabled,
  * every stage kernel of sq_map_batch / sq_eq_accumulate is bracketed by hipEventRecord on the ctx

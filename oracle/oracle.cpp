@@ -1500,6 +1500,21 @@ void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const
 }
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
 void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }
+// SPEC §MG: fold the state of rank `src` into `dst` (call in rank order 1, 2, ... on rank 0's state): class counts and fixed-point
+// weight sums add, unique / total counts and fragment counters add, masses combine by logAdd(dst, src); the fragment-length
+// distribution and the effective lengths stay rank 0's
+void orc_state_merge(orc_state* dst, const orc_state* src) {
+  QuantState& D = dst->S; const QuantState& R = src->S;
+  for (auto& kv : R.eq) {
+    EqVal& ev = D.eq[kv.first];
+    if (ev.wq.empty()) ev.wq.assign(kv.second.wq.size(), 0);
+    ev.count += kv.second.count;
+    for (size_t i = 0; i < ev.wq.size(); ++i) ev.wq[i] += kv.second.wq[i];
+  }
+  for (size_t t = 0; t < D.mass.size(); ++t) { D.mass[t] = sq_log_add(D.mass[t], R.mass[t]); D.uniq[t] += R.uniq[t]; D.total[t] += R.total[t]; }
+  D.numObserved += R.numObserved; D.numAssigned += R.numAssigned; D.numMappedUB += R.numMappedUB; D.numCompat += R.numCompat;
+  for (int f = 0; f < 64; ++f) D.libCounts[f] += R.libCounts[f];
+}
 void orc_state_summary(orc_state* s, sq_model_summary* m) {
   m->lib_format_id = (uint32_t)(s->S.op.o.lib_type | (s->S.op.o.lib_orientation << 1) | (s->S.op.o.lib_strand << 3)); m->lib_detected = s->S.detected ? 1u : 0u;
   m->num_observed = s->S.numObserved;

@@ -438,6 +438,68 @@ def bootstrap(eq, eff_len, num_bootstraps, seed, num_mapped, opts=None, device=0
     return np.array(rows)
 
 
+def bootstrap_range(eq, eff_len, num_bootstraps, first, count, seed, num_mapped, opts=None, device=0):
+    """Replicates [first, first + count) of num_bootstraps (sq_bootstrap_range_dev): what a rank of a multi-GPU job computes."""
+    o = opts or em_opts(); t = eq.table(); txp = make_txp_in(eff_len)
+    rows, cb = _collect(txp.num_txp)
+    check(lib().sq_bootstrap_range_dev(device, C.byref(t), C.byref(txp), C.byref(o), num_bootstraps, first, count, seed, num_mapped, cb, None),
+        "sq_bootstrap_range_dev")
+    return np.array(rows)
+
+
+def gibbs_range(eq, eff_len, alpha_init, num_samples, first, count, seed, num_mapped, gopts=None, device=0):
+    g = gopts or gibbs_opts(); t = eq.table(); txp = make_txp_in(eff_len)
+    a = np.ascontiguousarray(alpha_init, np.float64)
+    rows, cb = _collect(txp.num_txp)
+    check(lib().sq_gibbs_range_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, first, count, seed, num_mapped,
+        cb, None), "sq_gibbs_range_dev")
+    return np.array(rows)
+
+
+class Dist:
+    """The multi-GPU seam (sq_dist_*): one process per GPU over RCCL.  `make_id()` on rank 0, hand the 128 bytes to every rank
+    (torch.distributed, MPI, a file), then Dist(id, rank, world, device) collectively."""
+
+    @staticmethod
+    def make_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().sq_dist_make_id(buf), "sq_dist_make_id")
+        return bytes(buf)
+
+    def __init__(self, id128, rank, world, device):
+        buf = (C.c_uint8 * 128).from_buffer_copy(id128)
+        h = C.c_void_p()
+        check(lib().sq_dist_init(buf, rank, world, device, C.byref(h)), "sq_dist_init")
+        self.h = h; self.rank = rank; self.world = world
+
+    def free(self):
+        if self.h:
+            lib().sq_dist_free(self.h); self.h = None
+
+    def merge_eq(self, ctx):
+        check(lib().sq_dist_merge_eq(self.h, ctx.h), "sq_dist_merge_eq")
+
+    def reduce_model(self, log_mass, uniq, total, log_eff_len):
+        lm = np.ascontiguousarray(log_mass, np.float64).copy(); uq = np.ascontiguousarray(uniq, np.uint64).copy()
+        tc = np.ascontiguousarray(total, np.uint64).copy(); le = np.ascontiguousarray(log_eff_len, np.float64).copy()
+        check(lib().sq_dist_reduce_model(self.h, len(lm), _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(le, C.c_double)),
+            "sq_dist_reduce_model")
+        return lm, uq, tc, le
+
+    def allreduce_u64(self, a):
+        a = np.ascontiguousarray(a, np.uint64).copy()
+        check(lib().sq_dist_allreduce_u64(self.h, a.ctypes.data, a.size), "sq_dist_allreduce_u64")
+        return a
+
+    def barrier(self):
+        check(lib().sq_dist_barrier(self.h), "sq_dist_barrier")
+
+    def share(self, total, unit=1):
+        f, n = C.c_uint32(), C.c_uint32()
+        lib().sq_dist_share(self.h, total, unit, C.byref(f), C.byref(n))
+        return f.value, n.value
+
+
 def gibbs_opts(thinning_factor=16, no_gamma_draw=0, use_vbem=1, per_transcript_prior=1, vb_prior=1e-2):
     return capi.GibbsOpts(thinning_factor, no_gamma_draw, use_vbem, per_transcript_prior, 0, vb_prior)
 

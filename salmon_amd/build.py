@@ -62,7 +62,7 @@ def build_product(verbose=True):
         if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
             os.remove(os.path.join(OBJ, f))
     if any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lz", "-lpthread", "-o", LIB]
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + ["-lz", "-lpthread", "-ldl", "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

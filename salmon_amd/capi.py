@@ -153,6 +153,15 @@ def lib():
         "sq_em_steps_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), P(f64), u32, P(f64), P(EmReport)]),
         "sq_bootstrap_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u64, u64, REPLICATE_CB, vp]),
+        "sq_bootstrap_range_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u32, u32, u64, u64, REPLICATE_CB, vp]),
+        "sq_gibbs_range_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u32, u32, u64, u64, REPLICATE_CB, vp]),
+        "sq_gibbs_chain_step": (u32, [u32]),
+        "sq_merge_log_masses": (C.c_int, [u32, u32, vp, vp]),
+        "sq_dist_make_id": (C.c_int, [vp]), "sq_dist_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]), "sq_dist_free": (None, [vp]),
+        "sq_dist_rank": (C.c_int, [vp]), "sq_dist_world": (C.c_int, [vp]), "sq_dist_merge_eq": (C.c_int, [vp, vp]),
+        "sq_dist_reduce_model": (C.c_int, [vp, u32, P(f64), P(u64), P(u64), P(f64)]), "sq_dist_allreduce_u64": (C.c_int, [vp, vp, C.c_size_t]),
+        "sq_dist_bcast": (C.c_int, [vp, vp, C.c_size_t, C.c_int]), "sq_dist_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "sq_dist_barrier": (C.c_int, [vp]), "sq_dist_share": (None, [vp, u32, u32, P(u32), P(u32)]),
         "sq_debug_tap": (C.c_int64, [vp, C.c_int, vp, u64]),
         "sq_ctx_reserve": (C.c_int, [vp, u64, u64]),
         "sq_debug_infix_align": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, vp, vp]),

@@ -4,6 +4,9 @@
 // eq-class and inference work happens in libsalmon_hip.so on the GPU.
 #include <zlib.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -102,26 +105,48 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
   {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
 
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
+static int part_cb(const double* a, uint32_t m, void* user) { return fwrite(a, 8, m, (FILE*)user) == m ? 0 : 1; }   // a rank's replicates, raw, for rank 0 to collect
 
 // posterior samples into aux_info/bootstrap (MappingPipelineStages.cpp:60-95): --numBootstraps wins over --numGibbsSamples
 struct SampInfo { uint64_t n = 0; const char* type = "none"; };   // meta_info.json: num_bootstraps / samp_type (GZipWriter.cpp:455-470)
 static SampInfo run_sampling(int argc, char** argv, int device, const sq_eq_table* t, const sq_txp_in* tx, const sq_em_opts* eop,
     const double* alphas, uint32_t M,
-                         const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped) {
+                         const std::vector<const char*>& names, const std::string& od, uint64_t num_mapped, sq_dist* dist = nullptr) {
   const char* v;
   const uint32_t nb = (v = arg(argc, argv, "--numBootstraps")) ? (uint32_t)atoi(v) : 0, ng = (v = arg(argc, argv,
       "--numGibbsSamples")) ? (uint32_t)atoi(v) : 0;
   if (!nb && !ng) return SampInfo();
   const uint64_t seed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
+  // multi-GPU: replicates (bootstrap) / whole chains (Gibbs) are sharded by rank; a replicate is the same bytes whichever GPU computes it
+  const uint32_t total = nb ? nb : ng; uint32_t first = 0, count = total;
+  const int rank = dist ? sq_dist_rank(dist) : 0, world = dist ? sq_dist_world(dist) : 1;
+  if (dist) sq_dist_share(dist, total, nb ? 1u : sq_gibbs_chain_step(ng), &first, &count);
+  sq_gibbs_opts go{};
+  go.thinning_factor = (v = arg(argc, argv, "--thinningFactor")) ? (uint32_t)atoi(v) : 16;
+  go.no_gamma_draw = flag(argc, argv, "--noGammaDraw");
+  go.use_vbem = eop->use_vbem;
+  go.per_transcript_prior = eop->per_transcript_prior; go.vb_prior = eop->vb_prior;
+  auto run = [&](sq_replicate_cb cb, void* user) {
+    if (nb) { if (sq_bootstrap_range_dev(device, t, tx, eop, nb, first, count, seed, num_mapped, cb, user)) die("bootstrap"); }
+    else if (sq_gibbs_range_dev(device, t, tx, &go, alphas, ng, first, count, seed, num_mapped, cb, user)) die("Gibbs sampling");
+  };
+  const std::string bdir = od + "/aux_info/bootstrap";
+  if (rank != 0) {   // raw rows into a part file; rank 0 appends them to bootstraps.gz in rank order
+    mkdir((od + "/aux_info").c_str(), 0755); mkdir(bdir.c_str(), 0755);
+    FILE* pf = fopen((bdir + "/.part" + std::to_string(rank)).c_str(), "wb"); if (!pf) { fprintf(stderr, "[salmon-hip] cannot write replicate part file\n"); exit(1); }
+    run(part_cb, pf); fclose(pf);
+    if (sq_dist_barrier(dist)) die("barrier");
+    SampInfo si; si.n = total; si.type = nb ? "bootstrap" : "gibbs"; return si;
+  }
   sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
-  if (nb) { if (sq_bootstrap_dev(device, t, tx, eop, nb, seed, num_mapped, boot_cb, bw)) die("bootstrap"); }
-  else {
-    sq_gibbs_opts go{};
-    go.thinning_factor = (v = arg(argc, argv, "--thinningFactor")) ? (uint32_t)atoi(v) : 16;
-    go.no_gamma_draw = flag(argc, argv, "--noGammaDraw");
-    go.use_vbem = eop->use_vbem;
-    go.per_transcript_prior = eop->per_transcript_prior; go.vb_prior = eop->vb_prior;
-    if (sq_gibbs_dev(device, t, tx, &go, alphas, ng, seed, num_mapped, boot_cb, bw)) die("Gibbs sampling");
+  run(boot_cb, bw);
+  if (dist && world > 1) {
+    if (sq_dist_barrier(dist)) die("barrier");
+    std::vector<double> row(M);
+    for (int r = 1; r < world; ++r) {
+      const std::string pp = bdir + "/.part" + std::to_string(r);
+      if (FILE* pf = fopen(pp.c_str(), "rb")) { while (fread(row.data(), 8, M, pf) == M) sq_boot_writer_append(bw, row.data(), M); fclose(pf); remove(pp.c_str()); }
+    }
   }
   SampInfo si; si.n = sq_boot_writer_close(bw); si.type = nb ? "bootstrap" : "gibbs";
   fprintf(stderr, "[salmon-hip] wrote %llu %s samples\n", (unsigned long long)si.n, nb ? "bootstrap" : "Gibbs");
@@ -166,8 +191,28 @@ static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
   return 0;
 }
 
+// `--gpus N` without a launcher: re-execute this binary N times, one process per GPU, with RANK / WORLD_SIZE / LOCAL_RANK in the
+// environment (the variables torchrun / mpirun wrappers set; under such a launcher --gpus is not needed)
+static int launch_ranks(char** argv, int n) {
+  std::vector<pid_t> kids;
+  for (int r = 0; r < n; ++r) {
+    pid_t p = fork();
+    if (p < 0) { perror("fork"); return 1; }
+    if (p == 0) {
+      setenv("RANK", std::to_string(r).c_str(), 1); setenv("LOCAL_RANK", std::to_string(r).c_str(), 1); setenv("WORLD_SIZE", std::to_string(n).c_str(), 1);
+      execv("/proc/self/exe", argv); perror("execv"); _exit(127);
+    }
+    kids.push_back(p);
+  }
+  int rc = 0;
+  for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1; }
+  return rc;
+}
+
 static int cmd_quant(int argc, char** argv) {
   if (const char* eqf = arg(argc, argv, "-e", "--eqclasses")) return cmd_quant_eq(argc, argv, eqf);
+  { const char* g = arg(argc, argv, "--gpus"); if (g && atoi(g) > 1 && !getenv("WORLD_SIZE")) return launch_ranks(argv, atoi(g)); }
+  const int world = getenv("WORLD_SIZE") ? std::max(1, atoi(getenv("WORLD_SIZE"))) : 1, rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
   const char* idir = arg(argc, argv, "-i", "--index"); const char* odir = arg(argc, argv, "-o", "--output");
   const char* r1 = arg(argc, argv, "-1", "--mates1");
   const char* r2 = arg(argc, argv, "-2", "--mates2");
@@ -178,7 +223,7 @@ static int cmd_quant(int argc, char** argv) {
         "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
     return 1;
   }
-  check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "--device", "--batch", "--lanes", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
+  check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "--device", "--batch", "--lanes", "--gpus", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
                           "--rangeFactorizationBins", "--mismatchSeedSkip", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor",
                           "--incompatPrior", "--maxOccsPerHit", "--maxReadOcc", "--fldMax", "--fldMean", "--fldSD", "--forgettingFactor", "--numPreAuxModelSamples",
                           "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth"},
@@ -192,9 +237,27 @@ static int cmd_quant(int argc, char** argv) {
   if (autodetect) lib = ru ? "U" : "IU";   // enableAutodetect(): the library starts unstranded / inward (LibraryTypeUtils.cpp:110-146)
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
   const char* v;
-  int device = (v = arg(argc, argv, "--device")) ? atoi(v) : 0;
+  int device = ((v = arg(argc, argv, "--device")) ? atoi(v) : 0) + (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0);
   uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
   const bool paired = !ru;
+  // multi-GPU (SPEC MG): the RCCL id travels through a file in the output directory (rank 0 writes it, the others wait for it)
+  sq_dist* dist = nullptr;
+  if (world > 1) {
+    mkdir(odir, 0755);
+    const std::string idf = std::string(odir) + "/.sq_dist_id"; uint8_t id[SQ_DIST_ID_BYTES];
+    if (rank == 0) {
+      if (sq_dist_make_id(id)) die("RCCL id");
+      FILE* f = fopen((idf + ".tmp").c_str(), "wb"); if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[salmon-hip] cannot write %s\n", idf.c_str()); return 1; }
+      fclose(f); rename((idf + ".tmp").c_str(), idf.c_str());
+    } else {
+      bool got = false;
+      for (int i = 0; i < 2400 && !got; ++i) { if (FILE* f = fopen(idf.c_str(), "rb")) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); } if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50)); }
+      if (!got) { fprintf(stderr, "[salmon-hip] rank %d: no RCCL id from rank 0 after 120 s\n", rank); return 1; }
+    }
+    if (sq_dist_init(id, rank, world, device, &dist)) die("RCCL communicator");
+    if (sq_dist_barrier(dist)) die("barrier");
+    if (rank == 0) remove(idf.c_str());
+  }
   auto t0 = std::chrono::steady_clock::now();
   sq_index* idx = nullptr; if (sq_index_load(idir, device, &idx)) die("loading index");
   sq_quant_opts qo;
@@ -257,10 +320,12 @@ static int cmd_quant(int argc, char** argv) {
     nfrag += st.num_reads;
     fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
   };
+  uint64_t batch_no = 0;
   for (;;) {
     sq_read_batch in; int slot = -1;
     if (sq_reader_next(rd, &in, &slot)) die("reading");
     if (in.n == 0) break;
+    if (world > 1 && (int)(batch_no++ % (uint64_t)world) != rank) { sq_reader_release(rd, slot); continue; }   // batch b -> rank b mod R (SPEC MG)
     if (inflight.size() == lanes) finish_one();
     if (sq_map_submit(ctx, &in, nullptr)) die("mapping");
     inflight.push_back(slot);
@@ -268,6 +333,10 @@ static int cmd_quant(int argc, char** argv) {
   while (!inflight.empty()) finish_one();
   sq_reader_close(rd);
   fprintf(stderr, "\n");
+  if (dist) {   // ONE exchange of the class tables, counters summed
+    if (sq_dist_merge_eq(dist, ctx)) die("eq-class exchange");
+    if (sq_dist_allreduce_u64(dist, (uint64_t*)&tot, sizeof(tot) / 8) || sq_dist_allreduce_u64(dist, &nfrag, 1)) die("counter all-reduce");
+  }
   // decoys are dropped before inference and output (readExp.dropDecoyTranscripts(), SalmonQuantify.cpp:2479): M = num_valid_targets;
   // no alignment ever names a decoy (SalmonMappingUtils.hpp:407-485), so the eq-class labels already lie below M
   const uint32_t Mall = sq_index_num_refs(idx), M = sq_index_first_decoy(idx);
@@ -280,6 +349,14 @@ static int cmd_quant(int argc, char** argv) {
   if (sq_model_fetch(ctx, lm.data(), uq.data(), tc.data(), le.data())) die("model fetch");
   for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
   sq_model_summary ms{}; sq_model_summary_get(ctx, &ms);
+  uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
+  if (dist) {   // SPEC MG: counts add, masses logAdd in rank order, effective lengths rank 0's
+    if (sq_dist_reduce_model(dist, Mall, lm.data(), uq.data(), tc.data(), le.data())) die("model reduction");
+    uint64_t c4[4] = {ms.num_observed, ms.num_assigned, ms.num_mapped_ub, ms.num_compatible};
+    if (sq_dist_allreduce_u64(dist, c4, 4) || sq_dist_allreduce_u64(dist, lc, 64)) die("counter all-reduce");
+    ms.num_observed = c4[0]; ms.num_assigned = c4[1]; ms.num_mapped_ub = c4[2]; ms.num_compatible = c4[3];
+    for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
+  }
   mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
   sq_em_report rep{}; SampInfo si;
   if (ms.num_assigned < 10) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
@@ -299,12 +376,12 @@ static int cmd_quant(int argc, char** argv) {
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
     if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
     std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_index_ref_name(idx, i);
-    si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned);
+    si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned, dist);
   }
+  if (rank != 0) { sq_dist_free(dist); sq_ctx_free(ctx); sq_index_free(idx); return 0; }   // every rank computed the same result; rank 0 writes it
   if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
   if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
-  { uint64_t lc[64]; if (sq_model_fetch_lib_counts(ctx, lc)) die("lib counts");
-    const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
+  { const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
     const uint8_t dt = (uint8_t)(ms.lib_format_id & 1), dor = (uint8_t)((ms.lib_format_id >> 1) & 3), dst = (uint8_t)(ms.lib_format_id >> 3);   // the detected format with -l A
     for (auto& kv : kLib) if (kv.second[0] == dt && kv.second[1] == dor && kv.second[2] == dst) lib = kv.first;
     if (autodetect) fprintf(stderr, "[salmon-hip] Automatically detected most likely library type as %s%s\n", lib.c_str(), ms.lib_detected ? "" : " (fewer than 50000 samples: the starting format was kept)");
@@ -356,7 +433,7 @@ static int cmd_quant(int argc, char** argv) {
           nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv,
               "--useEM") ? "EM" : "VBEM", secs,
               odir);
-  sq_ctx_free(ctx); sq_index_free(idx);
+  sq_dist_free(dist); sq_ctx_free(ctx); sq_index_free(idx);
   return 0;
 }
 

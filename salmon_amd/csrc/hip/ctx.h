@@ -177,6 +177,7 @@ enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGF
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`
+extern "C" int sq_merge_log_masses(uint32_t M, uint32_t R, const double* all_log_mass, double* out);   // host/opts.cpp
 void sq_detect_lib_format(uint8_t type, const uint64_t* counts64, uint8_t* out_type, uint8_t* out_orient, uint8_t* out_strand);   // host/opts.cpp
 int sq_online_create(sq_ctx* c);
 void sq_online_free(sq_ctx* c);

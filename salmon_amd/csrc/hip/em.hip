@@ -903,6 +903,14 @@ extern "C" int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_i
 extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed,
     uint64_t num_mapped,
     sq_replicate_cb cb, void* user) {
+  return sq_bootstrap_range_dev(device, eq, txp, o, B, 0, B, seed, num_mapped, cb, user);
+}
+// replicates [first, first + count) of B: replicate b draws from the counter RNG keyed (seed, b), so a replicate is the same
+// whichever GPU computes it — the ranks of a multi-GPU job take disjoint ranges (replicates -> GPUs)
+extern "C" int sq_bootstrap_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint32_t first,
+    uint32_t count, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  if (first > B || count > B - first) { sq_set_error("sq_bootstrap_range_dev: range [%u, %u) outside %u replicates", first, first + count, B); return SQ_ERR_ARG; }
+  if (count == 0) return SQ_OK;
   if (!eq || !txp || !o || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
     sq_set_error("sq_bootstrap_dev: bad arguments");
     return SQ_ERR_ARG;
@@ -926,7 +934,7 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
     return SQ_ERR_NOMEM;
   }
   const int TB = 256;
-  for (uint32_t b = 0; b < B; ++b) {
+  for (uint32_t b = first; b < first + count; ++b) {
     SQ_HIP_CHECK(hipMemsetAsync(d_samp.p, 0, (size_t)E * 8, S.st));
     uint32_t grid = (uint32_t)std::min<uint64_t>((total + TB - 1) / TB, 65536);
     k_bs_sample<<<grid, TB, 0, S.st>>>(total, E, d_cum.p, seed, b, d_samp.p);
@@ -947,6 +955,21 @@ extern "C" int sq_bootstrap_dev(int device, const sq_eq_table* eq, const sq_txp_
 extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init,
     uint32_t S_n, uint64_t seed,
     uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  return sq_gibbs_range_dev(device, eq, txp, go, alpha_init, S_n, 0, S_n, seed, num_mapped, cb, user);
+}
+extern "C" uint32_t sq_gibbs_chain_step(uint32_t S_n) {   // samples per chain: 1 / 2 / 4 / 8 chains from 1 / 50 / 100 / 200 samples (CollapsedGibbsSampler.cpp:425-434)
+  uint32_t nchains = 1; if (S_n >= 50) nchains = 2; if (S_n >= 100) nchains = 4; if (S_n >= 200) nchains = 8;
+  return nchains > 1 ? S_n / nchains : (S_n ? S_n : 1);
+}
+// samples [first, first + count) of S_n; `first` must start a chain (a multiple of sq_gibbs_chain_step(S_n), below nchains * step): every
+// chain restarts from alpha_init and round r of sample s draws from the counter RNG keyed (seed, s * thin + r), so whole chains can
+// run on different GPUs and give the samples a single GPU would have produced
+extern "C" int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init,
+    uint32_t S_n, uint32_t first, uint32_t count, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  if (first > S_n || count > S_n - first) { sq_set_error("sq_gibbs_range_dev: range [%u, %u) outside %u samples", first, first + count, S_n); return SQ_ERR_ARG; }
+  { const uint32_t stp = sq_gibbs_chain_step(S_n); uint32_t nch = 1; if (S_n >= 50) nch = 2; if (S_n >= 100) nch = 4; if (S_n >= 200) nch = 8;
+    if (first && (nch == 1 || first % stp != 0 || first / stp >= nch)) { sq_set_error("sq_gibbs_range_dev: sample %u does not start a chain (step %u)", first, stp); return SQ_ERR_ARG; } }
+  if (count == 0) return SQ_OK;
   if (!eq || !txp || !go || !alpha_init || !cb || !eq->off || !eq->tid || !eq->w || !eq->count || !txp->eff_len) {
     sq_set_error("sq_gibbs_dev: bad arguments");
     return SQ_ERR_ARG;
@@ -1001,8 +1024,8 @@ extern "C" int sq_gibbs_dev(int device, const sq_eq_table* eq, const sq_txp_in* 
   const int TB = 256;
   const uint32_t nitems = (uint32_t)item_cls.size();
   std::vector<double> me(M), alphas(M);
-  for (uint32_t sid = 0; sid < S_n; ++sid) {
-    // chain restart (:452-455)
+  for (uint32_t sid = first; sid < first + count; ++sid) {
+    // chain restart (:452-455); a range that starts at a later chain starts from the initial counts as well
     if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpy(d_cf.p, init.data(), (size_t)M * 8,
         hipMemcpyHostToDevice));
     for (uint32_t r = 0; r < thin; ++r) {

@@ -1,6 +1,7 @@
 // host/opts.cpp — defaults mirrored from include/salmon/internal/config/SalmonDefaults.hpp:8-127.
 #include "../../../include/salmon_hip.h"
 #include <string.h>
+#include "../../../include/sq_math.h"
 extern "C" void sq_quant_opts_default(sq_quant_opts* o) {
   memset(o, 0, sizeof(*o));
   o->lib_type = 1; o->lib_orientation = 2; o->lib_strand = 4;  // -l IU
@@ -55,4 +56,15 @@ void sq_detect_lib_format(uint8_t type, const uint64_t* counts64, uint8_t* out_t
     const double rfw = (double)nsf / (double)(nsf + nsr);
     if (rfw < 0.3) *out_strand = same ? 3 : 1; else if (rfw < 0.7) *out_strand = 4; else *out_strand = same ? 2 : 0;
   } else { *out_orient = 2; *out_strand = 4; }
+}
+
+// SPEC §MG: masses of R ranks (row r = rank r's log-masses, LOG_0 = +inf where a transcript has none) -> logAdd in rank order
+extern "C" int sq_merge_log_masses(uint32_t M, uint32_t R, const double* all_log_mass, double* out) {
+  if (!all_log_mass || !out || R == 0) return SQ_ERR_ARG;
+  for (uint32_t t = 0; t < M; ++t) {
+    double m = SQ_LOG_0;
+    for (uint32_t r = 0; r < R; ++r) m = sq_log_add(m, all_log_mass[(size_t)r * M + t]);
+    out[t] = m;
+  }
+  return SQ_OK;
 }

@@ -37,16 +37,21 @@ def all_gather_tables(eq, dist, device):
 
 
 def reduce_model(log_mass, uniq, total, log_eff_len, dist, device):
-    """uniq/total: exact int64 all-reduce; masses: summed in linear space; effective lengths: rank 0's FLD."""
+    """SPEC §MG over torch.distributed (the gloo harness path; the product path is sq_dist_reduce_model over RCCL): uniq / total exact int64
+    all-reduce; masses all-gathered and combined by logAdd in rank order (sq_merge_log_masses); effective lengths: rank 0's."""
     import torch
+    from . import capi
+    world = dist.get_world_size()
     tq = torch.from_numpy(np.stack([uniq.astype(np.int64), total.astype(np.int64)])).to(device)
     dist.all_reduce(tq)
     uq, tc = tq[0].cpu().numpy().astype(np.uint64), tq[1].cpu().numpy().astype(np.uint64)
-    lin = torch.from_numpy(np.where(np.isinf(log_mass), 0.0, np.exp(np.where(np.isinf(log_mass), 0.0, log_mass)))).to(device)
-    dist.all_reduce(lin)
-    linc = lin.cpu().numpy()
-    lm = np.where(linc > 0, np.log(np.maximum(linc, 1e-300)), np.inf)
-    le = torch.from_numpy(np.ascontiguousarray(log_eff_len)).to(device)
+    mine = torch.from_numpy(np.ascontiguousarray(log_mass, np.float64).copy()).to(device)
+    outs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    allm = np.ascontiguousarray(np.stack([o.cpu().numpy() for o in outs]))
+    lm = np.zeros(len(log_mass))
+    capi.check(capi.lib().sq_merge_log_masses(len(lm), world, allm.ctypes.data, lm.ctypes.data), "sq_merge_log_masses")
+    le = torch.from_numpy(np.ascontiguousarray(log_eff_len).copy()).to(device)
     dist.broadcast(le, 0)
     return lm, uq, tc, le.cpu().numpy()
 

@@ -34,6 +34,7 @@ def lib():
         L.orc_state_free.argtypes = [vp]
         L.orc_eq_accumulate.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64]
         L.orc_state_finish.argtypes = [vp]
+        L.orc_state_merge.argtypes = [vp, vp]
         L.orc_state_summary.argtypes = [vp, P(capi.ModelSummary)]
         L.orc_state_lib_counts.argtypes = [vp, vp]
         L.orc_state_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -117,6 +118,10 @@ class OrcState:
 
     def finish(self):
         lib().orc_state_finish(self.h)
+
+    def merge(self, other):
+        """SPEC §MG: fold the state of the next rank into this one (call in rank order on rank 0's state)."""
+        lib().orc_state_merge(self.h, other.h)
 
     def summary(self):
         s = capi.ModelSummary(); lib().orc_state_summary(self.h, C.byref(s))

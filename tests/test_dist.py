@@ -1,6 +1,7 @@
-"""N>1 path on CPU: two gloo ranks shard the reads, all-gather their eq-class tables with the same
-helper bench.py uses over RCCL, and merge them; the result must equal the single-process table bit
-for bit (counts and fixed-point weight sums are integers, so the merge is exact in any order)."""
+"""N>1 semantics on CPU (SPEC §MG), online model enabled: two gloo ranks shard the reads, each learns its own model, the tables are
+all-gathered and merged and the per-transcript state reduced (masses: logAdd in rank order through the library's
+sq_merge_log_masses); the result must equal the R-rank checker (orc_state_merge) bit for bit.  The product path does the same
+exchange over RCCL in C (sq_dist_*, hip/dist.hip); tests/test_dist_gpu.py drives that on the GPU box."""
 import os, socket
 import numpy as np
 import pytest
@@ -41,28 +42,37 @@ def _worker(rank, world, port, q):
     oidx = orc.OrcIndex(idx)
     N = 1200; per = N // world
     seq, off, _, _ = tx.reads(N, read_len=100, seed=3, threads=1)
-    opts = api.quant_opts(num_burnin_frags=10**9, num_pre_burnin_frags=10**9)   # weights independent of the online model
+    # the online model is ON (small burn-in, so the shards cross pre-burn-in -> aux params -> burned in): every rank learns its own
+    # model on its own shard, exactly what SPEC §MG defines
+    opts = api.quant_opts(mini_batch_size=100, num_pre_burnin_frags=80, num_burnin_frags=350)
     def run(lo, hi):
         s = seq[lo * 200: hi * 200]; o = (off[2 * lo: 2 * hi + 1] - off[2 * lo]).copy()
         rb = api.make_read_batch(s, o, hi - lo, paired=True)
         ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=1)
         ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish()
-        return ost.eq_finish(), ost.model()
-    eq, (lm, uq, tc, le, _) = run(rank * per, (rank + 1) * per)
+        return ost
+    mine = run(rank * per, (rank + 1) * per)
+    eq = mine.eq_finish(); lm, uq, tc, le, _ = mine.model()
     dev = torch.device("cpu")
     tables = sqdist.all_gather_tables(eq, dist, dev)
     lm2, uq2, tc2, le2 = sqdist.reduce_model(lm, uq, tc, le, dist, dev)
     keys, rows = merge_tables_host(tables)
     ok = True; msg = ""
     if rank == 0:
-        full, (lmf, uqf, tcf, lef, _) = run(0, N)
+        # the R-rank checker: every rank's state, folded into rank 0's in rank order (orc_state_merge = SPEC §MG)
+        states = [run(r * per, (r + 1) * per) for r in range(world)]
+        assert states[0].summary()["burned_in"]
+        for r in range(1, world): states[0].merge(states[r])
+        full = states[0].eq_finish(); lmf, uqf, tcf, lef, _ = states[0].model()
         fk = [(int(a), int(b)) for a, b in zip(full.h1, full.h2)]
         ok = fk == keys
         for c, row in enumerate(rows):
             a, b = int(full.off[c]), int(full.off[c + 1])
             ok = ok and np.array_equal(full.tid[a:b],
                 row[0]) and int(full.count[c]) == row[3] and [int(x) for x in full.wq[a:b]] == [int(x) for x in row[2]]
-        ok = ok and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf)
+        ok = ok and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf) and np.array_equal(lm2, lmf) and np.array_equal(le2, lef)
+        single = run(0, N)        # one rank over everything is a different realisation of the online phase (SPEC §MG) with the same totals
+        ok = ok and int(single.eq_finish().count.sum()) == int(full.count.sum())
         msg = "classes=%d" % len(keys)
     # every rank must hold identical merged keys: compare a digest
     digest = torch.tensor([hash(tuple(keys)) % (2**31)], dtype=torch.int64)
