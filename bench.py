@@ -33,6 +33,9 @@ def parse():
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
+    ap.add_argument("--fastq-pairs", type=int, default=4000000,
+        help="second measurement (outside the timed steps, rank 0, N=1): this many pairs written as plain FASTQ files to /dev/shm and run through "
+             "the host read pipeline (sq_reader) + the same GPU path, end to end from files (0 = skip)")
     ap.add_argument("--py-dist", action="store_true",
         help="N>1: exchange the class tables with torch.distributed collectives (salmon_amd/dist.py) instead of the library's own RCCL path (sq_dist_*, the default)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -64,6 +67,62 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         "eq_mini_batches": st["num_alignments"] * (40 + 12 + 3 * 16) + n_pairs * 32,
         "eq_table": st["num_alignments"] * (40 + 12 + 8) + n_pairs * (16 + 4 + 32),
     }
+
+
+def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
+    import ctypes as C
+    ctx.reset()
+    a1 = (C.c_char_p * 1)(files[0].encode()); a2 = (C.c_char_p * 1)(files[1].encode()); h = C.c_void_p()
+    lanes = 2
+    lib.sq_ctx_set_lanes(ctx.h, lanes)
+    t0 = time.perf_counter()
+    capi.check(lib.sq_reader_open(a1, 1, a2, 1, batch, lanes + 1, C.byref(h)), "sq_reader_open")
+    inflight = []; n = 0; tot_mapped = 0
+    def finish_one():
+        nonlocal tot_mapped
+        _, _, _, st = ctx.map_wait(); ctx.eq_accumulate(); tot_mapped += st["num_mapped"]
+        lib.sq_reader_release(h, inflight.pop(0)[1])
+    while True:
+        rb = capi.ReadBatch(); slot = C.c_int(-1)
+        capi.check(lib.sq_reader_next(h, C.byref(rb), C.byref(slot)), "sq_reader_next")
+        if rb.n == 0: break
+        if len(inflight) == lanes: finish_one()
+        ctx.map_submit(rb); inflight.append((rb, slot.value)); n += rb.n
+    while inflight: finish_one()
+    t_read_map = time.perf_counter() - t0
+    eq = ctx.eq_finish(); lm, uq, tc, le = ctx.model()
+    proj = api.normalize_alphas(eq, lm, uq, tc)
+    alphas, rep = ctx.em_optimize(np.exp(le), proj, api.em_opts())
+    dt = time.perf_counter() - t0
+    lib.sq_reader_close(h)
+    return {"value": round(n / dt / 1e6, 3), "unit": "M read-pairs/s", "pairs": int(n), "seconds": round(dt, 4), "read_map_eq_s": round(t_read_map, 4),
+            "mapped_frac": round(tot_mapped / max(1, n), 4), "em_iters": rep["iters"], "input": "2 plain FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n,
+                read_len, batch), "host_threads": os.cpu_count(), "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(16, hw/2)"),
+            "what": "end to end from files through sq_reader (mmap + parallel record split + page-locked batch assembly), H2D included; gzip input is bound by one inflate thread per mate file (~1.4 M pairs/s per file pair on this class of host)"}
+
+
+def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
+    """`salmon quant` from FASTQ files: sq_reader (parallel record splitting into page-locked batches) -> H2D -> mapping lanes -> online model /
+    eq-classes -> export -> normalizeAlphas -> VBEM.  Wall time from opening the files to the converged alphas."""
+    import ctypes as C, shutil, tempfile
+    d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        seq, off, _, _ = tx.reads(n_pairs, read_len=read_len, seed=77, first_pair=0, threads=threads, truth=False)
+        recs = seq.reshape(2 * n_pairs, read_len)
+        L = read_len; row = np.empty((n_pairs, 3 + L + 3 + L + 1), np.uint8)
+        row[:, 0:3] = np.frombuffer(b"@r\n", np.uint8); row[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", np.uint8); row[:, 6 + L:6 + 2 * L] = ord("I"); row[:, -1] = 10
+        files = []
+        for m in (0, 1):
+            row[:, 3:3 + L] = recs[m::2]
+            f = os.path.join(d, "r_%d.fq" % (m + 1)); row.tofile(f); files.append(f)
+        del row, recs, seq
+        lib = capi.lib(); ctx.set_profiling(False)
+        res = None
+        for attempt in range(2):   # the first pass sizes the work buffers of both mapping lanes and the reader's page-locked slots; the second is reported
+            res = _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len)
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def baseline_metric():
@@ -274,6 +333,9 @@ def main():
                "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S,
                    B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
                "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2)}
+    fq = None
+    if a.fastq_pairs > 0 and world == 1:
+        fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi)
     out = {
         "metric": baseline_metric(), "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
@@ -292,7 +354,7 @@ def main():
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes,
             "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
-        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu, "parity_check": parity,
+        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -9,7 +9,20 @@
 // keep one batch on every mapping lane (H2D + mapping) while the next one is being assembled.
 // A single gzip stream cannot be inflated in parallel; several files per mate are consumed in
 // order by the same producer, as the reference does.
+//
+// Fast path (round 2): FASTQ with one-line sequences and qualities — what sequencers write.  A stream thread cuts the input into
+// ~8 MB chunks at record boundaries (plain files are mmap'ed: the chunk is a window of the page cache, nothing is copied; .gz files
+// are inflated by the stream thread — the sequential floor of a gzip stream — into chunk buffers), a pool of workers finds the
+// records of the chunks in parallel (memchr per line, every record checked for the 4-line shape), and sq_reader_next assembles the
+// interleaved batch in the page-locked slot with the same pool (per-part byte totals, a scan, parallel copies): one copy per base from
+// the page cache to the buffer the GPU reads.  FASTA, multi-line records and SQ_READER_SAFE=1 take the kseq-rules path below.
 #include "index.h"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <functional>
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 #include <condition_variable>
@@ -132,6 +145,174 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
   out->finish();
 }
 
+
+// ---- fast path ----------------------------------------------------------------------------------------------------------------
+struct Pool {   // a few workers shared by the parse tasks of both streams and the batch assembly
+  std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th; bool stop = false;
+  explicit Pool(unsigned n) { for (unsigned i = 0; i < n; ++i) th.emplace_back([this] { run(); }); }
+  ~Pool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+  void run() { for (;;) { std::function<void()> f; { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); } f(); } }
+  void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+  // run fn(0..n-1) on the pool and wait
+  void parallel(unsigned n, const std::function<void(unsigned)>& fn) {
+    if (n <= 1) { if (n) fn(0); return; }
+    std::mutex m; std::condition_variable c; unsigned left = n;
+    for (unsigned i = 0; i < n; ++i) submit([&, i] { fn(i); std::lock_guard<std::mutex> lk(m); if (--left == 0) c.notify_one(); });
+    std::unique_lock<std::mutex> lk(m); c.wait(lk, [&] { return left == 0; });
+  }
+};
+
+struct Mapping { void* p = nullptr; size_t n = 0; ~Mapping() { if (p) munmap(p, n); } };
+struct Chunk {   // a run of whole records of one stream, in stream order
+  const char* text = nullptr; size_t bytes = 0; std::vector<char> own; std::shared_ptr<Mapping> map;   // window of an mmap, or an owned buffer (.gz)
+  std::vector<uint32_t> pos, len;   // per record: where its bases start in `text`, how many
+  std::string path; uint64_t first_record = 0;
+  bool done = false; std::string err;
+};
+struct ChunkQueue {   // ordered, bounded: the stream thread appends chunks, workers complete them, the consumer takes them in order
+  std::mutex mu; std::condition_variable cv_done, cv_room; std::deque<std::shared_ptr<Chunk>> q; bool eof = false; std::string err; size_t cap = 24;
+  void push(std::shared_ptr<Chunk> c) { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return q.size() < cap || eof; }); if (eof) return; q.push_back(std::move(c)); }
+  void complete() { { std::lock_guard<std::mutex> lk(mu); } cv_done.notify_all(); }
+  void finish(const std::string& e = std::string()) { { std::lock_guard<std::mutex> lk(mu); eof = true; if (!e.empty() && err.empty()) err = e; } cv_done.notify_all(); cv_room.notify_all(); }
+  std::shared_ptr<Chunk> pop() {   // next chunk in order once its records are known; nullptr at the end (or on error: see err)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return (!q.empty() && q.front()->done) || (q.empty() && eof); });
+    if (q.empty()) return nullptr;
+    auto c = q.front(); q.pop_front(); cv_room.notify_one();
+    if (!c->err.empty() && err.empty()) err = c->err;
+    return c;
+  }
+};
+
+// start of the first whole 4-line record at or after `from` (which must be a line start), or `end` if none begins there
+const char* record_start(const char* from, const char* end) {
+  const char* p = from;
+  while (p < end) {
+    const char* e0 = (const char*)memchr(p, '\n', (size_t)(end - p)); if (!e0) return end;
+    if (*p == '@') {
+      const char* l1 = e0 + 1; const char* e1 = l1 < end ? (const char*)memchr(l1, '\n', (size_t)(end - l1)) : nullptr;
+      if (!e1) return end;
+      const char* l2 = e1 + 1; const char* e2 = l2 < end ? (const char*)memchr(l2, '\n', (size_t)(end - l2)) : nullptr;
+      if (!e2) return end;
+      const char* l3 = e2 + 1; const char* e3 = l3 < end ? (const char*)memchr(l3, '\n', (size_t)(end - l3)) : end;
+      if (!e3) e3 = end;
+      if (*l2 == '+' && (e3 - l3) - ((e3 > l3 && e3[-1] == '\r') ? 1 : 0) == (e1 - l1) - ((e1 > l1 && e1[-1] == '\r') ? 1 : 0)) return p;
+    }
+    p = e0 + 1;
+  }
+  return end;
+}
+
+void parse_chunk(Chunk* c) {
+  const char* p = c->text; const char* end = c->text + c->bytes;
+  c->pos.reserve(c->bytes / 200 + 16); c->len.reserve(c->bytes / 200 + 16);
+  uint64_t rec = c->first_record;
+  auto fail = [&](const char* what) { c->err = "'" + c->path + "': record " + std::to_string(rec + 1) + " " + what + " (multi-line FASTQ? set SQ_READER_SAFE=1)"; };
+  while (p < end) {
+    if (*p == '\n' || *p == '\r') { ++p; continue; }                       // blank line between records
+    if (*p != '@') { fail("does not start with '@'"); return; }
+    const char* e0 = (const char*)memchr(p, '\n', (size_t)(end - p)); if (!e0) { fail("is truncated"); return; }
+    const char* l1 = e0 + 1; const char* e1 = (const char*)memchr(l1, '\n', (size_t)(end - l1)); if (!e1) { fail("is truncated"); return; }
+    const char* l2 = e1 + 1; const char* e2 = l2 < end ? (const char*)memchr(l2, '\n', (size_t)(end - l2)) : nullptr; if (!e2 || *l2 != '+') { fail(e2 ? "has no '+' line after one sequence line" : "is truncated"); return; }
+    const char* l3 = e2 + 1; const char* e3 = l3 <= end ? (const char*)memchr(l3, '\n', (size_t)(end - l3)) : nullptr; if (!e3) e3 = end;
+    size_t sl = (size_t)(e1 - l1); if (sl && l1[sl - 1] == '\r') --sl;
+    size_t ql = (size_t)(e3 - l3); if (ql && l3[ql - 1] == '\r') --ql;
+    if (ql != sl) { fail(ql > sl ? "has a quality string longer than its sequence" : "has a quality string shorter than its sequence: truncated record"); return; }
+    c->pos.push_back((uint32_t)(l1 - c->text)); c->len.push_back((uint32_t)sl); ++rec;
+    p = e3 < end ? e3 + 1 : end;
+  }
+}
+
+// does the file look like 4-line FASTQ?  Every record that lies wholly inside the first bytes of the file must have the shape
+// '@' header / one sequence line / '+' line / one quality line of the same length (wrapped files wrap from the first record on)
+bool looks_like_simple_fastq(const char* b, size_t n) {
+  if (!n || b[0] != '@') return false;
+  const char* end = b + n; const char* p = b; int seen = 0;
+  while (p < end) {
+    if (*p == '\n' || *p == '\r') { ++p; continue; }
+    const char* e0 = (const char*)memchr(p, '\n', (size_t)(end - p)); if (!e0) break;
+    const char* l1 = e0 + 1; const char* e1 = l1 < end ? (const char*)memchr(l1, '\n', (size_t)(end - l1)) : nullptr; if (!e1) break;
+    const char* l2 = e1 + 1; const char* e2 = l2 < end ? (const char*)memchr(l2, '\n', (size_t)(end - l2)) : nullptr; if (!e2) break;
+    const char* l3 = e2 + 1; const char* e3 = l3 < end ? (const char*)memchr(l3, '\n', (size_t)(end - l3)) : nullptr; if (!e3) break;
+    size_t sl = (size_t)(e1 - l1); if (sl && l1[sl - 1] == '\r') --sl;
+    size_t ql = (size_t)(e3 - l3); if (ql && l3[ql - 1] == '\r') --ql;
+    if (*p != '@' || *l2 != '+' || sl != ql) return false;
+    ++seen; p = e3 + 1;
+  }
+  return seen > 0 || n < 65536;   // a tiny file without one whole record: let the parser say what is wrong with it
+}
+
+const size_t CHUNK_BYTES = 8u << 20;
+
+// one mate stream on the fast path; returns false (nothing consumed) if the first file is not simple FASTQ and the safe path should run
+void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool) {
+  uint64_t nrec_before = 0;
+  auto dispatch = [&](std::shared_ptr<Chunk> c) {
+    out->push(c);
+    pool->submit([c, out] { parse_chunk(c.get()); c->done = true; out->complete(); });
+  };
+  for (const auto& path : files) {
+    const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    if (!gz) {
+      int fd = open(path.c_str(), O_RDONLY); if (fd < 0) { out->finish("cannot open '" + path + "'"); return; }
+      struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); out->finish("cannot stat '" + path + "'"); return; }
+      const size_t n = (size_t)sb.st_size;
+      if (n == 0) { close(fd); continue; }
+      void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+      if (m == MAP_FAILED) { out->finish("cannot map '" + path + "'"); return; }
+      (void)madvise(m, n, MADV_SEQUENTIAL);
+      auto map = std::make_shared<Mapping>(); map->p = m; map->n = n;
+      const char* base = (const char*)m; const char* end = base + n; const char* p = base;
+      while (p < end) {
+        const char* q = p + CHUNK_BYTES;
+        if (q >= end) q = end;
+        else { const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q)); q = nl ? record_start(nl + 1, end) : end; }
+        auto c = std::make_shared<Chunk>(); c->text = p; c->bytes = (size_t)(q - p); c->map = map; c->path = path; c->first_record = nrec_before;
+        nrec_before += c->bytes / 250;   // only used in messages
+        dispatch(c); p = q;
+      }
+    } else {
+      gzFile f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; }
+      gzbuffer(f, 1 << 20);
+      std::vector<char> carry;
+      for (;;) {
+        auto c = std::make_shared<Chunk>(); c->own.resize(carry.size() + CHUNK_BYTES);
+        if (!carry.empty()) memcpy(c->own.data(), carry.data(), carry.size());
+        size_t have = carry.size(); carry.clear();
+        size_t got = 0; bool eof = false;
+        while (got < CHUNK_BYTES) {
+          const int r = gzread(f, c->own.data() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
+          if (r < 0) { int e; std::string msg = gzerror(f, &e); gzclose(f); out->finish("read error in '" + path + "': " + msg); return; }
+          if (r == 0) { eof = true; break; }
+          got += (size_t)r;
+        }
+        const size_t tot = have + got;
+        if (tot == 0) break;
+        size_t cut = tot;
+        if (!eof) {   // keep the incomplete tail for the next chunk: cut at the last record start whose four lines are all here
+          const char* b = c->own.data(); const char* e = b + tot; cut = 0;
+          size_t back = std::min<size_t>(tot, 1u << 16);
+          for (;;) {
+            const char* from = e - back; const char* nl = (const char*)memchr(from, '\n', (size_t)(e - from));
+            const char* last = nullptr; const char* x = (from == b) ? b : (nl ? nl + 1 : e);
+            while (x < e) { const char* r0 = record_start(x, e); if (r0 >= e) break; last = r0; const char* n0 = (const char*)memchr(r0, '\n', (size_t)(e - r0)); x = n0 ? n0 + 1 : e; }
+            if (last) { cut = (size_t)(last - b); break; }
+            if (back == tot) break;
+            back = std::min<size_t>(tot, back * 4);
+          }
+          if (cut == 0) { gzclose(f); out->finish("'" + path + "': no FASTQ record boundary in a " + std::to_string(tot) + "-byte window (set SQ_READER_SAFE=1)"); return; }
+          carry.assign(c->own.data() + cut, c->own.data() + tot);
+        }
+        c->text = c->own.data(); c->bytes = cut; c->path = path; c->first_record = nrec_before; nrec_before += cut / 250;
+        dispatch(c);
+        if (eof) break;
+      }
+      gzclose(f);
+    }
+  }
+  out->finish();
+}
+
 struct Slot { uint8_t* seq = nullptr; size_t seq_cap = 0; uint64_t* off = nullptr; size_t off_cap = 0; bool pinned = false,
     off_pinned = false; bool busy = false; };
 
@@ -149,10 +330,41 @@ void host_free(void* p, bool pinned) { if (!p) return; if (pinned) (void)hipHost
 
 struct sq_reader {
   bool paired = false; uint32_t batch = 0; BlockQueue q[2]; std::thread th[2];
+  // fast path
+  bool fast = false; std::unique_ptr<Pool> pool; ChunkQueue cq[2]; std::shared_ptr<Chunk> fc[2]; size_t fidx[2] = {0, 0}; bool fend[2] = {false, false};
+  struct Seg { std::shared_ptr<Chunk> c; size_t first, count; };
+  // up to `want` records of stream i, in order, without consuming them
+  size_t gather(int i, size_t want, std::vector<Seg>& out) {
+    size_t got = 0; std::shared_ptr<Chunk> c = fc[i]; size_t idx = fidx[i];
+    out.clear();
+    // records of chunks beyond the current one are looked at by popping: popped chunks are kept in `ahead`
+    size_t ai = 0;
+    while (got < want) {
+      if (!c || idx >= c->pos.size()) {
+        if (ai < ahead[i].size()) { c = ahead[i][ai++]; idx = 0; continue; }
+        if (fend[i]) break;
+        auto nc = cq[i].pop();
+        if (!nc) { fend[i] = true; break; }
+        ahead[i].push_back(nc); continue;
+      }
+      const size_t take = std::min(want - got, c->pos.size() - idx);
+      out.push_back({c, idx, take}); got += take; idx += take;
+    }
+    return got;
+  }
+  void consume(int i, size_t n) {   // advance the cursor of stream i by n records
+    while (n) {
+      if (!fc[i] || fidx[i] >= fc[i]->pos.size()) { fc[i] = ahead[i].front(); ahead[i].erase(ahead[i].begin()); fidx[i] = 0; continue; }
+      const size_t take = std::min(n, fc[i]->pos.size() - fidx[i]); fidx[i] += take; n -= take;
+    }
+    if (fc[i] && fidx[i] >= fc[i]->pos.size() && !ahead[i].empty()) { fc[i] = ahead[i].front(); ahead[i].erase(ahead[i].begin()); fidx[i] = 0; }
+  }
+  std::vector<std::shared_ptr<Chunk>> ahead[2];
   std::unique_ptr<RecBlock> cur[2]; size_t cur_rec[2] = {0, 0}, cur_byte[2] = {0, 0};
   std::vector<Slot> slots; uint64_t total = 0; bool ended = false;
   ~sq_reader() {
-    for (int i = 0; i < 2; ++i) { q[i].finish(); if (th[i].joinable()) th[i].join(); }
+    for (int i = 0; i < 2; ++i) { q[i].finish(); cq[i].finish(); if (th[i].joinable()) th[i].join(); }
+    pool.reset();   // after the stream threads: no more tasks are submitted
     for (auto& s : slots) { host_free(s.seq, s.pinned); host_free(s.off, s.off_pinned); }
   }
   // next record of stream i -> (ptr, len); false at end of stream
@@ -181,8 +393,23 @@ extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char
   std::unique_ptr<sq_reader> R(new sq_reader()); R->paired = n2 > 0; R->batch = batch_reads;
   R->slots.resize(num_slots < 2 ? 2 : (num_slots > 8 ? 8 : num_slots));
   std::vector<std::string> a(files1, files1 + n1), b; if (n2) b.assign(files2, files2 + n2);
-  R->th[0] = std::thread(produce, a, &R->q[0]);
-  if (n2) R->th[1] = std::thread(produce, b, &R->q[1]);
+  // fast path for 4-line FASTQ (the first record of every file is looked at); anything else takes the kseq-rules path
+  bool fast = !getenv("SQ_READER_SAFE");
+  for (int st = 0; st < 2 && fast; ++st) for (const auto& path : (st ? b : a)) {
+    std::vector<char> head(65536); gzFile f = gzopen(path.c_str(), "rb"); if (!f) { fast = false; break; }   // the stream thread reports it
+    const int n = gzread(f, head.data(), (unsigned)head.size()); gzclose(f);
+    if (n > 0 && !looks_like_simple_fastq(head.data(), (size_t)n)) { fast = false; break; }
+  }
+  R->fast = fast;
+  if (fast) {
+    unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    R->pool.reset(new Pool(std::max(1u, nt)));
+    R->th[0] = std::thread(produce_fast, a, &R->cq[0], R->pool.get());
+    if (n2) R->th[1] = std::thread(produce_fast, b, &R->cq[1], R->pool.get());
+  } else {
+    R->th[0] = std::thread(produce, a, &R->q[0]);
+    if (n2) R->th[1] = std::thread(produce, b, &R->q[1]);
+  }
   *out = R.release();
   return SQ_OK;
 }
@@ -218,6 +445,51 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
     S.seq = nb; S.seq_cap = cap; S.pinned = pin; return true;
   };
   if (!grow((size_t)nrec_max * 160 + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
+  if (R->fast) {
+    std::vector<sq_reader::Seg> sg[2];
+    const int ns = R->paired ? 2 : 1;
+    size_t got[2] = {0, 0};
+    for (int i = 0; i < ns; ++i) got[i] = R->gather(i, R->batch, sg[i]);
+    for (int i = 0; i < ns; ++i) if (!R->cq[i].err.empty()) { R->ended = true; sq_set_error("%s", R->cq[i].err.c_str()); return SQ_ERR_IO; }
+    size_t n = got[0];
+    if (R->paired && got[0] != got[1]) {   // one stream ended early
+      R->ended = true;
+      sq_set_error("mate files have different numbers of records (stopped after %llu pairs)", (unsigned long long)(R->total + std::min(got[0], got[1])));
+      return SQ_ERR_IO;
+    }
+    if (n < R->batch) R->ended = true;
+    if (n == 0) return SQ_OK;
+    // flat per-stream views of the batch's records: segment prefix counts
+    std::vector<size_t> pre[2]; for (int i = 0; i < ns; ++i) { pre[i].assign(sg[i].size() + 1, 0); for (size_t k = 0; k < sg[i].size(); ++k) pre[i][k + 1] = pre[i][k] + sg[i][k].count; }
+    const unsigned K = (unsigned)std::max<size_t>(1, std::min<size_t>(R->pool->th.size(), n / 4096 + 1));
+    std::vector<uint64_t> part_bytes(K + 1, 0);
+    auto walk = [&](unsigned j, bool fill) {
+      const size_t a = n * j / K, b2 = n * (j + 1) / K;
+      size_t k[2] = {0, 0}; for (int i = 0; i < ns; ++i) while (pre[i][k[i] + 1] <= a && k[i] + 1 < sg[i].size()) ++k[i];
+      uint64_t bytes = fill ? part_bytes[j] : 0;
+      for (size_t r = a; r < b2; ++r) {
+        for (int i = 0; i < ns; ++i) {
+          while (r >= pre[i][k[i] + 1]) ++k[i];
+          const sq_reader::Seg& g = sg[i][k[i]]; const size_t x = g.first + (r - pre[i][k[i]]);
+          const uint32_t l = g.c->len[x];
+          if (fill) { memcpy(S.seq + bytes, g.c->text + g.c->pos[x], l); S.off[(R->paired ? 2 * r : r) + (size_t)i + 1] = bytes + l; }
+          bytes += l;
+        }
+      }
+      if (!fill) part_bytes[j + 1] = bytes;
+    };
+    R->pool->parallel(K, [&](unsigned j) { walk(j, false); });
+    { uint64_t acc = 0; for (unsigned j = 0; j < K; ++j) { const uint64_t v = part_bytes[j + 1]; part_bytes[j] = acc; acc += v; } part_bytes[K] = acc; }
+    const uint64_t bytes = part_bytes[K];
+    if (!grow(bytes + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
+    S.off[0] = 0;
+    R->pool->parallel(K, [&](unsigned j) { walk(j, true); });
+    memset(S.seq + bytes, 0, 16);
+    for (int i = 0; i < ns; ++i) R->consume(i, n);
+    S.busy = true; R->total += n;
+    b->n = (uint32_t)n; b->seq = S.seq; b->seq_off = S.off; b->on_device = 0; *slot = si;
+    return SQ_OK;
+  }
   uint32_t n = 0; uint64_t bytes = 0; S.off[0] = 0;
   while (n < R->batch) {
     const char* p1; uint32_t l1; const char* p2 = nullptr; uint32_t l2 = 0;

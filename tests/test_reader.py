@@ -114,3 +114,38 @@ def test_reader_multi_line_records(built, tmp_path):
     open(tmp_path / "u.fq", "w").write("@r0\nACGT\n+\nII\n")
     h = _open([str(tmp_path / "u.fq")], None, batch=8); got, err = _drain(h); capi.lib().sq_reader_close(h)
     assert err is not None and "truncated" in err
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_reader_fast_path_across_chunks(built, tmp_path, gz, monkeypatch):
+    # the parallel path (4-line FASTQ): files larger than several 8 MB chunks, ragged read lengths, quality lines that begin with '@',
+    # CRLF in one mate, two files per mate, a batch size that divides nothing; the same bytes must come out as from the kseq-rules path
+    rng = np.random.default_rng(11)
+    def write(path, n, crlf, seed):
+        r = np.random.default_rng(seed); nl = b"\r\n" if crlf else b"\n"
+        lens = r.integers(80, 152, n); bases = r.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(lens.sum()), p=[.24, .24, .24, .24, .04]).tobytes()
+        out = []; p = 0; recs = []
+        for i, l in enumerate(lens):
+            s = bases[p:p + l]; p += l; recs.append(s)
+            q = (b"@" if i % 7 == 0 else b"I") + b"F" * (l - 1)
+            out.append(b"@read%d/1 extra" % i + nl + s + nl + b"+" + nl + q + nl)
+        data = b"".join(out)
+        (gzip.open(path, "wb", compresslevel=1) if gz else open(path, "wb")).write(data)
+        return recs
+    ext = ".fq.gz" if gz else ".fq"
+    n1, n2 = 90000, 30011
+    a1 = write(tmp_path / ("a_1" + ext), n1, False, 1); a2 = write(tmp_path / ("a_2" + ext), n1, True, 2)
+    b1 = write(tmp_path / ("b_1" + ext), n2, False, 3); b2 = write(tmp_path / ("b_2" + ext), n2, False, 4)
+    assert os.path.getsize(tmp_path / ("a_1" + ext)) > (3 << 20)
+    f1 = [str(tmp_path / ("a_1" + ext)), str(tmp_path / ("b_1" + ext))]; f2 = [str(tmp_path / ("a_2" + ext)), str(tmp_path / ("b_2" + ext))]
+    want = [x for pair in zip(a1 + b1, a2 + b2) for x in pair]
+    for threads in ("1", "5"):
+        monkeypatch.setenv("SQ_READER_THREADS", threads)
+        h = _open(f1, f2, batch=33333); got, err = _drain(h)
+        assert err is None, err
+        assert capi.lib().sq_reader_total(h) == n1 + n2
+        capi.lib().sq_reader_close(h)
+        assert [len(b) // 2 for b in got][:3] == [33333] * 3 and [r for b in got for r in b] == want
+    monkeypatch.setenv("SQ_READER_SAFE", "1")
+    h = _open(f1, f2, batch=50000); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is None and [r for b in got for r in b] == want
