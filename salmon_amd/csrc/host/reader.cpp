@@ -172,7 +172,7 @@ struct Chunk {   // a run of whole records of one stream, in stream order
 struct ChunkQueue {   // ordered, bounded: the stream thread appends chunks, workers complete them, the consumer takes them in order
   std::mutex mu; std::condition_variable cv_done, cv_room; std::deque<std::shared_ptr<Chunk>> q; bool eof = false; std::string err; size_t cap = 24;
   void push(std::shared_ptr<Chunk> c) { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return q.size() < cap || eof; }); if (eof) return; q.push_back(std::move(c)); }
-  void complete() { { std::lock_guard<std::mutex> lk(mu); } cv_done.notify_all(); }
+  void complete(Chunk* c) { { std::lock_guard<std::mutex> lk(mu); c->done = true; } cv_done.notify_all(); }
   void finish(const std::string& e = std::string()) { { std::lock_guard<std::mutex> lk(mu); eof = true; if (!e.empty() && err.empty()) err = e; } cv_done.notify_all(); cv_room.notify_all(); }
   std::shared_ptr<Chunk> pop() {   // next chunk in order once its records are known; nullptr at the end (or on error: see err)
     std::unique_lock<std::mutex> lk(mu);
@@ -249,7 +249,7 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool) {
   uint64_t nrec_before = 0;
   auto dispatch = [&](std::shared_ptr<Chunk> c) {
     out->push(c);
-    pool->submit([c, out] { parse_chunk(c.get()); c->done = true; out->complete(); });
+    pool->submit([c, out] { parse_chunk(c.get()); out->complete(c.get()); });
   };
   for (const auto& path : files) {
     const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
@@ -444,13 +444,13 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
     if (S.seq) { memcpy(nb, S.seq, S.seq_cap); host_free(S.seq, S.pinned); }
     S.seq = nb; S.seq_cap = cap; S.pinned = pin; return true;
   };
-  if (!grow((size_t)nrec_max * 160 + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
+  if (!grow((size_t)nrec_max * 128 + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
   if (R->fast) {
     std::vector<sq_reader::Seg> sg[2];
     const int ns = R->paired ? 2 : 1;
     size_t got[2] = {0, 0};
     for (int i = 0; i < ns; ++i) got[i] = R->gather(i, R->batch, sg[i]);
-    for (int i = 0; i < ns; ++i) if (!R->cq[i].err.empty()) { R->ended = true; sq_set_error("%s", R->cq[i].err.c_str()); return SQ_ERR_IO; }
+    for (int i = 0; i < ns; ++i) { std::string e; { std::lock_guard<std::mutex> lk(R->cq[i].mu); e = R->cq[i].err; } if (!e.empty()) { R->ended = true; sq_set_error("%s", e.c_str()); return SQ_ERR_IO; } }
     size_t n = got[0];
     if (R->paired && got[0] != got[1]) {   // one stream ended early
       R->ended = true;
