@@ -276,11 +276,11 @@ def main():
         ach = per_launch / (stage_rows[dom]["avg_ms"] * 1e-3) / 1e9
         traffic = None; tnote = "no PMC profile committed for this kernel"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             kk = pm["kernels"].get(single[dom])
             if kk and kk.get("fetch_bytes_per_launch") is not None:
                 traffic = int(kk["fetch_bytes_per_launch"] + (kk.get("write_bytes_per_launch") or 0))
-                tnote = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload at --steps 2); PMC cannot be sampled inside the timed run"
+                tnote = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload at --steps 2); PMC cannot be sampled inside the timed run"
         except Exception:
             pass
         roof = {"kernel": single[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
