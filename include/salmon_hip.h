@@ -135,7 +135,8 @@ typedef struct {
   uint8_t lib_autodetect;     /* 0; 1 = `-l A` (LibraryTypeDetector.hpp, SalmonQuantify.cpp:496-501,692-704): lib_* above hold the starting format
                                  (IU paired / U single, nothing is penalised as incompatible meanwhile); once 50 000 alignments of the
                                  library's read type have been seen the most likely format replaces it for the online model (SPEC §D8) */
-  uint8_t _pad1;
+  uint8_t gc_bias;            /* 0; 1 = --gcBias: collect the observed fragment-GC model while mapping (SalmonQuantify.cpp:938-972; paired-end
+                                 libraries); the expected model and the bias-corrected effective lengths come from sq_bias_gc_eff_lengths */
   /* online model (SalmonQuantify.cpp:426-1023) */
   uint32_t mini_batch_size;   /* 5000 (SalmonQuantify.cpp:150) */
   uint32_t num_pre_burnin_frags; /* 5000 */
@@ -348,6 +349,25 @@ int sq_em_optimize_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp,
 /* Run exactly `iters` update steps from the given alpha (benchmarking / parity of single steps). */
 int sq_em_steps_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts,
                     const double* alpha_in, uint32_t iters, double* alpha_out, sq_em_report* report);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bias-corrected effective lengths (row f-3; --gcBias).  The observed fragment-GC model is collected by the online stage when
+ * sq_quant_opts.gc_bias is set (observedGCMass, SalmonQuantify.cpp:938-972); the expected model and the corrected lengths replace
+ * salmon::utils::updateEffectiveLengths (src/util/SalmonUtils.cpp:1208-1985, gcBiasCorrect branches), which the optimizer calls at
+ * iteration > 10 (CollapsedEMOptimizer.cpp:901-928): sq_em_optimize_bias does that call through `cb`.
+ * ---------------------------------------------------------------------------------------------- */
+int sq_model_fetch_gc_observed(sq_ctx*, double* out /*[3][25] conditional bin x fragment-GC bin, linear-space masses*/);
+typedef struct { uint32_t num_processed; int32_t fld_low, fld_high; uint32_t _pad; double gc_bias_row0[25]; } sq_bias_report;
+/* idx must be on a device: the sweep over (transcript, fragment start, sampled length) runs there. */
+int sq_bias_gc_eff_lengths(sq_index* idx, const double* gc_observed /*[75]*/, const double* log_pmf_1001, uint32_t num_txp,
+                           const double* alphas, const double* eff_len_in, double* eff_len_out, sq_bias_report* report);
+/* updateEffectiveLengths as a callback: alphas and current effective lengths in, new effective lengths out; non-zero aborts. */
+typedef int (*sq_efflen_cb)(const double* alphas, const double* eff_len_in, double* eff_len_out, uint32_t m, void* user);
+/* sq_em_optimize with the bias hook: after 11 updates (itNum > 10) `cb` is called once, priors and combined class weights are rebuilt
+ * from the new effective lengths (updateEqClassWeights, CollapsedEMOptimizer.cpp:160-176) and the iteration goes on.
+ * eff_len_out (may be NULL) receives the lengths the optimisation ended with (Transcript::EffectiveLength, :1024-1027). */
+int sq_em_optimize_bias(sq_ctx*, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, sq_efflen_cb cb, void* user,
+                        double* alpha_out, double* eff_len_out, sq_em_report* report);
 
 /* Host-side, once per run: salmon::utils::normalizeAlphas (src/util/SalmonUtils.cpp:461-529) with
  * TranscriptCluster::projectToPolytope — online masses -> projectedCounts used to initialise EM. */

@@ -786,6 +786,28 @@ struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, ke
   }
 };
 
+// ---- fragment-GC bias (row f-3, --gcBias): own restatement, G/C counted base by base ------------------------------------------
+static inline bool is_gc(const Index& ix, uint32_t t, int32_t i) { uint32_t b = base_at(ix.refseq.data(), ix.ref_accum[t] + (uint64_t)i); return b == 1 || b == 2; }
+static inline int64_t gc_upto(const Index& ix, uint32_t t, int32_t i) { int64_t c = 0; for (int32_t x = 0; x <= i; ++x) c += is_gc(ix, t, x) ? 1 : 0; return c; }   // GCCount_[i]
+// Transcript::gcDesc (Transcript.hpp:294-341)
+static bool gc_desc(const Index& ix, uint32_t t, int32_t s, int32_t e, int32_t* fragFrac, int32_t* ctxFrac) {
+  const int32_t RefLength = (int32_t)ix.ref_len[t]; const int lastPos = RefLength - 1;
+  auto G = [&](int32_t i) { return gc_upto(ix, t, i); };
+  int64_t cs = (s > 0) ? G(s - 1) : 0, ce = G(e);
+  int fs = s - 4, fe = s + 1, ts = e - 2, te = e + 3;
+  bool fpLeftExists = fs >= 0, fpRightExists = fe <= lastPos, tpLeftExists = ts >= 0, tpRightExists = te <= lastPos;
+  int64_t fps = fpLeftExists ? G(fs) : 0, fpe = fpRightExists ? G(fe) : ce, tps = tpLeftExists ? G(ts) : 0, tpe = tpRightExists ? G(te) : ce;
+  fs = fs < 0 ? 0 : fs; fe = fe > lastPos ? lastPos : fe; ts = ts < 0 ? 0 : ts; te = te > lastPos ? lastPos : te;
+  int fpContextSize = !fpLeftExists ? (fe + 1) : (fe - fs), tpContextSize = !tpLeftExists ? (te + 1) : (te - ts);
+  double contextSize = (double)(fpContextSize + tpContextSize);
+  if (contextSize == 0) return false;
+  *fragFrac = (int32_t)std::lrint((100.0 * (double)(ce - cs)) / (double)(e - s + 1));
+  *ctxFrac = (int32_t)std::lrint(100.0 * ((double)((fpe - fps) + (tpe - tps)) / contextSize));
+  return true;
+}
+static inline int32_t gc_frag_bin(int32_t f) { double w = 100.0 / 25; return std::min(24, (int32_t)((double)f / w)); }   // GCDesc::fragBin(25)
+static inline int32_t gc_ctx_bin(int32_t f) { double w = 100.0 / 3; return std::min(2, (int32_t)((double)f / w)); }       // GCDesc::contextBin(3)
+
 struct EqVal { uint64_t count = 0; std::vector<uint64_t> wq; };
 struct QuantState {
   const Index* ix; Opts op;
@@ -796,6 +818,7 @@ struct QuantState {
   uint64_t numObserved = 0, numAssigned = 0, numMappedUB = 0, batchNo = 0, numCompat = 0; bool burnedIn = false;
   std::map<std::vector<uint32_t>, EqVal> eq;  // label (tids + bins) -> value
   std::vector<uint64_t> libCounts;
+  uint64_t gcObs[75] = {0};   // observedGCMass (SalmonQuantify.cpp:938-972): sums of the normalised alignment probabilities, fixed point 2^-32 (order-free)
   uint64_t readCounter = 0;
   // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
@@ -995,6 +1018,12 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       double nlp = lp[i] - sumProbs; double pr = sq_exp(nlp);
       S.massAcc[tids[i]] += sq_to_fixed(pr, SQ_MFRAC_BITS);
       S.total[tids[i]] += 1;
+      if (o.gc_bias && (ka[i]->format_id & 1u) == 1u) {   // :938-951, paired-end observation
+        const sq_aln& a = *ka[i];
+        int32_t start = std::min(a.pos, a.mate_pos), stop = start + (int32_t)a.frag_len - 1, ff, cf;
+        if (start >= 0 && stop < (int32_t)ix.ref_len[tids[i]] && stop >= start && gc_desc(ix, tids[i], start, stop, &ff, &cf))
+          S.gcObs[gc_ctx_bin(cf) * 25 + gc_frag_bin(ff)] += sq_to_fixed(pr, 32);
+      }
       if (!burned) {
         double rr = u01(o.seed, readIdx, i);
         if (rr < pr) {
@@ -1125,11 +1154,11 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
 
 // iteration loop shared by optimize (minIter 100) and the bootstrap replicates (minIter 50)
 static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters,
-    bool* converged, double* max_rel) {
+    bool* converged, double* max_rel, uint32_t it0 = 0, uint32_t stop_at = 0 /* > 0: exactly the iterations [it0, stop_at) */) {
   const uint32_t M = P.M;
   std::vector<double> alphaP(M), theta(M), inv(P.E);
-  uint32_t it = 0; bool conv = false; double maxRel = -1.7976931348623157e308;
-  while (it < min_iter || (it < o->max_iter && !conv)) {
+  uint32_t it = it0; bool conv = false; double maxRel = -1.7976931348623157e308;
+  while (stop_at ? it < stop_at : (it < min_iter || (it < o->max_iter && !conv))) {
     em_step(P, o, alpha, alphaP, theta, inv);
     conv = true; maxRel = -1.7976931348623157e308;
     for (uint32_t i = 0; i < M; ++i) {
@@ -1185,6 +1214,131 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
 }
 
 // a16 — gatherBootstraps / doBootstrap (CollapsedEMOptimizer.cpp:398-690); SPEC §a16
+static int bias_gc_eff_lengths(const Index& ix, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in,
+                               double* eff_out, double* bias_row0_out);
+// salmon::utils::updateEffectiveLengths, gcBiasCorrect branches only (SalmonUtils.cpp:1208-1985), restated loop by loop; the sums follow
+// SPEC §B: windows are counted as integers per (transcript, sampled length, GC bin), per-transcript terms are added in length order, the
+// expected model is the canonical (blocked-64) sum over the processed transcripts in ascending id
+static int bias_gc_eff_lengths(const Index& ix, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in,
+                               double* eff_out, double* bias_row0_out) {
+  const int MAXV = 1000; const int32_t gcSamp = 5;
+  std::vector<double> pdf(MAXV + 1), cdf(MAXV + 1); int32_t fldLow = 0, fldHigh = 1; bool lb = false, ub = false;
+  for (int i = 0; i <= MAXV; ++i) {
+    pdf[i] = sq_exp(log_pmf[i]); cdf[i] = (i > 0) ? cdf[i - 1] + pdf[i] : pdf[i];
+    if (!lb && cdf[i] >= 0.005) { lb = true; fldLow = i; }
+    if (!ub && cdf[i] >= 1.0 - 0.005) { ub = true; fldHigh = i; }
+  }
+  std::vector<std::vector<double>> contrib(25);
+  std::vector<uint32_t> processed;
+  // per transcript: G/C prefix (GCCount_), then the two sweeps
+  auto prefix = [&](uint32_t t) { std::vector<int32_t> g(ix.ref_len[t]); int32_t c = 0; for (uint32_t i = 0; i < ix.ref_len[t]; ++i) { c += is_gc(ix, t, (int32_t)i) ? 1 : 0; g[i] = c; } return g; };
+  auto gcFrac = [](const std::vector<int32_t>& g, int32_t s, int32_t e) { int32_t cs = s > 0 ? g[s - 1] : 0, ce = g[e]; return (int32_t)std::lrint((100.0 * (double)(ce - cs)) / (double)(e - s + 1)); };
+  for (uint32_t t = 0; t < M; ++t) {
+    const int32_t refLen = (int32_t)ix.ref_len[t], elen = (int32_t)eff_in[t], unprocessedLen = std::max(0, refLen - elen);
+    const int32_t cdfMaxArg = std::min(MAXV, refLen); const double cdfMaxVal = cdf[cdfMaxArg];
+    if (cdfMaxVal < 1e-10) continue;
+    if (alphas[t] < 1e-8 || unprocessedLen <= 0) continue;
+    auto cCDF = [&](int32_t x) { return x > cdfMaxArg ? 1.0 : cdf[x] / cdfMaxVal; };
+    processed.push_back(t);
+    const double weight = alphas[t] / eff_in[t];
+    const std::vector<int32_t> g = prefix(t);
+    const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
+    double E[25] = {0};
+    double prev = cCDF(locFLDLow > 0 ? locFLDLow - 1 : 0);
+    for (int32_t fl = locFLDLow; fl <= locFLDHigh; fl += gcSamp) {      // length-major form of the (start, length) double loop: same terms
+      uint64_t N[25] = {0}; bool any = false;
+      for (int32_t fragStart = 0; fragStart < refLen - 1; ++fragStart) {
+        const int32_t fragEnd = fragStart + fl - 1;
+        if (fragEnd < refLen) { N[gc_frag_bin(gcFrac(g, fragStart, fragEnd))]++; any = true; } else break;
+      }
+      if (fl > refLen || fl < 1) break;
+      (void)any;
+      const double d = cCDF(fl) - prev; prev = cCDF(fl);
+      for (int b = 0; b < 25; ++b) E[b] += d * (double)N[b];
+    }
+    for (int b = 0; b < 25; ++b) contrib[b].push_back(weight * E[b]);
+  }
+  double expect[3][25] = {{0}};
+  for (int b = 0; b < 25; ++b) expect[0][b] = canonical_sum(contrib[b]);
+  double obsN[3][25], expN[3][25], bias[3][25];
+  auto normalize = [](const double* in, double* out) {   // GCFragModel::normalize, LINEAR branch (prior 0.1)
+    double rowMass = 0.0; for (int c = 0; c < 25; ++c) rowMass += (0.1 + in[c]);
+    if (rowMass > 0.0) { double norm = 1.0 / rowMass; for (int c = 0; c < 25; ++c) out[c] = (0.1 + in[c]) * norm; } else for (int c = 0; c < 25; ++c) out[c] = in[c];
+  };
+  for (int r = 0; r < 3; ++r) {
+    normalize(gc_obs + 25 * r, obsN[r]); normalize(expect[r], expN[r]);
+    for (int c = 0; c < 25; ++c) { double rat = obsN[r][c] / expN[r][c]; if (rat > 1000.0) rat = 1000.0; if (rat < 1.0 / 1000.0) rat = 1.0 / 1000.0; bias[r][c] = rat; }   // ratio(other, 1000)
+  }
+  if (bias_row0_out) for (int c = 0; c < 25; ++c) bias_row0_out[c] = bias[0][c];
+  for (uint32_t t = 0; t < M; ++t) {
+    const int32_t refLen = (int32_t)ix.ref_len[t], elen = (int32_t)eff_in[t], unprocessedLen = std::max(0, refLen - elen);
+    const int32_t cdfMaxArg = std::min(MAXV, refLen); const double cdfMaxVal = cdf[cdfMaxArg];
+    auto cCDF = [&](int32_t x) { return x > cdfMaxArg ? 1.0 : cdf[x] / cdfMaxVal; };
+    const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
+    if (!(alphas[t] >= 1e-8 && unprocessedLen > 0 && cdfMaxVal > 1e-10)) { eff_out[t] = (double)elen; continue; }
+    const std::vector<int32_t> g = prefix(t);
+    double effLength = 0.0;
+    int32_t fl = locFLDLow; const int32_t maxLen = std::min(refLen, locFLDHigh + 1); bool done = fl >= maxLen;
+    double prevFLMass = cCDF(fl > 0 ? fl - 1 : 0);
+    while (!done) {
+      if (fl >= maxLen) { done = true; fl = maxLen - 1; }
+      const double flWeight = cCDF(fl) - prevFLMass; prevFLMass = cCDF(fl);
+      uint64_t N[25] = {0};
+      for (int32_t kmerStartPos = 0; kmerStartPos < refLen - fl; ++kmerStartPos) {
+        const int32_t fragStart = kmerStartPos, fragEnd = fragStart + fl - 1;
+        if (fragStart < refLen && fragEnd < refLen && fl >= 1) N[gc_frag_bin(gcFrac(g, fragStart, fragEnd))]++; else break;
+      }
+      double flMassTotal = 0.0; for (int b = 0; b < 25; ++b) flMassTotal += (double)N[b] * bias[0][b];   // every fragment factor is one of 25 values
+      effLength += flWeight * flMassTotal;
+      fl += gcSamp;
+    }
+    const double thresh = (double)unprocessedLen, offset = std::max(1.0, thresh), effLengthNoBias = (double)elen;
+    eff_out[t] = std::max(effLength, std::min(effLengthNoBias, offset));
+  }
+  return (int)processed.size();
+}
+
+// optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928): after 11 updates updateEffectiveLengths, new priors
+// (populatePriorAlphas_) and combined weights (updateEqClassWeights :160-176; degenerate classes stay dropped), then on to convergence
+static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const Index& ix, const double* gc_obs, const double* log_pmf,
+                          double* alpha_out, double* eff_out, sq_em_report* rep) {
+  EMProblem P; em_setup(P, eq, txp, o);
+  const uint32_t M = P.M;
+  std::vector<double> alpha(M), pc(M), eff(txp->eff_len, txp->eff_len + M), eff2(M);
+  for (uint32_t i = 0; i < M; ++i) pc[i] = txp->projected_counts ? txp->projected_counts[i] : 0.0;
+  const double totalWeight = canonical_sum(pc), uniformPrior = totalWeight / (double)M, fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
+  const bool alt = o->alt_init_mode && txp->unique_count;
+  for (uint32_t i = 0; i < M; ++i) { const double uni = alt ? ((double)txp->unique_count[i] + 0.5) * 1e-3 * txp->eff_len[i] : uniformPrior; alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uni * (1.0 - fracObserved)); }
+  uint32_t ndeg = 0; std::vector<uint8_t> dropped(P.E, 0);
+  for (uint64_t c = 0; c < P.E; ++c) {
+    double denom = 0.0;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) { double v = alpha[P.tid[i]] * P.cw[i]; if (!std::isnan(v)) denom += v; }
+    if (denom <= 2.2250738585072014e-308) { P.count[c] = 0; dropped[c] = 1; for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = 0.0; ++ndeg; }
+  }
+  uint32_t it; bool conv; double maxRel;
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 11);
+  bias_gc_eff_lengths(ix, gc_obs, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);
+  for (uint64_t c = 0; c < P.E; ++c) {   // updateEqClassWeights with the new lengths
+    if (dropped[c]) continue;
+    double wsum = 0.0;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) {
+      double el = eff2[P.tid[i]]; if (el <= 1.0) el = 1.0;
+      double w = o->no_rich_eq_classes ? 1.0 : eq->w[i];
+      double wt = o->eq_class_mode ? w : (double)eq->count[c] * w * (1.0 / el);
+      P.cw[i] = wt; wsum += wt;
+    }
+    double wn = 1.0 / wsum;
+    for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = P.cw[i] * wn;
+  }
+  if (!o->per_transcript_prior) for (uint32_t i = 0; i < M; ++i) P.prior[i] = o->vb_prior * eff2[i];
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 11, 0);
+  for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;
+  double asum = canonical_sum(alpha);
+  for (uint32_t i = 0; i < M; ++i) { alpha_out[i] = alpha[i]; if (eff_out) eff_out[i] = eff2[i]; }
+  if (rep) { rep->iters = it; rep->converged = conv; rep->max_rel_diff = maxRel; rep->alpha_sum = asum; rep->device_ms = 0; rep->ms_per_iter = 0; rep->num_degenerate = ndeg; rep->_pad = 0; }
+  return asum < 2.2250738585072014e-308 ? SQ_ERR_STATE : SQ_OK;
+}
+
 static int bootstrap(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t B, uint64_t seed, uint64_t num_mapped,
     double* out) {
   EMProblem P; em_setup(P, eq, txp, o);
@@ -1634,6 +1788,13 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
     }
   }
 }
+
+void orc_state_gc_observed(orc_state* s, double* out75) { for (int i = 0; i < 75; ++i) out75[i] = sq_from_fixed(s->S.gcObs[i], 32); }
+
+int orc_bias_gc_eff_lengths(const orc_index* oi, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in,
+                            double* eff_out, double* bias_row0_out) { return bias_gc_eff_lengths(oi->ix, gc_obs, log_pmf, M, alphas, eff_in, eff_out, bias_row0_out); }
+int orc_em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const orc_index* oi, const double* gc_obs, const double* log_pmf,
+                       double* alpha_out, double* eff_out, sq_em_report* rep) { return em_optimize_gc(eq, txp, o, oi->ix, gc_obs, log_pmf, alpha_out, eff_out, rep); }
 
 int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   return em_optimize(eq, txp, o, alpha_out, rep);

@@ -322,6 +322,29 @@ class QuantContext:
         check(lib().sq_model_fetch(self.h, _ptr(lm, C.c_double), _ptr(uq, C.c_uint64), _ptr(tc, C.c_uint64), _ptr(le, C.c_double)), "sq_model_fetch")
         return lm, uq, tc, le
 
+    def gc_observed(self):
+        """observedGCMass (needs quant_opts(gc_bias=1)): [3, 25] linear-space masses."""
+        g = np.zeros(75)
+        check(lib().sq_model_fetch_gc_observed(self.h, g.ctypes.data), "sq_model_fetch_gc_observed")
+        return g.reshape(3, 25)
+
+    def em_optimize_gc(self, eff_len, projected, gc_obs, log_pmf, opts=None, eq=None):
+        """CollapsedEMOptimizer::optimize with --gcBias: the effective lengths are re-derived from the GC models at iteration 11
+        (sq_em_optimize_bias with sq_bias_gc_eff_lengths as the callback).  Returns (alphas, eff_lens, report)."""
+        o = opts or em_opts(); txp = make_txp_in(eff_len, projected); M = txp.num_txp
+        out = np.zeros(M); eff_out = np.zeros(M); rep = capi.EmReport(); brep = capi.BiasReport()
+        g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1); lp = np.ascontiguousarray(log_pmf, np.float64)
+        idx_h = self.index.h
+        def cb(alphas, eff_in, eff_o, m, user):
+            return lib().sq_bias_gc_eff_lengths(idx_h, g.ctypes.data, lp.ctypes.data, m, C.cast(alphas, C.c_void_p), C.cast(eff_in, C.c_void_p),
+                C.cast(eff_o, C.c_void_p), C.byref(brep))
+        cbf = capi.EFFLEN_CB(cb)
+        t = eq.table() if eq is not None else None
+        check(lib().sq_em_optimize_bias(self.h, C.byref(t) if t is not None else None, C.byref(txp), C.byref(o), cbf, None, _ptr(out, C.c_double),
+            _ptr(eff_out, C.c_double), C.byref(rep)), "sq_em_optimize_bias")
+        return out, eff_out, dict(iters=rep.iters, converged=bool(rep.converged), num_degenerate=rep.num_degenerate, num_processed=brep.num_processed,
+            fld_low=brep.fld_low, fld_high=brep.fld_high, gc_bias=np.array(brep.gc_bias_row0))
+
     def fld(self):
         f = np.zeros(1001)
         check(lib().sq_model_fetch_fld(self.h, _ptr(f, C.c_double)), "sq_model_fetch_fld")
@@ -364,6 +387,15 @@ def em_steps(eq, eff_len, alpha_in, iters, opts=None, device=0):
     check(lib().sq_em_steps_dev(device, C.byref(t), C.byref(txp), C.byref(o), _ptr(a, C.c_double), iters, _ptr(out, C.c_double), C.byref(rep)),
         "sq_em_steps_dev")
     return out, dict(iters=rep.iters, device_ms=rep.device_ms, ms_per_iter=rep.ms_per_iter)
+
+
+def bias_gc_eff_lengths(index, gc_obs, log_pmf, alphas, eff_in):
+    """salmon::utils::updateEffectiveLengths (gcBias) -> (eff_out, report dict); the index must be on a device."""
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1); lp = np.ascontiguousarray(log_pmf, np.float64)
+    a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); rep = capi.BiasReport()
+    check(lib().sq_bias_gc_eff_lengths(index.h, g.ctypes.data, lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, C.byref(rep)),
+        "sq_bias_gc_eff_lengths")
+    return out, dict(num_processed=rep.num_processed, fld_low=rep.fld_low, fld_high=rep.fld_high, gc_bias=np.array(rep.gc_bias_row0))
 
 
 def normalize_alphas(eq, log_mass, uniq, total):

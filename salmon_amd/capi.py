@@ -31,7 +31,7 @@ class QuantOpts(C.Structure):
                 ("post_merge_chain_sub_thresh", f64), ("orphan_chain_sub_thresh", f64), ("score_exp", f64),
                 ("decoy_threshold", f64), ("min_aln_prob", f64),
                 ("hard_filter", u8), ("allow_dovetail", u8), ("allow_orphans", u8), ("disable_chaining_heuristic", u8),
-                ("ignore_incompat", u8), ("recover_orphans", u8), ("lib_autodetect", u8), ("_pad1", u8),
+                ("ignore_incompat", u8), ("recover_orphans", u8), ("lib_autodetect", u8), ("gc_bias", u8),
                 ("mini_batch_size", u32), ("num_pre_burnin_frags", u32), ("num_burnin_frags", u64),
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
@@ -86,6 +86,13 @@ class TxpIn(C.Structure):
 class EmReport(C.Structure):
     _fields_ = [("iters", u32), ("converged", C.c_int), ("max_rel_diff", f64), ("alpha_sum", f64), ("device_ms", f64),
                 ("ms_per_iter", f64), ("num_degenerate", u32), ("_pad", u32)]
+
+
+class BiasReport(C.Structure):
+    _fields_ = [("num_processed", u32), ("fld_low", i32), ("fld_high", i32), ("_pad", u32), ("gc_bias_row0", f64 * 25)]
+
+
+EFFLEN_CB = C.CFUNCTYPE(C.c_int, P(f64), P(f64), P(f64), u32, C.c_void_p)
 
 
 class GibbsOpts(C.Structure):
@@ -157,6 +164,9 @@ def lib():
         "sq_gibbs_range_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u32, u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_chain_step": (u32, [u32]),
         "sq_merge_log_masses": (C.c_int, [u32, u32, vp, vp]),
+        "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
+        "sq_bias_gc_eff_lengths": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, P(BiasReport)]),
+        "sq_em_optimize_bias": (C.c_int, [vp, P(EqTable), P(TxpIn), P(EmOpts), EFFLEN_CB, vp, P(f64), P(f64), P(EmReport)]),
         "sq_dist_make_id": (C.c_int, [vp]), "sq_dist_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]), "sq_dist_free": (None, [vp]),
         "sq_dist_rank": (C.c_int, [vp]), "sq_dist_world": (C.c_int, [vp]), "sq_dist_merge_eq": (C.c_int, [vp, vp]),
         "sq_dist_reduce_model": (C.c_int, [vp, u32, P(f64), P(u64), P(u64), P(f64)]), "sq_dist_allreduce_u64": (C.c_int, [vp, vp, C.c_size_t]),

@@ -104,6 +104,12 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
   {"IU", {1, 2, 4}}, {"ISF", {1, 2, 0}}, {"ISR", {1, 2, 1}}, {"OU", {1, 1, 4}}, {"OSF", {1, 1, 0}}, {"OSR", {1, 1, 1}},
   {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
 
+struct GcHook { sq_index* idx; std::vector<double> obs, logpmf; sq_bias_report rep; };   // updateEffectiveLengths at EM iteration 11
+static int gc_hook_cb(const double* alphas, const double* eff_in, double* eff_out, uint32_t m, void* user) {
+  GcHook* h = (GcHook*)user;
+  fprintf(stderr, "[salmon-hip] iteration 11, adjusting effective lengths to account for biases\n");
+  return sq_bias_gc_eff_lengths(h->idx, h->obs.data(), h->logpmf.data(), m, alphas, eff_in, eff_out, &h->rep);
+}
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 static int part_cb(const double* a, uint32_t m, void* user) { return fwrite(a, 8, m, (FILE*)user) == m ? 0 : 1; }   // a rank's replicates, raw, for rank 0 to collect
 
@@ -229,7 +235,7 @@ static int cmd_quant(int argc, char** argv) {
                           "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
@@ -266,6 +272,9 @@ static int cmd_quant(int argc, char** argv) {
   qo.lib_orientation = li->second[1];
   qo.lib_strand = li->second[2];
   qo.lib_autodetect = autodetect ? 1 : 0;
+  const bool gc_bias = flag(argc, argv, "--gcBias");
+  if (gc_bias && !paired) { fprintf(stderr, "[salmon-hip] --gcBias is implemented for paired-end libraries (the single-end form needs the conditional fragment means)\n"); return 1; }
+  qo.gc_bias = gc_bias ? 1 : 0;
   if ((v = arg(argc, argv, "--incompatPrior"))) { qo.incompat_prior = atof(v) > 0 ? std::log(atof(v)) : 0.0; qo.ignore_incompat = atof(v) == 0.0; }   // QuantOptionsUtils.cpp:608-612
   if ((v = arg(argc, argv, "--maxOccsPerHit"))) qo.max_occs_per_hit = (uint32_t)atoi(v);
   if ((v = arg(argc, argv, "--maxReadOcc"))) qo.max_read_occs = (uint32_t)atoi(v);
@@ -374,7 +383,19 @@ static int cmd_quant(int argc, char** argv) {
     if (qo.no_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = 100.0;                              // CollapsedEMOptimizer.cpp:783-785
     else if (qo.no_eff_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = (double)sq_index_ref_len(idx, i);   // :780-782
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
-    if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
+    if (gc_bias) {   // CollapsedEMOptimizer.cpp:901-928: the effective lengths are re-derived from the GC models inside the optimisation
+      GcHook hook; hook.idx = idx; hook.obs.resize(75); hook.logpmf.resize(1001);
+      if (sq_model_fetch_gc_observed(ctx, hook.obs.data()) || sq_model_fetch_fld(ctx, hook.logpmf.data())) die("GC model fetch");
+      if (dist) {   // observed masses of all ranks: exact through their fixed-point form
+        uint64_t q[75]; for (int i = 0; i < 75; ++i) q[i] = (uint64_t)std::llround(hook.obs[i] * 4294967296.0);
+        if (sq_dist_allreduce_u64(dist, q, 75)) die("GC all-reduce");
+        for (int i = 0; i < 75; ++i) hook.obs[i] = (double)q[i] / 4294967296.0;
+      }
+      std::vector<double> eff2(M);
+      if (sq_em_optimize_bias(ctx, &t, &tx, &eop, gc_hook_cb, &hook, alphas.data(), eff2.data(), &rep)) die("EM (gcBias)");
+      fprintf(stderr, "[salmon-hip] GC bias: %u transcripts in the background model, fragment lengths %d..%d\n", hook.rep.num_processed, hook.rep.fld_low, hook.rep.fld_high);
+      eff = eff2; tx.eff_len = eff.data();
+    } else if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
     std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_index_ref_name(idx, i);
     si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned, dist);
   }
@@ -409,7 +430,7 @@ static int cmd_quant(int argc, char** argv) {
                 "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
                 "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f,\n"
                 "  \"samp_type\": \"%s\",\n  \"num_bootstraps\": %llu,\n  \"num_libraries\": 1,\n  \"frag_length_mean\": %.6f,\n  \"frag_length_sd\": %.6f,\n  \"frag_dist_length\": 1001,\n"
-                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u\n}\n",
+                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u,\n  \"gc_bias_correct\": %s,\n  \"seq_bias_correct\": false\n}\n",
             sq_version(), M, Mall - M, (unsigned long long)t.num_classes,
                 (unsigned long long)nfrag,
                 (unsigned long long)ms.num_assigned,
@@ -418,7 +439,7 @@ static int cmd_quant(int argc, char** argv) {
                 (unsigned long long)tot.num_mappings_filtered,
             nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
                 rep.iters,
-                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate);
+                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false");
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");

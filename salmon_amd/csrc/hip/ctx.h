@@ -180,4 +180,6 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
 extern "C" int sq_merge_log_masses(uint32_t M, uint32_t R, const double* all_log_mass, double* out);   // host/opts.cpp
 void sq_detect_lib_format(uint8_t type, const uint64_t* counts64, uint8_t* out_type, uint8_t* out_orient, uint8_t* out_strand);   // host/opts.cpp
 int sq_online_create(sq_ctx* c);
+int sq_em_optimize_bias_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, sq_efflen_cb cb, void* user,
+    double* alpha_out, double* eff_len_out, sq_em_report* rep, void** arena_slot, void* lent_stream);   // em.hip
 void sq_online_free(sq_ctx* c);

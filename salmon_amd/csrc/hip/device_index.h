@@ -12,6 +12,7 @@ struct sq_device_index {
   const uint32_t* ref_len = nullptr;    // [nrefs]
   const uint32_t* ref_clen = nullptr;
   const uint64_t* refseq = nullptr;
+  const uint32_t* gcpre = nullptr;      // G/C prefix of refseq per 32-nt word (fragment-GC bias: sq_gc_before)
   const uint64_t* ctab_off = nullptr;
   const uint64_t* ctab = nullptr;
   std::vector<void*> allocs;

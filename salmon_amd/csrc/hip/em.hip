@@ -401,6 +401,13 @@ __global__ void k_mark_degenerate(uint32_t E, const uint64_t* __restrict__ off, 
     cnt_f[c] = 0.0; for (uint64_t i = off[c]; i < off[c + 1]; ++i) cw[i] = 0.0; atomicAdd(ndrop, 1u);
   }
 }
+__global__ void k_zero_dropped(uint32_t E, const uint64_t* __restrict__ off, const double* __restrict__ cnt_f, double* __restrict__ cw) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= E) return;
+  if (cnt_f[c] == 0.0) for (uint64_t i = off[c]; i < off[c + 1]; ++i) cw[i] = 0.0;
+}
+__global__ void k_refresh_tcw(uint64_t L, const uint32_t* __restrict__ cscpos, const double* __restrict__ cw, double* __restrict__ t_cw) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < L) t_cw[i] = cw[cscpos[i]];
+}
 __global__ void k_prep_prior(uint32_t M, const double* __restrict__ eff, double vb_prior, int per_txp, double* __restrict__ prior) {   // populatePriorAlphas_ :82-99
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t < M) prior[t] = per_txp ? vb_prior : vb_prior * eff[t];
 }
@@ -537,6 +544,7 @@ struct EmSession {
       SQ_HIP_CHECK(hipMemcpyAsync(d_cntu.p, eq->count, (size_t)E * 8, hipMemcpyHostToDevice, st));
       p_off = d_off.p; p_tid = d_tid.p; p_w = d_w.p; p_cnt = (const unsigned long long*)d_cntu.p;
     }
+    p_off_ = p_off; p_tid_ = p_tid; p_w_ = p_w; p_cnt_ = p_cnt;
     DBuf<unsigned long long> key, key2; DBuf<uint32_t> val, val2, ns[4], base[4], d_err, nxt; DBuf<uint8_t> tmp;
     bool ok = !d_eff.alloc(M) && !d_cw.alloc(L) && !d_cnt.alloc(E) && !d_prior.alloc(M) && !d_toff.alloc((size_t)M + 1) &&
         !d_tcls.alloc(L) && !d_tcw.alloc(L) &&
@@ -567,6 +575,8 @@ struct EmSession {
       if (tmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (sort)"); return SQ_ERR_NOMEM; }
       SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st));
       k_prep_csc<<<nb(L), TB, 0, st>>>(L, M, key2.p, val2.p, d_cw.p, d_tcls.p, d_tcw.p, d_toff.p);
+      if (keep_cscpos) { if (d_cscpos.alloc(L)) { sq_set_error("device allocation failed in EM (CSC positions)"); return SQ_ERR_NOMEM; }
+        SQ_HIP_CHECK(hipMemcpyAsync(d_cscpos.p, val2.p, L * 4, hipMemcpyDeviceToDevice, st)); }
       pt.mark("prep:sort+csc-launched");
     }
     // blocked-64 plan: per-transcript segment counts, exclusive scans, fill
@@ -659,7 +669,7 @@ struct EmSession {
   // mode 0: optimise to convergence (min_iter / o->max_iter); mode 1: exactly `fixed_iters` steps.
   // alpha_dev != nullptr: the initial alphas are already in d_a0 (device); else they are uploaded from `alpha`.
   int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false,
-      bool fetch = true) {
+      bool fetch = true, uint32_t it0 = 0 /* iterations already done (the bias hook splits an optimisation in two runs) */) {
     const int TB = 256;
     if (!alpha_on_device) {
       if (h_stage) {
@@ -669,8 +679,8 @@ struct EmSession {
       else SQ_HIP_CHECK(hipMemcpyAsync(d_a0.p, alpha.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
     }
     SQ_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(uint32_t), st));
-    num_degenerate = 0;
-    if (mark_degenerate && E) {   // optimize() only: the initial alphas decide (flags[3] counts the dropped classes)
+    if (it0 == 0) num_degenerate = 0;
+    if (mark_degenerate && E && it0 == 0) {   // optimize() only: the initial alphas decide (flags[3] counts the dropped classes)
       k_mark_degenerate<<<(E + TB - 1) / TB, TB, 0, st>>>(E, d.off, d.tid, d_cw.p, d_a0.p, d_cnt.p, d_flags.p + 3);
       SQ_HIP_CHECK(hipMemcpyAsync(&num_degenerate, d_flags.p + 3, 4, hipMemcpyDeviceToHost, st));
     }
@@ -707,11 +717,11 @@ struct EmSession {
       std::swap(cur, nxt);
     };
     if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0); }
-    uint32_t it = 0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
+    uint32_t it = it0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     if (mode == 1) {
-      for (; it < fixed_iters; ++it) launch_iter(it);
-      executed = fixed_iters;
+      for (; it < it0 + fixed_iters; ++it) launch_iter(it);
+      executed = it0 + fixed_iters;
     } else {
       const uint32_t maxIter = o->max_iter, minIter = min_iter;
       // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
@@ -728,7 +738,7 @@ struct EmSession {
     }
     SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    result_dev = (executed % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed` swaps starting from d_a0
+    result_dev = ((executed - it0) % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed - it0` swaps starting from d_a0
     if (fetch) {
       if (h_stage) {
         SQ_HIP_CHECK(hipMemcpyAsync(h_stage + 2 * (size_t)M, result_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st));
@@ -740,12 +750,26 @@ struct EmSession {
     unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
     if (rep) {
       rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
-      rep->device_ms = ms; rep->ms_per_iter = executed ? ms / (double)executed : 0.0; rep->alpha_sum = 0; rep->num_degenerate = num_degenerate; rep->_pad = 0;
+      rep->device_ms = ms; rep->ms_per_iter = executed > it0 ? ms / (double)(executed - it0) : 0.0; rep->alpha_sum = 0; rep->num_degenerate = num_degenerate; rep->_pad = 0;
     }
     return SQ_OK;
   }
   double* result_dev = nullptr; double* h_stage = nullptr;
-  bool mark_degenerate = false; uint32_t num_degenerate = 0;
+  bool mark_degenerate = false, keep_cscpos = false; uint32_t num_degenerate = 0;
+  // updateEqClassWeights + populatePriorAlphas_ after the bias hook (CollapsedEMOptimizer.cpp:160-176, 906-916): new effective lengths ->
+  // combined weights (classes dropped as degenerate stay dropped), their CSC copies, priors
+  const uint64_t* p_off_ = nullptr; const uint32_t* p_tid_ = nullptr; const double* p_w_ = nullptr; const unsigned long long* p_cnt_ = nullptr;
+  DBuf<uint32_t> d_cscpos;
+  int refresh_weights(const double* eff_host) {
+    const int TB = 256;
+    SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, eff_host, (size_t)M * 8, hipMemcpyHostToDevice, st));
+    if (E) k_prep_cw<<<(E + TB - 1) / TB, TB, 0, st>>>(E, M, p_off_, p_tid_, p_w_, (const uint64_t*)p_cnt_, d_eff.p, o->no_rich_eq_classes, o->eq_class_mode, d_cw.p, nullptr, d_flags.p + 3);
+    if (E) k_zero_dropped<<<(E + TB - 1) / TB, TB, 0, st>>>(E, p_off_, d_cnt.p, d_cw.p);
+    k_prep_prior<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_eff.p, o->vb_prior, o->per_transcript_prior, d_prior.p);
+    if (L) k_refresh_tcw<<<(uint32_t)((L + TB - 1) / TB), TB, 0, st>>>(L, d_cscpos.p, d_cw.p, d_tcw.p);
+    SQ_HIP_CHECK(hipStreamSynchronize(st));
+    return SQ_OK;
+  }
 };
 
 int run_em(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, std::vector<double>& alpha, int mode,
@@ -885,6 +909,37 @@ int sq_em_optimize_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* 
     sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly.");
     return SQ_ERR_STATE;
   }
+  return SQ_OK;
+}
+
+// optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928): 11 updates, updateEffectiveLengths through `cb`, new priors and class
+// weights, then on to convergence (iteration counts and minIter = 100 run over both parts)
+int sq_em_optimize_bias_impl(int device, const sq_eq_table* eq, const sq_eq_dev_csr* dv, const sq_txp_in* txp, const sq_em_opts* o, sq_efflen_cb cb, void* user,
+    double* alpha_out, double* eff_len_out, sq_em_report* rep, void** arena_slot, void* lent_stream) {
+  if (!txp || !o || !alpha_out || !txp->eff_len || !cb) { sq_set_error("sq_em_optimize_bias: bad arguments"); return SQ_ERR_ARG; }
+  if (arena_slot && !*arena_slot) *arena_slot = new EmArena();
+  const uint32_t M = txp->num_txp;
+  std::vector<double> pc(M, 0.0); if (txp->projected_counts) pc.assign(txp->projected_counts, txp->projected_counts + M);
+  const double totalWeight = canonical_sum_host(pc), uniformPrior = totalWeight / (double)M, fracObserved = std::min(0.999, totalWeight / o->num_required_fragments);
+  const bool alt = o->alt_init_mode && txp->unique_count;
+  std::vector<double> alpha(M), eff(txp->eff_len, txp->eff_len + M), eff2(M);
+  for (uint32_t i = 0; i < M; ++i) { const double uni = alt ? ((double)txp->unique_count[i] + 0.5) * 1e-3 * txp->eff_len[i] : uniformPrior; alpha[i] = o->init_uniform ? 100.0 : (pc[i] * fracObserved + uni * (1.0 - fracObserved)); }
+  EmSession S; S.arena = arena_slot ? (EmArena*)*arena_slot : nullptr; S.mark_degenerate = true; S.keep_cscpos = true;
+  if (lent_stream) { S.st = (hipStream_t)lent_stream; S.own_stream = false; }
+  int rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
+  sq_em_report r1{}, r2{};
+  const uint32_t HOOK_AT = 11;   // needBias and itNum > targetIt (= 10)
+  rc = S.run(alpha, 1, HOOK_AT, 0, &r1); if (rc) return rc;
+  const uint32_t ndeg = S.num_degenerate;
+  if (cb(alpha.data(), eff.data(), eff2.data(), M, user)) { sq_set_error("sq_em_optimize_bias: the effective-length callback failed"); return SQ_ERR_STATE; }
+  rc = S.refresh_weights(eff2.data()); if (rc) return rc;
+  rc = S.run(alpha, 0, 0, o->min_iter, &r2, false, true, HOOK_AT); if (rc) return rc;
+  for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;
+  const double asum = canonical_sum_host(alpha);
+  memcpy(alpha_out, alpha.data(), (size_t)M * 8);
+  if (eff_len_out) memcpy(eff_len_out, eff2.data(), (size_t)M * 8);
+  if (rep) { *rep = r2; rep->alpha_sum = asum; rep->device_ms = r1.device_ms + r2.device_ms; rep->num_degenerate = ndeg; }
+  if (asum < 2.2250738585072014e-308) { sq_set_error("Total alpha weight was too small! Make sure you ran salmon correctly."); return SQ_ERR_STATE; }
   return SQ_OK;
 }
 

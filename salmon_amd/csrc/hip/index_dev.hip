@@ -56,7 +56,7 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
   rc |= up(d, idx->skew_keys, &v.skew_keys); rc |= up(d, idx->skew_vals, &v.skew_vals);
   rc |= up(d, idx->useq, &v.useq); rc |= up(d, idx->uoff, &v.uoff);
   rc |= up(d, idx->ref_accum, &d->ref_accum); rc |= up(d, idx->ref_len, &d->ref_len); rc |= up(d, idx->ref_clen, &d->ref_clen);
-  rc |= up(d, idx->refseq, &d->refseq); rc |= up(d, idx->ctab_off, &d->ctab_off); rc |= up(d, idx->ctab, &d->ctab);
+  rc |= up(d, idx->refseq, &d->refseq); rc |= up(d, sq_index_gc_prefix(idx), &d->gcpre); rc |= up(d, idx->ctab_off, &d->ctab_off); rc |= up(d, idx->ctab, &d->ctab);
   if (rc) { sq_device_index_free(d); return SQ_ERR_DEVICE; }
   v.kfilter = nullptr; v.kfilter_words = 0;
   if (!getenv("SQ_NO_KFILTER") && idx->num_kmers > 0) {   // k-mer membership filter (sq_internal.h): SQ_KF_BITS_PER_KEY bits per distinct k-mer

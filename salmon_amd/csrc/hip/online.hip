@@ -76,6 +76,7 @@ struct sq_online_dev {
   // `-l A` (SPEC §D8): per-format sample counts of the mini-batches seen so far while detection is active
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
+  sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
 };
 
@@ -131,6 +132,7 @@ struct OnlineView {
   uint32_t* fld_cnt;
   unsigned long long* ctr;
   uint32_t* touched; uint32_t* touched_n; uint32_t* tflag;
+  unsigned long long* gc_obs;   // nullptr unless --gcBias
 };
 
 // LibraryTypeDetector::addSample (LibraryTypeDetector.hpp:155-160): every alignment whose observed format has the library's read type
@@ -181,7 +183,8 @@ enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEX
 
 __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len,
     const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
-    PreAln* __restrict__ pre) {
+    PreAln* __restrict__ pre, const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
+    uint8_t* __restrict__ gcbin) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
   const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
@@ -212,6 +215,16 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
     p.max_fl = (uint16_t)(maxFL > 1000 ? 1000 : maxFL); p.tl = (uint16_t)(tl > 1000 ? 1000 : tl);   // tables saturate at 1000
   }
   pre[ai] = p;
+  if (gcbin) {   // observedGCMass.inc(transcript.gcDesc(start, stop), aln.logProb) — SalmonQuantify.cpp:938-951 (paired-end observations)
+    uint8_t b = 255;
+    if ((a.format_id & 1u) == 1u) {
+      const int32_t start = a.pos < a.mate_pos ? a.pos : a.mate_pos, stop = start + (int32_t)a.frag_len - 1;
+      int32_t ff, cf;
+      if (start >= 0 && stop < (int32_t)rl && stop >= start && sq_gc_desc(refseq, gcpre, ref_accum[a.tid], (int32_t)rl, start, stop, &ff, &cf))
+        b = (uint8_t)(sq_gc_ctx_bin(cf) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(ff));
+    }
+    gcbin[ai] = b;
+  }
 }
 
 // one mini-batch: fragments [r0, r1) of the current mapped batch (thread per fragment)
@@ -235,7 +248,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
                              unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin,
                                  uint64_t* __restrict__ rh1,
-                                 uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out) {
+                                 uint64_t* __restrict__ rh2, uint64_t* fmt_out, uint32_t par, int* compat_out, const uint8_t* __restrict__ gcbin) {
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   rh1[r] = EQ_EMPTY; rh2[r] = 0;
@@ -307,6 +320,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     const double pr = sq_exp(alp[ai] - sumProbs);
     mass_add(V, par, mbs, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
     atomicAdd(&V.total[t], 1ULL);
+    if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
       if (rr < pr) {
@@ -344,7 +358,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
                                  const uint64_t* __restrict__ assigned_prefix, uint64_t assigned_base,
                              unsigned long long* __restrict__ awq, double* __restrict__ alp, uint32_t* __restrict__ abin,
                                  uint64_t* __restrict__ rh1,
-                                 uint64_t* __restrict__ rh2, uint32_t par) {
+                                 uint64_t* __restrict__ rh2, uint32_t par, const uint8_t* __restrict__ gcbin) {
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = r0 + gtid / MB_G; const uint32_t j = threadIdx.x & (MB_G - 1);
   uint64_t fmtSeen = 0; int compatFrag = 0;   // this lane reports an assigned fragment that has a compatible alignment
@@ -355,7 +369,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   if (valid && nA > MB_G * MB_S) {
     if (j == 0) mini_batch_fragment(V, o, r, r0, r1, mbs, read_counter0, aln_off, aln, pre, assigned_prefix, assigned_base, awq, alp, abin, rh1,
         rh2, &fmtSeen, par,
-        &compatFrag);
+        &compatFrag, gcbin);
   } else if (valid) {
     if (j == 0) { rh1[r] = EQ_EMPTY; rh2[r] = 0; }
     if (nA > 0) {
@@ -444,6 +458,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             const double pr = sq_exp(logProb[sl] - sumProbs);
             mass_add(V, par, mbs, t[sl], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
             atomicAdd(&V.total[t[sl]], 1ULL);
+            if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
             if (!burned) {
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
               if (rr < pr && fl_ped[sl] > 0) {
@@ -794,6 +809,7 @@ OnlineView make_view(sq_ctx* c) {
   V.touched = o->touched.p;
   V.touched_n = o->touched_n.p;
   V.tflag = o->tflag.p;
+  V.gc_obs = c->opts.gc_bias ? o->gc_obs.p : nullptr;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
@@ -827,7 +843,7 @@ int sq_online_create(sq_ctx* c) {
       o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
              o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->tflag.ensure(M) || o->mass_acc.ensure((size_t)W * M) || o->uniq.ensure(M) ||
                  o->total.ensure(M) ||
-                 o->lib_counts.ensure(64) || o->fld_cnt.ensure((size_t)W * 1024) || o->ctr.ensure(8) ||
+                 o->lib_counts.ensure(64) || o->gc_obs.ensure(SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) || o->fld_cnt.ensure((size_t)W * 1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) ||
                  o->rh1.ensure(c->max_reads) ||
                  o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
@@ -882,6 +898,7 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemset(o->uniq.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8));
+  SQ_HIP_CHECK(hipMemset(o->gc_obs.p, 0, (SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) * 8));
   SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, (size_t)W * 1024 * 4));
   SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
@@ -914,6 +931,8 @@ void sq_online_free(sq_ctx* c) {
   o->touched_n.free_();
   o->tflag.free_();
   o->mb_samples.free_();
+  o->gcbin.free_();
+  o->gc_obs.free_();
   o->assigned_prefix_b.free_();
   o->mass_acc.free_();
   o->uniq.free_();
@@ -1085,15 +1104,16 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   const uint64_t last_total_aln = J.total_aln;
   SQ_HIP_CHECK(hipStreamWaitEvent(st, src->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)last_total_aln + 8;
-  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln))) {
+  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln)) || (q.gc_bias && o->gcbin.ensure(A))) {
     sq_set_error("device allocation failed (online scratch)");
     return SQ_ERR_NOMEM;
   }
   OnlineView V = make_view(c);
   mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
+  uint8_t* d_gcbin = q.gc_bias ? o->gcbin.p : nullptr;
   if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
-      (PreAln*)o->pre.p);
+      (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
@@ -1144,7 +1164,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     const uint32_t par = (uint32_t)(o->group_no & 1);
     k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, mb, c->reads_seen + r0, d_aln_off, d_aln,
         (const PreAln*)o->pre.p,
-        o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, par);
+        o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, par, d_gcbin);
     { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
       k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, FM, nw, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, par); }
     if (burn_now) {
@@ -1164,7 +1184,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       if (b < nmb) {
         const uint32_t rs = r1;
         assigned_base = assigned_after;
-        if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p);
+        if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p,
+            c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
         k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, rs, d_aln_off, d_aln, q, o->assigned_flag.p);
         { size_t tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
             (int)(n + 1), st)); }
@@ -1254,6 +1275,19 @@ extern "C" int sq_model_fetch_lib_counts(sq_ctx* c, uint64_t* out64) {
   { int rs = sq_eq_sync(c); if (rs) return rs; }
   SQ_HIP_CHECK(hipSetDevice(c->device));
   SQ_HIP_CHECK(hipMemcpy(out64, c->online->lib_counts.p, 64 * 8, hipMemcpyDeviceToHost));
+  return SQ_OK;
+}
+
+// observed fragment-GC masses (observedGCMass, SalmonQuantify.cpp:938-972): [SQ_GC_COND_BINS][SQ_GC_FRAG_BINS] sums of the normalised
+// alignment probabilities, linear space
+extern "C" int sq_model_fetch_gc_observed(sq_ctx* c, double* out75) {
+  if (!c || !out75) return SQ_ERR_ARG;
+  if (!c->opts.gc_bias) { sq_set_error("sq_model_fetch_gc_observed: the context was created without gc_bias"); return SQ_ERR_STATE; }
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long h[SQ_GC_COND_BINS * SQ_GC_FRAG_BINS];
+  SQ_HIP_CHECK(hipMemcpy(h, c->online->gc_obs.p, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < SQ_GC_COND_BINS * SQ_GC_FRAG_BINS; ++i) out75[i] = sq_from_fixed(h[i], 32);
   return SQ_OK;
 }
 
@@ -1488,6 +1522,15 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
   return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
+}
+
+extern "C" int sq_em_optimize_bias(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, sq_efflen_cb cb, void* user,
+    double* alpha_out, double* eff_len_out, sq_em_report* rep) {
+  if (!c) { sq_set_error("sq_em_optimize_bias: null ctx"); return SQ_ERR_ARG; }
+  if (eq) return sq_em_optimize_bias_impl(c->device, eq, nullptr, txp, o, cb, user, alpha_out, eff_len_out, rep, nullptr, nullptr);
+  sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
+  if (dv.E == 0) { sq_set_error("sq_em_optimize_bias: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
+  return sq_em_optimize_bias_impl(c->device, nullptr, &dv, txp, o, cb, user, alpha_out, eff_len_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));
 }
 
 // Pre-size everything the end of a job allocates — the device buffers and the page-locked staging area of the eq-class

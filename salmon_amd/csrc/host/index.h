@@ -15,6 +15,7 @@ struct sq_index {
   std::vector<std::string> names;
   std::vector<uint32_t> ref_len, ref_clen;
   std::vector<uint64_t> ref_accum;  // [nrefs+1]
+  std::vector<uint32_t> gcpre;      // G/C count before every word of refseq (built on demand: sq_index_gc_prefix)
   std::vector<uint64_t> refseq;     // 2-bit, padded by 2 words
   std::vector<uint64_t> useq;       // unitig pool, padded by 2 words
   std::vector<uint64_t> uoff;       // [U+1]
@@ -49,6 +50,7 @@ void sq_set_error(const char* fmt, ...);
 int sq_index_save(const sq_index& idx, const std::string& dir);
 int sq_index_load_host(const std::string& dir, sq_index** out);
 void sq_device_index_free(sq_device_index*);  // hip side
+const std::vector<uint32_t>& sq_index_gc_prefix(sq_index* idx);   // host/bias.cpp: builds idx->gcpre once
 
 // small parallel-for helper (dynamic chunks)
 #include <thread>

@@ -11,6 +11,7 @@
 // the string pool, so absent k-mers can never produce false hits.
 #pragma once
 #include <stdint.h>
+#include <math.h>
 #include "../../include/sq_math.h"
 
 #define SQ_INDEX_MAGIC 0x3158444951535153ULL /* "SQSQIDX1" */
@@ -48,6 +49,42 @@ SQ_HD uint64_t sq_fetch_bases(const uint64_t* pool, uint64_t p, uint32_t n) {
 SQ_HD uint32_t sq_fetch_base(const uint64_t* pool, uint64_t p) {
   return (uint32_t)(pool[p >> 5] >> ((p & 31) * 2)) & 3u;
 }
+
+// G/C content through a sampled prefix: gcpre[w] = number of G/C bases in the words before word w of a 2-bit pool (A 0, C 1, G 2, T 3:
+// a base is G or C iff its two bits differ).  sq_gc_before(pool, gcpre, p) = G/C among pool positions [0, p).
+SQ_HD uint32_t sq_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }   // clang lowers it to s_bcnt / v_bcnt on the device
+SQ_HD uint32_t sq_gc_word(uint64_t w) { return sq_popc64((w ^ (w >> 1)) & 0x5555555555555555ULL); }
+SQ_HD uint64_t sq_gc_before(const uint64_t* pool, const uint32_t* gcpre, uint64_t p) {
+  const uint64_t w = p >> 5; const uint32_t r = (uint32_t)(p & 31);
+  uint64_t c = gcpre[w];
+  if (r) c += sq_popc64((pool[w] ^ (pool[w] >> 1)) & 0x5555555555555555ULL & ((1ULL << (2 * r)) - 1));
+  return c;
+}
+
+// Transcript::gcDesc (include/salmon/internal/model/Transcript.hpp:294-341): GC percentage of the fragment [s, e] on a transcript that
+// starts at pool position g and has refLen bases, and of its 5' / 3' context windows (3 bases outside + 2 inside each end).
+// Returns false when there is no context.  frag / context percentages are lrint()-rounded as in the reference.
+#define SQ_GC_FRAG_BINS 25   /* numFragGCBins, SalmonDefaults.hpp:105 */
+#define SQ_GC_COND_BINS 3    /* numConditionalGCBins, :106 */
+SQ_HD bool sq_gc_desc(const uint64_t* pool, const uint32_t* gcpre, uint64_t g, int32_t refLen, int32_t s, int32_t e, int32_t* fragFrac, int32_t* ctxFrac) {
+  const uint64_t g0 = sq_gc_before(pool, gcpre, g);
+  #define SQ_GCI(i) ((int64_t)(sq_gc_before(pool, gcpre, g + (uint64_t)(i) + 1) - g0))   /* GCCount_[i]: G/C in [0, i] */
+  const int lastPos = refLen - 1;
+  const int64_t cs = (s > 0) ? SQ_GCI(s - 1) : 0, ce = SQ_GCI(e);
+  int fs = s - 4, fe = s + 1, ts = e - 2, te = e + 3;
+  const bool fpL = fs >= 0, fpR = fe <= lastPos, tpL = ts >= 0, tpR = te <= lastPos;
+  const int64_t fps = fpL ? SQ_GCI(fs) : 0, fpe = fpR ? SQ_GCI(fe) : ce, tps = tpL ? SQ_GCI(ts) : 0, tpe = tpR ? SQ_GCI(te) : ce;
+  #undef SQ_GCI
+  fs = fs < 0 ? 0 : fs; fe = fe > lastPos ? lastPos : fe; ts = ts < 0 ? 0 : ts; te = te > lastPos ? lastPos : te;
+  const int fpSize = !fpL ? (fe + 1) : (fe - fs), tpSize = !tpL ? (te + 1) : (te - ts);
+  const double contextSize = (double)(fpSize + tpSize);
+  if (contextSize == 0) return false;
+  *fragFrac = (int32_t)rint((100.0 * (double)(ce - cs)) / (double)(e - s + 1));
+  *ctxFrac = (int32_t)rint(100.0 * ((double)((fpe - fps) + (tpe - tps)) / contextSize));
+  return true;
+}
+SQ_HD int32_t sq_gc_frag_bin(int32_t fragFrac) { const double w = 100.0 / SQ_GC_FRAG_BINS; const int32_t b = (int32_t)((double)fragFrac / w); return b < SQ_GC_FRAG_BINS - 1 ? b : SQ_GC_FRAG_BINS - 1; }   // GCDesc::fragBin(n)
+SQ_HD int32_t sq_gc_ctx_bin(int32_t ctxFrac) { const double w = 100.0 / SQ_GC_COND_BINS; const int32_t b = (int32_t)((double)ctxFrac / w); return b < SQ_GC_COND_BINS - 1 ? b : SQ_GC_COND_BINS - 1; }       // GCDesc::contextBin(n)
 
 SQ_HD uint32_t sq_fastrange32(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * (uint64_t)n) >> 32); }
 

@@ -35,6 +35,9 @@ def lib():
         L.orc_eq_accumulate.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64]
         L.orc_state_finish.argtypes = [vp]
         L.orc_state_merge.argtypes = [vp, vp]
+        L.orc_state_gc_observed.argtypes = [vp, vp]
+        L.orc_bias_gc_eff_lengths.restype = C.c_int; L.orc_bias_gc_eff_lengths.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
+        L.orc_em_optimize_gc.restype = C.c_int; L.orc_em_optimize_gc.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, vp, vp, vp, vp, P(capi.EmReport)]
         L.orc_state_summary.argtypes = [vp, P(capi.ModelSummary)]
         L.orc_state_lib_counts.argtypes = [vp, vp]
         L.orc_state_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -119,6 +122,9 @@ class OrcState:
     def finish(self):
         lib().orc_state_finish(self.h)
 
+    def gc_observed(self):
+        g = np.zeros(75); lib().orc_state_gc_observed(self.h, g.ctypes.data); return g.reshape(3, 25)
+
     def merge(self, other):
         """SPEC §MG: fold the state of the next rank into this one (call in rank order on rank 0's state)."""
         lib().orc_state_merge(self.h, other.h)
@@ -184,3 +190,18 @@ def gibbs(eq, eff_len, alpha_init, S, seed, num_mapped, gopts):
     rc = lib().orc_gibbs(C.byref(t), C.byref(txp), C.byref(gopts), a.ctypes.data, S, seed, num_mapped, out.ctypes.data)
     assert rc == 0
     return out
+
+
+def bias_gc_eff_lengths(oidx, gc_obs, log_pmf, alphas, eff_in):
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1); lp = np.ascontiguousarray(log_pmf, np.float64)
+    a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); bias = np.zeros(25)
+    n = lib().orc_bias_gc_eff_lengths(oidx.h, g.ctypes.data, lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, bias.ctypes.data)
+    return out, dict(num_processed=n, gc_bias=bias)
+
+
+def em_optimize_gc(eq, eff_len, projected, oidx, gc_obs, log_pmf, opts=None):
+    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len, projected)
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1); lp = np.ascontiguousarray(log_pmf, np.float64)
+    out = np.zeros(txp.num_txp); eff = np.zeros(txp.num_txp); rep = capi.EmReport()
+    rc = lib().orc_em_optimize_gc(C.byref(t), C.byref(txp), C.byref(o), oidx.h, g.ctypes.data, lp.ctypes.data, out.ctypes.data, eff.ctypes.data, C.byref(rep))
+    return out, eff, dict(iters=rep.iters, converged=bool(rep.converged), rc=rc, num_degenerate=rep.num_degenerate)

@@ -1,0 +1,90 @@
+"""Fragment-GC bias (row f-3, --gcBias): the observed model collected while mapping, the expected model + bias-corrected effective
+lengths (updateEffectiveLengths, SalmonUtils.cpp:1208-1985, gc branches) and the EM with the bias hook at iteration 11
+(CollapsedEMOptimizer.cpp:901-928) — HIP path vs the CPU checker, bit for bit — plus what the correction must do on data with a
+planted GC bias."""
+import numpy as np
+import pytest
+from salmon_amd import api, synth
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(w, seq, off, n):
+    opts = api.quant_opts(gc_bias=1, mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=3000)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=max(4096, n))
+    rb = api.make_read_batch(seq, off, n, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8)
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    return ctx, ost
+
+
+def test_gc_models_effective_lengths_and_em_match_checker(small_world):
+    w = small_world; w["idx"].to_device(0)
+    ctx, ost = _run(w, w["seq"], w["off"], w["n"])
+    assert ctx.summary() == ost.summary()
+    g_g, g_c = ctx.gc_observed(), ost.gc_observed()
+    assert np.array_equal(g_g, g_c) and g_g.sum() > 0.5 * w["n"] and g_g.shape == (3, 25)       # every properly paired, assigned fragment is an observation
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    lm, uq, tc, le = ctx.model(); fld = ctx.fld(); mc = ost.model()
+    assert np.array_equal(fld, mc[4])
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le)
+    # the effective-length update on its own, from the same inputs
+    a0 = np.maximum(proj, 0.0)
+    e_g, r_g = api.bias_gc_eff_lengths(w["idx"], g_g, fld, a0, eff)
+    e_c, r_c = orc.bias_gc_eff_lengths(w["oidx"], g_c, mc[4], a0, eff)
+    assert r_g["num_processed"] == r_c["num_processed"] > 50
+    assert np.array_equal(r_g["gc_bias"], r_c["gc_bias"]) and np.array_equal(e_g, e_c)
+    assert 150 < r_g["fld_low"] < 250 < r_g["fld_high"] < 400
+    # the whole optimisation with the hook
+    al_g, ef_g, rep_g = ctx.em_optimize_gc(eff, proj, g_g, fld, api.em_opts())
+    al_c, ef_c, rep_c = orc.em_optimize_gc(eq_c, eff, proj, w["oidx"], g_c, mc[4], api.em_opts())
+    assert rep_g["iters"] == rep_c["iters"] and np.array_equal(ef_g, ef_c) and np.array_equal(al_g, al_c)
+    assert abs(al_g.sum() - ctx.summary()["num_assigned"]) < 1e-6 * al_g.sum()
+    plain, _ = ctx.em_optimize(eff, proj, api.em_opts())
+    assert not np.array_equal(plain, al_g)
+    ctx.free(); ost.free()
+
+
+def test_gc_correction_on_a_gc_filtered_library(small_world):
+    # a library that lost most of its GC-rich fragments: the HIP path must still equal the checker, the bias factors stay inside the
+    # reference's clamp [1/1000, 1000], and processed transcripts get new, positive effective lengths no shorter than the barrier allows.
+    # (In gc-only mode the reference compares the observed fragments of the LOW-context bin with all expected fragments —
+    # SalmonUtils.cpp:1562-1565 leaves the context counts empty — so the factors are not a clean function of GC; parity is the test.)
+    w = small_world; w["idx"].to_device(0)
+    seq, off, tt, tp = w["tx"].reads(20000, read_len=100, seed=31, threads=4)
+    recs = seq.reshape(-1, 100); gc = ((recs == ord("G")) | (recs == ord("C"))).mean(axis=1); pair_gc = 0.5 * (gc[0::2] + gc[1::2])
+    rng = np.random.default_rng(5); keep = rng.random(len(pair_gc)) < np.clip(1.6 - 2.4 * pair_gc, 0.05, 1.0)
+    idxs = np.nonzero(keep)[0]; n = len(idxs)
+    sel = np.stack([recs[2 * idxs], recs[2 * idxs + 1]], axis=1).reshape(-1)
+    off2 = np.arange(0, 2 * n + 1, dtype=np.uint64) * np.uint64(100)
+    ctx, ost = _run(w, np.ascontiguousarray(sel), off2, n)
+    assert np.array_equal(ctx.gc_observed(), ost.gc_observed())
+    eq = ctx.eq_finish(); lm, uq, tc, le = ctx.model(); fld = ctx.fld()
+    proj = api.normalize_alphas(eq, lm, uq, tc); eff = np.exp(le)
+    e_new, rep = api.bias_gc_eff_lengths(w["idx"], ctx.gc_observed(), fld, np.maximum(proj, 0.0), eff)
+    e_chk, rep_c = orc.bias_gc_eff_lengths(w["oidx"], ost.gc_observed(), ost.model()[4], np.maximum(proj, 0.0), eff)
+    assert np.array_equal(e_new, e_chk) and np.array_equal(rep["gc_bias"], rep_c["gc_bias"])
+    b = rep["gc_bias"]
+    assert np.all(b >= 1e-3) and np.all(b <= 1e3) and len(np.unique(np.round(b, 9))) >= 4 and rep["num_processed"] > 50
+    assert np.all(e_new > 0) and np.any(np.abs(e_new - eff) > 1.0)
+    ctx.free(); ost.free()
+
+
+def test_cli_gcbias_writes_corrected_effective_lengths(built, tmp_path):
+    import os, subprocess, json, fixtures
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "salmon_amd", "bin", "salmon-hip")
+    g = fixtures.G
+    subprocess.check_call([exe, "index", "-t", os.path.join(g, "transcripts.fa.gz"), "-i", str(tmp_path / "idx"), "-p", "2"])
+    for out, extra in (("plain", []), ("gc", ["--gcBias"])):
+        subprocess.check_call([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "IU", "-1", os.path.join(g, "reads_1.fq.gz"), "-2", os.path.join(g, "reads_2.fq.gz"),
+                               "-o", str(tmp_path / out)] + extra)
+    rows = {o: [l.split("\t") for l in open(tmp_path / o / "quant.sf").read().splitlines()[1:]] for o in ("plain", "gc")}
+    assert open(tmp_path / "plain" / "quant.sf").read() == open(os.path.join(g, "golden_quant.sf")).read()
+    e0 = np.array([float(r[2]) for r in rows["plain"]]); e1 = np.array([float(r[2]) for r in rows["gc"]])
+    n0 = np.array([float(r[4]) for r in rows["plain"]]); n1 = np.array([float(r[4]) for r in rows["gc"]])
+    assert np.any(np.abs(e1 - e0) > 1.0) and abs(n1.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n1)[0, 1] > 0.99
+    assert json.load(open(tmp_path / "gc" / "aux_info" / "meta_info.json"))["gc_bias_correct"] is True
+    r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "U", "-r", os.path.join(g, "reads_1.fq.gz"), "-o", str(tmp_path / "se"), "--gcBias"], capture_output=True, text=True)
+    assert r.returncode != 0 and "paired-end" in r.stderr
