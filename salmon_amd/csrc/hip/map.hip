@@ -162,7 +162,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
                  c->mem_off.ensure((size_t)nends + 2) ||
              c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) ||
-                 c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(8) ||
+                 c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(16) ||
              c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) ||
                  c->aln_off.ensure((size_t)max_batch_reads + 2) ||
                  c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
@@ -365,7 +365,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     d_seq = c->seq.p; d_seq_off = c->seq_off.p;
   }
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
-  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint32_t), st));
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
   sq_prof_begin(c);
   k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p);
@@ -491,12 +491,12 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
       (uint32_t)total_mems, c->stats.p);
   if (total_cands) {
     for (int attempt = 0; attempt < 2; ++attempt) {
-      SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(uint32_t), st));
+      SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 8, 0, 2 * sizeof(uint32_t), st));
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_DP, 0, sizeof(unsigned long long), st));
       k_score<<<nblk(total_cands), TB, 0, st>>>(P, S, total_cands, paired, c->mem_off.p, c->cand_off.p, n, c->chains.p, c->cands.p,
           cand_frag.p, c->stats.p);
       sq_prof_mark(c, SG_SCORE);
-      SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p, 8, hipMemcpyDeviceToHost, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(hcount, c->counters.p + 8, sizeof(hcount), hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));
       if (hcount[0] <= S.dpq_cap) break;
       if (attempt == 1 || c->dpq.ensure((size_t)hcount[0] + 1024)) {

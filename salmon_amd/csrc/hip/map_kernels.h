@@ -786,7 +786,7 @@ __device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, co
   if (tl == 0) { *sc = (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF; if (!queue) ++*ndp; return true; }
   if (!queue) ++*ndp;
   if (queue) {
-    uint32_t slot = wave_alloc(&S.counters[0]);
+    uint32_t slot = wave_alloc(&S.counters[8]);   // (queues per DP height were tried: k_dp gained 0.15 ms, the extra same-address atomics cost k_score 1 ms)
     if (slot < S.dpq_cap) {
       sq_dp_item it;
       it.cand = cand;
@@ -898,7 +898,7 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
   }
 }
 
-__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,
+__global__ void __attribute__((amdgpu_waves_per_eu(5))) k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,
     const uint64_t* __restrict__ cand_off,
     uint32_t nfrag,
                         const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
@@ -911,8 +911,13 @@ __global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t pa
     const bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
     const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
     bool lfw = hasL ? chains[c.lc].fw != 0 : false, rfw = hasR ? chains[c.rc].fw != 0 : false;
+    const int32_t lpos_ = hasL ? chains[c.lc].pos : 0, rpos_ = hasR ? chains[c.rc].pos : 0;
     bool isc = paired ? joint_compat(P, orphan, hasL, lfw, rfw) : compat_se(P, lfw, SQ_MS_SINGLE_END);
     c.compat = isc;
+    // the joining coverage has done its work (k_join2): its 8 bytes now carry the chains' implied positions and pad[1] their strands,
+    // so the per-fragment selection (k_select) builds the alignment records without touching the chain slabs again
+    c.cov = __longlong_as_double((long long)(((unsigned long long)(uint32_t)rpos_ << 32) | (unsigned long long)(uint32_t)lpos_));
+    c.pad[1] = (uint8_t)((lfw ? 1 : 0) | (rfw ? 2 : 0));
     if (!isc && P.ignore_incompat) { c.valid = 0; c.lfail = c.rfail = 2; }   // 2 = skipped (not scored)
     else {
       uint32_t e0 = paired ? 2 * f : f, e1 = 2 * f + 1;
@@ -1128,21 +1133,22 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
       a.est_aln_prob = p;
       a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END;
       a.frag_len = c.frag_len;
+      const unsigned long long posbits = (unsigned long long)__double_as_longlong(c.cov);   // written by k_score: implied positions of the two chains
+      const int32_t lpos = (int32_t)(uint32_t)posbits, rpos = (int32_t)(uint32_t)(posbits >> 32); const uint8_t lfwb = c.pad[1] & 1, rfwb = (c.pad[1] >> 1) & 1;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
-        const sq_chain_dev& l = chains[c.lc]; const sq_chain_dev& rr = chains[c.rc];
-        a.pos = l.pos;
-        a.fwd = l.fw;
+        a.pos = lpos;
+        a.fwd = lfwb;
         a.read_len = (uint16_t)n1;
-        a.mate_pos = rr.pos;
-        a.mate_fwd = rr.fw;
+        a.mate_pos = rpos;
+        a.mate_fwd = rfwb;
         a.mate_len = (uint16_t)n2;
         a.score = c.lscore;
         a.mate_score = c.rscore;
         int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
         a.format_id = hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len);
       } else {
-        const bool left = c.lc != 0xFFFFFFFFu; const sq_chain_dev& o = left ? chains[c.lc] : chains[c.rc];
-        a.pos = o.pos; a.fwd = o.fw; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
+        const bool left = c.lc != 0xFFFFFFFFu;
+        a.pos = left ? lpos : rpos; a.fwd = left ? lfwb : rfwb; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
         a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
         a.format_id = a.fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3);
       }
