@@ -214,7 +214,8 @@ typedef struct {           /* HitCounters / MappingStatistics subset (SalmonQuan
       num_mapped /* >=1 kept alignment */, num_alignments /* validHits */,
       num_mappings_filtered, num_fragments_filtered, num_dovetails, num_decoy_fragments,
       num_seeds, num_lookups, num_mems, num_chains, num_candidates, num_dp_alignments,
-      num_orphans_rescued /* fragments with a recovered mate (mstats.numOrphansRescued) */;
+      num_orphans_rescued /* fragments with a recovered mate (mstats.numOrphansRescued) */,
+      num_truncated_ends /* read ends longer than the 256-base packing limit, cut to their first 256 bases (SPEC §I; the reference has no limit) */;
 } sq_map_stats;
 
 /* Map one batch. Results stay resident on the device for sq_eq_accumulate(); if out != NULL they

@@ -565,7 +565,8 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
                          FragResult& out, sq_map_stats& st, Taps* taps) {
   out.alns.clear(); out.map_type = SQ_MT_UNMAPPED;
   st.num_reads++;
-  if (n1 > 256) n1 = 256;
+  if (n1 > 256) { n1 = 256; st.num_truncated_ends++; }
+  if (paired && n2 > 256) { n2 = 256; st.num_truncated_ends++; }
   if (n2 > 256) n2 = 256;   // SPEC §I: a read end is its first 256 bases (the product's packing limit)
   std::vector<uint8_t> rd[2]; std::vector<UniMem> um[2]; std::vector<Mem> mems[2]; std::vector<Chain> ch[2];
   const int nends = paired ? 2 : 1;

@@ -56,7 +56,8 @@ class AlnBatch(C.Structure):
 class MapStats(C.Structure):
     _names = ["num_reads", "num_mapped_at_least_a_kmer", "num_with_joint_hits", "num_mapped", "num_alignments",
               "num_mappings_filtered", "num_fragments_filtered", "num_dovetails", "num_decoy_fragments", "num_seeds",
-              "num_lookups", "num_mems", "num_chains", "num_candidates", "num_dp_alignments", "num_orphans_rescued"]
+              "num_lookups", "num_mems", "num_chains", "num_candidates", "num_dp_alignments", "num_orphans_rescued",
+              "num_truncated_ends"]
     _fields_ = [(n, u64) for n in _names]
 
     def as_dict(self):

@@ -173,7 +173,7 @@ void sq_eq_worker_stop(sq_ctx* c);                                // wait for ou
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS,
     ST_CHAINS, ST_CANDS, ST_DP,
-    ST_RESCUED, ST_N };
+    ST_RESCUED, ST_TRUNC, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`

@@ -57,12 +57,13 @@ __device__ inline uint32_t wave_alloc(uint32_t* ctr) {
 // ------------------------------------------------------------------------------------------------
 // 8 threads per record, 32 bases each: adjacent lanes read adjacent 32-byte runs (coalesced)
 __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
-                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen) {
+                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, unsigned long long* __restrict__ stats) {
   uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t e = (uint32_t)(gid >> 3), wi = (uint32_t)(gid & 7);
   if (e >= nrec) return;
   uint64_t a = seq_off[e], b = seq_off[e + 1];
-  uint32_t L = (uint32_t)(b - a); if (L > SQ_MAX_READ_LEN) L = SQ_MAX_READ_LEN;
+  uint32_t L = (uint32_t)(b - a);
+  if (L > SQ_MAX_READ_LEN) { L = SQ_MAX_READ_LEN; if (wi == 0) atomicAdd(&stats[ST_TRUNC], 1ULL); }   // rare by construction (RNA-seq reads are 50-250 bases)
   const uint8_t* s = seq + a + 32 * wi;
   uint64_t cw = 0; uint32_t cn = 0;
   const uint32_t lo = 32 * wi; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);

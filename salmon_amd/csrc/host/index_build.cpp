@@ -505,7 +505,22 @@ static int finish_opts(const sq_index_opts* o, sq_index* idx) {
   return SQ_OK;
 }
 
-extern "C" int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, const char* const* names,
+static int index_build_mem_impl(const sq_index_opts* opts, uint32_t nrefs, const char* const* names, const char* const* seqs, const uint32_t* lens,
+                                uint32_t first_decoy, const char* outdir, sq_index** out);
+static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir);
+// the C ABI never lets a C++ exception out (a ctypes / cgo host would abort): allocation failures become SQ_ERR_NOMEM
+extern "C" int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, const char* const* names, const char* const* seqs, const uint32_t* lens,
+                                  uint32_t first_decoy, const char* outdir, sq_index** out) {
+  try { return index_build_mem_impl(opts, nrefs, names, seqs, lens, first_decoy, outdir, out); }
+  catch (const std::bad_alloc&) { sq_set_error("out of memory while building the index"); return SQ_ERR_NOMEM; }
+  catch (const std::exception& e) { sq_set_error("index build failed: %s", e.what()); return SQ_ERR_STATE; }
+}
+extern "C" int sq_index_build(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir) {
+  try { return index_build_impl(opts, fasta_path, decoys_path, outdir); }
+  catch (const std::bad_alloc&) { sq_set_error("out of memory while building the index"); return SQ_ERR_NOMEM; }
+  catch (const std::exception& e) { sq_set_error("index build failed: %s", e.what()); return SQ_ERR_STATE; }
+}
+static int index_build_mem_impl(const sq_index_opts* opts, uint32_t nrefs, const char* const* names,
                                   const char* const* seqs, const uint32_t* lens, uint32_t first_decoy,
                                   const char* outdir, sq_index** out) {
   if (!names || !seqs || !lens || nrefs == 0) { sq_set_error("sq_index_build_mem: bad arguments"); return SQ_ERR_ARG; }
@@ -521,7 +536,7 @@ extern "C" int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, con
   return SQ_OK;
 }
 
-extern "C" int sq_index_build(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir) {
+static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir) {
   if (!fasta_path || !outdir) { sq_set_error("sq_index_build: bad arguments"); return SQ_ERR_ARG; }
   sq_index* idx = new sq_index();
   int rc = finish_opts(opts, idx); if (rc) { delete idx; return rc; }
@@ -556,9 +571,11 @@ template <class T> bool wvec(FILE* f, const std::vector<T>& v) {
   uint64_t n = v.size();
   return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
 }
-template <class T> bool rvec(FILE* f, std::vector<T>& v) {
+template <class T> bool rvec(FILE* f, std::vector<T>& v, uint64_t file_bytes) {
   uint64_t n;
   if (fread(&n, 8, 1, f) != 1) return false;
+  const long at = ftell(f);
+  if (at < 0 || n > (file_bytes - (uint64_t)at) / sizeof(T)) return false;   // a section cannot be longer than what is left of the file
   v.resize(n);
   return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
@@ -609,7 +626,13 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
   return SQ_OK;
 }
 
-int sq_index_load_host(const std::string& dir, sq_index** out) {
+static int index_load_host_impl(const std::string& dir, sq_index** out);
+int sq_index_load_host(const std::string& dir, sq_index** out) {   // never lets an exception cross the C ABI
+  try { return index_load_host_impl(dir, out); }
+  catch (const std::bad_alloc&) { sq_set_error("out of memory while loading the index in '%s'", dir.c_str()); return SQ_ERR_NOMEM; }
+  catch (const std::exception& e) { sq_set_error("cannot load the index in '%s': %s", dir.c_str(), e.what()); return SQ_ERR_IO; }
+}
+static int index_load_host_impl(const std::string& dir, sq_index** out) {
   std::string p = dir + "/index.bin";
   struct stat st;
   // SalmonIndex.hpp:124-131
@@ -624,6 +647,8 @@ int sq_index_load_host(const std::string& dir, sq_index** out) {
     sq_set_error("'%s' is not a salmon-hip index of version %u", p.c_str(), SQ_INDEX_VERSION);
     return SQ_ERR_IO;
   }
+  struct stat fst; if (stat(p.c_str(), &fst) != 0) { fclose(f); sq_set_error("cannot stat '%s'", p.c_str()); return SQ_ERR_IO; }
+  const uint64_t FB = (uint64_t)fst.st_size;
   sq_index* idx = new sq_index();
   idx->k = h.k;
   idx->m = h.m;
@@ -631,16 +656,29 @@ int sq_index_load_host(const std::string& dir, sq_index** out) {
   idx->n_parts = h.n_parts;
   idx->num_kmers = h.num_kmers;
   std::vector<char> nm;
-  bool ok = rvec(f, nm) && rvec(f, idx->ref_len) && rvec(f, idx->ref_clen) && rvec(f, idx->ref_accum) && rvec(f, idx->refseq) && rvec(f,
-      idx->useq) && rvec(f,
-      idx->uoff) &&
-            rvec(f, idx->ctab_off) && rvec(f, idx->ctab) && rvec(f, idx->part_slot_off) && rvec(f, idx->part_bkt_off) && rvec(f,
-                idx->pilots) && rvec(f, idx->slots) &&
-            rvec(f, idx->entries) && rvec(f, idx->skew_keys) && rvec(f, idx->skew_vals);
+  bool ok = rvec(f, nm, FB) && rvec(f, idx->ref_len, FB) && rvec(f, idx->ref_clen, FB) && rvec(f, idx->ref_accum, FB) && rvec(f, idx->refseq, FB) &&
+            rvec(f, idx->useq, FB) && rvec(f, idx->uoff, FB) && rvec(f, idx->ctab_off, FB) && rvec(f, idx->ctab, FB) && rvec(f, idx->part_slot_off, FB) &&
+            rvec(f, idx->part_bkt_off, FB) && rvec(f, idx->pilots, FB) && rvec(f, idx->slots, FB) && rvec(f, idx->entries, FB) &&
+            rvec(f, idx->skew_keys, FB) && rvec(f, idx->skew_vals, FB);
   fclose(f);
   if (!ok) { delete idx; sq_set_error("truncated index '%s'", p.c_str()); return SQ_ERR_IO; }
+  if (!nm.empty() && nm.back() != '\0') { delete idx; sq_set_error("corrupt name table in '%s' (no terminator)", p.c_str()); return SQ_ERR_IO; }
   for (size_t i = 0; i < nm.size();) { idx->names.emplace_back(&nm[i]); i += idx->names.back().size() + 1; }
   if (idx->names.size() != h.nrefs) { delete idx; sq_set_error("corrupt name table in '%s'", p.c_str()); return SQ_ERR_IO; }
+  // the sections must agree with the header and with each other before anything indexes them on the device
+  const uint64_t U = idx->uoff.empty() ? 0 : idx->uoff.size() - 1;
+  const bool sane = h.k >= 3 && h.k <= 31 && (h.k & 1) && h.m >= 1 && h.m <= h.k && h.first_decoy <= h.nrefs &&
+      idx->ref_len.size() == h.nrefs && idx->ref_clen.size() == h.nrefs && idx->ref_accum.size() == (size_t)h.nrefs + 1 &&
+      !idx->uoff.empty() && idx->ctab_off.size() == idx->uoff.size() && idx->ctab_off.back() == idx->ctab.size() &&
+      idx->uoff.back() <= 32 * (uint64_t)idx->useq.size() && idx->ref_accum.back() <= 32 * (uint64_t)idx->refseq.size() &&
+      idx->part_slot_off.size() == (size_t)h.n_parts + 1 && idx->part_bkt_off.size() == (size_t)h.n_parts + 1 &&
+      (h.n_parts == 0 || (idx->part_slot_off.back() == idx->slots.size() && idx->part_bkt_off.back() == idx->pilots.size())) &&
+      idx->skew_keys.size() == idx->skew_vals.size() && (idx->skew_keys.empty() || (idx->skew_keys.size() & (idx->skew_keys.size() - 1)) == 0);
+  bool mono = sane;
+  for (size_t i = 0; mono && i + 1 < idx->uoff.size(); ++i) mono = idx->uoff[i] <= idx->uoff[i + 1] && idx->ctab_off[i] <= idx->ctab_off[i + 1];
+  for (size_t r = 0; mono && r < h.nrefs; ++r) mono = idx->ref_accum[r + 1] - idx->ref_accum[r] == idx->ref_len[r];
+  if (mono) for (uint64_t o : idx->ctab) if ((uint32_t)(o >> 32) >= h.nrefs) { mono = false; break; }
+  if (!mono) { delete idx; sq_set_error("inconsistent index sections in '%s' (%llu unitigs): rebuild the index", p.c_str(), (unsigned long long)U); return SQ_ERR_IO; }
   *out = idx;
   return SQ_OK;
 }

@@ -360,7 +360,7 @@ def test_limits_capacity_and_long_reads(small_world):
     ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=2)
     assert st_g == st_c and np.array_equal(ro_g, ro_c)
     _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
-    assert len(aln_g) > 0 and int(aln_g["read_len"].max()) == 256
+    assert len(aln_g) > 0 and int(aln_g["read_len"].max()) == 256 and st_g["num_truncated_ends"] == 600
     ctx.free()
 
 
