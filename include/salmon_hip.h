@@ -230,6 +230,10 @@ int sq_map_batch(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out, sq_map_sta
 int sq_ctx_set_lanes(sq_ctx*, int lanes /* 1..4, default 2 */);
 int sq_map_submit(sq_ctx*, const sq_read_batch* in, sq_aln_batch* out /* may be NULL */);
 int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stats);
+/* Alignments of the batch sq_map_wait / sq_map_batch returned last, copied out of HBM on demand (they stay in that lane's
+ * buffers until the lane maps again).  out->read_off == out->aln == NULL: only out->n and out->aln_cap (= alignments
+ * held) are filled — the size query the SAM writer makes before it sizes its arrays. */
+int sq_map_fetch(sq_ctx*, sq_aln_batch* out);
 
 /* ------------------------------------------------------------------------------------------------
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +
@@ -243,7 +247,14 @@ int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stat
 typedef struct sq_reader sq_reader;
 int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2,
                    uint32_t batch_reads, uint32_t num_slots, sq_reader** out);
+/* flags: SQ_READER_KEEP_NAMES also keeps the read names of the mate-1 stream (header up to the first blank, a
+ * trailing /1 or /2 dropped) for sq_reader_names — only the SAM writer (--writeMappings) asks for them. */
+#define SQ_READER_KEEP_NAMES 1u
+int sq_reader_open_ex(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2,
+                      uint32_t batch_reads, uint32_t num_slots, uint32_t flags, sq_reader** out);
 int sq_reader_next(sq_reader*, sq_read_batch* batch, int* slot);
+/* names of the batch held in `slot`: name i = names[name_off[i] .. name_off[i+1]); valid until the slot is released */
+int sq_reader_names(const sq_reader*, int slot, const char** names, const uint64_t** name_off);
 void sq_reader_release(sq_reader*, int slot);
 uint64_t sq_reader_total(const sq_reader*);
 void sq_reader_close(sq_reader*);

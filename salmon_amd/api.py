@@ -236,6 +236,16 @@ class QuantContext:
             return None, None, None, st.as_dict()
         return ent["read_off"], ent["aln"][: int(ent["read_off"][-1])], ent["mt"], st.as_dict()
 
+    def map_fetch(self):
+        """Alignments of the batch map_wait / map_batch returned last (sq_map_fetch: size query, then the copy)."""
+        ab = capi.AlnBatch()
+        check(lib().sq_map_fetch(self.h, C.byref(ab)), "sq_map_fetch")
+        n, cap = int(ab.n), int(ab.aln_cap)
+        read_off = np.zeros(n + 1, np.uint64); aln = np.zeros(max(cap, 1), ALN_DTYPE); mt = np.zeros(n, np.uint8)
+        ab = capi.AlnBatch(n, _ptr(read_off, C.c_uint64), aln.ctypes.data_as(C.POINTER(capi.Aln)), max(cap, 1), _ptr(mt, C.c_uint8))
+        check(lib().sq_map_fetch(self.h, C.byref(ab)), "sq_map_fetch")
+        return read_off, aln[:cap], mt
+
     def tap(self, what, dtype):
         n = lib().sq_debug_tap(self.h, what, None, 0)
         if n < 0:

@@ -151,6 +151,8 @@ def lib():
         "sq_map_submit": (C.c_int, [vp, P(ReadBatch), P(AlnBatch)]), "sq_ctx_set_lanes": (C.c_int, [vp, C.c_int]),
         "sq_reader_open": (C.c_int, [P(C.c_char_p), u32, P(C.c_char_p), u32, u32, u32, P(vp)]), "sq_reader_next": (C.c_int, [vp, P(ReadBatch),
             P(C.c_int)]),
+        "sq_reader_open_ex": (C.c_int, [P(C.c_char_p), u32, P(C.c_char_p), u32, u32, u32, u32, P(vp)]),
+        "sq_reader_names": (C.c_int, [vp, C.c_int, P(C.c_void_p), P(P(u64))]), "sq_map_fetch": (C.c_int, [vp, P(AlnBatch)]),
         "sq_reader_release": (None, [vp, C.c_int]), "sq_reader_total": (u64, [vp]), "sq_reader_close": (None, [vp]),
         "sq_map_wait": (C.c_int, [vp, P(AlnBatch), P(MapStats)]),
         "sq_eq_accumulate": (C.c_int, [vp]), "sq_eq_finish": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge": (C.c_int, [vp, P(EqTable)]),

@@ -37,6 +37,7 @@ static void check_args(int argc, char** argv, const std::vector<const char*>& ta
     if (in(multi, a)) { if (i + 1 >= argc) { fprintf(stderr, "[salmon-hip] option %s needs a value\n", a); exit(1); } ++i; while (i + 1 < argc && argv[i + 1][0] != '-') ++i; continue; }
     if (in(takes, a)) { if (i + 1 >= argc) { fprintf(stderr, "[salmon-hip] option %s needs a value\n", a); exit(1); } ++i; continue; }
     if (in(flags, a)) continue;
+    if (in(flags, "--writeMappings") && !strncmp(a, "--writeMappings=", 16)) continue;   // implicit-value option: --writeMappings[=file]
     fprintf(stderr, "[salmon-hip] option %s is not supported by this driver (no silent fallback: a salmon option that is ignored would change the results)\n", a);
     exit(1);
   }
@@ -110,6 +111,71 @@ static int gc_hook_cb(const double* alphas, const double* eff_in, double* eff_ou
   fprintf(stderr, "[salmon-hip] iteration 11, adjusting effective lengths to account for biases\n");
   return sq_bias_gc_eff_lengths(h->idx, h->obs.data(), h->logpmf.data(), m, alphas, eff_in, eff_out, &h->rep);
 }
+
+// ---- --writeMappings: the selected alignments as SAM (the records pufferfish's writeAlignmentsToStream emits from the same
+// QuasiAlignment fields [external pufferfish@ace68c1c, include/pufferfish/Util.hpp], as called at SalmonQuantify.cpp:1637-1650).  No
+// base-level CIGAR is kept on the GPU path: an end is written as <len>M, with soft clips where it overhangs the transcript.
+struct SamWriter {
+  FILE* f = nullptr; bool own = false; std::string line; uint64_t nrec = 0;
+  bool open(const char* path, sq_index* idx, uint32_t M, int argc, char** argv) {
+    if (!path || !strcmp(path, "-")) f = stdout; else { f = fopen(path, "w"); own = true; }
+    if (!f) return false;
+    fprintf(f, "@HD\tVN:1.0\tSO:unsorted\n");
+    for (uint32_t i = 0; i < M; ++i) fprintf(f, "@SQ\tSN:%s\tLN:%llu\n", sq_index_ref_name(idx, i), (unsigned long long)sq_index_ref_len(idx, i));
+    fprintf(f, "@PG\tID:salmon-hip\tPN:salmon-hip\tVN:0.2\tCL:"); for (int i = 0; i < argc; ++i) fprintf(f, "%s%s", i ? " " : "", argv[i]); fprintf(f, "\n");
+    return true;
+  }
+  void close() { if (f && own) fclose(f); else if (f) fflush(f); f = nullptr; }
+  static void cigar(std::string& o, int32_t pos, uint32_t len, uint64_t tlen) {   // pos may be negative / run past the end
+    int64_t lead = pos < 0 ? -(int64_t)pos : 0; if (lead > (int64_t)len) lead = len;
+    int64_t over = (int64_t)pos + (int64_t)len - (int64_t)tlen; if (over < 0) over = 0; if (over > (int64_t)len - lead) over = (int64_t)len - lead;
+    const int64_t mid = (int64_t)len - lead - over; char b[64];
+    if (lead) { snprintf(b, sizeof b, "%lldS", (long long)lead); o += b; }
+    if (mid) { snprintf(b, sizeof b, "%lldM", (long long)mid); o += b; }
+    if (over) { snprintf(b, sizeof b, "%lldS", (long long)over); o += b; }
+    if (!len) o += "*";
+  }
+  static void seq(std::string& o, const uint8_t* s, uint32_t n, bool rc) {
+    if (!n) { o += "*"; return; }
+    if (!rc) { o.append((const char*)s, n); return; }
+    for (uint32_t i = n; i-- > 0;) { char c = (char)s[i]; switch (c) { case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break;
+      case 'a': c = 't'; break; case 'c': c = 'g'; break; case 'g': c = 'c'; break; case 't': c = 'a'; break; default: break; } o.push_back(c); }
+  }
+  void rec(const char* nm, size_t nl, int flag, const char* rname, int32_t pos, uint32_t len, uint64_t tlen, const char* rnext, int32_t pnext, int64_t isize,
+           const uint8_t* s, bool rc, uint32_t nh, bool mapped) {
+    char b[96]; line.clear(); line.append(nm, nl);
+    snprintf(b, sizeof b, "\t%d\t", flag); line += b; line += rname;
+    snprintf(b, sizeof b, "\t%d\t%d\t", mapped ? (pos < 0 ? 1 : pos + 1) : (pos < 0 ? 1 : pos + 1), mapped ? 1 : 0); line += b;
+    if (mapped) cigar(line, pos, len, tlen); else line += "*";
+    line += "\t"; line += rnext; snprintf(b, sizeof b, "\t%d\t%lld\t", pnext < 0 ? 1 : pnext + 1, (long long)isize); line += b;
+    seq(line, s, len, rc); line += "\t*";
+    snprintf(b, sizeof b, "\tNH:i:%u\n", nh); line += b;
+    fwrite(line.data(), 1, line.size(), f); ++nrec;
+  }
+  // one batch: reads `in` (host), names, alignments
+  void batch(sq_index* idx, const sq_read_batch& in, const char* names, const uint64_t* noff, const sq_aln_batch& ab) {
+    for (uint32_t r = 0; r < ab.n; ++r) {
+      const uint64_t a0 = ab.read_off[r], a1 = ab.read_off[r + 1]; if (a0 == a1) continue;
+      const char* nm = names + noff[r]; const size_t nl = (size_t)(noff[r + 1] - noff[r]); const uint32_t nh = (uint32_t)(a1 - a0);
+      const uint8_t* s1 = in.seq + in.seq_off[in.paired ? 2 * r : r]; const uint32_t l1 = (uint32_t)(in.seq_off[(in.paired ? 2 * r : r) + 1] - in.seq_off[in.paired ? 2 * r : r]);
+      const uint8_t* s2 = in.paired ? in.seq + in.seq_off[2 * r + 1] : nullptr; const uint32_t l2 = in.paired ? (uint32_t)(in.seq_off[2 * r + 2] - in.seq_off[2 * r + 1]) : 0;
+      for (uint64_t i = a0; i < a1; ++i) {
+        const sq_aln& a = ab.aln[i]; const char* tn = sq_index_ref_name(idx, a.tid); const uint64_t tl = sq_index_ref_len(idx, a.tid); const int sec = i > a0 ? 0x100 : 0;
+        if (!in.paired) { rec(nm, nl, (a.fwd ? 0 : 0x10) | sec, tn, a.pos, l1, tl, "*", -1, 0, s1, !a.fwd, nh, true); continue; }
+        if (a.mate_status == SQ_MS_PAIRED_END_PAIRED) {
+          const int64_t lo = std::min<int64_t>(a.pos, a.mate_pos), hi = std::max<int64_t>((int64_t)a.pos + l1, (int64_t)a.mate_pos + l2); const int64_t span = hi - lo;
+          const bool first_left = a.pos <= a.mate_pos;
+          rec(nm, nl, 0x1 | 0x2 | (a.fwd ? 0 : 0x10) | (a.mate_fwd ? 0 : 0x20) | 0x40 | sec, tn, a.pos, l1, tl, "=", a.mate_pos, first_left ? span : -span, s1, !a.fwd, nh, true);
+          rec(nm, nl, 0x1 | 0x2 | (a.mate_fwd ? 0 : 0x10) | (a.fwd ? 0 : 0x20) | 0x80 | sec, tn, a.mate_pos, l2, tl, "=", a.pos, first_left ? -span : span, s2, !a.mate_fwd, nh, true);
+        } else {   // orphan: the mapped end, then its unmapped mate placed at the same position (SAM convention)
+          const bool left = a.mate_status == SQ_MS_PAIRED_END_LEFT;
+          rec(nm, nl, 0x1 | 0x8 | (a.fwd ? 0 : 0x10) | (left ? 0x40 : 0x80) | sec, tn, a.pos, left ? l1 : l2, tl, "=", a.pos, 0, left ? s1 : s2, !a.fwd, nh, true);
+          rec(nm, nl, 0x1 | 0x4 | (a.fwd ? 0 : 0x20) | (left ? 0x80 : 0x40) | sec, tn, a.pos, left ? l2 : l1, tl, "=", a.pos, 0, left ? s2 : s1, false, nh, false);
+        }
+      }
+    }
+  }
+};
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 static int part_cb(const double* a, uint32_t m, void* user) { return fwrite(a, 8, m, (FILE*)user) == m ? 0 : 1; }   // a rank's replicates, raw, for rank 0 to collect
 
@@ -235,7 +301,7 @@ static int cmd_quant(int argc, char** argv) {
                           "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--writeMappings", "-z"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
@@ -317,12 +383,29 @@ static int cmd_quant(int argc, char** argv) {
   const uint32_t lanes = (v = arg(argc, argv, "--lanes")) ? (uint32_t)std::max(1, std::min(4, atoi(v))) : 2;
   if (sq_ctx_set_lanes(ctx, (int)lanes)) die("lanes");
   sq_reader* rd = nullptr;
-  if (sq_reader_open(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1,
+  // --writeMappings[=file] / -z: SAM records of the selected alignments ("-" or no value = stdout, as in the reference)
+  const char* sam_path = nullptr;
+  for (int i = 2; i < argc; ++i) { if (!strcmp(argv[i], "--writeMappings") || !strcmp(argv[i], "-z")) sam_path = "-"; else if (!strncmp(argv[i], "--writeMappings=", 16)) sam_path = argv[i] + 16; }
+  SamWriter sam;
+  if (sam_path) {
+    if (world > 1) { fprintf(stderr, "[salmon-hip] --writeMappings needs one GPU (the ranks would interleave their records)\n"); return 1; }
+    if (!sam.open(sam_path, idx, sq_index_first_decoy(idx), argc, argv)) { fprintf(stderr, "[salmon-hip] cannot open %s\n", sam_path); return 1; }
+  }
+  if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, sam_path ? SQ_READER_KEEP_NAMES : 0,
       &rd)) die("opening reads");
-  sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight;
+  sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight; std::vector<sq_read_batch> inflight_in;
+  std::vector<uint64_t> sam_off; std::vector<sq_aln> sam_aln;
   auto finish_one = [&]() {
     sq_map_stats st{};
     if (sq_map_wait(ctx, nullptr, &st)) die("mapping");
+    if (sam_path) {
+      sq_aln_batch ab{}; if (sq_map_fetch(ctx, &ab)) die("alignment size query");
+      sam_off.resize((size_t)ab.n + 1); sam_aln.resize((size_t)ab.aln_cap + 1); ab.read_off = sam_off.data(); ab.aln = sam_aln.data();
+      if (sq_map_fetch(ctx, &ab)) die("alignment fetch");
+      const char* nm; const uint64_t* no; if (sq_reader_names(rd, inflight.front(), &nm, &no)) die("read names");
+      sam.batch(idx, inflight_in.front(), nm, no, ab);
+    }
+    inflight_in.erase(inflight_in.begin());
     if (sq_eq_accumulate(ctx)) die("eq-class accumulation");
     sq_reader_release(rd, inflight.front()); inflight.erase(inflight.begin());
     uint64_t* a = (uint64_t*)&tot; const uint64_t* b = (const uint64_t*)&st; for (size_t i = 0; i < sizeof(st) / 8; ++i) a[i] += b[i];
@@ -337,9 +420,10 @@ static int cmd_quant(int argc, char** argv) {
     if (world > 1 && (int)(batch_no++ % (uint64_t)world) != rank) { sq_reader_release(rd, slot); continue; }   // batch b -> rank b mod R (SPEC MG)
     if (inflight.size() == lanes) finish_one();
     if (sq_map_submit(ctx, &in, nullptr)) die("mapping");
-    inflight.push_back(slot);
+    inflight.push_back(slot); inflight_in.push_back(in);
   }
   while (!inflight.empty()) finish_one();
+  if (sam_path) { sam.close(); fprintf(stderr, "\n[salmon-hip] wrote %llu SAM records to %s", (unsigned long long)sam.nrec, !strcmp(sam_path, "-") ? "stdout" : sam_path); }
   sq_reader_close(rd);
   fprintf(stderr, "\n");
   if (tot.num_truncated_ends) fprintf(stderr, "[salmon-hip] warning: %llu read ends were longer than 256 bases and were cut to their first 256 (the packing limit of the GPU path)\n",

@@ -3,6 +3,7 @@
 // stages; the host only reads back three totals (MEMs, candidates, DP regions) to size buffers.
 #include "map_kernels.h"
 #include "mem_kernels.h"
+#include "scan_kernels.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
@@ -13,12 +14,11 @@ namespace {
 const int TB = 256;
 inline uint32_t nblk(uint64_t n) { return (uint32_t)((n + TB - 1) / TB); }
 
-int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_plus_1) {
-  size_t tmp = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n_plus_1, c->stream);
-  if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
-  tmp = c->sort_tmp.n;
-  SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->sort_tmp.p, tmp, in, out, (int)n_plus_1, c->stream));
+int exclusive_scan_u32(sq_ctx* c, const uint32_t* in, uint64_t* out, uint32_t n_plus_1) {   // scan_kernels.h
+  const uint64_t n = (uint64_t)n_plus_1 - 1;
+  if (c->sort_tmp.ensure((size_t)scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
+  exclusive_scan_u32_u64(in, out, n, (uint64_t*)c->sort_tmp.p, c->stream);
+  SQ_HIP_CHECK(hipGetLastError());
   return SQ_OK;
 }
 
@@ -332,6 +332,22 @@ extern "C" int sq_map_wait(sq_ctx* c, sq_aln_batch* out, sq_map_stats* stats) {
   if (out && J->has_out) *out = J->out;
   c->last_src = lane; c->api_have = true;
   c->acc_n = J->n; c->acc_buf = J->buf; c->acc_total_aln = J->total_aln; c->acc_joint = J->joint;
+  return SQ_OK;
+}
+
+// alignments of the batch sq_map_wait / sq_map_batch returned last (they stay in that lane's buffers until the lane maps again)
+extern "C" int sq_map_fetch(sq_ctx* c, sq_aln_batch* out) {
+  if (!c || c->owner || !out) { sq_set_error("sq_map_fetch: bad arguments"); return SQ_ERR_ARG; }
+  if (!c->api_have || !c->last_src) { sq_set_error("sq_map_fetch: no mapped batch"); return SQ_ERR_STATE; }
+  sq_ctx* src = c->last_src; const uint32_t n = c->acc_n; const uint64_t total = c->acc_total_aln; const int buf = c->acc_buf;
+  out->n = n;
+  if (!out->aln && !out->read_off) { out->aln_cap = total; return SQ_OK; }     // size query
+  if (!out->read_off || (!out->aln && total)) { sq_set_error("sq_map_fetch: output arrays missing"); return SQ_ERR_ARG; }
+  if (total > out->aln_cap) { sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total, (unsigned long long)out->aln_cap); return SQ_ERR_OVERFLOW; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  SQ_HIP_CHECK(hipMemcpy(out->read_off, src->aln_off_ptr(buf), (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+  if (total) SQ_HIP_CHECK(hipMemcpy(out->aln, src->aln_ptr(buf), (size_t)total * sizeof(sq_aln), hipMemcpyDeviceToHost));
+  if (out->map_type) SQ_HIP_CHECK(hipMemcpy(out->map_type, src->map_type.p, n, hipMemcpyDeviceToHost));
   return SQ_OK;
 }
 

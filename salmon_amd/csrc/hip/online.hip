@@ -12,6 +12,7 @@
 // so results do not depend on thread order and equal the CPU checker bit for bit (SPEC §D1).
 // The equivalence-class table is an HBM open-addressing table keyed by a 128-bit label hash.
 #include "ctx.h"
+#include "scan_kernels.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -858,16 +859,15 @@ int sq_online_create(sq_ctx* c) {
     double nm = phi((i + 0.5 - q.fld_mean) / q.fld_sd) - phi((i - 0.5 - q.fld_mean) / q.fld_sd);
     hist[i] = (nm != 0) ? sq_log(nm) : SQ_LOG_EPSILON;
   }
-  { std::vector<double> v(1024,
-      SQ_LOG_0); for (int i = 0;
-      i <= 1000;
-      ++i) v[i] = hist[i]; for (int s = 512;
-      s >= 1;
-      s >>= 1) for (int i = 0;
-      i < s;
-      ++i) v[i] = sq_log_add(v[i], v[i + s]);
-    tot0 = v[0]; double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal),
-        hipMemcpyHostToDevice)); }
+  {   // total mass of the prior histogram: the canonical strided-halving sum (SPEC D2)
+    std::vector<double> v(1024, SQ_LOG_0);
+    for (int i = 0; i <= 1000; ++i) v[i] = hist[i];
+    for (int s = 512; s >= 1; s >>= 1)
+      for (int i = 0; i < s; ++i) v[i] = sq_log_add(v[i], v[i + s]);
+    tot0 = v[0];
+    double scal[8] = {v[0], 0, 0, 0, 0, 0, 0, 0};
+    SQ_HIP_CHECK(hipMemcpy(o->scal.p, scal, sizeof(scal), hipMemcpyHostToDevice));
+  }
   // evaluateLogCMF as written (DistributionUtils.cpp:104-118)
   {
     double cum = SQ_LOG_0;
@@ -1116,10 +1116,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
-  { size_t tmp = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, o->assigned_flag.p, o->assigned_prefix.p, (int)(n + 1), st);
-    if (o->scan_tmp.ensure(tmp + 256)) { sq_set_error("scan temp allocation failed"); return SQ_ERR_NOMEM; }
-    tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
-        (int)(n + 1), st)); }
+  if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
+  sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
@@ -1187,8 +1185,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p,
             c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
         k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, rs, d_aln_off, d_aln, q, o->assigned_flag.p);
-        { size_t tmp = o->scan_tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(o->scan_tmp.p, tmp, o->assigned_flag.p, o->assigned_prefix.p,
-            (int)(n + 1), st)); }
+        sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
         // the mini-batches still to come read rh1/rh2 only after writing them: rh2 doubles as the bounds scratch again
         sq_dbuf<uint64_t>& scratch = o->assigned_prefix_b;
         if (scratch.ensure(nmb + 2)) { sq_set_error("device allocation failed (bounds scratch)"); return SQ_ERR_NOMEM; }

@@ -36,7 +36,14 @@
 
 namespace {
 
-struct RecBlock { std::vector<char> seq; std::vector<uint32_t> len; };   // sequences back to back
+struct RecBlock { std::vector<char> seq; std::vector<uint32_t> len; std::vector<char> names; std::vector<uint32_t> nlen; };   // sequences back to back (+ names on request)
+
+// read name = the header up to the first blank, without a trailing /1 or /2 (what both mates of a pair share)
+inline size_t name_len(const char* h, size_t n) {
+  size_t l = 0; while (l < n && h[l] != ' ' && h[l] != '\t' && h[l] != '\r') ++l;
+  if (l > 2 && h[l - 2] == '/' && (h[l - 1] == '1' || h[l - 1] == '2')) l -= 2;
+  return l;
+}
 
 // bounded single-producer / single-consumer queue of record blocks
 struct BlockQueue {
@@ -75,7 +82,7 @@ struct BlockQueue {
 
 // one mate stream: inflate + split records.  FASTQ and FASTA, sequences and qualities on one or several lines
 // (what the reference's kseq-based parser accepts), LF or CRLF, blank lines between records tolerated.
-void produce(std::vector<std::string> files, BlockQueue* out) {
+void produce(std::vector<std::string> files, BlockQueue* out, bool keep_names) {
   const size_t BUF = 4u << 20; std::vector<char> buf(BUF); const uint32_t PER_BLOCK = 16384;
   auto fresh = [&] { auto b = std::make_unique<RecBlock>(); b->seq.reserve((size_t)PER_BLOCK * 128); b->len.reserve(PER_BLOCK); return b; };
   auto blk = fresh();
@@ -99,6 +106,7 @@ void produce(std::vector<std::string> files, BlockQueue* out) {
         if (ls[0] == '@') fastq = true; else if (ls[0] == '>') fastq = false;
         else { bad = "'" + path + "': record " + std::to_string(have + 1) + " does not start with '@' or '>'"; return; }
         state = 1; cur_len = 0; qual_len = 0;
+        if (keep_names) { const size_t nl = name_len(ls + 1, ll - 1); blk->names.insert(blk->names.end(), ls + 1, ls + 1 + nl); blk->nlen.push_back((uint32_t)nl); }
       } else if (state == 1) {
         if (fastq && ll && ls[0] == '+') { state = 3; if (cur_len == 0) close_record(); return; }
         blk->seq.insert(blk->seq.end(), ls, ls + ll); cur_len += (uint32_t)ll;
@@ -166,6 +174,7 @@ struct Mapping { void* p = nullptr; size_t n = 0; ~Mapping() { if (p) munmap(p, 
 struct Chunk {   // a run of whole records of one stream, in stream order
   const char* text = nullptr; size_t bytes = 0; std::vector<char> own; std::shared_ptr<Mapping> map;   // window of an mmap, or an owned buffer (.gz)
   std::vector<uint32_t> pos, len;   // per record: where its bases start in `text`, how many
+  std::vector<uint32_t> npos, nlen; bool keep_names = false;   // on request: where its name starts, how long it is
   std::string path; uint64_t first_record = 0;
   bool done = false; std::string err;
 };
@@ -219,6 +228,7 @@ void parse_chunk(Chunk* c) {
     size_t ql = (size_t)(e3 - l3); if (ql && l3[ql - 1] == '\r') --ql;
     if (ql != sl) { fail(ql > sl ? "has a quality string longer than its sequence" : "has a quality string shorter than its sequence: truncated record"); return; }
     c->pos.push_back((uint32_t)(l1 - c->text)); c->len.push_back((uint32_t)sl); ++rec;
+    if (c->keep_names) { c->npos.push_back((uint32_t)(p + 1 - c->text)); c->nlen.push_back((uint32_t)name_len(p + 1, (size_t)(e0 - p - 1))); }
     p = e3 < end ? e3 + 1 : end;
   }
 }
@@ -245,9 +255,10 @@ bool looks_like_simple_fastq(const char* b, size_t n) {
 const size_t CHUNK_BYTES = 8u << 20;
 
 // one mate stream on the fast path; returns false (nothing consumed) if the first file is not simple FASTQ and the safe path should run
-void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool) {
+void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, bool keep_names) {
   uint64_t nrec_before = 0;
   auto dispatch = [&](std::shared_ptr<Chunk> c) {
+    c->keep_names = keep_names;
     out->push(c);
     pool->submit([c, out] { parse_chunk(c.get()); out->complete(c.get()); });
   };
@@ -314,7 +325,7 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool) {
 }
 
 struct Slot { uint8_t* seq = nullptr; size_t seq_cap = 0; uint64_t* off = nullptr; size_t off_cap = 0; bool pinned = false,
-    off_pinned = false; bool busy = false; };
+    off_pinned = false; bool busy = false; std::vector<char> names; std::vector<uint64_t> name_off; };
 
 void* host_alloc(size_t bytes, bool* pinned) {
   void* p = nullptr;
@@ -329,7 +340,7 @@ void host_free(void* p, bool pinned) { if (!p) return; if (pinned) (void)hipHost
 }  // namespace
 
 struct sq_reader {
-  bool paired = false; uint32_t batch = 0; BlockQueue q[2]; std::thread th[2];
+  bool paired = false, keep_names = false; uint32_t batch = 0; BlockQueue q[2]; std::thread th[2];
   // fast path
   bool fast = false; std::unique_ptr<Pool> pool; ChunkQueue cq[2]; std::shared_ptr<Chunk> fc[2]; size_t fidx[2] = {0, 0}; bool fend[2] = {false, false};
   struct Seg { std::shared_ptr<Chunk> c; size_t first, count; };
@@ -360,7 +371,7 @@ struct sq_reader {
     if (fc[i] && fidx[i] >= fc[i]->pos.size() && !ahead[i].empty()) { fc[i] = ahead[i].front(); ahead[i].erase(ahead[i].begin()); fidx[i] = 0; }
   }
   std::vector<std::shared_ptr<Chunk>> ahead[2];
-  std::unique_ptr<RecBlock> cur[2]; size_t cur_rec[2] = {0, 0}, cur_byte[2] = {0, 0};
+  std::unique_ptr<RecBlock> cur[2]; size_t cur_rec[2] = {0, 0}, cur_byte[2] = {0, 0}, cur_nbyte[2] = {0, 0};
   std::vector<Slot> slots; uint64_t total = 0; bool ended = false;
   ~sq_reader() {
     for (int i = 0; i < 2; ++i) { q[i].finish(); cq[i].finish(); if (th[i].joinable()) th[i].join(); }
@@ -368,29 +379,31 @@ struct sq_reader {
     for (auto& s : slots) { host_free(s.seq, s.pinned); host_free(s.off, s.off_pinned); }
   }
   // next record of stream i -> (ptr, len); false at end of stream
-  bool rec(int i, const char** p, uint32_t* l) {
+  bool rec(int i, const char** p, uint32_t* l, const char** nm = nullptr, uint32_t* nl = nullptr) {
     for (;;) {
       if (cur[i] && cur_rec[i] < cur[i]->len.size()) {
         *l = cur[i]->len[cur_rec[i]];
         *p = cur[i]->seq.data() + cur_byte[i];
         cur_byte[i] += *l;
+        if (nm && keep_names) { *nl = cur[i]->nlen[cur_rec[i]]; *nm = cur[i]->names.data() + cur_nbyte[i]; cur_nbyte[i] += *nl; }
         ++cur_rec[i];
         return true;
       }
-      cur[i] = q[i].get(); cur_rec[i] = 0; cur_byte[i] = 0;
+      cur[i] = q[i].get(); cur_rec[i] = 0; cur_byte[i] = 0; cur_nbyte[i] = 0;
       if (!cur[i]) return false;
     }
   }
 };
 
-extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2, uint32_t batch_reads,
-    uint32_t num_slots, sq_reader** out) {
+extern "C" int sq_reader_open_ex(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2, uint32_t batch_reads,
+    uint32_t num_slots, uint32_t flags, sq_reader** out) {
   if (!files1 || n1 == 0 || !out || batch_reads == 0 || (n2 && !files2)) {
     sq_set_error("sq_reader_open: bad arguments");
     return SQ_ERR_ARG;
   }
   if (n2 && n2 != n1) { sq_set_error("sq_reader_open: %u mate-1 files but %u mate-2 files", n1, n2); return SQ_ERR_ARG; }
-  std::unique_ptr<sq_reader> R(new sq_reader()); R->paired = n2 > 0; R->batch = batch_reads;
+  std::unique_ptr<sq_reader> R(new sq_reader()); R->paired = n2 > 0; R->batch = batch_reads; R->keep_names = (flags & SQ_READER_KEEP_NAMES) != 0;
+  const bool kn = R->keep_names;
   R->slots.resize(num_slots < 2 ? 2 : (num_slots > 8 ? 8 : num_slots));
   std::vector<std::string> a(files1, files1 + n1), b; if (n2) b.assign(files2, files2 + n2);
   // fast path for 4-line FASTQ (the first record of every file is looked at); anything else takes the kseq-rules path
@@ -404,14 +417,19 @@ extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char
   if (fast) {
     unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
     R->pool.reset(new Pool(std::max(1u, nt)));
-    R->th[0] = std::thread(produce_fast, a, &R->cq[0], R->pool.get());
-    if (n2) R->th[1] = std::thread(produce_fast, b, &R->cq[1], R->pool.get());
+    R->th[0] = std::thread(produce_fast, a, &R->cq[0], R->pool.get(), kn);
+    if (n2) R->th[1] = std::thread(produce_fast, b, &R->cq[1], R->pool.get(), false);
   } else {
-    R->th[0] = std::thread(produce, a, &R->q[0]);
-    if (n2) R->th[1] = std::thread(produce, b, &R->q[1]);
+    R->th[0] = std::thread(produce, a, &R->q[0], kn);
+    if (n2) R->th[1] = std::thread(produce, b, &R->q[1], false);
   }
   *out = R.release();
   return SQ_OK;
+}
+
+extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2, uint32_t batch_reads,
+    uint32_t num_slots, sq_reader** out) {
+  return sq_reader_open_ex(files1, n1, files2, n2, batch_reads, num_slots, 0, out);
 }
 
 // Fills *b with the next batch (b->n == 0 at the end of input).  The arrays live in slot *slot of the reader and stay
@@ -485,15 +503,22 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
     S.off[0] = 0;
     R->pool->parallel(K, [&](unsigned j) { walk(j, true); });
     memset(S.seq + bytes, 0, 16);
+    if (R->keep_names) {   // names of the mate-1 stream, in batch order (serial: only the SAM writer asks for them)
+      S.names.clear(); S.name_off.assign(1, 0);
+      for (const auto& g : sg[0]) for (size_t x = g.first; x < g.first + g.count; ++x) {
+        S.names.insert(S.names.end(), g.c->text + g.c->npos[x], g.c->text + g.c->npos[x] + g.c->nlen[x]); S.name_off.push_back(S.names.size());
+      }
+    }
     for (int i = 0; i < ns; ++i) R->consume(i, n);
     S.busy = true; R->total += n;
     b->n = (uint32_t)n; b->seq = S.seq; b->seq_off = S.off; b->on_device = 0; *slot = si;
     return SQ_OK;
   }
   uint32_t n = 0; uint64_t bytes = 0; S.off[0] = 0;
+  if (R->keep_names) { S.names.clear(); S.name_off.assign(1, 0); }
   while (n < R->batch) {
-    const char* p1; uint32_t l1; const char* p2 = nullptr; uint32_t l2 = 0;
-    const bool h1 = R->rec(0, &p1, &l1); const bool h2 = R->paired ? R->rec(1, &p2, &l2) : h1;
+    const char* p1; uint32_t l1; const char* p2 = nullptr; uint32_t l2 = 0; const char* nm = nullptr; uint32_t nl = 0;
+    const bool h1 = R->rec(0, &p1, &l1, &nm, &nl); const bool h2 = R->paired ? R->rec(1, &p2, &l2) : h1;
     if (!h1 || !h2) {
       R->ended = true;
       for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
@@ -511,6 +536,7 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
     }
     if (!grow(bytes + l1 + l2 + 64)) { sq_set_error("sq_reader: out of memory"); return SQ_ERR_NOMEM; }
     memcpy(S.seq + bytes, p1, l1); bytes += l1; S.off[R->paired ? 2 * n + 1 : n + 1] = bytes;
+    if (R->keep_names) { S.names.insert(S.names.end(), nm, nm + nl); S.name_off.push_back(S.names.size()); }
     if (R->paired) { memcpy(S.seq + bytes, p2, l2); bytes += l2; S.off[2 * n + 2] = bytes; }
     ++n;
   }
@@ -522,6 +548,12 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
 }
 extern "C" void sq_reader_release(sq_reader* R, int slot) {
   if (R && slot >= 0 && (size_t)slot < R->slots.size()) R->slots[(size_t)slot].busy = false;
+}
+// names of the batch in `slot` (reader opened with SQ_READER_KEEP_NAMES): name i = names[name_off[i] .. name_off[i+1])
+extern "C" int sq_reader_names(const sq_reader* R, int slot, const char** names, const uint64_t** name_off) {
+  if (!R || !names || !name_off || slot < 0 || (size_t)slot >= R->slots.size()) { sq_set_error("sq_reader_names: bad arguments"); return SQ_ERR_ARG; }
+  if (!R->keep_names) { sq_set_error("sq_reader_names: the reader was opened without SQ_READER_KEEP_NAMES"); return SQ_ERR_STATE; }
+  const Slot& S = R->slots[(size_t)slot]; *names = S.names.data(); *name_off = S.name_off.data(); return SQ_OK;
 }
 extern "C" uint64_t sq_reader_total(const sq_reader* R) { return R ? R->total : 0; }
 extern "C" void sq_reader_close(sq_reader* R) { delete R; }

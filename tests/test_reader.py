@@ -149,3 +149,34 @@ def test_reader_fast_path_across_chunks(built, tmp_path, gz, monkeypatch):
     monkeypatch.setenv("SQ_READER_SAFE", "1")
     h = _open(f1, f2, batch=50000); got, err = _drain(h); capi.lib().sq_reader_close(h)
     assert err is None and [r for b in got for r in b] == want
+
+
+@pytest.mark.parametrize("safe", [False, True])
+def test_reader_keeps_read_names_on_request(built, tmp_path, safe, monkeypatch):
+    # SQ_READER_KEEP_NAMES: name = header up to the first blank, trailing /1 dropped; both parser paths; without the flag the call is refused
+    if safe: monkeypatch.setenv("SQ_READER_SAFE", "1")
+    L = capi.lib(); rng = np.random.default_rng(5); n = 5000
+    hdr = ["frag%d/1 extra words" % i if i % 3 == 0 else ("frag%d\tx" % i if i % 3 == 1 else "frag%d" % i) for i in range(n)]
+    seqs = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(40, 120)))) for _ in range(n)]
+    for m in (1, 2):
+        with open(tmp_path / ("n_%d.fq" % m), "w") as f:
+            for i in range(n): f.write("@%s\n%s\n+\n%s\n" % (hdr[i].replace("/1", "/%d" % m), seqs[i], "I" * len(seqs[i])))
+    f1 = [str(tmp_path / "n_1.fq")]; f2 = [str(tmp_path / "n_2.fq")]
+    a1 = (C.c_char_p * 1)(f1[0].encode()); a2 = (C.c_char_p * 1)(f2[0].encode())
+    h = C.c_void_p(); assert L.sq_reader_open_ex(a1, 1, a2, 1, 1500, 3, 1, C.byref(h)) == 0
+    names = []
+    while True:
+        rb = capi.ReadBatch(); slot = C.c_int(-1)
+        assert L.sq_reader_next(h, C.byref(rb), C.byref(slot)) == 0
+        if rb.n == 0: break
+        nm = C.c_void_p(); no = C.POINTER(C.c_uint64)()
+        assert L.sq_reader_names(h, slot.value, C.byref(nm), C.byref(no)) == 0
+        off = [no[i] for i in range(rb.n + 1)]; raw = C.string_at(nm, off[-1])
+        names += [raw[off[i]:off[i + 1]].decode() for i in range(rb.n)]
+        L.sq_reader_release(h, slot.value)
+    L.sq_reader_close(h)
+    assert names == ["frag%d" % i for i in range(n)]
+    h = _open(f1, f2, batch=100); rb = capi.ReadBatch(); slot = C.c_int(-1); L.sq_reader_next(h, C.byref(rb), C.byref(slot))
+    nm = C.c_void_p(); no = C.POINTER(C.c_uint64)()
+    assert L.sq_reader_names(h, slot.value, C.byref(nm), C.byref(no)) != 0 and b"KEEP_NAMES" in L.sq_last_error()
+    L.sq_reader_close(h)
