@@ -1,6 +1,7 @@
 // hip/ctx.h — per-device quantification context: HBM work buffers of the mapping pipeline, the
 // online model and the equivalence-class table.  One sq_ctx per GPU (one process per GPU).
 #pragma once
+#include <cstddef>
 #include <memory>
 #include <thread>
 #include <atomic>
@@ -24,10 +25,14 @@
 
 struct sq_unimem_dev { uint32_t unitig, ustart; uint16_t qpos, len; uint8_t fw, pad[3]; };  // 16 B
 
-struct sq_chain_dev {   // 40 B
-  double score; uint32_t tid; int32_t pos; int32_t last_end; uint32_t first; uint16_t n_mems, read_len; uint8_t fw, pad[3]; uint32_t pad2;
+struct sq_chain_dev {   // 40 B.  Bytes 16..31 are everything the scorer reads of a chain (its transcript is in the candidate): ONE 16-byte load
+  double score; uint32_t tid; int32_t last_end;
+  int32_t pos; uint32_t first; uint32_t pad2; uint16_t n_mems; uint8_t fw, pad[3];   // pad[0]: MEMs given by the bit mask pad2 (else linked through mnext)
+  uint16_t read_len; uint32_t spare;
 };
-struct sq_cand_dev {    // 48 B
+static_assert(sizeof(sq_chain_dev) == 40 && offsetof(sq_chain_dev, pos) == 16 && offsetof(sq_chain_dev, n_mems) == 28 && offsetof(sq_chain_dev, pad) == 31,
+              "sq_chain_dev layout");
+struct alignas(16) sq_cand_dev {    // 48 B
   double cov;
   uint32_t tid;
   uint32_t lc, rc;
@@ -37,15 +42,16 @@ struct sq_cand_dev {    // 48 B
   uint32_t pad2;
 };
 
-struct sq_dp_item {     // one banded-DP region queued by the fast scorer
+struct sq_dp_item {     // one banded-DP region queued by the fast scorer (40 B)
   // region scores below `budget` cannot yield a valid alignment
+  int64_t tstart;
   uint32_t cand;
   uint8_t end, mode, rc, pad;
   int32_t qstart, qdir, n;
-  int64_t tstart;
   int32_t tdir, tl;
   int32_t budget;
 };
+static_assert(sizeof(sq_dp_item) == 40, "sq_dp_item layout");
 
 struct sq_map_params {
   int32_t ma, mp, go, ge, bw;

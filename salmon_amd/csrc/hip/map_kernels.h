@@ -14,6 +14,11 @@
 
 namespace sqk {
 
+typedef uint32_t sq_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t sq_u64x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(8))) sq_u32x4_a8 { sq_u32x4 v; };   // 16 bytes at an 8-byte aligned address: still one global_load_dwordx4
+struct __attribute__((aligned(8))) sq_u64x2_a8 { sq_u64x2 v; };
+
 struct ReadView { const uint64_t* w; const uint64_t* nm; int L; };
 
 // Same-address atomics serialise at ~4-12 ns each on gfx950 (one per THREAD turned a 1M-thread kernel
@@ -41,6 +46,14 @@ __device__ inline uint32_t norm_base(const ReadView& r, bool fw, int x) {  // st
 }
 __device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnmask, const uint16_t* rlen, uint32_t e) {
   ReadView r; r.w = rpack + (size_t)e * SQ_READ_WORDS; r.nm = rnmask + (size_t)e * SQ_NMASK_WORDS; r.L = rlen[e]; return r;
+}
+
+// [r2] One same-address atomic per WAVE is still too many when a launch has 10^5 waves: L2 retires them one per 4-12 ns, and 95 000
+// waves x ~5 atomics were the whole 3.1 ms of k_score while every counter said "waiting for memory".  Per-launch counters and queue
+// cursors are therefore summed in LDS and leave with one atomic per BLOCK.  All 64 lanes call this; `s_slot` is in LDS.
+__device__ inline void block_stat_add(unsigned long long* s_slot, unsigned long long v) {
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_down(v, s, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(s_slot, v);
 }
 
 // unique slot for every calling lane with ONE atomic per wave (works in divergent code: the ballot
@@ -483,6 +496,7 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
 // (Tried in round 2: copying the compact form of a fragment's chains into thread-private LDS columns first — three loads per chain —
 // and enumerating from there: 1.95 -> 2.46 ms per 10^6 pairs; the 40 KB of LDS per 128 threads cost more occupancy than the loads saved.)
 #define JP 8
+#define JB 8   // chains per end whose transcripts are matched in registers
 __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off,
     const sq_chain_dev* __restrict__ chains,
     const uint32_t* __restrict__ n_chains,
@@ -500,8 +514,32 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
   for (int i = 0; i < JP; ++i) { pc[i] = 0.0; pt[i] = 0; pa[i] = 0; pb[i] = 0; pf[i] = 0; }
   if (act && paired) {
     const uint32_t e0 = 2 * f, e1 = 2 * f + 1;
-    lbase = (uint32_t)chain_off[e0]; rbase = (uint32_t)chain_off[e1]; nl = n_chains[e0]; nr = n_chains[e1];
+    { const sq_u64x2 co = *reinterpret_cast<const sq_u64x2*>(chain_off + e0); lbase = (uint32_t)co.x; rbase = (uint32_t)co.y;   // e0 is even: one 16-byte load
+      const uint2 nc2 = *reinterpret_cast<const uint2*>(n_chains + e0); nl = nc2.x; nr = nc2.y; }
     lc = chains + lbase; rc = chains + rbase;
+    if (nl <= JB && nr <= JB) {
+      // [r2] the usual fragment (at most JB chains per end): the transcripts of all its chains are requested at once and matched in
+      // registers, instead of a merge whose every step waits for the load of the step before; the chains are sorted by transcript on
+      // both ends, so visiting the matches in (a, b) order is the order of the merge below
+      uint32_t lt[JB], rt[JB];
+#pragma unroll
+      for (int a = 0; a < JB; ++a) { lt[a] = (uint32_t)a < nl ? lc[a].tid : 0xFFFFFFFFu; rt[a] = (uint32_t)a < nr ? rc[a].tid : 0xFFFFFFFEu; }
+      unsigned long long M = 0;
+#pragma unroll
+      for (int a = 0; a < JB; ++a)
+#pragma unroll
+        for (int b = 0; b < JB; ++b) if (lt[a] == rt[b]) M |= 1ULL << (a * JB + b);
+      while (M) {
+        const int bit = __ffsll((long long)M) - 1; M &= M - 1;
+        const uint32_t a = (uint32_t)bit / JB, b = (uint32_t)bit % JB;
+        int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue;
+        const double cov = lc[a].score + rc[b].score; if (cov > best) best = cov;
+        const uint32_t ti = lc[a].tid;
+#pragma unroll
+        for (int q = 0; q < JP; ++q) if ((uint32_t)q == np) { pc[q] = cov; pt[q] = ti; pa[q] = a; pb[q] = b; pf[q] = (uint32_t)fl; }
+        ++np;
+      }
+    } else
     for (uint32_t i = 0, j = 0; i < nl && j < nr;) {
       const uint32_t ti = lc[i].tid, tj = rc[j].tid;
       if (ti < tj) { ++i; continue; }
@@ -535,10 +573,15 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
   // block allocation: exclusive prefix of cnt over the wave + one atomic
   uint32_t incl = cnt;
   for (int sft = 1; sft < 64; sft <<= 1) { uint32_t o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
-  const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
-  unsigned long long base = 0;
-  if (lane == 0 && wave_total) base = atomicAdd(cursor, (unsigned long long)wave_total);
-  base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+  // one cursor atomic per block (not per wave: see block_stat_add): wave totals meet in LDS
+  __shared__ uint32_t s_wt[16]; __shared__ unsigned long long s_base;
+  const int wv = (int)(threadIdx.x >> 6), nwv = (int)((blockDim.x + 63) >> 6);
+  if (lane == 63) s_wt[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < nwv; ++i) tot += s_wt[i]; s_base = tot ? atomicAdd(cursor, tot) : 0ULL; }
+  __syncthreads();
+  unsigned long long base = s_base;
+  for (int i = 0; i < wv; ++i) base += s_wt[i];
   const uint64_t start = base + (incl - cnt);
   if (!act) return;
   n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0);
@@ -740,26 +783,41 @@ __global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uin
 }
 
 
-// mismatch count of q[0..n) vs t[0..n).  A mismatch count does not depend on the order in which the
-// aligned pairs are visited, so reversed (leftward) regions are compared as forward windows; the
-// strand-normalised read window comes from one revcomp of the packed read.  32 bases per step.
-__device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir, const uint64_t* refseq, int64_t tstart, int tdir, int n) {
-  const int qlo = qdir > 0 ? qstart : qstart - n + 1;
-  const int64_t tlo = tdir > 0 ? tstart : tstart - n + 1;
+// ---- scoring a chain: written so that the lanes of a wave walk the same instruction stream ---------------------------------------
+// [r2] The SQ counters of the first version (tools/profile_sq.sh) showed k_score parked in s_waitcnt 91 % of its wave cycles with 23 %
+// of the lanes active: head, gap and tail regions were three inlined copies of the comparison, forward and reverse-complement windows
+// two more, every second pool word sat behind its own branch, and a second walk queued the DP regions — each a separately serialised
+// round of dependent loads.  Here every step of the walk produces at most ONE region descriptor per lane and a single copy of the
+// comparison evaluates it; pool reads always load both words; the strand is a select; the next MEM is in flight while the current
+// region is compared; regions that need the DP are remembered (two per end) and queued after the walk with their budgets.
+
+// `n` (<= 32) bases from nt position p of a packed pool: both words come with one 16-byte load (no data-dependent branch around a load)
+__device__ inline uint64_t fetch_bases_u(const uint64_t* __restrict__ pool, uint64_t p, uint32_t n) {
+  const uint64_t w = p >> 5; const uint32_t sh = (uint32_t)(p & 31) * 2;
+  const sq_u64x2 ab = reinterpret_cast<const sq_u64x2_a8*>(pool + w)->v;   // words w and w + 1 (every pool is padded by a word)
+  const uint64_t lo = (ab.x >> sh) | (sh ? (ab.y << (64 - sh)) : 0ULL);   // bits of the second word beyond 2n are masked off: same value as sq_fetch_bases
+  return lo & sq_kmask(n);
+}
+__device__ inline uint64_t fetch_bits_u(const uint64_t* __restrict__ m, uint32_t p, uint32_t n) {   // n <= 32 one-bit flags from p
+  const uint32_t w = p >> 6, sh = p & 63;
+  const sq_u64x2 ab = reinterpret_cast<const sq_u64x2_a8*>(m + w)->v;
+  const uint64_t lo = (ab.x >> sh) | (sh ? (ab.y << (64 - sh)) : 0ULL);
+  return lo & ((1ULL << n) - 1);
+}
+// mismatch count of the strand-normalised read window R[qlo, qlo+n) against the reference text [tlo, tlo+n).  A mismatch count does
+// not depend on the order in which the aligned pairs are visited, so leftward regions are compared as forward windows.
+__device__ inline int count_mm_u(const ReadView& r, bool fw, int qlo, const uint64_t* __restrict__ refseq, int64_t tlo, int n) {
   int mm = 0;
   for (int j = 0; j < n; j += 32) {
     const int c = (n - j) < 32 ? (n - j) : 32;
-    uint64_t q, nn;
-    if (fw) { q = sq_fetch_bases(r.w, (uint64_t)(qlo + j), (uint32_t)c); nn = fetch_bits(r.nm, (uint32_t)(qlo + j), (uint32_t)c); }
-    else {
-      const int p = r.L - (qlo + j + c);   // read window whose reverse complement is R[qlo+j .. qlo+j+c)
-      q = sq_revcomp(sq_fetch_bases(r.w, (uint64_t)p, (uint32_t)c), (uint32_t)c);
-      nn = __brevll(fetch_bits(r.nm, (uint32_t)p, (uint32_t)c)) >> (64 - c);
-    }
-    const uint64_t t = sq_fetch_bases(refseq, (uint64_t)(tlo + j), (uint32_t)c);
-    const uint64_t x = q ^ t; uint64_t d = (x | (x >> 1)) & 0x5555555555555555ULL;
-    // spread the N flags to even bit positions and OR them in
-    uint64_t ns = nn;
+    const int p = fw ? (qlo + j) : (r.L - (qlo + j + c));   // rc: the read window whose reverse complement is R[qlo+j .. qlo+j+c)
+    const uint64_t raw = fetch_bases_u(r.w, (uint64_t)p, (uint32_t)c);
+    const uint64_t nb = fetch_bits_u(r.nm, (uint32_t)p, (uint32_t)c);
+    const uint64_t t = fetch_bases_u(refseq, (uint64_t)(tlo + j), (uint32_t)c);
+    const uint64_t q = fw ? raw : sq_revcomp(raw, (uint32_t)c);
+    const uint64_t nn = fw ? nb : (__brevll(nb) >> (64 - c));
+    const uint64_t x = q ^ t; const uint64_t d = (x | (x >> 1)) & 0x5555555555555555ULL;
+    uint64_t ns = nn;   // spread the N flags to even bit positions and OR them in
     ns = (ns | (ns << 16)) & 0x0000FFFF0000FFFFULL;
     ns = (ns | (ns << 8)) & 0x00FF00FF00FF00FFULL;
     ns = (ns | (ns << 4)) & 0x0F0F0F0F0F0F0F0FULL;
@@ -770,106 +828,117 @@ __device__ inline int count_mm(const ReadView& r, bool fw, int qstart, int qdir,
   return mm;
 }
 
-// region score; returns true if resolved immediately (value in *sc), false if it needs the DP.
-// In `collect` mode nothing is queued: the caller only accumulates the upper bound ma*n of the
-// region; in queue mode the region is appended to the DP queue with its pass/fail budget.
-__device__ inline bool region_fast(const sq_map_params& P, const ScoreCtx& S, const ReadView& r, bool fw, uint32_t cand, uint8_t end,
-    int mode,
-                                   int qstart, int qdir, int n, int64_t tstart, int tdir, int tl, int32_t* sc, bool queue, int32_t budget,
-                                       uint32_t* ndp) {
-  if (n == 0 && mode == 1) { *sc = 0; return true; }
-  if (n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n))) {
-    int mm = count_mm(r, fw, qstart, qdir, S.refseq, tstart, tdir, n);
-    int lim = (mode == 0) ? (2 * (P.go + P.ge) + P.ma) : (P.go + P.ge);
-    if (mm * (P.ma - P.mp) <= lim) { *sc = P.ma * (n - mm) + P.mp * mm; return true; }
-  }
-  // trivial DP outcomes that need no matrix (mirrors dp_align's early returns)
-  // num_dp_alignments counts every region the fast path cannot decide (pass 0 sees them all once)
-  if (n == 0) { *sc = (tl == 0) ? 0 : (tl <= P.bw ? -(P.go + P.ge * tl) : SQ_NEG_INF); if (!queue) ++*ndp; return true; }
-  if (tl == 0) { *sc = (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF; if (!queue) ++*ndp; return true; }
-  if (!queue) ++*ndp;
-  if (queue) {
-    uint32_t slot = wave_alloc(&S.counters[8]);   // (queues per DP height were tried: k_dp gained 0.15 ms, the extra same-address atomics cost k_score 1 ms)
-    if (slot < S.dpq_cap) {
-      sq_dp_item it;
-      it.cand = cand;
-      it.end = end;
-      it.mode = (uint8_t)mode;
-      it.rc = fw ? 0 : 1;
-      it.pad = 0;
-      it.qstart = qstart;
-      it.qdir = qdir;
-      it.n = n;
-      it.tstart = tstart;
-      it.tdir = tdir;
-      it.tl = tl;
-      it.budget = budget;
-      S.dpq[slot] = it;
-    }
-  }
-  return false;
+struct ChainHead { uint32_t tid, first, pad2; int32_t pos; uint16_t n_mems; uint8_t fw, by_mask; };   // what scoring reads of a chain
+// A record or window is requested with ONE load instruction: a second load that touches a cache line whose fill is still in flight
+// parks the CU's in-order L1 until the fill arrives (TCP_PENDING_STALL_CYCLES was 72 % of k_score's cycles with field-by-field loads).
+__device__ inline ChainHead chain_head(const sq_chain_dev* __restrict__ ch, uint32_t tid) {
+  const sq_u32x4 v = reinterpret_cast<const sq_u32x4_a8*>(reinterpret_cast<const char*>(ch) + 16)->v;   // pos, first, pad2, n_mems | fw << 16 | pad[0] << 24
+  ChainHead h; h.tid = tid; h.pos = (int32_t)v.x; h.first = v.y; h.pad2 = v.z; h.n_mems = (uint16_t)(v.w & 0xFFFFu); h.fw = (uint8_t)((v.w >> 16) & 0xFFu);
+  h.by_mask = (uint8_t)(v.w >> 24);
+  return h;
+}
+#define SC_QCAP 192   // DP regions a block stages in LDS (a block of 256 candidates queues ~60); the overflow goes straight to the global queue
+struct DpStage { sq_dp_item* q; uint32_t* n; };   // LDS
+__device__ inline void dp_enqueue(const ScoreCtx& S, const DpStage& Q, uint32_t cand, uint8_t end, bool fw, int mode, int qstart, int dir, int n,
+    int64_t tstart, int tl, int32_t budget) {
+  sq_dp_item it;
+  it.cand = cand; it.end = end; it.mode = (uint8_t)mode; it.rc = fw ? 0 : 1; it.pad = 0;
+  it.qstart = qstart; it.qdir = dir; it.n = n; it.tstart = tstart; it.tdir = dir; it.tl = tl; it.budget = budget;
+  const uint32_t slot = wave_alloc(Q.n);   // LDS cursor
+  if (slot < SC_QCAP) { Q.q[slot] = it; return; }
+  const uint32_t g = wave_alloc(&S.counters[8]);   // (queues per DP height were tried: k_dp gained 0.15 ms, the extra same-address atomics cost k_score 1 ms)
+  if (g < S.dpq_cap) S.dpq[g] = it;
 }
 
-// Score one chain against its read end.  Pass 0 resolves every region the mismatch-count fast path
-// can decide and sums an upper bound (ma * n) for the rest; if even that bound misses
-// minScoreFraction the end is invalid and no DP is queued.  Otherwise pass 1 queues the DP regions,
-// each with the lowest region score that could still make the end valid (k_dp stops early below it).
-__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const sq_chain_dev& ch, uint64_t mem_base,
-    uint32_t end_id, uint32_t cand, uint8_t end,
-    uint32_t* ndp, uint8_t* fail) {
-  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
-  const int L = r.L; const bool fw = ch.fw != 0;
-  const uint32_t tid = ch.tid; const int Tlen = (int)S.ref_len[tid]; const int64_t g = (int64_t)S.ref_accum[tid];
+// Score one chain against its read end (SPEC §a4).  The walk resolves every region the mismatch-count fast path can decide and sums
+// an upper bound (ma * n) for the rest; if even that bound misses minScoreFraction the end is invalid and no DP is queued.
+// Otherwise the remembered regions are queued, each with the lowest region score that could still make the end valid (k_dp stops
+// early below it).  num_dp_alignments counts every region the fast path cannot decide, once.
+#define SC_PEND 2
+__device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const DpStage& Q, const ChainHead& ch, int Tlen, int64_t g, uint64_t mem_base,
+    uint32_t end_id, uint32_t cand, uint8_t end, uint32_t* ndp, uint8_t* fail) {
+  const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  const int L = r.L; const bool fw = ch.fw != 0; const uint32_t nm = ch.n_mems;
   const int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * L));
-  int64_t score = 0; int64_t ub_dp = 0;
+  const bool by_mask = ch.by_mask != 0;
+  int64_t score = 0, ub = 0;
+  // regions waiting for the DP: qstart | n << 9 | mode << 18 | leftward << 19; tstart - g; tl
+  uint32_t pq[SC_PEND]; int32_t pt[SC_PEND], pl[SC_PEND]; uint32_t npend = 0;
+#pragma unroll
+  for (int i = 0; i < SC_PEND; ++i) { pq[i] = 0; pt[i] = 0; pl[i] = 0; }
   for (int pass = 0; pass < 2; ++pass) {
-    const bool queue = pass == 1;
-    const int64_t fast_total = score; const int64_t ub_total = ub_dp;
-    if (queue) { score = 0; }
-    // n_mems == 0: recovered mate (SPEC §a5), one extension alignment from its start
-    int prevQ = 0, prevR = (ch.n_mems == 0) ? ch.pos : 0;
-    bool first = true;
-    const bool by_mask = ch.pad[0] != 0;
+    const bool requeue = pass == 1;                           // only when an end has more than SC_PEND DP regions (rare)
+    const int64_t fast_total = score, ub_total = ub;
+    int64_t sc_fast = 0; ub = 0;
+    int prevQ = 0, prevR = (nm == 0) ? ch.pos : 0;            // n_mems == 0: recovered mate (SPEC §a5), one extension alignment from its start
     uint32_t mbits = ch.pad2;
     uint32_t mi = by_mask ? ch.first + (uint32_t)(__ffs((int)mbits) - 1) : ch.first;
-    int64_t sc_fast = 0;
-    int64_t ub = 0;
-    auto region = [&](int mode, int qstart, int qdir, int n, int64_t tstart, int tdir, int tl) {
-      int32_t sc;
-      // budget for this region: minacc - (everything else at its best)
-      int32_t budget = queue ? (int32_t)max((int64_t)SQ_NEG_INF, (int64_t)minacc - (fast_total + ub_total - (int64_t)P.ma * n)) : 0;
-      if (region_fast(P, S, r, fw, cand, end, mode, qstart, qdir, n, tstart, tdir, tl, &sc, queue, budget, ndp)) sc_fast += sc;
-      else ub += (int64_t)P.ma * n;
-    };
-    for (uint32_t it = 0; it < ch.n_mems; ++it) {
-      MemD m = mem_decode(S.mkey[mem_base + mi], S.mval[mem_base + mi], S.ref_accum);
-      int qs = m.q, rs = m.rpos, ln = m.len;
-      bool use = true;
-      if (first) {
-        if (qs > 0) { int ws = max(0, rs - qs - SQ_REF_EXTEND); int tl = max(0, rs - ws); region(1, qs - 1, -1, qs, g + rs - 1, -1, tl); }
-        first = false;
-      } else {
-        int ov = max(0, max(prevQ - qs, prevR - rs));
-        if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) use = false; }
-        if (use) { int gq = qs - prevQ, gr = rs - prevR; if (gq > 0 || gr > 0) region(0, prevQ, 1, gq, g + prevR, 1, gr); }
+    uint64_t key = 0, val = 0;
+    if (nm) { key = S.mkey[mem_base + mi]; val = S.mval[mem_base + mi]; }
+    for (uint32_t s = 0; s <= nm; ++s) {
+      bool have = false; int mode = 1, qstart = 0, dir = 1, n = 0, tl = 0; int32_t trel = 0;
+      if (s < nm) {
+        int qs = (int32_t)((val >> 10) & 1023), ln = (int32_t)(val & 1023);
+        int rs = (int32_t)((int64_t)(key & ((1ULL << 40) - 1)) - g);        // the chain's transcript is known: no ref_accum look-up per MEM
+        // the next MEM is requested before this step's region is compared
+        if (s + 1 < nm) {
+          if (by_mask) { mbits &= mbits - 1; mi = ch.first + (uint32_t)(__ffs((int)mbits) - 1); } else mi = S.mnext[mem_base + mi];
+          key = S.mkey[mem_base + mi]; val = S.mval[mem_base + mi];
+        }
+        bool use = true;
+        if (s == 0) {
+          if (qs > 0) { const int ws = max(0, rs - qs - SQ_REF_EXTEND); have = true; mode = 1; qstart = qs - 1; dir = -1; n = qs; trel = rs - 1; tl = max(0, rs - ws); }
+        } else {
+          const int ov = max(0, max(prevQ - qs, prevR - rs));
+          if (ov > 0) { qs += ov; rs += ov; ln -= ov; if (ln <= 0) use = false; }
+          if (use) { const int gq = qs - prevQ, gr = rs - prevR; if (gq > 0 || gr > 0) { have = true; mode = 0; qstart = prevQ; dir = 1; n = gq; trel = prevR; tl = gr; } }
+        }
+        if (use) { sc_fast += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
+      } else if (prevQ < L) {
+        const int tail = L - prevQ; const int we = min(Tlen, prevR + tail + SQ_REF_EXTEND);
+        have = true; mode = 1; qstart = prevQ; dir = 1; n = tail; trel = prevR; tl = max(0, we - prevR);
       }
-      if (use) { sc_fast += (int64_t)P.ma * ln; prevQ = qs + ln; prevR = rs + ln; }
-      if (by_mask) { mbits &= mbits - 1; mi = ch.first + (uint32_t)(__ffs((int)mbits) - 1); } else mi = S.mnext[mem_base + mi];
-    }
-    if (prevQ < L) {
-      int tail = L - prevQ;
-      int we = min(Tlen, prevR + tail + SQ_REF_EXTEND);
-      int tl = max(0, we - prevR);
-      region(1, prevQ, 1, tail, g + prevR, 1, tl);
-    }
-    score = sc_fast; ub_dp = ub;
-    if (!queue) {
-      if (ub == 0) break;                                   // nothing needs the DP
-      // cannot reach minScoreFraction: invalid without any DP
-      if (score + ub < (int64_t)minacc || score < -(1 << 29)) {
-        *fail = 1;
-        break;
+      // the one copy of the comparison: lanes without a comparable region run it with n = 0
+      const bool cmp = have && n > 0 && ((mode == 0 && tl == n) || (mode == 1 && tl >= n));
+      const int qlo = dir > 0 ? qstart : qstart - n + 1;
+      const int64_t tlo = g + (dir > 0 ? (int64_t)trel : (int64_t)trel - n + 1);
+      const int mm = count_mm_u(r, fw, qlo, S.refseq, tlo, cmp ? n : 0);
+      if (have) {
+        const int lim = (mode == 0) ? (2 * (P.go + P.ge) + P.ma) : (P.go + P.ge);
+        if (n == 0 && mode == 1) { /* nothing to align: 0 */ }
+        else if (cmp && mm * (P.ma - P.mp) <= lim) sc_fast += P.ma * (n - mm) + P.mp * mm;
+        else {
+          if (!requeue) ++*ndp;
+          // trivial DP outcomes that need no matrix (mirrors dp_align's early returns)
+          if (n == 0) sc_fast += (tl == 0) ? 0 : (tl <= P.bw ? -(P.go + P.ge * tl) : SQ_NEG_INF);
+          else if (tl == 0) sc_fast += (n <= P.bw) ? -(P.go + P.ge * n) : SQ_NEG_INF;
+          else {
+            ub += (int64_t)P.ma * n;
+            if (requeue) {
+              const int32_t budget = (int32_t)max((int64_t)SQ_NEG_INF, (int64_t)minacc - (fast_total + ub_total - (int64_t)P.ma * n));
+              dp_enqueue(S, Q, cand, end, fw, mode, qstart, dir, n, g + trel, tl, budget);
+            } else {
+              const uint32_t q = (uint32_t)qstart | ((uint32_t)n << 9) | ((uint32_t)mode << 18) | (dir < 0 ? (1u << 19) : 0u);
+#pragma unroll
+              for (int i = 0; i < SC_PEND; ++i) if ((uint32_t)i == npend) { pq[i] = q; pt[i] = trel; pl[i] = tl; }
+              ++npend;
+            }
+          }
+        }
       }
+    }
+    score = sc_fast;
+    if (requeue) break;
+    if (ub == 0) break;                                     // nothing needs the DP
+    if (score + ub < (int64_t)minacc || score < -(1 << 29)) { *fail = 1; break; }   // cannot reach minScoreFraction: invalid without any DP
+    if (npend <= SC_PEND) {
+#pragma unroll
+      for (int i = 0; i < SC_PEND; ++i) if ((uint32_t)i < npend) {
+        const int n = (int)((pq[i] >> 9) & 511), mode = (int)((pq[i] >> 18) & 1), dir = (pq[i] >> 19) & 1 ? -1 : 1;
+        const int32_t budget = (int32_t)max((int64_t)SQ_NEG_INF, (int64_t)minacc - (score + ub - (int64_t)P.ma * n));
+        dp_enqueue(S, Q, cand, end, fw, mode, (int)(pq[i] & 511), dir, n, g + pt[i], pl[i], budget);
+      }
+      break;
     }
   }
   if (score < -(1 << 30)) score = -(1 << 30);
@@ -908,13 +977,35 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5))) k_score(sq_map_params P,
                             unsigned long long* __restrict__ stats) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ndp = 0;
+  // the block's 256 candidate records (12 KB, contiguous) come in through LDS with coalesced 16-byte loads, every cache line requested
+  // once; each thread then takes its own 48 bytes.  They leave the same way.
+  __shared__ sq_u32x4 s_c[256 * 3];
+  __shared__ sq_dp_item s_q[SC_QCAP]; __shared__ uint32_t s_qn, s_qbase; __shared__ unsigned long long s_ndp;
+  static_assert(sizeof(sq_cand_dev) == 48, "sq_cand_dev is moved as three 16-byte pieces");
+  static_assert(sizeof(sq_dp_item) == 40, "sq_dp_item is copied out as five 8-byte words");
+  if (threadIdx.x == 0) { s_qn = 0; s_ndp = 0; }
+  const DpStage Q{s_q, &s_qn};
+  const uint64_t blk0 = (uint64_t)blockIdx.x * blockDim.x;                       // first candidate of the block
+  const uint64_t npiece = (ncand - blk0 < blockDim.x ? ncand - blk0 : (uint64_t)blockDim.x) * 3;
+  sq_u32x4* gsrc = reinterpret_cast<sq_u32x4*>(cands + blk0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const uint32_t i = (uint32_t)k * blockDim.x + threadIdx.x; if (i < npiece) s_c[i] = gsrc[i]; }
+  __syncthreads();
+  sq_cand_dev c;
+  { sq_u32x4* cp = reinterpret_cast<sq_u32x4*>(&c); cp[0] = s_c[threadIdx.x * 3]; cp[1] = s_c[threadIdx.x * 3 + 1]; cp[2] = s_c[threadIdx.x * 3 + 2]; }
   if (ci < ncand) {
-    sq_cand_dev c = cands[ci];
     const uint32_t f = cand_frag[ci];
     const bool orphan = c.mate_status != SQ_MS_PAIRED_END_PAIRED;
     const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
-    bool lfw = hasL ? chains[c.lc].fw != 0 : false, rfw = hasR ? chains[c.rc].fw != 0 : false;
-    const int32_t lpos_ = hasL ? chains[c.lc].pos : 0, rpos_ = hasR ? chains[c.rc].pos : 0;
+    // both chains and their transcripts' bounds are requested up front: the right end's loads are in flight while the left end is scored
+    ChainHead hl{}, hr{};
+    if (hasL) hl = chain_head(chains + c.lc, c.tid);
+    if (hasR) hr = chain_head(chains + c.rc, c.tid);
+    int Tl = 0, Tr = 0; int64_t gl = 0, gr = 0;
+    if (hasL) { Tl = (int)S.ref_len[hl.tid]; gl = (int64_t)S.ref_accum[hl.tid]; }
+    if (hasR) { Tr = (int)S.ref_len[hr.tid]; gr = (int64_t)S.ref_accum[hr.tid]; }
+    const bool lfw = hasL ? hl.fw != 0 : false, rfw = hasR ? hr.fw != 0 : false;
+    const int32_t lpos_ = hasL ? hl.pos : 0, rpos_ = hasR ? hr.pos : 0;
     bool isc = paired ? joint_compat(P, orphan, hasL, lfw, rfw) : compat_se(P, lfw, SQ_MS_SINGLE_END);
     c.compat = isc;
     // the joining coverage has done its work (k_join2): its 8 bytes now carry the chains' implied positions and pad[1] their strands,
@@ -925,14 +1016,26 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5))) k_score(sq_map_params P,
     else {
       uint32_t e0 = paired ? 2 * f : f, e1 = 2 * f + 1;
       c.lfail = c.rfail = 0;
-      if (hasL) c.lscore = score_chain(P, S, chains[c.lc], mem_off[e0], e0, (uint32_t)ci, 0, &ndp, &c.lfail);
+      uint64_t mo0, mo1 = 0;
+      if (paired) { const sq_u64x2 mo = *reinterpret_cast<const sq_u64x2*>(mem_off + e0); mo0 = mo.x; mo1 = mo.y; } else mo0 = mem_off[e0];
+      if (hasL) c.lscore = score_chain(P, S, Q, hl, Tl, gl, mo0, e0, (uint32_t)ci, 0, &ndp, &c.lfail);
       // an end that already failed makes the pair invalid: the mate's DP regions are not needed
       // (SPEC §a4: the pair is dropped either way; only num_dp_alignments would differ, so the mate is still scored)
-      if (hasR) c.rscore = score_chain(P, S, chains[c.rc], mem_off[e1], e1, (uint32_t)ci, 1, &ndp, &c.rfail);
+      if (hasR) c.rscore = score_chain(P, S, Q, hr, Tr, gr, mo1, e1, (uint32_t)ci, 1, &ndp, &c.rfail);
     }
-    cands[ci] = c;
   }
-  wave_stat_add(&stats[ST_DP], ndp);
+  { const sq_u32x4* cp = reinterpret_cast<const sq_u32x4*>(&c); s_c[threadIdx.x * 3] = cp[0]; s_c[threadIdx.x * 3 + 1] = cp[1]; s_c[threadIdx.x * 3 + 2] = cp[2]; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const uint32_t i = (uint32_t)k * blockDim.x + threadIdx.x; if (i < npiece) gsrc[i] = s_c[i]; }
+  // the block's DP regions take one range of the global queue (one atomic), copied out coalesced; the counter as well
+  block_stat_add(&s_ndp, ndp);
+  const uint32_t nq = s_qn < SC_QCAP ? s_qn : SC_QCAP;   // stable: every enqueue happened before the barrier above
+  if (threadIdx.x == 0) s_qbase = nq ? atomicAdd(&S.counters[8], nq) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_ndp) atomicAdd(&stats[ST_DP], s_ndp);
+  { const uint64_t* src = reinterpret_cast<const uint64_t*>(s_q); uint64_t* dst = reinterpret_cast<uint64_t*>(S.dpq + s_qbase);
+    for (uint32_t i = threadIdx.x; i < nq * 5; i += blockDim.x) if (s_qbase + i / 5 < S.dpq_cap) dst[i] = src[i]; }
 }
 
 // banded Gotoh in registers: band index b = j - i + W, W = SQ_MAX_BAND (runtime bw <= W). SPEC §a4.
@@ -1173,12 +1276,22 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
     ffilt = 1; fdecoy = onlyDecoy ? 1 : 0;
   }
   if (act) { n_aln[f] = na; map_type[f] = mt; }
-  wave_stat_add(&stats[ST_FRAGFILT], ffilt); wave_stat_add(&stats[ST_DECOY], fdecoy);
-  wave_stat_add(&stats[ST_MAPFILT], nfilt);
-  wave_stat_add(&stats[ST_ALNS], na);
-  wave_stat_add(&stats[ST_MAPPED], na ? 1 : 0);
-  wave_stat_add(&stats[ST_JOINT], nc ? 1 : 0);
-  wave_stat_add(&stats[ST_DOVETAIL], (act && !nc && (frag_flags[f] & 1)) ? 1 : 0);
+  // seven counters: summed per block in LDS, one atomic per counter and block (see block_stat_add)
+  __shared__ unsigned long long s_st[7];
+  if (threadIdx.x < 7) s_st[threadIdx.x] = 0;
+  __syncthreads();
+  block_stat_add(&s_st[0], ffilt); block_stat_add(&s_st[1], fdecoy);
+  block_stat_add(&s_st[2], nfilt);
+  block_stat_add(&s_st[3], na);
+  block_stat_add(&s_st[4], na ? 1 : 0);
+  block_stat_add(&s_st[5], nc ? 1 : 0);
+  block_stat_add(&s_st[6], (act && !nc && (frag_flags[f] & 1)) ? 1 : 0);
+  __syncthreads();
+  if (threadIdx.x < 7 && s_st[threadIdx.x]) {
+    const int which = threadIdx.x == 0 ? ST_FRAGFILT : threadIdx.x == 1 ? ST_DECOY : threadIdx.x == 2 ? ST_MAPFILT : threadIdx.x == 3 ? ST_ALNS
+                      : threadIdx.x == 4 ? ST_MAPPED : threadIdx.x == 5 ? ST_JOINT : ST_DOVETAIL;
+    atomicAdd(&stats[which], s_st[threadIdx.x]);
+  }
 }
 
 __global__ void k_compact_alns(uint32_t nfrag, const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ aln_off,
@@ -1195,7 +1308,12 @@ __global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   bool any = false; uint32_t nch = 0;
   if (f < nfrag) { nch = paired ? (n_chains[2 * f] + n_chains[2 * f + 1]) : n_chains[f]; any = nch != 0; }
-  wave_stat_add(&stats[ST_KMER], any ? 1 : 0); wave_stat_add(&stats[ST_CHAINS], nch);
+  __shared__ unsigned long long s_st[2];
+  if (threadIdx.x < 2) s_st[threadIdx.x] = 0;
+  __syncthreads();
+  block_stat_add(&s_st[0], any ? 1 : 0); block_stat_add(&s_st[1], nch);
+  __syncthreads();
+  if (threadIdx.x < 2 && s_st[threadIdx.x]) atomicAdd(&stats[threadIdx.x == 0 ? ST_KMER : ST_CHAINS], s_st[threadIdx.x]);
 }
 
 }  // namespace sqk
