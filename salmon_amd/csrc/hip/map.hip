@@ -114,12 +114,14 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
   c->owner = owner;
   c->last_src = c;
   fill_params(c);
-  { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 32 of 256; SQ_EQ_CUS=0 disables) and the
-    // mapping stream keeps off them.  Measured on MI355X (configs[1]): mapping kernels lose ~3% on 224 CUs, while
-    // the eq chain no longer waits behind their workgroups (mapping stalled ~30 ms per 10 M pairs on it).
+  { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 64 of 256; SQ_EQ_CUS=0 disables) and the mapping stream keeps
+    // off them, so the eq chain never waits behind mapping workgroups.  The mask takes whole XCDs (the top CU indices; 32 CUs each):
+    // workgroups are dealt round-robin to the XCDs a stream may use, so a partly masked XCD gets a full share of the blocks with a
+    // fraction of the CUs and sets the pace (measured [r2], 4·10^6-pair batches: 32 / 40 / 48 / 64 CUs -> eq chain 44 / 44 / 44 / 28 ms).
+    // With the mapping kernels at ~37 ms per batch on 192 CUs, two XCDs keep the eq chain off the critical path.
     hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int ncu = prop.multiProcessorCount;
-    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 8 : 0);
+    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
     if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
     c->eq_cus = eq_cus;
     if (eq_cus > 0) {
@@ -404,14 +406,14 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
   // size classes of the ends (mem_kernels.h); their counts come back with the MEM total in the same read-back
-  if (c->mlist.ensure((size_t)3 * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
-  uint32_t* list_s = c->mlist.p; uint32_t* list_m = c->mlist.p + nrec; uint32_t* list_l = c->mlist.p + 2 * (size_t)nrec;
-  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 4, 0, 4 * sizeof(uint32_t), st));
-  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, list_s, list_m, list_l, c->mlbase.p, c->n_chains.p, c->counters.p + 4);
-  uint64_t total_mems = 0; uint32_t hcls[4] = {0, 0, 0, 0};
+  if (c->mlist.ensure((size_t)4 * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
+  uint32_t* list_t = c->mlist.p; uint32_t* list_s = c->mlist.p + nrec; uint32_t* list_m = c->mlist.p + 2 * (size_t)nrec; uint32_t* list_l = c->mlist.p + 3 * (size_t)nrec;
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 10, 0, 5 * sizeof(uint32_t), st));
+  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, list_t, list_s, list_m, list_l, c->mlbase.p, c->n_chains.p, c->counters.p + 10);
+  uint64_t total_mems = 0; uint32_t hcls[5] = {0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 4, sizeof(hcls), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 10, sizeof(hcls), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_mems = total_mems;
   if (total_mems >= 0x7FFFFFF0ull) {   // 32-bit slab indices (candidates name chains by slab index; recovery doubles the slabs)
@@ -423,7 +425,9 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   if (c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->mnext.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey2.p; uint64_t* sval = c->mval2.p;
-  const uint32_t nS = hcls[0], nM = hcls[1], nL = hcls[2], memsL = hcls[3];
+  const uint32_t nT = hcls[0], nS = hcls[1], nM = hcls[2], nL = hcls[3], memsL = hcls[4];
+  if (nT) k_mems<16, MK_T_CAP, 256><<<(nT + 15) / 16, 256, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_t, nT,
+      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
   if (nS) k_mems<16, MK_S_CAP, 256><<<(nS + 15) / 16, 256, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_s, nS,
       c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
   if (nM) k_mems<64, MK_M_CAP, 128><<<(nM + 1) / 2, 128, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_m, nM,

@@ -5,7 +5,8 @@
 // records crossed HBM about ten times, and the thread-per-end projection stored them 8 bytes at a time.)
 //
 // A read end with n projected MEMs is handled by a group of G lanes:
-//   n <= 64    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 64, 256>
+//   n <= 32    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 32, 256>
+//   n <= 64    G = 16  (the same with twice the LDS rows: 44 KB per block hold 3 blocks per CU, 28 KB hold 5)     k_mems<16, 64, 256>
 //   n <= 1024  G = 64  (one wave per end)                                                       k_mems<64, 1024, 128>
 //   larger     the round-1 path on a compacted list (k_project_list -> radix sort -> k_chain)
 // Lanes expand one occurrence each (coalesced contig-table loads, all gathers in flight), rank-sort the keys held
@@ -16,27 +17,28 @@
 
 namespace sqk {
 
+#define MK_T_CAP 32
 #define MK_S_CAP 64
 #define MK_M_CAP 1024
 
 __device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// ends by size class; an end without MEMs has no chains.  ctr: [0] small [1] medium [2] large [3] MEMs of the large ends.
-// Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs three same-address atomics.
-__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ list_s,
-                              uint32_t* __restrict__ list_m, uint32_t* __restrict__ list_l, uint32_t* __restrict__ lbase, uint32_t* __restrict__ n_chains,
-                              uint32_t* __restrict__ ctr) {
-  __shared__ uint32_t s_cnt[3][16]; __shared__ uint32_t s_base[3];
+// ends by size class; an end without MEMs has no chains.  ctr: [0] tiny [1] small [2] medium [3] large [4] MEMs of the large ends.
+// Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs four same-address atomics.
+__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ list_t,
+                              uint32_t* __restrict__ list_s, uint32_t* __restrict__ list_m, uint32_t* __restrict__ list_l, uint32_t* __restrict__ lbase,
+                              uint32_t* __restrict__ n_chains, uint32_t* __restrict__ ctr) {
+  __shared__ uint32_t s_cnt[4][16]; __shared__ uint32_t s_base[4];
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
   const uint32_t n = e < nends ? n_proj[e] : 0;
-  const int cls = (e >= nends || n == 0) ? -1 : (n <= MK_S_CAP ? 0 : (n <= MK_M_CAP ? 1 : 2));
+  const int cls = (e >= nends || n == 0) ? -1 : (n <= MK_T_CAP ? 0 : (n <= MK_S_CAP ? 1 : (n <= MK_M_CAP ? 2 : 3)));
   if (e < nends && n == 0) n_chains[e] = 0;
-  unsigned long long m[3];
+  unsigned long long m[4];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { m[c] = __ballot(cls == c); if (lane == 0) s_cnt[c][wv] = (uint32_t)__popcll(m[c]); }
+  for (int c = 0; c < 4; ++c) { m[c] = __ballot(cls == c); if (lane == 0) s_cnt[c][wv] = (uint32_t)__popcll(m[c]); }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     uint32_t tot = 0;
     for (int w = 0; w < 16; ++w) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += v; }
     s_base[threadIdx.x] = tot ? atomicAdd(&ctr[threadIdx.x], tot) : 0u;
@@ -44,8 +46,8 @@ __global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint
   __syncthreads();
   if (cls >= 0) {
     const uint32_t pos = s_base[cls] + s_cnt[cls][wv] + (uint32_t)__popcll(m[cls] & ((1ULL << lane) - 1));
-    if (cls == 0) list_s[pos] = e; else if (cls == 1) list_m[pos] = e;
-    else { list_l[pos] = e; lbase[pos] = atomicAdd(&ctr[3], n); }
+    if (cls == 0) list_t[pos] = e; else if (cls == 1) list_s[pos] = e; else if (cls == 2) list_m[pos] = e;
+    else { list_l[pos] = e; lbase[pos] = atomicAdd(&ctr[4], n); }
   }
 }
 
@@ -62,12 +64,21 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
   static_assert(G == 16 || G == 32 || G == 64, "group = a power-of-two slice of a wave");
   constexpr int CP8 = CAP + 1, CP4 = CAP + 1, CP2 = CAP + 2, CP1 = CAP + 4;   // padded rows: the groups of a wave must not sit on the same banks
   __shared__ uint64_t s_key[GPB][CP8];                 // ranking keys, then (same bytes) the DP scores f[] as doubles
-  __shared__ int32_t s_r[GPB][CP4]; __shared__ uint32_t s_tid[GPB][CP4];
-  __shared__ int16_t s_q[GPB][CP2]; __shared__ uint16_t s_lf[GPB][CP2];      // len | fw << 15
-  __shared__ int16_t s_p[GPB][CP2]; __shared__ uint16_t s_acc[GPB][CP2]; __shared__ uint16_t s_gs[GPB][CP2 + 2]; __shared__ uint16_t s_gc[GPB][CP2];
-  __shared__ uint8_t s_fl[GPB][CP1];
-  __shared__ MkHdr s_h[GPB][SQ_MAX_UNIMEMS];
+  // The uni-MEM headers are dead once the projection is done: the sorted MEM columns and the DP's arrays take their bytes (LDS per
+  // block decides how many blocks a CU holds: 29 -> 17 KB for the tiny class).
+  constexpr int O_R = 0, O_TID = O_R + 4 * CP4, O_Q = O_TID + 4 * CP4, O_LF = O_Q + 2 * CP2, O_P = O_LF + 2 * CP2, O_ACC = O_P + 2 * CP2,
+                O_GS = O_ACC + 2 * CP2, O_GC = O_GS + 2 * (CP2 + 2), O_FL = O_GC + 2 * CP2, O_END = O_FL + CP1;
+  constexpr int HB = SQ_MAX_UNIMEMS * (int)sizeof(MkHdr);
+  constexpr int UW = ((O_END > HB ? O_END : HB) + 7) / 8 + 1;   // 8-byte words per group; + 1: the groups of a wave must not sit on the same banks
+  __shared__ uint64_t s_u[GPB][UW];
   __shared__ double s_gap[SQ_MAX_CHAIN_GAP + 1];
+  char* const ub = reinterpret_cast<char*>(s_u[threadIdx.x / G]);
+  MkHdr* const g_h = reinterpret_cast<MkHdr*>(ub);
+  int32_t* const g_r = reinterpret_cast<int32_t*>(ub + O_R); uint32_t* const g_tid = reinterpret_cast<uint32_t*>(ub + O_TID);
+  int16_t* const g_q = reinterpret_cast<int16_t*>(ub + O_Q); uint16_t* const g_lf = reinterpret_cast<uint16_t*>(ub + O_LF);      // len | fw << 15
+  int16_t* const g_p = reinterpret_cast<int16_t*>(ub + O_P); uint16_t* const g_acc = reinterpret_cast<uint16_t*>(ub + O_ACC);
+  uint16_t* const g_gs = reinterpret_cast<uint16_t*>(ub + O_GS); uint16_t* const g_gc = reinterpret_cast<uint16_t*>(ub + O_GC);
+  uint8_t* const g_fl = reinterpret_cast<uint8_t*>(ub + O_FL);
   const int tx = (int)threadIdx.x, gl = tx % G, gi = tx / G, lane = tx & 63, gsh = lane & ~(G - 1);
   for (int i = tx; i <= SQ_MAX_CHAIN_GAP; i += TBK) s_gap[i] = gapcost[i];
   __syncthreads();
@@ -84,7 +95,7 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     const uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
     MkHdr h; h.a = a; h.cnt = (b - a > P.max_occ) ? 0u : (uint32_t)(b - a);
     h.ulen = (uint32_t)(uoff[m.unitig + 1] - uoff[m.unitig]); h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u));
-    s_h[gi][i] = h;
+    g_h[i] = h;
   }
   mk_wsync();
   // ---- projection: output slot p = occurrence (uni-MEM i, j - a_i) in emission order; one lane per occurrence ----
@@ -96,8 +107,8 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
       const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
       K[t] = 0; R[t] = 0; T[t] = 0; Q[t] = 0; LF[t] = 0; rk[t] = 0;
       if (p < n) {
-        while (p >= hacc + s_h[gi][hi].cnt) { hacc += s_h[gi][hi].cnt; ++hi; }
-        const MkHdr h = s_h[gi][hi];
+        while (p >= hacc + g_h[hi].cnt) { hacc += g_h[hi].cnt; ++hi; }
+        const MkHdr h = g_h[hi];
         const uint64_t o = ctab[h.a + (p - hacc)];
         const uint32_t tid = (uint32_t)(o >> 32); const bool ufw = (o >> 31) & 1; const int upos = (int)(o & 0x7FFFFFFF);
         const int mlen = (int)(h.lenfw & 0x7FFFu); const bool mfw = (h.lenfw & 0x8000u) != 0;
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
     if (p < n) {
       const uint32_t r = rk[t];
-      s_r[gi][r] = R[t]; s_tid[gi][r] = T[t]; s_q[gi][r] = Q[t]; s_lf[gi][r] = LF[t]; s_fl[gi][r] = 0;
+      g_r[r] = R[t]; g_tid[r] = T[t]; g_q[r] = Q[t]; g_lf[r] = LF[t]; g_fl[r] = 0;
       mkey[base + r] = ((uint64_t)e << 40) | K[t];
       mval[base + r] = mem_pack_val(T[t], (uint32_t)(uint16_t)Q[t], (uint32_t)(LF[t] & 0x7FFFu), (LF[t] >> 15) & 1u);
     }
@@ -136,28 +147,28 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
 #pragma unroll
   for (int t = 0; t < E; ++t) {
     const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
-    const bool st = p < n && (p == 0 || s_tid[gi][p] != s_tid[gi][p - 1]);
+    const bool st = p < n && (p == 0 || g_tid[p] != g_tid[p - 1]);
     const unsigned long long bm = __ballot(st);
     const uint32_t gm = (G == 64) ? 0u : (uint32_t)((bm >> gsh) & ((1ull << (G & 63)) - 1));
     const uint32_t below = (G == 64) ? (uint32_t)__popcll(bm & ((1ull << lane) - 1)) : (uint32_t)__popc(gm & ((1u << gl) - 1));
     const uint32_t tot = (G == 64) ? (uint32_t)__popcll(bm) : (uint32_t)__popc(gm);
-    if (st) s_gs[gi][ng + below] = (uint16_t)p;
+    if (st) g_gs[ng + below] = (uint16_t)p;
     ng += tot;
   }
-  if (gl == 0) s_gs[gi][ng] = (uint16_t)n;
+  if (gl == 0) g_gs[ng] = (uint16_t)n;
   mk_wsync();
   // ---- chaining DP, one lane per transcript (SPEC §a2; same operations in the same order as the checker) ----
   double* f = (double*)s_key[gi];
   double lbest = 0.0;
   for (uint32_t k = (uint32_t)gl; k < ng; k += G) {
-    const int g0 = (int)s_gs[gi][k], g1 = (int)s_gs[gi][k + 1];
+    const int g0 = (int)g_gs[k], g1 = (int)g_gs[k + 1];
     double best = 0.0;
     for (int i = g0; i < g1; ++i) {
-      const int qi = s_q[gi][i], ri = s_r[gi][i], len_i = (int)(s_lf[gi][i] & 0x7FFFu); const uint32_t fwi = s_lf[gi][i] >> 15;
+      const int qi = g_q[i], ri = g_r[i], len_i = (int)(g_lf[i] & 0x7FFFu); const uint32_t fwi = g_lf[i] >> 15;
       double fi = (double)len_i; int pi = -1; int rounds = 2;
       for (int j = i - 1; j >= g0; --j) {
-        if ((uint32_t)(s_lf[gi][j] >> 15) != fwi) continue;
-        const int qd = qi - (int)s_q[gi][j], rd = ri - s_r[gi][j];
+        if ((uint32_t)(g_lf[j] >> 15) != fwi) continue;
+        const int qd = qi - (int)g_q[j], rd = ri - g_r[j];
         if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
         const int l = abs(qd - rd);
         const double a = (double)min(len_i, min(qd, rd));
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
         if (sc > fi) { fi = sc; pi = j; }
         if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
       }
-      f[i] = fi; s_p[gi][i] = (int16_t)pi;
+      f[i] = fi; g_p[i] = (int16_t)pi;
       if (fi > best) best = fi;
     }
     const double thr = P.pre_thr * best;
@@ -173,19 +184,19 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     for (;;) {   // accept chain ends by (score desc, index asc); s_fl: bit 0 used by an accepted chain, bit 1 tried and dropped
       int bi = -1; double bf = 0.0;
       for (int i = g0; i < g1; ++i) {
-        if (s_fl[gi][i]) continue;
+        if (g_fl[i]) continue;
         const double fv = f[i];
         if (fv >= thr && (bi < 0 || fv > bf)) { bi = i; bf = fv; }
       }
       if (bi < 0) break;
       bool clash = false;
-      for (int x = bi; x >= 0; x = s_p[gi][x]) if (s_fl[gi][x] & 1) { clash = true; break; }
-      if (clash) { s_fl[gi][bi] |= 2; continue; }
-      for (int x = bi; x >= 0; x = s_p[gi][x]) s_fl[gi][x] |= 1;
-      s_acc[gi][g0 + (int)nacc] = (uint16_t)bi; ++nacc;
+      for (int x = bi; x >= 0; x = g_p[x]) if (g_fl[x] & 1) { clash = true; break; }
+      if (clash) { g_fl[bi] |= 2; continue; }
+      for (int x = bi; x >= 0; x = g_p[x]) g_fl[x] |= 1;
+      g_acc[g0 + (int)nacc] = (uint16_t)bi; ++nacc;
       if (bf > lbest) lbest = bf;
     }
-    s_gc[gi][k] = (uint16_t)nacc;
+    g_gc[k] = (uint16_t)nacc;
   }
   // ---- hitFilterPolicy AFTER + consensus fraction over the end's chains; chains go out in (transcript, acceptance) order ----
   double bestAll = lbest;
@@ -201,8 +212,8 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     const uint32_t k = t0 + (uint32_t)gl;
     uint32_t kept = 0; int g0 = 0, g1 = 0; uint32_t nacc = 0;
     if (k < ng) {
-      g0 = (int)s_gs[gi][k]; g1 = (int)s_gs[gi][k + 1]; nacc = s_gc[gi][k];
-      for (uint32_t c = 0; c < nacc; ++c) if (f[s_acc[gi][g0 + (int)c]] >= cthr) ++kept;
+      g0 = (int)g_gs[k]; g1 = (int)g_gs[k + 1]; nacc = g_gc[k];
+      for (uint32_t c = 0; c < nacc; ++c) if (f[g_acc[g0 + (int)c]] >= cthr) ++kept;
     }
     uint32_t incl = kept;
 #pragma unroll
@@ -212,20 +223,20 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     if (k < ng && kept) {
       const int gn = g1 - g0; const bool by_mask = gn <= 32;
       for (uint32_t c = 0; c < nacc; ++c) {
-        const int bi = (int)s_acc[gi][g0 + (int)c];
+        const int bi = (int)g_acc[g0 + (int)c];
         const double bf = f[bi];
         if (bf < cthr) continue;
         uint32_t mask = 0, cnt = 0; int first = bi;
-        for (int x = bi; x >= 0; x = s_p[gi][x]) {
+        for (int x = bi; x >= 0; x = g_p[x]) {
           ++cnt; first = x;
           if (by_mask) mask |= 1u << (x - g0);
-          else { const int pr = s_p[gi][x]; if (pr >= 0) mnext[base + (uint32_t)pr] = (uint32_t)x; }
+          else { const int pr = g_p[x]; if (pr >= 0) mnext[base + (uint32_t)pr] = (uint32_t)x; }
         }
         sq_chain_dev ch;
-        ch.score = bf; ch.tid = s_tid[gi][bi]; ch.pos = s_r[gi][first] - (int32_t)s_q[gi][first];
-        ch.last_end = s_r[gi][bi] + (int32_t)(s_lf[gi][bi] & 0x7FFFu);
+        ch.score = bf; ch.tid = g_tid[bi]; ch.pos = g_r[first] - (int32_t)g_q[first];
+        ch.last_end = g_r[bi] + (int32_t)(g_lf[bi] & 0x7FFFu);
         ch.first = by_mask ? (uint32_t)g0 : (uint32_t)first; ch.n_mems = (uint16_t)cnt; ch.read_len = (uint16_t)L;
-        ch.fw = (uint8_t)(s_lf[gi][bi] >> 15); ch.pad[0] = by_mask ? 1 : 0; ch.pad[1] = ch.pad[2] = 0; ch.pad2 = mask;
+        ch.fw = (uint8_t)(g_lf[bi] >> 15); ch.pad[0] = by_mask ? 1 : 0; ch.pad[1] = ch.pad[2] = 0; ch.pad2 = mask;
         chains[base + w] = ch; ++w;
       }
     }

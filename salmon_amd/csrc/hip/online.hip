@@ -428,7 +428,10 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
         }
       }
       // chains, replayed identically by the lanes of the group (alignment i lives in lane i & 7, slot i >> 3)
-      double auxDenom = SQ_LOG_0, sumProbs = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtAll = 0;
+      // [r2] the two log-sum chains are independent: the even lanes of the group run sumProbs, the odd lanes auxDenom (one sq_log_add
+      // per step in every lane instead of two), each chain in its sequential order
+      const bool odd = (j & 1) != 0;
+      double chain = SQ_LOG_0; uint32_t nk = 0; uint64_t fmtAll = 0;
       for (uint32_t i = 0; i < nA; ++i) {
         const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
         const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G);
@@ -436,8 +439,9 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
         const double xl = __shfl(hi ? logProb[1] : logProb[0], src, MB_G);
         const unsigned long long fm = __shfl((unsigned long long)(hi ? fmtBit[1] : fmtBit[0]), src, MB_G);
         fmtAll |= fm;
-        if (kp) { sumProbs = sq_log_add(sumProbs, xl); auxDenom = sq_log_add(auxDenom, xa); ++nk; }
+        if (kp) { chain = sq_log_add(chain, odd ? xa : xl); ++nk; }
       }
+      const double sumProbs = __shfl(chain, 0, MB_G), auxDenom = __shfl(chain, 1, MB_G);
       const bool assigned = !(nk == 0 || sumProbs == SQ_LOG_0);
       // kept-index of this lane's alignments (ki of the sequential form); ballots in group-uniform code
       const unsigned long long kb0 = __ballot(keep[0]), kb1 = __ballot(keep[1]);
@@ -476,19 +480,27 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
       // label hash (tids of kept alignments, then their bins), replayed by all lanes; lane 0 publishes
       if (assigned) {
         const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
-        uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen;
+        // the two halves of the label hash are independent as well: even lanes carry `a`, odd lanes `b` of label_hash_step, with the
+        // one sq_mix64 of a step shared through selects
+        uint64_t hh = odd ? (0x13198A2E03707344ULL + (uint64_t)labLen) : (0x243F6A8885A308D3ULL ^ (uint64_t)labLen);
+        auto half_step = [&](uint32_t x) {
+          const uint64_t u = odd ? (hh + (uint64_t)x * 0xD6E8FEB86659FD93ULL) : (hh ^ (uint64_t)x);
+          const uint64_t m = sq_mix64(u);
+          hh = odd ? (m ^ (hh >> 29)) : (m + 0x9E3779B97F4A7C15ULL);
+        };
         uint32_t firstTid = 0;
         bool gotFirst = false;
         for (uint32_t i = 0; i < nA; ++i) {
           const int src = (int)(i & (MB_G - 1)); const bool hi = i >= MB_G;
           const int kp = __shfl((int)(hi ? keep[1] : keep[0]), src, MB_G);
           const uint32_t ti = (uint32_t)__shfl((int)(hi ? t[1] : t[0]), src, MB_G);
-          if (kp) { label_hash_step(ha, hb, ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } }
+          if (kp) { half_step(ti); if (!gotFirst) { firstTid = ti; gotFirst = true; } }
         }
         if (o.range_factorization_bins > 0) for (uint32_t i = 0; i < nA; ++i) {
           const uint32_t bi = (uint32_t)__shfl((int)(i >= MB_G ? bin[1] : bin[0]), (int)(i & (MB_G - 1)), MB_G);
-          if (bi != 0xFFFFFFFFu) label_hash_step(ha, hb, bi);
+          if (bi != 0xFFFFFFFFu) half_step(bi);
         }
+        const uint64_t ha = (uint64_t)__shfl((unsigned long long)hh, 0, MB_G), hb = (uint64_t)__shfl((unsigned long long)hh, 1, MB_G);
         if (j == 0) {
           uint64_t h1 = sq_mix64(ha), h2 = sq_mix64(hb);
           if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
