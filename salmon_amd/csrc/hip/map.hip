@@ -464,9 +464,15 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
         return SQ_ERR_NOMEM;
       }
       SQ_HIP_CHECK(hipMemsetAsync(c->stats.p + ST_CANDS, 0, sizeof(unsigned long long), st));
+      SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 15, 0, sizeof(uint32_t), st));
+      uint32_t* rest = c->mlist.p;   // the class lists of k_mems are done with: n entries hold the fragments left to k_join2_rest
       k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p,
           c->cand_frag.p, c->cands.n,
-          c->frag_flags.p, c->stats.p + ST_CANDS);
+          c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);
+      if (paired) k_join2_group<<<(n + 15) / 16, 256, 0, st>>>(P, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p,
+          c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);
+      else k_join2_rest<<<nblk(n), TB, 0, st>>>(P, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p,
+          c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);
       unsigned long long tc = 0;
       SQ_HIP_CHECK(hipMemcpyAsync(&tc, c->stats.p + ST_CANDS, 8, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipStreamSynchronize(st));

@@ -490,37 +490,57 @@ __device__ inline uint32_t join_fragment(const sq_map_params& P, const sq_chain_
 
 // Single-pass join: the chains of a fragment are read from HBM once.  Concordant pairs (almost always
 // < 8 per fragment) are held in registers for the consensus / post-merge filters; the candidate block of
-// the fragment is carved out of one global array with a wave-aggregated cursor (one atomic per wave), so
-// there is no count kernel, no scan and no second enumeration.  Fragments with more than JP pairs, and
-// orphan-only fragments, fall back to the multi-pass enumeration of join_fragment<>.
+// the fragment is carved out of one global array with a block-aggregated cursor (one atomic per block), so
+// there is no count kernel, no scan and no second enumeration.
+// [r2] Two kernels.  k_join2 takes the usual fragment — at most JB chains per end, at most JP concordant pairs, or orphans only —
+// with straight-line code: the transcripts of all chains are requested at once and matched in registers.  Anything else (repeat
+// families, single-end libraries) is put on a list and k_join2_rest runs the general merge (join_fragment<>) over that list, a lane
+// per fragment among its own kind: one slow lane used to hold the other 63 of its wave (SQ counters: 21 % of the lanes active).
 // (Tried in round 2: copying the compact form of a fragment's chains into thread-private LDS columns first — three loads per chain —
 // and enumerating from there: 1.95 -> 2.46 ms per 10^6 pairs; the 40 KB of LDS per 128 threads cost more occupancy than the loads saved.)
 #define JP 8
 #define JB 8   // chains per end whose transcripts are matched in registers
+
+// the block's share of the candidate array: wave totals meet in LDS, one cursor atomic per block (see block_stat_add)
+__device__ inline uint64_t join_alloc(uint32_t cnt, unsigned long long* cursor) {
+  __shared__ uint32_t s_wt[16]; __shared__ unsigned long long s_base;
+  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6), nwv = (int)((blockDim.x + 63) >> 6);
+  uint32_t incl = cnt;
+  for (int sft = 1; sft < 64; sft <<= 1) { uint32_t o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
+  if (lane == 63) s_wt[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < nwv; ++i) tot += s_wt[i]; s_base = tot ? atomicAdd(cursor, tot) : 0ULL; }
+  __syncthreads();
+  unsigned long long base = s_base;
+  for (int i = 0; i < wv; ++i) base += s_wt[i];
+  return base + (incl - cnt);
+}
+
 __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off,
     const sq_chain_dev* __restrict__ chains,
     const uint32_t* __restrict__ n_chains,
                         uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands,
                             uint32_t* __restrict__ cand_frag,
                             uint64_t cand_cap,
-                        uint8_t* __restrict__ frag_flags, unsigned long long* __restrict__ cursor) {
+                        uint8_t* __restrict__ frag_flags, unsigned long long* __restrict__ cursor, uint32_t* __restrict__ rest, uint32_t* __restrict__ nrest) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = f < nfrag;
   const int lane = (int)(threadIdx.x & 63);
-  uint32_t cnt = 0; bool dove = false; int mode = 0;   // mode 1: pairs in registers, 2: multi-pass pairs, 3: orphans, 4: single-end
-  double pc[JP]; uint32_t pt[JP], pa[JP], pb[JP], pf[JP]; uint32_t np = 0; double best = -1.0;
+  uint32_t cnt = 0; bool dove = false; int mode = 0;   // mode 1: pairs in registers, 3: orphans; `later`: left to k_join2_rest
+  bool later = false;
+  double pc[JP]; uint32_t pt[JP], pa[JP], pb[JP], pf[JP]; uint32_t np = 0; double best = -1.0, othr = 0.0;
   const sq_chain_dev* lc = nullptr; const sq_chain_dev* rc = nullptr; uint32_t nl = 0, nr = 0, lbase = 0, rbase = 0;
 #pragma unroll
   for (int i = 0; i < JP; ++i) { pc[i] = 0.0; pt[i] = 0; pa[i] = 0; pb[i] = 0; pf[i] = 0; }
-  if (act && paired) {
-    const uint32_t e0 = 2 * f, e1 = 2 * f + 1;
+  if (act && !paired) later = true;
+  else if (act) {
+    const uint32_t e0 = 2 * f;
     { const sq_u64x2 co = *reinterpret_cast<const sq_u64x2*>(chain_off + e0); lbase = (uint32_t)co.x; rbase = (uint32_t)co.y;   // e0 is even: one 16-byte load
       const uint2 nc2 = *reinterpret_cast<const uint2*>(n_chains + e0); nl = nc2.x; nr = nc2.y; }
     lc = chains + lbase; rc = chains + rbase;
-    if (nl <= JB && nr <= JB) {
-      // [r2] the usual fragment (at most JB chains per end): the transcripts of all its chains are requested at once and matched in
-      // registers, instead of a merge whose every step waits for the load of the step before; the chains are sorted by transcript on
-      // both ends, so visiting the matches in (a, b) order is the order of the merge below
+    if (nl > JB || nr > JB) later = true;
+    else {
+      // the chains are sorted by transcript on both ends, so visiting the matches in (a, b) order is the order of the general merge
       uint32_t lt[JB], rt[JB];
 #pragma unroll
       for (int a = 0; a < JB; ++a) { lt[a] = (uint32_t)a < nl ? lc[a].tid : 0xFFFFFFFFu; rt[a] = (uint32_t)a < nr ? rc[a].tid : 0xFFFFFFFEu; }
@@ -539,66 +559,220 @@ __global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const 
         for (int q = 0; q < JP; ++q) if ((uint32_t)q == np) { pc[q] = cov; pt[q] = ti; pa[q] = a; pb[q] = b; pf[q] = (uint32_t)fl; }
         ++np;
       }
-    } else
-    for (uint32_t i = 0, j = 0; i < nl && j < nr;) {
-      const uint32_t ti = lc[i].tid, tj = rc[j].tid;
-      if (ti < tj) { ++i; continue; }
-      if (ti > tj) { ++j; continue; }
-      uint32_t i1 = i, j1 = j; while (i1 < nl && lc[i1].tid == ti) ++i1; while (j1 < nr && rc[j1].tid == ti) ++j1;
-      for (uint32_t a = i; a < i1; ++a) for (uint32_t b = j; b < j1; ++b) {
-        int32_t fl; if (!pair_ok(P, lc[a], rc[b], &fl, &dove)) continue;
-        const double cov = lc[a].score + rc[b].score; if (cov > best) best = cov;
+      if (np > JP) later = true;
+      else if (np > 0) {
+        mode = 1;
+        const double thr = P.consensus_frac * best;
 #pragma unroll
-        for (int q = 0; q < JP; ++q) if ((uint32_t)q == np) { pc[q] = cov; pt[q] = ti; pa[q] = a; pb[q] = b; pf[q] = (uint32_t)fl; }
-        ++np;
+        for (int q = 0; q < JP; ++q) {
+          bool keep = (uint32_t)q < np && pc[q] >= thr;
+          if (keep) { double bt = 0.0;
+#pragma unroll
+            for (int z = 0; z < JP; ++z) if ((uint32_t)z < np && pt[z] == pt[q] && pc[z] >= thr && pc[z] > bt) bt = pc[z];
+            keep = pc[q] >= P.post_thr * bt; }
+          if (keep) ++cnt; else if ((uint32_t)q < np) pf[q] = 0xFFFFFFFFu;   // dropped
+        }
+      } else if (P.allow_orphans && (nl || nr)) {   // no concordant pair: the orphan rule of join_fragment<>, scores requested together
+        mode = 3;
+        double ob = 0.0;
+#pragma unroll
+        for (int a = 0; a < JB; ++a) { const double sl = (uint32_t)a < nl ? lc[a].score : 0.0, sr = (uint32_t)a < nr ? rc[a].score : 0.0; if (sl > ob) ob = sl; if (sr > ob) ob = sr; }
+        othr = P.orphan_thr * ob;
+#pragma unroll
+        for (int a = 0; a < JB; ++a) { if ((uint32_t)a < nl && lc[a].score >= othr) ++cnt; if ((uint32_t)a < nr && rc[a].score >= othr) ++cnt; }
       }
-      i = i1; j = j1;
     }
-    if (np > JP) { mode = 2; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &d2); }
-    else if (np > 0) {
-      mode = 1;
-      const double thr = P.consensus_frac * best;
-#pragma unroll
-      for (int q = 0; q < JP; ++q) {
-        bool keep = (uint32_t)q < np && pc[q] >= thr;
-        if (keep) { double bt = 0.0;
-#pragma unroll
-          for (int z = 0; z < JP; ++z) if ((uint32_t)z < np && pt[z] == pt[q] && pc[z] >= thr && pc[z] > bt) bt = pc[z];
-          keep = pc[q] >= P.post_thr * bt; }
-        if (keep) ++cnt; else if ((uint32_t)q < np) pf[q] = 0xFFFFFFFFu;   // dropped
-      }
-    } else if (P.allow_orphans && (nl || nr)) { mode = 3; bool d2; cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr,
-        &d2); }
-  } else if (act) { mode = 4; lbase = (uint32_t)chain_off[f]; nl = n_chains[f]; lc = chains + lbase; cnt = nl; }
-  // block allocation: exclusive prefix of cnt over the wave + one atomic
-  uint32_t incl = cnt;
-  for (int sft = 1; sft < 64; sft <<= 1) { uint32_t o = __shfl_up(incl, sft, 64); if (lane >= sft) incl += o; }
-  // one cursor atomic per block (not per wave: see block_stat_add): wave totals meet in LDS
-  __shared__ uint32_t s_wt[16]; __shared__ unsigned long long s_base;
-  const int wv = (int)(threadIdx.x >> 6), nwv = (int)((blockDim.x + 63) >> 6);
-  if (lane == 63) s_wt[wv] = incl;
-  __syncthreads();
-  if (threadIdx.x == 0) { unsigned long long tot = 0; for (int i = 0; i < nwv; ++i) tot += s_wt[i]; s_base = tot ? atomicAdd(cursor, tot) : 0ULL; }
-  __syncthreads();
-  unsigned long long base = s_base;
-  for (int i = 0; i < wv; ++i) base += s_wt[i];
-  const uint64_t start = base + (incl - cnt);
-  if (!act) return;
+  }
+  // the rest list: one cursor atomic per block
+  { __shared__ uint32_t s_rw[16]; __shared__ uint32_t s_rbase;
+    const unsigned long long lm = __ballot(later); const int wv = (int)(threadIdx.x >> 6), nwv = (int)((blockDim.x + 63) >> 6);
+    if (lane == 0) s_rw[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int i = 0; i < nwv; ++i) { const uint32_t v = s_rw[i]; s_rw[i] = tot; tot += v; } s_rbase = tot ? atomicAdd(nrest, tot) : 0u; }
+    __syncthreads();
+    if (later) rest[s_rbase + s_rw[wv] + (uint32_t)__popcll(lm & ((1ULL << lane) - 1))] = f; }
+  const uint64_t start = join_alloc(cnt, cursor);
+  if (!act || later) return;
   n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0);
   if (cnt == 0 || start + cnt > cand_cap) return;   // overflow: the host re-runs with a larger array
   sq_cand_dev* out = cands + start;
+  uint32_t w = 0;
   if (mode == 1) {
-    uint32_t w = 0;
 #pragma unroll
     for (int q = 0; q < JP; ++q) if ((uint32_t)q < np && pf[q] != 0xFFFFFFFFu) {
       cand_init(out[w], pc[q], pt[q], lbase + pa[q], rbase + pb[q], pf[q], SQ_MS_PAIRED_END_PAIRED);
       ++w;
     }
-  } else if (mode == 2 || mode == 3) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); }
-  else if (mode == 4) {
-    for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END);
+  } else {   // mode 3; pad[0] remembers which end anchors an orphan candidate (see join_fragment<>)
+#pragma unroll
+    for (int a = 0; a < JB; ++a) if ((uint32_t)a < nl) { const double sc = lc[a].score; if (sc >= othr) {
+      cand_init(out[w], sc, lc[a].tid, lbase + (uint32_t)a, 0xFFFFFFFFu, 0, SQ_MS_PAIRED_END_LEFT); out[w].pad[0] = 1; ++w; } }
+#pragma unroll
+    for (int b = 0; b < JB; ++b) if ((uint32_t)b < nr) { const double sc = rc[b].score; if (sc >= othr) {
+      cand_init(out[w], sc, rc[b].tid, 0xFFFFFFFFu, rbase + (uint32_t)b, 0, SQ_MS_PAIRED_END_RIGHT); out[w].pad[0] = 2; ++w; } }
   }
   for (uint32_t i = 0; i < cnt; ++i) cand_frag[start + i] = f;
+}
+
+// the fragments k_join2 left on the list: the general multi-pass enumeration, a lane per fragment
+__global__ void k_join2_rest(sq_map_params P, uint32_t paired, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains,
+                             const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start,
+                             sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag, uint64_t cand_cap, uint8_t* __restrict__ frag_flags,
+                             unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ rest, const uint32_t* __restrict__ nrest) {
+  const uint32_t nlist = *nrest;
+  if (blockIdx.x * blockDim.x >= nlist) return;   // the grid is sized for the worst case: whole blocks leave here
+  const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = li < nlist;
+  const uint32_t f = act ? rest[li] : 0;
+  uint32_t cnt = 0; bool dove = false;
+  const sq_chain_dev* lc = nullptr; const sq_chain_dev* rc = nullptr; uint32_t nl = 0, nr = 0, lbase = 0, rbase = 0;
+  if (act && paired) {
+    const uint32_t e0 = 2 * f, e1 = 2 * f + 1;
+    lbase = (uint32_t)chain_off[e0]; rbase = (uint32_t)chain_off[e1]; nl = n_chains[e0]; nr = n_chains[e1];
+    lc = chains + lbase; rc = chains + rbase;
+    cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &dove);
+  } else if (act) { lbase = (uint32_t)chain_off[f]; nl = n_chains[f]; lc = chains + lbase; cnt = nl; }
+  const uint64_t start = join_alloc(cnt, cursor);
+  if (!act) return;
+  n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0);
+  if (cnt == 0 || start + cnt > cand_cap) return;
+  sq_cand_dev* out = cands + start;
+  if (paired) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); }
+  else for (uint32_t a = 0; a < nl; ++a) cand_init(out[a], lc[a].score, lc[a].tid, lbase + a, 0xFFFFFFFFu, 0, SQ_MS_SINGLE_END);
+  for (uint32_t i = 0; i < cnt; ++i) cand_frag[start + i] = f;
+}
+
+// The fragments k_join2 left on the list, paired libraries: a group of 16 lanes per fragment.  The group copies what the join reads
+// of the fragment's chains (transcript, position, strand, read length, score: 20 bytes per chain) into LDS once, coalesced, and every
+// pass of join_fragment<> — best coverage, per-transcript best, count, fill — runs from there, a lane per left chain; the candidates come
+// out in the same (left chain, right chain) order.  Fragments with more than JG_CAP chains on an end take join_fragment<> itself on lane 0.
+#define JG 16
+#define JG_CAP 48
+__global__ void __launch_bounds__(256) k_join2_group(sq_map_params P, const uint64_t* __restrict__ chain_off, const sq_chain_dev* __restrict__ chains,
+                             const uint32_t* __restrict__ n_chains, uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start,
+                             sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag, uint64_t cand_cap, uint8_t* __restrict__ frag_flags,
+                             unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ rest, const uint32_t* __restrict__ nrest) {
+  constexpr int GPB = 256 / JG, CP = JG_CAP + 1;
+  const uint32_t nlist = *nrest;
+  if (blockIdx.x * GPB >= nlist) return;   // the grid is sized for the worst case: whole blocks leave here
+  __shared__ uint32_t s_tid[GPB][2][CP]; __shared__ int32_t s_pos[GPB][2][CP]; __shared__ uint32_t s_meta[GPB][2][CP];   // meta: fw | read_len << 1
+  __shared__ double s_sc[GPB][2][CP]; __shared__ double s_bt[GPB][CP]; __shared__ uint32_t s_cnt[GPB][CP];
+  const int gi = (int)(threadIdx.x / JG), gl = (int)(threadIdx.x % JG);
+  const uint32_t li = blockIdx.x * GPB + (uint32_t)gi;
+  const bool act = li < nlist;
+  const uint32_t f = act ? rest[li] : 0;
+  uint32_t nl = 0, nr = 0, lbase = 0, rbase = 0;
+  if (act) { const uint32_t e0 = 2 * f; const sq_u64x2 co = *reinterpret_cast<const sq_u64x2*>(chain_off + e0); lbase = (uint32_t)co.x; rbase = (uint32_t)co.y;
+    const uint2 nc2 = *reinterpret_cast<const uint2*>(n_chains + e0); nl = nc2.x; nr = nc2.y; }
+  const sq_chain_dev* lc = chains + lbase; const sq_chain_dev* rc = chains + rbase;
+  const bool big = nl > JG_CAP || nr > JG_CAP;
+  uint32_t cnt = 0; bool dove = false;
+  double best = -1.0, thr = 0.0, othr = 0.0;
+  if (act && big) {
+    if (gl == 0) cnt = join_fragment<false>(P, lc, nl, lbase, rc, nr, rbase, nullptr, &dove);
+  } else if (act) {
+    for (uint32_t i = (uint32_t)gl; i < nl + nr; i += JG) {
+      const int side = i < nl ? 0 : 1; const uint32_t x = side ? i - nl : i; const sq_chain_dev* ch = (side ? rc : lc) + x;
+      const sq_u32x4 h = reinterpret_cast<const sq_u32x4_a8*>(reinterpret_cast<const char*>(ch) + 16)->v;   // pos, first, pad2, n_mems | fw << 16 | ..
+      s_tid[gi][side][x] = ch->tid; s_pos[gi][side][x] = (int32_t)h.x; s_meta[gi][side][x] = ((h.w >> 16) & 1u) | ((uint32_t)ch->read_len << 1); s_sc[gi][side][x] = ch->score;
+    }
+  }
+  __syncthreads();
+  // pair test of join_fragment<> / pair_ok from the LDS copy
+  auto pair = [&](uint32_t a, uint32_t b, int32_t* fl, bool* dv) -> bool {
+    const uint32_t ma = s_meta[gi][0][a], mb = s_meta[gi][1][b];
+    if ((ma & 1u) == (mb & 1u)) return false;
+    const bool afw = (ma & 1u) != 0;
+    const int32_t fpos = afw ? s_pos[gi][0][a] : s_pos[gi][1][b], rpos = afw ? s_pos[gi][1][b] : s_pos[gi][0][a];
+    const int32_t rlen = (int32_t)((afw ? mb : ma) >> 1);
+    if (rpos < fpos) { *dv = true; if (!P.allow_dovetail) return false; }
+    const int32_t fr = rpos + rlen - fpos;
+    if (fr <= 0 || fr > (int32_t)P.frag_len_max) return false;
+    *fl = fr; return true;
+  };
+  // right-chain range of left chain a: the chains of an end are sorted by transcript
+  auto rrange = [&](uint32_t a, uint32_t* j0, uint32_t* j1) {
+    const uint32_t t = s_tid[gi][0][a]; uint32_t lo = 0, hi = nr;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (s_tid[gi][1][m] < t) lo = m + 1; else hi = m; }
+    uint32_t e = lo; while (e < nr && s_tid[gi][1][e] == t) ++e;
+    *j0 = lo; *j1 = e;
+  };
+  const bool grp = act && !big;
+  if (grp) {
+    for (uint32_t a = (uint32_t)gl; a < nl; a += JG) {
+      uint32_t j0, j1; rrange(a, &j0, &j1);
+      for (uint32_t b = j0; b < j1; ++b) { int32_t fl; if (!pair(a, b, &fl, &dove)) continue; const double cov = s_sc[gi][0][a] + s_sc[gi][1][b]; if (cov > best) best = cov; }
+    }
+  }
+  // group-wide best coverage and dovetail flag (all lanes take part: inactive groups carry the neutral values)
+#pragma unroll
+  for (int sft = 1; sft < JG; sft <<= 1) { const double o = __shfl_xor(best, sft, 64); if (o > best) best = o; const int d = __shfl_xor((int)dove, sft, 64); dove = dove || d; }
+  const bool pairs = grp && best >= 0.0;
+  if (pairs) {
+    thr = P.consensus_frac * best;
+    for (uint32_t a = (uint32_t)gl; a < nl; a += JG) {   // best coverage of left chain a among its pairs that pass the consensus threshold
+      uint32_t j0, j1; rrange(a, &j0, &j1); double bt = 0.0; bool d2;
+      for (uint32_t b = j0; b < j1; ++b) { int32_t fl; if (!pair(a, b, &fl, &d2)) continue; const double cov = s_sc[gi][0][a] + s_sc[gi][1][b]; if (cov < thr) continue; if (cov > bt) bt = cov; }
+      s_bt[gi][a] = bt;
+    }
+  }
+  __syncthreads();
+  if (pairs) {
+    for (uint32_t a = (uint32_t)gl; a < nl; a += JG) {   // per-transcript best: the left chains of one transcript are neighbours
+      const uint32_t t = s_tid[gi][0][a]; double bt = s_bt[gi][a];
+      for (uint32_t x = a; x-- > 0 && s_tid[gi][0][x] == t;) if (s_bt[gi][x] > bt) bt = s_bt[gi][x];
+      for (uint32_t x = a + 1; x < nl && s_tid[gi][0][x] == t; ++x) if (s_bt[gi][x] > bt) bt = s_bt[gi][x];
+      const double pthr = P.post_thr * bt;
+      uint32_t j0, j1; rrange(a, &j0, &j1); uint32_t c = 0; bool d2;
+      for (uint32_t b = j0; b < j1; ++b) { int32_t fl; if (!pair(a, b, &fl, &d2)) continue; const double cov = s_sc[gi][0][a] + s_sc[gi][1][b]; if (cov < thr || cov < pthr) continue; ++c; }
+      s_cnt[gi][a] = c;
+    }
+  } else if (grp && P.allow_orphans) {
+    double ob = 0.0;
+    for (uint32_t i = (uint32_t)gl; i < nl + nr; i += JG) { const double sc = i < nl ? s_sc[gi][0][i] : s_sc[gi][1][i - nl]; if (sc > ob) ob = sc; }
+    othr = ob;
+  }
+  // the orphan threshold needs the group maximum (neutral 0 elsewhere)
+#pragma unroll
+  for (int sft = 1; sft < JG; sft <<= 1) { const double o = __shfl_xor(othr, sft, 64); if (o > othr) othr = o; }
+  othr = P.orphan_thr * othr;
+  __syncthreads();
+  // counts -> offsets (lane 0 of the group walks them: at most JG_CAP entries), total per fragment
+  uint32_t tot = 0;
+  if (pairs) {
+    if (gl == 0) { for (uint32_t a = 0; a < nl; ++a) { const uint32_t c = s_cnt[gi][a]; s_cnt[gi][a] = tot; tot += c; } cnt = tot; }
+  } else if (grp && P.allow_orphans && gl == 0) {
+    for (uint32_t a = 0; a < nl; ++a) if (s_sc[gi][0][a] >= othr) ++tot;
+    for (uint32_t b = 0; b < nr; ++b) if (s_sc[gi][1][b] >= othr) ++tot;
+    cnt = tot;
+  }
+  const uint64_t start0 = join_alloc(gl == 0 ? cnt : 0u, cursor);   // ends with a barrier: the offsets in s_cnt are visible to the group
+  const uint32_t lead = (uint32_t)((threadIdx.x & 63) & ~(JG - 1));
+  const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(start0 >> 32), (int)lead, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)start0, (int)lead, 64);
+  cnt = (uint32_t)__shfl((int)cnt, (int)lead, 64);
+  if (!act) return;
+  if (gl == 0) { n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0); }
+  if (cnt == 0 || start + cnt > cand_cap) return;
+  sq_cand_dev* out = cands + start;
+  if (big) { if (gl == 0) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); } }
+  else if (pairs) {
+    for (uint32_t a = (uint32_t)gl; a < nl; a += JG) {
+      const uint32_t t = s_tid[gi][0][a]; double bt = s_bt[gi][a];
+      for (uint32_t x = a; x-- > 0 && s_tid[gi][0][x] == t;) if (s_bt[gi][x] > bt) bt = s_bt[gi][x];
+      for (uint32_t x = a + 1; x < nl && s_tid[gi][0][x] == t; ++x) if (s_bt[gi][x] > bt) bt = s_bt[gi][x];
+      const double pthr = P.post_thr * bt;
+      uint32_t j0, j1; rrange(a, &j0, &j1); uint32_t w = s_cnt[gi][a]; bool d2;
+      for (uint32_t b = j0; b < j1; ++b) {
+        int32_t fl; if (!pair(a, b, &fl, &d2)) continue; const double cov = s_sc[gi][0][a] + s_sc[gi][1][b]; if (cov < thr || cov < pthr) continue;
+        cand_init(out[w], cov, t, lbase + a, rbase + b, (uint32_t)fl, SQ_MS_PAIRED_END_PAIRED); ++w;
+      }
+    }
+  } else if (gl == 0) {   // orphans: pad[0] remembers which end anchors the candidate (see join_fragment<>)
+    uint32_t w = 0;
+    for (uint32_t a = 0; a < nl; ++a) if (s_sc[gi][0][a] >= othr) { cand_init(out[w], s_sc[gi][0][a], s_tid[gi][0][a], lbase + a, 0xFFFFFFFFu, 0, SQ_MS_PAIRED_END_LEFT); out[w].pad[0] = 1; ++w; }
+    for (uint32_t b = 0; b < nr; ++b) if (s_sc[gi][1][b] >= othr) { cand_init(out[w], s_sc[gi][1][b], s_tid[gi][1][b], 0xFFFFFFFFu, rbase + b, 0, SQ_MS_PAIRED_END_RIGHT); out[w].pad[0] = 2; ++w; }
+  }
+  for (uint32_t i = (uint32_t)gl; i < cnt; i += JG) cand_frag[start + i] = f;
 }
 
 // ---- a4 scoring --------------------------------------------------------------------------------
