@@ -91,6 +91,7 @@ struct sq_ctx {
   // seeds / MEMs
   sq_dbuf<sq_unimem_dev> unimems; sq_dbuf<uint32_t> n_uni; sq_dbuf<uint32_t> n_proj; sq_dbuf<uint64_t> mem_off;
   sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;
+  sq_dbuf<uint32_t> dp_bh, dp_perm; sq_dbuf<uint64_t> dp_off;   // DP queue order (k_dp_hist / k_dp_scatter)
   sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
   sq_dbuf<uint32_t> mlist, mlbase; sq_dbuf<uint64_t> lkey, lval;   // read ends by MEM-count class (mem_kernels.h); sorted compact buffer of the large class
   // chains

@@ -220,7 +220,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->mval.free_();
   c->mkey2.free_();
   c->mval2.free_();
-  c->sort_tmp.free_();
+  c->sort_tmp.free_(); c->dp_bh.free_(); c->dp_perm.free_(); c->dp_off.free_();
   c->cf.free_();
   c->cp.free_();
   c->mnext.free_();
@@ -531,7 +531,15 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
       }
       S.dpq = c->dpq.p; S.dpq_cap = (uint32_t)c->dpq.n;
     }
-    if (hcount[0]) k_dp<<<(hcount[0] + 63) / 64, 64, 0, st>>>(P, S, hcount[0], c->cands.p, cand_frag.p, paired);
+    if (hcount[0]) {
+      const uint32_t nq = hcount[0], nb = std::min<uint32_t>(1024u, (nq + 4095) / 4096), chunk = (nq + nb - 1) / nb;
+      if (c->dp_bh.ensure((size_t)DP_CLASSES * nb + 8) || c->dp_off.ensure((size_t)DP_CLASSES * nb + 8) || c->dp_perm.ensure((size_t)nq + 8) ||
+          c->sort_tmp.ensure((size_t)scan_tiles((uint64_t)DP_CLASSES * nb) * 8 + 256)) { sq_set_error("device allocation failed (DP queue order)"); return SQ_ERR_NOMEM; }
+      k_dp_hist<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_bh.p);
+      exclusive_scan_u32_u64(c->dp_bh.p, c->dp_off.p, (uint64_t)DP_CLASSES * nb, (uint64_t*)c->sort_tmp.p, st);
+      k_dp_scatter<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_off.p, c->dp_perm.p);
+      k_dp<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);
+    }
     sq_prof_mark(c, SG_DP);
   }
   if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p,

@@ -1216,16 +1216,42 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5))) k_score(sq_map_params P,
 // One thread per queued region; both DP rows (H, F) live in VGPRs (launch bound 64 -> no spills) and
 // the 31 target bases under the band ride in one 64-bit window that shifts by one base per row, so a
 // row costs one query base + one target base fetch instead of 31 gathers.
+// [r2] The rows of a DP region (its query length) decide how long its lane runs; in queue order a wave waited for its longest region with
+// 44 % of the lanes active.  A counting sort of the queue by length class (longest first) makes the waves uniform: per-block LDS
+// histograms, one scan (scan_kernels.h), a scatter of region indices; k_dp reads its region through the permutation.
+#define DP_CLASSES 32
+__device__ inline uint32_t dp_class(int n) { const uint32_t c = (uint32_t)n >> 3; return (DP_CLASSES - 1) - (c < DP_CLASSES - 1 ? c : DP_CLASSES - 1); }
+__global__ void __launch_bounds__(256) k_dp_hist(const sq_dp_item* __restrict__ q, uint32_t n, uint32_t chunk, uint32_t nb, uint32_t* __restrict__ bh) {
+  __shared__ uint32_t h[DP_CLASSES];
+  if (threadIdx.x < DP_CLASSES) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+  for (uint32_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) atomicAdd(&h[dp_class(q[i].n)], 1u);
+  __syncthreads();
+  if (threadIdx.x < DP_CLASSES) bh[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];   // class-major: the scan yields (class, block) offsets
+}
+__global__ void __launch_bounds__(256) k_dp_scatter(const sq_dp_item* __restrict__ q, uint32_t n, uint32_t chunk, uint32_t nb, const uint64_t* __restrict__ off,
+    uint32_t* __restrict__ perm) {
+  __shared__ uint32_t h[DP_CLASSES];
+  if (threadIdx.x < DP_CLASSES) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+  for (uint32_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) {
+    const uint32_t c = dp_class(q[i].n); const uint32_t r = atomicAdd(&h[c], 1u);
+    perm[off[c * nb + blockIdx.x] + r] = i;
+  }
+}
+
 __device__ inline uint32_t dp_tbase(const uint64_t* refseq, const sq_dp_item& it, int x) {   // target base x of the region (0 when outside)
   if (x < 0 || x >= it.tl) return 0u;
   return sq_fetch_base(refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * x));
 }
-__global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
     const uint32_t* __restrict__ cand_frag,
-    uint32_t paired) {
+    uint32_t paired, const uint32_t* __restrict__ perm) {
   uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii >= nitems) return;
-  const sq_dp_item it = S.dpq[ii];
+  const sq_dp_item it = S.dpq[perm[ii]];   // regions in the order of k_dp_scatter: the 64 lanes of a wave run about the same number of rows
   const uint32_t f = cand_frag[it.cand];
   const uint32_t end_id = paired ? 2 * f + it.end : f;
   ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
@@ -1242,8 +1268,14 @@ __global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t
 #pragma unroll
   for (int b = 0; b < BW; ++b) twin |= (uint64_t)dp_tbase(S.refseq, it, b - W) << (2 * b);
   bool hopeless = false;
+  // the query and the target advance one base per row: their packed words are fetched once per 32 rows, not once per row
+  int q_wi = -1; uint64_t q_w = 0, q_n = 0; int64_t t_wi = -1; uint64_t t_w = 0;
   for (int i = 1; i <= n; ++i) {
-    const uint32_t qb = norm_base(r, fw, it.qstart + it.qdir * (i - 1));
+    uint32_t qb;
+    { const int x = it.qstart + it.qdir * (i - 1); const int idx = fw ? x : r.L - 1 - x; const int wi = idx >> 5;
+      if (wi != q_wi) { q_wi = wi; q_w = r.w[wi]; q_n = r.nm[idx >> 6]; }
+      const uint32_t b = ((q_n >> (idx & 63)) & 1) ? 4u : ((uint32_t)(q_w >> ((idx & 31) * 2)) & 3u);
+      qb = fw ? b : (b > 3 ? 4u : 3u - b); }
     int32_t left_h = SQ_NEG_INF, left_e = SQ_NEG_INF, rowmax = SQ_NEG_INF;
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
@@ -1265,7 +1297,10 @@ __global__ void __launch_bounds__(64) k_dp(sq_map_params P, ScoreCtx S, uint32_t
     }
     // every remaining query base adds at most `ma`: once even that cannot reach the budget the end is invalid
     if ((int64_t)rowmax + (int64_t)P.ma * (n - i) < (int64_t)it.budget) { hopeless = true; break; }
-    twin = (twin >> 2) | ((uint64_t)dp_tbase(S.refseq, it, i + W) << (2 * (BW - 1)));
+    { const int x = i + W; uint32_t tb = 0;
+      if (x < it.tl) { const int64_t gp = it.tstart + (int64_t)it.tdir * x; const int64_t wi = gp >> 5; if (wi != t_wi) { t_wi = wi; t_w = S.refseq[wi]; }
+        tb = (uint32_t)(t_w >> ((gp & 31) * 2)) & 3u; }
+      twin = (twin >> 2) | ((uint64_t)tb << (2 * (BW - 1))); }
   }
   sq_cand_dev* c = &cands[it.cand];
   if (hopeless) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; return; }
