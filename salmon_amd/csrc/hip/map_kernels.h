@@ -110,6 +110,7 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 // lane does ONE probe step per loop trip and, when its read end is finished, takes the next one
 // from a global cursor (one atomic per wave via ballot).  The persistent grid keeps every lane busy
 // until the batch is drained; results are keyed by read end, so they do not depend on scheduling.
+#define SEED_SPEC 4   // probe positions laid out per trip (measured: 1 -> 7.7 ms, 4 -> 6.6 ms, 8 -> 7.7 ms per 4x10^6 pairs: wider costs registers and wasted filter words)
 template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
@@ -153,13 +154,50 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
       const int L = r.L; bool done = false;
       if (!(L >= k && pos + k <= L && nu < SQ_MAX_UNIMEMS)) done = true;
       else {
-        uint64_t nb = fetch_bits(r.nm, (uint32_t)pos, (uint32_t)k);
-        if (nb) pos = pos + (63 - __clzll((long long)nb)) + 1;
-        else {
-          uint64_t km = sq_fetch_bases(r.w, (uint64_t)pos, (uint32_t)k);
+        // [r2] Most probes are misses that end at the membership filter, and where the walk goes after a miss does not depend on
+        // memory: the next SEED_SPEC probe positions (N skips applied) are laid out first and their filter words requested
+        // together; the walk then takes the first position the filter lets through.  Positions behind it are simply laid out again
+        // on the next trip, so the look-ups performed — and counted — are those of the one-at-a-time walk.
+        const int nspec = d.kfilter ? SEED_SPEC : 1;   // without a filter: one probe per trip, as before
+        int cp[SEED_SPEC]; uint64_t ckm[SEED_SPEC]; bool cv[SEED_SPEC], cpass[SEED_SPEC]; int p = pos; bool ended = false;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          cv[s2] = false; cp[s2] = p; ckm[s2] = 0; cpass[s2] = false;
+          if (s2 < nspec) {
+            while (!ended) {
+              if (p + k > L) { ended = true; break; }
+              const uint64_t nb = fetch_bits(r.nm, (uint32_t)p, (uint32_t)k);
+              if (nb) { p = p + (63 - __clzll((long long)nb)) + 1; continue; }
+              cv[s2] = true; break;
+            }
+            if (cv[s2]) {
+              cp[s2] = p; ckm[s2] = sq_fetch_bases(r.w, (uint64_t)p, (uint32_t)k);
+              if (p < skip_until) { int np2 = p + alt; if (np2 > skip_until) np2 = skip_until; p = np2; } else p += 1;
+            }
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          if (cv[s2]) {
+            if (d.kfilter) { const uint64_t rc2 = sq_revcomp(ckm[s2], (uint32_t)k); const uint64_t h = sq_kf_hash(ckm[s2] < rc2 ? ckm[s2] : rc2), msk = sq_kf_mask(h);
+              cpass[s2] = (d.kfilter[sq_kf_word(h, d.kfilter_words)] & msk) == msk; }
+            else cpass[s2] = true;
+          }
+        }
+        int pick = -1; uint32_t looked = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (pick < 0 && cv[s2]) { ++looked; if (cpass[s2]) pick = s2; }
+        tot_look += looked;
+        uint64_t km = 0; int ppos = pos;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (s2 == pick) { km = ckm[s2]; ppos = cp[s2]; }
+        if (pick < 0) {   // every laid-out probe was a miss, or the read ran out: the walk continues behind them
+          pos = p;
+          if (ended) done = true;
+        } else {
+          pos = ppos;
           uint64_t u; uint32_t off; int fw;
-          ++tot_look;
-          if (!sq_dict_lookup_t<KT, MT>(d, km, &u, &off, &fw)) {
+          if (!sq_dict_lookup_t<KT, MT>(d, km, &u, &off, &fw, d.kfilter != nullptr)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
             const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);

@@ -193,11 +193,11 @@ SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_
 // probe kernel is instruction-issue bound: constant shifts/masks and fully unrolled window loops
 // roughly halve its instruction count); 0 = take them from the view.
 template <int KT, int MT>
-SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
+SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw, bool filtered = false) {
   const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
   const uint64_t mm = sq_kmask(m);
   const uint64_t rc = sq_revcomp(kmer, k);
-  if (d.kfilter) {   // membership filter first: most misses end here after one 8-byte load
+  if (d.kfilter && !filtered) {   // membership filter first: most misses end here after one 8-byte load (`filtered`: the caller has asked it already)
     const uint64_t h = sq_kf_hash(kmer < rc ? kmer : rc), msk = sq_kf_mask(h);
     if ((d.kfilter[sq_kf_word(h, d.kfilter_words)] & msk) != msk) return 0;
   }
