@@ -164,7 +164,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
              c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
                  c->mem_off.ensure((size_t)nends + 2) ||
              c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) ||
-                 c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(16) ||
+                 c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(32) ||
              c->frag_flags.ensure(max_batch_reads) || c->n_aln.ensure(max_batch_reads + 1) ||
                  c->aln_off.ensure((size_t)max_batch_reads + 2) ||
                  c->aln_off_b1.ensure((size_t)max_batch_reads + 2) || c->map_type.ensure(max_batch_reads) ||
@@ -383,7 +383,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     d_seq = c->seq.p; d_seq_off = c->seq_off.p;
   }
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
-  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint32_t), st));
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
   sq_prof_begin(c);
   k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
@@ -406,14 +406,14 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
   // size classes of the ends (mem_kernels.h); their counts come back with the MEM total in the same read-back
-  if (c->mlist.ensure((size_t)4 * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
-  uint32_t* list_t = c->mlist.p; uint32_t* list_s = c->mlist.p + nrec; uint32_t* list_m = c->mlist.p + 2 * (size_t)nrec; uint32_t* list_l = c->mlist.p + 3 * (size_t)nrec;
-  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 10, 0, 5 * sizeof(uint32_t), st));
-  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, list_t, list_s, list_m, list_l, c->mlbase.p, c->n_chains.p, c->counters.p + 10);
-  uint64_t total_mems = 0; uint32_t hcls[5] = {0, 0, 0, 0, 0};
+  if (c->mlist.ensure((size_t)MK_NCLS * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
+  uint32_t* const lists = c->mlist.p; uint32_t* const list_l = lists + (size_t)(MK_NCLS - 1) * nrec;
+  SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 16, 0, (MK_NCLS + 1) * sizeof(uint32_t), st));
+  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, lists, c->mlbase.p, c->n_chains.p, c->counters.p + 16);
+  uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
-  SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 10, sizeof(hcls), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 16, sizeof(hcls), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
   c->last_total_mems = total_mems;
   if (total_mems >= 0x7FFFFFF0ull) {   // 32-bit slab indices (candidates name chains by slab index; recovery doubles the slabs)
@@ -425,13 +425,15 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   if (c->mkey2.ensure(MP) || c->mval2.ensure(MP) || c->mnext.ensure(MP) || c->chains.ensure(recover ? 2 * MP : MP)) {
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey2.p; uint64_t* sval = c->mval2.p;
-  const uint32_t nT = hcls[0], nS = hcls[1], nM = hcls[2], nL = hcls[3], memsL = hcls[4];
-  if (nT) k_mems<16, MK_T_CAP, 256><<<(nT + 15) / 16, 256, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_t, nT,
-      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
-  if (nS) k_mems<16, MK_S_CAP, 256><<<(nS + 15) / 16, 256, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_s, nS,
-      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
-  if (nM) k_mems<64, MK_M_CAP, 128><<<(nM + 1) / 2, 128, 0, st>>>(di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, list_m, nM,
-      c->rlen.p, c->unimems.p, c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p);
+  const uint32_t nL = hcls[MK_NCLS - 1], memsL = hcls[MK_NCLS];
+#define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, lists + (size_t)(cls) * nrec, hcls[cls], c->rlen.p, c->unimems.p, \
+      c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
+  if (hcls[0]) k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0));
+  if (hcls[1]) k_mems<16, MK_X_CAP, 256><<<(hcls[1] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(1));
+  if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
+  if (hcls[3]) k_mems<16, MK_S_CAP, 256><<<(hcls[3] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(3));
+  if (hcls[4]) k_mems<64, MK_M_CAP, 128><<<(hcls[4] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(4));
+#undef SQ_MEMS_ARGS
   sq_prof_mark(c, SG_PROJECT);
   if (nL) {   // ends with more than MK_M_CAP MEMs (deep repeats): compact projection, library radix sort, back into the slabs, HBM chaining
     const size_t LP = (size_t)memsL + 8;

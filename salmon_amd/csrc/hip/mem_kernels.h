@@ -5,7 +5,8 @@
 // records crossed HBM about ten times, and the thread-per-end projection stored them 8 bytes at a time.)
 //
 // A read end with n projected MEMs is handled by a group of G lanes:
-//   n <= 32    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 32, 256>
+//   n <= 16    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 16, 256>
+//   n <= 32    G = 16                                                                           k_mems<16, 32, 256>
 //   n <= 64    G = 16  (the same with twice the LDS rows: 44 KB per block hold 3 blocks per CU, 28 KB hold 5)     k_mems<16, 64, 256>
 //   n <= 1024  G = 64  (one wave per end)                                                       k_mems<64, 1024, 128>
 //   larger     the round-1 path on a compacted list (k_project_list -> radix sort -> k_chain)
@@ -17,37 +18,44 @@
 
 namespace sqk {
 
+#define MK_X_CAP 16
 #define MK_T_CAP 32
 #define MK_S_CAP 64
 #define MK_M_CAP 1024
 
 __device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// ends by size class; an end without MEMs has no chains.  ctr: [0] tiny [1] small [2] medium [3] large [4] MEMs of the large ends.
-// Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs four same-address atomics.
-__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ list_t,
-                              uint32_t* __restrict__ list_s, uint32_t* __restrict__ list_m, uint32_t* __restrict__ list_l, uint32_t* __restrict__ lbase,
-                              uint32_t* __restrict__ n_chains, uint32_t* __restrict__ ctr) {
-  __shared__ uint32_t s_cnt[4][16]; __shared__ uint32_t s_base[4];
+// ends by size class; an end without MEMs has no chains.  Classes (MEMs per end): 0: <= 8, 1: <= 16, 2: <= 32, 3: <= 64, 4: <= 1024,
+// 5: larger.  ctr[c] = ends in class c, ctr[6] = MEMs of the large ends.  Classes 0 and 1 share a kernel instantiation (as 2, 3 and 4
+// have theirs) but are launched from their own lists: the four ends of a wave then cost about the same, and a wave waits for its
+// slowest end.  Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs at most six cursor atomics.
+#define MK_NCLS 6
+__device__ inline int mk_class(uint32_t n) { return n <= 8 ? 0 : (n <= MK_X_CAP ? 1 : (n <= MK_T_CAP ? 2 : (n <= MK_S_CAP ? 3 : (n <= MK_M_CAP ? 4 : 5)))); }
+__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ lists /* [MK_NCLS][nends] */,
+                              uint32_t* __restrict__ lbase, uint32_t* __restrict__ n_chains, uint32_t* __restrict__ ctr) {
+  __shared__ uint32_t s_cnt[MK_NCLS][16]; __shared__ uint32_t s_base[MK_NCLS];
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
   const uint32_t n = e < nends ? n_proj[e] : 0;
-  const int cls = (e >= nends || n == 0) ? -1 : (n <= MK_T_CAP ? 0 : (n <= MK_S_CAP ? 1 : (n <= MK_M_CAP ? 2 : 3)));
+  const int cls = (e >= nends || n == 0) ? -1 : mk_class(n);
   if (e < nends && n == 0) n_chains[e] = 0;
-  unsigned long long m[4];
+  unsigned long long m[MK_NCLS];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { m[c] = __ballot(cls == c); if (lane == 0) s_cnt[c][wv] = (uint32_t)__popcll(m[c]); }
+  for (int c = 0; c < MK_NCLS; ++c) { m[c] = __ballot(cls == c); if (lane == 0) s_cnt[c][wv] = (uint32_t)__popcll(m[c]); }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < MK_NCLS) {
     uint32_t tot = 0;
     for (int w = 0; w < 16; ++w) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = tot; tot += v; }
     s_base[threadIdx.x] = tot ? atomicAdd(&ctr[threadIdx.x], tot) : 0u;
   }
   __syncthreads();
   if (cls >= 0) {
-    const uint32_t pos = s_base[cls] + s_cnt[cls][wv] + (uint32_t)__popcll(m[cls] & ((1ULL << lane) - 1));
-    if (cls == 0) list_t[pos] = e; else if (cls == 1) list_s[pos] = e; else if (cls == 2) list_m[pos] = e;
-    else { list_l[pos] = e; lbase[pos] = atomicAdd(&ctr[4], n); }
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int c = 0; c < MK_NCLS; ++c) if (c == cls) mine = m[c];
+    const uint32_t pos = s_base[cls] + s_cnt[cls][wv] + (uint32_t)__popcll(mine & ((1ULL << lane) - 1));
+    lists[(size_t)cls * nends + pos] = e;
+    if (cls == MK_NCLS - 1) lbase[pos] = atomicAdd(&ctr[MK_NCLS], n);
   }
 }
 

@@ -513,19 +513,26 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
         compatFrag = (j == 0 && assigned && ((cb >> gsh) & ((1u << MB_G) - 1))) ? 1 : 0; }
     }
   }
-  // library-format counts: one atomic per (wave, format)
+  // library-format counts and numCompatibleFragments (:811-815): summed per block in LDS, one atomic per (block, format) — a launch has
+  // 5000 waves and the same-address atomics of one per wave were a large part of its 190 us
+  __shared__ unsigned long long s_lib[64]; __shared__ unsigned long long s_cf;
+  if (threadIdx.x < 64) s_lib[threadIdx.x] = 0;
+  if (threadIdx.x == 64) s_cf = 0;
+  __syncthreads();
   uint64_t any = fmtSeen; for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s, 64);
   while (any) {
     int f = __ffsll((long long)any) - 1;
     any &= any - 1;
     unsigned long long m = __ballot((fmtSeen >> f) & 1);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&V.lib_counts[f], (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_lib[f], (unsigned long long)__popcll(m));
   }
-  // numCompatibleFragments (:811-815)
   {
     const unsigned long long m = __ballot(compatFrag);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&V.ctr[5], (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cf, (unsigned long long)__popcll(m));
   }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_lib[threadIdx.x]) atomicAdd(&V.lib_counts[threadIdx.x], s_lib[threadIdx.x]);
+  if (threadIdx.x == 64 && s_cf) atomicAdd(&V.ctr[5], s_cf);
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -1175,7 +1182,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, mb, c->reads_seen + r0, d_aln_off, d_aln,
         (const PreAln*)o->pre.p,
         o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, par, d_gcbin);
-    { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 64u); const int with_fld = burned_host ? 0 : 1;
+    { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 256u); const int with_fld = burned_host ? 0 : 1;
       k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, FM, nw, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, par); }
     if (burn_now) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
