@@ -23,7 +23,12 @@
 #define SQ_INVALID_SCORE INT32_MIN
 #define SQ_NEG_INF (-(1 << 29))
 
-struct sq_unimem_dev { uint32_t unitig, ustart; uint16_t qpos, len; uint8_t fw, pad[3]; };  // 16 B
+struct sq_unimem_dev {   // 32 B: the uni-MEM, and what its projection needs of the contig table and the unitig (k_seed has them at hand)
+  uint32_t unitig, ustart; uint16_t qpos, len; uint8_t fw, pad[3];
+  uint64_t ctab_a;      // start of the unitig's run in the contig table
+  uint32_t cnt, ulen;   // occurrences (0: more than maxOccsPerHit, not projected); unitig length
+};
+static_assert(sizeof(sq_unimem_dev) == 32, "sq_unimem_dev layout");
 
 struct sq_chain_dev {   // 40 B.  Bytes 16..31 are everything the scorer reads of a chain (its transcript is in the candidate): ONE 16-byte load
   double score; uint32_t tid; int32_t last_end;
@@ -91,6 +96,7 @@ struct sq_ctx {
   // seeds / MEMs
   sq_dbuf<sq_unimem_dev> unimems; sq_dbuf<uint32_t> n_uni; sq_dbuf<uint32_t> n_proj; sq_dbuf<uint64_t> mem_off;
   sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;
+  sq_dbuf<uint4> mlinfo;   // list entries of the MEM size classes (mem_kernels.h)
   sq_dbuf<uint32_t> dp_bh, dp_perm; sq_dbuf<uint64_t> dp_off;   // DP queue order (k_dp_hist / k_dp_scatter)
   sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
   sq_dbuf<uint32_t> mlist, mlbase; sq_dbuf<uint64_t> lkey, lval;   // read ends by MEM-count class (mem_kernels.h); sorted compact buffer of the large class

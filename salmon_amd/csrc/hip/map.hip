@@ -220,7 +220,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->mval.free_();
   c->mkey2.free_();
   c->mval2.free_();
-  c->sort_tmp.free_(); c->dp_bh.free_(); c->dp_perm.free_(); c->dp_off.free_();
+  c->mlinfo.free_(); c->sort_tmp.free_(); c->dp_bh.free_(); c->dp_perm.free_(); c->dp_off.free_();
   c->cf.free_();
   c->cp.free_();
   c->mnext.free_();
@@ -406,10 +406,11 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
   int rc = exclusive_scan_u32(c, c->n_proj.p, c->mem_off.p, nrec + 1); if (rc) return rc;
   // size classes of the ends (mem_kernels.h); their counts come back with the MEM total in the same read-back
-  if (c->mlist.ensure((size_t)MK_NCLS * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
+  if (c->mlist.ensure((size_t)MK_NCLS * nrec + 8) || c->mlbase.ensure((size_t)nrec + 8) || c->mlinfo.ensure((size_t)(MK_NCLS - 1) * nrec + 8)) { sq_set_error("device allocation failed (MEM class lists)"); return SQ_ERR_NOMEM; }
   uint32_t* const lists = c->mlist.p; uint32_t* const list_l = lists + (size_t)(MK_NCLS - 1) * nrec;
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 16, 0, (MK_NCLS + 1) * sizeof(uint32_t), st));
-  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, lists, c->mlbase.p, c->n_chains.p, c->counters.p + 16);
+  k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, c->mem_off.p, c->n_uni.p, c->rlen.p, lists, c->mlinfo.p, c->mlbase.p, c->n_chains.p,
+      c->counters.p + 16);
   uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
@@ -426,8 +427,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey2.p; uint64_t* sval = c->mval2.p;
   const uint32_t nL = hcls[MK_NCLS - 1], memsL = hcls[MK_NCLS];
-#define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, lists + (size_t)(cls) * nrec, hcls[cls], c->rlen.p, c->unimems.p, \
-      c->n_uni.p, c->mem_off.p, skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
+#define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, c->mlinfo.p + (size_t)(cls) * nrec, hcls[cls], c->unimems.p, \
+      skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
   if (hcls[0]) k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0));
   if (hcls[1]) k_mems<16, MK_X_CAP, 256><<<(hcls[1] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(1));
   if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
@@ -471,7 +472,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
       k_join2<<<nblk(n), TB, 0, st>>>(P, n, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p,
           c->cand_frag.p, c->cands.n,
           c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);
-      if (paired) k_join2_group<<<(n + 15) / 16, 256, 0, st>>>(P, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p,
+      if (paired) k_join2_group<<<std::min<uint32_t>((n + 15) / 16, 192u * 12u), 256, 0, st>>>(P, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p,
           c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);
       else k_join2_rest<<<nblk(n), TB, 0, st>>>(P, paired, c->mem_off.p, c->chains.p, c->n_chains.p, c->n_cand.p, c->cand_off.p, c->cands.p, c->cand_frag.p,
           c->cands.n, c->frag_flags.p, c->stats.p + ST_CANDS, rest, c->counters.p + 15);

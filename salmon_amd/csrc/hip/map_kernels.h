@@ -229,8 +229,9 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             m.fw = (uint8_t)fw;
             m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
             m.pad[0] = m.pad[1] = m.pad[2] = 0;
+            const uint64_t ca = ctab_off[u]; const uint64_t occ = ctab_off[u + 1] - ca;
+            m.ctab_a = ca; m.cnt = occ <= P.max_occ ? (uint32_t)occ : 0u; m.ulen = (uint32_t)ulen;
             out[nu++] = m;
-            uint64_t occ = ctab_off[u + 1] - ctab_off[u];
             if (occ <= P.max_occ) np += (uint32_t)occ;
             if (rend) done = true;
             else { int ee = pos + len; pos = pos + len - k + 1; skip_until = uend ? -1 : ee + 1; }
@@ -691,12 +692,12 @@ __global__ void __launch_bounds__(256) k_join2_group(sq_map_params P, const uint
                              sq_cand_dev* __restrict__ cands, uint32_t* __restrict__ cand_frag, uint64_t cand_cap, uint8_t* __restrict__ frag_flags,
                              unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ rest, const uint32_t* __restrict__ nrest) {
   constexpr int GPB = 256 / JG, CP = JG_CAP + 1;
-  const uint32_t nlist = *nrest;
-  if (blockIdx.x * GPB >= nlist) return;   // the grid is sized for the worst case: whole blocks leave here
+  const uint32_t nlist = *nrest;   // the list length is only known on the device: a fixed grid walks the list
   __shared__ uint32_t s_tid[GPB][2][CP]; __shared__ int32_t s_pos[GPB][2][CP]; __shared__ uint32_t s_meta[GPB][2][CP];   // meta: fw | read_len << 1
   __shared__ double s_sc[GPB][2][CP]; __shared__ double s_bt[GPB][CP]; __shared__ uint32_t s_cnt[GPB][CP];
   const int gi = (int)(threadIdx.x / JG), gl = (int)(threadIdx.x % JG);
-  const uint32_t li = blockIdx.x * GPB + (uint32_t)gi;
+  for (uint32_t b0 = blockIdx.x * GPB; b0 < nlist; b0 += gridDim.x * GPB) {
+  const uint32_t li = b0 + (uint32_t)gi;
   const bool act = li < nlist;
   const uint32_t f = act ? rest[li] : 0;
   uint32_t nl = 0, nr = 0, lbase = 0, rbase = 0;
@@ -788,9 +789,8 @@ __global__ void __launch_bounds__(256) k_join2_group(sq_map_params P, const uint
   const uint32_t lead = (uint32_t)((threadIdx.x & 63) & ~(JG - 1));
   const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(start0 >> 32), (int)lead, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)start0, (int)lead, 64);
   cnt = (uint32_t)__shfl((int)cnt, (int)lead, 64);
-  if (!act) return;
-  if (gl == 0) { n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0); }
-  if (cnt == 0 || start + cnt > cand_cap) return;
+  if (act && gl == 0) { n_cand[f] = cnt; cand_start[f] = start; frag_flags[f] = (uint8_t)(dove ? 1 : 0); }
+  if (act && cnt != 0 && start + cnt <= cand_cap) {
   sq_cand_dev* out = cands + start;
   if (big) { if (gl == 0) { bool d2; join_fragment<true>(P, lc, nl, lbase, rc, nr, rbase, out, &d2); } }
   else if (pairs) {
@@ -811,6 +811,9 @@ __global__ void __launch_bounds__(256) k_join2_group(sq_map_params P, const uint
     for (uint32_t b = 0; b < nr; ++b) if (s_sc[gi][1][b] >= othr) { cand_init(out[w], s_sc[gi][1][b], s_tid[gi][1][b], 0xFFFFFFFFu, rbase + b, 0, SQ_MS_PAIRED_END_RIGHT); out[w].pad[0] = 2; ++w; }
   }
   for (uint32_t i = (uint32_t)gl; i < cnt; i += JG) cand_frag[start + i] = f;
+  }
+  __syncthreads();   // the next fragment of the group reuses the LDS rows
+  }
 }
 
 // ---- a4 scoring --------------------------------------------------------------------------------

@@ -31,8 +31,12 @@ __device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wo
 // slowest end.  Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs at most six cursor atomics.
 #define MK_NCLS 6
 __device__ inline int mk_class(uint32_t n) { return n <= 8 ? 0 : (n <= MK_X_CAP ? 1 : (n <= MK_T_CAP ? 2 : (n <= MK_S_CAP ? 3 : (n <= MK_M_CAP ? 4 : 5)))); }
-__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, uint32_t* __restrict__ lists /* [MK_NCLS][nends] */,
-                              uint32_t* __restrict__ lbase, uint32_t* __restrict__ n_chains, uint32_t* __restrict__ ctr) {
+// A list entry carries what k_mems needs to start on the end — slab offset, MEM and uni-MEM counts, read length — so that its first load
+// is its only load before the uni-MEM records: x = end, y = MEMs | uni-MEMs << 16 | length << 22, (z, w) = slab offset.
+__global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, const uint64_t* __restrict__ mem_off,
+                              const uint32_t* __restrict__ n_uni, const uint16_t* __restrict__ rlen, uint32_t* __restrict__ lists /* [MK_NCLS][nends] */,
+                              uint4* __restrict__ linfo /* [MK_NCLS - 1][nends] */, uint32_t* __restrict__ lbase, uint32_t* __restrict__ n_chains,
+                              uint32_t* __restrict__ ctr) {
   __shared__ uint32_t s_cnt[MK_NCLS][16]; __shared__ uint32_t s_base[MK_NCLS];
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -56,6 +60,7 @@ __global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint
     const uint32_t pos = s_base[cls] + s_cnt[cls][wv] + (uint32_t)__popcll(mine & ((1ULL << lane) - 1));
     lists[(size_t)cls * nends + pos] = e;
     if (cls == MK_NCLS - 1) lbase[pos] = atomicAdd(&ctr[MK_NCLS], n);
+    else { const uint64_t mo = mem_off[e]; linfo[(size_t)cls * nends + pos] = make_uint4(e, n | (n_uni[e] << 16) | ((uint32_t)rlen[e] << 22), (uint32_t)mo, (uint32_t)(mo >> 32)); }
   }
 }
 
@@ -64,8 +69,8 @@ struct MkHdr { uint64_t a; uint32_t cnt, ulen, ustart; uint16_t qpos, lenfw; }; 
 template <int G, int CAP, int TBK>
 __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab,
                                               const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost,
-                                              const uint32_t* __restrict__ list, uint32_t nlist, const uint16_t* __restrict__ rlen,
-                                              const sq_unimem_dev* __restrict__ um, const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off,
+                                              const uint4* __restrict__ list, uint32_t nlist,
+                                              const sq_unimem_dev* __restrict__ um,
                                               uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval, uint32_t* __restrict__ mnext,
                                               sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains) {
   constexpr int GPB = TBK / G, E = CAP / G;
@@ -92,17 +97,17 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
   __syncthreads();
   const uint32_t li = blockIdx.x * GPB + (uint32_t)gi;
   const bool act = li < nlist;
-  const uint32_t e = act ? list[li] : 0;
-  const uint64_t base = act ? mem_off[e] : 0;
-  const uint32_t n = act ? (uint32_t)(mem_off[e + 1] - base) : 0;
-  const uint32_t nu = act ? n_uni[e] : 0;
-  const int L = act ? (int)rlen[e] : 0;
-  // ---- uni-MEM headers: lane i fetches uni-MEM i, its contig-table run and its unitig's length ----
+  uint4 li4 = make_uint4(0, 0, 0, 0); if (act) li4 = list[li];
+  const uint32_t e = li4.x;
+  const uint64_t base = ((uint64_t)li4.w << 32) | li4.z;
+  const uint32_t n = li4.y & 0xFFFFu;
+  const uint32_t nu = (li4.y >> 16) & 0x3Fu;
+  const int L = (int)(li4.y >> 22);
+  // ---- uni-MEM headers: lane i fetches uni-MEM i; its contig-table run and unitig length came with it from k_seed ----
   for (uint32_t i = (uint32_t)gl; i < nu; i += G) {
     const sq_unimem_dev m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
-    const uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
-    MkHdr h; h.a = a; h.cnt = (b - a > P.max_occ) ? 0u : (uint32_t)(b - a);
-    h.ulen = (uint32_t)(uoff[m.unitig + 1] - uoff[m.unitig]); h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u));
+    MkHdr h; h.a = m.ctab_a; h.cnt = m.cnt;
+    h.ulen = m.ulen; h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u));
     g_h[i] = h;
   }
   mk_wsync();
