@@ -200,7 +200,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
           if (!sq_dict_lookup_t<KT, MT>(d, km, &u, &off, &fw, d.kfilter != nullptr)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
-            const uint64_t ub = d.uoff[u]; const int ulen = (int)(d.uoff[u + 1] - ub);
+            uint64_t ub, ue; sq_ld_pair(d.uoff + u, &ub, &ue); const int ulen = (int)(ue - ub);
             int len = k;
             int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
             bool mism = false;
@@ -229,7 +229,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             m.fw = (uint8_t)fw;
             m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
             m.pad[0] = m.pad[1] = m.pad[2] = 0;
-            const uint64_t ca = ctab_off[u]; const uint64_t occ = ctab_off[u + 1] - ca;
+            uint64_t ca, cb; sq_ld_pair(ctab_off + u, &ca, &cb); const uint64_t occ = cb - ca;
             m.ctab_a = ca; m.cnt = occ <= P.max_occ ? (uint32_t)occ : 0u; m.ulen = (uint32_t)ulen;
             out[nu++] = m;
             if (occ <= P.max_occ) np += (uint32_t)occ;

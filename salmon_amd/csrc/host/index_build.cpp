@@ -670,7 +670,8 @@ static int index_load_host_impl(const std::string& dir, sq_index** out) {
   const bool sane = h.k >= 3 && h.k <= 31 && (h.k & 1) && h.m >= 1 && h.m <= h.k && h.first_decoy <= h.nrefs &&
       idx->ref_len.size() == h.nrefs && idx->ref_clen.size() == h.nrefs && idx->ref_accum.size() == (size_t)h.nrefs + 1 &&
       !idx->uoff.empty() && idx->ctab_off.size() == idx->uoff.size() && idx->ctab_off.back() == idx->ctab.size() &&
-      idx->uoff.back() <= 32 * (uint64_t)idx->useq.size() && idx->ref_accum.back() <= 32 * (uint64_t)idx->refseq.size() &&
+      (idx->uoff.back() + 31) / 32 + 1 <= (uint64_t)idx->useq.size() && (idx->ref_accum.back() + 31) / 32 + 1 <= (uint64_t)idx->refseq.size() &&   // one padding word: the device reads word pairs
+
       idx->part_slot_off.size() == (size_t)h.n_parts + 1 && idx->part_bkt_off.size() == (size_t)h.n_parts + 1 &&
       (h.n_parts == 0 || (idx->part_slot_off.back() == idx->slots.size() && idx->part_bkt_off.back() == idx->pilots.size())) &&
       idx->skew_keys.size() == idx->skew_vals.size() && (idx->skew_keys.empty() || (idx->skew_keys.size() & (idx->skew_keys.size() - 1)) == 0);

@@ -38,12 +38,28 @@ SQ_HD uint64_t sq_revcomp(uint64_t x, uint32_t k) {
   return x >> (64 - 2 * k);
 }
 
+// two consecutive 8-byte words.  On the device they come with ONE 16-byte load: a second load instruction that touches a cache line
+// whose fill is still in flight parks the CU's in-order L1 until the fill arrives (every packed pool is padded by a word, and the
+// offset tables are read as (x[i], x[i+1]) pairs anyway).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint64_t sq_u64x2_t __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(8))) sq_u64x2_al8 { sq_u64x2_t v; };
+SQ_HD void sq_ld_pair(const uint64_t* p, uint64_t* a, uint64_t* b) { const sq_u64x2_t v = reinterpret_cast<const sq_u64x2_al8*>(p)->v; *a = v.x; *b = v.y; }
+#else
+SQ_HD void sq_ld_pair(const uint64_t* p, uint64_t* a, uint64_t* b) { *a = p[0]; *b = p[1]; }
+#endif
+
 // fetch `n` (<=32) bases starting at nt position p from a packed pool
 SQ_HD uint64_t sq_fetch_bases(const uint64_t* pool, uint64_t p, uint32_t n) {
   uint64_t w = p >> 5;
   uint32_t sh = (uint32_t)(p & 31) * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t a, b; sq_ld_pair(pool + w, &a, &b);
+  const uint64_t lo = (a >> sh) | (sh ? (b << (64 - sh)) : 0ULL);   // bits of b beyond 2n are masked off below
+#else
   uint64_t lo = pool[w] >> sh;
   if (sh != 0 && sh + 2 * n > 64) lo |= pool[w + 1] << (64 - sh);
+#endif
   return lo & sq_kmask(n);
 }
 SQ_HD uint32_t sq_fetch_base(const uint64_t* pool, uint64_t p) {
@@ -182,7 +198,7 @@ SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_
   if (s == kmer) f = 1;
   else if (s == rc) f = 0;
   else return 0;
-  const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
+  uint64_t b, e; sq_ld_pair(d.uoff + u, &b, &e);
   if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
   *unitig = u; *off = (uint32_t)((uint64_t)sp - b); *fw = f;
   return 1;
