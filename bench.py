@@ -55,13 +55,14 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         # every probe reads one word (a 64 B sector) of the k-mer membership filter; a probe that passes (every hit; < 1 % of the misses)
         # then walks 4 dependent sectors (pilot, slot record, string-pool word, unitig bounds) and a uni-MEM adds extension words,
         # contig-table bounds and its record
-        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32),
+        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32 + 16),
         "scan_mems": nrec * (4 + 8),
         # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
-        "k_mems": st["num_seeds"] * (16 + 16) + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (4 + 16 + 2 + 4),
+        # (the uni-MEM record carries its contig-table run since round 2: 32 B each, no bounds gathers; 16 B list entry per end)
+        "k_mems": st["num_seeds"] * 32 + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (16 + 4),
         "k_join_fill": st["num_chains"] * 40 + st["num_candidates"] * 52 + n_pairs * 16,
         "k_score": st["num_candidates"] * (48 * 2 + 2 * 40 + 2 * (96 + 64) + 4) + st["num_mems"] * 0,
-        "k_dp": st["num_dp_alignments"] * (48 + 96 + 64),
+        "k_dp": st["num_dp_alignments"] * (48 + 96 + 64 + 2 * 40 + 2 * 4),   # + the queue read twice more and the permutation (counting sort by length)
         "k_select": st["num_candidates"] * (48 * 2) + st["num_alignments"] * 40 + n_pairs * 30,
         "compact_alns": st["num_alignments"] * 80 + n_pairs * 28,
         "eq_flags_scan": st["num_alignments"] * 40 + n_pairs * 24,
