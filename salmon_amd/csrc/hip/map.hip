@@ -553,7 +553,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   sq_prof_mark(c, SG_SELECT);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
   rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off_ptr(buf), n + 1); if (rc) return rc;
-  k_compact_alns<<<nblk(n), TB, 0, st>>>(n, c->cand_off.p, c->aln_off_ptr(buf), c->n_aln.p, c->aln_slots.p, c->aln_ptr(buf));
+  if (total_cands) k_compact_alns<<<nblk(total_cands), TB, 0, st>>>(total_cands, cand_frag.p, c->cand_off.p, c->aln_off_ptr(buf), c->n_aln.p, c->aln_slots.p, c->aln_ptr(buf));
   SQ_HIP_CHECK(hipEventRecord(c->ev_map_done[buf], st));
   sq_prof_mark(c, SG_COMPACT);
   uint64_t total_aln = 0; unsigned long long hst[ST_N];
