@@ -110,7 +110,7 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 // lane does ONE probe step per loop trip and, when its read end is finished, takes the next one
 // from a global cursor (one atomic per wave via ballot).  The persistent grid keeps every lane busy
 // until the batch is drained; results are keyed by read end, so they do not depend on scheduling.
-#define SEED_SPEC 4   // probe positions laid out per trip (measured: 1 -> 7.7 ms, 4 -> 6.6 ms, 8 -> 7.7 ms per 4x10^6 pairs: wider costs registers and wasted filter words)
+#define SEED_SPEC 2   // probe positions laid out per trip (measured per 4x10^6 pairs: 1 -> 7.7 ms, 2 -> 5.5 ms, 3 -> 5.8 ms, 4 -> 6.2 ms, 8 -> 7.7 ms: wider costs registers and wasted filter words)
 template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
@@ -555,7 +555,7 @@ __device__ inline uint64_t join_alloc(uint32_t cnt, unsigned long long* cursor) 
   return base + (incl - cnt);
 }
 
-__global__ void k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off,
+__global__ void __attribute__((amdgpu_waves_per_eu(5))) k_join2(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ chain_off,
     const sq_chain_dev* __restrict__ chains,
     const uint32_t* __restrict__ n_chains,
                         uint32_t* __restrict__ n_cand, uint64_t* __restrict__ cand_start, sq_cand_dev* __restrict__ cands,
@@ -1185,7 +1185,8 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
   }
 }
 
-__global__ void __attribute__((amdgpu_waves_per_eu(5))) k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,
+// (126 VGPRs: four waves per SIMD.  Capping it at five waves (amdgpu_waves_per_eu) spills 108 bytes per lane: 4.0 instead of 3.0 ms per 4x10^6 pairs.)
+__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,
     const uint64_t* __restrict__ cand_off,
     uint32_t nfrag,
                         const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
