@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Merge the FETCH_SIZE and WRITE_SIZE pass summaries of tools/profile_round.sh into the per-kernel traffic file bench.py reads.
+   python tools/pmc_traffic.py gpurun_out/r02_pmc_FETCH_SIZE.json gpurun_out/r02_pmc_WRITE_SIZE.json profiles/r02_pmc_traffic.json "provenance text" """
+import json, sys
+f = json.load(open(sys.argv[1])); w = json.load(open(sys.argv[2]))
+out = {"_provenance": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+for k in sorted(set(f) | set(w)):
+    fe = f.get(k, {}).get("FETCH_SIZE"); wr = w.get(k, {}).get("WRITE_SIZE")
+    out["kernels"][k] = {"launches": int((fe or wr)["launches"]),
+                         "fetch_bytes_per_launch": int(fe["avg_per_launch"] * 1024) if fe else None,    # rocprofv3 reports KiB
+                         "write_bytes_per_launch": int(wr["avg_per_launch"] * 1024) if wr else None}
+json.dump(out, open(sys.argv[3], "w"), indent=0)
+print("wrote", sys.argv[3], len(out["kernels"]), "kernels")
