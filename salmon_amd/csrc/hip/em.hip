@@ -563,6 +563,10 @@ struct EmSession {
     else SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));
     pt.mark("alloc+upload");
+    // [r2] the "first submission gap": without this drain the first synchronisation of the set-up (after the sort and the block plans, 0.9 ms
+    // of device work in the kernel trace) returned 17-21 ms late when the stream had been idle since the export; with it the whole
+    // set-up takes 2 ms (SQ_TIMING, MI355X / ROCm 7.2).  The upload is 1.3 MB from page-locked memory: the drain itself costs 0.03 ms.
+    SQ_HIP_CHECK(hipStreamSynchronize(st)); pt.mark("upload drained");
     // combined weights, prior, CSC
     if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes,
         o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
