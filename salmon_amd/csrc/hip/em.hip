@@ -256,7 +256,15 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
     if (n2) {   // level 2 of the blocked-64 sum, folded in: <= 64 level-1 partials, left to right
       const double* src = d.part[0] + d.l2_lo[t];
       acc = 0.0;
-      for (uint32_t i = 0; i < n2; ++i) acc += src[i];
+      // eight partials are requested together, then added left to right (a missing one is +0.0: x + 0.0 = x for these non-negative sums):
+      // the additions keep their order, the loads no longer wait for one another
+      for (uint32_t i = 0; i < n2; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < n2) ? src[i + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+      }
       alpha_out[t] = acc;
     } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
     else acc = alpha_out[t];
