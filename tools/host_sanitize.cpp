@@ -51,9 +51,12 @@ int main(int argc, char** argv) {
       gzprintf(f1, "@r%d/1\n%s\n+\n%s\n", i, a.c_str(), std::string(a.size(), 'I').c_str()); gzprintf(f2, "@r%d/2\n%s\n+\n%s\n", i, b.c_str(), std::string(b.size(), 'I').c_str()); }
     gzclose(f1); gzclose(f2);
     const char* a1[] = {(dir + "/r_1.fq.gz").c_str()}; std::string p1 = dir + "/r_1.fq.gz", p2 = dir + "/r_2.fq.gz"; const char* q1[] = {p1.c_str()}; const char* q2[] = {p2.c_str()}; (void)a1;
-    sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, q2, 1, 700, 3, &rd) == SQ_OK);
+    sq_reader* rd = nullptr; CHECK(sq_reader_open_ex(q1, 1, q2, 1, 700, 3, SQ_READER_KEEP_NAMES, &rd) == SQ_OK);   // names kept: the SAM writer's path
     uint64_t n = 0, bytes = 0; int held[2] = {-1, -1};
-    for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break; n += b.n; bytes += b.seq_off[2 * b.n];
+    for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break;
+      { const char* nm; const uint64_t* no; CHECK(sq_reader_names(rd, slot, &nm, &no) == SQ_OK);
+        for (uint32_t i = 0; i < b.n; i += 131) { char want[32]; snprintf(want, sizeof want, "r%llu", (unsigned long long)(n + i)); CHECK(std::string(nm + no[i], nm + no[i + 1]) == want); } }
+      n += b.n; bytes += b.seq_off[2 * b.n];
       for (uint64_t i = 0; i < b.seq_off[2 * b.n]; i += 97) CHECK(strchr("ACGT", (char)b.seq[i]) != nullptr);
       if (held[0] >= 0) sq_reader_release(rd, held[0]); held[0] = held[1]; held[1] = slot; }
     CHECK(n == 5000 && sq_reader_total(rd) == 5000 && bytes > 5000 * 100); sq_reader_close(rd); }
@@ -97,8 +100,10 @@ int main(int argc, char** argv) {
         if (op == 0) b[p] = (char)(g() & 0xFF); else if (op == 1) b.resize(p); else if (op == 2) b.insert(p, "\n@x\n"); else b[p] = "@+>\n\rACGTN"[g() % 10];
         if (b.empty()) b = "@"; }
       const std::string mp = dir + "/mut.fq"; FILE* f = fopen(mp.c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
-      const char* q1[] = {mp.c_str()}; sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, nullptr, 0, 16, 2, &rd) == SQ_OK);
-      for (;;) { sq_read_batch rb; int slot; if (sq_reader_next(rd, &rb, &slot) != SQ_OK || rb.n == 0) break; CHECK(rb.seq_off[rb.n] < (1u << 20)); ok_reads += (int)rb.n; sq_reader_release(rd, slot); }
+      const char* q1[] = {mp.c_str()}; sq_reader* rd = nullptr; CHECK(sq_reader_open_ex(q1, 1, nullptr, 0, 16, 2, (it & 1) ? SQ_READER_KEEP_NAMES : 0u, &rd) == SQ_OK);
+      for (;;) { sq_read_batch rb; int slot; if (sq_reader_next(rd, &rb, &slot) != SQ_OK || rb.n == 0) break; CHECK(rb.seq_off[rb.n] < (1u << 20)); ok_reads += (int)rb.n;
+        if (it & 1) { const char* nm; const uint64_t* no; CHECK(sq_reader_names(rd, slot, &nm, &no) == SQ_OK); CHECK(no[rb.n] < (1u << 20)); }
+        sq_reader_release(rd, slot); }
       sq_reader_close(rd); }
     // corrupt index files: truncated anywhere, or with bytes of the header / section tables overwritten
     { std::string ib; { FILE* f = fopen((dir + "/idx/index.bin").c_str(), "rb"); CHECK(f != nullptr); char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) ib.append(buf, n); fclose(f); }
