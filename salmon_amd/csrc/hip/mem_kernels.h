@@ -5,9 +5,9 @@
 // records crossed HBM about ten times, and the thread-per-end projection stored them 8 bytes at a time.)
 //
 // A read end with n projected MEMs is handled by a group of G lanes:
-//   n <= 16    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 16, 256>
-//   n <= 32    G = 16                                                                           k_mems<16, 32, 256>
-//   n <= 64    G = 16  (the same with twice the LDS rows: 44 KB per block hold 3 blocks per CU, 28 KB hold 5)     k_mems<16, 64, 256>
+//   n <= 16    G = 16  (four ends per wave; the common case: ~13 MEMs on ~7 transcripts)        k_mems<16, 16, 256>   16 KB of LDS per block
+//   n <= 32    G = 16                                                                           k_mems<16, 32, 256>   18 KB
+//   n <= 64    G = 16                                                                           k_mems<16, 64, 256>   32 KB
 //   n <= 1024  G = 64  (one wave per end)                                                       k_mems<64, 1024, 128>
 //   larger     the round-1 path on a compacted list (k_project_list -> radix sort -> k_chain)
 // Lanes expand one occurrence each (coalesced contig-table loads, all gathers in flight), rank-sort the keys held
