@@ -99,7 +99,7 @@ def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
     lib.sq_reader_close(h)
     return {"value": round(n / dt / 1e6, 3), "unit": "M read-pairs/s", "pairs": int(n), "seconds": round(dt, 4), "read_map_eq_s": round(t_read_map, 4),
             "mapped_frac": round(tot_mapped / max(1, n), 4), "em_iters": rep["iters"], "input": "2 plain FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n,
-                read_len, batch), "host_threads": os.cpu_count(), "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(16, hw/2)"),
+                read_len, batch), "host_threads": os.cpu_count(), "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
             "what": "end to end from files through sq_reader (mmap + parallel record split + page-locked batch assembly), H2D included; gzip input is bound by one inflate thread per mate file (~1.4 M pairs/s per file pair on this class of host)"}
 
 

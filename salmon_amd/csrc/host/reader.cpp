@@ -415,7 +415,7 @@ extern "C" int sq_reader_open_ex(const char* const* files1, uint32_t n1, const c
   }
   R->fast = fast;
   if (fast) {
-    unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 2));
     R->pool.reset(new Pool(std::max(1u, nt)));
     R->th[0] = std::thread(produce_fast, a, &R->cq[0], R->pool.get(), kn);
     if (n2) R->th[1] = std::thread(produce_fast, b, &R->cq[1], R->pool.get(), false);
