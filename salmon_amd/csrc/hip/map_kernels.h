@@ -1186,7 +1186,7 @@ __device__ inline bool compat_se(const sq_map_params& P, bool fwd, uint8_t ms) {
 }
 
 // (126 VGPRs: four waves per SIMD.  Capping it at five waves (amdgpu_waves_per_eu) spills 108 bytes per lane: 4.0 instead of 3.0 ms per 4x10^6 pairs.)
-__global__ void __launch_bounds__(256) k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,   // blocks of 256: the LDS stages below are sized for them
+__global__ void k_score(sq_map_params P, ScoreCtx S, uint64_t ncand, uint32_t paired, const uint64_t* __restrict__ mem_off,   // launched with blocks of 256 (the LDS stages below are sized for them); __launch_bounds__(256) doubled its time (6.0 vs 3.0 ms)
     const uint64_t* __restrict__ cand_off,
     uint32_t nfrag,
                         const sq_chain_dev* __restrict__ chains, sq_cand_dev* __restrict__ cands, const uint32_t* __restrict__ cand_frag,
