@@ -12,7 +12,8 @@
 //
 // Fast path (round 2): FASTQ with one-line sequences and qualities — what sequencers write.  A stream thread cuts the input into
 // ~8 MB chunks at record boundaries (plain files are mmap'ed: the chunk is a window of the page cache, nothing is copied; .gz files
-// are inflated by the stream thread — the sequential floor of a gzip stream — into chunk buffers), a pool of workers finds the
+// are inflated by the stream thread — the sequential floor of a gzip stream — into chunk buffers; BGZF files, whose 64 KB members are
+// independent, are inflated by the pool), a pool of workers finds the
 // records of the chunks in parallel (memchr per line, every record checked for the 4-line shape), and sq_reader_next assembles the
 // interleaved batch in the page-locked slot with the same pool (per-part byte totals, a scan, parallel copies): one copy per base from
 // the page cache to the buffer the GPU reads.  FASTA, multi-line records and SQ_READER_SAFE=1 take the kseq-rules path below.
@@ -254,6 +255,71 @@ bool looks_like_simple_fastq(const char* b, size_t n) {
 
 const size_t CHUNK_BYTES = 8u << 20;
 
+// ---- BGZF (bgzip / htslib): a gzip file made of members of at most 64 KB that each name their compressed size in a 'BC' extra field.
+// A plain gzip stream can only be inflated by one thread; these members are independent, so the pool inflates them in parallel and the
+// stream thread takes the text in file order.  (The reference reads .gz through one zlib stream per file: include/salmon/internal/io/FastxReader.hpp.)
+struct BgzfSource {
+  struct Blk { size_t off = 0, csize = 0; std::vector<char> out; size_t used = 0; bool done = false; std::string err; };
+  std::shared_ptr<Mapping> map; const uint8_t* base = nullptr; size_t n = 0, next_off = 0; Pool* pool = nullptr;
+  std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<Blk>> win; size_t window = 64; std::string path;
+  // size of the member starting at p (0: not a BGZF member)
+  static size_t member_size(const uint8_t* p, size_t left) {
+    if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8); if (12 + xlen > left) return 0;
+    for (size_t q = 12; q + 4 <= 12 + xlen;) {
+      const size_t slen = (size_t)p[q + 2] | ((size_t)p[q + 3] << 8);
+      if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) return ((size_t)p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+      q += 4 + slen;
+    }
+    return 0;
+  }
+  static void inflate_block(const uint8_t* p, Blk* b) {
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8); const size_t hdr = 12 + xlen;
+    if (b->csize < hdr + 8) { b->err = "truncated BGZF member"; return; }
+    const uint8_t* tail = p + b->csize - 8;
+    const uint32_t crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+    const uint32_t isize = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    if (isize > (1u << 16)) { b->err = "BGZF member larger than 64 KB"; return; }
+    b->out.resize(isize);
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { b->err = "zlib initialisation failed"; return; }
+    zs.next_in = const_cast<Bytef*>(p + hdr); zs.avail_in = (uInt)(b->csize - hdr - 8); zs.next_out = (Bytef*)b->out.data(); zs.avail_out = isize;
+    const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END; inflateEnd(&zs);
+    if ((isize && rc != Z_STREAM_END) || (isize && zs.total_out != isize)) { b->err = "corrupt BGZF member"; return; }
+    if (crc32(crc32(0L, Z_NULL, 0), (const Bytef*)b->out.data(), isize) != crc) b->err = "BGZF checksum mismatch";
+  }
+  void schedule() {   // caller holds mu
+    while (win.size() < window && next_off < n) {
+      const size_t ms = member_size(base + next_off, n - next_off);
+      auto b = std::make_shared<Blk>(); b->off = next_off;
+      if (ms == 0 || ms > n - next_off) { b->err = ms ? "truncated BGZF member" : "not a BGZF member (mixed gzip file?)"; b->done = true; win.push_back(b); next_off = n; break; }
+      b->csize = ms; next_off += ms; win.push_back(b);
+      pool->submit([this, b] { inflate_block(base + b->off, b.get()); { std::lock_guard<std::mutex> lk(mu); b->done = true; } cv.notify_all(); });
+    }
+  }
+  // up to `want` bytes of text in file order; 0 at the end; -1 on error (see err)
+  std::string err;
+  long read(char* dst, size_t want) {
+    size_t got = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    while (got < want) {
+      schedule();
+      if (win.empty()) break;
+      auto b = win.front();
+      cv.wait(lk, [&] { return b->done; });
+      if (!b->err.empty()) { err = "'" + path + "': " + b->err; return -1; }
+      const size_t take = std::min(want - got, b->out.size() - b->used);
+      if (take) { lk.unlock(); memcpy(dst + got, b->out.data() + b->used, take); lk.lock(); b->used += take; got += take; }
+      if (b->used == b->out.size()) win.pop_front();
+    }
+    return (long)got;
+  }
+  ~BgzfSource() {   // let the queued tasks finish: they hold `this`
+    std::unique_lock<std::mutex> lk(mu);
+    for (auto& b : win) cv.wait(lk, [&] { return b->done; });
+  }
+};
+
 // one mate stream on the fast path; returns false (nothing consumed) if the first file is not simple FASTQ and the safe path should run
 void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, bool keep_names) {
   uint64_t nrec_before = 0;
@@ -283,8 +349,22 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
         dispatch(c); p = q;
       }
     } else {
-      gzFile f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; }
-      gzbuffer(f, 1 << 20);
+      // BGZF: the members are inflated by the pool; any other gzip file by this thread through zlib
+      std::unique_ptr<BgzfSource> bg;
+      { int fd = open(path.c_str(), O_RDONLY); struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size >= 28) {
+          void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+          if (m != MAP_FAILED) {
+            if (BgzfSource::member_size((const uint8_t*)m, (size_t)sb.st_size)) {
+              bg.reset(new BgzfSource()); bg->map = std::make_shared<Mapping>(); bg->map->p = m; bg->map->n = (size_t)sb.st_size;
+              bg->base = (const uint8_t*)m; bg->n = (size_t)sb.st_size; bg->pool = pool; bg->path = path; bg->window = std::max<size_t>(32, 8 * pool->th.size());
+              (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+            } else munmap(m, (size_t)sb.st_size);
+          }
+        }
+        if (fd >= 0) close(fd); }
+      gzFile f = nullptr;
+      if (!bg) { f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; } gzbuffer(f, 1 << 20); }
       std::vector<char> carry;
       for (;;) {
         auto c = std::make_shared<Chunk>(); c->own.resize(carry.size() + CHUNK_BYTES);
@@ -292,8 +372,12 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
         size_t have = carry.size(); carry.clear();
         size_t got = 0; bool eof = false;
         while (got < CHUNK_BYTES) {
-          const int r = gzread(f, c->own.data() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
-          if (r < 0) { int e; std::string msg = gzerror(f, &e); gzclose(f); out->finish("read error in '" + path + "': " + msg); return; }
+          long r;
+          if (bg) { r = bg->read(c->own.data() + have + got, CHUNK_BYTES - got); if (r < 0) { out->finish(bg->err); return; } }
+          else {
+            r = gzread(f, c->own.data() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
+            if (r < 0) { int e; std::string msg = gzerror(f, &e); gzclose(f); out->finish("read error in '" + path + "': " + msg); return; }
+          }
           if (r == 0) { eof = true; break; }
           got += (size_t)r;
         }
@@ -311,14 +395,14 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
             if (back == tot) break;
             back = std::min<size_t>(tot, back * 4);
           }
-          if (cut == 0) { gzclose(f); out->finish("'" + path + "': no FASTQ record boundary in a " + std::to_string(tot) + "-byte window (set SQ_READER_SAFE=1)"); return; }
+          if (cut == 0) { if (f) gzclose(f); out->finish("'" + path + "': no FASTQ record boundary in a " + std::to_string(tot) + "-byte window (set SQ_READER_SAFE=1)"); return; }
           carry.assign(c->own.data() + cut, c->own.data() + tot);
         }
         c->text = c->own.data(); c->bytes = cut; c->path = path; c->first_record = nrec_before; nrec_before += cut / 250;
         dispatch(c);
         if (eof) break;
       }
-      gzclose(f);
+      if (f) gzclose(f);
     }
   }
   out->finish();

@@ -180,3 +180,33 @@ def test_reader_keeps_read_names_on_request(built, tmp_path, safe, monkeypatch):
     nm = C.c_void_p(); no = C.POINTER(C.c_uint64)()
     assert L.sq_reader_names(h, slot.value, C.byref(nm), C.byref(no)) != 0 and b"KEEP_NAMES" in L.sq_last_error()
     L.sq_reader_close(h)
+
+
+def _bgzf_write(path, data, block=60000):
+    """bgzip-style file: gzip members of at most 64 KB, each with the 'BC' extra field naming its compressed size"""
+    import struct, zlib
+    with open(path, "wb") as f:
+        for i in list(range(0, len(data), block)) + [None]:
+            chunk = data[i:i + block] if i is not None else b""          # the last, empty member is bgzip's end-of-file marker
+            co = zlib.compressobj(6, zlib.DEFLATED, -15); cd = co.compress(chunk) + co.flush()
+            bsize = 18 + len(cd) + 8
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + cd + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+
+def test_reader_bgzf_members_are_inflated_in_parallel_and_in_order(built, tmp_path):
+    # a BGZF file gives the same batches as the plain file; a damaged member is reported, not skipped
+    rng = np.random.default_rng(11); n = 20000
+    seqs1 = ["".join(rng.choice(list("ACGTN"), size=int(rng.integers(50, 151)))) for _ in range(n)]
+    seqs2 = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(50, 151)))) for _ in range(n)]
+    def text(seqs, m): return "".join("@q%d/%d\n%s\n+\n%s\n" % (i, m, s, "F" * len(s)) for i, s in enumerate(seqs)).encode()
+    t1, t2 = text(seqs1, 1), text(seqs2, 2)
+    open(tmp_path / "p_1.fq", "wb").write(t1); open(tmp_path / "p_2.fq", "wb").write(t2)
+    _bgzf_write(tmp_path / "b_1.fq.gz", t1); _bgzf_write(tmp_path / "b_2.fq.gz", t2, block=30011)
+    assert gzip.open(tmp_path / "b_1.fq.gz", "rb").read() == t1            # a valid multi-member gzip file for everybody else
+    h = _open([str(tmp_path / "p_1.fq")], [str(tmp_path / "p_2.fq")], batch=3000); want, err = _drain(h); capi.lib().sq_reader_close(h); assert err is None
+    h = _open([str(tmp_path / "b_1.fq.gz")], [str(tmp_path / "b_2.fq.gz")], batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is None and got == want and sum(len(b) for b in got) == 2 * n
+    raw = bytearray(open(tmp_path / "b_1.fq.gz", "rb").read()); raw[len(raw) // 2] ^= 0x5A
+    open(tmp_path / "bad_1.fq.gz", "wb").write(bytes(raw))
+    h = _open([str(tmp_path / "bad_1.fq.gz")], None, batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "bad_1.fq.gz" in err and ("BGZF" in err or "record" in err)

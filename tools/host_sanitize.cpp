@@ -60,6 +60,28 @@ int main(int argc, char** argv) {
       for (uint64_t i = 0; i < b.seq_off[2 * b.n]; i += 97) CHECK(strchr("ACGT", (char)b.seq[i]) != nullptr);
       if (held[0] >= 0) sq_reader_release(rd, held[0]); held[0] = held[1]; held[1] = slot; }
     CHECK(n == 5000 && sq_reader_total(rd) == 5000 && bytes > 5000 * 100); sq_reader_close(rd); }
+  // ---- reader: the same reads as BGZF (64 KB gzip members inflated by the pool, taken in order by the stream thread)
+  { auto bgzf = [&](const std::string& src, const std::string& dst) {
+      std::string text; { gzFile f = gzopen(src.c_str(), "rb"); char buf[1 << 16]; int n; while ((n = gzread(f, buf, sizeof buf)) > 0) text.append(buf, (size_t)n); gzclose(f); }
+      FILE* o = fopen(dst.c_str(), "wb");
+      for (size_t i = 0; i <= text.size(); i += 50000) {   // the last round writes the empty end-of-file member when the text ends on a boundary or not
+        const size_t len = i < text.size() ? std::min<size_t>(50000, text.size() - i) : 0;
+        std::vector<unsigned char> cd(len + len / 100 + 1024); z_stream zs; memset(&zs, 0, sizeof zs); deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)(text.data() + i); zs.avail_in = (uInt)len; zs.next_out = cd.data(); zs.avail_out = (uInt)cd.size(); deflate(&zs, Z_FINISH); const size_t cl = zs.total_out; deflateEnd(&zs);
+        const unsigned bs = (unsigned)(18 + cl + 8 - 1); const unsigned long crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(text.data() + i), (uInt)len);
+        const unsigned char hd[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bs & 0xff), (unsigned char)(bs >> 8)};
+        fwrite(hd, 1, 18, o); fwrite(cd.data(), 1, cl, o);
+        const unsigned char tl[8] = {(unsigned char)crc, (unsigned char)(crc >> 8), (unsigned char)(crc >> 16), (unsigned char)(crc >> 24), (unsigned char)len, (unsigned char)(len >> 8), (unsigned char)(len >> 16), (unsigned char)(len >> 24)};
+        fwrite(tl, 1, 8, o);
+        if (len == 0) break;
+      }
+      fclose(o); };
+    bgzf(dir + "/r_1.fq.gz", dir + "/b_1.fq.gz"); bgzf(dir + "/r_2.fq.gz", dir + "/b_2.fq.gz");
+    std::string p1 = dir + "/b_1.fq.gz", p2 = dir + "/b_2.fq.gz"; const char* q1[] = {p1.c_str()}; const char* q2[] = {p2.c_str()};
+    sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, q2, 1, 900, 3, &rd) == SQ_OK);
+    uint64_t n = 0;
+    for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break; n += b.n; sq_reader_release(rd, slot); }
+    CHECK(n == 5000); sq_reader_close(rd); }
   // ---- eq classes inside gene-like groups -> normalizeAlphas (parallel union-find), twice, same answer
   std::vector<uint64_t> off{0}, cnt; std::vector<uint32_t> tid; std::vector<double> w;
   for (int c = 0; c < 4000; ++c) { uint32_t base = (uint32_t)(g() % (M - 8)); int n = 1 + (int)(g() % 5); std::vector<uint32_t> lab; for (int j = 0; j < n; ++j) lab.push_back(base + (uint32_t)(g() % 8)); std::sort(lab.begin(), lab.end()); lab.erase(std::unique(lab.begin(), lab.end()), lab.end());
