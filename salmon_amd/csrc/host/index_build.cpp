@@ -9,6 +9,7 @@
 // and reference-terminal flags; unitig boundaries are then *local* predicates evaluated while
 // walking each reference, so unitigs are found without ever walking the graph.
 #include "index.h"
+#include <chrono>
 #include <zlib.h>
 #include <algorithm>
 #include <cstdarg>
@@ -36,17 +37,19 @@ inline int base_code(char c) {
   }
 }
 
-struct KTable {  // concurrent open-addressing table over canonical k-mers
-  uint64_t cap = 0, mask = 0;
+// Concurrent open-addressing table over canonical k-mers -> what was seen next to them.  [r2] It holds ONE PARTITION of the k-mers at a
+// time (build_core walks the references once per partition), so its size is a parameter and not the genome: 10 bytes per slot.
+struct KTable {
+  uint64_t cap = 0;
   std::vector<uint64_t> keys;
-  std::vector<uint32_t> info;  // bits0-3 R edge mask, 4-7 L edge mask, 8 Rterm, 9 Lterm
-  std::vector<uint32_t> aux;   // first segment index (atomic min) then unitig id
+  std::vector<uint16_t> info;  // bits0-3 R edge mask, 4-7 L edge mask, 8 Rterm, 9 Lterm
   void init(uint64_t need) {
-    cap = 1024; while (cap < need) cap <<= 1; mask = cap - 1;
-    keys.assign(cap, ~0ULL); info.assign(cap, 0); aux.assign(cap, 0xFFFFFFFFu);
+    cap = need < 1024 ? 1024 : need;
+    keys.assign(cap, ~0ULL); info.assign(cap, 0);
   }
+  inline uint64_t home(uint64_t c) const { return (uint64_t)(((unsigned __int128)sq_mix64(c) * (unsigned __int128)cap) >> 64); }
   inline uint64_t insert(uint64_t c) {
-    uint64_t h = sq_mix64(c) & mask;
+    uint64_t h = home(c);
     for (;;) {
       uint64_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
       if (cur == c) return h;
@@ -55,21 +58,37 @@ struct KTable {  // concurrent open-addressing table over canonical k-mers
         if (__atomic_compare_exchange_n(&keys[h], &exp, c, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return h;
         if (exp == c) return h;
       }
-      h = (h + 1) & mask;
+      if (++h == cap) h = 0;
     }
   }
   inline uint64_t find(uint64_t c) const {
-    uint64_t h = sq_mix64(c) & mask;
+    uint64_t h = home(c);
     for (;;) {
       uint64_t cur = keys[h];
       if (cur == c) return h;
       if (cur == ~0ULL) return ~0ULL;
-      h = (h + 1) & mask;
+      if (++h == cap) h = 0;
     }
   }
 };
+// the unitigs: key k-mer (the smaller of a unitig's two end k-mers) -> first occurrence (atomic min), then the unitig id
+struct UMap {
+  uint64_t cap = 0; std::vector<uint64_t> keys; std::vector<uint32_t> aux;
+  void init(uint64_t need) { cap = need < 1024 ? 1024 : need; keys.assign(cap, ~0ULL); aux.assign(cap, 0xFFFFFFFFu); }
+  inline uint64_t home(uint64_t c) const { return (uint64_t)(((unsigned __int128)sq_mix64(c ^ 0xA24BAED4963EE407ULL) * (unsigned __int128)cap) >> 64); }
+  inline uint64_t insert(uint64_t c) {
+    uint64_t h = home(c);
+    for (;;) {
+      uint64_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+      if (cur == c) return h;
+      if (cur == ~0ULL) { uint64_t exp = ~0ULL; if (__atomic_compare_exchange_n(&keys[h], &exp, c, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return h; if (exp == c) return h; }
+      if (++h == cap) h = 0;
+    }
+  }
+  inline uint64_t find(uint64_t c) const { uint64_t h = home(c); for (;;) { uint64_t cur = keys[h]; if (cur == c) return h; if (cur == ~0ULL) return ~0ULL; if (++h == cap) h = 0; } }
+};
 
-struct Seg { uint32_t ref, pos, nk, key_slot_lo; uint8_t key_slot_hi; };  // key slot up to 2^40
+struct Seg { uint32_t ref, pos, nk, key_lo, key_hi; };  // one unitig occurrence; key = the smaller of its two end k-mers (canonical)
 
 inline void pool_or_bases(uint64_t* pool, uint64_t dst, const uint64_t* src, uint64_t sp, uint64_t n) {
   // copy n bases from src@sp to pool@dst using atomic OR (pool pre-zeroed; ranges may share words)
@@ -90,6 +109,9 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
                       std::vector<uint32_t>& clen, uint32_t first_decoy, sq_index* idx) {
   const uint32_t k = idx->k, m = idx->m;
   const uint32_t nthreads = std::max(1u, o && o->threads ? o->threads : std::thread::hardware_concurrency());
+  const bool timing = getenv("SQ_TIMING") != nullptr; auto tph = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) { if (!timing) return; const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sq-timing] index %s %.1f s\n", what, std::chrono::duration<double>(t1 - tph).count()); tph = t1; };
   const uint32_t nrefs = (uint32_t)names.size();
   idx->names = names; idx->first_decoy = first_decoy;
   idx->ref_len.resize(nrefs); idx->ref_clen = clen; idx->ref_accum.assign(nrefs + 1, 0);
@@ -112,69 +134,108 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     }
   });
   std::vector<std::string>().swap(seqs);  // free ASCII
+  phase("pack references");
   const uint64_t* rs = idx->refseq.data();
-  // ---- k-mer table: edges + terminal flags ----
+  // ---- k-mer table: edges + terminal flags -> two bits per reference position ----
+  // [r2] What the unitig walk needs of a k-mer is local: does the unitig end on its right / on its left (a terminal, or not exactly one
+  // neighbour).  So the table is built one PARTITION of the k-mers at a time (partition = hash of the canonical k-mer): a pass inserts the
+  // k-mers of its partition with what was seen next to them, then writes, for every reference position whose k-mer it owns, the two
+  // verdicts into bit arrays indexed by position.  The table's size is a budget (SQ_INDEX_TABLE_GB, default 12 GB), not the genome: a
+  // transcriptome takes one pass, a 3-Gnt decoy genome five; the bit arrays are 2 bits per nucleotide.
   uint64_t npos = 0;
   for (uint32_t r = 0; r < nrefs; ++r) if (idx->ref_len[r] >= k) npos += idx->ref_len[r] - k + 1;
-  KTable T; T.init((uint64_t)(npos * 1.35) + 1024);
   const uint64_t km = sq_kmask(k);
-  std::vector<uint32_t> order(nrefs);
-  for (uint32_t r = 0; r < nrefs; ++r) order[r] = r;
-  sq_parallel_for(nrefs, nthreads, 16, [&](uint64_t b, uint64_t e, uint32_t) {
-    for (uint64_t r = b; r < e; ++r) {
-      uint32_t L = idx->ref_len[r]; if (L < k) continue;
-      uint64_t g = idx->ref_accum[r];
-      uint64_t fw = sq_fetch_bases(rs, g, k), rc = sq_revcomp(fw, k);
-      uint32_t nk = L - k + 1;
-      for (uint32_t i = 0; i < nk; ++i) {
-        if (i) { uint64_t nb = sq_fetch_base(rs, g + i + k - 1); fw = (fw >> 2) | (nb << (2 * (k - 1))); rc = ((rc << 2) | (3 - nb)) & km; }
-        bool o1 = fw < rc; uint64_t c = o1 ? fw : rc;
-        uint64_t slot = T.insert(c);
-        uint32_t bits = 0;
-        if (i + 1 < nk) { uint32_t s = sq_fetch_base(rs, g + i + k); bits |= o1 ? (1u << s) : (1u << (4 + (3 - s))); }
-        else bits |= o1 ? (1u << 8) : (1u << 9);
-        if (i > 0) { uint32_t p = sq_fetch_base(rs, g + i - 1); bits |= o1 ? (1u << (4 + p)) : (1u << (3 - p)); }
-        else bits |= o1 ? (1u << 9) : (1u << 8);
-        __atomic_fetch_or(&T.info[slot], bits, __ATOMIC_RELAXED);
-      }
-    }
-  });
-  // ---- walk references: local boundary predicate -> segments (unitig occurrences) ----
-  std::vector<std::vector<Seg>> rsegs(nrefs);
+  const double budget_gb = getenv("SQ_INDEX_TABLE_GB") ? std::max(0.001, atof(getenv("SQ_INDEX_TABLE_GB"))) : 12.0;
+  const uint64_t slot_budget = (uint64_t)(budget_gb * 1e9 / 10.0);                        // 10 bytes per slot
+  const uint32_t nparts_k = (uint32_t)std::max<uint64_t>(1, ((uint64_t)(npos * 1.35) + slot_budget - 1) / slot_budget);
+  auto kmer_part = [&](uint64_t c) -> uint32_t { return nparts_k == 1 ? 0u : (uint32_t)((sq_mix64(c ^ 0x51ED270B1A2C3D4FULL) >> 17) % nparts_k); };
+  // positions in pieces of at most 4 M k-mers, so that a few chromosomes still fill every thread
+  struct Piece { uint32_t ref, i0, i1; };
+  std::vector<Piece> pieces;
+  for (uint32_t r = 0; r < nrefs; ++r) { const uint32_t L = idx->ref_len[r]; if (L < k) continue; const uint32_t nk = L - k + 1;
+    for (uint32_t i0 = 0; i0 < nk; i0 += (4u << 20)) pieces.push_back({r, i0, std::min(nk, i0 + (4u << 20))}); }
+  std::vector<uint64_t> brkR((total_nt + 63) / 64 + 1, 0), brkL((total_nt + 63) / 64 + 1, 0);   // by global position of the k-mer's first base
   auto side_break = [](uint32_t inf, bool right) -> bool {
     uint32_t msk = right ? (inf & 15u) : ((inf >> 4) & 15u);
     bool term = right ? ((inf >> 8) & 1u) : ((inf >> 9) & 1u);
     return term || __builtin_popcount(msk) != 1;
   };
+  {
+    KTable T;
+    for (uint32_t part = 0; part < nparts_k; ++part) {
+      // a partition holds ~1/nparts of the DISTINCT k-mers; sized for 1/nparts of the positions (+ 8 % for the spread of the hash)
+      T.init((uint64_t)((double)npos / nparts_k * (nparts_k > 1 ? 1.08 : 1.0) * 1.35) + 1024);
+      std::atomic<int> full(0);
+      sq_parallel_for(pieces.size(), nthreads, 1, [&](uint64_t b, uint64_t e, uint32_t) {
+        for (uint64_t pi = b; pi < e; ++pi) {
+          const Piece pc = pieces[pi]; const uint32_t L = idx->ref_len[pc.ref], nk = L - k + 1; const uint64_t g = idx->ref_accum[pc.ref];
+          uint64_t fw = sq_fetch_bases(rs, g + pc.i0, k), rc = sq_revcomp(fw, k);
+          for (uint32_t i = pc.i0; i < pc.i1; ++i) {
+            if (i > pc.i0) { uint64_t nb = sq_fetch_base(rs, g + i + k - 1); fw = (fw >> 2) | (nb << (2 * (k - 1))); rc = ((rc << 2) | (3 - nb)) & km; }
+            bool o1 = fw < rc; uint64_t c = o1 ? fw : rc;
+            if (kmer_part(c) != part) continue;
+            uint64_t slot = T.insert(c);
+            uint32_t bits = 0;
+            if (i + 1 < nk) { uint32_t sb = sq_fetch_base(rs, g + i + k); bits |= o1 ? (1u << sb) : (1u << (4 + (3 - sb))); }
+            else bits |= o1 ? (1u << 8) : (1u << 9);
+            if (i > 0) { uint32_t pb = sq_fetch_base(rs, g + i - 1); bits |= o1 ? (1u << (4 + pb)) : (1u << (3 - pb)); }
+            else bits |= o1 ? (1u << 9) : (1u << 8);
+            __atomic_fetch_or(&T.info[slot], (uint16_t)bits, __ATOMIC_RELAXED);
+          }
+        }
+      });
+      (void)full;
+      sq_parallel_for(pieces.size(), nthreads, 1, [&](uint64_t b, uint64_t e, uint32_t) {
+        for (uint64_t pi = b; pi < e; ++pi) {
+          const Piece pc = pieces[pi]; const uint64_t g = idx->ref_accum[pc.ref];
+          uint64_t fw = sq_fetch_bases(rs, g + pc.i0, k), rc = sq_revcomp(fw, k);
+          for (uint32_t i = pc.i0; i < pc.i1; ++i) {
+            if (i > pc.i0) { uint64_t nb = sq_fetch_base(rs, g + i + k - 1); fw = (fw >> 2) | (nb << (2 * (k - 1))); rc = ((rc << 2) | (3 - nb)) & km; }
+            bool o1 = fw < rc; uint64_t c = o1 ? fw : rc;
+            if (kmer_part(c) != part) continue;
+            const uint32_t inf = T.info[T.find(c)]; const uint64_t gp = g + i;
+            if (side_break(inf, o1)) __atomic_fetch_or(&brkR[gp >> 6], 1ULL << (gp & 63), __ATOMIC_RELAXED);     // the unitig ends after this occurrence
+            if (side_break(inf, !o1)) __atomic_fetch_or(&brkL[gp >> 6], 1ULL << (gp & 63), __ATOMIC_RELAXED);    // ... before it
+          }
+        }
+      });
+    }
+  }
+  phase("k-mer table passes");
+  // ---- walk references: local boundary predicate -> segments (unitig occurrences) ----
+  std::vector<std::vector<Seg>> rsegs(nrefs);
   sq_parallel_for(nrefs, nthreads, 16, [&](uint64_t b, uint64_t e, uint32_t) {
     for (uint64_t r = b; r < e; ++r) {
       uint32_t L = idx->ref_len[r]; if (L < k) continue;
       uint64_t g = idx->ref_accum[r];
       uint64_t fw = sq_fetch_bases(rs, g, k), rc = sq_revcomp(fw, k);
       uint32_t nk = L - k + 1;
-      bool o1 = fw < rc; uint64_t c = o1 ? fw : rc; uint64_t slot = T.find(c); uint32_t inf = T.info[slot];
-      uint32_t seg_start = 0; uint64_t first_c = c, first_slot = slot;
+      bool o1 = fw < rc; uint64_t c = o1 ? fw : rc;
+      uint32_t seg_start = 0; uint64_t first_c = c;
       auto& out = rsegs[r];
       for (uint32_t i = 0; i < nk; ++i) {
         bool last = (i + 1 == nk);
-        bool brk = true; uint64_t nc = 0, nslot = 0; uint32_t ninf = 0; bool no1 = false;
+        bool brk = true; uint64_t nc = 0; bool no1 = false;
         if (!last) {
           uint64_t nb = sq_fetch_base(rs, g + i + k);
           fw = (fw >> 2) | (nb << (2 * (k - 1))); rc = ((rc << 2) | (3 - nb)) & km;
-          no1 = fw < rc; nc = no1 ? fw : rc; nslot = T.find(nc); ninf = T.info[nslot];
-          brk = side_break(inf, o1) || side_break(ninf, !no1) || (nc == c);
+          no1 = fw < rc; nc = no1 ? fw : rc;
+          const uint64_t gp = g + i, gn = gp + 1;
+          brk = ((brkR[gp >> 6] >> (gp & 63)) & 1) || ((brkL[gn >> 6] >> (gn & 63)) & 1) || (nc == c);
         }
         if (brk) {
-          uint64_t ks = (c < first_c) ? slot : first_slot;  // slot of min(c_first, c_last)
+          const uint64_t key = (c < first_c) ? c : first_c;  // min(c_first, c_last): the unitig's identity
           Seg s; s.ref = (uint32_t)r; s.pos = seg_start; s.nk = i - seg_start + 1;
-          s.key_slot_lo = (uint32_t)ks; s.key_slot_hi = (uint8_t)(ks >> 32);
+          s.key_lo = (uint32_t)key; s.key_hi = (uint32_t)(key >> 32);
           out.push_back(s);
-          seg_start = i + 1; first_c = nc; first_slot = nslot;
+          seg_start = i + 1; first_c = nc;
         }
-        c = nc; slot = nslot; inf = ninf; o1 = no1;
+        c = nc; o1 = no1;
       }
     }
   });
+  std::vector<uint64_t>().swap(brkR); std::vector<uint64_t>().swap(brkL);
+  phase("walk");
   std::vector<uint64_t> seg_off(nrefs + 1, 0);
   for (uint32_t r = 0; r < nrefs; ++r) seg_off[r + 1] = seg_off[r] + rsegs[r].size();
   const uint64_t S = seg_off[nrefs];
@@ -189,15 +250,21 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       std::vector<Seg>().swap(rsegs[r]);
     }
   });
-  auto kslot = [](const Seg& s) { return (uint64_t)s.key_slot_lo | ((uint64_t)s.key_slot_hi << 32); };
+  phase("  segments gathered");
+  auto skey = [](const Seg& s) { return (uint64_t)s.key_lo | ((uint64_t)s.key_hi << 32); };
   // first occurrence (in reference order) of every unitig defines its id, orientation and sequence
+  UMap T; T.init((uint64_t)(S * 1.5) + 1024);
+  std::vector<uint64_t> seg_slot(S);
   sq_parallel_for(S, nthreads, 1 << 16, [&](uint64_t b, uint64_t e, uint32_t) {
     for (uint64_t i = b; i < e; ++i) {
-      uint32_t* a = &T.aux[kslot(segs[i])]; uint32_t v = (uint32_t)i;
+      const uint64_t sl = T.insert(skey(segs[i])); seg_slot[i] = sl;
+      uint32_t* a = &T.aux[sl]; uint32_t v = (uint32_t)i;
       uint32_t cur = __atomic_load_n(a, __ATOMIC_RELAXED);
       while (v < cur && !__atomic_compare_exchange_n(a, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     }
   });
+  phase("  unitig keys hashed");
+  auto kslot = [&](const Seg& s) { return seg_slot[(uint64_t)(&s - segs.data())]; };
   std::vector<uint8_t> defining(S);
   std::vector<uint64_t> def_idx;
   for (uint64_t i = 0; i < S; ++i) { defining[i] = (T.aux[kslot(segs[i])] == (uint32_t)i); if (defining[i]) def_idx.push_back(i); }
@@ -211,6 +278,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     idx->uoff[u + 1] = idx->uoff[u] + ulen;
     T.aux[kslot(s)] = (uint32_t)u;  // now: unitig id
   }
+  phase("  unitig ids");
   const uint64_t pool_nt = idx->uoff[U];
   if (pool_nt >= (1ULL << SQ_APOS_BITS)) {
     sq_set_error("unitig pool too large (%llu nt)", (unsigned long long)pool_nt);
@@ -223,6 +291,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       pool_or_bases(idx->useq.data(), idx->uoff[u], rs, idx->ref_accum[s.ref] + s.pos, (uint64_t)s.nk + k - 1);
     }
   });
+  phase("unitigs");
   // ---- contig table (stable counting sort by unitig id keeps (tid,pos) order) ----
   std::vector<uint32_t> seg_uid(S); std::vector<uint8_t> seg_fw(S);
   sq_parallel_for(S, nthreads, 1 << 14, [&](uint64_t b, uint64_t e, uint32_t) {
@@ -237,6 +306,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       }
     }
   });
+  phase("  orientations");
   idx->ctab_off.assign(U + 1, 0);
   for (uint64_t i = 0; i < S; ++i) idx->ctab_off[seg_uid[i] + 1]++;
   for (uint64_t u = 0; u < U; ++u) idx->ctab_off[u + 1] += idx->ctab_off[u];
@@ -254,34 +324,43 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   // free the table before the dictionary build
   std::vector<Seg>().swap(segs);
   std::vector<uint64_t>().swap(T.keys);
-  std::vector<uint32_t>().swap(T.info);
   std::vector<uint32_t>().swap(T.aux);
+  std::vector<uint64_t>().swap(seg_slot);
 
+  phase("contig table");
   // ---- minimizers / super-k-mers ----
   const uint64_t* up = idx->useq.data();
   const uint32_t w = k - m; const uint64_t mm = sq_kmask(m);
   std::vector<std::vector<MiniEnt>> tent(nthreads);
-  sq_parallel_for(U, nthreads, 2048, [&](uint64_t b, uint64_t e, uint32_t t) {
+  // [r2] k-mer positions in pieces of at most 4 M per task: a decoy chromosome can be ONE unitig of 10^8 nt, and a thread per unitig
+  // left the others idle for minutes.  A super-k-mer cut by a piece boundary comes out as two entries with the same minimizer
+  // occurrence; they are merged after the sort below (an occurrence is the minimizer of one contiguous run of k-mers).
+  struct UPiece { uint64_t u; uint32_t p0, p1; };
+  std::vector<UPiece> upieces;
+  for (uint64_t u = 0; u < U; ++u) { const uint32_t nk = (uint32_t)(idx->uoff[u + 1] - idx->uoff[u]) - k + 1;
+    for (uint32_t p0 = 0; p0 < nk; p0 += (4u << 20)) upieces.push_back({u, p0, std::min(nk, p0 + (4u << 20))}); }
+  sq_parallel_for(upieces.size(), nthreads, 64, [&](uint64_t b, uint64_t e, uint32_t t) {
     std::vector<uint64_t> hv, cv;
     auto& out = tent[t];
-    for (uint64_t u = b; u < e; ++u) {
-      uint64_t ub = idx->uoff[u]; uint32_t ulen = (uint32_t)(idx->uoff[u + 1] - ub);
-      uint32_t nm = ulen - m + 1, nk = ulen - k + 1;
+    for (uint64_t pi = b; pi < e; ++pi) {
+      const uint64_t u = upieces[pi].u; const uint32_t p0 = upieces[pi].p0, p1 = upieces[pi].p1;
+      const uint64_t ub = idx->uoff[u];
+      const uint32_t nm = (p1 - p0) + w;               // m-mers p0 .. p1 - 1 + w
       hv.resize(nm); cv.resize(nm);
-      uint64_t f = sq_fetch_bases(up, ub, m), r = sq_revcomp(f, m);
+      uint64_t f = sq_fetch_bases(up, ub + p0, m), r = sq_revcomp(f, m);
       for (uint32_t i = 0; i < nm; ++i) {
-        if (i) { uint64_t nb = sq_fetch_base(up, ub + i + m - 1); f = (f >> 2) | (nb << (2 * (m - 1))); r = ((r << 2) | (3 - nb)) & mm; }
+        if (i) { uint64_t nb = sq_fetch_base(up, ub + p0 + i + m - 1); f = (f >> 2) | (nb << (2 * (m - 1))); r = ((r << 2) | (3 - nb)) & mm; }
         uint64_t c = f < r ? f : r; cv[i] = c; hv[i] = sq_mhash(c);
       }
       uint32_t prev = 0xFFFFFFFFu;
-      for (uint32_t p = 0; p < nk; ++p) {
-        uint32_t bj = p; uint64_t bh = hv[p];
+      for (uint32_t p = p0; p < p1; ++p) {
+        const uint32_t q = p - p0; uint32_t bj = q; uint64_t bh = hv[q];
         // leftmost minimum of (sq_mhash, value)
-        for (uint32_t j = p + 1; j <= p + w; ++j) if (hv[j] < bh || (hv[j] == bh && cv[j] < cv[bj])) {
+        for (uint32_t j = q + 1; j <= q + w; ++j) if (hv[j] < bh || (hv[j] == bh && cv[j] < cv[bj])) {
           bh = hv[j];
           bj = j;
         }
-        if (bj != prev) { out.push_back({cv[bj], (u << SQ_APOS_BITS) | (ub + bj), p, 1}); prev = bj; }
+        if (bj != prev) { out.push_back({cv[bj], (u << SQ_APOS_BITS) | (ub + p0 + bj), p, 1}); prev = bj; }
         else out.back().nk++;
       }
     }
@@ -297,6 +376,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     }
   }
   idx->num_superkmers = ents.size();
+  phase("minimizers");
   // parallel sort by (v, e): bucket by top bits of mix(v) is unnecessary; a plain parallel merge is enough
   {
     uint64_t n = ents.size(); uint32_t P = nthreads; std::vector<uint64_t> cut(P + 1);
@@ -314,12 +394,21 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       for (auto& x : th) x.join();
     }
   }
+  // the halves of super-k-mers cut by a piece boundary: same (minimizer, occurrence), adjacent k-mer runs
+  { uint64_t wq = 0;
+    for (uint64_t i = 0; i < ents.size(); ++i) {
+      if (wq && ents[wq - 1].v == ents[i].v && ents[wq - 1].e == ents[i].e) { ents[wq - 1].kstart = std::min(ents[wq - 1].kstart, ents[i].kstart); ents[wq - 1].nk += ents[i].nk; }
+      else ents[wq++] = ents[i];
+    }
+    ents.resize(wq); idx->num_superkmers = wq; }
+  phase("sort super-k-mers");
   // distinct minimizers
   std::vector<uint64_t> keys, kstart;  // key value, first index into ents
   for (uint64_t i = 0; i < ents.size(); ++i) if (i == 0 || ents[i].v != ents[i - 1].v) { keys.push_back(ents[i].v); kstart.push_back(i); }
   kstart.push_back(ents.size());
   const uint64_t NK = keys.size();
   idx->num_minimizers = NK;
+  phase("distinct minimizers");
   // ---- partitioned pilot MPHF ----
   uint32_t nparts = (uint32_t)std::max<uint64_t>(1, (NK + SQ_MPHF_PART_KEYS - 1) / SQ_MPHF_PART_KEYS);
   idx->n_parts = nparts;
@@ -383,6 +472,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     }
   });
   if (mphf_fail.load()) { sq_set_error("MPHF pilot search failed (increase slack)"); return SQ_ERR_STATE; }
+  phase("MPHF");
   // ---- slot records, entry lists, skew table ----
   idx->slots.assign(slot_key.size(), SQ_SLOT_EMPTY);
   idx->entries.clear();
@@ -417,6 +507,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       idx->skew_keys[h] = skew_k[i]; idx->skew_vals[h] = skew_v[i];
     }
   }
+  phase("slot records");
   return SQ_OK;
 }
 
