@@ -87,3 +87,20 @@ def test_polya_clipping_duplicates_and_short_refs(built):
     idx2 = api.SalmonIndex.build_mem(names, seqs, threads=1, keep_duplicates=True, no_clip=True)
     assert idx2.num_refs == 4 and list(idx2.ref_lens()) == [100, 100, 110, 10]
     assert orc.check_cdbg(idx2) == 0
+
+
+def test_partitioned_kmer_table_builds_the_same_index(built, tmp_path, monkeypatch):
+    # the builder's k-mer table under a tiny memory budget (dozens of hash partitions, SQ_INDEX_TABLE_GB) writes the same index file,
+    # byte for byte, as the single pass; long unitigs (a decoy "chromosome") go through the 4 M-position pieces of the minimizer phase
+    import hashlib
+    rng = np.random.default_rng(4)
+    tx = synth.Txome(seed=8, n_genes=60, iso_per_gene=4, threads=2)
+    names = [n if isinstance(n, str) else n.decode() for n in tx.names()]; seqs = [s.decode() for s in tx.seqs()]
+    chrom = "".join(rng.choice(list("ACGT"), 5_000_000)); chrom = chrom[:100000] + seqs[3] + chrom[100000:]
+    def build(tag):
+        d = str(tmp_path / tag)
+        api.SalmonIndex.build_mem(names + ["chrD"], seqs + [chrom], threads=4, first_decoy=len(seqs), outdir=d).free()
+        return hashlib.sha256(open(os.path.join(d, "index.bin"), "rb").read()).hexdigest()
+    one = build("one")
+    monkeypatch.setenv("SQ_INDEX_TABLE_GB", "0.004")      # 400 k slots per pass: ~17 passes over 5 M k-mers
+    assert build("many") == one
