@@ -233,7 +233,7 @@ int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stat
 /* Alignments of the batch sq_map_wait / sq_map_batch returned last, copied out of HBM on demand (they stay in that lane's
  * buffers until the lane maps again).  out->read_off == out->aln == NULL: only out->n and out->aln_cap (= alignments
  * held) are filled — the size query the SAM writer makes before it sizes its arrays. */
-int sq_map_fetch(sq_ctx*, sq_aln_batch* out);
+int sq_map_fetch(sq_ctx*, sq_aln_batch* out);   /* out->map_type alone (read_off == aln == NULL): only the per-fragment mapping types */
 
 /* ------------------------------------------------------------------------------------------------
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +
@@ -247,8 +247,8 @@ int sq_map_fetch(sq_ctx*, sq_aln_batch* out);
 typedef struct sq_reader sq_reader;
 int sq_reader_open(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2,
                    uint32_t batch_reads, uint32_t num_slots, sq_reader** out);
-/* flags: SQ_READER_KEEP_NAMES also keeps the read names of the mate-1 stream (header up to the first blank, a
- * trailing /1 or /2 dropped) for sq_reader_names — only the SAM writer (--writeMappings) asks for them. */
+/* flags: SQ_READER_KEEP_NAMES also keeps the read names of the mate-1 stream (header up to the first blank) for
+ * sq_reader_names — the SAM writer (--writeMappings) and --writeUnmappedNames ask for them. */
 #define SQ_READER_KEEP_NAMES 1u
 int sq_reader_open_ex(const char* const* files1, uint32_t n1, const char* const* files2, uint32_t n2,
                       uint32_t batch_reads, uint32_t num_slots, uint32_t flags, sq_reader** out);
@@ -388,6 +388,8 @@ int sq_normalize_alphas(uint32_t num_txp, const sq_eq_table* eq, const double* l
 /* B4 output files: quant.sf (GZipWriter.cpp:684-739; num_mapped_frags <= 0 -> explicit sum) and
  * aux_info/eq_classes.txt.gz (GZipWriter.cpp:64-168). */
 int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags);
+/* the same with --sigDigits decimals for EffectiveLength and NumReads (GZipWriter.cpp:734-736; default 3) */
+int sq_write_quant_sf_digits(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags, int sig_digits);
 int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights);
 
 /* aux_info/ambig_info.tsv (GZipWriter.cpp:601-638): UniqueCount / AmbigCount per transcript from the eq-classes. */

@@ -184,6 +184,7 @@ def lib():
         "sq_model_fetch_lib_counts": (C.c_int, [vp, P(u64)]), "sq_write_lib_format_counts": (C.c_int, [C.c_char_p, C.c_char_p, u8, u8, u8, P(u64),
             u64, u64]),
         "sq_write_ambig_info": (C.c_int, [C.c_char_p, u32, P(EqTable)]),
+        "sq_write_quant_sf_digits": (C.c_int, [C.c_char_p, vp, P(f64), P(f64), f64, C.c_int]),
         "sq_write_quant_sf_names": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(u32), P(f64), P(f64), f64]),
         "sq_eq_file_read": (C.c_int, [C.c_char_p, P(vp)]), "sq_eq_file_free": (None, [vp]), "sq_eq_file_num_txp": (u32,
             [vp]), "sq_eq_file_name": (C.c_char_p, [vp, u32]),

@@ -156,7 +156,8 @@ struct SamWriter {
   void batch(sq_index* idx, const sq_read_batch& in, const char* names, const uint64_t* noff, const sq_aln_batch& ab) {
     for (uint32_t r = 0; r < ab.n; ++r) {
       const uint64_t a0 = ab.read_off[r], a1 = ab.read_off[r + 1]; if (a0 == a1) continue;
-      const char* nm = names + noff[r]; const size_t nl = (size_t)(noff[r + 1] - noff[r]); const uint32_t nh = (uint32_t)(a1 - a0);
+      const char* nm = names + noff[r]; size_t nl = (size_t)(noff[r + 1] - noff[r]); const uint32_t nh = (uint32_t)(a1 - a0);
+      if (nl > 2 && nm[nl - 2] == '/' && (nm[nl - 1] == '1' || nm[nl - 1] == '2')) nl -= 2;   // QNAME: what both mates share
       const uint8_t* s1 = in.seq + in.seq_off[in.paired ? 2 * r : r]; const uint32_t l1 = (uint32_t)(in.seq_off[(in.paired ? 2 * r : r) + 1] - in.seq_off[in.paired ? 2 * r : r]);
       const uint8_t* s2 = in.paired ? in.seq + in.seq_off[2 * r + 1] : nullptr; const uint32_t l2 = in.paired ? (uint32_t)(in.seq_off[2 * r + 2] - in.seq_off[2 * r + 1]) : 0;
       for (uint64_t i = a0; i < a1; ++i) {
@@ -176,6 +177,7 @@ struct SamWriter {
     }
   }
 };
+static std::string g_aux_name = "aux_info";   // --auxDir
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 static int part_cb(const double* a, uint32_t m, void* user) { return fwrite(a, 8, m, (FILE*)user) == m ? 0 : 1; }   // a rank's replicates, raw, for rank 0 to collect
 
@@ -202,15 +204,15 @@ static SampInfo run_sampling(int argc, char** argv, int device, const sq_eq_tabl
     if (nb) { if (sq_bootstrap_range_dev(device, t, tx, eop, nb, first, count, seed, num_mapped, cb, user)) die("bootstrap"); }
     else if (sq_gibbs_range_dev(device, t, tx, &go, alphas, ng, first, count, seed, num_mapped, cb, user)) die("Gibbs sampling");
   };
-  const std::string bdir = od + "/aux_info/bootstrap";
+  const std::string bdir = od + "/" + g_aux_name + "/bootstrap";
   if (rank != 0) {   // raw rows into a part file; rank 0 appends them to bootstraps.gz in rank order
-    mkdir((od + "/aux_info").c_str(), 0755); mkdir(bdir.c_str(), 0755);
+    mkdir((od + "/" + g_aux_name).c_str(), 0755); mkdir(bdir.c_str(), 0755);
     FILE* pf = fopen((bdir + "/.part" + std::to_string(rank)).c_str(), "wb"); if (!pf) { fprintf(stderr, "[salmon-hip] cannot write replicate part file\n"); exit(1); }
     run(part_cb, pf); fclose(pf);
     if (sq_dist_barrier(dist)) die("barrier");
     SampInfo si; si.n = total; si.type = nb ? "bootstrap" : "gibbs"; return si;
   }
-  sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/aux_info").c_str(), M, names.data(), &bw)) die("bootstrap writer");
+  sq_boot_writer* bw = nullptr; if (sq_boot_writer_open((od + "/" + g_aux_name).c_str(), M, names.data(), &bw)) die("bootstrap writer");
   run(boot_cb, bw);
   if (dist && world > 1) {
     if (sq_dist_barrier(dist)) die("barrier");
@@ -298,10 +300,11 @@ static int cmd_quant(int argc, char** argv) {
   check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "--device", "--batch", "--lanes", "--gpus", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
                           "--rangeFactorizationBins", "--mismatchSeedSkip", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor",
                           "--incompatPrior", "--maxOccsPerHit", "--maxReadOcc", "--fldMax", "--fldMean", "--fldSD", "--forgettingFactor", "--numPreAuxModelSamples",
-                          "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth"},
+                          "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth",
+                          "--minAssignedFrags", "--sigDigits", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--writeMappings", "-z"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
@@ -372,6 +375,17 @@ static int cmd_quant(int argc, char** argv) {
   if (flag(argc, argv, "--recoverOrphans")) qo.recover_orphans = 1;   // ProgramOptionsGenerator.cpp:202-206
   if (flag(argc, argv, "--discardOrphansQuasi")) qo.allow_orphans = 0;
   if (flag(argc, argv, "--disableChainingHeuristic")) qo.disable_chaining_heuristic = 1;
+  if ((v = arg(argc, argv, "--preMergeChainSubThresh"))) qo.pre_merge_chain_sub_thresh = atof(v);      // ProgramOptionsGenerator.cpp: chain filters before / after
+  if ((v = arg(argc, argv, "--postMergeChainSubThresh"))) qo.post_merge_chain_sub_thresh = atof(v);    // merging the ends, and for orphans
+  if ((v = arg(argc, argv, "--orphanChainSubThresh"))) qo.orphan_chain_sub_thresh = atof(v);
+  if ((v = arg(argc, argv, "--hitFilterPolicy"))) { std::string pol(v); for (auto& ch : pol) ch = (char)toupper((unsigned char)ch);
+    if (pol != "AFTER") { fprintf(stderr, "[salmon-hip] --hitFilterPolicy %s is not supported (only the default AFTER is built)\n", v); return 1; } }
+  const bool quiet = flag(argc, argv, "--quiet") || flag(argc, argv, "-q");
+  const uint64_t min_assigned = (v = arg(argc, argv, "--minAssignedFrags")) ? strtoull(v, nullptr, 10) : 10;      // SalmonDefaults.hpp: minAssignedFrags
+  const int sig_digits = (v = arg(argc, argv, "--sigDigits")) ? std::max(0, std::min(15, atoi(v))) : 3;
+  const std::string aux_name = (v = arg(argc, argv, "--auxDir")) ? v : "aux_info";
+  const bool write_unmapped = flag(argc, argv, "--writeUnmappedNames");
+  g_aux_name = aux_name;
   sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
   if (sq_ctx_reserve(ctx, 0, 0)) die("reserving end-of-job buffers");   // the reference pre-sizes its eq-class map the same way (EquivalenceClassBuilder.hpp:140)
   // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
@@ -391,7 +405,16 @@ static int cmd_quant(int argc, char** argv) {
     if (world > 1) { fprintf(stderr, "[salmon-hip] --writeMappings needs one GPU (the ranks would interleave their records)\n"); return 1; }
     if (!sam.open(sam_path, idx, sq_index_first_decoy(idx), argc, argv)) { fprintf(stderr, "[salmon-hip] cannot open %s\n", sam_path); return 1; }
   }
-  if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, sam_path ? SQ_READER_KEEP_NAMES : 0,
+  // --writeUnmappedNames: aux_info/unmapped_names.txt, "<read name> <u|m1|m2|m12|d|..>" for every fragment that is not (pair- / single-) mapped
+  // (SalmonQuantify.cpp:1793-1799, :2270-2274; the codes are salmon::utils::str(MappingType), SalmonUtils.cpp:62-81)
+  FILE* unm = nullptr; std::vector<uint8_t> unm_mt;
+  if (write_unmapped) {
+    if (world > 1) { fprintf(stderr, "[salmon-hip] --writeUnmappedNames needs one GPU\n"); return 1; }
+    mkdir(odir, 0755); mkdir((std::string(odir) + "/" + g_aux_name).c_str(), 0755);
+    unm = fopen((std::string(odir) + "/" + g_aux_name + "/unmapped_names.txt").c_str(), "w");
+    if (!unm) { fprintf(stderr, "[salmon-hip] cannot write unmapped_names.txt\n"); return 1; }
+  }
+  if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, (sam_path || unm) ? SQ_READER_KEEP_NAMES : 0,
       &rd)) die("opening reads");
   sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight; std::vector<sq_read_batch> inflight_in;
   std::vector<uint64_t> sam_off; std::vector<sq_aln> sam_aln;
@@ -405,12 +428,19 @@ static int cmd_quant(int argc, char** argv) {
       const char* nm; const uint64_t* no; if (sq_reader_names(rd, inflight.front(), &nm, &no)) die("read names");
       sam.batch(idx, inflight_in.front(), nm, no, ab);
     }
+    if (unm) {
+      sq_aln_batch ab{}; unm_mt.resize((size_t)st.num_reads + 1); ab.map_type = unm_mt.data(); if (sq_map_fetch(ctx, &ab)) die("mapping types");
+      const char* nm; const uint64_t* no; if (sq_reader_names(rd, inflight.front(), &nm, &no)) die("read names");
+      static const char* code[] = {"u", "m1", "m2", "m12", "mp", "ms", "d"};
+      for (uint32_t r = 0; r < ab.n; ++r) { const uint8_t mt = unm_mt[r]; if (mt == SQ_MT_PAIRED_MAPPED || mt == SQ_MT_SINGLE_MAPPED) continue;
+        fwrite(nm + no[r], 1, (size_t)(no[r + 1] - no[r]), unm); fprintf(unm, " %s\n", code[mt < 7 ? mt : 0]); }
+    }
     inflight_in.erase(inflight_in.begin());
     if (sq_eq_accumulate(ctx)) die("eq-class accumulation");
     sq_reader_release(rd, inflight.front()); inflight.erase(inflight.begin());
     uint64_t* a = (uint64_t*)&tot; const uint64_t* b = (const uint64_t*)&st; for (size_t i = 0; i < sizeof(st) / 8; ++i) a[i] += b[i];
     nfrag += st.num_reads;
-    fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
+    if (!quiet) fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
   };
   uint64_t batch_no = 0;
   for (;;) {
@@ -424,8 +454,9 @@ static int cmd_quant(int argc, char** argv) {
   }
   while (!inflight.empty()) finish_one();
   if (sam_path) { sam.close(); fprintf(stderr, "\n[salmon-hip] wrote %llu SAM records to %s", (unsigned long long)sam.nrec, !strcmp(sam_path, "-") ? "stdout" : sam_path); }
+  if (unm) fclose(unm);
   sq_reader_close(rd);
-  fprintf(stderr, "\n");
+  if (!quiet) fprintf(stderr, "\n");
   if (tot.num_truncated_ends) fprintf(stderr, "[salmon-hip] warning: %llu read ends were longer than 256 bases and were cut to their first 256 (the packing limit of the GPU path)\n",
       (unsigned long long)tot.num_truncated_ends);
   if (dist) {   // ONE exchange of the class tables, counters summed
@@ -452,9 +483,9 @@ static int cmd_quant(int argc, char** argv) {
     ms.num_observed = c4[0]; ms.num_assigned = c4[1]; ms.num_mapped_ub = c4[2]; ms.num_compatible = c4[3];
     for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
   }
-  mkdir(odir, 0755); std::string od(odir); mkdir((od + "/aux_info").c_str(), 0755);
+  mkdir(odir, 0755); std::string od(odir); mkdir((od + "/" + g_aux_name + "").c_str(), 0755);
   sq_em_report rep{}; SampInfo si;
-  if (ms.num_assigned < 10) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
+  if (ms.num_assigned < min_assigned) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
     fprintf(stderr, "[salmon-hip] only %llu fragments were assigned; writing empty quantification\n", (unsigned long long)ms.num_assigned);
   } else {
     if (sq_normalize_alphas(M, &t, lm.data(), uq.data(), tc.data(), proj.data())) die("normalizeAlphas");
@@ -486,8 +517,8 @@ static int cmd_quant(int argc, char** argv) {
     si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned, dist);
   }
   if (rank != 0) { sq_dist_free(dist); sq_ctx_free(ctx); sq_index_free(idx); return 0; }   // every rank computed the same result; rank 0 writes it
-  if (sq_write_quant_sf((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits)) die("quant.sf");
-  if (sq_write_ambig_info((od + "/aux_info/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
+  if (sq_write_quant_sf_digits((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits, sig_digits)) die("quant.sf");
+  if (sq_write_ambig_info((od + "/" + g_aux_name + "/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
   { const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
     const uint8_t dt = (uint8_t)(ms.lib_format_id & 1), dor = (uint8_t)((ms.lib_format_id >> 1) & 3), dst = (uint8_t)(ms.lib_format_id >> 3);   // the detected format with -l A
     for (auto& kv : kLib) if (kv.second[0] == dt && kv.second[1] == dor && kv.second[2] == dst) lib = kv.first;
@@ -503,13 +534,13 @@ static int cmd_quant(int argc, char** argv) {
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
     if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
   if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv,
-      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/aux_info/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv,
+      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/" + g_aux_name + "/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv,
           "--dumpEqWeights"))) die("eq_classes");
   // SalmonQuantify.cpp:2697-2701
   if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n",
       (unsigned long long)tot.num_orphans_rescued);
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  FILE* mf = fopen((od + "/aux_info/meta_info.json").c_str(), "w");
+  FILE* mf = fopen((od + "/" + g_aux_name + "/meta_info.json").c_str(), "w");
   if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)
     fprintf(mf,
         "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
@@ -525,7 +556,7 @@ static int cmd_quant(int argc, char** argv) {
                 (unsigned long long)tot.num_mappings_filtered,
             nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
                 rep.iters,
-                ms.num_assigned < 10 ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false");
+                ms.num_assigned < min_assigned ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false");
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
@@ -534,7 +565,7 @@ static int cmd_quant(int argc, char** argv) {
         lib.c_str(), odir);
     fclose(cf);
   }
-  fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n",
+  if (!quiet) fprintf(stderr, "[salmon-hip] %llu fragments, %llu assigned (%.2f%%), %llu eq-classes, %u %s iterations, %.2fs -> %s/quant.sf\n",
       (unsigned long long)nfrag,
       (unsigned long long)ms.num_assigned,
           nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv,

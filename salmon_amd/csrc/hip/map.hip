@@ -343,7 +343,11 @@ extern "C" int sq_map_fetch(sq_ctx* c, sq_aln_batch* out) {
   if (!c->api_have || !c->last_src) { sq_set_error("sq_map_fetch: no mapped batch"); return SQ_ERR_STATE; }
   sq_ctx* src = c->last_src; const uint32_t n = c->acc_n; const uint64_t total = c->acc_total_aln; const int buf = c->acc_buf;
   out->n = n;
-  if (!out->aln && !out->read_off) { out->aln_cap = total; return SQ_OK; }     // size query
+  if (!out->aln && !out->read_off) {     // size query; with map_type given: the mapping types alone
+    out->aln_cap = total;
+    if (out->map_type) { SQ_HIP_CHECK(hipSetDevice(c->device)); SQ_HIP_CHECK(hipMemcpy(out->map_type, src->map_type.p, n, hipMemcpyDeviceToHost)); }
+    return SQ_OK;
+  }
   if (!out->read_off || (!out->aln && total)) { sq_set_error("sq_map_fetch: output arrays missing"); return SQ_ERR_ARG; }
   if (total > out->aln_cap) { sq_set_error("alignment buffer too small: need %llu, have %llu", (unsigned long long)total, (unsigned long long)out->aln_cap); return SQ_ERR_OVERFLOW; }
   SQ_HIP_CHECK(hipSetDevice(c->device));

@@ -133,7 +133,11 @@ extern "C" int sq_normalize_alphas(uint32_t M, const sq_eq_table* eq, const doub
 // quant.sf: Name Length EffectiveLength TPM NumReads (GZipWriter.cpp:698-736)
 extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads,
     double num_mapped_frags) {
-  if (!path || !idx || !eff_len || !num_reads) { sq_set_error("sq_write_quant_sf: bad arguments"); return SQ_ERR_ARG; }
+  return sq_write_quant_sf_digits(path, idx, eff_len, num_reads, num_mapped_frags, 3);   // salmon::defaults::sigDigits
+}
+extern "C" int sq_write_quant_sf_digits(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads,
+    double num_mapped_frags, int sig_digits) {
+  if (!path || !idx || !eff_len || !num_reads || sig_digits < 0 || sig_digits > 30) { sq_set_error("sq_write_quant_sf: bad arguments"); return SQ_ERR_ARG; }
   FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
   // decoys are dropped before inference and output (readExp.dropDecoyTranscripts(), SalmonQuantify.cpp:2479): targets only
   const uint32_t M = std::min<uint32_t>((uint32_t)idx->names.size(), idx->first_decoy);
@@ -147,7 +151,7 @@ extern "C" int sq_write_quant_sf(const char* path, const sq_index* idx, const do
   fprintf(f, "Name\tLength\tEffectiveLength\tTPM\tNumReads\n");
   for (uint32_t i = 0; i < M; ++i) {
     double npm = num_reads[i] / num_mapped_frags; double tpm = denom > 0 ? ((npm / eff_len[i]) / denom) * 1000000.0 : 0.0;
-    fprintf(f, "%s\t%u\t%.3f\t%f\t%.3f\n", idx->names[i].c_str(), idx->ref_clen[i], eff_len[i], tpm, num_reads[i]);              // sigDigits = 3
+    fprintf(f, "%s\t%u\t%.*f\t%f\t%.*f\n", idx->names[i].c_str(), idx->ref_clen[i], sig_digits, eff_len[i], tpm, sig_digits, num_reads[i]);   // --sigDigits (GZipWriter.cpp:734-736)
   }
   fclose(f);
   return SQ_OK;

@@ -39,10 +39,10 @@ namespace {
 
 struct RecBlock { std::vector<char> seq; std::vector<uint32_t> len; std::vector<char> names; std::vector<uint32_t> nlen; };   // sequences back to back (+ names on request)
 
-// read name = the header up to the first blank, without a trailing /1 or /2 (what both mates of a pair share)
+// read name = the header up to the first blank (kseq's name field: what the reference prints in unmapped_names.txt; the SAM writer
+// drops a trailing /1 or /2 itself)
 inline size_t name_len(const char* h, size_t n) {
   size_t l = 0; while (l < n && h[l] != ' ' && h[l] != '\t' && h[l] != '\r') ++l;
-  if (l > 2 && h[l - 2] == '/' && (h[l - 1] == '1' || h[l - 1] == '2')) l -= 2;
   return l;
 }
 

@@ -153,7 +153,7 @@ def test_reader_fast_path_across_chunks(built, tmp_path, gz, monkeypatch):
 
 @pytest.mark.parametrize("safe", [False, True])
 def test_reader_keeps_read_names_on_request(built, tmp_path, safe, monkeypatch):
-    # SQ_READER_KEEP_NAMES: name = header up to the first blank, trailing /1 dropped; both parser paths; without the flag the call is refused
+    # SQ_READER_KEEP_NAMES: name = header up to the first blank (kseq's name field); both parser paths; without the flag the call is refused
     if safe: monkeypatch.setenv("SQ_READER_SAFE", "1")
     L = capi.lib(); rng = np.random.default_rng(5); n = 5000
     hdr = ["frag%d/1 extra words" % i if i % 3 == 0 else ("frag%d\tx" % i if i % 3 == 1 else "frag%d" % i) for i in range(n)]
@@ -175,7 +175,7 @@ def test_reader_keeps_read_names_on_request(built, tmp_path, safe, monkeypatch):
         names += [raw[off[i]:off[i + 1]].decode() for i in range(rb.n)]
         L.sq_reader_release(h, slot.value)
     L.sq_reader_close(h)
-    assert names == ["frag%d" % i for i in range(n)]
+    assert names == [("frag%d/1" % i if i % 3 == 0 else "frag%d" % i) for i in range(n)]
     h = _open(f1, f2, batch=100); rb = capi.ReadBatch(); slot = C.c_int(-1); L.sq_reader_next(h, C.byref(rb), C.byref(slot))
     nm = C.c_void_p(); no = C.POINTER(C.c_uint64)()
     assert L.sq_reader_names(h, slot.value, C.byref(nm), C.byref(no)) != 0 and b"KEEP_NAMES" in L.sq_last_error()

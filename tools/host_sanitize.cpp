@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
     uint64_t n = 0, bytes = 0; int held[2] = {-1, -1};
     for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break;
       { const char* nm; const uint64_t* no; CHECK(sq_reader_names(rd, slot, &nm, &no) == SQ_OK);
-        for (uint32_t i = 0; i < b.n; i += 131) { char want[32]; snprintf(want, sizeof want, "r%llu", (unsigned long long)(n + i)); CHECK(std::string(nm + no[i], nm + no[i + 1]) == want); } }
+        for (uint32_t i = 0; i < b.n; i += 131) { char want[32]; snprintf(want, sizeof want, "r%llu/1", (unsigned long long)(n + i)); CHECK(std::string(nm + no[i], nm + no[i + 1]) == want); } }
       n += b.n; bytes += b.seq_off[2 * b.n];
       for (uint64_t i = 0; i < b.seq_off[2 * b.n]; i += 97) CHECK(strchr("ACGT", (char)b.seq[i]) != nullptr);
       if (held[0] >= 0) sq_reader_release(rd, held[0]); held[0] = held[1]; held[1] = slot; }
