@@ -419,8 +419,12 @@ def normalize_alphas(eq, log_mass, uniq, total):
     return out
 
 
-def write_quant_sf(path, index, eff_len, num_reads, num_mapped=0.0):
+def write_quant_sf(path, index, eff_len, num_reads, num_mapped=0.0, sig_digits=None):
     e = np.ascontiguousarray(eff_len, np.float64); r = np.ascontiguousarray(num_reads, np.float64)
+    if sig_digits is not None:   # --sigDigits
+        check(lib().sq_write_quant_sf_digits(path.encode(), index.h, _ptr(e, C.c_double), _ptr(r, C.c_double), float(num_mapped), int(sig_digits)),
+              "sq_write_quant_sf_digits")
+        return
     check(lib().sq_write_quant_sf(path.encode(), index.h, _ptr(e, C.c_double), _ptr(r, C.c_double), float(num_mapped)), "sq_write_quant_sf")
 
 

@@ -104,3 +104,18 @@ def test_partitioned_kmer_table_builds_the_same_index(built, tmp_path, monkeypat
     one = build("one")
     monkeypatch.setenv("SQ_INDEX_TABLE_GB", "0.004")      # 400 k slots per pass: ~17 passes over 5 M k-mers
     assert build("many") == one
+
+
+def test_quant_sf_writer_digits_and_decoy_rows(built, tmp_path):
+    # sq_write_quant_sf(_digits): rows for the targets only (decoys are dropped), TPM normalised over them, --sigDigits decimals
+    names = ["t0", "t1", "t2", "decoyA"]; rng = np.random.default_rng(2)
+    seqs = ["".join(rng.choice(list("ACGT"), n)) for n in (400, 500, 600, 3000)]
+    idx = api.SalmonIndex.build_mem(names, seqs, threads=1, first_decoy=3)
+    eff = np.array([250.123456, 350.5, 450.0, 1.0]); reads = np.array([10.0, 30.25, 0.0, 99.0])
+    api.write_quant_sf(str(tmp_path / "a.sf"), idx, eff, reads); api.write_quant_sf(str(tmp_path / "b.sf"), idx, eff, reads, sig_digits=6)
+    a = [l.split("\t") for l in open(tmp_path / "a.sf").read().splitlines()]; b = [l.split("\t") for l in open(tmp_path / "b.sf").read().splitlines()]
+    assert a[0] == ["Name", "Length", "EffectiveLength", "TPM", "NumReads"] and [r[0] for r in a[1:]] == ["t0", "t1", "t2"]
+    assert a[1][2] == "250.123" and b[1][2] == "250.123456" and a[2][4] == "30.250" and b[2][4] == "30.250000" and a[3][4] == "0.000"
+    tpm = np.array([float(r[3]) for r in a[1:]]); w = reads[:3] / eff[:3]
+    assert abs(tpm.sum() - 1e6) < 1.0 and np.allclose(tpm, 1e6 * w / w.sum(), rtol=1e-6) and [r[3] for r in a[1:]] == [r[3] for r in b[1:]]
+    idx.free()
