@@ -96,8 +96,9 @@ def build_oracle():
 
 def build_oracle_ref(reference="/root/reference"):
     """oracle/_ref/libedlib_ref.so: the reference's own infix aligner (src/edlib.cpp, row a5) compiled from where it lies
-    under /root/reference plus a C shim.  Only where the reference tree exists (this container); the GPU box uses the
-    prebuilt file that travels with the snapshot.  Returns the path or None."""
+    under /root/reference plus a C shim; oracle/_ref/libdefaults_ref.so: its option defaults and log-space helpers (two header-only
+    files).  Only where the reference tree exists (this container); the GPU box uses the prebuilt files that travel with the
+    snapshot.  Returns the path of the first or None."""
     out = os.path.join(ROOT, "oracle", "_ref", "libedlib_ref.so")
     if not os.path.exists(os.path.join(reference, "src", "edlib.cpp")):
         return out if os.path.exists(out) else None
