@@ -1,14 +1,21 @@
 #!/usr/bin/env python
 """bench.py — `salmon quant` hot path (map + eq-classes + EM) on MI355X, BASELINE.json metric.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c2s|c5|c4]   (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path (sq_map_batch + sq_eq_accumulate) over one batch of synthetic
-read pairs already resident in HBM.  The default N=1 workload is BASELINE.json configs[1]: a
-human-transcriptome-shaped index (synthetic T200k: 20 000 genes x ~10 isoforms, k=31) and
-K x batch = 10 x 4 000 000 = 40 M synthetic 2x100 bp pairs, followed by the job's inference tail
-(eq-class export, normalizeAlphas, VBEM to convergence), all inside the timed region.  Weak scaling:
-every rank maps its own K batches; eq-class tables are all-gathered over RCCL and merged exactly.
+A "step" is one pass of the hot path (sq_map_batch + sq_eq_accumulate) over one batch of synthetic read pairs already
+resident in HBM; a batch is handed over as `--sub` consecutive sq_map_batch calls of `--batch` pairs (the library maps at
+most 2^23 pairs per call).  Workloads (BASELINE.json `configs`):
+
+  c2  (default, configs[1]/[2])  human-transcriptome-shaped index (synthetic: 60 000 genes x ~4 isoforms, ~190 k transcripts,
+        ~430 Mnt, ~150 M distinct 31-mers — SURVEY.md §8 shape C2), K x 16 M 2x100 bp pairs, then the job's inference tail
+        (eq-class export, normalizeAlphas, VBEM to convergence), all inside the timed region.
+  c2s the round-1/2 index (20 000 genes x ~10 isoforms: 54 M distinct k-mers, 5.3 alignments per fragment), same job.
+  c5  (configs[4]) c2's index, 50 M pairs, VBEM, then 100 Gibbs samples (4 chains x 25 samples x 16 thinning rounds) in the timed region.
+  c4  (configs[3]) decoy-aware index: c2's transcriptome + a synthetic genome (`--genome-gnt`, default 1.0 Gnt; every gene's exons
+        with introns, 45 % repeat families) as decoys, 2x150 bp pairs of which 5 % come from gene loci of the genome.
+
+Weak scaling: every rank maps its own K batches; eq-class tables are all-gathered over RCCL and merged exactly.
 Prints ONE JSON line on rank 0.
 """
 import argparse, json, os, sys, time
@@ -17,39 +24,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np
 
+WORKLOADS = {
+    # genes, iso, read_len, batch, sub, genome_gnt, genomic_frac
+    "c2": dict(genes=60000, iso=4, read_len=100, batch=8000000, sub=2, genome_gnt=0.0, genomic=0.0),
+    "c2s": dict(genes=20000, iso=10, read_len=100, batch=4000000, sub=1, genome_gnt=0.0, genomic=0.0),
+    "c5": dict(genes=60000, iso=4, read_len=100, batch=5000000, sub=1, genome_gnt=0.0, genomic=0.0),
+    "c4": dict(genes=60000, iso=4, read_len=150, batch=4000000, sub=1, genome_gnt=1.0, genomic=0.05),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="default: 10 (c2, c2s, c5 = 50 M pairs), 6 (c4)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4000000,
-        help="read pairs per step (one sq_map_batch call); 4 x 10^6 amortises the tails of the persistent kernels: 65 vs 52 M pairs/s at 10^6 on MI355X")
-    ap.add_argument("--genes", type=int, default=20000)
-    ap.add_argument("--iso", type=int, default=10)
-    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="read pairs per sq_map_batch call (<= 2^23)")
+    ap.add_argument("--sub", type=int, default=None, help="sq_map_batch calls per step")
+    ap.add_argument("--genes", type=int, default=None)
+    ap.add_argument("--iso", type=int, default=None)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--genome-gnt", type=float, default=None, help="c4: decoy genome size in 10^9 nt")
+    ap.add_argument("--gibbs-samples", type=int, default=100, help="c5: posterior samples (100 = 4 chains, 1600 rounds)")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
-        help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (device-resident all_gather + merge) runs on a 1-GPU box")
+        help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (the RCCL exchange + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
     ap.add_argument("--fastq-pairs", type=int, default=4000000,
-        help="second measurement (outside the timed steps, rank 0, N=1): this many pairs written as plain FASTQ files to /dev/shm and run through "
+        help="second measurement (outside the timed steps, rank 0, N=1, c2/c2s): this many pairs written as FASTQ files to /dev/shm and run through "
              "the host read pipeline (sq_reader) + the same GPU path, end to end from files (0 = skip)")
     ap.add_argument("--py-dist", action="store_true",
         help="N>1: exchange the class tables with torch.distributed collectives (salmon_amd/dist.py) instead of the library's own RCCL path (sq_dist_*, the default)")
     ap.add_argument("--inflight", type=int, default=0,
         help="mini-batches per model snapshot (sq_quant_opts.mini_batches_in_flight = the reference's -p / numThreads); 0 = the library default (8)")
-    ap.add_argument("--lanes", type=int, default=1,
-        help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch. Measured on MI355X: 2 lanes shorten mapping (18.4 -> 17.4 ms per step) but the ordered online/eq chain (14.6 ms per step on its CU partition) then lags and the job does not finish sooner")
-    return ap.parse_args()
+    ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch")
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload]
+    for k_arg, k_w in (("batch", "batch"), ("sub", "sub"), ("genes", "genes"), ("iso", "iso"), ("read_len", "read_len"), ("genome_gnt", "genome_gnt")):
+        if getattr(a, k_arg) is None: setattr(a, k_arg, w[k_w])
+    a.genomic = w["genomic"] if a.genome_gnt > 0 else 0.0
+    if a.steps is None: a.steps = 6 if a.workload == "c4" else 10
+    return a
 
 
-# algorithmic bytes per unit for every stage (DESIGN.md §5 states the same table)
+# algorithmic bytes per unit for every stage (DESIGN.md §5 states the same table); `st` = the sq_map_stats counters summed over the timed steps
 def stage_bytes(st, n_pairs, read_len, paired=True):
     nrec = 2 * n_pairs if paired else n_pairs
     L = read_len
+    pk = 8 * ((L + 31) // 32) + 4 * ((L + 63) // 64) * 2     # packed read + N mask actually touched
     return {
         "k_pack": nrec * (L + 8 + 64 + 32 + 2),
         # every probe reads one word (a 64 B sector) of the k-mer membership filter; a probe that passes (every hit; < 1 % of the misses)
@@ -58,17 +82,24 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32 + 16),
         "scan_mems": nrec * (4 + 8),
         # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
-        # (the uni-MEM record carries its contig-table run since round 2: 32 B each, no bounds gathers; 16 B list entry per end)
         "k_mems": st["num_seeds"] * 32 + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (16 + 4),
         "k_join_fill": st["num_chains"] * 40 + st["num_candidates"] * 52 + n_pairs * 16,
-        "k_score": st["num_candidates"] * (48 * 2 + 2 * 40 + 2 * (96 + 64) + 4) + st["num_mems"] * 0,
+        # [r3] SURVEY §8(d): each distinct sector once per read — the packed reads and chain heads of a fragment are charged once per
+        # fragment (its candidates share them), the candidate record, its reference window and its score once per candidate
+        "k_score": st["num_candidates"] * (48 + 64 * ((L + 40 + 255) // 256) + 16 + 4) + n_pairs * 2 * pk + st["num_chains"] * 16,
         "k_dp": st["num_dp_alignments"] * (48 + 96 + 64 + 2 * 40 + 2 * 4),   # + the queue read twice more and the permutation (counting sort by length)
-        "k_select": st["num_candidates"] * (48 * 2) + st["num_alignments"] * 40 + n_pairs * 30,
+        "k_finalize": st["num_candidates"] * (48 + 8) + n_pairs * 8,
+        "k_select": st["num_candidates"] * 48 + st["num_alignments"] * 40 + n_pairs * 30,
         "compact_alns": st["num_alignments"] * 80 + n_pairs * 28,
-        "eq_flags_scan": st["num_alignments"] * 40 + n_pairs * 24,
-        "eq_mini_batches": st["num_alignments"] * (40 + 12 + 3 * 16) + n_pairs * 32,
-        "eq_table": st["num_alignments"] * (40 + 12 + 8) + n_pairs * (16 + 4 + 32),
+        "eq_flags_scan": st["num_alignments"] * (40 + 32) + n_pairs * 24,
+        "eq_mini_batches": st["num_alignments"] * (32 + 8 + 8 + 4 + 3 * 16) + n_pairs * 32,
+        "eq_table": st["num_alignments"] * (4 + 4 + 8 + 8) + n_pairs * (16 + 4 + 32),
     }
+
+
+KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
+                   "k_select": "k_select", "k_finalize": "k_finalize", "compact_alns": "k_compact_alns", "eq_mini_batches": "k_mini_batch",
+                   "eq_table": "k_eq_insert"}
 
 
 def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
@@ -98,16 +129,17 @@ def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
     dt = time.perf_counter() - t0
     lib.sq_reader_close(h)
     return {"value": round(n / dt / 1e6, 3), "unit": "M read-pairs/s", "pairs": int(n), "seconds": round(dt, 4), "read_map_eq_s": round(t_read_map, 4),
-            "mapped_frac": round(tot_mapped / max(1, n), 4), "em_iters": rep["iters"], "input": "2 plain FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n,
-                read_len, batch), "host_threads": os.cpu_count(), "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
-            "what": "end to end from files through sq_reader (mmap + parallel record split + page-locked batch assembly), H2D included; gzip input is bound by one inflate thread per mate file (~1.4 M pairs/s per file pair on this class of host)"}
+            "mapped_frac": round(tot_mapped / max(1, n), 4), "em_iters": rep["iters"]}
 
 
 def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
     """`salmon quant` from FASTQ files: sq_reader (parallel record splitting into page-locked batches) -> H2D -> mapping lanes -> online model /
-    eq-classes -> export -> normalizeAlphas -> VBEM.  Wall time from opening the files to the converged alphas."""
-    import ctypes as C, shutil, tempfile
+    eq-classes -> export -> normalizeAlphas -> VBEM.  Wall time from opening the files to the converged alphas; plain, BGZF and gzip input."""
+    import shutil, tempfile, subprocess, gzip
     d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n_pairs, read_len, batch), "host_threads": os.cpu_count(),
+           "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
+           "what": "end to end from files through sq_reader (mmap + parallel record split + page-locked batch assembly), H2D included"}
     try:
         seq, off, _, _ = tx.reads(n_pairs, read_len=read_len, seed=77, first_pair=0, threads=threads, truth=False)
         recs = seq.reshape(2 * n_pairs, read_len)
@@ -122,9 +154,38 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
         res = None
         for attempt in range(2):   # the first pass sizes the work buffers of both mapping lanes and the reader's page-locked slots; the second is reported
             res = _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len)
-        return res
+        out["plain"] = res; out["value"] = res["value"]; out["unit"] = res["unit"]
+        # gzip (one member: the reader inflates it on one thread per mate file unless it can split it) and BGZF (blocked gzip: members inflate in parallel)
+        try:
+            gz = []
+            for f in files:
+                g = f + ".gz"
+                subprocess.check_call("gzip -1 -c %s > %s" % (f, g), shell=True); gz.append(g)
+            out["gzip"] = _fastq_pass(ctx, idx, gz, batch, lib, api, capi, read_len)
+            bg = []
+            for f in files:
+                g = f + ".bgz.gz"; _write_bgzf(f, g); bg.append(g)
+            out["bgzf"] = _fastq_pass(ctx, idx, bg, batch, lib, api, capi, read_len)
+        except Exception as e:   # the compressed legs are extras: never lose the bench line over them
+            out["compressed_error"] = str(e)[:200]
+        return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _write_bgzf(src, dst, block=0xff00):
+    """Blocked gzip (BGZF: every member carries its compressed size in a 'BC' extra field), written with zlib from Python threads."""
+    import zlib, struct
+    from concurrent.futures import ThreadPoolExecutor
+    data = np.fromfile(src, np.uint8)
+    def member(i):
+        chunk = data[i:i + block].tobytes()
+        co = zlib.compressobj(1, zlib.DEFLATED, -15); body = co.compress(chunk) + co.flush()
+        hdr = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25)
+        return hdr + body + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex, open(dst, "wb") as f:
+        for m in ex.map(member, range(0, len(data), block)): f.write(m)
+        f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
 
 
 def baseline_metric():
@@ -133,6 +194,11 @@ def baseline_metric():
         return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")))["metric"]
     except Exception:
         return "M reads/s quantified (map+EM), 100M 2x100bp vs human txome; EM iters/s"
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def main():
@@ -163,36 +229,51 @@ def main():
     t_setup = time.time()
     tx = synth.Txome(seed=1, n_genes=a.genes, iso_per_gene=a.iso, threads=min(thr, 32))
     names, seqs, lens = tx.tables()
-    idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=thr)
-    t_index = time.time() - t_setup
+    genome = None; first_decoy = None; n_refs_in = tx.n
+    if a.genome_gnt > 0:   # c4: the genome's chromosomes follow the transcripts as decoys (`salmon index -d decoys.txt`)
+        import ctypes as C
+        genome = synth.Genome(tx, seed=3, total_nt=int(a.genome_gnt * 1e9), n_chrom=25, repeat_frac=0.45, threads=min(thr, 32))
+        names, seqs, lens = genome.append_tables(tx)
+        first_decoy = tx.n; n_refs_in = tx.n + genome.n
+    t_synth = time.time() - t_setup
+    idx = api.SalmonIndex.build_mem_raw(n_refs_in, names, seqs, lens, threads=thr, first_decoy=first_decoy)
+    t_index = time.time() - t_setup - t_synth
     idx.to_device(local)
-    B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len
+    B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len; S = max(1, a.sub)
+    if B > (1 << 23): raise SystemExit("--batch above 2^23 pairs per sq_map_batch call")
     opts = api.quant_opts()
     if a.inflight > 0: opts.mini_batches_in_flight = a.inflight
     ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
     # end-of-job buffers (eq-class export, EM workspace) sized like the reference's initial eq-class map (10^6 classes); with several
     # ranks every GPU ends up holding the union of all ranks' classes, so the class table is sized for that
     ctx.reserve(1000000 * max(1, world // 2), 0)
-    # synthetic reads: rank r, step s -> pairs [((r*(K+W))+s)*B, ...), generated on the host, parked in HBM
+    # synthetic reads: rank r, step s, sub-batch u -> pairs [(((r*(K+W))+s)*S+u)*B, ...), generated on the host, parked in HBM
     dev = torch.device("cuda", local)
     off_np = (np.arange(0, 2 * B + 1, dtype=np.int64) * RL)
     off_d = torch.from_numpy(off_np).to(dev)
     batches = []
     host_first = None
+    t_gen0 = time.time()
     for s in range(W + K):
-        seq, off, tt, tp = tx.reads(B, read_len=RL, seed=2, first_pair=(rank * (K + W) + s) * B, threads=min(thr, 64), truth=False)
-        if s == W and rank == 0:
-            host_first = seq[: 2 * RL * min(B, a.cpu_sample)].copy() if a.cpu_sample > 0 else None
-        batches.append(torch.from_numpy(seq).to(dev))
+        for u in range(S):
+            first = ((rank * (K + W) + s) * S + u) * B
+            if genome is not None:
+                seq, off, tt, tp = genome.reads(tx, B, read_len=RL, seed=2, first_pair=first, genomic_frac=a.genomic, threads=min(thr, 64), truth=False)
+            else:
+                seq, off, tt, tp = tx.reads(B, read_len=RL, seed=2, first_pair=first, threads=min(thr, 64), truth=False)
+            if s == W and u == 0 and rank == 0:
+                host_first = seq[: 2 * RL * min(B, a.cpu_sample)].copy() if a.cpu_sample > 0 else None
+            batches.append(torch.from_numpy(seq).to(dev))
     torch.cuda.synchronize()
+    t_gen = time.time() - t_gen0
     rbs = [api.make_read_batch(int(b.data_ptr()), int(off_d.data_ptr()), B, paired=True, on_device=True) for b in batches]
     # ---- warmup (sizes every work buffer; model/eq state is reset afterwards) ----
-    for s in range(W):
+    for s in range(W * S):
         ctx.map_batch(rbs[s], fetch=False); ctx.eq_accumulate()
     if a.lanes > 1:
-        for s in range(min(W, a.lanes)):   # size the work buffers of every lane
+        for s in range(min(W * S, a.lanes)):   # size the work buffers of every lane
             ctx.map_submit(rbs[0])
-        for s in range(min(W, a.lanes)):
+        for s in range(min(W * S, a.lanes)):
             ctx.map_wait()
     if W:
         e = ctx.eq_finish()
@@ -200,30 +281,31 @@ def main():
     ctx.reset()
     ctx.set_profiling(not a.no_profile)
     ctx.stage_times(reset=True)
-    eff_ref = idx.ref_lens().astype(np.float64)
+    M = idx.num_refs
     # ---- timed region: exactly K steps + the job's inference tail ----
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot = None
     depth = max(1, a.lanes)          # batches in flight on the mapping lanes (sq_map_submit / sq_map_wait)
+    lo, hi = W * S, (W + K) * S
     if depth > 1:
-        for s in range(W, min(W + K, W + depth)):
+        for s in range(lo, min(hi, lo + depth)):
             ctx.map_submit(rbs[s])
-    for s in range(W, W + K):
+    for s in range(lo, hi):
         if depth > 1:
             _, _, _, st = ctx.map_wait()
         else:
             _, _, _, st = ctx.map_batch(rbs[s], fetch=False)
         ctx.eq_accumulate()
-        if depth > 1 and s + depth < W + K:
+        if depth > 1 and s + depth < hi:
             ctx.map_submit(rbs[s + depth])
         tot = st if tot is None else {k: tot[k] + v for k, v in st.items()}
     t_map = time.perf_counter() - t0
     eq = ctx.eq_finish()
     t_eqf = time.perf_counter() - t0 - t_map
     lm, uq, tc, le = ctx.model()
-    if dist:  # one RCCL all-gather per packed field; every rank merges the others' tables exactly (integer sums)
+    if dist:  # one RCCL all-gather of the packed tables; every rank merges the others' tables exactly (integer sums)
         from salmon_amd import dist as sqdist
         cdev = torch.device("cpu") if a.debug_one_device else dev
         if a.debug_one_device:      # gloo has no device collectives: host tables
@@ -245,6 +327,15 @@ def main():
     t_a = time.perf_counter()
     alphas, rep = ctx.em_optimize(eff, proj, api.em_opts())   # the ctx's own classes (incl. merged ones), read from the export resident in HBM
     t_em = time.perf_counter() - t_a
+    gibbs = None
+    if a.workload == "c5":   # configs[4]: posterior samples by collapsed Gibbs, whole chains sharded by rank (sq_dist_share)
+        t_a = time.perf_counter()
+        nmapped = int(eq.count.sum()); Sn = a.gibbs_samples
+        first, cnt = (sqd.share(Sn, capi.lib().sq_gibbs_chain_step(Sn)) if sqd is not None else (0, Sn))
+        gs, grep = api.gibbs_range(eq, eff, alphas, Sn, first, cnt, 2024, nmapped, api.gibbs_opts(), device=local, report=True)
+        t_g = time.perf_counter() - t_a
+        gibbs = {"samples": Sn, "samples_this_rank": int(cnt), "seconds": round(t_g, 4), "report": grep,
+                 "mean_abs_dev_from_vbem": float(np.mean(np.abs(gs.mean(axis=0) - alphas))) if len(gs) else None}
     torch.cuda.synchronize()
     if dist: dist.barrier()
     t1 = time.perf_counter()
@@ -260,43 +351,55 @@ def main():
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
-    E = len(eq.count); Lb = len(eq.tid); M = idx.num_refs
+    E = len(eq.count); Lb = len(eq.tid)
     em_bytes = 36 * Lb + 16 * E + 64 * M
     em_gbs = em_bytes / (rep_it["ms_per_iter"] * 1e-3) / 1e9
-    sb = stage_bytes(tot, K * B, RL)
+    NP = K * S * B
+    sb = stage_bytes(tot, NP, RL)
     stage_rows = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / max(1, v[1]), 4),
         "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
-    # roofline: the dominant SINGLE kernel (stages that aggregate many launches — the library sort, the scans, the
-    # eq stage's mini-batch chain that overlaps mapping on its own stream — are not kernels and are excluded)
-    single = {"k_pack": "k_pack", "k_seed": "k_seed", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
-        "k_select": "k_select"}
-    cand = [k for k in stage_rows if k in single]
-    dom = max(cand, key=lambda k: stage_rows[k]["ms_total"]) if cand else None
-    roof = None
-    if dom:
-        per_launch = sb[dom] / max(1, stage_rows[dom]["launches"])
-        ach = per_launch / (stage_rows[dom]["avg_ms"] * 1e-3) / 1e9
-        traffic = None; tnote = "no PMC profile committed for this kernel"
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            kk = pm["kernels"].get(single[dom])
-            if kk and kk.get("fetch_bytes_per_launch") is not None:
-                traffic = int(kk["fetch_bytes_per_launch"] + (kk.get("write_bytes_per_launch") or 0))
-                tnote = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload at --steps 2); PMC cannot be sampled inside the timed run"
-        except Exception:
-            pass
-        roof = {"kernel": single[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
-            "traffic": traffic,
-                "avg_launch_ms": stage_rows[dom]["avg_ms"], "alg_bytes_per_launch": int(per_launch), "traffic_note": tnote,
-                "alg_bytes_note": "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5); k_seed: 64 B filter word per probe + 4 dependent 64 B sectors (pilot, slot record, string-pool word, unitig bounds) per hit + 64 B per uni-MEM (extension words, contig-table bounds, record) + the packed read"}
+    # roofline: the stage kernel with the largest total time in the timed region — every stage is a candidate, the online model's mini-batch
+    # chain included (it runs on its own CU partition beside mapping; its row aggregates one launch pair per group of mini-batches)
+    pm = {}
+    try: pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+    except Exception: pass
+    cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
+    roof = None; roofs = {}
+    for k in cand:
+        per_launch = sb[k] / max(1, stage_rows[k]["launches"])
+        ach = per_launch / (stage_rows[k]["avg_ms"] * 1e-3) / 1e9
+        kk = pm.get(KERNEL_OF_STAGE[k]); traffic = None
+        if kk and kk.get("fetch_bytes_per_launch") is not None:
+            traffic = int(kk["fetch_bytes_per_launch"] + (kk.get("write_bytes_per_launch") or 0))
+        roofs[k] = {"kernel": KERNEL_OF_STAGE[k], "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
+                    "traffic": traffic, "avg_launch_ms": stage_rows[k]["avg_ms"], "alg_bytes_per_launch": int(per_launch), "ms_total": stage_rows[k]["ms_total"],
+                    # second denominator: the measured ceiling of random 64-byte-sector gathers on this chip (tools/gather_bench.hip)
+                    "frac_of_random_sector_ceiling_3400GBps": round(ach / 3400.0, 5)}
+    if roofs:
+        dom = max(roofs, key=lambda k: roofs[k]["ms_total"])
+        roof = dict(roofs[dom])
+        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload "
+                                "at --steps 2); PMC cannot be sampled inside the timed run") if roof["traffic"] is not None else "no PMC profile committed for this kernel"
+        roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
+        roof["all_kernels"] = {roofs[k]["kernel"]: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
+    if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
+        g = gibbs["report"]; bg = 28 * Lb + 16 * E + 32 * M
+        if g.get("rounds"):
+            ach = bg / (g["ms_per_round"] * 1e-3) / 1e9
+            gibbs["roofline"] = {"kernel": "k_gibbs_round (mu + per-class multinomials + counts)", "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(ach / 8000.0, 5), "alg_bytes_per_round": bg, "rounds_per_s": round(1e3 / g["ms_per_round"], 1),
+                                 "draws_per_s": round(g.get("draws_per_round", 0) / (g["ms_per_round"] * 1e-3), 1),
+                                 "note": "B_gibbs = 28 L + 16 E + 32 M per round (SURVEY 8d); the working set is cache-resident and a round's time is its N categorical draws"}
     cpu = None; parity = None
     if a.cpu_sample > 0 and world == 1 and host_first is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
-        S = min(B, a.cpu_sample)
+        Sn = min(B, a.cpu_sample)
+        c_a = time.perf_counter()
         oidx = orc.OrcIndex(idx)
-        soff = (np.arange(0, 2 * S + 1, dtype=np.uint64) * np.uint64(RL))
-        rb = api.make_read_batch(host_first, soff, S, paired=True)
+        t_oidx = time.perf_counter() - c_a
+        soff = (np.arange(0, 2 * Sn + 1, dtype=np.uint64) * np.uint64(RL))
+        rb = api.make_read_batch(host_first, soff, Sn, paired=True)
         c0 = time.perf_counter()
         ro, aln, mt, stc = orc.map_batch(oidx, opts, rb, threads=ncores)
         c1 = time.perf_counter()
@@ -314,11 +417,9 @@ def main():
         if em_single_s < em_thr_s: em_thr_n, em_thr_s = 1, em_single_s       # the CPU side gets its best configuration
         em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
         t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
-        # parity at bench scale (outside the timed region): the same S pairs through the HIP path on a reset context, compared with
+        # parity at bench scale (outside the timed region): the same pairs through the HIP path on a reset context, compared with
         # what the checker just produced — alignment records, per-read offsets, mapping types, counters, the class table (labels,
         # bins, counts, fixed-point weight sums), the online model, projected counts and the VBEM result
-        import hashlib
-        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
         ctx.set_profiling(False); ctx.reset()
         ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
         ctx.eq_accumulate(); eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
@@ -329,37 +430,52 @@ def main():
             "eq_classes": all(sha(getattr(eq_g, f)) == sha(getattr(eqc, f)) for f in ("off", "tid", "bins", "count", "wq", "h1", "h2")),
             "online_model": sha(lm_g) == sha(lmc) and sha(uq_g) == sha(uqc) and sha(tc_g) == sha(tcc) and sha(le_g) == sha(lec),
             "projected_counts": sha(p_g) == sha(pc), "vbem": rep_g["iters"] == repc["iters"] and sha(a_g) == sha(a_c)}
-        parity = {"pairs": S, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
-            "checks": checks, "alignments_sha256": sha(aln_g), "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % S}
-        cpu = {"value": round(S / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d)" % (S,
-                   B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n),
-               "map_only_M_pairs_per_s": round(S / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
+        parity = {"pairs": Sn, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
+            "checks": checks, "alignments_sha256": sha(aln_g), "decoy_fragments": int(st_g["num_decoy_fragments"]),
+            "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % Sn}
+        if gibbs is not None and Sn >= 1000:   # c5: the Gibbs sampler on the sample's classes, every sample byte-equal to the checker's
+            g_g = api.gibbs(eq_g, np.exp(le_g), a_g, 8, 7, int(eq_g.count.sum()), api.gibbs_opts(), device=local)
+            g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())
+            parity["checks"]["gibbs_8_samples"] = sha(g_g) == sha(g_c); parity["equal"] = all(parity["checks"].values())
+        cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
+               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); checker index built in %.1fs (not counted)" % (Sn,
+                   B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_oidx),
+               "map_only_M_pairs_per_s": round(Sn / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
                # what the sample's rates would mean for the whole timed job (a model, not a measurement): per-pair costs scale with the pairs,
                # the EM runs once over the full table for as many iterations as the GPU job needed
-               "extrapolated_full_job_M_pairs_per_s": round(K * B / ((K * B) * ((c1 - c0) + (c2 - c1)) / S + rep["iters"] * em_cpu_s) / 1e6, 4)}
+               "extrapolated_full_job_M_pairs_per_s": round(NP / (NP * ((c1 - c0) + (c2 - c1)) / Sn + rep["iters"] * em_cpu_s) / 1e6, 4)}
     fq = None
-    if a.fastq_pairs > 0 and world == 1:
+    if a.fastq_pairs > 0 and world == 1 and a.workload in ("c2", "c2s"):
         fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi)
+    cfg_name = {"c2": "configs[1]: human-transcriptome-shaped synthetic index (60k genes x ~4 isoforms; SURVEY C2 shape)",
+                "c2s": "configs[1], round-1/2 index (T200k: 20k genes x ~10 isoforms, 54 M distinct k-mers)",
+                "c5": "configs[4]: human-shaped index, 50 M pairs, VBEM + %d Gibbs samples" % a.gibbs_samples,
+                "c4": "configs[3]: decoy-aware index (human-shaped txome + %.2f Gnt synthetic genome as decoys), 2x%d bp, %.0f %% genomic pairs" % (a.genome_gnt, RL, 100 * a.genomic)}[a.workload]
     out = {
-        "metric": baseline_metric(), "value": round(world * K * B / dt / 1e6, 4), "unit": "M read-pairs/s",
+        "metric": baseline_metric(), "value": round(world * NP / dt / 1e6, 4), "unit": "M read-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
-        "config": {"workload": "configs[1]: T200k synthetic human-shaped txome index (k=31, m=20), %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (K,
-            B, K * B, RL),
-                   "transcripts": int(M), "txome_nt": int(tx.total_nt()), "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
-                   "pairs_per_step": B, "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly (%s); EM replicated" % (world,
+        "config": {"workload": "%s (k=31, m=20), %d steps x %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (cfg_name, K, S, B, NP, RL),
+                   "workload_id": a.workload,
+                   "transcripts": int(tx.n), "refs": int(M), "txome_nt": int(tx.total_nt()), "decoy_nt": int(genome.total_nt()) if genome is not None else 0,
+                   "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
+                   "pairs_per_step": S * B, "pairs_per_map_call": B,
+                   "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly (%s); EM replicated" % (world,
                        "sq_dist_* over RCCL" if sqd is not None else ("torch.distributed" if dist is not None else "single rank"))},
-        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM)": round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
+        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
             "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
-            "em_device_ms": round(rep["device_ms"], 2),
-                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"],
-                          4), "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
+            "em_device_ms": round(rep["device_ms"], 2), "synth_s": round(t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
+                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4),
+                      "decoy_frac": round(tot["num_decoy_fragments"] / tot["num_reads"], 4),
+                      "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes,
             "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
-        "stages": stage_rows, "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq,
+        "gibbs": gibbs,
+        "stages": stage_rows, "roofline": (gibbs or {}).get("roofline") if a.workload == "c5" and gibbs and gibbs.get("roofline") else roof,
+        "mapping_roofline": roof if a.workload == "c5" else None,
+        "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

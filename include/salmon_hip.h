@@ -443,6 +443,13 @@ int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, 
                        const double* alpha_init, uint32_t num_samples, uint32_t first, uint32_t count, uint64_t seed,
                        uint64_t num_mapped, sq_replicate_cb cb, void* user);
 
+/* The same with the device time of the sampling rounds (HIP events around each sample's thinning rounds): measurement for configs[4]. */
+typedef struct { uint64_t rounds; double device_ms, ms_per_round; uint64_t draws_per_round; /* categorical draws of one round = fragments in multi-label classes */
+                 uint32_t items[3]; /* work items (<= 256 draws of one class) by class size: <= 8, <= 16, larger */ uint32_t _pad; } sq_gibbs_report;
+int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* opts,
+                              const double* alpha_init, uint32_t num_samples, uint32_t first, uint32_t count, uint64_t seed,
+                              uint64_t num_mapped, sq_replicate_cb cb, void* user, sq_gibbs_report* report);
+
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU (oracle/SPEC.md §MG): one process per GPU.  Reads shard by rank — there is no collective on the mapping path;
  * after mapping ONE exchange of the equivalence-class tables over RCCL (xGMI inside a node), the per-transcript model state reduced
@@ -460,6 +467,10 @@ int sq_dist_world(const sq_dist*);
 /* Collective. All-gathers every rank's canonical-order class table (HBM -> xGMI -> HBM) and merges the others' into this ctx: every
  * rank ends with the same table; counts and fixed-point weight sums add exactly, so the bits do not depend on the gather order. */
 int sq_dist_merge_eq(sq_dist*, sq_ctx*);
+/* The same exchange when the box has fewer GPUs than ranks (tests, bring-up): `n` contexts on the communicator's device stand for the ranks of an
+ * n-rank job.  Needs a communicator of ONE rank; every context's table is packed, sent through the size and payload all-gathers of that
+ * communicator (RCCL executes them) into a receive slot, and every context merges the other contexts' slots as sq_dist_merge_eq does. */
+int sq_dist_merge_eq_loopback(sq_dist*, sq_ctx* const* ctxs, uint32_t n);
 /* Collective. SPEC §MG: unique / total counts add; masses combine by logAdd in rank order; effective lengths are rank 0's. */
 int sq_dist_reduce_model(sq_dist*, uint32_t num_txp, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len);
 /* The mass rule on its own (host arithmetic, no device): row r of all_log_mass = rank r's log-masses; out[t] = logAdd over r = 0..R-1. */

@@ -67,18 +67,32 @@ struct Index {
     uint64_t cap = 16; while (cap < nk * 2) cap <<= 1;
     hkeys.assign(cap, ~0ULL); hvals.assign(cap, 0); hmask = cap - 1;
     const uint64_t km = kmask(k);
-    for (uint64_t u = 0; u < U; ++u) {
-      uint64_t b = uoff[u]; uint32_t ulen = (uint32_t)(uoff[u + 1] - b);
-      uint64_t fw = 0;
-      for (uint32_t i = 0; i < ulen; ++i) {
-        fw = (fw >> 2) | ((uint64_t)base_at(useq.data(), b + i) << (2 * (k - 1)));
-        if (i + 1 < k) continue;
-        fw &= km; uint64_t rc = revcomp(fw, k); bool cf = fw < rc; uint64_t c = cf ? fw : rc;
-        uint64_t h = sq_mix64(c) & hmask;
-        while (hkeys[h] != ~0ULL && hkeys[h] != c) h = (h + 1) & hmask;
-        hkeys[h] = c; hvals[h] = (u << 31) | ((uint64_t)(i + 1 - k) << 1) | (cf ? 1 : 0);
+    // every canonical k-mer occurs once in the unitigs (cDBG), so threads insert disjoint keys: one CAS claims a slot
+    unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency())); if (nk < (1u << 20)) nt = 1;
+    std::atomic<uint64_t> next(0); std::vector<std::thread> th;
+    auto work = [&]() {
+      for (;;) {
+        const uint64_t u0 = next.fetch_add(1024); if (u0 >= U) break; const uint64_t u1 = std::min(U, u0 + 1024);
+        for (uint64_t u = u0; u < u1; ++u) {
+          uint64_t b = uoff[u]; uint32_t ulen = (uint32_t)(uoff[u + 1] - b);
+          uint64_t fw = 0;
+          for (uint32_t i = 0; i < ulen; ++i) {
+            fw = (fw >> 2) | ((uint64_t)base_at(useq.data(), b + i) << (2 * (k - 1)));
+            if (i + 1 < k) continue;
+            fw &= km; uint64_t rc = revcomp(fw, k); bool cf = fw < rc; uint64_t c = cf ? fw : rc;
+            uint64_t h = sq_mix64(c) & hmask;
+            for (;;) {
+              uint64_t cur = __atomic_load_n(&hkeys[h], __ATOMIC_RELAXED);
+              if (cur == ~0ULL) { uint64_t exp = ~0ULL; if (__atomic_compare_exchange_n(&hkeys[h], &exp, c, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; cur = exp; }
+              if (cur == c) break;
+              h = (h + 1) & hmask;
+            }
+            hvals[h] = (u << 31) | ((uint64_t)(i + 1 - k) << 1) | (cf ? 1 : 0);
+          }
+        }
       }
-    }
+    };
+    if (nt == 1) work(); else { for (unsigned t = 0; t < nt; ++t) th.emplace_back(work); for (auto& x : th) x.join(); }
   }
   // SPEC §a1: canonical k-mer -> (unitig, offset, orientation of the *query* w.r.t. the unitig)
   inline bool lookup(uint64_t kmer, uint64_t& u, uint32_t& off, bool& fw) const {

@@ -493,12 +493,17 @@ def bootstrap_range(eq, eff_len, num_bootstraps, first, count, seed, num_mapped,
     return np.array(rows)
 
 
-def gibbs_range(eq, eff_len, alpha_init, num_samples, first, count, seed, num_mapped, gopts=None, device=0):
+def gibbs_range(eq, eff_len, alpha_init, num_samples, first, count, seed, num_mapped, gopts=None, device=0, report=False):
+    """Samples [first, first + count) of num_samples (sq_gibbs_range_dev); report=True: also the device time of the sampling rounds."""
     g = gopts or gibbs_opts(); t = eq.table(); txp = make_txp_in(eff_len)
     a = np.ascontiguousarray(alpha_init, np.float64)
     rows, cb = _collect(txp.num_txp)
-    check(lib().sq_gibbs_range_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, first, count, seed, num_mapped,
-        cb, None), "sq_gibbs_range_dev")
+    rep = capi.GibbsReport()
+    check(lib().sq_gibbs_range_report_dev(device, C.byref(t), C.byref(txp), C.byref(g), _ptr(a, C.c_double), num_samples, first, count, seed, num_mapped,
+        cb, None, C.byref(rep)), "sq_gibbs_range_dev")
+    if report:
+        return np.array(rows), dict(rounds=int(rep.rounds), device_ms=rep.device_ms, ms_per_round=rep.ms_per_round, draws_per_round=int(rep.draws_per_round),
+                                    items=[int(x) for x in rep.items])
     return np.array(rows)
 
 
@@ -524,6 +529,22 @@ class Dist:
 
     def merge_eq(self, ctx):
         check(lib().sq_dist_merge_eq(self.h, ctx.h), "sq_dist_merge_eq")
+
+    def merge_eq_loopback(self, ctxs):
+        """sq_dist_merge_eq_loopback: the contexts stand for the ranks of a len(ctxs)-rank job on this one device."""
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        check(lib().sq_dist_merge_eq_loopback(self.h, arr, len(ctxs)), "sq_dist_merge_eq_loopback")
+
+    def allgather(self, a):
+        """sq_dist_allgather of a host array: [world, len(a)]."""
+        a = np.ascontiguousarray(a); out = np.zeros((self.world,) + a.shape, a.dtype)
+        check(lib().sq_dist_allgather(self.h, a.ctypes.data, a.nbytes, out.ctypes.data), "sq_dist_allgather")
+        return out
+
+    def bcast(self, a, root=0):
+        a = np.ascontiguousarray(a).copy()
+        check(lib().sq_dist_bcast(self.h, a.ctypes.data, a.nbytes, root), "sq_dist_bcast")
+        return a
 
     def reduce_model(self, log_mass, uniq, total, log_eff_len):
         lm = np.ascontiguousarray(log_mass, np.float64).copy(); uq = np.ascontiguousarray(uniq, np.uint64).copy()

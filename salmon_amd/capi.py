@@ -101,6 +101,10 @@ class GibbsOpts(C.Structure):
                 ("vb_prior", f64)]
 
 
+class GibbsReport(C.Structure):
+    _fields_ = [("rounds", u64), ("device_ms", f64), ("ms_per_round", f64), ("draws_per_round", u64), ("items", u32 * 3), ("_pad", u32)]
+
+
 class UniMem(C.Structure):
     _fields_ = [("end", u32), ("qpos", u16), ("len", u16), ("unitig", u64), ("uoff", u32), ("fw", u8), ("_p", u8 * 3)]
 
@@ -165,6 +169,7 @@ def lib():
         "sq_gibbs_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u64, u64, REPLICATE_CB, vp]),
         "sq_bootstrap_range_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(EmOpts), u32, u32, u32, u64, u64, REPLICATE_CB, vp]),
         "sq_gibbs_range_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u32, u32, u64, u64, REPLICATE_CB, vp]),
+        "sq_gibbs_range_report_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u32, u32, u64, u64, REPLICATE_CB, vp, P(GibbsReport)]),
         "sq_gibbs_chain_step": (u32, [u32]),
         "sq_merge_log_masses": (C.c_int, [u32, u32, vp, vp]),
         "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
@@ -172,6 +177,7 @@ def lib():
         "sq_em_optimize_bias": (C.c_int, [vp, P(EqTable), P(TxpIn), P(EmOpts), EFFLEN_CB, vp, P(f64), P(f64), P(EmReport)]),
         "sq_dist_make_id": (C.c_int, [vp]), "sq_dist_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]), "sq_dist_free": (None, [vp]),
         "sq_dist_rank": (C.c_int, [vp]), "sq_dist_world": (C.c_int, [vp]), "sq_dist_merge_eq": (C.c_int, [vp, vp]),
+        "sq_dist_merge_eq_loopback": (C.c_int, [vp, P(vp), u32]),
         "sq_dist_reduce_model": (C.c_int, [vp, u32, P(f64), P(u64), P(u64), P(f64)]), "sq_dist_allreduce_u64": (C.c_int, [vp, vp, C.c_size_t]),
         "sq_dist_bcast": (C.c_int, [vp, vp, C.c_size_t, C.c_int]), "sq_dist_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
         "sq_dist_barrier": (C.c_int, [vp]), "sq_dist_share": (None, [vp, u32, u32, P(u32), P(u32)]),

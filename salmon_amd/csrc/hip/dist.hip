@@ -103,44 +103,88 @@ static int gather_var(sq_dist* d, const void* dev_src, size_t bytes, std::vector
   return SQ_OK;
 }
 
-// The eq-class exchange: every rank ends with the union of all ranks' classes (counts and fixed-point weight sums added exactly).
-extern "C" int sq_dist_merge_eq(sq_dist* d, sq_ctx* c) {
-  if (!d || !c) { sq_set_error("sq_dist_merge_eq: bad arguments"); return SQ_ERR_ARG; }
-  if (d->world == 1) return SQ_OK;
-  SQ_HIP_CHECK(hipSetDevice(d->device));
+// One rank's table as it travels: [E, L | off (E+1) | count E | h1 E | h2 E | wq L | tid L (u32) | bins L (u32)], packed from the
+// canonical-order export resident in HBM (device-to-device copies on the communicator's stream).
+static size_t packed_bytes(uint64_t E, uint64_t L) { return 16 + (E ? (E + 1) * 8 + 3 * E * 8 + L * 8 + L * 4 + L * 4 : 0); }
+static int pack_table(sq_dist* d, sq_ctx* c, sq_dbuf<uint8_t>& pack, size_t* bytes_out) {
   sq_eq_table mine; int rc = sq_eq_export_device(c, &mine); if (rc) return rc;
   const uint64_t E = mine.num_classes, L = mine.num_labels;
-  // one packed buffer per rank: [E, L | off (E+1) | count E | h1 E | h2 E | wq L | tid L (u32) | bins L (u32)]
-  const size_t bytes = 16 + (E ? (E + 1) * 8 + 3 * E * 8 + L * 8 + L * 4 + L * 4 : 0);
-  sq_dbuf<uint8_t> pack; if (pack.ensure(bytes + 16)) { sq_set_error("device allocation failed (dist pack)"); return SQ_ERR_NOMEM; }
-  { uint64_t hdr[2] = {E, L}; SQ_HIP_CHECK(hipMemcpyAsync(pack.p, hdr, 16, hipMemcpyHostToDevice, d->st));
-    uint8_t* p = pack.p + 16;
-    auto put = [&](const void* src, size_t n) -> int { if (n && hipMemcpyAsync(p, src, n, hipMemcpyDeviceToDevice, d->st) != hipSuccess) return 1; p += n; return 0; };
-    if (E && (put(mine.off, (E + 1) * 8) || put(mine.count, E * 8) || put(mine.h1, E * 8) || put(mine.h2, E * 8) || put(mine.wq, L * 8) ||
-              put(mine.tid, L * 4) || put(mine.bins, L * 4))) { pack.free_(); sq_set_error("dist pack copy failed"); return SQ_ERR_DEVICE; }
-    SQ_HIP_CHECK(hipStreamSynchronize(d->st)); }
+  const size_t bytes = packed_bytes(E, L);
+  if (pack.ensure(bytes + 16)) { sq_set_error("device allocation failed (dist pack)"); return SQ_ERR_NOMEM; }
+  uint64_t hdr[2] = {E, L}; SQ_HIP_CHECK(hipMemcpyAsync(pack.p, hdr, 16, hipMemcpyHostToDevice, d->st));
+  uint8_t* p = pack.p + 16;
+  auto put = [&](const void* src, size_t n) -> int { if (n && hipMemcpyAsync(p, src, n, hipMemcpyDeviceToDevice, d->st) != hipSuccess) return 1; p += n; return 0; };
+  if (E && (put(mine.off, (E + 1) * 8) || put(mine.count, E * 8) || put(mine.h1, E * 8) || put(mine.h2, E * 8) || put(mine.wq, L * 8) ||
+            put(mine.tid, L * 4) || put(mine.bins, L * 4))) { sq_set_error("dist pack copy failed"); return SQ_ERR_DEVICE; }
+  SQ_HIP_CHECK(hipStreamSynchronize(d->st));
+  *bytes_out = bytes;
+  return SQ_OK;
+}
+// a received packed table (device memory, `size` bytes as announced by its sender) folded into c's class table
+static int merge_packed(sq_ctx* c, uint8_t* base, uint64_t size, int from_rank) {
+  uint64_t hdr[2]; SQ_HIP_CHECK(hipMemcpy(hdr, base, 16, hipMemcpyDeviceToHost));
+  const uint64_t Er = hdr[0], Lr = hdr[1];
+  if (packed_bytes(Er, Lr) != size) { sq_set_error("sq_dist_merge_eq: rank %d sent a malformed table (%llu classes, %llu labels, %llu bytes)", from_rank,
+      (unsigned long long)Er, (unsigned long long)Lr, (unsigned long long)size); return SQ_ERR_STATE; }
+  if (!Er) return SQ_OK;
+  uint8_t* p = base + 16;
+  sq_eq_table t; memset(&t, 0, sizeof(t)); t.num_classes = Er; t.num_labels = Lr;
+  t.off = (uint64_t*)p; p += (Er + 1) * 8; t.count = (uint64_t*)p; p += Er * 8; t.h1 = (uint64_t*)p; p += Er * 8; t.h2 = (uint64_t*)p; p += Er * 8;
+  t.wq = (uint64_t*)p; p += Lr * 8; t.tid = (uint32_t*)p; p += Lr * 4; t.bins = (uint32_t*)p;
+  return sq_eq_merge_device(c, &t);
+}
+
+// The eq-class exchange: every rank ends with the union of all ranks' classes (counts and fixed-point weight sums added exactly).
+// A communicator of one rank runs the same collectives (the sizes' and the payload's all-gather) and merges nothing.
+extern "C" int sq_dist_merge_eq(sq_dist* d, sq_ctx* c) {
+  if (!d || !c) { sq_set_error("sq_dist_merge_eq: bad arguments"); return SQ_ERR_ARG; }
+  SQ_HIP_CHECK(hipSetDevice(d->device));
+  sq_dbuf<uint8_t> pack; size_t bytes = 0;
+  int rc = pack_table(d, c, pack, &bytes); if (rc) { pack.free_(); return rc; }
   std::vector<uint64_t> sizes; size_t stride = 0; uint8_t* base = nullptr;
   rc = gather_var(d, pack.p, bytes, sizes, &stride, &base);
   pack.free_();
   if (rc) return rc;
   for (int r = 0; r < d->world; ++r) {
     if (r == d->rank) continue;
-    uint64_t hdr[2]; SQ_HIP_CHECK(hipMemcpy(hdr, base + (size_t)r * stride, 16, hipMemcpyDeviceToHost));
-    const uint64_t Er = hdr[0], Lr = hdr[1];
-    if (!Er) continue;
-    if (16 + (Er + 1) * 8 + 3 * Er * 8 + Lr * 16 != sizes[r]) { sq_set_error("sq_dist_merge_eq: rank %d sent a malformed table", r); return SQ_ERR_STATE; }
-    uint8_t* p = base + (size_t)r * stride + 16;
-    sq_eq_table t; memset(&t, 0, sizeof(t)); t.num_classes = Er; t.num_labels = Lr;
-    t.off = (uint64_t*)p; p += (Er + 1) * 8; t.count = (uint64_t*)p; p += Er * 8; t.h1 = (uint64_t*)p; p += Er * 8; t.h2 = (uint64_t*)p; p += Er * 8;
-    t.wq = (uint64_t*)p; p += Lr * 8; t.tid = (uint32_t*)p; p += Lr * 4; t.bins = (uint32_t*)p;
-    rc = sq_eq_merge_device(c, &t); if (rc) return rc;
+    rc = merge_packed(c, base + (size_t)r * stride, sizes[r], r); if (rc) return rc;
   }
+  return SQ_OK;
+}
+
+// Loop-back form for a box with fewer GPUs than ranks (tests, bring-up): `n` contexts on this communicator's device stand for the ranks of an
+// n-rank job.  Every context's table takes the path a rank's table takes — packed, its size and its bytes all-gathered over RCCL on the
+// one-rank communicator, landed in a receive slot with the stride an n-rank all-gather would use — and every context then merges the
+// slots of the others, exactly as sq_dist_merge_eq does with what arrived over xGMI.
+extern "C" int sq_dist_merge_eq_loopback(sq_dist* d, sq_ctx* const* ctxs, uint32_t n) {
+  if (!d || !ctxs || n == 0) { sq_set_error("sq_dist_merge_eq_loopback: bad arguments"); return SQ_ERR_ARG; }
+  if (d->world != 1) { sq_set_error("sq_dist_merge_eq_loopback: needs a communicator of one rank (it stands in for %u)", n); return SQ_ERR_STATE; }
+  SQ_HIP_CHECK(hipSetDevice(d->device));
+  std::vector<sq_dbuf<uint8_t>> slot(n); std::vector<uint64_t> bytes_of(n, 0);
+  auto release = [&]() { for (auto& s : slot) s.free_(); };
+  for (uint32_t v = 0; v < n; ++v) {
+    sq_dbuf<uint8_t> pack; size_t bytes = 0;
+    int rc = pack_table(d, ctxs[v], pack, &bytes); if (rc) { pack.free_(); release(); return rc; }
+    std::vector<uint64_t> sizes; size_t stride = 0; uint8_t* base = nullptr;
+    rc = gather_var(d, pack.p, bytes, sizes, &stride, &base);
+    pack.free_();
+    if (rc) { release(); return rc; }
+    if (sizes.size() != 1 || sizes[0] != bytes) { release(); sq_set_error("sq_dist_merge_eq_loopback: the size all-gather returned %llu for %zu bytes", (unsigned long long)(sizes.empty() ? 0 : sizes[0]), bytes); return SQ_ERR_STATE; }
+    if (slot[v].ensure(stride + 16)) { release(); sq_set_error("device allocation failed (loop-back slot)"); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpy(slot[v].p, base, stride, hipMemcpyDeviceToDevice));
+    bytes_of[v] = sizes[0];
+  }
+  for (uint32_t u = 0; u < n; ++u) for (uint32_t v = 0; v < n; ++v) {
+    if (u == v) continue;
+    int rc = merge_packed(ctxs[u], slot[v].p, bytes_of[v], (int)v); if (rc) { release(); return rc; }
+  }
+  release();
   return SQ_OK;
 }
 
 extern "C" int sq_dist_allreduce_u64(sq_dist* d, uint64_t* host, size_t n) {   // element-wise sums over the ranks (counters)
   if (!d || (!host && n)) { sq_set_error("sq_dist_allreduce_u64: bad arguments"); return SQ_ERR_ARG; }
-  if (d->world == 1 || n == 0) return SQ_OK;
+  if (n == 0) return SQ_OK;
   SQ_HIP_CHECK(hipSetDevice(d->device));
   if (d->send.ensure(n * 8 + 16)) { sq_set_error("device allocation failed (dist all-reduce)"); return SQ_ERR_NOMEM; }
   SQ_HIP_CHECK(hipMemcpyAsync(d->send.p, host, n * 8, hipMemcpyHostToDevice, d->st));
@@ -151,7 +195,7 @@ extern "C" int sq_dist_allreduce_u64(sq_dist* d, uint64_t* host, size_t n) {   /
 }
 extern "C" int sq_dist_bcast(sq_dist* d, void* host, size_t bytes, int root) {
   if (!d || (!host && bytes) || root < 0 || root >= d->world) { sq_set_error("sq_dist_bcast: bad arguments"); return SQ_ERR_ARG; }
-  if (d->world == 1 || bytes == 0) return SQ_OK;
+  if (bytes == 0) return SQ_OK;
   SQ_HIP_CHECK(hipSetDevice(d->device));
   if (d->send.ensure(bytes + 16)) { sq_set_error("device allocation failed (dist broadcast)"); return SQ_ERR_NOMEM; }
   if (d->rank == root) SQ_HIP_CHECK(hipMemcpyAsync(d->send.p, host, bytes, hipMemcpyHostToDevice, d->st));
@@ -163,7 +207,7 @@ extern "C" int sq_dist_bcast(sq_dist* d, void* host, size_t bytes, int root) {
 // every rank's `bytes` of host data to every rank: out holds rank r's block at r * bytes (equal sizes)
 extern "C" int sq_dist_allgather(sq_dist* d, const void* host_in, size_t bytes, void* host_out) {
   if (!d || !host_in || !host_out) { sq_set_error("sq_dist_allgather: bad arguments"); return SQ_ERR_ARG; }
-  if (d->world == 1) { memcpy(host_out, host_in, bytes); return SQ_OK; }
+  if (bytes == 0) return SQ_OK;
   SQ_HIP_CHECK(hipSetDevice(d->device));
   if (d->send.ensure(bytes + 16) || d->recv.ensure(bytes * d->world + 16)) { sq_set_error("device allocation failed (dist all-gather)"); return SQ_ERR_NOMEM; }
   SQ_HIP_CHECK(hipMemcpyAsync(d->send.p, host_in, bytes, hipMemcpyHostToDevice, d->st));
@@ -179,7 +223,6 @@ extern "C" int sq_dist_barrier(sq_dist* d) { uint64_t x = 1; return sq_dist_allr
 //   are rank 0's (its fragment-length distribution).
 extern "C" int sq_dist_reduce_model(sq_dist* d, uint32_t M, double* log_mass, uint64_t* unique_count, uint64_t* total_count, double* log_eff_len) {
   if (!d || !log_mass || !unique_count || !total_count || !log_eff_len) { sq_set_error("sq_dist_reduce_model: bad arguments"); return SQ_ERR_ARG; }
-  if (d->world == 1) return SQ_OK;
   int rc = sq_dist_allreduce_u64(d, unique_count, M); if (rc) return rc;
   rc = sq_dist_allreduce_u64(d, total_count, M); if (rc) return rc;
   std::vector<double> all((size_t)M * d->world);

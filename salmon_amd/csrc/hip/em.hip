@@ -837,25 +837,68 @@ __device__ inline double gibbs_class_p(const GibbsDev& g, uint64_t a, uint32_t n
   uint32_t t = g.tid[a + i];
   return mode == 0 ? (1000.0 * g.mu[t]) * g.w[a + i] : (mode == 1 ? 1.0 / g.eff[t] : 1.0);
 }
-__global__ void k_gibbs_items(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
-    uint64_t seed,
-    uint64_t round_key) {
-  uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
+// [r3] per round and class: the running sums acc_i = p_0 + .. + p_i in label order (the order the draw's scan adds them in) and
+// their total; minEQClassWeight fallbacks as in the reference (:224-250).  A draw then picks the first i with u < acc_i.
+__global__ void k_gibbs_prep(GibbsDev g, double* __restrict__ cum, double* __restrict__ denom) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= g.E) return;
+  const uint64_t a = g.off[c]; const uint32_t n = (uint32_t)(g.off[c + 1] - a);
+  if (n < 2) { denom[c] = 0.0; return; }
+  int mode = 0; double d = 0.0;
+  for (uint32_t i = 0; i < n; ++i) { d += gibbs_class_p(g, a, n, 0, i); cum[a + i] = d; }
+  if (d <= 2.2250738585072014e-308) { mode = 1; d = 0.0; for (uint32_t i = 0; i < n; ++i) { d += gibbs_class_p(g, a, n, 1, i); cum[a + i] = d; }
+    if (d <= 2.2250738585072014e-308) { mode = 2; double acc = 0.0; for (uint32_t i = 0; i < n; ++i) { acc += 1.0; cum[a + i] = acc; } d = (double)n; } }
+  (void)mode;
+  denom[c] = d;
+}
+// An item = up to 256 consecutive draws of one class.  Classes of at most NMAX labels: the NMAX - 1 thresholds live in registers and a
+// draw is its random number against all of them (no dependent scan); the item's counts leave as one atomic per label instead of one
+// per draw — the sums are integers, so the result is the same whatever the order.  pick = #{i < n-1 : !(u < acc_i)}: the running
+// sums never decrease, so that is the first i with u < acc_i (n - 1 when there is none).
+template <int NMAX>
+__global__ void __launch_bounds__(256) k_gibbs_items_reg(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+    uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
+  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
   const uint32_t c = item_cls[it];
   const uint64_t a = g.off[c];
   const uint32_t n = (uint32_t)(g.off[c + 1] - a);
   const uint64_t cnt = g.cnt[c];
   if (n == 1) { if (item_s0[it] == 0) atomicAdd(&g.count_i[g.tid[a]], (unsigned long long)cnt); return; }
-  int mode = 0; double denom = 0.0;
-  for (uint32_t i = 0; i < n; ++i) denom += gibbs_class_p(g, a, n, 0, i);
-  if (denom <= 2.2250738585072014e-308) { mode = 1; denom = 0.0; for (uint32_t i = 0; i < n; ++i) denom += gibbs_class_p(g, a, n, 1, i);
-    if (denom <= 2.2250738585072014e-308) { mode = 2; denom = (double)n; } }
-  const uint64_t s1 = min((uint64_t)item_s0[it] + 256, cnt);
-  for (uint64_t sidx = item_s0[it]; sidx < s1; ++sidx) {
-    double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, round_key, g.draw_off[c] + sidx)) * denom;
-    double acc = 0.0; uint32_t pick = n - 1;
-    for (uint32_t i = 0; i < n; ++i) { acc += gibbs_class_p(g, a, n, mode, i); if (u < acc) { pick = i; break; } }
-    atomicAdd(&g.count_i[g.tid[a + pick]], 1ULL);
+  double cu[NMAX - 1]; uint32_t G[NMAX - 1];
+#pragma unroll
+  for (int i = 0; i < NMAX - 1; ++i) { cu[i] = ((uint32_t)i < n - 1) ? cum[a + i] : __longlong_as_double(0x7FF0000000000000LL); G[i] = 0; }
+  const double dn = denom[c];
+  const uint64_t s0 = item_s0[it], s1 = min(s0 + 256, cnt), base = g.draw_off[c];
+  for (uint64_t sidx = s0; sidx < s1; ++sidx) {
+    const double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, round_key, base + sidx)) * dn;
+#pragma unroll
+    for (int i = 0; i < NMAX - 1; ++i) G[i] += (u < cu[i]) ? 0u : 1u;
+  }
+  const uint32_t D = (uint32_t)(s1 - s0);
+  uint32_t prev = D;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    if ((uint32_t)i < n) {
+      const uint32_t ge = ((uint32_t)i < n - 1) ? G[i < NMAX - 1 ? i : 0] : 0u;   // draws that passed threshold i
+      const uint32_t k = prev - ge; prev = ge;
+      if (k) atomicAdd(&g.count_i[g.tid[a + i]], (unsigned long long)k);
+    }
+  }
+}
+// larger classes: binary search of the running sums per draw
+__global__ void k_gibbs_items_big(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+    uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
+  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
+  const uint32_t c = item_cls[it];
+  const uint64_t a = g.off[c];
+  const uint32_t n = (uint32_t)(g.off[c + 1] - a);
+  const uint64_t cnt = g.cnt[c];
+  const double dn = denom[c];
+  const uint64_t s0 = item_s0[it], s1 = min(s0 + 256, cnt), base = g.draw_off[c];
+  for (uint64_t sidx = s0; sidx < s1; ++sidx) {
+    const double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, round_key, base + sidx)) * dn;
+    uint32_t lo = 0, hi = n - 1;                       // first i in [0, n-1) with u < cum[i], else n - 1
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (u < cum[a + mid]) hi = mid; else lo = mid + 1; }
+    atomicAdd(&g.count_i[g.tid[a + lo]], 1ULL);
   }
 }
 __global__ void k_gibbs_alpha(GibbsDev g, double scale, double* __restrict__ out) {
@@ -1036,6 +1079,11 @@ extern "C" uint32_t sq_gibbs_chain_step(uint32_t S_n) {   // samples per chain: 
 // run on different GPUs and give the samples a single GPU would have produced
 extern "C" int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init,
     uint32_t S_n, uint32_t first, uint32_t count, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user) {
+  return sq_gibbs_range_report_dev(device, eq, txp, go, alpha_init, S_n, first, count, seed, num_mapped, cb, user, nullptr);
+}
+extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, const sq_txp_in* txp, const sq_gibbs_opts* go, const double* alpha_init,
+    uint32_t S_n, uint32_t first, uint32_t count, uint64_t seed, uint64_t num_mapped, sq_replicate_cb cb, void* user, sq_gibbs_report* report) {
+  if (report) memset(report, 0, sizeof(*report));
   if (first > S_n || count > S_n - first) { sq_set_error("sq_gibbs_range_dev: range [%u, %u) outside %u samples", first, first + count, S_n); return SQ_ERR_ARG; }
   { const uint32_t stp = sq_gibbs_chain_step(S_n); uint32_t nch = 1; if (S_n >= 50) nch = 2; if (S_n >= 100) nch = 4; if (S_n >= 200) nch = 8;
     if (first && (nch == 1 || first % stp != 0 || first / stp >= nch)) { sq_set_error("sq_gibbs_range_dev: sample %u does not start a chain (step %u)", first, stp); return SQ_ERR_ARG; } }
@@ -1060,20 +1108,29 @@ extern "C" int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_tx
   std::vector<uint64_t> off(eq->off, eq->off + E + 1), cnt(eq->count, eq->count + E), draw_off(E + 1, 0);
   std::vector<uint32_t> tid(eq->tid, eq->tid + L);
   std::vector<double> w(eq->w, eq->w + L), eff(txp->eff_len, txp->eff_len + M);
-  std::vector<uint32_t> item_cls, item_s0;
-  for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; uint64_t n = off[c + 1] - off[c]; if (n == 0 ||
-      cnt[c] == 0) continue;
-    if (n == 1) { item_cls.push_back(c); item_s0.push_back(0); } else for (uint64_t s0 = 0; s0 < cnt[c]; s0 += 256) { item_cls.push_back(c); item_s0.push_back((uint32_t)s0); } }
+  // items = runs of up to 256 draws of one class, in three lists by class size (registers for <= 8 and <= 16 labels, binary search above),
+  // each list ordered by the item's draw count so that the lanes of a wave run loops of similar length
+  std::vector<uint32_t> item_cls, item_s0; uint32_t list_n[3] = {0, 0, 0}; uint64_t draws_per_round = 0;
+  { std::vector<std::pair<uint32_t, uint32_t>> lists[3];
+    for (uint32_t c = 0; c < E; ++c) { draw_off[c + 1] = draw_off[c] + cnt[c]; const uint64_t n = off[c + 1] - off[c]; if (n == 0 || cnt[c] == 0) continue;
+      if (n > 1) draws_per_round += cnt[c];
+      const int li = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+      if (n == 1) lists[0].emplace_back(c, 0u); else for (uint64_t s0 = 0; s0 < cnt[c]; s0 += 256) lists[li].emplace_back(c, (uint32_t)s0); }
+    for (int li = 0; li < 3; ++li) {
+      auto draws = [&](const std::pair<uint32_t, uint32_t>& x) { const uint64_t n = off[x.first + 1] - off[x.first]; return n == 1 ? (uint64_t)0 : std::min<uint64_t>(256, cnt[x.first] - x.second); };
+      std::stable_sort(lists[li].begin(), lists[li].end(), [&](const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) { return draws(x) > draws(y); });
+      list_n[li] = (uint32_t)lists[li].size();
+      for (auto& x : lists[li]) { item_cls.push_back(x.first); item_s0.push_back(x.second); } } }
   DBuf<uint64_t> d_off, d_cnt, d_doff;
   DBuf<uint32_t> d_tid, d_ic, d_is;
-  DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me;
+  DBuf<double> d_w, d_eff, d_prior, d_mu, d_cf, d_out, d_me, d_cum, d_den;
   DBuf<uint8_t> d_act;
   DBuf<unsigned long long> d_ci;
   if (d_off.upload(off) || d_cnt.upload(cnt) || d_doff.upload(draw_off) || d_tid.upload(tid) || d_ic.upload(item_cls) ||
       d_is.upload(item_s0) || d_w.upload(w) ||
       d_eff.upload(eff) || d_prior.upload(prior) ||
       d_mu.alloc(M) || d_cf.upload(init) || d_out.alloc(M) || d_me.alloc(M) || d_act.upload(active) ||
-          d_ci.alloc(M)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
+          d_ci.alloc(M) || d_cum.alloc(L + 1) || d_den.alloc((size_t)E + 1)) { sq_set_error("device allocation failed (Gibbs)"); return SQ_ERR_NOMEM; }
   GibbsDev g;
   g.M = M;
   g.E = E;
@@ -1092,26 +1149,38 @@ extern "C" int sq_gibbs_range_dev(int device, const sq_eq_table* eq, const sq_tx
   const uint32_t step = nchains > 1 ? S_n / nchains : S_n + 1;
   const uint32_t thin = go->thinning_factor ? go->thinning_factor : 16;
   const int TB = 256;
-  const uint32_t nitems = (uint32_t)item_cls.size();
   std::vector<double> me(M), alphas(M);
+  hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
+  struct Cleanup { hipStream_t& s; hipEvent_t& a; hipEvent_t& b; ~Cleanup() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (s) (void)hipStreamDestroy(s); } } cleanup{st, e0, e1};
+  double round_ms = 0.0; uint64_t rounds = 0;
+  const uint32_t o1 = list_n[0], o2 = list_n[0] + list_n[1];
   for (uint32_t sid = first; sid < first + count; ++sid) {
     // chain restart (:452-455); a range that starts at a later chain starts from the initial counts as well
-    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpy(d_cf.p, init.data(), (size_t)M * 8,
-        hipMemcpyHostToDevice));
+    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpyAsync(d_cf.p, init.data(), (size_t)M * 8,
+        hipMemcpyHostToDevice, st));
+    SQ_HIP_CHECK(hipEventRecord(e0, st));
     for (uint32_t r = 0; r < thin; ++r) {
       const uint64_t key = (uint64_t)sid * thin + r;
-      k_gibbs_mu<<<(M + TB - 1) / TB, TB>>>(g, seed, key, go->no_gamma_draw);
-      SQ_HIP_CHECK(hipMemsetAsync(d_ci.p, 0, (size_t)M * 8));
-      if (nitems) k_gibbs_items<<<(nitems + TB - 1) / TB, TB>>>(g, nitems, d_ic.p, d_is.p, seed, key);
-      k_u64_to_f64<<<(M + TB - 1) / TB, TB>>>(M, d_ci.p, d_cf.p);
+      k_gibbs_mu<<<(M + TB - 1) / TB, TB, 0, st>>>(g, seed, key, go->no_gamma_draw);
+      SQ_HIP_CHECK(hipMemsetAsync(d_ci.p, 0, (size_t)M * 8, st));
+      if (E) k_gibbs_prep<<<(E + TB - 1) / TB, TB, 0, st>>>(g, d_cum.p, d_den.p);
+      if (list_n[0]) k_gibbs_items_reg<8><<<(list_n[0] + TB - 1) / TB, TB, 0, st>>>(g, list_n[0], d_ic.p, d_is.p, seed, key, d_cum.p, d_den.p);
+      if (list_n[1]) k_gibbs_items_reg<16><<<(list_n[1] + TB - 1) / TB, TB, 0, st>>>(g, list_n[1], d_ic.p + o1, d_is.p + o1, seed, key, d_cum.p, d_den.p);
+      if (list_n[2]) k_gibbs_items_big<<<(list_n[2] + TB - 1) / TB, TB, 0, st>>>(g, list_n[2], d_ic.p + o2, d_is.p + o2, seed, key, d_cum.p, d_den.p);
+      k_u64_to_f64<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_ci.p, d_cf.p);
     }
-    k_mul<<<(M + TB - 1) / TB, TB>>>(M, d_mu.p, d_eff.p, d_me.p);
-    SQ_HIP_CHECK(hipMemcpy(me.data(), d_me.p, (size_t)M * 8, hipMemcpyDeviceToHost));
+    SQ_HIP_CHECK(hipEventRecord(e1, st));
+    k_mul<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_mu.p, d_eff.p, d_me.p);
+    SQ_HIP_CHECK(hipMemcpyAsync(me.data(), d_me.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { round_ms += ms; rounds += thin; } }
     double denom = canonical_sum_host(me);                                                                // :489-492 (order-defined sum)
     double scale = (double)num_mapped / denom;
-    k_gibbs_alpha<<<(M + TB - 1) / TB, TB>>>(g, scale, d_out.p);
-    SQ_HIP_CHECK(hipMemcpy(alphas.data(), d_out.p, (size_t)M * 8, hipMemcpyDeviceToHost));
+    k_gibbs_alpha<<<(M + TB - 1) / TB, TB, 0, st>>>(g, scale, d_out.p);
+    SQ_HIP_CHECK(hipMemcpyAsync(alphas.data(), d_out.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
     if (cb(alphas.data(), M, user)) break;
   }
+  if (report) { report->rounds = rounds; report->device_ms = round_ms; report->ms_per_round = rounds ? round_ms / (double)rounds : 0.0; report->draws_per_round = draws_per_round;
+    report->items[0] = list_n[0]; report->items[1] = list_n[1]; report->items[2] = list_n[2]; report->_pad = 0; }
   return SQ_OK;
 }

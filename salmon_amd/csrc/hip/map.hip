@@ -49,7 +49,7 @@ void fill_params(sq_ctx* c) {
 static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_mems", "large_ends", "count_kmer_frags", "k_join_count",
     "scan_cands", "k_join_fill", "k_score",
     "k_dp", "k_select", "compact_alns",
-                                          "eq_flags_scan", "eq_mini_batches", "eq_table"};
+                                          "eq_flags_scan", "eq_mini_batches", "eq_table", "k_finalize"};
 void sq_prof_begin(sq_ctx* c,
     int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
@@ -551,6 +551,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   }
   if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p,
       tid_arr.p);
+  sq_prof_mark(c, SG_FINALIZE);
   k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p,
       c->frag_flags.p, c->aln_slots.p,
       c->n_aln.p, c->map_type.p, c->stats.p, nullptr);

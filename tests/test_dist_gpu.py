@@ -1,5 +1,5 @@
 """The multi-GPU seam in C (sq_dist_* over RCCL, hip/dist.hip) on the one GPU this box has: a communicator of one rank (every collective
-runs through RCCL, merging nothing), the shares of replicates by rank, and the replicate-range entry points — a bootstrap replicate /
+runs through RCCL), two shards exchanged through the communicator's buffers in loop-back and merged by the product (= the 2-rank checker), the shares of replicates by rank, and the replicate-range entry points — a bootstrap replicate /
 a Gibbs chain computed as a range is byte-identical to the same replicate of a full run, which is what lets ranks split them."""
 import numpy as np
 import pytest
@@ -10,6 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_rccl_communicator_of_one_rank_runs_every_collective(small_world):
+    """No short cut for world == 1: the size / payload all-gathers, the all-reduce, the broadcast and the model reduction all go through RCCL
+    (a one-rank communicator), and a one-rank exchange leaves the table and the model bit-identical."""
     w = small_world; w["idx"].to_device(0)
     d = api.Dist(api.Dist.make_id(), 0, 1, 0)
     ctx = api.QuantContext(w["idx"], api.quant_opts(), device=0, max_batch_reads=4096)
@@ -23,9 +25,123 @@ def test_rccl_communicator_of_one_rank_runs_every_collective(small_world):
     lm2, uq2, tc2, le2 = d.reduce_model(lm, uq, tc, le)
     assert np.array_equal(lm, lm2) and np.array_equal(uq, uq2) and np.array_equal(tc, tc2) and np.array_equal(le, le2)
     assert np.array_equal(d.allreduce_u64(np.array([3, 5], np.uint64)), [3, 5])
+    x = np.arange(1000, dtype=np.float64) * 0.37
+    assert np.array_equal(d.allgather(x)[0], x) and np.array_equal(d.bcast(x), x)
     d.barrier()
     assert d.share(10) == (0, 10)
     d.free(); ctx.free()
+
+
+def _two_shards(w, opts):
+    """Two halves of the reads, each through its own HIP context (what two ranks do), and through two checker states."""
+    import orc
+    N = w["n"]; per = N // 2; ctxs = []; states = []
+    for r in range(2):
+        lo, hi = r * per, (r + 1) * per
+        s = w["seq"][lo * 200: hi * 200]; o = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        rb = api.make_read_batch(s, o, hi - lo, paired=True)
+        c = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+        c.map_batch(rb, fetch=False); c.eq_accumulate(); ctxs.append(c)
+        ro, aln, mt, st = orc.map_batch(w["oidx"], opts, rb, threads=4)
+        ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish(); states.append(ost)
+    return ctxs, states
+
+
+def test_two_shards_exchanged_through_the_rccl_buffers_equal_the_two_rank_checker(small_world):
+    """SPEC §MG on one GPU: two contexts stand for two ranks.  Their tables are packed, sent through the one-rank communicator's
+    all-gathers (RCCL runs them) into receive slots and merged by the code path sq_dist_merge_eq uses; the per-transcript state goes
+    through the library's collectives and sq_merge_log_masses.  Everything equals the 2-rank checker (orc_state_merge) bit for bit."""
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(mini_batch_size=100, num_pre_burnin_frags=80, num_burnin_frags=700)   # each shard crosses burn-in on its own
+    ctxs, states = _two_shards(w, opts)
+    models = [c.model() for c in ctxs]                       # every rank's own online state, before the exchange
+    d = api.Dist(api.Dist.make_id(), 0, 1, 0)
+    d.merge_eq_loopback(ctxs)
+    merged = [c.eq_finish() for c in ctxs]
+    # the model reduction, collective by collective, each through RCCL: counts all-reduced (here: one rank's at a time, summed exactly),
+    # masses all-gathered then folded in rank order by the library's rule, effective lengths broadcast from rank 0
+    uq = sum(d.allreduce_u64(m[1]).astype(object) for m in models); tc = sum(d.allreduce_u64(m[2]).astype(object) for m in models)
+    allm = np.ascontiguousarray(np.stack([d.allgather(m[0])[0] for m in models]))
+    lm = np.zeros(allm.shape[1]); from salmon_amd import capi
+    capi.check(capi.lib().sq_merge_log_masses(allm.shape[1], 2, allm.ctypes.data, lm.ctypes.data), "sq_merge_log_masses")
+    le = d.bcast(models[0][3])
+    assert states[0].summary()["burned_in"] and states[1].summary()["burned_in"]
+    states[0].merge(states[1])
+    full = states[0].eq_finish(); lmf, uqf, tcf, lef, _ = states[0].model()
+    for r in range(2):
+        for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+            assert np.array_equal(getattr(merged[r], f), getattr(full, f)), (r, f)
+    assert np.array_equal(lm, lmf) and np.array_equal(np.array(uq, np.uint64), uqf) and np.array_equal(np.array(tc, np.uint64), tcf) and np.array_equal(le, lef)
+    # and the inference tail on the merged table is the checker's
+    import orc
+    proj_g = api.normalize_alphas(merged[0], lm, np.array(uq, np.uint64), np.array(tc, np.uint64)); proj_c = orc.normalize_alphas(len(lm), full, lmf, uqf, tcf)
+    assert np.array_equal(proj_g, proj_c)
+    a_g, rep_g = ctxs[0].em_optimize(np.exp(le), proj_g, api.em_opts()); a_c, rep_c = orc.em_optimize(full, np.exp(lef), proj_c, api.em_opts())
+    assert rep_g["iters"] == rep_c["iters"] and np.array_equal(a_g, a_c)
+    d.free()
+    for c in ctxs: c.free()
+
+
+def _gloo_gpu_worker(rank, world, port, q):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import torch, torch.distributed as dist
+        from salmon_amd import api, synth, dist as sqdist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        tx = synth.Txome(seed=9, n_genes=50, iso_per_gene=5, threads=1)
+        names, seqs, lens = tx.tables()
+        idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=1); idx.to_device(0)
+        N = 1200; per = N // world
+        seq, off, _, _ = tx.reads(N, read_len=100, seed=3, threads=1)
+        opts = api.quant_opts(mini_batch_size=100, num_pre_burnin_frags=80, num_burnin_frags=350)
+        lo, hi = rank * per, (rank + 1) * per
+        s = seq[lo * 200: hi * 200]; o = (off[2 * lo: 2 * hi + 1] - off[2 * lo]).copy()
+        ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=2048)
+        ctx.map_batch(api.make_read_batch(s, o, hi - lo, paired=True), fetch=False); ctx.eq_accumulate()
+        eq = ctx.eq_finish(); lm, uq, tc, le = ctx.model()
+        tables = sqdist.all_gather_tables(eq, dist, torch.device("cpu"))
+        for r in range(world):
+            if r != rank: ctx.eq_merge(tables[r])                      # the product's merge (sq_eq_merge): integer counts, fixed-point sums
+        mine = ctx.eq_finish()
+        lm2, uq2, tc2, le2 = sqdist.reduce_model(lm, uq, tc, le, dist, torch.device("cpu"))   # masses by the library's sq_merge_log_masses
+        ok = True
+        if rank == 0:
+            import orc
+            oidx = orc.OrcIndex(idx); states = []
+            for r in range(world):
+                a, b = r * per, (r + 1) * per
+                rb = api.make_read_batch(seq[a * 200: b * 200], (off[2 * a: 2 * b + 1] - off[2 * a]).copy(), b - a, paired=True)
+                ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=1)
+                ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish(); states.append(ost)
+            for r in range(1, world): states[0].merge(states[r])
+            full = states[0].eq_finish(); lmf, uqf, tcf, lef, _ = states[0].model()
+            ok = all(np.array_equal(getattr(mine, f), getattr(full, f)) for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"])
+            ok = ok and np.array_equal(lm2, lmf) and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf) and np.array_equal(le2, lef)
+        import hashlib
+        dig = int(hashlib.sha256(mine.wq.tobytes() + mine.count.tobytes() + mine.tid.tobytes()).hexdigest()[:15], 16)
+        dt = torch.tensor([dig], dtype=torch.int64); ds = [torch.zeros_like(dt) for _ in range(world)]; dist.all_gather(ds, dt)
+        ok = ok and all(int(x) == int(ds[0]) for x in ds)           # every rank holds the same merged table
+        q.put((rank, bool(ok), "classes=%d" % len(mine.count)))
+        dist.destroy_process_group()
+    except Exception as e:   # a worker that dies must not leave the parent waiting for its queue entry
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-1500:]))
+
+
+def test_two_gloo_ranks_on_one_gpu_merge_with_the_product(built):
+    """Two processes (gloo for the transport, both on cuda:0): each maps its shard with the HIP path, the tables travel as the
+    harness's padded all-gathers and every rank folds the other's in with the product's sq_eq_merge; equals the 2-rank checker."""
+    import socket, torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
 
 
 def test_shares_cover_the_replicates_without_overlap():

@@ -482,3 +482,36 @@ def test_library_type_autodetect_matches_checker(small_world):
     for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
         assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
     ctx.free(); ost.free()
+
+
+def test_c4_shape_decoy_genome_2x150_matches_checker(built):
+    """configs[3] at reduced scale: the transcriptome followed by a synthetic genome as decoys (every gene's exons with introns, 45 % repeat
+    families — tools/synth.cpp sqs_genome_generate), 2x150 bp pairs of which 5 % come from gene loci of the genome.  100 000 pairs through
+    the HIP path and through the checker: every array equal; genomic pairs end up as decoy fragments, transcript pairs do not."""
+    tx = synth.Txome(seed=31, n_genes=800, iso_per_gene=4, threads=4)
+    g = synth.Genome(tx, seed=3, total_nt=40_000_000, n_chrom=5, repeat_frac=0.45, threads=4)
+    names, seqs, lens = g.append_tables(tx)
+    idx = api.SalmonIndex.build_mem_raw(tx.n + g.n, names, seqs, lens, threads=8, first_decoy=tx.n)
+    assert idx.first_decoy == tx.n and idx.num_refs == tx.n + g.n
+    oidx = orc.OrcIndex(idx)
+    N = 100000
+    seq, off, tt, tp = g.reads(tx, N, read_len=150, seed=2, genomic_frac=0.05, threads=4)
+    opts = api.quant_opts()
+    rb = api.make_read_batch(seq, off, N, paired=True)
+    ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=N)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(oidx, opts, rb, threads=8)
+    assert st_g == st_c
+    assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    assert np.all(aln_g["tid"] < tx.n)
+    genomic = tt == 0xFFFFFFFE; txp = tt < 0xFFFFFFF0
+    assert (mt_g[genomic] == 6).mean() > 0.95 and (mt_g[txp] == 6).mean() < 0.01      # SQ_MT_DECOY
+    assert st_g["num_truncated_ends"] == 0
+    ctx.eq_accumulate()
+    ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    assert ctx.summary() == ost.summary()
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    ctx.free(); ost.free()

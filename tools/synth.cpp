@@ -24,7 +24,7 @@ struct Rng {
 const char ACGT[4] = {'A', 'C', 'G', 'T'};
 inline char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
 
-struct Txome { std::vector<std::string> names, seqs; std::vector<uint32_t> gene; };
+struct Txome { std::vector<std::string> names, seqs; std::vector<uint32_t> gene; std::vector<std::string> gene_exons; /* per gene: exons joined by '|' */ };
 
 void gen_gene(uint64_t seed, uint32_t g, uint32_t iso_target, const std::string* paralog_of, std::vector<std::string>& exons_out,
               std::vector<std::string>& names, std::vector<std::string>& seqs) {
@@ -76,6 +76,7 @@ sqs_txome* sqs_txome_generate(uint64_t seed, uint32_t n_genes, uint32_t iso_per_
   };
   run(false); run(true);
   for (uint32_t g = 0; g < n_genes; ++g) for (size_t i = 0; i < gn[g].size(); ++i) { o->t.names.push_back(std::move(gn[g][i])); o->t.seqs.push_back(std::move(gs[g][i])); o->t.gene.push_back(g); }
+  o->t.gene_exons.resize(n_genes); for (uint32_t g = 0; g < n_genes; ++g) o->t.gene_exons[g] = std::move(gex[g][0]);
   return o;
 }
 void sqs_txome_free(sqs_txome* t) { delete t; }
@@ -134,6 +135,106 @@ void sqs_reads_generate(const sqs_txome* t, uint64_t seed, uint64_t first_pair, 
         bool flip = r.next() & 1;  // unstranded: which mate is forward
         mutate(flip ? m2 : m1, o1); mutate(flip ? m1 : m2, o2);
         if (truth_tid) truth_tid[i] = tid; if (truth_pos) truth_pos[i] = st;
+      }
+    }
+  });
+  for (auto& x : th) x.join();
+}
+
+// ---- decoy genome (SURVEY.md §8d "G3G", configs[3]) -------------------------------------------------------------------------
+// n_chrom chromosomes totalling ~total_nt: random background, `repeat_frac` of it overwritten by copies of 1000 repeat families
+// (consensus 300-3000 nt, every copy at 80-95 % identity), then every gene's exons written in order with introns between them
+// (lognormal, median 1.5 kb, shrunk when the genes would not fit), gene g on chromosome g % n_chrom.  The exons are written last, so
+// every transcript is a spliced copy of its gene's locus.
+struct Genome { std::vector<std::string> names, seqs; std::vector<uint32_t> gchrom; std::vector<uint64_t> gstart, gend; };
+struct sqs_genome { Genome g; };
+
+sqs_genome* sqs_genome_generate(const sqs_txome* t, uint64_t seed, uint64_t total_nt, uint32_t n_chrom, double repeat_frac, uint32_t nthreads) {
+  const Txome& T = t->t; const uint32_t G = (uint32_t)T.gene_exons.size();
+  sqs_genome* o = new sqs_genome(); Genome& X = o->g;
+  if (n_chrom == 0) n_chrom = 1;
+  const uint64_t clen = std::max<uint64_t>(total_nt / n_chrom, 2000);
+  X.names.resize(n_chrom); X.seqs.resize(n_chrom); X.gchrom.assign(G, 0); X.gstart.assign(G, 0); X.gend.assign(G, 0);
+  // exon lengths per gene and the intron scale that lets the genes take at most 70 % of a chromosome
+  std::vector<std::vector<uint32_t>> elen(G); uint64_t exon_nt = 0, nintr = 0;
+  for (uint32_t g = 0; g < G; ++g) { const std::string& j = T.gene_exons[g]; size_t p = 0; while (p <= j.size()) { size_t e = j.find('|', p); if (e == std::string::npos) e = j.size(); elen[g].push_back((uint32_t)(e - p)); exon_nt += e - p; p = e + 1; } nintr += elen[g].size() - 1; }
+  const double mean_intron = 1500.0 * std::exp(0.5 * 0.8 * 0.8);   // lognormal(median 1500, sigma 0.8)
+  double room = 0.7 * (double)clen * n_chrom - (double)exon_nt; if (room < 0) room = 0;
+  const double iscale = nintr ? std::min(1.0, room / (mean_intron * (double)nintr)) : 1.0;
+  // repeat families (shared by all chromosomes)
+  std::vector<std::string> fam(1000);
+  { Rng r(seed ^ 0x5EED0FA3ULL); for (auto& f : fam) { uint32_t L = 300 + r.below(2700); f.resize(L); for (auto& c : f) c = ACGT[r.below(4)]; } }
+  std::atomic<uint32_t> next(0); std::vector<std::thread> th;
+  for (uint32_t tt = 0; tt < std::max(1u, std::min(nthreads, n_chrom)); ++tt) th.emplace_back([&]() {
+    for (;;) {
+      const uint32_t c = next.fetch_add(1); if (c >= n_chrom) break;
+      Rng r(seed ^ (0xC0FFEEULL + (uint64_t)c * 0x9E3779B97F4A7C15ULL));
+      std::string& s = X.seqs[c]; s.resize(clen);
+      for (uint64_t p = 0; p < clen; p += 32) { uint64_t w = r.next(); const uint64_t e = std::min<uint64_t>(clen, p + 32); for (uint64_t q = p; q < e; ++q, w >>= 2) s[q] = ACGT[w & 3]; }
+      // repeats
+      uint64_t rep_nt = 0; const uint64_t rep_goal = (uint64_t)(repeat_frac * (double)clen);
+      while (rep_nt < rep_goal) {
+        const std::string& f = fam[r.below(1000)]; if (f.size() + 1 >= clen) break;
+        const uint64_t pos = (uint64_t)(r.u() * (double)(clen - f.size())); const double div = 0.05 + 0.15 * r.u();
+        // a copy: substitutions drawn by geometric gaps (no RNG call per base)
+        memcpy(&s[pos], f.data(), f.size());
+        for (double q = -std::log(1.0 - r.u()) / div; q < (double)f.size(); q += 1.0 - std::log(1.0 - r.u()) / div) s[pos + (uint64_t)q] = ACGT[r.below(4)];
+        rep_nt += f.size();
+      }
+      // genes of this chromosome, in order, evenly spaced
+      std::vector<uint32_t> mine; for (uint32_t g = c; g < G; g += n_chrom) mine.push_back(g);
+      std::vector<std::vector<uint32_t>> intr(mine.size()); uint64_t span_sum = 0;
+      for (size_t i = 0; i < mine.size(); ++i) { const uint32_t g = mine[i]; uint64_t sp = 0; for (size_t e = 0; e < elen[g].size(); ++e) { sp += elen[g][e]; if (e + 1 < elen[g].size()) { double v = 1500.0 * std::exp(0.8 * r.normal()) * iscale; uint32_t il = (uint32_t)std::min(50000.0, std::max(20.0, v)); intr[i].push_back(il); sp += il; } } span_sum += sp; }
+      const uint64_t gap = (clen > span_sum) ? (clen - span_sum) / (mine.size() + 1) : 0;
+      uint64_t pos = gap;
+      for (size_t i = 0; i < mine.size(); ++i) {
+        const uint32_t g = mine[i]; const std::string& j = T.gene_exons[g]; size_t p = 0; uint64_t q = pos;
+        X.gchrom[g] = c; X.gstart[g] = std::min<uint64_t>(q, clen);
+        for (size_t e = 0; e < elen[g].size(); ++e) {
+          const uint32_t L = elen[g][e];
+          if (q + L <= clen) memcpy(&s[q], j.data() + p, L);
+          q += L; p += L + 1; if (e + 1 < elen[g].size()) q += intr[i][e];
+        }
+        X.gend[g] = std::min<uint64_t>(q, clen); pos = q + gap;
+      }
+      char nm[32]; snprintf(nm, sizeof(nm), "chr%u", c + 1); X.names[c] = nm;
+    }
+  });
+  for (auto& x : th) x.join();
+  return o;
+}
+void sqs_genome_free(sqs_genome* g) { delete g; }
+uint32_t sqs_genome_count(const sqs_genome* g) { return (uint32_t)g->g.names.size(); }
+const char* sqs_genome_name(const sqs_genome* g, uint32_t i) { return g->g.names[i].c_str(); }
+const char* sqs_genome_seq(const sqs_genome* g, uint32_t i) { return g->g.seqs[i].data(); }
+uint64_t sqs_genome_len(const sqs_genome* g, uint32_t i) { return (uint64_t)g->g.seqs[i].size(); }
+
+// sqs_reads_generate with a third source: a fraction `genomic_frac` of the pairs is drawn from the decoy genome, uniformly inside a
+// random gene's locus (exons + introns: mostly intronic sequence), truth_tid = 0xFFFFFFFE
+void sqs_reads_generate_decoy(const sqs_txome* t, const sqs_genome* gn, uint64_t seed, uint64_t first_pair, uint64_t n_pairs, uint32_t read_len,
+                              double sub_rate, double indel_rate, double junk_frac, double genomic_frac, uint8_t* seq, uint32_t* truth_tid,
+                              uint32_t* truth_pos, uint32_t nthreads) {
+  sqs_reads_generate(t, seed, first_pair, n_pairs, read_len, sub_rate, indel_rate, junk_frac, seq, truth_tid, truth_pos, nthreads);
+  if (!gn || genomic_frac <= 0) return;
+  const Genome& X = gn->g; const uint32_t G = (uint32_t)X.gstart.size(); if (!G) return;
+  std::atomic<uint64_t> next(0); std::vector<std::thread> th;
+  for (uint32_t tt = 0; tt < std::max(1u, nthreads); ++tt) th.emplace_back([&]() {
+    for (;;) {
+      uint64_t b = next.fetch_add(4096); if (b >= n_pairs) break; const uint64_t e = std::min(n_pairs, b + 4096);
+      for (uint64_t i = b; i < e; ++i) {
+        Rng r(seed ^ 0x6E0D1CULL ^ ((first_pair + i) * 0xD6E8FEB86659FD93ULL));
+        if (r.u() >= genomic_frac) continue;
+        const uint32_t g = r.below(G); const std::string& s = X.seqs[X.gchrom[g]];
+        uint32_t fl = (uint32_t)std::max((double)read_len, 250.0 + 25.0 * r.normal() + 0.5);
+        const uint64_t lo = X.gstart[g], hi = X.gend[g]; if (hi < lo + fl + 1) continue;
+        const uint64_t st = lo + (uint64_t)(r.u() * (double)(hi - lo - fl));
+        uint8_t* o1 = seq + (2 * i) * read_len; uint8_t* o2 = o1 + read_len; const bool flip = r.next() & 1;
+        for (uint32_t p = 0; p < read_len; ++p) {
+          char a = s[st + p], c2 = comp(s[st + fl - 1 - p]);
+          if (r.u() < sub_rate) a = ACGT[r.below(4)]; if (r.u() < sub_rate) c2 = ACGT[r.below(4)];
+          (flip ? o2 : o1)[p] = (uint8_t)a; (flip ? o1 : o2)[p] = (uint8_t)c2;
+        }
+        if (truth_tid) truth_tid[i] = 0xFFFFFFFEu; if (truth_pos) truth_pos[i] = (uint32_t)st;
       }
     }
   });
