@@ -294,7 +294,8 @@ struct BgzfSource {
       auto b = std::make_shared<Blk>(); b->off = next_off;
       if (ms == 0 || ms > n - next_off) { b->err = ms ? "truncated BGZF member" : "not a BGZF member (mixed gzip file?)"; b->done = true; win.push_back(b); next_off = n; break; }
       b->csize = ms; next_off += ms; win.push_back(b);
-      pool->submit([this, b] { inflate_block(base + b->off, b.get()); { std::lock_guard<std::mutex> lk(mu); b->done = true; } cv.notify_all(); });
+      // notify while holding mu: once `done` is visible the destructor may run, and it must not free cv under a task still about to signal it
+      pool->submit([this, b] { inflate_block(base + b->off, b.get()); std::lock_guard<std::mutex> lk(mu); b->done = true; cv.notify_all(); });
     }
   }
   // up to `want` bytes of text in file order; 0 at the end; -1 on error (see err)
@@ -492,6 +493,11 @@ extern "C" int sq_reader_open_ex(const char* const* files1, uint32_t n1, const c
   std::vector<std::string> a(files1, files1 + n1), b; if (n2) b.assign(files2, files2 + n2);
   // fast path for 4-line FASTQ (the first record of every file is looked at); anything else takes the kseq-rules path
   bool fast = !getenv("SQ_READER_SAFE");
+  // Only regular files are probed (and later mapped / reopened): a FIFO or /dev/fd/N from process substitution — the usual way to feed
+  // salmon from a decompressor — can be opened once and read once, so those go straight to the streaming path, untouched.
+  for (int st = 0; st < 2 && fast; ++st) for (const auto& path : (st ? b : a)) {
+    struct stat sb; if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) { fast = false; break; }
+  }
   for (int st = 0; st < 2 && fast; ++st) for (const auto& path : (st ? b : a)) {
     std::vector<char> head(65536); gzFile f = gzopen(path.c_str(), "rb"); if (!f) { fast = false; break; }   // the stream thread reports it
     const int n = gzread(f, head.data(), (unsigned)head.size()); gzclose(f);

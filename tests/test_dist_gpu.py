@@ -107,7 +107,7 @@ def _gloo_gpu_worker(rank, world, port, q):
             if r != rank: ctx.eq_merge(tables[r])                      # the product's merge (sq_eq_merge): integer counts, fixed-point sums
         mine = ctx.eq_finish()
         lm2, uq2, tc2, le2 = sqdist.reduce_model(lm, uq, tc, le, dist, torch.device("cpu"))   # masses by the library's sq_merge_log_masses
-        ok = True
+        ok = True; msg = ""
         if rank == 0:
             import orc
             oidx = orc.OrcIndex(idx); states = []
@@ -116,15 +116,22 @@ def _gloo_gpu_worker(rank, world, port, q):
                 rb = api.make_read_batch(seq[a * 200: b * 200], (off[2 * a: 2 * b + 1] - off[2 * a]).copy(), b - a, paired=True)
                 ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=1)
                 ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish(); states.append(ost)
+            states_own_eq = states[0].eq_finish(); own_model = states[0].model()[:4]
             for r in range(1, world): states[0].merge(states[r])
             full = states[0].eq_finish(); lmf, uqf, tcf, lef, _ = states[0].model()
-            ok = all(np.array_equal(getattr(mine, f), getattr(full, f)) for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"])
-            ok = ok and np.array_equal(lm2, lmf) and np.array_equal(uq2, uqf) and np.array_equal(tc2, tcf) and np.array_equal(le2, lef)
+            bad = [f for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"] if not np.array_equal(getattr(mine, f), getattr(full, f))]
+            bad += [n for n, x, y in (("log_mass", lm2, lmf), ("uniq", uq2, uqf), ("total", tc2, tcf), ("log_eff_len", le2, lef)) if not np.array_equal(x, y)]
+            # which side differs: this rank's own shard against its checker state
+            own = states_own_eq
+            bad += ["own:" + f for f in ["off", "tid", "count", "wq"] if not np.array_equal(getattr(eq, f), getattr(own, f))]
+            bad += ["own_model:%d" % i for i, (x, y) in enumerate(zip((lm, uq, tc, le), own_model)) if not np.array_equal(x, y)]
+            ok = not bad
+            if bad: msg = "differs: " + ",".join(bad)
         import hashlib
         dig = int(hashlib.sha256(mine.wq.tobytes() + mine.count.tobytes() + mine.tid.tobytes()).hexdigest()[:15], 16)
         dt = torch.tensor([dig], dtype=torch.int64); ds = [torch.zeros_like(dt) for _ in range(world)]; dist.all_gather(ds, dt)
         ok = ok and all(int(x) == int(ds[0]) for x in ds)           # every rank holds the same merged table
-        q.put((rank, bool(ok), "classes=%d" % len(mine.count)))
+        q.put((rank, bool(ok), msg or "classes=%d" % len(mine.count)))
         dist.destroy_process_group()
     except Exception as e:   # a worker that dies must not leave the parent waiting for its queue entry
         import traceback

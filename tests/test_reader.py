@@ -210,3 +210,33 @@ def test_reader_bgzf_members_are_inflated_in_parallel_and_in_order(built, tmp_pa
     open(tmp_path / "bad_1.fq.gz", "wb").write(bytes(raw))
     h = _open([str(tmp_path / "bad_1.fq.gz")], None, batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
     assert err is not None and "bad_1.fq.gz" in err and ("BGZF" in err or "record" in err)
+
+
+def test_reader_streams_from_fifos_and_dev_fd(built, tmp_path):
+    """Non-seekable inputs — named FIFOs and /dev/fd/N (process substitution, the documented way to feed salmon from a decompressor) — are
+    read once, front to back, by the streaming path: nothing is probed, reopened or mapped."""
+    import threading
+    rng = np.random.default_rng(3)
+    recs1 = ["".join(rng.choice(list("ACGT"), size=100)) for _ in range(1000)]; recs2 = ["".join(rng.choice(list("ACGT"), size=100)) for _ in range(1000)]
+    _fq(tmp_path / "a_1.fq", recs1); _fq(tmp_path / "a_2.fq", recs2)
+    # named FIFOs, one writer thread each
+    f1, f2 = str(tmp_path / "p1.fq"), str(tmp_path / "p2.fq"); os.mkfifo(f1); os.mkfifo(f2)
+    def feed(src, dst):
+        with open(dst, "wb") as o: o.write(open(src, "rb").read())
+    th = [threading.Thread(target=feed, args=(str(tmp_path / "a_1.fq"), f1)), threading.Thread(target=feed, args=(str(tmp_path / "a_2.fq"), f2))]
+    for t in th: t.start()
+    h = _open([f1], [f2], batch=300); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    for t in th: t.join(timeout=30)
+    assert err is None
+    assert [r for b in got for r in b] == [x.encode() for pair in zip(recs1, recs2) for x in pair]
+    # /dev/fd/N of a pipe (what `<(zcat reads.fq.gz)` hands over)
+    r, w = os.pipe()
+    t = threading.Thread(target=lambda: (os.write(w, b""), [os.write(w, c) for c in _chunks(open(tmp_path / "a_1.fq", "rb").read())], os.close(w)))
+    t.start()
+    h = _open(["/dev/fd/%d" % r], None, batch=256); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    t.join(timeout=30); os.close(r)
+    assert err is None and [x for b in got for x in b] == [x.encode() for x in recs1]
+
+
+def _chunks(b, n=65536):
+    return [b[i:i + n] for i in range(0, len(b), n)]
