@@ -30,7 +30,8 @@ def test_live_bench_line_has_the_contract_fields_and_parity(built):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["n_gpus"] == 1
     assert d["steps"] == 2 and d["warmup"] == 1 and "workload" in d["config"] and "model" not in d["config"]
     assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    assert abs(d["value"] - 2 * 60000 / (d["ms_per_step"] * 2e-3) / 1e6) < 0.01 * d["value"]          # value = pairs / wall time
+    assert d["config"]["pairs_per_step"] == 2 * 60000 and d["config"]["workload_id"] == "c2"          # a step = `--sub` (2) sq_map_batch calls
+    assert abs(d["value"] - 2 * d["config"]["pairs_per_step"] / (d["ms_per_step"] * 2e-3) / 1e6) < 0.01 * d["value"]          # value = pairs / wall time
     ro = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(ro) and ro["bound"] == "hbm" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-4
