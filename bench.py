@@ -92,13 +92,17 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         "k_select": st["num_candidates"] * 48 + st["num_alignments"] * 40 + n_pairs * 30,
         "compact_alns": st["num_alignments"] * 80 + n_pairs * 28,
         "eq_flags_scan": st["num_alignments"] * (40 + 32) + n_pairs * 24,
-        "eq_mini_batches": st["num_alignments"] * (32 + 8 + 8 + 4 + 3 * 16) + n_pairs * 32,
+        # [r3] after burn-in the online stage is a model-independent launch per batch (eq_static: per alignment the 32-byte pre-record in, the 24-byte
+        # dynamic record + fixed-point weight + bin out, two counters; per fragment offsets and the label hash) and per group of mini-batches
+        # the mass terms (eq_mini_batches = k_frag_dynamic + k_apply_dynamic: the dynamic record, the transcript's log-count, one mass slot)
+        "eq_static": st["num_alignments"] * (32 + 24 + 8 + 4 + 2 * 8) + n_pairs * (16 + 16),
+        "eq_mini_batches": st["num_alignments"] * (24 + 8 + 16 + 8) + n_pairs * 16,
         "eq_table": st["num_alignments"] * (4 + 4 + 8 + 8) + n_pairs * (16 + 4 + 32),
     }
 
 
 KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
-                   "k_select": "k_select", "k_finalize": "k_finalize", "compact_alns": "k_compact_alns", "eq_mini_batches": "k_mini_batch",
+                   "k_select": "k_select", "k_finalize": "k_finalize", "compact_alns": "k_compact_alns", "eq_mini_batches": "k_frag_dynamic+k_apply_dynamic", "eq_static": "k_frag_static",
                    "eq_table": "k_eq_insert"}
 
 

@@ -381,6 +381,10 @@ typedef int (*sq_efflen_cb)(const double* alphas, const double* eff_len_in, doub
 int sq_em_optimize_bias(sq_ctx*, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, sq_efflen_cb cb, void* user,
                         double* alpha_out, double* eff_len_out, sq_em_report* report);
 
+/* The learning-rate schedule of the online phase (ForgettingMassCalculator.hpp:23-40: prefill; :64-90 getLogMassAndTimestep as called at
+ * SalmonQuantify.cpp:515): out[b] = log forgetting mass of mini-batch b for b < n.  sq_eq_accumulate uses exactly these values. */
+int sq_forgetting_masses(double forgetting_factor, uint64_t n, double* out);
+
 /* Host-side, once per run: salmon::utils::normalizeAlphas (src/util/SalmonUtils.cpp:461-529) with
  * TranscriptCluster::projectToPolytope — online masses -> projectedCounts used to initialise EM. */
 int sq_normalize_alphas(uint32_t num_txp, const sq_eq_table* eq, const double* log_mass, const uint64_t* unique_count,

@@ -911,7 +911,9 @@ struct QuantState {
       if (fm.empty()) { fm.push_back(0.0); continue; }
       uint64_t i = fm.size() + 1;  // i = 2,3,... for index 1,2,...
       double ff = op.o.forgetting_factor;
-      fm.push_back(fm.back() + ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0));
+      // `fm += a - b` in prefill (:30-33): the increment is formed first, then added — not (fm + a) - b
+      const double inc = ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0);
+      fm.push_back(fm.back() + inc);
     }
     return fm[b];
   }

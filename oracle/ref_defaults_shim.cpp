@@ -2,11 +2,17 @@
 // they lie under /root/reference (never copied) into oracle/_ref/libdefaults_ref.so by oracle/Makefile:
 //   include/salmon/internal/config/SalmonDefaults.hpp   the default value of every option (needs <thread> only)
 //   include/salmon/internal/util/SalmonMath.hpp          LOG_0 / LOG_EPSILON / ..., logAdd, logSub (needs an empty boost/config.hpp: oracle/_stub)
+//   include/salmon/internal/quant/ForgettingMassCalculator.hpp   the learning-rate schedule of the online phase
 // They pin what the product and the checker take as defaults (sq_quant_opts_default, sq_em_opts_default, the CLI) and the log-space
 // helpers of include/sq_math.h to the reference's own values (tests/test_defaults_pin.py).
 #include <string>   // the header uses std::string without including it
 #include "salmon/internal/config/SalmonDefaults.hpp"
 #include "salmon/internal/util/SalmonMath.hpp"
+#include <mutex>
+#include <vector>
+#include <cmath>
+#include <cstdint>
+#include "salmon/internal/quant/ForgettingMassCalculator.hpp"   // header-only too (its spdlog include is vendored under the reference's include/)
 #include <cstring>
 namespace d = salmon::defaults;
 extern "C" int ref_default(const char* name, double* out) {
@@ -38,4 +44,9 @@ extern "C" double ref_log_sub(double x, double y) { return salmon::math::logSub(
 extern "C" double ref_math_const(int which) {   // 0 LOG_0, 1 LOG_1, 2 LOG_ONEHALF, 3 LOG_ORPHAN_PROB, 4 EPSILON, 5 LOG_EPSILON
   switch (which) { case 0: return salmon::math::LOG_0; case 1: return salmon::math::LOG_1; case 2: return salmon::math::LOG_ONEHALF;
     case 3: return salmon::math::LOG_ORPHAN_PROB; case 4: return salmon::math::EPSILON; default: return salmon::math::LOG_EPSILON; }
+}
+// the schedule as salmon quant consumes it (SalmonQuantify.cpp:2544-2545 prefill, :515 getLogMassAndTimestep): out[b] = log forgetting mass of mini-batch b
+extern "C" void ref_forgetting_masses(double ff, uint32_t n, double* out) {
+  ForgettingMassCalculator fm(ff); fm.prefill((uint64_t)n + 8);
+  for (uint32_t b = 0; b < n; ++b) { double m; uint64_t t; fm.getLogMassAndTimestep(m, t); out[b] = m; }
 }

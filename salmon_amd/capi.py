@@ -172,6 +172,7 @@ def lib():
         "sq_gibbs_range_report_dev": (C.c_int, [C.c_int, P(EqTable), P(TxpIn), P(GibbsOpts), P(f64), u32, u32, u32, u64, u64, REPLICATE_CB, vp, P(GibbsReport)]),
         "sq_gibbs_chain_step": (u32, [u32]),
         "sq_merge_log_masses": (C.c_int, [u32, u32, vp, vp]),
+        "sq_forgetting_masses": (C.c_int, [f64, u64, vp]),
         "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
         "sq_bias_gc_eff_lengths": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, P(BiasReport)]),
         "sq_em_optimize_bias": (C.c_int, [vp, P(EqTable), P(TxpIn), P(EmOpts), EFFLEN_CB, vp, P(f64), P(f64), P(EmReport)]),

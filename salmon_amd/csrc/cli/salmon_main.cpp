@@ -5,6 +5,8 @@
 #include <zlib.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
+#include <signal.h>
+#include <ctime>
 #include <unistd.h>
 #include <thread>
 #include <chrono>
@@ -268,18 +270,26 @@ static int cmd_quant_eq(int argc, char** argv, const char* eqf) {
 // `--gpus N` without a launcher: re-execute this binary N times, one process per GPU, with RANK / WORLD_SIZE / LOCAL_RANK in the
 // environment (the variables torchrun / mpirun wrappers set; under such a launcher --gpus is not needed)
 static int launch_ranks(char** argv, int n) {
+  // a nonce per launch names the rendezvous file (<out>/.sq_dist_id.<nonce>): a file left by a crashed earlier run is never read
+  { char nb[64]; snprintf(nb, sizeof(nb), "%ld.%d", (long)time(nullptr), (int)getpid()); setenv("SQ_DIST_NONCE", nb, 1); }
   std::vector<pid_t> kids;
   for (int r = 0; r < n; ++r) {
     pid_t p = fork();
-    if (p < 0) { perror("fork"); return 1; }
+    if (p < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGTERM); return 1; }
     if (p == 0) {
       setenv("RANK", std::to_string(r).c_str(), 1); setenv("LOCAL_RANK", std::to_string(r).c_str(), 1); setenv("WORLD_SIZE", std::to_string(n).c_str(), 1);
       execv("/proc/self/exe", argv); perror("execv"); _exit(127);
     }
     kids.push_back(p);
   }
-  int rc = 0;
-  for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1; }
+  // a rank that fails leaves its peers blocked in a collective: take them down with it
+  int rc = 0; size_t left = kids.size();
+  while (left) {
+    int st = 0; const pid_t p = wait(&st); if (p < 0) break;
+    auto it = std::find(kids.begin(), kids.end(), p); if (it == kids.end()) continue;
+    *it = -1; --left;
+    if (!WIFEXITED(st) || WEXITSTATUS(st)) { if (!rc) for (pid_t k : kids) if (k > 0) kill(k, SIGTERM); rc = 1; }
+  }
   return rc;
 }
 
@@ -319,7 +329,8 @@ static int cmd_quant(int argc, char** argv) {
   sq_dist* dist = nullptr;
   if (world > 1) {
     mkdir(odir, 0755);
-    const std::string idf = std::string(odir) + "/.sq_dist_id"; uint8_t id[SQ_DIST_ID_BYTES];
+    const std::string idf = std::string(odir) + "/.sq_dist_id" + (getenv("SQ_DIST_NONCE") ? std::string(".") + getenv("SQ_DIST_NONCE") : std::string()); uint8_t id[SQ_DIST_ID_BYTES];
+    if (rank == 0 && !getenv("SQ_DIST_NONCE")) remove(idf.c_str());   // under an external launcher (no nonce) at least a stale file of ours goes first
     if (rank == 0) {
       if (sq_dist_make_id(id)) die("RCCL id");
       FILE* f = fopen((idf + ".tmp").c_str(), "wb"); if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[salmon-hip] cannot write %s\n", idf.c_str()); return 1; }

@@ -171,11 +171,12 @@ struct sq_ctx {
   std::vector<int> prof_stage;
   double stage_ms[32] = {0};
   uint64_t stage_calls[32] = {0};
+  uint64_t eq_groups = 0;   // groups of mini-batches run while profiling (launch pairs of the online chain)
 };
 
 enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP,
     SG_SELECT, SG_COMPACT,
-       SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_FINALIZE, SG_NUM };
+       SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_FINALIZE, SG_EQ_STATIC, SG_NUM };
 void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream)
 void sq_prof_begin(sq_ctx* c, int which = 0);
 void sq_prof_end(sq_ctx* c, int which = 0);               // call after the stream has been synchronised

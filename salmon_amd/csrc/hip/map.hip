@@ -49,7 +49,7 @@ void fill_params(sq_ctx* c) {
 static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_mems", "large_ends", "count_kmer_frags", "k_join_count",
     "scan_cands", "k_join_fill", "k_score",
     "k_dp", "k_select", "compact_alns",
-                                          "eq_flags_scan", "eq_mini_batches", "eq_table", "k_finalize"};
+                                          "eq_flags_scan", "eq_mini_batches", "eq_table", "k_finalize", "eq_static"};
 void sq_prof_begin(sq_ctx* c,
     int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
@@ -85,6 +85,9 @@ extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int re
       }
     }
     if (ms) ms[i] = m; if (calls) calls[i] = n; if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; } }
+  // the online chain's row counts its launch pairs (one per group of mini-batches), not mapped batches
+  if (calls && c->eq_groups) calls[SG_EQ_MINIBATCH] = c->eq_groups;
+  if (reset) c->eq_groups = 0;
   return SQ_OK;
 }
 

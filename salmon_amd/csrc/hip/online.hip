@@ -26,7 +26,7 @@ struct sq_online_dev {
   // model
   sq_dbuf<double> hist, cpmf, ccmf, ambig, mass, prior_mass, log_eff_len, fm_table, cfac, tlc; sq_dbuf<double> scal;  // scal[0]=totMass
   sq_dbuf<uint32_t> touched, touched_n, tflag;   // transcripts whose mass changed in the current group of mini-batches: two lists (group parity), [2*M] + [2]; tflag[M] = already listed
-  uint32_t inflight = 1;                          // W: mini-batches per model snapshot (SPEC §D1); mass_acc is [W][M], fld_cnt [W][1024]
+  uint32_t inflight = 1;                          // W: mini-batches per model snapshot (SPEC §D1); mass_acc is [M][W], fld_cnt [W][1024]
   // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
   sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts;
   sq_dbuf<uint32_t> fld_cnt;
@@ -34,7 +34,7 @@ struct sq_online_dev {
   // per big batch
   sq_dbuf<uint8_t> has_compat;
   struct PreAln;
-  sq_dbuf<uint8_t> pre;
+  sq_dbuf<uint8_t> pre, dyn;   // dyn: DynAln per alignment (the post-burn-in split, k_frag_static -> k_frag_dynamic)
   sq_dbuf<double> alp;
   sq_dbuf<uint32_t> assigned_flag;
   sq_dbuf<uint64_t> assigned_prefix;
@@ -116,7 +116,7 @@ __device__ inline bool is_compatible(uint8_t fid, uint8_t et, uint8_t eo, uint8_
 }
 
 struct OnlineView {
-  uint32_t M; const uint32_t* ref_len; const uint32_t* ref_clen; double* tlc;
+  uint32_t M, W; const uint32_t* ref_len; const uint32_t* ref_clen; double* tlc;
   double* hist;
   double* cpmf;
   double* ccmf;
@@ -232,7 +232,7 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
 // first toucher of a transcript in this mini-batch records it (one atomic per wave: the ballot sees the calling lanes only)
 __device__ inline void mass_add(const OnlineView& V, uint32_t par, uint32_t w, uint32_t t, unsigned long long q) {
   if (!q) return;
-  const unsigned long long old = atomicAdd(&V.mass_acc[(size_t)w * V.M + t], q);
+  const unsigned long long old = atomicAdd(&V.mass_acc[(size_t)t * V.W + w], q);   // [r3] the W slots of a transcript share a line: k_apply reads one sector per transcript
   if (old == 0 && atomicExch(&V.tflag[t], 1u) == 0u) {   // first toucher of (mini-batch slot, transcript), and the transcript is not listed yet
     const unsigned long long m = __ballot(1);
     const int leader = __ffsll((long long)m) - 1, lane = (int)(threadIdx.x & 63);
@@ -352,6 +352,9 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
 // increments).  Fragments with more than 16 alignments take the sequential path on lane 0.  Same
 // arithmetic, same order as the checker.  (8 rather than 16 lanes: half the workgroups per mini-batch,
 // so the kernel fits the eq stage's CU partition in one round.)
+#define AP_TB_ 256
+#define SQ_MAX_INFLIGHT 64
+struct FmArr { double v[SQ_MAX_INFLIGHT]; };   // forgetting masses of the group's mini-batches, in order
 #define MB_G 8
 #define MB_S 2
 __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_t r1, uint32_t mb, uint64_t read_counter0,
@@ -535,10 +538,145 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   if (threadIdx.x == 64 && s_cf) atomicAdd(&V.ctr[5], s_cf);
 }
 
+// ---- [r3] after burn-in: the model-independent half of a mini-batch, once per mapped batch -----------------------------------------
+// Once the fragment-length tables are cached and the effective lengths fixed (burn-in, SalmonQuantify.cpp:1012-1018), everything a
+// fragment contributes except its transcript-mass terms no longer depends on the evolving model: auxProb, the range-factorization
+// weights and bins, the label and its hash, the unique / total counts, the library-format counts.  k_frag_static computes all of
+// that for the WHOLE mapped batch in one launch (no mini-batch chain), leaving per kept alignment the two addends the chain still
+// needs: logProb = (transcriptLogCount + auxProb) + startPosProb, in that order.  Same arithmetic, same order as k_mini_batch.
+struct DynAln { double aux, start; uint32_t tid, keep; };   // 24 B
+__global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts o, uint32_t n, const uint64_t* __restrict__ aln_off,
+    const PreAln* __restrict__ pre, unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2,
+    DynAln* __restrict__ dyn) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t fmtSeen = 0; int compatFrag = 0;
+  if (r < n) {
+    const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
+    uint64_t h1o = EQ_EMPTY, h2o = 0;
+    if (a1 > a0) {
+      const bool singleEnd = (o.lib_type == 0);
+      double auxDenom = SQ_LOG_0; uint32_t nk = 0; bool hasCompat = false; uint64_t fm = 0;
+      for (uint64_t ai = a0; ai < a1; ++ai) {
+        const PreAln p = pre[ai];
+        DynAln d; d.aux = 0.0; d.start = 0.0; d.tid = p.tid; d.keep = 0;
+        uint32_t bn = 0xFFFFFFFFu;
+        if (p.flags & PF_KEEP) {
+          if (p.flags & PF_COMPAT) hasCompat = true;
+          double logFragProb = 0.0;
+          if (p.flags & PF_ORPHAN_MODEL) {
+            const double* tab = V.ccmf; (void)singleEnd;          // burned and cached: FLD::cmf from the cached table either way
+            const double refCM = tab[p.tl]; const bool cm = !(refCM == SQ_LOG_0);
+            logFragProb = cm ? (tab[p.max_fl] - refCM) : SQ_LOG_EPSILON;
+          } else if (p.flags & PF_UNEXP_ORPHAN) logFragProb = SQ_LOG_EPSILON;
+          if (p.flen > 0 && o.use_frag_len_dist) {
+            const uint32_t fi = p.flen > 1000 ? 1000 : p.flen;
+            const double lenProb = V.cpmf[fi], cm = V.ccmf[fi];
+            const bool ok = (p.flags & PF_FLEN_IN_REF) && !(cm == SQ_LOG_0);
+            logFragProb = ok ? (lenProb - cm) : SQ_LOG_EPSILON;
+          }
+          const double logCompat = (p.flags & PF_COMPAT) ? 0.0 : o.incompat_prior;
+          double startPosProb;
+          if (p.flags & PF_PE_START) startPosProb = p.c_start;
+          else { const double logRefLength = o.no_length_correction ? 1.0 : (o.no_eff_length_correction ? p.c_start : V.log_eff_len[p.tid]); startPosProb = -logRefLength; }
+          const double auxProb = logFragProb + p.c_cov + logCompat;
+          // transcriptLogCount is finite for every transcript that can be aligned to (its prior is log(0.005 len)), so the reference's
+          // `logProb == LOG_0` test reduces to the finiteness of the two model-independent addends
+          fm |= 1ULL << p.fmt;
+          if (!(fabs(auxProb + startPosProb) == SQ_LOG_0)) {
+            auxDenom = sq_log_add(auxDenom, auxProb);
+            d.aux = auxProb; d.start = startPosProb; d.keep = 1; bn = 0; ++nk;
+          }
+        }
+        dyn[ai] = d; abin[ai] = bn;
+      }
+      if (nk > 0) {
+        const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
+        const uint32_t labLen = o.range_factorization_bins > 0 ? 2 * nk : nk;
+        uint64_t ha = 0x243F6A8885A308D3ULL ^ (uint64_t)labLen, hb = 0x13198A2E03707344ULL + (uint64_t)labLen;
+        uint32_t firstTid = 0; bool got = false;
+        for (uint64_t ai = a0; ai < a1; ++ai) if (abin[ai] == 0) { const uint32_t t = dyn[ai].tid; label_hash_step(ha, hb, t); if (!got) { firstTid = t; got = true; } }
+        for (uint64_t ai = a0; ai < a1; ++ai) {
+          if (abin[ai] != 0) continue;
+          const double w = sq_exp(dyn[ai].aux - auxDenom);
+          const uint32_t bin = (o.range_factorization_bins > 0) ? (uint32_t)(int32_t)(w * (double)rangeCount) : 0u;
+          awq[ai] = sq_to_fixed(w, SQ_WFRAC_BITS);
+          atomicAdd(&V.total[dyn[ai].tid], 1ULL);
+          abin[ai] = bin;
+        }
+        if (o.range_factorization_bins > 0) for (uint64_t ai = a0; ai < a1; ++ai) if (abin[ai] != 0xFFFFFFFFu) label_hash_step(ha, hb, abin[ai]);
+        uint64_t h1 = sq_mix64(ha), h2 = sq_mix64(hb);
+        if (h1 == EQ_EMPTY) h1 = EQ_EMPTY - 1; if (h2 == 0) h2 = 1;
+        h1o = h1; h2o = h2;
+        if (nk == 1) atomicAdd(&V.uniq[firstTid], 1ULL);
+        fmtSeen = fm; compatFrag = hasCompat ? 1 : 0;
+      }
+    }
+    rh1[r] = h1o; rh2[r] = h2o;
+  }
+  __shared__ unsigned long long s_lib[64]; __shared__ unsigned long long s_cf;
+  if (threadIdx.x < 64) s_lib[threadIdx.x] = 0;
+  if (threadIdx.x == 64) s_cf = 0;
+  __syncthreads();
+  uint64_t any = fmtSeen; for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s, 64);
+  while (any) {
+    const int f = __ffsll((long long)any) - 1; any &= any - 1;
+    const unsigned long long m = __ballot((fmtSeen >> f) & 1);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_lib[f], (unsigned long long)__popcll(m));
+  }
+  { const unsigned long long m = __ballot(compatFrag); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cf, (unsigned long long)__popcll(m)); }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_lib[threadIdx.x]) atomicAdd(&V.lib_counts[threadIdx.x], s_lib[threadIdx.x]);
+  if (threadIdx.x == 64 && s_cf) atomicAdd(&V.ctr[5], s_cf);
+}
+
+// the model-dependent half, one launch per group of W mini-batches (fragments [r0, r1)): logProb from the current transcript masses, the
+// in-order log-sum, and the fixed-point mass increments (+ the observed GC model, which is weighted by the same probabilities)
+__global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0, uint32_t r1, uint32_t mb, const uint64_t* __restrict__ aln_off,
+    const DynAln* __restrict__ dyn, uint32_t par, const uint8_t* __restrict__ gcbin) {
+  const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r1) return;
+  const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
+  if (a1 == a0) return;
+  const uint32_t mbs = (r - r0) / mb;
+  double sumProbs = SQ_LOG_0; uint32_t nk = 0;
+  for (uint64_t ai = a0; ai < a1; ++ai) {
+    const DynAln d = dyn[ai];
+    if (!d.keep) continue;
+    const double logProb = V.tlc[d.tid] + d.aux + d.start;
+    sumProbs = sq_log_add(sumProbs, logProb); ++nk;
+  }
+  if (nk == 0) return;
+  for (uint64_t ai = a0; ai < a1; ++ai) {
+    const DynAln d = dyn[ai];
+    if (!d.keep) continue;
+    const double logProb = V.tlc[d.tid] + d.aux + d.start;
+    const double pr = sq_exp(logProb - sumProbs);
+    mass_add(V, par, mbs, d.tid, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
+    if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
+  }
+}
+// group end after burn-in: masses of the touched transcripts (as apply_mass_part) and the running count of assigned fragments
+__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1, uint32_t par) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]); V.touched_n[par ^ 1] = 0; }
+  const uint32_t n = V.touched_n[par]; const uint32_t* list = V.touched + (size_t)par * V.M;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t t = list[i];
+    double m = V.mass[t];
+    unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
+    for (uint32_t w = 0; w < nw; ++w) {
+      const unsigned long long q = acc[w];
+      if (!q) continue;
+      m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
+      acc[w] = 0;
+    }
+    V.mass[t] = m;
+    V.tlc[t] = sq_log_add(V.prior_mass[t], m);
+    V.tflag[t] = 0;
+  }
+}
+
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
 // transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
-#define SQ_MAX_INFLIGHT 64
-struct FmArr { double v[SQ_MAX_INFLIGHT]; };   // forgetting masses of the group's mini-batches, in order
 __device__ inline void apply_mass_part(const OnlineView& V, const FmArr& FM, uint32_t nw, uint64_t assigned_after, int set_ctr, uint32_t par,
     uint32_t mass_blocks) {
   // the other list is idle until the next mini-batch
@@ -551,10 +689,10 @@ __device__ inline void apply_mass_part(const OnlineView& V, const FmArr& FM, uin
     const uint32_t t = list[i];
     double m = V.mass[t];
     for (uint32_t w = 0; w < nw; ++w) {                    // the group's mini-batches in order, each with its own forgetting mass
-      const unsigned long long q = V.mass_acc[(size_t)w * V.M + t];
+      const unsigned long long q = V.mass_acc[(size_t)t * V.W + w];
       if (!q) continue;
       m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
-      V.mass_acc[(size_t)w * V.M + t] = 0;
+      V.mass_acc[(size_t)t * V.W + w] = 0;
     }
     V.mass[t] = m;
     V.tlc[t] = sq_log_add(V.prior_mass[t], m);
@@ -807,7 +945,7 @@ __global__ void k_eq_gather(EqView T, uint64_t E, const uint32_t* __restrict__ s
 
 OnlineView make_view(sq_ctx* c) {
   sq_online_dev* o = c->online; OnlineView V;
-  V.M = o->M;
+  V.M = o->M; V.W = o->inflight;
   V.ref_len = c->di->ref_len;
   V.ref_clen = c->di->ref_clen;
   V.tlc = o->tlc.p;
@@ -940,7 +1078,7 @@ void sq_online_free(sq_ctx* c) {
   o->log_eff_len.free_();
   o->tlc.free_();
   o->pre.free_();
-  o->alp.free_();
+  o->alp.free_(); o->dyn.free_();
   o->fm_table.free_();
   o->cfac.free_();
   o->scal.free_();
@@ -980,12 +1118,8 @@ void sq_online_free(sq_ctx* c) {
   delete o; c->online = nullptr;
 }
 
-static double forgetting_mass(sq_online_dev* o, double ff, uint64_t b) {  // ForgettingMassCalculator.hpp:30-40
-  while (o->fm_host.size() <= b) {
-    if (o->fm_host.empty()) { o->fm_host.push_back(0.0); continue; }
-    uint64_t i = o->fm_host.size() + 1;
-    o->fm_host.push_back(o->fm_host.back() + ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0));
-  }
+static double forgetting_mass(sq_online_dev* o, double ff, uint64_t b) {  // ForgettingMassCalculator.hpp:30-40 — the schedule of sq_forgetting_masses (host/opts.cpp)
+  if (o->fm_host.size() <= b) { const size_t n = std::max<size_t>(b + 1, o->fm_host.size() * 2 + 4096); o->fm_host.resize(n); (void)sq_forgetting_masses(ff, n, o->fm_host.data()); }
   return o->fm_host[b];
 }
 
@@ -1138,9 +1272,27 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
   sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
-  std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
+  if (o->burned_known && !o->detect_active && !getenv("SQ_EQ_SLOW_PATH")) {
+    // [r3] burned in: one model-independent launch over the whole batch, then per group of W mini-batches only the mass terms
+    // (k_frag_dynamic) and their application (k_apply_dynamic).  Nothing comes back to the host.
+    if (o->dyn.ensure(A * sizeof(DynAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
+    k_frag_static<<<nblk(n), 256, 0, st>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p);
+    sq_prof_mark(c, SG_EQ_STATIC, 1);
+    const uint32_t W = o->inflight; const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB_ - 1) / AP_TB_, 256u);
+    for (uint32_t b = 0; b < nmb;) {
+      FmArr FM; uint32_t nw = 0; const uint32_t b0 = b;
+      while (b < nmb && nw < W) { FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++); ++b; }
+      for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
+      const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
+      const uint32_t par = (uint32_t)(o->group_no & 1);
+      k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, par, d_gcbin);
+      k_apply_dynamic<<<mass_blocks, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, par);
+      o->group_no++; if (c->prof_on) c->eq_groups++;
+    }
+  } else {
+  std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   std::vector<uint64_t> bound(nmb + 1);
   if (o->rh2.n < nmb + 2) { sq_set_error("internal: bounds scratch too small"); return SQ_ERR_STATE; }
   k_gather_bounds<<<nblk(nmb + 1), TB, 0, st>>>(o->assigned_prefix.p, mb, n, nmb, o->rh2.p);   // rh2 is rewritten by the mini-batches below
@@ -1190,7 +1342,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       k_burnin_done<<<1, 64, 0, st>>>(V);
       burned_host = true;
     }
-    o->group_no++;
+    o->group_no++; if (c->prof_on) c->eq_groups++;
     if (detect_now) {
       // mostLikelyType (LibraryTypeDetector.hpp:33-152): from here on the online model expects the detected format.  What depended
       // on the format — the per-alignment compatibility flags, the assigned flags and their prefix — is made again for the rest of
@@ -1213,6 +1365,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         SQ_HIP_CHECK(hipStreamSynchronize(st));
       }
     }
+  }
+  if (burned_host) o->burned_known = true;
   }
   sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
   // eq-class table: insert labels, then add counts / fixed-point weights

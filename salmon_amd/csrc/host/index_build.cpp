@@ -50,7 +50,7 @@ struct KTable {
   inline uint64_t home(uint64_t c) const { return (uint64_t)(((unsigned __int128)sq_mix64(c) * (unsigned __int128)cap) >> 64); }
   inline uint64_t insert(uint64_t c) {
     uint64_t h = home(c);
-    for (;;) {
+    for (uint64_t probes = 0; probes < cap; ++probes) {
       uint64_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
       if (cur == c) return h;
       if (cur == ~0ULL) {
@@ -60,6 +60,7 @@ struct KTable {
       }
       if (++h == cap) h = 0;
     }
+    return ~0ULL;   // every slot taken by other k-mers: the partition got more distinct k-mers than it was sized for (the caller retries larger)
   }
   inline uint64_t find(uint64_t c) const {
     uint64_t h = home(c);
@@ -162,9 +163,11 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   };
   {
     KTable T;
+    double grow = 1.0;
     for (uint32_t part = 0; part < nparts_k; ++part) {
-      // a partition holds ~1/nparts of the DISTINCT k-mers; sized for 1/nparts of the positions (+ 8 % for the spread of the hash)
-      T.init((uint64_t)((double)npos / nparts_k * (nparts_k > 1 ? 1.08 : 1.0) * 1.35) + 1024);
+      // a partition holds ~1/nparts of the DISTINCT k-mers; sized for 1/nparts of the positions (+ 8 % for the spread of the hash);
+      // a partition that overflows all the same (a skewed hash under a tiny SQ_INDEX_TABLE_GB) is redone with a larger table
+      T.init((uint64_t)((double)npos / nparts_k * (nparts_k > 1 ? 1.08 : 1.0) * 1.35 * grow) + 1024);
       std::atomic<int> full(0);
       sq_parallel_for(pieces.size(), nthreads, 1, [&](uint64_t b, uint64_t e, uint32_t) {
         for (uint64_t pi = b; pi < e; ++pi) {
@@ -175,6 +178,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
             bool o1 = fw < rc; uint64_t c = o1 ? fw : rc;
             if (kmer_part(c) != part) continue;
             uint64_t slot = T.insert(c);
+            if (slot == ~0ULL) { full.store(1, std::memory_order_relaxed); return; }
             uint32_t bits = 0;
             if (i + 1 < nk) { uint32_t sb = sq_fetch_base(rs, g + i + k); bits |= o1 ? (1u << sb) : (1u << (4 + (3 - sb))); }
             else bits |= o1 ? (1u << 8) : (1u << 9);
@@ -184,7 +188,10 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
           }
         }
       });
-      (void)full;
+      if (full.load()) {
+        if (grow > 64.0) throw std::runtime_error("k-mer table partition keeps overflowing (SQ_INDEX_TABLE_GB too small for this input?)");
+        grow *= 1.5; --part; continue;
+      }
       sq_parallel_for(pieces.size(), nthreads, 1, [&](uint64_t b, uint64_t e, uint32_t) {
         for (uint64_t pi = b; pi < e; ++pi) {
           const Piece pc = pieces[pi]; const uint64_t g = idx->ref_accum[pc.ref];

@@ -1,4 +1,5 @@
 // host/opts.cpp — defaults mirrored from include/salmon/internal/config/SalmonDefaults.hpp:8-127.
+#include <cmath>
 #include "../../../include/salmon_hip.h"
 #include <string.h>
 #include "../../../include/sq_math.h"
@@ -65,6 +66,18 @@ extern "C" int sq_merge_log_masses(uint32_t M, uint32_t R, const double* all_log
     double m = SQ_LOG_0;
     for (uint32_t r = 0; r < R; ++r) m = sq_log_add(m, all_log_mass[(size_t)r * M + t]);
     out[t] = m;
+  }
+  return SQ_OK;
+}
+
+// ForgettingMassCalculator (include/salmon/internal/quant/ForgettingMassCalculator.hpp:23-40,64-90): log forgetting mass of mini-batch b,
+// fm_0 = 0, fm_b = fm_{b-1} + ff log(b) - log((b+1)^ff - 1).  The online stage (hip/online.hip) takes its schedule from here.
+extern "C" int sq_forgetting_masses(double ff, uint64_t n, double* out) {
+  if (!out && n) return SQ_ERR_ARG;
+  double fm = 0.0;
+  for (uint64_t b = 0; b < n; ++b) {
+    if (b > 0) { const uint64_t i = b + 1; fm += ff * std::log((double)(i - 1)) - std::log(std::pow((double)i, ff) - 1.0); }   // prefill's `fm += a - b`: the increment first
+    out[b] = fm;
   }
   return SQ_OK;
 }

@@ -37,7 +37,7 @@ def labels(seqs, reads, off, n_pairs, opts, threads=8):
     return lab_off, lab_tid[:w], lab_score[:w], kind
 
 
-def compare(lab_off, lab_tid, read_off, aln_tid):
+def compare(lab_off, lab_tid, read_off, aln_tid, max_examples=40):
     """Per-fragment label sets of the exhaustive aligner vs a mapper's alignment lists -> dict of counts by disagreement class."""
     n = len(lab_off) - 1
     out = dict(n=n, equal=0, both_unmapped=0, heuristic_subset=0, heuristic_superset=0, other=0, heuristic_unmapped=0, exhaustive_unmapped=0, examples=[])
@@ -53,6 +53,6 @@ def compare(lab_off, lab_tid, read_off, aln_tid):
         elif a < b: k = "heuristic_superset"
         else: k = "other"
         out[k] += 1
-        if len(out["examples"]) < 40: out["examples"].append((f, k, sorted(a), sorted(b)))
+        if len(out["examples"]) < max_examples: out["examples"].append((f, k, sorted(a), sorted(b)))
     out["agreement"] = out["equal"] / max(1, n)
     return out

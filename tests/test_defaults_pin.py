@@ -73,3 +73,17 @@ def test_log_space_helpers_follow_the_references(built):
     for x in (-3.5, 0.0, 12.0):
         assert O.orc_log_add(math.inf, x) == L.ref_log_add(math.inf, x) == x and O.orc_log_add(x, math.inf) == L.ref_log_add(x, math.inf) == x
         assert O.orc_log_add(x, -800.0) == x == L.ref_log_add(x, -800.0)
+
+
+def test_forgetting_mass_schedule_is_the_reference_calculators(built):
+    """ForgettingMassCalculator.hpp compiled from the reference tree (prefill + getLogMassAndTimestep, as SalmonQuantify.cpp uses it) against the
+    schedule the online stage takes (sq_forgetting_masses) and the checker's (orc_forgetting_mass): the same libm calls in the same order."""
+    L = _ref(); L.ref_forgetting_masses.argtypes = [C.c_double, C.c_uint32, C.c_void_p]
+    from salmon_amd import capi
+    n = 50000
+    for ff in (0.65, 0.9):
+        ref = np.zeros(n); L.ref_forgetting_masses(ff, n, ref.ctypes.data)
+        mine = np.zeros(n); capi.check(capi.lib().sq_forgetting_masses(ff, n, mine.ctypes.data), "sq_forgetting_masses")
+        assert ref[0] == 0.0 and np.array_equal(ref, mine)
+        for b in (0, 1, 2, 17, 4999, n - 1):
+            assert orc.lib().orc_forgetting_mass(ff, b) == ref[b]

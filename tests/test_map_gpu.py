@@ -515,3 +515,46 @@ def test_c4_shape_decoy_genome_2x150_matches_checker(built):
     for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
         assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
     ctx.free(); ost.free()
+
+
+@pytest.mark.parametrize("variant", ["default", "W1", "W3", "gc", "single_end", "incompat_prior", "no_len_corr", "ISF"])
+def test_batches_after_burn_in_take_the_split_path_and_match_checker(small_world, variant):
+    """After burn-in the online stage runs as one model-independent launch per mapped batch (k_frag_static) plus, per group of W mini-batches,
+    the mass terms (k_frag_dynamic / k_apply_dynamic).  Four batches of 1000 pairs with burn-in inside the first: batches 2-4 take that path.
+    Model arrays, counters, library-format counts, the class table (labels, bins, counts, fixed-point weights) equal the checker's."""
+    w = small_world; idx = w["idx"]; idx.to_device(0)
+    kw = dict(mini_batch_size=100, num_pre_burnin_frags=80, num_burnin_frags=600)
+    paired = True
+    if variant == "W1": kw["mini_batches_in_flight"] = 1
+    if variant == "W3": kw["mini_batches_in_flight"] = 3
+    if variant == "gc": kw["gc_bias"] = 1
+    if variant == "incompat_prior": kw.update(incompat_prior=-9.2, ignore_incompat=0)
+    if variant == "no_len_corr": kw["no_length_correction"] = 1
+    opts = api.quant_opts(**kw)
+    if variant == "single_end": api.set_libtype(opts, "U"); paired = False
+    if variant in ("ISF", "incompat_prior"): api.set_libtype(opts, "ISF")
+    ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=4096)
+    ost = orc.OrcState(w["oidx"], opts)
+    B = 1000
+    for i in range(4):
+        lo, hi = i * B, (i + 1) * B
+        if paired:
+            s = w["seq"][lo * 200: hi * 200]; o = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        else:   # mate 1 of every pair as a single-end library
+            s = np.concatenate([w["seq"][(2 * j) * 100:(2 * j + 1) * 100] for j in range(lo, hi)]); o = np.arange(0, B + 1, dtype=np.uint64) * np.uint64(100)
+        rb = api.make_read_batch(s, o, B, paired=paired)
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=4); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+        assert st_g == st_c and aln_g.tobytes() == aln_c.tobytes()
+        if i == 0: assert ctx.summary()["burned_in"]
+    ost.finish()
+    assert ctx.summary() == ost.summary()
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"]:
+        assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    mg, mc = ctx.model(), ost.model()
+    for a, b, what in zip(mg, mc[:4], ["log mass", "unique counts", "total counts", "log effective length"]):
+        assert np.array_equal(a, b), what
+    assert np.array_equal(ctx.fld(), mc[4]) and np.array_equal(ctx.lib_counts(), ost.lib_counts())
+    if variant == "gc": assert np.array_equal(ctx.gc_observed(), ost.gc_observed())
+    ctx.free(); ost.free()
