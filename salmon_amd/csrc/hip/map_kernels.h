@@ -88,16 +88,23 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
     cw |= (uint64_t)(ok ? c : 0u) << (i * 2); cn |= (ok ^ 1u) << i;
   };
   if (cnt == 32 && (((uintptr_t)s) & 3) == 0) {
-    const uint32_t* s4 = (const uint32_t*)s;
+    // [r3] the lane's 32 bytes as two 16-byte loads (dword-aligned is enough for global_load_dwordx4): a quarter of the load instructions
+    struct __attribute__((packed, aligned(4))) Q4 { uint32_t v[4]; };
+    const Q4 q0 = *(const Q4*)s, q1 = *(const Q4*)(s + 16);
 #pragma unroll
     for (uint32_t q = 0; q < 8; ++q) {
-      uint32_t v = s4[q];
+      const uint32_t v = q < 4 ? q0.v[q] : q1.v[q - 4];
       put(4 * q, v & 0xFF);
       put(4 * q + 1, (v >> 8) & 0xFF);
       put(4 * q + 2, (v >> 16) & 0xFF);
       put(4 * q + 3, v >> 24);
     }
-  } else for (uint32_t i = 0; i < cnt; ++i) put(i, s[i]);
+  } else if (cnt) {
+    // a partial word (the read's last bases): whole dwords first
+    uint32_t i = 0;
+    if ((((uintptr_t)s) & 3) == 0) for (; i + 4 <= cnt; i += 4) { const uint32_t v = *(const uint32_t*)(s + i); put(i, v & 0xFF); put(i + 1, (v >> 8) & 0xFF); put(i + 2, (v >> 16) & 0xFF); put(i + 3, v >> 24); }
+    for (; i < cnt; ++i) put(i, s[i]);
+  }
   rpack[(size_t)e * SQ_READ_WORDS + wi] = cw;
   ((uint32_t*)(rnmask + (size_t)e * SQ_NMASK_WORDS))[wi] = cn;
   if (wi == 0) rlen[e] = (uint16_t)L;

@@ -108,7 +108,14 @@ def _gloo_gpu_worker(rank, world, port, q):
         mine = ctx.eq_finish()
         lm2, uq2, tc2, le2 = sqdist.reduce_model(lm, uq, tc, le, dist, torch.device("cpu"))   # masses by the library's sq_merge_log_masses
         ok = True; msg = ""
-        if rank == 0:
+        # the last collective comes first: every rank must hold the same merged table (nothing below talks to the other rank any more,
+        # so a failing check on one rank cannot leave the other waiting)
+        import hashlib
+        dig = int(hashlib.sha256(mine.wq.tobytes() + mine.count.tobytes() + mine.tid.tobytes()).hexdigest()[:15], 16)
+        dt = torch.tensor([dig], dtype=torch.int64); ds = [torch.zeros_like(dt) for _ in range(world)]; dist.all_gather(ds, dt)
+        dist.barrier(); dist.destroy_process_group()
+        if not all(int(x) == int(ds[0]) for x in ds): ok = False; msg = "ranks hold different merged tables"
+        if rank == 0 and ok:
             import orc
             oidx = orc.OrcIndex(idx); states = []
             for r in range(world):
@@ -116,23 +123,17 @@ def _gloo_gpu_worker(rank, world, port, q):
                 rb = api.make_read_batch(seq[a * 200: b * 200], (off[2 * a: 2 * b + 1] - off[2 * a]).copy(), b - a, paired=True)
                 ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=1)
                 ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, st["num_with_joint_hits"]); ost.finish(); states.append(ost)
-            states_own_eq = states[0].eq_finish(); own_model = states[0].model()[:4]
+            own = states[0].eq_finish(); own_model = states[0].model()[:4]
             for r in range(1, world): states[0].merge(states[r])
             full = states[0].eq_finish(); lmf, uqf, tcf, lef, _ = states[0].model()
             bad = [f for f in ["off", "tid", "count", "wq", "bins", "h1", "h2", "w"] if not np.array_equal(getattr(mine, f), getattr(full, f))]
             bad += [n for n, x, y in (("log_mass", lm2, lmf), ("uniq", uq2, uqf), ("total", tc2, tcf), ("log_eff_len", le2, lef)) if not np.array_equal(x, y)]
             # which side differs: this rank's own shard against its checker state
-            own = states_own_eq
             bad += ["own:" + f for f in ["off", "tid", "count", "wq"] if not np.array_equal(getattr(eq, f), getattr(own, f))]
             bad += ["own_model:%d" % i for i, (x, y) in enumerate(zip((lm, uq, tc, le), own_model)) if not np.array_equal(x, y)]
             ok = not bad
             if bad: msg = "differs: " + ",".join(bad)
-        import hashlib
-        dig = int(hashlib.sha256(mine.wq.tobytes() + mine.count.tobytes() + mine.tid.tobytes()).hexdigest()[:15], 16)
-        dt = torch.tensor([dig], dtype=torch.int64); ds = [torch.zeros_like(dt) for _ in range(world)]; dist.all_gather(ds, dt)
-        ok = ok and all(int(x) == int(ds[0]) for x in ds)           # every rank holds the same merged table
         q.put((rank, bool(ok), msg or "classes=%d" % len(mine.count)))
-        dist.destroy_process_group()
     except Exception as e:   # a worker that dies must not leave the parent waiting for its queue entry
         import traceback
         q.put((rank, False, traceback.format_exc()[-1500:]))
@@ -146,8 +147,12 @@ def test_two_gloo_ranks_on_one_gpu_merge_with_the_product(built):
     ctx = mp.get_context("spawn"); q = ctx.Queue()
     procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs: p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs: p.join(timeout=60)
+    try:
+        res = [q.get(timeout=240) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive(): p.terminate()
     assert all(ok for _, ok, _ in res), res
 
 

@@ -492,7 +492,8 @@ def test_c4_shape_decoy_genome_2x150_matches_checker(built):
     g = synth.Genome(tx, seed=3, total_nt=40_000_000, n_chrom=5, repeat_frac=0.45, threads=4)
     names, seqs, lens = g.append_tables(tx)
     idx = api.SalmonIndex.build_mem_raw(tx.n + g.n, names, seqs, lens, threads=8, first_decoy=tx.n)
-    assert idx.first_decoy == tx.n and idx.num_refs == tx.n + g.n
+    nt = idx.first_decoy                                   # sequence-identical transcripts are dropped (SPEC §I); the decoys follow the rest
+    assert 0.8 * tx.n < nt <= tx.n and idx.num_refs == nt + g.n
     oidx = orc.OrcIndex(idx)
     N = 100000
     seq, off, tt, tp = g.reads(tx, N, read_len=150, seed=2, genomic_frac=0.05, threads=4)
@@ -504,7 +505,7 @@ def test_c4_shape_decoy_genome_2x150_matches_checker(built):
     assert st_g == st_c
     assert np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
     _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
-    assert np.all(aln_g["tid"] < tx.n)
+    assert np.all(aln_g["tid"] < nt)
     genomic = tt == 0xFFFFFFFE; txp = tt < 0xFFFFFFF0
     assert (mt_g[genomic] == 6).mean() > 0.95 and (mt_g[txp] == 6).mean() < 0.01      # SQ_MT_DECOY
     assert st_g["num_truncated_ends"] == 0
