@@ -1,6 +1,7 @@
 // hip/ctx.h — per-device quantification context: HBM work buffers of the mapping pipeline, the
 // online model and the equivalence-class table.  One sq_ctx per GPU (one process per GPU).
 #pragma once
+#include <cstdlib>
 #include <cstddef>
 #include <memory>
 #include <thread>
@@ -79,7 +80,12 @@ struct sq_dbuf {
       cap = want ? want : 1;
       if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) return -1;
     }
-    n = cap; return 0;
+    n = cap;
+    // SQ_POISON=1 (tests): fresh device memory is usually zero, memory handed back by another allocation or another process is not.
+    // Filling every new buffer with a pattern makes any read-before-write show up as a parity failure instead of hiding behind zeros.
+    static const bool poison = getenv("SQ_POISON") != nullptr;
+    if (poison) (void)hipMemset(p, 0xA5, cap * sizeof(T));
+    return 0;
   }
   void free_() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };

@@ -334,6 +334,7 @@ struct EmArena {
   int add_chunk(size_t bytes) {
     Chunk c{nullptr, bytes, 0};
     if (hipMalloc((void**)&c.base, bytes) != hipSuccess) return -1;
+    if (getenv("SQ_POISON")) (void)hipMemset(c.base, 0xA5, bytes);   // tests: no reliance on zeroed fresh memory (hip/ctx.h)
     chunks.push_back(c);
     return 0;
   }
@@ -353,7 +354,9 @@ struct DBuf {
   int alloc(size_t n) {
     const size_t bytes = (n ? n : 1) * sizeof(T);
     if (tl_arena) { p = (T*)tl_arena->take(bytes); owned = false; return p ? 0 : -1; }
-    owned = true; return hipMalloc((void**)&p, bytes) == hipSuccess ? 0 : -1;
+    owned = true; if (hipMalloc((void**)&p, bytes) != hipSuccess) return -1;
+    if (getenv("SQ_POISON")) (void)hipMemset(p, 0xA5, bytes);
+    return 0;
   }
   int upload(const std::vector<T>& v) {
     if (alloc(v.size())) return -1;

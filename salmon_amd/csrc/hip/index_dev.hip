@@ -14,8 +14,8 @@ static int up(sq_device_index* d, const std::vector<T>& v, const T** out) {
 }
 
 // one wave per unitig (grid-stride): every k-mer of the string pool sets its four signature bits in its filter word
-__global__ void k_build_kfilter(const uint64_t* __restrict__ useq, const uint64_t* __restrict__ uoff, uint64_t num_unitigs, uint32_t k,
-                                unsigned long long* __restrict__ filter, uint64_t nwords) {
+__global__ void k_build_kfilter(const uint64_t* __restrict__ useq, const uint64_t* __restrict__ uoff, uint64_t num_unitigs, uint32_t k, uint32_t m,
+                                unsigned long long* __restrict__ filter, uint64_t nblocks) {
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   for (uint64_t u = wave; u < num_unitigs; u += nwaves) {
@@ -24,7 +24,7 @@ __global__ void k_build_kfilter(const uint64_t* __restrict__ useq, const uint64_
     for (uint64_t p = b + lane; p + k <= e; p += 64) {
       const uint64_t km = sq_fetch_bases(useq, p, k), rc = sq_revcomp(km, k);
       const uint64_t h = sq_kf_hash(km < rc ? km : rc);
-      atomicOr(&filter[sq_kf_word(h, nwords)], (unsigned long long)sq_kf_mask(h));
+      atomicOr(&filter[sq_kf_word_of(sq_minimizer(km, rc, k, m), h, nblocks)], (unsigned long long)sq_kf_mask(h));   // the block of the k-mer's minimizer (sq_internal.h)
     }
   }
 }
@@ -60,12 +60,13 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
   if (rc) { sq_device_index_free(d); return SQ_ERR_DEVICE; }
   v.kfilter = nullptr; v.kfilter_words = 0;
   if (!getenv("SQ_NO_KFILTER") && idx->num_kmers > 0) {   // k-mer membership filter (sq_internal.h): SQ_KF_BITS_PER_KEY bits per distinct k-mer
-    const uint64_t nwords = std::max<uint64_t>(1024, (idx->num_kmers * SQ_KF_BITS_PER_KEY + 63) / 64);
+    const uint64_t nblocks = std::max<uint64_t>(1024, (idx->num_kmers * SQ_KF_BITS_PER_KEY + 511) / 512);   // 64-byte blocks, one per ~2.5 minimizers
+    const uint64_t nwords = nblocks * SQ_KF_BLOCK_WORDS;
     void* p = nullptr;
     SQ_HIP_CHECK(hipMalloc(&p, nwords * 8));
     d->allocs.push_back(p); d->bytes += nwords * 8;
     SQ_HIP_CHECK(hipMemset(p, 0, nwords * 8));
-    k_build_kfilter<<<4096, 256>>>(v.useq, v.uoff, v.num_unitigs, idx->k, (unsigned long long*)p, nwords);
+    k_build_kfilter<<<4096, 256>>>(v.useq, v.uoff, v.num_unitigs, idx->k, idx->m, (unsigned long long*)p, nblocks);
     SQ_HIP_CHECK(hipDeviceSynchronize());
     v.kfilter = (const uint64_t*)p; v.kfilter_words = nwords;
   }

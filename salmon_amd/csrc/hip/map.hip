@@ -418,7 +418,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p + 16, 0, (MK_NCLS + 1) * sizeof(uint32_t), st));
   k_mem_classes<<<(nrec + 1023) / 1024, 1024, 0, st>>>(nrec, c->n_proj.p, c->mem_off.p, c->n_uni.p, c->rlen.p, lists, c->mlinfo.p, c->mlbase.p, c->n_chains.p,
       c->counters.p + 16);
-  uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 16, sizeof(hcls), hipMemcpyDeviceToHost, st));
@@ -440,7 +440,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   if (hcls[1]) k_mems<16, MK_X_CAP, 256><<<(hcls[1] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(1));
   if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
   if (hcls[3]) k_mems<16, MK_S_CAP, 256><<<(hcls[3] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(3));
-  if (hcls[4]) k_mems<64, MK_M_CAP, 128><<<(hcls[4] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(4));
+  if (hcls[4]) k_mems<64, MK_L_CAP, 128><<<(hcls[4] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(4));
+  if (hcls[5]) k_mems<64, MK_M_CAP, 128><<<(hcls[5] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(5));
 #undef SQ_MEMS_ARGS
   sq_prof_mark(c, SG_PROJECT);
   if (nL) {   // ends with more than MK_M_CAP MEMs (deep repeats): compact projection, library radix sort, back into the slabs, HBM chaining

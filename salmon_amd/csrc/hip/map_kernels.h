@@ -166,10 +166,10 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
         // together; the walk then takes the first position the filter lets through.  Positions behind it are simply laid out again
         // on the next trip, so the look-ups performed — and counted — are those of the one-at-a-time walk.
         const int nspec = d.kfilter ? SEED_SPEC : 1;   // without a filter: one probe per trip, as before
-        int cp[SEED_SPEC]; uint64_t ckm[SEED_SPEC]; bool cv[SEED_SPEC], cpass[SEED_SPEC]; int p = pos; bool ended = false;
+        int cp[SEED_SPEC]; uint64_t ckm[SEED_SPEC], crc[SEED_SPEC], cmini[SEED_SPEC]; uint32_t cat[SEED_SPEC]; bool cv[SEED_SPEC], cpass[SEED_SPEC]; int p = pos; bool ended = false;
 #pragma unroll
         for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
-          cv[s2] = false; cp[s2] = p; ckm[s2] = 0; cpass[s2] = false;
+          cv[s2] = false; cp[s2] = p; ckm[s2] = 0; crc[s2] = 0; cmini[s2] = 0; cat[s2] = 0; cpass[s2] = false;
           if (s2 < nspec) {
             while (!ended) {
               if (p + k > L) { ended = true; break; }
@@ -183,11 +183,20 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             }
           }
         }
+        // [r3] the minimizer scan comes first: it picks the filter block (consecutive probes share it, so their words sit in one 64-byte
+        // line) and is reused by the dictionary walk of the probe that passes
 #pragma unroll
         for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
           if (cv[s2]) {
-            if (d.kfilter) { const uint64_t rc2 = sq_revcomp(ckm[s2], (uint32_t)k); const uint64_t h = sq_kf_hash(ckm[s2] < rc2 ? ckm[s2] : rc2), msk = sq_kf_mask(h);
-              cpass[s2] = (d.kfilter[sq_kf_word(h, d.kfilter_words)] & msk) == msk; }
+            crc[s2] = sq_revcomp(ckm[s2], (uint32_t)k);
+            sq_min_scan<KT, MT>(d, ckm[s2], crc[s2], &cmini[s2], &cat[s2]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          if (cv[s2]) {
+            if (d.kfilter) { const uint64_t h = sq_kf_hash(ckm[s2] < crc[s2] ? ckm[s2] : crc[s2]), msk = sq_kf_mask(h);
+              cpass[s2] = (d.kfilter[sq_kf_word_of(cmini[s2], h, d.kfilter_words / SQ_KF_BLOCK_WORDS)] & msk) == msk; }
             else cpass[s2] = true;
           }
         }
@@ -195,16 +204,16 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
 #pragma unroll
         for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (pick < 0 && cv[s2]) { ++looked; if (cpass[s2]) pick = s2; }
         tot_look += looked;
-        uint64_t km = 0; int ppos = pos;
+        uint64_t km = 0, krc = 0, kmini = 0; uint32_t kat = 0; int ppos = pos;
 #pragma unroll
-        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (s2 == pick) { km = ckm[s2]; ppos = cp[s2]; }
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (s2 == pick) { km = ckm[s2]; krc = crc[s2]; kmini = cmini[s2]; kat = cat[s2]; ppos = cp[s2]; }
         if (pick < 0) {   // every laid-out probe was a miss, or the read ran out: the walk continues behind them
           pos = p;
           if (ended) done = true;
         } else {
           pos = ppos;
           uint64_t u; uint32_t off; int fw;
-          if (!sq_dict_lookup_t<KT, MT>(d, km, &u, &off, &fw, d.kfilter != nullptr)) {
+          if (!sq_dict_lookup_pre<KT, MT>(d, km, krc, kmini, kat, &u, &off, &fw)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
             uint64_t ub, ue; sq_ld_pair(d.uoff + u, &ub, &ue); const int ulen = (int)(ue - ub);

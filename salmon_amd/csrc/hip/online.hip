@@ -545,6 +545,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
 // that for the WHOLE mapped batch in one launch (no mini-batch chain), leaving per kept alignment the two addends the chain still
 // needs: logProb = (transcriptLogCount + auxProb) + startPosProb, in that order.  Same arithmetic, same order as k_mini_batch.
 struct DynAln { double aux, start; uint32_t tid, keep; };   // 24 B
+typedef unsigned long long sqk_u64x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts o, uint32_t n, const uint64_t* __restrict__ aln_off,
     const PreAln* __restrict__ pre, unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2,
     DynAln* __restrict__ dyn) {
@@ -630,49 +631,71 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
 }
 
 // the model-dependent half, one launch per group of W mini-batches (fragments [r0, r1)): logProb from the current transcript masses, the
-// in-order log-sum, and the fixed-point mass increments (+ the observed GC model, which is weighted by the same probabilities)
+// in-order log-sum, and the fixed-point mass increments (+ the observed GC model, which is weighted by the same probabilities).
+// The increments leave as fire-and-forget atomics (nothing waits for their return): the transcripts a group touched are found by
+// k_apply_dynamic's sweep, not by a list.
 __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0, uint32_t r1, uint32_t mb, const uint64_t* __restrict__ aln_off,
-    const DynAln* __restrict__ dyn, uint32_t par, const uint8_t* __restrict__ gcbin) {
+    const DynAln* __restrict__ dyn, const uint8_t* __restrict__ gcbin) {
   const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= r1) return;
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   if (a1 == a0) return;
   const uint32_t mbs = (r - r0) / mb;
   double sumProbs = SQ_LOG_0; uint32_t nk = 0;
+  double lp[4];                                  // the first four kept alignments stay in registers (a fragment has 2-3 on average)
   for (uint64_t ai = a0; ai < a1; ++ai) {
     const DynAln d = dyn[ai];
     if (!d.keep) continue;
     const double logProb = V.tlc[d.tid] + d.aux + d.start;
+    if (nk < 4) lp[nk] = logProb;
     sumProbs = sq_log_add(sumProbs, logProb); ++nk;
   }
   if (nk == 0) return;
+  uint32_t ki = 0;
   for (uint64_t ai = a0; ai < a1; ++ai) {
     const DynAln d = dyn[ai];
     if (!d.keep) continue;
-    const double logProb = V.tlc[d.tid] + d.aux + d.start;
+    const double logProb = ki < 4 ? lp[ki] : (V.tlc[d.tid] + d.aux + d.start);
+    ++ki;
     const double pr = sq_exp(logProb - sumProbs);
-    mass_add(V, par, mbs, d.tid, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
-    if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
+    const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
+    if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gcbin && gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// group end after burn-in: masses of the touched transcripts (as apply_mass_part) and the running count of assigned fragments
-__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1, uint32_t par) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]); V.touched_n[par ^ 1] = 0; }
-  const uint32_t n = V.touched_n[par]; const uint32_t* list = V.touched + (size_t)par * V.M;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t t = list[i];
+// group end after burn-in: one thread per transcript reads its W mass slots (one 64-byte line at W = 8) and, where the group left
+// something, folds the mini-batches' increments in order, each with its own forgetting mass (as apply_mass_part); thread 0 keeps
+// the running count of assigned fragments
+__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
+  if (t >= V.M) return;
+  unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
+  if (V.W == 8) {   // the default: the eight slots as four 16-byte loads, held in registers
+    unsigned long long q[8]; unsigned long long any = 0;
+    const sqk_u64x2* a2 = (const sqk_u64x2*)acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const sqk_u64x2 v = a2[i]; q[2 * i] = v.x; q[2 * i + 1] = v.y; any |= v.x | v.y; }
+    if (!any) return;
     double m = V.mass[t];
-    unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
-    for (uint32_t w = 0; w < nw; ++w) {
-      const unsigned long long q = acc[w];
-      if (!q) continue;
-      m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
-      acc[w] = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      if ((uint32_t)w < nw && q[w]) { m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q[w], SQ_MFRAC_BITS))); acc[w] = 0; }
     }
     V.mass[t] = m;
     V.tlc[t] = sq_log_add(V.prior_mass[t], m);
-    V.tflag[t] = 0;
+    return;
   }
+  double m = V.mass[t]; bool any = false;
+  for (uint32_t w = 0; w < nw; ++w) {
+    const unsigned long long q = acc[w];
+    if (!q) continue;
+    m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
+    acc[w] = 0; any = true;
+  }
+  if (!any) return;
+  V.mass[t] = m;
+  V.tlc[t] = sq_log_add(V.prior_mass[t], m);
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -1280,15 +1303,14 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     if (o->dyn.ensure(A * sizeof(DynAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
     k_frag_static<<<nblk(n), 256, 0, st>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
-    const uint32_t W = o->inflight; const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB_ - 1) / AP_TB_, 256u);
+    const uint32_t W = o->inflight;
     for (uint32_t b = 0; b < nmb;) {
       FmArr FM; uint32_t nw = 0; const uint32_t b0 = b;
       while (b < nmb && nw < W) { FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++); ++b; }
       for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
       const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
-      const uint32_t par = (uint32_t)(o->group_no & 1);
-      k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, par, d_gcbin);
-      k_apply_dynamic<<<mass_blocks, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, par);
+      k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin);
+      k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1);
       o->group_no++; if (c->prof_on) c->eq_groups++;
     }
   } else {

@@ -153,7 +153,13 @@ struct sq_dict_view {
 // the index" for > 99 % of them: the word is picked by the hash of the canonical k-mer, four of its 64 bits are the k-mer's
 // signature.  No false negatives (every k-mer of every unitig is inserted when the index is uploaded: index_dev.hip), so results
 // are unchanged; false positives (~0.6 % at 16 bits per k-mer) just take the full path.  288 GB of HBM buys this: 2 bytes per k-mer.
-#define SQ_KF_BITS_PER_KEY 16
+#define SQ_KF_BITS_PER_KEY 32
+// [r3] Blocked by MINIMIZER: the filter is an array of 64-byte blocks (8 words); a k-mer's block is chosen by the hash of its minimizer, its
+// word inside the block and its four signature bits by the hash of the k-mer itself.  The ~12 consecutive k-mers of a read that share a
+// minimizer — in particular the run of missing k-mers the mismatchSeedSkip walk probes across a sequencing error — therefore ask the SAME
+// 64-byte line: one HBM sector per run instead of one per probe (round 2 measured 1.66x the algorithmic traffic in k_seed, all of it filter
+// sectors).  The price is the minimizer scan before the filter (ALU the kernel had idle) and 4 bytes per k-mer instead of 2.
+#define SQ_KF_BLOCK_WORDS 8
 SQ_HD uint64_t sq_kf_hash(uint64_t canonical_kmer) { return sq_mix64(canonical_kmer ^ 0xA24BAED4963EE407ULL); }
 SQ_HD uint64_t sq_kf_mask(uint64_t h) { return (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63)) | (1ULL << ((h >> 18) & 63)); }
 SQ_HD uint64_t sq_kf_word(uint64_t h, uint64_t nwords) {   // mulhi(h, nwords): the high bits of h choose the word, the low 24 the signature
@@ -161,6 +167,10 @@ SQ_HD uint64_t sq_kf_word(uint64_t h, uint64_t nwords) {   // mulhi(h, nwords): 
   const uint64_t p0 = a_lo * b_lo, p1 = a_lo * b_hi, p2 = a_hi * b_lo, p3 = a_hi * b_hi;
   const uint64_t mid = (p0 >> 32) + (uint32_t)p1 + (uint32_t)p2;
   return p3 + (p1 >> 32) + (p2 >> 32) + (mid >> 32);
+}
+
+SQ_HD uint64_t sq_kf_word_of(uint64_t mini, uint64_t h_kmer, uint64_t nblocks) {   // word index of a k-mer with minimizer `mini` and filter hash h_kmer
+  return sq_kf_word(sq_mix64(mini ^ 0x6A09E667F3BCC909ULL), nblocks) * SQ_KF_BLOCK_WORDS + ((h_kmer >> 24) & (SQ_KF_BLOCK_WORDS - 1));
 }
 
 // displacement of a key hash by its bucket's pilot (PTHash: hash(key) xor hash(pilot), then reduce); one multiply each
@@ -208,18 +218,13 @@ SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_
 // equals the unitig's forward string at (unitig, off).  KT/MT > 0 fix k and m at compile time (the
 // probe kernel is instruction-issue bound: constant shifts/masks and fully unrolled window loops
 // roughly halve its instruction count); 0 = take them from the view.
+// one pass over the window of a k-mer: its minimizer (the canonical m-mer with the smallest (sq_mhash, value)) and the set of positions j
+// that hold it (bit j of *at)
 template <int KT, int MT>
-SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw, bool filtered = false) {
+SQ_HD void sq_min_scan(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t* mini_out, uint32_t* at_out) {
   const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
   const uint64_t mm = sq_kmask(m);
-  const uint64_t rc = sq_revcomp(kmer, k);
-  if (d.kfilter && !filtered) {   // membership filter first: most misses end here after one 8-byte load (`filtered`: the caller has asked it already)
-    const uint64_t h = sq_kf_hash(kmer < rc ? kmer : rc), msk = sq_kf_mask(h);
-    if ((d.kfilter[sq_kf_word(h, d.kfilter_words)] & msk) != msk) return 0;
-  }
-  // one pass over the window: the minimizer and the set of positions j that hold it (bit j of `at`),
-  // with the strand of the canonical form at each of them (bit j of `fwc`: the read-orientation m-mer is the canonical one)
-  uint32_t best = 0xFFFFFFFFu; uint64_t mini = ~0ULL; uint32_t at = 0, fwc = 0;
+  uint32_t best = 0xFFFFFFFFu; uint64_t mini = ~0ULL; uint32_t at = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -228,9 +233,15 @@ SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* uniti
     const uint64_t b = (rc >> (2 * (w - j))) & mm;
     const uint64_t c = a < b ? a : b;
     const uint32_t h = sq_mhash(c);
-    if (h < best || (h == best && c < mini)) { best = h; mini = c; at = 0; fwc = 0; }
-    if (c == mini) { at |= 1u << j; if (a <= b) fwc |= 1u << j; }
+    if (h < best || (h == best && c < mini)) { best = h; mini = c; at = 0; }
+    if (c == mini) at |= 1u << j;
   }
+  *mini_out = mini; *at_out = at;
+}
+// the dictionary walk for a k-mer whose minimizer scan has been done: pilot -> slot record -> {string pool, unitig bounds}
+template <int KT, int MT>
+SQ_HD int sq_dict_lookup_pre(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t mini, uint32_t at, uint64_t* unitig, uint32_t* off, int* fw) {
+  const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
   const uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
   if (rec == SQ_SLOT_EMPTY) return 0;
   const bool inl = (rec & SQ_SLOT_INLINE) != 0;     // the common case: the record IS the single occurrence (no pointer, no scratch)
@@ -264,8 +275,22 @@ SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* uniti
       if (j != w - j && sq_dict_try(d, kmer, rc, u, A - (int64_t)(w - j), unitig, off, fw)) return 1;
     }
   }
-  (void)fwc;
   return 0;
+}
+// Full dictionary query. kmer in read orientation; on success fw tells whether the read k-mer
+// equals the unitig's forward string at (unitig, off).  KT/MT > 0 fix k and m at compile time (the
+// probe kernel is instruction-issue bound: constant shifts/masks and fully unrolled window loops
+// roughly halve its instruction count); 0 = take them from the view.
+template <int KT, int MT>
+SQ_HD int sq_dict_lookup_t(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw, bool filtered = false) {
+  const uint32_t k = KT ? (uint32_t)KT : d.k;
+  const uint64_t rc = sq_revcomp(kmer, k);
+  uint64_t mini; uint32_t at; sq_min_scan<KT, MT>(d, kmer, rc, &mini, &at);
+  if (d.kfilter && !filtered) {   // membership filter first (`filtered`: the caller has asked it already)
+    const uint64_t h = sq_kf_hash(kmer < rc ? kmer : rc), msk = sq_kf_mask(h);
+    if ((d.kfilter[sq_kf_word_of(mini, h, d.kfilter_words / SQ_KF_BLOCK_WORDS)] & msk) != msk) return 0;
+  }
+  return sq_dict_lookup_pre<KT, MT>(d, kmer, rc, mini, at, unitig, off, fw);
 }
 SQ_HD int sq_dict_lookup(const sq_dict_view& d, uint64_t kmer, uint64_t* unitig, uint32_t* off, int* fw) {
   return sq_dict_lookup_t<0, 0>(d, kmer, unitig, off, fw);

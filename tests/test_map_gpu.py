@@ -392,7 +392,7 @@ def test_reserved_class_table_and_workspace(small_world):
 
 def test_repeat_families_cover_every_mem_size_class(built):
     # The fused projection / sort / chaining kernels pick a lane-group size by the MEM count of a read end (mem_kernels.h:
-    # <= 64, <= 1024, larger -> compact radix-sort path).  Two repeat families put reads in every class: family A (900
+    # <= 16 / 32 / 64 in 16-lane groups, <= 256 and <= 1024 one wave per end, larger -> compact radix-sort path).  Two repeat families put reads in every class: family A (900
     # transcripts share a 160-base element that comes in two variants differing by one base: a read across the variant
     # site collects three uni-MEMs of 900 / ~450 / 900 occurrences = ~2250 MEMs), family B (150 copies of another element).
     rng = np.random.default_rng(17)
@@ -425,7 +425,7 @@ def test_repeat_families_cover_every_mem_size_class(built):
     um_c, mm_c, ch_c, cd_c = orc.map_taps(oidx, opts, rb, cap=1 << 23)
     mm_g = ctx.tap(2, api.MEM_DTYPE)
     per_end = np.bincount(mm_g["end"], minlength=2 * n)
-    assert per_end.max() > 1024 and np.any((per_end > 64) & (per_end <= 1024)) and np.any((per_end > 0) & (per_end <= 64))
+    assert per_end.max() > 1024 and np.any((per_end > 64) & (per_end <= 256)) and np.any((per_end > 256) & (per_end <= 1024)) and np.any((per_end > 0) & (per_end <= 64))
     _fields_equal(mm_g, mm_c, ["end", "tid", "rpos", "qpos", "len", "fw"], "MEMs")
     ch_g = ctx.tap(3, api.CHAIN_DTYPE)
     _fields_equal(ch_g, ch_c, ["end", "tid", "pos", "last_end", "fw", "n_mems", "score"], "chains")
@@ -534,6 +534,7 @@ def test_batches_after_burn_in_take_the_split_path_and_match_checker(small_world
     opts = api.quant_opts(**kw)
     if variant == "single_end": api.set_libtype(opts, "U"); paired = False
     if variant in ("ISF", "incompat_prior"): api.set_libtype(opts, "ISF")
+    if variant == "ISF": opts.num_burnin_frags = 300      # the library is unstranded: about half the fragments are compatible and assigned
     ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=4096)
     ost = orc.OrcState(w["oidx"], opts)
     B = 1000
