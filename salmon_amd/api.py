@@ -141,6 +141,7 @@ def make_read_batch(seq, seq_off, n, paired=True, on_device=False):
     rb.seq = seq if isinstance(seq, int) else seq.ctypes.data
     rb.seq_off = seq_off if isinstance(seq_off, int) else seq_off.ctypes.data
     rb.on_device = int(on_device)
+    rb._keep = (seq, seq_off)   # the struct holds raw pointers: the arrays must outlive it
     return rb
 
 
