@@ -400,10 +400,15 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
      // slots per CU stay free for the eq stage's small kernels on stream2 — a full grid starves them for the whole 5 ms.
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
-    if (P.k == 31 && di->dict.m == 20)   // the default (k = 31, m = 20) gets the fully specialised kernel
-      k_seed<31, 20><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p,
-          c->n_proj.p, c->stats.p,
-          c->counters.p + 2);
+    static const int spec = getenv("SQ_SEED_SPEC") ? atoi(getenv("SQ_SEED_SPEC")) : 2;
+#define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2
+    if (P.k == 31 && di->dict.m == 20) {   // the default (k = 31, m = 20) gets the fully specialised kernel
+      if (spec == 1) k_seed<31, 20, 1><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
+      else if (spec == 3) k_seed<31, 20, 3><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
+      else if (spec == 4) k_seed<31, 20, 4><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
+      else k_seed<31, 20, 2><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
+    }
+#undef SQ_SEED_ARGS
     else
       k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p,
           c->n_proj.p, c->stats.p,

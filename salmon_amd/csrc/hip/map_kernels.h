@@ -117,8 +117,9 @@ __global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restri
 // lane does ONE probe step per loop trip and, when its read end is finished, takes the next one
 // from a global cursor (one atomic per wave via ballot).  The persistent grid keeps every lane busy
 // until the batch is drained; results are keyed by read end, so they do not depend on scheduling.
-#define SEED_SPEC 2   // probe positions laid out per trip (measured per 4x10^6 pairs: 1 -> 7.7 ms, 2 -> 5.5 ms, 3 -> 5.8 ms, 4 -> 6.2 ms, 8 -> 7.7 ms: wider costs registers and wasted filter words)
-template <int KT, int MT>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
+// SEED_SPEC = probe positions laid out per trip (a template argument since round 3; 2 by default, SQ_SEED_SPEC=1|3|4 selects another instantiation for measurements)
+// round 2, word-per-k-mer filter (measured per 4x10^6 pairs: 1 -> 7.7 ms, 2 -> 5.5 ms, 3 -> 5.8 ms, 4 -> 6.2 ms, 8 -> 7.7 ms: wider costs registers and wasted filter words)
+template <int KT, int MT, int SEED_SPEC = 2>   // k, minimizer length fixed at compile time (0 = runtime): the kernel is instruction-issue bound
 __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
