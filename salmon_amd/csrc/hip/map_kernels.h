@@ -133,7 +133,6 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
   unsigned long long tot_nu = 0, tot_look = 0;
   sq_unimem_dev* out = nullptr;
   uint32_t pool_next = 0, pool_end = 0; bool global_drained = false;   // wave-uniform: the wave's private run of read ends
-  uint64_t fb[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t fb_blk = ~0ULL;   // the filter block held by this lane
   for (;;) {
     // refill: lanes without a read end take the next ones of the wave's run; the run is renewed 64 at a time with ONE
     // atomic (a per-trip atomic on the single cursor serialised the whole grid: ~700 k same-address atomics per batch)
@@ -194,29 +193,11 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             sq_min_scan<KT, MT>(d, ckm[s2], crc[s2], &cmini[s2], &cat[s2]);
           }
         }
-        // [r3] the lane keeps the 64-byte filter block of its last first-probe in registers: consecutive probes of the walk share
-        // their minimizer, hence their block, about 2.5 times running, and then cost no memory request at all (the kernel sits at the
-        // chip's random-sector rate: requests are what it pays for).  Later probes of the trip use the held block when it is theirs,
-        // else they fetch their one word.
 #pragma unroll
         for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
           if (cv[s2]) {
-            if (d.kfilter) {
-              const uint64_t h = sq_kf_hash(ckm[s2] < crc[s2] ? ckm[s2] : crc[s2]), msk = sq_kf_mask(h);
-              const uint64_t blk = sq_kf_word(sq_mix64(cmini[s2] ^ 0x6A09E667F3BCC909ULL), d.kfilter_words / SQ_KF_BLOCK_WORDS);
-              const uint32_t wsel = (uint32_t)((h >> 24) & (SQ_KF_BLOCK_WORDS - 1));
-              if (s2 == 0 && blk != fb_blk) {
-                const sq_u64x2* bp = (const sq_u64x2*)(d.kfilter + blk * SQ_KF_BLOCK_WORDS);
-                const sq_u64x2 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-                fb[0] = b0.x; fb[1] = b0.y; fb[2] = b1.x; fb[3] = b1.y; fb[4] = b2.x; fb[5] = b2.y; fb[6] = b3.x; fb[7] = b3.y; fb_blk = blk;
-              }
-              uint64_t word;
-              if (blk == fb_blk) { word = fb[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) word = (wsel == (uint32_t)q) ? fb[q] : word; }
-              else word = d.kfilter[blk * SQ_KF_BLOCK_WORDS + wsel];
-              cpass[s2] = (word & msk) == msk;
-            }
+            if (d.kfilter) { const uint64_t h = sq_kf_hash(ckm[s2] < crc[s2] ? ckm[s2] : crc[s2]), msk = sq_kf_mask(h);
+              cpass[s2] = (d.kfilter[sq_kf_word_of(cmini[s2], h, d.kfilter_words / SQ_KF_BLOCK_WORDS)] & msk) == msk; }
             else cpass[s2] = true;
           }
         }
