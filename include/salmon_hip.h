@@ -150,10 +150,14 @@ typedef struct {
   uint8_t no_length_correction;   /* 0 */
   uint8_t no_eff_length_correction; /* 0 */
   uint64_t seed;              /* seed of the counter-based RNG for FLD sampling (reference: random_device) */
+  uint8_t seq_bias;           /* 0; 1 = --seqBias: collect the observed read-start context models (SBModel) from one sampled alignment per paired-end
+                                 fragment (SalmonQuantify.cpp:1668-1747); the expected models and the corrected lengths come from sq_bias_eff_lengths */
+  uint8_t pos_bias;           /* 0; reserved for --posBias */
+  uint8_t _pad3[2];
+  uint32_t num_bias_samples;  /* 2,000,000 (SalmonDefaults.hpp numBiasSamples): fragments that contribute to the observed sequence-bias models */
   uint32_t mini_batches_in_flight; /* 8 = the reference's default numThreads (SalmonDefaults.hpp:15): W worker threads each run a mini-batch
                                       against the shared model (SalmonQuantify.cpp:2390-2403); here W consecutive mini-batches read
                                       one model snapshot and their increments are applied in order (SPEC §D1).  1..64; 1 = strictly serial */
-  uint32_t _pad2;
 } sq_quant_opts;
 void sq_quant_opts_default(sq_quant_opts* o); /* -l IU defaults */
 
@@ -373,6 +377,14 @@ typedef struct { uint32_t num_processed; int32_t fld_low, fld_high; uint32_t _pa
 /* idx must be on a device: the sweep over (transcript, fragment start, sampled length) runs there. */
 int sq_bias_gc_eff_lengths(sq_index* idx, const double* gc_observed /*[75]*/, const double* log_pmf_1001, uint32_t num_txp,
                            const double* alphas, const double* eff_len_in, double* eff_len_out, sq_bias_report* report);
+/* --seqBias, alone (use_gc = 0) or with --gcBias: the expected read-start context models (SBModel), the expected GC model with its context
+ * bins, and the corrected lengths (SalmonUtils.cpp:1576-1600, 1810-1960).  seq_fw / seq_rc: the observed context counts collected by the online
+ * stage (sq_model_fetch_seq_observed).  models_out (may be NULL) receives the four normalised log-probability tables [expected fw, expected rc,
+ * observed fw, observed rc][9 positions x 64 contexts]. */
+int sq_model_fetch_seq_observed(sq_ctx*, uint64_t* fw576, uint64_t* rc576, uint64_t* num_samples);
+int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_observed /*[75] or NULL*/, const uint64_t* seq_fw /*[576]*/, const uint64_t* seq_rc,
+                            const double* log_pmf_1001, uint32_t num_txp, const double* alphas, const double* eff_len_in, double* eff_len_out,
+                            double* models_out, sq_bias_report* report);
 /* updateEffectiveLengths as a callback: alphas and current effective lengths in, new effective lengths out; non-zero aborts. */
 typedef int (*sq_efflen_cb)(const double* alphas, const double* eff_len_in, double* eff_len_out, uint32_t m, void* user);
 /* sq_em_optimize with the bias hook: after 11 updates (itNum > 10) `cb` is called once, priors and combined class weights are rebuilt

@@ -835,6 +835,7 @@ struct QuantState {
   std::vector<uint64_t> libCounts;
   uint64_t gcObs[75] = {0};   // observedGCMass (SalmonQuantify.cpp:938-972): sums of the normalised alignment probabilities, fixed point 2^-32 (order-free)
   uint64_t readCounter = 0;
+  uint64_t seqObs[2][576] = {{0}}; uint64_t seqSamples = 0;   // observed read-start context counts (SBModel cells [position][context]; FW, RC) and fragments sampled so far (SPEC §B2)
   // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
   struct PendingMB { double logFM; std::vector<std::pair<uint32_t, uint64_t>> massInc; std::vector<uint32_t> fldCnt; bool anyFld; uint32_t minLen; };
@@ -958,6 +959,75 @@ static inline uint32_t frag_len_pedantic(const sq_aln& a, uint32_t txpLen) {  //
 }
 
 // one mini-batch [r0, r1) of a CSR alignment batch
+// ---- sequence-specific bias: the read-start context model (SBModel, src/model/SBModel.cpp) — SPEC §B2 --------------------------------
+// A context is the 9 bases from 3 before a read's first base to 5 after it, as an 18-bit code with the first base in the high bits;
+// position i of the model conditions on the SB_ORDER[i] bases before it: cell = (code >> (18 - 2 (i + 1))) & (4^(order + 1) - 1).
+static const int SB_K = 9, SB_LEFT = 3, SB_RIGHT = 5;
+static const int SB_ORDER[9] = {0, 1, 2, 2, 2, 2, 2, 2, 2};
+static inline uint32_t sb_ctx(const Index& ix, uint32_t t, int32_t p) { uint32_t v = 0; for (int i = 0; i < SB_K; ++i) v = (v << 2) | base_at(ix.refseq.data(), ix.ref_accum[t] + (uint64_t)(p + i)); return v; }
+static inline uint32_t sb_rc(uint32_t v) { uint32_t r = 0; for (int i = 0; i < SB_K; ++i) { r = (r << 2) | (3u - (v & 3u)); v >>= 2; } return r; }
+static inline uint32_t sb_cell(uint32_t v, int i) { const int shift = 2 * SB_K - 2 * (i + 1), width = 2 * (SB_ORDER[i] + 1); return (uint32_t)i * 64u + ((v >> shift) & ((1u << width) - 1u)); }
+// SalmonQuantify.cpp:1668-1747: one alignment of a paired-end fragment is drawn (index uniform over 0..n, n = "none"); if it is a proper
+// pair on opposite strands whose two read starts have their whole contexts inside the transcript and the forward read starts before the
+// reverse one, the forward read's context goes to the FW model and the reverse read's context, reverse-complemented, to the RC model —
+// for the first num_bias_samples such fragments in read order (the reference counts down a shared counter in arrival order and draws
+// from random_device; here the draw is u01(seed ^ C, read index) and the cap is applied in read order).
+static void seq_observe(QuantState& S, uint32_t n, const uint64_t* off, const sq_aln* alns) {
+  const sq_quant_opts& o = S.op.o; const Index& ix = *S.ix;
+  if (!o.seq_bias) return;
+  for (uint32_t r = 0; r < n; ++r) {
+    if (S.seqSamples >= o.num_bias_samples) break;
+    const uint64_t a0 = off[r], a1 = off[r + 1]; const uint32_t na = (uint32_t)(a1 - a0);
+    if (!na) continue;
+    const uint64_t x = sq_mix64((o.seed ^ 0x5EB1A5ULL) ^ sq_mix64((S.readCounter + r) * 0x9E3779B97F4A7C15ULL + 1));
+    const uint32_t pick = (uint32_t)sq_mulhi64(x, (uint64_t)na + 1);
+    if (pick >= na) continue;
+    const sq_aln& h = alns[a0 + pick];
+    if (o.lib_type != T_PE) {   // single-end library (:2211-2257): one context; the start of a reverse read is pos + readLen there
+      const int32_t RL = (int32_t)ix.ref_len[h.tid]; const int32_t sp = h.fwd ? h.pos : h.pos + (int32_t)h.read_len; const bool rc = !h.fwd;
+      const int32_t b = rc ? SB_RIGHT : SB_LEFT, a = rc ? SB_LEFT : SB_RIGHT;
+      if (!(sp > 0 && sp < RL && sp >= b && sp + a < RL)) continue;
+      uint32_t c = sb_ctx(ix, h.tid, sp - b); if (rc) c = sb_rc(c);
+      for (int i = 0; i < SB_K; ++i) S.seqObs[h.fwd ? 0 : 1][sb_cell(c, i)]++;
+      S.seqSamples++; continue;
+    }
+    if (h.mate_status != SQ_MS_PAIRED_END_PAIRED || h.fwd == h.mate_fwd) continue;
+    const int32_t RL = (int32_t)ix.ref_len[h.tid];
+    const int32_t s1 = h.fwd ? h.pos : h.pos + (int32_t)h.read_len - 1, s2 = h.mate_fwd ? h.mate_pos : h.mate_pos + (int32_t)h.mate_len - 1;
+    if (!(s1 > 0 && s1 < RL && s2 > 0 && s2 < RL)) continue;
+    const bool rc1 = !h.fwd, rc2 = !h.mate_fwd;
+    const int32_t b1 = rc1 ? SB_RIGHT : SB_LEFT, a1c = rc1 ? SB_LEFT : SB_RIGHT, b2 = rc2 ? SB_RIGHT : SB_LEFT, a2c = rc2 ? SB_LEFT : SB_RIGHT;
+    if (!(s1 >= b1 && s1 + a1c < RL && s2 >= b2 && s2 + a2c < RL)) continue;
+    const int32_t fwPos = h.fwd ? s1 : s2, rcPos = h.fwd ? s2 : s1;
+    if (!(fwPos < rcPos)) continue;
+    uint32_t left = sb_ctx(ix, h.tid, s1 - b1), right = sb_ctx(ix, h.tid, s2 - b2);
+    if (rc1) left = sb_rc(left); else right = sb_rc(right);
+    for (int i = 0; i < SB_K; ++i) { S.seqObs[h.fwd ? 0 : 1][sb_cell(left, i)]++; S.seqObs[h.mate_fwd ? 0 : 1][sb_cell(right, i)]++; }
+    S.seqSamples++;
+  }
+}
+// SBModel::normalize (:216-252): counts (+ the 1e-10 prior every cell starts with) -> conditional probabilities per context -> logs
+static void sb_normalize(const double* counts, double* logp) {
+  for (int i = 0; i < SB_K; ++i) {
+    const int nstates = 1 << (2 * SB_ORDER[i]);
+    for (int c = 0; c < 64; ++c) logp[i * 64 + c] = 0.0;
+    for (int g = 0; g < nstates; ++g) {
+      const double* q = counts + i * 64 + 4 * g;
+      const double tot = ((q[0] + q[1]) + q[2]) + q[3];
+      for (int b = 0; b < 4; ++b) { const double pr = q[b] / tot; logp[i * 64 + 4 * g + b] = pr > 0.0 ? sq_log(pr) : sq_log(1e-5); }
+    }
+  }
+}
+static inline double sb_eval(const double* logp, uint32_t v) { double p = 0.0; for (int i = 0; i < SB_K; ++i) p += logp[sb_cell(v, i)]; return p; }
+// the lane-strided sum the device uses for sums over fragment starts (SPEC §B2): lane l of 256 adds the terms l, l + 256, ... in order,
+// then the lanes combine by strided halving
+template <class F> static double lane_sum256(int64_t n, F term) {
+  double v[256];
+  for (int l = 0; l < 256; ++l) { double a = 0.0; for (int64_t i = l; i < n; i += 256) a += term(i); v[l] = a; }
+  for (int st = 128; st >= 1; st >>= 1) for (int i = 0; i < st; ++i) v[i] = v[i] + v[i + st];
+  return v[0];
+}
+
 static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln* alns, uint64_t r0, uint64_t r1) {
   const Opts& op = S.op; const sq_quant_opts& o = op.o; const Index& ix = *S.ix;
   const double logFM = S.forgetting_mass(S.batchNo);
@@ -1315,10 +1385,140 @@ static int bias_gc_eff_lengths(const Index& ix, const double* gc_obs, const doub
   return (int)processed.size();
 }
 
+// salmon::utils::updateEffectiveLengths with --seqBias, alone or with --gcBias (SalmonUtils.cpp:1208-1985), restated loop by loop.  SPEC §B2:
+//  * expected context models: a transcript contributes weight x (C + F) to a cell, C = the integer count of its starts whose
+//    conditional-CDF factor is exactly 1 (the fragment could be longer than the distribution reaches), F = the factors of the other
+//    starts (the last <= 1000) added in start order; a model cell = 1e-10 + the canonical sum over the processed transcripts;
+//  * expected GC model (with --gcBias): integer windows per (sampled length, context bin, GC bin), as in §B, over the starts the
+//    reference's loop visits (fragStart < refLen - K, K = 9);
+//  * effective length: for every sampled length the sum over fragment starts of seqFW[start] * seqRC[end] (* gcBias) is the lane-strided
+//    sum (lane_sum256); the lengths are added in order.
+struct SeqBiasOut { double exp_fw[576], exp_rc[576], obs_fw[576], obs_rc[576]; uint32_t processed; };
+static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M,
+                                const double* alphas, const double* eff_in, double* eff_out, SeqBiasOut* out) {
+  const int MAXV = 1000; const int32_t gcSamp = 5; const int K = SB_K;
+  std::vector<double> pdf(MAXV + 1), cdf(MAXV + 1); int32_t fldLow = 0, fldHigh = 1; bool lb = false, ub = false;
+  for (int i = 0; i <= MAXV; ++i) {
+    pdf[i] = sq_exp(log_pmf[i]); cdf[i] = (i > 0) ? cdf[i - 1] + pdf[i] : pdf[i];
+    if (!lb && cdf[i] >= 0.005) { lb = true; fldLow = i; }
+    if (!ub && cdf[i] >= 1.0 - 0.005) { ub = true; fldHigh = i; }
+  }
+  auto prefix = [&](uint32_t t) { std::vector<int32_t> g(ix.ref_len[t]); int32_t c = 0; for (uint32_t i = 0; i < ix.ref_len[t]; ++i) { c += is_gc(ix, t, (int32_t)i) ? 1 : 0; g[i] = c; } return g; };
+  auto gcFrac = [](const std::vector<int32_t>& g, int32_t s, int32_t e) { int32_t cs = s > 0 ? g[s - 1] : 0, ce = g[e]; return (int32_t)std::lrint((100.0 * (double)(ce - cs)) / (double)(e - s + 1)); };
+  // populateContextCounts (:1372-1424), the loop as written (including what it does once the window reaches the last base)
+  auto context = [&](uint32_t t, const std::vector<int32_t>& g, std::vector<int32_t>& cFP, std::vector<int32_t>& cTP, std::vector<int32_t>& wFP, std::vector<int32_t>& wTP) {
+    const int32_t refLen = (int32_t)ix.ref_len[t]; cFP.assign(refLen, 0); cTP.assign(refLen, 0); wFP.assign(refLen, 0); wTP.assign(refLen, 0);
+    const int outside = 3, inside = 2, csize = outside + inside;
+    if (refLen > csize) {
+      int windowEnd = inside - 1, windowStart = -outside, fp = 0, tp = windowStart + (inside - 1);
+      int32_t count = g[windowEnd - 1];
+      for (; tp < refLen; ++fp, ++tp) {
+        if (windowStart > 0 && is_gc(ix, t, windowStart - 1)) count -= 1;
+        if (windowEnd < refLen && is_gc(ix, t, windowEnd)) count += 1;
+        const int32_t wl = (windowEnd < csize) ? windowEnd + 1 : (windowEnd - windowStart + 1);
+        if (fp < refLen) { cFP[fp] = count; wFP[fp] = wl; }
+        if (tp >= 0) { cTP[tp] = count; wTP[tp] = wl; }
+        if (windowEnd < refLen - 1) ++windowEnd;
+        ++windowStart;
+      }
+    }
+  };
+  auto ctxFrac = [](const std::vector<int32_t>& cFP, const std::vector<int32_t>& cTP, const std::vector<int32_t>& wFP, const std::vector<int32_t>& wTP, int32_t s, int32_t e) {
+    const double cl = (double)(wFP[s] + wTP[e]);
+    return cl > 0 ? (int32_t)std::lrint(100.0 * (double)(cFP[s] + cTP[e]) / cl) : 0;
+  };
+  std::vector<uint32_t> processed;
+  std::vector<std::vector<double>> cfw(576), crc(576), cgc(75);
+  for (uint32_t t = 0; t < M; ++t) {
+    const int32_t refLen = (int32_t)ix.ref_len[t], elen = (int32_t)eff_in[t], unprocessedLen = std::max(0, refLen - elen);
+    const int32_t cdfMaxArg = std::min(MAXV, refLen); const double cdfMaxVal = cdf[cdfMaxArg];
+    if (cdfMaxVal < 1e-10) continue;
+    if (alphas[t] < 1e-8 || unprocessedLen <= 0) continue;
+    auto cCDF = [&](int32_t x) { return x > cdfMaxArg ? 1.0 : cdf[x] / cdfMaxVal; };
+    processed.push_back(t);
+    const double weight = alphas[t] / eff_in[t];
+    // sequence contexts
+    { uint64_t Cf[576] = {0}, Cr[576] = {0}; double Ff[576] = {0}, Fr[576] = {0};
+      for (int32_t fsp = 0; fsp < refLen - K; ++fsp) {
+        const int32_t maxFragLen = refLen - (fsp + SB_LEFT);
+        if (!(maxFragLen >= 0 && maxFragLen < refLen)) continue;
+        const uint32_t fw = sb_ctx(ix, t, fsp), rc = sb_rc(sb_ctx(ix, t, refLen - K - fsp));
+        if (maxFragLen > cdfMaxArg) { for (int i = 0; i < K; ++i) { Cf[sb_cell(fw, i)]++; Cr[sb_cell(rc, i)]++; } }
+        else { const double cd = cdf[maxFragLen] / cdfMaxVal; for (int i = 0; i < K; ++i) { Ff[sb_cell(fw, i)] += cd; Fr[sb_cell(rc, i)] += cd; } }
+      }
+      for (int c = 0; c < 576; ++c) { cfw[c].push_back(weight * ((double)Cf[c] + Ff[c])); crc[c].push_back(weight * ((double)Cr[c] + Fr[c])); } }
+    if (gc) {
+      const std::vector<int32_t> g = prefix(t); std::vector<int32_t> cFP, cTP, wFP, wTP; context(t, g, cFP, cTP, wFP, wTP);
+      const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
+      double E[75] = {0};
+      double prev = cCDF(locFLDLow > 0 ? locFLDLow - 1 : 0);
+      for (int32_t fl = locFLDLow; fl <= locFLDHigh; fl += gcSamp) {
+        if (fl > refLen || fl < 1) break;
+        uint64_t N[75] = {0};
+        for (int32_t fs = 0; fs < refLen - K; ++fs) { const int32_t fe = fs + fl - 1; if (fe < refLen) N[gc_ctx_bin(ctxFrac(cFP, cTP, wFP, wTP, fs, fe)) * 25 + gc_frag_bin(gcFrac(g, fs, fe))]++; else break; }
+        const double d = cCDF(fl) - prev; prev = cCDF(fl);
+        for (int b = 0; b < 75; ++b) E[b] += d * (double)N[b];
+      }
+      for (int b = 0; b < 75; ++b) cgc[b].push_back(weight * E[b]);
+    }
+  }
+  // models
+  double cnt_efw[576], cnt_erc[576], cnt_ofw[576], cnt_orc[576], efw[576], erc[576], ofw[576], orc_[576];
+  for (int c = 0; c < 576; ++c) { cnt_efw[c] = 1e-10 + canonical_sum(cfw[c]); cnt_erc[c] = 1e-10 + canonical_sum(crc[c]); cnt_ofw[c] = 1e-10 + (double)seq_fw[c]; cnt_orc[c] = 1e-10 + (double)seq_rc[c]; }
+  sb_normalize(cnt_efw, efw); sb_normalize(cnt_erc, erc); sb_normalize(cnt_ofw, ofw); sb_normalize(cnt_orc, orc_);
+  if (out) { memcpy(out->exp_fw, efw, sizeof(efw)); memcpy(out->exp_rc, erc, sizeof(erc)); memcpy(out->obs_fw, ofw, sizeof(ofw)); memcpy(out->obs_rc, orc_, sizeof(orc_)); out->processed = (uint32_t)processed.size(); }
+  double bias[3][25]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 25; ++c) bias[r][c] = 1.0;
+  if (gc) {
+    double expect[3][25], obsN[3][25], expN[3][25];
+    for (int b = 0; b < 75; ++b) expect[b / 25][b % 25] = canonical_sum(cgc[b]);
+    auto normalize = [](const double* in, double* o2) { double rowMass = 0.0; for (int c = 0; c < 25; ++c) rowMass += (0.1 + in[c]);
+      if (rowMass > 0.0) { double norm = 1.0 / rowMass; for (int c = 0; c < 25; ++c) o2[c] = (0.1 + in[c]) * norm; } else for (int c = 0; c < 25; ++c) o2[c] = in[c]; };
+    for (int r = 0; r < 3; ++r) { normalize(gc_obs + 25 * r, obsN[r]); normalize(expect[r], expN[r]);
+      for (int c = 0; c < 25; ++c) { double rat = obsN[r][c] / expN[r][c]; if (rat > 1000.0) rat = 1000.0; if (rat < 1.0 / 1000.0) rat = 1.0 / 1000.0; bias[r][c] = rat; } }
+  }
+  // effective lengths
+  for (uint32_t t = 0; t < M; ++t) {
+    const int32_t refLen = (int32_t)ix.ref_len[t], elen = (int32_t)eff_in[t], unprocessedLen = std::max(0, refLen - elen);
+    const int32_t cdfMaxArg = std::min(MAXV, refLen); const double cdfMaxVal = cdf[cdfMaxArg];
+    auto cCDF = [&](int32_t x) { return x > cdfMaxArg ? 1.0 : cdf[x] / cdfMaxVal; };
+    const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
+    if (!(alphas[t] >= 1e-8 && unprocessedLen > 0 && cdfMaxVal > 1e-10)) { eff_out[t] = (double)elen; continue; }
+    std::vector<double> sFW(refLen, 1.0), sRCt(refLen, 1.0), sRC(refLen, 1.0);
+    for (int32_t fs = 0; fs < refLen - K; ++fs) {
+      const int32_t readStart = fs + SB_LEFT;
+      if (readStart < refLen) {
+        const uint32_t fw = sb_ctx(ix, t, fs), rc = sb_rc(sb_ctx(ix, t, refLen - K - fs));
+        sFW[readStart] = sq_exp(sb_eval(ofw, fw) - sb_eval(efw, fw));
+        sRCt[readStart] = sq_exp(sb_eval(orc_, rc) - sb_eval(erc, rc));
+      }
+    }
+    for (int32_t j = 0; j < refLen; ++j) sRC[j] = sRCt[refLen - 1 - j];
+    std::vector<int32_t> g, cFP, cTP, wFP, wTP; if (gc) { g = prefix(t); context(t, g, cFP, cTP, wFP, wTP); }
+    double effLength = 0.0;
+    int32_t fl = locFLDLow; const int32_t maxLen = std::min(refLen, locFLDHigh + 1); bool done = fl >= maxLen;
+    double prevFLMass = cCDF(fl > 0 ? fl - 1 : 0);
+    while (!done) {
+      if (fl >= maxLen) { done = true; fl = maxLen - 1; }
+      const double flWeight = cCDF(fl) - prevFLMass; prevFLMass = cCDF(fl);
+      const int32_t cur = fl;
+      const double flMassTotal = lane_sum256((int64_t)std::max(0, refLen - cur), [&](int64_t s0) {
+        const int32_t fs = (int32_t)s0, fe = fs + cur - 1;
+        double f = sFW[fs] * sRC[fe];
+        if (gc) f *= bias[gc_ctx_bin(ctxFrac(cFP, cTP, wFP, wTP, fs, fe))][gc_frag_bin(gcFrac(g, fs, fe))];
+        return f; });
+      effLength += flWeight * flMassTotal;
+      fl += gcSamp;
+    }
+    const double thresh = (double)unprocessedLen, offset = std::max(1.0, thresh), effLengthNoBias = (double)elen;
+    eff_out[t] = std::max(effLength, std::min(effLengthNoBias, offset));
+  }
+  return (int)processed.size();
+}
+
 // optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928): after 11 updates updateEffectiveLengths, new priors
 // (populatePriorAlphas_) and combined weights (updateEqClassWeights :160-176; degenerate classes stay dropped), then on to convergence
 static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const Index& ix, const double* gc_obs, const double* log_pmf,
-                          double* alpha_out, double* eff_out, sq_em_report* rep) {
+                          double* alpha_out, double* eff_out, sq_em_report* rep, const uint64_t* seq_fw = nullptr, const uint64_t* seq_rc = nullptr) {
   EMProblem P; em_setup(P, eq, txp, o);
   const uint32_t M = P.M;
   std::vector<double> alpha(M), pc(M), eff(txp->eff_len, txp->eff_len + M), eff2(M);
@@ -1334,7 +1534,8 @@ static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_
   }
   uint32_t it; bool conv; double maxRel;
   em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 11);
-  bias_gc_eff_lengths(ix, gc_obs, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);
+  if (seq_fw) bias_seq_eff_lengths(ix, gc_obs != nullptr, gc_obs, seq_fw, seq_rc, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);   // --seqBias [+ --gcBias]
+  else bias_gc_eff_lengths(ix, gc_obs, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);
   for (uint64_t c = 0; c < P.E; ++c) {   // updateEqClassWeights with the new lengths
     if (dropped[c]) continue;
     double wsum = 0.0;
@@ -1665,6 +1866,7 @@ void orc_state_free(orc_state* s) { delete s; }
 // feed one mapped batch (CSR) through the online model in mini-batches, in input order
 void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, uint64_t num_with_joint_hits) {
   QuantState& S = s->S; uint32_t mb = S.op.o.mini_batch_size ? S.op.o.mini_batch_size : 5000;
+  seq_observe(S, n, read_off, alns);
   for (uint64_t r0 = 0; r0 < n; r0 += mb) process_mini_batch(S, read_off, alns, r0, std::min<uint64_t>(n, r0 + mb));
   S.flush_pending();   // a group never straddles two mapped batches
   S.numMappedUB += num_with_joint_hits;
@@ -1806,12 +2008,21 @@ void orc_normalize_alphas(uint32_t M, const sq_eq_table* eq, const double* log_m
   }
 }
 
+void orc_state_seq_observed(orc_state* s, uint64_t* fw576, uint64_t* rc576, uint64_t* nsamples) { memcpy(fw576, s->S.seqObs[0], 576 * 8); memcpy(rc576, s->S.seqObs[1], 576 * 8); if (nsamples) *nsamples = s->S.seqSamples; }
+int orc_bias_seq_eff_lengths(const orc_index* oi, int gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M, const double* alphas,
+                             const double* eff_in, double* eff_out, double* models4x576) {
+  SeqBiasOut o; int rc = bias_seq_eff_lengths(oi->ix, gc != 0, gc_obs, seq_fw, seq_rc, log_pmf, M, alphas, eff_in, eff_out, &o);
+  if (models4x576) { memcpy(models4x576, o.exp_fw, 576 * 8); memcpy(models4x576 + 576, o.exp_rc, 576 * 8); memcpy(models4x576 + 1152, o.obs_fw, 576 * 8); memcpy(models4x576 + 1728, o.obs_rc, 576 * 8); }
+  return rc;
+}
 void orc_state_gc_observed(orc_state* s, double* out75) { for (int i = 0; i < 75; ++i) out75[i] = sq_from_fixed(s->S.gcObs[i], 32); }
 
 int orc_bias_gc_eff_lengths(const orc_index* oi, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in,
                             double* eff_out, double* bias_row0_out) { return bias_gc_eff_lengths(oi->ix, gc_obs, log_pmf, M, alphas, eff_in, eff_out, bias_row0_out); }
 int orc_em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const orc_index* oi, const double* gc_obs, const double* log_pmf,
                        double* alpha_out, double* eff_out, sq_em_report* rep) { return em_optimize_gc(eq, txp, o, oi->ix, gc_obs, log_pmf, alpha_out, eff_out, rep); }
+int orc_em_optimize_bias(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const orc_index* oi, const double* gc_obs /* or NULL */, const uint64_t* seq_fw, const uint64_t* seq_rc,
+                         const double* log_pmf, double* alpha_out, double* eff_out, sq_em_report* rep) { return em_optimize_gc(eq, txp, o, oi->ix, gc_obs, log_pmf, alpha_out, eff_out, rep, seq_fw, seq_rc); }
 
 int orc_em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out, sq_em_report* rep) {
   return em_optimize(eq, txp, o, alpha_out, rep);

@@ -339,6 +339,28 @@ class QuantContext:
         check(lib().sq_model_fetch_gc_observed(self.h, g.ctypes.data), "sq_model_fetch_gc_observed")
         return g.reshape(3, 25)
 
+    def seq_observed(self):
+        """Observed read-start context counts (needs quant_opts(seq_bias=1)): (fw[576], rc[576], fragments sampled)."""
+        fw = np.zeros(576, np.uint64); rc = np.zeros(576, np.uint64); n = C.c_uint64()
+        check(lib().sq_model_fetch_seq_observed(self.h, fw.ctypes.data, rc.ctypes.data, C.byref(n)), "sq_model_fetch_seq_observed")
+        return fw, rc, int(n.value)
+
+    def em_optimize_seq(self, eff_len, projected, seq_fw, seq_rc, log_pmf, gc_obs=None, opts=None, eq=None):
+        """CollapsedEMOptimizer::optimize with --seqBias [and --gcBias]: sq_em_optimize_bias with sq_bias_seq_eff_lengths as the callback."""
+        o = opts or em_opts(); txp = make_txp_in(eff_len, projected); M = txp.num_txp
+        out = np.zeros(M); eff_out = np.zeros(M); rep = capi.EmReport(); brep = capi.BiasReport()
+        fw = np.ascontiguousarray(seq_fw, np.uint64); rc = np.ascontiguousarray(seq_rc, np.uint64); lp = np.ascontiguousarray(log_pmf, np.float64)
+        g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1) if gc_obs is not None else None
+        idx_h = self.index.h
+        def cb(alphas, eff_in, eff_o, m, user):
+            return lib().sq_bias_seq_eff_lengths(idx_h, 1 if g is not None else 0, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data, m,
+                C.cast(alphas, C.c_void_p), C.cast(eff_in, C.c_void_p), C.cast(eff_o, C.c_void_p), None, C.byref(brep))
+        cbf = capi.EFFLEN_CB(cb)
+        t = eq.table() if eq is not None else None
+        check(lib().sq_em_optimize_bias(self.h, C.byref(t) if t is not None else None, C.byref(txp), C.byref(o), cbf, None, _ptr(out, C.c_double),
+            _ptr(eff_out, C.c_double), C.byref(rep)), "sq_em_optimize_bias")
+        return out, eff_out, dict(iters=rep.iters, converged=bool(rep.converged), num_degenerate=rep.num_degenerate, num_processed=brep.num_processed)
+
     def em_optimize_gc(self, eff_len, projected, gc_obs, log_pmf, opts=None, eq=None):
         """CollapsedEMOptimizer::optimize with --gcBias: the effective lengths are re-derived from the GC models at iteration 11
         (sq_em_optimize_bias with sq_bias_gc_eff_lengths as the callback).  Returns (alphas, eff_lens, report)."""
@@ -407,6 +429,16 @@ def bias_gc_eff_lengths(index, gc_obs, log_pmf, alphas, eff_in):
     check(lib().sq_bias_gc_eff_lengths(index.h, g.ctypes.data, lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, C.byref(rep)),
         "sq_bias_gc_eff_lengths")
     return out, dict(num_processed=rep.num_processed, fld_low=rep.fld_low, fld_high=rep.fld_high, gc_bias=np.array(rep.gc_bias_row0))
+
+
+def bias_seq_eff_lengths(index, seq_fw, seq_rc, log_pmf, alphas, eff_in, gc_obs=None):
+    """updateEffectiveLengths with --seqBias [+ --gcBias] -> (eff_out, models[4, 576], report); the index must be on a device."""
+    fw = np.ascontiguousarray(seq_fw, np.uint64); rc = np.ascontiguousarray(seq_rc, np.uint64); lp = np.ascontiguousarray(log_pmf, np.float64)
+    a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); models = np.zeros((4, 576)); rep = capi.BiasReport()
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1) if gc_obs is not None else None
+    check(lib().sq_bias_seq_eff_lengths(index.h, 1 if g is not None else 0, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data, len(a),
+        a.ctypes.data, e.ctypes.data, out.ctypes.data, models.ctypes.data, C.byref(rep)), "sq_bias_seq_eff_lengths")
+    return out, models, dict(num_processed=rep.num_processed, fld_low=rep.fld_low, fld_high=rep.fld_high, gc_bias=np.array(rep.gc_bias_row0))
 
 
 def normalize_alphas(eq, log_mass, uniq, total):

@@ -36,7 +36,7 @@ class QuantOpts(C.Structure):
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
                 ("no_length_correction", u8), ("no_eff_length_correction", u8), ("seed", u64),
-                ("mini_batches_in_flight", u32), ("_pad2", u32)]
+                ("seq_bias", u8), ("pos_bias", u8), ("_pad3", u8 * 2), ("num_bias_samples", u32), ("mini_batches_in_flight", u32)]
 
 
 class ReadBatch(C.Structure):
@@ -175,6 +175,8 @@ def lib():
         "sq_forgetting_masses": (C.c_int, [f64, u64, vp]),
         "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
         "sq_bias_gc_eff_lengths": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, P(BiasReport)]),
+        "sq_model_fetch_seq_observed": (C.c_int, [vp, vp, vp, P(u64)]),
+        "sq_bias_seq_eff_lengths": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, u32, vp, vp, vp, vp, P(BiasReport)]),
         "sq_em_optimize_bias": (C.c_int, [vp, P(EqTable), P(TxpIn), P(EmOpts), EFFLEN_CB, vp, P(f64), P(f64), P(EmReport)]),
         "sq_dist_make_id": (C.c_int, [vp]), "sq_dist_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]), "sq_dist_free": (None, [vp]),
         "sq_dist_rank": (C.c_int, [vp]), "sq_dist_world": (C.c_int, [vp]), "sq_dist_merge_eq": (C.c_int, [vp, vp]),

@@ -158,6 +158,283 @@ extern "C" int sq_bias_gc_eff_lengths(sq_index* idx, const double* gc_obs, const
   return SQ_OK;
 }
 
+// ================================================================================================================================
+// --seqBias (alone or with --gcBias): read-start context models (reference src/model/SBModel.cpp) and the bias-corrected effective
+// lengths of salmon::utils::updateEffectiveLengths (SalmonUtils.cpp:1208-1985, the seqBiasCorrect branches).  SPEC §B2 fixes the
+// order of every floating-point sum so that the result does not depend on the launch geometry:
+//   expected context models   per transcript: integer counts of the starts whose conditional-CDF factor is exactly 1 + the other
+//                             (<= 1000) factors added in start order by one lane per model column; across transcripts: canonical sums
+//   expected GC model         integer windows per (sampled length, context bin, GC bin)
+//   effective length          per sampled length the lane-strided sum over fragment starts (256 lanes, strided-halving tree)
+namespace {
+#define SB_K 9
+#define SB_LEFT 3
+__device__ __host__ inline uint32_t sb_cell(uint32_t v, int i) {   // SBModel _shifts / _widths (:44-52): orders {0,1,2,2,2,2,2,2,2}
+  const int order = i == 0 ? 0 : (i == 1 ? 1 : 2); const int shift = 2 * SB_K - 2 * (i + 1), width = 2 * (order + 1);
+  return (uint32_t)i * 64u + ((v >> shift) & ((1u << width) - 1u));
+}
+__device__ inline uint32_t sb_ctx(const uint64_t* refseq, uint64_t g, int32_t p) {   // 9 bases from p, first base in the high bits
+  const uint64_t w = sq_fetch_bases(refseq, g + (uint64_t)p, SB_K); uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < SB_K; ++i) v = (v << 2) | (uint32_t)((w >> (2 * i)) & 3u);
+  return v;
+}
+__device__ inline uint32_t sb_rc(uint32_t v) { uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < SB_K; ++i) { r = (r << 2) | (3u - (v & 3u)); v >>= 2; } return r; }
+
+// block per processed transcript: out[p][0..575] = weight * (count + fraction) of the forward contexts, [576..1151] of the reverse ones
+__global__ void __launch_bounds__(256) k_seq_expect(const uint64_t* __restrict__ refseq, const uint64_t* __restrict__ ref_accum, const uint32_t* __restrict__ ref_len,
+                                                    const uint32_t* __restrict__ list, const double* __restrict__ weight, const double* __restrict__ cdf /*[1001]*/,
+                                                    double* __restrict__ out) {
+  __shared__ uint32_t cnt[2][576]; __shared__ double frac[2][576];
+  const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t];
+  for (int i = threadIdx.x; i < 1152; i += 256) { (&cnt[0][0])[i] = 0; (&frac[0][0])[i] = 0.0; }
+  __syncthreads();
+  const int32_t cdfMaxArg = refLen < 1000 ? refLen : 1000; const double cdfMaxVal = cdf[cdfMaxArg];
+  const int32_t nstart = refLen - SB_K;                       // fragStartPos in [0, nstart)
+  // maxFragLen = refLen - (fsp + 3) > cdfMaxArg  <=>  fsp < refLen - 3 - cdfMaxArg
+  int32_t tail0 = refLen - SB_LEFT - cdfMaxArg; if (tail0 < 0) tail0 = 0; if (tail0 > nstart) tail0 = nstart < 0 ? 0 : nstart;
+  for (int32_t fsp = (int32_t)threadIdx.x; fsp < tail0; fsp += 256) {
+    const uint32_t fw = sb_ctx(refseq, g, fsp), rc = sb_rc(sb_ctx(refseq, g, refLen - SB_K - fsp));
+#pragma unroll
+    for (int i = 0; i < SB_K; ++i) { atomicAdd(&cnt[0][sb_cell(fw, i)], 1u); atomicAdd(&cnt[1][sb_cell(rc, i)], 1u); }
+  }
+  if (threadIdx.x < 2 * SB_K) {   // one lane per (strand, model column): the fractional factors in start order
+    const int strand = threadIdx.x / SB_K, col = threadIdx.x % SB_K;
+    for (int32_t fsp = tail0; fsp < nstart; ++fsp) {
+      const int32_t x = refLen - (fsp + SB_LEFT);
+      const uint32_t v = strand == 0 ? sb_ctx(refseq, g, fsp) : sb_rc(sb_ctx(refseq, g, refLen - SB_K - fsp));
+      frac[strand][sb_cell(v, col)] += cdf[x] / cdfMaxVal;
+    }
+  }
+  __syncthreads();
+  const double w = weight[p];
+  for (int i = threadIdx.x; i < 1152; i += 256) out[(size_t)p * 1152 + i] = w * ((double)(&cnt[0][0])[i] + (&frac[0][0])[i]);
+}
+// one level of the canonical sum (SPEC §D2) over the rows of X[n][ncol]: out[g][c] = strided-halving tree of rows 64 g .. 64 g + 63
+__global__ void k_canon_level(const double* __restrict__ X, uint64_t n, uint32_t ncol, double* __restrict__ out) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; const uint64_t ng = (n + 63) / 64;
+  if (gid >= ng * ncol) return;
+  const uint64_t gq = gid / ncol; const uint32_t c = (uint32_t)(gid % ncol);
+  double v[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) { const uint64_t r = gq * 64 + (uint64_t)i; v[i] = r < n ? X[r * ncol + c] : 0.0; }
+#pragma unroll
+  for (int st = 32; st >= 1; st >>= 1)
+#pragma unroll
+    for (int i = 0; i < st; ++i) v[i] = v[i] + v[i + st];
+  out[gq * ncol + c] = v[0];
+}
+
+// GC of [s, e] and the context fraction of (s, e): Transcript::gcFrac and populateContextCounts (SalmonUtils.cpp:1372-1424) in closed form —
+// count(it) = G(it + 1) - G(it - 4) while the window has not reached the last base, G(n-1) + (it + 2 - n) gc(n-1) - G(it - 4) after
+// (the loop as written keeps adding the last base); window length it + 2 for it <= 3, else 5, else n + 3 - it.  cFP[f] = count(f),
+// cTP[t] = count(t + 2), likewise the window lengths.
+struct GcCtx { const uint64_t* refseq; const uint32_t* gcpre; uint64_t g; int32_t n; uint64_t g0; int32_t last_gc; };
+__device__ inline int64_t gc_G(const GcCtx& C, int32_t i) { if (i < 0) return 0; if (i > C.n - 1) i = C.n - 1; return (int64_t)(sq_gc_before(C.refseq, C.gcpre, C.g + (uint64_t)i + 1) - C.g0); }
+__device__ inline int32_t ctx_count(const GcCtx& C, int32_t it) { return (it + 1 <= C.n - 1) ? (int32_t)(gc_G(C, it + 1) - gc_G(C, it - 4)) : (int32_t)(gc_G(C, C.n - 1) + (int64_t)(it + 2 - C.n) * C.last_gc - gc_G(C, it - 4)); }
+__device__ inline int32_t ctx_wl(const GcCtx& C, int32_t it) { return it <= 3 ? it + 2 : ((it + 1 <= C.n - 1) ? 5 : C.n + 3 - it); }
+__device__ inline int32_t ctx_frac(const GcCtx& C, int32_t s, int32_t e) {
+  if (C.n <= 5) return 0;
+  const double cl = (double)(ctx_wl(C, s) + ctx_wl(C, e + 2));
+  return cl > 0 ? (int32_t)rint(100.0 * (double)(ctx_count(C, s) + ctx_count(C, e + 2)) / cl) : 0;
+}
+__device__ inline GcCtx make_gcctx(const uint64_t* refseq, const uint32_t* gcpre, uint64_t g, int32_t n) {
+  GcCtx C; C.refseq = refseq; C.gcpre = gcpre; C.g = g; C.n = n; C.g0 = sq_gc_before(refseq, gcpre, g);
+  const uint32_t b = n > 0 ? sq_fetch_base(refseq, g + (uint64_t)n - 1) : 0u; C.last_gc = (b == 1 || b == 2) ? 1 : 0; return C;
+}
+// expected GC model with context bins: hist[p][slot][ctx * 25 + bin] = starts s in [0, refLen - K) with s + fl - 1 < refLen (the loop of :1577-1623)
+__global__ void __launch_bounds__(256) k_gc_hist_ctx(const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
+                                                     const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, int32_t fld_low_g, int32_t fld_high_g, int32_t samp,
+                                                     uint32_t nslots, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[75];
+  const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t];
+  const GcCtx C = make_gcctx(refseq, gcpre, g, refLen);
+  const int32_t cdfMaxArg = refLen < 1000 ? refLen : 1000;
+  const int32_t lo = (refLen < cdfMaxArg) ? 1 : fld_low_g, hi = (refLen < cdfMaxArg) ? cdfMaxArg : fld_high_g;   // refLen < cdfMaxArg never holds; kept as the reference writes it
+  for (uint32_t slot = 0; slot < nslots; ++slot) {
+    const int32_t fl = lo + samp * (int32_t)slot;
+    if (threadIdx.x < 75) h[threadIdx.x] = 0;
+    __syncthreads();
+    if (fl <= hi && fl >= 1 && fl <= refLen) {
+      int32_t nst = refLen - SB_K; const int32_t lim = refLen - fl + 1; if (lim < nst) nst = lim;      // s < refLen - K and s + fl - 1 < refLen
+      for (int32_t s = (int32_t)threadIdx.x; s < nst; s += 256) {
+        const int32_t e = s + fl - 1;
+        const uint64_t c = sq_gc_before(refseq, gcpre, g + (uint64_t)e + 1) - sq_gc_before(refseq, gcpre, g + (uint64_t)s);
+        const int32_t frac = (int32_t)rint((100.0 * (double)c) / (double)fl);
+        atomicAdd(&h[sq_gc_ctx_bin(ctx_frac(C, s, e)) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 75) hist[((size_t)p * nslots + slot) * 75 + threadIdx.x] = h[threadIdx.x];
+    __syncthreads();
+  }
+}
+// per position of a transcript: seqFW[readStart] = exp(obs5 - exp5) of the forward context, seqRC (already reversed into 5'->3' order)
+__device__ inline double sb_eval(const double* __restrict__ logp, uint32_t v) { double p = 0.0;
+#pragma unroll
+  for (int i = 0; i < SB_K; ++i) p += logp[sb_cell(v, i)]; return p; }
+__global__ void k_seq_factors(const uint64_t* __restrict__ refseq, const uint64_t* __restrict__ ref_accum, const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list,
+                              const uint64_t* __restrict__ foff /* start of transcript p's factors */, const double* __restrict__ models /* exp_fw, exp_rc, obs_fw, obs_rc */,
+                              double* __restrict__ sfw, double* __restrict__ src) {
+  const uint32_t p = blockIdx.y, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t], o = foff[p];
+  for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < refLen; j += gridDim.x * blockDim.x) {
+    // forward factor at position j: set by fs = j - 3 when 0 <= fs < refLen - K
+    double f = 1.0; { const int32_t fs = j - SB_LEFT; if (fs >= 0 && fs < refLen - SB_K) { const uint32_t v = sb_ctx(refseq, g, fs); f = sq_exp(sb_eval(models + 1152, v) - sb_eval(models, v)); } }
+    sfw[o + (uint64_t)j] = f;
+    // reverse factor at 5'->3' position j = the value the loop stores at rc position refLen - 1 - j, i.e. fs = refLen - 1 - j - 3
+    double r = 1.0; { const int32_t fs = refLen - 1 - j - SB_LEFT; if (fs >= 0 && fs < refLen - SB_K) { const uint32_t v = sb_rc(sb_ctx(refseq, g, refLen - SB_K - fs)); r = sq_exp(sb_eval(models + 1728, v) - sb_eval(models + 576, v)); } }
+    src[o + (uint64_t)j] = r;
+  }
+}
+struct EffArgs { int32_t fld_low, fld_high, samp; int use_gc; double bias[75]; };
+// block per transcript: the effective length loop of :1888-1945 with the lane-strided sum over fragment starts
+__global__ void __launch_bounds__(256) k_seq_efflen(const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
+                                                    const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, const uint64_t* __restrict__ foff,
+                                                    const double* __restrict__ sfw, const double* __restrict__ src, const double* __restrict__ cdf, EffArgs A,
+                                                    double* __restrict__ eff /*[P]*/) {
+  __shared__ double v[256];
+  const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t], o = foff[p];
+  const GcCtx C = make_gcctx(refseq, gcpre, g, refLen);
+  const int32_t cdfMaxArg = refLen < 1000 ? refLen : 1000; const double cdfMaxVal = cdf[cdfMaxArg];
+  const int32_t lo = (refLen < cdfMaxArg) ? 1 : A.fld_low, hi = (refLen < cdfMaxArg) ? cdfMaxArg : A.fld_high;
+  int32_t fl = lo; const int32_t maxLen = refLen < hi + 1 ? refLen : hi + 1; bool done = fl >= maxLen;
+  auto cCDF = [&](int32_t x) { return x > cdfMaxArg ? 1.0 : cdf[x] / cdfMaxVal; };
+  double prev = cCDF(fl > 0 ? fl - 1 : 0), effLength = 0.0;
+  while (!done) {
+    if (fl >= maxLen) { done = true; fl = maxLen - 1; }
+    const double flWeight = cCDF(fl) - prev; prev = cCDF(fl);
+    const int32_t ns = refLen - fl > 0 ? refLen - fl : 0;
+    double a = 0.0;
+    for (int32_t s = (int32_t)threadIdx.x; s < ns; s += 256) {
+      const int32_t e = s + fl - 1;
+      double f = sfw[o + (uint64_t)s] * src[o + (uint64_t)e];
+      if (A.use_gc) {
+        const uint64_t c = sq_gc_before(refseq, gcpre, g + (uint64_t)e + 1) - sq_gc_before(refseq, gcpre, g + (uint64_t)s);
+        const int32_t frac = (int32_t)rint((100.0 * (double)c) / (double)fl);
+        f *= A.bias[sq_gc_ctx_bin(ctx_frac(C, s, e)) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)];
+      }
+      a += f;
+    }
+    v[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if ((int)threadIdx.x < st) v[threadIdx.x] = v[threadIdx.x] + v[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) effLength += flWeight * v[0];
+    __syncthreads();
+    fl += A.samp;
+  }
+  if (threadIdx.x == 0) eff[p] = effLength;
+}
+void sb_normalize_host(const double* counts, double* logp) {   // SBModel::normalize (:216-252)
+  for (int i = 0; i < SB_K; ++i) {
+    const int order = i == 0 ? 0 : (i == 1 ? 1 : 2), nstates = 1 << (2 * order);
+    for (int c = 0; c < 64; ++c) logp[i * 64 + c] = 0.0;
+    for (int gq = 0; gq < nstates; ++gq) {
+      const double* q = counts + i * 64 + 4 * gq; const double tot = ((q[0] + q[1]) + q[2]) + q[3];
+      for (int b = 0; b < 4; ++b) { const double pr = q[b] / tot; logp[i * 64 + 4 * gq + b] = pr > 0.0 ? sq_log(pr) : sq_log(1e-5); }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M,
+                                       const double* alphas, const double* eff_in, double* eff_out, double* models_out /* [4][576] or NULL */, sq_bias_report* rep) {
+  if (!idx || !seq_fw || !seq_rc || !log_pmf || !alphas || !eff_in || !eff_out || (use_gc && !gc_obs)) { sq_set_error("sq_bias_seq_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
+  if (!idx->dev) { sq_set_error("sq_bias_seq_eff_lengths: the index is not on a device (there is no CPU path)"); return SQ_ERR_DEVICE; }
+  if (M > idx->names.size()) { sq_set_error("sq_bias_seq_eff_lengths: %u transcripts but the index has %zu", M, idx->names.size()); return SQ_ERR_ARG; }
+  const sq_device_index* di = idx->dev;
+  SQ_HIP_CHECK(hipSetDevice(di->device));
+  const int MAXV = 1000; const int32_t samp = 5;
+  std::vector<double> pdf(MAXV + 1), cdf(MAXV + 1); int32_t fldLow = 0, fldHigh = 1; bool lb = false, ub = false;
+  for (int i = 0; i <= MAXV; ++i) {
+    pdf[i] = sq_exp(log_pmf[i]); cdf[i] = i > 0 ? cdf[i - 1] + pdf[i] : pdf[i];
+    if (!lb && cdf[i] >= 0.005) { lb = true; fldLow = i; }
+    if (!ub && cdf[i] >= 1.0 - 0.005) { ub = true; fldHigh = i; }
+  }
+  std::vector<uint32_t> list; std::vector<int32_t> elen(M), unproc(M); std::vector<double> weight;
+  for (uint32_t t = 0; t < M; ++t) {
+    const int32_t refLen = (int32_t)idx->ref_len[t]; elen[t] = (int32_t)eff_in[t]; unproc[t] = std::max(0, refLen - elen[t]);
+    if (cdf[std::min(MAXV, refLen)] < 1e-10 || alphas[t] < 1e-8 || unproc[t] <= 0) continue;
+    list.push_back(t); weight.push_back(alphas[t] / eff_in[t]);
+  }
+  const size_t P = list.size();
+  for (uint32_t t = 0; t < M; ++t) eff_out[t] = (double)elen[t];
+  double models[4 * 576]; double bias[75]; for (double& b : bias) b = 1.0;
+  double cnt[4][576];
+  for (int c = 0; c < 576; ++c) { cnt[0][c] = 1e-10; cnt[1][c] = 1e-10; cnt[2][c] = 1e-10 + (double)seq_fw[c]; cnt[3][c] = 1e-10 + (double)seq_rc[c]; }
+  sq_dbuf<uint32_t> d_list; sq_dbuf<double> d_w, d_cdf, d_x, d_y, d_models, d_sfw, d_src, d_eff; sq_dbuf<uint64_t> d_foff; sq_dbuf<uint32_t> d_hist;
+  auto release = [&]() { d_list.free_(); d_w.free_(); d_cdf.free_(); d_x.free_(); d_y.free_(); d_models.free_(); d_sfw.free_(); d_src.free_(); d_eff.free_(); d_foff.free_(); d_hist.free_(); };
+  struct Guard { decltype(release)& r; ~Guard() { r(); } } guard{release};
+  if (P) {
+    if (d_list.ensure(P) || d_w.ensure(P) || d_cdf.ensure(MAXV + 1) || d_x.ensure(P * 1152) || d_y.ensure(((P + 63) / 64) * 1152 + 1152) || d_models.ensure(4 * 576)) {
+      sq_set_error("device allocation failed (sequence-bias models for %zu transcripts)", P); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpy(d_list.p, list.data(), P * 4, hipMemcpyHostToDevice));
+    SQ_HIP_CHECK(hipMemcpy(d_w.p, weight.data(), P * 8, hipMemcpyHostToDevice));
+    SQ_HIP_CHECK(hipMemcpy(d_cdf.p, cdf.data(), (MAXV + 1) * 8, hipMemcpyHostToDevice));
+    // ---- expected context models: per-transcript terms, then the canonical sum over the processed transcripts ----
+    k_seq_expect<<<(uint32_t)P, 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p, d_w.p, d_cdf.p, d_x.p);
+    { double* in = d_x.p; double* out = d_y.p; uint64_t n = P;
+      while (n > 1) { const uint64_t ng = (n + 63) / 64; k_canon_level<<<(uint32_t)((ng * 1152 + 255) / 256), 256>>>(in, n, 1152, out); std::swap(in, out); n = ng; }
+      double e[1152]; SQ_HIP_CHECK(hipMemcpy(e, in, sizeof(e), hipMemcpyDeviceToHost));
+      for (int c = 0; c < 576; ++c) { cnt[0][c] = 1e-10 + e[c]; cnt[1][c] = 1e-10 + e[576 + c]; } }
+  }
+  for (int m = 0; m < 4; ++m) sb_normalize_host(cnt[m], models + m * 576);
+  if (models_out) memcpy(models_out, models, sizeof(models));
+  if (P) {
+    SQ_HIP_CHECK(hipMemcpy(d_models.p, models, sizeof(models), hipMemcpyHostToDevice));
+    // ---- expected GC model with context bins ----
+    if (use_gc) {
+      const uint32_t nslots = fldHigh >= fldLow ? (uint32_t)((fldHigh - fldLow) / samp + 1) : 0u;
+      std::vector<uint32_t> hist(P * (size_t)nslots * 75, 0);
+      if (nslots) {
+        if (d_hist.ensure(hist.size())) { sq_set_error("device allocation failed (GC histograms)"); return SQ_ERR_NOMEM; }
+        k_gc_hist_ctx<<<(uint32_t)P, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p, fldLow, fldHigh, samp, nslots, d_hist.p);
+        SQ_HIP_CHECK(hipMemcpy(hist.data(), d_hist.p, hist.size() * 4, hipMemcpyDeviceToHost));
+      }
+      auto cond_cdf = [&](int32_t refLen, int32_t x) { const int32_t a = std::min(MAXV, refLen); return x > a ? 1.0 : cdf[x] / cdf[a]; };
+      std::vector<std::vector<double>> contrib(75, std::vector<double>(P, 0.0));
+      for (size_t p = 0; p < P; ++p) {
+        const uint32_t t = list[p]; const int32_t refLen = (int32_t)idx->ref_len[t]; double E[75] = {0};
+        double prev = cond_cdf(refLen, fldLow > 0 ? fldLow - 1 : 0);
+        for (uint32_t j = 0; j < nslots; ++j) {
+          const int32_t fl = fldLow + samp * (int32_t)j;
+          if (fl > refLen || fl < 1) break;
+          const double d = cond_cdf(refLen, fl) - prev; prev = cond_cdf(refLen, fl);
+          const uint32_t* h = &hist[(p * nslots + j) * 75];
+          for (int b = 0; b < 75; ++b) E[b] += d * (double)h[b];
+        }
+        for (int b = 0; b < 75; ++b) contrib[b][p] = weight[p] * E[b];
+      }
+      double expect[75]; for (int b = 0; b < 75; ++b) expect[b] = canonical_sum_vec(contrib[b]);
+      auto normalize = [](const double* in, double* out) { double row = 0.0; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) row += (0.1 + in[b]);
+        if (row > 0.0) { const double nrm = 1.0 / row; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) out[b] = (0.1 + in[b]) * nrm; } else for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) out[b] = in[b]; };
+      for (int r = 0; r < SQ_GC_COND_BINS; ++r) { double on[25], en[25]; normalize(gc_obs + r * 25, on); normalize(expect + r * 25, en);
+        for (int b = 0; b < 25; ++b) { double rat = on[b] / en[b]; if (rat > 1000.0) rat = 1000.0; if (rat < 1.0 / 1000.0) rat = 1.0 / 1000.0; bias[r * 25 + b] = rat; } }
+    }
+    // ---- effective lengths, in groups of transcripts whose factors fit the scratch ----
+    EffArgs A; A.fld_low = fldLow; A.fld_high = fldHigh; A.samp = samp; A.use_gc = use_gc ? 1 : 0; memcpy(A.bias, bias, sizeof(bias));
+    const uint64_t CH = 64ull << 20;   // positions per group
+    std::vector<double> effh;
+    for (size_t p0 = 0; p0 < P;) {
+      size_t p1 = p0; uint64_t tot = 0; std::vector<uint64_t> foff;
+      while (p1 < P && (p1 == p0 || tot + idx->ref_len[list[p1]] <= CH)) { foff.push_back(tot); tot += idx->ref_len[list[p1]]; ++p1; }
+      const size_t np = p1 - p0;
+      if (d_sfw.ensure(tot + 8) || d_src.ensure(tot + 8) || d_foff.ensure(np) || d_eff.ensure(np)) { sq_set_error("device allocation failed (sequence-bias factors)"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemcpy(d_foff.p, foff.data(), np * 8, hipMemcpyHostToDevice));
+      k_seq_factors<<<dim3(8, (uint32_t)np), 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, d_models.p, d_sfw.p, d_src.p);
+      k_seq_efflen<<<(uint32_t)np, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, d_sfw.p, d_src.p, d_cdf.p, A, d_eff.p);
+      effh.resize(np); SQ_HIP_CHECK(hipMemcpy(effh.data(), d_eff.p, np * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < np; ++i) { const uint32_t t = list[p0 + i];
+        const double offset = std::max(1.0, (double)unproc[t]), noBias = (double)elen[t];
+        eff_out[t] = std::max(effh[i], std::min(noBias, offset)); }
+      p0 = p1;
+    }
+  }
+  if (rep) { rep->num_processed = (uint32_t)P; rep->fld_low = fldLow; rep->fld_high = fldHigh; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) rep->gc_bias_row0[b] = bias[b]; }
+  return SQ_OK;
+}
+
 const std::vector<uint32_t>& sq_index_gc_prefix(sq_index* idx) {
   if (idx->gcpre.size() != idx->refseq.size() + 1) {
     idx->gcpre.assign(idx->refseq.size() + 1, 0);

@@ -13,6 +13,7 @@
 // The equivalence-class table is an HBM open-addressing table keyed by a 128-bit label hash.
 #include "ctx.h"
 #include "scan_kernels.h"
+#include "sq_rng.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -79,6 +80,8 @@ struct sq_online_dev {
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
   sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
+  sq_dbuf<unsigned long long> seq_obs;   // --seqBias: observed context counts [FW 576 | RC 576] + [1152] fragments sampled so far
+  sq_dbuf<uint32_t> seq_flag; sq_dbuf<uint64_t> seq_pref, seq_code;
 };
 
 namespace {
@@ -536,6 +539,69 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   __syncthreads();
   if (threadIdx.x < 64 && s_lib[threadIdx.x]) atomicAdd(&V.lib_counts[threadIdx.x], s_lib[threadIdx.x]);
   if (threadIdx.x == 64 && s_cf) atomicAdd(&V.ctr[5], s_cf);
+}
+
+// ---- --seqBias: observed read-start context models (SalmonQuantify.cpp:1668-1747; SPEC §B2) ----------------------------------------
+// One alignment of every paired-end fragment is drawn; a qualifying draw yields two 9-base contexts.  Pass 1 decides per fragment and
+// keeps the two context codes, an exclusive scan ranks the successes in read order, pass 2 counts the first num_bias_samples of them.
+__device__ inline uint32_t sbo_ctx(const uint64_t* refseq, uint64_t g, int32_t p) { const uint64_t w = sq_fetch_bases(refseq, g + (uint64_t)p, 9); uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v = (v << 2) | (uint32_t)((w >> (2 * i)) & 3u); return v; }
+__device__ inline uint32_t sbo_rc(uint32_t v) { uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { r = (r << 2) | (3u - (v & 3u)); v >>= 2; } return r; }
+__device__ inline uint32_t sbo_cell(uint32_t v, int i) { const int order = i == 0 ? 0 : (i == 1 ? 1 : 2); return (uint32_t)i * 64u + ((v >> (18 - 2 * (i + 1))) & ((1u << (2 * (order + 1))) - 1u)); }
+__global__ void k_seq_pick(uint32_t n, int paired_lib, uint64_t read0, uint64_t seed, const uint64_t* __restrict__ aln_off, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len,
+                           const uint64_t* __restrict__ refseq, const uint64_t* __restrict__ ref_accum, uint32_t* __restrict__ flag, uint64_t* __restrict__ code) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  uint32_t ok = 0; uint64_t cd = 0;
+  if (r < n) {
+    const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1]; const uint32_t na = (uint32_t)(a1 - a0);
+    if (na) {
+      const uint64_t x = sq_mix64((seed ^ 0x5EB1A5ULL) ^ sq_mix64((read0 + r) * 0x9E3779B97F4A7C15ULL + 1));
+      const uint32_t pick = (uint32_t)sq_mulhi64(x, (uint64_t)na + 1);
+      if (pick < na) {
+        const sq_aln h = aln[a0 + pick];
+        if (!paired_lib) {   // single-end library (SalmonQuantify.cpp:2211-2257): one context
+          const int32_t RL = (int32_t)ref_len[h.tid]; const int32_t sp = h.fwd ? h.pos : h.pos + (int32_t)h.read_len; const bool rc = !h.fwd;
+          const int32_t b = rc ? 5 : 3, a = rc ? 3 : 5;
+          if (sp > 0 && sp < RL && sp >= b && sp + a < RL) {
+            uint32_t cx = sbo_ctx(refseq, ref_accum[h.tid], sp - b); if (rc) cx = sbo_rc(cx);
+            ok = 1; cd = (uint64_t)cx | ((uint64_t)(h.fwd ? 1 : 0) << 36) | (1ULL << 37);
+          }
+        } else
+        if (h.mate_status == SQ_MS_PAIRED_END_PAIRED && h.fwd != h.mate_fwd) {
+          const int32_t RL = (int32_t)ref_len[h.tid];
+          const int32_t s1 = h.fwd ? h.pos : h.pos + (int32_t)h.read_len - 1, s2 = h.mate_fwd ? h.mate_pos : h.mate_pos + (int32_t)h.mate_len - 1;
+          const bool rc1 = !h.fwd, rc2 = !h.mate_fwd;
+          const int32_t b1 = rc1 ? 5 : 3, c1 = rc1 ? 3 : 5, b2 = rc2 ? 5 : 3, c2 = rc2 ? 3 : 5;
+          const int32_t fwPos = h.fwd ? s1 : s2, rcPos = h.fwd ? s2 : s1;
+          if (s1 > 0 && s1 < RL && s2 > 0 && s2 < RL && s1 >= b1 && s1 + c1 < RL && s2 >= b2 && s2 + c2 < RL && fwPos < rcPos) {
+            const uint64_t g = ref_accum[h.tid];
+            uint32_t left = sbo_ctx(refseq, g, s1 - b1), right = sbo_ctx(refseq, g, s2 - b2);
+            if (rc1) left = sbo_rc(left); else right = sbo_rc(right);
+            ok = 1; cd = (uint64_t)left | ((uint64_t)right << 18) | ((uint64_t)(h.fwd ? 1 : 0) << 36);
+          }
+        }
+      }
+    }
+  }
+  flag[r] = ok; if (r < n) code[r] = cd;
+}
+__global__ void k_seq_count(uint32_t n, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ pref, const uint64_t* __restrict__ code, uint64_t cap,
+                            unsigned long long* __restrict__ obs /* [1152] counts + [1152] sampled so far */) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || !flag[r]) return;
+  const uint64_t before = obs[1152];                      // successes of earlier batches (updated by k_seq_close after this launch)
+  if (before + pref[r] >= cap) return;
+  const uint64_t cd = code[r]; const uint32_t left = (uint32_t)(cd & 0x3FFFFu), right = (uint32_t)((cd >> 18) & 0x3FFFFu); const bool fwd = (cd >> 36) & 1, single = (cd >> 37) & 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { atomicAdd(&obs[(fwd ? 0 : 576) + sbo_cell(left, i)], 1ULL); if (!single) atomicAdd(&obs[(fwd ? 576 : 0) + sbo_cell(right, i)], 1ULL); }
+}
+__global__ void k_seq_close(uint32_t n, const uint64_t* __restrict__ pref, uint64_t cap, unsigned long long* __restrict__ obs) {
+  if (blockIdx.x || threadIdx.x) return;
+  unsigned long long v = obs[1152] + pref[n]; obs[1152] = v > cap ? cap : v;
 }
 
 // ---- [r3] after burn-in: the model-independent half of a mini-batch, once per mapped batch -----------------------------------------
@@ -1030,7 +1096,7 @@ int sq_online_create(sq_ctx* c) {
                  o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
              o->tk1.ensure(cap) || o->tk2.ensure(cap) || o->tcount.ensure(cap) || o->tpool.ensure(cap) || o->tn.ensure(cap) ||
                  o->pool_tid.ensure(o->pool_cap) ||
-                 o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4);
+                 o->pool_bin.ensure(o->pool_cap) || o->pool_wq.ensure(o->pool_cap) || o->pool_cursor.ensure(4) || o->seq_obs.ensure(1160);
   if (bad) { sq_set_error("device allocation failed (online model / eq table)"); return SQ_ERR_NOMEM; }
   const sq_quant_opts& q = c->opts;
   o->detect_active = q.lib_autodetect != 0;
@@ -1080,6 +1146,7 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8));
   SQ_HIP_CHECK(hipMemset(o->gc_obs.p, 0, (SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) * 8));
   SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, (size_t)W * 1024 * 4));
+  SQ_HIP_CHECK(hipMemset(o->seq_obs.p, 0, 1160 * 8));
   SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemset(o->tk1.p, 0xFF, cap * 8));
@@ -1101,7 +1168,7 @@ void sq_online_free(sq_ctx* c) {
   o->log_eff_len.free_();
   o->tlc.free_();
   o->pre.free_();
-  o->alp.free_(); o->dyn.free_();
+  o->alp.free_(); o->dyn.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
   o->fm_table.free_();
   o->cfac.free_();
   o->scal.free_();
@@ -1294,6 +1361,13 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
   sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
+  if (q.seq_bias) {   // observed read-start contexts of this batch (order-free integer counts, capped in read order)
+    if (o->seq_flag.ensure((size_t)n + 2) || o->seq_pref.ensure((size_t)n + 2) || o->seq_code.ensure((size_t)n + 2)) { sq_set_error("device allocation failed (sequence-bias samples)"); return SQ_ERR_NOMEM; }
+    k_seq_pick<<<nblk(n + 1), TB, 0, st>>>(n, q.lib_type == 1 ? 1 : 0, c->reads_seen, q.seed, d_aln_off, d_aln, c->di->ref_len, c->di->refseq, c->di->ref_accum, o->seq_flag.p, o->seq_code.p);
+    sqk::exclusive_scan_u32_u64(o->seq_flag.p, o->seq_pref.p, n, (uint64_t*)o->scan_tmp.p, st);
+    k_seq_count<<<nblk(n), TB, 0, st>>>(n, o->seq_flag.p, o->seq_pref.p, o->seq_code.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
+    k_seq_close<<<1, 64, 0, st>>>(n, o->seq_pref.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
+  }
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
@@ -1480,6 +1554,16 @@ extern "C" int sq_model_fetch_gc_observed(sq_ctx* c, double* out75) {
   unsigned long long h[SQ_GC_COND_BINS * SQ_GC_FRAG_BINS];
   SQ_HIP_CHECK(hipMemcpy(h, c->online->gc_obs.p, sizeof(h), hipMemcpyDeviceToHost));
   for (int i = 0; i < SQ_GC_COND_BINS * SQ_GC_FRAG_BINS; ++i) out75[i] = sq_from_fixed(h[i], 32);
+  return SQ_OK;
+}
+
+extern "C" int sq_model_fetch_seq_observed(sq_ctx* c, uint64_t* fw576, uint64_t* rc576, uint64_t* nsamples) {
+  if (!c || !fw576 || !rc576) return SQ_ERR_ARG;
+  if (!c->opts.seq_bias) { sq_set_error("sq_model_fetch_seq_observed: the context was created without seq_bias"); return SQ_ERR_STATE; }
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long h[1153]; SQ_HIP_CHECK(hipMemcpy(h, c->online->seq_obs.p, sizeof(h), hipMemcpyDeviceToHost));
+  memcpy(fw576, h, 576 * 8); memcpy(rc576, h + 576, 576 * 8); if (nsamples) *nsamples = h[1152];
   return SQ_OK;
 }
 

@@ -38,6 +38,9 @@ def lib():
         L.orc_state_gc_observed.argtypes = [vp, vp]
         L.orc_bias_gc_eff_lengths.restype = C.c_int; L.orc_bias_gc_eff_lengths.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
         L.orc_em_optimize_gc.restype = C.c_int; L.orc_em_optimize_gc.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, vp, vp, vp, vp, P(capi.EmReport)]
+        L.orc_state_seq_observed.argtypes = [vp, vp, vp, P(C.c_uint64)]
+        L.orc_bias_seq_eff_lengths.restype = C.c_int; L.orc_bias_seq_eff_lengths.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
+        L.orc_em_optimize_bias.restype = C.c_int; L.orc_em_optimize_bias.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, vp, vp, vp, vp, vp, vp, P(capi.EmReport)]
         L.orc_state_summary.argtypes = [vp, P(capi.ModelSummary)]
         L.orc_state_lib_counts.argtypes = [vp, vp]
         L.orc_state_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -122,6 +125,10 @@ class OrcState:
     def finish(self):
         lib().orc_state_finish(self.h)
 
+    def seq_observed(self):
+        fw = np.zeros(576, np.uint64); rc = np.zeros(576, np.uint64); n = C.c_uint64()
+        lib().orc_state_seq_observed(self.h, fw.ctypes.data, rc.ctypes.data, C.byref(n)); return fw, rc, int(n.value)
+
     def gc_observed(self):
         g = np.zeros(75); lib().orc_state_gc_observed(self.h, g.ctypes.data); return g.reshape(3, 25)
 
@@ -197,6 +204,25 @@ def bias_gc_eff_lengths(oidx, gc_obs, log_pmf, alphas, eff_in):
     a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); bias = np.zeros(25)
     n = lib().orc_bias_gc_eff_lengths(oidx.h, g.ctypes.data, lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, bias.ctypes.data)
     return out, dict(num_processed=n, gc_bias=bias)
+
+
+def bias_seq_eff_lengths(oidx, seq_fw, seq_rc, log_pmf, alphas, eff_in, gc_obs=None):
+    fw = np.ascontiguousarray(seq_fw, np.uint64); rc = np.ascontiguousarray(seq_rc, np.uint64); lp = np.ascontiguousarray(log_pmf, np.float64)
+    a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); models = np.zeros((4, 576))
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1) if gc_obs is not None else None
+    n = lib().orc_bias_seq_eff_lengths(oidx.h, 1 if g is not None else 0, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data, len(a),
+        a.ctypes.data, e.ctypes.data, out.ctypes.data, models.ctypes.data)
+    return out, models, dict(num_processed=n)
+
+
+def em_optimize_bias(eq, eff_len, projected, oidx, seq_fw, seq_rc, log_pmf, gc_obs=None, opts=None):
+    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len, projected)
+    fw = np.ascontiguousarray(seq_fw, np.uint64); rc = np.ascontiguousarray(seq_rc, np.uint64); lp = np.ascontiguousarray(log_pmf, np.float64)
+    g = np.ascontiguousarray(gc_obs, np.float64).reshape(-1) if gc_obs is not None else None
+    out = np.zeros(txp.num_txp); eff = np.zeros(txp.num_txp); rep = capi.EmReport()
+    rc_ = lib().orc_em_optimize_bias(C.byref(t), C.byref(txp), C.byref(o), oidx.h, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data,
+        out.ctypes.data, eff.ctypes.data, C.byref(rep))
+    return out, eff, dict(iters=rep.iters, converged=bool(rep.converged), rc=rc_, num_degenerate=rep.num_degenerate)
 
 
 def em_optimize_gc(eq, eff_len, projected, oidx, gc_obs, log_pmf, opts=None):

@@ -88,3 +88,63 @@ def test_cli_gcbias_writes_corrected_effective_lengths(built, tmp_path):
     assert json.load(open(tmp_path / "gc" / "aux_info" / "meta_info.json"))["gc_bias_correct"] is True
     r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "U", "-r", os.path.join(g, "reads_1.fq.gz"), "-o", str(tmp_path / "se"), "--gcBias"], capture_output=True, text=True)
     assert r.returncode != 0 and "paired-end" in r.stderr
+
+
+@pytest.mark.parametrize("with_gc", [False, True])
+def test_seq_bias_models_effective_lengths_and_em_match_checker(small_world, with_gc):
+    """--seqBias (alone and with --gcBias): the observed read-start context models collected by the online stage (one sampled alignment per
+    fragment, first num_bias_samples in read order), the expected context models, the expected GC model with its context bins, the
+    corrected effective lengths and the EM with the bias hook — HIP path vs the checker, bit for bit (SPEC §B2)."""
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(seq_bias=1, gc_bias=1 if with_gc else 0, num_bias_samples=2500, mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=3000)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ost = orc.OrcState(w["oidx"], opts)
+    for lo in (0, 2000):   # two batches: the cap of 2500 sampled fragments falls inside the second
+        hi = lo + 2000
+        s = w["seq"][lo * 200: hi * 200]; o = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        rb = api.make_read_batch(s, o, hi - lo, paired=True)
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+    ost.finish()
+    fw_g, rc_g, n_g = ctx.seq_observed(); fw_c, rc_c, n_c = ost.seq_observed()
+    assert n_g == n_c == 2500 and np.array_equal(fw_g, fw_c) and np.array_equal(rc_g, rc_c)
+    assert int(fw_g[:4].sum()) == 2500 and int(rc_g[:4].sum()) == 2500          # every sampled fragment adds one context to each model (column 0 has 4 cells)
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    lm, uq, tc, le = ctx.model(); fld = ctx.fld(); mc = ost.model()
+    assert np.array_equal(fld, mc[4])
+    gcg = ctx.gc_observed() if with_gc else None; gcc = ost.gc_observed() if with_gc else None
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
+    e_g, m_g, r_g = api.bias_seq_eff_lengths(w["idx"], fw_g, rc_g, fld, a0, eff, gc_obs=gcg)
+    e_c, m_c, r_c = orc.bias_seq_eff_lengths(w["oidx"], fw_c, rc_c, mc[4], a0, eff, gc_obs=gcc)
+    assert r_g["num_processed"] == r_c["num_processed"] > 50
+    for k, name in enumerate(["expected fw", "expected rc", "observed fw", "observed rc"]):
+        assert np.array_equal(m_g[k], m_c[k]), name
+    assert np.array_equal(e_g, e_c) and np.all(e_g > 0) and np.any(np.abs(e_g - eff) > 0.5)
+    # conditional probabilities: every context's four cells sum to one
+    p = np.exp(m_g[2].reshape(9, 64)); assert abs(p[0, :4].sum() - 1) < 1e-9 and abs(p[5, 8:12].sum() - 1) < 1e-9
+    al_g, ef_g, rep_g = ctx.em_optimize_seq(eff, proj, fw_g, rc_g, fld, gc_obs=gcg)
+    al_c, ef_c, rep_c = orc.em_optimize_bias(eq_c, eff, proj, w["oidx"], fw_c, rc_c, mc[4], gc_obs=gcc)
+    assert rep_g["iters"] == rep_c["iters"] and np.array_equal(ef_g, ef_c) and np.array_equal(al_g, al_c)
+    ctx.free(); ost.free()
+
+
+def test_seq_bias_single_end_library_matches_checker(small_world):
+    # single-end libraries sample one context per read (SalmonQuantify.cpp:2211-2257: the start of a reverse read is pos + readLen there)
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(seq_bias=1, mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=3000); api.set_libtype(opts, "U")
+    n = 3000
+    s = np.concatenate([w["seq"][(2 * j) * 100:(2 * j + 1) * 100] for j in range(n)]); o = np.arange(0, n + 1, dtype=np.uint64) * np.uint64(100)
+    rb = api.make_read_batch(s, o, n, paired=False)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8)
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    fw_g, rc_g, n_g = ctx.seq_observed(); fw_c, rc_c, n_c = ost.seq_observed()
+    assert n_g == n_c > 1000 and np.array_equal(fw_g, fw_c) and np.array_equal(rc_g, rc_c)
+    assert int(fw_g[:4].sum() + rc_g[:4].sum()) == n_g                       # one context per sampled read, in one of the two models
+    eq_g = ctx.eq_finish(); lm, uq, tc, le = ctx.model(); fld = ctx.fld()
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
+    e_g, m_g, r_g = api.bias_seq_eff_lengths(w["idx"], fw_g, rc_g, fld, a0, eff)
+    e_c, m_c, r_c = orc.bias_seq_eff_lengths(w["oidx"], fw_c, rc_c, ost.model()[4], a0, eff)
+    assert np.array_equal(m_g, m_c) and np.array_equal(e_g, e_c)
+    ctx.free(); ost.free()
