@@ -835,6 +835,7 @@ struct QuantState {
   std::vector<uint64_t> libCounts;
   uint64_t gcObs[75] = {0};   // observedGCMass (SalmonQuantify.cpp:938-972): sums of the normalised alignment probabilities, fixed point 2^-32 (order-free)
   uint64_t readCounter = 0;
+  std::vector<int32_t> condMeans;   // conditional fragment-length means of the PRIOR distribution (ReadExperiment.inl:25-43), used by single-end --gcBias
   uint64_t seqObs[2][576] = {{0}}; uint64_t seqSamples = 0;   // observed read-start context counts (SBModel cells [position][context]; FW, RC) and fragments sampled so far (SPEC §B2)
   // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
@@ -896,6 +897,11 @@ struct QuantState {
         cum = sq_log_add(cum, fld.hist[j]);
         liveCMF[j] = cum - fld.totMass;
       }
+    }
+    {   // correctionFactorsFromMass over the prior's normalised pmf (x 100), lengths 1..999
+      double sum = SQ_LOG_0; for (int j = 1; j <= 1000; ++j) sum = sq_log_add(sum, fld.pmf(j));
+      condMeans.assign(1001, 0); double vals = 0.0, mult = 0.0;
+      for (int j = 1; j <= 1000; ++j) { const double p = j < 1000 ? 100.0 * sq_exp(fld.pmf(j) - sum) : 0.0; vals = p * (double)j + vals; mult = p + mult; condMeans[j] = (int32_t)(mult > 0 ? vals / mult : 0.0); }
     }
     mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
     // Transcript.hpp:48-56, ReadExperiment.inl:114
@@ -1110,6 +1116,11 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
         int32_t start = std::min(a.pos, a.mate_pos), stop = start + (int32_t)a.frag_len - 1, ff, cf;
         if (start >= 0 && stop < (int32_t)ix.ref_len[tids[i]] && stop >= start && gc_desc(ix, tids[i], start, stop, &ff, &cf))
           S.gcObs[gc_ctx_bin(cf) * 25 + gc_frag_bin(ff)] += sq_to_fixed(pr, 32);
+      } else if (o.gc_bias && o.lib_type == T_SE) {   // :952-971: a single-end library takes every fragment to have the conditional mean length
+        const sq_aln& a = *ka[i]; const int32_t RL = (int32_t)ix.ref_len[tids[i]];
+        const int32_t cmean = S.condMeans[RL >= 1001 ? 1000 : RL];
+        const int32_t start = a.fwd ? a.pos : std::max(0, a.pos - cmean), stop = start + cmean; int32_t ff, cf;
+        if (start >= 0 && stop < RL && gc_desc(ix, tids[i], start, stop, &ff, &cf)) S.gcObs[gc_ctx_bin(cf) * 25 + gc_frag_bin(ff)] += sq_to_fixed(pr, 32);
       }
       if (!burned) {
         double rr = u01(o.seed, readIdx, i);

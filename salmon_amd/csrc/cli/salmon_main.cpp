@@ -354,7 +354,6 @@ static int cmd_quant(int argc, char** argv) {
   qo.lib_strand = li->second[2];
   qo.lib_autodetect = autodetect ? 1 : 0;
   const bool gc_bias = flag(argc, argv, "--gcBias");
-  if (gc_bias && !paired) { fprintf(stderr, "[salmon-hip] --gcBias is implemented for paired-end libraries (the single-end form needs the conditional fragment means)\n"); return 1; }
   qo.gc_bias = gc_bias ? 1 : 0;
   const bool seq_bias = flag(argc, argv, "--seqBias");
   qo.seq_bias = seq_bias ? 1 : 0;

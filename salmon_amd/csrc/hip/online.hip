@@ -78,6 +78,7 @@ struct sq_online_dev {
   // `-l A` (SPEC §D8): per-format sample counts of the mini-batches seen so far while detection is active
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
+  sq_dbuf<int32_t> cmeans;   // conditional fragment-length means of the prior distribution [1001] (single-end --gcBias)
   sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
   sq_dbuf<unsigned long long> seq_obs;   // --seqBias: observed context counts [FW 576 | RC 576] + [1152] fragments sampled so far
@@ -188,7 +189,7 @@ enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEX
 __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len,
     const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
     PreAln* __restrict__ pre, const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
-    uint8_t* __restrict__ gcbin) {
+    uint8_t* __restrict__ gcbin, const int32_t* __restrict__ cmeans) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
   const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
@@ -225,6 +226,12 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
       const int32_t start = a.pos < a.mate_pos ? a.pos : a.mate_pos, stop = start + (int32_t)a.frag_len - 1;
       int32_t ff, cf;
       if (start >= 0 && stop < (int32_t)rl && stop >= start && sq_gc_desc(refseq, gcpre, ref_accum[a.tid], (int32_t)rl, start, stop, &ff, &cf))
+        b = (uint8_t)(sq_gc_ctx_bin(cf) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(ff));
+    } else if (o.lib_type == 0) {   // :952-971: a single-end library takes every fragment to have the conditional mean length of the prior
+      const int32_t cmean = cmeans[rl >= 1001 ? 1000 : rl];
+      int32_t start = a.fwd ? a.pos : a.pos - cmean; if (!a.fwd && start < 0) start = 0;
+      const int32_t stop = start + cmean; int32_t ff, cf;
+      if (start >= 0 && stop < (int32_t)rl && sq_gc_desc(refseq, gcpre, ref_accum[a.tid], (int32_t)rl, start, stop, &ff, &cf))
         b = (uint8_t)(sq_gc_ctx_bin(cf) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(ff));
     }
     gcbin[ai] = b;
@@ -1132,6 +1139,13 @@ int sq_online_create(sq_ctx* c) {
     pm[t] = sq_log(0.005 * len);
     le[t] = sq_log(len);
   }
+  {   // conditional means of the prior (ReadExperiment.inl:25-43: correctionFactorsFromMass over its normalised pmf x 100, lengths 1..999)
+    if (o->cmeans.ensure(1024)) { sq_set_error("device allocation failed (conditional means)"); return SQ_ERR_NOMEM; }
+    double sum = SQ_LOG_0; for (int j = 1; j <= 1000; ++j) sum = sq_log_add(sum, hist[j] - tot0);
+    std::vector<int32_t> cm(1024, 0); double vals = 0.0, mult = 0.0;
+    for (int j = 1; j <= 1000; ++j) { const double p = j < 1000 ? 100.0 * sq_exp((hist[j] - tot0) - sum) : 0.0; vals = p * (double)j + vals; mult = p + mult; cm[j] = (int32_t)(mult > 0 ? vals / mult : 0.0); }
+    SQ_HIP_CHECK(hipMemcpy(o->cmeans.p, cm.data(), 1024 * 4, hipMemcpyHostToDevice));
+  }
   SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
@@ -1168,7 +1182,7 @@ void sq_online_free(sq_ctx* c) {
   o->log_eff_len.free_();
   o->tlc.free_();
   o->pre.free_();
-  o->alp.free_(); o->dyn.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
+  o->alp.free_(); o->dyn.free_(); o->cmeans.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
   o->fm_table.free_();
   o->cfac.free_();
   o->scal.free_();
@@ -1356,7 +1370,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   sq_prof_begin(c, 1);
   uint8_t* d_gcbin = q.gc_bias ? o->gcbin.p : nullptr;
   if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
-      (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
+      (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
@@ -1450,7 +1464,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         const uint32_t rs = r1;
         assigned_base = assigned_after;
         if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p,
-            c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin);
+            c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p);
         k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, rs, d_aln_off, d_aln, q, o->assigned_flag.p);
         sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
         // the mini-batches still to come read rh1/rh2 only after writing them: rh2 doubles as the bounds scratch again

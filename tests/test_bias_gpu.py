@@ -148,3 +148,23 @@ def test_seq_bias_single_end_library_matches_checker(small_world):
     e_c, m_c, r_c = orc.bias_seq_eff_lengths(w["oidx"], fw_c, rc_c, ost.model()[4], a0, eff)
     assert np.array_equal(m_g, m_c) and np.array_equal(e_g, e_c)
     ctx.free(); ost.free()
+
+
+def test_gc_bias_single_end_library_matches_checker(small_world):
+    # a single-end library observes every fragment at the conditional mean length of the prior distribution (SalmonQuantify.cpp:952-971)
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(gc_bias=1, mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=3000); api.set_libtype(opts, "U")
+    n = 3000
+    s = np.concatenate([w["seq"][(2 * j) * 100:(2 * j + 1) * 100] for j in range(n)]); o = np.arange(0, n + 1, dtype=np.uint64) * np.uint64(100)
+    rb = api.make_read_batch(s, o, n, paired=False)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8)
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    g_g, g_c = ctx.gc_observed(), ost.gc_observed()
+    assert np.array_equal(g_g, g_c) and g_g.sum() > 0.3 * n
+    eq_g = ctx.eq_finish(); lm, uq, tc, le = ctx.model(); fld = ctx.fld()
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
+    e_g, r_g = api.bias_gc_eff_lengths(w["idx"], g_g, fld, a0, eff); e_c, r_c = orc.bias_gc_eff_lengths(w["oidx"], g_c, ost.model()[4], a0, eff)
+    assert np.array_equal(e_g, e_c) and np.array_equal(r_g["gc_bias"], r_c["gc_bias"])
+    ctx.free(); ost.free()
