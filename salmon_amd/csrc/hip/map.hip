@@ -393,7 +393,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
   sq_prof_begin(c);
-  k_pack<<<nblk((uint64_t)nrec * 8), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
+  k_pack<<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
   sq_prof_mark(c, SG_PACK);
   {  // persistent grid: 256 CUs x 6 blocks of 256 threads; lanes pull read ends from counters[2].  The probe rate is
      // bound by the memory system, not by occupancy (4..8 blocks/CU measure the same), so two blocks' worth of wave

@@ -68,46 +68,53 @@ __device__ inline uint32_t wave_alloc(uint32_t* ctr) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 8 threads per record, 32 bases each: adjacent lanes read adjacent 32-byte runs (coalesced)
-__global__ void k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
+// [r3] one thread per read end: its (up to) eight 32-base words are loaded with 16-byte loads that are all in flight together, packed
+// in registers and stored as 16-byte pairs.  (Round 2 used 8 threads per end, one word each: 128 M threads per 8 M pairs whose two
+// dependent round trips — offsets, then bases — set the pace at 2.2 ms; here a wave covers 64 ends and there are 8x fewer waves.)
+__global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
                        uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, unsigned long long* __restrict__ stats) {
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t e = (uint32_t)(gid >> 3), wi = (uint32_t)(gid & 7);
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrec) return;
-  uint64_t a = seq_off[e], b = seq_off[e + 1];
+  const uint64_t a = seq_off[e], b = seq_off[e + 1];
   uint32_t L = (uint32_t)(b - a);
-  if (L > SQ_MAX_READ_LEN) { L = SQ_MAX_READ_LEN; if (wi == 0) atomicAdd(&stats[ST_TRUNC], 1ULL); }   // rare by construction (RNA-seq reads are 50-250 bases)
-  const uint8_t* s = seq + a + 32 * wi;
-  uint64_t cw = 0; uint32_t cn = 0;
-  const uint32_t lo = 32 * wi; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);
-  // branch-free base code: upper-case, then (x >> 1) & 3 maps A,C,T,G -> 0,1,2,3; x ^ (x >> 1) swaps the last two
-  auto put = [&](uint32_t i, uint32_t ch) {
-    const uint32_t x = ch & 0xDFu;
-    const uint32_t ok = (x == 0x41u) | (x == 0x43u) | (x == 0x47u) | (x == 0x54u);
-    const uint32_t c2 = (x >> 1) & 3u; const uint32_t c = c2 ^ (c2 >> 1);
-    cw |= (uint64_t)(ok ? c : 0u) << (i * 2); cn |= (ok ^ 1u) << i;
-  };
-  if (cnt == 32 && (((uintptr_t)s) & 3) == 0) {
-    // [r3] the lane's 32 bytes as two 16-byte loads (dword-aligned is enough for global_load_dwordx4): a quarter of the load instructions
-    struct __attribute__((packed, aligned(4))) Q4 { uint32_t v[4]; };
-    const Q4 q0 = *(const Q4*)s, q1 = *(const Q4*)(s + 16);
+  if (L > SQ_MAX_READ_LEN) { L = SQ_MAX_READ_LEN; atomicAdd(&stats[ST_TRUNC], 1ULL); }   // rare by construction (RNA-seq reads are 50-250 bases)
+  const uint8_t* s = seq + a;
+  struct __attribute__((packed, aligned(4))) Q4 { uint32_t v[4]; };
+  // reads start at any byte (2x150: every other record is 2 mod 4): dwords are loaded from the aligned address below and funnel-shifted;
+  // the dword past a full word is only touched when it lies inside the batch's buffer (not for the last record)
+  const uint32_t mis = (uint32_t)(((uintptr_t)s) & 3); const uint8_t* s0 = s - mis; const bool wide = mis == 0 || e + 1 < nrec;
+  uint64_t cw[SQ_READ_WORDS]; uint32_t cn[SQ_READ_WORDS];
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) {
-      const uint32_t v = q < 4 ? q0.v[q] : q1.v[q - 4];
-      put(4 * q, v & 0xFF);
-      put(4 * q + 1, (v >> 8) & 0xFF);
-      put(4 * q + 2, (v >> 16) & 0xFF);
-      put(4 * q + 3, v >> 24);
+  for (uint32_t w = 0; w < SQ_READ_WORDS; ++w) {
+    cw[w] = 0; cn[w] = 0;
+    const uint32_t lo = 32 * w; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);
+    // branch-free base code: upper-case, then (x >> 1) & 3 maps A,C,T,G -> 0,1,2,3; x ^ (x >> 1) swaps the last two
+    auto put = [&](uint32_t i, uint32_t ch) {
+      const uint32_t x = ch & 0xDFu;
+      const uint32_t ok = (x == 0x41u) | (x == 0x43u) | (x == 0x47u) | (x == 0x54u);
+      const uint32_t c2 = (x >> 1) & 3u; const uint32_t c = c2 ^ (c2 >> 1);
+      cw[w] |= (uint64_t)(ok ? c : 0u) << (i * 2); cn[w] |= (ok ^ 1u) << i;
+    };
+    if (cnt == 32 && wide) {
+      const Q4 q0 = *(const Q4*)(s0 + lo), q1 = *(const Q4*)(s0 + lo + 16);
+      uint32_t d[9] = {q0.v[0], q0.v[1], q0.v[2], q0.v[3], q1.v[0], q1.v[1], q1.v[2], q1.v[3], 0u};
+      if (mis) d[8] = *(const uint32_t*)(s0 + lo + 32);
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t v = mis ? (uint32_t)((((uint64_t)d[q + 1] << 32) | d[q]) >> (8 * mis)) : d[q];
+        put(4 * q, v & 0xFF); put(4 * q + 1, (v >> 8) & 0xFF); put(4 * q + 2, (v >> 16) & 0xFF); put(4 * q + 3, v >> 24);
+      }
+    } else if (cnt) {
+      for (uint32_t i = 0; i < cnt; ++i) put(i, s[lo + i]);
     }
-  } else if (cnt) {
-    // a partial word (the read's last bases): whole dwords first
-    uint32_t i = 0;
-    if ((((uintptr_t)s) & 3) == 0) for (; i + 4 <= cnt; i += 4) { const uint32_t v = *(const uint32_t*)(s + i); put(i, v & 0xFF); put(i + 1, (v >> 8) & 0xFF); put(i + 2, (v >> 16) & 0xFF); put(i + 3, v >> 24); }
-    for (; i < cnt; ++i) put(i, s[i]);
   }
-  rpack[(size_t)e * SQ_READ_WORDS + wi] = cw;
-  ((uint32_t*)(rnmask + (size_t)e * SQ_NMASK_WORDS))[wi] = cn;
-  if (wi == 0) rlen[e] = (uint16_t)L;
+  sq_u64x2* rp = (sq_u64x2*)(rpack + (size_t)e * SQ_READ_WORDS);
+#pragma unroll
+  for (uint32_t w = 0; w < SQ_READ_WORDS; w += 2) { sq_u64x2 v; v.x = cw[w]; v.y = cw[w + 1]; rp[w / 2] = v; }
+  sq_u64x2* np = (sq_u64x2*)(rnmask + (size_t)e * SQ_NMASK_WORDS);
+#pragma unroll
+  for (uint32_t w = 0; w < SQ_NMASK_WORDS; w += 2) { sq_u64x2 v; v.x = (uint64_t)cn[2 * w] | ((uint64_t)cn[2 * w + 1] << 32); v.y = (uint64_t)cn[2 * w + 2] | ((uint64_t)cn[2 * w + 3] << 32); np[w / 2] = v; }
+  rlen[e] = (uint16_t)L;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -87,7 +87,15 @@ def test_cli_gcbias_writes_corrected_effective_lengths(built, tmp_path):
     assert np.any(np.abs(e1 - e0) > 1.0) and abs(n1.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n1)[0, 1] > 0.99
     assert json.load(open(tmp_path / "gc" / "aux_info" / "meta_info.json"))["gc_bias_correct"] is True
     r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "U", "-r", os.path.join(g, "reads_1.fq.gz"), "-o", str(tmp_path / "se"), "--gcBias"], capture_output=True, text=True)
-    assert r.returncode != 0 and "paired-end" in r.stderr
+    # [r3] single-end libraries are corrected too (fragments taken at the conditional mean length of the prior), and --seqBias with --gcBias
+    assert r.returncode == 0, r.stderr[-800:]
+    assert json.load(open(tmp_path / "se" / "aux_info" / "meta_info.json"))["gc_bias_correct"] is True
+    r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "IU", "-1", os.path.join(g, "reads_1.fq.gz"), "-2", os.path.join(g, "reads_2.fq.gz"),
+                        "-o", str(tmp_path / "sg"), "--gcBias", "--seqBias"], capture_output=True, text=True)
+    assert r.returncode == 0 and "fragments sampled for the read-start context models" in r.stderr, r.stderr[-800:]
+    m = json.load(open(tmp_path / "sg" / "aux_info" / "meta_info.json")); assert m["gc_bias_correct"] is True and m["seq_bias_correct"] is True
+    n2 = np.array([float(l.split("\t")[4]) for l in open(tmp_path / "sg" / "quant.sf").read().strip().split("\n")[1:]])
+    assert abs(n2.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n2)[0, 1] > 0.98
 
 
 @pytest.mark.parametrize("with_gc", [False, True])
