@@ -152,7 +152,8 @@ typedef struct {
   uint64_t seed;              /* seed of the counter-based RNG for FLD sampling (reference: random_device) */
   uint8_t seq_bias;           /* 0; 1 = --seqBias: collect the observed read-start context models (SBModel) from one sampled alignment per paired-end
                                  fragment (SalmonQuantify.cpp:1668-1747); the expected models and the corrected lengths come from sq_bias_eff_lengths */
-  uint8_t pos_bias;           /* 0; reserved for --posBias */
+  uint8_t pos_bias;           /* 0; 1 = --posBias: collect the observed read-start position models by transcript length class (SimplePosBias,
+                                 SalmonQuantify.cpp:895-934); the expected models and the corrected lengths come from sq_bias_eff_lengths */
   uint8_t _pad3[2];
   uint32_t num_bias_samples;  /* 2,000,000 (SalmonDefaults.hpp numBiasSamples): fragments that contribute to the observed sequence-bias models */
   uint32_t mini_batches_in_flight; /* 8 = the reference's default numThreads (SalmonDefaults.hpp:15): W worker threads each run a mini-batch
@@ -385,6 +386,18 @@ int sq_model_fetch_seq_observed(sq_ctx*, uint64_t* fw576, uint64_t* rc576, uint6
 int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_observed /*[75] or NULL*/, const uint64_t* seq_fw /*[576]*/, const uint64_t* seq_rc,
                             const double* log_pmf_1001, uint32_t num_txp, const double* alphas, const double* eff_len_in, double* eff_len_out,
                             double* models_out, sq_bias_report* report);
+/* --posBias and every combination of the three corrections (SalmonUtils.cpp:1639-1652, 1708-1712, 1815-1835, 1941-1944; SimplePosBias.cpp).
+ * pos_observed: sq_model_fetch_pos_observed's [5' model, 3' model][5 length classes][20 bins]; threads = the reference's numThreads (every
+ * bin of the shared model and of each worker's local copy starts with mass 1, so a model bin starts at 1 + threads).  NULL members switch a
+ * correction off; --gcBias alone takes sq_bias_gc_eff_lengths' path.  seq_models_out as in sq_bias_seq_eff_lengths; pos_models_out (may be
+ * NULL) receives the normalised bin masses [observed 5', observed 3', expected 5', expected 3'][5][20] (SimplePosBias::writeBinary's values). */
+typedef struct { const double* gc_observed; const uint64_t* seq_fw; const uint64_t* seq_rc; const double* pos_observed; uint32_t threads; uint32_t _pad; } sq_bias_models;
+int sq_model_fetch_pos_observed(sq_ctx*, double* out200);
+int sq_bias_eff_lengths(sq_index* idx, const sq_bias_models* models, const double* log_pmf_1001, uint32_t num_txp, const double* alphas, const double* eff_len_in,
+                        double* eff_len_out, double* seq_models_out, double* pos_models_out, sq_bias_report* report);
+/* Transcript::lengthClassIndex (ReadExperiment.inl:352-388): the length quantiles of the non-decoy references and the class of every reference;
+ * returns the number of classes (5, or the number of references when there are no more than 5), < 0 on error. */
+int sq_index_length_classes(const sq_index* idx, uint32_t* quantiles5, uint8_t* cls /* [num_refs] or NULL */);
 /* updateEffectiveLengths as a callback: alphas and current effective lengths in, new effective lengths out; non-zero aborts. */
 typedef int (*sq_efflen_cb)(const double* alphas, const double* eff_len_in, double* eff_len_out, uint32_t m, void* user);
 /* sq_em_optimize with the bias hook: after 11 updates (itNum > 10) `cb` is called once, priors and combined class weights are rebuilt

@@ -823,6 +823,7 @@ static bool gc_desc(const Index& ix, uint32_t t, int32_t s, int32_t e, int32_t* 
 static inline int32_t gc_frag_bin(int32_t f) { double w = 100.0 / 25; return std::min(24, (int32_t)((double)f / w)); }   // GCDesc::fragBin(25)
 static inline int32_t gc_ctx_bin(int32_t f) { double w = 100.0 / 3; return std::min(2, (int32_t)((double)f / w)); }       // GCDesc::contextBin(3)
 
+static void length_classes(const Index& ix, std::vector<uint32_t>& quant, std::vector<uint8_t>& cls);
 struct EqVal { uint64_t count = 0; std::vector<uint64_t> wq; };
 struct QuantState {
   const Index* ix; Opts op;
@@ -836,6 +837,8 @@ struct QuantState {
   uint64_t gcObs[75] = {0};   // observedGCMass (SalmonQuantify.cpp:938-972): sums of the normalised alignment probabilities, fixed point 2^-32 (order-free)
   uint64_t readCounter = 0;
   std::vector<int32_t> condMeans;   // conditional fragment-length means of the PRIOR distribution (ReadExperiment.inl:25-43), used by single-end --gcBias
+  uint64_t posObs[2][100] = {{0}};   // --posBias (SPEC §P): observed read-start masses [5' model, 3' model][length class x 20 bins], fixed point 2^-32
+  std::vector<uint8_t> lenClass;     // Transcript::lengthClassIndex (ReadExperiment.inl:352-388)
   uint64_t seqObs[2][576] = {{0}}; uint64_t seqSamples = 0;   // observed read-start context counts (SBModel cells [position][context]; FW, RC) and fragments sampled so far (SPEC §B2)
   // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
@@ -903,6 +906,7 @@ struct QuantState {
       condMeans.assign(1001, 0); double vals = 0.0, mult = 0.0;
       for (int j = 1; j <= 1000; ++j) { const double p = j < 1000 ? 100.0 * sq_exp(fld.pmf(j) - sum) : 0.0; vals = p * (double)j + vals; mult = p + mult; condMeans[j] = (int32_t)(mult > 0 ? vals / mult : 0.0); }
     }
+    { std::vector<uint32_t> q; length_classes(*ix, q, lenClass); }
     mass.assign(M, SQ_LOG_0); priorMass.resize(M); logEffLen.resize(M); uniq.assign(M, 0); total.assign(M, 0); massAcc.assign(M, 0);
     // Transcript.hpp:48-56, ReadExperiment.inl:114
     for (size_t t = 0; t < M; ++t) {
@@ -1025,6 +1029,63 @@ static void sb_normalize(const double* counts, double* logp) {
   }
 }
 static inline double sb_eval(const double* logp, uint32_t v) { double p = 0.0; for (int i = 0; i < SB_K; ++i) p += logp[sb_cell(v, i)]; return p; }
+// ---- --posBias (SPEC §P) ------------------------------------------------------------------------------------------------------
+// setTranscriptLengthClasses_ (ReadExperiment.inl:352-388): quantiles of the non-decoy lengths (:152, only those are collected), the
+// class of a transcript = the number of quantiles <= its length, capped at the last class
+static void length_classes(const Index& ix, std::vector<uint32_t>& quant, std::vector<uint8_t>& cls) {
+  const size_t M = ix.ref_len.size(), n = std::min<size_t>(ix.first_decoy ? ix.first_decoy : M, M), nbins = 5;
+  std::vector<uint32_t> len(ix.ref_len.begin(), ix.ref_len.begin() + n); std::sort(len.begin(), len.end());
+  quant.clear();
+  if (n > nbins) { const size_t step = n / nbins; size_t cum = 0; for (size_t i = 0; i < nbins; ++i) { cum += step; quant.push_back(len[std::min(cum, n - 1)]); } }
+  else quant = len;
+  cls.assign(M, 0);
+  if (quant.empty()) return;
+  const long maxQ = (long)quant.size() - 1;
+  for (size_t t = 0; t < M; ++t) cls[t] = (uint8_t)std::min<long>(maxQ, std::upper_bound(quant.begin(), quant.end(), ix.ref_len[t]) - quant.begin());
+}
+// SimplePosBias::addMass(pos, length, mass) (SimplePosBias.cpp:20-28): the bin of a read start
+static inline int pos_bin(int32_t pos, uint32_t length) {
+  const double step = (double)length / 20.0; int b = (int)std::floor((double)pos / step); return b > 19 ? 19 : b;   // > 19 is out of the reference's array; unreachable for pos < length
+}
+static inline int32_t pos_clamp(int32_t p, uint32_t rl) { if (p < 0) p = 0; if (p >= (int32_t)rl) p = (int32_t)rl - 1; return p; }
+// SimplePosBias::finalize (SimplePosBias.cpp:51-83) on linear masses + tk::spline's constructor (vendor/upstream/misc/spline.h:264-376:
+// natural cubic spline, band-matrix LU with the rows scaled to a unit diagonal first), operation by operation
+struct PosSpline { double x[22], y[22], a[22], b[22], c[22]; };
+static void pos_spline_build(const double* xs, const double* ys, int n, PosSpline& S) {
+  std::vector<double> lo(n, 0.0), di(n, 0.0), up(n, 0.0), rhs(n, 0.0), sd(n, 0.0);   // A(i,i-1), A(i,i), A(i,i+1)
+  for (int i = 0; i < n; ++i) { S.x[i] = xs[i]; S.y[i] = ys[i]; }
+  for (int i = 1; i < n - 1; ++i) {
+    lo[i] = 1.0 / 3.0 * (xs[i] - xs[i - 1]); di[i] = 2.0 / 3.0 * (xs[i + 1] - xs[i - 1]); up[i] = 1.0 / 3.0 * (xs[i + 1] - xs[i]);
+    rhs[i] = (ys[i + 1] - ys[i]) / (xs[i + 1] - xs[i]) - (ys[i] - ys[i - 1]) / (xs[i] - xs[i - 1]);
+  }
+  di[0] = 2.0; up[0] = 0.0; rhs[0] = 0.0; di[n - 1] = 2.0; lo[n - 1] = 0.0; rhs[n - 1] = 0.0;
+  for (int i = 0; i < n; ++i) { sd[i] = 1.0 / di[i]; if (i > 0) lo[i] *= sd[i]; di[i] *= sd[i]; if (i < n - 1) up[i] *= sd[i]; di[i] = 1.0; }   // preconditioning
+  for (int k = 0; k < n - 1; ++k) { const double x = -lo[k + 1] / di[k]; lo[k + 1] = -x; di[k + 1] = di[k + 1] + x * up[k]; }                   // LU
+  std::vector<double> y(n), b(n);
+  for (int i = 0; i < n; ++i) { double sum = 0; if (i > 0) sum += lo[i] * y[i - 1]; y[i] = (rhs[i] * sd[i]) - sum; }                             // L y = rhs
+  for (int i = n - 1; i >= 0; --i) { double sum = 0; if (i < n - 1) sum += up[i] * b[i + 1]; b[i] = (y[i] - sum) / di[i]; }                      // R b = y
+  for (int i = 0; i < n; ++i) { S.b[i] = b[i]; S.a[i] = 0.0; S.c[i] = 0.0; }
+  for (int i = 0; i < n - 1; ++i) {
+    S.a[i] = 1.0 / 3.0 * (b[i + 1] - b[i]) / (xs[i + 1] - xs[i]);
+    S.c[i] = (ys[i + 1] - ys[i]) / (xs[i + 1] - xs[i]) - 1.0 / 3.0 * (2.0 * b[i] + b[i + 1]) * (xs[i + 1] - xs[i]);
+  }
+  const double h = xs[n - 1] - xs[n - 2]; S.a[n - 1] = 0.0; S.c[n - 1] = 3.0 * S.a[n - 2] * h * h + 2.0 * S.b[n - 2] * h + S.c[n - 2];
+}
+static inline double pos_spline_eval(const PosSpline& S, int n, double x) {   // spline::operator() for x in [x0, x_{n-1}] (:385-402)
+  int idx = (int)(std::lower_bound(S.x, S.x + n, x) - S.x); idx = idx == 0 ? 0 : idx - 1;
+  const double h = x - S.x[idx];
+  return ((S.a[idx] * h + S.b[idx]) * h + S.c[idx]) * h + S.y[idx];
+}
+static const double POS_BINS[20] = {.02, .04, .06, .08, .10, .15, .2, .3, .4, .5, .6, .7, .8, .85, .9, .92, .94, .96, .98, 1.0};
+static void pos_finalize(const double* mass /*[20] linear*/, PosSpline& S, double* norm /*[20] or null*/) {
+  double sum = 0.0; for (int i = 0; i < 20; ++i) sum += mass[i];
+  double ys[22], xs[22]; const double startKnot = mass[0] / sum, stopKnot = mass[19] / sum, splineSum = sum + startKnot + stopKnot;
+  ys[0] = startKnot; for (int i = 0; i < 20; ++i) { ys[i + 1] = mass[i] / splineSum; if (norm) norm[i] = mass[i] / sum; } ys[21] = stopKnot;
+  xs[0] = 0.0; for (int i = 0; i < 20; ++i) xs[i + 1] = POS_BINS[i] - 0.01; xs[21] = 1.0;
+  pos_spline_build(xs, ys, 22, S);
+}
+static inline double pos_weight(const PosSpline& S, int32_t p, int32_t len) { const double f = (double)p / (double)len; return std::max(0.001, pos_spline_eval(S, 22, f)); }   // projectWeights (:32-39)
+
 // the lane-strided sum the device uses for sums over fragment starts (SPEC §B2): lane l of 256 adds the terms l, l + 256, ... in order,
 // then the lanes combine by strided halving
 template <class F> static double lane_sum256(int64_t n, F term) {
@@ -1121,6 +1182,15 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
         const int32_t cmean = S.condMeans[RL >= 1001 ? 1000 : RL];
         const int32_t start = a.fwd ? a.pos : std::max(0, a.pos - cmean), stop = start + cmean; int32_t ff, cf;
         if (start >= 0 && stop < RL && gc_desc(ix, tids[i], start, stop, &ff, &cf)) S.gcObs[gc_ctx_bin(cf) * 25 + gc_frag_bin(ff)] += sq_to_fixed(pr, 32);
+      }
+      if (o.pos_bias) {   // :895-934: read starts by length class, weighted like the masses
+        const sq_aln& a = *ka[i]; const uint32_t RL = ix.ref_len[tids[i]]; const int li = S.lenClass[tids[i]];
+        if (a.mate_status == SQ_MS_PAIRED_END_PAIRED) {
+          if (a.fwd != a.mate_fwd) {
+            const int32_t pf = pos_clamp(a.fwd ? a.pos : a.mate_pos, RL), pr_ = pos_clamp(a.fwd ? a.mate_pos : a.pos, RL);
+            S.posObs[0][li * 20 + pos_bin(pf, RL)] += sq_to_fixed(pr, 32); S.posObs[1][li * 20 + pos_bin(pr_, RL)] += sq_to_fixed(pr, 32);
+          }
+        } else S.posObs[a.fwd ? 0 : 1][li * 20 + pos_bin(pos_clamp(a.pos, RL), RL)] += sq_to_fixed(pr, 32);
       }
       if (!burned) {
         double rr = u01(o.seed, readIdx, i);
@@ -1404,10 +1474,18 @@ static int bias_gc_eff_lengths(const Index& ix, const double* gc_obs, const doub
 //    reference's loop visits (fragStart < refLen - K, K = 9);
 //  * effective length: for every sampled length the sum over fragment starts of seqFW[start] * seqRC[end] (* gcBias) is the lane-strided
 //    sum (lane_sum256); the lengths are added in order.
+//  * --posBias (SPEC §P; :1639-1652, 1708-1712, 1815-1835, 1941-1944): the expected read-start models get, per processed transcript and
+//    bin, the lane-strided sum over the bin's starts of weight x conditional CDF (terms <= EPSILON dropped), summed canonically over the
+//    transcripts; every model bin starts with mass 1 + T (the shared model and one local copy per worker, each initialised to LOG_1);
+//    masses are kept linear (the reference keeps logs and exponentiates in finalize()).
 struct SeqBiasOut { double exp_fw[576], exp_rc[576], obs_fw[576], obs_rc[576]; uint32_t processed; };
+struct PosIn { const double* obs; uint32_t threads; };           // [2][100] linear observed masses without the prior; T
+struct PosOut { double obs_norm[2][100], exp_norm[2][100]; };    // SimplePosBias::masses_ after finalize()
 static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M,
-                                const double* alphas, const double* eff_in, double* eff_out, SeqBiasOut* out) {
-  const int MAXV = 1000; const int32_t gcSamp = 5; const int K = SB_K;
+                                const double* alphas, const double* eff_in, double* eff_out, SeqBiasOut* out, const PosIn* pos = nullptr, PosOut* pout = nullptr) {
+  const int MAXV = 1000; const int32_t gcSamp = 5; const bool seq = seq_fw != nullptr; const int K = seq ? SB_K : 1;
+  std::vector<uint32_t> lq; std::vector<uint8_t> lcls; if (pos) length_classes(ix, lq, lcls);
+  std::vector<std::vector<double>> cpos(pos ? 200 : 0);
   std::vector<double> pdf(MAXV + 1), cdf(MAXV + 1); int32_t fldLow = 0, fldHigh = 1; bool lb = false, ub = false;
   for (int i = 0; i <= MAXV; ++i) {
     pdf[i] = sq_exp(log_pmf[i]); cdf[i] = (i > 0) ? cdf[i - 1] + pdf[i] : pdf[i];
@@ -1449,7 +1527,7 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
     processed.push_back(t);
     const double weight = alphas[t] / eff_in[t];
     // sequence contexts
-    { uint64_t Cf[576] = {0}, Cr[576] = {0}; double Ff[576] = {0}, Fr[576] = {0};
+    if (seq) { uint64_t Cf[576] = {0}, Cr[576] = {0}; double Ff[576] = {0}, Fr[576] = {0};
       for (int32_t fsp = 0; fsp < refLen - K; ++fsp) {
         const int32_t maxFragLen = refLen - (fsp + SB_LEFT);
         if (!(maxFragLen >= 0 && maxFragLen < refLen)) continue;
@@ -1459,7 +1537,8 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
       }
       for (int c = 0; c < 576; ++c) { cfw[c].push_back(weight * ((double)Cf[c] + Ff[c])); crc[c].push_back(weight * ((double)Cr[c] + Fr[c])); } }
     if (gc) {
-      const std::vector<int32_t> g = prefix(t); std::vector<int32_t> cFP, cTP, wFP, wTP; context(t, g, cFP, cTP, wFP, wTP);
+      const std::vector<int32_t> g = prefix(t); std::vector<int32_t> cFP, cTP, wFP, wTP;
+      if (seq) context(t, g, cFP, cTP, wFP, wTP); else { cFP.assign(refLen, 0); cTP.assign(refLen, 0); wFP.assign(refLen, 0); wTP.assign(refLen, 0); }   // :1566: contexts only with both
       const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
       double E[75] = {0};
       double prev = cCDF(locFLDLow > 0 ? locFLDLow - 1 : 0);
@@ -1472,10 +1551,33 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
       }
       for (int b = 0; b < 75; ++b) cgc[b].push_back(weight * E[b]);
     }
+    if (pos) {   // :1639-1652
+      double e[200] = {0}; const int li = lcls[t]; const int32_t ns = refLen - K;
+      int32_t s0 = 0;
+      while (s0 < ns) {
+        const int b = pos_bin(s0, (uint32_t)refLen); int32_t s1 = s0; while (s1 < ns && pos_bin(s1, (uint32_t)refLen) == b) ++s1;
+        e[li * 20 + b] = lane_sum256((int64_t)(s1 - s0), [&](int64_t i) { const double v = weight * cCDF(refLen - (s0 + (int32_t)i) + 1); return v > 0.375e-10 ? v : 0.0; });
+        e[100 + li * 20 + b] = lane_sum256((int64_t)(s1 - s0), [&](int64_t i) { const double v = weight * cCDF(s0 + (int32_t)i); return v > 0.375e-10 ? v : 0.0; });
+        s0 = s1;
+      }
+      for (int c = 0; c < 200; ++c) cpos[c].push_back(e[c]);
+    }
+  }
+  PosSpline O5[5], O3[5], E5[5], E3[5];
+  if (pos) {
+    const double prior = 1.0 + (double)pos->threads;
+    for (int li = 0; li < 5; ++li) {
+      double mo5[20], mo3[20], me5[20], me3[20];
+      for (int b = 0; b < 20; ++b) { mo5[b] = prior + pos->obs[li * 20 + b]; mo3[b] = prior + pos->obs[100 + li * 20 + b];
+        me5[b] = prior + canonical_sum(cpos[li * 20 + b]); me3[b] = prior + canonical_sum(cpos[100 + li * 20 + b]); }
+      pos_finalize(mo5, O5[li], pout ? &pout->obs_norm[0][li * 20] : nullptr); pos_finalize(mo3, O3[li], pout ? &pout->obs_norm[1][li * 20] : nullptr);
+      pos_finalize(me5, E5[li], pout ? &pout->exp_norm[0][li * 20] : nullptr); pos_finalize(me3, E3[li], pout ? &pout->exp_norm[1][li * 20] : nullptr);
+    }
   }
   // models
   double cnt_efw[576], cnt_erc[576], cnt_ofw[576], cnt_orc[576], efw[576], erc[576], ofw[576], orc_[576];
-  for (int c = 0; c < 576; ++c) { cnt_efw[c] = 1e-10 + canonical_sum(cfw[c]); cnt_erc[c] = 1e-10 + canonical_sum(crc[c]); cnt_ofw[c] = 1e-10 + (double)seq_fw[c]; cnt_orc[c] = 1e-10 + (double)seq_rc[c]; }
+  if (!seq) { for (int c = 0; c < 576; ++c) { cnt_efw[c] = cnt_erc[c] = cnt_ofw[c] = cnt_orc[c] = 1.0; cfw[c].clear(); crc[c].clear(); } }
+  else for (int c = 0; c < 576; ++c) { cnt_efw[c] = 1e-10 + canonical_sum(cfw[c]); cnt_erc[c] = 1e-10 + canonical_sum(crc[c]); cnt_ofw[c] = 1e-10 + (double)seq_fw[c]; cnt_orc[c] = 1e-10 + (double)seq_rc[c]; }
   sb_normalize(cnt_efw, efw); sb_normalize(cnt_erc, erc); sb_normalize(cnt_ofw, ofw); sb_normalize(cnt_orc, orc_);
   if (out) { memcpy(out->exp_fw, efw, sizeof(efw)); memcpy(out->exp_rc, erc, sizeof(erc)); memcpy(out->obs_fw, ofw, sizeof(ofw)); memcpy(out->obs_rc, orc_, sizeof(orc_)); out->processed = (uint32_t)processed.size(); }
   double bias[3][25]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 25; ++c) bias[r][c] = 1.0;
@@ -1495,7 +1597,7 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
     const int32_t locFLDLow = (refLen < cdfMaxArg) ? 1 : fldLow, locFLDHigh = (refLen < cdfMaxArg) ? cdfMaxArg : fldHigh;
     if (!(alphas[t] >= 1e-8 && unprocessedLen > 0 && cdfMaxVal > 1e-10)) { eff_out[t] = (double)elen; continue; }
     std::vector<double> sFW(refLen, 1.0), sRCt(refLen, 1.0), sRC(refLen, 1.0);
-    for (int32_t fs = 0; fs < refLen - K; ++fs) {
+    if (seq) for (int32_t fs = 0; fs < refLen - K; ++fs) {
       const int32_t readStart = fs + SB_LEFT;
       if (readStart < refLen) {
         const uint32_t fw = sb_ctx(ix, t, fs), rc = sb_rc(sb_ctx(ix, t, refLen - K - fs));
@@ -1504,7 +1606,11 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
       }
     }
     for (int32_t j = 0; j < refLen; ++j) sRC[j] = sRCt[refLen - 1 - j];
-    std::vector<int32_t> g, cFP, cTP, wFP, wTP; if (gc) { g = prefix(t); context(t, g, cFP, cTP, wFP, wTP); }
+    std::vector<int32_t> g, cFP, cTP, wFP, wTP;
+    if (gc) { g = prefix(t); if (seq) context(t, g, cFP, cTP, wFP, wTP); else { cFP.assign(refLen, 0); cTP.assign(refLen, 0); wFP.assign(refLen, 0); wTP.assign(refLen, 0); } }
+    std::vector<double> pFW, pRC;
+    if (pos) { pFW.assign(refLen, 1.0); pRC.assign(refLen, 1.0); const int li = lcls[t];
+      for (int32_t fs = 0; fs < refLen - K; ++fs) { pFW[fs] = pos_weight(O5[li], fs, refLen) / pos_weight(E5[li], fs, refLen); pRC[fs] = pos_weight(O3[li], fs, refLen) / pos_weight(E3[li], fs, refLen); } }
     double effLength = 0.0;
     int32_t fl = locFLDLow; const int32_t maxLen = std::min(refLen, locFLDHigh + 1); bool done = fl >= maxLen;
     double prevFLMass = cCDF(fl > 0 ? fl - 1 : 0);
@@ -1516,6 +1622,7 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
         const int32_t fs = (int32_t)s0, fe = fs + cur - 1;
         double f = sFW[fs] * sRC[fe];
         if (gc) f *= bias[gc_ctx_bin(ctxFrac(cFP, cTP, wFP, wTP, fs, fe))][gc_frag_bin(gcFrac(g, fs, fe))];
+        if (pos) f *= pFW[fs] * pRC[fe];
         return f; });
       effLength += flWeight * flMassTotal;
       fl += gcSamp;
@@ -1529,7 +1636,7 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
 // optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928): after 11 updates updateEffectiveLengths, new priors
 // (populatePriorAlphas_) and combined weights (updateEqClassWeights :160-176; degenerate classes stay dropped), then on to convergence
 static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const Index& ix, const double* gc_obs, const double* log_pmf,
-                          double* alpha_out, double* eff_out, sq_em_report* rep, const uint64_t* seq_fw = nullptr, const uint64_t* seq_rc = nullptr) {
+                          double* alpha_out, double* eff_out, sq_em_report* rep, const uint64_t* seq_fw = nullptr, const uint64_t* seq_rc = nullptr, const PosIn* pos = nullptr) {
   EMProblem P; em_setup(P, eq, txp, o);
   const uint32_t M = P.M;
   std::vector<double> alpha(M), pc(M), eff(txp->eff_len, txp->eff_len + M), eff2(M);
@@ -1545,7 +1652,7 @@ static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_
   }
   uint32_t it; bool conv; double maxRel;
   em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 11);
-  if (seq_fw) bias_seq_eff_lengths(ix, gc_obs != nullptr, gc_obs, seq_fw, seq_rc, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);   // --seqBias [+ --gcBias]
+  if (seq_fw || pos) bias_seq_eff_lengths(ix, gc_obs != nullptr, gc_obs, seq_fw, seq_rc, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr, pos);   // --seqBias / --posBias [+ --gcBias]
   else bias_gc_eff_lengths(ix, gc_obs, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);
   for (uint64_t c = 0; c < P.E; ++c) {   // updateEqClassWeights with the new lengths
     if (dropped[c]) continue;
@@ -2026,6 +2133,23 @@ int orc_bias_seq_eff_lengths(const orc_index* oi, int gc, const double* gc_obs, 
   if (models4x576) { memcpy(models4x576, o.exp_fw, 576 * 8); memcpy(models4x576 + 576, o.exp_rc, 576 * 8); memcpy(models4x576 + 1152, o.obs_fw, 576 * 8); memcpy(models4x576 + 1728, o.obs_rc, 576 * 8); }
   return rc;
 }
+void orc_state_pos_observed(orc_state* s, double* out200) { for (int i = 0; i < 200; ++i) out200[i] = sq_from_fixed(s->S.posObs[i / 100][i % 100], 32); }
+int orc_length_classes(const orc_index* oi, uint32_t* quant5, uint8_t* cls) { std::vector<uint32_t> q; std::vector<uint8_t> c; length_classes(oi->ix, q, c);
+  for (size_t i = 0; i < q.size() && i < 5; ++i) quant5[i] = q[i]; memcpy(cls, c.data(), c.size()); return (int)q.size(); }
+int orc_pos_bin(int32_t pos, uint32_t len) { return pos_bin(pos, len); }
+void orc_pos_project(const double* mass20, int32_t len, double* out, double* norm20) { PosSpline S; pos_finalize(mass20, S, norm20); for (int32_t p = 0; p < len; ++p) out[p] = pos_weight(S, p, len); }
+void orc_spline_eval(const double* xs, const double* ys, int n, const double* q, int nq, double* out) { PosSpline S; pos_spline_build(xs, ys, n, S); for (int i = 0; i < nq; ++i) out[i] = pos_spline_eval(S, n, q[i]); }
+// every bias combination that needs the per-position sweep: seq_fw / pos_obs may be NULL
+int orc_bias_eff_lengths(const orc_index* oi, int gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* pos_obs, uint32_t threads,
+                         const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in, double* eff_out, double* pos_models_out /*[4][100] or NULL*/) {
+  PosIn pi{pos_obs, threads}; PosOut po;
+  int rc = bias_seq_eff_lengths(oi->ix, gc != 0, gc_obs, seq_fw, seq_rc, log_pmf, M, alphas, eff_in, eff_out, nullptr, pos_obs ? &pi : nullptr, &po);
+  if (pos_obs && pos_models_out) { memcpy(pos_models_out, po.obs_norm, 1600); memcpy(pos_models_out + 200, po.exp_norm, 1600); }
+  return rc;
+}
+int orc_em_optimize_bias_pos(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const orc_index* oi, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc,
+                             const double* pos_obs, uint32_t threads, const double* log_pmf, double* alpha_out, double* eff_out, sq_em_report* rep) {
+  PosIn pi{pos_obs, threads}; return em_optimize_gc(eq, txp, o, oi->ix, gc_obs, log_pmf, alpha_out, eff_out, rep, seq_fw, seq_rc, pos_obs ? &pi : nullptr); }
 void orc_state_gc_observed(orc_state* s, double* out75) { for (int i = 0; i < 75; ++i) out75[i] = sq_from_fixed(s->S.gcObs[i], 32); }
 
 int orc_bias_gc_eff_lengths(const orc_index* oi, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in,

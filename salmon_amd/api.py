@@ -345,6 +345,26 @@ class QuantContext:
         check(lib().sq_model_fetch_seq_observed(self.h, fw.ctypes.data, rc.ctypes.data, C.byref(n)), "sq_model_fetch_seq_observed")
         return fw, rc, int(n.value)
 
+    def pos_observed(self):
+        """Observed read-start masses by length class (needs quant_opts(pos_bias=1)): [2 (5', 3'), 5, 20], linear, without the models' initial mass."""
+        g = np.zeros(200)
+        check(lib().sq_model_fetch_pos_observed(self.h, g.ctypes.data), "sq_model_fetch_pos_observed")
+        return g.reshape(2, 5, 20)
+
+    def em_optimize_bias(self, eff_len, projected, log_pmf, gc_obs=None, seq=None, pos_obs=None, threads=8, opts=None, eq=None):
+        """CollapsedEMOptimizer::optimize with any combination of --gcBias / --seqBias / --posBias: sq_em_optimize_bias with sq_bias_eff_lengths as the callback."""
+        o = opts or em_opts(); txp = make_txp_in(eff_len, projected); M = txp.num_txp
+        out = np.zeros(M); eff_out = np.zeros(M); rep = capi.EmReport(); brep = capi.BiasReport()
+        lp = np.ascontiguousarray(log_pmf, np.float64); bm, keep = _bias_models(gc_obs, seq, pos_obs, threads)
+        idx_h = self.index.h
+        def cb(alphas, eff_in, eff_o, m, user):
+            return lib().sq_bias_eff_lengths(idx_h, C.byref(bm), lp.ctypes.data, m, C.cast(alphas, C.c_void_p), C.cast(eff_in, C.c_void_p), C.cast(eff_o, C.c_void_p), None, None, C.byref(brep))
+        cbf = capi.EFFLEN_CB(cb)
+        t = eq.table() if eq is not None else None
+        check(lib().sq_em_optimize_bias(self.h, C.byref(t) if t is not None else None, C.byref(txp), C.byref(o), cbf, None, _ptr(out, C.c_double),
+            _ptr(eff_out, C.c_double), C.byref(rep)), "sq_em_optimize_bias")
+        return out, eff_out, dict(iters=rep.iters, converged=bool(rep.converged), num_degenerate=rep.num_degenerate, num_processed=brep.num_processed)
+
     def em_optimize_seq(self, eff_len, projected, seq_fw, seq_rc, log_pmf, gc_obs=None, opts=None, eq=None):
         """CollapsedEMOptimizer::optimize with --seqBias [and --gcBias]: sq_em_optimize_bias with sq_bias_seq_eff_lengths as the callback."""
         o = opts or em_opts(); txp = make_txp_in(eff_len, projected); M = txp.num_txp
@@ -439,6 +459,32 @@ def bias_seq_eff_lengths(index, seq_fw, seq_rc, log_pmf, alphas, eff_in, gc_obs=
     check(lib().sq_bias_seq_eff_lengths(index.h, 1 if g is not None else 0, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data, len(a),
         a.ctypes.data, e.ctypes.data, out.ctypes.data, models.ctypes.data, C.byref(rep)), "sq_bias_seq_eff_lengths")
     return out, models, dict(num_processed=rep.num_processed, fld_low=rep.fld_low, fld_high=rep.fld_high, gc_bias=np.array(rep.gc_bias_row0))
+
+
+def _bias_models(gc_obs, seq, pos_obs, threads):
+    keep = [np.ascontiguousarray(gc_obs, np.float64).reshape(-1) if gc_obs is not None else None,
+            np.ascontiguousarray(seq[0], np.uint64) if seq is not None else None, np.ascontiguousarray(seq[1], np.uint64) if seq is not None else None,
+            np.ascontiguousarray(pos_obs, np.float64).reshape(-1) if pos_obs is not None else None]
+    d = [k.ctypes.data if k is not None else None for k in keep]
+    bm = capi.BiasModels(d[0], d[1], d[2], d[3], threads, 0); bm._keep = keep
+    return bm, keep
+
+
+def bias_eff_lengths(index, log_pmf, alphas, eff_in, gc_obs=None, seq=None, pos_obs=None, threads=8):
+    """updateEffectiveLengths with any combination of --gcBias / --seqBias (seq = (fw, rc) counts) / --posBias (pos_obs [2, 5, 20])
+    -> (eff_out, seq models [4, 576], positional models [4, 5, 20], report); the index must be on a device."""
+    lp = np.ascontiguousarray(log_pmf, np.float64); a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64)
+    out = np.zeros(len(a)); sm = np.zeros((4, 576)); pm = np.zeros((4, 5, 20)); rep = capi.BiasReport(); bm, keep = _bias_models(gc_obs, seq, pos_obs, threads)
+    check(lib().sq_bias_eff_lengths(index.h, C.byref(bm), lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, sm.ctypes.data, pm.ctypes.data, C.byref(rep)), "sq_bias_eff_lengths")
+    return out, sm, pm, dict(num_processed=rep.num_processed, fld_low=rep.fld_low, fld_high=rep.fld_high, gc_bias=np.array(rep.gc_bias_row0))
+
+
+def length_classes(index):
+    """Transcript::lengthClassIndex: (quantiles, class of every reference)."""
+    q = np.zeros(5, np.uint32); cls = np.zeros(index.num_refs, np.uint8)
+    n = lib().sq_index_length_classes(index.h, q.ctypes.data, cls.ctypes.data)
+    if n < 0: raise RuntimeError("sq_index_length_classes failed")
+    return q[:n], cls
 
 
 def normalize_alphas(eq, log_mass, uniq, total):

@@ -89,6 +89,10 @@ class EmReport(C.Structure):
                 ("ms_per_iter", f64), ("num_degenerate", u32), ("_pad", u32)]
 
 
+class BiasModels(C.Structure):   # sq_bias_models
+    _fields_ = [("gc_observed", C.c_void_p), ("seq_fw", C.c_void_p), ("seq_rc", C.c_void_p), ("pos_observed", C.c_void_p), ("threads", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class BiasReport(C.Structure):
     _fields_ = [("num_processed", u32), ("fld_low", i32), ("fld_high", i32), ("_pad", u32), ("gc_bias_row0", f64 * 25)]
 
@@ -176,6 +180,9 @@ def lib():
         "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
         "sq_bias_gc_eff_lengths": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, P(BiasReport)]),
         "sq_model_fetch_seq_observed": (C.c_int, [vp, vp, vp, P(u64)]),
+        "sq_model_fetch_pos_observed": (C.c_int, [vp, vp]),
+        "sq_bias_eff_lengths": (C.c_int, [vp, P(BiasModels), vp, u32, vp, vp, vp, vp, vp, P(BiasReport)]),
+        "sq_index_length_classes": (C.c_int, [vp, vp, vp]),
         "sq_bias_seq_eff_lengths": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, u32, vp, vp, vp, vp, P(BiasReport)]),
         "sq_em_optimize_bias": (C.c_int, [vp, P(EqTable), P(TxpIn), P(EmOpts), EFFLEN_CB, vp, P(f64), P(f64), P(EmReport)]),
         "sq_dist_make_id": (C.c_int, [vp]), "sq_dist_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, P(vp)]), "sq_dist_free": (None, [vp]),

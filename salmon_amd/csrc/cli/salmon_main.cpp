@@ -107,12 +107,12 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
   {"IU", {1, 2, 4}}, {"ISF", {1, 2, 0}}, {"ISR", {1, 2, 1}}, {"OU", {1, 1, 4}}, {"OSF", {1, 1, 0}}, {"OSR", {1, 1, 1}},
   {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
 
-struct GcHook { sq_index* idx; std::vector<double> obs, logpmf; sq_bias_report rep; bool gc = true, seq = false; std::vector<uint64_t> sfw, src; };   // updateEffectiveLengths at EM iteration 11
+struct GcHook { sq_index* idx; std::vector<double> obs, logpmf, pobs; sq_bias_report rep; bool gc = true, seq = false, pos = false; std::vector<uint64_t> sfw, src; uint32_t threads = 8; };   // updateEffectiveLengths at EM iteration 11
 static int gc_hook_cb(const double* alphas, const double* eff_in, double* eff_out, uint32_t m, void* user) {
   GcHook* h = (GcHook*)user;
   fprintf(stderr, "[salmon-hip] iteration 11, adjusting effective lengths to account for biases\n");
-  if (h->seq) return sq_bias_seq_eff_lengths(h->idx, h->gc ? 1 : 0, h->gc ? h->obs.data() : nullptr, h->sfw.data(), h->src.data(), h->logpmf.data(), m, alphas, eff_in, eff_out, nullptr, &h->rep);
-  return sq_bias_gc_eff_lengths(h->idx, h->obs.data(), h->logpmf.data(), m, alphas, eff_in, eff_out, &h->rep);
+  sq_bias_models bm{h->gc ? h->obs.data() : nullptr, h->seq ? h->sfw.data() : nullptr, h->seq ? h->src.data() : nullptr, h->pos ? h->pobs.data() : nullptr, h->threads, 0};
+  return sq_bias_eff_lengths(h->idx, &bm, h->logpmf.data(), m, alphas, eff_in, eff_out, nullptr, nullptr, &h->rep);
 }
 
 // ---- --writeMappings: the selected alignments as SAM (the records pufferfish's writeAlignmentsToStream emits from the same
@@ -315,7 +315,7 @@ static int cmd_quant(int argc, char** argv) {
                           "--minAssignedFrags", "--sigDigits", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
@@ -357,6 +357,8 @@ static int cmd_quant(int argc, char** argv) {
   qo.gc_bias = gc_bias ? 1 : 0;
   const bool seq_bias = flag(argc, argv, "--seqBias");
   qo.seq_bias = seq_bias ? 1 : 0;
+  const bool pos_bias = flag(argc, argv, "--posBias");
+  qo.pos_bias = pos_bias ? 1 : 0;
   if ((v = arg(argc, argv, "--incompatPrior"))) { qo.incompat_prior = atof(v) > 0 ? std::log(atof(v)) : 0.0; qo.ignore_incompat = atof(v) == 0.0; }   // QuantOptionsUtils.cpp:608-612
   if ((v = arg(argc, argv, "--maxOccsPerHit"))) qo.max_occs_per_hit = (uint32_t)atoi(v);
   if ((v = arg(argc, argv, "--maxReadOcc"))) qo.max_read_occs = (uint32_t)atoi(v);
@@ -513,8 +515,8 @@ static int cmd_quant(int argc, char** argv) {
     if (qo.no_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = 100.0;                              // CollapsedEMOptimizer.cpp:783-785
     else if (qo.no_eff_length_correction) for (uint32_t i = 0; i < M; ++i) eff[i] = (double)sq_index_ref_len(idx, i);   // :780-782
     sq_txp_in tx{M, proj.data(), uq.data(), eff.data()};
-    if (gc_bias || seq_bias) {   // CollapsedEMOptimizer.cpp:901-928: the effective lengths are re-derived from the bias models inside the optimisation
-      GcHook hook; hook.idx = idx; hook.obs.resize(75); hook.logpmf.resize(1001); hook.gc = gc_bias; hook.seq = seq_bias;
+    if (gc_bias || seq_bias || pos_bias) {   // CollapsedEMOptimizer.cpp:901-928: the effective lengths are re-derived from the bias models inside the optimisation
+      GcHook hook; hook.idx = idx; hook.obs.resize(75); hook.logpmf.resize(1001); hook.gc = gc_bias; hook.seq = seq_bias; hook.pos = pos_bias; hook.threads = qo.mini_batches_in_flight;
       if ((gc_bias && sq_model_fetch_gc_observed(ctx, hook.obs.data())) || sq_model_fetch_fld(ctx, hook.logpmf.data())) die("bias model fetch");
       if (seq_bias) { hook.sfw.resize(576); hook.src.resize(576); uint64_t ns = 0; if (sq_model_fetch_seq_observed(ctx, hook.sfw.data(), hook.src.data(), &ns)) die("sequence-bias model fetch");
         if (dist) { if (sq_dist_allreduce_u64(dist, hook.sfw.data(), 576) || sq_dist_allreduce_u64(dist, hook.src.data(), 576)) die("sequence-bias all-reduce"); }
@@ -523,6 +525,12 @@ static int cmd_quant(int argc, char** argv) {
         uint64_t q[75]; for (int i = 0; i < 75; ++i) q[i] = (uint64_t)std::llround(hook.obs[i] * 4294967296.0);
         if (sq_dist_allreduce_u64(dist, q, 75)) die("GC all-reduce");
         for (int i = 0; i < 75; ++i) hook.obs[i] = (double)q[i] / 4294967296.0;
+      }
+      if (pos_bias) {   // observed read-start models; all ranks' masses add exactly through their fixed-point form
+        hook.pobs.resize(200); if (sq_model_fetch_pos_observed(ctx, hook.pobs.data())) die("positional-bias model fetch");
+        if (dist) { uint64_t q[200]; for (int i = 0; i < 200; ++i) q[i] = (uint64_t)std::llround(hook.pobs[i] * 4294967296.0);
+          if (sq_dist_allreduce_u64(dist, q, 200)) die("positional-bias all-reduce");
+          for (int i = 0; i < 200; ++i) hook.pobs[i] = (double)q[i] / 4294967296.0; }
       }
       std::vector<double> eff2(M);
       if (sq_em_optimize_bias(ctx, &t, &tx, &eop, gc_hook_cb, &hook, alphas.data(), eff2.data(), &rep)) die("EM (bias correction)");
@@ -563,7 +571,7 @@ static int cmd_quant(int argc, char** argv) {
                 "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
                 "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f,\n"
                 "  \"samp_type\": \"%s\",\n  \"num_bootstraps\": %llu,\n  \"num_libraries\": 1,\n  \"frag_length_mean\": %.6f,\n  \"frag_length_sd\": %.6f,\n  \"frag_dist_length\": 1001,\n"
-                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u,\n  \"gc_bias_correct\": %s,\n  \"seq_bias_correct\": %s\n}\n",
+                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u,\n  \"gc_bias_correct\": %s,\n  \"seq_bias_correct\": %s,\n  \"pos_bias_correct\": %s\n}\n",
             sq_version(), M, Mall - M, (unsigned long long)t.num_classes,
                 (unsigned long long)nfrag,
                 (unsigned long long)ms.num_assigned,
@@ -572,7 +580,7 @@ static int cmd_quant(int argc, char** argv) {
                 (unsigned long long)tot.num_mappings_filtered,
             nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
                 rep.iters,
-                ms.num_assigned < min_assigned ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false", seq_bias ? "true" : "false");
+                ms.num_assigned < min_assigned ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false", seq_bias ? "true" : "false", pos_bias ? "true" : "false");
     fclose(mf);
   }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");

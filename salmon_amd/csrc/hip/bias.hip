@@ -7,6 +7,7 @@
 // (transcript, sampled length), read off a sampled G/C prefix of the 2-bit reference pool — and the floating-point part (25-term dot
 // products in a fixed order) is a few hundred flops per transcript on the host: exact, order-defined, the same on every run (SPEC §B).
 #include "ctx.h"
+#include "../host/posbias.h"
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -247,7 +248,7 @@ __device__ inline GcCtx make_gcctx(const uint64_t* refseq, const uint32_t* gcpre
 // expected GC model with context bins: hist[p][slot][ctx * 25 + bin] = starts s in [0, refLen - K) with s + fl - 1 < refLen (the loop of :1577-1623)
 __global__ void __launch_bounds__(256) k_gc_hist_ctx(const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
                                                      const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, int32_t fld_low_g, int32_t fld_high_g, int32_t samp,
-                                                     uint32_t nslots, uint32_t* __restrict__ hist) {
+                                                     uint32_t nslots, uint32_t* __restrict__ hist, int32_t K /* 9 with --seqBias, else 1 */, int use_ctx /* contexts only with --seqBias (:1566) */) {
   __shared__ uint32_t h[75];
   const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t];
   const GcCtx C = make_gcctx(refseq, gcpre, g, refLen);
@@ -258,12 +259,12 @@ __global__ void __launch_bounds__(256) k_gc_hist_ctx(const uint64_t* __restrict_
     if (threadIdx.x < 75) h[threadIdx.x] = 0;
     __syncthreads();
     if (fl <= hi && fl >= 1 && fl <= refLen) {
-      int32_t nst = refLen - SB_K; const int32_t lim = refLen - fl + 1; if (lim < nst) nst = lim;      // s < refLen - K and s + fl - 1 < refLen
+      int32_t nst = refLen - K; const int32_t lim = refLen - fl + 1; if (lim < nst) nst = lim;      // s < refLen - K and s + fl - 1 < refLen
       for (int32_t s = (int32_t)threadIdx.x; s < nst; s += 256) {
         const int32_t e = s + fl - 1;
         const uint64_t c = sq_gc_before(refseq, gcpre, g + (uint64_t)e + 1) - sq_gc_before(refseq, gcpre, g + (uint64_t)s);
         const int32_t frac = (int32_t)rint((100.0 * (double)c) / (double)fl);
-        atomicAdd(&h[sq_gc_ctx_bin(ctx_frac(C, s, e)) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)], 1u);
+        atomicAdd(&h[sq_gc_ctx_bin(use_ctx ? ctx_frac(C, s, e) : 0) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)], 1u);
       }
     }
     __syncthreads();
@@ -288,12 +289,71 @@ __global__ void k_seq_factors(const uint64_t* __restrict__ refseq, const uint64_
     src[o + (uint64_t)j] = r;
   }
 }
-struct EffArgs { int32_t fld_low, fld_high, samp; int use_gc; double bias[75]; };
+struct EffArgs { int32_t fld_low, fld_high, samp; int use_gc, use_ctx; double bias[75]; };
+// ---- --posBias (SalmonUtils.cpp:1639-1652, 1815-1835, 1941-1944; SimplePosBias.cpp) --------------------------------------------------
+// the bin of read start p on a transcript of length len: SimplePosBias::addMass(pos, length, .)
+__device__ inline int pos_bin_dev(int32_t p, int32_t len) { const double step = (double)len / 20.0; const int b = (int)floor((double)p / step); return b > 19 ? 19 : b; }
+// expected read-start models: block per processed transcript; for every bin the lane-strided sum over its starts s < refLen - K of
+// weight * conditionalCDF(refLen - s + 1) (5' model) and weight * conditionalCDF(s) (3' model), terms <= EPSILON dropped;
+// x[p][dir * 100 + class * 20 + bin], zero elsewhere (the canonical sum over the transcripts follows: k_canon_level)
+__global__ void __launch_bounds__(256) k_pos_expect(const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, const double* __restrict__ weight,
+                                                    const double* __restrict__ cdf, const uint8_t* __restrict__ lenclass, int32_t K, double* __restrict__ x /*[P][200]*/) {
+  __shared__ double v5[256], v3[256]; __shared__ int32_t lo[21];
+  const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t], ns = refLen - K; const double w = weight[p];
+  const int32_t cdfMaxArg = refLen < 1000 ? refLen : 1000; const double cdfMaxVal = cdf[cdfMaxArg];
+  auto cCDF = [&](int32_t a) { return a > cdfMaxArg ? 1.0 : cdf[a] / cdfMaxVal; };
+  for (int i = (int)threadIdx.x; i < 200; i += 256) x[(size_t)p * 200 + i] = 0.0;
+  if (threadIdx.x <= 20) {   // lo[b] = the first start whose bin is >= b (bins grow with the start): an estimate, then a short walk
+    const int b = (int)threadIdx.x; int32_t s = (int32_t)((double)b * ((double)refLen / 20.0)) - 2; if (s < 0) s = 0;
+    while (s > 0 && pos_bin_dev(s - 1, refLen) >= b) --s;
+    while (s < refLen && pos_bin_dev(s, refLen) < b) ++s;
+    lo[b] = b == 20 ? refLen : s;
+  }
+  __syncthreads();
+  const uint32_t li = lenclass[t];
+  for (int b = 0; b < 20; ++b) {
+    const int32_t s0 = lo[b] < ns ? lo[b] : ns, s1 = lo[b + 1] < ns ? lo[b + 1] : ns;
+    double a5 = 0.0, a3 = 0.0;
+    for (int32_t s = s0 + (int32_t)threadIdx.x; s < s1; s += 256) {
+      const double f5 = w * cCDF(refLen - s + 1), f3 = w * cCDF(s);
+      a5 += f5 > 0.375e-10 ? f5 : 0.0; a3 += f3 > 0.375e-10 ? f3 : 0.0;
+    }
+    v5[threadIdx.x] = a5; v3[threadIdx.x] = a3;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if ((int)threadIdx.x < st) { v5[threadIdx.x] = v5[threadIdx.x] + v5[threadIdx.x + st]; v3[threadIdx.x] = v3[threadIdx.x] + v3[threadIdx.x + st]; } __syncthreads(); }
+    if (threadIdx.x == 0 && s1 > s0) { x[(size_t)p * 200 + li * 20 + b] = v5[0]; x[(size_t)p * 200 + 100 + li * 20 + b] = v3[0]; }
+    __syncthreads();
+  }
+}
+// tk::spline::operator() inside the knots + projectWeights' floor (SimplePosBias.cpp:32-39)
+__device__ inline double pos_weight_dev(const sq_pos_spline& S, int32_t p, int32_t len) {
+  const double f = (double)p / (double)len;
+  int idx = 0; while (idx < SQ_POS_KNOTS && S.x[idx] < f) ++idx;   // lower_bound: the first knot >= f
+  idx = idx == 0 ? 0 : idx - 1;
+  const double h = f - S.x[idx], r = ((S.a[idx] * h + S.b[idx]) * h + S.c[idx]) * h + S.y[idx];
+  return r > 0.001 ? r : 0.001;
+}
+// posFactorsFW / posFactorsRC (:1829-1834): observed over expected weight at every start < refLen - K, 1 elsewhere
+__global__ void k_pos_factors(const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, const uint64_t* __restrict__ foff, const uint8_t* __restrict__ lenclass,
+                              const sq_pos_spline* __restrict__ sp /* [obs5, obs3, exp5, exp3][class] */, int32_t K, double* __restrict__ pfw, double* __restrict__ prc) {
+  __shared__ sq_pos_spline S[4];
+  const uint32_t p = blockIdx.y, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t o = foff[p]; const uint32_t li = lenclass[t];
+  for (int i = (int)threadIdx.x; i < (int)(4 * sizeof(sq_pos_spline) / 8); i += (int)blockDim.x) {
+    const int m = i / (int)(sizeof(sq_pos_spline) / 8), j = i % (int)(sizeof(sq_pos_spline) / 8);
+    ((double*)&S[m])[j] = ((const double*)&sp[m * SQ_POS_CLASSES + li])[j];
+  }
+  __syncthreads();
+  for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < refLen; j += gridDim.x * blockDim.x) {
+    double f = 1.0, r = 1.0;
+    if (j < refLen - K) { f = pos_weight_dev(S[0], j, refLen) / pos_weight_dev(S[2], j, refLen); r = pos_weight_dev(S[1], j, refLen) / pos_weight_dev(S[3], j, refLen); }
+    pfw[o + (uint64_t)j] = f; prc[o + (uint64_t)j] = r;
+  }
+}
 // block per transcript: the effective length loop of :1888-1945 with the lane-strided sum over fragment starts
 __global__ void __launch_bounds__(256) k_seq_efflen(const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
                                                     const uint32_t* __restrict__ ref_len, const uint32_t* __restrict__ list, const uint64_t* __restrict__ foff,
-                                                    const double* __restrict__ sfw, const double* __restrict__ src, const double* __restrict__ cdf, EffArgs A,
-                                                    double* __restrict__ eff /*[P]*/) {
+                                                    const double* __restrict__ sfw, const double* __restrict__ src /* null without --seqBias */, const double* __restrict__ pfw,
+                                                    const double* __restrict__ prc /* null without --posBias */, const double* __restrict__ cdf, EffArgs A, double* __restrict__ eff /*[P]*/) {
   __shared__ double v[256];
   const uint32_t p = blockIdx.x, t = list[p]; const int32_t refLen = (int32_t)ref_len[t]; const uint64_t g = ref_accum[t], o = foff[p];
   const GcCtx C = make_gcctx(refseq, gcpre, g, refLen);
@@ -309,12 +369,13 @@ __global__ void __launch_bounds__(256) k_seq_efflen(const uint64_t* __restrict__
     double a = 0.0;
     for (int32_t s = (int32_t)threadIdx.x; s < ns; s += 256) {
       const int32_t e = s + fl - 1;
-      double f = sfw[o + (uint64_t)s] * src[o + (uint64_t)e];
+      double f = sfw ? sfw[o + (uint64_t)s] * src[o + (uint64_t)e] : 1.0;
       if (A.use_gc) {
         const uint64_t c = sq_gc_before(refseq, gcpre, g + (uint64_t)e + 1) - sq_gc_before(refseq, gcpre, g + (uint64_t)s);
         const int32_t frac = (int32_t)rint((100.0 * (double)c) / (double)fl);
-        f *= A.bias[sq_gc_ctx_bin(ctx_frac(C, s, e)) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)];
+        f *= A.bias[sq_gc_ctx_bin(A.use_ctx ? ctx_frac(C, s, e) : 0) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(frac)];
       }
+      if (pfw) f *= pfw[o + (uint64_t)s] * prc[o + (uint64_t)e];
       a += f;
     }
     v[threadIdx.x] = a;
@@ -338,11 +399,14 @@ void sb_normalize_host(const double* counts, double* logp) {   // SBModel::norma
 }
 }  // namespace
 
-extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M,
-                                       const double* alphas, const double* eff_in, double* eff_out, double* models_out /* [4][576] or NULL */, sq_bias_report* rep) {
-  if (!idx || !seq_fw || !seq_rc || !log_pmf || !alphas || !eff_in || !eff_out || (use_gc && !gc_obs)) { sq_set_error("sq_bias_seq_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
-  if (!idx->dev) { sq_set_error("sq_bias_seq_eff_lengths: the index is not on a device (there is no CPU path)"); return SQ_ERR_DEVICE; }
-  if (M > idx->names.size()) { sq_set_error("sq_bias_seq_eff_lengths: %u transcripts but the index has %zu", M, idx->names.size()); return SQ_ERR_ARG; }
+// the per-position sweep every combination with --seqBias or --posBias takes (--gcBias alone: sq_bias_gc_eff_lengths' histograms)
+static int bias_sweep(sq_index* idx, int use_gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* pos_obs, uint32_t threads,
+                      const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in, double* eff_out, double* models_out /* [4][576] or NULL */,
+                      double* pos_models_out /* [4][100] or NULL */, sq_bias_report* rep) {
+  const bool use_seq = seq_fw != nullptr, use_pos = pos_obs != nullptr; const int32_t K = use_seq ? SB_K : 1;
+  if (!idx || (use_seq && !seq_rc) || !log_pmf || !alphas || !eff_in || !eff_out || (use_gc && !gc_obs) || (!use_seq && !use_pos)) { sq_set_error("sq_bias_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
+  if (!idx->dev) { sq_set_error("sq_bias_eff_lengths: the index is not on a device (there is no CPU path)"); return SQ_ERR_DEVICE; }
+  if (M > idx->names.size()) { sq_set_error("sq_bias_eff_lengths: %u transcripts but the index has %zu", M, idx->names.size()); return SQ_ERR_ARG; }
   const sq_device_index* di = idx->dev;
   SQ_HIP_CHECK(hipSetDevice(di->device));
   const int MAXV = 1000; const int32_t samp = 5;
@@ -362,24 +426,49 @@ extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* 
   for (uint32_t t = 0; t < M; ++t) eff_out[t] = (double)elen[t];
   double models[4 * 576]; double bias[75]; for (double& b : bias) b = 1.0;
   double cnt[4][576];
-  for (int c = 0; c < 576; ++c) { cnt[0][c] = 1e-10; cnt[1][c] = 1e-10; cnt[2][c] = 1e-10 + (double)seq_fw[c]; cnt[3][c] = 1e-10 + (double)seq_rc[c]; }
-  sq_dbuf<uint32_t> d_list; sq_dbuf<double> d_w, d_cdf, d_x, d_y, d_models, d_sfw, d_src, d_eff; sq_dbuf<uint64_t> d_foff; sq_dbuf<uint32_t> d_hist;
-  auto release = [&]() { d_list.free_(); d_w.free_(); d_cdf.free_(); d_x.free_(); d_y.free_(); d_models.free_(); d_sfw.free_(); d_src.free_(); d_eff.free_(); d_foff.free_(); d_hist.free_(); };
+  for (int c = 0; c < 576; ++c) { cnt[0][c] = 1e-10; cnt[1][c] = 1e-10; cnt[2][c] = 1e-10 + (use_seq ? (double)seq_fw[c] : 0.0); cnt[3][c] = 1e-10 + (use_seq ? (double)seq_rc[c] : 0.0); }
+  sq_dbuf<uint32_t> d_list; sq_dbuf<double> d_w, d_cdf, d_x, d_y, d_models, d_sfw, d_src, d_pfw, d_prc, d_eff; sq_dbuf<uint64_t> d_foff; sq_dbuf<uint32_t> d_hist; sq_dbuf<uint8_t> d_cls; sq_dbuf<sq_pos_spline> d_sp;
+  auto release = [&]() { d_list.free_(); d_w.free_(); d_cdf.free_(); d_x.free_(); d_y.free_(); d_models.free_(); d_sfw.free_(); d_src.free_(); d_pfw.free_(); d_prc.free_(); d_eff.free_(); d_foff.free_(); d_hist.free_(); d_cls.free_(); d_sp.free_(); };
   struct Guard { decltype(release)& r; ~Guard() { r(); } } guard{release};
   if (P) {
-    if (d_list.ensure(P) || d_w.ensure(P) || d_cdf.ensure(MAXV + 1) || d_x.ensure(P * 1152) || d_y.ensure(((P + 63) / 64) * 1152 + 1152) || d_models.ensure(4 * 576)) {
+    const size_t xw = use_seq ? 1152 : 200;
+    if (d_list.ensure(P) || d_w.ensure(P) || d_cdf.ensure(MAXV + 1) || d_x.ensure(P * xw) || d_y.ensure(((P + 63) / 64) * xw + xw) || d_models.ensure(4 * 576)) {
       sq_set_error("device allocation failed (sequence-bias models for %zu transcripts)", P); return SQ_ERR_NOMEM; }
     SQ_HIP_CHECK(hipMemcpy(d_list.p, list.data(), P * 4, hipMemcpyHostToDevice));
     SQ_HIP_CHECK(hipMemcpy(d_w.p, weight.data(), P * 8, hipMemcpyHostToDevice));
     SQ_HIP_CHECK(hipMemcpy(d_cdf.p, cdf.data(), (MAXV + 1) * 8, hipMemcpyHostToDevice));
     // ---- expected context models: per-transcript terms, then the canonical sum over the processed transcripts ----
-    k_seq_expect<<<(uint32_t)P, 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p, d_w.p, d_cdf.p, d_x.p);
-    { double* in = d_x.p; double* out = d_y.p; uint64_t n = P;
+    if (use_seq) { k_seq_expect<<<(uint32_t)P, 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p, d_w.p, d_cdf.p, d_x.p);
+      double* in = d_x.p; double* out = d_y.p; uint64_t n = P;
       while (n > 1) { const uint64_t ng = (n + 63) / 64; k_canon_level<<<(uint32_t)((ng * 1152 + 255) / 256), 256>>>(in, n, 1152, out); std::swap(in, out); n = ng; }
       double e[1152]; SQ_HIP_CHECK(hipMemcpy(e, in, sizeof(e), hipMemcpyDeviceToHost));
       for (int c = 0; c < 576; ++c) { cnt[0][c] = 1e-10 + e[c]; cnt[1][c] = 1e-10 + e[576 + c]; } }
   }
-  for (int m = 0; m < 4; ++m) sb_normalize_host(cnt[m], models + m * 576);
+  // ---- --posBias: expected read-start models, then the four splines per length class ----
+  if (use_pos) {
+    double expect[200] = {0};
+    std::vector<uint8_t> cls; uint32_t quant[SQ_POS_CLASSES]; sq_pos_length_classes(idx, quant, cls);
+    if (d_cls.ensure(cls.size() + 8) || d_sp.ensure(4 * SQ_POS_CLASSES)) { sq_set_error("device allocation failed (positional models)"); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpy(d_cls.p, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    if (P) {
+      k_pos_expect<<<(uint32_t)P, 256>>>(di->ref_len, d_list.p, d_w.p, d_cdf.p, d_cls.p, K, d_x.p);
+      double* in = d_x.p; double* out = d_y.p; uint64_t n = P;
+      while (n > 1) { const uint64_t ng = (n + 63) / 64; k_canon_level<<<(uint32_t)((ng * 200 + 255) / 256), 256>>>(in, n, 200, out); std::swap(in, out); n = ng; }
+      SQ_HIP_CHECK(hipMemcpy(expect, in, sizeof(expect), hipMemcpyDeviceToHost));
+    }
+    // every bin of the shared model and of each of the T workers' local models starts with mass 1 (LOG_1): BiasParams.hpp:41, WorkerRuntimeContext.hpp:40-45; the
+    // expected side likewise (CombineableBiasParams :1319-1320 per thread + the library's model)
+    const double prior = 1.0 + (double)threads;
+    sq_pos_spline sp[4 * SQ_POS_CLASSES]; double norm[4][100];
+    for (int li = 0; li < SQ_POS_CLASSES; ++li) {
+      double m[4][SQ_POS_BINS];
+      for (int b = 0; b < SQ_POS_BINS; ++b) { m[0][b] = prior + pos_obs[li * 20 + b]; m[1][b] = prior + pos_obs[100 + li * 20 + b]; m[2][b] = prior + expect[li * 20 + b]; m[3][b] = prior + expect[100 + li * 20 + b]; }
+      for (int k = 0; k < 4; ++k) sq_pos_finalize(m[k], &sp[k * SQ_POS_CLASSES + li], &norm[k][li * 20]);
+    }
+    if (pos_models_out) memcpy(pos_models_out, norm, sizeof(norm));
+    SQ_HIP_CHECK(hipMemcpy(d_sp.p, sp, sizeof(sp), hipMemcpyHostToDevice));
+  }
+  if (use_seq) for (int m = 0; m < 4; ++m) sb_normalize_host(cnt[m], models + m * 576); else memset(models, 0, sizeof(models));
   if (models_out) memcpy(models_out, models, sizeof(models));
   if (P) {
     SQ_HIP_CHECK(hipMemcpy(d_models.p, models, sizeof(models), hipMemcpyHostToDevice));
@@ -389,7 +478,7 @@ extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* 
       std::vector<uint32_t> hist(P * (size_t)nslots * 75, 0);
       if (nslots) {
         if (d_hist.ensure(hist.size())) { sq_set_error("device allocation failed (GC histograms)"); return SQ_ERR_NOMEM; }
-        k_gc_hist_ctx<<<(uint32_t)P, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p, fldLow, fldHigh, samp, nslots, d_hist.p);
+        k_gc_hist_ctx<<<(uint32_t)P, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p, fldLow, fldHigh, samp, nslots, d_hist.p, K, use_seq ? 1 : 0);
         SQ_HIP_CHECK(hipMemcpy(hist.data(), d_hist.p, hist.size() * 4, hipMemcpyDeviceToHost));
       }
       auto cond_cdf = [&](int32_t refLen, int32_t x) { const int32_t a = std::min(MAXV, refLen); return x > a ? 1.0 : cdf[x] / cdf[a]; };
@@ -413,17 +502,20 @@ extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* 
         for (int b = 0; b < 25; ++b) { double rat = on[b] / en[b]; if (rat > 1000.0) rat = 1000.0; if (rat < 1.0 / 1000.0) rat = 1.0 / 1000.0; bias[r * 25 + b] = rat; } }
     }
     // ---- effective lengths, in groups of transcripts whose factors fit the scratch ----
-    EffArgs A; A.fld_low = fldLow; A.fld_high = fldHigh; A.samp = samp; A.use_gc = use_gc ? 1 : 0; memcpy(A.bias, bias, sizeof(bias));
+    EffArgs A; A.fld_low = fldLow; A.fld_high = fldHigh; A.samp = samp; A.use_gc = use_gc ? 1 : 0; A.use_ctx = use_seq ? 1 : 0; memcpy(A.bias, bias, sizeof(bias));
     const uint64_t CH = 64ull << 20;   // positions per group
     std::vector<double> effh;
     for (size_t p0 = 0; p0 < P;) {
       size_t p1 = p0; uint64_t tot = 0; std::vector<uint64_t> foff;
       while (p1 < P && (p1 == p0 || tot + idx->ref_len[list[p1]] <= CH)) { foff.push_back(tot); tot += idx->ref_len[list[p1]]; ++p1; }
       const size_t np = p1 - p0;
-      if (d_sfw.ensure(tot + 8) || d_src.ensure(tot + 8) || d_foff.ensure(np) || d_eff.ensure(np)) { sq_set_error("device allocation failed (sequence-bias factors)"); return SQ_ERR_NOMEM; }
+      if ((use_seq && (d_sfw.ensure(tot + 8) || d_src.ensure(tot + 8))) || (use_pos && (d_pfw.ensure(tot + 8) || d_prc.ensure(tot + 8))) || d_foff.ensure(np) || d_eff.ensure(np)) {
+        sq_set_error("device allocation failed (per-position bias factors)"); return SQ_ERR_NOMEM; }
       SQ_HIP_CHECK(hipMemcpy(d_foff.p, foff.data(), np * 8, hipMemcpyHostToDevice));
-      k_seq_factors<<<dim3(8, (uint32_t)np), 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, d_models.p, d_sfw.p, d_src.p);
-      k_seq_efflen<<<(uint32_t)np, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, d_sfw.p, d_src.p, d_cdf.p, A, d_eff.p);
+      if (use_seq) k_seq_factors<<<dim3(8, (uint32_t)np), 256>>>(di->refseq, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, d_models.p, d_sfw.p, d_src.p);
+      if (use_pos) k_pos_factors<<<dim3(8, (uint32_t)np), 256>>>(di->ref_len, d_list.p + p0, d_foff.p, d_cls.p, d_sp.p, K, d_pfw.p, d_prc.p);
+      k_seq_efflen<<<(uint32_t)np, 256>>>(di->refseq, di->gcpre, di->ref_accum, di->ref_len, d_list.p + p0, d_foff.p, use_seq ? d_sfw.p : nullptr, use_seq ? d_src.p : nullptr,
+                                          use_pos ? d_pfw.p : nullptr, use_pos ? d_prc.p : nullptr, d_cdf.p, A, d_eff.p);
       effh.resize(np); SQ_HIP_CHECK(hipMemcpy(effh.data(), d_eff.p, np * 8, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < np; ++i) { const uint32_t t = list[p0 + i];
         const double offset = std::max(1.0, (double)unproc[t]), noBias = (double)elen[t];
@@ -433,6 +525,27 @@ extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* 
   }
   if (rep) { rep->num_processed = (uint32_t)P; rep->fld_low = fldLow; rep->fld_high = fldHigh; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) rep->gc_bias_row0[b] = bias[b]; }
   return SQ_OK;
+}
+
+extern "C" int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_obs, const uint64_t* seq_fw, const uint64_t* seq_rc, const double* log_pmf, uint32_t M,
+                                       const double* alphas, const double* eff_in, double* eff_out, double* models_out /* [4][576] or NULL */, sq_bias_report* rep) {
+  if (!seq_fw || !seq_rc) { sq_set_error("sq_bias_seq_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
+  return bias_sweep(idx, use_gc, gc_obs, seq_fw, seq_rc, nullptr, 0, log_pmf, M, alphas, eff_in, eff_out, models_out, nullptr, rep);
+}
+extern "C" int sq_bias_eff_lengths(sq_index* idx, const sq_bias_models* m, const double* log_pmf, uint32_t M, const double* alphas, const double* eff_in, double* eff_out,
+                                   double* seq_models_out, double* pos_models_out, sq_bias_report* rep) {
+  if (!m) { sq_set_error("sq_bias_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
+  if (!m->seq_fw && !m->pos_observed) {   // --gcBias alone: the histogram form
+    if (!m->gc_observed) { sq_set_error("sq_bias_eff_lengths: no model given"); return SQ_ERR_ARG; }
+    return sq_bias_gc_eff_lengths(idx, m->gc_observed, log_pmf, M, alphas, eff_in, eff_out, rep);
+  }
+  return bias_sweep(idx, m->gc_observed != nullptr, m->gc_observed, m->seq_fw, m->seq_rc, m->pos_observed, m->threads, log_pmf, M, alphas, eff_in, eff_out, seq_models_out, pos_models_out, rep);
+}
+extern "C" int sq_index_length_classes(const sq_index* idx, uint32_t* quantiles5, uint8_t* cls /* [num_refs] or NULL */) {
+  if (!idx || !quantiles5) { sq_set_error("sq_index_length_classes: bad arguments"); return -1; }
+  std::vector<uint8_t> c; const int n = sq_pos_length_classes(idx, quantiles5, c);
+  if (cls) memcpy(cls, c.data(), c.size());
+  return n;
 }
 
 const std::vector<uint32_t>& sq_index_gc_prefix(sq_index* idx) {

@@ -14,6 +14,7 @@
 #include "ctx.h"
 #include "scan_kernels.h"
 #include "sq_rng.h"
+#include "../host/posbias.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -79,6 +80,7 @@ struct sq_online_dev {
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
   sq_dbuf<int32_t> cmeans;   // conditional fragment-length means of the prior distribution [1001] (single-end --gcBias)
+  sq_dbuf<uint16_t> posbin; sq_dbuf<unsigned long long> pos_obs; sq_dbuf<uint8_t> lenclass;   // --posBias: per alignment the 5' bin | 3' bin << 8 (class * 20 + bin, 255 = none); observed masses [2][100], fixed point 2^-32; Transcript::lengthClassIndex
   sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
   sq_dbuf<unsigned long long> seq_obs;   // --seqBias: observed context counts [FW 576 | RC 576] + [1152] fragments sampled so far
@@ -138,7 +140,14 @@ struct OnlineView {
   unsigned long long* ctr;
   uint32_t* touched; uint32_t* touched_n; uint32_t* tflag;
   unsigned long long* gc_obs;   // nullptr unless --gcBias
+  unsigned long long* pos_obs; const uint16_t* posbin;   // nullptr unless --posBias
 };
+// observedPosBiasFwd / RC [lengthClassIndex].addMass(pos, RefLength, aln.logProb) — SalmonQuantify.cpp:895-934; the bins were chosen by k_pre_aln
+__device__ inline void pos_observe(const OnlineView& V, uint64_t ai, double pr) {
+  const uint32_t pb = V.posbin[ai]; const unsigned long long q = (unsigned long long)sq_to_fixed(pr, 32);
+  if ((pb & 255u) != 255u) (void)__hip_atomic_fetch_add(&V.pos_obs[pb & 255u], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((pb >> 8) != 255u) (void)__hip_atomic_fetch_add(&V.pos_obs[100u + (pb >> 8)], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // LibraryTypeDetector::addSample (LibraryTypeDetector.hpp:155-160): every alignment whose observed format has the library's read type
 // is a sample; block b histograms the samples of mini-batch b by format id
@@ -189,7 +198,7 @@ enum { PF_KEEP = 1, PF_COMPAT = 2, PF_PE_START = 4, PF_ORPHAN_MODEL = 8, PF_UNEX
 __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uint32_t* __restrict__ ref_len,
     const uint32_t* __restrict__ ref_clen, sq_quant_opts o,
     PreAln* __restrict__ pre, const uint64_t* __restrict__ refseq, const uint32_t* __restrict__ gcpre, const uint64_t* __restrict__ ref_accum,
-    uint8_t* __restrict__ gcbin, const int32_t* __restrict__ cmeans) {
+    uint8_t* __restrict__ gcbin, const int32_t* __restrict__ cmeans, uint16_t* __restrict__ posbin, const uint8_t* __restrict__ lenclass) {
   uint64_t ai = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ai >= na) return;
   const sq_aln a = aln[ai]; const uint32_t rl = ref_len[a.tid];
@@ -235,6 +244,14 @@ __global__ void k_pre_aln(uint64_t na, const sq_aln* __restrict__ aln, const uin
         b = (uint8_t)(sq_gc_ctx_bin(cf) * SQ_GC_FRAG_BINS + sq_gc_frag_bin(ff));
     }
     gcbin[ai] = b;
+  }
+  if (posbin) {   // SimplePosBias::addMass(pos, length, mass) (SimplePosBias.cpp:20-28): bin = floor(pos / (length / 20)) of the clamped read start
+    const uint32_t li = lenclass[a.tid]; const double step = (double)rl / 20.0;
+    auto bin_of = [&](int32_t p) -> uint32_t { if (p < 0) p = 0; if (p >= (int32_t)rl) p = (int32_t)rl - 1; int b = (int)floor((double)p / step); if (b > 19) b = 19; return li * 20u + (uint32_t)b; };
+    uint32_t b5 = 255u, b3 = 255u;
+    if (a.mate_status == SQ_MS_PAIRED_END_PAIRED) { if (a.fwd != a.mate_fwd) { b5 = bin_of(a.fwd ? a.pos : a.mate_pos); b3 = bin_of(a.fwd ? a.mate_pos : a.pos); } }
+    else if (a.fwd) b5 = bin_of(a.pos); else b3 = bin_of(a.pos);
+    posbin[ai] = (uint16_t)(b5 | (b3 << 8));
   }
 }
 
@@ -332,6 +349,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     mass_add(V, par, mbs, t, (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
     atomicAdd(&V.total[t], 1ULL);
     if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
+    if (V.posbin) pos_observe(V, ai, pr);
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
       if (rr < pr) {
@@ -477,6 +495,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             mass_add(V, par, mbs, t[sl], (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS));
             atomicAdd(&V.total[t[sl]], 1ULL);
             if (gcbin && gcbin[ai] != 255) atomicAdd(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32));
+            if (V.posbin) pos_observe(V, ai, pr);
             if (!burned) {
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
               if (rr < pr && fl_ped[sl] > 0) {
@@ -734,6 +753,7 @@ __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0,
     const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
     if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gcbin && gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (V.posbin) pos_observe(V, ai, pr);
   }
 }
 // group end after burn-in: one thread per transcript reads its W mass slots (one 64-byte line at W = 8) and, where the group left
@@ -1064,6 +1084,7 @@ OnlineView make_view(sq_ctx* c) {
   V.touched_n = o->touched_n.p;
   V.tflag = o->tflag.p;
   V.gc_obs = c->opts.gc_bias ? o->gc_obs.p : nullptr;
+  V.pos_obs = c->opts.pos_bias ? o->pos_obs.p : nullptr; V.posbin = c->opts.pos_bias ? o->posbin.p : nullptr;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
@@ -1097,7 +1118,7 @@ int sq_online_create(sq_ctx* c) {
       o->log_eff_len.ensure(M) || o->tlc.ensure(M) || o->scal.ensure(8) || o->cfac.ensure(1024) ||
              o->touched.ensure((size_t)2 * M) || o->touched_n.ensure(2) || o->tflag.ensure(M) || o->mass_acc.ensure((size_t)W * M) || o->uniq.ensure(M) ||
                  o->total.ensure(M) ||
-                 o->lib_counts.ensure(64) || o->gc_obs.ensure(SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) || o->fld_cnt.ensure((size_t)W * 1024) || o->ctr.ensure(8) ||
+                 o->lib_counts.ensure(64) || o->gc_obs.ensure(SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) || o->pos_obs.ensure(208) || o->fld_cnt.ensure((size_t)W * 1024) || o->ctr.ensure(8) ||
              o->assigned_flag.ensure((size_t)c->max_reads + 2) || o->assigned_prefix.ensure((size_t)c->max_reads + 2) ||
                  o->rh1.ensure(c->max_reads) ||
                  o->rh2.ensure(c->max_reads) || o->rslot.ensure(c->max_reads) ||
@@ -1146,6 +1167,11 @@ int sq_online_create(sq_ctx* c) {
     for (int j = 1; j <= 1000; ++j) { const double p = j < 1000 ? 100.0 * sq_exp((hist[j] - tot0) - sum) : 0.0; vals = p * (double)j + vals; mult = p + mult; cm[j] = (int32_t)(mult > 0 ? vals / mult : 0.0); }
     SQ_HIP_CHECK(hipMemcpy(o->cmeans.p, cm.data(), 1024 * 4, hipMemcpyHostToDevice));
   }
+  if (c->opts.pos_bias) {   // Transcript::lengthClassIndex of every reference (host/posbias.cpp)
+    std::vector<uint8_t> cls; uint32_t quant[SQ_POS_CLASSES]; sq_pos_length_classes(c->idx, quant, cls);
+    if (o->lenclass.ensure(M + 8)) { sq_set_error("device allocation failed (length classes)"); return SQ_ERR_NOMEM; }
+    SQ_HIP_CHECK(hipMemcpy(o->lenclass.p, cls.data(), M, hipMemcpyHostToDevice));
+  }
   SQ_HIP_CHECK(hipMemcpy(o->hist.p, hist.data(), 1024 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->ambig.p, ambig.data(), 2048 * 8, hipMemcpyHostToDevice));
   SQ_HIP_CHECK(hipMemcpy(o->prior_mass.p, pm.data(), (size_t)M * 8, hipMemcpyHostToDevice));
@@ -1159,6 +1185,7 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemset(o->total.p, 0, (size_t)M * 8));
   SQ_HIP_CHECK(hipMemset(o->lib_counts.p, 0, 64 * 8));
   SQ_HIP_CHECK(hipMemset(o->gc_obs.p, 0, (SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) * 8));
+  SQ_HIP_CHECK(hipMemset(o->pos_obs.p, 0, 208 * 8));
   SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, (size_t)W * 1024 * 4));
   SQ_HIP_CHECK(hipMemset(o->seq_obs.p, 0, 1160 * 8));
   SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
@@ -1193,7 +1220,7 @@ void sq_online_free(sq_ctx* c) {
   o->tflag.free_();
   o->mb_samples.free_();
   o->gcbin.free_();
-  o->gc_obs.free_();
+  o->gc_obs.free_(); o->posbin.free_(); o->pos_obs.free_(); o->lenclass.free_();
   o->assigned_prefix_b.free_();
   o->mass_acc.free_();
   o->uniq.free_();
@@ -1361,7 +1388,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   const uint64_t last_total_aln = J.total_aln;
   SQ_HIP_CHECK(hipStreamWaitEvent(st, src->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)last_total_aln + 8;
-  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln)) || (q.gc_bias && o->gcbin.ensure(A))) {
+  if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln)) || (q.gc_bias && o->gcbin.ensure(A)) || (q.pos_bias && o->posbin.ensure(A))) {
     sq_set_error("device allocation failed (online scratch)");
     return SQ_ERR_NOMEM;
   }
@@ -1370,7 +1397,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   sq_prof_begin(c, 1);
   uint8_t* d_gcbin = q.gc_bias ? o->gcbin.p : nullptr;
   if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
-      (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p);
+      (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p, q.pos_bias ? o->posbin.p : nullptr, o->lenclass.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
   k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
@@ -1464,7 +1491,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         const uint32_t rs = r1;
         assigned_base = assigned_after;
         if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q, (PreAln*)o->pre.p,
-            c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p);
+            c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p, q.pos_bias ? o->posbin.p : nullptr, o->lenclass.p);
         k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, rs, d_aln_off, d_aln, q, o->assigned_flag.p);
         sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
         // the mini-batches still to come read rh1/rh2 only after writing them: rh2 doubles as the bounds scratch again
@@ -1568,6 +1595,19 @@ extern "C" int sq_model_fetch_gc_observed(sq_ctx* c, double* out75) {
   unsigned long long h[SQ_GC_COND_BINS * SQ_GC_FRAG_BINS];
   SQ_HIP_CHECK(hipMemcpy(h, c->online->gc_obs.p, sizeof(h), hipMemcpyDeviceToHost));
   for (int i = 0; i < SQ_GC_COND_BINS * SQ_GC_FRAG_BINS; ++i) out75[i] = sq_from_fixed(h[i], 32);
+  return SQ_OK;
+}
+
+// observed read-start masses by length class (observedPosBiasFwd / RC, SalmonQuantify.cpp:895-934): [5', 3'][class][bin] sums of the
+// normalised alignment probabilities, linear space, WITHOUT the initial mass of the reference's models (sq_bias_eff_lengths adds it)
+extern "C" int sq_model_fetch_pos_observed(sq_ctx* c, double* out200) {
+  if (!c || !out200) return SQ_ERR_ARG;
+  if (!c->opts.pos_bias) { sq_set_error("sq_model_fetch_pos_observed: the context was created without pos_bias"); return SQ_ERR_STATE; }
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long h[200];
+  SQ_HIP_CHECK(hipMemcpy(h, c->online->pos_obs.p, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 200; ++i) out200[i] = sq_from_fixed(h[i], 32);
   return SQ_OK;
 }
 

@@ -41,6 +41,14 @@ def lib():
         L.orc_state_seq_observed.argtypes = [vp, vp, vp, P(C.c_uint64)]
         L.orc_bias_seq_eff_lengths.restype = C.c_int; L.orc_bias_seq_eff_lengths.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
         L.orc_em_optimize_bias.restype = C.c_int; L.orc_em_optimize_bias.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, vp, vp, vp, vp, vp, vp, P(capi.EmReport)]
+        L.orc_state_pos_observed.argtypes = [vp, vp]
+        L.orc_length_classes.restype = C.c_int; L.orc_length_classes.argtypes = [vp, vp, vp]
+        L.orc_pos_bin.restype = C.c_int; L.orc_pos_bin.argtypes = [C.c_int32, C.c_uint32]
+        L.orc_pos_project.argtypes = [vp, C.c_int32, vp, vp]
+        L.orc_spline_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+        L.orc_bias_eff_lengths.restype = C.c_int; L.orc_bias_eff_lengths.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp]
+        L.orc_em_optimize_bias_pos.restype = C.c_int
+        L.orc_em_optimize_bias_pos.argtypes = [P(capi.EqTable), P(capi.TxpIn), P(capi.EmOpts), vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, P(capi.EmReport)]
         L.orc_state_summary.argtypes = [vp, P(capi.ModelSummary)]
         L.orc_state_lib_counts.argtypes = [vp, vp]
         L.orc_state_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -129,6 +137,9 @@ class OrcState:
         fw = np.zeros(576, np.uint64); rc = np.zeros(576, np.uint64); n = C.c_uint64()
         lib().orc_state_seq_observed(self.h, fw.ctypes.data, rc.ctypes.data, C.byref(n)); return fw, rc, int(n.value)
 
+    def pos_observed(self):
+        g = np.zeros(200); lib().orc_state_pos_observed(self.h, g.ctypes.data); return g.reshape(2, 5, 20)
+
     def gc_observed(self):
         g = np.zeros(75); lib().orc_state_gc_observed(self.h, g.ctypes.data); return g.reshape(3, 25)
 
@@ -213,6 +224,35 @@ def bias_seq_eff_lengths(oidx, seq_fw, seq_rc, log_pmf, alphas, eff_in, gc_obs=N
     n = lib().orc_bias_seq_eff_lengths(oidx.h, 1 if g is not None else 0, g.ctypes.data if g is not None else None, fw.ctypes.data, rc.ctypes.data, lp.ctypes.data, len(a),
         a.ctypes.data, e.ctypes.data, out.ctypes.data, models.ctypes.data)
     return out, models, dict(num_processed=n)
+
+
+def length_classes(oidx):
+    q = np.zeros(5, np.uint32); cls = np.zeros(oidx.src.num_refs, np.uint8)
+    n = lib().orc_length_classes(oidx.h, q.ctypes.data, cls.ctypes.data); return q[:n], cls
+
+
+def _opt(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dt).reshape(-1)
+
+
+def bias_eff_lengths(oidx, log_pmf, alphas, eff_in, gc_obs=None, seq=None, pos_obs=None, threads=8):
+    """every combination that takes the per-position sweep (SPEC §B2, §P): seq = (fw, rc) counts or None, pos_obs [2][5][20] or None"""
+    g = _opt(gc_obs, np.float64); fw = _opt(seq[0], np.uint64) if seq is not None else None; rc = _opt(seq[1], np.uint64) if seq is not None else None
+    po = _opt(pos_obs, np.float64); lp = np.ascontiguousarray(log_pmf, np.float64)
+    a = np.ascontiguousarray(alphas, np.float64); e = np.ascontiguousarray(eff_in, np.float64); out = np.zeros(len(a)); pm = np.zeros((4, 100))
+    d = lambda x: x.ctypes.data if x is not None else None
+    n = lib().orc_bias_eff_lengths(oidx.h, 1 if g is not None else 0, d(g), d(fw), d(rc), d(po), threads, lp.ctypes.data, len(a), a.ctypes.data, e.ctypes.data, out.ctypes.data, pm.ctypes.data)
+    return out, pm, dict(num_processed=n)
+
+
+def em_optimize_bias_pos(eq, eff_len, projected, oidx, log_pmf, gc_obs=None, seq=None, pos_obs=None, threads=8, opts=None):
+    o = opts or api.em_opts(); t = eq.table(); txp = api.make_txp_in(eff_len, projected)
+    g = _opt(gc_obs, np.float64); fw = _opt(seq[0], np.uint64) if seq is not None else None; rc = _opt(seq[1], np.uint64) if seq is not None else None
+    po = _opt(pos_obs, np.float64); lp = np.ascontiguousarray(log_pmf, np.float64)
+    d = lambda x: x.ctypes.data if x is not None else None
+    out = np.zeros(txp.num_txp); eff = np.zeros(txp.num_txp); rep = capi.EmReport()
+    rc_ = lib().orc_em_optimize_bias_pos(C.byref(t), C.byref(txp), C.byref(o), oidx.h, d(g), d(fw), d(rc), d(po), threads, lp.ctypes.data, out.ctypes.data, eff.ctypes.data, C.byref(rep))
+    return out, eff, dict(iters=rep.iters, converged=bool(rep.converged), rc=rc_, num_degenerate=rep.num_degenerate)
 
 
 def em_optimize_bias(eq, eff_len, projected, oidx, seq_fw, seq_rc, log_pmf, gc_obs=None, opts=None):

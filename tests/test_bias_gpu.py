@@ -96,6 +96,12 @@ def test_cli_gcbias_writes_corrected_effective_lengths(built, tmp_path):
     m = json.load(open(tmp_path / "sg" / "aux_info" / "meta_info.json")); assert m["gc_bias_correct"] is True and m["seq_bias_correct"] is True
     n2 = np.array([float(l.split("\t")[4]) for l in open(tmp_path / "sg" / "quant.sf").read().strip().split("\n")[1:]])
     assert abs(n2.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n2)[0, 1] > 0.98
+    r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "IU", "-1", os.path.join(g, "reads_1.fq.gz"), "-2", os.path.join(g, "reads_2.fq.gz"),
+                        "-o", str(tmp_path / "all3"), "--gcBias", "--seqBias", "--posBias"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    m = json.load(open(tmp_path / "all3" / "aux_info" / "meta_info.json")); assert m["pos_bias_correct"] is True and m["seq_bias_correct"] is True
+    n3 = np.array([float(l.split("\t")[4]) for l in open(tmp_path / "all3" / "quant.sf").read().strip().split("\n")[1:]])
+    assert abs(n3.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n3)[0, 1] > 0.97 and not np.array_equal(n3, n2)
 
 
 @pytest.mark.parametrize("with_gc", [False, True])
@@ -175,4 +181,71 @@ def test_gc_bias_single_end_library_matches_checker(small_world):
     proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
     e_g, r_g = api.bias_gc_eff_lengths(w["idx"], g_g, fld, a0, eff); e_c, r_c = orc.bias_gc_eff_lengths(w["oidx"], g_c, ost.model()[4], a0, eff)
     assert np.array_equal(e_g, e_c) and np.array_equal(r_g["gc_bias"], r_c["gc_bias"])
+    ctx.free(); ost.free()
+
+
+@pytest.mark.parametrize("combo", ["pos", "pos+gc", "pos+seq", "pos+seq+gc"])
+def test_pos_bias_models_effective_lengths_and_em_match_checker(small_world, combo):
+    """--posBias, alone and with the other corrections (SPEC §P): the observed read-start models by transcript length class collected by the
+    online stage (general kernels before burn-in, the split path after), the expected models, the splines, the corrected effective lengths
+    and the EM with the bias hook — HIP path vs the checker, bit for bit."""
+    w = small_world; w["idx"].to_device(0)
+    gc, sq = "gc" in combo, "seq" in combo
+    opts = api.quant_opts(pos_bias=1, gc_bias=1 if gc else 0, seq_bias=1 if sq else 0, num_bias_samples=2500, mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=1200,
+                          mini_batches_in_flight=3)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ost = orc.OrcState(w["oidx"], opts)
+    for lo in (0, 2000):   # burn-in ends inside the first batch: the second one takes the static / dynamic kernels
+        hi = lo + 2000
+        s = w["seq"][lo * 200: hi * 200]; o = (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy()
+        rb = api.make_read_batch(s, o, hi - lo, paired=True)
+        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+        ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"])
+    ost.finish()
+    assert ctx.summary() == ost.summary()
+    q_g, c_g = api.length_classes(w["idx"]); q_c, c_c = orc.length_classes(w["oidx"])
+    assert np.array_equal(q_g, q_c) and np.array_equal(c_g, c_c) and len(q_g) == 5 and set(np.unique(c_g)) == {0, 1, 2, 3, 4}
+    p_g, p_c = ctx.pos_observed(), ost.pos_observed()
+    assert np.array_equal(p_g, p_c) and p_g.shape == (2, 5, 20)
+    na = ctx.summary()["num_assigned"]
+    assert abs(p_g[0].sum() - na) < 1e-3 * na and abs(p_g[1].sum() - na) < 1e-3 * na     # every assigned (properly paired) fragment adds mass 1 to each model
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    lm, uq, tc, le = ctx.model(); fld = ctx.fld(); mc = ost.model()
+    assert np.array_equal(fld, mc[4])
+    gcg = ctx.gc_observed() if gc else None; gcc = ost.gc_observed() if gc else None
+    sg = ctx.seq_observed()[:2] if sq else None; sc = ost.seq_observed()[:2] if sq else None
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
+    e_g, sm_g, pm_g, r_g = api.bias_eff_lengths(w["idx"], fld, a0, eff, gc_obs=gcg, seq=sg, pos_obs=p_g, threads=3)
+    e_c, pm_c, r_c = orc.bias_eff_lengths(w["oidx"], mc[4], a0, eff, gc_obs=gcc, seq=sc, pos_obs=p_c, threads=3)
+    assert r_g["num_processed"] == r_c["num_processed"] > 50
+    assert np.array_equal(pm_g.reshape(4, 100), pm_c), "normalised positional models (observed 5', 3', expected 5', 3')"
+    assert np.allclose(pm_g.reshape(4, 5, 20).sum(axis=2), 1.0)
+    assert np.array_equal(e_g, e_c) and np.all(e_g > 0) and np.any(np.abs(e_g - eff) > 0.5)
+    e1, _, _, _ = api.bias_eff_lengths(w["idx"], fld, a0, eff, gc_obs=gcg, seq=sg, pos_obs=p_g, threads=8)
+    assert not np.array_equal(e1, e_g)                                                   # the initial mass per bin is 1 + threads
+    al_g, ef_g, rep_g = ctx.em_optimize_bias(eff, proj, fld, gc_obs=gcg, seq=sg, pos_obs=p_g, threads=3)
+    al_c, ef_c, rep_c = orc.em_optimize_bias_pos(eq_c, eff, proj, w["oidx"], mc[4], gc_obs=gcc, seq=sc, pos_obs=p_c, threads=3)
+    assert rep_g["iters"] == rep_c["iters"] and np.array_equal(ef_g, ef_c) and np.array_equal(al_g, al_c)
+    ctx.free(); ost.free()
+
+
+def test_pos_bias_single_end_library_and_cli(small_world, built, tmp_path):
+    # single-end reads: the forward ones feed the 5' model, the others the 3' model (SalmonQuantify.cpp:917-933)
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(pos_bias=1, mini_batch_size=1000, num_pre_burnin_frags=400, num_burnin_frags=3000); api.set_libtype(opts, "U")
+    n = 3000
+    s = np.concatenate([w["seq"][(2 * j) * 100:(2 * j + 1) * 100] for j in range(n)]); o = np.arange(0, n + 1, dtype=np.uint64) * np.uint64(100)
+    rb = api.make_read_batch(s, o, n, paired=False)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb); ctx.eq_accumulate()
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(w["oidx"], opts, rb, threads=8)
+    ost = orc.OrcState(w["oidx"], opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish()
+    p_g, p_c = ctx.pos_observed(), ost.pos_observed()
+    na = ctx.summary()["num_assigned"]
+    assert np.array_equal(p_g, p_c) and abs(p_g.sum() - na) < 1e-3 * na and p_g[0].sum() > 0.2 * na and p_g[1].sum() > 0.2 * na
+    eq_g = ctx.eq_finish(); lm, uq, tc, le = ctx.model(); fld = ctx.fld()
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le); a0 = np.maximum(proj, 0.0)
+    e_g, _, pm_g, _ = api.bias_eff_lengths(w["idx"], fld, a0, eff, pos_obs=p_g)
+    e_c, pm_c, _ = orc.bias_eff_lengths(w["oidx"], ost.model()[4], a0, eff, pos_obs=p_c)
+    assert np.array_equal(pm_g.reshape(4, 100), pm_c) and np.array_equal(e_g, e_c)
     ctx.free(); ost.free()
