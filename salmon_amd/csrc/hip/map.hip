@@ -554,7 +554,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
       k_dp_hist<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_bh.p);
       exclusive_scan_u32_u64(c->dp_bh.p, c->dp_off.p, (uint64_t)DP_CLASSES * nb, (uint64_t*)c->sort_tmp.p, st);
       k_dp_scatter<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_off.p, c->dp_perm.p);
-      k_dp<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);
+      if (P.bw == SQ_MAX_BAND && !getenv("SQ_DP_GENERAL")) k_dp<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);   // full band: the condition-free form
+      else k_dp_general<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);
     }
     sq_prof_mark(c, SG_DP);
   }

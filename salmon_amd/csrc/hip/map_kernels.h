@@ -1,7 +1,7 @@
 // hip/map_kernels.h — device kernels of the mapping pipeline (seam B1), one stage per kernel:
 //   k_pack      ASCII reads -> 2-bit words + N mask                        (K1 of SURVEY.md §7.4)
 //   k_seed      per read end: SSHash lookup + uni-MEM extension            (K2+K3; row a1)
-//   k_project   uni-MEM x contig-table occurrences -> MEM sort records     (K4;    row a2)
+//   k_project_list  large ends only: uni-MEM x contig-table occurrences -> MEM sort records (row a2; everything else: mem_kernels.h)
 //   [radix sort by (read end, global reference position)]
 //   k_chain     per read end: minimap2-style chaining DP per transcript    (K5;    row a2)
 //   k_join      per fragment: pair / orphan candidates                     (K6;    row a3)
@@ -276,33 +276,6 @@ struct MemD { uint32_t tid; int32_t rpos; int32_t q; int32_t len; bool fw; };
 __device__ inline MemD mem_decode(uint64_t key, uint64_t val, const uint64_t* ref_accum) {
   MemD m; m.tid = (uint32_t)(val >> 32); m.fw = (val >> 20) & 1; m.q = (int32_t)((val >> 10) & 1023); m.len = (int32_t)(val & 1023);
   m.rpos = (int32_t)((key & ((1ULL << 40) - 1)) - ref_accum[m.tid]); return m;
-}
-
-// a2a — projection through the contig table (fillMemCollection); SPEC §a2.
-__global__ void k_project(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab,
-    const uint64_t* __restrict__ ref_accum,
-                          sq_map_params P, uint32_t nends, const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um,
-                          const uint32_t* __restrict__ n_uni, const uint64_t* __restrict__ mem_off, uint64_t* __restrict__ mkey,
-                              uint64_t* __restrict__ mval) {
-  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nends) return;
-  uint64_t w = mem_off[e]; const int L = rlen[e];
-  const sq_unimem_dev* in = um + (size_t)e * SQ_MAX_UNIMEMS;
-  for (uint32_t i = 0; i < n_uni[e]; ++i) {
-    sq_unimem_dev m = in[i];
-    uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];
-    if (b - a > P.max_occ) continue;
-    int ulen = (int)(d.uoff[m.unitig + 1] - d.uoff[m.unitig]);
-    for (uint64_t j = a; j < b; ++j) {
-      uint64_t o = ctab[j]; uint32_t tid = (uint32_t)(o >> 32); bool ufw = (o >> 31) & 1; int upos = (int)(o & 0x7FFFFFFF);
-      int rpos = ufw ? upos + (int)m.ustart : upos + (ulen - ((int)m.ustart + (int)m.len));
-      bool fw = (ufw == (m.fw != 0));
-      uint32_t q = fw ? m.qpos : (uint32_t)(L - ((int)m.qpos + (int)m.len));
-      mkey[w] = ((uint64_t)e << 40) | (ref_accum[tid] + (uint64_t)rpos);
-      mval[w] = mem_pack_val(tid, q, m.len, fw);
-      ++w;
-    }
-  }
 }
 
 // a2b — findChains / findOptChain; SPEC §a2.
@@ -1312,7 +1285,7 @@ __device__ inline uint32_t dp_tbase(const uint64_t* refseq, const sq_dp_item& it
   if (x < 0 || x >= it.tl) return 0u;
   return sq_fetch_base(refseq, (uint64_t)(it.tstart + (int64_t)it.tdir * x));
 }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dp_general(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
     const uint32_t* __restrict__ cand_frag,
     uint32_t paired, const uint32_t* __restrict__ perm) {
   uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1379,6 +1352,76 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   } else {
 #pragma unroll
     for (int b = 0; b < BW; ++b) { int j = n + b - W; if (j >= max(0, n - w) && j <= min(tl, n + w) && Hp[b] > res) res = Hp[b]; }
+  }
+  if (res <= SQ_NEG_INF / 2 || res < it.budget) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; }
+  else atomicAdd(it.end == 0 ? &c->lscore : &c->rscore, res);
+}
+
+// [r3] The same DP with the full band (bw == SQ_MAX_BAND, the default) and NO per-cell conditions: 12 VALU operations per cell instead of 25.
+//  * cells left of the matrix (j < 0) simply hold SQ_NEG_INF-ish values: column 0 then comes out of the recurrence by itself
+//    (F(i,0) = max(F(i-1,0), H(i-1,0) - go) - ge = -(go + ge i); the diagonal and E parents are "minus infinity", so H(i,0) = F(i,0));
+//  * cells right of the target (j > tl) are computed like any other (the window holds base 0 there): a cell's parents are (i-1,j-1),
+//    (i-1,j), (i,j-1), so a cell inside the target never reads one outside, and the result picks below only look inside.  They can only
+//    delay the `hopeless` exit, which is a shortcut, not a result (the final score is compared with the budget again);
+//  * no clamping at SQ_NEG_INF: values drift by at most (go + ge + mp) per step, 2^29 away from real scores, and every "is this cell
+//    reachable" test is `<= SQ_NEG_INF / 2`.
+// Every reachable cell holds exactly the value k_dp_general computes; the tests compare both with the checker.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_dp(sq_map_params P, ScoreCtx S, uint32_t nitems, sq_cand_dev* __restrict__ cands,
+    const uint32_t* __restrict__ cand_frag,
+    uint32_t paired, const uint32_t* __restrict__ perm) {
+  uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= nitems) return;
+  const sq_dp_item it = S.dpq[perm[ii]];
+  const uint32_t f = cand_frag[it.cand];
+  const uint32_t end_id = paired ? 2 * f + it.end : f;
+  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  const bool fw = it.rc == 0;
+  const int n = it.n, tl = it.tl, go = P.go, ge = P.ge;
+  constexpr int W = SQ_MAX_BAND, BW = 2 * SQ_MAX_BAND + 1;
+  int32_t Hp[BW + 1], Fp[BW + 1];
+#pragma unroll
+  for (int b = 0; b <= BW; ++b) { Hp[b] = SQ_NEG_INF; Fp[b] = SQ_NEG_INF; }
+#pragma unroll
+  for (int b = 0; b < BW; ++b) { int j = b - W; if (j >= 0 && j <= tl) Hp[b] = (j == 0) ? 0 : -(go + ge * j); }
+  uint64_t twin = 0;
+#pragma unroll
+  for (int b = 0; b < BW; ++b) twin |= (uint64_t)dp_tbase(S.refseq, it, b - W) << (2 * b);
+  bool hopeless = false;
+  int q_wi = -1; uint64_t q_w = 0, q_n = 0; int64_t t_wi = -1; uint64_t t_w = 0;
+  for (int i = 1; i <= n; ++i) {
+    uint32_t qb;
+    { const int x = it.qstart + it.qdir * (i - 1); const int idx = fw ? x : r.L - 1 - x; const int wi = idx >> 5;
+      if (wi != q_wi) { q_wi = wi; q_w = r.w[wi]; q_n = r.nm[idx >> 6]; }
+      const uint32_t b = ((q_n >> (idx & 63)) & 1) ? 4u : ((uint32_t)(q_w >> ((idx & 31) * 2)) & 3u);
+      qb = fw ? b : (b > 3 ? 4u : 3u - b); }
+    const uint32_t tlo = (uint32_t)twin, thi = (uint32_t)(twin >> 32);
+    int32_t left_g = SQ_NEG_INF, left_e = SQ_NEG_INF, rowmax = SQ_NEG_INF;   // left_g = H of the cell to the left, minus go
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+      const int32_t ev = max(left_e, left_g) - ge;
+      const int32_t fv = max(Fp[b + 1], Hp[b + 1] - go) - ge;
+      const uint32_t tb = b < 16 ? ((tlo >> (2 * b)) & 3u) : ((thi >> (2 * b - 32)) & 3u);
+      const int32_t sc = (qb == tb) ? P.ma : P.mp;   // qb == 4 (N) never equals a target base
+      const int32_t hv = max(Hp[b] + sc, max(ev, fv));
+      Hp[b] = hv; Fp[b] = fv; left_g = hv - go; left_e = ev; rowmax = max(rowmax, hv);
+    }
+    if ((int64_t)rowmax + (int64_t)P.ma * (n - i) < (int64_t)it.budget) { hopeless = true; break; }
+    { const int x = i + W; uint32_t tb = 0;
+      if (x < it.tl) { const int64_t gp = it.tstart + (int64_t)it.tdir * x; const int64_t wi = gp >> 5; if (wi != t_wi) { t_wi = wi; t_w = S.refseq[wi]; }
+        tb = (uint32_t)(t_w >> ((gp & 31) * 2)) & 3u; }
+      twin = (twin >> 2) | ((uint64_t)tb << (2 * (BW - 1))); }
+  }
+  sq_cand_dev* c = &cands[it.cand];
+  if (hopeless) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; return; }
+  int32_t res = SQ_NEG_INF;
+  if (it.mode == 0) {
+    if (abs(n - tl) <= W) {
+#pragma unroll
+      for (int b = 0; b < BW; ++b) if (b == tl - n + W) res = Hp[b];
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BW; ++b) { int j = n + b - W; if (j >= max(0, n - W) && j <= min(tl, n + W) && Hp[b] > res) res = Hp[b]; }
   }
   if (res <= SQ_NEG_INF / 2 || res < it.budget) { if (it.end == 0) c->lfail = 1; else c->rfail = 1; }
   else atomicAdd(it.end == 0 ? &c->lscore : &c->rscore, res);
