@@ -373,11 +373,11 @@ def main():
     # kernels in the proportion the committed rocprofv3 summary shows (profiles/r03_kernel_stats_c2_final.txt; 50/50 without it)
     pair_share = {"k_frag_dynamic": 0.5, "k_apply_dynamic": 0.5}
     try:
-        tot = {}
+        ktot = {}
         for line in open(os.path.join(ROOT, "profiles", "r03_kernel_stats_c2_final.txt")):
             for kn in pair_share:
-                if kn + "(" in line and "total=" in line: tot[kn] = float(line.split("total=")[1].split("ms")[0])
-        if len(tot) == 2: pair_share = {kn: tot[kn] / sum(tot.values()) for kn in tot}
+                if kn + "(" in line and "total=" in line: ktot[kn] = float(line.split("total=")[1].split("ms")[0])
+        if len(ktot) == 2: pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
     except Exception: pass
     for k in cand:
         per_launch = sb[k] / max(1, stage_rows[k]["launches"])

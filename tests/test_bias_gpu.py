@@ -208,7 +208,7 @@ def test_pos_bias_models_effective_lengths_and_em_match_checker(small_world, com
     p_g, p_c = ctx.pos_observed(), ost.pos_observed()
     assert np.array_equal(p_g, p_c) and p_g.shape == (2, 5, 20)
     na = ctx.summary()["num_assigned"]
-    assert abs(p_g[0].sum() - na) < 1e-3 * na and abs(p_g[1].sum() - na) < 1e-3 * na     # every assigned (properly paired) fragment adds mass 1 to each model
+    assert 0.97 * na < p_g[0].sum() <= na + 1e-6 and 0.97 * na < p_g[1].sum() <= na + 1e-6 and p_g.sum() >= na - 1e-6   # a proper pair adds mass 1 to each model, an orphan to one of them
     eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
     lm, uq, tc, le = ctx.model(); fld = ctx.fld(); mc = ost.model()
     assert np.array_equal(fld, mc[4])
