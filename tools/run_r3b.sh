@@ -4,11 +4,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 O=$R/gpurun_out/r3b; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_bias_gpu.py tests/test_map_gpu.py tests/test_golden.py tests/test_exhaustive.py tests/test_scale_gpu.py -m gpu -x -q --timeout 300 > $O/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_bias_gpu.py tests/test_map_gpu.py tests/test_golden.py tests/test_exhaustive.py tests/test_scale_gpu.py tests/test_bench_contract.py -m gpu -q --timeout 300 > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
-cd /tmp
-timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --fastq-pairs 0 > $O/kt.json 2> $O/kt.err
-db=$(find $O/kt -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/kstats.py $db "" 40 > $O/kernel_stats.txt; rm -rf $O/kt
 cd $R
 for cfg in "1 6" "2 6" "2 4" "2 3"; do set -- $cfg
   SQ_SEED_BPC=$2 timeout 400 python bench.py --steps 6 --warmup 1 --cpu-sample 0 --fastq-pairs 0 --lanes $1 > $O/sweep_l$1_b$2.json 2> $O/sweep_l$1_b$2.err
