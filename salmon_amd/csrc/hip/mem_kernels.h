@@ -136,13 +136,37 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
     }
   }
   mk_wsync();
-  // ---- stable rank sort: rank = number of records that come before mine ----
-  for (uint32_t q2 = 0; q2 < n; ++q2) {
-    const uint64_t kq = s_key[gi][q2];
+  // ---- stable sort: rank = number of records that come before mine in (key, emission index) order ----
+  if constexpr (G == 64) {
+    // [r3] a wave per end (65 .. 1024 MEMs: repeat families, a decoy genome): counting the records before mine costs n x CAP / 64 compares per
+    // lane — 13 of the 18.7 ms per 4 x 10^6 pairs on the configs[3] index went there.  A bitonic network over (key << 10 | emission index) in LDS
+    // sorts the same total order in log^2 steps; the ranks are read back through the index bits.
+    uint32_t N = 64; while (N < n) N <<= 1;
+    uint64_t* const sk = s_key[gi];
+    for (uint32_t p = (uint32_t)gl; p < N; p += 64) sk[p] = p < n ? ((sk[p] << 10) | (uint64_t)p) : ~0ull;   // every lane rewrites the keys it stored
+    mk_wsync();
+    for (uint32_t k2 = 2; k2 <= N; k2 <<= 1)
+      for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+        for (uint32_t x = (uint32_t)gl; x < N / 2; x += 64) {
+          const uint32_t i = ((x & ~(j - 1)) << 1) | (x & (j - 1)), l = i | j;
+          const uint64_t a = sk[i], b = sk[l];
+          if ((a > b) == ((i & k2) == 0)) { sk[i] = b; sk[l] = a; }
+        }
+        mk_wsync();
+      }
+    uint16_t* const rank_of = reinterpret_cast<uint16_t*>(g_p);   // the DP's predecessor column is not in use yet
+    for (uint32_t r = (uint32_t)gl; r < n; r += 64) rank_of[(uint32_t)(sk[r] & 1023u)] = (uint16_t)r;
+    mk_wsync();
 #pragma unroll
-    for (int t = 0; t < E; ++t) {
-      const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
-      rk[t] += ((kq < K[t]) | ((kq == K[t]) & (q2 < p))) ? 1u : 0u;
+    for (int t = 0; t < E; ++t) { const uint32_t p = (uint32_t)gl + (uint32_t)(G * t); if (p < n) rk[t] = rank_of[p]; }
+  } else {
+    for (uint32_t q2 = 0; q2 < n; ++q2) {
+      const uint64_t kq = s_key[gi][q2];
+#pragma unroll
+      for (int t = 0; t < E; ++t) {
+        const uint32_t p = (uint32_t)gl + (uint32_t)(G * t);
+        rk[t] += ((kq < K[t]) | ((kq == K[t]) & (q2 < p))) ? 1u : 0u;
+      }
     }
   }
   mk_wsync();
