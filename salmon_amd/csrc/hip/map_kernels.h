@@ -224,7 +224,10 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
           if (!sq_dict_lookup_pre<KT, MT>(d, km, krc, kmini, kat, &u, &off, &fw)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
-            uint64_t ub, ue; sq_ld_pair(d.uoff + u, &ub, &ue); const int ulen = (int)(ue - ub);
+            uint64_t ub, ue, ca, cb;   // the sector sq_dict_try has just brought in: both tables' bounds of unitig u
+            if (d.uinfo) { sq_ld_pair(d.uinfo + 2 * u, &ub, &ca); sq_ld_pair(d.uinfo + 2 * u + 2, &ue, &cb); }
+            else { sq_ld_pair(d.uoff + u, &ub, &ue); sq_ld_pair(ctab_off + u, &ca, &cb); }
+            const int ulen = (int)(ue - ub);
             int len = k;
             int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
             bool mism = false;
@@ -253,7 +256,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
             m.fw = (uint8_t)fw;
             m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
             m.pad[0] = m.pad[1] = m.pad[2] = 0;
-            uint64_t ca, cb; sq_ld_pair(ctab_off + u, &ca, &cb); const uint64_t occ = cb - ca;
+            const uint64_t occ = cb - ca;
             m.ctab_a = ca; m.cnt = occ <= P.max_occ ? (uint32_t)occ : 0u; m.ulen = (uint32_t)ulen;
             out[nu++] = m;
             if (occ <= P.max_occ) np += (uint32_t)occ;
@@ -377,6 +380,7 @@ __global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ re
       double fi = (double)hi.len; int pi = -1; int rounds = 2;
       for (int j = (int)i - 1; j >= (int)g0; --j) {
         MemD hj = mem_decode(mkey[base + j], mval[base + j], ref_accum);
+        if (hi.rpos - hj.rpos > SQ_MAX_CHAIN_GAP) break;   // [r3] sorted by reference position: every earlier MEM of the transcript is farther still (same result as skipping them one by one)
         if (hj.fw != hi.fw) continue;
         int qd = hi.q - hj.q, rd = hi.rpos - hj.rpos;
         if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;

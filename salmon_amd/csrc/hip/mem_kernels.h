@@ -206,8 +206,11 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
       const int qi = g_q[i], ri = g_r[i], len_i = (int)(g_lf[i] & 0x7FFFu); const uint32_t fwi = g_lf[i] >> 15;
       double fi = (double)len_i; int pi = -1; int rounds = 2;
       for (int j = i - 1; j >= g0; --j) {
+        const int rd = ri - g_r[j];
+        if (rd > SQ_MAX_CHAIN_GAP) break;   // [r3] the MEMs of a transcript are sorted by reference position: every earlier one is farther still.  Exactly what
+                                            // skipping them one by one gives, without the quadratic walk over the copies of a repeat family on a chromosome
         if ((uint32_t)(g_lf[j] >> 15) != fwi) continue;
-        const int qd = qi - (int)g_q[j], rd = ri - g_r[j];
+        const int qd = qi - (int)g_q[j];
         if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
         const int l = abs(qd - rd);
         const double a = (double)min(len_i, min(qd, rd));

@@ -143,6 +143,8 @@ struct sq_dict_view {
   const uint64_t* useq;           // string pool
   const uint64_t* uoff;           // [U+1]
   uint64_t num_unitigs;
+  const uint64_t* uinfo;          // [r3] device only (nullptr on the host): [U+1][2] = {uoff[u], ctab_off[u]} interleaved — a hit needs the bounds of unitig u in both
+                                  // tables, and here they are 32 contiguous bytes (one 64-byte sector three times out of four) instead of two sectors
   const uint64_t* kfilter;        // k-mer membership filter (device only; nullptr = none): word-blocked Bloom, SQ_KF_BITS_PER_KEY bits per k-mer
   uint64_t kfilter_words;
 };
@@ -208,7 +210,8 @@ SQ_HD int sq_dict_try(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_
   if (s == kmer) f = 1;
   else if (s == rc) f = 0;
   else return 0;
-  uint64_t b, e; sq_ld_pair(d.uoff + u, &b, &e);
+  uint64_t b, e;
+  if (d.uinfo) { b = d.uinfo[2 * u]; e = d.uinfo[2 * u + 2]; } else sq_ld_pair(d.uoff + u, &b, &e);
   if ((uint64_t)sp < b || (uint64_t)sp + d.k > e) return 0;
   *unitig = u; *off = (uint32_t)((uint64_t)sp - b); *fw = f;
   return 1;
