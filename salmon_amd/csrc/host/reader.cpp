@@ -26,6 +26,7 @@
 #include <functional>
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
+#include "pgzip.h"
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -364,8 +365,26 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
           }
         }
         if (fd >= 0) close(fd); }
+      // [r3] any other gzip file of some size: cut into pieces that the pool inflates in parallel (pgzip.h); SQ_READER_PGZ=0 keeps it on zlib
+      std::shared_ptr<Mapping> pmap; PgzStream* pz = nullptr;
+      struct PzGuard { PgzStream*& p; ~PzGuard() { if (p) pgz_close(p); } } pzg{pz};
+      if (!bg && !(getenv("SQ_READER_PGZ") && atoi(getenv("SQ_READER_PGZ")) == 0)) {
+        int fd = open(path.c_str(), O_RDONLY); struct stat sb;
+        const long min_bytes = getenv("SQ_READER_PGZ_MIN") ? atol(getenv("SQ_READER_PGZ_MIN")) : (8L << 20);   // smaller files: one zlib stream is as fast
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= min_bytes) {
+          void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+          if (m != MAP_FAILED) {
+            pmap = std::make_shared<Mapping>(); pmap->p = m; pmap->n = (size_t)sb.st_size; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+            const unsigned th = (unsigned)std::max<size_t>(1, std::min<size_t>(pool->th.size(), 16));
+            const size_t piece = getenv("SQ_READER_PGZ_PIECE") ? (size_t)atol(getenv("SQ_READER_PGZ_PIECE")) : std::max<size_t>(1u << 20, std::min<size_t>(4u << 20, (size_t)sb.st_size / (4 * th)));
+            pz = pgz_open((const uint8_t*)m, (size_t)sb.st_size, [pool](std::function<void()> f) { pool->submit(std::move(f)); }, th, piece);
+            if (!pz) pmap.reset();
+          }
+        }
+        if (fd >= 0) close(fd);
+      }
       gzFile f = nullptr;
-      if (!bg) { f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; } gzbuffer(f, 1 << 20); }
+      if (!bg && !pz) { f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; } gzbuffer(f, 1 << 20); }
       std::vector<char> carry;
       for (;;) {
         auto c = std::make_shared<Chunk>(); c->own.resize(carry.size() + CHUNK_BYTES);
@@ -375,6 +394,7 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
         while (got < CHUNK_BYTES) {
           long r;
           if (bg) { r = bg->read(c->own.data() + have + got, CHUNK_BYTES - got); if (r < 0) { out->finish(bg->err); return; } }
+          else if (pz) { std::string e; r = pgz_read(pz, c->own.data() + have + got, CHUNK_BYTES - got, &e); if (r < 0) { out->finish("'" + path + "': " + e); return; } }
           else {
             r = gzread(f, c->own.data() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
             if (r < 0) { int e; std::string msg = gzerror(f, &e); gzclose(f); out->finish("read error in '" + path + "': " + msg); return; }

@@ -240,3 +240,35 @@ def test_reader_streams_from_fifos_and_dev_fd(built, tmp_path):
 
 def _chunks(b, n=65536):
     return [b[i:i + n] for i in range(0, len(b), n)]
+
+
+def test_reader_plain_gzip_is_inflated_in_pieces_by_the_pool(built, tmp_path, monkeypatch):
+    # [r3] a gzip file of some size (not BGZF) is cut into pieces that find their own block starts (host/pgzip.cpp): same batches as the
+    # plain files and as the one-thread zlib path, whatever the compression level, for several members in one file; damage is reported
+    rng = np.random.default_rng(12); n = 120000
+    def text(m):
+        L = rng.integers(60, 151, n); b = rng.integers(0, 4, int(L.sum())).astype(np.uint8); seq = np.frombuffer(b"ACGT", np.uint8)[b].tobytes()
+        q = (rng.integers(0, 40, int(L.sum())) + 33).astype(np.uint8).tobytes(); o = np.concatenate([[0], np.cumsum(L)])
+        return b"".join(b"@r%d/%d some text\n%s\n+\n%s\n" % (i, m, seq[o[i]:o[i + 1]], q[o[i]:o[i + 1]]) for i in range(n))
+    t1, t2 = text(1), text(2)
+    open(tmp_path / "p_1.fq", "wb").write(t1); open(tmp_path / "p_2.fq", "wb").write(t2)
+    open(tmp_path / "g_1.fq.gz", "wb").write(gzip.compress(t1, 6))                                                      # one member, default level
+    cut = [0, 1000, 1000, len(t2) // 3, len(t2)]                                                                        # four members, one of them empty
+    open(tmp_path / "g_2.fq.gz", "wb").write(b"".join(gzip.compress(t2[a:b], lvl) for a, b, lvl in zip(cut[:-1], cut[1:], (1, 6, 9, 4))))
+    assert os.path.getsize(tmp_path / "g_1.fq.gz") > (8 << 20) and os.path.getsize(tmp_path / "g_2.fq.gz") > (8 << 20)   # above the size where the pieces start
+    L = capi.lib()
+    def run(f1, f2):
+        h = _open([str(f1)], [str(f2)] if f2 else None, batch=50000); got, err = _drain(h); L.sq_reader_close(h); return got, err
+    want, err = run(tmp_path / "p_1.fq", tmp_path / "p_2.fq"); assert err is None
+    got, err = run(tmp_path / "g_1.fq.gz", tmp_path / "g_2.fq.gz")
+    assert err is None and got == want and sum(len(b) for b in got) == 2 * n
+    monkeypatch.setenv("SQ_READER_PGZ", "0")
+    got0, err = run(tmp_path / "g_1.fq.gz", tmp_path / "g_2.fq.gz"); assert err is None and got0 == want
+    monkeypatch.delenv("SQ_READER_PGZ")
+    raw = bytearray(open(tmp_path / "g_1.fq.gz", "rb").read()); raw[len(raw) // 2] ^= 0x5A
+    open(tmp_path / "bad_1.fq.gz", "wb").write(bytes(raw))
+    got, err = run(tmp_path / "bad_1.fq.gz", None)
+    assert err is not None and "bad_1.fq.gz" in err
+    open(tmp_path / "cut_1.fq.gz", "wb").write(bytes(raw[: len(raw) // 3]))
+    got, err = run(tmp_path / "cut_1.fq.gz", None)
+    assert err is not None and "cut_1.fq.gz" in err

@@ -60,6 +60,14 @@ int main(int argc, char** argv) {
       for (uint64_t i = 0; i < b.seq_off[2 * b.n]; i += 97) CHECK(strchr("ACGT", (char)b.seq[i]) != nullptr);
       if (held[0] >= 0) sq_reader_release(rd, held[0]); held[0] = held[1]; held[1] = slot; }
     CHECK(n == 5000 && sq_reader_total(rd) == 5000 && bytes > 5000 * 100); sq_reader_close(rd); }
+  // ---- reader: the same two gzip files cut into 64 KB pieces that the pool inflates in parallel (host/pgzip.cpp)
+  { setenv("SQ_READER_PGZ_MIN", "1000", 1); setenv("SQ_READER_PGZ_PIECE", "65536", 1);
+    std::string p1 = dir + "/r_1.fq.gz", p2 = dir + "/r_2.fq.gz"; const char* q1[] = {p1.c_str()}; const char* q2[] = {p2.c_str()};
+    sq_reader* rd = nullptr; CHECK(sq_reader_open(q1, 1, q2, 1, 800, 3, &rd) == SQ_OK);
+    uint64_t n = 0, bytes = 0;
+    for (;;) { sq_read_batch b; int slot; CHECK(sq_reader_next(rd, &b, &slot) == SQ_OK); if (b.n == 0) break; n += b.n; bytes += b.seq_off[2 * b.n]; sq_reader_release(rd, slot); }
+    CHECK(n == 5000 && bytes > 5000 * 100); sq_reader_close(rd);
+    unsetenv("SQ_READER_PGZ_MIN"); unsetenv("SQ_READER_PGZ_PIECE"); }
   // ---- reader: the same reads as BGZF (64 KB gzip members inflated by the pool, taken in order by the stream thread)
   { auto bgzf = [&](const std::string& src, const std::string& dst) {
       std::string text; { gzFile f = gzopen(src.c_str(), "rb"); char buf[1 << 16]; int n; while ((n = gzread(f, buf, sizeof buf)) > 0) text.append(buf, (size_t)n); gzclose(f); }
