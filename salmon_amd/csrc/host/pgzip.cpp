@@ -12,6 +12,8 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
+#include <sys/mman.h>
 #include <vector>
 
 namespace {
@@ -84,8 +86,10 @@ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13,
 struct Out {   // symbols of a piece, preceded by the 32 K window symbols
   uint16_t* b = nullptr; size_t n = 0, cap = 0;
   ~Out() { free(b); }
-  bool reserve(size_t want) { if (want <= cap) return true; size_t nc = std::max(want, cap + cap / 2 + (1u << 20)); uint16_t* nb = (uint16_t*)realloc(b, nc * 2); if (!nb) return false; b = nb; cap = nc; return true; }
-  void start() { reserve(WIN + (1u << 22)); for (uint32_t k = 0; k < WIN; ++k) b[k] = (uint16_t)(MARK | k); n = WIN; }
+  bool reserve(size_t want) { if (want <= cap) return true; size_t nc = std::max(want, cap + cap / 2 + (1u << 20)); uint16_t* nb = (uint16_t*)realloc(b, nc * 2); if (!nb) return false; b = nb; cap = nc;
+    if (nc * 2 >= (4u << 20)) { const uintptr_t a = ((uintptr_t)b + 4095) & ~(uintptr_t)4095; (void)madvise((void*)a, (nc * 2 - (a - (uintptr_t)b)) & ~(size_t)4095, MADV_HUGEPAGE); }   // fewer first-touch faults
+    return true; }
+  void start(size_t expect = 1u << 22) { reserve(WIN + expect); for (uint32_t k = 0; k < WIN; ++k) b[k] = (uint16_t)(MARK | k); n = WIN; }
 };
 
 inline bool texty(int c) { return (c >= 32 && c < 127) || c == '\n' || c == '\r' || c == '\t'; }
@@ -229,6 +233,18 @@ struct PgzStream {
   std::vector<uint8_t> tail;        // last 32 KB of text of the current member
   uint32_t crc = 0; uint64_t mlen = 0;
   std::deque<std::unique_ptr<Text>> ready; size_t ready_off = 0; std::vector<std::unique_ptr<Text>> spare;
+  // rounds run ahead of the consumer on a thread of their own (they wait for the pool most of the time): ready / spare / eof / err are shared
+  std::mutex mu; std::condition_variable cv_ready, cv_room; std::thread producer; bool stop = false, failed = false; size_t ready_bytes = 0, ahead_bytes = 0;
+  void produce() {
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return stop || ready_bytes < ahead_bytes; }); if (stop) return; }
+      const bool ok = round();
+      std::lock_guard<std::mutex> lk(mu);
+      if (!ok) failed = true;
+      cv_ready.notify_all();
+      if (!ok || eof) return;
+    }
+  }
   std::vector<std::unique_ptr<Piece>> pc;   // kept between rounds: their symbol buffers are reused
   pgz_counters ctr{0, 0, 0, 0};
   unsigned alone = 0;               // rounds left to run as one piece (after a round in which no other piece found a block start: stored or binary data)
@@ -278,7 +294,7 @@ struct PgzStream {
       Piece& P = *pc[i]; if (P.start == ~0ull) return;
       auto tp0 = std::chrono::steady_clock::now();
       struct TP { decltype(tp0) t0; unsigned i; Piece* P; bool on; ~TP() { if (on) fprintf(stderr, "[pgz]   piece %u: %.1f ms, %zu symbols, bits %llu..%llu\n", i, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), P->out.n, (unsigned long long)P->start, (unsigned long long)P->end); } } tp{tp0, i, &P, timing};
-      P.ran = true; Bits br(base, n); br.seek(P.start); P.out.start();
+      P.ran = true; Bits br(base, n); br.seek(P.start); P.out.start(piece_bytes * 5);   // sequence data inflates ~3-4 x: no regrowth on the way
       unsigned nxt = i + 1;
       for (;;) {
         const uint64_t pos = br.tell();
@@ -316,7 +332,8 @@ struct PgzStream {
       w.swap(nw);
     }
     tail = w;
-    for (unsigned t : chain) { if (!spare.empty()) { pc[t]->text = std::move(spare.back()); spare.pop_back(); } else pc[t]->text.reset(new Text()); }
+    { std::lock_guard<std::mutex> lk(mu);
+      for (unsigned t : chain) { if (!spare.empty()) { pc[t]->text = std::move(spare.back()); spare.pop_back(); } else pc[t]->text.reset(new Text()); } }
     mark("windows");
     parallel((unsigned)chain.size(), [&](unsigned t) {
       Piece& P = *pc[chain[t]]; const size_t L = P.out.n - WIN;
@@ -328,8 +345,9 @@ struct PgzStream {
       P.crc = c;
     });
     mark("text+crc");
+    bool at_end = false;
     for (unsigned t : chain) { Piece& P = *pc[t]; if (P.status == B_BAD) { err = "out of memory"; return false; }
-      crc = (uint32_t)crc32_combine(crc, P.crc, (z_off_t)P.text->n); mlen += P.text->n; if (P.text->n) ready.push_back(std::move(P.text)); else spare.push_back(std::move(P.text)); }
+      crc = (uint32_t)crc32_combine(crc, P.crc, (z_off_t)P.text->n); mlen += P.text->n; }
     bitpos = pc[chain.back()]->end;
     if (final_seen) {   // trailer: CRC-32 and length of the member, then maybe another member
       size_t at = (size_t)((bitpos + 7) / 8);
@@ -338,8 +356,11 @@ struct PgzStream {
       const uint32_t flen = (uint32_t)base[at + 4] | ((uint32_t)base[at + 5] << 8) | ((uint32_t)base[at + 6] << 16) | ((uint32_t)base[at + 7] << 24);
       if (fcrc != crc || flen != (uint32_t)mlen) { err = "gzip checksum mismatch (CRC-32 or length of a member)"; return false; }
       in_member = false; at += 8;
-      if (at >= n || !begin_member(at)) eof = true;          // like gzip: whatever follows the last member is ignored
+      if (at >= n || !begin_member(at)) at_end = true;       // like gzip: whatever follows the last member is ignored
     } else if (bitpos >= nbits) { err = "truncated gzip file (the last block is missing)"; return false; }
+    { std::lock_guard<std::mutex> lk(mu);   // the text becomes visible only once its member's trailer (if it ended here) has been checked
+      if (at_end) eof = true;
+      for (unsigned t : chain) { Piece& P = *pc[t]; if (P.text->n) { ready_bytes += P.text->n; ready.push_back(std::move(P.text)); } else spare.push_back(std::move(P.text)); } }
     return true;
   }
 };
@@ -348,22 +369,33 @@ PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::f
   std::unique_ptr<PgzStream> s(new PgzStream());
   s->base = data; s->n = bytes; s->submit = std::move(submit); s->threads = std::max(1u, threads); s->piece_bytes = std::max<size_t>(piece_bytes, 1u << 16);
   if (!s->begin_member(0)) return nullptr;
-  return s.release();
+  s->ahead_bytes = (size_t)s->threads * s->piece_bytes * 4;          // about one round of text waiting while the next is decoded
+  PgzStream* p = s.release();
+  p->producer = std::thread([p] { p->produce(); });
+  return p;
 }
 long pgz_read(PgzStream* s, char* dst, size_t want, std::string* err) {
   size_t got = 0;
+  std::unique_lock<std::mutex> lk(s->mu);
   while (got < want) {
     if (s->ready.empty()) {
+      if (s->failed) { if (err) *err = s->err; return -1; }
       if (s->eof) break;
-      if (!s->round()) { if (err) *err = s->err; return -1; }
+      s->cv_ready.wait(lk, [&] { return !s->ready.empty() || s->failed || s->eof; });
       continue;
     }
     Text& f = *s->ready.front();
     const size_t take = std::min(want - got, f.n - s->ready_off);
-    memcpy(dst + got, f.p + s->ready_off, take); got += take; s->ready_off += take;
-    if (s->ready_off == f.n) { s->spare.push_back(std::move(s->ready.front())); s->ready.pop_front(); s->ready_off = 0; }
+    lk.unlock(); memcpy(dst + got, f.p + s->ready_off, take); lk.lock();      // the front buffer is the consumer's until it is returned
+    got += take; s->ready_off += take;
+    if (s->ready_off == f.n) { s->ready_bytes -= f.n; s->spare.push_back(std::move(s->ready.front())); s->ready.pop_front(); s->ready_off = 0; s->cv_room.notify_one(); }
   }
   return (long)got;
 }
-void pgz_close(PgzStream* s) { delete s; }
+void pgz_close(PgzStream* s) {
+  if (!s) return;
+  { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; } s->cv_room.notify_all();
+  if (s->producer.joinable()) s->producer.join();
+  delete s;
+}
 pgz_counters pgz_stats(const PgzStream* s) { return s->ctr; }
