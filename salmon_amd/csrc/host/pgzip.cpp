@@ -220,6 +220,7 @@ uint64_t find_block(const uint8_t* base, size_t n, uint64_t from, uint64_t to) {
 
 struct Text { char* p = nullptr; size_t n = 0, cap = 0; ~Text() { free(p); }   // a piece's text; buffers go round (a fresh page is the expensive part)
   bool size(size_t want) { if (want > cap) { free(p); cap = want + want / 8 + 4096; p = (char*)malloc(cap); if (!p) { cap = 0; return false; } } n = want; return true; } };
+struct Recycler { std::mutex mu; std::vector<std::unique_ptr<Text>> spare; };   // outlives the stream while text buffers are still out
 struct alignas(128) Piece {
   uint64_t start = ~0ull, end = 0; Out out; int status = B_BAD; bool ran = false;     // status of the LAST block decoded: B_MORE = stopped at a boundary
   std::unique_ptr<Text> text; uint32_t crc = 0;
@@ -232,7 +233,7 @@ struct PgzStream {
   bool in_member = false, eof = false;
   std::vector<uint8_t> tail;        // last 32 KB of text of the current member
   uint32_t crc = 0; uint64_t mlen = 0;
-  std::deque<std::unique_ptr<Text>> ready; size_t ready_off = 0; std::vector<std::unique_ptr<Text>> spare;
+  std::deque<std::unique_ptr<Text>> ready; size_t ready_off = 0; std::shared_ptr<Recycler> rec = std::make_shared<Recycler>();
   // rounds run ahead of the consumer on a thread of their own (they wait for the pool most of the time): ready / spare / eof / err are shared
   std::mutex mu; std::condition_variable cv_ready, cv_room; std::thread producer; bool stop = false, failed = false; size_t ready_bytes = 0, ahead_bytes = 0;
   void produce() {
@@ -332,8 +333,8 @@ struct PgzStream {
       w.swap(nw);
     }
     tail = w;
-    { std::lock_guard<std::mutex> lk(mu);
-      for (unsigned t : chain) { if (!spare.empty()) { pc[t]->text = std::move(spare.back()); spare.pop_back(); } else pc[t]->text.reset(new Text()); } }
+    { std::lock_guard<std::mutex> lk(rec->mu);
+      for (unsigned t : chain) { if (!rec->spare.empty()) { pc[t]->text = std::move(rec->spare.back()); rec->spare.pop_back(); } else pc[t]->text.reset(new Text()); } }
     mark("windows");
     parallel((unsigned)chain.size(), [&](unsigned t) {
       Piece& P = *pc[chain[t]]; const size_t L = P.out.n - WIN;
@@ -360,7 +361,7 @@ struct PgzStream {
     } else if (bitpos >= nbits) { err = "truncated gzip file (the last block is missing)"; return false; }
     { std::lock_guard<std::mutex> lk(mu);   // the text becomes visible only once its member's trailer (if it ended here) has been checked
       if (at_end) eof = true;
-      for (unsigned t : chain) { Piece& P = *pc[t]; if (P.text->n) { ready_bytes += P.text->n; ready.push_back(std::move(P.text)); } else spare.push_back(std::move(P.text)); } }
+      for (unsigned t : chain) { Piece& P = *pc[t]; if (P.text->n) { ready_bytes += P.text->n; ready.push_back(std::move(P.text)); } else { std::lock_guard<std::mutex> l2(rec->mu); rec->spare.push_back(std::move(P.text)); } } }
     return true;
   }
 };
@@ -388,9 +389,19 @@ long pgz_read(PgzStream* s, char* dst, size_t want, std::string* err) {
     const size_t take = std::min(want - got, f.n - s->ready_off);
     lk.unlock(); memcpy(dst + got, f.p + s->ready_off, take); lk.lock();      // the front buffer is the consumer's until it is returned
     got += take; s->ready_off += take;
-    if (s->ready_off == f.n) { s->ready_bytes -= f.n; s->spare.push_back(std::move(s->ready.front())); s->ready.pop_front(); s->ready_off = 0; s->cv_room.notify_one(); }
+    if (s->ready_off == f.n) { s->ready_bytes -= f.n; { std::lock_guard<std::mutex> l2(s->rec->mu); s->rec->spare.push_back(std::move(s->ready.front())); } s->ready.pop_front(); s->ready_off = 0; s->cv_room.notify_one(); }
   }
   return (long)got;
+}
+int pgz_next(PgzStream* s, PgzBuf* out, std::string* err) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->cv_ready.wait(lk, [&] { return !s->ready.empty() || s->failed || s->eof; });
+  if (s->ready.empty()) { if (s->failed) { if (err) *err = s->err; return -1; } return 0; }
+  Text* t = s->ready.front().release(); s->ready.pop_front(); s->ready_bytes -= t->n; s->cv_room.notify_one();
+  std::shared_ptr<Recycler> rec = s->rec;
+  out->p = t->p; out->n = t->n;
+  out->hold = std::shared_ptr<void>((void*)t, [rec](void* v) { std::lock_guard<std::mutex> l(rec->mu); rec->spare.emplace_back((Text*)v); });
+  return 1;
 }
 void pgz_close(PgzStream* s) {
   if (!s) return;

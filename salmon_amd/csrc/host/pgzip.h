@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 
 struct PgzStream;
@@ -19,6 +20,10 @@ struct PgzStream;
 PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::function<void()>)> submit, unsigned threads, size_t piece_bytes);
 // up to `want` bytes of text in file order; 0 at the end; -1 on error (*err says what)
 long pgz_read(PgzStream*, char* dst, size_t want, std::string* err);
+// the same text without the copy: the next whole buffer of the stream (a few megabytes; 1), the end (0) or an error (-1).  `hold` keeps the
+// buffer alive — also past pgz_close — and hands it back for reuse when the last reference goes.  Do not mix with pgz_read.
+struct PgzBuf { const char* p = nullptr; size_t n = 0; std::shared_ptr<void> hold; };
+int pgz_next(PgzStream*, PgzBuf* out, std::string* err);
 void pgz_close(PgzStream*);
 // what happened, for tests and SQ_TIMING: pieces decoded, pieces whose start was not confirmed by the predecessor (decoded twice), members
 struct pgz_counters { uint64_t pieces, resynced, members, rounds; };

@@ -174,7 +174,7 @@ struct Pool {   // a few workers shared by the parse tasks of both streams and t
 
 struct Mapping { void* p = nullptr; size_t n = 0; ~Mapping() { if (p) munmap(p, n); } };
 struct Chunk {   // a run of whole records of one stream, in stream order
-  const char* text = nullptr; size_t bytes = 0; std::vector<char> own; std::shared_ptr<Mapping> map;   // window of an mmap, or an owned buffer (.gz)
+  const char* text = nullptr; size_t bytes = 0; std::unique_ptr<char[]> own; std::shared_ptr<Mapping> map; std::shared_ptr<void> hold;   // window of an mmap, an owned buffer (.gz), or a window of somebody's buffer kept alive by `hold`
   std::vector<uint32_t> pos, len;   // per record: where its bases start in `text`, how many
   std::vector<uint32_t> npos, nlen; bool keep_names = false;   // on request: where its name starts, how long it is
   std::string path; uint64_t first_record = 0;
@@ -386,17 +386,58 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
       gzFile f = nullptr;
       if (!bg && !pz) { f = gzopen(path.c_str(), "rb"); if (!f) { out->finish("cannot open '" + path + "'"); return; } gzbuffer(f, 1 << 20); }
       std::vector<char> carry;
+      if (pz) {   // [r3] the pieces' text is parsed where it lies: only the record that straddles two buffers is copied
+        auto last_whole = [](const char* b, const char* e) -> const char* {   // the last record start in [b, e) whose four lines are all there (b if none)
+          size_t back = std::min<size_t>((size_t)(e - b), 1u << 16);
+          for (;;) {
+            const char* from = e - back; const char* nl = (const char*)memchr(from, '\n', (size_t)(e - from));
+            const char* last = nullptr; const char* x = (from == b) ? b : (nl ? nl + 1 : e);
+            while (x < e) { const char* r0 = record_start(x, e); if (r0 >= e) break; last = r0; const char* n0 = (const char*)memchr(r0, '\n', (size_t)(e - r0)); x = n0 ? n0 + 1 : e; }
+            if (last) return last;
+            if (back == (size_t)(e - b)) return b;
+            back = std::min<size_t>((size_t)(e - b), back * 4);
+          }
+        };
+        auto owned = [&](const char* a, size_t na, const char* b2, size_t nb) {
+          auto c = std::make_shared<Chunk>(); c->own.reset(new char[na + nb + 1]); memcpy(c->own.get(), a, na); if (nb) memcpy(c->own.get() + na, b2, nb);
+          c->text = c->own.get(); c->bytes = na + nb; c->path = path; c->first_record = nrec_before; nrec_before += (na + nb) / 250; dispatch(c);
+        };
+        for (;;) {
+          PgzBuf B; std::string e; const int rc = pgz_next(pz, &B, &e);
+          if (rc < 0) { out->finish("'" + path + "': " + e); return; }
+          if (rc == 0) break;
+          const char* b = B.p; const char* end = b + B.n; const char* p = b;
+          if (!carry.empty()) {   // the record begun in the previous buffer: its missing lines are at the head of this one
+            size_t have_nl = 0; for (char ch : carry) have_nl += ch == '\n';
+            const size_t lines = have_nl + (carry.back() != '\n' ? 1 : 0), want_nl = (lines + 3) / 4 * 4;   // the carry holds whole records and the head of one more
+            while (have_nl < want_nl && p < end) { const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p)); if (!nl) { p = end; break; } p = nl + 1; ++have_nl; }
+            if (have_nl < want_nl) { carry.insert(carry.end(), b, end); continue; }   // a buffer shorter than a record
+            owned(carry.data(), carry.size(), b, (size_t)(p - b)); carry.clear();
+          }
+          const char* cut = last_whole(p, end);
+          // the last record of [p, end) may be complete only by luck of where the buffer ends: it waits for the next buffer (or the end of the file)
+          while (p < cut) {
+            const char* q = p + CHUNK_BYTES;
+            if (q >= cut) q = cut; else { const char* nl = (const char*)memchr(q, '\n', (size_t)(cut - q)); q = nl ? record_start(nl + 1, cut) : cut; }
+            auto c = std::make_shared<Chunk>(); c->text = p; c->bytes = (size_t)(q - p); c->hold = B.hold; c->path = path; c->first_record = nrec_before; nrec_before += c->bytes / 250;
+            dispatch(c); p = q;
+          }
+          carry.assign(cut, end);
+        }
+        if (!carry.empty()) owned(carry.data(), carry.size(), nullptr, 0);
+        continue;   // next file
+      }
       for (;;) {
-        auto c = std::make_shared<Chunk>(); c->own.resize(carry.size() + CHUNK_BYTES);
-        if (!carry.empty()) memcpy(c->own.data(), carry.data(), carry.size());
+        auto c = std::make_shared<Chunk>(); c->own.reset(new char[carry.size() + CHUNK_BYTES]);   // not zero-filled: every byte used is written below
+        if (!carry.empty()) memcpy(c->own.get(), carry.data(), carry.size());
         size_t have = carry.size(); carry.clear();
         size_t got = 0; bool eof = false;
         while (got < CHUNK_BYTES) {
           long r;
-          if (bg) { r = bg->read(c->own.data() + have + got, CHUNK_BYTES - got); if (r < 0) { out->finish(bg->err); return; } }
-          else if (pz) { std::string e; r = pgz_read(pz, c->own.data() + have + got, CHUNK_BYTES - got, &e); if (r < 0) { out->finish("'" + path + "': " + e); return; } }
+          if (bg) { r = bg->read(c->own.get() + have + got, CHUNK_BYTES - got); if (r < 0) { out->finish(bg->err); return; } }
+          else if (pz) { std::string e; r = pgz_read(pz, c->own.get() + have + got, CHUNK_BYTES - got, &e); if (r < 0) { out->finish("'" + path + "': " + e); return; } }
           else {
-            r = gzread(f, c->own.data() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
+            r = gzread(f, c->own.get() + have + got, (unsigned)std::min<size_t>(CHUNK_BYTES - got, 1u << 30));
             if (r < 0) { int e; std::string msg = gzerror(f, &e); gzclose(f); out->finish("read error in '" + path + "': " + msg); return; }
           }
           if (r == 0) { eof = true; break; }
@@ -406,7 +447,7 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
         if (tot == 0) break;
         size_t cut = tot;
         if (!eof) {   // keep the incomplete tail for the next chunk: cut at the last record start whose four lines are all here
-          const char* b = c->own.data(); const char* e = b + tot; cut = 0;
+          const char* b = c->own.get(); const char* e = b + tot; cut = 0;
           size_t back = std::min<size_t>(tot, 1u << 16);
           for (;;) {
             const char* from = e - back; const char* nl = (const char*)memchr(from, '\n', (size_t)(e - from));
@@ -417,9 +458,9 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
             back = std::min<size_t>(tot, back * 4);
           }
           if (cut == 0) { if (f) gzclose(f); out->finish("'" + path + "': no FASTQ record boundary in a " + std::to_string(tot) + "-byte window (set SQ_READER_SAFE=1)"); return; }
-          carry.assign(c->own.data() + cut, c->own.data() + tot);
+          carry.assign(c->own.get() + cut, c->own.get() + tot);
         }
-        c->text = c->own.data(); c->bytes = cut; c->path = path; c->first_record = nrec_before; nrec_before += cut / 250;
+        c->text = c->own.get(); c->bytes = cut; c->path = path; c->first_record = nrec_before; nrec_before += cut / 250;
         dispatch(c);
         if (eof) break;
       }
