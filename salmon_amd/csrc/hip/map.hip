@@ -441,7 +441,8 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   const uint32_t nL = hcls[MK_NCLS - 1], memsL = hcls[MK_NCLS];
 #define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, c->mlinfo.p + (size_t)(cls) * nrec, hcls[cls], c->unimems.p, \
       skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
-  if (hcls[0]) k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0));
+  if (hcls[0]) { if (!getenv("SQ_MEMS_G16")) k_mems<8, 8, 256><<<(hcls[0] + 31) / 32, 256, 0, st>>>(SQ_MEMS_ARGS(0));   // [r3] the common end has <= 8 MEMs: eight ends per wave
+                 else k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0)); }
   if (hcls[1]) k_mems<16, MK_X_CAP, 256><<<(hcls[1] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(1));
   if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
   if (hcls[3]) k_mems<16, MK_S_CAP, 256><<<(hcls[3] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(3));

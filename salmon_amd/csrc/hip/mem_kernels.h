@@ -27,7 +27,7 @@ namespace sqk {
 
 __device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// ends by size class; an end without MEMs has no chains.  Classes (MEMs per end): 0: <= 8, 1: <= 16, 2: <= 32, 3: <= 64, 4: <= 256, 5: <= 1024,
+// ends by size class; an end without MEMs has no chains.  Classes (MEMs per end): 0: <= 8 (eight lanes per end: k_mems<8, 8, 256>), 1: <= 16, 2: <= 32, 3: <= 64, 4: <= 256, 5: <= 1024,
 // 6: larger.  ctr[c] = ends in class c, ctr[7] = MEMs of the large ends.  Classes 0 and 1 share a kernel instantiation (as 2, 3 and 4
 // have theirs) but are launched from their own lists: the four ends of a wave then cost about the same, and a wave waits for its
 // slowest end.  Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs at most seven cursor atomics.
@@ -76,14 +76,15 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
                                               uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval, uint32_t* __restrict__ mnext,
                                               sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains) {
   constexpr int GPB = TBK / G, E = CAP / G;
-  static_assert(G == 16 || G == 32 || G == 64, "group = a power-of-two slice of a wave");
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group = a power-of-two slice of a wave");
   constexpr int CP8 = CAP + 1, CP4 = CAP + 1, CP2 = CAP + 2, CP1 = CAP + 4;   // padded rows: the groups of a wave must not sit on the same banks
   __shared__ uint64_t s_key[GPB][CP8];                 // ranking keys, then (same bytes) the DP scores f[] as doubles
   // The uni-MEM headers are dead once the projection is done: the sorted MEM columns and the DP's arrays take their bytes (LDS per
   // block decides how many blocks a CU holds: 29 -> 17 KB for the tiny class).
   constexpr int O_R = 0, O_TID = O_R + 4 * CP4, O_Q = O_TID + 4 * CP4, O_LF = O_Q + 2 * CP2, O_P = O_LF + 2 * CP2, O_ACC = O_P + 2 * CP2,
                 O_GS = O_ACC + 2 * CP2, O_GC = O_GS + 2 * (CP2 + 2), O_FL = O_GC + 2 * CP2, O_END = O_FL + CP1;
-  constexpr int HB = SQ_MAX_UNIMEMS * (int)sizeof(MkHdr);
+  // [r3] only uni-MEMs with occurrences are kept (those over max_occ project nothing), so an end of n MEMs has at most n headers
+  constexpr int HB = (CAP < (int)SQ_MAX_UNIMEMS ? CAP : (int)SQ_MAX_UNIMEMS) * (int)sizeof(MkHdr);
   constexpr int UW = ((O_END > HB ? O_END : HB) + 7) / 8 + 1;   // 8-byte words per group; + 1: the groups of a wave must not sit on the same banks
   __shared__ uint64_t s_u[GPB][UW];
   __shared__ double s_gap[SQ_MAX_CHAIN_GAP + 1];
@@ -106,12 +107,17 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
   const uint32_t nu = (li4.y >> 16) & 0x3Fu;
   const int L = (int)(li4.y >> 22);
   // ---- uni-MEM headers: lane i fetches uni-MEM i; its contig-table run and unitig length came with it from k_seed ----
-  for (uint32_t i = (uint32_t)gl; i < nu; i += G) {
-    const sq_unimem_dev m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
-    MkHdr h; h.a = m.ctab_a; h.cnt = m.cnt;
-    h.ulen = m.ulen; h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u));
-    g_h[i] = h;
-  }
+  { uint32_t kept = 0;
+    for (uint32_t i0 = 0; i0 < nu; i0 += G) {   // the lanes of a group run this loop together: the ballot below sees all of them
+      const uint32_t i = i0 + (uint32_t)gl; const bool in = i < nu;
+      sq_unimem_dev m{}; if (in) m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
+      const bool has = in && m.cnt != 0;
+      const unsigned long long bm = __ballot(has);
+      const uint32_t gm = (G == 64) ? 0u : (uint32_t)((bm >> gsh) & ((1ull << (G & 63)) - 1));
+      const uint32_t below = (G == 64) ? (uint32_t)__popcll(bm & ((1ull << lane) - 1)) : (uint32_t)__popc(gm & ((1u << gl) - 1));
+      if (has) { MkHdr h; h.a = m.ctab_a; h.cnt = m.cnt; h.ulen = m.ulen; h.ustart = m.ustart; h.qpos = m.qpos; h.lenfw = (uint16_t)(m.len | (m.fw ? 0x8000u : 0u)); g_h[kept + below] = h; }
+      kept += (G == 64) ? (uint32_t)__popcll(bm) : (uint32_t)__popc(gm);
+    } }
   mk_wsync();
   // ---- projection: output slot p = occurrence (uni-MEM i, j - a_i) in emission order; one lane per occurrence ----
   uint64_t K[E]; int32_t R[E]; uint32_t T[E]; int16_t Q[E]; uint16_t LF[E]; uint32_t rk[E];
