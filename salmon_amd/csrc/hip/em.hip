@@ -830,10 +830,14 @@ struct GibbsDev { uint32_t M,
     const double* prior;
     const uint8_t* active;
                   double* mu; double* count_f; unsigned long long* count_i; const uint64_t* draw_off; };
-__global__ void k_gibbs_mu(GibbsDev g, uint64_t seed, uint64_t round_key, int no_gamma) {
+// [r3] the counts of the round before arrive as integers (count_i, filled by the item kernels' atomics) and are cleared here for this round's
+// draws — the memset and the integer-to-double pass in between are gone; from_f = 1: the chain (re)starts from count_f (the initial counts)
+__global__ void k_gibbs_mu(GibbsDev g, uint64_t seed, uint64_t round_key, int no_gamma, int from_f) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
+  const double cprev = from_f ? g.count_f[i] : (double)g.count_i[i];
+  g.count_i[i] = 0;
   if (!g.active[i]) { g.mu[i] = 0.0; return; }
-  double ci = g.count_f[i] + g.prior[i];
+  double ci = cprev + g.prior[i];
   g.mu[i] = no_gamma ? ci / g.eff[i] : sq_gamma_draw(ci, 1.0 / (0.1 + g.eff[i]), seed, round_key, (uint64_t)i);   // beta = 0.1 (:104)
 }
 __device__ inline double gibbs_class_p(const GibbsDev& g, uint64_t a, uint32_t n, int mode, uint32_t i) {
@@ -858,9 +862,9 @@ __global__ void k_gibbs_prep(GibbsDev g, double* __restrict__ cum, double* __res
 // per draw — the sums are integers, so the result is the same whatever the order.  pick = #{i < n-1 : !(u < acc_i)}: the running
 // sums never decrease, so that is the first i with u < acc_i (n - 1 when there is none).
 template <int NMAX>
-__global__ void __launch_bounds__(256) k_gibbs_items_reg(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+__device__ inline void gibbs_items_reg(const GibbsDev& g, uint32_t it, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
     uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
-  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
+  if (it >= nitems) return;
   const uint32_t c = item_cls[it];
   const uint64_t a = g.off[c];
   const uint32_t n = (uint32_t)(g.off[c + 1] - a);
@@ -888,9 +892,9 @@ __global__ void __launch_bounds__(256) k_gibbs_items_reg(GibbsDev g, uint32_t ni
   }
 }
 // larger classes: binary search of the running sums per draw
-__global__ void k_gibbs_items_big(GibbsDev g, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+__device__ inline void gibbs_items_big(const GibbsDev& g, uint32_t it, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
     uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
-  const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; if (it >= nitems) return;
+  if (it >= nitems) return;
   const uint32_t c = item_cls[it];
   const uint64_t a = g.off[c];
   const uint32_t n = (uint32_t)(g.off[c + 1] - a);
@@ -903,6 +907,15 @@ __global__ void k_gibbs_items_big(GibbsDev g, uint32_t nitems, const uint32_t* _
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (u < cum[a + mid]) hi = mid; else lo = mid + 1; }
     atomicAdd(&g.count_i[g.tid[a + lo]], 1ULL);
   }
+}
+// [r3] the three item lists of a round in ONE launch (blocks [0, nb0): <= 8 labels, [nb0, nb0 + nb1): <= 16, the rest: larger): they are
+// independent, and four launches per round instead of seven leave less of a round to launch gaps (84 of 187 us before)
+__global__ void __launch_bounds__(256) k_gibbs_items(GibbsDev g, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t nb0, uint32_t nb1, const uint32_t* __restrict__ item_cls,
+    const uint32_t* __restrict__ item_s0, uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
+  const uint32_t b = blockIdx.x;
+  if (b < nb0) gibbs_items_reg<8>(g, b * 256u + threadIdx.x, n0, item_cls, item_s0, seed, round_key, cum, denom);
+  else if (b < nb0 + nb1) gibbs_items_reg<16>(g, (b - nb0) * 256u + threadIdx.x, n1, item_cls + n0, item_s0 + n0, seed, round_key, cum, denom);
+  else gibbs_items_big(g, (b - nb0 - nb1) * 256u + threadIdx.x, n2, item_cls + n0 + n1, item_s0 + n0 + n1, seed, round_key, cum, denom);
 }
 __global__ void k_gibbs_alpha(GibbsDev g, double scale, double* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
@@ -1157,21 +1170,18 @@ extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, cons
   SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
   struct Cleanup { hipStream_t& s; hipEvent_t& a; hipEvent_t& b; ~Cleanup() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (s) (void)hipStreamDestroy(s); } } cleanup{st, e0, e1};
   double round_ms = 0.0; uint64_t rounds = 0;
-  const uint32_t o1 = list_n[0], o2 = list_n[0] + list_n[1];
+  const uint32_t nb0 = (list_n[0] + TB - 1) / TB, nb1 = (list_n[1] + TB - 1) / TB, nb2 = (list_n[2] + TB - 1) / TB;
   for (uint32_t sid = first; sid < first + count; ++sid) {
     // chain restart (:452-455); a range that starts at a later chain starts from the initial counts as well
-    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) SQ_HIP_CHECK(hipMemcpyAsync(d_cf.p, init.data(), (size_t)M * 8,
-        hipMemcpyHostToDevice, st));
+    bool from_f = sid == first;
+    if (sid > 0 && nchains > 1 && sid % step == 0 && sid / step < nchains) { SQ_HIP_CHECK(hipMemcpyAsync(d_cf.p, init.data(), (size_t)M * 8,
+        hipMemcpyHostToDevice, st)); from_f = true; }
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     for (uint32_t r = 0; r < thin; ++r) {
       const uint64_t key = (uint64_t)sid * thin + r;
-      k_gibbs_mu<<<(M + TB - 1) / TB, TB, 0, st>>>(g, seed, key, go->no_gamma_draw);
-      SQ_HIP_CHECK(hipMemsetAsync(d_ci.p, 0, (size_t)M * 8, st));
+      k_gibbs_mu<<<(M + TB - 1) / TB, TB, 0, st>>>(g, seed, key, go->no_gamma_draw, (from_f && r == 0) ? 1 : 0);
       if (E) k_gibbs_prep<<<(E + TB - 1) / TB, TB, 0, st>>>(g, d_cum.p, d_den.p);
-      if (list_n[0]) k_gibbs_items_reg<8><<<(list_n[0] + TB - 1) / TB, TB, 0, st>>>(g, list_n[0], d_ic.p, d_is.p, seed, key, d_cum.p, d_den.p);
-      if (list_n[1]) k_gibbs_items_reg<16><<<(list_n[1] + TB - 1) / TB, TB, 0, st>>>(g, list_n[1], d_ic.p + o1, d_is.p + o1, seed, key, d_cum.p, d_den.p);
-      if (list_n[2]) k_gibbs_items_big<<<(list_n[2] + TB - 1) / TB, TB, 0, st>>>(g, list_n[2], d_ic.p + o2, d_is.p + o2, seed, key, d_cum.p, d_den.p);
-      k_u64_to_f64<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_ci.p, d_cf.p);
+      if (nb0 + nb1 + nb2) k_gibbs_items<<<nb0 + nb1 + nb2, TB, 0, st>>>(g, list_n[0], list_n[1], list_n[2], nb0, nb1, d_ic.p, d_is.p, seed, key, d_cum.p, d_den.p);
     }
     SQ_HIP_CHECK(hipEventRecord(e1, st));
     k_mul<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_mu.p, d_eff.p, d_me.p);
