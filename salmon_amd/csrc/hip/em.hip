@@ -908,14 +908,19 @@ __device__ inline void gibbs_items_big(const GibbsDev& g, uint32_t it, uint32_t 
     atomicAdd(&g.count_i[g.tid[a + lo]], 1ULL);
   }
 }
-// [r3] the three item lists of a round in ONE launch (blocks [0, nb0): <= 8 labels, [nb0, nb0 + nb1): <= 16, the rest: larger): they are
-// independent, and four launches per round instead of seven leave less of a round to launch gaps (84 of 187 us before)
-__global__ void __launch_bounds__(256) k_gibbs_items(GibbsDev g, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t nb0, uint32_t nb1, const uint32_t* __restrict__ item_cls,
+// [r3] the item lists of a round in as few launches as their sizes allow: blocks [0, nb0) take the items of at most 8 labels (thresholds in
+// registers), the blocks behind them the items [rest0, rest0 + nrest) by binary search — the large classes and, when there are only a few of
+// them, the 9..16-label ones too (either way a draw picks the first label whose running sum exceeds it; the binary search needs few
+// registers, so the common path keeps its occupancy).  Seven stream operations per round became three or four.
+__global__ void __launch_bounds__(256) k_gibbs_items(GibbsDev g, uint32_t n0, uint32_t nb0, uint32_t rest0, uint32_t nrest, const uint32_t* __restrict__ item_cls,
     const uint32_t* __restrict__ item_s0, uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
   const uint32_t b = blockIdx.x;
   if (b < nb0) gibbs_items_reg<8>(g, b * 256u + threadIdx.x, n0, item_cls, item_s0, seed, round_key, cum, denom);
-  else if (b < nb0 + nb1) gibbs_items_reg<16>(g, (b - nb0) * 256u + threadIdx.x, n1, item_cls + n0, item_s0 + n0, seed, round_key, cum, denom);
-  else gibbs_items_big(g, (b - nb0 - nb1) * 256u + threadIdx.x, n2, item_cls + n0 + n1, item_s0 + n0 + n1, seed, round_key, cum, denom);
+  else gibbs_items_big(g, (b - nb0) * 256u + threadIdx.x, nrest, item_cls + rest0, item_s0 + rest0, seed, round_key, cum, denom);
+}
+__global__ void __launch_bounds__(256) k_gibbs_items16(GibbsDev g, uint32_t n1, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed,
+    uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
+  gibbs_items_reg<16>(g, blockIdx.x * 256u + threadIdx.x, n1, item_cls, item_s0, seed, round_key, cum, denom);
 }
 __global__ void k_gibbs_alpha(GibbsDev g, double scale, double* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= g.M) return;
@@ -1170,7 +1175,9 @@ extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, cons
   SQ_HIP_CHECK(hipStreamCreate(&st)); SQ_HIP_CHECK(hipEventCreate(&e0)); SQ_HIP_CHECK(hipEventCreate(&e1));
   struct Cleanup { hipStream_t& s; hipEvent_t& a; hipEvent_t& b; ~Cleanup() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (s) (void)hipStreamDestroy(s); } } cleanup{st, e0, e1};
   double round_ms = 0.0; uint64_t rounds = 0;
-  const uint32_t nb0 = (list_n[0] + TB - 1) / TB, nb1 = (list_n[1] + TB - 1) / TB, nb2 = (list_n[2] + TB - 1) / TB;
+  const bool fold16 = list_n[1] < 65536;   // few 9..16-label items: they ride with the large ones
+  const uint32_t rest0 = list_n[0] + (fold16 ? 0u : list_n[1]), nrest = list_n[2] + (fold16 ? list_n[1] : 0u);
+  const uint32_t nb0 = (list_n[0] + TB - 1) / TB, nb1 = fold16 ? 0u : (list_n[1] + TB - 1) / TB, nbr = (nrest + TB - 1) / TB;
   for (uint32_t sid = first; sid < first + count; ++sid) {
     // chain restart (:452-455); a range that starts at a later chain starts from the initial counts as well
     bool from_f = sid == first;
@@ -1181,7 +1188,8 @@ extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, cons
       const uint64_t key = (uint64_t)sid * thin + r;
       k_gibbs_mu<<<(M + TB - 1) / TB, TB, 0, st>>>(g, seed, key, go->no_gamma_draw, (from_f && r == 0) ? 1 : 0);
       if (E) k_gibbs_prep<<<(E + TB - 1) / TB, TB, 0, st>>>(g, d_cum.p, d_den.p);
-      if (nb0 + nb1 + nb2) k_gibbs_items<<<nb0 + nb1 + nb2, TB, 0, st>>>(g, list_n[0], list_n[1], list_n[2], nb0, nb1, d_ic.p, d_is.p, seed, key, d_cum.p, d_den.p);
+      if (nb0 + nbr) k_gibbs_items<<<nb0 + nbr, TB, 0, st>>>(g, list_n[0], nb0, rest0, nrest, d_ic.p, d_is.p, seed, key, d_cum.p, d_den.p);
+      if (nb1) k_gibbs_items16<<<nb1, TB, 0, st>>>(g, list_n[1], d_ic.p + list_n[0], d_is.p + list_n[0], seed, key, d_cum.p, d_den.p);
     }
     SQ_HIP_CHECK(hipEventRecord(e1, st));
     k_mul<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_mu.p, d_eff.p, d_me.p);
