@@ -400,7 +400,8 @@ int sq_bias_eff_lengths(sq_index* idx, const sq_bias_models* models, const doubl
 int sq_index_length_classes(const sq_index* idx, uint32_t* quantiles5, uint8_t* cls /* [num_refs] or NULL */);
 /* updateEffectiveLengths as a callback: alphas and current effective lengths in, new effective lengths out; non-zero aborts. */
 typedef int (*sq_efflen_cb)(const double* alphas, const double* eff_len_in, double* eff_len_out, uint32_t m, void* user);
-/* sq_em_optimize with the bias hook: after 11 updates (itNum > 10) `cb` is called once, priors and combined class weights are rebuilt
+/* sq_em_optimize with the bias hook: after 11 updates (itNum > 10) — or at the first update after which the convergence test holds, if that
+ * comes earlier (CollapsedEMOptimizer.cpp:901: `itNum > targetIt or converged`) — `cb` is called once, priors and combined class weights are rebuilt
  * from the new effective lengths (updateEqClassWeights, CollapsedEMOptimizer.cpp:160-176) and the iteration goes on.
  * eff_len_out (may be NULL) receives the lengths the optimisation ended with (Transcript::EffectiveLength, :1024-1027). */
 int sq_em_optimize_bias(sq_ctx*, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* opts, sq_efflen_cb cb, void* user,

@@ -1322,11 +1322,11 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
 
 // iteration loop shared by optimize (minIter 100) and the bootstrap replicates (minIter 50)
 static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters,
-    bool* converged, double* max_rel, uint32_t it0 = 0, uint32_t stop_at = 0 /* > 0: exactly the iterations [it0, stop_at) */) {
+    bool* converged, double* max_rel, uint32_t it0 = 0, uint32_t stop_at = 0 /* > 0: the part before the bias hook — until the convergence test holds, stop_at iterations at most */) {
   const uint32_t M = P.M;
   std::vector<double> alphaP(M), theta(M), inv(P.E);
   uint32_t it = it0; bool conv = false; double maxRel = -1.7976931348623157e308;
-  while (stop_at ? it < stop_at : (it < min_iter || (it < o->max_iter && !conv))) {
+  while (stop_at ? (it < stop_at && !conv) : (it < min_iter || (it < o->max_iter && !conv))) {
     em_step(P, o, alpha, alphaP, theta, inv);
     conv = true; maxRel = -1.7976931348623157e308;
     for (uint32_t i = 0; i < M; ++i) {
@@ -1633,7 +1633,8 @@ static int bias_seq_eff_lengths(const Index& ix, bool gc, const double* gc_obs, 
   return (int)processed.size();
 }
 
-// optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928): after 11 updates updateEffectiveLengths, new priors
+// optimize() with the bias hook (CollapsedEMOptimizer.cpp:901-928: `itNum > targetIt or converged`): after 11 updates — or at the first update
+// after which the convergence test holds, if that comes earlier — updateEffectiveLengths, new priors
 // (populatePriorAlphas_) and combined weights (updateEqClassWeights :160-176; degenerate classes stay dropped), then on to convergence
 static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, const Index& ix, const double* gc_obs, const double* log_pmf,
                           double* alpha_out, double* eff_out, sq_em_report* rep, const uint64_t* seq_fw = nullptr, const uint64_t* seq_rc = nullptr, const PosIn* pos = nullptr) {
@@ -1667,7 +1668,7 @@ static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_
     for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = P.cw[i] * wn;
   }
   if (!o->per_transcript_prior) for (uint32_t i = 0; i < M; ++i) P.prior[i] = o->vb_prior * eff2[i];
-  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 11, 0);
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, it, 0);
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;
   double asum = canonical_sum(alpha);
   for (uint32_t i = 0; i < M; ++i) { alpha_out[i] = alpha[i]; if (eff_out) eff_out[i] = eff2[i]; }

@@ -684,7 +684,8 @@ struct EmSession {
   // mode 0: optimise to convergence (min_iter / o->max_iter); mode 1: exactly `fixed_iters` steps.
   // alpha_dev != nullptr: the initial alphas are already in d_a0 (device); else they are uploaded from `alpha`.
   int run(std::vector<double>& alpha, int mode, uint32_t fixed_iters, uint32_t min_iter, sq_em_report* rep, bool alpha_on_device = false,
-      bool fetch = true, uint32_t it0 = 0 /* iterations already done (the bias hook splits an optimisation in two runs) */) {
+      bool fetch = true, uint32_t it0 = 0 /* iterations already done (the bias hook splits an optimisation in two runs) */,
+      uint32_t max_iter_cap = 0 /* > 0: stop after this many iterations at the latest (the part before the bias hook) */) {
     const int TB = 256;
     if (!alpha_on_device) {
       if (h_stage) {
@@ -738,7 +739,7 @@ struct EmSession {
       for (; it < it0 + fixed_iters; ++it) launch_iter(it);
       executed = it0 + fixed_iters;
     } else {
-      const uint32_t maxIter = o->max_iter, minIter = min_iter;
+      const uint32_t maxIter = max_iter_cap ? max_iter_cap : o->max_iter, minIter = min_iter;
       // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
       while (it < maxIter || it < minIter) {
         uint32_t chunk = (it < minIter) ? (minIter - it) : 64;   // a look costs a stream drain (~25 us); an iteration queued past convergence is five no-op launches
@@ -1007,12 +1008,15 @@ int sq_em_optimize_bias_impl(int device, const sq_eq_table* eq, const sq_eq_dev_
   if (lent_stream) { S.st = (hipStream_t)lent_stream; S.own_stream = false; }
   int rc = S.setup(device, eq, txp, o, dv); if (rc) return rc;
   sq_em_report r1{}, r2{};
-  const uint32_t HOOK_AT = 11;   // needBias and itNum > targetIt (= 10)
-  rc = S.run(alpha, 1, HOOK_AT, 0, &r1); if (rc) return rc;
+  // `needBias and (itNum > targetIt or converged)` (CollapsedEMOptimizer.cpp:901): the hook fires after 11 updates, or earlier at the first
+  // update after which the convergence test holds (it is evaluated every iteration, whatever minIter says)
+  const uint32_t HOOK_AT = 11;
+  rc = S.run(alpha, 0, 0, 0, &r1, false, true, 0, HOOK_AT); if (rc) return rc;
+  const uint32_t it1 = r1.iters;
   const uint32_t ndeg = S.num_degenerate;
   if (cb(alpha.data(), eff.data(), eff2.data(), M, user)) { sq_set_error("sq_em_optimize_bias: the effective-length callback failed"); return SQ_ERR_STATE; }
   rc = S.refresh_weights(eff2.data()); if (rc) return rc;
-  rc = S.run(alpha, 0, 0, o->min_iter, &r2, false, true, HOOK_AT); if (rc) return rc;
+  rc = S.run(alpha, 0, 0, o->min_iter, &r2, false, true, it1); if (rc) return rc;
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;
   const double asum = canonical_sum_host(alpha);
   memcpy(alpha_out, alpha.data(), (size_t)M * 8);

@@ -249,3 +249,20 @@ def test_pos_bias_single_end_library_and_cli(small_world, built, tmp_path):
     e_c, pm_c, _ = orc.bias_eff_lengths(w["oidx"], ost.model()[4], a0, eff, pos_obs=p_c)
     assert np.array_equal(pm_g.reshape(4, 100), pm_c) and np.array_equal(e_g, e_c)
     ctx.free(); ost.free()
+
+
+def test_bias_hook_fires_at_the_first_convergence_when_that_comes_before_iteration_11(small_world):
+    # CollapsedEMOptimizer.cpp:901 `itNum > targetIt or converged`: with a tolerance everything meets the hook comes after the first update
+    w = small_world; w["idx"].to_device(0)
+    ctx, ost = _run(w, w["seq"], w["off"], w["n"])
+    g_g, g_c = ctx.gc_observed(), ost.gc_observed()
+    eq_g, eq_c = ctx.eq_finish(), ost.eq_finish()
+    lm, uq, tc, le = ctx.model(); fld = ctx.fld(); mc = ost.model()
+    proj = api.normalize_alphas(eq_g, lm, uq, tc); eff = np.exp(le)
+    loose = api.em_opts(); loose.rel_diff_tolerance = 1e9; loose.min_iter = 30
+    al_g, ef_g, rep_g = ctx.em_optimize_gc(eff, proj, g_g, fld, loose)
+    al_c, ef_c, rep_c = orc.em_optimize_gc(eq_c, eff, proj, w["oidx"], g_c, mc[4], loose)
+    assert rep_g["iters"] == rep_c["iters"] == 30 and np.array_equal(ef_g, ef_c) and np.array_equal(al_g, al_c)
+    al_d, ef_d, rep_d = ctx.em_optimize_gc(eff, proj, g_g, fld, api.em_opts())
+    assert not np.array_equal(ef_d, ef_g)            # the default run calls the hook with the alphas of iteration 11, this one with those of iteration 1
+    ctx.free(); ost.free()
