@@ -893,7 +893,9 @@ __device__ inline void gibbs_items_reg(const GibbsDev& g, uint32_t it, uint32_t 
   }
 }
 // larger classes: binary search of the running sums per draw
-__device__ inline void gibbs_items_big(const GibbsDev& g, uint32_t it, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
+// [r3] a WAVE per item: lane l takes the draws s0 + l, s0 + l + 64, ... — a thread walking its item's 256 draws through four dependent loads
+// each was the long pole of a round whenever this list was short (23 items took as long as the 639 000 of the register path)
+__device__ inline void gibbs_items_big(const GibbsDev& g, uint32_t it, uint32_t lane, uint32_t nitems, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0,
     uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
   if (it >= nitems) return;
   const uint32_t c = item_cls[it];
@@ -902,7 +904,7 @@ __device__ inline void gibbs_items_big(const GibbsDev& g, uint32_t it, uint32_t 
   const uint64_t cnt = g.cnt[c];
   const double dn = denom[c];
   const uint64_t s0 = item_s0[it], s1 = min(s0 + 256, cnt), base = g.draw_off[c];
-  for (uint64_t sidx = s0; sidx < s1; ++sidx) {
+  for (uint64_t sidx = s0 + lane; sidx < s1; sidx += 64) {
     const double u = sq_u01(sq_r64(seed ^ 0xC1A55ULL, round_key, base + sidx)) * dn;
     uint32_t lo = 0, hi = n - 1;                       // first i in [0, n-1) with u < cum[i], else n - 1
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (u < cum[a + mid]) hi = mid; else lo = mid + 1; }
@@ -917,7 +919,7 @@ __global__ void __launch_bounds__(256) k_gibbs_items(GibbsDev g, uint32_t n0, ui
     const uint32_t* __restrict__ item_s0, uint64_t seed, uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
   const uint32_t b = blockIdx.x;
   if (b < nb0) gibbs_items_reg<8>(g, b * 256u + threadIdx.x, n0, item_cls, item_s0, seed, round_key, cum, denom);
-  else gibbs_items_big(g, (b - nb0) * 256u + threadIdx.x, nrest, item_cls + rest0, item_s0 + rest0, seed, round_key, cum, denom);
+  else gibbs_items_big(g, (b - nb0) * 4u + (threadIdx.x >> 6), threadIdx.x & 63u, nrest, item_cls + rest0, item_s0 + rest0, seed, round_key, cum, denom);
 }
 __global__ void __launch_bounds__(256) k_gibbs_items16(GibbsDev g, uint32_t n1, const uint32_t* __restrict__ item_cls, const uint32_t* __restrict__ item_s0, uint64_t seed,
     uint64_t round_key, const double* __restrict__ cum, const double* __restrict__ denom) {
@@ -1181,7 +1183,7 @@ extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, cons
   double round_ms = 0.0; uint64_t rounds = 0;
   const bool fold16 = list_n[1] < 65536;   // few 9..16-label items: they ride with the large ones
   const uint32_t rest0 = list_n[0] + (fold16 ? 0u : list_n[1]), nrest = list_n[2] + (fold16 ? list_n[1] : 0u);
-  const uint32_t nb0 = (list_n[0] + TB - 1) / TB, nb1 = fold16 ? 0u : (list_n[1] + TB - 1) / TB, nbr = (nrest + TB - 1) / TB;
+  const uint32_t nb0 = (list_n[0] + TB - 1) / TB, nb1 = fold16 ? 0u : (list_n[1] + TB - 1) / TB, nbr = (nrest + 3) / 4;   // a wave per item
   for (uint32_t sid = first; sid < first + count; ++sid) {
     // chain restart (:452-455); a range that starts at a later chain starts from the initial counts as well
     bool from_f = sid == first;
