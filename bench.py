@@ -365,7 +365,8 @@ def main():
     # roofline: the stage kernel with the largest total time in the timed region — every stage is a candidate, the online model's mini-batch
     # chain included (it runs on its own CU partition beside mapping; its row aggregates one launch pair per group of mini-batches)
     pm = {}
-    try: pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+    try:   # the counter passes were taken on the c2 workload: no traffic figure for the others
+        if a.workload == "c2": pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
     except Exception: pass
     cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
     roof = None; roofs = {}
@@ -397,7 +398,7 @@ def main():
         dom = max(roofs, key=lambda k: roofs[k]["ms_total"])
         roof = dict(roofs[dom])
         roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload "
-                                "at --steps 2; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run") if roof["traffic"] is not None else "no PMC profile committed for this kernel"
+                                "at --steps 2; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run") if roof["traffic"] is not None else "no PMC profile committed for this kernel on this workload"
         roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
         roof["all_kernels"] = {k: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
     if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
