@@ -131,6 +131,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
       // a partition is an optimisation: if the platform refuses CU masks, fall back to plain streams
+      if (getenv("SQ_MAP_ALL_CUS")) for (int i = 0; i < ncu; ++i) m1[i / 32] |= 1u << (i % 32);   // experiment: mapping may use the eq stage's CUs too
       bool ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()) == hipSuccess;
       if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess &&
           hipStreamCreate(&c->stream3) == hipSuccess;
