@@ -129,6 +129,9 @@ struct sq_ctx {
   // dependent kernels then never queues behind the mapping kernels' workgroups.  stream3 is unmasked: an eq job that
   // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
   hipStream_t stream3 = nullptr;
+  // [r3, experimental: SQ_EQ_CHAIN=1] no partition: mapping and the eq stage's throughput kernels share all CUs, and the mass-dependent chain of a
+  // batch is ONE resident kernel (k_chain, hip/online.hip) on a stream masked to a single XCD, with a barrier of its own between the groups
+  hipStream_t stream_chain = nullptr; hipEvent_t ev_chain_in = nullptr, ev_chain_out = nullptr; uint32_t chain_blocks = 0;
   hipStream_t eq_stream_cur = nullptr;
   int eq_cus = 0;
   std::atomic<int> map_active{0};

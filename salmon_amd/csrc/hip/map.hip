@@ -127,6 +127,21 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
     if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
     c->eq_cus = eq_cus;
+    if (getenv("SQ_EQ_CHAIN") && ncu >= 64 && !owner) {   // experiment: see ctx.h
+      std::vector<uint32_t> mc((ncu + 31) / 32, 0);
+      for (int i = ncu - 32; i < ncu; ++i) mc[i / 32] |= 1u << (i % 32);                     // the last XCD
+      SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2)); SQ_HIP_CHECK(hipStreamCreate(&c->stream3));
+      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream_chain, (uint32_t)mc.size(), mc.data()));
+      SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_in, hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_out, hipEventDisableTiming));
+      c->chain_blocks = getenv("SQ_CHAIN_BLOCKS") ? (uint32_t)atoi(getenv("SQ_CHAIN_BLOCKS")) : 64u;   // two per CU of the XCD: they must all be resident at once
+      c->eq_cus = 0;
+    } else
+    if (getenv("SQ_EQ_PRIO")) {   // experiment: no partition; the eq chain on a high-priority stream, mapping on a low-priority one
+      int lo = 0, hi = 0; SQ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      SQ_HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lo));
+      if (!owner) { SQ_HIP_CHECK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)); SQ_HIP_CHECK(hipStreamCreate(&c->stream3)); }
+      c->eq_cus = 0;
+    } else
     if (eq_cus > 0) {
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
@@ -253,6 +268,9 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  if (c->stream_chain) { (void)hipStreamSynchronize(c->stream_chain); (void)hipStreamDestroy(c->stream_chain); }
+  if (c->ev_chain_in) (void)hipEventDestroy(c->ev_chain_in);
+  if (c->ev_chain_out) (void)hipEventDestroy(c->ev_chain_out);
   for (int b = 0; b < 2; ++b) {
     if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]);
     if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]);

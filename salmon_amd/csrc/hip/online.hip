@@ -80,6 +80,7 @@ struct sq_online_dev {
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
   sq_dbuf<int32_t> cmeans;   // conditional fragment-length means of the prior distribution [1001] (single-end --gcBias)
+  sq_dbuf<double> fm_dev; sq_dbuf<unsigned> chain_bar; bool chain_bar_zeroed = false; size_t fm_dev_n = 0;   // [r3] k_chain: the batch's forgetting masses, the barrier's counter and generation
   sq_dbuf<uint16_t> posbin; sq_dbuf<unsigned long long> pos_obs; sq_dbuf<uint8_t> lenclass;   // --posBias: per alignment the 5' bin | 3' bin << 8 (class * 20 + bin, 255 = none); observed masses [2][100], fixed point 2^-32; Transcript::lengthClassIndex
   sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
@@ -791,6 +792,90 @@ __global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM
   V.tlc[t] = sq_log_add(V.prior_mass[t], m);
 }
 
+// [r3, SQ_EQ_CHAIN=1] The mass-dependent chain of a whole mapped batch as ONE kernel: all its blocks are resident at once on one XCD
+// (the stream's CU mask), a group of W mini-batches is phase A (k_frag_dynamic's work) + phase B (k_apply_dynamic's) with a barrier
+// of the kernel's own in between, and no launch separates the ~200 groups of a batch.  Everything the phases hand to each other
+// crosses the XCD's L2: the masses are read with agent-scope loads (the per-CU L1 is not coherent inside a kernel), the
+// increments are agent-scope atomics, tlc is stored with an agent-scope store, and a thread waits for its memory operations
+// (s_waitcnt) before its block arrives at the barrier.  Same arithmetic, same order per transcript as the two-kernel form.
+struct ChainArgs { uint32_t n, mb, W, nmb; const double* fm; const uint64_t* aln_off; const DynAln* dyn; const uint8_t* gcbin; const uint64_t* assigned_prefix; unsigned* bar; };
+__device__ inline double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ inline void chain_barrier(unsigned* bar) {
+  __builtin_amdgcn_s_waitcnt(0);                       // this thread's loads, stores and atomics have been answered by the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);
+      (void)__hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_chain(OnlineView V, ChainArgs A) {   // <= 96 registers: a wave of it fits beside the six resident waves of the seed kernel
+  const uint32_t nth = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t b0 = 0; b0 < A.nmb; b0 += A.W) {
+    const uint32_t nw = A.nmb - b0 < A.W ? A.nmb - b0 : A.W;
+    const uint32_t r0 = b0 * A.mb; uint32_t r1 = (b0 + nw) * A.mb; if (r1 > A.n) r1 = A.n;
+    // ---- phase A: the fragments of the group against the masses as the group before left them ----
+    for (uint32_t r = r0 + tid; r < r1; r += nth) {
+      const uint64_t a0 = A.aln_off[r], a1 = A.aln_off[r + 1];
+      if (a1 == a0) continue;
+      const uint32_t mbs = (r - r0) / A.mb;
+      double sumProbs = SQ_LOG_0; uint32_t nk = 0; double lp[4];
+      for (uint64_t ai = a0; ai < a1; ++ai) {
+        const DynAln d = A.dyn[ai];
+        if (!d.keep) continue;
+        const double logProb = ld_agent(&V.tlc[d.tid]) + d.aux + d.start;
+        if (nk < 4) lp[nk] = logProb;
+        sumProbs = sq_log_add(sumProbs, logProb); ++nk;
+      }
+      if (nk == 0) continue;
+      uint32_t ki = 0;
+      for (uint64_t ai = a0; ai < a1; ++ai) {
+        const DynAln d = A.dyn[ai];
+        if (!d.keep) continue;
+        const double logProb = ki < 4 ? lp[ki] : (ld_agent(&V.tlc[d.tid]) + d.aux + d.start);
+        ++ki;
+        const double pr = sq_exp(logProb - sumProbs);
+        const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
+        if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (A.gcbin && A.gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[A.gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (V.posbin) pos_observe(V, ai, pr);
+      }
+    }
+    chain_barrier(A.bar);
+    // ---- phase B: every transcript folds its slots in mini-batch order, each with its forgetting mass ----
+    if (tid == 0) V.ctr[0] += (unsigned long long)(A.assigned_prefix[r1] - A.assigned_prefix[r0]);
+    for (uint32_t t = tid; t < V.M; t += nth) {
+      unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
+      unsigned long long qv[SQ_MAX_INFLIGHT <= 8 ? 8 : 8]; unsigned long long any = 0;
+      if (V.W <= 8) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
+        if (!any) continue;
+        double m = V.mass[t];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) if ((uint32_t)w < nw && qv[w]) { m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(qv[w], SQ_MFRAC_BITS))); acc[w] = 0; }
+        V.mass[t] = m;
+        __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        double m = V.mass[t]; bool hit = false;
+        for (uint32_t w = 0; w < nw; ++w) {
+          const unsigned long long q = __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!q) continue;
+          m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); acc[w] = 0; hit = true;
+        }
+        if (!hit) continue;
+        V.mass[t] = m;
+        __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    chain_barrier(A.bar);
+  }
+}
+
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
 // transcript.mass(withPrior) = logAdd(priorMass, mass) (Transcript.hpp:214-217)
 __device__ inline void apply_mass_part(const OnlineView& V, const FmArr& FM, uint32_t nw, uint64_t assigned_after, int set_ctr, uint32_t par,
@@ -1220,7 +1305,7 @@ void sq_online_free(sq_ctx* c) {
   o->tflag.free_();
   o->mb_samples.free_();
   o->gcbin.free_();
-  o->gc_obs.free_(); o->posbin.free_(); o->pos_obs.free_(); o->lenclass.free_();
+  o->gc_obs.free_(); o->posbin.free_(); o->pos_obs.free_(); o->lenclass.free_(); o->fm_dev.free_(); o->chain_bar.free_();
   o->assigned_prefix_b.free_();
   o->mass_acc.free_();
   o->uniq.free_();
@@ -1419,6 +1504,23 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     k_frag_static<<<nblk(n), 256, 0, st>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
     const uint32_t W = o->inflight;
+    if (c->stream_chain && nmb) {   // [r3, SQ_EQ_CHAIN=1] the whole chain of the batch as one resident kernel on its own XCD
+      (void)forgetting_mass(o, q.forgetting_factor, o->batch_no + nmb);   // the schedule up to this batch's last mini-batch
+      if (o->fm_dev_n < o->fm_host.size()) {   // the whole schedule lives on the device; it grows by doubling, a handful of times per job
+        SQ_HIP_CHECK(hipStreamSynchronize(c->stream_chain));
+        if (o->fm_dev.ensure(o->fm_host.size() + 8)) { sq_set_error("device allocation failed (chain)"); return SQ_ERR_NOMEM; }
+        SQ_HIP_CHECK(hipMemcpyAsync(o->fm_dev.p, o->fm_host.data(), o->fm_host.size() * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+        o->fm_dev_n = o->fm_host.size();
+      }
+      if (o->chain_bar.ensure(4)) { sq_set_error("device allocation failed (chain)"); return SQ_ERR_NOMEM; }
+      if (!o->chain_bar_zeroed) { SQ_HIP_CHECK(hipMemsetAsync(o->chain_bar.p, 0, 16, st)); o->chain_bar_zeroed = true; }
+      ChainArgs CA{n, mb, W, nmb, o->fm_dev.p + o->batch_no, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin, o->assigned_prefix.p, o->chain_bar.p};
+      SQ_HIP_CHECK(hipEventRecord(c->ev_chain_in, st)); SQ_HIP_CHECK(hipStreamWaitEvent(c->stream_chain, c->ev_chain_in, 0));
+      k_chain<<<c->chain_blocks, 256, 0, c->stream_chain>>>(V, CA);
+      SQ_HIP_CHECK(hipEventRecord(c->ev_chain_out, c->stream_chain)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_chain_out, 0));
+      const uint32_t ng = (nmb + W - 1) / W;
+      o->batch_no += nmb; o->group_no += ng; if (c->prof_on) c->eq_groups += ng;
+    } else
     for (uint32_t b = 0; b < nmb;) {
       FmArr FM; uint32_t nw = 0; const uint32_t b0 = b;
       while (b < nmb && nw < W) { FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++); ++b; }
