@@ -804,12 +804,16 @@ __device__ inline void chain_barrier(unsigned* bar) {
   __builtin_amdgcn_s_waitcnt(0);                       // this thread's loads, stores and atomics have been answered by the L2
   __syncthreads();
   if (threadIdx.x == 0) {
+    // the CU mask does not promise one XCD (its bits are dealt across the shader engines): the block's writes leave its XCD's L2 before it
+    // arrives, and what it reads afterwards is fetched afresh (agent-scope release / acquire = L2 write-back / invalidate on this chip)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);
       (void)__hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
