@@ -129,7 +129,10 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     c->eq_cus = eq_cus;
     if (getenv("SQ_EQ_CHAIN") && ncu >= 64 && !owner) {   // experiment: see ctx.h
       std::vector<uint32_t> mc((ncu + 31) / 32, 0);
-      for (int i = ncu - 32; i < ncu; ++i) mc[i / 32] |= 1u << (i % 32);                     // the last XCD
+      // the driver deals the mask's bits round-robin to the XCDs (bit i -> XCD i mod 8 on this chip: amdkfd's symmetric CU-mask mapping), so one
+      // XCD = every eighth bit.  (The 64-CU partition above is therefore 8 CUs in each of the 8 XCDs.)
+      const int nx = getenv("SQ_CHAIN_NXCD") ? atoi(getenv("SQ_CHAIN_NXCD")) : 8, xk = nx - 1;
+      for (int i = xk; i < ncu; i += nx) mc[i / 32] |= 1u << (i % 32);
       SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2)); SQ_HIP_CHECK(hipStreamCreate(&c->stream3));
       SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream_chain, (uint32_t)mc.size(), mc.data()));
       SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_in, hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_out, hipEventDisableTiming));

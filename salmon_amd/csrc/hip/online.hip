@@ -798,22 +798,22 @@ __global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM
 // crosses the XCD's L2: the masses are read with agent-scope loads (the per-CU L1 is not coherent inside a kernel), the
 // increments are agent-scope atomics, tlc is stored with an agent-scope store, and a thread waits for its memory operations
 // (s_waitcnt) before its block arrives at the barrier.  Same arithmetic, same order per transcript as the two-kernel form.
-struct ChainArgs { uint32_t n, mb, W, nmb; const double* fm; const uint64_t* aln_off; const DynAln* dyn; const uint8_t* gcbin; const uint64_t* assigned_prefix; unsigned* bar; };
+struct ChainArgs { uint32_t n, mb, W, nmb; int fence; const double* fm; const uint64_t* aln_off; const DynAln* dyn; const uint8_t* gcbin; const uint64_t* assigned_prefix; unsigned* bar; };
 __device__ inline double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ inline void chain_barrier(unsigned* bar) {
+__device__ inline void chain_barrier(unsigned* bar, int fence) {
   __builtin_amdgcn_s_waitcnt(0);                       // this thread's loads, stores and atomics have been answered by the L2
   __syncthreads();
   if (threadIdx.x == 0) {
-    // the CU mask does not promise one XCD (its bits are dealt across the shader engines): the block's writes leave its XCD's L2 before it
-    // arrives, and what it reads afterwards is fetched afresh (agent-scope release / acquire = L2 write-back / invalidate on this chip)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // fence = 1 (SQ_CHAIN_FENCE=1): the blocks may sit on several XCDs — the block's writes leave its XCD's L2 before it arrives, and what it
+    // reads afterwards is fetched afresh (agent-scope release / acquire = L2 write-back / invalidate on this chip: ~100 us on a busy chip)
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);
       (void)__hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
         if (V.posbin) pos_observe(V, ai, pr);
       }
     }
-    chain_barrier(A.bar);
+    chain_barrier(A.bar, A.fence);
     // ---- phase B: every transcript folds its slots in mini-batch order, each with its forgetting mass ----
     if (tid == 0) V.ctr[0] += (unsigned long long)(A.assigned_prefix[r1] - A.assigned_prefix[r0]);
     for (uint32_t t = tid; t < V.M; t += nth) {
@@ -857,26 +857,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
       unsigned long long qv[SQ_MAX_INFLIGHT <= 8 ? 8 : 8]; unsigned long long any = 0;
       if (V.W <= 8) {
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
+        // read-and-clear as ONE atomic: the slot is read where the increments were added, whatever level of the memory system that is
+        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
         if (!any) continue;
         double m = V.mass[t];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) if ((uint32_t)w < nw && qv[w]) { m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(qv[w], SQ_MFRAC_BITS))); acc[w] = 0; }
+        for (int w = 0; w < 8; ++w) if ((uint32_t)w < nw && qv[w]) m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(qv[w], SQ_MFRAC_BITS)));
         V.mass[t] = m;
         __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         double m = V.mass[t]; bool hit = false;
         for (uint32_t w = 0; w < nw; ++w) {
-          const unsigned long long q = __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long q = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!q) continue;
-          m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); acc[w] = 0; hit = true;
+          m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); hit = true;
         }
         if (!hit) continue;
         V.mass[t] = m;
         __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    chain_barrier(A.bar);
+    chain_barrier(A.bar, A.fence);
   }
 }
 
@@ -1518,7 +1519,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       }
       if (o->chain_bar.ensure(4)) { sq_set_error("device allocation failed (chain)"); return SQ_ERR_NOMEM; }
       if (!o->chain_bar_zeroed) { SQ_HIP_CHECK(hipMemsetAsync(o->chain_bar.p, 0, 16, st)); o->chain_bar_zeroed = true; }
-      ChainArgs CA{n, mb, W, nmb, o->fm_dev.p + o->batch_no, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin, o->assigned_prefix.p, o->chain_bar.p};
+      ChainArgs CA{n, mb, W, nmb, getenv("SQ_CHAIN_FENCE") ? 1 : 0, o->fm_dev.p + o->batch_no, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin, o->assigned_prefix.p, o->chain_bar.p};
       SQ_HIP_CHECK(hipEventRecord(c->ev_chain_in, st)); SQ_HIP_CHECK(hipStreamWaitEvent(c->stream_chain, c->ev_chain_in, 0));
       k_chain<<<c->chain_blocks, 256, 0, c->stream_chain>>>(V, CA);
       SQ_HIP_CHECK(hipEventRecord(c->ev_chain_out, c->stream_chain)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_chain_out, 0));
