@@ -857,9 +857,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
       unsigned long long qv[SQ_MAX_INFLIGHT <= 8 ? 8 : 8]; unsigned long long any = 0;
       if (V.W <= 8) {
 #pragma unroll
-        // read-and-clear as ONE atomic: the slot is read where the increments were added, whatever level of the memory system that is
-        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
+        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
         if (!any) continue;
+        // a slot that holds something is read-and-cleared as ONE atomic (most slots of most transcripts are empty in a group: a load finds that out)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) if (qv[w]) qv[w] = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double m = V.mass[t];
 #pragma unroll
         for (int w = 0; w < 8; ++w) if ((uint32_t)w < nw && qv[w]) m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(qv[w], SQ_MFRAC_BITS)));
@@ -868,8 +870,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
       } else {
         double m = V.mass[t]; bool hit = false;
         for (uint32_t w = 0; w < nw; ++w) {
-          const unsigned long long q = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long q = __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!q) continue;
+          q = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); hit = true;
         }
         if (!hit) continue;
