@@ -147,6 +147,12 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     } else
     if (eq_cus > 0) {
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
+      // [r3] the driver deals the mask's bits round-robin to the XCDs (bit i -> XCD i mod 8: amdkfd's symmetric CU-mask mapping), so the top
+      // eq_cus bits are eq_cus / 8 CUs in EVERY XCD (default: 8 of 32) — not whole XCDs, as the round-2 comment above assumed.
+      // SQ_EQ_XCD=1 (experiment): whole XCDs instead — the eq stage gets the XCDs with the highest numbers.
+      if (getenv("SQ_EQ_XCD")) { const int nx = 8, take = std::max(1, eq_cus / 32);
+        for (int i = 0; i < ncu; ++i) { if (i % nx >= nx - take) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); } }
+      else
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
       // a partition is an optimisation: if the platform refuses CU masks, fall back to plain streams
       if (getenv("SQ_MAP_ALL_CUS")) for (int i = 0; i < ncu; ++i) m1[i / 32] |= 1u << (i % 32);   // experiment: mapping may use the eq stage's CUs too
