@@ -118,9 +118,10 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
   c->last_src = c;
   fill_params(c);
   { // CU partition: the eq stage gets `eq_cus` CUs of its own (default 64 of 256; SQ_EQ_CUS=0 disables) and the mapping stream keeps
-    // off them, so the eq chain never waits behind mapping workgroups.  The mask takes whole XCDs (the top CU indices; 32 CUs each):
-    // workgroups are dealt round-robin to the XCDs a stream may use, so a partly masked XCD gets a full share of the blocks with a
-    // fraction of the CUs and sets the pace (measured [r2], 4·10^6-pair batches: 32 / 40 / 48 / 64 CUs -> eq chain 44 / 44 / 44 / 28 ms).
+    // off them, so the eq chain never waits behind mapping workgroups.  The mask is a multiple of 64 bits from the top: workgroups are dealt
+    // round-robin to the XCDs, and an XCD with fewer CUs than the others still gets a full share of the blocks and sets the pace
+    // (measured [r2], 4·10^6-pair batches: 32 / 40 / 48 / 64 CUs -> eq chain 44 / 44 / 44 / 28 ms; [r3] mask bit i is a CU of XCD i mod 8,
+    // so 64 bits = 8 CUs in every XCD — see the note at the loop below).
     // With the mapping kernels at ~37 ms per batch on 192 CUs, two XCDs keep the eq chain off the critical path.
     hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int ncu = prop.multiProcessorCount;
