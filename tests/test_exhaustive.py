@@ -2,11 +2,14 @@
 reference vectors: the labels of an EXHAUSTIVE aligner (oracle/exhaustive.cpp — no index, no seeds, no chains, no band: every read end
 against every position of every transcript by full affine DP with salmon's selective-alignment scoring, then the in-tree pairing / filtering
 rules), committed as tests/golden/exhaustive_labels.npz by tests/golden/make_exhaustive.py, for
-  C1: all 10 000 pairs of the reference's bundled sample data,   S1: 20 000 synthetic 2x100 pairs against ~1300 synthetic transcripts.
+  C1: all 10 000 pairs of the reference's bundled sample data,   S1: 20 000 synthetic 2x100 pairs against ~1300 synthetic transcripts,
+  S2: 6 000 noisy pairs (2 % substitutions, 0.4 % indels) against the same transcripts.
 The checker's labels (CPU) and the HIP path's (GPU) are held to them: C1 — every fragment; S1 — >= 99.9 % of the fragments for which the
 exhaustive aligner finds a concordant pair, >= 99.3 % of all fragments (measured 99.97 % / 99.44 %: the gap is ONE class — a pair candidate
 whose mate overhangs a clipped poly-A tail fails validation and the mapping is dropped, SalmonQuantify.cpp:1524-1529, where the exhaustive
-tool falls back to the orphan), and identical alignment scores on every (fragment, transcript) both name.  oracle/SPEC.md §X lists the
+tool falls back to the orphan), and identical alignment scores on every (fragment, transcript) both name; S2 — all 16 616 shared scores
+equal (the banded, chain-guided DP finds the full DP's optimum wherever it aligns at all), 96.0 % of the label sets (97.0 % where a concordant pair
+exists): errors closer than a k-mer leave ends without a seed, which the seed-and-extend scheme — the reference's as much as this one — cannot map.  oracle/SPEC.md §X lists the
 disagreement classes with their counts."""
 import os, sys
 import numpy as np
@@ -21,7 +24,8 @@ G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "
 @pytest.fixture(scope="module")
 def worlds(built):
     import make_exhaustive as mk
-    return dict(c1=mk.c1_world(), s1=mk.s1_world())
+    s1 = mk.s1_world()
+    return dict(c1=mk.c1_world(), s1=s1, s2=mk.s2_world(s1))
 
 
 def _check(tag, w, read_off, aln, floor, floor_pairs=None):
@@ -43,13 +47,13 @@ def _check(tag, w, read_off, aln, floor, floor_pairs=None):
             if t in a and (x["mate_status"] == 3) == (kind[f] == 1):      # a pair's sum against a pair's sum, an orphan's score against an orphan's
                 shared += 1
                 differs += a[t] != int(x["score"]) + (int(x["mate_score"]) if x["mate_status"] == 3 else 0)
-    assert shared > w["n"] and differs <= shared // 2000, (shared, differs)
+    assert shared > w["n"] and differs <= (0 if tag == "s2" else shared // 2000), (shared, differs)   # S2 (noisy reads: gaps are common): every one of the 16 616 shared scores is the full DP's optimum
     return c
 
 
 def test_golden_labels_are_what_the_exhaustive_aligner_produces(worlds):
     # a live run on a slice of each set (the whole of it takes minutes: make_exhaustive.py)
-    for tag, k in (("c1", 150), ("s1", 40)):
+    for tag, k in (("c1", 150), ("s1", 40), ("s2", 30)):
         w = worlds[tag]
         lo, lt, ls, kind = exh.labels(w["refs"], w["seq"], w["off"], k, api.quant_opts(), threads=os.cpu_count() or 8)
         glo = G[tag + "_off"]
@@ -59,7 +63,7 @@ def test_golden_labels_are_what_the_exhaustive_aligner_produces(worlds):
 
 def test_checker_labels_agree_with_the_exhaustive_aligner(worlds):
     res = {}
-    for tag, floor, fp in (("c1", 1.0, 1.0), ("s1", 0.993, 0.999)):
+    for tag, floor, fp in (("c1", 1.0, 1.0), ("s1", 0.993, 0.999), ("s2", 0.955, 0.965)):
         w = worlds[tag]; oidx = orc.OrcIndex(w["idx"])
         rb = api.make_read_batch(w["seq"], w["off"], w["n"], paired=True)
         ro, aln, mt, st = orc.map_batch(oidx, api.quant_opts(), rb, threads=os.cpu_count() or 8)
@@ -69,7 +73,7 @@ def test_checker_labels_agree_with_the_exhaustive_aligner(worlds):
 
 @pytest.mark.gpu
 def test_hip_labels_agree_with_the_exhaustive_aligner(worlds):
-    for tag, floor, fp in (("c1", 1.0, 1.0), ("s1", 0.993, 0.999)):
+    for tag, floor, fp in (("c1", 1.0, 1.0), ("s1", 0.993, 0.999), ("s2", 0.955, 0.965)):
         w = worlds[tag]; w["idx"].to_device(0)
         ctx = api.QuantContext(w["idx"], api.quant_opts(), device=0, max_batch_reads=max(4096, w["n"]))
         ro, aln, mt, st = ctx.map_batch(api.make_read_batch(w["seq"], w["off"], w["n"], paired=True))
