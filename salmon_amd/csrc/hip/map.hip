@@ -122,7 +122,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     // round-robin to the XCDs, and an XCD with fewer CUs than the others still gets a full share of the blocks and sets the pace
     // (measured [r2], 4·10^6-pair batches: 32 / 40 / 48 / 64 CUs -> eq chain 44 / 44 / 44 / 28 ms; [r3] mask bit i is a CU of XCD i mod 8,
     // so 64 bits = 8 CUs in every XCD — see the note at the loop below).
-    // With the mapping kernels at ~37 ms per batch on 192 CUs, two XCDs keep the eq chain off the critical path.
+    // With the mapping kernels on 192 CUs, the 64 keep the eq chain (22 ms per 8·10^6 pairs) off the critical path (24.7 ms).
     hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int ncu = prop.multiProcessorCount;
     int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
