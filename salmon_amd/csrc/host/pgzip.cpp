@@ -227,28 +227,22 @@ struct alignas(128) Piece {
 };
 }  // namespace
 
+struct Round {   // what the decoding stage hands to the finishing stage
+  std::vector<std::unique_ptr<Piece>> pc; unsigned T = 0; std::vector<unsigned> chain;
+  bool final_seen = false, starts_member = false, at_end = false; uint64_t end_bit = 0; std::string err;
+};
+
 struct PgzStream {
   const uint8_t* base; size_t n; std::function<void(std::function<void()>)> submit; unsigned threads; size_t piece_bytes;
-  uint64_t bitpos = 0;              // where the next round starts (a block boundary of the current member)
-  bool in_member = false, eof = false;
-  std::vector<uint8_t> tail;        // last 32 KB of text of the current member
-  uint32_t crc = 0; uint64_t mlen = 0;
+  // ---- stage 1 (its own thread): where the pieces start, their symbols, the chain; needs only the bit position the round before ended on
+  uint64_t bitpos = 0; bool next_starts_member = true; unsigned alone = 0;   // alone: rounds left to run as one piece (no other piece found a block start: stored or binary data)
+  std::thread decoder; std::mutex qmu; std::condition_variable cv_q; std::deque<std::unique_ptr<Round>> decoded; bool dec_done = false;
+  std::mutex pmu; std::vector<std::unique_ptr<Piece>> free_pc;               // pieces go round: their symbol buffers are reused
+  // ---- stage 2 (its own thread): the 32 KB windows in chain order, text and checksums, the member's trailer; then the text is published
+  std::vector<uint8_t> tail; uint32_t crc = 0; uint64_t mlen = 0;            // of the current member
   std::deque<std::unique_ptr<Text>> ready; size_t ready_off = 0; std::shared_ptr<Recycler> rec = std::make_shared<Recycler>();
-  // rounds run ahead of the consumer on a thread of their own (they wait for the pool most of the time): ready / spare / eof / err are shared
-  std::mutex mu; std::condition_variable cv_ready, cv_room; std::thread producer; bool stop = false, failed = false; size_t ready_bytes = 0, ahead_bytes = 0;
-  void produce() {
-    for (;;) {
-      { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return stop || ready_bytes < ahead_bytes; }); if (stop) return; }
-      const bool ok = round();
-      std::lock_guard<std::mutex> lk(mu);
-      if (!ok) failed = true;
-      cv_ready.notify_all();
-      if (!ok || eof) return;
-    }
-  }
-  std::vector<std::unique_ptr<Piece>> pc;   // kept between rounds: their symbol buffers are reused
+  std::mutex mu; std::condition_variable cv_ready, cv_room; std::thread producer; bool stop = false, failed = false, eof = false; size_t ready_bytes = 0, ahead_bytes = 0;
   pgz_counters ctr{0, 0, 0, 0};
-  unsigned alone = 0;               // rounds left to run as one piece (after a round in which no other piece found a block start: stored or binary data)
   std::string err;
 
   void parallel(unsigned k, const std::function<void(unsigned)>& fn) {
@@ -268,33 +262,28 @@ struct PgzStream {
     if (q >= n) return false;
     *data_off = q; return true;
   }
-  bool begin_member(size_t at) {
-    size_t off; if (!member_header(at, &off)) return false;
-    bitpos = (uint64_t)off * 8; in_member = true; tail.assign(WIN, 0); crc = (uint32_t)crc32(0L, Z_NULL, 0); mlen = 0; ctr.members++;
-    return true;
-  }
-  // one round: up to `threads` pieces from bitpos; their text goes to `ready`
-  bool round() {
-    ctr.rounds++;
+  bool begin_member(size_t at) { size_t off; if (!member_header(at, &off)) return false; bitpos = (uint64_t)off * 8; next_starts_member = true; return true; }
+
+  // stage 1, one round: up to `threads` pieces from bitpos
+  void decode_round(Round& R) {
     const bool timing = getenv("SQ_TIMING") != nullptr; auto tm = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[pgz] %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm).count()); tm = t; };
     const uint64_t nbits = (uint64_t)n * 8, pb = (uint64_t)piece_bytes * 8;
     const unsigned T = alone ? 1u : (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, (nbits - bitpos + pb - 1) / pb));
     if (alone) --alone;
-    while (pc.size() < T) pc.emplace_back(new Piece());
+    R.T = T; R.starts_member = next_starts_member; next_starts_member = false;
+    { std::lock_guard<std::mutex> lk(pmu); while (R.pc.size() < T) { if (!free_pc.empty()) { R.pc.push_back(std::move(free_pc.back())); free_pc.pop_back(); } else R.pc.emplace_back(new Piece()); } }
+    auto& pc = R.pc;
     for (auto& p : pc) { p->start = ~0ull; p->end = 0; p->status = B_BAD; p->ran = false; p->crc = 0; }
     pc[0]->start = bitpos;
     const uint64_t round_end = bitpos + (uint64_t)T * pb;
-    // where the others start
     parallel(T - 1, [&](unsigned k) { const unsigned i = k + 1; const uint64_t from = bitpos + (uint64_t)i * pb; if (from < nbits) pc[i]->start = find_block(base, n, from, std::min(from + pb, nbits)); });
     mark("sync");
     if (T > 1) { bool any = false; for (unsigned i = 1; i < T; ++i) any |= pc[i]->start != ~0ull; if (!any) alone = 16; }
-    // decode: a piece runs until it stands exactly on the start of a later piece (a later piece whose start it runs past was not on a
-    // block boundary), the last one to the first boundary past the end of the round
+    // a piece runs until it stands exactly on the start of a later piece (a later piece whose start it runs past was not on a block boundary),
+    // the last one to the first boundary past the end of the round
     parallel(T, [&](unsigned i) {
       Piece& P = *pc[i]; if (P.start == ~0ull) return;
-      auto tp0 = std::chrono::steady_clock::now();
-      struct TP { decltype(tp0) t0; unsigned i; Piece* P; bool on; ~TP() { if (on) fprintf(stderr, "[pgz]   piece %u: %.1f ms, %zu symbols, bits %llu..%llu\n", i, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), P->out.n, (unsigned long long)P->start, (unsigned long long)P->end); } } tp{tp0, i, &P, timing};
       P.ran = true; Bits br(base, n); br.seek(P.start); P.out.start(piece_bytes * 5);   // sequence data inflates ~3-4 x: no regrowth on the way
       unsigned nxt = i + 1;
       for (;;) {
@@ -310,16 +299,44 @@ struct PgzStream {
     });
     mark("decode");
     // the chain of pieces that follow one another exactly
-    std::vector<unsigned> chain; unsigned cur = 0; bool final_seen = false;
+    unsigned cur = 0;
     for (;;) {
-      Piece& P = *pc[cur]; chain.push_back(cur);
-      if (P.status == B_BAD) { err = "corrupt deflate data near byte " + std::to_string(P.end / 8); return false; }
-      if (P.status == B_FINAL) { final_seen = true; break; }
+      Piece& P = *pc[cur]; R.chain.push_back(cur);
+      if (P.status == B_BAD) { R.err = "corrupt deflate data near byte " + std::to_string(P.end / 8); return; }
+      if (P.status == B_FINAL) { R.final_seen = true; break; }
       unsigned k = cur + 1; while (k < T && pc[k]->start != P.end) ++k;
       if (k >= T) break;
       cur = k;
     }
-    for (unsigned i = 1; i < T; ++i) if (pc[i]->ran && std::find(chain.begin(), chain.end(), i) == chain.end()) ctr.resynced++;
+    R.end_bit = pc[R.chain.back()]->end;
+    if (R.final_seen) {   // the trailer (checked by stage 2), then maybe another member
+      const size_t at = (size_t)((R.end_bit + 7) / 8);
+      if (at + 8 > n) { R.err = "truncated gzip member (no trailer)"; return; }
+      if (at + 8 >= n || !begin_member(at + 8)) R.at_end = true;     // like gzip: whatever follows the last member is ignored
+    } else if (R.end_bit >= nbits) { R.err = "truncated gzip file (the last block is missing)"; return; }
+    else bitpos = R.end_bit;
+  }
+  void decode_loop() {
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || decoded.empty(); }); if (stop) { dec_done = true; cv_q.notify_all(); return; } }   // one round ahead of stage 2
+      std::unique_ptr<Round> R(new Round()); decode_round(*R);
+      const bool last = !R->err.empty() || R->at_end;
+      { std::lock_guard<std::mutex> lk(qmu); decoded.push_back(std::move(R)); if (last) dec_done = true; }
+      cv_q.notify_all();
+      if (last) return;
+    }
+  }
+
+  // stage 2, one round
+  bool finish_round(Round& R) {
+    const bool timing = getenv("SQ_TIMING") != nullptr; auto tm = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[pgz] %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm).count()); tm = t; };
+    ctr.rounds++;
+    if (R.starts_member) { tail.assign(WIN, 0); crc = (uint32_t)crc32(0L, Z_NULL, 0); mlen = 0; ctr.members++; }
+    if (!R.err.empty() && R.chain.empty()) { err = R.err; return false; }
+    auto& pc = R.pc; auto& chain = R.chain;
+    if (!R.err.empty()) { err = R.err; return false; }
+    for (unsigned i = 1; i < R.T; ++i) if (pc[i]->ran && std::find(chain.begin(), chain.end(), i) == chain.end()) ctr.resynced++;
     ctr.pieces += chain.size();
     // windows: the 32 KB in front of every piece of the chain (sequential, 32 K symbols each), then text + checksums in parallel
     std::vector<std::vector<uint8_t>> win(chain.size());
@@ -346,23 +363,35 @@ struct PgzStream {
       P.crc = c;
     });
     mark("text+crc");
-    bool at_end = false;
     for (unsigned t : chain) { Piece& P = *pc[t]; if (P.status == B_BAD) { err = "out of memory"; return false; }
       crc = (uint32_t)crc32_combine(crc, P.crc, (z_off_t)P.text->n); mlen += P.text->n; }
-    bitpos = pc[chain.back()]->end;
-    if (final_seen) {   // trailer: CRC-32 and length of the member, then maybe another member
-      size_t at = (size_t)((bitpos + 7) / 8);
-      if (at + 8 > n) { err = "truncated gzip member (no trailer)"; return false; }
+    if (R.final_seen) {   // trailer: CRC-32 and length of the member
+      const size_t at = (size_t)((R.end_bit + 7) / 8);
       const uint32_t fcrc = (uint32_t)base[at] | ((uint32_t)base[at + 1] << 8) | ((uint32_t)base[at + 2] << 16) | ((uint32_t)base[at + 3] << 24);
       const uint32_t flen = (uint32_t)base[at + 4] | ((uint32_t)base[at + 5] << 8) | ((uint32_t)base[at + 6] << 16) | ((uint32_t)base[at + 7] << 24);
       if (fcrc != crc || flen != (uint32_t)mlen) { err = "gzip checksum mismatch (CRC-32 or length of a member)"; return false; }
-      in_member = false; at += 8;
-      if (at >= n || !begin_member(at)) at_end = true;       // like gzip: whatever follows the last member is ignored
-    } else if (bitpos >= nbits) { err = "truncated gzip file (the last block is missing)"; return false; }
+    }
     { std::lock_guard<std::mutex> lk(mu);   // the text becomes visible only once its member's trailer (if it ended here) has been checked
-      if (at_end) eof = true;
+      if (R.at_end) eof = true;
       for (unsigned t : chain) { Piece& P = *pc[t]; if (P.text->n) { ready_bytes += P.text->n; ready.push_back(std::move(P.text)); } else { std::lock_guard<std::mutex> l2(rec->mu); rec->spare.push_back(std::move(P.text)); } } }
+    { std::lock_guard<std::mutex> lk(pmu); for (auto& p : pc) free_pc.push_back(std::move(p)); pc.clear(); }
     return true;
+  }
+  void produce() {
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return stop || ready_bytes < ahead_bytes; }); if (stop) return; }
+      std::unique_ptr<Round> R;
+      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || !decoded.empty() || dec_done; });
+        if (stop) return;
+        if (decoded.empty()) { std::lock_guard<std::mutex> l2(mu); eof = true; cv_ready.notify_all(); return; }   // the decoder stopped without a last round (cannot happen; do not hang)
+        R = std::move(decoded.front()); decoded.pop_front(); }
+      cv_q.notify_all();
+      const bool ok = finish_round(*R);
+      std::lock_guard<std::mutex> lk(mu);
+      if (!ok) failed = true;
+      cv_ready.notify_all();
+      if (!ok || eof) return;
+    }
   }
 };
 
@@ -370,8 +399,9 @@ PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::f
   std::unique_ptr<PgzStream> s(new PgzStream());
   s->base = data; s->n = bytes; s->submit = std::move(submit); s->threads = std::max(1u, threads); s->piece_bytes = std::max<size_t>(piece_bytes, 1u << 16);
   if (!s->begin_member(0)) return nullptr;
-  s->ahead_bytes = (size_t)s->threads * s->piece_bytes * 4;          // about one round of text waiting while the next is decoded
+  s->ahead_bytes = (size_t)s->threads * s->piece_bytes * 4;          // about one round of text waiting while the next is finished
   PgzStream* p = s.release();
+  p->decoder = std::thread([p] { p->decode_loop(); });
   p->producer = std::thread([p] { p->produce(); });
   return p;
 }
@@ -405,7 +435,8 @@ int pgz_next(PgzStream* s, PgzBuf* out, std::string* err) {
 }
 void pgz_close(PgzStream* s) {
   if (!s) return;
-  { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; } s->cv_room.notify_all();
+  { std::lock_guard<std::mutex> lk(s->mu); std::lock_guard<std::mutex> l2(s->qmu); s->stop = true; } s->cv_room.notify_all(); s->cv_q.notify_all();
+  if (s->decoder.joinable()) s->decoder.join();
   if (s->producer.joinable()) s->producer.join();
   delete s;
 }
