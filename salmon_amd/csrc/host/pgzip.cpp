@@ -236,7 +236,8 @@ struct PgzStream {
   const uint8_t* base; size_t n; std::function<void(std::function<void()>)> submit; unsigned threads; size_t piece_bytes;
   // ---- stage 1 (its own thread): where the pieces start, their symbols, the chain; needs only the bit position the round before ended on
   uint64_t bitpos = 0; bool next_starts_member = true; unsigned alone = 0;   // alone: rounds left to run as one piece (no other piece found a block start: stored or binary data)
-  std::thread decoder; std::mutex qmu; std::condition_variable cv_q; std::deque<std::unique_ptr<Round>> decoded; bool dec_done = false;
+  std::thread decoder; std::mutex qmu; std::condition_variable cv_q; std::deque<std::unique_ptr<Round>> decoded; bool dec_done = false, finishing = false;
+  bool pipelined = true;   // stage 1 of round r + 1 beside stage 2 of round r (SQ_PGZ_PIPE=0: one after the other)
   std::mutex pmu; std::vector<std::unique_ptr<Piece>> free_pc;               // pieces go round: their symbol buffers are reused
   // ---- stage 2 (its own thread): the 32 KB windows in chain order, text and checksums, the member's trailer; then the text is published
   std::vector<uint8_t> tail; uint32_t crc = 0; uint64_t mlen = 0;            // of the current member
@@ -318,7 +319,8 @@ struct PgzStream {
   }
   void decode_loop() {
     for (;;) {
-      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || decoded.empty(); }); if (stop) { dec_done = true; cv_q.notify_all(); return; } }   // one round ahead of stage 2
+      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || (decoded.empty() && (pipelined || !finishing)); });   // one round ahead of stage 2 (or none)
+        if (stop) { dec_done = true; cv_q.notify_all(); return; } }
       std::unique_ptr<Round> R(new Round()); decode_round(*R);
       const bool last = !R->err.empty() || R->at_end;
       { std::lock_guard<std::mutex> lk(qmu); decoded.push_back(std::move(R)); if (last) dec_done = true; }
@@ -384,9 +386,10 @@ struct PgzStream {
       { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || !decoded.empty() || dec_done; });
         if (stop) return;
         if (decoded.empty()) { std::lock_guard<std::mutex> l2(mu); eof = true; cv_ready.notify_all(); return; }   // the decoder stopped without a last round (cannot happen; do not hang)
-        R = std::move(decoded.front()); decoded.pop_front(); }
+        R = std::move(decoded.front()); decoded.pop_front(); finishing = true; }
       cv_q.notify_all();
       const bool ok = finish_round(*R);
+      { std::lock_guard<std::mutex> lk(qmu); finishing = false; } cv_q.notify_all();
       std::lock_guard<std::mutex> lk(mu);
       if (!ok) failed = true;
       cv_ready.notify_all();
@@ -400,6 +403,7 @@ PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::f
   s->base = data; s->n = bytes; s->submit = std::move(submit); s->threads = std::max(1u, threads); s->piece_bytes = std::max<size_t>(piece_bytes, 1u << 16);
   if (!s->begin_member(0)) return nullptr;
   s->ahead_bytes = (size_t)s->threads * s->piece_bytes * 4;          // about one round of text waiting while the next is finished
+  if (getenv("SQ_PGZ_PIPE") && atoi(getenv("SQ_PGZ_PIPE")) == 0) s->pipelined = false;
   PgzStream* p = s.release();
   p->decoder = std::thread([p] { p->decode_loop(); });
   p->producer = std::thread([p] { p->produce(); });
