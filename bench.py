@@ -1,16 +1,21 @@
 #!/usr/bin/env python
 """bench.py — `salmon quant` hot path (map + eq-classes + EM) on MI355X, BASELINE.json metric.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2|c2s|c5|c4]   (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c2s|c3|c5|c4]   (N>1: launched by torch.distributed.run)
 
 A "step" is one pass of the hot path (sq_map_batch + sq_eq_accumulate) over one batch of synthetic read pairs already
 resident in HBM; a batch is handed over as `--sub` consecutive sq_map_batch calls of `--batch` pairs (the library maps at
 most 2^23 pairs per call).  Workloads (BASELINE.json `configs`):
 
   c2  (default, configs[1]/[2])  human-transcriptome-shaped index (synthetic: 60 000 genes x ~4 isoforms, ~190 k transcripts,
-        ~430 Mnt, ~150 M distinct 31-mers — SURVEY.md §8 shape C2), K x 16 M 2x100 bp pairs, then the job's inference tail
-        (eq-class export, normalizeAlphas, VBEM to convergence), all inside the timed region.
+        ~430 Mnt, ~150 M distinct 31-mers — SURVEY.md §8 shape C2), K x 5 M 2x100 bp pairs (the driver's --steps 20 = the 100 M-pair
+        job BASELINE.json's metric names), then the job's inference tail (eq-class export, normalizeAlphas, VBEM to convergence),
+        all inside the timed region.  [r4] Beside it, outside the timed steps (rank 0, N = 1): the same job on the first 10 M pairs
+        (`jobs.10M` = configs[1] as stated), the same job on the c2s index (`c2s`), and `spread` (how far NumReads / TPM move with the
+        mini-batches in flight, the batch size and the rank count).
   c2s the round-1/2 index (20 000 genes x ~10 isoforms: 54 M distinct k-mers, 5.3 alignments per fragment), same job.
+  c3  (configs[2]) STRONG scaling: a fixed total of K x 5 M pairs (100 M at --steps 20) split over the WORLD_SIZE ranks; every rank
+        maps its share, one RCCL exchange of the class tables, EM replicated.  `"scaling": "strong"`.
   c5  (configs[4]) c2's index, 50 M pairs, VBEM, then 100 Gibbs samples (4 chains x 25 samples x 16 thinning rounds) in the timed region.
   c4  (configs[3]) decoy-aware index: c2's transcriptome + a synthetic genome (`--genome-gnt`, default 1.0 Gnt; every gene's exons
         with introns, 45 % repeat families) as decoys, 2x150 bp pairs of which 5 % come from gene loci of the genome.
@@ -26,8 +31,9 @@ import numpy as np
 
 WORKLOADS = {
     # genes, iso, read_len, batch, sub, genome_gnt, genomic_frac
-    "c2": dict(genes=60000, iso=4, read_len=100, batch=8000000, sub=2, genome_gnt=0.0, genomic=0.0),
-    "c2s": dict(genes=20000, iso=10, read_len=100, batch=4000000, sub=1, genome_gnt=0.0, genomic=0.0),
+    "c2": dict(genes=60000, iso=4, read_len=100, batch=5000000, sub=1, genome_gnt=0.0, genomic=0.0),
+    "c2s": dict(genes=20000, iso=10, read_len=100, batch=5000000, sub=1, genome_gnt=0.0, genomic=0.0),
+    "c3": dict(genes=60000, iso=4, read_len=100, batch=5000000, sub=1, genome_gnt=0.0, genomic=0.0),
     "c5": dict(genes=60000, iso=4, read_len=100, batch=5000000, sub=1, genome_gnt=0.0, genomic=0.0),
     "c4": dict(genes=60000, iso=4, read_len=150, batch=4000000, sub=1, genome_gnt=1.0, genomic=0.05),
 }
@@ -36,7 +42,7 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 10 (c2, c2s, c5 = 50 M pairs), 6 (c4)")
+    ap.add_argument("--steps", type=int, default=None, help="default: 20 (c2, c2s, c3 = 100 M pairs), 10 (c5 = 50 M pairs), 6 (c4)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="read pairs per sq_map_batch call (<= 2^23)")
@@ -46,7 +52,10 @@ def parse():
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--genome-gnt", type=float, default=None, help="c4: decoy genome size in 10^9 nt")
     ap.add_argument("--gibbs-samples", type=int, default=100, help="c5: posterior samples (100 = 4 chains, 1600 rounds)")
-    ap.add_argument("--cpu-sample", type=int, default=200000, help="pairs timed through the CPU checker (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2000000, help="pairs timed through the CPU checker and compared with the HIP path (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="c2: skip the 10 M-pair job, the c2s leg and the spread measurement")
+    ap.add_argument("--spread-pairs", type=int, default=10000000, help="c2 extras: pairs of the job the spread variants run (0 = skip)")
+    ap.add_argument("--index-cache", default=None, help="directory to keep the built index in between runs (experiments; the driver's run builds it)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (the RCCL exchange + merge) runs on a 1-GPU box")
@@ -65,7 +74,7 @@ def parse():
     for k_arg, k_w in (("batch", "batch"), ("sub", "sub"), ("genes", "genes"), ("iso", "iso"), ("read_len", "read_len"), ("genome_gnt", "genome_gnt")):
         if getattr(a, k_arg) is None: setattr(a, k_arg, w[k_w])
     a.genomic = w["genomic"] if a.genome_gnt > 0 else 0.0
-    if a.steps is None: a.steps = 6 if a.workload == "c4" else 10
+    if a.steps is None: a.steps = {"c4": 6, "c5": 10}.get(a.workload, 20)
     return a
 
 
@@ -205,6 +214,140 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def kernel_source_sha():
+    """sha of the kernel sources the PMC traffic profile was taken on: a traffic figure is attached only when it still matches (weak #10 of the round-3 review)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("map_kernels.h", "mem_kernels.h", "map.hip", "ctx.h", "online.hip"):
+        h.update(open(os.path.join(ROOT, "salmon_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class World:
+    """A workload's index on the device + its read generator."""
+
+    def __init__(self, a, genes, iso, genome_gnt, genomic, thr, local, api, synth):
+        t0 = time.time()
+        self.tx = synth.Txome(seed=1, n_genes=genes, iso_per_gene=iso, threads=min(thr, 32))
+        names, seqs, lens = self.tx.tables()
+        self.genome = None; first_decoy = None; n_in = self.tx.n
+        if genome_gnt > 0:   # c4: the genome's chromosomes follow the transcripts as decoys (`salmon index -d decoys.txt`)
+            self.genome = synth.Genome(self.tx, seed=3, total_nt=int(genome_gnt * 1e9), n_chrom=25, repeat_frac=0.45, threads=min(thr, 32))
+            names, seqs, lens = self.genome.append_tables(self.tx)
+            first_decoy = self.tx.n; n_in = self.tx.n + self.genome.n
+        self.t_synth = time.time() - t0
+        cache = os.path.join(a.index_cache, "idx_g%d_i%d_d%.3f" % (genes, iso, genome_gnt)) if a.index_cache else None
+        if cache: os.makedirs(a.index_cache, exist_ok=True)
+        if cache and os.path.exists(os.path.join(cache, "info.json")):      # experiments: several runs of one gpurun call share the index files
+            self.idx = api.SalmonIndex.load(cache)
+        else:
+            self.idx = api.SalmonIndex.build_mem_raw(n_in, names, seqs, lens, threads=thr, first_decoy=first_decoy, outdir=cache)
+        self.t_index = time.time() - t0 - self.t_synth
+        self.idx.to_device(local)
+        self.genomic = genomic; self.thr = thr
+
+    def reads(self, n, read_len, first_pair):
+        if self.genome is not None:
+            return self.genome.reads(self.tx, n, read_len=read_len, seed=2, first_pair=first_pair, genomic_frac=self.genomic, threads=min(self.thr, 64), truth=False)[0]
+        return self.tx.reads(n, read_len=read_len, seed=2, first_pair=first_pair, threads=min(self.thr, 64), truth=False)[0]
+
+    def free(self):
+        self.idx.free(); self.tx.free()
+        if self.genome is not None: self.genome.free()
+
+
+def one_job(ctx, rbs, api, idx, em_opts=None):
+    """One whole job on one rank, timed like the headline: reset, map + online model + eq-classes over `rbs`, export, normalizeAlphas, VBEM to
+    convergence.  Returns (seconds, alphas, eff_lens, report)."""
+    import torch
+    ctx.reset(); ctx.set_profiling(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); n = 0; mapped = 0
+    for rb in rbs:
+        _, _, _, st = ctx.map_batch(rb, fetch=False); ctx.eq_accumulate(); n += rb.n; mapped += st["num_mapped"]
+    t_map = time.perf_counter() - t0
+    eq = ctx.eq_finish(); lm, uq, tc, le = ctx.model()
+    proj = api.normalize_alphas(eq, lm, uq, tc); eff = np.exp(le)
+    alphas, rep = ctx.em_optimize(eff, proj, em_opts or api.em_opts())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rep = dict(rep); rep.update(pairs=n, seconds=dt, map_eq_s=t_map, mapped=mapped, eq_classes=len(eq.count), labels=len(eq.tid))
+    return dt, alphas, eff, rep
+
+
+def tpm_of(alphas, eff):
+    r = alphas / np.maximum(eff, 1e-300); s = r.sum()
+    return r * (1e6 / s) if s > 0 else r
+
+
+def rel_spread(base, other, floor):
+    """Relative difference |x - y| / max(x, y) over the entries where either side is >= floor: (max, 99.9th percentile, 99th, median, entries)."""
+    m = (base >= floor) | (other >= floor)
+    if not m.any(): return None
+    d = np.abs(base[m] - other[m]) / np.maximum(base[m], other[m])
+    return {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "p99": float(np.quantile(d, 0.99)), "median": float(np.median(d)), "entries": int(m.sum())}
+
+
+def run_spread(a, world_obj, parked, off_d, B, RL, api, capi, local):
+    """[r4] What the deterministic online stage's free constants do to the result (oracle/SPEC.md §D1, §MG): the same `--spread-pairs` job with
+    W = mini-batches per model snapshot in {1, 8, 32}, handed over in batches of 1 M instead of 5 M pairs, and split over two ranks (two
+    contexts on this device, tables exchanged through the communicator's buffers: sq_dist_merge_eq_loopback).  For every variant the relative
+    difference of NumReads and TPM against the default (W = 8, one rank, 5 M-pair batches)."""
+    import torch, ctypes as C
+    idx = world_obj.idx; nb = max(1, min(len(parked), a.spread_pairs // B)); N = nb * B
+    def rbs_of(batch_pairs):
+        out = []
+        for t in parked[:nb]:
+            for lo in range(0, B, batch_pairs):
+                n = min(batch_pairs, B - lo)
+                out.append(api.make_read_batch(int(t.data_ptr()) + 2 * RL * lo, int(off_d.data_ptr()), n, paired=True, on_device=True))
+        return out
+    res = {}; base = None
+    def variant(name, W, batch_pairs):
+        nonlocal base
+        o = api.quant_opts();
+        if W: o.mini_batches_in_flight = W
+        c = api.QuantContext(idx, o, device=local, max_batch_reads=batch_pairs); c.reserve(1000000, 0)
+        one_job(c, rbs_of(batch_pairs)[:1], api, idx)                       # sizes the work buffers
+        dt, al, eff, rep = one_job(c, rbs_of(batch_pairs), api, idx)
+        c.free()
+        tp = tpm_of(al, eff)
+        if base is None: base = (al, tp)
+        res[name] = {"W": W or 8, "batch_pairs": batch_pairs, "ranks": 1, "seconds": round(dt, 4), "em_iters": rep["iters"], "eq_classes": rep["eq_classes"],
+                     "num_reads_ge_0.01": rel_spread(base[0], al, 1e-2), "num_reads_ge_10": rel_spread(base[0], al, 10.0),
+                     "tpm_ge_0.01": rel_spread(base[1], tp, 1e-2), "tpm_ge_1": rel_spread(base[1], tp, 1.0)}
+    variant("W8_default", 0, B)
+    variant("W1", 1, B); variant("W32", 32, B); variant("W64", 64, B)
+    variant("batch_1M", 0, min(B, 1000000))
+    # two ranks: batches alternate between two contexts (b -> rank b mod 2, SPEC MG), exchanged and merged in loop-back
+    try:
+        o = api.quant_opts(); ctxs = [api.QuantContext(idx, o, device=local, max_batch_reads=B) for _ in range(2)]
+        for c in ctxs: c.reserve(2000000, 0)
+        rb_all = rbs_of(B); t0 = time.perf_counter()
+        for i, rb in enumerate(rb_all):
+            c = ctxs[i % 2]; c.map_batch(rb, fetch=False); c.eq_accumulate()
+        models = [c.model() for c in ctxs]
+        d = api.Dist(api.Dist.make_id(), 0, 1, local)
+        d.merge_eq_loopback(ctxs)
+        eq = ctxs[0].eq_finish()
+        uq = (models[0][1] + models[1][1]).astype(np.uint64); tc = (models[0][2] + models[1][2]).astype(np.uint64)
+        allm = np.ascontiguousarray(np.stack([m[0] for m in models])); lm = np.zeros(allm.shape[1])
+        capi.check(capi.lib().sq_merge_log_masses(allm.shape[1], 2, allm.ctypes.data, lm.ctypes.data), "sq_merge_log_masses")
+        le = models[0][3]
+        proj = api.normalize_alphas(eq, lm, uq, tc); eff = np.exp(le)
+        al, rep = ctxs[0].em_optimize(eff, proj, api.em_opts())
+        dt = time.perf_counter() - t0; tp = tpm_of(al, eff)
+        res["ranks_2"] = {"W": 8, "batch_pairs": B, "ranks": 2, "seconds": round(dt, 4), "em_iters": rep["iters"], "eq_classes": len(eq.count),
+                          "num_reads_ge_0.01": rel_spread(base[0], al, 1e-2), "num_reads_ge_10": rel_spread(base[0], al, 10.0),
+                          "tpm_ge_0.01": rel_spread(base[1], tp, 1e-2), "tpm_ge_1": rel_spread(base[1], tp, 1.0)}
+        d.free()
+        for c in ctxs: c.free()
+    except Exception as e:
+        res["ranks_2"] = {"error": str(e)[:300]}
+    return {"pairs": N, "what": "relative difference |x - y| / max(x, y) of NumReads and TPM against the default (W = 8 mini-batches per model snapshot, one rank, "
+            "%d-pair batches), over the transcripts where either side reaches the floor; VBEM to convergence in every variant" % B, "variants": res}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -230,47 +373,63 @@ def main():
         sqd = api.Dist(bytes(idt.cpu().numpy().tobytes()), rank, world, local)
     ncores = os.cpu_count() or 8
     thr = max(4, ncores // max(1, world))
-    t_setup = time.time()
-    tx = synth.Txome(seed=1, n_genes=a.genes, iso_per_gene=a.iso, threads=min(thr, 32))
-    names, seqs, lens = tx.tables()
-    genome = None; first_decoy = None; n_refs_in = tx.n
-    if a.genome_gnt > 0:   # c4: the genome's chromosomes follow the transcripts as decoys (`salmon index -d decoys.txt`)
-        import ctypes as C
-        genome = synth.Genome(tx, seed=3, total_nt=int(a.genome_gnt * 1e9), n_chrom=25, repeat_frac=0.45, threads=min(thr, 32))
-        names, seqs, lens = genome.append_tables(tx)
-        first_decoy = tx.n; n_refs_in = tx.n + genome.n
-    t_synth = time.time() - t_setup
-    idx = api.SalmonIndex.build_mem_raw(n_refs_in, names, seqs, lens, threads=thr, first_decoy=first_decoy)
-    t_index = time.time() - t_setup - t_synth
-    idx.to_device(local)
-    B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len; S = max(1, a.sub)
+    out = run_workload(a, a.workload, rank, world, local, dist, sqd, thr, ncores, api, synth, capi, extras=not a.no_extras)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, capi, extras=True, leg=False):
+    """One workload: index, parked reads, warm-up, the timed job; on rank 0 the JSON object.  `leg` = a secondary leg inside another
+    workload's run (c2s beside c2): no CPU sample, no FASTQ pass, no extras."""
+    import torch
+    w = WORKLOADS[wl]
+    # a leg keeps its own workload's shape, scaled like the caller's (`--genes 600` for a test shrinks both)
+    genes, iso, gnt = (a.genes, a.iso, a.genome_gnt) if not leg else (max(50, w["genes"] * a.genes // WORKLOADS[a.workload]["genes"]), w["iso"], w["genome_gnt"])
+    genomic = a.genomic if not leg else w["genomic"]
+    strong = wl == "c3"
+    Wd = World(a, genes, iso, gnt, genomic, thr, local, api, synth)
+    tx, genome, idx = Wd.tx, Wd.genome, Wd.idx
+    B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len if not leg else w["read_len"]; S = max(1, a.sub)
     if B > (1 << 23): raise SystemExit("--batch above 2^23 pairs per sq_map_batch call")
+    total_pairs = K * S * B            # c3: the whole job's pairs, whatever the rank count
+    if strong:                         # this rank's share of the fixed total, cut into calls of at most B pairs
+        share = total_pairs // world + (1 if rank < total_pairs % world else 0)
+        first_of_rank = (total_pairs // world) * rank + min(rank, total_pairs % world)
+        ncalls = max(1, -(-share // B)); per = -(-share // ncalls)
+        call_sizes = [min(per, share - i * per) for i in range(ncalls) if share - i * per > 0]
+    else:
+        call_sizes = [B] * (K * S)
     opts = api.quant_opts()
     if a.inflight > 0: opts.mini_batches_in_flight = a.inflight
     ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
     # end-of-job buffers (eq-class export, EM workspace) sized like the reference's initial eq-class map (10^6 classes); with several
     # ranks every GPU ends up holding the union of all ranks' classes, so the class table is sized for that
     ctx.reserve(1000000 * max(1, world // 2), 0)
-    # synthetic reads: rank r, step s, sub-batch u -> pairs [(((r*(K+W))+s)*S+u)*B, ...), generated on the host, parked in HBM
+    # synthetic reads generated on the host, parked in HBM.  Weak scaling: rank r, step s, call u -> pairs [(((r*(K+W))+s)*S+u)*B, ...);
+    # strong (c3): the timed calls cut the job's pair range [0, total) by rank, the warm-up calls lie beyond it
     dev = torch.device("cuda", local)
     off_np = (np.arange(0, 2 * B + 1, dtype=np.int64) * RL)
     off_d = torch.from_numpy(off_np).to(dev)
-    batches = []
+    batches = []; sizes = []
     host_first = None
     t_gen0 = time.time()
-    for s in range(W + K):
-        for u in range(S):
-            first = ((rank * (K + W) + s) * S + u) * B
-            if genome is not None:
-                seq, off, tt, tp = genome.reads(tx, B, read_len=RL, seed=2, first_pair=first, genomic_frac=a.genomic, threads=min(thr, 64), truth=False)
-            else:
-                seq, off, tt, tp = tx.reads(B, read_len=RL, seed=2, first_pair=first, threads=min(thr, 64), truth=False)
-            if s == W and u == 0 and rank == 0:
-                host_first = seq[: 2 * RL * min(B, a.cpu_sample)].copy() if a.cpu_sample > 0 else None
-            batches.append(torch.from_numpy(seq).to(dev))
+    def park(first, n):
+        seq = Wd.reads(n, RL, first)
+        batches.append(torch.from_numpy(seq).to(dev)); sizes.append(n)
+        return seq
+    for s in range(W * S):
+        park((total_pairs + (rank * W * S + s) * B) if strong else ((rank * (K + W)) * S + s) * B, B)
+    pos = 0
+    for i, n in enumerate(call_sizes):
+        first = (first_of_rank + pos) if strong else ((rank * (K + W) + W) * S + i) * B
+        seq = park(first, n); pos += n
+        if i == 0 and rank == 0 and not leg and a.cpu_sample > 0:
+            host_first = seq[: 2 * RL * min(n, a.cpu_sample)].copy()
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen0
-    rbs = [api.make_read_batch(int(b.data_ptr()), int(off_d.data_ptr()), B, paired=True, on_device=True) for b in batches]
+    rbs = [api.make_read_batch(int(b.data_ptr()), int(off_d.data_ptr()), n, paired=True, on_device=True) for b, n in zip(batches, sizes)]
     # ---- warmup (sizes every work buffer; model/eq state is reset afterwards) ----
     for s in range(W * S):
         ctx.map_batch(rbs[s], fetch=False); ctx.eq_accumulate()
@@ -292,7 +451,7 @@ def main():
     t0 = time.perf_counter()
     tot = None
     depth = max(1, a.lanes)          # batches in flight on the mapping lanes (sq_map_submit / sq_map_wait)
-    lo, hi = W * S, (W + K) * S
+    lo, hi = W * S, len(rbs)
     if depth > 1:
         for s in range(lo, min(hi, lo + depth)):
             ctx.map_submit(rbs[s])
@@ -309,7 +468,9 @@ def main():
     eq = ctx.eq_finish()
     t_eqf = time.perf_counter() - t0 - t_map
     lm, uq, tc, le = ctx.model()
+    t_merge = 0.0
     if dist:  # one RCCL all-gather of the packed tables; every rank merges the others' tables exactly (integer sums)
+        t_a = time.perf_counter()
         from salmon_amd import dist as sqdist
         cdev = torch.device("cpu") if a.debug_one_device else dev
         if a.debug_one_device:      # gloo has no device collectives: host tables
@@ -324,6 +485,7 @@ def main():
         eq = ctx.eq_finish()
         if sqd is not None: lm, uq, tc, le = sqd.reduce_model(lm, uq, tc, le)      # SPEC MG
         else: lm, uq, tc, le = sqdist.reduce_model(lm, uq, tc, le, dist, cdev)
+        t_merge = time.perf_counter() - t_a
     t_a = time.perf_counter()
     proj = api.normalize_alphas(eq, lm, uq, tc)
     t_norm = time.perf_counter() - t_a
@@ -332,7 +494,7 @@ def main():
     alphas, rep = ctx.em_optimize(eff, proj, api.em_opts())   # the ctx's own classes (incl. merged ones), read from the export resident in HBM
     t_em = time.perf_counter() - t_a
     gibbs = None
-    if a.workload == "c5":   # configs[4]: posterior samples by collapsed Gibbs, whole chains sharded by rank (sq_dist_share)
+    if wl == "c5":   # configs[4]: posterior samples by collapsed Gibbs, whole chains sharded by rank (sq_dist_share)
         t_a = time.perf_counter()
         nmapped = int(eq.count.sum()); Sn = a.gibbs_samples
         first, cnt = (sqd.share(Sn, capi.lib().sq_gibbs_chain_step(Sn)) if sqd is not None else (0, Sn))
@@ -352,30 +514,33 @@ def main():
     # EM iteration rate from a fixed-count run on the final table (outside the timed region)
     _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)
     if rank != 0:
-        if dist is not None:
-            dist.barrier(); dist.destroy_process_group()
-        return
+        ctx.free(); Wd.free()
+        return None
     E = len(eq.count); Lb = len(eq.tid)
     em_bytes = 36 * Lb + 16 * E + 64 * M
     em_gbs = em_bytes / (rep_it["ms_per_iter"] * 1e-3) / 1e9
-    NP = K * S * B
+    NP = sum(call_sizes)               # pairs this rank mapped in the timed region
+    job_pairs = total_pairs if strong else world * NP
     sb = stage_bytes(tot, NP, RL)
     stage_rows = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / max(1, v[1]), 4),
         "alg_GBps": round(sb.get(k, 0) / max(v[0], 1e-9) / 1e6, 1)} for k, v in stages.items() if v[1]}
     # roofline: the stage kernel with the largest total time in the timed region — every stage is a candidate, the online model's mini-batch
-    # chain included (it runs on its own CU partition beside mapping; its row aggregates one launch pair per group of mini-batches)
-    pm = {}
-    try:   # the counter passes were taken on the c2 workload: no traffic figure for the others
-        if a.workload == "c2": pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+    # chain included (its row aggregates one launch pair per group of mini-batches)
+    pm = {}; pm_note = "no PMC profile committed for this kernel on this workload"
+    try:   # the counter passes were taken on the c2 workload: no traffic figure for the others; [r4] nor when the kernel sources changed since
+        if wl in ("c2", "c3"):
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            if prof.get("kernel_source_sha") == kernel_source_sha() and prof.get("pairs_per_launch") == B: pm = prof["kernels"]
+            else: pm_note = "profiles/r04_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))
     except Exception: pass
     cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
     roof = None; roofs = {}
     # the online chain's row is a launch PAIR per group of mini-batches (k_frag_dynamic, k_apply_dynamic): its time is split between the two
-    # kernels in the proportion the committed rocprofv3 summary shows (profiles/r03_kernel_stats_c2_final.txt; 50/50 without it)
+    # kernels in the proportion the committed rocprofv3 summary shows (50/50 without it)
     pair_share = {"k_frag_dynamic": 0.5, "k_apply_dynamic": 0.5}
     try:
         ktot = {}
-        for line in open(os.path.join(ROOT, "profiles", "r03_kernel_stats_c2_final.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r04_kernel_stats_c2_final.txt")):
             for kn in pair_share:
                 if kn + "(" in line and "total=" in line: ktot[kn] = float(line.split("total=")[1].split("ms")[0])
         if len(ktot) == 2: pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
@@ -397,8 +562,8 @@ def main():
     if roofs:
         dom = max(roofs, key=lambda k: roofs[k]["ms_total"])
         roof = dict(roofs[dom])
-        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r03_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload "
-                                "at --steps 2; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run") if roof["traffic"] is not None else "no PMC profile committed for this kernel on this workload"
+        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r04_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload and batch size, "
+                                "kernel sources unchanged since: sha %s; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run" % kernel_source_sha()) if roof["traffic"] is not None else pm_note
         roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
         roof["all_kernels"] = {k: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
     if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
@@ -413,7 +578,7 @@ def main():
     if a.cpu_sample > 0 and world == 1 and host_first is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
-        Sn = min(B, a.cpu_sample)
+        Sn = min(sizes[W * S], a.cpu_sample)
         c_a = time.perf_counter()
         oidx = orc.OrcIndex(idx)
         t_oidx = time.perf_counter() - c_a
@@ -426,7 +591,7 @@ def main():
         lmc, uqc, tcc, lec, _ = ost.model()
         pc = orc.normalize_alphas(M, eqc, lmc, uqc, tcc)
         c2 = time.perf_counter()
-        _, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
+        a_c, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
         c3 = time.perf_counter()
         # the checker's EM loop is single-threaded (order-defined sums); its multi-threaded iteration (same arithmetic,
         # transcripts split over threads) is timed separately and used for the composite so the CPU gets its cores
@@ -444,7 +609,6 @@ def main():
         ctx.eq_accumulate(); eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
         p_g = api.normalize_alphas(eq_g, lm_g, uq_g, tc_g)
         a_g, rep_g = ctx.em_optimize(np.exp(le_g), p_g, api.em_opts())
-        a_c, _ = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
         checks = {"alignments": sha(aln_g) == sha(aln), "read_offsets": sha(ro_g) == sha(ro), "map_types": sha(mt_g) == sha(mt), "counters": st_g == stc,
             "eq_classes": all(sha(getattr(eq_g, f)) == sha(getattr(eqc, f)) for f in ("off", "tid", "bins", "count", "wq", "h1", "h2")),
             "online_model": sha(lm_g) == sha(lmc) and sha(uq_g) == sha(uqc) and sha(tc_g) == sha(tcc) and sha(le_g) == sha(lec),
@@ -457,48 +621,72 @@ def main():
             g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())
             parity["checks"]["gibbs_8_samples"] = sha(g_g) == sha(g_c); parity["equal"] = all(parity["checks"].values())
         cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); checker index built in %.1fs (not counted)" % (Sn,
-                   B, c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_oidx),
+               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); %.1fs of CPU work in all; checker index built in %.1fs (not counted)" % (Sn,
+                   sizes[W * S], c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_cpu, t_oidx),
                "map_only_M_pairs_per_s": round(Sn / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
                # what the sample's rates would mean for the whole timed job (a model, not a measurement): per-pair costs scale with the pairs,
                # the EM runs once over the full table for as many iterations as the GPU job needed
                "extrapolated_full_job_M_pairs_per_s": round(NP / (NP * ((c1 - c0) + (c2 - c1)) / Sn + rep["iters"] * em_cpu_s) / 1e6, 4)}
+        del oidx, ost
+    jobs = {}; spread = None; c2s = None
+    if K * S * B == 100000000 and world == 1: jobs["100M"] = {"value": round(NP / dt / 1e6, 4), "pairs": NP, "seconds": round(dt, 4), "what": "the timed region of this line"}
+    if extras and not leg and world == 1 and wl == "c2":
+        # configs[1] as stated: the SAME job (map + online model + eq-classes + export + normalizeAlphas + VBEM to convergence) on the first 10 M pairs
+        n10 = max(1, min(K * S, 10000000 // B))
+        d10, al10, eff10, rep10 = one_job(ctx, rbs[W * S: W * S + n10], api, idx)
+        jobs["10M" if n10 * B == 10000000 else "%d" % (n10 * B)] = {"value": round(rep10["pairs"] / d10 / 1e6, 4), "pairs": rep10["pairs"], "seconds": round(d10, 4), "map_eq_s": round(rep10["map_eq_s"], 4),
+                        "em_iters": rep10["iters"], "eq_classes": rep10["eq_classes"], "what": "configs[1] as stated: the whole job on the first %d pairs, timed the same way (outside the timed steps of this line)" % rep10["pairs"]}
+        if a.spread_pairs > 0:
+            try: spread = run_spread(a, Wd, batches[W * S:], off_d, B, RL, api, capi, local)
+            except Exception as e: spread = {"error": str(e)[:300]}
     fq = None
-    if a.fastq_pairs > 0 and world == 1 and a.workload in ("c2", "c2s"):
+    if a.fastq_pairs > 0 and world == 1 and wl in ("c2", "c2s") and not leg:
         fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi)
     cfg_name = {"c2": "configs[1]: human-transcriptome-shaped synthetic index (60k genes x ~4 isoforms; SURVEY C2 shape)",
+                "c3": "configs[2]: human-transcriptome-shaped synthetic index (as c2), a fixed total of %d pairs split over %d rank(s)" % (total_pairs, world),
                 "c2s": "configs[1], round-1/2 index (T200k: 20k genes x ~10 isoforms, 54 M distinct k-mers)",
                 "c5": "configs[4]: human-shaped index, 50 M pairs, VBEM + %d Gibbs samples" % a.gibbs_samples,
-                "c4": "configs[3]: decoy-aware index (human-shaped txome + %.2f Gnt synthetic genome as decoys), 2x%d bp, %.0f %% genomic pairs" % (a.genome_gnt, RL, 100 * a.genomic)}[a.workload]
+                "c4": "configs[3]: decoy-aware index (human-shaped txome + %.2f Gnt synthetic genome as decoys), 2x%d bp, %.0f %% genomic pairs" % (gnt, RL, 100 * genomic)}[wl]
     out = {
-        "metric": baseline_metric(), "value": round(world * NP / dt / 1e6, 4), "unit": "M read-pairs/s",
+        "metric": baseline_metric(), "value": round(job_pairs / dt / 1e6, 4), "unit": "M read-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
-        "config": {"workload": "%s (k=31, m=20), %d steps x %d x %d = %d synthetic 2x%dbp pairs per GPU, -l IU defaults, VBEM" % (cfg_name, K, S, B, NP, RL),
-                   "workload_id": a.workload,
+        "config": {"workload": "%s (k=31, m=20), %s, -l IU defaults, VBEM" % (cfg_name, ("%d synthetic 2x%dbp pairs in all, %d on this rank in %d calls" % (total_pairs, RL, NP, len(call_sizes))) if strong
+                       else ("%d steps x %d x %d = %d synthetic 2x%dbp pairs per GPU" % (K, S, B, NP, RL))),
+                   "workload_id": wl,
                    "transcripts": int(tx.n), "refs": int(M), "txome_nt": int(tx.total_nt()), "decoy_nt": int(genome.total_nt()) if genome is not None else 0,
                    "distinct_kmers": int(idx.num_kmers), "unitigs": int(idx.num_unitigs), "index_hbm_bytes": int(idx.device_bytes),
-                   "pairs_per_step": S * B, "pairs_per_map_call": B,
+                   "pairs_per_step": S * B, "pairs_per_map_call": B, "job_pairs": int(job_pairs),
                    "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly (%s); EM replicated" % (world,
                        "sq_dist_* over RCCL" if sqd is not None else ("torch.distributed" if dist is not None else "single rank"))},
-        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
-            "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
-            "em_device_ms": round(rep["device_ms"], 2), "synth_s": round(t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
-                      "index_build_s": round(t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4),
+        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+merge+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
+            "dist_merge_s": round(t_merge, 4), "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
+            "em_device_ms": round(rep["device_ms"], 2), "synth_s": round(Wd.t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
+                      "index_build_s": round(Wd.t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4),
                       "decoy_frac": round(tot["num_decoy_fragments"] / tot["num_reads"], 4),
                       "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),
                       "eq_classes": E, "label_entries": Lb, "stats": tot},
         "em": {"iters_per_s": round(1e3 / rep_it["ms_per_iter"], 1), "ms_per_iter": round(rep_it["ms_per_iter"], 4), "alg_bytes_per_iter": em_bytes,
             "alg_GBps": round(em_gbs, 1), "frac_of_8TBps": round(em_gbs / 8000.0, 4)},
         "gibbs": gibbs,
-        "stages": stage_rows, "roofline": (gibbs or {}).get("roofline") if a.workload == "c5" and gibbs and gibbs.get("roofline") else roof,
-        "mapping_roofline": roof if a.workload == "c5" else None,
-        "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq,
+        "stages": stage_rows, "roofline": (gibbs or {}).get("roofline") if wl == "c5" and gibbs and gibbs.get("roofline") else roof,
+        "mapping_roofline": roof if wl == "c5" else None,
+        "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq, "jobs": jobs or None, "spread": spread,
     }
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    ctx.free(); del batches, rbs; Wd.free(); torch.cuda.empty_cache()
+    if extras and not leg and world == 1 and wl == "c2":
+        # the same job on the round-1/2 index (T200k: 20 000 genes x ~10 isoforms, 5.3 alignments per fragment) — the workload the headline
+        # was quoted on before round 3, carried beside it so the two can be compared at equal job size
+        try:
+            leg_out = run_workload(a, "c2s", rank, world, local, None, None, thr, ncores, api, synth, capi, extras=False, leg=True)
+            out["c2s"] = {k: leg_out[k] for k in ("value", "unit", "steps", "ms_per_step")}
+            out["c2s"].update(workload=leg_out["config"]["workload"], distinct_kmers=leg_out["config"]["distinct_kmers"], hits_per_frag=leg_out["breakdown"]["hits_per_frag"],
+                              map_eq_s=leg_out["breakdown"]["map_eq_s"], em_iters=leg_out["breakdown"]["em_iters"], em_ms_per_iter=leg_out["em"]["ms_per_iter"],
+                              k_seed_frac=(leg_out["roofline"] or {}).get("all_kernels", {}).get("k_seed", {}).get("frac"))
+        except Exception as e:
+            out["c2s"] = {"error": str(e)[:300]}
+    return out
 
 
 if __name__ == "__main__":

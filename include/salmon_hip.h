@@ -73,6 +73,10 @@ const char* sq_index_ref_name(const sq_index*, uint32_t tid);
 uint32_t sq_index_ref_len(const sq_index*, uint32_t tid);          /* RefLength (post-clipping) */
 uint32_t sq_index_ref_complete_len(const sq_index*, uint32_t tid); /* CompleteLength */
 int sq_index_is_decoy(const sq_index*, uint32_t tid);
+/* [r4] SHA-2 digests of the records the index was built from, lower-case hex (SalmonIndex.hpp:94-98 <- info.json's SeqHash, NameHash, SeqHash512,
+ * NameHash512, DecoySeqHash, DecoyNameHash): which = 0..5 in that order; "" for an index written before they were kept. */
+const char* sq_index_hash(const sq_index*, int which);
+int sq_index_keeps_duplicates(const sq_index*);   /* --keepDuplicates at build time (info.json "keep_duplicates") */
 uint64_t sq_index_num_unitigs(const sq_index*);
 uint64_t sq_index_num_kmers(const sq_index*);
 uint64_t sq_index_device_bytes(const sq_index*);
@@ -305,6 +309,7 @@ int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
 int sq_model_fetch(sq_ctx*, double* log_mass, uint64_t* unique_count, uint64_t* total_count,
                    double* log_eff_len);
 int sq_model_fetch_fld(sq_ctx*, double* log_pmf_1001); /* log PMF bins 0..1000 (flenDist) */
+int sq_model_fld_min(sq_ctx*, uint32_t* min_len);      /* [r4] FragmentLengthDistribution::minVal(): the smallest fragment length added so far, 1 when none (FragmentLengthDistribution.cpp:78-83) */
 /* fragments per observed library format id (type | orientation << 1 | strandedness << 3), 64 slots
  * (ReadLibrary::libTypeCounts, SalmonQuantify.cpp:1000-1021). */
 int sq_model_fetch_lib_counts(sq_ctx*, uint64_t* counts64);
@@ -393,6 +398,9 @@ int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_observed
  * NULL) receives the normalised bin masses [observed 5', observed 3', expected 5', expected 3'][5][20] (SimplePosBias::writeBinary's values). */
 typedef struct { const double* gc_observed; const uint64_t* seq_fw; const uint64_t* seq_rc; const double* pos_observed; uint32_t threads; uint32_t _pad; } sq_bias_models;
 int sq_model_fetch_pos_observed(sq_ctx*, double* out200);
+/* [r4] the expected fragment-GC masses [3 context classes][25 bins] (linear) of the calling thread's last sq_bias_*eff_lengths sweep with a GC model:
+ * what aux_info/exp_gc.gz holds (GZipWriter.cpp:405-413) */
+int sq_bias_last_gc_expected(double* out75);
 int sq_bias_eff_lengths(sq_index* idx, const sq_bias_models* models, const double* log_pmf_1001, uint32_t num_txp, const double* alphas, const double* eff_len_in,
                         double* eff_len_out, double* seq_models_out, double* pos_models_out, sq_bias_report* report);
 /* Transcript::lengthClassIndex (ReadExperiment.inl:352-388): the length quantiles of the non-decoy references and the class of every reference;
@@ -421,6 +429,47 @@ int sq_write_quant_sf(const char* path, const sq_index* idx, const double* eff_l
 /* the same with --sigDigits decimals for EffectiveLength and NumReads (GZipWriter.cpp:734-736; default 3) */
 int sq_write_quant_sf_digits(const char* path, const sq_index* idx, const double* eff_len, const double* num_reads, double num_mapped_frags, int sig_digits);
 int sq_write_eq_classes(const char* path, const sq_index* idx, const sq_eq_table* eq, int with_weights);
+
+/* [r4] the rest of aux_info (GZipWriter::writeMeta, src/output/GZipWriter.cpp:294-599).
+ * sq_write_fld_samples = aux_info/fld.gz: distribution_utils::samplesFromLogPMF (src/util/DistributionUtils.cpp:57-102) over the log PMF's bins
+ *   [min_len, max_len] (FragmentLengthDistribution::minVal / maxVal; sq_model_fld_min gives the former) — `num_samples` (the reference: 10 000) draws
+ *   histogrammed into int32[max_len + 1], gzipped raw; also returns the summary's mean / sd / support (meta_info's frag_length_mean, frag_length_sd,
+ *   frag_dist_length).  path may be NULL (summary only).  The reference draws from a randomly seeded Mersenne twister; here draw j is a pure function of (seed, j).
+ * sq_write_legacy_bias = expected_bias.gz, observed_bias.gz, observed_bias_3p.gz (:335-351): the 4^6-entry tables of the retired k-mer bias model at their
+ *   initial values (nothing updates them in the reference either); *num_bias_bins = 4096.
+ * sq_write_gc_model / sq_write_seq_model / sq_write_pos_models = GCFragModel::writeBinary (GCFragModel.hpp:63-79), SBModel::writeBinary (SBModel.cpp:77-116)
+ *   and the positional-model file of GZipWriter.cpp:424-447 (SimplePosBias::writeBinary, SimplePosBias.cpp:84-101), gzipped. */
+int sq_write_fld_samples(const char* path, const double* log_pmf, uint32_t min_len, uint32_t max_len, uint32_t num_samples, uint64_t seed,
+                         double* mean_out, double* sd_out, uint32_t* support_out);
+int sq_write_legacy_bias(const char* aux_dir, uint32_t* num_bias_bins);
+int sq_write_gc_model(const char* path, int32_t dtype /* 0 linear, 1 log */, uint32_t rows, uint32_t cols, const double* totals /*[rows]*/, const double* counts /*[rows][cols]*/);
+int sq_write_seq_model(const char* path, const double* log_probs_9x64 /* position-major: sq_bias_eff_lengths' seq_models_out rows */);
+int sq_write_pos_models(const char* path, uint32_t num_models, const uint32_t* len_bounds, uint32_t model_len, const double* masses /*[num_models][model_len]*/);
+/* aux_info/meta_info.json with GZipWriter::writeMeta's keys (:497-597) in its order.  Strings may be NULL (written as ""). */
+typedef struct {
+  const char* salmon_version;   /* NULL -> "1.11.4" (the semantics this library follows) */
+  const char* samp_type;        /* "none" | "gibbs" | "bootstrap" */
+  const char* opt_type;         /* "vb" | "em" | "none" */
+  const char* quant_errors;     /* NULL / "" -> []; else one entry (writeEmptyMeta, :180-290) */
+  uint32_t num_libraries; uint32_t frag_dist_length;
+  const char* const* library_types;   /* [num_libraries], LibraryFormat::toString() */
+  double frag_length_mean, frag_length_sd;
+  int32_t seq_bias_correct, gc_bias_correct, pos_bias_correct;
+  uint32_t num_bias_bins;
+  const char* mapping_type;     /* "mapping" | "alignment" */
+  int32_t keep_duplicates;      /* 1 / 0; < 0 = unknown: no key (:518-529) */
+  int32_t serialized_eq_classes, range_factorized, scalar_weights;
+  uint64_t num_valid_targets, num_decoy_targets, num_eq_classes;
+  uint32_t num_length_classes; uint32_t _pad0;
+  const uint32_t* length_classes;     /* ReadExperiment::getLengthQuantiles (sq_index_length_classes) */
+  const char *index_seq_hash, *index_name_hash, *index_seq_hash512, *index_name_hash512, *index_decoy_seq_hash, *index_decoy_name_hash;
+  uint64_t num_bootstraps, num_processed, num_mapped, num_decoy_fragments, num_dovetail_fragments, num_fragments_filtered_vm, num_alignments_below_threshold_vm;
+  double percent_mapped;
+  const char *start_time, *end_time;  /* asctime-style, as SalmonOpts::runStartTime */
+  /* not reference keys: written last, under one "salmon_hip" object, when backend != NULL */
+  const char* backend; uint32_t num_em_iterations, num_degenerate_eq_classes; double runtime_s;
+} sq_meta_info;
+int sq_write_meta_info(const char* path, const sq_meta_info* m);
 
 /* aux_info/ambig_info.tsv (GZipWriter.cpp:601-638): UniqueCount / AmbigCount per transcript from the eq-classes. */
 int sq_write_ambig_info(const char* path, uint32_t m, const sq_eq_table* eq);

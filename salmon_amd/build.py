@@ -118,7 +118,7 @@ def build_tools():
 def build_microbench():
     """tools/*.hip: stand-alone gfx950 microbenchmarks quoted in DESIGN.md (random-sector gather ceiling, grid-barrier cost)."""
     out = os.path.join(ROOT, "tools", "_build"); os.makedirs(out, exist_ok=True)
-    for name in ("gather_bench", "gridbar_bench"):
+    for name in ("gather_bench", "gridbar_bench", "gridbar2_bench"):
         src = os.path.join(ROOT, "tools", name + ".hip"); exe = os.path.join(out, name)
         if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
             continue

@@ -131,6 +131,22 @@ REPLICATE_CB = C.CFUNCTYPE(C.c_int, P(f64), u32, C.c_void_p)
 _lib = None
 
 
+class MetaInfo(C.Structure):   # sq_meta_info
+    _fields_ = [("salmon_version", C.c_char_p), ("samp_type", C.c_char_p), ("opt_type", C.c_char_p), ("quant_errors", C.c_char_p),
+                ("num_libraries", C.c_uint32), ("frag_dist_length", C.c_uint32), ("library_types", C.POINTER(C.c_char_p)),
+                ("frag_length_mean", C.c_double), ("frag_length_sd", C.c_double),
+                ("seq_bias_correct", C.c_int32), ("gc_bias_correct", C.c_int32), ("pos_bias_correct", C.c_int32), ("num_bias_bins", C.c_uint32),
+                ("mapping_type", C.c_char_p), ("keep_duplicates", C.c_int32), ("serialized_eq_classes", C.c_int32), ("range_factorized", C.c_int32), ("scalar_weights", C.c_int32),
+                ("num_valid_targets", C.c_uint64), ("num_decoy_targets", C.c_uint64), ("num_eq_classes", C.c_uint64),
+                ("num_length_classes", C.c_uint32), ("_pad0", C.c_uint32), ("length_classes", C.POINTER(C.c_uint32)),
+                ("index_seq_hash", C.c_char_p), ("index_name_hash", C.c_char_p), ("index_seq_hash512", C.c_char_p), ("index_name_hash512", C.c_char_p),
+                ("index_decoy_seq_hash", C.c_char_p), ("index_decoy_name_hash", C.c_char_p),
+                ("num_bootstraps", C.c_uint64), ("num_processed", C.c_uint64), ("num_mapped", C.c_uint64), ("num_decoy_fragments", C.c_uint64),
+                ("num_dovetail_fragments", C.c_uint64), ("num_fragments_filtered_vm", C.c_uint64), ("num_alignments_below_threshold_vm", C.c_uint64),
+                ("percent_mapped", C.c_double), ("start_time", C.c_char_p), ("end_time", C.c_char_p),
+                ("backend", C.c_char_p), ("num_em_iterations", C.c_uint32), ("num_degenerate_eq_classes", C.c_uint32), ("runtime_s", C.c_double)]
+
+
 def lib():
     """Load libsalmon_hip.so (raises if it has not been built: there is no fallback)."""
     global _lib
@@ -207,6 +223,11 @@ def lib():
         "sq_eq_file_eff_lens": (P(f64), [vp]), "sq_eq_file_table": (C.c_int, [vp, P(EqTable)]),
         "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64),
             u32]), "sq_boot_writer_close": (u64, [vp]),
+        "sq_bias_last_gc_expected": (C.c_int, [vp]),
+        "sq_index_hash": (C.c_char_p, [vp, C.c_int]), "sq_index_keeps_duplicates": (C.c_int, [vp]), "sq_model_fld_min": (C.c_int, [vp, P(u32)]),
+        "sq_write_fld_samples": (C.c_int, [C.c_char_p, vp, u32, u32, u32, u64, P(f64), P(f64), P(u32)]), "sq_write_legacy_bias": (C.c_int, [C.c_char_p, P(u32)]),
+        "sq_write_gc_model": (C.c_int, [C.c_char_p, C.c_int32, u32, u32, vp, vp]), "sq_write_seq_model": (C.c_int, [C.c_char_p, vp]),
+        "sq_write_pos_models": (C.c_int, [C.c_char_p, u32, vp, u32, vp]), "sq_write_meta_info": (C.c_int, [C.c_char_p, P(MetaInfo)]),
         "sq_ctx_set_profiling": (C.c_int, [vp, C.c_int]), "sq_ctx_num_stages": (C.c_int, []), "sq_ctx_stage_name": (C.c_char_p, [C.c_int]),
         "sq_ctx_stage_times": (C.c_int, [vp, P(f64), P(u64), C.c_int]),
     }

@@ -107,12 +107,17 @@ static const std::map<std::string, std::array<uint8_t, 3>> kLib = {  // src/util
   {"IU", {1, 2, 4}}, {"ISF", {1, 2, 0}}, {"ISR", {1, 2, 1}}, {"OU", {1, 1, 4}}, {"OSF", {1, 1, 0}}, {"OSR", {1, 1, 1}},
   {"MU", {1, 0, 4}}, {"MSF", {1, 0, 2}}, {"MSR", {1, 0, 3}}, {"U", {0, 3, 4}}, {"SF", {0, 3, 2}}, {"SR", {0, 3, 3}}};
 
-struct GcHook { sq_index* idx; std::vector<double> obs, logpmf, pobs; sq_bias_report rep; bool gc = true, seq = false, pos = false; std::vector<uint64_t> sfw, src; uint32_t threads = 8; };   // updateEffectiveLengths at EM iteration 11
+struct GcHook { sq_index* idx; std::vector<double> obs, logpmf, pobs; sq_bias_report rep; bool gc = true, seq = false, pos = false; std::vector<uint64_t> sfw, src; uint32_t threads = 8;
+  std::vector<double> seq_models = std::vector<double>(4 * 576, 0.0), pos_models = std::vector<double>(4 * 100, 0.0), gc_exp; bool ran = false; };   // updateEffectiveLengths at EM iteration 11; the models it evaluated are kept for the aux_info dumps
+struct BiasDump { bool have = false; std::vector<double> seq, pos, gc_obs, gc_exp; };
 static int gc_hook_cb(const double* alphas, const double* eff_in, double* eff_out, uint32_t m, void* user) {
   GcHook* h = (GcHook*)user;
   fprintf(stderr, "[salmon-hip] iteration 11, adjusting effective lengths to account for biases\n");
   sq_bias_models bm{h->gc ? h->obs.data() : nullptr, h->seq ? h->sfw.data() : nullptr, h->seq ? h->src.data() : nullptr, h->pos ? h->pobs.data() : nullptr, h->threads, 0};
-  return sq_bias_eff_lengths(h->idx, &bm, h->logpmf.data(), m, alphas, eff_in, eff_out, nullptr, nullptr, &h->rep);
+  h->ran = true;
+  const int rc = sq_bias_eff_lengths(h->idx, &bm, h->logpmf.data(), m, alphas, eff_in, eff_out, h->seq ? h->seq_models.data() : nullptr, h->pos ? h->pos_models.data() : nullptr, &h->rep);
+  if (!rc && h->gc) { h->gc_exp.resize(75); if (sq_bias_last_gc_expected(h->gc_exp.data())) h->gc_exp.clear(); }
+  return rc;
 }
 
 // ---- --writeMappings: the selected alignments as SAM (the records pufferfish's writeAlignmentsToStream emits from the same
@@ -181,6 +186,10 @@ struct SamWriter {
   }
 };
 static std::string g_aux_name = "aux_info";   // --auxDir
+static std::string now_string() {   // salmon::utils::getCurrentTimeAsString (SalmonUtils.cpp:988-1006): asctime of the local time, newline removed
+  std::time_t t = std::time(nullptr); struct tm lt; ::localtime_r(&t, &lt); char b[64]; ::asctime_r(&lt, b);
+  std::string r(b); while (!r.empty() && (r.back() == '\n' || r.back() == '\r')) r.pop_back(); return r;
+}
 static int boot_cb(const double* a, uint32_t m, void* user) { return sq_boot_writer_append((sq_boot_writer*)user, a, m); }
 static int part_cb(const double* a, uint32_t m, void* user) { return fwrite(a, 8, m, (FILE*)user) == m ? 0 : 1; }   // a rank's replicates, raw, for rank 0 to collect
 
@@ -345,7 +354,7 @@ static int cmd_quant(int argc, char** argv) {
     if (sq_dist_barrier(dist)) die("barrier");
     if (rank == 0) remove(idf.c_str());
   }
-  auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now(); const std::string start_time = now_string();
   sq_index* idx = nullptr; if (sq_index_load(idir, device, &idx)) die("loading index");
   sq_quant_opts qo;
   sq_quant_opts_default(&qo);
@@ -499,7 +508,7 @@ static int cmd_quant(int argc, char** argv) {
     for (uint32_t i = 0; i < M; ++i) eff[i] = std::exp(le[i]);
   }
   mkdir(odir, 0755); std::string od(odir); mkdir((od + "/" + g_aux_name + "").c_str(), 0755);
-  sq_em_report rep{}; SampInfo si;
+  sq_em_report rep{}; SampInfo si; BiasDump bias_dump;
   if (ms.num_assigned < min_assigned) {  // --minAssignedFrags (SalmonQuantify.cpp:2909-2925): empty quant.sf + error in meta_info
     fprintf(stderr, "[salmon-hip] only %llu fragments were assigned; writing empty quantification\n", (unsigned long long)ms.num_assigned);
   } else {
@@ -536,6 +545,7 @@ static int cmd_quant(int argc, char** argv) {
       if (sq_em_optimize_bias(ctx, &t, &tx, &eop, gc_hook_cb, &hook, alphas.data(), eff2.data(), &rep)) die("EM (bias correction)");
       fprintf(stderr, "[salmon-hip] bias correction: %u transcripts in the background model, fragment lengths %d..%d\n", hook.rep.num_processed, hook.rep.fld_low, hook.rep.fld_high);
       eff = eff2; tx.eff_len = eff.data();
+      bias_dump.have = hook.ran; bias_dump.seq = hook.seq_models; bias_dump.pos = hook.pos_models; if (gc_bias) { bias_dump.gc_obs = hook.obs; bias_dump.gc_exp = hook.gc_exp; }
     } else if (sq_em_optimize(ctx, &t, &tx, &eop, alphas.data(), &rep)) die("EM");
     std::vector<const char*> names(M); for (uint32_t i = 0; i < M; ++i) names[i] = sq_index_ref_name(idx, i);
     si = run_sampling(argc, argv, device, &t, &tx, &eop, alphas.data(), M, names, od, ms.num_assigned, dist);
@@ -550,39 +560,53 @@ static int cmd_quant(int argc, char** argv) {
     if (sq_write_lib_format_counts((od + "/lib_format_counts.json").c_str(), rf.c_str(), dt, dor, dst,
         lc, ms.num_assigned,
         ms.num_compatible)) die("lib_format_counts"); }
-  double fl_mean = 0.0, fl_sd = 0.0;
+  double fl_mean = 0.0, fl_sd = 0.0; uint32_t fl_support = 0;
+  const std::string aux = od + "/" + g_aux_name;
   { // libParams/flenDist.txt: exp(pmf(i)) for i = 0..1000, tab separated (FragmentLengthDistribution::toString, MappingPipelineStages.cpp:167-173)
     std::vector<double> fld(1001); if (sq_model_fetch_fld(ctx, fld.data())) die("fld fetch");
-    { double tot = 0, m1 = 0, m2 = 0; for (int i = 0; i <= 1000; ++i) { const double p = std::exp(fld[i]); tot += p; m1 += p * i; m2 += p * (double)i * i; }
-      if (tot > 0) { fl_mean = m1 / tot; fl_sd = std::sqrt(std::max(0.0, m2 / tot - fl_mean * fl_mean)); } }
     mkdir((od + "/libParams").c_str(), 0755); FILE* ff = fopen((od + "/libParams/flenDist.txt").c_str(), "w");
-    if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); } }
-  if (flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv,
-      "--dumpEqWeights")) if (sq_write_eq_classes((od + "/" + g_aux_name + "/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv,
-          "--dumpEqWeights"))) die("eq_classes");
+    if (ff) { for (int i = 0; i <= 1000; ++i) fprintf(ff, "%g%c", std::exp(fld[i]), i == 1000 ? '\n' : '\t'); fclose(ff); }
+    // aux_info/fld.gz + the summary meta_info quotes (GZipWriter.cpp:329-333, :489-491)
+    uint32_t fmin = 1; if (sq_model_fld_min(ctx, &fmin)) die("fld min");
+    const uint64_t fseed = (v = arg(argc, argv, "--seed")) ? strtoull(v, nullptr, 10) : 42;
+    if (sq_write_fld_samples((aux + "/fld.gz").c_str(), fld.data(), fmin, 1000, 10000, fseed, &fl_mean, &fl_sd, &fl_support)) die("fld.gz"); }
+  uint32_t num_bias_bins = 0; if (sq_write_legacy_bias(aux.c_str(), &num_bias_bins)) die("bias vectors");
+  const bool dump_eq = flag(argc, argv, "--dumpEq") || flag(argc, argv, "-d") || flag(argc, argv, "--dumpEqWeights");
+  if (dump_eq) if (sq_write_eq_classes((aux + "/eq_classes.txt.gz").c_str(), idx, &t, flag(argc, argv, "--dumpEqWeights"))) die("eq_classes");
   // SalmonQuantify.cpp:2697-2701
   if (qo.recover_orphans) fprintf(stderr, "[salmon-hip] Number of orphans recovered using orphan rescue : %llu\n",
       (unsigned long long)tot.num_orphans_rescued);
-  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  FILE* mf = fopen((od + "/" + g_aux_name + "/meta_info.json").c_str(), "w");
-  if (mf) {  // GZipWriter.cpp:294-599 (subset of keys)
-    fprintf(mf,
-        "{\n  \"salmon_version\": \"1.11.4\",\n  \"backend\": \"%s\",\n  \"num_valid_targets\": %u,\n  \"num_decoy_targets\": %u,\n  \"num_eq_classes\": %llu,\n  \"num_processed\": %llu,\n  \"num_mapped\": %llu,\n"
-                "  \"num_decoy_fragments\": %llu,\n  \"num_dovetail_fragments\": %llu,\n  \"num_fragments_filtered_vm\": %llu,\n  \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n  \"percent_mapped\": %.6f,\n"
-                "  \"library_types\": [\"%s\"],\n  \"opt_type\": \"%s\",\n  \"num_em_iterations\": %u,\n  \"quant_errors\": [%s],\n  \"runtime_s\": %.3f,\n"
-                "  \"samp_type\": \"%s\",\n  \"num_bootstraps\": %llu,\n  \"num_libraries\": 1,\n  \"frag_length_mean\": %.6f,\n  \"frag_length_sd\": %.6f,\n  \"frag_dist_length\": 1001,\n"
-                "  \"mapping_type\": \"mapping\",\n  \"num_degenerate_eq_classes\": %u,\n  \"gc_bias_correct\": %s,\n  \"seq_bias_correct\": %s,\n  \"pos_bias_correct\": %s\n}\n",
-            sq_version(), M, Mall - M, (unsigned long long)t.num_classes,
-                (unsigned long long)nfrag,
-                (unsigned long long)ms.num_assigned,
-            (unsigned long long)tot.num_decoy_fragments, (unsigned long long)tot.num_dovetails,
-                (unsigned long long)tot.num_fragments_filtered,
-                (unsigned long long)tot.num_mappings_filtered,
-            nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, lib.c_str(), flag(argc, argv, "--useEM") ? "em" : "vb",
-                rep.iters,
-                ms.num_assigned < min_assigned ? "\"insufficient_assigned_fragments\"" : "", secs, si.type, (unsigned long long)si.n, fl_mean, fl_sd, rep.num_degenerate, gc_bias ? "true" : "false", seq_bias ? "true" : "false", pos_bias ? "true" : "false");
-    fclose(mf);
+  uint32_t lq[5] = {0, 0, 0, 0, 0}; const int nlq = sq_index_length_classes(idx, lq, nullptr);
+  if (bias_dump.have) {   // the binary model dumps (GZipWriter.cpp:353-478), from the models the last bias round evaluated
+    if (seq_bias) { static const char* nm[4] = {"exp5_seq.gz", "exp3_seq.gz", "obs5_seq.gz", "obs3_seq.gz"};
+      for (int k = 0; k < 4; ++k) if (sq_write_seq_model((aux + "/" + nm[k]).c_str(), bias_dump.seq.data() + (size_t)k * 576)) die("sequence-bias model dump"); }
+    if (pos_bias && nlq > 0) { static const char* nm[4] = {"obs5_pos.gz", "obs3_pos.gz", "exp5_pos.gz", "exp3_pos.gz"};
+      for (int k = 0; k < 4; ++k) if (sq_write_pos_models((aux + "/" + nm[k]).c_str(), (uint32_t)nlq, lq, 20, bias_dump.pos.data() + (size_t)k * 100)) die("positional-bias model dump"); }
   }
+  if (gc_bias && !bias_dump.gc_obs.empty()) {   // obs_gc.gz: the observed fragment-GC masses as collected (3 context classes x 25 bins, linear space), totals = row sums
+    double totals[3]; for (int r = 0; r < 3; ++r) { totals[r] = 0; for (int c2 = 0; c2 < 25; ++c2) totals[r] += bias_dump.gc_obs[(size_t)r * 25 + c2]; }
+    if (sq_write_gc_model((aux + "/obs_gc.gz").c_str(), 0, 3, 25, totals, bias_dump.gc_obs.data())) die("GC model dump");
+    if (bias_dump.gc_exp.size() == 75) { for (int r = 0; r < 3; ++r) { totals[r] = 0; for (int c2 = 0; c2 < 25; ++c2) totals[r] += bias_dump.gc_exp[(size_t)r * 25 + c2]; }
+      if (sq_write_gc_model((aux + "/exp_gc.gz").c_str(), 0, 3, 25, totals, bias_dump.gc_exp.data())) die("GC model dump"); }
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  { const std::string end_time = now_string(); const char* libs[1] = {lib.c_str()};
+    sq_meta_info mi{}; const bool short_of_frags = ms.num_assigned < min_assigned;
+    mi.samp_type = si.type; mi.opt_type = short_of_frags ? "none" : (flag(argc, argv, "--useEM") ? "em" : "vb");
+    mi.quant_errors = short_of_frags ? "insufficient_assigned_fragments" : nullptr;      // SalmonQuantify.cpp:2909-2925
+    mi.num_libraries = 1; mi.library_types = libs; mi.frag_dist_length = fl_support; mi.frag_length_mean = fl_mean; mi.frag_length_sd = fl_sd;
+    mi.seq_bias_correct = seq_bias; mi.gc_bias_correct = gc_bias; mi.pos_bias_correct = pos_bias; mi.num_bias_bins = num_bias_bins;
+    mi.mapping_type = "mapping"; mi.keep_duplicates = sq_index_keeps_duplicates(idx);
+    mi.serialized_eq_classes = dump_eq; mi.range_factorized = qo.range_factorization_bins > 0; mi.scalar_weights = flag(argc, argv, "--dumpEqWeights");
+    mi.num_valid_targets = M; mi.num_decoy_targets = Mall - M; mi.num_eq_classes = t.num_classes;
+    mi.num_length_classes = nlq > 0 ? (uint32_t)nlq : 0; mi.length_classes = lq;
+    mi.index_seq_hash = sq_index_hash(idx, 0); mi.index_name_hash = sq_index_hash(idx, 1); mi.index_seq_hash512 = sq_index_hash(idx, 2); mi.index_name_hash512 = sq_index_hash(idx, 3);
+    mi.index_decoy_seq_hash = sq_index_hash(idx, 4); mi.index_decoy_name_hash = sq_index_hash(idx, 5);
+    mi.num_bootstraps = si.n; mi.num_processed = nfrag; mi.num_mapped = ms.num_assigned; mi.num_decoy_fragments = tot.num_decoy_fragments; mi.num_dovetail_fragments = tot.num_dovetails;
+    mi.num_fragments_filtered_vm = tot.num_fragments_filtered; mi.num_alignments_below_threshold_vm = tot.num_mappings_filtered;
+    mi.percent_mapped = nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0; mi.start_time = start_time.c_str(); mi.end_time = end_time.c_str();
+    mi.backend = sq_version(); mi.num_em_iterations = rep.iters; mi.num_degenerate_eq_classes = rep.num_degenerate; mi.runtime_s = secs;
+    if (sq_write_meta_info((aux + "/meta_info.json").c_str(), &mi)) die("meta_info"); }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
   if (cf) {
     fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir,

@@ -62,6 +62,13 @@ double canonical_sum_vec(std::vector<double> x) {   // SPEC §D2: 64-leaf stride
 }
 }  // namespace
 
+// the expected fragment-GC masses of the calling thread's last sweep (aux_info/exp_gc.gz, GZipWriter.cpp:405-413): [context class][GC bin], linear
+static thread_local double tl_gc_expected[SQ_GC_COND_BINS * SQ_GC_FRAG_BINS]; static thread_local int tl_gc_expected_rows = 0;
+extern "C" int sq_bias_last_gc_expected(double* out75) {
+  if (!out75) return SQ_ERR_ARG;
+  if (!tl_gc_expected_rows) { sq_set_error("sq_bias_last_gc_expected: no --gcBias sweep has run on this thread"); return SQ_ERR_STATE; }
+  memcpy(out75, tl_gc_expected, sizeof(tl_gc_expected)); return SQ_OK;
+}
 extern "C" int sq_bias_gc_eff_lengths(sq_index* idx, const double* gc_obs, const double* log_pmf, uint32_t M, const double* alphas,
                                       const double* eff_in, double* eff_out, sq_bias_report* rep) {
   if (!idx || !gc_obs || !log_pmf || !alphas || !eff_in || !eff_out) { sq_set_error("sq_bias_gc_eff_lengths: bad arguments"); return SQ_ERR_ARG; }
@@ -124,6 +131,7 @@ extern "C" int sq_bias_gc_eff_lengths(sq_index* idx, const double* gc_obs, const
   }
   double expect[SQ_GC_COND_BINS][SQ_GC_FRAG_BINS] = {{0}};
   for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) expect[0][b] = canonical_sum_vec(contrib[b]);
+  memcpy(tl_gc_expected, expect, sizeof(tl_gc_expected)); tl_gc_expected_rows = SQ_GC_COND_BINS;
   // ---- GCFragModel::normalize (prior 0.1) and ratio (maxRatio 1000), linear space (GCFragModel.hpp:118-140, 191-231) ----
   double obsN[SQ_GC_COND_BINS][SQ_GC_FRAG_BINS], expN[SQ_GC_COND_BINS][SQ_GC_FRAG_BINS], bias[SQ_GC_COND_BINS][SQ_GC_FRAG_BINS];
   auto normalize = [](const double* in, double* out) {
@@ -496,6 +504,7 @@ static int bias_sweep(sq_index* idx, int use_gc, const double* gc_obs, const uin
         for (int b = 0; b < 75; ++b) contrib[b][p] = weight[p] * E[b];
       }
       double expect[75]; for (int b = 0; b < 75; ++b) expect[b] = canonical_sum_vec(contrib[b]);
+      memcpy(tl_gc_expected, expect, sizeof(tl_gc_expected)); tl_gc_expected_rows = SQ_GC_COND_BINS;
       auto normalize = [](const double* in, double* out) { double row = 0.0; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) row += (0.1 + in[b]);
         if (row > 0.0) { const double nrm = 1.0 / row; for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) out[b] = (0.1 + in[b]) * nrm; } else for (int b = 0; b < SQ_GC_FRAG_BINS; ++b) out[b] = in[b]; };
       for (int r = 0; r < SQ_GC_COND_BINS; ++r) { double on[25], en[25]; normalize(gc_obs + r * 25, on); normalize(expect + r * 25, en);

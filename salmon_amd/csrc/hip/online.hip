@@ -1731,6 +1731,14 @@ extern "C" int sq_model_fetch_seq_observed(sq_ctx* c, uint64_t* fw576, uint64_t*
   return SQ_OK;
 }
 
+extern "C" int sq_model_fld_min(sq_ctx* c, uint32_t* min_len) {
+  if (!c || !min_len) return SQ_ERR_ARG;
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  unsigned long long hctr[8]; SQ_HIP_CHECK(hipMemcpy(hctr, c->online->ctr.p, sizeof(hctr), hipMemcpyDeviceToHost));
+  *min_len = hctr[2] >= 1000 ? 1u : (uint32_t)hctr[2];   // min_ == hist_.size() - 1 means nothing was added
+  return SQ_OK;
+}
 extern "C" int sq_model_fetch_fld(sq_ctx* c, double* out) {
   if (!c || !out) return SQ_ERR_ARG;
   { int rs = sq_eq_sync(c); if (rs) return rs; }

@@ -410,3 +410,150 @@ extern "C" int sq_write_lib_format_counts(const char* path, const char* read_fil
   fclose(f);
   return SQ_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// [r4] the rest of aux_info (GZipWriter::writeMeta, src/output/GZipWriter.cpp:294-599): fld.gz, the legacy k-mer bias vectors, the
+// binary bias-model dumps and meta_info.json with the reference's key set in the reference's order.
+namespace {
+// sq_rng.h's sq_r64 / sq_u01 (that header pulls device intrinsics in; this file is host code)
+inline uint64_t fin_r64(uint64_t seed, uint64_t a, uint64_t b) { return sq_mix64(seed ^ sq_mix64(a * 0x9E3779B97F4A7C15ULL + 0x1234567ULL) ^ sq_mix64(b * 0xD1B54A32D192ED03ULL + 0x89ABCDEFULL)); }
+inline double fin_u01(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+bool gz_write_all(const std::string& path, const void* p, size_t bytes) {   // writeVectorToFile (:41-56): gzip level 6 of the raw bytes
+  gzFile g = gzopen(path.c_str(), "wb6"); if (!g) return false;
+  const char* c = (const char*)p; size_t left = bytes; bool ok = true;
+  while (left && ok) { const unsigned n = (unsigned)std::min<size_t>(left, 1u << 30); ok = gzwrite(g, c, n) == (int)n; c += n; left -= n; }
+  return gzclose(g) == Z_OK && ok;
+}
+std::string json_escape(const char* s) {
+  std::string o; for (; s && *s; ++s) { const unsigned char c = (unsigned char)*s;
+    if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back((char)c); } else if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", c); o += b; } else o.push_back((char)c); }
+  return o;
+}
+}  // namespace
+
+// distribution_utils::samplesFromLogPMF (src/util/DistributionUtils.cpp:57-102) + writeVectorToFile: the log PMF over [minVal, maxVal] is
+// renormalised, `mean` = exp(logsum_i log(i) + logPMF_i) and `sd` from sum p_i i^2 over i in [minVal, maxVal) — the loop's own bounds —,
+// then 10 000 draws from the discrete distribution are histogrammed into int32[maxVal + 1] and gzipped.  The reference seeds a Mersenne
+// twister from the random device; here draw j is the inverse-CDF of u01(seed, 0xF1D, j) (sq_rng.h): the same file for the same run.
+extern "C" int sq_write_fld_samples(const char* path, const double* log_pmf, uint32_t min_len, uint32_t max_len, uint32_t num_samples, uint64_t seed,
+                                    double* mean_out, double* sd_out, uint32_t* support_out) {
+  if (!log_pmf || max_len < 1 || max_len > 1000000 || min_len > max_len) { sq_set_error("sq_write_fld_samples: bad arguments"); return SQ_ERR_ARG; }
+  const size_t minV = min_len, maxV = max_len, n = maxV - minV + 1;
+  std::vector<double> lp(log_pmf + minV, log_pmf + maxV + 1);
+  double sum = SQ_LOG_0; for (double v : lp) sum = sq_log_add(sum, v);
+  for (double& v : lp) v -= sum;
+  double mean = SQ_LOG_0, var = 0.0; std::vector<double> pmf(maxV + 1, 0.0);
+  for (size_t i = minV; i < maxV; ++i) {
+    if (i > 0) mean = sq_log_add(mean, sq_log((double)i) + lp[i - minV]);
+    pmf[i] = sq_exp(lp[i - minV]); var += pmf[i] * (double)(i * i);
+  }
+  mean = sq_exp(mean); var -= mean * mean; const double sd = std::sqrt(var);
+  (void)n;
+  std::vector<double> cdf(maxV + 1, 0.0); double acc = 0.0; for (size_t i = 0; i <= maxV; ++i) { acc += pmf[i]; cdf[i] = acc; }
+  std::vector<int32_t> samples(maxV + 1, 0);
+  if (acc > 0.0) for (uint32_t j = 0; j < num_samples; ++j) {
+    const double u = fin_u01(fin_r64(seed, 0xF1DULL, j)) * acc;
+    size_t k = (size_t)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin()); if (k > maxV) k = maxV;
+    ++samples[k];
+  }
+  if (mean_out) *mean_out = mean; if (sd_out) *sd_out = sd; if (support_out) *support_out = (uint32_t)samples.size();
+  if (path && !gz_write_all(path, samples.data(), samples.size() * sizeof(int32_t))) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  return SQ_OK;
+}
+
+// observed_bias.gz / observed_bias_3p.gz / expected_bias.gz (GZipWriter.cpp:335-351): the 6-mer read-start tables of the old bias model.
+// Nothing in the reference updates them any more (SalmonQuantify.cpp:1097-1100 are comments), so they hold their initial values: 4^6
+// pseudo-counts of 1 (ReadKmerDist.hpp:20-26) and 4^6 expected weights of 1.0 (BiasLibraryState.hpp:35).  num_bias_bins = 4096.
+extern "C" int sq_write_legacy_bias(const char* aux_dir, uint32_t* num_bias_bins) {
+  if (!aux_dir) { sq_set_error("sq_write_legacy_bias: bad arguments"); return SQ_ERR_ARG; }
+  const std::vector<int32_t> obs(4096, 1); const std::vector<double> expd(4096, 1.0); const std::string d(aux_dir);
+  if (!gz_write_all(d + "/expected_bias.gz", expd.data(), expd.size() * 8) || !gz_write_all(d + "/observed_bias.gz", obs.data(), obs.size() * 4) ||
+      !gz_write_all(d + "/observed_bias_3p.gz", obs.data(), obs.size() * 4)) { sq_set_error("cannot write the bias vectors into '%s'", aux_dir); return SQ_ERR_IO; }
+  if (num_bias_bins) *num_bias_bins = 4096;
+  return SQ_OK;
+}
+
+// GCFragModel::writeBinary (include/salmon/internal/model/GCFragModel.hpp:63-79): int32 dtype (0 linear, 1 log), Eigen::Index rows, cols
+// (8 bytes each), `rows` model totals, then the rows x cols counts in Eigen's default column-major order.  `counts` arrives row-major
+// [rows][cols] (context class x GC bin), as sq_model_fetch_gc_observed / the bias report hold it.
+extern "C" int sq_write_gc_model(const char* path, int32_t dtype, uint32_t rows, uint32_t cols, const double* totals, const double* counts) {
+  if (!path || !totals || !counts || !rows || !cols) { sq_set_error("sq_write_gc_model: bad arguments"); return SQ_ERR_ARG; }
+  std::vector<char> b; auto put = [&](const void* p, size_t n) { b.insert(b.end(), (const char*)p, (const char*)p + n); };
+  const int64_t r = rows, c = cols; put(&dtype, 4); put(&r, 8); put(&c, 8); put(totals, (size_t)rows * 8);
+  for (uint32_t j = 0; j < cols; ++j) for (uint32_t i = 0; i < rows; ++i) put(&counts[(size_t)i * cols + j], 8);
+  if (!gz_write_all(path, b.data(), b.size())) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  return SQ_OK;
+}
+
+// SBModel::writeBinary (src/model/SBModel.cpp:77-116): context length 9 = 3 bases left + the read start + 5 right (SBModel.cpp:21-33), the
+// per-position orders {0,1,2,2,2,2,2,2,2}, shifts 18 - 2(i+1) and widths 2(order+1) (:56-59), then the 64 x 9 matrix of log transition
+// probabilities (column = position, Eigen's column-major = `log_probs` as sq_bias_eff_lengths returns a model: [9][64]) and the 4 x 9 marginals.
+// The marginals are what SBModel::normalize leaves (:233-246): prior 1e-10 plus the mean over a position's 4^order states of the state's
+// four transition probabilities, here recovered from the log probabilities (a state that was never seen carries log(1e-5) in the table and
+// contributes that, not 0: a dump for inspection, not an input of anything).
+extern "C" int sq_write_seq_model(const char* path, const double* lp) {
+  if (!path || !lp) { sq_set_error("sq_write_seq_model: bad arguments"); return SQ_ERR_ARG; }
+  std::vector<char> b; auto put = [&](const void* p, size_t n) { b.insert(b.end(), (const char*)p, (const char*)p + n); };
+  const int32_t len = 9, left = 3, right = 5, order[9] = {0, 1, 2, 2, 2, 2, 2, 2, 2}; int32_t shifts[9], widths[9];
+  for (int i = 0; i < 9; ++i) { shifts[i] = 2 * len - 2 * (i + 1); widths[i] = 2 * (order[i] + 1); }
+  put(&len, 4); put(&left, 4); put(&right, 4); put(order, 36); put(shifts, 36); put(widths, 36);
+  double marg[9][4];
+  for (int pos = 0; pos < 9; ++pos) {
+    const int states = 1 << (2 * order[pos]);
+    for (int x = 0; x < 4; ++x) { double m = 1e-10; for (int st = 0; st < states; ++st) m += std::exp(lp[pos * 64 + st * 4 + x]); marg[pos][x] = m / states; }
+  }
+  const int64_t pr = 64, pc = 9, mr = 4, mc = 9; put(&pr, 8); put(&pc, 8); put(lp, 9 * 64 * 8); put(&mr, 8); put(&mc, 8); put(marg, sizeof(marg));
+  if (!gz_write_all(path, b.data(), b.size())) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  return SQ_OK;
+}
+
+// the lambda of GZipWriter.cpp:424-447: uint32 number of models, the length-class bounds, then per model SimplePosBias::writeBinary
+// (src/model/SimplePosBias.cpp:84-101): uint32 model length + that many doubles (the finalized masses)
+extern "C" int sq_write_pos_models(const char* path, uint32_t num_models, const uint32_t* len_bounds, uint32_t model_len, const double* masses) {
+  if (!path || !len_bounds || !masses || !num_models || !model_len) { sq_set_error("sq_write_pos_models: bad arguments"); return SQ_ERR_ARG; }
+  std::vector<char> b; auto put = [&](const void* p, size_t n) { b.insert(b.end(), (const char*)p, (const char*)p + n); };
+  put(&num_models, 4); put(len_bounds, (size_t)num_models * 4);
+  for (uint32_t m = 0; m < num_models; ++m) { put(&model_len, 4); put(masses + (size_t)m * model_len, (size_t)model_len * 8); }
+  if (!gz_write_all(path, b.data(), b.size())) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  return SQ_OK;
+}
+
+// aux_info/meta_info.json — GZipWriter::writeMeta's keys (GZipWriter.cpp:497-597), same names, same order, same JSON types (cereal's
+// layout: four-space indent).  `m->quant_errors` non-NULL = the writeEmptyMeta form's error list (:180-290).
+extern "C" int sq_write_meta_info(const char* path, const sq_meta_info* m) {
+  if (!path || !m) { sq_set_error("sq_write_meta_info: bad arguments"); return SQ_ERR_ARG; }
+  FILE* f = fopen(path, "w"); if (!f) { sq_set_error("cannot write '%s'", path); return SQ_ERR_IO; }
+  auto S = [&](const char* s) { return "\"" + json_escape(s ? s : "") + "\""; };
+  auto B = [](int v) { return v ? "true" : "false"; };
+  fprintf(f, "{\n    \"salmon_version\": %s,\n    \"samp_type\": %s,\n    \"opt_type\": %s,\n    \"quant_errors\": [", S(m->salmon_version ? m->salmon_version : "1.11.4").c_str(), S(m->samp_type).c_str(), S(m->opt_type).c_str());
+  if (m->quant_errors && m->quant_errors[0]) fprintf(f, "\n        %s\n    ", S(m->quant_errors).c_str());
+  fprintf(f, "],\n    \"num_libraries\": %u,\n    \"library_types\": [", m->num_libraries);
+  for (uint32_t i = 0; i < m->num_libraries; ++i) fprintf(f, "%s\n        %s", i ? "," : "", S(m->library_types ? m->library_types[i] : "").c_str());
+  fprintf(f, "%s],\n", m->num_libraries ? "\n    " : "");
+  fprintf(f, "    \"frag_dist_length\": %u,\n    \"frag_length_mean\": %.17g,\n    \"frag_length_sd\": %.17g,\n    \"seq_bias_correct\": %s,\n    \"gc_bias_correct\": %s,\n    \"num_bias_bins\": %u,\n",
+          m->frag_dist_length, m->frag_length_mean, m->frag_length_sd, B(m->seq_bias_correct), B(m->gc_bias_correct), m->num_bias_bins);
+  fprintf(f, "    \"mapping_type\": %s,\n", S(m->mapping_type).c_str());
+  if (m->keep_duplicates >= 0) fprintf(f, "    \"keep_duplicates\": %s,\n", B(m->keep_duplicates));   // the UNKNOWN status writes no key (:518-529)
+  fprintf(f, "    \"num_valid_targets\": %llu,\n    \"num_decoy_targets\": %llu,\n    \"num_eq_classes\": %llu,\n    \"serialized_eq_classes\": %s,\n    \"eq_class_properties\": [",
+          (unsigned long long)m->num_valid_targets, (unsigned long long)m->num_decoy_targets, (unsigned long long)m->num_eq_classes, B(m->serialized_eq_classes));
+  { std::vector<const char*> props; if (m->range_factorized) props.push_back("range_factorized"); if (m->scalar_weights) props.push_back("scalar_weights"); props.push_back("gzipped");
+    for (size_t i = 0; i < props.size(); ++i) fprintf(f, "%s\n        \"%s\"", i ? "," : "", props[i]);
+    fprintf(f, "\n    ],\n"); }
+  fprintf(f, "    \"length_classes\": [");
+  for (uint32_t i = 0; i < m->num_length_classes; ++i) fprintf(f, "%s\n        %u", i ? "," : "", m->length_classes[i]);
+  fprintf(f, "%s],\n", m->num_length_classes ? "\n    " : "");
+  fprintf(f, "    \"index_seq_hash\": %s,\n    \"index_name_hash\": %s,\n    \"index_seq_hash512\": %s,\n    \"index_name_hash512\": %s,\n    \"index_decoy_seq_hash\": %s,\n    \"index_decoy_name_hash\": %s,\n",
+          S(m->index_seq_hash).c_str(), S(m->index_name_hash).c_str(), S(m->index_seq_hash512).c_str(), S(m->index_name_hash512).c_str(), S(m->index_decoy_seq_hash).c_str(), S(m->index_decoy_name_hash).c_str());
+  fprintf(f, "    \"num_bootstraps\": %llu,\n    \"num_processed\": %llu,\n    \"num_mapped\": %llu,\n    \"num_decoy_fragments\": %llu,\n    \"num_dovetail_fragments\": %llu,\n"
+             "    \"num_fragments_filtered_vm\": %llu,\n    \"num_alignments_below_threshold_for_mapped_fragments_vm\": %llu,\n    \"percent_mapped\": %.17g,\n    \"call\": \"quant\",\n"
+             "    \"start_time\": %s,\n    \"end_time\": %s",
+          (unsigned long long)m->num_bootstraps, (unsigned long long)m->num_processed, (unsigned long long)m->num_mapped, (unsigned long long)m->num_decoy_fragments,
+          (unsigned long long)m->num_dovetail_fragments, (unsigned long long)m->num_fragments_filtered_vm, (unsigned long long)m->num_alignments_below_threshold_vm,
+          m->percent_mapped, S(m->start_time).c_str(), S(m->end_time).c_str());
+  // keys the reference does not have come last, under one object, so a reader of the reference's keys never meets them in between
+  if (m->backend) fprintf(f, ",\n    \"salmon_hip\": {\n        \"backend\": %s,\n        \"num_em_iterations\": %u,\n        \"num_degenerate_eq_classes\": %u,\n        \"pos_bias_correct\": %s,\n        \"runtime_s\": %.3f\n    }",
+                          S(m->backend).c_str(), m->num_em_iterations, m->num_degenerate_eq_classes, B(m->pos_bias_correct), m->runtime_s);
+  fprintf(f, "\n}\n");
+  fclose(f);
+  return SQ_OK;
+}

@@ -30,6 +30,10 @@ struct sq_index {
   // build statistics (info.json)
   uint64_t num_minimizers = 0, num_superkmers = 0, num_skew_kmers = 0, max_bucket = 0;
   std::vector<std::pair<std::string, std::string>> duplicates;  // retained, duplicate
+  // SHA-2 digests of the input records (SalmonIndex.hpp:94-98): [0] SeqHash, [1] NameHash, [2] SeqHash512, [3] NameHash512 over the targets,
+  // [4] DecoySeqHash, [5] DecoyNameHash over the decoys; info.json carries them, meta_info.json repeats them
+  std::string hashes[6];
+  bool keep_duplicates = false;
   // device mirror (owned; created by sq_index_to_device)
   sq_device_index* dev = nullptr;
 

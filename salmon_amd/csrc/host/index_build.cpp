@@ -9,6 +9,7 @@
 // and reference-terminal flags; unitig boundaries are then *local* predicates evaluated while
 // walking each reference, so unitigs are found without ever walking the graph.
 #include "index.h"
+#include "sha2.h"
 #include <chrono>
 #include <zlib.h>
 #include <algorithm>
@@ -519,11 +520,28 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Digests of the input records, in input order, before anything is changed (upstream pufferfish hashes every record as it is read —
+// sequence bytes as given, name = the first token, cut at '|' with --gencode — the targets into SeqHash / NameHash (+ the 512-bit
+// forms), the decoys into DecoySeqHash / DecoyNameHash; recalled, not verifiable here: SURVEY.md Appendix B).  Six independent
+// streams, one thread each.
+static void hash_refs(const std::vector<std::string>& names, const std::vector<std::string>& seqs, const std::vector<uint8_t>& is_decoy, bool gencode, std::string out[6]) {
+  auto name_of = [&](size_t i) { const std::string& s = names[i]; const size_t p = gencode ? s.find('|') : std::string::npos; return p == std::string::npos ? s.size() : p; };
+  std::thread th[6];
+  th[0] = std::thread([&] { sqsha::Sha256 h; for (size_t i = 0; i < seqs.size(); ++i) if (!is_decoy[i]) h.update(seqs[i].data(), seqs[i].size()); out[0] = h.hex(); });
+  th[1] = std::thread([&] { sqsha::Sha256 h; for (size_t i = 0; i < seqs.size(); ++i) if (!is_decoy[i]) h.update(names[i].data(), name_of(i)); out[1] = h.hex(); });
+  th[2] = std::thread([&] { sqsha::Sha512 h; for (size_t i = 0; i < seqs.size(); ++i) if (!is_decoy[i]) h.update(seqs[i].data(), seqs[i].size()); out[2] = h.hex(); });
+  th[3] = std::thread([&] { sqsha::Sha512 h; for (size_t i = 0; i < seqs.size(); ++i) if (!is_decoy[i]) h.update(names[i].data(), name_of(i)); out[3] = h.hex(); });
+  th[4] = std::thread([&] { sqsha::Sha256 h; for (size_t i = 0; i < seqs.size(); ++i) if (is_decoy[i]) h.update(seqs[i].data(), seqs[i].size()); out[4] = h.hex(); });
+  th[5] = std::thread([&] { sqsha::Sha256 h; for (size_t i = 0; i < seqs.size(); ++i) if (is_decoy[i]) h.update(names[i].data(), name_of(i)); out[5] = h.hex(); });
+  for (auto& t : th) t.join();
+}
+
 static void prep_refs(const sq_index_opts* o, std::vector<std::string>& names, std::vector<std::string>& seqs,
                       std::vector<uint32_t>& clen, std::vector<uint8_t>& is_decoy, uint32_t* first_decoy,
-                      std::vector<std::pair<std::string, std::string>>& dups) {
+                      std::vector<std::pair<std::string, std::string>>& dups, sq_index* idx = nullptr) {
   const bool clip = !(o && o->no_clip_polya), keepdup = (o && o->keep_duplicates), gencode = (o && o->gencode);
   size_t n = names.size();
+  if (idx) { idx->keep_duplicates = keepdup; hash_refs(names, seqs, is_decoy, gencode, idx->hashes); }
   clen.resize(n);
   for (size_t i = 0; i < n; ++i) {
     if (gencode) { size_t p = names[i].find('|'); if (p != std::string::npos) names[i].resize(p); }
@@ -627,7 +645,7 @@ static int index_build_mem_impl(const sq_index_opts* opts, uint32_t nrefs, const
   std::vector<std::string> n(nrefs), s(nrefs); std::vector<uint8_t> dec(nrefs, 0);
   for (uint32_t i = 0; i < nrefs; ++i) { n[i] = names[i]; s[i].assign(seqs[i], lens[i]); dec[i] = (i >= first_decoy); }
   std::vector<uint32_t> clen; uint32_t fd = 0;
-  prep_refs(opts, n, s, clen, dec, &fd, idx->duplicates);
+  prep_refs(opts, n, s, clen, dec, &fd, idx->duplicates, idx);
   rc = build_core(opts, n, s, clen, fd, idx); if (rc) { delete idx; return rc; }
   if (outdir) { rc = sq_index_save(*idx, outdir); if (rc) { delete idx; return rc; } }
   if (out) *out = idx; else delete idx;
@@ -653,7 +671,7 @@ static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, c
     for (size_t i = 0; i < n.size(); ++i) if (ds.count(n[i])) dec[i] = 1;
   }
   std::vector<uint32_t> clen; uint32_t fd = 0;
-  prep_refs(opts, n, s, clen, dec, &fd, idx->duplicates);
+  prep_refs(opts, n, s, clen, dec, &fd, idx->duplicates, idx);
   rc = build_core(opts, n, s, clen, fd, idx);
   if (!rc) rc = sq_index_save(*idx, outdir);
   delete idx;
@@ -692,20 +710,18 @@ int sq_index_save(const sq_index& idx, const std::string& dir) {
            idx.skew_vals);
   fclose(f);
   if (!ok) { sq_set_error("short write on '%s'", p.c_str()); return SQ_ERR_IO; }
-  uint64_t sh = 0, nh = 0;
-  for (auto w : idx.refseq) sh = sq_mix64(sh ^ w); for (auto& s : idx.names) for (unsigned char c : s) nh = sq_mix64(nh ^ c);
   f = fopen((dir + "/info.json").c_str(), "w");
   if (f) {
     fprintf(f,
         "{\n  \"index_version\": %u,\n  \"sampling_type\": \"sshash-hip\",\n  \"k\": %u,\n  \"m\": %u,\n  \"num_kmers\": %llu,\n  \"num_contigs\": %llu,\n  \"seq_len\": %llu,\n"
                "  \"num_refs\": %zu,\n  \"first_decoy_index\": %u,\n  \"num_minimizers\": %llu,\n  \"num_super_kmers\": %llu,\n  \"num_skew_kmers\": %llu,\n  \"max_bucket\": %llu,\n"
-               "  \"keep_duplicates\": false,\n  \"SeqHash\": \"%016llx\",\n  \"NameHash\": \"%016llx\",\n  \"SeqHash512\": \"\",\n  \"NameHash512\": \"\",\n  \"DecoySeqHash\": \"\",\n  \"DecoyNameHash\": \"\"\n}\n",
+               "  \"keep_duplicates\": %s,\n  \"SeqHash\": \"%s\",\n  \"NameHash\": \"%s\",\n  \"SeqHash512\": \"%s\",\n  \"NameHash512\": \"%s\",\n  \"DecoySeqHash\": \"%s\",\n  \"DecoyNameHash\": \"%s\"\n}\n",
             SQ_INDEX_VERSION, idx.k, idx.m, (unsigned long long)idx.num_kmers, (unsigned long long)(idx.uoff.size() - 1),
                 (unsigned long long)idx.uoff.back(),
                 idx.names.size(), idx.first_decoy,
             (unsigned long long)idx.num_minimizers, (unsigned long long)idx.num_superkmers, (unsigned long long)idx.num_skew_kmers,
-                (unsigned long long)idx.max_bucket,
-                (unsigned long long)sh, (unsigned long long)nh);
+                (unsigned long long)idx.max_bucket, idx.keep_duplicates ? "true" : "false",
+                idx.hashes[0].c_str(), idx.hashes[1].c_str(), idx.hashes[2].c_str(), idx.hashes[3].c_str(), idx.hashes[4].c_str(), idx.hashes[5].c_str());
     fclose(f);
   }
   f = fopen((dir + "/versionInfo.json").c_str(), "w");
@@ -778,6 +794,19 @@ static int index_load_host_impl(const std::string& dir, sq_index** out) {
   for (size_t r = 0; mono && r < h.nrefs; ++r) mono = idx->ref_accum[r + 1] - idx->ref_accum[r] == idx->ref_len[r];
   if (mono) for (uint64_t o : idx->ctab) if ((uint32_t)(o >> 32) >= h.nrefs) { mono = false; break; }
   if (!mono) { delete idx; sq_set_error("inconsistent index sections in '%s' (%llu unitigs): rebuild the index", p.c_str(), (unsigned long long)U); return SQ_ERR_IO; }
+  // the digests and the duplicate policy live in info.json, where the reference keeps them (SalmonIndex.hpp:138-154); an index written
+  // before they existed simply has none
+  if (FILE* jf = fopen((dir + "/info.json").c_str(), "r")) {
+    std::string js; char bufj[4096]; size_t got; while ((got = fread(bufj, 1, sizeof(bufj), jf)) > 0) js.append(bufj, got); fclose(jf);
+    static const char* keys[6] = {"\"SeqHash\"", "\"NameHash\"", "\"SeqHash512\"", "\"NameHash512\"", "\"DecoySeqHash\"", "\"DecoyNameHash\""};
+    for (int i = 0; i < 6; ++i) {
+      size_t at = js.find(keys[i]); if (at == std::string::npos) continue;
+      at = js.find(':', at); if (at == std::string::npos) continue;
+      const size_t a = js.find('"', at), b = a == std::string::npos ? a : js.find('"', a + 1);
+      if (b != std::string::npos) idx->hashes[i] = js.substr(a + 1, b - a - 1);
+    }
+    const size_t kd = js.find("\"keep_duplicates\""); if (kd != std::string::npos) idx->keep_duplicates = js.compare(js.find(':', kd) + 1, 5, " true") == 0;
+  }
   *out = idx;
   return SQ_OK;
 }
@@ -788,6 +817,8 @@ uint32_t sq_index_k(const sq_index* i) { return i->k; }
 uint32_t sq_index_m(const sq_index* i) { return i->m; }
 uint32_t sq_index_num_refs(const sq_index* i) { return (uint32_t)i->names.size(); }
 uint32_t sq_index_first_decoy(const sq_index* i) { return i->first_decoy; }
+const char* sq_index_hash(const sq_index* i, int which) { return (i && which >= 0 && which < 6) ? i->hashes[which].c_str() : ""; }
+int sq_index_keeps_duplicates(const sq_index* i) { return i && i->keep_duplicates ? 1 : 0; }
 const char* sq_index_ref_name(const sq_index* i, uint32_t t) { return t < i->names.size() ? i->names[t].c_str() : nullptr; }
 uint32_t sq_index_ref_len(const sq_index* i, uint32_t t) { return t < i->ref_len.size() ? i->ref_len[t] : 0; }
 uint32_t sq_index_ref_complete_len(const sq_index* i, uint32_t t) { return t < i->ref_clen.size() ? i->ref_clen[t] : 0; }

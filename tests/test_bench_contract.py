@@ -30,7 +30,7 @@ def test_live_bench_line_has_the_contract_fields_and_parity(built):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["n_gpus"] == 1
     assert d["steps"] == 2 and d["warmup"] == 1 and "workload" in d["config"] and "model" not in d["config"]
     assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    assert d["config"]["pairs_per_step"] == 2 * 60000 and d["config"]["workload_id"] == "c2"          # a step = `--sub` (2) sq_map_batch calls
+    assert d["config"]["pairs_per_step"] == 60000 and d["config"]["workload_id"] == "c2" and d["config"]["job_pairs"] == 120000   # a step = `--sub` (1) sq_map_batch call
     assert abs(d["value"] - 2 * d["config"]["pairs_per_step"] / (d["ms_per_step"] * 2e-3) / 1e6) < 0.01 * d["value"]          # value = pairs / wall time
     ro = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(ro) and ro["bound"] == "hbm" and ro["peak"] == 8000.0
@@ -39,3 +39,28 @@ def test_live_bench_line_has_the_contract_fields_and_parity(built):
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     p = d["parity_check"]
     assert p["pairs"] == 30000 and p["equal"] is True and all(p["checks"].values())
+    # [r4] beside the headline: the same job on a smaller pair count, the spread of the result over the online stage's free constants, and the c2s leg
+    assert d["jobs"] and all(j["value"] > 0 and j["em_iters"] > 0 for j in d["jobs"].values())
+    v = d["spread"]["variants"]
+    assert set(("W8_default", "W1", "W32", "W64", "batch_1M", "ranks_2")) <= set(v) and "error" not in v["ranks_2"]
+    assert v["W8_default"]["num_reads_ge_0.01"]["max"] == 0.0                       # the base against itself
+    assert all(0.0 <= v[k]["num_reads_ge_10"]["p999"] <= 1.0 for k in v if v[k].get("num_reads_ge_10"))
+    assert d["c2s"]["value"] > 0 and d["c2s"]["hits_per_frag"] > d["breakdown"]["hits_per_frag"]   # ~10 isoforms per gene: more alignments per fragment
+
+
+@pytest.mark.gpu
+def test_strong_scaling_workload_splits_a_fixed_total_over_the_ranks(built):
+    """--workload c3 (configs[2]): two ranks (gloo rendezvous, both on the one GPU) share a fixed total of pairs; the line says "strong"
+    and the job's pair count does not grow with the rank count."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--debug-one-device", "--steps", "3", "--warmup", "1", "--batch", "40000", "--genes", "400",
+                        "--cpu-sample", "0", "--fastq-pairs", "0"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["job_pairs"] == 120000 and d["config"]["workload_id"] == "c3"
+    assert d["breakdown"]["stats"]["num_reads"] == 60000                      # rank 0 mapped its half
+    assert abs(d["value"] - 120000 / (d["ms_per_step"] * 3e-3) / 1e6) < 0.01 * d["value"]
