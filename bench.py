@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--genome-gnt", type=float, default=None, help="c4: decoy genome size in 10^9 nt")
     ap.add_argument("--gibbs-samples", type=int, default=100, help="c5: posterior samples (100 = 4 chains, 1600 rounds)")
-    ap.add_argument("--cpu-sample", type=int, default=2000000, help="pairs timed through the CPU checker and compared with the HIP path (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=5000000, help="pairs timed through the CPU checker and compared with the HIP path (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="c2: skip the 10 M-pair job, the c2s leg and the spread measurement")
     ap.add_argument("--spread-pairs", type=int, default=10000000, help="c2 extras: pairs of the job the spread variants run (0 = skip)")
     ap.add_argument("--index-cache", default=None, help="directory to keep the built index in between runs (experiments; the driver's run builds it)")

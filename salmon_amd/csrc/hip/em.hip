@@ -70,7 +70,13 @@ struct EmDev {
   const uint32_t* chunk_seg; uint32_t nchunks; const uint8_t* t_seg8;   // t_seg8[p] = index of entry p's run within its block
   // level 2 folded into k_fin (plans with exactly two levels): transcript t sums part[0][l2_lo[t] .. +l2_cnt[t])
   const uint32_t* l2_lo; const uint8_t* l2_cnt;
+  // [r4] three launches per iteration: k_fin also leaves psi[t] = digamma(alpha'_t + prior_t) (-inf where the VBEM rule zeroes theta), its last
+  // block to finish closes the iteration and publishes logNorm; k_class / k_l1 form theta = exp(psi - logNorm) where they gather it
+  int psi_mode; const double* psi; const double* log_norm; double* psi_out; double* log_norm_out;
+  unsigned* fin_ctr;                 // [0 .. FIN_GROUPS) arrival counters of the block groups (one 128-byte line each), [FIN_GROUPS * 32] the top counter
+  unsigned long long* blk_rel; uint32_t* blk_bad;   // per block of k_fin: max relDiff (bit pattern) and "a transcript moved more than the tolerance"
 };
+#define FIN_GROUPS 16
 
 __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long* maxrel_log) {
   uint32_t it = it_index + 1;
@@ -89,11 +95,27 @@ __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long*
 // strided-halving trees, level by level) and publishes logNorm = digamma(sum).  Being a single
 // block, the `done` flag it may set is visible to every later kernel of the iteration.
 __global__ void __launch_bounds__(1024) k_top(EmDev d, const double* __restrict__ partials, uint32_t n1, int close_prev, uint32_t prev_it,
-    unsigned long long* maxrel_log, double* __restrict__ log_norm) {
+    unsigned long long* maxrel_log, double* __restrict__ log_norm, uint32_t nblk /* > 0: k_fin3 left per-block maxima / flags instead of the global atomics */) {
   __shared__ double buf[2][4096];
+  if (nblk && close_prev && !d.flags[0]) {   // [r4] four-launch form: the iteration is closed from k_fin3's per-block results (plain loads: a kernel boundary lies in between)
+    __shared__ unsigned long long smr[16]; __shared__ int sab[16];
+    unsigned long long mr = 0; int anybad = 0;
+    for (uint32_t b = threadIdx.x; b < nblk; b += blockDim.x) { const unsigned long long r = d.blk_rel[b]; if (r > mr) mr = r; anybad |= (int)d.blk_bad[b]; }
+    for (int s = 32; s >= 1; s >>= 1) { const unsigned long long o = __shfl_down(mr, s, 64); const int ob = __shfl_down(anybad, s, 64); if (o > mr) mr = o; anybad |= ob; }
+    if ((threadIdx.x & 63) == 0) { smr[threadIdx.x >> 6] = mr; sab[threadIdx.x >> 6] = anybad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (smr[w] > mr) mr = smr[w]; anybad |= sab[w]; }
+      const uint32_t it = prev_it + 1;
+      d.flags[2] = it; maxrel_log[0] = mr;
+      if (!anybad && it >= d.min_iter) d.flags[0] = it;
+    }
+  } else
   if (threadIdx.x == 0 && close_prev && !d.flags[0]) em_close(d, prev_it, maxrel_log);
+  __shared__ int s_stop;
+  if (threadIdx.x == 0) s_stop = __hip_atomic_load(&d.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // what this thread may just have written
   __syncthreads();
-  if (d.flags[0]) return;
+  if (s_stop || n1 == 0) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (uint32_t i = threadIdx.x; i < n1; i += blockDim.x) buf[0][i] = partials[i];
   __syncthreads();
@@ -123,6 +145,9 @@ __global__ void k_theta(EmDev d, const double* __restrict__ alpha, const double*
   }
 }
 
+// theta_t where a kernel gathers it: the stored value (EM: alpha; five-launch VBEM: k_theta's table) or, in psi mode, exp(psi_t - logNorm) —
+// the same two operations k_theta performs, on the same operands
+__device__ inline double theta_from(const EmDev& d, double x, double ln) { return d.psi_mode ? (x == -HUGE_VAL ? 0.0 : sq_exp(x - ln)) : x; }
 // class pass: inv_c = count_c / sum_t theta_t * w_ct.  A block owns a run of consecutive classes whose
 // label entries (<= CL_CHUNK) are staged through LDS: coalesced loads of (tid, weight), all theta[]
 // gathers in flight at once, the products parked in LDS, then one thread per class adds its terms in
@@ -135,10 +160,11 @@ __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restri
   __shared__ double s_term[CL_CHUNK];
   const uint32_t c0 = d.cchunk[blockIdx.x], c1 = d.cchunk[blockIdx.x + 1];
   const uint64_t e0 = d.off[c0], e1 = d.off[c1];
+  const double ln = d.psi_mode ? *d.log_norm : 0.0;
   if (e1 - e0 > CL_CHUNK) {   // c1 == c0 + 1
     if (threadIdx.x == 0) {
       double denom = 0.0;
-      for (uint64_t i = e0; i < e1; ++i) { const double th = theta[d.tid[i]]; if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
+      for (uint64_t i = e0; i < e1; ++i) { const double th = theta_from(d, theta[d.tid[i]], ln); if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
       d.inv[c0] = (denom <= 2.2250738585072014e-308) ? 0.0 : d.cnt[c0] / denom;
     }
     return;
@@ -154,6 +180,10 @@ __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restri
     }
 #pragma unroll
     for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta[t[j]];
+    if (d.psi_mode) {
+#pragma unroll
+      for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta_from(d, h[j], ln);
+    }
 #pragma unroll
     for (int j = 0; j < CL_CHUNK / CL_TB; ++j) {
       const uint64_t p = e0 + j * CL_TB + threadIdx.x;
@@ -195,7 +225,7 @@ __global__ void __launch_bounds__(L1_TB) k_l1(EmDev d, const double* __restrict_
     w[j] = d.t_cw[q];
     sg[j] = d.t_seg8[q];
   }
-  if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; s_th[threadIdx.x] = theta[tt & ~SEG_TOP]; }
+  if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; s_th[threadIdx.x] = theta_from(d, theta[tt & ~SEG_TOP], d.psi_mode ? *d.log_norm : 0.0); }
 #pragma unroll
   for (int j = 0; j < L1_CHUNK / L1_TB; ++j) iv[j] = d.inv[c[j]];
   __syncthreads();
@@ -306,6 +336,123 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
 __global__ void k_close(EmDev d, uint32_t it_index /* 0-based index of the iteration just run */, unsigned long long* maxrel_log) {
   if (d.flags[0]) return;
   em_close(d, it_index, maxrel_log);
+}
+
+// [r4] k_fin with the iteration's end folded in (the default; SQ_EM_LAUNCHES=5 keeps the five-launch form).  What a block hands to the block
+// that finishes last — its level-1 partial sums, its max relDiff, its "moved" flag — is written with agent-scope stores and read with
+// agent-scope loads (served by the memory side, so no cache maintenance is needed between XCDs: tools/gridbar2_bench.hip), every thread drains
+// its memory operations before its block arrives, and the arrival counters are two-level (FIN_GROUPS counters on their own lines, then one)
+// so that no address sees more than ~50 atomics.  The last block does what k_top / k_close did: closes the iteration (convergence, counters)
+// and, for VBEM, finishes the canonical sum of (alpha + prior) level by level and publishes logNorm = digamma(sum) for the next iteration.
+__device__ inline double em_ld_ag(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ inline void em_st_ag(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int TAIL>   // 1: the last block closes the iteration (three launches); 0: k_top does, from the per-block results (four launches)
+__global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials,
+    uint32_t it_index, unsigned long long* maxrel_log) {
+  if (d.flags[0]) return;
+  __shared__ double lvl[64];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  double rel = -1.0; int bad = 0; double leaf = 0.0;
+  if (t < d.M) {
+    const bool empty = d.t_off[t + 1] == d.t_off[t];
+    double acc;
+    const uint32_t n2 = d.l2_cnt ? d.l2_cnt[t] : 0;
+    if (n2) {
+      const double* src = d.part[0] + d.l2_lo[t];
+      acc = 0.0;
+      for (uint32_t i = 0; i < n2; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + k < n2) ? src[i + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+      }
+      alpha_out[t] = acc;
+    } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
+    else acc = alpha_out[t];
+    leaf = acc + d.prior[t];
+    if (acc > 1e-2) {  // alphaCheckCutoff (:884)
+      rel = fabs(alpha[t] - acc) / acc;
+      if (rel > d.tol) bad = 1;
+    }
+    if (d.psi_out) d.psi_out[t] = (leaf > 1e-10) ? sq_digamma(leaf) : -HUGE_VAL;   // digammaMin (:43): what k_theta computes from the same sum
+  }
+  if (partials) {
+    const double ls = wave_halving_sum(leaf);
+    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) { if (TAIL) em_st_ag(&partials[t >> 6], ls); else partials[t >> 6] = ls; }
+  }
+  for (int s = 32; s >= 1; s >>= 1) {
+    const double o = __shfl_down(rel, s, 64); const int ob = __shfl_down(bad, s, 64);
+    rel = o > rel ? o : rel; bad |= ob;
+  }
+  __shared__ double srel[4]; __shared__ int sbad[4]; __shared__ int s_last;
+  if ((threadIdx.x & 63) == 0) { srel[threadIdx.x >> 6] = rel; sbad[threadIdx.x >> 6] = bad; }
+  if (!TAIL) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; }
+      d.blk_rel[blockIdx.x] = rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL; d.blk_bad[blockIdx.x] = (uint32_t)bad;
+    }
+    return;
+  }
+  __builtin_amdgcn_s_waitcnt(0);                      // this thread's stores have been answered
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; }
+    __hip_atomic_store(&d.blk_rel[blockIdx.x], rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&d.blk_bad[blockIdx.x], (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint32_t grp = blockIdx.x % FIN_GROUPS, gsize = gridDim.x / FIN_GROUPS + (grp < gridDim.x % FIN_GROUPS ? 1u : 0u);
+    int last = 0;
+    if (__hip_atomic_fetch_add(&d.fin_ctr[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(&d.fin_ctr[grp * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t ngroups = gridDim.x < FIN_GROUPS ? gridDim.x : FIN_GROUPS;
+      if (__hip_atomic_fetch_add(&d.fin_ctr[FIN_GROUPS * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+        __hip_atomic_store(&d.fin_ctr[FIN_GROUPS * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the block that arrived last: every other block's partials / maxima are in memory ----
+  unsigned long long mr = 0; int anybad = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+    const unsigned long long r = __hip_atomic_load(&d.blk_rel[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (r > mr) mr = r;   // non-negative doubles order like their bit patterns
+    anybad |= (int)__hip_atomic_load(&d.blk_bad[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __shared__ unsigned long long smr[256]; __shared__ int sab[256]; __shared__ int s_done;
+  smr[threadIdx.x] = mr; sab[threadIdx.x] = anybad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t i = 1; i < blockDim.x; ++i) { if (smr[i] > mr) mr = smr[i]; anybad |= sab[i]; }
+    const uint32_t it = it_index + 1;              // em_close
+    d.flags[2] = it; maxrel_log[0] = mr;
+    const bool done = !anybad && it >= d.min_iter;
+    if (done) d.flags[0] = it;
+    s_done = done ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_done || !partials) return;
+  // SPEC D2: 64-leaf strided-halving trees, level by level (as k_top): the <= 4096 level-1 partials straight from memory, then <= 64 in LDS
+  const uint32_t n1 = (d.M + 63) >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, g = (n1 + 63) / 64;
+  for (uint32_t j = wave; j < g; j += nw) {
+    const uint32_t i = j * 64 + lane;
+    double v = (i < n1) ? em_ld_ag(&partials[i]) : 0.0;
+    v = wave_halving_sum(v);
+    if (lane == 0) lvl[j] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double v = lvl[0];
+    if (g > 1) { v = (lane < g) ? lvl[lane] : 0.0; v = wave_halving_sum(v); }
+    if (lane == 0) *d.log_norm_out = sq_digamma(v);
+  }
+}
+__global__ void k_psi0(EmDev d, const double* __restrict__ alpha, double* __restrict__ psi) {   // psi of the initial alphas (the iterations get theirs from k_fin3)
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.M) { const double ap = alpha[i] + d.prior[i]; psi[i] = (ap > 1e-10) ? sq_digamma(ap) : -HUGE_VAL; }
 }
 
 // Workspace arena: an EM session needs ~50 device buffers; hipMalloc + hipFree of each costs more (≈ 6 ms per
@@ -505,7 +652,8 @@ struct EmSession {
   DBuf<uint32_t> d_tid, d_tcls, d_flags;
   DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part;
   DBuf<unsigned long long> d_maxrel, d_log;
-  DBuf<double> d_lognorm;
+  DBuf<double> d_lognorm, d_psi0, d_psi1;
+  DBuf<unsigned> d_finctr; DBuf<unsigned long long> d_blkrel; DBuf<uint32_t> d_blkbad;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -562,7 +710,8 @@ struct EmSession {
         !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
               !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) &&
                   !d_flags.alloc(4) &&
-                  !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1);
+                  !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) && !d_psi0.alloc(M) && !d_psi1.alloc(M) &&
+                  !d_finctr.alloc((FIN_GROUPS + 1) * 32) && !d_blkrel.alloc((M + 255) / 256 + 1) && !d_blkbad.alloc((M + 255) / 256 + 1);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     pt.mark("buffers");
@@ -677,6 +826,9 @@ struct EmSession {
     d.cchunk = d_cchunk.p; d.ncchunks = h_cchunk.size() > 1 ? (uint32_t)h_cchunk.size() - 1 : 0;
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
     d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
+    d.psi_mode = 0; d.psi = nullptr; d.log_norm = d_lognorm.p; d.psi_out = nullptr; d.log_norm_out = d_lognorm.p;
+    d.fin_ctr = d_finctr.p; d.blk_rel = d_blkrel.p; d.blk_bad = d_blkbad.p;
+    SQ_HIP_CHECK(hipMemsetAsync(d_finctr.p, 0, (FIN_GROUPS + 1) * 32 * sizeof(unsigned), st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
     pt.mark("device-prepare");
     return SQ_OK;
   }
@@ -707,6 +859,7 @@ struct EmSession {
     // level-1 partials of (alpha + prior) live in d.partial (written by k_fin); k_top finishes the
     // levels above (<= 4096 partials); for M > 262144 k_sum_level kernels shrink the list first.
     double* part_lvl1 = d.partial; double* part_tmp = d.partial + g1 + 64;
+    uint32_t top_nblk = 0;
     auto launch_top = [&](int close_prev, uint32_t prev_it) {
       const double* pin = part_lvl1; uint32_t n1 = g1;
       double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
@@ -716,9 +869,38 @@ struct EmSession {
         n1 = (n1 + 63) / 64;
         std::swap(a, b);
       }
-      k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p);
+      k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p, top_nblk);
     };
-    auto launch_iter = [&](uint32_t it) {
+    // [r4] three launches per iteration unless the plan needs more than two reduction levels, M is beyond one block's reach, or SQ_EM_LAUNCHES=5
+    // [r4] measured on MI355X (c2, E = 0.63 M, L = 1.66 M, M = 191 k): five launches 40.9 us per iteration; three (k_fin3's last block closes the
+    // iteration and finishes the sum) 45.7 us — the serial tail of one block costs more than the two launches it replaces; four (k_theta folded
+    // into the gathers, k_top closes from per-block results) is the default.  SQ_EM_LAUNCHES=3|4|5 selects.
+    static const int nl_env = getenv("SQ_EM_LAUNCHES") ? atoi(getenv("SQ_EM_LAUNCHES")) : 4;
+    const bool can_fold = g1 <= 4096 && (d.l2_cnt || d.nlevels <= 1);
+    const bool fold = can_fold && nl_env == 3, four = can_fold && nl_env == 4;
+    if (four) top_nblk = (M + TB - 1) / TB;
+    double* psi_cur = d_psi0.p; double* psi_nxt = d_psi1.p;
+    auto launch_iter3 = [&](uint32_t it) {
+      EmDev dd = d;
+      if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
+      const double* src = o->use_vbem ? psi_cur : cur;
+      if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
+      if (dd.nchunks) k_l1<<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt);
+      k_fin3<1><<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
+      std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
+    };
+    auto launch_iter4 = [&](uint32_t it) {
+      EmDev dd = d;
+      if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
+      const double* src = o->use_vbem ? psi_cur : cur;
+      if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
+      if (dd.nchunks) k_l1<<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt);
+      k_fin3<0><<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
+      if (o->use_vbem) launch_top(1, it);
+      else k_top<<<1, 1024, 0, st>>>(d, part_lvl1, 0, 1, it, d_log.p, d_lognorm.p, top_nblk);   // EM: only closes the iteration
+      std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
+    };
+    auto launch_iter5 = [&](uint32_t it) {
       const double* theta_src = cur;
       if (o->use_vbem) { k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p); theta_src = d.theta; }
       if (d.ncchunks) k_class<<<d.ncchunks, CL_TB, 0, st>>>(d, theta_src);
@@ -732,7 +914,9 @@ struct EmSession {
       else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);
       std::swap(cur, nxt);
     };
-    if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0); }
+    auto launch_iter = [&](uint32_t it) { if (fold) launch_iter3(it); else if (four) launch_iter4(it); else launch_iter5(it); };
+    if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0);
+      if (fold || four) k_psi0<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, psi_cur); }
     uint32_t it = it0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     if (mode == 1) {

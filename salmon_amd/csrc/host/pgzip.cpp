@@ -89,7 +89,7 @@ struct Out {   // symbols of a piece, preceded by the 32 K window symbols
   bool reserve(size_t want) { if (want <= cap) return true; size_t nc = std::max(want, cap + cap / 2 + (1u << 20)); uint16_t* nb = (uint16_t*)realloc(b, nc * 2); if (!nb) return false; b = nb; cap = nc;
     if (nc * 2 >= (4u << 20)) { const uintptr_t a = ((uintptr_t)b + 4095) & ~(uintptr_t)4095; (void)madvise((void*)a, (nc * 2 - (a - (uintptr_t)b)) & ~(size_t)4095, MADV_HUGEPAGE); }   // fewer first-touch faults
     return true; }
-  void start(size_t expect = 1u << 22) { reserve(WIN + expect); for (uint32_t k = 0; k < WIN; ++k) b[k] = (uint16_t)(MARK | k); n = WIN; }
+  bool start(size_t expect = 1u << 22) { n = 0; if (!reserve(WIN + expect)) return false; for (uint32_t k = 0; k < WIN; ++k) b[k] = (uint16_t)(MARK | k); n = WIN; return true; }
 };
 
 inline bool texty(int c) { return (c >= 32 && c < 127) || c == '\n' || c == '\r' || c == '\t'; }
@@ -156,6 +156,9 @@ int inflate_block(Bits& br, Out& o, bool text_only, size_t max_out) {
   // per symbol into a shared cache line made four threads slower than one)
   Bits b = br; uint16_t* ob = o.b; size_t on = o.n, ocap = o.cap; int rc = -1;
   for (;;) {
+    // [r4] a truncated or damaged stream can decode literals for ever (past the end of the input the reader yields zeros, and the all-zero
+    // code may be a literal): the end of the input and the trial's output bound are looked at on every trip, not only after a match
+    if (on > max_out || b.tell() > end_bits) { rc = B_BAD; break; }
     if (on + 300 > ocap) { o.n = on; if (!o.reserve(on + (1u << 20))) { rc = B_BAD; break; } ob = o.b; ocap = o.cap; }
     b.refill();                                    // >= 56 bits: a literal/length code (15) + extra (5) + distance code (15) + extra (13) = 48
     int s = lit->decode(b);
@@ -206,7 +209,7 @@ uint64_t find_block(const uint8_t* base, size_t n, uint64_t from, uint64_t to) {
       if (left != 0) continue; }
     { Bits b1(base, n); b1.seek(bit + 3); Huff a, b; if (!read_dynamic(b1, a, b, true)) continue; }   // both code tables valid and complete
     Bits br(base, n); br.seek(bit);
-    trial.start();
+    if (!trial.start()) return ~0ULL;                                     // out of memory: no block start is claimed
     if (inflate_block(br, trial, true, WIN + (8u << 20)) != B_MORE) continue;
     if (trial.n < WIN + 1024) continue;                                   // a real block of a large file holds kilobytes
     // the next header must parse too
@@ -222,7 +225,7 @@ struct Text { char* p = nullptr; size_t n = 0, cap = 0; ~Text() { free(p); }   /
   bool size(size_t want) { if (want > cap) { free(p); cap = want + want / 8 + 4096; p = (char*)malloc(cap); if (!p) { cap = 0; return false; } } n = want; return true; } };
 struct Recycler { std::mutex mu; std::vector<std::unique_ptr<Text>> spare; };   // outlives the stream while text buffers are still out
 struct alignas(128) Piece {
-  uint64_t start = ~0ull, end = 0; Out out; int status = B_BAD; bool ran = false;     // status of the LAST block decoded: B_MORE = stopped at a boundary
+  uint64_t start = ~0ull, end = 0; Out out; int status = B_BAD; bool oom = false; bool ran = false;     // status of the LAST block decoded: B_MORE = stopped at a boundary
   std::unique_ptr<Text> text; uint32_t crc = 0;
 };
 }  // namespace
@@ -276,7 +279,7 @@ struct PgzStream {
     R.T = T; R.starts_member = next_starts_member; next_starts_member = false;
     { std::lock_guard<std::mutex> lk(pmu); while (R.pc.size() < T) { if (!free_pc.empty()) { R.pc.push_back(std::move(free_pc.back())); free_pc.pop_back(); } else R.pc.emplace_back(new Piece()); } }
     auto& pc = R.pc;
-    for (auto& p : pc) { p->start = ~0ull; p->end = 0; p->status = B_BAD; p->ran = false; p->crc = 0; }
+    for (auto& p : pc) { p->start = ~0ull; p->end = 0; p->status = B_BAD; p->ran = false; p->crc = 0; p->oom = false; }
     pc[0]->start = bitpos;
     const uint64_t round_end = bitpos + (uint64_t)T * pb;
     parallel(T - 1, [&](unsigned k) { const unsigned i = k + 1; const uint64_t from = bitpos + (uint64_t)i * pb; if (from < nbits) pc[i]->start = find_block(base, n, from, std::min(from + pb, nbits)); });
@@ -286,7 +289,8 @@ struct PgzStream {
     // the last one to the first boundary past the end of the round
     parallel(T, [&](unsigned i) {
       Piece& P = *pc[i]; if (P.start == ~0ull) return;
-      P.ran = true; Bits br(base, n); br.seek(P.start); P.out.start(piece_bytes * 5);   // sequence data inflates ~3-4 x: no regrowth on the way
+      P.ran = true; Bits br(base, n); br.seek(P.start);
+      if (!P.out.start(piece_bytes * 5)) { P.status = B_BAD; P.end = P.start; P.oom = true; return; }   // sequence data inflates ~3-4 x: no regrowth on the way
       unsigned nxt = i + 1;
       for (;;) {
         const uint64_t pos = br.tell();
@@ -304,7 +308,7 @@ struct PgzStream {
     unsigned cur = 0;
     for (;;) {
       Piece& P = *pc[cur]; R.chain.push_back(cur);
-      if (P.status == B_BAD) { R.err = "corrupt deflate data near byte " + std::to_string(P.end / 8); return; }
+      if (P.status == B_BAD) { R.err = P.oom ? std::string("out of memory while inflating (SQ_READER_PGZ_PIECE sets the piece size)") : "corrupt deflate data near byte " + std::to_string(P.end / 8); return; }
       if (P.status == B_FINAL) { R.final_seen = true; break; }
       unsigned k = cur + 1; while (k < T && pc[k]->start != P.end) ++k;
       if (k >= T) break;

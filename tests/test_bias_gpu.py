@@ -99,7 +99,7 @@ def test_cli_gcbias_writes_corrected_effective_lengths(built, tmp_path):
     r = subprocess.run([exe, "quant", "-i", str(tmp_path / "idx"), "-l", "IU", "-1", os.path.join(g, "reads_1.fq.gz"), "-2", os.path.join(g, "reads_2.fq.gz"),
                         "-o", str(tmp_path / "all3"), "--gcBias", "--seqBias", "--posBias"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-800:]
-    m = json.load(open(tmp_path / "all3" / "aux_info" / "meta_info.json")); assert m["pos_bias_correct"] is True and m["seq_bias_correct"] is True
+    m = json.load(open(tmp_path / "all3" / "aux_info" / "meta_info.json")); assert m["salmon_hip"]["pos_bias_correct"] is True and m["seq_bias_correct"] is True
     n3 = np.array([float(l.split("\t")[4]) for l in open(tmp_path / "all3" / "quant.sf").read().strip().split("\n")[1:]])
     assert abs(n3.sum() - n0.sum()) < 1e-3 * n0.sum() and np.corrcoef(n0, n3)[0, 1] > 0.97 and not np.array_equal(n3, n2)
 

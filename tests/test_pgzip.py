@@ -56,3 +56,22 @@ def test_damage_and_truncation_are_reported(built, tmp_path):
     r = _run(f, 4, 65536); assert r.returncode != 0 and "pgz error" in r.stdout, r.stdout
     bad = bytearray(z); bad[-6] ^= 0xFF; open(f, "wb").write(bytes(bad))          # the stored CRC-32
     r = _run(f, 4, 65536); assert r.returncode != 0 and "checksum" in r.stdout, r.stdout
+
+
+def test_truncated_literal_only_stream_fails_fast_and_small(built, tmp_path):
+    """[r4, ADVICE r3] A Z_HUFFMAN_ONLY stream has no matches, so a block is literals only; past the end of a truncated file the bit reader yields
+    zeros and the all-zero code may be a literal — the decoder must notice the end of the input on the literal path too, not grow its output until
+    memory runs out.  Run under a 2 GB address-space limit and a short timeout."""
+    import resource
+    rng = np.random.default_rng(33); fq = _fastq(rng, 40000)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_HUFFMAN_ONLY); z = co.compress(fq) + co.flush(); f = tmp_path / "h.gz"
+    open(f, "wb").write(z); r = _run(f, 4, 65536)
+    assert r.returncode == 0 and "equal=1" in r.stdout, r.stdout[-300:]
+    def limit(): resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30))
+    import time
+    for frac in (0.4, 0.77, 0.999):
+        open(f, "wb").write(z[: int(len(z) * frac)])
+        t0 = time.time()
+        r = subprocess.run([EXE, str(f), "4", "65536"], capture_output=True, text=True, timeout=60, preexec_fn=limit)
+        assert r.returncode != 0 and "pgz error" in r.stdout and "memory" not in r.stdout, (frac, r.stdout[-300:], r.stderr[-300:])
+        assert time.time() - t0 < 20, "a truncated file must be reported at once"
