@@ -2211,6 +2211,22 @@ void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) {
 }
 double orc_forgetting_mass(double ff, uint64_t b) { QuantState S; S.op.o.forgetting_factor = ff; return S.forgetting_mass(b); }
 
+// ---- [r4] the bias models' arithmetic on its own, so that tests/test_models_pin.py can hold it against the reference's SBModel.cpp / GCFragModel.hpp
+// compiled into oracle/_ref/libmodels_ref.so ----
+// counts[9][64] (the cells sb_cell addresses, WITHOUT the 1e-10 every cell of the reference starts with: added here) -> log probabilities
+void orc_sb_normalize(const double* counts576, double* logp576) { double c[576]; for (int i = 0; i < 576; ++i) c[i] = counts576[i] + 1e-10; sb_normalize(c, logp576); }
+uint32_t orc_sb_cell(uint32_t ctx18, int pos) { return sb_cell(ctx18, pos); }
+uint32_t orc_sb_rc(uint32_t ctx18) { return sb_rc(ctx18); }
+double orc_sb_eval(const double* logp576, uint32_t ctx18) { return sb_eval(logp576, ctx18); }
+int orc_gc_frag_bin(int frag_frac) { return gc_frag_bin(frag_frac); }
+int orc_gc_ctx_bin(int ctx_frac) { return gc_ctx_bin(ctx_frac); }
+// normalize (prior 0.1) both models and clamp the ratio to [1/1000, 1000]: the lines of bias_gc_eff_lengths / bias_seq_eff_lengths above
+void orc_gc_ratio(const double* obs75, const double* exp75, double* out75) {
+  auto normalize = [](const double* in, double* out) { double rowMass = 0.0; for (int c = 0; c < 25; ++c) rowMass += (0.1 + in[c]);
+    if (rowMass > 0.0) { double norm = 1.0 / rowMass; for (int c = 0; c < 25; ++c) out[c] = (0.1 + in[c]) * norm; } else for (int c = 0; c < 25; ++c) out[c] = in[c]; };
+  for (int r = 0; r < 3; ++r) { double on[25], en[25]; normalize(obs75 + 25 * r, on); normalize(exp75 + 25 * r, en);
+    for (int c = 0; c < 25; ++c) { double rat = on[c] / en[c]; if (rat > 1000.0) rat = 1000.0; if (rat < 1.0 / 1000.0) rat = 1.0 / 1000.0; out75[r * 25 + c] = rat; } }
+}
 }  // extern "C"
 
 // threads split classes / transcripts statically; per-iteration barrier via join (coarse but fair)

@@ -278,6 +278,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  c->warm_stop(); if (c->stream_warm) { (void)hipStreamSynchronize(c->stream_warm); (void)hipStreamDestroy(c->stream_warm); } if (c->warm_flag) (void)hipHostFree(c->warm_flag);
   if (c->stream_chain) { (void)hipStreamSynchronize(c->stream_chain); (void)hipStreamDestroy(c->stream_chain); }
   if (c->ev_chain_in) (void)hipEventDestroy(c->ev_chain_in);
   if (c->ev_chain_out) (void)hipEventDestroy(c->ev_chain_out);
@@ -390,6 +391,7 @@ extern "C" int sq_map_fetch(sq_ctx* c, sq_aln_batch* out) {
 }
 
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
+  if (c && !c->owner) c->warm_stop();
   if (!c || !in || !in->seq_off || !in->seq) { sq_set_error("sq_map_batch: bad arguments"); return SQ_ERR_ARG; }
   const uint32_t n = in->n, paired = in->paired ? 1 : 0, nrec = paired ? 2 * n : n;
   if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }

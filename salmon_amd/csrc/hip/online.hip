@@ -1629,6 +1629,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
 
 extern "C" int sq_ctx_reset(sq_ctx* c) {
   if (!c) return SQ_ERR_ARG;
+  c->warm_stop();
   (void)sq_eq_sync(c);
   SQ_HIP_CHECK(hipSetDevice(c->device));
   // the export buffers and their page-locked staging area are work buffers (sized by earlier jobs / sq_ctx_reserve): they survive
@@ -1840,7 +1841,27 @@ static int eq_export_run(sq_ctx* c) {
   X.model_valid = model_final;
   mark("kernels+d2h");
   X.valid = true;
+  c->warm_start();   // the host now copies the table out and runs normalizeAlphas: the device stays awake for the optimiser that follows
   return SQ_OK;
+}
+
+// see ctx.h: one sleeping wave between the export and the optimiser
+__global__ void k_keep_warm(volatile int* stop, long long max_ticks) {
+  const long long t0 = (long long)wall_clock64();   // constant-rate counter (100 MHz)
+  while (!*stop && (long long)wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
+}
+void sq_ctx::warm_start() {
+  static const int on = getenv("SQ_KEEP_WARM") ? atoi(getenv("SQ_KEEP_WARM")) : 1;
+  if (!on || warm_running) return;
+  if (!warm_flag) { if (hipHostMalloc((void**)&warm_flag, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); warm_flag = nullptr; return; }
+    if (hipStreamCreateWithFlags(&stream_warm, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(warm_flag); warm_flag = nullptr; return; } }
+  *warm_flag = 0; __sync_synchronize();
+  k_keep_warm<<<1, 64, 0, stream_warm>>>(warm_flag, 100000LL * 40);   // at most 40 ms
+  warm_running = true;
+}
+void sq_ctx::warm_stop() {
+  if (!warm_running) return;
+  *warm_flag = 1; __sync_synchronize(); warm_running = false;     // the wave sees it within a few microseconds; nothing waits for it
 }
 
 extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
@@ -1969,6 +1990,7 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
+  struct WarmOff { sq_ctx* c; ~WarmOff() { c->warm_stop(); } } warm_off{c};   // once the optimiser's own work is queued the sleeping wave may go
   return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
 }
 
