@@ -224,7 +224,7 @@ typedef struct {           /* HitCounters / MappingStatistics subset (SalmonQuan
       num_mappings_filtered, num_fragments_filtered, num_dovetails, num_decoy_fragments,
       num_seeds, num_lookups, num_mems, num_chains, num_candidates, num_dp_alignments,
       num_orphans_rescued /* fragments with a recovered mate (mstats.numOrphansRescued) */,
-      num_truncated_ends /* read ends longer than the 256-base packing limit, cut to their first 256 bases (SPEC §I; the reference has no limit) */;
+      num_truncated_ends /* [r4] always 0: nothing is cut — a batch with a read of more than 1000 bases is refused (SQ_ERR_ARG), longer strides and uni-MEM slabs are taken as needed (SPEC §I, §a1) */;
 } sq_map_stats;
 
 /* Map one batch. Results stay resident on the device for sq_eq_accumulate(); if out != NULL they

@@ -35,7 +35,7 @@
 
 namespace orc {
 
-constexpr int MAX_UNIMEMS = 32;      // SPEC §a1
+// [r4] no cap on the uni-MEMs of a read end (SPEC §a1: the reference keeps them all; the product widens its slab until they fit)
 constexpr int MAX_CHAIN_GAP = 200;   // SPEC §a2
 constexpr double AVG_SEED = 31.0;    // SPEC §a2 (pufferfish uses a constant average seed length)
 constexpr int REF_EXTEND = 20;       // aconf.refExtendLength (SalmonMappingUtils.hpp:184)
@@ -147,7 +147,7 @@ static void collect_unimems(const Index& ix, const Opts& op, const std::vector<u
   const uint32_t k = ix.k; const int L = (int)rd.size();
   if (L < (int)k) return;
   int pos = 0, skip_until = -1; const int alt = (int)op.o.mismatch_seed_skip;
-  while (pos + (int)k <= L && (int)out.size() < MAX_UNIMEMS) {
+  while (pos + (int)k <= L) {
     int lastN = -1; for (int i = pos; i < pos + (int)k; ++i) if (rd[i] > 3) lastN = i;
     if (lastN >= 0) { pos = lastN + 1; continue; }
     uint64_t km = 0; for (uint32_t i = 0; i < k; ++i) km |= (uint64_t)rd[pos + i] << (2 * i);
@@ -579,9 +579,7 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
                          FragResult& out, sq_map_stats& st, Taps* taps) {
   out.alns.clear(); out.map_type = SQ_MT_UNMAPPED;
   st.num_reads++;
-  if (n1 > 256) { n1 = 256; st.num_truncated_ends++; }
-  if (paired && n2 > 256) { n2 = 256; st.num_truncated_ends++; }
-  if (n2 > 256) n2 = 256;   // SPEC §I: a read end is its first 256 bases (the product's packing limit)
+  // [r4] SPEC §I: read ends are mapped whole (the product takes up to 1000 bases and refuses longer reads with an error; nothing is cut)
   std::vector<uint8_t> rd[2]; std::vector<UniMem> um[2]; std::vector<Mem> mems[2]; std::vector<Chain> ch[2];
   const int nends = paired ? 2 : 1;
   for (int e = 0; e < nends; ++e) {

@@ -481,8 +481,6 @@ static int cmd_quant(int argc, char** argv) {
   if (unm) fclose(unm);
   sq_reader_close(rd);
   if (!quiet) fprintf(stderr, "\n");
-  if (tot.num_truncated_ends) fprintf(stderr, "[salmon-hip] warning: %llu read ends were longer than 256 bases and were cut to their first 256 (the packing limit of the GPU path)\n",
-      (unsigned long long)tot.num_truncated_ends);
   if (dist) {   // ONE exchange of the class tables, counters summed
     if (sq_dist_merge_eq(dist, ctx)) die("eq-class exchange");
     if (sq_dist_allreduce_u64(dist, (uint64_t*)&tot, sizeof(tot) / 8) || sq_dist_allreduce_u64(dist, &nfrag, 1)) die("counter all-reduce");

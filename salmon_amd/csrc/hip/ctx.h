@@ -14,10 +14,15 @@
 #include <vector>
 #include "device_index.h"
 
-#define SQ_MAX_READ_LEN 256u
-#define SQ_READ_WORDS 8u          // 2-bit words per read end
-#define SQ_NMASK_WORDS 4u         // N-mask words per read end (1 bit / base)
-#define SQ_MAX_UNIMEMS 32u        // SPEC §a1
+// [r4] a read end of up to SQ_MAX_READ_LEN bases is mapped whole (the 10-bit position / length fields of a MEM record hold 0..1023); a longer one is
+// refused with an error, not cut.  The packed reads' stride is a property of the context: 8 words (256 bases) until a batch brings a longer read,
+// then 16 or 32 (the batch is packed again; sticky).  N-mask words = stride / 2.
+#define SQ_MAX_READ_LEN 1000u
+#define SQ_READ_WORDS_MIN 8u      // 2-bit words per read end (the default stride: 256 bases)
+#define SQ_READ_WORDS_MAX 32u
+#define SQ_MAX_UNIMEMS 32u        // uni-MEM slots per read end by default, and the most a size class of k_mems keeps in LDS; [r4] an end that needs more makes the
+                                  // context widen its slab (uni_slots: 64, 128, ... 1024) and takes the large-end path — nothing is dropped (SPEC §a1)
+#define SQ_MAX_UNI_SLOTS 1024u
 #define SQ_MAX_CHAIN_GAP 200      // SPEC §a2
 #define SQ_REF_EXTEND 20          // aconf.refExtendLength (SalmonMappingUtils.hpp:184)
 #define SQ_MAX_BAND 15            // DP band kept in registers (runtime bandwidth must be <= this)
@@ -96,6 +101,8 @@ struct sq_eq_dev;      // eq.hip
 struct sq_ctx {
   sq_index* idx = nullptr; sq_device_index* di = nullptr; int device = 0;
   sq_quant_opts opts; sq_map_params mp; uint32_t max_reads = 0;
+  uint32_t uni_slots = SQ_MAX_UNIMEMS;       // stride of the uni-MEM slab; raised (and the batch seeded again) when an end produces more
+  uint32_t read_words = SQ_READ_WORDS_MIN;   // stride of rpack (rnmask: half of it); raised when a batch holds reads of more than 32 * read_words bases
   hipStream_t stream = nullptr;
   // reads
   sq_dbuf<uint8_t> seq; sq_dbuf<uint64_t> seq_off; sq_dbuf<uint64_t> rpack; sq_dbuf<uint64_t> rnmask; sq_dbuf<uint16_t> rlen;
@@ -133,7 +140,7 @@ struct sq_ctx {
   // idle; the first submission after such a gap behind heavy load was measured to come back ~20 ms late on MI355X (SQ_TIMING: "upload drained"
   // 20.2 ms for a 1.3 MB copy).  One wave that sleeps on a page-locked flag (k_keep_warm, at most `warm_ms`) keeps the device out of that state;
   // the next entry point that uses the device stops it.  SQ_KEEP_WARM=0 switches it off.
-  hipStream_t stream_warm = nullptr; int* warm_flag = nullptr; bool warm_running = false;
+  int* warm_flag = nullptr; bool warm_running = false;
   void warm_start(); void warm_stop();
   // [r3, experimental: SQ_EQ_CHAIN=1] no partition: mapping and the eq stage's throughput kernels share all CUs, and the mass-dependent chain of a
   // batch is ONE resident kernel (k_chain, hip/online.hip) on a stream masked to a single XCD, with a barrier of its own between the groups
@@ -202,7 +209,8 @@ void sq_eq_worker_stop(sq_ctx* c);                                // wait for ou
 // stats slots (device array of unsigned long long, same order as sq_map_stats)
 enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGFILT, ST_DOVETAIL, ST_DECOY, ST_SEEDS, ST_LOOKUPS, ST_MEMS,
     ST_CHAINS, ST_CANDS, ST_DP,
-    ST_RESCUED, ST_TRUNC, ST_N };
+    ST_RESCUED, ST_TRUNC, ST_MAXLEN /* longest read end of the batch when it did not fit the packing stride (k_pack) */,
+    ST_UNIOVER /* read ends whose uni-MEMs did not fit the slab's stride (k_seed) */, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`

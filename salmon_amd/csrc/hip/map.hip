@@ -187,10 +187,10 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_eq_done[b], hipEventDisableTiming));
   }
   const uint32_t nends = 2 * max_batch_reads;
-  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * SQ_READ_WORDS + 8) ||
-      c->rnmask.ensure((size_t)nends * SQ_NMASK_WORDS + 8) ||
+  bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * c->read_words + 8) ||
+      c->rnmask.ensure((size_t)nends * (c->read_words / 2) + 8) ||
       c->rlen.ensure(nends) ||
-             c->unimems.ensure((size_t)nends * SQ_MAX_UNIMEMS) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
+             c->unimems.ensure((size_t)nends * c->uni_slots) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
                  c->mem_off.ensure((size_t)nends + 2) ||
              c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) ||
                  c->cand_off.ensure((size_t)max_batch_reads + 2) || c->counters.ensure(32) ||
@@ -211,6 +211,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  c->warm_stop();
   if (c->lane_thread.joinable()) {
     {
       std::lock_guard<std::mutex> lk(c->lane_mu);
@@ -276,9 +277,10 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->aln_b1.free_();
   c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
+  c->warm_stop();
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
-  c->warm_stop(); if (c->stream_warm) { (void)hipStreamSynchronize(c->stream_warm); (void)hipStreamDestroy(c->stream_warm); } if (c->warm_flag) (void)hipHostFree(c->warm_flag);
+
   if (c->stream_chain) { (void)hipStreamSynchronize(c->stream_chain); (void)hipStreamDestroy(c->stream_chain); }
   if (c->ev_chain_in) (void)hipEventDestroy(c->ev_chain_in);
   if (c->ev_chain_out) (void)hipEventDestroy(c->ev_chain_out);
@@ -287,6 +289,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
     if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->warm_flag) (void)hipHostFree(c->warm_flag);
   delete c;
 }
 
@@ -420,11 +423,15 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     SQ_HIP_CHECK(hipMemcpyAsync(c->seq_off.p, in->seq_off, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, st));
     d_seq = c->seq.p; d_seq_off = c->seq_off.p;
   }
+  const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
+  int pack_attempt = 0, uni_attempt = 0;
+pack_again:   // [r4] taken once more when the batch holds a read end longer than the packing stride allows (the stride is raised and stays raised)
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
-  const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
   sq_prof_begin(c);
-  k_pack<<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
+  if (c->read_words == 8) k_pack<8><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
+  else if (c->read_words == 16) k_pack<16><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
+  else k_pack<32><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
   sq_prof_mark(c, SG_PACK);
   {  // persistent grid: 256 CUs x 6 blocks of 256 threads; lanes pull read ends from counters[2].  The probe rate is
      // bound by the memory system, not by occupancy (4..8 blocks/CU measure the same), so two blocks' worth of wave
@@ -432,7 +439,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     static const int spec = getenv("SQ_SEED_SPEC") ? atoi(getenv("SQ_SEED_SPEC")) : 2;
-#define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2
+#define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
     if (P.k == 31 && di->dict.m == 20) {   // the default (k = 31, m = 20) gets the fully specialised kernel
       if (spec == 1) k_seed<31, 20, 1><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
       else if (spec == 3) k_seed<31, 20, 3><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
@@ -443,7 +450,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     else
       k_seed<0, 0><<<grid, TB, 0, st>>>(di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p,
           c->n_proj.p, c->stats.p,
-          c->counters.p + 2);
+          c->counters.p + 2, c->read_words, c->uni_slots);
   }
   sq_prof_mark(c, SG_SEED);
   SQ_HIP_CHECK(hipMemsetAsync(c->n_proj.p + nrec, 0, sizeof(uint32_t), st));
@@ -456,9 +463,31 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
       c->counters.p + 16);
   uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
+  unsigned long long h_maxlen = 0, h_uniover = 0;
+  SQ_HIP_CHECK(hipMemcpyAsync(&h_uniover, c->stats.p + ST_UNIOVER, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 16, sizeof(hcls), hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(&h_maxlen, c->stats.p + ST_MAXLEN, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));
+  if (h_maxlen) {   // [r4] a read end did not fit: refuse it (the reference has no limit; this path maps reads of up to SQ_MAX_READ_LEN bases) or widen the stride and pack again
+    if (h_maxlen > SQ_MAX_READ_LEN) { sq_set_error("a read of %llu bases: the GPU path maps reads of up to %u bases (nothing is cut silently)", h_maxlen, SQ_MAX_READ_LEN); return SQ_ERR_ARG; }
+    if (P.recover_orphans && paired && h_maxlen > 256) { sq_set_error("--recoverOrphans is built for reads of up to 256 bases (a read of %llu bases is in the batch)", h_maxlen); return SQ_ERR_ARG; }
+    const uint32_t need = h_maxlen <= 512 ? 16u : 32u;
+    if (pack_attempt++ || need <= c->read_words) { sq_set_error("internal: read of %llu bases with a stride of %u words", h_maxlen, c->read_words); return SQ_ERR_STATE; }
+    c->read_words = need;
+    const size_t cap_ends = std::max<size_t>(2 * (size_t)c->max_reads, nrec);
+    if (c->rpack.ensure(cap_ends * need + 8) || c->rnmask.ensure(cap_ends * (need / 2) + 8)) { sq_set_error("device allocation failed (packed reads of up to %u bases)", 32 * need); return SQ_ERR_NOMEM; }
+    goto pack_again;
+  }
+  if (h_uniover) {   // [r4] read ends with more uni-MEMs than the slab has slots per end (the reference keeps them all): a wider slab, and the batch is seeded again
+    const uint32_t need = c->uni_slots * 2;
+    const size_t cap_ends = std::max<size_t>(2 * (size_t)c->max_reads, nrec);
+    if (need > SQ_MAX_UNI_SLOTS || uni_attempt++ >= 6 || cap_ends * need * sizeof(sq_unimem_dev) > ((size_t)96 << 30)) {
+      sq_set_error("%llu read ends have more than %u uni-MEMs and the slab cannot grow further; split the batch", h_uniover, c->uni_slots); return SQ_ERR_OVERFLOW; }
+    c->uni_slots = need;
+    if (c->unimems.ensure(cap_ends * need)) { sq_set_error("device allocation failed (uni-MEM slab of %u slots per end); split the batch", need); return SQ_ERR_NOMEM; }
+    goto pack_again;
+  }
   c->last_total_mems = total_mems;
   if (total_mems >= 0x7FFFFFF0ull) {   // 32-bit slab indices (candidates name chains by slab index; recovery doubles the slabs)
     sq_set_error("too many MEMs in one batch (%llu); split the batch", (unsigned long long)total_mems);
@@ -470,7 +499,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     sq_set_error("device allocation failed for %llu MEMs; split the batch", (unsigned long long)total_mems); return SQ_ERR_NOMEM; }
   uint64_t* skey = c->mkey2.p; uint64_t* sval = c->mval2.p;
   const uint32_t nL = hcls[MK_NCLS - 1], memsL = hcls[MK_NCLS];
-#define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, c->mlinfo.p + (size_t)(cls) * nrec, hcls[cls], c->unimems.p, \
+#define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, c->mlinfo.p + (size_t)(cls) * nrec, hcls[cls], c->unimems.p, c->uni_slots, \
       skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
   if (hcls[0]) { if (!getenv("SQ_MEMS_G16")) k_mems<8, 8, 256><<<(hcls[0] + 31) / 32, 256, 0, st>>>(SQ_MEMS_ARGS(0));   // [r3] the common end has <= 8 MEMs: eight ends per wave
                  else k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0)); }
@@ -485,7 +514,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     const size_t LP = (size_t)memsL + 8;
     if (c->mkey.ensure(LP) || c->mval.ensure(LP) || c->lkey.ensure(LP) || c->lval.ensure(LP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mused.ensure(MP)) {
       sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }
-    k_project_list<<<(nL + 3) / 4, 256, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, list_l, c->mlbase.p, nL, c->rlen.p, c->unimems.p,
+    k_project_list<<<(nL + 3) / 4, 256, 0, st>>>(di->dict, di->ctab_off, di->ctab, di->ref_accum, P, list_l, c->mlbase.p, nL, c->rlen.p, c->unimems.p, c->uni_slots,
         c->n_uni.p, c->mkey.p, c->mval.p);
     int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
     size_t tmp = 0;
@@ -552,7 +581,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
   S.ref_len = di->ref_len;
   S.rpack = c->rpack.p;
   S.rnmask = c->rnmask.p;
-  S.rlen = c->rlen.p;
+  S.rlen = c->rlen.p; S.rw = c->read_words;
   S.mkey = skey;
   S.mval = sval;
   S.mnext = c->mnext.p;
@@ -656,8 +685,8 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
   if (!ncases) return SQ_OK;
   if (!queries || !q_off || !windows || !w_off || !k || !out) { sq_set_error("sq_debug_infix_align: null argument"); return SQ_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { sq_set_error("sq_debug_infix_align: no device %d", device); return SQ_ERR_DEVICE; }
-  // host-side packing into the layouts the pipeline uses: read ends as SQ_READ_WORDS 2-bit words + N mask, text as one 2-bit pool
-  std::vector<uint64_t> rp((size_t)ncases * SQ_READ_WORDS, 0), rn((size_t)ncases * SQ_NMASK_WORDS, 0), toff(ncases + 1, 0);
+  // host-side packing into the layouts the pipeline uses: read ends as SQ_READ_WORDS_MIN 2-bit words + N mask, text as one 2-bit pool
+  std::vector<uint64_t> rp((size_t)ncases * SQ_READ_WORDS_MIN, 0), rn((size_t)ncases * (SQ_READ_WORDS_MIN / 2), 0), toff(ncases + 1, 0);
   std::vector<uint16_t> rl(ncases);
   auto code = [](uint8_t ch) -> int { switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } };
   for (uint32_t i = 0; i < ncases; ++i) {
@@ -669,8 +698,8 @@ extern "C" int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* 
     rl[i] = (uint16_t)n;
     for (uint64_t j = 0; j < n; ++j) {
       const int cd = code(queries[q_off[i] + j]);
-      if (cd > 3) rn[(size_t)i * SQ_NMASK_WORDS + (j >> 6)] |= 1ull << (j & 63);
-      else rp[(size_t)i * SQ_READ_WORDS + (j >> 5)] |= (uint64_t)cd << ((j & 31) * 2);
+      if (cd > 3) rn[(size_t)i * (SQ_READ_WORDS_MIN / 2) + (j >> 6)] |= 1ull << (j & 63);
+      else rp[(size_t)i * SQ_READ_WORDS_MIN + (j >> 5)] |= (uint64_t)cd << ((j & 31) * 2);
     }
     toff[i + 1] = toff[i] + (w_off[i + 1] - w_off[i]);
   }
@@ -726,14 +755,14 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
   if (nrec && hipMemcpy(moff.data(), c->mem_off.p, (size_t)(nrec + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
   const uint64_t* racc = c->idx->ref_accum.data();
   if (what == SQ_TAP_UNIMEMS) {
-    std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * SQ_MAX_UNIMEMS);
+    std::vector<uint32_t> nu(nrec); std::vector<sq_unimem_dev> um((size_t)nrec * c->uni_slots);
     if (hipMemcpy(nu.data(), c->n_uni.p, (size_t)nrec * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(um.data(), c->unimems.p,
         um.size() * sizeof(sq_unimem_dev),
         hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     uint64_t cnt = 0; sq_unimem* o = (sq_unimem*)buf;
     for (uint32_t e = 0; e < nrec; ++e) for (uint32_t i = 0; i < nu[e]; ++i) {
       if (o && cnt < cap) {
-        const sq_unimem_dev& m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
+        const sq_unimem_dev& m = um[(size_t)e * c->uni_slots + i];
         sq_unimem x;
         memset(&x, 0, sizeof(x));
         x.end = e;

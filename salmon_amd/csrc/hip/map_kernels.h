@@ -44,8 +44,8 @@ __device__ inline uint32_t norm_base(const ReadView& r, bool fw, int x) {  // st
   uint32_t b = rd_base(r, r.L - 1 - x);
   return b > 3 ? 4u : 3u - b;
 }
-__device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnmask, const uint16_t* rlen, uint32_t e) {
-  ReadView r; r.w = rpack + (size_t)e * SQ_READ_WORDS; r.nm = rnmask + (size_t)e * SQ_NMASK_WORDS; r.L = rlen[e]; return r;
+__device__ inline ReadView read_view(const uint64_t* rpack, const uint64_t* rnmask, const uint16_t* rlen, uint32_t e, uint32_t rw) {   // rw = the context's packing stride (words)
+  ReadView r; r.w = rpack + (size_t)e * rw; r.nm = rnmask + (size_t)e * (rw >> 1); r.L = rlen[e]; return r;
 }
 
 // [r2] One same-address atomic per WAVE is still too many when a launch has 10^5 waves: L2 retires them one per 4-12 ns, and 95 000
@@ -71,21 +71,23 @@ __device__ inline uint32_t wave_alloc(uint32_t* ctr) {
 // [r3] one thread per read end: its (up to) eight 32-base words are loaded with 16-byte loads that are all in flight together, packed
 // in registers and stored as 16-byte pairs.  (Round 2 used 8 threads per end, one word each: 128 M threads per 8 M pairs whose two
 // dependent round trips — offsets, then bases — set the pace at 2.2 ms; here a wave covers 64 ends and there are 8x fewer waves.)
+template <uint32_t RW>   // packing stride in words: 8 (reads of up to 256 bases, the default), 16, 32
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
                        uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, unsigned long long* __restrict__ stats) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrec) return;
   const uint64_t a = seq_off[e], b = seq_off[e + 1];
   uint32_t L = (uint32_t)(b - a);
-  if (L > SQ_MAX_READ_LEN) { L = SQ_MAX_READ_LEN; atomicAdd(&stats[ST_TRUNC], 1ULL); }   // rare by construction (RNA-seq reads are 50-250 bases)
+  // [r4] a read that does not fit the stride is reported, not cut: the host packs the batch again with a wider stride, or refuses it (> SQ_MAX_READ_LEN)
+  if (L > 32u * RW || L > SQ_MAX_READ_LEN) { atomicMax(&stats[ST_MAXLEN], (unsigned long long)(b - a)); atomicAdd(&stats[ST_TRUNC], 1ULL); L = 32u * RW < SQ_MAX_READ_LEN ? 32u * RW : SQ_MAX_READ_LEN; }
   const uint8_t* s = seq + a;
   struct __attribute__((packed, aligned(4))) Q4 { uint32_t v[4]; };
   // reads start at any byte (2x150: every other record is 2 mod 4): dwords are loaded from the aligned address below and funnel-shifted;
   // the dword past a full word is only touched when it lies inside the batch's buffer (not for the last record)
   const uint32_t mis = (uint32_t)(((uintptr_t)s) & 3); const uint8_t* s0 = s - mis; const bool wide = mis == 0 || e + 1 < nrec;
-  uint64_t cw[SQ_READ_WORDS]; uint32_t cn[SQ_READ_WORDS];
+  uint64_t cw[RW]; uint32_t cn[RW];
 #pragma unroll
-  for (uint32_t w = 0; w < SQ_READ_WORDS; ++w) {
+  for (uint32_t w = 0; w < RW; ++w) {
     cw[w] = 0; cn[w] = 0;
     const uint32_t lo = 32 * w; const uint32_t cnt = lo >= L ? 0 : (L - lo < 32 ? L - lo : 32);
     // branch-free base code: upper-case, then (x >> 1) & 3 maps A,C,T,G -> 0,1,2,3; x ^ (x >> 1) swaps the last two
@@ -108,12 +110,12 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, c
       for (uint32_t i = 0; i < cnt; ++i) put(i, s[lo + i]);
     }
   }
-  sq_u64x2* rp = (sq_u64x2*)(rpack + (size_t)e * SQ_READ_WORDS);
+  sq_u64x2* rp = (sq_u64x2*)(rpack + (size_t)e * RW);
 #pragma unroll
-  for (uint32_t w = 0; w < SQ_READ_WORDS; w += 2) { sq_u64x2 v; v.x = cw[w]; v.y = cw[w + 1]; rp[w / 2] = v; }
-  sq_u64x2* np = (sq_u64x2*)(rnmask + (size_t)e * SQ_NMASK_WORDS);
+  for (uint32_t w = 0; w < RW; w += 2) { sq_u64x2 v; v.x = cw[w]; v.y = cw[w + 1]; rp[w / 2] = v; }
+  sq_u64x2* np = (sq_u64x2*)(rnmask + (size_t)e * (RW / 2));
 #pragma unroll
-  for (uint32_t w = 0; w < SQ_NMASK_WORDS; w += 2) { sq_u64x2 v; v.x = (uint64_t)cn[2 * w] | ((uint64_t)cn[2 * w + 1] << 32); v.y = (uint64_t)cn[2 * w + 2] | ((uint64_t)cn[2 * w + 3] << 32); np[w / 2] = v; }
+  for (uint32_t w = 0; w < RW / 2; w += 2) { sq_u64x2 v; v.x = (uint64_t)cn[2 * w] | ((uint64_t)cn[2 * w + 1] << 32); v.y = (uint64_t)cn[2 * w + 2] | ((uint64_t)cn[2 * w + 3] << 32); np[w / 2] = v; }
   rlen[e] = (uint16_t)L;
 }
 
@@ -131,7 +133,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
                            unsigned long long* __restrict__ stats,
-                           uint32_t* __restrict__ cursor) {
+                           uint32_t* __restrict__ cursor, uint32_t rw, uint32_t us /* uni-MEM slots per end */) {
   const int k = KT ? KT : (int)P.k; const int alt = (int)P.alt_skip;
   const int lane = (int)(threadIdx.x & 63);
   uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false;
@@ -158,7 +160,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
       const uint32_t rank = (uint32_t)__popcll(want & ((1ULL << lane) - 1));
       if (!have && !drained && rank < take) {
         e = pool_next + rank; have = true;
-        r = read_view(rpack, rnmask, rlen, e); pos = 0; skip_until = -1; nu = 0; np = 0; out = um + (size_t)e * SQ_MAX_UNIMEMS;
+        r = read_view(rpack, rnmask, rlen, e, rw); pos = 0; skip_until = -1; nu = 0; np = 0; out = um + (size_t)e * us;
       }
       pool_next += take;
       want = __ballot(!have && !drained);
@@ -167,7 +169,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
     if (!__ballot(have)) break;
     if (have) {
       const int L = r.L; bool done = false;
-      if (!(L >= k && pos + k <= L && nu < SQ_MAX_UNIMEMS)) done = true;
+      if (!(L >= k && pos + k <= L && nu < us)) { done = true; if (nu >= us && L >= k && pos + k <= L) atomicAdd(&stats[ST_UNIOVER], 1ULL); }   // the walk is not over but the slots are: the host widens the slab and seeds the batch again
       else {
         // [r2] Most probes are misses that end at the membership filter, and where the walk goes after a miss does not depend on
         // memory: the next SEED_SPEC probe positions (N skips applied) are laid out first and their filter words requested
@@ -823,6 +825,7 @@ struct ScoreCtx {
   const uint64_t* rpack; const uint64_t* rnmask; const uint16_t* rlen;
   const uint64_t* mkey; const uint64_t* mval; const uint32_t* mnext;
   sq_dp_item* dpq; uint32_t* counters; uint32_t dpq_cap;
+  uint32_t rw;   // packing stride of rpack (words per read end)
 };
 
 // ---- a5 — recoverOrphans (SalmonQuantify.cpp:1356-1364) with the in-tree edlib infix aligner (src/edlib.cpp:290-372) ----
@@ -925,7 +928,7 @@ __global__ void k_infix_cases(uint32_t ncases, const uint64_t* __restrict__ rpac
                                   int32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ncases) return;
-  const ReadView r = read_view(rpack, rnmask, rlen, i);
+  const ReadView r = read_view(rpack, rnmask, rlen, i, SQ_READ_WORDS_MIN);   // the tap's queries are packed with the default stride (map.hip)
   int st = -1, en = -1, ed = -1;
   bool ok = false;
   const int wl = (int)(toff[i + 1] - toff[i]);
@@ -959,7 +962,7 @@ __global__ void k_recover(sq_map_params P, ScoreCtx S, uint32_t nfrag, const uin
         const uint32_t ai = left ? C[i].lc : C[i].rc;
         const sq_chain_dev an = chains[ai];
         const uint32_t me = 2 * f + (left ? 1u : 0u);
-        const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, me);
+        const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, me, S.rw);
         const int ML = r.L;
         if (ML == 0) continue;
         const int Tlen = (int)S.ref_len[an.tid];
@@ -1073,7 +1076,7 @@ __device__ inline void dp_enqueue(const ScoreCtx& S, const DpStage& Q, uint32_t 
 #define SC_PEND 2
 __device__ inline int32_t score_chain(const sq_map_params& P, const ScoreCtx& S, const DpStage& Q, const ChainHead& ch, int Tlen, int64_t g, uint64_t mem_base,
     uint32_t end_id, uint32_t cand, uint8_t end, uint32_t* ndp, uint8_t* fail) {
-  const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  const ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id, S.rw);
   const int L = r.L; const bool fw = ch.fw != 0; const uint32_t nm = ch.n_mems;
   const int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * L));
   const bool by_mask = ch.by_mask != 0;
@@ -1297,7 +1300,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const sq_dp_item it = S.dpq[perm[ii]];   // regions in the order of k_dp_scatter: the 64 lanes of a wave run about the same number of rows
   const uint32_t f = cand_frag[it.cand];
   const uint32_t end_id = paired ? 2 * f + it.end : f;
-  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id, S.rw);
   const bool fw = it.rc == 0;
   const int n = it.n, tl = it.tl, w = P.bw, go = P.go, ge = P.ge;
   constexpr int W = SQ_MAX_BAND, BW = 2 * SQ_MAX_BAND + 1;
@@ -1378,7 +1381,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const sq_dp_item it = S.dpq[perm[ii]];
   const uint32_t f = cand_frag[it.cand];
   const uint32_t end_id = paired ? 2 * f + it.end : f;
-  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id);
+  ReadView r = read_view(S.rpack, S.rnmask, S.rlen, end_id, S.rw);
   const bool fw = it.rc == 0;
   const int n = it.n, tl = it.tl, go = P.go, ge = P.ge;
   constexpr int W = SQ_MAX_BAND, BW = 2 * SQ_MAX_BAND + 1;

@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
   const uint32_t n = e < nends ? n_proj[e] : 0;
-  const int cls = (e >= nends || n == 0) ? -1 : mk_class(n);
+  // [r4] an end with more uni-MEMs than a size class keeps headers for (rare: a read across many short unitigs) takes the large-end path, whatever its MEM count
+  const int cls = (e >= nends || n == 0) ? -1 : (n_uni[e] > SQ_MAX_UNIMEMS ? MK_NCLS - 1 : mk_class(n));
   if (e < nends && n == 0) n_chains[e] = 0;
   unsigned long long m[MK_NCLS];
 #pragma unroll
@@ -72,7 +73,7 @@ template <int G, int CAP, int TBK>
 __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab,
                                               const uint64_t* __restrict__ ref_accum, sq_map_params P, const double* __restrict__ gapcost,
                                               const uint4* __restrict__ list, uint32_t nlist,
-                                              const sq_unimem_dev* __restrict__ um,
+                                              const sq_unimem_dev* __restrict__ um, uint32_t us /* uni-MEM slots per end in `um` */,
                                               uint64_t* __restrict__ mkey, uint64_t* __restrict__ mval, uint32_t* __restrict__ mnext,
                                               sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains) {
   constexpr int GPB = TBK / G, E = CAP / G;
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
   { uint32_t kept = 0;
     for (uint32_t i0 = 0; i0 < nu; i0 += G) {   // the lanes of a group run this loop together: the ballot below sees all of them
       const uint32_t i = i0 + (uint32_t)gl; const bool in = i < nu;
-      sq_unimem_dev m{}; if (in) m = um[(size_t)e * SQ_MAX_UNIMEMS + i];
+      sq_unimem_dev m{}; if (in) m = um[(size_t)e * us + i];
       const bool has = in && m.cnt != 0;
       const unsigned long long bm = __ballot(has);
       const uint32_t gm = (G == 64) ? 0u : (uint32_t)((bm >> gsh) & ((1ull << (G & 63)) - 1));
@@ -298,13 +299,13 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
 // ---- the rare large ends (more than MK_M_CAP MEMs): projection into a compact buffer, library radix sort, scatter back ----
 __global__ void k_project_list(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab, const uint64_t* __restrict__ ref_accum,
                                sq_map_params P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ lbase, uint32_t nlist,
-                               const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um, const uint32_t* __restrict__ n_uni,
+                               const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um, uint32_t us, const uint32_t* __restrict__ n_uni,
                                uint64_t* __restrict__ ckey, uint64_t* __restrict__ cval) {
   // one wave per end, a lane per occurrence of the current uni-MEM (runs of up to maxOccsPerHit = 1000 entries)
   const uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; const uint32_t lane = threadIdx.x & 63;
   if (wi >= nlist) return;
   const uint32_t e = list[wi]; uint64_t w = lbase[wi]; const int L = rlen[e];
-  const sq_unimem_dev* in = um + (size_t)e * SQ_MAX_UNIMEMS;
+  const sq_unimem_dev* in = um + (size_t)e * us;
   for (uint32_t i = 0; i < n_uni[e]; ++i) {
     const sq_unimem_dev m = in[i];
     const uint64_t a = ctab_off[m.unitig], b = ctab_off[m.unitig + 1];

@@ -1386,6 +1386,9 @@ int sq_eq_sync(sq_ctx* c) {
     fprintf(stderr, "[sq-timing] eq_sync %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
     tm0 = t1;
   };
+  // the sleeping wave between export and optimiser (ctx.h) sits on an eq stream: the export that started it has drained the stage, and mapping a
+  // new batch stops it — while it runs there is nothing to wait for
+  if (c->warm_running) { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_enqueued >= c->eq_submitted && !c->eq_err) return SQ_OK; }
   { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= c->eq_submitted; }); }
   mark("worker");
   SQ_HIP_CHECK(hipSetDevice(c->device));
@@ -1853,10 +1856,11 @@ __global__ void k_keep_warm(volatile int* stop, long long max_ticks) {
 void sq_ctx::warm_start() {
   static const int on = getenv("SQ_KEEP_WARM") ? atoi(getenv("SQ_KEEP_WARM")) : 1;
   if (!on || warm_running) return;
-  if (!warm_flag) { if (hipHostMalloc((void**)&warm_flag, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); warm_flag = nullptr; return; }
-    if (hipStreamCreateWithFlags(&stream_warm, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(warm_flag); warm_flag = nullptr; return; } }
+  if (!warm_flag) { if (hipHostMalloc((void**)&warm_flag, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); warm_flag = nullptr; return; } }
   *warm_flag = 0; __sync_synchronize();
-  k_keep_warm<<<1, 64, 0, stream_warm>>>(warm_flag, 100000LL * 40);   // at most 40 ms
+  // on the stream the optimiser will use (a stream of its own was measured to share a hardware queue with it: the optimiser's first copy then
+  // waited for the wave's time-out, 22.8 ms instead of 5); the optimiser stops the wave before it queues anything.  At most 12 ms.
+  k_keep_warm<<<1, 64, 0, stream3 ? stream3 : stream2>>>(warm_flag, 100000LL * 12);
   warm_running = true;
 }
 void sq_ctx::warm_stop() {
@@ -1988,9 +1992,9 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
   if (eq) return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
+  c->warm_stop();   // the sleeping wave in front of the optimiser's work (ctx.h) leaves its stream
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  struct WarmOff { sq_ctx* c; ~WarmOff() { c->warm_stop(); } } warm_off{c};   // once the optimiser's own work is queued the sleeping wave may go
   return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
 }
 
