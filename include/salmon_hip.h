@@ -243,6 +243,26 @@ int sq_map_wait(sq_ctx*, sq_aln_batch* out /* may be NULL */, sq_map_stats* stat
  * buffers until the lane maps again).  out->read_off == out->aln == NULL: only out->n and out->aln_cap (= alignments
  * held) are filled — the size query the SAM writer makes before it sizes its arrays. */
 int sq_map_fetch(sq_ctx*, sq_aln_batch* out);   /* out->map_type alone (read_off == aln == NULL): only the per-fragment mapping types */
+/* [r4] alignment-based mode (`salmon quant -a`, src/alignment/SalmonQuantifyAlignments.cpp:125-937): a batch of alignments that came from a SAM file
+ * (sq_sam_* below) takes the place of a mapped batch — in->n fragments, in->read_off[n + 1] a prefix sum into in->aln — and sq_eq_accumulate
+ * runs the same online model / equivalence-class stage on it.  num_with_joint_hits = fragments with at least one alignment record. */
+int sq_aln_inject(sq_ctx* ctx, const sq_aln_batch* in, uint64_t num_with_joint_hits);
+/* The record source of alignment-based mode: a name-collated SAM text file (plain or gzip; BAM is refused — no htslib here), read as the reference's
+ * BAMQueue reads it (include/salmon/internal/alignment/BAMQueue.tpp:288-600): proper pairs on one target -> pair alignments, a mapped read whose mate
+ * is not -> an orphan, consecutive alignments of one read name -> one fragment ordered by transcript.  paired_library: 1 = ReadPair rules, 0 = every
+ * mapped record is a single-end alignment.  sq_sam_set_tid_map: SAM target i -> transcript id of the index (0xFFFFFFFF: skip its alignments); the
+ * default is the identity.  sq_sam_next: up to max_frags fragments into arrays the reader owns (valid until the next call); out->n == 0 at the end.
+ * use_as_scores: est_aln_prob = exp(-score_exp (bestAS - AS)) within a fragment (--useASWithoutCIGAR, SalmonQuantifyAlignments.cpp:516-521), else 1
+ * (--noErrorModel).  The CIGAR-based error model of alignment mode (AlignmentModel.hpp) is not built. */
+typedef struct sq_sam sq_sam;
+typedef struct { uint64_t num_records, num_fragments, num_alignments, num_unaligned, num_suspicious_pairs, num_skipped_unknown_target, num_frags_without_as; } sq_sam_counts;
+int sq_sam_open(const char* path, int paired_library, sq_sam** out);
+uint32_t sq_sam_num_refs(const sq_sam*);
+const char* sq_sam_ref_name(const sq_sam*, uint32_t i);
+uint32_t sq_sam_ref_len(const sq_sam*, uint32_t i);
+int sq_sam_set_tid_map(sq_sam*, const uint32_t* map, uint32_t n);
+int sq_sam_next(sq_sam*, uint32_t max_frags, int use_as_scores, double score_exp, sq_aln_batch* out, sq_sam_counts* counts);
+void sq_sam_close(sq_sam*);
 
 /* ------------------------------------------------------------------------------------------------
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +

@@ -131,6 +131,10 @@ REPLICATE_CB = C.CFUNCTYPE(C.c_int, P(f64), u32, C.c_void_p)
 _lib = None
 
 
+class SamCounts(C.Structure):   # sq_sam_counts
+    _fields_ = [(n, C.c_uint64) for n in ("num_records", "num_fragments", "num_alignments", "num_unaligned", "num_suspicious_pairs", "num_skipped_unknown_target", "num_frags_without_as")]
+
+
 class MetaInfo(C.Structure):   # sq_meta_info
     _fields_ = [("salmon_version", C.c_char_p), ("samp_type", C.c_char_p), ("opt_type", C.c_char_p), ("quant_errors", C.c_char_p),
                 ("num_libraries", C.c_uint32), ("frag_dist_length", C.c_uint32), ("library_types", C.POINTER(C.c_char_p)),
@@ -223,7 +227,9 @@ def lib():
         "sq_eq_file_eff_lens": (P(f64), [vp]), "sq_eq_file_table": (C.c_int, [vp, P(EqTable)]),
         "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64),
             u32]), "sq_boot_writer_close": (u64, [vp]),
-        "sq_bias_last_gc_expected": (C.c_int, [vp]),
+        "sq_bias_last_gc_expected": (C.c_int, [vp]), "sq_aln_inject": (C.c_int, [vp, P(AlnBatch), u64]),
+        "sq_sam_open": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_sam_num_refs": (u32, [vp]), "sq_sam_ref_name": (C.c_char_p, [vp, u32]), "sq_sam_ref_len": (u32, [vp, u32]),
+        "sq_sam_set_tid_map": (C.c_int, [vp, vp, u32]), "sq_sam_next": (C.c_int, [vp, u32, C.c_int, f64, P(AlnBatch), P(SamCounts)]), "sq_sam_close": (None, [vp]),
         "sq_index_hash": (C.c_char_p, [vp, C.c_int]), "sq_index_keeps_duplicates": (C.c_int, [vp]), "sq_model_fld_min": (C.c_int, [vp, P(u32)]),
         "sq_write_fld_samples": (C.c_int, [C.c_char_p, vp, u32, u32, u32, u64, P(f64), P(f64), P(u32)]), "sq_write_legacy_bias": (C.c_int, [C.c_char_p, P(u32)]),
         "sq_write_gc_model": (C.c_int, [C.c_char_p, C.c_int32, u32, u32, vp, vp]), "sq_write_seq_model": (C.c_int, [C.c_char_p, vp]),

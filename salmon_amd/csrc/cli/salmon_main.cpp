@@ -312,29 +312,44 @@ static int cmd_quant(int argc, char** argv) {
   const char* r2 = arg(argc, argv, "-2", "--mates2");
   const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
-  if (!idir || !odir || (!ru && !(r1 && r2))) {
+  // [r4] alignment-based mode: `quant -t transcripts.fa -l LIB -a alignments.sam -o out` (SalmonQuantifyAlignments.cpp; the records come from a SAM file, not the mapper)
+  const char* alnf = arg(argc, argv, "-a", "--alignments"); const char* targets = arg(argc, argv, "-t", "--targets");
+  if (alnf && (!targets || !odir)) { fprintf(stderr, "usage: salmon-hip quant -t transcripts.fa -l IU -a alignments.sam[.gz] -o out_dir --noErrorModel|--useASWithoutCIGAR\n"); return 1; }
+  if (!alnf && (!idir || !odir || (!ru && !(r1 && r2)))) {
     fprintf(stderr,
         "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
     return 1;
   }
-  check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "--device", "--batch", "--lanes", "--gpus", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
+  check_args(argc, argv, {"-i", "--index", "-o", "--output", "-l", "--libType", "-a", "--alignments", "-t", "--targets", "--device", "--batch", "--lanes", "--gpus", "-p", "--threads", "--minScoreFraction", "--consensusSlack",
                           "--rangeFactorizationBins", "--mismatchSeedSkip", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor",
                           "--incompatPrior", "--maxOccsPerHit", "--maxReadOcc", "--fldMax", "--fldMean", "--fldSD", "--forgettingFactor", "--numPreAuxModelSamples",
                           "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth",
                           "--minAssignedFrags", "--sigDigits", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames", "--noErrorModel", "--useASWithoutCIGAR"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
   const bool autodetect = lib == "A";
-  if (autodetect) lib = ru ? "U" : "IU";   // enableAutodetect(): the library starts unstranded / inward (LibraryTypeUtils.cpp:110-146)
+  bool aln_paired = true;
+  if (alnf) {
+    if (!flag(argc, argv, "--noErrorModel") && !flag(argc, argv, "--useASWithoutCIGAR")) {
+      fprintf(stderr, "[salmon-hip] alignment-based mode: the CIGAR-based error model (the reference's default there) is not built; pass --noErrorModel (every alignment of a fragment weighs the same) "
+                      "or --useASWithoutCIGAR (weights from the AS tags)\n"); return 1; }
+    if (flag(argc, argv, "--gcBias") || flag(argc, argv, "--seqBias") || flag(argc, argv, "--posBias") || flag(argc, argv, "--writeMappings") || flag(argc, argv, "--writeUnmappedNames") || world > 1) {
+      fprintf(stderr, "[salmon-hip] alignment-based mode runs on one GPU without bias correction, --writeMappings and --writeUnmappedNames\n"); return 1; }
+    // the library's read type decides how records are grouped; with -l A the first record's PAIRED flag says which (the reference peeks at the file too)
+    if (autodetect) { gzFile g = gzopen(alnf, "rb"); if (!g) { fprintf(stderr, "[salmon-hip] cannot open %s\n", alnf); return 1; } char lb[1 << 16]; aln_paired = true;
+      while (gzgets(g, lb, sizeof(lb))) { if (lb[0] == '@') continue; const char* t1 = strchr(lb, '\t'); if (t1) aln_paired = (atoi(t1 + 1) & 1) != 0; break; } gzclose(g); }
+  }
+  if (autodetect) lib = alnf ? (aln_paired ? "IU" : "U") : (ru ? "U" : "IU");   // enableAutodetect(): the library starts unstranded / inward (LibraryTypeUtils.cpp:110-146)
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
   const char* v;
   int device = ((v = arg(argc, argv, "--device")) ? atoi(v) : 0) + (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0);
   uint32_t B = (v = arg(argc, argv, "--batch")) ? (uint32_t)atoi(v) : 1000000u;
-  const bool paired = !ru;
+  if (alnf && !autodetect) aln_paired = kLib.count(lib) ? kLib.at(lib)[0] == 1 : true;
+  const bool paired = alnf ? aln_paired : !ru;
   // multi-GPU (SPEC MG): the RCCL id travels through a file in the output directory (rank 0 writes it, the others wait for it)
   sq_dist* dist = nullptr;
   if (world > 1) {
@@ -355,7 +370,15 @@ static int cmd_quant(int argc, char** argv) {
     if (rank == 0) remove(idf.c_str());
   }
   auto t0 = std::chrono::steady_clock::now(); const std::string start_time = now_string();
-  sq_index* idx = nullptr; if (sq_index_load(idir, device, &idx)) die("loading index");
+  sq_index* idx = nullptr;
+  if (alnf) {   // the targets come from the FASTA; every record keeps its identity (no duplicate removal, no clipping) so that the SAM header's targets are the index's
+    sq_index_opts io{}; io.k = 31; io.keep_duplicates = 1; io.no_clip_polya = 1; io.threads = (v = arg(argc, argv, "-p", "--threads")) ? (uint32_t)atoi(v) : 8;
+    mkdir(odir, 0755); const std::string tdir = std::string(odir) + "/.targets_index";
+    if (sq_index_build(&io, targets, nullptr, tdir.c_str())) die("indexing the targets");
+    if (sq_index_load(tdir.c_str(), device, &idx)) die("loading the targets");
+    for (const char* fn : {"index.bin", "info.json", "versionInfo.json", "duplicate_clusters.tsv"}) remove((tdir + "/" + fn).c_str());
+    rmdir(tdir.c_str());
+  } else if (sq_index_load(idir, device, &idx)) die("loading index");
   sq_quant_opts qo;
   sq_quant_opts_default(&qo);
   qo.lib_type = li->second[0];
@@ -412,6 +435,29 @@ static int cmd_quant(int argc, char** argv) {
   g_aux_name = aux_name;
   sq_ctx* ctx = nullptr; if (sq_ctx_create(idx, &qo, device, B, &ctx)) die("creating context");
   if (sq_ctx_reserve(ctx, 0, 0)) die("reserving end-of-job buffers");   // the reference pre-sizes its eq-class map the same way (EquivalenceClassBuilder.hpp:140)
+  sq_map_stats tot{}; uint64_t nfrag = 0;
+  if (alnf) {   // [r4] alignment-based mode: fragments of alignments from the SAM file take the place of mapped batches
+    sq_sam* sam_in = nullptr; if (sq_sam_open(alnf, paired ? 1 : 0, &sam_in)) die("opening alignments");
+    { // the SAM header's targets by name -> transcript ids of the index
+      std::map<std::string, uint32_t> by; for (uint32_t i = 0; i < sq_index_num_refs(idx); ++i) by[sq_index_ref_name(idx, i)] = i;
+      const uint32_t ns = sq_sam_num_refs(sam_in); std::vector<uint32_t> tm(ns, 0xFFFFFFFFu); uint32_t known = 0;
+      for (uint32_t i = 0; i < ns; ++i) { auto it = by.find(sq_sam_ref_name(sam_in, i)); if (it != by.end()) { tm[i] = it->second; ++known; } }
+      if (!known) { fprintf(stderr, "[salmon-hip] none of the %u targets of %s is in %s\n", ns, alnf, targets); return 1; }
+      if (known < ns) fprintf(stderr, "[salmon-hip] warning: %u of the %u targets in the alignment file's header are not in %s; alignments to them are skipped\n", ns - known, ns, targets);
+      if (sq_sam_set_tid_map(sam_in, tm.data(), ns)) die("target map"); }
+    const int use_as = flag(argc, argv, "--useASWithoutCIGAR") ? 1 : 0; sq_sam_counts sc{};
+    for (;;) {
+      sq_aln_batch ab{}; if (sq_sam_next(sam_in, B, use_as, qo.score_exp, &ab, &sc)) die("reading alignments");
+      if (ab.n == 0) break;
+      if (sq_aln_inject(ctx, &ab, ab.n) || sq_eq_accumulate(ctx)) die("alignment batch");
+      tot.num_reads += ab.n; tot.num_with_joint_hits += ab.n; tot.num_mapped += ab.n; tot.num_alignments += ab.read_off[ab.n];
+      if (!quiet) fprintf(stderr, "\r[salmon-hip] processed %llu aligned fragments", (unsigned long long)tot.num_reads);
+    }
+    sq_sam_close(sam_in);
+    nfrag = sc.num_fragments + sc.num_unaligned; tot.num_reads = nfrag;
+    if (!quiet) fprintf(stderr, "\n[salmon-hip] %llu records, %llu fragments with alignments (%llu alignments), %llu unaligned%s\n", (unsigned long long)sc.num_records, (unsigned long long)sc.num_fragments,
+        (unsigned long long)sc.num_alignments, (unsigned long long)sc.num_unaligned, (use_as && sc.num_frags_without_as) ? "; some fragments carry no AS tags and were weighted uniformly" : "");
+  } else {
   // host read pipeline (sq_reader: one inflate+parse thread per mate stream, rotating page-locked batch buffers) feeding
   // the mapping lanes: up to `lanes` batches are in flight (H2D + mapping) while the next one is parsed
   std::vector<std::string> l1 = paired ? file_args(argc, argv, "-1", "--mates1") : file_args(argc, argv, "-r", "--unmatedReads");
@@ -440,7 +486,7 @@ static int cmd_quant(int argc, char** argv) {
   }
   if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 1, (sam_path || unm) ? SQ_READER_KEEP_NAMES : 0,
       &rd)) die("opening reads");
-  sq_map_stats tot{}; uint64_t nfrag = 0; std::vector<int> inflight; std::vector<sq_read_batch> inflight_in;
+  std::vector<int> inflight; std::vector<sq_read_batch> inflight_in;
   std::vector<uint64_t> sam_off; std::vector<sq_aln> sam_aln;
   auto finish_one = [&]() {
     sq_map_stats st{};
@@ -481,6 +527,7 @@ static int cmd_quant(int argc, char** argv) {
   if (unm) fclose(unm);
   sq_reader_close(rd);
   if (!quiet) fprintf(stderr, "\n");
+  }
   if (dist) {   // ONE exchange of the class tables, counters summed
     if (sq_dist_merge_eq(dist, ctx)) die("eq-class exchange");
     if (sq_dist_allreduce_u64(dist, (uint64_t*)&tot, sizeof(tot) / 8) || sq_dist_allreduce_u64(dist, &nfrag, 1)) die("counter all-reduce");
@@ -551,7 +598,7 @@ static int cmd_quant(int argc, char** argv) {
   if (rank != 0) { sq_dist_free(dist); sq_ctx_free(ctx); sq_index_free(idx); return 0; }   // every rank computed the same result; rank 0 writes it
   if (sq_write_quant_sf_digits((od + "/quant.sf").c_str(), idx, eff.data(), alphas.data(), (double)tot.num_with_joint_hits, sig_digits)) die("quant.sf");
   if (sq_write_ambig_info((od + "/" + g_aux_name + "/ambig_info.tsv").c_str(), M, &t)) die("ambig_info");
-  { const std::string rf = paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
+  { const std::string rf = alnf ? ("[ " + std::string(alnf) + "]") : paired ? ("[ " + std::string(r1) + ", " + std::string(r2) + "]") : ("[ " + std::string(ru) + "]");
     const uint8_t dt = (uint8_t)(ms.lib_format_id & 1), dor = (uint8_t)((ms.lib_format_id >> 1) & 3), dst = (uint8_t)(ms.lib_format_id >> 3);   // the detected format with -l A
     for (auto& kv : kLib) if (kv.second[0] == dt && kv.second[1] == dor && kv.second[2] == dst) lib = kv.first;
     if (autodetect) fprintf(stderr, "[salmon-hip] Automatically detected most likely library type as %s%s\n", lib.c_str(), ms.lib_detected ? "" : " (fewer than 50000 samples: the starting format was kept)");
@@ -594,7 +641,7 @@ static int cmd_quant(int argc, char** argv) {
     mi.quant_errors = short_of_frags ? "insufficient_assigned_fragments" : nullptr;      // SalmonQuantify.cpp:2909-2925
     mi.num_libraries = 1; mi.library_types = libs; mi.frag_dist_length = fl_support; mi.frag_length_mean = fl_mean; mi.frag_length_sd = fl_sd;
     mi.seq_bias_correct = seq_bias; mi.gc_bias_correct = gc_bias; mi.pos_bias_correct = pos_bias; mi.num_bias_bins = num_bias_bins;
-    mi.mapping_type = "mapping"; mi.keep_duplicates = sq_index_keeps_duplicates(idx);
+    mi.mapping_type = alnf ? "alignment" : "mapping"; mi.keep_duplicates = sq_index_keeps_duplicates(idx);
     mi.serialized_eq_classes = dump_eq; mi.range_factorized = qo.range_factorization_bins > 0; mi.scalar_weights = flag(argc, argv, "--dumpEqWeights");
     mi.num_valid_targets = M; mi.num_decoy_targets = Mall - M; mi.num_eq_classes = t.num_classes;
     mi.num_length_classes = nlq > 0 ? (uint32_t)nlq : 0; mi.length_classes = lq;
@@ -607,7 +654,7 @@ static int cmd_quant(int argc, char** argv) {
     if (sq_write_meta_info((aux + "/meta_info.json").c_str(), &mi)) die("meta_info"); }
   FILE* cf = fopen((od + "/cmd_info.json").c_str(), "w");
   if (cf) {
-    fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", idir,
+    fprintf(cf, "{\n  \"salmon_version\": \"1.11.4\",\n  \"index\": \"%s\",\n  \"libType\": \"%s\",\n  \"output\": \"%s\"\n}\n", alnf ? targets : idir,
         lib.c_str(), odir);
     fclose(cf);
   }

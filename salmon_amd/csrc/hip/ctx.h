@@ -139,7 +139,7 @@ struct sq_ctx {
   // [r4] Between the export (sq_eq_finish) and the optimiser (sq_em_optimize) the host works for a few ms (normalizeAlphas) and the device would sit
   // idle; the first submission after such a gap behind heavy load was measured to come back ~20 ms late on MI355X (SQ_TIMING: "upload drained"
   // 20.2 ms for a 1.3 MB copy).  One wave that sleeps on a page-locked flag (k_keep_warm, at most `warm_ms`) keeps the device out of that state;
-  // the next entry point that uses the device stops it.  SQ_KEEP_WARM=0 switches it off.
+  // the next entry point that uses the device stops it.  Measured: no reliable effect (online.hip) — an experiment, SQ_KEEP_WARM=1 switches it on.
   int* warm_flag = nullptr; bool warm_running = false;
   void warm_start(); void warm_stop();
   // [r3, experimental: SQ_EQ_CHAIN=1] no partition: mapping and the eq stage's throughput kernels share all CUs, and the mass-dependent chain of a

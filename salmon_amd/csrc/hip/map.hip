@@ -305,6 +305,36 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
   return rc;
 }
 
+// [r4] alignment-based mode (`salmon quant -a`, src/alignment/SalmonQuantifyAlignments.cpp:125-937): the alignments come from a SAM file instead of the
+// mapping kernels.  A batch of them is put where sq_map_batch would have left its own — the lane's alignment buffer, offsets by fragment —
+// and sq_eq_accumulate then runs the same online model / equivalence-class stage on it.
+extern "C" int sq_aln_inject(sq_ctx* c, const sq_aln_batch* in, uint64_t num_with_joint_hits) {
+  if (!c || c->owner || !in || !in->read_off || (!in->aln && in->n && in->read_off[in->n])) { sq_set_error("sq_aln_inject: bad arguments"); return SQ_ERR_ARG; }
+  if (!c->tickets.empty()) { sq_set_error("sq_aln_inject: submitted batches are still outstanding"); return SQ_ERR_STATE; }
+  const uint32_t n = in->n; if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
+  c->warm_stop();
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = c->stream; const int buf = c->cur_buf;
+  const uint64_t total = n ? in->read_off[n] : 0; const uint32_t M = (uint32_t)c->idx->names.size();
+  for (uint32_t f = 0; f < n; ++f) if (in->read_off[f] > in->read_off[f + 1] || in->read_off[f + 1] > total) { sq_set_error("sq_aln_inject: read_off is not a prefix sum"); return SQ_ERR_ARG; }
+  for (uint64_t a = 0; a < total; ++a) if (in->aln[a].tid >= M) { sq_set_error("sq_aln_inject: alignment %llu names transcript %u of %u", (unsigned long long)a, in->aln[a].tid, M); return SQ_ERR_ARG; }
+  const size_t CP = (size_t)total + 8;
+  if (c->eq_pending[buf]) {   // the eq stage that read this buffer two batches ago (as in sq_map_batch)
+    sq_eq_wait_enqueued(c, c->eq_job_of_buf[buf]);
+    if ((buf ? c->aln_b1.n : c->aln.n) < CP) SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf]));
+    SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
+  }
+  if ((buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP))) { sq_set_error("device allocation failed (injected alignments)"); return SQ_ERR_NOMEM; }
+  SQ_HIP_CHECK(hipMemcpyAsync(c->aln_off_ptr(buf), in->read_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  if (total) SQ_HIP_CHECK(hipMemcpyAsync(c->aln_ptr(buf), in->aln, (size_t)total * sizeof(sq_aln), hipMemcpyHostToDevice, st));
+  SQ_HIP_CHECK(hipEventRecord(c->ev_map_done[buf], st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));          // the caller's arrays may go
+  c->last_n = n; c->last_paired = 1; c->last_total_aln = total; c->last_joint = num_with_joint_hits; c->have_batch = true; c->last_buf = buf; c->cur_buf = buf ^ 1;
+  c->last_src = c; c->api_have = true;
+  c->acc_n = n; c->acc_buf = buf; c->acc_total_aln = total; c->acc_joint = num_with_joint_hits;
+  return SQ_OK;
+}
+
 // ---- lanes: asynchronous submit / in-order wait ---------------------------------------------------
 static void lane_worker(sq_ctx* c) {
   (void)hipSetDevice(c->device);

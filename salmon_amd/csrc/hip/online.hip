@@ -1854,7 +1854,7 @@ __global__ void k_keep_warm(volatile int* stop, long long max_ticks) {
   while (!*stop && (long long)wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
 }
 void sq_ctx::warm_start() {
-  static const int on = getenv("SQ_KEEP_WARM") ? atoi(getenv("SQ_KEEP_WARM")) : 1;
+  static const int on = getenv("SQ_KEEP_WARM") ? atoi(getenv("SQ_KEEP_WARM")) : 0;   // measured: 10 / 20 ms with it, 22 / 19 ms without (two runs each): not the cause of the stall; off by default
   if (!on || warm_running) return;
   if (!warm_flag) { if (hipHostMalloc((void**)&warm_flag, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); warm_flag = nullptr; return; } }
   *warm_flag = 0; __sync_synchronize();

@@ -1,0 +1,186 @@
+// host/sam_reader.cpp — [r4] the record source of alignment-based mode (`salmon quant -a`): a name-collated SAM text file (plain or gzip) read
+// into the alignment records the online stage consumes (sq_aln), fragment by fragment.  Follows the reference's BAMQueue
+// (include/salmon/internal/alignment/BAMQueue.tpp:288-343 getPairedAlignmentType_, :355-545 getFrag_(ReadPair), :548-600 getFrag_(UnpairedRead)),
+// ReadPair / UnpairedRead (ReadPair.hpp:61-200: pos, fwd, fragLen, getAS, mateStatus) and salmon::utils::hitType (SalmonUtils.cpp:531-652); the
+// reference reads BAM/SAM through htslib (staden io_lib), which is not available here — a SAM text parser takes its place, BAM input is refused.
+//   paired library: a record whose read and mate are mapped, flagged proper pair, on the same target -> a pair together with the NEXT record;
+//     read mapped, mate not (or not a proper pair, or another target) -> an orphan alignment (left if FREAD1 else right);
+//     read unmapped -> skipped; both unmapped -> an unaligned fragment (counted).
+//   consecutive alignments with the same read name are one fragment; its alignments are ordered by transcript (AlignmentGroup::sortHits).
+// The error model of alignment mode (AlignmentModel.hpp, learned from CIGAR strings) is NOT built: the conditional probability of an alignment is
+// either 1 (`--noErrorModel`) or exp(-scoreExp (bestAS - AS)) from the AS tags (`--useASWithoutCIGAR`, SalmonQuantifyAlignments.cpp:516-521).
+#include "index.h"
+#include <zlib.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+
+namespace {
+enum { F_PAIRED = 1, F_PROPER = 2, F_UNMAP = 4, F_MUNMAP = 8, F_REVERSE = 16, F_READ1 = 64, F_READ2 = 128 };
+struct Rec { std::string name; int flag = 0; int32_t ref = -1, mref = -1, pos = 0; uint32_t len = 0; int32_t as = 0; bool has_as = false; };
+inline uint8_t fmt_id(uint8_t t, uint8_t o, uint8_t s) { return (uint8_t)(t | (o << 1) | (s << 3)); }
+// hitType(end1Start, end1Fwd, end2Start, end2Fwd) — SalmonUtils.cpp:531-575 (the four-argument form: no dovetail stretch)
+inline uint8_t hit_type_pair(int32_t s1, bool f1, int32_t s2, bool f2) {
+  if (f1 != f2) { if (f1) return s1 <= s2 ? fmt_id(1, 2, 0) : fmt_id(1, 1, 0); return s2 <= s1 ? fmt_id(1, 2, 1) : fmt_id(1, 1, 1); }
+  return f1 ? fmt_id(1, 0, 2) : fmt_id(1, 0, 3);
+}
+inline uint8_t hit_type_single(bool fwd) { return fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3); }   // :638-646
+}  // namespace
+
+struct sq_sam {
+  gzFile f = nullptr; std::string path; bool paired = true;
+  std::vector<std::string> names; std::vector<uint32_t> lens; std::unordered_map<std::string, int32_t> by_name;
+  std::vector<uint32_t> tid_map;
+  std::vector<char> buf; size_t bpos = 0, bend = 0; bool eof = false;
+  std::string line; bool have_pending_line = false;
+  // the alignment that opened the next fragment (read ahead)
+  bool have_next = false; sq_aln next_aln{}; std::string next_name; int32_t next_as = 0; bool next_has_as = false;
+  sq_sam_counts cnt{};
+  // output arrays of the current batch
+  std::vector<uint64_t> off; std::vector<sq_aln> alns; std::vector<int32_t> as_of; std::vector<uint8_t> has_as_of;
+  bool getline(std::string& out) {
+    out.clear();
+    for (;;) {
+      if (bpos == bend) { if (eof) return !out.empty(); const int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return !out.empty(); } bpos = 0; bend = (size_t)n; }
+      const char* s = buf.data() + bpos; const char* e = (const char*)memchr(s, '\n', bend - bpos);
+      if (e) { out.append(s, e - s); bpos = (size_t)(e - buf.data()) + 1; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+      out.append(s, bend - bpos); bpos = bend;
+    }
+  }
+  bool next_record(Rec& r, std::string& err) {
+    while (getline(line)) {
+      if (line.empty() || line[0] == '@') continue;
+      // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [TAG...]
+      const char* p = line.c_str(); const char* fld[12]; int nf = 0; fld[nf++] = p;
+      std::vector<const char*> tags;
+      for (const char* q = p; *q; ++q) if (*q == '\t') { if (nf < 11) fld[nf++] = q + 1; else tags.push_back(q + 1); }
+      if (nf < 11) { err = "malformed SAM record (fewer than 11 fields): " + line.substr(0, 80); return false; }
+      auto field = [&](int i) { const char* a = fld[i]; const char* b = (i + 1 < nf) ? fld[i + 1] - 1 : (tags.empty() ? p + line.size() : tags[0] - 1); return std::string(a, b - a); };
+      r.name = field(0); r.flag = atoi(fld[1]);
+      const std::string rn = field(2), rnext = field(6);
+      auto it = by_name.find(rn); r.ref = (rn == "*" || it == by_name.end()) ? -1 : it->second;
+      if (rnext == "=") r.mref = r.ref; else { auto it2 = by_name.find(rnext); r.mref = (rnext == "*" || it2 == by_name.end()) ? -1 : it2->second; }
+      r.pos = atoi(fld[3]) - 1;
+      const std::string seq = field(9);
+      if (seq != "*") r.len = (uint32_t)seq.size();
+      else {   // no sequence stored (secondary records): the read length is what the CIGAR consumes of the query
+        const std::string cg = field(5); uint32_t num = 0, L = 0;
+        for (char ch : cg) { if (ch >= '0' && ch <= '9') num = num * 10 + (uint32_t)(ch - '0'); else { if (ch == 'M' || ch == 'I' || ch == 'S' || ch == '=' || ch == 'X') L += num; num = 0; } }
+        r.len = L;
+      }
+      r.has_as = false; r.as = 0;
+      for (size_t t = 0; t < tags.size(); ++t) if (!strncmp(tags[t], "AS:i:", 5)) { r.as = atoi(tags[t] + 5); r.has_as = true; break; }
+      if (r.ref < 0 && !(r.flag & F_UNMAP)) { r.flag |= F_UNMAP; }   // a target that is not in the header cannot be used
+      cnt.num_records++;
+      return true;
+    }
+    return false;
+  }
+  static std::string base_name(const std::string& n) { if (n.size() > 2 && n[n.size() - 2] == '/') return n.substr(0, n.size() - 2); return n; }   // ReadPair::getNameLength
+  // the next alignment (a pair or an orphan / single read) or false at the end of the file
+  bool next_alignment(sq_aln& a, std::string& name, int32_t& as, bool& has_as, std::string& err) {
+    Rec r1, r2;
+    for (;;) {
+      if (!next_record(r1, err)) return false;
+      const bool mapped = !(r1.flag & F_UNMAP);
+      if (!paired) {   // getFrag_(UnpairedRead): every mapped record is an alignment
+        if (!mapped) { cnt.num_unaligned++; continue; }
+        memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.fwd = !(r1.flag & F_REVERSE); a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u);
+        a.mate_status = SQ_MS_SINGLE_END; a.format_id = hit_type_single(a.fwd); a.score = r1.as; a.est_aln_prob = 1.0;
+        name = r1.name; as = r1.as; has_as = r1.has_as; return true;
+      }
+      const bool mate_mapped = !(r1.flag & F_MUNMAP);
+      if (mapped && mate_mapped && (r1.flag & F_PROPER) && r1.ref == r1.mref) {   // MappedConcordantPair: this record and the next one
+        if (!next_record(r2, err)) { if (err.empty()) err = "the SAM file ends in the middle of a read pair (" + r1.name + ")"; return false; }
+        if (!(r1.flag & F_PAIRED) || !(r2.flag & F_PAIRED)) { err = "found an unpaired read in a paired-end library; the two ends of a pair must be adjacent (" + r1.name + ")"; return false; }
+        if (base_name(r1.name) != base_name(r2.name)) cnt.num_suspicious_pairs++;
+        if (r1.flag & F_READ2) std::swap(r1, r2);
+        memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.mate_pos = r2.pos; a.fwd = !(r1.flag & F_REVERSE); a.mate_fwd = !(r2.flag & F_REVERSE);
+        a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u); a.mate_len = (uint16_t)std::min<uint32_t>(r2.len, 65535u);
+        a.frag_len = (uint32_t)std::abs(r1.pos - r2.pos) + (r1.pos < r2.pos ? r2.len : r1.len);   // ReadPair::fragLen
+        a.mate_status = SQ_MS_PAIRED_END_PAIRED; a.format_id = hit_type_pair(r1.pos, a.fwd, r2.pos, a.mate_fwd);
+        a.score = r1.as; a.mate_score = (r2.flag & F_UNMAP) ? 0 : r2.as; a.est_aln_prob = 1.0;
+        name = base_name(r1.name); as = a.score + a.mate_score; has_as = r1.has_as; return true;   // ReadPair::getAS: the sum of the mapped ends' AS tags
+      }
+      if (mapped) {   // MappedOrphan (also: not a proper pair, or the ends on different targets — BAMQueue.tpp:308-331)
+        memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.fwd = !(r1.flag & F_REVERSE); a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u);
+        a.mate_status = (r1.flag & F_READ1) ? SQ_MS_PAIRED_END_LEFT : SQ_MS_PAIRED_END_RIGHT; a.format_id = hit_type_single(a.fwd); a.score = r1.as; a.est_aln_prob = 1.0;
+        name = base_name(r1.name); as = r1.as; has_as = r1.has_as; return true;
+      }
+      if (mate_mapped) continue;   // UnmappedOrphan: its mate's record carries the alignment
+      // UnmappedPair: both records of the pair are consumed
+      if (!next_record(r2, err)) return false;
+      cnt.num_unaligned++;
+    }
+  }
+};
+
+extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
+  if (!path || !out) { sq_set_error("sq_sam_open: bad arguments"); return SQ_ERR_ARG; }
+  gzFile f = gzopen(path, "rb"); if (!f) { sq_set_error("cannot open alignment file '%s'", path); return SQ_ERR_IO; }
+  gzbuffer(f, 1 << 20);
+  sq_sam* s = new sq_sam(); s->f = f; s->path = path; s->paired = paired_library != 0; s->buf.resize(4 << 20);
+  // the header: @SQ lines name the targets in the order the records refer to them
+  std::string l; bool first = true;
+  for (;;) {
+    // peek: header lines start with '@'; the first record line is kept for next_record
+    if (s->bpos == s->bend) { const int n = gzread(f, s->buf.data(), (unsigned)s->buf.size()); if (n <= 0) { s->eof = true; break; } s->bpos = 0; s->bend = (size_t)n; }
+    if (first) { first = false; if (s->bend - s->bpos >= 4 && !memcmp(s->buf.data() + s->bpos, "BAM\1", 4)) { gzclose(f); delete s; sq_set_error("'%s' is a BAM file: this build reads SAM text (samtools view -h file.bam); htslib is not available", path); return SQ_ERR_IO; } }
+    if (s->buf[s->bpos] != '@') break;
+    if (!s->getline(l)) break;
+    if (!strncmp(l.c_str(), "@SQ", 3)) {
+      std::string sn; uint32_t ln = 0; size_t p = 0;
+      while ((p = l.find('\t', p)) != std::string::npos) { ++p; if (!l.compare(p, 3, "SN:")) { const size_t e = l.find('\t', p); sn = l.substr(p + 3, e == std::string::npos ? std::string::npos : e - p - 3); } else if (!l.compare(p, 3, "LN:")) ln = (uint32_t)strtoul(l.c_str() + p + 3, nullptr, 10); }
+      if (!sn.empty()) { s->by_name[sn] = (int32_t)s->names.size(); s->names.push_back(sn); s->lens.push_back(ln); }
+    }
+  }
+  if (s->names.empty()) { gzclose(f); delete s; sq_set_error("'%s' has no @SQ header lines: the targets of the alignments are unknown", path); return SQ_ERR_IO; }
+  s->tid_map.resize(s->names.size()); for (size_t i = 0; i < s->names.size(); ++i) s->tid_map[i] = (uint32_t)i;
+  *out = s; return SQ_OK;
+}
+extern "C" uint32_t sq_sam_num_refs(const sq_sam* s) { return s ? (uint32_t)s->names.size() : 0; }
+extern "C" const char* sq_sam_ref_name(const sq_sam* s, uint32_t i) { return (s && i < s->names.size()) ? s->names[i].c_str() : ""; }
+extern "C" uint32_t sq_sam_ref_len(const sq_sam* s, uint32_t i) { return (s && i < s->lens.size()) ? s->lens[i] : 0; }
+extern "C" int sq_sam_set_tid_map(sq_sam* s, const uint32_t* map, uint32_t n) {
+  if (!s || !map || n != s->names.size()) { sq_set_error("sq_sam_set_tid_map: one entry per @SQ line"); return SQ_ERR_ARG; }
+  s->tid_map.assign(map, map + n); return SQ_OK;
+}
+extern "C" void sq_sam_close(sq_sam* s) { if (s) { if (s->f) gzclose(s->f); delete s; } }
+
+extern "C" int sq_sam_next(sq_sam* s, uint32_t max_frags, int use_as_scores, double score_exp, sq_aln_batch* out, sq_sam_counts* counts) {
+  if (!s || !out || !max_frags) { sq_set_error("sq_sam_next: bad arguments"); return SQ_ERR_ARG; }
+  s->off.assign(1, 0); s->alns.clear(); s->as_of.clear(); s->has_as_of.clear();
+  std::string err; uint32_t nfrag = 0;
+  auto close_fragment = [&](size_t a0) {   // order by transcript (AlignmentGroup::sortHits), then the AS-based conditional probabilities
+    const size_t a1 = s->alns.size(); if (a1 == a0) return;
+    std::vector<uint32_t> ord(a1 - a0); for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return s->alns[a0 + x].tid < s->alns[a0 + y].tid; });
+    std::vector<sq_aln> tmp(ord.size()); std::vector<int32_t> tas(ord.size()); bool all_as = true;
+    for (size_t i = 0; i < ord.size(); ++i) { tmp[i] = s->alns[a0 + ord[i]]; tas[i] = s->as_of[a0 + ord[i]]; all_as = all_as && s->has_as_of[a0 + ord[i]]; }
+    int32_t best = INT32_MIN; for (int32_t v : tas) best = std::max(best, v);
+    for (size_t i = 0; i < ord.size(); ++i) { if (use_as_scores && all_as) tmp[i].est_aln_prob = std::exp(-score_exp * (double)(best - tas[i])); s->alns[a0 + i] = tmp[i]; }
+    if (use_as_scores && !all_as) s->cnt.num_frags_without_as++;
+    s->off.push_back(a1); ++nfrag; s->cnt.num_fragments++;
+  };
+  size_t frag_start = 0; std::string cur_name; bool open = false;
+  for (;;) {
+    sq_aln a; std::string name; int32_t as = 0; bool has_as = false;
+    if (s->have_next) { a = s->next_aln; name = s->next_name; as = s->next_as; has_as = s->next_has_as; s->have_next = false; }
+    else if (!s->next_alignment(a, name, as, has_as, err)) { if (!err.empty()) { sq_set_error("%s: %s", s->path.c_str(), err.c_str()); return SQ_ERR_IO; } break; }
+    if (open && name != cur_name) {
+      close_fragment(frag_start); open = false;
+      if (nfrag == max_frags) { s->have_next = true; s->next_aln = a; s->next_name = name; s->next_as = as; s->next_has_as = has_as; break; }
+    }
+    if (!open) { open = true; cur_name = name; frag_start = s->alns.size(); }
+    const uint32_t t = a.tid < s->tid_map.size() ? s->tid_map[a.tid] : 0xFFFFFFFFu;
+    if (t == 0xFFFFFFFFu) { s->cnt.num_skipped_unknown_target++; continue; }
+    a.tid = t; s->alns.push_back(a); s->as_of.push_back(as); s->has_as_of.push_back(has_as ? 1 : 0); s->cnt.num_alignments++;
+  }
+  if (open && !s->have_next) close_fragment(frag_start);
+  out->n = nfrag; out->read_off = s->off.data(); out->aln = s->alns.data(); out->aln_cap = s->alns.size(); out->map_type = nullptr;
+  if (counts) *counts = s->cnt;
+  return SQ_OK;
+}

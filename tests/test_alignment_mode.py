@@ -1,0 +1,159 @@
+"""[r4] Alignment-based mode (`salmon quant -a`, row f-4): the SAM record source (host/sam_reader.cpp, after the reference's BAMQueue / ReadPair) and
+sq_aln_inject, which hands a batch of such alignments to the online model / equivalence-class stage in place of a mapped batch.  The SAM files here
+are written from alignment arrays, so every field the reader derives can be checked against its source; the stage that follows is held to the checker
+on the very records the reader produced."""
+import ctypes as C, gzip, os, subprocess
+import numpy as np
+import pytest
+import orc
+from salmon_amd import api, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_sam(path, names, lens, read_off, aln, unaligned_every=0, with_as=True):
+    """The alignments of every fragment as SAM records (pairs: two records, READ1 first; orphans and single-end reads: one), name-collated."""
+    op = gzip.open if str(path).endswith(".gz") else open
+    with op(path, "wt") as f:
+        f.write("@HD\tVN:1.6\tSO:unsorted\tGO:query\n")
+        for n, l in zip(names, lens): f.write("@SQ\tSN:%s\tLN:%d\n" % (n, l))
+        f.write("@PG\tID:test\n")
+        for fr in range(len(read_off) - 1):
+            if unaligned_every and fr % unaligned_every == 0:
+                f.write("u%d\t77\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n" % fr); f.write("u%d\t141\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n" % fr)
+            for a in aln[int(read_off[fr]):int(read_off[fr + 1])]:
+                t = names[int(a["tid"])]; tag = ("\tAS:i:%d" % a["score"]) if with_as else ""; tag2 = ("\tAS:i:%d" % a["mate_score"]) if with_as else ""
+                if a["mate_status"] == 3:
+                    fl1 = 1 | 2 | 64 | (0 if a["fwd"] else 16) | (0 if a["mate_fwd"] else 32); fl2 = 1 | 2 | 128 | (0 if a["mate_fwd"] else 16) | (0 if a["fwd"] else 32)
+                    f.write("r%d/1\t%d\t%s\t%d\t255\t%dM\t=\t%d\t0\t*\t*%s\n" % (fr, fl1, t, a["pos"] + 1, a["read_len"], a["mate_pos"] + 1, tag))
+                    f.write("r%d/2\t%d\t%s\t%d\t255\t%dM\t=\t%d\t0\t*\t*%s\n" % (fr, fl2, t, a["mate_pos"] + 1, a["mate_len"], a["pos"] + 1, tag2))
+                elif a["mate_status"] in (1, 2):
+                    fl = 1 | 8 | (64 if a["mate_status"] == 1 else 128) | (0 if a["fwd"] else 16)
+                    f.write("r%d/%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t*\t*%s\n" % (fr, 1 if a["mate_status"] == 1 else 2, fl, t, a["pos"] + 1, a["read_len"], tag))
+                else:
+                    f.write("r%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t*%s\n" % (fr, 0 if a["fwd"] else 16, t, a["pos"] + 1, a["read_len"], "A" * int(a["read_len"]), tag))
+
+
+def read_sam(path, paired=True, max_frags=1 << 20, use_as=True, score_exp=1.0, tid_map=None):
+    L = capi.lib(); h = C.c_void_p(); capi.check(L.sq_sam_open(str(path).encode(), int(paired), C.byref(h)), "sq_sam_open")
+    names = [L.sq_sam_ref_name(h, i).decode() for i in range(L.sq_sam_num_refs(h))]; lens = [L.sq_sam_ref_len(h, i) for i in range(len(names))]
+    if tid_map is not None:
+        tm = np.ascontiguousarray(tid_map, np.uint32); capi.check(L.sq_sam_set_tid_map(h, tm.ctypes.data, len(tm)), "sq_sam_set_tid_map")
+    offs = [np.zeros(1, np.uint64)]; alns = []; cnt = capi.SamCounts(); batches = 0
+    while True:
+        ab = capi.AlnBatch(); capi.check(L.sq_sam_next(h, max_frags, int(use_as), float(score_exp), C.byref(ab), C.byref(cnt)), "sq_sam_next")
+        if ab.n == 0: break
+        batches += 1
+        ro = np.ctypeslib.as_array(ab.read_off, shape=(ab.n + 1,)).copy(); na = int(ro[-1])
+        a = np.frombuffer(C.string_at(ab.aln, na * api.ALN_DTYPE.itemsize), api.ALN_DTYPE).copy() if na else np.zeros(0, api.ALN_DTYPE)
+        offs.append(ro[1:] + offs[-1][-1]); alns.append(a)
+    L.sq_sam_close(h)
+    return names, lens, np.concatenate(offs), (np.concatenate(alns) if alns else np.zeros(0, api.ALN_DTYPE)), {k: int(getattr(cnt, k)) for k, _ in capi.SamCounts._fields_}, batches
+
+
+def _toy_alignments(rng, n_frag, n_txp):
+    """Random fragments: pairs on one or several transcripts, orphans of either side, with scores."""
+    ro = [0]; rows = []
+    for f in range(n_frag):
+        k = int(rng.integers(1, 5)); kind = rng.choice([3, 3, 3, 1, 2])
+        for t in sorted(rng.choice(n_txp, k, replace=False)):
+            a = np.zeros(1, api.ALN_DTYPE)[0]
+            a["tid"] = t; a["pos"] = int(rng.integers(0, 800)); a["fwd"] = int(rng.integers(0, 2)); a["read_len"] = 100; a["score"] = int(rng.integers(150, 201)); a["mate_status"] = kind
+            if kind == 3:
+                a["mate_fwd"] = 1 - a["fwd"]; a["mate_pos"] = a["pos"] + int(rng.integers(-40, 300)); a["mate_len"] = int(rng.integers(80, 101)); a["mate_score"] = int(rng.integers(150, 201))
+            rows.append(a)
+        ro.append(len(rows))
+    return np.array(ro, np.uint64), np.array(rows, api.ALN_DTYPE)
+
+
+def test_sam_reader_rebuilds_the_alignment_records(built, tmp_path):
+    rng = np.random.default_rng(4); names = ["t%d" % i for i in range(12)]; lens = [1000 + 10 * i for i in range(12)]
+    ro, aln = _toy_alignments(rng, 300, 12)
+    for ext in ("sam", "sam.gz"):
+        p = tmp_path / ("a." + ext); write_sam(p, names, lens, ro, aln, unaligned_every=7)
+        n2, l2, ro2, aln2, cnt, nb = read_sam(p, paired=True, max_frags=64)            # several batches: a fragment never straddles two
+        assert n2 == names and l2 == lens and nb == 5 and np.array_equal(ro2, ro)
+        for f in ("tid", "pos", "fwd", "read_len", "mate_status", "score"): assert np.array_equal(aln2[f], aln[f]), f
+        pr = aln["mate_status"] == 3
+        for f in ("mate_pos", "mate_fwd", "mate_len", "mate_score"): assert np.array_equal(aln2[f][pr], aln[f][pr]), f
+        # ReadPair::fragLen: |pos1 - pos2| + the length of the rightmost read; orphans 0
+        want_fl = np.where(pr, np.abs(aln["pos"] - aln["mate_pos"]) + np.where(aln["pos"] < aln["mate_pos"], aln["mate_len"], aln["read_len"]), 0)
+        assert np.array_equal(aln2["frag_len"], want_fl.astype(np.uint32))
+        # hitType: pairs by strand and order of the starts (SalmonUtils.cpp:531-575), orphans as single-end S / A (:638-646)
+        def fid(a):
+            if a["mate_status"] != 3: return 0 | (3 << 1) | ((2 if a["fwd"] else 3) << 3)
+            if a["fwd"] != a["mate_fwd"]:
+                if a["fwd"]: return 1 | ((2 if a["pos"] <= a["mate_pos"] else 1) << 1) | (0 << 3)
+                return 1 | ((2 if a["mate_pos"] <= a["pos"] else 1) << 1) | (1 << 3)
+            return 1 | (0 << 1) | ((2 if a["fwd"] else 3) << 3)
+        assert np.array_equal(aln2["format_id"], np.array([fid(a) for a in aln], np.uint8))
+        # --useASWithoutCIGAR: exp(-scoreExp (bestAS - AS)) with AS = the sum of the mapped ends' tags
+        tot = aln["score"].astype(np.int64) + np.where(pr, aln["mate_score"], 0)
+        want = np.concatenate([np.exp(-1.0 * (tot[int(a):int(b)].max() - tot[int(a):int(b)])) for a, b in zip(ro[:-1], ro[1:])])
+        assert np.allclose(aln2["est_aln_prob"], want, rtol=1e-15)
+        assert cnt["num_fragments"] == 300 and cnt["num_unaligned"] == len(range(0, 300, 7)) and cnt["num_alignments"] == len(aln)
+    # --noErrorModel: every alignment weighs 1; single-end files; a target that is not in the index is skipped
+    _, _, _, a3, _, _ = read_sam(tmp_path / "a.sam", use_as=False); assert (a3["est_aln_prob"] == 1.0).all()
+    tm = np.arange(12, dtype=np.uint32); tm[5] = 0xFFFFFFFF
+    _, _, ro4, a4, c4, _ = read_sam(tmp_path / "a.sam", tid_map=tm)
+    assert not (a4["tid"] == 5).any() and c4["num_skipped_unknown_target"] == int((aln["tid"] == 5).sum()) and len(a4) == len(aln) - c4["num_skipped_unknown_target"]
+    se = aln.copy(); se["mate_status"] = 0; write_sam(tmp_path / "se.sam", names, lens, ro, se)
+    _, _, ro5, a5, _, _ = read_sam(tmp_path / "se.sam", paired=False)
+    assert np.array_equal(ro5, ro) and (a5["mate_status"] == 0).all() and np.array_equal(a5["pos"], aln["pos"]) and (a5["read_len"] == 100).all()
+    # BAM is refused by name, a file without @SQ lines too
+    open(tmp_path / "x.bam", "wb").write(b"BAM\1" + b"\0" * 64)
+    with pytest.raises(capi.SalmonHipError, match="BAM"): read_sam(tmp_path / "x.bam")
+    open(tmp_path / "nohdr.sam", "w").write("r1\t4\t*\t0\t0\t*\t*\t0\t0\tA\tI\n")
+    with pytest.raises(capi.SalmonHipError, match="@SQ"): read_sam(tmp_path / "nohdr.sam")
+
+
+@pytest.mark.gpu
+def test_injected_alignments_run_the_same_stage_as_mapped_ones(small_world, tmp_path):
+    """Alignments the mapper produced, written as SAM and read back, are injected in batches; the online model, the class table and the VBEM result equal
+    the checker's on the records the reader produced — and, with the mapper's own conditional probabilities restored, the mapping-mode run."""
+    w = small_world; w["idx"].to_device(0); opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=300, num_burnin_frags=2500)
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=8192)
+    rb = api.make_read_batch(w["seq"], w["off"], w["n"], paired=True)
+    ro, aln, mt, st = ctx.map_batch(rb); ctx.eq_accumulate(); eq_map = ctx.eq_finish()
+    names = w["idx"].ref_names(); lens = w["idx"].ref_lens()
+    keep = np.array([ro[f + 1] > ro[f] for f in range(w["n"])]); ro_k = np.concatenate([[0], np.cumsum((ro[1:] - ro[:-1])[keep])]).astype(np.uint64)
+    write_sam(tmp_path / "m.sam", names, lens, ro_k, aln)
+    _, _, ro_s, aln_s, cnt, _ = read_sam(tmp_path / "m.sam", use_as=True, score_exp=opts.score_exp)
+    assert np.array_equal(ro_s, ro_k) and np.array_equal(aln_s["tid"], aln["tid"]) and np.array_equal(aln_s["pos"], aln["pos"])
+    # the alignment-mode records through the HIP stage, 1000 fragments at a time, against the checker on the same records
+    ctx.reset(); L = capi.lib(); nf = len(ro_s) - 1
+    for lo in range(0, nf, 1000):
+        hi = min(nf, lo + 1000); r = (ro_s[lo:hi + 1] - ro_s[lo]).astype(np.uint64); a = np.ascontiguousarray(aln_s[int(ro_s[lo]):int(ro_s[hi])])
+        ab = capi.AlnBatch(hi - lo, r.ctypes.data_as(C.POINTER(C.c_uint64)), a.ctypes.data_as(C.POINTER(capi.Aln)), len(a), None)
+        capi.check(L.sq_aln_inject(ctx.h, C.byref(ab), hi - lo), "sq_aln_inject"); ctx.eq_accumulate()
+    eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
+    oidx = orc.OrcIndex(w["idx"]); ost = orc.OrcState(oidx, opts)
+    for lo in range(0, nf, 1000):
+        hi = min(nf, lo + 1000); ost.eq_accumulate((ro_s[lo:hi + 1] - ro_s[lo]).astype(np.uint64), np.ascontiguousarray(aln_s[int(ro_s[lo]):int(ro_s[hi])]), hi - lo)
+    ost.finish(); eq_c = ost.eq_finish(); lm_c, uq_c, tc_c, le_c, _ = ost.model()
+    for f in ("off", "tid", "bins", "count", "wq"): assert np.array_equal(getattr(eq_g, f), getattr(eq_c, f)), f
+    assert np.array_equal(lm_g, lm_c) and np.array_equal(uq_g, uq_c) and np.array_equal(tc_g, tc_c) and np.array_equal(le_g, le_c)
+    p_g = api.normalize_alphas(eq_g, lm_g, uq_g, tc_g); a_g, rep_g = ctx.em_optimize(np.exp(le_g), p_g, api.em_opts())
+    a_c, rep_c = orc.em_optimize(eq_c, np.exp(le_c), orc.normalize_alphas(len(lm_c), eq_c, lm_c, uq_c, tc_c), api.em_opts())
+    assert rep_g["iters"] == rep_c["iters"] and np.array_equal(a_g, a_c)
+    assert int(eq_g.count.sum()) == int(eq_map.count.sum())                      # every fragment the mapper assigned is assigned here too
+    ctx.free()
+
+
+@pytest.mark.gpu
+def test_cli_alignment_mode_quantifies_from_a_sam_file(small_world, tmp_path):
+    w = small_world; w["idx"].to_device(0); exe = os.path.join(ROOT, "salmon_amd", "bin", "salmon-hip")
+    ctx = api.QuantContext(w["idx"], api.quant_opts(), device=0, max_batch_reads=8192)
+    ro, aln, mt, st = ctx.map_batch(api.make_read_batch(w["seq"], w["off"], w["n"], paired=True)); ctx.free()
+    names = w["idx"].ref_names(); lens = w["idx"].ref_lens()
+    keep = np.array([ro[f + 1] > ro[f] for f in range(w["n"])]); ro_k = np.concatenate([[0], np.cumsum((ro[1:] - ro[:-1])[keep])]).astype(np.uint64)
+    write_sam(tmp_path / "m.sam.gz", names, lens, ro_k, aln, unaligned_every=50)
+    w["tx"].write_fasta(str(tmp_path / "t.fa"))
+    r = subprocess.run([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "m.sam.gz"), "-o", str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode != 0 and "--noErrorModel" in r.stderr                      # the CIGAR-based error model is not built: say so, do not pretend
+    subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "m.sam.gz"), "-o", str(tmp_path / "out"), "--useASWithoutCIGAR", "-q"])
+    import json
+    meta = json.load(open(tmp_path / "out" / "aux_info" / "meta_info.json"))
+    assert meta["mapping_type"] == "alignment" and meta["num_mapped"] == int(keep.sum()) and meta["num_processed"] == int(keep.sum()) + len(range(0, int(keep.sum()), 50))
+    rows = [l.split("\t") for l in open(tmp_path / "out" / "quant.sf").read().splitlines()[1:]]
+    assert abs(sum(float(x[4]) for x in rows) - keep.sum()) < 1e-3 * keep.sum() and abs(sum(float(x[3]) for x in rows) - 1e6) < 1.0

@@ -16,7 +16,9 @@ def world300(built):
     idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=4)
     n = 1500
     seq, off, tt, tp = tx.reads(n, read_len=300, seed=5, threads=4)
-    return dict(tx=tx, idx=idx, seq=seq, off=off, n=n, refs=[bytes(s) for s in tx.seqs()])
+    raw = dict(zip(tx.names(), tx.seqs()))
+    refs = [raw[nm][:l] for nm, l in zip(idx.ref_names(), idx.ref_lens())]   # the index's references: duplicates dropped, poly-A tails clipped (as tests/golden/make_exhaustive.py)
+    return dict(tx=tx, idx=idx, seq=seq, off=off, n=n, refs=refs)
 
 
 def _haplotype_world(read_len=400, n_hap=24, n=400, seed=3):
@@ -56,6 +58,16 @@ def test_checker_keeps_every_unimem_and_whole_reads(built):
     assert st["num_truncated_ends"] == 0 and st["num_mapped"] > 0.95 * w["n"] and int(aln["read_len"].max()) == 400
 
 
+def test_checker_on_2x300_pairs_agrees_with_the_exhaustive_aligner(world300):
+    # CPU: reads three times the old packing limit against the all-positions aligner — the same label sets, the same scores
+    w = world300; opts = api.quant_opts(); oidx = orc.OrcIndex(w["idx"]); k = 150
+    rb = api.make_read_batch(w["seq"], w["off"], k, paired=True)
+    ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=os.cpu_count() or 8)
+    lo, lt, ls, kind = exh.labels(w["refs"], w["seq"], w["off"], k, opts, threads=os.cpu_count() or 8)
+    c = exh.compare(lo, lt, ro, aln["tid"]); assert c["agreement"] >= 0.98, {x: v for x, v in c.items() if x != "examples"}
+    assert int(aln["read_len"].max()) == 300 and st["num_truncated_ends"] == 0
+
+
 def _fields_equal(a, b, fields, what):
     assert len(a) == len(b), (what, len(a), len(b))
     for f in fields: assert np.array_equal(a[f], b[f]), (what, f)
@@ -81,7 +93,7 @@ def test_2x300_pairs_equal_the_checker_at_every_stage_and_the_exhaustive_aligner
     r1, a1, _, _ = ctx.map_batch(rb100); r1c, a1c, _, _ = orc.map_batch(oidx, opts, rb100, threads=8)
     assert np.array_equal(r1, r1c) and a1.tobytes() == a1c.tobytes()
     # the exhaustive aligner (no index, no seeds, no band) on the first 60 pairs: the same label sets wherever it finds a concordant pair, the same scores
-    k = 60
+    k = 200
     lo, lt, ls, kind = exh.labels(w["refs"], w["seq"], w["off"], k, opts, threads=os.cpu_count() or 8)
     c = exh.compare(lo, lt, ro_g[:k + 1], aln_g["tid"])
     assert c["agreement"] >= 0.95, {x: v for x, v in c.items() if x != "examples"}
