@@ -316,18 +316,32 @@ def run_spread(a, world_obj, parked, off_d, B, RL, api, capi, local):
         res[name] = {"W": W or 8, "batch_pairs": batch_pairs, "ranks": 1, "seconds": round(dt, 4), "em_iters": rep["iters"], "eq_classes": rep["eq_classes"],
                      "num_reads_ge_0.01": rel_spread(base[0], al, 1e-2), "num_reads_ge_10": rel_spread(base[0], al, 10.0),
                      "tpm_ge_0.01": rel_spread(base[1], tp, 1e-2), "tpm_ge_1": rel_spread(base[1], tp, 1.0)}
+    tables = {}
+    def eq_digest(eq): return sha(np.concatenate([eq.off.view(np.uint8), eq.tid.view(np.uint8), eq.bins.view(np.uint8), eq.count.view(np.uint8), eq.wq.view(np.uint8)]))
     variant("W8_default", 0, B)
     variant("W1", 1, B); variant("W32", 32, B); variant("W64", 64, B)
-    variant("batch_1M", 0, min(B, 1000000))
-    # two ranks: batches alternate between two contexts (b -> rank b mod 2, SPEC MG), exchanged and merged in loop-back
+    B1 = min(B, 1000000)
+    # the one-rank job in 1 M-pair batches, kept: the two-rank job below uses the same batch plan
+    o = api.quant_opts(); c1 = api.QuantContext(idx, o, device=local, max_batch_reads=B1); c1.reserve(1000000, 0)
+    one_job(c1, rbs_of(B1)[:1], api, idx)
+    dt, al1, eff1, rep1 = one_job(c1, rbs_of(B1), api, idx); tp1 = tpm_of(al1, eff1); tables["one_rank_1M"] = eq_digest(c1.eq_finish()); c1.free()
+    res["batch_1M"] = {"W": 8, "batch_pairs": B1, "ranks": 1, "seconds": round(dt, 4), "em_iters": rep1["iters"], "eq_classes": rep1["eq_classes"],
+                       "num_reads_ge_0.01": rel_spread(base[0], al1, 1e-2), "num_reads_ge_10": rel_spread(base[0], al1, 10.0),
+                       "tpm_ge_0.01": rel_spread(base[1], tp1, 1e-2), "tpm_ge_1": rel_spread(base[1], tp1, 1.0)}
+    # two ranks (two contexts on this device), SPEC MG: the shared burn-in prefix on both, rank 1 drops its counts, the rest alternates;
+    # the tables go through the communicator's buffers in loop-back
     try:
-        o = api.quant_opts(); ctxs = [api.QuantContext(idx, o, device=local, max_batch_reads=B) for _ in range(2)]
+        o = api.quant_opts(); ctxs = [api.QuantContext(idx, o, device=local, max_batch_reads=B1) for _ in range(2)]
         for c in ctxs: c.reserve(2000000, 0)
-        rb_all = rbs_of(B); t0 = time.perf_counter()
-        for i, rb in enumerate(rb_all):
+        rb_all = rbs_of(B1); d = api.Dist(api.Dist.make_id(), 0, 1, local)
+        import torch; torch.cuda.synchronize(); t0 = time.perf_counter(); npfx = 0
+        while npfx < len(rb_all) and not ctxs[0].summary()["burned_in"]:
+            for c in ctxs: c.map_batch(rb_all[npfx], fetch=False); c.eq_accumulate()
+            npfx += 1
+        ctxs[1].drop_counts()
+        for i, rb in enumerate(rb_all[npfx:]):
             c = ctxs[i % 2]; c.map_batch(rb, fetch=False); c.eq_accumulate()
         models = [c.model() for c in ctxs]
-        d = api.Dist(api.Dist.make_id(), 0, 1, local)
         d.merge_eq_loopback(ctxs)
         eq = ctxs[0].eq_finish()
         uq = (models[0][1] + models[1][1]).astype(np.uint64); tc = (models[0][2] + models[1][2]).astype(np.uint64)
@@ -336,8 +350,10 @@ def run_spread(a, world_obj, parked, off_d, B, RL, api, capi, local):
         le = models[0][3]
         proj = api.normalize_alphas(eq, lm, uq, tc); eff = np.exp(le)
         al, rep = ctxs[0].em_optimize(eff, proj, api.em_opts())
-        dt = time.perf_counter() - t0; tp = tpm_of(al, eff)
-        res["ranks_2"] = {"W": 8, "batch_pairs": B, "ranks": 2, "seconds": round(dt, 4), "em_iters": rep["iters"], "eq_classes": len(eq.count),
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0; tp = tpm_of(al, eff)
+        res["ranks_2"] = {"W": 8, "batch_pairs": B1, "ranks": 2, "shared_prefix_batches": npfx, "seconds": round(dt, 4), "em_iters": rep["iters"], "eq_classes": len(eq.count),
+                          "class_table_equals_one_rank_job": eq_digest(eq) == tables["one_rank_1M"],
+                          "vs_one_rank_same_batches": {"num_reads_ge_10": rel_spread(al1, al, 10.0), "tpm_ge_1": rel_spread(tp1, tp, 1.0)},
                           "num_reads_ge_0.01": rel_spread(base[0], al, 1e-2), "num_reads_ge_10": rel_spread(base[0], al, 10.0),
                           "tpm_ge_0.01": rel_spread(base[1], tp, 1e-2), "tpm_ge_1": rel_spread(base[1], tp, 1.0)}
         d.free()
@@ -394,13 +410,18 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     B = a.batch; K = a.steps; W = a.warmup; RL = a.read_len if not leg else w["read_len"]; S = max(1, a.sub)
     if B > (1 << 23): raise SystemExit("--batch above 2^23 pairs per sq_map_batch call")
     total_pairs = K * S * B            # c3: the whole job's pairs, whatever the rank count
-    if strong:                         # this rank's share of the fixed total, cut into calls of at most B pairs
-        share = total_pairs // world + (1 if rank < total_pairs % world else 0)
-        first_of_rank = (total_pairs // world) * rank + min(rank, total_pairs % world)
-        ncalls = max(1, -(-share // B)); per = -(-share // ncalls)
-        call_sizes = [min(per, share - i * per) for i in range(ncalls) if share - i * per > 0]
+    if strong:
+        # [r4] SPEC MG: the job's batch plan does not depend on the rank count.  The shared burn-in prefix — batches of <= 1 M pairs covering the
+        # first ~5.5 M pairs (numAuxModelSamples = 5 M assigned fragments at >= 92 % mapped) — is mapped by EVERY rank; the rest, in batches of
+        # <= 2 M pairs, is dealt out (batch j -> rank j mod R).  With one rank this is simply the job in that batch order.
+        PB = min(B, 1000000); RB = min(B, 2000000)
+        prefix_pairs = min(total_pairs, 6 * PB if total_pairs > 6 * PB else total_pairs)
+        plan = [(i * PB, min(PB, prefix_pairs - i * PB), True) for i in range(-(-prefix_pairs // PB))]
+        nrest = -(-(total_pairs - prefix_pairs) // RB)
+        plan += [(prefix_pairs + j * RB, min(RB, total_pairs - prefix_pairs - j * RB), False) for j in range(nrest) if j % world == rank]
     else:
-        call_sizes = [B] * (K * S)
+        plan = [(((rank * (K + W) + W) * S + i) * B, B, False) for i in range(K * S)]
+    call_sizes = [n for _, n, _ in plan]
     opts = api.quant_opts()
     if a.inflight > 0: opts.mini_batches_in_flight = a.inflight
     ctx = api.QuantContext(idx, opts, device=local, max_batch_reads=B)
@@ -421,10 +442,8 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         return seq
     for s in range(W * S):
         park((total_pairs + (rank * W * S + s) * B) if strong else ((rank * (K + W)) * S + s) * B, B)
-    pos = 0
-    for i, n in enumerate(call_sizes):
-        first = (first_of_rank + pos) if strong else ((rank * (K + W) + W) * S + i) * B
-        seq = park(first, n); pos += n
+    for i, (first, n, _) in enumerate(plan):
+        seq = park(first, n)
         if i == 0 and rank == 0 and not leg and a.cpu_sample > 0:
             host_first = seq[: 2 * RL * min(n, a.cpu_sample)].copy()
     torch.cuda.synchronize()
@@ -449,7 +468,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot = None
+    tot = None; t_prefix = 0.0; prefix_burned = None
     depth = max(1, a.lanes)          # batches in flight on the mapping lanes (sq_map_submit / sq_map_wait)
     lo, hi = W * S, len(rbs)
     if depth > 1:
@@ -464,6 +483,9 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         if depth > 1 and s + depth < hi:
             ctx.map_submit(rbs[s + depth])
         tot = st if tot is None else {k: tot[k] + v for k, v in st.items()}
+        if strong and plan[s - lo][2] and (s + 1 == hi or not plan[s + 1 - lo][2]):      # the last batch of the shared prefix
+            t_prefix = time.perf_counter() - t0; prefix_burned = ctx.summary()["burned_in"]
+            if rank != 0: ctx.drop_counts()
     t_map = time.perf_counter() - t0
     eq = ctx.eq_finish()
     t_eqf = time.perf_counter() - t0 - t_map
@@ -652,7 +674,8 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
-        "config": {"workload": "%s (k=31, m=20), %s, -l IU defaults, VBEM" % (cfg_name, ("%d synthetic 2x%dbp pairs in all, %d on this rank in %d calls" % (total_pairs, RL, NP, len(call_sizes))) if strong
+        "config": {"workload": "%s (k=31, m=20), %s, -l IU defaults, VBEM" % (cfg_name, ("%d synthetic 2x%dbp pairs in all; every rank maps the shared burn-in prefix (%d pairs), the rest is dealt out: %d pairs on this rank in %d calls" % (total_pairs, RL,
+                           sum(n for _, n, sh in plan if sh), NP, len(call_sizes))) if strong
                        else ("%d steps x %d x %d = %d synthetic 2x%dbp pairs per GPU" % (K, S, B, NP, RL))),
                    "workload_id": wl,
                    "transcripts": int(tx.n), "refs": int(M), "txome_nt": int(tx.total_nt()), "decoy_nt": int(genome.total_nt()) if genome is not None else 0,
@@ -660,7 +683,8 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
                    "pairs_per_step": S * B, "pairs_per_map_call": B, "job_pairs": int(job_pairs),
                    "parallelism": "reads sharded over %d GPU(s); eq-class tables all-gathered + merged exactly (%s); EM replicated" % (world,
                        "sq_dist_* over RCCL" if sqd is not None else ("torch.distributed" if dist is not None else "single rank"))},
-        "breakdown": {"map_eq_s": round(t_map, 4), "tail_s(eq_export+merge+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
+        "breakdown": {"map_eq_s": round(t_map, 4), "shared_prefix_s": round(t_prefix, 4) if strong else None, "shared_prefix_pairs": int(sum(n for _, n, sh in plan if sh)) if strong else None,
+            "model_burned_in_at_prefix_end": prefix_burned, "tail_s(eq_export+merge+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
             "dist_merge_s": round(t_merge, 4), "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
             "em_device_ms": round(rep["device_ms"], 2), "synth_s": round(Wd.t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
                       "index_build_s": round(Wd.t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4),

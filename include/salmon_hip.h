@@ -324,6 +324,12 @@ typedef struct {          /* online-model state needed downstream (Transcript, F
   uint32_t lib_detected;     /* 1 once `-l A` auto-detection has replaced the starting format */
 } sq_model_summary;
 int sq_model_summary_get(sq_ctx*, sq_model_summary* out);
+/* [r4] multi-GPU, the shared burn-in prefix (oracle/SPEC.md §MG): every rank maps and accumulates the same batches until the model is burned in
+ * (sq_model_summary.burned_in), so all ranks hold the same fragment-length model and effective lengths — the reference learns them ONCE too; the ranks
+ * other than 0 then call this: the classes, counts and observed bias masses the prefix added are forgotten (rank 0 keeps them), the model is kept, the
+ * transcript masses move into the prior term.  After it the rank's table holds only what it maps from here on, and the merged table of an N-rank job
+ * is the one-rank job's table bit for bit. */
+int sq_model_drop_counts(sq_ctx*);
 /* per-transcript state after the online phase: log-mass (LOG_0 = +inf when none), unique/total
  * counts, log effective length (Transcript.hpp:136-141,210-283). Arrays of length num_refs. */
 int sq_model_fetch(sq_ctx*, double* log_mass, uint64_t* unique_count, uint64_t* total_count,

@@ -2005,6 +2005,15 @@ void orc_state_merge(orc_state* dst, const orc_state* src) {
   D.numObserved += R.numObserved; D.numAssigned += R.numAssigned; D.numMappedUB += R.numMappedUB; D.numCompat += R.numCompat;
   for (int f = 0; f < 64; ++f) D.libCounts[f] += R.libCounts[f];
 }
+// SPEC MG, end of the shared burn-in prefix on a rank other than 0: what the prefix added is forgotten, what it taught is kept; the masses move
+// into the prior term (logAdd(prior, mass) is unchanged), `mass` restarts and ends as the rank's own increments
+void orc_state_drop_counts(orc_state* s) {
+  QuantState& S = s->S;
+  for (size_t t = 0; t < S.mass.size(); ++t) { S.priorMass[t] = sq_log_add(S.priorMass[t], S.mass[t]); S.mass[t] = SQ_LOG_0; S.uniq[t] = 0; S.total[t] = 0; }
+  S.eq.clear(); S.numObserved = 0; S.numAssigned = 0; S.numMappedUB = 0; S.numCompat = 0;
+  for (auto& v : S.libCounts) v = 0;
+  memset(S.gcObs, 0, sizeof(S.gcObs)); memset(S.posObs, 0, sizeof(S.posObs)); memset(S.seqObs, 0, sizeof(S.seqObs)); S.seqSamples = 0;
+}
 void orc_state_summary(orc_state* s, sq_model_summary* m) {
   m->lib_format_id = (uint32_t)(s->S.op.o.lib_type | (s->S.op.o.lib_orientation << 1) | (s->S.op.o.lib_strand << 3)); m->lib_detected = s->S.detected ? 1u : 0u;
   m->num_observed = s->S.numObserved;

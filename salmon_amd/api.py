@@ -322,6 +322,10 @@ class QuantContext:
         return dict(num_observed=int(s.num_observed), num_assigned=int(s.num_assigned), num_mapped_ub=int(s.num_mapped_ub),
             burned_in=bool(s.burned_in), num_compatible=int(s.num_compatible), lib_format_id=int(s.lib_format_id), lib_detected=int(s.lib_detected))
 
+    def drop_counts(self):
+        """SPEC MG, end of the shared burn-in prefix on a rank other than 0 (sq_model_drop_counts)."""
+        check(lib().sq_model_drop_counts(self.h), "sq_model_drop_counts")
+
     def lib_counts(self):
         out = np.zeros(64, np.uint64)
         check(lib().sq_model_fetch_lib_counts(self.h, _ptr(out, C.c_uint64)), "sq_model_fetch_lib_counts")

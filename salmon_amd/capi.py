@@ -227,7 +227,7 @@ def lib():
         "sq_eq_file_eff_lens": (P(f64), [vp]), "sq_eq_file_table": (C.c_int, [vp, P(EqTable)]),
         "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64),
             u32]), "sq_boot_writer_close": (u64, [vp]),
-        "sq_bias_last_gc_expected": (C.c_int, [vp]), "sq_aln_inject": (C.c_int, [vp, P(AlnBatch), u64]),
+        "sq_bias_last_gc_expected": (C.c_int, [vp]), "sq_aln_inject": (C.c_int, [vp, P(AlnBatch), u64]), "sq_model_drop_counts": (C.c_int, [vp]),
         "sq_sam_open": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_sam_num_refs": (u32, [vp]), "sq_sam_ref_name": (C.c_char_p, [vp, u32]), "sq_sam_ref_len": (u32, [vp, u32]),
         "sq_sam_set_tid_map": (C.c_int, [vp, vp, u32]), "sq_sam_next": (C.c_int, [vp, u32, C.c_int, f64, P(AlnBatch), P(SamCounts)]), "sq_sam_close": (None, [vp]),
         "sq_index_hash": (C.c_char_p, [vp, C.c_int]), "sq_index_keeps_duplicates": (C.c_int, [vp]), "sq_model_fld_min": (C.c_int, [vp, P(u32)]),

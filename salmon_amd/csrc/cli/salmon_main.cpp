@@ -513,16 +513,27 @@ static int cmd_quant(int argc, char** argv) {
     if (!quiet) fprintf(stderr, "\r[salmon-hip] processed %llu fragments, %llu mapped", (unsigned long long)nfrag, (unsigned long long)tot.num_mapped);
   };
   uint64_t batch_no = 0;
+  // [r4] SPEC MG, the shared burn-in prefix: until the online model is burned in EVERY rank maps and accumulates every batch (the model is learned
+  // once, as in the reference, and is the same on all ranks); the ranks other than 0 then drop what the prefix counted and the batches are dealt out
+  bool prefix = world > 1;
   for (;;) {
     sq_read_batch in; int slot = -1;
     if (sq_reader_next(rd, &in, &slot)) die("reading");
     if (in.n == 0) break;
-    if (world > 1 && (int)(batch_no++ % (uint64_t)world) != rank) { sq_reader_release(rd, slot); continue; }   // batch b -> rank b mod R (SPEC MG)
+    if (prefix) {
+      if (sq_map_submit(ctx, &in, nullptr)) die("mapping");
+      inflight.push_back(slot); inflight_in.push_back(in); finish_one();
+      sq_model_summary pms{}; if (sq_model_summary_get(ctx, &pms)) die("model summary");
+      if (pms.burned_in) { prefix = false; if (rank != 0) { if (sq_model_drop_counts(ctx)) die("dropping the prefix's counts"); tot = sq_map_stats{}; nfrag = 0; } }
+      continue;
+    }
+    if (world > 1 && (int)(batch_no++ % (uint64_t)world) != rank) { sq_reader_release(rd, slot); continue; }   // after the prefix: batch b -> rank b mod R (SPEC MG)
     if (inflight.size() == lanes) finish_one();
     if (sq_map_submit(ctx, &in, nullptr)) die("mapping");
     inflight.push_back(slot); inflight_in.push_back(in);
   }
   while (!inflight.empty()) finish_one();
+  if (prefix && rank != 0) { if (sq_model_drop_counts(ctx)) die("dropping the prefix's counts"); tot = sq_map_stats{}; nfrag = 0; }   // the input ended inside the prefix: rank 0 holds all of it
   if (sam_path) { sam.close(); fprintf(stderr, "\n[salmon-hip] wrote %llu SAM records to %s", (unsigned long long)sam.nrec, !strcmp(sam_path, "-") ? "stdout" : sam_path); }
   if (unm) fclose(unm);
   sq_reader_close(rd);

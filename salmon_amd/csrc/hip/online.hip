@@ -1645,6 +1645,33 @@ extern "C" int sq_ctx_reset(sq_ctx* c) {
   return rc;
 }
 
+// [r4] SPEC MG, the shared burn-in prefix: every rank runs the batches up to the end of the burn-in itself, so every rank holds the same model; ranks other
+// than 0 then forget what the prefix ADDED — classes, counts, observed bias masses — and keep what it TAUGHT: the fragment-length tables, the effective
+// lengths, the burned-in flag, and the transcript masses, which move into the prior term (logAdd(prior, mass) stays what it was, bit for bit, while
+// `mass` restarts at LOG_0 and ends the run as this rank's own increments — what the rank-ordered merge of the masses wants to add).
+__global__ void k_fold_mass(uint32_t M, double* __restrict__ prior, double* __restrict__ mass) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= M) return;
+  prior[t] = sq_log_add(prior[t], mass[t]); mass[t] = SQ_LOG_0;
+}
+extern "C" int sq_model_drop_counts(sq_ctx* c) {
+  if (!c || c->owner || !c->online) { sq_set_error("sq_model_drop_counts: bad context"); return SQ_ERR_ARG; }
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device));
+  sq_online_dev* o = c->online; hipStream_t st = c->stream2; const uint32_t M = o->M;
+  k_fold_mass<<<nblk(M), TB, 0, st>>>(M, o->prior_mass.p, o->mass.p);
+  SQ_HIP_CHECK(hipMemsetAsync(o->uniq.p, 0, (size_t)M * 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->total.p, 0, (size_t)M * 8, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->lib_counts.p, 0, 64 * 8, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->gc_obs.p, 0, (SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) * 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->pos_obs.p, 0, 208 * 8, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->seq_obs.p, 0, 1160 * 8, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->ctr.p + 0, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->ctr.p + 5, 0, 8, st));          // numAssigned, numCompatible (the burned-in flag and the FLD's bookkeeping stay)
+  SQ_HIP_CHECK(hipMemsetAsync(o->tk1.p, 0xFF, o->tcap * 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->tk2.p, 0, o->tcap * 8, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->tcount.p, 0, o->tcap * 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->tn.p, 0, o->tcap * 4, st));
+  SQ_HIP_CHECK(hipMemsetAsync(o->pool_wq.p, 0, o->pool_cap * 8, st)); SQ_HIP_CHECK(hipMemsetAsync(o->pool_cursor.p, 0, 4 * 8, st));
+  SQ_HIP_CHECK(hipStreamSynchronize(st));
+  o->num_observed = 0; o->num_mapped_ub = 0; o->exp.valid = false; o->exp.model_valid = false;
+  return SQ_OK;
+}
+
 extern "C" int sq_model_summary_get(sq_ctx* c, sq_model_summary* out) {
   if (!c || !out) return SQ_ERR_ARG;
   { int rs = sq_eq_sync(c); if (rs) return rs; }

@@ -143,6 +143,9 @@ class OrcState:
     def gc_observed(self):
         g = np.zeros(75); lib().orc_state_gc_observed(self.h, g.ctypes.data); return g.reshape(3, 25)
 
+    def drop_counts(self):
+        lib().orc_state_drop_counts(self.h)
+
     def merge(self, other):
         """SPEC §MG: fold the state of the next rank into this one (call in rank order on rank 0's state)."""
         lib().orc_state_merge(self.h, other.h)

@@ -62,5 +62,5 @@ def test_strong_scaling_workload_splits_a_fixed_total_over_the_ranks(built):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["job_pairs"] == 120000 and d["config"]["workload_id"] == "c3"
-    assert d["breakdown"]["stats"]["num_reads"] == 60000                      # rank 0 mapped its half
+    assert d["breakdown"]["stats"]["num_reads"] == 120000 and d["breakdown"]["shared_prefix_pairs"] == 120000   # a job shorter than the burn-in is all prefix: every rank maps it, rank 0 keeps it
     assert abs(d["value"] - 120000 / (d["ms_per_step"] * 3e-3) / 1e6) < 0.01 * d["value"]

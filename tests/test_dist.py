@@ -91,3 +91,44 @@ def test_two_rank_gloo_eq_table_reduction(built):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def test_shared_burn_in_prefix_makes_the_n_rank_table_the_one_rank_table(built):
+    """[r4] SPEC §MG: every rank runs the batches up to the end of the burn-in itself (the model is learned once, as in the reference), ranks other
+    than 0 then drop what the prefix counted; the rest of the batches are dealt round-robin.  Checker level (no GPU): the merged class table, the
+    unique / total counts and the fragment counters of a 3-rank job equal the one-rank job's exactly; the masses are a different realisation."""
+    import orc
+    from salmon_amd import api, synth
+    tx = synth.Txome(seed=9, n_genes=50, iso_per_gene=5, threads=1)
+    names, seqs, lens = tx.tables()
+    idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=1); oidx = orc.OrcIndex(idx)
+    N, B = 3000, 200; seq, off, _, _ = tx.reads(N, read_len=100, seed=3, threads=1)
+    opts = api.quant_opts(mini_batch_size=50, num_pre_burnin_frags=80, num_burnin_frags=500)
+    def batch(b):
+        lo, hi = b * B, (b + 1) * B
+        rb = api.make_read_batch(seq[lo * 200: hi * 200], (off[2 * lo: 2 * hi + 1] - off[2 * lo]).copy(), B, paired=True)
+        ro, aln, mt, st = orc.map_batch(oidx, opts, rb, threads=2); return ro, aln, st["num_with_joint_hits"]
+    batches = [batch(b) for b in range(N // B)]
+    one = orc.OrcState(oidx, opts)
+    for ro, aln, j in batches: one.eq_accumulate(ro, aln, j)
+    one.finish(); eq1 = one.eq_finish(); lm1, uq1, tc1, le1, _ = one.model(); s1 = one.summary()
+    R = 3; ranks = [orc.OrcState(oidx, opts) for _ in range(R)]; prefix = 0
+    while not ranks[0].summary()["burned_in"]:          # the shared prefix: the same batches on every rank
+        for st in ranks: st.eq_accumulate(*batches[prefix])
+        prefix += 1
+    assert 2 <= prefix < len(batches) - R and all(st.summary()["burned_in"] for st in ranks)
+    for st in ranks[1:]: st.drop_counts()
+    for i, b in enumerate(range(prefix, len(batches))): ranks[i % R].eq_accumulate(*batches[b])
+    for st in ranks: st.finish()
+    assert len(ranks[1].eq_finish().count) < len(ranks[0].eq_finish().count)               # a dropped rank holds only what it mapped after the prefix
+    for st in ranks[1:]: ranks[0].merge(st)
+    eqn = ranks[0].eq_finish(); lmn, uqn, tcn, len_, _ = ranks[0].model(); sn = ranks[0].summary()
+    for f in ("off", "tid", "bins", "count", "wq", "h1", "h2", "w"): assert np.array_equal(getattr(eqn, f), getattr(eq1, f)), f
+    assert np.array_equal(uqn, uq1) and np.array_equal(tcn, tc1) and np.array_equal(len_, le1)
+    assert sn["num_assigned"] == s1["num_assigned"] and sn["num_observed"] == s1["num_observed"] and sn["num_compatible"] == s1["num_compatible"]
+    assert not np.array_equal(lmn, lm1) and np.isfinite(lmn[np.isfinite(lm1)]).all()      # masses: the same transcripts carry mass, the values are another realisation
+    # and the inference on the merged table starts from a different point but lands within the optimiser's tolerance
+    a1, r1 = orc.em_optimize(eq1, np.exp(le1), orc.normalize_alphas(len(lm1), eq1, lm1, uq1, tc1), api.em_opts())
+    an, rn = orc.em_optimize(eqn, np.exp(len_), orc.normalize_alphas(len(lmn), eqn, lmn, uqn, tcn), api.em_opts())
+    big = a1 >= 10.0
+    assert np.quantile(np.abs(an[big] - a1[big]) / a1[big], 0.9) < 2e-2

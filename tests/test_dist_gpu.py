@@ -188,3 +188,37 @@ def test_replicate_ranges_equal_the_full_run(built):
     assert np.array_equal(gfull, gpart)
     with pytest.raises(Exception, match="does not start a chain"):
         api.gibbs_range(eq, eff, a0, S, 10, 5, 13, int(eq.count.sum()))
+
+
+def test_shared_burn_in_prefix_two_hip_ranks_hold_the_one_rank_table(small_world):
+    """[r4] SPEC §MG on one GPU: two contexts stand for two ranks.  Both run the batches up to the end of the burn-in (the shared prefix), rank 1 drops
+    what the prefix counted (sq_model_drop_counts), the remaining batches alternate, the tables go through the communicator's buffers
+    (sq_dist_merge_eq_loopback) — and the merged table is the ONE-context job's table bit for bit: labels, bins, counts, fixed-point weights."""
+    w = small_world; w["idx"].to_device(0)
+    opts = api.quant_opts(mini_batch_size=100, num_pre_burnin_frags=80, num_burnin_frags=900)
+    N, B = w["n"], 400
+    def rb_of(b):
+        lo, hi = b * B, (b + 1) * B
+        return api.make_read_batch(w["seq"][lo * 200: hi * 200], (w["off"][2 * lo: 2 * hi + 1] - w["off"][2 * lo]).copy(), B, paired=True)
+    nb = N // B
+    one = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=512)
+    for b in range(nb): one.map_batch(rb_of(b), fetch=False); one.eq_accumulate()
+    eq1 = one.eq_finish(); lm1, uq1, tc1, le1 = one.model(); s1 = one.summary()
+    ranks = [api.QuantContext(w["idx"], opts, device=0, max_batch_reads=512) for _ in range(2)]; prefix = 0
+    while not ranks[0].summary()["burned_in"]:
+        for c in ranks: c.map_batch(rb_of(prefix), fetch=False); c.eq_accumulate()
+        prefix += 1
+    assert 2 <= prefix < nb - 2 and ranks[1].summary()["burned_in"]
+    ranks[1].drop_counts()
+    assert ranks[1].summary()["num_assigned"] == 0 and ranks[1].summary()["burned_in"]
+    for i, b in enumerate(range(prefix, nb)): c = ranks[i % 2]; c.map_batch(rb_of(b), fetch=False); c.eq_accumulate()
+    own1 = ranks[1].eq_finish(); assert 0 < len(own1.count) < len(eq1.count)
+    models = [c.model() for c in ranks]
+    d = api.Dist(api.Dist.make_id(), 0, 1, 0); d.merge_eq_loopback(ranks)
+    for c in ranks:
+        eqn = c.eq_finish()
+        for f in ("off", "tid", "bins", "count", "wq", "h1", "h2", "w"): assert np.array_equal(getattr(eqn, f), getattr(eq1, f)), f
+    assert np.array_equal(models[0][1] + models[1][1], uq1) and np.array_equal(models[0][2] + models[1][2], tc1) and np.array_equal(models[0][3], le1) and np.array_equal(models[1][3], le1)
+    assert ranks[0].summary()["num_assigned"] + ranks[1].summary()["num_assigned"] == s1["num_assigned"]
+    d.free(); one.free()
+    for c in ranks: c.free()

@@ -104,8 +104,8 @@ def test_2x300_pairs_equal_the_checker_at_every_stage_and_the_exhaustive_aligner
             if int(x["tid"]) in a and (x["mate_status"] == 3) == (kind[f] == 1):
                 shared += 1; differs += a[int(x["tid"])] != int(x["score"]) + (int(x["mate_score"]) if x["mate_status"] == 3 else 0)
     assert shared >= k and differs == 0, (shared, differs)
-    # the whole path: eq-classes and VBEM equal the checker's
-    ctx.eq_accumulate(); eq_g = ctx.eq_finish()
+    # the whole path: eq-classes equal the checker's
+    ctx.reset(); ctx.map_batch(rb, fetch=False); ctx.eq_accumulate(); eq_g = ctx.eq_finish()
     ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro_c, aln_c, st_c["num_with_joint_hits"]); ost.finish(); eq_c = ost.eq_finish()
     assert np.array_equal(eq_g.tid, eq_c.tid) and np.array_equal(eq_g.count, eq_c.count) and np.array_equal(eq_g.wq, eq_c.wq)
     ctx.free()
