@@ -150,6 +150,12 @@ struct sq_ctx {
   std::atomic<int> map_active{0};
   hipEvent_t ev_eq_last = nullptr;
   hipStream_t stream2 = nullptr;
+  // [r4, SQ_EQ_SPLIT=1] the eq stage in two parts: its THROUGHPUT kernels (pre-records, flags + scan, k_frag_static, the class table) run on
+  // stream_eqt, which shares the mapping stream's CU mask (they are a few big launches: they queue with the mapping kernels and take their share), and
+  // only the mass-dependent CHAIN (hundreds of small dependent launches per batch) keeps CUs of its own on stream2 — 16 instead of 64, so mapping
+  // gets 240 of the 256 CUs instead of 192
+  hipStream_t stream_eqt = nullptr; hipEvent_t ev_static = nullptr, ev_table = nullptr;
+  std::vector<hipEvent_t> prof_ev3; std::vector<int> prof_stage3;
   hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr};
   int cur_buf = 0, last_buf = 0;
   bool eq_pending[2] = {false, false};
@@ -199,7 +205,7 @@ struct sq_ctx {
 enum { SG_PACK = 0, SG_SEED, SG_SCAN_MEMS, SG_PROJECT, SG_SORT, SG_CHAIN, SG_JOIN_COUNT, SG_SCAN_CANDS, SG_JOIN_FILL, SG_SCORE, SG_DP,
     SG_SELECT, SG_COMPACT,
        SG_EQ_FLAGS, SG_EQ_MINIBATCH, SG_EQ_TABLE, SG_FINALIZE, SG_EQ_STATIC, SG_NUM };
-void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream)
+void sq_prof_mark(sq_ctx* c, int stage, int which = 0);   // records an event: time since the previous mark is charged to `stage` (which: 0 map stream, 1 eq stream, 2 the chain's stream when the eq stage is split)
 void sq_prof_begin(sq_ctx* c, int which = 0);
 void sq_prof_end(sq_ctx* c, int which = 0);               // call after the stream has been synchronised
 int sq_eq_sync(sq_ctx* c);

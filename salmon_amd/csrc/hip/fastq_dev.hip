@@ -1,0 +1,279 @@
+// hip/fastq_dev.hip — [r4] FASTQ record splitting on the device (the north_star's "newline ballot + segmented scan").
+//
+// The host read pipeline (host/reader.cpp: mmap + memchr per line + a gather into page-locked batches) tops out near 33 M pairs/s whatever the
+// number of worker threads (page faults of one address space, two passes over every record); the GPU path behind it maps > 200 M pairs/s.  Here
+// the host only moves TEXT: the bytes of the next batch's records of each mate file are pread() into a page-locked buffer by a few threads (which
+// count newlines as they go, to cut exactly 4 n lines), copied to HBM, and the device finds the records itself:
+//   k_fq_count    newlines per 4 KB tile (16 bytes per lane, zero-byte SWAR on x ^ 0x0A0A0A0A)
+//   scan          tile bases (scan_kernels.h)
+//   k_fq_index    position of every newline (block-exclusive scan of the lanes' counts + the tile base)
+//   k_fq_records  record r = lines 4r .. 4r+3: '@' / sequence / '+' / quality of the same length (CR stripped), length + start of the sequence
+//   scan          read offsets of the interleaved batch (mate 1, mate 2, mate 1, ...)
+//   k_fq_copy     the bases into the compact buffer sq_map_batch takes (on_device = 1)
+// A producer thread keeps the slots filled, so staging / H2D / splitting of batch b + 1 overlap the mapping of batch b.  Plain, regular, 4-line
+// FASTQ files only; anything else (gzip, FASTA, wrapped records, FIFOs, read names wanted) stays on the host path.  Replaces, for such input, the
+// reference's FastxParser producer threads (include/salmon/internal/io/FastxReader.hpp:13-32, SalmonQuantify.cpp:2419-2443).
+#include <hip/hip_runtime.h>
+#include <immintrin.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "scan_kernels.h"
+#include "../host/index.h"
+#include "../host/reader_dev.h"
+
+namespace {
+constexpr int FQ_TB = 256;   // 16 bytes per lane: a 4 KB tile per block
+__device__ inline uint32_t nl_mask4(uint32_t w) {   // 0x80 in every byte of w that is '\n' (exact zero-byte detection on w ^ 0x0A0A0A0A)
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+__global__ void __launch_bounds__(FQ_TB) k_fq_count(const uint4* __restrict__ text, uint64_t nvec, uint32_t* __restrict__ tile_cnt) {
+  const uint64_t i = (uint64_t)blockIdx.x * FQ_TB + threadIdx.x;
+  uint32_t c = 0;
+  if (i < nvec) { const uint4 v = text[i]; c = __popc(nl_mask4(v.x)) + __popc(nl_mask4(v.y)) + __popc(nl_mask4(v.z)) + __popc(nl_mask4(v.w)); }
+  for (int s = 32; s >= 1; s >>= 1) c += __shfl_down(c, s, 64);
+  __shared__ uint32_t sw[FQ_TB / 64];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < FQ_TB / 64; ++w) t += sw[w]; tile_cnt[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(FQ_TB) k_fq_index(const uint4* __restrict__ text, uint64_t nvec, const uint64_t* __restrict__ tile_base, uint32_t* __restrict__ nlpos, uint64_t cap) {
+  __shared__ uint64_t wsum[FQ_TB / 64 + 1];
+  const uint64_t i = (uint64_t)blockIdx.x * FQ_TB + threadIdx.x;
+  uint32_t m[4] = {0, 0, 0, 0};
+  if (i < nvec) { const uint4 v = text[i]; m[0] = nl_mask4(v.x); m[1] = nl_mask4(v.y); m[2] = nl_mask4(v.z); m[3] = nl_mask4(v.w); }
+  const uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+  uint64_t tot; uint64_t at = tile_base[blockIdx.x] + sqk::scan_block_excl<FQ_TB>(c, &tot, wsum);
+  const uint32_t byte0 = (uint32_t)(i * 16);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { uint32_t x = m[w]; while (x) { const int b = (__ffs((int)x) - 1) >> 3; x &= x - 1; if (at < cap) nlpos[at] = byte0 + 4u * w + (uint32_t)b; ++at; } }
+}
+// err[0] = first bad record (global index within the batch) + 1, err[1] = what was wrong with it
+__global__ void k_fq_records(const uint8_t* __restrict__ text, const uint32_t* __restrict__ nlpos, uint32_t n, uint32_t mate, uint32_t stride,
+                             uint32_t* __restrict__ len, uint32_t* __restrict__ start, unsigned* __restrict__ err) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n) return;
+  const uint32_t s0 = r ? nlpos[4 * r - 1] + 1 : 0, e0 = nlpos[4 * r], s1 = e0 + 1; uint32_t e1 = nlpos[4 * r + 1]; const uint32_t s2 = e1 + 1, e2 = nlpos[4 * r + 2], s3 = e2 + 1; uint32_t e3 = nlpos[4 * r + 3];
+  if (e1 > s1 && text[e1 - 1] == '\r') --e1;
+  if (e3 > s3 && text[e3 - 1] == '\r') --e3;
+  unsigned what = 0;
+  if (text[s0] != '@') what = 1; else if (text[s2] != '+') what = 2; else if (e1 - s1 != e3 - s3) what = 3;
+  if (what) { const unsigned old = atomicMin(&err[0], r + 1); if (r + 1 <= old) err[1 + mate] = what; }
+  len[(size_t)r * stride + mate] = e1 - s1; start[r] = s1;
+}
+__global__ void k_fq_copy(const uint8_t* __restrict__ text, const uint32_t* __restrict__ start, const uint64_t* __restrict__ off, uint32_t n, uint32_t mate, uint32_t stride,
+                          uint8_t* __restrict__ seq) {
+  // a group of 8 lanes per record: 8 consecutive bytes per trip (a record's bases are contiguous in the text and in the batch)
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7; if (g >= n) return;
+  const uint64_t o0 = off[(size_t)g * stride + mate], o1 = off[(size_t)g * stride + mate + 1]; const uint32_t L = (uint32_t)(o1 - o0); const uint8_t* s = text + start[g]; uint8_t* d = seq + o0;
+  for (uint32_t j = l; j < L; j += 8) d[j] = s[j];
+}
+
+struct Workers {   // a few threads for pread + newline counting
+  std::mutex mu; std::condition_variable cv, cvd; std::deque<std::function<void()>> q; std::vector<std::thread> th; bool stop = false; int busy = 0;
+  explicit Workers(unsigned n) { for (unsigned i = 0; i < n; ++i) th.emplace_back([this] { for (;;) { std::function<void()> f; { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); ++busy; } f(); { std::lock_guard<std::mutex> lk(mu); --busy; } cvd.notify_all(); } }); }
+  ~Workers() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+  void run(unsigned n, const std::function<void(unsigned)>& fn) { { std::lock_guard<std::mutex> lk(mu); for (unsigned i = 0; i < n; ++i) q.push_back([&fn, i] { fn(i); }); } cv.notify_all(); std::unique_lock<std::mutex> lk(mu); cvd.wait(lk, [&] { return q.empty() && busy == 0; }); }
+};
+inline uint64_t count_nl(const char* p, size_t n) {
+  uint64_t c = 0; size_t i = 0; const __m256i nl = _mm256_set1_epi8('\n');
+  for (; i + 32 <= n; i += 32) c += (uint64_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nl)));
+  for (; i < n; ++i) c += p[i] == '\n';
+  return c;
+}
+}  // namespace
+
+struct sq_dev_reader {
+  int device = 0; hipStream_t st = nullptr; uint32_t batch = 0; bool paired = false;
+  // a mate stream = its files end to end; a file that does not end with a newline gets one (pad = 1), so records never straddle files
+  struct File { std::string path; int fd = -1; uint64_t size = 0, vbase = 0; uint32_t pad = 0; };
+  struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; } sm[2];
+  struct Slot {
+    char* stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
+    void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
+    void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
+    void* d_start[2] = {nullptr, nullptr}; size_t start_cap[2] = {0, 0};
+    void* d_tile = nullptr; size_t tile_cap = 0; void* d_tbase = nullptr; size_t tbase_cap = 0; void* d_spine = nullptr; size_t spine_cap = 0;
+    void* d_len = nullptr; size_t len_cap = 0; void* d_off = nullptr; size_t off_cap = 0;
+    void* d_seq = nullptr; size_t seq_cap = 0; unsigned* d_err = nullptr;
+    uint32_t n = 0;
+  };
+  std::vector<Slot> slots;
+  std::unique_ptr<Workers> pool;
+  // producer <-> consumer
+  std::thread prod; std::mutex mu; std::condition_variable cv; std::deque<int> ready, free_slots; bool stop = false, done = false; std::string err; int err_rc = SQ_OK; uint64_t total = 0;
+
+  static int dev_grow(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0; const size_t c = need + need / 4 + 4096;
+    if (hipMalloc(p, c) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    *cap = c; return 0;
+  }
+  // bytes [pos, pos + n) of the stream into dst
+  bool vread(Stream& S, uint64_t pos, size_t n, char* dst, std::string* e) {
+    size_t k = 0; while (k + 1 < S.files.size() && S.files[k + 1].vbase <= pos) ++k;
+    while (n) {
+      File& F = S.files[k]; const uint64_t in = pos - F.vbase;
+      if (in < F.size) {
+        const size_t take = (size_t)std::min<uint64_t>(F.size - in, n); size_t done_b = 0;
+        while (done_b < take) { const ssize_t r = pread(F.fd, dst + done_b, take - done_b, (off_t)(in + done_b)); if (r <= 0) { *e = "cannot read '" + F.path + "'"; return false; } done_b += (size_t)r; }
+        dst += take; pos += take; n -= take;
+      } else if (in < F.size + F.pad) { *dst++ = '\n'; ++pos; --n; }
+      else ++k;
+    }
+    return true;
+  }
+  // the text of up to `want` records of stream i into s.stage[i]: *got records in *bytes bytes (whole lines)
+  bool stage_text(int i, Slot& s, uint32_t want, uint32_t* got, size_t* bytes, std::string* e) {
+    Stream& S = sm[i]; *got = 0; *bytes = 0;
+    const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0;
+    const size_t PIECE = 4u << 20;
+    std::vector<std::pair<size_t, uint64_t>> pl;   // (offset in the staging buffer, newlines) per piece
+    while (lines < need_lines && S.vpos + have < S.vsize) {
+      const uint64_t missing = (need_lines - lines + 3) / 4;
+      size_t more = (size_t)std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20));
+      if (have + more + 64 > s.stage_cap[i]) {
+        const size_t cap = have + more + (have + more) / 4 + (8u << 20); char* nb = nullptr;
+        if (hipHostMalloc((void**)&nb, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *e = "page-locked staging allocation failed (" + std::to_string(cap >> 20) + " MB)"; return false; }
+        if (s.stage[i]) { memcpy(nb, s.stage[i], have); (void)hipHostFree(s.stage[i]); }
+        s.stage[i] = nb; s.stage_cap[i] = cap;
+      }
+      const unsigned np = (unsigned)((more + PIECE - 1) / PIECE); std::vector<uint64_t> cnt(np, 0); std::vector<std::string> errs(np);
+      char* base = s.stage[i]; const uint64_t v0 = S.vpos + have;
+      pool->run(np, [&](unsigned k) {
+        const size_t o = (size_t)k * PIECE, n = std::min(PIECE, more - o);
+        if (!vread(S, v0 + o, n, base + have + o, &errs[k])) return;
+        cnt[k] = count_nl(base + have + o, n);
+      });
+      for (unsigned k = 0; k < np; ++k) { if (!errs[k].empty()) { *e = errs[k]; return false; } pl.push_back({have + (size_t)k * PIECE, cnt[k]}); lines += cnt[k]; }
+      have += more;
+    }
+    size_t cut = have;
+    if (lines >= need_lines && want) {   // just behind newline number need_lines
+      uint64_t acc = 0; size_t k = 0;
+      while (acc + pl[k].second < need_lines) { acc += pl[k].second; ++k; }
+      const char* p = s.stage[i] + pl[k].first; const char* pe = s.stage[i] + have; uint64_t left = need_lines - acc;
+      while (left) { const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p)); p = nl + 1; --left; }
+      cut = (size_t)(p - s.stage[i]); *got = want;
+    } else {   // the end of the input: what is left must be whole records (blank lines at the very end are tolerated, as on the host path)
+      while (cut >= 2 && s.stage[i][cut - 1] == '\n' && (s.stage[i][cut - 2] == '\n' || (cut >= 3 && s.stage[i][cut - 2] == '\r' && s.stage[i][cut - 3] == '\n'))) { cut -= (s.stage[i][cut - 2] == '\r') ? 2 : 1; --lines; }
+      if (lines % 4) { *e = "'" + S.files.back().path + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; return false; }
+      *got = (uint32_t)(lines / 4);
+    }
+    *bytes = cut; S.vpos += (lines >= need_lines && want) ? cut : have;
+    if (*got) S.est = 0.7 * S.est + 0.3 * ((double)cut / (double)*got);
+    return true;
+  }
+  int fill(Slot& s, std::string* e) {
+    uint32_t n[2] = {0, 0}; size_t bytes[2] = {0, 0};
+    if (!stage_text(0, s, batch, &n[0], &bytes[0], e)) return SQ_ERR_IO;
+    if (paired) {
+      if (!stage_text(1, s, n[0] ? n[0] : 1u, &n[1], &bytes[1], e)) return SQ_ERR_IO;   // (one record is asked for at the end: has the second file more than the first?)
+      if (n[0] != n[1]) { *e = "mate files have different numbers of records (stopped after " + std::to_string(total + std::min(n[0], n[1])) + " pairs)"; return SQ_ERR_IO; }
+    }
+    s.n = n[0]; if (s.n == 0) return SQ_OK;
+    const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns; const uint32_t nrec = s.n * stride;
+    for (int i = 0; i < ns; ++i) if (bytes[i] >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(s.n) + " records spans more than 4 GB of text: use a smaller batch"; return SQ_ERR_ARG; }
+    if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
+    if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8)) { *e = "device allocation failed (reader offsets)"; return SQ_ERR_NOMEM; }
+    unsigned herr[4] = {0xFFFFFFFFu, 0, 0, 0};
+    if (hipMemcpyAsync(s.d_err, herr, 16, hipMemcpyHostToDevice, st) != hipSuccess) { *e = "device copy failed (reader)"; return SQ_ERR_DEVICE; }
+    for (int i = 0; i < ns; ++i) {
+      const size_t padded = (bytes[i] + 15) & ~(size_t)15; memset(s.stage[i] + bytes[i], 0, padded - bytes[i] + 16);
+      const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
+      if (dev_grow(&s.d_text[i], &s.text_cap[i], padded + 64) || dev_grow(&s.d_nlpos[i], &s.nl_cap[i], ((size_t)4 * s.n + 8) * 4) || dev_grow(&s.d_start[i], &s.start_cap[i], ((size_t)s.n + 8) * 4) ||
+          dev_grow(&s.d_tile, &s.tile_cap, ((size_t)ntile + 8) * 4) || dev_grow(&s.d_tbase, &s.tbase_cap, ((size_t)ntile + 8) * 8) ||
+          dev_grow(&s.d_spine, &s.spine_cap, ((size_t)std::max(sqk::scan_tiles(ntile), sqk::scan_tiles(nrec)) + 8) * 8)) { *e = "device allocation failed (reader text)"; return SQ_ERR_NOMEM; }
+      if (hipMemcpyAsync(s.d_text[i], s.stage[i], padded + 16, hipMemcpyHostToDevice, st) != hipSuccess) { *e = "device copy failed (reader text)"; return SQ_ERR_DEVICE; }
+      k_fq_count<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (uint32_t*)s.d_tile);
+      sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_tile, (uint64_t*)s.d_tbase, ntile, (uint64_t*)s.d_spine, st);
+      k_fq_index<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (const uint64_t*)s.d_tbase, (uint32_t*)s.d_nlpos[i], (uint64_t)4 * s.n);
+      k_fq_records<<<(s.n + 255) / 256, 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_nlpos[i], s.n, (uint32_t)i, stride, (uint32_t*)s.d_len, (uint32_t*)s.d_start[i], s.d_err);
+    }
+    sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_len, (uint64_t*)s.d_off, nrec, (uint64_t*)s.d_spine, st);
+    uint64_t tot_bytes = 0;
+    if (hipMemcpyAsync(&tot_bytes, (uint64_t*)s.d_off + nrec, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(herr, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    if (herr[0] != 0xFFFFFFFFu) {
+      const unsigned what = herr[1] ? herr[1] : herr[2];
+      *e = "record " + std::to_string(total + herr[0]) + (what == 1 ? " does not start with '@'" : what == 2 ? " has no '+' line after one sequence line" : " has a quality string whose length differs from its sequence's") +
+           " (multi-line FASTQ? set SQ_READER_DEVICE=0)"; return SQ_ERR_IO; }
+    if (dev_grow(&s.d_seq, &s.seq_cap, tot_bytes + 64)) { *e = "device allocation failed (reader sequences)"; return SQ_ERR_NOMEM; }
+    for (int i = 0; i < ns; ++i) k_fq_copy<<<(uint32_t)(((uint64_t)s.n * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_start[i], (const uint64_t*)s.d_off, s.n, (uint32_t)i, stride, (uint8_t*)s.d_seq);
+    (void)hipMemsetAsync((uint8_t*)s.d_seq + tot_bytes, 0, 16, st);
+    if (hipStreamSynchronize(st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
+    return SQ_OK;
+  }
+  void produce() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      int si = -1;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_slots.empty(); }); if (stop) return; si = free_slots.front(); free_slots.pop_front(); }
+      std::string e; const int rc = fill(slots[(size_t)si], &e);
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc != SQ_OK) { err = e; err_rc = rc; done = true; cv.notify_all(); return; }
+      if (slots[(size_t)si].n == 0) { done = true; free_slots.push_back(si); cv.notify_all(); return; }
+      total += slots[(size_t)si].n; ready.push_back(si); cv.notify_all();
+    }
+  }
+};
+
+int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std::string>& f2, uint32_t batch, uint32_t nslots, sq_dev_reader** out) {
+  int dev = 0, ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return SQ_ERR_DEVICE; }   // no device: the caller keeps the host path
+  std::unique_ptr<sq_dev_reader> R(new sq_dev_reader()); R->device = dev; R->batch = batch; R->paired = !f2.empty();
+  for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
+    uint64_t v = 0;
+    for (const auto& path : (i ? f2 : f1)) {
+      sq_dev_reader::File F; F.path = path; F.fd = open(path.c_str(), O_RDONLY); struct stat sb;
+      if (F.fd < 0 || fstat(F.fd, &sb) != 0) { sq_set_error("cannot open '%s'", path.c_str()); for (auto& s : R->sm) for (auto& f : s.files) close(f.fd); if (F.fd >= 0) close(F.fd); return SQ_ERR_IO; }
+      F.size = (uint64_t)sb.st_size; F.vbase = v;
+      if (F.size) { char last = 0; if (pread(F.fd, &last, 1, (off_t)(F.size - 1)) == 1 && last != '\n') F.pad = 1; }
+      v += F.size + F.pad; R->sm[i].files.push_back(F);
+    }
+    R->sm[i].vsize = v;
+  }
+  if (hipStreamCreateWithFlags(&R->st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); for (auto& s : R->sm) for (auto& f : s.files) close(f.fd); return SQ_ERR_DEVICE; }
+  R->slots.resize(nslots < 2 ? 2 : (nslots > 8 ? 8 : nslots));
+  for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
+  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
+  R->pool.reset(new Workers(std::max(1u, nt)));
+  sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce(); });
+  *out = r; return SQ_OK;
+}
+int sq_dev_reader_next(sq_dev_reader* R, sq_read_batch* b, int* slot) {
+  std::unique_lock<std::mutex> lk(R->mu);
+  R->cv.wait(lk, [&] { return !R->ready.empty() || R->done; });
+  if (R->ready.empty()) { if (R->err_rc != SQ_OK) { sq_set_error("%s", R->err.c_str()); return R->err_rc; } return SQ_OK; }   // b->n == 0: the end
+  const int si = R->ready.front(); R->ready.pop_front(); sq_dev_reader::Slot& S = R->slots[(size_t)si];
+  b->n = S.n; b->paired = R->paired ? 1 : 0; b->seq = (const uint8_t*)S.d_seq; b->seq_off = (const uint64_t*)S.d_off; b->on_device = 1; *slot = si;
+  return SQ_OK;
+}
+void sq_dev_reader_release(sq_dev_reader* R, int slot) {
+  if (slot < 0 || (size_t)slot >= R->slots.size()) return;
+  { std::lock_guard<std::mutex> lk(R->mu); R->free_slots.push_back(slot); } R->cv.notify_all();
+}
+uint64_t sq_dev_reader_total(const sq_dev_reader* R) { return R->total; }
+void sq_dev_reader_close(sq_dev_reader* R) {
+  if (!R) return;
+  { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
+  if (R->prod.joinable()) R->prod.join();
+  R->pool.reset(); (void)hipSetDevice(R->device);
+  if (R->st) { (void)hipStreamSynchronize(R->st); (void)hipStreamDestroy(R->st); }
+  for (auto& s : R->slots) {
+    for (int i = 0; i < 2; ++i) { if (s.stage[i]) (void)hipHostFree(s.stage[i]); if (s.d_text[i]) (void)hipFree(s.d_text[i]); if (s.d_nlpos[i]) (void)hipFree(s.d_nlpos[i]); if (s.d_start[i]) (void)hipFree(s.d_start[i]); }
+    for (void* p : {s.d_tile, s.d_tbase, s.d_spine, s.d_len, s.d_off, s.d_seq, (void*)s.d_err}) if (p) (void)hipFree(p);
+  }
+  for (auto& sm : R->sm) for (auto& f : sm.files) if (f.fd >= 0) close(f.fd);
+  delete R;
+}

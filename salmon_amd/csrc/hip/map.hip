@@ -50,19 +50,22 @@ static const char* kStageNames[SG_NUM] = {"k_pack", "k_seed", "scan_mems", "k_me
     "scan_cands", "k_join_fill", "k_score",
     "k_dp", "k_select", "compact_alns",
                                           "eq_flags_scan", "eq_mini_batches", "eq_table", "k_finalize", "eq_static"};
-void sq_prof_begin(sq_ctx* c,
-    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
+static hipStream_t prof_stream(sq_ctx* c, int which) { return which == 0 ? c->stream : which == 2 ? c->stream2 : (c->eq_stream_cur ? c->eq_stream_cur : c->stream2); }
+static std::vector<hipEvent_t>& prof_evs(sq_ctx* c, int which) { return which == 0 ? c->prof_ev : which == 2 ? c->prof_ev3 : c->prof_ev2; }
+static std::vector<int>& prof_stgs(sq_ctx* c, int which) { return which == 0 ? c->prof_stage : which == 2 ? c->prof_stage3 : c->prof_stage2; }
+void sq_prof_begin(sq_ctx* c, int which) {
+  if (!c->prof_on) return; auto& ev = prof_evs(c, which); auto& stg = prof_stgs(c, which); hipStream_t st = prof_stream(c, which);
   if (!(which && !stg.empty())) stg.clear();   // eq stages not collected yet keep their marks; a new origin event separates the stages
-  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i],
-      st); stg.push_back(-1); }
-void sq_prof_mark(sq_ctx* c, int stage,
-    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage; hipStream_t st = which ? (c->eq_stream_cur ? c->eq_stream_cur : c->stream2) : c->stream;
-  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i],
-      st); stg.push_back(stage); }
-void sq_prof_end(sq_ctx* c,
-    int which) { if (!c->prof_on) return; auto& ev = which ? c->prof_ev2 : c->prof_ev; auto& stg = which ? c->prof_stage2 : c->prof_stage;
-  for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1],
-      ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } } stg.clear(); }
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(-1); }
+void sq_prof_mark(sq_ctx* c, int stage, int which) {
+  if (!c->prof_on) return; auto& ev = prof_evs(c, which); auto& stg = prof_stgs(c, which); hipStream_t st = prof_stream(c, which);
+  size_t i = stg.size(); if (ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); } hipEventRecord(ev[i], st); stg.push_back(stage); }
+void sq_prof_end(sq_ctx* c, int which) {
+  if (!c->prof_on) return;
+  for (int w = which; w <= (which == 1 ? 2 : which); ++w) {   // the eq stage's two sequences end together
+    auto& ev = prof_evs(c, w); auto& stg = prof_stgs(c, w);
+    for (size_t i = 1; i < stg.size(); ++i) { if (stg[i] < 0) continue; float ms = 0; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { c->stage_ms[stg[i]] += ms; c->stage_calls[stg[i]]++; } }
+    stg.clear(); } }
 extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) {
   if (!c) return SQ_ERR_ARG;
   c->prof_on = on != 0;
@@ -125,7 +128,8 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     // With the mapping kernels on 192 CUs, the 64 keep the eq chain (22 ms per 8·10^6 pairs) off the critical path (24.7 ms).
     hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int ncu = prop.multiProcessorCount;
-    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
+    static const int split = getenv("SQ_EQ_SPLIT") ? atoi(getenv("SQ_EQ_SPLIT")) : 0;   // [r4] ctx.h: only the chain keeps CUs of its own (16 by default)
+    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? (split ? ncu / 16 : ncu / 4) : 0);
     if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
     c->eq_cus = eq_cus;
     if (getenv("SQ_EQ_CHAIN") && ncu >= 64 && !owner) {   // experiment: see ctx.h
@@ -160,6 +164,8 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
       bool ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()) == hipSuccess;
       if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess &&
           hipStreamCreate(&c->stream3) == hipSuccess;
+      if (ok && !owner && split) ok = hipExtStreamCreateWithCUMask(&c->stream_eqt, (uint32_t)m1.size(), m1.data()) == hipSuccess &&
+          hipEventCreateWithFlags(&c->ev_static, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) == hipSuccess;
       if (!ok) {
         (void)hipGetLastError();
         if (c->stream) {
@@ -278,6 +284,8 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
   c->warm_stop();
+  if (c->stream_eqt) { (void)hipStreamSynchronize(c->stream_eqt); (void)hipStreamDestroy(c->stream_eqt); }
+  if (c->ev_static) (void)hipEventDestroy(c->ev_static); if (c->ev_table) (void)hipEventDestroy(c->ev_table);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
 

@@ -37,6 +37,7 @@ struct sq_online_dev {
   sq_dbuf<uint8_t> has_compat;
   struct PreAln;
   sq_dbuf<uint8_t> pre, dyn;   // dyn: DynAln per alignment (the post-burn-in split, k_frag_static -> k_frag_dynamic)
+  sq_dbuf<uint32_t> tbm, tcur, tlist;   // [r4] the transcripts every group of a batch touches (TouchArgs)
   sq_dbuf<double> alp;
   sq_dbuf<uint32_t> assigned_flag;
   sq_dbuf<uint64_t> assigned_prefix;
@@ -638,10 +639,13 @@ __global__ void k_seq_close(uint32_t n, const uint64_t* __restrict__ pref, uint6
 // that for the WHOLE mapped batch in one launch (no mini-batch chain), leaving per kept alignment the two addends the chain still
 // needs: logProb = (transcriptLogCount + auxProb) + startPosProb, in that order.  Same arithmetic, same order as k_mini_batch.
 struct DynAln { double aux, start; uint32_t tid, keep; };   // 24 B
+// [r4] per batch: bm[group][M / 32] bits "transcript seen in this group", cur[group] = entries of the group's list, list = one region per group that
+// starts at the group's first alignment (a group has at most as many distinct transcripts as alignments); gsize = fragments per group (mini-batch size x W)
+struct TouchArgs { uint32_t* bm; uint32_t* cur; uint32_t* list; uint32_t gsize, words; };
 typedef unsigned long long sqk_u64x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts o, uint32_t n, const uint64_t* __restrict__ aln_off,
     const PreAln* __restrict__ pre, unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2,
-    DynAln* __restrict__ dyn) {
+    DynAln* __restrict__ dyn, TouchArgs TA) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t fmtSeen = 0; int compatFrag = 0;
   if (r < n) {
@@ -682,6 +686,18 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
           }
         }
         dyn[ai] = d; abin[ai] = bn;
+        if (TA.bm && d.keep) {   // [r4] the transcripts a group of mini-batches touches, each once: k_apply_dynamic walks this list instead of all M transcripts
+          const uint32_t g = r / TA.gsize; const uint32_t bit = 1u << (p.tid & 31); uint32_t* const word = &TA.bm[(size_t)g * TA.words + (p.tid >> 5)];
+          // a plain look first (most alignments name a transcript its group has seen already); the atomic decides who appends
+          if (!(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) && !(atomicOr(word, bit) & bit)) {
+            // one cursor atomic per wave where the lanes that got here are in the same group (all but the one wave that straddles a group boundary)
+            const unsigned long long act = __ballot(1); const int leader = __ffsll((long long)act) - 1, lane = (int)(threadIdx.x & 63);
+            const uint32_t g0 = (uint32_t)__shfl((int)g, leader, 64); uint32_t at;
+            if (__ballot(g != g0) == 0ull) { uint32_t base = 0; if (lane == leader) base = atomicAdd(&TA.cur[g0], (uint32_t)__popcll(act)); base = (uint32_t)__shfl((int)base, leader, 64); at = base + (uint32_t)__popcll(act & ((1ull << lane) - 1)); }
+            else at = atomicAdd(&TA.cur[g], 1u);
+            TA.list[aln_off[(size_t)g * TA.gsize] + at] = p.tid;
+          }
+        }
       }
       if (nk > 0) {
         const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
@@ -725,8 +741,8 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
 
 // the model-dependent half, one launch per group of W mini-batches (fragments [r0, r1)): logProb from the current transcript masses, the
 // in-order log-sum, and the fixed-point mass increments (+ the observed GC model, which is weighted by the same probabilities).
-// The increments leave as fire-and-forget atomics (nothing waits for their return): the transcripts a group touched are found by
-// k_apply_dynamic's sweep, not by a list.
+// The increments leave as fire-and-forget atomics (nothing waits for their return); the transcripts a group touched were listed by
+// k_frag_static (TouchArgs), or are found by k_apply_dynamic's sweep over all M (SQ_EQ_TOUCHED=0).
 __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0, uint32_t r1, uint32_t mb, const uint64_t* __restrict__ aln_off,
     const DynAln* __restrict__ dyn, const uint8_t* __restrict__ gcbin) {
   const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -760,9 +776,11 @@ __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0,
 // group end after burn-in: one thread per transcript reads its W mass slots (one 64-byte line at W = 8) and, where the group left
 // something, folds the mini-batches' increments in order, each with its own forgetting mass (as apply_mass_part); thread 0 keeps
 // the running count of assigned fragments
-__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1,
+    const uint32_t* __restrict__ tlist, const uint32_t* __restrict__ tcur, const uint64_t* __restrict__ aln_off) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
+  if (tlist) { if (t >= *tcur) return; t = tlist[aln_off[r0] + t]; }   // [r4] the group's own transcripts (k_frag_static listed them) instead of a sweep over all M
   if (t >= V.M) return;
   unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
   if (V.W == 8) {   // the default: the eight slots as four 16-byte loads, held in registers
@@ -1302,7 +1320,7 @@ void sq_online_free(sq_ctx* c) {
   o->log_eff_len.free_();
   o->tlc.free_();
   o->pre.free_();
-  o->alp.free_(); o->dyn.free_(); o->cmeans.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
+  o->alp.free_(); o->dyn.free_(); o->tbm.free_(); o->tcur.free_(); o->tlist.free_(); o->cmeans.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
   o->fm_table.free_();
   o->cfac.free_();
   o->scal.free_();
@@ -1393,6 +1411,7 @@ int sq_eq_sync(sq_ctx* c) {
   mark("worker");
   SQ_HIP_CHECK(hipSetDevice(c->device));
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream2));
+  if (c->stream_eqt) SQ_HIP_CHECK(hipStreamSynchronize(c->stream_eqt));
   mark("stream2");
   if (c->stream3) SQ_HIP_CHECK(hipStreamSynchronize(c->stream3));
   mark("stream3");
@@ -1477,12 +1496,19 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
     if (!c->map_active.load()) st = c->stream3;
   }
-  c->eq_stream_cur = st;
-  if (c->ev_eq_last) SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_last, 0));   // eq jobs run in order even when they change streams
+  // [r4] split layout (ctx.h): `sq` takes the throughput kernels, `st` the chain; before burn-in the generic path is one chain of heavy kernels and
+  // runs wholly on the wide pool.  Without the split (or when no mapping is in flight) both are the same stream and the events below are no-ops.
+  const bool split = c->stream_eqt && st == c->stream2;
+  const bool post_burn = c->online->burned_known && !c->online->detect_active && !getenv("SQ_EQ_SLOW_PATH");
+  hipStream_t sq = split ? c->stream_eqt : st;
+  if (split && !post_burn) st = sq;
+  const bool two = sq != st;
+  c->eq_stream_cur = sq;
+  if (c->ev_eq_last) { SQ_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_eq_last, 0)); if (two) SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_last, 0)); }   // eq jobs run in order even when they change streams
   sq_ctx* src = J.src ? J.src : c;
   const int buf = J.buf; const sq_aln* d_aln = src->aln_ptr(buf); const uint64_t* d_aln_off = src->aln_off_ptr(buf);
   const uint64_t last_total_aln = J.total_aln;
-  SQ_HIP_CHECK(hipStreamWaitEvent(st, src->ev_map_done[buf], 0));   // alignments of this batch are complete
+  SQ_HIP_CHECK(hipStreamWaitEvent(sq, src->ev_map_done[buf], 0));   // alignments of this batch are complete
   const size_t A = (size_t)last_total_aln + 8;
   if (o->awq.ensure(A) || o->abin.ensure(A) || o->alp.ensure(A) || o->pre.ensure(A * sizeof(PreAln)) || (q.gc_bias && o->gcbin.ensure(A)) || (q.pos_bias && o->posbin.ensure(A))) {
     sq_set_error("device allocation failed (online scratch)");
@@ -1492,18 +1518,18 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
   uint8_t* d_gcbin = q.gc_bias ? o->gcbin.p : nullptr;
-  if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, st>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
+  if (last_total_aln) k_pre_aln<<<nblk(last_total_aln), TB, 0, sq>>>(last_total_aln, d_aln, c->di->ref_len, c->di->ref_clen, q,
       (PreAln*)o->pre.p, c->di->refseq, c->di->gcpre, c->di->ref_accum, d_gcbin, o->cmeans.p, q.pos_bias ? o->posbin.p : nullptr, o->lenclass.p);
   // assigned flags + exclusive prefix over the batch (model-independent: SPEC §D1)
-  k_flag_compat<<<nblk(n + 1), TB, 0, st>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
+  k_flag_compat<<<nblk(n + 1), TB, 0, sq>>>(n, 0, d_aln_off, d_aln, q, o->assigned_flag.p);
   if (o->scan_tmp.ensure((size_t)sqk::scan_tiles(n) * 8 + 256)) { sq_set_error("scan spine allocation failed"); return SQ_ERR_NOMEM; }
-  sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, st);
+  sqk::exclusive_scan_u32_u64(o->assigned_flag.p, o->assigned_prefix.p, n, (uint64_t*)o->scan_tmp.p, sq);
   if (q.seq_bias) {   // observed read-start contexts of this batch (order-free integer counts, capped in read order)
     if (o->seq_flag.ensure((size_t)n + 2) || o->seq_pref.ensure((size_t)n + 2) || o->seq_code.ensure((size_t)n + 2)) { sq_set_error("device allocation failed (sequence-bias samples)"); return SQ_ERR_NOMEM; }
-    k_seq_pick<<<nblk(n + 1), TB, 0, st>>>(n, q.lib_type == 1 ? 1 : 0, c->reads_seen, q.seed, d_aln_off, d_aln, c->di->ref_len, c->di->refseq, c->di->ref_accum, o->seq_flag.p, o->seq_code.p);
-    sqk::exclusive_scan_u32_u64(o->seq_flag.p, o->seq_pref.p, n, (uint64_t*)o->scan_tmp.p, st);
-    k_seq_count<<<nblk(n), TB, 0, st>>>(n, o->seq_flag.p, o->seq_pref.p, o->seq_code.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
-    k_seq_close<<<1, 64, 0, st>>>(n, o->seq_pref.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
+    k_seq_pick<<<nblk(n + 1), TB, 0, sq>>>(n, q.lib_type == 1 ? 1 : 0, c->reads_seen, q.seed, d_aln_off, d_aln, c->di->ref_len, c->di->refseq, c->di->ref_accum, o->seq_flag.p, o->seq_code.p);
+    sqk::exclusive_scan_u32_u64(o->seq_flag.p, o->seq_pref.p, n, (uint64_t*)o->scan_tmp.p, sq);
+    k_seq_count<<<nblk(n), TB, 0, sq>>>(n, o->seq_flag.p, o->seq_pref.p, o->seq_code.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
+    k_seq_close<<<1, 64, 0, sq>>>(n, o->seq_pref.p, (uint64_t)q.num_bias_samples, o->seq_obs.p);
   }
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
@@ -1512,8 +1538,17 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     // [r3] burned in: one model-independent launch over the whole batch, then per group of W mini-batches only the mass terms
     // (k_frag_dynamic) and their application (k_apply_dynamic).  Nothing comes back to the host.
     if (o->dyn.ensure(A * sizeof(DynAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
-    k_frag_static<<<nblk(n), 256, 0, st>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p);
+    static const int use_touched = getenv("SQ_EQ_TOUCHED") ? atoi(getenv("SQ_EQ_TOUCHED")) : 1;
+    TouchArgs TA{nullptr, nullptr, nullptr, mb * o->inflight, (o->M + 31) / 32};
+    if (use_touched && !c->stream_chain) {
+      const uint32_t ngrp = (n + TA.gsize - 1) / TA.gsize;
+      if (o->tbm.ensure((size_t)ngrp * TA.words + 8) || o->tcur.ensure(ngrp + 8) || o->tlist.ensure(A)) { sq_set_error("device allocation failed (touched lists)"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemsetAsync(o->tbm.p, 0, (size_t)ngrp * TA.words * 4, sq)); SQ_HIP_CHECK(hipMemsetAsync(o->tcur.p, 0, (size_t)ngrp * 4, sq));
+      TA.bm = o->tbm.p; TA.cur = o->tcur.p; TA.list = o->tlist.p;
+    }
+    k_frag_static<<<nblk(n), 256, 0, sq>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p, TA);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
+    if (two) { SQ_HIP_CHECK(hipEventRecord(c->ev_static, sq)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_static, 0)); sq_prof_begin(c, 2); }   // the chain starts when the static records are there
     const uint32_t W = o->inflight;
     if (c->stream_chain && nmb) {   // [r3, SQ_EQ_CHAIN=1] the whole chain of the batch as one resident kernel on its own XCD
       (void)forgetting_mass(o, q.forgetting_factor, o->batch_no + nmb);   // the schedule up to this batch's last mini-batch
@@ -1538,9 +1573,10 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
       const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
       k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin);
-      k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1);
+      k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.list, TA.cur ? TA.cur + b0 / W : nullptr, d_aln_off);
       o->group_no++; if (c->prof_on) c->eq_groups++;
     }
+    if (two) sq_prof_mark(c, SG_EQ_MINIBATCH, 2);
   } else {
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   std::vector<uint64_t> bound(nmb + 1);
@@ -1618,12 +1654,13 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   }
   if (burned_host) o->burned_known = true;
   }
-  sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
-  // eq-class table: insert labels, then add counts / fixed-point weights
+  if (!two) sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
+  // eq-class table: insert labels, then add counts / fixed-point weights (labels, bins and weights are the static stage's: on the throughput stream, beside the chain)
   EqView T = make_eq_view(o);
-  k_eq_insert<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
-  k_eq_add<<<nblk(n), TB, 0, st>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
+  k_eq_insert<<<nblk(n), TB, 0, sq>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
+  k_eq_add<<<nblk(n), TB, 0, sq>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
   sq_prof_mark(c, SG_EQ_TABLE, 1);
+  if (two) { SQ_HIP_CHECK(hipEventRecord(c->ev_table, sq)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_table, 0)); }   // the job is done when both parts are
   SQ_HIP_CHECK(hipEventRecord(src->ev_eq_done[buf], st)); c->ev_eq_last = src->ev_eq_done[buf];
   mark("chain-launches");
   o->num_observed += n; o->num_mapped_ub += J.joint; c->reads_seen += n;

@@ -18,6 +18,7 @@
 // interleaved batch in the page-locked slot with the same pool (per-part byte totals, a scan, parallel copies): one copy per base from
 // the page cache to the buffer the GPU reads.  FASTA, multi-line records and SQ_READER_SAFE=1 take the kseq-rules path below.
 #include "index.h"
+#include "reader_dev.h"
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -486,6 +487,7 @@ void host_free(void* p, bool pinned) { if (!p) return; if (pinned) (void)hipHost
 }  // namespace
 
 struct sq_reader {
+  sq_dev_reader* dev = nullptr;   // [r4] plain 4-line FASTQ files with a device present: the records are split on the GPU (hip/fastq_dev.hip); everything below is then unused
   bool paired = false, keep_names = false; uint32_t batch = 0; BlockQueue q[2]; std::thread th[2];
   // fast path
   bool fast = false; std::unique_ptr<Pool> pool; ChunkQueue cq[2]; std::shared_ptr<Chunk> fc[2]; size_t fidx[2] = {0, 0}; bool fend[2] = {false, false};
@@ -520,6 +522,7 @@ struct sq_reader {
   std::unique_ptr<RecBlock> cur[2]; size_t cur_rec[2] = {0, 0}, cur_byte[2] = {0, 0}, cur_nbyte[2] = {0, 0};
   std::vector<Slot> slots; uint64_t total = 0; bool ended = false;
   ~sq_reader() {
+    if (dev) sq_dev_reader_close(dev);
     for (int i = 0; i < 2; ++i) { q[i].finish(); cq[i].finish(); if (th[i].joinable()) th[i].join(); }
     pool.reset();   // after the stream threads: no more tasks are submitted
     for (auto& s : slots) { host_free(s.seq, s.pinned); host_free(s.off, s.off_pinned); }
@@ -565,6 +568,18 @@ extern "C" int sq_reader_open_ex(const char* const* files1, uint32_t n1, const c
     if (n > 0 && !looks_like_simple_fastq(head.data(), (size_t)n)) { fast = false; break; }
   }
   R->fast = fast;
+  // [r4] device-side record splitting: plain (not gzip) regular 4-line FASTQ files, no read names wanted, a device present, SQ_READER_DEVICE != 0
+  bool plain = fast && !kn && !(getenv("SQ_READER_DEVICE") && atoi(getenv("SQ_READER_DEVICE")) == 0);
+  for (int st = 0; st < 2 && plain; ++st) for (const auto& path : (st ? b : a)) {
+    unsigned char mg[2] = {0, 0}; FILE* f = fopen(path.c_str(), "rb"); if (!f) { plain = false; break; }
+    const size_t got = fread(mg, 1, 2, f); fclose(f); if (got == 2 && mg[0] == 0x1f && mg[1] == 0x8b) { plain = false; break; }
+  }
+  if (plain) {
+    const int rc = sq_dev_reader_open(a, b, batch_reads, (uint32_t)R->slots.size(), &R->dev);
+    if (rc == SQ_OK) { *out = R.release(); return SQ_OK; }
+    if (rc != SQ_ERR_DEVICE) return rc;   // no device: the host path below
+    R->dev = nullptr;
+  }
   if (fast) {
     unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 2));
     R->pool.reset(new Pool(std::max(1u, nt)));
@@ -588,6 +603,7 @@ extern "C" int sq_reader_open(const char* const* files1, uint32_t n1, const char
 extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
   if (!R || !b || !slot) { sq_set_error("sq_reader_next: bad arguments"); return SQ_ERR_ARG; }
   memset(b, 0, sizeof(*b)); *slot = -1; b->paired = R->paired ? 1 : 0;
+  if (R->dev) return sq_dev_reader_next(R->dev, b, slot);
   if (R->ended) return SQ_OK;
   int si = -1; for (size_t i = 0; i < R->slots.size(); ++i) if (!R->slots[i].busy) { si = (int)i; break; }
   if (si < 0) {
@@ -698,6 +714,7 @@ extern "C" int sq_reader_next(sq_reader* R, sq_read_batch* b, int* slot) {
   return SQ_OK;
 }
 extern "C" void sq_reader_release(sq_reader* R, int slot) {
+  if (R && R->dev) { sq_dev_reader_release(R->dev, slot); return; }
   if (R && slot >= 0 && (size_t)slot < R->slots.size()) R->slots[(size_t)slot].busy = false;
 }
 // names of the batch in `slot` (reader opened with SQ_READER_KEEP_NAMES): name i = names[name_off[i] .. name_off[i+1])
@@ -706,5 +723,5 @@ extern "C" int sq_reader_names(const sq_reader* R, int slot, const char** names,
   if (!R->keep_names) { sq_set_error("sq_reader_names: the reader was opened without SQ_READER_KEEP_NAMES"); return SQ_ERR_STATE; }
   const Slot& S = R->slots[(size_t)slot]; *names = S.names.data(); *name_off = S.name_off.data(); return SQ_OK;
 }
-extern "C" uint64_t sq_reader_total(const sq_reader* R) { return R ? R->total : 0; }
+extern "C" uint64_t sq_reader_total(const sq_reader* R) { return R ? (R->dev ? sq_dev_reader_total(R->dev) : R->total) : 0; }
 extern "C" void sq_reader_close(sq_reader* R) { delete R; }

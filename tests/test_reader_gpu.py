@@ -1,0 +1,122 @@
+"""[r4] FASTQ record splitting on the device (hip/fastq_dev.hip) against the host reader (host/reader.cpp, SQ_READER_DEVICE=0) on the same files:
+the same batches, byte for byte — ragged read lengths, CR LF line ends, a last line without a newline, several files per mate, single-end input,
+batches that end inside a file — and the same complaints about damaged input."""
+import ctypes as C, os
+import numpy as np
+import pytest
+from salmon_amd import api, capi
+
+pytestmark = pytest.mark.gpu
+HIP = None
+
+
+def _d2h(ptr, nbytes):
+    global HIP
+    if HIP is None: HIP = C.CDLL("libamdhip64.so"); HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    buf = np.zeros(max(nbytes, 1), np.uint8); assert HIP.hipMemcpy(buf.ctypes.data, ptr, nbytes, 2) == 0; return buf[:nbytes]
+
+
+def _drain(files1, files2, batch, device):
+    """All batches of a reader as (seq bytes, offsets) pairs; device batches are copied back to the host."""
+    os.environ["SQ_READER_DEVICE"] = "1" if device else "0"
+    L = capi.lib(); a1 = (C.c_char_p * len(files1))(*[f.encode() for f in files1]); h = C.c_void_p()
+    a2 = (C.c_char_p * len(files2))(*[f.encode() for f in files2]) if files2 else None
+    capi.check(L.sq_reader_open(a1, len(files1), a2, len(files2) if files2 else 0, batch, 3, C.byref(h)), "sq_reader_open")
+    out = []
+    try:
+        while True:
+            rb = capi.ReadBatch(); s = C.c_int(-1)
+            capi.check(L.sq_reader_next(h, C.byref(rb), C.byref(s)), "sq_reader_next")
+            if rb.n == 0: break
+            nrec = rb.n * (2 if rb.paired else 1)
+            if rb.on_device:
+                off = _d2h(rb.seq_off, (nrec + 1) * 8).view(np.uint64).copy(); seq = _d2h(rb.seq, int(off[-1])).copy()
+            else:
+                off = np.ctypeslib.as_array(C.cast(rb.seq_off, C.POINTER(C.c_uint64)), shape=(nrec + 1,)).copy()
+                seq = np.ctypeslib.as_array(C.cast(rb.seq, C.POINTER(C.c_uint8)), shape=(int(off[-1]),)).copy()
+            out.append((int(rb.n), bool(rb.on_device), seq, off)); L.sq_reader_release(h, s.value)
+    finally:
+        L.sq_reader_close(h); os.environ.pop("SQ_READER_DEVICE", None)
+    return out
+
+
+def _write(path, recs, eol="\n", last_newline=True):
+    body = eol.join("@%s%s%s%s+%s%s" % (n, eol, s, eol, eol, q) for n, s, q in recs) + (eol if last_newline else "")
+    open(path, "wb").write(body.encode())
+
+
+def _recs(rng, n, tag, lo=30, hi=151):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi)); s = "".join(rng.choice(list("ACGTN"), L, p=[0.24, 0.24, 0.24, 0.24, 0.04])); q = "".join(chr(int(x)) for x in rng.integers(33, 74, L))
+        out.append(("%s.%d some comment@+" % (tag, i), s, q))      # '@' and '+' inside the header line must not confuse the splitter
+    return out
+
+
+def test_device_batches_equal_host_batches(built, tmp_path):
+    rng = np.random.default_rng(8)
+    r1 = _recs(rng, 23456, "a"); r2 = _recs(rng, 23456, "b")
+    cases = []
+    f1, f2 = str(tmp_path / "p_1.fq"), str(tmp_path / "p_2.fq"); _write(f1, r1); _write(f2, r2); cases.append(("paired", [f1], [f2], 5000))
+    g1, g2 = str(tmp_path / "c_1.fq"), str(tmp_path / "c_2.fq"); _write(g1, r1, eol="\r\n"); _write(g2, r2, eol="\r\n", last_newline=False); cases.append(("CR LF, no last newline", [g1], [g2], 7777))
+    # several files per mate: the first of each lacks its last newline; batches straddle the file boundary
+    h = [str(tmp_path / ("m%d_%d.fq" % (k, m))) for k in range(3) for m in (1, 2)]
+    cuts = [0, 9000, 9001, 23456]
+    for k in range(3): _write(h[2 * k], r1[cuts[k]:cuts[k + 1]], last_newline=(k != 0)); _write(h[2 * k + 1], r2[cuts[k]:cuts[k + 1]], last_newline=(k != 0))
+    cases.append(("three files per mate", h[0::2], h[1::2], 4096))
+    cases.append(("single-end", [f1], None, 6000))
+    cases.append(("one batch holds everything", [f1], [f2], 30000))
+    for name, a, b, batch in cases:
+        dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
+        assert all(d[1] for d in dev) and not any(x[1] for x in host), name          # the device path really ran, the host path really did not
+        assert [d[0] for d in dev] == [x[0] for x in host], name
+        for d, x in zip(dev, host):
+            assert np.array_equal(d[3], x[3]) and d[2].tobytes() == x[2].tobytes(), name
+    # and the batches are what the files say
+    dev = _drain([f1], [f2], 5000, True); i = 0
+    for n, _, seq, off in dev:
+        for r in range(n):
+            assert seq[int(off[2 * r]):int(off[2 * r + 1])].tobytes().decode() == r1[i][1] and seq[int(off[2 * r + 1]):int(off[2 * r + 2])].tobytes().decode() == r2[i][1]; i += 1
+    assert i == 23456
+
+
+def test_device_reader_feeds_the_mapper_and_reports_damage(small_world, tmp_path):
+    w = small_world; w["idx"].to_device(0)
+    recs = w["seq"].reshape(2 * w["n"], 100)
+    def fq(path, rows):
+        with open(path, "wb") as f:
+            for i, r in enumerate(rows): f.write(b"@r%d\n" % i + r.tobytes() + b"\n+\n" + b"I" * 100 + b"\n")
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq"); fq(f1, recs[0::2]); fq(f2, recs[1::2])
+    ctx = api.QuantContext(w["idx"], api.quant_opts(), device=0, max_batch_reads=4096)
+    ro_ref, aln_ref, _, _ = ctx.map_batch(api.make_read_batch(w["seq"], w["off"], w["n"], paired=True))
+    os.environ["SQ_READER_DEVICE"] = "1"
+    L = capi.lib(); a1 = (C.c_char_p * 1)(f1.encode()); a2 = (C.c_char_p * 1)(f2.encode()); h = C.c_void_p()
+    capi.check(L.sq_reader_open(a1, 1, a2, 1, 1500, 3, C.byref(h)), "sq_reader_open")
+    got = []; tot = 0
+    while True:
+        rb = capi.ReadBatch(); s = C.c_int(-1); capi.check(L.sq_reader_next(h, C.byref(rb), C.byref(s)), "sq_reader_next")
+        if rb.n == 0: break
+        assert rb.on_device == 1
+        ro, aln, _, _ = ctx.map_batch(rb); got.append(aln); tot += rb.n; L.sq_reader_release(h, s.value)
+    assert L.sq_reader_total(h) == w["n"] == tot
+    L.sq_reader_close(h)
+    assert np.concatenate(got).tobytes() == aln_ref.tobytes()                      # batches cut from device-split text map like the in-memory reads
+    # damage: a record without its '+' line, a truncated last record, mate files of different lengths
+    bad = str(tmp_path / "bad.fq"); txt = open(f1, "rb").read().split(b"\n"); txt[4 * 700 + 2] = b"-"; open(bad, "wb").write(b"\n".join(txt))
+    for files, msg in (((bad, f2), "no '\\+' line"), ((f1, None), None)):
+        pass
+    def first_error(p1, p2):
+        a1 = (C.c_char_p * 1)(p1.encode()); a2 = (C.c_char_p * 1)(p2.encode()); h = C.c_void_p(); capi.check(L.sq_reader_open(a1, 1, a2, 1, 1500, 3, C.byref(h)), "open")
+        try:
+            while True:
+                rb = capi.ReadBatch(); s = C.c_int(-1); rc = L.sq_reader_next(h, C.byref(rb), C.byref(s))
+                if rc != 0: return L.sq_last_error().decode()
+                if rb.n == 0: return None
+                L.sq_reader_release(h, s.value)
+        finally: L.sq_reader_close(h)
+    e = first_error(bad, f2); assert e and "record 701" in e and "'+'" in e, e
+    trunc = str(tmp_path / "trunc.fq"); open(trunc, "wb").write(open(f1, "rb").read()[:-150])
+    e = first_error(trunc, f2); assert e and ("middle of a record" in e or "different numbers" in e or "quality" in e), e
+    short = str(tmp_path / "short.fq"); fq(short, recs[0::2][:3000])
+    e = first_error(short, f2); assert e and "different numbers of records" in e, e
+    os.environ.pop("SQ_READER_DEVICE", None); ctx.free()

@@ -1,6 +1,13 @@
 // tools/host_sanitize.cpp — drives the HOST side of the library (index builder + dictionary, read pipeline,
 // normalizeAlphas with its lock-free union-find, the file writers / readers) so that it can be run under
 // AddressSanitizer + UBSan and under ThreadSanitizer:  make -C tools sanitize   (g++ only, no GPU).
+// the device-side FASTQ splitter lives in a .hip file: this host-only build has none and says "no device" (reader.cpp then keeps its own path)
+#include "../salmon_amd/csrc/host/reader_dev.h"
+int sq_dev_reader_open(const std::vector<std::string>&, const std::vector<std::string>&, uint32_t, uint32_t, sq_dev_reader**) { return SQ_ERR_DEVICE; }
+int sq_dev_reader_next(sq_dev_reader*, sq_read_batch*, int*) { return SQ_ERR_DEVICE; }
+void sq_dev_reader_release(sq_dev_reader*, int) {}
+uint64_t sq_dev_reader_total(const sq_dev_reader*) { return 0; }
+void sq_dev_reader_close(sq_dev_reader*) {}
 #include "../include/salmon_hip.h"
 #include <zlib.h>
 #include <cstdio>
