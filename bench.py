@@ -122,7 +122,7 @@ def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
     lanes = 2
     lib.sq_ctx_set_lanes(ctx.h, lanes)
     t0 = time.perf_counter()
-    capi.check(lib.sq_reader_open(a1, 1, a2, 1, batch, lanes + 1, C.byref(h)), "sq_reader_open")
+    capi.check(lib.sq_reader_open(a1, 1, a2, 1, batch, lanes + 3, C.byref(h)), "sq_reader_open")   # one slot staging, two uploading, one per mapping lane
     inflight = []; n = 0; tot_mapped = 0
     def finish_one():
         nonlocal tot_mapped
@@ -152,7 +152,8 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
     d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n_pairs, read_len, batch), "host_threads": os.cpu_count(),
            "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
-           "what": "end to end from files through sq_reader (mmap + parallel record split + page-locked batch assembly), H2D included"}
+           "what": "end to end from files through sq_reader, H2D included; plain files: text staged in page-locked memory, records split on the device "
+                   "(hip/fastq_dev.hip); gzip/BGZF: inflated and split on the host (host/reader.cpp, host/pgzip.cpp)"}
     try:
         seq, off, _, _ = tx.reads(n_pairs, read_len=read_len, seed=77, first_pair=0, threads=threads, truth=False)
         recs = seq.reshape(2 * n_pairs, read_len)

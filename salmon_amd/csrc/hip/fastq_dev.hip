@@ -10,7 +10,8 @@
 //   k_fq_records  record r = lines 4r .. 4r+3: '@' / sequence / '+' / quality of the same length (CR stripped), length + start of the sequence
 //   scan          read offsets of the interleaved batch (mate 1, mate 2, mate 1, ...)
 //   k_fq_copy     the bases into the compact buffer sq_map_batch takes (on_device = 1)
-// A producer thread keeps the slots filled, so staging / H2D / splitting of batch b + 1 overlap the mapping of batch b.  Plain, regular, 4-line
+// Two producer threads keep the slots filled: one stages text (parallel pread into page-locked memory + newline counts), one uploads and splits
+// (two batches in flight, each slot on its own stream), so staging of batch b + 2, H2D of b + 1 and the kernels of b overlap each other and the mapping.  Plain, regular, 4-line
 // FASTQ files only; anything else (gzip, FASTA, wrapped records, FIFOs, read names wanted) stays on the host path.  Replaces, for such input, the
 // reference's FastxParser producer threads (include/salmon/internal/io/FastxReader.hpp:13-32, SalmonQuantify.cpp:2419-2443).
 #include <hip/hip_runtime.h>
@@ -19,6 +20,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <memory>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -71,11 +75,16 @@ __global__ void k_fq_records(const uint8_t* __restrict__ text, const uint32_t* _
   len[(size_t)r * stride + mate] = e1 - s1; start[r] = s1;
 }
 __global__ void k_fq_copy(const uint8_t* __restrict__ text, const uint32_t* __restrict__ start, const uint64_t* __restrict__ off, uint32_t n, uint32_t mate, uint32_t stride,
-                          uint8_t* __restrict__ seq) {
+                          uint8_t* __restrict__ seq, const unsigned* __restrict__ err) {
   // a group of 8 lanes per record: 8 consecutive bytes per trip (a record's bases are contiguous in the text and in the batch)
+  if (err[0] != 0xFFFFFFFFu) return;   // a damaged record: its "lengths" mean nothing (and the batch buffer is sized for sound records); the host reports it
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7; if (g >= n) return;
   const uint64_t o0 = off[(size_t)g * stride + mate], o1 = off[(size_t)g * stride + mate + 1]; const uint32_t L = (uint32_t)(o1 - o0); const uint8_t* s = text + start[g]; uint8_t* d = seq + o0;
   for (uint32_t j = l; j < L; j += 8) d[j] = s[j];
+}
+
+__global__ void k_fq_pad(const uint64_t* __restrict__ off, uint32_t nrec, uint8_t* __restrict__ seq, const unsigned* __restrict__ err) {   // 16 zero bytes behind the last base
+  if (err[0] == 0xFFFFFFFFu && threadIdx.x < 16) seq[off[nrec] + threadIdx.x] = 0;
 }
 
 struct Workers {   // a few threads for pread + newline counting
@@ -93,7 +102,7 @@ inline uint64_t count_nl(const char* p, size_t n) {
 }  // namespace
 
 struct sq_dev_reader {
-  int device = 0; hipStream_t st = nullptr; uint32_t batch = 0; bool paired = false;
+  int device = 0; uint32_t batch = 0; bool paired = false;
   // a mate stream = its files end to end; a file that does not end with a newline gets one (pad = 1), so records never straddle files
   struct File { std::string path; int fd = -1; uint64_t size = 0, vbase = 0; uint32_t pad = 0; };
   struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; } sm[2];
@@ -104,13 +113,16 @@ struct sq_dev_reader {
     void* d_start[2] = {nullptr, nullptr}; size_t start_cap[2] = {0, 0};
     void* d_tile = nullptr; size_t tile_cap = 0; void* d_tbase = nullptr; size_t tbase_cap = 0; void* d_spine = nullptr; size_t spine_cap = 0;
     void* d_len = nullptr; size_t len_cap = 0; void* d_off = nullptr; size_t off_cap = 0;
-    void* d_seq = nullptr; size_t seq_cap = 0; unsigned* d_err = nullptr;
-    uint32_t n = 0;
+    void* d_seq = nullptr; size_t seq_cap = 0; unsigned* d_err = nullptr; unsigned* h_res = nullptr; hipStream_t st = nullptr;
+    uint32_t n = 0; size_t bytes[2] = {0, 0};
   };
   std::vector<Slot> slots;
   std::unique_ptr<Workers> pool;
-  // producer <-> consumer
-  std::thread prod; std::mutex mu; std::condition_variable cv; std::deque<int> ready, free_slots; bool stop = false, done = false; std::string err; int err_rc = SQ_OK; uint64_t total = 0;
+  // two producers (staging the text of batch k+1 in page-locked memory overlaps the upload and the kernels of batch k) <-> the consumer:
+  // a slot goes free -> staged -> ready -> (sq_reader_release) free
+  std::thread prod, prod2; std::mutex mu; std::condition_variable cv; std::deque<int> ready, staged, free_slots; bool stop = false, stage_done = false, done = false;
+  std::string err; int err_rc = SQ_OK; uint64_t total = 0, staged_total = 0;
+  double t_stage = 0, t_upload = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
 
   static int dev_grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
@@ -174,20 +186,27 @@ struct sq_dev_reader {
     if (*got) S.est = 0.7 * S.est + 0.3 * ((double)cut / (double)*got);
     return true;
   }
-  int fill(Slot& s, std::string* e) {
-    uint32_t n[2] = {0, 0}; size_t bytes[2] = {0, 0};
+  int stage(Slot& s, std::string* e) {
+    uint32_t n[2] = {0, 0}; size_t* bytes = s.bytes; bytes[0] = bytes[1] = 0;
     if (!stage_text(0, s, batch, &n[0], &bytes[0], e)) return SQ_ERR_IO;
     if (paired) {
       if (!stage_text(1, s, n[0] ? n[0] : 1u, &n[1], &bytes[1], e)) return SQ_ERR_IO;   // (one record is asked for at the end: has the second file more than the first?)
-      if (n[0] != n[1]) { *e = "mate files have different numbers of records (stopped after " + std::to_string(total + std::min(n[0], n[1])) + " pairs)"; return SQ_ERR_IO; }
+      if (n[0] != n[1]) { *e = "mate files have different numbers of records (stopped after " + std::to_string(staged_total + std::min(n[0], n[1])) + " pairs)"; return SQ_ERR_IO; }
     }
-    s.n = n[0]; if (s.n == 0) return SQ_OK;
+    s.n = n[0];
+    for (int i = 0; i < (paired ? 2 : 1); ++i) if (bytes[i] >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(s.n) + " records spans more than 4 GB of text: use a smaller batch"; return SQ_ERR_ARG; }
+    return SQ_OK;
+  }
+  // the device half of a batch, asynchronous on the slot's own stream: nothing here waits (the sequence buffer is sized by the text, which is
+  // more than twice the sequence bytes: a record is '@' + name + sequence + '+' + a quality string as long as the sequence + 4 line ends)
+  int issue(Slot& s, std::string* e) {
+    const size_t* bytes = s.bytes; hipStream_t st = s.st;
     const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns; const uint32_t nrec = s.n * stride;
-    for (int i = 0; i < ns; ++i) if (bytes[i] >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(s.n) + " records spans more than 4 GB of text: use a smaller batch"; return SQ_ERR_ARG; }
     if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
-    if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8)) { *e = "device allocation failed (reader offsets)"; return SQ_ERR_NOMEM; }
-    unsigned herr[4] = {0xFFFFFFFFu, 0, 0, 0};
-    if (hipMemcpyAsync(s.d_err, herr, 16, hipMemcpyHostToDevice, st) != hipSuccess) { *e = "device copy failed (reader)"; return SQ_ERR_DEVICE; }
+    if (!s.h_res && hipHostMalloc((void**)&s.h_res, 64, hipHostMallocDefault) != hipSuccess) { *e = "page-locked allocation failed (reader)"; return SQ_ERR_NOMEM; }
+    if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8) ||
+        dev_grow(&s.d_seq, &s.seq_cap, (bytes[0] + bytes[1]) / 2 + 64)) { *e = "device allocation failed (reader offsets)"; return SQ_ERR_NOMEM; }
+    if (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
     for (int i = 0; i < ns; ++i) {
       const size_t padded = (bytes[i] + 15) & ~(size_t)15; memset(s.stage[i] + bytes[i], 0, padded - bytes[i] + 16);
       const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
@@ -201,29 +220,50 @@ struct sq_dev_reader {
       k_fq_records<<<(s.n + 255) / 256, 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_nlpos[i], s.n, (uint32_t)i, stride, (uint32_t*)s.d_len, (uint32_t*)s.d_start[i], s.d_err);
     }
     sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_len, (uint64_t*)s.d_off, nrec, (uint64_t*)s.d_spine, st);
-    uint64_t tot_bytes = 0;
-    if (hipMemcpyAsync(&tot_bytes, (uint64_t*)s.d_off + nrec, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(herr, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    for (int i = 0; i < ns; ++i) k_fq_copy<<<(uint32_t)(((uint64_t)s.n * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_start[i], (const uint64_t*)s.d_off, s.n, (uint32_t)i, stride, (uint8_t*)s.d_seq, s.d_err);
+    k_fq_pad<<<1, 64, 0, st>>>((const uint64_t*)s.d_off, nrec, (uint8_t*)s.d_seq, s.d_err);
+    if (hipMemcpyAsync(s.h_res, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    return SQ_OK;
+  }
+  int finish(Slot& s, std::string* e) {
+    if (hipStreamSynchronize(s.st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    const unsigned* herr = s.h_res;
     if (herr[0] != 0xFFFFFFFFu) {
       const unsigned what = herr[1] ? herr[1] : herr[2];
       *e = "record " + std::to_string(total + herr[0]) + (what == 1 ? " does not start with '@'" : what == 2 ? " has no '+' line after one sequence line" : " has a quality string whose length differs from its sequence's") +
            " (multi-line FASTQ? set SQ_READER_DEVICE=0)"; return SQ_ERR_IO; }
-    if (dev_grow(&s.d_seq, &s.seq_cap, tot_bytes + 64)) { *e = "device allocation failed (reader sequences)"; return SQ_ERR_NOMEM; }
-    for (int i = 0; i < ns; ++i) k_fq_copy<<<(uint32_t)(((uint64_t)s.n * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_start[i], (const uint64_t*)s.d_off, s.n, (uint32_t)i, stride, (uint8_t*)s.d_seq);
-    (void)hipMemsetAsync((uint8_t*)s.d_seq + tot_bytes, 0, 16, st);
-    if (hipStreamSynchronize(st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
     return SQ_OK;
   }
-  void produce() {
-    (void)hipSetDevice(device);
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void produce_stage() {
     for (;;) {
       int si = -1;
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_slots.empty(); }); if (stop) return; si = free_slots.front(); free_slots.pop_front(); }
-      std::string e; const int rc = fill(slots[(size_t)si], &e);
-      std::lock_guard<std::mutex> lk(mu);
-      if (rc != SQ_OK) { err = e; err_rc = rc; done = true; cv.notify_all(); return; }
-      if (slots[(size_t)si].n == 0) { done = true; free_slots.push_back(si); cv.notify_all(); return; }
-      total += slots[(size_t)si].n; ready.push_back(si); cv.notify_all();
+      std::string e; const double t0 = now(); const int rc = stage(slots[(size_t)si], &e); const double dt = now() - t0;
+      std::lock_guard<std::mutex> lk(mu); t_stage += dt;
+      if (rc != SQ_OK) { err = e; err_rc = rc; stage_done = true; cv.notify_all(); return; }
+      if (slots[(size_t)si].n == 0) { stage_done = true; free_slots.push_back(si); cv.notify_all(); return; }
+      staged_total += slots[(size_t)si].n; text_bytes += slots[(size_t)si].bytes[0] + slots[(size_t)si].bytes[1]; staged.push_back(si); cv.notify_all();
+    }
+  }
+  void produce_upload() {   // up to two batches in flight on the device side: the kernels and the host's wait for batch k overlap the upload of batch k + 1
+    (void)hipSetDevice(device);
+    std::deque<int> pending;
+    for (;;) {
+      int take = -1;
+      { std::unique_lock<std::mutex> lk(mu);
+        if (pending.empty()) cv.wait(lk, [&] { return stop || !staged.empty() || stage_done; });
+        if (stop) return;
+        if (!staged.empty() && pending.size() < 2) { take = staged.front(); staged.pop_front(); }
+        else if (pending.empty()) { done = true; cv.notify_all(); return; }   // the end of the input, or the stager's complaint (err_rc) once everything before it has gone out
+      }
+      std::string e; const double t0 = now(); int rc, si;
+      if (take >= 0) { si = take; rc = issue(slots[(size_t)si], &e); if (rc == SQ_OK) pending.push_back(si); }
+      else { si = pending.front(); pending.pop_front(); rc = finish(slots[(size_t)si], &e); }
+      const double dt = now() - t0;
+      std::lock_guard<std::mutex> lk(mu); t_upload += dt;
+      if (rc != SQ_OK) { for (int p : pending) (void)hipStreamSynchronize(slots[(size_t)p].st); err = e; err_rc = rc; done = true; cv.notify_all(); return; }
+      if (take < 0) { total += slots[(size_t)si].n; ready.push_back(si); cv.notify_all(); }
     }
   }
 };
@@ -243,12 +283,13 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
     }
     R->sm[i].vsize = v;
   }
-  if (hipStreamCreateWithFlags(&R->st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); for (auto& s : R->sm) for (auto& f : s.files) close(f.fd); return SQ_ERR_DEVICE; }
   R->slots.resize(nslots < 2 ? 2 : (nslots > 8 ? 8 : nslots));
+  for (auto& s : R->slots) if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError(); for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd); return SQ_ERR_DEVICE; }
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
-  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
+  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 4));
   R->pool.reset(new Workers(std::max(1u, nt)));
-  sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce(); });
+  sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); });
   *out = r; return SQ_OK;
 }
 int sq_dev_reader_next(sq_dev_reader* R, sq_read_batch* b, int* slot) {
@@ -268,9 +309,13 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   if (!R) return;
   { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
   if (R->prod.joinable()) R->prod.join();
+  if (R->prod2.joinable()) R->prod2.join();
+  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total, (double)R->text_bytes / 1e9,
+      R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
   R->pool.reset(); (void)hipSetDevice(R->device);
-  if (R->st) { (void)hipStreamSynchronize(R->st); (void)hipStreamDestroy(R->st); }
   for (auto& s : R->slots) {
+    if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
+    if (s.h_res) (void)hipHostFree(s.h_res);
     for (int i = 0; i < 2; ++i) { if (s.stage[i]) (void)hipHostFree(s.stage[i]); if (s.d_text[i]) (void)hipFree(s.d_text[i]); if (s.d_nlpos[i]) (void)hipFree(s.d_nlpos[i]); if (s.d_start[i]) (void)hipFree(s.d_start[i]); }
     for (void* p : {s.d_tile, s.d_tbase, s.d_spine, s.d_len, s.d_off, s.d_seq, (void*)s.d_err}) if (p) (void)hipFree(p);
   }

@@ -37,7 +37,7 @@ struct sq_online_dev {
   sq_dbuf<uint8_t> has_compat;
   struct PreAln;
   sq_dbuf<uint8_t> pre, dyn;   // dyn: DynAln per alignment (the post-burn-in split, k_frag_static -> k_frag_dynamic)
-  sq_dbuf<uint32_t> tbm, tcur, tlist;   // [r4] the transcripts every group of a batch touches (TouchArgs)
+  sq_dbuf<uint8_t> gflag;   // [r4] the transcripts every group of a batch touches (TouchArgs)
   sq_dbuf<double> alp;
   sq_dbuf<uint32_t> assigned_flag;
   sq_dbuf<uint64_t> assigned_prefix;
@@ -639,9 +639,9 @@ __global__ void k_seq_close(uint32_t n, const uint64_t* __restrict__ pref, uint6
 // that for the WHOLE mapped batch in one launch (no mini-batch chain), leaving per kept alignment the two addends the chain still
 // needs: logProb = (transcriptLogCount + auxProb) + startPosProb, in that order.  Same arithmetic, same order as k_mini_batch.
 struct DynAln { double aux, start; uint32_t tid, keep; };   // 24 B
-// [r4] per batch: bm[group][M / 32] bits "transcript seen in this group", cur[group] = entries of the group's list, list = one region per group that
-// starts at the group's first alignment (a group has at most as many distinct transcripts as alignments); gsize = fragments per group (mini-batch size x W)
-struct TouchArgs { uint32_t* bm; uint32_t* cur; uint32_t* list; uint32_t gsize, words; };
+// [r4] per batch: flag[group][stride] bytes "a kept alignment of this group names this transcript" (plain byte stores, nothing waits on them);
+// stride = M rounded up to AP_TB_ * 8 so that k_apply_dynamic's blocks read whole 8-byte words; gsize = fragments per group (mini-batch size x W)
+struct TouchArgs { uint8_t* flag; uint32_t gsize, stride; };
 typedef unsigned long long sqk_u64x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts o, uint32_t n, const uint64_t* __restrict__ aln_off,
     const PreAln* __restrict__ pre, unsigned long long* __restrict__ awq, uint32_t* __restrict__ abin, uint64_t* __restrict__ rh1, uint64_t* __restrict__ rh2,
@@ -686,18 +686,7 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
           }
         }
         dyn[ai] = d; abin[ai] = bn;
-        if (TA.bm && d.keep) {   // [r4] the transcripts a group of mini-batches touches, each once: k_apply_dynamic walks this list instead of all M transcripts
-          const uint32_t g = r / TA.gsize; const uint32_t bit = 1u << (p.tid & 31); uint32_t* const word = &TA.bm[(size_t)g * TA.words + (p.tid >> 5)];
-          // a plain look first (most alignments name a transcript its group has seen already); the atomic decides who appends
-          if (!(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) && !(atomicOr(word, bit) & bit)) {
-            // one cursor atomic per wave where the lanes that got here are in the same group (all but the one wave that straddles a group boundary)
-            const unsigned long long act = __ballot(1); const int leader = __ffsll((long long)act) - 1, lane = (int)(threadIdx.x & 63);
-            const uint32_t g0 = (uint32_t)__shfl((int)g, leader, 64); uint32_t at;
-            if (__ballot(g != g0) == 0ull) { uint32_t base = 0; if (lane == leader) base = atomicAdd(&TA.cur[g0], (uint32_t)__popcll(act)); base = (uint32_t)__shfl((int)base, leader, 64); at = base + (uint32_t)__popcll(act & ((1ull << lane) - 1)); }
-            else at = atomicAdd(&TA.cur[g], 1u);
-            TA.list[aln_off[(size_t)g * TA.gsize] + at] = p.tid;
-          }
-        }
+        if (TA.flag && d.keep) TA.flag[(size_t)(r / TA.gsize) * TA.stride + p.tid] = 1;   // [r4] k_apply_dynamic visits the flagged transcripts only
       }
       if (nk > 0) {
         const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
@@ -776,12 +765,7 @@ __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0,
 // group end after burn-in: one thread per transcript reads its W mass slots (one 64-byte line at W = 8) and, where the group left
 // something, folds the mini-batches' increments in order, each with its own forgetting mass (as apply_mass_part); thread 0 keeps
 // the running count of assigned fragments
-__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1,
-    const uint32_t* __restrict__ tlist, const uint32_t* __restrict__ tcur, const uint64_t* __restrict__ aln_off) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
-  if (tlist) { if (t >= *tcur) return; t = tlist[aln_off[r0] + t]; }   // [r4] the group's own transcripts (k_frag_static listed them) instead of a sweep over all M
-  if (t >= V.M) return;
+__device__ __forceinline__ void apply_one(const OnlineView& V, const FmArr& FM, uint32_t nw, uint32_t t) {
   unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
   if (V.W == 8) {   // the default: the eight slots as four 16-byte loads, held in registers
     unsigned long long q[8]; unsigned long long any = 0;
@@ -808,6 +792,29 @@ __global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM
   if (!any) return;
   V.mass[t] = m;
   V.tlc[t] = sq_log_add(V.prior_mass[t], m);
+}
+__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
+  if (t < V.M) apply_one(V, FM, nw, t);
+}
+// [r4] the same over the group's flagged transcripts: a block reads the flags of AP_TB_ * 8 transcripts (8 per thread, one load), gathers the
+// flagged ones in LDS (their order is free: every transcript is its own update) and shares them out evenly
+__global__ void __launch_bounds__(AP_TB_) k_apply_flagged(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1,
+    const uint8_t* __restrict__ flag) {
+  __shared__ uint32_t s_list[AP_TB_ * 8]; __shared__ uint32_t s_n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t t0 = (blockIdx.x * AP_TB_ + threadIdx.x) * 8;
+  unsigned long long f = ((const unsigned long long*)flag)[blockIdx.x * AP_TB_ + threadIdx.x];
+  if (f) {
+    uint32_t at = atomicAdd(&s_n, (uint32_t)__popcll(f));
+    while (f) { const int i = (__ffsll((long long)f) - 1) >> 3; s_list[at++] = t0 + (uint32_t)i; f &= ~(0xffull << (8 * i)); }
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  for (uint32_t i = threadIdx.x; i < n; i += AP_TB_) apply_one(V, FM, nw, s_list[i]);
 }
 
 // [r3, SQ_EQ_CHAIN=1] The mass-dependent chain of a whole mapped batch as ONE kernel: all its blocks are resident at once on one XCD
@@ -1320,7 +1327,7 @@ void sq_online_free(sq_ctx* c) {
   o->log_eff_len.free_();
   o->tlc.free_();
   o->pre.free_();
-  o->alp.free_(); o->dyn.free_(); o->tbm.free_(); o->tcur.free_(); o->tlist.free_(); o->cmeans.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
+  o->alp.free_(); o->dyn.free_(); o->gflag.free_(); o->cmeans.free_(); o->seq_obs.free_(); o->seq_flag.free_(); o->seq_pref.free_(); o->seq_code.free_();
   o->fm_table.free_();
   o->cfac.free_();
   o->scal.free_();
@@ -1539,12 +1546,12 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     // (k_frag_dynamic) and their application (k_apply_dynamic).  Nothing comes back to the host.
     if (o->dyn.ensure(A * sizeof(DynAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
     static const int use_touched = getenv("SQ_EQ_TOUCHED") ? atoi(getenv("SQ_EQ_TOUCHED")) : 1;
-    TouchArgs TA{nullptr, nullptr, nullptr, mb * o->inflight, (o->M + 31) / 32};
+    TouchArgs TA{nullptr, mb * o->inflight, (o->M + AP_TB_ * 8 - 1) / (AP_TB_ * 8) * (AP_TB_ * 8)};
     if (use_touched && !c->stream_chain) {
-      const uint32_t ngrp = (n + TA.gsize - 1) / TA.gsize;
-      if (o->tbm.ensure((size_t)ngrp * TA.words + 8) || o->tcur.ensure(ngrp + 8) || o->tlist.ensure(A)) { sq_set_error("device allocation failed (touched lists)"); return SQ_ERR_NOMEM; }
-      SQ_HIP_CHECK(hipMemsetAsync(o->tbm.p, 0, (size_t)ngrp * TA.words * 4, sq)); SQ_HIP_CHECK(hipMemsetAsync(o->tcur.p, 0, (size_t)ngrp * 4, sq));
-      TA.bm = o->tbm.p; TA.cur = o->tcur.p; TA.list = o->tlist.p;
+      const size_t bytes = (size_t)((n + TA.gsize - 1) / TA.gsize) * TA.stride;
+      if (o->gflag.ensure(bytes + 64)) { sq_set_error("device allocation failed (touched flags)"); return SQ_ERR_NOMEM; }
+      SQ_HIP_CHECK(hipMemsetAsync(o->gflag.p, 0, bytes, sq));
+      TA.flag = o->gflag.p;
     }
     k_frag_static<<<nblk(n), 256, 0, sq>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p, TA);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
@@ -1573,7 +1580,8 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
       const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
       k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin);
-      k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.list, TA.cur ? TA.cur + b0 / W : nullptr, d_aln_off);
+      if (TA.flag) k_apply_flagged<<<TA.stride / (AP_TB_ * 8), AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.flag + (size_t)(b0 / W) * TA.stride);
+      else k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1);
       o->group_no++; if (c->prof_on) c->eq_groups++;
     }
     if (two) sq_prof_mark(c, SG_EQ_MINIBATCH, 2);
