@@ -122,7 +122,7 @@ def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
     lanes = 2
     lib.sq_ctx_set_lanes(ctx.h, lanes)
     t0 = time.perf_counter()
-    capi.check(lib.sq_reader_open(a1, 1, a2, 1, batch, lanes + 3, C.byref(h)), "sq_reader_open")   # one slot staging, two uploading, one per mapping lane
+    capi.check(lib.sq_reader_open(a1, 1, a2, 1, batch, lanes + 2, C.byref(h)), "sq_reader_open")   # one slot staging, one uploading, one per mapping lane
     inflight = []; n = 0; tot_mapped = 0
     def finish_one():
         nonlocal tot_mapped

@@ -484,7 +484,7 @@ static int cmd_quant(int argc, char** argv) {
     unm = fopen((std::string(odir) + "/" + g_aux_name + "/unmapped_names.txt").c_str(), "w");
     if (!unm) { fprintf(stderr, "[salmon-hip] cannot write unmapped_names.txt\n"); return 1; }
   }
-  if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 3, (sam_path || unm) ? SQ_READER_KEEP_NAMES : 0,
+  if (sq_reader_open_ex(p1.data(), (uint32_t)p1.size(), paired ? p2.data() : nullptr, (uint32_t)p2.size(), B, lanes + 2, (sam_path || unm) ? SQ_READER_KEEP_NAMES : 0,
       &rd)) die("opening reads");
   std::vector<int> inflight; std::vector<sq_read_batch> inflight_in;
   std::vector<uint64_t> sam_off; std::vector<sq_aln> sam_aln;

@@ -112,6 +112,7 @@ struct sq_ctx {
   sq_dbuf<uint4> mlinfo;   // list entries of the MEM size classes (mem_kernels.h)
   sq_dbuf<uint32_t> dp_bh, dp_perm; sq_dbuf<uint64_t> dp_off;   // DP queue order (k_dp_hist / k_dp_scatter)
   sq_dbuf<double> cf; sq_dbuf<int32_t> cp; sq_dbuf<uint32_t> mnext; sq_dbuf<uint8_t> mused;
+  sq_dbuf<uint64_t> lg_a, lg_b; sq_dbuf<uint32_t> lg_c, lg_d, lg_first, lg_cnt; sq_dbuf<uint8_t> lg_flags;   // [r4] flat chaining of the large class (mem_kernels.h: k_lg_*)
   sq_dbuf<uint32_t> mlist, mlbase; sq_dbuf<uint64_t> lkey, lval;   // read ends by MEM-count class (mem_kernels.h); sorted compact buffer of the large class
   // chains
   sq_dbuf<sq_chain_dev> chains; sq_dbuf<uint32_t> n_chains; uint64_t last_total_chains = 0;

@@ -11,7 +11,7 @@
 //   scan          read offsets of the interleaved batch (mate 1, mate 2, mate 1, ...)
 //   k_fq_copy     the bases into the compact buffer sq_map_batch takes (on_device = 1)
 // Two producer threads keep the slots filled: one stages text (parallel pread into page-locked memory + newline counts), one uploads and splits
-// (two batches in flight, each slot on its own stream), so staging of batch b + 2, H2D of b + 1 and the kernels of b overlap each other and the mapping.  Plain, regular, 4-line
+// (each slot on its own stream; SQ_READER_DEPTH batches in flight, default 1), so staging of batch b + 1, H2D + splitting of b and the mapping overlap.  Plain, regular, 4-line
 // FASTQ files only; anything else (gzip, FASTA, wrapped records, FIFOs, read names wanted) stays on the host path.  Replaces, for such input, the
 // reference's FastxParser producer threads (include/salmon/internal/io/FastxReader.hpp:13-32, SalmonQuantify.cpp:2419-2443).
 #include <hip/hip_runtime.h>
@@ -246,7 +246,10 @@ struct sq_dev_reader {
       staged_total += slots[(size_t)si].n; text_bytes += slots[(size_t)si].bytes[0] + slots[(size_t)si].bytes[1]; staged.push_back(si); cv.notify_all();
     }
   }
-  void produce_upload() {   // up to two batches in flight on the device side: the kernels and the host's wait for batch k overlap the upload of batch k + 1
+  // SQ_READER_DEPTH batches in flight on the device side (default 1: with 2, the upload of batch k + 1 overlaps the kernels of batch k, but on the
+  // box measured — 16.6 GB of text, 40 x 10^6 pairs — the two streams' copies and the staging threads got in each other's way: 57 against 72 M pairs/s)
+  size_t depth = 1;
+  void produce_upload() {
     (void)hipSetDevice(device);
     std::deque<int> pending;
     for (;;) {
@@ -254,7 +257,7 @@ struct sq_dev_reader {
       { std::unique_lock<std::mutex> lk(mu);
         if (pending.empty()) cv.wait(lk, [&] { return stop || !staged.empty() || stage_done; });
         if (stop) return;
-        if (!staged.empty() && pending.size() < 2) { take = staged.front(); staged.pop_front(); }
+        if (!staged.empty() && pending.size() < depth) { take = staged.front(); staged.pop_front(); }
         else if (pending.empty()) { done = true; cv.notify_all(); return; }   // the end of the input, or the stager's complaint (err_rc) once everything before it has gone out
       }
       std::string e; const double t0 = now(); int rc, si;
@@ -287,8 +290,9 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   for (auto& s : R->slots) if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError(); for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd); return SQ_ERR_DEVICE; }
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
-  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 4));
+  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
   R->pool.reset(new Workers(std::max(1u, nt)));
+  if (getenv("SQ_READER_DEPTH")) R->depth = (size_t)std::max(1, std::min(4, atoi(getenv("SQ_READER_DEPTH"))));
   sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); });
   *out = r; return SQ_OK;
 }

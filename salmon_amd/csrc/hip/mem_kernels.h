@@ -334,4 +334,136 @@ __global__ void k_scatter_sorted(uint64_t total, const uint64_t* __restrict__ sk
   mkey[dst] = key; mval[dst] = sval[i];
 }
 
+// ---- [r4] chaining of the large ends as flat passes over the sorted compact records (all large ends of a batch at once) ----
+// The thread-per-end walk (k_chain) took 40 ms per 4 x 10^6 pairs on the 3.1 Gnt decoy index: an end in a genomic repeat family has
+// thousands of MEMs on one decoy chromosome, and one lane went through them one by one (and through the accepted-chain search once per chain).
+// What makes it parallel: the MEMs of a (end, transcript) group are sorted by reference position, and a MEM can only chain onto MEMs at most
+// SQ_MAX_CHAIN_GAP before it — so a gap of more than that between neighbours splits the group into CLUSTERS that no chain crosses.  The DP and
+// the clash rule of the acceptance run per cluster (a handful of MEMs); the group's threshold and the end's best score are maxima (atomics);
+// the order the reference's loop accepts chains in — by score, ties by index — is restored by two stable radix sorts at the end.
+// Same operations on the same values as k_chain / SPEC §a2, so the chains are bit for bit the same.
+#define LG_CL 1u   // first MEM of a cluster
+#define LG_GR 2u   // first MEM of an (end, transcript) group
+#define LG_EN 4u   // first MEM of an end
+struct LgMaxPair { __host__ __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const {
+  const uint32_t ah = (uint32_t)(a >> 32), bh = (uint32_t)(b >> 32), al = (uint32_t)a, bl = (uint32_t)b;
+  return ((uint64_t)(ah > bh ? ah : bh) << 32) | (uint64_t)(al > bl ? al : bl); } };
+struct LgIsCluster { __host__ __device__ __forceinline__ uint8_t operator()(uint8_t f) const { return (uint8_t)(f & LG_CL); } };
+// flags per record + the input of the running-maximum scan (hi: index of the end's first record, lo: of the group's); group / end maxima start at 0
+__global__ void k_lg_flags(uint32_t total, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, uint8_t* __restrict__ flags,
+                           uint64_t* __restrict__ se_in, uint64_t* __restrict__ gbest, uint64_t* __restrict__ ebest, uint32_t* __restrict__ n_chains) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= total) return;
+  const uint64_t k = skey[i]; const uint32_t tid = (uint32_t)(sval[i] >> 32);
+  uint32_t f = 0;
+  if (i == 0) f = LG_CL | LG_GR | LG_EN;
+  else {
+    const uint64_t kp = skey[i - 1]; const uint32_t tp = (uint32_t)(sval[i - 1] >> 32);
+    if ((kp >> 40) != (k >> 40)) f = LG_CL | LG_GR | LG_EN;
+    else if (tp != tid) f = LG_CL | LG_GR;
+    else if ((k & ((1ull << 40) - 1)) - (kp & ((1ull << 40) - 1)) > (uint64_t)SQ_MAX_CHAIN_GAP) f = LG_CL;
+  }
+  flags[i] = (uint8_t)f;
+  se_in[i] = ((uint64_t)((f & LG_EN) ? i : 0u) << 32) | (uint64_t)((f & LG_GR) ? i : 0u);
+  if (f & LG_GR) gbest[i] = 0;
+  if (f & LG_EN) { ebest[i] = 0; n_chains[(uint32_t)(k >> 40)] = 0; }
+}
+struct LgMem { int32_t r, q, len; uint32_t fw; };
+__device__ __forceinline__ LgMem lg_mem(const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, uint32_t i, uint64_t r0) {
+  const uint64_t v = sval[i]; LgMem m; m.r = (int32_t)((skey[i] & ((1ull << 40) - 1)) - r0); m.q = (int32_t)((v >> 10) & 1023); m.len = (int32_t)(v & 1023); m.fw = (uint32_t)((v >> 20) & 1); return m;
+}
+// one thread per cluster: the chaining DP (f in cf, predecessor in cp as a compact index), the group's best f
+__global__ void k_lg_dp(const uint32_t* __restrict__ ncl_p, uint32_t total, const uint32_t* __restrict__ cl_start, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval,
+                        const uint64_t* __restrict__ se, sq_map_params P, const double* __restrict__ gapcost, double* __restrict__ cf, int32_t* __restrict__ cp,
+                        uint8_t* __restrict__ mused, uint64_t* __restrict__ gbest) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t ncl = *ncl_p; if (t >= ncl) return;
+  const uint32_t s0 = cl_start[t], s1 = t + 1 < ncl ? cl_start[t + 1] : total;
+  const uint64_t r0 = skey[s0] & ((1ull << 40) - 1);   // positions relative to the cluster's first MEM: only differences enter
+  double best = 0.0;
+  for (uint32_t i = s0; i < s1; ++i) {
+    const LgMem hi = lg_mem(skey, sval, i, r0);
+    double fi = (double)hi.len; int pi = -1; int rounds = 2;
+    for (int j = (int)i - 1; j >= (int)s0; --j) {
+      const LgMem hj = lg_mem(skey, sval, (uint32_t)j, r0);
+      if (hi.r - hj.r > SQ_MAX_CHAIN_GAP) break;
+      if (hj.fw != hi.fw) continue;
+      const int qd = hi.q - hj.q, rd = hi.r - hj.r;
+      if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
+      const int l = abs(qd - rd);
+      const double a = (double)min(hi.len, min(qd, rd));
+      const double sc = cf[j] + a - gapcost[l];
+      if (sc > fi) { fi = sc; pi = j; }
+      if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
+    }
+    cf[i] = fi; cp[i] = pi; mused[i] = 0;
+    if (fi > best) best = fi;
+  }
+  atomicMax((unsigned long long*)&gbest[(uint32_t)se[s0]], (unsigned long long)__double_as_longlong(best));   // f > 0: the bit pattern orders like the value
+}
+// one thread per cluster: chain ends by (score desc, index asc) among the cluster's MEMs over the group's threshold; a chain that runs into
+// an accepted one is dropped (SPEC §a2).  mused: 1 member of an accepted chain, 2 tried and dropped, 4 the last MEM of an accepted chain
+__global__ void k_lg_accept(const uint32_t* __restrict__ ncl_p, uint32_t total, const uint32_t* __restrict__ cl_start, const uint64_t* __restrict__ se, sq_map_params P,
+                            const double* __restrict__ cf, const int32_t* __restrict__ cp, uint8_t* __restrict__ mused, const uint64_t* __restrict__ gbest,
+                            uint64_t* __restrict__ ebest) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t ncl = *ncl_p; if (t >= ncl) return;
+  const uint32_t s0 = cl_start[t], s1 = t + 1 < ncl ? cl_start[t + 1] : total;
+  const uint64_t sev = se[s0];
+  const double thr = P.pre_thr * __longlong_as_double((long long)gbest[(uint32_t)sev]);
+  double top = 0.0;
+  for (;;) {
+    int bi = -1; double bf = 0.0;
+    for (uint32_t i = s0; i < s1; ++i) {
+      if (mused[i]) continue;
+      const double fv = cf[i];
+      if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; }
+    }
+    if (bi < 0) break;
+    bool clash = false;
+    for (int x = bi; x >= 0; x = cp[x]) if (mused[x] & 1) { clash = true; break; }
+    if (clash) { mused[bi] |= 2; continue; }
+    for (int x = bi; x >= 0; x = cp[x]) mused[x] |= 1;
+    mused[bi] |= 4;
+    if (bf > top) top = bf;
+  }
+  if (top > 0.0) atomicMax((unsigned long long*)&ebest[(uint32_t)(sev >> 32)], (unsigned long long)__double_as_longlong(top));
+}
+// hitFilterPolicy AFTER + consensus fraction over the end's chains (k_chain's last loop): which accepted chains stay
+__global__ void k_lg_keep(uint32_t total, const uint64_t* __restrict__ se, sq_map_params P, const double* __restrict__ cf, const uint8_t* __restrict__ mused,
+                          const uint64_t* __restrict__ ebest, uint8_t* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= total) return;
+  uint8_t k = 0;
+  if (mused[i] & 4) { const double cthr = P.consensus_frac * __longlong_as_double((long long)ebest[(uint32_t)(se[i] >> 32)]); k = cf[i] >= cthr ? 1 : 0; }
+  keep[i] = k;
+}
+__global__ void k_lg_key_score(uint32_t n, const uint32_t* __restrict__ idx, const double* __restrict__ cf, uint64_t* __restrict__ key) {   // ascending in ~bits = descending in score
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; if (k < n) key[k] = ~(uint64_t)__double_as_longlong(cf[idx[k]]);
+}
+__global__ void k_lg_key_group(uint32_t n, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, int tbits, uint64_t* __restrict__ key) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; if (k < n) { const uint32_t i = idx[k]; key[k] = ((skey[i] >> 40) << tbits) | (sval[i] >> 32); }
+}
+__global__ void k_lg_first(uint32_t n, const uint64_t* __restrict__ gkey, int tbits, uint32_t* __restrict__ first) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; if (k >= n) return;
+  const uint32_t e = (uint32_t)(gkey[k] >> tbits);
+  if (k == 0 || (uint32_t)(gkey[k - 1] >> tbits) != e) first[e] = k;
+}
+// chain k of the sorted list: its record into the end's slab (members linked through mnext, as k_chain's groups of more than CH_SMALL MEMs)
+__global__ void k_lg_write(uint32_t n, const uint64_t* __restrict__ gkey, int tbits, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ first,
+                           const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, const uint64_t* __restrict__ se, const uint64_t* __restrict__ ref_accum,
+                           const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const double* __restrict__ cf, const int32_t* __restrict__ cp,
+                           uint32_t* __restrict__ mnext, sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; if (k >= n) return;
+  const uint64_t gk = gkey[k]; const uint32_t e = (uint32_t)(gk >> tbits); const uint32_t tid = (uint32_t)(gk & ((1ull << tbits) - 1));
+  const uint32_t bi = idx[k]; const uint32_t es = (uint32_t)(se[bi] >> 32); const uint64_t base = mem_off[e];
+  uint32_t cnt = 0; int fi = (int)bi;
+  mnext[base + (bi - es)] = 0xFFFFFFFFu;
+  for (int x = (int)bi; x >= 0; x = cp[x]) { ++cnt; fi = x; const int pr = cp[x]; if (pr >= 0) mnext[base + ((uint32_t)pr - es)] = (uint32_t)x - es; }
+  const uint64_t ra = ref_accum[tid];
+  const LgMem m0 = lg_mem(skey, sval, (uint32_t)fi, ra), ml = lg_mem(skey, sval, bi, ra);
+  sq_chain_dev c;
+  c.score = cf[bi]; c.tid = tid; c.pos = m0.r - m0.q; c.last_end = ml.r + ml.len; c.first = (uint32_t)fi - es; c.n_mems = (uint16_t)cnt; c.read_len = rlen[e];
+  c.fw = (uint8_t)ml.fw; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0; c.spare = 0;
+  const uint32_t w = k - first[e];
+  chains[base + w] = c;
+  if (k + 1 == n || (uint32_t)(gkey[k + 1] >> tbits) != e) n_chains[e] = w + 1;
+}
+
 }  // namespace sqk

@@ -435,6 +435,64 @@ def test_repeat_families_cover_every_mem_size_class(built):
     ctx.free()
 
 
+def test_large_ends_on_a_decoy_chromosome(built):
+    # [r4] The large class (more than 1024 MEMs per end) is chained by flat passes over all its records (mem_kernels.h: k_lg_*): clusters of
+    # MEMs no chain can cross, the reference's acceptance order restored by two stable sorts.  A decoy "chromosome" carries 665 copies of a
+    # 160-base element (two variants), some of them back to back (several copies in one cluster: the DP and the clash rule see neighbours),
+    # so a read across the variant site has ~1600 MEMs on ONE reference; 300 transcripts carry the element too (many small groups in the same end).
+    rng = np.random.default_rng(23)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    rep = rnd(160); rep2 = rep[:80] + comp[rep[80]] + rep[81:]
+    chrom = []
+    for i in range(560):
+        chrom.append(rnd(int(rng.integers(260, 500))))
+        for _ in range(2 if i % 8 == 0 else 1): chrom.append(rep if rng.random() < 0.5 else rep2)      # i % 8 == 0: two copies back to back
+        if i % 16 == 3: chrom.append(rnd(int(rng.integers(5, 30))) + (rep if i % 32 == 3 else rep2))   # ... or a few bases apart
+    chrom = "".join(chrom) + rnd(300)
+    seqs = []
+    for i in range(500):
+        body = rnd(int(rng.integers(500, 900)))
+        if i < 300: body = body[:250] + (rep if i % 2 else rep2) + body[250:]
+        seqs.append(body)
+    ncopies = chrom.count(rep) + chrom.count(rep2) + 300
+    assert 900 < ncopies <= 1000          # under maxOccsPerHit, or the element's uni-MEMs would be dropped
+    seqs.append(chrom)
+    names = ["t%d" % i for i in range(len(seqs) - 1)] + ["chrD"]
+    idx = api.SalmonIndex.build_mem(names, seqs, threads=4, keep_duplicates=True).to_device(0)
+    oidx = orc.OrcIndex(idx)
+    recs = []
+    def pair(s, p, fl):
+        r1 = s[p:p + 100]; r2 = "".join(comp[c] for c in reversed(s[p + fl - 100:p + fl]))
+        return [r1, r2] if rng.random() < 0.5 else [r2, r1]
+    starts = [m for m in range(len(chrom) - 400) if chrom.startswith(rep, m) or chrom.startswith(rep2, m)]
+    for _ in range(200): m = starts[int(rng.integers(len(starts)))]; recs += pair(chrom, max(0, m - int(rng.integers(5, 25))), int(rng.integers(200, 300)))   # across the variant site
+    for _ in range(100): m = starts[int(rng.integers(len(starts)))]; recs += pair(chrom, max(0, m - int(rng.integers(60, 90))), int(rng.integers(200, 300)))  # partly inside
+    for _ in range(100): recs += pair(seqs[int(rng.integers(0, 300))], int(rng.integers(225, 245)), int(rng.integers(200, 300)))
+    for _ in range(100): recs += pair(seqs[int(rng.integers(300, 500))], int(rng.integers(0, 200)), int(rng.integers(200, 300)))
+    seq = np.frombuffer("".join(recs).encode(), np.uint8).copy(); off = np.arange(0, len(recs) + 1, dtype=np.uint64) * np.uint64(100)
+    n = len(recs) // 2
+    opts = api.quant_opts()
+    ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=1024)
+    rb = api.make_read_batch(seq, off, n, paired=True)
+    ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+    um_c, mm_c, ch_c, cd_c = orc.map_taps(oidx, opts, rb, cap=1 << 23)
+    mm_g = ctx.tap(2, api.MEM_DTYPE)
+    per_end = np.bincount(mm_g["end"], minlength=2 * n)
+    big = np.flatnonzero(per_end > 1024)
+    assert len(big) > 100
+    chr_tid = int(mm_g["tid"].max())
+    e0 = int(big[0]); on_chr = np.count_nonzero((mm_g["end"] == e0) & (mm_g["tid"] == chr_tid))
+    assert on_chr > 1024                                                  # one (end, reference) group beyond every LDS class
+    _fields_equal(mm_g, mm_c, ["end", "tid", "rpos", "qpos", "len", "fw"], "MEMs")
+    ch_g = ctx.tap(3, api.CHAIN_DTYPE)
+    _fields_equal(ch_g, ch_c, ["end", "tid", "pos", "last_end", "fw", "n_mems", "score"], "chains")
+    ro_c, aln_c, mt_c, st_c = orc.map_batch(oidx, opts, rb, threads=8)
+    assert st_g == st_c and np.array_equal(ro_g, ro_c) and np.array_equal(mt_g, mt_c)
+    _fields_equal(aln_g, aln_c, list(api.ALN_DTYPE.names), "alignments")
+    ctx.free()
+
+
 def _stranded_pairs(seqs, n, rng, flip_from=None):
     # fragments read in ISF orientation (mate 1 = forward strand of the transcript, mate 2 = reverse complement of the fragment's end);
     # from pair index `flip_from` on every third pair is turned into ISR (the mates swapped)
