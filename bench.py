@@ -61,7 +61,8 @@ def parse():
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (the RCCL exchange + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
-    ap.add_argument("--fastq-pairs", type=int, default=4000000,
+    ap.add_argument("--fastq-gz-pairs", type=int, default=4000000, help="pairs of the gzip / BGZF legs of the from-FASTQ run (compressing the input is what takes the time)")
+    ap.add_argument("--fastq-pairs", type=int, default=20000000,
         help="second measurement (outside the timed steps, rank 0, N=1, c2/c2s): this many pairs written as FASTQ files to /dev/shm and run through "
              "the host read pipeline (sq_reader) + the same GPU path, end to end from files (0 = skip)")
     ap.add_argument("--py-dist", action="store_true",
@@ -103,7 +104,7 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         "eq_flags_scan": st["num_alignments"] * (40 + 32) + n_pairs * 24,
         # [r3] after burn-in the online stage is a model-independent launch per batch (eq_static: per alignment the 32-byte pre-record in, the 24-byte
         # dynamic record + fixed-point weight + bin out, two counters; per fragment offsets and the label hash) and per group of mini-batches
-        # the mass terms (eq_mini_batches = k_frag_dynamic + k_apply_dynamic: the dynamic record, the transcript's log-count, one mass slot)
+        # the mass terms (eq_mini_batches = k_frag_dynamic + k_apply_flagged: the dynamic record, the transcript's log-count, one mass slot)
         "eq_static": st["num_alignments"] * (32 + 24 + 8 + 4 + 2 * 8) + n_pairs * (16 + 16),
         "eq_mini_batches": st["num_alignments"] * (24 + 8 + 16 + 8) + n_pairs * 16,
         "eq_table": st["num_alignments"] * (4 + 4 + 8 + 8) + n_pairs * (16 + 4 + 32),
@@ -145,12 +146,13 @@ def _fastq_pass(ctx, idx, files, batch, lib, api, capi, read_len):
             "mapped_frac": round(tot_mapped / max(1, n), 4), "em_iters": rep["iters"]}
 
 
-def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
+def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, gz_pairs=None):
     """`salmon quant` from FASTQ files: sq_reader (parallel record splitting into page-locked batches) -> H2D -> mapping lanes -> online model /
     eq-classes -> export -> normalizeAlphas -> VBEM.  Wall time from opening the files to the converged alphas; plain, BGZF and gzip input."""
     import shutil, tempfile, subprocess, gzip
     d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs" % (n_pairs, read_len, batch), "host_threads": os.cpu_count(),
+    gz_pairs = min(n_pairs, gz_pairs or n_pairs)
+    out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(),
            "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
            "what": "end to end from files through sq_reader, H2D included; plain files: text staged in page-locked memory, records split on the device "
                    "(hip/fastq_dev.hip); gzip/BGZF: inflated and split on the host (host/reader.cpp, host/pgzip.cpp)"}
@@ -171,6 +173,12 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi):
         out["plain"] = res; out["value"] = res["value"]; out["unit"] = res["unit"]
         # gzip (one member: the reader inflates it on one thread per mate file unless it can split it) and BGZF (blocked gzip: members inflate in parallel)
         try:
+            rowb = 3 + read_len + 3 + read_len + 1
+            if gz_pairs < n_pairs:
+                short = []
+                for f in files:
+                    h = f + ".head.fq"; subprocess.check_call("head -c %d %s > %s" % (gz_pairs * rowb, f, h), shell=True); short.append(h)
+                files = short
             gz = []
             for f in files:
                 g = f + ".gz"
@@ -558,9 +566,9 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     except Exception: pass
     cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
     roof = None; roofs = {}
-    # the online chain's row is a launch PAIR per group of mini-batches (k_frag_dynamic, k_apply_dynamic): its time is split between the two
+    # the online chain's row is a launch PAIR per group of mini-batches (k_frag_dynamic, k_apply_flagged): its time is split between the two
     # kernels in the proportion the committed rocprofv3 summary shows (50/50 without it)
-    pair_share = {"k_frag_dynamic": 0.5, "k_apply_dynamic": 0.5}
+    pair_share = {"k_frag_dynamic": 0.5, "k_apply_flagged": 0.5}
     try:
         ktot = {}
         for line in open(os.path.join(ROOT, "profiles", "r04_kernel_stats_c2_final.txt")):
@@ -664,7 +672,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
             except Exception as e: spread = {"error": str(e)[:300]}
     fq = None
     if a.fastq_pairs > 0 and world == 1 and wl in ("c2", "c2s") and not leg:
-        fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi)
+        fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi, gz_pairs=a.fastq_gz_pairs)
     cfg_name = {"c2": "configs[1]: human-transcriptome-shaped synthetic index (60k genes x ~4 isoforms; SURVEY C2 shape)",
                 "c3": "configs[2]: human-transcriptome-shaped synthetic index (as c2), a fixed total of %d pairs split over %d rank(s)" % (total_pairs, world),
                 "c2s": "configs[1], round-1/2 index (T200k: 20k genes x ~10 isoforms, 54 M distinct k-mers)",

@@ -482,8 +482,8 @@ def test_large_ends_on_a_decoy_chromosome(built):
     big = np.flatnonzero(per_end > 1024)
     assert len(big) > 100
     chr_tid = int(mm_g["tid"].max())
-    e0 = int(big[0]); on_chr = np.count_nonzero((mm_g["end"] == e0) & (mm_g["tid"] == chr_tid))
-    assert on_chr > 1024                                                  # one (end, reference) group beyond every LDS class
+    on_chr = np.bincount(mm_g["end"][mm_g["tid"] == chr_tid], minlength=2 * n)
+    assert np.count_nonzero(on_chr > 1024) > 50                           # (end, reference) groups beyond every LDS class
     _fields_equal(mm_g, mm_c, ["end", "tid", "rpos", "qpos", "len", "fw"], "MEMs")
     ch_g = ctx.tap(3, api.CHAIN_DTYPE)
     _fields_equal(ch_g, ch_c, ["end", "tid", "pos", "last_end", "fw", "n_mems", "score"], "chains")
