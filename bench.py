@@ -375,6 +375,9 @@ def run_spread(a, world_obj, parked, off_d, B, RL, api, capi, local):
 
 def main():
     a = parse()
+    # ONE line on stdout: the communicator libraries print a version banner to the C-level stdout when the first communicator is made (RCCL does,
+    # with one rank too) — everything but the JSON line is sent to stderr, by descriptor, for the life of the process
+    sys.stdout.flush(); real_stdout = os.dup(1); os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     if not torch.cuda.is_available():
@@ -400,7 +403,7 @@ def main():
     thr = max(4, ncores // max(1, world))
     out = run_workload(a, a.workload, rank, world, local, dist, sqd, thr, ncores, api, synth, capi, extras=not a.no_extras)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
@@ -559,7 +562,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     # chain included (its row aggregates one launch pair per group of mini-batches)
     pm = {}; pm_note = "no PMC profile committed for this kernel on this workload"
     try:   # the counter passes were taken on the c2 workload: no traffic figure for the others; [r4] nor when the kernel sources changed since
-        if wl in ("c2", "c3"):
+        if wl == "c2":   # (c3 maps the same index in other batch sizes: not the launches that were counted)
             prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
             if prof.get("kernel_source_sha") == kernel_source_sha() and prof.get("pairs_per_launch") == B: pm = prof["kernels"]
             else: pm_note = "profiles/r04_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))

@@ -10,8 +10,8 @@
 //   k_fq_records  record r = lines 4r .. 4r+3: '@' / sequence / '+' / quality of the same length (CR stripped), length + start of the sequence
 //   scan          read offsets of the interleaved batch (mate 1, mate 2, mate 1, ...)
 //   k_fq_copy     the bases into the compact buffer sq_map_batch takes (on_device = 1)
-// Two producer threads keep the slots filled: one stages text (parallel pread into page-locked memory + newline counts), one uploads and splits
-// (each slot on its own stream; SQ_READER_DEPTH batches in flight, default 1), so staging of batch b + 1, H2D + splitting of b and the mapping overlap.  Plain, regular, 4-line
+// Two producer threads keep the slots filled: one stages text (parallel pread into a ring of page-locked pieces + newline counts), one uploads the
+// pieces and splits (each slot on its own stream), so reading, H2D, splitting and the mapping of earlier batches overlap.  Plain, regular, 4-line
 // FASTQ files only; anything else (gzip, FASTA, wrapped records, FIFOs, read names wanted) stays on the host path.  Replaces, for such input, the
 // reference's FastxParser producer threads (include/salmon/internal/io/FastxReader.hpp:13-32, SalmonQuantify.cpp:2419-2443).
 #include <hip/hip_runtime.h>
@@ -106,8 +106,7 @@ struct sq_dev_reader {
   // a mate stream = its files end to end; a file that does not end with a newline gets one (pad = 1), so records never straddle files
   struct File { std::string path; int fd = -1; uint64_t size = 0, vbase = 0; uint32_t pad = 0; };
   struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; } sm[2];
-  struct Slot {
-    char* stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
+  struct Slot {   // device side only: the text of a batch never sits in host memory as a whole
     void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
     void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
     void* d_start[2] = {nullptr, nullptr}; size_t start_cap[2] = {0, 0};
@@ -118,11 +117,22 @@ struct sq_dev_reader {
   };
   std::vector<Slot> slots;
   std::unique_ptr<Workers> pool;
-  // two producers (staging the text of batch k+1 in page-locked memory overlaps the upload and the kernels of batch k) <-> the consumer:
-  // a slot goes free -> staged -> ready -> (sq_reader_release) free
-  std::thread prod, prod2; std::mutex mu; std::condition_variable cv; std::deque<int> ready, staged, free_slots; bool stop = false, stage_done = false, done = false;
+  // [r4] The page-locked memory is a RING of pieces (PIECE bytes each, RING_PIECES of them: 256 MB whatever the batch size — page-locking memory
+  // costs ~0.2 s per GB, as much as reading it).  The stager fills a ROUND of up to ROUND_PIECES pieces at a time (parallel pread + newline
+  // counts), finds where the batch ends, and hands the round to the uploader, which copies the pieces behind each other into the slot's text
+  // buffer and gives them back; once a mate's text is complete its splitting kernels go out.
+  static constexpr size_t PIECE = 4u << 20; static constexpr int RING_PIECES = 64, ROUND_PIECES = 16;
+  char* ring = nullptr; std::deque<int> free_pieces;
+  struct Round {
+    int slot = -1, mate = 0; std::vector<std::pair<int, size_t>> pieces;   // (ring piece, valid bytes)
+    size_t dst = 0;                       // where this round's first byte goes in the mate's text
+    bool first_of_batch = false, last_of_mate = false, last_of_batch = false, end_of_input = false; uint32_t n = 0; size_t total = 0;   // n, total: valid with last_of_mate
+    int rc = SQ_OK; std::string err;
+  };
+  // stager -> (rounds) -> uploader -> (ready) -> consumer -> (free_slots) -> stager
+  std::thread prod, prod2; std::mutex mu; std::condition_variable cv; std::deque<int> ready, free_slots; std::deque<Round> rounds; bool stop = false, done = false;
   std::string err; int err_rc = SQ_OK; uint64_t total = 0, staged_total = 0;
-  double t_stage = 0, t_upload = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
+  double t_stage = 0, t_upload = 0, t_wait_piece = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
 
   static int dev_grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
@@ -130,6 +140,14 @@ struct sq_dev_reader {
     *p = nullptr; *cap = 0; const size_t c = need + need / 4 + 4096;
     if (hipMalloc(p, c) != hipSuccess) { (void)hipGetLastError(); return -1; }
     *cap = c; return 0;
+  }
+  static int dev_grow_keep(void** p, size_t* cap, size_t need, size_t keep, hipStream_t st) {   // as dev_grow, the first `keep` bytes survive
+    if (need <= *cap) return 0;
+    void* nb = nullptr; const size_t c = need + need / 4 + 4096;
+    if (hipMalloc(&nb, c) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (*p && keep && (hipMemcpyAsync(nb, *p, keep, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { (void)hipFree(nb); return -1; }
+    if (*p) (void)hipFree(*p);
+    *p = nb; *cap = c; return 0;
   }
   // bytes [pos, pos + n) of the stream into dst
   bool vread(Stream& S, uint64_t pos, size_t n, char* dst, std::string* e) {
@@ -145,128 +163,144 @@ struct sq_dev_reader {
     }
     return true;
   }
-  // the text of up to `want` records of stream i into s.stage[i]: *got records in *bytes bytes (whole lines)
-  bool stage_text(int i, Slot& s, uint32_t want, uint32_t* got, size_t* bytes, std::string* e) {
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void push(Round&& r) { { std::lock_guard<std::mutex> lk(mu); rounds.push_back(std::move(r)); } cv.notify_all(); }
+  void give_back(const std::vector<std::pair<int, size_t>>& ps, size_t from = 0) { { std::lock_guard<std::mutex> lk(mu); for (size_t k = from; k < ps.size(); ++k) free_pieces.push_back(ps[k].first); } cv.notify_all(); }
+  // the text of up to `want` records of stream i, round by round, to the uploader: *got records in *bytes bytes (whole lines).  false: stop (error in *e, or the reader is closing)
+  // hold: the mate's last round is kept back (the caller checks the record counts of the mates before a batch's last round may go out)
+  bool stage_text(int i, int si, bool first_of_batch, uint32_t want, bool last_mate, Round* hold, uint32_t* got, size_t* bytes, std::string* e) {
     Stream& S = sm[i]; *got = 0; *bytes = 0;
-    const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0;
-    const size_t PIECE = 4u << 20;
-    std::vector<std::pair<size_t, uint64_t>> pl;   // (offset in the staging buffer, newlines) per piece
-    while (lines < need_lines && S.vpos + have < S.vsize) {
+    const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0; bool reached = false, first = first_of_batch;
+    while (!reached && S.vpos + have < S.vsize) {
       const uint64_t missing = (need_lines - lines + 3) / 4;
-      size_t more = (size_t)std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20));
-      if (have + more + 64 > s.stage_cap[i]) {
-        const size_t cap = have + more + (have + more) / 4 + (8u << 20); char* nb = nullptr;
-        if (hipHostMalloc((void**)&nb, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *e = "page-locked staging allocation failed (" + std::to_string(cap >> 20) + " MB)"; return false; }
-        if (s.stage[i]) { memcpy(nb, s.stage[i], have); (void)hipHostFree(s.stage[i]); }
-        s.stage[i] = nb; s.stage_cap[i] = cap;
-      }
-      const unsigned np = (unsigned)((more + PIECE - 1) / PIECE); std::vector<uint64_t> cnt(np, 0); std::vector<std::string> errs(np);
-      char* base = s.stage[i]; const uint64_t v0 = S.vpos + have;
+      const size_t more = (size_t)std::min<uint64_t>(std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20)), (uint64_t)ROUND_PIECES * PIECE);
+      const unsigned np = (unsigned)((more + PIECE - 1) / PIECE);
+      Round r; r.slot = si; r.mate = i; r.dst = have; r.first_of_batch = first; first = false;
+      { const double t0 = now(); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || free_pieces.size() >= np; }); if (stop) return false;
+        for (unsigned k = 0; k < np; ++k) { r.pieces.push_back({free_pieces.front(), std::min(PIECE, more - (size_t)k * PIECE)}); free_pieces.pop_front(); } t_wait_piece += now() - t0; }
+      std::vector<uint64_t> cnt(np, 0); std::vector<std::string> errs(np); const uint64_t v0 = S.vpos + have;
       pool->run(np, [&](unsigned k) {
-        const size_t o = (size_t)k * PIECE, n = std::min(PIECE, more - o);
-        if (!vread(S, v0 + o, n, base + have + o, &errs[k])) return;
-        cnt[k] = count_nl(base + have + o, n);
+        char* dst = ring + (size_t)r.pieces[k].first * PIECE;
+        if (!vread(S, v0 + (size_t)k * PIECE, r.pieces[k].second, dst, &errs[k])) return;
+        cnt[k] = count_nl(dst, r.pieces[k].second);
       });
-      for (unsigned k = 0; k < np; ++k) { if (!errs[k].empty()) { *e = errs[k]; return false; } pl.push_back({have + (size_t)k * PIECE, cnt[k]}); lines += cnt[k]; }
-      have += more;
+      for (unsigned k = 0; k < np; ++k) if (!errs[k].empty()) { *e = errs[k]; give_back(r.pieces); return false; }
+      size_t emitted = 0;
+      for (unsigned k = 0; k < np; ++k) {
+        if (want && lines + cnt[k] >= need_lines) {   // the batch ends in this piece: just behind newline number need_lines
+          const char* p0 = ring + (size_t)r.pieces[k].first * PIECE; const char* p = p0; const char* pe = p0 + r.pieces[k].second; uint64_t left = need_lines - lines;
+          while (left) { const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p)); p = nl + 1; --left; }
+          r.pieces[k].second = (size_t)(p - p0); emitted += r.pieces[k].second; lines = need_lines; reached = true;
+          give_back(r.pieces, k + 1); r.pieces.resize(k + 1);
+          break;
+        }
+        lines += cnt[k]; emitted += r.pieces[k].second;
+      }
+      const bool at_end = !reached && S.vpos + have + emitted >= S.vsize;
+      if (at_end) {   // the end of the input: what is left must be whole records (blank lines at the very end are tolerated, as on the host path)
+        char tail[4096]; size_t tn = 0;   // the last bytes of the round, gathered (they may straddle pieces)
+        { size_t want_b = std::min(sizeof(tail), emitted); size_t skip = emitted - want_b;
+          for (auto& pc : r.pieces) { if (skip >= pc.second) { skip -= pc.second; continue; } const size_t c = pc.second - skip; memcpy(tail + tn, ring + (size_t)pc.first * PIECE + skip, c); tn += c; skip = 0; } }
+        size_t cut = tn;
+        while (cut >= 2 && tail[cut - 1] == '\n' && (tail[cut - 2] == '\n' || (cut >= 3 && tail[cut - 2] == '\r' && tail[cut - 3] == '\n'))) { cut -= (tail[cut - 2] == '\r') ? 2 : 1; --lines; }
+        size_t drop = tn - cut;
+        while (drop && !r.pieces.empty()) { auto& pc = r.pieces.back(); const size_t c = std::min(drop, pc.second); pc.second -= c; drop -= c; emitted -= c; if (!pc.second) { give_back(r.pieces, r.pieces.size() - 1); r.pieces.pop_back(); } }
+        if (lines % 4) { *e = "'" + S.files.back().path + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; give_back(r.pieces); return false; }
+      }
+      have += emitted;
+      if (reached || at_end) {
+        *got = reached ? want : (uint32_t)(lines / 4); *bytes = have;
+        if (have >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(*got) + " records spans more than 4 GB of text: use a smaller batch"; give_back(r.pieces); return false; }
+        r.last_of_mate = true; r.last_of_batch = last_mate; r.n = *got; r.total = have;
+        S.vpos = reached ? S.vpos + have : S.vsize;
+        if (*got) S.est = 0.7 * S.est + 0.3 * ((double)have / (double)*got);
+        text_bytes += have;
+        if (*got == 0) { give_back(r.pieces); return true; }   // nothing but blank lines was left: no round goes out
+      }
+      if (hold && r.last_of_mate) *hold = std::move(r); else push(std::move(r));
     }
-    size_t cut = have;
-    if (lines >= need_lines && want) {   // just behind newline number need_lines
-      uint64_t acc = 0; size_t k = 0;
-      while (acc + pl[k].second < need_lines) { acc += pl[k].second; ++k; }
-      const char* p = s.stage[i] + pl[k].first; const char* pe = s.stage[i] + have; uint64_t left = need_lines - acc;
-      while (left) { const char* nl = (const char*)memchr(p, '\n', (size_t)(pe - p)); p = nl + 1; --left; }
-      cut = (size_t)(p - s.stage[i]); *got = want;
-    } else {   // the end of the input: what is left must be whole records (blank lines at the very end are tolerated, as on the host path)
-      while (cut >= 2 && s.stage[i][cut - 1] == '\n' && (s.stage[i][cut - 2] == '\n' || (cut >= 3 && s.stage[i][cut - 2] == '\r' && s.stage[i][cut - 3] == '\n'))) { cut -= (s.stage[i][cut - 2] == '\r') ? 2 : 1; --lines; }
-      if (lines % 4) { *e = "'" + S.files.back().path + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; return false; }
-      *got = (uint32_t)(lines / 4);
-    }
-    *bytes = cut; S.vpos += (lines >= need_lines && want) ? cut : have;
-    if (*got) S.est = 0.7 * S.est + 0.3 * ((double)cut / (double)*got);
     return true;
   }
-  int stage(Slot& s, std::string* e) {
-    uint32_t n[2] = {0, 0}; size_t* bytes = s.bytes; bytes[0] = bytes[1] = 0;
-    if (!stage_text(0, s, batch, &n[0], &bytes[0], e)) return SQ_ERR_IO;
-    if (paired) {
-      if (!stage_text(1, s, n[0] ? n[0] : 1u, &n[1], &bytes[1], e)) return SQ_ERR_IO;   // (one record is asked for at the end: has the second file more than the first?)
-      if (n[0] != n[1]) { *e = "mate files have different numbers of records (stopped after " + std::to_string(staged_total + std::min(n[0], n[1])) + " pairs)"; return SQ_ERR_IO; }
+  void produce_stage() {
+    (void)hipSetDevice(device);
+    auto fail = [&](int rc, const std::string& e) { Round r; r.rc = rc; r.err = e; push(std::move(r)); };
+    for (;;) {
+      int si = -1;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_slots.empty(); }); if (stop) return; si = free_slots.front(); free_slots.pop_front(); }
+      const double t0 = now(); std::string e; uint32_t n[2] = {0, 0}; size_t bytes[2] = {0, 0}; Round held;
+      bool ok = stage_text(0, si, true, batch, !paired, paired ? nullptr : &held, &n[0], &bytes[0], &e);
+      if (ok && paired && n[0]) ok = stage_text(1, si, false, n[0], true, &held, &n[1], &bytes[1], &e);
+      if (ok && paired && n[0] && n[1] != n[0]) { ok = false; e = "mate files have different numbers of records (stopped after " + std::to_string(staged_total + n[1]) + " pairs)"; }
+      if (ok && paired && !n[0] && sm[1].vpos < sm[1].vsize) {   // the first file is at its end: is there a record left in the second?
+        Round probe; uint32_t g = 0; size_t b = 0; ok = stage_text(1, si, true, 1, true, &probe, &g, &b, &e); give_back(probe.pieces);
+        if (ok && g) { ok = false; e = "mate files have different numbers of records (stopped after " + std::to_string(staged_total) + " pairs)"; }
+      }
+      { std::lock_guard<std::mutex> lk(mu); t_stage += now() - t0; if (stop) { for (auto& pc : held.pieces) free_pieces.push_back(pc.first); return; } }
+      if (!ok) { give_back(held.pieces); fail(e.empty() ? SQ_ERR_STATE : SQ_ERR_IO, e); return; }
+      if (n[0] == 0) { Round r; r.end_of_input = true; { std::lock_guard<std::mutex> lk(mu); free_slots.push_back(si); } push(std::move(r)); return; }
+      push(std::move(held));
+      staged_total += n[0];
     }
-    s.n = n[0];
-    for (int i = 0; i < (paired ? 2 : 1); ++i) if (bytes[i] >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(s.n) + " records spans more than 4 GB of text: use a smaller batch"; return SQ_ERR_ARG; }
-    return SQ_OK;
   }
-  // the device half of a batch, asynchronous on the slot's own stream: nothing here waits (the sequence buffer is sized by the text, which is
-  // more than twice the sequence bytes: a record is '@' + name + sequence + '+' + a quality string as long as the sequence + 4 line ends)
-  int issue(Slot& s, std::string* e) {
-    const size_t* bytes = s.bytes; hipStream_t st = s.st;
-    const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns; const uint32_t nrec = s.n * stride;
-    if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
-    if (!s.h_res && hipHostMalloc((void**)&s.h_res, 64, hipHostMallocDefault) != hipSuccess) { *e = "page-locked allocation failed (reader)"; return SQ_ERR_NOMEM; }
-    if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8) ||
-        dev_grow(&s.d_seq, &s.seq_cap, (bytes[0] + bytes[1]) / 2 + 64)) { *e = "device allocation failed (reader offsets)"; return SQ_ERR_NOMEM; }
-    if (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
-    for (int i = 0; i < ns; ++i) {
-      const size_t padded = (bytes[i] + 15) & ~(size_t)15; memset(s.stage[i] + bytes[i], 0, padded - bytes[i] + 16);
+  // one round: its pieces behind each other into the mate's text; with the mate's last round, its splitting kernels; with the batch's, the rest
+  int upload(const Round& r, std::string* e) {
+    Slot& s = slots[(size_t)r.slot]; hipStream_t st = s.st; const int i = r.mate;
+    const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns;
+    if (r.first_of_batch) {
+      if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
+      if (!s.h_res && hipHostMalloc((void**)&s.h_res, 64, hipHostMallocDefault) != hipSuccess) { *e = "page-locked allocation failed (reader)"; return SQ_ERR_NOMEM; }
+      if (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
+    }
+    size_t rb = 0; for (auto& pc : r.pieces) rb += pc.second;
+    if (r.dst == 0) { const size_t guess = (size_t)((double)batch * sm[i].est * 1.05) + (8u << 20); if (dev_grow(&s.d_text[i], &s.text_cap[i], std::max(guess, rb + 64))) { *e = "device allocation failed (reader text)"; return SQ_ERR_NOMEM; } }
+    if (dev_grow_keep(&s.d_text[i], &s.text_cap[i], r.dst + rb + 64, r.dst, st)) { *e = "device allocation failed (reader text)"; return SQ_ERR_NOMEM; }
+    size_t at = r.dst;
+    for (auto& pc : r.pieces) { if (hipMemcpyAsync((char*)s.d_text[i] + at, ring + (size_t)pc.first * PIECE, pc.second, hipMemcpyHostToDevice, st) != hipSuccess) { *e = "device copy failed (reader text)"; return SQ_ERR_DEVICE; } at += pc.second; }
+    if (r.last_of_mate) {
+      const size_t bytes = r.total; s.bytes[i] = bytes; s.n = r.n; const uint32_t nrec = s.n * stride;
+      const size_t padded = (bytes + 15) & ~(size_t)15;
+      if (hipMemsetAsync((char*)s.d_text[i] + bytes, 0, padded - bytes + 16, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
       const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
-      if (dev_grow(&s.d_text[i], &s.text_cap[i], padded + 64) || dev_grow(&s.d_nlpos[i], &s.nl_cap[i], ((size_t)4 * s.n + 8) * 4) || dev_grow(&s.d_start[i], &s.start_cap[i], ((size_t)s.n + 8) * 4) ||
+      if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8) ||
+          dev_grow(&s.d_nlpos[i], &s.nl_cap[i], ((size_t)4 * s.n + 8) * 4) || dev_grow(&s.d_start[i], &s.start_cap[i], ((size_t)s.n + 8) * 4) ||
           dev_grow(&s.d_tile, &s.tile_cap, ((size_t)ntile + 8) * 4) || dev_grow(&s.d_tbase, &s.tbase_cap, ((size_t)ntile + 8) * 8) ||
-          dev_grow(&s.d_spine, &s.spine_cap, ((size_t)std::max(sqk::scan_tiles(ntile), sqk::scan_tiles(nrec)) + 8) * 8)) { *e = "device allocation failed (reader text)"; return SQ_ERR_NOMEM; }
-      if (hipMemcpyAsync(s.d_text[i], s.stage[i], padded + 16, hipMemcpyHostToDevice, st) != hipSuccess) { *e = "device copy failed (reader text)"; return SQ_ERR_DEVICE; }
+          dev_grow(&s.d_spine, &s.spine_cap, ((size_t)std::max(sqk::scan_tiles(ntile), sqk::scan_tiles(nrec)) + 8) * 8)) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
       k_fq_count<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (uint32_t*)s.d_tile);
       sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_tile, (uint64_t*)s.d_tbase, ntile, (uint64_t*)s.d_spine, st);
       k_fq_index<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (const uint64_t*)s.d_tbase, (uint32_t*)s.d_nlpos[i], (uint64_t)4 * s.n);
       k_fq_records<<<(s.n + 255) / 256, 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_nlpos[i], s.n, (uint32_t)i, stride, (uint32_t*)s.d_len, (uint32_t*)s.d_start[i], s.d_err);
+      if (r.last_of_batch) {
+        // (the sequence buffer is sized by the text, which is more than twice the sequence bytes: a record is '@' + name + sequence + '+' + a quality
+        // string as long as the sequence + 4 line ends; a damaged record is reported, and nothing is copied for its batch)
+        if (dev_grow(&s.d_seq, &s.seq_cap, (s.bytes[0] + (paired ? s.bytes[1] : 0)) / 2 + 64)) { *e = "device allocation failed (reader sequences)"; return SQ_ERR_NOMEM; }
+        sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_len, (uint64_t*)s.d_off, nrec, (uint64_t*)s.d_spine, st);
+        for (int m = 0; m < ns; ++m) k_fq_copy<<<(uint32_t)(((uint64_t)s.n * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[m], (const uint32_t*)s.d_start[m], (const uint64_t*)s.d_off, s.n, (uint32_t)m, stride, (uint8_t*)s.d_seq, s.d_err);
+        k_fq_pad<<<1, 64, 0, st>>>((const uint64_t*)s.d_off, nrec, (uint8_t*)s.d_seq, s.d_err);
+        if (hipMemcpyAsync(s.h_res, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
+      }
     }
-    sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_len, (uint64_t*)s.d_off, nrec, (uint64_t*)s.d_spine, st);
-    for (int i = 0; i < ns; ++i) k_fq_copy<<<(uint32_t)(((uint64_t)s.n * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_start[i], (const uint64_t*)s.d_off, s.n, (uint32_t)i, stride, (uint8_t*)s.d_seq, s.d_err);
-    k_fq_pad<<<1, 64, 0, st>>>((const uint64_t*)s.d_off, nrec, (uint8_t*)s.d_seq, s.d_err);
-    if (hipMemcpyAsync(s.h_res, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    // the pieces go back to the stager once their copies are through (a mate's kernels and a batch's last kernels are waited for here too: 1 of ~20 ms)
+    if (hipStreamSynchronize(st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
+    if (r.last_of_batch) {
+      const unsigned* herr = s.h_res;
+      if (herr[0] != 0xFFFFFFFFu) {
+        const unsigned what = herr[1] ? herr[1] : herr[2];
+        *e = "record " + std::to_string(total + herr[0]) + (what == 1 ? " does not start with '@'" : what == 2 ? " has no '+' line after one sequence line" : " has a quality string whose length differs from its sequence's") +
+             " (multi-line FASTQ? set SQ_READER_DEVICE=0)"; return SQ_ERR_IO; }
+    }
     return SQ_OK;
   }
-  int finish(Slot& s, std::string* e) {
-    if (hipStreamSynchronize(s.st) != hipSuccess) { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; }
-    const unsigned* herr = s.h_res;
-    if (herr[0] != 0xFFFFFFFFu) {
-      const unsigned what = herr[1] ? herr[1] : herr[2];
-      *e = "record " + std::to_string(total + herr[0]) + (what == 1 ? " does not start with '@'" : what == 2 ? " has no '+' line after one sequence line" : " has a quality string whose length differs from its sequence's") +
-           " (multi-line FASTQ? set SQ_READER_DEVICE=0)"; return SQ_ERR_IO; }
-    return SQ_OK;
-  }
-  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-  void produce_stage() {
-    for (;;) {
-      int si = -1;
-      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_slots.empty(); }); if (stop) return; si = free_slots.front(); free_slots.pop_front(); }
-      std::string e; const double t0 = now(); const int rc = stage(slots[(size_t)si], &e); const double dt = now() - t0;
-      std::lock_guard<std::mutex> lk(mu); t_stage += dt;
-      if (rc != SQ_OK) { err = e; err_rc = rc; stage_done = true; cv.notify_all(); return; }
-      if (slots[(size_t)si].n == 0) { stage_done = true; free_slots.push_back(si); cv.notify_all(); return; }
-      staged_total += slots[(size_t)si].n; text_bytes += slots[(size_t)si].bytes[0] + slots[(size_t)si].bytes[1]; staged.push_back(si); cv.notify_all();
-    }
-  }
-  // SQ_READER_DEPTH batches in flight on the device side (default 1: with 2, the upload of batch k + 1 overlaps the kernels of batch k, but on the
-  // box measured — 16.6 GB of text, 40 x 10^6 pairs — the two streams' copies and the staging threads got in each other's way: 57 against 72 M pairs/s)
-  size_t depth = 1;
   void produce_upload() {
     (void)hipSetDevice(device);
-    std::deque<int> pending;
     for (;;) {
-      int take = -1;
-      { std::unique_lock<std::mutex> lk(mu);
-        if (pending.empty()) cv.wait(lk, [&] { return stop || !staged.empty() || stage_done; });
-        if (stop) return;
-        if (!staged.empty() && pending.size() < depth) { take = staged.front(); staged.pop_front(); }
-        else if (pending.empty()) { done = true; cv.notify_all(); return; }   // the end of the input, or the stager's complaint (err_rc) once everything before it has gone out
-      }
-      std::string e; const double t0 = now(); int rc, si;
-      if (take >= 0) { si = take; rc = issue(slots[(size_t)si], &e); if (rc == SQ_OK) pending.push_back(si); }
-      else { si = pending.front(); pending.pop_front(); rc = finish(slots[(size_t)si], &e); }
-      const double dt = now() - t0;
+      Round r;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !rounds.empty(); }); if (stop) return; r = std::move(rounds.front()); rounds.pop_front(); }
+      if (r.rc != SQ_OK || r.end_of_input) { std::lock_guard<std::mutex> lk(mu); if (r.rc != SQ_OK) { err = r.err; err_rc = r.rc; } done = true; cv.notify_all(); return; }
+      std::string e; const double t0 = now(); const int rc = upload(r, &e); const double dt = now() - t0;
+      give_back(r.pieces);
       std::lock_guard<std::mutex> lk(mu); t_upload += dt;
-      if (rc != SQ_OK) { for (int p : pending) (void)hipStreamSynchronize(slots[(size_t)p].st); err = e; err_rc = rc; done = true; cv.notify_all(); return; }
-      if (take < 0) { total += slots[(size_t)si].n; ready.push_back(si); cv.notify_all(); }
+      if (rc != SQ_OK) { err = e; err_rc = rc; done = true; stop = true; cv.notify_all(); return; }
+      if (r.last_of_batch) { total += slots[(size_t)r.slot].n; ready.push_back(r.slot); cv.notify_all(); }
     }
   }
 };
@@ -292,7 +326,10 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
   const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
   R->pool.reset(new Workers(std::max(1u, nt)));
-  if (getenv("SQ_READER_DEPTH")) R->depth = (size_t)std::max(1, std::min(4, atoi(getenv("SQ_READER_DEPTH"))));
+  if (hipHostMalloc((void**)&R->ring, (size_t)sq_dev_reader::RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError(); R->ring = nullptr; for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd);
+    sq_set_error("page-locked allocation failed (reader: %zu MB)", ((size_t)sq_dev_reader::RING_PIECES * sq_dev_reader::PIECE) >> 20); return SQ_ERR_NOMEM; }
+  for (int k = 0; k < sq_dev_reader::RING_PIECES; ++k) R->free_pieces.push_back(k);
   sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); });
   *out = r; return SQ_OK;
 }
@@ -314,15 +351,16 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
   if (R->prod.joinable()) R->prod.join();
   if (R->prod2.joinable()) R->prod2.join();
-  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total, (double)R->text_bytes / 1e9,
-      R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
+  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
+      (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
   R->pool.reset(); (void)hipSetDevice(R->device);
   for (auto& s : R->slots) {
     if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     if (s.h_res) (void)hipHostFree(s.h_res);
-    for (int i = 0; i < 2; ++i) { if (s.stage[i]) (void)hipHostFree(s.stage[i]); if (s.d_text[i]) (void)hipFree(s.d_text[i]); if (s.d_nlpos[i]) (void)hipFree(s.d_nlpos[i]); if (s.d_start[i]) (void)hipFree(s.d_start[i]); }
+    for (int i = 0; i < 2; ++i) { if (s.d_text[i]) (void)hipFree(s.d_text[i]); if (s.d_nlpos[i]) (void)hipFree(s.d_nlpos[i]); if (s.d_start[i]) (void)hipFree(s.d_start[i]); }
     for (void* p : {s.d_tile, s.d_tbase, s.d_spine, s.d_len, s.d_off, s.d_seq, (void*)s.d_err}) if (p) (void)hipFree(p);
   }
+  if (R->ring) (void)hipHostFree(R->ring);
   for (auto& sm : R->sm) for (auto& f : sm.files) if (f.fd >= 0) close(f.fd);
   delete R;
 }
