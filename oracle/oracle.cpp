@@ -954,6 +954,18 @@ static void compute_eff_lengths(const FLD& fld, const std::vector<uint32_t>& ref
 }
 void QuantState::burnin_finalize() { compute_eff_lengths(fld, ix->ref_len, logEffLen); fld.cache(); burnedIn = true; }
 
+// LogCMFCache::getAmbigFragLengthProb (DistributionUtils.cpp:151-172): the probability that a fragment whose one read lies here is no longer than
+// the transcript lets it be.  liveCMF = FLD::cmf before cacheCMF; ambigCMF = LogCMFCache's own table (evaluateLogCMF, :104-118)
+static double ambig_frag_prob(const FLD& fld, const std::vector<double>& liveCMF, const std::vector<double>& ambigCMF, bool singleEnd, bool burned, bool fwd,
+                              int32_t pos, int32_t rlen, int32_t tl) {
+  int32_t maxFL;
+  if (fwd) { int32_t p1 = pos < 0 ? 0 : pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
+  else { int32_t p1 = pos + rlen; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
+  const bool useFLD = singleEnd || burned;
+  auto cmfv = [&](size_t len) -> double { if (useFLD) return fld.cached ? fld.cmf(len) : liveCMF[std::min<size_t>(len, 1000)]; return len < 1001 ? ambigCMF[len] : ambigCMF[1000]; };
+  const double refCM = cmfv((size_t)tl); const bool cm = !(refCM == SQ_LOG_0);
+  return cm ? (cmfv((size_t)maxFL) - refCM) : SQ_LOG_EPSILON;
+}
 static inline double u01(uint64_t seed, uint64_t read, uint64_t aln) {
   uint64_t x = sq_mix64(seed ^ sq_mix64(read * 0x9E3779B97F4A7C15ULL + aln + 1));
   return (double)(x >> 11) * (1.0 / 9007199254740992.0);
@@ -1120,15 +1132,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       double logFragProb = 0.0;
       bool unexpectedOrphan = (expf.type == T_PE && a.mate_status != SQ_MS_PAIRED_END_PAIRED);
       if (o.model_single_frag_prob && o.use_frag_len_dist && (singleEnd || unexpectedOrphan)) {
-        // LogCMFCache::getAmbigFragLengthProb (DistributionUtils.cpp:151-172)
-        int32_t tl = (int32_t)ix.ref_clen[t], maxFL;
-        if (a.fwd) { int32_t p1 = a.pos < 0 ? 0 : a.pos; p1 = p1 > tl ? tl : p1; maxFL = tl - p1; }
-        else { int32_t p1 = a.pos + (int32_t)a.read_len; p1 = p1 < 0 ? 0 : p1; p1 = p1 > tl ? tl : p1; maxFL = p1; }
-        bool useFLD = singleEnd || burned;
-        auto cmfv = [&](size_t len) -> double { if (useFLD) return S.fld.cached ? S.fld.cmf(len) : S.liveCMF[std::min<size_t>(len,
-            1000)]; return len < 1001 ? S.ambigCMF[len] : S.ambigCMF[1000]; };
-        double refCM = cmfv((size_t)tl); bool cm = !(refCM == SQ_LOG_0);
-        logFragProb = cm ? (cmfv((size_t)maxFL) - refCM) : SQ_LOG_EPSILON;
+        logFragProb = ambig_frag_prob(S.fld, S.liveCMF, S.ambigCMF, singleEnd, burned, a.fwd != 0, a.pos, (int32_t)a.read_len, (int32_t)ix.ref_clen[t]);
       } else if (unexpectedOrphan) logFragProb = SQ_LOG_EPSILON;
       if (flen > 0 && o.use_frag_len_dist && cond) {
         double lenProb = S.fld.pmf(flen);
@@ -2215,6 +2219,22 @@ void orc_fld_prior(double mu, double sd, double* log_hist_1001, double* tot) {
   f.init(mu, sd);
   for (int i = 0; i <= 1000; ++i) log_hist_1001[i] = f.hist[i];
   *tot = f.totMass;
+}
+// [r4] the FLD on its own (tests/test_fld_pin.py holds it against the reference's FragmentLengthDistribution.cpp compiled into oracle/_ref/libfld_ref.so):
+// counts_1001[len] fragments of every length enter with the same log mass, as one mini-batch does it (SPEC §D3)
+void* orc_fld_new(double mu, double sd) { FLD* f = new FLD(); f->init(mu, sd); return f; }
+void orc_fld_free(void* h) { delete (FLD*)h; }
+void orc_fld_apply(void* h, const uint32_t* counts_1001, double log_mass) { FLD* f = (FLD*)h; std::vector<uint32_t> c(counts_1001, counts_1001 + 1001); for (int l = 0; l <= 1000; ++l) if (c[l] && (uint32_t)l < f->minLen) f->minLen = (uint32_t)l; f->apply_counts(c, log_mass); }
+void orc_fld_cache(void* h) { ((FLD*)h)->cache(); }
+void orc_fld_pmf(void* h, double* out, uint32_t n) { FLD* f = (FLD*)h; for (uint32_t i = 0; i < n; ++i) out[i] = f->pmf(i); }
+void orc_fld_cmf(void* h, double* out, uint32_t n) { FLD* f = (FLD*)h; for (uint32_t i = 0; i < n; ++i) out[i] = f->cmf(i); }
+uint32_t orc_fld_min(void* h) { return ((FLD*)h)->minLen; }
+void orc_fld_eff_lengths(void* h, const uint32_t* ref_len, uint32_t n, double* log_eff_len) { std::vector<uint32_t> rl(ref_len, ref_len + n); std::vector<double> out(n); compute_eff_lengths(*(FLD*)h, rl, out); memcpy(log_eff_len, out.data(), (size_t)n * 8); }
+// the two tables QuantState::init builds beside the FLD, then the question processMiniBatch asks per orphan / single-end alignment
+double orc_fld_ambig_prob(void* h, int single_end, int burned, int fwd, int32_t pos, int32_t rlen, int32_t tlen) {
+  const FLD& f = *(FLD*)h; std::vector<double> live(1001), amb(1001); double c1 = SQ_LOG_0, c2 = SQ_LOG_0;
+  for (int j = 0; j <= 1000; ++j) { c1 = sq_log_add(c1, f.hist[j]); live[j] = c1 - f.totMass; c2 = sq_log_add(c2, SQ_LOG_EPSILON); amb[j] = c2; }
+  return ambig_frag_prob(f, live, amb, single_end != 0, burned != 0, fwd != 0, pos, rlen, tlen);
 }
 double orc_forgetting_mass(double ff, uint64_t b) { QuantState S; S.op.o.forgetting_factor = ff; return S.forgetting_mass(b); }
 
