@@ -2190,6 +2190,8 @@ int orc_em_steps(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* 
   for (uint32_t i = 0; i < P.M; ++i) alpha_out[i] = a[i];
   return 0;
 }
+// [r4] the combined weights em_setup forms (CollapsedEMOptimizer.cpp:830-873), label by label: tests/test_em_pin.py hands them to the reference's EMUpdate_
+int orc_em_combined_weights(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* cw_out) { EMProblem P; em_setup(P, eq, txp, o); memcpy(cw_out, P.cw.data(), P.cw.size() * 8); return 0; }
 // multi-threaded EM timing leg for the CPU baseline: class pass + transcript pass over thread ranges
 double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, uint32_t iters, uint32_t nthreads);
 
