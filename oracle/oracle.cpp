@@ -15,6 +15,11 @@
 // The infix aligner of orphan recovery (a5) IS pinned against the reference's own src/edlib.cpp, compiled from
 // /root/reference into oracle/_ref/libedlib_ref.so (oracle/Makefile `ref`), and through 600 committed vectors made
 // from it (tests/golden/edlib_infix_vectors.json.gz).
+// Compiled from the reference tree the same way and held against this file (tests/test_*_pin.py): the option defaults and log-space helpers, the
+// forgetting-mass schedule, SimplePosBias.cpp + spline.h (--posBias), SBModel.cpp and GCFragModel.hpp (--seqBias / --gcBias),
+// [r4] FragmentLengthDistribution.cpp and DistributionUtils.cpp (the FLD, the effective lengths of burn-in, an orphan's fragment-length probability:
+// rows a10-a13) and EMUtils.cpp (the EM update: rows a15-a16).  What cannot be compiled here (SalmonQuantify.cpp, CollapsedEMOptimizer.cpp: Boost,
+// TBB, pufferfish) is followed line by line and cited.
 //
 // Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.
 #include <algorithm>
