@@ -23,6 +23,18 @@
 #include <cstdlib>
 #include <cstdio>
 
+// [r4] experiment, off by default (SQ_EM_SPIN=1): waiting for the EM's stream by polling instead of hipStreamSynchronize.  The first drain of the set-up
+// returns 3-28 ms late for 1 ms of device work when the stream has been idle since the export; the suspicion was the blocking wait's interrupt.  Measured
+// (tools/runs/r4r.sh, three runs each): 14 / 6.5 / 25 ms polling, 6.8 / 11 / 3 ms blocking — the work itself completes late, not its notification.
+static inline hipError_t sq_em_wait(hipStream_t st) {
+  static const int spin = getenv("SQ_EM_SPIN") ? atoi(getenv("SQ_EM_SPIN")) : 0;
+  if (!spin) return hipStreamSynchronize(st);
+  for (bool spun = false;; spun = true) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) { if (spun && e == hipSuccess) (void)hipGetLastError(); return e; }   // "not ready" is not an error: do not leave it behind as the thread's last one
+    __builtin_ia32_pause();
+  }
+}
 namespace {
 
 // SQ_TIMING=1: host-side phase timings on stderr (diagnostics only)
@@ -450,6 +462,7 @@ __global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict_
     if (lane == 0) *d.log_norm_out = sq_digamma(v);
   }
 }
+__global__ void k_copy_f64(uint32_t n, const double* __restrict__ src, double* __restrict__ dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
 __global__ void k_psi0(EmDev d, const double* __restrict__ alpha, double* __restrict__ psi) {   // psi of the initial alphas (the iterations get theirs from k_fin3)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.M) { const double ap = alpha[i] + d.prior[i]; psi[i] = (ap > 1e-10) ? sq_digamma(ap) : -HUGE_VAL; }
@@ -718,7 +731,13 @@ struct EmSession {
     h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down; nullptr: plain pageable copies
     if (h_stage) {
       memcpy(h_stage, txp->eff_len, (size_t)M * 8);
-      SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st));
+      // [r4] experiment, off by default (SQ_EM_KUP=1): the effective lengths come up by a KERNEL reading the page-locked buffer instead of a copy command
+      // (in a job whose reads are resident in HBM this is the first host-to-device copy for seconds: a sleeping copy engine was the suspicion for the late
+      // drain below).  Measured (tools/runs/r4s.sh, four runs each): 19 / 15 / 16 / 15 ms with the kernel, 10 / 28 / 21 / 22 ms with the command: not the engine.
+      static const int kup = getenv("SQ_EM_KUP") ? atoi(getenv("SQ_EM_KUP")) : 0;
+      void* hdev = nullptr;
+      if (kup && hipHostGetDevicePointer(&hdev, h_stage, 0) == hipSuccess && hdev) k_copy_f64<<<nb(M), TB, 0, st>>>(M, (const double*)hdev, d_eff.p);
+      else { (void)hipGetLastError(); SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
     }
     else SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));
@@ -726,7 +745,7 @@ struct EmSession {
     // [r2] the "first submission gap": without this drain the first synchronisation of the set-up (after the sort and the block plans, 0.9 ms
     // of device work in the kernel trace) returned 17-21 ms late when the stream had been idle since the export; with it the whole
     // set-up takes 2 ms (SQ_TIMING, MI355X / ROCm 7.2).  The upload is 1.3 MB from page-locked memory: the drain itself costs 0.03 ms.
-    SQ_HIP_CHECK(hipStreamSynchronize(st)); pt.mark("upload drained");
+    SQ_HIP_CHECK(sq_em_wait(st)); pt.mark("upload drained");
     // combined weights, prior, CSC
     if (E) k_prep_cw<<<nb(E), TB, 0, st>>>(E, M, p_off, p_tid, p_w, (const uint64_t*)p_cnt, d_eff.p, o->no_rich_eq_classes,
         o->eq_class_mode, d_cw.p, d_cnt.p, d_err.p);
@@ -754,7 +773,7 @@ struct EmSession {
       uint32_t S[4] = {0, 0, 0, 0}, herr = 0;
       for (int l = 0; l < 4; ++l) SQ_HIP_CHECK(hipMemcpyAsync(&S[l], base[l].p + M, 4, hipMemcpyDeviceToHost, st));
       SQ_HIP_CHECK(hipMemcpyAsync(&herr, d_err.p, 4, hipMemcpyDeviceToHost, st));
-      SQ_HIP_CHECK(hipStreamSynchronize(st));
+      SQ_HIP_CHECK(sq_em_wait(st));
       pt.mark("prep:csc+plan-sizes");
       if (herr == 0xFFFFFFFFu) { sq_set_error("EM reduction plan deeper than 4 levels"); return SQ_ERR_OVERFLOW; }
       if (herr) { sq_set_error("eq-class label references transcript %u >= %u", herr - 1, M); return SQ_ERR_ARG; }
@@ -779,11 +798,11 @@ struct EmSession {
       std::vector<uint32_t> hn_pageable; uint32_t* hn = (uint32_t*)arena->pinned(1, (std::max<size_t>(S0, E) + 1) * 4);
       if (!hn) { hn_pageable.resize(std::max<size_t>(S0, E) + 1); hn = hn_pageable.data(); }
       if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, L1_CHUNK, L1_TB, nxt.p);
-        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
         for (uint32_t g = 0; g < S0; g = hn[g]) h_chunk.push_back(g); h_chunk.push_back(S0); }
       pt.mark("prep:jump1");
       if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, CL_CHUNK, 0, nxt.p);
-        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+        SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
         for (uint32_t c = 0; c < E; c = hn[c]) h_cchunk.push_back(c); h_cchunk.push_back(E); }
       pt.mark("prep:jump2");
       if (d_chunk.upload(h_chunk) || d_cchunk.upload(h_cchunk) || d_seg8.alloc(L)) {
@@ -798,7 +817,7 @@ struct EmSession {
       SQ_HIP_CHECK(hipMemsetAsync(d_l2cnt.p, 0, M, st)); SQ_HIP_CHECK(hipMemsetAsync(d_l2lo.p, 0, (size_t)M * 4, st));
       k_plan_l2<<<nb(d.nseg[1]), TB, 0, st>>>(d.nseg[1], d_slo[1].p, d_scn[1].p, d_stx[1].p, d_l2lo.p, d_l2cnt.p);
     }
-    SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(sq_em_wait(st));
     d.M = M;
     d.E = E;
     d.L = L;
@@ -828,7 +847,7 @@ struct EmSession {
     d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
     d.psi_mode = 0; d.psi = nullptr; d.log_norm = d_lognorm.p; d.psi_out = nullptr; d.log_norm_out = d_lognorm.p;
     d.fin_ctr = d_finctr.p; d.blk_rel = d_blkrel.p; d.blk_bad = d_blkbad.p;
-    SQ_HIP_CHECK(hipMemsetAsync(d_finctr.p, 0, (FIN_GROUPS + 1) * 32 * sizeof(unsigned), st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(hipMemsetAsync(d_finctr.p, 0, (FIN_GROUPS + 1) * 32 * sizeof(unsigned), st)); SQ_HIP_CHECK(sq_em_wait(st));
     pt.mark("device-prepare");
     return SQ_OK;
   }
@@ -934,18 +953,18 @@ struct EmSession {
         if (it + chunk > lim) chunk = lim - it;
         for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
           SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
-        SQ_HIP_CHECK(hipStreamSynchronize(st));
+        SQ_HIP_CHECK(sq_em_wait(st));
         if (hflags[0]) { done = hflags[0]; break; }
       }
       executed = done ? done : it;
     }
-    SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(hipEventRecord(e1, st)); SQ_HIP_CHECK(sq_em_wait(st));
     float ms = 0; SQ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     result_dev = ((executed - it0) % 2 == 0) ? d_a0.p : d_a1.p;   // after `executed - it0` swaps starting from d_a0
     if (fetch) {
       if (h_stage) {
         SQ_HIP_CHECK(hipMemcpyAsync(h_stage + 2 * (size_t)M, result_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st));
-        SQ_HIP_CHECK(hipStreamSynchronize(st));
+        SQ_HIP_CHECK(sq_em_wait(st));
         memcpy(alpha.data(), h_stage + 2 * (size_t)M, (size_t)M * 8);
       }
       else SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
@@ -970,7 +989,7 @@ struct EmSession {
     if (E) k_zero_dropped<<<(E + TB - 1) / TB, TB, 0, st>>>(E, p_off_, d_cnt.p, d_cw.p);
     k_prep_prior<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_eff.p, o->vb_prior, o->per_transcript_prior, d_prior.p);
     if (L) k_refresh_tcw<<<(uint32_t)((L + TB - 1) / TB), TB, 0, st>>>(L, d_cscpos.p, d_cw.p, d_tcw.p);
-    SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(sq_em_wait(st));
     return SQ_OK;
   }
 };
@@ -1383,12 +1402,12 @@ extern "C" int sq_gibbs_range_report_dev(int device, const sq_eq_table* eq, cons
     }
     SQ_HIP_CHECK(hipEventRecord(e1, st));
     k_mul<<<(M + TB - 1) / TB, TB, 0, st>>>(M, d_mu.p, d_eff.p, d_me.p);
-    SQ_HIP_CHECK(hipMemcpyAsync(me.data(), d_me.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(hipMemcpyAsync(me.data(), d_me.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
     { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { round_ms += ms; rounds += thin; } }
     double denom = canonical_sum_host(me);                                                                // :489-492 (order-defined sum)
     double scale = (double)num_mapped / denom;
     k_gibbs_alpha<<<(M + TB - 1) / TB, TB, 0, st>>>(g, scale, d_out.p);
-    SQ_HIP_CHECK(hipMemcpyAsync(alphas.data(), d_out.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
+    SQ_HIP_CHECK(hipMemcpyAsync(alphas.data(), d_out.p, (size_t)M * 8, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
     if (cb(alphas.data(), M, user)) break;
   }
   if (report) { report->rounds = rounds; report->device_ms = round_ms; report->ms_per_round = rounds ? round_ms / (double)rounds : 0.0; report->draws_per_round = draws_per_round;
