@@ -283,10 +283,17 @@ struct BgzfSource {
     const uint32_t isize = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
     if (isize > (1u << 16)) { b->err = "BGZF member larger than 64 KB"; return; }
     b->out.resize(isize);
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { b->err = "zlib initialisation failed"; return; }
+    // [r4] one inflate state per worker thread, reset per member: setting one up and tearing it down for every 64 KB member (two allocations of ~40 KB
+    // each way, from 32 threads at once) cost more than the inflating
+    struct Z { z_stream zs; bool ok = false; Z() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; } ~Z() { if (ok) inflateEnd(&zs); } };
+    static thread_local Z tz;
+    static const bool per_member = getenv("SQ_BGZF_TLS") && atoi(getenv("SQ_BGZF_TLS")) == 0;   // 0: a fresh state per member (the round-2 form), for comparison
+    z_stream fresh; if (per_member) { memset(&fresh, 0, sizeof fresh); if (inflateInit2(&fresh, -15) != Z_OK) { b->err = "zlib initialisation failed"; return; } }
+    else if (!tz.ok || inflateReset2(&tz.zs, -15) != Z_OK) { b->err = "zlib initialisation failed"; return; }
+    z_stream& zs = per_member ? fresh : tz.zs;
     zs.next_in = const_cast<Bytef*>(p + hdr); zs.avail_in = (uInt)(b->csize - hdr - 8); zs.next_out = (Bytef*)b->out.data(); zs.avail_out = isize;
-    const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END; inflateEnd(&zs);
+    const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+    if (per_member) inflateEnd(&fresh);
     if ((isize && rc != Z_STREAM_END) || (isize && zs.total_out != isize)) { b->err = "corrupt BGZF member"; return; }
     if (crc32(crc32(0L, Z_NULL, 0), (const Bytef*)b->out.data(), isize) != crc) b->err = "BGZF checksum mismatch";
   }
