@@ -151,6 +151,52 @@ int main(int argc, char** argv) {
         sq_index* bad = nullptr; if (sq_index_load((dir + "/idx_mut").c_str(), -1, &bad) == SQ_OK) { ++loaded; sq_index_free(bad); } }
       printf("corrupt index: %d of 200 damaged files still loaded\n", loaded); }
     printf("malformed input: %d of 300 mutated eq files still parsed, %d reads came out of 300 mutated FASTQ files\n", accepted, ok_reads); }
+  // ---- [r4] alignment-based input: a name-grouped SAM file of pairs, orphans and unmapped reads through sq_sam_*; then mutated copies (never a crash)
+  { std::string sam = "@HD\tVN:1.6\tSO:unsorted\n"; for (uint32_t t = 0; t < M; ++t) sam += "@SQ\tSN:" + std::string(sq_index_ref_name(idx, t)) + "\tLN:" + std::to_string(sq_index_ref_len(idx, t)) + "\n";
+    sam += "@PG\tID:x\n"; uint64_t want_frags = 0;
+    for (int i = 0; i < 600; ++i) { const std::string nm = "q" + std::to_string(i); const int kind = (int)(g() % 10); const int nal = 1 + (int)(g() % 3);
+      if (kind == 0) { sam += nm + "\t77\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n" + nm + "\t141\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n"; continue; }
+      ++want_frags;
+      for (int a = 0; a < nal; ++a) { const uint32_t t = (uint32_t)(g() % M); const uint32_t L = sq_index_ref_len(idx, t); const int p1 = 1 + (int)(g() % (L > 400 ? L - 400 : 1)), fl = 150 + (int)(g() % 200);
+        const std::string rn = sq_index_ref_name(idx, t); const int as = -(int)(g() % 30); const int sec = a ? 256 : 0;
+        if (kind == 1) sam += nm + "\t" + std::to_string(73 + sec) + "\t" + rn + "\t" + std::to_string(p1) + "\t1\t100M\t*\t0\t0\t*\t*\tAS:i:" + std::to_string(as) + "\n";      // mate unmapped: an orphan
+        else { sam += nm + "\t" + std::to_string(99 + sec) + "\t" + rn + "\t" + std::to_string(p1) + "\t1\t100M\t=\t" + std::to_string(p1 + fl - 100) + "\t" + std::to_string(fl) + "\t*\t*\tAS:i:" + std::to_string(as) + "\tNH:i:" + std::to_string(nal) + "\n";
+               sam += nm + "\t" + std::to_string(147 + sec) + "\t" + rn + "\t" + std::to_string(p1 + fl - 100) + "\t1\t100M\t=\t" + std::to_string(p1) + "\t-" + std::to_string(fl) + "\t*\t*\tAS:i:" + std::to_string(as) + "\n"; } } }
+    const std::string sp = dir + "/a.sam"; { FILE* f = fopen(sp.c_str(), "wb"); fwrite(sam.data(), 1, sam.size(), f); fclose(f); }
+    auto drain = [&](const std::string& path, bool must_open, uint64_t* frags) -> bool {
+      sq_sam* sm = nullptr; const int rc = sq_sam_open(path.c_str(), 1, &sm); if (rc != SQ_OK) { CHECK(!must_open); return false; }
+      const uint32_t nr = sq_sam_num_refs(sm); for (uint32_t i = 0; i < nr && i < 3; ++i) { CHECK(sq_sam_ref_name(sm, i) != nullptr); (void)sq_sam_ref_len(sm, i); }
+      bool ok = true; *frags = 0;
+      for (;;) { sq_aln_batch ab; memset(&ab, 0, sizeof ab); sq_sam_counts sc; const int r2 = sq_sam_next(sm, 97, (int)(g() & 1), 1.0, &ab, &sc); if (r2 != SQ_OK) { ok = false; break; } if (!ab.n) break;
+        *frags += ab.n; CHECK(ab.read_off[0] == 0);
+        for (uint32_t i = 0; i < ab.n; ++i) { CHECK(ab.read_off[i] <= ab.read_off[i + 1]); for (uint64_t a = ab.read_off[i]; a < ab.read_off[i + 1]; ++a) CHECK(ab.aln[a].tid < nr); } }
+      sq_sam_close(sm); return ok; };
+    uint64_t frags = 0; CHECK(drain(sp, true, &frags)); CHECK(frags == want_frags);
+    int sam_ok = 0;
+    for (int it = 0; it < 300; ++it) { std::string b = sam; const int nm = 1 + (int)(g() % 4);
+      for (int j = 0; j < nm; ++j) { const size_t p = g() % b.size(); const int op = (int)(g() % 5);
+        if (op == 0) b[p] = (char)(g() & 0xFF); else if (op == 1) b.resize(p); else if (op == 2) b.insert(p, std::to_string(g())); else if (op == 3) b[p] = "\t\n@*=-0123456789"[g() % 16]; else b.insert(p, "\t");
+        if (b.empty()) b = "@"; }
+      const std::string mp = dir + "/mut.sam"; FILE* f = fopen(mp.c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
+      uint64_t fr = 0; sam_ok += drain(mp, false, &fr) ? 1 : 0; }
+    printf("malformed SAM: %d of 300 mutated files read to the end\n", sam_ok); }
+  // ---- [r4] the rest of the output directory: meta_info.json, the index digests, fld.gz, the bias dumps
+  { const std::string aux = dir + "/out/aux_info";
+    for (int wch = 0; wch < 6; ++wch) { const char* h = sq_index_hash(idx, wch); CHECK(h != nullptr); }
+    std::vector<double> lp(1001); for (int i = 0; i <= 1000; ++i) lp[i] = -0.5 * ((i - 250.0) / 25.0) * ((i - 250.0) / 25.0) - 4.0;
+    double mean = 0, sd = 0; uint32_t sup = 0; CHECK(sq_write_fld_samples((aux + "/fld.gz").c_str(), lp.data(), 1, 1000, 10000, 7, &mean, &sd, &sup) == SQ_OK); CHECK(sup == 1001 && mean > 200 && mean < 300 && sd > 10 && sd < 40);
+    uint32_t nbins = 0; CHECK(sq_write_legacy_bias(aux.c_str(), &nbins) == SQ_OK); CHECK(nbins > 0);
+    std::vector<double> tot(3, 1.0), cn(75, 0.5); CHECK(sq_write_gc_model((aux + "/obs_gc.gz").c_str(), 0, 3, 25, tot.data(), cn.data()) == SQ_OK);
+    std::vector<double> sm(9 * 64, -1.386); CHECK(sq_write_seq_model((aux + "/obs5_seq.gz").c_str(), sm.data()) == SQ_OK);
+    const uint32_t lb[5] = {791, 1265, 1707, 2433, 0xFFFFFFFFu}; std::vector<double> pm(5 * 20, 0.05); CHECK(sq_write_pos_models((aux + "/obs5_pos.gz").c_str(), 5, lb, 20, pm.data()) == SQ_OK);
+    sq_meta_info mi; memset(&mi, 0, sizeof mi); const char* lt[] = {"IU"}; const uint32_t lcl[5] = {791, 1265, 1707, 2433, 100000};
+    mi.samp_type = "none"; mi.opt_type = "vb"; mi.num_libraries = 1; mi.library_types = lt; mi.frag_dist_length = 1001; mi.frag_length_mean = mean; mi.frag_length_sd = sd; mi.num_bias_bins = nbins;
+    mi.mapping_type = "mapping"; mi.keep_duplicates = 0; mi.num_valid_targets = M; mi.num_eq_classes = cnt.size(); mi.num_length_classes = 5; mi.length_classes = lcl;
+    mi.index_seq_hash = sq_index_hash(idx, 0); mi.index_name_hash = sq_index_hash(idx, 1); mi.index_seq_hash512 = sq_index_hash(idx, 2); mi.index_name_hash512 = sq_index_hash(idx, 3);
+    mi.index_decoy_seq_hash = sq_index_hash(idx, 4); mi.index_decoy_name_hash = sq_index_hash(idx, 5);
+    mi.num_processed = 5000; mi.num_mapped = 4900; mi.percent_mapped = 98.0; mi.start_time = "Thu Sep 24 12:00:00 2026"; mi.end_time = "Thu Sep 24 12:00:01 2026"; mi.backend = "gfx950"; mi.runtime_s = 1.0;
+    CHECK(sq_write_meta_info((aux + "/meta_info.json").c_str(), &mi) == SQ_OK);
+    mi.quant_errors = "a \"quoted\" reason\n"; mi.keep_duplicates = -1; mi.library_types = nullptr; mi.num_libraries = 0; CHECK(sq_write_meta_info((aux + "/meta_info_err.json").c_str(), &mi) == SQ_OK); }
   sq_index_free(idx);
   printf("host sanitize run ok: %u refs, %llu k-mer lookups, 5000 read pairs, %zu classes\n", M, (unsigned long long)tried, cnt.size());
   return 0;
