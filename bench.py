@@ -151,6 +151,9 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
     eq-classes -> export -> normalizeAlphas -> VBEM.  Wall time from opening the files to the converged alphas; plain, BGZF and gzip input."""
     import shutil, tempfile, subprocess, gzip
     d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # the files (2 x n x (2 L + 7) bytes, the head copies and their compressed forms: ~1.4 x) have to fit where they are written: fewer pairs if they do not
+    room = shutil.disk_usage(d).free; need = lambda n: int(1.4 * 2 * n * (2 * read_len + 7)) + (256 << 20)
+    while n_pairs > 1000000 and need(n_pairs) > room: n_pairs //= 2
     gz_pairs = min(n_pairs, gz_pairs or n_pairs)
     out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(),
            "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
@@ -610,72 +613,79 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
                                  "note": "B_gibbs = 28 L + 16 E + 32 M per round (SURVEY 8d); the working set is cache-resident and a round's time is its N categorical draws"}
     cpu = None; parity = None
     if a.cpu_sample > 0 and world == 1 and host_first is not None:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc
-        Sn = min(sizes[W * S], a.cpu_sample)
-        c_a = time.perf_counter()
-        oidx = orc.OrcIndex(idx)
-        t_oidx = time.perf_counter() - c_a
-        soff = (np.arange(0, 2 * Sn + 1, dtype=np.uint64) * np.uint64(RL))
-        rb = api.make_read_batch(host_first, soff, Sn, paired=True)
-        c0 = time.perf_counter()
-        ro, aln, mt, stc = orc.map_batch(oidx, opts, rb, threads=ncores)
-        c1 = time.perf_counter()
-        ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, stc["num_with_joint_hits"]); ost.finish(); eqc = ost.eq_finish()
-        lmc, uqc, tcc, lec, _ = ost.model()
-        pc = orc.normalize_alphas(M, eqc, lmc, uqc, tcc)
-        c2 = time.perf_counter()
-        a_c, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
-        c3 = time.perf_counter()
-        # the checker's EM loop is single-threaded (order-defined sums); its multi-threaded iteration (same arithmetic,
-        # transcripts split over threads) is timed separately and used for the composite so the CPU gets its cores
-        em_single_s = c3 - c2
-        em_try = {t: orc.em_time_iters(eqc, np.exp(lec), 20, t) / 20.0 * repc["iters"] for t in sorted({min(ncores, 8), min(ncores, 32), ncores})}
-        em_thr_n, em_thr_s = min(em_try.items(), key=lambda kv: kv[1])
-        if em_single_s < em_thr_s: em_thr_n, em_thr_s = 1, em_single_s       # the CPU side gets its best configuration
-        em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
-        t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
-        # parity at bench scale (outside the timed region): the same pairs through the HIP path on a reset context, compared with
-        # what the checker just produced — alignment records, per-read offsets, mapping types, counters, the class table (labels,
-        # bins, counts, fixed-point weight sums), the online model, projected counts and the VBEM result
-        ctx.set_profiling(False); ctx.reset()
-        ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
-        ctx.eq_accumulate(); eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
-        p_g = api.normalize_alphas(eq_g, lm_g, uq_g, tc_g)
-        a_g, rep_g = ctx.em_optimize(np.exp(le_g), p_g, api.em_opts())
-        checks = {"alignments": sha(aln_g) == sha(aln), "read_offsets": sha(ro_g) == sha(ro), "map_types": sha(mt_g) == sha(mt), "counters": st_g == stc,
-            "eq_classes": all(sha(getattr(eq_g, f)) == sha(getattr(eqc, f)) for f in ("off", "tid", "bins", "count", "wq", "h1", "h2")),
-            "online_model": sha(lm_g) == sha(lmc) and sha(uq_g) == sha(uqc) and sha(tc_g) == sha(tcc) and sha(le_g) == sha(lec),
-            "projected_counts": sha(p_g) == sha(pc), "vbem": rep_g["iters"] == repc["iters"] and sha(a_g) == sha(a_c)}
-        parity = {"pairs": Sn, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
-            "checks": checks, "alignments_sha256": sha(aln_g), "decoy_fragments": int(st_g["num_decoy_fragments"]),
-            "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % Sn}
-        if gibbs is not None and Sn >= 1000:   # c5: the Gibbs sampler on the sample's classes, every sample byte-equal to the checker's
-            g_g = api.gibbs(eq_g, np.exp(le_g), a_g, 8, 7, int(eq_g.count.sum()), api.gibbs_opts(), device=local)
-            g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())
-            parity["checks"]["gibbs_8_samples"] = sha(g_g) == sha(g_c); parity["equal"] = all(parity["checks"].values())
-        cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
-               "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); %.1fs of CPU work in all; checker index built in %.1fs (not counted)" % (Sn,
-                   sizes[W * S], c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_cpu, t_oidx),
-               "map_only_M_pairs_per_s": round(Sn / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
-               # what the sample's rates would mean for the whole timed job (a model, not a measurement): per-pair costs scale with the pairs,
-               # the EM runs once over the full table for as many iterations as the GPU job needed
-               "extrapolated_full_job_M_pairs_per_s": round(NP / (NP * ((c1 - c0) + (c2 - c1)) / Sn + rep["iters"] * em_cpu_s) / 1e6, 4)}
-        del oidx, ost
+        try:   # the checker's leg: its failure must not cost the bench line (cpu_baseline / parity_check then say what went wrong)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+            Sn = min(sizes[W * S], a.cpu_sample)
+            c_a = time.perf_counter()
+            oidx = orc.OrcIndex(idx)
+            t_oidx = time.perf_counter() - c_a
+            soff = (np.arange(0, 2 * Sn + 1, dtype=np.uint64) * np.uint64(RL))
+            rb = api.make_read_batch(host_first, soff, Sn, paired=True)
+            c0 = time.perf_counter()
+            ro, aln, mt, stc = orc.map_batch(oidx, opts, rb, threads=ncores)
+            c1 = time.perf_counter()
+            ost = orc.OrcState(oidx, opts); ost.eq_accumulate(ro, aln, stc["num_with_joint_hits"]); ost.finish(); eqc = ost.eq_finish()
+            lmc, uqc, tcc, lec, _ = ost.model()
+            pc = orc.normalize_alphas(M, eqc, lmc, uqc, tcc)
+            c2 = time.perf_counter()
+            a_c, repc = orc.em_optimize(eqc, np.exp(lec), pc, api.em_opts())
+            c3 = time.perf_counter()
+            # the checker's EM loop is single-threaded (order-defined sums); its multi-threaded iteration (same arithmetic,
+            # transcripts split over threads) is timed separately and used for the composite so the CPU gets its cores
+            em_single_s = c3 - c2
+            em_try = {t: orc.em_time_iters(eqc, np.exp(lec), 20, t) / 20.0 * repc["iters"] for t in sorted({min(ncores, 8), min(ncores, 32), ncores})}
+            em_thr_n, em_thr_s = min(em_try.items(), key=lambda kv: kv[1])
+            if em_single_s < em_thr_s: em_thr_n, em_thr_s = 1, em_single_s       # the CPU side gets its best configuration
+            em_cpu_s = orc.em_time_iters(eq, eff, 20, ncores) / 20.0
+            t_cpu = (c1 - c0) + (c2 - c1) + em_thr_s
+            # parity at bench scale (outside the timed region): the same pairs through the HIP path on a reset context, compared with
+            # what the checker just produced — alignment records, per-read offsets, mapping types, counters, the class table (labels,
+            # bins, counts, fixed-point weight sums), the online model, projected counts and the VBEM result
+            ctx.set_profiling(False); ctx.reset()
+            ro_g, aln_g, mt_g, st_g = ctx.map_batch(rb)
+            ctx.eq_accumulate(); eq_g = ctx.eq_finish(); lm_g, uq_g, tc_g, le_g = ctx.model()
+            p_g = api.normalize_alphas(eq_g, lm_g, uq_g, tc_g)
+            a_g, rep_g = ctx.em_optimize(np.exp(le_g), p_g, api.em_opts())
+            checks = {"alignments": sha(aln_g) == sha(aln), "read_offsets": sha(ro_g) == sha(ro), "map_types": sha(mt_g) == sha(mt), "counters": st_g == stc,
+                "eq_classes": all(sha(getattr(eq_g, f)) == sha(getattr(eqc, f)) for f in ("off", "tid", "bins", "count", "wq", "h1", "h2")),
+                "online_model": sha(lm_g) == sha(lmc) and sha(uq_g) == sha(uqc) and sha(tc_g) == sha(tcc) and sha(le_g) == sha(lec),
+                "projected_counts": sha(p_g) == sha(pc), "vbem": rep_g["iters"] == repc["iters"] and sha(a_g) == sha(a_c)}
+            parity = {"pairs": Sn, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
+                "checks": checks, "alignments_sha256": sha(aln_g), "decoy_fragments": int(st_g["num_decoy_fragments"]),
+                "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % Sn}
+            if gibbs is not None and Sn >= 1000:   # c5: the Gibbs sampler on the sample's classes, every sample byte-equal to the checker's
+                g_g = api.gibbs(eq_g, np.exp(le_g), a_g, 8, 7, int(eq_g.count.sum()), api.gibbs_opts(), device=local)
+                g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())
+                parity["checks"]["gibbs_8_samples"] = sha(g_g) == sha(g_c); parity["equal"] = all(parity["checks"].values())
+            cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
+                   "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); %.1fs of CPU work in all; checker index built in %.1fs (not counted)" % (Sn,
+                       sizes[W * S], c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_cpu, t_oidx),
+                   "map_only_M_pairs_per_s": round(Sn / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
+                   # what the sample's rates would mean for the whole timed job (a model, not a measurement): per-pair costs scale with the pairs,
+                   # the EM runs once over the full table for as many iterations as the GPU job needed
+                   "extrapolated_full_job_M_pairs_per_s": round(NP / (NP * ((c1 - c0) + (c2 - c1)) / Sn + rep["iters"] * em_cpu_s) / 1e6, 4)}
+            del oidx, ost
+        except Exception as e:
+            cpu = cpu or {"error": str(e)[:300]}; parity = parity or {"error": str(e)[:300]}
     jobs = {}; spread = None; c2s = None
     if K * S * B == 100000000 and world == 1: jobs["100M"] = {"value": round(NP / dt / 1e6, 4), "pairs": NP, "seconds": round(dt, 4), "what": "the timed region of this line"}
     if extras and not leg and world == 1 and wl == "c2":
         # configs[1] as stated: the SAME job (map + online model + eq-classes + export + normalizeAlphas + VBEM to convergence) on the first 10 M pairs
         n10 = max(1, min(K * S, 10000000 // B))
-        d10, al10, eff10, rep10 = one_job(ctx, rbs[W * S: W * S + n10], api, idx)
-        jobs["10M" if n10 * B == 10000000 else "%d" % (n10 * B)] = {"value": round(rep10["pairs"] / d10 / 1e6, 4), "pairs": rep10["pairs"], "seconds": round(d10, 4), "map_eq_s": round(rep10["map_eq_s"], 4),
+        try:   # an extra: never lose the bench line over it
+            d10, al10, eff10, rep10 = one_job(ctx, rbs[W * S: W * S + n10], api, idx)
+            jobs["10M" if n10 * B == 10000000 else "%d" % (n10 * B)] = {"value": round(rep10["pairs"] / d10 / 1e6, 4), "pairs": rep10["pairs"], "seconds": round(d10, 4), "map_eq_s": round(rep10["map_eq_s"], 4),
                         "em_iters": rep10["iters"], "eq_classes": rep10["eq_classes"], "what": "configs[1] as stated: the whole job on the first %d pairs, timed the same way (outside the timed steps of this line)" % rep10["pairs"]}
+        except Exception as e: jobs["10M"] = {"error": str(e)[:300]}
         if a.spread_pairs > 0:
             try: spread = run_spread(a, Wd, batches[W * S:], off_d, B, RL, api, capi, local)
             except Exception as e: spread = {"error": str(e)[:300]}
     fq = None
     if a.fastq_pairs > 0 and world == 1 and wl in ("c2", "c2s") and not leg:
-        fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi, gz_pairs=a.fastq_gz_pairs)
+        try:   # an extra (and one that needs room for its files): never lose the bench line over it
+            fq = run_from_fastq(ctx, idx, tx, a.fastq_pairs, RL, min(B, 1000000), min(thr, 64), api, capi, gz_pairs=a.fastq_gz_pairs)
+        except Exception as e: fq = {"error": str(e)[:300]}
     cfg_name = {"c2": "configs[1]: human-transcriptome-shaped synthetic index (60k genes x ~4 isoforms; SURVEY C2 shape)",
                 "c3": "configs[2]: human-transcriptome-shaped synthetic index (as c2), a fixed total of %d pairs split over %d rank(s)" % (total_pairs, world),
                 "c2s": "configs[1], round-1/2 index (T200k: 20k genes x ~10 isoforms, 54 M distinct k-mers)",
