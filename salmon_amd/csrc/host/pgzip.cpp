@@ -1,6 +1,8 @@
 // host/pgzip.cpp — see pgzip.h.  An own inflate (RFC 1951) that writes 16-bit symbols: 0..255 = a byte, 0x8000 | k = byte k of the 32 KB
 // of text that precede the piece (unknown while the piece is decoded).  zlib supplies crc32 / crc32_combine only.
 #include "pgzip.h"
+#include "crc32_fast.h"
+#include <immintrin.h>
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
@@ -221,6 +223,21 @@ uint64_t find_block(const uint8_t* base, size_t n, uint64_t from, uint64_t to) {
   return ~0ull;
 }
 
+// symbols -> bytes: a symbol with MARK set is "byte k of the 32 KB in front of the piece" (wv), anything else is the byte itself.  [r4] Past a piece's
+// first few hundred KB no marked symbols are left (every copy of one is resolved text by then), so 32 symbols at a time are tested for a mark and narrowed
+// with one pack when there is none: ~8 GB/s against 1.3 for the symbol-by-symbol loop
+static inline void resolve_symbols(const uint16_t* s, size_t L, const uint8_t* wv, char* d) {
+  size_t k = 0;
+#if defined(__AVX2__)
+  const __m256i mark = _mm256_set1_epi16((short)MARK);
+  for (; k + 32 <= L; k += 32) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(s + k)), b = _mm256_loadu_si256((const __m256i*)(s + k + 16));
+    if (_mm256_testz_si256(_mm256_or_si256(a, b), mark)) { _mm256_storeu_si256((__m256i*)(d + k), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8)); continue; }
+    for (size_t j = k; j < k + 32; ++j) { const uint16_t v = s[j]; d[j] = (char)(v & MARK ? wv[v & (WIN - 1)] : (uint8_t)v); }
+  }
+#endif
+  for (; k < L; ++k) { const uint16_t v = s[k]; d[k] = (char)(v & MARK ? wv[v & (WIN - 1)] : (uint8_t)v); }
+}
 struct Text { char* p = nullptr; size_t n = 0, cap = 0; ~Text() { free(p); }   // a piece's text; buffers go round (a fresh page is the expensive part)
   bool size(size_t want) { if (want > cap) { free(p); cap = want + want / 8 + 4096; p = (char*)malloc(cap); if (!p) { cap = 0; return false; } } n = want; return true; } };
 struct Recycler { std::mutex mu; std::vector<std::unique_ptr<Text>> spare; };   // outlives the stream while text buffers are still out
@@ -364,10 +381,8 @@ struct PgzStream {
       Piece& P = *pc[chain[t]]; const size_t L = P.out.n - WIN;
       if (!P.text->size(L)) { P.status = B_BAD; return; }
       const uint16_t* s = P.out.b + WIN; const uint8_t* wv = win[t].data(); char* d = P.text->p;
-      for (size_t k = 0; k < L; ++k) { const uint16_t v = s[k]; d[k] = (char)(v & MARK ? wv[v & (WIN - 1)] : (uint8_t)v); }
-      size_t off = 0; uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-      while (off < L) { const size_t step = std::min<size_t>(L - off, 1u << 30); c = (uint32_t)crc32(c, (const Bytef*)d + off, (uInt)step); off += step; }
-      P.crc = c;
+      resolve_symbols(s, L, wv, d);
+      P.crc = sqcrc::crc32((uint32_t)crc32(0L, Z_NULL, 0), d, L);   // [r4] by carry-less multiplication (crc32_fast.h): ~6 GB/s against zlib's 1
     });
     mark("text+crc");
     for (unsigned t : chain) { Piece& P = *pc[t]; if (P.status == B_BAD) { err = "out of memory"; return false; }

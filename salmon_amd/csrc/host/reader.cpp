@@ -19,6 +19,7 @@
 // the page cache to the buffer the GPU reads.  FASTA, multi-line records and SQ_READER_SAFE=1 take the kseq-rules path below.
 #include "index.h"
 #include "reader_dev.h"
+#include "crc32_fast.h"
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -295,7 +296,7 @@ struct BgzfSource {
     const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
     if (per_member) inflateEnd(&fresh);
     if ((isize && rc != Z_STREAM_END) || (isize && zs.total_out != isize)) { b->err = "corrupt BGZF member"; return; }
-    if (crc32(crc32(0L, Z_NULL, 0), (const Bytef*)b->out.data(), isize) != crc) b->err = "BGZF checksum mismatch";
+    if (sqcrc::crc32((uint32_t)crc32(0L, Z_NULL, 0), b->out.data(), isize) != crc) b->err = "BGZF checksum mismatch";
   }
   void schedule() {   // caller holds mu
     while (win.size() < window && next_off < n) {
