@@ -167,8 +167,10 @@ int inflate_block(Bits& br, Out& o, bool text_only, size_t max_out) {
     if (s < 256) {
       if (s < 0 || (text_only && !texty(s))) { rc = B_BAD; break; }
       ob[on++] = (uint16_t)s;
-      // a second literal from the same refill when it is there (most symbols of sequence data are literals)
-      if (b.cnt >= 15) { const uint16_t e = lit->fast[b.buf & ((1u << FB) - 1)]; if (e && (e >> 4) < 256) { if (text_only && !texty(e >> 4)) { rc = B_BAD; break; } b.drop(e & 15); ob[on++] = (uint16_t)(e >> 4); } }
+      // more literals from the same refill while they are there (most symbols of sequence data are literals; a refill holds at least three codes)
+      bool bad = false;
+      while (b.cnt >= 15) { const uint16_t e = lit->fast[b.buf & ((1u << FB) - 1)]; if (!e || (e >> 4) >= 256) break; if (text_only && !texty(e >> 4)) { bad = true; break; } b.drop(e & 15); ob[on++] = (uint16_t)(e >> 4); }
+      if (bad) { rc = B_BAD; break; }
       continue;
     }
     if (s == 256) break;
@@ -179,6 +181,12 @@ int inflate_block(Bits& br, Out& o, bool text_only, size_t max_out) {
     const uint32_t d = DBASE[ds] + b.get(DEXT[ds]);
     if (d > WIN) { rc = B_BAD; break; }
     uint16_t* dst = ob + on; const uint16_t* src = dst - d;       // the window symbols in front make every distance valid
+#if defined(__AVX2__)
+    // [r4] 16 symbols per copy where the source lies at least that far back (in sequence data it nearly always does: a match is a piece of an earlier
+    // record); the last copy may run up to 15 symbols past the match — into space the next symbols overwrite (the 300-symbol margin above covers it)
+    if (d >= 16) { for (uint32_t i = 0; i < ln; i += 16) _mm256_storeu_si256((__m256i*)(dst + i), _mm256_loadu_si256((const __m256i*)(src + i))); }
+    else
+#endif
     for (uint32_t i = 0; i < ln; ++i) dst[i] = src[i];
     on += ln;
     if (on > max_out || b.tell() > end_bits) { rc = B_BAD; break; }
