@@ -210,6 +210,17 @@ def test_reader_bgzf_members_are_inflated_in_parallel_and_in_order(built, tmp_pa
     open(tmp_path / "bad_1.fq.gz", "wb").write(bytes(raw))
     h = _open([str(tmp_path / "bad_1.fq.gz")], None, batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
     assert err is not None and "bad_1.fq.gz" in err and ("BGZF" in err or "record" in err)
+    # [r4] (the members are inflated in groups of ~4 MB of text, each straight into its place) a file cut inside a member, and one cut between two members
+    whole = open(tmp_path / "b_1.fq.gz", "rb").read()
+    open(tmp_path / "cut_1.fq.gz", "wb").write(whole[: len(whole) * 2 // 3 + 7])
+    h = _open([str(tmp_path / "cut_1.fq.gz")], None, batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is not None and "cut_1.fq.gz" in err
+    offs = []; q = 0
+    while q < len(whole): ms = (whole[q + 16] | (whole[q + 17] << 8)) + 1; offs.append(q); q += ms          # 'BC' is the only extra field _bgzf_write makes: BSIZE sits at 16
+    open(tmp_path / "half_1.fq.gz", "wb").write(whole[: offs[len(offs) // 2]])
+    h = _open([str(tmp_path / "half_1.fq.gz")], None, batch=3000); got, err = _drain(h); capi.lib().sq_reader_close(h)
+    assert err is None or "record" in err                                         # whole members: either every record is whole too, or the last one is reported as cut
+    assert 0 < sum(len(b) for b in got) < n
 
 
 def test_reader_streams_from_fifos_and_dev_fd(built, tmp_path):
