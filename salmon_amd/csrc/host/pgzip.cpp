@@ -196,6 +196,58 @@ int inflate_block(Bits& br, Out& o, bool text_only, size_t max_out) {
   return fin ? B_FINAL : B_MORE;
 }
 
+// [r4] A whole raw deflate stream whose output size is known (a BGZF member: pgz_inflate_raw) straight into bytes: the decoder above without the 16-bit
+// symbols — nothing of the stream's past is unknown here.  dst has room for `cap` bytes + 32 (a match is copied 32 bytes at a time and may run past its
+// end; the caller places streams one behind the other or leaves that slack).  Returns the bytes written, -1 for a damaged stream.
+static long inflate_raw_bytes(const uint8_t* in, size_t n, char* dst, size_t cap) {
+  Bits b(in, n); const uint64_t end_bits = (uint64_t)n * 8; size_t on = 0;
+  for (;;) {
+    b.refill();
+    const uint32_t fin = b.get(1), type = b.get(2);
+    if (type == 3) return -1;
+    if (type == 0) {
+      b.drop(b.cnt & 7); b.refill();
+      const uint32_t ln = b.get(16); b.refill(); const uint32_t nl = b.get(16);
+      if ((ln ^ nl) != 0xFFFFu) return -1;
+      const uint64_t at = b.tell() >> 3;
+      if (at + ln > n || on + ln > cap) return -1;
+      memcpy(dst + on, in + at, ln); on += ln; b.seek((at + ln) * 8);
+    } else {
+      Huff dl, dd; const Huff* lit; const Huff* dist;
+      if (type == 1) { lit = &fixed_tables().lit; dist = &fixed_tables().dist; }
+      else { if (!read_dynamic(b, dl, dd, false)) return -1; lit = &dl; dist = &dd; }
+      for (;;) {
+        if (b.tell() > end_bits) return -1;
+        b.refill();
+        int s = lit->decode(b);
+        if (s < 256) {
+          if (s < 0 || on >= cap) return -1;
+          dst[on++] = (char)s;
+          while (b.cnt >= 15 && on < cap) { const uint16_t e = lit->fast[b.buf & ((1u << FB) - 1)]; if (!e || (e >> 4) >= 256) break; b.drop(e & 15); dst[on++] = (char)(e >> 4); }
+          continue;
+        }
+        if (s == 256) break;
+        s -= 257; if (s >= 29) return -1;
+        const uint32_t ln = LBASE[s] + b.get(LEXT[s]);
+        const int ds = dist->decode(b); if (ds < 0 || ds >= 30) return -1;
+        if (b.cnt < 13) b.refill();
+        const uint32_t d = DBASE[ds] + b.get(DEXT[ds]);
+        if (d > on || on + ln > cap) return -1;            // a distance before the stream's first byte, or more output than the stream said it holds
+        char* o = dst + on; const char* src = o - d;
+#if defined(__AVX2__)
+        if (d >= 32) { for (uint32_t i = 0; i < ln; i += 32) _mm256_storeu_si256((__m256i*)(o + i), _mm256_loadu_si256((const __m256i*)(src + i))); }
+        else
+#endif
+        for (uint32_t i = 0; i < ln; ++i) o[i] = src[i];
+        on += ln;
+      }
+    }
+    if (fin) break;
+    if (b.tell() > end_bits) return -1;
+  }
+  return b.tell() > end_bits ? -1 : (long)on;
+}
+
 // bits [bit, bit + n) of the file without a reader (n <= 32)
 inline uint32_t bits_at(const uint8_t* base, size_t nbytes, uint64_t bit, int n) {
   const size_t by = (size_t)(bit >> 3); uint64_t v = 0;
@@ -256,6 +308,8 @@ struct alignas(128) Piece {
   std::unique_ptr<Text> text; uint32_t crc = 0;
 };
 }  // namespace
+
+long pgz_inflate_raw(const uint8_t* deflate, size_t n, char* dst, size_t isize) { return inflate_raw_bytes(deflate, n, dst, isize); }
 
 struct Round {   // what the decoding stage hands to the finishing stage
   std::vector<std::unique_ptr<Piece>> pc; unsigned T = 0; std::vector<unsigned> chain;

@@ -22,6 +22,9 @@ PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::f
 long pgz_read(PgzStream*, char* dst, size_t want, std::string* err);
 // the same text without the copy: the next whole buffer of the stream (a few megabytes; 1), the end (0) or an error (-1).  `hold` keeps the
 // buffer alive — also past pgz_close — and hands it back for reuse when the last reference goes.  Do not mix with pgz_read.
+// [r4] a whole raw deflate stream of known output size (a BGZF member) into dst, which has room for isize + 32 bytes (or is followed by the next stream's place):
+// the bytes written (== isize for a sound member), -1 for a damaged stream.  ~2 x zlib's inflate on sequence text.
+long pgz_inflate_raw(const uint8_t* deflate, size_t n, char* dst, size_t isize);
 struct PgzBuf { const char* p = nullptr; size_t n = 0; std::shared_ptr<void> hold; };
 int pgz_next(PgzStream*, PgzBuf* out, std::string* err);
 void pgz_close(PgzStream*);

@@ -289,14 +289,18 @@ struct BgzfSource {
     if (m.csize < hdr + 8) return "truncated BGZF member";
     const uint32_t crc = le32(p + m.csize - 8);
     if (!m.isize) return "";
-    // one inflate state per worker thread, reset per member
-    struct Z { z_stream zs; bool ok = false; Z() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; } ~Z() { if (ok) inflateEnd(&zs); } };
-    static thread_local Z tz;
-    if (!tz.ok || inflateReset2(&tz.zs, -15) != Z_OK) return "zlib initialisation failed";
-    z_stream& zs = tz.zs;
-    zs.next_in = const_cast<Bytef*>(p + hdr); zs.avail_in = (uInt)(m.csize - hdr - 8); zs.next_out = (Bytef*)dst; zs.avail_out = m.isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    if (rc != Z_STREAM_END || zs.total_out != m.isize) return "corrupt BGZF member";
+    static const bool use_zlib = getenv("SQ_BGZF_ZLIB") && atoi(getenv("SQ_BGZF_ZLIB")) != 0;   // the library's inflate instead of the own one (pgzip.cpp), for comparison
+    if (!use_zlib) { if (pgz_inflate_raw(p + hdr, m.csize - hdr - 8, dst, m.isize) != (long)m.isize) return "corrupt BGZF member"; }
+    else {
+      // one inflate state per worker thread, reset per member
+      struct Z { z_stream zs; bool ok = false; Z() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; } ~Z() { if (ok) inflateEnd(&zs); } };
+      static thread_local Z tz;
+      if (!tz.ok || inflateReset2(&tz.zs, -15) != Z_OK) return "zlib initialisation failed";
+      z_stream& zs = tz.zs;
+      zs.next_in = const_cast<Bytef*>(p + hdr); zs.avail_in = (uInt)(m.csize - hdr - 8); zs.next_out = (Bytef*)dst; zs.avail_out = m.isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.total_out != m.isize) return "corrupt BGZF member";
+    }
     if (sqcrc::crc32((uint32_t)crc32(0L, Z_NULL, 0), dst, m.isize) != crc) return "BGZF checksum mismatch";
     return "";
   }
@@ -316,7 +320,7 @@ struct BgzfSource {
       // notify while holding mu: once `done` is visible the destructor may run, and it must not free cv under a task still about to signal it
       pool->submit([this, g] {
         std::string e;
-        g->text.reset(new (std::nothrow) char[g->total + 1]);
+        g->text.reset(new (std::nothrow) char[g->total + 64]);   // + slack: the own inflate copies matches 32 bytes at a time
         if (!g->text) e = "out of memory";
         else for (const Mem& m : g->mem) { const char* w = inflate_member(base + m.off, m, g->text.get() + m.at); if (*w) { e = w; break; } }
         std::lock_guard<std::mutex> lk(mu); g->err = e; g->done = true; cv.notify_all(); });
