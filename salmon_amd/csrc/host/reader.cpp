@@ -549,7 +549,9 @@ struct sq_reader {
   std::thread prealloc; std::mutex amu; std::condition_variable acv; std::vector<char> alloc_state; size_t alloc_asked = 0; bool alloc_stop = false;   // per slot: 0 pending, 1 done, 2 failed / not made
   void start_prealloc() {
     alloc_state.assign(slots.size(), 0);
-    prealloc = std::thread([this] {
+    int dev_id = -1; if (hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); dev_id = -1; }   // the opener's device: the thread below must not wake device 0 in a process that works on another
+    prealloc = std::thread([this, dev_id] {
+      if (dev_id >= 0 && hipSetDevice(dev_id) != hipSuccess) (void)hipGetLastError();
       const size_t nrec_max = (size_t)batch * (paired ? 2 : 1);
       for (size_t i = 0; i < slots.size(); ++i) {
         // one slot ahead of what has been asked for: a job of one batch locks two buffers, not all of them
