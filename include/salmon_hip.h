@@ -247,7 +247,7 @@ int sq_map_fetch(sq_ctx*, sq_aln_batch* out);   /* out->map_type alone (read_off
  * (sq_sam_* below) takes the place of a mapped batch — in->n fragments, in->read_off[n + 1] a prefix sum into in->aln — and sq_eq_accumulate
  * runs the same online model / equivalence-class stage on it.  num_with_joint_hits = fragments with at least one alignment record. */
 int sq_aln_inject(sq_ctx* ctx, const sq_aln_batch* in, uint64_t num_with_joint_hits);
-/* The record source of alignment-based mode: a name-collated SAM text file (plain or gzip; BAM is refused — no htslib here), read as the reference's
+/* The record source of alignment-based mode: a name-collated SAM text file (plain or gzip) or BAM file (decoded here: no htslib), read as the reference's
  * BAMQueue reads it (include/salmon/internal/alignment/BAMQueue.tpp:288-600): proper pairs on one target -> pair alignments, a mapped read whose mate
  * is not -> an orphan, consecutive alignments of one read name -> one fragment ordered by transcript.  paired_library: 1 = ReadPair rules, 0 = every
  * mapped record is a single-end alignment.  sq_sam_set_tid_map: SAM target i -> transcript id of the index (0xFFFFFFFF: skip its alignments); the

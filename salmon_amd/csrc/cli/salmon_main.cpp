@@ -312,9 +312,9 @@ static int cmd_quant(int argc, char** argv) {
   const char* r2 = arg(argc, argv, "-2", "--mates2");
   const char* ru = arg(argc, argv, "-r", "--unmatedReads");
   const char* lt = arg(argc, argv, "-l", "--libType");
-  // [r4] alignment-based mode: `quant -t transcripts.fa -l LIB -a alignments.sam -o out` (SalmonQuantifyAlignments.cpp; the records come from a SAM file, not the mapper)
+  // [r4] alignment-based mode: `quant -t transcripts.fa -l LIB -a alignments.sam -o out` (SalmonQuantifyAlignments.cpp; the records come from a SAM or BAM file, not the mapper)
   const char* alnf = arg(argc, argv, "-a", "--alignments"); const char* targets = arg(argc, argv, "-t", "--targets");
-  if (alnf && (!targets || !odir)) { fprintf(stderr, "usage: salmon-hip quant -t transcripts.fa -l IU -a alignments.sam[.gz] -o out_dir --noErrorModel|--useASWithoutCIGAR\n"); return 1; }
+  if (alnf && (!targets || !odir)) { fprintf(stderr, "usage: salmon-hip quant -t transcripts.fa -l IU -a alignments.{sam,sam.gz,bam} -o out_dir --noErrorModel|--useASWithoutCIGAR\n"); return 1; }
   if (!alnf && (!idir || !odir || (!ru && !(r1 && r2)))) {
     fprintf(stderr,
         "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");

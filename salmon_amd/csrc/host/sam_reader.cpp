@@ -2,7 +2,8 @@
 // into the alignment records the online stage consumes (sq_aln), fragment by fragment.  Follows the reference's BAMQueue
 // (include/salmon/internal/alignment/BAMQueue.tpp:288-343 getPairedAlignmentType_, :355-545 getFrag_(ReadPair), :548-600 getFrag_(UnpairedRead)),
 // ReadPair / UnpairedRead (ReadPair.hpp:61-200: pos, fwd, fragLen, getAS, mateStatus) and salmon::utils::hitType (SalmonUtils.cpp:531-652); the
-// reference reads BAM/SAM through htslib (staden io_lib), which is not available here — a SAM text parser takes its place, BAM input is refused.
+// reference reads BAM/SAM through htslib (staden io_lib), which is not available here — an own parser takes its place: SAM text (plain or gzip), and
+// [r4] BAM (the BGZF members are inflated through zlib's gzip reader; header and records are decoded here: SAM spec section 4.2).
 //   paired library: a record whose read and mate are mapped, flagged proper pair, on the same target -> a pair together with the NEXT record;
 //     read mapped, mate not (or not a proper pair, or another target) -> an orphan alignment (left if FREAD1 else right);
 //     read unmapped -> skipped; both unmapped -> an unaligned fragment (counted).
@@ -50,7 +51,62 @@ struct sq_sam {
       out.append(s, bend - bpos); bpos = bend;
     }
   }
+  // ---- BAM (binary; the decompressed stream): little-endian fields
+  bool bam = false;
+  bool read_exact(void* dst, size_t n) {
+    char* d = (char*)dst;
+    while (n) {
+      if (bpos == bend) { if (eof) return false; const int k = gzread(f, buf.data(), (unsigned)buf.size()); if (k <= 0) { eof = true; return false; } bpos = 0; bend = (size_t)k; }
+      const size_t take = std::min(n, bend - bpos); memcpy(d, buf.data() + bpos, take); d += take; bpos += take; n -= take;
+    }
+    return true;
+  }
+  static int32_t i32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+  std::vector<uint8_t> blk;
+  bool next_record_bam(Rec& r, std::string& err) {
+    uint8_t b4[4];
+    if (!read_exact(b4, 4)) return false;                       // the end of the file
+    const int32_t bs = i32(b4);
+    if (bs < 32 || bs > (64 << 20)) { err = "malformed BAM record (block size " + std::to_string(bs) + ")"; return false; }
+    blk.resize((size_t)bs);
+    if (!read_exact(blk.data(), (size_t)bs)) { err = "truncated BAM file (inside a record)"; return false; }
+    const uint8_t* p = blk.data();
+    const int32_t ref = i32(p), pos = i32(p + 4); const uint32_t l_name = p[8]; const uint32_t n_cig = (uint32_t)p[12] | ((uint32_t)p[13] << 8); const uint32_t flag = (uint32_t)p[14] | ((uint32_t)p[15] << 8);
+    const int32_t l_seq = i32(p + 16), mref = i32(p + 20);
+    const size_t fixed = 32, need = fixed + l_name + (size_t)n_cig * 4 + ((size_t)std::max(l_seq, 0) + 1) / 2 + (size_t)std::max(l_seq, 0);
+    if (l_seq < 0 || l_name == 0 || need > (size_t)bs) { err = "malformed BAM record (field lengths exceed the block)"; return false; }
+    r.name.assign((const char*)p + fixed, strnlen((const char*)p + fixed, l_name));
+    r.flag = (int)flag; r.ref = (ref >= 0 && (size_t)ref < names.size()) ? ref : -1; r.mref = (mref >= 0 && (size_t)mref < names.size()) ? mref : -1; r.pos = pos;
+    if (l_seq > 0) r.len = (uint32_t)l_seq;
+    else { uint32_t L = 0; const uint8_t* c = p + fixed + l_name; for (uint32_t i = 0; i < n_cig; ++i) { const uint32_t v = (uint32_t)i32(c + 4 * i); const uint32_t op = v & 15u; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) L += v >> 4; } r.len = L; }   // M I S = X consume the query
+    // the optional fields: TAG (2) TYPE (1) VALUE; AS is an integer of whatever width the writer chose
+    r.has_as = false; r.as = 0;
+    const uint8_t* a = p + need; const uint8_t* e = p + bs;
+    while (a + 3 <= e) {
+      const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2]; a += 3; size_t w = 0; long long iv = 0; bool isint = true;
+      switch (ty) {
+        case 'A': w = 1; isint = false; break;
+        case 'c': w = 1; if (a + 1 <= e) iv = (int8_t)a[0]; break;
+        case 'C': w = 1; if (a + 1 <= e) iv = a[0]; break;
+        case 's': w = 2; if (a + 2 <= e) iv = (int16_t)((uint16_t)a[0] | ((uint16_t)a[1] << 8)); break;
+        case 'S': w = 2; if (a + 2 <= e) iv = (uint16_t)((uint16_t)a[0] | ((uint16_t)a[1] << 8)); break;
+        case 'i': w = 4; if (a + 4 <= e) iv = i32(a); break;
+        case 'I': w = 4; if (a + 4 <= e) iv = (uint32_t)i32(a); break;
+        case 'f': w = 4; isint = false; break;
+        case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(a, 0, (size_t)(e - a)); if (!z) { a = e; w = 0; } else w = (size_t)(z - a) + 1; isint = false; break; }
+        case 'B': { if (a + 5 > e) { a = e; w = 0; break; } const char st = (char)a[0]; const uint32_t cnt2 = (uint32_t)i32(a + 1); const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; w = 5 + (size_t)cnt2 * es; isint = false; break; }
+        default: a = e; w = 0; isint = false; break;   // an unknown type: nothing behind it can be found
+      }
+      if (a + w > e) break;
+      if (t0 == 'A' && t1 == 'S' && isint) { r.as = (int32_t)iv; r.has_as = true; }
+      a += w;
+    }
+    if (r.ref < 0 && !(r.flag & F_UNMAP)) r.flag |= F_UNMAP;
+    cnt.num_records++;
+    return true;
+  }
   bool next_record(Rec& r, std::string& err) {
+    if (bam) return next_record_bam(r, err);
     while (getline(line)) {
       if (line.empty() || line[0] == '@') continue;
       // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [TAG...]
@@ -128,7 +184,19 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
   for (;;) {
     // peek: header lines start with '@'; the first record line is kept for next_record
     if (s->bpos == s->bend) { const int n = gzread(f, s->buf.data(), (unsigned)s->buf.size()); if (n <= 0) { s->eof = true; break; } s->bpos = 0; s->bend = (size_t)n; }
-    if (first) { first = false; if (s->bend - s->bpos >= 4 && !memcmp(s->buf.data() + s->bpos, "BAM\1", 4)) { gzclose(f); delete s; sq_set_error("'%s' is a BAM file: this build reads SAM text (samtools view -h file.bam); htslib is not available", path); return SQ_ERR_IO; } }
+    if (first) { first = false;
+      if (s->bend - s->bpos >= 4 && !memcmp(s->buf.data() + s->bpos, "BAM\1", 4)) {   // [r4] BAM: magic, l_text, text, n_ref, then (l_name, name, l_ref) per target
+        s->bam = true; uint8_t b4[4]; bool ok = s->read_exact(b4, 4) && s->read_exact(b4, 4);
+        if (ok) { int32_t lt = sq_sam::i32(b4); ok = lt >= 0; std::vector<char> skip; while (ok && lt > 0) { skip.resize((size_t)std::min(lt, 1 << 20)); ok = s->read_exact(skip.data(), skip.size()); lt -= (int32_t)skip.size(); } }
+        int32_t nref = 0; if (ok) { ok = s->read_exact(b4, 4); nref = sq_sam::i32(b4); ok = ok && nref >= 0; }
+        for (int32_t i = 0; ok && i < nref; ++i) {
+          ok = s->read_exact(b4, 4); const int32_t ln = sq_sam::i32(b4); if (!ok || ln <= 0 || ln > (1 << 20)) { ok = false; break; }
+          std::string nm((size_t)ln, '\0'); ok = s->read_exact(&nm[0], (size_t)ln) && s->read_exact(b4, 4); if (!ok) break;
+          nm.resize(strnlen(nm.c_str(), nm.size())); s->by_name[nm] = (int32_t)s->names.size(); s->names.push_back(nm); s->lens.push_back((uint32_t)sq_sam::i32(b4));
+        }
+        if (!ok) { gzclose(f); delete s; sq_set_error("'%s': damaged BAM header", path); return SQ_ERR_IO; }
+        break;
+      } }
     if (s->buf[s->bpos] != '@') break;
     if (!s->getline(l)) break;
     if (!strncmp(l.c_str(), "@SQ", 3)) {
@@ -137,7 +205,7 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
       if (!sn.empty()) { s->by_name[sn] = (int32_t)s->names.size(); s->names.push_back(sn); s->lens.push_back(ln); }
     }
   }
-  if (s->names.empty()) { gzclose(f); delete s; sq_set_error("'%s' has no @SQ header lines: the targets of the alignments are unknown", path); return SQ_ERR_IO; }
+  if (s->names.empty()) { const bool was_bam = s->bam; gzclose(f); delete s; sq_set_error(was_bam ? "'%s' names no reference sequences in its BAM header" : "'%s' has no @SQ header lines: the targets of the alignments are unknown", path); return SQ_ERR_IO; }
   s->tid_map.resize(s->names.size()); for (size_t i = 0; i < s->names.size(); ++i) s->tid_map[i] = (uint32_t)i;
   *out = s; return SQ_OK;
 }

@@ -34,6 +34,47 @@ def write_sam(path, names, lens, read_off, aln, unaligned_every=0, with_as=True)
                     f.write("r%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t*%s\n" % (fr, 0 if a["fwd"] else 16, t, a["pos"] + 1, a["read_len"], "A" * int(a["read_len"]), tag))
 
 
+def sam_to_bam(sam_path, bam_path, block=40000):
+    """The same records as BAM (SAM spec 4.2), BGZF-compressed: what an aligner piped through `samtools view -b` leaves.  AS goes out in the narrowest
+    integer type, as samtools writes it; other tags (a string, an array) stand in front of it."""
+    import struct, zlib
+    op = gzip.open if str(sam_path).endswith(".gz") else open
+    text = ""; refs = []; recs = []
+    with op(sam_path, "rt") as f:
+        for line in f:
+            if line.startswith("@"):
+                text += line
+                if line.startswith("@SQ"): d = dict(x.split(":", 1) for x in line.rstrip("\n").split("\t")[1:]); refs.append((d["SN"], int(d["LN"])))
+            else: recs.append(line.rstrip("\n").split("\t"))
+    rid = {n: i for i, (n, _) in enumerate(refs)}
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs)))
+    for n, l in refs: out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    ops = "MIDNSHP=X"
+    for r in recs:
+        qn, flag, rn, pos, mapq, cig, rnext, pnext, tlen, seq, qual = r[:11]; tags = r[11:]
+        ref = rid.get(rn, -1); mref = ref if rnext == "=" else rid.get(rnext, -1)
+        c = []; num = ""
+        for ch in ("" if cig == "*" else cig):
+            if ch.isdigit(): num += ch
+            else: c.append((int(num) << 4) | ops.index(ch)); num = ""
+        l_seq = 0 if seq == "*" else len(seq)
+        sq4 = bytearray((l_seq + 1) // 2)
+        for i, ch in enumerate("" if seq == "*" else seq): sq4[i // 2] |= "=ACMGRSVTWYHKDBN".index(ch) << (4 if i % 2 == 0 else 0)
+        aux = b"XZZhello\0" + b"XBBs" + struct.pack("<i", 3) + struct.pack("<3h", 1, -2, 3)
+        for t in tags:
+            tg, ty, v = t.split(":", 2)
+            if ty == "i":
+                v = int(v)
+                aux += tg.encode() + (b"C" + struct.pack("<B", v) if 0 <= v < 256 else b"c" + struct.pack("<b", v) if -128 <= v < 0 else b"S" + struct.pack("<H", v) if 0 <= v < 65536 else b"s" + struct.pack("<h", v) if -32768 <= v < 0 else b"i" + struct.pack("<i", v))
+        body = struct.pack("<iiBBHHHiiii", ref, int(pos) - 1, len(qn) + 1, int(mapq), 4680, len(c), int(flag), l_seq, mref, int(pnext) - 1, int(tlen)) + qn.encode() + b"\0" + b"".join(struct.pack("<I", x) for x in c) + bytes(sq4) + b"\xff" * l_seq + aux
+        out += struct.pack("<i", len(body)) + body
+    with open(bam_path, "wb") as f:
+        for i in list(range(0, len(out), block)) + [None]:
+            chunk = bytes(out[i:i + block]) if i is not None else b""
+            co = zlib.compressobj(6, zlib.DEFLATED, -15); cd = co.compress(chunk) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(cd) + 8 - 1) + cd + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+
 def read_sam(path, paired=True, max_frags=1 << 20, use_as=True, score_exp=1.0, tid_map=None):
     L = capi.lib(); h = C.c_void_p(); capi.check(L.sq_sam_open(str(path).encode(), int(paired), C.byref(h)), "sq_sam_open")
     names = [L.sq_sam_ref_name(h, i).decode() for i in range(L.sq_sam_num_refs(h))]; lens = [L.sq_sam_ref_len(h, i) for i in range(len(names))]
@@ -105,6 +146,48 @@ def test_sam_reader_rebuilds_the_alignment_records(built, tmp_path):
     with pytest.raises(capi.SalmonHipError, match="BAM"): read_sam(tmp_path / "x.bam")
     open(tmp_path / "nohdr.sam", "w").write("r1\t4\t*\t0\t0\t*\t*\t0\t0\tA\tI\n")
     with pytest.raises(capi.SalmonHipError, match="@SQ"): read_sam(tmp_path / "nohdr.sam")
+
+
+def test_bam_gives_the_same_records_as_sam(built, tmp_path):
+    """[r4] BAM input: header and records decoded from the binary form (BGZF inflated through the gzip reader) — the same targets, fragments, alignments,
+    AS-based probabilities and counters as the SAM text they were made from; paired and single-end libraries; records that store no sequence (length
+    from the CIGAR) and records that do; damaged files are refused."""
+    rng = np.random.default_rng(14); names = ["tx%d" % i for i in range(9)]; lens = [900 + 13 * i for i in range(9)]
+    ro, aln = _toy_alignments(rng, 400, 9)
+    aln["score"] = rng.integers(-300, 70000, len(aln)); aln["mate_score"] = np.where(aln["mate_status"] == 3, rng.integers(-40, 300, len(aln)), 0)      # every integer width of the AS tag
+    sam = tmp_path / "p.sam"; bam = tmp_path / "p.bam"; write_sam(sam, names, lens, ro, aln, unaligned_every=9); sam_to_bam(sam, bam)
+    a = read_sam(sam, paired=True, max_frags=90); b = read_sam(bam, paired=True, max_frags=90)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3].tobytes() == b[3].tobytes() and a[4] == b[4] and a[5] == b[5]
+    assert a[4]["num_fragments"] == 400 - 0 and a[4]["num_unaligned"] > 0
+    # single-end: the records carry their sequence
+    se = aln.copy(); se["mate_status"] = 0; se["mate_pos"] = 0; se["mate_len"] = 0; se["mate_fwd"] = 0; se["mate_score"] = 0
+    sam2 = tmp_path / "s.sam"; bam2 = tmp_path / "s.bam"; write_sam(sam2, names, lens, ro, se); sam_to_bam(sam2, bam2)
+    a = read_sam(sam2, paired=False); b = read_sam(bam2, paired=False)
+    assert a[0] == b[0] and np.array_equal(a[2], b[2]) and a[3].tobytes() == b[3].tobytes() and a[4] == b[4]
+    # damage: cut inside the header, cut inside a record, a record whose lengths exceed its block
+    raw = gzip.open(bam, "rb").read(); L = capi.lib()
+    def refused(data):
+        p = tmp_path / "bad.bam"; gzip.open(p, "wb").write(data); h = C.c_void_p()
+        if L.sq_sam_open(str(p).encode(), 1, C.byref(h)) != 0: return True
+        try:
+            while True:
+                ab = capi.AlnBatch()
+                if L.sq_sam_next(h, 1000, 0, 1.0, C.byref(ab), None) != 0: return True
+                if ab.n == 0: return False
+        finally: L.sq_sam_close(h)
+    assert refused(raw[:60]) and refused(raw[: len(raw) // 2 + 3])
+    hdr_end = raw.index(b"tx8\0") + 8; broken = bytearray(raw); broken[hdr_end + 4 + 8] = 250          # l_read_name of the first record: longer than its block
+    assert refused(bytes(broken))
+    # and 300 randomly damaged copies: refused or read, never a crash (every length in a record is checked against its block)
+    for it in range(300):
+        b2 = bytearray(raw)
+        for _ in range(int(rng.integers(1, 5))):
+            op = int(rng.integers(0, 3)); q = int(rng.integers(0, len(b2)))
+            if op == 0: b2[q] = int(rng.integers(0, 256))
+            elif op == 1: del b2[q:]
+            else: b2[q:q] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+            if not b2: b2 = bytearray(b"B")
+        refused(bytes(b2))
 
 
 @pytest.mark.gpu
