@@ -3,7 +3,8 @@
 // (include/salmon/internal/alignment/BAMQueue.tpp:288-343 getPairedAlignmentType_, :355-545 getFrag_(ReadPair), :548-600 getFrag_(UnpairedRead)),
 // ReadPair / UnpairedRead (ReadPair.hpp:61-200: pos, fwd, fragLen, getAS, mateStatus) and salmon::utils::hitType (SalmonUtils.cpp:531-652); the
 // reference reads BAM/SAM through htslib (staden io_lib), which is not available here — an own parser takes its place: SAM text (plain or gzip), and
-// [r4] BAM (the BGZF members are inflated through zlib's gzip reader; header and records are decoded here: SAM spec section 4.2).
+// [r4] BAM (the BGZF members are inflated in parallel by bgzf_source.h — or, for a plain gzip stream, through zlib's gzip reader; header and records are
+// decoded here: SAM spec section 4.2).
 //   paired library: a record whose read and mate are mapped, flagged proper pair, on the same target -> a pair together with the NEXT record;
 //     read mapped, mate not (or not a proper pair, or another target) -> an orphan alignment (left if FREAD1 else right);
 //     read unmapped -> skipped; both unmapped -> an unaligned fragment (counted).
@@ -11,13 +12,18 @@
 // The error model of alignment mode (AlignmentModel.hpp, learned from CIGAR strings) is NOT built: the conditional probability of an alignment is
 // either 1 (`--noErrorModel`) or exp(-scoreExp (bestAS - AS)) from the AS tags (`--useASWithoutCIGAR`, SalmonQuantifyAlignments.cpp:516-521).
 #include "index.h"
+#include "bgzf_source.h"
 #include <zlib.h>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <string>
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 enum { F_PAIRED = 1, F_PROPER = 2, F_UNMAP = 4, F_MUNMAP = 8, F_REVERSE = 16, F_READ1 = 64, F_READ2 = 128 };
@@ -33,6 +39,17 @@ inline uint8_t hit_type_single(bool fwd) { return fwd ? fmt_id(0, 3, 2) : fmt_id
 
 struct sq_sam {
   gzFile f = nullptr; std::string path; bool paired = true;
+  // [r4] a BGZF file (every BAM, a bgzipped SAM) is inflated by a small pool, member groups in parallel (bgzf_source.h), and handed over as one byte
+  // stream; anything else goes through zlib's gzip reader (plain text too)
+  std::unique_ptr<sqio::Pool> pool; std::unique_ptr<sqio::BgzfSource> bg; PgzBuf cur; size_t cur_off = 0; std::string io_err;
+  ~sq_sam() { cur = PgzBuf(); bg.reset(); pool.reset(); }   // the source's tasks run on the pool: the source goes first
+  int fill(char* dst, size_t cap) {   // > 0 bytes, 0 at the end, < 0 on error (io_err)
+    if (!bg) return gzread(f, dst, (unsigned)cap);
+    for (;;) {
+      if (cur_off < cur.n) { const size_t take = std::min(cap, cur.n - cur_off); memcpy(dst, cur.p + cur_off, take); cur_off += take; return (int)take; }
+      cur = PgzBuf(); cur_off = 0; const int rc = bg->next_buf(&cur); if (rc < 0) { io_err = bg->err; return -1; } if (rc == 0) return 0;
+    }
+  }
   std::vector<std::string> names; std::vector<uint32_t> lens; std::unordered_map<std::string, int32_t> by_name;
   std::vector<uint32_t> tid_map;
   std::vector<char> buf; size_t bpos = 0, bend = 0; bool eof = false;
@@ -45,7 +62,7 @@ struct sq_sam {
   bool getline(std::string& out) {
     out.clear();
     for (;;) {
-      if (bpos == bend) { if (eof) return !out.empty(); const int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return !out.empty(); } bpos = 0; bend = (size_t)n; }
+      if (bpos == bend) { if (eof) return !out.empty(); const int n = fill(buf.data(), buf.size()); if (n <= 0) { eof = true; return !out.empty(); } bpos = 0; bend = (size_t)n; }
       const char* s = buf.data() + bpos; const char* e = (const char*)memchr(s, '\n', bend - bpos);
       if (e) { out.append(s, e - s); bpos = (size_t)(e - buf.data()) + 1; if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
       out.append(s, bend - bpos); bpos = bend;
@@ -56,7 +73,7 @@ struct sq_sam {
   bool read_exact(void* dst, size_t n) {
     char* d = (char*)dst;
     while (n) {
-      if (bpos == bend) { if (eof) return false; const int k = gzread(f, buf.data(), (unsigned)buf.size()); if (k <= 0) { eof = true; return false; } bpos = 0; bend = (size_t)k; }
+      if (bpos == bend) { if (eof) return false; const int k = fill(buf.data(), buf.size()); if (k <= 0) { eof = true; return false; } bpos = 0; bend = (size_t)k; }
       const size_t take = std::min(n, bend - bpos); memcpy(d, buf.data() + bpos, take); d += take; bpos += take; n -= take;
     }
     return true;
@@ -179,11 +196,27 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
   gzFile f = gzopen(path, "rb"); if (!f) { sq_set_error("cannot open alignment file '%s'", path); return SQ_ERR_IO; }
   gzbuffer(f, 1 << 20);
   sq_sam* s = new sq_sam(); s->f = f; s->path = path; s->paired = paired_library != 0; s->buf.resize(4 << 20);
+  { // BGZF?  (the first member names its compressed size in a 'BC' extra field)
+    FILE* rf = fopen(path, "rb"); unsigned char h[64]; const size_t got = rf ? fread(h, 1, sizeof h, rf) : 0; if (rf) fclose(rf);
+    if (got >= 28 && sqio::BgzfSource::member_size(h, 1u << 20) && !(getenv("SQ_SAM_BGZF") && atoi(getenv("SQ_SAM_BGZF")) == 0)) {
+      int fd = open(path, O_RDONLY); struct stat sb;
+      if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 28) {
+        void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+          const unsigned nt = std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
+          s->pool.reset(new sqio::Pool(nt)); s->bg.reset(new sqio::BgzfSource());
+          s->bg->map = std::make_shared<sqio::Mapping>(); s->bg->map->p = m; s->bg->map->n = (size_t)sb.st_size; s->bg->base = (const uint8_t*)m; s->bg->n = (size_t)sb.st_size;
+          s->bg->pool = s->pool.get(); s->bg->path = path; s->bg->window = 2 * nt; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        }
+      }
+      if (fd >= 0) close(fd);
+    }
+  }
   // the header: @SQ lines name the targets in the order the records refer to them
   std::string l; bool first = true;
   for (;;) {
     // peek: header lines start with '@'; the first record line is kept for next_record
-    if (s->bpos == s->bend) { const int n = gzread(f, s->buf.data(), (unsigned)s->buf.size()); if (n <= 0) { s->eof = true; break; } s->bpos = 0; s->bend = (size_t)n; }
+    if (s->bpos == s->bend) { const int n = s->fill(s->buf.data(), s->buf.size()); if (n <= 0) { s->eof = true; break; } s->bpos = 0; s->bend = (size_t)n; }
     if (first) { first = false;
       if (s->bend - s->bpos >= 4 && !memcmp(s->buf.data() + s->bpos, "BAM\1", 4)) {   // [r4] BAM: magic, l_text, text, n_ref, then (l_name, name, l_ref) per target
         s->bam = true; uint8_t b4[4]; bool ok = s->read_exact(b4, 4) && s->read_exact(b4, 4);
@@ -216,7 +249,7 @@ extern "C" int sq_sam_set_tid_map(sq_sam* s, const uint32_t* map, uint32_t n) {
   if (!s || !map || n != s->names.size()) { sq_set_error("sq_sam_set_tid_map: one entry per @SQ line"); return SQ_ERR_ARG; }
   s->tid_map.assign(map, map + n); return SQ_OK;
 }
-extern "C" void sq_sam_close(sq_sam* s) { if (s) { if (s->f) gzclose(s->f); delete s; } }
+extern "C" void sq_sam_close(sq_sam* s) { if (s) { s->cur = PgzBuf(); s->bg.reset(); s->pool.reset(); if (s->f) gzclose(s->f); delete s; } }
 
 extern "C" int sq_sam_next(sq_sam* s, uint32_t max_frags, int use_as_scores, double score_exp, sq_aln_batch* out, sq_sam_counts* counts) {
   if (!s || !out || !max_frags) { sq_set_error("sq_sam_next: bad arguments"); return SQ_ERR_ARG; }
@@ -237,7 +270,9 @@ extern "C" int sq_sam_next(sq_sam* s, uint32_t max_frags, int use_as_scores, dou
   for (;;) {
     sq_aln a; std::string name; int32_t as = 0; bool has_as = false;
     if (s->have_next) { a = s->next_aln; name = s->next_name; as = s->next_as; has_as = s->next_has_as; s->have_next = false; }
-    else if (!s->next_alignment(a, name, as, has_as, err)) { if (!err.empty()) { sq_set_error("%s: %s", s->path.c_str(), err.c_str()); return SQ_ERR_IO; } break; }
+    else if (!s->next_alignment(a, name, as, has_as, err)) {
+      if (err.empty() && !s->io_err.empty()) err = s->io_err;
+      if (!err.empty()) { sq_set_error("%s: %s", s->path.c_str(), err.c_str()); return SQ_ERR_IO; } break; }
     if (open && name != cur_name) {
       close_fragment(frag_start); open = false;
       if (nfrag == max_frags) { s->have_next = true; s->next_aln = a; s->next_name = name; s->next_as = as; s->next_has_as = has_as; break; }

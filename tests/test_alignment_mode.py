@@ -159,6 +159,13 @@ def test_bam_gives_the_same_records_as_sam(built, tmp_path):
     a = read_sam(sam, paired=True, max_frags=90); b = read_sam(bam, paired=True, max_frags=90)
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3].tobytes() == b[3].tobytes() and a[4] == b[4] and a[5] == b[5]
     assert a[4]["num_fragments"] == 400 - 0 and a[4]["num_unaligned"] > 0
+    # the BGZF members went through the parallel source (bgzf_source.h); through zlib's reader the same
+    os.environ["SQ_SAM_BGZF"] = "0"
+    try: c = read_sam(bam, paired=True, max_frags=90)
+    finally: os.environ.pop("SQ_SAM_BGZF")
+    assert np.array_equal(c[2], b[2]) and c[3].tobytes() == b[3].tobytes() and c[4] == b[4]
+    flipped = bytearray(open(bam, "rb").read()); flipped[len(flipped) // 2] ^= 0x41; open(tmp_path / "flip.bam", "wb").write(bytes(flipped))
+    with pytest.raises(Exception): read_sam(tmp_path / "flip.bam", paired=True)
     # single-end: the records carry their sequence
     se = aln.copy(); se["mate_status"] = 0; se["mate_pos"] = 0; se["mate_len"] = 0; se["mate_fwd"] = 0; se["mate_score"] = 0
     sam2 = tmp_path / "s.sam"; bam2 = tmp_path / "s.bam"; write_sam(sam2, names, lens, ro, se); sam_to_bam(sam2, bam2)
