@@ -18,6 +18,7 @@ void sq_dev_reader_close(sq_dev_reader*) {}
 #include <random>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include <sys/stat.h>
 
 #include "../salmon_amd/csrc/host/index.h"
@@ -189,7 +190,32 @@ int main(int argc, char** argv) {
         if (b.empty()) b = "@"; }
       const std::string mp = dir + "/mut.sam"; FILE* f = fopen(mp.c_str(), "wb"); fwrite(b.data(), 1, b.size(), f); fclose(f);
       uint64_t fr = 0; sam_ok += drain(mp, false, &fr) ? 1 : 0; }
-    printf("malformed SAM: %d of 300 mutated files read to the end\n", sam_ok); }
+    printf("malformed SAM: %d of 300 mutated files read to the end\n", sam_ok);
+    // the same records as BAM (binary: SAM spec 4.2; written here field by field), then damaged copies of the byte stream
+    { std::string bamb("BAM\1", 4); auto put32 = [&](std::string& o, int32_t v) { for (int k = 0; k < 4; ++k) o.push_back((char)((uint32_t)v >> (8 * k))); };
+      std::string text; std::vector<std::pair<std::string, uint32_t>> refs; std::vector<std::vector<std::string>> recs;
+      { size_t p0 = 0; while (p0 < sam.size()) { const size_t nl = sam.find('\n', p0); std::string ln = sam.substr(p0, nl - p0); p0 = nl + 1;
+          if (ln[0] == '@') { text += ln + "\n"; if (!ln.compare(0, 3, "@SQ")) { const size_t a = ln.find("SN:"), b = ln.find("\tLN:"); refs.push_back({ln.substr(a + 3, b - a - 3), (uint32_t)atoi(ln.c_str() + b + 4)}); } continue; }
+          std::vector<std::string> f; size_t q = 0; for (;;) { const size_t t = ln.find('\t', q); f.push_back(ln.substr(q, t == std::string::npos ? std::string::npos : t - q)); if (t == std::string::npos) break; q = t + 1; } recs.push_back(f); } }
+      put32(bamb, (int32_t)text.size()); bamb += text; put32(bamb, (int32_t)refs.size());
+      std::unordered_map<std::string, int32_t> rid; for (size_t i = 0; i < refs.size(); ++i) { rid[refs[i].first] = (int32_t)i; put32(bamb, (int32_t)refs[i].first.size() + 1); bamb += refs[i].first; bamb.push_back('\0'); put32(bamb, (int32_t)refs[i].second); }
+      for (auto& f : recs) { std::string body; const int32_t ref = rid.count(f[2]) ? rid[f[2]] : -1, mref = f[6] == "=" ? ref : (rid.count(f[6]) ? rid[f[6]] : -1);
+        std::vector<uint32_t> cg; { uint32_t num = 0; for (char ch : f[5]) { if (ch >= '0' && ch <= '9') num = num * 10 + (uint32_t)(ch - '0'); else if (ch != '*') { cg.push_back((num << 4) | (uint32_t)(std::string("MIDNSHP=X").find(ch))); num = 0; } } }
+        const int32_t lseq = f[9] == "*" ? 0 : (int32_t)f[9].size();
+        put32(body, ref); put32(body, atoi(f[3].c_str()) - 1); body.push_back((char)(f[0].size() + 1)); body.push_back((char)atoi(f[4].c_str())); body.push_back(0x48); body.push_back(0x12);
+        body.push_back((char)(cg.size() & 0xFF)); body.push_back((char)(cg.size() >> 8)); const int fl = atoi(f[1].c_str()); body.push_back((char)(fl & 0xFF)); body.push_back((char)(fl >> 8));
+        put32(body, lseq); put32(body, mref); put32(body, atoi(f[7].c_str()) - 1); put32(body, atoi(f[8].c_str()));
+        body += f[0]; body.push_back('\0'); for (uint32_t c : cg) put32(body, (int32_t)c); body.append((size_t)(lseq + 1) / 2, (char)0x11); body.append((size_t)lseq, (char)0xFF);
+        for (size_t t = 11; t < f.size(); ++t) if (!f[t].compare(0, 5, "AS:i:")) { body += "ASi"; put32(body, atoi(f[t].c_str() + 5)); } else if (!f[t].compare(0, 5, "NH:i:")) { body += "NHC"; body.push_back((char)atoi(f[t].c_str() + 5)); }
+        put32(bamb, (int32_t)body.size()); bamb += body; }
+      auto write_gz = [&](const std::string& path, const std::string& bytes) { gzFile o = gzopen(path.c_str(), "wb1"); gzwrite(o, bytes.data(), (unsigned)bytes.size()); gzclose(o); };
+      const std::string bp = dir + "/a.bam"; write_gz(bp, bamb);
+      uint64_t fb = 0; CHECK(drain(bp, true, &fb)); CHECK(fb == want_frags);
+      int bam_ok = 0;
+      for (int it = 0; it < 300; ++it) { std::string b = bamb; const int nm = 1 + (int)(g() % 4);
+        for (int j = 0; j < nm; ++j) { const size_t p = g() % b.size(); const int op = (int)(g() % 3); if (op == 0) b[p] = (char)(g() & 0xFF); else if (op == 1) b.resize(p); else b.insert(p, std::string(1 + g() % 8, (char)(g() & 0xFF))); if (b.empty()) b = "B"; }
+        const std::string mp = dir + "/mut.bam"; write_gz(mp, b); uint64_t fr = 0; bam_ok += drain(mp, false, &fr) ? 1 : 0; }
+      printf("malformed BAM: %d of 300 damaged byte streams read to the end\n", bam_ok); } }
   // ---- [r4] the rest of the output directory: meta_info.json, the index digests, fld.gz, the bias dumps
   { const std::string aux = dir + "/out/aux_info";
     for (int wch = 0; wch < 6; ++wch) { const char* h = sq_index_hash(idx, wch); CHECK(h != nullptr); }
