@@ -29,6 +29,37 @@ __global__ void k_build_kfilter(const uint64_t* __restrict__ useq, const uint64_
   }
 }
 
+// [r5] the minimizer table (sq_internal.h: sq_mtab_*): one wave per unitig walks its k-mers; where the minimizer changes from one k-mer to the next the
+// new one is entered with the record the MPHF gives for it (claimed with one compare-and-swap on the key; a key met again is left alone — its
+// record is the same).  A bucket is filled front to back and never emptied, which is what lets a search stop at the first bucket with a free place.
+__global__ void k_build_mtab(sq_dict_view d, unsigned long long* __restrict__ tab, uint64_t nbuckets, unsigned long long* __restrict__ fail) {
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63, k = d.k, m = d.m;
+  for (uint64_t u = wave; u < d.num_unitigs; u += nwaves) {
+    const uint64_t b = d.uoff[u], e = d.uoff[u + 1];
+    if (e - b < k) continue;
+    for (uint64_t p0 = b; p0 + k <= e; p0 += 64) {   // wave-uniform trip count: the shuffle below needs every lane
+      const uint64_t p = p0 + lane; const bool valid = p + k <= e;
+      uint64_t mini = ~0ULL;
+      if (valid) { const uint64_t km = sq_fetch_bases(d.useq, p, k), rc = sq_revcomp(km, k); mini = sq_minimizer(km, rc, k, m); }
+      const uint64_t prev = (uint64_t)__shfl_up((unsigned long long)mini, 1, 64);
+      if (!valid || (lane != 0 && prev == mini)) continue;
+      const uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
+      uint64_t bk = sq_mtab_bucket_of(mini, nbuckets); bool placed = false;
+      for (uint64_t tries = 0; tries < nbuckets && !placed; ++tries) {
+        for (uint32_t j = 0; j < SQ_MTAB_BUCKET && !placed; ++j) {
+          unsigned long long* kp = tab + (bk * SQ_MTAB_BUCKET + j) * 2;
+          const unsigned long long old = atomicCAS(kp, (unsigned long long)SQ_MTAB_EMPTY, (unsigned long long)mini);
+          if (old == SQ_MTAB_EMPTY) { kp[1] = rec; placed = true; }
+          else if (old == mini) placed = true;
+        }
+        if (++bk == nbuckets) bk = 0;
+      }
+      if (!placed) atomicAdd(fail, 1ULL);
+    }
+  }
+}
+
 void sq_device_index_free(sq_device_index* d) {
   if (!d) return;
   if (d->device >= 0) (void)hipSetDevice(d->device);
@@ -76,6 +107,21 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
     k_build_kfilter<<<4096, 256>>>(v.useq, v.uoff, v.num_unitigs, idx->k, idx->m, (unsigned long long*)p, nblocks);
     SQ_HIP_CHECK(hipDeviceSynchronize());
     v.kfilter = (const uint64_t*)p; v.kfilter_words = nwords;
+  }
+  v.mtab = nullptr; v.mtab_buckets = 0;
+  if (!getenv("SQ_NO_MTAB") && idx->num_kmers > 0) {   // minimizer table (sq_internal.h): 1.6 minimizers per 64-byte bucket of four
+    uint64_t nmin = 0; for (uint64_t r : idx->slots) nmin += r != SQ_SLOT_EMPTY;
+    const uint64_t nb = nmin * 5 / 8 + 1024;
+    void* p = nullptr; unsigned long long* fail = nullptr;
+    SQ_HIP_CHECK(hipMalloc(&p, nb * 64));
+    d->allocs.push_back(p); d->bytes += nb * 64;
+    SQ_HIP_CHECK(hipMemset(p, 0xFF, nb * 64));
+    SQ_HIP_CHECK(hipMalloc((void**)&fail, 8)); SQ_HIP_CHECK(hipMemset(fail, 0, 8));
+    k_build_mtab<<<4096, 256>>>(v, (unsigned long long*)p, nb, fail);
+    unsigned long long hfail = 0;
+    SQ_HIP_CHECK(hipMemcpy(&hfail, fail, 8, hipMemcpyDeviceToHost)); (void)hipFree(fail);
+    if (hfail) { sq_set_error("internal: %llu minimizers found no place in the minimizer table", hfail); sq_device_index_free(d); return SQ_ERR_STATE; }
+    v.mtab = (const uint64_t*)p; v.mtab_buckets = nb;
   }
   d->k = idx->k; d->first_decoy = idx->first_decoy; d->num_refs = (uint32_t)idx->names.size();
   idx->dev = d;

@@ -462,7 +462,7 @@ int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_
     d_seq = c->seq.p; d_seq_off = c->seq_off.p;
   }
   const sq_device_index* di = c->di; const sq_map_params& P = c->mp;
-  int pack_attempt = 0, uni_attempt = 0;
+  int pack_attempt = 0, uni_attempt = 0, seed_attempt = 0;
 pack_again:   // [r4] taken once more when the batch holds a read end longer than the packing stride allows (the stride is raised and stays raised)
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
@@ -477,6 +477,25 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     static const int spec = getenv("SQ_SEED_SPEC") ? atoi(getenv("SQ_SEED_SPEC")) : 2;
+    // [r5] k_seed2 (read words, filter block and — SQ_SEED_V >= 3 — the minimizer table's one-sector records) for the default k / m with reads of up to
+    // 256 bases; everything else takes the general kernel.  SQ_SEED_V: 0 = k_seed, 1 = LDS read words only, 2 = + filter block in LDS, 3 = + minimizer table
+    static const int seedv = getenv("SQ_SEED_V") ? atoi(getenv("SQ_SEED_V")) : 3;
+    static const int force_lw = getenv("SQ_SEED_LW") ? atoi(getenv("SQ_SEED_LW")) : 0;
+    const bool v2 = seedv > 0 && P.k == 31 && di->dict.m == 20 && c->read_words == 8 && di->dict.kfilter && di->dict.uinfo && (seedv == 1 || seedv == 2 || seedv == 6 || di->dict.mtab);
+    if (v2) {
+      if (force_lw == 8) c->seed_lw = 8;
+      const uint32_t lw = c->seed_lw;
+      // LDS per block: (LW + 8) x 2 KB -> 24 KB (LW 4: six blocks per CU) or 32 KB (five)
+      const uint32_t grid2 = std::min<uint32_t>(nblk(nrec), 256u * bpc);
+#define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
+      if (seedv == 1) { if (lw == 4) k_seed2<31, 20, 2, 4, false, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, false, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      else if (seedv == 2) { if (lw == 4) k_seed2<31, 20, 2, 4, true, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      else if (seedv == 4) { if (lw == 4) k_seed2<31, 20, 2, 4, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      else if (seedv == 5) { if (lw == 4) k_seed2<31, 20, 2, 4, true, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      else if (seedv == 6) { if (lw == 4) k_seed2<31, 20, 2, 4, true, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      else { if (lw == 4) k_seed2<31, 20, 2, 4, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+#undef SQ_SEED2_ARGS
+    } else
 #define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
     if (P.k == 31 && di->dict.m == 20) {   // the default (k = 31, m = 20) gets the fully specialised kernel
       if (spec == 1) k_seed<31, 20, 1><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
@@ -501,8 +520,9 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
       c->counters.p + 16);
   uint64_t total_mems = 0; uint32_t hcls[MK_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0, 0};
   sq_prof_mark(c, SG_SCAN_MEMS);
-  unsigned long long h_maxlen = 0, h_uniover = 0;
+  unsigned long long h_maxlen = 0, h_uniover = 0, h_seedlw = 0;
   SQ_HIP_CHECK(hipMemcpyAsync(&h_uniover, c->stats.p + ST_UNIOVER, 8, hipMemcpyDeviceToHost, st));
+  SQ_HIP_CHECK(hipMemcpyAsync(&h_seedlw, c->stats.p + ST_SEEDLW, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(&total_mems, c->mem_off.p + nrec, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hcls, c->counters.p + 16, sizeof(hcls), hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(&h_maxlen, c->stats.p + ST_MAXLEN, 8, hipMemcpyDeviceToHost, st));
@@ -515,6 +535,11 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     c->read_words = need;
     const size_t cap_ends = std::max<size_t>(2 * (size_t)c->max_reads, nrec);
     if (c->rpack.ensure(cap_ends * need + 8) || c->rnmask.ensure(cap_ends * (need / 2) + 8)) { sq_set_error("device allocation failed (packed reads of up to %u bases)", 32 * need); return SQ_ERR_NOMEM; }
+    goto pack_again;
+  }
+  if (h_seedlw) {   // [r5] reads of more than 128 bases met the four-word instantiation of k_seed2: the eight-word one from now on, and this batch again
+    if (c->seed_lw >= 8 || seed_attempt++) { sq_set_error("internal: %llu read ends did not fit k_seed2's LDS column of %u words", h_seedlw, c->seed_lw); return SQ_ERR_STATE; }
+    c->seed_lw = 8;
     goto pack_again;
   }
   if (h_uniover) {   // [r4] read ends with more uni-MEMs than the slab has slots per end (the reference keeps them all): a wider slab, and the batch is seeded again

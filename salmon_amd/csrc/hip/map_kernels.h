@@ -273,6 +273,217 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
   wave_stat_add(&stats[ST_SEEDS], tot_nu); wave_stat_add(&stats[ST_LOOKUPS], tot_look);
 }
 
+// ------------------------------------------------------------------------------------------------
+// [r5] k_seed2 — the same walk with the lane's state where the lane can reach it.  Round 4's counters said what k_seed waits for: a lane
+// holds a read end for ~5 trips of the loop, a few microseconds apart, and between two trips the other ~37 000 lanes of its XCD pull
+// several 64-byte sectors each through a 4 MB L2 — so the lane's own read words and the filter block it asked a moment ago are gone
+// when it comes back, and every trip began with two or three dependent trips to memory for data the lane had already had (PMC: 1.31 x
+// the byte model).  Here:
+//   * the packed words of the read end are loaded ONCE, at refill, into the lane's column of LDS (LW words; the N-mask stays in HBM and
+//     is consulted only by the rare lane whose read has an N: one flag in a register);
+//   * FC: the 64-byte filter block of the lane's current minimizer is kept in LDS too.  Consecutive probes of a walk mostly share their
+//     minimizer — that is what the blocked filter was built for — so the run of misses across a sequencing error, or along an unmappable
+//     read, asks memory once per minimizer instead of once per probe;
+//   * DT: the slot record of the minimizer comes from the minimizer table (sq_mtab_find: one sector) instead of pilot -> slot (two).
+// The walk, and therefore every uni-MEM, is k_seed's: tests hold both kernels to the checker.  Read ends longer than 32 * LW bases raise
+// ST_SEEDLW and the host seeds the batch again with the next wider instantiation (map.hip).
+#define SEED_TB 256
+template <int LW>
+__device__ inline uint64_t seed_lds_bases(const uint64_t (*rd)[SEED_TB], uint32_t tx, uint32_t p, uint32_t n) {
+  const uint32_t w = p >> 5, sh = (p & 31) * 2;
+  const uint64_t a = rd[w][tx];
+  const uint64_t b = (w + 1 < (uint32_t)LW) ? rd[w + 1][tx] : 0ULL;   // bits beyond the read are masked off below
+  const uint64_t lo = (a >> sh) | (sh ? (b << (64 - sh)) : 0ULL);
+  return lo & sq_kmask(n);
+}
+template <int KT, int MT, int SEED_SPEC, int LW, bool FC, bool DT, bool GL = false>   // GL: the filter block goes from memory to LDS without passing through registers (global_load_lds_dwordx4)
+__global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params P, uint32_t nends,
+                       const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
+                       sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
+                       unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor, uint32_t rw, uint32_t us) {
+  static_assert(KT > 0 && MT > 0 && SEED_SPEC >= 1 && SEED_SPEC <= 2, "k_seed2 is the specialised kernel");
+  __shared__ uint64_t s_rd[LW][SEED_TB];
+  __shared__ uint64_t s_fb[(FC && !GL) ? SQ_KF_BLOCK_WORDS : 1][SEED_TB];
+  __shared__ sq_u64x2 s_fq[(FC && GL) ? SQ_KF_BLOCK_WORDS / 2 : 1][SEED_TB];   // GL: quarter q of lane t's block at [q][t] — the layout the LDS-DMA writes (wave base + lane x 16 bytes)
+  constexpr int k = KT; const int alt = (int)P.alt_skip;
+  const uint32_t tx = threadIdx.x; const int lane = (int)(tx & 63);
+  const uint64_t nfb = d.kfilter_words / SQ_KF_BLOCK_WORDS;
+  uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false, anyN = false;
+  int L = 0, pos = 0, skip_until = -1; uint32_t nu = 0, np = 0;
+  uint64_t cur_blk = ~0ULL;   // the filter block in this lane's column of s_fb
+  unsigned long long tot_nu = 0, tot_look = 0;
+  uint32_t pool_next = 0, pool_end = 0; bool global_drained = false;   // wave-uniform: the wave's private run of read ends
+  for (;;) {
+    unsigned long long want = __ballot(!have && !drained);
+    while (want) {
+      if (pool_next == pool_end) {
+        if (global_drained) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (base >= nends) { global_drained = true; break; }
+        pool_next = base; pool_end = base + 64u < nends ? base + 64u : nends;
+      }
+      const uint32_t avail = pool_end - pool_next, nw = (uint32_t)__popcll(want);
+      const uint32_t take = avail < nw ? avail : nw;
+      const uint32_t rank = (uint32_t)__popcll(want & ((1ULL << lane) - 1));
+      if (!have && !drained && rank < take) {
+        e = pool_next + rank; have = true; pos = 0; skip_until = -1; nu = 0; np = 0;
+        L = rlen[e];
+        // the read end moves into the lane's LDS column: all loads in flight together, 16 bytes each
+        const sq_u64x2* rp = (const sq_u64x2*)(rpack + (size_t)e * rw);
+        const sq_u64x2* qn = (const sq_u64x2*)(rnmask + (size_t)e * (rw >> 1));
+        sq_u64x2 v[LW / 2];
+#pragma unroll
+        for (int w = 0; w < LW / 2; ++w) v[w] = rp[w];
+        const sq_u64x2 n0 = qn[0], n1 = qn[1];   // rw = 8: four mask words
+        if (L > 32 * LW) { atomicAdd(&stats[ST_SEEDLW], 1ULL); L = 0; }   // does not fit this instantiation: nothing is seeded, the host runs the wider one
+#pragma unroll
+        for (int w = 0; w < LW / 2; ++w) { s_rd[2 * w][tx] = v[w].x; s_rd[2 * w + 1][tx] = v[w].y; }
+        anyN = (n0.x | n0.y | n1.x | n1.y) != 0;
+      }
+      pool_next += take;
+      want = __ballot(!have && !drained);
+    }
+    if (global_drained && !have) drained = true;
+    if (!__ballot(have)) break;
+    if (have) {
+      bool done = false;
+      const uint64_t* nm = rnmask + (size_t)e * (rw >> 1);   // only lanes with anyN look at it
+      if (!(L >= k && pos + k <= L && nu < us)) { done = true; if (nu >= us && L >= k && pos + k <= L) atomicAdd(&stats[ST_UNIOVER], 1ULL); }
+      else {
+        int cp[SEED_SPEC]; uint64_t ckm[SEED_SPEC], crc[SEED_SPEC], cmini[SEED_SPEC]; uint32_t cat[SEED_SPEC]; bool cv[SEED_SPEC], cpass[SEED_SPEC]; int p = pos; bool ended = false;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          cv[s2] = false; cp[s2] = p; ckm[s2] = 0; crc[s2] = 0; cmini[s2] = 0; cat[s2] = 0; cpass[s2] = false;
+          if (!ended) {
+            if (p + k > L) ended = true;
+            else if (anyN) {
+              while (!ended) {
+                if (p + k > L) { ended = true; break; }
+                const uint64_t nb = fetch_bits(nm, (uint32_t)p, (uint32_t)k);
+                if (nb) { p = p + (63 - __clzll((long long)nb)) + 1; continue; }
+                cv[s2] = true; break;
+              }
+            } else cv[s2] = true;
+          }
+          if (cv[s2]) {
+            cp[s2] = p; ckm[s2] = seed_lds_bases<LW>(s_rd, tx, (uint32_t)p, (uint32_t)k);
+            if (p < skip_until) { int np2 = p + alt; if (np2 > skip_until) np2 = skip_until; p = np2; } else p += 1;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          if (cv[s2]) {
+            crc[s2] = sq_revcomp(ckm[s2], (uint32_t)k);
+            sq_min_scan<KT, MT>(d, ckm[s2], crc[s2], &cmini[s2], &cat[s2]);
+          }
+        }
+        // filter words.  The block of the LAST candidate laid out becomes the lane's block (the walk moves forward: that minimizer is the one the next
+        // trips will ask about) and is fetched whole unless the lane already holds it; the candidate before it reads the block the lane held so far,
+        // or the new one, or — rarely, a third minimizer — asks memory for its one word.  In a run of k-mers that share a minimizer no trip loads anything.
+        uint64_t fblk[SEED_SPEC], fmsk[SEED_SPEC], fword[SEED_SPEC]; uint32_t fwi[SEED_SPEC];
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) {
+          fblk[s2] = 0; fmsk[s2] = 0; fwi[s2] = 0; fword[s2] = 0;
+          if (cv[s2]) { const uint64_t h = sq_kf_hash(ckm[s2] < crc[s2] ? ckm[s2] : crc[s2]); fmsk[s2] = sq_kf_mask(h);
+            fblk[s2] = sq_kf_word(sq_mix64(cmini[s2] ^ 0x6A09E667F3BCC909ULL), nfb); fwi[s2] = (uint32_t)(h >> 24) & (SQ_KF_BLOCK_WORDS - 1); }
+        }
+        if (FC) {
+          const bool two = SEED_SPEC > 1 && cv[SEED_SPEC - 1];
+          const uint64_t blast = two ? fblk[SEED_SPEC - 1] : fblk[0]; const uint32_t wlast = two ? fwi[SEED_SPEC - 1] : fwi[0];
+          const bool old0 = two && fblk[0] == cur_blk, far0 = two && !old0 && fblk[0] != blast;
+          auto lds_word = [&](uint32_t wi) -> uint64_t { return GL ? ((const uint64_t*)&s_fq[wi >> 1][tx])[wi & 1] : s_fb[wi][tx]; };
+          if (old0) fword[0] = lds_word(fwi[0]);
+          if (far0) fword[0] = d.kfilter[fblk[0] * SQ_KF_BLOCK_WORDS + fwi[0]];
+          const bool fill = cv[0] && blast != cur_blk;
+          if (GL) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the read of the block held so far is done before the DMA may overwrite it
+            if (fill) {
+              typedef __attribute__((address_space(3))) void* lds_vp; typedef const __attribute__((address_space(1))) void* glb_vp;
+              const char* g = (const char*)(d.kfilter + blast * SQ_KF_BLOCK_WORDS);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds((glb_vp)(g + 16 * q), (lds_vp)&s_fq[q][tx & ~63u], 16, 0, 0);
+              cur_blk = blast;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the block has landed
+          } else if (fill) {
+            const sq_u64x2* bp = (const sq_u64x2*)(d.kfilter + blast * SQ_KF_BLOCK_WORDS);
+            const sq_u64x2 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+            s_fb[0][tx] = b0.x; s_fb[1][tx] = b0.y; s_fb[2][tx] = b1.x; s_fb[3][tx] = b1.y; s_fb[4][tx] = b2.x; s_fb[5][tx] = b2.y; s_fb[6][tx] = b3.x; s_fb[7][tx] = b3.y;
+            cur_blk = blast;
+          }
+          if (cv[0]) { const uint64_t w = lds_word(wlast); if (two) fword[SEED_SPEC - 1] = w; else fword[0] = w; }
+          if (two && !old0 && !far0) fword[0] = lds_word(fwi[0]);
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (cv[s2]) fword[s2] = d.kfilter[fblk[s2] * SQ_KF_BLOCK_WORDS + fwi[s2]];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) cpass[s2] = cv[s2] && (fword[s2] & fmsk[s2]) == fmsk[s2];
+        int pick = -1; uint32_t looked = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (pick < 0 && cv[s2]) { ++looked; if (cpass[s2]) pick = s2; }
+        tot_look += looked;
+        uint64_t km = 0, krc = 0, kmini = 0; uint32_t kat = 0; int ppos = pos;
+#pragma unroll
+        for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (s2 == pick) { km = ckm[s2]; krc = crc[s2]; kmini = cmini[s2]; kat = cat[s2]; ppos = cp[s2]; }
+        if (pick < 0) {   // every laid-out probe was a miss, or the read ran out: the walk continues behind them
+          pos = p;
+          if (ended) done = true;
+        } else {
+          pos = ppos;
+          uint64_t u; uint32_t off; int fw;
+          const uint64_t rec = DT ? sq_mtab_find(d.mtab, d.mtab_buckets, kmini) : d.slots[sq_mphf_slot(d, kmini)];
+          if (!sq_dict_lookup_rec<KT, MT>(d, km, krc, rec, kat, &u, &off, &fw)) {
+            if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
+          } else {
+            uint64_t ub, ue, ca, cb;   // the sector sq_dict_try has just brought in: both tables' bounds of unitig u
+            sq_ld_pair(d.uinfo + 2 * u, &ub, &ca); sq_ld_pair(d.uinfo + 2 * u + 2, &ue, &cb);
+            const int ulen = (int)(ue - ub);
+            int len = k;
+            int avail = fw ? min(L - (pos + len), ulen - ((int)off + len)) : min(L - (pos + len), (int)off - (len - k));
+            bool mism = false;
+            while (avail > 0) {
+              const int c = avail < 32 ? avail : 32;
+              const uint64_t rc_ = seed_lds_bases<LW>(s_rd, tx, (uint32_t)(pos + len), (uint32_t)c);
+              const uint64_t nn = anyN ? fetch_bits(nm, (uint32_t)(pos + len), (uint32_t)c) : 0ULL;
+              uint64_t uc;
+              if (fw) uc = sq_fetch_bases(d.useq, ub + off + len, (uint32_t)c);
+              else {
+                const int up = (int)off - 1 - (len - k);
+                uc = sq_revcomp(sq_fetch_bases(d.useq, ub + (uint64_t)(up - c + 1), (uint32_t)c), (uint32_t)c);
+              }
+              const uint64_t x = rc_ ^ uc; const uint64_t mm = (x | (x >> 1)) & 0x5555555555555555ULL;
+              const int i1 = mm ? (__ffsll((long long)mm) - 1) / 2 : 64; const int i2 = nn ? (__ffsll((long long)nn) - 1) : 64;
+              const int im = i1 < i2 ? i1 : i2;
+              if (im < c) { len += im; mism = true; break; }
+              len += c; avail -= c;
+            }
+            const bool rend = (pos + len >= L);
+            const bool uend = !rend && !mism;
+            sq_unimem_dev m;
+            m.unitig = (uint32_t)u;
+            m.qpos = (uint16_t)pos;
+            m.len = (uint16_t)len;
+            m.fw = (uint8_t)fw;
+            m.ustart = fw ? off : (uint32_t)((int)off - (len - k));
+            m.pad[0] = m.pad[1] = m.pad[2] = 0;
+            const uint64_t occ = cb - ca;
+            m.ctab_a = ca; m.cnt = occ <= P.max_occ ? (uint32_t)occ : 0u; m.ulen = (uint32_t)ulen;
+            um[(size_t)e * us + nu] = m; ++nu;
+            if (occ <= P.max_occ) np += (uint32_t)occ;
+            if (rend) done = true;
+            else { const int ee = pos + len; pos = pos + len - k + 1; skip_until = uend ? -1 : ee + 1; }
+          }
+        }
+      }
+      if (done) { n_uni[e] = nu; n_proj[e] = np; tot_nu += nu; have = false; }
+    }
+  }
+  wave_stat_add(&stats[ST_SEEDS], tot_nu); wave_stat_add(&stats[ST_LOOKUPS], tot_look);
+}
+
 // val layout: len[0,10) q[10,20) fw[20] tid[32,64)
 __device__ inline uint64_t mem_pack_val(uint32_t tid, uint32_t q, uint32_t len, uint32_t fw) {
   return ((uint64_t)tid << 32) | ((uint64_t)fw << 20) | ((uint64_t)q << 10) | len;

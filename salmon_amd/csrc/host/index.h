@@ -45,7 +45,7 @@ struct sq_index {
     v.skew_keys = skew_keys.data(); v.skew_vals = skew_vals.data();
     v.skew_mask = skew_keys.empty() ? 0 : skew_keys.size() - 1;
     v.useq = useq.data(); v.uoff = uoff.data(); v.num_unitigs = uoff.empty() ? 0 : uoff.size() - 1;
-    v.kfilter = nullptr; v.kfilter_words = 0; v.uinfo = nullptr;   // the filter and the interleaved unitig bounds live on the device only (built at upload)
+    v.kfilter = nullptr; v.kfilter_words = 0; v.uinfo = nullptr; v.mtab = nullptr; v.mtab_buckets = 0;   // the filter and the interleaved unitig bounds live on the device only (built at upload)
     return v;
   }
 };

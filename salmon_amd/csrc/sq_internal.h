@@ -147,6 +147,8 @@ struct sq_dict_view {
                                   // tables, and here they are 32 contiguous bytes (one 64-byte sector three times out of four) instead of two sectors
   const uint64_t* kfilter;        // k-mer membership filter (device only; nullptr = none): word-blocked Bloom, SQ_KF_BITS_PER_KEY bits per k-mer
   uint64_t kfilter_words;
+  const uint64_t* mtab;           // [r5] device only (nullptr = none): minimizer -> slot record in ONE dependent sector (sq_mtab_*, below) instead of pilot -> slot
+  uint64_t mtab_buckets;
 };
 
 // k-mer membership filter in front of the dictionary.  ~80 % of the probes of a read are misses (the mismatchSeedSkip walk across a
@@ -241,11 +243,32 @@ SQ_HD void sq_min_scan(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64
   }
   *mini_out = mini; *at_out = at;
 }
-// the dictionary walk for a k-mer whose minimizer scan has been done: pilot -> slot record -> {string pool, unitig bounds}
+// [r5] The minimizer table (device only, built at upload from the MPHF's own answers: hip/index_dev.hip).  The MPHF costs two dependent
+// 64-byte sectors per hit (pilot, then slot record); the table keeps (minimizer, slot record) pairs in 64-byte buckets of four chosen by
+// the minimizer's hash, so the record of a present minimizer arrives with ONE sector (linear probing over buckets for the few that
+// overflow; a bucket with a free place ends the search).  Same records, so everything behind it is unchanged.
+#define SQ_MTAB_BUCKET 4u            /* (key, record) pairs per 64-byte bucket */
+#define SQ_MTAB_EMPTY (~0ULL)
+SQ_HD uint64_t sq_mtab_bucket_of(uint64_t mini, uint64_t nbuckets) { return sq_kf_word(sq_mix64(mini ^ 0xBB67AE8584CAA73BULL), nbuckets); }
+SQ_HD uint64_t sq_mtab_find(const uint64_t* tab, uint64_t nbuckets, uint64_t mini) {   // the slot record of `mini`, SQ_SLOT_EMPTY if it has none
+  uint64_t b = sq_mtab_bucket_of(mini, nbuckets);
+  for (;;) {
+    const uint64_t* q = tab + b * (2 * SQ_MTAB_BUCKET);
+    uint64_t k0, r0, k1, r1, k2, r2, k3, r3;   // four 16-byte loads of one sector, in flight together
+    sq_ld_pair(q, &k0, &r0); sq_ld_pair(q + 2, &k1, &r1); sq_ld_pair(q + 4, &k2, &r2); sq_ld_pair(q + 6, &k3, &r3);
+    if (k0 == mini) return r0;
+    if (k1 == mini) return r1;
+    if (k2 == mini) return r2;
+    if (k3 == mini) return r3;
+    if (k0 == SQ_MTAB_EMPTY || k1 == SQ_MTAB_EMPTY || k2 == SQ_MTAB_EMPTY || k3 == SQ_MTAB_EMPTY) return SQ_SLOT_EMPTY;
+    if (++b == nbuckets) b = 0;
+  }
+}
+
+// the dictionary walk for a k-mer whose minimizer scan has been done and whose minimizer's slot record is at hand: record -> {string pool, unitig bounds}
 template <int KT, int MT>
-SQ_HD int sq_dict_lookup_pre(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t mini, uint32_t at, uint64_t* unitig, uint32_t* off, int* fw) {
+SQ_HD int sq_dict_lookup_rec(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t rec, uint32_t at, uint64_t* unitig, uint32_t* off, int* fw) {
   const uint32_t k = KT ? (uint32_t)KT : d.k, m = MT ? (uint32_t)MT : d.m, w = k - m;
-  const uint64_t rec = d.slots[sq_mphf_slot(d, mini)];
   if (rec == SQ_SLOT_EMPTY) return 0;
   const bool inl = (rec & SQ_SLOT_INLINE) != 0;     // the common case: the record IS the single occurrence (no pointer, no scratch)
   uint64_t nent = 1; const uint64_t* ent = nullptr;
@@ -279,6 +302,11 @@ SQ_HD int sq_dict_lookup_pre(const sq_dict_view& d, uint64_t kmer, uint64_t rc, 
     }
   }
   return 0;
+}
+// the dictionary walk for a k-mer whose minimizer scan has been done: pilot -> slot record -> {string pool, unitig bounds}
+template <int KT, int MT>
+SQ_HD int sq_dict_lookup_pre(const sq_dict_view& d, uint64_t kmer, uint64_t rc, uint64_t mini, uint32_t at, uint64_t* unitig, uint32_t* off, int* fw) {
+  return sq_dict_lookup_rec<KT, MT>(d, kmer, rc, d.slots[sq_mphf_slot(d, mini)], at, unitig, off, fw);
 }
 // Full dictionary query. kmer in read orientation; on success fw tells whether the read k-mer
 // equals the unitig's forward string at (unitig, off).  KT/MT > 0 fix k and m at compile time (the
