@@ -52,6 +52,9 @@ typedef struct {
  * info.json, versionInfo.json, duplicate_clusters.tsv. */
 int sq_index_build(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path,
                    const char* outdir);
+/* [r5] The same from a FASTA file, kept in memory and written nowhere (the -t targets of alignment-based mode: SalmonQuantifyAlignments.cpp reads them
+ * into its AlignmentLibrary without an index directory). */
+int sq_index_build_fasta_mem(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, sq_index** out);
 /* Build from in-memory sequences (ASCII, not NUL-terminated; lens in nt). Names NUL-terminated.
  * first_decoy = index of the first decoy sequence (== nrefs when none). Either writes outdir (if
  * non-NULL) and/or returns a host-resident handle in *out (if non-NULL). */
@@ -257,6 +260,7 @@ int sq_aln_inject(sq_ctx* ctx, const sq_aln_batch* in, uint64_t num_with_joint_h
 typedef struct sq_sam sq_sam;
 typedef struct { uint64_t num_records, num_fragments, num_alignments, num_unaligned, num_suspicious_pairs, num_skipped_unknown_target, num_frags_without_as; } sq_sam_counts;
 int sq_sam_open(const char* path, int paired_library, sq_sam** out);
+int sq_sam_first_flag(const char* path, int* flag);   /* [r5] FLAG of the first record (SAM, gzip, BAM): -l A decides paired / single-end from it (the reference peeks at the file too: SalmonQuantifyAlignments.cpp, AlignmentLibrary's constructor) */
 uint32_t sq_sam_num_refs(const sq_sam*);
 const char* sq_sam_ref_name(const sq_sam*, uint32_t i);
 uint32_t sq_sam_ref_len(const sq_sam*, uint32_t i);

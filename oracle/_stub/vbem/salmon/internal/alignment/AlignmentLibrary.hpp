@@ -1,0 +1,6 @@
+// oracle/_stub/vbem — TEST INFRASTRUCTURE.  Stand-ins on the include path of the VBEM pin only (oracle/Makefile, ref_vbem_shim.cpp): they let
+// /root/reference/src/inference/CollapsedEMOptimizer.cpp compile where it lies, without TBB / Boost / spdlog / pufferfish.
+#pragma once
+#include "salmon/internal/quant/ReadExperiment.hpp"
+class AlignmentModel {}; class ONTAlignmentModel {};
+template <class F, class B, class A> class AlignmentLibrary : public ReadExperiment<B> {};

@@ -18,8 +18,11 @@
 // Compiled from the reference tree the same way and held against this file (tests/test_*_pin.py): the option defaults and log-space helpers, the
 // forgetting-mass schedule, SimplePosBias.cpp + spline.h (--posBias), SBModel.cpp and GCFragModel.hpp (--seqBias / --gcBias),
 // [r4] FragmentLengthDistribution.cpp and DistributionUtils.cpp (the FLD, the effective lengths of burn-in, an orphan's fragment-length probability:
-// rows a10-a13) and EMUtils.cpp (the EM update: rows a15-a16).  What cannot be compiled here (SalmonQuantify.cpp, CollapsedEMOptimizer.cpp: Boost,
-// TBB, pufferfish) is followed line by line and cited.
+// rows a10-a13) and EMUtils.cpp (the EM update: rows a15-a16); [r5] CollapsedEMOptimizer.cpp itself — the serial VBEMUpdate_ and the whole of
+// CollapsedEMOptimizer::optimize, the default optimiser, with TBB / Boost / spdlog / ReadExperiment stood in for (oracle/_stub/vbem; tests/test_vbem_pin.py: same
+// iteration counts, alphas to 1e-9; the pin found that the reference's plain-EM first iteration adds into alphasPrime left at 1.0 — now followed) and
+// TranscriptCluster.hpp + ClusterForest.hpp (projectToPolytope and the cluster forest of normalizeAlphas, row a14: tests/test_polytope_pin.py).  What cannot be
+// compiled here (SalmonQuantify.cpp, SalmonUtils.cpp: Boost, TBB, pufferfish) is followed line by line and cited.
 //
 // Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.
 #include <algorithm>
@@ -1329,12 +1332,14 @@ static void em_step(const EMProblem& P, const sq_em_opts* o, const std::vector<d
 
 // iteration loop shared by optimize (minIter 100) and the bootstrap replicates (minIter 50)
 static void em_loop(const EMProblem& P, const sq_em_opts* o, std::vector<double>& alpha, uint32_t min_iter, uint32_t* iters,
-    bool* converged, double* max_rel, uint32_t it0 = 0, uint32_t stop_at = 0 /* > 0: the part before the bias hook — until the convergence test holds, stop_at iterations at most */) {
+    bool* converged, double* max_rel, uint32_t it0 = 0, uint32_t stop_at = 0 /* > 0: the part before the bias hook — until the convergence test holds, stop_at iterations at most */,
+    bool plus_one = false /* [r5] optimize() without VBEM: the reference's alphasPrime hold 1.0 when its first EMUpdate_ adds into them (:797-823, :178-234 — no clearing there, unlike VBEMUpdate_ :265-283); found by tests/test_vbem_pin.py */) {
   const uint32_t M = P.M;
   std::vector<double> alphaP(M), theta(M), inv(P.E);
   uint32_t it = it0; bool conv = false; double maxRel = -1.7976931348623157e308;
   while (stop_at ? (it < stop_at && !conv) : (it < min_iter || (it < o->max_iter && !conv))) {
     em_step(P, o, alpha, alphaP, theta, inv);
+    if (plus_one && it == 0 && !o->use_vbem) for (uint32_t i = 0; i < M; ++i) alphaP[i] += 1.0;
     conv = true; maxRel = -1.7976931348623157e308;
     for (uint32_t i = 0; i < M; ++i) {
       if (alphaP[i] > 1e-2) {
@@ -1372,7 +1377,7 @@ static int em_optimize(const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_
     if (denom <= 2.2250738585072014e-308) { P.count[c] = 0; for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = 0.0; ++ndeg; }   // no count, no weight (the weights may be NaN)
   }
   uint32_t it; bool conv; double maxRel;
-  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel);
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 0, true);
   for (uint32_t i = 0; i < M; ++i) if (alpha[i] <= 1e-8) alpha[i] = 0.0;  // truncateCountVector :64-76
   double asum = canonical_sum(alpha);
   for (uint32_t i = 0; i < M; ++i) alpha_out[i] = alpha[i];
@@ -1659,7 +1664,7 @@ static int em_optimize_gc(const sq_eq_table* eq, const sq_txp_in* txp, const sq_
     if (denom <= 2.2250738585072014e-308) { P.count[c] = 0; dropped[c] = 1; for (uint64_t i = P.off[c]; i < P.off[c + 1]; ++i) P.cw[i] = 0.0; ++ndeg; }
   }
   uint32_t it; bool conv; double maxRel;
-  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 11);
+  em_loop(P, o, alpha, o->min_iter, &it, &conv, &maxRel, 0, 11, true);
   if (seq_fw || pos) bias_seq_eff_lengths(ix, gc_obs != nullptr, gc_obs, seq_fw, seq_rc, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr, pos);   // --seqBias / --posBias [+ --gcBias]
   else bias_gc_eff_lengths(ix, gc_obs, log_pmf, M, alpha.data(), eff.data(), eff2.data(), nullptr);
   for (uint64_t c = 0; c < P.E; ++c) {   // updateEqClassWeights with the new lengths

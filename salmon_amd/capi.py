@@ -164,6 +164,7 @@ def lib():
     sig = {
         "sq_last_error": (C.c_char_p, []), "sq_version": (C.c_char_p, []),
         "sq_index_build": (C.c_int, [P(IndexOpts), C.c_char_p, C.c_char_p, C.c_char_p]),
+        "sq_index_build_fasta_mem": (C.c_int, [P(IndexOpts), C.c_char_p, C.c_char_p, P(vp)]),
         "sq_index_build_mem": (C.c_int, [P(IndexOpts), u32, P(C.c_char_p), P(C.c_char_p), P(u32), u32, C.c_char_p, P(vp)]),
         "sq_index_load": (C.c_int, [C.c_char_p, C.c_int, P(vp)]),
         "sq_index_to_device": (C.c_int, [vp, C.c_int]), "sq_index_free": (None, [vp]),
@@ -228,7 +229,7 @@ def lib():
         "sq_boot_writer_open": (C.c_int, [C.c_char_p, u32, P(C.c_char_p), P(vp)]), "sq_boot_writer_append": (C.c_int, [vp, P(f64),
             u32]), "sq_boot_writer_close": (u64, [vp]),
         "sq_bias_last_gc_expected": (C.c_int, [vp]), "sq_aln_inject": (C.c_int, [vp, P(AlnBatch), u64]), "sq_model_drop_counts": (C.c_int, [vp]),
-        "sq_sam_open": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_sam_num_refs": (u32, [vp]), "sq_sam_ref_name": (C.c_char_p, [vp, u32]), "sq_sam_ref_len": (u32, [vp, u32]),
+        "sq_sam_open": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_sam_first_flag": (C.c_int, [C.c_char_p, P(C.c_int)]), "sq_sam_num_refs": (u32, [vp]), "sq_sam_ref_name": (C.c_char_p, [vp, u32]), "sq_sam_ref_len": (u32, [vp, u32]),
         "sq_sam_set_tid_map": (C.c_int, [vp, vp, u32]), "sq_sam_next": (C.c_int, [vp, u32, C.c_int, f64, P(AlnBatch), P(SamCounts)]), "sq_sam_close": (None, [vp]),
         "sq_index_hash": (C.c_char_p, [vp, C.c_int]), "sq_index_keeps_duplicates": (C.c_int, [vp]), "sq_model_fld_min": (C.c_int, [vp, P(u32)]),
         "sq_write_fld_samples": (C.c_int, [C.c_char_p, vp, u32, u32, u32, u64, P(f64), P(f64), P(u32)]), "sq_write_legacy_bias": (C.c_int, [C.c_char_p, P(u32)]),

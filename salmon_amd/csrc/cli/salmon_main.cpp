@@ -340,8 +340,7 @@ static int cmd_quant(int argc, char** argv) {
     if (flag(argc, argv, "--gcBias") || flag(argc, argv, "--seqBias") || flag(argc, argv, "--posBias") || flag(argc, argv, "--writeMappings") || flag(argc, argv, "--writeUnmappedNames") || world > 1) {
       fprintf(stderr, "[salmon-hip] alignment-based mode runs on one GPU without bias correction, --writeMappings and --writeUnmappedNames\n"); return 1; }
     // the library's read type decides how records are grouped; with -l A the first record's PAIRED flag says which (the reference peeks at the file too)
-    if (autodetect) { gzFile g = gzopen(alnf, "rb"); if (!g) { fprintf(stderr, "[salmon-hip] cannot open %s\n", alnf); return 1; } char lb[1 << 16]; aln_paired = true;
-      while (gzgets(g, lb, sizeof(lb))) { if (lb[0] == '@') continue; const char* t1 = strchr(lb, '\t'); if (t1) aln_paired = (atoi(t1 + 1) & 1) != 0; break; } gzclose(g); }
+    if (autodetect) { int fl = 0; if (sq_sam_first_flag(alnf, &fl)) die("reading the first alignment record"); aln_paired = (fl & 1) != 0; }
   }
   if (autodetect) lib = alnf ? (aln_paired ? "IU" : "U") : (ru ? "U" : "IU");   // enableAutodetect(): the library starts unstranded / inward (LibraryTypeUtils.cpp:110-146)
   auto li = kLib.find(lib); if (li == kLib.end()) { fprintf(stderr, "[salmon-hip] unknown library type %s\n", lib.c_str()); return 1; }
@@ -373,11 +372,8 @@ static int cmd_quant(int argc, char** argv) {
   sq_index* idx = nullptr;
   if (alnf) {   // the targets come from the FASTA; every record keeps its identity (no duplicate removal, no clipping) so that the SAM header's targets are the index's
     sq_index_opts io{}; io.k = 31; io.keep_duplicates = 1; io.no_clip_polya = 1; io.threads = (v = arg(argc, argv, "-p", "--threads")) ? (uint32_t)atoi(v) : 8;
-    mkdir(odir, 0755); const std::string tdir = std::string(odir) + "/.targets_index";
-    if (sq_index_build(&io, targets, nullptr, tdir.c_str())) die("indexing the targets");
-    if (sq_index_load(tdir.c_str(), device, &idx)) die("loading the targets");
-    for (const char* fn : {"index.bin", "info.json", "versionInfo.json", "duplicate_clusters.tsv"}) remove((tdir + "/" + fn).c_str());
-    rmdir(tdir.c_str());
+    if (sq_index_build_fasta_mem(&io, targets, nullptr, &idx)) die("reading the targets");   // in memory: nothing is left behind in the output directory
+    if (sq_index_to_device(idx, device)) die("uploading the targets");
   } else if (sq_index_load(idir, device, &idx)) die("loading index");
   sq_quant_opts qo;
   sq_quant_opts_default(&qo);

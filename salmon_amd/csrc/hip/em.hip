@@ -77,6 +77,9 @@ struct EmDev {
   uint32_t* flags;   // [0] = done (iteration count at convergence, 0 = running), [1] = not-converged marker, [2] = iters executed
   unsigned long long* maxrel;  // bit pattern of max relDiff (non-negative doubles order like integers)
   double tol; int use_vbem; uint32_t min_iter;
+  double first_add;  // [r5] 1.0 in the first iteration of optimize() without VBEM, else 0: the reference leaves alphasPrime at 1.0 after its initialisation
+                     // (CollapsedEMOptimizer.cpp:797-823) and its EMUpdate_ (:178-234) adds into it without clearing it first — VBEMUpdate_ (:265-283) clears —
+                     // so every transcript starts the second iteration one count up.  Found by the pin against the compiled optimiser (tests/test_vbem_pin.py)
   // k_l1 work plan: block b stages the CSC entries of level-1 segments [chunk_seg[b], chunk_seg[b+1]) through LDS
   const uint32_t* cchunk; uint32_t ncchunks;   // k_class work plan: block b owns classes [cchunk[b], cchunk[b+1])
   const uint32_t* chunk_seg; uint32_t nchunks; const uint8_t* t_seg8;   // t_seg8[p] = index of entry p's run within its block
@@ -310,6 +313,7 @@ __global__ void __launch_bounds__(256) k_fin(EmDev d, const double* __restrict__
       alpha_out[t] = acc;
     } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
     else acc = alpha_out[t];
+    if (d.first_add != 0.0) { acc += d.first_add; alpha_out[t] = acc; }
     leaf = acc + d.prior[t];
     if (acc > 1e-2) {  // alphaCheckCutoff (:884)
       rel = fabs(alpha[t] - acc) / acc;
@@ -382,6 +386,7 @@ __global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict_
       alpha_out[t] = acc;
     } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
     else acc = alpha_out[t];
+    if (d.first_add != 0.0) { acc += d.first_add; alpha_out[t] = acc; }
     leaf = acc + d.prior[t];
     if (acc > 1e-2) {  // alphaCheckCutoff (:884)
       rel = fabs(alpha[t] - acc) / acc;
@@ -835,7 +840,7 @@ struct EmSession {
     d.flags = d_flags.p;
     d.maxrel = d_maxrel.p;
     d.tol = o->rel_diff_tolerance;
-    d.use_vbem = o->use_vbem;
+    d.use_vbem = o->use_vbem; d.first_add = 0.0;
     for (int l = 0; l < 4; ++l) {
       d.seg_lo[l] = d_slo[l].p;
       d.seg_cnt[l] = d_scn[l].p;
@@ -899,8 +904,9 @@ struct EmSession {
     const bool fold = can_fold && nl_env == 3, four = can_fold && nl_env == 4;
     if (four) top_nblk = (M + TB - 1) / TB;
     double* psi_cur = d_psi0.p; double* psi_nxt = d_psi1.p;
+    const bool plus_one = mark_degenerate && !o->use_vbem;   // optimize() only (the replicates' alphasPrime start at zero: :413-414)
     auto launch_iter3 = [&](uint32_t it) {
-      EmDev dd = d;
+      EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
       if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
       const double* src = o->use_vbem ? psi_cur : cur;
       if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
@@ -909,7 +915,7 @@ struct EmSession {
       std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
     };
     auto launch_iter4 = [&](uint32_t it) {
-      EmDev dd = d;
+      EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
       if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
       const double* src = o->use_vbem ? psi_cur : cur;
       if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
@@ -927,7 +933,7 @@ struct EmSession {
       if (!d.l2_cnt) { int l = 1; for (; l < d.nlevels && d.nseg[l] > 1024; ++l) k_level<<<(d.nseg[l] + TB - 1) / TB, TB, 0, st>>>(d, l,
           nxt);
         if (l < d.nlevels) k_upper<<<1, 1024, 0, st>>>(d, l, nxt); }
-      k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, nxt, o->use_vbem ? part_lvl1 : nullptr);
+      { EmDev df = d; df.first_add = (plus_one && it == 0) ? 1.0 : 0.0; k_fin<<<(M + TB - 1) / TB, TB, 0, st>>>(df, cur, nxt, o->use_vbem ? part_lvl1 : nullptr); }
       // closes iteration `it`; VBEM: also logNorm for the next one
       if (o->use_vbem) launch_top(1, it);
       else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);

@@ -170,7 +170,7 @@ struct sq_dev_reader {
   // hold: the mate's last round is kept back (the caller checks the record counts of the mates before a batch's last round may go out)
   bool stage_text(int i, int si, bool first_of_batch, uint32_t want, bool last_mate, Round* hold, uint32_t* got, size_t* bytes, std::string* e) {
     Stream& S = sm[i]; *got = 0; *bytes = 0;
-    const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0; bool reached = false, first = first_of_batch;
+    const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0; bool reached = false, first = first_of_batch; char last2[2] = {'X', '\n'};
     while (!reached && S.vpos + have < S.vsize) {
       const uint64_t missing = (need_lines - lines + 3) / 4;
       const size_t more = (size_t)std::min<uint64_t>(std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20)), (uint64_t)ROUND_PIECES * PIECE);
@@ -198,14 +198,26 @@ struct sq_dev_reader {
       }
       const bool at_end = !reached && S.vpos + have + emitted >= S.vsize;
       if (at_end) {   // the end of the input: what is left must be whole records (blank lines at the very end are tolerated, as on the host path)
-        char tail[4096]; size_t tn = 0;   // the last bytes of the round, gathered (they may straddle pieces)
-        { size_t want_b = std::min(sizeof(tail), emitted); size_t skip = emitted - want_b;
-          for (auto& pc : r.pieces) { if (skip >= pc.second) { skip -= pc.second; continue; } const size_t c = pc.second - skip; memcpy(tail + tn, ring + (size_t)pc.first * PIECE + skip, c); tn += c; skip = 0; } }
-        size_t cut = tn;
-        while (cut >= 2 && tail[cut - 1] == '\n' && (tail[cut - 2] == '\n' || (cut >= 3 && tail[cut - 2] == '\r' && tail[cut - 3] == '\n'))) { cut -= (tail[cut - 2] == '\r') ? 2 : 1; --lines; }
-        size_t drop = tn - cut;
+        // [r5] T = the two bytes in front of the round's tail + the tail: a blank line is a line end that follows a line end, and the one it follows may be the last
+        // byte of the previous round or of the previous batch (a batch is cut right behind a newline, so a call starts at the start of a line) — a file whose
+        // records fill its batches exactly and then ends with an empty line leaves a round that is nothing but "\n"
+        char T[4096 + 2]; size_t tn = 0;   // the last bytes of the round, gathered (they may straddle pieces)
+        { size_t want_b = std::min(sizeof(T) - 2, emitted); size_t skip = emitted - want_b;
+          for (auto& pc : r.pieces) { if (skip >= pc.second) { skip -= pc.second; continue; } const size_t c = pc.second - skip; memcpy(T + 2 + tn, ring + (size_t)pc.first * PIECE + skip, c); tn += c; skip = 0; } }
+        if (tn < emitted) { T[0] = 'X'; T[1] = 'X'; } else { T[0] = last2[0]; T[1] = last2[1]; }
+        size_t cut = tn + 2;
+        for (;;) {
+          if (cut >= 3 && T[cut - 1] == '\n' && T[cut - 2] == '\n') { cut -= 1; --lines; }
+          else if (cut >= 4 && T[cut - 1] == '\n' && T[cut - 2] == '\r' && T[cut - 3] == '\n') { cut -= 2; --lines; }
+          else break;
+        }
+        size_t drop = tn + 2 - cut;
         while (drop && !r.pieces.empty()) { auto& pc = r.pieces.back(); const size_t c = std::min(drop, pc.second); pc.second -= c; drop -= c; emitted -= c; if (!pc.second) { give_back(r.pieces, r.pieces.size() - 1); r.pieces.pop_back(); } }
         if (lines % 4) { *e = "'" + S.files.back().path + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; give_back(r.pieces); return false; }
+      } else if (!reached && emitted) {   // the last two bytes of this round, for the blank-line rule of the round that ends the input
+        char b2[2] = {last2[1], 0}; size_t got2 = 0;
+        for (size_t q = r.pieces.size(); q-- > 0 && got2 < 2;) { const auto& pc = r.pieces[q]; const char* base = ring + (size_t)pc.first * PIECE; for (size_t c = pc.second; c-- > 0 && got2 < 2;) { b2[1 - got2] = base[c]; ++got2; } }
+        if (got2 == 2) { last2[0] = b2[0]; last2[1] = b2[1]; } else if (got2 == 1) { last2[0] = last2[1]; last2[1] = b2[1]; }
       }
       have += emitted;
       if (reached || at_end) {

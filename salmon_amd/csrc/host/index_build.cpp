@@ -623,7 +623,7 @@ static int finish_opts(const sq_index_opts* o, sq_index* idx) {
 
 static int index_build_mem_impl(const sq_index_opts* opts, uint32_t nrefs, const char* const* names, const char* const* seqs, const uint32_t* lens,
                                 uint32_t first_decoy, const char* outdir, sq_index** out);
-static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir);
+static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir, sq_index** out);
 // the C ABI never lets a C++ exception out (a ctypes / cgo host would abort): allocation failures become SQ_ERR_NOMEM
 extern "C" int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, const char* const* names, const char* const* seqs, const uint32_t* lens,
                                   uint32_t first_decoy, const char* outdir, sq_index** out) {
@@ -632,7 +632,14 @@ extern "C" int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, con
   catch (const std::exception& e) { sq_set_error("index build failed: %s", e.what()); return SQ_ERR_STATE; }
 }
 extern "C" int sq_index_build(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir) {
-  try { return index_build_impl(opts, fasta_path, decoys_path, outdir); }
+  try { return index_build_impl(opts, fasta_path, decoys_path, outdir, nullptr); }
+  catch (const std::bad_alloc&) { sq_set_error("out of memory while building the index"); return SQ_ERR_NOMEM; }
+  catch (const std::exception& e) { sq_set_error("index build failed: %s", e.what()); return SQ_ERR_STATE; }
+}
+// [r5] the same, kept in memory (nothing is written): the targets of alignment-based mode
+extern "C" int sq_index_build_fasta_mem(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, sq_index** out) {
+  if (!out) { sq_set_error("sq_index_build_fasta_mem: bad arguments"); return SQ_ERR_ARG; }
+  try { return index_build_impl(opts, fasta_path, decoys_path, nullptr, out); }
   catch (const std::bad_alloc&) { sq_set_error("out of memory while building the index"); return SQ_ERR_NOMEM; }
   catch (const std::exception& e) { sq_set_error("index build failed: %s", e.what()); return SQ_ERR_STATE; }
 }
@@ -652,8 +659,8 @@ static int index_build_mem_impl(const sq_index_opts* opts, uint32_t nrefs, const
   return SQ_OK;
 }
 
-static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir) {
-  if (!fasta_path || !outdir) { sq_set_error("sq_index_build: bad arguments"); return SQ_ERR_ARG; }
+static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, const char* decoys_path, const char* outdir, sq_index** out) {
+  if (!fasta_path || (!outdir && !out)) { sq_set_error("sq_index_build: bad arguments"); return SQ_ERR_ARG; }
   sq_index* idx = new sq_index();
   int rc = finish_opts(opts, idx); if (rc) { delete idx; return rc; }
   std::vector<std::string> n, s;
@@ -673,8 +680,8 @@ static int index_build_impl(const sq_index_opts* opts, const char* fasta_path, c
   std::vector<uint32_t> clen; uint32_t fd = 0;
   prep_refs(opts, n, s, clen, dec, &fd, idx->duplicates, idx);
   rc = build_core(opts, n, s, clen, fd, idx);
-  if (!rc) rc = sq_index_save(*idx, outdir);
-  delete idx;
+  if (!rc && outdir) rc = sq_index_save(*idx, outdir);
+  if (!rc && out) *out = idx; else delete idx;
   return rc;
 }
 

@@ -44,7 +44,11 @@ struct sq_sam {
   std::unique_ptr<sqio::Pool> pool; std::unique_ptr<sqio::BgzfSource> bg; PgzBuf cur; size_t cur_off = 0; std::string io_err;
   ~sq_sam() { cur = PgzBuf(); bg.reset(); pool.reset(); }   // the source's tasks run on the pool: the source goes first
   int fill(char* dst, size_t cap) {   // > 0 bytes, 0 at the end, < 0 on error (io_err)
-    if (!bg) return gzread(f, dst, (unsigned)cap);
+    if (!bg) {   // zlib's reader: a damaged or truncated stream is an error, not a shorter file
+      const int n = gzread(f, dst, (unsigned)cap);
+      if (n <= 0) { int e = Z_OK; const char* msg = gzerror(f, &e); if (n < 0 || (e != Z_OK && e != Z_STREAM_END)) { io_err = std::string("damaged or truncated compressed stream (") + (msg ? msg : "zlib") + ")"; return -1; } }
+      return n;
+    }
     for (;;) {
       if (cur_off < cur.n) { const size_t take = std::min(cap, cur.n - cur_off); memcpy(dst, cur.p + cur_off, take); cur_off += take; return (int)take; }
       cur = PgzBuf(); cur_off = 0; const int rc = bg->next_buf(&cur); if (rc < 0) { io_err = bg->err; return -1; } if (rc == 0) return 0;
@@ -198,7 +202,7 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
   sq_sam* s = new sq_sam(); s->f = f; s->path = path; s->paired = paired_library != 0; s->buf.resize(4 << 20);
   { // BGZF?  (the first member names its compressed size in a 'BC' extra field)
     FILE* rf = fopen(path, "rb"); unsigned char h[64]; const size_t got = rf ? fread(h, 1, sizeof h, rf) : 0; if (rf) fclose(rf);
-    if (got >= 28 && sqio::BgzfSource::member_size(h, 1u << 20) && !(getenv("SQ_SAM_BGZF") && atoi(getenv("SQ_SAM_BGZF")) == 0)) {
+    if (got >= 28 && sqio::BgzfSource::member_size(h, got) && !(getenv("SQ_SAM_BGZF") && atoi(getenv("SQ_SAM_BGZF")) == 0)) {
       int fd = open(path, O_RDONLY); struct stat sb;
       if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 28) {
         void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -241,6 +245,14 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
   if (s->names.empty()) { const bool was_bam = s->bam; gzclose(f); delete s; sq_set_error(was_bam ? "'%s' names no reference sequences in its BAM header" : "'%s' has no @SQ header lines: the targets of the alignments are unknown", path); return SQ_ERR_IO; }
   s->tid_map.resize(s->names.size()); for (size_t i = 0; i < s->names.size(); ++i) s->tid_map[i] = (uint32_t)i;
   *out = s; return SQ_OK;
+}
+// [r5] the FLAG field of the first record (SAM text, gzip, BAM alike): what `-l A` looks at to tell a paired from a single-end file
+extern "C" int sq_sam_first_flag(const char* path, int* flag) {
+  if (!flag) { sq_set_error("sq_sam_first_flag: bad arguments"); return SQ_ERR_ARG; }
+  sq_sam* s = nullptr; const int rc = sq_sam_open(path, 0, &s); if (rc) return rc;
+  Rec r; std::string err; const bool got = s->next_record(r, err);
+  if (!got) { if (err.empty()) err = s->io_err.empty() ? "no alignment records" : s->io_err; sq_set_error("%s: %s", path, err.c_str()); sq_sam_close(s); return SQ_ERR_IO; }
+  *flag = r.flag; sq_sam_close(s); return SQ_OK;
 }
 extern "C" uint32_t sq_sam_num_refs(const sq_sam* s) { return s ? (uint32_t)s->names.size() : 0; }
 extern "C" const char* sq_sam_ref_name(const sq_sam* s, uint32_t i) { return (s && i < s->names.size()) ? s->names[i].c_str() : ""; }

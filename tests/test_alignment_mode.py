@@ -171,8 +171,15 @@ def test_bam_gives_the_same_records_as_sam(built, tmp_path):
     sam2 = tmp_path / "s.sam"; bam2 = tmp_path / "s.bam"; write_sam(sam2, names, lens, ro, se); sam_to_bam(sam2, bam2)
     a = read_sam(sam2, paired=False); b = read_sam(bam2, paired=False)
     assert a[0] == b[0] and np.array_equal(a[2], b[2]) and a[3].tobytes() == b[3].tobytes() and a[4] == b[4]
+    # [r5] `-l A` reads the first record's FLAG through the same reader, whatever the container (the CLI used to read BAM as text there)
+    L = capi.lib(); gz = tmp_path / "p.sam.gz"; gzip.open(gz, "wb").write(open(sam, "rb").read())
+    for path, want_paired in ((sam, True), (gz, True), (bam, True), (sam2, False), (bam2, False)):
+        fl = C.c_int(-1); assert L.sq_sam_first_flag(str(path).encode(), C.byref(fl)) == 0 and bool(fl.value & 1) == want_paired, path
+    # a gzip stream cut short is an error on the zlib path too, not a shorter file
+    cut = tmp_path / "cut.sam.gz"; open(cut, "wb").write(open(gz, "rb").read()[:-40])
+    with pytest.raises(capi.SalmonHipError): read_sam(cut, paired=True)
     # damage: cut inside the header, cut inside a record, a record whose lengths exceed its block
-    raw = gzip.open(bam, "rb").read(); L = capi.lib()
+    raw = gzip.open(bam, "rb").read()
     def refused(data):
         p = tmp_path / "bad.bam"; gzip.open(p, "wb").write(data); h = C.c_void_p()
         if L.sq_sam_open(str(p).encode(), 1, C.byref(h)) != 0: return True
@@ -247,3 +254,13 @@ def test_cli_alignment_mode_quantifies_from_a_sam_file(small_world, tmp_path):
     assert meta["mapping_type"] == "alignment" and meta["num_mapped"] == int(keep.sum()) and meta["num_processed"] == int(keep.sum()) + len(range(0, int(keep.sum()), 50))
     rows = [l.split("\t") for l in open(tmp_path / "out" / "quant.sf").read().splitlines()[1:]]
     assert abs(sum(float(x[4]) for x in rows) - keep.sum()) < 1e-3 * keep.sum() and abs(sum(float(x[3]) for x in rows) - 1e6) < 1.0
+    # [r5] BAM input with the default `-l A`: paired-ness comes from the first record's FLAG (read through sq_sam, not as text), for a paired and a single-end file
+    write_sam(tmp_path / "m.sam", names, lens, ro_k, aln, unaligned_every=50); sam_to_bam(tmp_path / "m.sam", tmp_path / "m.bam")
+    subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-a", str(tmp_path / "m.bam"), "-o", str(tmp_path / "out_bam"), "--useASWithoutCIGAR", "-q"])
+    mb = json.load(open(tmp_path / "out_bam" / "aux_info" / "meta_info.json")); lf = json.load(open(tmp_path / "out_bam" / "lib_format_counts.json"))
+    assert mb["num_mapped"] == meta["num_mapped"] and mb["num_processed"] == meta["num_processed"] and lf["expected_format"] in ("IU", "ISF", "ISR"), lf["expected_format"]
+    se = aln.copy(); se["mate_status"] = 0; se["mate_pos"] = 0; se["mate_len"] = 0; se["mate_fwd"] = 0; se["mate_score"] = 0
+    write_sam(tmp_path / "s.sam", names, lens, ro_k, se); sam_to_bam(tmp_path / "s.sam", tmp_path / "s.bam")
+    subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-a", str(tmp_path / "s.bam"), "-o", str(tmp_path / "out_se"), "--useASWithoutCIGAR", "-q"])
+    ms = json.load(open(tmp_path / "out_se" / "aux_info" / "meta_info.json")); ls = json.load(open(tmp_path / "out_se" / "lib_format_counts.json"))
+    assert ms["num_mapped"] == int(keep.sum()) and ls["expected_format"] in ("U", "SF", "SR"), ls["expected_format"]

@@ -66,6 +66,12 @@ def test_device_batches_equal_host_batches(built, tmp_path):
     cases.append(("three files per mate", h[0::2], h[1::2], 4096))
     cases.append(("single-end", [f1], None, 6000))
     cases.append(("one batch holds everything", [f1], [f2], 30000))
+    # [r5] blank lines at the very end: behind mate 2 only; behind a file whose records fill the batches exactly (the round that ends the input is
+    # then nothing but the blank line); several of them, and with CR LF
+    b2 = str(tmp_path / "bl_2.fq"); open(b2, "wb").write(open(f2, "rb").read() + b"\n"); cases.append(("mate 2 ends with a blank line", [f1], [b2], 5000))
+    e1 = str(tmp_path / "ex_1.fq"); _write(e1, r1[:20000]); open(e1, "ab").write(b"\n"); cases.append(("single-end, k * batch records + a blank line", [e1], None, 5000))
+    e2 = str(tmp_path / "ex_2.fq"); _write(e2, r2[:20000]); open(e2, "ab").write(b"\n\n\n"); cases.append(("paired, k * batch records + blank lines", [e1], [e2], 10000))
+    c1 = str(tmp_path / "ec_1.fq"); _write(c1, r1[:20000], eol="\r\n"); open(c1, "ab").write(b"\r\n\r\n"); cases.append(("CR LF, k * batch records + blank lines", [c1], None, 4000))
     for name, a, b, batch in cases:
         dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
         assert all(d[1] for d in dev) and not any(x[1] for x in host), name          # the device path really ran, the host path really did not
