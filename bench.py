@@ -90,6 +90,11 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
         # then walks 4 dependent sectors (pilot, slot record, string-pool word, unitig bounds) and a uni-MEM adds extension words,
         # contig-table bounds and its record
         "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32 + 16),
+        # [r5] the same job with k_seed2's own structures: 32 of a read end's 64 packed bytes (reads of up to 128 bases), the filter block once per
+        # run of probes that share a minimizer (`filter_fills`, counted by the kernel) instead of once per probe, and a hit walks three
+        # dependent sectors (minimizer-table bucket, string-pool word, unitig bounds) instead of four.  Reported beside the fixed model above
+        # (`own_bytes`), never instead of it: a kernel that needs fewer bytes for the same walk is faster, not less efficient
+        "k_seed_own": nrec * (32 + 32 + 2 + 8) + st.get("filter_fills", st["num_lookups"]) * 64 + st["num_seeds"] * (3 * 64 + 16 + 16 + 32 + 16),
         "scan_mems": nrec * (4 + 8),
         # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
         "k_mems": st["num_seeds"] * 32 + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (16 + 4),
@@ -111,7 +116,7 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
     }
 
 
-KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
+KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed2", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
                    "k_select": "k_select", "k_finalize": "k_finalize", "compact_alns": "k_compact_alns", "eq_mini_batches": "k_frag_dynamic", "eq_static": "k_frag_static",
                    "eq_table": "k_eq_insert"}
 
@@ -478,6 +483,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     ctx.reset()
     ctx.set_profiling(not a.no_profile)
     ctx.stage_times(reset=True)
+    capi.lib().sq_ctx_seed_filter_fills(ctx.h, 1)
     M = idx.num_refs
     # ---- timed region: exactly K steps + the job's inference tail ----
     if dist: dist.barrier()
@@ -548,6 +554,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
         dt = float(tt_.item())
     stages = ctx.stage_times()
+    tot["filter_fills"] = int(capi.lib().sq_ctx_seed_filter_fills(ctx.h, 0))
     # EM iteration rate from a fixed-count run on the final table (outside the timed region)
     _, rep_it = api.em_steps(eq, eff, np.maximum(alphas, 1e-3), 200, api.em_opts(), device=local)
     if rank != 0:
@@ -566,21 +573,23 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     pm = {}; pm_note = "no PMC profile committed for this kernel on this workload"
     try:   # the counter passes were taken on the c2 workload: no traffic figure for the others; [r4] nor when the kernel sources changed since
         if wl == "c2":   # (c3 maps the same index in other batch sizes: not the launches that were counted)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
             if prof.get("kernel_source_sha") == kernel_source_sha() and prof.get("pairs_per_launch") == B: pm = prof["kernels"]
-            else: pm_note = "profiles/r04_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))
+            else: pm_note = "profiles/r05_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))
     except Exception: pass
     cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
     roof = None; roofs = {}
     # the online chain's row is a launch PAIR per group of mini-batches (k_frag_dynamic, k_apply_flagged): its time is split between the two
     # kernels in the proportion the committed rocprofv3 summary shows (50/50 without it)
-    pair_share = {"k_frag_dynamic": 0.5, "k_apply_flagged": 0.5}
+    pair_share = {"k_frag_dynamic": 0.5, "k_apply_flagged": 0.5}; pair_note = "no committed rocprofv3 summary found: the launch pair's time is split 50/50"
     try:
         ktot = {}
-        for line in open(os.path.join(ROOT, "profiles", "r04_kernel_stats_c2_final.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r05_kernel_stats_c2_final.txt")):
             for kn in pair_share:
                 if kn + "(" in line and "total=" in line: ktot[kn] = float(line.split("total=")[1].split("ms")[0])
-        if len(ktot) == 2: pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
+        if len(ktot) == 2:
+            pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
+            pair_note = "split %.2f / %.2f between k_frag_dynamic and k_apply_flagged as in profiles/r05_kernel_stats_c2_final.txt" % (pair_share["k_frag_dynamic"], pair_share["k_apply_flagged"])
     except Exception: pass
     for k in cand:
         per_launch = sb[k] / max(1, stage_rows[k]["launches"])
@@ -599,9 +608,15 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     if roofs:
         dom = max(roofs, key=lambda k: roofs[k]["ms_total"])
         roof = dict(roofs[dom])
-        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r04_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload and batch size, "
+        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r05_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload and batch size, "
                                 "kernel sources unchanged since: sha %s; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run" % kernel_source_sha()) if roof["traffic"] is not None else pm_note
         roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
+        roof["chain_pair_note"] = pair_note
+        if dom == "k_seed2" and "k_seed_own" in sb:   # [r5] the kernel's own algorithmic bytes (fewer than the fixed model's: stage_bytes)
+            own = sb["k_seed_own"] / max(1, stage_rows["k_seed"]["launches"])
+            roof["own_bytes"] = {"alg_bytes_per_launch": int(own), "achieved": round(own / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "frac": round(own / (roof["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0, 5),
+                                 "traffic_over_own_bytes": round(roof["traffic"] / own, 3) if roof.get("traffic") else None,
+                                 "note": "k_seed2 reads 32 B of a read end's packed words, a filter block per run of probes sharing a minimizer (counted: filter_fills) and three dependent sectors per hit; `frac` above stays on the round-4 model (one filter sector per probe, four per hit) so that rounds compare"}
         roof["all_kernels"] = {k: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
     if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
         g = gibbs["report"]; bg = 28 * Lb + 16 * E + 32 * M

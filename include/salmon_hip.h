@@ -598,6 +598,9 @@ int sq_ctx_set_profiling(sq_ctx*, int on);
 int sq_ctx_num_stages(void);
 const char* sq_ctx_stage_name(int stage);
 int sq_ctx_stage_times(sq_ctx*, double* ms /*[num_stages]*/, uint64_t* calls /*[num_stages]*/, int reset);
+/* [r5] measurement: 64-byte filter sectors the seeding kernel fetched since the last reset (a probe whose minimizer's filter block is already in the
+ * lane's LDS column fetches none) — with num_lookups and num_seeds of sq_map_stats the kernel's own algorithmic bytes. */
+uint64_t sq_ctx_seed_filter_fills(sq_ctx*, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Debug / parity taps: copy an intermediate stage of the LAST sq_map_batch to the host.

@@ -126,6 +126,7 @@ struct sq_ctx {
   // last batch bookkeeping
   uint32_t last_n = 0;
   uint32_t last_paired = 0;
+  uint64_t seed_fills = 0;   // [r5] sum of ST_FILLS over this lane's batches (sq_ctx_seed_filter_fills)
   uint64_t last_total_aln = 0, last_total_mems = 0, last_total_cands = 0, last_joint = 0, last_chain_slots = 0;
   void* em_arena = nullptr;   // persistent EM workspace (em.hip: EmArena), grown by sq_ctx_reserve / sq_em_optimize(ctx, ...)
   bool have_batch = false;
@@ -219,7 +220,8 @@ enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGF
     ST_CHAINS, ST_CANDS, ST_DP,
     ST_RESCUED, ST_TRUNC, ST_MAXLEN /* longest read end of the batch when it did not fit the packing stride (k_pack) */,
     ST_UNIOVER /* read ends whose uni-MEMs did not fit the slab's stride (k_seed) */,
-    ST_SEEDLW /* [r5] read ends longer than the LDS column of the k_seed2 instantiation that ran (the host seeds again with the wider one) */, ST_N };
+    ST_SEEDLW /* [r5] read ends longer than the LDS column of the k_seed2 instantiation that ran (the host seeds again with the wider one) */,
+    ST_FILLS /* [r5] filter blocks k_seed2 brought into LDS (+ the rare single words read past them): the filter's sectors per launch */, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats);   // runs one batch on lane ctx `c`

@@ -109,7 +109,7 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
     v.kfilter = (const uint64_t*)p; v.kfilter_words = nwords;
   }
   v.mtab = nullptr; v.mtab_buckets = 0;
-  if (!getenv("SQ_NO_MTAB") && idx->num_kmers > 0) {   // minimizer table (sq_internal.h): 1.6 minimizers per 64-byte bucket of four
+  if (v.kfilter && v.uinfo && idx->num_kmers > 0 && idx->k == 31 && v.m == 20) {   // what k_seed2 needs (map.hip); other k / m take the general kernel and the MPHF   // minimizer table (sq_internal.h): 1.6 minimizers per 64-byte bucket of four
     uint64_t nmin = 0; for (uint64_t r : idx->slots) nmin += r != SQ_SLOT_EMPTY;
     const uint64_t nb = nmin * 5 / 8 + 1024;
     void* p = nullptr; unsigned long long* fail = nullptr;

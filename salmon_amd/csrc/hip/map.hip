@@ -74,6 +74,12 @@ extern "C" int sq_ctx_set_profiling(sq_ctx* c, int on) {
 }
 extern "C" int sq_ctx_num_stages(void) { return SG_NUM; }
 extern "C" const char* sq_ctx_stage_name(int s) { return (s >= 0 && s < SG_NUM) ? kStageNames[s] : nullptr; }
+extern "C" uint64_t sq_ctx_seed_filter_fills(sq_ctx* c, int reset) {   // [r5] filter sectors k_seed2 fetched since the last reset (all lanes)
+  if (!c) return 0;
+  uint64_t v = c->seed_fills; if (reset) c->seed_fills = 0;
+  for (sq_ctx* sh : c->shadows) { v += sh->seed_fills; if (reset) sh->seed_fills = 0; }
+  return v;
+}
 extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int reset) {
   if (!c) return SQ_ERR_ARG;
   (void)sq_eq_sync(c);
@@ -477,23 +483,17 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
     uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
     static const int spec = getenv("SQ_SEED_SPEC") ? atoi(getenv("SQ_SEED_SPEC")) : 2;
-    // [r5] k_seed2 (read words, filter block and — SQ_SEED_V >= 3 — the minimizer table's one-sector records) for the default k / m with reads of up to
-    // 256 bases; everything else takes the general kernel.  SQ_SEED_V: 0 = k_seed, 1 = LDS read words only, 2 = + filter block in LDS, 3 = + minimizer table
-    static const int seedv = getenv("SQ_SEED_V") ? atoi(getenv("SQ_SEED_V")) : 3;
+    // [r5] k_seed2 (read words and filter block in LDS, the minimizer table's one-sector records) for the default k / m with reads of up to 256 bases;
+    // everything else takes the general kernel (SQ_SEED_GENERAL=1 forces it: the tests run both)
+    static const bool general = getenv("SQ_SEED_GENERAL") && atoi(getenv("SQ_SEED_GENERAL")) != 0;
     static const int force_lw = getenv("SQ_SEED_LW") ? atoi(getenv("SQ_SEED_LW")) : 0;
-    const bool v2 = seedv > 0 && P.k == 31 && di->dict.m == 20 && c->read_words == 8 && di->dict.kfilter && di->dict.uinfo && (seedv == 1 || seedv == 2 || seedv == 6 || di->dict.mtab);
+    const bool v2 = !general && P.k == 31 && di->dict.m == 20 && c->read_words == 8 && di->dict.kfilter && di->dict.uinfo && di->dict.mtab;
     if (v2) {
       if (force_lw == 8) c->seed_lw = 8;
       const uint32_t lw = c->seed_lw;
       // LDS per block: (LW + 8) x 2 KB -> 24 KB (LW 4: six blocks per CU) or 32 KB (five)
-      const uint32_t grid2 = std::min<uint32_t>(nblk(nrec), 256u * bpc);
 #define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
-      if (seedv == 1) { if (lw == 4) k_seed2<31, 20, 2, 4, false, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, false, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
-      else if (seedv == 2) { if (lw == 4) k_seed2<31, 20, 2, 4, true, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, false><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
-      else if (seedv == 4) { if (lw == 4) k_seed2<31, 20, 2, 4, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
-      else if (seedv == 5) { if (lw == 4) k_seed2<31, 20, 2, 4, true, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
-      else if (seedv == 6) { if (lw == 4) k_seed2<31, 20, 2, 4, true, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, false, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
-      else { if (lw == 4) k_seed2<31, 20, 2, 4, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8, true, true><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); }
+      if (lw == 4) k_seed2<31, 20, 2, 4><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
 #undef SQ_SEED2_ARGS
     } else
 #define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
@@ -742,6 +742,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   c->last_paired = paired;
   c->last_total_aln = total_aln;
   c->last_joint = hst[ST_JOINT];
+  c->seed_fills += hst[ST_FILLS];
   c->have_batch = true;
   c->last_buf = buf;
   c->cur_buf = buf ^ 1;

@@ -281,10 +281,13 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
 // the byte model).  Here:
 //   * the packed words of the read end are loaded ONCE, at refill, into the lane's column of LDS (LW words; the N-mask stays in HBM and
 //     is consulted only by the rare lane whose read has an N: one flag in a register);
-//   * FC: the 64-byte filter block of the lane's current minimizer is kept in LDS too.  Consecutive probes of a walk mostly share their
-//     minimizer — that is what the blocked filter was built for — so the run of misses across a sequencing error, or along an unmappable
-//     read, asks memory once per minimizer instead of once per probe;
-//   * DT: the slot record of the minimizer comes from the minimizer table (sq_mtab_find: one sector) instead of pilot -> slot (two).
+//   * the 64-byte filter block of the lane's current minimizer is kept in LDS too, brought there by LDS-DMA (global_load_lds_dwordx4: the
+//     block never passes through registers).  Consecutive probes of a walk mostly share their minimizer — that is what the blocked
+//     filter was built for — so the run of misses across a sequencing error, or along an unmappable read, asks memory once per
+//     minimizer instead of once per probe;
+//   * the slot record of the minimizer comes from the minimizer table (sq_mtab_find: one sector) instead of pilot -> slot (two).
+// Measured on MI355X, c2, 5x10^6 pairs per launch (profiles/r05_seed_variants.txt): k_seed 6.61 ms; read words in LDS 4.70; + minimizer
+// table 4.56; + filter block through registers into LDS 4.71 (the eight ds_write cost what the saved loads gave), by LDS-DMA 4.40.
 // The walk, and therefore every uni-MEM, is k_seed's: tests hold both kernels to the checker.  Read ends longer than 32 * LW bases raise
 // ST_SEEDLW and the host seeds the batch again with the next wider instantiation (map.hip).
 #define SEED_TB 256
@@ -296,22 +299,21 @@ __device__ inline uint64_t seed_lds_bases(const uint64_t (*rd)[SEED_TB], uint32_
   const uint64_t lo = (a >> sh) | (sh ? (b << (64 - sh)) : 0ULL);
   return lo & sq_kmask(n);
 }
-template <int KT, int MT, int SEED_SPEC, int LW, bool FC, bool DT, bool GL = false>   // GL: the filter block goes from memory to LDS without passing through registers (global_load_lds_dwordx4)
+template <int KT, int MT, int SEED_SPEC, int LW>
 __global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor, uint32_t rw, uint32_t us) {
   static_assert(KT > 0 && MT > 0 && SEED_SPEC >= 1 && SEED_SPEC <= 2, "k_seed2 is the specialised kernel");
   __shared__ uint64_t s_rd[LW][SEED_TB];
-  __shared__ uint64_t s_fb[(FC && !GL) ? SQ_KF_BLOCK_WORDS : 1][SEED_TB];
-  __shared__ sq_u64x2 s_fq[(FC && GL) ? SQ_KF_BLOCK_WORDS / 2 : 1][SEED_TB];   // GL: quarter q of lane t's block at [q][t] — the layout the LDS-DMA writes (wave base + lane x 16 bytes)
+  __shared__ sq_u64x2 s_fq[SQ_KF_BLOCK_WORDS / 2][SEED_TB];   // quarter q of lane t's filter block at [q][t] — the layout the LDS-DMA writes (wave base + lane x 16 bytes)
   constexpr int k = KT; const int alt = (int)P.alt_skip;
   const uint32_t tx = threadIdx.x; const int lane = (int)(tx & 63);
   const uint64_t nfb = d.kfilter_words / SQ_KF_BLOCK_WORDS;
   uint32_t e = 0xFFFFFFFFu; bool have = false, drained = false, anyN = false;
   int L = 0, pos = 0, skip_until = -1; uint32_t nu = 0, np = 0;
-  uint64_t cur_blk = ~0ULL;   // the filter block in this lane's column of s_fb
-  unsigned long long tot_nu = 0, tot_look = 0;
+  uint64_t cur_blk = ~0ULL;   // the filter block in this lane's column of s_fq
+  unsigned long long tot_nu = 0, tot_look = 0, tot_fill = 0;
   uint32_t pool_next = 0, pool_end = 0; bool global_drained = false;   // wave-uniform: the wave's private run of read ends
   for (;;) {
     unsigned long long want = __ballot(!have && !drained);
@@ -389,35 +391,25 @@ __global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params
           if (cv[s2]) { const uint64_t h = sq_kf_hash(ckm[s2] < crc[s2] ? ckm[s2] : crc[s2]); fmsk[s2] = sq_kf_mask(h);
             fblk[s2] = sq_kf_word(sq_mix64(cmini[s2] ^ 0x6A09E667F3BCC909ULL), nfb); fwi[s2] = (uint32_t)(h >> 24) & (SQ_KF_BLOCK_WORDS - 1); }
         }
-        if (FC) {
+        {
           const bool two = SEED_SPEC > 1 && cv[SEED_SPEC - 1];
           const uint64_t blast = two ? fblk[SEED_SPEC - 1] : fblk[0]; const uint32_t wlast = two ? fwi[SEED_SPEC - 1] : fwi[0];
           const bool old0 = two && fblk[0] == cur_blk, far0 = two && !old0 && fblk[0] != blast;
-          auto lds_word = [&](uint32_t wi) -> uint64_t { return GL ? ((const uint64_t*)&s_fq[wi >> 1][tx])[wi & 1] : s_fb[wi][tx]; };
+          auto lds_word = [&](uint32_t wi) -> uint64_t { return ((const uint64_t*)&s_fq[wi >> 1][tx])[wi & 1]; };
           if (old0) fword[0] = lds_word(fwi[0]);
-          if (far0) fword[0] = d.kfilter[fblk[0] * SQ_KF_BLOCK_WORDS + fwi[0]];
+          if (far0) { fword[0] = d.kfilter[fblk[0] * SQ_KF_BLOCK_WORDS + fwi[0]]; ++tot_fill; }
           const bool fill = cv[0] && blast != cur_blk;
-          if (GL) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the read of the block held so far is done before the DMA may overwrite it
-            if (fill) {
-              typedef __attribute__((address_space(3))) void* lds_vp; typedef const __attribute__((address_space(1))) void* glb_vp;
-              const char* g = (const char*)(d.kfilter + blast * SQ_KF_BLOCK_WORDS);
+          __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the read of the block held so far is done before the DMA may overwrite it
+          if (fill) {
+            typedef __attribute__((address_space(3))) void* lds_vp; typedef const __attribute__((address_space(1))) void* glb_vp;
+            const char* g = (const char*)(d.kfilter + blast * SQ_KF_BLOCK_WORDS);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds((glb_vp)(g + 16 * q), (lds_vp)&s_fq[q][tx & ~63u], 16, 0, 0);
-              cur_blk = blast;
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the block has landed
-          } else if (fill) {
-            const sq_u64x2* bp = (const sq_u64x2*)(d.kfilter + blast * SQ_KF_BLOCK_WORDS);
-            const sq_u64x2 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-            s_fb[0][tx] = b0.x; s_fb[1][tx] = b0.y; s_fb[2][tx] = b1.x; s_fb[3][tx] = b1.y; s_fb[4][tx] = b2.x; s_fb[5][tx] = b2.y; s_fb[6][tx] = b3.x; s_fb[7][tx] = b3.y;
-            cur_blk = blast;
+            for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds((glb_vp)(g + 16 * q), (lds_vp)&s_fq[q][tx & ~63u], 16, 0, 0);
+            cur_blk = blast; ++tot_fill;
           }
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the block has landed
           if (cv[0]) { const uint64_t w = lds_word(wlast); if (two) fword[SEED_SPEC - 1] = w; else fword[0] = w; }
           if (two && !old0 && !far0) fword[0] = lds_word(fwi[0]);
-        } else {
-#pragma unroll
-          for (int s2 = 0; s2 < SEED_SPEC; ++s2) if (cv[s2]) fword[s2] = d.kfilter[fblk[s2] * SQ_KF_BLOCK_WORDS + fwi[s2]];
         }
 #pragma unroll
         for (int s2 = 0; s2 < SEED_SPEC; ++s2) cpass[s2] = cv[s2] && (fword[s2] & fmsk[s2]) == fmsk[s2];
@@ -434,7 +426,7 @@ __global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params
         } else {
           pos = ppos;
           uint64_t u; uint32_t off; int fw;
-          const uint64_t rec = DT ? sq_mtab_find(d.mtab, d.mtab_buckets, kmini) : d.slots[sq_mphf_slot(d, kmini)];
+          const uint64_t rec = sq_mtab_find(d.mtab, d.mtab_buckets, kmini);
           if (!sq_dict_lookup_rec<KT, MT>(d, km, krc, rec, kat, &u, &off, &fw)) {
             if (pos < skip_until) { int npos = pos + alt; if (npos > skip_until) npos = skip_until; pos = npos; } else pos += 1;
           } else {
@@ -481,7 +473,7 @@ __global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params
       if (done) { n_uni[e] = nu; n_proj[e] = np; tot_nu += nu; have = false; }
     }
   }
-  wave_stat_add(&stats[ST_SEEDS], tot_nu); wave_stat_add(&stats[ST_LOOKUPS], tot_look);
+  wave_stat_add(&stats[ST_SEEDS], tot_nu); wave_stat_add(&stats[ST_LOOKUPS], tot_look); wave_stat_add(&stats[ST_FILLS], tot_fill);
 }
 
 // val layout: len[0,10) q[10,20) fw[20] tid[32,64)

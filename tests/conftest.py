@@ -9,6 +9,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # [r5] the first `import torch` on a fresh GPU box pages the image in and has been seen to take more than seven minutes — inside a test it ran
+    # into pytest-timeout and cost the run a test that never started.  For a GPU run it happens here, before any test's clock
+    m = config.getoption("-m", default="") or ""
+    if "gpu" in m and "not gpu" not in m:
+        try: import torch  # noqa: F401
+        except Exception: pass
 
 
 @pytest.fixture(scope="session")
