@@ -139,25 +139,11 @@ struct sq_ctx {
   // dependent kernels then never queues behind the mapping kernels' workgroups.  stream3 is unmasked: an eq job that
   // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
   hipStream_t stream3 = nullptr;
-  // [r4] Between the export (sq_eq_finish) and the optimiser (sq_em_optimize) the host works for a few ms (normalizeAlphas) and the device would sit
-  // idle; the first submission after such a gap behind heavy load was measured to come back ~20 ms late on MI355X (SQ_TIMING: "upload drained"
-  // 20.2 ms for a 1.3 MB copy).  One wave that sleeps on a page-locked flag (k_keep_warm, at most `warm_ms`) keeps the device out of that state;
-  // the next entry point that uses the device stops it.  Measured: no reliable effect (online.hip) — an experiment, SQ_KEEP_WARM=1 switches it on.
-  int* warm_flag = nullptr; bool warm_running = false;
-  void warm_start(); void warm_stop();
-  // [r3, experimental: SQ_EQ_CHAIN=1] no partition: mapping and the eq stage's throughput kernels share all CUs, and the mass-dependent chain of a
-  // batch is ONE resident kernel (k_chain, hip/online.hip) on a stream masked to a single XCD, with a barrier of its own between the groups
-  hipStream_t stream_chain = nullptr; hipEvent_t ev_chain_in = nullptr, ev_chain_out = nullptr; uint32_t chain_blocks = 0;
   hipStream_t eq_stream_cur = nullptr;
   int eq_cus = 0;
   std::atomic<int> map_active{0};
   hipEvent_t ev_eq_last = nullptr;
   hipStream_t stream2 = nullptr;
-  // [r4, SQ_EQ_SPLIT=1] the eq stage in two parts: its THROUGHPUT kernels (pre-records, flags + scan, k_frag_static, the class table) run on
-  // stream_eqt, which shares the mapping stream's CU mask (they are a few big launches: they queue with the mapping kernels and take their share), and
-  // only the mass-dependent CHAIN (hundreds of small dependent launches per batch) keeps CUs of its own on stream2 — 16 instead of 64, so mapping
-  // gets 240 of the 256 CUs instead of 192
-  hipStream_t stream_eqt = nullptr; hipEvent_t ev_static = nullptr, ev_table = nullptr;
   std::vector<hipEvent_t> prof_ev3; std::vector<int> prof_stage3;
   hipEvent_t ev_map_done[2] = {nullptr, nullptr}, ev_eq_done[2] = {nullptr, nullptr};
   int cur_buf = 0, last_buf = 0;

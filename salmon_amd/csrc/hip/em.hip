@@ -23,18 +23,7 @@
 #include <cstdlib>
 #include <cstdio>
 
-// [r4] experiment, off by default (SQ_EM_SPIN=1): waiting for the EM's stream by polling instead of hipStreamSynchronize.  The first drain of the set-up
-// returns 3-28 ms late for 1 ms of device work when the stream has been idle since the export; the suspicion was the blocking wait's interrupt.  Measured
-// (tools/runs/r4r.sh, three runs each): 14 / 6.5 / 25 ms polling, 6.8 / 11 / 3 ms blocking — the work itself completes late, not its notification.
-static inline hipError_t sq_em_wait(hipStream_t st) {
-  static const int spin = getenv("SQ_EM_SPIN") ? atoi(getenv("SQ_EM_SPIN")) : 0;
-  if (!spin) return hipStreamSynchronize(st);
-  for (bool spun = false;; spun = true) {
-    const hipError_t e = hipStreamQuery(st);
-    if (e != hipErrorNotReady) { if (spun && e == hipSuccess) (void)hipGetLastError(); return e; }   // "not ready" is not an error: do not leave it behind as the thread's last one
-    __builtin_ia32_pause();
-  }
-}
+static inline hipError_t sq_em_wait(hipStream_t st) { return hipStreamSynchronize(st); }
 namespace {
 
 // SQ_TIMING=1: host-side phase timings on stderr (diagnostics only)
@@ -736,13 +725,7 @@ struct EmSession {
     h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down; nullptr: plain pageable copies
     if (h_stage) {
       memcpy(h_stage, txp->eff_len, (size_t)M * 8);
-      // [r4] experiment, off by default (SQ_EM_KUP=1): the effective lengths come up by a KERNEL reading the page-locked buffer instead of a copy command
-      // (in a job whose reads are resident in HBM this is the first host-to-device copy for seconds: a sleeping copy engine was the suspicion for the late
-      // drain below).  Measured (tools/runs/r4s.sh, four runs each): 19 / 15 / 16 / 15 ms with the kernel, 10 / 28 / 21 / 22 ms with the command: not the engine.
-      static const int kup = getenv("SQ_EM_KUP") ? atoi(getenv("SQ_EM_KUP")) : 0;
-      void* hdev = nullptr;
-      if (kup && hipHostGetDevicePointer(&hdev, h_stage, 0) == hipSuccess && hdev) k_copy_f64<<<nb(M), TB, 0, st>>>(M, (const double*)hdev, d_eff.p);
-      else { (void)hipGetLastError(); SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st)); }
+      SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st));
     }
     else SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, txp->eff_len, (size_t)M * 8, hipMemcpyHostToDevice, st));
     SQ_HIP_CHECK(hipMemsetAsync(d_err.p, 0, 4, st)); SQ_HIP_CHECK(hipMemsetAsync(d_toff.p, 0, ((size_t)M + 1) * 8, st));

@@ -134,44 +134,18 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     // With the mapping kernels on 192 CUs, the 64 keep the eq chain (22 ms per 8·10^6 pairs) off the critical path (24.7 ms).
     hipDeviceProp_t prop; SQ_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int ncu = prop.multiProcessorCount;
-    static const int split = getenv("SQ_EQ_SPLIT") ? atoi(getenv("SQ_EQ_SPLIT")) : 0;   // [r4] ctx.h: only the chain keeps CUs of its own (16 by default)
-    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? (split ? ncu / 16 : ncu / 4) : 0);
+    int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
     if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
     c->eq_cus = eq_cus;
-    if (getenv("SQ_EQ_CHAIN") && ncu >= 64 && !owner) {   // experiment: see ctx.h
-      std::vector<uint32_t> mc((ncu + 31) / 32, 0);
-      // the driver deals the mask's bits round-robin to the XCDs (bit i -> XCD i mod 8 on this chip: amdkfd's symmetric CU-mask mapping), so one
-      // XCD = every eighth bit.  (The 64-CU partition above is therefore 8 CUs in each of the 8 XCDs.)
-      const int nx = getenv("SQ_CHAIN_NXCD") ? atoi(getenv("SQ_CHAIN_NXCD")) : 8, xk = nx - 1;
-      for (int i = xk; i < ncu; i += nx) mc[i / 32] |= 1u << (i % 32);
-      SQ_HIP_CHECK(hipStreamCreate(&c->stream)); SQ_HIP_CHECK(hipStreamCreate(&c->stream2)); SQ_HIP_CHECK(hipStreamCreate(&c->stream3));
-      SQ_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->stream_chain, (uint32_t)mc.size(), mc.data()));
-      SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_in, hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chain_out, hipEventDisableTiming));
-      c->chain_blocks = getenv("SQ_CHAIN_BLOCKS") ? (uint32_t)atoi(getenv("SQ_CHAIN_BLOCKS")) : 64u;   // two per CU of the XCD: they must all be resident at once
-      c->eq_cus = 0;
-    } else
-    if (getenv("SQ_EQ_PRIO")) {   // experiment: no partition; the eq chain on a high-priority stream, mapping on a low-priority one
-      int lo = 0, hi = 0; SQ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      SQ_HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lo));
-      if (!owner) { SQ_HIP_CHECK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi)); SQ_HIP_CHECK(hipStreamCreate(&c->stream3)); }
-      c->eq_cus = 0;
-    } else
     if (eq_cus > 0) {
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       // [r3] the driver deals the mask's bits round-robin to the XCDs (bit i -> XCD i mod 8: amdkfd's symmetric CU-mask mapping), so the top
       // eq_cus bits are eq_cus / 8 CUs in EVERY XCD (default: 8 of 32) — not whole XCDs, as the round-2 comment above assumed.
-      // SQ_EQ_XCD=1 (experiment): whole XCDs instead — the eq stage gets the XCDs with the highest numbers.
-      if (getenv("SQ_EQ_XCD")) { const int nx = 8, take = std::max(1, eq_cus / 32);
-        for (int i = 0; i < ncu; ++i) { if (i % nx >= nx - take) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); } }
-      else
       for (int i = 0; i < ncu; ++i) { if (i >= ncu - eq_cus) m2[i / 32] |= 1u << (i % 32); else m1[i / 32] |= 1u << (i % 32); }
       // a partition is an optimisation: if the platform refuses CU masks, fall back to plain streams
-      if (getenv("SQ_MAP_ALL_CUS")) for (int i = 0; i < ncu; ++i) m1[i / 32] |= 1u << (i % 32);   // experiment: mapping may use the eq stage's CUs too
       bool ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m1.size(), m1.data()) == hipSuccess;
       if (ok && !owner) ok = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)m2.size(), m2.data()) == hipSuccess &&
           hipStreamCreate(&c->stream3) == hipSuccess;
-      if (ok && !owner && split) ok = hipExtStreamCreateWithCUMask(&c->stream_eqt, (uint32_t)m1.size(), m1.data()) == hipSuccess &&
-          hipEventCreateWithFlags(&c->ev_static, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) == hipSuccess;
       if (!ok) {
         (void)hipGetLastError();
         if (c->stream) {
@@ -223,7 +197,6 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
 extern "C" void sq_ctx_free(sq_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  c->warm_stop();
   if (c->lane_thread.joinable()) {
     {
       std::lock_guard<std::mutex> lk(c->lane_mu);
@@ -289,21 +262,14 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->aln_b1.free_();
   c->aln_off_b1.free_();
   c->map_type.free_(); c->gapcost.free_(); c->stats.free_();
-  c->warm_stop();
-  if (c->stream_eqt) { (void)hipStreamSynchronize(c->stream_eqt); (void)hipStreamDestroy(c->stream_eqt); }
-  if (c->ev_static) (void)hipEventDestroy(c->ev_static); if (c->ev_table) (void)hipEventDestroy(c->ev_table);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
 
-  if (c->stream_chain) { (void)hipStreamSynchronize(c->stream_chain); (void)hipStreamDestroy(c->stream_chain); }
-  if (c->ev_chain_in) (void)hipEventDestroy(c->ev_chain_in);
-  if (c->ev_chain_out) (void)hipEventDestroy(c->ev_chain_out);
   for (int b = 0; b < 2; ++b) {
     if (c->ev_map_done[b]) (void)hipEventDestroy(c->ev_map_done[b]);
     if (c->ev_eq_done[b]) (void)hipEventDestroy(c->ev_eq_done[b]);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->warm_flag) (void)hipHostFree(c->warm_flag);
   delete c;
 }
 
@@ -326,7 +292,6 @@ extern "C" int sq_aln_inject(sq_ctx* c, const sq_aln_batch* in, uint64_t num_wit
   if (!c || c->owner || !in || !in->read_off || (!in->aln && in->n && in->read_off[in->n])) { sq_set_error("sq_aln_inject: bad arguments"); return SQ_ERR_ARG; }
   if (!c->tickets.empty()) { sq_set_error("sq_aln_inject: submitted batches are still outstanding"); return SQ_ERR_STATE; }
   const uint32_t n = in->n; if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
-  c->warm_stop();
   SQ_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = c->stream; const int buf = c->cur_buf;
   const uint64_t total = n ? in->read_off[n] : 0; const uint32_t M = (uint32_t)c->idx->names.size();
@@ -438,7 +403,6 @@ extern "C" int sq_map_fetch(sq_ctx* c, sq_aln_batch* out) {
 }
 
 int sq_map_batch_impl(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* out, sq_map_stats* stats) {
-  if (c && !c->owner) c->warm_stop();
   if (!c || !in || !in->seq_off || !in->seq) { sq_set_error("sq_map_batch: bad arguments"); return SQ_ERR_ARG; }
   const uint32_t n = in->n, paired = in->paired ? 1 : 0, nrec = paired ? 2 * n : n;
   if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
@@ -480,9 +444,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   {  // persistent grid: 256 CUs x 6 blocks of 256 threads; lanes pull read ends from counters[2].  The probe rate is
      // bound by the memory system, not by occupancy (4..8 blocks/CU measure the same), so two blocks' worth of wave
      // slots per CU stay free for the eq stage's small kernels on stream2 — a full grid starves them for the whole 5 ms.
-    static const uint32_t bpc = getenv("SQ_SEED_BPC") ? (uint32_t)atoi(getenv("SQ_SEED_BPC")) : 6u;
-    uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * bpc);
-    static const int spec = getenv("SQ_SEED_SPEC") ? atoi(getenv("SQ_SEED_SPEC")) : 2;
+    const uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * 6u);
     // [r5] k_seed2 (read words and filter block in LDS, the minimizer table's one-sector records) for the default k / m with reads of up to 256 bases;
     // everything else takes the general kernel (SQ_SEED_GENERAL=1 forces it: the tests run both)
     static const bool general = getenv("SQ_SEED_GENERAL") && atoi(getenv("SQ_SEED_GENERAL")) != 0;
@@ -498,10 +460,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     } else
 #define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
     if (P.k == 31 && di->dict.m == 20) {   // the default (k = 31, m = 20) gets the fully specialised kernel
-      if (spec == 1) k_seed<31, 20, 1><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
-      else if (spec == 3) k_seed<31, 20, 3><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
-      else if (spec == 4) k_seed<31, 20, 4><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
-      else k_seed<31, 20, 2><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
+      k_seed<31, 20, 2><<<grid, TB, 0, st>>>(SQ_SEED_ARGS);
     }
 #undef SQ_SEED_ARGS
     else
@@ -564,8 +523,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   const uint32_t nL = hcls[MK_NCLS - 1], memsL = hcls[MK_NCLS];
 #define SQ_MEMS_ARGS(cls) di->dict.uoff, di->ctab_off, di->ctab, di->ref_accum, P, c->gapcost.p, c->mlinfo.p + (size_t)(cls) * nrec, hcls[cls], c->unimems.p, c->uni_slots, \
       skey, sval, c->mnext.p, c->chains.p, c->n_chains.p
-  if (hcls[0]) { if (!getenv("SQ_MEMS_G16")) k_mems<8, 8, 256><<<(hcls[0] + 31) / 32, 256, 0, st>>>(SQ_MEMS_ARGS(0));   // [r3] the common end has <= 8 MEMs: eight ends per wave
-                 else k_mems<16, MK_X_CAP, 256><<<(hcls[0] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(0)); }
+  if (hcls[0]) k_mems<8, 8, 256><<<(hcls[0] + 31) / 32, 256, 0, st>>>(SQ_MEMS_ARGS(0));   // [r3] the common end has <= 8 MEMs: eight ends per wave
   if (hcls[1]) k_mems<16, MK_X_CAP, 256><<<(hcls[1] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(1));
   if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
   if (hcls[3]) k_mems<16, MK_S_CAP, 256><<<(hcls[3] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(3));
@@ -586,11 +544,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     tmp = c->sort_tmp.n;
     SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (int)memsL, 0, 40 + endbits, st));
     k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->mem_off.p, skey, sval);
-    static const int lg_flat = getenv("SQ_LG_FLAT") ? atoi(getenv("SQ_LG_FLAT")) : 1;
-    if (!lg_flat)
-    k_chain<<<nblk(nL), TB, 0, st>>>(di->ref_accum, P, c->gapcost.p, nL, c->rlen.p, c->mem_off.p, skey, sval, c->cf.p, c->cp.p, c->mnext.p, c->mused.p,
-        c->chains.p, c->n_chains.p, nullptr, list_l);
-    else {   // [r4] flat passes over the sorted compact records (mem_kernels.h: k_lg_*); cf / cp / mused are indexed by compact record here
+    {   // [r4] flat passes over the sorted compact records (mem_kernels.h: k_lg_*); cf / cp / mused are indexed by compact record here
       if (c->lg_a.ensure(LP) || c->lg_b.ensure(LP) || c->lg_c.ensure(LP) || c->lg_d.ensure(LP) || c->lg_flags.ensure(LP) || c->lg_first.ensure((size_t)nrec + 8) || c->lg_cnt.ensure(8)) {
         sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }
       uint64_t* se_in = c->mkey.p; uint64_t* se = c->mval.p;   // the unsorted compact projection is dead once it is sorted
@@ -716,7 +670,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
       k_dp_hist<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_bh.p);
       exclusive_scan_u32_u64(c->dp_bh.p, c->dp_off.p, (uint64_t)DP_CLASSES * nb, (uint64_t*)c->sort_tmp.p, st);
       k_dp_scatter<<<nb, 256, 0, st>>>(S.dpq, nq, chunk, nb, c->dp_off.p, c->dp_perm.p);
-      if (P.bw == SQ_MAX_BAND && !getenv("SQ_DP_GENERAL")) k_dp<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);   // full band: the condition-free form
+      if (P.bw == SQ_MAX_BAND) k_dp<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);   // full band: the condition-free form
       else k_dp_general<<<(nq + 63) / 64, 64, 0, st>>>(P, S, nq, c->cands.p, cand_frag.p, paired, c->dp_perm.p);
     }
     sq_prof_mark(c, SG_DP);

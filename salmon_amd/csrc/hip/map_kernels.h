@@ -3,7 +3,6 @@
 //   k_seed      per read end: SSHash lookup + uni-MEM extension            (K2+K3; row a1)
 //   k_project_list  large ends only: uni-MEM x contig-table occurrences -> MEM sort records (row a2; everything else: mem_kernels.h)
 //   [radix sort by (read end, global reference position)]
-//   k_chain     per read end: minimap2-style chaining DP per transcript    (K5;    row a2)
 //   k_join      per fragment: pair / orphan candidates                     (K6;    row a3)
 //   k_score     per candidate: selective-alignment score, fast path        (K7;    row a4)
 //   k_dp        queued banded affine-gap DP regions                        (K7)
@@ -484,167 +483,6 @@ struct MemD { uint32_t tid; int32_t rpos; int32_t q; int32_t len; bool fw; };
 __device__ inline MemD mem_decode(uint64_t key, uint64_t val, const uint64_t* ref_accum) {
   MemD m; m.tid = (uint32_t)(val >> 32); m.fw = (val >> 20) & 1; m.q = (int32_t)((val >> 10) & 1023); m.len = (int32_t)(val & 1023);
   m.rpos = (int32_t)((key & ((1ULL << 40) - 1)) - ref_accum[m.tid]); return m;
-}
-
-// a2b — findChains / findOptChain; SPEC §a2.
-// A transcript's MEMs for one read end are almost always a handful: groups of <= CH_SMALL MEMs run
-// the DP entirely in LDS (thread-private columns, [slot][thread] layout, no bank conflicts) and hand
-// the chain's members on as a bit mask, so nothing but the chain record is written to HBM.  Larger
-// groups use the HBM scratch arrays (f, prev, flags, next links).
-#define CH_SMALL 8
-#define CH_TB 256
-__global__ void __launch_bounds__(CH_TB) k_chain(const uint64_t* __restrict__ ref_accum, sq_map_params P,
-    const double* __restrict__ gapcost, uint32_t nends,
-                        const uint16_t* __restrict__ rlen, const uint64_t* __restrict__ mem_off, const uint64_t* __restrict__ mkey,
-                            const uint64_t* __restrict__ mval,
-                        double* __restrict__ cf, int32_t* __restrict__ cp, uint32_t* __restrict__ mnext, uint8_t* __restrict__ mused,
-                        sq_chain_dev* __restrict__ chains, uint32_t* __restrict__ n_chains, unsigned long long* __restrict__ stats,
-                            const uint32_t* __restrict__ perm) {
-  __shared__ double s_f[CH_SMALL][CH_TB];
-  __shared__ int32_t s_r[CH_SMALL][CH_TB];
-  __shared__ int16_t s_q[CH_SMALL][CH_TB];
-  __shared__ int16_t s_len[CH_SMALL][CH_TB];
-  __shared__ int8_t s_p[CH_SMALL][CH_TB];
-  const uint32_t tx = threadIdx.x;
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = gid < nends;
-  const uint32_t e = act ? (perm ? perm[gid] : gid) : 0;   // optional work-balancing permutation
-  const uint64_t base = act ? mem_off[e] : 0; const uint32_t n = act ? (uint32_t)(mem_off[e + 1] - base) : 0;
-  const int L = act ? rlen[e] : 0;
-  uint32_t nch = 0; double bestAll = 0.0;
-  uint32_t g0 = 0;
-  while (g0 < n) {
-    const uint32_t tid0 = (uint32_t)(mval[base + g0] >> 32);
-    uint32_t g1 = g0; while (g1 < n && (uint32_t)(mval[base + g1] >> 32) == tid0) ++g1;
-    const uint32_t gn = g1 - g0;
-    if (gn <= CH_SMALL) {
-      uint32_t fwbits = 0;
-      for (uint32_t i = 0; i < gn; ++i) {
-        MemD m = mem_decode(mkey[base + g0 + i], mval[base + g0 + i], ref_accum);
-        s_r[i][tx] = m.rpos;
-        s_q[i][tx] = (int16_t)m.q;
-        s_len[i][tx] = (int16_t)m.len;
-        if (m.fw) fwbits |= 1u << i;
-      }
-      double best = 0.0;
-      for (uint32_t i = 0; i < gn; ++i) {
-        const int qi = s_q[i][tx], ri = s_r[i][tx], li = s_len[i][tx]; const bool fwi = (fwbits >> i) & 1;
-        double fi = (double)li; int pi = -1; int rounds = 2;
-        for (int j = (int)i - 1; j >= 0; --j) {
-          if ((((fwbits >> j) & 1) != 0) != fwi) continue;
-          int qd = qi - s_q[j][tx], rd = ri - s_r[j][tx];
-          if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
-          int l = abs(qd - rd);
-          double a = (double)min(li, min(qd, rd));
-          double sc = s_f[j][tx] + a - gapcost[l];
-          if (sc > fi) { fi = sc; pi = j; }
-          if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
-        }
-        s_f[i][tx] = fi; s_p[i][tx] = (int8_t)pi;
-        if (fi > best) best = fi;
-      }
-      const double thr = P.pre_thr * best;
-      uint32_t used = 0, tried = 0;
-      for (;;) {
-        int bi = -1; double bf = 0.0;
-        for (uint32_t i = 0; i < gn; ++i) {
-          if (((used | tried) >> i) & 1) continue;
-          double fv = s_f[i][tx];
-          if (fv >= thr && (bi < 0 || fv > bf)) {
-            bi = (int)i;
-            bf = fv;
-          }
-        }
-        if (bi < 0) break;
-        uint32_t mask = 0; bool clash = false;
-        for (int x = bi; x >= 0; x = s_p[x][tx]) { if ((used >> x) & 1) { clash = true; break; } mask |= 1u << x; }
-        if (clash) { tried |= 1u << bi; continue; }
-        used |= mask;
-        const int first = __ffs((int)mask) - 1;
-        sq_chain_dev c;
-        c.score = bf;
-        c.tid = tid0;
-        c.pos = s_r[first][tx] - s_q[first][tx];
-        c.last_end = s_r[bi][tx] + s_len[bi][tx];
-        c.first = g0;
-        c.n_mems = (uint16_t)__popc(mask);
-        c.read_len = (uint16_t)L;
-        // pad[0] = 1: members are the bits of pad2 relative to `first`
-        c.fw = (fwbits >> bi) & 1;
-        c.pad[0] = 1;
-        c.pad[1] = c.pad[2] = 0;
-        c.pad2 = mask;
-        chains[base + nch++] = c;
-        if (bf > bestAll) bestAll = bf;
-      }
-      g0 = g1; continue;
-    }
-    double best = 0.0;
-    for (uint32_t i = g0; i < g1; ++i) {
-      MemD hi = mem_decode(mkey[base + i], mval[base + i], ref_accum);
-      double fi = (double)hi.len; int pi = -1; int rounds = 2;
-      for (int j = (int)i - 1; j >= (int)g0; --j) {
-        MemD hj = mem_decode(mkey[base + j], mval[base + j], ref_accum);
-        if (hi.rpos - hj.rpos > SQ_MAX_CHAIN_GAP) break;   // [r3] sorted by reference position: every earlier MEM of the transcript is farther still (same result as skipping them one by one)
-        if (hj.fw != hi.fw) continue;
-        int qd = hi.q - hj.q, rd = hi.rpos - hj.rpos;
-        if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
-        int l = abs(qd - rd);
-        double a = (double)min(hi.len, min(qd, rd));
-        double s = cf[base + j] + a - gapcost[l];
-        if (s > fi) { fi = s; pi = j; }
-        if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
-      }
-      cf[base + i] = fi; cp[base + i] = pi; mused[base + i] = 0; mnext[base + i] = 0xFFFFFFFFu;
-      if (fi > best) best = fi;
-    }
-    const double thr = P.pre_thr * best;
-    // accept chain ends by (score desc, index asc); mused: bit0 used, bit1 tried
-    for (;;) {
-      int bi = -1; double bf = 0.0;
-      for (uint32_t i = g0; i < g1; ++i) {
-        uint8_t fl = mused[base + i];
-        if (fl) continue;
-        double fv = cf[base + i];
-        if (fv >= thr && (bi < 0 || fv > bf)) {
-          bi = (int)i;
-          bf = fv;
-        }
-      }
-      if (bi < 0) break;
-      bool clash = false;
-      for (int x = bi; x >= 0; x = cp[base + x]) if (mused[base + x] & 1) { clash = true; break; }
-      if (clash) { mused[base + bi] |= 2; continue; }
-      uint32_t cnt = 0; int first = bi;
-      for (int x = bi; x >= 0; x = cp[base + x]) {
-        mused[base + x] |= 1;
-        ++cnt;
-        int pr = cp[base + x];
-        if (pr >= 0) mnext[base + pr] = (uint32_t)x;
-        first = x;
-      }
-      MemD m0 = mem_decode(mkey[base + first], mval[base + first], ref_accum);
-      MemD ml = mem_decode(mkey[base + bi], mval[base + bi], ref_accum);
-      sq_chain_dev c;
-      c.score = bf;
-      c.tid = tid0;
-      c.pos = m0.rpos - m0.q;
-      c.last_end = ml.rpos + ml.len;
-      c.first = (uint32_t)first;
-      c.n_mems = (uint16_t)cnt;
-      c.read_len = (uint16_t)L;
-      c.fw = ml.fw; c.pad[0] = c.pad[1] = c.pad[2] = 0; c.pad2 = 0;
-      chains[base + nch++] = c;
-      if (bf > bestAll) bestAll = bf;
-    }
-    g0 = g1;
-  }
-  // hitFilterPolicy AFTER + consensus fraction, per read end
-  const double cthr = P.consensus_frac * bestAll;
-  uint32_t kept = 0;
-  for (uint32_t i = 0; i < nch; ++i) { sq_chain_dev c = chains[base + i]; if (c.score < cthr) continue; chains[base + kept++] = c; }
-  if (act) n_chains[e] = kept;
-  if (stats) { wave_stat_add(&stats[ST_MEMS], n); wave_stat_add(&stats[ST_CHAINS], kept); }   // stats == nullptr: counted elsewhere (map.hip)
 }
 
 // a3 — joinReadsAndFilter; SPEC §a3. Two-phase (count / fill) enumeration.

@@ -81,7 +81,6 @@ struct sq_online_dev {
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
   sq_dbuf<uint32_t> mb_samples;   // [mini-batches of a batch][64]
   sq_dbuf<int32_t> cmeans;   // conditional fragment-length means of the prior distribution [1001] (single-end --gcBias)
-  sq_dbuf<double> fm_dev; sq_dbuf<unsigned> chain_bar; bool chain_bar_zeroed = false; size_t fm_dev_n = 0;   // [r3] k_chain: the batch's forgetting masses, the barrier's counter and generation
   sq_dbuf<uint16_t> posbin; sq_dbuf<unsigned long long> pos_obs; sq_dbuf<uint8_t> lenclass;   // --posBias: per alignment the 5' bin | 3' bin << 8 (class * 20 + bin, 255 = none); observed masses [2][100], fixed point 2^-32; Transcript::lengthClassIndex
   sq_dbuf<uint8_t> gcbin; sq_dbuf<unsigned long long> gc_obs;   // --gcBias: GC bin (ctx * 25 + frag bin, 255 = none) per alignment of the batch; observed masses [75], fixed point 2^-32
   sq_dbuf<uint64_t> assigned_prefix_b;   // bounds scratch after a format switch
@@ -640,7 +639,7 @@ __global__ void k_seq_close(uint32_t n, const uint64_t* __restrict__ pref, uint6
 // needs: logProb = (transcriptLogCount + auxProb) + startPosProb, in that order.  Same arithmetic, same order as k_mini_batch.
 struct DynAln { double aux, start; uint32_t tid, keep; };   // 24 B
 // [r4] per batch: flag[group][stride] bytes "a kept alignment of this group names this transcript" (plain byte stores, nothing waits on them);
-// stride = M rounded up to AP_TB_ * 8 so that k_apply_dynamic's blocks read whole 8-byte words; gsize = fragments per group (mini-batch size x W)
+// stride = M rounded up to AP_TB_ * 8 so that k_apply_flagged's blocks read whole 8-byte words; gsize = fragments per group (mini-batch size x W)
 struct TouchArgs { uint8_t* flag; uint32_t gsize, stride; };
 typedef unsigned long long sqk_u64x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts o, uint32_t n, const uint64_t* __restrict__ aln_off,
@@ -686,7 +685,7 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
           }
         }
         dyn[ai] = d; abin[ai] = bn;
-        if (TA.flag && d.keep) TA.flag[(size_t)(r / TA.gsize) * TA.stride + p.tid] = 1;   // [r4] k_apply_dynamic visits the flagged transcripts only
+        if (TA.flag && d.keep) TA.flag[(size_t)(r / TA.gsize) * TA.stride + p.tid] = 1;   // [r4] k_apply_flagged visits the flagged transcripts only
       }
       if (nk > 0) {
         const int32_t rangeCount = (int32_t)(sqrt((double)nk) + (double)o.range_factorization_bins);
@@ -731,7 +730,7 @@ __global__ void __launch_bounds__(256) k_frag_static(OnlineView V, sq_quant_opts
 // the model-dependent half, one launch per group of W mini-batches (fragments [r0, r1)): logProb from the current transcript masses, the
 // in-order log-sum, and the fixed-point mass increments (+ the observed GC model, which is weighted by the same probabilities).
 // The increments leave as fire-and-forget atomics (nothing waits for their return); the transcripts a group touched were listed by
-// k_frag_static (TouchArgs), or are found by k_apply_dynamic's sweep over all M (SQ_EQ_TOUCHED=0).
+// k_frag_static (TouchArgs).
 __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0, uint32_t r1, uint32_t mb, const uint64_t* __restrict__ aln_off,
     const DynAln* __restrict__ dyn, const uint8_t* __restrict__ gcbin) {
   const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,12 +792,7 @@ __device__ __forceinline__ void apply_one(const OnlineView& V, const FmArr& FM, 
   V.mass[t] = m;
   V.tlc[t] = sq_log_add(V.prior_mass[t], m);
 }
-__global__ void __launch_bounds__(AP_TB_) k_apply_dynamic(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
-  if (t < V.M) apply_one(V, FM, nw, t);
-}
-// [r4] the same over the group's flagged transcripts: a block reads the flags of AP_TB_ * 8 transcripts (8 per thread, one load), gathers the
+// [r4] a group's flagged transcripts: a block reads the flags of AP_TB_ * 8 transcripts (8 per thread, one load), gathers the
 // flagged ones in LDS (their order is free: every transcript is its own update) and shares them out evenly
 __global__ void __launch_bounds__(AP_TB_) k_apply_flagged(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1,
     const uint8_t* __restrict__ flag) {
@@ -815,98 +809,6 @@ __global__ void __launch_bounds__(AP_TB_) k_apply_flagged(OnlineView V, FmArr FM
   __syncthreads();
   const uint32_t n = s_n;
   for (uint32_t i = threadIdx.x; i < n; i += AP_TB_) apply_one(V, FM, nw, s_list[i]);
-}
-
-// [r3, SQ_EQ_CHAIN=1] The mass-dependent chain of a whole mapped batch as ONE kernel: all its blocks are resident at once on one XCD
-// (the stream's CU mask), a group of W mini-batches is phase A (k_frag_dynamic's work) + phase B (k_apply_dynamic's) with a barrier
-// of the kernel's own in between, and no launch separates the ~200 groups of a batch.  Everything the phases hand to each other
-// crosses the XCD's L2: the masses are read with agent-scope loads (the per-CU L1 is not coherent inside a kernel), the
-// increments are agent-scope atomics, tlc is stored with an agent-scope store, and a thread waits for its memory operations
-// (s_waitcnt) before its block arrives at the barrier.  Same arithmetic, same order per transcript as the two-kernel form.
-struct ChainArgs { uint32_t n, mb, W, nmb; int fence; const double* fm; const uint64_t* aln_off; const DynAln* dyn; const uint8_t* gcbin; const uint64_t* assigned_prefix; unsigned* bar; };
-__device__ inline double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ inline void chain_barrier(unsigned* bar, int fence) {
-  __builtin_amdgcn_s_waitcnt(0);                       // this thread's loads, stores and atomics have been answered by the L2
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // fence = 1 (SQ_CHAIN_FENCE=1): the blocks may sit on several XCDs — the block's writes leave its XCD's L2 before it arrives, and what it
-    // reads afterwards is fetched afresh (agent-scope release / acquire = L2 write-back / invalidate on this chip: ~100 us on a busy chip)
-    if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_s_waitcnt(0);
-      (void)__hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
-    if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_chain(OnlineView V, ChainArgs A) {   // <= 96 registers: a wave of it fits beside the six resident waves of the seed kernel
-  const uint32_t nth = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint32_t b0 = 0; b0 < A.nmb; b0 += A.W) {
-    const uint32_t nw = A.nmb - b0 < A.W ? A.nmb - b0 : A.W;
-    const uint32_t r0 = b0 * A.mb; uint32_t r1 = (b0 + nw) * A.mb; if (r1 > A.n) r1 = A.n;
-    // ---- phase A: the fragments of the group against the masses as the group before left them ----
-    for (uint32_t r = r0 + tid; r < r1; r += nth) {
-      const uint64_t a0 = A.aln_off[r], a1 = A.aln_off[r + 1];
-      if (a1 == a0) continue;
-      const uint32_t mbs = (r - r0) / A.mb;
-      double sumProbs = SQ_LOG_0; uint32_t nk = 0; double lp[4];
-      for (uint64_t ai = a0; ai < a1; ++ai) {
-        const DynAln d = A.dyn[ai];
-        if (!d.keep) continue;
-        const double logProb = ld_agent(&V.tlc[d.tid]) + d.aux + d.start;
-        if (nk < 4) lp[nk] = logProb;
-        sumProbs = sq_log_add(sumProbs, logProb); ++nk;
-      }
-      if (nk == 0) continue;
-      uint32_t ki = 0;
-      for (uint64_t ai = a0; ai < a1; ++ai) {
-        const DynAln d = A.dyn[ai];
-        if (!d.keep) continue;
-        const double logProb = ki < 4 ? lp[ki] : (ld_agent(&V.tlc[d.tid]) + d.aux + d.start);
-        ++ki;
-        const double pr = sq_exp(logProb - sumProbs);
-        const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
-        if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.gcbin && A.gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[A.gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (V.posbin) pos_observe(V, ai, pr);
-      }
-    }
-    chain_barrier(A.bar, A.fence);
-    // ---- phase B: every transcript folds its slots in mini-batch order, each with its forgetting mass ----
-    if (tid == 0) V.ctr[0] += (unsigned long long)(A.assigned_prefix[r1] - A.assigned_prefix[r0]);
-    for (uint32_t t = tid; t < V.M; t += nth) {
-      unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
-      unsigned long long qv[SQ_MAX_INFLIGHT <= 8 ? 8 : 8]; unsigned long long any = 0;
-      if (V.W <= 8) {
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { qv[w] = (uint32_t)w < nw ? __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; any |= qv[w]; }
-        if (!any) continue;
-        // a slot that holds something is read-and-cleared as ONE atomic (most slots of most transcripts are empty in a group: a load finds that out)
-#pragma unroll
-        for (int w = 0; w < 8; ++w) if (qv[w]) qv[w] = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double m = V.mass[t];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) if ((uint32_t)w < nw && qv[w]) m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(qv[w], SQ_MFRAC_BITS)));
-        V.mass[t] = m;
-        __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        double m = V.mass[t]; bool hit = false;
-        for (uint32_t w = 0; w < nw; ++w) {
-          unsigned long long q = __hip_atomic_load(&acc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!q) continue;
-          q = __hip_atomic_exchange(&acc[w], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          m = sq_log_add(m, A.fm[b0 + w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); hit = true;
-        }
-        if (!hit) continue;
-        V.mass[t] = m;
-        __hip_atomic_store((unsigned long long*)&V.tlc[t], (unsigned long long)__double_as_longlong(sq_log_add(V.prior_mass[t], m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    chain_barrier(A.bar, A.fence);
-  }
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -1338,7 +1240,7 @@ void sq_online_free(sq_ctx* c) {
   o->tflag.free_();
   o->mb_samples.free_();
   o->gcbin.free_();
-  o->gc_obs.free_(); o->posbin.free_(); o->pos_obs.free_(); o->lenclass.free_(); o->fm_dev.free_(); o->chain_bar.free_();
+  o->gc_obs.free_(); o->posbin.free_(); o->pos_obs.free_(); o->lenclass.free_();
   o->assigned_prefix_b.free_();
   o->mass_acc.free_();
   o->uniq.free_();
@@ -1411,14 +1313,10 @@ int sq_eq_sync(sq_ctx* c) {
     fprintf(stderr, "[sq-timing] eq_sync %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tm0).count());
     tm0 = t1;
   };
-  // the sleeping wave between export and optimiser (ctx.h) sits on an eq stream: the export that started it has drained the stage, and mapping a
-  // new batch stops it — while it runs there is nothing to wait for
-  if (c->warm_running) { std::lock_guard<std::mutex> lk(c->eq_mu); if (c->eq_enqueued >= c->eq_submitted && !c->eq_err) return SQ_OK; }
   { std::unique_lock<std::mutex> lk(c->eq_mu); c->eq_cv_done.wait(lk, [&] { return c->eq_enqueued >= c->eq_submitted; }); }
   mark("worker");
   SQ_HIP_CHECK(hipSetDevice(c->device));
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream2));
-  if (c->stream_eqt) SQ_HIP_CHECK(hipStreamSynchronize(c->stream_eqt));
   mark("stream2");
   if (c->stream3) SQ_HIP_CHECK(hipStreamSynchronize(c->stream3));
   mark("stream3");
@@ -1503,15 +1401,9 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
         std::chrono::steady_clock::now() < t_end;) std::this_thread::yield();
     if (!c->map_active.load()) st = c->stream3;
   }
-  // [r4] split layout (ctx.h): `sq` takes the throughput kernels, `st` the chain; before burn-in the generic path is one chain of heavy kernels and
-  // runs wholly on the wide pool.  Without the split (or when no mapping is in flight) both are the same stream and the events below are no-ops.
-  const bool split = c->stream_eqt && st == c->stream2;
-  const bool post_burn = c->online->burned_known && !c->online->detect_active && !getenv("SQ_EQ_SLOW_PATH");
-  hipStream_t sq = split ? c->stream_eqt : st;
-  if (split && !post_burn) st = sq;
-  const bool two = sq != st;
+  hipStream_t sq = st;
   c->eq_stream_cur = sq;
-  if (c->ev_eq_last) { SQ_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_eq_last, 0)); if (two) SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_last, 0)); }   // eq jobs run in order even when they change streams
+  if (c->ev_eq_last) SQ_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_eq_last, 0));   // eq jobs run in order even when they change streams
   sq_ctx* src = J.src ? J.src : c;
   const int buf = J.buf; const sq_aln* d_aln = src->aln_ptr(buf); const uint64_t* d_aln_off = src->aln_off_ptr(buf);
   const uint64_t last_total_aln = J.total_aln;
@@ -1541,13 +1433,12 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   sq_prof_mark(c, SG_EQ_FLAGS, 1);
   const uint32_t mb = q.mini_batch_size ? q.mini_batch_size : 5000;
   const uint32_t nmb = (n + mb - 1) / mb;
-  if (o->burned_known && !o->detect_active && !getenv("SQ_EQ_SLOW_PATH")) {
+  if (o->burned_known && !o->detect_active) {
     // [r3] burned in: one model-independent launch over the whole batch, then per group of W mini-batches only the mass terms
-    // (k_frag_dynamic) and their application (k_apply_dynamic).  Nothing comes back to the host.
+    // (k_frag_dynamic) and their application (k_apply_flagged).  Nothing comes back to the host.
     if (o->dyn.ensure(A * sizeof(DynAln))) { sq_set_error("device allocation failed (online scratch)"); return SQ_ERR_NOMEM; }
-    static const int use_touched = getenv("SQ_EQ_TOUCHED") ? atoi(getenv("SQ_EQ_TOUCHED")) : 1;
     TouchArgs TA{nullptr, mb * o->inflight, (o->M + AP_TB_ * 8 - 1) / (AP_TB_ * 8) * (AP_TB_ * 8)};
-    if (use_touched && !c->stream_chain) {
+    {
       const size_t bytes = (size_t)((n + TA.gsize - 1) / TA.gsize) * TA.stride;
       if (o->gflag.ensure(bytes + 64)) { sq_set_error("device allocation failed (touched flags)"); return SQ_ERR_NOMEM; }
       SQ_HIP_CHECK(hipMemsetAsync(o->gflag.p, 0, bytes, sq));
@@ -1555,36 +1446,16 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     }
     k_frag_static<<<nblk(n), 256, 0, sq>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p, TA);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
-    if (two) { SQ_HIP_CHECK(hipEventRecord(c->ev_static, sq)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_static, 0)); sq_prof_begin(c, 2); }   // the chain starts when the static records are there
     const uint32_t W = o->inflight;
-    if (c->stream_chain && nmb) {   // [r3, SQ_EQ_CHAIN=1] the whole chain of the batch as one resident kernel on its own XCD
-      (void)forgetting_mass(o, q.forgetting_factor, o->batch_no + nmb);   // the schedule up to this batch's last mini-batch
-      if (o->fm_dev_n < o->fm_host.size()) {   // the whole schedule lives on the device; it grows by doubling, a handful of times per job
-        SQ_HIP_CHECK(hipStreamSynchronize(c->stream_chain));
-        if (o->fm_dev.ensure(o->fm_host.size() + 8)) { sq_set_error("device allocation failed (chain)"); return SQ_ERR_NOMEM; }
-        SQ_HIP_CHECK(hipMemcpyAsync(o->fm_dev.p, o->fm_host.data(), o->fm_host.size() * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
-        o->fm_dev_n = o->fm_host.size();
-      }
-      if (o->chain_bar.ensure(4)) { sq_set_error("device allocation failed (chain)"); return SQ_ERR_NOMEM; }
-      if (!o->chain_bar_zeroed) { SQ_HIP_CHECK(hipMemsetAsync(o->chain_bar.p, 0, 16, st)); o->chain_bar_zeroed = true; }
-      ChainArgs CA{n, mb, W, nmb, getenv("SQ_CHAIN_FENCE") ? 1 : 0, o->fm_dev.p + o->batch_no, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin, o->assigned_prefix.p, o->chain_bar.p};
-      SQ_HIP_CHECK(hipEventRecord(c->ev_chain_in, st)); SQ_HIP_CHECK(hipStreamWaitEvent(c->stream_chain, c->ev_chain_in, 0));
-      k_chain<<<c->chain_blocks, 256, 0, c->stream_chain>>>(V, CA);
-      SQ_HIP_CHECK(hipEventRecord(c->ev_chain_out, c->stream_chain)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_chain_out, 0));
-      const uint32_t ng = (nmb + W - 1) / W;
-      o->batch_no += nmb; o->group_no += ng; if (c->prof_on) c->eq_groups += ng;
-    } else
     for (uint32_t b = 0; b < nmb;) {
       FmArr FM; uint32_t nw = 0; const uint32_t b0 = b;
       while (b < nmb && nw < W) { FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++); ++b; }
       for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
       const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
       k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin);
-      if (TA.flag) k_apply_flagged<<<TA.stride / (AP_TB_ * 8), AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.flag + (size_t)(b0 / W) * TA.stride);
-      else k_apply_dynamic<<<(o->M + AP_TB_ - 1) / AP_TB_, AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1);
+      k_apply_flagged<<<TA.stride / (AP_TB_ * 8), AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.flag + (size_t)(b0 / W) * TA.stride);
       o->group_no++; if (c->prof_on) c->eq_groups++;
     }
-    if (two) sq_prof_mark(c, SG_EQ_MINIBATCH, 2);
   } else {
   std::vector<uint64_t> prefix_host;  // host needs assigned totals per mini-batch boundary: copy the prefix at the boundaries only
   std::vector<uint64_t> bound(nmb + 1);
@@ -1662,13 +1533,12 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
   }
   if (burned_host) o->burned_known = true;
   }
-  if (!two) sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
-  // eq-class table: insert labels, then add counts / fixed-point weights (labels, bins and weights are the static stage's: on the throughput stream, beside the chain)
+  sq_prof_mark(c, SG_EQ_MINIBATCH, 1);
+  // eq-class table: insert labels, then add counts / fixed-point weights (labels, bins and weights are the static stage's)
   EqView T = make_eq_view(o);
   k_eq_insert<<<nblk(n), TB, 0, sq>>>(T, n, d_aln_off, d_aln, o->abin.p, o->rh1.p, o->rh2.p, o->rslot.p, q.range_factorization_bins > 0);
   k_eq_add<<<nblk(n), TB, 0, sq>>>(T, n, d_aln_off, o->abin.p, o->awq.p, o->rslot.p);
   sq_prof_mark(c, SG_EQ_TABLE, 1);
-  if (two) { SQ_HIP_CHECK(hipEventRecord(c->ev_table, sq)); SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_table, 0)); }   // the job is done when both parts are
   SQ_HIP_CHECK(hipEventRecord(src->ev_eq_done[buf], st)); c->ev_eq_last = src->ev_eq_done[buf];
   mark("chain-launches");
   o->num_observed += n; o->num_mapped_ub += J.joint; c->reads_seen += n;
@@ -1677,7 +1547,6 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
 
 extern "C" int sq_ctx_reset(sq_ctx* c) {
   if (!c) return SQ_ERR_ARG;
-  c->warm_stop();
   (void)sq_eq_sync(c);
   SQ_HIP_CHECK(hipSetDevice(c->device));
   // the export buffers and their page-locked staging area are work buffers (sized by earlier jobs / sq_ctx_reserve): they survive
@@ -1916,28 +1785,7 @@ static int eq_export_run(sq_ctx* c) {
   X.model_valid = model_final;
   mark("kernels+d2h");
   X.valid = true;
-  c->warm_start();   // the host now copies the table out and runs normalizeAlphas: the device stays awake for the optimiser that follows
   return SQ_OK;
-}
-
-// see ctx.h: one sleeping wave between the export and the optimiser
-__global__ void k_keep_warm(volatile int* stop, long long max_ticks) {
-  const long long t0 = (long long)wall_clock64();   // constant-rate counter (100 MHz)
-  while (!*stop && (long long)wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
-}
-void sq_ctx::warm_start() {
-  static const int on = getenv("SQ_KEEP_WARM") ? atoi(getenv("SQ_KEEP_WARM")) : 0;   // measured: 10 / 20 ms with it, 22 / 19 ms without (two runs each): not the cause of the stall; off by default
-  if (!on || warm_running) return;
-  if (!warm_flag) { if (hipHostMalloc((void**)&warm_flag, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); warm_flag = nullptr; return; } }
-  *warm_flag = 0; __sync_synchronize();
-  // on the stream the optimiser will use (a stream of its own was measured to share a hardware queue with it: the optimiser's first copy then
-  // waited for the wave's time-out, 22.8 ms instead of 5); the optimiser stops the wave before it queues anything.  At most 12 ms.
-  k_keep_warm<<<1, 64, 0, stream3 ? stream3 : stream2>>>(warm_flag, 100000LL * 12);
-  warm_running = true;
-}
-void sq_ctx::warm_stop() {
-  if (!warm_running) return;
-  *warm_flag = 1; __sync_synchronize(); warm_running = false;     // the wave sees it within a few microseconds; nothing waits for it
 }
 
 extern "C" int sq_eq_finish(sq_ctx* c, sq_eq_table* out) {
@@ -2064,7 +1912,6 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
   if (eq) return sq_em_optimize_dev(c->device, eq, txp, o, alpha_out, rep);
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
-  c->warm_stop();   // the sleeping wave in front of the optimiser's work (ctx.h) leaves its stream
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
   return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
