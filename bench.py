@@ -61,7 +61,7 @@ def parse():
         help="initialise torch.distributed (RCCL) even for one rank, so the N>1 code path (the RCCL exchange + merge) runs on a 1-GPU box")
     ap.add_argument("--debug-one-device", action="store_true",
         help="functional check of the N>1 path on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo (numbers meaningless)")
-    ap.add_argument("--fastq-gz-pairs", type=int, default=4000000, help="pairs of the gzip / BGZF legs of the from-FASTQ run (compressing the input is what takes the time)")
+    ap.add_argument("--fastq-gz-pairs", type=int, default=20000000, help="pairs of the gzip / BGZF legs of the from-FASTQ run (compressing the input is what takes the time)")
     ap.add_argument("--fastq-pairs", type=int, default=20000000,
         help="second measurement (outside the timed steps, rank 0, N=1, c2/c2s): this many pairs written as FASTQ files to /dev/shm and run through "
              "the host read pipeline (sq_reader) + the same GPU path, end to end from files (0 = skip)")
@@ -117,7 +117,7 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
 
 
 KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed2", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
-                   "k_select": "k_select", "k_finalize": "k_finalize", "compact_alns": "k_compact_alns", "eq_mini_batches": "k_frag_dynamic", "eq_static": "k_frag_static",
+                   "k_select": "k_select", "k_finalize": "k_finalize", "eq_mini_batches": "k_frag_dynamic", "eq_static": "k_frag_static",
                    "eq_table": "k_eq_insert"}
 
 
@@ -157,7 +157,7 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
     import shutil, tempfile, subprocess, gzip
     d = tempfile.mkdtemp(prefix="sq_bench_fq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     # the files (2 x n x (2 L + 7) bytes, the head copies and their compressed forms: ~1.4 x) have to fit where they are written: fewer pairs if they do not
-    room = shutil.disk_usage(d).free; need = lambda n: int(1.4 * 2 * n * (2 * read_len + 7)) + (256 << 20)
+    room = shutil.disk_usage(d).free; need = lambda n: int(1.8 * 2 * n * (2 * read_len + 7)) + (256 << 20)
     while n_pairs > 1000000 and need(n_pairs) > room: n_pairs //= 2
     gz_pairs = min(n_pairs, gz_pairs or n_pairs)
     out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(),
@@ -189,8 +189,7 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
                 files = short
             gz = []
             for f in files:
-                g = f + ".gz"
-                subprocess.check_call("gzip -1 -c %s > %s" % (f, g), shell=True); gz.append(g)
+                g = f + ".gz"; _write_gzip(f, g); gz.append(g)
             out["gzip"] = _fastq_pass(ctx, idx, gz, batch, lib, api, capi, read_len)
             bg = []
             for f in files:
@@ -201,6 +200,46 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _write_gzip(src, dst, chunk=16 << 20):
+    """ONE gzip member (what `gzip -1` writes: a single deflate stream), compressed by Python threads the way pigz does it: every chunk is deflated on
+    its own and ends with a sync flush (byte-aligned, no final block), the last one finishes the stream; header, bodies, CRC-32 and length follow each other."""
+    import zlib, struct
+    from concurrent.futures import ThreadPoolExecutor
+    data = np.fromfile(src, np.uint8); starts = list(range(0, len(data), chunk)) or [0]
+    def part(i):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15); piece = data[i:i + chunk].tobytes()
+        return co.compress(piece) + co.flush(zlib.Z_FINISH if i == starts[-1] else zlib.Z_FULL_FLUSH), zlib.crc32(piece), len(piece)
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex, open(dst, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\x03"); crc = 0; first = True
+        for body, c, n in ex.map(part, starts):
+            f.write(body); crc = c if first else _crc32_combine(crc, c, n); first = False
+        f.write(struct.pack("<II", crc & 0xffffffff, len(data) & 0xffffffff))
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (not exposed by Python): the CRC-32 of A || B from CRC(A), CRC(B) and len(B), by squaring the shift operator over GF(2)."""
+    def times(mat, vec):
+        s = 0; i = 0
+        while vec:
+            if vec & 1: s ^= mat[i]
+            vec >>= 1; i += 1
+        return s
+    def square(mat): return [times(mat, mat[n]) for n in range(32)]
+    if len2 <= 0: return crc1
+    odd = [0xedb88320] + [1 << n for n in range(31)]
+    even = square(odd); odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1: crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2: break
+        odd = square(even)
+        if len2 & 1: crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2: break
+    return crc1 ^ crc2
 
 
 def _write_bgzf(src, dst, block=0xff00):

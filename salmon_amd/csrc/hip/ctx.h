@@ -121,7 +121,7 @@ struct sq_ctx {
   sq_dbuf<uint32_t> n_cand; sq_dbuf<uint64_t> cand_off; sq_dbuf<sq_cand_dev> cands; uint64_t cand_cap = 0;
   sq_dbuf<uint32_t> cand_frag, tid_arr; sq_dbuf<int32_t> hs_arr;
   sq_dbuf<sq_dp_item> dpq; sq_dbuf<uint32_t> counters; sq_dbuf<uint8_t> frag_flags;
-  sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
+  sq_dbuf<uint32_t> n_aln; sq_dbuf<uint64_t> aln_off; sq_dbuf<sq_aln> aln_slots; sq_dbuf<uint64_t> sel_desc /* [r5] k_select: ticket + one look-back descriptor per block */; sq_dbuf<sq_aln> aln; sq_dbuf<uint8_t> map_type;
   sq_dbuf<double> gapcost; sq_dbuf<unsigned long long> stats;
   // last batch bookkeeping
   uint32_t last_n = 0;

@@ -34,6 +34,7 @@
 #include "scan_kernels.h"
 #include "../host/index.h"
 #include "../host/reader_dev.h"
+#include "../host/bgzf_source.h"
 
 namespace {
 constexpr int FQ_TB = 256;   // 16 bytes per lane: a 4 KB tile per block
@@ -105,7 +106,22 @@ struct sq_dev_reader {
   int device = 0; uint32_t batch = 0; bool paired = false;
   // a mate stream = its files end to end; a file that does not end with a newline gets one (pad = 1), so records never straddle files
   struct File { std::string path; int fd = -1; uint64_t size = 0, vbase = 0; uint32_t pad = 0; };
-  struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; } sm[2];
+  // [r5] a gzip / BGZF file: its text arrives as buffers in file order from the pool that inflates it (BGZF: groups of members, each inflated where it will
+  // lie; any other gzip stream: pieces, host/pgzip.cpp) and is copied into the ring like the bytes of a plain file — the device then splits the records.
+  // A stream with such a file is SEQUENTIAL: its size is known only at its end (vsize stays at its maximum until then), the stager asks for the text up
+  // to an offset (seq_ensure) before the round's pieces are filled from the buffers (vread_seq), and buffers behind the batch cut are let go (seq_trim).
+  struct SeqFile {
+    std::string path; std::shared_ptr<sqio::Mapping> map; std::unique_ptr<sqio::BgzfSource> bg; PgzStream* pz = nullptr;
+    ~SeqFile() { if (pz) pgz_close(pz); bg.reset(); }
+    int next(PgzBuf* B, std::string* e) {
+      if (bg) { const int rc = bg->next_buf(B); if (rc < 0) *e = bg->err; return rc; }
+      std::string w; const int rc = pgz_next(pz, B, &w); if (rc < 0) *e = "'" + path + "': " + w; return rc;
+    }
+  };
+  struct SeqChunk { uint64_t voff; PgzBuf b; };
+  struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; std::string name;   // name: the last file, for messages
+    bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
+  std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the sequential streams
   struct Slot {   // device side only: the text of a batch never sits in host memory as a whole
     void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
     void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
@@ -132,7 +148,7 @@ struct sq_dev_reader {
   // stager -> (rounds) -> uploader -> (ready) -> consumer -> (free_slots) -> stager
   std::thread prod, prod2; std::mutex mu; std::condition_variable cv; std::deque<int> ready, free_slots; std::deque<Round> rounds; bool stop = false, done = false;
   std::string err; int err_rc = SQ_OK; uint64_t total = 0, staged_total = 0;
-  double t_stage = 0, t_upload = 0, t_wait_piece = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
+  double t_stage = 0, t_upload = 0, t_wait_piece = 0, t_wait_text = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
 
   static int dev_grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
@@ -149,8 +165,36 @@ struct sq_dev_reader {
     if (*p) (void)hipFree(*p);
     *p = nb; *cap = c; return 0;
   }
+  // [r5] sequential streams: the text up to `upto` is in the window, or the stream is at its end (then vsize is its size)
+  bool seq_ensure(Stream& S, uint64_t upto, std::string* e) {
+    static const char nl_pad[2] = "\n";
+    while (!S.final_ && S.wend < upto) {
+      if (S.sfile_cur == S.sfiles.size()) { S.final_ = true; S.vsize = S.wend; break; }
+      PgzBuf B; const int rc = S.sfiles[S.sfile_cur]->next(&B, e);
+      if (rc < 0) return false;
+      if (rc == 0) {   // the end of a file: one that does not end with a newline gets one, so that records never straddle files
+        if (S.file_bytes && S.last_byte != '\n') { PgzBuf P; P.p = nl_pad; P.n = 1; S.win.push_back(SeqChunk{S.wend, P}); S.wend += 1; S.last_byte = '\n'; }
+        S.sfiles[S.sfile_cur].reset(); ++S.sfile_cur; S.file_bytes = 0; continue;
+      }
+      if (!B.n) continue;
+      S.last_byte = B.p[B.n - 1]; S.file_bytes += B.n; S.win.push_back(SeqChunk{S.wend, B}); S.wend += B.n;
+    }
+    return true;
+  }
+  void seq_trim(Stream& S) { while (!S.win.empty() && S.win.front().voff + S.win.front().b.n <= S.vpos) S.win.pop_front(); }
+  bool vread_seq(const Stream& S, uint64_t pos, size_t n, char* dst, std::string* e) {
+    size_t lo = 0, hi = S.win.size();   // the last buffer that starts at or before pos
+    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (S.win[mid].voff <= pos) lo = mid; else hi = mid; }
+    for (size_t k = lo; n; ++k) {
+      if (k >= S.win.size() || S.win[k].voff > pos) { *e = "internal: the reader's text window does not cover a round"; return false; }
+      const SeqChunk& c = S.win[k]; const uint64_t in = pos - c.voff; if (in >= c.b.n) continue;
+      const size_t take = (size_t)std::min<uint64_t>(c.b.n - in, n); memcpy(dst, c.b.p + in, take); dst += take; pos += take; n -= take;
+    }
+    return true;
+  }
   // bytes [pos, pos + n) of the stream into dst
   bool vread(Stream& S, uint64_t pos, size_t n, char* dst, std::string* e) {
+    if (S.seq) return vread_seq(S, pos, n, dst, e);
     size_t k = 0; while (k + 1 < S.files.size() && S.files[k + 1].vbase <= pos) ++k;
     while (n) {
       File& F = S.files[k]; const uint64_t in = pos - F.vbase;
@@ -173,6 +217,12 @@ struct sq_dev_reader {
     const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0; bool reached = false, first = first_of_batch; char last2[2] = {'X', '\n'};
     while (!reached && S.vpos + have < S.vsize) {
       const uint64_t missing = (need_lines - lines + 3) / 4;
+      if (S.seq) {   // the text this round may take is inflated (or the end of the stream is known) before its pieces are filled
+        const double t0 = now();
+        if (!seq_ensure(S, S.vpos + have + std::min<uint64_t>((uint64_t)((double)missing * S.est * 1.03) + (1u << 20), (uint64_t)ROUND_PIECES * PIECE) + 1, e)) return false;   // + 1: whether the stream ends with this round must be known in this round
+        t_wait_text += now() - t0;
+        if (S.vpos + have >= S.vsize) break;
+      }
       const size_t more = (size_t)std::min<uint64_t>(std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20)), (uint64_t)ROUND_PIECES * PIECE);
       const unsigned np = (unsigned)((more + PIECE - 1) / PIECE);
       Round r; r.slot = si; r.mate = i; r.dst = have; r.first_of_batch = first; first = false;
@@ -213,7 +263,7 @@ struct sq_dev_reader {
         }
         size_t drop = tn + 2 - cut;
         while (drop && !r.pieces.empty()) { auto& pc = r.pieces.back(); const size_t c = std::min(drop, pc.second); pc.second -= c; drop -= c; emitted -= c; if (!pc.second) { give_back(r.pieces, r.pieces.size() - 1); r.pieces.pop_back(); } }
-        if (lines % 4) { *e = "'" + S.files.back().path + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; give_back(r.pieces); return false; }
+        if (lines % 4) { *e = "'" + S.name + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; give_back(r.pieces); return false; }
       } else if (!reached && emitted) {   // the last two bytes of this round, for the blank-line rule of the round that ends the input
         char b2[2] = {last2[1], 0}; size_t got2 = 0;
         for (size_t q = r.pieces.size(); q-- > 0 && got2 < 2;) { const auto& pc = r.pieces[q]; const char* base = ring + (size_t)pc.first * PIECE; for (size_t c = pc.second; c-- > 0 && got2 < 2;) { b2[1 - got2] = base[c]; ++got2; } }
@@ -225,6 +275,7 @@ struct sq_dev_reader {
         if (have >= 0xFFFFFFF0ull) { *e = "a batch of " + std::to_string(*got) + " records spans more than 4 GB of text: use a smaller batch"; give_back(r.pieces); return false; }
         r.last_of_mate = true; r.last_of_batch = last_mate; r.n = *got; r.total = have;
         S.vpos = reached ? S.vpos + have : S.vsize;
+        if (S.seq) seq_trim(S);
         if (*got) S.est = 0.7 * S.est + 0.3 * ((double)have / (double)*got);
         text_bytes += have;
         if (*got == 0) { give_back(r.pieces); return true; }   // nothing but blank lines was left: no round goes out
@@ -321,14 +372,47 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   int dev = 0, ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return SQ_ERR_DEVICE; }   // no device: the caller keeps the host path
   std::unique_ptr<sq_dev_reader> R(new sq_dev_reader()); R->device = dev; R->batch = batch; R->paired = !f2.empty();
+  auto close_all = [&]() { for (auto& s : R->sm) for (auto& f : s.files) if (f.fd >= 0) close(f.fd); };
+  auto is_gz = [](const std::string& path) { unsigned char mg[2] = {0, 0}; FILE* f = fopen(path.c_str(), "rb"); if (!f) return false; const size_t got = fread(mg, 1, 2, f); fclose(f); return got == 2 && mg[0] == 0x1f && mg[1] == 0x8b; };
+  bool any_gz = false, any_plain = false;
+  for (int i = 0; i < (R->paired ? 2 : 1); ++i) for (const auto& path : (i ? f2 : f1)) { if (is_gz(path)) any_gz = true; else any_plain = true; }
+  if (any_gz && any_plain) return SQ_ERR_DEVICE;   // a mix of compressed and plain files: the host path takes it
+  if (any_gz) {   // [r5] compressed input: inflated by a pool of its own into buffers, copied into the ring, split on the device
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    const unsigned nz = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(64u, std::max(2u, hw / 2));
+    R->zpool.reset(new sqio::Pool(std::max(1u, nz)));
+    sqio::Pool* zp = R->zpool.get();
+    const int nstreams = R->paired ? 2 : 1;
+    for (int i = 0; i < nstreams; ++i) {
+      sq_dev_reader::Stream& S = R->sm[i]; S.seq = true; S.vsize = ~0ull;
+      for (const auto& path : (i ? f2 : f1)) {
+        std::unique_ptr<sq_dev_reader::SeqFile> F(new sq_dev_reader::SeqFile()); F->path = path;
+        int fd = open(path.c_str(), O_RDONLY); struct stat sb;
+        if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) { if (fd >= 0) close(fd); sq_set_error("cannot open '%s'", path.c_str()); return SQ_ERR_IO; }
+        void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+        if (m == MAP_FAILED) { sq_set_error("cannot map '%s'", path.c_str()); return SQ_ERR_IO; }
+        F->map = std::make_shared<sqio::Mapping>(); F->map->p = m; F->map->n = (size_t)sb.st_size; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        if (sqio::BgzfSource::member_size((const uint8_t*)m, (size_t)sb.st_size)) {
+          F->bg.reset(new sqio::BgzfSource()); F->bg->map = F->map; F->bg->base = (const uint8_t*)m; F->bg->n = (size_t)sb.st_size; F->bg->pool = zp; F->bg->path = path;
+          F->bg->window = std::max<size_t>(8, (size_t)(2 * nz) / (size_t)nstreams);
+        } else {
+          const unsigned th = std::max(1u, std::min(32u, nz / (unsigned)nstreams));
+          const size_t piece = std::max<size_t>(1u << 20, std::min<size_t>(4u << 20, (size_t)sb.st_size / (4 * th)));
+          F->pz = pgz_open((const uint8_t*)m, (size_t)sb.st_size, [zp](std::function<void()> f) { zp->submit(std::move(f)); }, th, piece);
+          if (!F->pz) { sq_set_error("'%s' does not start with a gzip member", path.c_str()); return SQ_ERR_IO; }
+        }
+        S.sfiles.push_back(std::move(F)); S.name = path;
+      }
+    }
+  } else
   for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
     uint64_t v = 0;
     for (const auto& path : (i ? f2 : f1)) {
       sq_dev_reader::File F; F.path = path; F.fd = open(path.c_str(), O_RDONLY); struct stat sb;
-      if (F.fd < 0 || fstat(F.fd, &sb) != 0) { sq_set_error("cannot open '%s'", path.c_str()); for (auto& s : R->sm) for (auto& f : s.files) close(f.fd); if (F.fd >= 0) close(F.fd); return SQ_ERR_IO; }
+      if (F.fd < 0 || fstat(F.fd, &sb) != 0) { sq_set_error("cannot open '%s'", path.c_str()); close_all(); if (F.fd >= 0) close(F.fd); return SQ_ERR_IO; }
       F.size = (uint64_t)sb.st_size; F.vbase = v;
       if (F.size) { char last = 0; if (pread(F.fd, &last, 1, (off_t)(F.size - 1)) == 1 && last != '\n') F.pad = 1; }
-      v += F.size + F.pad; R->sm[i].files.push_back(F);
+      v += F.size + F.pad; R->sm[i].files.push_back(F); R->sm[i].name = path;
     }
     R->sm[i].vsize = v;
   }
@@ -363,9 +447,11 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
   if (R->prod.joinable()) R->prod.join();
   if (R->prod2.joinable()) R->prod2.join();
-  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
-      (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
+  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
+      (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_wait_text, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
   R->pool.reset(); (void)hipSetDevice(R->device);
+  for (auto& m : R->sm) { m.win.clear(); m.sfiles.clear(); }   // the sources' tasks run on zpool: they go first
+  R->zpool.reset();
   for (auto& s : R->slots) {
     if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     if (s.h_res) (void)hipHostFree(s.h_res);

@@ -257,7 +257,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->frag_flags.free_();
   c->n_aln.free_();
   c->aln_off.free_();
-  c->aln_slots.free_();
+  c->aln_slots.free_(); c->sel_desc.free_();
   c->aln.free_();
   c->aln_b1.free_();
   c->aln_off_b1.free_();
@@ -678,15 +678,16 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   if (total_cands) k_finalize<<<nblk(total_cands), TB, 0, st>>>(P, total_cands, paired, c->cands.p, cand_frag.p, c->rlen.p, hs_arr.p,
       tid_arr.p);
   sq_prof_mark(c, SG_FINALIZE);
-  k_select<<<nblk(n), TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->chains.p, c->rlen.p,
-      c->frag_flags.p, c->aln_slots.p,
-      c->n_aln.p, c->map_type.p, c->stats.p, nullptr);
+  // [r5] selection + compact alignment array in one launch (map_kernels.h): one descriptor per block for the look-back, a ticket counter in front of them
+  const uint32_t sel_blocks = (n + SEL_TB - 1) / SEL_TB;
+  if (c->sel_desc.ensure((size_t)sel_blocks + 8)) { sq_set_error("device allocation failed (selection descriptors)"); return SQ_ERR_NOMEM; }
+  SQ_HIP_CHECK(hipMemsetAsync(c->sel_desc.p, 0, ((size_t)sel_blocks + 2) * 8, st));
+  if (n == 0) SQ_HIP_CHECK(hipMemsetAsync(c->aln_off_ptr(buf), 0, 8, st));
+  else k_select<<<sel_blocks, SEL_TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->rlen.p,
+      c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p, c->aln_ptr(buf), c->aln_off_ptr(buf),
+      (unsigned long long*)c->sel_desc.p + 1, (uint32_t*)c->sel_desc.p);
   sq_prof_mark(c, SG_SELECT);
-  SQ_HIP_CHECK(hipMemsetAsync(c->n_aln.p + n, 0, sizeof(uint32_t), st));
-  rc = exclusive_scan_u32(c, c->n_aln.p, c->aln_off_ptr(buf), n + 1); if (rc) return rc;
-  if (total_cands) k_compact_alns<<<nblk(total_cands), TB, 0, st>>>(total_cands, cand_frag.p, c->cand_off.p, c->aln_off_ptr(buf), c->n_aln.p, c->aln_slots.p, c->aln_ptr(buf));
   SQ_HIP_CHECK(hipEventRecord(c->ev_map_done[buf], st));
-  sq_prof_mark(c, SG_COMPACT);
   uint64_t total_aln = 0; unsigned long long hst[ST_N];
   SQ_HIP_CHECK(hipMemcpyAsync(&total_aln, c->aln_off_ptr(buf) + n, 8, hipMemcpyDeviceToHost, st));
   SQ_HIP_CHECK(hipMemcpyAsync(hst, c->stats.p, sizeof(hst), hipMemcpyDeviceToHost, st));
@@ -892,12 +893,17 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
     if (hipMemcpy(coff.data(), c->cand_off.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ncd.data(), c->n_cand.p,
         (size_t)n * 4,
         hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
+    std::vector<uint16_t> rl(nrec);
+    if (nrec && hipMemcpy(rl.data(), c->rlen.p, (size_t)nrec * 2, hipMemcpyDeviceToHost) != hipSuccess) return SQ_ERR_DEVICE;
     sq_cand* o = (sq_cand*)buf; uint64_t cnt = 0;
     for (uint32_t f = 0; f < n; ++f) for (uint64_t i = coff[f]; i < coff[f] + ncd[f]; ++i) {
       if (o && cnt < cap) { const sq_cand_dev& d = cd[i]; sq_cand x; memset(&x, 0,
           sizeof(x)); x.frag = f; x.tid = d.tid; bool hl = d.lc != 0xFFFFFFFFu,
           hr = d.rc != 0xFFFFFFFFu;
-        x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status; x.valid = d.valid; x.lscore = d.lscore; x.rscore = d.rscore; x.frag_len = d.frag_len; o[cnt] = x; }
+        x.lpos = hl ? ch[d.lc].pos : 0; x.rpos = hr ? ch[d.rc].pos : 0; x.lfw = hl ? ch[d.lc].fw : 0; x.rfw = hr ? ch[d.rc].fw : 0; x.mate_status = d.mate_status;
+        const uint32_t e0 = c->last_paired ? 2 * f : f;   // [r5] the scores as the selection saw them (the device no longer writes them back)
+        const sqk::CandFinal cf = sqk::cand_final(c->mp, d, rl[e0], c->last_paired ? rl[e0 + 1] : 0);
+        x.valid = cf.ok; x.lscore = d.lfail == 2 ? d.lscore : cf.ls; x.rscore = d.lfail == 2 ? d.rscore : cf.rs; x.frag_len = d.frag_len; o[cnt] = x; }
       ++cnt; }
     return (int64_t)cnt;
   }

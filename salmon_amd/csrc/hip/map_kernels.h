@@ -1483,47 +1483,67 @@ __device__ inline uint8_t hit_type_pe(int32_t e1, bool f1, uint32_t l1, int32_t 
   return f1 ? fmt_id(1, 0, 2) : fmt_id(1, 0, 3);
 }
 
-// thread per candidate: validity against minScoreFraction and the hit score, written as two compact
-// arrays (SoA) so the per-fragment selection below streams 8 bytes per candidate instead of 48
-__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, sq_cand_dev* __restrict__ cands,
+// a candidate's scores against minScoreFraction (SalmonMappingUtils.hpp:225-281): the two ends' scores as the selection sees them, whether the
+// candidate stands, and its hit score (SQ_INVALID_SCORE: incompatible, skipped before alignment and not counted as filtered;
+// SQ_INVALID_SCORE + 1: scored but invalid — a filtered mapping; else the score).  Shared by k_finalize and the host's candidate tap.
+struct CandFinal { int32_t ls, rs, hs; bool ok; };
+__host__ __device__ inline CandFinal cand_final(const sq_map_params& P, const sq_cand_dev& c, uint32_t n1, uint32_t n2) {
+  CandFinal r; r.ls = SQ_INVALID_SCORE; r.rs = SQ_INVALID_SCORE; r.ok = false; r.hs = SQ_INVALID_SCORE;
+  if (c.lfail == 2) return r;
+  const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
+  if (hasL) {
+    const int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1));
+    r.ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore;
+  }
+  if (hasR) {
+    const int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2));
+    r.rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore;
+  }
+  r.ok = (hasL && hasR) ? (r.ls != SQ_INVALID_SCORE && r.rs != SQ_INVALID_SCORE) : ((hasL ? r.ls : r.rs) != SQ_INVALID_SCORE);
+  r.hs = r.ok ? ((hasL && hasR) ? r.ls + r.rs : (hasL ? r.ls : r.rs)) : (SQ_INVALID_SCORE + 1);
+  return r;
+}
+// thread per candidate: the hit score and the transcript as two compact arrays (SoA), so that the per-fragment selection below streams
+// 8 bytes per candidate instead of 48.  [r5] The candidate records are no longer written back (0.75 GB per 5 x 10^6 pairs that only the
+// debug tap read: a standing candidate's scores ARE its raw scores, and the tap applies cand_final itself).
+__global__ void k_finalize(sq_map_params P, uint64_t ncand, uint32_t paired, const sq_cand_dev* __restrict__ cands,
     const uint32_t* __restrict__ cand_frag,
     const uint16_t* __restrict__ rlen,
                            int32_t* __restrict__ hs_out, uint32_t* __restrict__ tid_out) {
   uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= ncand) return;
-  sq_cand_dev c = cands[ci];
+  const sq_cand_dev c = cands[ci];
   tid_out[ci] = c.tid;
-  if (c.lfail == 2) { hs_out[ci] = SQ_INVALID_SCORE; return; }   // incompatible, skipped before alignment (not counted as filtered)
   const uint32_t f = cand_frag[ci]; const uint32_t e0 = paired ? 2 * f : f;
-  const uint32_t n1 = rlen[e0], n2 = paired ? rlen[e0 + 1] : 0;
-  const bool hasL = c.lc != 0xFFFFFFFFu, hasR = c.rc != 0xFFFFFFFFu;
-  int32_t ls = SQ_INVALID_SCORE, rs = SQ_INVALID_SCORE;
-  if (hasL) {
-    int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n1));
-    ls = (c.lfail || c.lscore < SQ_NEG_INF / 2 || c.lscore < minacc) ? SQ_INVALID_SCORE : c.lscore;
-  }
-  if (hasR) {
-    int32_t minacc = (int32_t)(P.min_score_fraction * (double)(P.ma * (int32_t)n2));
-    rs = (c.rfail || c.rscore < SQ_NEG_INF / 2 || c.rscore < minacc) ? SQ_INVALID_SCORE : c.rscore;
-  }
-  const bool ok = (hasL && hasR) ? (ls != SQ_INVALID_SCORE && rs != SQ_INVALID_SCORE) : ((hasL ? ls : rs) != SQ_INVALID_SCORE);
-  c.lscore = ls; c.rscore = rs; c.valid = ok;
-  cands[ci] = c;
-  // INVALID_SCORE + 1 marks "scored but invalid" (counts as a filtered mapping); valid hits carry their score
-  hs_out[ci] = ok ? ((hasL && hasR) ? ls + rs : (hasL ? ls : rs)) : (SQ_INVALID_SCORE + 1);
+  hs_out[ci] = cand_final(P, c, rlen[e0], paired ? rlen[e0 + 1] : 0).hs;
 }
 
-__global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off,
+// [r5] Per-fragment selection AND the compact alignment array in one launch.  Round 4 wrote the winners into per-candidate slots, scanned the
+// counts in three more launches and copied the slots together in a fifth (k_compact_alns: every alignment written twice and read once in
+// between).  Here a block takes a ticket (so that blocks start in fragment order), selects, scans its 256 counts in LDS and learns where its
+// alignments begin from the blocks before it by a decoupled look-back over one 64-bit descriptor per block (top two bits: 1 = this block's own
+// total, 2 = the total of everything up to and including this block; a block only ever waits for blocks that hold earlier tickets, which are
+// running).  The winners are remembered as (candidate, score) pairs — the first SEL_KW of a fragment in LDS, further ones as finished records
+// in the old slots — and materialised once, at their final place.
+#define SEL_TB 256
+#define SEL_KW 8
+__global__ void __launch_bounds__(SEL_TB) k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const uint64_t* __restrict__ cand_off,
     const uint32_t* __restrict__ n_cand,
     const sq_cand_dev* __restrict__ cands, const int32_t* __restrict__ hs_arr,
-                         const uint32_t* __restrict__ tid_arr, const sq_chain_dev* __restrict__ chains,
+                         const uint32_t* __restrict__ tid_arr,
                          const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ frag_flags, sq_aln* __restrict__ aln_slots,
                              uint32_t* __restrict__ n_aln,
                              uint8_t* __restrict__ map_type,
-                         unsigned long long* __restrict__ stats, const uint32_t* __restrict__ perm) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+                         unsigned long long* __restrict__ stats, sq_aln* __restrict__ aln_out, uint64_t* __restrict__ aln_off,
+                         unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t s_bid; __shared__ uint32_t s_wsum[SEL_TB / 64]; __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_widx[SEL_KW][SEL_TB]; __shared__ int32_t s_wsc[SEL_KW][SEL_TB];
+  if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t bid = s_bid, tx = threadIdx.x;
+  const uint32_t gid = bid * SEL_TB + tx;
   const bool act = gid < nfrag;
-  const uint32_t f = act ? (perm ? perm[gid] : gid) : 0;
+  const uint32_t f = act ? gid : 0;
   const uint64_t c0 = act ? cand_off[f] : 0; const uint32_t nc = act ? n_cand[f] : 0;
   const sq_cand_dev* C = cands + c0; const int32_t* HS = hs_arr + c0; const uint32_t* TID = tid_arr + c0;
   const uint32_t e0 = act ? (paired ? 2 * f : f) : 0;
@@ -1544,8 +1564,37 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
     }
   }
   const bool onlyDecoy = (bestScore < decoy_cut(bestDecoy)) && (bestDecoy > SQ_INVALID_SCORE);
-  uint32_t na = 0; uint8_t mt = SQ_MT_UNMAPPED; uint32_t ffilt = 0, fdecoy = 0;
-  sq_aln* out = aln_slots + c0;
+  uint32_t na = 0; uint8_t mt = SQ_MT_UNMAPPED; uint32_t ffilt = 0, fdecoy = 0; uint8_t first_ms = 0;
+  // the alignment record of a winner: candidate `ci` of the fragment with hit score `hs`
+  auto make_aln = [&](uint32_t ci, int32_t hs) -> sq_aln {
+    const sq_cand_dev c = C[ci];
+    const double v = (double)bestScore - (double)hs;
+    sq_aln a;
+    a.tid = c.tid;
+    a.est_aln_prob = P.hard_filter ? -1.0 : sq_exp(-P.score_exp * v);
+    a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END;
+    a.frag_len = c.frag_len;
+    const unsigned long long posbits = (unsigned long long)__double_as_longlong(c.cov);   // written by k_score: implied positions of the two chains
+    const int32_t lpos = (int32_t)(uint32_t)posbits, rpos = (int32_t)(uint32_t)(posbits >> 32); const uint8_t lfwb = c.pad[1] & 1, rfwb = (c.pad[1] >> 1) & 1;
+    if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
+      a.pos = lpos;
+      a.fwd = lfwb;
+      a.read_len = (uint16_t)n1;
+      a.mate_pos = rpos;
+      a.mate_fwd = rfwb;
+      a.mate_len = (uint16_t)n2;
+      a.score = c.lscore;
+      a.mate_score = c.rscore;
+      int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
+      a.format_id = hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len);
+    } else {
+      const bool left = c.lc != 0xFFFFFFFFu;
+      a.pos = left ? lpos : rpos; a.fwd = left ? lfwb : rfwb; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
+      a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
+      a.format_id = a.fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3);
+    }
+    return a;
+  };
   if (bestScore > SQ_INVALID_SCORE && !onlyDecoy) {
     const int32_t bd = (bestDecoy == SQ_INVALID_SCORE) ? SQ_INVALID_SCORE + 1 : bestDecoy;
     const int32_t thr = P.hard_filter ? bestScore : decoy_cut(bd);
@@ -1596,38 +1645,14 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
         }
         ++ib; }
       if (curi < 0 || cur < thr) continue;
-      const sq_cand_dev c = C[curi]; const int32_t hs = cur;
-      double v = (double)bestScore - (double)hs;
-      double p = P.hard_filter ? -1.0 : sq_exp(-P.score_exp * v);
-      if (!P.hard_filter && p < P.min_aln_prob) continue;
-      sq_aln a;
-      a.tid = c.tid;
-      a.est_aln_prob = p;
-      a.mate_status = paired ? c.mate_status : (uint8_t)SQ_MS_SINGLE_END;
-      a.frag_len = c.frag_len;
-      const unsigned long long posbits = (unsigned long long)__double_as_longlong(c.cov);   // written by k_score: implied positions of the two chains
-      const int32_t lpos = (int32_t)(uint32_t)posbits, rpos = (int32_t)(uint32_t)(posbits >> 32); const uint8_t lfwb = c.pad[1] & 1, rfwb = (c.pad[1] >> 1) & 1;
-      if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
-        a.pos = lpos;
-        a.fwd = lfwb;
-        a.read_len = (uint16_t)n1;
-        a.mate_pos = rpos;
-        a.mate_fwd = rfwb;
-        a.mate_len = (uint16_t)n2;
-        a.score = c.lscore;
-        a.mate_score = c.rscore;
-        int32_t e1 = a.fwd ? a.pos : a.pos + (int32_t)a.read_len, e2 = a.mate_fwd ? a.mate_pos : a.mate_pos + (int32_t)a.mate_len;
-        a.format_id = hit_type_pe(e1, a.fwd, a.read_len, e2, a.mate_fwd, a.mate_len);
-      } else {
-        const bool left = c.lc != 0xFFFFFFFFu;
-        a.pos = left ? lpos : rpos; a.fwd = left ? lfwb : rfwb; a.read_len = (uint16_t)(left ? n1 : n2); a.score = left ? c.lscore : c.rscore;
-        a.mate_pos = 0; a.mate_fwd = 1; a.mate_len = paired ? 0 : a.read_len; a.mate_score = 0;
-        a.format_id = a.fwd ? fmt_id(0, 3, 2) : fmt_id(0, 3, 3);
-      }
-      out[na++] = a;
+      if (!P.hard_filter && sq_exp(-P.score_exp * ((double)bestScore - (double)cur)) < P.min_aln_prob) continue;
+      if (na == 0) first_ms = paired ? C[curi].mate_status : (uint8_t)SQ_MS_SINGLE_END;
+      if (na < SEL_KW) { s_widx[na][tx] = (uint32_t)curi; s_wsc[na][tx] = cur; }
+      else aln_slots[c0 + na] = make_aln((uint32_t)curi, cur);   // a fragment with more winners than the LDS columns hold: the rest waits in its slots
+      ++na;
     }
     if (na) {
-      switch (out[0].mate_status) {
+      switch (first_ms) {
         case SQ_MS_PAIRED_END_PAIRED: mt = SQ_MT_PAIRED_MAPPED;
         break;
         case SQ_MS_PAIRED_END_LEFT: mt = SQ_MT_LEFT_ORPHAN;
@@ -1642,6 +1667,42 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
     ffilt = 1; fdecoy = onlyDecoy ? 1 : 0;
   }
   if (act) { n_aln[f] = na; map_type[f] = mt; }
+  // where the block's alignments begin: exclusive scan of the 256 counts, then the look-back
+  const uint32_t lane = tx & 63, wave = tx >> 6;
+  uint32_t incl = na;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += t; }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < SEL_TB / 64; ++w) { if (w < wave) woff += s_wsum[w]; total += s_wsum[w]; }
+  if (tx == 0) {
+    const unsigned long long VM = (1ULL << 62) - 1;
+    unsigned long long before = 0;
+    if (bid == 0) __hip_atomic_store(&desc[0], (2ULL << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      __hip_atomic_store(&desc[bid], (1ULL << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t j = bid - 1;;) {
+        const unsigned long long dsc = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long fl = dsc >> 62;
+        if (fl == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        before += dsc & VM;
+        if (fl == 2) break;
+        --j;
+      }
+      __hip_atomic_store(&desc[bid], (2ULL << 62) | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_base = before;
+    if ((uint64_t)(bid + 1) * SEL_TB >= nfrag) aln_off[nfrag] = before + total;   // the block of the last fragments closes the offsets
+  }
+  __syncthreads();
+  if (act) {
+    const uint64_t at = s_base + woff + (incl - na);
+    aln_off[f] = at;
+    sq_aln* out = aln_out + at;
+    for (uint32_t j = 0; j < na; ++j) out[j] = j < SEL_KW ? make_aln(s_widx[j][tx], s_wsc[j][tx]) : aln_slots[c0 + j];
+  }
   // seven counters: summed per block in LDS, one atomic per counter and block (see block_stat_add)
   __shared__ unsigned long long s_st[7];
   if (threadIdx.x < 7) s_st[threadIdx.x] = 0;
@@ -1658,18 +1719,6 @@ __global__ void k_select(sq_map_params P, uint32_t nfrag, uint32_t paired, const
                       : threadIdx.x == 4 ? ST_MAPPED : threadIdx.x == 5 ? ST_JOINT : ST_DOVETAIL;
     atomicAdd(&stats[which], s_st[threadIdx.x]);
   }
-}
-
-// [r2] a thread per candidate slot (k_select left alignment i of fragment f in slot cand_off[f] + i): neighbouring threads read neighbouring
-// slots and write neighbouring records.  (A thread per fragment copied its records one after the other with 8-byte accesses 40 bytes
-// apart from its neighbours': 82 % of the wave cycles were issue stalls.)
-__global__ void k_compact_alns(uint64_t ncand, const uint32_t* __restrict__ cand_frag, const uint64_t* __restrict__ cand_off,
-    const uint64_t* __restrict__ aln_off, const uint32_t* __restrict__ n_aln, const sq_aln* __restrict__ slots, sq_aln* __restrict__ out) {
-  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ncand) return;
-  const uint32_t f = cand_frag[s];
-  const uint64_t i = s - cand_off[f];
-  if (i < n_aln[f]) out[aln_off[f] + i] = slots[s];
 }
 
 __global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains,

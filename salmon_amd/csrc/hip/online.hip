@@ -1907,6 +1907,13 @@ int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out) {
 }
 
 // eq == NULL: optimise over the ctx's own accumulated classes, straight from the export that already sits in HBM
+// [r5] measurement switch, removed once decided: which stream the optimiser runs on (0: the unmasked stream3, 1: the mapping stream the export ran on, 2: the eq stream)
+static void* em_stream_of(sq_ctx* c) {
+  static const int which = getenv("SQ_EM_STREAM") ? atoi(getenv("SQ_EM_STREAM")) : 0;
+  if (which == 1) return (void*)c->stream;
+  if (which == 2) return (void*)c->stream2;
+  return (void*)(c->stream3 ? c->stream3 : c->stream2);
+}
 extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out,
     sq_em_report* rep) {
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
@@ -1914,7 +1921,7 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
+  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, em_stream_of(c));   // the eq stage's streams are idle after the export
 }
 
 extern "C" int sq_em_optimize_bias(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, sq_efflen_cb cb, void* user,
@@ -1923,7 +1930,7 @@ extern "C" int sq_em_optimize_bias(sq_ctx* c, const sq_eq_table* eq, const sq_tx
   if (eq) return sq_em_optimize_bias_impl(c->device, eq, nullptr, txp, o, cb, user, alpha_out, eff_len_out, rep, nullptr, nullptr);
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize_bias: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  return sq_em_optimize_bias_impl(c->device, nullptr, &dv, txp, o, cb, user, alpha_out, eff_len_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));
+  return sq_em_optimize_bias_impl(c->device, nullptr, &dv, txp, o, cb, user, alpha_out, eff_len_out, rep, &c->em_arena, em_stream_of(c));
 }
 
 // Pre-size everything the end of a job allocates — the device buffers and the page-locked staging area of the eq-class

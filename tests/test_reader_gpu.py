@@ -72,6 +72,22 @@ def test_device_batches_equal_host_batches(built, tmp_path):
     e1 = str(tmp_path / "ex_1.fq"); _write(e1, r1[:20000]); open(e1, "ab").write(b"\n"); cases.append(("single-end, k * batch records + a blank line", [e1], None, 5000))
     e2 = str(tmp_path / "ex_2.fq"); _write(e2, r2[:20000]); open(e2, "ab").write(b"\n\n\n"); cases.append(("paired, k * batch records + blank lines", [e1], [e2], 10000))
     c1 = str(tmp_path / "ec_1.fq"); _write(c1, r1[:20000], eol="\r\n"); open(c1, "ab").write(b"\r\n\r\n"); cases.append(("CR LF, k * batch records + blank lines", [c1], None, 4000))
+    # [r5] gzip / BGZF files take the device path too (inflated by the reader's pool into the ring, split on the device): a plain gzip stream big enough for
+    # the parallel inflater, a multi-member BGZF file, several files per mate, a last line without its newline
+    import gzip
+    from test_reader import _bgzf_write
+    z1, z2 = str(tmp_path / "z_1.fq.gz"), str(tmp_path / "z_2.fq.gz"); open(z1, "wb").write(gzip.compress(open(f1, "rb").read(), 6)); open(z2, "wb").write(gzip.compress(open(g2, "rb").read().replace(b"\r\n", b"\n"), 1))
+    cases.append(("gzip", [z1], [z2], 5000))
+    y1, y2 = str(tmp_path / "y_1.fq.gz"), str(tmp_path / "y_2.fq.gz"); _bgzf_write(y1, open(f1, "rb").read()); _bgzf_write(y2, open(f2, "rb").read(), block=30011)
+    cases.append(("BGZF", [y1], [y2], 7001)); cases.append(("BGZF single-end, one batch", [y1], None, 30000))
+    hz = []
+    for k in range(3):
+        for m in (1, 2):
+            zp = str(tmp_path / ("mz%d_%d.fq.gz" % (k, m))); raw = open(h[2 * k + (m - 1)], "rb").read()
+            if k == 1: _bgzf_write(zp, raw)
+            else: open(zp, "wb").write(gzip.compress(raw, 4))
+            hz.append(zp)
+    cases.append(("three compressed files per mate (gzip, BGZF, gzip)", hz[0::2], hz[1::2], 4096))
     for name, a, b, batch in cases:
         dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
         assert all(d[1] for d in dev) and not any(x[1] for x in host), name          # the device path really ran, the host path really did not
