@@ -13,7 +13,8 @@
 // GPU result is bit-identical run to run and to the CPU checker.  Memory-bound gather/stream:
 // per iteration 36·L + 16·E + 64·M algorithmic bytes.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -742,9 +743,9 @@ struct EmSession {
     if (L) {
       k_prep_keys<<<nb(E), TB, 0, st>>>(E, p_off, p_tid, key.p, val.p);
       int tbits = 1; while ((1ull << tbits) < M) ++tbits;
-      size_t tb = 0; hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st);
+      size_t tb = 0; (void)rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, val.p, val2.p, (size_t)L, 0u, (unsigned)(32 + tbits), st);
       if (tmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (sort)"); return SQ_ERR_NOMEM; }
-      SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, key2.p, val.p, val2.p, (int)L, 0, 32 + tbits, st));
+      SQ_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, key.p, key2.p, val.p, val2.p, (size_t)L, 0u, (unsigned)(32 + tbits), st));
       k_prep_csc<<<nb(L), TB, 0, st>>>(L, M, key2.p, val2.p, d_cw.p, d_tcls.p, d_tcw.p, d_toff.p);
       if (keep_cscpos) { if (d_cscpos.alloc(L)) { sq_set_error("device allocation failed in EM (CSC positions)"); return SQ_ERR_NOMEM; }
         SQ_HIP_CHECK(hipMemcpyAsync(d_cscpos.p, val2.p, L * 4, hipMemcpyDeviceToDevice, st)); }
@@ -752,11 +753,11 @@ struct EmSession {
     }
     // blocked-64 plan: per-transcript segment counts, exclusive scans, fill
     k_plan_counts<<<nb((uint64_t)M + 1), TB, 0, st>>>(M, d_toff.p, ns[0].p, ns[1].p, ns[2].p, ns[3].p, d_err.p);
-    { size_t tb = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ns[0].p, base[0].p, (int)(M + 1), st);
+    { size_t tb = 0; (void)rocprim::exclusive_scan(nullptr, tb, ns[0].p, base[0].p, 0u, (size_t)M + 1, rocprim::plus<uint32_t>(), st);
       DBuf<uint8_t> stmp; if (stmp.alloc(tb + 256)) { sq_set_error("device allocation failed in EM (scan)"); return SQ_ERR_NOMEM; }
       for (int l = 0; l < 4; ++l) {
         size_t t2 = tb + 256;
-        SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(stmp.p, t2, ns[l].p, base[l].p, (int)(M + 1), st));
+        SQ_HIP_CHECK(rocprim::exclusive_scan(stmp.p, t2, ns[l].p, base[l].p, 0u, (size_t)M + 1, rocprim::plus<uint32_t>(), st));
       }
       uint32_t S[4] = {0, 0, 0, 0}, herr = 0;
       for (int l = 0; l < 4; ++l) SQ_HIP_CHECK(hipMemcpyAsync(&S[l], base[l].p + M, 4, hipMemcpyDeviceToHost, st));

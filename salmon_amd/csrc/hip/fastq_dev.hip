@@ -111,7 +111,7 @@ struct sq_dev_reader {
   // A stream with such a file is SEQUENTIAL: its size is known only at its end (vsize stays at its maximum until then), the stager asks for the text up
   // to an offset (seq_ensure) before the round's pieces are filled from the buffers (vread_seq), and buffers behind the batch cut are let go (seq_trim).
   struct SeqFile {
-    std::string path; std::shared_ptr<sqio::Mapping> map; std::unique_ptr<sqio::BgzfSource> bg; PgzStream* pz = nullptr;
+    std::string path; std::shared_ptr<sqio::Mapping> map; std::unique_ptr<sqio::BgzfSource> bg; PgzStream* pz = nullptr; bool is_bgzf = false;
     ~SeqFile() { if (pz) pgz_close(pz); bg.reset(); }
     int next(PgzBuf* B, std::string* e) {
       if (bg) { const int rc = bg->next_buf(B); if (rc < 0) *e = bg->err; return rc; }
@@ -120,8 +120,12 @@ struct sq_dev_reader {
   };
   struct SeqChunk { uint64_t voff; PgzBuf b; };
   struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; std::string name;   // name: the last file, for messages
+    // BGZF files only (bgz): no buffers in between — the members of a round are inflated straight into its ring pieces.  mem: every non-empty member
+    // scanned so far, with the offset of its text in the stream (file = ~0u: the newline a file without a last one gets)
+    bool bgz = false; struct BzMember { uint32_t file; uint32_t csize; uint64_t coff; uint32_t isize; uint64_t voff; }; std::vector<BzMember> mem; size_t scan_file = 0; uint64_t scan_off = 0, scan_voff = 0, scan_file_bytes = 0; bool scan_done = false;
     bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
-  std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the sequential streams
+  std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the buffered sequential streams
+  bool any_buffered = false, any_bgz = false;
   struct Slot {   // device side only: the text of a batch never sits in host memory as a whole
     void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
     void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
@@ -148,7 +152,7 @@ struct sq_dev_reader {
   // stager -> (rounds) -> uploader -> (ready) -> consumer -> (free_slots) -> stager
   std::thread prod, prod2; std::mutex mu; std::condition_variable cv; std::deque<int> ready, free_slots; std::deque<Round> rounds; bool stop = false, done = false;
   std::string err; int err_rc = SQ_OK; uint64_t total = 0, staged_total = 0;
-  double t_stage = 0, t_upload = 0, t_wait_piece = 0, t_wait_text = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
+  double t_stage = 0, t_upload = 0, t_wait_piece = 0, t_wait_text = 0, t_fill = 0; uint64_t text_bytes = 0;   // SQ_READER_STATS=1 prints them at close
 
   static int dev_grow(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
@@ -164,6 +168,50 @@ struct sq_dev_reader {
     if (*p && keep && (hipMemcpyAsync(nb, *p, keep, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { (void)hipFree(nb); return -1; }
     if (*p) (void)hipFree(*p);
     *p = nb; *cap = c; return 0;
+  }
+  // [r5] BGZF streams: the member table reaches `upto`, or the stream's end (then vsize is its size).  A member names its compressed size in its header and
+  // its text size in its trailer: the scan hops from member to member and inflates nothing — but the last member of a file, once, for its last byte.
+  bool bz_scan(Stream& S, uint64_t upto, std::string* e) {
+    using sqio::BgzfSource;
+    while (!S.scan_done && S.scan_voff < upto) {
+      if (S.scan_file == S.sfiles.size()) { S.scan_done = true; S.final_ = true; S.vsize = S.scan_voff; break; }
+      SeqFile& F = *S.sfiles[S.scan_file]; const uint8_t* base = (const uint8_t*)F.map->p; const size_t n = F.map->n;
+      if (S.scan_off >= n) {   // the end of a file: a last line without its newline gets one
+        if (S.scan_file_bytes) {
+          size_t j = S.mem.size(); while (j > 0 && (S.mem[j - 1].file != (uint32_t)S.scan_file || !S.mem[j - 1].isize)) --j;
+          if (j > 0) { const Stream::BzMember& M = S.mem[j - 1]; std::vector<char> tmp((size_t)M.isize + 64);
+            const char* w = BgzfSource::inflate_member(base + M.coff, BgzfSource::Mem{(size_t)M.coff, (size_t)M.csize, M.isize, 0}, tmp.data());
+            if (*w) { *e = "'" + F.path + "': " + w; return false; }
+            if (tmp[M.isize - 1] != '\n') { S.mem.push_back(Stream::BzMember{~0u, 0, 0, 1, S.scan_voff}); S.scan_voff += 1; } }
+        }
+        ++S.scan_file; S.scan_off = 0; S.scan_file_bytes = 0; continue;
+      }
+      const size_t ms = BgzfSource::member_size(base + S.scan_off, n - S.scan_off);
+      if (ms == 0 || ms > n - S.scan_off || ms < 26) { *e = "'" + F.path + "': " + (ms ? "truncated BGZF member" : "not a BGZF member (mixed gzip file?)"); return false; }
+      const uint32_t isize = BgzfSource::le32(base + S.scan_off + ms - 4);
+      if (isize > (1u << 16)) { *e = "'" + F.path + "': BGZF member larger than 64 KB"; return false; }
+      if (isize) { S.mem.push_back(Stream::BzMember{(uint32_t)S.scan_file, (uint32_t)ms, S.scan_off, isize, S.scan_voff}); S.scan_voff += isize; S.scan_file_bytes += isize; }
+      S.scan_off += ms;
+    }
+    return true;
+  }
+  // members [m0, m1) of the stream into dst, the first one from byte `skip` of its text.  The inflater may write up to 32 bytes past a member's text: inside a
+  // run that is the next member's place (inflated afterwards), but the last member of the run — the neighbour is another task's — and a member entered
+  // in its middle go through a buffer of the thread's own
+  bool bz_fill(const Stream& S, size_t m0, size_t m1, uint32_t skip, char* dst, std::string* e) const {
+    using sqio::BgzfSource;
+    static thread_local std::vector<char> tmp((1u << 16) + 64);
+    for (size_t j = m0; j < m1; ++j) {
+      const Stream::BzMember& M = S.mem[j]; const uint32_t sk = j == m0 ? skip : 0;
+      if (M.file == ~0u) { *dst++ = '\n'; continue; }
+      const SeqFile& F = *S.sfiles[M.file]; const uint8_t* base = (const uint8_t*)F.map->p;
+      const bool direct = sk == 0 && j + 1 < m1;
+      const char* w = BgzfSource::inflate_member(base + M.coff, BgzfSource::Mem{(size_t)M.coff, (size_t)M.csize, M.isize, 0}, direct ? dst : tmp.data());
+      if (*w) { *e = "'" + F.path + "': " + w; return false; }
+      if (!direct) memcpy(dst, tmp.data() + sk, M.isize - sk);
+      dst += M.isize - sk;
+    }
+    return true;
   }
   // [r5] sequential streams: the text up to `upto` is in the window, or the stream is at its end (then vsize is its size)
   bool seq_ensure(Stream& S, uint64_t upto, std::string* e) {
@@ -217,23 +265,53 @@ struct sq_dev_reader {
     const uint64_t need_lines = 4ull * want; uint64_t lines = 0; size_t have = 0; bool reached = false, first = first_of_batch; char last2[2] = {'X', '\n'};
     while (!reached && S.vpos + have < S.vsize) {
       const uint64_t missing = (need_lines - lines + 3) / 4;
-      if (S.seq) {   // the text this round may take is inflated (or the end of the stream is known) before its pieces are filled
+      const uint64_t want_more = std::min<uint64_t>((uint64_t)((double)missing * S.est * 1.03) + (1u << 20), (uint64_t)ROUND_PIECES * PIECE);
+      if (S.seq) {   // the text this round may take is inflated (bgz: its members are known) — or the end of the stream is — before its pieces are filled
         const double t0 = now();
-        if (!seq_ensure(S, S.vpos + have + std::min<uint64_t>((uint64_t)((double)missing * S.est * 1.03) + (1u << 20), (uint64_t)ROUND_PIECES * PIECE) + 1, e)) return false;   // + 1: whether the stream ends with this round must be known in this round
+        if (!(S.bgz ? bz_scan(S, S.vpos + have + want_more + 1, e) : seq_ensure(S, S.vpos + have + want_more + 1, e))) return false;   // + 1: whether the stream ends with this round must be known in this round
         t_wait_text += now() - t0;
         if (S.vpos + have >= S.vsize) break;
       }
-      const size_t more = (size_t)std::min<uint64_t>(std::min<uint64_t>(S.vsize - S.vpos - have, (uint64_t)((double)missing * S.est * 1.03) + (1u << 20)), (uint64_t)ROUND_PIECES * PIECE);
-      const unsigned np = (unsigned)((more + PIECE - 1) / PIECE);
+      const size_t more = (size_t)std::min<uint64_t>(S.vsize - S.vpos - have, want_more);
       Round r; r.slot = si; r.mate = i; r.dst = have; r.first_of_batch = first; first = false;
+      const uint64_t v0 = S.vpos + have;
+      // what goes where.  Plain files and buffered streams: pieces of PIECE bytes, a task each.  BGZF: whole members, as many as fit a piece (64 bytes
+      // stay free behind them for the inflater), in tasks of about 1 MB of text so that a round keeps the whole pool busy
+      struct Task { unsigned piece; size_t at; size_t m0, m1; uint32_t skip; };
+      std::vector<Task> tasks; std::vector<size_t> fill;
+      if (S.bgz) {
+        size_t lo = 0, hi = S.mem.size();   // the member that holds v0
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (S.mem[mid].voff <= v0) lo = mid; else hi = mid; }
+        size_t mi = lo; uint32_t skip = (uint32_t)(v0 - S.mem[mi].voff); size_t planned = 0;
+        while (planned < more && mi < S.mem.size() && fill.size() < (size_t)ROUND_PIECES) {
+          size_t f = 0; Task t{(unsigned)fill.size(), 0, mi, mi, skip}; size_t tb = 0;
+          while (planned < more && mi < S.mem.size() && f + (S.mem[mi].isize - skip) + 64 <= PIECE) {
+            const size_t b = S.mem[mi].isize - skip; f += b; tb += b; planned += b; skip = 0; ++mi; t.m1 = mi;
+            if (tb >= (1u << 20)) { tasks.push_back(t); t = Task{(unsigned)fill.size(), f, mi, mi, 0}; tb = 0; }
+          }
+          if (t.m1 > t.m0) tasks.push_back(t);
+          fill.push_back(f);
+        }
+      } else {
+        const unsigned npp = (unsigned)((more + PIECE - 1) / PIECE);
+        for (unsigned k = 0; k < npp; ++k) { fill.push_back(std::min(PIECE, more - (size_t)k * PIECE)); tasks.push_back(Task{k, 0, 0, 0, 0}); }
+      }
+      const unsigned np = (unsigned)fill.size();
       { const double t0 = now(); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || free_pieces.size() >= np; }); if (stop) return false;
-        for (unsigned k = 0; k < np; ++k) { r.pieces.push_back({free_pieces.front(), std::min(PIECE, more - (size_t)k * PIECE)}); free_pieces.pop_front(); } t_wait_piece += now() - t0; }
-      std::vector<uint64_t> cnt(np, 0); std::vector<std::string> errs(np); const uint64_t v0 = S.vpos + have;
-      pool->run(np, [&](unsigned k) {
-        char* dst = ring + (size_t)r.pieces[k].first * PIECE;
-        if (!vread(S, v0 + (size_t)k * PIECE, r.pieces[k].second, dst, &errs[k])) return;
-        cnt[k] = count_nl(dst, r.pieces[k].second);
+        for (unsigned k = 0; k < np; ++k) { r.pieces.push_back({free_pieces.front(), fill[k]}); free_pieces.pop_front(); } t_wait_piece += now() - t0; }
+      std::vector<uint64_t> tcnt(tasks.size(), 0); std::vector<std::string> terrs(tasks.size());
+      { const double t0 = now();
+      pool->run((unsigned)tasks.size(), [&](unsigned q) {
+        const Task& t = tasks[q]; char* dst = ring + (size_t)r.pieces[t.piece].first * PIECE + t.at;
+        if (S.bgz) { size_t nb = 0; for (size_t j = t.m0; j < t.m1; ++j) nb += S.mem[j].isize; nb -= t.skip;
+          if (!bz_fill(S, t.m0, t.m1, t.skip, dst, &terrs[q])) return;
+          tcnt[q] = count_nl(dst, nb); }
+        else { if (!vread(S, v0 + (size_t)t.piece * PIECE, r.pieces[t.piece].second, dst, &terrs[q])) return;
+          tcnt[q] = count_nl(dst, r.pieces[t.piece].second); }
       });
+      t_fill += now() - t0; }
+      std::vector<uint64_t> cnt(np, 0); std::vector<std::string> errs(np);
+      for (size_t q = 0; q < tasks.size(); ++q) { cnt[tasks[q].piece] += tcnt[q]; if (!terrs[q].empty() && errs[tasks[q].piece].empty()) errs[tasks[q].piece] = terrs[q]; }
       for (unsigned k = 0; k < np; ++k) if (!errs[k].empty()) { *e = errs[k]; give_back(r.pieces); return false; }
       size_t emitted = 0;
       for (unsigned k = 0; k < np; ++k) {
@@ -393,6 +471,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
         if (m == MAP_FAILED) { sq_set_error("cannot map '%s'", path.c_str()); return SQ_ERR_IO; }
         F->map = std::make_shared<sqio::Mapping>(); F->map->p = m; F->map->n = (size_t)sb.st_size; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
         if (sqio::BgzfSource::member_size((const uint8_t*)m, (size_t)sb.st_size)) {
+          F->is_bgzf = true;
           F->bg.reset(new sqio::BgzfSource()); F->bg->map = F->map; F->bg->base = (const uint8_t*)m; F->bg->n = (size_t)sb.st_size; F->bg->pool = zp; F->bg->path = path;
           F->bg->window = std::max<size_t>(8, (size_t)(2 * nz) / (size_t)nstreams);
         } else {
@@ -403,6 +482,9 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
         }
         S.sfiles.push_back(std::move(F)); S.name = path;
       }
+      S.bgz = true; for (auto& F : S.sfiles) if (!F->is_bgzf) S.bgz = false;
+      if (S.bgz) { for (auto& F : S.sfiles) F->bg.reset(); R->any_bgz = true; }   // the members go straight into the ring (bz_scan / bz_fill): no buffering source
+      else R->any_buffered = true;
     }
   } else
   for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
@@ -420,7 +502,10 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   for (auto& s : R->slots) if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError(); for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd); return SQ_ERR_DEVICE; }
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
-  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4));
+  if (!R->any_buffered) R->zpool.reset();
+  // plain files: a few threads move bytes; BGZF: the same pool inflates, so it gets what the buffered streams' pool would have had
+  const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS"))
+                      : (R->any_bgz ? std::min(64u, std::max(2u, std::thread::hardware_concurrency() / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
   R->pool.reset(new Workers(std::max(1u, nt)));
   if (hipHostMalloc((void**)&R->ring, (size_t)sq_dev_reader::RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError(); R->ring = nullptr; for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd);
@@ -447,8 +532,8 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
   if (R->prod.joinable()) R->prod.join();
   if (R->prod2.joinable()) R->prod2.join();
-  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
-      (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_wait_text, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
+  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text / member scans, %.3f s filling the pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
+      (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_wait_text, R->t_fill, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
   R->pool.reset(); (void)hipSetDevice(R->device);
   for (auto& m : R->sm) { m.win.clear(); m.sfiles.clear(); }   // the sources' tasks run on zpool: they go first
   R->zpool.reset();

@@ -4,7 +4,8 @@
 #include "map_kernels.h"
 #include "mem_kernels.h"
 #include "scan_kernels.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cstring>
 
@@ -539,10 +540,10 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
         c->n_uni.p, c->mkey.p, c->mval.p);
     int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
     size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (int)memsL, 0, 40 + endbits, st);
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (size_t)memsL, 0u, (unsigned)(40 + endbits), st);
     if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = c->sort_tmp.n;
-    SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (int)memsL, 0, 40 + endbits, st));
+    SQ_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (size_t)memsL, 0u, (unsigned)(40 + endbits), st));
     k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->mem_off.p, skey, sval);
     {   // [r4] flat passes over the sorted compact records (mem_kernels.h: k_lg_*); cf / cp / mused are indexed by compact record here
       if (c->lg_a.ensure(LP) || c->lg_b.ensure(LP) || c->lg_c.ensure(LP) || c->lg_d.ensure(LP) || c->lg_flags.ensure(LP) || c->lg_first.ensure((size_t)nrec + 8) || c->lg_cnt.ensure(8)) {
@@ -552,29 +553,29 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
       k_lg_flags<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->lg_flags.p, se_in, gbest, ebest, c->n_chains.p);
       auto tmp_for = [&](size_t need) -> int { if (c->sort_tmp.ensure(need + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; } return SQ_OK; };
       size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-      hipcub::CountingInputIterator<uint32_t> cnt_it(0u);
-      hipcub::TransformInputIterator<uint8_t, LgIsCluster, const uint8_t*> cl_it(c->lg_flags.p, LgIsCluster());
-      (void)hipcub::DeviceScan::InclusiveScan(nullptr, t1, se_in, se, LgMaxPair(), (int)memsL, st);
-      (void)hipcub::DeviceSelect::Flagged(nullptr, t2, cnt_it, cl_it, cl_start, c->lg_cnt.p, (int)memsL, st);
-      (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, c->lg_a.p, c->lg_b.p, c->lg_d.p, c->lg_c.p, (int)memsL, 0, 64, st);
-      (void)hipcub::DeviceSelect::Flagged(nullptr, t4, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (int)memsL, st);
+      rocprim::counting_iterator<uint32_t> cnt_it(0u);
+      rocprim::transform_iterator<const uint8_t*, LgIsCluster, uint8_t> cl_it(c->lg_flags.p, LgIsCluster());
+      (void)rocprim::inclusive_scan(nullptr, t1, se_in, se, (size_t)memsL, LgMaxPair(), st);
+      (void)rocprim::select(nullptr, t2, cnt_it, cl_it, cl_start, c->lg_cnt.p, (size_t)memsL, st);
+      (void)rocprim::radix_sort_pairs(nullptr, t3, c->lg_a.p, c->lg_b.p, c->lg_d.p, c->lg_c.p, (size_t)memsL, 0u, 64u, st);
+      (void)rocprim::select(nullptr, t4, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (size_t)memsL, st);
       if (int rc = tmp_for(std::max(std::max(t1, t2), std::max(t3, t4)))) return rc;
       size_t tb = c->sort_tmp.n;
-      SQ_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->sort_tmp.p, tb, se_in, se, LgMaxPair(), (int)memsL, st));
-      tb = c->sort_tmp.n; SQ_HIP_CHECK(hipcub::DeviceSelect::Flagged(c->sort_tmp.p, tb, cnt_it, cl_it, cl_start, c->lg_cnt.p, (int)memsL, st));
+      SQ_HIP_CHECK(rocprim::inclusive_scan(c->sort_tmp.p, tb, se_in, se, (size_t)memsL, LgMaxPair(), st));
+      tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::select(c->sort_tmp.p, tb, cnt_it, cl_it, cl_start, c->lg_cnt.p, (size_t)memsL, st));
       k_lg_dp<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, c->lkey.p, c->lval.p, se, P, c->gapcost.p, c->cf.p, c->cp.p, c->mused.p, gbest);
       k_lg_accept<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, se, P, c->cf.p, c->cp.p, c->mused.p, gbest, ebest);
       k_lg_keep<<<nblk(memsL), TB, 0, st>>>(memsL, se, P, c->cf.p, c->mused.p, ebest, c->lg_flags.p);
-      tb = c->sort_tmp.n; SQ_HIP_CHECK(hipcub::DeviceSelect::Flagged(c->sort_tmp.p, tb, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (int)memsL, st));
+      tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::select(c->sort_tmp.p, tb, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (size_t)memsL, st));
       uint32_t nkept = 0;
       SQ_HIP_CHECK(hipMemcpyAsync(&nkept, c->lg_cnt.p + 1, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
       if (nkept) {
         int tbits = 1; while ((1ull << tbits) < (uint64_t)di->num_refs) ++tbits;
         // by score (descending; the sort is stable, so equal scores stay in index order), then by (end, transcript): k_chain's output order
         k_lg_key_score<<<nblk(nkept), TB, 0, st>>>(nkept, c->lg_d.p, c->cf.p, c->lg_a.p);
-        tb = c->sort_tmp.n; SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tb, c->lg_a.p, c->lg_b.p, c->lg_d.p, c->lg_c.p, (int)nkept, 0, 64, st));
+        tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, tb, c->lg_a.p, c->lg_b.p, c->lg_d.p, c->lg_c.p, (size_t)nkept, 0u, 64u, st));
         k_lg_key_group<<<nblk(nkept), TB, 0, st>>>(nkept, c->lg_c.p, c->lkey.p, c->lval.p, tbits, c->lg_a.p);
-        tb = c->sort_tmp.n; SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tb, c->lg_a.p, c->lg_b.p, c->lg_c.p, c->lg_d.p, (int)nkept, 0, std::min(64, endbits + tbits), st));
+        tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, tb, c->lg_a.p, c->lg_b.p, c->lg_c.p, c->lg_d.p, (size_t)nkept, 0u, (unsigned)std::min(64, endbits + tbits), st));
         k_lg_first<<<nblk(nkept), TB, 0, st>>>(nkept, c->lg_b.p, tbits, c->lg_first.p);
         k_lg_write<<<nblk(nkept), TB, 0, st>>>(nkept, c->lg_b.p, tbits, c->lg_d.p, c->lg_first.p, c->lkey.p, c->lval.p, se, di->ref_accum, c->rlen.p, c->mem_off.p,
             c->cf.p, c->cp.p, c->mnext.p, c->chains.p, c->n_chains.p);

@@ -1125,7 +1125,8 @@ EqView make_eq_view(sq_online_dev* o) {
 double phi(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
 }  // namespace
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 int sq_online_create(sq_ctx* c) {
   sq_online_dev* o = new sq_online_dev(); c->online = o;
@@ -1741,13 +1742,13 @@ static int eq_export_run(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemsetAsync(X.d_ctr.p, 0, 8, st)); SQ_HIP_CHECK(hipMemsetAsync(X.d_tie.p, 0, 4, st));
   k_eq_collect<<<nblk(T.cap), TB, 0, st>>>(T, X.keys.p, X.slots.p, X.d_ctr.p);
   size_t tb = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (int)E, 0, 64, st);
-  size_t tb2 = 0; hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st);
+  (void)rocprim::radix_sort_pairs(nullptr, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (size_t)E, 0u, 64u, st);
+  size_t tb2 = 0; (void)rocprim::exclusive_scan(nullptr, tb2, X.nlab.p, X.d_off.p, (uint64_t)0, (size_t)E + 1, rocprim::plus<uint64_t>(), st);
   if (X.tmp.ensure(std::max(tb, tb2) + 256)) { sq_set_error("device allocation failed (eq export temp)"); return SQ_ERR_NOMEM; }
   tb = X.tmp.n;
-  SQ_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(X.tmp.p, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (int)E, 0, 64, st));
+  SQ_HIP_CHECK(rocprim::radix_sort_pairs(X.tmp.p, tb, X.keys.p, X.keys2.p, X.slots.p, X.slots2.p, (size_t)E, 0u, 64u, st));
   k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, X.slots2.p, X.keys2.p, X.nlab.p, X.d_tie.p);
-  tb2 = X.tmp.n; SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st));
+  tb2 = X.tmp.n; SQ_HIP_CHECK(rocprim::exclusive_scan(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (uint64_t)0, (size_t)E + 1, rocprim::plus<uint64_t>(), st));
   uint32_t tie = 0; SQ_HIP_CHECK(hipMemcpyAsync(&tie, X.d_tie.p, 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(hipStreamSynchronize(st));
   if (tie) {  // two classes share a sort key and arrived out of (h1,h2) order: re-sort the slot list on the host (rare)
     std::vector<uint32_t> hs(E), ord(E); std::vector<unsigned long long> hk(E), k1(o->tcap), k2(o->tcap);
@@ -1761,7 +1762,7 @@ static int eq_export_run(sq_ctx* c) {
     std::vector<uint32_t> hs2(E); for (uint64_t i = 0; i < E; ++i) hs2[i] = hs[ord[i]];
     SQ_HIP_CHECK(hipMemcpy(X.slots2.p, hs2.data(), E * 4, hipMemcpyHostToDevice));
     k_eq_sizes<<<nblk(E + 1), TB, 0, st>>>(T, E, X.slots2.p, X.keys2.p, X.nlab.p, X.d_tie.p);
-    SQ_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (int)(E + 1), st));
+    SQ_HIP_CHECK(rocprim::exclusive_scan(X.tmp.p, tb2, X.nlab.p, X.d_off.p, (uint64_t)0, (size_t)E + 1, rocprim::plus<uint64_t>(), st));
   }
   k_eq_gather<<<nblk(E), TB, 0, st>>>(T, E, X.slots2.p, X.d_off.p, X.d_tid.p, X.d_w.p, X.d_wq.p, X.d_cnt.p, X.d_bins.p, X.d_h1.p, X.d_h2.p);
   // staging layout: off[E+1] | count[E] | h1[E] | h2[E] | wq[L] | w[L] | tid[L] | bins[L]
@@ -1907,13 +1908,6 @@ int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out) {
 }
 
 // eq == NULL: optimise over the ctx's own accumulated classes, straight from the export that already sits in HBM
-// [r5] measurement switch, removed once decided: which stream the optimiser runs on (0: the unmasked stream3, 1: the mapping stream the export ran on, 2: the eq stream)
-static void* em_stream_of(sq_ctx* c) {
-  static const int which = getenv("SQ_EM_STREAM") ? atoi(getenv("SQ_EM_STREAM")) : 0;
-  if (which == 1) return (void*)c->stream;
-  if (which == 2) return (void*)c->stream2;
-  return (void*)(c->stream3 ? c->stream3 : c->stream2);
-}
 extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, double* alpha_out,
     sq_em_report* rep) {
   if (!c) { sq_set_error("sq_em_optimize: null ctx"); return SQ_ERR_ARG; }
@@ -1921,7 +1915,7 @@ extern "C" int sq_em_optimize(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in*
   if (!txp || !o || !alpha_out || !txp->eff_len) { sq_set_error("sq_em_optimize: bad arguments"); return SQ_ERR_ARG; }
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, em_stream_of(c));   // the eq stage's streams are idle after the export
+  return sq_em_optimize_impl(c->device, nullptr, &dv, txp, o, alpha_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));   // the eq stage's streams are idle after the export
 }
 
 extern "C" int sq_em_optimize_bias(sq_ctx* c, const sq_eq_table* eq, const sq_txp_in* txp, const sq_em_opts* o, sq_efflen_cb cb, void* user,
@@ -1930,7 +1924,7 @@ extern "C" int sq_em_optimize_bias(sq_ctx* c, const sq_eq_table* eq, const sq_tx
   if (eq) return sq_em_optimize_bias_impl(c->device, eq, nullptr, txp, o, cb, user, alpha_out, eff_len_out, rep, nullptr, nullptr);
   sq_eq_dev_csr dv; int rc = sq_eq_export_dev(c, &dv); if (rc) return rc;
   if (dv.E == 0) { sq_set_error("sq_em_optimize_bias: the ctx holds no equivalence classes"); return SQ_ERR_STATE; }
-  return sq_em_optimize_bias_impl(c->device, nullptr, &dv, txp, o, cb, user, alpha_out, eff_len_out, rep, &c->em_arena, em_stream_of(c));
+  return sq_em_optimize_bias_impl(c->device, nullptr, &dv, txp, o, cb, user, alpha_out, eff_len_out, rep, &c->em_arena, (void*)(c->stream3 ? c->stream3 : c->stream2));
 }
 
 // Pre-size everything the end of a job allocates — the device buffers and the page-locked staging area of the eq-class

@@ -64,3 +64,22 @@ def test_strong_scaling_workload_splits_a_fixed_total_over_the_ranks(built):
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["job_pairs"] == 120000 and d["config"]["workload_id"] == "c3"
     assert d["breakdown"]["stats"]["num_reads"] == 120000 and d["breakdown"]["shared_prefix_pairs"] == 120000   # a job shorter than the burn-in is all prefix: every rank maps it, rank 0 keeps it
     assert abs(d["value"] - 120000 / (d["ms_per_step"] * 3e-3) / 1e6) < 0.01 * d["value"]
+
+
+@pytest.mark.gpu
+def test_batch_size_and_rank_count_move_the_result_by_less_than_1e_4(built):
+    """[r5] What "within 1e-4" can mean for this path (README): the online stage is deterministic here, and the two things a user of the library is free
+    to choose — how many pairs are handed over per call, and how many ranks share the job (shared burn-in prefix, SPEC §MG) — move NumReads and TPM by less than
+    1e-4 at the 99.9th percentile, with a class table that is bit for bit the one-rank table.  (W, the number of mini-batches per model snapshot, is NOT such a free
+    choice: it is fixed at 8 and documented, because it moves the result by more — the line's `spread` block quantifies it, as the reference's thread count does
+    for the reference.)  An 8 M-pair job in 2 M-pair batches, so that the burn-in ends inside the third batch and the rest is dealt out to the two ranks."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "2000000", "--genes", "6000", "--spread-pairs", "8000000",
+                        "--cpu-sample", "0", "--fastq-pairs", "0"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]); v = d["spread"]["variants"]
+    assert d["spread"]["pairs"] == 8000000 and "error" not in v["ranks_2"]
+    assert v["ranks_2"]["class_table_equals_one_rank_job"] is True and 0 < v["ranks_2"]["shared_prefix_batches"] < 8
+    for name in ("batch_1M", "ranks_2"):
+        for key in ("num_reads_ge_10", "tpm_ge_1"):
+            assert v[name][key]["p999"] <= 1e-4, (name, key, v[name][key])
+    assert v["W1"]["num_reads_ge_10"]["p999"] > v["batch_1M"]["num_reads_ge_10"]["p999"]      # the constant that does matter shows up in the same block
