@@ -141,7 +141,7 @@ struct sq_dev_reader {
   // costs ~0.2 s per GB, as much as reading it).  The stager fills a ROUND of up to ROUND_PIECES pieces at a time (parallel pread + newline
   // counts), finds where the batch ends, and hands the round to the uploader, which copies the pieces behind each other into the slot's text
   // buffer and gives them back; once a mate's text is complete its splitting kernels go out.
-  static constexpr size_t PIECE = 4u << 20; static constexpr int RING_PIECES = 64, ROUND_PIECES = 16;
+  static constexpr size_t PIECE = 4u << 20; int RING_PIECES = 64, ROUND_PIECES = 16;   // [r5] compressed input: 96 / 32 (a round is then 128 MB of text: ~500 tasks for the inflating pool)
   char* ring = nullptr; std::deque<int> free_pieces;
   struct Round {
     int slot = -1, mate = 0; std::vector<std::pair<int, size_t>> pieces;   // (ring piece, valid bytes)
@@ -276,7 +276,7 @@ struct sq_dev_reader {
       Round r; r.slot = si; r.mate = i; r.dst = have; r.first_of_batch = first; first = false;
       const uint64_t v0 = S.vpos + have;
       // what goes where.  Plain files and buffered streams: pieces of PIECE bytes, a task each.  BGZF: whole members, as many as fit a piece (64 bytes
-      // stay free behind them for the inflater), in tasks of about 1 MB of text so that a round keeps the whole pool busy
+      // stay free behind them for the inflater), in tasks of about 256 KB of text: a round is ~500 of them, which the pool's threads take as they come
       struct Task { unsigned piece; size_t at; size_t m0, m1; uint32_t skip; };
       std::vector<Task> tasks; std::vector<size_t> fill;
       if (S.bgz) {
@@ -287,7 +287,7 @@ struct sq_dev_reader {
           size_t f = 0; Task t{(unsigned)fill.size(), 0, mi, mi, skip}; size_t tb = 0;
           while (planned < more && mi < S.mem.size() && f + (S.mem[mi].isize - skip) + 64 <= PIECE) {
             const size_t b = S.mem[mi].isize - skip; f += b; tb += b; planned += b; skip = 0; ++mi; t.m1 = mi;
-            if (tb >= (1u << 20)) { tasks.push_back(t); t = Task{(unsigned)fill.size(), f, mi, mi, 0}; tb = 0; }
+            if (tb >= (256u << 10)) { tasks.push_back(t); t = Task{(unsigned)fill.size(), f, mi, mi, 0}; tb = 0; }
           }
           if (t.m1 > t.m0) tasks.push_back(t);
           fill.push_back(f);
@@ -457,7 +457,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   if (any_gz && any_plain) return SQ_ERR_DEVICE;   // a mix of compressed and plain files: the host path takes it
   if (any_gz) {   // [r5] compressed input: inflated by a pool of its own into buffers, copied into the ring, split on the device
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    const unsigned nz = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(64u, std::max(2u, hw / 2));
+    const unsigned nz = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(128u, std::max(2u, hw / 2));   // a plain gzip stream decodes at ~100 MB/s per thread in the two-pass scheme (host/pgzip.cpp): it takes many
     R->zpool.reset(new sqio::Pool(std::max(1u, nz)));
     sqio::Pool* zp = R->zpool.get();
     const int nstreams = R->paired ? 2 : 1;
@@ -475,7 +475,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
           F->bg.reset(new sqio::BgzfSource()); F->bg->map = F->map; F->bg->base = (const uint8_t*)m; F->bg->n = (size_t)sb.st_size; F->bg->pool = zp; F->bg->path = path;
           F->bg->window = std::max<size_t>(8, (size_t)(2 * nz) / (size_t)nstreams);
         } else {
-          const unsigned th = std::max(1u, std::min(32u, nz / (unsigned)nstreams));
+          const unsigned th = std::max(1u, std::min(64u, nz / (unsigned)nstreams));
           const size_t piece = std::max<size_t>(1u << 20, std::min<size_t>(4u << 20, (size_t)sb.st_size / (4 * th)));
           F->pz = pgz_open((const uint8_t*)m, (size_t)sb.st_size, [zp](std::function<void()> f) { zp->submit(std::move(f)); }, th, piece);
           if (!F->pz) { sq_set_error("'%s' does not start with a gzip member", path.c_str()); return SQ_ERR_IO; }
@@ -503,14 +503,16 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
     (void)hipGetLastError(); for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd); return SQ_ERR_DEVICE; }
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
   if (!R->any_buffered) R->zpool.reset();
+  if (any_gz) { R->RING_PIECES = 96; R->ROUND_PIECES = 32; }
+  const unsigned hw_all = std::max(2u, std::thread::hardware_concurrency());
   // plain files: a few threads move bytes; BGZF: the same pool inflates, so it gets what the buffered streams' pool would have had
   const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS"))
-                      : (R->any_bgz ? std::min(64u, std::max(2u, std::thread::hardware_concurrency() / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
+                      : (R->any_bgz ? std::min(128u, std::max(2u, hw_all / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
   R->pool.reset(new Workers(std::max(1u, nt)));
-  if (hipHostMalloc((void**)&R->ring, (size_t)sq_dev_reader::RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&R->ring, (size_t)R->RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError(); R->ring = nullptr; for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd);
-    sq_set_error("page-locked allocation failed (reader: %zu MB)", ((size_t)sq_dev_reader::RING_PIECES * sq_dev_reader::PIECE) >> 20); return SQ_ERR_NOMEM; }
-  for (int k = 0; k < sq_dev_reader::RING_PIECES; ++k) R->free_pieces.push_back(k);
+    sq_set_error("page-locked allocation failed (reader: %zu MB)", ((size_t)R->RING_PIECES * sq_dev_reader::PIECE) >> 20); return SQ_ERR_NOMEM; }
+  for (int k = 0; k < R->RING_PIECES; ++k) R->free_pieces.push_back(k);
   sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); });
   *out = r; return SQ_OK;
 }

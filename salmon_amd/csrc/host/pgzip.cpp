@@ -185,6 +185,11 @@ int inflate_block(Bits& br, Out& o, bool text_only, size_t max_out) {
     // [r4] 16 symbols per copy where the source lies at least that far back (in sequence data it nearly always does: a match is a piece of an earlier
     // record); the last copy may run up to 15 symbols past the match — into space the next symbols overwrite (the 300-symbol margin above covers it)
     if (d >= 16) { for (uint32_t i = 0; i < ln; i += 16) _mm256_storeu_si256((__m256i*)(dst + i), _mm256_loadu_si256((const __m256i*)(src + i))); }
+    else if (ln >= 24) {   // [r5] long match, short distance (see inflate_raw_bytes): the period over 16 symbols, stored at strides of the largest multiple of d that fits
+      alignas(32) uint16_t pat[16]; for (uint32_t i = 0; i < 16; ++i) pat[i] = src[i % d];
+      const __m256i pv = _mm256_load_si256((const __m256i*)pat); const uint32_t step = (16u / d) * d;
+      for (uint32_t i = 0; i < ln; i += step) _mm256_storeu_si256((__m256i*)(dst + i), pv);
+    }
     else
 #endif
     for (uint32_t i = 0; i < ln; ++i) dst[i] = src[i];
@@ -236,6 +241,14 @@ static long inflate_raw_bytes(const uint8_t* in, size_t n, char* dst, size_t cap
         char* o = dst + on; const char* src = o - d;
 #if defined(__AVX2__)
         if (d >= 32) { for (uint32_t i = 0; i < ln; i += 32) _mm256_storeu_si256((__m256i*)(o + i), _mm256_loadu_si256((const __m256i*)(src + i))); }
+        else if (ln >= 24) {
+          // [r5] a long match at a short distance — a run of one quality value, a homopolymer, a tandem repeat: the source overlaps the destination, and the
+          // bytewise copy that handled it made such text inflate slower than zlib.  The period is laid out once over 32 bytes and stored at strides of
+          // the largest multiple of the distance that fits (the last store may run up to 31 bytes past the match, as the long-distance copy may)
+          alignas(32) char pat[64]; for (uint32_t i = 0; i < 32; ++i) pat[i] = src[i % d];
+          const __m256i pv = _mm256_load_si256((const __m256i*)pat); const uint32_t step = (32u / d) * d;
+          for (uint32_t i = 0; i < ln; i += step) _mm256_storeu_si256((__m256i*)(o + i), pv);
+        }
         else
 #endif
         for (uint32_t i = 0; i < ln; ++i) o[i] = src[i];

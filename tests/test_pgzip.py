@@ -38,6 +38,11 @@ def test_pieces_equal_zlib_on_every_kind_of_gzip_file(built, tmp_path):
     cases.append(("trailing zeros", gzip.compress(fq, 6) + b"\0" * 64))
     cases.append(("repetitive text", gzip.compress(b"the quick brown fox jumps over the lazy dog\n" * 150000, 6)))
     cases.append(("binary data", gzip.compress(rng.integers(0, 256, 2_000_000, dtype=np.uint8).tobytes(), 6)))
+    # [r5] long matches at short distances (a constant quality string, homopolymers, tandem repeats of every period below the vector width): the inflaters
+    # lay the period out once and store it in strides
+    runs = b"".join(bytes(rng.integers(65, 91, int(per), dtype=np.uint8)) * int(rng.integers(1, 40)) + b"\n" for per in rng.integers(1, 40, 60000))
+    cases.append(("tandem repeats, periods 1..39", gzip.compress(runs, 6)))
+    cases.append(("constant qualities", gzip.compress(b"".join(b"@r\n%s\n+\n%s\n" % (bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 100)]), b"I" * 100) for _ in range(20000)), 1)))
     for name, z in cases:
         open(f, "wb").write(z)
         for threads, piece, zc in ((4, 65536, False), (3, 250000, True), (8, 1 << 20, False)):

@@ -198,7 +198,7 @@ def test_reader_bgzf_members_are_inflated_in_parallel_and_in_order(built, tmp_pa
     rng = np.random.default_rng(11); n = 20000
     seqs1 = ["".join(rng.choice(list("ACGTN"), size=int(rng.integers(50, 151)))) for _ in range(n)]
     seqs2 = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(50, 151)))) for _ in range(n)]
-    def text(seqs, m): return "".join("@q%d/%d\n%s\n+\n%s\n" % (i, m, s, "F" * len(s)) for i, s in enumerate(seqs)).encode()
+    def text(seqs, m): return "".join("@q%d/%d\n%s\n+\n%s\n" % (i, m, s if i % 7 else (s[:5] * 40)[:len(s)], "F" * len(s)) for i, s in enumerate(seqs)).encode()   # constant qualities and, every seventh read, a tandem repeat of period 5: long matches at distances 1 and 5 (the BGZF inflater's strided copy)
     t1, t2 = text(seqs1, 1), text(seqs2, 2)
     open(tmp_path / "p_1.fq", "wb").write(t1); open(tmp_path / "p_2.fq", "wb").write(t2)
     _bgzf_write(tmp_path / "b_1.fq.gz", t1); _bgzf_write(tmp_path / "b_2.fq.gz", t2, block=30011)
