@@ -161,7 +161,9 @@ typedef struct {
                                  fragment (SalmonQuantify.cpp:1668-1747); the expected models and the corrected lengths come from sq_bias_eff_lengths */
   uint8_t pos_bias;           /* 0; 1 = --posBias: collect the observed read-start position models by transcript length class (SimplePosBias,
                                  SalmonQuantify.cpp:895-934); the expected models and the corrected lengths come from sq_bias_eff_lengths */
-  uint8_t _pad3[2];
+  uint8_t error_model;        /* [r5] alignment-based input only: 1 = the CIGAR-based alignment error model (AlignmentModel.cpp; the reference's default there:
+                                 --noErrorModel switches it off): the reads travel with their alignments (sq_aln_inject_reads) */
+  uint8_t num_error_bins;     /* 6 (--numErrorBins): read-position bins of the error model's transition matrices */
   uint32_t num_bias_samples;  /* 2,000,000 (SalmonDefaults.hpp numBiasSamples): fragments that contribute to the observed sequence-bias models */
   uint32_t mini_batches_in_flight; /* 8 = the reference's default numThreads (SalmonDefaults.hpp:15): W worker threads each run a mini-batch
                                       against the shared model (SalmonQuantify.cpp:2390-2403); here W consecutive mini-batches read
@@ -267,6 +269,27 @@ uint32_t sq_sam_ref_len(const sq_sam*, uint32_t i);
 int sq_sam_set_tid_map(sq_sam*, const uint32_t* map, uint32_t n);
 int sq_sam_next(sq_sam*, uint32_t max_frags, int use_as_scores, double score_exp, sq_aln_batch* out, sq_sam_counts* counts);
 void sq_sam_close(sq_sam*);
+/* [r5] The reads behind the alignments of a batch, for the CIGAR-based error model (src/alignment/AlignmentModel.cpp): per alignment a two records — [2a] the one
+ * AlignmentModel scores with its "left" transition matrices (a pair's record with the smaller position — on a tie the file's second —, a left orphan, a
+ * single-end read), [2a + 1] the one scored with the "right" ones (empty where there is none).  A record = its leftmost reference position, its CIGAR
+ * operations in BAM encoding (length << 4 | op) and its bases as the file stores them (reference strand), one byte each, 0..3 = ACGT (anything else: 0,
+ * as the reference's samToTwoBit maps it).  aligner_score: the sum of the fragment's AS tags when the file's @PG line names bowtie2, else 0 — the weight p
+ * of AlignmentModel::update (SalmonQuantifyAlignments.cpp:265-285).  sq_sam_keep_reads(reader, 1) before the first sq_sam_next; sq_sam_reads returns the
+ * arrays of the batch sq_sam_next returned last (valid until the next call). */
+typedef struct {
+  uint64_t num_alignments;
+  const uint64_t* cig_off;       /* [2 * num_alignments + 1] */
+  const uint32_t* cigar;
+  const uint64_t* seq_off;       /* [2 * num_alignments + 1] */
+  const uint8_t* seq;
+  const int32_t* pos;            /* [2 * num_alignments] */
+  const int32_t* aligner_score;  /* [num_alignments] */
+} sq_aln_reads;
+int sq_sam_keep_reads(sq_sam*, int on);
+int sq_sam_reads(sq_sam*, sq_aln_reads* out);
+/* sq_aln_inject with the reads: required when sq_quant_opts.error_model is set (the online stage then weighs every alignment by
+ * AlignmentModel::logLikelihood and, until the burn-in ends, learns the transition matrices from the sampled alignments: SalmonQuantifyAlignments.cpp:516-523, :861-864) */
+int sq_aln_inject_reads(sq_ctx* ctx, const sq_aln_batch* in, const sq_aln_reads* reads, uint64_t num_with_joint_hits);
 
 /* ------------------------------------------------------------------------------------------------
  * B2  equivalence classes — replaces processMiniBatch (SalmonQuantify.cpp:426-1023) +

@@ -831,6 +831,81 @@ static inline int32_t gc_ctx_bin(int32_t f) { double w = 100.0 / 3; return std::
 
 static void length_classes(const Index& ix, std::vector<uint32_t>& quant, std::vector<uint8_t>& cls);
 struct EqVal { uint64_t count = 0; std::vector<uint64_t> wq; };
+// ---- the CIGAR-based alignment error model of alignment-based input (row f4; src/alignment/AlignmentModel.cpp, include/.../AlignmentModel.hpp,
+// AlignmentCommon.cpp:39-79 setBasesFromCIGAROp_, AtomicMatrix.hpp) -------------------------------------------------------------------------
+// A first-order Markov chain over alignment columns: state = refSymbol * 9 + readSymbol (A C G T, '-' 4, soft clip 5, hard clip 6, pad 7, reference skip 8),
+// 82 x 82 transition weights per read-position bin, one set for the read scored "left" and one for the read scored "right", kept in log space with
+// their row sums (AtomicMatrix: every cell starts at log(alpha = 1), every row sum at log(82)).  logLikelihood walks a record's CIGAR and adds the
+// log transition probabilities (foreground) and, per column, the bin's (0, 0) entry (background); update adds `logForgettingMass + p` to the cells the
+// walk visits.  The two walks are restated separately because they differ (:190-191 resets both "advance" flags at the start of a CIGAR operation,
+// :354 only one; :197-212 returns what it has when a CIGAR runs past the read, :358-373 stops updating).
+// SPEC D1 applies: a group of mini-batches reads the matrices as of the group's start; the increments of a mini-batch are collected per cell as
+// sums of exp(p) in fixed point (p = 0 unless the aligner is bowtie2: plain counts) and applied at the group's end in mini-batch order:
+// cell = logAdd(cell, logFM_b + log(sum)), and the row sum likewise with the row's sum.
+struct ErrModel {
+  static constexpr uint32_t NS = 82, START = 81;
+  uint32_t bins = 0; std::vector<double> cell[2], row[2];
+  void init(uint32_t b) { bins = b; for (int s = 0; s < 2; ++s) { cell[s].assign((size_t)b * NS * NS, sq_log(1.0)); row[s].assign((size_t)b * NS, sq_log((double)NS * 1.0)); } }
+  double tp(int side, uint32_t bin, uint32_t prev, uint32_t cur) const { return cell[side][((size_t)bin * NS + prev) * NS + cur] - row[side][(size_t)bin * NS + prev]; }
+};
+static inline int cig_type(uint32_t op) { return op < 9 ? (int)((0x3C1A7u >> (op << 1)) & 3u) : 0; }   // htslib bam_cigar_type: bit 0 consumes the read, bit 1 the reference
+static inline void cig_states(uint32_t op, uint32_t& refB, uint32_t& readB) {   // setBasesFromCIGAROp_ (AlignmentCommon.cpp:39-79)
+  switch (op) { case 1: refB = 4; break; case 2: readB = 4; break; case 3: readB = 8; break; case 4: refB = 5; break; case 5: refB = 6; readB = 6; break; case 6: refB = 7; readB = 7; break; default: break; }
+}
+struct ErrRec { int32_t pos; const uint32_t* cig; uint32_t ncig; const uint8_t* seq; int32_t len; };
+// AlignmentModel::logLikelihood(bam_seq_t*, ...) (:98-244): fg and bg of one record against transcript t
+static void err_like_rec(const ErrModel& E, int side, const Index& ix, uint32_t t, const ErrRec& R, double* fg, double* bg) {
+  size_t readIdx = 0; int64_t tIdx = R.pos; const size_t tLen = ix.ref_len[t];
+  if (tIdx < 0) { readIdx = (size_t)(-tIdx); tIdx = 0; }
+  size_t uT = (size_t)tIdx;
+  if (uT >= tLen) { *fg = SQ_LOG_0; *bg = 0.0; return; }
+  if (R.ncig == 0) { *fg = SQ_LOG_EPSILON; *bg = 0.0; return; }
+  if (R.len <= 0) { *fg = 0.0; *bg = 0.0; return; }   // no sequence to be had for this record (SPEC: it says nothing)
+  double ll = 0.0, bl = 0.0; uint32_t bin = 0, prev = ErrModel::START; const double invLen = (double)E.bins / (double)R.len;
+  auto rb = [&](size_t i) -> uint32_t { return i < (size_t)R.len ? R.seq[i] : 0u; };
+  auto tb = [&](size_t i) -> uint32_t { return i < tLen ? base_at(ix.refseq.data(), ix.ref_accum[t] + i) : 0u; };
+  for (uint32_t ci = 0; ci < R.ncig; ++ci) {
+    const uint32_t opLen = R.cig[ci] >> 4, op = R.cig[ci] & 15u; const int ty = cig_type(op);
+    uint32_t curRead = (ty & 1) ? rb(readIdx) : 0u, curRef = (ty & 2) ? tb(uT) : 0u;
+    bool advRead = false, advRef = false;
+    for (uint32_t i = 0; i < opLen; ++i) {
+      if (advRead) { if (readIdx >= (size_t)R.len) { *fg = ll; *bg = bl; return; } curRead = rb(readIdx); bin = (uint32_t)((double)readIdx * invLen); advRead = false; }
+      if (advRef) { if (uT >= tLen) { *fg = ll; *bg = bl; return; } curRef = tb(uT); advRef = false; }
+      cig_states(op, curRef, curRead);
+      const uint32_t cur = curRef * 9 + curRead;
+      ll += E.tp(side, bin, prev, cur); bl += E.tp(side, bin, 0, 0); prev = cur;
+      if (ty & 1) { ++readIdx; advRead = true; }
+      if (ty & 2) { ++uT; advRef = true; }
+    }
+  }
+  *fg = ll; *bg = bl;
+}
+// AlignmentModel::update(bam_seq_t*, ...) (:308-424): the cells one record's walk visits, as (bin * 82 + prev) * 82 + cur
+static void err_update_rec(uint32_t bins, const Index& ix, uint32_t t, const ErrRec& R, std::vector<uint32_t>& cells) {
+  int32_t readIdx = 0; int64_t tIdx = R.pos; const size_t tLen = ix.ref_len[t];
+  if (tIdx < 0) { readIdx = (int32_t)(-tIdx); tIdx = 0; }
+  size_t uT = (size_t)tIdx;
+  if (uT >= tLen || R.ncig == 0 || R.len <= 0) return;
+  bool advRead = false, advRef = false; uint32_t bin = 0, prev = ErrModel::START; const double invLen = (double)bins / (double)R.len;
+  auto rb = [&](int32_t i) -> uint32_t { return (i >= 0 && i < R.len) ? R.seq[i] : 0u; };
+  auto tb = [&](size_t i) -> uint32_t { return i < tLen ? base_at(ix.refseq.data(), ix.ref_accum[t] + i) : 0u; };
+  for (uint32_t ci = 0; ci < R.ncig; ++ci) {
+    const uint32_t opLen = R.cig[ci] >> 4, op = R.cig[ci] & 15u; const int ty = cig_type(op);
+    uint32_t curRead = (ty & 1) ? rb(readIdx) : 0u, curRef = (ty & 2) ? tb(uT) : 0u;
+    advRef = false;                                   // (:354: the read's flag keeps its value across operations)
+    for (uint32_t i = 0; i < opLen; ++i) {
+      if (advRead) { if (readIdx >= R.len) return; curRead = rb(readIdx); bin = (uint32_t)((double)readIdx * invLen); advRead = false; }
+      if (advRef) { if (uT >= tLen) return; curRef = tb(uT); advRef = false; }
+      cig_states(op, curRef, curRead);
+      const uint32_t cur = curRef * 9 + curRead;
+      cells.push_back((bin * ErrModel::NS + prev) * ErrModel::NS + cur);
+      prev = cur;
+      if (ty & 1) { ++readIdx; advRead = true; }
+      if (ty & 2) { ++uT; advRef = true; }
+    }
+  }
+}
+
 struct QuantState {
   const Index* ix; Opts op;
   FLD fld; std::vector<double> ambigCMF;  // LogCMFCache pre-burn-in table (DistributionUtils.cpp:104-118)
@@ -848,8 +923,11 @@ struct QuantState {
   uint64_t seqObs[2][576] = {{0}}; uint64_t seqSamples = 0;   // observed read-start context counts (SBModel cells [position][context]; FW, RC) and fragments sampled so far (SPEC §B2)
   // SPEC §D1: up to W = mini_batches_in_flight consecutive mini-batches read one model snapshot (the reference's numThreads workers
   // read a shared, slightly stale model: SalmonQuantify.cpp:2390-2403); their increments wait here and are applied in order
-  struct PendingMB { double logFM; std::vector<std::pair<uint32_t, uint64_t>> massInc; std::vector<uint32_t> fldCnt; bool anyFld; uint32_t minLen; };
+  struct PendingMB { double logFM; std::vector<std::pair<uint32_t, uint64_t>> massInc; std::vector<uint32_t> fldCnt; bool anyFld; uint32_t minLen;
+    std::vector<std::pair<uint32_t, uint64_t>> errInc[2]; };   // [r5] (cell, fixed-point sum of exp(p)) per side
   std::vector<PendingMB> pending;
+  // [r5] alignment-based input with the CIGAR error model: the matrices, this mini-batch's increments, the reads of the batch being accumulated
+  ErrModel em; bool errOn = false; std::vector<uint64_t> errAcc[2]; const sq_aln_reads* reads = nullptr;
   // `-l A` (SPEC §D8): LibraryTypeDetector restated at mini-batch granularity
   bool detectActive = false, detected = false; uint64_t detCounts[64] = {0}; uint64_t detSamples = 0;
   void detect_format() {  // mostLikelyType, LibraryTypeDetector.hpp:33-152
@@ -884,6 +962,11 @@ struct QuantState {
     for (PendingMB& p : pending) {
       for (auto& tq : p.massInc) mass[tq.first] = sq_log_add(mass[tq.first], p.logFM + sq_log(sq_from_fixed(tq.second, SQ_MFRAC_BITS)));
       if (p.anyFld) { fld.apply_counts(p.fldCnt, p.logFM); fld.minLen = std::min(fld.minLen, p.minLen); }
+      for (int sd = 0; sd < 2; ++sd) {   // AtomicMatrix::increment: the cell and its row sum (SPEC D1: per mini-batch, in cell order)
+        std::map<uint32_t, uint64_t> rowsum;
+        for (auto& cq : p.errInc[sd]) { em.cell[sd][cq.first] = sq_log_add(em.cell[sd][cq.first], p.logFM + sq_log(sq_from_fixed(cq.second, SQ_MFRAC_BITS))); rowsum[cq.first / ErrModel::NS] += cq.second; }
+        for (auto& rq : rowsum) em.row[sd][rq.first] = sq_log_add(em.row[sd][rq.first], p.logFM + sq_log(sq_from_fixed(rq.second, SQ_MFRAC_BITS)));
+      }
     }
     pending.clear();
   }
@@ -922,6 +1005,8 @@ struct QuantState {
     }
     libCounts.assign(64, 0);
     detectActive = o->lib_autodetect != 0;
+    errOn = o->error_model != 0;
+    if (errOn) { em.init(o->num_error_bins ? o->num_error_bins : 6); for (int sd = 0; sd < 2; ++sd) errAcc[sd].assign(em.cell[sd].size(), 0); }
   }
   double forgetting_mass(uint64_t b) {  // ForgettingMassCalculator.hpp:30-40 (prefill recurrence)
     while (fm.size() <= b) {
@@ -1113,6 +1198,17 @@ template <class F> static double lane_sum256(int64_t n, F term) {
   return v[0];
 }
 
+static inline ErrRec err_rec(const sq_aln_reads* R, uint64_t ai, int k) {
+  const uint64_t j = 2 * ai + (uint64_t)k; ErrRec e; e.pos = R->pos[j]; e.cig = R->cigar + R->cig_off[j]; e.ncig = (uint32_t)(R->cig_off[j + 1] - R->cig_off[j]);
+  e.seq = R->seq + R->seq_off[j]; e.len = (int32_t)(R->seq_off[j + 1] - R->seq_off[j]); return e;
+}
+// AlignmentModel::logLikelihood(const ReadPair& / const UnpairedRead&) (:246-306): foreground minus background over the alignment's records
+static double err_like_aln(const QuantState& S, uint64_t ai, uint32_t t) {
+  double ll = 0.0, bg = 0.0;
+  for (int k = 0; k < 2; ++k) { const ErrRec R = err_rec(S.reads, ai, k); if (R.ncig == 0 && R.len == 0) continue;   // no such record (an orphan's mate, a single-end read's second slot)
+    double f, b; err_like_rec(S.em, k, *S.ix, t, R, &f, &b); ll += f; bg += b; }
+  return ll - bg;
+}
 static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln* alns, uint64_t r0, uint64_t r1) {
   const Opts& op = S.op; const sq_quant_opts& o = op.o; const Index& ix = *S.ix;
   const double logFM = S.forgetting_mass(S.batchNo);
@@ -1133,6 +1229,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       const sq_aln& a = alns[ai]; uint32_t t = a.tid;
       double refLength = ix.ref_len[t] > 0 ? (double)ix.ref_len[t] : 1.0;
       double logFragCov = a.est_aln_prob > 0 ? sq_log(a.est_aln_prob) : 0.0;
+      if (S.errOn) logFragCov = (useAux && S.reads) ? err_like_aln(S, ai, t) : 0.0;   // errLike (SalmonQuantifyAlignments.cpp:513-523): LOG_1 until the auxiliary models count
       double logRefLength = o.no_length_correction ? 1.0 : ((o.no_eff_length_correction || !burned) ? sq_log((double)ix.ref_len[t]) : S.logEffLen[t]);
       double tlc = sq_log_add(S.priorMass[t], S.mass[t]);  // transcript.mass(initialRound = true)
       uint32_t flen = a.frag_len;
@@ -1205,6 +1302,10 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
       if (!burned) {
         double rr = u01(o.seed, readIdx, i);
         if (rr < pr) {
+          if (S.errOn && S.reads) {   // alnMod.update(*aln, ..., alignerScore, logForgettingMass) (:860-864): exp(p) joins every cell of the walk
+            const uint64_t ai = (uint64_t)(ka[i] - alns); const uint64_t q = sq_to_fixed(sq_exp((double)S.reads->aligner_score[ai]), SQ_MFRAC_BITS); std::vector<uint32_t> cells;
+            for (int k = 0; k < 2; ++k) { cells.clear(); err_update_rec(S.em.bins, ix, tids[i], err_rec(S.reads, ai, k), cells); for (uint32_t c : cells) S.errAcc[k][c] += q; }
+          }
           uint32_t fl = frag_len_pedantic(*ka[i], ix.ref_len[tids[i]]);
           if (fl > 0) {
             if (fl > 1000) fl = 1000;
@@ -1221,6 +1322,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
   // it, at the mini-batch that reaches numBurninFrags (:1012-1018), or at the end of the mapped batch (orc_eq_accumulate)
   QuantState::PendingMB pm; pm.logFM = logFM; pm.anyFld = false; pm.minLen = minLen;
   for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) { pm.massInc.emplace_back((uint32_t)t, S.massAcc[t]); S.massAcc[t] = 0; }
+  if (S.errOn && !burned) for (int sd = 0; sd < 2; ++sd) for (size_t c = 0; c < S.errAcc[sd].size(); ++c) if (S.errAcc[sd][c]) { pm.errInc[sd].emplace_back((uint32_t)c, S.errAcc[sd][c]); S.errAcc[sd][c] = 0; }
   if (!burned) {
     for (auto c : fldCnt) pm.anyFld |= (c != 0);
     if (pm.anyFld) pm.fldCnt = fldCnt;
@@ -2001,6 +2103,45 @@ void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const
   for (uint64_t r0 = 0; r0 < n; r0 += mb) process_mini_batch(S, read_off, alns, r0, std::min<uint64_t>(n, r0 + mb));
   S.flush_pending();   // a group never straddles two mapped batches
   S.numMappedUB += num_with_joint_hits;
+}
+// [r5] the same with the reads behind the alignments (alignment-based input with the CIGAR error model)
+void orc_eq_accumulate_reads(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, const sq_aln_reads* reads, uint64_t num_with_joint_hits) {
+  s->S.reads = reads; orc_eq_accumulate(s, n, read_off, alns, num_with_joint_hits); s->S.reads = nullptr;
+}
+// [r5] the error model alone, for its pin against the compiled reference (tests/test_alnmodel_pin.py): a one-transcript world; kind 0 = proper pair (records in
+// file order; the one with the smaller position is the left one, on a tie the second: host/sam_reader.cpp makes the same choice), 1 / 2 = left / right orphan,
+// 3 = single-end.  Returns the alignment's log-likelihood; do_update applies update(p, mass) as a mini-batch of its own
+struct orc_errmodel { Index ix; ErrModel em; };
+orc_errmodel* orc_errmodel_new(uint32_t bins, const uint8_t* txp_bases, uint32_t txp_len) {
+  orc_errmodel* h = new orc_errmodel(); h->em.init(bins); h->ix.ref_len.assign(1, txp_len); h->ix.ref_accum.assign(2, 0); h->ix.ref_accum[1] = txp_len; h->ix.refseq.assign((txp_len + 31) / 32 + 1, 0);
+  for (uint32_t i = 0; i < txp_len; ++i) h->ix.refseq[i >> 5] |= (uint64_t)(txp_bases[i] & 3) << ((i & 31) * 2);
+  return h;
+}
+void orc_errmodel_free(orc_errmodel* h) { delete h; }
+double orc_errmodel_eval(orc_errmodel* h, int kind, int32_t pos1, const uint32_t* cig1, uint32_t n1, const uint8_t* seq1, int32_t len1,
+                         int32_t pos2, const uint32_t* cig2, uint32_t n2, const uint8_t* seq2, int32_t len2, int do_update, double p, double mass) {
+  ErrRec r[2]; bool have[2] = {false, false}; const ErrRec a{pos1, cig1, n1, seq1, len1}, b{pos2, cig2, n2, seq2, len2};
+  if (kind == 0) { const bool first_left = pos1 < pos2; r[first_left ? 0 : 1] = a; r[first_left ? 1 : 0] = b; have[0] = have[1] = true; }
+  else { const int k = kind == 2 ? 1 : 0; r[k] = a; have[k] = true; }
+  double ll = 0.0, bg = 0.0;
+  for (int k = 0; k < 2; ++k) if (have[k]) { double f, g; err_like_rec(h->em, k, h->ix, 0, r[k], &f, &g); ll += f; bg += g; }
+  if (do_update && mass != SQ_LOG_0) {
+    const uint64_t q = sq_to_fixed(sq_exp(p), SQ_MFRAC_BITS);
+    for (int k = 0; k < 2; ++k) if (have[k]) {
+      std::vector<uint32_t> cells; err_update_rec(h->em.bins, h->ix, 0, r[k], cells); std::map<uint32_t, uint64_t> inc, rows;
+      for (uint32_t c : cells) { inc[c] += q; rows[c / ErrModel::NS] += q; }
+      for (auto& cq : inc) h->em.cell[k][cq.first] = sq_log_add(h->em.cell[k][cq.first], mass + sq_log(sq_from_fixed(cq.second, SQ_MFRAC_BITS)));
+      for (auto& rq : rows) h->em.row[k][rq.first] = sq_log_add(h->em.row[k][rq.first], mass + sq_log(sq_from_fixed(rq.second, SQ_MFRAC_BITS)));
+    }
+  }
+  return ll - bg;
+}
+// the error model's matrices, for the tests: log-space cells [2][bins * 82 * 82] and row sums [2][bins * 82]
+uint32_t orc_state_err_model(orc_state* s, double* cells, double* rows) {
+  const ErrModel& E = s->S.em; if (!s->S.errOn) return 0;
+  if (cells) for (int sd = 0; sd < 2; ++sd) memcpy(cells + (size_t)sd * E.cell[0].size(), E.cell[sd].data(), E.cell[sd].size() * 8);
+  if (rows) for (int sd = 0; sd < 2; ++sd) memcpy(rows + (size_t)sd * E.row[0].size(), E.row[sd].data(), E.row[sd].size() * 8);
+  return E.bins;
 }
 // finalisation when burn-in was never reached (SalmonQuantify.cpp:2734-2745)
 void orc_state_finish(orc_state* s) { QuantState& S = s->S; if (!S.burnedIn) { compute_eff_lengths(S.fld, S.ix->ref_len, S.logEffLen); } }

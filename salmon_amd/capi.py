@@ -36,7 +36,7 @@ class QuantOpts(C.Structure):
                 ("fld_mean", f64), ("fld_sd", f64), ("forgetting_factor", f64), ("incompat_prior", f64),
                 ("range_factorization_bins", u32), ("use_frag_len_dist", u8), ("model_single_frag_prob", u8),
                 ("no_length_correction", u8), ("no_eff_length_correction", u8), ("seed", u64),
-                ("seq_bias", u8), ("pos_bias", u8), ("_pad3", u8 * 2), ("num_bias_samples", u32), ("mini_batches_in_flight", u32)]
+                ("seq_bias", u8), ("pos_bias", u8), ("error_model", u8), ("num_error_bins", u8), ("num_bias_samples", u32), ("mini_batches_in_flight", u32)]
 
 
 class ReadBatch(C.Structure):
@@ -51,6 +51,10 @@ class Aln(C.Structure):
 
 class AlnBatch(C.Structure):
     _fields_ = [("n", u32), ("read_off", P(u64)), ("aln", P(Aln)), ("aln_cap", u64), ("map_type", P(u8))]
+
+
+class AlnReads(C.Structure):   # sq_aln_reads
+    _fields_ = [("num_alignments", u64), ("cig_off", P(u64)), ("cigar", P(u32)), ("seq_off", P(u64)), ("seq", P(u8)), ("pos", P(C.c_int32)), ("aligner_score", P(C.c_int32))]
 
 
 class MapStats(C.Structure):
@@ -231,7 +235,8 @@ def lib():
             u32]), "sq_boot_writer_close": (u64, [vp]),
         "sq_bias_last_gc_expected": (C.c_int, [vp]), "sq_aln_inject": (C.c_int, [vp, P(AlnBatch), u64]), "sq_model_drop_counts": (C.c_int, [vp]),
         "sq_sam_open": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_sam_first_flag": (C.c_int, [C.c_char_p, P(C.c_int)]), "sq_sam_num_refs": (u32, [vp]), "sq_sam_ref_name": (C.c_char_p, [vp, u32]), "sq_sam_ref_len": (u32, [vp, u32]),
-        "sq_sam_set_tid_map": (C.c_int, [vp, vp, u32]), "sq_sam_next": (C.c_int, [vp, u32, C.c_int, f64, P(AlnBatch), P(SamCounts)]), "sq_sam_close": (None, [vp]),
+        "sq_sam_set_tid_map": (C.c_int, [vp, vp, u32]), "sq_sam_keep_reads": (C.c_int, [vp, C.c_int]), "sq_sam_reads": (C.c_int, [vp, P(AlnReads)]),
+        "sq_aln_inject_reads": (C.c_int, [vp, P(AlnBatch), P(AlnReads), u64]), "sq_sam_next": (C.c_int, [vp, u32, C.c_int, f64, P(AlnBatch), P(SamCounts)]), "sq_sam_close": (None, [vp]),
         "sq_index_hash": (C.c_char_p, [vp, C.c_int]), "sq_index_keeps_duplicates": (C.c_int, [vp]), "sq_model_fld_min": (C.c_int, [vp, P(u32)]),
         "sq_write_fld_samples": (C.c_int, [C.c_char_p, vp, u32, u32, u32, u64, P(f64), P(f64), P(u32)]), "sq_write_legacy_bias": (C.c_int, [C.c_char_p, P(u32)]),
         "sq_write_gc_model": (C.c_int, [C.c_char_p, C.c_int32, u32, u32, vp, vp]), "sq_write_seq_model": (C.c_int, [C.c_char_p, vp]),

@@ -457,7 +457,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   if (any_gz && any_plain) return SQ_ERR_DEVICE;   // a mix of compressed and plain files: the host path takes it
   if (any_gz) {   // [r5] compressed input: inflated by a pool of its own into buffers, copied into the ring, split on the device
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    const unsigned nz = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(128u, std::max(2u, hw / 2));   // a plain gzip stream decodes at ~100 MB/s per thread in the two-pass scheme (host/pgzip.cpp): it takes many
+    const unsigned nz = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS")) : std::min(64u, std::max(2u, hw / 2));   // (128 threads measured no faster than 64 on the GPU box: profiles/r05_reader_compressed.txt)
     R->zpool.reset(new sqio::Pool(std::max(1u, nz)));
     sqio::Pool* zp = R->zpool.get();
     const int nstreams = R->paired ? 2 : 1;
@@ -475,7 +475,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
           F->bg.reset(new sqio::BgzfSource()); F->bg->map = F->map; F->bg->base = (const uint8_t*)m; F->bg->n = (size_t)sb.st_size; F->bg->pool = zp; F->bg->path = path;
           F->bg->window = std::max<size_t>(8, (size_t)(2 * nz) / (size_t)nstreams);
         } else {
-          const unsigned th = std::max(1u, std::min(64u, nz / (unsigned)nstreams));
+          const unsigned th = std::max(1u, std::min(32u, nz / (unsigned)nstreams));
           const size_t piece = std::max<size_t>(1u << 20, std::min<size_t>(4u << 20, (size_t)sb.st_size / (4 * th)));
           F->pz = pgz_open((const uint8_t*)m, (size_t)sb.st_size, [zp](std::function<void()> f) { zp->submit(std::move(f)); }, th, piece);
           if (!F->pz) { sq_set_error("'%s' does not start with a gzip member", path.c_str()); return SQ_ERR_IO; }
@@ -507,7 +507,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   const unsigned hw_all = std::max(2u, std::thread::hardware_concurrency());
   // plain files: a few threads move bytes; BGZF: the same pool inflates, so it gets what the buffered streams' pool would have had
   const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS"))
-                      : (R->any_bgz ? std::min(128u, std::max(2u, hw_all / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
+                      : (R->any_bgz ? std::min(64u, std::max(2u, hw_all / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
   R->pool.reset(new Workers(std::max(1u, nt)));
   if (hipHostMalloc((void**)&R->ring, (size_t)R->RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError(); R->ring = nullptr; for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd);

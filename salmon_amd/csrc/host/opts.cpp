@@ -17,7 +17,7 @@ extern "C" void sq_quant_opts_default(sq_quant_opts* o) {
   o->fld_mean = 250.0; o->fld_sd = 25.0; o->forgetting_factor = 0.65; o->incompat_prior = 0.0;           // :59-61,16
   o->range_factorization_bins = 4; o->use_frag_len_dist = 1; o->model_single_frag_prob = 1;             // :78
   o->no_length_correction = 0; o->no_eff_length_correction = 0; o->seed = 0x5EED5A1A0ULL;
-  o->mini_batches_in_flight = 8; o->seq_bias = 0; o->pos_bias = 0; o->_pad3[0] = o->_pad3[1] = 0; o->num_bias_samples = 2000000;                                                          // numThreads, SalmonDefaults.hpp:15
+  o->mini_batches_in_flight = 8; o->seq_bias = 0; o->pos_bias = 0; o->error_model = 0; o->num_error_bins = 6;   /* SalmonDefaults.hpp:124 numErrorBins; the model itself is alignment-mode only and set by the driver */ o->num_bias_samples = 2000000;                                                          // numThreads, SalmonDefaults.hpp:15
 }
 extern "C" void sq_em_opts_default(sq_em_opts* o) {
   memset(o, 0, sizeof(*o));

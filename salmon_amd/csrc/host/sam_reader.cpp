@@ -27,7 +27,12 @@
 
 namespace {
 enum { F_PAIRED = 1, F_PROPER = 2, F_UNMAP = 4, F_MUNMAP = 8, F_REVERSE = 16, F_READ1 = 64, F_READ2 = 128 };
-struct Rec { std::string name; int flag = 0; int32_t ref = -1, mref = -1, pos = 0; uint32_t len = 0; int32_t as = 0; bool has_as = false; };
+struct Rec { std::string name; int flag = 0; int32_t ref = -1, mref = -1, pos = 0; uint32_t len = 0; int32_t as = 0; bool has_as = false;
+  std::vector<uint32_t> cig; std::vector<uint8_t> seq; };   // [r5] kept on request (sq_sam_keep_reads): BAM-encoded CIGAR operations, bases as 0..3 (anything but ACGT: 0, as the reference's samToTwoBit maps them)
+// what the error model needs of an alignment: the record scored with the left matrices [0] and the one scored with the right ones [1]
+struct Side { int32_t pos[2] = {0, 0}; std::vector<uint32_t> cig[2]; std::vector<uint8_t> seq[2]; uint8_t mate[2] = {0, 0} /* 1 = first read, 2 = second */, rev[2] = {0, 0}; int32_t as_sum = 0;
+  void put(int k, Rec& r) { pos[k] = r.pos; cig[k] = std::move(r.cig); seq[k] = std::move(r.seq); mate[k] = (r.flag & F_READ2) ? 2 : 1; rev[k] = (r.flag & F_REVERSE) ? 1 : 0; }
+  void clear() { for (int k = 0; k < 2; ++k) { pos[k] = 0; cig[k].clear(); seq[k].clear(); mate[k] = rev[k] = 0; } as_sum = 0; } };
 inline uint8_t fmt_id(uint8_t t, uint8_t o, uint8_t s) { return (uint8_t)(t | (o << 1) | (s << 3)); }
 // hitType(end1Start, end1Fwd, end2Start, end2Fwd) — SalmonUtils.cpp:531-575 (the four-argument form: no dovetail stretch)
 inline uint8_t hit_type_pair(int32_t s1, bool f1, int32_t s2, bool f2) {
@@ -63,6 +68,9 @@ struct sq_sam {
   sq_sam_counts cnt{};
   // output arrays of the current batch
   std::vector<uint64_t> off; std::vector<sq_aln> alns; std::vector<int32_t> as_of; std::vector<uint8_t> has_as_of;
+  // [r5] the reads behind the alignments, for the CIGAR-based error model (AlignmentModel.cpp): per alignment two records (left / right matrices)
+  bool keep_reads = false, bowtie2 = false; std::vector<Side> sides; Side next_side; std::vector<uint8_t> frag_seq[2];
+  std::vector<uint64_t> r_cig_off, r_seq_off; std::vector<uint32_t> r_cig; std::vector<uint8_t> r_seq; std::vector<int32_t> r_pos, r_score;
   bool getline(std::string& out) {
     out.clear();
     for (;;) {
@@ -98,6 +106,11 @@ struct sq_sam {
     if (l_seq < 0 || l_name == 0 || need > (size_t)bs) { err = "malformed BAM record (field lengths exceed the block)"; return false; }
     r.name.assign((const char*)p + fixed, strnlen((const char*)p + fixed, l_name));
     r.flag = (int)flag; r.ref = (ref >= 0 && (size_t)ref < names.size()) ? ref : -1; r.mref = (mref >= 0 && (size_t)mref < names.size()) ? mref : -1; r.pos = pos;
+    if (keep_reads) {
+      const uint8_t* cg = p + fixed + l_name; r.cig.resize(n_cig); for (uint32_t i = 0; i < n_cig; ++i) r.cig[i] = (uint32_t)i32(cg + 4 * i);
+      const uint8_t* sq = cg + (size_t)n_cig * 4; r.seq.resize((size_t)l_seq);
+      for (int32_t i = 0; i < l_seq; ++i) { const uint8_t c = (sq[i >> 1] >> ((~i & 1) << 2)) & 15u; r.seq[(size_t)i] = c == 2 ? 1 : c == 4 ? 2 : c == 8 ? 3 : 0; }
+    }
     if (l_seq > 0) r.len = (uint32_t)l_seq;
     else { uint32_t L = 0; const uint8_t* c = p + fixed + l_name; for (uint32_t i = 0; i < n_cig; ++i) { const uint32_t v = (uint32_t)i32(c + 4 * i); const uint32_t op = v & 15u; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) L += v >> 4; } r.len = L; }   // M I S = X consume the query
     // the optional fields: TAG (2) TYPE (1) VALUE; AS is an integer of whatever width the writer chose
@@ -142,6 +155,11 @@ struct sq_sam {
       if (rnext == "=") r.mref = r.ref; else { auto it2 = by_name.find(rnext); r.mref = (rnext == "*" || it2 == by_name.end()) ? -1 : it2->second; }
       r.pos = atoi(fld[3]) - 1;
       const std::string seq = field(9);
+      if (keep_reads) {
+        r.cig.clear(); r.seq.clear(); const std::string cg = field(5);
+        if (cg != "*") { uint32_t num = 0; for (char ch : cg) { if (ch >= '0' && ch <= '9') num = num * 10 + (uint32_t)(ch - '0'); else { const char* ops = "MIDNSHP=X"; const char* w = strchr(ops, ch); r.cig.push_back((num << 4) | (uint32_t)(w ? w - ops : 15)); num = 0; } } }
+        if (seq != "*") { r.seq.resize(seq.size()); for (size_t i = 0; i < seq.size(); ++i) { const char ch = (char)(seq[i] & ~0x20); r.seq[i] = ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 0; } }
+      }
       if (seq != "*") r.len = (uint32_t)seq.size();
       else {   // no sequence stored (secondary records): the read length is what the CIGAR consumes of the query
         const std::string cg = field(5); uint32_t num = 0, L = 0;
@@ -158,8 +176,8 @@ struct sq_sam {
   }
   static std::string base_name(const std::string& n) { if (n.size() > 2 && n[n.size() - 2] == '/') return n.substr(0, n.size() - 2); return n; }   // ReadPair::getNameLength
   // the next alignment (a pair or an orphan / single read) or false at the end of the file
-  bool next_alignment(sq_aln& a, std::string& name, int32_t& as, bool& has_as, std::string& err) {
-    Rec r1, r2;
+  bool next_alignment(sq_aln& a, std::string& name, int32_t& as, bool& has_as, std::string& err, Side& sd) {
+    Rec r1, r2; sd.clear();
     for (;;) {
       if (!next_record(r1, err)) return false;
       const bool mapped = !(r1.flag & F_UNMAP);
@@ -167,13 +185,16 @@ struct sq_sam {
         if (!mapped) { cnt.num_unaligned++; continue; }
         memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.fwd = !(r1.flag & F_REVERSE); a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u);
         a.mate_status = SQ_MS_SINGLE_END; a.format_id = hit_type_single(a.fwd); a.score = r1.as; a.est_aln_prob = 1.0;
-        name = r1.name; as = r1.as; has_as = r1.has_as; return true;
+        name = r1.name; as = r1.as; has_as = r1.has_as; if (keep_reads) { sd.as_sum = r1.has_as ? r1.as : 0; sd.put(0, r1); } return true;
       }
       const bool mate_mapped = !(r1.flag & F_MUNMAP);
       if (mapped && mate_mapped && (r1.flag & F_PROPER) && r1.ref == r1.mref) {   // MappedConcordantPair: this record and the next one
         if (!next_record(r2, err)) { if (err.empty()) err = "the SAM file ends in the middle of a read pair (" + r1.name + ")"; return false; }
         if (!(r1.flag & F_PAIRED) || !(r2.flag & F_PAIRED)) { err = "found an unpaired read in a paired-end library; the two ends of a pair must be adjacent (" + r1.name + ")"; return false; }
         if (base_name(r1.name) != base_name(r2.name)) cnt.num_suspicious_pairs++;
+        if (keep_reads) {   // AlignmentModel::update / logLikelihood (AlignmentModel.cpp:258-268, :436-441): the record with the smaller position is scored with the left matrices; on a tie the SECOND record of the file is
+          sd.as_sum = (r1.has_as ? r1.as : 0) + ((r2.flag & F_UNMAP) || !r2.has_as ? 0 : r2.as);
+          const bool first_left = r1.pos < r2.pos; Rec c1 = r1, c2 = r2; sd.put(first_left ? 0 : 1, c1); sd.put(first_left ? 1 : 0, c2); }
         if (r1.flag & F_READ2) std::swap(r1, r2);
         memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.mate_pos = r2.pos; a.fwd = !(r1.flag & F_REVERSE); a.mate_fwd = !(r2.flag & F_REVERSE);
         a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u); a.mate_len = (uint16_t)std::min<uint32_t>(r2.len, 65535u);
@@ -185,7 +206,7 @@ struct sq_sam {
       if (mapped) {   // MappedOrphan (also: not a proper pair, or the ends on different targets — BAMQueue.tpp:308-331)
         memset(&a, 0, sizeof(a)); a.tid = (uint32_t)r1.ref; a.pos = r1.pos; a.fwd = !(r1.flag & F_REVERSE); a.read_len = (uint16_t)std::min<uint32_t>(r1.len, 65535u);
         a.mate_status = (r1.flag & F_READ1) ? SQ_MS_PAIRED_END_LEFT : SQ_MS_PAIRED_END_RIGHT; a.format_id = hit_type_single(a.fwd); a.score = r1.as; a.est_aln_prob = 1.0;
-        name = base_name(r1.name); as = r1.as; has_as = r1.has_as; return true;
+        name = base_name(r1.name); as = r1.as; has_as = r1.has_as; if (keep_reads) { sd.as_sum = r1.has_as ? r1.as : 0; sd.put((r1.flag & F_READ1) ? 0 : 1, r1); } return true;
       }
       if (mate_mapped) continue;   // UnmappedOrphan: its mate's record carries the alignment
       // UnmappedPair: both records of the pair are consumed
@@ -224,7 +245,8 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
     if (first) { first = false;
       if (s->bend - s->bpos >= 4 && !memcmp(s->buf.data() + s->bpos, "BAM\1", 4)) {   // [r4] BAM: magic, l_text, text, n_ref, then (l_name, name, l_ref) per target
         s->bam = true; uint8_t b4[4]; bool ok = s->read_exact(b4, 4) && s->read_exact(b4, 4);
-        if (ok) { int32_t lt = sq_sam::i32(b4); ok = lt >= 0; std::vector<char> skip; while (ok && lt > 0) { skip.resize((size_t)std::min(lt, 1 << 20)); ok = s->read_exact(skip.data(), skip.size()); lt -= (int32_t)skip.size(); } }
+        if (ok) { int32_t lt = sq_sam::i32(b4); ok = lt >= 0; std::vector<char> skip; std::string tail; while (ok && lt > 0) { skip.resize((size_t)std::min(lt, 1 << 20)); ok = s->read_exact(skip.data(), skip.size()); lt -= (int32_t)skip.size();
+            if (ok) { tail.append(skip.data(), skip.size()); size_t at = 0; while ((at = tail.find("@PG", at)) != std::string::npos) { const size_t e = tail.find('\n', at); if (tail.substr(at, e == std::string::npos ? std::string::npos : e - at).find("ID:bowtie2") != std::string::npos) s->bowtie2 = true; at += 3; } if (tail.size() > 4096) tail.erase(0, tail.size() - 4096); } } }
         int32_t nref = 0; if (ok) { ok = s->read_exact(b4, 4); nref = sq_sam::i32(b4); ok = ok && nref >= 0; }
         for (int32_t i = 0; ok && i < nref; ++i) {
           ok = s->read_exact(b4, 4); const int32_t ln = sq_sam::i32(b4); if (!ok || ln <= 0 || ln > (1 << 20)) { ok = false; break; }
@@ -236,6 +258,7 @@ extern "C" int sq_sam_open(const char* path, int paired_library, sq_sam** out) {
       } }
     if (s->buf[s->bpos] != '@') break;
     if (!s->getline(l)) break;
+    if (!strncmp(l.c_str(), "@PG", 3) && l.find("ID:bowtie2") != std::string::npos) s->bowtie2 = true;   // the aligner whose AS tags weigh the error model's updates (SalmonQuantifyAlignments.cpp:265-285)
     if (!strncmp(l.c_str(), "@SQ", 3)) {
       std::string sn; uint32_t ln = 0; size_t p = 0;
       while ((p = l.find('\t', p)) != std::string::npos) { ++p; if (!l.compare(p, 3, "SN:")) { const size_t e = l.find('\t', p); sn = l.substr(p + 3, e == std::string::npos ? std::string::npos : e - p - 3); } else if (!l.compare(p, 3, "LN:")) ln = (uint32_t)strtoul(l.c_str() + p + 3, nullptr, 10); }
@@ -254,6 +277,12 @@ extern "C" int sq_sam_first_flag(const char* path, int* flag) {
   if (!got) { if (err.empty()) err = s->io_err.empty() ? "no alignment records" : s->io_err; sq_set_error("%s: %s", path, err.c_str()); sq_sam_close(s); return SQ_ERR_IO; }
   *flag = r.flag; sq_sam_close(s); return SQ_OK;
 }
+extern "C" int sq_sam_keep_reads(sq_sam* s, int on) { if (!s) { sq_set_error("sq_sam_keep_reads: bad arguments"); return SQ_ERR_ARG; } s->keep_reads = on != 0; return SQ_OK; }
+extern "C" int sq_sam_reads(sq_sam* s, sq_aln_reads* out) {
+  if (!s || !out || !s->keep_reads) { sq_set_error("sq_sam_reads: the reader does not keep the reads (sq_sam_keep_reads)"); return SQ_ERR_STATE; }
+  out->num_alignments = s->alns.size(); out->cig_off = s->r_cig_off.data(); out->cigar = s->r_cig.data(); out->seq_off = s->r_seq_off.data(); out->seq = s->r_seq.data();
+  out->pos = s->r_pos.data(); out->aligner_score = s->r_score.data(); return SQ_OK;
+}
 extern "C" uint32_t sq_sam_num_refs(const sq_sam* s) { return s ? (uint32_t)s->names.size() : 0; }
 extern "C" const char* sq_sam_ref_name(const sq_sam* s, uint32_t i) { return (s && i < s->names.size()) ? s->names[i].c_str() : ""; }
 extern "C" uint32_t sq_sam_ref_len(const sq_sam* s, uint32_t i) { return (s && i < s->lens.size()) ? s->lens[i] : 0; }
@@ -265,13 +294,20 @@ extern "C" void sq_sam_close(sq_sam* s) { if (s) { s->cur = PgzBuf(); s->bg.rese
 
 extern "C" int sq_sam_next(sq_sam* s, uint32_t max_frags, int use_as_scores, double score_exp, sq_aln_batch* out, sq_sam_counts* counts) {
   if (!s || !out || !max_frags) { sq_set_error("sq_sam_next: bad arguments"); return SQ_ERR_ARG; }
-  s->off.assign(1, 0); s->alns.clear(); s->as_of.clear(); s->has_as_of.clear();
+  s->off.assign(1, 0); s->alns.clear(); s->as_of.clear(); s->has_as_of.clear(); s->sides.clear();
   std::string err; uint32_t nfrag = 0;
   auto close_fragment = [&](size_t a0) {   // order by transcript (AlignmentGroup::sortHits), then the AS-based conditional probabilities
     const size_t a1 = s->alns.size(); if (a1 == a0) return;
     std::vector<uint32_t> ord(a1 - a0); for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return s->alns[a0 + x].tid < s->alns[a0 + y].tid; });
     std::vector<sq_aln> tmp(ord.size()); std::vector<int32_t> tas(ord.size()); bool all_as = true;
+    if (s->keep_reads) {   // the side records follow their alignments; a record without its sequence (a secondary alignment's "*") borrows the fragment's stored one of the same read, turned round if the strands differ
+      std::vector<Side> ts(ord.size()); for (size_t i = 0; i < ord.size(); ++i) ts[i] = std::move(s->sides[a0 + ord[i]]);
+      for (size_t i = 0; i < ord.size(); ++i) for (int k = 0; k < 2; ++k) { Side& x = ts[i]; if (x.cig[k].empty() || !x.seq[k].empty()) continue;
+        for (size_t j = 0; j < ord.size() && x.seq[k].empty(); ++j) for (int q = 0; q < 2; ++q) if (!ts[j].seq[q].empty() && ts[j].mate[q] == x.mate[k]) { x.seq[k] = ts[j].seq[q];
+          if (ts[j].rev[q] != x.rev[k]) { std::reverse(x.seq[k].begin(), x.seq[k].end()); for (auto& b : x.seq[k]) b = (uint8_t)(3 - b); } break; } }
+      for (size_t i = 0; i < ord.size(); ++i) s->sides[a0 + i] = std::move(ts[i]);
+    }
     for (size_t i = 0; i < ord.size(); ++i) { tmp[i] = s->alns[a0 + ord[i]]; tas[i] = s->as_of[a0 + ord[i]]; all_as = all_as && s->has_as_of[a0 + ord[i]]; }
     int32_t best = INT32_MIN; for (int32_t v : tas) best = std::max(best, v);
     for (size_t i = 0; i < ord.size(); ++i) { if (use_as_scores && all_as) tmp[i].est_aln_prob = std::exp(-score_exp * (double)(best - tas[i])); s->alns[a0 + i] = tmp[i]; }
@@ -280,21 +316,27 @@ extern "C" int sq_sam_next(sq_sam* s, uint32_t max_frags, int use_as_scores, dou
   };
   size_t frag_start = 0; std::string cur_name; bool open = false;
   for (;;) {
-    sq_aln a; std::string name; int32_t as = 0; bool has_as = false;
-    if (s->have_next) { a = s->next_aln; name = s->next_name; as = s->next_as; has_as = s->next_has_as; s->have_next = false; }
-    else if (!s->next_alignment(a, name, as, has_as, err)) {
+    sq_aln a; std::string name; int32_t as = 0; bool has_as = false; Side sd;
+    if (s->have_next) { a = s->next_aln; name = s->next_name; as = s->next_as; has_as = s->next_has_as; sd = std::move(s->next_side); s->have_next = false; }
+    else if (!s->next_alignment(a, name, as, has_as, err, sd)) {
       if (err.empty() && !s->io_err.empty()) err = s->io_err;
       if (!err.empty()) { sq_set_error("%s: %s", s->path.c_str(), err.c_str()); return SQ_ERR_IO; } break; }
     if (open && name != cur_name) {
       close_fragment(frag_start); open = false;
-      if (nfrag == max_frags) { s->have_next = true; s->next_aln = a; s->next_name = name; s->next_as = as; s->next_has_as = has_as; break; }
+      if (nfrag == max_frags) { s->have_next = true; s->next_aln = a; s->next_name = name; s->next_as = as; s->next_has_as = has_as; s->next_side = std::move(sd); break; }
     }
     if (!open) { open = true; cur_name = name; frag_start = s->alns.size(); }
     const uint32_t t = a.tid < s->tid_map.size() ? s->tid_map[a.tid] : 0xFFFFFFFFu;
     if (t == 0xFFFFFFFFu) { s->cnt.num_skipped_unknown_target++; continue; }
     a.tid = t; s->alns.push_back(a); s->as_of.push_back(as); s->has_as_of.push_back(has_as ? 1 : 0); s->cnt.num_alignments++;
+    if (s->keep_reads) s->sides.push_back(std::move(sd));
   }
   if (open && !s->have_next) close_fragment(frag_start);
+  if (s->keep_reads) {   // flat arrays for sq_sam_reads
+    const size_t na = s->alns.size(); s->r_cig_off.assign(1, 0); s->r_seq_off.assign(1, 0); s->r_cig.clear(); s->r_seq.clear(); s->r_pos.resize(2 * na); s->r_score.resize(na);
+    for (size_t i = 0; i < na; ++i) { const Side& x = s->sides[i]; s->r_score[i] = s->bowtie2 ? x.as_sum : 0;
+      for (int k = 0; k < 2; ++k) { s->r_cig.insert(s->r_cig.end(), x.cig[k].begin(), x.cig[k].end()); s->r_seq.insert(s->r_seq.end(), x.seq[k].begin(), x.seq[k].end()); s->r_cig_off.push_back(s->r_cig.size()); s->r_seq_off.push_back(s->r_seq.size()); s->r_pos[2 * i + k] = x.pos[k]; } }
+  }
   out->n = nfrag; out->read_off = s->off.data(); out->aln = s->alns.data(); out->aln_cap = s->alns.size(); out->map_type = nullptr;
   if (counts) *counts = s->cnt;
   return SQ_OK;
