@@ -451,6 +451,9 @@ int sq_bias_seq_eff_lengths(sq_index* idx, int use_gc, const double* gc_observed
  * NULL) receives the normalised bin masses [observed 5', observed 3', expected 5', expected 3'][5][20] (SimplePosBias::writeBinary's values). */
 typedef struct { const double* gc_observed; const uint64_t* seq_fw; const uint64_t* seq_rc; const double* pos_observed; uint32_t threads; uint32_t _pad; } sq_bias_models;
 int sq_model_fetch_pos_observed(sq_ctx*, double* out200);
+/* [r5] the CIGAR error model's transition matrices as learned so far (AlignmentModel::transitionProbsLeft_ / Right_, AtomicMatrix storage_ and rowsums_, log space):
+ * cells [2][bins][82][82], rows [2][bins][82] (either may be NULL); *bins = the number of read-position bins */
+int sq_model_fetch_error_model(sq_ctx*, double* cells, double* rows, uint32_t* bins);
 /* [r4] the expected fragment-GC masses [3 context classes][25 bins] (linear) of the calling thread's last sq_bias_*eff_lengths sweep with a GC model:
  * what aux_info/exp_gc.gz holds (GZipWriter.cpp:405-413) */
 int sq_bias_last_gc_expected(double* out75);

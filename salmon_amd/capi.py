@@ -206,7 +206,7 @@ def lib():
         "sq_model_fetch_gc_observed": (C.c_int, [vp, vp]),
         "sq_bias_gc_eff_lengths": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, P(BiasReport)]),
         "sq_model_fetch_seq_observed": (C.c_int, [vp, vp, vp, P(u64)]),
-        "sq_model_fetch_pos_observed": (C.c_int, [vp, vp]),
+        "sq_model_fetch_pos_observed": (C.c_int, [vp, vp]), "sq_model_fetch_error_model": (C.c_int, [vp, vp, vp, P(u32)]),
         "sq_bias_eff_lengths": (C.c_int, [vp, P(BiasModels), vp, u32, vp, vp, vp, vp, vp, P(BiasReport)]),
         "sq_index_length_classes": (C.c_int, [vp, vp, vp]),
         "sq_bias_seq_eff_lengths": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, u32, vp, vp, vp, vp, P(BiasReport)]),

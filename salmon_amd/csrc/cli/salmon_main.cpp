@@ -314,7 +314,7 @@ static int cmd_quant(int argc, char** argv) {
   const char* lt = arg(argc, argv, "-l", "--libType");
   // [r4] alignment-based mode: `quant -t transcripts.fa -l LIB -a alignments.sam -o out` (SalmonQuantifyAlignments.cpp; the records come from a SAM or BAM file, not the mapper)
   const char* alnf = arg(argc, argv, "-a", "--alignments"); const char* targets = arg(argc, argv, "-t", "--targets");
-  if (alnf && (!targets || !odir)) { fprintf(stderr, "usage: salmon-hip quant -t transcripts.fa -l IU -a alignments.{sam,sam.gz,bam} -o out_dir --noErrorModel|--useASWithoutCIGAR\n"); return 1; }
+  if (alnf && (!targets || !odir)) { fprintf(stderr, "usage: salmon-hip quant -t transcripts.fa -l IU -a alignments.{sam,sam.gz,bam} -o out_dir [--noErrorModel | --useASWithoutCIGAR] [--numErrorBins 6]\n"); return 1; }
   if (!alnf && (!idir || !odir || (!ru && !(r1 && r2)))) {
     fprintf(stderr,
         "usage: salmon-hip quant -i index_dir -l IU -1 r1.fq[.gz] -2 r2.fq[.gz] | -r reads.fq -o out_dir [--useEM] [--initUniform] [--dumpEq] [--dumpEqWeights] [--recoverOrphans] [--device 0] [--batch 1000000]\n");
@@ -324,7 +324,7 @@ static int cmd_quant(int argc, char** argv) {
                           "--rangeFactorizationBins", "--mismatchSeedSkip", "--vbPrior", "--numBootstraps", "--numGibbsSamples", "--seed", "--thinningFactor",
                           "--incompatPrior", "--maxOccsPerHit", "--maxReadOcc", "--fldMax", "--fldMean", "--fldSD", "--forgettingFactor", "--numPreAuxModelSamples",
                           "--numAuxModelSamples", "--scoreExp", "--decoyThreshold", "--minAlnProb", "--ma", "--mp", "--go", "--ge", "--bandwidth",
-                          "--minAssignedFrags", "--sigDigits", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
+                          "--minAssignedFrags", "--sigDigits", "--numErrorBins", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
               "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames", "--noErrorModel", "--useASWithoutCIGAR"},
@@ -334,9 +334,6 @@ static int cmd_quant(int argc, char** argv) {
   const bool autodetect = lib == "A";
   bool aln_paired = true;
   if (alnf) {
-    if (!flag(argc, argv, "--noErrorModel") && !flag(argc, argv, "--useASWithoutCIGAR")) {
-      fprintf(stderr, "[salmon-hip] alignment-based mode: the CIGAR-based error model (the reference's default there) is not built; pass --noErrorModel (every alignment of a fragment weighs the same) "
-                      "or --useASWithoutCIGAR (weights from the AS tags)\n"); return 1; }
     if (flag(argc, argv, "--gcBias") || flag(argc, argv, "--seqBias") || flag(argc, argv, "--posBias") || flag(argc, argv, "--writeMappings") || flag(argc, argv, "--writeUnmappedNames") || world > 1) {
       fprintf(stderr, "[salmon-hip] alignment-based mode runs on one GPU without bias correction, --writeMappings and --writeUnmappedNames\n"); return 1; }
     // the library's read type decides how records are grouped; with -l A the first record's PAIRED flag says which (the reference peeks at the file too)
@@ -404,6 +401,9 @@ static int cmd_quant(int argc, char** argv) {
   if ((v = arg(argc, argv, "--go"))) qo.gap_open = atoi(v);
   if ((v = arg(argc, argv, "--ge"))) qo.gap_extend = atoi(v);
   if ((v = arg(argc, argv, "--bandwidth"))) qo.bandwidth = atoi(v);
+  // [r5] alignment-based input: the CIGAR-based error model is the default (ProgramOptionsGenerator.cpp:345-353), --noErrorModel / --useASWithoutCIGAR take its place
+  const bool err_model = alnf && !flag(argc, argv, "--noErrorModel") && !flag(argc, argv, "--useASWithoutCIGAR");
+  if (err_model) { qo.error_model = 1; if ((v = arg(argc, argv, "--numErrorBins"))) qo.num_error_bins = (uint8_t)std::max(1, std::min(64, atoi(v))); }
   if ((v = arg(argc, argv, "-p", "--threads"))) qo.mini_batches_in_flight = (uint32_t)std::max(1, std::min(64, atoi(v)));   // workers = mini-batches in flight (SPEC D1)
   if (flag(argc, argv, "--noLengthCorrection")) qo.no_length_correction = 1;
   if (flag(argc, argv, "--noEffectiveLengthCorrection")) qo.no_eff_length_correction = 1;
@@ -442,10 +442,12 @@ static int cmd_quant(int argc, char** argv) {
       if (known < ns) fprintf(stderr, "[salmon-hip] warning: %u of the %u targets in the alignment file's header are not in %s; alignments to them are skipped\n", ns - known, ns, targets);
       if (sq_sam_set_tid_map(sam_in, tm.data(), ns)) die("target map"); }
     const int use_as = flag(argc, argv, "--useASWithoutCIGAR") ? 1 : 0; sq_sam_counts sc{};
+    if (err_model && sq_sam_keep_reads(sam_in, 1)) die("alignment reader");
     for (;;) {
       sq_aln_batch ab{}; if (sq_sam_next(sam_in, B, use_as, qo.score_exp, &ab, &sc)) die("reading alignments");
       if (ab.n == 0) break;
-      if (sq_aln_inject(ctx, &ab, ab.n) || sq_eq_accumulate(ctx)) die("alignment batch");
+      if (err_model) { sq_aln_reads rd{}; if (sq_sam_reads(sam_in, &rd) || sq_aln_inject_reads(ctx, &ab, &rd, ab.n) || sq_eq_accumulate(ctx)) die("alignment batch"); }
+      else if (sq_aln_inject(ctx, &ab, ab.n) || sq_eq_accumulate(ctx)) die("alignment batch");
       tot.num_reads += ab.n; tot.num_with_joint_hits += ab.n; tot.num_mapped += ab.n; tot.num_alignments += ab.read_off[ab.n];
       if (!quiet) fprintf(stderr, "\r[salmon-hip] processed %llu aligned fragments", (unsigned long long)tot.num_reads);
     }

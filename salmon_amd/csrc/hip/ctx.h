@@ -149,6 +149,8 @@ struct sq_ctx {
   int cur_buf = 0, last_buf = 0;
   bool eq_pending[2] = {false, false};
   sq_dbuf<sq_aln> aln_b1; sq_dbuf<uint64_t> aln_off_b1;
+  // [r5] the reads behind an injected batch (sq_aln_inject_reads), one set per alignment buffer: CIGARs, bases, positions, aligner scores
+  sq_dbuf<uint64_t> rd_cig_off[2], rd_seq_off[2]; sq_dbuf<uint32_t> rd_cig[2]; sq_dbuf<uint8_t> rd_seq[2]; sq_dbuf<int32_t> rd_pos[2], rd_score[2]; bool rd_have[2] = {false, false};
   sq_aln* aln_ptr(int b) { return b ? aln_b1.p : aln.p; }
   uint64_t* aln_off_ptr(int b) { return b ? aln_off_b1.p : aln_off.p; }
   std::vector<hipEvent_t> prof_ev2; std::vector<int> prof_stage2;

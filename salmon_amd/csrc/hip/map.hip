@@ -289,7 +289,14 @@ extern "C" int sq_map_batch(sq_ctx* c, const sq_read_batch* in, sq_aln_batch* ou
 // [r4] alignment-based mode (`salmon quant -a`, src/alignment/SalmonQuantifyAlignments.cpp:125-937): the alignments come from a SAM file instead of the
 // mapping kernels.  A batch of them is put where sq_map_batch would have left its own — the lane's alignment buffer, offsets by fragment —
 // and sq_eq_accumulate then runs the same online model / equivalence-class stage on it.
-extern "C" int sq_aln_inject(sq_ctx* c, const sq_aln_batch* in, uint64_t num_with_joint_hits) {
+static int aln_inject_impl(sq_ctx* c, const sq_aln_batch* in, const sq_aln_reads* reads, uint64_t num_with_joint_hits);
+extern "C" int sq_aln_inject(sq_ctx* c, const sq_aln_batch* in, uint64_t num_with_joint_hits) { return aln_inject_impl(c, in, nullptr, num_with_joint_hits); }
+// [r5] the same with the reads behind the alignments (CIGARs, bases, positions): what the CIGAR-based error model scores and learns from (hip/online.hip)
+extern "C" int sq_aln_inject_reads(sq_ctx* c, const sq_aln_batch* in, const sq_aln_reads* reads, uint64_t num_with_joint_hits) {
+  if (!reads) { sq_set_error("sq_aln_inject_reads: bad arguments"); return SQ_ERR_ARG; }
+  return aln_inject_impl(c, in, reads, num_with_joint_hits);
+}
+static int aln_inject_impl(sq_ctx* c, const sq_aln_batch* in, const sq_aln_reads* reads, uint64_t num_with_joint_hits) {
   if (!c || c->owner || !in || !in->read_off || (!in->aln && in->n && in->read_off[in->n])) { sq_set_error("sq_aln_inject: bad arguments"); return SQ_ERR_ARG; }
   if (!c->tickets.empty()) { sq_set_error("sq_aln_inject: submitted batches are still outstanding"); return SQ_ERR_STATE; }
   const uint32_t n = in->n; if (n > c->max_reads) { sq_set_error("batch of %u fragments exceeds ctx capacity %u", n, c->max_reads); return SQ_ERR_ARG; }
@@ -307,6 +314,21 @@ extern "C" int sq_aln_inject(sq_ctx* c, const sq_aln_batch* in, uint64_t num_wit
   if ((buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP))) { sq_set_error("device allocation failed (injected alignments)"); return SQ_ERR_NOMEM; }
   SQ_HIP_CHECK(hipMemcpyAsync(c->aln_off_ptr(buf), in->read_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
   if (total) SQ_HIP_CHECK(hipMemcpyAsync(c->aln_ptr(buf), in->aln, (size_t)total * sizeof(sq_aln), hipMemcpyHostToDevice, st));
+  c->rd_have[buf] = false;
+  if (reads) {
+    if (reads->num_alignments != total || (total && (!reads->cig_off || !reads->seq_off || !reads->pos || !reads->aligner_score))) { sq_set_error("sq_aln_inject_reads: the reads do not belong to this batch (%llu alignments, reads of %llu)", (unsigned long long)total, (unsigned long long)reads->num_alignments); return SQ_ERR_ARG; }
+    const uint64_t nc = total ? reads->cig_off[2 * total] : 0, ns = total ? reads->seq_off[2 * total] : 0;
+    for (uint64_t j = 0; j < 2 * total; ++j) if (reads->cig_off[j] > reads->cig_off[j + 1] || reads->seq_off[j] > reads->seq_off[j + 1]) { sq_set_error("sq_aln_inject_reads: offsets are not prefix sums"); return SQ_ERR_ARG; }
+    if (c->rd_cig_off[buf].ensure(2 * total + 2) || c->rd_seq_off[buf].ensure(2 * total + 2) || c->rd_cig[buf].ensure(nc + 8) || c->rd_seq[buf].ensure(ns + 8) || c->rd_pos[buf].ensure(2 * total + 2) || c->rd_score[buf].ensure(total + 2)) {
+      sq_set_error("device allocation failed (injected reads)"); return SQ_ERR_NOMEM; }
+    if (total) {
+      SQ_HIP_CHECK(hipMemcpyAsync(c->rd_cig_off[buf].p, reads->cig_off, (2 * total + 1) * 8, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(c->rd_seq_off[buf].p, reads->seq_off, (2 * total + 1) * 8, hipMemcpyHostToDevice, st));
+      if (nc) SQ_HIP_CHECK(hipMemcpyAsync(c->rd_cig[buf].p, reads->cigar, nc * 4, hipMemcpyHostToDevice, st));
+      if (ns) SQ_HIP_CHECK(hipMemcpyAsync(c->rd_seq[buf].p, reads->seq, ns, hipMemcpyHostToDevice, st));
+      SQ_HIP_CHECK(hipMemcpyAsync(c->rd_pos[buf].p, reads->pos, 2 * total * 4, hipMemcpyHostToDevice, st)); SQ_HIP_CHECK(hipMemcpyAsync(c->rd_score[buf].p, reads->aligner_score, total * 4, hipMemcpyHostToDevice, st));
+    }
+    c->rd_have[buf] = true;
+  }
   SQ_HIP_CHECK(hipEventRecord(c->ev_map_done[buf], st));
   SQ_HIP_CHECK(hipStreamSynchronize(st));          // the caller's arrays may go
   c->last_n = n; c->last_paired = 1; c->last_total_aln = total; c->last_joint = num_with_joint_hits; c->have_batch = true; c->last_buf = buf; c->cur_buf = buf ^ 1;
@@ -697,7 +719,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   c->last_n = n;
   c->last_paired = paired;
   c->last_total_aln = total_aln;
-  c->last_joint = hst[ST_JOINT];
+  c->last_joint = hst[ST_JOINT]; c->rd_have[buf] = false;
   c->seed_fills += hst[ST_FILLS];
   c->have_batch = true;
   c->last_buf = buf;

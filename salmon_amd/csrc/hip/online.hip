@@ -32,6 +32,9 @@ struct sq_online_dev {
   // ctr: [0]=numAssigned [1]=burnedIn [2]=minLen [3]=cached [4]=pending_finalize [5]=numCompatible
   sq_dbuf<unsigned long long> mass_acc, uniq, total, lib_counts;
   sq_dbuf<uint32_t> fld_cnt;
+  // [r5] alignment-based input with the CIGAR error model (AlignmentModel.cpp): log-space cells [2][bins][82][82] and row sums [2][bins][82], the increments of the
+  // W mini-batches of a group [W][2][bins][82][82] (fixed-point sums of exp(p)), one byte per alignment: mini-batch slot + 1 where the update was drawn
+  sq_dbuf<double> err_cell, err_row; sq_dbuf<unsigned long long> err_acc; sq_dbuf<uint8_t> err_flag; uint32_t err_bins = 0;
   sq_dbuf<unsigned long long> ctr;
   // per big batch
   sq_dbuf<uint8_t> has_compat;
@@ -142,6 +145,7 @@ struct OnlineView {
   uint32_t* touched; uint32_t* touched_n; uint32_t* tflag;
   unsigned long long* gc_obs;   // nullptr unless --gcBias
   unsigned long long* pos_obs; const uint16_t* posbin;   // nullptr unless --posBias
+  double* err_cell; double* err_row; unsigned long long* err_acc; uint8_t* err_flag; uint32_t err_bins;   // nullptr / 0 unless the error model is on
 };
 // observedPosBiasFwd / RC [lengthClassIndex].addMass(pos, RefLength, aln.logProb) — SalmonQuantify.cpp:895-934; the bins were chosen by k_pre_aln
 __device__ inline void pos_observe(const OnlineView& V, uint64_t ai, double pr) {
@@ -354,6 +358,7 @@ __device__ inline void mini_batch_fragment(const OnlineView& V, const sq_quant_o
     if (!burned) {
       double rr = dev_u01(o.seed, readIdx, ki);
       if (rr < pr) {
+        if (V.err_flag) V.err_flag[ai] = (uint8_t)(mbs + 1);   // [r5] the error model learns from this alignment too (k_err_count)
         uint32_t fl = pre[ai].fl_ped;
         if (fl > 0) {
           atomicAdd(&V.fld_cnt[mbs * 1024u + fl], 1u);
@@ -499,6 +504,7 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
             if (V.posbin) pos_observe(V, ai, pr);
             if (!burned) {
               double rr = dev_u01(o.seed, read_counter0 + (r - r0), kis[sl]);
+              if (rr < pr && V.err_flag) V.err_flag[ai] = (uint8_t)(mbs + 1);
               if (rr < pr && fl_ped[sl] > 0) {
                 atomicAdd(&V.fld_cnt[mbs * 1024u + fl_ped[sl]], 1u);
                 if ((unsigned long long)fl_ped[sl] < __hip_atomic_load(&V.ctr[2], __ATOMIC_RELAXED,
@@ -566,6 +572,124 @@ __global__ void k_mini_batch(OnlineView V, sq_quant_opts o, uint32_t r0, uint32_
   __syncthreads();
   if (threadIdx.x < 64 && s_lib[threadIdx.x]) atomicAdd(&V.lib_counts[threadIdx.x], s_lib[threadIdx.x]);
   if (threadIdx.x == 64 && s_cf) atomicAdd(&V.ctr[5], s_cf);
+}
+
+// ---- [r5] the CIGAR-based alignment error model of alignment-based input (src/alignment/AlignmentModel.cpp; SPEC f4) ------------------------------------
+// The checker's err_like_rec / err_update_rec (oracle.cpp), walk for walk: state = refSymbol * 9 + readSymbol, 82 x 82 log transition weights per
+// read-position bin and side, foreground minus background; the update walk differs from the likelihood walk where the reference's two functions do.
+struct ErrReads { const uint64_t* cig_off; const uint32_t* cig; const uint64_t* seq_off; const uint8_t* seq; const int32_t* pos; const int32_t* score; };
+#define ERR_NS 82u
+__device__ inline int err_cig_type(uint32_t op) { return op < 9 ? (int)((0x3C1A7u >> (op << 1)) & 3u) : 0; }
+__device__ inline void err_cig_states(uint32_t op, uint32_t& refB, uint32_t& readB) {
+  switch (op) { case 1: refB = 4; break; case 2: readB = 4; break; case 3: readB = 8; break; case 4: refB = 5; break; case 5: refB = 6; readB = 6; break; case 6: refB = 7; readB = 7; break; default: break; }
+}
+__device__ inline void err_like_rec(const OnlineView& V, int side, const uint64_t* __restrict__ refseq, uint64_t g0, uint32_t tLen, int32_t pos, const uint32_t* cig, uint32_t ncig,
+                                    const uint8_t* seq, int32_t len, double* fg, double* bg) {
+  size_t readIdx = 0; long long tIdx = pos;
+  if (tIdx < 0) { readIdx = (size_t)(-tIdx); tIdx = 0; }
+  size_t uT = (size_t)tIdx;
+  if (uT >= tLen) { *fg = SQ_LOG_0; *bg = 0.0; return; }
+  if (ncig == 0) { *fg = SQ_LOG_EPSILON; *bg = 0.0; return; }
+  if (len <= 0) { *fg = 0.0; *bg = 0.0; return; }
+  const double* cell = V.err_cell + (size_t)side * V.err_bins * ERR_NS * ERR_NS; const double* row = V.err_row + (size_t)side * V.err_bins * ERR_NS;
+  double ll = 0.0, bl = 0.0; uint32_t bin = 0, prev = ERR_NS - 1; const double invLen = (double)V.err_bins / (double)len;
+  for (uint32_t ci = 0; ci < ncig; ++ci) {
+    const uint32_t opLen = cig[ci] >> 4, op = cig[ci] & 15u; const int ty = err_cig_type(op);
+    uint32_t curRead = (ty & 1) ? (readIdx < (size_t)len ? seq[readIdx] : 0u) : 0u, curRef = (ty & 2) ? (uT < tLen ? sq_fetch_base(refseq, g0 + uT) : 0u) : 0u;
+    bool advRead = false, advRef = false;
+    for (uint32_t i = 0; i < opLen; ++i) {
+      if (advRead) { if (readIdx >= (size_t)len) { *fg = ll; *bg = bl; return; } curRead = seq[readIdx]; bin = (uint32_t)((double)readIdx * invLen); advRead = false; }
+      if (advRef) { if (uT >= tLen) { *fg = ll; *bg = bl; return; } curRef = sq_fetch_base(refseq, g0 + uT); advRef = false; }
+      err_cig_states(op, curRef, curRead);
+      const uint32_t cur = curRef * 9 + curRead;
+      ll += cell[((size_t)bin * ERR_NS + prev) * ERR_NS + cur] - row[(size_t)bin * ERR_NS + prev];
+      bl += cell[((size_t)bin * ERR_NS + 0) * ERR_NS + 0] - row[(size_t)bin * ERR_NS + 0];
+      prev = cur;
+      if (ty & 1) { ++readIdx; advRead = true; }
+      if (ty & 2) { ++uT; advRef = true; }
+    }
+  }
+  *fg = ll; *bg = bl;
+}
+// one thread per fragment of [r0, r1): the conditional probability of every alignment under the matrices as they stand (the group's snapshot), written where
+// the mini-batch kernels read the alignment's score term (PreAln::c_cov); LOG_1 until the auxiliary models count (useAuxParams)
+__global__ void k_err_like(OnlineView V, ErrReads R, uint32_t r0, uint32_t r1, const uint64_t* __restrict__ aln_off, PreAln* __restrict__ pre,
+                           const uint64_t* __restrict__ assigned_prefix, unsigned long long assigned_base, int base_from_ctr, uint32_t num_pre_burnin,
+                           const uint32_t* __restrict__ ref_len, const uint64_t* __restrict__ ref_accum, const uint64_t* __restrict__ refseq) {
+  const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; if (r >= r1) return;
+  const unsigned long long base = base_from_ctr ? V.ctr[0] : assigned_base;
+  const bool useAux = (base + assigned_prefix[r]) >= num_pre_burnin;
+  for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) {
+    double ll = 0.0, bg = 0.0;
+    if (useAux) {
+      const uint32_t t = pre[ai].tid;
+      for (int k = 0; k < 2; ++k) {
+        const uint64_t j = 2 * ai + (uint64_t)k; const uint32_t ncig = (uint32_t)(R.cig_off[j + 1] - R.cig_off[j]); const int32_t len = (int32_t)(R.seq_off[j + 1] - R.seq_off[j]);
+        if (ncig == 0 && len == 0) continue;
+        double f, b; err_like_rec(V, k, refseq, ref_accum[t], ref_len[t], R.pos[j], R.cig + R.cig_off[j], ncig, R.seq + R.seq_off[j], len, &f, &b); ll += f; bg += b;
+      }
+    }
+    pre[ai].c_cov = ll - bg;
+  }
+}
+// one thread per fragment of the group: the alignments the mini-batch kernel drew (err_flag = mini-batch slot + 1) add exp(p) to every cell their walk visits
+__global__ void k_err_count(OnlineView V, ErrReads R, uint32_t r0, uint32_t r1, const uint64_t* __restrict__ aln_off, const PreAln* __restrict__ pre,
+                            const uint32_t* __restrict__ ref_len, const uint64_t* __restrict__ ref_accum, const uint64_t* __restrict__ refseq) {
+  const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; if (r >= r1) return;
+  const size_t ncell = (size_t)V.err_bins * ERR_NS * ERR_NS;
+  for (uint64_t ai = aln_off[r]; ai < aln_off[r + 1]; ++ai) {
+    const uint32_t fl = V.err_flag[ai]; if (!fl) continue;
+    const unsigned long long q = (unsigned long long)sq_to_fixed(sq_exp((double)R.score[ai]), SQ_MFRAC_BITS);
+    const uint32_t t = pre[ai].tid; const uint64_t g0 = ref_accum[t]; const uint32_t tLen = ref_len[t];
+    for (int k = 0; k < 2; ++k) {
+      const uint64_t j = 2 * ai + (uint64_t)k; const uint32_t ncig = (uint32_t)(R.cig_off[j + 1] - R.cig_off[j]); const int32_t len = (int32_t)(R.seq_off[j + 1] - R.seq_off[j]);
+      const uint32_t* cig = R.cig + R.cig_off[j]; const uint8_t* seq = R.seq + R.seq_off[j];
+      unsigned long long* acc = V.err_acc + ((size_t)(fl - 1) * 2 + (size_t)k) * ncell;
+      int32_t readIdx = 0; long long tIdx = R.pos[j];
+      if (tIdx < 0) { readIdx = (int32_t)(-tIdx); tIdx = 0; }
+      size_t uT = (size_t)tIdx;
+      if (uT >= tLen || ncig == 0 || len <= 0) continue;
+      bool advRead = false, advRef = false, stop = false; uint32_t bin = 0, prev = ERR_NS - 1; const double invLen = (double)V.err_bins / (double)len;
+      for (uint32_t ci = 0; ci < ncig && !stop; ++ci) {
+        const uint32_t opLen = cig[ci] >> 4, op = cig[ci] & 15u; const int ty = err_cig_type(op);
+        uint32_t curRead = (ty & 1) ? ((readIdx >= 0 && readIdx < len) ? seq[readIdx] : 0u) : 0u, curRef = (ty & 2) ? (uT < tLen ? sq_fetch_base(refseq, g0 + uT) : 0u) : 0u;
+        advRef = false;
+        for (uint32_t i = 0; i < opLen; ++i) {
+          if (advRead) { if (readIdx >= len) { stop = true; break; } curRead = seq[readIdx]; bin = (uint32_t)((double)readIdx * invLen); advRead = false; }
+          if (advRef) { if (uT >= tLen) { stop = true; break; } curRef = sq_fetch_base(refseq, g0 + uT); advRef = false; }
+          err_cig_states(op, curRef, curRead);
+          const uint32_t cur = curRef * 9 + curRead;
+          (void)__hip_atomic_fetch_add(&acc[((size_t)bin * ERR_NS + prev) * ERR_NS + cur], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          prev = cur;
+          if (ty & 1) { ++readIdx; advRead = true; }
+          if (ty & 2) { ++uT; advRef = true; }
+        }
+      }
+    }
+  }
+}
+// a block per (side, bin, row): thread `cur` folds its cell's increments in, mini-batch after mini-batch, each with its forgetting mass (AtomicMatrix::increment);
+// the row's sums (exact integer sums of its cells' increments) go into the row sum the same way
+__global__ void __launch_bounds__(128) k_err_apply(OnlineView V, FmArr FM, uint32_t nw) {
+  __shared__ unsigned long long s_row[SQ_MAX_INFLIGHT];
+  const size_t ncell = (size_t)V.err_bins * ERR_NS * ERR_NS; const uint32_t side = blockIdx.x / (V.err_bins * ERR_NS), br = blockIdx.x % (V.err_bins * ERR_NS), cur = threadIdx.x;
+  if (threadIdx.x < SQ_MAX_INFLIGHT) s_row[threadIdx.x] = 0;
+  __syncthreads();
+  if (cur < ERR_NS) {
+    const size_t cellI = (size_t)br * ERR_NS + cur; double v = V.err_cell[(size_t)side * ncell + cellI]; bool any = false;
+    for (uint32_t w = 0; w < nw; ++w) {
+      unsigned long long* a = V.err_acc + ((size_t)w * 2 + side) * ncell + cellI; const unsigned long long q = *a;
+      if (!q) continue;
+      v = sq_log_add(v, FM.v[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS))); *a = 0; any = true; atomicAdd(&s_row[w], q);
+    }
+    if (any) V.err_cell[(size_t)side * ncell + cellI] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double rv = V.err_row[(size_t)side * V.err_bins * ERR_NS + br]; bool any = false;
+    for (uint32_t w = 0; w < nw; ++w) if (s_row[w]) { rv = sq_log_add(rv, FM.v[w] + sq_log(sq_from_fixed(s_row[w], SQ_MFRAC_BITS))); any = true; }
+    if (any) V.err_row[(size_t)side * V.err_bins * ERR_NS + br] = rv;
+  }
 }
 
 // ---- --seqBias: observed read-start context models (SalmonQuantify.cpp:1668-1747; SPEC §B2) ----------------------------------------
@@ -1105,6 +1229,7 @@ OnlineView make_view(sq_ctx* c) {
   V.tflag = o->tflag.p;
   V.gc_obs = c->opts.gc_bias ? o->gc_obs.p : nullptr;
   V.pos_obs = c->opts.pos_bias ? o->pos_obs.p : nullptr; V.posbin = c->opts.pos_bias ? o->posbin.p : nullptr;
+  V.err_cell = o->err_cell.p; V.err_row = o->err_row.p; V.err_acc = o->err_acc.p; V.err_flag = o->err_bins ? o->err_flag.p : nullptr; V.err_bins = o->err_bins;
   return V;
 }
 EqView make_eq_view(sq_online_dev* o) {
@@ -1208,6 +1333,13 @@ int sq_online_create(sq_ctx* c) {
   SQ_HIP_CHECK(hipMemset(o->gc_obs.p, 0, (SQ_GC_COND_BINS * SQ_GC_FRAG_BINS + 8) * 8));
   SQ_HIP_CHECK(hipMemset(o->pos_obs.p, 0, 208 * 8));
   SQ_HIP_CHECK(hipMemset(o->fld_cnt.p, 0, (size_t)W * 1024 * 4));
+  if (c->opts.error_model) {   // [r5] AlignmentModel(1.0, numErrorBins): every cell log(alpha) = log(1), every row sum log(82 alpha) (AtomicMatrix.hpp:19-33)
+    const uint32_t bins = c->opts.num_error_bins ? c->opts.num_error_bins : 6; const size_t ncell = (size_t)bins * 82 * 82, nrow = (size_t)bins * 82;
+    if (o->err_cell.ensure(2 * ncell) || o->err_row.ensure(2 * nrow) || o->err_acc.ensure((size_t)W * 2 * ncell)) { sq_set_error("device allocation failed (error model)"); return SQ_ERR_NOMEM; }
+    std::vector<double> c0(2 * ncell, sq_log(1.0)), r0(2 * nrow, sq_log(82.0 * 1.0));
+    SQ_HIP_CHECK(hipMemcpy(o->err_cell.p, c0.data(), c0.size() * 8, hipMemcpyHostToDevice)); SQ_HIP_CHECK(hipMemcpy(o->err_row.p, r0.data(), r0.size() * 8, hipMemcpyHostToDevice));
+    SQ_HIP_CHECK(hipMemset(o->err_acc.p, 0, (size_t)W * 2 * ncell * 8)); o->err_bins = bins;
+  }
   SQ_HIP_CHECK(hipMemset(o->seq_obs.p, 0, 1160 * 8));
   SQ_HIP_CHECK(hipMemset(o->cfac.p, 0, 1024 * 8));
   unsigned long long ctr[8] = {0, 0, 1000, 0, 0, 0, 0, 0}; SQ_HIP_CHECK(hipMemcpy(o->ctr.p, ctr, sizeof(ctr), hipMemcpyHostToDevice));
@@ -1247,7 +1379,7 @@ void sq_online_free(sq_ctx* c) {
   o->uniq.free_();
   o->total.free_();
   o->lib_counts.free_();
-  o->fld_cnt.free_();
+  o->fld_cnt.free_(); o->err_cell.free_(); o->err_row.free_(); o->err_acc.free_(); o->err_flag.free_();
   o->ctr.free_();
   o->has_compat.free_();
   o->assigned_flag.free_();
@@ -1414,7 +1546,15 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     sq_set_error("device allocation failed (online scratch)");
     return SQ_ERR_NOMEM;
   }
+  // [r5] the CIGAR error model: this batch must have come with its reads (sq_aln_inject_reads)
+  const bool err_on = o->err_bins != 0; ErrReads ER{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (err_on) {
+    if (!src->rd_have[buf]) { sq_set_error("the error model is on (sq_quant_opts.error_model) but the batch came without its reads: use sq_aln_inject_reads"); return SQ_ERR_STATE; }
+    if (o->err_flag.ensure(A)) { sq_set_error("device allocation failed (error model flags)"); return SQ_ERR_NOMEM; }
+    ER = ErrReads{src->rd_cig_off[buf].p, src->rd_cig[buf].p, src->rd_seq_off[buf].p, src->rd_seq[buf].p, src->rd_pos[buf].p, src->rd_score[buf].p};
+  }
   OnlineView V = make_view(c);
+  if (err_on) SQ_HIP_CHECK(hipMemsetAsync(o->err_flag.p, 0, A, sq));
   mark("pick-stream+ensure");
   sq_prof_begin(c, 1);
   uint8_t* d_gcbin = q.gc_bias ? o->gcbin.p : nullptr;
@@ -1445,6 +1585,7 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
       SQ_HIP_CHECK(hipMemsetAsync(o->gflag.p, 0, bytes, sq));
       TA.flag = o->gflag.p;
     }
+    if (err_on && n) k_err_like<<<nblk(n), TB, 0, sq>>>(V, ER, 0, n, d_aln_off, (PreAln*)o->pre.p, o->assigned_prefix.p, 0ull, 1, q.num_pre_burnin_frags, c->di->ref_len, c->di->ref_accum, c->di->refseq);   // the matrices are final after burn-in: once per batch
     k_frag_static<<<nblk(n), 256, 0, sq>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p, TA);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
     const uint32_t W = o->inflight;
@@ -1497,10 +1638,15 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
     const uint64_t assigned_after = assigned_base + bound[b];
     const uint32_t par = (uint32_t)(o->group_no & 1);
+    if (err_on && r1 > r0) k_err_like<<<nblk(r1 - r0), TB, 0, st>>>(V, ER, r0, r1, d_aln_off, (PreAln*)o->pre.p, o->assigned_prefix.p, (unsigned long long)assigned_base, 0, q.num_pre_burnin_frags, c->di->ref_len, c->di->ref_accum, c->di->refseq);
     k_mini_batch<<<(uint32_t)(((uint64_t)(r1 - r0) * MB_G + 255) / 256), 256, 0, st>>>(V, q, r0, r1, mb, c->reads_seen + r0, d_aln_off, d_aln,
         (const PreAln*)o->pre.p,
         o->assigned_prefix.p, assigned_base, o->awq.p, o->alp.p, o->abin.p, o->rh1.p, o->rh2.p, par, d_gcbin);
     { const uint32_t mass_blocks = std::min<uint32_t>((o->M + AP_TB - 1) / AP_TB, 256u); const int with_fld = burned_host ? 0 : 1;
+      if (err_on && !burned_host && r1 > r0) {   // what the group's drawn alignments teach the matrices (AlignmentModel::update), folded in mini-batch by mini-batch
+        k_err_count<<<nblk(r1 - r0), TB, 0, st>>>(V, ER, r0, r1, d_aln_off, (const PreAln*)o->pre.p, c->di->ref_len, c->di->ref_accum, c->di->refseq);
+        k_err_apply<<<2 * o->err_bins * 82, 128, 0, st>>>(V, FM, nw);
+      }
       k_apply<<<mass_blocks + (uint32_t)with_fld, AP_TB, 0, st>>>(V, FM, nw, assigned_after, q.num_burnin_frags, mass_blocks, with_fld, par); }
     if (burn_now) {
       k_burnin_tables<<<1, 64, 0, st>>>(V, 0);
@@ -1664,6 +1810,18 @@ extern "C" int sq_model_fetch_pos_observed(sq_ctx* c, double* out200) {
   unsigned long long h[200];
   SQ_HIP_CHECK(hipMemcpy(h, c->online->pos_obs.p, sizeof(h), hipMemcpyDeviceToHost));
   for (int i = 0; i < 200; ++i) out200[i] = sq_from_fixed(h[i], 32);
+  return SQ_OK;
+}
+
+// [r5] the error model's matrices (log space): cells [2][bins][82][82], row sums [2][bins][82]; *bins_out = the number of read-position bins
+extern "C" int sq_model_fetch_error_model(sq_ctx* c, double* cells, double* rows, uint32_t* bins_out) {
+  if (!c) return SQ_ERR_ARG;
+  if (!c->online->err_bins) { sq_set_error("sq_model_fetch_error_model: the context was created without error_model"); return SQ_ERR_STATE; }
+  { int rs = sq_eq_sync(c); if (rs) return rs; }
+  SQ_HIP_CHECK(hipSetDevice(c->device)); const size_t b = c->online->err_bins;
+  if (bins_out) *bins_out = (uint32_t)b;
+  if (cells) SQ_HIP_CHECK(hipMemcpy(cells, c->online->err_cell.p, 2 * b * 82 * 82 * 8, hipMemcpyDeviceToHost));
+  if (rows) SQ_HIP_CHECK(hipMemcpy(rows, c->online->err_row.p, 2 * b * 82 * 8, hipMemcpyDeviceToHost));
   return SQ_OK;
 }
 

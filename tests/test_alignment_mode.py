@@ -246,8 +246,8 @@ def test_cli_alignment_mode_quantifies_from_a_sam_file(small_world, tmp_path):
     keep = np.array([ro[f + 1] > ro[f] for f in range(w["n"])]); ro_k = np.concatenate([[0], np.cumsum((ro[1:] - ro[:-1])[keep])]).astype(np.uint64)
     write_sam(tmp_path / "m.sam.gz", names, lens, ro_k, aln, unaligned_every=50)
     w["tx"].write_fasta(str(tmp_path / "t.fa"))
-    r = subprocess.run([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "m.sam.gz"), "-o", str(tmp_path / "out")], capture_output=True, text=True)
-    assert r.returncode != 0 and "--noErrorModel" in r.stderr                      # the CIGAR-based error model is not built: say so, do not pretend
+    # [r5] without a flag the CIGAR-based error model runs (the reference's default); these records carry no sequences, so it has nothing to say and the job goes through
+    subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "m.sam.gz"), "-o", str(tmp_path / "out_em"), "-q"])
     subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "m.sam.gz"), "-o", str(tmp_path / "out"), "--useASWithoutCIGAR", "-q"])
     import json
     meta = json.load(open(tmp_path / "out" / "aux_info" / "meta_info.json"))
