@@ -160,7 +160,7 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
     room = shutil.disk_usage(d).free; need = lambda n: int(1.8 * 2 * n * (2 * read_len + 7)) + (256 << 20)
     while n_pairs > 1000000 and need(n_pairs) > room: n_pairs //= 2
     gz_pairs = min(n_pairs, gz_pairs or n_pairs)
-    out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(),
+    out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(), "host_cpu_quota_cores": cpu_allowance()[1],
            "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
            "what": "end to end from files through sq_reader, H2D included; plain files: text staged in page-locked memory, records split on the device "
                    "(hip/fastq_dev.hip); gzip/BGZF: inflated and split on the host (host/reader.cpp, host/pgzip.cpp)"}
@@ -255,6 +255,21 @@ def _write_bgzf(src, dst, block=0xff00):
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex, open(dst, "wb") as f:
         for m in ex.map(member, range(0, len(data), block)): f.write(m)
         f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
+
+
+def cpu_allowance():
+    """(hardware threads the process may be scheduled on, CPU quota of its cgroup in cores or None): the GPU boxes of this pool show 256 threads and give a
+    container 16 cores' worth of time (cpu.max = 1600000 100000) — the quota, not the thread count, is what the host legs have."""
+    hw = os.cpu_count() or 8; quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max": quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0: quota = q / p
+        except Exception: pass
+    return hw, quota
 
 
 def baseline_metric():
@@ -712,7 +727,9 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
                 g_g = api.gibbs(eq_g, np.exp(le_g), a_g, 8, 7, int(eq_g.count.sum()), api.gibbs_opts(), device=local)
                 g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())
                 parity["checks"]["gibbs_8_samples"] = sha(g_g) == sha(g_c); parity["equal"] = all(parity["checks"].values())
-            cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": ncores, "kind": "port",
+            hw_thr, quota = cpu_allowance()
+            cpu = {"value": round(Sn / t_cpu / 1e6, 4), "unit": "M read-pairs/s", "cores": int(round(min(ncores, quota))) if quota else ncores, "kind": "port",
+                   "threads_started": ncores, "cpu_quota_cores": quota,
                    "sample": "%d of the %d pairs of step 0 through the CPU checker (oracle/): map %.2fs (%d threads) + online model / eq-classes %.2fs (1 thread: the mini-batch chain is sequential) + VBEM %d iters %.2fs (best of 1/8/32/%d threads: %d); %.1fs of CPU work in all; checker index built in %.1fs (not counted)" % (Sn,
                        sizes[W * S], c1 - c0, ncores, c2 - c1, repc["iters"], em_thr_s, ncores, em_thr_n, t_cpu, t_oidx),
                    "map_only_M_pairs_per_s": round(Sn / (c1 - c0) / 1e6, 4), "em_iters_per_s_full_table_%dthr" % ncores: round(1.0 / em_cpu_s, 2),
