@@ -649,6 +649,12 @@ int sq_debug_infix_align(int device, uint32_t ncases, const uint8_t* queries, co
                          const uint8_t* windows, const uint64_t* w_off /*[ncases+1]*/, const int32_t* k /*[ncases]*/,
                          int32_t* out /*[4*ncases]*/);
 
+/* [r5] test hooks of the device BGZF inflater (hip/inflate_dev.hip).  sq_debug_bgzf_inflate: members (raw deflate streams in `comp`, descriptors
+ * {coff, voff, csize, isize, crc, 0} of 32 bytes each) through the device kernel; status2[0] = 0xFFFFFFFF or index + 1 of the first damaged member, status2[1] = why.
+ * sq_debug_inflate_core_host: the decoder's source compiled for the CPU (tests check it against zlib where there is no GPU; 0 = sound). */
+int sq_debug_bgzf_inflate(int device, const uint8_t* comp, uint64_t comp_bytes, const void* members, uint32_t nmem, uint8_t* text, uint64_t text_bytes, uint32_t* status2);
+int sq_debug_inflate_core_host(const uint8_t* comp, uint64_t csize, uint8_t* out, uint32_t isize, uint32_t* crc_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@
 #include "../host/index.h"
 #include "../host/reader_dev.h"
 #include "../host/bgzf_source.h"
+#include "inflate_dev.h"
 
 namespace {
 constexpr int FQ_TB = 256;   // 16 bytes per lane: a 4 KB tile per block
@@ -122,10 +123,13 @@ struct sq_dev_reader {
   struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; std::string name;   // name: the last file, for messages
     // BGZF files only (bgz): no buffers in between — the members of a round are inflated straight into its ring pieces.  mem: every non-empty member
     // scanned so far, with the offset of its text in the stream (file = ~0u: the newline a file without a last one gets)
-    bool bgz = false; struct BzMember { uint32_t file; uint32_t csize; uint64_t coff; uint32_t isize; uint64_t voff; }; std::vector<BzMember> mem; size_t scan_file = 0; uint64_t scan_off = 0, scan_voff = 0, scan_file_bytes = 0; bool scan_done = false;
+    bool bgz = false; struct BzMember { uint32_t file; uint32_t csize; uint64_t coff; uint32_t isize; uint64_t voff; uint32_t crc, hdr; };   // crc: of the text (trailer); hdr: bytes of gzip header in front of the deflate stream
+    std::vector<BzMember> mem; size_t scan_file = 0; uint64_t scan_off = 0, scan_voff = 0, scan_file_bytes = 0; bool scan_done = false;
     bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
   std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the buffered sequential streams
-  bool any_buffered = false, any_bgz = false;
+  bool any_buffered = false, any_bgz = false, dev_inflate = false;   // dev_inflate: every stream is BGZF and the members are inflated by hip/inflate_dev.hip (produce_devinf)
+  struct Carry { int slot = -1; size_t off = 0, n = 0; } carry[2];   // the text behind the last batch's records: it opens the next batch
+  size_t dv_next[2] = {0, 0};   // the next member of each stream to be inflated
   struct Slot {   // device side only: the text of a batch never sits in host memory as a whole
     void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
     void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
@@ -134,6 +138,8 @@ struct sq_dev_reader {
     void* d_len = nullptr; size_t len_cap = 0; void* d_off = nullptr; size_t off_cap = 0;
     void* d_seq = nullptr; size_t seq_cap = 0; unsigned* d_err = nullptr; unsigned* h_res = nullptr; hipStream_t st = nullptr;
     uint32_t n = 0; size_t bytes[2] = {0, 0};
+    // [r5] BGZF inflated on the device: the round's compressed bytes and member descriptors; what of the mate's text is left over behind the batch's last record
+    void* d_comp[2] = {nullptr, nullptr}; size_t comp_cap[2] = {0, 0}; void* d_mem[2] = {nullptr, nullptr}; size_t mem_cap[2] = {0, 0}; uint32_t* d_st = nullptr; size_t total[2] = {0, 0};
   };
   std::vector<Slot> slots;
   std::unique_ptr<Workers> pool;
@@ -182,7 +188,7 @@ struct sq_dev_reader {
           if (j > 0) { const Stream::BzMember& M = S.mem[j - 1]; std::vector<char> tmp((size_t)M.isize + 64);
             const char* w = BgzfSource::inflate_member(base + M.coff, BgzfSource::Mem{(size_t)M.coff, (size_t)M.csize, M.isize, 0}, tmp.data());
             if (*w) { *e = "'" + F.path + "': " + w; return false; }
-            if (tmp[M.isize - 1] != '\n') { S.mem.push_back(Stream::BzMember{~0u, 0, 0, 1, S.scan_voff}); S.scan_voff += 1; } }
+            if (tmp[M.isize - 1] != '\n') { S.mem.push_back(Stream::BzMember{~0u, 0, 0, 1, S.scan_voff, 0, 0}); S.scan_voff += 1; } }
         }
         ++S.scan_file; S.scan_off = 0; S.scan_file_bytes = 0; continue;
       }
@@ -190,7 +196,8 @@ struct sq_dev_reader {
       if (ms == 0 || ms > n - S.scan_off || ms < 26) { *e = "'" + F.path + "': " + (ms ? "truncated BGZF member" : "not a BGZF member (mixed gzip file?)"); return false; }
       const uint32_t isize = BgzfSource::le32(base + S.scan_off + ms - 4);
       if (isize > (1u << 16)) { *e = "'" + F.path + "': BGZF member larger than 64 KB"; return false; }
-      if (isize) { S.mem.push_back(Stream::BzMember{(uint32_t)S.scan_file, (uint32_t)ms, S.scan_off, isize, S.scan_voff}); S.scan_voff += isize; S.scan_file_bytes += isize; }
+      if (isize) { const uint8_t* hp = base + S.scan_off; const uint32_t hdr = 12u + ((uint32_t)hp[10] | ((uint32_t)hp[11] << 8));
+        S.mem.push_back(Stream::BzMember{(uint32_t)S.scan_file, (uint32_t)ms, S.scan_off, isize, S.scan_voff, BgzfSource::le32(hp + ms - 8), hdr}); S.scan_voff += isize; S.scan_file_bytes += isize; }
       S.scan_off += ms;
     }
     return true;

@@ -1,0 +1,288 @@
+// hip/inflate_core.h — [r5] one raw deflate stream of known output size (a BGZF member: at most 64 KB of text) decoded by ONE wave.
+//
+// Why: the GPU boxes give a process 16 cores' worth of CPU time, and 16 cores inflate ~10 GB/s of FASTQ text — a quarter of what the PCIe link
+// moves for plain files (profiles/r05_reader_compressed.txt).  A BGZF file is ~130 000 independent members per 20 M reads, and the compressed bytes
+// are a third of the text: inflated on the device, such a file crosses PCIe faster than a plain one.
+//
+// How it runs on the device (hip/inflate_dev.hip): a WAVE per member.  The decoder's state (bit buffer, positions, the symbol just decoded) is the same in
+// every lane — the kernel makes the wave's index uniform, so the compiler keeps that state in scalar registers and reads the compressed bytes with scalar
+// loads; the wave is a scalar processor that walks the Huffman codes (RFC 1951: a table of LIT_BITS / DIST_BITS peeked bits answers all but the longest
+// codes, those are walked bit by bit through the canonical counts as in zlib's contrib/puff).  The LANES are used where bytes move: literals gather in one
+// register, a lane each, and leave as one store of up to 64 bytes; a match is copied by up to 64 lanes at once (lane i takes byte i mod distance of the
+// window, which also lays out the period of an overlapping match); the CRC-32 is taken over 64 stretches at once and folded (x^(8n) mod P).  Memory
+// operations of one wave complete in order, so a lane may read what another lane of its wave stored by an earlier instruction.
+// Parallelism across members does the rest: a batch of 10^6 read pairs is ~13 000 members = 13 000 waves.
+//
+// The same source compiles for the host (SQ_HD; the lane parts have plain loops there), which is how tests/test_inflate.py checks tables, bit reader and
+// the CRC folding against zlib on machines without a GPU; the host build is a test hook (sq_debug_inflate_core_host), not a path of the product.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../sq_internal.h"
+
+namespace sqinf {
+
+// a value every lane holds alike, said so to the compiler (it then lives in a scalar register and the arithmetic on it is scalar)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SQ_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define SQ_INL SQ_HD __attribute__((always_inline))
+#else
+#define SQ_UNI(x) ((uint32_t)(x))
+#define SQ_INL SQ_HD
+#endif
+
+constexpr int LIT_BITS = 10, DIST_BITS = 9;
+struct Huff { uint16_t count[16]; uint16_t symbol[288]; };                 // codes of each length; symbols in code order
+struct HuffS { uint16_t count[16]; uint16_t symbol[32]; };                 // the same for the 30 distance codes and the 19 code-length codes
+// per wave (LDS on the device).  *_fast[peeked bits] = symbol << 4 | code length, 0 where the code is longer than the peek
+struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_BITS]; Huff lit; HuffS dist, clen; uint8_t lengths[320]; uint16_t offs[16]; };
+
+enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF_BAD_CODES = 4, INF_BAD_SYMBOL = 5, INF_BAD_DISTANCE = 6, INF_OUTPUT_SIZE = 7 };
+
+// the input, least significant bit first.  Words of four bytes are read at aligned addresses (scalar loads on the device); the bytes in front of the
+// first aligned word and behind the last whole one go one by one.  Past the end of the input the buffer yields zeros and `cnt` goes negative: the
+// callers look at bad() once per symbol, before anything decoded from those zeros is stored
+struct Bits {
+  const uint8_t* p; uint32_t n, pos; uint64_t buf; int cnt;      // (a member is at most 64 KB: 32-bit positions compare in one scalar instruction)
+  SQ_INL void init(const uint8_t* p_, size_t n_) {
+    p = p_; n = (uint32_t)n_; pos = 0; buf = 0; cnt = 0;
+    while (pos < n && ((uintptr_t)(p + pos) & 3)) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
+  }
+  SQ_INL void refill() {                 // behind it at least 33 bits are there (unless the input ends): a length code with its extra bits, or a distance code with its
+    if (cnt > 32 || cnt < 0) return;
+    if (pos + 4 <= n) { buf |= (uint64_t)SQ_UNI(*(const uint32_t*)(p + pos)) << cnt; cnt += 32; pos += 4; }
+    else while (cnt <= 56 && pos < n) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
+  }
+  SQ_INL uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1); }
+  SQ_INL void drop(int k) { buf >>= k; cnt -= k; }
+  SQ_INL uint32_t take(int k) { const uint32_t v = peek(k); drop(k); return v; }      // k <= 16, refilled by the caller
+  SQ_INL uint32_t get(int k) { refill(); return take(k); }
+  SQ_INL bool bad() const { return cnt < 0; }
+};
+
+// canonical Huffman table from code lengths (puff.c construct): < 0 over-subscribed, 0 complete, > 0 incomplete
+// (offs: where the next symbol of each length goes — 16 slots borrowed from the caller's table memory, not registers: they are indexed by a variable)
+template <class H> SQ_INL int build(H& h, const uint8_t* length, int n, uint16_t* offs) {
+  for (int l = 0; l < 16; ++l) h.count[l] = 0;
+#pragma unroll 1
+  for (int s = 0; s < n; ++s) { const uint32_t l = SQ_UNI(length[s]); h.count[l] = (uint16_t)(SQ_UNI(h.count[l]) + 1); }
+  if ((int)SQ_UNI(h.count[0]) == n) return 0;
+  int left = 1;
+#pragma unroll 1
+  for (int l = 1; l < 16; ++l) { left <<= 1; left -= (int)SQ_UNI(h.count[l]); if (left < 0) return left; }
+  offs[1] = 0;
+#pragma unroll 1
+  for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(SQ_UNI(offs[l]) + SQ_UNI(h.count[l]));
+#pragma unroll 1
+  for (int s = 0; s < n; ++s) { const uint32_t l = SQ_UNI(length[s]); if (l) { const uint32_t at = SQ_UNI(offs[l]); offs[l] = (uint16_t)(at + 1); h.symbol[at] = (uint16_t)s; } }
+  return left;
+}
+// the peek table of a code: every `bits`-bit pattern that starts with a code of at most `bits` bits (codes are sent most significant bit first, the
+// input is read least significant bit first: the pattern is the reversed code, and every setting of the bits behind it)
+template <class H> SQ_INL void build_fast(const H& h, uint16_t* fast, int bits) {
+  uint64_t* z = (uint64_t*)fast;
+#pragma unroll 4
+  for (int i = 0; i < (1 << bits) / 4; ++i) z[i] = 0;
+  uint32_t code = 0, index = 0;
+#pragma unroll 1
+  for (int len = 1; len <= bits; ++len) {
+    const uint32_t count = SQ_UNI(h.count[len]);
+#pragma unroll 1
+    for (uint32_t j = 0; j < count; ++j) {
+      const uint32_t r = __builtin_bitreverse32(code + j) >> (32 - len);
+      const uint16_t e = (uint16_t)((SQ_UNI(h.symbol[index + j]) << 4) | (uint32_t)len);
+#pragma unroll 1
+      for (uint32_t k = r; k < (1u << bits); k += 1u << len) fast[k] = e;
+    }
+    index += count; code = (code + count) << 1;
+  }
+}
+// a symbol whose code the peek table does not hold, bit by bit through the canonical counts (puff.c decode): -1 on a code that is not in the table
+template <class H> SQ_INL int decode_long(Bits& b, const H& h) {
+  int code = 0, first = 0, index = 0;
+#pragma unroll 1
+  for (int len = 1; len <= 15; ++len) {
+    code |= (int)b.take(1);
+    const int count = (int)SQ_UNI(h.count[len]);
+    if (code - count < first) return (int)SQ_UNI(h.symbol[index + (code - first)]);
+    index += count; first += count; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+// one symbol (the caller has refilled)
+template <class H> SQ_INL int decode(Bits& b, const H& h, const uint16_t* fast, int bits) {
+  const uint32_t e = SQ_UNI(fast[b.peek(bits)]);
+  if (e) { b.drop((int)(e & 15)); return (int)(e >> 4); }
+  return decode_long(b, h);
+}
+
+SQ_INL void fixed_tables(Tables& T) {
+  int s = 0;
+  for (; s < 144; ++s) T.lengths[s] = 8;
+  for (; s < 256; ++s) T.lengths[s] = 9;
+  for (; s < 280; ++s) T.lengths[s] = 7;
+  for (; s < 288; ++s) T.lengths[s] = 8;
+  (void)build(T.lit, T.lengths, 288, T.offs); build_fast(T.lit, T.lit_fast, LIT_BITS);
+  for (s = 0; s < 30; ++s) T.lengths[s] = 5;
+  (void)build(T.dist, T.lengths, 30, T.offs); build_fast(T.dist, T.dist_fast, DIST_BITS);
+}
+SQ_INL int dynamic_tables(Bits& b, Tables& T) {
+  const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+  if (b.bad()) return INF_EOF_INPUT;
+  if (nlen > 286 || ndist > 30) return INF_BAD_CODES;
+  int i = 0;
+  for (; i < ncode; ++i) T.lengths[SQ_UNI(order[i])] = (uint8_t)b.get(3);
+  for (; i < 19; ++i) T.lengths[SQ_UNI(order[i])] = 0;
+  if (b.bad()) return INF_EOF_INPUT;
+  if (build(T.clen, T.lengths, 19, T.offs) != 0) return INF_BAD_CODES;       // the code-length code must be complete
+  build_fast(T.clen, T.dist_fast, 7);                                  // (its peek table borrows the distance table's place: that one is built below)
+  i = 0;
+  while (i < nlen + ndist) {
+    b.refill();
+    int sym = decode(b, T.clen, T.dist_fast, 7);
+    if (b.bad()) return INF_EOF_INPUT;
+    if (sym < 0) return INF_BAD_CODES;
+    if (sym < 16) T.lengths[i++] = (uint8_t)sym;
+    else {
+      int len = 0, rep;
+      if (sym == 16) { if (i == 0) return INF_BAD_CODES; len = (int)SQ_UNI(T.lengths[i - 1]); rep = 3 + (int)b.take(2); }
+      else if (sym == 17) rep = 3 + (int)b.take(3);
+      else rep = 11 + (int)b.take(7);
+      if (b.bad()) return INF_EOF_INPUT;
+      if (i + rep > nlen + ndist) return INF_BAD_CODES;
+      while (rep--) T.lengths[i++] = (uint8_t)len;
+    }
+  }
+  if (SQ_UNI(T.lengths[256]) == 0) return INF_BAD_CODES;                      // no end-of-block code
+  int err = build(T.lit, T.lengths, nlen, T.offs);
+  if (err < 0 || (err > 0 && nlen - (int)SQ_UNI(T.lit.count[0]) != 1)) return INF_BAD_CODES;
+  build_fast(T.lit, T.lit_fast, LIT_BITS);
+  // the distance lengths follow the literal/length lengths in the same array: shifted to its start for build
+  for (int s = 0; s < ndist; ++s) T.lengths[s] = (uint8_t)SQ_UNI(T.lengths[nlen + s]);
+  err = build(T.dist, T.lengths, ndist, T.offs);
+  if (err < 0 || (err > 0 && ndist - (int)SQ_UNI(T.dist.count[0]) != 1)) return INF_BAD_CODES;
+  build_fast(T.dist, T.dist_fast, DIST_BITS);
+  return INF_OK;
+}
+
+// where the text goes.  Device: `lane` is the thread's lane; literals wait in `litv` (lane k holds literal k of the run) until 64 are there or a
+// match needs them in memory.  Host: bytes, in order.
+struct Out {
+  uint8_t* out; uint32_t on; uint32_t nlit;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t lane, litv;
+  __device__ void init(uint8_t* o) { out = o; on = 0; nlit = 0; litv = 0; lane = __lane_id(); }
+  __device__ void flush() { if (lane < nlit) out[on + lane] = (uint8_t)litv; on += nlit; nlit = 0; }
+  __device__ void put(uint32_t byte) { if (lane == nlit) litv = byte; if (++nlit == 64) flush(); }
+  __device__ void copy(uint32_t dist, uint32_t len) {
+    flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
+    if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
+    else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }       // the window's last `dist` bytes, repeated
+    on += len;
+  }
+#else
+  void init(uint8_t* o) { out = o; on = 0; nlit = 0; }
+  void flush() {}
+  void put(uint32_t byte) { out[on++] = (uint8_t)byte; }
+  void copy(uint32_t dist, uint32_t len) { const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; }
+#endif
+  SQ_HD uint32_t size() const { return on + nlit; }
+};
+
+// the whole stream: `isize` bytes of output are expected (a BGZF member's trailer says how many).  Returns INF_OK or what was wrong.
+SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t isize, Tables& T) {
+  // base | extra bits << 12 of the 29 length symbols; base | extra bits << 16 of the 30 distance symbols
+  const uint32_t lenx[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 12, 13 | 1 << 12, 15 | 1 << 12, 17 | 1 << 12, 19 | 2 << 12, 23 | 2 << 12, 27 | 2 << 12, 31 | 2 << 12, 35 | 3 << 12, 43 | 3 << 12,
+                             51 | 3 << 12, 59 | 3 << 12, 67 | 4 << 12, 83 | 4 << 12, 99 | 4 << 12, 115 | 4 << 12, 131 | 5 << 12, 163 | 5 << 12, 195 | 5 << 12, 227 | 5 << 12, 258};
+  const uint32_t distx[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16, 65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16,
+                              193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16, 1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16,
+                              6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
+  Bits b; b.init(in, n); Out o; o.init(out); int rc = INF_OK;
+  for (;;) {
+    const uint32_t last = b.get(1), type = b.take(2);
+    if (b.bad()) return INF_EOF_INPUT;
+    if (type == 3) return INF_BAD_BLOCK;
+    if (type == 0) {
+      b.take(b.cnt & 7);                                              // to the next byte boundary; the buffer then holds whole bytes
+      const uint32_t len = b.get(16), nlen = b.get(16);
+      if (b.bad()) return INF_EOF_INPUT;
+      if ((len ^ nlen) != 0xFFFFu) return INF_BAD_STORED;
+      if (o.size() + len > isize) return INF_OUTPUT_SIZE;
+#pragma unroll 1
+      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); }
+    } else {
+      if (type == 1) fixed_tables(T);
+      else { rc = dynamic_tables(b, T); if (rc) return rc; }
+      // the loop that does the work: one literal, or one length / distance pair, per turn; every way out of it leaves through the one test behind it
+#pragma unroll 1
+      for (;;) {
+        b.refill();
+        int sym = decode(b, T.lit, T.lit_fast, LIT_BITS);
+        if (sym < 256) {
+          if (sym < 0 || b.bad() || o.size() >= isize) { rc = b.bad() ? INF_EOF_INPUT : sym < 0 ? INF_BAD_SYMBOL : INF_OUTPUT_SIZE; break; }
+          o.put((uint32_t)sym); continue;
+        }
+        if (sym == 256) { if (b.bad()) rc = INF_EOF_INPUT; break; }
+        sym -= 257; if (sym >= 29) { rc = INF_BAD_SYMBOL; break; }
+        const uint32_t lx = SQ_UNI(lenx[sym]); const uint32_t len = (lx & 0xFFF) + b.take((int)(lx >> 12));
+        b.refill();
+        const int ds = decode(b, T.dist, T.dist_fast, DIST_BITS);
+        if (ds < 0 || ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
+        const uint32_t dx = SQ_UNI(distx[ds]); const uint32_t dist = (dx & 0xFFFF) + b.take((int)(dx >> 16));
+        if (b.bad() || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : dist > o.size() ? INF_BAD_DISTANCE : INF_OUTPUT_SIZE; break; }
+        o.copy(dist, len);
+      }
+      if (rc) return rc;
+    }
+    if (last) break;
+  }
+  o.flush();
+  return o.size() == isize ? INF_OK : INF_OUTPUT_SIZE;
+}
+
+// CRC-32 (the gzip polynomial, reflected) of n bytes, a byte at a time through a 256-entry table
+SQ_HD uint32_t crc32_bytes(const uint32_t* table, const uint8_t* p, uint32_t n) {
+  uint32_t c = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+SQ_HD uint32_t crc32_entry(uint32_t i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1); return c; }
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0), and x^(8n) mod P: crc(A || B) = crc(A) * x^(8 |B|) + crc(B), which is how the CRCs
+// of 64 stretches of a member, taken by 64 lanes at once, fold into the member's (zlib's crc32_combine states the same identity)
+SQ_HD uint32_t crc_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll 1
+  for (int i = 0; i < 32; ++i) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+  return p;
+}
+SQ_HD uint32_t crc_xpow8(uint32_t n) {
+  uint32_t r = 0x80000000u, sq = 0x00800000u;      // x^0; x^8
+  for (; n; n >>= 1) { if (n & 1) r = crc_mul(sq, r); sq = crc_mul(sq, sq); }
+  return r;
+}
+// the stretches: lane 0 takes n / 64 + n % 64 bytes, every other lane n / 64
+SQ_HD void crc_stretch(uint32_t n, uint32_t lane, uint32_t* start, uint32_t* len) {
+  const uint32_t q = n / 64, first = q + n % 64;
+  *start = lane ? first + (lane - 1) * q : 0; *len = lane ? q : first;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline uint32_t crc32_wave(const uint32_t* table, const uint8_t* p, uint32_t n) {
+  const uint32_t lane = __lane_id(); uint32_t start, len; crc_stretch(n, lane, &start, &len);
+  uint32_t c = crc32_bytes(table, p + start, len), X = crc_xpow8(n / 64);
+  for (uint32_t s = 1; s < 64; s <<= 1) {       // lanes i and i + s hold the CRCs of s stretches each: behind the step lane i holds that of 2 s
+    const uint32_t other = (uint32_t)__shfl_down((int)c, (int)s);
+    if ((lane & (2 * s - 1)) == 0) c = crc_mul(X, c) ^ other;
+    X = crc_mul(X, X);
+  }
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+}
+#else
+inline uint32_t crc32_wave(const uint32_t* table, const uint8_t* p, uint32_t n) {      // the same stretches, folded left to right
+  const uint32_t X = crc_xpow8(n / 64); uint32_t c = 0;
+  for (uint32_t lane = 0; lane < 64; ++lane) { uint32_t start, len; crc_stretch(n, lane, &start, &len); const uint32_t ci = crc32_bytes(table, p + start, len); c = lane ? crc_mul(X, c) ^ ci : ci; }
+  return c;
+}
+#endif
+
+}  // namespace sqinf
