@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -127,9 +128,24 @@ struct sq_dev_reader {
     std::vector<BzMember> mem; size_t scan_file = 0; uint64_t scan_off = 0, scan_voff = 0, scan_file_bytes = 0; bool scan_done = false;
     bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
   std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the buffered sequential streams
-  bool any_buffered = false, any_bgz = false, dev_inflate = false;   // dev_inflate: every stream is BGZF and the members are inflated by hip/inflate_dev.hip (produce_devinf)
-  struct Carry { int slot = -1; size_t off = 0, n = 0; } carry[2];   // the text behind the last batch's records: it opens the next batch
-  size_t dv_next[2] = {0, 0};   // the next member of each stream to be inflated
+  bool any_buffered = false, any_bgz = false, dev_inflate = false;   // dev_inflate: every stream is BGZF and the members are inflated by hip/inflate_dev.hip
+  // [r5] BGZF inflated on the device.  The stager thread feeds each mate stream's CHUNKS: the next members of the stream (up to DV_MEMBERS of them — a wave each,
+  // so a chunk is a launch that fills the chip), their compressed bytes copied from the file mapping into ring pieces, sent to the device, inflated there into the
+  // chunk's buffer (a ring of DV_CHUNKS buffers per stream).  The splitter thread cuts batches out of that text: it copies what it expects a batch to take from the
+  // chunk buffers into the slot's text (device to device), counts lines there, takes more if the records were longer than expected, and moves the stream's
+  // position behind the batch's last line; a chunk whose text is all behind the position goes back to the stager.
+  static constexpr int DV_CHUNKS = 6; uint32_t DV_MEMBERS = 4096;
+  struct DvChunk { int idx = 0; uint64_t voff = 0; size_t n = 0; bool last = false; std::vector<std::pair<uint32_t, uint64_t>> where; };   // where: (file, offset) of its members, for messages
+  struct DvStream {
+    void* text[DV_CHUNKS] = {}; size_t text_cap[DV_CHUNKS] = {}; void* comp[DV_CHUNKS] = {}; size_t comp_cap[DV_CHUNKS] = {}; void* mem[DV_CHUNKS] = {}; size_t mem_cap[DV_CHUNKS] = {};
+    uint32_t* st = nullptr;                      // 2 words per chunk buffer (inflate_dev.hip's status)
+    hipStream_t hs[2] = {nullptr, nullptr}; hipEvent_t ev_h2d[DV_CHUNKS] = {}, ev_done[DV_CHUNKS] = {};
+    std::deque<DvChunk> q;                        // inflated or being inflated, in stream order (mu)
+    std::deque<std::pair<int, std::vector<int>>> lent;   // (chunk buffer, ring pieces) whose copies to the device may still run (stager only)
+    uint64_t produced = 0, ahead = 0; size_t next_mem = 0; bool finished = false;   // stager; `ahead`: the stream offset behind the last chunk made
+    uint64_t pos = 0;                             // splitter: the stream offset of the next batch's first byte
+  } dv[2];
+  double t_dv_fill = 0, t_dv_wait = 0, t_dv_split = 0;
   struct Slot {   // device side only: the text of a batch never sits in host memory as a whole
     void* d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
     void* d_nlpos[2] = {nullptr, nullptr}; size_t nl_cap[2] = {0, 0};
@@ -138,8 +154,6 @@ struct sq_dev_reader {
     void* d_len = nullptr; size_t len_cap = 0; void* d_off = nullptr; size_t off_cap = 0;
     void* d_seq = nullptr; size_t seq_cap = 0; unsigned* d_err = nullptr; unsigned* h_res = nullptr; hipStream_t st = nullptr;
     uint32_t n = 0; size_t bytes[2] = {0, 0};
-    // [r5] BGZF inflated on the device: the round's compressed bytes and member descriptors; what of the mate's text is left over behind the batch's last record
-    void* d_comp[2] = {nullptr, nullptr}; size_t comp_cap[2] = {0, 0}; void* d_mem[2] = {nullptr, nullptr}; size_t mem_cap[2] = {0, 0}; uint32_t* d_st = nullptr; size_t total[2] = {0, 0};
   };
   std::vector<Slot> slots;
   std::unique_ptr<Workers> pool;
@@ -396,7 +410,7 @@ struct sq_dev_reader {
     const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns;
     if (r.first_of_batch) {
       if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { *e = "device allocation failed (reader)"; return SQ_ERR_NOMEM; }
-      if (!s.h_res && hipHostMalloc((void**)&s.h_res, 64, hipHostMallocDefault) != hipSuccess) { *e = "page-locked allocation failed (reader)"; return SQ_ERR_NOMEM; }
+      if (!s.h_res && hipHostMalloc((void**)&s.h_res, 256, hipHostMallocDefault) != hipSuccess) { *e = "page-locked allocation failed (reader)"; return SQ_ERR_NOMEM; }
       if (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess) { *e = "device failure in the reader"; return SQ_ERR_DEVICE; }
     }
     size_t rb = 0; for (auto& pc : r.pieces) rb += pc.second;
@@ -449,6 +463,193 @@ struct sq_dev_reader {
       std::lock_guard<std::mutex> lk(mu); t_upload += dt;
       if (rc != SQ_OK) { err = e; err_rc = rc; done = true; stop = true; cv.notify_all(); return; }
       if (r.last_of_batch) { total += slots[(size_t)r.slot].n; ready.push_back(r.slot); cv.notify_all(); }
+    }
+  }
+  // ---- [r5] BGZF inflated on the device ---------------------------------------------------------------------------------------------------------
+  void dv_fail(int rc, const std::string& e) { std::lock_guard<std::mutex> lk(mu); if (err_rc == SQ_OK) { err = e; err_rc = rc; } done = true; stop = true; cv.notify_all(); }
+  std::deque<std::pair<hipEvent_t, std::vector<int>>> dv_lent;   // ring pieces whose copy to the device may still run, oldest first (stager only)
+  // the stager: chunk after chunk of the stream that is the least ahead of its splitter
+  void produce_inflate() {
+    (void)hipSetDevice(device);
+    const int ns = paired ? 2 : 1;
+    for (;;) {
+      int i = -1;
+      { std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { if (stop) return true; bool all = true; for (int k = 0; k < ns; ++k) { if (!dv[k].finished && dv[k].q.size() < (size_t)DV_CHUNKS) return true; all = all && dv[k].finished; } return all; });
+        if (stop) return;
+        uint64_t best = ~0ull;
+        for (int k = 0; k < ns; ++k) if (!dv[k].finished && dv[k].q.size() < (size_t)DV_CHUNKS) { const uint64_t a = dv[k].ahead - dv[k].pos; if (a < best) { best = a; i = k; } }
+        if (i < 0) return; }   // every stream has been inflated to its end
+      Stream& S = sm[i]; DvStream& D = dv[i]; std::string e; const double t0 = now();
+      const int idx = (int)(D.produced % DV_CHUNKS); hipStream_t hs = D.hs[D.produced & 1];
+      if (!bz_scan(S, D.ahead + (uint64_t)DV_MEMBERS * 65536 + 1, &e)) { dv_fail(SQ_ERR_IO, e); return; }
+      const size_t m0 = D.next_mem; size_t m1 = m0, tbytes = 0, cbytes = 0;
+      while (m1 < S.mem.size() && m1 - m0 < DV_MEMBERS) { tbytes += S.mem[m1].isize; cbytes += S.mem[m1].csize; ++m1; }
+      const uint32_t nmem = (uint32_t)(m1 - m0); const bool last = m1 == S.mem.size() && S.scan_done;
+      DvChunk ch; ch.idx = idx; ch.voff = D.ahead; ch.n = tbytes; ch.last = last; ch.where.reserve(nmem);
+      if (nmem) {
+        // the compressed stream of the chunk = its members' bytes behind each other (headers and trailers included: the descriptors point behind the headers);
+        // then the descriptors, in a piece of their own
+        std::vector<uint64_t> coffs((size_t)nmem + 1, 0); for (uint32_t k = 0; k < nmem; ++k) coffs[k + 1] = coffs[k] + S.mem[m0 + k].csize;
+        const size_t ncp = (cbytes + PIECE - 1) / PIECE, np = ncp + 1;
+        if ((size_t)nmem * sizeof(sq_bgzf_member) > PIECE || np > (size_t)RING_PIECES) { dv_fail(SQ_ERR_STATE, "internal: a chunk of BGZF members does not fit the reader's ring"); return; }
+        std::vector<int> pcs;
+        { std::unique_lock<std::mutex> lk(mu);
+          while (free_pieces.size() < np) {
+            if (dv_lent.empty()) { lk.unlock(); dv_fail(SQ_ERR_STATE, "internal: the reader's ring ran out of pieces"); return; }
+            auto L = std::move(dv_lent.front()); dv_lent.pop_front(); lk.unlock();
+            if (hipEventSynchronize(L.first) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError())); return; }
+            lk.lock(); for (int pc : L.second) free_pieces.push_back(pc);
+          }
+          for (size_t k = 0; k < np; ++k) { pcs.push_back(free_pieces.front()); free_pieces.pop_front(); } }
+        constexpr size_t TASK = 1u << 20; const unsigned ntask = (unsigned)((cbytes + TASK - 1) / TASK);
+        pool->run(ntask, [&](unsigned t) {
+          const uint64_t a = (uint64_t)t * TASK, b = std::min<uint64_t>(a + TASK, cbytes);
+          size_t k = (size_t)(std::upper_bound(coffs.begin(), coffs.end(), a) - coffs.begin()) - 1;   // the member that holds byte a
+          for (uint64_t at = a; at < b; ++k) {
+            const Stream::BzMember& M = S.mem[m0 + k]; if (!M.csize) continue;
+            const uint64_t in = at - coffs[k], take = std::min<uint64_t>(M.csize - in, b - at);
+            memcpy(ring + (size_t)pcs[(size_t)(at / PIECE)] * PIECE + (size_t)(at % PIECE), (const uint8_t*)S.sfiles[M.file]->map->p + M.coff + in, (size_t)std::min<uint64_t>(take, PIECE - at % PIECE));
+            if (take > PIECE - at % PIECE) { const uint64_t d1 = PIECE - at % PIECE; memcpy(ring + (size_t)pcs[(size_t)(at / PIECE) + 1] * PIECE, (const uint8_t*)S.sfiles[M.file]->map->p + M.coff + in + d1, (size_t)(take - d1)); }
+            at += take;
+          }
+        });
+        sq_bgzf_member* desc = (sq_bgzf_member*)(ring + (size_t)pcs[ncp] * PIECE); uint64_t tv = 0;
+        for (uint32_t k = 0; k < nmem; ++k) { const Stream::BzMember& M = S.mem[m0 + k];
+          desc[k] = M.file == ~0u ? sq_bgzf_member{0, tv, 0, M.isize, 0, 0} : sq_bgzf_member{coffs[k] + M.hdr, tv, M.csize - M.hdr - 8, M.isize, M.crc, 0};
+          tv += M.isize; ch.where.push_back({M.file, M.coff}); }
+        if (dev_grow(&D.text[idx], &D.text_cap[idx], tbytes + 64) || dev_grow(&D.comp[idx], &D.comp_cap[idx], cbytes + 64) || dev_grow(&D.mem[idx], &D.mem_cap[idx], (size_t)nmem * sizeof(sq_bgzf_member) + 64)) {
+          dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return; }
+        bool okc = true;
+        for (size_t k = 0; k < ncp && okc; ++k) okc = hipMemcpyAsync((char*)D.comp[idx] + k * PIECE, ring + (size_t)pcs[k] * PIECE, std::min(PIECE, cbytes - k * PIECE), hipMemcpyHostToDevice, hs) == hipSuccess;
+        okc = okc && hipMemcpyAsync(D.mem[idx], desc, (size_t)nmem * sizeof(sq_bgzf_member), hipMemcpyHostToDevice, hs) == hipSuccess && hipEventRecord(D.ev_h2d[idx], hs) == hipSuccess;
+        okc = okc && hipMemsetAsync(D.st + 2 * idx, 0xFF, 4, hs) == hipSuccess && hipMemsetAsync(D.st + 2 * idx + 1, 0, 4, hs) == hipSuccess;
+        okc = okc && sq_bgzf_inflate_launch((const uint8_t*)D.comp[idx], (const sq_bgzf_member*)D.mem[idx], nmem, (uint8_t*)D.text[idx], D.st + 2 * idx, hs) == SQ_OK;
+        if (!okc) { dv_fail(SQ_ERR_DEVICE, std::string("device failure in the reader (inflate): ") + hipGetErrorString(hipGetLastError())); return; }
+        dv_lent.push_back({D.ev_h2d[idx], std::move(pcs)});
+      }
+      if (hipEventRecord(D.ev_done[idx], hs) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, "device failure in the reader (inflate)"); return; }
+      { std::lock_guard<std::mutex> lk(mu); D.q.push_back(std::move(ch)); D.ahead += tbytes; D.next_mem = m1; ++D.produced; if (last) D.finished = true; t_dv_fill += now() - t0; }
+      cv.notify_all();
+    }
+  }
+  // the next `want` records of stream i: their text into the slot, their lines indexed, their sequences located.  false: an error (in *e), or the reader is closing (*e empty)
+  bool dv_split(int i, int si, uint32_t want, uint32_t* got, std::string* e, int* rc) {
+    Stream& S = sm[i]; DvStream& D = dv[i]; Slot& s = slots[(size_t)si]; hipStream_t st = s.st; *got = 0; *rc = SQ_ERR_DEVICE;
+    const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns;
+    auto dev_err = [&]() { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return false; };
+    size_t copied = 0, need = (size_t)((double)want * S.est * 1.02) + (256u << 10); uint64_t lines = 0; bool reached = false; uint64_t pos;
+    unsigned* h = s.h_res + 4;   // [0] the last tile's count / a newline position, [2..3] the last tile's base, [4 + 2 k ..] the status of the k-th chunk looked at
+    struct Part { int idx; uint64_t voff; size_t n; };
+    for (;;) {
+      std::vector<Part> parts; uint64_t avail; bool ended;
+      { const double t0 = now(); std::unique_lock<std::mutex> lk(mu); pos = D.pos;
+        cv.wait(lk, [&] { return stop || (!D.q.empty() && (D.q.back().last || D.q.back().voff + D.q.back().n >= pos + need || D.q.size() == (size_t)DV_CHUNKS)); });
+        if (stop) return false;
+        t_dv_wait += now() - t0;
+        const uint64_t end = D.q.back().voff + D.q.back().n; ended = D.q.back().last && end <= pos + need; avail = end - pos;
+        if (!D.q.back().last && end < pos + need) { *rc = SQ_ERR_STATE;
+          *e = "a batch of " + std::to_string(want) + " records of '" + S.name + "' takes more text than the device inflater holds at a time (" + std::to_string(need >> 20) + " MB): use a smaller batch, or SQ_READER_BGZF_DEVICE=0"; return false; }
+        for (auto& c : D.q) parts.push_back(Part{c.idx, c.voff, c.n}); }
+      const size_t take = (size_t)std::min<uint64_t>(avail, need);
+      if (take >= 0xFFFFFFF0ull) { *rc = SQ_ERR_STATE; *e = "a batch of " + std::to_string(want) + " records spans more than 4 GB of text: use a smaller batch"; return false; }
+      if (dev_grow_keep(&s.d_text[i], &s.text_cap[i], std::max(take, need) + 64, copied, st)) { *rc = SQ_ERR_NOMEM; *e = "device allocation failed (reader text)"; return false; }
+      const uint64_t a = pos + copied, b = pos + take; unsigned np = 0;
+      for (auto& pt : parts) {
+        const uint64_t lo = std::max(a, pt.voff), hi = std::min<uint64_t>(b, pt.voff + pt.n); if (lo >= hi) continue;
+        if (hipStreamWaitEvent(st, D.ev_done[pt.idx], 0) != hipSuccess || hipMemcpyAsync((char*)s.d_text[i] + (lo - pos), (const char*)D.text[pt.idx] + (lo - pt.voff), (size_t)(hi - lo), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(h + 4 + 2 * np, D.st + 2 * pt.idx, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return dev_err();
+        parts[np++] = pt;
+      }
+      copied = take;
+      const size_t padded = (copied + 15) & ~(size_t)15; const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
+      if (hipMemsetAsync((char*)s.d_text[i] + copied, 0, padded - copied + 16, st) != hipSuccess) return dev_err();
+      if (dev_grow(&s.d_tile, &s.tile_cap, ((size_t)ntile + 8) * 4) || dev_grow(&s.d_tbase, &s.tbase_cap, ((size_t)ntile + 8) * 8) ||
+          dev_grow(&s.d_spine, &s.spine_cap, ((size_t)std::max(sqk::scan_tiles(ntile), sqk::scan_tiles((uint64_t)batch * stride)) + 8) * 8)) { *rc = SQ_ERR_NOMEM; *e = "device allocation failed (reader)"; return false; }
+      h[0] = 0; h[2] = 0; h[3] = 0;
+      if (ntile) {
+        k_fq_count<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (uint32_t*)s.d_tile);
+        sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_tile, (uint64_t*)s.d_tbase, ntile, (uint64_t*)s.d_spine, st);
+        if (hipMemcpyAsync(h, (const uint32_t*)s.d_tile + (ntile - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(h + 2, (const uint64_t*)s.d_tbase + (ntile - 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess) return dev_err();
+      }
+      if (hipStreamSynchronize(st) != hipSuccess) return dev_err();
+      for (unsigned k = 0; k < np; ++k) if (h[4 + 2 * k] != 0xFFFFFFFFu) {   // a damaged member: which file, where
+        std::lock_guard<std::mutex> lk(mu); std::string where = "'" + S.name + "'";
+        for (auto& c : D.q) if (c.idx == parts[k].idx && c.voff == parts[k].voff && h[4 + 2 * k] - 1 < c.where.size()) { const auto& w = c.where[h[4 + 2 * k] - 1]; if (w.first != ~0u) where = "'" + S.sfiles[w.first]->path + "': member at offset " + std::to_string(w.second); }
+        *rc = SQ_ERR_IO; *e = where + ": " + sq_bgzf_status_text(h[5 + 2 * k]); return false; }
+      uint64_t tb; memcpy(&tb, h + 2, 8); lines = tb + h[0];
+      if (lines >= 4ull * want) { reached = true; break; }
+      if (ended) break;
+      need = copied + (size_t)((double)(want - lines / 4) * S.est * 1.05) + (256u << 10);
+    }
+    uint32_t n = want; size_t used = copied;
+    if (!reached) {   // the end of the stream: what is left must be whole records (blank lines at the very end are tolerated, as on the host path)
+      char T[4096 + 2]; const size_t tn = std::min(sizeof(T) - 2, copied);
+      if (tn && (hipMemcpyAsync(T + 2, (const char*)s.d_text[i] + copied - tn, tn, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) return dev_err();
+      T[0] = 'X'; T[1] = tn == copied ? '\n' : 'X';   // a batch starts behind a line end
+      size_t cut = tn + 2;
+      for (;;) {
+        if (cut >= 3 && T[cut - 1] == '\n' && T[cut - 2] == '\n') { cut -= 1; --lines; }
+        else if (cut >= 4 && T[cut - 1] == '\n' && T[cut - 2] == '\r' && T[cut - 3] == '\n') { cut -= 2; --lines; }
+        else break;
+      }
+      used = copied - (tn + 2 - cut);
+      if (lines % 4) { *rc = SQ_ERR_IO; *e = "'" + S.name + "' ends in the middle of a record (" + std::to_string(lines) + " lines in its last batch)"; return false; }
+      n = (uint32_t)(lines / 4);
+    }
+    if (n) {
+      const uint32_t nrec = std::max(n, i == 0 ? n : s.n) * stride;
+      if (dev_grow(&s.d_len, &s.len_cap, ((size_t)nrec + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)nrec + 8) * 8) ||
+          dev_grow(&s.d_nlpos[i], &s.nl_cap[i], ((size_t)4 * n + 8) * 4) || dev_grow(&s.d_start[i], &s.start_cap[i], ((size_t)n + 8) * 4)) { *rc = SQ_ERR_NOMEM; *e = "device allocation failed (reader)"; return false; }
+      const size_t padded = (copied + 15) & ~(size_t)15; const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
+      k_fq_index<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (const uint64_t*)s.d_tbase, (uint32_t*)s.d_nlpos[i], (uint64_t)4 * n);
+      if (reached) {   // the batch ends behind line 4 n
+        if (hipMemcpyAsync(h, (const uint32_t*)s.d_nlpos[i] + ((size_t)4 * n - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return dev_err();
+        used = (size_t)h[0] + 1;
+      }
+      k_fq_records<<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_nlpos[i], n, (uint32_t)i, stride, (uint32_t*)s.d_len, (uint32_t*)s.d_start[i], s.d_err);
+      S.est = 0.7 * S.est + 0.3 * ((double)used / (double)n);
+    }
+    s.bytes[i] = used; text_bytes += used; *got = n;
+    { std::lock_guard<std::mutex> lk(mu); D.pos += reached ? used : copied;   // chunks whose text is all behind the position go back to the stager (the last one stays: it says the stream is at its end)
+      while (!D.q.empty() && !D.q.front().last && D.q.front().voff + D.q.front().n <= D.pos) D.q.pop_front(); }
+    cv.notify_all();
+    return true;
+  }
+  void produce_split() {
+    (void)hipSetDevice(device);
+    const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns;
+    for (;;) {
+      int si = -1;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !free_slots.empty(); }); if (stop) return; si = free_slots.front(); free_slots.pop_front(); }
+      Slot& s = slots[(size_t)si]; hipStream_t st = s.st; const double t0 = now(); std::string e; int rc = SQ_ERR_DEVICE; uint32_t n0 = 0, n1 = 0;
+      bool ok = true;
+      if (!s.d_err && hipMalloc((void**)&s.d_err, 64) != hipSuccess) { ok = false; rc = SQ_ERR_NOMEM; e = "device allocation failed (reader)"; }
+      if (ok && !s.h_res && hipHostMalloc((void**)&s.h_res, 256, hipHostMallocDefault) != hipSuccess) { ok = false; rc = SQ_ERR_NOMEM; e = "page-locked allocation failed (reader)"; }
+      if (ok && (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess)) { ok = false; e = "device failure in the reader"; }
+      s.n = 0;
+      if (ok) ok = dv_split(0, si, batch, &n0, &e, &rc);
+      if (ok) s.n = n0;
+      if (ok && paired && n0) { ok = dv_split(1, si, n0, &n1, &e, &rc);
+        if (ok && n1 != n0) { ok = false; rc = SQ_ERR_IO; e = "mate files have different numbers of records (stopped after " + std::to_string(total + n1) + " pairs)"; } }
+      if (ok && paired && !n0) { ok = dv_split(1, si, 1, &n1, &e, &rc);   // the first file is at its end: is there a record left in the second?
+        if (ok && n1) { ok = false; rc = SQ_ERR_IO; e = "mate files have different numbers of records (stopped after " + std::to_string(total) + " pairs)"; } }
+      if (ok && n0) {
+        const uint32_t nrec = n0 * stride;
+        if (dev_grow(&s.d_seq, &s.seq_cap, (s.bytes[0] + (paired ? s.bytes[1] : 0)) / 2 + 64)) { ok = false; rc = SQ_ERR_NOMEM; e = "device allocation failed (reader sequences)"; }
+        if (ok) {
+          sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_len, (uint64_t*)s.d_off, nrec, (uint64_t*)s.d_spine, st);
+          for (int m = 0; m < ns; ++m) k_fq_copy<<<(uint32_t)(((uint64_t)n0 * 8 + 255) / 256), 256, 0, st>>>((const uint8_t*)s.d_text[m], (const uint32_t*)s.d_start[m], (const uint64_t*)s.d_off, n0, (uint32_t)m, stride, (uint8_t*)s.d_seq, s.d_err);
+          k_fq_pad<<<1, 64, 0, st>>>((const uint64_t*)s.d_off, nrec, (uint8_t*)s.d_seq, s.d_err);
+          if (hipMemcpyAsync(s.h_res, s.d_err, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = false; rc = SQ_ERR_DEVICE; e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); }
+        }
+        if (ok && s.h_res[0] != 0xFFFFFFFFu) { const unsigned* herr = s.h_res; const unsigned what = herr[1] ? herr[1] : herr[2]; ok = false; rc = SQ_ERR_IO;
+          e = "record " + std::to_string(total + herr[0]) + (what == 1 ? " does not start with '@'" : what == 2 ? " has no '+' line after one sequence line" : " has a quality string whose length differs from its sequence's") + " (multi-line FASTQ? set SQ_READER_DEVICE=0)"; }
+      }
+      if (!ok) { if (e.empty()) return; dv_fail(rc, e); return; }   // (e empty: the reader is closing)
+      std::lock_guard<std::mutex> lk(mu); t_dv_split += now() - t0;
+      if (!n0) { free_slots.push_back(si); done = true; cv.notify_all(); return; }
+      total += n0; ready.push_back(si); cv.notify_all();
     }
   }
 };
@@ -511,16 +712,44 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   for (size_t i = 0; i < R->slots.size(); ++i) R->free_slots.push_back((int)i);
   if (!R->any_buffered) R->zpool.reset();
   if (any_gz) { R->RING_PIECES = 96; R->ROUND_PIECES = 32; }
+  // [r5] every stream BGZF: the members are inflated on the device (SQ_READER_BGZF_DEVICE=0: by the host's threads, as a mixed or plain-gzip input is)
+  R->dev_inflate = R->any_bgz && !R->any_buffered && !(getenv("SQ_READER_BGZF_DEVICE") && atoi(getenv("SQ_READER_BGZF_DEVICE")) == 0);
+  if (R->dev_inflate) {
+    auto fail_dv = [&](int rc) { for (auto& D : R->dv) { for (auto& h : D.hs) if (h) (void)hipStreamDestroy(h); for (auto& ev : D.ev_h2d) if (ev) (void)hipEventDestroy(ev); for (auto& ev : D.ev_done) if (ev) (void)hipEventDestroy(ev); if (D.st) (void)hipFree(D.st); }
+      for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); (void)hipGetLastError(); return rc; };
+    double est_max = 0;
+    for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
+      sq_dev_reader::Stream& S = R->sm[i]; sq_dev_reader::DvStream& D = R->dv[i];
+      // the size of a record, from the first member with text (the splitter keeps the estimate current; a first guess far off would make the first batch copy twice)
+      for (auto& F : S.sfiles) { const uint8_t* base = (const uint8_t*)F->map->p; const size_t n = F->map->n; size_t off = 0; bool found = false;
+        while (off < n) { const size_t ms = sqio::BgzfSource::member_size(base + off, n - off); if (ms < 26 || ms > n - off) break;
+          const uint32_t isize = sqio::BgzfSource::le32(base + off + ms - 4);
+          if (isize && isize <= (1u << 16)) { std::vector<char> tmp((size_t)isize + 64); const char* w = sqio::BgzfSource::inflate_member(base + off, sqio::BgzfSource::Mem{off, ms, isize, 0}, tmp.data());
+            if (!*w) { const uint64_t nl = count_nl(tmp.data(), isize); if (nl >= 8) S.est = (double)isize / ((double)nl / 4.0); } found = true; break; }
+          off += ms; }
+        if (found) break; }
+      est_max = std::max(est_max, S.est);
+      for (auto& h : D.hs) if (hipStreamCreateWithFlags(&h, hipStreamNonBlocking) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
+      for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) if (hipEventCreateWithFlags(&D.ev_h2d[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.ev_done[k], hipEventDisableTiming) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
+      if (hipMalloc((void**)&D.st, sq_dev_reader::DV_CHUNKS * 8) != hipSuccess) return fail_dv(SQ_ERR_NOMEM);
+    }
+    // a chunk is a launch of DV_MEMBERS waves; the ring of chunk buffers holds at least three batches' text
+    const double want_text = 3.0 * (double)batch * est_max / (double)sq_dev_reader::DV_CHUNKS;
+    R->DV_MEMBERS = getenv("SQ_READER_BGZF_MEMBERS") ? (uint32_t)std::max(4, atoi(getenv("SQ_READER_BGZF_MEMBERS"))) : (uint32_t)std::min(32768.0, std::max(4096.0, want_text / 65280.0 + 1.0));
+    R->RING_PIECES = std::max(96, (int)(2 * ((size_t)R->DV_MEMBERS * 65536 / 2 / sq_dev_reader::PIECE + 2)));   // two chunks' compressed bytes (at the usual ratio and worse) in flight
+  }
   const unsigned hw_all = std::max(2u, std::thread::hardware_concurrency());
   // plain files: a few threads move bytes; BGZF: the same pool inflates, so it gets what the buffered streams' pool would have had
   const unsigned nt = getenv("SQ_READER_THREADS") ? (unsigned)atoi(getenv("SQ_READER_THREADS"))
-                      : (R->any_bgz ? std::min(64u, std::max(2u, hw_all / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
+                      : (R->any_bgz && !R->dev_inflate ? std::min(64u, std::max(2u, hw_all / 2)) : std::min(16u, std::max(2u, std::thread::hardware_concurrency() / 4)));
   R->pool.reset(new Workers(std::max(1u, nt)));
   if (hipHostMalloc((void**)&R->ring, (size_t)R->RING_PIECES * sq_dev_reader::PIECE, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError(); R->ring = nullptr; for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); for (auto& m : R->sm) for (auto& f : m.files) close(f.fd);
     sq_set_error("page-locked allocation failed (reader: %zu MB)", ((size_t)R->RING_PIECES * sq_dev_reader::PIECE) >> 20); return SQ_ERR_NOMEM; }
   for (int k = 0; k < R->RING_PIECES; ++k) R->free_pieces.push_back(k);
-  sq_dev_reader* r = R.release(); r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); });
+  sq_dev_reader* r = R.release();
+  if (r->dev_inflate) { r->prod = std::thread([r] { r->produce_inflate(); }); r->prod2 = std::thread([r] { r->produce_split(); }); }
+  else { r->prod = std::thread([r] { r->produce_stage(); }); r->prod2 = std::thread([r] { r->produce_upload(); }); }
   *out = r; return SQ_OK;
 }
 int sq_dev_reader_next(sq_dev_reader* R, sq_read_batch* b, int* slot) {
@@ -543,7 +772,15 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   if (R->prod2.joinable()) R->prod2.join();
   if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text / member scans, %.3f s filling the pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
       (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_wait_text, R->t_fill, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
+  if (getenv("SQ_READER_STATS") && R->dev_inflate) fprintf(stderr, "[sq_dev_reader] BGZF inflated on the device: chunks of %u members; stager busy %.3f s, splitter busy %.3f s (%.3f s of it waiting for inflated text)\n", R->DV_MEMBERS, R->t_dv_fill, R->t_dv_split, R->t_dv_wait);
   R->pool.reset(); (void)hipSetDevice(R->device);
+  for (auto& D : R->dv) {
+    for (auto& h : D.hs) if (h) { (void)hipStreamSynchronize(h); (void)hipStreamDestroy(h); }
+    for (auto& ev : D.ev_h2d) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : D.ev_done) if (ev) (void)hipEventDestroy(ev);
+    for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) for (void* p : {D.text[k], D.comp[k], D.mem[k]}) if (p) (void)hipFree(p);
+    if (D.st) (void)hipFree(D.st);
+  }
   for (auto& m : R->sm) { m.win.clear(); m.sfiles.clear(); }   // the sources' tasks run on zpool: they go first
   R->zpool.reset();
   for (auto& s : R->slots) {

@@ -142,3 +142,43 @@ def test_device_reader_feeds_the_mapper_and_reports_damage(small_world, tmp_path
     short = str(tmp_path / "short.fq"); fq(short, recs[0::2][:3000])
     e = first_error(short, f2); assert e and "different numbers of records" in e, e
     os.environ.pop("SQ_READER_DEVICE", None); ctx.free()
+
+
+def test_bgzf_members_inflated_on_the_device(built, tmp_path):
+    """[r5] All-BGZF input: the members are inflated by hip/inflate_dev.hip into chunk buffers and the batches cut out of those.  Against the host reader:
+    several files per mate (the first without its last newline: the line end it gets is a pseudo-member), blank lines at the very end, CR LF, k * batch
+    records exactly, chunks of a few members (batches span chunks, the ring of chunk buffers goes round many times) and of thousands; the same files through
+    the host's inflating threads (SQ_READER_BGZF_DEVICE=0); a damaged member is named."""
+    from test_reader import _bgzf_write
+    rng = np.random.default_rng(18); r1 = _recs(rng, 23456, "a"); r2 = _recs(rng, 23456, "b")
+    def bz(name, recs, block=0xff00, **kw):
+        raw = str(tmp_path / (name + ".fq")); _write(raw, recs, **kw); z = str(tmp_path / (name + ".fq.gz")); _bgzf_write(z, open(raw, "rb").read(), block=block); return z
+    cases = [("paired", [bz("a1", r1)], [bz("a2", r2, block=30011)], 5000)]
+    cuts = [0, 9000, 9001, 23456]
+    m1 = [bz("m%d_1" % k, r1[cuts[k]:cuts[k + 1]], last_newline=(k != 0), block=20000 + 7 * k) for k in range(3)]
+    m2 = [bz("m%d_2" % k, r2[cuts[k]:cuts[k + 1]], last_newline=(k != 1)) for k in range(3)]
+    cases.append(("three files per mate", m1, m2, 4096))
+    cases.append(("single-end, one batch", [cases[0][1][0]], None, 30000))
+    e1 = str(tmp_path / "e1.fq"); _write(e1, r1[:20000]); open(e1, "ab").write(b"\n\n"); z1 = str(tmp_path / "e1.fq.gz"); _bgzf_write(z1, open(e1, "rb").read())
+    e2 = str(tmp_path / "e2.fq"); _write(e2, r2[:20000], eol="\r\n"); open(e2, "ab").write(b"\r\n"); z2 = str(tmp_path / "e2.fq.gz"); _bgzf_write(z2, open(e2, "rb").read(), block=4099)
+    cases.append(("k * batch records + blank lines, CR LF in mate 2", [z1], [z2], 5000))
+    for members in ("5", "64", None):
+        if members: os.environ["SQ_READER_BGZF_MEMBERS"] = members
+        try:
+            for name, a, b, batch in cases:
+                dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
+                assert all(d[1] for d in dev) and [d[0] for d in dev] == [x[0] for x in host], (name, members)
+                for d, x in zip(dev, host): assert np.array_equal(d[3], x[3]) and d[2].tobytes() == x[2].tobytes(), (name, members)
+        finally: os.environ.pop("SQ_READER_BGZF_MEMBERS", None)
+    os.environ["SQ_READER_BGZF_DEVICE"] = "0"
+    try:
+        name, a, b, batch = cases[1]; dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
+        assert all(d[1] for d in dev) and [d[0] for d in dev] == [x[0] for x in host]
+        for d, x in zip(dev, host): assert np.array_equal(d[3], x[3]) and d[2].tobytes() == x[2].tobytes()
+    finally: os.environ.pop("SQ_READER_BGZF_DEVICE", None)
+    # different numbers of records; a member with a flipped bit; a cut file
+    with pytest.raises(Exception, match="different numbers"): _drain([cases[0][1][0]], [bz("short2", r2[:23000])], 5000, True)
+    good = open(cases[0][1][0], "rb").read(); bad = bytearray(good); bad[len(bad) // 2] ^= 0x20; zb = str(tmp_path / "bad.fq.gz"); open(zb, "wb").write(bytes(bad))
+    with pytest.raises(Exception, match="BGZF|member|record"): _drain([zb], None, 5000, True)
+    zc = str(tmp_path / "cut.fq.gz"); open(zc, "wb").write(good[: len(good) * 2 // 3])
+    with pytest.raises(Exception, match="truncated|BGZF|middle of a record"): _drain([zc], None, 5000, True)
