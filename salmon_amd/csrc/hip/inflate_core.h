@@ -45,8 +45,10 @@ enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF
 struct Bits {
   const uint8_t* p; uint32_t n, pos; uint64_t buf; int cnt;      // (a member is at most 64 KB: 32-bit positions compare in one scalar instruction)
   SQ_INL void init(const uint8_t* p_, size_t n_) {
-    p = p_; n = (uint32_t)n_; pos = 0; buf = 0; cnt = 0;
-    while (pos < n && ((uintptr_t)(p + pos) & 3)) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
+    // p: the aligned address at or below the stream's first byte, positions count from there (a scalar load drops the low address bits of its base register and
+    // of its offset separately: both must be multiples of four)
+    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = mis; buf = 0; cnt = 0;
+    while (pos < n && (pos & 3)) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
   }
   SQ_INL void refill() {                 // behind it at least 33 bits are there (unless the input ends): a length code with its extra bits, or a distance code with its
     if (cnt > 32 || cnt < 0) return;
