@@ -129,12 +129,12 @@ struct sq_dev_reader {
     bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
   std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the buffered sequential streams
   bool any_buffered = false, any_bgz = false, dev_inflate = false;   // dev_inflate: every stream is BGZF and the members are inflated by hip/inflate_dev.hip
-  // [r5] BGZF inflated on the device.  The stager thread feeds each mate stream's CHUNKS: the next members of the stream (up to DV_MEMBERS of them — a wave each,
-  // so a chunk is a launch that fills the chip), their compressed bytes copied from the file mapping into ring pieces, sent to the device, inflated there into the
+  // [r5] BGZF inflated on the device.  The stager thread feeds each mate stream's CHUNKS: the next members of the stream (256 MB of text or more: ~4000 members of the usual
+  // size, a wave each — a launch that fills the chip), their compressed bytes copied from the file mapping into ring pieces, sent to the device, inflated there into the
   // chunk's buffer (a ring of DV_CHUNKS buffers per stream).  The splitter thread cuts batches out of that text: it copies what it expects a batch to take from the
   // chunk buffers into the slot's text (device to device), counts lines there, takes more if the records were longer than expected, and moves the stream's
   // position behind the batch's last line; a chunk whose text is all behind the position goes back to the stager.
-  static constexpr int DV_CHUNKS = 6; uint32_t DV_MEMBERS = 4096;
+  static constexpr int DV_CHUNKS = 6; uint32_t DV_MEMBERS = 32768; uint64_t DV_TEXT = 256u << 20;   // a chunk ends at DV_TEXT bytes of text or DV_MEMBERS members, whichever comes first
   struct DvChunk { int idx = 0; uint64_t voff = 0; size_t n = 0; bool last = false; std::vector<std::pair<uint32_t, uint64_t>> where; };   // where: (file, offset) of its members, for messages
   struct DvStream {
     void* text[DV_CHUNKS] = {}; size_t text_cap[DV_CHUNKS] = {}; void* comp[DV_CHUNKS] = {}; size_t comp_cap[DV_CHUNKS] = {}; void* mem[DV_CHUNKS] = {}; size_t mem_cap[DV_CHUNKS] = {};
@@ -482,9 +482,9 @@ struct sq_dev_reader {
         if (i < 0) return; }   // every stream has been inflated to its end
       Stream& S = sm[i]; DvStream& D = dv[i]; std::string e; const double t0 = now();
       const int idx = (int)(D.produced % DV_CHUNKS); hipStream_t hs = D.hs[D.produced & 1];
-      if (!bz_scan(S, D.ahead + (uint64_t)DV_MEMBERS * 65536 + 1, &e)) { dv_fail(SQ_ERR_IO, e); return; }
+      if (!bz_scan(S, D.ahead + DV_TEXT + 65536 + 1, &e)) { dv_fail(SQ_ERR_IO, e); return; }
       const size_t m0 = D.next_mem; size_t m1 = m0, tbytes = 0, cbytes = 0;
-      while (m1 < S.mem.size() && m1 - m0 < DV_MEMBERS) { tbytes += S.mem[m1].isize; cbytes += S.mem[m1].csize; ++m1; }
+      while (m1 < S.mem.size() && m1 - m0 < DV_MEMBERS && tbytes < DV_TEXT) { tbytes += S.mem[m1].isize; cbytes += S.mem[m1].csize; ++m1; }
       const uint32_t nmem = (uint32_t)(m1 - m0); const bool last = m1 == S.mem.size() && S.scan_done;
       DvChunk ch; ch.idx = idx; ch.voff = D.ahead; ch.n = tbytes; ch.last = last; ch.where.reserve(nmem);
       if (nmem) {
@@ -733,10 +733,10 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
       for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) if (hipEventCreateWithFlags(&D.ev_h2d[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.ev_done[k], hipEventDisableTiming) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
       if (hipMalloc((void**)&D.st, sq_dev_reader::DV_CHUNKS * 8) != hipSuccess) return fail_dv(SQ_ERR_NOMEM);
     }
-    // a chunk is a launch of DV_MEMBERS waves; the ring of chunk buffers holds at least three batches' text
-    const double want_text = 3.0 * (double)batch * est_max / (double)sq_dev_reader::DV_CHUNKS;
-    R->DV_MEMBERS = getenv("SQ_READER_BGZF_MEMBERS") ? (uint32_t)std::max(4, atoi(getenv("SQ_READER_BGZF_MEMBERS"))) : (uint32_t)std::min(32768.0, std::max(4096.0, want_text / 65280.0 + 1.0));
-    R->RING_PIECES = std::max(96, (int)(2 * ((size_t)R->DV_MEMBERS * 65536 / 2 / sq_dev_reader::PIECE + 2)));   // two chunks' compressed bytes (at the usual ratio and worse) in flight
+    // a chunk is a launch of some thousand waves; the ring of chunk buffers holds at least three batches' text (SQ_READER_BGZF_MEMBERS: fewer members per chunk, for tests)
+    R->DV_TEXT = std::max<uint64_t>(256u << 20, (uint64_t)(3.0 * (double)batch * est_max / (double)sq_dev_reader::DV_CHUNKS));
+    if (getenv("SQ_READER_BGZF_MEMBERS")) R->DV_MEMBERS = (uint32_t)std::min(32768, std::max(4, atoi(getenv("SQ_READER_BGZF_MEMBERS"))));
+    R->RING_PIECES = std::max(96, (int)(2 * (R->DV_TEXT / 2 / sq_dev_reader::PIECE + 2)));   // two chunks' compressed bytes (at the usual ratio and worse) in flight
   }
   const unsigned hw_all = std::max(2u, std::thread::hardware_concurrency());
   // plain files: a few threads move bytes; BGZF: the same pool inflates, so it gets what the buffered streams' pool would have had
@@ -770,9 +770,10 @@ void sq_dev_reader_close(sq_dev_reader* R) {
   { std::lock_guard<std::mutex> lk(R->mu); R->stop = true; } R->cv.notify_all();
   if (R->prod.joinable()) R->prod.join();
   if (R->prod2.joinable()) R->prod2.join();
-  if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text / member scans, %.3f s filling the pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
+  if (getenv("SQ_READER_STATS") && !R->dev_inflate) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text: staging %.3f s (%.1f GB/s; %.3f s of it waiting for ring pieces, %.3f s for inflated text / member scans, %.3f s filling the pieces), upload + split %.3f s (%.1f GB/s)\n", (unsigned long long)R->total,
       (double)R->text_bytes / 1e9, R->t_stage, (double)R->text_bytes / 1e9 / std::max(R->t_stage, 1e-9), R->t_wait_piece, R->t_wait_text, R->t_fill, R->t_upload, (double)R->text_bytes / 1e9 / std::max(R->t_upload, 1e-9));
-  if (getenv("SQ_READER_STATS") && R->dev_inflate) fprintf(stderr, "[sq_dev_reader] BGZF inflated on the device: chunks of %u members; stager busy %.3f s, splitter busy %.3f s (%.3f s of it waiting for inflated text)\n", R->DV_MEMBERS, R->t_dv_fill, R->t_dv_split, R->t_dv_wait);
+  if (getenv("SQ_READER_STATS") && R->dev_inflate) fprintf(stderr, "[sq_dev_reader] %llu records, %.3f GB of text, BGZF inflated on the device (chunks of %llu MB of text): stager busy %.3f s, splitter busy %.3f s (%.3f s of it waiting for inflated text)\n",
+      (unsigned long long)R->total, (double)R->text_bytes / 1e9, (unsigned long long)(R->DV_TEXT >> 20), R->t_dv_fill, R->t_dv_split, R->t_dv_wait);
   R->pool.reset(); (void)hipSetDevice(R->device);
   for (auto& D : R->dv) {
     for (auto& h : D.hs) if (h) { (void)hipStreamSynchronize(h); (void)hipStreamDestroy(h); }

@@ -39,25 +39,36 @@ struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_B
 
 enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF_BAD_CODES = 4, INF_BAD_SYMBOL = 5, INF_BAD_DISTANCE = 6, INF_OUTPUT_SIZE = 7 };
 
-// the input, least significant bit first.  Words of four bytes are read at aligned addresses (scalar loads on the device); the bytes in front of the
-// first aligned word and behind the last whole one go one by one.  Past the end of the input the buffer yields zeros and `cnt` goes negative: the
-// callers look at bad() once per symbol, before anything decoded from those zeros is stored
+// the input, least significant bit first: up to 64 bits wait in (hi, lo).  Words of four bytes are read at aligned addresses (scalar loads on the device); the
+// bytes in front of the first aligned word and behind the last whole one go one by one.  Past the end of the input the buffer yields zeros and `cnt` goes
+// negative: the callers look at bad() where a wrong symbol could do harm (before a match is copied, before literals are stored, at the end of a block).
+// On the device the two words live in VECTOR registers (every lane the same value) although they are uniform: a compute unit issues one scalar instruction per
+// cycle for all its waves, and with 32 decoding waves that port is what bounds the kernel — the shifts and masks of the bit buffer and the address of the
+// table look-up go to the vector ALUs, which idle otherwise; only what steers the control flow (the code's length, the symbol) comes back to a scalar register.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline uint32_t vector_zero() { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }     // 0, in a vector register and opaque to the compiler
+__device__ inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return __builtin_amdgcn_alignbit(hi, lo, k); }   // bits k .. k+31 of hi:lo (k < 32)
+#else
+inline uint32_t vector_zero() { return 0; }
+inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (k & 31)); }
+#endif
 struct Bits {
-  const uint8_t* p; uint32_t n, pos; uint64_t buf; int cnt;      // (a member is at most 64 KB: 32-bit positions compare in one scalar instruction)
+  const uint8_t* p; uint32_t n, pos; uint32_t lo, hi; int cnt;      // (a member is at most 64 KB: 32-bit positions compare in one scalar instruction)
+  SQ_INL void add(uint32_t v, int at) { const uint64_t w = (uint64_t)v << at; lo |= (uint32_t)w; hi |= (uint32_t)(w >> 32); }     // at <= 56, v < 2^32 (v < 256 for at > 32)
   SQ_INL void init(const uint8_t* p_, size_t n_) {
     // p: the aligned address at or below the stream's first byte, positions count from there (a scalar load drops the low address bits of its base register and
     // of its offset separately: both must be multiples of four)
-    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = mis; buf = 0; cnt = 0;
-    while (pos < n && (pos & 3)) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
+    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = mis; lo = vector_zero(); hi = lo; cnt = 0;
+    while (pos < n && (pos & 3)) { add(SQ_UNI(p[pos++]), cnt); cnt += 8; }
   }
   SQ_INL void refill() {                 // behind it at least 33 bits are there (unless the input ends): a length code with its extra bits, or a distance code with its
     if (cnt > 32 || cnt < 0) return;
-    if (pos + 4 <= n) { buf |= (uint64_t)SQ_UNI(*(const uint32_t*)(p + pos)) << cnt; cnt += 32; pos += 4; }
-    else while (cnt <= 56 && pos < n) { buf |= (uint64_t)SQ_UNI(p[pos++]) << cnt; cnt += 8; }
+    if (pos + 4 <= n) { add(SQ_UNI(*(const uint32_t*)(p + pos)), cnt); cnt += 32; pos += 4; }
+    else while (cnt <= 56 && pos < n) { add(SQ_UNI(p[pos++]), cnt); cnt += 8; }
   }
-  SQ_INL uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1); }
-  SQ_INL void drop(int k) { buf >>= k; cnt -= k; }
-  SQ_INL uint32_t take(int k) { const uint32_t v = peek(k); drop(k); return v; }      // k <= 16, refilled by the caller
+  SQ_INL uint32_t peek(int k) const { return lo & ((1u << k) - 1); }                     // (a vector value on the device)
+  SQ_INL void drop(int k) { lo = funnel(hi, lo, (uint32_t)k); hi >>= k; cnt -= k; }      // k < 32
+  SQ_INL uint32_t take(int k) { const uint32_t v = SQ_UNI(peek(k)); drop(k); return v; } // k <= 16, refilled by the caller
   SQ_INL uint32_t get(int k) { refill(); return take(k); }
   SQ_INL bool bad() const { return cnt < 0; }
 };
@@ -169,24 +180,25 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
 }
 
 // where the text goes.  Device: `lane` is the thread's lane; literals wait in `litv` (lane k holds literal k of the run) until 64 are there or a
-// match needs them in memory.  Host: bytes, in order.
+// match needs them in memory.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text begins there); whether the stream
+// wanted to is seen from size() when a run is flushed.
 struct Out {
-  uint8_t* out; uint32_t on; uint32_t nlit;
+  uint8_t* out; uint32_t on, nlit, cap;
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t lane, litv;
-  __device__ void init(uint8_t* o) { out = o; on = 0; nlit = 0; litv = 0; lane = __lane_id(); }
-  __device__ void flush() { if (lane < nlit) out[on + lane] = (uint8_t)litv; on += nlit; nlit = 0; }
-  __device__ void put(uint32_t byte) { if (lane == nlit) litv = byte; if (++nlit == 64) flush(); }
-  __device__ void copy(uint32_t dist, uint32_t len) {
-    flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
+  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; litv = 0; lane = __lane_id(); }
+  __device__ void flush() { if (lane < nlit && on + lane < cap) out[on + lane] = (uint8_t)litv; on += nlit; nlit = 0; }
+  __device__ void put(uint32_t byte) { litv = lane == nlit ? byte : litv; ++nlit; }   // the caller flushes at 64
+  __device__ void copy(uint32_t dist, uint32_t len) {      // the caller has flushed and checked dist <= on, on + len <= cap
+    const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
     if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
     else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }       // the window's last `dist` bytes, repeated
     on += len;
   }
 #else
-  void init(uint8_t* o) { out = o; on = 0; nlit = 0; }
-  void flush() {}
-  void put(uint32_t byte) { out[on++] = (uint8_t)byte; }
+  void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; }
+  void flush() { on += nlit; nlit = 0; }
+  void put(uint32_t byte) { if (on + nlit < cap) out[on + nlit] = (uint8_t)byte; ++nlit; }
   void copy(uint32_t dist, uint32_t len) { const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; }
 #endif
   SQ_HD uint32_t size() const { return on + nlit; }
@@ -200,7 +212,7 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
   const uint32_t distx[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16, 65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16,
                               193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16, 1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16,
                               6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
-  Bits b; b.init(in, n); Out o; o.init(out); int rc = INF_OK;
+  Bits b; b.init(in, n); Out o; o.init(out, isize); int rc = INF_OK;
   for (;;) {
     const uint32_t last = b.get(1), type = b.take(2);
     if (b.bad()) return INF_EOF_INPUT;
@@ -212,18 +224,24 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
       if ((len ^ nlen) != 0xFFFFu) return INF_BAD_STORED;
       if (o.size() + len > isize) return INF_OUTPUT_SIZE;
 #pragma unroll 1
-      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); }
+      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); if (o.nlit == 64) o.flush(); }
     } else {
       if (type == 1) fixed_tables(T);
       else { rc = dynamic_tables(b, T); if (rc) return rc; }
-      // the loop that does the work: one literal, or one length / distance pair, per turn; every way out of it leaves through the one test behind it
+      // the loop that does the work: one literal, or one length / distance pair, per turn; every way out of it leaves through the one test behind it.  A literal
+      // costs a dozen scalar instructions: whether the input ended or the text overflows is looked at when a run of 64 is stored, not per literal (zeros decode
+      // to something harmless until then: nothing is stored at or behind the member's end)
 #pragma unroll 1
       for (;;) {
         b.refill();
-        int sym = decode(b, T.lit, T.lit_fast, LIT_BITS);
+        const uint32_t e = SQ_UNI(T.lit_fast[b.peek(LIT_BITS)]);
+        int sym;
+        if (e) { b.drop((int)(e & 15)); sym = (int)(e >> 4); }
+        else { sym = decode_long(b, T.lit); if (sym < 0) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; } }
         if (sym < 256) {
-          if (sym < 0 || b.bad() || o.size() >= isize) { rc = b.bad() ? INF_EOF_INPUT : sym < 0 ? INF_BAD_SYMBOL : INF_OUTPUT_SIZE; break; }
-          o.put((uint32_t)sym); continue;
+          o.put((uint32_t)sym);
+          if (o.nlit == 64) { o.flush(); if (b.bad() || o.on > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } }
+          continue;
         }
         if (sym == 256) { if (b.bad()) rc = INF_EOF_INPUT; break; }
         sym -= 257; if (sym >= 29) { rc = INF_BAD_SYMBOL; break; }
@@ -232,7 +250,8 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
         const int ds = decode(b, T.dist, T.dist_fast, DIST_BITS);
         if (ds < 0 || ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
         const uint32_t dx = SQ_UNI(distx[ds]); const uint32_t dist = (dx & 0xFFFF) + b.take((int)(dx >> 16));
-        if (b.bad() || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : dist > o.size() ? INF_BAD_DISTANCE : INF_OUTPUT_SIZE; break; }
+        o.flush();
+        if (b.bad() || dist > o.on || o.on + len > isize) { rc = b.bad() ? INF_EOF_INPUT : o.on > isize || o.on + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
         o.copy(dist, len);
       }
       if (rc) return rc;
@@ -240,7 +259,7 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
     if (last) break;
   }
   o.flush();
-  return o.size() == isize ? INF_OK : INF_OUTPUT_SIZE;
+  return b.bad() ? INF_EOF_INPUT : o.on == isize ? INF_OK : INF_OUTPUT_SIZE;
 }
 
 // CRC-32 (the gzip polynomial, reflected) of n bytes, a byte at a time through a 256-entry table
