@@ -35,7 +35,7 @@ constexpr int LIT_BITS = 10, DIST_BITS = 9;
 struct Huff { uint16_t count[16]; uint16_t symbol[288]; };                 // codes of each length; symbols in code order
 struct HuffS { uint16_t count[16]; uint16_t symbol[32]; };                 // the same for the 30 distance codes and the 19 code-length codes
 // per wave (LDS on the device).  *_fast[peeked bits] = symbol << 4 | code length, 0 where the code is longer than the peek
-struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_BITS]; Huff lit; HuffS dist, clen; uint8_t lengths[320]; uint16_t offs[16]; };
+struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_BITS]; Huff lit; HuffS dist, clen; uint8_t lengths[320]; uint16_t offs[16]; uint32_t win[64]; };   // win: the input window (Bits)
 
 enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF_BAD_CODES = 4, INF_BAD_SYMBOL = 5, INF_BAD_DISTANCE = 6, INF_OUTPUT_SIZE = 7 };
 
@@ -52,19 +52,33 @@ __device__ inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return
 inline uint32_t vector_zero() { return 0; }
 inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (k & 31)); }
 #endif
+// How the input reaches the bit buffer: in BLOCKS of 256 bytes.  A word read from memory where the decoder needs it costs a trip to HBM (1 - 2 us with
+// thousands of waves asking) per four bytes of input, and the decoder can do nothing until it is back: measured, that was what a member took.  Instead the 64
+// lanes fetch a block with one coalesced load, a word each, a block AHEAD of the one being decoded (the words wait in a register, `pend`); when the decoder
+// enters a block its words go to the wave's window in LDS, the load of the next block is issued, and the bit buffer is fed from the window.
 struct Bits {
-  const uint8_t* p; uint32_t n, pos; uint32_t lo, hi; int cnt;      // (a member is at most 64 KB: 32-bit positions compare in one scalar instruction)
-  SQ_INL void add(uint32_t v, int at) { const uint64_t w = (uint64_t)v << at; lo |= (uint32_t)w; hi |= (uint32_t)(w >> 32); }     // at <= 56, v < 2^32 (v < 256 for at > 32)
-  SQ_INL void init(const uint8_t* p_, size_t n_) {
-    // p: the aligned address at or below the stream's first byte, positions count from there (a scalar load drops the low address bits of its base register and
-    // of its offset separately: both must be multiples of four)
-    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = mis; lo = vector_zero(); hi = lo; cnt = 0;
-    while (pos < n && (pos & 3)) { add(SQ_UNI(p[pos++]), cnt); cnt += 8; }
+  const uint8_t* p; uint32_t n, pos, nblk; uint32_t lo, hi; int cnt; uint32_t* win;      // win: 64 words (LDS on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t pend, lane;
+  __device__ void fetch(uint32_t b) { const uint32_t off = b * 256u + lane * 4u; pend = off < n ? *(const uint32_t*)(p + off) : 0u; }      // (reads up to 3 bytes behind n: the buffers have slack)
+  __device__ void enter() { win[lane] = pend; ++nblk; fetch(nblk); }
+  __device__ void start() { lane = __lane_id(); fetch(0); }
+#else
+  void enter() { for (uint32_t l = 0; l < 64; ++l) { uint32_t w = 0; for (uint32_t k = 0; k < 4; ++k) { const uint32_t off = nblk * 256u + l * 4u + k; if (off < n) w |= (uint32_t)p[off] << (8 * k); } win[l] = w; } ++nblk; }
+  void start() {}
+#endif
+  SQ_INL uint32_t word() { if ((pos >> 8) == nblk) enter(); return win[(pos >> 2) & 63u]; }      // the word that holds byte `pos` (a vector value on the device)
+  SQ_INL void add(uint32_t v, int at) { const uint64_t w = (uint64_t)v << at; lo |= (uint32_t)w; hi |= (uint32_t)(w >> 32); }     // at <= 32
+  SQ_INL void init(const uint8_t* p_, size_t n_, uint32_t* win_) {
+    // p: the aligned address at or below the stream's first byte, positions count from there
+    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = 0; nblk = 0; win = win_; lo = vector_zero(); hi = lo; cnt = 0;
+    start();
+    if (n > mis) { const uint32_t nb = (n < 4u ? n : 4u) - mis; uint32_t w = word() >> (8 * mis); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, 0); cnt = (int)(8 * nb); pos = n < 4u ? n : 4u; }
   }
   SQ_INL void refill() {                 // behind it at least 33 bits are there (unless the input ends): a length code with its extra bits, or a distance code with its
-    if (cnt > 32 || cnt < 0) return;
-    if (pos + 4 <= n) { add(SQ_UNI(*(const uint32_t*)(p + pos)), cnt); cnt += 32; pos += 4; }
-    else while (cnt <= 56 && pos < n) { add(SQ_UNI(p[pos++]), cnt); cnt += 8; }
+    if (cnt > 32 || cnt < 0 || pos >= n) return;
+    const uint32_t nb = n - pos < 4u ? n - pos : 4u; uint32_t w = word(); if (nb < 4) w &= (1u << (8 * nb)) - 1;
+    add(w, cnt); cnt += (int)(8 * nb); pos += nb;
   }
   SQ_INL uint32_t peek(int k) const { return lo & ((1u << k) - 1); }                     // (a vector value on the device)
   SQ_INL void drop(int k) { lo = funnel(hi, lo, (uint32_t)k); hi >>= k; cnt -= k; }      // k < 32
@@ -180,26 +194,36 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
 }
 
 // where the text goes.  Device: `lane` is the thread's lane; literals wait in `litv` (lane k holds literal k of the run) until 64 are there or a
-// match needs them in memory.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text begins there); whether the stream
-// wanted to is seen from size() when a run is flushed.
+// match needs them in memory.  A match of up to 64 bytes whose source lies in text already stored is a load now and a store LATER (`pcv`: lane k holds byte k,
+// stored when the next match or the end comes): the decoder goes on with the next symbol while the bytes travel — a wave that waited for every match's load
+// spent most of its time waiting.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text begins there); whether the
+// stream wanted to is seen from size().
 struct Out {
-  uint8_t* out; uint32_t on, nlit, cap;
+  uint8_t* out; uint32_t on, nlit, cap;      // on: the text decided so far without the literals in litv (it includes a match waiting in pcv)
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t lane, litv;
-  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; litv = 0; lane = __lane_id(); }
+  uint32_t lane, litv, pcv, pcn, pcat;
+  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; litv = 0; pcv = 0; pcn = 0; pcat = 0; lane = __lane_id(); }
   __device__ void flush() { if (lane < nlit && on + lane < cap) out[on + lane] = (uint8_t)litv; on += nlit; nlit = 0; }
+  __device__ void settle() { if (pcn) { if (lane < pcn) out[pcat + lane] = (uint8_t)pcv; pcn = 0; } }
+  __device__ void finish() { settle(); flush(); }
   __device__ void put(uint32_t byte) { litv = lane == nlit ? byte : litv; ++nlit; }   // the caller flushes at 64
-  __device__ void copy(uint32_t dist, uint32_t len) {      // the caller has flushed and checked dist <= on, on + len <= cap
-    const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
-    if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
-    else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }       // the window's last `dist` bytes, repeated
-    on += len;
+  __device__ void copy(uint32_t dist, uint32_t len) {      // the caller has checked dist <= size(), size() + len <= cap
+    settle();
+    if (dist < len + nlit || len > 64) {      // the source reaches into literals not stored yet, or repeats itself, or is wider than a wave: stored at once
+      flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
+      if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
+      else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }     // the window's last `dist` bytes, repeated
+      on += len; return;
+    }
+    pcat = on + nlit; pcn = len; if (lane < len) pcv = out[pcat - dist + lane];
+    flush(); on += len;                        // (the literals in front of the match go out behind its load)
   }
 #else
   void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; }
   void flush() { on += nlit; nlit = 0; }
+  void finish() { flush(); }
   void put(uint32_t byte) { if (on + nlit < cap) out[on + nlit] = (uint8_t)byte; ++nlit; }
-  void copy(uint32_t dist, uint32_t len) { const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; }
+  void copy(uint32_t dist, uint32_t len) { flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; }
 #endif
   SQ_HD uint32_t size() const { return on + nlit; }
 };
@@ -212,7 +236,7 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
   const uint32_t distx[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16, 65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16,
                               193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16, 1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16,
                               6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
-  Bits b; b.init(in, n); Out o; o.init(out, isize); int rc = INF_OK;
+  Bits b; b.init(in, n, T.win); Out o; o.init(out, isize); int rc = INF_OK;
   for (;;) {
     const uint32_t last = b.get(1), type = b.take(2);
     if (b.bad()) return INF_EOF_INPUT;
@@ -250,15 +274,14 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
         const int ds = decode(b, T.dist, T.dist_fast, DIST_BITS);
         if (ds < 0 || ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
         const uint32_t dx = SQ_UNI(distx[ds]); const uint32_t dist = (dx & 0xFFFF) + b.take((int)(dx >> 16));
-        o.flush();
-        if (b.bad() || dist > o.on || o.on + len > isize) { rc = b.bad() ? INF_EOF_INPUT : o.on > isize || o.on + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
+        if (b.bad() || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
         o.copy(dist, len);
       }
       if (rc) return rc;
     }
     if (last) break;
   }
-  o.flush();
+  o.finish();
   return b.bad() ? INF_EOF_INPUT : o.on == isize ? INF_OK : INF_OUTPUT_SIZE;
 }
 
