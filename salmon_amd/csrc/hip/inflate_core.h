@@ -40,8 +40,8 @@ struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_B
 enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF_BAD_CODES = 4, INF_BAD_SYMBOL = 5, INF_BAD_DISTANCE = 6, INF_OUTPUT_SIZE = 7 };
 
 // the input, least significant bit first: up to 64 bits wait in (hi, lo).  Words of four bytes are read at aligned addresses (scalar loads on the device); the
-// bytes in front of the first aligned word and behind the last whole one go one by one.  Past the end of the input the buffer yields zeros and `cnt` goes
-// negative: the callers look at bad() where a wrong symbol could do harm (before a match is copied, before literals are stored, at the end of a block).
+// bytes in front of the first aligned word and behind the last whole one go one by one.  Past the end of the input the buffer yields zeros (counted
+// in `virt`): the callers look at bad() where a wrong symbol could do harm (before a match is copied, before literals are stored, at the end of a block).
 // On the device the two words live in VECTOR registers (every lane the same value) although they are uniform: a compute unit issues one scalar instruction per
 // cycle for all its waves, and with 32 decoding waves that port is what bounds the kernel — the shifts and masks of the bit buffer and the address of the
 // table look-up go to the vector ALUs, which idle otherwise; only what steers the control flow (the code's length, the symbol) comes back to a scalar register.
@@ -57,7 +57,7 @@ inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return (uint32_t)
 // lanes fetch a block with one coalesced load, a word each, a block AHEAD of the one being decoded (the words wait in a register, `pend`); when the decoder
 // enters a block its words go to the wave's window in LDS, the load of the next block is issued, and the bit buffer is fed from the window.
 struct Bits {
-  const uint8_t* p; uint32_t n, pos, nblk; uint32_t lo, hi; int cnt; uint32_t* win;      // win: 64 words (LDS on the device)
+  const uint8_t* p; uint32_t n, pos, nblk; uint32_t lo, hi; uint32_t cnt, virt; uint32_t* win;      // win: 64 words (LDS on the device); virt: how many of the cnt bits lie behind the end of the input
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t pend, lane;
   __device__ void fetch(uint32_t b) { const uint32_t off = b * 256u + lane * 4u; pend = off < n ? *(const uint32_t*)(p + off) : 0u; }      // (reads up to 3 bytes behind n: the buffers have slack)
@@ -71,20 +71,22 @@ struct Bits {
   SQ_INL void add(uint32_t v, int at) { const uint64_t w = (uint64_t)v << at; lo |= (uint32_t)w; hi |= (uint32_t)(w >> 32); }     // at <= 32
   SQ_INL void init(const uint8_t* p_, size_t n_, uint32_t* win_) {
     // p: the aligned address at or below the stream's first byte, positions count from there
-    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = 0; nblk = 0; win = win_; lo = vector_zero(); hi = lo; cnt = 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = 0; nblk = 0; win = win_; lo = vector_zero(); hi = lo; cnt = 0; virt = 0;
     start();
-    if (n > mis) { const uint32_t nb = (n < 4u ? n : 4u) - mis; uint32_t w = word() >> (8 * mis); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, 0); cnt = (int)(8 * nb); pos = n < 4u ? n : 4u; }
+    if (n > mis) { const uint32_t nb = (n < 4u ? n : 4u) - mis; uint32_t w = word() >> (8 * mis); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, 0); cnt = 8 * nb; pos = n < 4u ? n : 4u; }
   }
-  SQ_INL void refill() {                 // behind it at least 33 bits are there (unless the input ends): a length code with its extra bits, or a distance code with its
-    if (cnt > 32 || cnt < 0 || pos >= n) return;
-    const uint32_t nb = n - pos < 4u ? n - pos : 4u; uint32_t w = word(); if (nb < 4) w &= (1u << (8 * nb)) - 1;
-    add(w, cnt); cnt += (int)(8 * nb); pos += nb;
+  // behind it at least 33 bits are there: a length code with its extra bits, or a distance code with its.  Past the end of the input the bits are zeros that
+  // count as `virt`: a decoder that has eaten into them sees bad() — looked at where a wrong symbol could do harm, not per symbol
+  SQ_INL void refill() {
+    if (cnt > 32) return;
+    if (pos < n) { const uint32_t nb = n - pos < 4u ? n - pos : 4u; uint32_t w = word(); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, (int)cnt); cnt += 8 * nb; pos += nb; }
+    else { cnt += 32; virt += 32; }
   }
   SQ_INL uint32_t peek(int k) const { return lo & ((1u << k) - 1); }                     // (a vector value on the device)
-  SQ_INL void drop(int k) { lo = funnel(hi, lo, (uint32_t)k); hi >>= k; cnt -= k; }      // k < 32
+  SQ_INL void drop(int k) { lo = funnel(hi, lo, (uint32_t)k); hi >>= k; cnt -= (uint32_t)k; }      // k < 32, k <= cnt (the callers refill first)
   SQ_INL uint32_t take(int k) { const uint32_t v = SQ_UNI(peek(k)); drop(k); return v; } // k <= 16, refilled by the caller
   SQ_INL uint32_t get(int k) { refill(); return take(k); }
-  SQ_INL bool bad() const { return cnt < 0; }
+  SQ_INL bool bad() const { return cnt < virt; }
 };
 
 // canonical Huffman table from code lengths (puff.c construct): < 0 over-subscribed, 0 complete, > 0 incomplete
@@ -124,7 +126,9 @@ template <class H> SQ_INL void build_fast(const H& h, uint16_t* fast, int bits) 
     index += count; code = (code + count) << 1;
   }
 }
-// a symbol whose code the peek table does not hold, bit by bit through the canonical counts (puff.c decode): -1 on a code that is not in the table
+// a symbol whose code the peek table does not hold, bit by bit through the canonical counts (puff.c decode).  NO_SYMBOL (not a symbol of any alphabet) on a
+// code that is not in the table: the callers' range checks catch it, the loop needs no way out of its own for it
+constexpr int NO_SYMBOL = 511;
 template <class H> SQ_INL int decode_long(Bits& b, const H& h) {
   int code = 0, first = 0, index = 0;
 #pragma unroll 1
@@ -134,7 +138,7 @@ template <class H> SQ_INL int decode_long(Bits& b, const H& h) {
     if (code - count < first) return (int)SQ_UNI(h.symbol[index + (code - first)]);
     index += count; first += count; first <<= 1; code <<= 1;
   }
-  return -1;
+  return NO_SYMBOL;
 }
 // one symbol (the caller has refilled)
 template <class H> SQ_INL int decode(Bits& b, const H& h, const uint16_t* fast, int bits) {
@@ -169,7 +173,7 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
     b.refill();
     int sym = decode(b, T.clen, T.dist_fast, 7);
     if (b.bad()) return INF_EOF_INPUT;
-    if (sym < 0) return INF_BAD_CODES;
+    if (sym > 18) return INF_BAD_CODES;
     if (sym < 16) T.lengths[i++] = (uint8_t)sym;
     else {
       int len = 0, rep;
@@ -258,21 +262,19 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
 #pragma unroll 1
       for (;;) {
         b.refill();
-        const uint32_t e = SQ_UNI(T.lit_fast[b.peek(LIT_BITS)]);
-        int sym;
-        if (e) { b.drop((int)(e & 15)); sym = (int)(e >> 4); }
-        else { sym = decode_long(b, T.lit); if (sym < 0) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; } }
-        if (sym < 256) {
-          o.put((uint32_t)sym);
+        const int sym0 = decode(b, T.lit, T.lit_fast, LIT_BITS);
+        if (sym0 < 256) {
+          o.put((uint32_t)sym0);
           if (o.nlit == 64) { o.flush(); if (b.bad() || o.on > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } }
           continue;
         }
+        int sym = sym0;
         if (sym == 256) { if (b.bad()) rc = INF_EOF_INPUT; break; }
         sym -= 257; if (sym >= 29) { rc = INF_BAD_SYMBOL; break; }
         const uint32_t lx = SQ_UNI(lenx[sym]); const uint32_t len = (lx & 0xFFF) + b.take((int)(lx >> 12));
         b.refill();
         const int ds = decode(b, T.dist, T.dist_fast, DIST_BITS);
-        if (ds < 0 || ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
+        if (ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
         const uint32_t dx = SQ_UNI(distx[ds]); const uint32_t dist = (dx & 0xFFFF) + b.take((int)(dx >> 16));
         if (b.bad() || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
         o.copy(dist, len);
