@@ -14,8 +14,10 @@ def fastq(rng, n, L, const_q):
 
 def main():
     L = capi.lib(); rng = np.random.default_rng(1); distinct, reps = 512, 16
+    only = sys.argv[1:] and tuple(int(x) for x in sys.argv[1].split(","))      # "0,1": random qualities, level 1 — for counter passes
     for const_q in (True, False):
         for level in (1, 6):
+            if only and (int(const_q), level) != only: continue
             text = fastq(rng, distinct * 65280 // 207 + 400, 100, const_q)
             members = []; comp = b""
             for k in range(distinct):
