@@ -34,8 +34,14 @@ namespace sqinf {
 constexpr int LIT_BITS = 10, DIST_BITS = 9;
 struct Huff { uint16_t count[16]; uint16_t symbol[288]; };                 // codes of each length; symbols in code order
 struct HuffS { uint16_t count[16]; uint16_t symbol[32]; };                 // the same for the 30 distance codes and the 19 code-length codes
-// per wave (LDS on the device).  *_fast[peeked bits] = symbol << 4 | code length, 0 where the code is longer than the peek
-struct Tables { uint16_t lit_fast[1 << LIT_BITS]; uint16_t dist_fast[1 << DIST_BITS]; Huff lit; HuffS dist, clen; uint8_t lengths[320]; uint16_t offs[16]; uint32_t win[64]; };   // win: the input window (Bits)
+// per wave (LDS on the device).  The peek tables answer a code of at most LIT_BITS / DIST_BITS bits with everything the decoder wants to know, so that a
+// symbol is ONE look-up (entry 0: the code is longer — walked through the canonical counts):
+//   lit[bits]:  bits 0-3 = bits to drop; K_LIT: a literal in bits 8-15, with K_PAIR a second one in bits 16-23 (two codes that fit the peek together);
+//               else a length symbol: bits 8-16 = base length (0: end of block, > 258: no such symbol), bits 17-19 = number of extra bits
+//   dist[bits]: bits 0-3 = bits to drop, bits 4-7 = number of extra bits, bits 8-23 = base distance (0: no such symbol)
+// (the code-length code of a dynamic block borrows dist[]: bits 0-3, symbol in bits 8-15)
+constexpr uint32_t K_LIT = 16, K_PAIR = 32;
+struct Tables { uint32_t lit[1 << LIT_BITS]; uint32_t dist[1 << DIST_BITS]; Huff hlit; HuffS hdist, hclen; uint8_t lengths[320]; uint16_t offs[16]; uint32_t win[64]; };   // win: the input window (Bits)
 
 enum { INF_OK = 0, INF_EOF_INPUT = 1, INF_BAD_BLOCK = 2, INF_BAD_STORED = 3, INF_BAD_CODES = 4, INF_BAD_SYMBOL = 5, INF_BAD_DISTANCE = 6, INF_OUTPUT_SIZE = 7 };
 
@@ -106,12 +112,34 @@ template <class H> SQ_INL int build(H& h, const uint8_t* length, int n, uint16_t
   for (int s = 0; s < n; ++s) { const uint32_t l = SQ_UNI(length[s]); if (l) { const uint32_t at = SQ_UNI(offs[l]); offs[l] = (uint16_t)(at + 1); h.symbol[at] = (uint16_t)s; } }
   return left;
 }
+// base | extra bits << 12 of the 29 length symbols; base | extra bits << 16 of the 30 distance symbols
+SQ_HD uint32_t len_base_extra(uint32_t s) {
+  const uint32_t lenx[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 12, 13 | 1 << 12, 15 | 1 << 12, 17 | 1 << 12, 19 | 2 << 12, 23 | 2 << 12, 27 | 2 << 12, 31 | 2 << 12, 35 | 3 << 12, 43 | 3 << 12,
+                             51 | 3 << 12, 59 | 3 << 12, 67 | 4 << 12, 83 | 4 << 12, 99 | 4 << 12, 115 | 4 << 12, 131 | 5 << 12, 163 | 5 << 12, 195 | 5 << 12, 227 | 5 << 12, 258};
+  return SQ_UNI(lenx[s]);
+}
+SQ_HD uint32_t dist_base_extra(uint32_t s) {
+  const uint32_t distx[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16, 65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16,
+                              193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16, 1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16,
+                              6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
+  return SQ_UNI(distx[s]);
+}
+// what the tables say about a symbol whose code has `len` bits (len = 0: the bits are gone already — the symbol came from decode_long)
+struct LitEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const {
+  if (sym < 256) return len | K_LIT | (sym << 8);
+  if (sym == 256) return len;                                          // end of block: base length 0
+  if (sym < 286) { const uint32_t lx = len_base_extra(sym - 257); return len | ((lx & 0xFFF) << 8) | ((lx >> 12) << 17); }
+  return len | (0x1FFu << 8); } };                                     // 286, 287 and NO_SYMBOL: in no valid stream
+struct DistEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const {
+  if (sym < 30) { const uint32_t dx = dist_base_extra(sym); return len | ((dx >> 16) << 4) | ((dx & 0xFFFF) << 8); }
+  return len; } };                                                     // base distance 0: no such symbol
+struct ClenEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const { return len | (sym << 8); } };
 // the peek table of a code: every `bits`-bit pattern that starts with a code of at most `bits` bits (codes are sent most significant bit first, the
 // input is read least significant bit first: the pattern is the reversed code, and every setting of the bits behind it)
-template <class H> SQ_INL void build_fast(const H& h, uint16_t* fast, int bits) {
+template <class H, class E> SQ_INL void build_fast(const H& h, uint32_t* fast, int bits, E entry) {
   uint64_t* z = (uint64_t*)fast;
 #pragma unroll 4
-  for (int i = 0; i < (1 << bits) / 4; ++i) z[i] = 0;
+  for (int i = 0; i < (1 << bits) / 2; ++i) z[i] = 0;
   uint32_t code = 0, index = 0;
 #pragma unroll 1
   for (int len = 1; len <= bits; ++len) {
@@ -119,32 +147,50 @@ template <class H> SQ_INL void build_fast(const H& h, uint16_t* fast, int bits) 
 #pragma unroll 1
     for (uint32_t j = 0; j < count; ++j) {
       const uint32_t r = __builtin_bitreverse32(code + j) >> (32 - len);
-      const uint16_t e = (uint16_t)((SQ_UNI(h.symbol[index + j]) << 4) | (uint32_t)len);
+      const uint32_t e = entry(SQ_UNI(h.symbol[index + j]), (uint32_t)len);
 #pragma unroll 1
       for (uint32_t k = r; k < (1u << bits); k += 1u << len) fast[k] = e;
     }
     index += count; code = (code + count) << 1;
   }
 }
+// two literals whose codes fit the peek together become one entry.  From the high patterns down: entry i looks at entry i >> (its code's length), which lies
+// below it and has not been rewritten yet (the device takes 64 entries at once, every lane reading before any lane writes)
+SQ_INL uint32_t pair_entry(const uint32_t* lit, uint32_t i) {
+  const uint32_t e1 = lit[i], l1 = e1 & 15;
+  if (!(e1 & K_LIT) || l1 >= (uint32_t)LIT_BITS) return e1;
+  const uint32_t e2 = lit[i >> l1], l2 = e2 & 15;                        // the pattern behind the first code: its upper l1 bits are unknown (zeros here)
+  if (!(e2 & K_LIT) || e2 == 0 || l1 + l2 > (uint32_t)LIT_BITS) return e1;   // ... which matters only to a code that needs them
+  return (l1 + l2) | K_LIT | K_PAIR | (e1 & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline void pair_literals(uint32_t* lit) {
+  const uint32_t lane = __lane_id();
+  for (int c = (1 << LIT_BITS) / 64 - 1; c >= 0; --c) { const uint32_t i = (uint32_t)c * 64u + lane; const uint32_t e = pair_entry(lit, i); lit[i] = e; }
+}
+#else
+inline void pair_literals(uint32_t* lit) { for (int i = (1 << LIT_BITS) - 1; i >= 0; --i) lit[i] = pair_entry(lit, (uint32_t)i); }
+#endif
 // a symbol whose code the peek table does not hold, bit by bit through the canonical counts (puff.c decode).  NO_SYMBOL (not a symbol of any alphabet) on a
 // code that is not in the table: the callers' range checks catch it, the loop needs no way out of its own for it
-constexpr int NO_SYMBOL = 511;
-template <class H> SQ_INL int decode_long(Bits& b, const H& h) {
+constexpr uint32_t NO_SYMBOL = 511;
+template <class H> SQ_INL uint32_t decode_long(Bits& b, const H& h) {
   int code = 0, first = 0, index = 0;
 #pragma unroll 1
   for (int len = 1; len <= 15; ++len) {
     code |= (int)b.take(1);
     const int count = (int)SQ_UNI(h.count[len]);
-    if (code - count < first) return (int)SQ_UNI(h.symbol[index + (code - first)]);
+    if (code - count < first) return SQ_UNI(h.symbol[index + (code - first)]);
     index += count; first += count; first <<= 1; code <<= 1;
   }
   return NO_SYMBOL;
 }
-// one symbol (the caller has refilled)
-template <class H> SQ_INL int decode(Bits& b, const H& h, const uint16_t* fast, int bits) {
-  const uint32_t e = SQ_UNI(fast[b.peek(bits)]);
-  if (e) { b.drop((int)(e & 15)); return (int)(e >> 4); }
-  return decode_long(b, h);
+// one entry (the caller has refilled): the table's, or the one made for a symbol with a long code; its bits are dropped
+template <class H, class E> SQ_INL uint32_t decode(Bits& b, const H& h, const uint32_t* fast, int bits, E entry) {
+  uint32_t e = SQ_UNI(fast[b.peek(bits)]);
+  if (e == 0) e = entry(decode_long(b, h), 0);
+  b.drop((int)(e & 15));
+  return e;
 }
 
 SQ_INL void fixed_tables(Tables& T) {
@@ -153,9 +199,9 @@ SQ_INL void fixed_tables(Tables& T) {
   for (; s < 256; ++s) T.lengths[s] = 9;
   for (; s < 280; ++s) T.lengths[s] = 7;
   for (; s < 288; ++s) T.lengths[s] = 8;
-  (void)build(T.lit, T.lengths, 288, T.offs); build_fast(T.lit, T.lit_fast, LIT_BITS);
+  (void)build(T.hlit, T.lengths, 288, T.offs); build_fast(T.hlit, T.lit, LIT_BITS, LitEntry()); pair_literals(T.lit);
   for (s = 0; s < 30; ++s) T.lengths[s] = 5;
-  (void)build(T.dist, T.lengths, 30, T.offs); build_fast(T.dist, T.dist_fast, DIST_BITS);
+  (void)build(T.hdist, T.lengths, 30, T.offs); build_fast(T.hdist, T.dist, DIST_BITS, DistEntry());
 }
 SQ_INL int dynamic_tables(Bits& b, Tables& T) {
   const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -166,12 +212,12 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
   for (; i < ncode; ++i) T.lengths[SQ_UNI(order[i])] = (uint8_t)b.get(3);
   for (; i < 19; ++i) T.lengths[SQ_UNI(order[i])] = 0;
   if (b.bad()) return INF_EOF_INPUT;
-  if (build(T.clen, T.lengths, 19, T.offs) != 0) return INF_BAD_CODES;       // the code-length code must be complete
-  build_fast(T.clen, T.dist_fast, 7);                                  // (its peek table borrows the distance table's place: that one is built below)
+  if (build(T.hclen, T.lengths, 19, T.offs) != 0) return INF_BAD_CODES;      // the code-length code must be complete
+  build_fast(T.hclen, T.dist, 7, ClenEntry());                                // (its peek table borrows the distance table's place: that one is built below)
   i = 0;
   while (i < nlen + ndist) {
     b.refill();
-    int sym = decode(b, T.clen, T.dist_fast, 7);
+    const uint32_t sym = decode(b, T.hclen, T.dist, 7, ClenEntry()) >> 8;
     if (b.bad()) return INF_EOF_INPUT;
     if (sym > 18) return INF_BAD_CODES;
     if (sym < 16) T.lengths[i++] = (uint8_t)sym;
@@ -186,14 +232,14 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
     }
   }
   if (SQ_UNI(T.lengths[256]) == 0) return INF_BAD_CODES;                      // no end-of-block code
-  int err = build(T.lit, T.lengths, nlen, T.offs);
-  if (err < 0 || (err > 0 && nlen - (int)SQ_UNI(T.lit.count[0]) != 1)) return INF_BAD_CODES;
-  build_fast(T.lit, T.lit_fast, LIT_BITS);
+  int err = build(T.hlit, T.lengths, nlen, T.offs);
+  if (err < 0 || (err > 0 && nlen - (int)SQ_UNI(T.hlit.count[0]) != 1)) return INF_BAD_CODES;
+  build_fast(T.hlit, T.lit, LIT_BITS, LitEntry()); pair_literals(T.lit);
   // the distance lengths follow the literal/length lengths in the same array: shifted to its start for build
   for (int s = 0; s < ndist; ++s) T.lengths[s] = (uint8_t)SQ_UNI(T.lengths[nlen + s]);
-  err = build(T.dist, T.lengths, ndist, T.offs);
-  if (err < 0 || (err > 0 && ndist - (int)SQ_UNI(T.dist.count[0]) != 1)) return INF_BAD_CODES;
-  build_fast(T.dist, T.dist_fast, DIST_BITS);
+  err = build(T.hdist, T.lengths, ndist, T.offs);
+  if (err < 0 || (err > 0 && ndist - (int)SQ_UNI(T.hdist.count[0]) != 1)) return INF_BAD_CODES;
+  build_fast(T.hdist, T.dist, DIST_BITS, DistEntry());
   return INF_OK;
 }
 
@@ -234,12 +280,6 @@ struct Out {
 
 // the whole stream: `isize` bytes of output are expected (a BGZF member's trailer says how many).  Returns INF_OK or what was wrong.
 SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t isize, Tables& T) {
-  // base | extra bits << 12 of the 29 length symbols; base | extra bits << 16 of the 30 distance symbols
-  const uint32_t lenx[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 12, 13 | 1 << 12, 15 | 1 << 12, 17 | 1 << 12, 19 | 2 << 12, 23 | 2 << 12, 27 | 2 << 12, 31 | 2 << 12, 35 | 3 << 12, 43 | 3 << 12,
-                             51 | 3 << 12, 59 | 3 << 12, 67 | 4 << 12, 83 | 4 << 12, 99 | 4 << 12, 115 | 4 << 12, 131 | 5 << 12, 163 | 5 << 12, 195 | 5 << 12, 227 | 5 << 12, 258};
-  const uint32_t distx[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16, 65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16,
-                              193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16, 1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16,
-                              6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
   Bits b; b.init(in, n, T.win); Out o; o.init(out, isize); int rc = INF_OK;
   for (;;) {
     const uint32_t last = b.get(1), type = b.take(2);
@@ -252,7 +292,7 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
       if ((len ^ nlen) != 0xFFFFu) return INF_BAD_STORED;
       if (o.size() + len > isize) return INF_OUTPUT_SIZE;
 #pragma unroll 1
-      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); if (o.nlit == 64) o.flush(); }
+      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); if (o.nlit >= 63) o.flush(); }
     } else {
       if (type == 1) fixed_tables(T);
       else { rc = dynamic_tables(b, T); if (rc) return rc; }
@@ -262,21 +302,20 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
 #pragma unroll 1
       for (;;) {
         b.refill();
-        const int sym0 = decode(b, T.lit, T.lit_fast, LIT_BITS);
-        if (sym0 < 256) {
-          o.put((uint32_t)sym0);
-          if (o.nlit == 64) { o.flush(); if (b.bad() || o.on > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } }
+        const uint32_t e = decode(b, T.hlit, T.lit, LIT_BITS, LitEntry());
+        if (e & K_LIT) {
+          o.put((e >> 8) & 255u); if (e & K_PAIR) o.put((e >> 16) & 255u);
+          if (o.nlit >= 63) { o.flush(); if (b.bad() || o.on > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } }
           continue;
         }
-        int sym = sym0;
-        if (sym == 256) { if (b.bad()) rc = INF_EOF_INPUT; break; }
-        sym -= 257; if (sym >= 29) { rc = INF_BAD_SYMBOL; break; }
-        const uint32_t lx = SQ_UNI(lenx[sym]); const uint32_t len = (lx & 0xFFF) + b.take((int)(lx >> 12));
+        const uint32_t base = (e >> 8) & 0x1FFu;
+        if (base == 0) { if (b.bad()) rc = INF_EOF_INPUT; break; }       // the end of the block
+        if (base > 258) { rc = INF_BAD_SYMBOL; break; }
+        const uint32_t len = base + b.take((int)((e >> 17) & 7u));
         b.refill();
-        const int ds = decode(b, T.dist, T.dist_fast, DIST_BITS);
-        if (ds >= 30) { rc = b.bad() ? INF_EOF_INPUT : INF_BAD_SYMBOL; break; }
-        const uint32_t dx = SQ_UNI(distx[ds]); const uint32_t dist = (dx & 0xFFFF) + b.take((int)(dx >> 16));
-        if (b.bad() || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
+        const uint32_t d = decode(b, T.hdist, T.dist, DIST_BITS, DistEntry());
+        const uint32_t dist = (d >> 8) + b.take((int)((d >> 4) & 15u));
+        if (b.bad() || (d >> 8) == 0 || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) == 0 ? INF_BAD_SYMBOL : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
         o.copy(dist, len);
       }
       if (rc) return rc;
