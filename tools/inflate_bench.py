@@ -13,7 +13,7 @@ def fastq(rng, n, L, const_q):
 
 
 def main():
-    L = capi.lib(); rng = np.random.default_rng(1); distinct, reps = 512, 16
+    L = capi.lib(); rng = np.random.default_rng(1); distinct, reps = 512, int(os.environ.get("INFLATE_REPS", "16"))
     only = sys.argv[1:] and tuple(int(x) for x in sys.argv[1].split(","))      # "0,1": random qualities, level 1 — for counter passes
     for const_q in (True, False):
         for level in (1, 6):
