@@ -206,17 +206,17 @@ def test_hip_stage_equals_checker_with_the_error_model(built, tmp_path):
 @pytest.mark.gpu
 def test_cli_alignment_mode_runs_the_error_model_by_default(built, tmp_path):
     """`salmon-hip quant -t T -a BAM` learns and applies the error model; --noErrorModel switches it off; both account for every fragment, with different estimates.
-    (-p 1: one mini-batch in flight, so the model learned from a mini-batch of 1000 fragments is what the next one sees — with the default eight in flight a
-    job of 4000 fragments is over before the first snapshot is taken, as it would be in the reference with eight threads' worth of batches on their way.)"""
+    (12 000 fragments and -p 1: a mini-batch is 5 000 fragments and sees the model as it was before it, so the second and third see what the first taught;
+    with the default eight mini-batches in flight a job this small is over before the first snapshot is taken — measured on the checker with the same options.)"""
     import json
-    rng = np.random.default_rng(3); names, seqs, ro, aln = _world(rng, n_txp=16, n_frag=4000)
+    rng = np.random.default_rng(3); names, seqs, ro, aln = _world(rng, n_txp=16, n_frag=12000)
     write_sam_with_reads(tmp_path / "e.sam", names, seqs, ro, aln, rng); sam_to_bam(tmp_path / "e.sam", tmp_path / "e.bam")
     open(tmp_path / "t.fa", "w").write("".join(">%s\n%s\n" % (n, "".join(BASES[b] for b in s)) for n, s in zip(names, seqs)))
     exe = os.path.join(ROOT, "salmon_amd", "bin", "salmon-hip"); res = {}
     for tag, extra in (("em", ["--numErrorBins", "4"]), ("noem", ["--noErrorModel"])):
-        subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "e.bam"), "-o", str(tmp_path / tag), "-q", "-p", "1", "--numPreAuxModelSamples", "200", "--numAuxModelSamples", "2000"] + extra)
+        subprocess.check_call([exe, "quant", "-t", str(tmp_path / "t.fa"), "-l", "IU", "-a", str(tmp_path / "e.bam"), "-o", str(tmp_path / tag), "-q", "-p", "1", "--numPreAuxModelSamples", "200", "--numAuxModelSamples", "20000"] + extra)
         rows = [l.split("\t") for l in open(tmp_path / tag / "quant.sf").read().splitlines()[1:]]; res[tag] = np.array([float(x[4]) for x in rows])
         meta = json.load(open(tmp_path / tag / "aux_info" / "meta_info.json")); res[tag + "_n"] = meta["num_mapped"]
-    # (a fragment whose every alignment is incompatible with -l IU is not assigned: fewer than 4 000 on this random input, the same number either way)
-    assert 3000 < res["em_n"] == res["noem_n"] <= 4000 and np.abs(res["em"] - res["noem"]).max() > 1e-3
+    # (a fragment whose every alignment is incompatible with -l IU is not assigned: fewer than 12 000 on this random input, the same number either way)
+    assert 9000 < res["em_n"] == res["noem_n"] <= 12000 and np.abs(res["em"] - res["noem"]).max() > 1e-3
     assert abs(res["em"].sum() - res["noem"].sum()) < 1e-6 * res["em"].sum() and 0.9 * res["em_n"] < res["em"].sum() <= res["em_n"] + 1
