@@ -78,10 +78,8 @@ struct EmDev {
   // [r4] three launches per iteration: k_fin also leaves psi[t] = digamma(alpha'_t + prior_t) (-inf where the VBEM rule zeroes theta), its last
   // block to finish closes the iteration and publishes logNorm; k_class / k_l1 form theta = exp(psi - logNorm) where they gather it
   int psi_mode; const double* psi; const double* log_norm; double* psi_out; double* log_norm_out;
-  unsigned* fin_ctr;                 // [0 .. FIN_GROUPS) arrival counters of the block groups (one 128-byte line each), [FIN_GROUPS * 32] the top counter
   unsigned long long* blk_rel; uint32_t* blk_bad;   // per block of k_fin: max relDiff (bit pattern) and "a transcript moved more than the tolerance"
 };
-#define FIN_GROUPS 16
 
 __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long* maxrel_log) {
   uint32_t it = it_index + 1;
@@ -344,19 +342,12 @@ __global__ void k_close(EmDev d, uint32_t it_index /* 0-based index of the itera
   em_close(d, it_index, maxrel_log);
 }
 
-// [r4] k_fin with the iteration's end folded in (the default; SQ_EM_LAUNCHES=5 keeps the five-launch form).  What a block hands to the block
-// that finishes last — its level-1 partial sums, its max relDiff, its "moved" flag — is written with agent-scope stores and read with
-// agent-scope loads (served by the memory side, so no cache maintenance is needed between XCDs: tools/gridbar2_bench.hip), every thread drains
-// its memory operations before its block arrives, and the arrival counters are two-level (FIN_GROUPS counters on their own lines, then one)
-// so that no address sees more than ~50 atomics.  The last block does what k_top / k_close did: closes the iteration (convergence, counters)
-// and, for VBEM, finishes the canonical sum of (alpha + prior) level by level and publishes logNorm = digamma(sum) for the next iteration.
-__device__ inline double em_ld_ag(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ inline void em_st_ag(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int TAIL>   // 1: the last block closes the iteration (three launches); 0: k_top does, from the per-block results (four launches)
+// [r4] k_fin of the four-launch iteration: the leaves of the canonical sum (level-1 partials), psi for the next iteration's gathers, and what this block saw of
+// the convergence test (its max relDiff, its "moved" flag) for k_top, which closes the iteration from the per-block results.  (A three-launch form in which the
+// block that finishes last closed the iteration itself was measured slower — 45.7 vs 38.5 us: its serial tail costs more than the launch it saves — and is gone.)
 __global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials,
     uint32_t it_index, unsigned long long* maxrel_log) {
   if (d.flags[0]) return;
-  __shared__ double lvl[64];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   double rel = -1.0; int bad = 0; double leaf = 0.0;
   if (t < d.M) {
@@ -386,75 +377,18 @@ __global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict_
   }
   if (partials) {
     const double ls = wave_halving_sum(leaf);
-    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) { if (TAIL) em_st_ag(&partials[t >> 6], ls); else partials[t >> 6] = ls; }
+    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls;
   }
   for (int s = 32; s >= 1; s >>= 1) {
     const double o = __shfl_down(rel, s, 64); const int ob = __shfl_down(bad, s, 64);
     rel = o > rel ? o : rel; bad |= ob;
   }
-  __shared__ double srel[4]; __shared__ int sbad[4]; __shared__ int s_last;
+  __shared__ double srel[4]; __shared__ int sbad[4];
   if ((threadIdx.x & 63) == 0) { srel[threadIdx.x >> 6] = rel; sbad[threadIdx.x >> 6] = bad; }
-  if (!TAIL) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; }
-      d.blk_rel[blockIdx.x] = rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL; d.blk_bad[blockIdx.x] = (uint32_t)bad;
-    }
-    return;
-  }
-  __builtin_amdgcn_s_waitcnt(0);                      // this thread's stores have been answered
   __syncthreads();
   if (threadIdx.x == 0) {
     for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; }
-    __hip_atomic_store(&d.blk_rel[blockIdx.x], rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&d.blk_bad[blockIdx.x], (uint32_t)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);
-    const uint32_t grp = blockIdx.x % FIN_GROUPS, gsize = gridDim.x / FIN_GROUPS + (grp < gridDim.x % FIN_GROUPS ? 1u : 0u);
-    int last = 0;
-    if (__hip_atomic_fetch_add(&d.fin_ctr[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
-      __hip_atomic_store(&d.fin_ctr[grp * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t ngroups = gridDim.x < FIN_GROUPS ? gridDim.x : FIN_GROUPS;
-      if (__hip_atomic_fetch_add(&d.fin_ctr[FIN_GROUPS * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
-        __hip_atomic_store(&d.fin_ctr[FIN_GROUPS * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // ---- the block that arrived last: every other block's partials / maxima are in memory ----
-  unsigned long long mr = 0; int anybad = 0;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-    const unsigned long long r = __hip_atomic_load(&d.blk_rel[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (r > mr) mr = r;   // non-negative doubles order like their bit patterns
-    anybad |= (int)__hip_atomic_load(&d.blk_bad[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __shared__ unsigned long long smr[256]; __shared__ int sab[256]; __shared__ int s_done;
-  smr[threadIdx.x] = mr; sab[threadIdx.x] = anybad;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (uint32_t i = 1; i < blockDim.x; ++i) { if (smr[i] > mr) mr = smr[i]; anybad |= sab[i]; }
-    const uint32_t it = it_index + 1;              // em_close
-    d.flags[2] = it; maxrel_log[0] = mr;
-    const bool done = !anybad && it >= d.min_iter;
-    if (done) d.flags[0] = it;
-    s_done = done ? 1 : 0;
-  }
-  __syncthreads();
-  if (s_done || !partials) return;
-  // SPEC D2: 64-leaf strided-halving trees, level by level (as k_top): the <= 4096 level-1 partials straight from memory, then <= 64 in LDS
-  const uint32_t n1 = (d.M + 63) >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, g = (n1 + 63) / 64;
-  for (uint32_t j = wave; j < g; j += nw) {
-    const uint32_t i = j * 64 + lane;
-    double v = (i < n1) ? em_ld_ag(&partials[i]) : 0.0;
-    v = wave_halving_sum(v);
-    if (lane == 0) lvl[j] = v;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    double v = lvl[0];
-    if (g > 1) { v = (lane < g) ? lvl[lane] : 0.0; v = wave_halving_sum(v); }
-    if (lane == 0) *d.log_norm_out = sq_digamma(v);
+    d.blk_rel[blockIdx.x] = rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL; d.blk_bad[blockIdx.x] = (uint32_t)bad;
   }
 }
 __global__ void k_copy_f64(uint32_t n, const double* __restrict__ src, double* __restrict__ dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
@@ -661,7 +595,7 @@ struct EmSession {
   DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part;
   DBuf<unsigned long long> d_maxrel, d_log;
   DBuf<double> d_lognorm, d_psi0, d_psi1;
-  DBuf<unsigned> d_finctr; DBuf<unsigned long long> d_blkrel; DBuf<uint32_t> d_blkbad;
+  DBuf<unsigned long long> d_blkrel; DBuf<uint32_t> d_blkbad;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -719,7 +653,7 @@ struct EmSession {
               !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) &&
                   !d_flags.alloc(4) &&
                   !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) && !d_psi0.alloc(M) && !d_psi1.alloc(M) &&
-                  !d_finctr.alloc((FIN_GROUPS + 1) * 32) && !d_blkrel.alloc((M + 255) / 256 + 1) && !d_blkbad.alloc((M + 255) / 256 + 1);
+                  !d_blkrel.alloc((M + 255) / 256 + 1) && !d_blkbad.alloc((M + 255) / 256 + 1);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     pt.mark("buffers");
@@ -835,8 +769,8 @@ struct EmSession {
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
     d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
     d.psi_mode = 0; d.psi = nullptr; d.log_norm = d_lognorm.p; d.psi_out = nullptr; d.log_norm_out = d_lognorm.p;
-    d.fin_ctr = d_finctr.p; d.blk_rel = d_blkrel.p; d.blk_bad = d_blkbad.p;
-    SQ_HIP_CHECK(hipMemsetAsync(d_finctr.p, 0, (FIN_GROUPS + 1) * 32 * sizeof(unsigned), st)); SQ_HIP_CHECK(sq_em_wait(st));
+    d.blk_rel = d_blkrel.p; d.blk_bad = d_blkbad.p;
+    SQ_HIP_CHECK(sq_em_wait(st));
     pt.mark("device-prepare");
     return SQ_OK;
   }
@@ -879,32 +813,19 @@ struct EmSession {
       }
       k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p, top_nblk);
     };
-    // [r4] three launches per iteration unless the plan needs more than two reduction levels, M is beyond one block's reach, or SQ_EM_LAUNCHES=5
-    // [r4] measured on MI355X (c2, E = 0.63 M, L = 1.66 M, M = 191 k): five launches 40.9 us per iteration; three (k_fin3's last block closes the
-    // iteration and finishes the sum) 45.7 us — the serial tail of one block costs more than the two launches it replaces; four (k_theta folded
-    // into the gathers, k_top closes from per-block results) is the default.  SQ_EM_LAUNCHES=3|4|5 selects.
-    static const int nl_env = getenv("SQ_EM_LAUNCHES") ? atoi(getenv("SQ_EM_LAUNCHES")) : 4;
-    const bool can_fold = g1 <= 4096 && (d.l2_cnt || d.nlevels <= 1);
-    const bool fold = can_fold && nl_env == 3, four = can_fold && nl_env == 4;
+    // [r4] measured on MI355X (c2, E = 0.63 M, L = 1.66 M, M = 191 k): five launches 40.9 us per iteration, four (k_theta folded into the gathers, k_top closes from
+    // per-block results) 38.5 us: the default whenever the plan has at most two reduction levels and M is within one block's reach; otherwise the five-launch form
+    const bool four = g1 <= 4096 && (d.l2_cnt || d.nlevels <= 1);
     if (four) top_nblk = (M + TB - 1) / TB;
     double* psi_cur = d_psi0.p; double* psi_nxt = d_psi1.p;
     const bool plus_one = mark_degenerate && !o->use_vbem;   // optimize() only (the replicates' alphasPrime start at zero: :413-414)
-    auto launch_iter3 = [&](uint32_t it) {
-      EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
-      if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
-      const double* src = o->use_vbem ? psi_cur : cur;
-      if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
-      if (dd.nchunks) k_l1<<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt);
-      k_fin3<1><<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
-      std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
-    };
     auto launch_iter4 = [&](uint32_t it) {
       EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
       if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
       const double* src = o->use_vbem ? psi_cur : cur;
       if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
       if (dd.nchunks) k_l1<<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt);
-      k_fin3<0><<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
+      k_fin3<<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
       if (o->use_vbem) launch_top(1, it);
       else k_top<<<1, 1024, 0, st>>>(d, part_lvl1, 0, 1, it, d_log.p, d_lognorm.p, top_nblk);   // EM: only closes the iteration
       std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
@@ -923,9 +844,9 @@ struct EmSession {
       else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);
       std::swap(cur, nxt);
     };
-    auto launch_iter = [&](uint32_t it) { if (fold) launch_iter3(it); else if (four) launch_iter4(it); else launch_iter5(it); };
+    auto launch_iter = [&](uint32_t it) { if (four) launch_iter4(it); else launch_iter5(it); };
     if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0);
-      if (fold || four) k_psi0<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, psi_cur); }
+      if (four) k_psi0<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, psi_cur); }
     uint32_t it = it0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     if (mode == 1) {
