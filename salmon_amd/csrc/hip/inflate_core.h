@@ -243,39 +243,57 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
   return INF_OK;
 }
 
-// where the text goes.  Device: `lane` is the thread's lane; literals wait in `litv` (lane k holds literal k of the run) until 64 are there or a
-// match needs them in memory.  A match of up to 64 bytes whose source lies in text already stored is a load now and a store LATER (`pcv`: lane k holds byte k,
-// stored when the next match or the end comes): the decoder goes on with the next symbol while the bytes travel — a wave that waited for every match's load
-// spent most of its time waiting.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text begins there); whether the
-// stream wanted to is seen from size().
+// where the text goes.  Device: the decoder does not touch memory per symbol.  What it decodes — a literal entry as the table gave it, or a match as
+// 1 << 31 | length << 16 | distance — waits as a TOKEN in `tokv`, lane k holding token k; at 64 tokens (or the end of a block) apply() lays them out
+// with one prefix sum over their lengths and all lanes store at once: a literal its byte(s), a match of up to 16 bytes whose source lies in text already in
+// memory its copy (the usual case in FASTQ text: short repeats of sequence far back).  Matches that reach into the batch's own text, repeat themselves or are
+// longer go one after the other behind that, in token order, the whole wave copying each (lane i takes byte i mod distance).  Per symbol the scalar unit — a
+// compute unit issues one scalar instruction per cycle for all its waves, and that port is what bounds this kernel — sees a table entry, a shift count and a
+// counter; the exec-mask work of a store is paid once per 64 tokens.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text
+// begins there); whether the stream wanted to is seen from size().
 struct Out {
-  uint8_t* out; uint32_t on, nlit, cap;      // on: the text decided so far without the literals in litv (it includes a match waiting in pcv)
+  uint8_t* out; uint32_t on, pend, ntok, cap;      // on: bytes in memory; pend: bytes the waiting tokens stand for
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t lane, litv, pcv, pcn, pcat;
-  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; litv = 0; pcv = 0; pcn = 0; pcat = 0; lane = __lane_id(); }
-  __device__ void flush() { if (lane < nlit && on + lane < cap) out[on + lane] = (uint8_t)litv; on += nlit; nlit = 0; }
-  __device__ void settle() { if (pcn) { if (lane < pcn) out[pcat + lane] = (uint8_t)pcv; pcn = 0; } }
-  __device__ void finish() { settle(); flush(); }
-  __device__ void put(uint32_t byte) { litv = lane == nlit ? byte : litv; ++nlit; }   // the caller flushes at 64
-  __device__ void copy(uint32_t dist, uint32_t len) {      // the caller has checked dist <= size(), size() + len <= cap
-    settle();
-    if (dist < len + nlit || len > 64) {      // the source reaches into literals not stored yet, or repeats itself, or is wider than a wave: stored at once
-      flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on;
-      if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
-      else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }     // the window's last `dist` bytes, repeated
-      on += len; return;
-    }
-    pcat = on + nlit; pcn = len; if (lane < len) pcv = out[pcat - dist + lane];
-    flush(); on += len;                        // (the literals in front of the match go out behind its load)
+  uint32_t lane, tokv;
+  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; tokv = 0; lane = __lane_id(); }
+  __device__ void token(uint32_t t, uint32_t nbytes) { tokv = lane == ntok ? t : tokv; ++ntok; pend += nbytes; }      // the caller applies at 64
+  __device__ void wide_copy(uint32_t pos, uint32_t dist, uint32_t len) {
+    const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos;
+    if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
+    else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }       // the window's last `dist` bytes, repeated
   }
+  __device__ void apply() {      // the caller has checked size() <= cap
+    const uint32_t t = lane < ntok ? tokv : 0u; const bool m = (t >> 31) != 0;
+    const uint32_t len = m ? (t >> 16) & 0x1FFu : (t & K_LIT) ? ((t & K_PAIR) ? 2u : 1u) : 0u;
+    uint32_t inc = len;                                                              // where each token's text begins: a prefix sum across the lanes
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += up; }
+    const uint32_t pos = on + inc - len, dist = t & 0xFFFFu;
+    const bool simple = m && len <= 16 && pos - dist + len <= on;                    // its source is in memory already
+    if (!m) { if (len >= 1) out[pos] = (uint8_t)(t >> 8); if (len == 2) out[pos + 1] = (uint8_t)(t >> 16); }
+    if (simple) {
+      const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos; uint8_t by[16];
+#pragma unroll
+      for (uint32_t k = 0; k < 16; ++k) if (k < len) by[k] = src[k];
+#pragma unroll
+      for (uint32_t k = 0; k < 16; ++k) if (k < len) dst[k] = by[k];
+    }
+    uint64_t rest = __ballot(m && !simple);
+    while (rest) {                                                                   // (uniform: every lane sees the same mask)
+      const int k = __builtin_ctzll(rest); rest &= rest - 1;
+      const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)t, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
+      wide_copy(pk, tk & 0xFFFFu, (tk >> 16) & 0x1FFu);
+    }
+    on += pend; pend = 0; ntok = 0;
+  }
+  __device__ void lit(uint32_t e) { token(e, (e & K_PAIR) ? 2u : 1u); }
+  __device__ void match(uint32_t dist, uint32_t len) { token(0x80000000u | (len << 16) | dist, len); }   // the caller has checked dist <= size(), size() + len <= cap
 #else
-  void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; nlit = 0; cap = cap_; }
-  void flush() { on += nlit; nlit = 0; }
-  void finish() { flush(); }
-  void put(uint32_t byte) { if (on + nlit < cap) out[on + nlit] = (uint8_t)byte; ++nlit; }
-  void copy(uint32_t dist, uint32_t len) { flush(); const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; }
+  void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; }
+  void apply() { ntok = 0; }
+  void lit(uint32_t e) { if (on < cap) out[on] = (uint8_t)(e >> 8); ++on; if (e & K_PAIR) { if (on < cap) out[on] = (uint8_t)(e >> 16); ++on; } ++ntok; }
+  void match(uint32_t dist, uint32_t len) { const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; ++ntok; }
 #endif
-  SQ_HD uint32_t size() const { return on + nlit; }
+  SQ_HD uint32_t size() const { return on + pend; }
 };
 
 // the whole stream: `isize` bytes of output are expected (a BGZF member's trailer says how many).  Returns INF_OK or what was wrong.
@@ -286,44 +304,45 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
     if (b.bad()) return INF_EOF_INPUT;
     if (type == 3) return INF_BAD_BLOCK;
     if (type == 0) {
-      b.take(b.cnt & 7);                                              // to the next byte boundary; the buffer then holds whole bytes
+      b.take((int)(b.cnt & 7));                                       // to the next byte boundary; the buffer then holds whole bytes
       const uint32_t len = b.get(16), nlen = b.get(16);
       if (b.bad()) return INF_EOF_INPUT;
       if ((len ^ nlen) != 0xFFFFu) return INF_BAD_STORED;
       if (o.size() + len > isize) return INF_OUTPUT_SIZE;
 #pragma unroll 1
-      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.put(v); if (o.nlit >= 63) o.flush(); }
+      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; o.lit(K_LIT | (v << 8)); if (o.ntok == 64) o.apply(); }
     } else {
       if (type == 1) fixed_tables(T);
       else { rc = dynamic_tables(b, T); if (rc) return rc; }
-      // the loop that does the work: one literal, or one length / distance pair, per turn; every way out of it leaves through the one test behind it.  A literal
-      // costs a dozen scalar instructions: whether the input ended or the text overflows is looked at when a run of 64 is stored, not per literal (zeros decode
-      // to something harmless until then: nothing is stored at or behind the member's end)
+      // the loop that does the work: one table entry (a literal, two, or a length symbol followed by its distance) per turn; every way out of it leaves through
+      // the one test behind it.  Whether the input ended or the text overflows is looked at per batch of tokens and per match, not per literal (zeros decode to
+      // something harmless until then: nothing is stored at or behind the member's end)
 #pragma unroll 1
       for (;;) {
         b.refill();
         const uint32_t e = decode(b, T.hlit, T.lit, LIT_BITS, LitEntry());
-        if (e & K_LIT) {
-          o.put((e >> 8) & 255u); if (e & K_PAIR) o.put((e >> 16) & 255u);
-          if (o.nlit >= 63) { o.flush(); if (b.bad() || o.on > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } }
-          continue;
+        if (e & K_LIT) o.lit(e);
+        else {
+          const uint32_t base = (e >> 8) & 0x1FFu;
+          if (base == 0) { if (b.bad()) rc = INF_EOF_INPUT; break; }       // the end of the block
+          if (base > 258) { rc = INF_BAD_SYMBOL; break; }
+          const uint32_t len = base + b.take((int)((e >> 17) & 7u));
+          b.refill();
+          const uint32_t d = decode(b, T.hdist, T.dist, DIST_BITS, DistEntry());
+          const uint32_t dist = (d >> 8) + b.take((int)((d >> 4) & 15u));
+          if (b.bad() || (d >> 8) == 0 || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) == 0 ? INF_BAD_SYMBOL : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
+          o.match(dist, len);
         }
-        const uint32_t base = (e >> 8) & 0x1FFu;
-        if (base == 0) { if (b.bad()) rc = INF_EOF_INPUT; break; }       // the end of the block
-        if (base > 258) { rc = INF_BAD_SYMBOL; break; }
-        const uint32_t len = base + b.take((int)((e >> 17) & 7u));
-        b.refill();
-        const uint32_t d = decode(b, T.hdist, T.dist, DIST_BITS, DistEntry());
-        const uint32_t dist = (d >> 8) + b.take((int)((d >> 4) & 15u));
-        if (b.bad() || (d >> 8) == 0 || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) == 0 ? INF_BAD_SYMBOL : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
-        o.copy(dist, len);
+        if (o.ntok == 64) { if (b.bad() || o.size() > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } o.apply(); }
       }
       if (rc) return rc;
     }
     if (last) break;
   }
-  o.finish();
-  return b.bad() ? INF_EOF_INPUT : o.on == isize ? INF_OK : INF_OUTPUT_SIZE;
+  if (b.bad()) return INF_EOF_INPUT;
+  if (o.size() != isize) return INF_OUTPUT_SIZE;
+  o.apply();
+  return INF_OK;
 }
 
 // CRC-32 (the gzip polynomial, reflected) of n bytes, a byte at a time through a 256-entry table
