@@ -34,15 +34,21 @@ def _deps_stamp():
                 h.update(open(os.path.join(base, f), "rb").read())
     for f in sorted(os.listdir(os.path.join(ROOT, "include"))):
         h.update(open(os.path.join(ROOT, "include", f), "rb").read())
-    h.update(" ".join(COMMON).encode())
+    h.update((" ".join(COMMON) + repr(sorted(PER_FILE.items()))).encode())
     return h.hexdigest()[:12]
+
+
+# inflate_dev.hip: its decoding loop is a wave acting as a scalar processor — every branch in it is uniform.  The structurizer's default turns such a region into
+# flag registers and mask tests all the same (half of the loop's scalar instructions, and the scalar port is what bounds the kernel: DESIGN.md section 4); with
+# uniform regions skipped the branches stay plain scalar jumps.  tests/test_inflate.py holds the result to zlib on the device.
+PER_FILE = {"inflate_dev.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
 
 
 def _compile(src, stamp):
     obj = os.path.join(OBJ, os.path.basename(src) + "." + stamp + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src):
         return obj, False
-    cmd = [HIPCC] + COMMON + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + COMMON + PER_FILE.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout[-4000:], r.stderr[-8000:]))

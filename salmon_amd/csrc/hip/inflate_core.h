@@ -66,9 +66,9 @@ struct Bits {
   const uint8_t* p; uint32_t n, pos, nblk; uint32_t lo, hi; uint32_t cnt, virt; uint32_t* win;      // win: 64 words (LDS on the device); virt: how many of the cnt bits lie behind the end of the input
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t pend, lane;
-  __device__ void fetch(uint32_t b) { const uint32_t off = b * 256u + lane * 4u; pend = off < n ? *(const uint32_t*)(p + off) : 0u; }      // (reads up to 3 bytes behind n: the buffers have slack)
-  __device__ void enter() { win[lane] = pend; ++nblk; fetch(nblk); }
-  __device__ void start() { lane = __lane_id(); fetch(0); }
+  __device__ void fetch(uint32_t b) { uint32_t off = b * 256u + lane * 4u; const uint32_t top = (n - 1u) & ~3u; off = off < top ? off : top; pend = *(const uint32_t*)(p + off); }   // no branch: lanes behind the input's end re-read its last word (never used); up to 3 bytes behind n are read (the buffers have slack)
+  __device__ void enter() { win[lane] = pend; ++nblk; fetch(nblk); }      // (n > 0 here: positions below n are all that is ever asked for)
+  __device__ void start() { lane = __lane_id(); pend = 0; if (n) fetch(0); }
 #else
   void enter() { for (uint32_t l = 0; l < 64; ++l) { uint32_t w = 0; for (uint32_t k = 0; k < 4; ++k) { const uint32_t off = nblk * 256u + l * 4u + k; if (off < n) w |= (uint32_t)p[off] << (8 * k); } win[l] = w; } ++nblk; }
   void start() {}
@@ -251,40 +251,42 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
 // compute unit issues one scalar instruction per cycle for all its waves, and that port is what bounds this kernel — sees a table entry, a shift count and a
 // counter; the exec-mask work of a store is paid once per 64 tokens.  Host: bytes, in order.  Nothing is ever stored at or behind `cap` (the next member's text
 // begins there); whether the stream wanted to is seen from size().
+#if defined(__HIP_DEVICE_COMPILE__)
+// the tokens of a batch into memory (Out::apply).  NOT inlined: it is the only code with lane-dependent branches, and with it out of the way the decoding loop
+// is a region of uniform branches that the compiler leaves as plain scalar jumps instead of structuring it into flags and masks
+__device__ __attribute__((noinline)) void apply_tokens(uint8_t* out, uint32_t on, uint32_t ntok, uint32_t tokv) {
+  const uint32_t lane = __lane_id();
+  const uint32_t t = lane < ntok ? tokv : 0u; const bool m = (t >> 31) != 0;
+  const uint32_t len = m ? (t >> 16) & 0x1FFu : (t & K_LIT) ? ((t & K_PAIR) ? 2u : 1u) : 0u;
+  uint32_t inc = len;                                                              // where each token's text begins: a prefix sum across the lanes
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += up; }
+  const uint32_t pos = on + inc - len, dist = t & 0xFFFFu;
+  const bool simple = m && len <= 16 && pos - dist + len <= on;                    // its source is in memory already
+  if (!m) { if (len >= 1) out[pos] = (uint8_t)(t >> 8); if (len == 2) out[pos + 1] = (uint8_t)(t >> 16); }
+  if (simple) {
+    const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos; uint8_t by[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) if (k < len) by[k] = src[k];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) if (k < len) dst[k] = by[k];
+  }
+  uint64_t rest = __ballot(m && !simple);
+  while (rest) {                                                                   // (uniform: every lane sees the same mask)
+    const int k = __builtin_ctzll(rest); rest &= rest - 1;
+    const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)t, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k), dk = tk & 0xFFFFu, lk = (tk >> 16) & 0x1FFu;
+    const uint8_t* src = out + pk - dk; uint8_t* dst = out + pk;
+    if (dk >= lk) { for (uint32_t i = lane; i < lk; i += 64) dst[i] = src[i]; }
+    else { for (uint32_t i = lane; i < lk; i += 64) dst[i] = src[i % dk]; }        // the window's last `dist` bytes, repeated
+  }
+}
+#endif
 struct Out {
   uint8_t* out; uint32_t on, pend, ntok, cap;      // on: bytes in memory; pend: bytes the waiting tokens stand for
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t lane, tokv;
   __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; tokv = 0; lane = __lane_id(); }
   __device__ void token(uint32_t t, uint32_t nbytes) { tokv = lane == ntok ? t : tokv; ++ntok; pend += nbytes; }      // the caller applies at 64
-  __device__ void wide_copy(uint32_t pos, uint32_t dist, uint32_t len) {
-    const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos;
-    if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i]; }
-    else { for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i % dist]; }       // the window's last `dist` bytes, repeated
-  }
-  __device__ void apply() {      // the caller has checked size() <= cap
-    const uint32_t t = lane < ntok ? tokv : 0u; const bool m = (t >> 31) != 0;
-    const uint32_t len = m ? (t >> 16) & 0x1FFu : (t & K_LIT) ? ((t & K_PAIR) ? 2u : 1u) : 0u;
-    uint32_t inc = len;                                                              // where each token's text begins: a prefix sum across the lanes
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += up; }
-    const uint32_t pos = on + inc - len, dist = t & 0xFFFFu;
-    const bool simple = m && len <= 16 && pos - dist + len <= on;                    // its source is in memory already
-    if (!m) { if (len >= 1) out[pos] = (uint8_t)(t >> 8); if (len == 2) out[pos + 1] = (uint8_t)(t >> 16); }
-    if (simple) {
-      const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos; uint8_t by[16];
-#pragma unroll
-      for (uint32_t k = 0; k < 16; ++k) if (k < len) by[k] = src[k];
-#pragma unroll
-      for (uint32_t k = 0; k < 16; ++k) if (k < len) dst[k] = by[k];
-    }
-    uint64_t rest = __ballot(m && !simple);
-    while (rest) {                                                                   // (uniform: every lane sees the same mask)
-      const int k = __builtin_ctzll(rest); rest &= rest - 1;
-      const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)t, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
-      wide_copy(pk, tk & 0xFFFFu, (tk >> 16) & 0x1FFu);
-    }
-    on += pend; pend = 0; ntok = 0;
-  }
+  __device__ void apply() { apply_tokens(out, on, ntok, tokv); on += pend; pend = 0; ntok = 0; }      // the caller has checked size() <= cap
   __device__ void lit(uint32_t e) { token(e, (e & K_PAIR) ? 2u : 1u); }
   __device__ void match(uint32_t dist, uint32_t len) { token(0x80000000u | (len << 16) | dist, len); }   // the caller has checked dist <= size(), size() + len <= cap
 #else

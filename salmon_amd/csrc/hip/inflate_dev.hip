@@ -55,7 +55,7 @@ extern "C" int sq_debug_bgzf_inflate(int device, const uint8_t* comp, uint64_t c
   if (!comp || !mem || !text || !status2) { sq_set_error("sq_debug_bgzf_inflate: bad arguments"); return SQ_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); sq_set_error("no HIP device %d", device); return SQ_ERR_DEVICE; }
   void *dc = nullptr, *dm = nullptr, *dt = nullptr, *ds = nullptr; int rc = SQ_OK;
-  if (hipMalloc(&dc, comp_bytes + 16) != hipSuccess || hipMalloc(&dm, (size_t)nmem * sizeof(sq_bgzf_member) + 16) != hipSuccess || hipMalloc(&dt, text_bytes + 64) != hipSuccess || hipMalloc(&ds, 16) != hipSuccess) rc = SQ_ERR_NOMEM;
+  if (hipMalloc(&dc, comp_bytes + 512) != hipSuccess || hipMalloc(&dm, (size_t)nmem * sizeof(sq_bgzf_member) + 16) != hipSuccess || hipMalloc(&dt, text_bytes + 64) != hipSuccess || hipMalloc(&ds, 16) != hipSuccess) rc = SQ_ERR_NOMEM;
   const uint32_t st0[2] = {0xFFFFFFFFu, 0};
   if (!rc && (hipMemcpy(dc, comp, comp_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dm, mem, (size_t)nmem * sizeof(sq_bgzf_member), hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(ds, st0, 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dt, 0, text_bytes) != hipSuccess)) rc = SQ_ERR_DEVICE;
