@@ -161,9 +161,10 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
     while n_pairs > 1000000 and need(n_pairs) > room: n_pairs //= 2
     gz_pairs = min(n_pairs, gz_pairs or n_pairs)
     out = {"input": "2 FASTQ files of %d x %d bp in /dev/shm (page cache), batches of %d pairs; the gzip / BGZF legs read the first %d pairs of them" % (n_pairs, read_len, batch, gz_pairs), "host_threads": os.cpu_count(), "host_cpu_quota_cores": cpu_allowance()[1],
-           "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(32, hw/2)"),
+           "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(64, hw/2) inflating, min(16, hw/4) copying"),
            "what": "end to end from files through sq_reader, H2D included; plain files: text staged in page-locked memory, records split on the device "
-                   "(hip/fastq_dev.hip); gzip/BGZF: inflated and split on the host (host/reader.cpp, host/pgzip.cpp)"}
+                   "(hip/fastq_dev.hip); BGZF: the compressed members cross PCIe and are inflated on the device (hip/inflate_dev.hip, a wave per member), records split there; "
+                   "gzip (one deflate stream): inflated in pieces by the host's threads (host/pgzip.cpp, bounded by the container's CPU quota), records split on the device"}
     try:
         seq, off, _, _ = tx.reads(n_pairs, read_len=read_len, seed=77, first_pair=0, threads=threads, truth=False)
         recs = seq.reshape(2 * n_pairs, read_len)
