@@ -616,6 +616,57 @@ struct sq_dev_reader {
     cv.notify_all();
     return true;
   }
+  // [r5] The usual batch without a wait per step: for BOTH mates the text a full batch is expected to take is copied, its lines counted and indexed, and the three
+  // numbers that say whether that was enough (the last tile's count and base, the position of line end 4 * batch) come back in ONE synchronisation.  Anything
+  // else — the end of a stream, records longer than expected, a damaged member — leaves the stream positions untouched and goes the careful way (dv_split).
+  // 0: issued; 1: not the usual case (the caller takes dv_split); < 0: the reader is closing or a device error (in *e)
+  int dv_issue(int i, int si, uint32_t want, unsigned* np_out, std::string* e) {
+    Stream& S = sm[i]; DvStream& D = dv[i]; Slot& s = slots[(size_t)si]; hipStream_t st = s.st; const uint32_t stride = paired ? 2u : 1u;
+    const size_t need = (size_t)((double)want * S.est * 1.02) + (256u << 10); unsigned* h = s.h_res + 4 + 24 * i;
+    struct Part { int idx; uint64_t voff; size_t n; }; std::vector<Part> parts; uint64_t pos;
+    { const double t0 = now(); std::unique_lock<std::mutex> lk(mu); pos = D.pos;
+      cv.wait(lk, [&] { return stop || (!D.q.empty() && (D.q.back().last || D.q.back().voff + D.q.back().n >= pos + need || D.q.size() == (size_t)DV_CHUNKS)); });
+      if (stop) return -1;
+      t_dv_wait += now() - t0;
+      if (D.q.back().voff + D.q.back().n < pos + need) return 1;      // the stream ends in this batch, or the ring is full
+      for (auto& c : D.q) parts.push_back(Part{c.idx, c.voff, c.n}); }
+    if (need >= 0xFFFFFFF0ull) return 1;
+    const size_t padded = (need + 15) & ~(size_t)15; const uint64_t nvec = padded / 16; const uint32_t ntile = (uint32_t)((nvec + FQ_TB - 1) / FQ_TB);
+    // the tile buffers are shared by the mates and mate 1's work may still be queued when mate 2's is issued: they are sized for the larger of the two at once
+    size_t need_max = need; for (int k = 0; k < (paired ? 2 : 1); ++k) need_max = std::max(need_max, (size_t)((double)want * sm[k].est * 1.02) + (256u << 10));
+    const uint32_t ntile_max = (uint32_t)((((need_max + 15) / 16) + FQ_TB - 1) / FQ_TB) + 1;
+    if (dev_grow(&s.d_text[i], &s.text_cap[i], need + 64) || dev_grow(&s.d_tile, &s.tile_cap, ((size_t)ntile_max + 8) * 4) || dev_grow(&s.d_tbase, &s.tbase_cap, ((size_t)ntile_max + 8) * 8) ||
+        dev_grow(&s.d_spine, &s.spine_cap, ((size_t)std::max(sqk::scan_tiles(ntile_max), sqk::scan_tiles((uint64_t)batch * stride)) + 8) * 8) ||
+        dev_grow(&s.d_len, &s.len_cap, ((size_t)want * stride + 8) * 4) || dev_grow(&s.d_off, &s.off_cap, ((size_t)want * stride + 8) * 8) ||
+        dev_grow(&s.d_nlpos[i], &s.nl_cap[i], ((size_t)4 * want + 8) * 4) || dev_grow(&s.d_start[i], &s.start_cap[i], ((size_t)want + 8) * 4)) { *e = "device allocation failed (reader)"; return -2; }
+    auto dev_err = [&]() { *e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); return -3; };
+    unsigned np = 0;
+    for (auto& pt : parts) {
+      const uint64_t lo = std::max(pos, pt.voff), hi = std::min<uint64_t>(pos + need, pt.voff + pt.n); if (lo >= hi) continue;
+      if (hipStreamWaitEvent(st, D.ev_done[pt.idx], 0) != hipSuccess || hipMemcpyAsync((char*)s.d_text[i] + (lo - pos), (const char*)D.text[pt.idx] + (lo - pt.voff), (size_t)(hi - lo), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(h + 4 + 2 * np, D.st + 2 * pt.idx, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return dev_err();
+      ++np;
+    }
+    if (hipMemsetAsync((char*)s.d_text[i] + need, 0, padded - need + 16, st) != hipSuccess) return dev_err();
+    k_fq_count<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (uint32_t*)s.d_tile);
+    // (mate 2 reuses the tile buffers of mate 1: the stream runs mate 1's index before mate 2's count)
+    sqk::exclusive_scan_u32_u64((const uint32_t*)s.d_tile, (uint64_t*)s.d_tbase, ntile, (uint64_t*)s.d_spine, st);
+    k_fq_index<<<ntile, FQ_TB, 0, st>>>((const uint4*)s.d_text[i], nvec, (const uint64_t*)s.d_tbase, (uint32_t*)s.d_nlpos[i], (uint64_t)4 * want);
+    if (hipMemcpyAsync(h, (const uint32_t*)s.d_tile + (ntile - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(h + 2, (const uint64_t*)s.d_tbase + (ntile - 1), 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h + 1, (const uint32_t*)s.d_nlpos[i] + ((size_t)4 * want - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess) return dev_err();
+    *np_out = np; return 0;
+  }
+  // after the synchronisation: were there 4 * want lines, and every member sound?  Then the batch's text ends behind line 4 * want and the stream moves on
+  bool dv_commit(int i, int si, uint32_t want, unsigned np) {
+    Stream& S = sm[i]; DvStream& D = dv[i]; Slot& s = slots[(size_t)si]; const unsigned* h = s.h_res + 4 + 24 * i; const uint32_t stride = paired ? 2u : 1u;
+    for (unsigned k = 0; k < np; ++k) if (h[4 + 2 * k] != 0xFFFFFFFFu) return false;      // (dv_split names the member)
+    uint64_t tb; memcpy(&tb, h + 2, 8); if (tb + h[0] < 4ull * want) return false;
+    const size_t used = (size_t)h[1] + 1;
+    k_fq_records<<<(want + 255) / 256, 256, 0, s.st>>>((const uint8_t*)s.d_text[i], (const uint32_t*)s.d_nlpos[i], want, (uint32_t)i, stride, (uint32_t*)s.d_len, (uint32_t*)s.d_start[i], s.d_err);
+    S.est = 0.7 * S.est + 0.3 * ((double)used / (double)want); s.bytes[i] = used; text_bytes += used;
+    { std::lock_guard<std::mutex> lk(mu); D.pos += used; while (!D.q.empty() && !D.q.front().last && D.q.front().voff + D.q.front().n <= D.pos) D.q.pop_front(); }
+    cv.notify_all(); return true;
+  }
   void produce_split() {
     (void)hipSetDevice(device);
     const int ns = paired ? 2 : 1; const uint32_t stride = (uint32_t)ns;
@@ -628,11 +679,24 @@ struct sq_dev_reader {
       if (ok && !s.h_res && hipHostMalloc((void**)&s.h_res, 256, hipHostMallocDefault) != hipSuccess) { ok = false; rc = SQ_ERR_NOMEM; e = "page-locked allocation failed (reader)"; }
       if (ok && (hipMemsetAsync(s.d_err, 0xFF, 4, st) != hipSuccess || hipMemsetAsync(s.d_err + 1, 0, 12, st) != hipSuccess)) { ok = false; e = "device failure in the reader"; }
       s.n = 0;
-      if (ok) ok = dv_split(0, si, batch, &n0, &e, &rc);
-      if (ok) s.n = n0;
-      if (ok && paired && n0) { ok = dv_split(1, si, n0, &n1, &e, &rc);
+      bool fast = false;
+      if (ok) {      // the usual case first: a full batch from every mate, one wait
+        unsigned np[2] = {0, 0}; int r0 = dv_issue(0, si, batch, &np[0], &e), r1 = (r0 == 0 && paired) ? dv_issue(1, si, batch, &np[1], &e) : 0;
+        if (r0 < 0 || r1 < 0) ok = false;
+        else if (r0 == 0 || r1 == 0) {      // something was issued: it has to be through before the buffers are used again, whichever way the batch goes
+          if (hipStreamSynchronize(st) != hipSuccess) { ok = false; e = std::string("device failure in the reader: ") + hipGetErrorString(hipGetLastError()); }
+          else if (r0 == 0 && r1 == 0) {
+            // both mates are looked at before either stream moves: a batch goes the fast way whole or not at all
+            auto full = [&](int i) { const unsigned* h = s.h_res + 4 + 24 * i; for (unsigned k = 0; k < np[i]; ++k) if (h[4 + 2 * k] != 0xFFFFFFFFu) return false; uint64_t tb; memcpy(&tb, h + 2, 8); return tb + h[0] >= 4ull * batch; };
+            if (full(0) && (!paired || full(1))) { fast = dv_commit(0, si, batch, np[0]) && (!paired || dv_commit(1, si, batch, np[1])); if (fast) { n0 = n1 = batch; s.n = batch; } else { ok = false; rc = SQ_ERR_STATE; e = "internal: the reader's fast path changed its mind"; } }
+          }
+        }
+      }
+      if (ok && !fast) ok = dv_split(0, si, batch, &n0, &e, &rc);
+      if (ok && !fast) s.n = n0;
+      if (ok && !fast && paired && n0) { ok = dv_split(1, si, n0, &n1, &e, &rc);
         if (ok && n1 != n0) { ok = false; rc = SQ_ERR_IO; e = "mate files have different numbers of records (stopped after " + std::to_string(total + n1) + " pairs)"; } }
-      if (ok && paired && !n0) { ok = dv_split(1, si, 1, &n1, &e, &rc);   // the first file is at its end: is there a record left in the second?
+      if (ok && !fast && paired && !n0) { ok = dv_split(1, si, 1, &n1, &e, &rc);   // the first file is at its end: is there a record left in the second?
         if (ok && n1) { ok = false; rc = SQ_ERR_IO; e = "mate files have different numbers of records (stopped after " + std::to_string(total) + " pairs)"; } }
       if (ok && n0) {
         const uint32_t nrec = n0 * stride;
