@@ -38,7 +38,7 @@ struct HuffS { uint16_t count[16]; uint16_t symbol[32]; };                 // th
 // symbol is ONE look-up (entry 0: the code is longer — walked through the canonical counts):
 //   lit[bits]:  bits 0-3 = bits to drop; K_LIT: a literal in bits 8-15, with K_PAIR a second one in bits 16-23 (two codes that fit the peek together);
 //               else a length symbol: bits 8-16 = base length (0: end of block, > 258: no such symbol), bits 17-19 = number of extra bits
-//   dist[bits]: bits 0-3 = bits to drop, bits 4-7 = number of extra bits, bits 8-23 = base distance (0: no such symbol)
+//   dist[bits]: bits 0-3 = bits to drop, bits 4-7 = number of extra bits, bits 8-24 = base distance (65 537: no such symbol — farther back than any member is long)
 // (the code-length code of a dynamic block borrows dist[]: bits 0-3, symbol in bits 8-15)
 constexpr uint32_t K_LIT = 16, K_PAIR = 32;
 struct Tables { uint32_t lit[1 << LIT_BITS]; uint32_t dist[1 << DIST_BITS]; Huff hlit; HuffS hdist, hclen; uint8_t lengths[320]; uint16_t offs[16]; uint32_t win[64]; };   // win: the input window (Bits)
@@ -85,7 +85,8 @@ struct Bits {
   // count as `virt`: a decoder that has eaten into them sees bad() — looked at where a wrong symbol could do harm, not per symbol
   SQ_INL void refill() {
     if (cnt > 32) return;
-    if (pos < n) { const uint32_t nb = n - pos < 4u ? n - pos : 4u; uint32_t w = word(); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, (int)cnt); cnt += 8 * nb; pos += nb; }
+    if (pos + 4u <= n) { add(word(), (int)cnt); cnt += 32; pos += 4; }                        // (all but the stream's last word)
+    else if (pos < n) { const uint32_t nb = n - pos; const uint32_t w = word() & ((1u << (8 * nb)) - 1); add(w, (int)cnt); cnt += 8 * nb; pos += nb; }
     else { cnt += 32; virt += 32; }
   }
   SQ_INL uint32_t peek(int k) const { return lo & ((1u << k) - 1); }                     // (a vector value on the device)
@@ -132,7 +133,7 @@ struct LitEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const {
   return len | (0x1FFu << 8); } };                                     // 286, 287 and NO_SYMBOL: in no valid stream
 struct DistEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const {
   if (sym < 30) { const uint32_t dx = dist_base_extra(sym); return len | ((dx >> 16) << 4) | ((dx & 0xFFFF) << 8); }
-  return len; } };                                                     // base distance 0: no such symbol
+  return len | (0x10001u << 8); } };                                   // no such symbol: a distance no member is long enough for
 struct ClenEntry { SQ_INL uint32_t operator()(uint32_t sym, uint32_t len) const { return len | (sym << 8); } };
 // the peek table of a code: every `bits`-bit pattern that starts with a code of at most `bits` bits (codes are sent most significant bit first, the
 // input is read least significant bit first: the pattern is the reversed code, and every setting of the bits behind it)
@@ -332,7 +333,8 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
           b.refill();
           const uint32_t d = decode(b, T.hdist, T.dist, DIST_BITS, DistEntry());
           const uint32_t dist = (d >> 8) + b.take((int)((d >> 4) & 15u));
-          if (b.bad() || (d >> 8) == 0 || dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) == 0 ? INF_BAD_SYMBOL : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
+          // (whether the input had ended is looked at before the tokens are applied: a length or distance decoded from the zeros behind it is held to the same two tests)
+          if (dist > o.size() || o.size() + len > isize) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) > 0x10000u ? INF_BAD_SYMBOL : o.size() + len > isize ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
           o.match(dist, len);
         }
         if (o.ntok == 64) { if (b.bad() || o.size() > isize) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } o.apply(); }
