@@ -21,7 +21,9 @@
 // rows a10-a13) and EMUtils.cpp (the EM update: rows a15-a16); [r5] CollapsedEMOptimizer.cpp itself — the serial VBEMUpdate_ and the whole of
 // CollapsedEMOptimizer::optimize, the default optimiser, with TBB / Boost / spdlog / ReadExperiment stood in for (oracle/_stub/vbem; tests/test_vbem_pin.py: same
 // iteration counts, alphas to 1e-9; the pin found that the reference's plain-EM first iteration adds into alphasPrime left at 1.0 — now followed) and
-// TranscriptCluster.hpp + ClusterForest.hpp (projectToPolytope and the cluster forest of normalizeAlphas, row a14: tests/test_polytope_pin.py).  What cannot be
+// TranscriptCluster.hpp + ClusterForest.hpp (projectToPolytope and the cluster forest of normalizeAlphas, row a14: tests/test_polytope_pin.py), AlignmentModel.cpp
+// (the CIGAR error model of alignment-based input: tests/test_alnmodel_pin.py) and SalmonMappingUtils.hpp's updateRefMappings / filterAndCollectAlignments with stand-in
+// pufferfish types (rows a7 / a8: tests/test_selection_pin.py).  What cannot be
 // compiled here (SalmonQuantify.cpp, SalmonUtils.cpp: Boost, TBB, pufferfish) is followed line by line and cited.
 //
 // Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.
@@ -578,6 +580,52 @@ static bool joint_compat(LibFmt exp, bool orphan, bool isLeft, bool lfw, bool rf
 }
 
 // ---- a7/a8 — updateRefMappings + filterAndCollectAlignments (SalmonMappingUtils.hpp:225-405) ------
+// The selection itself, as a function of what the candidates' alignment left behind: pinned to the reference's own header compiled with stand-in
+// pufferfish types (oracle/ref_mapping_utils_shim.cpp, tests/test_selection_pin.py).  scored[i] == 0: the candidate was skipped (incompatible under
+// ignoreIncompat) or its alignment failed — updateRefMappings never sees it (SalmonQuantify.cpp:1521-1533).  The candidates are taken in index order:
+// updateRefMappings compares a hit with the best decoy score seen SO FAR (:231-246), which is why the cut-off is replayed and not taken from the end.
+// NOTE (a quirk of the reference that is NOT followed, SPEC section a7): at the call site the slot index `idx` is not advanced when an incompatible
+// candidate is skipped (SalmonQuantify.cpp:1521-1523, 2148-2150), so the record emitted for a later candidate takes its positions from jointHits[idx],
+// an EARLIER candidate.  Which candidate that is depends on pufferfish's order of jointHits, which is not in this tree; here a record is built from
+// its own candidate.  It never happens for an unstranded library (every candidate pufferfish returns is compatible with IU).
+struct Selection { std::vector<size_t> kept; std::vector<double> prob; int32_t bestScore = INVALID_SCORE, bestDecoy = INVALID_SCORE; bool onlyDecoy = false; };
+static void select_hits(const uint32_t* tid, const int32_t* score, const uint8_t* compat, const uint8_t* scored, size_t n, uint32_t first_decoy, double decoy_threshold,
+                        bool hard_filter, double score_exp, double min_aln_prob, Selection& S) {
+  S.kept.clear(); S.prob.clear(); S.bestScore = INVALID_SCORE; S.bestDecoy = INVALID_SCORE; S.onlyDecoy = false;
+  for (size_t i = 0; i < n; ++i) if (scored[i] && tid[i] >= first_decoy) S.bestDecoy = std::max(S.bestDecoy, score[i]);
+  auto decoy_cut = [&](int32_t bd) -> int32_t { return (int32_t)(decoy_threshold * (double)bd); };
+  std::vector<uint8_t> keep(n, 0);
+  {
+    int32_t runDecoy = INVALID_SCORE;
+    std::unordered_map<uint32_t, size_t> bestPer;
+    for (size_t i = 0; i < n; ++i) {
+      if (!scored[i]) continue;
+      if (tid[i] >= first_decoy) { runDecoy = std::max(runDecoy, score[i]); continue; }
+      if (score[i] < decoy_cut(runDecoy)) continue;
+      auto it = bestPer.find(tid[i]);
+      if (it == bestPer.end()) { bestPer[tid[i]] = i; keep[i] = 1; }
+      else if (score[i] > score[it->second] || (score[i] == score[it->second] && compat[i])) {
+        keep[it->second] = 0;
+        it->second = i;
+        keep[i] = 1;
+      }
+      if (score[i] > S.bestScore) S.bestScore = score[i];
+    }
+  }
+  S.onlyDecoy = (S.bestScore < decoy_cut(S.bestDecoy)) && (S.bestDecoy > INVALID_SCORE);  // MappingScoreInfo::haveOnlyDecoyMappings :115-122
+  if (S.bestScore > INVALID_SCORE && !S.onlyDecoy) {
+    int32_t bd = (S.bestDecoy == INVALID_SCORE) ? INVALID_SCORE + 1 : S.bestDecoy;  // :292-294
+    int32_t thr = hard_filter ? S.bestScore : decoy_cut(bd);
+    std::vector<size_t> kept; for (size_t i = 0; i < n; ++i) if (keep[i] && score[i] >= thr) kept.push_back(i);
+    std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t b) { return tid[a] < tid[b]; });
+    for (size_t i : kept) {
+      double v = (double)S.bestScore - (double)score[i];
+      double p = hard_filter ? -1.0 : sq_exp(-score_exp * v);
+      if (!hard_filter && p < min_aln_prob) continue;
+      S.kept.push_back(i); S.prob.push_back(p);
+    }
+  }
+}
 struct FragResult { std::vector<sq_aln> alns; uint8_t map_type = SQ_MT_UNMAPPED; };
 
 struct Taps { std::vector<sq_unimem> unimems; std::vector<sq_mem> mems; std::vector<sq_chain> chains; std::vector<sq_cand> cands; bool on = false; };
@@ -680,39 +728,14 @@ static void map_fragment(const Index& ix, const Opts& op, uint32_t frag, const u
   if (taps &&
       taps->on) for (auto& c : cands) { sq_cand x{}; x.frag = frag; x.tid = c.tid; x.lpos = c.lc >= 0 ? ch[0][c.lc].pos : 0; x.rpos = c.rc >= 0 ? ch[1][c.rc].pos : 0;
       x.lfw = c.lc >= 0 ? ch[0][c.lc].fw : 0; x.rfw = c.rc >= 0 ? ch[1][c.rc].fw : 0; x.mate_status = c.mate_status; x.valid = c.valid; x.lscore = c.lscore; x.rscore = c.rscore; x.frag_len = c.frag_len; taps->cands.push_back(x); }
-  // updateRefMappings, order-independent form (SPEC §a7): decoys only set bestDecoy; non-decoys
-  // keep one best hit per transcript (ties: the later compatible hit wins).
-  for (size_t i = 0; i < cands.size(); ++i) if (scored[i] && cands[i].tid >= ix.first_decoy) bestDecoy = std::max(bestDecoy, score[i]);
-  auto decoy_cut = [&](int32_t bd) -> int32_t { return (int32_t)(op.o.decoy_threshold * (double)bd); };
-  std::vector<uint8_t> keep(cands.size(), 0);
-  {
-    int32_t runDecoy = INVALID_SCORE;
-    std::unordered_map<uint32_t, size_t> bestPer;
-    for (size_t i = 0; i < cands.size(); ++i) {
-      if (!scored[i]) continue;
-      if (cands[i].tid >= ix.first_decoy) { runDecoy = std::max(runDecoy, score[i]); continue; }
-      if (score[i] < decoy_cut(runDecoy)) continue;
-      auto it = bestPer.find(cands[i].tid);
-      if (it == bestPer.end()) { bestPer[cands[i].tid] = i; keep[i] = 1; }
-      else if (score[i] > score[it->second] || (score[i] == score[it->second] && compat[i])) {
-        keep[it->second] = 0;
-        it->second = i;
-        keep[i] = 1;
-      }
-      if (score[i] > bestScore) bestScore = score[i];
-    }
-  }
-  bool onlyDecoy = (bestScore < decoy_cut(bestDecoy)) && (bestDecoy > INVALID_SCORE);  // MappingScoreInfo::haveOnlyDecoyMappings :115-122
+  // updateRefMappings + filterAndCollectAlignments (select_hits above)
+  Selection sel;
+  { std::vector<uint32_t> tids(cands.size()); for (size_t i = 0; i < cands.size(); ++i) tids[i] = cands[i].tid;
+    select_hits(tids.data(), score.data(), compat.data(), scored.data(), cands.size(), ix.first_decoy, op.o.decoy_threshold, op.o.hard_filter != 0, op.o.score_exp, op.o.min_aln_prob, sel); }
+  bestScore = sel.bestScore; bestDecoy = sel.bestDecoy; const bool onlyDecoy = sel.onlyDecoy;
   if (bestScore > INVALID_SCORE && !onlyDecoy) {
-    int32_t bd = (bestDecoy == INVALID_SCORE) ? INVALID_SCORE + 1 : bestDecoy;  // :292-294
-    int32_t thr = op.o.hard_filter ? bestScore : decoy_cut(bd);
-    std::vector<size_t> kept; for (size_t i = 0; i < cands.size(); ++i) if (keep[i] && score[i] >= thr) kept.push_back(i);
-    std::stable_sort(kept.begin(), kept.end(), [&](size_t a, size_t b) { return cands[a].tid < cands[b].tid; });
-    for (size_t i : kept) {
-      const Cand& c = cands[i];
-      double v = (double)bestScore - (double)score[i];
-      double p = op.o.hard_filter ? -1.0 : sq_exp(-op.o.score_exp * v);
-      if (!op.o.hard_filter && p < op.o.min_aln_prob) continue;
+    for (size_t k = 0; k < sel.kept.size(); ++k) {
+      const size_t i = sel.kept[k]; const Cand& c = cands[i]; const double p = sel.prob[k];
       sq_aln a{}; a.tid = c.tid; a.est_aln_prob = p; a.mate_status = paired ? c.mate_status : SQ_MS_SINGLE_END; a.frag_len = c.frag_len;
       if (c.mate_status == SQ_MS_PAIRED_END_PAIRED) {
         const Chain& l = ch[0][c.lc]; const Chain& r = ch[1][c.rc];
@@ -2435,3 +2458,16 @@ double orc_em_time_iters(const sq_eq_table* eq, const sq_txp_in* txp, const sq_e
   }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+
+// the selection of a fragment's alignments from its candidates' scores (select_hits): what tests/test_selection_pin.py holds to the reference's
+// updateRefMappings / haveOnlyDecoyMappings / filterAndCollectAlignments compiled from include/salmon/internal/quant/SalmonMappingUtils.hpp.
+// info: [0] bestScore, [1] bestDecoyScore, [2] 1 when the fragment has only decoy mappings.  Returns the number of alignments kept (their candidate indices, in
+// emission order, and estAlnProb).
+extern "C" uint32_t orc_select_hits(uint32_t n, const uint32_t* tid, const int32_t* score, const uint8_t* compat, const uint8_t* scored, uint32_t first_decoy, double decoy_threshold,
+                                    int hard_filter, double score_exp, double min_aln_prob, uint32_t* kept_out, double* prob_out, int32_t* info) {
+  Selection S; select_hits(tid, score, compat, scored, n, first_decoy, decoy_threshold, hard_filter != 0, score_exp, min_aln_prob, S);
+  for (size_t k = 0; k < S.kept.size(); ++k) { kept_out[k] = (uint32_t)S.kept[k]; prob_out[k] = S.prob[k]; }
+  info[0] = S.bestScore; info[1] = S.bestDecoy; info[2] = S.onlyDecoy ? 1 : 0;
+  return (uint32_t)S.kept.size();
+}
+
