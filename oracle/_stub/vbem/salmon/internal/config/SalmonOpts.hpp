@@ -5,9 +5,12 @@
 #include <cstdint>
 #include <memory>
 #include "spdlog/fmt/fmt.h"
+#include <boost/filesystem.hpp>
 struct SalmonOpts {
   uint32_t numThreads = 1; bool biasCorrect = false, gcBiasCorrect = false, posBiasCorrect = false, meta = false, alternativeInitMode = false, noRichEqClasses = false;
   bool useVBOpt = true, perTranscriptPrior = false, noEffectiveLengthCorrection = false, noLengthCorrection = false, initUniform = false, eqClassMode = false;
   bool useQuasi = false, allowOrphans = true, bootstrapReproject = false; double vbPrior = 1e-2; uint32_t numBootstraps = 0; uint32_t numRequiredFragments = 50000000;
+  // (CollapsedGibbsSampler.cpp, the Gibbs pin)
+  uint32_t thinningFactor = 16; bool quiet = true, noGammaDraw = false, dontExtrapolateCounts = false; boost::filesystem::path outputDirectory;
   std::shared_ptr<spdlog::logger> jointLog = std::make_shared<spdlog::logger>();
 };
