@@ -23,7 +23,7 @@
 // iteration counts, alphas to 1e-9; the pin found that the reference's plain-EM first iteration adds into alphasPrime left at 1.0 — now followed) and
 // TranscriptCluster.hpp + ClusterForest.hpp (projectToPolytope and the cluster forest of normalizeAlphas, row a14: tests/test_polytope_pin.py), AlignmentModel.cpp
 // (the CIGAR error model of alignment-based input: tests/test_alnmodel_pin.py) and SalmonMappingUtils.hpp's updateRefMappings / filterAndCollectAlignments with stand-in
-// pufferfish types (rows a7 / a8: tests/test_selection_pin.py); CollapsedGibbsSampler.cpp (row a17, compared in distribution: tests/test_gibbs_pin.py).  What cannot be
+// pufferfish types (rows a7 / a8: tests/test_selection_pin.py); gatherBootstraps / doBootstrap and CollapsedGibbsSampler.cpp (rows a16 / a17, compared in distribution: tests/test_bootstrap_pin.py, tests/test_gibbs_pin.py).  What cannot be
 // compiled here (SalmonQuantify.cpp, SalmonUtils.cpp: Boost, TBB, pufferfish) is followed line by line and cited.
 //
 // Deliberate, documented deviations from the (nondeterministic) reference: see oracle/SPEC.md §D.

@@ -34,7 +34,7 @@ def _ref_gibbs(eq, eff, init, S, seed, N, use_vbem, per_txp, vb_prior, thinning,
     return out
 
 
-@pytest.mark.parametrize("name,use_vbem,per_txp,vb_prior,no_gamma", [("VB, per-nucleotide prior (the default)", 1, 0, 1e-2, 0), ("VB, per-transcript prior", 1, 1, 1e-2, 0),
+@pytest.mark.parametrize("name,use_vbem,per_txp,vb_prior,no_gamma", [("VB, per-nucleotide prior", 1, 0, 1e-2, 0), ("VB, per-transcript prior (the default)", 1, 1, 1e-2, 0),
                                                                      ("VB, a larger per-transcript prior", 1, 1, 3.0, 0), ("EM", 0, 0, 1e-2, 0), ("no Gamma draw", 1, 0, 1e-2, 1)])
 def test_gibbs_samples_follow_the_reference_samplers_distribution(built, name, use_vbem, per_txp, vb_prior, no_gamma):
     M, E, S, thin = 60, 260, 200, 8
