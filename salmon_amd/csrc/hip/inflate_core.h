@@ -31,7 +31,7 @@ namespace sqinf {
 #define SQ_INL SQ_HD
 #endif
 
-constexpr int LIT_BITS = 10, DIST_BITS = 9;
+constexpr int LIT_BITS = 10, DIST_BITS = 8;
 struct Huff { uint16_t count[16]; uint16_t symbol[288]; };                 // codes of each length; symbols in code order
 struct HuffS { uint16_t count[16]; uint16_t symbol[32]; };                 // the same for the 30 distance codes and the 19 code-length codes
 // per wave (LDS on the device).  The peek tables answer a code of at most LIT_BITS / DIST_BITS bits with everything the decoder wants to know, so that a
