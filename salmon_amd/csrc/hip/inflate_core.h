@@ -2,16 +2,20 @@
 //
 // Why: the GPU boxes give a process 16 cores' worth of CPU time, and 16 cores inflate ~10 GB/s of FASTQ text — a quarter of what the PCIe link
 // moves for plain files (profiles/r05_reader_compressed.txt).  A BGZF file is ~130 000 independent members per 20 M reads, and the compressed bytes
-// are a third of the text: inflated on the device, such a file crosses PCIe faster than a plain one.
+// are a fifth to a half of the text: inflated on the device, such a file crosses PCIe faster than a plain one.
 //
-// How it runs on the device (hip/inflate_dev.hip): a WAVE per member.  The decoder's state (bit buffer, positions, the symbol just decoded) is the same in
-// every lane — the kernel makes the wave's index uniform, so the compiler keeps that state in scalar registers and reads the compressed bytes with scalar
-// loads; the wave is a scalar processor that walks the Huffman codes (RFC 1951: a table of LIT_BITS / DIST_BITS peeked bits answers all but the longest
-// codes, those are walked bit by bit through the canonical counts as in zlib's contrib/puff).  The LANES are used where bytes move: literals gather in one
-// register, a lane each, and leave as one store of up to 64 bytes; a match is copied by up to 64 lanes at once (lane i takes byte i mod distance of the
-// window, which also lays out the period of an overlapping match); the CRC-32 is taken over 64 stretches at once and folded (x^(8n) mod P).  Memory
-// operations of one wave complete in order, so a lane may read what another lane of its wave stored by an earlier instruction.
-// Parallelism across members does the rest: a batch of 10^6 read pairs is ~13 000 members = 13 000 waves.
+// How it runs on the device (hip/inflate_dev.hip): a WAVE per member.  A deflate stream is a serial chain — a code's length says where the next one starts —
+// so the wave is a scalar processor: positions, counters and what steers the control flow live in scalar registers, the 64-bit bit buffer in two vector
+// registers whose lanes all hold the same value (the scalar port, one instruction per CU and cycle for all its waves, is what bounds the kernel: shifts,
+// masks and table addresses go to the vector ALUs), the input comes through a 256-byte LDS window that the lanes fetch a block ahead with one coalesced load.
+// One look-up per symbol: 32-bit peek tables of LIT_BITS / DIST_BITS bits whose entries carry the bits to drop, the literal (two, where two codes fit the peek)
+// or the base length / distance with its number of extra bits; longer codes are walked bit by bit through the canonical counts as in zlib's contrib/puff
+// (RFC 1951).  The LANES are used where bytes move: symbols wait as tokens, a lane each; 64 of them are laid out by a prefix sum over their lengths and stored
+// by all lanes at once (a literal its bytes, a short match from text already in memory its copy); matches that reach into the batch's own text, repeat
+// themselves or are long are copied one after the other by the whole wave (lane i takes byte i mod distance of the window, which also lays out the period of
+// an overlapping match); the CRC-32 is taken over 64 stretches at once and folded (x^(8n) mod P).  Memory operations of one wave complete in order, so a lane
+// may read what another lane of its wave stored by an earlier instruction.  Parallelism across members does the rest: a batch of 10^6 read pairs is ~13 000
+// members = 13 000 waves.  What each of these steps bought, and the counters behind "the scalar port": profiles/r05_inflate_kernel.txt.
 //
 // The same source compiles for the host (SQ_HD; the lane parts have plain loops there), which is how tests/test_inflate.py checks tables, bit reader and
 // the CRC folding against zlib on machines without a GPU; the host build is a test hook (sq_debug_inflate_core_host), not a path of the product.
