@@ -69,6 +69,7 @@ def parse():
         help="N>1: exchange the class tables with torch.distributed collectives (salmon_amd/dist.py) instead of the library's own RCCL path (sq_dist_*, the default)")
     ap.add_argument("--inflight", type=int, default=0,
         help="mini-batches per model snapshot (sq_quant_opts.mini_batches_in_flight = the reference's -p / numThreads); 0 = the library default (8)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the command `--gpus N` would start its ranks with, and exit (no device needed)")
     ap.add_argument("--lanes", type=int, default=1, help="batches in flight on the mapping lanes (sq_map_submit/sq_map_wait); 1 = plain sq_map_batch")
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
@@ -86,15 +87,15 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
     pk = 8 * ((L + 31) // 32) + 4 * ((L + 63) // 64) * 2     # packed read + N mask actually touched
     return {
         "k_pack": nrec * (L + 8 + 64 + 32 + 2),
-        # every probe reads one word (a 64 B sector) of the k-mer membership filter; a probe that passes (every hit; < 1 % of the misses)
-        # then walks 4 dependent sectors (pilot, slot record, string-pool word, unitig bounds) and a uni-MEM adds extension words,
-        # contig-table bounds and its record
-        "k_seed": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32 + 16),
-        # [r5] the same job with k_seed2's own structures: 32 of a read end's 64 packed bytes (reads of up to 128 bases), the filter block once per
-        # run of probes that share a minimizer (`filter_fills`, counted by the kernel) instead of once per probe, and a hit walks three
-        # dependent sectors (minimizer-table bucket, string-pool word, unitig bounds) instead of four.  Reported beside the fixed model above
-        # (`own_bytes`), never instead of it: a kernel that needs fewer bytes for the same walk is faster, not less efficient
-        "k_seed_own": nrec * (32 + 32 + 2 + 8) + st.get("filter_fills", st["num_lookups"]) * 64 + st["num_seeds"] * (3 * 64 + 16 + 16 + 32 + 16),
+        # [r6] k_seed2's own algorithmic bytes — what `roofline.frac` is quoted on: the packed words of a read end the kernel loads (32 B for reads of
+        # up to 128 bases, 64 B up to 256) + N mask + offsets, the 64-byte filter block once per run of probes that share a minimizer
+        # (`filter_fills`, counted by the kernel), and per uni-MEM three dependent sectors (minimizer-table bucket, string-pool word, unitig bounds)
+        # + extension words, contig-table bounds and its 32-byte record
+        "k_seed": nrec * ((32 if L <= 128 else 64) + 32 + 2 + 8) + st.get("filter_fills", st["num_lookups"]) * 64 + st["num_seeds"] * (3 * 64 + 16 + 16 + 32 + 16),
+        # round 4's model of the same job for the kernel k_seed2 replaced (one filter sector per PROBE, four dependent sectors per hit: pilot, slot
+        # record, string-pool word, unitig bounds).  k_seed2 does not move these bytes; kept as a separately named field (`roofline.round4_model`)
+        # so that rounds 3-5 can still be compared, never as `frac`
+        "k_seed_r4model": nrec * (64 + 32 + 2 + 8) + st["num_lookups"] * 64 + st["num_seeds"] * (4 * 64 + 16 + 16 + 32 + 16),
         "scan_mems": nrec * (4 + 8),
         # fused projection + per-end sort + chaining (mem_kernels.h): uni-MEM records and contig-table runs in, sorted MEM records and chains out
         "k_mems": st["num_seeds"] * 32 + st["num_mems"] * (8 + 8 + 16) + st["num_chains"] * 40 + nrec * (16 + 4),
@@ -436,12 +437,28 @@ def run_spread(a, world_obj, parked, off_d, B, RL, api, capi, local):
             "%d-pair batches), over the transcripts where either side reaches the floor; VBEM to convergence in every variant" % B, "variants": res}
 
 
+def launch_command(a, argv, env):
+    """The command that runs this script as `--gpus N` ranks: None when the ranks exist already (a launcher set WORLD_SIZE) or one rank is asked for."""
+    if "WORLD_SIZE" in env or a.gpus <= 1: return None
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + [x for x in argv if x != "--dry-launch"]
+
+
 def main():
     a = parse()
     # ONE line on stdout: the communicator libraries print a version banner to the C-level stdout when the first communicator is made (RCCL does,
     # with one rank too) — everything but the JSON line is sent to stderr, by descriptor, for the life of the process
+    cmd = launch_command(a, sys.argv[1:], os.environ)
+    if a.dry_launch:
+        print(json.dumps({"relaunch": cmd})); return
+    if cmd is not None:        # [r6] `python bench.py --gpus N` outside a launcher: N ranks are started here, one per GPU (the driver's own N > 1 command is this one)
+        sys.stdout.flush(); os.execv(cmd[0], cmd)
     sys.stdout.flush(); real_stdout = os.dup(1); os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would not describe the run" % (a.gpus, world))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -667,11 +684,11 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
                                 "kernel sources unchanged since: sha %s; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run" % kernel_source_sha()) if roof["traffic"] is not None else pm_note
         roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
         roof["chain_pair_note"] = pair_note
-        if dom == "k_seed2" and "k_seed_own" in sb:   # [r5] the kernel's own algorithmic bytes (fewer than the fixed model's: stage_bytes)
-            own = sb["k_seed_own"] / max(1, stage_rows["k_seed"]["launches"])
-            roof["own_bytes"] = {"alg_bytes_per_launch": int(own), "achieved": round(own / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "frac": round(own / (roof["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0, 5),
-                                 "traffic_over_own_bytes": round(roof["traffic"] / own, 3) if roof.get("traffic") else None,
-                                 "note": "k_seed2 reads 32 B of a read end's packed words, a filter block per run of probes sharing a minimizer (counted: filter_fills) and three dependent sectors per hit; `frac` above stays on the round-4 model (one filter sector per probe, four per hit) so that rounds compare"}
+        if dom == "k_seed2" and "k_seed_r4model" in sb:   # the round-4 byte model of the kernel k_seed2 replaced, for comparison across rounds only
+            r4 = sb["k_seed_r4model"] / max(1, stage_rows["k_seed"]["launches"])
+            roof["round4_model"] = {"alg_bytes_per_launch": int(r4), "achieved": round(r4 / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "frac": round(r4 / (roof["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0, 5),
+                                    "note": "one filter sector per probe and four dependent sectors per hit — the bytes rounds 3-5 quoted `frac` on; k_seed2 moves fewer (frac above is on its own bytes)"}
+            roof["traffic_over_alg_bytes"] = round(roof["traffic"] / roof["alg_bytes_per_launch"], 3) if roof.get("traffic") else None
         roof["all_kernels"] = {k: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
     if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
         g = gibbs["report"]; bg = 28 * Lb + 16 * E + 32 * M
@@ -766,6 +783,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     out = {
         "metric": baseline_metric(), "value": round(job_pairs / dt / 1e6, 4), "unit": "M read-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
+        "rccl_ranks": int(capi.lib().sq_dist_world(sqd.h)) if sqd is not None else None,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64/i32 (2-bit k-mers, integer scores) + f64 (log-space model, EM)", "data": "synthetic",
         "config": {"workload": "%s (k=31, m=20), %s, -l IU defaults, VBEM" % (cfg_name, ("%d synthetic 2x%dbp pairs in all; every rank maps the shared burn-in prefix (%d pairs), the rest is dealt out: %d pairs on this rank in %d calls" % (total_pairs, RL,

@@ -17,6 +17,22 @@ def test_bench_refuses_to_run_without_a_device(built):
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
 
 
+def test_gpus_n_starts_n_ranks_itself(built):
+    """[r6] `python bench.py --gpus N` outside a launcher re-executes itself through torch.distributed.run with N ranks on 127.0.0.1; under a launcher
+    (WORLD_SIZE set) it does not, and a rank count that differs from --gpus is refused."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-launch"], capture_output=True, text=True, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    cmd = json.loads(r.stdout)["relaunch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="8"))
+    assert json.loads(r.stdout)["relaunch"] is None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-launch"], capture_output=True, text=True, cwd=ROOT)
+    assert json.loads(r.stdout)["relaunch"] is None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="4", RANK="0"))
+    assert r.returncode != 0 and "--gpus 2 but the launcher started 4" in r.stderr
+
+
 @pytest.mark.gpu
 def test_live_bench_line_has_the_contract_fields_and_parity(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "60000", "--genes", "600",
@@ -52,11 +68,10 @@ def test_live_bench_line_has_the_contract_fields_and_parity(built):
 def test_strong_scaling_workload_splits_a_fixed_total_over_the_ranks(built):
     """--workload c3 (configs[2]): two ranks (gloo rendezvous, both on the one GPU) share a fixed total of pairs; the line says "strong"
     and the job's pair count does not grow with the rank count."""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--debug-one-device", "--steps", "3", "--warmup", "1", "--batch", "40000", "--genes", "400",
-                        "--cpu-sample", "0", "--fastq-pairs", "0"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    # [r6] no launcher here: `--gpus 2` starts the two ranks itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--debug-one-device", "--steps", "3", "--warmup", "1", "--batch", "40000", "--genes", "400",
+                        "--cpu-sample", "0", "--fastq-pairs", "0"], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
