@@ -211,6 +211,9 @@ struct sq_dev_reader {
       const uint32_t isize = BgzfSource::le32(base + S.scan_off + ms - 4);
       if (isize > (1u << 16)) { *e = "'" + F.path + "': BGZF member larger than 64 KB"; return false; }
       if (isize) { const uint8_t* hp = base + S.scan_off; const uint32_t hdr = 12u + ((uint32_t)hp[10] | ((uint32_t)hp[11] << 8));
+        // a member that has text has a deflate stream between its header and its 8-byte trailer: XLEN comes from the file and must leave room for one (the host
+        // inflater refuses the same member, BgzfSource::inflate_member; unchecked, the device's stream length `ms - hdr - 8` would wrap)
+        if ((size_t)hdr + 8 >= ms) { *e = "'" + F.path + "': truncated BGZF member"; return false; }
         S.mem.push_back(Stream::BzMember{(uint32_t)S.scan_file, (uint32_t)ms, S.scan_off, isize, S.scan_voff, BgzfSource::le32(hp + ms - 8), hdr}); S.scan_voff += isize; S.scan_file_bytes += isize; }
       S.scan_off += ms;
     }
@@ -516,7 +519,7 @@ struct sq_dev_reader {
         });
         sq_bgzf_member* desc = (sq_bgzf_member*)(ring + (size_t)pcs[ncp] * PIECE); uint64_t tv = 0;
         for (uint32_t k = 0; k < nmem; ++k) { const Stream::BzMember& M = S.mem[m0 + k];
-          desc[k] = M.file == ~0u ? sq_bgzf_member{0, tv, 0, M.isize, 0, 0} : sq_bgzf_member{coffs[k] + M.hdr, tv, M.csize - M.hdr - 8, M.isize, M.crc, 0};
+          desc[k] = M.file == ~0u ? sq_bgzf_member{0, tv, 0, M.isize, 0, SQ_BGZF_LINE_END} : sq_bgzf_member{coffs[k] + M.hdr, tv, M.csize - M.hdr - 8, M.isize, M.crc, 0};
           tv += M.isize; ch.where.push_back({M.file, M.coff}); }
         if (dev_grow(&D.text[idx], &D.text_cap[idx], tbytes + 64) || dev_grow(&D.comp[idx], &D.comp_cap[idx], cbytes + 64) || dev_grow(&D.mem[idx], &D.mem_cap[idx], (size_t)nmem * sizeof(sq_bgzf_member) + 64)) {
           dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return; }

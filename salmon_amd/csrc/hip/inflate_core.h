@@ -305,6 +305,7 @@ struct Out {
 
 // the whole stream: `isize` bytes of output are expected (a BGZF member's trailer says how many).  Returns INF_OK or what was wrong.
 SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t isize, Tables& T) {
+  if (n == 0) return INF_EOF_INPUT;   // (Bits::init counts positions from the aligned address below `in`: with no input at all the bytes in front of it would pass for the stream)
   Bits b; b.init(in, n, T.win); Out o; o.init(out, isize); int rc = INF_OK;
   for (;;) {
     const uint32_t last = b.get(1), type = b.take(2);

@@ -19,8 +19,8 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_bgzf_inflate(const uint8_t* 
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), m = blockIdx.x * INF_WAVES + wave;
   if (m >= nmem) return;
   const sq_bgzf_member M = mem[m];
-  if (M.csize == 0) { if ((threadIdx.x & 63) < M.isize) text[M.voff + (threadIdx.x & 63)] = '\n'; return; }   // the line end a file without a last one gets (the reader's pseudo-member)
-  int rc = sqinf::inflate_member(comp + M.coff, M.csize, text + M.voff, M.isize, s_tab[wave]);
+  if (M.flags & SQ_BGZF_LINE_END) { if ((threadIdx.x & 63) < M.isize) text[M.voff + (threadIdx.x & 63)] = '\n'; return; }   // the line end a file without a last one gets (the reader's pseudo-member)
+  int rc = M.csize ? sqinf::inflate_member(comp + M.coff, M.csize, text + M.voff, M.isize, s_tab[wave]) : (M.isize ? (int)sqinf::INF_EOF_INPUT : (int)sqinf::INF_OK);   // text without a stream: damaged
   if (rc == sqinf::INF_OK && sqinf::crc32_wave(s_crc, text + M.voff, M.isize) != M.crc) rc = 8;
   if (rc != sqinf::INF_OK && (threadIdx.x & 63) == 0) { const uint32_t old = atomicMin(&status[0], m + 1); if (m + 1 <= old) status[1] = (uint32_t)rc; }
 }

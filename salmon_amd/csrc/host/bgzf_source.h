@@ -64,7 +64,7 @@ struct BgzfSource {
   // one member into dst (its isize bytes); "" or what is wrong with it
   static const char* inflate_member(const uint8_t* p, const Mem& m, char* dst) {
     const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8); const size_t hdr = 12 + xlen;
-    if (m.csize < hdr + 8) return "truncated BGZF member";
+    if (m.csize < hdr + 8 || (m.isize && m.csize == hdr + 8)) return "truncated BGZF member";   // (text without a deflate stream in front of the trailer)
     const uint32_t crc = le32(p + m.csize - 8);
     if (!m.isize) return "";
     static const bool use_zlib = getenv("SQ_BGZF_ZLIB") && atoi(getenv("SQ_BGZF_ZLIB")) != 0;   // the library's inflate instead of the own one (pgzip.cpp), for comparison

@@ -512,10 +512,11 @@ extern "C" int sq_reader_open_ex(const char* const* files1, uint32_t n1, const c
   // [r4] device-side record splitting: regular 4-line FASTQ files, no read names wanted, a device present, SQ_READER_DEVICE != 0.  [r5] gzip / BGZF files
   // too (all of them compressed, or none): the device reader inflates them into its ring itself (hip/fastq_dev.hip); SQ_READER_DEVICE_GZ=0 keeps them here
   bool plain = fast && !kn && !(getenv("SQ_READER_DEVICE") && atoi(getenv("SQ_READER_DEVICE")) == 0);
-  if (plain && getenv("SQ_READER_DEVICE_GZ") && atoi(getenv("SQ_READER_DEVICE_GZ")) == 0)
-  for (int st = 0; st < 2 && plain; ++st) for (const auto& path : (st ? b : a)) {
-    unsigned char mg[2] = {0, 0}; FILE* f = fopen(path.c_str(), "rb"); if (!f) { plain = false; break; }
-    const size_t got = fread(mg, 1, 2, f); fclose(f); if (got == 2 && mg[0] == 0x1f && mg[1] == 0x8b) { plain = false; break; }
+  if (plain && getenv("SQ_READER_DEVICE_GZ") && atoi(getenv("SQ_READER_DEVICE_GZ")) == 0) {   // compressed files stay on the host path: look for the gzip magic
+    for (int st = 0; st < 2 && plain; ++st) for (const auto& path : (st ? b : a)) {
+      unsigned char mg[2] = {0, 0}; FILE* f = fopen(path.c_str(), "rb"); if (!f) { plain = false; break; }
+      const size_t got = fread(mg, 1, 2, f); fclose(f); if (got == 2 && mg[0] == 0x1f && mg[1] == 0x8b) { plain = false; break; }
+    }
   }
   if (plain) {
     const int rc = sq_dev_reader_open(a, b, batch_reads, (uint32_t)R->slots.size(), &R->dev);

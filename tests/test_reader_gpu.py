@@ -183,3 +183,10 @@ def test_bgzf_members_inflated_on_the_device(built, tmp_path):
     with pytest.raises(Exception, match="BGZF|member|record"): _drain([zb], None, 5000, True)
     zc = str(tmp_path / "cut.fq.gz"); open(zc, "wb").write(good[: len(good) * 2 // 3])
     with pytest.raises(Exception, match="truncated|BGZF|middle of a record"): _drain([zc], None, 5000, True)
+    # [r6] a member whose XLEN leaves no room for a deflate stream in front of the trailer (header + 8 >= its size) although its trailer claims text: refused by
+    # the scan on both paths — the stream length handed to the device would wrap otherwise — whether XLEN swallows exactly the stream or reaches far past the member
+    ms0 = (good[16] | (good[17] << 8)) + 1; ms1 = (good[ms0 + 16] | (good[ms0 + 17] << 8)) + 1
+    for xlen in (ms1 - 20, ms1 - 12, ms1 + 3000):
+        x = bytearray(good); x[ms0 + 10] = xlen & 0xFF; x[ms0 + 11] = xlen >> 8; zx = str(tmp_path / ("xlen%d.fq.gz" % xlen)); open(zx, "wb").write(bytes(x))
+        for device in (True, False):
+            with pytest.raises(Exception, match="truncated BGZF member"): _drain([zx], None, 5000, device)
