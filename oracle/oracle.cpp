@@ -821,6 +821,10 @@ struct FLD {  // FragmentLengthDistribution.cpp:23-186 (bin size 1, max 1000, ke
       }
     totMass = tree_total();
   }
+  void add_val(uint32_t len, double logFM) {  // addVal (:85-110) for ONE fragment (reference-order mode, SPEC D1r): the kernel's five bins around len, bin 0 kept empty
+    for (int i = 0; i < 5; ++i) { const int b = (int)len - 2 + i; if (b > 0 && b <= 1000) hist[b] = sq_log_add(hist[b], logFM + kernel[i]); }
+    totMass = tree_total();
+  }
   void cache() {  // cacheCMF (:174-186) + getLockedPMF (:159-172)
     cpmf.resize(1001); double tot = SQ_LOG_0;
     for (int i = 0; i <= 1000; ++i) { cpmf[i] = hist[i] - totMass; tot = sq_log_add(tot, cpmf[i]); }
@@ -940,6 +944,10 @@ struct QuantState {
   std::vector<uint64_t> libCounts;
   uint64_t gcObs[75] = {0};   // observedGCMass (SalmonQuantify.cpp:938-972): sums of the normalised alignment probabilities, fixed point 2^-32 (order-free)
   uint64_t readCounter = 0;
+  // SPEC D1r — reference-order mode (pin of row a10 only, tests/test_minibatch_pin.py): one mini-batch in flight AND every fragment's increments applied before the next
+  // fragment reads the model (masses by logAdd in alignment order, FLD one fragment at a time), exactly the order of SalmonQuantify.cpp:547-1003 on one thread; the
+  // uniform draws come from the caller (the reference's engine), one per kept alignment whether burned in or not (:974)
+  bool refOrder = false; const double* draws = nullptr; uint64_t drawPos = 0, drawCap = 0;
   std::vector<int32_t> condMeans;   // conditional fragment-length means of the PRIOR distribution (ReadExperiment.inl:25-43), used by single-end --gcBias
   uint64_t posObs[2][100] = {{0}};   // --posBias (SPEC §P): observed read-start masses [5' model, 3' model][length class x 20 bins], fixed point 2^-32
   std::vector<uint8_t> lenClass;     // Transcript::lengthClassIndex (ReadExperiment.inl:352-388)
@@ -1300,7 +1308,8 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
     ev.count++; for (size_t i = 0; i < n; ++i) ev.wq[i] += sq_to_fixed(aux[i], SQ_WFRAC_BITS);
     for (size_t i = 0; i < n; ++i) {
       double nlp = lp[i] - sumProbs; double pr = sq_exp(nlp);
-      S.massAcc[tids[i]] += sq_to_fixed(pr, SQ_MFRAC_BITS);
+      if (S.refOrder) S.mass[tids[i]] = sq_log_add(S.mass[tids[i]], logFM + nlp);      // transcript.addMass(logForgettingMass + aln.logProb) (:871-872), at once
+      else S.massAcc[tids[i]] += sq_to_fixed(pr, SQ_MFRAC_BITS);
       S.total[tids[i]] += 1;
       if (o.gc_bias && (ka[i]->format_id & 1u) == 1u) {   // :938-951, paired-end observation
         const sq_aln& a = *ka[i];
@@ -1322,8 +1331,9 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
           }
         } else S.posObs[a.fwd ? 0 : 1][li * 20 + pos_bin(pos_clamp(a.pos, RL), RL)] += sq_to_fixed(pr, 32);
       }
+      double rr_ref = 0.0; if (S.refOrder) rr_ref = S.drawPos < S.drawCap ? S.draws[S.drawPos] : 2.0, ++S.drawPos;     // uni(randEng) is drawn for every kept alignment (:974)
       if (!burned) {
-        double rr = u01(o.seed, readIdx, i);
+        double rr = S.refOrder ? rr_ref : u01(o.seed, readIdx, i);
         if (rr < pr) {
           if (S.errOn && S.reads) {   // alnMod.update(*aln, ..., alignerScore, logForgettingMass) (:860-864): exp(p) joins every cell of the walk
             const uint64_t ai = (uint64_t)(ka[i] - alns); const uint64_t q = sq_to_fixed(sq_exp((double)S.reads->aligner_score[ai]), SQ_MFRAC_BITS); std::vector<uint32_t> cells;
@@ -1332,8 +1342,8 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
           uint32_t fl = frag_len_pedantic(*ka[i], ix.ref_len[tids[i]]);
           if (fl > 0) {
             if (fl > 1000) fl = 1000;
-            fldCnt[fl]++;
-            if (fl < minLen) minLen = fl;
+            if (S.refOrder) { S.fld.add_val(fl, logFM); if (fl < S.fld.minLen) S.fld.minLen = fl; }
+            else { fldCnt[fl]++; if (fl < minLen) minLen = fl; }
           }
         }
       }
@@ -1343,7 +1353,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
   }
   // mini-batch end: its increments join the group's queue; the group is applied (in mini-batch order) once W mini-batches are in
   // it, at the mini-batch that reaches numBurninFrags (:1012-1018), or at the end of the mapped batch (orc_eq_accumulate)
-  QuantState::PendingMB pm; pm.logFM = logFM; pm.anyFld = false; pm.minLen = minLen;
+  QuantState::PendingMB pm; pm.logFM = logFM; pm.anyFld = false; pm.minLen = S.refOrder ? S.fld.minLen : minLen;
   for (size_t t = 0; t < S.massAcc.size(); ++t) if (S.massAcc[t]) { pm.massInc.emplace_back((uint32_t)t, S.massAcc[t]); S.massAcc[t] = 0; }
   if (S.errOn && !burned) for (int sd = 0; sd < 2; ++sd) for (size_t c = 0; c < S.errAcc[sd].size(); ++c) if (S.errAcc[sd][c]) { pm.errInc[sd].emplace_back((uint32_t)c, S.errAcc[sd][c]); S.errAcc[sd][c] = 0; }
   if (!burned) {
@@ -1358,7 +1368,7 @@ static void process_mini_batch(QuantState& S, const uint64_t* off, const sq_aln*
     for (uint64_t ai = off[r0]; ai < off[r1]; ++ai) if ((alns[ai].format_id & 1u) == o.lib_type) { S.detCounts[alns[ai].format_id & 63u]++; S.detSamples++; }
     detectNow = S.detSamples >= 50000;
   }
-  const uint32_t W = std::max(1u, std::min(o.mini_batches_in_flight ? o.mini_batches_in_flight : 1u, 64u));
+  const uint32_t W = S.refOrder ? 1u : std::max(1u, std::min(o.mini_batches_in_flight ? o.mini_batches_in_flight : 1u, 64u));
   if (S.pending.size() >= W || burnNow || detectNow) S.flush_pending();
   if (burnNow) S.burnin_finalize();
   if (detectNow) S.detect_format();   // the following mini-batches expect the detected format
@@ -2119,6 +2129,9 @@ orc_state* orc_state_create(const orc_index* oi, const sq_quant_opts* o) {
   return s;
 }
 void orc_state_free(orc_state* s) { delete s; }
+// SPEC D1r: reference-order mode for the next orc_eq_accumulate calls; `draws` (n of them, caller-owned, must outlive the calls) are consumed one per kept alignment
+void orc_state_reference_order(orc_state* s, const double* draws, uint64_t n) { s->S.refOrder = true; s->S.draws = draws; s->S.drawCap = n; s->S.drawPos = 0; }
+uint64_t orc_state_draws_used(orc_state* s) { return s->S.drawPos; }
 // feed one mapped batch (CSR) through the online model in mini-batches, in input order
 void orc_eq_accumulate(orc_state* s, uint32_t n, const uint64_t* read_off, const sq_aln* alns, uint64_t num_with_joint_hits) {
   QuantState& S = s->S; uint32_t mb = S.op.o.mini_batch_size ? S.op.o.mini_batch_size : 5000;

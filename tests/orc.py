@@ -34,6 +34,7 @@ def lib():
         L.orc_state_free.argtypes = [vp]
         L.orc_eq_accumulate.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64]
         L.orc_state_finish.argtypes = [vp]
+        L.orc_state_reference_order.argtypes = [vp, vp, C.c_uint64]; L.orc_state_draws_used.restype = C.c_uint64; L.orc_state_draws_used.argtypes = [vp]
         L.orc_state_merge.argtypes = [vp, vp]
         L.orc_state_gc_observed.argtypes = [vp, vp]
         L.orc_bias_gc_eff_lengths.restype = C.c_int; L.orc_bias_gc_eff_lengths.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp]
@@ -132,6 +133,14 @@ class OrcState:
 
     def finish(self):
         lib().orc_state_finish(self.h)
+
+    def reference_order(self, draws):
+        """SPEC D1r (pin of row a10): every fragment's increments applied before the next one reads the model; uniform draws from the caller."""
+        self._draws = np.ascontiguousarray(draws, np.float64)
+        lib().orc_state_reference_order(self.h, self._draws.ctypes.data, len(self._draws))
+
+    def draws_used(self):
+        return int(lib().orc_state_draws_used(self.h))
 
     def seq_observed(self):
         fw = np.zeros(576, np.uint64); rc = np.zeros(576, np.uint64); n = C.c_uint64()
