@@ -27,6 +27,10 @@ import argparse, json, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# [r6] before anything initialises the HIP runtime: pageable copies go through the runtime's staging buffers instead of pinning the caller's pages — cached pins of memory that
+# is freed later make amdkfd evict the process's queues, and the next submission starts 6-30 ms late (libsalmon_hip.so sets the same default when it is loaded first:
+# salmon_amd/csrc/hip/map.hip, sq_runtime_defaults; profiles/r06_eviction_ab.txt).  An explicit setting of the caller wins
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 import numpy as np
 
 WORKLOADS = {
@@ -257,6 +261,23 @@ def _write_bgzf(src, dst, block=0xff00):
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex, open(dst, "wb") as f:
         for m in ex.map(member, range(0, len(data), block)): f.write(m)
         f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
+
+
+def cpu_stat():
+    """The cgroup's CPU accounting (usage_usec, nr_periods, nr_throttled, throttled_usec), {} where there is none: read before and after the timed region, it says how many
+    cores the host side used and whether the container's CPU quota stopped it meanwhile."""
+    try: return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines()) if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}
+    except Exception: return {}
+
+
+def kfd_evicted_ms():
+    """Milliseconds this process's device queues have spent EVICTED so far (amdkfd's per-process counter; None where it is not exposed).  The driver takes a process's
+    queues off the device while it rebuilds mappings — e.g. when host memory it had pinned for a copy is unmapped — and the next submission waits for their return."""
+    import glob
+    try:
+        fs = glob.glob("/sys/class/kfd/kfd/proc/*/stats_*/evicted_ms")    # (the directories carry host pids, not this container's: all of them are summed, a difference over the timed region is this job's unless the node is shared)
+        return sum(int(open(f).read()) for f in fs) if fs else None
+    except Exception: return None
 
 
 def cpu_allowance():
@@ -560,6 +581,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     # ---- timed region: exactly K steps + the job's inference tail ----
     if dist: dist.barrier()
     torch.cuda.synchronize()
+    cs0 = cpu_stat(); ev0 = kfd_evicted_ms()
     t0 = time.perf_counter()
     tot = None; t_prefix = 0.0; prefix_burned = None
     depth = max(1, a.lanes)          # batches in flight on the mapping lanes (sq_map_submit / sq_map_wait)
@@ -621,6 +643,9 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     if dist: dist.barrier()
     t1 = time.perf_counter()
     dt = t1 - t0
+    cs1 = cpu_stat(); ev1 = kfd_evicted_ms()
+    host_cpu = {"cores_used": round((cs1["usage_usec"] - cs0["usage_usec"]) / (dt * 1e6), 2), "quota_periods_throttled": cs1["nr_throttled"] - cs0["nr_throttled"],
+                "throttled_ms": round((cs1["throttled_usec"] - cs0["throttled_usec"]) / 1e3, 2)} if cs0 and cs1 else None
     if dist:
         tt_ = torch.tensor([dt], device=(torch.device("cpu") if a.debug_one_device else dev), dtype=torch.float64)
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
@@ -798,7 +823,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         "breakdown": {"map_eq_s": round(t_map, 4), "shared_prefix_s": round(t_prefix, 4) if strong else None, "shared_prefix_pairs": int(sum(n for _, n, sh in plan if sh)) if strong else None,
             "model_burned_in_at_prefix_end": prefix_burned, "tail_s(eq_export+merge+normalize+EM%s)" % ("+Gibbs" if gibbs else ""): round(dt - t_map, 4), "eq_finish_s": round(t_eqf, 4),
             "dist_merge_s": round(t_merge, 4), "normalize_alphas_s": round(t_norm, 4), "em_call_s": round(t_em, 4), "em_iters": rep["iters"], "em_converged": rep["converged"],
-            "em_device_ms": round(rep["device_ms"], 2), "synth_s": round(Wd.t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
+            "em_device_ms": round(rep["device_ms"], 2), "host_cpu_in_timed_region": host_cpu, "kfd_queues_evicted_ms_in_timed_region": (ev1 - ev0) if ev0 is not None and ev1 is not None else None, "synth_s": round(Wd.t_synth, 1), "read_gen_and_park_s": round(t_gen, 1),
                       "index_build_s": round(Wd.t_index, 1), "mapped_frac": round(tot["num_mapped"] / tot["num_reads"], 4),
                       "decoy_frac": round(tot["num_decoy_fragments"] / tot["num_reads"], 4),
                       "hits_per_frag": round(tot["num_alignments"] / max(1, tot["num_mapped"]), 3),

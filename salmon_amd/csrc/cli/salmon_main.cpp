@@ -678,6 +678,7 @@ static int cmd_quant(int argc, char** argv) {
 }
 
 int main(int argc, char** argv) {
+  setenv("GPU_PINNED_MIN_XFER_SIZE", "1048576", 0);   // before the HIP runtime initialises: no pageable host memory is pinned behind our back (hip/map.hip: sq_runtime_defaults says why)
   if (argc < 2) { fprintf(stderr, "salmon-hip (%s)\nusage: salmon-hip index|quant ...\n", sq_version()); return 1; }
   if (!strcmp(argv[1], "index")) return cmd_index(argc, argv);
   if (!strcmp(argv[1], "quant")) return cmd_quant(argc, argv);

@@ -78,8 +78,17 @@ struct EmDev {
   // [r4] three launches per iteration: k_fin also leaves psi[t] = digamma(alpha'_t + prior_t) (-inf where the VBEM rule zeroes theta), its last
   // block to finish closes the iteration and publishes logNorm; k_class / k_l1 form theta = exp(psi - logNorm) where they gather it
   int psi_mode; const double* psi; const double* log_norm; double* psi_out; double* log_norm_out;
-  unsigned long long* blk_rel; uint32_t* blk_bad;   // per block of k_fin: max relDiff (bit pattern) and "a transcript moved more than the tolerance"
+  // [r6] three launches per iteration (k_class3, k_l13, k_fin4): see EmIterState / FinRec below
+  struct EmIterState* state; struct FinRec* rec; uint32_t nrec;   // nrec = 4 * ceil(ceil(M / 64) / 64) records
+  const uint4* cplan; const uint4* lplan;                          // per block of k_class3 / k_l13: {first unit, end unit, first entry, end entry}
 };
+// [r6] The bookkeeping of an iteration lives in two alternating slots: the class pass of iteration `it` reads slot it & 1 (written by the class pass before it — an
+// earlier kernel) and its block 0 writes slot (it + 1) & 1, which k_l13 / k_fin4 of the same iteration and the next class pass read.  No kernel reads what it writes.
+struct EmIterState { uint32_t done; uint32_t closed; unsigned long long maxrel; };   // done: iteration count at convergence (0 = running); closed: iterations closed so far
+// What a block of k_fin4 leaves for the next class pass: a QUARTER of a level-2 tree of the canonical sum (SPEC D2) and what the block saw of the convergence test.
+// Block b = 4 G + i owns the level-1 groups 64 G + i + 4 k (k = 0..15: its 16 waves) of level-2 group G; the strided-halving tree over the 64 leaves of G adds
+// leaf j to leaf j + 32, + 16, + 8, + 4 — within this block's leaves — and only then across blocks: sum(G) = (q0 + q2) + (q1 + q3), the tree's last two steps.
+struct FinRec { double q; unsigned long long relbad; };   // relbad: bits 0..62 = bit pattern of the block's max relDiff (>= 0), bit 63 = "a transcript moved more than the tolerance"
 
 __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long* maxrel_log) {
   uint32_t it = it_index + 1;
@@ -98,22 +107,8 @@ __device__ inline bool em_close(EmDev& d, uint32_t it_index, unsigned long long*
 // strided-halving trees, level by level) and publishes logNorm = digamma(sum).  Being a single
 // block, the `done` flag it may set is visible to every later kernel of the iteration.
 __global__ void __launch_bounds__(1024) k_top(EmDev d, const double* __restrict__ partials, uint32_t n1, int close_prev, uint32_t prev_it,
-    unsigned long long* maxrel_log, double* __restrict__ log_norm, uint32_t nblk /* > 0: k_fin3 left per-block maxima / flags instead of the global atomics */) {
+    unsigned long long* maxrel_log, double* __restrict__ log_norm) {
   __shared__ double buf[2][4096];
-  if (nblk && close_prev && !d.flags[0]) {   // [r4] four-launch form: the iteration is closed from k_fin3's per-block results (plain loads: a kernel boundary lies in between)
-    __shared__ unsigned long long smr[16]; __shared__ int sab[16];
-    unsigned long long mr = 0; int anybad = 0;
-    for (uint32_t b = threadIdx.x; b < nblk; b += blockDim.x) { const unsigned long long r = d.blk_rel[b]; if (r > mr) mr = r; anybad |= (int)d.blk_bad[b]; }
-    for (int s = 32; s >= 1; s >>= 1) { const unsigned long long o = __shfl_down(mr, s, 64); const int ob = __shfl_down(anybad, s, 64); if (o > mr) mr = o; anybad |= ob; }
-    if ((threadIdx.x & 63) == 0) { smr[threadIdx.x >> 6] = mr; sab[threadIdx.x >> 6] = anybad; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (smr[w] > mr) mr = smr[w]; anybad |= sab[w]; }
-      const uint32_t it = prev_it + 1;
-      d.flags[2] = it; maxrel_log[0] = mr;
-      if (!anybad && it >= d.min_iter) d.flags[0] = it;
-    }
-  } else
   if (threadIdx.x == 0 && close_prev && !d.flags[0]) em_close(d, prev_it, maxrel_log);
   __shared__ int s_stop;
   if (threadIdx.x == 0) s_stop = __hip_atomic_load(&d.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // what this thread may just have written
@@ -156,15 +151,15 @@ __device__ inline double theta_from(const EmDev& d, double x, double ln) { retur
 // gathers in flight at once, the products parked in LDS, then one thread per class adds its terms in
 // label order.  A skipped term (VBEM, theta = 0) is stored as +0.0, which leaves the non-negative
 // sum unchanged bit for bit.  A single class larger than the chunk (rare) is walked by one thread.
-#define CL_CHUNK 2048
+#define CL_CHUNK_5 1024
 #define CL_TB 256
 __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restrict__ theta) {
   if (d.flags[0]) return;
-  __shared__ double s_term[CL_CHUNK];
+  __shared__ double s_term[CL_CHUNK_5];
   const uint32_t c0 = d.cchunk[blockIdx.x], c1 = d.cchunk[blockIdx.x + 1];
   const uint64_t e0 = d.off[c0], e1 = d.off[c1];
   const double ln = d.psi_mode ? *d.log_norm : 0.0;
-  if (e1 - e0 > CL_CHUNK) {   // c1 == c0 + 1
+  if (e1 - e0 > CL_CHUNK_5) {   // c1 == c0 + 1
     if (threadIdx.x == 0) {
       double denom = 0.0;
       for (uint64_t i = e0; i < e1; ++i) { const double th = theta_from(d, theta[d.tid[i]], ln); if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
@@ -173,22 +168,22 @@ __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restri
     return;
   }
   if (e1 > e0) {
-    uint32_t t[CL_CHUNK / CL_TB]; double w[CL_CHUNK / CL_TB], h[CL_CHUNK / CL_TB];
+    uint32_t t[CL_CHUNK_5 / CL_TB]; double w[CL_CHUNK_5 / CL_TB], h[CL_CHUNK_5 / CL_TB];
 #pragma unroll
-    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) {
+    for (int j = 0; j < CL_CHUNK_5 / CL_TB; ++j) {
       const uint64_t p = e0 + j * CL_TB + threadIdx.x;
       const uint64_t q = p < e1 ? p : e1 - 1;
       t[j] = d.tid[q];
       w[j] = d.cw[q];
     }
 #pragma unroll
-    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta[t[j]];
+    for (int j = 0; j < CL_CHUNK_5 / CL_TB; ++j) h[j] = theta[t[j]];
     if (d.psi_mode) {
 #pragma unroll
-      for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta_from(d, h[j], ln);
+      for (int j = 0; j < CL_CHUNK_5 / CL_TB; ++j) h[j] = theta_from(d, h[j], ln);
     }
 #pragma unroll
-    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) {
+    for (int j = 0; j < CL_CHUNK_5 / CL_TB; ++j) {
       const uint64_t p = e0 + j * CL_TB + threadIdx.x;
       if (p < e1) s_term[p - e0] = (!d.use_vbem || h[j] > 0.0) ? h[j] * w[j] : 0.0;
     }
@@ -210,18 +205,18 @@ __global__ void __launch_bounds__(CL_TB) k_class(EmDev d, const double* __restri
 // (theta of the owning run comes from LDS via a 1-byte run index per entry), parks them in LDS, then
 // each thread adds up its own run left to right (SPEC §D4) — no chain of dependent global gathers.
 // A skipped term is stored as +0.0, which leaves the non-negative running sum unchanged bit for bit.
-#define L1_CHUNK 2048
+#define L1_CHUNK_5 1024
 #define L1_TB 256
 __global__ void __launch_bounds__(L1_TB) k_l1(EmDev d, const double* __restrict__ theta, double* __restrict__ alpha_out) {
   if (d.flags[0]) return;
-  __shared__ double s_term[L1_CHUNK]; __shared__ double s_th[L1_TB];
+  __shared__ double s_term[L1_CHUNK_5]; __shared__ double s_th[L1_TB];
   const uint32_t s0 = d.chunk_seg[blockIdx.x], s1 = d.chunk_seg[blockIdx.x + 1];
   const uint32_t e0 = d.seg_lo[0][s0], e1 = d.seg_lo[0][s1 - 1] + d.seg_cnt[0][s1 - 1];
   const uint32_t g = s0 + threadIdx.x; const bool has = g < s1;
   uint32_t tt = 0, lo = 0, n = 0;
-  uint32_t c[L1_CHUNK / L1_TB]; double w[L1_CHUNK / L1_TB], iv[L1_CHUNK / L1_TB]; uint8_t sg[L1_CHUNK / L1_TB];
+  uint32_t c[L1_CHUNK_5 / L1_TB]; double w[L1_CHUNK_5 / L1_TB], iv[L1_CHUNK_5 / L1_TB]; uint8_t sg[L1_CHUNK_5 / L1_TB];
 #pragma unroll
-  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) {
+  for (int j = 0; j < L1_CHUNK_5 / L1_TB; ++j) {
     const uint32_t p = e0 + j * L1_TB + threadIdx.x;
     const uint32_t q = p < e1 ? p : e1 - 1;
     c[j] = d.t_cls[q];
@@ -230,10 +225,10 @@ __global__ void __launch_bounds__(L1_TB) k_l1(EmDev d, const double* __restrict_
   }
   if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; s_th[threadIdx.x] = theta_from(d, theta[tt & ~SEG_TOP], d.psi_mode ? *d.log_norm : 0.0); }
 #pragma unroll
-  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) iv[j] = d.inv[c[j]];
+  for (int j = 0; j < L1_CHUNK_5 / L1_TB; ++j) iv[j] = d.inv[c[j]];
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) {
+  for (int j = 0; j < L1_CHUNK_5 / L1_TB; ++j) {
     const uint32_t p = e0 + j * L1_TB + threadIdx.x;
     if (p < e1) {
       const double th = s_th[sg[j]]; double term = 0.0;
@@ -342,20 +337,142 @@ __global__ void k_close(EmDev d, uint32_t it_index /* 0-based index of the itera
   em_close(d, it_index, maxrel_log);
 }
 
-// [r4] k_fin of the four-launch iteration: the leaves of the canonical sum (level-1 partials), psi for the next iteration's gathers, and what this block saw of
-// the convergence test (its max relDiff, its "moved" flag) for k_top, which closes the iteration from the per-block results.  (A three-launch form in which the
-// block that finishes last closed the iteration itself was measured slower — 45.7 vs 38.5 us: its serial tail costs more than the launch it saves — and is gone.)
-__global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, double* __restrict__ partials,
-    uint32_t it_index, unsigned long long* maxrel_log) {
-  if (d.flags[0]) return;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- [r6] the three-launch iteration ------------------------------------------------------------------------------------------------------------------------
+// What k_top did in a launch of its own — close the iteration before (convergence test over k_fin's per-block results), finish the canonical sum of alpha + prior and
+// take its digamma — is the prologue of EVERY block of the class pass: one wave reads the <= 256 records k_fin4 left (64 bytes per lane, one request), while the
+// block's other waves already have the loads of their class chunk in flight.  Every block derives the same values from the same inputs; block 0 publishes them.
+// Returns true when the iteration must not run (converged before, or just now).
+__device__ inline bool em_prologue(const EmDev& d, uint32_t it, int close_prev, double* s_ln, uint32_t* s_done) {
+  if (threadIdx.x < 64) {
+    const uint32_t lane = threadIdx.x, ng = d.nrec >> 2;
+    const EmIterState sin = d.state[it & 1];
+    double p2 = 0.0; unsigned long long rb = 0;
+    if (lane < ng) {
+      const FinRec* r = d.rec + 4 * lane; const FinRec r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+      p2 = (r0.q + r2.q) + (r1.q + r3.q);                       // the last two steps of the level-2 tree
+      rb = r0.relbad; rb = r1.relbad > rb ? r1.relbad : rb; rb = r2.relbad > rb ? r2.relbad : rb; rb = r3.relbad > rb ? r3.relbad : rb;   // (bit 63 dominates: max is also the OR of the flags)
+    }
+    for (int s = 32; s >= 1; s >>= 1) { const unsigned long long o = __shfl_down(rb, s, 64); rb = o > rb ? o : rb; }
+    const double sum = wave_halving_sum(p2);                    // level 3: the tree over the <= 64 level-2 sums
+    if (lane == 0) {
+      EmIterState so = sin;
+      if (!sin.done && close_prev) {
+        so.closed = it; so.maxrel = rb & 0x7FFFFFFFFFFFFFFFull;
+        if (!(rb >> 63) && it >= d.min_iter) so.done = it;
+      }
+      if (blockIdx.x == 0) d.state[(it + 1) & 1] = so;
+      *s_done = so.done;
+      if (!so.done && d.use_vbem) { const double ln = sq_digamma(sum); *s_ln = ln; if (blockIdx.x == 0) *d.log_norm_out = ln; }
+    }
+  }
+  __syncthreads();
+  return *s_done != 0;
+}
+// closes the last iteration of a chunk before the host looks (the class pass that would have done it has not been launched yet); what it writes is what that class
+// pass will write again from the same inputs
+__global__ void __launch_bounds__(64) k_close3(EmDev d, uint32_t it) { __shared__ double s_ln; __shared__ uint32_t s_done; EmDev e = d; e.use_vbem = 0; (void)em_prologue(e, it, 1, &s_ln, &s_done); }
+
+template <int CL_CHUNK>
+__global__ void __launch_bounds__(CL_TB) k_class3(EmDev d, const double* __restrict__ theta, uint32_t it, int close_prev) {
+  __shared__ double s_term[CL_CHUNK]; __shared__ uint16_t s_off[CL_CHUNK + 2]; __shared__ double s_ln; __shared__ uint32_t s_done;
+  const uint4 pl = d.cplan[blockIdx.x]; const uint32_t c0 = pl.x, c1 = pl.y; const uint64_t e0 = pl.z, e1 = pl.w;
+  const bool big = e1 - e0 > CL_CHUNK;   // one class larger than the chunk (c1 == c0 + 1): walked by one thread
+  uint32_t t[CL_CHUNK / CL_TB]; double w[CL_CHUNK / CL_TB], h[CL_CHUNK / CL_TB];
+  if (!big && e1 > e0) {
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; const uint64_t q = p < e1 ? p : e1 - 1; t[j] = d.tid[q]; w[j] = d.cw[q]; }
+    for (uint32_t i = threadIdx.x; i <= c1 - c0; i += CL_TB) s_off[i] = (uint16_t)(d.off[c0 + i] - e0);     // class bounds inside the chunk (<= 2048): requested with the entries, not after them
+  }
+  double cn[CL_CHUNK / CL_TB];      // the counts of this thread's classes, requested now (a chunk holds at most CL_CHUNK classes)
+#pragma unroll
+  for (int r = 0; r < CL_CHUNK / CL_TB; ++r) { const uint32_t c = c0 + r * CL_TB + threadIdx.x; cn[r] = (!big && c < c1) ? d.cnt[c] : 0.0; }
+  if (em_prologue(d, it, close_prev, &s_ln, &s_done)) return;
+  const double ln = d.psi_mode ? s_ln : 0.0;
+  if (big) {
+    if (threadIdx.x == 0) {
+      double denom = 0.0;
+      for (uint64_t i = e0; i < e1; ++i) { const double th = theta_from(d, theta[d.tid[i]], ln); if (!d.use_vbem || th > 0.0) denom += th * d.cw[i]; }
+      d.inv[c0] = (denom <= 2.2250738585072014e-308) ? 0.0 : d.cnt[c0] / denom;
+    }
+    return;
+  }
+  if (e1 > e0) {
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta[t[j]];
+    if (d.psi_mode) {
+#pragma unroll
+      for (int j = 0; j < CL_CHUNK / CL_TB; ++j) h[j] = theta_from(d, h[j], ln);
+    }
+#pragma unroll
+    for (int j = 0; j < CL_CHUNK / CL_TB; ++j) { const uint64_t p = e0 + j * CL_TB + threadIdx.x; if (p < e1) s_term[p - e0] = (!d.use_vbem || h[j] > 0.0) ? h[j] * w[j] : 0.0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < CL_CHUNK / CL_TB; ++r) {
+    const uint32_t c = c0 + r * CL_TB + threadIdx.x; if (c >= c1) break;
+    const uint32_t lo = e1 > e0 ? s_off[c - c0] : 0, n = e1 > e0 ? (uint32_t)s_off[c - c0 + 1] - lo : 0;
+    if (n <= 1) { d.inv[c] = (n == 1) ? -cn[r] : 0.0; continue; }  // single-transcript class gets the full count (:316-318)
+    double denom = 0.0;
+    for (uint32_t i = 0; i < n; ++i) denom += s_term[lo + i];
+    d.inv[c] = (denom <= 2.2250738585072014e-308) ? 0.0 : cn[r] / denom;  // minEQClassWeight (:40)
+  }
+}
+template <int L1_CHUNK>
+__global__ void __launch_bounds__(L1_TB) k_l13(EmDev d, const double* __restrict__ theta, double* __restrict__ alpha_out, uint32_t it) {
+  __shared__ double s_term[L1_CHUNK]; __shared__ double s_th[L1_TB];
+  const uint4 pl = d.lplan[blockIdx.x]; const uint32_t s0 = pl.x, s1 = pl.y, e0 = pl.z, e1 = pl.w;
+  const uint32_t g = s0 + threadIdx.x; const bool has = g < s1;
+  uint32_t tt = 0, lo = 0, n = 0;
+  uint32_t c[L1_CHUNK / L1_TB]; double w[L1_CHUNK / L1_TB], iv[L1_CHUNK / L1_TB]; uint8_t sg[L1_CHUNK / L1_TB];
+#pragma unroll
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) { const uint32_t p = e0 + j * L1_TB + threadIdx.x; const uint32_t q = p < e1 ? p : e1 - 1; c[j] = d.t_cls[q]; w[j] = d.t_cw[q]; sg[j] = d.t_seg8[q]; }
+  if (has) { tt = d.seg_txp[0][g]; lo = d.seg_lo[0][g] - e0; n = d.seg_cnt[0][g]; }
+  if (d.state[(it + 1) & 1].done) return;      // (uniform; behind the requests above so that it does not stand in front of them)
+  if (has) s_th[threadIdx.x] = theta_from(d, theta[tt & ~SEG_TOP], d.psi_mode ? *d.log_norm : 0.0);
+#pragma unroll
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) iv[j] = d.inv[c[j]];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < L1_CHUNK / L1_TB; ++j) {
+    const uint32_t p = e0 + j * L1_TB + threadIdx.x;
+    if (p < e1) {
+      const double th = s_th[sg[j]]; double term = 0.0;
+      if (iv[j] < 0.0) term = -iv[j];                                                   // single-transcript class: the full count
+      else if (iv[j] != 0.0 && (!d.use_vbem || th > 0.0)) { const double v = th * w[j]; term = v * iv[j]; }
+      s_term[p - e0] = term;
+    }
+  }
+  __syncthreads();
+  if (!has) return;
+  double acc = 0.0;
+  for (uint32_t i = 0; i < n; ++i) acc += s_term[lo + i];
+  if (tt & SEG_TOP) alpha_out[tt & ~SEG_TOP] = acc; else d.part[0][g] = acc;
+}
+// the transcript a thread of k_fin4 / k_leaf0 owns: block 4 G + i, wave k, lane l -> level-1 group 64 G + i + 4 k (FinRec)
+__device__ inline uint32_t fin4_txp() { const uint32_t G = blockIdx.x >> 2, i = blockIdx.x & 3, k = threadIdx.x >> 6; return ((64u * G + i + 4u * k) << 6) + (threadIdx.x & 63); }
+// the block's quarter of its level-2 tree from the 16 wave sums, and its record
+__device__ inline void fin4_record(const EmDev& d, double wave_sum, double rel, int bad) {
+  __shared__ double s_v[16]; __shared__ double s_rel[16]; __shared__ int s_bad[16];
+  for (int s = 32; s >= 1; s >>= 1) { const double o = __shfl_down(rel, s, 64); const int ob = __shfl_down(bad, s, 64); rel = o > rel ? o : rel; bad |= ob; }
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = wave_sum; s_rel[threadIdx.x >> 6] = rel; s_bad[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v[16]; for (int k = 0; k < 16; ++k) { v[k] = s_v[k]; if (s_rel[k] > rel) rel = s_rel[k]; bad |= s_bad[k]; }
+    for (int st = 8; st >= 1; st >>= 1) for (int k = 0; k < st; ++k) v[k] = v[k] + v[k + st];          // leaves j and j + 32, + 16, + 8, + 4 of the level-2 tree
+    FinRec r; r.q = v[0]; r.relbad = (rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL) | (bad ? 1ULL << 63 : 0ULL);
+    d.rec[blockIdx.x] = r;
+  }
+}
+__global__ void __launch_bounds__(1024) k_fin4(EmDev d, const double* __restrict__ alpha, double* __restrict__ alpha_out, uint32_t it) {
+  const uint32_t t = fin4_txp();
   double rel = -1.0; int bad = 0; double leaf = 0.0;
+  uint32_t n2 = 0; bool empty = false; double a_old = 0.0, pr = 0.0; const double* src = nullptr;
+  double a_new = 0.0;
+  if (t < d.M) { empty = d.t_off[t + 1] == d.t_off[t]; n2 = d.l2_cnt ? d.l2_cnt[t] : 0; a_old = alpha[t]; pr = d.prior[t]; a_new = alpha_out[t]; if (n2) src = d.part[0] + d.l2_lo[t]; }
+  if (d.state[(it + 1) & 1].done) return;
   if (t < d.M) {
-    const bool empty = d.t_off[t + 1] == d.t_off[t];
     double acc;
-    const uint32_t n2 = d.l2_cnt ? d.l2_cnt[t] : 0;
     if (n2) {
-      const double* src = d.part[0] + d.l2_lo[t];
       acc = 0.0;
       for (uint32_t i = 0; i < n2; i += 8) {
         double v[8];
@@ -366,36 +483,30 @@ __global__ void __launch_bounds__(256) k_fin3(EmDev d, const double* __restrict_
       }
       alpha_out[t] = acc;
     } else if (empty) { acc = 0.0; alpha_out[t] = 0.0; }
-    else acc = alpha_out[t];
+    else acc = a_new;        // (what k_l13 stored: requested with everything else above)
     if (d.first_add != 0.0) { acc += d.first_add; alpha_out[t] = acc; }
-    leaf = acc + d.prior[t];
+    leaf = acc + pr;
     if (acc > 1e-2) {  // alphaCheckCutoff (:884)
-      rel = fabs(alpha[t] - acc) / acc;
+      rel = fabs(a_old - acc) / acc;
       if (rel > d.tol) bad = 1;
     }
     if (d.psi_out) d.psi_out[t] = (leaf > 1e-10) ? sq_digamma(leaf) : -HUGE_VAL;   // digammaMin (:43): what k_theta computes from the same sum
   }
-  if (partials) {
-    const double ls = wave_halving_sum(leaf);
-    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((d.M + 63) >> 6)) partials[t >> 6] = ls;
-  }
-  for (int s = 32; s >= 1; s >>= 1) {
-    const double o = __shfl_down(rel, s, 64); const int ob = __shfl_down(bad, s, 64);
-    rel = o > rel ? o : rel; bad |= ob;
-  }
-  __shared__ double srel[4]; __shared__ int sbad[4];
-  if ((threadIdx.x & 63) == 0) { srel[threadIdx.x >> 6] = rel; sbad[threadIdx.x >> 6] = bad; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) { if (srel[w] > rel) rel = srel[w]; bad |= sbad[w]; }
-    d.blk_rel[blockIdx.x] = rel >= 0.0 ? (unsigned long long)__double_as_longlong(rel) : 0ULL; d.blk_bad[blockIdx.x] = (uint32_t)bad;
-  }
+  fin4_record(d, wave_halving_sum(leaf), rel, bad);
+}
+// before the first iteration: the records (canonical sum of the initial alphas + prior) and psi of the initial alphas
+__global__ void __launch_bounds__(1024) k_leaf0(EmDev d, const double* __restrict__ alpha, double* __restrict__ psi) {
+  const uint32_t t = fin4_txp(); double leaf = 0.0;
+  if (t < d.M) { leaf = alpha[t] + d.prior[t]; if (psi) psi[t] = (leaf > 1e-10) ? sq_digamma(leaf) : -HUGE_VAL; }
+  fin4_record(d, wave_halving_sum(leaf), -1.0, 0);
+}
+__global__ void k_pack_cplan(uint32_t n, const uint32_t* __restrict__ cchunk, const uint64_t* __restrict__ off, uint4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { const uint32_t c0 = cchunk[i], c1 = cchunk[i + 1]; out[i] = make_uint4(c0, c1, (uint32_t)off[c0], (uint32_t)off[c1]); }
+}
+__global__ void k_pack_lplan(uint32_t n, const uint32_t* __restrict__ chunk_seg, const uint32_t* __restrict__ seg_lo, const uint8_t* __restrict__ seg_cnt, uint4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { const uint32_t s0 = chunk_seg[i], s1 = chunk_seg[i + 1]; out[i] = make_uint4(s0, s1, seg_lo[s0], seg_lo[s1 - 1] + seg_cnt[s1 - 1]); }
 }
 __global__ void k_copy_f64(uint32_t n, const double* __restrict__ src, double* __restrict__ dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
-__global__ void k_psi0(EmDev d, const double* __restrict__ alpha, double* __restrict__ psi) {   // psi of the initial alphas (the iterations get theirs from k_fin3)
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < d.M) { const double ap = alpha[i] + d.prior[i]; psi[i] = (ap > 1e-10) ? sq_digamma(ap) : -HUGE_VAL; }
-}
 
 // Workspace arena: an EM session needs ~50 device buffers; hipMalloc + hipFree of each costs more (≈ 6 ms per
 // session) than the 1.3 ms the device-side preparation takes.  While a session sets itself up its buffers are
@@ -595,7 +706,11 @@ struct EmSession {
   DBuf<double> d_w, d_eff, d_cw, d_cnt, d_tcw, d_prior, d_theta, d_inv, d_a0, d_a1, d_part;
   DBuf<unsigned long long> d_maxrel, d_log;
   DBuf<double> d_lognorm, d_psi0, d_psi1;
-  DBuf<unsigned long long> d_blkrel; DBuf<uint32_t> d_blkbad;
+  // entries a block of the class pass / of level 1 stages through LDS.  Measured on MI355X (c2 table of 40 M pairs: 0.52 M classes, 1.33 M labels; tools/em_sweep.py): 4096 / 2048 /
+  // 1024 / 512 entries per class block 32.3 / 28.3 / 26.6 / 26.7 us per iteration, per level-1 block 29.4 / 28.3 / 28.1 / 28.8: the kernels are chains of dependent requests, and
+  // more, smaller blocks hide them better than longer unrolled ones
+  static constexpr int cl_chunk = CL_CHUNK_5, l1_chunk = L1_CHUNK_5;
+  DBuf<EmIterState> d_state; DBuf<FinRec> d_rec; DBuf<uint4> d_cplan, d_lplan; uint32_t nrec = 0;
   DBuf<uint32_t> d_slo[4], d_stx[4]; DBuf<uint8_t> d_scn[4]; DBuf<double> d_lpart[4];
   DBuf<uint32_t> d_chunk, d_l2lo, d_cchunk; DBuf<uint8_t> d_l2cnt, d_seg8;
   hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -604,6 +719,7 @@ struct EmSession {
   ~EmSession() {
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    for (hipEvent_t e : ev_look) if (e) (void)hipEventDestroy(e);
     if (st && own_stream) (void)hipStreamDestroy(st);
     if (arena && arena != &own_arena) arena->reset();
   }
@@ -652,12 +768,12 @@ struct EmSession {
         !key.alloc(L) && !key2.alloc(L) && !val.alloc(L) && !val2.alloc(L) && !d_err.alloc(1) &&
               !d_theta.alloc(M) && !d_inv.alloc(E) && !d_a0.alloc(M) && !d_a1.alloc(M) && !d_part.alloc((size_t)g1 * 3 + 512) &&
                   !d_flags.alloc(4) &&
-                  !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) && !d_psi0.alloc(M) && !d_psi1.alloc(M) &&
-                  !d_blkrel.alloc((M + 255) / 256 + 1) && !d_blkbad.alloc((M + 255) / 256 + 1);
+                  !d_maxrel.alloc(1) && !d_log.alloc(1) && !d_lognorm.alloc(1) && !d_psi0.alloc(M) && !d_psi1.alloc(M);
     for (int l = 0; l < 4 && ok; ++l) ok = !ns[l].alloc((size_t)M + 1) && !base[l].alloc((size_t)M + 1);
     if (!ok) { sq_set_error("device allocation failed in EM (%s)", hipGetErrorString(hipGetLastError())); return SQ_ERR_NOMEM; }
     pt.mark("buffers");
-    h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down; nullptr: plain pageable copies
+    h_stage = (double*)arena->pinned(0, (size_t)3 * M * 8 + 64);   // [0,M) eff_len up, [M,2M) alphas up, [2M,3M) alphas down, then two look slots (run()); nullptr: plain pageable copies
+    h_look = h_stage ? (EmIterState*)(h_stage + (size_t)3 * M) : nullptr;
     if (h_stage) {
       memcpy(h_stage, txp->eff_len, (size_t)M * 8);
       SQ_HIP_CHECK(hipMemcpyAsync(d_eff.p, h_stage, (size_t)M * 8, hipMemcpyHostToDevice, st));
@@ -720,11 +836,11 @@ struct EmSession {
       if (nxt.alloc(std::max<size_t>(S0, E) + 1)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
       std::vector<uint32_t> hn_pageable; uint32_t* hn = (uint32_t*)arena->pinned(1, (std::max<size_t>(S0, E) + 1) * 4);
       if (!hn) { hn_pageable.resize(std::max<size_t>(S0, E) + 1); hn = hn_pageable.data(); }
-      if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, L1_CHUNK, L1_TB, nxt.p);
+      if (S0) { k_next_block<uint32_t><<<nb(S0), TB, 0, st>>>(S0, d_slo[0].p, (uint32_t)l1_chunk, L1_TB, nxt.p);
         SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)S0 * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
         for (uint32_t g = 0; g < S0; g = hn[g]) h_chunk.push_back(g); h_chunk.push_back(S0); }
       pt.mark("prep:jump1");
-      if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, CL_CHUNK, 0, nxt.p);
+      if (E) { k_next_block<uint64_t><<<nb(E), TB, 0, st>>>(E, p_off, (uint32_t)cl_chunk, (uint32_t)cl_chunk, nxt.p);
         SQ_HIP_CHECK(hipMemcpyAsync(hn, nxt.p, (size_t)E * 4, hipMemcpyDeviceToHost, st)); SQ_HIP_CHECK(sq_em_wait(st));
         for (uint32_t c = 0; c < E; c = hn[c]) h_cchunk.push_back(c); h_cchunk.push_back(E); }
       pt.mark("prep:jump2");
@@ -733,6 +849,12 @@ struct EmSession {
         return SQ_ERR_NOMEM;
       }
       if (S0) k_plan_seg8<<<nb(S0), TB, 0, st>>>(S0, d_chunk.p, (uint32_t)h_chunk.size() - 1, d_slo[0].p, d_scn[0].p, d_seg8.p);
+      // [r6] the block plans as one 16-byte record per block (first / end unit, first / end entry): a block's first request brings everything it needs to issue the rest
+      const uint32_t ncc = h_cchunk.size() > 1 ? (uint32_t)h_cchunk.size() - 1 : 0, nlc = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
+      nrec = 4 * ((g1 + 63) / 64);
+      if (d_cplan.alloc(ncc + 1) || d_lplan.alloc(nlc + 1) || d_state.alloc(2) || d_rec.alloc(nrec + 4)) { sq_set_error("device allocation failed in EM plan"); return SQ_ERR_NOMEM; }
+      if (ncc) k_pack_cplan<<<nb(ncc), TB, 0, st>>>(ncc, d_cchunk.p, p_off, d_cplan.p);
+      if (nlc) k_pack_lplan<<<nb(nlc), TB, 0, st>>>(nlc, d_chunk.p, d_slo[0].p, d_scn[0].p, d_lplan.p);
     }
     const bool fold_l2 = d.nlevels == 2;
     if (fold_l2) {
@@ -769,7 +891,7 @@ struct EmSession {
     d.t_seg8 = d_seg8.p; d.chunk_seg = d_chunk.p; d.nchunks = h_chunk.size() > 1 ? (uint32_t)h_chunk.size() - 1 : 0;
     d.l2_lo = fold_l2 ? d_l2lo.p : nullptr; d.l2_cnt = fold_l2 ? d_l2cnt.p : nullptr;
     d.psi_mode = 0; d.psi = nullptr; d.log_norm = d_lognorm.p; d.psi_out = nullptr; d.log_norm_out = d_lognorm.p;
-    d.blk_rel = d_blkrel.p; d.blk_bad = d_blkbad.p;
+    d.state = d_state.p; d.rec = d_rec.p; d.nrec = nrec; d.cplan = d_cplan.p; d.lplan = d_lplan.p;
     SQ_HIP_CHECK(sq_em_wait(st));
     pt.mark("device-prepare");
     return SQ_OK;
@@ -801,7 +923,6 @@ struct EmSession {
     // level-1 partials of (alpha + prior) live in d.partial (written by k_fin); k_top finishes the
     // levels above (<= 4096 partials); for M > 262144 k_sum_level kernels shrink the list first.
     double* part_lvl1 = d.partial; double* part_tmp = d.partial + g1 + 64;
-    uint32_t top_nblk = 0;
     auto launch_top = [&](int close_prev, uint32_t prev_it) {
       const double* pin = part_lvl1; uint32_t n1 = g1;
       double* a = part_tmp; double* b = part_tmp + g1 / 64 + 64;
@@ -811,25 +932,17 @@ struct EmSession {
         n1 = (n1 + 63) / 64;
         std::swap(a, b);
       }
-      k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p, top_nblk);
+      k_top<<<1, 1024, 0, st>>>(d, pin, n1, close_prev, prev_it, d_log.p, d_lognorm.p);
     };
-    // [r4] measured on MI355X (c2, E = 0.63 M, L = 1.66 M, M = 191 k): five launches 40.9 us per iteration, four (k_theta folded into the gathers, k_top closes from
-    // per-block results) 38.5 us: the default whenever the plan has at most two reduction levels and M is within one block's reach; otherwise the five-launch form
-    const bool four = g1 <= 4096 && (d.l2_cnt || d.nlevels <= 1);
-    if (four) top_nblk = (M + TB - 1) / TB;
+    // Measured on MI355X (c2, E = 0.62 M, L = 1.64 M, M = 191 k): five launches 40.9 us per iteration; [r4] four (k_theta folded into the gathers, k_top closing from per-block
+    // results) 38.5; [r6] three — k_top's work as the prologue of the class pass, one 16-byte plan record per block, every request of a block issued before the first is waited
+    // for, 1024-entry blocks — 29.4 us (profiles/r06_kernel_stats_c2_*.txt).  The five-launch form remains for plans with more than two reduction levels or M > 262 144.
+    // [r6] three launches (k_top's work is the prologue of the class pass: the canonical sum reaches it as <= 256 records): the default under the same conditions
+    const bool three = g1 <= 4096 && (d.l2_cnt || d.nlevels <= 1);
+    if (three) SQ_HIP_CHECK(hipMemsetAsync(d_state.p, 0, 2 * sizeof(EmIterState), st));
+    bool first3 = true;
     double* psi_cur = d_psi0.p; double* psi_nxt = d_psi1.p;
     const bool plus_one = mark_degenerate && !o->use_vbem;   // optimize() only (the replicates' alphasPrime start at zero: :413-414)
-    auto launch_iter4 = [&](uint32_t it) {
-      EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
-      if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
-      const double* src = o->use_vbem ? psi_cur : cur;
-      if (dd.ncchunks) k_class<<<dd.ncchunks, CL_TB, 0, st>>>(dd, src);
-      if (dd.nchunks) k_l1<<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt);
-      k_fin3<<<(M + TB - 1) / TB, TB, 0, st>>>(dd, cur, nxt, o->use_vbem ? part_lvl1 : nullptr, it, d_log.p);
-      if (o->use_vbem) launch_top(1, it);
-      else k_top<<<1, 1024, 0, st>>>(d, part_lvl1, 0, 1, it, d_log.p, d_lognorm.p, top_nblk);   // EM: only closes the iteration
-      std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
-    };
     auto launch_iter5 = [&](uint32_t it) {
       const double* theta_src = cur;
       if (o->use_vbem) { k_theta<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, d_lognorm.p); theta_src = d.theta; }
@@ -844,17 +957,52 @@ struct EmSession {
       else k_close<<<1, 1, 0, st>>>(d, it, d_log.p);
       std::swap(cur, nxt);
     };
-    auto launch_iter = [&](uint32_t it) { if (four) launch_iter4(it); else launch_iter5(it); };
-    if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0);
-      if (four) k_psi0<<<(M + TB - 1) / TB, TB, 0, st>>>(d, cur, psi_cur); }
-    uint32_t it = it0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0};
+    auto launch_iter3 = [&](uint32_t it) {
+      EmDev dd = d; dd.first_add = (plus_one && it == 0) ? 1.0 : 0.0;
+      if (o->use_vbem) { dd.psi_mode = 1; dd.psi_out = psi_nxt; }
+      const double* src = o->use_vbem ? psi_cur : cur;
+      // (a problem without classes still runs the class pass's prologue: one block that only closes the iteration before)
+      const int cp = first3 ? 0 : 1;
+      if (dd.ncchunks) k_class3<CL_CHUNK_5><<<dd.ncchunks, CL_TB, 0, st>>>(dd, src, it, cp); else { EmDev de = dd; if (first3) de.min_iter = 0xFFFFFFFFu; k_close3<<<1, 64, 0, st>>>(de, it); }
+      if (dd.nchunks) k_l13<L1_CHUNK_5><<<dd.nchunks, L1_TB, 0, st>>>(dd, src, nxt, it);
+      k_fin4<<<nrec, 1024, 0, st>>>(dd, cur, nxt, it);
+      first3 = false;
+      std::swap(cur, nxt); std::swap(psi_cur, psi_nxt);
+    };
+    auto launch_iter = [&](uint32_t it) { if (three) launch_iter3(it); else launch_iter5(it); };
+    if (three) k_leaf0<<<nrec, 1024, 0, st>>>(d, cur, o->use_vbem ? psi_cur : nullptr);
+    else if (o->use_vbem) { k_sum_level<<<(M + TB - 1) / TB, TB, 0, st>>>(cur, d.prior, M, part_lvl1); launch_top(0, 0); }
+    uint32_t it = it0, executed = 0; uint32_t done = 0; uint32_t hflags[4] = {0, 0, 0, 0}; EmIterState hstate = {0, 0, 0};
     SQ_HIP_CHECK(hipEventRecord(e0, st));
     if (mode == 1) {
       for (; it < it0 + fixed_iters; ++it) launch_iter(it);
       executed = it0 + fixed_iters;
+      if (three && fixed_iters) { EmDev de = d; de.min_iter = 0xFFFFFFFFu; k_close3<<<1, 64, 0, st>>>(de, it); SQ_HIP_CHECK(hipMemcpyAsync(&hstate, d_state.p + ((it + 1) & 1), sizeof(hstate), hipMemcpyDeviceToHost, st)); }
     } else {
       const uint32_t maxIter = max_iter_cap ? max_iter_cap : o->max_iter, minIter = min_iter;
       // run to min_iter without looking, then in chunks; kernels of iterations after convergence are no-ops
+      // [r6] three-launch form with page-locked look slots: the host stays ONE CHUNK AHEAD of the look — chunk k + 1 is queued before the host waits for what chunk k left
+      // (an event behind the copy of its closing state), so the stream never drains inside the loop; a chunk queued past convergence is 192 no-op launches
+      if (three && h_look) {
+        if (!ev_look[0]) { SQ_HIP_CHECK(hipEventCreateWithFlags(&ev_look[0], hipEventDisableTiming)); SQ_HIP_CHECK(hipEventCreateWithFlags(&ev_look[1], hipEventDisableTiming)); }
+        int pend[2]; int np = 0, nxt_slot = 0;
+        const uint32_t lim = std::max(maxIter, minIter);
+        for (;;) {
+          if (it < lim && np < 2) {
+            uint32_t chunk = (it < minIter) ? (minIter - it) : 64; if (it + chunk > lim) chunk = lim - it;
+            for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
+            k_close3<<<1, 64, 0, st>>>(d, it);
+            SQ_HIP_CHECK(hipMemcpyAsync(h_look + nxt_slot, d_state.p + ((it + 1) & 1), sizeof(EmIterState), hipMemcpyDeviceToHost, st));
+            SQ_HIP_CHECK(hipEventRecord(ev_look[nxt_slot], st));
+            pend[np++] = nxt_slot; nxt_slot ^= 1;
+            continue;
+          }
+          if (!np) break;
+          SQ_HIP_CHECK(hipEventSynchronize(ev_look[pend[0]]));
+          hstate = h_look[pend[0]]; pend[0] = pend[1]; --np;
+          if (hstate.done) { done = hstate.done; break; }
+        }
+      } else
       while (it < maxIter || it < minIter) {
         uint32_t chunk = (it < minIter) ? (minIter - it) : 64;   // a look costs a stream drain (~25 us); an iteration queued past convergence is five no-op launches
         // [r2] The loop is bound by the DEVICE: 44 us of kernels + five ~2 us hand-overs per iteration (the host fills the hardware queue and
@@ -863,7 +1011,14 @@ struct EmSession {
         uint32_t lim = std::max(maxIter, minIter);
         if (it + chunk > lim) chunk = lim - it;
         for (uint32_t j = 0; j < chunk; ++j, ++it) launch_iter(it);
-          SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
+        if (three) {   // the last iteration of the chunk is closed by the class pass that follows it: do that part now, then look at the slot it wrote
+          k_close3<<<1, 64, 0, st>>>(d, it);
+          SQ_HIP_CHECK(hipMemcpyAsync(&hstate, d_state.p + ((it + 1) & 1), sizeof(hstate), hipMemcpyDeviceToHost, st));
+          SQ_HIP_CHECK(sq_em_wait(st));
+          if (hstate.done) { done = hstate.done; break; }
+          continue;
+        }
+        SQ_HIP_CHECK(hipMemcpyAsync(hflags, d_flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
         SQ_HIP_CHECK(sq_em_wait(st));
         if (hflags[0]) { done = hflags[0]; break; }
       }
@@ -880,14 +1035,14 @@ struct EmSession {
       }
       else SQ_HIP_CHECK(hipMemcpy(alpha.data(), result_dev, (size_t)M * 8, hipMemcpyDeviceToHost));
     }
-    unsigned long long mr = 0; SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
+    unsigned long long mr = 0; if (three) mr = hstate.maxrel; else SQ_HIP_CHECK(hipMemcpy(&mr, d_log.p, 8, hipMemcpyDeviceToHost));
     if (rep) {
       rep->iters = executed; rep->converged = (mode == 0) ? (done != 0) : 0; double mrd; memcpy(&mrd, &mr, 8); rep->max_rel_diff = mrd;
       rep->device_ms = ms; rep->ms_per_iter = executed > it0 ? ms / (double)(executed - it0) : 0.0; rep->alpha_sum = 0; rep->num_degenerate = num_degenerate; rep->_pad = 0;
     }
     return SQ_OK;
   }
-  double* result_dev = nullptr; double* h_stage = nullptr;
+  double* result_dev = nullptr; double* h_stage = nullptr; EmIterState* h_look = nullptr; hipEvent_t ev_look[2] = {nullptr, nullptr};
   bool mark_degenerate = false, keep_cscpos = false; uint32_t num_degenerate = 0;
   // updateEqClassWeights + populatePriorAlphas_ after the bias hook (CollapsedEMOptimizer.cpp:160-176, 906-916): new effective lengths ->
   // combined weights (classes dropped as degenerate stay dropped), their CSC copies, priors

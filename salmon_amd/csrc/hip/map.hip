@@ -102,6 +102,15 @@ extern "C" int sq_ctx_stage_times(sq_ctx* c, double* ms, uint64_t* calls, int re
 }
 
 static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx* owner, sq_ctx** out);
+// [r6] The "late first synchronisation" of rounds 3-5, explained.  For a copy between the device and PAGEABLE host memory above a size threshold the HIP runtime pins the caller's
+// pages for the transfer (a userptr buffer object) and keeps the pin cached; when the caller later frees or remaps that memory the kernel's MMU notifier fires and amdkfd EVICTS
+// THE PROCESS'S QUEUES until it has rebuilt the mapping — the next submission, whatever it is, then starts 6-30 ms late (measured: the first 1.5 MB upload of the EM set-up began
+// 15.9 ms after it was queued, the device idle, `evicted_ms` of the process counting up; profiles/r06_eviction_ab.txt: 11-15 ms with the default, 0.04 ms with the threshold beyond
+// any copy, three times each in one session).  GPU_PINNED_MIN_XFER_SIZE (MiB) is that threshold: beyond any copy, pageable transfers go through the runtime's own staging buffers
+// and nothing of the caller's memory is ever pinned behind its back.  The runtime reads it when it initialises, so it is set when this library is loaded — unless the host
+// application has set it itself; an application that initialises HIP before loading the library sets it in its own environment (bench.py and salmon-hip do).
+__attribute__((constructor)) static void sq_runtime_defaults() { setenv("GPU_PINNED_MIN_XFER_SIZE", "1048576", 0); }
+
 extern "C" int sq_ctx_create(sq_index* idx, const sq_quant_opts* opts, int device, uint32_t max_batch_reads, sq_ctx** out) {
   return ctx_create_lane(idx, opts, device, max_batch_reads, nullptr, out);
 }
