@@ -102,7 +102,7 @@ struct sq_ctx {
   sq_index* idx = nullptr; sq_device_index* di = nullptr; int device = 0;
   sq_quant_opts opts; sq_map_params mp; uint32_t max_reads = 0;
   uint32_t uni_slots = SQ_MAX_UNIMEMS;       // stride of the uni-MEM slab; raised (and the batch seeded again) when an end produces more
-  uint32_t seed_lw = 4;                      // [r5] words of a read end k_seed2 keeps in LDS: 4 (reads of up to 128 bases) until a batch brings a longer one, then 8 (sticky)
+  uint32_t seed_lw = 4;                      // [r5] words of a read end k_seed2 keeps in LDS: 4 (reads of up to 128 bases) until a batch brings a longer one, then [r6] 5 (up to 160: 2 x 150 keeps six blocks per CU) or 8 (sticky)
   uint32_t read_words = SQ_READ_WORDS_MIN;   // stride of rpack (rnmask: half of it); raised when a batch holds reads of more than 32 * read_words bases
   hipStream_t stream = nullptr;
   // reads
@@ -208,7 +208,7 @@ enum { ST_READS = 0, ST_KMER, ST_JOINT, ST_MAPPED, ST_ALNS, ST_MAPFILT, ST_FRAGF
     ST_CHAINS, ST_CANDS, ST_DP,
     ST_RESCUED, ST_TRUNC, ST_MAXLEN /* longest read end of the batch when it did not fit the packing stride (k_pack) */,
     ST_UNIOVER /* read ends whose uni-MEMs did not fit the slab's stride (k_seed) */,
-    ST_SEEDLW /* [r5] read ends longer than the LDS column of the k_seed2 instantiation that ran (the host seeds again with the wider one) */,
+    ST_SEEDLW /* [r5] the longest read end that did not fit the LDS column of the k_seed2 instantiation that ran, 0 if all did (the host seeds again with a wider one) */,
     ST_FILLS /* [r5] filter blocks k_seed2 brought into LDS (+ the rare single words read past them): the filter's sectors per launch */, ST_N };
 
 int sq_eq_export_dev(sq_ctx* c, sq_eq_dev_csr* out);     // runs the export if needed; pointers stay valid until the next accumulate / merge / reset

@@ -483,11 +483,12 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     static const int force_lw = getenv("SQ_SEED_LW") ? atoi(getenv("SQ_SEED_LW")) : 0;
     const bool v2 = !general && P.k == 31 && di->dict.m == 20 && c->read_words == 8 && di->dict.kfilter && di->dict.uinfo && di->dict.mtab;
     if (v2) {
-      if (force_lw == 8) c->seed_lw = 8;
+      if (force_lw == 5 || force_lw == 8) c->seed_lw = std::max<uint32_t>(c->seed_lw, (uint32_t)force_lw);
       const uint32_t lw = c->seed_lw;
-      // LDS per block: (LW + 8) x 2 KB -> 24 KB (LW 4: six blocks per CU) or 32 KB (five)
+      // LDS per block: (LW + 8) x 2 KB -> 24 KB (LW 4) or [r6] 26 KB (LW 5: reads of up to 160 bases): six blocks per CU; 32 KB (LW 8): five
 #define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
-      if (lw == 4) k_seed2<31, 20, 2, 4><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else k_seed2<31, 20, 2, 8><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
+      if (lw == 4) k_seed2<31, 20, 2, 4><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else if (lw == 5) k_seed2<31, 20, 2, 5><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
+      else k_seed2<31, 20, 2, 8><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
 #undef SQ_SEED2_ARGS
     } else
 #define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
@@ -529,8 +530,8 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     goto pack_again;
   }
   if (h_seedlw) {   // [r5] reads of more than 128 bases met the four-word instantiation of k_seed2: the eight-word one from now on, and this batch again
-    if (c->seed_lw >= 8 || seed_attempt++) { sq_set_error("internal: %llu read ends did not fit k_seed2's LDS column of %u words", h_seedlw, c->seed_lw); return SQ_ERR_STATE; }
-    c->seed_lw = 8;
+    if (c->seed_lw >= 8 || seed_attempt++) { sq_set_error("internal: a read end of %llu bases did not fit k_seed2's LDS column of %u words", h_seedlw, c->seed_lw); return SQ_ERR_STATE; }
+    c->seed_lw = h_seedlw <= 160 ? 5 : 8;       // (h_seedlw: the longest end that did not fit)
     goto pack_again;
   }
   if (h_uniover) {   // [r4] read ends with more uni-MEMs than the slab has slots per end (the reference keeps them all): a wider slab, and the batch is seeded again

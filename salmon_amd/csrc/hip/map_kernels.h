@@ -334,13 +334,13 @@ __global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params
         // the read end moves into the lane's LDS column: all loads in flight together, 16 bytes each
         const sq_u64x2* rp = (const sq_u64x2*)(rpack + (size_t)e * rw);
         const sq_u64x2* qn = (const sq_u64x2*)(rnmask + (size_t)e * (rw >> 1));
-        sq_u64x2 v[LW / 2];
+        sq_u64x2 v[(LW + 1) / 2];         // (an odd LW reads one word more than it keeps: still inside the end's row of rw >= 8 words)
 #pragma unroll
-        for (int w = 0; w < LW / 2; ++w) v[w] = rp[w];
+        for (int w = 0; w < (LW + 1) / 2; ++w) v[w] = rp[w];
         const sq_u64x2 n0 = qn[0], n1 = qn[1];   // rw = 8: four mask words
-        if (L > 32 * LW) { atomicAdd(&stats[ST_SEEDLW], 1ULL); L = 0; }   // does not fit this instantiation: nothing is seeded, the host runs the wider one
+        if (L > 32 * LW) { atomicMax(&stats[ST_SEEDLW], (unsigned long long)L); L = 0; }   // does not fit this instantiation: nothing is seeded, the host runs a wider one (it learns the longest such end)
 #pragma unroll
-        for (int w = 0; w < LW / 2; ++w) { s_rd[2 * w][tx] = v[w].x; s_rd[2 * w + 1][tx] = v[w].y; }
+        for (int w = 0; w < (LW + 1) / 2; ++w) { s_rd[2 * w][tx] = v[w].x; if (2 * w + 1 < LW) s_rd[2 * w + 1][tx] = v[w].y; }
         anyN = (n0.x | n0.y | n1.x | n1.y) != 0;
       }
       pool_next += take;
