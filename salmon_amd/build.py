@@ -41,7 +41,7 @@ def _deps_stamp():
 # inflate_dev.hip: its decoding loop is a wave acting as a scalar processor — every branch in it is uniform.  The structurizer's default turns such a region into
 # flag registers and mask tests all the same (half of the loop's scalar instructions, and the scalar port is what bounds the kernel: DESIGN.md section 4); with
 # uniform regions skipped the branches stay plain scalar jumps.  tests/test_inflate.py holds the result to zlib on the device.
-PER_FILE = {"inflate_dev.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+PER_FILE = {"inflate_dev.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"], "gzip_dev.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
 
 
 def _compile(src, stamp):

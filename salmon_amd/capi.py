@@ -169,6 +169,8 @@ def lib():
         "sq_last_error": (C.c_char_p, []), "sq_version": (C.c_char_p, []),
         "sq_index_build": (C.c_int, [P(IndexOpts), C.c_char_p, C.c_char_p, C.c_char_p]),
         "sq_ctx_seed_filter_fills": (u64, [vp, C.c_int]), "sq_debug_bgzf_inflate": (C.c_int, [C.c_int, vp, u64, vp, u32, vp, u64, vp]), "sq_debug_inflate_core_host": (C.c_int, [vp, u64, vp, u32, vp]),
+        "sq_debug_gzip_inflate": (C.c_int, [C.c_int, vp, u64, u64, vp, u64, vp, vp]), "sq_debug_inflate_span_host": (C.c_int, [vp, u64, u64, u64, vp, u32, vp, vp, vp]),
+        "sq_debug_find_block_start_host": (u64, [vp, u64, u64, u64]),
         "sq_index_build_fasta_mem": (C.c_int, [P(IndexOpts), C.c_char_p, C.c_char_p, P(vp)]),
         "sq_index_build_mem": (C.c_int, [P(IndexOpts), u32, P(C.c_char_p), P(C.c_char_p), P(u32), u32, C.c_char_p, P(vp)]),
         "sq_index_load": (C.c_int, [C.c_char_p, C.c_int, P(vp)]),

@@ -68,6 +68,8 @@ inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t k) { return (uint32_t)
 // enters a block its words go to the wave's window in LDS, the load of the next block is issued, and the bit buffer is fed from the window.
 struct Bits {
   const uint8_t* p; uint32_t n, pos, nblk; uint32_t lo, hi; uint32_t cnt, virt; uint32_t* win;      // win: 64 words (LDS on the device); virt: how many of the cnt bits lie behind the end of the input
+  uint32_t mis;                                                                                     // bytes between the aligned address p and the stream's first byte
+  SQ_INL uint64_t tell() const { return 8ull * (uint64_t)(pos - mis) - (uint64_t)cnt; }             // bits of the stream consumed so far (meaningless once bad())
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t pend, lane;
   __device__ void fetch(uint32_t b) { uint32_t off = b * 256u + lane * 4u; const uint32_t top = (n - 1u) & ~3u; off = off < top ? off : top; pend = *(const uint32_t*)(p + off); }   // no branch: lanes behind the input's end re-read its last word (never used); up to 3 bytes behind n are read (the buffers have slack)
@@ -81,7 +83,7 @@ struct Bits {
   SQ_INL void add(uint32_t v, int at) { const uint64_t w = (uint64_t)v << at; lo |= (uint32_t)w; hi |= (uint32_t)(w >> 32); }     // at <= 32
   SQ_INL void init(const uint8_t* p_, size_t n_, uint32_t* win_) {
     // p: the aligned address at or below the stream's first byte, positions count from there
-    const uint32_t mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = 0; nblk = 0; win = win_; lo = vector_zero(); hi = lo; cnt = 0; virt = 0;
+    mis = (uint32_t)((uintptr_t)p_ & 3); p = p_ - mis; n = (uint32_t)n_ + mis; pos = 0; nblk = 0; win = win_; lo = vector_zero(); hi = lo; cnt = 0; virt = 0;
     start();
     if (n > mis) { const uint32_t nb = (n < 4u ? n : 4u) - mis; uint32_t w = word() >> (8 * mis); if (nb < 4) w &= (1u << (8 * nb)) - 1; add(w, 0); cnt = 8 * nb; pos = n < 4u ? n : 4u; }
   }
@@ -259,19 +261,25 @@ SQ_INL int dynamic_tables(Bits& b, Tables& T) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // the tokens of a batch into memory (Out::apply).  NOT inlined: it is the only code with lane-dependent branches, and with it out of the way the decoding loop
 // is a region of uniform branches that the compiler leaves as plain scalar jumps instead of structuring it into flags and masks
-__device__ __attribute__((noinline)) void apply_tokens(uint8_t* out, uint32_t on, uint32_t ntok, uint32_t tokv) {
+// element idx of a span's output; [r6] symbols only: in front of the output lies the unknown window, whose byte k is the symbol SYM_MARK | k (k = SPAN_WINDOW + idx)
+template <class T> __device__ inline T span_src(const T* out, int32_t idx) {
+  if constexpr (sizeof(T) == 2) { if (idx < 0) return (T)(0x8000u | (uint32_t)(32768 + idx)); }
+  return out[idx];
+}
+template <class T>
+__device__ __attribute__((noinline)) void apply_tokens(T* out, uint32_t on, uint32_t ntok, uint32_t tokv) {
   const uint32_t lane = __lane_id();
   const uint32_t t = lane < ntok ? tokv : 0u; const bool m = (t >> 31) != 0;
   const uint32_t len = m ? (t >> 16) & 0x1FFu : (t & K_LIT) ? ((t & K_PAIR) ? 2u : 1u) : 0u;
   uint32_t inc = len;                                                              // where each token's text begins: a prefix sum across the lanes
   for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += up; }
   const uint32_t pos = on + inc - len, dist = t & 0xFFFFu;
-  const bool simple = m && len <= 16 && pos - dist + len <= on;                    // its source is in memory already
-  if (!m) { if (len >= 1) out[pos] = (uint8_t)(t >> 8); if (len == 2) out[pos + 1] = (uint8_t)(t >> 16); }
+  const bool simple = m && len <= 16 && pos + len <= on + dist;                    // its source is in memory already (possibly in front of `out`: the window of a span, [r6])
+  if (!m) { if (len >= 1) out[pos] = (T)((t >> 8) & 0xFFu); if (len == 2) out[pos + 1] = (T)((t >> 16) & 0xFFu); }
   if (simple) {
-    const uint8_t* src = out + pos - dist; uint8_t* dst = out + pos; uint8_t by[16];
+    const int32_t s0 = (int32_t)pos - (int32_t)dist; T* dst = out + pos; T by[16];
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) if (k < len) by[k] = src[k];
+    for (uint32_t k = 0; k < 16; ++k) if (k < len) by[k] = span_src<T>(out, s0 + (int32_t)k);
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) if (k < len) dst[k] = by[k];
   }
@@ -279,29 +287,33 @@ __device__ __attribute__((noinline)) void apply_tokens(uint8_t* out, uint32_t on
   while (rest) {                                                                   // (uniform: every lane sees the same mask)
     const int k = __builtin_ctzll(rest); rest &= rest - 1;
     const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)t, k), pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k), dk = tk & 0xFFFFu, lk = (tk >> 16) & 0x1FFu;
-    const uint8_t* src = out + pk - dk; uint8_t* dst = out + pk;
-    if (dk >= lk) { for (uint32_t i = lane; i < lk; i += 64) dst[i] = src[i]; }
-    else { for (uint32_t i = lane; i < lk; i += 64) dst[i] = src[i % dk]; }        // the window's last `dist` bytes, repeated
+    const int32_t s0 = (int32_t)pk - (int32_t)dk; T* dst = out + pk;
+    if (dk >= lk) { for (uint32_t i = lane; i < lk; i += 64) dst[i] = span_src<T>(out, s0 + (int32_t)i); }
+    else { for (uint32_t i = lane; i < lk; i += 64) dst[i] = span_src<T>(out, s0 + (int32_t)(i % dk)); }        // the window's last `dist` bytes, repeated
   }
 }
 #endif
-struct Out {
-  uint8_t* out; uint32_t on, pend, ntok, cap;      // on: bytes in memory; pend: bytes the waiting tokens stand for
+// T: uint8_t (text) or, [r6], uint16_t (the symbols of a span of a gzip stream whose preceding 32 KB are not known yet: 0..255 = a byte, 0x8000 | k = byte k of that window)
+template <class T> struct OutT {
+  T* out; uint32_t on, pend, ntok, cap;      // on: elements in memory; pend: elements the waiting tokens stand for
+  bool dry = false;                          // [r6] a trial of a candidate block start: everything is decoded and counted, nothing is stored
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t lane, tokv;
-  __device__ void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; tokv = 0; lane = __lane_id(); }
+  __device__ void init(T* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; tokv = 0; lane = __lane_id(); }
   __device__ void token(uint32_t t, uint32_t nbytes) { tokv = lane == ntok ? t : tokv; ++ntok; pend += nbytes; }      // the caller applies at 64
-  __device__ void apply() { apply_tokens(out, on, ntok, tokv); on += pend; pend = 0; ntok = 0; }      // the caller has checked size() <= cap
+  __device__ void apply() { if (!dry) apply_tokens<T>(out, on, ntok, tokv); on += pend; pend = 0; ntok = 0; }      // the caller has checked size() <= cap
   __device__ void lit(uint32_t e) { token(e, (e & K_PAIR) ? 2u : 1u); }
-  __device__ void match(uint32_t dist, uint32_t len) { token(0x80000000u | (len << 16) | dist, len); }   // the caller has checked dist <= size(), size() + len <= cap
+  __device__ void match(uint32_t dist, uint32_t len) { token(0x80000000u | (len << 16) | dist, len); }   // the caller has checked dist <= size() (+ the window), size() + len <= cap
 #else
-  void init(uint8_t* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; }
+  void init(T* o, uint32_t cap_) { out = o; on = 0; pend = 0; ntok = 0; cap = cap_; }
   void apply() { ntok = 0; }
-  void lit(uint32_t e) { if (on < cap) out[on] = (uint8_t)(e >> 8); ++on; if (e & K_PAIR) { if (on < cap) out[on] = (uint8_t)(e >> 16); ++on; } ++ntok; }
-  void match(uint32_t dist, uint32_t len) { const uint8_t* src = out + on - dist; uint8_t* dst = out + on; for (uint32_t i = 0; i < len; ++i) dst[i] = src[i % dist]; on += len; ++ntok; }
+  void lit(uint32_t e) { if (on < cap && !dry) out[on] = (T)((e >> 8) & 0xFFu); ++on; if (e & K_PAIR) { if (on < cap && !dry) out[on] = (T)((e >> 16) & 0xFFu); ++on; } ++ntok; }
+  void match(uint32_t dist, uint32_t len) { if (!dry) { const int32_t s0 = (int32_t)on - (int32_t)dist; T* dst = out + on;
+      for (uint32_t i = 0; i < len; ++i) { const int32_t idx = s0 + (int32_t)(i % dist); dst[i] = (sizeof(T) == 2 && idx < 0) ? (T)(0x8000u | (uint32_t)(32768 + idx)) : out[idx]; } } on += len; ++ntok; }
 #endif
   SQ_HD uint32_t size() const { return on + pend; }
 };
+typedef OutT<uint8_t> Out;
 
 // the whole stream: `isize` bytes of output are expected (a BGZF member's trailer says how many).  Returns INF_OK or what was wrong.
 SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t isize, Tables& T) {
@@ -352,6 +364,123 @@ SQ_INL int inflate_member(const uint8_t* in, size_t n, uint8_t* out, uint32_t is
   if (o.size() != isize) return INF_OUTPUT_SIZE;
   o.apply();
   return INF_OK;
+}
+
+// ---- [r6] a SPAN of an ordinary gzip stream (hip/gzip_dev.hip) ------------------------------------------------------------------------------------------------------
+// A plain .gz file is one deflate stream: where its blocks begin is only known by decoding, and a block may copy from the 32 KB of text before it.  As in host/pgzip.cpp
+// (after pugz, Kerbiriou & Chikhi 2019) the stream is cut at block starts FOUND by trying bit offsets (find_block_start), every span between two found starts is decoded
+// by a wave into 16-bit symbols in which "byte k of the 32 KB in front of the span" is a symbol of its own (the span's output is preceded by SPAN_WINDOW such symbols, so a
+// copy out of the unknown window is an ordinary copy), and the windows are resolved afterwards, span after span.  Nothing is taken on trust: a span must end exactly on
+// the bit where the next one was found to start, and the member's CRC-32 and length are checked against its trailer (gzip_dev.hip).
+constexpr uint32_t SPAN_WINDOW = 32768, SYM_MARK = 0x8000u;
+enum { INF_OVERRUN = 9 /* a block ended behind the bit where the next span starts: that start was not a block boundary */, INF_NOT_TEXT = 10 };
+SQ_INL bool text_byte(uint32_t c) { return c == 10u || c == 13u || c == 9u || (c >= 32u && c < 127u); }
+// from bit `start_bit` of `in` (n bytes in all) to the block boundary at `stop_bit` (~0: none) or to the end of a final block, whichever comes first.
+// T = uint16_t: symbols, `out` preceded by SPAN_WINDOW marker symbols (window = SPAN_WINDOW); T = uint8_t with window = 0: plain text.
+// max_sym > 0: a TRIAL of a candidate block start — stops (INF_OK) behind max_sym symbols, every literal must be a byte a FASTA / FASTQ file can hold.
+template <class T> SQ_INL int inflate_span(const uint8_t* in, size_t n, uint64_t start_bit, uint64_t stop_bit, T* out, uint32_t cap, uint32_t window, Tables& Tb,
+                                           uint32_t* out_n, uint64_t* end_bit, uint32_t* ended_final, uint32_t max_sym) {
+  const size_t sb = (size_t)(start_bit >> 3); *ended_final = 0; *out_n = 0; *end_bit = start_bit;
+  if (sb >= n) return INF_EOF_INPUT;
+  Bits b; b.init(in + sb, n - sb, Tb.win); OutT<T> o; o.init(out, cap); o.dry = max_sym != 0; int rc = INF_OK; uint32_t nsym = 0;
+  if (start_bit & 7) (void)b.get((int)(start_bit & 7));
+  const uint64_t base = (uint64_t)sb * 8ull;
+  for (;;) {
+    if (!b.bad() && stop_bit != ~0ull) { const uint64_t at = base + b.tell(); if (at == stop_bit) break; if (at > stop_bit) return INF_OVERRUN; }
+    const uint32_t last = b.get(1), type = b.take(2);
+    if (b.bad()) return INF_EOF_INPUT;
+    if (type == 3) return INF_BAD_BLOCK;
+    if (type == 0) {
+      b.take((int)(b.cnt & 7));
+      const uint32_t len = b.get(16), nlen = b.get(16);
+      if (b.bad()) return INF_EOF_INPUT;
+      if ((len ^ nlen) != 0xFFFFu) return INF_BAD_STORED;
+      if (o.size() + len > cap) return INF_OUTPUT_SIZE;
+#pragma unroll 1
+      for (uint32_t i = 0; i < len; ++i) { const uint32_t v = b.get(8); if (b.bad()) return INF_EOF_INPUT; if (max_sym && !text_byte(v)) return INF_NOT_TEXT; o.lit(K_LIT | (v << 8)); if (o.ntok == 64) o.apply(); }
+      nsym += len;
+    } else {
+      if (type == 1) fixed_tables(Tb);
+      else { rc = dynamic_tables(b, Tb); if (rc) return rc; }
+#pragma unroll 1
+      for (;;) {
+        b.refill();
+        const uint32_t e = decode(b, Tb.hlit, Tb.lit, LIT_BITS, LitEntry());
+        if (e & K_LIT) { if (max_sym && (!text_byte((e >> 8) & 0xFFu) || ((e & K_PAIR) && !text_byte((e >> 16) & 0xFFu)))) { rc = INF_NOT_TEXT; break; } o.lit(e); }
+        else {
+          const uint32_t bl = (e >> 8) & 0x1FFu;
+          if (bl == 0) { if (b.bad()) rc = INF_EOF_INPUT; break; }
+          if (bl > 258) { rc = INF_BAD_SYMBOL; break; }
+          const uint32_t len = bl + b.take((int)((e >> 17) & 7u));
+          b.refill();
+          const uint32_t d = decode(b, Tb.hdist, Tb.dist, DIST_BITS, DistEntry());
+          const uint32_t dist = (d >> 8) + b.take((int)((d >> 4) & 15u));
+          if (dist > o.size() + window || dist > SPAN_WINDOW || o.size() + len > cap) { rc = b.bad() ? INF_EOF_INPUT : (d >> 8) > 0x10000u ? INF_BAD_SYMBOL : o.size() + len > cap ? INF_OUTPUT_SIZE : INF_BAD_DISTANCE; break; }
+          o.match(dist, len);
+        }
+        ++nsym;
+        if (o.ntok == 64) { if (b.bad() || o.size() > cap) { rc = b.bad() ? INF_EOF_INPUT : INF_OUTPUT_SIZE; break; } o.apply(); if (max_sym && nsym >= max_sym) break; }
+      }
+      if (rc) return rc;
+    }
+    if (max_sym && nsym >= max_sym) break;
+    if (last) { *ended_final = 1; break; }
+  }
+  if (b.bad()) return INF_EOF_INPUT;
+  if (o.size() > cap) return INF_OUTPUT_SIZE;
+  o.apply();
+  *out_n = o.size(); *end_bit = base + b.tell();
+  return INF_OK;
+}
+// bits [bit, bit + k) of the stream, k <= 32, straight from memory (positions behind the end read as zeros)
+SQ_INL uint32_t peek_bits(const uint8_t* in, size_t n, uint64_t bit, int k) {
+  const size_t by = (size_t)(bit >> 3); uint64_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) w |= (by + i < n ? (uint64_t)in[by + i] : 0ull) << (8 * i);
+  return (uint32_t)((w >> (bit & 7)) & (k == 32 ? 0xFFFFFFFFull : ((1ull << k) - 1)));
+}
+// what a block start must look like before it is worth a trial: not the final block, dynamic codes, counts in range, and a COMPLETE code-length code (Kraft sum = 1)
+SQ_INL bool plausible_dynamic_header(const uint8_t* in, size_t n, uint64_t bit) {
+  // the 74 bits of header a dynamic block starts with, from two unaligned 8-byte reads (the caller's buffer has 16 bytes of slack behind n)
+  const size_t by = (size_t)(bit >> 3); if (by + 10 > n) return false;
+  uint64_t w0, w1; __builtin_memcpy(&w0, in + by, 8); __builtin_memcpy(&w1, in + by + 8, 8);
+  const uint32_t sh = (uint32_t)(bit & 7); const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0, hi = w1 >> sh;
+  const uint32_t h = (uint32_t)lo & 0x1FFFFu;
+  if ((h & 7u) != 4u) return false;                                   // BFINAL = 0, BTYPE = 2 (sent least significant bit first: 0, then 01 -> value 0b100)
+  const uint32_t hlit = (h >> 3) & 31u, hdist = (h >> 8) & 31u, hclen = ((h >> 13) & 15u) + 4u;
+  if (hlit > 29u || hdist > 29u) return false;
+  uint32_t kraft = 0, used = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 19u; ++i) {
+    const uint32_t o = 17u + 3u * i;
+    const uint32_t l = i < hclen ? (uint32_t)((o < 64u ? (lo >> o) | (o > 61u ? hi << (64u - o) : 0ull) : hi >> (o - 64u)) & 7ull) : 0u;
+    if (l) { kraft += 128u >> l; ++used; }
+  }
+  return kraft == 128u && used >= 2u;
+}
+// the first bit in [lo, hi) at which a non-final dynamic block starts whose first 512 symbols decode and are text; ~0 if there is none.  A trial stores nothing (its copies
+// may reach back into the unknown window); whether the start is real is settled later: the span in front of it must end exactly there (inflate_span: INF_OVERRUN)
+SQ_INL uint64_t find_block_start(const uint8_t* in, size_t n, uint64_t lo, uint64_t hi, Tables& Tb) {
+  typedef uint16_t T; T* const scratch = nullptr; const uint32_t scratch_cap = 0x7FFFFFFFu;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lane = __lane_id();
+  for (uint64_t base = lo; base < hi; base += 64) {
+    const uint64_t bit = base + lane;
+    uint64_t cand = __ballot(bit < hi && plausible_dynamic_header(in, n, bit));
+    while (cand) {                                                     // (uniform)
+      const int k = __builtin_ctzll(cand); cand &= cand - 1;
+      uint32_t on, fin; uint64_t eb;
+      if (inflate_span<T>(in, n, base + (uint64_t)k, ~0ull, scratch, scratch_cap, SPAN_WINDOW, Tb, &on, &eb, &fin, 512u) == INF_OK) return base + (uint64_t)k;
+    }
+  }
+#else
+  for (uint64_t bit = lo; bit < hi; ++bit) {
+    if (!plausible_dynamic_header(in, n, bit)) continue;
+    uint32_t on, fin; uint64_t eb;
+    if (inflate_span<T>(in, n, bit, ~0ull, scratch, scratch_cap, SPAN_WINDOW, Tb, &on, &eb, &fin, 512u) == INF_OK) return bit;
+  }
+#endif
+  return ~0ull;
 }
 
 // CRC-32 (the gzip polynomial, reflected) of n bytes, a byte at a time through a 256-entry table
