@@ -37,6 +37,7 @@
 #include "../host/reader_dev.h"
 #include "../host/bgzf_source.h"
 #include "inflate_dev.h"
+#include "gzip_dev.h"
 
 namespace {
 constexpr int FQ_TB = 256;   // 16 bytes per lane: a 4 KB tile per block
@@ -124,10 +125,12 @@ struct sq_dev_reader {
   struct Stream { std::vector<File> files; uint64_t vsize = 0, vpos = 0; double est = 260.0; std::string name;   // name: the last file, for messages
     // BGZF files only (bgz): no buffers in between — the members of a round are inflated straight into its ring pieces.  mem: every non-empty member
     // scanned so far, with the offset of its text in the stream (file = ~0u: the newline a file without a last one gets)
+    bool gzdev = false;   // [r6] every file an ordinary gzip file, inflated on the device
     bool bgz = false; struct BzMember { uint32_t file; uint32_t csize; uint64_t coff; uint32_t isize; uint64_t voff; uint32_t crc, hdr; };   // crc: of the text (trailer); hdr: bytes of gzip header in front of the deflate stream
     std::vector<BzMember> mem; size_t scan_file = 0; uint64_t scan_off = 0, scan_voff = 0, scan_file_bytes = 0; bool scan_done = false;
     bool seq = false; std::vector<std::unique_ptr<SeqFile>> sfiles; size_t sfile_cur = 0; std::deque<SeqChunk> win; uint64_t wend = 0, file_bytes = 0; bool final_ = false; char last_byte = '\n'; } sm[2];
   std::unique_ptr<sqio::Pool> zpool;   // the inflating threads of the buffered sequential streams
+  bool any_gzdev = false;   // [r6] the streams are ordinary gzip files inflated on the device (all of them, or none)
   bool any_buffered = false, any_bgz = false, dev_inflate = false;   // dev_inflate: every stream is BGZF and the members are inflated by hip/inflate_dev.hip
   // [r5] BGZF inflated on the device.  The stager thread feeds each mate stream's CHUNKS: the next members of the stream (256 MB of text or more: ~4000 members of the usual
   // size, a wave each — a launch that fills the chip), their compressed bytes copied from the file mapping into ring pieces, sent to the device, inflated there into the
@@ -143,6 +146,8 @@ struct sq_dev_reader {
     std::deque<DvChunk> q;                        // inflated or being inflated, in stream order (mu)
     std::deque<std::pair<int, std::vector<int>>> lent;   // (chunk buffer, ring pieces) whose copies to the device may still run (stager only)
     uint64_t produced = 0, ahead = 0; size_t next_mem = 0; bool finished = false;   // stager; `ahead`: the stream offset behind the last chunk made
+    // [r6] ordinary gzip files inflated on the device (hip/gzip_dev.hip): the decoder of the file being read, which file that is, its text so far and its last byte
+    sq_gzdev* gz = nullptr; size_t gz_file = 0; uint64_t gz_file_bytes = 0; char gz_last = '\n';
     uint64_t pos = 0;                             // splitter: the stream offset of the next batch's first byte
   } dv[2];
   double t_dv_fill = 0, t_dv_wait = 0, t_dv_split = 0;
@@ -471,10 +476,57 @@ struct sq_dev_reader {
   // ---- [r5] BGZF inflated on the device ---------------------------------------------------------------------------------------------------------
   void dv_fail(int rc, const std::string& e) { std::lock_guard<std::mutex> lk(mu); if (err_rc == SQ_OK) { err = e; err_rc = rc; } done = true; stop = true; cv.notify_all(); }
   std::deque<std::pair<hipEvent_t, std::vector<int>>> dv_lent;   // ring pieces whose copy to the device may still run, oldest first (stager only)
+  // ---- [r6] ordinary gzip files inflated on the device (hip/gzip_dev.hip) ------------------------------------------------------------------------
+  // the next chunk of stream i: the next segment of its current file, decoded into the chunk's buffer.  Every stream has a stager thread of its own: a segment is a chain of
+  // dependent launches with the host in between (block search -> spans -> windows -> text), and two files' chains fill each other's gaps
+  bool gz_make_chunk(int i) {
+    Stream& S = sm[i]; DvStream& D = dv[i]; const double t0 = now();
+    const int idx = (int)(D.produced % DV_CHUNKS); hipStream_t hs = D.hs[0];
+    DvChunk ch; ch.idx = idx; ch.voff = D.ahead; ch.n = 0; ch.last = false; bool have = false;
+    while (!have) {
+      if (!D.gz) {
+        if (D.gz_file == S.sfiles.size()) { ch.last = true; have = true; break; }      // the end of the stream: an empty last chunk
+        SeqFile& F = *S.sfiles[D.gz_file]; std::string w;
+        const int rc = sq_gzdev_open((const uint8_t*)F.map->p, F.map->n, device, hs, 0, &D.gz, &w);
+        if (rc) { dv_fail(rc, "'" + F.path + "': " + w); return false; }
+        D.gz_file_bytes = 0; D.gz_last = '\n';
+      }
+      SeqFile& F = *S.sfiles[D.gz_file]; size_t n = 0; std::string w;
+      int rc = sq_gzdev_next(D.gz, &n, &w);
+      if (rc) { dv_fail(rc, "'" + F.path + "': " + w); return false; }
+      if (n == 0) {      // the file's end: a last line without its newline gets one
+        sq_gzdev_close(D.gz); D.gz = nullptr; ++D.gz_file;
+        if (D.gz_file_bytes && D.gz_last != '\n') {
+          if (dev_grow(&D.text[idx], &D.text_cap[idx], 64) || hipMemsetAsync(D.text[idx], '\n', 1, hs) != hipSuccess) { dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return false; }
+          ch.n = 1; have = true;
+        }
+        continue;
+      }
+      if (dev_grow(&D.text[idx], &D.text_cap[idx], n + 64)) { dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return false; }
+      rc = sq_gzdev_emit(D.gz, (uint8_t*)D.text[idx], &w);
+      if (rc) { dv_fail(rc, "'" + F.path + "': " + w); return false; }
+      if (hipMemcpy(&D.gz_last, (const char*)D.text[idx] + n - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }
+      D.gz_file_bytes += n; ch.n = n; have = true;
+    }
+    if (hipMemsetAsync(D.st + 2 * idx, 0xFF, 4, hs) != hipSuccess || hipMemsetAsync(D.st + 2 * idx + 1, 0, 4, hs) != hipSuccess || hipEventRecord(D.ev_done[idx], hs) != hipSuccess) {
+      dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }
+    { std::lock_guard<std::mutex> lk(mu); const bool last = ch.last; const size_t n = ch.n; D.q.push_back(std::move(ch)); D.ahead += n; ++D.produced; if (last) D.finished = true; t_dv_fill += now() - t0; }
+    cv.notify_all();
+    return true;
+  }
+  void gz_stream_loop(int i) {
+    (void)hipSetDevice(device);
+    DvStream& D = dv[i];
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || D.finished || D.q.size() < (size_t)DV_CHUNKS; }); if (stop || D.finished) return; }
+      if (!gz_make_chunk(i)) return;
+    }
+  }
   // the stager: chunk after chunk of the stream that is the least ahead of its splitter
   void produce_inflate() {
     (void)hipSetDevice(device);
     const int ns = paired ? 2 : 1;
+    if (any_gzdev) { std::thread second; if (ns == 2) second = std::thread([this] { gz_stream_loop(1); }); gz_stream_loop(0); if (second.joinable()) second.join(); return; }
     for (;;) {
       int i = -1;
       { std::unique_lock<std::mutex> lk(mu);
@@ -736,6 +788,13 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
     R->zpool.reset(new sqio::Pool(std::max(1u, nz)));
     sqio::Pool* zp = R->zpool.get();
     const int nstreams = R->paired ? 2 : 1;
+    // [r6] every file an ORDINARY gzip file (none of them BGZF): inflated on the device, hip/gzip_dev.hip (SQ_READER_GZIP_DEVICE=0: by the host's threads, host/pgzip.cpp)
+    bool dev_gz = !(getenv("SQ_READER_GZIP_DEVICE") && atoi(getenv("SQ_READER_GZIP_DEVICE")) == 0);
+    for (int i = 0; i < nstreams && dev_gz; ++i) for (const auto& path : (i ? f2 : f1)) {
+      std::vector<uint8_t> head(70000); FILE* f = fopen(path.c_str(), "rb"); if (!f) { dev_gz = false; break; }
+      const size_t got = fread(head.data(), 1, head.size(), f); fclose(f);
+      if (got < 18 || sqio::BgzfSource::member_size(head.data(), got)) { dev_gz = false; break; }
+    }
     for (int i = 0; i < nstreams; ++i) {
       sq_dev_reader::Stream& S = R->sm[i]; S.seq = true; S.vsize = ~0ull;
       for (const auto& path : (i ? f2 : f1)) {
@@ -749,6 +808,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
           F->is_bgzf = true;
           F->bg.reset(new sqio::BgzfSource()); F->bg->map = F->map; F->bg->base = (const uint8_t*)m; F->bg->n = (size_t)sb.st_size; F->bg->pool = zp; F->bg->path = path;
           F->bg->window = std::max<size_t>(8, (size_t)(2 * nz) / (size_t)nstreams);
+        } else if (dev_gz) { S.gzdev = true;      // (nothing to set up here: the stager opens the file's decoder when it gets to it)
         } else {
           const unsigned th = std::max(1u, std::min(32u, nz / (unsigned)nstreams));
           const size_t piece = std::max<size_t>(1u << 20, std::min<size_t>(4u << 20, (size_t)sb.st_size / (4 * th)));
@@ -758,7 +818,8 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
         S.sfiles.push_back(std::move(F)); S.name = path;
       }
       S.bgz = true; for (auto& F : S.sfiles) if (!F->is_bgzf) S.bgz = false;
-      if (S.bgz) { for (auto& F : S.sfiles) F->bg.reset(); R->any_bgz = true; }   // the members go straight into the ring (bz_scan / bz_fill): no buffering source
+      if (S.gzdev) R->any_gzdev = true;
+      else if (S.bgz) { for (auto& F : S.sfiles) F->bg.reset(); R->any_bgz = true; }   // the members go straight into the ring (bz_scan / bz_fill): no buffering source
       else R->any_buffered = true;
     }
   } else
@@ -780,7 +841,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
   if (!R->any_buffered) R->zpool.reset();
   if (any_gz) { R->RING_PIECES = 96; R->ROUND_PIECES = 32; }
   // [r5] every stream BGZF: the members are inflated on the device (SQ_READER_BGZF_DEVICE=0: by the host's threads, as a mixed or plain-gzip input is)
-  R->dev_inflate = R->any_bgz && !R->any_buffered && !(getenv("SQ_READER_BGZF_DEVICE") && atoi(getenv("SQ_READER_BGZF_DEVICE")) == 0);
+  R->dev_inflate = R->any_gzdev || (R->any_bgz && !R->any_buffered && !(getenv("SQ_READER_BGZF_DEVICE") && atoi(getenv("SQ_READER_BGZF_DEVICE")) == 0));
   if (R->dev_inflate) {
     auto fail_dv = [&](int rc) { for (auto& D : R->dv) { for (auto& h : D.hs) if (h) (void)hipStreamDestroy(h); for (auto& ev : D.ev_h2d) if (ev) (void)hipEventDestroy(ev); for (auto& ev : D.ev_done) if (ev) (void)hipEventDestroy(ev); if (D.st) (void)hipFree(D.st); }
       for (auto& t : R->slots) if (t.st) (void)hipStreamDestroy(t.st); (void)hipGetLastError(); return rc; };
@@ -788,6 +849,12 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
     for (int i = 0; i < (R->paired ? 2 : 1); ++i) {
       sq_dev_reader::Stream& S = R->sm[i]; sq_dev_reader::DvStream& D = R->dv[i];
       // the size of a record, from the first member with text (the splitter keeps the estimate current; a first guess far off would make the first batch copy twice)
+      if (S.gzdev && !S.sfiles.empty()) {      // [r6] an ordinary gzip file: the first 256 KB of its text through zlib
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 31) == Z_OK) { std::vector<char> tmp(256u << 10); zs.next_in = (Bytef*)const_cast<void*>(S.sfiles[0]->map->p); zs.avail_in = (uInt)std::min<size_t>(S.sfiles[0]->map->n, 1u << 20);
+          zs.next_out = (Bytef*)tmp.data(); zs.avail_out = (uInt)tmp.size(); (void)inflate(&zs, Z_SYNC_FLUSH);
+          const size_t got = tmp.size() - zs.avail_out; const uint64_t nl = count_nl(tmp.data(), got); if (nl >= 8) S.est = (double)got / ((double)nl / 4.0); inflateEnd(&zs); }
+      }
       for (auto& F : S.sfiles) { const uint8_t* base = (const uint8_t*)F->map->p; const size_t n = F->map->n; size_t off = 0; bool found = false;
         while (off < n) { const size_t ms = sqio::BgzfSource::member_size(base + off, n - off); if (ms < 26 || ms > n - off) break;
           const uint32_t isize = sqio::BgzfSource::le32(base + off + ms - 4);
@@ -843,7 +910,9 @@ void sq_dev_reader_close(sq_dev_reader* R) {
       (unsigned long long)R->total, (double)R->text_bytes / 1e9, (unsigned long long)(R->DV_TEXT >> 20), R->t_dv_fill, R->t_dv_split, R->t_dv_wait);
   R->pool.reset(); (void)hipSetDevice(R->device);
   for (auto& D : R->dv) {
-    for (auto& h : D.hs) if (h) { (void)hipStreamSynchronize(h); (void)hipStreamDestroy(h); }
+    for (auto& h : D.hs) if (h) (void)hipStreamSynchronize(h);
+    if (D.gz) { sq_gzdev_close(D.gz); D.gz = nullptr; }
+    for (auto& h : D.hs) if (h) (void)hipStreamDestroy(h);
     for (auto& ev : D.ev_h2d) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : D.ev_done) if (ev) (void)hipEventDestroy(ev);
     for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) for (void* p : {D.text[k], D.comp[k], D.mem[k]}) if (p) (void)hipFree(p);

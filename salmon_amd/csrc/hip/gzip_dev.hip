@@ -17,7 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,18 +52,44 @@ __global__ void __launch_bounds__(64 * GZ_WAVES) k_gz_decode(const uint8_t* __re
   const int rc = sqinf::inflate_span<uint16_t>(comp, n, U.start_bit, U.stop_bit, sym + U.sym_off, U.cap, sqinf::SPAN_WINDOW, s_tab[wave], &on, &eb, &fin, 0u);
   if ((threadIdx.x & 63) == 0) { GzUnitOut o; o.end_bit = eb; o.n_sym = on; o.rc = (uint32_t)rc; o.final_ = fin; o._pad = 0; out[u] = o; }
 }
-// windows: (nunits + 1) x 32 KB; windows[0] is the text in front of the segment's first span (given), windows[u + 1] what lies in front of span u + 1
-__global__ void __launch_bounds__(1024) k_gz_chain(const GzUnit* __restrict__ units, const GzUnitOut* __restrict__ uo, uint32_t nunits, const uint16_t* __restrict__ sym, uint8_t* __restrict__ windows) {
+// What a span does to the window, as symbols: tails[u][j] = what lies at place j of the 32 KB in front of span u + 1, in terms of the 32 KB in front of span u — the span's
+// own symbol (a byte, or a marker into that window), or, for a span shorter than the window, "byte n + j of it".  One block per span; the chain below then reads fixed addresses.
+__global__ void __launch_bounds__(256) k_gz_tails(const GzUnit* __restrict__ units, const GzUnitOut* __restrict__ uo, const uint16_t* __restrict__ sym, uint16_t* __restrict__ tails) {
+  constexpr uint32_t WN = sqinf::SPAN_WINDOW;
+  const uint32_t u = blockIdx.x, n = uo[u].n_sym; const uint16_t* S = sym + units[u].sym_off; uint16_t* F = tails + (size_t)u * WN;
+  for (uint32_t j = threadIdx.x; j < WN; j += 256) F[j] = ((uint64_t)n + j < WN) ? (uint16_t)(sqinf::SYM_MARK | (n + j)) : S[(size_t)n + j - WN];
+}
+// windows: (nunits + 1) x 32 KB; windows[0] is the text in front of the segment's first span (given), windows[u + 1] what lies in front of span u + 1.
+// The chain is serial in the spans — some four thousand steps per segment — so a step must cost next to nothing: the window lives in LDS (two buffers of 32 KB: a step reads
+// one and writes the other), a thread resolves four neighbouring places at a time (one 8-byte load, one 4-byte store to LDS and to memory), the tails of the next two spans
+// are on their way while this one is resolved, and one barrier separates two steps.  (The first version kept the window in global memory with a fence per step and read each
+// span's bounds where it needed them: 19 us per span, 76 ms per segment — ten times what decoding the segment takes.)
+__global__ void __launch_bounds__(1024) k_gz_chain(uint32_t nunits, const uint16_t* __restrict__ tails, uint8_t* __restrict__ windows) {
+  extern __shared__ uint8_t s_win[];      // [2][SPAN_WINDOW]
+  constexpr uint32_t WN = sqinf::SPAN_WINDOW, PER = WN / 4 / 1024;      // 8 groups of four places per thread
+  for (uint32_t j = threadIdx.x; j < WN / 4; j += 1024) ((uint32_t*)s_win)[j] = ((const uint32_t*)windows)[j];
+  uint2 a[PER], b[PER];                                                   // the tails of span u (a) and u + 1 (b)
+  auto fetch = [&](uint2* d, uint32_t u) { const uint2* F = (const uint2*)(tails + (size_t)u * WN);
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) d[i] = F[threadIdx.x + 1024u * i]; };
+  if (nunits > 0) fetch(a, 0);
+  if (nunits > 1) fetch(b, 1);
+  __syncthreads();
   for (uint32_t u = 0; u < nunits; ++u) {
-    const uint8_t* W = windows + (size_t)u * sqinf::SPAN_WINDOW; uint8_t* Wn = windows + (size_t)(u + 1) * sqinf::SPAN_WINDOW;
-    const uint16_t* S = sym + units[u].sym_off; const uint32_t n = uo[u].n_sym;
-    for (uint32_t j = threadIdx.x; j < sqinf::SPAN_WINDOW; j += 1024) {
-      uint8_t v;
-      if ((uint64_t)n + j < sqinf::SPAN_WINDOW) v = W[n + j];
-      else { const uint16_t s = S[(size_t)n + j - sqinf::SPAN_WINDOW]; v = (s & sqinf::SYM_MARK) ? W[s & 0x7FFFu] : (uint8_t)s; }
-      Wn[j] = v;
+    const uint8_t* cur = s_win + (u & 1u) * WN; uint32_t* nxt = (uint32_t*)(s_win + ((u & 1u) ^ 1u) * WN); uint32_t* Wn = (uint32_t*)(windows + (size_t)(u + 1) * WN);
+    uint2 c[PER];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) { c[i] = a[i]; a[i] = b[i]; }
+    if (u + 2 < nunits) fetch(b, u + 2);
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t s0 = c[i].x & 0xFFFFu, s1 = c[i].x >> 16, s2 = c[i].y & 0xFFFFu, s3 = c[i].y >> 16;
+      const uint32_t v0 = (s0 & sqinf::SYM_MARK) ? cur[s0 & 0x7FFFu] : (s0 & 0xFFu), v1 = (s1 & sqinf::SYM_MARK) ? cur[s1 & 0x7FFFu] : (s1 & 0xFFu);
+      const uint32_t v2 = (s2 & sqinf::SYM_MARK) ? cur[s2 & 0x7FFFu] : (s2 & 0xFFu), v3 = (s3 & sqinf::SYM_MARK) ? cur[s3 & 0x7FFFu] : (s3 & 0xFFu);
+      const uint32_t v = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24); const uint32_t jj = threadIdx.x + 1024u * i;
+      nxt[jj] = v; Wn[jj] = v;
     }
-    __threadfence(); __syncthreads();      // the next span's lanes read what other waves of this block have just stored
+    __syncthreads();
   }
 }
 // tile t: symbols [tile_first[t], + GZ_TILE) of span tile_unit[t]
@@ -98,7 +126,7 @@ template <class T> struct DevBuf { T* p = nullptr; size_t cap = 0;
 struct sq_gzdev {
   const uint8_t* data = nullptr; size_t bytes = 0; int device = 0; hipStream_t st = nullptr; size_t SEG = 64u << 20;
   size_t hdr_at = 0; bool in_member = false, eof = false; uint64_t pos_bit = 0; uint32_t m_crc = 0; uint64_t m_len = 0; uint32_t ratio = 10;
-  DevBuf<uint8_t> d_comp, d_win; DevBuf<uint64_t> d_found, d_toff; DevBuf<GzUnit> d_units; DevBuf<GzUnitOut> d_uout; DevBuf<uint16_t> d_sym; DevBuf<uint32_t> d_tile_unit, d_tile_first, d_crc;
+  DevBuf<uint8_t> d_comp, d_win; DevBuf<uint64_t> d_found, d_toff; DevBuf<GzUnit> d_units; DevBuf<GzUnitOut> d_uout; DevBuf<uint16_t> d_sym, d_tails; DevBuf<uint32_t> d_tile_unit, d_tile_first, d_crc;
   uint8_t* h_pin = nullptr; size_t h_pin_cap = 0;      // page-locked staging: the segment's compressed bytes up, the small tables down
   uint8_t carry[sqinf::SPAN_WINDOW];                   // (host copy not needed: the carried window stays on the device, d_carry)
   DevBuf<uint8_t> d_carry;
@@ -106,7 +134,11 @@ struct sq_gzdev {
   std::vector<GzUnit> units; std::vector<GzUnitOut> uout; std::vector<uint64_t> toff; size_t text_n = 0; bool pending = false;
   bool seg_ends_member = false; uint32_t trailer_crc = 0, trailer_isize = 0;
   sq_gzdev_counters ctr = {0, 0, 0, 0};
-  ~sq_gzdev() { if (h_pin) (void)hipHostFree(h_pin); }
+  double t_copy = 0, t_find = 0, t_decode = 0, t_chain_emit = 0; uint64_t text_total = 0;      // SQ_READER_STATS=1: where the host waited
+  ~sq_gzdev() {
+    if (getenv("SQ_READER_STATS")) fprintf(stderr, "[sq_gzdev] %.3f GB of text, %llu segments, %llu spans, %llu members, %llu retries: staging copy %.3f s, block search %.3f s, decode %.3f s, windows + text + crc %.3f s\n",
+        (double)text_total / 1e9, (unsigned long long)ctr.segments, (unsigned long long)ctr.spans, (unsigned long long)ctr.members, (unsigned long long)ctr.retries, t_copy, t_find, t_decode, t_chain_emit);
+    if (h_pin) (void)hipHostFree(h_pin); }
   int pin(size_t n) { if (n <= h_pin_cap) return 0; if (h_pin) (void)hipHostFree(h_pin); h_pin = nullptr; h_pin_cap = 0; if (hipHostMalloc((void**)&h_pin, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; } h_pin_cap = n; return 0; }
 };
 
@@ -151,11 +183,13 @@ int sq_gzdev_next(sq_gzdev* g, size_t* n_out, std::string* err) {
       if (nb >= 0xFFFFFFF0ull) { *err = "gzip segment larger than 4 GB"; return SQ_ERR_STATE; }
       const uint32_t nsub = (uint32_t)((nb + GZ_SUB - 1) / GZ_SUB);
       if (g->pin(std::max<size_t>(nb + 64, (size_t)nsub * 64 + 4096)) || g->d_comp.need(nb + 64) || g->d_found.need(nsub + 8)) { *err = "allocation failed (gzip segment)"; return SQ_ERR_NOMEM; }
-      memcpy(g->h_pin, g->data + c0, nb); memset(g->h_pin + nb, 0, 64);
+      auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; double t0 = tnow();
+      memcpy(g->h_pin, g->data + c0, nb); memset(g->h_pin + nb, 0, 64); g->t_copy += tnow() - t0; t0 = tnow();
       if (hipMemcpyAsync(g->d_comp.p, g->h_pin, nb + 64, hipMemcpyHostToDevice, g->st) != hipSuccess) return dev_fail("upload");
       const uint64_t start_rel = g->pos_bit - (uint64_t)c0 * 8ull;
       k_gz_find<<<(nsub + GZ_WAVES - 1) / GZ_WAVES, 64 * GZ_WAVES, 0, g->st>>>(g->d_comp.p, (uint32_t)nb, start_rel + 1, nsub, g->d_found.p);
       if (hipStreamSynchronize(g->st) != hipSuccess) return dev_fail("block search");      // (the staging buffer is free again behind this)
+      g->t_find += tnow() - t0; t0 = tnow();
       std::vector<uint64_t> found(nsub);
       if (hipMemcpy(found.data(), g->d_found.p, (size_t)nsub * 8, hipMemcpyDeviceToHost) != hipSuccess) return dev_fail("block search");
       std::vector<uint64_t> starts; starts.push_back(start_rel);
@@ -174,6 +208,7 @@ int sq_gzdev_next(sq_gzdev* g, size_t* n_out, std::string* err) {
       k_gz_decode<<<(K + GZ_WAVES - 1) / GZ_WAVES, 64 * GZ_WAVES, 0, g->st>>>(g->d_comp.p, (uint32_t)nb, g->d_units.p, K, g->d_sym.p, g->d_uout.p);
       g->uout.resize(K);
       if (hipMemcpyAsync(g->uout.data(), g->d_uout.p, (size_t)K * sizeof(GzUnitOut), hipMemcpyDeviceToHost, g->st) != hipSuccess || hipStreamSynchronize(g->st) != hipSuccess) return dev_fail("decode");
+      g->t_decode += tnow() - t0;
       // what the spans say, in order
       uint32_t keep = 0; bool again = false; g->seg_ends_member = false;
       for (uint32_t i = 0; i < K && !again; ++i) {
@@ -204,7 +239,9 @@ int sq_gzdev_next(sq_gzdev* g, size_t* n_out, std::string* err) {
     if (K) {   // the windows: the carried one in front, then span after span
       if (g->d_win.need(((size_t)K + 1) * sqinf::SPAN_WINDOW)) { *err = "device allocation failed (gzip windows)"; return SQ_ERR_NOMEM; }
       if (hipMemcpyAsync(g->d_win.p, g->d_carry.p, sqinf::SPAN_WINDOW, hipMemcpyDeviceToDevice, g->st) != hipSuccess) return dev_fail("window");
-      k_gz_chain<<<1, 1024, 0, g->st>>>(g->d_units.p, g->d_uout.p, K, g->d_sym.p, g->d_win.p);
+      if (g->d_tails.need((size_t)K * sqinf::SPAN_WINDOW + 64)) { *err = "device allocation failed (gzip windows)"; return SQ_ERR_NOMEM; }
+      k_gz_tails<<<K, 256, 0, g->st>>>(g->d_units.p, g->d_uout.p, g->d_sym.p, g->d_tails.p);
+      k_gz_chain<<<1, 1024, 2 * sqinf::SPAN_WINDOW, g->st>>>(K, g->d_tails.p, g->d_win.p);
       if (hipMemcpyAsync(g->d_carry.p, g->d_win.p + (size_t)K * sqinf::SPAN_WINDOW, sqinf::SPAN_WINDOW, hipMemcpyDeviceToDevice, g->st) != hipSuccess) return dev_fail("window");
     }
     g->pending = true;
@@ -219,7 +256,8 @@ int sq_gzdev_next(sq_gzdev* g, size_t* n_out, std::string* err) {
 int sq_gzdev_emit(sq_gzdev* g, uint8_t* d_dst, std::string* err) {
   auto dev_fail = [&](const char* what) { *err = std::string("device failure in the gzip decoder (") + what + "): " + hipGetErrorString(hipGetLastError()); return SQ_ERR_DEVICE; };
   if (!g->pending) { *err = "internal: sq_gzdev_emit without a decoded segment"; return SQ_ERR_STATE; }
-  g->pending = false;
+  g->pending = false; const auto te0 = std::chrono::steady_clock::now(); g->text_total += g->text_n;
+  struct Tm { sq_gzdev* g; std::chrono::steady_clock::time_point t0; ~Tm() { g->t_chain_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm{g, te0};
   const uint32_t K = (uint32_t)g->units.size(); std::vector<uint32_t> crcs(K, 0);
   if (K && g->text_n) {
     std::vector<uint32_t> tu, tf;

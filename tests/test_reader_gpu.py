@@ -190,3 +190,41 @@ def test_bgzf_members_inflated_on_the_device(built, tmp_path):
         x = bytearray(good); x[ms0 + 10] = xlen & 0xFF; x[ms0 + 11] = xlen >> 8; zx = str(tmp_path / ("xlen%d.fq.gz" % xlen)); open(zx, "wb").write(bytes(x))
         for device in (True, False):
             with pytest.raises(Exception, match="truncated BGZF member"): _drain([zx], None, 5000, device)
+
+
+def test_ordinary_gzip_files_inflated_on_the_device(built, tmp_path):
+    """[r6] All-gzip input (no BGZF member table): every file is inflated by hip/gzip_dev.hip — block starts found on the device, a wave per span, windows resolved,
+    CRC-32 and length of every member checked — and the batches are cut out of that text.  Against the host reader: several files per mate (the first without its last
+    newline), a file of three members (one of them empty), CR LF, levels 1 and 9, k * batch records exactly; the same files through the host's inflating threads
+    (SQ_READER_GZIP_DEVICE=0); a flipped bit, a wrong checksum and a cut file are refused with the file's name."""
+    import gzip, zlib
+    rng = np.random.default_rng(28); r1 = _recs(rng, 30000, "a"); r2 = _recs(rng, 30000, "b")
+    def gz(name, recs, level=6, members=None, **kw):
+        raw = str(tmp_path / (name + ".fq")); _write(raw, recs, **kw); data = open(raw, "rb").read(); z = str(tmp_path / (name + ".fq.gz"))
+        if members: cuts = [0] + [len(data) * k // members for k in range(1, members)] + [len(data)]; blob = b"".join(gzip.compress(data[cuts[k]:cuts[k + 1]], level) for k in range(members)) + gzip.compress(b"", level)
+        else: blob = gzip.compress(data, level)
+        open(z, "wb").write(blob); return z
+    cases = [("paired", [gz("a1", r1)], [gz("a2", r2, level=1)], 5000)]
+    cuts = [0, 11000, 11001, 30000]
+    m1 = [gz("m%d_1" % k, r1[cuts[k]:cuts[k + 1]], last_newline=(k != 0), level=(9 if k == 2 else 6)) for k in range(3)]
+    m2 = [gz("m%d_2" % k, r2[cuts[k]:cuts[k + 1]], last_newline=(k != 1)) for k in range(3)]
+    cases.append(("three files per mate", m1, m2, 4096))
+    cases.append(("three members + an empty one, CR LF in mate 2", [gz("c1", r1, members=3)], [gz("c2", r2, eol="\r\n")], 7000))
+    cases.append(("single-end, k * batch records", [gz("s1", r1)], None, 10000))
+    for name, a, b, batch in cases:
+        dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
+        assert all(d[1] for d in dev) and [d[0] for d in dev] == [x[0] for x in host], name
+        for d, x in zip(dev, host): assert np.array_equal(d[3], x[3]) and d[2].tobytes() == x[2].tobytes(), name
+    os.environ["SQ_READER_GZIP_DEVICE"] = "0"
+    try:
+        name, a, b, batch = cases[1]; dev = _drain(a, b, batch, True); host = _drain(a, b, batch, False)
+        assert all(d[1] for d in dev) and [d[0] for d in dev] == [x[0] for x in host]
+        for d, x in zip(dev, host): assert np.array_equal(d[3], x[3]) and d[2].tobytes() == x[2].tobytes()
+    finally: os.environ.pop("SQ_READER_GZIP_DEVICE", None)
+    good = open(cases[0][1][0], "rb").read()
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x20; zb = str(tmp_path / "bad.fq.gz"); open(zb, "wb").write(bytes(bad))
+    with pytest.raises(Exception, match="bad.fq.gz"): _drain([zb], None, 5000, True)
+    bad = bytearray(good); bad[-7] ^= 0x01; zs = str(tmp_path / "sum.fq.gz"); open(zs, "wb").write(bytes(bad))
+    with pytest.raises(Exception, match="sum.fq.gz.*checksum"): _drain([zs], None, 5000, True)
+    zc = str(tmp_path / "cut.fq.gz"); open(zc, "wb").write(good[: len(good) * 2 // 3])
+    with pytest.raises(Exception, match="cut.fq.gz"): _drain([zc], None, 5000, True)
