@@ -147,7 +147,7 @@ struct sq_dev_reader {
     std::deque<std::pair<int, std::vector<int>>> lent;   // (chunk buffer, ring pieces) whose copies to the device may still run (stager only)
     uint64_t produced = 0, ahead = 0; size_t next_mem = 0; bool finished = false;   // stager; `ahead`: the stream offset behind the last chunk made
     // [r6] ordinary gzip files inflated on the device (hip/gzip_dev.hip): the decoder of the file being read, which file that is, its text so far and its last byte
-    sq_gzdev* gz = nullptr; size_t gz_file = 0; uint64_t gz_file_bytes = 0; char gz_last = '\n';
+    sq_gzdev* gz = nullptr; size_t gz_file = 0; uint64_t gz_file_bytes = 0; char gz_last = '\n'; const char* gz_last_at = nullptr;   // gz_last_at: where the file's last byte so far lies (device)
     uint64_t pos = 0;                             // splitter: the stream offset of the next batch's first byte
   } dv[2];
   double t_dv_fill = 0, t_dv_wait = 0, t_dv_split = 0;
@@ -482,7 +482,7 @@ struct sq_dev_reader {
   bool gz_make_chunk(int i) {
     Stream& S = sm[i]; DvStream& D = dv[i]; const double t0 = now();
     const int idx = (int)(D.produced % DV_CHUNKS); hipStream_t hs = D.hs[0];
-    DvChunk ch; ch.idx = idx; ch.voff = D.ahead; ch.n = 0; ch.last = false; bool have = false;
+    DvChunk ch; ch.idx = idx; ch.voff = D.ahead; ch.n = 0; ch.last = false; bool have = false, recorded = false;
     while (!have) {
       if (!D.gz) {
         if (D.gz_file == S.sfiles.size()) { ch.last = true; have = true; break; }      // the end of the stream: an empty last chunk
@@ -494,8 +494,9 @@ struct sq_dev_reader {
       SeqFile& F = *S.sfiles[D.gz_file]; size_t n = 0; std::string w;
       int rc = sq_gzdev_next(D.gz, &n, &w);
       if (rc) { dv_fail(rc, "'" + F.path + "': " + w); return false; }
-      if (n == 0) {      // the file's end: a last line without its newline gets one
-        sq_gzdev_close(D.gz); D.gz = nullptr; ++D.gz_file;
+      if (n == 0) {      // the file's end (everything queued for it is complete and checked): a last line without its newline gets one
+        if (D.gz_file_bytes && D.gz_last_at && hipMemcpy(&D.gz_last, D.gz_last_at, 1, hipMemcpyDeviceToHost) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }
+        sq_gzdev_close(D.gz); D.gz = nullptr; ++D.gz_file; D.gz_last_at = nullptr;
         if (D.gz_file_bytes && D.gz_last != '\n') {
           if (dev_grow(&D.text[idx], &D.text_cap[idx], 64) || hipMemsetAsync(D.text[idx], '\n', 1, hs) != hipSuccess) { dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return false; }
           ch.n = 1; have = true;
@@ -503,13 +504,11 @@ struct sq_dev_reader {
         continue;
       }
       if (dev_grow(&D.text[idx], &D.text_cap[idx], n + 64)) { dv_fail(SQ_ERR_NOMEM, "device allocation failed (reader: inflated text)"); return false; }
-      rc = sq_gzdev_emit(D.gz, (uint8_t*)D.text[idx], &w);
+      rc = sq_gzdev_emit(D.gz, (uint8_t*)D.text[idx], D.ev_done[idx], &w);      // queued on the decoder's own stream: the event is recorded behind the text
       if (rc) { dv_fail(rc, "'" + F.path + "': " + w); return false; }
-      if (hipMemcpy(&D.gz_last, (const char*)D.text[idx] + n - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }
-      D.gz_file_bytes += n; ch.n = n; have = true;
+      D.gz_last_at = (const char*)D.text[idx] + n - 1; D.gz_file_bytes += n; ch.n = n; have = true; recorded = true;
     }
-    if (hipMemsetAsync(D.st + 2 * idx, 0xFF, 4, hs) != hipSuccess || hipMemsetAsync(D.st + 2 * idx + 1, 0, 4, hs) != hipSuccess || hipEventRecord(D.ev_done[idx], hs) != hipSuccess) {
-      dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }
+    if (!recorded && hipEventRecord(D.ev_done[idx], hs) != hipSuccess) { dv_fail(SQ_ERR_DEVICE, "device failure in the reader (gzip)"); return false; }      // (the newline chunk, the empty last chunk)
     { std::lock_guard<std::mutex> lk(mu); const bool last = ch.last; const size_t n = ch.n; D.q.push_back(std::move(ch)); D.ahead += n; ++D.produced; if (last) D.finished = true; t_dv_fill += now() - t0; }
     cv.notify_all();
     return true;
@@ -866,6 +865,8 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
       for (auto& h : D.hs) if (hipStreamCreateWithFlags(&h, hipStreamNonBlocking) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
       for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) if (hipEventCreateWithFlags(&D.ev_h2d[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.ev_done[k], hipEventDisableTiming) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
       if (hipMalloc((void**)&D.st, sq_dev_reader::DV_CHUNKS * 8) != hipSuccess) return fail_dv(SQ_ERR_NOMEM);
+      if (S.gzdev) { uint32_t ok8[2 * sq_dev_reader::DV_CHUNKS]; for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) { ok8[2 * k] = 0xFFFFFFFFu; ok8[2 * k + 1] = 0; }      // (status words are the BGZF inflater's: "no damaged member")
+        if (hipMemcpy(D.st, ok8, sizeof(ok8), hipMemcpyHostToDevice) != hipSuccess) return fail_dv(SQ_ERR_DEVICE); }
     }
     // a chunk is a launch of some thousand waves; the ring of chunk buffers holds at least three batches' text (SQ_READER_BGZF_MEMBERS: fewer members per chunk, for tests)
     R->DV_TEXT = std::max<uint64_t>(256u << 20, (uint64_t)(3.0 * (double)batch * est_max / (double)sq_dev_reader::DV_CHUNKS));

@@ -11,8 +11,11 @@ struct sq_gzdev;
 int sq_gzdev_open(const uint8_t* data, size_t bytes, int device, hipStream_t st, size_t seg_bytes, sq_gzdev** out, std::string* err);
 // the next segment is decoded as far as its size: *n = bytes of text it holds (0: the end of the file).  Synchronises with the stream.
 int sq_gzdev_next(sq_gzdev*, size_t* n, std::string* err);
-// its text is written to d_dst (room for the *n of sq_gzdev_next) and the members that ended in it are checked against their trailers (CRC-32, length).  Synchronises.
-int sq_gzdev_emit(sq_gzdev*, uint8_t* d_dst, std::string* err);
+// its text is written to d_dst (room for the *n of sq_gzdev_next) by work queued on the decoder's own stream: returns at once, `done` (may be null) is recorded behind the
+// text.  The members' checksums (CRC-32, length against the trailer) are looked at by a later sq_gzdev_next or by sq_gzdev_wait: a damaged file is refused a segment late.
+int sq_gzdev_emit(sq_gzdev*, uint8_t* d_dst, hipEvent_t done, std::string* err);
+// everything queued so far is complete and checked
+int sq_gzdev_wait(sq_gzdev*, std::string* err);
 void sq_gzdev_close(sq_gzdev*);
 struct sq_gzdev_counters { uint64_t segments, spans, members, retries; };
 sq_gzdev_counters sq_gzdev_stats(const sq_gzdev*);

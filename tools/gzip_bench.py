@@ -4,9 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from salmon_amd import capi
 os.environ["SQ_READER_STATS"] = "1"
-mb = int(sys.argv[1]) if len(sys.argv) > 1 else 400; rng = np.random.default_rng(1); L = capi.lib()
+mb = int(sys.argv[1]) if len(sys.argv) > 1 else 400; constq = len(sys.argv) > 2 and sys.argv[2] == 'const'; rng = np.random.default_rng(1); L = capi.lib()
 n = mb * 1000000 // 207; b = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, 100))]; q = (rng.integers(0, 41, (n, 100)) + 33).astype(np.uint8)
-rec = np.zeros((n, 207), np.uint8); rec[:, 0] = ord("@"); rec[:, 1:4] = np.frombuffer(b"r1\n", np.uint8); rec[:, 4:104] = b; rec[:, 104] = 10; rec[:, 105] = ord("+"); rec[:, 106] = 10; rec[:, 107:207] = q; rec[:, 206] = 10
+rec = np.zeros((n, 207), np.uint8); rec[:, 0] = ord("@"); rec[:, 1:4] = np.frombuffer(b"r1\n", np.uint8); rec[:, 4:104] = b; rec[:, 104] = 10; rec[:, 105] = ord("+"); rec[:, 106] = 10; rec[:, 107:207] = (ord('F') if constq else q); rec[:, 206] = 10
 text = rec.tobytes(); t0 = time.time(); co = zlib.compressobj(6, zlib.DEFLATED, 31); gz = co.compress(text) + co.flush(); print("text %.1f MB, gzip -6 %.1f MB (%.1f s to compress)" % (len(text) / 1e6, len(gz) / 1e6, time.time() - t0), flush=True)
 buf = np.frombuffer(gz, np.uint8).copy(); out = np.zeros(len(text) + 1024, np.uint8); nn = C.c_uint64(); ctr = (C.c_uint64 * 4)()
 for rep in range(3):
