@@ -90,14 +90,14 @@ extern "C" int sq_index_to_device(sq_index* idx, int device) {
   rc |= up(d, idx->refseq, &d->refseq); rc |= up(d, sq_index_gc_prefix(idx), &d->gcpre); rc |= up(d, idx->ctab_off, &d->ctab_off); rc |= up(d, idx->ctab, &d->ctab);
   if (rc) { sq_device_index_free(d); return SQ_ERR_DEVICE; }
   v.uinfo = nullptr;
-  if (!getenv("SQ_NO_UINFO")) {   // unitig bounds of the string pool and of the contig table, interleaved (sq_internal.h)
+  {   // unitig bounds of the string pool and of the contig table, interleaved (sq_internal.h)
     std::vector<uint64_t> ui(2 * idx->uoff.size());
     for (size_t u = 0; u < idx->uoff.size(); ++u) { ui[2 * u] = idx->uoff[u]; ui[2 * u + 1] = idx->ctab_off[u]; }
     rc |= up(d, ui, &v.uinfo);
     if (rc) { sq_device_index_free(d); return SQ_ERR_DEVICE; }
   }
   v.kfilter = nullptr; v.kfilter_words = 0;
-  if (!getenv("SQ_NO_KFILTER") && idx->num_kmers > 0) {   // k-mer membership filter (sq_internal.h): SQ_KF_BITS_PER_KEY bits per distinct k-mer
+  if (idx->num_kmers > 0) {   // k-mer membership filter (sq_internal.h): SQ_KF_BITS_PER_KEY bits per distinct k-mer
     const uint64_t nblocks = std::max<uint64_t>(1024, (idx->num_kmers * SQ_KF_BITS_PER_KEY + 511) / 512);   // 64-byte blocks, one per ~2.5 minimizers
     const uint64_t nwords = nblocks * SQ_KF_BLOCK_WORDS;
     void* p = nullptr;

@@ -67,18 +67,7 @@ struct BgzfSource {
     if (m.csize < hdr + 8 || (m.isize && m.csize == hdr + 8)) return "truncated BGZF member";   // (text without a deflate stream in front of the trailer)
     const uint32_t crc = le32(p + m.csize - 8);
     if (!m.isize) return "";
-    static const bool use_zlib = getenv("SQ_BGZF_ZLIB") && atoi(getenv("SQ_BGZF_ZLIB")) != 0;   // the library's inflate instead of the own one (pgzip.cpp), for comparison
-    if (!use_zlib) { if (pgz_inflate_raw(p + hdr, m.csize - hdr - 8, dst, m.isize) != (long)m.isize) return "corrupt BGZF member"; }
-    else {
-      // one inflate state per worker thread, reset per member
-      struct Z { z_stream zs; bool ok = false; Z() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; } ~Z() { if (ok) inflateEnd(&zs); } };
-      static thread_local Z tz;
-      if (!tz.ok || inflateReset2(&tz.zs, -15) != Z_OK) return "zlib initialisation failed";
-      z_stream& zs = tz.zs;
-      zs.next_in = const_cast<Bytef*>(p + hdr); zs.avail_in = (uInt)(m.csize - hdr - 8); zs.next_out = (Bytef*)dst; zs.avail_out = m.isize;
-      const int rc = inflate(&zs, Z_FINISH);
-      if (rc != Z_STREAM_END || zs.total_out != m.isize) return "corrupt BGZF member";
-    }
+    if (pgz_inflate_raw(p + hdr, m.csize - hdr - 8, dst, m.isize) != (long)m.isize) return "corrupt BGZF member";      // the own inflate in byte mode (host/pgzip.cpp; measured against zlib's in round 4: 510 against 283 MB/s per thread)
     if (sqcrc::crc32((uint32_t)crc32(0L, Z_NULL, 0), dst, m.isize) != crc) return "BGZF checksum mismatch";
     return "";
   }

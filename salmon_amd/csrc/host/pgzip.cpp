@@ -334,8 +334,8 @@ struct PgzStream {
   // ---- stage 1 (its own thread): where the pieces start, their symbols, the chain; needs only the bit position the round before ended on
   uint64_t bitpos = 0; bool next_starts_member = true; unsigned alone = 0;   // alone: rounds left to run as one piece (no other piece found a block start: stored or binary data)
   std::thread decoder; std::mutex qmu; std::condition_variable cv_q; std::deque<std::unique_ptr<Round>> decoded; bool dec_done = false, finishing = false;
-  bool pipelined = false;  // SQ_PGZ_PIPE=1: stage 1 of round r + 1 beside stage 2 of round r.  Measured on the 256-thread host and left off: both stages want the
-                           // whole pool, so the overlap buys nothing (9.5 vs 10.7 M pairs/s on 2 x 24 M reads) and the extra buffers cost page faults on short files
+  // (stage 1 of round r + 1 beside stage 2 of round r was measured on the 256-thread host and dropped: both stages want the whole pool, the overlap bought nothing —
+  // 9.5 vs 10.7 M pairs/s on 2 x 24 M reads — and the extra buffers cost page faults on short files)
   std::mutex pmu; std::vector<std::unique_ptr<Piece>> free_pc;               // pieces go round: their symbol buffers are reused
   // ---- stage 2 (its own thread): the 32 KB windows in chain order, text and checksums, the member's trailer; then the text is published
   std::vector<uint8_t> tail; uint32_t crc = 0; uint64_t mlen = 0;            // of the current member
@@ -418,7 +418,7 @@ struct PgzStream {
   }
   void decode_loop() {
     for (;;) {
-      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || (decoded.empty() && (pipelined || !finishing)); });   // one round ahead of stage 2 (or none)
+      { std::unique_lock<std::mutex> lk(qmu); cv_q.wait(lk, [&] { return stop || (decoded.empty() && !finishing); });   // one round ahead of stage 2 (or none)
         if (stop) { dec_done = true; cv_q.notify_all(); return; } }
       std::unique_ptr<Round> R(new Round()); decode_round(*R);
       const bool last = !R->err.empty() || R->at_end;
@@ -500,7 +500,6 @@ PgzStream* pgz_open(const uint8_t* data, size_t bytes, std::function<void(std::f
   s->base = data; s->n = bytes; s->submit = std::move(submit); s->threads = std::max(1u, threads); s->piece_bytes = std::max<size_t>(piece_bytes, 1u << 16);
   if (!s->begin_member(0)) return nullptr;
   s->ahead_bytes = (size_t)s->threads * s->piece_bytes * 4;          // about one round of text waiting while the next is finished
-  if (getenv("SQ_PGZ_PIPE") && atoi(getenv("SQ_PGZ_PIPE")) != 0) s->pipelined = true;
   PgzStream* p = s.release();
   p->decoder = std::thread([p] { p->decode_loop(); });
   p->producer = std::thread([p] { p->produce(); });

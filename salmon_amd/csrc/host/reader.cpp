@@ -287,12 +287,12 @@ void produce_fast(std::vector<std::string> files, ChunkQueue* out, Pool* pool, b
           }
         }
         if (fd >= 0) close(fd); }
-      // [r3] any other gzip file of some size: cut into pieces that the pool inflates in parallel (pgzip.h); SQ_READER_PGZ=0 keeps it on zlib
+      // [r3] any other gzip file of some size: cut into pieces that the pool inflates in parallel (pgzip.h); smaller files stay on one zlib stream
       std::shared_ptr<Mapping> pmap; PgzStream* pz = nullptr;
       struct PzGuard { PgzStream*& p; ~PzGuard() { if (p) pgz_close(p); } } pzg{pz};
-      if (!bg && !(getenv("SQ_READER_PGZ") && atoi(getenv("SQ_READER_PGZ")) == 0)) {
+      if (!bg) {
         int fd = open(path.c_str(), O_RDONLY); struct stat sb;
-        const long min_bytes = getenv("SQ_READER_PGZ_MIN") ? atol(getenv("SQ_READER_PGZ_MIN")) : (8L << 20);   // smaller files: one zlib stream is as fast
+        const long min_bytes = getenv("SQ_READER_PGZ_MIN") ? atol(getenv("SQ_READER_PGZ_MIN")) : (8L << 20);   // smaller files: one zlib stream is as fast (the variable: tests reach the pieces with small files)
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= min_bytes) {
           void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
           if (m != MAP_FAILED) {

@@ -273,9 +273,9 @@ def test_reader_plain_gzip_is_inflated_in_pieces_by_the_pool(built, tmp_path, mo
     want, err = run(tmp_path / "p_1.fq", tmp_path / "p_2.fq"); assert err is None
     got, err = run(tmp_path / "g_1.fq.gz", tmp_path / "g_2.fq.gz")
     assert err is None and got == want and sum(len(b) for b in got) == 2 * n
-    monkeypatch.setenv("SQ_READER_PGZ", "0")
+    monkeypatch.setenv("SQ_READER_PGZ_MIN", str(1 << 40))          # the same files through one zlib stream each (what files below 8 MB take)
     got0, err = run(tmp_path / "g_1.fq.gz", tmp_path / "g_2.fq.gz"); assert err is None and got0 == want
-    monkeypatch.delenv("SQ_READER_PGZ")
+    monkeypatch.delenv("SQ_READER_PGZ_MIN")
     raw = bytearray(open(tmp_path / "g_1.fq.gz", "rb").read()); raw[len(raw) // 2] ^= 0x5A
     open(tmp_path / "bad_1.fq.gz", "wb").write(bytes(raw))
     got, err = run(tmp_path / "bad_1.fq.gz", None)

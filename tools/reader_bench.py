@@ -47,13 +47,13 @@ if __name__ == "__main__":
         ext = ".fq.gz" if gz else ".fq"; f1, f2 = d + "/r_1" + ext, d + "/r_2" + ext
         if not os.path.exists(f1): write(f1, N, 1, gz); write(f2, N, 2, gz)
         for mode in ("fast", "safe") + (("zlib",) if gz else ()):   # gzip "fast" = pieces inflated by the pool (host/pgzip.cpp); "zlib" = one stream per file
-            os.environ.pop("SQ_READER_SAFE", None); os.environ.pop("SQ_READER_PGZ", None)
+            os.environ.pop("SQ_READER_SAFE", None); os.environ.pop("SQ_READER_PGZ_MIN", None)
             if mode == "safe": os.environ["SQ_READER_SAFE"] = "1"
-            if mode == "zlib": os.environ["SQ_READER_PGZ"] = "0"
+            if mode == "zlib": os.environ["SQ_READER_PGZ_MIN"] = str(1 << 40)
             n, dt = drain(f1, f2, 1000000)
             print("%-5s %-4s %d pairs in %.3f s = %.2f M pairs/s (%d host threads, SQ_READER_THREADS=%s)" % ("gzip" if gz else "plain", mode, n, dt, n / dt / 1e6,
                 os.cpu_count(), os.environ.get("SQ_READER_THREADS", "default")))
-    os.environ.pop("SQ_READER_SAFE", None); os.environ.pop("SQ_READER_PGZ", None)
+    os.environ.pop("SQ_READER_SAFE", None); os.environ.pop("SQ_READER_PGZ_MIN", None)
     b1, b2 = d + "/b_1.fq.gz", d + "/b_2.fq.gz"
     if not os.path.exists(b1): bgzf_write(b1, open(d + "/r_1.fq", "rb").read()); bgzf_write(b2, open(d + "/r_2.fq", "rb").read())
     n, dt = drain(b1, b2, 1000000); n, dt = drain(b1, b2, 1000000)
