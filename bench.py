@@ -169,7 +169,7 @@ def run_from_fastq(ctx, idx, tx, n_pairs, read_len, batch, threads, api, capi, g
            "reader_threads": os.environ.get("SQ_READER_THREADS", "default: min(64, hw/2) inflating, min(16, hw/4) copying"),
            "what": "end to end from files through sq_reader, H2D included; plain files: text staged in page-locked memory, records split on the device "
                    "(hip/fastq_dev.hip); BGZF: the compressed members cross PCIe and are inflated on the device (hip/inflate_dev.hip, a wave per member), records split there; "
-                   "gzip (one deflate stream): inflated in pieces by the host's threads (host/pgzip.cpp, bounded by the container's CPU quota), records split on the device"}
+                   "gzip (one deflate stream per file, no member table): [r6] inflated on the device as well (hip/gzip_dev.hip: block starts found by trying bit offsets, a wave per span between two of them into 16-bit symbols, the 32 KB windows resolved span after span, CRC-32 and length checked), records split there"}
     try:
         seq, off, _, _ = tx.reads(n_pairs, read_len=read_len, seed=77, first_pair=0, threads=threads, truth=False)
         recs = seq.reshape(2 * n_pairs, read_len)
