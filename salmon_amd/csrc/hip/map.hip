@@ -473,10 +473,11 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   else if (c->read_words == 16) k_pack<16><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
   else k_pack<32><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
   sq_prof_mark(c, SG_PACK);
-  {  // persistent grid: 256 CUs x 6 blocks of 256 threads; lanes pull read ends from counters[2].  The probe rate is
-     // bound by the memory system, not by occupancy (4..8 blocks/CU measure the same), so two blocks' worth of wave
-     // slots per CU stay free for the eq stage's small kernels on stream2 — a full grid starves them for the whole 5 ms.
-    const uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * 6u);
+  {  // persistent grid: 256 CUs x 24 waves; lanes pull read ends from counters[2].  The probe rate is bound by the memory system once six waves per SIMD are resident
+     // (profiles/r06_seed_grid.txt: 16 / 20 / 24 waves per CU 5.30 / 4.76 / 4.38 ms, 26 and 28 no faster), so two blocks' worth of wave slots per CU stay free for the
+     // eq stage's small kernels on stream2 — a full grid starves them for the whole launch.  [r6] k_seed2's blocks are ONE wave (nothing in it is shared between waves:
+     // 4.38 -> 4.22 ms; the general kernel keeps 256 threads)
+    const uint32_t grid = std::min<uint32_t>(nblk(nrec), 256u * 6u), grid2 = std::min<uint32_t>((nrec + SEED_TB - 1) / SEED_TB, 256u * 6u * (256u / SEED_TB));
     // [r5] k_seed2 (read words and filter block in LDS, the minimizer table's one-sector records) for the default k / m with reads of up to 256 bases;
     // everything else takes the general kernel (SQ_SEED_GENERAL=1 forces it: the tests run both)
     static const bool general = getenv("SQ_SEED_GENERAL") && atoi(getenv("SQ_SEED_GENERAL")) != 0;
@@ -485,10 +486,10 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     if (v2) {
       if (force_lw == 5 || force_lw == 8) c->seed_lw = std::max<uint32_t>(c->seed_lw, (uint32_t)force_lw);
       const uint32_t lw = c->seed_lw;
-      // LDS per block: (LW + 8) x 2 KB -> 24 KB (LW 4) or [r6] 26 KB (LW 5: reads of up to 160 bases): six blocks per CU; 32 KB (LW 8): five
+      // LDS per wave: (LW + 8) x 512 B -> 6 KB (LW 4) or [r6] 6.5 KB (LW 5: reads of up to 160 bases): 24 waves per CU and more; 8 KB (LW 8): 20
 #define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
-      if (lw == 4) k_seed2<31, 20, 2, 4><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else if (lw == 5) k_seed2<31, 20, 2, 5><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
-      else k_seed2<31, 20, 2, 8><<<grid, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
+      if (lw == 4) k_seed2<31, 20, 2, 4><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else if (lw == 5) k_seed2<31, 20, 2, 5><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
+      else k_seed2<31, 20, 2, 8><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
 #undef SQ_SEED2_ARGS
     } else
 #define SQ_SEED_ARGS di->dict, di->ctab_off, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots

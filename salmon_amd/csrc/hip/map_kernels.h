@@ -289,7 +289,7 @@ __global__ void k_seed(sq_dict_view d, const uint64_t* __restrict__ ctab_off, sq
 // table 4.56; + filter block through registers into LDS 4.71 (the eight ds_write cost what the saved loads gave), by LDS-DMA 4.40.
 // The walk, and therefore every uni-MEM, is k_seed's: tests hold both kernels to the checker.  Read ends longer than 32 * LW bases raise
 // ST_SEEDLW and the host seeds the batch again with the next wider instantiation (map.hip).
-#define SEED_TB 256
+#define SEED_TB 64
 template <int LW>
 __device__ inline uint64_t seed_lds_bases(const uint64_t (*rd)[SEED_TB], uint32_t tx, uint32_t p, uint32_t n) {
   const uint32_t w = p >> 5, sh = (p & 31) * 2;
@@ -299,7 +299,7 @@ __device__ inline uint64_t seed_lds_bases(const uint64_t (*rd)[SEED_TB], uint32_
   return lo & sq_kmask(n);
 }
 template <int KT, int MT, int SEED_SPEC, int LW>
-__global__ void __launch_bounds__(SEED_TB) k_seed2(sq_dict_view d, sq_map_params P, uint32_t nends,
+__global__ void __launch_bounds__(SEED_TB) __attribute__((amdgpu_waves_per_eu(7))) k_seed2(sq_dict_view d, sq_map_params P, uint32_t nends,
                        const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor, uint32_t rw, uint32_t us) {
