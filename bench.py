@@ -670,9 +670,9 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     pm = {}; pm_note = "no PMC profile committed for this kernel on this workload"
     try:   # the counter passes were taken on the c2 workload: no traffic figure for the others; [r4] nor when the kernel sources changed since
         if wl == "c2":   # (c3 maps the same index in other batch sizes: not the launches that were counted)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))
             if prof.get("kernel_source_sha") == kernel_source_sha() and prof.get("pairs_per_launch") == B: pm = prof["kernels"]
-            else: pm_note = "profiles/r05_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))
+            else: pm_note = "profiles/r06_pmc_traffic.json was taken on other kernel sources or another batch size (sha %s, %s pairs): no traffic figure attached" % (prof.get("kernel_source_sha"), prof.get("pairs_per_launch"))
     except Exception: pass
     cand = [k for k in stage_rows if k in KERNEL_OF_STAGE]
     roof = None; roofs = {}
@@ -681,12 +681,12 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     pair_share = {"k_frag_dynamic": 0.5, "k_apply_flagged": 0.5}; pair_note = "no committed rocprofv3 summary found: the launch pair's time is split 50/50"
     try:
         ktot = {}
-        for line in open(os.path.join(ROOT, "profiles", "r05_kernel_stats_c2_final.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r06_kernel_stats_c2_final.txt")):
             for kn in pair_share:
                 if kn + "(" in line and "total=" in line: ktot[kn] = float(line.split("total=")[1].split("ms")[0])
         if len(ktot) == 2:
             pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
-            pair_note = "split %.2f / %.2f between k_frag_dynamic and k_apply_flagged as in profiles/r05_kernel_stats_c2_final.txt" % (pair_share["k_frag_dynamic"], pair_share["k_apply_flagged"])
+            pair_note = "split %.2f / %.2f between k_frag_dynamic and k_apply_flagged as in profiles/r06_kernel_stats_c2_final.txt" % (pair_share["k_frag_dynamic"], pair_share["k_apply_flagged"])
     except Exception: pass
     for k in cand:
         per_launch = sb[k] / max(1, stage_rows[k]["launches"])
@@ -705,7 +705,7 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     if roofs:
         dom = max(roofs, key=lambda k: roofs[k]["ms_total"])
         roof = dict(roofs[dom])
-        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r05_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload and batch size, "
+        roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r06_pmc_traffic.json (rocprofv3 --pmc, separate passes, same workload and batch size, "
                                 "kernel sources unchanged since: sha %s; calibrated on tools/gather_bench: no correction for this access pattern); PMC cannot be sampled inside the timed run" % kernel_source_sha()) if roof["traffic"] is not None else pm_note
         roof["alg_bytes_note"] = "per-kernel byte model = bench.py::stage_bytes (DESIGN.md section 5)"
         roof["chain_pair_note"] = pair_note

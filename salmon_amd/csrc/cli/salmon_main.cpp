@@ -673,7 +673,10 @@ static int cmd_quant(int argc, char** argv) {
           nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv,
               "--useEM") ? "EM" : "VBEM", secs,
               odir);
-  sq_dist_free(dist); sq_ctx_free(ctx); sq_index_free(idx);
+  const bool xt = getenv("SQ_EXIT_TRACE") != nullptr;   // where a process that does not end is: each step of the teardown says when it is through
+  sq_dist_free(dist); if (xt) fprintf(stderr, "[exit] dist freed\n");
+  sq_ctx_free(ctx); if (xt) fprintf(stderr, "[exit] ctx freed\n");
+  sq_index_free(idx); if (xt) fprintf(stderr, "[exit] index freed\n");
   return 0;
 }
 
