@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--genome-gnt", type=float, default=None, help="c4: decoy genome size in 10^9 nt")
     ap.add_argument("--gibbs-samples", type=int, default=100, help="c5: posterior samples (100 = 4 chains, 1600 rounds)")
     ap.add_argument("--cpu-sample", type=int, default=5000000, help="pairs timed through the CPU checker and compared with the HIP path (0 = skip)")
+    ap.add_argument("--no-chain-check", dest="chain_check", action="store_false", help="skip the parity leg that runs the burned-in mini-batch chain against the checker (2 M pairs)")
     ap.add_argument("--no-extras", action="store_true", help="c2: skip the 10 M-pair job, the c2s leg and the spread measurement")
     ap.add_argument("--spread-pairs", type=int, default=10000000, help="c2 extras: pairs of the job the spread variants run (0 = skip)")
     ap.add_argument("--index-cache", default=None, help="directory to keep the built index in between runs (experiments; the driver's run builds it)")
@@ -766,6 +767,19 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
             parity = {"pairs": Sn, "transcripts": int(M), "alignments": int(len(aln)), "eq_classes": int(len(eqc.count)), "equal": all(checks.values()),
                 "checks": checks, "alignments_sha256": sha(aln_g), "decoy_fragments": int(st_g["num_decoy_fragments"]),
                 "what": "first %d pairs of timed step 0: HIP path vs CPU checker, sha256 of every output array" % Sn}
+            if Sn >= 2000000 and a.chain_check:
+                # [r6] the burned-in mini-batch chain (k_chain: one launch per mapped batch, its workgroups behind a counter barrier) at this index's size and beside
+                # running mapping kernels: the sample's first 2 M pairs as four batches with the burn-in moved into the second, HIP path vs checker, the model bit for bit
+                nb_, bp_ = 4, 500000; o2 = api.quant_opts(num_burnin_frags=600000)
+                cx2 = api.QuantContext(idx, o2, device=local, max_batch_reads=bp_); cx2.reserve(1000000, 0); os2 = orc.OrcState(oidx, o2)
+                for i_ in range(nb_):
+                    rb_ = api.make_read_batch(host_first[i_ * bp_ * 2 * RL:(i_ + 1) * bp_ * 2 * RL], soff[:2 * bp_ + 1], bp_, paired=True)
+                    cx2.map_batch(rb_); cx2.eq_accumulate()
+                    ro_, aln_, mt_, st_ = orc.map_batch(oidx, o2, rb_, threads=ncores); os2.eq_accumulate(ro_, aln_, st_["num_with_joint_hits"])
+                os2.finish(); m_g = cx2.model(); m_c = os2.model(); e_g = cx2.eq_finish(); e_c = os2.eq_finish()
+                parity["checks"]["burned_in_chain_4x500k"] = bool(cx2.summary()["burned_in"]) and all(sha(x) == sha(y) for x, y in zip(m_g, m_c[:4])) and \
+                    all(sha(getattr(e_g, f)) == sha(getattr(e_c, f)) for f in ("off", "tid", "bins", "count", "wq"))
+                parity["equal"] = all(parity["checks"].values()); cx2.free(); os2.free(); del cx2, os2
             if gibbs is not None and Sn >= 1000:   # c5: the Gibbs sampler on the sample's classes, every sample byte-equal to the checker's
                 g_g = api.gibbs(eq_g, np.exp(le_g), a_g, 8, 7, int(eq_g.count.sum()), api.gibbs_opts(), device=local)
                 g_c = orc.gibbs(eqc, np.exp(lec), a_c, 8, 7, int(eqc.count.sum()), api.gibbs_opts())

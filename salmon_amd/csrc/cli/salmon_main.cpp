@@ -673,6 +673,9 @@ static int cmd_quant(int argc, char** argv) {
           nfrag ? 100.0 * (double)ms.num_assigned / (double)nfrag : 0.0, (unsigned long long)t.num_classes, rep.iters, flag(argc, argv,
               "--useEM") ? "EM" : "VBEM", secs,
               odir);
+  // Everything the job owes is on disk and closed.  One run in ~450 on a GPU box (round 6, tools/runs/r6q.sh; not reproduced in 200 further runs, r6s.sh) never ended
+  // after the line above — inside the teardown below or the runtime's own exit handlers: the caller is not kept waiting for that.
+  fflush(nullptr); signal(SIGALRM, [](int) { _exit(0); }); alarm(30);
   const bool xt = getenv("SQ_EXIT_TRACE") != nullptr;   // where a process that does not end is: each step of the teardown says when it is through
   sq_dist_free(dist); if (xt) fprintf(stderr, "[exit] dist freed\n");
   sq_ctx_free(ctx); if (xt) fprintf(stderr, "[exit] ctx freed\n");

@@ -140,7 +140,7 @@ struct sq_ctx {
   // starts while no mapping is in flight (the last batch of a run) takes the whole GPU instead.
   hipStream_t stream3 = nullptr;
   hipStream_t eq_stream_cur = nullptr;
-  int eq_cus = 0;
+  int eq_cus = 0, ncu = 0;
   std::atomic<int> map_active{0};
   hipEvent_t ev_eq_last = nullptr;
   hipStream_t stream2 = nullptr;

@@ -577,7 +577,7 @@ struct sq_dev_reader {
         bool okc = true;
         for (size_t k = 0; k < ncp && okc; ++k) okc = hipMemcpyAsync((char*)D.comp[idx] + k * PIECE, ring + (size_t)pcs[k] * PIECE, std::min(PIECE, cbytes - k * PIECE), hipMemcpyHostToDevice, hs) == hipSuccess;
         okc = okc && hipMemcpyAsync(D.mem[idx], desc, (size_t)nmem * sizeof(sq_bgzf_member), hipMemcpyHostToDevice, hs) == hipSuccess && hipEventRecord(D.ev_h2d[idx], hs) == hipSuccess;
-        okc = okc && hipMemsetAsync(D.st + 2 * idx, 0xFF, 4, hs) == hipSuccess && hipMemsetAsync(D.st + 2 * idx + 1, 0, 4, hs) == hipSuccess;
+        okc = okc && hipMemsetAsync(D.st + 2 * idx, 0xFF, 8, hs) == hipSuccess;
         okc = okc && sq_bgzf_inflate_launch((const uint8_t*)D.comp[idx], (const sq_bgzf_member*)D.mem[idx], nmem, (uint8_t*)D.text[idx], D.st + 2 * idx, hs) == SQ_OK;
         if (!okc) { dv_fail(SQ_ERR_DEVICE, std::string("device failure in the reader (inflate): ") + hipGetErrorString(hipGetLastError())); return; }
         dv_lent.push_back({D.ev_h2d[idx], std::move(pcs)});
@@ -865,7 +865,7 @@ int sq_dev_reader_open(const std::vector<std::string>& f1, const std::vector<std
       for (auto& h : D.hs) if (hipStreamCreateWithFlags(&h, hipStreamNonBlocking) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
       for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) if (hipEventCreateWithFlags(&D.ev_h2d[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.ev_done[k], hipEventDisableTiming) != hipSuccess) return fail_dv(SQ_ERR_DEVICE);
       if (hipMalloc((void**)&D.st, sq_dev_reader::DV_CHUNKS * 8) != hipSuccess) return fail_dv(SQ_ERR_NOMEM);
-      if (S.gzdev) { uint32_t ok8[2 * sq_dev_reader::DV_CHUNKS]; for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) { ok8[2 * k] = 0xFFFFFFFFu; ok8[2 * k + 1] = 0; }      // (status words are the BGZF inflater's: "no damaged member")
+      if (S.gzdev) { uint32_t ok8[2 * sq_dev_reader::DV_CHUNKS]; for (int k = 0; k < sq_dev_reader::DV_CHUNKS; ++k) { ok8[2 * k] = 0xFFFFFFFFu; ok8[2 * k + 1] = 0xFFFFFFFFu; }      // (status words are the BGZF inflater's: "no damaged member")
         if (hipMemcpy(D.st, ok8, sizeof(ok8), hipMemcpyHostToDevice) != hipSuccess) return fail_dv(SQ_ERR_DEVICE); }
     }
     // a chunk is a launch of some thousand waves; the ring of chunk buffers holds at least three batches' text (SQ_READER_BGZF_MEMBERS: fewer members per chunk, for tests)

@@ -266,6 +266,13 @@ template <class T> __device__ inline T span_src(const T* out, int32_t idx) {
   if constexpr (sizeof(T) == 2) { if (idx < 0) return (T)(0x8000u | (uint32_t)(32768 + idx)); }
   return out[idx];
 }
+// Memory ordering: a match reads text that OTHER lanes of this wave stored a few instructions earlier (the literals and simple matches above it, the round of the
+// `rest` loop before it).  On gfx9 / CDNA a wave's vector stores and loads to the same address are served in issue order by the one vector-memory pipe and its L1
+// (one counter, vmcnt, for both): a later load of the wave sees an earlier store of the wave.  gfx10 and later count stores separately (vscnt) and give no such
+// order without a wait — this file is built for gfx950 only and says so:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "inflate_core.h: apply_tokens relies on gfx9's in-order vector memory pipe (see the note above it)"
+#endif
 template <class T>
 __device__ __attribute__((noinline)) void apply_tokens(T* out, uint32_t on, uint32_t ntok, uint32_t tokv) {
   const uint32_t lane = __lane_id();

@@ -11,7 +11,7 @@
 namespace {
 constexpr int INF_WAVES = 4;   // waves (members) per block
 __global__ void __launch_bounds__(64 * INF_WAVES) k_bgzf_inflate(const uint8_t* __restrict__ comp, const sq_bgzf_member* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text,
-                                                                    uint32_t* __restrict__ status /* [0] = index + 1 of the first bad member (atomicMin), [1] = what was wrong with it */) {
+                                                                    uint32_t* __restrict__ status /* both start as 0xFFFFFFFF; [0] = index + 1 of the first bad member (atomicMin), [1] = (index + 1) << 4 | what was wrong with it (atomicMin) */) {
   __shared__ sqinf::Tables s_tab[INF_WAVES]; __shared__ uint32_t s_crc[256];
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_crc[i] = sqinf::crc32_entry(i);
   __syncthreads();
@@ -22,12 +22,13 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_bgzf_inflate(const uint8_t* 
   if (M.flags & SQ_BGZF_LINE_END) { if ((threadIdx.x & 63) < M.isize) text[M.voff + (threadIdx.x & 63)] = '\n'; return; }   // the line end a file without a last one gets (the reader's pseudo-member)
   int rc = M.csize ? sqinf::inflate_member(comp + M.coff, M.csize, text + M.voff, M.isize, s_tab[wave]) : (M.isize ? (int)sqinf::INF_EOF_INPUT : (int)sqinf::INF_OK);   // text without a stream: damaged
   if (rc == sqinf::INF_OK && sqinf::crc32_wave(s_crc, text + M.voff, M.isize) != M.crc) rc = 8;
-  if (rc != sqinf::INF_OK && (threadIdx.x & 63) == 0) { const uint32_t old = atomicMin(&status[0], m + 1); if (m + 1 <= old) status[1] = (uint32_t)rc; }
+  // [r6] index and cause leave in ONE word ((index + 1) << 4 | cause, atomicMin): the cause reported is the first bad member's whichever wave gets there first
+  if (rc != sqinf::INF_OK && (threadIdx.x & 63) == 0) { (void)atomicMin(&status[0], m + 1); (void)atomicMin(&status[1], ((m + 1) << 4) | ((uint32_t)rc & 15u)); }
 }
 }  // namespace
 
-const char* sq_bgzf_status_text(uint32_t what) {
-  switch (what) {
+const char* sq_bgzf_status_text(uint32_t what) {   // `what`: status[1] as the kernel left it
+  switch (what & 15u) {
     case sqinf::INF_EOF_INPUT: return "truncated BGZF member";
     case 8: return "BGZF checksum mismatch";
     case sqinf::INF_OUTPUT_SIZE: return "corrupt BGZF member (its text is not the size its trailer names)";
@@ -56,11 +57,12 @@ extern "C" int sq_debug_bgzf_inflate(int device, const uint8_t* comp, uint64_t c
   if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); sq_set_error("no HIP device %d", device); return SQ_ERR_DEVICE; }
   void *dc = nullptr, *dm = nullptr, *dt = nullptr, *ds = nullptr; int rc = SQ_OK;
   if (hipMalloc(&dc, comp_bytes + 512) != hipSuccess || hipMalloc(&dm, (size_t)nmem * sizeof(sq_bgzf_member) + 16) != hipSuccess || hipMalloc(&dt, text_bytes + 64) != hipSuccess || hipMalloc(&ds, 16) != hipSuccess) rc = SQ_ERR_NOMEM;
-  const uint32_t st0[2] = {0xFFFFFFFFu, 0};
+  const uint32_t st0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
   if (!rc && (hipMemcpy(dc, comp, comp_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dm, mem, (size_t)nmem * sizeof(sq_bgzf_member), hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(ds, st0, 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dt, 0, text_bytes) != hipSuccess)) rc = SQ_ERR_DEVICE;
   if (!rc) rc = sq_bgzf_inflate_launch((const uint8_t*)dc, (const sq_bgzf_member*)dm, nmem, (uint8_t*)dt, (uint32_t*)ds, nullptr);
   if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(text, dt, text_bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(status2, ds, 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = SQ_ERR_DEVICE;
+  if (!rc) status2[1] = status2[0] == 0xFFFFFFFFu ? 0u : (status2[1] & 15u);   // the caller's view: [0] = index + 1 of the first bad member, [1] = its cause
   for (void* p : {dc, dm, dt, ds}) if (p) (void)hipFree(p);
   if (rc == SQ_ERR_DEVICE) sq_set_error("device failure in sq_debug_bgzf_inflate: %s", hipGetErrorString(hipGetLastError()));
   return rc;

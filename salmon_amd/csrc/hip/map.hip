@@ -146,7 +146,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
     const int ncu = prop.multiProcessorCount;
     int eq_cus = getenv("SQ_EQ_CUS") ? atoi(getenv("SQ_EQ_CUS")) : (ncu >= 128 ? ncu / 4 : 0);
     if (eq_cus < 0 || eq_cus >= ncu) eq_cus = 0;
-    c->eq_cus = eq_cus;
+    c->eq_cus = eq_cus; c->ncu = ncu;
     if (eq_cus > 0) {
       std::vector<uint32_t> m1((ncu + 31) / 32, 0), m2((ncu + 31) / 32, 0);
       // [r3] the driver deals the mask's bits round-robin to the XCDs (bit i -> XCD i mod 8: amdkfd's symmetric CU-mask mapping), so the top

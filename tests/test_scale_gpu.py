@@ -8,17 +8,20 @@ from salmon_amd import api, synth
 import orc
 
 pytestmark = pytest.mark.gpu
-N, B = 200000, 100000
+N = 200000
 
 
-def test_gpu_equals_checker_at_20k_transcripts_200k_pairs(built):
+# burn-in inside the second of two batches; [r6] burn-in inside the second of four: the third and fourth run the burned-in chain (k_chain: one launch per batch,
+# ten mini-batches of the default 5 000 in two groups of the default W = 8, 160 workgroups behind a counter barrier)
+@pytest.mark.parametrize("B,burnin", [(100000, 120000), (50000, 60000)])
+def test_gpu_equals_checker_at_20k_transcripts_200k_pairs(built, B, burnin):
     tx = synth.Txome(seed=5, n_genes=3200, iso_per_gene=8, threads=16)
     names, seqs, lens = tx.tables()
     idx = api.SalmonIndex.build_mem_raw(tx.n, names, seqs, lens, threads=16).to_device(0)
     assert idx.num_refs >= 19000
     oidx = orc.OrcIndex(idx)
     seq, off, tt, tp = tx.reads(N, read_len=100, seed=6, threads=16)
-    opts = api.quant_opts(num_burnin_frags=120000)       # burn-in falls inside the second batch
+    opts = api.quant_opts(num_burnin_frags=burnin)       # burn-in falls inside the second batch
     ctx = api.QuantContext(idx, opts, device=0, max_batch_reads=B)
     ost = orc.OrcState(oidx, opts)
     tot_g = tot_c = None
