@@ -61,6 +61,10 @@ int sq_index_build_fasta_mem(const sq_index_opts* opts, const char* fasta_path, 
 int sq_index_build_mem(const sq_index_opts* opts, uint32_t nrefs, const char* const* names,
                        const char* const* seqs, const uint32_t* lens, uint32_t first_decoy,
                        const char* outdir, sq_index** out);
+/* [r6] Where index construction builds its k-mer table (the phase of BuildSalmonIndex.cpp:49-262 -> pufferfishIndex that decides where unitigs end): -2 = on GPU 0 when
+ * there is one and the input has >= 2*10^7 k-mer positions (the default), -1 = on the host, >= 0 = on that device (a build then fails if it cannot).  The index is
+ * byte for byte the same either way.  Process-wide; call before sq_index_build*. */
+int sq_index_build_set_device(int device);
 /* Load index.bin from dir. device >= 0 uploads the query structures to that GPU's HBM;
  * device < 0 keeps a host-only handle (metadata queries, tests without a GPU). */
 int sq_index_load(const char* dir, int device, sq_index** out);

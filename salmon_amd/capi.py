@@ -173,7 +173,7 @@ def lib():
         "sq_debug_find_block_start_host": (u64, [vp, u64, u64, u64]),
         "sq_index_build_fasta_mem": (C.c_int, [P(IndexOpts), C.c_char_p, C.c_char_p, P(vp)]),
         "sq_index_build_mem": (C.c_int, [P(IndexOpts), u32, P(C.c_char_p), P(C.c_char_p), P(u32), u32, C.c_char_p, P(vp)]),
-        "sq_index_load": (C.c_int, [C.c_char_p, C.c_int, P(vp)]),
+        "sq_index_load": (C.c_int, [C.c_char_p, C.c_int, P(vp)]), "sq_index_build_set_device": (C.c_int, [C.c_int]),
         "sq_index_to_device": (C.c_int, [vp, C.c_int]), "sq_index_free": (None, [vp]),
         "sq_index_k": (u32, [vp]), "sq_index_m": (u32, [vp]), "sq_index_num_refs": (u32, [vp]), "sq_index_first_decoy": (u32, [vp]),
         "sq_index_ref_name": (C.c_char_p, [vp, u32]), "sq_index_ref_len": (u32, [vp, u32]), "sq_index_ref_complete_len": (u32, [vp, u32]),

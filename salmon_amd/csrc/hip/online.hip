@@ -79,8 +79,6 @@ struct sq_online_dev {
   } exp;
   sq_dbuf<uint32_t> merge_slot;
   std::vector<double> fm_host;
-  sq_dbuf<double> fm_dev; size_t fm_dev_n = 0;   // [r6] the same schedule on the device (k_chain)
-  sq_dbuf<unsigned long long> chain_bar;          // k_chain's barrier counter
   uint64_t num_observed = 0, num_mapped_ub = 0, batch_no = 0, group_no = 0; bool burned_known = false;
   // `-l A` (SPEC §D8): per-format sample counts of the mini-batches seen so far while detection is active
   bool detect_active = false, detected = false; uint64_t det_counts[64] = {0}; uint64_t det_samples = 0;
@@ -864,27 +862,39 @@ __global__ void __launch_bounds__(256) k_frag_dynamic(OnlineView V, uint32_t r0,
   const uint64_t a0 = aln_off[r], a1 = aln_off[r + 1];
   if (a1 == a0) return;
   const uint32_t mbs = (r - r0) / mb;
+  // [r6] a fragment has 2-3 alignments: the records of the first four are requested together, then their transcripts' log-counts together — three dependent trips
+  // to memory (offsets, records, log-counts) where the loop took two per alignment.  Same sums in the same order.
+  constexpr int NR = 4;
+  const uint32_t na = (uint32_t)((a1 - a0) < (uint64_t)NR ? (a1 - a0) : (uint64_t)NR);
+  DynAln d[NR]; double lp[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) d[i] = dyn[a0 + ((uint32_t)i < na ? (uint32_t)i : na - 1)];   // no branch around a load: a fragment with fewer reads its last record again
+#pragma unroll
+  for (int i = 0; i < NR; ++i) lp[i] = V.tlc[d[i].tid];                                        // (every record names a transcript, kept or not)
+#pragma unroll
+  for (int i = 0; i < NR; ++i) if ((uint32_t)i >= na) d[i].keep = 0;
   double sumProbs = SQ_LOG_0; uint32_t nk = 0;
-  double lp[4];                                  // the first four kept alignments stay in registers (a fragment has 2-3 on average)
-  for (uint64_t ai = a0; ai < a1; ++ai) {
-    const DynAln d = dyn[ai];
-    if (!d.keep) continue;
-    const double logProb = V.tlc[d.tid] + d.aux + d.start;
-    if (nk < 4) lp[nk] = logProb;
-    sumProbs = sq_log_add(sumProbs, logProb); ++nk;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) if (d[i].keep) { lp[i] = lp[i] + d[i].aux + d[i].start; sumProbs = sq_log_add(sumProbs, lp[i]); ++nk; }
+  for (uint64_t ai = a0 + NR; ai < a1; ++ai) {
+    const DynAln x = dyn[ai];
+    if (!x.keep) continue;
+    sumProbs = sq_log_add(sumProbs, V.tlc[x.tid] + x.aux + x.start); ++nk;
   }
   if (nk == 0) return;
-  uint32_t ki = 0;
-  for (uint64_t ai = a0; ai < a1; ++ai) {
-    const DynAln d = dyn[ai];
-    if (!d.keep) continue;
-    const double logProb = ki < 4 ? lp[ki] : (V.tlc[d.tid] + d.aux + d.start);
-    ++ki;
+  auto add = [&](uint64_t ai, uint32_t tid, double logProb) {
     const double pr = sq_exp(logProb - sumProbs);
     const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
-    if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gcbin && gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (V.posbin) pos_observe(V, ai, pr);
+  };
+#pragma unroll
+  for (int i = 0; i < NR; ++i) if (d[i].keep) add(a0 + i, d[i].tid, lp[i]);
+  for (uint64_t ai = a0 + NR; ai < a1; ++ai) {
+    const DynAln x = dyn[ai];
+    if (!x.keep) continue;
+    add(ai, x.tid, V.tlc[x.tid] + x.aux + x.start);
   }
 }
 // group end after burn-in: one thread per transcript reads its W mass slots (one 64-byte line at W = 8) and, where the group left
@@ -897,14 +907,14 @@ __device__ __forceinline__ void apply_one(const OnlineView& V, const FmArr& FM, 
     const sqk_u64x2* a2 = (const sqk_u64x2*)acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const sqk_u64x2 v = a2[i]; q[2 * i] = v.x; q[2 * i + 1] = v.y; any |= v.x | v.y; }
+    double m = V.mass[t]; const double pm = V.prior_mass[t];   // [r6] requested with the slots, not behind them: a flagged transcript nearly always has something to fold in
     if (!any) return;
-    double m = V.mass[t];
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       if ((uint32_t)w < nw && q[w]) { m = sq_log_add(m, FM.v[w] + sq_log(sq_from_fixed(q[w], SQ_MFRAC_BITS))); acc[w] = 0; }
     }
     V.mass[t] = m;
-    V.tlc[t] = sq_log_add(V.prior_mass[t], m);
+    V.tlc[t] = sq_log_add(pm, m);
     return;
   }
   double m = V.mass[t]; bool any = false;
@@ -918,160 +928,25 @@ __device__ __forceinline__ void apply_one(const OnlineView& V, const FmArr& FM, 
   V.mass[t] = m;
   V.tlc[t] = sq_log_add(V.prior_mass[t], m);
 }
-// [r4] a group's flagged transcripts: a block reads the flags of AP_TB_ * 8 transcripts (8 per thread, one load), gathers the
-// flagged ones in LDS (their order is free: every transcript is its own update) and shares them out evenly
+// [r4] a group's flagged transcripts: a block reads the flags of AP_TB_ * 4 transcripts (4 per thread, one load), gathers the
+// flagged ones in LDS (their order is free: every transcript is its own update) and shares them out evenly.  [r6] Four flags per thread, not eight: a quarter of the
+// transcripts are flagged in a group of 40 000 fragments, so with eight a thread had two transcripts to update one after the other — a third dependent trip to memory
+// in a kernel that is nothing but trips (flags -> mass slots -> done is two)
 __global__ void __launch_bounds__(AP_TB_) k_apply_flagged(OnlineView V, FmArr FM, uint32_t nw, const uint64_t* __restrict__ assigned_prefix, uint32_t r0, uint32_t r1,
     const uint8_t* __restrict__ flag) {
-  __shared__ uint32_t s_list[AP_TB_ * 8]; __shared__ uint32_t s_n;
+  __shared__ uint32_t s_list[AP_TB_ * 4]; __shared__ uint32_t s_n;
   if (blockIdx.x == 0 && threadIdx.x == 0) V.ctr[0] += (unsigned long long)(assigned_prefix[r1] - assigned_prefix[r0]);
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const uint32_t t0 = (blockIdx.x * AP_TB_ + threadIdx.x) * 8;
-  unsigned long long f = ((const unsigned long long*)flag)[blockIdx.x * AP_TB_ + threadIdx.x];
+  const uint32_t t0 = (blockIdx.x * AP_TB_ + threadIdx.x) * 4;
+  uint32_t f = ((const uint32_t*)flag)[blockIdx.x * AP_TB_ + threadIdx.x];
   if (f) {
-    uint32_t at = atomicAdd(&s_n, (uint32_t)__popcll(f));
-    while (f) { const int i = (__ffsll((long long)f) - 1) >> 3; s_list[at++] = t0 + (uint32_t)i; f &= ~(0xffull << (8 * i)); }
+    uint32_t at = atomicAdd(&s_n, (uint32_t)__popc(f));
+    while (f) { const int i = (__ffs((int)f) - 1) >> 3; s_list[at++] = t0 + (uint32_t)i; f &= ~(0xffu << (8 * i)); }
   }
   __syncthreads();
   const uint32_t n = s_n;
   for (uint32_t i = threadIdx.x; i < n; i += AP_TB_) apply_one(V, FM, nw, s_list[i]);
-}
-
-// [r6] The chain after burn-in as ONE launch per mapped batch.  A group used to be two launches (k_frag_dynamic, k_apply_flagged), ~30 us each for 40 000
-// fragments: three dependent trips to memory behind a launch, 125 times per 5 x 10^6-pair batch = 7.6 ms of the eq stream's 13.8.  k_chain keeps the workgroups
-// resident and puts a counter barrier where the launch boundaries were (two per group: the masses a group reads are the ones the group before left, and what
-// it adds must be in before it is folded).  What a group needs that does not depend on the model — the offsets and DynAln records of its fragments, the flag
-// word of its transcripts — is loaded while the previous group's barrier is waited for.  Cross-workgroup data (tlc, mass, mass_acc) moves by 8-byte agent-scope
-// atomic loads / stores / adds only (MI355X_MICROARCH "valid forms": no L1 or foreign-L2 copy is ever read), every wave drains its stores before it arrives.
-// Same arithmetic in the same order as the two kernels it replaces (tests: the chain against the checker, bit for bit; SQ_CHAIN=0 runs the launch pairs).
-// The barrier's spin is bounded: a workgroup that waits ~seconds raises cursor[3] (check_eq_overflow reports it) and every workgroup leaves.
-struct ChainArgs { uint32_t n, mb, ngroups, stride; const uint64_t* aln_off; const DynAln* dyn; const uint8_t* gcbin; const uint8_t* flag; const double* fm;
-                   const uint64_t* assigned_prefix; unsigned long long* bar; unsigned long long* fail; };
-__device__ __forceinline__ double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename F>
-__device__ __forceinline__ bool chain_barrier(const ChainArgs& A, uint32_t target, int* s_fail, F&& between) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores and atomics have been taken
-  __syncthreads();
-  if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(A.bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  between();   // loads that depend on nothing the other workgroups write: in flight while the others arrive
-  if (threadIdx.x == 0) {
-    uint32_t spins = 0; int fail = 0;
-    for (;;) {
-      if (__hip_atomic_load(A.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)target) break;
-      if ((++spins & 255u) == 0) {
-        if (__hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = 1; break; }
-        if (spins > (1u << 23)) { __hip_atomic_store(A.fail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fail = 1; break; }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    *s_fail = fail;
-  }
-  __syncthreads();
-  return *s_fail == 0;
-}
-__device__ __forceinline__ void chain_apply_one(const OnlineView& V, const double* __restrict__ fm, uint32_t nw, uint32_t t) {
-  unsigned long long* acc = V.mass_acc + (size_t)t * V.W;
-  if (V.W == 8) {
-    unsigned long long q[8]; unsigned long long any = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { q[i] = __hip_atomic_load(acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any |= q[i]; }
-    if (!any) return;
-    double m = ld_agent(V.mass + t);
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      if ((uint32_t)w < nw && q[w]) { m = sq_log_add(m, fm[w] + sq_log(sq_from_fixed(q[w], SQ_MFRAC_BITS))); __hip_atomic_store(acc + w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    }
-    st_agent(V.mass + t, m);
-    st_agent(V.tlc + t, sq_log_add(V.prior_mass[t], m));
-    return;
-  }
-  double m = ld_agent(V.mass + t); bool any = false;
-  for (uint32_t w = 0; w < nw; ++w) {
-    const unsigned long long q = __hip_atomic_load(acc + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!q) continue;
-    m = sq_log_add(m, fm[w] + sq_log(sq_from_fixed(q, SQ_MFRAC_BITS)));
-    __hip_atomic_store(acc + w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); any = true;
-  }
-  if (!any) return;
-  st_agent(V.mass + t, m);
-  st_agent(V.tlc + t, sq_log_add(V.prior_mass[t], m));
-}
-#define CH_PRE 3   // alignments of the thread's next fragment held in registers across the barrier (a fragment has 2-3 on average)
-__global__ void __launch_bounds__(AP_TB_, 4) k_chain(OnlineView V, ChainArgs A) {   // (four waves per SIMD: four workgroups fit a CU; the host asks for three per CU at most)
-  __shared__ uint32_t s_list[AP_TB_ * 8]; __shared__ uint32_t s_n; __shared__ int s_fail;
-  const uint32_t T = gridDim.x * AP_TB_, gt = blockIdx.x * AP_TB_ + threadIdx.x, G = gridDim.x;
-  const uint32_t gsize = A.mb * V.W, nwblk = A.stride / (AP_TB_ * 8);
-  uint32_t epoch = 0;
-  // what the thread's first fragment of the coming group needs, model apart
-  uint64_t pa0 = 0, pa1 = 0; unsigned long long pflag = 0;
-  double px0 = 0, ps0 = 0, px1 = 0, ps1 = 0, px2 = 0, ps2 = 0; uint32_t pt0 = 0, pk0 = 0, pt1 = 0, pk1 = 0, pt2 = 0, pk2 = 0;   // (aux, start, tid, keep) x CH_PRE, as scalars: they stay in registers
-#define CH_PREFETCH(g_) do { const uint32_t r0_ = (g_) * gsize, r1_ = min(A.n, r0_ + gsize), r_ = r0_ + gt; pa0 = pa1 = 0; \
-    if (r_ < r1_) { pa0 = A.aln_off[r_]; pa1 = A.aln_off[r_ + 1]; } \
-    if (pa0 < pa1) { const DynAln x_ = A.dyn[pa0]; px0 = x_.aux; ps0 = x_.start; pt0 = x_.tid; pk0 = x_.keep; } \
-    if (pa0 + 1 < pa1) { const DynAln x_ = A.dyn[pa0 + 1]; px1 = x_.aux; ps1 = x_.start; pt1 = x_.tid; pk1 = x_.keep; } \
-    if (pa0 + 2 < pa1) { const DynAln x_ = A.dyn[pa0 + 2]; px2 = x_.aux; ps2 = x_.start; pt2 = x_.tid; pk2 = x_.keep; } \
-    pflag = blockIdx.x < nwblk ? ((const unsigned long long*)(A.flag + (size_t)(g_) * A.stride))[blockIdx.x * AP_TB_ + threadIdx.x] : 0ull; } while (0)
-  CH_PREFETCH(0u);
-  for (uint32_t g = 0; g < A.ngroups; ++g) {
-    const uint32_t r0 = g * gsize, r1 = min(A.n, r0 + gsize);
-    const uint32_t nw = (r1 - r0 + A.mb - 1) / A.mb;
-    const double* fm = A.fm + (size_t)g * V.W;
-    // ---- the group's fragments: logProb from the masses as the last group left them, fixed-point increments (k_frag_dynamic) ----
-    for (uint32_t r = r0 + gt, it = 0; r < r1; r += T, ++it) {
-      uint64_t a0, a1;
-      if (it == 0) { a0 = pa0; a1 = pa1; } else { a0 = A.aln_off[r]; a1 = A.aln_off[r + 1]; }
-      if (a1 == a0) continue;
-      const uint32_t mbs = (r - r0) / A.mb;
-      double sumProbs = SQ_LOG_0; uint32_t nk = 0; double lp[4];
-      for (uint64_t ai = a0; ai < a1; ++ai) {
-        const uint32_t j = (uint32_t)(ai - a0);
-        DynAln d;
-        if (it == 0 && j < CH_PRE) { d.aux = j == 0 ? px0 : j == 1 ? px1 : px2; d.start = j == 0 ? ps0 : j == 1 ? ps1 : ps2; d.tid = j == 0 ? pt0 : j == 1 ? pt1 : pt2; d.keep = j == 0 ? pk0 : j == 1 ? pk1 : pk2; }
-        else d = A.dyn[ai];
-        if (!d.keep) continue;
-        const double logProb = ld_agent(V.tlc + d.tid) + d.aux + d.start;
-        if (nk < 4) { if (nk == 0) lp[0] = logProb; else if (nk == 1) lp[1] = logProb; else if (nk == 2) lp[2] = logProb; else lp[3] = logProb; }
-        sumProbs = sq_log_add(sumProbs, logProb); ++nk;
-      }
-      if (nk == 0) continue;
-      uint32_t ki = 0;
-      for (uint64_t ai = a0; ai < a1; ++ai) {
-        const uint32_t j = (uint32_t)(ai - a0);
-        DynAln d;
-        if (it == 0 && j < CH_PRE) { d.aux = j == 0 ? px0 : j == 1 ? px1 : px2; d.start = j == 0 ? ps0 : j == 1 ? ps1 : ps2; d.tid = j == 0 ? pt0 : j == 1 ? pt1 : pt2; d.keep = j == 0 ? pk0 : j == 1 ? pk1 : pk2; }
-        else d = A.dyn[ai];
-        if (!d.keep) continue;
-        double logProb;
-        if (ki < 4) { logProb = lp[0]; if (ki == 1) logProb = lp[1]; if (ki == 2) logProb = lp[2]; if (ki == 3) logProb = lp[3]; }
-        else logProb = ld_agent(V.tlc + d.tid) + d.aux + d.start;
-        ++ki;
-        const double pr = sq_exp(logProb - sumProbs);
-        const unsigned long long q = (unsigned long long)sq_to_fixed(pr, SQ_MFRAC_BITS);
-        if (q) (void)__hip_atomic_fetch_add(&V.mass_acc[(size_t)d.tid * V.W + mbs], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.gcbin && A.gcbin[ai] != 255) (void)__hip_atomic_fetch_add(&V.gc_obs[A.gcbin[ai]], (unsigned long long)sq_to_fixed(pr, 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (V.posbin) pos_observe(V, ai, pr);
-      }
-    }
-    if (!chain_barrier(A, ++epoch * G, &s_fail, [] {})) return;
-    // ---- the group's flagged transcripts: the mini-batches' increments folded in order (k_apply_flagged) ----
-    if (gt == 0) (void)__hip_atomic_fetch_add(&V.ctr[0], (unsigned long long)(A.assigned_prefix[r1] - A.assigned_prefix[r0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t wb = blockIdx.x, it = 0; wb < nwblk; wb += G, ++it) {
-      if (threadIdx.x == 0) s_n = 0;
-      __syncthreads();
-      const uint32_t t0 = (wb * AP_TB_ + threadIdx.x) * 8;
-      unsigned long long f = it == 0 ? pflag : ((const unsigned long long*)(A.flag + (size_t)g * A.stride))[wb * AP_TB_ + threadIdx.x];
-      if (f) {
-        uint32_t at = atomicAdd(&s_n, (uint32_t)__popcll(f));
-        while (f) { const int i = (__ffsll((long long)f) - 1) >> 3; s_list[at++] = t0 + (uint32_t)i; f &= ~(0xffull << (8 * i)); }
-      }
-      __syncthreads();
-      const uint32_t n = s_n;
-      for (uint32_t i = threadIdx.x; i < n; i += AP_TB_) chain_apply_one(V, fm, nw, s_list[i]);
-      __syncthreads();
-    }
-    if (!chain_barrier(A, ++epoch * G, &s_fail, [&] { if (g + 1 < A.ngroups) CH_PREFETCH(g + 1); })) return;
-  }
 }
 
 // batch end, part 1: masses (one thread per transcript); also refreshes the cached
@@ -1537,7 +1412,7 @@ void sq_online_free(sq_ctx* c) {
   o->pool_tid.free_();
   o->pool_bin.free_();
   o->pool_wq.free_();
-  o->pool_cursor.free_(); o->fm_dev.free_(); o->fm_dev_n = 0; o->chain_bar.free_();
+  o->pool_cursor.free_();
   delete o; c->online = nullptr;
 }
 
@@ -1559,7 +1434,6 @@ static int check_eq_overflow(sq_ctx* c) {
   mark("memcpyAsync");
   SQ_HIP_CHECK(hipStreamSynchronize(c->stream));   // not the null stream (device-wide implicit sync), not the eq streams (the runtime may still be retiring their thousands of launches)
   mark("streamSync");
-  if (cur[3]) { sq_set_error("internal: the mini-batch chain's workgroups did not all arrive at a barrier (k_chain gave up after its bounded wait); SQ_CHAIN=0 runs the chain as separate launches"); return SQ_ERR_STATE; }
   if (cur[2]) {
     sq_set_error("equivalence-class table overflow (%s): %llu classes, %llu labels", cur[2] == 1 ? "slots" : "label pool", cur[1], cur[0]);
     return SQ_ERR_OVERFLOW;
@@ -1729,36 +1603,13 @@ static int eq_accumulate_job(sq_ctx* c, const sq_ctx::eq_job& J) {
     k_frag_static<<<nblk(n), 256, 0, sq>>>(V, q, n, d_aln_off, (const PreAln*)o->pre.p, o->awq.p, o->abin.p, o->rh1.p, o->rh2.p, (DynAln*)o->dyn.p, TA);
     sq_prof_mark(c, SG_EQ_STATIC, 1);
     const uint32_t W = o->inflight;
-    static const bool chain_one = !(getenv("SQ_CHAIN") && atoi(getenv("SQ_CHAIN")) == 0);
-    if (chain_one && nmb) {
-      // [r6] the whole chain of the batch in one launch (k_chain).  The forgetting masses of every mini-batch to come are a table on the device (the schedule
-      // depends on nothing but the mini-batch's number): grown by doubling, uploaded again when it grows.
-      const uint64_t need = o->batch_no + nmb;
-      if (o->fm_dev_n < need) {
-        (void)forgetting_mass(o, q.forgetting_factor, std::max<uint64_t>(need * 2, 1u << 16) - 1);
-        const size_t tn = o->fm_host.size();
-        if (o->fm_dev.ensure(tn)) { sq_set_error("device allocation failed (forgetting masses)"); return SQ_ERR_NOMEM; }
-        SQ_HIP_CHECK(hipMemcpyAsync(o->fm_dev.p, o->fm_host.data(), tn * sizeof(double), hipMemcpyHostToDevice, st));
-        SQ_HIP_CHECK(hipStreamSynchronize(st));   // (once per doubling: the host table may move when it grows next)
-        o->fm_dev_n = tn;
-      }
-      if (o->chain_bar.ensure(8)) { sq_set_error("device allocation failed (chain barrier)"); return SQ_ERR_NOMEM; }
-      SQ_HIP_CHECK(hipMemsetAsync(o->chain_bar.p, 0, 8, st));
-      const uint32_t ngroups = (nmb + W - 1) / W;
-      ChainArgs CA{n, mb, ngroups, TA.stride, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin, TA.flag, o->fm_dev.p + o->batch_no, o->assigned_prefix.p, o->chain_bar.p, o->pool_cursor.p + 3};
-      // every workgroup must be resident (they wait for each other): at most three per CU of the stream's share of the chip — 160 x 256 threads = one per fragment of a default group
-      static const uint32_t chain_wgs = getenv("SQ_CHAIN_WGS") ? (uint32_t)std::max(1, atoi(getenv("SQ_CHAIN_WGS"))) : 160u;
-      const uint32_t cus = c->eq_cus > 0 ? (uint32_t)c->eq_cus : (uint32_t)std::max(8, c->ncu);   // with a partition the eq stage's CUs are never the mapping kernels'; without one the whole chip is shared
-      k_chain<<<std::min(chain_wgs, 3u * cus), AP_TB_, 0, st>>>(V, CA);
-      o->batch_no += nmb; o->group_no += ngroups; if (c->prof_on) c->eq_groups += ngroups;
-    } else
     for (uint32_t b = 0; b < nmb;) {
       FmArr FM; uint32_t nw = 0; const uint32_t b0 = b;
       while (b < nmb && nw < W) { FM.v[nw++] = forgetting_mass(o, q.forgetting_factor, o->batch_no++); ++b; }
       for (uint32_t i = nw; i < SQ_MAX_INFLIGHT; ++i) FM.v[i] = 0.0;
       const uint32_t r0 = b0 * mb, r1 = (uint32_t)std::min<uint64_t>((uint64_t)b * mb, n);
       k_frag_dynamic<<<(r1 - r0 + 255) / 256, 256, 0, st>>>(V, r0, r1, mb, d_aln_off, (const DynAln*)o->dyn.p, d_gcbin);
-      k_apply_flagged<<<TA.stride / (AP_TB_ * 8), AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.flag + (size_t)(b0 / W) * TA.stride);
+      k_apply_flagged<<<TA.stride / (AP_TB_ * 4), AP_TB_, 0, st>>>(V, FM, nw, o->assigned_prefix.p, r0, r1, TA.flag + (size_t)(b0 / W) * TA.stride);
       o->group_no++; if (c->prof_on) c->eq_groups++;
     }
   } else {

@@ -28,6 +28,12 @@ void sq_set_error(const char* fmt, ...) {
 extern "C" const char* sq_last_error(void) { return g_err; }
 extern "C" const char* sq_version(void) { return "salmon-hip 0.1 (salmon 1.11.4 hot-path semantics)"; }
 
+// [r6] where the builder's k-mer table is made: -2 = a GPU when there is one and the input is large enough to gain (default), -1 = the host, >= 0 = that device (an error if it cannot)
+static std::atomic<int> g_build_device{-2};
+extern "C" int sq_index_build_set_device(int device) { if (device < -2) { sq_set_error("sq_index_build_set_device: -2 (automatic), -1 (host) or a device number"); return SQ_ERR_ARG; } g_build_device.store(device); return SQ_OK; }
+int sq_index_breaks_dev(int device, const uint64_t* refseq, uint64_t refseq_words, const uint32_t* ref_len, const uint64_t* ref_accum, uint32_t nrefs, uint32_t k,
+                        uint64_t total_nt, uint64_t* brkR, uint64_t* brkL);   // hip/index_build_dev.hip
+
 namespace {
 
 inline int base_code(char c) {
@@ -162,7 +168,22 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
     bool term = right ? ((inf >> 8) & 1u) : ((inf >> 9) & 1u);
     return term || __builtin_popcount(msk) != 1;
   };
+  // [r6] with a GPU at hand the table is built there (hip/index_build_dev.hip: one partition in HBM, two launches); the host's passes below are what runs without one
+  bool on_device = false;
   {
+    const int choice = g_build_device.load();
+    const uint64_t min_pos = getenv("SQ_INDEX_DEVICE_MIN_POS") ? (uint64_t)atoll(getenv("SQ_INDEX_DEVICE_MIN_POS")) : 20000000ull;
+    if (choice >= 0 || (choice == -2 && npos >= min_pos)) {
+      const int rc = sq_index_breaks_dev(choice >= 0 ? choice : 0, rs, idx->refseq.size(), idx->ref_len.data(), idx->ref_accum.data(), nrefs, k, total_nt, brkR.data(), brkL.data());
+      if (rc == SQ_OK) on_device = true;
+      else if (choice >= 0) throw std::runtime_error(std::string("index builder on device ") + std::to_string(choice) + ": " + sq_last_error());
+      else {   // automatic choice: without a device the host builds (silently); anything else is said
+        if (rc != SQ_ERR_DEVICE) fprintf(stderr, "[salmon-hip] index: the k-mer table could not be built on the device (%s): building it on the host\n", sq_last_error());
+        std::fill(brkR.begin(), brkR.end(), 0); std::fill(brkL.begin(), brkL.end(), 0);
+      }
+    }
+  }
+  if (!on_device) {
     KTable T;
     double grow = 1.0;
     for (uint32_t part = 0; part < nparts_k; ++part) {
@@ -209,7 +230,7 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
       });
     }
   }
-  phase("k-mer table passes");
+  phase(on_device ? "k-mer table (device)" : "k-mer table passes");
   // ---- walk references: local boundary predicate -> segments (unitig occurrences) ----
   std::vector<std::vector<Seg>> rsegs(nrefs);
   sq_parallel_for(nrefs, nthreads, 16, [&](uint64_t b, uint64_t e, uint32_t) {
