@@ -131,16 +131,29 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   // ---- pack references (non-ACGT -> deterministic pseudo-random base; pufferfish fixFasta does
   // the same with an RNG) ----
   idx->refseq.assign((total_nt + 31) / 32 + 2, 0);
-  sq_parallel_for(nrefs, nthreads, 64, [&](uint64_t b, uint64_t e, uint32_t) {
-    for (uint64_t r = b; r < e; ++r) {
-      const std::string& s = seqs[r]; uint64_t g = idx->ref_accum[r];
-      for (size_t i = 0; i < s.size(); ++i) {
-        int c = base_code(s[i]);
-        if (c < 0) c = (int)(sq_mix64((r << 32) ^ i ^ 0x5bd1e995ULL) & 3);
-        __atomic_fetch_or(&idx->refseq[(g + i) >> 5], (uint64_t)c << (((g + i) & 31) * 2), __ATOMIC_RELAXED);
+  {
+    // [r6] in pieces of 4 M bases (a decoy chromosome is one reference of 10^8 nt: by reference, one thread packed a genome), a 64-bit word at a time: only a piece's
+    // first and last word can be shared with a neighbour, and only those are OR-ed atomically (21 s -> ~1 s for 3.5 Gnt on the GPU box's 16 cores)
+    struct PPiece { uint32_t r; uint32_t i0, i1; };
+    std::vector<PPiece> pp;
+    for (uint32_t r = 0; r < nrefs; ++r) { const uint32_t L = (uint32_t)seqs[r].size(); for (uint32_t i0 = 0; i0 < L; i0 += (4u << 20)) pp.push_back({r, i0, std::min(L, i0 + (4u << 20))}); }
+    sq_parallel_for(pp.size(), nthreads, 16, [&](uint64_t b, uint64_t e, uint32_t) {
+      for (uint64_t pi = b; pi < e; ++pi) {
+        const PPiece pc = pp[pi]; const uint64_t r = pc.r; const std::string& s = seqs[r]; const uint64_t g = idx->ref_accum[r];
+        const uint64_t w_first = (g + pc.i0) >> 5, w_last = (g + pc.i1 - 1) >> 5;
+        uint64_t cur_w = w_first, acc = 0;
+        auto flush = [&](uint64_t wi, uint64_t v) { if (wi == w_first || wi == w_last) __atomic_fetch_or(&idx->refseq[wi], v, __ATOMIC_RELAXED); else idx->refseq[wi] = v; };
+        for (uint32_t i = pc.i0; i < pc.i1; ++i) {
+          int c = base_code(s[i]);
+          if (c < 0) c = (int)(sq_mix64((r << 32) ^ (uint64_t)i ^ 0x5bd1e995ULL) & 3);
+          const uint64_t gp = g + i, wi = gp >> 5;
+          if (wi != cur_w) { flush(cur_w, acc); cur_w = wi; acc = 0; }
+          acc |= (uint64_t)c << ((gp & 31) * 2);
+        }
+        flush(cur_w, acc);
       }
-    }
-  });
+    });
+  }
   std::vector<std::string>().swap(seqs);  // free ASCII
   phase("pack references");
   const uint64_t* rs = idx->refseq.data();
@@ -507,15 +520,32 @@ static int build_core(const sq_index_opts* o, std::vector<std::string>& names, s
   idx->entries.clear();
   std::vector<uint64_t> skew_k, skew_v;
   uint64_t maxb = 0;
-  for (uint64_t s = 0; s < slot_key.size(); ++s) {
-    uint64_t ki = slot_key[s]; if (ki == ~0ULL) continue;
-    uint64_t a = kstart[ki], b = kstart[ki + 1], cnt = b - a; maxb = std::max(maxb, cnt);
-    if (cnt == 1) { idx->slots[s] = SQ_SLOT_INLINE | ents[a].e; continue; }
-    if (cnt >= (1ULL << 23)) { sq_set_error("minimizer bucket too large"); return SQ_ERR_OVERFLOW; }
-    idx->slots[s] = (uint64_t)idx->entries.size() | (cnt << SQ_POS_BITS);
-    for (uint64_t i = a; i < b; ++i) idx->entries.push_back(ents[i].e);
-    if (cnt > SQ_SKEW_THRESH) {
-      for (uint64_t i = a; i < b; ++i) {
+  {
+    // [r6] three steps instead of one thread's walk over every slot (33 s for the 3.5 Gnt index, most of it cache misses on `kstart` / `ents`): the buckets' sizes in
+    // parallel, their places in `entries` by one running sum in slot order (the order the walk gave them), the records and entry lists in parallel again.  The skew
+    // table's k-mers (buckets of more than SQ_SKEW_THRESH occurrences: few) are still collected in slot order by one thread.
+    const uint64_t NS = slot_key.size(); const uint64_t CH = 1u << 16; const uint64_t nch = (NS + CH - 1) / CH;
+    std::vector<uint64_t> ch_ent(nch + 1, 0), ch_max(nch, 0); std::atomic<int> too_large(0);
+    sq_parallel_for(nch, nthreads, 4, [&](uint64_t b, uint64_t e, uint32_t) {
+      for (uint64_t c = b; c < e; ++c) { uint64_t n = 0, mx = 0;
+        for (uint64_t s = c * CH; s < std::min(NS, (c + 1) * CH); ++s) { const uint64_t ki = slot_key[s]; if (ki == ~0ULL) continue; const uint64_t cnt = kstart[ki + 1] - kstart[ki]; mx = std::max(mx, cnt);
+          if (cnt >= (1ULL << 23)) too_large.store(1); if (cnt > 1) n += cnt; }
+        ch_ent[c + 1] = n; ch_max[c] = mx; }
+    });
+    if (too_large.load()) { sq_set_error("minimizer bucket too large"); return SQ_ERR_OVERFLOW; }
+    for (uint64_t c = 0; c < nch; ++c) { ch_ent[c + 1] += ch_ent[c]; maxb = std::max(maxb, ch_max[c]); }
+    idx->entries.resize(ch_ent[nch]);
+    sq_parallel_for(nch, nthreads, 4, [&](uint64_t b, uint64_t e, uint32_t) {
+      for (uint64_t c = b; c < e; ++c) { uint64_t at = ch_ent[c];
+        for (uint64_t s = c * CH; s < std::min(NS, (c + 1) * CH); ++s) { const uint64_t ki = slot_key[s]; if (ki == ~0ULL) continue; const uint64_t a = kstart[ki], bb = kstart[ki + 1], cnt = bb - a;
+          if (cnt == 1) { idx->slots[s] = SQ_SLOT_INLINE | ents[a].e; continue; }
+          idx->slots[s] = at | (cnt << SQ_POS_BITS);
+          for (uint64_t i = a; i < bb; ++i) idx->entries[at++] = ents[i].e; } }
+    });
+    if (maxb > SQ_SKEW_THRESH) for (uint64_t s = 0; s < NS; ++s) {
+      const uint64_t ki = slot_key[s]; if (ki == ~0ULL) continue; const uint64_t a = kstart[ki], bb = kstart[ki + 1];
+      if (bb - a <= SQ_SKEW_THRESH) continue;
+      for (uint64_t i = a; i < bb; ++i) {
         uint64_t u = ents[i].e >> SQ_APOS_BITS;
         for (uint32_t q = 0; q < ents[i].nk; ++q) {
           uint64_t st = ents[i].kstart + q;
