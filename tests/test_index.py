@@ -89,6 +89,30 @@ def test_polya_clipping_duplicates_and_short_refs(built):
     assert orc.check_cdbg(idx2) == 0
 
 
+def test_a_minimizer_with_many_occurrences_goes_through_the_skew_table(built, tmp_path):
+    # [r6] one 20-mer (chosen for a tiny minimizer hash: it is the minimizer of every k-mer that contains it) in 90 different contexts = a bucket of more than
+    # SQ_SKEW_THRESH occurrences: its k-mers are found through the skew table.  Every k-mer of every reference against the checker's own k-mer map, absent ones too;
+    # one thread and eight build the same file (the slot records are laid out in three parallel steps)
+    import hashlib, json
+    rng = np.random.default_rng(3); X = "CTATGTTGATCCAAAAGCAA"
+    R = lambda n: "".join("ACGT"[x] for x in rng.integers(0, 4, n))
+    names = ["s%d" % i for i in range(90)] + ["r%d" % i for i in range(120)]; seqs = [R(60) + X + R(60) for _ in range(90)] + [R(400) for _ in range(120)]
+    idx = api.SalmonIndex.build_mem(names, seqs, threads=8, outdir=str(tmp_path / "t8"))
+    info = json.load(open(os.path.join(str(tmp_path / "t8"), "info.json")))
+    assert info["max_bucket"] > 32 and info["num_skew_kmers"] > 500
+    assert orc.check_cdbg(idx) == 0
+    oi = orc.OrcIndex(idx); k = idx.k
+    for s_ in seqs[:90:7] + seqs[90::17]:
+        for p in range(len(s_) - k + 1):
+            x = enc(s_[p:p + k]); got = idx.lookup_host(x)
+            assert got is not None and got == oi.lookup(x)
+    for x in rng.integers(0, 1 << 62, 2000): assert idx.lookup_host(int(x)) == oi.lookup(int(x))
+    idx.free()
+    api.SalmonIndex.build_mem(names, seqs, threads=1, outdir=str(tmp_path / "t1")).free()
+    sha = lambda d: hashlib.sha256(open(os.path.join(str(tmp_path / d), "index.bin"), "rb").read()).hexdigest()
+    assert sha("t1") == sha("t8")
+
+
 def test_partitioned_kmer_table_builds_the_same_index(built, tmp_path, monkeypatch):
     # the builder's k-mer table under a tiny memory budget (dozens of hash partitions, SQ_INDEX_TABLE_GB) writes the same index file,
     # byte for byte, as the single pass; long unitigs (a decoy "chromosome") go through the 4 M-position pieces of the minimizer phase
