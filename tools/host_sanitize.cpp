@@ -24,6 +24,7 @@ void sq_dev_reader_close(sq_dev_reader*) {}
 #include "../salmon_amd/csrc/host/index.h"
 // the HIP side (hip/index_dev.hip) is not linked here: host-only stand-ins for its three entry points
 void sq_device_index_free(sq_device_index*) {}
+int sq_index_breaks_dev(int, const uint64_t*, uint64_t, const uint32_t*, const uint64_t*, uint32_t, uint32_t, uint64_t, uint64_t*, uint64_t*) { return SQ_ERR_DEVICE; }   // [r6] hip/index_build_dev.hip: without it the builder's host passes run
 extern "C" int sq_index_load(const char* dir, int, sq_index** out) { return sq_index_load_host(dir, out); }
 extern "C" void sq_index_free(sq_index* idx) { delete idx; }
 #define CHECK(x) do { if (!(x)) { fprintf(stderr, "FAILED %s:%d: %s  [%s]\n", __FILE__, __LINE__, #x, sq_last_error()); exit(1); } } while (0)
