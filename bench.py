@@ -91,12 +91,13 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
     L = read_len
     pk = 8 * ((L + 31) // 32) + 4 * ((L + 63) // 64) * 2     # packed read + N mask actually touched
     return {
-        "k_pack": nrec * (L + 8 + 64 + 32 + 2),
+        "k_pack": nrec * (L + 8 + 64 + 32 + 2 + 1),
         # [r6] k_seed2's own algorithmic bytes — what `roofline.frac` is quoted on: the packed words of a read end the kernel loads (32 B for reads of
-        # up to 128 bases, 64 B up to 256) + N mask + offsets, the 64-byte filter block once per run of probes that share a minimizer
+        # up to 128 bases, 64 B up to 256) + its length, the byte "this end has an N" (the 32-byte mask itself is read for those ends only: not charged) and the two
+        # counts it leaves, the 64-byte filter block once per run of probes that share a minimizer
         # (`filter_fills`, counted by the kernel), and per uni-MEM three dependent sectors (minimizer-table bucket, string-pool word, unitig bounds)
         # + extension words, contig-table bounds and its 32-byte record
-        "k_seed": nrec * ((32 if L <= 128 else 64) + 32 + 2 + 8) + st.get("filter_fills", st["num_lookups"]) * 64 + st["num_seeds"] * (3 * 64 + 16 + 16 + 32 + 16),
+        "k_seed": nrec * ((32 if L <= 128 else 64) + 1 + 2 + 8) + st.get("filter_fills", st["num_lookups"]) * 64 + st["num_seeds"] * (3 * 64 + 16 + 16 + 32 + 16),
         # round 4's model of the same job for the kernel k_seed2 replaced (one filter sector per PROBE, four dependent sectors per hit: pilot, slot
         # record, string-pool word, unitig bounds).  k_seed2 does not move these bytes; kept as a separately named field (`roofline.round4_model`)
         # so that rounds 3-5 can still be compared, never as `frac`

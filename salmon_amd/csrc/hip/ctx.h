@@ -106,7 +106,7 @@ struct sq_ctx {
   uint32_t read_words = SQ_READ_WORDS_MIN;   // stride of rpack (rnmask: half of it); raised when a batch holds reads of more than 32 * read_words bases
   hipStream_t stream = nullptr;
   // reads
-  sq_dbuf<uint8_t> seq; sq_dbuf<uint64_t> seq_off; sq_dbuf<uint64_t> rpack; sq_dbuf<uint64_t> rnmask; sq_dbuf<uint16_t> rlen;
+  sq_dbuf<uint8_t> seq; sq_dbuf<uint64_t> seq_off; sq_dbuf<uint64_t> rpack; sq_dbuf<uint64_t> rnmask; sq_dbuf<uint16_t> rlen; sq_dbuf<uint8_t> rany;   // rany [r6]: one byte per end, "its N-mask has a bit set" (k_seed2 asks this instead of reading the mask)
   // seeds / MEMs
   sq_dbuf<sq_unimem_dev> unimems; sq_dbuf<uint32_t> n_uni; sq_dbuf<uint32_t> n_proj; sq_dbuf<uint64_t> mem_off;
   sq_dbuf<uint64_t> mkey, mval, mkey2, mval2; sq_dbuf<uint8_t> sort_tmp; uint64_t mem_cap = 0;

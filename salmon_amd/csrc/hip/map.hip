@@ -185,7 +185,7 @@ static int ctx_create_lane(sq_index* idx, const sq_quant_opts* opts, int device,
   const uint32_t nends = 2 * max_batch_reads;
   bool bad = c->seq_off.ensure((size_t)nends + 2) || c->rpack.ensure((size_t)nends * c->read_words + 8) ||
       c->rnmask.ensure((size_t)nends * (c->read_words / 2) + 8) ||
-      c->rlen.ensure(nends) ||
+      c->rlen.ensure(nends) || c->rany.ensure(nends) ||
              c->unimems.ensure((size_t)nends * c->uni_slots) || c->n_uni.ensure(nends + 1) || c->n_proj.ensure(nends + 1) ||
                  c->mem_off.ensure((size_t)nends + 2) ||
              c->n_chains.ensure(nends + 1) || c->n_cand.ensure(max_batch_reads + 1) ||
@@ -236,7 +236,7 @@ extern "C" void sq_ctx_free(sq_ctx* c) {
   c->seq_off.free_();
   c->rpack.free_();
   c->rnmask.free_();
-  c->rlen.free_();
+  c->rlen.free_(); c->rany.free_();
   c->unimems.free_();
   c->n_uni.free_();
   c->n_proj.free_();
@@ -469,9 +469,9 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
   sq_prof_begin(c);
-  if (c->read_words == 8) k_pack<8><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
-  else if (c->read_words == 16) k_pack<16><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
-  else k_pack<32><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->stats.p);
+  if (c->read_words == 8) k_pack<8><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
+  else if (c->read_words == 16) k_pack<16><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
+  else k_pack<32><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
   sq_prof_mark(c, SG_PACK);
   {  // persistent grid: 256 CUs x 24 waves; lanes pull read ends from counters[2].  The probe rate is bound by the memory system once six waves per SIMD are resident
      // (profiles/r06_seed_grid.txt: 16 / 20 / 24 waves per CU 5.30 / 4.76 / 4.38 ms, 26 and 28 no faster), so two blocks' worth of wave slots per CU stay free for the
@@ -487,7 +487,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
       if (force_lw == 5 || force_lw == 8) c->seed_lw = std::max<uint32_t>(c->seed_lw, (uint32_t)force_lw);
       const uint32_t lw = c->seed_lw;
       // LDS per wave: (LW + 8) x 512 B -> 6 KB (LW 4) or [r6] 6.5 KB (LW 5: reads of up to 160 bases): 24 waves per CU and more; 8 KB (LW 8): 20
-#define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
+#define SQ_SEED2_ARGS di->dict, P, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->unimems.p, c->n_uni.p, c->n_proj.p, c->stats.p, c->counters.p + 2, c->read_words, c->uni_slots
       if (lw == 4) k_seed2<31, 20, 2, 4><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS); else if (lw == 5) k_seed2<31, 20, 2, 5><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
       else k_seed2<31, 20, 2, 8><<<grid2, SEED_TB, 0, st>>>(SQ_SEED2_ARGS);
 #undef SQ_SEED2_ARGS

@@ -72,7 +72,7 @@ __device__ inline uint32_t wave_alloc(uint32_t* ctr) {
 // dependent round trips — offsets, then bases — set the pace at 2.2 ms; here a wave covers 64 ends and there are 8x fewer waves.)
 template <uint32_t RW>   // packing stride in words: 8 (reads of up to 256 bases, the default), 16, 32
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
-                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, unsigned long long* __restrict__ stats) {
+                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, uint8_t* __restrict__ rany, unsigned long long* __restrict__ stats) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nrec) return;
   const uint64_t a = seq_off[e], b = seq_off[e + 1];
@@ -116,6 +116,10 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, c
 #pragma unroll
   for (uint32_t w = 0; w < RW / 2; w += 2) { sq_u64x2 v; v.x = (uint64_t)cn[2 * w] | ((uint64_t)cn[2 * w + 1] << 32); v.y = (uint64_t)cn[2 * w + 2] | ((uint64_t)cn[2 * w + 3] << 32); np[w / 2] = v; }
   rlen[e] = (uint16_t)L;
+  { uint32_t any = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RW; ++w) any |= cn[w];
+    rany[e] = any ? 1 : 0; }   // [r6] k_seed2 asks this byte (64 consecutive ends: one sector) instead of reading the end's 32-byte mask
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,7 +304,7 @@ __device__ inline uint64_t seed_lds_bases(const uint64_t (*rd)[SEED_TB], uint32_
 }
 template <int KT, int MT, int SEED_SPEC, int LW>
 __global__ void __launch_bounds__(SEED_TB) __attribute__((amdgpu_waves_per_eu(7))) k_seed2(sq_dict_view d, sq_map_params P, uint32_t nends,
-                       const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen,
+                       const uint64_t* __restrict__ rpack, const uint64_t* __restrict__ rnmask, const uint16_t* __restrict__ rlen, const uint8_t* __restrict__ rany,
                        sq_unimem_dev* __restrict__ um, uint32_t* __restrict__ n_uni, uint32_t* __restrict__ n_proj,
                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ cursor, uint32_t rw, uint32_t us) {
   static_assert(KT > 0 && MT > 0 && SEED_SPEC >= 1 && SEED_SPEC <= 2, "k_seed2 is the specialised kernel");
@@ -333,15 +337,14 @@ __global__ void __launch_bounds__(SEED_TB) __attribute__((amdgpu_waves_per_eu(7)
         L = rlen[e];
         // the read end moves into the lane's LDS column: all loads in flight together, 16 bytes each
         const sq_u64x2* rp = (const sq_u64x2*)(rpack + (size_t)e * rw);
-        const sq_u64x2* qn = (const sq_u64x2*)(rnmask + (size_t)e * (rw >> 1));
         sq_u64x2 v[(LW + 1) / 2];         // (an odd LW reads one word more than it keeps: still inside the end's row of rw >= 8 words)
 #pragma unroll
         for (int w = 0; w < (LW + 1) / 2; ++w) v[w] = rp[w];
-        const sq_u64x2 n0 = qn[0], n1 = qn[1];   // rw = 8: four mask words
+        const uint8_t hasN = rany[e];   // [r6] k_pack's byte "the mask has a bit set": the 32-byte mask itself stays where it is unless the end has an N
         if (L > 32 * LW) { atomicMax(&stats[ST_SEEDLW], (unsigned long long)L); L = 0; }   // does not fit this instantiation: nothing is seeded, the host runs a wider one (it learns the longest such end)
 #pragma unroll
         for (int w = 0; w < (LW + 1) / 2; ++w) { s_rd[2 * w][tx] = v[w].x; if (2 * w + 1 < LW) s_rd[2 * w + 1][tx] = v[w].y; }
-        anyN = (n0.x | n0.y | n1.x | n1.y) != 0;
+        anyN = hasN != 0;
       }
       pool_next += take;
       want = __ballot(!have && !drained);
