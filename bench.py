@@ -850,6 +850,19 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
         "mapping_roofline": roof if wl == "c5" else None,
         "cpu_baseline": cpu, "parity_check": parity, "from_fastq": fq, "jobs": jobs or None, "spread": spread,
     }
+    # DESIGN.md section 8's arithmetic on THIS run's own components, for every N a SCALE run takes: weak scaling keeps the mapping time and pays one exchange of the class
+    # tables (a table of N shards' classes also lengthens the replicated EM: not modelled — the figure is an upper bound); strong scaling (--workload c3) divides what
+    # lies behind the shared burn-in prefix.  A measured line at N ranks is to be read against "N" here.
+    try:
+        t_tail = dt - t_map; merge = {1: 0.0, 2: 0.003, 4: 0.004, 8: 0.005}
+        if strong:
+            t_rest1 = (t_map - t_prefix) * world   # what lies behind the prefix, summed over the ranks
+            pred = {str(n): round(total_pairs / 1e6 / (t_prefix + t_rest1 / n + merge[n] + (t_tail - t_merge)), 1) for n in (1, 2, 4, 8)}
+        else:
+            pred = {str(n): round(n * NP / 1e6 / (t_map + merge[n] + (t_tail - t_merge)), 1) for n in (1, 2, 4, 8)}
+        out["scaling_prediction"] = {"unit": "M read-pairs/s", "by_n_gpus": pred, "from": "this run's prefix / mapping / tail times (DESIGN.md section 8); merge 3-5 ms assumed; the replicated EM on the merged table of N shards is not modelled (weak: upper bound)"}
+    except Exception as e:
+        out["scaling_prediction"] = {"error": str(e)[:200]}
     ctx.free(); del batches, rbs; Wd.free(); torch.cuda.empty_cache()
     if extras and not leg and world == 1 and wl == "c2":
         # the same job on the round-1/2 index (T200k: 20 000 genes x ~10 isoforms, 5.3 alignments per fragment) — the workload the headline
