@@ -562,10 +562,9 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   if (hcls[2]) k_mems<16, MK_T_CAP, 256><<<(hcls[2] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(2));
   if (hcls[3]) k_mems<16, MK_S_CAP, 256><<<(hcls[3] + 15) / 16, 256, 0, st>>>(SQ_MEMS_ARGS(3));
   if (hcls[4]) k_mems<64, MK_L_CAP, 128><<<(hcls[4] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(4));
-  if (hcls[5]) k_mems<64, MK_M_CAP, 128><<<(hcls[5] + 1) / 2, 128, 0, st>>>(SQ_MEMS_ARGS(5));
 #undef SQ_MEMS_ARGS
   sq_prof_mark(c, SG_PROJECT);
-  if (nL) {   // ends with more than MK_M_CAP MEMs (deep repeats): compact projection, library radix sort, back into the slabs, HBM chaining
+  if (nL) {   // ends with more than MK_L_CAP MEMs (repeats): compact projection, library radix sort, back into the slabs, HBM chaining
     const size_t LP = (size_t)memsL + 8;
     if (c->mkey.ensure(LP) || c->mval.ensure(LP) || c->lkey.ensure(LP) || c->lval.ensure(LP) || c->cf.ensure(MP) || c->cp.ensure(MP) || c->mused.ensure(MP)) {
       sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }

@@ -9,8 +9,9 @@
 //   n <= 32    G = 16                                                                           k_mems<16, 32, 256>   18 KB
 //   n <= 64    G = 16                                                                           k_mems<16, 64, 256>   32 KB
 //   n <= 256   G = 64  (one wave per end, four MEMs per lane) [r3: the rank sort of a wave costs n x CAP / 64 compares whatever n is]   k_mems<64, 256, 128>
-//   n <= 1024  G = 64  (one wave per end, sixteen per lane)                                          k_mems<64, 1024, 128>
-//   larger     the round-1 path on a compacted list (k_project_list -> radix sort -> k_chain)
+//   larger     the flat passes over a compacted list (k_project_list -> radix sort -> k_lg_*).  [r6] A class of 257 .. 1024 MEMs (a wave per end, sixteen MEMs per lane,
+//              k_mems<64, 1024, 128>) existed until round 6: its chaining is a lane per transcript group, and an end of that size on a decoy chromosome is ONE group — on
+//              configs[3] it took 7.4 ms per 4 x 10^6 pairs where the flat passes take 5.0 for the same ends (profiles/r06_large_end_threshold.txt)
 // Lanes expand one occurrence each (coalesced contig-table loads, all gathers in flight), rank-sort the keys held
 // in LDS (stable: ties keep emission order, SPEC §a2), then every lane runs the chaining DP of whole transcripts.
 // Same arithmetic, same order of operations as the checker: results are bit-identical whatever the class.
@@ -23,16 +24,15 @@ namespace sqk {
 #define MK_T_CAP 32
 #define MK_S_CAP 64
 #define MK_L_CAP 256
-#define MK_M_CAP 1024
 
 __device__ inline void mk_wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// ends by size class; an end without MEMs has no chains.  Classes (MEMs per end): 0: <= 8 (eight lanes per end: k_mems<8, 8, 256>), 1: <= 16, 2: <= 32, 3: <= 64, 4: <= 256, 5: <= 1024,
-// 6: larger.  ctr[c] = ends in class c, ctr[7] = MEMs of the large ends.  Classes 0 and 1 share a kernel instantiation (as 2, 3 and 4
+// ends by size class; an end without MEMs has no chains.  Classes (MEMs per end): 0: <= 8 (eight lanes per end: k_mems<8, 8, 256>), 1: <= 16, 2: <= 32, 3: <= 64, 4: <= 256, 5: unused
+// since round 6 (its list stays empty), 6: larger.  ctr[c] = ends in class c, ctr[7] = MEMs of the large ends.  Classes 0 and 1 share a kernel instantiation (as 2, 3 and 4
 // have theirs) but are launched from their own lists: the four ends of a wave then cost about the same, and a wave waits for its
 // slowest end.  Blocks of 1024: the per-class counts of the 16 waves are summed in LDS, so a block costs at most seven cursor atomics.
 #define MK_NCLS 7
-__device__ inline int mk_class(uint32_t n) { return n <= 8 ? 0 : (n <= MK_X_CAP ? 1 : (n <= MK_T_CAP ? 2 : (n <= MK_S_CAP ? 3 : (n <= MK_L_CAP ? 4 : (n <= MK_M_CAP ? 5 : 6))))); }
+__device__ inline int mk_class(uint32_t n) { return n <= 8 ? 0 : (n <= MK_X_CAP ? 1 : (n <= MK_T_CAP ? 2 : (n <= MK_S_CAP ? 3 : (n <= MK_L_CAP ? 4 : 6)))); }
 // A list entry carries what k_mems needs to start on the end — slab offset, MEM and uni-MEM counts, read length — so that its first load
 // is its only load before the uni-MEM records: x = end, y = MEMs | uni-MEMs << 16 | length << 22, (z, w) = slab offset.
 __global__ void __launch_bounds__(1024) k_mem_classes(uint32_t nends, const uint32_t* __restrict__ n_proj, const uint64_t* __restrict__ mem_off,
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(TBK) k_mems(const uint64_t* __restrict__ uoff,
   // the MEM total is the scan's last element and the chains are counted per fragment in k_count_kmer_frags
 }
 
-// ---- the rare large ends (more than MK_M_CAP MEMs): projection into a compact buffer, library radix sort, scatter back ----
+// ---- the large ends (more than MK_L_CAP MEMs): projection into a compact buffer, library radix sort, scatter back ----
 __global__ void k_project_list(sq_dict_view d, const uint64_t* __restrict__ ctab_off, const uint64_t* __restrict__ ctab, const uint64_t* __restrict__ ref_accum,
                                sq_map_params P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ lbase, uint32_t nlist,
                                const uint16_t* __restrict__ rlen, const sq_unimem_dev* __restrict__ um, uint32_t us, const uint32_t* __restrict__ n_uni,
