@@ -576,7 +576,6 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = c->sort_tmp.n;
     SQ_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (size_t)memsL, 0u, (unsigned)(40 + endbits), st));
-    k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->mem_off.p, skey, sval);
     {   // [r4] flat passes over the sorted compact records (mem_kernels.h: k_lg_*); cf / cp / mused are indexed by compact record here
       if (c->lg_a.ensure(LP) || c->lg_b.ensure(LP) || c->lg_c.ensure(LP) || c->lg_d.ensure(LP) || c->lg_flags.ensure(LP) || c->lg_first.ensure((size_t)nrec + 8) || c->lg_cnt.ensure(8)) {
         sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }
@@ -594,6 +593,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
       if (int rc = tmp_for(std::max(std::max(t1, t2), std::max(t3, t4)))) return rc;
       size_t tb = c->sort_tmp.n;
       SQ_HIP_CHECK(rocprim::inclusive_scan(c->sort_tmp.p, tb, se_in, se, (size_t)memsL, LgMaxPair(), st));
+      k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, se, c->mem_off.p, skey, sval);   // the sorted records into the ends' slabs (what scoring reads)
       tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::select(c->sort_tmp.p, tb, cnt_it, cl_it, cl_start, c->lg_cnt.p, (size_t)memsL, st));
       k_lg_dp<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, c->lkey.p, c->lval.p, se, P, c->gapcost.p, c->cf.p, c->cp.p, c->mused.p, gbest);
       k_lg_accept<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, se, P, c->cf.p, c->cp.p, c->mused.p, gbest, ebest);
