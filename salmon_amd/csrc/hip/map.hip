@@ -572,31 +572,37 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
         c->n_uni.p, c->mkey.p, c->mval.p);
     int endbits = 1; while ((1ull << endbits) < nrec) ++endbits;
     size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (size_t)memsL, 0u, (unsigned)(40 + endbits), st);
+    // [r6] every end's records lie together in the compact projection (k_mem_classes hands each large end a run of n_proj[e] records), so the sort by (end, position) is a
+    // SEGMENTED sort by position alone: a block per end sorts its run in LDS (one trip through memory for an end of up to 4 096 MEMs, where the sort of the whole buffer by
+    // 40 + endbits bits made eight).  Stable, as the whole-buffer sort was: MEMs at the same position keep their emission order.  The ends then stand in the order the cursor
+    // handed out their runs, not by end id — nothing behind this point asks for that (boundaries are found by comparing neighbours, the chains are grouped by a sort of their own).
+    int posbits = 1; while (posbits < 40 && (1ull << posbits) < c->idx->ref_accum.back()) ++posbits;
+    rocprim::counting_iterator<uint32_t> seg_it(0u);
+    typedef rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, LgSegBound, uint32_t> SegIt;
+    SegIt seg_begin(seg_it, LgSegBound{c->mlbase.p, list_l, c->n_proj.p, 0u}), seg_end(seg_it, LgSegBound{c->mlbase.p, list_l, c->n_proj.p, 1u});
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, memsL, nL, seg_begin, seg_end, 0u, (unsigned)posbits, st);
     if (c->sort_tmp.ensure(tmp + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; }
     tmp = c->sort_tmp.n;
-    SQ_HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, (size_t)memsL, 0u, (unsigned)(40 + endbits), st));
+    SQ_HIP_CHECK(rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, tmp, c->mkey.p, c->lkey.p, c->mval.p, c->lval.p, memsL, nL, seg_begin, seg_end, 0u, (unsigned)posbits, st));
     {   // [r4] flat passes over the sorted compact records (mem_kernels.h: k_lg_*); cf / cp / mused are indexed by compact record here
       if (c->lg_a.ensure(LP) || c->lg_b.ensure(LP) || c->lg_c.ensure(LP) || c->lg_d.ensure(LP) || c->lg_flags.ensure(LP) || c->lg_first.ensure((size_t)nrec + 8) || c->lg_cnt.ensure(8)) {
         sq_set_error("device allocation failed for %u MEMs of large read ends; split the batch", memsL); return SQ_ERR_NOMEM; }
       uint64_t* se_in = c->mkey.p; uint64_t* se = c->mval.p;   // the unsorted compact projection is dead once it is sorted
-      uint64_t* gbest = c->lg_a.p; uint64_t* ebest = c->lg_b.p; uint32_t* cl_start = c->lg_c.p;
+      uint64_t* gbest = c->lg_a.p; uint64_t* ebest = c->lg_b.p;
       k_lg_flags<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, c->lg_flags.p, se_in, gbest, ebest, c->n_chains.p);
       auto tmp_for = [&](size_t need) -> int { if (c->sort_tmp.ensure(need + 256)) { sq_set_error("sort temp allocation failed"); return SQ_ERR_NOMEM; } return SQ_OK; };
-      size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+      size_t t1 = 0, t3 = 0, t4 = 0;
       rocprim::counting_iterator<uint32_t> cnt_it(0u);
-      rocprim::transform_iterator<const uint8_t*, LgIsCluster, uint8_t> cl_it(c->lg_flags.p, LgIsCluster());
       (void)rocprim::inclusive_scan(nullptr, t1, se_in, se, (size_t)memsL, LgMaxPair(), st);
-      (void)rocprim::select(nullptr, t2, cnt_it, cl_it, cl_start, c->lg_cnt.p, (size_t)memsL, st);
       (void)rocprim::radix_sort_pairs(nullptr, t3, c->lg_a.p, c->lg_b.p, c->lg_d.p, c->lg_c.p, (size_t)memsL, 0u, 64u, st);
       (void)rocprim::select(nullptr, t4, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (size_t)memsL, st);
-      if (int rc = tmp_for(std::max(std::max(t1, t2), std::max(t3, t4)))) return rc;
+      if (int rc = tmp_for(std::max(t1, std::max(t3, t4)))) return rc;
       size_t tb = c->sort_tmp.n;
       SQ_HIP_CHECK(rocprim::inclusive_scan(c->sort_tmp.p, tb, se_in, se, (size_t)memsL, LgMaxPair(), st));
       k_scatter_sorted<<<nblk(memsL), TB, 0, st>>>(memsL, c->lkey.p, c->lval.p, se, c->mem_off.p, skey, sval);   // the sorted records into the ends' slabs (what scoring reads)
-      tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::select(c->sort_tmp.p, tb, cnt_it, cl_it, cl_start, c->lg_cnt.p, (size_t)memsL, st));
-      k_lg_dp<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, c->lkey.p, c->lval.p, se, P, c->gapcost.p, c->cf.p, c->cp.p, c->mused.p, gbest);
-      k_lg_accept<<<nblk(memsL), TB, 0, st>>>(c->lg_cnt.p, memsL, cl_start, se, P, c->cf.p, c->cp.p, c->mused.p, gbest, ebest);
+      const uint32_t lg_cap = LG_T + (getenv("SQ_LG_OVERHANG") ? (uint32_t)std::min(std::max(atoi(getenv("SQ_LG_OVERHANG")), 0), (int)LG_O) : LG_O);   // (tests: 0 sends every cluster that crosses a tile's edge through the global-memory path)
+      k_lg_dp2<<<(memsL + LG_T - 1) / LG_T, LG_TB, 0, st>>>(memsL, lg_cap, c->lkey.p, c->lval.p, c->lg_flags.p, se, P, c->gapcost.p, c->cf.p, c->cp.p, c->mused.p, gbest);
+      k_lg_accept2<<<(memsL + LG_T - 1) / LG_T, LG_TB, 0, st>>>(memsL, lg_cap, c->lg_flags.p, se, P, c->cf.p, c->cp.p, c->mused.p, gbest, ebest);
       k_lg_keep<<<nblk(memsL), TB, 0, st>>>(memsL, se, P, c->cf.p, c->mused.p, ebest, c->lg_flags.p);
       tb = c->sort_tmp.n; SQ_HIP_CHECK(rocprim::select(c->sort_tmp.p, tb, cnt_it, (const uint8_t*)c->lg_flags.p, c->lg_d.p, c->lg_cnt.p + 1, (size_t)memsL, st));
       uint32_t nkept = 0;

@@ -348,7 +348,9 @@ __global__ void k_scatter_sorted(uint64_t total, const uint64_t* __restrict__ sk
 struct LgMaxPair { __host__ __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const {
   const uint32_t ah = (uint32_t)(a >> 32), bh = (uint32_t)(b >> 32), al = (uint32_t)a, bl = (uint32_t)b;
   return ((uint64_t)(ah > bh ? ah : bh) << 32) | (uint64_t)(al > bl ? al : bl); } };
-struct LgIsCluster { __host__ __device__ __forceinline__ uint8_t operator()(uint8_t f) const { return (uint8_t)(f & LG_CL); } };
+// start / end of large end i's run in the compact projection (the runs tile the buffer in the order the cursor handed them out)
+struct LgSegBound { const uint32_t* lbase; const uint32_t* list; const uint32_t* n_proj; uint32_t end;
+  __host__ __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return lbase[i] + (end ? n_proj[list[i]] : 0u); } };
 // flags per record + the input of the running-maximum scan (hi: index of the end's first record, lo: of the group's); group / end maxima start at 0
 __global__ void k_lg_flags(uint32_t total, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, uint8_t* __restrict__ flags,
                            uint64_t* __restrict__ se_in, uint64_t* __restrict__ gbest, uint64_t* __restrict__ ebest, uint32_t* __restrict__ n_chains) {
@@ -371,60 +373,126 @@ struct LgMem { int32_t r, q, len; uint32_t fw; };
 __device__ __forceinline__ LgMem lg_mem(const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval, uint32_t i, uint64_t r0) {
   const uint64_t v = sval[i]; LgMem m; m.r = (int32_t)((skey[i] & ((1ull << 40) - 1)) - r0); m.q = (int32_t)((v >> 10) & 1023); m.len = (int32_t)(v & 1023); m.fw = (uint32_t)((v >> 20) & 1); return m;
 }
-// one thread per cluster: the chaining DP (f in cf, predecessor in cp as a compact index), the group's best f
-__global__ void k_lg_dp(const uint32_t* __restrict__ ncl_p, uint32_t total, const uint32_t* __restrict__ cl_start, const uint64_t* __restrict__ skey, const uint64_t* __restrict__ sval,
-                        const uint64_t* __restrict__ se, sq_map_params P, const double* __restrict__ gapcost, double* __restrict__ cf, int32_t* __restrict__ cp,
-                        uint8_t* __restrict__ mused, uint64_t* __restrict__ gbest) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t ncl = *ncl_p; if (t >= ncl) return;
-  const uint32_t s0 = cl_start[t], s1 = t + 1 < ncl ? cl_start[t + 1] : total;
-  const uint64_t r0 = skey[s0] & ((1ull << 40) - 1);   // positions relative to the cluster's first MEM: only differences enter
-  double best = 0.0;
-  for (uint32_t i = s0; i < s1; ++i) {
-    const LgMem hi = lg_mem(skey, sval, i, r0);
-    double fi = (double)hi.len; int pi = -1; int rounds = 2;
-    for (int j = (int)i - 1; j >= (int)s0; --j) {
-      const LgMem hj = lg_mem(skey, sval, (uint32_t)j, r0);
-      if (hi.r - hj.r > SQ_MAX_CHAIN_GAP) break;
-      if (hj.fw != hi.fw) continue;
-      const int qd = hi.q - hj.q, rd = hi.r - hj.r;
-      if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
-      const int l = abs(qd - rd);
-      const double a = (double)min(hi.len, min(qd, rd));
-      const double sc = cf[j] + a - gapcost[l];
-      if (sc > fi) { fi = sc; pi = j; }
-      if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
-    }
-    cf[i] = fi; cp[i] = pi; mused[i] = 0;
-    if (fi > best) best = fi;
+// ---- [r6] the DP and the acceptance over TILES of the sorted records, in LDS ----
+// A thread per cluster walking global memory (round 4's k_lg_dp / k_lg_accept) pays a trip to memory per MEM it looks at, and the 64 clusters of a wave lie ~70 bytes apart: every
+// load is 64 lines.  On configs[3] a batch has 77 M such records in 8.9 M clusters (8.6 MEMs on average, 120 at most; 1.7 looks back per MEM): 6.2 + 2.2 ms.  Here a block owns the
+// clusters that START in its tile of LG_T records: the tile and LG_O records behind it are loaded once, coalesced, the cluster starts are compacted from the flags, a thread takes a
+// cluster and works in LDS (a record = one 16-byte word: position and packed MEM in 61 bits, f beside them), results leave coalesced.  A cluster that runs past the loaded records
+// (none does on configs[3]) continues in global memory: same operations in the same order on the same values either way.
+#define LG_T 1024u
+#define LG_O 128u
+#define LG_N (LG_T + LG_O)
+#define LG_TB 128u
+#define LG_POS_MASK ((1ull << 40) - 1)
+struct LgRec { uint64_t pv; double f; };   // pv = position << 21 | fw << 20 | q << 10 | len
+__device__ __forceinline__ uint64_t lg_pv(uint64_t key, uint64_t val) { return ((key & LG_POS_MASK) << 21) | (val & 0x1FFFFFull); }
+// local start indices of the clusters that start in [0, nown) into s_cl (ascending), *s_end = where the last one ends (local; may lie beyond the loaded records); returns their count.
+// s_flag: the loaded records' flags (the low byte of a 16-bit word: the array is the predecessor distances' afterwards)
+__device__ inline uint32_t lg_tile_clusters(const uint8_t* __restrict__ flags, uint32_t total, uint32_t T0, uint32_t nown, uint32_t nload, const uint16_t* s_flag, uint16_t* s_cl, uint32_t* s_cnt, uint32_t* s_end) {
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr uint32_t R = LG_T / LG_TB, W = LG_TB / 64;
+  unsigned long long b[R];
+#pragma unroll
+  for (uint32_t r = 0; r < R; ++r) { const uint32_t i = r * LG_TB + threadIdx.x; b[r] = __ballot(i < nown && (s_flag[i] & LG_CL)); if (lane == 0) s_cnt[r * W + wv] = (uint32_t)__popcll(b[r]); }
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t k = 0; k < LG_T / 64; ++k) { const uint32_t v = s_cnt[k]; s_cnt[k] = t; t += v; } s_cnt[LG_T / 64] = t; }
+  __syncthreads();
+  const uint32_t ncl = s_cnt[LG_T / 64];
+#pragma unroll
+  for (uint32_t r = 0; r < R; ++r) { const uint32_t i = r * LG_TB + threadIdx.x; if ((b[r] >> lane) & 1) s_cl[s_cnt[r * W + wv] + (uint32_t)__popcll(b[r] & ((1ull << lane) - 1))] = (uint16_t)i; }
+  if (threadIdx.x == 0 && ncl) {
+    uint32_t i = nown;
+    while (T0 + i < total) { const uint32_t f = i < nload ? (uint32_t)s_flag[i] : (uint32_t)flags[T0 + i]; if (f & LG_CL) break; ++i; }
+    *s_end = i;
   }
-  atomicMax((unsigned long long*)&gbest[(uint32_t)se[s0]], (unsigned long long)__double_as_longlong(best));   // f > 0: the bit pattern orders like the value
+  __syncthreads();
+  return ncl;
 }
-// one thread per cluster: chain ends by (score desc, index asc) among the cluster's MEMs over the group's threshold; a chain that runs into
-// an accepted one is dropped (SPEC §a2).  mused: 1 member of an accepted chain, 2 tried and dropped, 4 the last MEM of an accepted chain
-__global__ void k_lg_accept(const uint32_t* __restrict__ ncl_p, uint32_t total, const uint32_t* __restrict__ cl_start, const uint64_t* __restrict__ se, sq_map_params P,
-                            const double* __restrict__ cf, const int32_t* __restrict__ cp, uint8_t* __restrict__ mused, const uint64_t* __restrict__ gbest,
-                            uint64_t* __restrict__ ebest) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t ncl = *ncl_p; if (t >= ncl) return;
-  const uint32_t s0 = cl_start[t], s1 = t + 1 < ncl ? cl_start[t + 1] : total;
-  const uint64_t sev = se[s0];
-  const double thr = P.pre_thr * __longlong_as_double((long long)gbest[(uint32_t)sev]);
-  double top = 0.0;
-  for (;;) {
-    int bi = -1; double bf = 0.0;
+__global__ void __launch_bounds__(LG_TB) k_lg_dp2(uint32_t total, uint32_t ncap /* records a block loads: LG_T .. LG_N (tests lower it to send clusters across the edge) */, const uint64_t* __restrict__ skey,
+                                                  const uint64_t* __restrict__ sval, const uint8_t* __restrict__ flags, const uint64_t* __restrict__ se, sq_map_params P,
+                                                  const double* __restrict__ gapcost, double* __restrict__ cf, int32_t* __restrict__ cp, uint8_t* __restrict__ mused, uint64_t* __restrict__ gbest) {
+  __shared__ LgRec s_rec[LG_N]; __shared__ double s_gap[SQ_MAX_CHAIN_GAP + 1]; __shared__ uint32_t s_cnt[LG_T / 64 + 1]; __shared__ uint32_t s_end; __shared__ uint16_t s_cp[LG_N]; __shared__ uint16_t s_cl[LG_T];
+  const uint32_t T0 = blockIdx.x * LG_T; const uint32_t nown = min(LG_T, total - T0), nload = min(ncap, total - T0);
+  for (uint32_t i = threadIdx.x; i < nload; i += LG_TB) { s_rec[i].pv = lg_pv(skey[T0 + i], sval[T0 + i]); s_cp[i] = flags[T0 + i]; }
+  for (uint32_t i = threadIdx.x; i <= SQ_MAX_CHAIN_GAP; i += LG_TB) s_gap[i] = gapcost[i];
+  __syncthreads();
+  const uint32_t ncl = lg_tile_clusters(flags, total, T0, nown, nload, s_cp, s_cl, s_cnt, &s_end);
+  if (ncl == 0) return;
+  for (uint32_t c = threadIdx.x; c < ncl; c += LG_TB) {
+    const uint32_t s0 = s_cl[c], s1 = c + 1 < ncl ? (uint32_t)s_cl[c + 1] : s_end;
+    double best = 0.0;
     for (uint32_t i = s0; i < s1; ++i) {
-      if (mused[i]) continue;
-      const double fv = cf[i];
-      if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; }
+      const uint64_t ipv = i < nload ? s_rec[i].pv : lg_pv(skey[T0 + i], sval[T0 + i]);
+      const int iq = (int)((ipv >> 10) & 1023), il = (int)(ipv & 1023); const uint32_t ifw = (uint32_t)(ipv >> 20) & 1u; const int64_t ip = (int64_t)(ipv >> 21);
+      double fi = (double)il; int pi = -1; int rounds = 2;
+      for (int j = (int)i - 1; j >= (int)s0; --j) {
+        uint64_t jpv; double jf;
+        if ((uint32_t)j < nload) { const LgRec r = s_rec[j]; jpv = r.pv; jf = r.f; } else { jpv = lg_pv(skey[T0 + j], sval[T0 + j]); jf = cf[T0 + j]; }
+        const int64_t rd64 = ip - (int64_t)(jpv >> 21);
+        if (rd64 > SQ_MAX_CHAIN_GAP) break;
+        if (((uint32_t)(jpv >> 20) & 1u) != ifw) continue;
+        const int rd = (int)rd64, qd = iq - (int)((jpv >> 10) & 1023);
+        if (qd < 0 || max(qd, rd) > SQ_MAX_CHAIN_GAP) continue;
+        const int l = abs(qd - rd);
+        const double a = (double)min(il, min(qd, rd));
+        const double sc = jf + a - s_gap[l];
+        if (sc > fi) { fi = sc; pi = j; }
+        if (!P.no_heuristic && pi >= 0) { if (--rounds <= 0) break; }
+      }
+      if (i < nload) { s_rec[i].f = fi; s_cp[i] = pi >= 0 ? (uint16_t)(i - (uint32_t)pi) : (uint16_t)0; }
+      else { cf[T0 + i] = fi; cp[T0 + i] = pi >= 0 ? (int32_t)(T0 + (uint32_t)pi) : -1; mused[T0 + i] = 0; }
+      if (fi > best) best = fi;
     }
-    if (bi < 0) break;
-    bool clash = false;
-    for (int x = bi; x >= 0; x = cp[x]) if (mused[x] & 1) { clash = true; break; }
-    if (clash) { mused[bi] |= 2; continue; }
-    for (int x = bi; x >= 0; x = cp[x]) mused[x] |= 1;
-    mused[bi] |= 4;
-    if (bf > top) top = bf;
+    atomicMax((unsigned long long*)&gbest[(uint32_t)se[T0 + s0]], (unsigned long long)__double_as_longlong(best));   // f > 0: the bit pattern orders like the value
   }
-  if (top > 0.0) atomicMax((unsigned long long*)&ebest[(uint32_t)(sev >> 32)], (unsigned long long)__double_as_longlong(top));
+  __syncthreads();
+  const uint32_t lo = s_cl[0], hi = min(s_end, nload);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += LG_TB) { cf[T0 + i] = s_rec[i].f; const uint32_t d = s_cp[i]; cp[T0 + i] = d ? (int32_t)(T0 + i - d) : -1; mused[T0 + i] = 0; }
+}
+// chain ends by (score desc, index asc) among the cluster's MEMs over the group's threshold; a chain that runs into an accepted one is dropped (SPEC §a2).
+// mused: 1 member of an accepted chain, 2 tried and dropped, 4 the last MEM of an accepted chain
+__global__ void __launch_bounds__(LG_TB) k_lg_accept2(uint32_t total, uint32_t ncap, const uint8_t* __restrict__ flags, const uint64_t* __restrict__ se, sq_map_params P, const double* __restrict__ cf,
+                                                      const int32_t* __restrict__ cp, uint8_t* __restrict__ mused, const uint64_t* __restrict__ gbest, uint64_t* __restrict__ ebest) {
+  __shared__ double s_cf[LG_N]; __shared__ uint32_t s_cnt[LG_T / 64 + 1]; __shared__ uint32_t s_end; __shared__ uint16_t s_cp[LG_N]; __shared__ uint16_t s_fm[LG_N]; __shared__ uint16_t s_cl[LG_T];
+  const uint32_t T0 = blockIdx.x * LG_T; const uint32_t nown = min(LG_T, total - T0), nload = min(ncap, total - T0);
+  for (uint32_t i = threadIdx.x; i < nload; i += LG_TB) { s_cf[i] = cf[T0 + i]; const int32_t p = cp[T0 + i]; s_cp[i] = p >= 0 ? (uint16_t)(T0 + i - (uint32_t)p) : (uint16_t)0; s_fm[i] = flags[T0 + i]; }
+  __syncthreads();
+  const uint32_t ncl = lg_tile_clusters(flags, total, T0, nown, nload, s_fm, s_cl, s_cnt, &s_end);
+  if (ncl == 0) return;
+  for (uint32_t i = threadIdx.x; i < nload; i += LG_TB) s_fm[i] = 0;    // the flags are done with: the array holds `mused` from here on
+  __syncthreads();
+  // (a predecessor's distance fits 16 bits for every record in LDS: it lies in the same cluster, which starts in this tile)
+#define LG_CF(i) ((i) < nload ? s_cf[i] : cf[T0 + (i)])
+#define LG_MU(i) ((i) < nload ? (uint32_t)s_fm[i] : (uint32_t)mused[T0 + (i)])
+#define LG_PREV(x) ((uint32_t)(x) < nload ? (s_cp[x] ? (int)(x) - (int)s_cp[x] : -1) : (cp[T0 + (x)] >= 0 ? (int)((uint32_t)cp[T0 + (x)] - T0) : -1))
+  for (uint32_t c = threadIdx.x; c < ncl; c += LG_TB) {
+    const uint32_t s0 = s_cl[c], s1 = c + 1 < ncl ? (uint32_t)s_cl[c + 1] : s_end;
+    const uint64_t sev = se[T0 + s0];
+    const double thr = P.pre_thr * __longlong_as_double((long long)gbest[(uint32_t)sev]);
+    double top = 0.0;
+    for (;;) {
+      int bi = -1; double bf = 0.0;
+      for (uint32_t i = s0; i < s1; ++i) {
+        if (LG_MU(i)) continue;
+        const double fv = LG_CF(i);
+        if (fv >= thr && (bi < 0 || fv > bf)) { bi = (int)i; bf = fv; }
+      }
+      if (bi < 0) break;
+      bool clash = false;
+      for (int x = bi; x >= 0; x = LG_PREV(x)) if (LG_MU((uint32_t)x) & 1) { clash = true; break; }
+      if (clash) { if ((uint32_t)bi < nload) s_fm[bi] |= 2; else mused[T0 + bi] |= 2; continue; }
+      for (int x = bi; x >= 0; x = LG_PREV(x)) { if ((uint32_t)x < nload) s_fm[x] |= 1; else mused[T0 + x] |= 1; }
+      if ((uint32_t)bi < nload) s_fm[bi] |= 4; else mused[T0 + bi] |= 4;
+      if (bf > top) top = bf;
+    }
+    if (top > 0.0) atomicMax((unsigned long long*)&ebest[(uint32_t)(sev >> 32)], (unsigned long long)__double_as_longlong(top));
+  }
+#undef LG_CF
+#undef LG_MU
+#undef LG_PREV
+  __syncthreads();
+  const uint32_t lo = s_cl[0], hi = min(s_end, nload);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += LG_TB) mused[T0 + i] = (uint8_t)s_fm[i];
 }
 // hitFilterPolicy AFTER + consensus fraction over the end's chains (k_chain's last loop): which accepted chains stay
 __global__ void k_lg_keep(uint32_t total, const uint64_t* __restrict__ se, sq_map_params P, const double* __restrict__ cf, const uint8_t* __restrict__ mused,

@@ -435,7 +435,10 @@ def test_repeat_families_cover_every_mem_size_class(built):
     ctx.free()
 
 
-def test_large_ends_on_a_decoy_chromosome(built):
+@pytest.mark.parametrize("overhang", [None, 0])
+def test_large_ends_on_a_decoy_chromosome(built, overhang, monkeypatch):
+    # [r6] overhang 0: the tiles of k_lg_dp2 / k_lg_accept2 load no records behind their own, so every cluster across a tile's edge continues in global memory
+    if overhang is not None: monkeypatch.setenv("SQ_LG_OVERHANG", str(overhang))
     # [r4] The large class (more than 1024 MEMs per end) is chained by flat passes over all its records (mem_kernels.h: k_lg_*): clusters of
     # MEMs no chain can cross, the reference's acceptance order restored by two stable sorts.  A decoy "chromosome" carries 665 copies of a
     # 160-base element (two variants), some of them back to back (several copies in one cluster: the DP and the clash rule see neighbours),
