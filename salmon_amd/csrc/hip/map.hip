@@ -621,7 +621,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
     }
   }
   sq_prof_mark(c, SG_SORT);
-  k_count_kmer_frags<<<nblk(n), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
+  k_count_kmer_frags<<<std::min<uint32_t>(nblk(n), 1024u), TB, 0, st>>>(n, paired, c->n_chains.p, c->stats.p);
   // chains stay in their per-end slabs (slab of end e starts at mem_off[e]: #chains <= #MEMs); candidates refer to them by
   // absolute slab index.  (A dense copy used to be made here: 0.8 ms and 1.8 GB of traffic per 10^6 pairs for nothing.)
   sq_prof_mark(c, SG_CHAIN);

@@ -1724,15 +1724,18 @@ __global__ void __launch_bounds__(SEL_TB) k_select(sq_map_params P, uint32_t nfr
   }
 }
 
+// [r6] a grid of at most 1 024 blocks: with a block per 256 fragments the kernel was its own 4 x 10^4 same-line atomics (0.24 ms per 5 x 10^6 pairs)
 __global__ void k_count_kmer_frags(uint32_t nfrag, uint32_t paired, const uint32_t* __restrict__ n_chains,
     unsigned long long* __restrict__ stats) {
-  uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  bool any = false; uint32_t nch = 0;
-  if (f < nfrag) { nch = paired ? (n_chains[2 * f] + n_chains[2 * f + 1]) : n_chains[f]; any = nch != 0; }
+  unsigned long long any = 0, nch = 0;
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < nfrag; f += gridDim.x * blockDim.x) {
+    const uint32_t v = paired ? (n_chains[2 * f] + n_chains[2 * f + 1]) : n_chains[f];
+    nch += v; any += v != 0;
+  }
   __shared__ unsigned long long s_st[2];
   if (threadIdx.x < 2) s_st[threadIdx.x] = 0;
   __syncthreads();
-  block_stat_add(&s_st[0], any ? 1 : 0); block_stat_add(&s_st[1], nch);
+  block_stat_add(&s_st[0], any); block_stat_add(&s_st[1], nch);
   __syncthreads();
   if (threadIdx.x < 2 && s_st[threadIdx.x]) atomicAdd(&stats[threadIdx.x == 0 ? ST_KMER : ST_CHAINS], s_st[threadIdx.x]);
 }
