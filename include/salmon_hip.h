@@ -174,6 +174,11 @@ typedef struct {
                                       one model snapshot and their increments are applied in order (SPEC §D1).  1..64; 1 = strictly serial */
 } sq_quant_opts;
 void sq_quant_opts_default(sq_quant_opts* o); /* -l IU defaults */
+/* --mimicBT2 (strict = 0) / --mimicStrictBT2 (strict = 1): the presets processQuantOptions applies on top of whatever else was set
+ * (src/util/QuantOptionsUtils.cpp:256-294): maxReadOccs 1000, consensusSlack 0.5, orphans discarded, then ma 2 / mp -4 / go 5 / ge 3, or
+ * minScoreFraction 0.8 with ma 1 / mp 0 / go 25 / ge 25.  (Both also switch soft-clipping of overhangs off, which this path never does.)
+ * Returns SQ_ERR_ARG for another value of `strict`. */
+int sq_quant_opts_mimic_bt2(sq_quant_opts* o, int strict);
 
 /* ------------------------------------------------------------------------------------------------
  * B1  mapping — replaces the worker-loop body between parser->refill(rg) and processMiniBatch

@@ -39,6 +39,13 @@ def quant_opts(**kw):
     return o
 
 
+def mimic_bt2(o, strict=False):
+    """--mimicBT2 / --mimicStrictBT2 on top of `o` (QuantOptionsUtils.cpp:256-294)."""
+    rc = lib().sq_quant_opts_mimic_bt2(C.byref(o), 1 if strict else 0)
+    if rc: raise ValueError("sq_quant_opts_mimic_bt2: %d" % rc)
+    return o
+
+
 LIBTYPES = {  # src/util/LibraryTypeUtils.cpp:22-46 -> (type, orientation, strandedness)
     "IU": (1, 2, 4), "ISF": (1, 2, 0), "ISR": (1, 2, 1), "OU": (1, 1, 4), "OSF": (1, 1, 0), "OSR": (1, 1, 1),
     "MU": (1, 0, 4), "MSF": (1, 0, 2), "MSR": (1, 0, 3), "U": (0, 3, 4), "SF": (0, 3, 2), "SR": (0, 3, 3)}

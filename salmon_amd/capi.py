@@ -180,7 +180,7 @@ def lib():
         "sq_index_is_decoy": (C.c_int, [vp, u32]), "sq_index_num_unitigs": (u64, [vp]), "sq_index_num_kmers": (u64, [vp]),
         "sq_index_device_bytes": (u64, [vp]), "sq_index_get_view": (C.c_int, [vp, P(IndexView)]),
         "sq_index_lookup_host": (C.c_int, [vp, u64, P(u64), P(u32), P(C.c_int)]),
-        "sq_quant_opts_default": (None, [P(QuantOpts)]), "sq_em_opts_default": (None, [P(EmOpts)]),
+        "sq_quant_opts_default": (None, [P(QuantOpts)]), "sq_quant_opts_mimic_bt2": (C.c_int, [P(QuantOpts), C.c_int]), "sq_em_opts_default": (None, [P(EmOpts)]),
         "sq_ctx_create": (C.c_int, [vp, P(QuantOpts), C.c_int, u32, P(vp)]), "sq_ctx_free": (None, [vp]), "sq_ctx_reset": (C.c_int, [vp]),
         "sq_map_batch": (C.c_int, [vp, P(ReadBatch), P(AlnBatch), P(MapStats)]),
         "sq_eq_export_device": (C.c_int, [vp, P(EqTable)]), "sq_eq_merge_device": (C.c_int, [vp, P(EqTable)]),

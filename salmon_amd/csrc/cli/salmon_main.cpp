@@ -327,7 +327,7 @@ static int cmd_quant(int argc, char** argv) {
                           "--minAssignedFrags", "--sigDigits", "--numErrorBins", "--auxDir", "--preMergeChainSubThresh", "--postMergeChainSubThresh", "--orphanChainSubThresh", "--hitFilterPolicy"},
              {"--useEM", "--useVBOpt", "--initUniform", "--dumpEq", "-d", "--dumpEqWeights", "--recoverOrphans", "--hardFilter", "--allowDovetail", "--discardOrphansQuasi",
               "--disableChainingHeuristic", "--perNucleotidePrior", "--perTranscriptPrior", "--noGammaDraw", "--validateMappings", "--alternativeInitMode", "--meta",
-              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames", "--noErrorModel", "--useASWithoutCIGAR"},
+              "--noLengthCorrection", "--noEffectiveLengthCorrection", "--noFragLengthDist", "--noSingleFragProb", "--noRichEqClasses", "--gcBias", "--seqBias", "--posBias", "--writeMappings", "-z", "--quiet", "-q", "--writeUnmappedNames", "--noErrorModel", "--useASWithoutCIGAR", "--mimicBT2", "--mimicStrictBT2"},
              {"-1", "--mates1", "-2", "--mates2", "-r", "--unmatedReads"});
   std::string lib = lt ? lt : "A";   // the reference's default is automatic detection
   for (auto& c : lib) c = (char)toupper((unsigned char)c);
@@ -423,6 +423,11 @@ static int cmd_quant(int argc, char** argv) {
   if ((v = arg(argc, argv, "--orphanChainSubThresh"))) qo.orphan_chain_sub_thresh = atof(v);
   if ((v = arg(argc, argv, "--hitFilterPolicy"))) { std::string pol(v); for (auto& ch : pol) ch = (char)toupper((unsigned char)ch);
     if (pol != "AFTER") { fprintf(stderr, "[salmon-hip] --hitFilterPolicy %s is not supported (only the default AFTER is built)\n", v); return 1; } }
+  {   // --mimicBT2 / --mimicStrictBT2 override what was set above (QuantOptionsUtils.cpp:250-294)
+    const bool bt2 = flag(argc, argv, "--mimicBT2"), sbt2 = flag(argc, argv, "--mimicStrictBT2");
+    if (bt2 && sbt2) { fprintf(stderr, "[salmon-hip] You passed both the --mimicBT2 and --mimicStrictBT2 parameters.  These are mutually exclusive.\n"); return 1; }
+    if (bt2 || sbt2) sq_quant_opts_mimic_bt2(&qo, sbt2 ? 1 : 0);
+  }
   const bool quiet = flag(argc, argv, "--quiet") || flag(argc, argv, "-q");
   const uint64_t min_assigned = (v = arg(argc, argv, "--minAssignedFrags")) ? strtoull(v, nullptr, 10) : 10;      // SalmonDefaults.hpp: minAssignedFrags
   const int sig_digits = (v = arg(argc, argv, "--sigDigits")) ? std::max(0, std::min(15, atoi(v))) : 3;

@@ -19,6 +19,15 @@ extern "C" void sq_quant_opts_default(sq_quant_opts* o) {
   o->no_length_correction = 0; o->no_eff_length_correction = 0; o->seed = 0x5EED5A1A0ULL;
   o->mini_batches_in_flight = 8; o->seq_bias = 0; o->pos_bias = 0; o->error_model = 0; o->num_error_bins = 6;   /* SalmonDefaults.hpp:124 numErrorBins; the model itself is alignment-mode only and set by the driver */ o->num_bias_samples = 2000000;                                                          // numThreads, SalmonDefaults.hpp:15
 }
+// --mimicBT2 / --mimicStrictBT2 (QuantOptionsUtils.cpp:256-294; the two flags together are refused by the caller, :250-254)
+extern "C" int sq_quant_opts_mimic_bt2(sq_quant_opts* o, int strict) {
+  if (!o || (strict != 0 && strict != 1)) return SQ_ERR_ARG;
+  o->max_read_occs = 1000; o->consensus_slack = 0.5;                                            // :257-261
+  o->allow_orphans = 0;                                                                          // discardOrphansQuasi = true (:266, :287)
+  if (!strict) { o->match_score = 2; o->mismatch_penalty = -4; o->gap_open = 5; o->gap_extend = 3; }   // :272-275
+  else { o->min_score_fraction = 0.8; o->match_score = 1; o->mismatch_penalty = 0; o->gap_open = 25; o->gap_extend = 25; }   // :288-292
+  return SQ_OK;
+}
 extern "C" void sq_em_opts_default(sq_em_opts* o) {
   memset(o, 0, sizeof(*o));
   o->use_vbem = 1; o->per_transcript_prior = 1; o->init_uniform = 0; o->eq_class_mode = 0; o->no_rich_eq_classes = 0;  // :76,87,63

@@ -57,6 +57,23 @@ def test_defaults_match_reference_defaults(built):
     assert (e.use_vbem, e.per_transcript_prior, e.vb_prior, e.rel_diff_tolerance, e.max_iter, e.min_iter) == (1, 1, 1e-2, 0.01, 10000, 100)
 
 
+def test_mimic_bt2_presets_match_reference(built):
+    # src/util/QuantOptionsUtils.cpp:256-294: both presets raise maxReadOccs to 1000 and consensusSlack to 0.5 and discard orphans; --mimicBT2 then sets
+    # Bowtie2-like scores (2 / -4 / 5 / 3), --mimicStrictBT2 RSEM+Bowtie2-like ones (1 / 0 / 25 / 25) with minScoreFraction 0.8; everything else stays
+    from salmon_amd import api
+    d = api.quant_opts()
+    o = api.mimic_bt2(api.quant_opts(hard_filter=1, match_score=7))
+    assert (o.max_read_occs, o.allow_orphans, o.match_score, o.mismatch_penalty, o.gap_open, o.gap_extend) == (1000, 0, 2, -4, 5, 3)
+    assert abs(o.consensus_slack - 0.5) < 1e-9 and o.min_score_fraction == d.min_score_fraction and o.hard_filter == 1
+    s = api.mimic_bt2(api.quant_opts(), strict=True)
+    assert (s.max_read_occs, s.allow_orphans, s.match_score, s.mismatch_penalty, s.gap_open, s.gap_extend) == (1000, 0, 1, 0, 25, 25)
+    assert abs(s.consensus_slack - 0.5) < 1e-9 and s.min_score_fraction == 0.8
+    assert (s.bandwidth, s.max_occs_per_hit, s.range_factorization_bins) == (d.bandwidth, d.max_occs_per_hit, d.range_factorization_bins)
+    from salmon_amd import capi
+    import ctypes
+    assert capi.lib().sq_quant_opts_mimic_bt2(ctypes.byref(s), 2) != 0
+
+
 def test_no_device_fails_loudly(built):
     # on a box without a GPU the device entry points must refuse, not fall back
     import numpy as np, pytest

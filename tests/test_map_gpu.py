@@ -312,6 +312,7 @@ OPTION_VARIANTS = [
     dict(pre_merge_chain_sub_thresh=0.9, post_merge_chain_sub_thresh=0.95, orphan_chain_sub_thresh=0.5), dict(frag_len_max=400, fld_mean=200.0,
         fld_sd=40.0),
     dict(forgetting_factor=0.8, seed=12345), dict(recover_orphans=1), dict(recover_orphans=1, max_read_occs=2, allow_dovetail=1),
+    dict(_mimic="bt2"), dict(_mimic="strict"),      # --mimicBT2 / --mimicStrictBT2 (QuantOptionsUtils.cpp:256-294)
 ]
 
 
@@ -323,6 +324,7 @@ def test_option_variants_match_checker(small_world, variant):
     kw = {k: v for k, v in variant.items() if not k.startswith("_")}
     opts = api.quant_opts(mini_batch_size=500, num_pre_burnin_frags=400, num_burnin_frags=1500, **kw)
     if "_lib" in variant: api.set_libtype(opts, variant["_lib"])
+    if "_mimic" in variant: api.mimic_bt2(opts, strict=variant["_mimic"] == "strict")
     N = 2500
     seq, off, _, _ = w["tx"].reads(N, read_len=100, seed=909, sub_rate=0.015, indel_rate=0.002, threads=4)
     ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=4096)
