@@ -469,7 +469,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   SQ_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, ST_N * sizeof(unsigned long long), st));
   SQ_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(uint32_t), st));
   sq_prof_begin(c);
-  if (c->read_words == 8) k_pack<8><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
+  if (c->read_words == 8) k_pack8_staged<<<nblk(nrec), 256, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);   // [r6] the text through LDS (waves it does not fit run k_pack<8>'s code)
   else if (c->read_words == 16) k_pack<16><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
   else k_pack<32><<<nblk(nrec), TB, 0, st>>>(d_seq, d_seq_off, nrec, c->rpack.p, c->rnmask.p, c->rlen.p, c->rany.p, c->stats.p);
   sq_prof_mark(c, SG_PACK);

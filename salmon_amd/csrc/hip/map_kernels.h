@@ -71,10 +71,8 @@ __device__ inline uint32_t wave_alloc(uint32_t* ctr) {
 // in registers and stored as 16-byte pairs.  (Round 2 used 8 threads per end, one word each: 128 M threads per 8 M pairs whose two
 // dependent round trips — offsets, then bases — set the pace at 2.2 ms; here a wave covers 64 ends and there are 8x fewer waves.)
 template <uint32_t RW>   // packing stride in words: 8 (reads of up to 256 bases, the default), 16, 32
-__global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
+__device__ __forceinline__ void pack_end(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec, uint32_t e,
                        uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, uint8_t* __restrict__ rany, unsigned long long* __restrict__ stats) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nrec) return;
   const uint64_t a = seq_off[e], b = seq_off[e + 1];
   uint32_t L = (uint32_t)(b - a);
   // [r4] a read that does not fit the stride is reported, not cut: the host packs the batch again with a wider stride, or refuses it (> SQ_MAX_READ_LEN)
@@ -120,6 +118,106 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, c
 #pragma unroll
     for (uint32_t w = 0; w < RW; ++w) any |= cn[w];
     rany[e] = any ? 1 : 0; }   // [r6] k_seed2 asks this byte (64 consecutive ends: one sector) instead of reading the end's 32-byte mask
+}
+template <uint32_t RW>
+__global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
+                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, uint8_t* __restrict__ rany, unsigned long long* __restrict__ stats) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nrec) pack_end<RW>(seq, seq_off, nrec, e, rpack, rnmask, rlen, rany, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// [r6] k_pack for the eight-word stride with the text of a wave's 64 read ends staged through LDS.  The thread-per-end kernel above asks for its end's bytes with 16-byte loads
+// at a 100- or 150-byte stride and stores 16-byte pieces at a 64-byte stride: the counters show 52.7 M read and 50.5 M write requests to L2 per 10^7 ends (3 x the lines the
+// bytes occupy) beside 1 536 vector instructions per end (profiles/r06_pack_counters.txt).  Here a wave copies the contiguous text of its ends into LDS with whole-line loads, every
+// lane takes its end out of LDS (dwords at an odd stride: no bank conflicts) and packs four characters at a time, the packed words go back through LDS and leave as whole lines.
+// A wave whose text does not fit PK_WCAP bytes (reads of more than ~159 bases) or holds an end beyond the stride runs the thread-per-end code.  Same words, masks, lengths, flags.
+#define PK_WCAP 9728u    // 64 ends of 150 bases and the alignment slack; four blocks of four waves per CU
+// 32 bases from nine dwords of LDS (the text from byte `mis` of sw[0] on) -> 2-bit codes + "not a base" bits
+__device__ __forceinline__ void pack_word32(const uint32_t* sw, uint32_t mis, uint64_t& cw, uint32_t& cn) {
+  cw = 0; cn = 0;
+  uint32_t prev = sw[0];
+#pragma unroll
+  for (uint32_t q = 0; q < 8; ++q) {
+    const uint32_t cur = sw[q + 1];
+    const uint32_t v = mis ? (uint32_t)((((uint64_t)cur << 32) | prev) >> (8 * mis)) : prev;
+    prev = cur;
+    // upper-case; c2 = (x >> 1) & 3 maps A, C, T, G -> 0, 1, 2, 3; the character that code stands for is 0x41 + 2 c2 (+ 0x0F for T): any other byte is not a base
+    const uint32_t x = v & 0xDFDFDFDFu;
+    const uint32_t c2 = (x >> 1) & 0x03030303u;
+    const uint32_t isT = (c2 >> 1) & ~c2 & 0x01010101u;
+    const uint32_t expect = 0x41414141u + (c2 << 1) + (isT << 4) - isT;
+    const uint32_t diff = x ^ expect;
+    const uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;      // bit 0 of every byte that is not A, C, G or T
+    const uint32_t code = (c2 ^ (c2 >> 1)) & 0x03030303u & ~(nz | (nz << 1));             // swap T and G (k_pack's code); a non-base packs as 0
+    cw |= (uint64_t)((code | (code >> 6) | (code >> 12) | (code >> 18)) & 0xFFu) << (8 * q);
+    cn |= ((nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu) << (4 * q);
+  }
+}
+__global__ void __launch_bounds__(256) k_pack8_staged(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ seq_off, uint32_t nrec,
+                       uint64_t* __restrict__ rpack, uint64_t* __restrict__ rnmask, uint16_t* __restrict__ rlen, uint8_t* __restrict__ rany, unsigned long long* __restrict__ stats) {
+  __shared__ sq_u32x4 s_buf[4][(PK_WCAP + 64) / 16];
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t e0 = (blockIdx.x * 4 + wv) * 64;
+  if (e0 >= nrec) return;
+  const uint32_t ne = nrec - e0 < 64 ? nrec - e0 : 64;
+  const uint32_t e = e0 + lane; const bool act = lane < ne;
+  const uint64_t a = act ? seq_off[e] : 0, b = act ? seq_off[e + 1] : 0;
+  const uint64_t A = __shfl(a, 0, 64), B = __shfl(b, (int)ne - 1, 64);
+  const uintptr_t gA = (uintptr_t)seq + A; const uint32_t pre = (uint32_t)(gA & 15);
+  const uint64_t span = pre + (B - A);
+  const bool fits = __ballot(act && b - a > 256) == 0 && span <= PK_WCAP;
+  if (!fits) { if (act) pack_end<8>(seq, seq_off, nrec, e, rpack, rnmask, rlen, rany, stats); return; }
+  uint8_t* sb = reinterpret_cast<uint8_t*>(s_buf[wv]);
+  { // the wave's text, whole 16-byte pieces (the first and the last piece of the batch's buffer byte by byte: nothing outside [seq, seq + seq_off[nrec]) is touched)
+    const uint8_t* g16 = reinterpret_cast<const uint8_t*>(gA - pre); const uint8_t* gend = seq + seq_off[nrec];
+    for (uint32_t off = lane * 16; off < (uint32_t)span; off += 1024) {
+      const uint8_t* p = g16 + off; sq_u32x4 v;
+      if (p >= seq && p + 16 <= gend) v = *reinterpret_cast<const sq_u32x4*>(p);
+      else {
+        auto word = [&](uint32_t k0) { uint32_t t = 0; for (uint32_t k = k0; k < k0 + 4; ++k) if (p + k >= seq && p + k < gend) t |= (uint32_t)p[k] << (8 * (k & 3)); return t; };
+        v.x = word(0); v.y = word(4); v.z = word(8); v.w = word(12);
+      }
+      *reinterpret_cast<sq_u32x4*>(sb + off) = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  uint64_t cw[8]; uint32_t cn[8]; const uint32_t L = (uint32_t)(b - a);
+  { const uint32_t o = pre + (uint32_t)(a - A), mis = o & 3; const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + (o & ~3u));
+#pragma unroll
+    for (uint32_t w = 0; w < 8; ++w) {
+      cw[w] = 0; cn[w] = 0;
+      const uint32_t lo = 32 * w; const uint32_t cnt = (!act || lo >= L) ? 0 : (L - lo < 32 ? L - lo : 32);
+      if (cnt) {
+        pack_word32(sw + 8 * w, mis, cw[w], cn[w]);
+        if (cnt < 32) { cw[w] &= (1ull << (2 * cnt)) - 1; cn[w] &= (1u << cnt) - 1; }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  // the packed words back through LDS (every lane is done with the text): the wave's 64 x 64 bytes of words and 64 x 32 bytes of masks are contiguous in memory
+  { sq_u64x2* lw = reinterpret_cast<sq_u64x2*>(sb + lane * 64);
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w += 2) { sq_u64x2 v; v.x = cw[w]; v.y = cw[w + 1]; lw[w / 2] = v; }
+    sq_u64x2* lm = reinterpret_cast<sq_u64x2*>(sb + 4096 + lane * 32);
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w += 2) { sq_u64x2 v; v.x = (uint64_t)cn[2 * w] | ((uint64_t)cn[2 * w + 1] << 32); v.y = (uint64_t)cn[2 * w + 2] | ((uint64_t)cn[2 * w + 3] << 32); lm[w / 2] = v; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  { sq_u32x4* gw = reinterpret_cast<sq_u32x4*>(rpack + (size_t)e0 * 8); const sq_u32x4* lw = reinterpret_cast<const sq_u32x4*>(sb);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) { const uint32_t x = i * 64 + lane; if (x < ne * 4) gw[x] = lw[x]; }
+    sq_u32x4* gm = reinterpret_cast<sq_u32x4*>(rnmask + (size_t)e0 * 4); const sq_u32x4* lm = reinterpret_cast<const sq_u32x4*>(sb + 4096);
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) { const uint32_t x = i * 64 + lane; if (x < ne * 2) gm[x] = lm[x]; }
+  }
+  if (act) {
+    rlen[e] = (uint16_t)L;
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 8; ++w) any |= cn[w];
+    rany[e] = any ? 1 : 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
