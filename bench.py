@@ -123,7 +123,7 @@ def stage_bytes(st, n_pairs, read_len, paired=True):
     }
 
 
-KERNEL_OF_STAGE = {"k_pack": "k_pack", "k_seed": "k_seed2", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
+KERNEL_OF_STAGE = {"k_pack": "k_pack8_staged", "k_seed": "k_seed2", "k_mems": "k_mems", "k_join_fill": "k_join2", "k_score": "k_score", "k_dp": "k_dp",
                    "k_select": "k_select", "k_finalize": "k_finalize", "eq_mini_batches": "k_frag_dynamic", "eq_static": "k_frag_static",
                    "eq_table": "k_eq_insert"}
 
@@ -683,12 +683,12 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
     pair_share = {"k_frag_dynamic": 0.5, "k_apply_flagged": 0.5}; pair_note = "no committed rocprofv3 summary found: the launch pair's time is split 50/50"
     try:
         ktot = {}
-        for line in open(os.path.join(ROOT, "profiles", "r06_kernel_stats_c2_final.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r06_kernel_stats_c2_last.txt")):
             for kn in pair_share:
                 if kn + "(" in line and "total=" in line: ktot[kn] = float(line.split("total=")[1].split("ms")[0])
         if len(ktot) == 2:
             pair_share = {kn: ktot[kn] / sum(ktot.values()) for kn in ktot}
-            pair_note = "split %.2f / %.2f between k_frag_dynamic and k_apply_flagged as in profiles/r06_kernel_stats_c2_final.txt" % (pair_share["k_frag_dynamic"], pair_share["k_apply_flagged"])
+            pair_note = "split %.2f / %.2f between k_frag_dynamic and k_apply_flagged as in profiles/r06_kernel_stats_c2_last.txt" % (pair_share["k_frag_dynamic"], pair_share["k_apply_flagged"])
     except Exception: pass
     for k in cand:
         per_launch = sb[k] / max(1, stage_rows[k]["launches"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call ZM: the measurement set on the round's FINAL kernels — the whole GPU suite, the driver's bench command, a kernel trace of it, the FETCH_SIZE / WRITE_SIZE passes
+# round 6, call ZM (run twice: the second time after k_pack8_staged): the measurement set on the round's FINAL kernels — the whole GPU suite, the driver's bench command, a kernel trace of it, the FETCH_SIZE / WRITE_SIZE passes
 # (separate; kernel-trace only), configs[3] at full size (bench + kernel trace come from call ZJ on the same large-end kernels; here the bench line again on the final tree)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
