@@ -657,10 +657,13 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   c->last_total_cands = total_cands;
   const size_t CP = (size_t)total_cands + 8;
   static_assert(sizeof(sq_aln) == 40, "sq_aln layout");
+  bool wait_eq = false;
   if (c->eq_pending[buf]) {   // the eq stage that read this alignment buffer two batches ago: wait (on the device) for it
     sq_eq_wait_enqueued(c->owner ? c->owner : c, c->eq_job_of_buf[buf]);
     if ((buf ? c->aln_b1.n : c->aln.n) < CP) SQ_HIP_CHECK(hipEventSynchronize(c->ev_eq_done[buf]));   // the buffer is about to be reallocated: the eq stage must be done with it
-    SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false;
+    // [r6] the wait itself stands in front of k_select, the only kernel that writes what the eq stage reads (the alignment array and its offsets): in front of k_score it held
+    // the mapping stream ~0.35 ms per 5 x 10^6 pairs while scoring, the DP and k_finalize (3.2 ms) had nothing to do with that buffer
+    wait_eq = true;
   }
   if (c->aln_slots.ensure(std::max(CP, c->cands.n)) || (buf ? c->aln_b1.ensure(CP) : c->aln.ensure(CP)) ||
       c->dpq.ensure(std::max<size_t>(c->dpq.n, CP * 2 + 1024))) {
@@ -721,6 +724,7 @@ pack_again:   // [r4] taken once more when the batch holds a read end longer tha
   const uint32_t sel_blocks = (n + SEL_TB - 1) / SEL_TB;
   if (c->sel_desc.ensure((size_t)sel_blocks + 8)) { sq_set_error("device allocation failed (selection descriptors)"); return SQ_ERR_NOMEM; }
   SQ_HIP_CHECK(hipMemsetAsync(c->sel_desc.p, 0, ((size_t)sel_blocks + 2) * 8, st));
+  if (wait_eq) { SQ_HIP_CHECK(hipStreamWaitEvent(st, c->ev_eq_done[buf], 0)); c->eq_pending[buf] = false; }
   if (n == 0) SQ_HIP_CHECK(hipMemsetAsync(c->aln_off_ptr(buf), 0, 8, st));
   else k_select<<<sel_blocks, SEL_TB, 0, st>>>(P, n, paired, c->cand_off.p, c->n_cand.p, c->cands.p, hs_arr.p, tid_arr.p, c->rlen.p,
       c->frag_flags.p, c->aln_slots.p, c->n_aln.p, c->map_type.p, c->stats.p, c->aln_ptr(buf), c->aln_off_ptr(buf),
