@@ -640,7 +640,8 @@ uint64_t sq_ctx_seed_filter_fills(sq_ctx*, int reset);
 /* ------------------------------------------------------------------------------------------------
  * Debug / parity taps: copy an intermediate stage of the LAST sq_map_batch to the host.
  * ---------------------------------------------------------------------------------------------- */
-enum { SQ_TAP_UNIMEMS = 1, SQ_TAP_MEMS = 2, SQ_TAP_CHAINS = 3, SQ_TAP_CANDIDATES = 4 };
+enum { SQ_TAP_UNIMEMS = 1, SQ_TAP_MEMS = 2, SQ_TAP_CHAINS = 3, SQ_TAP_CANDIDATES = 4,
+       SQ_TAP_PACKED = 5 /* the packed read ends as 64-bit words, per end: length | (has a non-base << 32), then the 2-bit words (32 bases each) and the non-base masks (64 bases each) of the context's packing stride; sq_debug_tap with buf = NULL returns the word count */ };
 typedef struct { uint32_t end; uint16_t qpos, len; uint64_t unitig; uint32_t uoff; uint8_t fw; uint8_t _p[3]; } sq_unimem;
 typedef struct { uint32_t end; uint32_t tid; int32_t rpos; uint16_t qpos, len; uint8_t fw; uint8_t _p[3]; } sq_mem;
 typedef struct { uint32_t end; uint32_t tid; int32_t pos; int32_t last_end; uint8_t fw; uint8_t _p[3];

@@ -950,6 +950,21 @@ static int64_t tap_impl(sq_ctx* c, int what, void* buf, uint64_t cap) {
       ++cnt; }
     return (int64_t)cnt;
   }
+  if (what == SQ_TAP_PACKED) {   // [r6] what k_pack left (tests hold it to a restatement of the packing rule)
+    const uint32_t RW = c->read_words, rec = 1 + RW + RW / 2;
+    const uint64_t cnt = (uint64_t)nrec * rec;
+    if (!buf) return (int64_t)cnt;
+    if (cap < cnt) { sq_set_error("sq_debug_tap: buffer of %llu words for %llu", (unsigned long long)cap, (unsigned long long)cnt); return SQ_ERR_ARG; }
+    std::vector<uint64_t> w((size_t)nrec * RW), m((size_t)nrec * (RW / 2)); std::vector<uint16_t> rl(nrec); std::vector<uint8_t> ra(nrec);
+    if (nrec && (hipMemcpy(w.data(), c->rpack.p, w.size() * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(m.data(), c->rnmask.p, m.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                 hipMemcpy(rl.data(), c->rlen.p, (size_t)nrec * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ra.data(), c->rany.p, nrec, hipMemcpyDeviceToHost) != hipSuccess)) return SQ_ERR_DEVICE;
+    uint64_t* o = (uint64_t*)buf;
+    for (uint32_t e = 0; e < nrec; ++e) {
+      uint64_t* r = o + (size_t)e * rec; r[0] = (uint64_t)rl[e] | ((uint64_t)ra[e] << 32);
+      memcpy(r + 1, w.data() + (size_t)e * RW, RW * 8); memcpy(r + 1 + RW, m.data() + (size_t)e * (RW / 2), (RW / 2) * 8);
+    }
+    return (int64_t)cnt;
+  }
   sq_set_error("sq_debug_tap: unknown tap %d", what);
   return SQ_ERR_ARG;
 }

@@ -623,3 +623,59 @@ def test_batches_after_burn_in_take_the_split_path_and_match_checker(small_world
     assert np.array_equal(ctx.fld(), mc[4]) and np.array_equal(ctx.lib_counts(), ost.lib_counts())
     if variant == "gc": assert np.array_equal(ctx.gc_observed(), ost.gc_observed())
     ctx.free(); ost.free()
+
+
+def _pack_rule(seq_bytes, off, nrec, rw):
+    # the packing rule of k_pack (map_kernels.h): A, C, G, T in either case -> 0, 1, 2, 3, two bits a base, 32 bases a word; any other byte packs as 0 and sets its bit in the mask
+    code = np.full(256, 255, np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]): code[ch] = v
+    rec = 1 + rw + rw // 2; out = np.zeros((nrec, rec), np.uint64)
+    for e in range(nrec):
+        s = seq_bytes[int(off[e]):int(off[e + 1])]; c = code[s]; L = len(s)
+        bad = c == 255
+        out[e, 0] = np.uint64(L) | (np.uint64(1 if bad.any() else 0) << np.uint64(32))
+        c2 = np.where(bad, 0, c).astype(np.uint64)
+        for i in range(L):
+            out[e, 1 + i // 32] |= c2[i] << np.uint64(2 * (i % 32))
+            if bad[i]: out[e, 1 + rw + i // 64] |= np.uint64(1) << np.uint64(i % 64)
+    return out.reshape(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["2x100", "2x151_odd_offsets", "ragged_20_256", "ragged_140_170_across_the_lds_cap", "device_buffer_at_an_odd_address"])
+def test_packed_reads_follow_the_packing_rule(small_world, shape):
+    # [r6] k_pack8_staged (a wave's text through LDS) and the thread-per-end code it falls back to, held to the rule itself through the SQ_TAP_PACKED tap: read starts at every
+    # byte alignment, lengths from 20 to 256 (waves whose text exceeds the LDS cap take the fallback; so does any wave with a longer end), non-bases and lower case anywhere
+    # (first / last base of a read, of a word, of the batch), a last wave of fewer than 64 ends, and a device-resident batch whose buffer starts at an odd address
+    w = small_world; rng = np.random.default_rng(77)
+    n = 1000 + 37                                   # pairs: 2 074 ends = 32 waves and a partial one
+    if shape == "2x100": lens = np.full(2 * n, 100)
+    elif shape == "2x151_odd_offsets": lens = np.full(2 * n, 151)
+    elif shape == "ragged_20_256": lens = rng.integers(20, 257, 2 * n)
+    elif shape == "ragged_140_170_across_the_lds_cap": lens = rng.integers(140, 171, 2 * n)
+    else: lens = rng.integers(31, 140, 2 * n)
+    off = np.zeros(2 * n + 1, np.uint64); off[1:] = np.cumsum(lens)
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(off[-1])).copy()
+    lower = rng.random(len(seq)) < 0.1; seq[lower] |= 0x20
+    junk = rng.random(len(seq)) < 0.01; seq[junk] = rng.choice(np.frombuffer(b"NnRY.-*@\x00\xff", np.uint8), int(junk.sum()))
+    for e in range(0, 2 * n, 7):                    # non-bases at the edges of reads and words
+        a, b = int(off[e]), int(off[e + 1])
+        seq[a if e % 3 == 0 else b - 1] = ord("N")
+        if b - a > 40: seq[a + (31 if e % 2 else 32)] = ord("n")
+    seq[0] = ord("N"); seq[-1] = ord("N")
+    opts = api.quant_opts()
+    ctx = api.QuantContext(w["idx"], opts, device=0, max_batch_reads=2048)
+    if shape == "device_buffer_at_an_odd_address":
+        import torch
+        pad = 5; dbuf = torch.zeros(len(seq) + pad + 64, dtype=torch.uint8, device="cuda:0"); dbuf[pad:pad + len(seq)] = torch.from_numpy(seq).to("cuda:0")
+        doff = torch.from_numpy(off.astype(np.int64)).to("cuda:0"); torch.cuda.synchronize()
+        rb = api.make_read_batch(int(dbuf.data_ptr()) + pad, int(doff.data_ptr()), n, paired=True, on_device=True)
+    else:
+        rb = api.make_read_batch(seq, off, n, paired=True)
+    ctx.map_batch(rb)
+    got = ctx.tap(5, np.uint64)
+    want = _pack_rule(seq, off, 2 * n, 8)
+    assert len(got) == len(want)
+    bad = np.flatnonzero(got != want)
+    assert len(bad) == 0, "end %d word %d: %x != %x" % (bad[0] // 13, bad[0] % 13, int(got[bad[0]]), int(want[bad[0]]))
+    ctx.free()
