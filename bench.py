@@ -716,6 +716,10 @@ def run_workload(a, wl, rank, world, local, dist, sqd, thr, ncores, api, synth, 
             roof["round4_model"] = {"alg_bytes_per_launch": int(r4), "achieved": round(r4 / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "frac": round(r4 / (roof["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0, 5),
                                     "note": "one filter sector per probe and four dependent sectors per hit — the bytes rounds 3-5 quoted `frac` on; k_seed2 moves fewer (frac above is on its own bytes)"}
             roof["traffic_over_alg_bytes"] = round(roof["traffic"] / roof["alg_bytes_per_launch"], 3) if roof.get("traffic") else None
+        if dom == "k_seed2" and wl == "c2":   # SQ counters of the same kernel on this workload (profiles/r06_pack_counters.txt, rocprofv3 --pmc, call ZN): how busy the vector issue ports are
+            roof["valu_issue"] = {"vector_instructions_per_launch": 1391333484, "busy_cycles_per_shader_engine": 9044344, "simds": 768, "frac_of_issue_cycles": round(1391333484 * 4 / 768 / 9044344.0, 3),
+                                  "waiting_for_memory_frac_of_wave_cycles": round(2030252060 / 10282191389.0, 3),
+                                  "note": "four cycles per wave64 vector instruction on a 16-lane SIMD; from the committed counter profile (5 M pairs per launch), not sampled in this run: the kernel is instruction-issue-bound at least as much as sector-rate-bound (DESIGN.md section 6)"}
         roof["all_kernels"] = {k: {"frac": roofs[k]["frac"], "ms_total": roofs[k]["ms_total"], "avg_launch_ms": roofs[k]["avg_launch_ms"]} for k in roofs}
     if gibbs is not None:   # c5 is inference-bound: its dominant kernel is the Gibbs round
         g = gibbs["report"]; bg = 28 * Lb + 16 * E + 32 * M
